@@ -1,0 +1,191 @@
+/* libkantts_hip.so -- C ABI of the MI355X (gfx950) kernels behind the KAN-TTS hot path.
+ *
+ * The reference (modelscope/KAN-TTS) has no FFI: every "kernel" is a stock ATen op called from
+ * the kantts/models Python modules.  Each entry point below names the reference call sites (file:line under
+ * /root/reference) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C, no C++ types / exceptions cross this boundary; every function returns int:
+ *     0 = KANTTS_OK, negative = KANTTS_E_* (bad arguments), positive = hipError_t.
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host; the caller
+ *     (PyTorch's caching allocator in the Python host layer) owns all buffers incl. workspaces;
+ *     the library never allocates device memory and keeps no references after returning.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); stateless and re-entrant.
+ *   - tensors are contiguous row-major fp32 unless stated; lengths/indices are int32 or int64
+ *     as stated; "tokens" are rows of a (B, T, C) channels-last activation, row = b*T + t.
+ */
+#ifndef KANTTS_HIP_H
+#define KANTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KANTTS_OK 0
+#define KANTTS_E_BADARG (-1)
+#define KANTTS_E_UNSUPPORTED (-2)
+#define KANTTS_E_WORKSPACE (-3)
+
+/* Library/ABI version and target ISA string ("gfx950"). */
+int kantts_abi_version(void);
+const char* kantts_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Segmented GEMM:  C[i][j] (op)= epilogue( alpha * sum_seg sum_tap sum_kk A(i,kk) * B(j,kk) )
+ *
+ * One kernel covers every dense contraction of the path (channels-last activations):
+ *   nn.Linear fwd / dgrad / wgrad      kantts/models/sambert/__init__.py:82,102,217,242,287,297
+ *   Conv1d k=1 and k=3 (im2col-free: one segment with ntaps shifted row windows)
+ *                                      kantts/models/sambert/__init__.py:115-127, fsmn.py:14-29
+ *   concatenated inputs (torch.cat + Linear) as several segments
+ *                                      kantts/models/sambert/kantts_sambert.py:173-174, adaptors.py:54
+ *   sums of projections (fc_x + fc_h)  kantts/models/sambert/__init__.py:287-299
+ *   HiFi-GAN dilated Conv1d / polyphase ConvTranspose1d (taps + strided C)
+ *                                      kantts/models/hifigan/layers.py:82-88,153-161
+ * A(i,kk) = a[i*a_is + kk*a_ks] and B(j,kk) = b[j*b_js + kk*b_ks + tap*b_tap]; a token shift
+ * (conv tap) moves the index that is a token (row of a (B,T,C) tensor) by s = shift0+tap*step and
+ * yields 0 when (tok % T) + s falls outside [0, T).  Arithmetic: precision 0 = fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32, exact f32 FMA chain), 1 = bf16 MFMA inputs with fp32 accumulate
+ * (v_mfma_f32_16x16x32_bf16), 2 = scalar fp32 reference kernel (debug).
+ */
+#define KANTTS_GEMM_MAX_SEG 4
+typedef struct kantts_gemm_seg {
+  const float* a;      /* A operand */
+  const float* a_gate; /* optional, same addressing as A: A(i,kk) is used only where gate > 0
+                          (ReLU / zeroed-row backward)                                           */
+  const float* b;      /* B operand */
+  int64_t a_is, a_ks;  /* A strides over i and kk (elements) */
+  int64_t b_js, b_ks;  /* B strides over j and kk */
+  int64_t b_tap;       /* B element offset per tap */
+  int32_t klen;        /* reduction length per tap */
+  int32_t ntaps;       /* >= 1 */
+  int32_t a_tok_axis;  /* 0: A has no token shift, 1: i is the token index, 2: kk is */
+  int32_t a_shift0, a_shift_step;
+  int32_t b_tok_axis;  /* 0: none, 2: kk is the token index of B */
+  int32_t b_shift0, b_shift_step;
+  float a_drop_p;      /* > 0: A(i,kk) *= dropout keep-scale regenerated from (a_drop_seed, element
+                          offset of A) -- backward of an epilogue dropout, A = dY contiguous (M,N) */
+  uint64_t a_drop_seed;
+} kantts_gemm_seg;
+
+typedef struct kantts_gemm_args {
+  kantts_gemm_seg seg[KANTTS_GEMM_MAX_SEG];
+  int32_t nseg;
+  int32_t M, N;        /* extent of i and j */
+  int32_t T;           /* tokens per sequence for token shifts (ignored when no shift) */
+  float* c;
+  int64_t c_is, c_js;  /* C strides */
+  const float* bias;   /* over j, optional: v = (acc + bias[j] + bias2[j]) * alpha */
+  const float* bias2;  /* optional second bias (sum of two projections) */
+  const float* res;    /* optional residual added after the activation */
+  int64_t r_is, r_js;
+  const uint8_t* rowmask; /* optional, over i: rows with mask != 0 are written as 0 */
+  const uint8_t* kmask;   /* optional, over kk (same for all segments): kk with mask != 0 skipped */
+  float* a_rowsum;     /* optional: a_rowsum[i] += sum_kk A(i,kk) of segment 0 (bias gradient) */
+  float alpha;
+  int32_t relu;        /* 1: v = max(v, 0) before residual */
+  int32_t accumulate;  /* 0: C = v, 1: atomicAdd(C, v) (required when splitk > 1) */
+  int32_t splitk;      /* >= 1: reduction tiles are dealt round-robin to gridDim.z slices */
+  int32_t precision;   /* 0 fp32 MFMA, 1 bf16 MFMA, 2 scalar reference */
+  float drop_p;        /* dropout applied to v after the activation, before the residual */
+  uint64_t drop_seed;  /* mask element (i,j) = rng(drop_seed, i*N + j) */
+} kantts_gemm_args;
+
+int kantts_gemm_seg_launch(const kantts_gemm_args* args_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (eps inside sqrt, biased variance).  Replaces nn.LayerNorm(eps=1e-6) at
+ * kantts/models/sambert/__init__.py:63,130,198 and kantts/models/sambert/kantts_sambert.py:58,128.
+ * x,y,dx,dy: (M,C); mean,rstd: (M) saved for backward; dgamma/dbeta are ACCUMULATED (atomicAdd). */
+int kantts_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                         float* rstd, int M, int C, float eps, void* stream);
+int kantts_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                         const float* rstd, float* dx, float* dgamma_accum, float* dbeta_accum, int M, int C,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Range-limited multi-head attention, d_head = 16.  Replaces ScaledDotProductAttention and the mask
+ * tensors (kantts/models/sambert/__init__.py:17-29,85-100; kantts_sambert.py:135-166).
+ * q/k/v/o/d*: element (b,t,h,d) at ptr[(b*L+t)*ld + h*16 + d].  mode 0: key padding (encoder),
+ * 1: PNCA x (causal band [i-bw, i]), 2: PNCA h (look-ahead band [i, i+bw]); lens (B) int32 = valid
+ * positions per sequence (NULL: all); bw_dev: optional device scalar overriding bw.
+ * lse: (B,H,L) saved; probs: optional (H*B, L, L) post-dropout probabilities (reference layout).
+ * Backward writes dq (or adds to it when accumulate_dq), dk, dv; dvec (B,H,L) is scratch. */
+int kantts_attn_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, float* o, int ldo,
+                    float* lse, float* probs, const int32_t* lens, const int32_t* bw_dev, int bw, int B, int H,
+                    int L, int d_head, int mode, float drop_p, uint64_t seed, void* stream);
+int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* o,
+                    int ldo, const float* d_o, int lddo, const float* lse, float* dvec, float* dq, float* dk,
+                    float* dv, int lddq, int lddk, int lddv, int accumulate_dq, const int32_t* lens,
+                    const int32_t* bw_dev, int bw, int B, int H, int L, int d_head, int mode, float drop_p,
+                    uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LSTM recurrence, H = 128 (time loop of torch.nn.LSTM: kantts/models/sambert/adaptors.py:44-57,
+ * :109-134; kantts_sambert.py:637-646).  gx (B,T,ndir*4H) = x W_ih^T + b_ih (from the GEMM);
+ * whh (ndir,4H,H), bhh (ndir,4H) or NULL; lens (B) int32 or NULL = pack_padded_sequence lengths;
+ * out (B,T,ndir*H); gates_save (ndir,B,T,4H) and c_save (ndir,B,T,H) are kept for backward.
+ * Backward returns dgates (ndir,B,T,4H) = gradient w.r.t. the pre-activation gates. */
+int kantts_lstm_fwd(const float* gx, const float* whh, const float* bhh, const int32_t* lens, float* out,
+                    float* gates_save, float* c_save, int B, int T, int H, int ndir, int reverse_first,
+                    void* stream);
+int kantts_lstm_bwd(const float* dout, const float* whh, const int32_t* lens, const float* gates_save,
+                    const float* c_save, float* dgates, int B, int T, int H, int ndir, int reverse_first,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding gather-sum: out[row] = scale * sum_k table_k[ids[row,k]] (+ pos[row % T]);
+ * scaled_out (optional) receives the value before the positional add.  tables_host is a HOST array
+ * of ntab (<=4) device pointers.  kantts/models/sambert/kantts_sambert.py:308-329, :62-64.
+ * Backward scatter-adds scale*dout into dtables (NULL entries skipped). */
+int kantts_embed_sum_fwd(const float* const* tables_host, int ntab, const int64_t* ids, const float* pos,
+                         float* out, float* scaled_out, int rows, int T, int D, float scale, void* stream);
+int kantts_embed_sum_bwd(float* const* dtables_host, int ntab, const int64_t* ids, const float* dout, int rows,
+                         int D, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Length regulator (kantts/models/sambert/adaptors.py:15-36, positions.py:72-90) in index form.
+ * kantts_lr_index: reps = trunc(dur + 0.5) (dur_int (B,N) int64 or dur_float (B,N) fp32);
+ *   idx (B,Tp) int32 token per frame or -1; pos (B,Tp) 1-based position inside the token (t+1 when
+ *   uncovered); cs (B,N+1) int32 exclusive prefix sums; lens (B) int64 totals.  Bit-exact.
+ * kantts_lr_gather_fwd: out[b,t, off:off+C] = x[b, idx[b,t], :] (0 when idx<0 or t >= valid_lens[b]);
+ *   out rows have stride ldo (lets three regulators write one concatenated buffer).
+ * kantts_lr_gather_bwd: deterministic segment sum over [cs[n], cs[n+1]). */
+int kantts_lr_index(const int64_t* dur_int, const float* dur_float, int32_t* idx, float* pos, int32_t* cs,
+                    int64_t* lens, int B, int N, int Tp, void* stream);
+int kantts_lr_gather_fwd(const float* x, const int32_t* idx, const int64_t* valid_lens, float* out, int B, int N,
+                         int Tp, int C, int ldo, int out_col_offset, void* stream);
+int kantts_lr_gather_bwd(const float* dout, const int32_t* cs, const int64_t* valid_lens, float* dx, int B, int N,
+                         int Tp, int C, int ldo, int out_col_offset, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FSMN memory block (kantts/models/sambert/fsmn.py:43-72), channels-last (B,T,C), w (C,K):
+ *   xm = x*keep; y = keep*(sum_k w[c,k]*xm[t+k-left_pad] + xm[t]) (+ res); keep[b,t] = t < lens[b].
+ * Backward: dx (w.r.t. x) and dw_accum (atomicAdd); d(res) = dy. */
+int kantts_fsmn_dwconv_fwd(const float* x, const float* w, const float* res, const int64_t* lens, float* y, int B,
+                           int T, int C, int K, int left_pad, void* stream);
+int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const float* w, const int64_t* lens, float* dx,
+                           float* dw_accum, int B, int T, int C, int K, int left_pad, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Masked L1 ("mae") reduction: loss_accum[0] += sum_{t<lens[b]} |target-pred| / (sum(lens)*C);
+ * grad (optional, (B,T,C)) = d loss / d pred.  kantts/train/loss.py:18-37, :51-85. */
+int kantts_masked_l1(const float* pred, const float* target, const int64_t* lens, float* loss_accum, float* grad,
+                     int B, int T, int C, void* stream);
+
+/* out_accum[0] += sum x^2 (global gradient norm, torch.nn.utils.clip_grad_norm_) */
+int kantts_sumsq(const float* x, float* out_accum, long long n, void* stream);
+
+/* torch.optim.Adam step on flat fp32 arenas with optional global-norm clipping read from device
+ * memory (gnorm_sq = sum of squares of all gradients): kantts/train/trainer.py:997-1004. */
+int kantts_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                     const float* gnorm_sq, float max_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KANTTS_HIP_H */

@@ -1,0 +1,281 @@
+// Range-limited multi-head attention for d_head = 16 (SAM-BERT: 8 heads x 16).
+//
+// Replaces ScaledDotProductAttention + the head split/merge permutes + the materialised masks:
+//   kantts/models/sambert/__init__.py:17-29 (bmm / temperature / masked_fill(-inf) / softmax / bmm)
+//   kantts/models/sambert/__init__.py:85-100 (permute+contiguous x4, mask.repeat)
+//   kantts/models/sambert/kantts_sambert.py:135-166 (get_pnca_attn_mask: L x L band masks)
+//
+// Every mask the reference builds is an index interval [lo, hi] of allowed keys per query:
+//   mode 0 (encoder, key padding)  : [0, len-1]                               for every query
+//   mode 1 (PNCA x, causal band)   : [max(0, i-bw), i]            if i < len, else [0, L-1]
+//   mode 2 (PNCA h, look-ahead band): [i, min(i+bw, L-1, len-1)]  if i < len, else [0, L-1]
+// (rows of padded queries are fully un-masked by the reference, kantts_sambert.py:158-164).
+// With d_head = 16 the QK^T contraction is a single MFMA k-step and the decoder bands hold
+// ~6 keys, so the op is exp/IO-bound: one thread owns one query row (q, o, running softmax in
+// registers), keys/values stream from L2 (wave-uniform addresses in mode 0, neighbouring rows in
+// the band modes).  Nothing of size L x L is written unless the caller asks for the probabilities.
+//
+// Layout: q/k/v/o are addressed as ptr[(b*L + t)*ld + h*16 + d], i.e. straight out of / into the
+// fused QKV projection buffers; probs (optional) is (H*B, L, L) head-major like the reference.
+#include "common.h"
+
+#define DH 16
+
+struct AttnArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  int ldq, ldk, ldv;
+  float* o;
+  int ldo;
+  float* lse;    // (B, H, L) log-sum-exp of the scaled scores (saved for backward)
+  float* probs;  // optional (H*B, L, L)
+  const int32_t* lens;    // optional (B)
+  const int32_t* bw_dev;  // optional device scalar band width (overrides bw)
+  int B, H, L, mode, bw;
+  float scale;  // 1 / sqrt(d_head)
+  float drop_p;
+  uint64_t seed;
+  // backward only
+  const float* d_o;
+  int lddo;
+  float* dq;
+  float* dk;
+  float* dv;
+  int lddq, lddk, lddv;
+  float* dvec;  // (B, H, L): D_i = dO_i . O_i
+  int accumulate_dq;
+};
+
+__device__ __forceinline__ void key_range(int mode, int i, int len, int L, int bw, int& lo, int& hi) {
+  if (mode == 0) {
+    lo = 0;
+    hi = len - 1;
+  } else if (i >= len) {
+    lo = 0;
+    hi = L - 1;
+  } else if (mode == 1) {
+    lo = max(0, i - bw);
+    hi = i;
+  } else {
+    lo = i;
+    hi = min(min(i + bw, L - 1), len - 1);
+  }
+}
+
+__device__ __forceinline__ void load16(const float* p, float* r) {
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float4 t = p4[e];
+    r[4 * e + 0] = t.x;
+    r[4 * e + 1] = t.y;
+    r[4 * e + 2] = t.z;
+    r[4 * e + 3] = t.w;
+  }
+}
+__device__ __forceinline__ void store16(float* p, const float* r) {
+  float4* p4 = reinterpret_cast<float4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p4[e] = make_float4(r[4 * e], r[4 * e + 1], r[4 * e + 2], r[4 * e + 3]);
+}
+__device__ __forceinline__ float dot16(const float* a, const float* b) {
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) s = fmaf(a[d], b[d], s);
+  return s;
+}
+
+// grid: (ceil(L/128), H, B), block 128: thread <-> query row i
+__global__ __launch_bounds__(128) void attn_fwd_kernel(const AttnArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (i >= a.L) return;
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  int lo, hi;
+  key_range(a.mode, i, len, a.L, bw, lo, hi);
+  const long long row = (long long)b * a.L + i;
+  float q[DH], o[DH];
+  load16(a.q + row * a.ldq + h * DH, q);
+#pragma unroll
+  for (int d = 0; d < DH; ++d) o[d] = 0.f;
+  const float* kb = a.k + (long long)b * a.L * a.ldk + h * DH;
+  const float* vb = a.v + (long long)b * a.L * a.ldv + h * DH;
+  float m = -INFINITY;
+  for (int j = lo; j <= hi; ++j) {
+    float kk[DH];
+    load16(kb + (long long)j * a.ldk, kk);
+    m = fmaxf(m, dot16(q, kk) * a.scale);
+  }
+  float l = 0.f;
+  float* prow = a.probs ? a.probs + (((long long)h * a.B + b) * a.L + i) * a.L : nullptr;
+  const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
+  for (int j = lo; j <= hi; ++j) {
+    float kk[DH], vv[DH];
+    load16(kb + (long long)j * a.ldk, kk);
+    load16(vb + (long long)j * a.ldv, vv);
+    float e = expf(dot16(q, kk) * a.scale - m);
+    l += e;
+    float ed = e * kantts_dropout_scale(a.drop_p, a.seed, rng_row + j);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
+  }
+  const float inv = (hi >= lo) ? 1.f / l : 0.f;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) o[d] *= inv;
+  store16(a.o + row * a.ldo + h * DH, o);
+  a.lse[((long long)b * a.H + h) * a.L + i] = (hi >= lo) ? (m + logf(l)) : 0.f;
+  if (prow) {
+    for (int j = 0; j < a.L; ++j) {
+      float p = 0.f;
+      if (j >= lo && j <= hi) {
+        float kk[DH];
+        load16(kb + (long long)j * a.ldk, kk);
+        p = expf(dot16(q, kk) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, a.seed, rng_row + j);
+      }
+      prow[j] = p;
+    }
+  }
+}
+
+// dQ (thread <-> query row); also stores D_i for the dK/dV pass.
+__global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const AttnArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (i >= a.L) return;
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  int lo, hi;
+  key_range(a.mode, i, len, a.L, bw, lo, hi);
+  const long long row = (long long)b * a.L + i;
+  float q[DH], go[DH], oo[DH], dq[DH];
+  load16(a.q + row * a.ldq + h * DH, q);
+  load16(a.d_o + row * a.lddo + h * DH, go);
+  load16(a.o + row * a.ldo + h * DH, oo);
+  const float D = dot16(go, oo);
+  const long long sidx = ((long long)b * a.H + h) * a.L + i;
+  const float lse = a.lse[sidx];
+  a.dvec[sidx] = D;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+  const float* kb = a.k + (long long)b * a.L * a.ldk + h * DH;
+  const float* vb = a.v + (long long)b * a.L * a.ldv + h * DH;
+  const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
+  for (int j = lo; j <= hi; ++j) {
+    float kk[DH], vv[DH];
+    load16(kb + (long long)j * a.ldk, kk);
+    load16(vb + (long long)j * a.ldv, vv);
+    float p = expf(dot16(q, kk) * a.scale - lse);
+    float dp = dot16(go, vv) * kantts_dropout_scale(a.drop_p, a.seed, rng_row + j);
+    float ds = p * (dp - D) * a.scale;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
+  }
+  float* dst = a.dq + row * a.lddq + h * DH;
+  if (a.accumulate_dq) {
+    float old[DH];
+    load16(dst, old);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] += old[d];
+  }
+  store16(dst, dq);
+}
+
+// dK, dV (thread <-> key row j): walks the queries whose interval contains j.
+__global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const AttnArgs a) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (j >= a.L) return;
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  const long long krow = (long long)b * a.L + j;
+  float kk[DH], vv[DH], dk[DH], dv[DH];
+  load16(a.k + krow * a.ldk + h * DH, kk);
+  load16(a.v + krow * a.ldv + h * DH, vv);
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    dk[d] = 0.f;
+    dv[d] = 0.f;
+  }
+  // candidate queries: two intervals [c0,c1] (banded, valid queries) and [p0,p1] (padded queries)
+  int c0, c1, p0 = len, p1 = a.L - 1;
+  if (a.mode == 0) {
+    c0 = 0;
+    c1 = a.L - 1;
+    p0 = 1;
+    p1 = 0;  // empty: mode 0 treats all queries alike
+  } else {
+    c0 = max(0, j - bw);
+    c1 = min(j + bw, len - 1);
+  }
+  const float* qb = a.q + (long long)b * a.L * a.ldq + h * DH;
+  const float* gb = a.d_o + (long long)b * a.L * a.lddo + h * DH;
+  const long long sbase = ((long long)b * a.H + h) * a.L;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int s = pass ? p0 : c0, e = pass ? p1 : c1;
+    for (int i = s; i <= e; ++i) {
+      int lo, hi;
+      key_range(a.mode, i, len, a.L, bw, lo, hi);
+      if (j < lo || j > hi) continue;
+      float q[DH], go[DH];
+      load16(qb + (long long)i * a.ldq, q);
+      load16(gb + (long long)i * a.lddo, go);
+      const float p = expf(dot16(q, kk) * a.scale - a.lse[sbase + i]);
+      const float dsc = kantts_dropout_scale(a.drop_p, a.seed, ((((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L) + j);
+      const float pd = p * dsc;
+      const float dp = dot16(go, vv) * dsc;
+      const float ds = p * (dp - a.dvec[sbase + i]) * a.scale;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        dv[d] = fmaf(pd, go[d], dv[d]);
+        dk[d] = fmaf(ds, q[d], dk[d]);
+      }
+    }
+  }
+  store16(a.dk + krow * a.lddk + h * DH, dk);
+  store16(a.dv + krow * a.lddv + h * DH, dv);
+}
+
+static int attn_check(const AttnArgs& a) {
+  if (!a.q || !a.k || !a.v || !a.o || !a.lse) return KANTTS_E_BADARG;
+  if (a.B < 0 || a.H < 1 || a.L < 0 || a.mode < 0 || a.mode > 2) return KANTTS_E_BADARG;
+  if ((a.ldq | a.ldk | a.ldv | a.ldo) & 3) return KANTTS_E_BADARG;  // float4 row access
+  return KANTTS_OK;
+}
+
+extern "C" int kantts_attn_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, float* o,
+                               int ldo, float* lse, float* probs, const int32_t* lens, const int32_t* bw_dev, int bw,
+                               int B, int H, int L, int d_head, int mode, float drop_p, uint64_t seed, void* stream) {
+  if (d_head != DH) return KANTTS_E_UNSUPPORTED;
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo; a.lse = lse;
+  a.probs = probs; a.lens = lens; a.bw_dev = bw_dev; a.bw = bw; a.B = B; a.H = H; a.L = L; a.mode = mode;
+  a.scale = 0.25f; a.drop_p = drop_p; a.seed = seed;
+  int rc = attn_check(a);
+  if (rc) return rc;
+  if (B == 0 || L == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(kantts_cdiv(L, 128), H, B), dim3(128), 0, (hipStream_t)stream, a);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv,
+                               const float* o, int ldo, const float* d_o, int lddo, const float* lse, float* dvec,
+                               float* dq, float* dk, float* dv, int lddq, int lddk, int lddv, int accumulate_dq,
+                               const int32_t* lens, const int32_t* bw_dev, int bw, int B, int H, int L, int d_head,
+                               int mode, float drop_p, uint64_t seed, void* stream) {
+  if (d_head != DH) return KANTTS_E_UNSUPPORTED;
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = const_cast<float*>(o); a.ldo = ldo;
+  a.lse = const_cast<float*>(lse); a.lens = lens; a.bw_dev = bw_dev; a.bw = bw; a.B = B; a.H = H; a.L = L;
+  a.mode = mode; a.scale = 0.25f; a.drop_p = drop_p; a.seed = seed; a.d_o = d_o; a.lddo = lddo; a.dq = dq;
+  a.dk = dk; a.dv = dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv; a.dvec = dvec; a.accumulate_dq = accumulate_dq;
+  int rc = attn_check(a);
+  if (rc) return rc;
+  if (!d_o || !dq || !dk || !dv || !dvec || ((lddo | lddq | lddk | lddv) & 3)) return KANTTS_E_BADARG;
+  if (B == 0 || L == 0) return KANTTS_OK;
+  dim3 grid(kantts_cdiv(L, 128), H, B), block(128);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, (hipStream_t)stream, a);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -1,0 +1,272 @@
+// Segmented GEMM on CDNA4 matrix cores -- see include/kantts_hip.h for the contract.
+//
+// Block = 256 threads (4 waves, 2x2), output tile 64x64, reduction tile BK = 32.
+// Each wave owns a 32x32 sub-tile = 2x2 MFMA 16x16 fragments (f32x4 accumulators).
+//   precision 0: v_mfma_f32_16x16x4_f32   (8 k-steps per tile; exact fp32 FMA chain)
+//   precision 1: v_mfma_f32_16x16x32_bf16 (1 k-step per tile; fp32 operands are rounded to bf16
+//                when they are staged into LDS, accumulation stays fp32)
+// LDS images are [row][k] with k contiguous: fp32 rows are padded to 34 words (conflict-free
+// ds_read_b32 for the 16x16x4 fragment: bank = 2*row + k), bf16 rows to 40 halfwords (80 B, keeps
+// the 16-byte fragment reads aligned).
+// The operand loaders are generic (strides, conv taps as token shifts, gating, masks) so that one
+// kernel serves forward, dgrad and wgrad of Linear / Conv1d / ConvTranspose1d in channels-last
+// layout.  Lanes walk whichever operand dimension has unit stride so global loads coalesce.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define G_BM 64
+#define G_BN 64
+#define G_BK 32
+#define G_THREADS 256
+#define G_LDF 34 /* fp32 LDS row stride (words)     */
+#define G_LDH 40 /* bf16 LDS row stride (halfwords) */
+
+struct TokShift {
+  int axis;  // 0 none, 1 i, 2 kk
+  int shift;
+};
+
+__device__ __forceinline__ float g_load_a(const kantts_gemm_seg& s, const kantts_gemm_args& g, int i, int kk,
+                                          int shift) {
+  if (i >= g.M || kk >= s.klen) return 0.f;
+  long long ii = i, kq = kk;
+  if (shift != 0) {
+    if (s.a_tok_axis == 1) {
+      int t = i % g.T + shift;
+      if (t < 0 || t >= g.T) return 0.f;
+      ii = i + shift;
+    } else if (s.a_tok_axis == 2) {
+      int t = kk % g.T + shift;
+      if (t < 0 || t >= g.T) return 0.f;
+      kq = kk + shift;
+    }
+  }
+  if (g.kmask && g.kmask[kk]) return 0.f;
+  long long off = ii * s.a_is + kq * s.a_ks;
+  float v = s.a[off];
+  if (s.a_gate && !(s.a_gate[off] > 0.f)) v = 0.f;
+  if (s.a_drop_p > 0.f) v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed, (uint64_t)off);
+  return v;
+}
+
+__device__ __forceinline__ float g_load_b(const kantts_gemm_seg& s, const kantts_gemm_args& g, int j, int kk,
+                                          int shift, int tap) {
+  if (j >= g.N || kk >= s.klen) return 0.f;
+  long long kq = kk;
+  if (shift != 0 && s.b_tok_axis == 2) {
+    int t = kk % g.T + shift;
+    if (t < 0 || t >= g.T) return 0.f;
+    kq = kk + shift;
+  }
+  return s.b[(long long)j * s.b_js + kq * s.b_ks + (long long)tap * s.b_tap];
+}
+
+__device__ __forceinline__ float g_epilogue(const kantts_gemm_args& g, float acc, int i, int j, bool first_slice) {
+  float v = acc;
+  if (first_slice && g.bias) v += g.bias[j];
+  if (first_slice && g.bias2) v += g.bias2[j];
+  v *= g.alpha;
+  if (g.relu) v = fmaxf(v, 0.f);
+  if (g.drop_p > 0.f) v *= kantts_dropout_scale(g.drop_p, g.drop_seed, (uint64_t)i * (uint64_t)g.N + (uint64_t)j);
+  if (first_slice && g.res) v += g.res[(long long)i * g.r_is + (long long)j * g.r_js];
+  if (g.rowmask && g.rowmask[i]) v = 0.f;
+  return v;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_gemm_args g) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[2 * G_BM * G_LDF];
+  float* Af = lds_raw;
+  float* Bf = lds_raw + G_BM * G_LDF;
+  __bf16* Ah = reinterpret_cast<__bf16*>(lds_raw);
+  __bf16* Bh = Ah + G_BM * G_LDH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i0 = blockIdx.y * G_BM;
+  const int j0 = blockIdx.x * G_BN;
+  const int zslice = blockIdx.z;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float rowsum = 0.f;
+  const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0);
+  int tile_counter = 0;
+
+  for (int sidx = 0; sidx < g.nseg; ++sidx) {
+    const kantts_gemm_seg& s = g.seg[sidx];
+    const bool a_lane_i = (s.a_is == 1 && s.a_ks != 1);
+    const bool b_lane_j = (s.b_js == 1 && s.b_ks != 1);
+    for (int tap = 0; tap < s.ntaps; ++tap) {
+      const int a_shift = s.a_tok_axis ? s.a_shift0 + tap * s.a_shift_step : 0;
+      const int b_shift = s.b_tok_axis ? s.b_shift0 + tap * s.b_shift_step : 0;
+      for (int k0 = 0; k0 < s.klen; k0 += G_BK) {
+        const bool mine = (tile_counter % g.splitk) == zslice;
+        ++tile_counter;
+        if (!mine) continue;
+        // ---- stage A and B tiles into LDS (8 elements per thread each)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          int r, k;
+          if (a_lane_i) {
+            r = tid & 63;
+            k = (tid >> 6) + 4 * e;
+          } else {
+            k = tid & 31;
+            r = (tid >> 5) + 8 * e;
+          }
+          float v = g_load_a(s, g, i0 + r, k0 + k, a_shift);
+          if (BF16)
+            Ah[r * G_LDH + k] = (__bf16)v;
+          else
+            Af[r * G_LDF + k] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          int r, k;
+          if (b_lane_j) {
+            r = tid & 63;
+            k = (tid >> 6) + 4 * e;
+          } else {
+            k = tid & 31;
+            r = (tid >> 5) + 8 * e;
+          }
+          float v = g_load_b(s, g, j0 + r, k0 + k, b_shift, tap);
+          if (BF16)
+            Bh[r * G_LDH + k] = (__bf16)v;
+          else
+            Bf[r * G_LDF + k] = v;
+        }
+        __syncthreads();
+        if (do_rowsum && sidx == 0 && tid < G_BM) {
+          float t = 0.f;
+          if (BF16) {
+            for (int k = 0; k < G_BK; ++k) t += (float)Ah[tid * G_LDH + k];
+          } else {
+            for (int k = 0; k < G_BK; ++k) t += Af[tid * G_LDF + k];
+          }
+          rowsum += t;
+        }
+        // ---- MFMA
+        if (BF16) {
+          bf16x8 af[2], bfr[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            af[m] = *reinterpret_cast<const bf16x8*>(&Ah[(wr * 32 + m * 16 + (lane & 15)) * G_LDH + (lane >> 4) * 8]);
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            bfr[n] = *reinterpret_cast<const bf16x8*>(&Bh[(wc * 32 + n * 16 + (lane & 15)) * G_LDH + (lane >> 4) * 8]);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < G_BK / 4; ++ks) {
+            float af[2], bfr[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) af[m] = Af[(wr * 32 + m * 16 + (lane & 15)) * G_LDF + ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bfr[n] = Bf[(wc * 32 + n * 16 + (lane & 15)) * G_LDF + ks * 4 + (lane >> 4)];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bfr[n], acc[m][n], 0, 0, 0);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  if (do_rowsum && tid < G_BM && (i0 + tid) < g.M) atomicAdd(&g.a_rowsum[i0 + tid], rowsum);
+
+  // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  const bool first_slice = (zslice == 0);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int i = i0 + wr * 32 + m * 16 + (lane >> 4) * 4 + r;
+        int j = j0 + wc * 32 + n * 16 + (lane & 15);
+        if (i < g.M && j < g.N) {
+          float v = g_epilogue(g, acc[m][n][r], i, j, first_slice);
+          float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js];
+          if (g.accumulate)
+            atomicAdd(dst, v);
+          else
+            *dst = v;
+        }
+      }
+}
+
+// Scalar fp32 reference of the same contract (debug / cross-check of the MFMA fragment maps).
+__global__ void gemm_seg_ref_kernel(const kantts_gemm_args g) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)g.M * g.N) return;
+  int i = (int)(idx / g.N), j = (int)(idx % g.N);
+  float acc = 0.f, rs = 0.f;
+  for (int sidx = 0; sidx < g.nseg; ++sidx) {
+    const kantts_gemm_seg& s = g.seg[sidx];
+    for (int tap = 0; tap < s.ntaps; ++tap) {
+      const int a_shift = s.a_tok_axis ? s.a_shift0 + tap * s.a_shift_step : 0;
+      const int b_shift = s.b_tok_axis ? s.b_shift0 + tap * s.b_shift_step : 0;
+      for (int kk = 0; kk < s.klen; ++kk) {
+        float a = g_load_a(s, g, i, kk, a_shift);
+        acc = fmaf(a, g_load_b(s, g, j, kk, b_shift, tap), acc);
+        if (sidx == 0) rs += a;
+      }
+    }
+  }
+  if (g.a_rowsum && j == 0) atomicAdd(&g.a_rowsum[i], rs);
+  float v = g_epilogue(g, acc, i, j, true);
+  float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js];
+  if (g.accumulate)
+    atomicAdd(dst, v);
+  else
+    *dst = v;
+}
+
+extern "C" int kantts_gemm_seg_launch(const kantts_gemm_args* a, void* stream) {
+  if (!a || a->nseg < 1 || a->nseg > KANTTS_GEMM_MAX_SEG || a->M < 0 || a->N < 0 || !a->c) return KANTTS_E_BADARG;
+  if (a->M == 0 || a->N == 0) return KANTTS_OK;
+  int splitk = a->splitk < 1 ? 1 : a->splitk;
+  if (splitk > 1 && (!a->accumulate || a->relu || a->drop_p > 0.f)) return KANTTS_E_BADARG;
+  for (int s = 0; s < a->nseg; ++s) {
+    const kantts_gemm_seg& sg = a->seg[s];
+    if (!sg.a || !sg.b || sg.klen < 0 || sg.ntaps < 1) return KANTTS_E_BADARG;
+    if ((sg.a_tok_axis || sg.b_tok_axis) && a->T <= 0) return KANTTS_E_BADARG;
+  }
+  kantts_gemm_args g = *a;
+  g.splitk = splitk;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.precision == 2) {
+    g.splitk = 1;
+    long long total = (long long)g.M * g.N;
+    hipLaunchKernelGGL(gemm_seg_ref_kernel, dim3(kantts_cdiv(total, 256)), dim3(256), 0, st, g);
+  } else {
+    dim3 grid(kantts_cdiv(g.N, G_BN), kantts_cdiv(g.M, G_BM), splitk);
+    if (g.precision == 1)
+      hipLaunchKernelGGL(gemm_seg_mfma_kernel<true>, grid, dim3(G_THREADS), 0, st, g);
+    else if (g.precision == 0)
+      hipLaunchKernelGGL(gemm_seg_mfma_kernel<false>, grid, dim3(G_THREADS), 0, st, g);
+    else
+      return KANTTS_E_BADARG;
+  }
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_abi_version(void) { return 1; }
+extern "C" const char* kantts_target_arch(void) { return "gfx950"; }

@@ -1,0 +1,106 @@
+// Masked L1 reductions, gradient-norm and fused Adam over flat parameter arenas.
+//   MelReconLoss / ProsodyReconLoss ("mae")   kantts/train/loss.py:18-37, :51-85
+//   clip_grad_norm_ + Adam step               kantts/train/trainer.py:997-1004, configs/sambert_16k.yaml:54-60
+// All are single-pass HBM-bound kernels; scalars that the reference pulls to the host (.item())
+// stay in device memory so that the whole training step can be enqueued without a sync.
+#include "common.h"
+
+// loss[0] += sum_{b, t < lens[b], c} |target - pred| / (sum_b lens[b] * C)
+// grad (optional) = sign(pred - target) / (sum lens * C) on valid rows, 0 elsewhere.
+__global__ __launch_bounds__(256) void masked_l1_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       const int64_t* __restrict__ lens, float* __restrict__ loss,
+                                                       float* __restrict__ grad, int B, int T, int C) {
+  __shared__ float red[4];
+  long long denom_rows = 0;
+  for (int b = 0; b < B; ++b) denom_rows += min((long long)lens[b], (long long)T);
+  const float inv = 1.f / ((float)denom_rows * (float)C);
+  const long long total = (long long)B * T * C;
+  float part = 0.f;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    long long bt = g / C;
+    int t = (int)(bt % T), b = (int)(bt / T);
+    float gr = 0.f;
+    if (t < (int)lens[b]) {
+      float d = pred[g] - target[g];
+      part += fabsf(d);
+      gr = (d > 0.f) ? inv : ((d < 0.f) ? -inv : 0.f);
+    }
+    if (grad) grad[g] = gr;
+  }
+  part = kantts_block_sum(part, red);
+  if (threadIdx.x == 0) atomicAdd(loss, part * inv);
+}
+
+extern "C" int kantts_masked_l1(const float* pred, const float* target, const int64_t* lens, float* loss_accum,
+                                float* grad, int B, int T, int C, void* stream) {
+  if (!pred || !target || !lens || !loss_accum || B < 0 || T < 0 || C < 1) return KANTTS_E_BADARG;
+  long long total = (long long)B * T * C;
+  if (total == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(total, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(masked_l1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, lens, loss_accum,
+                     grad, B, T, C);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// out[0] += sum x^2
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long long n) {
+  __shared__ float red[4];
+  float part = 0.f;
+  const long long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = x4[i];
+    part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    part += x[i] * x[i];
+  part = kantts_block_sum(part, red);
+  if (threadIdx.x == 0) atomicAdd(out, part);
+}
+
+extern "C" int kantts_sumsq(const float* x, float* out_accum, long long n, void* stream) {
+  if (!x || !out_accum || n < 0 || ((uintptr_t)x & 15)) return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(n, 1024);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out_accum, n);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// torch.optim.Adam (amsgrad=False) on flat fp32 buffers with optional global-norm clipping:
+//   clip = max_norm > 0 ? min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)) : 1      (clip_grad_norm_)
+//   g *= clip; g += wd * p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                  float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                  const float* __restrict__ gnorm_sq, float max_norm) {
+  float clip = 1.f;
+  if (max_norm > 0.f && gnorm_sq) clip = fminf(1.f, max_norm / (sqrtf(*gnorm_sq) + 1e-6f));
+  const float step = lr / bc1;
+  const float rbc2 = 1.f / sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i] * clip;
+    float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+    float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi) * rbc2 + eps);
+  }
+}
+
+extern "C" int kantts_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                                const float* gnorm_sq, float max_norm, void* stream) {
+  if (!p || !g || !m || !v || n < 0) return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bias_corr1, bias_corr2, gnorm_sq, max_norm);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -1,0 +1,193 @@
+// LSTM recurrence (H = 128) as a persistent per-sequence kernel.
+//
+// Replaces the time loop of torch.nn.LSTM at
+//   kantts/models/sambert/adaptors.py:44-57 (2-layer duration LSTM), :109-134 (packed BiLSTM),
+//   kantts/models/sambert/kantts_sambert.py:637-646 (postnet LSTM over T_mel frames).
+// The input projection x @ W_ih^T + b_ih for all t is hoisted into one segmented GEMM (MFMA); this
+// kernel only runs the sequential part.  One workgroup (512 threads = 8 waves) owns one
+// (sequence, direction): thread r keeps row r of W_hh (128 floats) in VGPRs for the whole
+// sequence, h_{t-1} lives in LDS and is read as wave-uniform (broadcast) float4s, so a step costs
+// 128 FMAs per lane + two workgroup barriers and no HBM traffic besides gx[t] in / h[t] out.
+// pack_padded_sequence semantics come from per-sequence lengths: a row only runs t < len (the
+// reverse direction starts at len-1) and writes zeros to the padded tail.
+//
+// Gate order i, f, g, o (torch).  Saved for backward: post-activation gates (B,T,4H) and c (B,T,H).
+#include "common.h"
+
+#define LH 128
+#define LG 512
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// gx: (B,T,ndir*4H) [direction d at column offset d*4H]; out: (B,T,ndir*H)
+// whh: (ndir, 4H, H), bhh: (ndir, 4H); gates_out: (ndir,B,T,4H); c_out: (ndir,B,T,H)
+__global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                      const float* __restrict__ bhh, const int32_t* __restrict__ lens,
+                                                      float* __restrict__ out, float* __restrict__ gates_out,
+                                                      float* __restrict__ c_out, int B, int T, int ndir,
+                                                      int reverse_first) {
+  __shared__ __attribute__((aligned(16))) float h_s[LH];
+  __shared__ float g_s[LG];
+  const int r = threadIdx.x;
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const bool rev = reverse_first ? true : (dir == 1);
+  const int len = lens ? min(lens[b], T) : T;
+  float w[LH];
+  {
+    const float4* wp = reinterpret_cast<const float4*>(whh + ((long long)dir * LG + r) * LH);
+#pragma unroll
+    for (int k = 0; k < LH / 4; ++k) {
+      float4 t = wp[k];
+      w[4 * k] = t.x;
+      w[4 * k + 1] = t.y;
+      w[4 * k + 2] = t.z;
+      w[4 * k + 3] = t.w;
+    }
+  }
+  const float bias = bhh ? bhh[dir * LG + r] : 0.f;
+  if (r < LH) h_s[r] = 0.f;
+  float c = 0.f;
+  const long long gx_ld = (long long)ndir * LG;
+  const float* gxb = gx + (long long)b * T * gx_ld + dir * LG + r;
+  float* outb = out + (long long)b * T * ndir * LH + dir * LH;
+  float* gob = gates_out + (((long long)dir * B + b) * T) * LG;
+  float* cob = c_out + (((long long)dir * B + b) * T) * LH;
+  __syncthreads();
+  int t = rev ? len - 1 : 0;
+  float gnext = (len > 0) ? gxb[(long long)t * gx_ld] : 0.f;
+  for (int step = 0; step < len; ++step) {
+    const float gcur = gnext;
+    const int tn = rev ? t - 1 : t + 1;
+    if (step + 1 < len) gnext = gxb[(long long)tn * gx_ld];
+    float acc0 = gcur + bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    const float4* hp = reinterpret_cast<const float4*>(h_s);
+#pragma unroll
+    for (int k = 0; k < LH / 4; ++k) {
+      float4 hv = hp[k];
+      acc0 = fmaf(w[4 * k], hv.x, acc0);
+      acc1 = fmaf(w[4 * k + 1], hv.y, acc1);
+      acc2 = fmaf(w[4 * k + 2], hv.z, acc2);
+      acc3 = fmaf(w[4 * k + 3], hv.w, acc3);
+    }
+    const float pre = (acc0 + acc1) + (acc2 + acc3);
+    // activation by gate block: rows [0,256) sigmoid (i,f), [256,384) tanh (g), [384,512) sigmoid (o)
+    const float act = (r >= 2 * LH && r < 3 * LH) ? tanhf(pre) : sigmoidf_(pre);
+    g_s[r] = act;
+    gob[(long long)t * LG + r] = act;
+    __syncthreads();
+    if (r < LH) {
+      const float ig = g_s[r], fg = g_s[LH + r], gg = g_s[2 * LH + r], og = g_s[3 * LH + r];
+      c = fmaf(fg, c, ig * gg);
+      const float hn = og * tanhf(c);
+      h_s[r] = hn;
+      outb[(long long)t * ndir * LH + r] = hn;
+      cob[(long long)t * LH + r] = c;
+    }
+    __syncthreads();
+    t = tn;
+  }
+  // zero the padded tail (pad_packed_sequence) -- outputs only; saved state is never read there
+  for (int tt = len; tt < T; ++tt)
+    if (r < LH) outb[(long long)tt * ndir * LH + r] = 0.f;
+}
+
+// Backward through time: produces dgates_pre (ndir,B,T,4H) (gradient w.r.t. the pre-activation
+// gates); the weight / input gradients are GEMMs over it (host layer).
+// dout: (B,T,ndir*H).  W_hh^T is held in registers as 4 K-slices: thread (k = tid&127, qd = tid>>7)
+// keeps W_hh[qd*128 + rr][k] for rr = 0..127.
+__global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ whh,
+                                                      const int32_t* __restrict__ lens,
+                                                      const float* __restrict__ gates, const float* __restrict__ cst,
+                                                      float* __restrict__ dgates, int B, int T, int ndir,
+                                                      int reverse_first) {
+  __shared__ __attribute__((aligned(16))) float dg_s[LG];
+  __shared__ float part_s[4][LH];
+  __shared__ float dh_s[LH];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const bool rev = reverse_first ? true : (dir == 1);
+  const int len = lens ? min(lens[b], T) : T;
+  const int kcol = tid & (LH - 1), qd = tid >> 7;
+  float w[LH];
+#pragma unroll
+  for (int rr = 0; rr < LH; ++rr) w[rr] = whh[((long long)dir * LG + qd * LH + rr) * LH + kcol];
+  const float* doutb = dout + (long long)b * T * ndir * LH + dir * LH;
+  const float* gb = gates + (((long long)dir * B + b) * T) * LG;
+  const float* cb = cst + (((long long)dir * B + b) * T) * LH;
+  float* dgb = dgates + (((long long)dir * B + b) * T) * LG;
+  if (tid < LH) dh_s[tid] = 0.f;
+  float dc = 0.f;
+  __syncthreads();
+  // time runs opposite to the forward recurrence
+  int t = rev ? 0 : len - 1;
+  for (int step = 0; step < len; ++step) {
+    const int tprev = rev ? t + 1 : t - 1;  // the step that was computed BEFORE t in forward
+    const bool has_prev = (step + 1 < len);
+    if (tid < LH) {
+      const float ig = gb[(long long)t * LG + tid], fg = gb[(long long)t * LG + LH + tid];
+      const float gg = gb[(long long)t * LG + 2 * LH + tid], og = gb[(long long)t * LG + 3 * LH + tid];
+      const float cc = cb[(long long)t * LH + tid];
+      const float cprev = has_prev ? cb[(long long)tprev * LH + tid] : 0.f;
+      const float dh = doutb[(long long)t * ndir * LH + tid] + dh_s[tid];
+      const float tc = tanhf(cc);
+      const float d_o = dh * tc;
+      dc = dc + dh * og * (1.f - tc * tc);
+      const float d_i = dc * gg, d_g = dc * ig, d_f = dc * cprev;
+      const float pi = d_i * ig * (1.f - ig), pf = d_f * fg * (1.f - fg);
+      const float pg = d_g * (1.f - gg * gg), po = d_o * og * (1.f - og);
+      dc = dc * fg;
+      dg_s[tid] = pi;
+      dg_s[LH + tid] = pf;
+      dg_s[2 * LH + tid] = pg;
+      dg_s[3 * LH + tid] = po;
+      float* dst = dgb + (long long)t * LG;
+      dst[tid] = pi;
+      dst[LH + tid] = pf;
+      dst[2 * LH + tid] = pg;
+      dst[3 * LH + tid] = po;
+    }
+    __syncthreads();
+    {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float4* dp = reinterpret_cast<const float4*>(dg_s + qd * LH);
+#pragma unroll
+      for (int rr = 0; rr < LH / 4; ++rr) {
+        float4 d4 = dp[rr];
+        a0 = fmaf(w[4 * rr], d4.x, a0);
+        a1 = fmaf(w[4 * rr + 1], d4.y, a1);
+        a2 = fmaf(w[4 * rr + 2], d4.z, a2);
+        a3 = fmaf(w[4 * rr + 3], d4.w, a3);
+      }
+      part_s[qd][kcol] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (tid < LH) dh_s[tid] = (part_s[0][tid] + part_s[1][tid]) + (part_s[2][tid] + part_s[3][tid]);
+    __syncthreads();
+    t = tprev;
+  }
+  // padded tail contributes nothing
+  for (int tt = len; tt < T; ++tt) dgb[(long long)tt * LG + tid] = 0.f;
+}
+
+extern "C" int kantts_lstm_fwd(const float* gx, const float* whh, const float* bhh, const int32_t* lens, float* out,
+                               float* gates_save, float* c_save, int B, int T, int H, int ndir, int reverse_first,
+                               void* stream) {
+  if (!gx || !whh || !out || !gates_save || !c_save || B < 0 || T < 0 || ndir < 1 || ndir > 2) return KANTTS_E_BADARG;
+  if (H != LH) return KANTTS_E_UNSUPPORTED;
+  if (B == 0 || T == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, gx, whh, bhh, lens, out,
+                     gates_save, c_save, B, T, ndir, reverse_first);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_lstm_bwd(const float* dout, const float* whh, const int32_t* lens, const float* gates_save,
+                               const float* c_save, float* dgates, int B, int T, int H, int ndir, int reverse_first,
+                               void* stream) {
+  if (!dout || !whh || !gates_save || !c_save || !dgates || B < 0 || T < 0 || ndir < 1 || ndir > 2)
+    return KANTTS_E_BADARG;
+  if (H != LH) return KANTTS_E_UNSUPPORTED;
+  if (B == 0 || T == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, dout, whh, lens, gates_save,
+                     c_save, dgates, B, T, ndir, reverse_first);
+  KANTTS_CHECK_LAUNCH();
+}

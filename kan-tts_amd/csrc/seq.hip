@@ -1,0 +1,301 @@
+// Sequence plumbing kernels of the SAM-BERT path (all HBM/L2-bound gathers and FIRs):
+//   * embedding gather-sum (+ sqrt(d) scale + sinusoid table add)  kantts_sambert.py:308-329, :62-64
+//   * length regulator as an index gather + segment-sum backward    adaptors.py:15-36
+//   * duration-relative positions                                   positions.py:72-90
+//   * FSMN memory block: depth-wise FIR (k taps) + residual + masks fsmn.py:43-72
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// out[row, :] = scale * sum_k table_k[ids[row, k], :]  (+ pos[(row % T), :]); optional copy of the
+// scaled sum before the positional add (the reference returns it as `ling_embedding`).
+struct EmbedArgs {
+  const float* tab[4];
+  int ntab;
+  const int64_t* ids;  // (rows, ntab)
+  const float* pos;    // optional (>=T, D)
+  float* out;
+  float* scaled;  // optional
+  int rows, T, D;
+  float scale;
+};
+
+__global__ void embed_sum_kernel(const EmbedArgs a) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)a.rows * a.D;
+  if (idx >= total) return;
+  int row = (int)(idx / a.D), d = (int)(idx % a.D);
+  float s = 0.f;
+  for (int k = 0; k < a.ntab; ++k) s += a.tab[k][(long long)a.ids[(long long)row * a.ntab + k] * a.D + d];
+  s *= a.scale;
+  if (a.scaled) a.scaled[idx] = s;
+  if (a.pos) s += a.pos[(long long)(row % a.T) * a.D + d];
+  a.out[idx] = s;
+}
+
+struct EmbedBwdArgs {
+  float* dtab[4];
+  int ntab;
+  const int64_t* ids;
+  const float* dout;
+  int rows, D;
+  float scale;
+};
+
+__global__ void embed_sum_bwd_kernel(const EmbedBwdArgs a) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)a.rows * a.D;
+  if (idx >= total) return;
+  int row = (int)(idx / a.D), d = (int)(idx % a.D);
+  float g = a.dout[idx] * a.scale;
+  for (int k = 0; k < a.ntab; ++k)
+    if (a.dtab[k]) atomicAdd(&a.dtab[k][(long long)a.ids[(long long)row * a.ntab + k] * a.D + d], g);
+}
+
+extern "C" int kantts_embed_sum_fwd(const float* const* tables_host, int ntab, const int64_t* ids, const float* pos,
+                                    float* out, float* scaled_out, int rows, int T, int D, float scale, void* stream) {
+  if (!tables_host || ntab < 1 || ntab > 4 || !ids || !out || rows < 0 || D < 1 || T < 1) return KANTTS_E_BADARG;
+  if (rows == 0) return KANTTS_OK;
+  EmbedArgs a = {};
+  for (int k = 0; k < ntab; ++k) a.tab[k] = tables_host[k];
+  a.ntab = ntab; a.ids = ids; a.pos = pos; a.out = out; a.scaled = scaled_out; a.rows = rows; a.T = T; a.D = D;
+  a.scale = scale;
+  hipLaunchKernelGGL(embed_sum_kernel, dim3(kantts_cdiv((long long)rows * D, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_embed_sum_bwd(float* const* dtables_host, int ntab, const int64_t* ids, const float* dout,
+                                    int rows, int D, float scale, void* stream) {
+  if (!dtables_host || ntab < 1 || ntab > 4 || !ids || !dout || rows < 0 || D < 1) return KANTTS_E_BADARG;
+  if (rows == 0) return KANTTS_OK;
+  EmbedBwdArgs a = {};
+  for (int k = 0; k < ntab; ++k) a.dtab[k] = dtables_host[k];
+  a.ntab = ntab; a.ids = ids; a.dout = dout; a.rows = rows; a.D = D; a.scale = scale;
+  hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(kantts_cdiv((long long)rows * D, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Length-regulator index: reps = (dur + 0.5) truncated; frame t of row b belongs to token n iff
+// cs[n] <= t < cs[n+1].  One wave per batch row: lane-strided tokens, sequential prefix by lane 0
+// would be slow for long rows, so a wave scan is used.
+//   idx  (B, Tp) int32: token index or -1      pos (B, Tp) float: t - start + 1 (t+1 when uncovered)
+//   cs   (B, N+1) int32 exclusive prefix        lens (B) int64 = cs[N]
+__global__ __launch_bounds__(64) void lr_index_kernel(const int64_t* __restrict__ dur_i, const float* __restrict__ dur_f,
+                                                      int32_t* __restrict__ idx, float* __restrict__ pos,
+                                                      int32_t* __restrict__ cs, int64_t* __restrict__ lens, int N,
+                                                      int Tp) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int32_t* csb = cs + (long long)b * (N + 1);
+  // inclusive scan in chunks of 64 tokens
+  int carry = 0;
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    int n = n0 + lane;
+    int rep = 0;
+    if (n < N) {
+      if (dur_i)
+        rep = (int)dur_i[(long long)b * N + n];  // (int + 0.5).long() == int for ints >= 0
+      else
+        rep = (int)(long long)(dur_f[(long long)b * N + n] + 0.5f);
+    }
+    int v = rep;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    if (n < N) csb[n + 1] = carry + v;
+    carry += __shfl(v, 63, 64);
+  }
+  if (lane == 0) {
+    csb[0] = 0;
+    lens[b] = carry;
+  }
+  __syncthreads();  // single wave: makes the cs writes visible to the lanes below (same CU)
+  __threadfence_block();
+  const int total = carry;
+  for (int t = lane; t < Tp; t += 64) {
+    int id = -1;
+    float p = (float)(t + 1);
+    if (t < total) {
+      // binary search: largest n with cs[n] <= t
+      int lo = 0, hi = N;  // cs[lo] <= t < cs[hi]
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (csb[mid] <= t)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      id = lo;
+      p = (float)(t - csb[lo] + 1);
+    }
+    idx[(long long)b * Tp + t] = id;
+    pos[(long long)b * Tp + t] = p;
+  }
+}
+
+extern "C" int kantts_lr_index(const int64_t* dur_int, const float* dur_float, int32_t* idx, float* pos, int32_t* cs,
+                               int64_t* lens, int B, int N, int Tp, void* stream) {
+  if ((!dur_int && !dur_float) || !idx || !pos || !cs || !lens || B < 0 || N < 1 || Tp < 0) return KANTTS_E_BADARG;
+  if (B == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(lr_index_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dur_int, dur_float, idx, pos, cs,
+                     lens, N, Tp);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// out[b,t,:] = x[b, idx[b,t], :] for covered, un-masked frames (t < valid[b]), else 0.
+__global__ void lr_gather_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                 const int64_t* __restrict__ valid, float* __restrict__ out, int B, int N, int Tp, int C,
+                                 int ldo, int ooff) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)B * Tp * C;
+  if (g >= total) return;
+  int c = (int)(g % C);
+  long long bt = g / C;
+  int t = (int)(bt % Tp), b = (int)(bt / Tp);
+  int id = idx[bt];
+  float v = 0.f;
+  if (id >= 0 && (!valid || t < (int)valid[b])) v = x[((long long)b * N + id) * C + c];
+  out[bt * ldo + ooff + c] = v;
+}
+
+// dx[b,n,:] = sum_{t in [cs[n], cs[n+1]) , t < valid[b]} dout[b,t,:]
+__global__ void lr_gather_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ cs,
+                                     const int64_t* __restrict__ valid, float* __restrict__ dx, int B, int N, int Tp,
+                                     int C, int ldo, int ooff, int accumulate) {
+  long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)B * N * C;
+  if (g >= total) return;
+  int c = (int)(g % C);
+  long long bn = g / C;
+  int n = (int)(bn % N), b = (int)(bn / N);
+  int s = cs[(long long)b * (N + 1) + n], e = cs[(long long)b * (N + 1) + n + 1];
+  if (e > Tp) e = Tp;
+  if (valid && e > (int)valid[b]) e = (int)valid[b];
+  float acc = 0.f;
+  for (int t = s; t < e; ++t) acc += dout[((long long)b * Tp + t) * ldo + ooff + c];
+  if (accumulate)
+    dx[g] += acc;
+  else
+    dx[g] = acc;
+}
+
+extern "C" int kantts_lr_gather_fwd(const float* x, const int32_t* idx, const int64_t* valid_lens, float* out, int B,
+                                    int N, int Tp, int C, int ldo, int out_col_offset, void* stream) {
+  if (!x || !idx || !out || B < 0 || N < 1 || Tp < 0 || C < 1 || ldo < C) return KANTTS_E_BADARG;
+  long long total = (long long)B * Tp * C;
+  if (total == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(lr_gather_kernel, dim3(kantts_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, idx,
+                     valid_lens, out, B, N, Tp, C, ldo, out_col_offset);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_lr_gather_bwd(const float* dout, const int32_t* cs, const int64_t* valid_lens, float* dx, int B,
+                                    int N, int Tp, int C, int ldo, int out_col_offset, int accumulate, void* stream) {
+  if (!dout || !cs || !dx || B < 0 || N < 1 || Tp < 0 || C < 1 || ldo < C) return KANTTS_E_BADARG;
+  long long total = (long long)B * N * C;
+  if (total == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(lr_gather_bwd_kernel, dim3(kantts_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, cs,
+                     valid_lens, dx, B, N, Tp, C, ldo, out_col_offset, accumulate);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// FSMN memory block (channels-last):  xm = x * keep;  y = keep * (sum_k w[c,k] xm[t+k-lp] + xm[t]) (+ res)
+// keep[b,t] = t < lens[b] (all ones when lens == NULL).  Block = one (b, 32-frame tile), thread = channel.
+#define DW_TT 32
+__global__ void fsmn_dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                       const float* __restrict__ res, const int64_t* __restrict__ lens,
+                                       float* __restrict__ y, int B, int T, int C, int K, int lp) {
+  const int b = blockIdx.y, t0 = blockIdx.x * DW_TT;
+  const int len = lens ? (int)min((long long)lens[b], (long long)T) : T;
+  const float* xb = x + (long long)b * T * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* wc = w + (long long)c * K;
+    for (int tt = 0; tt < DW_TT; ++tt) {
+      const int t = t0 + tt;
+      if (t >= T) break;
+      float acc = 0.f;
+      if (t < len) {
+        for (int k = 0; k < K; ++k) {
+          int ts = t + k - lp;
+          if (ts >= 0 && ts < len) acc = fmaf(wc[k], xb[(long long)ts * C + c], acc);
+        }
+        acc += xb[(long long)t * C + c];
+      }
+      long long o = ((long long)b * T + t) * C + c;
+      if (res) acc += res[o];
+      y[o] = acc;
+    }
+  }
+}
+
+// dx = keep * ( sum_k w[c,k] dyk[t-k+lp] + dyk[t] ),  dyk = dy * keep
+__global__ void fsmn_dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                          const int64_t* __restrict__ lens, float* __restrict__ dx, int B, int T, int C,
+                                          int K, int lp) {
+  const int b = blockIdx.y, t0 = blockIdx.x * DW_TT;
+  const int len = lens ? (int)min((long long)lens[b], (long long)T) : T;
+  const float* db = dy + (long long)b * T * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* wc = w + (long long)c * K;
+    for (int tt = 0; tt < DW_TT; ++tt) {
+      const int t = t0 + tt;
+      if (t >= T) break;
+      float acc = 0.f;
+      if (t < len) {
+        for (int k = 0; k < K; ++k) {
+          int ts = t - k + lp;
+          if (ts >= 0 && ts < len) acc = fmaf(wc[k], db[(long long)ts * C + c], acc);
+        }
+        acc += db[(long long)t * C + c];
+      }
+      dx[((long long)b * T + t) * C + c] = acc;
+    }
+  }
+}
+
+// dw[c,k] += sum_{b,t<len} dy[b,t,c] * xm[b,t+k-lp,c];  block = (b, 128-frame tile), thread = channel
+#define DW_WT 128
+__global__ void fsmn_dwconv_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                          const int64_t* __restrict__ lens, float* __restrict__ dw, int B, int T, int C,
+                                          int K, int lp) {
+  const int b = blockIdx.y, t0 = blockIdx.x * DW_WT;
+  const int len = lens ? (int)min((long long)lens[b], (long long)T) : T;
+  if (t0 >= len) return;
+  const int t1 = min(t0 + DW_WT, len);
+  const float* db = dy + (long long)b * T * C;
+  const float* xb = x + (long long)b * T * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int k = 0; k < K; ++k) {
+      float acc = 0.f;
+      for (int t = t0; t < t1; ++t) {
+        int ts = t + k - lp;
+        if (ts >= 0 && ts < len) acc = fmaf(db[(long long)t * C + c], xb[(long long)ts * C + c], acc);
+      }
+      atomicAdd(&dw[(long long)c * K + k], acc);
+    }
+  }
+}
+
+extern "C" int kantts_fsmn_dwconv_fwd(const float* x, const float* w, const float* res, const int64_t* lens, float* y,
+                                      int B, int T, int C, int K, int left_pad, void* stream) {
+  if (!x || !w || !y || B < 0 || T < 0 || C < 1 || K < 1) return KANTTS_E_BADARG;
+  if (B == 0 || T == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(fsmn_dwconv_fwd_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)),
+                     0, (hipStream_t)stream, x, w, res, lens, y, B, T, C, K, left_pad);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const float* w, const int64_t* lens, float* dx,
+                                      float* dw_accum, int B, int T, int C, int K, int left_pad, void* stream) {
+  if (!dy || !x || !w || !dx || !dw_accum || B < 0 || T < 0 || C < 1 || K < 1) return KANTTS_E_BADARG;
+  if (B == 0 || T == 0) return KANTTS_OK;
+  int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+  hipLaunchKernelGGL(fsmn_dwconv_bwd_dx_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(threads), 0, (hipStream_t)stream,
+                     dy, w, lens, dx, B, T, C, K, left_pad);
+  hipLaunchKernelGGL(fsmn_dwconv_bwd_dw_kernel, dim3(kantts_cdiv(T, DW_WT), B), dim3(threads), 0, (hipStream_t)stream,
+                     dy, x, lens, dw_accum, B, T, C, K, left_pad);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -1,0 +1,166 @@
+"""ctypes binding of libkantts_hip.so (the C ABI declared in include/kantts_hip.h).
+
+This is the only place the product talks to native code.  There is NO CPU fallback: every wrapper
+raises if the library is missing or a tensor is not on a HIP device, so a GPU test can never pass
+on a silent eager path.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_longlong,
+                    c_uint64, c_void_p)
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "libkantts_hip.so"))
+_lib = None
+
+GEMM_MAX_SEG = 4
+PREC_FP32, PREC_BF16, PREC_REF = 0, 1, 2
+
+
+class GemmSeg(Structure):
+    _fields_ = [
+        ("a", c_void_p), ("a_gate", c_void_p), ("b", c_void_p),
+        ("a_is", c_int64), ("a_ks", c_int64), ("b_js", c_int64), ("b_ks", c_int64), ("b_tap", c_int64),
+        ("klen", c_int32), ("ntaps", c_int32),
+        ("a_tok_axis", c_int32), ("a_shift0", c_int32), ("a_shift_step", c_int32),
+        ("b_tok_axis", c_int32), ("b_shift0", c_int32), ("b_shift_step", c_int32),
+        ("a_drop_p", c_float), ("a_drop_seed", c_uint64),
+    ]
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("seg", GemmSeg * GEMM_MAX_SEG),
+        ("nseg", c_int32), ("M", c_int32), ("N", c_int32), ("T", c_int32),
+        ("c", c_void_p), ("c_is", c_int64), ("c_js", c_int64),
+        ("bias", c_void_p), ("bias2", c_void_p), ("res", c_void_p), ("r_is", c_int64), ("r_js", c_int64),
+        ("rowmask", c_void_p), ("kmask", c_void_p), ("a_rowsum", c_void_p),
+        ("alpha", c_float), ("relu", c_int32), ("accumulate", c_int32), ("splitk", c_int32),
+        ("precision", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64),
+    ]
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Load (once) and return the C-ABI library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libkantts_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C kan-tts_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.kantts_abi_version.restype = c_int
+        L.kantts_target_arch.restype = c_char_p
+        L.kantts_gemm_seg_launch.argtypes = [POINTER(GemmArgs), c_void_p]
+        i, f, p, ll, u64 = c_int, c_float, c_void_p, c_longlong, c_uint64
+        L.kantts_layernorm_fwd.argtypes = [p, p, p, p, p, p, i, i, f, p]
+        L.kantts_layernorm_bwd.argtypes = [p, p, p, p, p, p, p, p, i, i, p]
+        L.kantts_attn_fwd.argtypes = [p, p, p, i, i, i, p, i, p, p, p, p, i, i, i, i, i, i, f, u64, p]
+        L.kantts_attn_bwd.argtypes = [p, p, p, i, i, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p, p, i, i, i, i, i,
+                                      i, f, u64, p]
+        L.kantts_lstm_fwd.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, p]
+        L.kantts_lstm_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, p]
+        L.kantts_embed_sum_fwd.argtypes = [POINTER(c_void_p), i, p, p, p, p, i, i, i, f, p]
+        L.kantts_embed_sum_bwd.argtypes = [POINTER(c_void_p), i, p, p, i, i, f, p]
+        L.kantts_lr_index.argtypes = [p, p, p, p, p, p, i, i, i, p]
+        L.kantts_lr_gather_fwd.argtypes = [p, p, p, p, i, i, i, i, i, i, p]
+        L.kantts_lr_gather_bwd.argtypes = [p, p, p, p, i, i, i, i, i, i, i, p]
+        L.kantts_fsmn_dwconv_fwd.argtypes = [p, p, p, p, p, i, i, i, i, i, p]
+        L.kantts_fsmn_dwconv_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, p]
+        L.kantts_masked_l1.argtypes = [p, p, p, p, p, i, i, i, p]
+        L.kantts_sumsq.argtypes = [p, p, ll, p]
+        L.kantts_adam_step.argtypes = [p, p, p, p, ll, f, f, f, f, f, f, f, p, f, p]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "kantts_abi_version", "kantts_target_arch", "kantts_gemm_seg_launch", "kantts_layernorm_fwd",
+    "kantts_layernorm_bwd", "kantts_attn_fwd", "kantts_attn_bwd", "kantts_lstm_fwd", "kantts_lstm_bwd",
+    "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
+    "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_masked_l1",
+    "kantts_sumsq", "kantts_adam_step",
+]
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("libkantts_hip: %s failed with code %d" % (what, rc))
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a tensor (None -> NULL); refuses host tensors -- no CPU fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("kantts HIP op called with a CPU tensor; the product path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------------
+# global numerics mode of the contraction kernels: "fp32" (parity path) or "bf16" (throughput)
+_precision = {"gemm": PREC_BF16 if os.environ.get("KANTTS_PRECISION", "fp32") == "bf16" else PREC_FP32}
+if os.environ.get("KANTTS_GEMM_IMPL", "") == "ref":
+    _precision["gemm"] = PREC_REF
+
+
+def set_precision(mode: str):
+    _precision["gemm"] = {"fp32": PREC_FP32, "bf16": PREC_BF16, "ref": PREC_REF}[mode]
+
+
+def get_precision() -> str:
+    return {PREC_FP32: "fp32", PREC_BF16: "bf16", PREC_REF: "ref"}[_precision["gemm"]]
+
+
+def make_seg(a, a_is, a_ks, b, b_js, b_ks, klen, ntaps=1, b_tap=0, a_tok_axis=0, a_shift0=0, a_shift_step=0,
+             b_tok_axis=0, b_shift0=0, b_shift_step=0, a_gate=None, a_drop_p=0.0, a_drop_seed=0):
+    """a / b / a_gate are (tensor, element_offset) pairs or tensors."""
+
+    def addr(x):
+        if x is None:
+            return None
+        if isinstance(x, tuple):
+            return ptr(x[0], torch.float32) + 4 * int(x[1])
+        return ptr(x, torch.float32)
+
+    s = GemmSeg()
+    s.a, s.a_gate, s.b = addr(a), addr(a_gate), addr(b)
+    s.a_is, s.a_ks, s.b_js, s.b_ks, s.b_tap = int(a_is), int(a_ks), int(b_js), int(b_ks), int(b_tap)
+    s.klen, s.ntaps = int(klen), int(ntaps)
+    s.a_tok_axis, s.a_shift0, s.a_shift_step = int(a_tok_axis), int(a_shift0), int(a_shift_step)
+    s.b_tok_axis, s.b_shift0, s.b_shift_step = int(b_tok_axis), int(b_shift0), int(b_shift_step)
+    s.a_drop_p, s.a_drop_seed = float(a_drop_p), int(a_drop_seed)
+    return s
+
+
+def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_js=0, rowmask=None, kmask=None,
+         a_rowsum=None, alpha=1.0, relu=False, accumulate=False, splitk=1, T=0, drop_p=0.0, drop_seed=0,
+         precision=None, c_off=0):
+    g = GemmArgs()
+    assert 1 <= len(segs) <= GEMM_MAX_SEG
+    for k, s in enumerate(segs):
+        g.seg[k] = s
+    g.nseg, g.M, g.N, g.T = len(segs), int(M), int(N), int(T)
+    g.c = ptr(c, torch.float32) + 4 * int(c_off)
+    g.c_is, g.c_js = int(c_is), int(c_js)
+    g.bias, g.bias2 = ptr(bias, torch.float32), ptr(bias2, torch.float32)
+    g.res, g.r_is, g.r_js = ptr(res, torch.float32), int(r_is), int(r_js)
+    g.rowmask = ptr(rowmask)
+    g.kmask = ptr(kmask)
+    g.a_rowsum = ptr(a_rowsum, torch.float32)
+    g.alpha, g.relu, g.accumulate, g.splitk = float(alpha), int(bool(relu)), int(bool(accumulate)), int(splitk)
+    g.precision = _precision["gemm"] if precision is None else precision
+    g.drop_p, g.drop_seed = float(drop_p), int(drop_seed)
+    check(lib().kantts_gemm_seg_launch(ctypes.byref(g), stream()), "gemm_seg")

@@ -1,0 +1,589 @@
+"""torch.autograd.Function wrappers over the C ABI (one forward + one backward entry per fused op).
+
+Activations are channels-last (rows = tokens) fp32; every Function saves only what its backward
+kernels need (outputs for ReLU gating, LayerNorm statistics, attention log-sum-exp, LSTM gates).
+Nothing here computes on the host or with ATen kernels except trivial views / allocations.
+"""
+import itertools
+import math
+
+import torch
+
+from . import (PREC_REF, check, gemm, lib, make_seg, ptr, stream)
+
+_seed_counter = itertools.count(1)
+
+
+def next_seed():
+    """Per-call dropout seed derived from torch's seed (deterministic under torch.manual_seed)."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & ((1 << 63) - 1)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _splitk_for(n_out_rows, n_out_cols, k_total):
+    tiles = ((n_out_rows + 63) // 64) * ((n_out_cols + 63) // 64)
+    ktiles = max(1, (k_total + 31) // 32)
+    want = max(1, 512 // max(1, tiles))
+    return int(max(1, min(want, ktiles, 64)))
+
+
+# ================================================================================================
+# Fused linear / token-convolution
+# ================================================================================================
+class _FusedLinear(torch.autograd.Function):
+    """y = rowmask( dropout( act( (sum_k x_k @ W_k^T + bias [+ bias2]) * alpha ) ) + res )
+
+    modes
+      concat : one weight (N, sum K_k), inputs x_k side by side      (torch.cat + nn.Linear)
+      sum    : separate weights W_k (N, K_k) and biases               (fc_x(.) + fc_h(.))
+      conv   : one input, weight (N, Cin, KT), taps shift tokens      (nn.Conv1d over time, 'same' pad)
+    """
+
+    @staticmethod
+    def forward(ctx, opts, bias, bias2, res, rowmask, *xw):
+        nx = opts["nx"]
+        xs = [_c(t) for t in xw[:nx]]
+        ws = list(xw[nx:])
+        mode = opts["mode"]
+        relu, alpha, drop_p = opts["relu"], opts["alpha"], opts["drop_p"]
+        lead = xs[0].shape[:-1]
+        M = int(math.prod(lead))
+        N = ws[0].shape[0]
+        T = opts.get("T", 0)
+        y = torch.empty((M, N), device=xs[0].device, dtype=torch.float32)
+        segs = []
+        if mode == "conv":
+            w = _c(ws[0])
+            ws = [w]
+            cin, kt = w.shape[1], w.shape[2]
+            pad = opts["pad"]
+            segs.append(make_seg(xs[0], cin, 1, w, cin * kt, kt, cin, ntaps=kt, b_tap=1, a_tok_axis=1,
+                                 a_shift0=-pad, a_shift_step=opts.get("dilation", 1)))
+        elif mode == "concat":
+            w = _c(ws[0])
+            ws = [w]
+            ldw = w.shape[1]
+            off = 0
+            for x in xs:
+                k = x.shape[-1]
+                segs.append(make_seg(x, k, 1, (w, off), ldw, 1, k))
+                off += k
+            assert off == ldw, "concat widths do not match the weight"
+        else:  # sum
+            ws = [_c(w) for w in ws]
+            for x, w in zip(xs, ws):
+                k = x.shape[-1]
+                assert w.shape[1] == k
+                segs.append(make_seg(x, k, 1, w, k, 1, k))
+        seed = next_seed() if drop_p > 0 else 0
+        r = _c(res).view(M, N) if res is not None else None
+        rm = _c(rowmask).view(M) if rowmask is not None else None
+        gemm(segs, M, N, y, N, 1, bias=bias, bias2=bias2, res=r, r_is=N, r_js=1, rowmask=rm, alpha=alpha,
+             relu=relu, T=T, drop_p=drop_p, drop_seed=seed)
+        ctx.opts, ctx.seed, ctx.M, ctx.N, ctx.lead = opts, seed, M, N, lead
+        ctx.has = (bias is not None, bias2 is not None, res is not None)
+        ctx.save_for_backward(y if relu else None, rm, *xs, *ws)
+        return y.view(*lead, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        opts, M, N = ctx.opts, ctx.M, ctx.N
+        nx, mode, relu, alpha, drop_p = opts["nx"], opts["mode"], opts["relu"], opts["alpha"], opts["drop_p"]
+        T = opts.get("T", 0)
+        saved = ctx.saved_tensors
+        y_gate, rm = saved[0], saved[1]
+        xs, ws = list(saved[2:2 + nx]), list(saved[2 + nx:])
+        has_bias, has_bias2, has_res = ctx.has
+        dy = _c(dy).view(M, N)
+        if rm is not None and not relu:
+            dy = dy.masked_fill(rm.bool().view(M, 1), 0.0)
+        d_res = dy.view(*ctx.lead, N) if has_res else None
+        if has_res and rm is not None and relu:
+            d_res = dy.masked_fill(rm.bool().view(M, 1), 0.0).view(*ctx.lead, N)
+        # gradient that reaches the pre-activation: gate / dropout are applied inside the A loader
+        gate = y_gate if relu else None
+        a_drop_p, a_seed, balpha = 0.0, 0, alpha
+        if drop_p > 0:
+            if relu:
+                balpha = alpha / (1.0 - drop_p)  # kept & active elements are exactly where y > 0
+            else:
+                a_drop_p, a_seed = drop_p, ctx.seed
+        needs = ctx.needs_input_grad  # (opts, bias, bias2, res, rowmask, *xw)
+        dxs, dws = [None] * nx, [None] * len(ws)
+        dbias = torch.zeros(N, device=dy.device, dtype=torch.float32) if (has_bias or has_bias2) else None
+        first_tn = True
+        if mode == "conv":
+            w = ws[0]
+            cin, kt = w.shape[1], w.shape[2]
+            pad, dil = opts["pad"], opts.get("dilation", 1)
+            x = xs[0]
+            if needs[5]:
+                dx = torch.empty_like(x)
+                seg = make_seg(dy, N, 1, w, kt, cin * kt, N, ntaps=kt, b_tap=1, a_tok_axis=1, a_shift0=pad,
+                               a_shift_step=-dil, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed)
+                gemm([seg], M, cin, dx, cin, 1, alpha=balpha, T=T)
+                dxs[0] = dx
+            if needs[5 + nx]:
+                dw = torch.zeros_like(w)
+                sk = _splitk_for(N, cin, M)
+                for tap in range(kt):
+                    seg = make_seg(dy, 1, N, x, 1, cin, M, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed,
+                                   b_tok_axis=2, b_shift0=tap * dil - pad)
+                    gemm([seg], N, cin, dw, cin * kt, kt, c_off=tap, alpha=balpha, accumulate=True, splitk=sk, T=T,
+                         a_rowsum=dbias if (first_tn and dbias is not None) else None)
+                    first_tn = False
+                dws[0] = dw
+        else:
+            off = 0
+            ldw = ws[0].shape[1]
+            if mode == "concat" and needs[5 + nx]:
+                dws[0] = torch.zeros_like(ws[0])
+            for k, x in enumerate(xs):
+                kk = x.shape[-1]
+                w = ws[0] if mode == "concat" else ws[k]
+                woff = off if mode == "concat" else 0
+                wld = ldw if mode == "concat" else kk
+                if needs[5 + k]:
+                    dx = torch.empty_like(x)
+                    seg = make_seg(dy, N, 1, (w, woff), 1, wld, N, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed)
+                    gemm([seg], M, kk, dx, kk, 1, alpha=balpha)
+                    dxs[k] = dx
+                need_w = needs[5 + nx] if mode == "concat" else needs[5 + nx + k]
+                if need_w:
+                    if mode != "concat":
+                        dws[k] = torch.zeros_like(w)
+                    dwt = dws[0] if mode == "concat" else dws[k]
+                    seg = make_seg(dy, 1, N, x, 1, kk, M, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed)
+                    gemm([seg], N, kk, dwt, wld, 1, c_off=woff, alpha=balpha, accumulate=True,
+                         splitk=_splitk_for(N, kk, M),
+                         a_rowsum=dbias if (first_tn and dbias is not None) else None)
+                    first_tn = False
+                off += kk
+        if dbias is not None and first_tn:
+            # no weight gradient was requested but a bias needs one: plain column sum through the GEMM
+            raise RuntimeError("bias gradient without weight gradient is not supported")
+        if dbias is not None and balpha != 1.0:
+            dbias = dbias * balpha
+        return (None, dbias if has_bias else None, dbias if has_bias2 else None, d_res, None, *dxs, *dws)
+
+
+def linear(xs, weights, bias=None, *, mode=None, bias2=None, res=None, rowmask=None, relu=False, alpha=1.0,
+           drop_p=0.0, pad=0, dilation=1, T=0):
+    """Functional entry: xs / weights are tensors or lists (see _FusedLinear)."""
+    xs = [xs] if torch.is_tensor(xs) else list(xs)
+    weights = [weights] if torch.is_tensor(weights) else list(weights)
+    if mode is None:
+        mode = "conv" if weights[0].dim() == 3 and (weights[0].shape[2] > 1 or pad) else (
+            "sum" if len(weights) > 1 else "concat")
+    if mode != "conv" and weights[0].dim() == 3:  # Conv1d with kernel 1 == Linear
+        weights = [w.squeeze(-1) if w.dim() == 3 else w for w in weights]
+    if mode == "conv":
+        T = T or xs[0].shape[-2]
+    opts = dict(nx=len(xs), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p), pad=int(pad),
+                dilation=int(dilation), T=int(T))
+    return _FusedLinear.apply(opts, bias, bias2, res, rowmask, *xs, *weights)
+
+
+# ================================================================================================
+# LayerNorm
+# ================================================================================================
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        check(lib().kantts_layernorm_fwd(ptr(x, torch.float32), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
+                                         M, C, float(eps), stream()), "layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        check(lib().kantts_layernorm_bwd(ptr(dy, torch.float32), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                         ptr(dg), ptr(db), M, C, stream()), "layernorm_bwd")
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ================================================================================================
+# Attention
+# ================================================================================================
+MODE_KEYPAD, MODE_BAND_X, MODE_BAND_H = 0, 1, 2
+
+
+def _attn_fwd(q, qo, k, ko, v, vo, lens, bw_dev, bw, B, H, L, mode, drop_p, seed, want_probs):
+    dev = q.device
+    o = torch.empty((B * L, H * 16), device=dev, dtype=torch.float32)
+    lse = torch.empty((B, H, L), device=dev, dtype=torch.float32)
+    probs = torch.empty((H * B, L, L), device=dev, dtype=torch.float32) if want_probs else None
+    check(lib().kantts_attn_fwd(ptr(q) + 4 * qo, ptr(k) + 4 * ko, ptr(v) + 4 * vo, q.shape[-1], k.shape[-1],
+                                v.shape[-1], ptr(o), H * 16, ptr(lse), ptr(probs), ptr(lens), ptr(bw_dev), int(bw),
+                                B, H, L, 16, mode, float(drop_p), int(seed), stream()), "attn_fwd")
+    return o, lse, probs
+
+
+def _attn_bwd(q, qo, k, ko, v, vo, o, d_o, lse, dq, dqo, dk, dko, dv, dvo, acc_dq, lens, bw_dev, bw, B, H, L, mode,
+              drop_p, seed):
+    dvec = torch.empty_like(lse)
+    check(lib().kantts_attn_bwd(ptr(q) + 4 * qo, ptr(k) + 4 * ko, ptr(v) + 4 * vo, q.shape[-1], k.shape[-1],
+                                v.shape[-1], ptr(o), o.shape[-1], ptr(d_o), d_o.shape[-1], ptr(lse), ptr(dvec),
+                                ptr(dq) + 4 * dqo, ptr(dk) + 4 * dko, ptr(dv) + 4 * dvo, dq.shape[-1], dk.shape[-1],
+                                dv.shape[-1], int(acc_dq), ptr(lens), ptr(bw_dev), int(bw), B, H, L, 16, mode,
+                                float(drop_p), int(seed), stream()), "attn_bwd")
+
+
+class _SelfAttention(torch.autograd.Function):
+    """qkv: (B, L, 3*H*16) = [q | k | v] (fused projection output) -> ctx (B, L, H*16) [, probs]."""
+
+    @staticmethod
+    def forward(ctx, qkv, lens, H, drop_p, want_probs):
+        qkv = _c(qkv)
+        B, L, W = qkv.shape
+        D = H * 16
+        assert W == 3 * D
+        seed = next_seed() if drop_p > 0 else 0
+        q2 = qkv.view(B * L, W)
+        o, lse, probs = _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, None, 0, B, H, L, MODE_KEYPAD, drop_p, seed,
+                                  want_probs)
+        ctx.save_for_backward(q2, o, lse, lens)
+        ctx.cfg = (B, H, L, drop_p, seed)
+        if want_probs:
+            ctx.mark_non_differentiable(probs)
+            return o.view(B, L, D), probs
+        return o.view(B, L, D), None
+
+    @staticmethod
+    def backward(ctx, d_o, _dp):
+        q2, o, lse, lens = ctx.saved_tensors
+        B, H, L, drop_p, seed = ctx.cfg
+        D = H * 16
+        d_o = _c(d_o).view(B * L, D)
+        dqkv = torch.empty_like(q2)
+        _attn_bwd(q2, 0, q2, D, q2, 2 * D, o, d_o, lse, dqkv, 0, dqkv, D, dqkv, 2 * D, 0, lens, None, 0, B, H, L,
+                  MODE_KEYPAD, drop_p, seed)
+        return dqkv.view(B, L, 3 * D), None, None, None, None
+
+
+class _PncaAttention(torch.autograd.Function):
+    """PNCA dual attention sharing Q: x-band over the decoder's own K/V (from qkv) and h-band over
+    the memory K/V (hkv = [k | v]).  Returns ctx_x, ctx_h (B, L, H*16) [, probs_x, probs_h]."""
+
+    @staticmethod
+    def forward(ctx, qkv, hkv, lens, bw_dev, bw_x, bw_h, H, drop_p, want_probs):
+        qkv, hkv = _c(qkv), _c(hkv)
+        B, L, W = qkv.shape
+        D = H * 16
+        q2, h2 = qkv.view(B * L, W), hkv.view(B * L, 2 * D)
+        sx = next_seed() if drop_p > 0 else 0
+        sh = next_seed() if drop_p > 0 else 0
+        ox, lsex, px = _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, bw_dev, bw_x, B, H, L, MODE_BAND_X, drop_p, sx,
+                                 want_probs)
+        oh, lseh, ph = _attn_fwd(q2, 0, h2, 0, h2, D, lens, bw_dev, bw_h, B, H, L, MODE_BAND_H, drop_p, sh,
+                                 want_probs)
+        ctx.save_for_backward(q2, h2, ox, oh, lsex, lseh, lens, bw_dev)
+        ctx.cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)
+        if want_probs:
+            ctx.mark_non_differentiable(px, ph)
+        return ox.view(B, L, D), oh.view(B, L, D), px, ph
+
+    @staticmethod
+    def backward(ctx, d_ox, d_oh, _a, _b):
+        q2, h2, ox, oh, lsex, lseh, lens, bw_dev = ctx.saved_tensors
+        B, H, L, bw_x, bw_h, drop_p, sx, sh = ctx.cfg
+        D = H * 16
+        d_ox, d_oh = _c(d_ox).view(B * L, D), _c(d_oh).view(B * L, D)
+        dqkv = torch.empty_like(q2)
+        dhkv = torch.empty_like(h2)
+        _attn_bwd(q2, 0, q2, D, q2, 2 * D, ox, d_ox, lsex, dqkv, 0, dqkv, D, dqkv, 2 * D, 0, lens, bw_dev, bw_x, B, H,
+                  L, MODE_BAND_X, drop_p, sx)
+        _attn_bwd(q2, 0, h2, 0, h2, D, oh, d_oh, lseh, dqkv, 0, dhkv, 0, dhkv, D, 1, lens, bw_dev, bw_h, B, H, L,
+                  MODE_BAND_H, drop_p, sh)
+        return dqkv.view(B, L, 3 * D), dhkv.view(B, L, 2 * D), None, None, None, None, None, None, None
+
+
+def self_attention(qkv, lens_i32, n_head, drop_p=0.0, want_probs=False):
+    return _SelfAttention.apply(qkv, lens_i32, n_head, float(drop_p), bool(want_probs))
+
+
+def pnca_attention(qkv, hkv, lens_i32, bw_x, bw_h, n_head, drop_p=0.0, want_probs=False, bw_dev=None):
+    return _PncaAttention.apply(qkv, hkv, lens_i32, bw_dev, int(bw_x), int(bw_h), n_head, float(drop_p),
+                                bool(want_probs))
+
+
+# ================================================================================================
+# LSTM
+# ================================================================================================
+class _LSTM(torch.autograd.Function):
+    """One LSTM layer (1 or 2 directions), zero initial state, batch_first.
+    xs: inputs concatenated along features (list); per direction (w_ih, w_hh, b_ih, b_hh)."""
+
+    @staticmethod
+    def forward(ctx, nx, ndir, lens, *t):
+        xs = [_c(x) for x in t[:nx]]
+        params = list(t[nx:])  # ndir * 4
+        B, T = xs[0].shape[0], xs[0].shape[1]
+        H = params[1].shape[1]
+        G = 4 * H
+        dev = xs[0].device
+        M = B * T
+        gx = torch.empty((M, ndir * G), device=dev, dtype=torch.float32)
+        for d in range(ndir):
+            w_ih, b_ih = _c(params[4 * d]), params[4 * d + 2]
+            ld = w_ih.shape[1]
+            off, segs = 0, []
+            for x in xs:
+                k = x.shape[-1]
+                segs.append(make_seg(x, k, 1, (w_ih, off), ld, 1, k))
+                off += k
+            gemm(segs, M, G, gx, ndir * G, 1, c_off=d * G, bias=b_ih)
+        whh = torch.stack([_c(params[4 * d + 1]) for d in range(ndir)], 0) if ndir > 1 else _c(params[1]).unsqueeze(0)
+        bhh = torch.stack([params[4 * d + 3] for d in range(ndir)], 0) if ndir > 1 else params[3].unsqueeze(0)
+        whh, bhh = _c(whh), _c(bhh)
+        out = torch.empty((B, T, ndir * H), device=dev, dtype=torch.float32)
+        gates = torch.empty((ndir, B, T, G), device=dev, dtype=torch.float32)
+        cst = torch.empty((ndir, B, T, H), device=dev, dtype=torch.float32)
+        check(lib().kantts_lstm_fwd(ptr(gx), ptr(whh), ptr(bhh), ptr(lens), ptr(out), ptr(gates), ptr(cst), B, T, H,
+                                    ndir, 0, stream()), "lstm_fwd")
+        ctx.cfg = (nx, ndir, B, T, H)
+        ctx.save_for_backward(lens, whh, out, gates, cst, *xs, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        nx, ndir, B, T, H = ctx.cfg
+        G, M = 4 * H, B * T
+        sv = ctx.saved_tensors
+        lens, whh, out, gates, cst = sv[:5]
+        xs, params = list(sv[5:5 + nx]), list(sv[5 + nx:])
+        dout = _c(dout)
+        dg = torch.empty((ndir, B, T, G), device=dout.device, dtype=torch.float32)
+        check(lib().kantts_lstm_bwd(ptr(dout, torch.float32), ptr(whh), ptr(lens), ptr(gates), ptr(cst), ptr(dg), B, T,
+                                    H, ndir, 0, stream()), "lstm_bwd")
+        needs = ctx.needs_input_grad  # (nx, ndir, lens, *xs, *params)
+        dxs = [None] * nx
+        dparams = [None] * (4 * ndir)
+        for d in range(ndir):
+            dgd = dg[d].view(M, G)
+            w_ih = _c(params[4 * d])
+            ld = w_ih.shape[1]
+            off = 0
+            dw_ih = torch.zeros_like(w_ih)
+            db = torch.zeros(G, device=dout.device, dtype=torch.float32)
+            first = True
+            for k, x in enumerate(xs):
+                kk = x.shape[-1]
+                if needs[3 + k]:
+                    if dxs[k] is None:
+                        dxs[k] = torch.zeros_like(x) if ndir > 1 else torch.empty_like(x)
+                    gemm([make_seg(dgd, G, 1, (w_ih, off), 1, ld, G)], M, kk, dxs[k], kk, 1, accumulate=(ndir > 1))
+                gemm([make_seg(dgd, 1, G, x, 1, kk, M)], G, kk, dw_ih, ld, 1, c_off=off, accumulate=True,
+                     splitk=_splitk_for(G, kk, M), a_rowsum=db if first else None)
+                first = False
+                off += kk
+            dw_hh = torch.zeros((G, H), device=dout.device, dtype=torch.float32)
+            shift = 1 if d == 1 else -1  # h_{prev}: previous step in this direction's time order
+            seg = make_seg(dgd, 1, G, (out, d * H), 1, ndir * H, M, b_tok_axis=2, b_shift0=shift)
+            gemm([seg], G, H, dw_hh, H, 1, accumulate=True, splitk=_splitk_for(G, H, M), T=T)
+            dparams[4 * d], dparams[4 * d + 1], dparams[4 * d + 2], dparams[4 * d + 3] = dw_ih, dw_hh, db, db
+        return (None, None, None, *dxs, *dparams)
+
+
+def lstm(xs, params, lens_i32=None):
+    """params: [w_ih, w_hh, b_ih, b_hh] (+ the 4 reverse-direction tensors for a BiLSTM)."""
+    xs = [xs] if torch.is_tensor(xs) else list(xs)
+    ndir = len(params) // 4
+    return _LSTM.apply(len(xs), ndir, lens_i32, *xs, *params)
+
+
+# ================================================================================================
+# Embedding gather-sum
+# ================================================================================================
+def _ptr_array(tensors):
+    import ctypes
+
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t, torch.float32) if t is not None else None
+    return arr
+
+
+class _EmbedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, pos, scale, want_scaled, *tables):
+        ids = _c(ids)
+        if ids.dim() == 2:
+            ids = ids.unsqueeze(-1)
+        B, T, n = ids.shape
+        assert n == len(tables) and ids.dtype == torch.int64
+        D = tables[0].shape[1]
+        out = torch.empty((B, T, D), device=ids.device, dtype=torch.float32)
+        scaled = torch.empty_like(out) if want_scaled else None
+        tabs = [_c(t) for t in tables]
+        check(lib().kantts_embed_sum_fwd(_ptr_array(tabs), n, ptr(ids), ptr(pos), ptr(out), ptr(scaled), B * T, T, D,
+                                         float(scale), stream()), "embed_sum_fwd")
+        ctx.save_for_backward(ids)
+        ctx.cfg = (scale, [tuple(t.shape) for t in tables])
+        if want_scaled:
+            ctx.mark_non_differentiable(scaled)
+        return out, scaled
+
+    @staticmethod
+    def backward(ctx, dout, _ds):
+        (ids,) = ctx.saved_tensors
+        scale, shapes = ctx.cfg
+        dout = _c(dout)
+        B, T, n = ids.shape
+        D = shapes[0][1]
+        dt = [torch.zeros(s, device=dout.device, dtype=torch.float32) for s in shapes]
+        check(lib().kantts_embed_sum_bwd(_ptr_array(dt), n, ptr(ids), ptr(dout, torch.float32), B * T, D, float(scale),
+                                         stream()), "embed_sum_bwd")
+        return (None, None, None, None, *dt)
+
+
+def embed_sum(ids, tables, pos=None, scale=1.0, want_scaled=False):
+    return _EmbedSum.apply(ids, pos, float(scale), bool(want_scaled), *tables)
+
+
+# ================================================================================================
+# Length regulator
+# ================================================================================================
+def lr_index(durations, Tp):
+    """durations (B,N) int64 or fp32 -> idx (B,Tp) i32, pos (B,Tp) f32, cs (B,N+1) i32, lens (B) i64."""
+    d = _c(durations)
+    B, N = d.shape
+    dev = d.device
+    idx = torch.empty((B, Tp), device=dev, dtype=torch.int32)
+    pos = torch.empty((B, Tp), device=dev, dtype=torch.float32)
+    cs = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
+    lens = torch.empty((B,), device=dev, dtype=torch.int64)
+    if d.dtype == torch.int64:
+        di, df = ptr(d), None
+    else:
+        di, df = None, ptr(d, torch.float32)
+    check(lib().kantts_lr_index(di, df, ptr(idx), ptr(pos), ptr(cs), ptr(lens), B, N, Tp, stream()), "lr_index")
+    return idx, pos, cs, lens
+
+
+class _LRGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, cs, valid):
+        x = _c(x)
+        B, N, C = x.shape
+        Tp = idx.shape[1]
+        out = torch.empty((B, Tp, C), device=x.device, dtype=torch.float32)
+        check(lib().kantts_lr_gather_fwd(ptr(x, torch.float32), ptr(idx), ptr(valid), ptr(out), B, N, Tp, C, C, 0,
+                                         stream()), "lr_gather_fwd")
+        ctx.save_for_backward(cs, valid)
+        ctx.cfg = (B, N, Tp, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cs, valid = ctx.saved_tensors
+        B, N, Tp, C = ctx.cfg
+        dout = _c(dout)
+        dx = torch.empty((B, N, C), device=dout.device, dtype=torch.float32)
+        check(lib().kantts_lr_gather_bwd(ptr(dout, torch.float32), ptr(cs), ptr(valid), ptr(dx), B, N, Tp, C, C, 0, 0,
+                                         stream()), "lr_gather_bwd")
+        return dx, None, None, None
+
+
+def lr_gather(x, idx, cs, valid_lens):
+    return _LRGather.apply(x, idx, cs, valid_lens)
+
+
+# ================================================================================================
+# FSMN memory block
+# ================================================================================================
+class _FsmnMemory(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, res, lens, lp):
+        x, w = _c(x), _c(w)
+        B, T, C = x.shape
+        K = w.shape[-1]
+        y = torch.empty_like(x)
+        r = _c(res) if res is not None else None
+        check(lib().kantts_fsmn_dwconv_fwd(ptr(x, torch.float32), ptr(w, torch.float32), ptr(r), ptr(lens), ptr(y), B,
+                                           T, C, K, int(lp), stream()), "fsmn_dwconv_fwd")
+        ctx.save_for_backward(x, w, lens)
+        ctx.cfg = (B, T, C, K, int(lp), res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, lens = ctx.saved_tensors
+        B, T, C, K, lp, has_res = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        check(lib().kantts_fsmn_dwconv_bwd(ptr(dy, torch.float32), ptr(x), ptr(w), ptr(lens), ptr(dx), ptr(dw), B, T, C,
+                                           K, lp, stream()), "fsmn_dwconv_bwd")
+        return dx, dw, (dy if has_res else None), None, None
+
+
+def fsmn_memory(x, w, lens_i64, left_pad, res=None):
+    return _FsmnMemory.apply(x, w, res, lens_i64, left_pad)
+
+
+# ================================================================================================
+# Masked L1
+# ================================================================================================
+class _MaskedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, lens):
+        pred, target = _c(pred), _c(target)
+        if pred.dim() == 2:
+            B, T = pred.shape
+            C = 1
+        else:
+            B, T, C = pred.shape
+        loss = torch.zeros((), device=pred.device, dtype=torch.float32)
+        need_grad = ctx.needs_input_grad[0]
+        grad = torch.empty_like(pred) if need_grad else None
+        check(lib().kantts_masked_l1(ptr(pred, torch.float32), ptr(target, torch.float32), ptr(lens, torch.int64),
+                                     ptr(loss), ptr(grad), B, T, C, stream()), "masked_l1")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def masked_l1(pred, target, lens_i64):
+    return _MaskedL1.apply(pred, target, lens_i64)
+
+
+# ================================================================================================
+# Optimiser kernels on flat arenas
+# ================================================================================================
+def sumsq_into(x_flat, out_scalar):
+    check(lib().kantts_sumsq(ptr(x_flat, torch.float32), ptr(out_scalar, torch.float32), x_flat.numel(), stream()),
+          "sumsq")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=None, max_norm=0.0):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(lib().kantts_adam_step(ptr(p, torch.float32), ptr(g, torch.float32), ptr(m, torch.float32),
+                                 ptr(v, torch.float32), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                 float(weight_decay), float(bc1), float(bc2), ptr(gnorm_sq),
+                                 float(max_norm if max_norm else 0.0), stream()), "adam_step")

@@ -1,0 +1,84 @@
+"""FSMN encoder on HIP kernels (reference kantts/models/sambert/fsmn.py:8-124), channels-last."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from kantts._hip import ops
+from kantts.models.utils import SeqInfo
+
+
+class FeedForwardNet(nn.Module):
+    """Conv1d(k=1)+ReLU+dropout, Conv1d(k=1, no bias) == two GEMM launches (reference :8-40)."""
+
+    def __init__(self, d_in, d_hid, d_out, kernel_size=[1, 1], dropout=0.1):
+        super().__init__()
+        self.w_1 = nn.Conv1d(d_in, d_hid, kernel_size=kernel_size[0], padding=(kernel_size[0] - 1) // 2)
+        self.w_2 = nn.Conv1d(d_hid, d_out, kernel_size=kernel_size[1], padding=(kernel_size[1] - 1) // 2, bias=False)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        p = float(self.dropout.p) if self.training else 0.0
+        h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=True, drop_p=p)
+        return ops.linear(h, self.w_2.weight, None)
+
+
+class MemoryBlockV2(nn.Module):
+    """Depth-wise FIR memory with asymmetric padding (reference :43-72); mask, residual and the FIR
+    are one kernel (kantts_fsmn_dwconv_fwd)."""
+
+    def __init__(self, d, filter_size, shift, dropout=0.0):
+        super(MemoryBlockV2, self).__init__()
+        left_padding = int(round((filter_size - 1) / 2))
+        right_padding = int((filter_size - 1) / 2)
+        if shift > 0:
+            left_padding += shift
+            right_padding -= shift
+        self.lp, self.rp = left_padding, right_padding
+        self.conv_dw = nn.Conv1d(d, d, filter_size, 1, 0, groups=d, bias=False)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, input, mask=None, res=None):
+        info = SeqInfo.of(mask)
+        lens = None if info is None else info.lens64
+        p = float(self.dropout.p) if self.training else 0.0
+        if p > 0.0:
+            out = ops.fsmn_memory(input, self.conv_dw.weight, lens, self.lp)
+            out = F.dropout(out, p, True)
+            return out if res is None else out + res
+        return ops.fsmn_memory(input, self.conv_dw.weight, lens, self.lp, res=res)
+
+
+class FsmnEncoderV2(nn.Module):
+    """Stack of [FFN -> memory block -> (+x)] (reference :75-124)."""
+
+    def __init__(self, filter_size, fsmn_num_layers, input_dim, num_memory_units, ffn_inner_dim, dropout=0.0,
+                 shift=0):
+        super(FsmnEncoderV2, self).__init__()
+        self.filter_size = filter_size
+        self.fsmn_num_layers = fsmn_num_layers
+        self.num_memory_units = num_memory_units
+        self.ffn_inner_dim = ffn_inner_dim
+        self.dropout = dropout
+        self.shift = shift
+        if not isinstance(shift, list):
+            self.shift = [shift for _ in range(self.fsmn_num_layers)]
+        self.ffn_lst = nn.ModuleList()
+        self.ffn_lst.append(FeedForwardNet(input_dim, ffn_inner_dim, num_memory_units, dropout=dropout))
+        for i in range(1, fsmn_num_layers):
+            self.ffn_lst.append(FeedForwardNet(num_memory_units, ffn_inner_dim, num_memory_units, dropout=dropout))
+        self.memory_block_lst = nn.ModuleList()
+        for i in range(fsmn_num_layers):
+            self.memory_block_lst.append(MemoryBlockV2(num_memory_units, filter_size, self.shift[i], dropout))
+
+    def forward(self, input, mask=None):
+        info = SeqInfo.of(mask)
+        p = float(self.dropout) if self.training else 0.0
+        x = F.dropout(input, p, True) if p > 0 else input
+        for ffn, memory_block in zip(self.ffn_lst, self.memory_block_lst):
+            context = ffn(x)
+            same = self.num_memory_units == x.size(-1)
+            if p > 0:
+                memory = F.dropout(memory_block(context, info), p, True)
+                x = memory + x if same else memory
+            else:
+                x = memory_block(context, info, res=x if same else None)
+        return x

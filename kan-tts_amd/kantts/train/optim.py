@@ -1,0 +1,150 @@
+"""Flat parameter arena + fused Adam for the MI355X training step.
+
+The reference steps ``torch.optim.Adam`` over ~400 small tensors after
+``torch.nn.utils.clip_grad_norm_`` (kantts/train/trainer.py:997-1004) and lets DDP all-reduce 25 MB
+buckets (kantts/models/__init__.py:118-121).  Here every trainable parameter of a module is a view
+into ONE contiguous fp32 buffer; gradients are packed into a mirror buffer after backward, so that
+  * the global gradient norm is one reduction kernel whose result stays in device memory,
+  * clip + Adam is one elementwise kernel over the arena (kantts_adam_step),
+  * data-parallel training exchanges the gradient arena with a handful of large RCCL all-reduces
+    (xGMI is per-link bound: few large messages, not hundreds of small ones).
+``ArenaAdam`` keeps ``torch.optim.Optimizer`` semantics (param_groups / state_dict layout of Adam:
+step, exp_avg, exp_avg_sq) so LR schedulers and reference checkpoints keep working.
+"""
+import torch
+import torch.distributed as dist
+
+from kantts._hip import ops
+
+
+class ParamArena:
+    def __init__(self, module):
+        self.module = module
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("module has no trainable parameters")
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                view = self.flat[off:off + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                self.offsets.append(off)
+                off += n
+        self._zero_cache = {}
+        self.world_size = 1
+        self.n_buckets = 4
+
+    def view_of(self, flat, i):
+        p = self.params[i]
+        return flat[self.offsets[i]:self.offsets[i] + p.numel()].view(p.shape)
+
+    def enable_data_parallel(self, n_buckets=4):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.world_size = dist.get_world_size()
+        self.n_buckets = n_buckets
+        # replicas must start from identical weights (DDP broadcasts rank 0's copy at wrap time)
+        dist.broadcast(self.flat, src=0)
+
+    def pack_grads(self):
+        """Pack every ``p.grad`` into the gradient arena (one concatenation kernel)."""
+        pieces = []
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                z = self._zero_cache.get(p.numel())
+                if z is None:
+                    z = torch.zeros(p.numel(), device=self.grad.device, dtype=torch.float32)
+                    self._zero_cache[p.numel()] = z
+                pieces.append(z)
+            else:
+                pieces.append(g.reshape(-1))
+        torch.cat(pieces, out=self.grad)
+        return self.grad
+
+    def all_reduce_grads(self):
+        """Average the gradient arena over the data-parallel group (RCCL over xGMI; gloo in CPU tests)."""
+        if self.world_size <= 1:
+            return
+        n = self.numel
+        step = (n + self.n_buckets - 1) // self.n_buckets
+        handles = []
+        for s in range(0, n, step):
+            handles.append(dist.all_reduce(self.grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, async_op=True))
+        for h in handles:
+            h.wait()
+        self.grad.mul_(1.0 / self.world_size)
+
+
+class ArenaAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(amsgrad=False) over a ParamArena, with optional fused global-norm clipping."""
+
+    def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **unused):
+        if amsgrad:
+            raise NotImplementedError("amsgrad")
+        self.arena = arena
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False)
+        super().__init__(arena.params, defaults)
+        dev = arena.flat.device
+        self.exp_avg = torch.zeros_like(arena.flat)
+        self.exp_avg_sq = torch.zeros_like(arena.flat)
+        self.gnorm_sq = torch.zeros((), device=dev, dtype=torch.float32)
+        self.max_grad_norm = 0.0
+        self._step = 0
+        for i, p in enumerate(arena.params):
+            self.state[p] = {
+                "step": torch.tensor(0.0),
+                "exp_avg": arena.view_of(self.exp_avg, i),
+                "exp_avg_sq": arena.view_of(self.exp_avg_sq, i),
+            }
+
+    def set_grad_clip(self, max_norm):
+        """Fold ``clip_grad_norm_(params, max_norm)`` into the step (norm never leaves the device)."""
+        self.max_grad_norm = float(max_norm) if max_norm and max_norm > 0 else 0.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure")
+        group = self.param_groups[0]
+        arena = self.arena
+        g = arena.pack_grads()
+        arena.all_reduce_grads()
+        gn = None
+        if self.max_grad_norm > 0:
+            self.gnorm_sq.zero_()
+            ops.sumsq_into(g, self.gnorm_sq)
+            gn = self.gnorm_sq
+        self._step += 1
+        b1, b2 = group["betas"]
+        ops.adam_step(arena.flat, g, self.exp_avg, self.exp_avg_sq, group["lr"], b1, b2, group["eps"],
+                      group["weight_decay"], self._step, gnorm_sq=gn, max_norm=self.max_grad_norm)
+        return None  # per-parameter "step" entries are materialised lazily in state_dict()
+
+    def grad_norm(self):
+        """Global gradient norm of the last clipped step (device scalar)."""
+        return torch.sqrt(self.gnorm_sq)
+
+    def state_dict(self):
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = []
+        for i, p in enumerate(self.arena.params):
+            st = self.state[p]
+            m, v = self.arena.view_of(self.exp_avg, i), self.arena.view_of(self.exp_avg_sq, i)
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            st["exp_avg"], st["exp_avg_sq"] = m, v
+            steps.append(int(float(st["step"])))
+        self._step = max(steps) if steps else 0

@@ -1,0 +1,472 @@
+"""TEST INFRASTRUCTURE -- a numpy/torch CPU model of the C ABI in include/kantts_hip.h.
+
+``EmulatedLib`` exposes the same entry points as libkantts_hip.so but interprets the raw pointers as
+HOST memory.  It exists so that
+  * the host logic of kan-tts_amd/kantts (segment strides, offsets, token shifts, backward
+    formulas, module wiring) is testable on a machine without a GPU (tests/, ``-m "not gpu"``), and
+  * every GPU kernel has a per-entry-point oracle with identical argument semantics
+    (tests call the same wrapper once with device tensors and once, under this emulation, with
+    host tensors).
+It is injected ONLY by test fixtures (tests/conftest.py::emulated_cabi).  The product never imports
+this file and has no CPU fallback; bench.py / smoke() never enable it.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+U64 = np.uint64
+
+
+def _arr(ptr, n, dtype=np.float32):
+    if not ptr or n <= 0:
+        return None
+    ct = {np.float32: ctypes.c_float, np.int32: ctypes.c_int32, np.int64: ctypes.c_int64,
+          np.uint8: ctypes.c_uint8}[dtype]
+    return np.ctypeslib.as_array(ctypes.cast(int(ptr), ctypes.POINTER(ct)), shape=(int(n),))
+
+
+def _gather(ptr, offs, valid, dtype=np.float32):
+    """values[...] = mem[ptr + offs] where valid else 0 (offs in elements)."""
+    out = np.zeros(offs.shape, dtype=dtype)
+    if valid is None:
+        valid = np.ones(offs.shape, dtype=bool)
+    if not valid.any():
+        return out
+    lo, hi = int(offs[valid].min()), int(offs[valid].max())
+    esz = np.dtype(dtype).itemsize
+    mem = _arr(int(ptr) + lo * esz, hi - lo + 1, dtype)
+    out[valid] = mem[(offs[valid] - lo)]
+    return out
+
+
+def rng_u32(seed, idx):
+    """numpy twin of kantts_rng_u32 (csrc/common.h)."""
+    with np.errstate(over="ignore"):
+        z = U64(seed & 0xFFFFFFFFFFFFFFFF) + idx.astype(U64) * U64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> U64(30))) * U64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> U64(27))) * U64(0x94D049BB133111EB)
+        z = z ^ (z >> U64(31))
+    return (z >> U64(32)).astype(np.uint32)
+
+
+def dropout_scale(p, seed, idx):
+    if p <= 0:
+        return np.ones(idx.shape, dtype=np.float32)
+    thr = np.uint32(min(np.float32(p) * np.float32(4294967296.0), np.float32(4294967295.0)))
+    r = rng_u32(seed, idx)
+    return np.where(r < thr, np.float32(0), np.float32(1.0) / (np.float32(1.0) - np.float32(p))).astype(np.float32)
+
+
+def _val(x):
+    return x.value if hasattr(x, "value") else x
+
+
+class EmulatedLib:
+    # ------------------------------------------------------------------------------------ misc
+    def kantts_abi_version(self):
+        return 1
+
+    def kantts_target_arch(self):
+        return b"emulated"
+
+    # ------------------------------------------------------------------------------------ GEMM
+    def kantts_gemm_seg_launch(self, args_ref, stream):
+        g = args_ref._obj
+        M, N, T = g.M, g.N, g.T
+        if M == 0 or N == 0:
+            return 0
+        acc = np.zeros((M, N), dtype=np.float32)
+        rowsum = np.zeros(M, dtype=np.float32)
+        ii = np.arange(M, dtype=np.int64)[:, None]
+        jj = np.arange(N, dtype=np.int64)[:, None]
+        for si in range(g.nseg):
+            s = g.seg[si]
+            K = s.klen
+            if K == 0:
+                continue
+            kk = np.arange(K, dtype=np.int64)[None, :]
+            kmask = None
+            if g.kmask:
+                kmask = _arr(g.kmask, K, np.uint8) != 0
+            for tap in range(s.ntaps):
+                a_shift = s.a_shift0 + tap * s.a_shift_step if s.a_tok_axis else 0
+                b_shift = s.b_shift0 + tap * s.b_shift_step if s.b_tok_axis else 0
+                ai, ak = ii + 0 * kk, kk + 0 * ii
+                valid = np.ones((M, K), dtype=bool)
+                if a_shift != 0:
+                    if s.a_tok_axis == 1:
+                        t = ai % T + a_shift
+                        valid &= (t >= 0) & (t < T)
+                        ai = ai + a_shift
+                    elif s.a_tok_axis == 2:
+                        t = ak % T + a_shift
+                        valid &= (t >= 0) & (t < T)
+                        ak = ak + a_shift
+                if kmask is not None:
+                    valid &= ~kmask[None, :]
+                offs = ai * s.a_is + ak * s.a_ks
+                A = _gather(s.a, offs, valid)
+                if s.a_gate:
+                    gate = _gather(s.a_gate, offs, valid)
+                    A = np.where(gate > 0, A, np.float32(0))
+                if s.a_drop_p > 0:
+                    A = A * dropout_scale(s.a_drop_p, s.a_drop_seed, offs)
+                bk = kk + 0 * jj
+                bvalid = np.ones((N, K), dtype=bool)
+                if b_shift != 0 and s.b_tok_axis == 2:
+                    t = bk % T + b_shift
+                    bvalid &= (t >= 0) & (t < T)
+                    bk = bk + b_shift
+                boffs = jj * s.b_js + bk * s.b_ks + tap * s.b_tap
+                Bm = _gather(s.b, boffs, bvalid)
+                acc += A @ Bm.T
+                if si == 0:
+                    rowsum += A.sum(axis=1)
+        v = acc
+        if g.bias:
+            v = v + _arr(g.bias, N)[None, :]
+        if g.bias2:
+            v = v + _arr(g.bias2, N)[None, :]
+        v = v * np.float32(g.alpha)
+        if g.relu:
+            v = np.maximum(v, 0)
+        if g.drop_p > 0:
+            idx = (ii * N + np.arange(N, dtype=np.int64)[None, :])
+            v = v * dropout_scale(g.drop_p, g.drop_seed, idx)
+        if g.res:
+            v = v + _gather(g.res, ii * g.r_is + np.arange(N, dtype=np.int64)[None, :] * g.r_js, None)
+        if g.rowmask:
+            rm = _arr(g.rowmask, M, np.uint8) != 0
+            v = np.where(rm[:, None], np.float32(0), v)
+        v = v.astype(np.float32)
+        coffs = ii * g.c_is + np.arange(N, dtype=np.int64)[None, :] * g.c_js
+        lo, hi = int(coffs.min()), int(coffs.max())
+        cmem = _arr(int(g.c) + 4 * lo, hi - lo + 1)
+        if g.accumulate:
+            np.add.at(cmem, (coffs - lo).ravel(), v.ravel())
+        else:
+            cmem[(coffs - lo).ravel()] = v.ravel()
+        if g.a_rowsum:
+            _arr(g.a_rowsum, M)[:] += rowsum
+        return 0
+
+    # ------------------------------------------------------------------------------------ LayerNorm
+    def kantts_layernorm_fwd(self, x, gamma, beta, y, mean, rstd, M, C, eps, stream):
+        X = torch.from_numpy(_arr(x, M * C)).view(M, C)
+        mu = X.mean(1)
+        var = ((X - mu[:, None]) ** 2).mean(1)
+        rs = 1.0 / torch.sqrt(var + _val(eps))
+        Y = (X - mu[:, None]) * rs[:, None] * torch.from_numpy(_arr(gamma, C)) + torch.from_numpy(_arr(beta, C))
+        _arr(y, M * C)[:] = Y.reshape(-1).numpy()
+        _arr(mean, M)[:] = mu.numpy()
+        _arr(rstd, M)[:] = rs.numpy()
+        return 0
+
+    def kantts_layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C, stream):
+        DY = torch.from_numpy(_arr(dy, M * C)).view(M, C)
+        X = torch.from_numpy(_arr(x, M * C)).view(M, C)
+        G = torch.from_numpy(_arr(gamma, C))
+        mu, rs = torch.from_numpy(_arr(mean, M)), torch.from_numpy(_arr(rstd, M))
+        xh = (X - mu[:, None]) * rs[:, None]
+        g = DY * G
+        DX = rs[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+        _arr(dx, M * C)[:] = DX.reshape(-1).numpy()
+        _arr(dgamma, C)[:] += (DY * xh).sum(0).numpy()
+        _arr(dbeta, C)[:] += DY.sum(0).numpy()
+        return 0
+
+    # ------------------------------------------------------------------------------------ attention
+    @staticmethod
+    def _ranges(mode, L, length, bw):
+        lo = np.zeros(L, dtype=np.int64)
+        hi = np.zeros(L, dtype=np.int64)
+        for i in range(L):
+            if mode == 0:
+                lo[i], hi[i] = 0, length - 1
+            elif i >= length:
+                lo[i], hi[i] = 0, L - 1
+            elif mode == 1:
+                lo[i], hi[i] = max(0, i - bw), i
+            else:
+                lo[i], hi[i] = i, min(i + bw, L - 1, length - 1)
+        return lo, hi
+
+    def _attn_mats(self, q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed):
+        rows = B * L
+        Q = _gather(q, (np.arange(rows)[:, None] * ldq + np.arange(H * 16)[None, :]).astype(np.int64), None)
+        K = _gather(k, (np.arange(rows)[:, None] * ldk + np.arange(H * 16)[None, :]).astype(np.int64), None)
+        V = _gather(v, (np.arange(rows)[:, None] * ldv + np.arange(H * 16)[None, :]).astype(np.int64), None)
+        Q = torch.from_numpy(Q).view(B, L, H, 16).permute(0, 2, 1, 3)
+        K = torch.from_numpy(K).view(B, L, H, 16).permute(0, 2, 1, 3)
+        V = torch.from_numpy(V).view(B, L, H, 16).permute(0, 2, 1, 3)
+        lens_a = _arr(lens, B, np.int32) if lens else None
+        if bw_dev:
+            bw = int(_arr(bw_dev, 1, np.int32)[0])
+        allow = torch.zeros(B, L, L, dtype=torch.bool)
+        jj = np.arange(L)
+        for b in range(B):
+            lo, hi = self._ranges(mode, L, int(lens_a[b]) if lens_a is not None else L, bw)
+            allow[b] = torch.from_numpy((jj[None, :] >= lo[:, None]) & (jj[None, :] <= hi[:, None]))
+        S = torch.einsum("bhid,bhjd->bhij", Q, K) * 0.25
+        S = S.masked_fill(~allow[:, None], float("-inf"))
+        P = torch.softmax(S, dim=-1)
+        P = torch.nan_to_num(P, nan=0.0)
+        lse = torch.logsumexp(S, dim=-1)
+        lse = torch.where(torch.isfinite(lse), lse, torch.zeros_like(lse))
+        ds = torch.ones(B, H, L, L)
+        if drop_p > 0:
+            b_i, h_i, i_i, j_i = np.meshgrid(np.arange(B), np.arange(H), np.arange(L), np.arange(L), indexing="ij")
+            idx = ((h_i.astype(np.int64) * B + b_i) * L + i_i) * L + j_i
+            ds = torch.from_numpy(dropout_scale(drop_p, seed, idx))
+        return Q, K, V, P, ds, lse, allow
+
+    def kantts_attn_fwd(self, q, k, v, ldq, ldk, ldv, o, ldo, lse, probs, lens, bw_dev, bw, B, H, L, d_head, mode,
+                        drop_p, seed, stream):
+        drop_p, seed = _val(drop_p), _val(seed)
+        Q, K, V, P, ds, lse_t, _ = self._attn_mats(q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed)
+        Pd = P * ds
+        O = torch.einsum("bhij,bhjd->bhid", Pd, V).permute(0, 2, 1, 3).reshape(B * L, H * 16)
+        offs = (np.arange(B * L)[:, None] * ldo + np.arange(H * 16)[None, :]).astype(np.int64)
+        mem = _arr(o, int(offs.max()) + 1)
+        mem[offs.ravel()] = O.numpy().ravel()
+        _arr(lse, B * H * L)[:] = lse_t.reshape(-1).numpy()
+        if probs:
+            _arr(probs, H * B * L * L)[:] = Pd.permute(1, 0, 2, 3).reshape(-1).numpy()
+        return 0
+
+    def kantts_attn_bwd(self, q, k, v, ldq, ldk, ldv, o, ldo, d_o, lddo, lse, dvec, dq, dk, dv, lddq, lddk, lddv,
+                        accumulate_dq, lens, bw_dev, bw, B, H, L, d_head, mode, drop_p, seed, stream):
+        drop_p, seed = _val(drop_p), _val(seed)
+        Q, K, V, P, ds, _, _ = self._attn_mats(q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed)
+        cols = np.arange(H * 16)[None, :]
+        dO = _gather(d_o, (np.arange(B * L)[:, None] * lddo + cols).astype(np.int64), None)
+        dO = torch.from_numpy(dO).view(B, L, H, 16).permute(0, 2, 1, 3)
+        Pd = P * ds
+        dV = torch.einsum("bhij,bhid->bhjd", Pd, dO)
+        dP = torch.einsum("bhid,bhjd->bhij", dO, V) * ds
+        D = (P * dP).sum(-1, keepdim=True)
+        dS = P * (dP - D) * 0.25
+        dQ = torch.einsum("bhij,bhjd->bhid", dS, K)
+        dK = torch.einsum("bhij,bhid->bhjd", dS, Q)
+
+        def scatter(ptr, ld, t, acc):
+            offs = (np.arange(B * L)[:, None] * ld + cols).astype(np.int64)
+            mem = _arr(ptr, int(offs.max()) + 1)
+            vals = t.permute(0, 2, 1, 3).reshape(B * L, H * 16).numpy()
+            if acc:
+                mem[offs.ravel()] += vals.ravel()
+            else:
+                mem[offs.ravel()] = vals.ravel()
+
+        scatter(dq, lddq, dQ, accumulate_dq)
+        scatter(dk, lddk, dK, 0)
+        scatter(dv, lddv, dV, 0)
+        return 0
+
+    # ------------------------------------------------------------------------------------ LSTM
+    def kantts_lstm_fwd(self, gx, whh, bhh, lens, out, gates_save, c_save, B, T, H, ndir, reverse_first, stream):
+        G = 4 * H
+        GX = torch.from_numpy(_arr(gx, B * T * ndir * G)).view(B, T, ndir, G)
+        W = torch.from_numpy(_arr(whh, ndir * G * H)).view(ndir, G, H)
+        Bh = torch.from_numpy(_arr(bhh, ndir * G)).view(ndir, G) if bhh else torch.zeros(ndir, G)
+        ln = _arr(lens, B, np.int32) if lens else None
+        OUT = torch.zeros(B, T, ndir, H)
+        GS = torch.zeros(ndir, B, T, G)
+        CS = torch.zeros(ndir, B, T, H)
+        for d in range(ndir):
+            rev = bool(reverse_first) or d == 1
+            for b in range(B):
+                n = min(int(ln[b]), T) if ln is not None else T
+                h = torch.zeros(H)
+                c = torch.zeros(H)
+                order = range(n - 1, -1, -1) if rev else range(n)
+                for t in order:
+                    pre = GX[b, t, d] + Bh[d] + W[d] @ h
+                    i, f, g, o = torch.sigmoid(pre[:H]), torch.sigmoid(pre[H:2 * H]), torch.tanh(pre[2 * H:3 * H]), \
+                        torch.sigmoid(pre[3 * H:])
+                    c = f * c + i * g
+                    h = o * torch.tanh(c)
+                    OUT[b, t, d] = h
+                    GS[d, b, t] = torch.cat([i, f, g, o])
+                    CS[d, b, t] = c
+        _arr(out, B * T * ndir * H)[:] = OUT.reshape(-1).numpy()
+        _arr(gates_save, ndir * B * T * G)[:] = GS.reshape(-1).numpy()
+        _arr(c_save, ndir * B * T * H)[:] = CS.reshape(-1).numpy()
+        return 0
+
+    def kantts_lstm_bwd(self, dout, whh, lens, gates_save, c_save, dgates, B, T, H, ndir, reverse_first, stream):
+        G = 4 * H
+        DO = torch.from_numpy(_arr(dout, B * T * ndir * H)).view(B, T, ndir, H)
+        W = torch.from_numpy(_arr(whh, ndir * G * H)).view(ndir, G, H)
+        GS = torch.from_numpy(_arr(gates_save, ndir * B * T * G)).view(ndir, B, T, G)
+        CS = torch.from_numpy(_arr(c_save, ndir * B * T * H)).view(ndir, B, T, H)
+        ln = _arr(lens, B, np.int32) if lens else None
+        DG = torch.zeros(ndir, B, T, G)
+        for d in range(ndir):
+            rev = bool(reverse_first) or d == 1
+            for b in range(B):
+                n = min(int(ln[b]), T) if ln is not None else T
+                fwd_order = list(range(n - 1, -1, -1)) if rev else list(range(n))
+                dh = torch.zeros(H)
+                dc = torch.zeros(H)
+                for pos in range(n - 1, -1, -1):
+                    t = fwd_order[pos]
+                    cprev = CS[d, b, fwd_order[pos - 1]] if pos > 0 else torch.zeros(H)
+                    i, f, g, o = GS[d, b, t].split(H)
+                    tc = torch.tanh(CS[d, b, t])
+                    dht = DO[b, t, d] + dh
+                    do = dht * tc
+                    dc = dc + dht * o * (1 - tc * tc)
+                    pre = torch.cat([dc * g * i * (1 - i), dc * cprev * f * (1 - f), dc * i * (1 - g * g),
+                                     do * o * (1 - o)])
+                    dc = dc * f
+                    DG[d, b, t] = pre
+                    dh = pre @ W[d]
+        _arr(dgates, ndir * B * T * G)[:] = DG.reshape(-1).numpy()
+        return 0
+
+    # ------------------------------------------------------------------------------------ embedding
+    def kantts_embed_sum_fwd(self, tables, ntab, ids, pos, out, scaled, rows, T, D, scale, stream):
+        scale = _val(scale)
+        ID = _arr(ids, rows * ntab, np.int64).reshape(rows, ntab)
+        acc = np.zeros((rows, D), dtype=np.float32)
+        for k in range(ntab):
+            nrow = int(ID[:, k].max()) + 1
+            tab = _arr(tables[k], nrow * D).reshape(nrow, D)
+            acc += tab[ID[:, k]]
+        acc *= np.float32(scale)
+        if scaled:
+            _arr(scaled, rows * D)[:] = acc.ravel()
+        if pos:
+            P = _arr(pos, T * D).reshape(T, D)
+            acc = acc + P[np.arange(rows) % T]
+        _arr(out, rows * D)[:] = acc.ravel()
+        return 0
+
+    def kantts_embed_sum_bwd(self, dtables, ntab, ids, dout, rows, D, scale, stream):
+        scale = _val(scale)
+        ID = _arr(ids, rows * ntab, np.int64).reshape(rows, ntab)
+        DO = _arr(dout, rows * D).reshape(rows, D) * np.float32(scale)
+        for k in range(ntab):
+            if not dtables[k]:
+                continue
+            nrow = int(ID[:, k].max()) + 1
+            tab = _arr(dtables[k], nrow * D).reshape(nrow, D)
+            np.add.at(tab, ID[:, k], DO)
+        return 0
+
+    # ------------------------------------------------------------------------------------ length regulator
+    def kantts_lr_index(self, dur_int, dur_float, idx, pos, cs, lens, B, N, Tp, stream):
+        if dur_int:
+            reps = _arr(dur_int, B * N, np.int64).reshape(B, N).astype(np.int64)
+        else:
+            reps = (_arr(dur_float, B * N).reshape(B, N) + np.float32(0.5)).astype(np.int64)
+        CS = np.zeros((B, N + 1), dtype=np.int32)
+        CS[:, 1:] = np.cumsum(reps, axis=1)
+        IDX = np.full((B, Tp), -1, dtype=np.int32)
+        POS = np.tile(np.arange(1, Tp + 1, dtype=np.float32)[None, :], (B, 1))
+        for b in range(B):
+            tot = min(int(CS[b, N]), Tp)
+            t = np.arange(tot)
+            n = np.searchsorted(CS[b, 1:], t, side="right")
+            IDX[b, :tot] = n
+            POS[b, :tot] = t - CS[b, n] + 1
+        _arr(idx, B * Tp, np.int32)[:] = IDX.ravel()
+        _arr(pos, B * Tp)[:] = POS.ravel()
+        _arr(cs, B * (N + 1), np.int32)[:] = CS.ravel()
+        _arr(lens, B, np.int64)[:] = CS[:, N]
+        return 0
+
+    def kantts_lr_gather_fwd(self, x, idx, valid, out, B, N, Tp, C, ldo, off, stream):
+        X = _arr(x, B * N * C).reshape(B, N, C)
+        IDX = _arr(idx, B * Tp, np.int32).reshape(B, Tp)
+        V = _arr(valid, B, np.int64) if valid else None
+        O = _arr(out, B * Tp * ldo).reshape(B, Tp, ldo)
+        for b in range(B):
+            ok = IDX[b] >= 0
+            if V is not None:
+                ok &= np.arange(Tp) < V[b]
+            O[b, :, off:off + C] = np.where(ok[:, None], X[b, np.maximum(IDX[b], 0)], 0)
+        return 0
+
+    def kantts_lr_gather_bwd(self, dout, cs, valid, dx, B, N, Tp, C, ldo, off, accumulate, stream):
+        DO = _arr(dout, B * Tp * ldo).reshape(B, Tp, ldo)
+        CS = _arr(cs, B * (N + 1), np.int32).reshape(B, N + 1)
+        V = _arr(valid, B, np.int64) if valid else None
+        DX = _arr(dx, B * N * C).reshape(B, N, C)
+        for b in range(B):
+            for n in range(N):
+                s, e = int(CS[b, n]), min(int(CS[b, n + 1]), Tp)
+                if V is not None:
+                    e = min(e, int(V[b]))
+                acc = DO[b, s:e, off:off + C].sum(0) if e > s else 0
+                DX[b, n] = DX[b, n] + acc if accumulate else acc
+        return 0
+
+    # ------------------------------------------------------------------------------------ FSMN
+    def kantts_fsmn_dwconv_fwd(self, x, w, res, lens, y, B, T, C, K, lp, stream):
+        X = torch.from_numpy(_arr(x, B * T * C)).view(B, T, C)
+        W = torch.from_numpy(_arr(w, C * K)).view(C, 1, K)
+        keep = torch.ones(B, T, 1)
+        if lens:
+            ln = torch.from_numpy(_arr(lens, B, np.int64))
+            keep = (torch.arange(T)[None, :] < ln[:, None]).float()[:, :, None]
+        xm = X * keep
+        conv = torch.nn.functional.conv1d(torch.nn.functional.pad(xm.transpose(1, 2), (lp, K - 1 - lp)), W, groups=C)
+        Y = keep * (conv.transpose(1, 2) + xm)
+        if res:
+            Y = Y + torch.from_numpy(_arr(res, B * T * C)).view(B, T, C)
+        _arr(y, B * T * C)[:] = Y.reshape(-1).numpy()
+        return 0
+
+    def kantts_fsmn_dwconv_bwd(self, dy, x, w, lens, dx, dw, B, T, C, K, lp, stream):
+        X = torch.from_numpy(_arr(x, B * T * C)).view(B, T, C).clone().requires_grad_(True)
+        W = torch.from_numpy(_arr(w, C * K)).view(C, 1, K).clone().requires_grad_(True)
+        DY = torch.from_numpy(_arr(dy, B * T * C)).view(B, T, C)
+        keep = torch.ones(B, T, 1)
+        if lens:
+            ln = torch.from_numpy(_arr(lens, B, np.int64))
+            keep = (torch.arange(T)[None, :] < ln[:, None]).float()[:, :, None]
+        with torch.enable_grad():
+            xm = X * keep
+            conv = torch.nn.functional.conv1d(torch.nn.functional.pad(xm.transpose(1, 2), (lp, K - 1 - lp)), W,
+                                              groups=C)
+            Y = keep * (conv.transpose(1, 2) + xm)
+            Y.backward(DY)
+        _arr(dx, B * T * C)[:] = X.grad.reshape(-1).numpy()
+        _arr(dw, C * K)[:] += W.grad.reshape(-1).numpy()
+        return 0
+
+    # ------------------------------------------------------------------------------------ loss / optim
+    def kantts_masked_l1(self, pred, target, lens, loss, grad, B, T, C, stream):
+        P = _arr(pred, B * T * C).reshape(B, T, C)
+        Tg = _arr(target, B * T * C).reshape(B, T, C)
+        ln = np.minimum(_arr(lens, B, np.int64), T)
+        keep = (np.arange(T)[None, :] < ln[:, None])[:, :, None]
+        inv = np.float32(1.0) / (np.float32(ln.sum()) * np.float32(C))
+        d = P - Tg
+        _arr(loss, 1)[0] += np.float32((np.abs(d) * keep).sum(dtype=np.float64)) * inv
+        if grad:
+            _arr(grad, B * T * C)[:] = (np.sign(d) * keep * inv).astype(np.float32).ravel()
+        return 0
+
+    def kantts_sumsq(self, x, out, n, stream):
+        a = _arr(x, n)
+        _arr(out, 1)[0] += np.float32((a.astype(np.float64) ** 2).sum())
+        return 0
+
+    def kantts_adam_step(self, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2, gnorm_sq, max_norm, stream):
+        lr, b1, b2, eps, wd, bc1, bc2, max_norm = (np.float32(_val(t)) for t in (lr, b1, b2, eps, wd, bc1, bc2, max_norm))
+        P, G, Mm, V = _arr(p, n), _arr(g, n), _arr(m, n), _arr(v, n)
+        clip = np.float32(1.0)
+        if max_norm > 0 and gnorm_sq:
+            clip = min(np.float32(1.0), max_norm / (np.sqrt(_arr(gnorm_sq, 1)[0]) + np.float32(1e-6)))
+        gi = G * clip
+        if wd != 0:
+            gi = gi + wd * P
+        Mm[:] = b1 * Mm + (1 - b1) * gi
+        V[:] = b2 * V + (1 - b2) * gi * gi
+        P[:] = P - (lr / bc1) * Mm / (np.sqrt(V) / np.sqrt(bc2) + eps)
+        return 0

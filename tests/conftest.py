@@ -1,0 +1,49 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "kan-tts_amd"), os.path.join(ROOT, "oracle"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _emulate(monkeypatch):
+    """Route the ctypes binding to oracle/cabi_numpy.EmulatedLib (HOST memory).  Test-only: lets the
+    host logic of the product run without a GPU; the product itself has no such switch."""
+    import cabi_numpy
+    import kantts._hip as hip
+    import kantts._hip.ops as ops
+
+    emu = cabi_numpy.EmulatedLib()
+
+    def ptr(t, dtype=None):
+        if t is None:
+            return None
+        if dtype is not None and t.dtype != dtype:
+            raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+        assert not t.is_cuda
+        return t.data_ptr()
+
+    for mod in (hip, ops):
+        monkeypatch.setattr(mod, "lib", lambda: emu, raising=True)
+        monkeypatch.setattr(mod, "ptr", ptr, raising=True)
+        monkeypatch.setattr(mod, "stream", lambda: None, raising=True)
+    return emu
+
+
+@pytest.fixture
+def emulated_cabi(monkeypatch):
+    return _emulate(monkeypatch)
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    import torch
+
+    return torch.cuda.is_available()
