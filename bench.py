@@ -1,0 +1,178 @@
+"""bench.py -- SAM-BERT training-step throughput on MI355X (BASELINE.json metric / config).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" = one full training step of the hot path on one seeded synthetic batch per rank
+(B=32 phoneme sequences, T_in=64, ~612 mel frames): forward, the five masked-L1
+losses, backward, global-norm clip (1.0), fused Adam, NoamLR -- i.e. Sambert_Trainer.train_step
+(reference kantts/train/trainer.py:898-1005) with dropout on as shipped.  Inputs are resident in HBM
+before the timed region.  value = valid mel frames of all ranks / max-over-ranks wall time.
+Extra objects on the JSON line: "roofline" (dominant kernel = the segmented MFMA GEMM, measured with
+HIP events around every launch of one instrumented step) and "cpu_baseline" (the CPU oracle port
+timed on the host cores on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "kan-tts_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def sambert_yaml_config(cfg):
+    return {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": cfg,
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1.0e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}},
+        "grad_norm": 1.0, "batch_size": 32}
+
+
+def cpu_baseline(cfg, sample_B=8, iters=2):
+    """CPU oracle ("port" of the reference path, pinned against it by tests/golden) fwd+bwd on a
+    bounded sample of the same workload; Adam omitted (negligible next to fwd+bwd on CPU)."""
+    import torch_oracle as O
+
+    torch.manual_seed(0)
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+
+    m = KanTtsSAMBERT(dict(cfg))
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    batch = O.synthetic_sambert_batch(B=sample_B, T_in=64, seed=1234)
+    frames = int(batch["output_lengths"].sum())
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one():
+        for p in P.values():
+            p.grad = None
+        out = O.sambert_forward(P, cfg, **batch)
+        O.sambert_losses(out, batch["input_lengths"], batch["output_lengths"], batch["mel_targets"])["total"].backward()
+
+    one()
+    t0 = time.time()
+    for _ in range(iters):
+        one()
+    dt = (time.time() - t0) / iters
+    return {"value": frames / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle/torch_oracle.py fwd+bwd, fp32, dropout off, B=%d of the same seeded batch (%d valid frames), "
+                      "%d timed iters, %.2f s/iter" % (sample_B, frames, iters, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    import kantts._hip as hip
+    import torch_oracle as O
+    from kantts.models import model_builder
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+
+    hip.lib()
+    hip.set_precision(args.precision)
+    cfg = O.sambert_config(tiny=False)
+    torch.manual_seed(0)
+    model, opt, sch = model_builder(sambert_yaml_config(cfg), device=dev, rank=local_rank, distributed=distributed)
+    net, optimizer, scheduler = model["KanTtsSAMBERT"], opt["KanTtsSAMBERT"], sch["KanTtsSAMBERT"]
+    optimizer.set_grad_clip(1.0)
+    net.train()
+    mel_crit, pros_crit = MelReconLoss(), ProsodyReconLoss()
+    batch = {k: v.to(dev) for k, v in O.synthetic_sambert_batch(B=args.batch, T_in=64, seed=1234 + rank).items()}
+    frames = int(batch["output_lengths"].sum())
+
+    def step():
+        optimizer.zero_grad()
+        res = net(**batch)
+        mel_, mel = mel_crit(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+        d, p, e = pros_crit(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                            res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                            res["energy_predictions"])
+        loss = mel_ + mel + d + p + e
+        loss.backward()
+        optimizer.step()
+        scheduler.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(frames)], device=dev, dtype=torch.float64)
+    if distributed:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, total_frames = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, total_frames = dt, float(frames)
+
+    # ---- roofline of the dominant kernel: HIP events around every GEMM launch of one extra step
+    roof = None
+    if rank == 0:
+        hip.profile_begin()
+        step()
+        torch.cuda.synchronize()
+        prof = hip.profile_end()
+        if prof["launches"]:
+            tf = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.precision]
+            roof = {"bound": "mfma", "kernel": "gemm_seg_mfma_kernel<%s>" % args.precision, "achieved": tf,
+                    "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
+                    "launches_per_step": prof["launches"], "avg_launch_us": 1e3 * prof["ms"] / prof["launches"],
+                    "gemm_ms_per_step": prof["ms"], "gemm_gflop_per_step": prof["flops"] / 1e9,
+                    "whole_step_algorithmic_tflops": 456.9e9 * args.batch / 32 / (dt_max / args.steps) / 1e12}
+
+    if rank == 0:
+        out = {
+            "metric": "mel-frames/sec (SAM-BERT train)", "value": total_frames * args.steps / dt_max,
+            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "SAM-BERT full (sambert_16k.yaml zhcn) fwd+bwd+clip+Adam, batch %d/GPU, T_in 64, "
+                                   "%d valid mel frames on rank 0, dropout on" % (args.batch, frames),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "final_loss": float(loss)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -163,4 +163,29 @@ def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_j
     g.alpha, g.relu, g.accumulate, g.splitk = float(alpha), int(bool(relu)), int(bool(accumulate)), int(splitk)
     g.precision = _precision["gemm"] if precision is None else precision
     g.drop_p, g.drop_seed = float(drop_p), int(drop_seed)
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().kantts_gemm_seg_launch(ctypes.byref(g), stream()), "gemm_seg")
+        e1.record()
+        _profile.append((e0, e1, 2.0 * M * N * sum(s.klen * s.ntaps for s in segs)))
+        return
     check(lib().kantts_gemm_seg_launch(ctypes.byref(g), stream()), "gemm_seg")
+
+
+# ----------------------------------------------------------------------------------------------
+# bench instrumentation: HIP events (on the launch stream) around every GEMM launch
+_profile = None
+
+
+def profile_begin():
+    global _profile
+    _profile = []
+
+
+def profile_end():
+    global _profile
+    rec, _profile = _profile, None
+    torch.cuda.synchronize()
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
+    return {"launches": len(rec), "ms": ms, "flops": sum(f for _, _, f in rec)}

@@ -1,0 +1,282 @@
+"""GPU parity of every C-ABI entry point: the same host wrapper is run once with device tensors
+through libkantts_hip.so and once with host tensors through the emulated ABI (oracle/cabi_numpy.py).
+fp32 tolerances are written at each assert; integer outputs must be bit-exact."""
+import pytest
+import torch
+
+from util import assert_close, emulation, rel_l2, run_both
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    import kantts._hip as hip
+
+    return hip
+
+
+def _rand(*shape, seed=0, scale=1.0, grad=False):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(*shape, generator=g) * scale
+    return t.requires_grad_(grad)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def test_mfma_fragment_maps_identity_and_asymmetric():
+    """A = I against an asymmetric B catches row/col swaps in the MFMA C-write (guide section 3)."""
+    hip = _hip()
+    from kantts._hip import gemm, make_seg
+
+    for prec in (hip.PREC_FP32, hip.PREC_BF16, hip.PREC_REF):
+        n = 64
+        a = torch.eye(n, device="cuda")
+        b = (torch.arange(n * n, device="cuda", dtype=torch.float32).view(n, n) % 13) + \
+            torch.arange(n, device="cuda", dtype=torch.float32)[:, None] * 0.5
+        c = torch.empty(n, n, device="cuda")
+        gemm([make_seg(a, n, 1, b, n, 1, n)], n, n, c, n, 1, precision=prec)  # C = A @ B^T = B^T
+        torch.cuda.synchronize()
+        assert torch.equal(c, b.t().contiguous()), "precision %d" % prec
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("ref", 2e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("M,N,K", [(70, 50, 45), (256, 384, 128), (33, 1, 256), (130, 240, 80)])
+def test_linear_fwd_bwd(prec, tol, M, N, K):
+    hip = _hip()
+    from kantts._hip import ops
+
+    hip.set_precision(prec)
+    try:
+        x, w, b = _rand(M, K, seed=1, grad=True), _rand(N, K, seed=2, scale=0.2, grad=True), _rand(N, seed=3, grad=True)
+        res = _rand(M, N, seed=4, grad=True)
+        mask = (torch.arange(M) % 7 == 3)
+
+        def f(x, w, b, res, mask):
+            return ops.linear(x, w, b, res=res, rowmask=mask, relu=False, alpha=0.5)
+
+        go, gg, co, cg = run_both(f, x, w, b, res, mask)
+        scale = float(co[0].abs().max())
+        assert_close(go[0], co[0], tol * max(1.0, scale), what="y")
+        for a, c, nm in zip(gg, cg, "x w b res".split()):
+            assert rel_l2(a, c) < (5e-2 if prec == "bf16" else 1e-4), nm
+
+        def f2(x, w, b):
+            return ops.linear(x, w, b, relu=True)
+
+        go, gg, co, cg = run_both(f2, x, w, b)
+        assert_close(go[0], co[0], tol * max(1.0, scale), what="relu y")
+        for a, c, nm in zip(gg, cg, "x w b".split()):
+            assert rel_l2(a, c) < (5e-2 if prec == "bf16" else 1e-4), "relu " + nm
+    finally:
+        hip.set_precision("fp32")
+
+
+def test_linear_concat_sum_conv_and_dropout_exact():
+    """Multi-segment (concat / sum) and conv-tap addressing; dropout masks are regenerated from the
+    counter RNG, so the GPU and the emulated ABI must agree element-for-element."""
+    from kantts._hip import ops
+
+    B, T = 3, 17
+    x1, x2 = _rand(B, T, 40, seed=1, grad=True), _rand(B, T, 24, seed=2, grad=True)
+    w = _rand(48, 64, seed=3, scale=0.2, grad=True)
+    b = _rand(48, seed=4, grad=True)
+    go, gg, co, cg = run_both(lambda a, c, w, b: ops.linear([a, c], w, b, mode="concat", alpha=2.0), x1, x2, w, b)
+    assert_close(go[0], co[0], 5e-5, what="concat")
+    for a, c in zip(gg, cg):
+        assert rel_l2(a, c) < 1e-4
+    w1, w2 = _rand(32, 40, seed=5, scale=0.2, grad=True), _rand(32, 24, seed=6, scale=0.2, grad=True)
+    b1, b2 = _rand(32, seed=7, grad=True), _rand(32, seed=8, grad=True)
+    go, gg, co, cg = run_both(lambda a, c, w1, w2, b1, b2: ops.linear([a, c], [w1, w2], b1, bias2=b2, mode="sum"),
+                              x1, x2, w1, w2, b1, b2)
+    assert_close(go[0], co[0], 5e-5, what="sum")
+    for a, c in zip(gg, cg):
+        assert rel_l2(a, c) < 1e-4
+    wc = _rand(72, 40, 3, seed=9, scale=0.2, grad=True)
+    bc = _rand(72, seed=10, grad=True)
+    mask = torch.arange(T)[None, :] >= torch.tensor([17, 9, 13])[:, None]
+    go, gg, co, cg = run_both(lambda a, w, b, m: ops.linear(a, w, b, mode="conv", pad=1, relu=True, rowmask=m),
+                              x1, wc, bc, mask)
+    assert_close(go[0], co[0], 5e-5, what="conv3")
+    for a, c, nm in zip(gg, cg, ("x", "w", "b")):
+        assert rel_l2(a, c) < 1e-4, "conv3 " + nm
+    w9 = _rand(32, 1, 9, seed=11, grad=True)
+    xs = _rand(B, T, 1, seed=12, grad=True)
+    go, gg, co, cg = run_both(lambda a, w, b, r: ops.linear(a, w, b, mode="conv", pad=4, res=r), xs, w9,
+                              _rand(32, seed=13, grad=True), _rand(B, T, 32, seed=14, grad=True))
+    assert_close(go[0], co[0], 5e-5, what="conv9")
+    for a, c in zip(gg, cg):
+        assert rel_l2(a, c) < 1e-4
+    # dropout: identical masks on both sides (same seed stream) -> near bit-equal results
+    import kantts._hip.ops as O_
+
+    for relu in (False, True):
+        O_._seed_counter = __import__("itertools").count(1000)
+        torch.manual_seed(5)
+        a = ops.linear(x1.detach().cuda(), w.detach()[:, :40].contiguous().cuda(), b.detach().cuda(), relu=relu,
+                       drop_p=0.25).cpu()
+        O_._seed_counter = __import__("itertools").count(1000)
+        torch.manual_seed(5)
+        with emulation():
+            c = ops.linear(x1.detach(), w.detach()[:, :40].contiguous(), b.detach(), relu=relu, drop_p=0.25)
+        assert_close(a, c, 5e-5, what="dropout relu=%s" % relu)
+        frac = float((a == 0).float().mean())
+        assert (0.15 < frac < 0.35) if not relu else (0.5 < frac < 0.75)
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("M,C", [(37, 128), (2048, 512), (5, 80)])
+def test_layernorm(M, C):
+    from kantts._hip import ops
+
+    x, g, b = _rand(M, C, seed=1, grad=True), _rand(C, seed=2, grad=True), _rand(C, seed=3, grad=True)
+    go, gg, co, cg = run_both(lambda x, g, b: ops.layer_norm(x, g, b, 1e-6), x, g, b)
+    assert_close(go[0], co[0], 2e-5, what="ln y")
+    for a, c, nm in zip(gg, cg, ("dx", "dgamma", "dbeta")):
+        assert rel_l2(a, c) < 1e-4, nm
+
+
+# ------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_self_attention(drop):
+    import itertools
+
+    import kantts._hip.ops as O_
+    from kantts._hip import ops
+
+    B, L, H = 3, 41, 8
+    qkv = _rand(B, L, 3 * H * 16, seed=1, grad=True)
+    lens = torch.tensor([41, 17, 30], dtype=torch.int32)
+
+    def f(qkv, lens):
+        O_._seed_counter = itertools.count(77)
+        return ops.self_attention(qkv, lens, H, drop_p=drop, want_probs=True)
+
+    go, gg, co, cg = run_both(f, qkv, lens)
+    assert_close(go[0], co[0], 2e-5, what="ctx")
+    assert_close(go[1], co[1], 2e-6, what="probs")
+    assert rel_l2(gg[0], cg[0]) < 1e-4
+
+
+@pytest.mark.parametrize("bw", [0, 3, 50])
+def test_pnca_attention(bw):
+    from kantts._hip import ops
+
+    B, L, H = 3, 37, 8
+    qkv = _rand(B, L, 3 * H * 16, seed=1, grad=True)
+    hkv = _rand(B, L, 2 * H * 16, seed=2, grad=True)
+    lens = torch.tensor([37, 12, 25], dtype=torch.int32)
+    go, gg, co, cg = run_both(lambda a, b, l: ops.pnca_attention(a, b, l, bw, bw, H, want_probs=True), qkv, hkv, lens)
+    for k in range(4):
+        assert_close(go[k], co[k], 2e-5, what="pnca out %d" % k)
+    assert rel_l2(gg[0], cg[0]) < 1e-4 and rel_l2(gg[1], cg[1]) < 1e-4
+    go, gg, co, cg = run_both(lambda a, b: ops.pnca_attention(a, b, None, bw, bw, H), qkv, hkv)
+    assert_close(go[0], co[0], 2e-5, what="pnca nolens")
+
+
+# ------------------------------------------------------------------------------------------- LSTM
+def test_lstm_uni_bi_and_concat():
+    from kantts._hip import ops
+
+    B, T, I, H = 4, 23, 48, 128
+
+    def params(seed, nin):
+        return [_rand(4 * H, nin, seed=seed, scale=0.1, grad=True), _rand(4 * H, H, seed=seed + 1, scale=0.1, grad=True),
+                _rand(4 * H, seed=seed + 2, scale=0.1, grad=True), _rand(4 * H, seed=seed + 3, scale=0.1, grad=True)]
+
+    x = _rand(B, T, I, seed=1, grad=True)
+    p = params(10, I)
+    go, gg, co, cg = run_both(lambda x, *p: ops.lstm(x, list(p)), x, *p)
+    assert_close(go[0], co[0], 2e-5, what="lstm uni")
+    for a, c, nm in zip(gg, cg, ("x", "w_ih", "w_hh", "b_ih", "b_hh")):
+        assert rel_l2(a, c) < 2e-4, "uni " + nm
+    lens = torch.tensor([23, 7, 15, 1], dtype=torch.int32)
+    p2 = params(10, I) + params(20, I)
+    go, gg, co, cg = run_both(lambda x, l, *p: ops.lstm(x, list(p), l), x, lens, *p2)
+    assert_close(go[0], co[0], 2e-5, what="lstm bi packed")
+    names = ["x"] + ["%s_%s" % (n, d) for d in ("f", "r") for n in ("w_ih", "w_hh", "b_ih", "b_hh")]
+    for a, c, nm in zip(gg, cg, names):
+        assert rel_l2(a, c) < 2e-4, "bi " + nm
+    xa, xb = _rand(B, T, 32, seed=3, grad=True), _rand(B, T, 16, seed=4, grad=True)
+    go, gg, co, cg = run_both(lambda a, b, *p: ops.lstm([a, b], list(p)), xa, xb, *p)
+    assert_close(go[0], co[0], 2e-5, what="lstm concat")
+    for a, c in zip(gg, cg):
+        assert rel_l2(a, c) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------- sequence ops
+def test_embedding_and_length_regulator_bit_exact():
+    from kantts._hip import ops
+
+    B, T, D = 3, 11, 64
+    g = torch.Generator().manual_seed(0)
+    ids = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in (20, 5, 4, 6)], -1)
+    tabs = [_rand(n, D, seed=k, grad=True) for k, n in enumerate((20, 5, 4, 6))]
+    pos = _rand(30, D, seed=9)
+    go, gg, co, cg = run_both(lambda i, p, *t: ops.embed_sum(i, list(t), pos=p, scale=3.0, want_scaled=True), ids, pos,
+                              *tabs)
+    assert_close(go[0], co[0], 1e-5, what="embed")
+    assert_close(go[1], co[1], 1e-5, what="embed scaled")
+    for a, c in zip(gg, cg):
+        assert_close(a, c, 1e-4, what="embed grad")
+    dur = torch.randint(0, 6, (B, T), generator=g)
+    Tp = 60
+    outs = {}
+    for dev in ("cuda", "cpu"):
+        import contextlib
+
+        with (emulation() if dev == "cpu" else contextlib.nullcontext()):
+            outs[dev] = [t.cpu() for t in ops.lr_index(dur.to(dev), Tp)]
+            outs[dev] += [t.cpu() for t in ops.lr_index((dur.float() * 1.3).to(dev), Tp)]
+    for a, c in zip(outs["cuda"], outs["cpu"]):
+        assert torch.equal(a, c)  # index tensors: bit-exact
+    x = _rand(B, T, 32, seed=5, grad=True)
+    valid = torch.tensor([60, 20, 33])
+
+    def f(x, dur, valid):
+        idx, pos_, cs, lens = ops.lr_index(dur, Tp)
+        return ops.lr_gather(x, idx, cs, valid)
+
+    go, gg, co, cg = run_both(f, x, dur, valid)
+    assert torch.equal(go[0], co[0])  # copies: bit-exact
+    assert_close(gg[0], cg[0], 1e-5, what="lr bwd")
+
+
+@pytest.mark.parametrize("C,K,lp", [(128, 41, 20), (256, 41, 37)])
+def test_fsmn_memory(C, K, lp):
+    from kantts._hip import ops
+
+    B, T = 3, 70
+    x, w = _rand(B, T, C, seed=1, grad=True), _rand(C, 1, K, seed=2, scale=0.2, grad=True)
+    res = _rand(B, T, C, seed=3, grad=True)
+    lens = torch.tensor([70, 33, 51])
+    go, gg, co, cg = run_both(lambda x, w, r, l: ops.fsmn_memory(x, w, l, lp, res=r), x, w, res, lens)
+    assert_close(go[0], co[0], 2e-5, what="fsmn y")
+    for a, c, nm in zip(gg, cg, ("dx", "dw", "dres")):
+        assert rel_l2(a, c) < 1e-4, nm
+
+
+def test_masked_l1_and_optimizer_kernels():
+    from kantts._hip import ops
+
+    B, T, C = 4, 50, 80
+    p, t = _rand(B, T, C, seed=1, grad=True), _rand(B, T, C, seed=2)
+    lens = torch.tensor([50, 10, 33, 1])
+    go, gg, co, cg = run_both(lambda p, t, l: ops.masked_l1(p, t, l) * 3.0, p, t, lens)
+    assert abs(float(go[0]) - float(co[0])) < 1e-5
+    assert_close(gg[0], cg[0], 1e-8, what="l1 grad")
+    n = 100003
+    vals = {}
+    for dev in ("cuda", "cpu"):
+        import contextlib
+
+        with (emulation() if dev == "cpu" else contextlib.nullcontext()):
+            prm, g = _rand(n, seed=3).to(dev), _rand(n, seed=4).to(dev)
+            m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+            s = torch.zeros((), device=dev)
+            for step in (1, 2, 3):
+                s.zero_()
+                ops.sumsq_into(g, s)
+                ops.adam_step(prm, g, m, v, 1e-3, 0.9, 0.98, 1e-9, 0.0, step, gnorm_sq=s, max_norm=1.0)
+            vals[dev] = [t_.cpu() for t_ in (prm, m, v, s)]
+    assert abs(float(vals["cuda"][3]) - float(vals["cpu"][3])) < 1e-3 * float(vals["cpu"][3])
+    for a, c, nm in zip(vals["cuda"], vals["cpu"], ("p", "m", "v")):
+        assert_close(a, c, 1e-6, what="adam " + nm)

@@ -1,0 +1,137 @@
+"""Host-logic tests (no GPU): the product's Python layer (segment descriptors, strides, token shifts,
+backward formulas, module wiring, optimizer arena) driven through the emulated C ABI
+(oracle/cabi_numpy.py) and compared with the oracle / plain torch."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+import torch_oracle as O
+from util import ROOT, assert_close, rel_l2
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """libkantts_hip.so loads and exports exactly what include/kantts_hip.h declares (no compute)."""
+    import kantts._hip as hip
+
+    if not hip.available():
+        import __graft_entry__ as g
+
+        g.build()
+    header = open(os.path.join(ROOT, "include", "kantts_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(kantts_[a-z0-9_]+)\s*\(", header)))
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), "missing export: " + sym
+    assert sorted(hip.EXPORTED_SYMBOLS) == declared
+    assert lib.kantts_abi_version() == 1
+    lib.kantts_target_arch.restype = ctypes.c_char_p
+    assert lib.kantts_target_arch() == b"gfx950"
+
+
+def test_product_has_no_cpu_path():
+    """Calling an op with host tensors must fail loudly (no silent eager fallback)."""
+    from kantts._hip import ops
+
+    with pytest.raises(RuntimeError):
+        ops.layer_norm(torch.randn(4, 128), torch.ones(128), torch.zeros(128))
+
+
+def test_tiny_sambert_forward_backward_matches_oracle(emulated_cabi):
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+
+    cfg = O.sambert_config(tiny=True)
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(dict(cfg))
+    m.eval()
+    m.return_attns = True
+    batch = O.synthetic_sambert_batch(B=3, T_in=12, min_len=6, dur_hi=6)
+    res = m(**batch)
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    out = O.sambert_forward(P, cfg, **batch)
+    assert torch.equal(res["LR_length_rounded"], out["LR_length_rounded"])
+    assert res["x_band_width"] == out["x_band_width"]
+    for k in ["dec_outputs", "postnet_outputs", "log_duration_predictions", "pitch_predictions",
+              "energy_predictions", "LR_text_outputs", "LR_emo_outputs", "LR_spk_outputs", "ling_embedding"]:
+        assert_close(res[k].detach(), out[k].detach(), 2e-5, what=k)
+    for key in ["enc_slf_attn_lst", "pnca_x_attn_lst", "pnca_h_attn_lst"]:
+        assert len(res[key]) == len(out[key])
+        for a, b in zip(res[key], out[key]):
+            assert_close(a, b.detach(), 1e-5, what=key)
+    mel_, mel = MelReconLoss()(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+    d, p, e = ProsodyReconLoss()(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                 res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                 res["energy_predictions"])
+    total = mel_ + mel + d + p + e
+    total.backward()
+    L = O.sambert_losses(out, batch["input_lengths"], batch["output_lengths"], batch["mel_targets"])
+    assert abs(float(total) - float(L["total"])) < 1e-5
+    L["total"].backward()
+    for n, p_ in m.named_parameters():
+        if p_.requires_grad:
+            assert p_.grad is not None, n
+            assert rel_l2(p_.grad, P[n].grad) < 1e-4, n
+
+
+def test_dropout_backward_consistent_with_forward_mask(emulated_cabi):
+    """Epilogue dropout (with and without ReLU) regenerates the same mask in backward."""
+    from kantts._hip import ops
+
+    torch.manual_seed(1)
+    x = torch.randn(37, 24, requires_grad=True)
+    w = torch.randn(19, 24, requires_grad=True)
+    b = torch.randn(19, requires_grad=True)
+    for relu in (False, True):
+        y = ops.linear(x, w, b, relu=relu, drop_p=0.3)
+        dense = torch.relu(x @ w.t() + b) if relu else (x @ w.t() + b)
+        keep = (y != 0) if relu else torch.isclose(y, dense / 0.7, atol=1e-5)
+        if relu:
+            keep = keep | (dense <= 0)
+        frac = keep.float().mean().item()
+        assert 0.55 < frac < 0.85
+        mask = torch.where(torch.isclose(y, dense / 0.7, atol=1e-5), 1 / 0.7, 0.0)
+        gx, gw, gb = torch.autograd.grad(y.sum(), (x, w, b))
+        ex, ew, eb = torch.autograd.grad((dense * mask).sum(), (x, w, b))
+        assert_close(gx, ex, 1e-4, what="dx relu=%s" % relu)
+        assert_close(gw, ew, 1e-4, what="dw relu=%s" % relu)
+        assert_close(gb, eb, 1e-4, what="db relu=%s" % relu)
+
+
+def test_arena_adam_matches_torch_adam(emulated_cabi):
+    from kantts.train.optim import ArenaAdam, ParamArena
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    ref.load_state_dict(net.state_dict())
+    arena = ParamArena(net)
+    opt = ArenaAdam(arena, lr=1e-2, betas=(0.9, 0.98), eps=1e-9)
+    opt.set_grad_clip(0.05)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, betas=(0.9, 0.98), eps=1e-9)
+    for step in range(4):
+        x = torch.randn(6, 7)
+        for mdl, o in ((net, opt), (ref, ropt)):
+            o.zero_grad()
+            mdl(x).pow(2).sum().backward()
+            if mdl is ref:
+                torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+            o.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert_close(a.detach(), b.detach(), 1e-6, what="param")
+    sd = opt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd["state"][0]["step"]) == 4.0
+
+
+def test_oracle_matches_live_reference_when_present():
+    """In the build container the restatement is also compared with the live reference (own process:
+    the reference package is also called ``kantts``)."""
+    if not os.path.isdir("/root/reference/kantts"):
+        pytest.skip("reference tree not present (GPU box)")
+    r = subprocess.run(["python", os.path.join(ROOT, "oracle", "check_vs_reference.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

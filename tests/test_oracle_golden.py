@@ -1,0 +1,71 @@
+"""Pins oracle/torch_oracle.py (and the product's parameter construction) against fixtures dumped
+from the UNTOUCHED reference by oracle/make_golden.py.  CPU only; travels to the GPU box."""
+import os
+
+import pytest
+import torch
+
+import torch_oracle as O
+from util import GOLDEN, assert_close
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLDEN, name + ".pt"), weights_only=False)
+
+
+def _product_weights(fix):
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+
+    torch.manual_seed(fix["seed_w"])
+    m = KanTtsSAMBERT(dict(fix["cfg"]))
+    return m.state_dict()
+
+
+@pytest.mark.parametrize("name", ["sambert_tiny", "sambert_tiny16"])
+def test_state_dict_matches_reference(name):
+    """Same keys, shapes and (seeded) values as the reference's KanTtsSAMBERT.state_dict()."""
+    fix = _load(name)
+    sd = _product_weights(fix)
+    ref = fix["weight_checksums"]
+    assert list(sd.keys()) == list(ref.keys())
+    for k, v in sd.items():
+        shape, s, a = ref[k]
+        assert tuple(v.shape) == tuple(shape), k
+        assert abs(float(v.double().sum()) - s) <= 1e-9 * max(1.0, abs(a)), k
+        assert abs(float(v.double().abs().sum()) - a) <= 1e-9 * max(1.0, abs(a)), k
+
+
+@pytest.mark.parametrize("name", ["sambert_tiny", "sambert_tiny16"])
+def test_oracle_reproduces_reference_outputs(name):
+    fix = _load(name)
+    sd = _product_weights(fix)
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    batch = O.synthetic_sambert_batch(**fix["batch_args"])
+    out = O.sambert_forward(P, fix["cfg"], **batch)
+    assert out["x_band_width"] == fix["x_band_width"] and out["h_band_width"] == fix["h_band_width"]
+    assert torch.equal(out["LR_length_rounded"], fix["outputs"]["LR_length_rounded"])  # bit-exact
+    for k, ref in fix["outputs"].items():
+        if ref.is_floating_point():
+            assert_close(out[k].detach(), ref, atol=2e-5, what=k)
+    nb = 2
+    assert_close(out["enc_slf_attn_lst"][0][:nb].detach(), fix["attn_checks"]["enc0"], 1e-6, what="enc attn")
+    assert_close(out["pnca_x_attn_lst"][-1][:nb].detach(), fix["attn_checks"]["pnca_x_last"], 1e-6, what="x attn")
+    assert_close(out["pnca_h_attn_lst"][-1][:nb].detach(), fix["attn_checks"]["pnca_h_last"], 1e-6, what="h attn")
+    L = O.sambert_losses(out, batch["input_lengths"], batch["output_lengths"], batch["mel_targets"])
+    for k, v in fix["losses"].items():
+        assert abs(float(L[k]) - v) <= 2e-5 * max(1.0, abs(v)), k
+    L["total"].backward()
+    for k, g in fix["grads"].items():
+        assert_close(P[k].grad, g, atol=1e-6 + 1e-4 * float(g.abs().max()), what="grad " + k)
+    for k, (s, nrm) in fix["grad_summaries"].items():
+        assert abs(float(P[k].grad.double().norm()) - nrm) <= 1e-3 * nrm + 1e-7, k
+
+
+def test_audio_oracle_reproduces_reference():
+    import audio_oracle as A
+
+    fix = _load("melspec")
+    x = fix["wav"]
+    assert_close(A.mel_spectrogram(x), fix["mel_v1"], 2e-5, what="mel V1")
+    assert_close(A.mel_spectrogram(x, 16000, 2048, 200, 1000, 80, 0, 8000), fix["mel_16k"], 2e-5, what="mel 16k")
+    assert_close(A.stft_magnitude(x, 1024, 120, 600), fix["stft_1024_120_600"], 2e-5, what="stft")

@@ -1,0 +1,96 @@
+"""Shared helpers for the test-suite."""
+import contextlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+class _Patch:
+    def __init__(self):
+        self.saved = []
+
+    def setattr(self, mod, name, val, raising=True):
+        self.saved.append((mod, name, getattr(mod, name)))
+        setattr(mod, name, val)
+
+    def undo(self):
+        for mod, name, val in reversed(self.saved):
+            setattr(mod, name, val)
+        self.saved = []
+
+
+@contextlib.contextmanager
+def emulation():
+    """Temporarily route the binding to oracle/cabi_numpy (host memory) -- test-only."""
+    import conftest
+
+    p = _Patch()
+    try:
+        yield conftest._emulate(p)
+    finally:
+        p.undo()
+
+
+def to_dev(x, device):
+    if torch.is_tensor(x):
+        y = x.detach().to(device)
+        if x.requires_grad:
+            y.requires_grad_(True)
+        return y
+    if isinstance(x, (list, tuple)):
+        return type(x)(to_dev(t, device) for t in x)
+    if isinstance(x, dict):
+        return {k: to_dev(v, device) for k, v in x.items()}
+    return x
+
+
+def run_both(fn, *args, grads_of=(), device="cuda"):
+    """Run ``fn(*args)`` on the GPU through libkantts_hip.so and on the CPU through the emulated C ABI.
+    fn returns a tensor or tuple of tensors; tensors in ``args`` flagged requires_grad get gradients of
+    sum(out_k * W_k) with fixed random cotangents.  Returns (gpu_outs, gpu_grads, cpu_outs, cpu_grads)."""
+    results = []
+    cots = None
+    for dev in (device, "cpu"):
+        a = [to_dev(t, dev) for t in args]
+        ctx = emulation() if dev == "cpu" else contextlib.nullcontext()
+        with ctx:
+            out = fn(*a)
+            outs = [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(o)]
+            leaves = [t for t in _flatten(a) if torch.is_tensor(t) and t.requires_grad]
+            grads = []
+            diff = [o for o in outs if o.requires_grad]
+            if leaves and diff:
+                if cots is None:
+                    g = torch.Generator().manual_seed(99)
+                    cots = [torch.randn(o.shape, generator=g) for o in diff]
+                loss = sum((o * c.to(o.device)).sum() for o, c in zip(diff, cots))
+                grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        results.append(([o.detach().cpu() for o in outs], [None if g is None else g.detach().cpu() for g in grads]))
+    return results[0][0], results[0][1], results[1][0], results[1][1]
+
+
+def _flatten(x):
+    for t in x:
+        if isinstance(t, (list, tuple)):
+            yield from _flatten(t)
+        else:
+            yield t
+
+
+def assert_close(a, b, atol, rtol=0.0, what=""):
+    assert a.shape == b.shape, "%s shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    err = (a.double() - b.double()).abs()
+    tol = atol + rtol * b.double().abs()
+    bad = err > tol
+    if bad.any():
+        i = int(err.argmax())
+        raise AssertionError("%s: max abs err %.3e (ref %.3e) at flat %d; %d/%d beyond tol %.1e" % (
+            what, float(err.max()), float(b.reshape(-1)[i]), i, int(bad.sum()), err.numel(), atol))
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
