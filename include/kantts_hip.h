@@ -185,6 +185,19 @@ int kantts_adam_step(float* p, const float* g, float* m, float* v, long long n, 
                      float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
                      const float* gnorm_sq, float max_norm, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused framed STFT -> |.| -> sparse mel filterbank -> 20 log10 - 20 -> clamp(8(x+100)/100-4, +-4).
+ * Replaces MelSpectrogram.forward (kantts/utils/audio_torch.py:155-186) and, with out_mag only,
+ * stft() (:8-31).  wav (B,T); window (n_fft) = hann(win_length) centred in n_fft; twiddle (n_fft/2
+ * complex pairs) = exp(-2 pi i t / n_fft); pad_mode 0 = zeros (MelSpectrogram), 1 = reflect (stft);
+ * frames = 1 + T / hop.  The mel basis is passed in support form: filter m covers bins
+ * [mel_start[m], mel_start[m]+mel_len[m]) with weights mel_w[mel_off[m] ...].
+ * out_mel (B, n_mels, frames) and/or out_mag (B, frames, n_fft/2+1). */
+int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                       const float* window, const float* twiddle, float eps_power, const int32_t* mel_start,
+                       const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels,
+                       float eps_mel, float* out_mel, float* out_mag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

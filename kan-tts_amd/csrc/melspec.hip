@@ -1,0 +1,162 @@
+// Fused framed STFT -> magnitude -> mel filterbank -> dB -> normalise, one pass over the waveform.
+//
+// Replaces (reference) kantts/utils/audio_torch.py:155-186 (MelSpectrogram.forward: torch.stft +
+// power + sqrt + matmul(513x80) + clamp + 20 log10 + symmetric normalise) and :8-31 (stft magnitude).
+// HBM-bound by construction: algorithmic traffic is hop*4 B read + n_mels*4 B written per frame
+// (1344 B at hop 256 / 80 mels); the windowed frame, the complex spectrum (4 KB/frame if it went
+// through HBM as with a library FFT) and the 513-bin magnitude never leave the CU.
+//   * one workgroup (256 threads) walks MEL_FB consecutive frames of one utterance;
+//   * real FFT of size N as a complex radix-2 Stockham FFT of size N/2 in LDS (ping-pong, twiddles
+//     from a host-built fp64->fp32 table), then the even/odd split post-pass;
+//   * the mel filterbank is applied in its sparse (triangular support) form straight from LDS;
+//   * each thread owns one mel channel and stores MEL_FB consecutive frames (contiguous in the
+//     (B, n_mels, frames) output) at once.
+#include "common.h"
+
+#define MEL_FB 4
+#define MEL_THREADS 256
+
+struct MelArgs {
+  const float* wav;
+  int B, T, n_fft, log2m, hop, frames, pad_mode;  // pad_mode 0: zeros ("constant"), 1: reflect
+  const float* window;                            // (n_fft) window already centred/padded to n_fft
+  const float2* tw;                               // (n_fft/2) exp(-2 pi i t / n_fft)
+  float eps_power;                                // clamp on re^2+im^2 before sqrt
+  // mel mode
+  const int32_t* mel_start;  // (n_mels) first bin of the support
+  const int32_t* mel_len;    // (n_mels)
+  const int32_t* mel_off;    // (n_mels) offset into mel_w
+  const float* mel_w;        // packed non-zero weights
+  int n_mels;
+  float eps_mel;
+  float* out_mel;  // (B, n_mels, frames) normalised, or NULL
+  float* out_mag;  // (B, frames, n_fft/2+1), or NULL
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+__global__ __launch_bounds__(MEL_THREADS) void melspec_kernel(const MelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = a.n_fft >> 1;
+  float2* buf0 = reinterpret_cast<float2*>(smem);
+  float2* buf1 = buf0 + M;
+  float* amp = reinterpret_cast<float*>(buf1 + M);  // M + 1 magnitudes
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * MEL_FB;
+  const float* x = a.wav + (long long)b * a.T;
+  float melv[MEL_FB];
+#pragma unroll
+  for (int q = 0; q < MEL_FB; ++q) melv[q] = 0.f;
+
+  for (int q = 0; q < MEL_FB; ++q) {
+    const int f = f0 + q;
+    if (f >= a.frames) break;  // uniform across the block
+    const int start = f * a.hop - M;  // centre padding of n_fft/2
+    // ---- windowed frame, packed as z[n] = x[2n] + i x[2n+1]
+    for (int n = tid; n < M; n += MEL_THREADS) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int s = start + 2 * n + e;
+        float xv = 0.f;
+        if (a.pad_mode == 1) {
+          if (s < 0) s = -s;
+          if (s >= a.T) s = 2 * (a.T - 1) - s;
+          xv = (s >= 0 && s < a.T) ? x[s] : 0.f;
+        } else if (s >= 0 && s < a.T) {
+          xv = x[s];
+        }
+        v[e] = xv * a.window[2 * n + e];
+      }
+      buf0[n] = make_float2(v[0], v[1]);
+    }
+    __syncthreads();
+    // ---- complex Stockham radix-2 FFT of size M
+    float2* src = buf0;
+    float2* dst = buf1;
+    for (int s = 0; s < a.log2m; ++s) {
+      const int Ns = 1 << s;
+      for (int j = tid; j < (M >> 1); j += MEL_THREADS) {
+        const int k = j & (Ns - 1);
+        // exp(-2 pi i k / (2 Ns)) = exp(-2 pi i (k * M/(2Ns)) / M) = tw_N[2 * k * M / (2 Ns)]
+        const float2 w = a.tw[(k * (M >> (s + 1))) << 1];
+        const float2 u = src[j];
+        const float2 t = cmul(src[j + (M >> 1)], w);
+        const int d = ((j >> s) << (s + 1)) + k;
+        dst[d] = make_float2(u.x + t.x, u.y + t.y);
+        dst[d + Ns] = make_float2(u.x - t.x, u.y - t.y);
+      }
+      __syncthreads();
+      float2* tmp = src;
+      src = dst;
+      dst = tmp;
+    }
+    // ---- split post-pass: X[k] = E + w_N^k O,  E = (Z[k] + conj Z[M-k]) / 2,  O = -i (Z[k] - conj Z[M-k]) / 2
+    for (int k = tid; k <= M; k += MEL_THREADS) {
+      float re, im;
+      if (k == 0 || k == M) {
+        const float2 z0 = src[0];
+        re = (k == 0) ? (z0.x + z0.y) : (z0.x - z0.y);
+        im = 0.f;
+      } else {
+        const float2 zk = src[k];
+        const float2 zc = src[M - k];  // conj applied below
+        const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+        const float dr = zk.x - zc.x, di = zk.y + zc.y;      // Z[k] - conj(Z[M-k])
+        const float orr = 0.5f * di, oi = -0.5f * dr;        // -i/2 * (dr + i di)
+        const float2 w = a.tw[k];
+        re = er + (orr * w.x - oi * w.y);
+        im = ei + (orr * w.y + oi * w.x);
+      }
+      const float mag = sqrtf(fmaxf(re * re + im * im, a.eps_power));
+      amp[k] = mag;
+      if (a.out_mag) a.out_mag[((long long)b * a.frames + f) * (M + 1) + k] = mag;
+    }
+    __syncthreads();
+    // ---- sparse mel filterbank + dB + symmetric normalisation
+    if (a.out_mel && tid < a.n_mels) {
+      const int st = a.mel_start[tid], ln = a.mel_len[tid];
+      const float* w = a.mel_w + a.mel_off[tid];
+      float acc = 0.f;
+      for (int i = 0; i < ln; ++i) acc = fmaf(amp[st + i], w[i], acc);
+      acc = fmaxf(acc, a.eps_mel);
+      const float db = 20.f * log10f(fmaxf(acc, 1e-5f)) - 20.f;
+      float nv = 8.f * ((db + 100.f) / 100.f) - 4.f;
+      melv[q] = fminf(fmaxf(nv, -4.f), 4.f);
+    }
+    __syncthreads();  // amp / buffers are reused by the next frame
+  }
+  if (a.out_mel && tid < a.n_mels) {
+    float* o = a.out_mel + ((long long)b * a.n_mels + tid) * a.frames + f0;
+#pragma unroll
+    for (int q = 0; q < MEL_FB; ++q)
+      if (f0 + q < a.frames) o[q] = melv[q];
+  }
+}
+
+extern "C" int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                                  const float* window, const float* twiddle, float eps_power,
+                                  const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                                  const float* mel_w, int n_mels, float eps_mel, float* out_mel, float* out_mag,
+                                  void* stream) {
+  if (!wav || !window || !twiddle || B < 0 || T < 1 || n_fft < 8 || hop < 1 || frames < 0) return KANTTS_E_BADARG;
+  if (n_fft & (n_fft - 1)) return KANTTS_E_UNSUPPORTED;
+  if (!out_mel && !out_mag) return KANTTS_E_BADARG;
+  if (out_mel && (!mel_start || !mel_len || !mel_off || !mel_w || n_mels < 1 || n_mels > MEL_THREADS))
+    return KANTTS_E_BADARG;
+  if (pad_mode == 1 && T <= n_fft / 2) return KANTTS_E_BADARG;  // reflect needs pad < T (torch.stft rule)
+  if (B == 0 || frames == 0) return KANTTS_OK;
+  MelArgs a = {};
+  a.wav = wav; a.B = B; a.T = T; a.n_fft = n_fft; a.hop = hop; a.frames = frames; a.pad_mode = pad_mode;
+  a.window = window; a.tw = reinterpret_cast<const float2*>(twiddle); a.eps_power = eps_power;
+  a.mel_start = mel_start; a.mel_len = mel_len; a.mel_off = mel_off; a.mel_w = mel_w; a.n_mels = n_mels;
+  a.eps_mel = eps_mel; a.out_mel = out_mel; a.out_mag = out_mag;
+  int m = n_fft >> 1, l2 = 0;
+  while ((1 << l2) < m) ++l2;
+  a.log2m = l2;
+  size_t lds = (size_t)m * 2 * sizeof(float2) + (size_t)(m + 1) * sizeof(float);
+  if (lds > 160 * 1024) return KANTTS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(melspec_kernel, dim3(kantts_cdiv(frames, MEL_FB), B), dim3(MEL_THREADS), lds, (hipStream_t)stream, a);
+  KANTTS_CHECK_LAUNCH();
+}

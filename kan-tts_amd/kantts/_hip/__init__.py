@@ -76,6 +76,7 @@ def lib():
         L.kantts_masked_l1.argtypes = [p, p, p, p, p, i, i, i, p]
         L.kantts_sumsq.argtypes = [p, p, ll, p]
         L.kantts_adam_step.argtypes = [p, p, p, p, ll, f, f, f, f, f, f, f, p, f, p]
+        L.kantts_melspec_fwd.argtypes = [p, i, i, i, i, i, i, p, p, f, p, p, p, p, i, f, p, p, p]
         _lib = L
     return _lib
 
@@ -85,7 +86,7 @@ EXPORTED_SYMBOLS = [
     "kantts_layernorm_bwd", "kantts_attn_fwd", "kantts_attn_bwd", "kantts_lstm_fwd", "kantts_lstm_bwd",
     "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
     "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_masked_l1",
-    "kantts_sumsq", "kantts_adam_step",
+    "kantts_sumsq", "kantts_adam_step", "kantts_melspec_fwd",
 ]
 
 

@@ -1,0 +1,143 @@
+"""mel-STFT feature extractor on the fused HIP kernel (reference kantts/utils/audio_torch.py).
+
+``MelSpectrogram`` / ``stft`` keep the reference signatures.  The Slaney mel basis (librosa 0.9.2
+``filters.mel`` in the reference, an un-vendored dependency) is built here from its published
+definition; the kernel consumes it in support form (start, length, packed weights per filter).
+"""
+import math
+
+import numpy as np
+import torch
+
+from kantts._hip import check, lib, ptr, stream
+
+
+def slaney_mel_basis(sr, n_fft, n_mels=80, fmin=0.0, fmax=None):
+    """(n_mels, 1 + n_fft//2) float32 triangular filters on the Slaney mel scale, area-normalised
+    (librosa.filters.mel(htk=False, norm='slaney') -- call sites audio_torch.py:125-131, dsp.py:135-139)."""
+    fmax = float(sr) / 2 if fmax is None else float(fmax)
+    f_sp, brk = 200.0 / 3.0, 1000.0
+    logstep = math.log(6.4) / 27.0
+
+    def to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f >= brk, brk / f_sp + np.log(np.maximum(f, 1e-30) / brk) / logstep, f / f_sp)
+
+    def to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= brk / f_sp, brk * np.exp(logstep * (m - brk / f_sp)), f_sp * m)
+
+    bins = np.linspace(0.0, float(sr) / 2, 1 + n_fft // 2)
+    edges = to_hz(np.linspace(to_mel(fmin), to_mel(fmax), n_mels + 2))
+    width = np.diff(edges)
+    rise = (bins[None, :] - edges[:-2, None]) / width[:-1, None]
+    fall = (edges[2:, None] - bins[None, :]) / width[1:, None]
+    tri = np.maximum(0.0, np.minimum(rise, fall)).astype(np.float32)
+    tri *= (2.0 / (edges[2:] - edges[:-2]))[:, None].astype(np.float32)
+    return tri
+
+
+def _support_form(melmat_t):
+    """melmat_t: (n_freq, n_mels) tensor -> int32 start/len/off + packed weights (host tensors)."""
+    m = melmat_t.t().contiguous().cpu().numpy()
+    starts, lens, offs, packed = [], [], [], []
+    for row in m:
+        nz = np.nonzero(row)[0]
+        s, e = (int(nz[0]), int(nz[-1]) + 1) if nz.size else (0, 0)
+        starts.append(s)
+        lens.append(e - s)
+        offs.append(len(packed))
+        packed.extend(row[s:e].tolist())
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32)  # noqa: E731
+    return i32(starts), i32(lens), i32(offs), torch.tensor(packed or [0.0], dtype=torch.float32)
+
+
+_const_cache = {}
+
+
+def _fft_consts(n_fft, win_length, window, device):
+    key = (n_fft, win_length, window, str(device))
+    c = _const_cache.get(key)
+    if c is None:
+        if window is None:
+            w = torch.ones(win_length, dtype=torch.float32)
+        else:
+            w = getattr(torch, "%s_window" % window)(win_length, dtype=torch.float32)
+        left = (n_fft - win_length) // 2
+        wpad = torch.zeros(n_fft, dtype=torch.float32)
+        wpad[left:left + win_length] = w
+        t = np.arange(n_fft // 2, dtype=np.float64)
+        tw = np.stack([np.cos(-2 * np.pi * t / n_fft), np.sin(-2 * np.pi * t / n_fft)], -1).astype(np.float32)
+        c = (wpad.to(device), torch.from_numpy(tw).contiguous().to(device))
+        _const_cache[key] = c
+    return c
+
+
+def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, eps_mel=0.0, want_mag=False):
+    if x.requires_grad:
+        raise NotImplementedError("mel-STFT backward (GAN mel loss) is not wired yet -- DESIGN.md, row c")
+    x = x.contiguous().float()
+    B, T = x.shape
+    frames = 1 + T // hop
+    wpad, tw = _fft_consts(n_fft, win_length, window, x.device)
+    out_mel = out_mag = None
+    ms = ml = mo = mw = None
+    n_mels = 0
+    if mel is not None:
+        ms, ml, mo, mw = mel
+        n_mels = ms.numel()
+        out_mel = torch.empty((B, n_mels, frames), device=x.device, dtype=torch.float32)
+    if want_mag:
+        out_mag = torch.empty((B, frames, n_fft // 2 + 1), device=x.device, dtype=torch.float32)
+    check(lib().kantts_melspec_fwd(ptr(x, torch.float32), B, T, n_fft, hop, frames, pad_mode, ptr(wpad), ptr(tw),
+                                   float(eps_power), ptr(ms), ptr(ml), ptr(mo), ptr(mw), n_mels, float(eps_mel),
+                                   ptr(out_mel), ptr(out_mag), stream()), "melspec_fwd")
+    return out_mel, out_mag
+
+
+def stft(x, fft_size, hop_size, win_length, window):
+    """|STFT| (B, frames, fft_size//2+1) with clamp(re^2+im^2, 1e-7) (reference :8-31).  ``window`` may
+    be a window tensor (as the reference's callers pass) or a name like "hann"."""
+    name = window if isinstance(window, str) else "hann"
+    name = name.replace("_window", "")
+    _, mag = _launch(x, fft_size, hop_size, win_length, name, 1, 1e-7, want_mag=True)
+    return mag
+
+
+class MelSpectrogram(torch.nn.Module):
+    """Normalised log-mel spectrogram (B, n_mels, frames) -- reference :86-186 (log_base is ignored there too)."""
+
+    def __init__(self, fs=22050, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=80,
+                 fmax=7600, center=True, normalized=False, onesided=True, eps=1e-10, log_base=10.0,
+                 pad_mode="constant"):
+        super().__init__()
+        if not center or normalized or not onesided:
+            raise NotImplementedError("only center=True, normalized=False, onesided=True (the shipped settings)")
+        if window is not None and not hasattr(torch, f"{window}_window"):
+            raise ValueError(f"{window} window is not implemented")
+        self.fft_size = fft_size
+        self.win_length = fft_size if win_length is None else win_length
+        self.hop_size = hop_size
+        self.center, self.normalized, self.onesided = center, normalized, onesided
+        self.window = window
+        self.eps = eps
+        self.pad_mode = pad_mode
+        self.log_base = log_base
+        fmin = 0 if fmin is None else fmin
+        fmax = fs / 2 if fmax is None else fmax
+        melmat = slaney_mel_basis(sr=fs, n_fft=fft_size, n_mels=num_mels, fmin=fmin, fmax=fmax)
+        self.register_buffer("melmat", torch.from_numpy(melmat.T.copy()).float())
+        self._support = None
+
+    def _mel_support(self, device):
+        if self._support is None or self._support[0].device != device:
+            self._support = tuple(t.to(device) for t in _support_form(self.melmat))
+        return self._support
+
+    def forward(self, x):
+        if x.dim() == 3:
+            x = x.reshape(-1, x.size(2))
+        pad = {"constant": 0, "reflect": 1}[self.pad_mode]
+        mel, _ = _launch(x, self.fft_size, self.hop_size, self.win_length, self.window, pad, self.eps,
+                         mel=self._mel_support(x.device), eps_mel=self.eps)
+        return mel

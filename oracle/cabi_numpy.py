@@ -470,3 +470,30 @@ class EmulatedLib:
         V[:] = b2 * V + (1 - b2) * gi * gi
         P[:] = P - (lr / bc1) * Mm / (np.sqrt(V) / np.sqrt(bc2) + eps)
         return 0
+
+    # ------------------------------------------------------------------------------------ mel-STFT
+    def kantts_melspec_fwd(self, wav, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
+                           mel_len, mel_off, mel_w, n_mels, eps_mel, out_mel, out_mag, stream):
+        eps_power, eps_mel = _val(eps_power), _val(eps_mel)
+        X = torch.from_numpy(_arr(wav, B * T)).view(B, T)
+        W = torch.from_numpy(_arr(window, n_fft))
+        xp = torch.nn.functional.pad(X[:, None, :], (n_fft // 2, n_fft // 2),
+                                     mode="reflect" if pad_mode == 1 else "constant")[:, 0]
+        fr = xp.unfold(1, n_fft, hop)[:, :frames] * W
+        spec = torch.fft.rfft(fr, n=n_fft, dim=-1)
+        amp = torch.sqrt(torch.clamp(spec.real ** 2 + spec.imag ** 2, min=eps_power))
+        nb = n_fft // 2 + 1
+        if out_mag:
+            _arr(out_mag, B * frames * nb)[:] = amp.reshape(-1).numpy()
+        if out_mel:
+            st, ln, of = (_arr(p, n_mels, np.int32) for p in (mel_start, mel_len, mel_off))
+            tot = int(of[-1] + ln[-1])
+            w = _arr(mel_w, max(tot, 1))
+            Mm = torch.zeros(nb, n_mels)
+            for m in range(n_mels):
+                Mm[st[m]:st[m] + ln[m], m] = torch.from_numpy(w[of[m]:of[m] + ln[m]].copy())
+            mel = torch.clamp(amp @ Mm, min=eps_mel)
+            db = 20 * torch.log10(torch.clamp(mel, min=1e-5)) - 20.0
+            out = torch.clamp(8.0 * ((db + 100.0) / 100.0) - 4.0, -4.0, 4.0).transpose(1, 2).contiguous()
+            _arr(out_mel, B * n_mels * frames)[:] = out.reshape(-1).numpy()
+        return 0
