@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
+                    help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +90,7 @@ def main():
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     import kantts._hip as hip
+    import kantts._hip.ops  # noqa: F401
     import torch_oracle as O
     from kantts.models import model_builder
     from kantts.train.loss import MelReconLoss, ProsodyReconLoss
@@ -104,7 +107,8 @@ def main():
     batch = {k: v.to(dev) for k, v in O.synthetic_sambert_batch(B=args.batch, T_in=64, seed=1234 + rank).items()}
     frames = int(batch["output_lengths"].sum())
 
-    def step():
+    def eager_step():
+        hip.ops.advance_rng(dev)
         optimizer.zero_grad()
         res = net(**batch)
         mel_, mel = mel_crit(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
@@ -116,6 +120,20 @@ def main():
         optimizer.step()
         scheduler.step()
         return loss
+
+    mode = args.mode
+    step = eager_step
+    if mode == "graph":
+        try:
+            from kantts.train.graph_step import GraphedSambertStep
+
+            step = GraphedSambertStep(net, optimizer, scheduler, mel_crit, pros_crit, batch)
+        except Exception as exc:  # capture is an optimisation; say so loudly and measure the eager path
+            print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" % (
+                type(exc).__name__, str(exc)[:300]), file=sys.stderr)
+            mode = "eager"
+            net.device_band_width = False
+            optimizer.dyn = None
 
     for _ in range(args.warmup):
         step()
@@ -143,8 +161,10 @@ def main():
     roof = None
     if rank == 0:
         hip.profile_begin()
-        step()
-        torch.cuda.synchronize()
+    net.device_band_width = False
+    eager_step()  # instrumented launches are issued eagerly on every rank (the step holds a collective)
+    torch.cuda.synchronize()
+    if rank == 0:
         prof = hip.profile_end()
         if prof["launches"]:
             tf = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
@@ -163,7 +183,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "SAM-BERT full (sambert_16k.yaml zhcn) fwd+bwd+clip+Adam, batch %d/GPU, T_in 64, "
                                    "%d valid mel frames on rank 0, dropout on" % (args.batch, frames),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "launch": mode,
                        "final_loss": float(loss)},
             "roofline": roof,
         }

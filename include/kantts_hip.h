@@ -69,6 +69,17 @@ typedef struct kantts_gemm_seg {
   float a_drop_p;      /* > 0: A(i,kk) *= dropout keep-scale regenerated from (a_drop_seed, element
                           offset of A) -- backward of an epilogue dropout, A = dY contiguous (M,N) */
   uint64_t a_drop_seed;
+  /* Extended token map (strided / transposed / period-folded / nearest-upsampled convolutions of the
+   * HiFi-GAN stack, kantts/models/hifigan/{layers,hifigan}.py).  All zero = the plain map above.
+   * A token tok of a (B, Tq, inner) domain reads source row ((b*Tsrc) + t)*inner + pi with
+   * t = q*mul + shift; when div > 1, t must be a multiple of div and t /= div; the element is 0
+   * unless 0 <= t < Tsrc*up; finally t /= up (nearest-neighbour upsampling of the source). */
+  int32_t a_inner, a_Tq, a_Tsrc, a_mul, a_div, a_up;
+  int32_t b_inner, b_Tq, b_Tsrc, b_mul, b_div, b_up;
+  float a_slope;       /* a_act = 1: A value x -> x > 0 ? x : a_slope * x (LeakyReLU fused on load) */
+  int32_t a_act;
+  float b_slope;
+  int32_t b_act;
 } kantts_gemm_seg;
 
 typedef struct kantts_gemm_args {
@@ -91,7 +102,17 @@ typedef struct kantts_gemm_args {
   int32_t splitk;      /* >= 1: reduction tiles are dealt round-robin to gridDim.z slices */
   int32_t precision;   /* 0 fp32 MFMA, 1 bf16 MFMA, 2 scalar reference */
   float drop_p;        /* dropout applied to v after the activation, before the residual */
-  uint64_t drop_seed;  /* mask element (i,j) = rng(drop_seed, i*N + j) */
+  uint64_t drop_seed;  /* mask element (i,j) = rng(drop_seed + *seed_dev, i*N + j) */
+  const uint64_t* seed_dev; /* optional device word added to every dropout seed of this launch (lets a
+                          captured hipGraph draw fresh masks on every replay) */
+  /* grouped convolutions: gridDim.z = groups * splitk; group g offsets every operand */
+  int32_t groups;      /* 0/1 = none */
+  int64_t a_gs, b_gs, c_gs, bias_gs, r_gs; /* element offsets per group for A, B, C(+gate), bias, res */
+  float out_slope;     /* out_act = 1: LeakyReLU(out_slope) on v instead of / after relu=0 */
+  int32_t out_act;
+  const float* gate;   /* optional, addressed like C: v *= (gate > 0 ? 1 : gate_slope)  (backward through
+                          an input-side LeakyReLU) */
+  float gate_slope;
 } kantts_gemm_args;
 
 int kantts_gemm_seg_launch(const kantts_gemm_args* args_host, void* stream);
@@ -116,12 +137,13 @@ int kantts_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
  * Backward writes dq (or adds to it when accumulate_dq), dk, dv; dvec (B,H,L) is scratch. */
 int kantts_attn_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, float* o, int ldo,
                     float* lse, float* probs, const int32_t* lens, const int32_t* bw_dev, int bw, int B, int H,
-                    int L, int d_head, int mode, float drop_p, uint64_t seed, void* stream);
+                    int L, int d_head, int mode, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                    void* stream);
 int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, const float* o,
                     int ldo, const float* d_o, int lddo, const float* lse, float* dvec, float* dq, float* dk,
                     float* dv, int lddq, int lddk, int lddv, int accumulate_dq, const int32_t* lens,
                     const int32_t* bw_dev, int bw, int B, int H, int L, int d_head, int mode, float drop_p,
-                    uint64_t seed, void* stream);
+                    uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LSTM recurrence, H = 128 (time loop of torch.nn.LSTM: kantts/models/sambert/adaptors.py:44-57,
@@ -183,7 +205,9 @@ int kantts_sumsq(const float* x, float* out_accum, long long n, void* stream);
  * memory (gnorm_sq = sum of squares of all gradients): kantts/train/trainer.py:997-1004. */
 int kantts_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
-                     const float* gnorm_sq, float max_norm, void* stream);
+                     const float* gnorm_sq, float max_norm, const float* dyn_lr_step, void* stream);
+/* dyn_lr_step (optional, device, 2 floats {lr, step}): when given, lr and the bias corrections
+ * 1 - beta^step are taken from device memory (hipGraph replay with a changing schedule). */
 
 /* ------------------------------------------------------------------------------------------
  * Fused framed STFT -> |.| -> sparse mel filterbank -> 20 log10 - 20 -> clamp(8(x+100)/100-4, +-4).

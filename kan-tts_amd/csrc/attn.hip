@@ -36,6 +36,7 @@ struct AttnArgs {
   float scale;  // 1 / sqrt(d_head)
   float drop_p;
   uint64_t seed;
+  const uint64_t* seed_dev;
   // backward only
   const float* d_o;
   int lddo;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(const AttnArgs a) {
   if (i >= a.L) return;
   const int len = a.lens ? a.lens[b] : a.L;
   const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
   int lo, hi;
   key_range(a.mode, i, len, a.L, bw, lo, hi);
   const long long row = (long long)b * a.L + i;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(const AttnArgs a) {
     load16(vb + (long long)j * a.ldv, vv);
     float e = expf(dot16(q, kk) * a.scale - m);
     l += e;
-    float ed = e * kantts_dropout_scale(a.drop_p, a.seed, rng_row + j);
+    float ed = e * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
   }
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(const AttnArgs a) {
       if (j >= lo && j <= hi) {
         float kk[DH];
         load16(kb + (long long)j * a.ldk, kk);
-        p = expf(dot16(q, kk) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, a.seed, rng_row + j);
+        p = expf(dot16(q, kk) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
       }
       prow[j] = p;
     }
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const AttnArgs a) {
   if (i >= a.L) return;
   const int len = a.lens ? a.lens[b] : a.L;
   const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
   int lo, hi;
   key_range(a.mode, i, len, a.L, bw, lo, hi);
   const long long row = (long long)b * a.L + i;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const AttnArgs a) {
     load16(kb + (long long)j * a.ldk, kk);
     load16(vb + (long long)j * a.ldv, vv);
     float p = expf(dot16(q, kk) * a.scale - lse);
-    float dp = dot16(go, vv) * kantts_dropout_scale(a.drop_p, a.seed, rng_row + j);
+    float dp = dot16(go, vv) * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
     float ds = p * (dp - D) * a.scale;
 #pragma unroll
     for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const AttnArgs a) {
   if (j >= a.L) return;
   const int len = a.lens ? a.lens[b] : a.L;
   const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
   const long long krow = (long long)b * a.L + j;
   float kk[DH], vv[DH], dk[DH], dv[DH];
   load16(a.k + krow * a.ldk + h * DH, kk);
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const AttnArgs a) {
       load16(qb + (long long)i * a.ldq, q);
       load16(gb + (long long)i * a.lddo, go);
       const float p = expf(dot16(q, kk) * a.scale - a.lse[sbase + i]);
-      const float dsc = kantts_dropout_scale(a.drop_p, a.seed, ((((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L) + j);
+      const float dsc = kantts_dropout_scale(a.drop_p, seed, ((((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L) + j);
       const float pd = p * dsc;
       const float dp = dot16(go, vv) * dsc;
       const float ds = p * (dp - a.dvec[sbase + i]) * a.scale;
@@ -246,9 +250,11 @@ static int attn_check(const AttnArgs& a) {
 
 extern "C" int kantts_attn_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, float* o,
                                int ldo, float* lse, float* probs, const int32_t* lens, const int32_t* bw_dev, int bw,
-                               int B, int H, int L, int d_head, int mode, float drop_p, uint64_t seed, void* stream) {
+                               int B, int H, int L, int d_head, int mode, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                               void* stream) {
   if (d_head != DH) return KANTTS_E_UNSUPPORTED;
   AttnArgs a = {};
+  a.seed_dev = seed_dev;
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo; a.lse = lse;
   a.probs = probs; a.lens = lens; a.bw_dev = bw_dev; a.bw = bw; a.B = B; a.H = H; a.L = L; a.mode = mode;
   a.scale = 0.25f; a.drop_p = drop_p; a.seed = seed;
@@ -263,9 +269,10 @@ extern "C" int kantts_attn_bwd(const float* q, const float* k, const float* v, i
                                const float* o, int ldo, const float* d_o, int lddo, const float* lse, float* dvec,
                                float* dq, float* dk, float* dv, int lddq, int lddk, int lddv, int accumulate_dq,
                                const int32_t* lens, const int32_t* bw_dev, int bw, int B, int H, int L, int d_head,
-                               int mode, float drop_p, uint64_t seed, void* stream) {
+                               int mode, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
   if (d_head != DH) return KANTTS_E_UNSUPPORTED;
   AttnArgs a = {};
+  a.seed_dev = seed_dev;
   a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = const_cast<float*>(o); a.ldo = ldo;
   a.lse = const_cast<float*>(lse); a.lens = lens; a.bw_dev = bw_dev; a.bw = bw; a.B = B; a.H = H; a.L = L;
   a.mode = mode; a.scale = 0.25f; a.drop_p = drop_p; a.seed = seed; a.d_o = d_o; a.lddo = lddo; a.dq = dq;

@@ -8,9 +8,10 @@
 // LDS images are [row][k] with k contiguous: fp32 rows are padded to 34 words (conflict-free
 // ds_read_b32 for the 16x16x4 fragment: bank = 2*row + k), bf16 rows to 40 halfwords (80 B, keeps
 // the 16-byte fragment reads aligned).
-// The operand loaders are generic (strides, conv taps as token shifts, gating, masks) so that one
-// kernel serves forward, dgrad and wgrad of Linear / Conv1d / ConvTranspose1d in channels-last
-// layout.  Lanes walk whichever operand dimension has unit stride so global loads coalesce.
+// The operand loaders are generic (strides, conv taps as token shifts, strided / upsampled /
+// period-folded token maps, gating, masks, fused LeakyReLU) so that one kernel serves forward, dgrad
+// and wgrad of Linear / Conv1d / ConvTranspose1d / (k,1)-Conv2d in channels-last layout.  Lanes walk
+// whichever operand dimension has unit stride so global loads coalesce.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,54 +24,86 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define G_LDF 34 /* fp32 LDS row stride (words)     */
 #define G_LDH 40 /* bf16 LDS row stride (halfwords) */
 
-struct TokShift {
-  int axis;  // 0 none, 1 i, 2 kk
-  int shift;
+struct TokMap {
+  int inner, Tq, Tsrc, mul, div, up;
 };
 
+__device__ __forceinline__ TokMap make_map(int inner, int Tq, int Tsrc, int mul, int div, int up, int T) {
+  TokMap m;
+  m.inner = inner > 0 ? inner : 1;
+  m.Tq = Tq > 0 ? Tq : T;
+  m.Tsrc = Tsrc > 0 ? Tsrc : T;
+  m.mul = mul > 0 ? mul : 1;
+  m.div = div > 0 ? div : 1;
+  m.up = up > 0 ? up : 1;
+  return m;
+}
+
+// token of the (B, Tq, inner) domain -> source row; false when the tap falls outside the sequence
+__device__ __forceinline__ bool map_token(int tok, int shift, const TokMap& m, long long& row) {
+  const int pi = tok % m.inner;
+  const int bq = tok / m.inner;
+  const int q = bq % m.Tq;
+  const int b = bq / m.Tq;
+  int t = q * m.mul + shift;
+  if (t < 0) return false;
+  if (m.div > 1) {
+    if (t % m.div) return false;
+    t /= m.div;
+  }
+  if (t >= m.Tsrc * m.up) return false;
+  t /= m.up;
+  row = ((long long)b * m.Tsrc + t) * m.inner + pi;
+  return true;
+}
+
 __device__ __forceinline__ float g_load_a(const kantts_gemm_seg& s, const kantts_gemm_args& g, int i, int kk,
-                                          int shift) {
+                                          int shift, const TokMap& m, long long goff) {
   if (i >= g.M || kk >= s.klen) return 0.f;
   long long ii = i, kq = kk;
-  if (shift != 0) {
-    if (s.a_tok_axis == 1) {
-      int t = i % g.T + shift;
-      if (t < 0 || t >= g.T) return 0.f;
-      ii = i + shift;
-    } else if (s.a_tok_axis == 2) {
-      int t = kk % g.T + shift;
-      if (t < 0 || t >= g.T) return 0.f;
-      kq = kk + shift;
-    }
+  if (s.a_tok_axis == 1) {
+    if (!map_token(i, shift, m, ii)) return 0.f;
+  } else if (s.a_tok_axis == 2) {
+    if (!map_token(kk, shift, m, kq)) return 0.f;
   }
   if (g.kmask && g.kmask[kk]) return 0.f;
-  long long off = ii * s.a_is + kq * s.a_ks;
+  long long off = ii * s.a_is + kq * s.a_ks + goff;
   float v = s.a[off];
+  if (s.a_act) v = v > 0.f ? v : v * s.a_slope;
   if (s.a_gate && !(s.a_gate[off] > 0.f)) v = 0.f;
-  if (s.a_drop_p > 0.f) v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed, (uint64_t)off);
+  if (s.a_drop_p > 0.f)
+    v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed + (g.seed_dev ? *g.seed_dev : 0ull), (uint64_t)off);
   return v;
 }
 
 __device__ __forceinline__ float g_load_b(const kantts_gemm_seg& s, const kantts_gemm_args& g, int j, int kk,
-                                          int shift, int tap) {
+                                          int shift, int tap, const TokMap& m, long long goff) {
   if (j >= g.N || kk >= s.klen) return 0.f;
   long long kq = kk;
-  if (shift != 0 && s.b_tok_axis == 2) {
-    int t = kk % g.T + shift;
-    if (t < 0 || t >= g.T) return 0.f;
-    kq = kk + shift;
+  if (s.b_tok_axis == 2) {
+    if (!map_token(kk, shift, m, kq)) return 0.f;
   }
-  return s.b[(long long)j * s.b_js + kq * s.b_ks + (long long)tap * s.b_tap];
+  float v = s.b[(long long)j * s.b_js + kq * s.b_ks + (long long)tap * s.b_tap + goff];
+  if (s.b_act) v = v > 0.f ? v : v * s.b_slope;
+  return v;
 }
 
-__device__ __forceinline__ float g_epilogue(const kantts_gemm_args& g, float acc, int i, int j, bool first_slice) {
+__device__ __forceinline__ float g_epilogue(const kantts_gemm_args& g, float acc, int i, int j, bool first_slice,
+                                            int grp) {
   float v = acc;
-  if (first_slice && g.bias) v += g.bias[j];
-  if (first_slice && g.bias2) v += g.bias2[j];
+  if (first_slice && g.bias) v += g.bias[j + grp * g.bias_gs];
+  if (first_slice && g.bias2) v += g.bias2[j + grp * g.bias_gs];
   v *= g.alpha;
   if (g.relu) v = fmaxf(v, 0.f);
-  if (g.drop_p > 0.f) v *= kantts_dropout_scale(g.drop_p, g.drop_seed, (uint64_t)i * (uint64_t)g.N + (uint64_t)j);
-  if (first_slice && g.res) v += g.res[(long long)i * g.r_is + (long long)j * g.r_js];
+  if (g.out_act) v = v > 0.f ? v : v * g.out_slope;
+  if (g.drop_p > 0.f)
+    v *= kantts_dropout_scale(g.drop_p, g.drop_seed + (g.seed_dev ? *g.seed_dev : 0ull),
+                              (uint64_t)i * (uint64_t)g.N + (uint64_t)j);
+  if (first_slice && g.res) v += g.res[(long long)i * g.r_is + (long long)j * g.r_js + grp * g.r_gs];
+  if (g.gate) {
+    const float gv = g.gate[(long long)i * g.c_is + (long long)j * g.c_js + grp * g.c_gs];
+    v *= (gv > 0.f) ? 1.f : g.gate_slope;
+  }
   if (g.rowmask && g.rowmask[i]) v = 0.f;
   return v;
 }
@@ -89,7 +122,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
   const int wr = wave >> 1, wc = wave & 1;
   const int i0 = blockIdx.y * G_BM;
   const int j0 = blockIdx.x * G_BN;
-  const int zslice = blockIdx.z;
+  const int grp = blockIdx.z / g.splitk;
+  const int zslice = blockIdx.z % g.splitk;
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -105,6 +139,9 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
     const kantts_gemm_seg& s = g.seg[sidx];
     const bool a_lane_i = (s.a_is == 1 && s.a_ks != 1);
     const bool b_lane_j = (s.b_js == 1 && s.b_ks != 1);
+    const TokMap am = make_map(s.a_inner, s.a_Tq, s.a_Tsrc, s.a_mul, s.a_div, s.a_up, g.T);
+    const TokMap bm = make_map(s.b_inner, s.b_Tq, s.b_Tsrc, s.b_mul, s.b_div, s.b_up, g.T);
+    const long long a_goff = (long long)grp * g.a_gs, b_goff = (long long)grp * g.b_gs;
     for (int tap = 0; tap < s.ntaps; ++tap) {
       const int a_shift = s.a_tok_axis ? s.a_shift0 + tap * s.a_shift_step : 0;
       const int b_shift = s.b_tok_axis ? s.b_shift0 + tap * s.b_shift_step : 0;
@@ -123,7 +160,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
             k = tid & 31;
             r = (tid >> 5) + 8 * e;
           }
-          float v = g_load_a(s, g, i0 + r, k0 + k, a_shift);
+          float v = g_load_a(s, g, i0 + r, k0 + k, a_shift, am, a_goff);
           if (BF16)
             Ah[r * G_LDH + k] = (__bf16)v;
           else
@@ -139,7 +176,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
             k = tid & 31;
             r = (tid >> 5) + 8 * e;
           }
-          float v = g_load_b(s, g, j0 + r, k0 + k, b_shift, tap);
+          float v = g_load_b(s, g, j0 + r, k0 + k, b_shift, tap, bm, b_goff);
           if (BF16)
             Bh[r * G_LDH + k] = (__bf16)v;
           else
@@ -189,7 +226,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
     }
   }
 
-  if (do_rowsum && tid < G_BM && (i0 + tid) < g.M) atomicAdd(&g.a_rowsum[i0 + tid], rowsum);
+  if (do_rowsum && tid < G_BM && (i0 + tid) < g.M) atomicAdd(&g.a_rowsum[i0 + tid + grp * g.bias_gs], rowsum);
 
   // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
   const bool first_slice = (zslice == 0);
@@ -202,8 +239,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
         int i = i0 + wr * 32 + m * 16 + (lane >> 4) * 4 + r;
         int j = j0 + wc * 32 + n * 16 + (lane & 15);
         if (i < g.M && j < g.N) {
-          float v = g_epilogue(g, acc[m][n][r], i, j, first_slice);
-          float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js];
+          float v = g_epilogue(g, acc[m][n][r], i, j, first_slice, grp);
+          float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js + (long long)grp * g.c_gs];
           if (g.accumulate)
             atomicAdd(dst, v);
           else
@@ -215,24 +252,28 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
 // Scalar fp32 reference of the same contract (debug / cross-check of the MFMA fragment maps).
 __global__ void gemm_seg_ref_kernel(const kantts_gemm_args g) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = blockIdx.y;
   if (idx >= (long long)g.M * g.N) return;
   int i = (int)(idx / g.N), j = (int)(idx % g.N);
   float acc = 0.f, rs = 0.f;
   for (int sidx = 0; sidx < g.nseg; ++sidx) {
     const kantts_gemm_seg& s = g.seg[sidx];
+    const TokMap am = make_map(s.a_inner, s.a_Tq, s.a_Tsrc, s.a_mul, s.a_div, s.a_up, g.T);
+    const TokMap bm = make_map(s.b_inner, s.b_Tq, s.b_Tsrc, s.b_mul, s.b_div, s.b_up, g.T);
+    const long long a_goff = (long long)grp * g.a_gs, b_goff = (long long)grp * g.b_gs;
     for (int tap = 0; tap < s.ntaps; ++tap) {
       const int a_shift = s.a_tok_axis ? s.a_shift0 + tap * s.a_shift_step : 0;
       const int b_shift = s.b_tok_axis ? s.b_shift0 + tap * s.b_shift_step : 0;
       for (int kk = 0; kk < s.klen; ++kk) {
-        float a = g_load_a(s, g, i, kk, a_shift);
-        acc = fmaf(a, g_load_b(s, g, j, kk, b_shift, tap), acc);
+        float a = g_load_a(s, g, i, kk, a_shift, am, a_goff);
+        acc = fmaf(a, g_load_b(s, g, j, kk, b_shift, tap, bm, b_goff), acc);
         if (sidx == 0) rs += a;
       }
     }
   }
-  if (g.a_rowsum && j == 0) atomicAdd(&g.a_rowsum[i], rs);
-  float v = g_epilogue(g, acc, i, j, true);
-  float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js];
+  if (g.a_rowsum && j == 0) atomicAdd(&g.a_rowsum[i + grp * g.bias_gs], rs);
+  float v = g_epilogue(g, acc, i, j, true, grp);
+  float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js + (long long)grp * g.c_gs];
   if (g.accumulate)
     atomicAdd(dst, v);
   else
@@ -243,21 +284,25 @@ extern "C" int kantts_gemm_seg_launch(const kantts_gemm_args* a, void* stream) {
   if (!a || a->nseg < 1 || a->nseg > KANTTS_GEMM_MAX_SEG || a->M < 0 || a->N < 0 || !a->c) return KANTTS_E_BADARG;
   if (a->M == 0 || a->N == 0) return KANTTS_OK;
   int splitk = a->splitk < 1 ? 1 : a->splitk;
-  if (splitk > 1 && (!a->accumulate || a->relu || a->drop_p > 0.f)) return KANTTS_E_BADARG;
+  int groups = a->groups < 1 ? 1 : a->groups;
+  if (splitk > 1 && (!a->accumulate || a->relu || a->out_act || a->gate || a->drop_p > 0.f)) return KANTTS_E_BADARG;
   for (int s = 0; s < a->nseg; ++s) {
     const kantts_gemm_seg& sg = a->seg[s];
     if (!sg.a || !sg.b || sg.klen < 0 || sg.ntaps < 1) return KANTTS_E_BADARG;
-    if ((sg.a_tok_axis || sg.b_tok_axis) && a->T <= 0) return KANTTS_E_BADARG;
+    if ((sg.a_tok_axis && sg.a_Tq <= 0 && a->T <= 0) || (sg.b_tok_axis && sg.b_Tq <= 0 && a->T <= 0))
+      return KANTTS_E_BADARG;
   }
+  if ((long long)groups * splitk > 65535) return KANTTS_E_BADARG;
   kantts_gemm_args g = *a;
   g.splitk = splitk;
+  g.groups = groups;
   hipStream_t st = (hipStream_t)stream;
   if (g.precision == 2) {
     g.splitk = 1;
     long long total = (long long)g.M * g.N;
-    hipLaunchKernelGGL(gemm_seg_ref_kernel, dim3(kantts_cdiv(total, 256)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gemm_seg_ref_kernel, dim3(kantts_cdiv(total, 256), groups), dim3(256), 0, st, g);
   } else {
-    dim3 grid(kantts_cdiv(g.N, G_BN), kantts_cdiv(g.M, G_BM), splitk);
+    dim3 grid(kantts_cdiv(g.N, G_BN), kantts_cdiv(g.M, G_BM), groups * splitk);
     if (g.precision == 1)
       hipLaunchKernelGGL(gemm_seg_mfma_kernel<true>, grid, dim3(G_THREADS), 0, st, g);
     else if (g.precision == 0)

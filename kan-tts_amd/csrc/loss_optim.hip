@@ -76,7 +76,13 @@ extern "C" int kantts_sumsq(const float* x, float* out_accum, long long n, void*
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ m, float* __restrict__ v, long long n, float lr,
                                                   float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                                  const float* __restrict__ gnorm_sq, float max_norm) {
+                                                  const float* __restrict__ gnorm_sq, float max_norm,
+                                                  const float* __restrict__ dyn) {
+  if (dyn) {
+    lr = dyn[0];
+    bc1 = 1.f - powf(b1, dyn[1]);
+    bc2 = 1.f - powf(b2, dyn[1]);
+  }
   float clip = 1.f;
   if (max_norm > 0.f && gnorm_sq) clip = fminf(1.f, max_norm / (sqrtf(*gnorm_sq) + 1e-6f));
   const float step = lr / bc1;
@@ -95,12 +101,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 extern "C" int kantts_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
-                                const float* gnorm_sq, float max_norm, void* stream) {
+                                const float* gnorm_sq, float max_norm, const float* dyn_lr_step, void* stream) {
   if (!p || !g || !m || !v || n < 0) return KANTTS_E_BADARG;
   if (n == 0) return KANTTS_OK;
   int blocks = kantts_cdiv(n, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bias_corr1, bias_corr2, gnorm_sq, max_norm);
+                     weight_decay, bias_corr1, bias_corr2, gnorm_sq, max_norm, dyn_lr_step);
   KANTTS_CHECK_LAUNCH();
 }

@@ -27,6 +27,11 @@ class GemmSeg(Structure):
         ("a_tok_axis", c_int32), ("a_shift0", c_int32), ("a_shift_step", c_int32),
         ("b_tok_axis", c_int32), ("b_shift0", c_int32), ("b_shift_step", c_int32),
         ("a_drop_p", c_float), ("a_drop_seed", c_uint64),
+        ("a_inner", c_int32), ("a_Tq", c_int32), ("a_Tsrc", c_int32), ("a_mul", c_int32), ("a_div", c_int32),
+        ("a_up", c_int32),
+        ("b_inner", c_int32), ("b_Tq", c_int32), ("b_Tsrc", c_int32), ("b_mul", c_int32), ("b_div", c_int32),
+        ("b_up", c_int32),
+        ("a_slope", c_float), ("a_act", c_int32), ("b_slope", c_float), ("b_act", c_int32),
     ]
 
 
@@ -38,7 +43,9 @@ class GemmArgs(Structure):
         ("bias", c_void_p), ("bias2", c_void_p), ("res", c_void_p), ("r_is", c_int64), ("r_js", c_int64),
         ("rowmask", c_void_p), ("kmask", c_void_p), ("a_rowsum", c_void_p),
         ("alpha", c_float), ("relu", c_int32), ("accumulate", c_int32), ("splitk", c_int32),
-        ("precision", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64),
+        ("precision", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64), ("seed_dev", c_void_p),
+        ("groups", c_int32), ("a_gs", c_int64), ("b_gs", c_int64), ("c_gs", c_int64), ("bias_gs", c_int64),
+        ("r_gs", c_int64), ("out_slope", c_float), ("out_act", c_int32), ("gate", c_void_p), ("gate_slope", c_float),
     ]
 
 
@@ -61,9 +68,9 @@ def lib():
         i, f, p, ll, u64 = c_int, c_float, c_void_p, c_longlong, c_uint64
         L.kantts_layernorm_fwd.argtypes = [p, p, p, p, p, p, i, i, f, p]
         L.kantts_layernorm_bwd.argtypes = [p, p, p, p, p, p, p, p, i, i, p]
-        L.kantts_attn_fwd.argtypes = [p, p, p, i, i, i, p, i, p, p, p, p, i, i, i, i, i, i, f, u64, p]
+        L.kantts_attn_fwd.argtypes = [p, p, p, i, i, i, p, i, p, p, p, p, i, i, i, i, i, i, f, u64, p, p]
         L.kantts_attn_bwd.argtypes = [p, p, p, i, i, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p, p, i, i, i, i, i,
-                                      i, f, u64, p]
+                                      i, f, u64, p, p]
         L.kantts_lstm_fwd.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, p]
         L.kantts_lstm_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, p]
         L.kantts_embed_sum_fwd.argtypes = [POINTER(c_void_p), i, p, p, p, p, i, i, i, f, p]
@@ -75,7 +82,7 @@ def lib():
         L.kantts_fsmn_dwconv_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, p]
         L.kantts_masked_l1.argtypes = [p, p, p, p, p, i, i, i, p]
         L.kantts_sumsq.argtypes = [p, p, ll, p]
-        L.kantts_adam_step.argtypes = [p, p, p, p, ll, f, f, f, f, f, f, f, p, f, p]
+        L.kantts_adam_step.argtypes = [p, p, p, p, ll, f, f, f, f, f, f, f, p, f, p, p]
         L.kantts_melspec_fwd.argtypes = [p, i, i, i, i, i, i, p, p, f, p, p, p, p, i, f, p, p, p]
         _lib = L
     return _lib
@@ -126,8 +133,10 @@ def get_precision() -> str:
 
 
 def make_seg(a, a_is, a_ks, b, b_js, b_ks, klen, ntaps=1, b_tap=0, a_tok_axis=0, a_shift0=0, a_shift_step=0,
-             b_tok_axis=0, b_shift0=0, b_shift_step=0, a_gate=None, a_drop_p=0.0, a_drop_seed=0):
-    """a / b / a_gate are (tensor, element_offset) pairs or tensors."""
+             b_tok_axis=0, b_shift0=0, b_shift_step=0, a_gate=None, a_drop_p=0.0, a_drop_seed=0, a_map=None,
+             b_map=None, a_leaky=None, b_leaky=None):
+    """a / b / a_gate are (tensor, element_offset) pairs or tensors.  a_map / b_map: dict(inner, Tq, Tsrc,
+    mul, div, up) extended token maps; a_leaky / b_leaky: LeakyReLU slope applied on load."""
 
     def addr(x):
         if x is None:
@@ -143,12 +152,23 @@ def make_seg(a, a_is, a_ks, b, b_js, b_ks, klen, ntaps=1, b_tap=0, a_tok_axis=0,
     s.a_tok_axis, s.a_shift0, s.a_shift_step = int(a_tok_axis), int(a_shift0), int(a_shift_step)
     s.b_tok_axis, s.b_shift0, s.b_shift_step = int(b_tok_axis), int(b_shift0), int(b_shift_step)
     s.a_drop_p, s.a_drop_seed = float(a_drop_p), int(a_drop_seed)
+    if a_map:
+        s.a_inner, s.a_Tq, s.a_Tsrc = int(a_map.get("inner", 0)), int(a_map.get("Tq", 0)), int(a_map.get("Tsrc", 0))
+        s.a_mul, s.a_div, s.a_up = int(a_map.get("mul", 0)), int(a_map.get("div", 0)), int(a_map.get("up", 0))
+    if b_map:
+        s.b_inner, s.b_Tq, s.b_Tsrc = int(b_map.get("inner", 0)), int(b_map.get("Tq", 0)), int(b_map.get("Tsrc", 0))
+        s.b_mul, s.b_div, s.b_up = int(b_map.get("mul", 0)), int(b_map.get("div", 0)), int(b_map.get("up", 0))
+    if a_leaky is not None:
+        s.a_act, s.a_slope = 1, float(a_leaky)
+    if b_leaky is not None:
+        s.b_act, s.b_slope = 1, float(b_leaky)
     return s
 
 
 def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_js=0, rowmask=None, kmask=None,
          a_rowsum=None, alpha=1.0, relu=False, accumulate=False, splitk=1, T=0, drop_p=0.0, drop_seed=0,
-         precision=None, c_off=0):
+         precision=None, c_off=0, groups=1, a_gs=0, b_gs=0, c_gs=0, bias_gs=0, r_gs=0, out_leaky=None, gate=None,
+         gate_slope=0.0, res_off=0):
     g = GemmArgs()
     assert 1 <= len(segs) <= GEMM_MAX_SEG
     for k, s in enumerate(segs):
@@ -158,20 +178,49 @@ def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_j
     g.c_is, g.c_js = int(c_is), int(c_js)
     g.bias, g.bias2 = ptr(bias, torch.float32), ptr(bias2, torch.float32)
     g.res, g.r_is, g.r_js = ptr(res, torch.float32), int(r_is), int(r_js)
+    if res is not None and res_off:
+        g.res = g.res + 4 * int(res_off)
+    g.groups, g.a_gs, g.b_gs, g.c_gs, g.bias_gs, g.r_gs = int(groups), int(a_gs), int(b_gs), int(c_gs), int(bias_gs), int(r_gs)
+    if out_leaky is not None:
+        g.out_act, g.out_slope = 1, float(out_leaky)
+    if gate is not None:
+        g.gate = ptr(gate, torch.float32) + 4 * int(c_off)
+        g.gate_slope = float(gate_slope)
     g.rowmask = ptr(rowmask)
     g.kmask = ptr(kmask)
     g.a_rowsum = ptr(a_rowsum, torch.float32)
     g.alpha, g.relu, g.accumulate, g.splitk = float(alpha), int(bool(relu)), int(bool(accumulate)), int(splitk)
     g.precision = _precision["gemm"] if precision is None else precision
     g.drop_p, g.drop_seed = float(drop_p), int(drop_seed)
+    g.seed_dev = rng_ptr(c.device) if (drop_p > 0 or any(s.a_drop_p > 0 for s in segs)) else None
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib().kantts_gemm_seg_launch(ctypes.byref(g), stream()), "gemm_seg")
         e1.record()
-        _profile.append((e0, e1, 2.0 * M * N * sum(s.klen * s.ntaps for s in segs)))
+        _profile.append((e0, e1, 2.0 * M * N * max(1, groups) * sum(s.klen * s.ntaps for s in segs)))
         return
     check(lib().kantts_gemm_seg_launch(ctypes.byref(g), stream()), "gemm_seg")
+
+
+# ----------------------------------------------------------------------------------------------
+# device-resident RNG offset: every dropout seed is (host seed + *rng_state).  A training step advances
+# it once (ops.advance_rng) -- when the step is captured in a hipGraph the increment is replayed too,
+# so each replay draws fresh masks although the host seeds are frozen in the kernel arguments.
+_rng_state = {}
+
+
+def rng_state(device):
+    key = str(device)
+    t = _rng_state.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=device)
+        _rng_state[key] = t
+    return t
+
+
+def rng_ptr(device):
+    return ptr(rng_state(device))
 
 
 # ----------------------------------------------------------------------------------------------

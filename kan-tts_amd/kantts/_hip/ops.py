@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import (PREC_REF, check, gemm, lib, make_seg, ptr, stream)
+from . import (PREC_REF, check, gemm, lib, make_seg, ptr, rng_state, stream)
 
 _seed_counter = itertools.count(1)
 
@@ -235,7 +235,8 @@ def _attn_fwd(q, qo, k, ko, v, vo, lens, bw_dev, bw, B, H, L, mode, drop_p, seed
     probs = torch.empty((H * B, L, L), device=dev, dtype=torch.float32) if want_probs else None
     check(lib().kantts_attn_fwd(ptr(q) + 4 * qo, ptr(k) + 4 * ko, ptr(v) + 4 * vo, q.shape[-1], k.shape[-1],
                                 v.shape[-1], ptr(o), H * 16, ptr(lse), ptr(probs), ptr(lens), ptr(bw_dev), int(bw),
-                                B, H, L, 16, mode, float(drop_p), int(seed), stream()), "attn_fwd")
+                                B, H, L, 16, mode, float(drop_p), int(seed),
+                                ptr(rng_state(q.device)) if drop_p > 0 else None, stream()), "attn_fwd")
     return o, lse, probs
 
 
@@ -246,7 +247,8 @@ def _attn_bwd(q, qo, k, ko, v, vo, o, d_o, lse, dq, dqo, dk, dko, dv, dvo, acc_d
                                 v.shape[-1], ptr(o), o.shape[-1], ptr(d_o), d_o.shape[-1], ptr(lse), ptr(dvec),
                                 ptr(dq) + 4 * dqo, ptr(dk) + 4 * dko, ptr(dv) + 4 * dvo, dq.shape[-1], dk.shape[-1],
                                 dv.shape[-1], int(acc_dq), ptr(lens), ptr(bw_dev), int(bw), B, H, L, 16, mode,
-                                float(drop_p), int(seed), stream()), "attn_bwd")
+                                float(drop_p), int(seed), ptr(rng_state(q.device)) if drop_p > 0 else None,
+                                stream()), "attn_bwd")
 
 
 class _SelfAttention(torch.autograd.Function):
@@ -580,10 +582,16 @@ def sumsq_into(x_flat, out_scalar):
           "sumsq")
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=None, max_norm=0.0):
-    bc1 = 1.0 - beta1 ** step
-    bc2 = 1.0 - beta2 ** step
+def advance_rng(device):
+    """Advance the device-resident dropout offset (call once per training step)."""
+    rng_state(device).add_(0x632BE59BD9B4E019)
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=None, max_norm=0.0, dyn=None):
+    """dyn: optional device tensor [lr, step] (fp32) overriding the host lr / step (graph replay)."""
+    bc1 = 1.0 - beta1 ** max(step, 1)
+    bc2 = 1.0 - beta2 ** max(step, 1)
     check(lib().kantts_adam_step(ptr(p, torch.float32), ptr(g, torch.float32), ptr(m, torch.float32),
                                  ptr(v, torch.float32), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                  float(weight_decay), float(bc1), float(bc2), ptr(gnorm_sq),
-                                 float(max_norm if max_norm else 0.0), stream()), "adam_step")
+                                 float(max_norm if max_norm else 0.0), ptr(dyn), stream()), "adam_step")

@@ -294,6 +294,9 @@ class KanTtsSAMBERT(nn.Module):
             raise NotImplementedError("filled-pause predictor is outside the hot path")
         # the reference always returns 8 + 24 dense attention maps; here opt-in
         self.return_attns = False
+        # True: the band width stays in device memory (no host sync) so that a whole training step can be
+        # captured in a hipGraph; res["x_band_width"] is then a 1-element int32 tensor instead of an int
+        self.device_band_width = False
 
     def get_lfr_mask_from_lengths(self, lengths, max_len):
         """ceil(len / r) valid decoder steps (reference :736-750, vectorised: no per-item .item())."""
@@ -334,12 +337,18 @@ class KanTtsSAMBERT(nn.Module):
             LR_emo_outputs.reshape(batch_size, -1, r * d_e)[:, :, :d_e],
         ], dim=-1)
         if duration_targets is not None:
-            x_band_width = int(duration_targets.float().masked_fill(in_info.mask, 0).max() / r + 0.5)
+            bw_val = duration_targets.float().masked_fill(in_info.mask, 0).max() / r + 0.5
         else:
-            x_band_width = int((torch.exp(log_duration_predictions) - 1).max() / r + 0.5)
-        h_band_width = x_band_width
+            bw_val = (torch.exp(log_duration_predictions) - 1).max() / r + 0.5
+        bw_dev = None
+        if self.device_band_width:
+            bw_dev = bw_val.to(torch.int32).reshape(1)  # trunc == int() for non-negative values
+            x_band_width = h_band_width = bw_dev
+            bw_int = 0
+        else:
+            x_band_width = h_band_width = bw_int = int(bw_val)  # host sync, as in the reference (:981-993)
         dec_outputs, pnca_x_attn_lst, pnca_h_attn_lst = self.mel_decoder(
-            memory, x_band_width, h_band_width, target=mel_targets, mask=lfr_info, return_attns=self.return_attns)
+            memory, bw_int, bw_int, target=mel_targets, mask=lfr_info, return_attns=self.return_attns, bw_dev=bw_dev)
         dec_outputs = dec_outputs.reshape(batch_size, -1, self.mel_decoder.d_mel)
         rows = out_info.mask
         if rows.size(1) != dec_outputs.size(1):

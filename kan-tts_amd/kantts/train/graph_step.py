@@ -1,0 +1,82 @@
+"""Whole-training-step hipGraph capture for the SAM-BERT hot path.
+
+The reference's Sambert_Trainer.train_step (kantts/train/trainer.py:898-1005) issues ~700 tiny
+kernels and >= B+12 host syncs per step; on MI355X the step is launch/host bound, not math bound.
+Here forward + losses + backward + gradient packing + clip + Adam are captured ONCE into a hipGraph
+(torch.cuda.CUDAGraph drives hipStreamBeginCapture) and replayed per step:
+  * band width, dropout offset, lr and step count live in device memory (no value is frozen into the
+    captured kernel arguments that must change between steps);
+  * inputs are static device buffers (`load_batch` copies a new batch of the same shape in place);
+  * the data-parallel all-reduce is issued between graph replays of the two halves when
+    world_size > 1 (RCCL calls are not captured).
+"""
+import torch
+
+from kantts._hip import ops
+
+
+class GraphedSambertStep:
+    def __init__(self, net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup=3):
+        self.net, self.optimizer, self.scheduler = net, optimizer, scheduler
+        self.mel_criterion, self.prosody_criterion = mel_criterion, prosody_criterion
+        self.batch = {k: v.clone() for k, v in batch.items()}
+        self.device = next(net.parameters()).device
+        net.device_band_width = True
+        self.distributed = optimizer.arena.world_size > 1
+        optimizer.enable_device_state()
+        self.loss = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        self.graph_b = None
+        optimizer.zero_grad(set_to_none=True)
+        if not self.distributed:
+            with torch.cuda.graph(self.graph_a):
+                self._forward_backward()
+                self._apply()
+        else:
+            with torch.cuda.graph(self.graph_a):
+                self._forward_backward()
+                optimizer.arena.pack_grads()
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                self._apply(packed=True)
+
+    def _forward_backward(self):
+        b = self.batch
+        ops.advance_rng(self.device)
+        self.optimizer.zero_grad(set_to_none=True)
+        res = self.net(**b)
+        mel_, mel = self.mel_criterion(b["output_lengths"], b["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+        d, p, e = self.prosody_criterion(b["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                         res["energy_targets"], res["log_duration_predictions"],
+                                         res["pitch_predictions"], res["energy_predictions"])
+        self.loss = mel_ + mel + d + p + e
+        self.loss.backward()
+
+    def _apply(self, packed=False):
+        self.optimizer.step(packed=packed) if packed else self.optimizer.step()
+
+    def _eager_step(self):
+        self._forward_backward()
+        self.optimizer.step()
+
+    def load_batch(self, batch):
+        for k, v in batch.items():
+            self.batch[k].copy_(v, non_blocking=True)
+
+    def __call__(self):
+        """One training step; returns the (device) loss tensor of this step."""
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            self.optimizer.arena.all_reduce_grads()
+            self.graph_b.replay()
+        self.optimizer._step += 1  # the device-side count advances inside the graph; mirror it on the host
+        self.scheduler.step()
+        self.optimizer.sync_lr()
+        return self.loss

@@ -98,6 +98,7 @@ class ArenaAdam(torch.optim.Optimizer):
         self.gnorm_sq = torch.zeros((), device=dev, dtype=torch.float32)
         self.max_grad_norm = 0.0
         self._step = 0
+        self.dyn = None  # optional device tensor [lr, step] (hipGraph replay), see enable_device_state()
         for i, p in enumerate(arena.params):
             self.state[p] = {
                 "step": torch.tensor(0.0),
@@ -105,27 +106,44 @@ class ArenaAdam(torch.optim.Optimizer):
                 "exp_avg_sq": arena.view_of(self.exp_avg_sq, i),
             }
 
+    def enable_device_state(self):
+        """Keep lr and the step count in device memory so that step() can be replayed from a hipGraph:
+        the captured kernels read {lr, step} from ``self.dyn``; call sync_lr() after scheduler.step()."""
+        self.dyn = torch.tensor([self.param_groups[0]["lr"], float(self._step)], device=self.arena.flat.device,
+                                dtype=torch.float32)
+        return self.dyn
+
+    def sync_lr(self):
+        if self.dyn is not None:
+            self.dyn[0:1].fill_(float(self.param_groups[0]["lr"]))
+
     def set_grad_clip(self, max_norm):
         """Fold ``clip_grad_norm_(params, max_norm)`` into the step (norm never leaves the device)."""
         self.max_grad_norm = float(max_norm) if max_norm and max_norm > 0 else 0.0
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, packed=False):
+        """packed=True: gradients are already packed (and all-reduced) in the arena."""
         if closure is not None:
             raise NotImplementedError("closure")
         group = self.param_groups[0]
         arena = self.arena
-        g = arena.pack_grads()
-        arena.all_reduce_grads()
+        if packed:
+            g = arena.grad
+        else:
+            g = arena.pack_grads()
+            arena.all_reduce_grads()
         gn = None
         if self.max_grad_norm > 0:
             self.gnorm_sq.zero_()
             ops.sumsq_into(g, self.gnorm_sq)
             gn = self.gnorm_sq
         self._step += 1
+        if self.dyn is not None:
+            self.dyn[1:2].add_(1.0)
         b1, b2 = group["betas"]
         ops.adam_step(arena.flat, g, self.exp_avg, self.exp_avg_sq, group["lr"], b1, b2, group["eps"],
-                      group["weight_decay"], self._step, gnorm_sq=gn, max_norm=self.max_grad_norm)
+                      group["weight_decay"], self._step, gnorm_sq=gn, max_norm=self.max_grad_norm, dyn=self.dyn)
         return None  # per-parameter "step" entries are materialised lazily in state_dict()
 
     def grad_norm(self):

@@ -72,84 +72,106 @@ class EmulatedLib:
         return b"emulated"
 
     # ------------------------------------------------------------------------------------ GEMM
+    @staticmethod
+    def _map_tokens(tok, shift, inner, Tq, Tsrc, mul, div, up, T):
+        """numpy twin of map_token (csrc/gemm.hip): returns (rows, valid)."""
+        inner, Tq, Tsrc = (inner or 1), (Tq or T), (Tsrc or T)
+        mul, div, up = (mul or 1), (div or 1), (up or 1)
+        pi, bq = tok % inner, tok // inner
+        q, b = bq % Tq, bq // Tq
+        t = q * mul + shift
+        valid = t >= 0
+        if div > 1:
+            valid &= (t % div) == 0
+            t = t // div
+        valid &= t < Tsrc * up
+        t = t // up
+        return (b * Tsrc + t) * inner + pi, valid
+
     def kantts_gemm_seg_launch(self, args_ref, stream):
         g = args_ref._obj
         M, N, T = g.M, g.N, g.T
         if M == 0 or N == 0:
             return 0
-        acc = np.zeros((M, N), dtype=np.float32)
-        rowsum = np.zeros(M, dtype=np.float32)
+        soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
         ii = np.arange(M, dtype=np.int64)[:, None]
         jj = np.arange(N, dtype=np.int64)[:, None]
-        for si in range(g.nseg):
-            s = g.seg[si]
-            K = s.klen
-            if K == 0:
-                continue
-            kk = np.arange(K, dtype=np.int64)[None, :]
-            kmask = None
-            if g.kmask:
-                kmask = _arr(g.kmask, K, np.uint8) != 0
-            for tap in range(s.ntaps):
-                a_shift = s.a_shift0 + tap * s.a_shift_step if s.a_tok_axis else 0
-                b_shift = s.b_shift0 + tap * s.b_shift_step if s.b_tok_axis else 0
-                ai, ak = ii + 0 * kk, kk + 0 * ii
-                valid = np.ones((M, K), dtype=bool)
-                if a_shift != 0:
+        jrow = np.arange(N, dtype=np.int64)[None, :]
+        for grp in range(max(1, g.groups)):
+            acc = np.zeros((M, N), dtype=np.float32)
+            rowsum = np.zeros(M, dtype=np.float32)
+            for si in range(g.nseg):
+                s = g.seg[si]
+                K = s.klen
+                if K == 0:
+                    continue
+                kk = np.arange(K, dtype=np.int64)[None, :]
+                kmask = (_arr(g.kmask, K, np.uint8) != 0) if g.kmask else None
+                for tap in range(s.ntaps):
+                    a_shift = s.a_shift0 + tap * s.a_shift_step if s.a_tok_axis else 0
+                    b_shift = s.b_shift0 + tap * s.b_shift_step if s.b_tok_axis else 0
+                    ai, ak = ii + 0 * kk, kk + 0 * ii
+                    valid = np.ones((M, K), dtype=bool)
+                    amap = (s.a_inner, s.a_Tq, s.a_Tsrc, s.a_mul, s.a_div, s.a_up, T)
                     if s.a_tok_axis == 1:
-                        t = ai % T + a_shift
-                        valid &= (t >= 0) & (t < T)
-                        ai = ai + a_shift
+                        ai, v2 = self._map_tokens(ai, a_shift, *amap)
+                        valid &= v2
                     elif s.a_tok_axis == 2:
-                        t = ak % T + a_shift
-                        valid &= (t >= 0) & (t < T)
-                        ak = ak + a_shift
-                if kmask is not None:
-                    valid &= ~kmask[None, :]
-                offs = ai * s.a_is + ak * s.a_ks
-                A = _gather(s.a, offs, valid)
-                if s.a_gate:
-                    gate = _gather(s.a_gate, offs, valid)
-                    A = np.where(gate > 0, A, np.float32(0))
-                if s.a_drop_p > 0:
-                    A = A * dropout_scale(s.a_drop_p, s.a_drop_seed, offs)
-                bk = kk + 0 * jj
-                bvalid = np.ones((N, K), dtype=bool)
-                if b_shift != 0 and s.b_tok_axis == 2:
-                    t = bk % T + b_shift
-                    bvalid &= (t >= 0) & (t < T)
-                    bk = bk + b_shift
-                boffs = jj * s.b_js + bk * s.b_ks + tap * s.b_tap
-                Bm = _gather(s.b, boffs, bvalid)
-                acc += A @ Bm.T
-                if si == 0:
-                    rowsum += A.sum(axis=1)
-        v = acc
-        if g.bias:
-            v = v + _arr(g.bias, N)[None, :]
-        if g.bias2:
-            v = v + _arr(g.bias2, N)[None, :]
-        v = v * np.float32(g.alpha)
-        if g.relu:
-            v = np.maximum(v, 0)
-        if g.drop_p > 0:
-            idx = (ii * N + np.arange(N, dtype=np.int64)[None, :])
-            v = v * dropout_scale(g.drop_p, g.drop_seed, idx)
-        if g.res:
-            v = v + _gather(g.res, ii * g.r_is + np.arange(N, dtype=np.int64)[None, :] * g.r_js, None)
-        if g.rowmask:
-            rm = _arr(g.rowmask, M, np.uint8) != 0
-            v = np.where(rm[:, None], np.float32(0), v)
-        v = v.astype(np.float32)
-        coffs = ii * g.c_is + np.arange(N, dtype=np.int64)[None, :] * g.c_js
-        lo, hi = int(coffs.min()), int(coffs.max())
-        cmem = _arr(int(g.c) + 4 * lo, hi - lo + 1)
-        if g.accumulate:
-            np.add.at(cmem, (coffs - lo).ravel(), v.ravel())
-        else:
-            cmem[(coffs - lo).ravel()] = v.ravel()
-        if g.a_rowsum:
-            _arr(g.a_rowsum, M)[:] += rowsum
+                        ak, v2 = self._map_tokens(ak, a_shift, *amap)
+                        valid &= v2
+                    if kmask is not None:
+                        valid &= ~kmask[None, :]
+                    offs = ai * s.a_is + ak * s.a_ks + grp * g.a_gs
+                    A = _gather(s.a, offs, valid)
+                    if s.a_act:
+                        A = np.where(A > 0, A, A * np.float32(s.a_slope))
+                    if s.a_gate:
+                        gate = _gather(s.a_gate, offs, valid)
+                        A = np.where(gate > 0, A, np.float32(0))
+                    if s.a_drop_p > 0:
+                        A = A * dropout_scale(s.a_drop_p, s.a_drop_seed + soff, offs)
+                    bk = kk + 0 * jj
+                    bvalid = np.ones((N, K), dtype=bool)
+                    if s.b_tok_axis == 2:
+                        bk, bvalid = self._map_tokens(bk, b_shift, s.b_inner, s.b_Tq, s.b_Tsrc, s.b_mul, s.b_div,
+                                                      s.b_up, T)
+                    boffs = jj * s.b_js + bk * s.b_ks + tap * s.b_tap + grp * g.b_gs
+                    Bm = _gather(s.b, boffs, bvalid)
+                    if s.b_act:
+                        Bm = np.where(Bm > 0, Bm, Bm * np.float32(s.b_slope))
+                    acc += A @ Bm.T
+                    if si == 0:
+                        rowsum += A.sum(axis=1)
+            v = acc
+            if g.bias:
+                v = v + _gather(g.bias, jrow + grp * g.bias_gs, None)
+            if g.bias2:
+                v = v + _gather(g.bias2, jrow + grp * g.bias_gs, None)
+            v = v * np.float32(g.alpha)
+            if g.relu:
+                v = np.maximum(v, 0)
+            if g.out_act:
+                v = np.where(v > 0, v, v * np.float32(g.out_slope))
+            if g.drop_p > 0:
+                v = v * dropout_scale(g.drop_p, g.drop_seed + soff, ii * N + jrow)
+            if g.res:
+                v = v + _gather(g.res, ii * g.r_is + jrow * g.r_js + grp * g.r_gs, None)
+            coffs = ii * g.c_is + jrow * g.c_js + grp * g.c_gs
+            if g.gate:
+                gv = _gather(g.gate, coffs, None)
+                v = v * np.where(gv > 0, np.float32(1), np.float32(g.gate_slope))
+            if g.rowmask:
+                rm = _arr(g.rowmask, M, np.uint8) != 0
+                v = np.where(rm[:, None], np.float32(0), v)
+            v = v.astype(np.float32)
+            lo, hi = int(coffs.min()), int(coffs.max())
+            cmem = _arr(int(g.c) + 4 * lo, hi - lo + 1)
+            if g.accumulate:
+                np.add.at(cmem, (coffs - lo).ravel(), v.ravel())
+            else:
+                cmem[(coffs - lo).ravel()] = v.ravel()
+            if g.a_rowsum:
+                _arr(int(g.a_rowsum) + 4 * grp * g.bias_gs, M)[:] += rowsum
         return 0
 
     # ------------------------------------------------------------------------------------ LayerNorm
@@ -223,8 +245,8 @@ class EmulatedLib:
         return Q, K, V, P, ds, lse, allow
 
     def kantts_attn_fwd(self, q, k, v, ldq, ldk, ldv, o, ldo, lse, probs, lens, bw_dev, bw, B, H, L, d_head, mode,
-                        drop_p, seed, stream):
-        drop_p, seed = _val(drop_p), _val(seed)
+                        drop_p, seed, seed_dev, stream):
+        drop_p, seed = _val(drop_p), _val(seed) + (int(_arr(seed_dev, 1, np.int64)[0]) if seed_dev else 0)
         Q, K, V, P, ds, lse_t, _ = self._attn_mats(q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed)
         Pd = P * ds
         O = torch.einsum("bhij,bhjd->bhid", Pd, V).permute(0, 2, 1, 3).reshape(B * L, H * 16)
@@ -237,8 +259,8 @@ class EmulatedLib:
         return 0
 
     def kantts_attn_bwd(self, q, k, v, ldq, ldk, ldv, o, ldo, d_o, lddo, lse, dvec, dq, dk, dv, lddq, lddk, lddv,
-                        accumulate_dq, lens, bw_dev, bw, B, H, L, d_head, mode, drop_p, seed, stream):
-        drop_p, seed = _val(drop_p), _val(seed)
+                        accumulate_dq, lens, bw_dev, bw, B, H, L, d_head, mode, drop_p, seed, seed_dev, stream):
+        drop_p, seed = _val(drop_p), _val(seed) + (int(_arr(seed_dev, 1, np.int64)[0]) if seed_dev else 0)
         Q, K, V, P, ds, _, _ = self._attn_mats(q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed)
         cols = np.arange(H * 16)[None, :]
         dO = _gather(d_o, (np.arange(B * L)[:, None] * lddo + cols).astype(np.int64), None)
@@ -457,8 +479,13 @@ class EmulatedLib:
         _arr(out, 1)[0] += np.float32((a.astype(np.float64) ** 2).sum())
         return 0
 
-    def kantts_adam_step(self, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2, gnorm_sq, max_norm, stream):
+    def kantts_adam_step(self, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2, gnorm_sq, max_norm, dyn, stream):
         lr, b1, b2, eps, wd, bc1, bc2, max_norm = (np.float32(_val(t)) for t in (lr, b1, b2, eps, wd, bc1, bc2, max_norm))
+        if dyn:
+            d = _arr(dyn, 2)
+            lr = d[0]
+            bc1 = np.float32(1.0) - np.float32(b1) ** d[1]
+            bc2 = np.float32(1.0) - np.float32(b2) ** d[1]
         P, G, Mm, V = _arr(p, n), _arr(g, n), _arr(m, n), _arr(v, n)
         clip = np.float32(1.0)
         if max_norm > 0 and gnorm_sq:
