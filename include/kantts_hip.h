@@ -80,6 +80,7 @@ typedef struct kantts_gemm_seg {
   int32_t a_act;
   float b_slope;
   int32_t b_act;
+  float a_gate_slope;  /* where the gate is <= 0, A is multiplied by this (0: hard gate; LeakyReLU backward) */
 } kantts_gemm_seg;
 
 typedef struct kantts_gemm_args {
@@ -113,6 +114,9 @@ typedef struct kantts_gemm_args {
   const float* gate;   /* optional, addressed like C: v *= (gate > 0 ? 1 : gate_slope)  (backward through
                           an input-side LeakyReLU) */
   float gate_slope;
+  int32_t z_taps;      /* > 0: gridDim.z additionally enumerates z_taps taps of segment 0 (each z-slab handles one
+                          tap and writes C + tap * c_tap): one launch for all taps of a conv weight gradient */
+  int64_t c_tap;
 } kantts_gemm_args;
 
 int kantts_gemm_seg_launch(const kantts_gemm_args* args_host, void* stream);
@@ -221,6 +225,17 @@ int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int hop, int f
                        const float* window, const float* twiddle, float eps_power, const int32_t* mel_start,
                        const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels,
                        float eps_mel, float* out_mel, float* out_mag, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * weight_norm reparametrisation w = g * v / ||v|| per output row (torch.nn.utils.weight_norm, dim=0):
+ * kantts/models/hifigan/layers.py:29,67,105,139, hifigan.py:224,332.  v,w,dw,dv: (rows, cols); g,dg: (rows). */
+int kantts_weight_norm_fwd(const float* v, const float* g, float* w, int rows, int cols, void* stream);
+int kantts_weight_norm_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int rows,
+                           int cols, void* stream);
+
+/* y = sin(x) + x and its backward dx = dy * (cos(x) + 1)  (kantts/models/hifigan/hifigan.py:157) */
+int kantts_sinadd_fwd(const float* x, float* y, long long n, void* stream);
+int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,82 @@
+// Small HBM-bound helpers of the HiFi-GAN stack.
+//   weight_norm (w = g * v / ||v||, one wave-group per output row)   layers.py:29,67,105,139
+//   x -> sin(x) + x                                                   hifigan.py:157
+#include "common.h"
+
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                             float* __restrict__ w, int rows, int cols) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* vr = v + (long long)r * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) s += vr[c] * vr[c];
+  s = kantts_block_sum(s, red);
+  const float sc = g[r] / sqrtf(s);
+  float* wr = w + (long long)r * cols;
+  for (int c = threadIdx.x; c < cols; c += 256) wr[c] = vr[c] * sc;
+}
+
+// dg = sum(dw * v) / ||v||;  dv = (g / ||v||) * (dw - v * dg / ||v||)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                             const float* __restrict__ g, float* __restrict__ dv,
+                                                             float* __restrict__ dg, int rows, int cols) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* vr = v + (long long)r * cols;
+  const float* dr = dw + (long long)r * cols;
+  float s = 0.f, d = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    s += vr[c] * vr[c];
+    d += dr[c] * vr[c];
+  }
+  s = kantts_block_sum(s, red);
+  d = kantts_block_sum(d, red);
+  const float nrm = sqrtf(s);
+  const float dgv = d / nrm;
+  if (threadIdx.x == 0) dg[r] = dgv;
+  const float a = g[r] / nrm, bq = dgv / nrm;
+  float* o = dv + (long long)r * cols;
+  for (int c = threadIdx.x; c < cols; c += 256) o[c] = a * (dr[c] - vr[c] * bq);
+}
+
+__global__ void sinadd_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    y[i] = sinf(v) + v;
+  }
+}
+__global__ void sinadd_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                  long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * (cosf(x[i]) + 1.f);
+}
+
+extern "C" int kantts_weight_norm_fwd(const float* v, const float* g, float* w, int rows, int cols, void* stream) {
+  if (!v || !g || !w || rows < 0 || cols < 1) return KANTTS_E_BADARG;
+  if (rows == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, w, rows, cols);
+  KANTTS_CHECK_LAUNCH();
+}
+extern "C" int kantts_weight_norm_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int rows,
+                                      int cols, void* stream) {
+  if (!dw || !v || !g || !dv || !dg || rows < 0 || cols < 1) return KANTTS_E_BADARG;
+  if (rows == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dw, v, g, dv, dg, rows, cols);
+  KANTTS_CHECK_LAUNCH();
+}
+extern "C" int kantts_sinadd_fwd(const float* x, float* y, long long n, void* stream) {
+  if (!x || !y || n < 0) return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sinadd_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  KANTTS_CHECK_LAUNCH();
+}
+extern "C" int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, long long n, void* stream) {
+  if (!dy || !x || !dx || n < 0) return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sinadd_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n);
+  KANTTS_CHECK_LAUNCH();
+}

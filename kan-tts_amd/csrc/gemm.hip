@@ -70,7 +70,7 @@ __device__ __forceinline__ float g_load_a(const kantts_gemm_seg& s, const kantts
   long long off = ii * s.a_is + kq * s.a_ks + goff;
   float v = s.a[off];
   if (s.a_act) v = v > 0.f ? v : v * s.a_slope;
-  if (s.a_gate && !(s.a_gate[off] > 0.f)) v = 0.f;
+  if (s.a_gate && !(s.a_gate[off] > 0.f)) v *= s.a_gate_slope;
   if (s.a_drop_p > 0.f)
     v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed + (g.seed_dev ? *g.seed_dev : 0ull), (uint64_t)off);
   return v;
@@ -122,8 +122,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
   const int wr = wave >> 1, wc = wave & 1;
   const int i0 = blockIdx.y * G_BM;
   const int j0 = blockIdx.x * G_BN;
-  const int grp = blockIdx.z / g.splitk;
-  const int zslice = blockIdx.z % g.splitk;
+  const int zper = g.groups * g.splitk;
+  const int ztap = g.z_taps > 0 ? (int)(blockIdx.z / zper) : -1;
+  const int zrem = blockIdx.z % zper;
+  const int grp = zrem / g.splitk;
+  const int zslice = zrem % g.splitk;
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
     for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float rowsum = 0.f;
-  const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0);
+  const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0) && (ztap <= 0);
   int tile_counter = 0;
 
   for (int sidx = 0; sidx < g.nseg; ++sidx) {
@@ -143,6 +146,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
     const TokMap bm = make_map(s.b_inner, s.b_Tq, s.b_Tsrc, s.b_mul, s.b_div, s.b_up, g.T);
     const long long a_goff = (long long)grp * g.a_gs, b_goff = (long long)grp * g.b_gs;
     for (int tap = 0; tap < s.ntaps; ++tap) {
+      if (ztap >= 0 && tap != ztap) continue;
       const int a_shift = s.a_tok_axis ? s.a_shift0 + tap * s.a_shift_step : 0;
       const int b_shift = s.b_tok_axis ? s.b_shift0 + tap * s.b_shift_step : 0;
       for (int k0 = 0; k0 < s.klen; k0 += G_BK) {
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
         int j = j0 + wc * 32 + n * 16 + (lane & 15);
         if (i < g.M && j < g.N) {
           float v = g_epilogue(g, acc[m][n][r], i, j, first_slice, grp);
-          float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js + (long long)grp * g.c_gs];
+          float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js + (long long)grp * g.c_gs +
+                            (ztap > 0 ? (long long)ztap * g.c_tap : 0)];
           if (g.accumulate)
             atomicAdd(dst, v);
           else
@@ -252,7 +257,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_g
 // Scalar fp32 reference of the same contract (debug / cross-check of the MFMA fragment maps).
 __global__ void gemm_seg_ref_kernel(const kantts_gemm_args g) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int grp = blockIdx.y;
+  const int grp = blockIdx.y % g.groups;
+  const int ztap = g.z_taps > 0 ? (int)(blockIdx.y / g.groups) : -1;
   if (idx >= (long long)g.M * g.N) return;
   int i = (int)(idx / g.N), j = (int)(idx % g.N);
   float acc = 0.f, rs = 0.f;
@@ -262,6 +268,7 @@ __global__ void gemm_seg_ref_kernel(const kantts_gemm_args g) {
     const TokMap bm = make_map(s.b_inner, s.b_Tq, s.b_Tsrc, s.b_mul, s.b_div, s.b_up, g.T);
     const long long a_goff = (long long)grp * g.a_gs, b_goff = (long long)grp * g.b_gs;
     for (int tap = 0; tap < s.ntaps; ++tap) {
+      if (ztap >= 0 && tap != ztap) continue;
       const int a_shift = s.a_tok_axis ? s.a_shift0 + tap * s.a_shift_step : 0;
       const int b_shift = s.b_tok_axis ? s.b_shift0 + tap * s.b_shift_step : 0;
       for (int kk = 0; kk < s.klen; ++kk) {
@@ -271,9 +278,10 @@ __global__ void gemm_seg_ref_kernel(const kantts_gemm_args g) {
       }
     }
   }
-  if (g.a_rowsum && j == 0) atomicAdd(&g.a_rowsum[i + grp * g.bias_gs], rs);
+  if (g.a_rowsum && j == 0 && ztap <= 0) atomicAdd(&g.a_rowsum[i + grp * g.bias_gs], rs);
   float v = g_epilogue(g, acc, i, j, true, grp);
-  float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js + (long long)grp * g.c_gs];
+  float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js + (long long)grp * g.c_gs +
+                    (ztap > 0 ? (long long)ztap * g.c_tap : 0)];
   if (g.accumulate)
     atomicAdd(dst, v);
   else
@@ -292,7 +300,9 @@ extern "C" int kantts_gemm_seg_launch(const kantts_gemm_args* a, void* stream) {
     if ((sg.a_tok_axis && sg.a_Tq <= 0 && a->T <= 0) || (sg.b_tok_axis && sg.b_Tq <= 0 && a->T <= 0))
       return KANTTS_E_BADARG;
   }
-  if ((long long)groups * splitk > 65535) return KANTTS_E_BADARG;
+  int ztaps = a->z_taps > 0 ? a->z_taps : 1;
+  if (a->z_taps > 0 && (a->nseg != 1 || a->z_taps != a->seg[0].ntaps)) return KANTTS_E_BADARG;
+  if ((long long)groups * splitk * ztaps > 65535) return KANTTS_E_BADARG;
   kantts_gemm_args g = *a;
   g.splitk = splitk;
   g.groups = groups;
@@ -300,9 +310,9 @@ extern "C" int kantts_gemm_seg_launch(const kantts_gemm_args* a, void* stream) {
   if (g.precision == 2) {
     g.splitk = 1;
     long long total = (long long)g.M * g.N;
-    hipLaunchKernelGGL(gemm_seg_ref_kernel, dim3(kantts_cdiv(total, 256), groups), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gemm_seg_ref_kernel, dim3(kantts_cdiv(total, 256), groups * ztaps), dim3(256), 0, st, g);
   } else {
-    dim3 grid(kantts_cdiv(g.N, G_BN), kantts_cdiv(g.M, G_BM), groups * splitk);
+    dim3 grid(kantts_cdiv(g.N, G_BN), kantts_cdiv(g.M, G_BM), groups * splitk * ztaps);
     if (g.precision == 1)
       hipLaunchKernelGGL(gemm_seg_mfma_kernel<true>, grid, dim3(G_THREADS), 0, st, g);
     else if (g.precision == 0)
