@@ -36,7 +36,7 @@ def sambert_yaml_config(cfg):
         "grad_norm": 1.0, "batch_size": 32}
 
 
-def cpu_baseline(cfg, sample_B=8, iters=2):
+def cpu_baseline(cfg, sample_B=8, iters=3, max_threads=16):
     """CPU oracle ("port" of the reference path, pinned against it by tests/golden) fwd+bwd on a
     bounded sample of the same workload; Adam omitted (negligible next to fwd+bwd on CPU)."""
     import torch_oracle as O
@@ -48,7 +48,8 @@ def cpu_baseline(cfg, sample_B=8, iters=2):
     P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
     batch = O.synthetic_sambert_batch(B=sample_B, T_in=64, seed=1234)
     frames = int(batch["output_lengths"].sum())
-    cores = os.cpu_count() or 1
+    # the port is many small ops + python LSTM loops: more than ~16 threads only adds fork/join overhead
+    cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
 
     def one():

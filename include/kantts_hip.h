@@ -81,6 +81,10 @@ typedef struct kantts_gemm_seg {
   float b_slope;
   int32_t b_act;
   float a_gate_slope;  /* where the gate is <= 0, A is multiplied by this (0: hard gate; LeakyReLU backward) */
+  int32_t a_mode, b_mode; /* staging layout hints, see csrc/gemm.hip: 0 scalar/lanes along k, 1 scalar/lanes
+                          along rows, 2 float4 along k (needs unit k stride, klen % 4 == 0, 16-byte aligned
+                          rows, no token map on kk), 3 float4 along rows (unit row stride, extent % 4 == 0,
+                          no token map on the row index).  0 is always valid. */
 } kantts_gemm_seg;
 
 typedef struct kantts_gemm_args {
@@ -194,7 +198,10 @@ int kantts_lr_gather_bwd(const float* dout, const int32_t* cs, const int64_t* va
 int kantts_fsmn_dwconv_fwd(const float* x, const float* w, const float* res, const int64_t* lens, float* y, int B,
                            int T, int C, int K, int left_pad, void* stream);
 int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const float* w, const int64_t* lens, float* dx,
-                           float* dw_accum, int B, int T, int C, int K, int left_pad, void* stream);
+                           float* dw_accum, float* workspace, long long ws_floats, int B, int T, int C, int K,
+                           int left_pad, void* stream);
+/* floats of caller-owned workspace the backward needs (weight-gradient partials; 0 when none) */
+long long kantts_fsmn_dwconv_bwd_ws(int B, int T, int C, int K);
 
 /* ------------------------------------------------------------------------------------------
  * Masked L1 ("mae") reduction: loss_accum[0] += sum_{t<lens[b]} |target-pred| / (sum(lens)*C);

@@ -241,6 +241,186 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const AttnArgs a) {
   store16(a.dv + krow * a.lddv + h * DH, dv);
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged versions: one workgroup per (batch, head) stages the K/V (or Q/dO) rows of that head
+// once (coalesced float4 rows, 17-float LDS row stride => conflict-free when neighbouring lanes read
+// neighbouring rows, broadcast when all lanes read one row) and every thread then walks its interval
+// out of LDS.  The direct-from-global kernels above are latency-bound (two dependent L2 round trips
+// per key); these are the ones used whenever the head fits in 64 KB of LDS (L <= ~440).
+#define AT_LD 17
+#define AT_THREADS 256
+
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld, int L, float* __restrict__ dst) {
+  for (int idx = threadIdx.x; idx < L * 4; idx += AT_THREADS) {
+    const int row = idx >> 2, part = idx & 3;
+    const float4 t = *reinterpret_cast<const float4*>(src + (long long)row * ld + part * 4);
+    float* d = dst + row * AT_LD + part * 4;
+    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+  }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;
+  float* Vs = sm + a.L * AT_LD;
+  const int h = blockIdx.x, b = blockIdx.y;
+  stage_rows(a.k + (long long)b * a.L * a.ldk + h * DH, a.ldk, a.L, Ks);
+  stage_rows(a.v + (long long)b * a.L * a.ldv + h * DH, a.ldv, a.L, Vs);
+  __syncthreads();
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  for (int i = threadIdx.x; i < a.L; i += AT_THREADS) {
+    int lo, hi;
+    key_range(a.mode, i, len, a.L, bw, lo, hi);
+    const long long row = (long long)b * a.L + i;
+    float q[DH], o[DH];
+    load16(a.q + row * a.ldq + h * DH, q);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = 0.f;
+    float m = -INFINITY;
+    for (int j = lo; j <= hi; ++j) m = fmaxf(m, dot16(q, Ks + j * AT_LD) * a.scale);
+    float l = 0.f;
+    const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
+    for (int j = lo; j <= hi; ++j) {
+      const float e = expf(dot16(q, Ks + j * AT_LD) * a.scale - m);
+      l += e;
+      const float ed = e * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+      const float* vv = Vs + j * AT_LD;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
+    }
+    const float inv = (hi >= lo) ? 1.f / l : 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] *= inv;
+    store16(a.o + row * a.ldo + h * DH, o);
+    a.lse[((long long)b * a.H + h) * a.L + i] = (hi >= lo) ? (m + logf(l)) : 0.f;
+    if (a.probs) {
+      float* prow = a.probs + (((long long)h * a.B + b) * a.L + i) * a.L;
+      for (int j = 0; j < a.L; ++j) {
+        float p = 0.f;
+        if (j >= lo && j <= hi)
+          p = expf(dot16(q, Ks + j * AT_LD) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+        prow[j] = p;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_lds_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ks = sm;
+  float* Vs = sm + a.L * AT_LD;
+  const int h = blockIdx.x, b = blockIdx.y;
+  stage_rows(a.k + (long long)b * a.L * a.ldk + h * DH, a.ldk, a.L, Ks);
+  stage_rows(a.v + (long long)b * a.L * a.ldv + h * DH, a.ldv, a.L, Vs);
+  __syncthreads();
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  for (int i = threadIdx.x; i < a.L; i += AT_THREADS) {
+    int lo, hi;
+    key_range(a.mode, i, len, a.L, bw, lo, hi);
+    const long long row = (long long)b * a.L + i;
+    float q[DH], go[DH], oo[DH], dq[DH];
+    load16(a.q + row * a.ldq + h * DH, q);
+    load16(a.d_o + row * a.lddo + h * DH, go);
+    load16(a.o + row * a.ldo + h * DH, oo);
+    const float D = dot16(go, oo);
+    const long long sidx = ((long long)b * a.H + h) * a.L + i;
+    const float lse = a.lse[sidx];
+    a.dvec[sidx] = D;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+    const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
+    for (int j = lo; j <= hi; ++j) {
+      const float* kk = Ks + j * AT_LD;
+      const float p = expf(dot16(q, kk) * a.scale - lse);
+      const float dp = dot16(go, Vs + j * AT_LD) * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+      const float ds = p * (dp - D) * a.scale;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
+    }
+    float* dst = a.dq + row * a.lddq + h * DH;
+    if (a.accumulate_dq) {
+      float old[DH];
+      load16(dst, old);
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dq[d] += old[d];
+    }
+    store16(dst, dq);
+  }
+}
+
+// must run after attn_bwd_dq_* (needs dvec)
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_lds_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm;
+  float* Gs = sm + a.L * AT_LD;
+  float* Ls = Gs + a.L * AT_LD;  // lse
+  float* Ds = Ls + a.L;          // dvec
+  const int h = blockIdx.x, b = blockIdx.y;
+  stage_rows(a.q + (long long)b * a.L * a.ldq + h * DH, a.ldq, a.L, Qs);
+  stage_rows(a.d_o + (long long)b * a.L * a.lddo + h * DH, a.lddo, a.L, Gs);
+  const long long sbase = ((long long)b * a.H + h) * a.L;
+  for (int i = threadIdx.x; i < a.L; i += AT_THREADS) {
+    Ls[i] = a.lse[sbase + i];
+    Ds[i] = a.dvec[sbase + i];
+  }
+  __syncthreads();
+  const int len = a.lens ? a.lens[b] : a.L;
+  const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  for (int j = threadIdx.x; j < a.L; j += AT_THREADS) {
+    const long long krow = (long long)b * a.L + j;
+    float kk[DH], vv[DH], dk[DH], dv[DH];
+    load16(a.k + krow * a.ldk + h * DH, kk);
+    load16(a.v + krow * a.ldv + h * DH, vv);
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      dk[d] = 0.f;
+      dv[d] = 0.f;
+    }
+    int c0, c1, p0 = len, p1 = a.L - 1;
+    if (a.mode == 0) {
+      c0 = 0;
+      c1 = a.L - 1;
+      p0 = 1;
+      p1 = 0;
+    } else {
+      c0 = max(0, j - bw);
+      c1 = min(j + bw, len - 1);
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+      const int s0 = pass ? p0 : c0, e0 = pass ? p1 : c1;
+      for (int i = s0; i <= e0; ++i) {
+        int lo, hi;
+        key_range(a.mode, i, len, a.L, bw, lo, hi);
+        if (j < lo || j > hi) continue;
+        const float* q = Qs + i * AT_LD;
+        const float* go = Gs + i * AT_LD;
+        const float p = expf(dot16(q, kk) * a.scale - Ls[i]);
+        const float dsc =
+            kantts_dropout_scale(a.drop_p, seed, ((((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L) + j);
+        const float pd = p * dsc;
+        const float dp = dot16(go, vv) * dsc;
+        const float ds = p * (dp - Ds[i]) * a.scale;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+          dv[d] = fmaf(pd, go[d], dv[d]);
+          dk[d] = fmaf(ds, q[d], dk[d]);
+        }
+      }
+    }
+    store16(a.dk + krow * a.lddk + h * DH, dk);
+    store16(a.dv + krow * a.lddv + h * DH, dv);
+  }
+}
+
+static inline size_t attn_lds_bytes(int L, bool dkv) {
+  return (size_t)(2 * L * AT_LD + (dkv ? 2 * L : 0)) * sizeof(float);
+}
+
 static int attn_check(const AttnArgs& a) {
   if (!a.q || !a.k || !a.v || !a.o || !a.lse) return KANTTS_E_BADARG;
   if (a.B < 0 || a.H < 1 || a.L < 0 || a.mode < 0 || a.mode > 2) return KANTTS_E_BADARG;
@@ -261,7 +441,10 @@ extern "C" int kantts_attn_fwd(const float* q, const float* k, const float* v, i
   int rc = attn_check(a);
   if (rc) return rc;
   if (B == 0 || L == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(kantts_cdiv(L, 128), H, B), dim3(128), 0, (hipStream_t)stream, a);
+  if (attn_lds_bytes(L, false) <= 64 * 1024)
+    hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, false), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(kantts_cdiv(L, 128), H, B), dim3(128), 0, (hipStream_t)stream, a);
   KANTTS_CHECK_LAUNCH();
 }
 
@@ -281,8 +464,15 @@ extern "C" int kantts_attn_bwd(const float* q, const float* k, const float* v, i
   if (rc) return rc;
   if (!d_o || !dq || !dk || !dv || !dvec || ((lddo | lddq | lddk | lddv) & 3)) return KANTTS_E_BADARG;
   if (B == 0 || L == 0) return KANTTS_OK;
-  dim3 grid(kantts_cdiv(L, 128), H, B), block(128);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, (hipStream_t)stream, a);
+  if (attn_lds_bytes(L, true) <= 64 * 1024) {
+    hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, false),
+                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, true),
+                       (hipStream_t)stream, a);
+  } else {
+    dim3 grid(kantts_cdiv(L, 128), H, B), block(128);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, (hipStream_t)stream, a);
+  }
   KANTTS_CHECK_LAUNCH();
 }

@@ -17,7 +17,6 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define G_BM 64
 #define G_BN 64
 #define G_BK 32
 #define G_THREADS 256
@@ -108,139 +107,287 @@ __device__ __forceinline__ float g_epilogue(const kantts_gemm_args& g, float acc
   return v;
 }
 
-template <bool BF16>
+// ---------------------------------------------------------------------------------------------
+// Operand staging.  Every thread owns 8 elements of the A tile and 8 of the B tile per reduction
+// tile, in one of four layouts chosen per segment by the host (seg.a_mode / seg.b_mode):
+//   0  scalar, lanes along k            (generic fallback, e.g. conv weights with tap stride)
+//   1  scalar, lanes along rows         (unit row stride, rows not a multiple of 4)
+//   2  float4 along k                   (unit k stride: activations / weights / dY of forward & dgrad)
+//   3  float4 along rows                (unit row stride: both operands of the weight gradient)
+// Addresses and validity are pure ALU; loads are issued unconditionally at a clamped address so
+// that all 16 loads of a tile are in flight together (a branch per load would serialise them on
+// s_waitcnt), and they are issued for tile t+1 before the MFMAs of tile t (register double buffer).
+struct TileCur {
+  int sidx, tap, k0;
+};
+
+__device__ __forceinline__ bool cur_step(TileCur& c, const kantts_gemm_args& g, int ztap) {
+  for (;;) {
+    if (c.sidx >= g.nseg) return false;
+    const kantts_gemm_seg& s = g.seg[c.sidx];
+    if (c.tap < s.ntaps && (ztap < 0 || c.tap == ztap)) {
+      c.k0 += G_BK;
+      if (c.k0 < s.klen) return true;
+    }
+    c.k0 = -G_BK;
+    c.tap++;
+    if (c.tap >= s.ntaps) {
+      c.tap = 0;
+      c.sidx++;
+    }
+  }
+}
+
+__device__ __forceinline__ bool addr_a(const kantts_gemm_seg& s, const kantts_gemm_args& g, int i, int kk, int shift,
+                                       const TokMap& m, long long goff, long long& off) {
+  long long ii = i, kq = kk;
+  bool ok = (i < g.M) && (kk < s.klen);
+  if (s.a_tok_axis == 1) {
+    ok = ok && map_token(i, shift, m, ii);
+  } else if (s.a_tok_axis == 2) {
+    ok = ok && map_token(kk, shift, m, kq);
+  }
+  if (g.kmask && ok) ok = (g.kmask[kk] == 0);
+  off = ok ? (ii * s.a_is + kq * s.a_ks + goff) : 0;
+  return ok;
+}
+
+__device__ __forceinline__ bool addr_b(const kantts_gemm_seg& s, const kantts_gemm_args& g, int j, int kk, int shift,
+                                       int tap, const TokMap& m, long long goff, long long& off) {
+  long long kq = kk;
+  bool ok = (j < g.N) && (kk < s.klen);
+  if (s.b_tok_axis == 2) ok = ok && map_token(kk, shift, m, kq);
+  off = ok ? ((long long)j * s.b_js + kq * s.b_ks + (long long)tap * s.b_tap + goff) : 0;
+  return ok;
+}
+
+template <int BM>
+__device__ __forceinline__ void elem_rk(int mode, int tid, int e, int rows, int& r, int& k) {
+  // rows = BM for A, 64 for B;  8 elements per thread when rows == 64, 4 when rows == 32
+  if (mode == 0) {            // lanes along k
+    k = tid & 31;
+    r = (tid >> 5) + 8 * e;
+  } else if (mode == 1) {     // lanes along rows
+    r = tid % rows;
+    k = tid / rows + (G_THREADS / rows) * e;
+  } else if (mode == 2) {     // float4 along k: 8 lanes per row
+    r = (tid >> 3) + 32 * (e >> 2);
+    k = ((tid & 7) << 2) + (e & 3);
+  } else {                    // float4 along rows
+    const int rg = rows >> 2;
+    r = ((tid % rg) << 2) + (e & 3);
+    k = tid / rg + (G_THREADS / rg) * (e >> 2);
+  }
+}
+
+template <bool BF16, int BM>
 __global__ __launch_bounds__(G_THREADS) void gemm_seg_mfma_kernel(const kantts_gemm_args g) {
-  __shared__ __attribute__((aligned(16))) float lds_raw[2 * G_BM * G_LDF];
+  __shared__ __attribute__((aligned(16))) float lds_raw[(BM + G_BN) * G_LDF];
   float* Af = lds_raw;
-  float* Bf = lds_raw + G_BM * G_LDF;
+  float* Bf = lds_raw + BM * G_LDF;
   __bf16* Ah = reinterpret_cast<__bf16*>(lds_raw);
-  __bf16* Bh = Ah + G_BM * G_LDH;
+  __bf16* Bh = Ah + BM * G_LDH;
+  constexpr int EA = BM / 8;   // staged A elements per thread (8 or 4)
+  constexpr int MREP = BM / 32;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int i0 = blockIdx.y * G_BM;
+  const int i0 = blockIdx.y * BM;
   const int j0 = blockIdx.x * G_BN;
   const int zper = g.groups * g.splitk;
   const int ztap = g.z_taps > 0 ? (int)(blockIdx.z / zper) : -1;
   const int zrem = blockIdx.z % zper;
   const int grp = zrem / g.splitk;
   const int zslice = zrem % g.splitk;
+  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
 
-  f32x4 acc[2][2];
+  f32x4 acc[MREP][2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MREP; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float rowsum = 0.f;
   const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0) && (ztap <= 0);
+
+  float ra[EA], rga[EA], rb[8];
+  unsigned oka = 0, okb = 0;
   int tile_counter = 0;
 
-  for (int sidx = 0; sidx < g.nseg; ++sidx) {
-    const kantts_gemm_seg& s = g.seg[sidx];
-    const bool a_lane_i = (s.a_is == 1 && s.a_ks != 1);
-    const bool b_lane_j = (s.b_js == 1 && s.b_ks != 1);
+  // fetch(): issue the global loads of tile `c` into registers (no dependent use here)
+  auto fetch = [&](const TileCur& c) {
+    const kantts_gemm_seg& s = g.seg[c.sidx];
     const TokMap am = make_map(s.a_inner, s.a_Tq, s.a_Tsrc, s.a_mul, s.a_div, s.a_up, g.T);
     const TokMap bm = make_map(s.b_inner, s.b_Tq, s.b_Tsrc, s.b_mul, s.b_div, s.b_up, g.T);
     const long long a_goff = (long long)grp * g.a_gs, b_goff = (long long)grp * g.b_gs;
-    for (int tap = 0; tap < s.ntaps; ++tap) {
-      if (ztap >= 0 && tap != ztap) continue;
-      const int a_shift = s.a_tok_axis ? s.a_shift0 + tap * s.a_shift_step : 0;
-      const int b_shift = s.b_tok_axis ? s.b_shift0 + tap * s.b_shift_step : 0;
-      for (int k0 = 0; k0 < s.klen; k0 += G_BK) {
-        const bool mine = (tile_counter % g.splitk) == zslice;
-        ++tile_counter;
-        if (!mine) continue;
-        // ---- stage A and B tiles into LDS (8 elements per thread each)
+    const int a_shift = s.a_tok_axis ? s.a_shift0 + c.tap * s.a_shift_step : 0;
+    const int b_shift = s.b_tok_axis ? s.b_shift0 + c.tap * s.b_shift_step : 0;
+    oka = 0;
+    okb = 0;
+    if (s.a_mode >= 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          int r, k;
-          if (a_lane_i) {
-            r = tid & 63;
-            k = (tid >> 6) + 4 * e;
-          } else {
-            k = tid & 31;
-            r = (tid >> 5) + 8 * e;
-          }
-          float v = g_load_a(s, g, i0 + r, k0 + k, a_shift, am, a_goff);
-          if (BF16)
-            Ah[r * G_LDH + k] = (__bf16)v;
-          else
-            Af[r * G_LDF + k] = v;
+      for (int v = 0; v < EA / 4; ++v) {
+        int r, k;
+        elem_rk<BM>(s.a_mode, tid, 4 * v, BM, r, k);
+        long long off;
+        const bool ok = addr_a(s, g, i0 + r, c.k0 + k, a_shift, am, a_goff, off);
+        const float4 t = *reinterpret_cast<const float4*>(s.a + off);
+        ra[4 * v] = t.x; ra[4 * v + 1] = t.y; ra[4 * v + 2] = t.z; ra[4 * v + 3] = t.w;
+        if (s.a_gate) {
+          const float4 u = *reinterpret_cast<const float4*>(s.a_gate + off);
+          rga[4 * v] = u.x; rga[4 * v + 1] = u.y; rga[4 * v + 2] = u.z; rga[4 * v + 3] = u.w;
         }
+        if (ok) oka |= 0xFu << (4 * v);
+      }
+    } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          int r, k;
-          if (b_lane_j) {
-            r = tid & 63;
-            k = (tid >> 6) + 4 * e;
-          } else {
-            k = tid & 31;
-            r = (tid >> 5) + 8 * e;
-          }
-          float v = g_load_b(s, g, j0 + r, k0 + k, b_shift, tap, bm, b_goff);
-          if (BF16)
-            Bh[r * G_LDH + k] = (__bf16)v;
-          else
-            Bf[r * G_LDF + k] = v;
-        }
-        __syncthreads();
-        if (do_rowsum && sidx == 0 && tid < G_BM) {
-          float t = 0.f;
-          if (BF16) {
-            for (int k = 0; k < G_BK; ++k) t += (float)Ah[tid * G_LDH + k];
-          } else {
-            for (int k = 0; k < G_BK; ++k) t += Af[tid * G_LDF + k];
-          }
-          rowsum += t;
-        }
-        // ---- MFMA
-        if (BF16) {
-          bf16x8 af[2], bfr[2];
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-            af[m] = *reinterpret_cast<const bf16x8*>(&Ah[(wr * 32 + m * 16 + (lane & 15)) * G_LDH + (lane >> 4) * 8]);
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-            bfr[n] = *reinterpret_cast<const bf16x8*>(&Bh[(wc * 32 + n * 16 + (lane & 15)) * G_LDH + (lane >> 4) * 8]);
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < G_BK / 4; ++ks) {
-            float af[2], bfr[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) af[m] = Af[(wr * 32 + m * 16 + (lane & 15)) * G_LDF + ks * 4 + (lane >> 4)];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) bfr[n] = Bf[(wc * 32 + n * 16 + (lane & 15)) * G_LDF + ks * 4 + (lane >> 4)];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-              for (int n = 0; n < 2; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bfr[n], acc[m][n], 0, 0, 0);
-          }
-        }
-        __syncthreads();
+      for (int e = 0; e < EA; ++e) {
+        int r, k;
+        elem_rk<BM>(s.a_mode, tid, e, BM, r, k);
+        long long off;
+        const bool ok = addr_a(s, g, i0 + r, c.k0 + k, a_shift, am, a_goff, off);
+        ra[e] = s.a[off];
+        if (s.a_gate) rga[e] = s.a_gate[off];
+        if (ok) oka |= 1u << e;
       }
     }
+    if (s.b_mode >= 2) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        int r, k;
+        elem_rk<BM>(s.b_mode, tid, 4 * v, G_BN, r, k);
+        long long off;
+        const bool ok = addr_b(s, g, j0 + r, c.k0 + k, b_shift, c.tap, bm, b_goff, off);
+        const float4 t = *reinterpret_cast<const float4*>(s.b + off);
+        rb[4 * v] = t.x; rb[4 * v + 1] = t.y; rb[4 * v + 2] = t.z; rb[4 * v + 3] = t.w;
+        if (ok) okb |= 0xFu << (4 * v);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int r, k;
+        elem_rk<BM>(s.b_mode, tid, e, G_BN, r, k);
+        long long off;
+        const bool ok = addr_b(s, g, j0 + r, c.k0 + k, b_shift, c.tap, bm, b_goff, off);
+        rb[e] = s.b[off];
+        if (ok) okb |= 1u << e;
+      }
+    }
+  };
+
+  // commit(): masks / activation / gate / dropout, convert and write the staged tile to LDS
+  auto commit = [&](const TileCur& c) {
+    const kantts_gemm_seg& s = g.seg[c.sidx];
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+      int r, k;
+      elem_rk<BM>(s.a_mode, tid, e, BM, r, k);
+      float v = ((oka >> e) & 1u) ? ra[e] : 0.f;
+      if (s.a_act) v = v > 0.f ? v : v * s.a_slope;
+      if (s.a_gate && !(rga[e] > 0.f)) v *= s.a_gate_slope;
+      if (s.a_drop_p > 0.f) {
+        const TokMap am = make_map(s.a_inner, s.a_Tq, s.a_Tsrc, s.a_mul, s.a_div, s.a_up, g.T);
+        const int a_shift = s.a_tok_axis ? s.a_shift0 + c.tap * s.a_shift_step : 0;
+        long long off;
+        int rr = r, kk2 = k;
+        if (s.a_mode == 2) { rr = r; kk2 = k; }
+        addr_a(s, g, i0 + rr, c.k0 + kk2, a_shift, am, (long long)grp * g.a_gs, off);
+        v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed + seed_off, (uint64_t)off);
+      }
+      if (BF16)
+        Ah[r * G_LDH + k] = (__bf16)v;
+      else
+        Af[r * G_LDF + k] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int r, k;
+      elem_rk<BM>(s.b_mode, tid, e, G_BN, r, k);
+      float v = ((okb >> e) & 1u) ? rb[e] : 0.f;
+      if (s.b_act) v = v > 0.f ? v : v * s.b_slope;
+      if (BF16)
+        Bh[r * G_LDH + k] = (__bf16)v;
+      else
+        Bf[r * G_LDF + k] = v;
+    }
+  };
+
+  auto next_owned = [&](TileCur& c) -> bool {
+    for (;;) {
+      if (!cur_step(c, g, ztap)) return false;
+      const bool mine = (tile_counter % g.splitk) == zslice;
+      ++tile_counter;
+      if (mine) return true;
+    }
+  };
+
+  TileCur cur = {0, 0, -G_BK};
+  bool has = next_owned(cur);
+  if (has) fetch(cur);
+  while (has) {
+    commit(cur);
+    __syncthreads();
+    const bool count_rowsum = do_rowsum && cur.sidx == 0;
+    TileCur nxt = cur;
+    const bool has_next = next_owned(nxt);
+    if (has_next) fetch(nxt);  // in flight during the MFMAs below
+    if (count_rowsum && tid < BM) {
+      float t = 0.f;
+      if (BF16) {
+        for (int k = 0; k < G_BK; ++k) t += (float)Ah[tid * G_LDH + k];
+      } else {
+        for (int k = 0; k < G_BK; ++k) t += Af[tid * G_LDF + k];
+      }
+      rowsum += t;
+    }
+    if (BF16) {
+      bf16x8 af[MREP], bfr[2];
+#pragma unroll
+      for (int m = 0; m < MREP; ++m)
+        af[m] = *reinterpret_cast<const bf16x8*>(
+            &Ah[(wr * (BM / 2) + m * 16 + (lane & 15)) * G_LDH + (lane >> 4) * 8]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        bfr[n] = *reinterpret_cast<const bf16x8*>(&Bh[(wc * 32 + n * 16 + (lane & 15)) * G_LDH + (lane >> 4) * 8]);
+#pragma unroll
+      for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < G_BK / 4; ++ks) {
+        float af[MREP], bfr[2];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+          af[m] = Af[(wr * (BM / 2) + m * 16 + (lane & 15)) * G_LDF + ks * 4 + (lane >> 4)];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bfr[n] = Bf[(wc * 32 + n * 16 + (lane & 15)) * G_LDF + ks * 4 + (lane >> 4)];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bfr[n], acc[m][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+    has = has_next;
   }
 
-  if (do_rowsum && tid < G_BM && (i0 + tid) < g.M) atomicAdd(&g.a_rowsum[i0 + tid + grp * g.bias_gs], rowsum);
+  if (do_rowsum && tid < BM && (i0 + tid) < g.M) atomicAdd(&g.a_rowsum[i0 + tid + grp * g.bias_gs], rowsum);
 
   // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
   const bool first_slice = (zslice == 0);
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MREP; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int i = i0 + wr * 32 + m * 16 + (lane >> 4) * 4 + r;
+        int i = i0 + wr * (BM / 2) + m * 16 + (lane >> 4) * 4 + r;
         int j = j0 + wc * 32 + n * 16 + (lane & 15);
         if (i < g.M && j < g.N) {
           float v = g_epilogue(g, acc[m][n][r], i, j, first_slice, grp);
@@ -312,13 +459,24 @@ extern "C" int kantts_gemm_seg_launch(const kantts_gemm_args* a, void* stream) {
     long long total = (long long)g.M * g.N;
     hipLaunchKernelGGL(gemm_seg_ref_kernel, dim3(kantts_cdiv(total, 256), groups * ztaps), dim3(256), 0, st, g);
   } else {
-    dim3 grid(kantts_cdiv(g.N, G_BN), kantts_cdiv(g.M, G_BM), groups * splitk * ztaps);
-    if (g.precision == 1)
-      hipLaunchKernelGGL(gemm_seg_mfma_kernel<true>, grid, dim3(G_THREADS), 0, st, g);
-    else if (g.precision == 0)
-      hipLaunchKernelGGL(gemm_seg_mfma_kernel<false>, grid, dim3(G_THREADS), 0, st, g);
-    else
+    // 32-row tiles when 64-row tiles would leave most of the 256 CUs idle
+    const long long blocks64 = (long long)kantts_cdiv(g.N, G_BN) * kantts_cdiv(g.M, 64) * groups * splitk * ztaps;
+    const bool small = blocks64 < 512;
+    const int bm = small ? 32 : 64;
+    dim3 grid(kantts_cdiv(g.N, G_BN), kantts_cdiv(g.M, bm), groups * splitk * ztaps);
+    if (g.precision == 1) {
+      if (small)
+        hipLaunchKernelGGL((gemm_seg_mfma_kernel<true, 32>), grid, dim3(G_THREADS), 0, st, g);
+      else
+        hipLaunchKernelGGL((gemm_seg_mfma_kernel<true, 64>), grid, dim3(G_THREADS), 0, st, g);
+    } else if (g.precision == 0) {
+      if (small)
+        hipLaunchKernelGGL((gemm_seg_mfma_kernel<false, 32>), grid, dim3(G_THREADS), 0, st, g);
+      else
+        hipLaunchKernelGGL((gemm_seg_mfma_kernel<false, 64>), grid, dim3(G_THREADS), 0, st, g);
+    } else {
       return KANTTS_E_BADARG;
+    }
   }
   KANTTS_CHECK_LAUNCH();
 }

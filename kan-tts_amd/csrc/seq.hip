@@ -279,23 +279,147 @@ __global__ void fsmn_dwconv_bwd_dw_kernel(const float* __restrict__ dy, const fl
   }
 }
 
+// ---- register-window versions (K == 41, every shipped FSMN): thread = channel, 16 consecutive frames
+// per thread; the 56-frame input window and the 41 taps live in VGPRs, all loads of a window are
+// issued back to back at clamped addresses (no branch per load), rows are contiguous in C so a
+// wave reads 256 B per load.  FLIP turns the same code into the input-gradient FIR.
+#define FS_K 41
+#define FS_TT 16
+template <bool FLIP>
+__global__ __launch_bounds__(256, 2) void fsmn_fir41_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ res,
+                                                        const int64_t* __restrict__ lens, float* __restrict__ y, int B,
+                                                        int T, int C, int lp) {
+  const int b = blockIdx.y, t0 = blockIdx.x * FS_TT;
+  const int len = lens ? (int)min((long long)lens[b], (long long)T) : T;
+  const int lpe = FLIP ? (FS_K - 1 - lp) : lp;
+  const float* xb = x + (long long)b * T * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float wk[FS_K];
+#pragma unroll
+    for (int k = 0; k < FS_K; ++k) wk[k] = w[(long long)c * FS_K + (FLIP ? (FS_K - 1 - k) : k)];
+    float xin[FS_TT + FS_K - 1];
+#pragma unroll
+    for (int n = 0; n < FS_TT + FS_K - 1; ++n) {
+      const int ts = t0 + n - lpe;
+      const bool ok = (ts >= 0) && (ts < len);
+      const float v = xb[(long long)(ok ? ts : 0) * C + c];
+      xin[n] = ok ? v : 0.f;
+    }
+    float ctr[FS_TT];  // centre tap x[t] (the "+ input" of the memory block); re-read, it is L1-resident
+#pragma unroll
+    for (int o = 0; o < FS_TT; ++o) {
+      const int t = t0 + o;
+      const bool ok = t < len;
+      const float v = xb[(long long)(ok ? t : 0) * C + c];
+      ctr[o] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < FS_TT; ++o) {
+      const int t = t0 + o;
+      float acc = ctr[o];
+#pragma unroll
+      for (int k = 0; k < FS_K; ++k) acc = fmaf(wk[k], xin[o + k], acc);
+      if (t < T) {
+        const long long oidx = ((long long)b * T + t) * C + c;
+        float outv = (t < len) ? acc : 0.f;
+        if (!FLIP && res) outv += res[oidx];
+        y[oidx] = outv;
+      }
+    }
+  }
+}
+
+// weight gradient partials: block = (chunk of FS_CH frames, b); part[(b*nchunk + chunk)][c][k]
+#define FS_CH 160
+__global__ __launch_bounds__(256, 2) void fsmn_dw41_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const int64_t* __restrict__ lens,
+                                                               float* __restrict__ part, int B, int T, int C, int lp) {
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int len = lens ? (int)min((long long)lens[b], (long long)T) : T;
+  const float* xb = x + (long long)b * T * C;
+  const float* db = dy + (long long)b * T * C;
+  const int tbeg = chunk * FS_CH, tend = min(tbeg + FS_CH, T);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc[FS_K];
+#pragma unroll
+    for (int k = 0; k < FS_K; ++k) acc[k] = 0.f;
+    for (int t0 = tbeg; t0 < tend && t0 < len; t0 += FS_TT) {
+      float xin[FS_TT + FS_K - 1], dv[FS_TT];
+#pragma unroll
+      for (int n = 0; n < FS_TT + FS_K - 1; ++n) {
+        const int ts = t0 + n - lp;
+        const bool ok = (ts >= 0) && (ts < len);
+        const float v = xb[(long long)(ok ? ts : 0) * C + c];
+        xin[n] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < FS_TT; ++o) {
+        const int t = t0 + o;
+        const bool ok = (t < tend) && (t < len);
+        const float v = db[(long long)(ok ? t : 0) * C + c];
+        dv[o] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < FS_TT; ++o)
+#pragma unroll
+        for (int k = 0; k < FS_K; ++k) acc[k] = fmaf(dv[o], xin[o + k], acc[k]);
+    }
+    float* p = part + (((long long)b * nchunk + chunk) * C + c) * FS_K;
+#pragma unroll
+    for (int k = 0; k < FS_K; ++k) p[k] = acc[k];
+  }
+}
+
+__global__ void fsmn_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < nblk; ++p) s += part[(long long)p * n + i];
+  dw[i] += s;
+}
+
+extern "C" long long kantts_fsmn_dwconv_bwd_ws(int B, int T, int C, int K) {
+  if (K != FS_K) return 0;
+  return (long long)B * kantts_cdiv(T, FS_CH) * C * K;
+}
+
 extern "C" int kantts_fsmn_dwconv_fwd(const float* x, const float* w, const float* res, const int64_t* lens, float* y,
                                       int B, int T, int C, int K, int left_pad, void* stream) {
   if (!x || !w || !y || B < 0 || T < 0 || C < 1 || K < 1) return KANTTS_E_BADARG;
   if (B == 0 || T == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(fsmn_dwconv_fwd_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)),
-                     0, (hipStream_t)stream, x, w, res, lens, y, B, T, C, K, left_pad);
+  const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+  if (K == FS_K) {
+    hipLaunchKernelGGL(fsmn_fir41_kernel<false>, dim3(kantts_cdiv(T, FS_TT), B), dim3(threads), 0, (hipStream_t)stream, x, w,
+                       res, lens, y, B, T, C, left_pad);
+  } else {
+    hipLaunchKernelGGL(fsmn_dwconv_fwd_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(threads), 0, (hipStream_t)stream, x, w,
+                       res, lens, y, B, T, C, K, left_pad);
+  }
   KANTTS_CHECK_LAUNCH();
 }
 
 extern "C" int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const float* w, const int64_t* lens, float* dx,
-                                      float* dw_accum, int B, int T, int C, int K, int left_pad, void* stream) {
+                                      float* dw_accum, float* workspace, long long ws_floats, int B, int T, int C, int K,
+                                      int left_pad, void* stream) {
   if (!dy || !x || !w || !dx || !dw_accum || B < 0 || T < 0 || C < 1 || K < 1) return KANTTS_E_BADARG;
   if (B == 0 || T == 0) return KANTTS_OK;
   int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
-  hipLaunchKernelGGL(fsmn_dwconv_bwd_dx_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(threads), 0, (hipStream_t)stream,
-                     dy, w, lens, dx, B, T, C, K, left_pad);
-  hipLaunchKernelGGL(fsmn_dwconv_bwd_dw_kernel, dim3(kantts_cdiv(T, DW_WT), B), dim3(threads), 0, (hipStream_t)stream,
-                     dy, x, lens, dw_accum, B, T, C, K, left_pad);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == FS_K) {
+    const int nchunk = kantts_cdiv(T, FS_CH);
+    if (!workspace || ws_floats < (long long)B * nchunk * C * K) return KANTTS_E_WORKSPACE;
+    hipLaunchKernelGGL(fsmn_fir41_kernel<true>, dim3(kantts_cdiv(T, FS_TT), B), dim3(threads), 0, st, dy, w,
+                       (const float*)nullptr, lens, dx, B, T, C, left_pad);
+    hipLaunchKernelGGL(fsmn_dw41_partial_kernel, dim3(nchunk, B), dim3(threads), 0, st, dy, x, lens, workspace, B, T, C,
+                       left_pad);
+    hipLaunchKernelGGL(fsmn_dw_reduce_kernel, dim3(kantts_cdiv(C * K, 256)), dim3(256), 0, st, workspace, dw_accum,
+                       B * nchunk, C * K);
+  } else {
+    hipLaunchKernelGGL(fsmn_dwconv_bwd_dx_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(threads), 0, st, dy, w, lens, dx, B,
+                       T, C, K, left_pad);
+    hipLaunchKernelGGL(fsmn_dwconv_bwd_dw_kernel, dim3(kantts_cdiv(T, DW_WT), B), dim3(threads), 0, st, dy, x, lens,
+                       dw_accum, B, T, C, K, left_pad);
+  }
   KANTTS_CHECK_LAUNCH();
 }

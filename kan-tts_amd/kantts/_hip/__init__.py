@@ -32,6 +32,7 @@ class GemmSeg(Structure):
         ("b_inner", c_int32), ("b_Tq", c_int32), ("b_Tsrc", c_int32), ("b_mul", c_int32), ("b_div", c_int32),
         ("b_up", c_int32),
         ("a_slope", c_float), ("a_act", c_int32), ("b_slope", c_float), ("b_act", c_int32),
+        ("a_gate_slope", c_float), ("a_mode", c_int32), ("b_mode", c_int32),
     ]
 
 
@@ -46,6 +47,7 @@ class GemmArgs(Structure):
         ("precision", c_int32), ("drop_p", c_float), ("drop_seed", c_uint64), ("seed_dev", c_void_p),
         ("groups", c_int32), ("a_gs", c_int64), ("b_gs", c_int64), ("c_gs", c_int64), ("bias_gs", c_int64),
         ("r_gs", c_int64), ("out_slope", c_float), ("out_act", c_int32), ("gate", c_void_p), ("gate_slope", c_float),
+        ("z_taps", c_int32), ("c_tap", c_int64),
     ]
 
 
@@ -79,11 +81,17 @@ def lib():
         L.kantts_lr_gather_fwd.argtypes = [p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_lr_gather_bwd.argtypes = [p, p, p, p, i, i, i, i, i, i, i, p]
         L.kantts_fsmn_dwconv_fwd.argtypes = [p, p, p, p, p, i, i, i, i, i, p]
-        L.kantts_fsmn_dwconv_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, p]
+        L.kantts_fsmn_dwconv_bwd.argtypes = [p, p, p, p, p, p, p, ll, i, i, i, i, i, p]
+        L.kantts_fsmn_dwconv_bwd_ws.argtypes = [i, i, i, i]
+        L.kantts_fsmn_dwconv_bwd_ws.restype = ll
         L.kantts_masked_l1.argtypes = [p, p, p, p, p, i, i, i, p]
         L.kantts_sumsq.argtypes = [p, p, ll, p]
         L.kantts_adam_step.argtypes = [p, p, p, p, ll, f, f, f, f, f, f, f, p, f, p, p]
         L.kantts_melspec_fwd.argtypes = [p, i, i, i, i, i, i, p, p, f, p, p, p, p, i, f, p, p, p]
+        L.kantts_weight_norm_fwd.argtypes = [p, p, p, i, i, p]
+        L.kantts_weight_norm_bwd.argtypes = [p, p, p, p, p, i, i, p]
+        L.kantts_sinadd_fwd.argtypes = [p, p, ll, p]
+        L.kantts_sinadd_bwd.argtypes = [p, p, p, ll, p]
         _lib = L
     return _lib
 
@@ -92,8 +100,9 @@ EXPORTED_SYMBOLS = [
     "kantts_abi_version", "kantts_target_arch", "kantts_gemm_seg_launch", "kantts_layernorm_fwd",
     "kantts_layernorm_bwd", "kantts_attn_fwd", "kantts_attn_bwd", "kantts_lstm_fwd", "kantts_lstm_bwd",
     "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
-    "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_masked_l1",
-    "kantts_sumsq", "kantts_adam_step", "kantts_melspec_fwd",
+    "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_fsmn_dwconv_bwd_ws", "kantts_masked_l1",
+    "kantts_sumsq", "kantts_adam_step", "kantts_melspec_fwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd",
+    "kantts_sinadd_fwd", "kantts_sinadd_bwd",
 ]
 
 
@@ -134,7 +143,7 @@ def get_precision() -> str:
 
 def make_seg(a, a_is, a_ks, b, b_js, b_ks, klen, ntaps=1, b_tap=0, a_tok_axis=0, a_shift0=0, a_shift_step=0,
              b_tok_axis=0, b_shift0=0, b_shift_step=0, a_gate=None, a_drop_p=0.0, a_drop_seed=0, a_map=None,
-             b_map=None, a_leaky=None, b_leaky=None):
+             b_map=None, a_leaky=None, b_leaky=None, a_gate_slope=0.0):
     """a / b / a_gate are (tensor, element_offset) pairs or tensors.  a_map / b_map: dict(inner, Tq, Tsrc,
     mul, div, up) extended token maps; a_leaky / b_leaky: LeakyReLU slope applied on load."""
 
@@ -162,16 +171,34 @@ def make_seg(a, a_is, a_ks, b, b_js, b_ks, klen, ntaps=1, b_tap=0, a_tok_axis=0,
         s.a_act, s.a_slope = 1, float(a_leaky)
     if b_leaky is not None:
         s.b_act, s.b_slope = 1, float(b_leaky)
+    s.a_gate_slope = float(a_gate_slope)
     return s
+
+
+def _staging_mode(base, row_stride, k_stride, klen, rows, tok_axis, group_stride, gate=None):
+    """Pick the operand staging layout of csrc/gemm.hip (0/1 scalar, 2 float4 along k, 3 float4 along rows)."""
+    aligned = (base % 16 == 0) and (gate is None or gate % 16 == 0) and (group_stride % 4 == 0)
+    if k_stride == 1 and aligned and klen % 4 == 0 and row_stride % 4 == 0 and tok_axis != 2:
+        return 2
+    if row_stride == 1 and aligned and rows % 4 == 0 and k_stride % 4 == 0 and tok_axis != 1:
+        return 3
+    if row_stride == 1 and k_stride != 1:
+        return 1
+    return 0
 
 
 def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_js=0, rowmask=None, kmask=None,
          a_rowsum=None, alpha=1.0, relu=False, accumulate=False, splitk=1, T=0, drop_p=0.0, drop_seed=0,
          precision=None, c_off=0, groups=1, a_gs=0, b_gs=0, c_gs=0, bias_gs=0, r_gs=0, out_leaky=None, gate=None,
-         gate_slope=0.0, res_off=0):
+         gate_slope=0.0, res_off=0, z_taps=0, c_tap=0):
     g = GemmArgs()
     assert 1 <= len(segs) <= GEMM_MAX_SEG
     for k, s in enumerate(segs):
+        s.a_mode = _staging_mode(s.a or 0, s.a_is, s.a_ks, s.klen, M, s.a_tok_axis, a_gs, s.a_gate)
+        s.b_mode = _staging_mode((s.b or 0) + 0, s.b_js, s.b_ks, s.klen, N, 1 if False else (2 if s.b_tok_axis == 2 else 0),
+                                 b_gs)
+        if s.b_mode == 2 and (s.b_tap % 4 != 0 and s.ntaps > 1):
+            s.b_mode = 0
         g.seg[k] = s
     g.nseg, g.M, g.N, g.T = len(segs), int(M), int(N), int(T)
     g.c = ptr(c, torch.float32) + 4 * int(c_off)
@@ -186,6 +213,7 @@ def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_j
     if gate is not None:
         g.gate = ptr(gate, torch.float32) + 4 * int(c_off)
         g.gate_slope = float(gate_slope)
+    g.z_taps, g.c_tap = int(z_taps), int(c_tap)
     g.rowmask = ptr(rowmask)
     g.kmask = ptr(kmask)
     g.a_rowsum = ptr(a_rowsum, torch.float32)

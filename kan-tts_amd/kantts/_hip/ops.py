@@ -535,8 +535,10 @@ class _FsmnMemory(torch.autograd.Function):
         dy = _c(dy)
         dx = torch.empty_like(x)
         dw = torch.zeros_like(w)
-        check(lib().kantts_fsmn_dwconv_bwd(ptr(dy, torch.float32), ptr(x), ptr(w), ptr(lens), ptr(dx), ptr(dw), B, T, C,
-                                           K, lp, stream()), "fsmn_dwconv_bwd")
+        ws_n = int(lib().kantts_fsmn_dwconv_bwd_ws(B, T, C, K))
+        ws = torch.empty(max(ws_n, 1), device=dy.device, dtype=torch.float32)
+        check(lib().kantts_fsmn_dwconv_bwd(ptr(dy, torch.float32), ptr(x), ptr(w), ptr(lens), ptr(dx), ptr(dw), ptr(ws),
+                                           ws_n, B, T, C, K, lp, stream()), "fsmn_dwconv_bwd")
         return dx, dw, (dy if has_res else None), None, None
 
 

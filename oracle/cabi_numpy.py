@@ -97,7 +97,8 @@ class EmulatedLib:
         ii = np.arange(M, dtype=np.int64)[:, None]
         jj = np.arange(N, dtype=np.int64)[:, None]
         jrow = np.arange(N, dtype=np.int64)[None, :]
-        for grp in range(max(1, g.groups)):
+        ztaps = g.z_taps if g.z_taps > 0 else 0
+        for grp, ztap in [(gg, zt) for gg in range(max(1, g.groups)) for zt in (range(ztaps) if ztaps else [-1])]:
             acc = np.zeros((M, N), dtype=np.float32)
             rowsum = np.zeros(M, dtype=np.float32)
             for si in range(g.nseg):
@@ -108,6 +109,8 @@ class EmulatedLib:
                 kk = np.arange(K, dtype=np.int64)[None, :]
                 kmask = (_arr(g.kmask, K, np.uint8) != 0) if g.kmask else None
                 for tap in range(s.ntaps):
+                    if ztap >= 0 and tap != ztap:
+                        continue
                     a_shift = s.a_shift0 + tap * s.a_shift_step if s.a_tok_axis else 0
                     b_shift = s.b_shift0 + tap * s.b_shift_step if s.b_tok_axis else 0
                     ai, ak = ii + 0 * kk, kk + 0 * ii
@@ -127,7 +130,7 @@ class EmulatedLib:
                         A = np.where(A > 0, A, A * np.float32(s.a_slope))
                     if s.a_gate:
                         gate = _gather(s.a_gate, offs, valid)
-                        A = np.where(gate > 0, A, np.float32(0))
+                        A = np.where(gate > 0, A, A * np.float32(s.a_gate_slope))
                     if s.a_drop_p > 0:
                         A = A * dropout_scale(s.a_drop_p, s.a_drop_seed + soff, offs)
                     bk = kk + 0 * jj
@@ -157,8 +160,11 @@ class EmulatedLib:
             if g.res:
                 v = v + _gather(g.res, ii * g.r_is + jrow * g.r_js + grp * g.r_gs, None)
             coffs = ii * g.c_is + jrow * g.c_js + grp * g.c_gs
+            gate_offs = coffs
+            if ztap > 0:
+                coffs = coffs + ztap * g.c_tap
             if g.gate:
-                gv = _gather(g.gate, coffs, None)
+                gv = _gather(g.gate, gate_offs, None)
                 v = v * np.where(gv > 0, np.float32(1), np.float32(g.gate_slope))
             if g.rowmask:
                 rm = _arr(g.rowmask, M, np.uint8) != 0
@@ -170,7 +176,7 @@ class EmulatedLib:
                 np.add.at(cmem, (coffs - lo).ravel(), v.ravel())
             else:
                 cmem[(coffs - lo).ravel()] = v.ravel()
-            if g.a_rowsum:
+            if g.a_rowsum and ztap <= 0:
                 _arr(int(g.a_rowsum) + 4 * grp * g.bias_gs, M)[:] += rowsum
         return 0
 
@@ -443,7 +449,10 @@ class EmulatedLib:
         _arr(y, B * T * C)[:] = Y.reshape(-1).numpy()
         return 0
 
-    def kantts_fsmn_dwconv_bwd(self, dy, x, w, lens, dx, dw, B, T, C, K, lp, stream):
+    def kantts_fsmn_dwconv_bwd_ws(self, B, T, C, K):
+        return 0
+
+    def kantts_fsmn_dwconv_bwd(self, dy, x, w, lens, dx, dw, ws, ws_n, B, T, C, K, lp, stream):
         X = torch.from_numpy(_arr(x, B * T * C)).view(B, T, C).clone().requires_grad_(True)
         W = torch.from_numpy(_arr(w, C * K)).view(C, 1, K).clone().requires_grad_(True)
         DY = torch.from_numpy(_arr(dy, B * T * C)).view(B, T, C)
@@ -523,4 +532,30 @@ class EmulatedLib:
             db = 20 * torch.log10(torch.clamp(mel, min=1e-5)) - 20.0
             out = torch.clamp(8.0 * ((db + 100.0) / 100.0) - 4.0, -4.0, 4.0).transpose(1, 2).contiguous()
             _arr(out_mel, B * n_mels * frames)[:] = out.reshape(-1).numpy()
+        return 0
+
+    # ------------------------------------------------------------------------------------ HiFi-GAN helpers
+    def kantts_weight_norm_fwd(self, v, g, w, rows, cols, stream):
+        V = _arr(v, rows * cols).reshape(rows, cols)
+        G = _arr(g, rows)
+        _arr(w, rows * cols)[:] = (V * (G / np.sqrt((V * V).sum(1)))[:, None]).ravel()
+        return 0
+
+    def kantts_weight_norm_bwd(self, dw, v, g, dv, dg, rows, cols, stream):
+        DW = _arr(dw, rows * cols).reshape(rows, cols)
+        V = _arr(v, rows * cols).reshape(rows, cols)
+        G = _arr(g, rows)
+        nrm = np.sqrt((V * V).sum(1))
+        dgv = (DW * V).sum(1) / nrm
+        _arr(dg, rows)[:] = dgv
+        _arr(dv, rows * cols)[:] = ((G / nrm)[:, None] * (DW - V * (dgv / nrm)[:, None])).ravel()
+        return 0
+
+    def kantts_sinadd_fwd(self, x, y, n, stream):
+        X = _arr(x, n)
+        _arr(y, n)[:] = np.sin(X) + X
+        return 0
+
+    def kantts_sinadd_bwd(self, dy, x, dx, n, stream):
+        _arr(dx, n)[:] = _arr(dy, n) * (np.cos(_arr(x, n)) + 1.0)
         return 0

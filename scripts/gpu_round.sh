@@ -8,18 +8,19 @@ export TMPDIR=/tmp
 rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
 nproc >> $OUT/gpu.txt; lscpu | grep "Model name" >> $OUT/gpu.txt
 echo "== pytest gpu ops" 
-timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -n 2 --timeout=600 -p no:cacheprovider -rA 2>&1 | tail -150 > $OUT/pytest_ops.log
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_melspec.py -m gpu -q -n 2 --timeout=600 -p no:cacheprovider -rA 2>&1 | tail -150 > $OUT/pytest_ops.log
 tail -40 $OUT/pytest_ops.log
 echo "== pytest gpu sambert"
-timeout 1200 python -m pytest tests/test_gpu_sambert.py -m gpu -q -n 2 --timeout=900 -p no:cacheprovider -rA -s 2>&1 | tail -150 > $OUT/pytest_sambert.log
+timeout 600 python -m pytest tests/test_gpu_sambert.py -m gpu -q -n 2 --timeout=900 -p no:cacheprovider -rA 2>&1 | tail -150 > $OUT/pytest_sambert.log
 tail -40 $OUT/pytest_sambert.log
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log
 echo "== bench"
-timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench_bf16.log 2>&1; tail -2 $OUT/bench_bf16.log
-timeout 600 python bench.py --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline > $OUT/bench_fp32.log 2>&1; tail -1 $OUT/bench_fp32.log
+timeout 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_bf16.log 2>&1; tail -2 $OUT/bench_bf16.log
+timeout 300 python bench.py --steps 20 --warmup 5 --mode eager --no-cpu-baseline > $OUT/bench_bf16_eager.log 2>&1; tail -1 $OUT/bench_bf16_eager.log
+timeout 300 python bench.py --steps 20 --warmup 5 --precision fp32 --no-cpu-baseline > $OUT/bench_fp32.log 2>&1; tail -1 $OUT/bench_fp32.log
 echo "== rocprof"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OLDPWD/$OUT/rocprof.log 2>&1 )
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --mode eager --no-cpu-baseline > $OLDPWD/$OUT/rocprof.log 2>&1 )
 find $OUT/prof -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" > $OUT/kernel_stats_top.csv && cat $OUT/kernel_stats_top.csv | cut -c1-180
 # keep the merged-back payload small

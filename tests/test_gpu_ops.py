@@ -172,6 +172,20 @@ def test_pnca_attention(bw):
     assert_close(go[0], co[0], 2e-5, what="pnca nolens")
 
 
+def test_attention_long_sequence_fallback_kernels():
+    """L = 600 does not fit the 64 KB LDS staging -> direct-from-global kernels."""
+    from kantts._hip import ops
+
+    B, L, H = 1, 600, 8
+    qkv = _rand(B, L, 3 * H * 16, seed=1, grad=True)
+    hkv = _rand(B, L, 2 * H * 16, seed=2, grad=True)
+    lens = torch.tensor([500], dtype=torch.int32)
+    go, gg, co, cg = run_both(lambda a, b, l: ops.pnca_attention(a, b, l, 4, 4, H), qkv, hkv, lens)
+    assert_close(go[0], co[0], 2e-5, what="x ctx")
+    assert_close(go[1], co[1], 2e-5, what="h ctx")
+    assert rel_l2(gg[0], cg[0]) < 1e-4 and rel_l2(gg[1], cg[1]) < 1e-4
+
+
 # ------------------------------------------------------------------------------------------- LSTM
 def test_lstm_uni_bi_and_concat():
     from kantts._hip import ops
