@@ -597,3 +597,204 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=No
                                  ptr(v, torch.float32), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                  float(weight_decay), float(bc1), float(bc2), ptr(gnorm_sq),
                                  float(max_norm if max_norm else 0.0), ptr(dyn), stream()), "adam_step")
+
+
+# ================================================================================================
+# HiFi-GAN: channels-last convolutions on the segmented GEMM
+# ================================================================================================
+class _ConvCL(torch.autograd.Function):
+    """Channels-last Conv1d / (k,1)-Conv2d:  x (B, Tin, inner, Cin) -> y (B, Tout, inner, Cout)
+
+        y[b,q,p,co] = act_out( bias[co] + sum_k sum_ci act_in(x[b, (q*stride + k*dil - pad) // up, p, ci]) w[co,ci,k] ) (+ res)
+
+    ``up`` > 1 reads a nearest-neighbour-upsampled view of x (the x``up`` tensor of the reference's
+    repeat_upsamples is never materialised); ``inner`` folds the period axis of the MPD; ``groups``
+    batches grouped convolutions over gridDim.z.  LeakyReLU on the way in / out is fused in the
+    loader / epilogue.  Reference: kantts/models/hifigan/layers.py:15-91, hifigan.py:82-97,217-267,332-407.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, cfg):
+        x, w = _c(x), _c(w)
+        stride, dil, pad, up, groups = cfg["stride"], cfg["dilation"], cfg["pad"], cfg["up"], cfg["groups"]
+        inner, Tout = cfg["inner"], cfg["Tout"]
+        B, Tin = x.shape[0], x.shape[1]
+        Cin = x.shape[-1]
+        Cout, Cin_g, K = w.shape
+        Cout_g = Cout // groups
+        assert Cin_g * groups == Cin
+        M = B * Tout * inner
+        y = torch.empty((B, Tout, inner, Cout) if x.dim() == 4 else (B, Tout, Cout), device=x.device, dtype=torch.float32)
+        seg = make_seg(x, Cin, 1, w, Cin_g * K, K, Cin_g, ntaps=K, b_tap=1, a_tok_axis=1, a_shift0=-pad,
+                       a_shift_step=dil, a_map=dict(inner=inner, Tq=Tout, Tsrc=Tin, mul=stride, up=up),
+                       a_leaky=cfg["in_leaky"])
+        r = _c(res) if res is not None else None
+        gemm([seg], M, Cout_g, y, Cout, 1, bias=bias, res=r, r_is=Cout, r_js=1, groups=groups, a_gs=Cin_g,
+             b_gs=Cout_g * Cin_g * K, c_gs=Cout_g, bias_gs=Cout_g, r_gs=Cout_g, out_leaky=cfg["out_leaky"])
+        ctx.cfg = cfg
+        ctx.has = (bias is not None, res is not None)
+        ctx.save_for_backward(x, w, y if cfg["out_leaky"] is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg = ctx.cfg
+        x, w, y = ctx.saved_tensors
+        has_bias, has_res = ctx.has
+        stride, dil, pad, up, groups = cfg["stride"], cfg["dilation"], cfg["pad"], cfg["up"], cfg["groups"]
+        inner, Tout = cfg["inner"], cfg["Tout"]
+        dy = _c(dy)
+        B, Tin, Cin = x.shape[0], x.shape[1], x.shape[-1]
+        Cout, Cin_g, K = w.shape
+        Cout_g = Cout // groups
+        gate, gslope = (y, cfg["out_leaky"]) if cfg["out_leaky"] is not None else (None, 0.0)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            Mx = B * Tin * inner
+            first = True
+            for r in range(up):
+                # x-domain token t receives dy[(t*up + r + pad - k*dil) / stride] (exact division only)
+                seg = make_seg(dy, Cout, 1, w, K, Cin_g * K, Cout_g, ntaps=K, b_tap=1, a_tok_axis=1,
+                               a_shift0=r + pad, a_shift_step=-dil,
+                               a_map=dict(inner=inner, Tq=Tin, Tsrc=Tout, mul=up, div=stride), a_gate=gate,
+                               a_gate_slope=gslope)
+                gemm([seg], Mx, Cin_g, dx, Cin, 1, groups=groups, a_gs=Cout_g, b_gs=Cout_g * Cin_g * K, c_gs=Cin_g,
+                     accumulate=not first, gate=x if cfg["in_leaky"] is not None else None,
+                     gate_slope=cfg["in_leaky"] or 0.0)
+                first = False
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            if has_bias:
+                db = torch.zeros(Cout, device=dy.device, dtype=torch.float32)
+            Mtok = B * Tout * inner
+            seg = make_seg(dy, 1, Cout, x, 1, Cin, Mtok, ntaps=K, a_gate=gate, a_gate_slope=gslope, b_tok_axis=2,
+                           b_shift0=-pad, b_shift_step=dil,
+                           b_map=dict(inner=inner, Tq=Tout, Tsrc=Tin, mul=stride, up=up), b_leaky=cfg["in_leaky"])
+            gemm([seg], Cout_g, Cin_g, dw, Cin_g * K, K, groups=groups, a_gs=Cout_g, b_gs=Cin_g,
+                 c_gs=Cout_g * Cin_g * K, bias_gs=Cout_g, accumulate=True,
+                 splitk=_splitk_for(Cout_g * groups * K, Cin_g, Mtok), z_taps=K, c_tap=1, a_rowsum=db)
+        elif has_bias and ctx.needs_input_grad[2]:
+            raise RuntimeError("bias gradient without weight gradient is not supported")
+        return dx, dw, db, (dy if has_res else None), None
+
+
+def conv_cl(x, w, bias=None, *, stride=1, dilation=1, pad=0, Tout=None, up=1, groups=1, inner=1, in_leaky=None,
+            out_leaky=None, res=None):
+    """pad = left padding in (upsampled) input samples; Tout defaults to the 'same'/causal length."""
+    K = w.shape[-1]
+    Tin = x.shape[1]
+    if Tout is None:
+        Tout = Tin * up if stride == 1 else (Tin + 2 * pad - dilation * (K - 1) - 1) // stride + 1
+    cfg = dict(stride=int(stride), dilation=int(dilation), pad=int(pad), Tout=int(Tout), up=int(up), groups=int(groups),
+               inner=int(inner), in_leaky=in_leaky, out_leaky=out_leaky)
+    return _ConvCL.apply(x, w, bias, res, cfg)
+
+
+class _ConvTransposeCL(torch.autograd.Function):
+    """Causal polyphase ConvTranspose1d (kernel K = taps*stride, output trimmed to Tin*stride):
+        y[b, q*s + r, co] = bias[co] + sum_j sum_ci act_in(x[b, q - j, ci]) w[ci, co, r + j*s]   (+ res)
+    One GEMM per output phase r (the s sub-filters of K/s taps); nothing is zero-stuffed.
+    Reference: CausalConvTranspose1d, kantts/models/hifigan/layers.py:125-165, hifigan.py:67-80,160."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, s, in_leaky):
+        x, w = _c(x), _c(w)
+        B, Tin, Cin = x.shape
+        _, Cout, K = w.shape
+        assert K % s == 0
+        taps = K // s
+        y = torch.empty((B, Tin * s, Cout), device=x.device, dtype=torch.float32)
+        r_t = _c(res) if res is not None else None
+        for r in range(s):
+            seg = make_seg(x, Cin, 1, (w, r), K, Cout * K, Cin, ntaps=taps, b_tap=s, a_tok_axis=1, a_shift0=0,
+                           a_shift_step=-1, a_map=dict(Tq=Tin, Tsrc=Tin), a_leaky=in_leaky)
+            gemm([seg], B * Tin, Cout, y, s * Cout, 1, c_off=r * Cout, bias=bias, res=r_t, r_is=s * Cout, r_js=1,
+                 res_off=r * Cout)
+        ctx.cfg = (s, in_leaky, bias is not None, res is not None)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, in_leaky, has_bias, has_res = ctx.cfg
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        B, Tin, Cin = x.shape
+        _, Cout, K = w.shape
+        taps = K // s
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            for r in range(s):
+                seg = make_seg((dy, r * Cout), s * Cout, 1, (w, r), Cout * K, K, Cout, ntaps=taps, b_tap=s, a_tok_axis=1,
+                               a_shift0=0, a_shift_step=1, a_map=dict(Tq=Tin, Tsrc=Tin))
+                gemm([seg], B * Tin, Cin, dx, Cin, 1, accumulate=(r > 0), gate=x if in_leaky is not None else None,
+                     gate_slope=in_leaky or 0.0)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            M = B * Tin
+            sk = _splitk_for(Cin, Cout, M)
+            for r in range(s):
+                for j in range(taps):
+                    seg = make_seg(x, 1, Cin, (dy, r * Cout), 1, s * Cout, M, a_tok_axis=2, a_shift0=-j,
+                                   a_map=dict(Tq=Tin, Tsrc=Tin), a_leaky=in_leaky)
+                    gemm([seg], Cin, Cout, dw, Cout * K, K, c_off=r + j * s, accumulate=True, splitk=sk)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 1))
+        return dx, dw, db, (dy if has_res else None), None, None
+
+
+def conv_transpose_cl(x, w, bias, stride, in_leaky=None, res=None):
+    return _ConvTransposeCL.apply(x, w, bias, res, int(stride), in_leaky)
+
+
+class _WeightNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, g):
+        v, g = _c(v), _c(g)
+        rows = v.shape[0]
+        cols = v.numel() // rows
+        w = torch.empty_like(v)
+        check(lib().kantts_weight_norm_fwd(ptr(v, torch.float32), ptr(g, torch.float32), ptr(w), rows, cols, stream()),
+              "weight_norm_fwd")
+        ctx.save_for_backward(v, g)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g = ctx.saved_tensors
+        dw = _c(dw)
+        rows = v.shape[0]
+        cols = v.numel() // rows
+        dv, dg = torch.empty_like(v), torch.empty_like(g)
+        check(lib().kantts_weight_norm_bwd(ptr(dw, torch.float32), ptr(v), ptr(g), ptr(dv), ptr(dg), rows, cols,
+                                           stream()), "weight_norm_bwd")
+        return dv, dg
+
+
+def weight_norm(v, g):
+    """w = g * v / ||v|| over all dims but 0 (torch.nn.utils.weight_norm, dim=0)."""
+    return _WeightNorm.apply(v, g)
+
+
+class _SinAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib().kantts_sinadd_fwd(ptr(x, torch.float32), ptr(y), x.numel(), stream()), "sinadd_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        check(lib().kantts_sinadd_bwd(ptr(dy, torch.float32), ptr(x), ptr(dx), x.numel(), stream()), "sinadd_bwd")
+        return dx
+
+
+def sin_add(x):
+    return _SinAdd.apply(x)

@@ -1,0 +1,292 @@
+"""HiFi-GAN generator and MPD / MSD discriminators on HIP kernels
+(reference kantts/models/hifigan/hifigan.py:22-478).  Same constructors, ``forward`` contracts
+(``(B, C, T)`` in, ``(B, out_ch, T*prod(scales))`` out; discriminators return ``(outputs, feature maps)``)
+and ``state_dict`` keys.  Internally everything is channels-last; feature maps are handed back as
+zero-copy ``(B, C, T[, p])`` views of the channels-last buffers.
+"""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils import weight_norm
+
+from kantts._hip import ops
+from kantts.models.hifigan.layers import (CausalConv1d, CausalConvTranspose1d, Conv1d, ConvTranspose1d,
+                                          ResidualBlock, effective_weight)
+
+DB3_DEC_LO = [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313,
+              0.8068915093133388, 0.3326705529509569]
+DB3_DEC_HI = [((-1.0) ** (k + 1)) * DB3_DEC_LO[5 - k] for k in range(6)]
+
+
+class Generator(torch.nn.Module):
+    """Dual-path upsampling generator (reference :22-197): per stage
+    x = sin(x)+x;  x = ConvT(LReLU(x)) + Conv_k7(LReLU(nearest_x_s(x)));  x = mean_j ResBlock_j(x).
+    The x_s repeated tensor is never materialised (the k=7 conv reads x through a //s token map) and the
+    transposed conv adds the repeat path in its epilogue, so each stage writes its output once."""
+
+    def __init__(self, in_channels=80, out_channels=1, channels=512, kernel_size=7, upsample_scales=(8, 8, 2, 2),
+                 upsample_kernal_sizes=(16, 16, 4, 4), resblock_kernel_sizes=(3, 7, 11),
+                 resblock_dilations=[(1, 3, 5), (1, 3, 5), (1, 3, 5)], repeat_upsample=True, bias=True, causal=True,
+                 nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
+                 use_weight_norm=True, nsf_params=None):
+        super(Generator, self).__init__()
+        assert kernel_size % 2 == 1, "Kernal size must be odd number."
+        assert len(upsample_scales) == len(upsample_kernal_sizes)
+        assert len(resblock_dilations) == len(resblock_kernel_sizes)
+        if nsf_params is not None:
+            raise NotImplementedError("NSF generators are SURVEY row 8f-4 (next)")
+        if nonlinear_activation != "LeakyReLU":
+            raise NotImplementedError("only LeakyReLU (every shipped yaml)")
+        self.upsample_scales = upsample_scales
+        self.repeat_upsample = repeat_upsample
+        self.num_upsamples = len(upsample_kernal_sizes)
+        self.num_kernels = len(resblock_kernel_sizes)
+        self.out_channels = out_channels
+        self.nsf_enable = False
+        self.causal = causal
+        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.transpose_upsamples = torch.nn.ModuleList()
+        self.repeat_upsamples = torch.nn.ModuleList()
+        self.conv_blocks = torch.nn.ModuleList()
+        conv_cls = CausalConv1d if causal else Conv1d
+        conv_transposed_cls = CausalConvTranspose1d if causal else ConvTranspose1d
+        self.conv_pre = conv_cls(in_channels, channels, kernel_size, 1, padding=(kernel_size - 1) // 2)
+        for i in range(len(upsample_kernal_sizes)):
+            self.transpose_upsamples.append(torch.nn.Sequential(
+                getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params),
+                conv_transposed_cls(channels // (2 ** i), channels // (2 ** (i + 1)), upsample_kernal_sizes[i],
+                                    upsample_scales[i], padding=(upsample_kernal_sizes[i] - upsample_scales[i]) // 2)))
+            if repeat_upsample:
+                self.repeat_upsamples.append(nn.Sequential(
+                    nn.Upsample(mode="nearest", scale_factor=upsample_scales[i]),
+                    getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params),
+                    conv_cls(channels // (2 ** i), channels // (2 ** (i + 1)), kernel_size=kernel_size, stride=1,
+                             padding=(kernel_size - 1) // 2)))
+            for j in range(len(resblock_kernel_sizes)):
+                self.conv_blocks.append(ResidualBlock(
+                    channels=channels // (2 ** (i + 1)), kernel_size=resblock_kernel_sizes[j],
+                    dilation=resblock_dilations[j], nonlinear_activation=nonlinear_activation,
+                    nonlinear_activation_params=nonlinear_activation_params, causal=causal))
+        self.conv_post = conv_cls(channels // (2 ** (i + 1)), out_channels, kernel_size, 1,
+                                  padding=(kernel_size - 1) // 2)
+
+    def forward(self, x):
+        h = self.conv_pre.forward_cl(x.transpose(1, 2).contiguous())
+        for i in range(self.num_upsamples):
+            s = self.upsample_scales[i]
+            h = ops.sin_add(h)
+            if self.repeat_upsample:
+                conv = self.repeat_upsamples[i][2]
+                c = conv.conv1d
+                rep = ops.conv_cl(h, effective_weight(c), c.bias, pad=conv.pad, up=s, Tout=h.shape[1] * s,
+                                  in_leaky=self.slope)
+            else:
+                rep = None
+            h = self.transpose_upsamples[i][1].forward_cl(h, in_leaky=self.slope, res=rep)
+            xs = None
+            for j in range(self.num_kernels):
+                y = self.conv_blocks[i * self.num_kernels + j].forward_cl(h)
+                xs = y if xs is None else xs + y
+            h = xs / self.num_kernels
+        # F.leaky_relu default slope 0.01 (reference :178), fused into conv_post's loader
+        h = self.conv_post.forward_cl(h, in_leaky=0.01)
+        return torch.tanh(h).transpose(1, 2)
+
+    def remove_weight_norm(self):
+        print("Removing weight norm...")
+        for layer in self.transpose_upsamples:
+            layer[-1].remove_weight_norm()
+        for layer in self.repeat_upsamples:
+            layer[-1].remove_weight_norm()
+        for layer in self.conv_blocks:
+            layer.remove_weight_norm()
+        self.conv_pre.remove_weight_norm()
+        self.conv_post.remove_weight_norm()
+
+
+class PeriodDiscriminator(torch.nn.Module):
+    """(k,1)-Conv2d stack over the period-folded waveform (reference :200-267).  In channels-last the
+    fold is a pure view: (B, T) -> (B, T/p, p, 1); each conv strides along T/p with p independent columns."""
+
+    def __init__(self, in_channels=1, out_channels=1, period=3, kernel_sizes=[5, 3], channels=32,
+                 downsample_scales=[3, 3, 3, 3, 1], max_downsample_channels=1024, bias=True,
+                 nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
+                 use_spectral_norm=False):
+        super(PeriodDiscriminator, self).__init__()
+        if use_spectral_norm:
+            raise NotImplementedError("spectral_norm discriminators (follow_official_norm) are not wired yet")
+        self.period = period
+        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.convs = nn.ModuleList()
+        in_chs, out_chs = in_channels, channels
+        for downsample_scale in downsample_scales:
+            self.convs.append(torch.nn.Sequential(
+                weight_norm(nn.Conv2d(in_chs, out_chs, (kernel_sizes[0], 1), (downsample_scale, 1),
+                                      padding=((kernel_sizes[0] - 1) // 2, 0))),
+                getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)))
+            in_chs = out_chs
+            out_chs = min(out_chs * 4, max_downsample_channels)
+        self.conv_post = nn.Conv2d(out_chs, out_channels, (kernel_sizes[1] - 1, 1), 1,
+                                   padding=((kernel_sizes[1] - 1) // 2, 0))
+
+    def forward(self, x):
+        b, c, t = x.shape
+        p = self.period
+        if t % p != 0:
+            x = F.pad(x, (0, p - (t % p)), "reflect")
+            t = x.shape[-1]
+        h = x.reshape(b, t // p, p, c) if c == 1 else x.transpose(1, 2).reshape(b, t // p, p, c)
+        fmap = []
+        for layer in self.convs:
+            conv = layer[0]
+            w = effective_weight(conv).squeeze(-1)
+            h = ops.conv_cl(h, w, conv.bias, stride=conv.stride[0], pad=conv.padding[0], inner=p,
+                            out_leaky=self.slope)
+            fmap.append(h.permute(0, 3, 1, 2))
+        cp = self.conv_post
+        h = ops.conv_cl(h, cp.weight.squeeze(-1), cp.bias, stride=1, pad=cp.padding[0], inner=p,
+                        Tout=h.shape[1] + 2 * cp.padding[0] - cp.kernel_size[0] + 1)
+        out = h.permute(0, 3, 1, 2)
+        fmap.append(out)
+        return torch.flatten(out, 1, -1), fmap
+
+
+class MultiPeriodDiscriminator(torch.nn.Module):
+    def __init__(self, periods=[2, 3, 5, 7, 11], discriminator_params={
+            "in_channels": 1, "out_channels": 1, "kernel_sizes": [5, 3], "channels": 32,
+            "downsample_scales": [3, 3, 3, 3, 1], "max_downsample_channels": 1024, "bias": True,
+            "nonlinear_activation": "LeakyReLU", "nonlinear_activation_params": {"negative_slope": 0.1},
+            "use_spectral_norm": False}):
+        super(MultiPeriodDiscriminator, self).__init__()
+        self.discriminators = nn.ModuleList()
+        for period in periods:
+            params = copy.deepcopy(discriminator_params)
+            params["period"] = period
+            self.discriminators += [PeriodDiscriminator(**params)]
+
+    def forward(self, y):
+        y_d_rs, fmap_rs = [], []
+        for d in self.discriminators:
+            y_d_r, fmap_r = d(y)
+            y_d_rs.append(y_d_r)
+            fmap_rs.append(fmap_r)
+        return y_d_rs, fmap_rs
+
+
+class ScaleDiscriminator(torch.nn.Module):
+    """Grouped strided Conv1d stack (reference :305-407); groups are batched over gridDim.z."""
+
+    def __init__(self, in_channels=1, out_channels=1, kernel_sizes=[15, 41, 5, 3], channels=128,
+                 max_downsample_channels=1024, max_groups=16, bias=True, downsample_scales=[2, 2, 4, 4, 1],
+                 nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
+                 use_spectral_norm=False):
+        super(ScaleDiscriminator, self).__init__()
+        if use_spectral_norm:
+            raise NotImplementedError("spectral_norm discriminators (follow_official_norm) are not wired yet")
+        assert len(kernel_sizes) == 4
+        for ks in kernel_sizes:
+            assert ks % 2 == 1
+        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        act = lambda: getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)  # noqa: E731
+        self.convs = nn.ModuleList()
+        self.convs.append(torch.nn.Sequential(
+            weight_norm(nn.Conv1d(in_channels, channels, kernel_sizes[0], bias=bias, padding=(kernel_sizes[0] - 1) // 2)),
+            act()))
+        in_chs, out_chs, groups = channels, channels, 4
+        for downsample_scale in downsample_scales:
+            self.convs.append(torch.nn.Sequential(
+                weight_norm(nn.Conv1d(in_chs, out_chs, kernel_size=kernel_sizes[1], stride=downsample_scale,
+                                      padding=(kernel_sizes[1] - 1) // 2, groups=groups, bias=bias)), act()))
+            in_chs = out_chs
+            out_chs = min(in_chs * 2, max_downsample_channels)
+            groups = min(groups * 4, max_groups)
+        out_chs = min(in_chs * 2, max_downsample_channels)
+        self.convs.append(torch.nn.Sequential(
+            weight_norm(nn.Conv1d(in_chs, out_chs, kernel_size=kernel_sizes[2], stride=1,
+                                  padding=(kernel_sizes[2] - 1) // 2, bias=bias)), act()))
+        self.conv_post = weight_norm(nn.Conv1d(out_chs, out_channels, kernel_size=kernel_sizes[3], stride=1,
+                                               padding=(kernel_sizes[3] - 1) // 2, bias=bias))
+
+    def forward_cl(self, h):
+        fmap = []
+        for layer in self.convs:
+            c = layer[0]
+            h = ops.conv_cl(h, effective_weight(c), c.bias, stride=c.stride[0], pad=c.padding[0], groups=c.groups,
+                            out_leaky=self.slope)
+            fmap.append(h.transpose(1, 2))
+        c = self.conv_post
+        h = ops.conv_cl(h, effective_weight(c), c.bias, stride=1, pad=c.padding[0])
+        out = h.transpose(1, 2)
+        fmap.append(out)
+        return torch.flatten(out, 1, -1), fmap
+
+    def forward(self, x):
+        return self.forward_cl(x.transpose(1, 2).contiguous())
+
+
+class DWT1DForward(nn.Module):
+    """Single-level db3 analysis, zero padding (pytorch_wavelets.DWT1DForward(wave="db3", J=1) in the reference,
+    hifigan.py:445-448 -- an un-vendored dependency, restated: PARITY UNPINNED).  One stride-2
+    two-channel FIR launch; output (B, out, 2) channels-last == cat([yl, yh], dim=1) of the reference."""
+
+    def __init__(self, J=1, wave="db3", mode="zero"):
+        super().__init__()
+        assert J == 1 and wave == "db3" and mode == "zero"
+        self.register_buffer("h0", torch.tensor(DB3_DEC_LO[::-1]).view(1, 1, 6))
+        self.register_buffer("h1", torch.tensor(DB3_DEC_HI[::-1]).view(1, 1, 6))
+
+    def forward_cl(self, x):
+        N = x.shape[1]
+        out = (N + 5) // 2
+        p = 2 * (out - 1) - N + 6
+        w = torch.cat([self.h0, self.h1], dim=0)  # (2, 1, 6) correlation filters
+        return ops.conv_cl(x, w, None, stride=2, pad=p // 2, Tout=out)
+
+    def forward(self, x):
+        y = self.forward_cl(x.transpose(1, 2).contiguous())
+        return y[:, :, 0:1].transpose(1, 2), [y[:, :, 1:2].transpose(1, 2)]
+
+
+class MultiScaleDiscriminator(torch.nn.Module):
+    def __init__(self, scales=3, downsample_pooling="DWT", downsample_pooling_params={
+            "kernel_size": 4, "stride": 2, "padding": 2}, discriminator_params={
+            "in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 3], "channels": 128,
+            "max_downsample_channels": 1024, "max_groups": 16, "bias": True, "downsample_scales": [2, 2, 4, 4, 1],
+            "nonlinear_activation": "LeakyReLU", "nonlinear_activation_params": {"negative_slope": 0.1}},
+            follow_official_norm=False):
+        super(MultiScaleDiscriminator, self).__init__()
+        self.discriminators = torch.nn.ModuleList()
+        for i in range(scales):
+            params = copy.deepcopy(discriminator_params)
+            if follow_official_norm:
+                params["use_spectral_norm"] = True if i == 0 else False
+            self.discriminators += [ScaleDiscriminator(**params)]
+        if downsample_pooling != "DWT":
+            raise NotImplementedError("AvgPool1d pooling is not used by any shipped yaml")
+        self.meanpools = nn.ModuleList([DWT1DForward(wave="db3", J=1), DWT1DForward(wave="db3", J=1)])
+        self.aux_convs = nn.ModuleList([weight_norm(nn.Conv1d(2, 1, 15, 1, padding=7)),
+                                        weight_norm(nn.Conv1d(2, 1, 15, 1, padding=7))])
+
+    def forward(self, y):
+        y_d_rs, fmap_rs = [], []
+        h = y.transpose(1, 2).contiguous()
+        for i, d in enumerate(self.discriminators):
+            if i != 0:
+                h = self.meanpools[i - 1].forward_cl(h)
+                c = self.aux_convs[i - 1]
+                h = ops.conv_cl(h, effective_weight(c), c.bias, pad=7, out_leaky=0.1)
+            y_d_r, fmap_r = d.forward_cl(h)
+            y_d_rs.append(y_d_r)
+            fmap_rs.append(fmap_r)
+        return y_d_rs, fmap_rs
+
+
+class MultiSpecDiscriminator(torch.nn.Module):
+    """Not enabled in any shipped yaml: out of scope."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("MultiSpecDiscriminator is out of scope (not enabled by any shipped yaml)")

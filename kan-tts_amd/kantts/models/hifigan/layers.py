@@ -1,0 +1,147 @@
+"""HiFi-GAN building blocks on HIP kernels (reference kantts/models/hifigan/layers.py:15-226).
+
+Same classes / constructor arguments / ``state_dict`` keys (``conv1d.weight_g``, ``conv1d.weight_v``,
+``deconv.weight_g`` ...).  The torch modules are parameter holders; the arithmetic is the segmented MFMA
+GEMM with convolution token maps (kantts._hip.ops.conv_cl / conv_transpose_cl) on channels-last
+activations ``(B, T, C)``.  ``forward`` keeps the reference's ``(B, C, T)`` contract (it transposes at the
+boundary); models call ``forward_cl`` and stay channels-last end to end, with the LeakyReLU that
+precedes a convolution fused into its operand loader and residual adds fused into its epilogue.
+"""
+import torch
+import torch.nn as nn
+from torch.nn.utils import remove_weight_norm, weight_norm
+
+from kantts._hip import ops
+from kantts.models.utils import init_weights
+
+
+def get_padding(kernel_size, dilation=1):
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+def effective_weight(m):
+    """g * v / ||v|| through the fused weight-norm kernel, or the plain weight after remove_weight_norm()."""
+    if hasattr(m, "weight_g"):
+        return ops.weight_norm(m.weight_v, m.weight_g)
+    return m.weight
+
+
+class Conv1d(torch.nn.Module):
+    """Weight-normed Conv1d with symmetric padding (reference :15-49)."""
+
+    causal = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 padding_mode="zeros"):
+        super().__init__()
+        self.conv1d = weight_norm(nn.Conv1d(in_channels, out_channels, kernel_size, stride,
+                                            padding=0 if self.causal else padding, dilation=dilation, groups=groups,
+                                            bias=bias, padding_mode=padding_mode))
+        self.conv1d.apply(init_weights)
+        self.pad = (kernel_size - 1) * dilation if self.causal else padding
+
+    def forward_cl(self, x, in_leaky=None, out_leaky=None, res=None):
+        c = self.conv1d
+        k, d, s = c.kernel_size[0], c.dilation[0], c.stride[0]
+        Tin = x.shape[1]
+        Tout = Tin if self.causal else (Tin + 2 * self.pad - d * (k - 1) - 1) // s + 1
+        return ops.conv_cl(x, effective_weight(c), c.bias, stride=s, dilation=d, pad=self.pad, Tout=Tout,
+                           groups=c.groups, in_leaky=in_leaky, out_leaky=out_leaky, res=res)
+
+    def forward(self, x):
+        return self.forward_cl(x.transpose(1, 2).contiguous()).transpose(1, 2)
+
+    def remove_weight_norm(self):
+        remove_weight_norm(self.conv1d)
+
+
+class CausalConv1d(Conv1d):
+    """Left-padded (k-1)*d causal Conv1d (reference :52-91); the pad is an index shift, never a copy."""
+
+    causal = True
+
+
+class ConvTranspose1d(torch.nn.Module):
+    """Non-causal weight-normed ConvTranspose1d (reference :94-121)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=0, output_padding=0):
+        super().__init__()
+        self.deconv = weight_norm(nn.ConvTranspose1d(in_channels, out_channels, kernel_size, stride, padding=padding,
+                                                     output_padding=0))
+        self.deconv.apply(init_weights)
+
+    def forward_cl(self, x, in_leaky=None, res=None):
+        raise NotImplementedError("non-causal transposed convolution (hifigan_noncausal_*.yaml) is not wired yet")
+
+    def forward(self, x):
+        return self.forward_cl(x.transpose(1, 2).contiguous()).transpose(1, 2)
+
+    def remove_weight_norm(self):
+        remove_weight_norm(self.deconv)
+
+
+class CausalConvTranspose1d(torch.nn.Module):
+    """Causal ConvTranspose1d: full transposed conv, last (k - stride) samples dropped (reference :125-165)
+    == polyphase form with k/stride taps per output phase (ops.conv_transpose_cl)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding=0, output_padding=0):
+        super().__init__()
+        self.deconv = weight_norm(nn.ConvTranspose1d(in_channels, out_channels, kernel_size, stride, padding=0,
+                                                     output_padding=0))
+        self.stride = stride
+        self.deconv.apply(init_weights)
+        self.pad = kernel_size - stride
+
+    def forward_cl(self, x, in_leaky=None, res=None):
+        return ops.conv_transpose_cl(x, effective_weight(self.deconv), self.deconv.bias, self.stride, in_leaky=in_leaky,
+                                     res=res)
+
+    def forward(self, x):
+        return self.forward_cl(x.transpose(1, 2).contiguous()).transpose(1, 2)
+
+    def remove_weight_norm(self):
+        remove_weight_norm(self.deconv)
+
+
+class ResidualBlock(torch.nn.Module):
+    """3 x [LeakyReLU -> dilated conv -> LeakyReLU -> conv -> + x] (reference :168-226): 6 GEMM launches,
+    activations and residual adds fused."""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5), nonlinear_activation="LeakyReLU",
+                 nonlinear_activation_params={"negative_slope": 0.1}, causal=False):
+        super().__init__()
+        assert kernel_size % 2 == 1, "Kernal size must be odd number."
+        if nonlinear_activation != "LeakyReLU":
+            raise NotImplementedError("only LeakyReLU (every shipped yaml)")
+        conv_cls = CausalConv1d if causal else Conv1d
+        self.convs1 = nn.ModuleList([
+            conv_cls(channels, channels, kernel_size, 1, dilation=dilation[i],
+                     padding=get_padding(kernel_size, dilation[i])) for i in range(len(dilation))])
+        self.convs2 = nn.ModuleList([
+            conv_cls(channels, channels, kernel_size, 1, dilation=1, padding=get_padding(kernel_size, 1))
+            for i in range(len(dilation))])
+        self.activation = getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)
+        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+
+    def forward_cl(self, x):
+        for c1, c2 in zip(self.convs1, self.convs2):
+            xt = c1.forward_cl(x, in_leaky=self.slope)
+            x = c2.forward_cl(xt, in_leaky=self.slope, res=x)
+        return x
+
+    def forward(self, x):
+        return self.forward_cl(x.transpose(1, 2).contiguous()).transpose(1, 2)
+
+    def remove_weight_norm(self):
+        for layer in self.convs1:
+            layer.remove_weight_norm()
+        for layer in self.convs2:
+            layer.remove_weight_norm()
+
+
+class SourceModule(torch.nn.Module):
+    """NSF sine-excitation source (reference :229-290) -- SURVEY row 8f-4 (next)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("NSF SourceModule is SURVEY row 8f-4 (next)")
