@@ -12,6 +12,8 @@
 // period-folded token maps, gating, masks, fused LeakyReLU) so that one kernel serves forward, dgrad
 // and wgrad of Linear / Conv1d / ConvTranspose1d / (k,1)-Conv2d in channels-last layout.  Lanes walk
 // whichever operand dimension has unit stride so global loads coalesce.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -435,6 +437,8 @@ __global__ void gemm_seg_ref_kernel(const kantts_gemm_args g) {
     *dst = v;
 }
 
+int kantts_gemm_try_fast(const kantts_gemm_args& g, hipStream_t st);  // gemm_fast.hip
+
 extern "C" int kantts_gemm_seg_launch(const kantts_gemm_args* a, void* stream) {
   if (!a || a->nseg < 1 || a->nseg > KANTTS_GEMM_MAX_SEG || a->M < 0 || a->N < 0 || !a->c) return KANTTS_E_BADARG;
   if (a->M == 0 || a->N == 0) return KANTTS_OK;
@@ -454,6 +458,10 @@ extern "C" int kantts_gemm_seg_launch(const kantts_gemm_args* a, void* stream) {
   g.splitk = splitk;
   g.groups = groups;
   hipStream_t st = (hipStream_t)stream;
+  static const bool no_fast = getenv("KANTTS_GEMM_NOFAST") != nullptr;
+  if (!no_fast && g.precision != 2 && kantts_gemm_try_fast(g, st)) {
+    KANTTS_CHECK_LAUNCH();
+  }
   if (g.precision == 2) {
     g.splitk = 1;
     long long total = (long long)g.M * g.N;

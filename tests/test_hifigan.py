@@ -1,0 +1,126 @@
+"""HiFi-GAN generator / MPD / MSD: host logic under the emulated ABI (CPU) and kernel parity on the GPU
+against oracle/hifigan_oracle.py (pinned live against the reference by oracle/check_vs_reference.py).
+Tolerances: fp32 path wav mean-abs <= 1e-4 (asserted at 1e-5), parameter gradients rel-L2 <= 2e-3."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hifigan_oracle as H
+from util import assert_close, emulation, rel_l2, run_both
+
+
+def _models(channels, seed=0):
+    from kantts.models.hifigan.hifigan import Generator, MultiPeriodDiscriminator, MultiScaleDiscriminator
+
+    torch.manual_seed(seed)
+    return Generator(channels=channels), MultiPeriodDiscriminator(), MultiScaleDiscriminator()
+
+
+def _check_models(device, channels, B, frames, T_wav, gtol, wtol):
+    G, D1, D2 = _models(channels)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 80, frames, generator=g)
+    y = torch.randn(B, 1, T_wav, generator=g).clamp(-1, 1)
+    PG = {k: v.detach().clone().requires_grad_(True) for k, v in G.state_dict().items()}
+    G = G.to(device)
+    yo = G(x.to(device))
+    yr = H.generator(PG, x)
+    assert yo.shape == yr.shape == (B, 1, frames * 256)
+    assert float((yo.detach().cpu() - yr.detach()).abs().mean()) <= wtol
+    cot = torch.randn(yr.shape, generator=g)
+    (yo * cot.to(device)).sum().backward()
+    (yr * cot).sum().backward()
+    for n, p in G.named_parameters():
+        assert rel_l2(p.grad.cpu(), PG[n].grad) <= gtol, "G " + n
+    for D, f, nm in ((D1, H.mpd, "mpd"), (D2, H.msd, "msd")):
+        P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in D.state_dict().items()}
+        D = D.to(device)
+        yy = y.clone().to(device).requires_grad_(True)
+        y2 = y.clone().requires_grad_(True)
+        o, fm = D(yy)
+        o_r, f_r = f(P, y2)
+        for a, b in zip(o, o_r):
+            assert_close(a.detach().cpu(), b.detach(), 2e-5, what=nm + " out")
+        for fa, fb in zip(fm, f_r):
+            assert len(fa) == len(fb)
+            for a, b in zip(fa, fb):
+                assert a.shape == b.shape
+                assert_close(a.detach().cpu(), b.detach(), 5e-5, what=nm + " fmap")
+        l1 = sum((a * a).sum() for a in o) + sum(a.abs().mean() for fa in fm for a in fa)
+        l2 = sum((a * a).sum() for a in o_r) + sum(a.abs().mean() for fa in f_r for a in fa)
+        l1.backward()
+        l2.backward()
+        for n, p in D.named_parameters():
+            assert rel_l2(p.grad.cpu(), P[n].grad) <= gtol, nm + " " + n
+        assert rel_l2(yy.grad.cpu(), y2.grad) <= gtol, nm + " d(input)"
+
+
+def test_hifigan_state_dict_keys_match_reference_layout():
+    G, D1, D2 = _models(32)
+    ks = list(G.state_dict().keys())
+    assert "transpose_upsamples.0.1.deconv.weight_g" in ks and "conv_blocks.11.convs2.2.conv1d.weight_v" in ks
+    assert len(ks) == 246  # reference Generator key count
+    assert "discriminators.4.convs.3.0.weight_g" in D1.state_dict() and "discriminators.0.conv_post.weight" in D1.state_dict()
+    kd = D2.state_dict()
+    assert "aux_convs.1.weight_v" in kd and "meanpools.0.h0" in kd and "discriminators.2.conv_post.weight_g" in kd
+
+
+def test_hifigan_host_logic_emulated():
+    with emulation():
+        _check_models("cpu", channels=32, B=2, frames=4, T_wav=640, gtol=1e-4, wtol=1e-6)
+
+
+def test_conv_variants_emulated_match_torch():
+    from kantts._hip import ops
+
+    with emulation():
+        B, T = 2, 19
+        x = torch.randn(B, T, 16, requires_grad=True)
+        w = torch.randn(32, 4, 7, requires_grad=True)
+        b = torch.randn(32, requires_grad=True)
+        y = ops.conv_cl(x, w, b, stride=2, pad=3, groups=4, out_leaky=0.1)
+        ref = F.leaky_relu(F.conv1d(x.transpose(1, 2), w, b, stride=2, padding=3, groups=4), 0.1).transpose(1, 2)
+        assert_close(y.detach(), ref.detach(), 1e-5, what="grouped strided")
+        gy = torch.autograd.grad(y.sum(), (x, w, b))
+        gr = torch.autograd.grad(ref.sum(), (x, w, b))
+        for a, c in zip(gy, gr):
+            assert rel_l2(a, c) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hifigan_gpu_matches_oracle():
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _check_models("cuda", channels=64, B=2, frames=8, T_wav=2048, gtol=2e-3, wtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_conv_ops_gpu_vs_emulated():
+    from kantts._hip import ops
+
+    B, T = 3, 37
+
+    def r(*s, seed, scale=1.0, grad=True):
+        g = torch.Generator().manual_seed(seed)
+        return (torch.randn(*s, generator=g) * scale).requires_grad_(grad)
+
+    cases = [
+        ("causal dilated + res", lambda x, w, b, res: ops.conv_cl(x, w, b, dilation=3, pad=12, in_leaky=0.1, res=res),
+         (r(B, T, 24, seed=1), r(40, 24, 5, seed=2, scale=0.2), r(40, seed=3), r(B, T, 40, seed=4))),
+        ("strided grouped", lambda x, w, b: ops.conv_cl(x, w, b, stride=4, pad=20, groups=4, out_leaky=0.1),
+         (r(B, 64, 32, seed=5), r(64, 8, 41, seed=6, scale=0.1), r(64, seed=7))),
+        ("period fold", lambda x, w, b: ops.conv_cl(x, w, b, stride=3, pad=2, inner=5, out_leaky=0.1),
+         (r(B, 20, 5, 8, seed=8), r(16, 8, 5, seed=9, scale=0.2), r(16, seed=10))),
+        ("nearest upsample", lambda x, w, b: ops.conv_cl(x, w, b, pad=6, up=8, in_leaky=0.1),
+         (r(B, T, 12, seed=11), r(20, 12, 7, seed=12, scale=0.2), r(20, seed=13))),
+        ("polyphase transposed", lambda x, w, b, res: ops.conv_transpose_cl(x, w, b, 8, in_leaky=0.1, res=res),
+         (r(B, T, 16, seed=14), r(16, 12, 16, seed=15, scale=0.2), r(12, seed=16), r(B, T * 8, 12, seed=17))),
+        ("weight norm", lambda v, g: ops.weight_norm(v, g), (r(33, 7, 5, seed=18), r(33, 1, 1, seed=19))),
+        ("sin add", lambda x: ops.sin_add(x), (r(5, 999, seed=20),)),
+    ]
+    for name, fn, args in cases:
+        go, gg, co, cg = run_both(fn, *args)
+        assert_close(go[0], co[0], 5e-5, what=name)
+        for a, c in zip(gg, cg):
+            assert rel_l2(a, c) < 2e-4, name
