@@ -142,6 +142,9 @@ int kantts_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
  * 1: PNCA x (causal band [i-bw, i]), 2: PNCA h (look-ahead band [i, i+bw]); lens (B) int32 = valid
  * positions per sequence (NULL: all); bw_dev: optional device scalar overriding bw.
  * lse: (B,H,L) saved; probs: optional (H*B, L, L) post-dropout probabilities (reference layout).
+ * Band modes: rows of padded queries (t >= lens[b]) are un-masked in the reference but zeroed by every
+ * caller; they are computed only when probs is requested, otherwise their context is 0, and they never
+ * receive / produce gradients.
  * Backward writes dq (or adds to it when accumulate_dq), dk, dv; dvec (B,H,L) is scratch. */
 int kantts_attn_fwd(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, float* o, int ldo,
                     float* lse, float* probs, const int32_t* lens, const int32_t* bw_dev, int bw, int B, int H,

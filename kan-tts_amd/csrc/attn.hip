@@ -9,7 +9,10 @@
 //   mode 0 (encoder, key padding)  : [0, len-1]                               for every query
 //   mode 1 (PNCA x, causal band)   : [max(0, i-bw), i]            if i < len, else [0, L-1]
 //   mode 2 (PNCA h, look-ahead band): [i, min(i+bw, L-1, len-1)]  if i < len, else [0, L-1]
-// (rows of padded queries are fully un-masked by the reference, kantts_sambert.py:158-164).
+// (rows of padded queries are fully un-masked by the reference, kantts_sambert.py:158-164; every caller
+// zeroes those rows right afterwards and they carry no gradient, so unless the probabilities are
+// requested the band modes skip them: context 0, no gradient -- a full-length attention per padded
+// row would otherwise dominate the kernel).
 // With d_head = 16 the QK^T contraction is a single MFMA k-step and the decoder bands hold
 // ~6 keys, so the op is exp/IO-bound: one thread owns one query row (q, o, running softmax in
 // registers), keys/values stream from L2 (wave-uniform addresses in mode 0, neighbouring rows in
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(const AttnArgs a) {
   const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
   int lo, hi;
   key_range(a.mode, i, len, a.L, bw, lo, hi);
+  if (a.mode != 0 && i >= len && !a.probs) hi = lo - 1;  // padded query: skipped (see header)
   const long long row = (long long)b * a.L + i;
   float q[DH], o[DH];
   load16(a.q + row * a.ldq + h * DH, q);
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const AttnArgs a) {
   const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
   int lo, hi;
   key_range(a.mode, i, len, a.L, bw, lo, hi);
+  if (a.mode != 0 && i >= len) hi = lo - 1;  // padded query rows carry no gradient
   const long long row = (long long)b * a.L + i;
   float q[DH], go[DH], oo[DH], dq[DH];
   load16(a.q + row * a.ldq + h * DH, q);
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const AttnArgs a) {
     dv[d] = 0.f;
   }
   // candidate queries: two intervals [c0,c1] (banded, valid queries) and [p0,p1] (padded queries)
-  int c0, c1, p0 = len, p1 = a.L - 1;
+  int c0, c1, p0 = 1, p1 = 0;  // padded queries contribute nothing (skipped in forward)
   if (a.mode == 0) {
     c0 = 0;
     c1 = a.L - 1;
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs
   for (int i = threadIdx.x; i < a.L; i += AT_THREADS) {
     int lo, hi;
     key_range(a.mode, i, len, a.L, bw, lo, hi);
+    if (a.mode != 0 && i >= len && !a.probs) hi = lo - 1;  // padded query: skipped (see header)
     const long long row = (long long)b * a.L + i;
     float q[DH], o[DH];
     load16(a.q + row * a.ldq + h * DH, q);
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_lds_kernel(const AttnA
   for (int i = threadIdx.x; i < a.L; i += AT_THREADS) {
     int lo, hi;
     key_range(a.mode, i, len, a.L, bw, lo, hi);
+    if (a.mode != 0 && i >= len) hi = lo - 1;  // padded query rows carry no gradient
     const long long row = (long long)b * a.L + i;
     float q[DH], go[DH], oo[DH], dq[DH];
     load16(a.q + row * a.ldq + h * DH, q);
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_lds_kernel(const Attn
       dk[d] = 0.f;
       dv[d] = 0.f;
     }
-    int c0, c1, p0 = len, p1 = a.L - 1;
+    int c0, c1, p0 = 1, p1 = 0;  // padded queries contribute nothing (skipped in forward)
     if (a.mode == 0) {
       c0 = 0;
       c1 = a.L - 1;

@@ -56,11 +56,13 @@ class _FusedLinear(torch.autograd.Function):
         y = torch.empty((M, N), device=xs[0].device, dtype=torch.float32)
         segs = []
         if mode == "conv":
-            w = _c(ws[0])
+            # tap-major copy (KT, N, Cin) of the (N, Cin, KT) Conv1d weight: every tap becomes a k-contiguous
+            # matrix, so forward / dgrad / wgrad all run on the float4-staged GEMM kernels
+            cin, kt = ws[0].shape[1], ws[0].shape[2]
+            w = ws[0].permute(2, 0, 1).contiguous()
             ws = [w]
-            cin, kt = w.shape[1], w.shape[2]
             pad = opts["pad"]
-            segs.append(make_seg(xs[0], cin, 1, w, cin * kt, kt, cin, ntaps=kt, b_tap=1, a_tok_axis=1,
+            segs.append(make_seg(xs[0], cin, 1, w, cin, 1, cin, ntaps=kt, b_tap=N * cin, a_tok_axis=1,
                                  a_shift0=-pad, a_shift_step=opts.get("dilation", 1)))
         elif mode == "concat":
             w = _c(ws[0])
@@ -116,13 +118,13 @@ class _FusedLinear(torch.autograd.Function):
         dbias = torch.zeros(N, device=dy.device, dtype=torch.float32) if (has_bias or has_bias2) else None
         first_tn = True
         if mode == "conv":
-            w = ws[0]
-            cin, kt = w.shape[1], w.shape[2]
+            w = ws[0]  # tap-major (KT, N, Cin)
+            kt, cin = w.shape[0], w.shape[2]
             pad, dil = opts["pad"], opts.get("dilation", 1)
             x = xs[0]
             if needs[5]:
                 dx = torch.empty_like(x)
-                seg = make_seg(dy, N, 1, w, kt, cin * kt, N, ntaps=kt, b_tap=1, a_tok_axis=1, a_shift0=pad,
+                seg = make_seg(dy, N, 1, w, 1, cin, N, ntaps=kt, b_tap=N * cin, a_tok_axis=1, a_shift0=pad,
                                a_shift_step=-dil, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed)
                 gemm([seg], M, cin, dx, cin, 1, alpha=balpha, T=T)
                 dxs[0] = dx
@@ -132,10 +134,10 @@ class _FusedLinear(torch.autograd.Function):
                 for tap in range(kt):
                     seg = make_seg(dy, 1, N, x, 1, cin, M, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed,
                                    b_tok_axis=2, b_shift0=tap * dil - pad)
-                    gemm([seg], N, cin, dw, cin * kt, kt, c_off=tap, alpha=balpha, accumulate=True, splitk=sk, T=T,
-                         a_rowsum=dbias if (first_tn and dbias is not None) else None)
+                    gemm([seg], N, cin, dw, cin, 1, c_off=tap * N * cin, alpha=balpha, accumulate=True, splitk=sk,
+                         T=T, a_rowsum=dbias if (first_tn and dbias is not None) else None)
                     first_tn = False
-                dws[0] = dw
+                dws[0] = dw.permute(1, 2, 0)  # back to the parameter's (N, Cin, KT) layout
         else:
             off = 0
             ldw = ws[0].shape[1]

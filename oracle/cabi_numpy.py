@@ -221,7 +221,7 @@ class EmulatedLib:
                 lo[i], hi[i] = i, min(i + bw, L - 1, length - 1)
         return lo, hi
 
-    def _attn_mats(self, q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed):
+    def _attn_mats(self, q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed, skip_padded=False):
         rows = B * L
         Q = _gather(q, (np.arange(rows)[:, None] * ldq + np.arange(H * 16)[None, :]).astype(np.int64), None)
         K = _gather(k, (np.arange(rows)[:, None] * ldk + np.arange(H * 16)[None, :]).astype(np.int64), None)
@@ -235,8 +235,11 @@ class EmulatedLib:
         allow = torch.zeros(B, L, L, dtype=torch.bool)
         jj = np.arange(L)
         for b in range(B):
-            lo, hi = self._ranges(mode, L, int(lens_a[b]) if lens_a is not None else L, bw)
+            ln_b = int(lens_a[b]) if lens_a is not None else L
+            lo, hi = self._ranges(mode, L, ln_b, bw)
             allow[b] = torch.from_numpy((jj[None, :] >= lo[:, None]) & (jj[None, :] <= hi[:, None]))
+            if skip_padded and mode != 0:
+                allow[b, ln_b:, :] = False
         S = torch.einsum("bhid,bhjd->bhij", Q, K) * 0.25
         S = S.masked_fill(~allow[:, None], float("-inf"))
         P = torch.softmax(S, dim=-1)
@@ -253,7 +256,8 @@ class EmulatedLib:
     def kantts_attn_fwd(self, q, k, v, ldq, ldk, ldv, o, ldo, lse, probs, lens, bw_dev, bw, B, H, L, d_head, mode,
                         drop_p, seed, seed_dev, stream):
         drop_p, seed = _val(drop_p), _val(seed) + (int(_arr(seed_dev, 1, np.int64)[0]) if seed_dev else 0)
-        Q, K, V, P, ds, lse_t, _ = self._attn_mats(q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed)
+        Q, K, V, P, ds, lse_t, _ = self._attn_mats(q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed,
+                                                   skip_padded=not probs)
         Pd = P * ds
         O = torch.einsum("bhij,bhjd->bhid", Pd, V).permute(0, 2, 1, 3).reshape(B * L, H * 16)
         offs = (np.arange(B * L)[:, None] * ldo + np.arange(H * 16)[None, :]).astype(np.int64)
@@ -267,7 +271,8 @@ class EmulatedLib:
     def kantts_attn_bwd(self, q, k, v, ldq, ldk, ldv, o, ldo, d_o, lddo, lse, dvec, dq, dk, dv, lddq, lddk, lddv,
                         accumulate_dq, lens, bw_dev, bw, B, H, L, d_head, mode, drop_p, seed, seed_dev, stream):
         drop_p, seed = _val(drop_p), _val(seed) + (int(_arr(seed_dev, 1, np.int64)[0]) if seed_dev else 0)
-        Q, K, V, P, ds, _, _ = self._attn_mats(q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed)
+        Q, K, V, P, ds, _, _ = self._attn_mats(q, k, v, ldq, ldk, ldv, lens, bw_dev, bw, B, H, L, mode, drop_p, seed,
+                                               skip_padded=True)
         cols = np.arange(H * 16)[None, :]
         dO = _gather(d_o, (np.arange(B * L)[:, None] * lddo + cols).astype(np.int64), None)
         dO = torch.from_numpy(dO).view(B, L, H, 16).permute(0, 2, 1, 3)

@@ -67,7 +67,7 @@ def test_hifigan_state_dict_keys_match_reference_layout():
 
 def test_hifigan_host_logic_emulated():
     with emulation():
-        _check_models("cpu", channels=32, B=2, frames=4, T_wav=640, gtol=1e-4, wtol=1e-6)
+        _check_models("cpu", channels=32, B=2, frames=4, T_wav=640, gtol=2e-3, wtol=1e-6)
 
 
 def test_conv_variants_emulated_match_torch():
