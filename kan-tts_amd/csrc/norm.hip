@@ -137,9 +137,9 @@ extern "C" int kantts_layernorm_bwd(const float* dy, const float* x, const float
     return KANTTS_E_BADARG;
   if (C > 64 * LN_MAXPL) return KANTTS_E_UNSUPPORTED;
   if (M == 0) return KANTTS_OK;
-  // enough blocks to fill 256 CUs while keeping the atomic traffic low
-  int rows_per_block = 32;
-  while (rows_per_block > 4 && kantts_cdiv(M, rows_per_block) < 512) rows_per_block >>= 1;
+  // about one block per CU: every block ends with 2*C same-address atomics, so more blocks only add contention
+  int rows_per_block = kantts_cdiv(M, 256);
+  if (rows_per_block < 4) rows_per_block = 4;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(kantts_cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, dy,
                      x, gamma, mean, rstd, dx, dgamma_accum, dbeta_accum, M, C, rows_per_block);
   KANTTS_CHECK_LAUNCH();

@@ -23,6 +23,51 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _ZeroPool:
+    """Bump allocator over one pre-zeroed device buffer for the per-step gradient accumulators (weight / bias
+    gradients are produced by split-K atomics and row sums, so they must start at zero).  One memset per step
+    (reset) replaces ~400 tiny fill kernels.  Opt-in (ArenaAdam enables it); tensors handed out are only
+    valid until the next reset, which ArenaAdam.zero_grad() performs."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+
+    def enable(self, numel, device):
+        if self.buf is None or self.buf.numel() < numel or self.buf.device != torch.device(device):
+            self.buf = torch.zeros(int(numel), device=device, dtype=torch.float32)
+        self.off = 0
+
+    def reset(self):
+        if self.buf is not None:
+            self.buf.zero_()
+            self.off = 0
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        a = (self.off + 63) // 64 * 64
+        if a + n > self.buf.numel():
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+        self.off = a + n
+        return self.buf[a:a + n].view(shape)
+
+
+zero_pool = _ZeroPool()
+
+
+def gzeros(shape, device):
+    """Zero-initialised fp32 accumulator (from the per-step pool when enabled)."""
+    return zero_pool.take(tuple(shape), torch.device(device))
+
+
+def gzeros_like(t):
+    return zero_pool.take(tuple(t.shape), t.device)
+
+
 def _splitk_for(n_out_rows, n_out_cols, k_total):
     tiles = ((n_out_rows + 63) // 64) * ((n_out_cols + 63) // 64)
     ktiles = max(1, (k_total + 31) // 32)
@@ -115,7 +160,7 @@ class _FusedLinear(torch.autograd.Function):
                 a_drop_p, a_seed = drop_p, ctx.seed
         needs = ctx.needs_input_grad  # (opts, bias, bias2, res, rowmask, *xw)
         dxs, dws = [None] * nx, [None] * len(ws)
-        dbias = torch.zeros(N, device=dy.device, dtype=torch.float32) if (has_bias or has_bias2) else None
+        dbias = gzeros((N,), dy.device) if (has_bias or has_bias2) else None
         first_tn = True
         if mode == "conv":
             w = ws[0]  # tap-major (KT, N, Cin)
@@ -129,7 +174,7 @@ class _FusedLinear(torch.autograd.Function):
                 gemm([seg], M, cin, dx, cin, 1, alpha=balpha, T=T)
                 dxs[0] = dx
             if needs[5 + nx]:
-                dw = torch.zeros_like(w)
+                dw = gzeros_like(w)
                 sk = _splitk_for(N, cin, M)
                 for tap in range(kt):
                     seg = make_seg(dy, 1, N, x, 1, cin, M, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed,
@@ -142,7 +187,7 @@ class _FusedLinear(torch.autograd.Function):
             off = 0
             ldw = ws[0].shape[1]
             if mode == "concat" and needs[5 + nx]:
-                dws[0] = torch.zeros_like(ws[0])
+                dws[0] = gzeros_like(ws[0])
             for k, x in enumerate(xs):
                 kk = x.shape[-1]
                 w = ws[0] if mode == "concat" else ws[k]
@@ -156,7 +201,7 @@ class _FusedLinear(torch.autograd.Function):
                 need_w = needs[5 + nx] if mode == "concat" else needs[5 + nx + k]
                 if need_w:
                     if mode != "concat":
-                        dws[k] = torch.zeros_like(w)
+                        dws[k] = gzeros_like(w)
                     dwt = dws[0] if mode == "concat" else dws[k]
                     seg = make_seg(dy, 1, N, x, 1, kk, M, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed)
                     gemm([seg], N, kk, dwt, wld, 1, c_off=woff, alpha=balpha, accumulate=True,
@@ -213,8 +258,8 @@ class _LayerNorm(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
+        dg = gzeros_like(gamma)
+        db = gzeros_like(gamma)
         check(lib().kantts_layernorm_bwd(ptr(dy, torch.float32), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
                                          ptr(dg), ptr(db), M, C, stream()), "layernorm_bwd")
         return dx, dg, db, None
@@ -388,8 +433,8 @@ class _LSTM(torch.autograd.Function):
             w_ih = _c(params[4 * d])
             ld = w_ih.shape[1]
             off = 0
-            dw_ih = torch.zeros_like(w_ih)
-            db = torch.zeros(G, device=dout.device, dtype=torch.float32)
+            dw_ih = gzeros_like(w_ih)
+            db = gzeros((G,), dout.device)
             first = True
             for k, x in enumerate(xs):
                 kk = x.shape[-1]
@@ -401,7 +446,7 @@ class _LSTM(torch.autograd.Function):
                      splitk=_splitk_for(G, kk, M), a_rowsum=db if first else None)
                 first = False
                 off += kk
-            dw_hh = torch.zeros((G, H), device=dout.device, dtype=torch.float32)
+            dw_hh = gzeros((G, H), dout.device)
             shift = 1 if d == 1 else -1  # h_{prev}: previous step in this direction's time order
             seg = make_seg(dgd, 1, G, (out, d * H), 1, ndir * H, M, b_tok_axis=2, b_shift0=shift)
             gemm([seg], G, H, dw_hh, H, 1, accumulate=True, splitk=_splitk_for(G, H, M), T=T)
@@ -455,7 +500,7 @@ class _EmbedSum(torch.autograd.Function):
         dout = _c(dout)
         B, T, n = ids.shape
         D = shapes[0][1]
-        dt = [torch.zeros(s, device=dout.device, dtype=torch.float32) for s in shapes]
+        dt = [gzeros(s, dout.device) for s in shapes]
         check(lib().kantts_embed_sum_bwd(_ptr_array(dt), n, ptr(ids), ptr(dout, torch.float32), B * T, D, float(scale),
                                          stream()), "embed_sum_bwd")
         return (None, None, None, None, *dt)
@@ -536,7 +581,7 @@ class _FsmnMemory(torch.autograd.Function):
         B, T, C, K, lp, has_res = ctx.cfg
         dy = _c(dy)
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
+        dw = gzeros_like(w)
         ws_n = int(lib().kantts_fsmn_dwconv_bwd_ws(B, T, C, K))
         ws = torch.empty(max(ws_n, 1), device=dy.device, dtype=torch.float32)
         check(lib().kantts_fsmn_dwconv_bwd(ptr(dy, torch.float32), ptr(x), ptr(w), ptr(lens), ptr(dx), ptr(dw), ptr(ws),

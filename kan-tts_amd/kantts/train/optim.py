@@ -24,19 +24,23 @@ class ParamArena:
         if not self.params:
             raise ValueError("module has no trainable parameters")
         dev = self.params[0].device
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        # every parameter starts on a 256-byte boundary: the GEMM kernels stage weights with 16-byte vector
+        # loads, which an unpadded pack would break after the first odd-sized tensor (e.g. a (1,) bias)
+        self.align = 64
         self.offsets = []
         off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + self.align - 1) // self.align * self.align
+        self.numel = off
+        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         with torch.no_grad():
-            for p in self.params:
-                n = p.numel()
-                view = self.flat[off:off + n].view(p.shape)
+            for p, o in zip(self.params, self.offsets):
+                view = self.flat[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
-                self.offsets.append(off)
-                off += n
+        self.grad_views = [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
         self._zero_cache = {}
         self.world_size = 1
         self.n_buckets = 4
@@ -54,19 +58,18 @@ class ParamArena:
         dist.broadcast(self.flat, src=0)
 
     def pack_grads(self):
-        """Pack every ``p.grad`` into the gradient arena (one concatenation kernel)."""
-        pieces = []
+        """Pack every ``p.grad`` into the (padded) gradient arena with one multi-tensor copy."""
+        src = []
         for p in self.params:
             g = p.grad
             if g is None:
-                z = self._zero_cache.get(p.numel())
+                z = self._zero_cache.get(tuple(p.shape))
                 if z is None:
-                    z = torch.zeros(p.numel(), device=self.grad.device, dtype=torch.float32)
-                    self._zero_cache[p.numel()] = z
-                pieces.append(z)
-            else:
-                pieces.append(g.reshape(-1))
-        torch.cat(pieces, out=self.grad)
+                    z = torch.zeros(p.shape, device=self.grad.device, dtype=torch.float32)
+                    self._zero_cache[tuple(p.shape)] = z
+                g = z
+            src.append(g)
+        torch._foreach_copy_(self.grad_views, src)
         return self.grad
 
     def all_reduce_grads(self):
@@ -99,12 +102,19 @@ class ArenaAdam(torch.optim.Optimizer):
         self.max_grad_norm = 0.0
         self._step = 0
         self.dyn = None  # optional device tensor [lr, step] (hipGraph replay), see enable_device_state()
+        if arena.flat.is_cuda:
+            # gradient accumulators of one backward pass: all parameter gradients plus slack for temporaries
+            ops.zero_pool.enable(arena.numel + arena.numel // 2 + (1 << 20), dev)
         for i, p in enumerate(arena.params):
             self.state[p] = {
                 "step": torch.tensor(0.0),
                 "exp_avg": arena.view_of(self.exp_avg, i),
                 "exp_avg_sq": arena.view_of(self.exp_avg_sq, i),
             }
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=True)
+        ops.zero_pool.reset()
 
     def enable_device_state(self):
         """Keep lr and the step count in device memory so that step() can be replayed from a hipGraph:
