@@ -3,22 +3,27 @@
 // gemm.hip's kernel interprets every feature of the segment descriptor at run time (token maps,
 // groups, scalar layouts ...); its instruction footprint (~18k instructions) does not fit the
 // instruction cache and it pays integer divisions per staged element.  The kernels here are compiled
-// per staging layout (float4 along k / float4 along rows for A and for B), support only the plain
-// descriptor (optional token shift, gate, dropout regeneration, kmask, the full epilogue, split-K,
-// bias row sums) and hoist all index arithmetic out of the reduction loop: per tile a thread issues
-// 2+2 float4 loads at precomputed bases.  The host (kantts/_hip/__init__.py) routes a launch here when
-// every segment qualifies; anything else goes to the generic kernel.  Same tile / MFMA structure:
-// 256 threads, BMx64x32 tile, 16x16 MFMA fragments, register double buffer.
+// per staging layout (float4 along k / 4x4 register-transposed blocks along rows, for A and for B),
+// support only the plain descriptor (optional token shift, gate, dropout regeneration, kmask, the full
+// epilogue, split-K, bias row sums) and hoist the index arithmetic out of the reduction loop.
+//
+// Tile: 256 threads (4 waves, 2x2), BM x 64 outputs, reduction tile BK = 128 (bf16) / 64 (fp32):
+// the SAM-BERT contractions have K = 128 ... 1024, so a tile covers 1/1 ... 1/8 of K and the
+// load-latency / barrier cost is paid 4x less often than with BK = 32 (PMC of the BK = 32 version:
+// 50 % of wave cycles in s_waitcnt/barrier, profiles/r01_gemm_fwd128x1024_pmc.txt).  Operands are
+// rounded to bf16 while they are staged (8-byte packed LDS stores); LDS rows are padded by 16 B so the
+// 16-byte MFMA fragment reads of 16 consecutive rows hit 16 distinct 16-byte slots.  Global loads of
+// tile t+1 are issued before the MFMAs of tile t (register double buffer).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define F_BN 64
-#define F_BK 32
 #define F_THREADS 256
-#define F_LDF 34
-#define F_LDH 40
 
 __device__ __forceinline__ float f_epilogue(const kantts_gemm_args& g, float acc, int i, int j, bool first_slice,
                                             uint64_t seed_off) {
@@ -34,18 +39,175 @@ __device__ __forceinline__ float f_epilogue(const kantts_gemm_args& g, float acc
   return v;
 }
 
+// 4 consecutive k of one LDS row
+template <bool BF16, int LD>
+__device__ __forceinline__ void lds_store4(void* base, int row, int k, float v0, float v1, float v2, float v3) {
+  if (BF16) {
+    bf16x4 p = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + row * LD + k) = p;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + row * LD + k) = make_float4(v0, v1, v2, v3);
+  }
+}
+
+// One operand (A when IS_A, else B) of a tile: fetch() issues the global loads, commit() writes LDS.
+template <bool BF16, int ROWS, int BK, bool ROWVEC, bool IS_A, int LD>
+struct Stager {
+  // k-vector layout: LPR lanes cover one row, NV vectors per thread
+  static constexpr int LPR = BK / 4;
+  static constexpr int RPP = F_THREADS / LPR;
+  static constexpr int NVK = ROWS / RPP;
+  // row-vector layout: 4x4 blocks (4 rows x 4 k), NB blocks per thread
+  static constexpr int RG = ROWS / 4;
+  static constexpr int NBLK = RG * (BK / 4);
+  static constexpr int NB = (NBLK + F_THREADS - 1) / F_THREADS;
+  static constexpr int NREG = ROWVEC ? NB * 4 : NVK;
+
+  float4 r[NREG], gt[NREG];
+  long long off[NREG];
+  unsigned ok;  // bit per register vector
+
+  const float* p;
+  const float* gp;
+  long long rs, ks;  // row stride (k-vector layout) / k stride (row-vector layout)
+  long long base[ROWVEC ? NB : NVK];
+  bool rok[ROWVEC ? NB : NVK];
+  int klen, shift, tok_axis, T;
+  const uint8_t* kmask;
+
+  __device__ __forceinline__ void setup(const kantts_gemm_seg& s, const kantts_gemm_args& g, int row0, int nrows,
+                                        int tap) {
+    const int tid = threadIdx.x;
+    p = IS_A ? s.a : s.b;
+    gp = IS_A ? s.a_gate : nullptr;
+    klen = s.klen;
+    T = g.T;
+    tok_axis = IS_A ? s.a_tok_axis : s.b_tok_axis;
+    shift = tok_axis ? (IS_A ? s.a_shift0 + tap * s.a_shift_step : s.b_shift0 + tap * s.b_shift_step) : 0;
+    kmask = IS_A ? g.kmask : nullptr;
+    const long long tapoff = IS_A ? 0 : (long long)tap * s.b_tap;
+    if (ROWVEC) {
+      ks = IS_A ? s.a_ks : s.b_ks;
+      rs = 1;
+#pragma unroll
+      for (int v = 0; v < NB; ++v) {
+        const int id = tid + F_THREADS * v;
+        const int row = row0 + (id % RG) * 4;
+        rok[v] = (id < NBLK) && (row < nrows);
+        base[v] = (long long)row + tapoff;
+      }
+    } else {
+      rs = IS_A ? s.a_is : s.b_js;
+      ks = 1;
+#pragma unroll
+      for (int v = 0; v < NVK; ++v) {
+        const int row = row0 + tid / LPR + RPP * v;
+        bool okr = row < nrows;
+        long long rr = row;
+        if (IS_A && tok_axis == 1 && shift != 0) {
+          const int t = row % T + shift;
+          okr = okr && t >= 0 && t < T;
+          rr = row + shift;
+        }
+        rok[v] = okr;
+        base[v] = rr * rs + (tid % LPR) * 4 + tapoff;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void fetch(int k0) {
+    const int tid = threadIdx.x;
+    ok = 0;
+    if (ROWVEC) {
+#pragma unroll
+      for (int v = 0; v < NB; ++v) {
+        const int id = tid + F_THREADS * v;
+        const int kb = k0 + (id / RG) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = kb + e;
+          bool o = rok[v] && kk < klen;
+          long long kq = kk;
+          if (tok_axis == 2 && shift != 0) {
+            const int t = kk % T + shift;
+            o = o && t >= 0 && t < T;
+            kq = kk + shift;
+          }
+          if (kmask && o) o = kmask[kk] == 0;
+          const long long f = o ? (kq * ks + base[v]) : 0;
+          off[v * 4 + e] = f;
+          r[v * 4 + e] = *reinterpret_cast<const float4*>(p + f);
+          if (gp) gt[v * 4 + e] = *reinterpret_cast<const float4*>(gp + f);
+          if (o) ok |= 1u << (v * 4 + e);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < NVK; ++v) {
+        const bool o = rok[v] && (k0 + (tid % LPR) * 4) < klen;
+        const long long f = o ? (base[v] + k0) : 0;
+        off[v] = f;
+        r[v] = *reinterpret_cast<const float4*>(p + f);
+        if (gp) gt[v] = *reinterpret_cast<const float4*>(gp + f);
+        if (o) ok |= 1u << v;
+      }
+    }
+  }
+
+  __device__ __forceinline__ float fix(float x, float gate, int reg, int lane_e, const kantts_gemm_seg& s,
+                                       uint64_t seed_off) const {
+    float v = ((ok >> reg) & 1u) ? x : 0.f;
+    if (IS_A) {
+      if (gp && !(gate > 0.f)) v *= s.a_gate_slope;
+      if (s.a_drop_p > 0.f) v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed + seed_off, (uint64_t)(off[reg] + lane_e));
+    }
+    return v;
+  }
+
+  __device__ __forceinline__ void commit(void* lds, const kantts_gemm_seg& s, uint64_t seed_off) const {
+    const int tid = threadIdx.x;
+    if (ROWVEC) {
+#pragma unroll
+      for (int v = 0; v < NB; ++v) {
+        const int id = tid + F_THREADS * v;
+        if (NBLK % F_THREADS != 0 && id >= NBLK) continue;
+        const int rl = (id % RG) * 4, kl = (id / RG) * 4;
+        // register v*4+e holds rows rl..rl+3 at k = kl+e : transpose to 4 k-contiguous row pieces
+        float m[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float4 x = r[v * 4 + e];
+          const float4 q = gp ? gt[v * 4 + e] : make_float4(1.f, 1.f, 1.f, 1.f);
+          m[0][e] = fix(x.x, q.x, v * 4 + e, 0, s, seed_off);
+          m[1][e] = fix(x.y, q.y, v * 4 + e, 1, s, seed_off);
+          m[2][e] = fix(x.z, q.z, v * 4 + e, 2, s, seed_off);
+          m[3][e] = fix(x.w, q.w, v * 4 + e, 3, s, seed_off);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) lds_store4<BF16, LD>(lds, rl + rr, kl, m[rr][0], m[rr][1], m[rr][2], m[rr][3]);
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < NVK; ++v) {
+        const float4 x = r[v];
+        const float4 q = gp ? gt[v] : make_float4(1.f, 1.f, 1.f, 1.f);
+        lds_store4<BF16, LD>(lds, tid / LPR + RPP * v, (tid % LPR) * 4, fix(x.x, q.x, v, 0, s, seed_off),
+                             fix(x.y, q.y, v, 1, s, seed_off), fix(x.z, q.z, v, 2, s, seed_off),
+                             fix(x.w, q.w, v, 3, s, seed_off));
+      }
+    }
+  }
+};
+
 template <bool BF16, int BM, bool A_ROW, bool B_ROW>
 __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_args g) {
-  __shared__ __attribute__((aligned(16))) float lds_raw[(BM + F_BN) * F_LDF];
-  float* Af = lds_raw;
-  float* Bf = lds_raw + BM * F_LDF;
-  __bf16* Ah = reinterpret_cast<__bf16*>(lds_raw);
-  __bf16* Bh = Ah + BM * F_LDH;
-  constexpr int NVA = BM / 32;  // float4 vectors of A per thread and tile
-  constexpr int NVB = 2;
+  constexpr int BK = BF16 ? 128 : 64;
+  constexpr int LD = BF16 ? (BK + 8) : (BK + 4);  // elements per LDS row (16-byte padded)
+  constexpr int ESZ = BF16 ? 2 : 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(BM + F_BN) * LD * ESZ];
+  void* Al = lds_raw;
+  void* Bl = lds_raw + BM * LD * ESZ;
   constexpr int MREP = BM / 32;
-  constexpr int ARG = BM / 4;          // row groups of A (row-vector layout)
-  constexpr int AKS = F_THREADS / ARG;  // k step between the vectors of a thread
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,196 +226,78 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   float rowsum = 0.f;
   const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0);
 
-  // static element ownership
-  int a_r[NVA], a_k[NVA], b_r[NVB], b_k[NVB];
-#pragma unroll
-  for (int v = 0; v < NVA; ++v) {
-    if (A_ROW) {
-      a_r[v] = (tid % ARG) * 4;
-      a_k[v] = tid / ARG + AKS * v;
-    } else {
-      a_r[v] = (tid >> 3) + 32 * v;
-      a_k[v] = (tid & 7) * 4;
-    }
-  }
-#pragma unroll
-  for (int v = 0; v < NVB; ++v) {
-    if (B_ROW) {
-      b_r[v] = (tid & 15) * 4;
-      b_k[v] = (tid >> 4) + 16 * v;
-    } else {
-      b_r[v] = (tid >> 3) + 32 * v;
-      b_k[v] = (tid & 7) * 4;
-    }
-  }
-
-  float4 ra[NVA], rg[NVA], rb[NVB];
-  long long ao[NVA];
-  bool oka[NVA], okb[NVB];
+  Stager<BF16, BM, BK, A_ROW, true, LD> sa;
+  Stager<BF16, F_BN, BK, B_ROW, false, LD> sb;
   int tile_counter = 0;
 
   for (int sidx = 0; sidx < g.nseg; ++sidx) {
     const kantts_gemm_seg& s = g.seg[sidx];
-    const float* __restrict__ ap = s.a;
-    const float* __restrict__ gp = s.a_gate;
-    const float* __restrict__ bp = s.b;
-    const int klen = s.klen;
+    const int ntile = (s.klen + BK - 1) / BK;
     for (int tap = 0; tap < s.ntaps; ++tap) {
-      const int a_shift = s.a_tok_axis ? s.a_shift0 + tap * s.a_shift_step : 0;
-      const int b_shift = s.b_tok_axis ? s.b_shift0 + tap * s.b_shift_step : 0;
-      // ---- per (segment, tap) bases (everything that does not depend on k0)
-      long long a_base[NVA], b_base[NVB];
-      bool a_rok[NVA], b_rok[NVB];
-#pragma unroll
-      for (int v = 0; v < NVA; ++v) {
-        const int i = i0 + a_r[v];
-        bool ok = i < g.M;
-        long long ii = i;
-        if (!A_ROW && s.a_tok_axis == 1 && a_shift != 0) {
-          const int t = i % g.T + a_shift;
-          ok = ok && t >= 0 && t < g.T;
-          ii = i + a_shift;
-        }
-        a_rok[v] = ok;
-        a_base[v] = A_ROW ? (long long)i : (ii * s.a_is + a_k[v]);
-      }
-#pragma unroll
-      for (int v = 0; v < NVB; ++v) {
-        const int j = j0 + b_r[v];
-        b_rok[v] = j < g.N;
-        b_base[v] = (B_ROW ? (long long)j : ((long long)j * s.b_js + b_k[v])) + (long long)tap * s.b_tap;
-      }
-
-      auto fetch = [&](int k0) {
-#pragma unroll
-        for (int v = 0; v < NVA; ++v) {
-          bool ok = a_rok[v];
-          long long off;
-          if (A_ROW) {
-            const int kk = k0 + a_k[v];
-            ok = ok && kk < klen;
-            long long kq = kk;
-            if (s.a_tok_axis == 2 && a_shift != 0) {
-              const int t = kk % g.T + a_shift;
-              ok = ok && t >= 0 && t < g.T;
-              kq = kk + a_shift;
-            }
-            if (g.kmask && ok) ok = g.kmask[kk] == 0;
-            off = kq * s.a_ks + a_base[v];
-          } else {
-            ok = ok && (k0 + a_k[v]) < klen;
-            off = a_base[v] + k0;
-          }
-          off = ok ? off : 0;
-          oka[v] = ok;
-          ao[v] = off;
-          ra[v] = *reinterpret_cast<const float4*>(ap + off);
-          if (gp) rg[v] = *reinterpret_cast<const float4*>(gp + off);
-        }
-#pragma unroll
-        for (int v = 0; v < NVB; ++v) {
-          bool ok = b_rok[v];
-          long long off;
-          if (B_ROW) {
-            const int kk = k0 + b_k[v];
-            ok = ok && kk < klen;
-            long long kq = kk;
-            if (s.b_tok_axis == 2 && b_shift != 0) {
-              const int t = kk % g.T + b_shift;
-              ok = ok && t >= 0 && t < g.T;
-              kq = kk + b_shift;
-            }
-            off = kq * s.b_ks + b_base[v];
-          } else {
-            ok = ok && (k0 + b_k[v]) < klen;
-            off = b_base[v] + k0;
-          }
-          okb[v] = ok;
-          rb[v] = *reinterpret_cast<const float4*>(bp + (ok ? off : 0));
-        }
-      };
-
-      auto commit = [&]() {
-#pragma unroll
-        for (int v = 0; v < NVA; ++v) {
-          float x[4] = {ra[v].x, ra[v].y, ra[v].z, ra[v].w};
-          const float gt[4] = {rg[v].x, rg[v].y, rg[v].z, rg[v].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float val = oka[v] ? x[e] : 0.f;
-            if (gp && !(gt[e] > 0.f)) val *= s.a_gate_slope;
-            if (s.a_drop_p > 0.f) val *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed + seed_off, (uint64_t)(ao[v] + e));
-            const int r = A_ROW ? a_r[v] + e : a_r[v];
-            const int k = A_ROW ? a_k[v] : a_k[v] + e;
-            if (BF16)
-              Ah[r * F_LDH + k] = (__bf16)val;
-            else
-              Af[r * F_LDF + k] = val;
-          }
-        }
-#pragma unroll
-        for (int v = 0; v < NVB; ++v) {
-          const float x[4] = {rb[v].x, rb[v].y, rb[v].z, rb[v].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float val = okb[v] ? x[e] : 0.f;
-            const int r = B_ROW ? b_r[v] + e : b_r[v];
-            const int k = B_ROW ? b_k[v] : b_k[v] + e;
-            if (BF16)
-              Bh[r * F_LDH + k] = (__bf16)val;
-            else
-              Bf[r * F_LDF + k] = val;
-          }
-        }
-      };
-
-      // ---- software-pipelined reduction over this (segment, tap): tiles owned by this split-K slice
-      const int ntile = (klen + F_BK - 1) / F_BK;
-      int t = 0;
+      sa.setup(s, g, i0, g.M, tap);
+      sb.setup(s, g, j0, g.N, tap);
+      // rows are block-relative inside the stagers' LDS writes: shift the bases instead of the row ids
       auto next_owned = [&](int from) {
         int q = from;
         while (q < ntile && ((tile_counter + q) % g.splitk) != zslice) ++q;
         return q;
       };
-      t = next_owned(0);
-      if (t < ntile) fetch(t * F_BK);
+      int t = next_owned(0);
+      if (t < ntile) {
+        sa.fetch(t * BK);
+        sb.fetch(t * BK);
+      }
       while (t < ntile) {
-        commit();
+        sa.commit(Al, s, seed_off);
+        sb.commit(Bl, s, seed_off);
         __syncthreads();
         const int tn = next_owned(t + 1);
-        if (tn < ntile) fetch(tn * F_BK);
+        if (tn < ntile) {
+          sa.fetch(tn * BK);
+          sb.fetch(tn * BK);
+        }
         if (do_rowsum && sidx == 0 && tid < BM) {
           float q = 0.f;
           if (BF16) {
-            for (int k = 0; k < F_BK; ++k) q += (float)Ah[tid * F_LDH + k];
+            const __bf16* row = reinterpret_cast<const __bf16*>(Al) + tid * LD;
+            for (int k = 0; k < BK; ++k) q += (float)row[k];
           } else {
-            for (int k = 0; k < F_BK; ++k) q += Af[tid * F_LDF + k];
+            const float* row = reinterpret_cast<const float*>(Al) + tid * LD;
+            for (int k = 0; k < BK; ++k) q += row[k];
           }
           rowsum += q;
         }
         if (BF16) {
-          bf16x8 af[MREP], bfr[2];
+          const __bf16* Ah = reinterpret_cast<const __bf16*>(Al);
+          const __bf16* Bh = reinterpret_cast<const __bf16*>(Bl);
 #pragma unroll
-          for (int m = 0; m < MREP; ++m)
-            af[m] = *reinterpret_cast<const bf16x8*>(
-                &Ah[(wr * (BM / 2) + m * 16 + (lane & 15)) * F_LDH + (lane >> 4) * 8]);
+          for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 af[MREP], bfr[2];
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
-            bfr[n] = *reinterpret_cast<const bf16x8*>(&Bh[(wc * 32 + n * 16 + (lane & 15)) * F_LDH + (lane >> 4) * 8]);
-#pragma unroll
-          for (int m = 0; m < MREP; ++m)
+            for (int m = 0; m < MREP; ++m)
+              af[m] = *reinterpret_cast<const bf16x8*>(
+                  &Ah[(wr * (BM / 2) + m * 16 + (lane & 15)) * LD + kk * 32 + (lane >> 4) * 8]);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
-        } else {
+              bfr[n] = *reinterpret_cast<const bf16x8*>(
+                  &Bh[(wc * 32 + n * 16 + (lane & 15)) * LD + kk * 32 + (lane >> 4) * 8]);
 #pragma unroll
-          for (int ks = 0; ks < F_BK / 4; ++ks) {
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+              for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[n], acc[m][n], 0, 0, 0);
+          }
+        } else {
+          const float* Af = reinterpret_cast<const float*>(Al);
+          const float* Bf = reinterpret_cast<const float*>(Bl);
+#pragma unroll
+          for (int ks = 0; ks < BK / 4; ++ks) {
             float af[MREP], bfr[2];
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
-              af[m] = Af[(wr * (BM / 2) + m * 16 + (lane & 15)) * F_LDF + ks * 4 + (lane >> 4)];
+              af[m] = Af[(wr * (BM / 2) + m * 16 + (lane & 15)) * LD + ks * 4 + (lane >> 4)];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bfr[n] = Bf[(wc * 32 + n * 16 + (lane & 15)) * F_LDF + ks * 4 + (lane >> 4)];
+            for (int n = 0; n < 2; ++n) bfr[n] = Bf[(wc * 32 + n * 16 + (lane & 15)) * LD + ks * 4 + (lane >> 4)];
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
@@ -323,7 +367,9 @@ int kantts_gemm_try_fast(const kantts_gemm_args& g, hipStream_t st) {
   }
   const int splitk = g.splitk < 1 ? 1 : g.splitk;
   const long long blocks64 = (long long)kantts_cdiv(g.N, F_BN) * kantts_cdiv(g.M, 64) * splitk;
-  const bool small = blocks64 < 512;
+  static const char* force_bm = getenv("KANTTS_GEMM_BM");
+  bool small = blocks64 < 512;
+  if (force_bm) small = (force_bm[0] == '3');
   const int bmr = small ? 32 : 64;
   dim3 grid(kantts_cdiv(g.N, F_BN), kantts_cdiv(g.M, bmr), splitk);
   const bool a_row = (am == 3), b_row = (bm == 3);
