@@ -64,8 +64,8 @@ struct Stager {
   static constexpr int NREG = ROWVEC ? NB * 4 : NVK;
 
   float4 r[NREG], gt[NREG];
-  long long off[NREG];
   unsigned ok;  // bit per register vector
+  int cur_k0;
 
   const float* p;
   const float* gp;
@@ -118,6 +118,7 @@ struct Stager {
   __device__ __forceinline__ void fetch(int k0) {
     const int tid = threadIdx.x;
     ok = 0;
+    cur_k0 = k0;
     if (ROWVEC) {
 #pragma unroll
       for (int v = 0; v < NB; ++v) {
@@ -135,7 +136,6 @@ struct Stager {
           }
           if (kmask && o) o = kmask[kk] == 0;
           const long long f = o ? (kq * ks + base[v]) : 0;
-          off[v * 4 + e] = f;
           r[v * 4 + e] = *reinterpret_cast<const float4*>(p + f);
           if (gp) gt[v * 4 + e] = *reinterpret_cast<const float4*>(gp + f);
           if (o) ok |= 1u << (v * 4 + e);
@@ -146,7 +146,6 @@ struct Stager {
       for (int v = 0; v < NVK; ++v) {
         const bool o = rok[v] && (k0 + (tid % LPR) * 4) < klen;
         const long long f = o ? (base[v] + k0) : 0;
-        off[v] = f;
         r[v] = *reinterpret_cast<const float4*>(p + f);
         if (gp) gt[v] = *reinterpret_cast<const float4*>(gp + f);
         if (o) ok |= 1u << v;
@@ -159,7 +158,19 @@ struct Stager {
     float v = ((ok >> reg) & 1u) ? x : 0.f;
     if (IS_A) {
       if (gp && !(gate > 0.f)) v *= s.a_gate_slope;
-      if (s.a_drop_p > 0.f) v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed + seed_off, (uint64_t)(off[reg] + lane_e));
+      if (s.a_drop_p > 0.f) {
+        // element offset of A (the dropout counter), recomputed instead of kept in registers
+        long long o;
+        if (ROWVEC) {
+          const int id = threadIdx.x + F_THREADS * (reg >> 2);
+          long long kq = cur_k0 + (id / RG) * 4 + (reg & 3);
+          if (tok_axis == 2) kq += shift;
+          o = kq * ks + base[reg >> 2] + lane_e;
+        } else {
+          o = base[reg] + cur_k0 + lane_e;
+        }
+        v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed + seed_off, (uint64_t)o);
+      }
     }
     return v;
   }
@@ -199,12 +210,15 @@ struct Stager {
   }
 };
 
-template <bool BF16, int BM, bool A_ROW, bool B_ROW>
+template <bool BF16, int BM, bool BIGK, bool A_ROW, bool B_ROW>
 __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_args g) {
-  constexpr int BK = BF16 ? 128 : 64;
+  // deep reduction tiles only when there are many of them to amortise (K >= 512, split-K weight gradients);
+  // short-K launches (the 128 -> 1024 projections) want occupancy instead: BK = 32 keeps them at ~70 VGPRs
+  constexpr int BK = BIGK ? (BF16 ? 128 : 64) : 32;
   constexpr int LD = BF16 ? (BK + 8) : (BK + 4);  // elements per LDS row (16-byte padded)
   constexpr int ESZ = BF16 ? 2 : 4;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(BM + F_BN) * LD * ESZ];
+  constexpr int OPB = (BM + F_BN) * LD * ESZ, CSB = BM * (F_BN + 4) * 4;  // operand tiles / epilogue staging
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[OPB > CSB ? OPB : CSB];
   void* Al = lds_raw;
   void* Bl = lds_raw + BM * LD * ESZ;
   constexpr int MREP = BM / 32;
@@ -315,6 +329,53 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   if (do_rowsum && tid < BM && (i0 + tid) < g.M) atomicAdd(&g.a_rowsum[i0 + tid], rowsum);
 
   const bool first_slice = (zslice == 0);
+  // ---- coalesced epilogue: accumulators go through LDS so that 16 lanes write one 256-byte output row
+  // (the MFMA C layout gives each lane 4 rows x 1 column: 64-byte pieces, which made the 26 MB output of the
+  // 128->1024 projections the slowest part of the kernel)
+  const bool vec_out = !g.accumulate && g.c_js == 1 && (g.c_is & 3) == 0 && ((uintptr_t)g.c & 15) == 0 &&
+                       (!g.res || (g.r_js == 1 && (g.r_is & 3) == 0 && ((uintptr_t)g.res & 15) == 0)) &&
+                       (g.N & 3) == 0;
+  if (vec_out) {
+    constexpr int CLD = F_BN + 4;
+    float* Cs = reinterpret_cast<float*>(lds_raw);  // BM x 68 floats <= the operand tiles
+#pragma unroll
+    for (int m = 0; m < MREP; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Cs[(wr * (BM / 2) + m * 16 + (lane >> 4) * 4 + r) * CLD + wc * 32 + n * 16 + (lane & 15)] = acc[m][n][r];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < BM / 16; ++v) {
+      const int rl = (tid >> 4) + 16 * v;
+      const int i = i0 + rl, j = j0 + (tid & 15) * 4;
+      if (i < g.M && j < g.N) {
+        const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rl * CLD + (tid & 15) * 4]);
+        float o[4] = {a4.x, a4.y, a4.z, a4.w};
+        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.res) {
+          const float4 r4 = *reinterpret_cast<const float4*>(g.res + (long long)i * g.r_is + j);
+          rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
+        }
+        const bool masked = g.rowmask && g.rowmask[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val = o[e];
+          if (g.bias) val += g.bias[j + e];
+          if (g.bias2) val += g.bias2[j + e];
+          val *= g.alpha;
+          if (g.relu) val = fmaxf(val, 0.f);
+          if (g.drop_p > 0.f)
+            val *= kantts_dropout_scale(g.drop_p, g.drop_seed + seed_off, (uint64_t)i * (uint64_t)g.N + (uint64_t)(j + e));
+          val += rr[e];
+          o[e] = masked ? 0.f : val;
+        }
+        *reinterpret_cast<float4*>(g.c + (long long)i * g.c_is + j) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MREP; ++m)
 #pragma unroll
@@ -334,19 +395,32 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
       }
 }
 
-template <bool BF16, int BM>
-static void launch_fast(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 grid, hipStream_t st) {
+template <bool BF16, int BM, bool BIGK>
+static void launch_fast2(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 grid, hipStream_t st) {
   if (a_row) {
     if (b_row)
-      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, true, true>), grid, dim3(F_THREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, true, true>), grid, dim3(F_THREADS), 0, st, g);
     else
-      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, true, false>), grid, dim3(F_THREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, true, false>), grid, dim3(F_THREADS), 0, st, g);
   } else {
     if (b_row)
-      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, false, true>), grid, dim3(F_THREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, false, true>), grid, dim3(F_THREADS), 0, st, g);
     else
-      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, false, false>), grid, dim3(F_THREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, false, false>), grid, dim3(F_THREADS), 0, st, g);
   }
+}
+
+template <bool BF16, int BM>
+static void launch_fast(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 grid, hipStream_t st) {
+  long long ktot = 0;
+  for (int s = 0; s < g.nseg; ++s) ktot += (long long)g.seg[s].klen * g.seg[s].ntaps;
+  static const char* force_bk = getenv("KANTTS_GEMM_BIGK");
+  bool big = (ktot >= 512);
+  if (force_bk) big = (force_bk[0] == '1');
+  if (big)
+    launch_fast2<BF16, BM, true>(g, a_row, b_row, grid, st);
+  else
+    launch_fast2<BF16, BM, false>(g, a_row, b_row, grid, st);
 }
 
 // Returns 1 when the launch was taken by a fast kernel, 0 when the descriptor does not qualify.
