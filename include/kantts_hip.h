@@ -212,6 +212,11 @@ long long kantts_fsmn_dwconv_bwd_ws(int B, int T, int C, int K);
 int kantts_masked_l1(const float* pred, const float* target, const int64_t* lens, float* loss_accum, float* grad,
                      int B, int T, int C, void* stream);
 
+/* Mean-style element losses of the GAN step (kantts/train/loss.py:108-256,310): mode 0: loss_accum += scale*sum|a-b|,
+ * grad = scale*sign(a-b); mode 1: loss_accum += scale*sum (a-target)^2, grad = 2*scale*(a-target).  grad optional. */
+int kantts_elem_loss(const float* a, const float* b, float target, int mode, float scale, float* loss_accum,
+                     float* grad, long long n, void* stream);
+
 /* out_accum[0] += sum x^2 (global gradient norm, torch.nn.utils.clip_grad_norm_) */
 int kantts_sumsq(const float* x, float* out_accum, long long n, void* stream);
 
@@ -235,6 +240,13 @@ int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int hop, int f
                        const float* window, const float* twiddle, float eps_power, const int32_t* mel_start,
                        const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels,
                        float eps_mel, float* out_mel, float* out_mag, void* stream);
+
+/* Backward of the mel path of kantts_melspec_fwd (MelSpectrogramLoss on generated audio, kantts/train/loss.py:
+ * 259-311): dwav_accum (B,T) += d loss / d wav given dmel (B, n_mels, frames).  The spectrum is recomputed. */
+int kantts_melspec_bwd(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames,
+                       int pad_mode, const float* window, const float* twiddle, float eps_power,
+                       const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off, const float* mel_w,
+                       int n_mels, float eps_mel, float* dwav_accum, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * weight_norm reparametrisation w = g * v / ||v|| per output row (torch.nn.utils.weight_norm, dim=0):

@@ -110,3 +110,38 @@ extern "C" int kantts_adam_step(float* p, const float* g, float* m, float* v, lo
                      weight_decay, bias_corr1, bias_corr2, gnorm_sq, max_norm, dyn_lr_step);
   KANTTS_CHECK_LAUNCH();
 }
+
+// Mean-reduced element losses of the GAN step (kantts/train/loss.py:108-256, :310):
+//   mode 0: loss += scale * sum |a - b|          grad = scale * sign(a - b)      (FeatureMatchLoss / mel L1)
+//   mode 1: loss += scale * sum (a - c)^2        grad = 2 * scale * (a - c)      (LSGAN real/fake targets)
+__global__ __launch_bounds__(256) void elem_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, float c,
+                                                       int mode, float scale, float* __restrict__ loss,
+                                                       float* __restrict__ grad, long long n) {
+  __shared__ float red[4];
+  float part = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float d = a[i] - (mode == 0 ? b[i] : c);
+    float g;
+    if (mode == 0) {
+      part += fabsf(d);
+      g = (d > 0.f) ? scale : ((d < 0.f) ? -scale : 0.f);
+    } else {
+      part += d * d;
+      g = 2.f * scale * d;
+    }
+    if (grad) grad[i] = g;
+  }
+  part = kantts_block_sum(part, red);
+  if (threadIdx.x == 0) atomicAdd(loss, part * scale);
+}
+
+extern "C" int kantts_elem_loss(const float* a, const float* b, float target, int mode, float scale, float* loss_accum,
+                                float* grad, long long n, void* stream) {
+  if (!a || !loss_accum || n < 0 || (mode == 0 && !b) || mode < 0 || mode > 1) return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(n, 1024);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(elem_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, target, mode, scale,
+                     loss_accum, grad, n);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -160,3 +160,173 @@ extern "C" int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int
   hipLaunchKernelGGL(melspec_kernel, dim3(kantts_cdiv(frames, MEL_FB), B), dim3(MEL_THREADS), lds, (hipStream_t)stream, a);
   KANTTS_CHECK_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the mel path (needed by MelSpectrogramLoss on generated audio, kantts/train/loss.py:259-311):
+// d wav += window * Re( sum_{k<=N/2} G[k] e^{+2 pi i k n / N} ),  G[k] = d amp[k] * X[k] / amp[k]  (0 where the
+// power clamp is active), d amp = melmat (sparse) * d mel, d mel from the dB / clamp chain.  One workgroup per
+// frame: the forward spectrum is recomputed in LDS (cheaper than saving 4 KB/frame), the adjoint transform is
+// one N-point complex Stockham FFT (of conj G, conjugated back), overlap-add into d wav with atomics.
+struct MelBwdArgs {
+  MelArgs f;
+  const float* dmel;  // (B, n_mels, frames)
+  float* dwav;        // (B, T) accumulated
+};
+
+__global__ __launch_bounds__(MEL_THREADS) void melspec_bwd_kernel(const MelBwdArgs ba) {
+  const MelArgs& a = ba.f;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.n_fft, M = N >> 1;
+  float2* buf0 = reinterpret_cast<float2*>(smem);       // N complex
+  float2* buf1 = buf0 + N;                              // N complex
+  float2* X = buf1 + N;                                 // M + 1 spectrum bins
+  float* damp = reinterpret_cast<float*>(X + M + 1);    // M + 1
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, f = blockIdx.x;
+  const float* x = a.wav + (long long)b * a.T;
+  const int start = f * a.hop - M;
+  // ---- forward spectrum of this frame (same steps as melspec_kernel)
+  for (int n = tid; n < M; n += MEL_THREADS) {
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int s = start + 2 * n + e;
+      float xv = 0.f;
+      if (a.pad_mode == 1) {
+        if (s < 0) s = -s;
+        if (s >= a.T) s = 2 * (a.T - 1) - s;
+        xv = (s >= 0 && s < a.T) ? x[s] : 0.f;
+      } else if (s >= 0 && s < a.T) {
+        xv = x[s];
+      }
+      v[e] = xv * a.window[2 * n + e];
+    }
+    buf0[n] = make_float2(v[0], v[1]);
+  }
+  __syncthreads();
+  float2* src = buf0;
+  float2* dst = buf1;
+  for (int s = 0; s < a.log2m; ++s) {
+    const int Ns = 1 << s;
+    for (int j = tid; j < (M >> 1); j += MEL_THREADS) {
+      const int k = j & (Ns - 1);
+      const float2 w = a.tw[(k * (M >> (s + 1))) << 1];
+      const float2 u = src[j];
+      const float2 t = cmul(src[j + (M >> 1)], w);
+      const int d = ((j >> s) << (s + 1)) + k;
+      dst[d] = make_float2(u.x + t.x, u.y + t.y);
+      dst[d + Ns] = make_float2(u.x - t.x, u.y - t.y);
+    }
+    __syncthreads();
+    float2* tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+  for (int k = tid; k <= M; k += MEL_THREADS) {
+    float re, im;
+    if (k == 0 || k == M) {
+      const float2 z0 = src[0];
+      re = (k == 0) ? (z0.x + z0.y) : (z0.x - z0.y);
+      im = 0.f;
+    } else {
+      const float2 zk = src[k];
+      const float2 zc = src[M - k];
+      const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
+      const float dr = zk.x - zc.x, di = zk.y + zc.y;
+      const float orr = 0.5f * di, oi = -0.5f * dr;
+      const float2 w = a.tw[k];
+      re = er + (orr * w.x - oi * w.y);
+      im = ei + (orr * w.y + oi * w.x);
+    }
+    X[k] = make_float2(re, im);
+    damp[k] = 0.f;
+  }
+  __syncthreads();
+  // ---- d mel -> d amp (scatter over each filter's support)
+  if (tid < a.n_mels) {
+    const int st = a.mel_start[tid], ln = a.mel_len[tid];
+    const float* w = a.mel_w + a.mel_off[tid];
+    float acc = 0.f;
+    for (int i = 0; i < ln; ++i) {
+      const float2 z = X[st + i];
+      acc = fmaf(sqrtf(fmaxf(z.x * z.x + z.y * z.y, a.eps_power)), w[i], acc);
+    }
+    const float g = ba.dmel[((long long)b * a.n_mels + tid) * a.frames + f];
+    const float melc = fmaxf(acc, a.eps_mel);
+    const float db = 20.f * log10f(fmaxf(melc, 1e-5f)) - 20.f;
+    const float nv = 8.f * ((db + 100.f) / 100.f) - 4.f;
+    float gm = 0.f;
+    if (nv > -4.f && nv < 4.f && melc > 1e-5f && acc > a.eps_mel) gm = g * 0.08f * 8.685889638065035f / melc;  // 20/ln(10)
+    if (gm != 0.f)
+      for (int i = 0; i < ln; ++i) atomicAdd(&damp[st + i], gm * w[i]);
+  }
+  __syncthreads();
+  // ---- conj(G) into the N-point buffer (zero above N/2)
+  for (int k = tid; k < N; k += MEL_THREADS) {
+    float2 gq = make_float2(0.f, 0.f);
+    if (k <= M) {
+      const float2 z = X[k];
+      const float p = z.x * z.x + z.y * z.y;
+      if (p > a.eps_power) {
+        const float sc = damp[k] / sqrtf(p);
+        gq = make_float2(sc * z.x, -sc * z.y);
+      }
+    }
+    buf0[k] = gq;
+  }
+  __syncthreads();
+  src = buf0;
+  dst = buf1;
+  for (int s = 0; s <= a.log2m; ++s) {  // log2(N) stages
+    const int Ns = 1 << s;
+    for (int j = tid; j < M; j += MEL_THREADS) {
+      const int k = j & (Ns - 1);
+      const float2 w = a.tw[k * (M >> s)];  // exp(-2 pi i k / (2 Ns)) = tw_N[k * N / (2 Ns)]
+      const float2 u = src[j];
+      const float2 t = cmul(src[j + M], w);
+      const int d = ((j >> s) << (s + 1)) + k;
+      dst[d] = make_float2(u.x + t.x, u.y + t.y);
+      dst[d + Ns] = make_float2(u.x - t.x, u.y - t.y);
+    }
+    __syncthreads();
+    float2* tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+  // y[n] = conj(FFT(conj G))[n];  d x_w[n] = Re y[n] = Re FFT(conj G)[n]
+  float* dx = ba.dwav + (long long)b * a.T;
+  for (int n = tid; n < N; n += MEL_THREADS) {
+    const float v = src[n].x * a.window[n];
+    int s = start + n;
+    if (a.pad_mode == 1) {
+      if (s < 0) s = -s;
+      if (s >= a.T) s = 2 * (a.T - 1) - s;
+    }
+    if (s >= 0 && s < a.T && v != 0.f) atomicAdd(&dx[s], v);
+  }
+}
+
+extern "C" int kantts_melspec_bwd(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames,
+                                  int pad_mode, const float* window, const float* twiddle, float eps_power,
+                                  const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                                  const float* mel_w, int n_mels, float eps_mel, float* dwav_accum, void* stream) {
+  if (!wav || !dmel || !window || !twiddle || !dwav_accum || !mel_start || !mel_len || !mel_off || !mel_w)
+    return KANTTS_E_BADARG;
+  if (B < 0 || T < 1 || n_fft < 8 || hop < 1 || frames < 0 || n_mels < 1 || n_mels > MEL_THREADS) return KANTTS_E_BADARG;
+  if (n_fft & (n_fft - 1)) return KANTTS_E_UNSUPPORTED;
+  if (B == 0 || frames == 0) return KANTTS_OK;
+  MelBwdArgs ba = {};
+  MelArgs& a = ba.f;
+  a.wav = wav; a.B = B; a.T = T; a.n_fft = n_fft; a.hop = hop; a.frames = frames; a.pad_mode = pad_mode;
+  a.window = window; a.tw = reinterpret_cast<const float2*>(twiddle); a.eps_power = eps_power;
+  a.mel_start = mel_start; a.mel_len = mel_len; a.mel_off = mel_off; a.mel_w = mel_w; a.n_mels = n_mels;
+  a.eps_mel = eps_mel;
+  ba.dmel = dmel; ba.dwav = dwav_accum;
+  int m = n_fft >> 1, l2 = 0;
+  while ((1 << l2) < m) ++l2;
+  a.log2m = l2;
+  size_t lds = (size_t)n_fft * 2 * sizeof(float2) + (size_t)(m + 1) * (sizeof(float2) + sizeof(float));
+  if (lds > 64 * 1024) return KANTTS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(melspec_bwd_kernel, dim3(frames, B), dim3(MEL_THREADS), lds, (hipStream_t)stream, ba);
+  KANTTS_CHECK_LAUNCH();
+}

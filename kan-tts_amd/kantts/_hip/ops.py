@@ -34,8 +34,10 @@ class _ZeroPool:
         self.off = 0
 
     def enable(self, numel, device):
-        if self.buf is None or self.buf.numel() < numel or self.buf.device != torch.device(device):
-            self.buf = torch.zeros(int(numel), device=device, dtype=torch.float32)
+        """Reserve room for ``numel`` more accumulators (every arena optimizer of the process adds its share:
+        a GAN generator backward also fills the discriminators' gradients)."""
+        have = 0 if (self.buf is None or self.buf.device != torch.device(device)) else self.buf.numel()
+        self.buf = torch.zeros(int(have + numel), device=device, dtype=torch.float32)
         self.off = 0
 
     def reset(self):
@@ -621,6 +623,36 @@ class _MaskedL1(torch.autograd.Function):
 
 def masked_l1(pred, target, lens_i64):
     return _MaskedL1.apply(pred, target, lens_i64)
+
+
+class _ElemLoss(torch.autograd.Function):
+    """scale * sum |a - b|  (mode 0)  or  scale * sum (a - target)^2  (mode 1); b is treated as a constant."""
+
+    @staticmethod
+    def forward(ctx, a, b, target, mode, scale):
+        a = _c(a)
+        b = _c(b) if b is not None else None
+        loss = torch.zeros((), device=a.device, dtype=torch.float32)
+        grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        check(lib().kantts_elem_loss(ptr(a, torch.float32), ptr(b), float(target), int(mode), float(scale), ptr(loss),
+                                     ptr(grad), a.numel(), stream()), "elem_loss")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g if grad is not None else None), None, None, None, None
+
+
+def l1_mean(a, b):
+    """F.l1_loss(a, b.detach()) in one pass (loss + gradient)."""
+    return _ElemLoss.apply(a, b.detach().reshape(a.shape), 0.0, 0, 1.0 / a.numel())
+
+
+def mse_to_const(a, target):
+    """F.mse_loss(a, full_like(a, target))."""
+    return _ElemLoss.apply(a, None, float(target), 1, 1.0 / a.numel())
 
 
 # ================================================================================================

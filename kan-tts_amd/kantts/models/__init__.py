@@ -58,20 +58,24 @@ def hifigan_model_builder(config, device, rank, distributed):
 
     model, optimizer, scheduler = {}, {}, {}
     model["discriminator"], optimizer["discriminator"], scheduler["discriminator"] = {}, {}, {}
+    def _opt(net, conf):
+        otype, oparams = conf["optimizer"].get("type", "Adam"), conf["optimizer"].get("params", {})
+        if _is_hip(device) and otype == "Adam" and not oparams.get("amsgrad", False) and not distributed:
+            return ArenaAdam(ParamArena(net), **oparams)
+        return optimizer_builder(net.parameters(), otype, oparams)
+
     for model_name in config["Model"].keys():
         conf = config["Model"][model_name]
         if model_name == "Generator":
             net = _h.Generator(**conf["params"]).to(device)
             model["generator"] = net
-            optimizer["generator"] = optimizer_builder(net.parameters(), conf["optimizer"].get("type", "Adam"),
-                                                       conf["optimizer"].get("params", {}))
+            optimizer["generator"] = _opt(net, conf)
             scheduler["generator"] = scheduler_builder(optimizer["generator"], conf["scheduler"].get("type", "StepLR"),
                                                        conf["scheduler"].get("params", {}))
         else:
             net = getattr(_h, model_name)(**conf["params"]).to(device)
             model["discriminator"][model_name] = net
-            optimizer["discriminator"][model_name] = optimizer_builder(
-                net.parameters(), conf["optimizer"].get("type", "Adam"), conf["optimizer"].get("params", {}))
+            optimizer["discriminator"][model_name] = _opt(net, conf)
             scheduler["discriminator"][model_name] = scheduler_builder(
                 optimizer["discriminator"][model_name], conf["scheduler"].get("type", "StepLR"),
                 conf["scheduler"].get("params", {}))

@@ -40,9 +40,92 @@ class ProsodyReconLoss(torch.nn.Module):
         return dur_loss, pitch_loss, energy_loss
 
 
+class GeneratorAdversarialLoss(torch.nn.Module):
+    """LSGAN generator loss: mean over discriminators of mse(D(G(x)), 1) (reference :108-151)."""
+
+    def __init__(self, average_by_discriminators=True, loss_type="mse"):
+        super().__init__()
+        if loss_type != "mse":
+            raise NotImplementedError("hinge adversarial loss is not used by the shipped yamls")
+        self.average_by_discriminators = average_by_discriminators
+
+    def forward(self, outputs):
+        if not isinstance(outputs, (tuple, list)):
+            return ops.mse_to_const(outputs, 1.0)
+        adv = 0.0
+        for o in outputs:
+            adv = adv + ops.mse_to_const(o[-1] if isinstance(o, (tuple, list)) else o, 1.0)
+        return adv / len(outputs) if self.average_by_discriminators else adv
+
+
+class DiscriminatorAdversarialLoss(torch.nn.Module):
+    """LSGAN discriminator loss -> (real, fake) (reference :154-216)."""
+
+    def __init__(self, average_by_discriminators=True, loss_type="mse"):
+        super().__init__()
+        if loss_type != "mse":
+            raise NotImplementedError("hinge adversarial loss is not used by the shipped yamls")
+        self.average_by_discriminators = average_by_discriminators
+
+    def forward(self, outputs_hat, outputs):
+        if not isinstance(outputs, (tuple, list)):
+            return ops.mse_to_const(outputs, 1.0), ops.mse_to_const(outputs_hat, 0.0)
+        real, fake = 0.0, 0.0
+        for oh, o in zip(outputs_hat, outputs):
+            if isinstance(oh, (tuple, list)):
+                oh, o = oh[-1], o[-1]
+            real = real + ops.mse_to_const(o, 1.0)
+            fake = fake + ops.mse_to_const(oh, 0.0)
+        if self.average_by_discriminators:
+            real, fake = real / len(outputs), fake / len(outputs)
+        return real, fake
+
+
+class FeatureMatchLoss(torch.nn.Module):
+    """Sum over discriminators of the mean L1 between feature maps (reference :219-256)."""
+
+    def __init__(self, average_by_layers=True, average_by_discriminators=True):
+        super().__init__()
+        self.average_by_layers = average_by_layers
+        self.average_by_discriminators = average_by_discriminators
+
+    def forward(self, feats_hat, feats):
+        total = 0.0
+        for fh, fr in zip(feats_hat, feats):
+            part = 0.0
+            for a, b in zip(fh, fr):
+                part = part + ops.l1_mean(a, b)
+            total = total + (part / len(fh) if self.average_by_layers else part)
+        return total / len(feats) if self.average_by_discriminators else total
+
+
+class MelSpectrogramLoss(torch.nn.Module):
+    """L1 between normalised log-mels of generated and real audio (reference :259-311); forward and backward
+    of the generated branch run in the fused mel-STFT kernels."""
+
+    def __init__(self, fs=22050, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80, fmin=80,
+                 fmax=7600, center=True, normalized=False, onesided=True, eps=1e-10, log_base=10.0):
+        super().__init__()
+        from kantts.utils.audio_torch import MelSpectrogram
+
+        self.mel_spectrogram = MelSpectrogram(fs=fs, fft_size=fft_size, hop_size=hop_size, win_length=win_length,
+                                              window=window, num_mels=num_mels, fmin=fmin, fmax=fmax, center=center,
+                                              normalized=normalized, onesided=onesided, eps=eps, log_base=log_base)
+
+    def forward(self, y_hat, y):
+        mel_hat = self.mel_spectrogram(y_hat)
+        with torch.no_grad():
+            mel = self.mel_spectrogram(y)
+        return ops.l1_mean(mel_hat, mel)
+
+
 loss_dict = {
     "MelReconLoss": MelReconLoss,
     "ProsodyReconLoss": ProsodyReconLoss,
+    "generator_adv_loss": GeneratorAdversarialLoss,
+    "discriminator_adv_loss": DiscriminatorAdversarialLoss,
+    "feat_match_loss": FeatureMatchLoss,
+    "mel_loss": MelSpectrogramLoss,
 }
 
 
@@ -54,6 +137,6 @@ def criterion_builder(config, device="cpu"):
             if value["enable"]:
                 criterion[key] = loss_dict[key](**value.get("params", {})).to(device)
                 setattr(criterion[key], "weights", value.get("weights", 1.0))
-        else:
+        elif value.get("enable", False):
             raise NotImplementedError("{} is not implemented".format(key))
     return criterion

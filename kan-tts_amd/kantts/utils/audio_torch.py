@@ -73,9 +73,38 @@ def _fft_consts(n_fft, win_length, window, device):
     return c
 
 
+class _MelSpecFn(torch.autograd.Function):
+    """Differentiable mel path (forward + kantts_melspec_bwd); the magnitude output has no backward yet."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, ms, ml, mo, mw):
+        n_fft, hop, win_length, window, pad_mode, eps_power, eps_mel = cfg
+        out_mel, _ = _launch(x.detach(), n_fft, hop, win_length, window, pad_mode, eps_power, mel=(ms, ml, mo, mw),
+                             eps_mel=eps_mel)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, ms, ml, mo, mw)
+        return out_mel
+
+    @staticmethod
+    def backward(ctx, dmel):
+        x, ms, ml, mo, mw = ctx.saved_tensors
+        n_fft, hop, win_length, window, pad_mode, eps_power, eps_mel = ctx.cfg
+        x = x.contiguous().float()
+        B, T = x.shape
+        frames = 1 + T // hop
+        wpad, tw = _fft_consts(n_fft, win_length, window, x.device)
+        dwav = torch.zeros_like(x)
+        check(lib().kantts_melspec_bwd(ptr(x, torch.float32), ptr(dmel.contiguous(), torch.float32), B, T, n_fft, hop,
+                                       frames, pad_mode, ptr(wpad), ptr(tw), float(eps_power), ptr(ms), ptr(ml), ptr(mo),
+                                       ptr(mw), ms.numel(), float(eps_mel), ptr(dwav), stream()), "melspec_bwd")
+        return dwav, None, None, None, None, None
+
+
 def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, eps_mel=0.0, want_mag=False):
     if x.requires_grad:
-        raise NotImplementedError("mel-STFT backward (GAN mel loss) is not wired yet -- DESIGN.md, row c")
+        if want_mag or mel is None:
+            raise NotImplementedError("STFT-magnitude backward (STFTLoss) is SURVEY row 8f-4 (next)")
+        return _MelSpecFn.apply(x, (n_fft, hop, win_length, window, pad_mode, eps_power, eps_mel), *mel), None
     x = x.contiguous().float()
     B, T = x.shape
     frames = 1 + T // hop

@@ -488,6 +488,20 @@ class EmulatedLib:
             _arr(grad, B * T * C)[:] = (np.sign(d) * keep * inv).astype(np.float32).ravel()
         return 0
 
+    def kantts_elem_loss(self, a, b, target, mode, scale, loss, grad, n, stream):
+        target, scale = np.float32(_val(target)), np.float32(_val(scale))
+        A = _arr(a, n)
+        d = A - (_arr(b, n) if mode == 0 else target)
+        if mode == 0:
+            _arr(loss, 1)[0] += np.float32(np.abs(d).sum(dtype=np.float64)) * scale
+            gr = np.sign(d) * scale
+        else:
+            _arr(loss, 1)[0] += np.float32((d.astype(np.float64) ** 2).sum()) * scale
+            gr = 2 * scale * d
+        if grad:
+            _arr(grad, n)[:] = gr.astype(np.float32)
+        return 0
+
     def kantts_sumsq(self, x, out, n, stream):
         a = _arr(x, n)
         _arr(out, 1)[0] += np.float32((a.astype(np.float64) ** 2).sum())
@@ -537,6 +551,31 @@ class EmulatedLib:
             db = 20 * torch.log10(torch.clamp(mel, min=1e-5)) - 20.0
             out = torch.clamp(8.0 * ((db + 100.0) / 100.0) - 4.0, -4.0, 4.0).transpose(1, 2).contiguous()
             _arr(out_mel, B * n_mels * frames)[:] = out.reshape(-1).numpy()
+        return 0
+
+    def kantts_melspec_bwd(self, wav, dmel, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
+                           mel_len, mel_off, mel_w, n_mels, eps_mel, dwav, stream):
+        eps_power, eps_mel = _val(eps_power), _val(eps_mel)
+        X = torch.from_numpy(_arr(wav, B * T).copy()).view(B, T).requires_grad_(True)
+        W = torch.from_numpy(_arr(window, n_fft))
+        G = torch.from_numpy(_arr(dmel, B * n_mels * frames)).view(B, n_mels, frames)
+        nb = n_fft // 2 + 1
+        st, ln, of = (_arr(p, n_mels, np.int32) for p in (mel_start, mel_len, mel_off))
+        w = _arr(mel_w, int(of[-1] + ln[-1]))
+        Mm = torch.zeros(nb, n_mels)
+        for m in range(n_mels):
+            Mm[st[m]:st[m] + ln[m], m] = torch.from_numpy(w[of[m]:of[m] + ln[m]].copy())
+        with torch.enable_grad():
+            xp = torch.nn.functional.pad(X[:, None, :], (n_fft // 2, n_fft // 2),
+                                         mode="reflect" if pad_mode == 1 else "constant")[:, 0]
+            fr = xp.unfold(1, n_fft, hop)[:, :frames] * W
+            spec = torch.fft.rfft(fr, n=n_fft, dim=-1)
+            amp = torch.sqrt(torch.clamp(spec.real ** 2 + spec.imag ** 2, min=eps_power))
+            mel = torch.clamp(amp @ Mm, min=eps_mel)
+            db = 20 * torch.log10(torch.clamp(mel, min=1e-5)) - 20.0
+            out = torch.clamp(8.0 * ((db + 100.0) / 100.0) - 4.0, -4.0, 4.0).transpose(1, 2)
+            (out * G).sum().backward()
+        _arr(dwav, B * T)[:] += X.grad.reshape(-1).numpy()
         return 0
 
     # ------------------------------------------------------------------------------------ HiFi-GAN helpers

@@ -124,3 +124,111 @@ def test_conv_ops_gpu_vs_emulated():
         assert_close(go[0], co[0], 5e-5, what=name)
         for a, c in zip(gg, cg):
             assert rel_l2(a, c) < 2e-4, name
+
+
+def _gan_losses_check(device, channels, B, frames):
+    """Generator / discriminator loss values and gradients of one GAN step vs the oracle
+    (hifigan_oracle + audio_oracle), reference weights 45 / 1 / 2 (hifigan_v1_16k.yaml:115-158)."""
+    import audio_oracle as A
+    from kantts.train.gan_step import discriminator_loss, generator_loss
+    from kantts.train.loss import (DiscriminatorAdversarialLoss, FeatureMatchLoss, GeneratorAdversarialLoss,
+                                   MelSpectrogramLoss)
+
+    G, D1, D2 = _models(channels)
+    PG = {k: v.detach().clone().requires_grad_(True) for k, v in G.state_dict().items()}
+    P1 = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in D1.state_dict().items()}
+    P2 = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in D2.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, 80, frames, generator=g)
+    y = torch.randn(B, 1, frames * 256, generator=g).clamp(-1, 1)
+    model = {"generator": G.to(device), "discriminator": {"MultiScaleDiscriminator": D2.to(device),
+                                                           "MultiPeriodDiscriminator": D1.to(device)}}
+    crit = {"mel_loss": MelSpectrogramLoss().to(device), "generator_adv_loss": GeneratorAdversarialLoss(),
+            "discriminator_adv_loss": DiscriminatorAdversarialLoss(), "feat_match_loss": FeatureMatchLoss()}
+    for k, w in (("mel_loss", 45.0), ("generator_adv_loss", 1.0), ("discriminator_adv_loss", 1.0),
+                 ("feat_match_loss", 2.0)):
+        crit[k].weights = w
+    gen_loss, losses, _ = generator_loss(model, crit, x.to(device), y.to(device))
+    gen_loss.backward()
+    # oracle
+    y_ = H.generator(PG, x)
+    mel_l = (A.mel_spectrogram(y_[:, 0]) - A.mel_spectrogram(y[:, 0])).abs().mean()
+    adv, fm = 0.0, 0.0
+    for P, f in ((P2, H.msd), (P1, H.mpd)):
+        o_h, f_h = f(P, y_)
+        adv = adv + H.gen_adv_loss(o_h)
+        with torch.no_grad():
+            _, f_r = f(P, y)
+        fm = fm + H.feat_match_loss(f_r, [[t.detach() for t in fl] for fl in f_h])
+    ref = 45.0 * mel_l + adv + 2.0 * fm
+    ref.backward()
+    assert abs(float(losses["mel_loss"]) - float(mel_l)) < 1e-4
+    assert abs(float(losses["adversarial_loss"]) - float(adv)) < 1e-4 * max(1.0, float(adv))
+    assert abs(float(gen_loss) - float(ref)) < 2e-4 * max(1.0, abs(float(ref)))
+    for n, p in model["generator"].named_parameters():
+        assert rel_l2(p.grad.cpu(), PG[n].grad) < 5e-3, "G " + n
+    for d in model["discriminator"].values():
+        d.zero_grad()
+    dis_loss, _ = discriminator_loss(model, crit, x.to(device), y.to(device))
+    dis_loss.backward()
+    for P in (P1, P2):
+        for v in P.values():
+            v.grad = None
+    ref_d = 0.0
+    with torch.no_grad():
+        y2 = H.generator(PG, x)
+    for P, f in ((P2, H.msd), (P1, H.mpd)):
+        real, fake = H.dis_adv_loss(f(P, y2)[0], f(P, y)[0])
+        ref_d = ref_d + real + fake
+    ref_d.backward()
+    assert abs(float(dis_loss) - float(ref_d)) < 1e-4 * max(1.0, float(ref_d))
+    for P, key in ((P1, "MultiPeriodDiscriminator"), (P2, "MultiScaleDiscriminator")):
+        for n, p in model["discriminator"][key].named_parameters():
+            assert rel_l2(p.grad.cpu(), P[n].grad) < 5e-3, key + " " + n
+
+
+def test_gan_step_losses_emulated():
+    with emulation():
+        _gan_losses_check("cpu", channels=16, B=1, frames=8)
+
+
+@pytest.mark.gpu
+def test_gan_step_losses_gpu():
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _gan_losses_check("cuda", channels=64, B=2, frames=16)
+
+
+@pytest.mark.gpu
+def test_gan_train_step_runs_and_updates():
+    """Full step through model_builder / ArenaAdam / MultiStepLR at a reduced width: parameters move, losses finite."""
+    import kantts._hip as hip
+    from kantts.models import model_builder
+    from kantts.train.gan_step import gan_train_step
+    from kantts.train.loss import criterion_builder
+
+    hip.set_precision("fp32")
+    opt = {"type": "Adam", "params": {"lr": 2e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}}
+    sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [200000]}}
+    config = {"model_type": "hifigan", "Model": {
+        "Generator": {"params": {"channels": 64}, "optimizer": opt, "scheduler": sch},
+        "MultiScaleDiscriminator": {"params": {}, "optimizer": opt, "scheduler": sch},
+        "MultiPeriodDiscriminator": {"params": {}, "optimizer": opt, "scheduler": sch}},
+        "Loss": {"generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "stft_loss": {"enable": False},
+                 "mel_loss": {"enable": True, "params": {}, "weights": 45.0},
+                 "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+        "generator_grad_norm": -1, "discriminator_grad_norm": -1, "discriminator_train_start_steps": 0,
+        "generator_train_start_steps": 0}
+    torch.manual_seed(0)
+    model, optimizer, scheduler = model_builder(config, device="cuda")
+    crit = criterion_builder(config, device="cuda")
+    x = torch.randn(2, 80, 16, device="cuda")
+    y = torch.randn(2, 1, 4096, device="cuda").clamp(-1, 1)
+    w0 = optimizer["generator"].arena.flat.clone()
+    for it in range(2):
+        out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
+    assert all(torch.isfinite(torch.as_tensor(float(v))) for v in out.values())
+    assert float((optimizer["generator"].arena.flat - w0).abs().max()) > 0

@@ -65,3 +65,29 @@ def test_melspec_linearity_and_batch_independence_full_size():
     assert float(((b - a) - 1.6)[inside].abs().max()) < 2e-4
     one = ms(x[5:6])
     assert torch.equal(one, a[5:6])
+
+
+def _check_backward(device):
+    """d(mel L1 loss)/d(wav): kernel (or emulated ABI) vs autograd through oracle/audio_oracle.py."""
+    from kantts.utils.audio_torch import MelSpectrogram
+
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 4096, generator=g) * 0.1
+    tgt = A.mel_spectrogram(torch.randn(3, 4096, generator=g) * 0.1)
+    xr = x.clone().requires_grad_(True)
+    (A.mel_spectrogram(xr) - tgt).abs().mean().backward()
+    ms = MelSpectrogram().to(device)
+    xd = x.clone().to(device).requires_grad_(True)
+    (ms(xd[:, None, :]) - tgt.to(device)).abs().mean().backward()
+    err = (xd.grad.cpu() - xr.grad).norm() / xr.grad.norm()
+    assert float(err) < 2e-3, float(err)
+
+
+def test_melspec_backward_emulated():
+    with emulation():
+        _check_backward("cpu")
+
+
+@pytest.mark.gpu
+def test_melspec_backward_gpu():
+    _check_backward("cuda")
