@@ -259,6 +259,38 @@ int kantts_weight_norm_bwd(const float* dw, const float* v, const float* g, floa
 int kantts_sinadd_fwd(const float* x, float* y, long long n, void* stream);
 int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, long long n, void* stream);
 
+/* Channels-last 1-D convolution with an LDS-resident input window (csrc/conv_win.hip): the im2col-free
+ * kernel behind Conv1d / CausalConv1d (kantts/models/hifigan/layers.py:15-91) and their input gradients.
+ *   for phase in [0, phases), m in [0, ceil((Tdst - phase) / phases)):      d = m*phases + phase
+ *     out[b,d,n] = post( bias[n] + sum_{k : u_k % in_div == 0} sum_c pre(in[b, m*in_mul + u_k/in_div, g*CR + c]) * w[k][n][c] )
+ *     u_k = in_add + phase + k*in_kstep;  taps whose source token falls outside [0, Tsrc) contribute 0;
+ *     g = n / NG is the group of output channel n (Ntot = groups*NG outputs, Cin_tot = groups*CR inputs).
+ *   pre(v)  : LeakyReLU(in_slope) when in_act, then v *= (in_gate > 0 ? 1 : in_gate_slope) when in_gate
+ *   post(v) : LeakyReLU(out_slope) when out_act, + res, then *= (out_gate > 0 ? 1 : out_gate_slope)
+ * forward : in_mul = stride, in_add = -pad, in_kstep = dilation, in_div = 1, phases = 1
+ * dgrad   : in = dy, in_mul = 1, in_add = pad, in_kstep = -dilation, in_div = phases = stride
+ * w is tap-major (K, Ntot, CR) fp32.  KANTTS_E_UNSUPPORTED when CR / Cin_tot are not multiples of 4,
+ * pointers are not 16-byte aligned, or K > 64 -- callers then use kantts_gemm_seg_launch. */
+typedef struct {
+  const float* in;
+  const float* in_gate;
+  const float* w;
+  float* out;
+  const float* bias;
+  const float* res;
+  const float* out_gate;
+  int B, Tsrc, Tdst, Cin_tot, Ntot, CR, NG, groups, K;
+  int in_mul, in_add, in_kstep, in_div, phases;
+  float in_slope;
+  int in_act;
+  float in_gate_slope;
+  float out_slope;
+  int out_act;
+  float out_gate_slope;
+  int precision; /* 0 fp32 MFMA, 1 bf16 MFMA (fp32 accumulate) */
+} kantts_conv_args;
+int kantts_conv_win_launch(const kantts_conv_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

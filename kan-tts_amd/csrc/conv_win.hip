@@ -1,0 +1,330 @@
+// Channels-last 1-D convolution with an LDS-resident input window (im2col-free).
+//
+// Replaces the per-tap token-shifted GEMM of gemm_fast.hip for the HiFi-GAN convolutions: there every
+// tap of a K-tap kernel re-reads its 64 x BK activation tile from L2/HBM (K = 3 ... 41 reads of every
+// input element).  Here a workgroup loads the window of input tokens its BQ outputs can touch
+//        W = (BQ-1)*in_mul + (off_max - off_min) + 1   tokens x 32 channels
+// ONCE per 32-channel chunk into LDS (LeakyReLU / LeakyReLU' gate applied and rounded to bf16 on the way
+// in) and walks the K taps over it: tap k multiplies the window rows  m*in_mul + off_k  with the tap's
+// 32 x BN weight tile on MFMA.  Only the weight tile (BN x 32, L2 resident) is fetched per tap, register
+// double-buffered against the MFMAs of the previous tap.
+//
+// One kernel covers
+//   forward   y[b,q,n]  = post( bias[n] + sum_k sum_c pre(x[b, q*stride + k*dil - pad, c]) w[k][n][c] )
+//   dgrad     dx[b,t,c] = post( sum_k sum_n pre(dy[b, (t + pad - k*dil)/stride, n]) w'[k][c][n] )
+// through the token rule   src = m*in_mul + (in_add + phase + k*in_kstep) / in_div   (exact division only),
+// dst = m*phases + phase: a strided convolution's input gradient is computed per output phase, so its
+// rows are dense (no zero-stuffed rows reach the MFMAs).  Strided windows are stored de-interleaved by
+// (token mod in_mul) so the 16 rows of an MFMA fragment are consecutive LDS rows for every stride.
+//
+// Reference: Conv1d / CausalConv1d of kantts/models/hifigan/layers.py:15-91 as used by the generator's
+// residual blocks (layers.py:168-288), conv_pre/conv_post (hifigan.py:40-66,118-160) and the scale
+// discriminators (hifigan.py:332-407).
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define CW_THREADS 256
+#define CW_CK 32        // channels per chunk = one bf16 MFMA k-step
+#define CW_MAXTAPS 64
+
+__device__ __forceinline__ int cw_floordiv(int a, int b) {
+  int q = a / b;
+  if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+  return q;
+}
+
+template <bool BF16>
+__device__ __forceinline__ void cw_store4(void* base, int idx, float v0, float v1, float v2, float v3) {
+  if (BF16) {
+    bf16x4 p = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) = p;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = make_float4(v0, v1, v2, v3);
+  }
+}
+
+// WM waves along the output tokens (4 or 2), the other 4/WM along the output channels;
+// every wave owns MREP x 4 accumulator fragments (16*MREP tokens x 64 channels).
+template <bool BF16, int WM, int MREP>
+__global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_args g) {
+  constexpr int WN = 4 / WM;
+  constexpr int BQ = WM * MREP * 16;
+  constexpr int BN = WN * 64;
+  // bf16 rows are 96 B apart (32 mod 64: conflict-free ds_read_b128 over 16 consecutive rows); fp32 rows 144 B
+  constexpr int LDW = BF16 ? 48 : 36;
+  constexpr int ESZ = BF16 ? 2 : 4;
+  constexpr int NBV = BN * 8 / CW_THREADS;  // float4 per thread of one weight tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds[];
+  __shared__ int s_off[CW_MAXTAPS], s_tap[CW_MAXTAPS];
+  __shared__ int s_nv;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int ntpg = (g.NG + BN - 1) / BN;
+  const int grp = blockIdx.x / ntpg;
+  const int n0 = grp * g.NG + (blockIdx.x % ntpg) * BN;
+  const int n_end = (grp + 1) * g.NG;
+  const int b = blockIdx.z / g.phases;
+  const int phase = blockIdx.z % g.phases;
+  const int m0 = blockIdx.y * BQ;
+  const int mrows = (g.Tdst - phase + g.phases - 1) / g.phases;
+  if (m0 >= mrows) return;
+
+  if (tid == 0) {
+    int nv = 0;
+    for (int k = 0; k < g.K; ++k) {
+      const int u = g.in_add + phase + k * g.in_kstep;
+      const int q = cw_floordiv(u, g.in_div);
+      if (q * g.in_div != u) continue;
+      s_off[nv] = q;
+      s_tap[nv] = k;
+      ++nv;
+    }
+    s_nv = nv;
+  }
+  __syncthreads();
+  const int nv = s_nv;
+  int offmin = 0, offmax = 0;
+  if (nv > 0) {
+    offmin = s_off[0];
+    offmax = s_off[0];
+    for (int i = 1; i < nv; ++i) {
+      offmin = min(offmin, s_off[i]);
+      offmax = max(offmax, s_off[i]);
+    }
+  }
+  const int W = (BQ - 1) * g.in_mul + (offmax - offmin) + 1;
+  const int Wp = (W + g.in_mul - 1) / g.in_mul;
+  const int lo = m0 * g.in_mul + offmin;  // first source token of the window
+
+  void* win = cw_lds;
+  unsigned char* bt = cw_lds + (size_t)Wp * g.in_mul * LDW * ESZ;
+
+  f32x4 acc[MREP][4];
+#pragma unroll
+  for (int f = 0; f < MREP; ++f)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* in_b = g.in + (long long)b * g.Tsrc * g.Cin_tot + (long long)grp * g.CR;
+  const float* gate_b = g.in_gate ? g.in_gate + (long long)b * g.Tsrc * g.Cin_tot + (long long)grp * g.CR : nullptr;
+  const int c4 = (tid & 7) * 4;  // channel offset of this thread's float4 inside a chunk
+  const int rslot = tid >> 3;    // 32 rows per pass
+
+  float4 wreg[NBV];
+  auto fetch_w = [&](int ti, int c0) {
+    const int k = s_tap[ti];
+#pragma unroll
+    for (int v = 0; v < NBV; ++v) {
+      const int j = rslot + 32 * v;
+      const bool ok = (n0 + j < n_end) && (c0 + c4 < g.CR);
+      const long long o = ok ? (((long long)k * g.Ntot + n0 + j) * g.CR + c0 + c4) : 0;
+      float4 x = *reinterpret_cast<const float4*>(g.w + o);
+      if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+      wreg[v] = x;
+    }
+  };
+  auto commit_w = [&](int buf) {
+    void* dst = bt + (size_t)buf * BN * LDW * ESZ;
+#pragma unroll
+    for (int v = 0; v < NBV; ++v) {
+      const int j = rslot + 32 * v;
+      cw_store4<BF16>(dst, j * LDW + c4, wreg[v].x, wreg[v].y, wreg[v].z, wreg[v].w);
+    }
+  };
+
+  for (int c0 = 0; c0 < g.CR && nv > 0; c0 += CW_CK) {
+    __syncthreads();  // every wave is done with the previous chunk's window and weight tiles
+    fetch_w(0, c0);
+    // ---- stage the window: W tokens x 32 channels, 4 rows in flight per thread
+    const bool cok = (c0 + c4) < g.CR;
+    for (int r0 = rslot; r0 < W; r0 += 32 * 4) {
+      float4 xv[4], gv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rel = r0 + 32 * u;
+        const int t = lo + rel;
+        ok[u] = cok && rel < W && t >= 0 && t < g.Tsrc;
+        const long long o = ok[u] ? ((long long)t * g.Cin_tot + c0 + c4) : 0;
+        xv[u] = *reinterpret_cast<const float4*>(in_b + o);
+        if (gate_b) gv[u] = *reinterpret_cast<const float4*>(gate_b + o);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rel = r0 + 32 * u;
+        if (rel >= W) continue;
+        float v0 = xv[u].x, v1 = xv[u].y, v2 = xv[u].z, v3 = xv[u].w;
+        if (!ok[u]) v0 = v1 = v2 = v3 = 0.f;
+        if (g.in_act) {
+          v0 = v0 > 0.f ? v0 : v0 * g.in_slope;
+          v1 = v1 > 0.f ? v1 : v1 * g.in_slope;
+          v2 = v2 > 0.f ? v2 : v2 * g.in_slope;
+          v3 = v3 > 0.f ? v3 : v3 * g.in_slope;
+        }
+        if (gate_b && ok[u]) {
+          v0 *= (gv[u].x > 0.f) ? 1.f : g.in_gate_slope;
+          v1 *= (gv[u].y > 0.f) ? 1.f : g.in_gate_slope;
+          v2 *= (gv[u].z > 0.f) ? 1.f : g.in_gate_slope;
+          v3 *= (gv[u].w > 0.f) ? 1.f : g.in_gate_slope;
+        }
+        const int row = (rel % g.in_mul) * Wp + rel / g.in_mul;
+        cw_store4<BF16>(win, row * LDW + c4, v0, v1, v2, v3);
+      }
+    }
+    commit_w(0);
+    __syncthreads();
+
+    for (int ti = 0; ti < nv; ++ti) {
+      if (ti + 1 < nv) fetch_w(ti + 1, c0);
+      const int a = s_off[ti] - offmin;
+      const int rbase = (a % g.in_mul) * Wp + a / g.in_mul + wm * (MREP * 16) + (lane & 15);
+      const unsigned char* bcur = bt + (size_t)(ti & 1) * BN * LDW * ESZ;
+      if (BF16) {
+        const __bf16* Wh = reinterpret_cast<const __bf16*>(win);
+        const __bf16* Bh = reinterpret_cast<const __bf16*>(bcur);
+        bf16x8 af[MREP], bfr[4];
+#pragma unroll
+        for (int f = 0; f < MREP; ++f)
+          af[f] = *reinterpret_cast<const bf16x8*>(&Wh[(rbase + f * 16) * LDW + (lane >> 4) * 8]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * 64 + j * 16 + (lane & 15)) * LDW + (lane >> 4) * 8]);
+#pragma unroll
+        for (int f = 0; f < MREP; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfr[j], acc[f][j], 0, 0, 0);
+      } else {
+        const float* Wf = reinterpret_cast<const float*>(win);
+        const float* Bf = reinterpret_cast<const float*>(bcur);
+#pragma unroll
+        for (int ks = 0; ks < CW_CK / 4; ++ks) {
+          float af[MREP], bfr[4];
+#pragma unroll
+          for (int f = 0; f < MREP; ++f) af[f] = Wf[(rbase + f * 16) * LDW + ks * 4 + (lane >> 4)];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bfr[j] = Bf[(wn * 64 + j * 16 + (lane & 15)) * LDW + ks * 4 + (lane >> 4)];
+#pragma unroll
+          for (int f = 0; f < MREP; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], bfr[j], acc[f][j], 0, 0, 0);
+        }
+      }
+      if (ti + 1 < nv) commit_w((ti + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: each wave transposes its fragments through a private 16 x 68 float LDS strip so that 16
+  // lanes write one 256-byte output row (bias, LeakyReLU, residual and LeakyReLU' gate fused)
+  __syncthreads();
+  float* strip = reinterpret_cast<float*>(cw_lds) + wave * (16 * 68);
+  const bool vec_ok = ((g.Ntot & 3) == 0) && ((g.NG & 3) == 0) && (((uintptr_t)g.out & 15) == 0) &&
+                      (!g.res || ((uintptr_t)g.res & 15) == 0) && (!g.out_gate || ((uintptr_t)g.out_gate & 15) == 0);
+#pragma unroll
+  for (int f = 0; f < MREP; ++f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) strip[((lane >> 4) * 4 + r) * 68 + j * 16 + (lane & 15)] = acc[f][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rl = p * 4 + (lane >> 4);
+      const int m = m0 + wm * (MREP * 16) + f * 16 + rl;
+      const int n = n0 + wn * 64 + (lane & 15) * 4;
+      if (m < mrows && n < n_end) {
+        const long long d = (long long)m * g.phases + phase;
+        const long long o = ((long long)b * g.Tdst + d) * g.Ntot + n;
+        const float4 a4 = *reinterpret_cast<const float4*>(&strip[rl * 68 + (lane & 15) * 4]);
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        const int cnt = min(4, n_end - n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (e < cnt) {
+            float x = v[e];
+            if (g.bias) x += g.bias[n + e];
+            if (g.out_act) x = x > 0.f ? x : x * g.out_slope;
+            if (g.res) x += g.res[o + e];
+            if (g.out_gate) x *= (g.out_gate[o + e] > 0.f) ? 1.f : g.out_gate_slope;
+            v[e] = x;
+          }
+        }
+        if (vec_ok && cnt == 4) {
+          *reinterpret_cast<float4*>(g.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int e = 0; e < cnt; ++e) g.out[o + e] = v[e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <bool BF16, int WM, int MREP>
+static int cw_launch(const kantts_conv_args& g, hipStream_t st) {
+  constexpr int WN = 4 / WM;
+  constexpr int BQ = WM * MREP * 16;
+  constexpr int BN = WN * 64;
+  constexpr int LDW = BF16 ? 48 : 36;
+  constexpr int ESZ = BF16 ? 2 : 4;
+  // worst-case window over the phases: the valid taps of a phase span at most (K-1)*|kstep|/div + 1 offsets
+  const int span = ((g.K - 1) * abs(g.in_kstep)) / g.in_div + 1;
+  const int W = (BQ - 1) * g.in_mul + span + 1;
+  const int Wp = (W + g.in_mul - 1) / g.in_mul;
+  size_t lds = (size_t)Wp * g.in_mul * LDW * ESZ + 2 * (size_t)BN * LDW * ESZ;
+  const size_t strip = 4 * 16 * 68 * sizeof(float);
+  if (lds < strip) lds = strip;
+  if (lds > 160 * 1024 - 1024) return KANTTS_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<BF16, WM, MREP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int mrows = (g.Tdst + g.phases - 1) / g.phases;
+  const int ntpg = (g.NG + BN - 1) / BN;
+  dim3 grid(g.groups * ntpg, kantts_cdiv(mrows, BQ), g.B * g.phases);
+  hipLaunchKernelGGL((conv_win_kernel<BF16, WM, MREP>), grid, dim3(CW_THREADS), lds, st, g);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_conv_win_launch(const kantts_conv_args* a, void* stream) {
+  if (!a || !a->in || !a->w || !a->out) return KANTTS_E_BADARG;
+  const kantts_conv_args& g = *a;
+  if (g.B < 0 || g.Tsrc < 0 || g.Tdst < 0 || g.K < 1 || g.groups < 1 || g.NG < 1 || g.CR < 1 || g.in_mul < 1 ||
+      g.in_div < 1 || g.phases < 1)
+    return KANTTS_E_BADARG;
+  if (g.Ntot != g.groups * g.NG || g.Cin_tot != g.groups * g.CR) return KANTTS_E_BADARG;
+  if (g.K > CW_MAXTAPS) return KANTTS_E_UNSUPPORTED;
+  // float4 staging of activations and weights
+  if ((g.CR & 3) || (g.Cin_tot & 3) || ((uintptr_t)g.in & 15) || ((uintptr_t)g.w & 15) ||
+      (g.in_gate && ((uintptr_t)g.in_gate & 15)))
+    return KANTTS_E_UNSUPPORTED;
+  if ((long long)g.B * g.phases > 65535) return KANTTS_E_UNSUPPORTED;
+  if (g.B == 0 || g.Tdst == 0) return KANTTS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int mrows = (g.Tdst + g.phases - 1) / g.phases;
+  const bool wide = (g.NG >= 128) && (mrows >= 128);
+  const bool tall = mrows >= 96;
+  if (g.precision == 1) {
+    if (wide) return cw_launch<true, 2, 4>(g, st);
+    if (tall) return cw_launch<true, 4, 2>(g, st);
+    return cw_launch<true, 4, 1>(g, st);
+  } else if (g.precision == 0) {
+    if (wide) return cw_launch<false, 2, 4>(g, st);
+    if (tall) return cw_launch<false, 4, 2>(g, st);
+    return cw_launch<false, 4, 1>(g, st);
+  }
+  return KANTTS_E_BADARG;
+}

@@ -26,17 +26,66 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define F_THREADS 256
 
 __device__ __forceinline__ float f_epilogue(const kantts_gemm_args& g, float acc, int i, int j, bool first_slice,
-                                            uint64_t seed_off) {
+                                            uint64_t seed_off, int grp) {
   float v = acc;
-  if (first_slice && g.bias) v += g.bias[j];
-  if (first_slice && g.bias2) v += g.bias2[j];
+  if (first_slice && g.bias) v += g.bias[j + grp * g.bias_gs];
+  if (first_slice && g.bias2) v += g.bias2[j + grp * g.bias_gs];
   v *= g.alpha;
   if (g.relu) v = fmaxf(v, 0.f);
+  if (g.out_act) v = v > 0.f ? v : v * g.out_slope;
   if (g.drop_p > 0.f)
     v *= kantts_dropout_scale(g.drop_p, g.drop_seed + seed_off, (uint64_t)i * (uint64_t)g.N + (uint64_t)j);
-  if (first_slice && g.res) v += g.res[(long long)i * g.r_is + (long long)j * g.r_js];
+  if (first_slice && g.res) v += g.res[(long long)i * g.r_is + (long long)j * g.r_js + grp * g.r_gs];
+  if (g.gate) {
+    const float gv = g.gate[(long long)i * g.c_is + (long long)j * g.c_js + grp * g.c_gs];
+    v *= (gv > 0.f) ? 1.f : g.gate_slope;
+  }
   if (g.rowmask && g.rowmask[i]) v = 0.f;
   return v;
+}
+
+struct FMap {
+  int inner, Tq, Tsrc, mul, div, up;
+  bool plain;
+};
+
+__device__ __forceinline__ FMap f_make_map(int inner, int Tq, int Tsrc, int mul, int div, int up, int T) {
+  FMap m;
+  m.inner = inner > 0 ? inner : 1;
+  m.Tq = Tq > 0 ? Tq : T;
+  m.Tsrc = Tsrc > 0 ? Tsrc : T;
+  m.mul = mul > 0 ? mul : 1;
+  m.div = div > 0 ? div : 1;
+  m.up = up > 0 ? up : 1;
+  m.plain = (m.inner == 1 && m.mul == 1 && m.div == 1 && m.up == 1 && m.Tq == m.Tsrc);
+  return m;
+}
+
+// token of the (B, Tq, inner) domain -> source row (see gemm.hip::map_token); plain maps take the cheap path
+__device__ __forceinline__ bool f_map_token(int tok, int shift, const FMap& m, long long& row) {
+  if (m.plain) {
+    if (shift == 0) {
+      row = tok;
+      return true;
+    }
+    const int t = tok % m.Tq + shift;
+    row = (long long)tok + shift;
+    return t >= 0 && t < m.Tq;
+  }
+  const int pi = tok % m.inner;
+  const int bq = tok / m.inner;
+  const int q = bq % m.Tq;
+  const int b = bq / m.Tq;
+  int t = q * m.mul + shift;
+  if (t < 0) return false;
+  if (m.div > 1) {
+    if (t % m.div) return false;
+    t /= m.div;
+  }
+  if (t >= m.Tsrc * m.up) return false;
+  t /= m.up;
+  row = ((long long)b * m.Tsrc + t) * m.inner + pi;
+  return true;
 }
 
 // 4 consecutive k of one LDS row
@@ -72,16 +121,23 @@ struct Stager {
   long long rs, ks;  // row stride (k-vector layout) / k stride (row-vector layout)
   long long base[ROWVEC ? NB : NVK];
   bool rok[ROWVEC ? NB : NVK];
-  int klen, shift, tok_axis, T;
+  int klen, shift, tok_axis, T, act;
+  float slope;
+  FMap map;
   const uint8_t* kmask;
 
   __device__ __forceinline__ void setup(const kantts_gemm_seg& s, const kantts_gemm_args& g, int row0, int nrows,
-                                        int tap) {
+                                        int tap, int grp) {
     const int tid = threadIdx.x;
-    p = IS_A ? s.a : s.b;
-    gp = IS_A ? s.a_gate : nullptr;
+    const long long goff = (long long)grp * (IS_A ? g.a_gs : g.b_gs);
+    p = (IS_A ? s.a : s.b) + goff;
+    gp = (IS_A && s.a_gate) ? s.a_gate + goff : nullptr;
     klen = s.klen;
     T = g.T;
+    act = IS_A ? s.a_act : s.b_act;
+    slope = IS_A ? s.a_slope : s.b_slope;
+    map = IS_A ? f_make_map(s.a_inner, s.a_Tq, s.a_Tsrc, s.a_mul, s.a_div, s.a_up, g.T)
+               : f_make_map(s.b_inner, s.b_Tq, s.b_Tsrc, s.b_mul, s.b_div, s.b_up, g.T);
     tok_axis = IS_A ? s.a_tok_axis : s.b_tok_axis;
     shift = tok_axis ? (IS_A ? s.a_shift0 + tap * s.a_shift_step : s.b_shift0 + tap * s.b_shift_step) : 0;
     kmask = IS_A ? g.kmask : nullptr;
@@ -104,11 +160,7 @@ struct Stager {
         const int row = row0 + tid / LPR + RPP * v;
         bool okr = row < nrows;
         long long rr = row;
-        if (IS_A && tok_axis == 1 && shift != 0) {
-          const int t = row % T + shift;
-          okr = okr && t >= 0 && t < T;
-          rr = row + shift;
-        }
+        if (IS_A && tok_axis == 1) okr = f_map_token(row, shift, map, rr) && okr;
         rok[v] = okr;
         base[v] = rr * rs + (tid % LPR) * 4 + tapoff;
       }
@@ -129,11 +181,7 @@ struct Stager {
           const int kk = kb + e;
           bool o = rok[v] && kk < klen;
           long long kq = kk;
-          if (tok_axis == 2 && shift != 0) {
-            const int t = kk % T + shift;
-            o = o && t >= 0 && t < T;
-            kq = kk + shift;
-          }
+          if (tok_axis == 2) o = f_map_token(kk, shift, map, kq) && o;
           if (kmask && o) o = kmask[kk] == 0;
           const long long f = o ? (kq * ks + base[v]) : 0;
           r[v * 4 + e] = *reinterpret_cast<const float4*>(p + f);
@@ -156,6 +204,7 @@ struct Stager {
   __device__ __forceinline__ float fix(float x, float gate, int reg, int lane_e, const kantts_gemm_seg& s,
                                        uint64_t seed_off) const {
     float v = ((ok >> reg) & 1u) ? x : 0.f;
+    if (act) v = v > 0.f ? v : v * slope;
     if (IS_A) {
       if (gp && !(gate > 0.f)) v *= s.a_gate_slope;
       if (s.a_drop_p > 0.f) {
@@ -164,7 +213,7 @@ struct Stager {
         if (ROWVEC) {
           const int id = threadIdx.x + F_THREADS * (reg >> 2);
           long long kq = cur_k0 + (id / RG) * 4 + (reg & 3);
-          if (tok_axis == 2) kq += shift;
+          if (tok_axis == 2) f_map_token((int)kq, shift, map, kq);
           o = kq * ks + base[reg >> 2] + lane_e;
         } else {
           o = base[reg] + cur_k0 + lane_e;
@@ -215,7 +264,9 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   // deep reduction tiles only when there are many of them to amortise (K >= 512, split-K weight gradients);
   // short-K launches (the 128 -> 1024 projections) want occupancy instead: BK = 32 keeps them at ~70 VGPRs
   constexpr int BK = BIGK ? (BF16 ? 128 : 64) : 32;
-  constexpr int LD = BF16 ? (BK + 8) : (BK + 4);  // elements per LDS row (16-byte padded)
+  // elements per LDS row: bf16 rows are 32 bytes (mod 64) apart, the pitch at which the 16-lane groups of
+  // ds_read_b128 touch 64 distinct banks (80- and 272-byte pitches are 2-way conflicted)
+  constexpr int LD = BF16 ? (BK + 16) : (BK + 4);
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int OPB = (BM + F_BN) * LD * ESZ, CSB = BM * (F_BN + 4) * 4;  // operand tiles / epilogue staging
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[OPB > CSB ? OPB : CSB];
@@ -229,7 +280,11 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   const int wr = wave >> 1, wc = wave & 1;
   const int i0 = blockIdx.y * BM;
   const int j0 = blockIdx.x * F_BN;
-  const int zslice = blockIdx.z;
+  const int zper = g.groups * g.splitk;
+  const int ztap = g.z_taps > 0 ? (int)(blockIdx.z / zper) : -1;  // one tap per z-slab (conv weight gradients)
+  const int zrem = blockIdx.z % zper;
+  const int grp = zrem / g.splitk;
+  const int zslice = zrem % g.splitk;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
 
   f32x4 acc[MREP][2];
@@ -238,7 +293,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float rowsum = 0.f;
-  const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0);
+  const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0) && (ztap <= 0);
 
   Stager<BF16, BM, BK, A_ROW, true, LD> sa;
   Stager<BF16, F_BN, BK, B_ROW, false, LD> sb;
@@ -248,8 +303,9 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
     const kantts_gemm_seg& s = g.seg[sidx];
     const int ntile = (s.klen + BK - 1) / BK;
     for (int tap = 0; tap < s.ntaps; ++tap) {
-      sa.setup(s, g, i0, g.M, tap);
-      sb.setup(s, g, j0, g.N, tap);
+      if (ztap >= 0 && tap != ztap) continue;
+      sa.setup(s, g, i0, g.M, tap, grp);
+      sb.setup(s, g, j0, g.N, tap, grp);
       // rows are block-relative inside the stagers' LDS writes: shift the bases instead of the row ids
       auto next_owned = [&](int from) {
         int q = from;
@@ -326,7 +382,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
     }
   }
 
-  if (do_rowsum && tid < BM && (i0 + tid) < g.M) atomicAdd(&g.a_rowsum[i0 + tid], rowsum);
+  if (do_rowsum && tid < BM && (i0 + tid) < g.M) atomicAdd(&g.a_rowsum[i0 + tid + grp * g.bias_gs], rowsum);
 
   const bool first_slice = (zslice == 0);
   // ---- coalesced epilogue: accumulators go through LDS so that 16 lanes write one 256-byte output row
@@ -334,7 +390,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   // 128->1024 projections the slowest part of the kernel)
   const bool vec_out = !g.accumulate && g.c_js == 1 && (g.c_is & 3) == 0 && ((uintptr_t)g.c & 15) == 0 &&
                        (!g.res || (g.r_js == 1 && (g.r_is & 3) == 0 && ((uintptr_t)g.res & 15) == 0)) &&
-                       (g.N & 3) == 0;
+                       (g.N & 3) == 0 && g.groups <= 1 && !g.gate && ztap < 0;
   if (vec_out) {
     constexpr int CLD = F_BN + 4;
     float* Cs = reinterpret_cast<float*>(lds_raw);  // BM x 68 floats <= the operand tiles
@@ -366,6 +422,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
           if (g.bias2) val += g.bias2[j + e];
           val *= g.alpha;
           if (g.relu) val = fmaxf(val, 0.f);
+          if (g.out_act) val = val > 0.f ? val : val * g.out_slope;
           if (g.drop_p > 0.f)
             val *= kantts_dropout_scale(g.drop_p, g.drop_seed + seed_off, (uint64_t)i * (uint64_t)g.N + (uint64_t)(j + e));
           val += rr[e];
@@ -385,8 +442,9 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
         const int i = i0 + wr * (BM / 2) + m * 16 + (lane >> 4) * 4 + r;
         const int j = j0 + wc * 32 + n * 16 + (lane & 15);
         if (i < g.M && j < g.N) {
-          const float v = f_epilogue(g, acc[m][n][r], i, j, first_slice, seed_off);
-          float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js];
+          const float v = f_epilogue(g, acc[m][n][r], i, j, first_slice, seed_off, grp);
+          float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js + (long long)grp * g.c_gs +
+                            (ztap > 0 ? (long long)ztap * g.c_tap : 0)];
           if (g.accumulate)
             atomicAdd(dst, v);
           else
@@ -413,9 +471,14 @@ static void launch_fast2(const kantts_gemm_args& g, bool a_row, bool b_row, dim3
 template <bool BF16, int BM>
 static void launch_fast(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 grid, hipStream_t st) {
   long long ktot = 0;
-  for (int s = 0; s < g.nseg; ++s) ktot += (long long)g.seg[s].klen * g.seg[s].ntaps;
+  int kmin = 1 << 30;
+  for (int s = 0; s < g.nseg; ++s) {
+    ktot += (long long)g.seg[s].klen * g.seg[s].ntaps;
+    kmin = g.seg[s].klen < kmin ? g.seg[s].klen : kmin;
+  }
   static const char* force_bk = getenv("KANTTS_GEMM_BIGK");
-  bool big = (ktot >= 512);
+  // a reduction tile never spans two taps / segments: deep tiles only pay when every run is at least one tile
+  bool big = (ktot >= 512) && (kmin >= (BF16 ? 128 : 64));
   if (force_bk) big = (force_bk[0] == '1');
   if (big)
     launch_fast2<BF16, BM, true>(g, a_row, b_row, grid, st);
@@ -425,27 +488,27 @@ static void launch_fast(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 
 
 // Returns 1 when the launch was taken by a fast kernel, 0 when the descriptor does not qualify.
 int kantts_gemm_try_fast(const kantts_gemm_args& g, hipStream_t st) {
-  if (g.precision > 1 || g.groups > 1 || g.z_taps > 0 || g.out_act || g.gate) return 0;
+  if (g.precision > 1) return 0;
   const int am = g.seg[0].a_mode, bm = g.seg[0].b_mode;
   if (am < 2 || bm < 2) return 0;
   for (int s = 0; s < g.nseg; ++s) {
     const kantts_gemm_seg& sg = g.seg[s];
     if (sg.a_mode != am || sg.b_mode != bm) return 0;
-    if (sg.a_inner || sg.a_Tq || sg.a_Tsrc || sg.a_mul || sg.a_div || sg.a_up) return 0;
-    if (sg.b_inner || sg.b_Tq || sg.b_Tsrc || sg.b_mul || sg.b_div || sg.b_up) return 0;
-    if (sg.a_act || sg.b_act) return 0;
     if (sg.a_tok_axis == 1 && am != 2) return 0;
     if (sg.a_tok_axis == 2 && am != 3) return 0;
     if (sg.b_tok_axis == 2 && bm != 3) return 0;
     if (sg.b_tok_axis == 1) return 0;
+    if (sg.a_drop_p > 0.f && g.groups > 1) return 0;  // dropout counters are group-relative here
   }
   const int splitk = g.splitk < 1 ? 1 : g.splitk;
-  const long long blocks64 = (long long)kantts_cdiv(g.N, F_BN) * kantts_cdiv(g.M, 64) * splitk;
+  const int groups = g.groups < 1 ? 1 : g.groups;
+  const int ztaps = g.z_taps > 0 ? g.z_taps : 1;
+  const long long blocks64 = (long long)kantts_cdiv(g.N, F_BN) * kantts_cdiv(g.M, 64) * splitk * groups * ztaps;
   static const char* force_bm = getenv("KANTTS_GEMM_BM");
   bool small = blocks64 < 512;
   if (force_bm) small = (force_bm[0] == '3');
   const int bmr = small ? 32 : 64;
-  dim3 grid(kantts_cdiv(g.N, F_BN), kantts_cdiv(g.M, bmr), splitk);
+  dim3 grid(kantts_cdiv(g.N, F_BN), kantts_cdiv(g.M, bmr), splitk * groups * ztaps);
   const bool a_row = (am == 3), b_row = (bm == 3);
   if (g.precision == 1) {
     if (small)

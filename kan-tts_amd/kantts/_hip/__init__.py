@@ -51,6 +51,20 @@ class GemmArgs(Structure):
     ]
 
 
+class ConvArgs(Structure):
+    """kantts_conv_args (include/kantts_hip.h); ``in_`` is the C field ``in``."""
+    _fields_ = [
+        ("in_", c_void_p), ("in_gate", c_void_p), ("w", c_void_p), ("out", c_void_p), ("bias", c_void_p),
+        ("res", c_void_p), ("out_gate", c_void_p),
+        ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cin_tot", c_int32), ("Ntot", c_int32),
+        ("CR", c_int32), ("NG", c_int32), ("groups", c_int32), ("K", c_int32),
+        ("in_mul", c_int32), ("in_add", c_int32), ("in_kstep", c_int32), ("in_div", c_int32), ("phases", c_int32),
+        ("in_slope", c_float), ("in_act", c_int32), ("in_gate_slope", c_float),
+        ("out_slope", c_float), ("out_act", c_int32), ("out_gate_slope", c_float),
+        ("precision", c_int32),
+    ]
+
+
 def available() -> bool:
     return os.path.exists(LIB_PATH)
 
@@ -94,6 +108,7 @@ def lib():
         L.kantts_weight_norm_bwd.argtypes = [p, p, p, p, p, i, i, p]
         L.kantts_sinadd_fwd.argtypes = [p, p, ll, p]
         L.kantts_sinadd_bwd.argtypes = [p, p, p, ll, p]
+        L.kantts_conv_win_launch.argtypes = [POINTER(ConvArgs), c_void_p]
         _lib = L
     return _lib
 
@@ -104,7 +119,7 @@ EXPORTED_SYMBOLS = [
     "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
     "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_fsmn_dwconv_bwd_ws", "kantts_masked_l1",
     "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd",
-    "kantts_sinadd_fwd", "kantts_sinadd_bwd",
+    "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch",
 ]
 
 
@@ -231,6 +246,42 @@ def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_j
         _profile.append((e0, e1, 2.0 * M * N * max(1, groups) * sum(s.klen * s.ntaps for s in segs)))
         return
     check(lib().kantts_gemm_seg_launch(ctypes.byref(g), stream()), "gemm_seg")
+
+
+E_UNSUPPORTED = -2
+
+
+def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add, in_kstep, in_div, phases,
+             bias=None, res=None, in_gate=None, in_gate_slope=0.0, in_leaky=None, out_leaky=None, out_gate=None,
+             out_gate_slope=0.0):
+    """Windowed channels-last convolution (csrc/conv_win.hip).  Returns False when the kernel does not
+    support the shape (the caller then takes the segmented-GEMM route); raises on any other error."""
+    if _precision["gemm"] not in (PREC_FP32, PREC_BF16):
+        return False
+    g = ConvArgs()
+    g.in_, g.in_gate, g.w, g.out = ptr(x, torch.float32), ptr(in_gate, torch.float32), ptr(w_tap, torch.float32), \
+        ptr(out, torch.float32)
+    g.bias, g.res, g.out_gate = ptr(bias, torch.float32), ptr(res, torch.float32), ptr(out_gate, torch.float32)
+    g.B, g.Tsrc, g.Tdst = int(B), int(Tsrc), int(Tdst)
+    g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K = int(groups * CR), int(groups * NG), int(CR), int(NG), int(groups), int(K)
+    g.in_mul, g.in_add, g.in_kstep, g.in_div, g.phases = int(in_mul), int(in_add), int(in_kstep), int(in_div), int(phases)
+    if in_leaky is not None:
+        g.in_act, g.in_slope = 1, float(in_leaky)
+    if out_leaky is not None:
+        g.out_act, g.out_slope = 1, float(out_leaky)
+    g.in_gate_slope, g.out_gate_slope = float(in_gate_slope), float(out_gate_slope)
+    g.precision = _precision["gemm"]
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().kantts_conv_win_launch(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "conv_win")
+    if _profile is not None:
+        e1.record()
+        _profile.append((e0, e1, 2.0 * B * Tdst * groups * NG * CR * K / max(1, in_div)))
+    return True
 
 
 # ----------------------------------------------------------------------------------------------

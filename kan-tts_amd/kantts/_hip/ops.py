@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import (PREC_REF, check, gemm, lib, make_seg, ptr, rng_state, stream)
+from . import (PREC_REF, check, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
 
 _seed_counter = itertools.count(1)
 
@@ -689,7 +689,10 @@ class _ConvCL(torch.autograd.Function):
     ``up`` > 1 reads a nearest-neighbour-upsampled view of x (the x``up`` tensor of the reference's
     repeat_upsamples is never materialised); ``inner`` folds the period axis of the MPD; ``groups``
     batches grouped convolutions over gridDim.z.  LeakyReLU on the way in / out is fused in the
-    loader / epilogue.  Reference: kantts/models/hifigan/layers.py:15-91, hifigan.py:82-97,217-267,332-407.
+    loader / epilogue.  Weights are re-laid tap-major ((K, Cout, Cin_g) for forward / weight gradient,
+    (K, groups, Cin_g, Cout_g) for the input gradient) so that every operand has a unit-stride reduction
+    axis and the launches qualify for the vector-staged kernels of csrc/gemm_fast.hip.
+    Reference: kantts/models/hifigan/layers.py:15-91, hifigan.py:82-97,217-267,332-407.
     """
 
     @staticmethod
@@ -704,15 +707,21 @@ class _ConvCL(torch.autograd.Function):
         assert Cin_g * groups == Cin
         M = B * Tout * inner
         y = torch.empty((B, Tout, inner, Cout) if x.dim() == 4 else (B, Tout, Cout), device=x.device, dtype=torch.float32)
-        seg = make_seg(x, Cin, 1, w, Cin_g * K, K, Cin_g, ntaps=K, b_tap=1, a_tok_axis=1, a_shift0=-pad,
-                       a_shift_step=dil, a_map=dict(inner=inner, Tq=Tout, Tsrc=Tin, mul=stride, up=up),
-                       a_leaky=cfg["in_leaky"])
+        wt = w.permute(2, 0, 1).contiguous() if K > 1 else w  # (K, Cout, Cin_g)
         r = _c(res) if res is not None else None
-        gemm([seg], M, Cout_g, y, Cout, 1, bias=bias, res=r, r_is=Cout, r_js=1, groups=groups, a_gs=Cin_g,
-             b_gs=Cout_g * Cin_g * K, c_gs=Cout_g, bias_gs=Cout_g, r_gs=Cout_g, out_leaky=cfg["out_leaky"])
         ctx.cfg = cfg
         ctx.has = (bias is not None, res is not None)
         ctx.save_for_backward(x, w, y if cfg["out_leaky"] is not None else None)
+        if inner == 1 and up == 1 and conv_win(
+                x, wt, y, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K, in_mul=stride,
+                in_add=-pad, in_kstep=dil, in_div=1, phases=1, bias=bias, res=r, in_leaky=cfg["in_leaky"],
+                out_leaky=cfg["out_leaky"]):
+            return y
+        seg = make_seg(x, Cin, 1, wt, Cin_g, 1, Cin_g, ntaps=K, b_tap=Cout * Cin_g, a_tok_axis=1, a_shift0=-pad,
+                       a_shift_step=dil, a_map=dict(inner=inner, Tq=Tout, Tsrc=Tin, mul=stride, up=up),
+                       a_leaky=cfg["in_leaky"])
+        gemm([seg], M, Cout_g, y, Cout, 1, bias=bias, res=r, r_is=Cout, r_js=1, groups=groups, a_gs=Cin_g,
+             b_gs=Cout_g * Cin_g, c_gs=Cout_g, bias_gs=Cout_g, r_gs=Cout_g, out_leaky=cfg["out_leaky"])
         return y
 
     @staticmethod
@@ -731,28 +740,34 @@ class _ConvCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             Mx = B * Tin * inner
+            wd = w.view(groups, Cout_g, Cin_g, K).permute(3, 0, 2, 1).contiguous()  # (K, groups, Cin_g, Cout_g)
+            done = inner == 1 and up == 1 and conv_win(
+                dy, wd, dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups, CR=Cout_g, NG=Cin_g, K=K, in_mul=1, in_add=pad,
+                in_kstep=-dil, in_div=stride, phases=stride, in_gate=gate, in_gate_slope=gslope,
+                out_gate=x if cfg["in_leaky"] is not None else None, out_gate_slope=cfg["in_leaky"] or 0.0)
             first = True
-            for r in range(up):
+            for r in range(0 if done else up):
                 # x-domain token t receives dy[(t*up + r + pad - k*dil) / stride] (exact division only)
-                seg = make_seg(dy, Cout, 1, w, K, Cin_g * K, Cout_g, ntaps=K, b_tap=1, a_tok_axis=1,
+                seg = make_seg(dy, Cout, 1, wd, Cout_g, 1, Cout_g, ntaps=K, b_tap=Cin_g * Cout, a_tok_axis=1,
                                a_shift0=r + pad, a_shift_step=-dil,
                                a_map=dict(inner=inner, Tq=Tin, Tsrc=Tout, mul=up, div=stride), a_gate=gate,
                                a_gate_slope=gslope)
-                gemm([seg], Mx, Cin_g, dx, Cin, 1, groups=groups, a_gs=Cout_g, b_gs=Cout_g * Cin_g * K, c_gs=Cin_g,
+                gemm([seg], Mx, Cin_g, dx, Cin, 1, groups=groups, a_gs=Cout_g, b_gs=Cin_g * Cout_g, c_gs=Cin_g,
                      accumulate=not first, gate=x if cfg["in_leaky"] is not None else None,
                      gate_slope=cfg["in_leaky"] or 0.0)
                 first = False
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
+            dwt = gzeros((K, Cout, Cin_g), dy.device)
             if has_bias:
-                db = torch.zeros(Cout, device=dy.device, dtype=torch.float32)
+                db = gzeros((Cout,), dy.device)
             Mtok = B * Tout * inner
             seg = make_seg(dy, 1, Cout, x, 1, Cin, Mtok, ntaps=K, a_gate=gate, a_gate_slope=gslope, b_tok_axis=2,
                            b_shift0=-pad, b_shift_step=dil,
                            b_map=dict(inner=inner, Tq=Tout, Tsrc=Tin, mul=stride, up=up), b_leaky=cfg["in_leaky"])
-            gemm([seg], Cout_g, Cin_g, dw, Cin_g * K, K, groups=groups, a_gs=Cout_g, b_gs=Cin_g,
-                 c_gs=Cout_g * Cin_g * K, bias_gs=Cout_g, accumulate=True,
-                 splitk=_splitk_for(Cout_g * groups * K, Cin_g, Mtok), z_taps=K, c_tap=1, a_rowsum=db)
+            gemm([seg], Cout_g, Cin_g, dwt, Cin_g, 1, groups=groups, a_gs=Cout_g, b_gs=Cin_g,
+                 c_gs=Cout_g * Cin_g, bias_gs=Cout_g, accumulate=True,
+                 splitk=_splitk_for(Cout_g * groups * K, Cin_g, Mtok), z_taps=K, c_tap=Cout * Cin_g, a_rowsum=db)
+            dw = dwt.permute(1, 2, 0)
         elif has_bias and ctx.needs_input_grad[2]:
             raise RuntimeError("bias gradient without weight gradient is not supported")
         return dx, dw, db, (dy if has_res else None), None
@@ -773,7 +788,9 @@ def conv_cl(x, w, bias=None, *, stride=1, dilation=1, pad=0, Tout=None, up=1, gr
 class _ConvTransposeCL(torch.autograd.Function):
     """Causal polyphase ConvTranspose1d (kernel K = taps*stride, output trimmed to Tin*stride):
         y[b, q*s + r, co] = bias[co] + sum_j sum_ci act_in(x[b, q - j, ci]) w[ci, co, r + j*s]   (+ res)
-    One GEMM per output phase r (the s sub-filters of K/s taps); nothing is zero-stuffed.
+    ONE contraction for all s output phases: the output (B, Tin*s, Cout) is the row-major matrix
+    (B*Tin, s*Cout), the weight is re-laid as W2[j][(r,co)][ci] and the K/s taps are token shifts of x --
+    nothing is zero-stuffed, x is read once per tap from L2 and y is written once, fully coalesced.
     Reference: CausalConvTranspose1d, kantts/models/hifigan/layers.py:125-165, hifigan.py:67-80,160."""
 
     @staticmethod
@@ -785,11 +802,11 @@ class _ConvTransposeCL(torch.autograd.Function):
         taps = K // s
         y = torch.empty((B, Tin * s, Cout), device=x.device, dtype=torch.float32)
         r_t = _c(res) if res is not None else None
-        for r in range(s):
-            seg = make_seg(x, Cin, 1, (w, r), K, Cout * K, Cin, ntaps=taps, b_tap=s, a_tok_axis=1, a_shift0=0,
-                           a_shift_step=-1, a_map=dict(Tq=Tin, Tsrc=Tin), a_leaky=in_leaky)
-            gemm([seg], B * Tin, Cout, y, s * Cout, 1, c_off=r * Cout, bias=bias, res=r_t, r_is=s * Cout, r_js=1,
-                 res_off=r * Cout)
+        w2 = w.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).contiguous()  # (taps, s, Cout, Cin)
+        seg = make_seg(x, Cin, 1, w2, Cin, 1, Cin, ntaps=taps, b_tap=s * Cout * Cin, a_tok_axis=1, a_shift0=0,
+                       a_shift_step=-1, a_map=dict(Tq=Tin, Tsrc=Tin), a_leaky=in_leaky)
+        gemm([seg], B * Tin, s * Cout, y, s * Cout, 1, bias=bias.repeat(s) if bias is not None else None, res=r_t,
+             r_is=s * Cout, r_js=1)
         ctx.cfg = (s, in_leaky, bias is not None, res is not None)
         ctx.save_for_backward(x, w)
         return y
@@ -802,24 +819,26 @@ class _ConvTransposeCL(torch.autograd.Function):
         B, Tin, Cin = x.shape
         _, Cout, K = w.shape
         taps = K // s
+        N2 = s * Cout
+        M = B * Tin
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            for r in range(s):
-                seg = make_seg((dy, r * Cout), s * Cout, 1, (w, r), Cout * K, K, Cout, ntaps=taps, b_tap=s, a_tok_axis=1,
-                               a_shift0=0, a_shift_step=1, a_map=dict(Tq=Tin, Tsrc=Tin))
-                gemm([seg], B * Tin, Cin, dx, Cin, 1, accumulate=(r > 0), gate=x if in_leaky is not None else None,
-                     gate_slope=in_leaky or 0.0)
+            w3 = w.view(Cin, Cout, taps, s).permute(2, 0, 3, 1).contiguous()  # (taps, Cin, s, Cout)
+            seg = make_seg(dy, N2, 1, w3, N2, 1, N2, ntaps=taps, b_tap=Cin * N2, a_tok_axis=1, a_shift0=0,
+                           a_shift_step=1, a_map=dict(Tq=Tin, Tsrc=Tin))
+            gemm([seg], M, Cin, dx, Cin, 1, gate=x if in_leaky is not None else None, gate_slope=in_leaky or 0.0)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
-            M = B * Tin
-            sk = _splitk_for(Cin, Cout, M)
-            for r in range(s):
-                for j in range(taps):
-                    seg = make_seg(x, 1, Cin, (dy, r * Cout), 1, s * Cout, M, a_tok_axis=2, a_shift0=-j,
-                                   a_map=dict(Tq=Tin, Tsrc=Tin), a_leaky=in_leaky)
-                    gemm([seg], Cin, Cout, dw, Cout * K, K, c_off=r + j * s, accumulate=True, splitk=sk)
-        if has_bias and ctx.needs_input_grad[2]:
+            dw2 = gzeros((taps, N2, Cin), dy.device)
+            db2 = gzeros((N2,), dy.device) if (has_bias and ctx.needs_input_grad[2]) else None
+            seg = make_seg(dy, 1, N2, x, 1, Cin, M, ntaps=taps, b_tok_axis=2, b_shift0=0, b_shift_step=-1,
+                           b_map=dict(Tq=Tin, Tsrc=Tin), b_leaky=in_leaky)
+            gemm([seg], N2, Cin, dw2, Cin, 1, accumulate=True, splitk=_splitk_for(N2 * taps, Cin, M), z_taps=taps,
+                 c_tap=N2 * Cin, a_rowsum=db2)
+            dw = dw2.view(taps, s, Cout, Cin).permute(3, 2, 0, 1).reshape(Cin, Cout, K)
+            if db2 is not None:
+                db = db2.view(s, Cout).sum(0)
+        elif has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1))
         return dx, dw, db, (dy if has_res else None), None, None
 

@@ -603,3 +603,46 @@ class EmulatedLib:
     def kantts_sinadd_bwd(self, dy, x, dx, n, stream):
         _arr(dx, n)[:] = _arr(dy, n) * (np.cos(_arr(x, n)) + 1.0)
         return 0
+
+    # ------------------------------------------------------------------------------------ windowed conv
+    def kantts_conv_win_launch(self, args_ref, stream):
+        g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
+        if (g.CR % 4) or (g.Cin_tot % 4) or g.K > 64:
+            return -2  # KANTTS_E_UNSUPPORTED (same rule as csrc/conv_win.hip)
+        B, Ts, Td, Ci, N, CR, NG, G, K = g.B, g.Tsrc, g.Tdst, g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K
+        x = _arr(g.in_, B * Ts * Ci).reshape(B, Ts, Ci).astype(np.float64)
+        if g.in_act:
+            x = np.where(x > 0, x, x * np.float32(g.in_slope))
+        if g.in_gate:
+            gt = _arr(g.in_gate, B * Ts * Ci).reshape(B, Ts, Ci)
+            x = x * np.where(gt > 0, 1.0, np.float32(g.in_gate_slope))
+        w = _arr(g.w, K * N * CR).reshape(K, N, CR).astype(np.float64)
+        out = _arr(g.out, B * Td * N).reshape(B, Td, N)
+        acc = np.zeros((B, Td, N), dtype=np.float64)
+        for ph in range(g.phases):
+            m = np.arange((Td - ph + g.phases - 1) // g.phases)
+            if m.size == 0:
+                continue
+            d = m * g.phases + ph
+            for k in range(K):
+                u = g.in_add + ph + k * g.in_kstep
+                if u % g.in_div:
+                    continue
+                src = m * g.in_mul + u // g.in_div
+                ok = (src >= 0) & (src < Ts)
+                if not ok.any():
+                    continue
+                for gi in range(G):
+                    xs = x[:, src[ok], gi * CR:(gi + 1) * CR]
+                    acc[:, d[ok], gi * NG:(gi + 1) * NG] += xs @ w[k, gi * NG:(gi + 1) * NG, :].T
+        if g.bias:
+            acc += _arr(g.bias, N)
+        if g.out_act:
+            acc = np.where(acc > 0, acc, acc * np.float32(g.out_slope))
+        if g.res:
+            acc += _arr(g.res, B * Td * N).reshape(B, Td, N)
+        if g.out_gate:
+            og = _arr(g.out_gate, B * Td * N).reshape(B, Td, N)
+            acc *= np.where(og > 0, 1.0, np.float32(g.out_gate_slope))
+        out[:] = acc.astype(np.float32)
+        return 0

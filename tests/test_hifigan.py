@@ -87,6 +87,77 @@ def test_conv_variants_emulated_match_torch():
             assert rel_l2(a, c) < 1e-5
 
 
+_WIN_CASES = [
+    # (B, Tin, Cin, Cout, K, stride, dil, pad, groups, in_leaky, out_leaky, use_res)
+    (2, 300, 64, 128, 41, 4, 1, 20, 4, None, 0.1, False),      # MSD strided grouped (tall tile)
+    (3, 150, 256, 256, 41, 1, 1, 20, 16, None, 0.1, False),    # MSD stride-1 grouped, CR = NG = 16
+    (2, 517, 32, 32, 11, 1, 5, 50, 1, 0.1, None, True),        # residual block: causal dilated + res
+    (2, 260, 128, 256, 7, 1, 1, 6, 1, 0.1, None, False),       # wide tile (NG >= 128)
+    (2, 200, 32, 1, 7, 1, 1, 6, 1, 0.01, None, False),         # conv_post: one output channel
+    (1, 40, 8, 12, 3, 2, 3, 3, 1, None, None, False),          # short, stride 2, Cout % 4 == 0 only
+    (2, 90, 24, 20, 5, 3, 2, 4, 2, 0.2, 0.3, False),           # stride 3 dil 2: dgrad phases with uneven taps
+]
+
+
+def _win_case(case, device):
+    from kantts._hip import ops
+
+    B, T, Cin, Cout, K, stride, dil, pad, groups, il, ol, use_res = case
+    g = torch.Generator().manual_seed(K * 1000 + Cin)
+    x = torch.randn(B, T, Cin, generator=g).to(device).requires_grad_(True)
+    w = (torch.randn(Cout, Cin // groups, K, generator=g) * (1.0 / (Cin // groups * K) ** 0.5)).to(device).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).to(device).requires_grad_(True)
+    if stride == 1:
+        Tout = T
+    else:
+        Tout = (T + 2 * pad - dil * (K - 1) - 1) // stride + 1
+    res = torch.randn(B, Tout, Cout, generator=g).to(device).requires_grad_(True) if use_res else None
+    y = ops.conv_cl(x, w, b, stride=stride, dilation=dil, pad=pad, Tout=Tout, groups=groups, in_leaky=il,
+                    out_leaky=ol, res=res)
+    xin = F.leaky_relu(x, il) if il is not None else x
+    # the op pads ``pad`` on the left and whatever Tout requires on the right
+    need = (Tout - 1) * stride + dil * (K - 1) + 1
+    xp = F.pad(xin.transpose(1, 2), (pad, max(0, need - T - pad)))
+    ref = F.conv1d(xp, w, b, stride=stride, dilation=dil, groups=groups)[..., :Tout]
+    if ol is not None:
+        ref = F.leaky_relu(ref, ol)
+    ref = ref.transpose(1, 2)
+    if res is not None:
+        ref = ref + res
+    cot = torch.randn(ref.shape, generator=g).to(device)
+    ins = (x, w, b) + ((res,) if use_res else ())
+    gy = torch.autograd.grad((y * cot).sum(), ins)
+    gr = torch.autograd.grad((ref * cot).sum(), ins)
+    return y.detach(), ref.detach(), gy, gr
+
+
+def test_conv_win_emulated_matches_torch():
+    with emulation():
+        for case in _WIN_CASES[2:]:
+            y, ref, gy, gr = _win_case(case, "cpu")
+            assert_close(y, ref, 2e-5, what=str(case))
+            for a, c in zip(gy, gr):
+                assert rel_l2(a, c) < 1e-5, case
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,otol,gtol", [("fp32", 5e-5, 2e-4), ("bf16", 4e-2, 6e-2), ("ref", 5e-5, 2e-4)])
+def test_conv_win_gpu_matches_torch(prec, otol, gtol):
+    """LDS-window convolution kernel (csrc/conv_win.hip) forward + input gradient, and the GEMM weight gradient,
+    against ATen's conv1d on the same device; 'ref' routes through the scalar reference GEMM instead."""
+    import kantts._hip as hip
+
+    hip.set_precision(prec)
+    try:
+        for case in _WIN_CASES:
+            y, ref, gy, gr = _win_case(case, "cuda")
+            assert float((y - ref).abs().max()) <= otol * max(1.0, float(ref.abs().max())), (prec, case)
+            for a, c in zip(gy, gr):
+                assert rel_l2(a, c) < gtol, (prec, case)
+    finally:
+        hip.set_precision("fp32")
+
+
 @pytest.mark.gpu
 def test_hifigan_gpu_matches_oracle():
     import kantts._hip as hip
