@@ -7,9 +7,16 @@ A "step" = one full training step of the hot path on one seeded synthetic batch 
 losses, backward, global-norm clip (1.0), fused Adam, NoamLR -- i.e. Sambert_Trainer.train_step
 (reference kantts/train/trainer.py:898-1005) with dropout on as shipped.  Inputs are resident in HBM
 before the timed region.  value = valid mel frames of all ranks / max-over-ranks wall time.
-Extra objects on the JSON line: "roofline" (dominant kernel = the segmented MFMA GEMM, measured with
-HIP events around every launch of one instrumented step) and "cpu_baseline" (the CPU oracle port
-timed on the host cores on a bounded sample, rank 0, N=1 only).
+Extra objects on the JSON line:
+  "roofline"     dominant kernel of the step = the MFMA GEMM on the decoder-FFN contractions.  With fp32 activations in
+                 HBM these are bandwidth-bound (57 flop/byte against a machine balance of ~310), so the binding roof
+                 is HBM: achieved = algorithmic bytes (A + B + C once, fp32) / mean launch duration, each contraction
+                 replayed from a captured hipGraph and timed with HIP events on the replay stream.  The MFMA view
+                 (flop/s against the dense bf16 peak) is reported beside it as "mfma_frac".
+  "cpu_baseline" the CPU oracle port timed on the host cores on a bounded sample (rank 0, N=1 only).
+  "hifigan"      the second half of BASELINE.json's metric (audio-samples/s): HiFi-GAN V1 at batch 32 x 8192 samples --
+                 full GAN training step, generator forward, and the transposed-conv upsampling stack against the HBM
+                 roofline (rank 0, N=1 only; --no-hifigan skips it).
 """
 import argparse
 import json
@@ -26,6 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0
 
 
 def sambert_yaml_config(cfg):
@@ -113,7 +121,92 @@ def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
         us = e0.elapsed_time(e1) * 1e3 / (reps * replays)
         per[name] = round(us, 2)
         tot_us += us
-    return flops * len(cases) / (tot_us * 1e-6) / 1e12, per, flops
+    bytes_per_launch = 4.0 * (M * C + C * F + M * F)  # both operands read once + the output written once, fp32
+    return flops * len(cases) / (tot_us * 1e-6) / 1e12, per, flops, bytes_per_launch * len(cases) / (tot_us * 1e-6) / 1e9, \
+        bytes_per_launch
+
+
+def hifigan_v1_config(channels=512):
+    opt = {"type": "Adam", "params": {"lr": 2e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}}
+    sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [200000, 400000, 600000, 800000]}}
+    return {"model_type": "hifigan", "Model": {
+        "Generator": {"params": {"channels": channels}, "optimizer": opt, "scheduler": sch},
+        "MultiScaleDiscriminator": {"params": {}, "optimizer": opt, "scheduler": sch},
+        "MultiPeriodDiscriminator": {"params": {}, "optimizer": opt, "scheduler": sch}},
+        "Loss": {"generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "mel_loss": {"enable": True, "params": {}, "weights": 45.0},
+                 "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+        "generator_grad_norm": -1, "discriminator_grad_norm": -1, "discriminator_train_start_steps": 0,
+        "generator_train_start_steps": 0}
+
+
+def _event_ms(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
+    """HiFi-GAN V1 (reference hifigan.py class defaults, the hifigan_v1 yaml loss weights) at batch 32:
+    GAN training step (generator + MPD + MSD, mel/adv/feature-matching losses, 3 Adam steps), generator forward,
+    and the four causal transposed-conv upsampling layers alone (x8, x8, x2, x2; SURVEY 8d: algorithmic traffic =
+    input + output activations, fp32)."""
+    from kantts.models import model_builder
+    from kantts.train.gan_step import gan_train_step
+    from kantts.train.loss import criterion_builder
+
+    hip.set_precision(precision)
+    config = hifigan_v1_config()
+    torch.manual_seed(0)
+    model, optimizer, scheduler = model_builder(config, device="cuda")
+    crit = criterion_builder(config, device="cuda")
+    frames = T_wav // 256
+    x = torch.randn(B, 80, frames, device="cuda")
+    y = torch.randn(B, 1, T_wav, device="cuda").clamp(-1, 1)
+    G = model["generator"]
+    res = {"workload": "HiFi-GAN V1 (512 ch, up 8/8/2/2, MPD 2/3/5/7/11, MSD x3), batch %d x %d samples" % (B, T_wav),
+           "dtype": precision}
+    with torch.no_grad():
+        ms = _event_ms(lambda: G(x), 5)
+        res["generator_forward_ms"] = ms
+        res["generator_forward_samples_per_s"] = B * T_wav / (ms * 1e-3)
+        hs, T, C, elems, flops = [], frames, 512, 0, 0.0
+        for s_ in (8, 8, 2, 2):
+            hs.append(torch.randn(B, T, C, device="cuda"))
+            elems += B * T * C + B * T * s_ * (C // 2)
+            flops += 2.0 * B * T * C * (C // 2) * 2 * s_
+            T, C = T * s_, C // 2
+
+        def up():
+            for i, h in enumerate(hs):
+                G.transpose_upsamples[i][1].forward_cl(h, in_leaky=0.1)
+
+        ms = _event_ms(up, 10)
+    gbps = elems * 4 / (ms * 1e-3) / 1e9
+    res["upsampling"] = {"ms": ms, "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes": elems * 4, "tflops": flops / (ms * 1e-3) / 1e12,
+                         "note": "4 launches (one polyphase GEMM per layer); at fp32 storage the first two layers are "
+                                 "MFMA-bound (410 / 200 flop per byte), the last two HBM-bound"}
+    out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    res["gan_step_ms"] = dt * 1e3
+    res["gan_step_samples_per_s"] = B * T_wav / dt
+    res["value"] = res["gan_step_samples_per_s"]
+    res["unit"] = "audio-samples/s (GAN training step)"
+    res["losses"] = {k: float(v) for k, v in out.items()}
+    return res
 
 
 def main():
@@ -124,6 +217,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hifigan", action="store_true")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     args = ap.parse_args()
@@ -215,11 +309,12 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         prof = hip.profile_end()
-        tf, per_launch_us, flops_per_launch = dominant_gemm_roofline(hip, args.precision)
+        tf, per_launch_us, flops_per_launch, gbps, bytes_per_launch = dominant_gemm_roofline(hip, args.precision)
         peak = PEAK_TFLOPS[args.precision]
-        roof = {"bound": "mfma", "kernel": "gemm_fast_kernel<%s> (decoder FFN contractions, M=6528, 128<->1024)" % args.precision,
-                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
-                "flops_per_launch": flops_per_launch, "launch_us": per_launch_us,
+        roof = {"bound": "hbm", "kernel": "gemm_fast_kernel<%s> (decoder FFN contractions, M=6528, 128<->1024)" % args.precision,
+                "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "traffic": None,
+                "bytes_per_launch": bytes_per_launch, "flops_per_launch": flops_per_launch, "launch_us": per_launch_us,
+                "mfma_tflops": tf, "mfma_peak": peak, "mfma_frac": tf / peak,
                 "gemm_launches_per_step": prof["launches"], "gemm_gflop_per_step": prof["flops"] / 1e9,
                 "gemm_ms_per_step_eager_events": prof["ms"],
                 "whole_step_algorithmic_tflops": 456.9e9 * args.batch / 32 / (dt_max / args.steps) / 1e12}
@@ -236,6 +331,13 @@ def main():
                        "final_loss": float(loss)},
             "roofline": roof,
         }
+        if world == 1 and not args.no_hifigan:
+            try:
+                del step, net, optimizer, model, opt
+                torch.cuda.empty_cache()
+                out["hifigan"] = hifigan_leg(hip, args.precision)
+            except Exception as exc:  # the SAM-BERT line must survive a failure of the secondary leg
+                out["hifigan"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

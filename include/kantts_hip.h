@@ -281,6 +281,7 @@ typedef struct {
   const float* out_gate;
   int B, Tsrc, Tdst, Cin_tot, Ntot, CR, NG, groups, K;
   int in_mul, in_add, in_kstep, in_div, phases;
+  int inner; /* folded axis between time and channels (MPD period): in is (B, Tsrc, inner, Cin_tot), out (B, Tdst, inner, Ntot) */
   float in_slope;
   int in_act;
   float in_gate_slope;

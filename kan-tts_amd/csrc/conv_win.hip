@@ -31,6 +31,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define CW_THREADS 256
 #define CW_CK 32        // channels per chunk = one bf16 MFMA k-step
 #define CW_MAXTAPS 64
+#define CW_HDR (2 * CW_MAXTAPS * 4 + 16)  // tap table ahead of the tiles (multiple of 16 bytes)
 
 __device__ __forceinline__ int cw_floordiv(int a, int b) {
   int q = a / b;
@@ -59,9 +60,13 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
   constexpr int LDW = BF16 ? 48 : 36;
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int NBV = BN * 8 / CW_THREADS;  // float4 per thread of one weight tile
-  extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds[];
-  __shared__ int s_off[CW_MAXTAPS], s_tap[CW_MAXTAPS];
-  __shared__ int s_nv;
+  // ALL LDS is dynamic: a static __shared__ array ahead of the dynamic region would shift its base off
+  // 16 bytes, and a misaligned ds_read_b128 is replayed at 64 cycles per wave-instruction
+  extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
+  int* s_off = reinterpret_cast<int*>(cw_lds_raw);
+  int* s_tap = s_off + CW_MAXTAPS;
+  int* s_nv_p = s_tap + CW_MAXTAPS;
+  unsigned char* cw_lds = cw_lds_raw + CW_HDR;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -71,8 +76,10 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
   const int grp = blockIdx.x / ntpg;
   const int n0 = grp * g.NG + (blockIdx.x % ntpg) * BN;
   const int n_end = (grp + 1) * g.NG;
-  const int b = blockIdx.z / g.phases;
   const int phase = blockIdx.z % g.phases;
+  const int bp = blockIdx.z / g.phases;  // (batch item, position on the folded `inner` axis)
+  const int b = bp / g.inner, pi = bp % g.inner;
+  const long long in_pitch = (long long)g.inner * g.Cin_tot;  // elements between consecutive source tokens
   const int m0 = blockIdx.y * BQ;
   const int mrows = (g.Tdst - phase + g.phases - 1) / g.phases;
   if (m0 >= mrows) return;
@@ -87,10 +94,10 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
       s_tap[nv] = k;
       ++nv;
     }
-    s_nv = nv;
+    *s_nv_p = nv;
   }
   __syncthreads();
-  const int nv = s_nv;
+  const int nv = *s_nv_p;
   int offmin = 0, offmax = 0;
   if (nv > 0) {
     offmin = s_off[0];
@@ -113,8 +120,9 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const float* in_b = g.in + (long long)b * g.Tsrc * g.Cin_tot + (long long)grp * g.CR;
-  const float* gate_b = g.in_gate ? g.in_gate + (long long)b * g.Tsrc * g.Cin_tot + (long long)grp * g.CR : nullptr;
+  const long long in_off = ((long long)b * g.Tsrc * g.inner + pi) * g.Cin_tot + (long long)grp * g.CR;
+  const float* in_b = g.in + in_off;
+  const float* gate_b = g.in_gate ? g.in_gate + in_off : nullptr;
   const int c4 = (tid & 7) * 4;  // channel offset of this thread's float4 inside a chunk
   const int rslot = tid >> 3;    // 32 rows per pass
 
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
         const int rel = r0 + 32 * u;
         const int t = lo + rel;
         ok[u] = cok && rel < W && t >= 0 && t < g.Tsrc;
-        const long long o = ok[u] ? ((long long)t * g.Cin_tot + c0 + c4) : 0;
+        const long long o = ok[u] ? ((long long)t * in_pitch + c0 + c4) : 0;
         xv[u] = *reinterpret_cast<const float4*>(in_b + o);
         if (gate_b) gv[u] = *reinterpret_cast<const float4*>(gate_b + o);
       }
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
       const int n = n0 + wn * 64 + (lane & 15) * 4;
       if (m < mrows && n < n_end) {
         const long long d = (long long)m * g.phases + phase;
-        const long long o = ((long long)b * g.Tdst + d) * g.Ntot + n;
+        const long long o = (((long long)b * g.Tdst + d) * g.inner + pi) * g.Ntot + n;
         const float4 a4 = *reinterpret_cast<const float4*>(&strip[rl * 68 + (lane & 15) * 4]);
         float v[4] = {a4.x, a4.y, a4.z, a4.w};
         const int cnt = min(4, n_end - n);
@@ -284,6 +292,7 @@ static int cw_launch(const kantts_conv_args& g, hipStream_t st) {
   size_t lds = (size_t)Wp * g.in_mul * LDW * ESZ + 2 * (size_t)BN * LDW * ESZ;
   const size_t strip = 4 * 16 * 68 * sizeof(float);
   if (lds < strip) lds = strip;
+  lds += CW_HDR;
   if (lds > 160 * 1024 - 1024) return KANTTS_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
@@ -294,7 +303,7 @@ static int cw_launch(const kantts_conv_args& g, hipStream_t st) {
   }
   const int mrows = (g.Tdst + g.phases - 1) / g.phases;
   const int ntpg = (g.NG + BN - 1) / BN;
-  dim3 grid(g.groups * ntpg, kantts_cdiv(mrows, BQ), g.B * g.phases);
+  dim3 grid(g.groups * ntpg, kantts_cdiv(mrows, BQ), g.B * g.inner * g.phases);
   hipLaunchKernelGGL((conv_win_kernel<BF16, WM, MREP>), grid, dim3(CW_THREADS), lds, st, g);
   KANTTS_CHECK_LAUNCH();
 }
@@ -303,7 +312,7 @@ extern "C" int kantts_conv_win_launch(const kantts_conv_args* a, void* stream) {
   if (!a || !a->in || !a->w || !a->out) return KANTTS_E_BADARG;
   const kantts_conv_args& g = *a;
   if (g.B < 0 || g.Tsrc < 0 || g.Tdst < 0 || g.K < 1 || g.groups < 1 || g.NG < 1 || g.CR < 1 || g.in_mul < 1 ||
-      g.in_div < 1 || g.phases < 1)
+      g.in_div < 1 || g.phases < 1 || g.inner < 1)
     return KANTTS_E_BADARG;
   if (g.Ntot != g.groups * g.NG || g.Cin_tot != g.groups * g.CR) return KANTTS_E_BADARG;
   if (g.K > CW_MAXTAPS) return KANTTS_E_UNSUPPORTED;
@@ -311,7 +320,7 @@ extern "C" int kantts_conv_win_launch(const kantts_conv_args* a, void* stream) {
   if ((g.CR & 3) || (g.Cin_tot & 3) || ((uintptr_t)g.in & 15) || ((uintptr_t)g.w & 15) ||
       (g.in_gate && ((uintptr_t)g.in_gate & 15)))
     return KANTTS_E_UNSUPPORTED;
-  if ((long long)g.B * g.phases > 65535) return KANTTS_E_UNSUPPORTED;
+  if ((long long)g.B * g.inner * g.phases > 65535) return KANTTS_E_UNSUPPORTED;
   if (g.B == 0 || g.Tdst == 0) return KANTTS_OK;
   hipStream_t st = (hipStream_t)stream;
   const int mrows = (g.Tdst + g.phases - 1) / g.phases;

@@ -58,7 +58,7 @@ class ConvArgs(Structure):
         ("res", c_void_p), ("out_gate", c_void_p),
         ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cin_tot", c_int32), ("Ntot", c_int32),
         ("CR", c_int32), ("NG", c_int32), ("groups", c_int32), ("K", c_int32),
-        ("in_mul", c_int32), ("in_add", c_int32), ("in_kstep", c_int32), ("in_div", c_int32), ("phases", c_int32),
+        ("in_mul", c_int32), ("in_add", c_int32), ("in_kstep", c_int32), ("in_div", c_int32), ("phases", c_int32), ("inner", c_int32),
         ("in_slope", c_float), ("in_act", c_int32), ("in_gate_slope", c_float),
         ("out_slope", c_float), ("out_act", c_int32), ("out_gate_slope", c_float),
         ("precision", c_int32),
@@ -251,7 +251,7 @@ def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_j
 E_UNSUPPORTED = -2
 
 
-def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add, in_kstep, in_div, phases,
+def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add, in_kstep, in_div, phases, inner=1,
              bias=None, res=None, in_gate=None, in_gate_slope=0.0, in_leaky=None, out_leaky=None, out_gate=None,
              out_gate_slope=0.0):
     """Windowed channels-last convolution (csrc/conv_win.hip).  Returns False when the kernel does not
@@ -265,6 +265,7 @@ def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add,
     g.B, g.Tsrc, g.Tdst = int(B), int(Tsrc), int(Tdst)
     g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K = int(groups * CR), int(groups * NG), int(CR), int(NG), int(groups), int(K)
     g.in_mul, g.in_add, g.in_kstep, g.in_div, g.phases = int(in_mul), int(in_add), int(in_kstep), int(in_div), int(phases)
+    g.inner = int(inner)
     if in_leaky is not None:
         g.in_act, g.in_slope = 1, float(in_leaky)
     if out_leaky is not None:
@@ -280,7 +281,7 @@ def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add,
     check(rc, "conv_win")
     if _profile is not None:
         e1.record()
-        _profile.append((e0, e1, 2.0 * B * Tdst * groups * NG * CR * K / max(1, in_div)))
+        _profile.append((e0, e1, 2.0 * B * Tdst * inner * groups * NG * CR * K / max(1, in_div)))
     return True
 
 

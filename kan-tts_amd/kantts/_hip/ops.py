@@ -712,9 +712,9 @@ class _ConvCL(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has = (bias is not None, res is not None)
         ctx.save_for_backward(x, w, y if cfg["out_leaky"] is not None else None)
-        if inner == 1 and up == 1 and conv_win(
+        if up == 1 and conv_win(
                 x, wt, y, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K, in_mul=stride,
-                in_add=-pad, in_kstep=dil, in_div=1, phases=1, bias=bias, res=r, in_leaky=cfg["in_leaky"],
+                in_add=-pad, in_kstep=dil, in_div=1, phases=1, inner=inner, bias=bias, res=r, in_leaky=cfg["in_leaky"],
                 out_leaky=cfg["out_leaky"]):
             return y
         seg = make_seg(x, Cin, 1, wt, Cin_g, 1, Cin_g, ntaps=K, b_tap=Cout * Cin_g, a_tok_axis=1, a_shift0=-pad,
@@ -741,9 +741,9 @@ class _ConvCL(torch.autograd.Function):
             dx = torch.empty_like(x)
             Mx = B * Tin * inner
             wd = w.view(groups, Cout_g, Cin_g, K).permute(3, 0, 2, 1).contiguous()  # (K, groups, Cin_g, Cout_g)
-            done = inner == 1 and up == 1 and conv_win(
+            done = up == 1 and conv_win(
                 dy, wd, dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups, CR=Cout_g, NG=Cin_g, K=K, in_mul=1, in_add=pad,
-                in_kstep=-dil, in_div=stride, phases=stride, in_gate=gate, in_gate_slope=gslope,
+                in_kstep=-dil, in_div=stride, phases=stride, inner=inner, in_gate=gate, in_gate_slope=gslope,
                 out_gate=x if cfg["in_leaky"] is not None else None, out_gate_slope=cfg["in_leaky"] or 0.0)
             first = True
             for r in range(0 if done else up):

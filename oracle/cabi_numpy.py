@@ -609,16 +609,20 @@ class EmulatedLib:
         g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
         if (g.CR % 4) or (g.Cin_tot % 4) or g.K > 64:
             return -2  # KANTTS_E_UNSUPPORTED (same rule as csrc/conv_win.hip)
+        P = g.inner
         B, Ts, Td, Ci, N, CR, NG, G, K = g.B, g.Tsrc, g.Tdst, g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K
-        x = _arr(g.in_, B * Ts * Ci).reshape(B, Ts, Ci).astype(np.float64)
+
+        def load(ptr, T, C):
+            # (B, T, inner, C) -> (B*inner, T, C): the folded axis (MPD period) is independent of the convolution
+            return _arr(ptr, B * T * P * C).reshape(B, T, P, C).transpose(0, 2, 1, 3).reshape(B * P, T, C)
+
+        x = load(g.in_, Ts, Ci).astype(np.float64)
         if g.in_act:
             x = np.where(x > 0, x, x * np.float32(g.in_slope))
         if g.in_gate:
-            gt = _arr(g.in_gate, B * Ts * Ci).reshape(B, Ts, Ci)
-            x = x * np.where(gt > 0, 1.0, np.float32(g.in_gate_slope))
+            x = x * np.where(load(g.in_gate, Ts, Ci) > 0, 1.0, np.float32(g.in_gate_slope))
         w = _arr(g.w, K * N * CR).reshape(K, N, CR).astype(np.float64)
-        out = _arr(g.out, B * Td * N).reshape(B, Td, N)
-        acc = np.zeros((B, Td, N), dtype=np.float64)
+        acc = np.zeros((B * P, Td, N), dtype=np.float64)
         for ph in range(g.phases):
             m = np.arange((Td - ph + g.phases - 1) // g.phases)
             if m.size == 0:
@@ -640,9 +644,9 @@ class EmulatedLib:
         if g.out_act:
             acc = np.where(acc > 0, acc, acc * np.float32(g.out_slope))
         if g.res:
-            acc += _arr(g.res, B * Td * N).reshape(B, Td, N)
+            acc += load(g.res, Td, N)
         if g.out_gate:
-            og = _arr(g.out_gate, B * Td * N).reshape(B, Td, N)
-            acc *= np.where(og > 0, 1.0, np.float32(g.out_gate_slope))
-        out[:] = acc.astype(np.float32)
+            acc *= np.where(load(g.out_gate, Td, N) > 0, 1.0, np.float32(g.out_gate_slope))
+        out = _arr(g.out, B * Td * P * N).reshape(B, Td, P, N)
+        out[:] = acc.reshape(B, P, Td, N).transpose(0, 2, 1, 3).astype(np.float32)
         return 0

@@ -183,6 +183,8 @@ def test_conv_ops_gpu_vs_emulated():
          (r(B, 64, 32, seed=5), r(64, 8, 41, seed=6, scale=0.1), r(64, seed=7))),
         ("period fold", lambda x, w, b: ops.conv_cl(x, w, b, stride=3, pad=2, inner=5, out_leaky=0.1),
          (r(B, 20, 5, 8, seed=8), r(16, 8, 5, seed=9, scale=0.2), r(16, seed=10))),
+        ("period fold, long", lambda x, w, b: ops.conv_cl(x, w, b, stride=3, pad=2, inner=7, in_leaky=0.1, out_leaky=0.1),
+         (r(2, 301, 7, 32, seed=21), r(128, 32, 5, seed=22, scale=0.1), r(128, seed=23))),
         ("nearest upsample", lambda x, w, b: ops.conv_cl(x, w, b, pad=6, up=8, in_leaky=0.1),
          (r(B, T, 12, seed=11), r(20, 12, 7, seed=12, scale=0.2), r(20, seed=13))),
         ("polyphase transposed", lambda x, w, b, res: ops.conv_transpose_cl(x, w, b, 8, in_leaky=0.1, res=res),
