@@ -256,7 +256,7 @@ def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add,
              out_gate_slope=0.0):
     """Windowed channels-last convolution (csrc/conv_win.hip).  Returns False when the kernel does not
     support the shape (the caller then takes the segmented-GEMM route); raises on any other error."""
-    if _precision["gemm"] not in (PREC_FP32, PREC_BF16):
+    if _precision["gemm"] not in (PREC_FP32, PREC_BF16) or os.environ.get("KANTTS_NO_CONVWIN"):
         return False
     g = ConvArgs()
     g.in_, g.in_gate, g.w, g.out = ptr(x, torch.float32), ptr(in_gate, torch.float32), ptr(w_tap, torch.float32), \

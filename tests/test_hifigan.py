@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 import hifigan_oracle as H
-from util import assert_close, emulation, rel_l2, run_both
+from util import assert_close, assert_grads_close, emulation, rel_l2, run_both
 
 
 def _models(channels, seed=0):
@@ -30,8 +30,7 @@ def _check_models(device, channels, B, frames, T_wav, gtol, wtol):
     cot = torch.randn(yr.shape, generator=g)
     (yo * cot.to(device)).sum().backward()
     (yr * cot).sum().backward()
-    for n, p in G.named_parameters():
-        assert rel_l2(p.grad.cpu(), PG[n].grad) <= gtol, "G " + n
+    assert_grads_close([(n, p.grad, PG[n].grad) for n, p in G.named_parameters()], gtol, "G")
     for D, f, nm in ((D1, H.mpd, "mpd"), (D2, H.msd, "msd")):
         P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in D.state_dict().items()}
         D = D.to(device)
@@ -50,8 +49,7 @@ def _check_models(device, channels, B, frames, T_wav, gtol, wtol):
         l2 = sum((a * a).sum() for a in o_r) + sum(a.abs().mean() for fa in f_r for a in fa)
         l1.backward()
         l2.backward()
-        for n, p in D.named_parameters():
-            assert rel_l2(p.grad.cpu(), P[n].grad) <= gtol, nm + " " + n
+        assert_grads_close([(n, p.grad, P[n].grad) for n, p in D.named_parameters()], gtol, nm)
         assert rel_l2(yy.grad.cpu(), y2.grad) <= gtol, nm + " d(input)"
 
 
@@ -238,8 +236,7 @@ def _gan_losses_check(device, channels, B, frames):
     assert abs(float(losses["mel_loss"]) - float(mel_l)) < 1e-4
     assert abs(float(losses["adversarial_loss"]) - float(adv)) < 1e-4 * max(1.0, float(adv))
     assert abs(float(gen_loss) - float(ref)) < 2e-4 * max(1.0, abs(float(ref)))
-    for n, p in model["generator"].named_parameters():
-        assert rel_l2(p.grad.cpu(), PG[n].grad) < 5e-3, "G " + n
+    assert_grads_close([(n, p.grad, PG[n].grad) for n, p in model["generator"].named_parameters()], 5e-3, "G")
     for d in model["discriminator"].values():
         d.zero_grad()
     dis_loss, _ = discriminator_loss(model, crit, x.to(device), y.to(device))
@@ -256,8 +253,8 @@ def _gan_losses_check(device, channels, B, frames):
     ref_d.backward()
     assert abs(float(dis_loss) - float(ref_d)) < 1e-4 * max(1.0, float(ref_d))
     for P, key in ((P1, "MultiPeriodDiscriminator"), (P2, "MultiScaleDiscriminator")):
-        for n, p in model["discriminator"][key].named_parameters():
-            assert rel_l2(p.grad.cpu(), P[n].grad) < 5e-3, key + " " + n
+        assert_grads_close([(n, p.grad, P[n].grad) for n, p in model["discriminator"][key].named_parameters()],
+                           5e-3, key)
 
 
 def test_gan_step_losses_emulated():

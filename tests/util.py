@@ -94,3 +94,18 @@ def assert_close(a, b, atol, rtol=0.0, what=""):
 
 def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def assert_grads_close(pairs, tol, what=""):
+    """Parameter-gradient parity for networks with LeakyReLU gates.  ``pairs``: iterable of (name, got, ref).
+    The whole gradient (all parameters concatenated) must agree to ``tol`` in relative L2.  Individual tensors
+    get 10x that: a pre-activation within an ulp of zero can take the other side of the LeakyReLU in two fp32
+    summation orders, and ONE such flip moves a 16-element bias gradient by ~1 % while leaving the large
+    tensors (and the global norm) untouched."""
+    num, den = 0.0, 0.0
+    for name, got, ref in pairs:
+        got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+        e, r = float((got - ref).pow(2).sum()), float(ref.pow(2).sum())
+        num, den = num + e, den + r
+        assert (e / (r + 1e-60)) ** 0.5 <= 10 * tol, "%s %s: rel-L2 %.3e" % (what, name, (e / (r + 1e-60)) ** 0.5)
+    assert (num / (den + 1e-60)) ** 0.5 <= tol, "%s global rel-L2 %.3e" % (what, (num / (den + 1e-60)) ** 0.5)
