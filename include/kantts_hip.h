@@ -292,6 +292,27 @@ typedef struct {
 } kantts_conv_args;
 int kantts_conv_win_launch(const kantts_conv_args* args, void* stream);
 
+/* Weight / bias gradient of the same convolutions (csrc/conv_wgrad.hip), accumulated (+=) with fp32 atomics:
+ *   dw[k][n][c] += sum_{b,p,q} gate(dy[b,q,p,n]) * act(x[b, q*stride + k*dil - pad, p, g*CR + c]),   g = n / NG
+ *   db[n]       += sum_{b,p,q} gate(dy[b,q,p,n])                                   (db may be NULL)
+ * x is (B, Tsrc, inner, Cin_tot), dy / dy_gate are (B, Tdst, inner, Ntot), dw is tap-major (K, Ntot, CR).
+ * gate(v) = v * (dy_gate > 0 ? 1 : dy_gate_slope) when dy_gate is given; act = LeakyReLU(x_slope) when x_act.
+ * KANTTS_E_UNSUPPORTED when CR or NG is not a multiple of 4 or a pointer is not 16-byte aligned. */
+typedef struct {
+  const float* x;
+  const float* dy;
+  const float* dy_gate;
+  float* dw;
+  float* db;
+  int B, Tsrc, Tdst, Cin_tot, Ntot, CR, NG, groups, K;
+  int stride, dil, pad, inner;
+  float x_slope;
+  int x_act;
+  float dy_gate_slope;
+  int precision; /* 0 fp32 MFMA, 1 bf16 MFMA (fp32 accumulate) */
+} kantts_convw_args;
+int kantts_conv_wgrad_launch(const kantts_convw_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,63 +44,36 @@ __device__ __forceinline__ float f_epilogue(const kantts_gemm_args& g, float acc
   return v;
 }
 
-struct FMap {
-  int inner, Tq, Tsrc, mul, div, up;
-  bool plain;
-};
-
-__device__ __forceinline__ FMap f_make_map(int inner, int Tq, int Tsrc, int mul, int div, int up, int T) {
-  FMap m;
-  m.inner = inner > 0 ? inner : 1;
-  m.Tq = Tq > 0 ? Tq : T;
-  m.Tsrc = Tsrc > 0 ? Tsrc : T;
-  m.mul = mul > 0 ? mul : 1;
-  m.div = div > 0 ? div : 1;
-  m.up = up > 0 ? up : 1;
-  m.plain = (m.inner == 1 && m.mul == 1 && m.div == 1 && m.up == 1 && m.Tq == m.Tsrc);
-  return m;
+// Token shifts (conv taps) of the plain kind only: a row / reduction index is a token of a (B, T) grid and
+// the tap reads token t + shift of the same sequence (zero outside [0, T)).  Strided / folded / upsampled token
+// maps go to conv_win.hip / conv_wgrad.hip (or the generic kernel of gemm.hip).
+__device__ __forceinline__ bool f_shift_token(int tok, int shift, int T, long long& row) {
+  row = (long long)tok + shift;
+  if (shift == 0) return true;
+  const int t = tok % T + shift;
+  return t >= 0 && t < T;
 }
 
-// token of the (B, Tq, inner) domain -> source row (see gemm.hip::map_token); plain maps take the cheap path
-__device__ __forceinline__ bool f_map_token(int tok, int shift, const FMap& m, long long& row) {
-  if (m.plain) {
-    if (shift == 0) {
-      row = tok;
-      return true;
-    }
-    const int t = tok % m.Tq + shift;
-    row = (long long)tok + shift;
-    return t >= 0 && t < m.Tq;
-  }
-  const int pi = tok % m.inner;
-  const int bq = tok / m.inner;
-  const int q = bq % m.Tq;
-  const int b = bq / m.Tq;
-  int t = q * m.mul + shift;
-  if (t < 0) return false;
-  if (m.div > 1) {
-    if (t % m.div) return false;
-    t /= m.div;
-  }
-  if (t >= m.Tsrc * m.up) return false;
-  t /= m.up;
-  row = ((long long)b * m.Tsrc + t) * m.inner + pi;
-  return true;
-}
-
-// 4 consecutive k of one LDS row
-template <bool BF16, int LD>
-__device__ __forceinline__ void lds_store4(void* base, int row, int k, float v0, float v1, float v2, float v3) {
+// 4 consecutive elements of the LDS image at element index idx (idx % 4 == 0)
+template <bool BF16>
+__device__ __forceinline__ void lds_store4(void* base, int idx, float v0, float v1, float v2, float v3) {
   if (BF16) {
     bf16x4 p = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + row * LD + k) = p;
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + idx) = p;
   } else {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + row * LD + k) = make_float4(v0, v1, v2, v3);
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx) = make_float4(v0, v1, v2, v3);
   }
+}
+
+// gfx950 LDS transpose read: the 16 lanes of a group each point at 4 contiguous bf16 of a [4 k][16 rows] block
+// (lane i: k-row i>>2, rows 4*(i&3)..+3, any row pitch) and receive column i: the 4 k values of row i.
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x4 lds_read_tr4(const __bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
 }
 
 // One operand (A when IS_A, else B) of a tile: fetch() issues the global loads, commit() writes LDS.
-template <bool BF16, int ROWS, int BK, bool ROWVEC, bool IS_A, int LD>
+template <bool BF16, int ROWS, int BK, bool ROWVEC, bool IS_A, int LD, bool GATE>
 struct Stager {
   // k-vector layout: LPR lanes cover one row, NV vectors per thread
   static constexpr int LPR = BK / 4;
@@ -112,57 +85,54 @@ struct Stager {
   static constexpr int NB = (NBLK + F_THREADS - 1) / F_THREADS;
   static constexpr int NREG = ROWVEC ? NB * 4 : NVK;
 
-  float4 r[NREG], gt[NREG];
+  float4 r[NREG], gt[GATE ? NREG : 1];
   unsigned ok;  // bit per register vector
   int cur_k0;
 
-  const float* p;
-  const float* gp;
-  long long rs, ks;  // row stride (k-vector layout) / k stride (row-vector layout)
-  long long base[ROWVEC ? NB : NVK];
+  // operands are addressed as (uniform 64-bit base) + (32-bit byte offset): one VGPR per vector instead of two,
+  // and the loads use the SGPR-base addressing mode.  kantts_gemm_try_fast() rejects operands >= 4 GiB.
+  const char* p;
+  const char* gp;
+  uint32_t ks4;  // k stride in bytes (row-vector layout)
+  uint32_t base[ROWVEC ? NB : NVK];
   bool rok[ROWVEC ? NB : NVK];
   int klen, shift, tok_axis, T, act;
   float slope;
-  FMap map;
   const uint8_t* kmask;
 
   __device__ __forceinline__ void setup(const kantts_gemm_seg& s, const kantts_gemm_args& g, int row0, int nrows,
                                         int tap, int grp) {
     const int tid = threadIdx.x;
-    const long long goff = (long long)grp * (IS_A ? g.a_gs : g.b_gs);
-    p = (IS_A ? s.a : s.b) + goff;
-    gp = (IS_A && s.a_gate) ? s.a_gate + goff : nullptr;
+    const long long goff = (long long)grp * (IS_A ? g.a_gs : g.b_gs) + (IS_A ? 0 : (long long)tap * s.b_tap);
+    p = reinterpret_cast<const char*>((IS_A ? s.a : s.b) + goff);
+    gp = (GATE && IS_A && s.a_gate) ? reinterpret_cast<const char*>(s.a_gate + goff) : nullptr;
     klen = s.klen;
-    T = g.T;
+    T = (IS_A ? s.a_Tq : s.b_Tq) > 0 ? (IS_A ? s.a_Tq : s.b_Tq) : g.T;
     act = IS_A ? s.a_act : s.b_act;
     slope = IS_A ? s.a_slope : s.b_slope;
-    map = IS_A ? f_make_map(s.a_inner, s.a_Tq, s.a_Tsrc, s.a_mul, s.a_div, s.a_up, g.T)
-               : f_make_map(s.b_inner, s.b_Tq, s.b_Tsrc, s.b_mul, s.b_div, s.b_up, g.T);
     tok_axis = IS_A ? s.a_tok_axis : s.b_tok_axis;
     shift = tok_axis ? (IS_A ? s.a_shift0 + tap * s.a_shift_step : s.b_shift0 + tap * s.b_shift_step) : 0;
     kmask = IS_A ? g.kmask : nullptr;
-    const long long tapoff = IS_A ? 0 : (long long)tap * s.b_tap;
     if (ROWVEC) {
-      ks = IS_A ? s.a_ks : s.b_ks;
-      rs = 1;
+      ks4 = (uint32_t)(IS_A ? s.a_ks : s.b_ks) * 4u;
 #pragma unroll
       for (int v = 0; v < NB; ++v) {
         const int id = tid + F_THREADS * v;
         const int row = row0 + (id % RG) * 4;
         rok[v] = (id < NBLK) && (row < nrows);
-        base[v] = (long long)row + tapoff;
+        base[v] = (uint32_t)row * 4u;
       }
     } else {
-      rs = IS_A ? s.a_is : s.b_js;
-      ks = 1;
+      const long long rs = IS_A ? s.a_is : s.b_js;
+      ks4 = 4u;
 #pragma unroll
       for (int v = 0; v < NVK; ++v) {
         const int row = row0 + tid / LPR + RPP * v;
         bool okr = row < nrows;
         long long rr = row;
-        if (IS_A && tok_axis == 1) okr = f_map_token(row, shift, map, rr) && okr;
+        if (IS_A && tok_axis == 1) okr = f_shift_token(row, shift, T, rr) && okr;
         rok[v] = okr;
-        base[v] = rr * rs + (tid % LPR) * 4 + tapoff;
+        base[v] = (uint32_t)((rr * rs + (tid % LPR) * 4) * 4);
       }
     }
   }
@@ -181,11 +151,11 @@ struct Stager {
           const int kk = kb + e;
           bool o = rok[v] && kk < klen;
           long long kq = kk;
-          if (tok_axis == 2) o = f_map_token(kk, shift, map, kq) && o;
+          if (tok_axis == 2) o = f_shift_token(kk, shift, T, kq) && o;
           if (kmask && o) o = kmask[kk] == 0;
-          const long long f = o ? (kq * ks + base[v]) : 0;
+          const uint32_t f = o ? ((uint32_t)kq * ks4 + base[v]) : 0u;
           r[v * 4 + e] = *reinterpret_cast<const float4*>(p + f);
-          if (gp) gt[v * 4 + e] = *reinterpret_cast<const float4*>(gp + f);
+          if (GATE && gp) gt[v * 4 + e] = *reinterpret_cast<const float4*>(gp + f);
           if (o) ok |= 1u << (v * 4 + e);
         }
       }
@@ -193,9 +163,9 @@ struct Stager {
 #pragma unroll
       for (int v = 0; v < NVK; ++v) {
         const bool o = rok[v] && (k0 + (tid % LPR) * 4) < klen;
-        const long long f = o ? (base[v] + k0) : 0;
+        const uint32_t f = o ? (base[v] + (uint32_t)k0 * 4u) : 0u;
         r[v] = *reinterpret_cast<const float4*>(p + f);
-        if (gp) gt[v] = *reinterpret_cast<const float4*>(gp + f);
+        if (GATE && gp) gt[v] = *reinterpret_cast<const float4*>(gp + f);
         if (o) ok |= 1u << v;
       }
     }
@@ -206,17 +176,17 @@ struct Stager {
     float v = ((ok >> reg) & 1u) ? x : 0.f;
     if (act) v = v > 0.f ? v : v * slope;
     if (IS_A) {
-      if (gp && !(gate > 0.f)) v *= s.a_gate_slope;
+      if (GATE && gp && !(gate > 0.f)) v *= s.a_gate_slope;
       if (s.a_drop_p > 0.f) {
         // element offset of A (the dropout counter), recomputed instead of kept in registers
         long long o;
         if (ROWVEC) {
           const int id = threadIdx.x + F_THREADS * (reg >> 2);
           long long kq = cur_k0 + (id / RG) * 4 + (reg & 3);
-          if (tok_axis == 2) f_map_token((int)kq, shift, map, kq);
-          o = kq * ks + base[reg >> 2] + lane_e;
+          if (tok_axis == 2) kq += shift;
+          o = (long long)(((uint32_t)kq * ks4 + base[reg >> 2]) >> 2) + lane_e;
         } else {
-          o = base[reg] + cur_k0 + lane_e;
+          o = (long long)(base[reg] >> 2) + cur_k0 + lane_e;
         }
         v *= kantts_dropout_scale(s.a_drop_p, s.a_drop_seed + seed_off, (uint64_t)o);
       }
@@ -227,51 +197,55 @@ struct Stager {
   __device__ __forceinline__ void commit(void* lds, const kantts_gemm_seg& s, uint64_t seed_off) const {
     const int tid = threadIdx.x;
     if (ROWVEC) {
+      // K-major image [k][rows] (pitch LD): a float4 of 4 consecutive rows at one k is stored as it was loaded;
+      // the MFMA fragments are formed by transpose reads (bf16) / scalar reads (fp32), never in registers
 #pragma unroll
       for (int v = 0; v < NB; ++v) {
         const int id = tid + F_THREADS * v;
         if (NBLK % F_THREADS != 0 && id >= NBLK) continue;
         const int rl = (id % RG) * 4, kl = (id / RG) * 4;
-        // register v*4+e holds rows rl..rl+3 at k = kl+e : transpose to 4 k-contiguous row pieces
-        float m[4][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float4 x = r[v * 4 + e];
-          const float4 q = gp ? gt[v * 4 + e] : make_float4(1.f, 1.f, 1.f, 1.f);
-          m[0][e] = fix(x.x, q.x, v * 4 + e, 0, s, seed_off);
-          m[1][e] = fix(x.y, q.y, v * 4 + e, 1, s, seed_off);
-          m[2][e] = fix(x.z, q.z, v * 4 + e, 2, s, seed_off);
-          m[3][e] = fix(x.w, q.w, v * 4 + e, 3, s, seed_off);
+          const float4 q = (GATE && gp) ? gt[v * 4 + e] : make_float4(1.f, 1.f, 1.f, 1.f);
+          lds_store4<BF16>(lds, (kl + e) * LD + rl, fix(x.x, q.x, v * 4 + e, 0, s, seed_off),
+                           fix(x.y, q.y, v * 4 + e, 1, s, seed_off), fix(x.z, q.z, v * 4 + e, 2, s, seed_off),
+                           fix(x.w, q.w, v * 4 + e, 3, s, seed_off));
         }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) lds_store4<BF16, LD>(lds, rl + rr, kl, m[rr][0], m[rr][1], m[rr][2], m[rr][3]);
       }
     } else {
 #pragma unroll
       for (int v = 0; v < NVK; ++v) {
         const float4 x = r[v];
-        const float4 q = gp ? gt[v] : make_float4(1.f, 1.f, 1.f, 1.f);
-        lds_store4<BF16, LD>(lds, tid / LPR + RPP * v, (tid % LPR) * 4, fix(x.x, q.x, v, 0, s, seed_off),
-                             fix(x.y, q.y, v, 1, s, seed_off), fix(x.z, q.z, v, 2, s, seed_off),
-                             fix(x.w, q.w, v, 3, s, seed_off));
+        const float4 q = (GATE && gp) ? gt[v] : make_float4(1.f, 1.f, 1.f, 1.f);
+        lds_store4<BF16>(lds, (tid / LPR + RPP * v) * LD + (tid % LPR) * 4, fix(x.x, q.x, v, 0, s, seed_off),
+                         fix(x.y, q.y, v, 1, s, seed_off), fix(x.z, q.z, v, 2, s, seed_off),
+                         fix(x.w, q.w, v, 3, s, seed_off));
       }
     }
   }
 };
 
-template <bool BF16, int BM, bool BIGK, bool A_ROW, bool B_ROW>
+template <bool BF16, int BM, bool BIGK, bool A_ROW, bool B_ROW, bool GATE>
 __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_args g) {
   // deep reduction tiles only when there are many of them to amortise (K >= 512, split-K weight gradients);
   // short-K launches (the 128 -> 1024 projections) want occupancy instead: BK = 32 keeps them at ~70 VGPRs
   constexpr int BK = BIGK ? (BF16 ? 128 : 64) : 32;
-  // elements per LDS row: bf16 rows are 32 bytes (mod 64) apart, the pitch at which the 16-lane groups of
-  // ds_read_b128 touch 64 distinct banks (80- and 272-byte pitches are 2-way conflicted)
-  constexpr int LD = BF16 ? (BK + 16) : (BK + 4);
   constexpr int ESZ = BF16 ? 2 : 4;
-  constexpr int OPB = (BM + F_BN) * LD * ESZ, CSB = BM * (F_BN + 4) * 4;  // operand tiles / epilogue staging
+  // LDS images.  k-vector operands: [rows][BK] with a row pitch chosen for the fragment read: 16-byte reads
+  // (both operands k-vector) are conflict-free at pitch = 32 B (mod 64 B), the 8-byte reads of the permuted-k
+  // convention (below) at pitch = 16 B (mod 32 B).  Row-vector operands: K-major [BK][rows], pitch 80 / 48
+  // elements (64 / 32 rows): 8 consecutive k-rows start 8 banks apart, which makes the transpose reads (bf16)
+  // and the scalar reads (fp32) of a 32-lane group touch every bank once.
+  constexpr bool MIXED = A_ROW || B_ROW;
+  constexpr int LDK = BF16 ? (MIXED ? BK + 8 : BK + 16) : (BK + 4);
+  constexpr int PA = (BM == 64) ? 80 : 48, PB = 80;
+  constexpr int LDA = A_ROW ? PA : LDK, LDB = B_ROW ? PB : LDK;
+  constexpr int A_BYTES = (A_ROW ? BK * PA : BM * LDK) * ESZ, B_BYTES = (B_ROW ? BK * PB : F_BN * LDK) * ESZ;
+  constexpr int OPB = A_BYTES + B_BYTES, CSB = BM * (F_BN + 4) * 4;  // operand tiles / epilogue staging
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[OPB > CSB ? OPB : CSB];
   void* Al = lds_raw;
-  void* Bl = lds_raw + BM * LD * ESZ;
+  void* Bl = lds_raw + A_BYTES;
   constexpr int MREP = BM / 32;
 
   const int tid = threadIdx.x;
@@ -280,11 +254,16 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   const int wr = wave >> 1, wc = wave & 1;
   const int i0 = blockIdx.y * BM;
   const int j0 = blockIdx.x * F_BN;
-  const int zper = g.groups * g.splitk;
-  const int ztap = g.z_taps > 0 ? (int)(blockIdx.z / zper) : -1;  // one tap per z-slab (conv weight gradients)
-  const int zrem = blockIdx.z % zper;
-  const int grp = zrem / g.splitk;
-  const int zslice = zrem % g.splitk;
+  int ztap = -1, grp = 0, zslice = 0;
+  if (gridDim.z > 1) {  // z = (tap slab, group, split-K slice); the common single-slice launch skips the divisions
+    const int zper = g.groups * g.splitk;
+    ztap = g.z_taps > 0 ? (int)(blockIdx.z / zper) : -1;  // one tap per z-slab (conv weight gradients)
+    const int zrem = blockIdx.z % zper;
+    grp = zrem / g.splitk;
+    zslice = zrem % g.splitk;
+  } else if (g.z_taps > 0) {
+    ztap = 0;
+  }
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
 
   f32x4 acc[MREP][2];
@@ -295,8 +274,8 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   float rowsum = 0.f;
   const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0) && (ztap <= 0);
 
-  Stager<BF16, BM, BK, A_ROW, true, LD> sa;
-  Stager<BF16, F_BN, BK, B_ROW, false, LD> sb;
+  Stager<BF16, BM, BK, A_ROW, true, LDA, GATE> sa;
+  Stager<BF16, F_BN, BK, B_ROW, false, LDB, false> sb;
   int tile_counter = 0;
 
   for (int sidx = 0; sidx < g.nseg; ++sidx) {
@@ -309,7 +288,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
       // rows are block-relative inside the stagers' LDS writes: shift the bases instead of the row ids
       auto next_owned = [&](int from) {
         int q = from;
-        while (q < ntile && ((tile_counter + q) % g.splitk) != zslice) ++q;
+        while (g.splitk > 1 && q < ntile && ((tile_counter + q) % g.splitk) != zslice) ++q;
         return q;
       };
       int t = next_owned(0);
@@ -328,29 +307,55 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
         }
         if (do_rowsum && sidx == 0 && tid < BM) {
           float q = 0.f;
+          const int rstep = A_ROW ? LDA : 1, rbase = A_ROW ? tid : tid * LDA;
           if (BF16) {
-            const __bf16* row = reinterpret_cast<const __bf16*>(Al) + tid * LD;
-            for (int k = 0; k < BK; ++k) q += (float)row[k];
+            const __bf16* row = reinterpret_cast<const __bf16*>(Al) + rbase;
+            for (int k = 0; k < BK; ++k) q += (float)row[k * rstep];
           } else {
-            const float* row = reinterpret_cast<const float*>(Al) + tid * LD;
-            for (int k = 0; k < BK; ++k) q += row[k];
+            const float* row = reinterpret_cast<const float*>(Al) + rbase;
+            for (int k = 0; k < BK; ++k) q += row[k * rstep];
           }
           rowsum += q;
         }
         if (BF16) {
           const __bf16* Ah = reinterpret_cast<const __bf16*>(Al);
           const __bf16* Bh = reinterpret_cast<const __bf16*>(Bl);
+          const int li = lane & 15, kg = lane >> 4;
 #pragma unroll
           for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 af[MREP], bfr[2];
+            // MIXED: lane group kg holds k = kg*4..+3 and 16+kg*4..+3 of the 32-k step (what two transpose reads
+            // deliver); the k-vector operand follows with two 8-byte reads.  Otherwise 8 consecutive k, one 16-byte read.
 #pragma unroll
-            for (int m = 0; m < MREP; ++m)
-              af[m] = *reinterpret_cast<const bf16x8*>(
-                  &Ah[(wr * (BM / 2) + m * 16 + (lane & 15)) * LD + kk * 32 + (lane >> 4) * 8]);
+            for (int m = 0; m < MREP; ++m) {
+              const int r0 = wr * (BM / 2) + m * 16;
+              if (A_ROW) {
+                const __bf16* p = &Ah[(kk * 32 + kg * 4 + (li >> 2)) * LDA + r0 + (li & 3) * 4];
+                const bf16x4 lo = lds_read_tr4(p), hi = lds_read_tr4(p + 16 * LDA);
+                af[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              } else if (MIXED) {
+                const __bf16* p = &Ah[(r0 + li) * LDA + kk * 32 + kg * 4];
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 16);
+                af[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              } else {
+                af[m] = *reinterpret_cast<const bf16x8*>(&Ah[(r0 + li) * LDA + kk * 32 + kg * 8]);
+              }
+            }
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-              bfr[n] = *reinterpret_cast<const bf16x8*>(
-                  &Bh[(wc * 32 + n * 16 + (lane & 15)) * LD + kk * 32 + (lane >> 4) * 8]);
+            for (int n = 0; n < 2; ++n) {
+              const int c0 = wc * 32 + n * 16;
+              if (B_ROW) {
+                const __bf16* p = &Bh[(kk * 32 + kg * 4 + (li >> 2)) * LDB + c0 + (li & 3) * 4];
+                const bf16x4 lo = lds_read_tr4(p), hi = lds_read_tr4(p + 16 * LDB);
+                bfr[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              } else if (MIXED) {
+                const __bf16* p = &Bh[(c0 + li) * LDB + kk * 32 + kg * 4];
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 16);
+                bfr[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              } else {
+                bfr[n] = *reinterpret_cast<const bf16x8*>(&Bh[(c0 + li) * LDB + kk * 32 + kg * 8]);
+              }
+            }
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
@@ -363,11 +368,17 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
 #pragma unroll
           for (int ks = 0; ks < BK / 4; ++ks) {
             float af[MREP], bfr[2];
+            const int kq = ks * 4 + (lane >> 4);
 #pragma unroll
-            for (int m = 0; m < MREP; ++m)
-              af[m] = Af[(wr * (BM / 2) + m * 16 + (lane & 15)) * LD + ks * 4 + (lane >> 4)];
+            for (int m = 0; m < MREP; ++m) {
+              const int r = wr * (BM / 2) + m * 16 + (lane & 15);
+              af[m] = A_ROW ? Af[kq * LDA + r] : Af[r * LDA + kq];
+            }
 #pragma unroll
-            for (int n = 0; n < 2; ++n) bfr[n] = Bf[(wc * 32 + n * 16 + (lane & 15)) * LD + ks * 4 + (lane >> 4)];
+            for (int n = 0; n < 2; ++n) {
+              const int c = wc * 32 + n * 16 + (lane & 15);
+              bfr[n] = B_ROW ? Bf[kq * LDB + c] : Bf[c * LDB + kq];
+            }
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
@@ -453,19 +464,29 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
       }
 }
 
-template <bool BF16, int BM, bool BIGK>
-static void launch_fast2(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 grid, hipStream_t st) {
+template <bool BF16, int BM, bool BIGK, bool GATE>
+static void launch_fast3(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 grid, hipStream_t st) {
   if (a_row) {
     if (b_row)
-      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, true, true>), grid, dim3(F_THREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, true, true, GATE>), grid, dim3(F_THREADS), 0, st, g);
     else
-      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, true, false>), grid, dim3(F_THREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, true, false, GATE>), grid, dim3(F_THREADS), 0, st, g);
   } else {
     if (b_row)
-      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, false, true>), grid, dim3(F_THREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, false, true, GATE>), grid, dim3(F_THREADS), 0, st, g);
     else
-      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, false, false>), grid, dim3(F_THREADS), 0, st, g);
+      hipLaunchKernelGGL((gemm_fast_kernel<BF16, BM, BIGK, false, false, GATE>), grid, dim3(F_THREADS), 0, st, g);
   }
+}
+
+template <bool BF16, int BM, bool BIGK>
+static void launch_fast2(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 grid, hipStream_t st) {
+  bool gate = false;
+  for (int s = 0; s < g.nseg; ++s) gate = gate || (g.seg[s].a_gate != nullptr);
+  if (gate)
+    launch_fast3<BF16, BM, BIGK, true>(g, a_row, b_row, grid, st);
+  else
+    launch_fast3<BF16, BM, BIGK, false>(g, a_row, b_row, grid, st);
 }
 
 template <bool BF16, int BM>
@@ -499,6 +520,20 @@ int kantts_gemm_try_fast(const kantts_gemm_args& g, hipStream_t st) {
     if (sg.b_tok_axis == 2 && bm != 3) return 0;
     if (sg.b_tok_axis == 1) return 0;
     if (sg.a_drop_p > 0.f && g.groups > 1) return 0;  // dropout counters are group-relative here
+    // plain token maps only (see f_shift_token)
+    if (sg.a_inner > 1 || sg.a_mul > 1 || sg.a_div > 1 || sg.a_up > 1 || (sg.a_Tsrc > 0 && sg.a_Tsrc != (sg.a_Tq > 0 ? sg.a_Tq : g.T)))
+      return 0;
+    if (sg.b_inner > 1 || sg.b_mul > 1 || sg.b_div > 1 || sg.b_up > 1 || (sg.b_Tsrc > 0 && sg.b_Tsrc != (sg.b_Tq > 0 ? sg.b_Tq : g.T)))
+      return 0;
+    // 32-bit byte offsets inside an operand: bound the farthest element either side can touch
+    const long long amul = sg.a_mul > 0 ? sg.a_mul : 1, bmul = sg.b_mul > 0 ? sg.b_mul : 1;
+    const long long a_rows = (long long)g.M * (sg.a_tok_axis == 1 ? amul : 1) + 8;
+    const long long a_ks_n = (long long)sg.klen * (sg.a_tok_axis == 2 ? amul : 1) + 8;
+    const long long b_ks_n = (long long)sg.klen * (sg.b_tok_axis == 2 ? bmul : 1) + 8;
+    const long long ext_a = a_rows * llabs(sg.a_is) + a_ks_n * llabs(sg.a_ks);
+    const long long ext_b = ((long long)g.N + 8) * llabs(sg.b_js) + b_ks_n * llabs(sg.b_ks);
+    if (ext_a >= (1ll << 30) || ext_b >= (1ll << 30)) return 0;
+    if (sg.a_is < 0 || sg.a_ks < 0 || sg.b_js < 0 || sg.b_ks < 0) return 0;
   }
   const int splitk = g.splitk < 1 ? 1 : g.splitk;
   const int groups = g.groups < 1 ? 1 : g.groups;

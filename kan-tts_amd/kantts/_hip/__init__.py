@@ -65,6 +65,17 @@ class ConvArgs(Structure):
     ]
 
 
+class ConvWArgs(Structure):
+    """kantts_convw_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("dy", c_void_p), ("dy_gate", c_void_p), ("dw", c_void_p), ("db", c_void_p),
+        ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cin_tot", c_int32), ("Ntot", c_int32),
+        ("CR", c_int32), ("NG", c_int32), ("groups", c_int32), ("K", c_int32),
+        ("stride", c_int32), ("dil", c_int32), ("pad", c_int32), ("inner", c_int32),
+        ("x_slope", c_float), ("x_act", c_int32), ("dy_gate_slope", c_float), ("precision", c_int32),
+    ]
+
+
 def available() -> bool:
     return os.path.exists(LIB_PATH)
 
@@ -109,6 +120,7 @@ def lib():
         L.kantts_sinadd_fwd.argtypes = [p, p, ll, p]
         L.kantts_sinadd_bwd.argtypes = [p, p, p, ll, p]
         L.kantts_conv_win_launch.argtypes = [POINTER(ConvArgs), c_void_p]
+        L.kantts_conv_wgrad_launch.argtypes = [POINTER(ConvWArgs), c_void_p]
         _lib = L
     return _lib
 
@@ -119,7 +131,7 @@ EXPORTED_SYMBOLS = [
     "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
     "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_fsmn_dwconv_bwd_ws", "kantts_masked_l1",
     "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd",
-    "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch",
+    "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch",
 ]
 
 
@@ -282,6 +294,35 @@ def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add,
     if _profile is not None:
         e1.record()
         _profile.append((e0, e1, 2.0 * B * Tdst * inner * groups * NG * CR * K / max(1, in_div)))
+    return True
+
+
+def conv_wgrad(x, dy, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, dil, pad, inner=1, dy_gate=None,
+               dy_gate_slope=0.0, x_leaky=None):
+    """Accumulate the tap-major weight gradient (K, Ntot, CR) and the bias gradient (csrc/conv_wgrad.hip).
+    Returns False when the kernel does not take the shape (caller falls back to the segmented GEMM)."""
+    if _precision["gemm"] not in (PREC_FP32, PREC_BF16) or os.environ.get("KANTTS_NO_CONVWIN"):
+        return False
+    g = ConvWArgs()
+    g.x, g.dy, g.dy_gate = ptr(x, torch.float32), ptr(dy, torch.float32), ptr(dy_gate, torch.float32)
+    g.dw, g.db = ptr(dw_tap, torch.float32), ptr(db, torch.float32)
+    g.B, g.Tsrc, g.Tdst = int(B), int(Tsrc), int(Tdst)
+    g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K = int(groups * CR), int(groups * NG), int(CR), int(NG), int(groups), int(K)
+    g.stride, g.dil, g.pad, g.inner = int(stride), int(dil), int(pad), int(inner)
+    if x_leaky is not None:
+        g.x_act, g.x_slope = 1, float(x_leaky)
+    g.dy_gate_slope = float(dy_gate_slope)
+    g.precision = _precision["gemm"]
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().kantts_conv_wgrad_launch(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "conv_wgrad")
+    if _profile is not None:
+        e1.record()
+        _profile.append((e0, e1, 2.0 * B * Tdst * inner * groups * NG * CR * K))
     return True
 
 

@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import (PREC_REF, check, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
+from . import (PREC_REF, check, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
 
 _seed_counter = itertools.count(1)
 
@@ -761,6 +761,10 @@ class _ConvCL(torch.autograd.Function):
             if has_bias:
                 db = gzeros((Cout,), dy.device)
             Mtok = B * Tout * inner
+            if up == 1 and conv_wgrad(x, dy, dwt, db, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K,
+                                      stride=stride, dil=dil, pad=pad, inner=inner, dy_gate=gate, dy_gate_slope=gslope,
+                                      x_leaky=cfg["in_leaky"]):
+                return dx, dwt.permute(1, 2, 0), db, (dy if has_res else None), None
             seg = make_seg(dy, 1, Cout, x, 1, Cin, Mtok, ntaps=K, a_gate=gate, a_gate_slope=gslope, b_tok_axis=2,
                            b_shift0=-pad, b_shift_step=dil,
                            b_map=dict(inner=inner, Tq=Tout, Tsrc=Tin, mul=stride, up=up), b_leaky=cfg["in_leaky"])

@@ -650,3 +650,33 @@ class EmulatedLib:
         out = _arr(g.out, B * Td * P * N).reshape(B, Td, P, N)
         out[:] = acc.reshape(B, P, Td, N).transpose(0, 2, 1, 3).astype(np.float32)
         return 0
+
+    def kantts_conv_wgrad_launch(self, args_ref, stream):
+        g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
+        if (g.CR % 4) or (g.NG % 4):
+            return -2
+        P, B, Ts, Td, Ci, N, CR, NG, G, K = g.inner, g.B, g.Tsrc, g.Tdst, g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K
+
+        def load(ptr, T, C):
+            return _arr(ptr, B * T * P * C).reshape(B, T, P, C).transpose(0, 2, 1, 3).reshape(B * P, T, C)
+
+        x = load(g.x, Ts, Ci).astype(np.float64)
+        if g.x_act:
+            x = np.where(x > 0, x, x * np.float32(g.x_slope))
+        dy = load(g.dy, Td, N).astype(np.float64)
+        if g.dy_gate:
+            dy = dy * np.where(load(g.dy_gate, Td, N) > 0, 1.0, np.float32(g.dy_gate_slope))
+        dw = _arr(g.dw, K * N * CR).reshape(K, N, CR)
+        q = np.arange(Td)
+        for k in range(K):
+            src = q * g.stride + k * g.dil - g.pad
+            ok = (src >= 0) & (src < Ts)
+            if not ok.any():
+                continue
+            for gi in range(G):
+                d = dy[:, q[ok], gi * NG:(gi + 1) * NG]
+                xs = x[:, src[ok], gi * CR:(gi + 1) * CR]
+                dw[k, gi * NG:(gi + 1) * NG, :] += np.einsum("btn,btc->nc", d, xs).astype(np.float32)
+        if g.db:
+            _arr(g.db, N)[:] += dy.sum(axis=(0, 1)).astype(np.float32)
+        return 0
