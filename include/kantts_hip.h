@@ -269,8 +269,9 @@ int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, long long n, v
  *   post(v) : LeakyReLU(out_slope) when out_act, + res, then *= (out_gate > 0 ? 1 : out_gate_slope)
  * forward : in_mul = stride, in_add = -pad, in_kstep = dilation, in_div = 1, phases = 1
  * dgrad   : in = dy, in_mul = 1, in_add = pad, in_kstep = -dilation, in_div = phases = stride
- * w is tap-major (K, Ntot, CR) fp32.  KANTTS_E_UNSUPPORTED when CR / Cin_tot are not multiples of 4,
- * pointers are not 16-byte aligned, or K > 64 -- callers then use kantts_gemm_seg_launch. */
+ * w is tap-major (K, Ntot, CR) fp32.  CR % 4 != 0 (1/2-channel layers) runs a direct one-thread-per-output kernel;
+ * otherwise KANTTS_E_UNSUPPORTED when pointers are not 16-byte aligned or K > 64 -- callers then use
+ * kantts_gemm_seg_launch. */
 typedef struct {
   const float* in;
   const float* in_gate;
@@ -282,6 +283,7 @@ typedef struct {
   int B, Tsrc, Tdst, Cin_tot, Ntot, CR, NG, groups, K;
   int in_mul, in_add, in_kstep, in_div, phases;
   int inner; /* folded axis between time and channels (MPD period): in is (B, Tsrc, inner, Cin_tot), out (B, Tdst, inner, Ntot) */
+  int up;    /* > 1: `in` is read through a nearest-neighbour upsampling: token u of the rule above is source token u / up */
   float in_slope;
   int in_act;
   float in_gate_slope;
@@ -297,7 +299,8 @@ int kantts_conv_win_launch(const kantts_conv_args* args, void* stream);
  *   db[n]       += sum_{b,p,q} gate(dy[b,q,p,n])                                   (db may be NULL)
  * x is (B, Tsrc, inner, Cin_tot), dy / dy_gate are (B, Tdst, inner, Ntot), dw is tap-major (K, Ntot, CR).
  * gate(v) = v * (dy_gate > 0 ? 1 : dy_gate_slope) when dy_gate is given; act = LeakyReLU(x_slope) when x_act.
- * KANTTS_E_UNSUPPORTED when CR or NG is not a multiple of 4 or a pointer is not 16-byte aligned. */
+ * CR or NG not a multiple of 4 runs a direct kernel (up must be 1); otherwise KANTTS_E_UNSUPPORTED when a
+ * pointer is not 16-byte aligned. */
 typedef struct {
   const float* x;
   const float* dy;
@@ -306,12 +309,36 @@ typedef struct {
   float* db;
   int B, Tsrc, Tdst, Cin_tot, Ntot, CR, NG, groups, K;
   int stride, dil, pad, inner;
+  int up; /* > 1: x is read through a nearest-neighbour upsampling (virtual token u = source token u / up) */
   float x_slope;
   int x_act;
   float dy_gate_slope;
   int precision; /* 0 fp32 MFMA, 1 bf16 MFMA (fp32 accumulate) */
 } kantts_convw_args;
 int kantts_conv_wgrad_launch(const kantts_convw_args* args, void* stream);
+
+/* Single-input-channel convolutions (first layer of the HiFi-GAN discriminators; csrc/conv_c1.hip), fp32 streaming kernels.
+ * x / dx are (B, Tsrc, inner), y (= dy for the gradients) and gate are (B, Tdst, inner, Cout), w / dw are (Cout, K) row-major.
+ *   mode 0  y[b,q,p,n]   = act( bias[n] + sum_k x[b, q*stride + k*dil - pad, p] * w[n][k] )      act = LeakyReLU(out_slope) when out_act
+ *   mode 1  dx[b,t,p]   += sum_k sum_n gate(y[b,q,p,n]) * w[n][k]   at t = q*stride + k*dil - pad   (dx must start at zero)
+ *   mode 2  dw[n][k]    += sum_{b,q,p} gate(y[b,q,p,n]) * x[b, q*stride + k*dil - pad, p];   db[n] += sum gate(y)   (db may be NULL)
+ * gate(v) = v * (gate > 0 ? 1 : gate_slope) when gate is given.
+ * KANTTS_E_UNSUPPORTED unless K <= 16, Cout % 4 == 0, Cout <= 256 and 256 % Cout == 0. */
+typedef struct {
+  const float* x;
+  float* dx;
+  float* y;
+  const float* gate;
+  const float* w;
+  const float* bias;
+  float* dw;
+  float* db;
+  int B, Tsrc, Tdst, Cout, K, stride, dil, pad, inner;
+  float out_slope;
+  int out_act;
+  float gate_slope;
+} kantts_conv_c1_args;
+int kantts_conv_c1_launch(const kantts_conv_c1_args* args, int mode, void* stream);
 
 #ifdef __cplusplus
 }

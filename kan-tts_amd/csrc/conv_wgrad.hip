@@ -77,8 +77,12 @@ __global__ __launch_bounds__(WG_THREADS, BF16 ? 2 : 1) void conv_wgrad_kernel(co
   const long long step_hi = min(total_steps, step_lo + steps_per_block);
   if (step_lo >= step_hi || nk <= 0) return;
 
-  const int W = (WG_BQ - 1) * s + (nk - 1) * g.dil + 1;  // x tokens one step can touch
-  const int Wp = (W + s - 1) / s;
+  // up > 1: x is read through a nearest-neighbour upsampling (virtual token u = source token u / up): the window
+  // holds source tokens and every lane computes its own (repeating) row for the transpose reads
+  const int up = g.up > 1 ? g.up : 1;
+  const int dm = (up > 1) ? 1 : s;
+  const int Wmax = (up > 1) ? ((WG_BQ - 1) * s + (nk - 1) * g.dil) / up + 3 : (WG_BQ - 1) * s + (nk - 1) * g.dil + 1;
+  const int Wp = (Wmax + dm - 1) / dm;
   void* dyt = wg_lds;
   void* xw = wg_lds + WG_BQ * PN * ESZ;
 
@@ -126,7 +130,11 @@ __global__ __launch_bounds__(WG_THREADS, BF16 ? 2 : 1) void conv_wgrad_kernel(co
       constexpr int LPR = CT / 4, RPP = WG_THREADS / LPR;
       const int c4 = (tid % LPR) * 4;
       const bool cok = (c0 + c4) < g.CR;
-      const int lo = q0 * s - g.pad + k0 * g.dil;
+      const int lo_u = q0 * s - g.pad + k0 * g.dil;
+      const int lo = (up > 1) ? ((lo_u >= 0) ? lo_u / up : -((-lo_u + up - 1) / up)) : lo_u;
+      const int W = (up > 1) ? (lo_u + (WG_BQ - 1) * s + (nk - 1) * g.dil >= 0
+                                    ? (lo_u + (WG_BQ - 1) * s + (nk - 1) * g.dil) / up - lo + 1 : 1)
+                             : Wmax;
       for (int r0 = tid / LPR; r0 < W; r0 += RPP * 4) {
         float4 xv[4];
         bool ok[4];
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(WG_THREADS, BF16 ? 2 : 1) void conv_wgrad_kernel(co
             v2 = v2 > 0.f ? v2 : v2 * g.x_slope;
             v3 = v3 > 0.f ? v3 : v3 * g.x_slope;
           }
-          wg_store4<BF16>(xw, ((rel % s) * Wp + rel / s) * PC + c4, v0, v1, v2, v3);
+          wg_store4<BF16>(xw, ((rel % dm) * Wp + rel / dm) * PC + c4, v0, v1, v2, v3);
         }
       }
     }
@@ -179,12 +187,21 @@ __global__ __launch_bounds__(WG_THREADS, BF16 ? 2 : 1) void conv_wgrad_kernel(co
       for (int t = 0; t < TG; ++t) {
         if (t < nk) {
           const int a_ = t * g.dil;
-          const int rb = (a_ % s) * Wp + a_ / s + kg * 4 + (li >> 2);
+          int rb = (a_ % dm) * Wp + a_ / dm + kg * 4 + (li >> 2), rb2 = rb + 16;
+          if (up > 1) {
+            const int lo_u = q0 * s - g.pad + k0 * g.dil;
+            const int lo = (lo_u >= 0) ? lo_u / up : -((-lo_u + up - 1) / up);
+            const int u1 = lo_u + (kg * 4 + (li >> 2)) * s + a_, u2 = u1 + 16 * s;
+            // negative virtual tokens only occur inside the zero padding: any zero row will do (row 0 is token lo <= -1)
+            rb = (u1 >= 0) ? u1 / up - lo : 0;
+            rb2 = (u2 >= 0) ? u2 / up - lo : 0;
+          }
           bf16x8 bfr[CF];
 #pragma unroll
           for (int c = 0; c < CF; ++c) {
             const __bf16* p = &Xh[rb * PC + (wc * CF + c) * 16 + (li & 3) * 4];
-            const bf16x4 lo4 = wg_read_tr4(p), hi4 = wg_read_tr4(p + 16 * PC);
+            const __bf16* p2 = &Xh[rb2 * PC + (wc * CF + c) * 16 + (li & 3) * 4];
+            const bf16x4 lo4 = wg_read_tr4(p), hi4 = wg_read_tr4(p2);
             bfr[c] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
           }
 #pragma unroll
@@ -207,7 +224,13 @@ __global__ __launch_bounds__(WG_THREADS, BF16 ? 2 : 1) void conv_wgrad_kernel(co
         for (int t = 0; t < TG; ++t) {
           if (t < nk) {
             const int a_ = t * g.dil;
-            const int rb = (a_ % s) * Wp + a_ / s + qq;
+            int rb = (a_ % dm) * Wp + a_ / dm + qq;
+            if (up > 1) {
+              const int lo_u = q0 * s - g.pad + k0 * g.dil;
+              const int lo = (lo_u >= 0) ? lo_u / up : -((-lo_u + up - 1) / up);
+              const int u1 = lo_u + qq * s + a_;
+              rb = (u1 >= 0) ? u1 / up - lo : 0;
+            }
             float bfr[CF];
 #pragma unroll
             for (int c = 0; c < CF; ++c) bfr[c] = Xf[rb * PC + (wc * CF + c) * 16 + li];
@@ -241,6 +264,86 @@ __global__ __launch_bounds__(WG_THREADS, BF16 ? 2 : 1) void conv_wgrad_kernel(co
   if (do_bias && tid < 64 && (n0 + tid) < n_end) atomicAdd(&g.db[n0 + tid], bsum);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Direct form for channel counts the MFMA tiles cannot use (CR or NG not a multiple of 4: the 1/2/4-channel
+// wavelet / projection convolutions and the Cout = 1 output convolutions).  A thread owns one (n, c) pair and
+// keeps its <= 16 taps in registers; it walks x tokens (x[t][c] is read once, coalesced over c, and meets the
+// K output tokens that tap it -- dy[q][n] is a broadcast).  With few pairs the block's threads also split the
+// tokens (PP pairs x 256/PP token lanes) and meet in LDS; every block adds its sums to dw with one atomic each.
+#define WD_MAXK 16
+__global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const kantts_convw_args g, int PP, int slab, int k0) {
+  extern __shared__ float wd_red[];  // [PP][WD_MAXK + 1] when token lanes > 1
+  const int npairs = g.Ntot * g.CR;
+  const int TL = 256 / PP;
+  const int pl = threadIdx.x % PP, tl = threadIdx.x / PP;
+  const int pair = blockIdx.x * PP + pl;
+  const bool own = pair < npairs;
+  const int n = own ? pair / g.CR : 0;
+  const int c = (own ? pair % g.CR : 0) + (n / g.NG) * g.CR;  // input channel inside the group of n
+  const int nk = min(WD_MAXK, g.K - k0);
+  const long long seqs = (long long)g.B * g.inner;            // (b, p) sequences
+  const int slabs_per_seq = (g.Tsrc + slab - 1) / slab;
+  const long long sq = blockIdx.y / slabs_per_seq;
+  const int t_lo = (int)(blockIdx.y % slabs_per_seq) * slab, t_hi = min(g.Tsrc, t_lo + slab);
+  const int b = (int)(sq / g.inner), pi = (int)(sq % g.inner);
+  (void)seqs;
+  float acc[WD_MAXK];
+#pragma unroll
+  for (int k = 0; k < WD_MAXK; ++k) acc[k] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = g.db != nullptr && k0 == 0 && own && (pair % g.CR) == 0;
+  const float* xb = g.x + ((long long)b * g.Tsrc * g.inner + pi) * g.Cin_tot + c;
+  const long long x_pitch = (long long)g.inner * g.Cin_tot, dy_pitch = (long long)g.inner * g.Ntot;
+  const float* dyb = g.dy + ((long long)b * g.Tdst * g.inner + pi) * g.Ntot + n;
+  const float* gtb = g.dy_gate ? g.dy_gate + ((long long)b * g.Tdst * g.inner + pi) * g.Ntot + n : nullptr;
+  if (own) {
+    for (int t = t_lo + tl; t < t_hi; t += TL) {
+      float v = xb[(long long)t * x_pitch];
+      if (g.x_act) v = v > 0.f ? v : v * g.x_slope;
+#pragma unroll
+      for (int k = 0; k < WD_MAXK; ++k) {
+        if (k < nk) {
+          const int u = t + g.pad - (k0 + k) * g.dil;  // = q * stride
+          const int q = u / g.stride;
+          if (u >= 0 && q * g.stride == u && q < g.Tdst) {
+            float d = dyb[(long long)q * dy_pitch];
+            if (gtb) d *= (gtb[(long long)q * dy_pitch] > 0.f) ? 1.f : g.dy_gate_slope;
+            acc[k] += d * v;
+          }
+        }
+      }
+    }
+    if (do_bias) {  // bias: the slab of OUTPUT tokens with the same index range (Tdst <= Tsrc-ish; cover the rest in the last slab)
+      const int q_hi = (t_hi == g.Tsrc) ? g.Tdst : min(g.Tdst, t_hi);
+      for (int q = t_lo + tl; q < q_hi; q += TL) {
+        float d = dyb[(long long)q * dy_pitch];
+        if (gtb) d *= (gtb[(long long)q * dy_pitch] > 0.f) ? 1.f : g.dy_gate_slope;
+        bsum += d;
+      }
+    }
+  }
+  if (TL > 1) {
+    for (int i = threadIdx.x; i < PP * (WD_MAXK + 1); i += 256) wd_red[i] = 0.f;
+    __syncthreads();
+    if (own) {
+#pragma unroll
+      for (int k = 0; k < WD_MAXK; ++k)
+        if (k < nk) atomicAdd(&wd_red[pl * (WD_MAXK + 1) + k], acc[k]);
+      if (do_bias) atomicAdd(&wd_red[pl * (WD_MAXK + 1) + WD_MAXK], bsum);
+    }
+    __syncthreads();
+    if (tl != 0 || !own) return;
+#pragma unroll
+    for (int k = 0; k < WD_MAXK; ++k) acc[k] = wd_red[pl * (WD_MAXK + 1) + k];
+    bsum = wd_red[pl * (WD_MAXK + 1) + WD_MAXK];
+  }
+  if (!own) return;
+#pragma unroll
+  for (int k = 0; k < WD_MAXK; ++k)
+    if (k < nk) atomicAdd(&g.dw[((long long)(k0 + k) * g.Ntot + n) * g.CR + (pair % g.CR)], acc[k]);
+  if (do_bias) atomicAdd(&g.db[n], bsum);
+}
+
 template <bool BF16, int CT>
 static int wg_launch(const kantts_convw_args& g, hipStream_t st) {
   constexpr int TG = (CT == 64) ? 8 : 16;
@@ -249,9 +352,11 @@ static int wg_launch(const kantts_convw_args& g, hipStream_t st) {
   const int ntg = kantts_cdiv(g.K, TG);
   const int tpb = kantts_cdiv(g.K, ntg);  // taps per block, balanced over the tap groups
   const int ntn = kantts_cdiv(g.NG, 64), ntc = kantts_cdiv(g.CR, CT);
-  const int W = (WG_BQ - 1) * g.stride + (tpb - 1) * g.dil + 1;
-  const int Wp = kantts_cdiv(W, g.stride);
-  const size_t lds = (size_t)WG_BQ * 80 * ESZ + (size_t)Wp * g.stride * PC * ESZ;
+  const int up = g.up > 1 ? g.up : 1;
+  const int dm = (up > 1) ? 1 : g.stride;
+  const int W = (up > 1) ? ((WG_BQ - 1) * g.stride + (tpb - 1) * g.dil) / up + 3 : (WG_BQ - 1) * g.stride + (tpb - 1) * g.dil + 1;
+  const int Wp = kantts_cdiv(W, dm);
+  const size_t lds = (size_t)WG_BQ * 80 * ESZ + (size_t)Wp * dm * PC * ESZ;
   if (lds > 150 * 1024) return KANTTS_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
@@ -278,9 +383,31 @@ extern "C" int kantts_conv_wgrad_launch(const kantts_convw_args* a, void* stream
   if (!a || !a->x || !a->dy || !a->dw) return KANTTS_E_BADARG;
   const kantts_convw_args& g = *a;
   if (g.B < 0 || g.Tsrc < 0 || g.Tdst < 0 || g.K < 1 || g.groups < 1 || g.NG < 1 || g.CR < 1 || g.stride < 1 ||
-      g.dil < 1 || g.inner < 1)
+      g.dil < 1 || g.inner < 1 || g.up < 0)
     return KANTTS_E_BADARG;
   if (g.Ntot != g.groups * g.NG || g.Cin_tot != g.groups * g.CR) return KANTTS_E_BADARG;
+  if (g.B == 0 || g.Tdst == 0) return KANTTS_OK;
+  if ((g.CR & 3) || (g.NG & 3)) {
+    if (g.up > 1) return KANTTS_E_UNSUPPORTED;
+    const int npairs = g.Ntot * g.CR;
+    int PP = 256;
+    while (PP > 1 && PP / 2 >= npairs) PP /= 2;
+    const long long gx = (npairs + PP - 1) / PP;
+    const long long seqs = (long long)g.B * g.inner;
+    // enough token slabs for ~2048 blocks, at least 8 x tokens per thread
+    long long want = (2048 + gx - 1) / gx;
+    long long slab = ((long long)g.Tsrc * seqs + want - 1) / want;
+    const int TL = 256 / PP;
+    if (slab < 8LL * TL) slab = 8LL * TL;
+    if (slab > g.Tsrc) slab = g.Tsrc > 0 ? g.Tsrc : 1;
+    const long long gy = seqs * ((g.Tsrc + slab - 1) / slab);
+    if (gy > 65535 || gx > 0x7fffffffLL) return KANTTS_E_UNSUPPORTED;
+    const size_t lds = (TL > 1) ? (size_t)PP * (WD_MAXK + 1) * sizeof(float) : 0;
+    for (int k0 = 0; k0 < g.K; k0 += WD_MAXK)
+      hipLaunchKernelGGL(conv_wgrad_direct_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, (hipStream_t)stream, g,
+                         PP, (int)slab, k0);
+    KANTTS_CHECK_LAUNCH();
+  }
   if ((g.CR & 3) || (g.NG & 3) || ((uintptr_t)g.x & 15) || ((uintptr_t)g.dy & 15) ||
       (g.dy_gate && ((uintptr_t)g.dy_gate & 15)))
     return KANTTS_E_UNSUPPORTED;

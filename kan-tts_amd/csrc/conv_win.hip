@@ -107,12 +107,17 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
       offmax = max(offmax, s_off[i]);
     }
   }
-  const int W = (BQ - 1) * g.in_mul + (offmax - offmin) + 1;
-  const int Wp = (W + g.in_mul - 1) / g.in_mul;
-  const int lo = m0 * g.in_mul + offmin;  // first source token of the window
+  // up > 1: the source is read through a nearest-neighbour upsampling (token u of the virtual sequence is source
+  // token u / up); the window then holds SOURCE tokens and every lane computes its own row (rows repeat).
+  const int up = g.up > 1 ? g.up : 1;
+  const int dm = (up > 1) ? 1 : g.in_mul;  // de-interleave modulus of the LDS window
+  const int lo = (up > 1) ? cw_floordiv(m0 * g.in_mul + offmin, up) : m0 * g.in_mul + offmin;  // first source token
+  const int W = (up > 1) ? cw_floordiv((m0 + BQ - 1) * g.in_mul + offmax, up) - lo + 1
+                         : (BQ - 1) * g.in_mul + (offmax - offmin) + 1;
+  const int Wp = (W + dm - 1) / dm;
 
   void* win = cw_lds;
-  unsigned char* bt = cw_lds + (size_t)Wp * g.in_mul * LDW * ESZ;
+  unsigned char* bt = cw_lds + (size_t)Wp * dm * LDW * ESZ;
 
   f32x4 acc[MREP][4];
 #pragma unroll
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
           v2 *= (gv[u].z > 0.f) ? 1.f : g.in_gate_slope;
           v3 *= (gv[u].w > 0.f) ? 1.f : g.in_gate_slope;
         }
-        const int row = (rel % g.in_mul) * Wp + rel / g.in_mul;
+        const int row = (rel % dm) * Wp + rel / dm;
         cw_store4<BF16>(win, row * LDW + c4, v0, v1, v2, v3);
       }
     }
@@ -193,7 +198,13 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
     for (int ti = 0; ti < nv; ++ti) {
       if (ti + 1 < nv) fetch_w(ti + 1, c0);
       const int a = s_off[ti] - offmin;
-      const int rbase = (a % g.in_mul) * Wp + a / g.in_mul + wm * (MREP * 16) + (lane & 15);
+      int arow[MREP];
+#pragma unroll
+      for (int f = 0; f < MREP; ++f) {
+        const int mloc = wm * (MREP * 16) + f * 16 + (lane & 15);
+        arow[f] = (up > 1) ? cw_floordiv((m0 + mloc) * g.in_mul + s_off[ti], up) - lo
+                           : (a % dm) * Wp + a / dm + mloc;
+      }
       const unsigned char* bcur = bt + (size_t)(ti & 1) * BN * LDW * ESZ;
       if (BF16) {
         const __bf16* Wh = reinterpret_cast<const __bf16*>(win);
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
         bf16x8 af[MREP], bfr[4];
 #pragma unroll
         for (int f = 0; f < MREP; ++f)
-          af[f] = *reinterpret_cast<const bf16x8*>(&Wh[(rbase + f * 16) * LDW + (lane >> 4) * 8]);
+          af[f] = *reinterpret_cast<const bf16x8*>(&Wh[arow[f] * LDW + (lane >> 4) * 8]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           bfr[j] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * 64 + j * 16 + (lane & 15)) * LDW + (lane >> 4) * 8]);
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
         for (int ks = 0; ks < CW_CK / 4; ++ks) {
           float af[MREP], bfr[4];
 #pragma unroll
-          for (int f = 0; f < MREP; ++f) af[f] = Wf[(rbase + f * 16) * LDW + ks * 4 + (lane >> 4)];
+          for (int f = 0; f < MREP; ++f) af[f] = Wf[arow[f] * LDW + ks * 4 + (lane >> 4)];
 #pragma unroll
           for (int j = 0; j < 4; ++j) bfr[j] = Bf[(wn * 64 + j * 16 + (lane & 15)) * LDW + ks * 4 + (lane >> 4)];
 #pragma unroll
@@ -278,6 +289,50 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Direct form of the same contract for channel counts the MFMA tiles cannot use (CR not a multiple of 4: the
+// 1/2/4-channel wavelet and projection convolutions of the scale discriminators, and the input gradient of the
+// Cout = 1 output convolutions): one thread per output element, taps x CR multiply-adds each.  These layers
+// are bound by the activations they stream, not by arithmetic.
+__global__ __launch_bounds__(256) void conv_direct_kernel(const kantts_conv_args g) {
+  const long long total = (long long)g.B * g.Tdst * g.inner * g.Ntot;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int n = (int)(e % g.Ntot);
+  long long r = e / g.Ntot;
+  const int pi = (int)(r % g.inner);
+  r /= g.inner;
+  const int d = (int)(r % g.Tdst);
+  const int b = (int)(r / g.Tdst);
+  const int phase = d % g.phases, m = d / g.phases;
+  const int grp = n / g.NG;
+  const long long in_pitch = (long long)g.inner * g.Cin_tot;
+  const float* in_b = g.in + ((long long)b * g.Tsrc * g.inner + pi) * g.Cin_tot + (long long)grp * g.CR;
+  const float* gate_b = g.in_gate ? g.in_gate + ((long long)b * g.Tsrc * g.inner + pi) * g.Cin_tot + (long long)grp * g.CR : nullptr;
+  float acc = 0.f;
+  for (int k = 0; k < g.K; ++k) {
+    const int u = g.in_add + phase + k * g.in_kstep;
+    const int q = cw_floordiv(u, g.in_div);
+    if (q * g.in_div != u) continue;
+    const int tu = m * g.in_mul + q;
+    const int up = g.up > 1 ? g.up : 1;
+    if (tu < 0 || tu >= g.Tsrc * up) continue;
+    const int t = tu / up;
+    const float* wr = g.w + ((long long)k * g.Ntot + n) * g.CR;
+    for (int c = 0; c < g.CR; ++c) {
+      float v = in_b[(long long)t * in_pitch + c];
+      if (g.in_act) v = v > 0.f ? v : v * g.in_slope;
+      if (gate_b) v *= (gate_b[(long long)t * in_pitch + c] > 0.f) ? 1.f : g.in_gate_slope;
+      acc += v * wr[c];
+    }
+  }
+  if (g.bias) acc += g.bias[n];
+  if (g.out_act) acc = acc > 0.f ? acc : acc * g.out_slope;
+  if (g.res) acc += g.res[e];
+  if (g.out_gate) acc *= (g.out_gate[e] > 0.f) ? 1.f : g.out_gate_slope;
+  g.out[e] = acc;
+}
+
 template <bool BF16, int WM, int MREP>
 static int cw_launch(const kantts_conv_args& g, hipStream_t st) {
   constexpr int WN = 4 / WM;
@@ -287,9 +342,11 @@ static int cw_launch(const kantts_conv_args& g, hipStream_t st) {
   constexpr int ESZ = BF16 ? 2 : 4;
   // worst-case window over the phases: the valid taps of a phase span at most (K-1)*|kstep|/div + 1 offsets
   const int span = ((g.K - 1) * abs(g.in_kstep)) / g.in_div + 1;
-  const int W = (BQ - 1) * g.in_mul + span + 1;
-  const int Wp = (W + g.in_mul - 1) / g.in_mul;
-  size_t lds = (size_t)Wp * g.in_mul * LDW * ESZ + 2 * (size_t)BN * LDW * ESZ;
+  const int up = g.up > 1 ? g.up : 1;
+  const int dm = (up > 1) ? 1 : g.in_mul;
+  const int W = (up > 1) ? ((BQ - 1) * g.in_mul + span) / up + 3 : (BQ - 1) * g.in_mul + span + 1;
+  const int Wp = (W + dm - 1) / dm;
+  size_t lds = (size_t)Wp * dm * LDW * ESZ + 2 * (size_t)BN * LDW * ESZ;
   const size_t strip = 4 * 16 * 68 * sizeof(float);
   if (lds < strip) lds = strip;
   lds += CW_HDR;
@@ -312,9 +369,16 @@ extern "C" int kantts_conv_win_launch(const kantts_conv_args* a, void* stream) {
   if (!a || !a->in || !a->w || !a->out) return KANTTS_E_BADARG;
   const kantts_conv_args& g = *a;
   if (g.B < 0 || g.Tsrc < 0 || g.Tdst < 0 || g.K < 1 || g.groups < 1 || g.NG < 1 || g.CR < 1 || g.in_mul < 1 ||
-      g.in_div < 1 || g.phases < 1 || g.inner < 1)
+      g.in_div < 1 || g.phases < 1 || g.inner < 1 || g.up < 0)
     return KANTTS_E_BADARG;
   if (g.Ntot != g.groups * g.NG || g.Cin_tot != g.groups * g.CR) return KANTTS_E_BADARG;
+  if (g.B == 0 || g.Tdst == 0) return KANTTS_OK;
+  if (g.CR & 3) {
+    const long long total = (long long)g.B * g.Tdst * g.inner * g.Ntot;
+    if (total > 0x7fffffffLL * 256) return KANTTS_E_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g);
+    KANTTS_CHECK_LAUNCH();
+  }
   if (g.K > CW_MAXTAPS) return KANTTS_E_UNSUPPORTED;
   // float4 staging of activations and weights
   if ((g.CR & 3) || (g.Cin_tot & 3) || ((uintptr_t)g.in & 15) || ((uintptr_t)g.w & 15) ||

@@ -58,7 +58,7 @@ class ConvArgs(Structure):
         ("res", c_void_p), ("out_gate", c_void_p),
         ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cin_tot", c_int32), ("Ntot", c_int32),
         ("CR", c_int32), ("NG", c_int32), ("groups", c_int32), ("K", c_int32),
-        ("in_mul", c_int32), ("in_add", c_int32), ("in_kstep", c_int32), ("in_div", c_int32), ("phases", c_int32), ("inner", c_int32),
+        ("in_mul", c_int32), ("in_add", c_int32), ("in_kstep", c_int32), ("in_div", c_int32), ("phases", c_int32), ("inner", c_int32), ("up", c_int32),
         ("in_slope", c_float), ("in_act", c_int32), ("in_gate_slope", c_float),
         ("out_slope", c_float), ("out_act", c_int32), ("out_gate_slope", c_float),
         ("precision", c_int32),
@@ -71,8 +71,19 @@ class ConvWArgs(Structure):
         ("x", c_void_p), ("dy", c_void_p), ("dy_gate", c_void_p), ("dw", c_void_p), ("db", c_void_p),
         ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cin_tot", c_int32), ("Ntot", c_int32),
         ("CR", c_int32), ("NG", c_int32), ("groups", c_int32), ("K", c_int32),
-        ("stride", c_int32), ("dil", c_int32), ("pad", c_int32), ("inner", c_int32),
+        ("stride", c_int32), ("dil", c_int32), ("pad", c_int32), ("inner", c_int32), ("up", c_int32),
         ("x_slope", c_float), ("x_act", c_int32), ("dy_gate_slope", c_float), ("precision", c_int32),
+    ]
+
+
+class ConvC1Args(Structure):
+    """kantts_conv_c1_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("dx", c_void_p), ("y", c_void_p), ("gate", c_void_p), ("w", c_void_p), ("bias", c_void_p),
+        ("dw", c_void_p), ("db", c_void_p),
+        ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cout", c_int32), ("K", c_int32), ("stride", c_int32),
+        ("dil", c_int32), ("pad", c_int32), ("inner", c_int32),
+        ("out_slope", c_float), ("out_act", c_int32), ("gate_slope", c_float),
     ]
 
 
@@ -121,6 +132,7 @@ def lib():
         L.kantts_sinadd_bwd.argtypes = [p, p, p, ll, p]
         L.kantts_conv_win_launch.argtypes = [POINTER(ConvArgs), c_void_p]
         L.kantts_conv_wgrad_launch.argtypes = [POINTER(ConvWArgs), c_void_p]
+        L.kantts_conv_c1_launch.argtypes = [POINTER(ConvC1Args), c_int, c_void_p]
         _lib = L
     return _lib
 
@@ -131,7 +143,7 @@ EXPORTED_SYMBOLS = [
     "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
     "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_fsmn_dwconv_bwd_ws", "kantts_masked_l1",
     "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd",
-    "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch",
+    "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch",
 ]
 
 
@@ -216,6 +228,9 @@ def _staging_mode(base, row_stride, k_stride, klen, rows, tok_axis, group_stride
     return 0
 
 
+_gemm_log = {} if os.environ.get("KANTTS_GEMM_LOG") else None
+
+
 def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_js=0, rowmask=None, kmask=None,
          a_rowsum=None, alpha=1.0, relu=False, accumulate=False, splitk=1, T=0, drop_p=0.0, drop_seed=0,
          precision=None, c_off=0, groups=1, a_gs=0, b_gs=0, c_gs=0, bias_gs=0, r_gs=0, out_leaky=None, gate=None,
@@ -230,6 +245,13 @@ def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_j
             s.b_mode = 0
         g.seg[k] = s
     g.nseg, g.M, g.N, g.T = len(segs), int(M), int(N), int(T)
+    if _gemm_log is not None:
+        s0 = segs[0]
+        slow = any(s.a_mode < 2 or s.b_mode < 2 or s.a_inner > 1 or s.a_mul > 1 or s.a_div > 1 or s.a_up > 1 or
+                   s.b_inner > 1 or s.b_mul > 1 or s.b_up > 1 for s in segs)
+        key = ("generic" if slow else "fast", int(M), int(N), s0.klen, s0.ntaps, int(groups), int(splitk), int(z_taps),
+               s0.a_mode, s0.b_mode)
+        _gemm_log[key] = _gemm_log.get(key, 0) + 1
     g.c = ptr(c, torch.float32) + 4 * int(c_off)
     g.c_is, g.c_js = int(c_is), int(c_js)
     g.bias, g.bias2 = ptr(bias, torch.float32), ptr(bias2, torch.float32)
@@ -263,7 +285,7 @@ def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_j
 E_UNSUPPORTED = -2
 
 
-def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add, in_kstep, in_div, phases, inner=1,
+def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add, in_kstep, in_div, phases, inner=1, up=1,
              bias=None, res=None, in_gate=None, in_gate_slope=0.0, in_leaky=None, out_leaky=None, out_gate=None,
              out_gate_slope=0.0):
     """Windowed channels-last convolution (csrc/conv_win.hip).  Returns False when the kernel does not
@@ -277,7 +299,7 @@ def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add,
     g.B, g.Tsrc, g.Tdst = int(B), int(Tsrc), int(Tdst)
     g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K = int(groups * CR), int(groups * NG), int(CR), int(NG), int(groups), int(K)
     g.in_mul, g.in_add, g.in_kstep, g.in_div, g.phases = int(in_mul), int(in_add), int(in_kstep), int(in_div), int(phases)
-    g.inner = int(inner)
+    g.inner, g.up = int(inner), int(up)
     if in_leaky is not None:
         g.in_act, g.in_slope = 1, float(in_leaky)
     if out_leaky is not None:
@@ -297,7 +319,7 @@ def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add,
     return True
 
 
-def conv_wgrad(x, dy, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, dil, pad, inner=1, dy_gate=None,
+def conv_wgrad(x, dy, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, dil, pad, inner=1, up=1, dy_gate=None,
                dy_gate_slope=0.0, x_leaky=None):
     """Accumulate the tap-major weight gradient (K, Ntot, CR) and the bias gradient (csrc/conv_wgrad.hip).
     Returns False when the kernel does not take the shape (caller falls back to the segmented GEMM)."""
@@ -308,7 +330,7 @@ def conv_wgrad(x, dy, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, d
     g.dw, g.db = ptr(dw_tap, torch.float32), ptr(db, torch.float32)
     g.B, g.Tsrc, g.Tdst = int(B), int(Tsrc), int(Tdst)
     g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K = int(groups * CR), int(groups * NG), int(CR), int(NG), int(groups), int(K)
-    g.stride, g.dil, g.pad, g.inner = int(stride), int(dil), int(pad), int(inner)
+    g.stride, g.dil, g.pad, g.inner, g.up = int(stride), int(dil), int(pad), int(inner), int(up)
     if x_leaky is not None:
         g.x_act, g.x_slope = 1, float(x_leaky)
     g.dy_gate_slope = float(dy_gate_slope)
@@ -323,6 +345,27 @@ def conv_wgrad(x, dy, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, d
     if _profile is not None:
         e1.record()
         _profile.append((e0, e1, 2.0 * B * Tdst * inner * groups * NG * CR * K))
+    return True
+
+
+def conv_c1(mode, *, x=None, dx=None, y=None, gate=None, w=None, bias=None, dw=None, db=None, B, Tsrc, Tdst, Cout, K,
+            stride, dil, pad, inner=1, out_leaky=None, gate_slope=0.0):
+    """Single-input-channel convolution kernels (csrc/conv_c1.hip): mode 0 forward, 1 input gradient, 2 weight /
+    bias gradient.  Returns False when the shape is not supported."""
+    if os.environ.get("KANTTS_NO_CONVWIN"):
+        return False
+    g = ConvC1Args()
+    g.x, g.dx, g.y, g.gate = ptr(x, torch.float32), ptr(dx, torch.float32), ptr(y, torch.float32), ptr(gate, torch.float32)
+    g.w, g.bias, g.dw, g.db = ptr(w, torch.float32), ptr(bias, torch.float32), ptr(dw, torch.float32), ptr(db, torch.float32)
+    g.B, g.Tsrc, g.Tdst, g.Cout, g.K = int(B), int(Tsrc), int(Tdst), int(Cout), int(K)
+    g.stride, g.dil, g.pad, g.inner = int(stride), int(dil), int(pad), int(inner)
+    if out_leaky is not None:
+        g.out_act, g.out_slope = 1, float(out_leaky)
+    g.gate_slope = float(gate_slope)
+    rc = lib().kantts_conv_c1_launch(ctypes.byref(g), int(mode), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "conv_c1")
     return True
 
 

@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import (PREC_REF, check, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
+from . import (PREC_REF, check, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
 
 _seed_counter = itertools.count(1)
 
@@ -681,6 +681,26 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=No
 # ================================================================================================
 # HiFi-GAN: channels-last convolutions on the segmented GEMM
 # ================================================================================================
+_tap_matrix_cache = {}
+
+
+def _upsample_tap_matrix(K, up, pad, dil, device):
+    """S[j - jmin, k] = #{r in [0, up): r + pad - k*dil == j}: combines the K taps of a convolution over a
+    nearest-upsampled input into the (K-1)*dil + up taps of the equivalent strided convolution over its output
+    gradient (see _ConvCL.backward)."""
+    key = (K, up, pad, dil, str(device))
+    hit = _tap_matrix_cache.get(key)
+    if hit is None:
+        jmin, jmax = pad - (K - 1) * dil, up - 1 + pad
+        S = torch.zeros(jmax - jmin + 1, K)
+        for r in range(up):
+            for k in range(K):
+                S[r + pad - k * dil - jmin, k] += 1.0
+        hit = (S.to(device), jmin)
+        _tap_matrix_cache[key] = hit
+    return hit
+
+
 class _ConvCL(torch.autograd.Function):
     """Channels-last Conv1d / (k,1)-Conv2d:  x (B, Tin, inner, Cin) -> y (B, Tout, inner, Cout)
 
@@ -707,14 +727,20 @@ class _ConvCL(torch.autograd.Function):
         assert Cin_g * groups == Cin
         M = B * Tout * inner
         y = torch.empty((B, Tout, inner, Cout) if x.dim() == 4 else (B, Tout, Cout), device=x.device, dtype=torch.float32)
-        wt = w.permute(2, 0, 1).contiguous() if K > 1 else w  # (K, Cout, Cin_g)
         r = _c(res) if res is not None else None
         ctx.cfg = cfg
         ctx.has = (bias is not None, res is not None)
         ctx.save_for_backward(x, w, y if cfg["out_leaky"] is not None else None)
-        if up == 1 and conv_win(
+        # one input channel (first discriminator layers): streaming kernels, weights stay (Cout, K)
+        ctx.c1 = (Cin == 1 and groups == 1 and up == 1 and res is None and cfg["in_leaky"] is None)
+        if ctx.c1 and conv_c1(0, x=x, y=y, w=w, bias=bias, B=B, Tsrc=Tin, Tdst=Tout, Cout=Cout, K=K, stride=stride,
+                              dil=dil, pad=pad, inner=inner, out_leaky=cfg["out_leaky"]):
+            return y
+        ctx.c1 = False
+        wt = w.permute(2, 0, 1).contiguous() if K > 1 else w  # (K, Cout, Cin_g)
+        if conv_win(
                 x, wt, y, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K, in_mul=stride,
-                in_add=-pad, in_kstep=dil, in_div=1, phases=1, inner=inner, bias=bias, res=r, in_leaky=cfg["in_leaky"],
+                in_add=-pad, in_kstep=dil, in_div=1, phases=1, inner=inner, up=up, bias=bias, res=r, in_leaky=cfg["in_leaky"],
                 out_leaky=cfg["out_leaky"]):
             return y
         seg = make_seg(x, Cin, 1, wt, Cin_g, 1, Cin_g, ntaps=K, b_tap=Cout * Cin_g, a_tok_axis=1, a_shift0=-pad,
@@ -737,14 +763,38 @@ class _ConvCL(torch.autograd.Function):
         Cout_g = Cout // groups
         gate, gslope = (y, cfg["out_leaky"]) if cfg["out_leaky"] is not None else (None, 0.0)
         dx = dw = db = None
+        if ctx.c1:
+            kw = dict(B=B, Tsrc=Tin, Tdst=Tout, Cout=Cout, K=K, stride=stride, dil=dil, pad=pad, inner=inner, gate=gate,
+                      gate_slope=gslope)
+            if ctx.needs_input_grad[0]:
+                dx = torch.zeros_like(x)
+                if not conv_c1(1, dx=dx, y=dy, w=w, **kw):
+                    raise RuntimeError("conv_c1 dgrad refused a shape its forward accepted")
+            if ctx.needs_input_grad[1]:
+                dw = gzeros(tuple(w.shape), dy.device)
+                db = gzeros((Cout,), dy.device) if has_bias else None
+                if not conv_c1(2, x=x, y=dy, w=w, dw=dw, db=db, **kw):
+                    raise RuntimeError("conv_c1 wgrad refused a shape its forward accepted")
+            return dx, dw, db, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             Mx = B * Tin * inner
             wd = w.view(groups, Cout_g, Cin_g, K).permute(3, 0, 2, 1).contiguous()  # (K, groups, Cin_g, Cout_g)
-            done = up == 1 and conv_win(
-                dy, wd, dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups, CR=Cout_g, NG=Cin_g, K=K, in_mul=1, in_add=pad,
-                in_kstep=-dil, in_div=stride, phases=stride, inner=inner, in_gate=gate, in_gate_slope=gslope,
-                out_gate=x if cfg["in_leaky"] is not None else None, out_gate_slope=cfg["in_leaky"] or 0.0)
+            if up > 1 and stride == 1:
+                # x-token t feeds the `up` virtual tokens t*up + r:  dx[t] = sum_j dy[t*up + j] W'[j] with
+                # W'[j] = sum_{(r,k): r + pad - k*dil = j} w[k] -- ONE strided window pass over dy instead of `up`
+                # accumulating passes (the tap-combination matrix is a tiny cached constant)
+                S, jmin = _upsample_tap_matrix(K, up, pad, dil, dy.device)
+                wj = torch.matmul(S, wd.reshape(K, -1)).view(S.shape[0], groups, Cin_g, Cout_g)
+                done = conv_win(dy, wj, dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups, CR=Cout_g, NG=Cin_g, K=S.shape[0],
+                                in_mul=up, in_add=jmin, in_kstep=1, in_div=1, phases=1, inner=inner, in_gate=gate,
+                                in_gate_slope=gslope, out_gate=x if cfg["in_leaky"] is not None else None,
+                                out_gate_slope=cfg["in_leaky"] or 0.0)
+            else:
+                done = up == 1 and conv_win(
+                    dy, wd, dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups, CR=Cout_g, NG=Cin_g, K=K, in_mul=1, in_add=pad,
+                    in_kstep=-dil, in_div=stride, phases=stride, inner=inner, in_gate=gate, in_gate_slope=gslope,
+                    out_gate=x if cfg["in_leaky"] is not None else None, out_gate_slope=cfg["in_leaky"] or 0.0)
             first = True
             for r in range(0 if done else up):
                 # x-domain token t receives dy[(t*up + r + pad - k*dil) / stride] (exact division only)
@@ -761,9 +811,9 @@ class _ConvCL(torch.autograd.Function):
             if has_bias:
                 db = gzeros((Cout,), dy.device)
             Mtok = B * Tout * inner
-            if up == 1 and conv_wgrad(x, dy, dwt, db, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K,
-                                      stride=stride, dil=dil, pad=pad, inner=inner, dy_gate=gate, dy_gate_slope=gslope,
-                                      x_leaky=cfg["in_leaky"]):
+            if conv_wgrad(x, dy, dwt, db, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K,
+                          stride=stride, dil=dil, pad=pad, inner=inner, up=up, dy_gate=gate, dy_gate_slope=gslope,
+                          x_leaky=cfg["in_leaky"]):
                 return dx, dwt.permute(1, 2, 0), db, (dy if has_res else None), None
             seg = make_seg(dy, 1, Cout, x, 1, Cin, Mtok, ntaps=K, a_gate=gate, a_gate_slope=gslope, b_tok_axis=2,
                            b_shift0=-pad, b_shift_step=dil,

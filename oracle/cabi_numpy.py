@@ -607,8 +607,8 @@ class EmulatedLib:
     # ------------------------------------------------------------------------------------ windowed conv
     def kantts_conv_win_launch(self, args_ref, stream):
         g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
-        if (g.CR % 4) or (g.Cin_tot % 4) or g.K > 64:
-            return -2  # KANTTS_E_UNSUPPORTED (same rule as csrc/conv_win.hip)
+        if g.K > 64 and not (g.CR % 4):
+            return -2  # KANTTS_E_UNSUPPORTED (same rule as csrc/conv_win.hip; CR % 4 != 0 takes the direct kernel)
         P = g.inner
         B, Ts, Td, Ci, N, CR, NG, G, K = g.B, g.Tsrc, g.Tdst, g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K
 
@@ -632,8 +632,10 @@ class EmulatedLib:
                 u = g.in_add + ph + k * g.in_kstep
                 if u % g.in_div:
                     continue
+                up = max(1, g.up)
                 src = m * g.in_mul + u // g.in_div
-                ok = (src >= 0) & (src < Ts)
+                ok = (src >= 0) & (src < Ts * up)
+                src = src // up
                 if not ok.any():
                     continue
                 for gi in range(G):
@@ -653,8 +655,8 @@ class EmulatedLib:
 
     def kantts_conv_wgrad_launch(self, args_ref, stream):
         g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
-        if (g.CR % 4) or (g.NG % 4):
-            return -2
+        if ((g.CR % 4) or (g.NG % 4)) and g.up > 1:
+            return -2  # the direct kernel does not read through an upsampling
         P, B, Ts, Td, Ci, N, CR, NG, G, K = g.inner, g.B, g.Tsrc, g.Tdst, g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K
 
         def load(ptr, T, C):
@@ -668,9 +670,11 @@ class EmulatedLib:
             dy = dy * np.where(load(g.dy_gate, Td, N) > 0, 1.0, np.float32(g.dy_gate_slope))
         dw = _arr(g.dw, K * N * CR).reshape(K, N, CR)
         q = np.arange(Td)
+        up = max(1, g.up)
         for k in range(K):
             src = q * g.stride + k * g.dil - g.pad
-            ok = (src >= 0) & (src < Ts)
+            ok = (src >= 0) & (src < Ts * up)
+            src = src // up
             if not ok.any():
                 continue
             for gi in range(G):
@@ -679,4 +683,46 @@ class EmulatedLib:
                 dw[k, gi * NG:(gi + 1) * NG, :] += np.einsum("btn,btc->nc", d, xs).astype(np.float32)
         if g.db:
             _arr(g.db, N)[:] += dy.sum(axis=(0, 1)).astype(np.float32)
+        return 0
+
+    def kantts_conv_c1_launch(self, args_ref, mode, stream):
+        g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
+        mode = _val(mode)
+        Co, K, P, B, Ts, Td = g.Cout, g.K, g.inner, g.B, g.Tsrc, g.Tdst
+        if K > 16 or (Co % 4) or Co > 256 or (256 % Co):
+            return -2
+        w = _arr(g.w, Co * K).reshape(Co, K).astype(np.float64)
+        q = np.arange(Td)
+        yv = _arr(g.y, B * Td * P * Co).reshape(B, Td, P, Co)
+        if mode == 0:
+            x = _arr(g.x, B * Ts * P).reshape(B, Ts, P).astype(np.float64)
+            acc = np.zeros((B, Td, P, Co))
+            for k in range(K):
+                src = q * g.stride + k * g.dil - g.pad
+                ok = (src >= 0) & (src < Ts)
+                acc[:, q[ok]] += x[:, src[ok], :, None] * w[:, k]
+            if g.bias:
+                acc += _arr(g.bias, Co)
+            if g.out_act:
+                acc = np.where(acc > 0, acc, acc * np.float32(g.out_slope))
+            yv[:] = acc.astype(np.float32)
+            return 0
+        dy = yv.astype(np.float64)
+        if g.gate:
+            dy = dy * np.where(_arr(g.gate, B * Td * P * Co).reshape(B, Td, P, Co) > 0, 1.0, np.float32(g.gate_slope))
+        if mode == 1:
+            dx = _arr(g.dx, B * Ts * P).reshape(B, Ts, P)
+            for k in range(K):
+                src = q * g.stride + k * g.dil - g.pad
+                ok = (src >= 0) & (src < Ts)
+                dx[:, src[ok]] += (dy[:, q[ok]] @ w[:, k]).astype(np.float32)
+            return 0
+        x = _arr(g.x, B * Ts * P).reshape(B, Ts, P).astype(np.float64)
+        dw = _arr(g.dw, Co * K).reshape(Co, K)
+        for k in range(K):
+            src = q * g.stride + k * g.dil - g.pad
+            ok = (src >= 0) & (src < Ts)
+            dw[:, k] += np.einsum("btpn,btp->n", dy[:, q[ok]], x[:, src[ok]]).astype(np.float32)
+        if g.db:
+            _arr(g.db, Co)[:] += dy.sum(axis=(0, 1, 2)).astype(np.float32)
         return 0

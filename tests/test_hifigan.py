@@ -94,6 +94,8 @@ _WIN_CASES = [
     (2, 200, 32, 1, 7, 1, 1, 6, 1, 0.01, None, False),         # conv_post: one output channel
     (1, 40, 8, 12, 3, 2, 3, 3, 1, None, None, False),          # short, stride 2, Cout % 4 == 0 only
     (2, 90, 24, 20, 5, 3, 2, 4, 2, 0.2, 0.3, False),           # stride 3 dil 2: dgrad phases with uneven taps
+    (3, 700, 1, 128, 15, 1, 1, 7, 1, None, 0.1, False),        # MSD first layer: one input channel (conv_c1.hip)
+    (2, 333, 1, 32, 5, 3, 1, 2, 1, None, 0.1, False),          # MPD first layer shape, strided
 ]
 
 
@@ -181,6 +183,8 @@ def test_conv_ops_gpu_vs_emulated():
          (r(B, 64, 32, seed=5), r(64, 8, 41, seed=6, scale=0.1), r(64, seed=7))),
         ("period fold", lambda x, w, b: ops.conv_cl(x, w, b, stride=3, pad=2, inner=5, out_leaky=0.1),
          (r(B, 20, 5, 8, seed=8), r(16, 8, 5, seed=9, scale=0.2), r(16, seed=10))),
+        ("period fold, one input channel", lambda x, w, b: ops.conv_cl(x, w, b, stride=3, pad=2, inner=11, out_leaky=0.1),
+         (r(2, 100, 11, 1, seed=24), r(32, 1, 5, seed=25, scale=0.3), r(32, seed=26))),
         ("period fold, long", lambda x, w, b: ops.conv_cl(x, w, b, stride=3, pad=2, inner=7, in_leaky=0.1, out_leaky=0.1),
          (r(2, 301, 7, 32, seed=21), r(128, 32, 5, seed=22, scale=0.1), r(128, seed=23))),
         ("nearest upsample", lambda x, w, b: ops.conv_cl(x, w, b, pad=6, up=8, in_leaky=0.1),
