@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true")
+    ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight gradients on the main stream (A/B switch)")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     args = ap.parse_args()
@@ -270,7 +271,8 @@ def main():
         try:
             from kantts.train.graph_step import GraphedSambertStep
 
-            step = GraphedSambertStep(net, optimizer, scheduler, mel_crit, pros_crit, batch)
+            step = GraphedSambertStep(net, optimizer, scheduler, mel_crit, pros_crit, batch,
+                                      overlap_wgrad=not args.no_wgrad_overlap)
         except Exception as exc:  # capture is an optimisation; say so loudly and measure the eager path
             print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" % (
                 type(exc).__name__, str(exc)[:300]), file=sys.stderr)
@@ -305,6 +307,7 @@ def main():
     if rank == 0:
         hip.profile_begin()
     net.device_band_width = False
+    hip.ops.wgrad_overlap.enable(False)
     eager_step()  # instrumented launches are issued eagerly on every rank (the step holds a collective)
     torch.cuda.synchronize()
     if rank == 0:

@@ -78,6 +78,69 @@ def _splitk_for(n_out_rows, n_out_cols, k_total):
 
 
 # ================================================================================================
+# Weight-gradient side stream
+# ================================================================================================
+class _WgradOverlap:
+    """Opt-in: weight-gradient contractions run on a second HIP stream.
+
+    In backward the chain of input gradients is the critical path; every weight gradient is a leaf that only the
+    optimizer reads.  The SAM-BERT contractions are small (1-6 workgroups per CU), so a leaf running beside the
+    chain fills CUs that would idle.  ``with wgrad_overlap.side(*tensors)`` forks the side stream from the
+    current one (event), runs the body there and keeps ``tensors`` alive until ``join()`` -- the caching
+    allocator may otherwise hand their memory to a later main-stream allocation while the side kernel is still
+    pending.  ``join()`` (ArenaAdam.step) makes the current stream wait for the side stream.  Under hipGraph
+    capture the fork / join become parallel graph branches.  Off by default: code that reads ``p.grad`` right
+    after ``backward()`` without an optimizer step (tests) must not enable it."""
+
+    def __init__(self):
+        self.enabled = False
+        self._stream = None
+        self._keep = []
+        self._used = False
+
+    def enable(self, on=True):
+        self.enabled = bool(on)
+
+    class _Ctx:
+        def __init__(self, owner, keep):
+            self.owner, self.keep, self.cm = owner, keep, None
+
+        def __enter__(self):
+            o = self.owner
+            if not o.enabled:
+                return self
+            if o._stream is None:
+                o._stream = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            o._stream.wait_event(ev)
+            self.cm = torch.cuda.stream(o._stream)
+            self.cm.__enter__()
+            o._keep.extend(t for t in self.keep if t is not None)
+            o._used = True
+            return self
+
+        def __exit__(self, *exc):
+            if self.cm is not None:
+                self.cm.__exit__(*exc)
+            return False
+
+    def side(self, *keep):
+        return _WgradOverlap._Ctx(self, keep)
+
+    def join(self):
+        if self._used:
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._keep.clear()
+            self._used = False
+
+
+wgrad_overlap = _WgradOverlap()
+
+
+# ================================================================================================
 # Fused linear / token-convolution
 # ================================================================================================
 class _FusedLinear(torch.autograd.Function):
@@ -178,13 +241,17 @@ class _FusedLinear(torch.autograd.Function):
             if needs[5 + nx]:
                 dw = gzeros_like(w)
                 sk = _splitk_for(N, cin, M)
-                for tap in range(kt):
-                    seg = make_seg(dy, 1, N, x, 1, cin, M, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed,
-                                   b_tok_axis=2, b_shift0=tap * dil - pad)
-                    gemm([seg], N, cin, dw, cin, 1, c_off=tap * N * cin, alpha=balpha, accumulate=True, splitk=sk,
-                         T=T, a_rowsum=dbias if (first_tn and dbias is not None) else None)
-                    first_tn = False
-                dws[0] = dw.permute(1, 2, 0)  # back to the parameter's (N, Cin, KT) layout
+                with wgrad_overlap.side(dy, x, gate):
+                    for tap in range(kt):
+                        seg = make_seg(dy, 1, N, x, 1, cin, M, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed,
+                                       b_tok_axis=2, b_shift0=tap * dil - pad)
+                        gemm([seg], N, cin, dw, cin, 1, c_off=tap * N * cin, alpha=balpha, accumulate=True, splitk=sk,
+                             T=T, a_rowsum=dbias if (first_tn and dbias is not None) else None)
+                        first_tn = False
+                    # back to the parameter's (N, Cin, KT) layout.  Materialised HERE (same stream as the
+                    # contractions): autograd clones a gradient whose strides differ from its parameter's, and
+                    # that clone would run on the main stream before a side-stream weight gradient has landed.
+                    dws[0] = dw.permute(1, 2, 0).contiguous()
         else:
             off = 0
             ldw = ws[0].shape[1]
@@ -206,16 +273,18 @@ class _FusedLinear(torch.autograd.Function):
                         dws[k] = gzeros_like(w)
                     dwt = dws[0] if mode == "concat" else dws[k]
                     seg = make_seg(dy, 1, N, x, 1, kk, M, a_gate=gate, a_drop_p=a_drop_p, a_drop_seed=a_seed)
-                    gemm([seg], N, kk, dwt, wld, 1, c_off=woff, alpha=balpha, accumulate=True,
-                         splitk=_splitk_for(N, kk, M),
-                         a_rowsum=dbias if (first_tn and dbias is not None) else None)
+                    with wgrad_overlap.side(dy, x, gate):
+                        gemm([seg], N, kk, dwt, wld, 1, c_off=woff, alpha=balpha, accumulate=True,
+                             splitk=_splitk_for(N, kk, M),
+                             a_rowsum=dbias if (first_tn and dbias is not None) else None)
                     first_tn = False
                 off += kk
         if dbias is not None and first_tn:
             # no weight gradient was requested but a bias needs one: plain column sum through the GEMM
             raise RuntimeError("bias gradient without weight gradient is not supported")
         if dbias is not None and balpha != 1.0:
-            dbias = dbias * balpha
+            with wgrad_overlap.side(dbias):
+                dbias = dbias * balpha
         return (None, dbias if has_bias else None, dbias if has_bias2 else None, d_res, None, *dxs, *dws)
 
 

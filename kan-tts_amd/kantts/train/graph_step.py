@@ -16,7 +16,10 @@ from kantts._hip import ops
 
 
 class GraphedSambertStep:
-    def __init__(self, net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup=3):
+    def __init__(self, net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup=3,
+                 overlap_wgrad=True):
+        # weight gradients as parallel branches of the captured graph (see ops._WgradOverlap)
+        ops.wgrad_overlap.enable(overlap_wgrad)
         self.net, self.optimizer, self.scheduler = net, optimizer, scheduler
         self.mel_criterion, self.prosody_criterion = mel_criterion, prosody_criterion
         self.batch = {k: v.clone() for k, v in batch.items()}
@@ -42,6 +45,7 @@ class GraphedSambertStep:
         else:
             with torch.cuda.graph(self.graph_a):
                 self._forward_backward()
+                ops.wgrad_overlap.join()
                 optimizer.arena.pack_grads()
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):

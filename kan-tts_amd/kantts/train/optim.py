@@ -138,6 +138,7 @@ class ArenaAdam(torch.optim.Optimizer):
             raise NotImplementedError("closure")
         group = self.param_groups[0]
         arena = self.arena
+        ops.wgrad_overlap.join()  # weight gradients produced on the side stream (no-op unless enabled)
         if packed:
             g = arena.grad
         else:

@@ -160,3 +160,29 @@ def test_training_steps_reduce_loss_and_dropout_runs():
         losses.append(float(loss))
     assert all(map(lambda v: v == v and abs(v) < 1e4, losses)), losses
     assert sum(losses[-3:]) < sum(losses[:3]), losses
+
+
+def test_wgrad_side_stream_gives_the_same_gradients():
+    """ops.wgrad_overlap (weight gradients on a second HIP stream, joined before the optimizer) must not change
+    any gradient: same model / batch with the switch off and on (fp32 path, dropout off; split-K atomics make the
+    sums order-dependent, hence the 1e-5 bound instead of equality)."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+
+    hip.set_precision("fp32")
+    cfg = O.sambert_config(tiny=True)
+    batch = {k: v.cuda() for k, v in O.synthetic_sambert_batch(B=3, T_in=12, seed=5, min_len=6, dur_hi=6).items()}
+    grads = []
+    for on in (False, True):
+        m, _ = _build(cfg)
+        ops.wgrad_overlap.enable(on)
+        try:
+            _losses(m(**batch), batch).backward()
+            ops.wgrad_overlap.join()
+            torch.cuda.synchronize()
+        finally:
+            ops.wgrad_overlap.enable(False)
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        assert rel_l2(grads[1][n], grads[0][n]) < 1e-5, n
