@@ -340,6 +340,18 @@ typedef struct {
 } kantts_conv_c1_args;
 int kantts_conv_c1_launch(const kantts_conv_c1_args* args, int mode, void* stream);
 
+/* Free-running inference steps.
+ * kantts_attn_decode: one query per sequence (decoder position `step`) against rows [lo, hi] of a (B, L, .) K/V
+ *   buffer; the interval is the training kernels' function of (mode, step, len, bw) (HybridAttentionDecoder.infer,
+ *   kantts/models/sambert/kantts_sambert.py:208-253; K/V state sambert/__init__.py:212-258).  q / o hold B rows.
+ *   bw_seq (optional, B entries) gives every sequence its own band width: the reference infers one utterance at a
+ *   time with the band of THAT utterance, which a batch can only reproduce per sequence.
+ * kantts_lstm_cell: gates (B, 4H) in PyTorch order [i|f|g|o] -> h, c (VarRnnARPredictor.infer, adaptors.py:67-83). */
+int kantts_attn_decode(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, float* o, int ldo,
+                       const int32_t* lens, const int32_t* bw_seq, int B, int H, int L, int d_head, int mode, int step,
+                       int bw, void* stream);
+int kantts_lstm_cell(const float* gates, const float* c_prev, float* h_out, float* c_out, int B, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -483,3 +483,62 @@ extern "C" int kantts_attn_bwd(const float* q, const float* k, const float* v, i
   }
   KANTTS_CHECK_LAUNCH();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Free-running decode step (HybridAttentionDecoder.infer, kantts/models/sambert/kantts_sambert.py:208-253 with
+// the K/V state of sambert/__init__.py:212-258): ONE query per sequence -- decoder position `step` -- against the
+// rows [lo, hi] of a K/V buffer, the interval being the same function of (mode, step, len, band) as in training.
+// The reference rebuilds two L x L masks and re-concatenates the K/V cache per layer and step; here the cache is
+// a preallocated (B, L, .) buffer whose row `step` was just written by the QKV projection.
+__global__ __launch_bounds__(128) void attn_decode_kernel(const AttnArgs a, int step, const int32_t* bw_seq) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.B * a.H) return;
+  const int b = t / a.H, h = t % a.H;
+  const int len = a.lens ? a.lens[b] : a.L;
+  int lo, hi;
+  key_range(a.mode, step, len, a.L, bw_seq ? bw_seq[b] : a.bw, lo, hi);
+  if (a.mode != 0 && step >= len) hi = lo - 1;  // padded query: context 0 (as in the training kernels)
+  float q[DH], o[DH];
+  load16(a.q + (long long)b * a.ldq + h * DH, q);
+#pragma unroll
+  for (int d = 0; d < DH; ++d) o[d] = 0.f;
+  const float* kb = a.k + (long long)b * a.L * a.ldk + h * DH;
+  const float* vb = a.v + (long long)b * a.L * a.ldv + h * DH;
+  float m = -INFINITY;
+  for (int j = lo; j <= hi; ++j) {
+    float kk[DH];
+    load16(kb + (long long)j * a.ldk, kk);
+    m = fmaxf(m, dot16(q, kk) * a.scale);
+  }
+  float l = 0.f;
+  for (int j = lo; j <= hi; ++j) {
+    float kk[DH], vv[DH];
+    load16(kb + (long long)j * a.ldk, kk);
+    load16(vb + (long long)j * a.ldv, vv);
+    const float e = expf(dot16(q, kk) * a.scale - m);
+    l += e;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = fmaf(e, vv[d], o[d]);
+  }
+  const float inv = (hi >= lo) ? 1.f / l : 0.f;
+#pragma unroll
+  for (int d = 0; d < DH; ++d) o[d] *= inv;
+  store16(a.o + (long long)b * a.ldo + h * DH, o);
+}
+
+extern "C" int kantts_attn_decode(const float* q, const float* k, const float* v, int ldq, int ldk, int ldv, float* o,
+                                  int ldo, const int32_t* lens, const int32_t* bw_seq, int B, int H, int L, int d_head,
+                                  int mode, int step, int bw, void* stream) {
+  if (!q || !k || !v || !o || B < 0 || H < 1 || L < 1 || mode < 0 || mode > 2 || step < 0 || step >= L)
+    return KANTTS_E_BADARG;
+  if (d_head != DH) return KANTTS_E_UNSUPPORTED;
+  if ((ldq | ldk | ldv | ldo) & 3) return KANTTS_E_UNSUPPORTED;
+  if (B == 0) return KANTTS_OK;
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.o = o; a.ldo = ldo;
+  a.lens = lens; a.B = B; a.H = H; a.L = L; a.mode = mode; a.bw = bw; a.scale = 0.25f;
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(kantts_cdiv((long long)B * H, 128)), dim3(128), 0, (hipStream_t)stream, a,
+                     step, bw_seq);
+  KANTTS_CHECK_LAUNCH();
+}

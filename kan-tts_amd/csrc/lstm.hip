@@ -191,3 +191,31 @@ extern "C" int kantts_lstm_bwd(const float* dout, const float* whh, const int32_
                      c_save, dgates, B, T, ndir, reverse_first);
   KANTTS_CHECK_LAUNCH();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// One LSTM cell update for stepwise (free-running) inference: gates = x W_ih^T + h W_hh^T + b (computed by the
+// two-segment GEMM), PyTorch gate order [i | f | g | o].  VarRnnARPredictor.infer, kantts/models/sambert/adaptors.py:67-83.
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                        float* __restrict__ h_out, float* __restrict__ c_out, int B, int H) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * H) return;
+  const int b = t / H, j = t % H;
+  const float* g = gates + (long long)b * 4 * H;
+  const float gi = 1.f / (1.f + expf(-g[j]));
+  const float gf = 1.f / (1.f + expf(-g[H + j]));
+  const float gg = tanhf(g[2 * H + j]);
+  const float go = 1.f / (1.f + expf(-g[3 * H + j]));
+  const float c = gf * (c_prev ? c_prev[t] : 0.f) + gi * gg;
+  c_out[t] = c;
+  h_out[t] = go * tanhf(c);
+}
+
+extern "C" int kantts_lstm_cell(const float* gates, const float* c_prev, float* h_out, float* c_out, int B, int H,
+                                void* stream) {
+  if (!gates || !h_out || !c_out || B < 0 || H < 1) return KANTTS_E_BADARG;
+  if (B == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3(kantts_cdiv((long long)B * H, 256)), dim3(256), 0, (hipStream_t)stream, gates,
+                     c_prev, h_out, c_out, B, H);
+  KANTTS_CHECK_LAUNCH();
+}

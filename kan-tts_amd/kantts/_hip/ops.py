@@ -447,6 +447,28 @@ def pnca_attention(qkv, hkv, lens_i32, bw_x, bw_h, n_head, drop_p=0.0, want_prob
                                 bool(want_probs))
 
 
+def attn_decode(q, k, v, out, lens_i32, n_head, step, bw, mode, bw_seq=None):
+    """One decoder position against a (B, L, .) K/V buffer (inference only, no autograd).  q / out: (B, .) row
+    views (any leading stride), k / v: column slices of contiguous (B, L, W) buffers; bw_seq: optional per-sequence
+    band widths (int32, B)."""
+    B, L = k.shape[0], k.shape[1]
+    check(lib().kantts_attn_decode(ptr(q, torch.float32), ptr(k, torch.float32), ptr(v, torch.float32), q.stride(0),
+                                   k.stride(1), v.stride(1), ptr(out, torch.float32), out.stride(0), ptr(lens_i32),
+                                   ptr(bw_seq), B, n_head, L, 16, int(mode), int(step), int(bw), stream()), "attn_decode")
+    return out
+
+
+def lstm_cell(gates, c_prev):
+    """gates (B, 4H) [i|f|g|o] -> (h, c); inference only."""
+    gates = _c(gates)
+    B, H = gates.shape[0], gates.shape[1] // 4
+    h = torch.empty((B, H), device=gates.device, dtype=torch.float32)
+    c = torch.empty_like(h)
+    check(lib().kantts_lstm_cell(ptr(gates, torch.float32), ptr(c_prev, torch.float32), ptr(h), ptr(c), B, H, stream()),
+          "lstm_cell")
+    return h, c
+
+
 # ================================================================================================
 # LSTM
 # ================================================================================================

@@ -180,6 +180,33 @@ class MultiHeadPNCAAttention(nn.Module):
         return output, attn_x, attn_h
 
 
+    @torch.no_grad()
+    def infer_step(self, step, x, h, x_band_width, h_band_width, zero_rows=None, lens32=None, bw_seq=None):
+        """Decoder position ``step`` of the free-running decode (reference forward() under update_x_state /
+        update_h_state).  State: ``qkv_buf`` (B, L, 3*H*d) receives row ``step`` from the QKV projection -- the K/V
+        cache is that buffer, never re-concatenated -- and ``hkv`` (memory K/V) is projected once at step 0."""
+        B, L = h.size(0), h.size(1)
+        D = self.n_head * self.d_head
+        if step == 0 or self.h_k is None:
+            self.h_k = ops.linear(h, self.w_h_kv.weight, self.w_h_kv.bias)           # (B, L, 2D)
+            self.x_k = torch.zeros((B, L, 3 * D), device=h.device, dtype=torch.float32)
+            self.h_state_size, self.x_state_size = L, 0
+        xr = x.reshape(B, -1)
+        xn = ops.layer_norm(xr, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        qkv = ops.linear(xn, self.w_x_qkv.weight, self.w_x_qkv.bias)              # (B, 3D)
+        self.x_k[:, step, :] = qkv
+        self.x_state_size = step + 1
+        ox = torch.empty((B, D), device=h.device, dtype=torch.float32)
+        oh = torch.empty((B, D), device=h.device, dtype=torch.float32)
+        ops.attn_decode(qkv[:, :D], self.x_k[:, :, D:2 * D], self.x_k[:, :, 2 * D:], ox, lens32, self.n_head, step,
+                        x_band_width, ops.MODE_BAND_X, bw_seq=bw_seq)
+        ops.attn_decode(qkv[:, :D], self.h_k[:, :, :D], self.h_k[:, :, D:], oh, lens32, self.n_head, step, h_band_width,
+                        ops.MODE_BAND_H, bw_seq=bw_seq)
+        out = ops.linear([ox, oh], [self.fc_x.weight, self.fc_h.weight], self.fc_x.bias, bias2=self.fc_h.bias,
+                         mode="sum", res=xr, rowmask=zero_rows)
+        return out.view(B, 1, -1)
+
+
 class PNCABlock(nn.Module):
     """PNCA block (reference :309-348)."""
 
@@ -197,6 +224,12 @@ class PNCABlock(nn.Module):
                                         return_attn=return_attn, bw_dev=bw_dev)
         output = self.pos_ffn(output, mask=info, zero_rows=rows)
         return output, ax, ah
+
+    @torch.no_grad()
+    def infer_step(self, step, input, memory, x_band_width, h_band_width, zero_rows=None, lens32=None, bw_seq=None):
+        output = self.pnca_attn.infer_step(step, input, memory, x_band_width, h_band_width, zero_rows=zero_rows,
+                                           lens32=lens32, bw_seq=bw_seq)
+        return self.pos_ffn(output, mask=None, zero_rows=zero_rows)
 
     def reset_state(self):
         self.pnca_attn.reset_state()

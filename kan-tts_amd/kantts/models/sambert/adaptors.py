@@ -71,8 +71,39 @@ class VarRnnARPredictor(nn.Module):
                        rowmask=None if info is None else info.mask).squeeze(-1)
         return x, None
 
+    @torch.no_grad()
     def infer(self, cond, masks=None):
-        raise NotImplementedError("free-running duration inference lands with the AR decode kernels (DESIGN.md)")
+        """Free-running prediction (reference :67-83): token i consumes the prediction of token i-1 through the
+        prenet.  Per token: prenet (2 GEMMs), two LSTM cells -- each gate pre-activation is ONE multi-segment
+        GEMM over [prenet | cond | h] -- and the output GEMM; no tensor is concatenated or re-allocated per
+        step (the reference re-runs nn.LSTM on a length-1 sequence and torch.cat's the outputs)."""
+        B, T = cond.size(0), cond.size(1)
+        w_ih0, w_hh0, b_ih0, b_hh0 = self._layer(0)
+        w_ih1, w_hh1, b_ih1, b_hh1 = self._layer(1)
+        d_p = w_ih0.shape[1] - cond.size(2)
+        # [x | cond | h] @ [W_ih | W_hh]^T : one weight with the segments side by side
+        w0 = torch.cat([w_ih0, w_hh0], dim=1).contiguous()
+        w1 = torch.cat([w_ih1, w_hh1], dim=1).contiguous()
+        H = w_hh0.shape[1]
+        dev = cond.device
+        h0 = torch.zeros((B, H), device=dev)
+        h1 = torch.zeros((B, H), device=dev)
+        c0 = c1 = None
+        x = torch.zeros((B, 1), device=dev)
+        out = torch.empty((B, T), device=dev)
+        assert d_p == self.prenet.fcs[-3].out_features
+        for i in range(T):
+            p = self.prenet(x)
+            g0 = ops.linear([p, cond[:, i, :], h0], w0, b_ih0, bias2=b_hh0, mode="concat")
+            h0, c0 = ops.lstm_cell(g0, c0)
+            g1 = ops.linear([h0, h1], w1, b_ih1, bias2=b_hh1, mode="concat")
+            h1, c1 = ops.lstm_cell(g1, c1)
+            x = ops.linear(h1, self.fc.weight, self.fc.bias, relu=True)
+            out[:, i] = x[:, 0]
+        info = SeqInfo.of(masks)
+        if info is not None:
+            out = out.masked_fill(info.mask, 0.0)
+        return out
 
 
 class VarFsmnRnnNARPredictor(nn.Module):

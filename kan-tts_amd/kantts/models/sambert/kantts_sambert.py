@@ -98,8 +98,26 @@ class HybridAttentionDecoder(nn.Module):
         x = ops.linear(x, self.dec_out_proj.weight, self.dec_out_proj.bias)
         return x, ax_l, ah_l
 
-    def infer(self, step, input, memory, x_band_width, h_band_width, mask=None, return_attns=False):
-        raise NotImplementedError("free-running decode step lands with the AR decode kernels (DESIGN.md)")
+    @torch.no_grad()
+    def infer(self, step, input, memory, x_band_width, h_band_width, mask=None, return_attns=False, bw_seq=None):
+        """One free-running decoder step (reference :208-253): input (B, 1, d_mel) = previous output frame.
+        Per-step masks are intervals inside the attention kernel; attention maps are not materialised."""
+        if return_attns:
+            raise NotImplementedError("attention maps of the free-running decode are not materialised")
+        info = SeqInfo.of(mask)
+        rows = None if info is None else info.mask[:, step].contiguous()
+        B = memory.size(0)
+        x = self.prenet(input.reshape(B, -1))
+        x = ops.linear([memory[:, step, :], x], self.dec_in_proj.weight, self.dec_in_proj.bias, mode="concat",
+                       alpha=self.d_model ** 0.5)
+        x = x.view(B, 1, -1)
+        lens32 = None if info is None else info.lens32
+        for layer in self.pnca:
+            x = layer.infer_step(step, x, memory, x_band_width, h_band_width, zero_rows=rows, lens32=lens32,
+                                 bw_seq=bw_seq)
+        x = ops.layer_norm(x, self.ln.weight, self.ln.bias, self.ln.eps)
+        x = ops.linear(x, self.dec_out_proj.weight, self.dec_out_proj.bias)
+        return x, [], []
 
 
 class TextFftEncoder(nn.Module):
@@ -238,7 +256,7 @@ class MelPNCADecoder(nn.Module):
 
     def forward(self, memory, x_band_width, h_band_width, target=None, mask=None, return_attns=False, bw_dev=None):
         if target is None:
-            raise NotImplementedError("free-running decode lands with the AR decode kernels (DESIGN.md)")
+            return self._free_run(memory, x_band_width, h_band_width, mask, bw_dev)
         self.mel_dec.reset_state()
         # go-frame followed by every r-th target frame, shifted by one decoder step (reference :556-559)
         B, L = memory.size(0), memory.size(1)
@@ -246,6 +264,22 @@ class MelPNCADecoder(nn.Module):
         input[:, 1:, :] = target[:, self.r - 1:: self.r, :][:, : L - 1, :]
         return self.mel_dec(input, memory, x_band_width, h_band_width, mask=mask, return_attns=return_attns,
                             bw_dev=bw_dev)
+
+
+    @torch.no_grad()
+    def _free_run(self, memory, x_band_width, h_band_width, mask, bw_seq=None):
+        """Free-running decode (reference :568-610): step t consumes the last mel frame of step t-1.  Outputs land
+        in one preallocated (B, L, r*d_mel) buffer instead of a python list + torch.cat."""
+        B, L = memory.size(0), memory.size(1)
+        self.mel_dec.reset_state()
+        memory = memory.contiguous()
+        out = torch.empty((B, L, self.d_mel * self.r), device=memory.device, dtype=torch.float32)
+        frame = torch.zeros((B, 1, self.d_mel), device=memory.device, dtype=torch.float32)
+        for step in range(L):
+            o, _, _ = self.mel_dec.infer(step, frame, memory, x_band_width, h_band_width, mask=mask, bw_seq=bw_seq)
+            out[:, step, :] = o[:, 0, :]
+            frame = o[:, :, -self.d_mel:]
+        return out, [], []
 
 
 class PostNet(nn.Module):
@@ -328,7 +362,9 @@ class KanTtsSAMBERT(nn.Module):
             lfr_info = SeqInfo((output_lengths + r - 1) // r, Tp // r)
         else:
             out_info = SeqInfo(LR_length_rounded, Tp)
-            lfr_info = None
+            # the reference infers one utterance at a time (mask None); in a batch every sequence keeps its own
+            # decoder length and band width so that batched inference equals per-utterance inference
+            lfr_info = SeqInfo((LR_length_rounded + r - 1) // r, Tp // r)
         # LFR: group r frames; memory = [text (r*d) | spk of the first frame | emo of the first frame]
         d_t, d_s, d_e = text_hid.shape[-1], spk_hid.shape[-1], emo_hid.shape[-1]
         memory = torch.cat([
@@ -341,7 +377,10 @@ class KanTtsSAMBERT(nn.Module):
         else:
             bw_val = (torch.exp(log_duration_predictions) - 1).max() / r + 0.5
         bw_dev = None
-        if self.device_band_width:
+        if duration_targets is None:
+            pred = (torch.exp(log_duration_predictions) - 1)
+            bw_dev = (pred.max(dim=1).values / r + 0.5).to(torch.int32).contiguous()  # per sequence (free-running)
+        if self.device_band_width and duration_targets is not None:
             bw_dev = bw_val.to(torch.int32).reshape(1)  # trunc == int() for non-negative values
             x_band_width = h_band_width = bw_dev
             bw_int = 0

@@ -726,3 +726,37 @@ class EmulatedLib:
         if g.db:
             _arr(g.db, Co)[:] += dy.sum(axis=(0, 1, 2)).astype(np.float32)
         return 0
+
+    # ------------------------------------------------------------------------------------ free-running steps
+    def kantts_attn_decode(self, q, k, v, ldq, ldk, ldv, o, ldo, lens, bw_seq, B, H, L, d_head, mode, step, bw, stream):
+        D = H * 16
+        Q = _gather(q, (np.arange(B)[:, None] * ldq + np.arange(D)[None, :]).astype(np.int64), None).reshape(B, H, 16)
+        K = _gather(k, (np.arange(B * L)[:, None] * ldk + np.arange(D)[None, :]).astype(np.int64), None).reshape(B, L, H, 16)
+        V = _gather(v, (np.arange(B * L)[:, None] * ldv + np.arange(D)[None, :]).astype(np.int64), None).reshape(B, L, H, 16)
+        lens_a = _arr(lens, B, np.int32) if lens else None
+        out = np.zeros((B, H, 16), dtype=np.float32)
+        for b in range(B):
+            ln_b = int(lens_a[b]) if lens_a is not None else L
+            bw_b = int(_arr(bw_seq, B, np.int32)[b]) if bw_seq else bw
+            lo, hi = self._ranges(mode, L, ln_b, bw_b)
+            lo, hi = int(lo[step]), int(hi[step])
+            if mode != 0 and step >= ln_b:
+                continue
+            for h in range(H):
+                sc = (K[b, lo:hi + 1, h].astype(np.float64) @ Q[b, h].astype(np.float64)) * 0.25
+                pr = np.exp(sc - sc.max())
+                pr /= pr.sum()
+                out[b, h] = (pr[:, None] * V[b, lo:hi + 1, h]).sum(0)
+        offs = (np.arange(B)[:, None] * ldo + np.arange(D)[None, :]).astype(np.int64)
+        mem = _arr(o, int(offs.max()) + 1)
+        mem[offs.ravel()] = out.reshape(B, D).ravel()
+        return 0
+
+    def kantts_lstm_cell(self, gates, c_prev, h_out, c_out, B, H, stream):
+        g = _arr(gates, B * 4 * H).reshape(B, 4, H).astype(np.float64)
+        sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+        c0 = _arr(c_prev, B * H).reshape(B, H) if c_prev else np.zeros((B, H))
+        c = sig(g[:, 1]) * c0 + sig(g[:, 0]) * np.tanh(g[:, 2])
+        _arr(c_out, B * H)[:] = c.astype(np.float32).ravel()
+        _arr(h_out, B * H)[:] = (sig(g[:, 3]) * np.tanh(c)).astype(np.float32).ravel()
+        return 0

@@ -63,6 +63,32 @@ def sambert_case(name, tiny, B, T_in, min_len, dur_hi, seed_w=0, seed_b=1234, gr
     print(name, "loss", float(total), "bytes", os.path.getsize(os.path.join(OUT, name + ".pt")))
 
 
+def sambert_infer_case(name, B, T_in, min_len, seed_w=0, seed_b=77, dur_bias=1.5):
+    """Free-running inference of the untouched reference (no targets): AR duration loop, predicted-duration length
+    regulation, AR decoder loop.  With random-init weights the duration ReLU outputs 0 and the reference crashes on
+    an empty memory (SURVEY section 7), so the duration head's bias is set to ``dur_bias`` (~3.5 frames / token);
+    the test applies the same override."""
+    cfg = O.sambert_config(tiny=True)
+    torch.manual_seed(seed_w)
+    m = KanTtsSAMBERT(dict(cfg))
+    m.eval()
+    with torch.no_grad():
+        m.variance_adaptor.duration_predictor.fc.bias.fill_(dur_bias)
+    batch = O.synthetic_sambert_batch(B=B, T_in=T_in, seed=seed_b, min_len=min_len, dur_hi=6)
+    args = {k: batch[k] for k in ("inputs_ling", "inputs_emotion", "inputs_speaker", "input_lengths")}
+    with torch.no_grad():
+        res = m(**args)
+    keep = ["dec_outputs", "postnet_outputs", "LR_length_rounded", "log_duration_predictions", "pitch_predictions",
+            "energy_predictions", "LR_text_outputs"]
+    fix = dict(cfg=cfg, seed_w=seed_w, dur_bias=dur_bias,
+               batch_args=dict(B=B, T_in=T_in, seed=seed_b, min_len=min_len, dur_hi=6),
+               outputs={k: res[k].detach().clone() for k in keep}, x_band_width=res["x_band_width"],
+               weight_checksums=checksums(m.state_dict()), torch_version=torch.__version__)
+    torch.save(fix, os.path.join(OUT, name + ".pt"))
+    print(name, "frames", res["LR_length_rounded"].tolist(), "xbw", res["x_band_width"], "bytes",
+          os.path.getsize(os.path.join(OUT, name + ".pt")))
+
+
 def melspec_case():
     g = torch.Generator().manual_seed(7)
     x = torch.randn(4, 2048, generator=g) * 0.1
@@ -79,4 +105,6 @@ if __name__ == "__main__":
           "variance_adaptor.duration_predictor.fc.weight", "emo_tokenizer.weight")
     sambert_case("sambert_tiny", True, B=3, T_in=12, min_len=6, dur_hi=6, grad_keys=gk)
     sambert_case("sambert_tiny16", True, B=16, T_in=32, min_len=12, dur_hi=9, grad_keys=gk)
+    # the reference's free-running path only works at batch 1 (its band masks are built without a batch axis)
+    sambert_infer_case("sambert_tiny_infer", B=1, T_in=12, min_len=6)
     melspec_case()

@@ -186,3 +186,29 @@ def test_wgrad_side_stream_gives_the_same_gradients():
     assert grads[0].keys() == grads[1].keys()
     for n in grads[0]:
         assert rel_l2(grads[1][n], grads[0][n]) < 1e-5, n
+
+
+def test_free_running_inference_matches_oracle_and_reference_fixture():
+    """Free-running inference (AR duration predictor, AR decoder with the K/V buffer + decode-step attention
+    kernel) on the GPU: against the oracle per utterance (batch 1 and a batch of 3), and against the fixture dumped
+    from the reference's own inference run.  Frame counts bit-exact, mel within 1e-4 (fp32 path)."""
+    import kantts._hip as hip
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+    from test_host_logic_emulated import _infer_case
+
+    hip.set_precision("fp32")
+    _infer_case("cuda", B=1, seed=77)
+    _infer_case("cuda", B=3, seed=5)
+    fix = torch.load(os.path.join(GOLDEN, "sambert_tiny_infer.pt"), weights_only=False)
+    torch.manual_seed(fix["seed_w"])
+    m = KanTtsSAMBERT(dict(fix["cfg"]))
+    with torch.no_grad():
+        m.variance_adaptor.duration_predictor.fc.bias.fill_(fix["dur_bias"])
+    m = m.cuda().eval()
+    batch = O.synthetic_sambert_batch(**fix["batch_args"])
+    with torch.no_grad():
+        res = m(**{k: batch[k].cuda() for k in ("inputs_ling", "inputs_emotion", "inputs_speaker", "input_lengths")})
+    assert torch.equal(res["LR_length_rounded"].cpu(), fix["outputs"]["LR_length_rounded"])
+    assert int(res["x_band_width"]) == fix["x_band_width"]
+    for k in ("dec_outputs", "postnet_outputs", "log_duration_predictions", "pitch_predictions", "energy_predictions"):
+        assert_close(res[k].cpu(), fix["outputs"][k], 1e-4, what=k)

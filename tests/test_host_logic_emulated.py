@@ -135,3 +135,39 @@ def test_oracle_matches_live_reference_when_present():
     r = subprocess.run(["python", os.path.join(ROOT, "oracle", "check_vs_reference.py")], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _infer_case(device, B, seed):
+    """Product free-running inference vs the oracle's (same weights, duration-head bias 1.5 as in the golden)."""
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+
+    cfg = O.sambert_config(tiny=True)
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(dict(cfg))
+    with torch.no_grad():
+        m.variance_adaptor.duration_predictor.fc.bias.fill_(1.5)
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    batch = O.synthetic_sambert_batch(B=B, T_in=12, seed=seed, min_len=6, dur_hi=6)
+    args = {k: batch[k] for k in ("inputs_ling", "inputs_emotion", "inputs_speaker", "input_lengths")}
+    m = m.to(device).eval()
+    with torch.no_grad():
+        res = m(**{k: v.to(device) for k, v in args.items()})
+    # the reference (and therefore the oracle) infers one utterance at a time: compare per utterance, and the
+    # batched product run must equal its own per-utterance results on the valid frames
+    for b in range(B):
+        one = {k: v[b:b + 1, : int(args["input_lengths"][b])] if v.dim() > 1 else v[b:b + 1] for k, v in args.items()}
+        with torch.no_grad():
+            out = O.sambert_forward(P, cfg, **one)
+        n = int(out["LR_length_rounded"][0])
+        assert int(res["LR_length_rounded"][b]) == n, (b, int(res["LR_length_rounded"][b]), n)
+        T = int(args["input_lengths"][b])
+        assert_close(res["log_duration_predictions"][b, :T].cpu(), out["log_duration_predictions"][0, :T], 2e-5,
+                     what="log dur")
+        assert_close(res["postnet_outputs"][b, :n].cpu(), out["postnet_outputs"][0, :n], 1e-4, what="mel %d" % b)
+        assert_close(res["dec_outputs"][b, :n].cpu(), out["dec_outputs"][0, :n], 1e-4, what="dec %d" % b)
+    return res
+
+
+def test_free_running_inference_matches_oracle(emulated_cabi):
+    _infer_case("cpu", B=1, seed=77)
+    _infer_case("cpu", B=3, seed=5)

@@ -69,3 +69,29 @@ def test_audio_oracle_reproduces_reference():
     assert_close(A.mel_spectrogram(x), fix["mel_v1"], 2e-5, what="mel V1")
     assert_close(A.mel_spectrogram(x, 16000, 2048, 200, 1000, 80, 0, 8000), fix["mel_16k"], 2e-5, what="mel 16k")
     assert_close(A.stft_magnitude(x, 1024, 120, 600), fix["stft_1024_120_600"], 2e-5, what="stft")
+
+
+def _infer_inputs(fix, B=None, seed=None):
+    args = dict(fix["batch_args"])
+    if B is not None:
+        args["B"] = B
+    if seed is not None:
+        args["seed"] = seed
+    batch = O.synthetic_sambert_batch(**args)
+    return {k: batch[k] for k in ("inputs_ling", "inputs_emotion", "inputs_speaker", "input_lengths")}
+
+
+def test_oracle_reproduces_reference_free_running_inference():
+    """Free-running path (AR duration predictor, predicted-duration length regulation, AR decoder loop) of the
+    oracle against the reference's own inference run (batch 1 -- the only size the reference can infer at)."""
+    fix = _load("sambert_tiny_infer")
+    sd = _product_weights(fix)
+    sd["variance_adaptor.duration_predictor.fc.bias"] = torch.full_like(
+        sd["variance_adaptor.duration_predictor.fc.bias"], fix["dur_bias"])
+    with torch.no_grad():
+        out = O.sambert_forward(dict(sd), fix["cfg"], **_infer_inputs(fix))
+    assert out["x_band_width"] == fix["x_band_width"]
+    assert torch.equal(out["LR_length_rounded"], fix["outputs"]["LR_length_rounded"])  # bit-exact frame counts
+    for k, ref in fix["outputs"].items():
+        if ref.is_floating_point():
+            assert_close(out[k], ref, atol=2e-5, what=k)
