@@ -60,20 +60,35 @@ __global__ __launch_bounds__(WG_THREADS, BF16 ? 2 : 1) void conv_wgrad_kernel(co
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wc = wave / WN;
   const int ntn = (g.NG + 63) / 64, ntc = (g.CR + CT - 1) / CT;
-  int bx = blockIdx.x;
+  // XCD-aware order: workgroup L runs on XCD L % 8; all channel tiles / tap groups of one token slab get consecutive
+  // virtual ids so that the slab's dy and x rows are fetched into one L2 only
+  int bx = blockIdx.x, bytap = blockIdx.y, bz = blockIdx.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const long long total = (long long)gx * gy * gridDim.z;
+    if (total >= 64 && total < 0x7fffffffLL && gx * gy > 1) {
+      const int L = (bz * gy + bytap) * gx + bx, k = L & 7, j = L >> 3;
+      const int q = (int)(total >> 3), r = (int)(total & 7);
+      const int vid = k * q + (k < r ? k : r) + j;
+      bz = vid / (gx * gy);
+      const int rem = vid - bz * (gx * gy);
+      bytap = rem / gx;
+      bx = rem - bytap * gx;
+    }
+  }
   const int ct = bx % ntc;
   bx /= ntc;
   const int nt = bx % ntn;
   const int grp = bx / ntn;
   const int n0 = grp * g.NG + nt * 64, n_end = (grp + 1) * g.NG;
   const int c0 = ct * CT;  // inside the group
-  const int k0 = blockIdx.y * ntaps_per_block;
+  const int k0 = bytap * ntaps_per_block;
   const int nk = min(ntaps_per_block, g.K - k0);
   const int s = g.stride;
 
   const int steps_per_seq = (g.Tdst + WG_BQ - 1) / WG_BQ;
   const long long total_steps = (long long)g.B * g.inner * steps_per_seq;
-  const long long step_lo = (long long)blockIdx.z * steps_per_block;
+  const long long step_lo = (long long)bz * steps_per_block;
   const long long step_hi = min(total_steps, step_lo + steps_per_block);
   if (step_lo >= step_hi || nk <= 0) return;
 
@@ -94,7 +109,7 @@ __global__ __launch_bounds__(WG_THREADS, BF16 ? 2 : 1) void conv_wgrad_kernel(co
 #pragma unroll
       for (int c = 0; c < CF; ++c) acc[t][a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;  // threads 0..63: column sums of dy (bias gradient)
-  const bool do_bias = (g.db != nullptr) && ct == 0 && blockIdx.y == 0;
+  const bool do_bias = (g.db != nullptr) && ct == 0 && bytap == 0;
 
   const long long x_pitch = (long long)g.inner * g.Cin_tot, dy_pitch = (long long)g.inner * g.Ntot;
   const int li = lane & 15, kg = lane >> 4;

@@ -73,14 +73,27 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
   const int wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int ntpg = (g.NG + BN - 1) / BN;
-  const int grp = blockIdx.x / ntpg;
-  const int n0 = grp * g.NG + (blockIdx.x % ntpg) * BN;
+  // XCD-aware order inside one (batch, phase) slab: workgroup L = y*gx + x runs on XCD L % 8; the gx channel tiles
+  // of one token window are dealt to ONE XCD (consecutive virtual ids) so the window crosses the fabric once
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    if (total >= 64 && gx > 1) {
+      const int L = by * gx + bx, k = L & 7, j = L >> 3;
+      const int q = total >> 3, r = total & 7;
+      const int vid = k * q + (k < r ? k : r) + j;
+      by = vid / gx;
+      bx = vid - by * gx;
+    }
+  }
+  const int grp = bx / ntpg;
+  const int n0 = grp * g.NG + (bx % ntpg) * BN;
   const int n_end = (grp + 1) * g.NG;
   const int phase = blockIdx.z % g.phases;
   const int bp = blockIdx.z / g.phases;  // (batch item, position on the folded `inner` axis)
   const int b = bp / g.inner, pi = bp % g.inner;
   const long long in_pitch = (long long)g.inner * g.Cin_tot;  // elements between consecutive source tokens
-  const int m0 = blockIdx.y * BQ;
+  const int m0 = by * BQ;
   const int mrows = (g.Tdst - phase + g.phases - 1) / g.phases;
   if (m0 >= mrows) return;
 

@@ -252,8 +252,23 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int i0 = blockIdx.y * BM;
-  const int j0 = blockIdx.x * F_BN;
+  // XCD-aware tile order.  The dispatcher deals workgroup L = y*gx + x to XCD L % 8, so the gx column tiles that
+  // share one A row tile would land on 8 different L2s and the A operand would cross the fabric 8 times
+  // (measured: 27 MB fetched for 3.3 MB of A at 6528x1024x128).  Workgroups of one XCD are given consecutive
+  // tiles in row-major order instead: XCD k owns a contiguous band of rows.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    if (total >= 64) {
+      const int L = by * gx + bx, k = L & 7, j = L >> 3;
+      const int q = total >> 3, r = total & 7;
+      const int vid = k * q + (k < r ? k : r) + j;
+      by = vid / gx;
+      bx = vid - by * gx;
+    }
+  }
+  const int i0 = by * BM;
+  const int j0 = bx * F_BN;
   int ztap = -1, grp = 0, zslice = 0;
   if (gridDim.z > 1) {  // z = (tap slab, group, split-K slice); the common single-slice launch skips the divisions
     const int zper = g.groups * g.splitk;
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
 #pragma unroll
     for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float rowsum = 0.f;
-  const bool do_rowsum = (g.a_rowsum != nullptr) && (blockIdx.x == 0) && (ztap <= 0);
+  const bool do_rowsum = (g.a_rowsum != nullptr) && (bx == 0) && (ztap <= 0);
 
   Stager<BF16, BM, BK, A_ROW, true, LDA, GATE> sa;
   Stager<BF16, F_BN, BK, B_ROW, false, LDB, false> sb;
