@@ -12,7 +12,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "libkantts_hip.so"))
+# KANTTS_LIB: experiment builds of the SAME sources (scripts/build_variants.sh); never a different implementation
+LIB_PATH = os.environ.get("KANTTS_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "libkantts_hip.so"))
 _lib = None
 
 GEMM_MAX_SEG = 4
