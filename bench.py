@@ -34,6 +34,8 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
+# mean over the FFN contractions profiled in profiles/r01_gemm_ffn_pmc_v2.txt (34.7 / 35.1 MB vs 30.6 MB algorithmic)
+MEASURED_TRAFFIC_BYTES = {"bf16": 34.9e6}
 
 
 def sambert_yaml_config(cfg):
@@ -315,7 +317,11 @@ def main():
         tf, per_launch_us, flops_per_launch, gbps, bytes_per_launch = dominant_gemm_roofline(hip, args.precision)
         peak = PEAK_TFLOPS[args.precision]
         roof = {"bound": "hbm", "kernel": "gemm_fast_kernel<%s> (decoder FFN contractions, M=6528, 128<->1024)" % args.precision,
-                "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "traffic": None,
+                "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                # memory-side bytes per launch from rocprofv3 PMC passes of the same contractions (2*FETCH_SIZE +
+                # WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); collected offline, see
+                # profiles/r01_gemm_ffn_pmc_v2.txt -- bench.py cannot run the profiler on itself
+                "traffic": MEASURED_TRAFFIC_BYTES.get(args.precision),
                 "bytes_per_launch": bytes_per_launch, "flops_per_launch": flops_per_launch, "launch_us": per_launch_us,
                 "mfma_tflops": tf, "mfma_peak": peak, "mfma_frac": tf / peak,
                 "gemm_launches_per_step": prof["launches"], "gemm_gflop_per_step": prof["flops"] / 1e9,

@@ -292,7 +292,8 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
           }
         }
         if (vec_ok && cnt == 4) {
-          *reinterpret_cast<float4*>(g.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+          f32x4 nt = {v[0], v[1], v[2], v[3]};
+          __builtin_nontemporal_store(nt, reinterpret_cast<f32x4*>(g.out + o));
         } else {
           for (int e = 0; e < cnt; ++e) g.out[o + e] = v[e];
         }

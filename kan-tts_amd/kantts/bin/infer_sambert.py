@@ -1,0 +1,91 @@
+"""SAM-BERT acoustic-model inference entry point: linguistic symbols -> mel (.npy) + duration / f0 / energy text files.
+
+Mirrors kantts/bin/infer_sambert.py:58-239 of the reference: ``am_synthesis(symbol_seq, fsnet, ling_unit, device)`` and
+``am_infer(sentence, ckpt, output_dir, se_file=None, config=None)`` with the same outputs (``feat/<id>_mel.npy`` holds
+the post-net mel).  The text front-end (``KanTtsLinguisticUnit``) is not part of the hot path: ``am_infer`` imports it
+from the reference package layout if it is installed, or accepts any object with ``encode_symbol_sequence`` /
+``get_unit_size`` / ``using_byte`` through ``ling_unit=``.  The model itself runs free-running on the MI355X kernels
+(AR duration predictor + AR decoder, kantts/models/sambert).
+"""
+import argparse
+import logging
+import os
+
+import numpy as np
+import torch
+import yaml
+
+logging.basicConfig(format="%(asctime)s, %(levelname)-4s [%(filename)s:%(lineno)d] %(message)s",
+                    datefmt="%Y-%m-%d:%H:%M:%S", level=logging.INFO)
+
+
+def am_synthesis(symbol_seq, fsnet, ling_unit, device, se=None):
+    if se is not None:
+        raise NotImplementedError("SE speaker-embedding input is outside the hot path (SURVEY 8f-4)")
+    if ling_unit.using_byte():
+        raise NotImplementedError("byte-index inputs (sambert_16k_MAS_byte.yaml) are outside the hot path")
+    feats = ling_unit.encode_symbol_sequence(symbol_seq)
+    sy, tone, syllable, ws, emo, spk = (torch.from_numpy(np.asarray(f)).long().to(device) for f in feats[:6])
+    # the trailing "~" token is dropped from every stream (reference :117-122)
+    inputs_ling = torch.stack([sy, tone, syllable, ws], dim=-1).unsqueeze(0)[:, :-1, :]
+    inputs_emo = emo.unsqueeze(0)[:, :-1]
+    inputs_spk = spk.unsqueeze(0)[:, :-1]
+    inputs_len = torch.full((1,), inputs_emo.size(1), dtype=torch.long, device=device)
+    res = fsnet(inputs_ling, inputs_emo, inputs_spk, inputs_len)
+    valid_length = int(res["LR_length_rounded"][0].item())
+    dec_outputs = res["dec_outputs"][0, :valid_length, :].cpu().numpy()
+    postnet_outputs = res["postnet_outputs"][0, :valid_length, :].cpu().numpy()
+    duration_predictions = (torch.exp(res["log_duration_predictions"]) - 1 + 0.5).long().squeeze().cpu().numpy()
+    pitch_predictions = res["pitch_predictions"].squeeze().cpu().numpy()
+    energy_predictions = res["energy_predictions"].squeeze().cpu().numpy()
+    logging.info("x_band_width:%s, h_band_width: %s", res["x_band_width"], res["h_band_width"])
+    return dec_outputs, postnet_outputs, duration_predictions, pitch_predictions, energy_predictions
+
+
+def am_infer(sentence, ckpt, output_dir, se_file=None, config=None, ling_unit=None):
+    device = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
+    if not isinstance(config, dict):
+        path = config if config is not None else os.path.join(os.path.dirname(os.path.dirname(ckpt)), "config.yaml")
+        with open(path) as f:
+            config = yaml.load(f, Loader=yaml.Loader)
+    if ling_unit is None:
+        try:
+            from kantts.preprocess.languages import KanTtsLinguisticUnit  # text front-end: not shipped here
+        except ImportError as exc:
+            raise ImportError("the text front-end (kantts.preprocess.languages) is not part of this package; pass "
+                              "ling_unit= (encode_symbol_sequence / get_unit_size / using_byte)") from exc
+        ling_unit = KanTtsLinguisticUnit(config)
+    config["Model"]["KanTtsSAMBERT"]["params"].update(ling_unit.get_unit_size())
+    if config["Model"]["KanTtsSAMBERT"]["params"].get("SE", False) or se_file is not None:
+        raise NotImplementedError("SE speaker-embedding input is outside the hot path (SURVEY 8f-4)")
+    from kantts.models import model_builder
+
+    model, _, _ = model_builder(config, device)
+    fsnet = model["KanTtsSAMBERT"]
+    logging.info("Loading checkpoint: %s", ckpt)
+    fsnet.load_state_dict(torch.load(ckpt, map_location="cpu")["model"], strict=False)
+    results_dir = os.path.join(output_dir, "feat")
+    os.makedirs(results_dir, exist_ok=True)
+    fsnet.eval()
+    with open(sentence, encoding="utf-8") as f:
+        for line in f:
+            line = line.strip().split("\t")
+            if len(line) < 2:
+                continue
+            logging.info("Inference sentence: %s", line[0])
+            with torch.no_grad():
+                _, mel_post, dur, f0, energy = am_synthesis(line[1], fsnet, ling_unit, device)
+            np.save("%s/%s_mel.npy" % (results_dir, line[0]), mel_post)
+            np.savetxt("%s/%s_dur.txt" % (results_dir, line[0]), dur)
+            np.savetxt("%s/%s_f0.txt" % (results_dir, line[0]), f0)
+            np.savetxt("%s/%s_energy.txt" % (results_dir, line[0]), energy)
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--sentence", type=str, required=True)
+    parser.add_argument("--output_dir", type=str, required=True)
+    parser.add_argument("--ckpt", type=str, required=True)
+    parser.add_argument("--se_file", type=str, required=False)
+    args = parser.parse_args()
+    am_infer(args.sentence, args.ckpt, args.output_dir, args.se_file)

@@ -1,0 +1,86 @@
+"""kantts.bin inference entry points (reference kantts/bin/infer_sambert.py, infer_hifigan.py) driven end to end on
+the emulated C ABI (CPU) and on the GPU: checkpoint / config discovery, file outputs, shapes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import torch_oracle as O
+from util import emulation
+
+
+class _FakeLingUnit:
+    """Stands in for the text front-end (out of scope): symbols are already integer streams."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def using_byte(self):
+        return False
+
+    def get_unit_size(self):
+        return {k: self.cfg[k] for k in O.SAMBERT_VOCAB}
+
+    def encode_symbol_sequence(self, seq):
+        n = len(seq.split()) + 1  # + the trailing "~"
+        g = np.random.default_rng(n)
+        return [g.integers(0, 5, n), g.integers(0, 5, n), g.integers(0, 5, n), g.integers(0, 5, n),
+                g.integers(0, 5, n), np.zeros(n, dtype=np.int64)]
+
+
+def _run(tmp_path, device):
+    from kantts.bin.infer_hifigan import hifigan_infer
+    from kantts.bin.infer_sambert import am_infer
+    from kantts.models.hifigan.hifigan import Generator
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+
+    cfg = O.sambert_config(tiny=True)
+    params = {k: v for k, v in cfg.items() if k not in O.SAMBERT_VOCAB}
+    am_dir = tmp_path / "am" / "ckpt"
+    am_dir.mkdir(parents=True)
+    config = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": params,
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}}, "grad_norm": 1.0, "batch_size": 2}
+    (tmp_path / "am" / "config.yaml").write_text(yaml.dump(config))
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(dict(cfg))
+    with torch.no_grad():
+        m.variance_adaptor.duration_predictor.fc.bias.fill_(1.2)
+    torch.save({"model": m.state_dict()}, am_dir / "checkpoint_1.pth")
+    sent = tmp_path / "sentences.txt"
+    sent.write_text("utt_a\ta b c d e f\nutt_b\tg h i j\n")
+    am_infer(str(sent), str(am_dir / "checkpoint_1.pth"), str(tmp_path / "out"), ling_unit=_FakeLingUnit(cfg))
+    mel = np.load(tmp_path / "out" / "feat" / "utt_a_mel.npy")
+    dur = np.loadtxt(tmp_path / "out" / "feat" / "utt_a_dur.txt")
+    assert mel.ndim == 2 and mel.shape[1] == 80 and mel.shape[0] == int(dur.sum()) and np.isfinite(mel).all()
+    assert os.path.exists(tmp_path / "out" / "feat" / "utt_b_energy.txt")
+    # vocoder: tiny generator checkpoint in the reference's layout
+    voc_dir = tmp_path / "voc" / "ckpt"
+    voc_dir.mkdir(parents=True)
+    gparams = {"channels": 32}
+    (tmp_path / "voc" / "config.yaml").write_text(yaml.dump(
+        {"Model": {"Generator": {"params": gparams}}, "audio_config": {"sampling_rate": 16000}}))
+    torch.manual_seed(1)
+    torch.save({"model": {"generator": Generator(**gparams).state_dict()}}, voc_dir / "checkpoint_1.pth")
+    np.save(tmp_path / "utt_a.npy", mel[:6].astype(np.float32))
+    rtf = hifigan_infer(str(tmp_path / "utt_a.npy"), str(voc_dir / "checkpoint_1.pth"), str(tmp_path / "wav"))
+    from scipy.io import wavfile
+
+    sr, wav = wavfile.read(tmp_path / "wav" / "utt_a_gen.wav")
+    assert sr == 16000 and wav.dtype == np.int16 and wav.shape[0] == 6 * 256 and rtf > 0
+
+
+def test_inference_entry_points_emulated(tmp_path):
+    with emulation():
+        _run(tmp_path, "cpu")
+
+
+@pytest.mark.gpu
+def test_inference_entry_points_gpu(tmp_path):
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _run(tmp_path, "cuda")
