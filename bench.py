@@ -237,20 +237,20 @@ def main():
 
     import kantts._hip as hip
     import kantts._hip.ops  # noqa: F401
-    import torch_oracle as O
     from kantts.models import model_builder
+    from kantts.utils import synthetic
     from kantts.train.loss import MelReconLoss, ProsodyReconLoss
 
     hip.lib()
     hip.set_precision(args.precision)
-    cfg = O.sambert_config(tiny=False)
+    cfg = synthetic.sambert_16k_config()
     torch.manual_seed(0)
     model, opt, sch = model_builder(sambert_yaml_config(cfg), device=dev, rank=local_rank, distributed=distributed)
     net, optimizer, scheduler = model["KanTtsSAMBERT"], opt["KanTtsSAMBERT"], sch["KanTtsSAMBERT"]
     optimizer.set_grad_clip(1.0)
     net.train()
     mel_crit, pros_crit = MelReconLoss(), ProsodyReconLoss()
-    batch = {k: v.to(dev) for k, v in O.synthetic_sambert_batch(B=args.batch, T_in=64, seed=1234 + rank).items()}
+    batch = {k: v.to(dev) for k, v in synthetic.sambert_batch(B=args.batch, T_in=64, seed=1234 + rank).items()}
     frames = int(batch["output_lengths"].sum())
 
     def eager_step():

@@ -84,3 +84,54 @@ def test_inference_entry_points_gpu(tmp_path):
 
     hip.set_precision("fp32")
     _run(tmp_path, "cuda")
+
+
+def test_synthetic_workload_matches_the_oracles_generator():
+    """bench.py draws its inputs from kantts.utils.synthetic (product side); the CPU baseline and the parity tests
+    use the oracle's generator: both must produce the same tensors and config."""
+    from kantts.utils import synthetic
+
+    assert synthetic.sambert_16k_config() == O.sambert_config(tiny=False)
+    assert synthetic.sambert_16k_config(tiny=True) == O.sambert_config(tiny=True)
+    a, b = synthetic.sambert_batch(B=5, T_in=40, seed=9), O.synthetic_sambert_batch(B=5, T_in=40, seed=9)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def _train_clis(tmp_path):
+    from kantts.bin.train_hifigan import train as train_voc
+    from kantts.bin.train_sambert import train as train_am
+    from kantts.utils.synthetic import sambert_16k_config
+
+    cfg = sambert_16k_config(tiny=True)
+    am = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": cfg,
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}},
+        "grad_norm": 1.0, "batch_size": 2, "log_interval_steps": 2, "save_interval_steps": 2, "train_max_steps": 100}
+    tr = train_am(am, [], str(tmp_path / "am"), synthetic=3)
+    assert tr.steps == 4 and os.path.exists(tmp_path / "am" / "ckpt" / "checkpoint_2.pth")
+    assert os.path.exists(tmp_path / "am" / "config.yaml")
+    tr2 = train_am(am, [], str(tmp_path / "am2"), resume_path=str(tmp_path / "am" / "ckpt" / "checkpoint_2.pth"),
+                   synthetic=1)
+    assert tr2.steps == 3  # resumed at step 2, one more batch
+    opt = {"type": "Adam", "params": {"lr": 2e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}}
+    sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [200000]}}
+    voc = {"model_type": "hifigan", "Model": {
+        "Generator": {"params": {"channels": 32}, "optimizer": opt, "scheduler": sch},
+        "MultiPeriodDiscriminator": {"params": {"periods": [2, 3]}, "optimizer": opt, "scheduler": sch}},
+        "Loss": {"generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "mel_loss": {"enable": True, "params": {}, "weights": 45.0},
+                 "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+        "generator_grad_norm": -1, "discriminator_grad_norm": -1, "discriminator_train_start_steps": 0,
+        "generator_train_start_steps": 0, "batch_size": 2, "batch_max_steps": 1024, "log_interval_steps": 1,
+        "save_interval_steps": 2, "audio_config": {"hop_length": 256, "sampling_rate": 16000}}
+    tv = train_voc(voc, [], str(tmp_path / "voc"), synthetic=2)
+    assert tv.steps == 3 and os.path.exists(tmp_path / "voc" / "ckpt" / "checkpoint_2.pth")
+
+
+def test_training_entry_points_emulated(tmp_path):
+    with emulation():
+        _train_clis(tmp_path)

@@ -1,0 +1,117 @@
+"""Trainer shells (reference kantts/train/trainer.py): a few SAM-BERT / GAN steps through the loop, checkpoint
+save -> fresh trainer -> resume must continue bit-identically (emulated ABI on CPU; GPU variant on the device)."""
+import os
+
+import pytest
+import torch
+
+import torch_oracle as O
+from util import emulation
+
+
+def _sambert_setup(device, save_dir, seed=0):
+    from kantts.models import model_builder
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+    from kantts.train.trainer import Sambert_Trainer
+
+    cfg = O.sambert_config(tiny=True)
+    for k in list(cfg):
+        if "dropout" in k:
+            cfg[k] = 0.0
+    config = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": cfg,
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}}, "grad_norm": 1.0, "batch_size": 3,
+        "log_interval_steps": 2}
+    torch.manual_seed(seed)
+    model, opt, sch = model_builder(config, device=device)
+    model["KanTtsSAMBERT"].eval()  # Prenet's hard-wired Dropout(0.5) off: deterministic steps
+    crit = {"MelReconLoss": MelReconLoss(), "ProsodyReconLoss": ProsodyReconLoss()}
+    batches = []
+    for s in range(4):
+        b = O.synthetic_sambert_batch(B=3, T_in=12, seed=10 + s, min_len=6, dur_hi=6)
+        batches.append({"input_lings": b["inputs_ling"], "input_emotions": b["inputs_emotion"],
+                        "input_speakers": b["inputs_speaker"], "valid_input_lengths": b["input_lengths"],
+                        "valid_output_lengths": b["output_lengths"], "mel_targets": b["mel_targets"],
+                        "durations": b["duration_targets"], "pitch_contours": b["pitch_targets"],
+                        "energy_contours": b["energy_targets"], "attn_priors": None})
+    tr = Sambert_Trainer(config, model, opt, sch, crit, torch.device(device), None, batches, None, max_steps=10 ** 6,
+                         save_dir=save_dir, save_interval=10 ** 6, valid_interval=10 ** 6, log_interval=2, grad_clip=1.0)
+    tr.set_model_state = lambda state="train": None  # keep eval-mode dropout for determinism
+    return tr, batches
+
+
+def _sambert_resume(device, tmp_path):
+    tr, batches = _sambert_setup(device, str(tmp_path / "a"))
+    l0 = float(tr.train_step(batches[0]))
+    tr.steps += 1
+    l1 = float(tr.train_step(batches[1]))
+    tr.steps += 1
+    assert l0 == l0 and l1 == l1  # finite
+    ck = str(tmp_path / "a" / "ckpt" / "checkpoint_x.pth")
+    tr.save_checkpoint(ck)
+    ref = [float(tr.train_step(b)) for b in batches[2:]]
+    tr2, _ = _sambert_setup(device, str(tmp_path / "b"), seed=123)  # different init: everything must come from the file
+    tr2.load_checkpoint(ck, restore_training_state=True)
+    assert tr2.steps == tr.steps
+    got = [float(tr2.train_step(b)) for b in batches[2:]]
+    for a, b in zip(got, ref):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (got, ref)
+
+
+def test_sambert_trainer_checkpoint_resume_emulated(tmp_path):
+    with emulation():
+        _sambert_resume("cpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_sambert_trainer_checkpoint_resume_gpu(tmp_path):
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _sambert_resume("cuda", tmp_path)
+
+
+def _gan_setup(device, save_dir, seed=0):
+    from kantts.models import model_builder
+    from kantts.train.loss import criterion_builder
+    from kantts.train.trainer import GAN_Trainer
+
+    opt = {"type": "Adam", "params": {"lr": 2e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}}
+    sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [200000]}}
+    config = {"model_type": "hifigan", "Model": {
+        "Generator": {"params": {"channels": 32}, "optimizer": opt, "scheduler": sch},
+        "MultiPeriodDiscriminator": {"params": {"periods": [2, 3]}, "optimizer": opt, "scheduler": sch}},
+        "Loss": {"generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "mel_loss": {"enable": True, "params": {}, "weights": 45.0},
+                 "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+        "generator_grad_norm": -1, "discriminator_grad_norm": -1, "discriminator_train_start_steps": 0,
+        "generator_train_start_steps": 0, "log_interval_steps": 2}
+    torch.manual_seed(seed)
+    model, optimizer, scheduler = model_builder(config, device=device)
+    crit = criterion_builder(config, device=device)
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(2, 1, 1024, generator=g).clamp(-1, 1), torch.randn(2, 80, 4, generator=g)) for _ in range(3)]
+    tr = GAN_Trainer(config, model, optimizer, scheduler, crit, torch.device(device), None, batches, None,
+                     save_dir=save_dir, save_interval=10 ** 6, valid_interval=10 ** 6, log_interval=2)
+    return tr, batches
+
+
+def test_gan_trainer_checkpoint_resume_emulated(tmp_path):
+    with emulation():
+        tr, batches = _gan_setup("cpu", str(tmp_path / "a"))
+        tr.train_step(batches[0])
+        tr.steps += 1
+        ck = str(tmp_path / "a" / "ckpt" / "checkpoint_x.pth")
+        tr.save_checkpoint(ck)
+        ref = {k: float(v) for k, v in tr.train_step(batches[1]).items()}
+        tr2, _ = _gan_setup("cpu", str(tmp_path / "b"), seed=99)
+        tr2.load_checkpoint(ck, restore_training_state=True)
+        got = {k: float(v) for k, v in tr2.train_step(batches[1]).items()}
+        for k in ref:
+            assert abs(got[k] - ref[k]) <= 1e-4 * max(1.0, abs(ref[k])), (k, got[k], ref[k])
+        # checkpoint layout of the reference (infer_hifigan reads states["model"]["generator"])
+        st = torch.load(ck, map_location="cpu")
+        assert set(st) == {"optimizer", "scheduler", "steps", "model"} and "generator" in st["model"]
+        assert set(st["model"]["discriminator"]) == {"MultiPeriodDiscriminator"}
