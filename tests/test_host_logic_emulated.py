@@ -89,10 +89,10 @@ def test_dropout_backward_consistent_with_forward_mask(emulated_cabi):
         y = ops.linear(x, w, b, relu=relu, drop_p=0.3)
         dense = torch.relu(x @ w.t() + b) if relu else (x @ w.t() + b)
         keep = (y != 0) if relu else torch.isclose(y, dense / 0.7, atol=1e-5)
-        if relu:
-            keep = keep | (dense <= 0)
-        frac = keep.float().mean().item()
-        assert 0.55 < frac < 0.85
+        # keep rate 0.7 among the elements dropout can act on (for ReLU only the positive half is observable;
+        # ~350-700 draws: +-4 sigma is about +-0.1)
+        frac = (keep[dense > 0] if relu else keep).float().mean().item()
+        assert 0.58 < frac < 0.82
         mask = torch.where(torch.isclose(y, dense / 0.7, atol=1e-5), 1 / 0.7, 0.0)
         gx, gw, gb = torch.autograd.grad(y.sum(), (x, w, b))
         ex, ew, eb = torch.autograd.grad((dense * mask).sum(), (x, w, b))
