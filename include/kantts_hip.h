@@ -255,6 +255,13 @@ int kantts_weight_norm_fwd(const float* v, const float* g, float* w, int rows, i
 int kantts_weight_norm_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int rows,
                            int cols, void* stream);
 
+/* The same reparametrisation writing / reading the weight through strides: element (row r, input channel ci, tap k) at
+ * r*rs + ci*cs + k*ks (tap-major (K, Cout, Cin_g): rs = Cin_g, cs = 1, ks = Cout*Cin_g); v / dv are (rows, cin, K). */
+int kantts_weight_norm_strided_fwd(const float* v, const float* g, float* w, int rows, int cin, int K, long long rs,
+                                   long long cs, long long ks, void* stream);
+int kantts_weight_norm_strided_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int rows,
+                                   int cin, int K, long long rs, long long cs, long long ks, void* stream);
+
 /* y = sin(x) + x and its backward dx = dy * (cos(x) + 1)  (kantts/models/hifigan/hifigan.py:157) */
 int kantts_sinadd_fwd(const float* x, float* y, long long n, void* stream);
 int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, long long n, void* stream);

@@ -813,7 +813,11 @@ class _ConvCL(torch.autograd.Function):
         inner, Tout = cfg["inner"], cfg["Tout"]
         B, Tin = x.shape[0], x.shape[1]
         Cin = x.shape[-1]
-        Cout, Cin_g, K = w.shape
+        tap_major = cfg.get("tap_major", False)
+        if tap_major:
+            K, Cout, Cin_g = w.shape
+        else:
+            Cout, Cin_g, K = w.shape
         Cout_g = Cout // groups
         assert Cin_g * groups == Cin
         M = B * Tout * inner
@@ -823,12 +827,12 @@ class _ConvCL(torch.autograd.Function):
         ctx.has = (bias is not None, res is not None)
         ctx.save_for_backward(x, w, y if cfg["out_leaky"] is not None else None)
         # one input channel (first discriminator layers): streaming kernels, weights stay (Cout, K)
-        ctx.c1 = (Cin == 1 and groups == 1 and up == 1 and res is None and cfg["in_leaky"] is None)
+        ctx.c1 = (Cin == 1 and groups == 1 and up == 1 and res is None and cfg["in_leaky"] is None and not tap_major)
         if ctx.c1 and conv_c1(0, x=x, y=y, w=w, bias=bias, B=B, Tsrc=Tin, Tdst=Tout, Cout=Cout, K=K, stride=stride,
                               dil=dil, pad=pad, inner=inner, out_leaky=cfg["out_leaky"]):
             return y
         ctx.c1 = False
-        wt = w.permute(2, 0, 1).contiguous() if K > 1 else w  # (K, Cout, Cin_g)
+        wt = w if tap_major else (w.permute(2, 0, 1).contiguous() if K > 1 else w)  # (K, Cout, Cin_g)
         if conv_win(
                 x, wt, y, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K, in_mul=stride,
                 in_add=-pad, in_kstep=dil, in_div=1, phases=1, inner=inner, up=up, bias=bias, res=r, in_leaky=cfg["in_leaky"],
@@ -850,7 +854,11 @@ class _ConvCL(torch.autograd.Function):
         inner, Tout = cfg["inner"], cfg["Tout"]
         dy = _c(dy)
         B, Tin, Cin = x.shape[0], x.shape[1], x.shape[-1]
-        Cout, Cin_g, K = w.shape
+        tap_major = cfg.get("tap_major", False)
+        if tap_major:
+            K, Cout, Cin_g = w.shape
+        else:
+            Cout, Cin_g, K = w.shape
         Cout_g = Cout // groups
         gate, gslope = (y, cfg["out_leaky"]) if cfg["out_leaky"] is not None else (None, 0.0)
         dx = dw = db = None
@@ -870,7 +878,10 @@ class _ConvCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             Mx = B * Tin * inner
-            wd = w.view(groups, Cout_g, Cin_g, K).permute(3, 0, 2, 1).contiguous()  # (K, groups, Cin_g, Cout_g)
+            if tap_major:
+                wd = w.view(K, groups, Cout_g, Cin_g).transpose(2, 3).contiguous()
+            else:
+                wd = w.view(groups, Cout_g, Cin_g, K).permute(3, 0, 2, 1).contiguous()  # (K, groups, Cin_g, Cout_g)
             if up > 1 and stride == 1:
                 # x-token t feeds the `up` virtual tokens t*up + r:  dx[t] = sum_j dy[t*up + j] W'[j] with
                 # W'[j] = sum_{(r,k): r + pad - k*dil = j} w[k] -- ONE strided window pass over dy instead of `up`
@@ -905,28 +916,29 @@ class _ConvCL(torch.autograd.Function):
             if conv_wgrad(x, dy, dwt, db, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K,
                           stride=stride, dil=dil, pad=pad, inner=inner, up=up, dy_gate=gate, dy_gate_slope=gslope,
                           x_leaky=cfg["in_leaky"]):
-                return dx, dwt.permute(1, 2, 0), db, (dy if has_res else None), None
+                return dx, (dwt if tap_major else dwt.permute(1, 2, 0)), db, (dy if has_res else None), None
             seg = make_seg(dy, 1, Cout, x, 1, Cin, Mtok, ntaps=K, a_gate=gate, a_gate_slope=gslope, b_tok_axis=2,
                            b_shift0=-pad, b_shift_step=dil,
                            b_map=dict(inner=inner, Tq=Tout, Tsrc=Tin, mul=stride, up=up), b_leaky=cfg["in_leaky"])
             gemm([seg], Cout_g, Cin_g, dwt, Cin_g, 1, groups=groups, a_gs=Cout_g, b_gs=Cin_g,
                  c_gs=Cout_g * Cin_g, bias_gs=Cout_g, accumulate=True,
                  splitk=_splitk_for(Cout_g * groups * K, Cin_g, Mtok), z_taps=K, c_tap=Cout * Cin_g, a_rowsum=db)
-            dw = dwt.permute(1, 2, 0)
+            dw = dwt if tap_major else dwt.permute(1, 2, 0)
         elif has_bias and ctx.needs_input_grad[2]:
             raise RuntimeError("bias gradient without weight gradient is not supported")
         return dx, dw, db, (dy if has_res else None), None
 
 
 def conv_cl(x, w, bias=None, *, stride=1, dilation=1, pad=0, Tout=None, up=1, groups=1, inner=1, in_leaky=None,
-            out_leaky=None, res=None):
-    """pad = left padding in (upsampled) input samples; Tout defaults to the 'same'/causal length."""
-    K = w.shape[-1]
+            out_leaky=None, res=None, tap_major=False):
+    """pad = left padding in (upsampled) input samples; Tout defaults to the 'same'/causal length.
+    tap_major: w is (K, Cout, Cin_g) (ops.weight_norm_tap) instead of the parameter layout (Cout, Cin_g, K)."""
+    K = w.shape[0] if tap_major else w.shape[-1]
     Tin = x.shape[1]
     if Tout is None:
         Tout = Tin * up if stride == 1 else (Tin + 2 * pad - dilation * (K - 1) - 1) // stride + 1
     cfg = dict(stride=int(stride), dilation=int(dilation), pad=int(pad), Tout=int(Tout), up=int(up), groups=int(groups),
-               inner=int(inner), in_leaky=in_leaky, out_leaky=out_leaky)
+               inner=int(inner), in_leaky=in_leaky, out_leaky=out_leaky, tap_major=bool(tap_major))
     return _ConvCL.apply(x, w, bias, res, cfg)
 
 
@@ -1014,6 +1026,36 @@ class _WeightNorm(torch.autograd.Function):
         check(lib().kantts_weight_norm_bwd(ptr(dw, torch.float32), ptr(v), ptr(g), ptr(dv), ptr(dg), rows, cols,
                                            stream()), "weight_norm_bwd")
         return dv, dg
+
+
+class _WeightNormTap(torch.autograd.Function):
+    """w_tap[k][co][ci] = g[co] * v[co][ci][k] / ||v[co]||: the weight-norm reparametrisation written straight into
+    the tap-major layout the convolution kernels read; backward takes the tap-major weight gradient they produce."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        v, g = _c(v), _c(g)
+        Cout, cin, K = v.shape
+        w = torch.empty((K, Cout, cin), device=v.device, dtype=torch.float32)
+        check(lib().kantts_weight_norm_strided_fwd(ptr(v, torch.float32), ptr(g, torch.float32), ptr(w), Cout, cin, K, cin,
+                                                   1, Cout * cin, stream()), "weight_norm_strided_fwd")
+        ctx.save_for_backward(v, g)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g = ctx.saved_tensors
+        dw = _c(dw)
+        Cout, cin, K = v.shape
+        dv, dg = torch.empty_like(v), torch.empty_like(g)
+        check(lib().kantts_weight_norm_strided_bwd(ptr(dw, torch.float32), ptr(v), ptr(g), ptr(dv), ptr(dg), Cout, cin, K,
+                                                   cin, 1, Cout * cin, stream()), "weight_norm_strided_bwd")
+        return dv, dg
+
+
+def weight_norm_tap(v, g):
+    """Weight-normed conv weight in tap-major layout (K, Cout, Cin_g) for conv_cl(..., tap_major=True)."""
+    return _WeightNormTap.apply(v, g)
 
 
 def weight_norm(v, g):

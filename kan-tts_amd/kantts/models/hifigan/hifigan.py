@@ -14,7 +14,7 @@ from torch.nn.utils import weight_norm
 
 from kantts._hip import ops
 from kantts.models.hifigan.layers import (CausalConv1d, CausalConvTranspose1d, Conv1d, ConvTranspose1d,
-                                          ResidualBlock, effective_weight)
+                                          ResidualBlock, conv_weight, effective_weight)
 
 DB3_DEC_LO = [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313,
               0.8068915093133388, 0.3326705529509569]
@@ -81,8 +81,9 @@ class Generator(torch.nn.Module):
             if self.repeat_upsample:
                 conv = self.repeat_upsamples[i][2]
                 c = conv.conv1d
-                rep = ops.conv_cl(h, effective_weight(c), c.bias, pad=conv.pad, up=s, Tout=h.shape[1] * s,
-                                  in_leaky=self.slope)
+                w, tap = conv_weight(c)
+                rep = ops.conv_cl(h, w, c.bias, pad=conv.pad, up=s, Tout=h.shape[1] * s, in_leaky=self.slope,
+                                  tap_major=tap)
             else:
                 rep = None
             h = self.transpose_upsamples[i][1].forward_cl(h, in_leaky=self.slope, res=rep)
@@ -142,9 +143,9 @@ class PeriodDiscriminator(torch.nn.Module):
         fmap = []
         for layer in self.convs:
             conv = layer[0]
-            w = effective_weight(conv).squeeze(-1)
+            w, tap = conv_weight(conv)
             h = ops.conv_cl(h, w, conv.bias, stride=conv.stride[0], pad=conv.padding[0], inner=p,
-                            out_leaky=self.slope)
+                            out_leaky=self.slope, tap_major=tap)
             fmap.append(h.permute(0, 3, 1, 2))
         cp = self.conv_post
         h = ops.conv_cl(h, cp.weight.squeeze(-1), cp.bias, stride=1, pad=cp.padding[0], inner=p,
@@ -214,11 +215,13 @@ class ScaleDiscriminator(torch.nn.Module):
         fmap = []
         for layer in self.convs:
             c = layer[0]
-            h = ops.conv_cl(h, effective_weight(c), c.bias, stride=c.stride[0], pad=c.padding[0], groups=c.groups,
-                            out_leaky=self.slope)
+            w, tap = conv_weight(c)
+            h = ops.conv_cl(h, w, c.bias, stride=c.stride[0], pad=c.padding[0], groups=c.groups,
+                            out_leaky=self.slope, tap_major=tap)
             fmap.append(h.transpose(1, 2))
         c = self.conv_post
-        h = ops.conv_cl(h, effective_weight(c), c.bias, stride=1, pad=c.padding[0])
+        w, tap = conv_weight(c)
+        h = ops.conv_cl(h, w, c.bias, stride=1, pad=c.padding[0], tap_major=tap)
         out = h.transpose(1, 2)
         fmap.append(out)
         return torch.flatten(out, 1, -1), fmap

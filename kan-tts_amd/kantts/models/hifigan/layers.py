@@ -26,6 +26,21 @@ def effective_weight(m):
     return m.weight
 
 
+def conv_weight(m):
+    """(weight, tap_major) for ops.conv_cl: weight-normed convolutions with >= 4 input channels per group get their
+    weight straight in the kernels' tap-major layout (K, Cout, Cin_g) from the weight-norm kernel; 1-3 channel
+    layers (streaming kernels) and plain weights keep the parameter layout (Cout, Cin_g, K)."""
+    if hasattr(m, "weight_g"):
+        v = m.weight_v
+        if v.dim() == 4:  # Conv2d((k,1)) of the period discriminators
+            v = v.squeeze(-1)
+        if v.shape[1] % 4 == 0:
+            return ops.weight_norm_tap(v, m.weight_g), True
+        return ops.weight_norm(v, m.weight_g), False
+    w = m.weight
+    return (w.squeeze(-1) if w.dim() == 4 else w), False
+
+
 class Conv1d(torch.nn.Module):
     """Weight-normed Conv1d with symmetric padding (reference :15-49)."""
 
@@ -45,8 +60,9 @@ class Conv1d(torch.nn.Module):
         k, d, s = c.kernel_size[0], c.dilation[0], c.stride[0]
         Tin = x.shape[1]
         Tout = Tin if self.causal else (Tin + 2 * self.pad - d * (k - 1) - 1) // s + 1
-        return ops.conv_cl(x, effective_weight(c), c.bias, stride=s, dilation=d, pad=self.pad, Tout=Tout,
-                           groups=c.groups, in_leaky=in_leaky, out_leaky=out_leaky, res=res)
+        w, tap = conv_weight(c)
+        return ops.conv_cl(x, w, c.bias, stride=s, dilation=d, pad=self.pad, Tout=Tout, groups=c.groups,
+                           in_leaky=in_leaky, out_leaky=out_leaky, res=res, tap_major=tap)
 
     def forward(self, x):
         return self.forward_cl(x.transpose(1, 2).contiguous()).transpose(1, 2)

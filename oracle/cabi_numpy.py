@@ -760,3 +760,24 @@ class EmulatedLib:
         _arr(c_out, B * H)[:] = c.astype(np.float32).ravel()
         _arr(h_out, B * H)[:] = (sig(g[:, 3]) * np.tanh(c)).astype(np.float32).ravel()
         return 0
+
+    def kantts_weight_norm_strided_fwd(self, v, g, w, rows, cin, K, rs, cs, ks, stream):
+        V = _arr(v, rows * cin * K).reshape(rows, cin, K).astype(np.float64)
+        G = _arr(g, rows).astype(np.float64)
+        W = V * (G / np.sqrt((V * V).sum(axis=(1, 2))))[:, None, None]
+        offs = (np.arange(rows)[:, None, None] * rs + np.arange(cin)[None, :, None] * cs + np.arange(K)[None, None, :] * ks)
+        mem = _arr(w, int(offs.max()) + 1)
+        mem[offs.ravel()] = W.astype(np.float32).ravel()
+        return 0
+
+    def kantts_weight_norm_strided_bwd(self, dw, v, g, dv, dg, rows, cin, K, rs, cs, ks, stream):
+        V = _arr(v, rows * cin * K).reshape(rows, cin, K).astype(np.float64)
+        G = _arr(g, rows).astype(np.float64)
+        offs = (np.arange(rows)[:, None, None] * rs + np.arange(cin)[None, :, None] * cs + np.arange(K)[None, None, :] * ks)
+        DW = _arr(dw, int(offs.max()) + 1)[offs.ravel()].reshape(rows, cin, K).astype(np.float64)
+        nrm = np.sqrt((V * V).sum(axis=(1, 2)))
+        dgv = (DW * V).sum(axis=(1, 2)) / nrm
+        _arr(dg, rows)[:] = dgv.astype(np.float32)
+        DV = (G / nrm)[:, None, None] * (DW - V * (dgv / nrm)[:, None, None])
+        _arr(dv, rows * cin * K)[:] = DV.astype(np.float32).ravel()
+        return 0
