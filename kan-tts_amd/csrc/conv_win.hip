@@ -90,12 +90,17 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
   const int n0 = grp * g.NG + (bx % ntpg) * BN;
   const int n_end = (grp + 1) * g.NG;
   const int phase = blockIdx.z % g.phases;
-  const int bp = blockIdx.z / g.phases;  // (batch item, position on the folded `inner` axis)
-  const int b = bp / g.inner, pi = bp % g.inner;
-  const long long in_pitch = (long long)g.inner * g.Cin_tot;  // elements between consecutive source tokens
-  const int m0 = by * BQ;
+  const int b = blockIdx.z / g.phases;
+  // The folded axis (MPD period p = inner) is part of the ROW axis of a tile: row m' = m*inner + p'.  A period
+  // discriminator's deep layers have 10-80 tokens per (batch, p') sequence; one tile per sequence would leave the
+  // MFMA rows 16-44 % full, folded tiles are dense.  Global rows (token, p') are contiguous, so the window of a tile
+  // is still one contiguous row range.
+  const int inner = g.inner;
+  const int m0 = by * BQ;  // first row (m' units) of the tile
   const int mrows = (g.Tdst - phase + g.phases - 1) / g.phases;
-  if (m0 >= mrows) return;
+  const int R = mrows * inner;
+  if (m0 >= R) return;
+  const int m_lo = m0 / inner, m_hi = min(R - 1, m0 + BQ - 1) / inner;
 
   if (tid == 0) {
     int nv = 0;
@@ -124,13 +129,13 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
   // token u / up); the window then holds SOURCE tokens and every lane computes its own row (rows repeat).
   const int up = g.up > 1 ? g.up : 1;
   const int dm = (up > 1) ? 1 : g.in_mul;  // de-interleave modulus of the LDS window
-  const int lo = (up > 1) ? cw_floordiv(m0 * g.in_mul + offmin, up) : m0 * g.in_mul + offmin;  // first source token
-  const int W = (up > 1) ? cw_floordiv((m0 + BQ - 1) * g.in_mul + offmax, up) - lo + 1
-                         : (BQ - 1) * g.in_mul + (offmax - offmin) + 1;
+  const int lo = (up > 1) ? cw_floordiv(m_lo * g.in_mul + offmin, up) : m_lo * g.in_mul + offmin;  // first source token
+  const int W = (up > 1) ? cw_floordiv(m_hi * g.in_mul + offmax, up) - lo + 1
+                         : (m_hi - m_lo) * g.in_mul + (offmax - offmin) + 1;
   const int Wp = (W + dm - 1) / dm;
 
   void* win = cw_lds;
-  unsigned char* bt = cw_lds + (size_t)Wp * dm * LDW * ESZ;
+  unsigned char* bt = cw_lds + (size_t)Wp * dm * inner * LDW * ESZ;
 
   f32x4 acc[MREP][4];
 #pragma unroll
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const long long in_off = ((long long)b * g.Tsrc * g.inner + pi) * g.Cin_tot + (long long)grp * g.CR;
+  const long long in_off = (long long)b * g.Tsrc * inner * g.Cin_tot + (long long)grp * g.CR;
   const float* in_b = g.in + in_off;
   const float* gate_b = g.in_gate ? g.in_gate + in_off : nullptr;
   const int c4 = (tid & 7) * 4;  // channel offset of this thread's float4 inside a chunk
@@ -171,22 +176,25 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
     fetch_w(0, c0);
     // ---- stage the window: W tokens x 32 channels, 4 rows in flight per thread
     const bool cok = (c0 + c4) < g.CR;
-    for (int r0 = rslot; r0 < W; r0 += 32 * 4) {
+    const int WR = W * inner;  // window rows = (token, p') pairs, contiguous in global memory
+    for (int r0 = rslot; r0 < WR; r0 += 32 * 4) {
       float4 xv[4], gv[4];
       bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int rel = r0 + 32 * u;
-        const int t = lo + rel;
-        ok[u] = cok && rel < W && t >= 0 && t < g.Tsrc;
-        const long long o = ok[u] ? ((long long)t * in_pitch + c0 + c4) : 0;
+        const int rr = r0 + 32 * u;
+        const int t = lo + ((inner > 1) ? rr / inner : rr);
+        ok[u] = cok && rr < WR && t >= 0 && t < g.Tsrc;
+        const long long o = ok[u] ? (((long long)lo * inner + rr) * g.Cin_tot + c0 + c4) : 0;
         xv[u] = *reinterpret_cast<const float4*>(in_b + o);
         if (gate_b) gv[u] = *reinterpret_cast<const float4*>(gate_b + o);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int rel = r0 + 32 * u;
-        if (rel >= W) continue;
+        const int rr = r0 + 32 * u;
+        if (rr >= WR) continue;
+        const int rel = (inner > 1) ? rr / inner : rr;
+        const int pin = (inner > 1) ? rr - rel * inner : 0;
         float v0 = xv[u].x, v1 = xv[u].y, v2 = xv[u].z, v3 = xv[u].w;
         if (!ok[u]) v0 = v1 = v2 = v3 = 0.f;
         if (g.in_act) {
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
           v2 *= (gv[u].z > 0.f) ? 1.f : g.in_gate_slope;
           v3 *= (gv[u].w > 0.f) ? 1.f : g.in_gate_slope;
         }
-        const int row = (rel % dm) * Wp + rel / dm;
+        const int row = ((rel % dm) * Wp + rel / dm) * inner + pin;
         cw_store4<BF16>(win, row * LDW + c4, v0, v1, v2, v3);
       }
     }
@@ -214,9 +222,12 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
       int arow[MREP];
 #pragma unroll
       for (int f = 0; f < MREP; ++f) {
-        const int mloc = wm * (MREP * 16) + f * 16 + (lane & 15);
-        arow[f] = (up > 1) ? cw_floordiv((m0 + mloc) * g.in_mul + s_off[ti], up) - lo
-                           : (a % dm) * Wp + a / dm + mloc;
+        // rows past the end of the sequence set are clamped (computed, never stored)
+        const int mp = min(m0 + wm * (MREP * 16) + f * 16 + (lane & 15), R - 1);
+        const int m = (inner > 1) ? mp / inner : mp;
+        const int pin = (inner > 1) ? mp - m * inner : 0;
+        arow[f] = (up > 1) ? cw_floordiv(m * g.in_mul + s_off[ti], up) - lo
+                           : ((a % dm) * Wp + a / dm + (m - m_lo)) * inner + pin;
       }
       const unsigned char* bcur = bt + (size_t)(ti & 1) * BN * LDW * ESZ;
       if (BF16) {
@@ -272,11 +283,13 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int rl = p * 4 + (lane >> 4);
-      const int m = m0 + wm * (MREP * 16) + f * 16 + rl;
+      const int mp = m0 + wm * (MREP * 16) + f * 16 + rl;
       const int n = n0 + wn * 64 + (lane & 15) * 4;
-      if (m < mrows && n < n_end) {
+      if (mp < R && n < n_end) {
+        const int m = (inner > 1) ? mp / inner : mp;
+        const int pin = (inner > 1) ? mp - m * inner : 0;
         const long long d = (long long)m * g.phases + phase;
-        const long long o = (((long long)b * g.Tdst + d) * g.inner + pi) * g.Ntot + n;
+        const long long o = (((long long)b * g.Tdst + d) * inner + pin) * g.Ntot + n;
         const float4 a4 = *reinterpret_cast<const float4*>(&strip[rl * 68 + (lane & 15) * 4]);
         float v[4] = {a4.x, a4.y, a4.z, a4.w};
         const int cnt = min(4, n_end - n);
@@ -358,9 +371,10 @@ static int cw_launch(const kantts_conv_args& g, hipStream_t st) {
   const int span = ((g.K - 1) * abs(g.in_kstep)) / g.in_div + 1;
   const int up = g.up > 1 ? g.up : 1;
   const int dm = (up > 1) ? 1 : g.in_mul;
-  const int W = (up > 1) ? ((BQ - 1) * g.in_mul + span) / up + 3 : (BQ - 1) * g.in_mul + span + 1;
+  const int mspan = (BQ - 1) / g.inner + 1;  // tokens m a tile of BQ folded rows can straddle, minus one
+  const int W = (up > 1) ? ((BQ - 1) * g.in_mul + span) / up + 3 : mspan * g.in_mul + span + 1;
   const int Wp = (W + dm - 1) / dm;
-  size_t lds = (size_t)Wp * dm * LDW * ESZ + 2 * (size_t)BN * LDW * ESZ;
+  size_t lds = (size_t)Wp * dm * g.inner * LDW * ESZ + 2 * (size_t)BN * LDW * ESZ;
   const size_t strip = 4 * 16 * 68 * sizeof(float);
   if (lds < strip) lds = strip;
   lds += CW_HDR;
@@ -374,7 +388,7 @@ static int cw_launch(const kantts_conv_args& g, hipStream_t st) {
   }
   const int mrows = (g.Tdst + g.phases - 1) / g.phases;
   const int ntpg = (g.NG + BN - 1) / BN;
-  dim3 grid(g.groups * ntpg, kantts_cdiv(mrows, BQ), g.B * g.inner * g.phases);
+  dim3 grid(g.groups * ntpg, kantts_cdiv((long long)mrows * g.inner, BQ), g.B * g.phases);
   hipLaunchKernelGGL((conv_win_kernel<BF16, WM, MREP>), grid, dim3(CW_THREADS), lds, st, g);
   KANTTS_CHECK_LAUNCH();
 }
@@ -398,10 +412,10 @@ extern "C" int kantts_conv_win_launch(const kantts_conv_args* a, void* stream) {
   if ((g.CR & 3) || (g.Cin_tot & 3) || ((uintptr_t)g.in & 15) || ((uintptr_t)g.w & 15) ||
       (g.in_gate && ((uintptr_t)g.in_gate & 15)))
     return KANTTS_E_UNSUPPORTED;
-  if ((long long)g.B * g.inner * g.phases > 65535) return KANTTS_E_UNSUPPORTED;
+  if ((long long)g.B * g.phases > 65535 || (g.up > 1 && g.inner > 1)) return KANTTS_E_UNSUPPORTED;
   if (g.B == 0 || g.Tdst == 0) return KANTTS_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int mrows = (g.Tdst + g.phases - 1) / g.phases;
+  const long long mrows = (long long)((g.Tdst + g.phases - 1) / g.phases) * g.inner;  // folded rows per batch item
   const bool wide = (g.NG >= 128) && (mrows >= 128);
   const bool tall = mrows >= 96;
   if (g.precision == 1) {

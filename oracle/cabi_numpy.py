@@ -607,7 +607,7 @@ class EmulatedLib:
     # ------------------------------------------------------------------------------------ windowed conv
     def kantts_conv_win_launch(self, args_ref, stream):
         g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
-        if g.K > 64 and not (g.CR % 4):
+        if (g.K > 64 and not (g.CR % 4)) or (g.up > 1 and g.inner > 1 and not (g.CR % 4)):
             return -2  # KANTTS_E_UNSUPPORTED (same rule as csrc/conv_win.hip; CR % 4 != 0 takes the direct kernel)
         P = g.inner
         B, Ts, Td, Ci, N, CR, NG, G, K = g.B, g.Tsrc, g.Tdst, g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K
