@@ -416,8 +416,15 @@ extern "C" int kantts_conv_win_launch(const kantts_conv_args* a, void* stream) {
   if (g.B == 0 || g.Tdst == 0) return KANTTS_OK;
   hipStream_t st = (hipStream_t)stream;
   const long long mrows = (long long)((g.Tdst + g.phases - 1) / g.phases) * g.inner;  // folded rows per batch item
-  const bool wide = (g.NG >= 128) && (mrows >= 128);
-  const bool tall = mrows >= 96;
+  // tile choice: the largest tile that still gives every CU about two workgroups (256 CUs); the early generator
+  // stages (256 tokens x 256 channels per item) would otherwise run 128 workgroups of 128x128
+  auto blocks = [&](int bq, int bn) {
+    return (long long)g.groups * ((g.NG + bn - 1) / bn) * ((mrows + bq - 1) / bq) * g.B * g.phases;
+  };
+  bool wide = (g.NG >= 128) && (mrows >= 128);
+  bool tall = mrows >= 96;
+  if (wide && blocks(128, 128) < 512) wide = false;
+  if (!wide && tall && blocks(128, 64) < 512 && mrows >= 64) tall = false;
   if (g.precision == 1) {
     if (wide) return cw_launch<true, 2, 4>(g, st);
     if (tall) return cw_launch<true, 4, 2>(g, st);
