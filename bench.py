@@ -191,9 +191,13 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
                 G.transpose_upsamples[i][1].forward_cl(h, in_leaky=0.1)
 
         ms = _event_ms(up, 10)
+        per_stage = []
+        for i, h in enumerate(hs):
+            per_stage.append(round(_event_ms(lambda: G.transpose_upsamples[i][1].forward_cl(h, in_leaky=0.1), 10) * 1e3, 1))
     gbps = elems * 4 / (ms * 1e-3) / 1e9
     res["upsampling"] = {"ms": ms, "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes": elems * 4, "tflops": flops / (ms * 1e-3) / 1e12,
+                         "stage_us": per_stage,
                          "note": "4 launches (one polyphase GEMM per layer); at fp32 storage the first two layers are "
                                  "MFMA-bound (410 / 200 flop per byte), the last two HBM-bound"}
     out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)

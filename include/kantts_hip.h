@@ -161,13 +161,15 @@ int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int
  * :109-134; kantts_sambert.py:637-646).  gx (B,T,ndir*4H) = x W_ih^T + b_ih (from the GEMM);
  * whh (ndir,4H,H), bhh (ndir,4H) or NULL; lens (B) int32 or NULL = pack_padded_sequence lengths;
  * out (B,T,ndir*H); gates_save (ndir,B,T,4H) and c_save (ndir,B,T,H) are kept for backward.
- * Backward returns dgates (ndir,B,T,4H) = gradient w.r.t. the pre-activation gates. */
+ * Backward returns dgates (ndir,B,T,4H) = gradient w.r.t. the pre-activation gates.
+ * precision 0: fp32 recurrent products; 1: h / dgates and W_hh rounded to bf16 for the recurrent product only
+ * (packed v_dot2c_f32_bf16, fp32 accumulate) -- gates, cell state, outputs stay fp32. */
 int kantts_lstm_fwd(const float* gx, const float* whh, const float* bhh, const int32_t* lens, float* out,
                     float* gates_save, float* c_save, int B, int T, int H, int ndir, int reverse_first,
-                    void* stream);
+                    int precision, void* stream);
 int kantts_lstm_bwd(const float* dout, const float* whh, const int32_t* lens, const float* gates_save,
                     const float* c_save, float* dgates, int B, int T, int H, int ndir, int reverse_first,
-                    void* stream);
+                    int precision, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Embedding gather-sum: out[row] = scale * sum_k table_k[ids[row,k]] (+ pos[row % T]);

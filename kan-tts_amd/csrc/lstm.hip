@@ -21,31 +21,51 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 // gx: (B,T,ndir*4H) [direction d at column offset d*4H]; out: (B,T,ndir*H)
 // whh: (ndir, 4H, H), bhh: (ndir, 4H); gates_out: (ndir,B,T,4H); c_out: (ndir,B,T,H)
+typedef __bf16 lstm_bf16x2 __attribute__((ext_vector_type(2)));
+union LstmPack4 {
+  uint4 u;
+  lstm_bf16x2 p[4];
+};
+
+// BF16 = true (throughput mode): the recurrent product h_{t-1} . W_hh[r] runs on packed bf16 pairs with fp32
+// accumulation (v_dot2c_f32_bf16): 64 instead of 128 multiply-add instructions and 16 instead of 32 LDS reads per
+// step and lane -- the two things the sequential loop is made of.  Gates, cell state and outputs stay fp32.
+template <bool BF16>
 __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
                                                       const float* __restrict__ bhh, const int32_t* __restrict__ lens,
                                                       float* __restrict__ out, float* __restrict__ gates_out,
                                                       float* __restrict__ c_out, int B, int T, int ndir,
                                                       int reverse_first) {
   __shared__ __attribute__((aligned(16))) float h_s[LH];
+  __shared__ __attribute__((aligned(16))) __bf16 h_b[LH];
   __shared__ float g_s[LG];
   const int r = threadIdx.x;
   const int b = blockIdx.x, dir = blockIdx.y;
   const bool rev = reverse_first ? true : (dir == 1);
   const int len = lens ? min(lens[b], T) : T;
-  float w[LH];
+  float w[BF16 ? 1 : LH];
+  lstm_bf16x2 wq[BF16 ? LH / 2 : 1];
   {
     const float4* wp = reinterpret_cast<const float4*>(whh + ((long long)dir * LG + r) * LH);
 #pragma unroll
     for (int k = 0; k < LH / 4; ++k) {
       float4 t = wp[k];
-      w[4 * k] = t.x;
-      w[4 * k + 1] = t.y;
-      w[4 * k + 2] = t.z;
-      w[4 * k + 3] = t.w;
+      if (BF16) {
+        wq[2 * k] = (lstm_bf16x2){(__bf16)t.x, (__bf16)t.y};
+        wq[2 * k + 1] = (lstm_bf16x2){(__bf16)t.z, (__bf16)t.w};
+      } else {
+        w[4 * k] = t.x;
+        w[4 * k + 1] = t.y;
+        w[4 * k + 2] = t.z;
+        w[4 * k + 3] = t.w;
+      }
     }
   }
   const float bias = bhh ? bhh[dir * LG + r] : 0.f;
-  if (r < LH) h_s[r] = 0.f;
+  if (r < LH) {
+    h_s[r] = 0.f;
+    h_b[r] = (__bf16)0.f;
+  }
   float c = 0.f;
   const long long gx_ld = (long long)ndir * LG;
   const float* gxb = gx + (long long)b * T * gx_ld + dir * LG + r;
@@ -60,14 +80,27 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
     const int tn = rev ? t - 1 : t + 1;
     if (step + 1 < len) gnext = gxb[(long long)tn * gx_ld];
     float acc0 = gcur + bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    const float4* hp = reinterpret_cast<const float4*>(h_s);
+    if (BF16) {
+      const uint4* hp = reinterpret_cast<const uint4*>(h_b);
 #pragma unroll
-    for (int k = 0; k < LH / 4; ++k) {
-      float4 hv = hp[k];
-      acc0 = fmaf(w[4 * k], hv.x, acc0);
-      acc1 = fmaf(w[4 * k + 1], hv.y, acc1);
-      acc2 = fmaf(w[4 * k + 2], hv.z, acc2);
-      acc3 = fmaf(w[4 * k + 3], hv.w, acc3);
+      for (int k = 0; k < LH / 8; ++k) {
+        LstmPack4 hv;
+        hv.u = hp[k];
+        acc0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k], hv.p[0], acc0, false);
+        acc1 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 1], hv.p[1], acc1, false);
+        acc2 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 2], hv.p[2], acc2, false);
+        acc3 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 3], hv.p[3], acc3, false);
+      }
+    } else {
+      const float4* hp = reinterpret_cast<const float4*>(h_s);
+#pragma unroll
+      for (int k = 0; k < LH / 4; ++k) {
+        float4 hv = hp[k];
+        acc0 = fmaf(w[4 * k], hv.x, acc0);
+        acc1 = fmaf(w[4 * k + 1], hv.y, acc1);
+        acc2 = fmaf(w[4 * k + 2], hv.z, acc2);
+        acc3 = fmaf(w[4 * k + 3], hv.w, acc3);
+      }
     }
     const float pre = (acc0 + acc1) + (acc2 + acc3);
     // activation by gate block: rows [0,256) sigmoid (i,f), [256,384) tanh (g), [384,512) sigmoid (o)
@@ -79,7 +112,10 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
       const float ig = g_s[r], fg = g_s[LH + r], gg = g_s[2 * LH + r], og = g_s[3 * LH + r];
       c = fmaf(fg, c, ig * gg);
       const float hn = og * tanhf(c);
-      h_s[r] = hn;
+      if (BF16)
+        h_b[r] = (__bf16)hn;
+      else
+        h_s[r] = hn;
       outb[(long long)t * ndir * LH + r] = hn;
       cob[(long long)t * LH + r] = c;
     }
@@ -95,12 +131,14 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
 // gates); the weight / input gradients are GEMMs over it (host layer).
 // dout: (B,T,ndir*H).  W_hh^T is held in registers as 4 K-slices: thread (k = tid&127, qd = tid>>7)
 // keeps W_hh[qd*128 + rr][k] for rr = 0..127.
+template <bool BF16>
 __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ whh,
                                                       const int32_t* __restrict__ lens,
                                                       const float* __restrict__ gates, const float* __restrict__ cst,
                                                       float* __restrict__ dgates, int B, int T, int ndir,
                                                       int reverse_first) {
   __shared__ __attribute__((aligned(16))) float dg_s[LG];
+  __shared__ __attribute__((aligned(16))) __bf16 dg_b[LG];
   __shared__ float part_s[4][LH];
   __shared__ float dh_s[LH];
   const int tid = threadIdx.x;
@@ -108,9 +146,19 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
   const bool rev = reverse_first ? true : (dir == 1);
   const int len = lens ? min(lens[b], T) : T;
   const int kcol = tid & (LH - 1), qd = tid >> 7;
-  float w[LH];
+  float w[BF16 ? 1 : LH];
+  lstm_bf16x2 wq[BF16 ? LH / 2 : 1];
 #pragma unroll
-  for (int rr = 0; rr < LH; ++rr) w[rr] = whh[((long long)dir * LG + qd * LH + rr) * LH + kcol];
+  for (int rr = 0; rr < LH; rr += 2) {
+    const float w0 = whh[((long long)dir * LG + qd * LH + rr) * LH + kcol];
+    const float w1 = whh[((long long)dir * LG + qd * LH + rr + 1) * LH + kcol];
+    if (BF16) {
+      wq[rr / 2] = (lstm_bf16x2){(__bf16)w0, (__bf16)w1};
+    } else {
+      w[rr] = w0;
+      w[rr + 1] = w1;
+    }
+  }
   const float* doutb = dout + (long long)b * T * ndir * LH + dir * LH;
   const float* gb = gates + (((long long)dir * B + b) * T) * LG;
   const float* cb = cst + (((long long)dir * B + b) * T) * LH;
@@ -136,10 +184,17 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
       const float pi = d_i * ig * (1.f - ig), pf = d_f * fg * (1.f - fg);
       const float pg = d_g * (1.f - gg * gg), po = d_o * og * (1.f - og);
       dc = dc * fg;
-      dg_s[tid] = pi;
-      dg_s[LH + tid] = pf;
-      dg_s[2 * LH + tid] = pg;
-      dg_s[3 * LH + tid] = po;
+      if (BF16) {
+        dg_b[tid] = (__bf16)pi;
+        dg_b[LH + tid] = (__bf16)pf;
+        dg_b[2 * LH + tid] = (__bf16)pg;
+        dg_b[3 * LH + tid] = (__bf16)po;
+      } else {
+        dg_s[tid] = pi;
+        dg_s[LH + tid] = pf;
+        dg_s[2 * LH + tid] = pg;
+        dg_s[3 * LH + tid] = po;
+      }
       float* dst = dgb + (long long)t * LG;
       dst[tid] = pi;
       dst[LH + tid] = pf;
@@ -149,14 +204,27 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
     __syncthreads();
     {
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      const float4* dp = reinterpret_cast<const float4*>(dg_s + qd * LH);
+      if (BF16) {
+        const uint4* dp = reinterpret_cast<const uint4*>(dg_b + qd * LH);
 #pragma unroll
-      for (int rr = 0; rr < LH / 4; ++rr) {
-        float4 d4 = dp[rr];
-        a0 = fmaf(w[4 * rr], d4.x, a0);
-        a1 = fmaf(w[4 * rr + 1], d4.y, a1);
-        a2 = fmaf(w[4 * rr + 2], d4.z, a2);
-        a3 = fmaf(w[4 * rr + 3], d4.w, a3);
+        for (int rr = 0; rr < LH / 8; ++rr) {
+          LstmPack4 d4;
+          d4.u = dp[rr];
+          a0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr], d4.p[0], a0, false);
+          a1 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 1], d4.p[1], a1, false);
+          a2 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 2], d4.p[2], a2, false);
+          a3 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 3], d4.p[3], a3, false);
+        }
+      } else {
+        const float4* dp = reinterpret_cast<const float4*>(dg_s + qd * LH);
+#pragma unroll
+        for (int rr = 0; rr < LH / 4; ++rr) {
+          float4 d4 = dp[rr];
+          a0 = fmaf(w[4 * rr], d4.x, a0);
+          a1 = fmaf(w[4 * rr + 1], d4.y, a1);
+          a2 = fmaf(w[4 * rr + 2], d4.z, a2);
+          a3 = fmaf(w[4 * rr + 3], d4.w, a3);
+        }
       }
       part_s[qd][kcol] = (a0 + a1) + (a2 + a3);
     }
@@ -171,24 +239,32 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
 
 extern "C" int kantts_lstm_fwd(const float* gx, const float* whh, const float* bhh, const int32_t* lens, float* out,
                                float* gates_save, float* c_save, int B, int T, int H, int ndir, int reverse_first,
-                               void* stream) {
+                               int precision, void* stream) {
   if (!gx || !whh || !out || !gates_save || !c_save || B < 0 || T < 0 || ndir < 1 || ndir > 2) return KANTTS_E_BADARG;
   if (H != LH) return KANTTS_E_UNSUPPORTED;
   if (B == 0 || T == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, gx, whh, bhh, lens, out,
-                     gates_save, c_save, B, T, ndir, reverse_first);
+  if (precision == 1)
+    hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, gx, whh, bhh, lens, out,
+                       gates_save, c_save, B, T, ndir, reverse_first);
+  else
+    hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, gx, whh, bhh, lens, out,
+                       gates_save, c_save, B, T, ndir, reverse_first);
   KANTTS_CHECK_LAUNCH();
 }
 
 extern "C" int kantts_lstm_bwd(const float* dout, const float* whh, const int32_t* lens, const float* gates_save,
                                const float* c_save, float* dgates, int B, int T, int H, int ndir, int reverse_first,
-                               void* stream) {
+                               int precision, void* stream) {
   if (!dout || !whh || !gates_save || !c_save || !dgates || B < 0 || T < 0 || ndir < 1 || ndir > 2)
     return KANTTS_E_BADARG;
   if (H != LH) return KANTTS_E_UNSUPPORTED;
   if (B == 0 || T == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, dout, whh, lens, gates_save,
-                     c_save, dgates, B, T, ndir, reverse_first);
+  if (precision == 1)
+    hipLaunchKernelGGL(lstm_bwd_kernel<true>, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, dout, whh, lens,
+                       gates_save, c_save, dgates, B, T, ndir, reverse_first);
+  else
+    hipLaunchKernelGGL(lstm_bwd_kernel<false>, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, dout, whh, lens,
+                       gates_save, c_save, dgates, B, T, ndir, reverse_first);
   KANTTS_CHECK_LAUNCH();
 }
 

@@ -49,13 +49,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // rows_per_block rows are walked by the block's 4 waves; dgamma/dbeta partials live in registers.
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+#define LN_BWD_WAVES 16
+__global__ __launch_bounds__(64 * LN_BWD_WAVES) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float* __restrict__ dx,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
                                                            int C, int rows_per_block) {
-  __shared__ float red[2][4][64 * LN_MAXPL / 4];  // [dg|db][wave][col chunk] -- only used when C <= 256*... see below
+  // 16 waves per block: a block still owns a contiguous slab of rows (one block per CU keeps the 2*C same-address
+  // atomics per block rare), but a wave now walks ~2 rows instead of ~7 -- the kernel is a chain of dependent
+  // row loads, so its duration follows rows-per-wave
+  __shared__ float red[2][LN_BWD_WAVES][64 * LN_MAXPL / 4];  // [dg|db][wave][col chunk]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * rows_per_block;
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     pb[e] = 0.f;
     gm[e] = (c < C) ? gamma[c] : 0.f;
   }
-  for (int r = wave; r < rows_per_block; r += 4) {
+  for (int r = wave; r < rows_per_block; r += LN_BWD_WAVES) {
     const int row = row0 + r;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
@@ -111,9 +115,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     __syncthreads();
     // thread t handles column chunk*256 + t;  note column = lane + e*64  <->  e4*64 + lane
     int c = chunk * 256 + threadIdx.x;
-    if (c < C) {
-      float a = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
-      float b = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+    if (threadIdx.x < 256 && c < C) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < LN_BWD_WAVES; ++w) {
+        a += red[0][w][threadIdx.x];
+        b += red[1][w][threadIdx.x];
+      }
       atomicAdd(&dgamma[c], a);
       atomicAdd(&dbeta[c], b);
     }
@@ -139,8 +147,8 @@ extern "C" int kantts_layernorm_bwd(const float* dy, const float* x, const float
   if (M == 0) return KANTTS_OK;
   // about one block per CU: every block ends with 2*C same-address atomics, so more blocks only add contention
   int rows_per_block = kantts_cdiv(M, 256);
-  if (rows_per_block < 4) rows_per_block = 4;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(kantts_cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, dy,
+  if (rows_per_block < LN_BWD_WAVES) rows_per_block = LN_BWD_WAVES;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(kantts_cdiv(M, rows_per_block)), dim3(64 * LN_BWD_WAVES), 0, (hipStream_t)stream, dy,
                      x, gamma, mean, rstd, dx, dgamma_accum, dbeta_accum, M, C, rows_per_block);
   KANTTS_CHECK_LAUNCH();
 }

@@ -110,10 +110,10 @@ def lib():
         L.kantts_attn_fwd.argtypes = [p, p, p, i, i, i, p, i, p, p, p, p, i, i, i, i, i, i, f, u64, p, p]
         L.kantts_attn_bwd.argtypes = [p, p, p, i, i, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p, p, i, i, i, i, i,
                                       i, f, u64, p, p]
-        L.kantts_lstm_fwd.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, p]
+        L.kantts_lstm_fwd.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_attn_decode.argtypes = [p, p, p, i, i, i, p, i, p, p, i, i, i, i, i, i, i, p]
         L.kantts_lstm_cell.argtypes = [p, p, p, p, i, i, p]
-        L.kantts_lstm_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, p]
+        L.kantts_lstm_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_embed_sum_fwd.argtypes = [POINTER(c_void_p), i, p, p, p, p, i, i, i, f, p]
         L.kantts_embed_sum_bwd.argtypes = [POINTER(c_void_p), i, p, p, i, i, f, p]
         L.kantts_lr_index.argtypes = [p, p, p, p, p, p, i, i, i, p]

@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import (PREC_REF, check, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
+from . import (PREC_REF, check, get_precision, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
 
 _seed_counter = itertools.count(1)
 
@@ -501,15 +501,16 @@ class _LSTM(torch.autograd.Function):
         out = torch.empty((B, T, ndir * H), device=dev, dtype=torch.float32)
         gates = torch.empty((ndir, B, T, G), device=dev, dtype=torch.float32)
         cst = torch.empty((ndir, B, T, H), device=dev, dtype=torch.float32)
+        prec = 1 if get_precision() == "bf16" else 0
         check(lib().kantts_lstm_fwd(ptr(gx), ptr(whh), ptr(bhh), ptr(lens), ptr(out), ptr(gates), ptr(cst), B, T, H,
-                                    ndir, 0, stream()), "lstm_fwd")
-        ctx.cfg = (nx, ndir, B, T, H)
+                                    ndir, 0, prec, stream()), "lstm_fwd")
+        ctx.cfg = (nx, ndir, B, T, H, prec)
         ctx.save_for_backward(lens, whh, out, gates, cst, *xs, *params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        nx, ndir, B, T, H = ctx.cfg
+        nx, ndir, B, T, H, prec = ctx.cfg
         G, M = 4 * H, B * T
         sv = ctx.saved_tensors
         lens, whh, out, gates, cst = sv[:5]
@@ -517,7 +518,7 @@ class _LSTM(torch.autograd.Function):
         dout = _c(dout)
         dg = torch.empty((ndir, B, T, G), device=dout.device, dtype=torch.float32)
         check(lib().kantts_lstm_bwd(ptr(dout, torch.float32), ptr(whh), ptr(lens), ptr(gates), ptr(cst), ptr(dg), B, T,
-                                    H, ndir, 0, stream()), "lstm_bwd")
+                                    H, ndir, 0, prec, stream()), "lstm_bwd")
         needs = ctx.needs_input_grad  # (nx, ndir, lens, *xs, *params)
         dxs = [None] * nx
         dparams = [None] * (4 * ndir)

@@ -299,7 +299,7 @@ class EmulatedLib:
         return 0
 
     # ------------------------------------------------------------------------------------ LSTM
-    def kantts_lstm_fwd(self, gx, whh, bhh, lens, out, gates_save, c_save, B, T, H, ndir, reverse_first, stream):
+    def kantts_lstm_fwd(self, gx, whh, bhh, lens, out, gates_save, c_save, B, T, H, ndir, reverse_first, precision, stream):
         G = 4 * H
         GX = torch.from_numpy(_arr(gx, B * T * ndir * G)).view(B, T, ndir, G)
         W = torch.from_numpy(_arr(whh, ndir * G * H)).view(ndir, G, H)
@@ -329,7 +329,7 @@ class EmulatedLib:
         _arr(c_save, ndir * B * T * H)[:] = CS.reshape(-1).numpy()
         return 0
 
-    def kantts_lstm_bwd(self, dout, whh, lens, gates_save, c_save, dgates, B, T, H, ndir, reverse_first, stream):
+    def kantts_lstm_bwd(self, dout, whh, lens, gates_save, c_save, dgates, B, T, H, ndir, reverse_first, precision, stream):
         G = 4 * H
         DO = torch.from_numpy(_arr(dout, B * T * ndir * H)).view(B, T, ndir, H)
         W = torch.from_numpy(_arr(whh, ndir * G * H)).view(ndir, G, H)

@@ -216,6 +216,29 @@ def test_lstm_uni_bi_and_concat():
         assert rel_l2(a, c) < 2e-4
 
 
+def test_lstm_bf16_recurrence_close_to_fp32():
+    """Throughput mode: the recurrent products run on packed bf16 pairs (v_dot2c_f32_bf16).  Outputs / gradients
+    must stay within bf16 rounding of the fp32 oracle (emulated ABI) -- a wrong pairing or gate order would be O(1)."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+
+    B, T, I, H = 3, 40, 32, 128
+    x = _rand(B, T, I, seed=1, grad=True)
+    p = [_rand(4 * H, I, seed=2, scale=0.1, grad=True), _rand(4 * H, H, seed=3, scale=0.1, grad=True),
+         _rand(4 * H, seed=4, scale=0.1, grad=True), _rand(4 * H, seed=5, scale=0.1, grad=True)]
+    p2 = p + [_rand(4 * H, I, seed=6, scale=0.1, grad=True), _rand(4 * H, H, seed=7, scale=0.1, grad=True),
+              _rand(4 * H, seed=8, scale=0.1, grad=True), _rand(4 * H, seed=9, scale=0.1, grad=True)]
+    lens = torch.tensor([40, 11, 29], dtype=torch.int32)
+    hip.set_precision("bf16")
+    try:
+        go, gg, co, cg = run_both(lambda x, l, *p: ops.lstm(x, list(p), l), x, lens, *p2)
+    finally:
+        hip.set_precision("fp32")
+    assert rel_l2(go[0], co[0]) < 2e-2
+    for a, c in zip(gg, cg):
+        assert rel_l2(a, c) < 5e-2
+
+
 # ------------------------------------------------------------------------------------------- sequence ops
 def test_embedding_and_length_regulator_bit_exact():
     from kantts._hip import ops
