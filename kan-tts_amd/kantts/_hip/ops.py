@@ -961,12 +961,18 @@ class _ConvTransposeCL(torch.autograd.Function):
         y = torch.empty((B, Tin * s, Cout), device=x.device, dtype=torch.float32)
         r_t = _c(res) if res is not None else None
         w2 = w.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).contiguous()  # (taps, s, Cout, Cin)
-        seg = make_seg(x, Cin, 1, w2, Cin, 1, Cin, ntaps=taps, b_tap=s * Cout * Cin, a_tok_axis=1, a_shift0=0,
-                       a_shift_step=-1, a_map=dict(Tq=Tin, Tsrc=Tin), a_leaky=in_leaky)
-        gemm([seg], B * Tin, s * Cout, y, s * Cout, 1, bias=bias.repeat(s) if bias is not None else None, res=r_t,
-             r_is=s * Cout, r_js=1)
+        brep = bias.repeat(s) if bias is not None else None
         ctx.cfg = (s, in_leaky, bias is not None, res is not None)
         ctx.save_for_backward(x, w)
+        # the polyphase form IS a stride-1 convolution with K/s taps onto s*Cout channels: the window kernel reads x
+        # once per 32-channel chunk (and runs 128x128 tiles on the wide early layers)
+        # (sequences shorter than a 64-row tile stay on the GEMM, whose rows run across batch items)
+        if Tin >= 64 and conv_win(x, w2, y, B=B, Tsrc=Tin, Tdst=Tin, groups=1, CR=Cin, NG=s * Cout, K=taps, in_mul=1, in_add=0,
+                    in_kstep=-1, in_div=1, phases=1, bias=brep, res=r_t, in_leaky=in_leaky):
+            return y
+        seg = make_seg(x, Cin, 1, w2, Cin, 1, Cin, ntaps=taps, b_tap=s * Cout * Cin, a_tok_axis=1, a_shift0=0,
+                       a_shift_step=-1, a_map=dict(Tq=Tin, Tsrc=Tin), a_leaky=in_leaky)
+        gemm([seg], B * Tin, s * Cout, y, s * Cout, 1, bias=brep, res=r_t, r_is=s * Cout, r_js=1)
         return y
 
     @staticmethod
@@ -983,16 +989,24 @@ class _ConvTransposeCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             w3 = w.view(Cin, Cout, taps, s).permute(2, 0, 3, 1).contiguous()  # (taps, Cin, s, Cout)
-            seg = make_seg(dy, N2, 1, w3, N2, 1, N2, ntaps=taps, b_tap=Cin * N2, a_tok_axis=1, a_shift0=0,
-                           a_shift_step=1, a_map=dict(Tq=Tin, Tsrc=Tin))
-            gemm([seg], M, Cin, dx, Cin, 1, gate=x if in_leaky is not None else None, gate_slope=in_leaky or 0.0)
+            if Tin < 64 or not conv_win(dy, w3, dx, B=B, Tsrc=Tin, Tdst=Tin, groups=1, CR=N2, NG=Cin, K=taps, in_mul=1, in_add=0,
+                            in_kstep=1, in_div=1, phases=1, out_gate=x if in_leaky is not None else None,
+                            out_gate_slope=in_leaky or 0.0):
+                seg = make_seg(dy, N2, 1, w3, N2, 1, N2, ntaps=taps, b_tap=Cin * N2, a_tok_axis=1, a_shift0=0,
+                               a_shift_step=1, a_map=dict(Tq=Tin, Tsrc=Tin))
+                gemm([seg], M, Cin, dx, Cin, 1, gate=x if in_leaky is not None else None, gate_slope=in_leaky or 0.0)
         if ctx.needs_input_grad[1]:
             dw2 = gzeros((taps, N2, Cin), dy.device)
             db2 = gzeros((N2,), dy.device) if (has_bias and ctx.needs_input_grad[2]) else None
-            seg = make_seg(dy, 1, N2, x, 1, Cin, M, ntaps=taps, b_tok_axis=2, b_shift0=0, b_shift_step=-1,
-                           b_map=dict(Tq=Tin, Tsrc=Tin), b_leaky=in_leaky)
-            gemm([seg], N2, Cin, dw2, Cin, 1, accumulate=True, splitk=_splitk_for(N2 * taps, Cin, M), z_taps=taps,
-                 c_tap=N2 * Cin, a_rowsum=db2)
+            # tap j reads x[q - j]: with k' = taps-1-j this is x[q + k' - (taps-1)], a stride-1 weight gradient
+            if conv_wgrad(x, dy.view(B, Tin, N2), dw2, db2, B=B, Tsrc=Tin, Tdst=Tin, groups=1, CR=Cin, NG=N2, K=taps,
+                          stride=1, dil=1, pad=taps - 1, x_leaky=in_leaky):
+                dw2 = dw2.flip(0)
+            else:
+                seg = make_seg(dy, 1, N2, x, 1, Cin, M, ntaps=taps, b_tok_axis=2, b_shift0=0, b_shift_step=-1,
+                               b_map=dict(Tq=Tin, Tsrc=Tin), b_leaky=in_leaky)
+                gemm([seg], N2, Cin, dw2, Cin, 1, accumulate=True, splitk=_splitk_for(N2 * taps, Cin, M), z_taps=taps,
+                     c_tap=N2 * Cin, a_rowsum=db2)
             dw = dw2.view(taps, s, Cout, Cin).permute(3, 2, 0, 1).reshape(Cin, Cout, K)
             if db2 is not None:
                 db = db2.view(s, Cout).sum(0)
