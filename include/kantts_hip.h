@@ -243,6 +243,17 @@ int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int hop, int f
                        const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels,
                        float eps_mel, float* out_mel, float* out_mag, void* stream);
 
+/* The same pipeline with the dB normalisation as parameters: S = 20 log10(max(mel, 1e-5)) - ref_level_db;
+ * symmetric: clip(2*max_norm*(S - min_level_db)/(-min_level_db) - max_norm, +-max_norm); else clip(max_norm*(S - min_level_db)
+ * /(-min_level_db), 0, max_norm).  Serves the offline feature extractor melspectrogram()
+ * (kantts/preprocess/audio_processor/core/dsp.py:165-201: eps_power = 0, eps_mel = 1e-5, ref 20, min -100, max_norm 1,
+ * asymmetric); kantts_melspec_fwd is this function at (20, -100, 4, symmetric). */
+int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                            const float* window, const float* twiddle, float eps_power, const int32_t* mel_start,
+                            const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels,
+                            float eps_mel, float ref_level_db, float min_level_db, float max_norm, int symmetric,
+                            float* out_mel, float* out_mag, void* stream);
+
 /* Backward of the mel path of kantts_melspec_fwd (MelSpectrogramLoss on generated audio, kantts/train/loss.py:
  * 259-311): dwav_accum (B,T) += d loss / d wav given dmel (B, n_mels, frames).  The spectrum is recomputed. */
 int kantts_melspec_bwd(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames,

@@ -31,7 +31,18 @@ struct MelArgs {
   float eps_mel;
   float* out_mel;  // (B, n_mels, frames) normalised, or NULL
   float* out_mag;  // (B, frames, n_fft/2+1), or NULL
+  // dB normalisation: S = 20 log10(max(mel, 1e-5)) - ref_db;  symmetric: clip(2*max_norm*(S-min_db)/(-min_db) - max_norm,
+  // +-max_norm) (spectral_normalize_torch);  else clip(max_norm*(S-min_db)/(-min_db), 0, max_norm) (dsp._normalize)
+  float ref_db, min_db, max_norm;
+  int symmetric;
 };
+
+__device__ __forceinline__ float mel_normalise(const MelArgs& a, float mel) {
+  const float db = 20.f * log10f(fmaxf(mel, 1e-5f)) - a.ref_db;
+  const float u = (db - a.min_db) / (-a.min_db);
+  if (a.symmetric) return fminf(fmaxf(2.f * a.max_norm * u - a.max_norm, -a.max_norm), a.max_norm);
+  return fminf(fmaxf(a.max_norm * u, 0.f), a.max_norm);
+}
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
@@ -121,9 +132,7 @@ __global__ __launch_bounds__(MEL_THREADS) void melspec_kernel(const MelArgs a) {
       float acc = 0.f;
       for (int i = 0; i < ln; ++i) acc = fmaf(amp[st + i], w[i], acc);
       acc = fmaxf(acc, a.eps_mel);
-      const float db = 20.f * log10f(fmaxf(acc, 1e-5f)) - 20.f;
-      float nv = 8.f * ((db + 100.f) / 100.f) - 4.f;
-      melv[q] = fminf(fmaxf(nv, -4.f), 4.f);
+      melv[q] = mel_normalise(a, acc);
     }
     __syncthreads();  // amp / buffers are reused by the next frame
   }
@@ -135,11 +144,30 @@ __global__ __launch_bounds__(MEL_THREADS) void melspec_kernel(const MelArgs a) {
   }
 }
 
+extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                                       const float* window, const float* twiddle, float eps_power,
+                                       const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                                       const float* mel_w, int n_mels, float eps_mel, float ref_level_db,
+                                       float min_level_db, float max_norm, int symmetric, float* out_mel, float* out_mag,
+                                       void* stream);
+
 extern "C" int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
                                   const float* window, const float* twiddle, float eps_power,
                                   const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
                                   const float* mel_w, int n_mels, float eps_mel, float* out_mel, float* out_mag,
                                   void* stream) {
+  // MelSpectrogram.forward's fixed normalisation: ref 20 dB, floor -100 dB, symmetric +-4
+  return kantts_melspec_norm_fwd(wav, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start, mel_len,
+                                 mel_off, mel_w, n_mels, eps_mel, 20.f, -100.f, 4.f, 1, out_mel, out_mag, stream);
+}
+
+extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                                       const float* window, const float* twiddle, float eps_power,
+                                       const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                                       const float* mel_w, int n_mels, float eps_mel, float ref_level_db,
+                                       float min_level_db, float max_norm, int symmetric, float* out_mel, float* out_mag,
+                                       void* stream) {
+  if (!(min_level_db < 0.f) || !(max_norm > 0.f)) return KANTTS_E_BADARG;
   if (!wav || !window || !twiddle || B < 0 || T < 1 || n_fft < 8 || hop < 1 || frames < 0) return KANTTS_E_BADARG;
   if (n_fft & (n_fft - 1)) return KANTTS_E_UNSUPPORTED;
   if (!out_mel && !out_mag) return KANTTS_E_BADARG;
@@ -152,6 +180,7 @@ extern "C" int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int
   a.window = window; a.tw = reinterpret_cast<const float2*>(twiddle); a.eps_power = eps_power;
   a.mel_start = mel_start; a.mel_len = mel_len; a.mel_off = mel_off; a.mel_w = mel_w; a.n_mels = n_mels;
   a.eps_mel = eps_mel; a.out_mel = out_mel; a.out_mag = out_mag;
+  a.ref_db = ref_level_db; a.min_db = min_level_db; a.max_norm = max_norm; a.symmetric = symmetric;
   int m = n_fft >> 1, l2 = 0;
   while ((1 << l2) < m) ++l2;
   a.log2m = l2;
@@ -321,6 +350,7 @@ extern "C" int kantts_melspec_bwd(const float* wav, const float* dmel, int B, in
   a.window = window; a.tw = reinterpret_cast<const float2*>(twiddle); a.eps_power = eps_power;
   a.mel_start = mel_start; a.mel_len = mel_len; a.mel_off = mel_off; a.mel_w = mel_w; a.n_mels = n_mels;
   a.eps_mel = eps_mel;
+  a.ref_db = 20.f; a.min_db = -100.f; a.max_norm = 4.f; a.symmetric = 1;
   ba.dmel = dmel; ba.dwav = dwav_accum;
   int m = n_fft >> 1, l2 = 0;
   while ((1 << l2) < m) ++l2;

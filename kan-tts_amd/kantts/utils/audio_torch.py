@@ -100,9 +100,10 @@ class _MelSpecFn(torch.autograd.Function):
         return dwav, None, None, None, None, None
 
 
-def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, eps_mel=0.0, want_mag=False):
+def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, eps_mel=0.0, want_mag=False, norm=None):
+    """norm: optional (ref_level_db, min_level_db, max_norm, symmetric) for the dB normalisation (forward only)."""
     if x.requires_grad:
-        if want_mag or mel is None:
+        if want_mag or mel is None or norm is not None:
             raise NotImplementedError("STFT-magnitude backward (STFTLoss) is SURVEY row 8f-4 (next)")
         return _MelSpecFn.apply(x, (n_fft, hop, win_length, window, pad_mode, eps_power, eps_mel), *mel), None
     x = x.contiguous().float()
@@ -118,6 +119,13 @@ def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, ep
         out_mel = torch.empty((B, n_mels, frames), device=x.device, dtype=torch.float32)
     if want_mag:
         out_mag = torch.empty((B, frames, n_fft // 2 + 1), device=x.device, dtype=torch.float32)
+    if norm is not None:
+        ref_db, min_db, max_norm, symmetric = norm
+        check(lib().kantts_melspec_norm_fwd(ptr(x, torch.float32), B, T, n_fft, hop, frames, pad_mode, ptr(wpad), ptr(tw),
+                                            float(eps_power), ptr(ms), ptr(ml), ptr(mo), ptr(mw), n_mels, float(eps_mel),
+                                            float(ref_db), float(min_db), float(max_norm), int(bool(symmetric)),
+                                            ptr(out_mel), ptr(out_mag), stream()), "melspec_norm_fwd")
+        return out_mel, out_mag
     check(lib().kantts_melspec_fwd(ptr(x, torch.float32), B, T, n_fft, hop, frames, pad_mode, ptr(wpad), ptr(tw),
                                    float(eps_power), ptr(ms), ptr(ml), ptr(mo), ptr(mw), n_mels, float(eps_mel),
                                    ptr(out_mel), ptr(out_mag), stream()), "melspec_fwd")

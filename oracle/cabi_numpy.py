@@ -529,7 +529,15 @@ class EmulatedLib:
     # ------------------------------------------------------------------------------------ mel-STFT
     def kantts_melspec_fwd(self, wav, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
                            mel_len, mel_off, mel_w, n_mels, eps_mel, out_mel, out_mag, stream):
+        return self.kantts_melspec_norm_fwd(wav, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
+                                            mel_len, mel_off, mel_w, n_mels, eps_mel, 20.0, -100.0, 4.0, 1, out_mel,
+                                            out_mag, stream)
+
+    def kantts_melspec_norm_fwd(self, wav, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
+                                mel_len, mel_off, mel_w, n_mels, eps_mel, ref_db, min_db, max_norm, symmetric, out_mel,
+                                out_mag, stream):
         eps_power, eps_mel = _val(eps_power), _val(eps_mel)
+        ref_db, min_db, max_norm = _val(ref_db), _val(min_db), _val(max_norm)
         X = torch.from_numpy(_arr(wav, B * T)).view(B, T)
         W = torch.from_numpy(_arr(window, n_fft))
         xp = torch.nn.functional.pad(X[:, None, :], (n_fft // 2, n_fft // 2),
@@ -548,8 +556,11 @@ class EmulatedLib:
             for m in range(n_mels):
                 Mm[st[m]:st[m] + ln[m], m] = torch.from_numpy(w[of[m]:of[m] + ln[m]].copy())
             mel = torch.clamp(amp @ Mm, min=eps_mel)
-            db = 20 * torch.log10(torch.clamp(mel, min=1e-5)) - 20.0
-            out = torch.clamp(8.0 * ((db + 100.0) / 100.0) - 4.0, -4.0, 4.0).transpose(1, 2).contiguous()
+            db = 20 * torch.log10(torch.clamp(mel, min=1e-5)) - ref_db
+            u = (db - min_db) / (-min_db)
+            out = torch.clamp(2 * max_norm * u - max_norm, -max_norm, max_norm) if symmetric else \
+                torch.clamp(max_norm * u, 0.0, max_norm)
+            out = out.transpose(1, 2).contiguous()
             _arr(out_mel, B * n_mels * frames)[:] = out.reshape(-1).numpy()
         return 0
 

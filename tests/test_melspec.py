@@ -91,3 +91,36 @@ def test_melspec_backward_emulated():
 @pytest.mark.gpu
 def test_melspec_backward_gpu():
     _check_backward("cuda")
+
+
+def _dsp_case(device):
+    """Offline extractor dsp.melspectrogram against the float64 numpy restatement."""
+    import numpy as np
+
+    import audio_oracle as A
+    from kantts.preprocess.audio_processor.core import dsp
+
+    g = np.random.default_rng(3)
+    y = (g.standard_normal(5000) * 0.1).astype(np.float32)
+    for kw in (dict(sample_rate=16000, n_fft=1024, hop_length=200, win_length=1000, fmin=0, fmax=8000),
+               dict(sample_rate=16000, n_fft=2048, hop_length=200, win_length=1000, fmin=0, fmax=8000, max_norm=1.0),
+               dict(sample_rate=22050, symmetric=True, max_norm=4.0, preemphasize=True)):
+        ref = A.dsp_melspectrogram(y, **kw)
+        wav = torch.from_numpy(y).to(device)[None, :]
+        args = dict(kw)
+        sr = args.pop("sample_rate")
+        got = dsp.melspectrogram_batch(wav, sr, **args)[0].cpu().numpy()
+        assert got.shape == ref.shape == (1 + len(y) // kw.get("hop_length", 256), 80)
+        assert np.abs(got - ref).max() < 2e-4 * kw.get("max_norm", 1.0) + 1e-5, kw
+
+
+def test_dsp_melspectrogram_emulated():
+    from util import emulation
+
+    with emulation():
+        _dsp_case("cpu")
+
+
+@pytest.mark.gpu
+def test_dsp_melspectrogram_gpu():
+    _dsp_case("cuda")
