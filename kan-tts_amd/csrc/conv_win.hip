@@ -31,7 +31,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define CW_THREADS 256
 #define CW_CK 32        // channels per chunk = one bf16 MFMA k-step
 #define CW_MAXTAPS 64
-#define CW_HDR (2 * CW_MAXTAPS * 4 + 16)  // tap table ahead of the tiles (multiple of 16 bytes)
+#define CW_HDR (3 * CW_MAXTAPS * 4 + 16)  // tap table ahead of the tiles (multiple of 16 bytes)
 
 __device__ __forceinline__ int cw_floordiv(int a, int b) {
   int q = a / b;
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
   extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
   int* s_off = reinterpret_cast<int*>(cw_lds_raw);
   int* s_tap = s_off + CW_MAXTAPS;
-  int* s_nv_p = s_tap + CW_MAXTAPS;
+  int* s_row = s_tap + CW_MAXTAPS;  // window row (before the fold multiplier) the tap starts at
+  int* s_nv_p = s_row + CW_MAXTAPS;
   unsigned char* cw_lds = cw_lds_raw + CW_HDR;
 
   const int tid = threadIdx.x;
@@ -136,6 +137,24 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
 
   void* win = cw_lds;
   unsigned char* bt = cw_lds + (size_t)Wp * dm * inner * LDW * ESZ;
+  // per-tap window row, computed ONCE: the tap loop used to redo two integer divisions per tap and lane (the PMC run
+  // of round 1 showed ~15 VALU + 14 SALU instructions per MFMA -- the kernels were issue-bound on index arithmetic)
+  if (tid < nv) {
+    const int a = s_off[tid] - offmin;
+    s_row[tid] = (a % dm) * Wp + a / dm;
+  }
+  __syncthreads();
+  // tap-invariant part of every fragment's window row: (m - m_lo) * inner + p'
+  int fbase[MREP], fm[MREP];
+#pragma unroll
+  for (int f = 0; f < MREP; ++f) {
+    // rows past the end of the sequence set are clamped (computed, never stored)
+    const int mp = min(m0 + wm * (MREP * 16) + f * 16 + (lane & 15), R - 1);
+    const int m = (inner > 1) ? mp / inner : mp;
+    const int pin = (inner > 1) ? mp - m * inner : 0;
+    fm[f] = m;
+    fbase[f] = (m - m_lo) * inner + pin;
+  }
 
   f32x4 acc[MREP][4];
 #pragma unroll
@@ -193,8 +212,9 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
       for (int u = 0; u < 4; ++u) {
         const int rr = r0 + 32 * u;
         if (rr >= WR) continue;
-        const int rel = (inner > 1) ? rr / inner : rr;
-        const int pin = (inner > 1) ? rr - rel * inner : 0;
+        // window row: stride-1 windows (dm == 1, most layers) store global row rr at LDS row rr -- no division
+        const int rel = (inner > 1 && dm > 1) ? rr / inner : rr;
+        const int pin = (inner > 1 && dm > 1) ? rr - rel * inner : 0;
         float v0 = xv[u].x, v1 = xv[u].y, v2 = xv[u].z, v3 = xv[u].w;
         if (!ok[u]) v0 = v1 = v2 = v3 = 0.f;
         if (g.in_act) {
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
           v2 *= (gv[u].z > 0.f) ? 1.f : g.in_gate_slope;
           v3 *= (gv[u].w > 0.f) ? 1.f : g.in_gate_slope;
         }
-        const int row = ((rel % dm) * Wp + rel / dm) * inner + pin;
+        const int row = (dm == 1) ? rr : ((rel % dm) * Wp + rel / dm) * inner + pin;
         cw_store4<BF16>(win, row * LDW + c4, v0, v1, v2, v3);
       }
     }
@@ -218,16 +238,15 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
 
     for (int ti = 0; ti < nv; ++ti) {
       if (ti + 1 < nv) fetch_w(ti + 1, c0);
-      const int a = s_off[ti] - offmin;
       int arow[MREP];
+      if (up > 1) {
+        const int off = __builtin_amdgcn_readfirstlane(s_off[ti]);
 #pragma unroll
-      for (int f = 0; f < MREP; ++f) {
-        // rows past the end of the sequence set are clamped (computed, never stored)
-        const int mp = min(m0 + wm * (MREP * 16) + f * 16 + (lane & 15), R - 1);
-        const int m = (inner > 1) ? mp / inner : mp;
-        const int pin = (inner > 1) ? mp - m * inner : 0;
-        arow[f] = (up > 1) ? cw_floordiv(m * g.in_mul + s_off[ti], up) - lo
-                           : ((a % dm) * Wp + a / dm + (m - m_lo)) * inner + pin;
+        for (int f = 0; f < MREP; ++f) arow[f] = cw_floordiv(fm[f] * g.in_mul + off, up) - lo;
+      } else {
+        const int trow = __builtin_amdgcn_readfirstlane(s_row[ti]) * inner;
+#pragma unroll
+        for (int f = 0; f < MREP; ++f) arow[f] = trow + fbase[f];
       }
       const unsigned char* bcur = bt + (size_t)(ti & 1) * BN * LDW * ESZ;
       if (BF16) {
