@@ -109,7 +109,7 @@ def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for _ in range(reps):
                 fn()
         g.replay()

@@ -39,16 +39,17 @@ class GraphedSambertStep:
         self.graph_b = None
         optimizer.zero_grad(set_to_none=True)
         if not self.distributed:
-            with torch.cuda.graph(self.graph_a):
+            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
                 self._forward_backward()
                 self._apply()
         else:
-            with torch.cuda.graph(self.graph_a):
+            # thread_local: the RCCL watchdog thread polls events while this thread captures
+            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
                 self._forward_backward()
                 ops.wgrad_overlap.join()
                 optimizer.arena.pack_grads()
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
                 self._apply(packed=True)
 
     def _forward_backward(self):
