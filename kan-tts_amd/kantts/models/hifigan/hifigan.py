@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.nn.utils import weight_norm
+from torch.nn.utils import spectral_norm, weight_norm
 
 from kantts._hip import ops
 from kantts.models.hifigan.layers import (CausalConv1d, CausalConvTranspose1d, Conv1d, ConvTranspose1d,
@@ -108,6 +108,11 @@ class Generator(torch.nn.Module):
         self.conv_post.remove_weight_norm()
 
 
+def _norm_f(use_spectral_norm):
+    """weight_norm, or torch's spectral_norm for the ``follow_official_norm`` discriminators (reference :217,321)."""
+    return spectral_norm if use_spectral_norm else weight_norm
+
+
 class PeriodDiscriminator(torch.nn.Module):
     """(k,1)-Conv2d stack over the period-folded waveform (reference :200-267).  In channels-last the
     fold is a pure view: (B, T) -> (B, T/p, p, 1); each conv strides along T/p with p independent columns."""
@@ -117,8 +122,7 @@ class PeriodDiscriminator(torch.nn.Module):
                  nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
                  use_spectral_norm=False):
         super(PeriodDiscriminator, self).__init__()
-        if use_spectral_norm:
-            raise NotImplementedError("spectral_norm discriminators (follow_official_norm) are not wired yet")
+        weight_norm = _norm_f(use_spectral_norm)
         self.period = period
         self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
         self.convs = nn.ModuleList()
@@ -185,8 +189,7 @@ class ScaleDiscriminator(torch.nn.Module):
                  nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
                  use_spectral_norm=False):
         super(ScaleDiscriminator, self).__init__()
-        if use_spectral_norm:
-            raise NotImplementedError("spectral_norm discriminators (follow_official_norm) are not wired yet")
+        weight_norm = _norm_f(use_spectral_norm)
         assert len(kernel_sizes) == 4
         for ks in kernel_sizes:
             assert ks % 2 == 1

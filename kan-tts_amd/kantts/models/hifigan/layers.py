@@ -37,6 +37,13 @@ def conv_weight(m):
         if v.shape[1] % 4 == 0:
             return ops.weight_norm_tap(v, m.weight_g), True
         return ops.weight_norm(v, m.weight_g), False
+    if hasattr(m, "weight_orig"):
+        # torch.nn.utils.spectral_norm (follow_official_norm discriminators, reference hifigan.py:217,321): the
+        # weight / sigma reparametrisation lives in a forward pre-hook of the holder module, which is never called
+        # here -- run the hook (one power iteration in training mode, on the small weight matrix) ourselves
+        for hook in m._forward_pre_hooks.values():
+            if type(hook).__name__ == "SpectralNorm":
+                hook(m, None)
     w = m.weight
     return (w.squeeze(-1) if w.dim() == 4 else w), False
 
@@ -86,8 +93,20 @@ class ConvTranspose1d(torch.nn.Module):
                                                      output_padding=0))
         self.deconv.apply(init_weights)
 
+        if kernel_size % stride != 0 or (kernel_size - stride) % 2 != 0 or padding != (kernel_size - stride) // 2:
+            raise NotImplementedError("only kernel = m*stride with padding (kernel - stride) / 2 (every shipped yaml)")
+        self.stride, self.padding = stride, padding
+
     def forward_cl(self, x, in_leaky=None, res=None):
-        raise NotImplementedError("non-causal transposed convolution (hifigan_noncausal_*.yaml) is not wired yet")
+        """Full transposed convolution = the polyphase form over one extra (zero) input token; the symmetric
+        padding of the reference (:94-121) drops ``padding`` samples at both ends of it."""
+        B, T, _ = x.shape
+        s, pad = self.stride, self.padding
+        taps = self.deconv.kernel_size[0] // s
+        xz = torch.nn.functional.pad(x, (0, 0, 0, taps - 1))
+        full = ops.conv_transpose_cl(xz, effective_weight(self.deconv), self.deconv.bias, s, in_leaky=in_leaky)
+        y = full[:, pad:pad + T * s, :]
+        return y if res is None else y + res
 
     def forward(self, x):
         return self.forward_cl(x.transpose(1, 2).contiguous()).transpose(1, 2)

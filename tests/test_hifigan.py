@@ -306,3 +306,56 @@ def test_gan_train_step_runs_and_updates():
         out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
     assert all(torch.isfinite(torch.as_tensor(float(v))) for v in out.values())
     assert float((optimizer["generator"].arena.flat - w0).abs().max()) > 0
+
+
+def _noncausal_and_spectral(device):
+    """causal=False generator (symmetric conv padding, ConvTranspose1d with padding (k-s)/2) vs the oracle, and the
+    follow_official_norm discriminators (torch spectral_norm holders) vs the oracle fed with weight / sigma."""
+    from kantts.models.hifigan.hifigan import Generator, MultiScaleDiscriminator
+
+    torch.manual_seed(3)
+    G = Generator(channels=32, causal=False)
+    PG = {k: v.detach().clone().requires_grad_(True) for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 80, 5, generator=g)
+    G = G.to(device)
+    yo = G(x.to(device))
+    yr = H.generator(PG, x, causal=False)
+    assert yo.shape == yr.shape == (2, 1, 5 * 256)
+    assert_close(yo.detach().cpu(), yr.detach(), 2e-5, what="non-causal generator")
+    cot = torch.randn(yr.shape, generator=g)
+    (yo * cot.to(device)).sum().backward()
+    (yr * cot).sum().backward()
+    assert_grads_close([(n, p.grad, PG[n].grad) for n, p in G.named_parameters()], 2e-3, "non-causal G")
+    # spectral norm: eval mode (no power iteration) -> weight = weight_orig / (u^T W v)
+    D = MultiScaleDiscriminator(follow_official_norm=True).eval()
+    sd = D.state_dict()
+    assert "discriminators.0.convs.0.0.weight_orig" in sd and "discriminators.1.convs.0.0.weight_g" in sd
+    P = {}
+    for k, v in sd.items():
+        if k.endswith("weight_orig"):
+            pre = k[: -len("weight_orig")]
+            W = v.flatten(1)
+            sigma = torch.dot(sd[pre + "weight_u"], W @ sd[pre + "weight_v"])
+            P[pre + "weight"] = v / sigma
+        elif not (k.endswith("weight_u") or (k.endswith("weight_v") and k[: -len("weight_v")] + "weight_orig" in sd)):
+            P[k] = v
+    y = torch.randn(2, 1, 1024, generator=g).clamp(-1, 1)
+    with torch.no_grad():
+        o, fm = D.to(device)(y.to(device))
+        o_r, f_r = H.msd(P, y)
+    for a, b in zip(o, o_r):
+        assert rel_l2(a.cpu(), b) < 1e-4, "spectral-norm MSD output"  # (1/sigma makes the untrained outputs huge)
+
+
+def test_noncausal_generator_and_spectral_norm_emulated():
+    with emulation():
+        _noncausal_and_spectral("cpu")
+
+
+@pytest.mark.gpu
+def test_noncausal_generator_and_spectral_norm_gpu():
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _noncausal_and_spectral("cuda")
