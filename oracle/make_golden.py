@@ -89,6 +89,46 @@ def sambert_infer_case(name, B, T_in, min_len, seed_w=0, seed_b=77, dur_bias=1.5
           os.path.getsize(os.path.join(OUT, name + ".pt")))
 
 
+def collate_case():
+    """Reference batch assembly (AM_Dataset.collate_fn with its Padder, Voc_Dataset.collate_fn) on random items."""
+    import numpy as np
+    import kantts.datasets.dataset as D
+
+    rs = np.random.RandomState(11)
+    pad_ids = [146, 9, 7, 7, 35, 3]
+    items = []
+    for n_sym, frames in ((7, 31), (12, 44), (3, 9), (9, 45)):
+        ling = [rs.randint(0, pad_ids[k], size=n_sym + 1).astype(np.int64) for k in range(6)]  # incl. the "~" slot
+        dur = rs.randint(1, 8, size=n_sym).astype(np.int64)
+        dur[-1] += frames - dur.sum() if frames > dur.sum() else 0
+        frames = int(dur.sum())
+        items.append((ling, rs.randn(frames, 80).astype(np.float32), dur, rs.randn(n_sym + 1).astype(np.float32),
+                      rs.randn(n_sym + 1).astype(np.float32), None, None, None))
+
+    class _LU:
+        _lfeat_type_list = ["sy", "tone", "syllable_flag", "word_segment", "emo_category", "speaker_category"]
+        _sub_unit_pad = dict(zip(_lfeat_type_list, pad_ids))
+
+        def using_byte(self):
+            return False
+
+    class _Self:
+        ling_unit, padder, with_duration, se_enable, fp_enable, r = _LU(), D.Padder(), True, False, False, 3
+
+    am = D.AM_Dataset.collate_fn(_Self(), items)
+
+    class _V:
+        hop_length, batch_max_steps, batch_max_frames, aux_context_window = 200, 1600, 8, 0
+        start_offset, end_offset = 0, -8
+
+    vitems = [(rs.randn(f * 200).astype(np.float32), rs.randn(f, 80).astype(np.float32)) for f in (20, 9, 33)]
+    np.random.seed(5)
+    wav_b, mel_b = D.Voc_Dataset.collate_fn(_V(), vitems)
+    torch.save(dict(items=items, pad_ids=pad_ids, r=3, am={k: v for k, v in am.items()}, vitems=vitems, voc_seed=5,
+                    voc=(wav_b, mel_b)), os.path.join(OUT, "collate.pt"))
+    print("collate bytes", os.path.getsize(os.path.join(OUT, "collate.pt")))
+
+
 def melspec_case():
     g = torch.Generator().manual_seed(7)
     x = torch.randn(4, 2048, generator=g) * 0.1
@@ -108,3 +148,4 @@ if __name__ == "__main__":
     # the reference's free-running path only works at batch 1 (its band masks are built without a batch axis)
     sambert_infer_case("sambert_tiny_infer", B=1, T_in=12, min_len=6)
     melspec_case()
+    collate_case()
