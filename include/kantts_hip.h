@@ -372,6 +372,24 @@ int kantts_attn_decode(const float* q, const float* k, const float* v, int ldq, 
                        int bw, void* stream);
 int kantts_lstm_cell(const float* gates, const float* c_prev, float* h_out, float* c_out, int B, int H, void* stream);
 
+/* Monotonic alignment search, width 1 (csrc/mas.hip): replaces the host round trip of binarize_attention_parallel
+ * (kantts/models/sambert/kantts_sambert.py:752-764 -> numba b_mas, alignment.py:32-71).  attn / opt are (B, To_max, Ti_max)
+ * (the reference's (B, 1, mel, text) with the singleton squeezed); opt receives the 0/1 hard alignment of the valid
+ * (out_lens[b] x in_lens[b]) corner and zeros elsewhere; workspace: B*To_max*Ti_max bytes of back-pointers. */
+int kantts_mas_width1(const float* attn, const int32_t* in_lens, const int32_t* out_lens, float* opt, uint8_t* workspace,
+                      int B, int To_max, int Ti_max, void* stream);
+
+/* Alignment attention of the MAS path (csrc/mas.hip): the part of ConvAttention.forward after the projections
+ * (kantts/models/sambert/attention.py:103-125).  q (B,T1,C) mel-side / k (B,T2,C) text-side encodings, channels last;
+ * prior (B,T1,T2) or NULL; in_lens[b] = unpadded text length (positions >= it are masked out of `soft`).
+ * logprob = attn_logprob, soft = attn of the reference, both (B,T1,T2) (= (B,1,T1,T2)).  T2 <= 1024.
+ * bwd: d_logprob / d_soft may be NULL; g_ws: B*T1*T2 floats of workspace; dq / dk are overwritten. */
+int kantts_align_attn_fwd(const float* q, const float* k, const float* prior, const int32_t* in_lens, float* logprob,
+                          float* soft, int B, int T1, int T2, int C, void* stream);
+int kantts_align_attn_bwd(const float* q, const float* k, const float* prior, const float* logprob, const float* soft,
+                          const float* d_logprob, const float* d_soft, float* g_ws, float* dq, float* dk, int B, int T1,
+                          int T2, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

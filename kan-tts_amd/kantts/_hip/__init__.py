@@ -113,6 +113,9 @@ def lib():
         L.kantts_lstm_fwd.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_attn_decode.argtypes = [p, p, p, i, i, i, p, i, p, p, i, i, i, i, i, i, i, p]
         L.kantts_lstm_cell.argtypes = [p, p, p, p, i, i, p]
+        L.kantts_mas_width1.argtypes = [p, p, p, p, p, i, i, i, p]
+        L.kantts_align_attn_fwd.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
+        L.kantts_align_attn_bwd.argtypes = [p, p, p, p, p, p, p, p, p, p, i, i, i, i, p]
         L.kantts_lstm_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_embed_sum_fwd.argtypes = [POINTER(c_void_p), i, p, p, p, p, i, i, i, f, p]
         L.kantts_embed_sum_bwd.argtypes = [POINTER(c_void_p), i, p, p, i, i, f, p]
@@ -150,7 +153,7 @@ EXPORTED_SYMBOLS = [
     "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_fsmn_dwconv_bwd_ws", "kantts_masked_l1",
     "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_norm_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd", "kantts_weight_norm_strided_fwd", "kantts_weight_norm_strided_bwd",
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
-    "kantts_lstm_cell",
+    "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
 ]
 
 

@@ -583,14 +583,16 @@ class _EmbedSum(torch.autograd.Function):
                                          float(scale), stream()), "embed_sum_fwd")
         ctx.save_for_backward(ids)
         ctx.cfg = (scale, [tuple(t.shape) for t in tables])
-        if want_scaled:
+        if want_scaled and want_scaled != "grad":
             ctx.mark_non_differentiable(scaled)
         return out, scaled
 
     @staticmethod
-    def backward(ctx, dout, _ds):
+    def backward(ctx, dout, d_scaled):
         (ids,) = ctx.saved_tensors
         scale, shapes = ctx.cfg
+        if d_scaled is not None:  # out = scaled + pos: both outputs feed the tables with the same factor
+            dout = d_scaled if dout is None else dout + d_scaled
         dout = _c(dout)
         B, T, n = ids.shape
         D = shapes[0][1]
@@ -601,7 +603,9 @@ class _EmbedSum(torch.autograd.Function):
 
 
 def embed_sum(ids, tables, pos=None, scale=1.0, want_scaled=False):
-    return _EmbedSum.apply(ids, pos, float(scale), bool(want_scaled), *tables)
+    """want_scaled: False | True (second output without gradient) | "grad" (second output differentiable: the MAS path
+    feeds the scaled embedding to the alignment attention)."""
+    return _EmbedSum.apply(ids, pos, float(scale), want_scaled if want_scaled == "grad" else bool(want_scaled), *tables)
 
 
 # ================================================================================================
@@ -1098,3 +1102,56 @@ class _SinAdd(torch.autograd.Function):
 
 def sin_add(x):
     return _SinAdd.apply(x)
+
+
+# ================================================================================================
+# MAS alignment path
+# ================================================================================================
+def mas_width1(attn, in_lens, out_lens):
+    """Hard monotonic alignment of a soft attention map, entirely on the device.
+    attn: (B, 1, T_mel, T_text) or (B, T_mel, T_text) float32; in_lens / out_lens: (B,) integer tensors.
+    Returns the 0/1 map with attn's shape (zeros outside each utterance's (out_len x in_len) corner)."""
+    a = _c(attn.detach())
+    B, To, Ti = a.shape[0], a.shape[-2], a.shape[-1]
+    opt = torch.empty_like(a)
+    ws = torch.empty((B, To, Ti), device=a.device, dtype=torch.uint8)
+    il = in_lens.to(device=a.device, dtype=torch.int32).contiguous()
+    ol = out_lens.to(device=a.device, dtype=torch.int32).contiguous()
+    check(lib().kantts_mas_width1(ptr(a, torch.float32), ptr(il), ptr(ol), ptr(opt), ptr(ws), B, To, Ti, stream()),
+          "mas_width1")
+    return opt
+
+
+class _AlignAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, prior, in_lens_i32):
+        q, k = _c(q), _c(k)
+        B, T1, C = q.shape
+        T2 = k.shape[1]
+        prior = None if prior is None else _c(prior.to(torch.float32))
+        logprob = torch.empty((B, 1, T1, T2), device=q.device, dtype=torch.float32)
+        soft = torch.empty_like(logprob)
+        check(lib().kantts_align_attn_fwd(ptr(q, torch.float32), ptr(k, torch.float32), ptr(prior), ptr(in_lens_i32),
+                                          ptr(logprob), ptr(soft), B, T1, T2, C, stream()), "align_attn_fwd")
+        ctx.save_for_backward(q, k, logprob, soft)
+        ctx.prior = prior
+        ctx.mark_non_differentiable(in_lens_i32)
+        return soft, logprob
+
+    @staticmethod
+    def backward(ctx, d_soft, d_logprob):
+        q, k, logprob, soft = ctx.saved_tensors
+        B, T1, C = q.shape
+        T2 = k.shape[1]
+        d_soft = None if d_soft is None else _c(d_soft)
+        d_logprob = None if d_logprob is None else _c(d_logprob)
+        g = torch.empty((B, T1, T2), device=q.device, dtype=torch.float32)
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        check(lib().kantts_align_attn_bwd(ptr(q), ptr(k), ptr(ctx.prior), ptr(logprob), ptr(soft), ptr(d_logprob),
+                                          ptr(d_soft), ptr(g), ptr(dq), ptr(dk), B, T1, T2, C, stream()), "align_attn_bwd")
+        return dq, dk, None, None
+
+
+def align_attention(q, k, prior, in_lens_i32):
+    """q (B, T_mel, C), k (B, T_text, C) -> (attn_soft, attn_logprob), each (B, 1, T_mel, T_text)."""
+    return _AlignAttention.apply(q, k, prior, in_lens_i32)

@@ -34,13 +34,14 @@ def train(model_config, root_dir, stage_dir, resume_path=None, resume_bert_path=
     sampler = {"train": None, "valid": None}
     ds = dataset_module()
     if synthetic:
-        from kantts.utils.synthetic import SAMBERT_VOCAB, sambert_batch, to_collate_format
+        from kantts.utils.synthetic import SAMBERT_VOCAB, sambert_batch, sambert_mas_batch, to_collate_format
 
         params = config["Model"]["KanTtsSAMBERT"]["params"]
         for k, v in SAMBERT_VOCAB.items():
             params.setdefault(k, v)
         rank = config.get("rank", 0)
-        train_loader = [to_collate_format(sambert_batch(B=config["batch_size"], seed=1234 + 1000 * rank + s))
+        make = sambert_mas_batch if params.get("MAS", False) else sambert_batch  # MAS: no durations, priors instead
+        train_loader = [to_collate_format(make(B=config["batch_size"], seed=1234 + 1000 * rank + s))
                         for s in range(synthetic)]
         valid_loader = None
     elif ds is not None:

@@ -9,6 +9,8 @@ samples with the matching mel frames.  Both return pinned host tensors when a GP
 trainers' ``.to(device, non_blocking=True)`` overlaps with compute.  Dataset discovery / feature files / the text
 front-end stay with the reference package.
 """
+import functools
+
 import numpy as np
 import torch
 
@@ -41,6 +43,22 @@ class Padder(object):
         return torch.from_numpy(np.stack([self._pad_durations(t, max_in_len, max_out_len) for t in durations])).long()
 
 
+@functools.lru_cache(maxsize=256)
+def beta_binomial_prior_distribution(phoneme_count, mel_count, scaling=1.0):
+    """(mel_count, phoneme_count) float64 tensor: row i is the Beta-Binomial(P, s*i, s*(M+1-i)) pmf over phoneme
+    positions 0..P-1 -- a diagonal-ish prior for the alignment attention (reference dataset.py:20-31, which
+    evaluates scipy.stats.betabinom row by row).  pmf(k) = C(P,k) B(k+a, P-k+b) / B(a,b), evaluated in log space for
+    all rows at once."""
+    from scipy.special import betaln, gammaln
+
+    P, M = int(phoneme_count), int(mel_count)
+    k = np.arange(0, P, dtype=np.float64)[None, :]
+    i = np.arange(1, M + 1, dtype=np.float64)[:, None]
+    a, b = scaling * i, scaling * (M + 1 - i)
+    log_comb = gammaln(P + 1) - gammaln(k + 1) - gammaln(P - k + 1)
+    return torch.tensor(np.exp(log_comb + betaln(k + a, P - k + b) - betaln(a, b)))
+
+
 def _pin(d, pin):
     if not (pin and torch.cuda.is_available()):
         return d
@@ -52,20 +70,28 @@ def am_collate(batch, r, pad_ids, pin=False):
     (ling_data = [sy, tone, syllable_flag, word_segment, emotion, speaker] integer arrays including the trailing "~");
     pad_ids: the six per-stream pad ids (ling_unit._sub_unit_pad in stream order)."""
     padder = Padder()
-    if any(item[2] is None for item in batch):
-        raise NotImplementedError("duration-free (MAS) batches are SURVEY row 8f-1")
+    with_duration = not any(item[2] is None for item in batch)
     max_in = max(len(x[0][0]) for x in batch)
-    max_dur = max(x[2].shape[0] for x in batch) + 1
+    max_dur = max(x[2].shape[0] for x in batch) + 1 if with_duration else None
     streams = [padder._prepare_scalar_inputs([x[0][k] for x in batch], max_in, pad_ids[k]).long() for k in range(6)]
     out = {"input_lings": torch.stack(streams[:4], dim=2), "input_emotions": streams[4], "input_speakers": streams[5]}
     out["valid_input_lengths"] = torch.as_tensor([len(x[0][0]) - 1 for x in batch], dtype=torch.long)  # minus "~"
     out["valid_output_lengths"] = torch.as_tensor([len(x[1]) for x in batch], dtype=torch.long)
     max_out = padder._round_up(int(out["valid_output_lengths"].max()), r)
     out["mel_targets"] = padder._prepare_targets([x[1] for x in batch], max_out, 0.0)
-    out["durations"] = padder._prepare_durations([x[2] for x in batch], max_dur, max_out)
-    out["pitch_contours"] = padder._prepare_scalar_inputs([x[3] for x in batch], max_in, 0.0).float()
-    out["energy_contours"] = padder._prepare_scalar_inputs([x[4] for x in batch], max_in, 0.0).float()
+    out["durations"] = padder._prepare_durations([x[2] for x in batch], max_dur, max_out) if with_duration else None
+    # duration-free (MAS) batches carry FRAME-level pitch / energy (averaged per phoneme inside the model) and the
+    # beta-binomial alignment prior, zero-padded to (max mel, max text) (reference dataset.py:798-827)
+    feat_len = max_in if with_duration else max_out
+    out["pitch_contours"] = padder._prepare_scalar_inputs([x[3] for x in batch], feat_len, 0.0).float()
+    out["energy_contours"] = padder._prepare_scalar_inputs([x[4] for x in batch], feat_len, 0.0).float()
     out["attn_priors"] = None
+    if not with_duration:
+        pri = torch.zeros(len(batch), max_out, max_in)
+        for i, item in enumerate(batch):
+            p = torch.as_tensor(item[5])
+            pri[i, :p.shape[0], :p.shape[1]] = p
+        out["attn_priors"] = pri
     return _pin(out, pin)
 
 

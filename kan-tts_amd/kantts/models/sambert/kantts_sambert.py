@@ -6,7 +6,8 @@ deliberate (documented in DESIGN.md):
   * attention probability tensors (8 + 24 dense (B*H, L, L) maps, ~1 GB at the training shape) are
     only materialised when ``model.return_attns`` is True; the dict keys are always present;
   * padding is described by lengths, never by materialised (B, L, L) masks;
-  * MAS / FP / SE / byte-input variants (off in sambert_16k.yaml) raise NotImplementedError.
+  * the MAS alignment path (sambert_16k_MAS.yaml) is implemented; FP / SE / byte-input variants raise
+    NotImplementedError.
 """
 import torch
 import torch.nn as nn
@@ -14,6 +15,8 @@ import torch.nn.functional as F
 
 from kantts._hip import ops
 from kantts.models.sambert import FFTBlock, PNCABlock, Prenet
+from kantts.models.sambert.alignment import b_mas
+from kantts.models.sambert.attention import ConvAttention
 from kantts.models.sambert.adaptors import LengthRegulator, VarFsmnRnnNARPredictor, VarRnnARPredictor
 from kantts.models.sambert.fsmn import FsmnEncoderV2
 from kantts.models.sambert.positions import DurSinusoidalPositionEncoder, SinusoidalPositionEncoder
@@ -127,6 +130,7 @@ class TextFftEncoder(nn.Module):
         super(TextFftEncoder, self).__init__()
         d_emb = config["embedding_dim"]
         self.using_byte = False
+        self.ling_embedding_grad = False  # set by KanTtsSAMBERT when the MAS attention consumes ling_embedding
         if config.get("using_byte", False):
             raise NotImplementedError("byte-index inputs (sambert_16k_MAS_byte.yaml) are outside the hot path")
         self.sy_emb = nn.Embedding(config["sy"], d_emb)
@@ -157,7 +161,7 @@ class TextFftEncoder(nn.Module):
         x, ling_embedding = ops.embed_sum(
             inputs_ling[:, :, :4],
             [self.sy_emb.weight, self.tone_emb.weight, self.syllable_flag_emb.weight, self.ws_emb.weight],
-            pos=pos, scale=self.d_model ** 0.5, want_scaled=True)
+            pos=pos, scale=self.d_model ** 0.5, want_scaled="grad" if self.ling_embedding_grad else True)
         enc_output, attns = self.ling_enc(x, masks, return_attns, prescaled=True)
         if hasattr(self, "ling_proj"):
             enc_output = ops.linear(enc_output, self.ling_proj.weight, None)
@@ -306,6 +310,21 @@ class PostNet(nn.Module):
         return ops.linear(h, self.fc.weight, self.fc.bias, res=res, rowmask=zero_rows)
 
 
+def average_frame_feat(pitch, durs):
+    """Frame-level contour (B, F, T_mel) -> per-phoneme mean over each phoneme's NON-ZERO frames (B, F, N), 0 where a
+    phoneme has none (reference :652-674).  Prefix sums + two gathers; durations are whole numbers stored as float."""
+    ends = torch.cumsum(durs, dim=1).long()
+    starts = F.pad(ends[:, :-1], (1, 0))
+    n_form = pitch.size(1)
+    e = ends[:, None, :].expand(-1, n_form, -1)
+    s = starts[:, None, :].expand(-1, n_form, -1)
+    count_ps = F.pad(torch.cumsum(pitch != 0.0, dim=2), (1, 0))
+    value_ps = F.pad(torch.cumsum(pitch, dim=2), (1, 0))
+    sums = (torch.gather(value_ps, 2, e) - torch.gather(value_ps, 2, s)).float()
+    counts = (torch.gather(count_ps, 2, e) - torch.gather(count_ps, 2, s)).float()
+    return torch.where(counts == 0.0, counts, sums / counts)
+
+
 class KanTtsSAMBERT(nn.Module):
     """SAM-BERT acoustic model (reference :712-1044)."""
 
@@ -322,7 +341,11 @@ class KanTtsSAMBERT(nn.Module):
         self.mel_postnet = PostNet(config)
         self.MAS = False
         if config.get("MAS", False):
-            raise NotImplementedError("MAS alignment path is SURVEY row 8f-1 (next)")
+            self.MAS = True
+            self.text_encoder.ling_embedding_grad = True
+            self.align_attention = ConvAttention(n_mel_channels=config["num_mels"],
+                                                 n_text_channels=config["embedding_dim"],
+                                                 n_att_channels=config["num_mels"])
         self.fp_enable = config.get("FP", False)
         if self.fp_enable:
             raise NotImplementedError("filled-pause predictor is outside the hot path")
@@ -337,6 +360,12 @@ class KanTtsSAMBERT(nn.Module):
         r = self.mel_decoder.r
         return get_mask_from_lengths((lengths + r - 1) // r, max_len=max_len // r)
 
+    def binarize_attention_parallel(self, attn, in_lens, out_lens):
+        """Hard alignment by monotonic alignment search; no gradient (reference :752-764).  The reference moves the
+        map to the host, runs numba and copies it back; this stays on the device (csrc/mas.hip)."""
+        with torch.no_grad():
+            return b_mas(attn, in_lens, out_lens, width=1)
+
     def forward(self, inputs_ling, inputs_emotion, inputs_speaker, input_lengths, output_lengths=None,
                 mel_targets=None, duration_targets=None, pitch_targets=None, energy_targets=None, attn_priors=None,
                 fp_label=None):
@@ -344,8 +373,23 @@ class KanTtsSAMBERT(nn.Module):
         r = self.mel_decoder.r
         T_in = inputs_ling.size(1)
         in_info = SeqInfo(input_lengths, T_in)
+        is_training = mel_targets is not None
         text_hid, enc_sla_attn_lst, ling_embedding = self.text_encoder(inputs_ling, in_info, self.return_attns)
         inter_lengths = input_lengths
+        attn_soft = attn_hard = attn_logprob = None
+        if self.MAS and is_training:
+            # Monotonic-Alignment-Search (reference :901-925): soft attention mel <-> (scaled) linguistic embedding,
+            # hard path by DP, durations = frames per phoneme, frame-level pitch / energy averaged per phoneme
+            attn_soft, attn_logprob = self.align_attention.forward_cl(mel_targets, ling_embedding, input_lengths,
+                                                                      attn_priors)
+            attn_hard = self.binarize_attention_parallel(attn_soft, input_lengths, output_lengths)
+            duration_targets = attn_hard.sum(2)[:, 0, :]
+            pitch_targets = average_frame_feat(pitch_targets.unsqueeze(1), duration_targets).squeeze(1)
+            energy_targets = average_frame_feat(energy_targets.unsqueeze(1), duration_targets).squeeze(1)
+            # the slot after the last phoneme absorbs the r-padding so that durations sum to the padded mel length
+            # (reference loop :921-924, vectorised: no per-item .item())
+            pad = (mel_targets.size(1) - output_lengths).to(duration_targets.dtype)
+            duration_targets.scatter_(1, input_lengths.view(-1, 1), pad.view(-1, 1))
         (emo_hid, _) = ops.embed_sum(inputs_emotion, [self.emo_tokenizer.weight])
         (spk_hid, _) = ops.embed_sum(inputs_speaker, [self.spk_tokenizer.weight])
         out_info = None
@@ -419,6 +463,10 @@ class KanTtsSAMBERT(nn.Module):
         res["LR_emo_outputs"] = LR_emo_outputs
         res["LR_spk_outputs"] = LR_spk_outputs
         res["ling_embedding"] = ling_embedding
+        if self.MAS and is_training:
+            res["attn_soft"] = attn_soft
+            res["attn_hard"] = attn_hard
+            res["attn_logprob"] = attn_logprob
         return res
 
 

@@ -119,7 +119,51 @@ class MelSpectrogramLoss(torch.nn.Module):
         return ops.l1_mean(mel_hat, mel)
 
 
+class AttentionBinarizationLoss(torch.nn.Module):
+    """-mean log soft attention on the hard (MAS) path, warmed up over epochs (reference :463-479).
+    ``soft[hard == 1]`` of the reference is a boolean gather with a host sync; hard is 0/1, so the same sum is
+    ``sum(hard * log(clamp(soft)))`` with static shapes."""
+
+    def __init__(self, start_epoch=0, warmup_epoch=100):
+        super(AttentionBinarizationLoss, self).__init__()
+        self.start_epoch = start_epoch
+        self.warmup_epoch = warmup_epoch
+
+    def forward(self, epoch, hard_attention, soft_attention, eps=1e-12):
+        log_sum = (hard_attention * torch.log(torch.clamp(soft_attention, min=eps))).sum()
+        kl_loss = -log_sum / hard_attention.sum()
+        if epoch < self.start_epoch:
+            warmup_ratio = 0
+        else:
+            warmup_ratio = min(1.0, (epoch - self.start_epoch) / self.warmup_epoch)
+        return kl_loss * warmup_ratio
+
+
+class AttentionCTCLoss(torch.nn.Module):
+    """CTC over the alignment log-probabilities with the phoneme sequence 1..N as target and a constant blank score
+    (reference :482-508).  The reference loops over utterances (slice, log_softmax, one CTCLoss call each); here the
+    batch goes through ONE ctc_loss call: classes beyond an utterance's phoneme count get a large negative score (their
+    softmax weight underflows to exactly 0, so every row's normaliser equals the sliced one) and frames beyond its mel
+    length are excluded by input_lengths.  'mean' reduction = mean_b(loss_b / target_len_b), which is what the
+    reference's sum of per-utterance means / B computes."""
+
+    def __init__(self, blank_logprob=-1):
+        super(AttentionCTCLoss, self).__init__()
+        self.blank_logprob = blank_logprob
+
+    def forward(self, attn_logprob, in_lens, out_lens):
+        B, _, T1, T2 = attn_logprob.shape
+        lp = F.pad(attn_logprob[:, 0], (1, 0), value=self.blank_logprob)  # (B, T1, T2 + 1), class 0 = blank
+        cls = torch.arange(T2 + 1, device=lp.device)
+        lp = lp.masked_fill((cls[None, :] > in_lens[:, None])[:, None, :], -1e9)
+        lp = F.log_softmax(lp, dim=2).transpose(0, 1)  # (T1, B, classes)
+        targets = cls[1:].unsqueeze(0).expand(B, -1)
+        return F.ctc_loss(lp, targets, out_lens, in_lens, blank=0, reduction="mean", zero_infinity=True)
+
+
 loss_dict = {
+    "AttentionBinarizationLoss": AttentionBinarizationLoss,
+    "AttentionCTCLoss": AttentionCTCLoss,
     "MelReconLoss": MelReconLoss,
     "ProsodyReconLoss": ProsodyReconLoss,
     "generator_adv_loss": GeneratorAdversarialLoss,
@@ -140,3 +184,4 @@ def criterion_builder(config, device="cpu"):
         elif value.get("enable", False):
             raise NotImplementedError("{} is not implemented".format(key))
     return criterion
+

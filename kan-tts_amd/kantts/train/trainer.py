@@ -189,8 +189,10 @@ class Sambert_Trainer(Trainer):
         super().__init__(*args, **kwargs)
         params = self.config["Model"][self.KEY]["params"]
         self.with_MAS, self.fp_enable = params.get("MAS", False), params.get("FP", False)
-        if self.with_MAS or self.fp_enable:
-            raise NotImplementedError("MAS / filled-pause training are outside the hot path (DESIGN.md section 7)")
+        if self.fp_enable:
+            raise NotImplementedError("filled-pause training is outside the hot path (DESIGN.md section 7)")
+        if self.with_MAS and graph:
+            raise NotImplementedError("graph=True covers the duration-supervised step; the MAS step runs eagerly")
         self.graph = graph
         self._graphs = {}
         if self.grad_clip is not None and hasattr(self.optimizer[self.KEY], "set_grad_clip"):
@@ -200,7 +202,7 @@ class Sambert_Trainer(Trainer):
         names = dict(inputs_ling="input_lings", inputs_emotion="input_emotions", inputs_speaker="input_speakers",
                      input_lengths="valid_input_lengths", output_lengths="valid_output_lengths",
                      mel_targets="mel_targets", duration_targets="durations", pitch_targets="pitch_contours",
-                     energy_targets="energy_contours")
+                     energy_targets="energy_contours", attn_priors="attn_priors")
         return {k: (batch[v].to(self.device, non_blocking=True) if batch.get(v) is not None else None)
                 for k, v in names.items()}
 
@@ -211,8 +213,14 @@ class Sambert_Trainer(Trainer):
             res["valid_inter_lengths"], res["duration_targets"], res["pitch_targets"], res["energy_targets"],
             res["log_duration_predictions"], res["pitch_predictions"], res["energy_predictions"])
         total = mel_ + mel + dur + pitch + energy
-        return total, {"TotalLoss": total, "mel_loss_": mel_, "mel_loss": mel, "dur_loss": dur, "pitch_loss": pitch,
-                       "energy_loss": energy}
+        losses = {"mel_loss_": mel_, "mel_loss": mel, "dur_loss": dur, "pitch_loss": pitch, "energy_loss": energy}
+        if self.with_MAS:  # reference :871-884 / :970-983
+            ctc = self.criterion["AttentionCTCLoss"](res["attn_logprob"], b["input_lengths"], b["output_lengths"])
+            kl = self.criterion["AttentionBinarizationLoss"](self.epoch, res["attn_hard"], res["attn_soft"])
+            total = total + ctc + kl
+            losses.update(attn_ctc_loss=ctc, attn_kl_loss=kl)
+        losses["TotalLoss"] = total
+        return total, losses
 
     def train_step(self, batch):
         b = self._to_device(batch)

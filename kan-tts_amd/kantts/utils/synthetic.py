@@ -52,9 +52,29 @@ def sambert_batch(B=32, T_in=64, seed=1234, min_len=32, dur_hi=17, r=3, num_mels
                 mel_targets=mel, duration_targets=dur, pitch_targets=pitch, energy_targets=energy)
 
 
+def sambert_mas_batch(B=32, T_in=64, seed=1234, min_len=32, dur_hi=17, r=3, num_mels=80):
+    """Duration-free batch of the MAS configuration (configs/sambert_16k_MAS.yaml): same draws as ``sambert_batch``, then
+    frame-level pitch (30 % unvoiced zeros) / energy and the beta-binomial alignment prior over len+1 symbols (the
+    trailing "~"), zero-padded, as AM_Dataset / collate_fn deliver them (dataset.py:498-503, 798-827)."""
+    from kantts.datasets.batching import beta_binomial_prior_distribution
+
+    b = sambert_batch(B=B, T_in=T_in, seed=seed, min_len=min_len, dur_hi=dur_hi, r=r, num_mels=num_mels)
+    g = torch.Generator().manual_seed(seed + 1)
+    T_mel = b["mel_targets"].shape[1]
+    valid = torch.arange(T_mel)[None, :] < b["output_lengths"][:, None]
+    pitch = torch.randn(B, T_mel, generator=g) * (torch.rand(B, T_mel, generator=g) > 0.3) * valid
+    energy = torch.randn(B, T_mel, generator=g) * valid
+    pri = torch.zeros(B, T_mel, T_in)
+    for i in range(B):
+        p = beta_binomial_prior_distribution(int(b["input_lengths"][i]) + 1, int(b["output_lengths"][i]))
+        pri[i, :p.shape[0], :p.shape[1]] = p
+    b.update(duration_targets=None, pitch_targets=pitch, energy_targets=energy, attn_priors=pri)
+    return b
+
+
 def to_collate_format(b):
     """Model-argument names -> the keys of the reference's collate_fn (what the trainers consume)."""
     return {"input_lings": b["inputs_ling"], "input_emotions": b["inputs_emotion"], "input_speakers": b["inputs_speaker"],
             "valid_input_lengths": b["input_lengths"], "valid_output_lengths": b["output_lengths"],
             "mel_targets": b["mel_targets"], "durations": b["duration_targets"], "pitch_contours": b["pitch_targets"],
-            "energy_contours": b["energy_targets"], "attn_priors": None}
+            "energy_contours": b["energy_targets"], "attn_priors": b.get("attn_priors")}

@@ -792,3 +792,68 @@ class EmulatedLib:
         DV = (G / nrm)[:, None, None] * (DW - V * (dgv / nrm)[:, None, None])
         _arr(dv, rows * cin * K)[:] = DV.astype(np.float32).ravel()
         return 0
+
+    # ------------------------------------------------------------------------------------ monotonic alignment search
+    def kantts_mas_width1(self, attn, in_lens, out_lens, opt, workspace, B, To_max, Ti_max, stream):
+        A = _arr(attn, B * To_max * Ti_max).reshape(B, To_max, Ti_max)
+        O = _arr(opt, B * To_max * Ti_max).reshape(B, To_max, Ti_max)
+        il, ol = _arr(in_lens, B, np.int32), _arr(out_lens, B, np.int32)
+        O[:] = 0
+        for b in range(B):
+            Ti, To = int(min(il[b], Ti_max)), int(min(ol[b], To_max))
+            if Ti <= 0 or To <= 0:
+                continue
+            with np.errstate(divide="ignore"):
+                la = np.log(A[b, :To, :Ti].astype(np.float64)).astype(np.float32)
+            la[0, 1:] = -np.inf
+            lp = la[0].copy()
+            prev = np.zeros((To, Ti), dtype=np.int64)
+            for i in range(1, To):
+                shifted = np.concatenate([[-np.inf], lp[:-1]]).astype(np.float32)
+                take = np.arange(Ti) >= 1
+                take &= shifted >= lp
+                best = np.where(take, shifted, lp)
+                prev[i] = np.arange(Ti) - take
+                lp = (la[i] + best).astype(np.float32)
+            c = Ti - 1
+            for i in range(To - 1, -1, -1):
+                O[b, i, c] = 1
+                c = prev[i, c]
+            O[b, 0, c] = 1
+        return 0
+
+    # ------------------------------------------------------------------------------------ alignment attention (MAS path)
+    def kantts_align_attn_fwd(self, q, k, prior, in_lens, logprob, soft, B, T1, T2, C, stream):
+        Q = torch.from_numpy(_arr(q, B * T1 * C).reshape(B, T1, C))
+        K = torch.from_numpy(_arr(k, B * T2 * C).reshape(B, T2, C))
+        il = _arr(in_lens, B, np.int32)
+        d = -0.0005 * ((Q[:, :, None, :] - K[:, None, :, :]) ** 2).sum(-1)
+        if prior:
+            P = torch.from_numpy(_arr(prior, B * T1 * T2).reshape(B, T1, T2))
+            d = torch.log_softmax(d, dim=2) + torch.log(P + 1e-8)
+        _arr(logprob, B * T1 * T2)[:] = d.reshape(-1).numpy()
+        mask = torch.arange(T2)[None, :] >= torch.from_numpy(il.astype(np.int64))[:, None]
+        s = torch.softmax(d.masked_fill(mask[:, None, :], -float("inf")), dim=2)
+        _arr(soft, B * T1 * T2)[:] = s.reshape(-1).numpy()
+        return 0
+
+    def kantts_align_attn_bwd(self, q, k, prior, logprob, soft, d_logprob, d_soft, g_ws, dq, dk, B, T1, T2, C, stream):
+        Q = _arr(q, B * T1 * C).reshape(B, T1, C).astype(np.float64)
+        K = _arr(k, B * T2 * C).reshape(B, T2, C).astype(np.float64)
+        S = _arr(soft, B * T1 * T2).reshape(B, T1, T2).astype(np.float64)
+        g = np.zeros((B, T1, T2))
+        if d_soft:
+            dS = _arr(d_soft, B * T1 * T2).reshape(B, T1, T2).astype(np.float64)
+            g = S * (dS - (S * dS).sum(-1, keepdims=True))
+        if d_logprob:
+            g = g + _arr(d_logprob, B * T1 * T2).reshape(B, T1, T2)
+        if prior:
+            P = _arr(prior, B * T1 * T2).reshape(B, T1, T2)
+            LP = _arr(logprob, B * T1 * T2).reshape(B, T1, T2)
+            p = np.exp(LP.astype(np.float64) - np.log(P + np.float32(1e-8)).astype(np.float64))
+            g = g - p * g.sum(-1, keepdims=True)
+        _arr(g_ws, B * T1 * T2)[:] = g.reshape(-1).astype(np.float32)
+        # dq = -0.001 (rowsum(g) q - g @ k);  dk = 0.001 (g^T @ q - colsum(g) k)
+        _arr(dq, B * T1 * C)[:] = (-0.001 * (g.sum(2)[:, :, None] * Q - g @ K)).reshape(-1).astype(np.float32)
+        _arr(dk, B * T2 * C)[:] = (0.001 * (g.transpose(0, 2, 1) @ Q - g.sum(1)[:, :, None] * K)).reshape(-1).astype(np.float32)
+        return 0

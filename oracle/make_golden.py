@@ -129,6 +129,88 @@ def collate_case():
     print("collate bytes", os.path.getsize(os.path.join(OUT, "collate.pt")))
 
 
+def mas_batch(B, T_in, min_len, dur_hi, seed_b):
+    """Duration-free batch as AM_Dataset produces with MAS: True (dataset.py:498-503, 798-827): frame-level pitch /
+    energy (with unvoiced zeros) and the beta-binomial prior over len+1 symbols (the trailing "~")."""
+    from kantts.datasets.dataset import beta_binomial_prior_distribution
+
+    batch = O.synthetic_sambert_batch(B=B, T_in=T_in, seed=seed_b, min_len=min_len, dur_hi=dur_hi)
+    g = torch.Generator().manual_seed(seed_b + 1)
+    T_mel = batch["mel_targets"].shape[1]
+    valid = torch.arange(T_mel)[None, :] < batch["output_lengths"][:, None]
+    pitch = torch.randn(B, T_mel, generator=g) * (torch.rand(B, T_mel, generator=g) > 0.3) * valid
+    energy = torch.randn(B, T_mel, generator=g) * valid
+    pri = torch.zeros(B, T_mel, T_in)
+    for b in range(B):
+        p = beta_binomial_prior_distribution(int(batch["input_lengths"][b]) + 1, int(batch["output_lengths"][b]))
+        pri[b, :p.shape[0], :p.shape[1]] = p
+    batch.update(duration_targets=None, pitch_targets=pitch, energy_targets=energy, attn_priors=pri)
+    return batch
+
+
+def sambert_mas_case(name, B, T_in, min_len, dur_hi, seed_w=0, seed_b=4321, epoch=50):
+    from kantts.train.loss import AttentionBinarizationLoss, AttentionCTCLoss
+
+    cfg = O.sambert_config(tiny=True)
+    cfg["MAS"] = True
+    torch.manual_seed(seed_w)
+    m = KanTtsSAMBERT(dict(cfg))
+    m.eval()
+    batch = mas_batch(B, T_in, min_len, dur_hi, seed_b)
+    # binarize_attention_parallel ends with .to(attn.get_device()), which is -1 (invalid) for CPU tensors: give it the
+    # tensor's device for the duration of the call -- no arithmetic is touched
+    orig_get_device = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: self.device
+    try:
+        res = m(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    finally:
+        torch.Tensor.get_device = orig_get_device
+    mel_, mel = MelReconLoss()(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+    d, p, e = ProsodyReconLoss()(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                 res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                 res["energy_predictions"])
+    ctc = AttentionCTCLoss()(res["attn_logprob"], batch["input_lengths"], batch["output_lengths"])
+    kl = AttentionBinarizationLoss()(epoch, res["attn_hard"], res["attn_soft"])
+    total = mel_ + mel + d + p + e + ctc + kl
+    total.backward()
+    grads = {n: p_.grad.clone() for n, p_ in m.named_parameters() if n.startswith("align_attention.") and p_.grad is not None and p_.numel() <= 20000}
+    gsum = {n: (float(p_.grad.double().sum()), float(p_.grad.double().norm())) for n, p_ in m.named_parameters()
+            if p_.grad is not None}
+    keep = ["dec_outputs", "postnet_outputs", "LR_length_rounded", "log_duration_predictions", "attn_soft", "attn_hard",
+            "attn_logprob", "duration_targets", "pitch_targets", "energy_targets"]
+    fix = dict(cfg=cfg, seed_w=seed_w, epoch=epoch, batch=batch,
+               outputs={k: res[k].detach().clone() for k in keep}, x_band_width=res["x_band_width"],
+               losses=dict(mel_loss_=float(mel_), mel_loss=float(mel), dur_loss=float(d), pitch_loss=float(p),
+                           energy_loss=float(e), attn_ctc_loss=float(ctc), attn_kl_loss=float(kl), total=float(total)),
+               grads=grads, grad_summaries=gsum, weight_checksums=checksums(m.state_dict()),
+               torch_version=torch.__version__)
+    torch.save(fix, os.path.join(OUT, name + ".pt"))
+    print(name, "loss", float(total), "ctc", float(ctc), "kl", float(kl), "bytes",
+          os.path.getsize(os.path.join(OUT, name + ".pt")))
+
+
+def mas_dp_case():
+    """b_mas (alignment.py:63-71; numba replaced by the identity jit of ref_harness, i.e. its plain-Python semantics)
+    on random soft maps, on maps with exact ties (uniform rows) and with zeros (log -> -inf)."""
+    import numpy as np
+    from kantts.models.sambert.alignment import b_mas
+
+    g = torch.Generator().manual_seed(99)
+    B, To, Ti = 6, 57, 19
+    logits = torch.randn(B, 1, To, Ti, generator=g) * 3
+    attn = torch.softmax(logits, dim=3)
+    attn[1] = 1.0 / Ti                                   # every comparison is a tie
+    attn[2] = attn[2] * (torch.rand(1, To, Ti, generator=g) > 0.3)   # zeros -> -inf scores
+    attn[3, :, :, 5:] = torch.round(attn[3, :, :, 5:] * 8) / 8       # coarse values: many ties, some zeros
+    in_lens = np.array([19, 19, 17, 12, 1, 7], dtype=np.int64)
+    out_lens = np.array([57, 40, 57, 33, 20, 7], dtype=np.int64)
+    hard = b_mas(attn.numpy().copy(), in_lens, out_lens, width=1)
+    fix = dict(attn=attn, in_lens=torch.from_numpy(in_lens), out_lens=torch.from_numpy(out_lens),
+               hard=torch.from_numpy(hard))
+    torch.save(fix, os.path.join(OUT, "mas_dp.pt"))
+    print("mas_dp durations", hard.sum(2)[:, 0, :8].tolist()[0], "bytes", os.path.getsize(os.path.join(OUT, "mas_dp.pt")))
+
+
 def melspec_case():
     g = torch.Generator().manual_seed(7)
     x = torch.randn(4, 2048, generator=g) * 0.1
@@ -149,3 +231,5 @@ if __name__ == "__main__":
     sambert_infer_case("sambert_tiny_infer", B=1, T_in=12, min_len=6)
     melspec_case()
     collate_case()
+    mas_dp_case()
+    sambert_mas_case("sambert_tiny_mas", B=3, T_in=12, min_len=6, dur_hi=6)
