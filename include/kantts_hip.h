@@ -375,8 +375,9 @@ int kantts_lstm_cell(const float* gates, const float* c_prev, float* h_out, floa
 /* Monotonic alignment search, width 1 (csrc/mas.hip): replaces the host round trip of binarize_attention_parallel
  * (kantts/models/sambert/kantts_sambert.py:752-764 -> numba b_mas, alignment.py:32-71).  attn / opt are (B, To_max, Ti_max)
  * (the reference's (B, 1, mel, text) with the singleton squeezed); opt receives the 0/1 hard alignment of the valid
- * (out_lens[b] x in_lens[b]) corner and zeros elsewhere; workspace: B*To_max*Ti_max bytes of back-pointers. */
-int kantts_mas_width1(const float* attn, const int32_t* in_lens, const int32_t* out_lens, float* opt, uint8_t* workspace,
+ * (out_lens[b] x in_lens[b]) corner and zeros elsewhere; workspace: B*To_max*Ti_max*4 bytes (float logs, or byte
+ * back-pointers on the wide-map fallback). */
+int kantts_mas_width1(const float* attn, const int32_t* in_lens, const int32_t* out_lens, float* opt, void* workspace,
                       int B, int To_max, int Ti_max, void* stream);
 
 /* Alignment attention of the MAS path (csrc/mas.hip): the part of ConvAttention.forward after the projections

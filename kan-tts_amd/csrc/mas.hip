@@ -7,14 +7,22 @@
 //   log_p[i][j] = log a[i][j] + max(log_p[i-1][j], log_p[i-1][j-1])        ties (>=) go to j-1, exactly as the reference
 //   backtrack from (To-1, Ti-1); opt[i][path(i)] = 1, and opt[0][0] = 1 (the reference's final assignment)
 //
-// One workgroup per utterance, rows sequential, text positions across the lanes; the two live rows of log_p sit in LDS,
-// the 1-bit back-pointers go to a byte workspace, lane 0 walks them back.  log() is evaluated in double and rounded to
-// float so that the comparisons see the same values as numpy's float32 log up to its (<= 1 ulp) approximation error.
+// One workgroup per utterance.  The recurrence is a chain of To dependent rows, so the kernel is latency-, not
+// bandwidth-bound, and is built to keep everything off that chain:
+//   1. all 1024 lanes of the workgroup take the logs in parallel into a float workspace.  log() is evaluated
+//      in double and rounded to float so that the comparisons see the same values as numpy's float32 log up to its
+//      (<= 1 ulp) approximation error;
+//   2. ONE wave then walks the rows with the previous row of log_p in registers (column r*64+lane), neighbours by
+//      DPP/shuffle, no barrier, no stores, the logs of the next 16 rows in flight; the back-pointers of a row are the
+//      ballot mask of the comparison -- one 64-bit LDS word per 64 columns;
+//   3. lane 0 walks the masks back through LDS (~100 cycles per frame instead of a dependent HBM/L2 load).
+// Maps wider than 256 symbols or with more than 64 KB of masks use the row-parallel fallback (LDS ping-pong rows, byte
+// back-pointers in a global workspace).
 #include "common.h"
 
 #define MAS_THREADS 256
 
-__global__ __launch_bounds__(MAS_THREADS) void mas_width1_kernel(const float* __restrict__ attn,
+__global__ __launch_bounds__(MAS_THREADS) void mas_block_kernel(const float* __restrict__ attn,
                                                                 const int32_t* __restrict__ in_lens,
                                                                 const int32_t* __restrict__ out_lens,
                                                                 float* __restrict__ opt, uint8_t* __restrict__ ws, int To_max,
@@ -62,13 +70,137 @@ __global__ __launch_bounds__(MAS_THREADS) void mas_width1_kernel(const float* __
   }
 }
 
+#define MASW_THREADS 1024
+
+template <int G, int CH>
+__global__ __launch_bounds__(MASW_THREADS) void mas_wave_kernel(const float* __restrict__ attn,
+                                                               const int32_t* __restrict__ in_lens,
+                                                               const int32_t* __restrict__ out_lens, float* __restrict__ opt,
+                                                               float* __restrict__ logs, int To_max, int Ti_max) {
+  extern __shared__ unsigned long long mas_bits[];  // To x G ballot masks
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Ti = min(in_lens[b], Ti_max), To = min(out_lens[b], To_max);
+  const float* a = attn + (long long)b * To_max * Ti_max;
+  float* o = opt + (long long)b * To_max * Ti_max;
+  float* lg = logs + (long long)b * To_max * Ti_max;
+  // 1. logs of the valid corner (row 0: only column 0 is reachable) by all 16 waves; the output starts as zeros
+  for (int e = tid; e < To_max * Ti_max; e += MASW_THREADS) {
+    int i = e / Ti_max, j = e - i * Ti_max;
+    if (i < To && j < Ti) lg[e] = (i == 0 && j > 0) ? -INFINITY : (float)log((double)a[e]);
+    o[e] = 0.f;
+  }
+  if (Ti <= 0 || To <= 0) return;
+  __syncthreads();
+  if (tid >= KANTTS_WAVE) return;
+  const int lane = tid;
+  int col[G];
+  float prev[G];
+#pragma unroll
+  for (int r = 0; r < G; ++r) {
+    col[r] = r * 64 + lane;
+    prev[r] = (col[r] < Ti) ? lg[col[r]] : -INFINITY;
+  }
+  if (lane == 0)
+    for (int r = 0; r < G; ++r) mas_bits[r] = 0ull;
+  // 2. the recurrence, CH rows per trip: the next CH rows of logs are in flight while this trip's rows are consumed
+  float buf[CH][G];
+#pragma unroll
+  for (int k = 0; k < CH; ++k)
+#pragma unroll
+    for (int r = 0; r < G; ++r)
+      buf[k][r] = (1 + k < To && col[r] < Ti) ? lg[(long long)(1 + k) * Ti_max + col[r]] : -INFINITY;
+  for (int base = 1; base < To; base += CH) {
+    float nb[CH][G];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+      for (int r = 0; r < G; ++r)
+        nb[k][r] = (base + CH + k < To && col[r] < Ti) ? lg[(long long)(base + CH + k) * Ti_max + col[r]] : -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int i = base + k;
+      if (i < To) {
+        float nv[G];
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+          const float p0 = prev[r];
+          // left neighbour: DPP wave_shr:1 (a VALU move, not an LDS bpermute -- this is the dependent chain); lane 0
+          // keeps `old` = column 63 of the previous 64-column group (unused for column 0)
+          const int wrap = (r > 0) ? __builtin_amdgcn_readlane(__float_as_int(prev[r > 0 ? r - 1 : 0]), 63) : 0;
+          const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(wrap, __float_as_int(p0), 0x138, 0xf, 0xf, false));
+          const bool take = (col[r] >= 1) && (p1 >= p0);
+          nv[r] = buf[k][r] + (take ? p1 : p0);
+          mas_bits[(long long)i * G + r] = __ballot(take && col[r] < Ti);  // same value from every lane
+        }
+#pragma unroll
+        for (int r = 0; r < G; ++r) prev[r] = nv[r];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+      for (int r = 0; r < G; ++r) buf[k][r] = nb[k][r];
+  }
+  // 3. backtrack, 64 frames per trip: lane k fetches the masks of frame top-k (one parallel LDS read), the column walks
+  //    down through v_readlane on a wave-uniform scalar, lane k keeps the column of its frame and stores its 1
+  int c = Ti - 1;
+  for (int top = To - 1; top >= 0; top -= 64) {
+    const int row = top - lane;
+    unsigned int wlo[G], whi[G];
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+      unsigned long long m = (row >= 0) ? mas_bits[(long long)row * G + r] : 0ull;
+      wlo[r] = (unsigned int)m;
+      whi[r] = (unsigned int)(m >> 32);
+    }
+    int myc = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      c = __builtin_amdgcn_readfirstlane(c);
+      if (lane == k) myc = c;
+      const int g = c >> 6;
+      unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)wlo[0], k);
+      unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)whi[0], k);
+#pragma unroll
+      for (int r = 1; r < G; ++r) {
+        unsigned int l2 = (unsigned int)__builtin_amdgcn_readlane((int)wlo[r], k);
+        unsigned int h2 = (unsigned int)__builtin_amdgcn_readlane((int)whi[r], k);
+        lo = (g == r) ? l2 : lo;
+        hi = (g == r) ? h2 : hi;
+      }
+      const unsigned int word = (c & 32) ? hi : lo;
+      c -= (int)((word >> (c & 31)) & 1u);
+    }
+    if (row >= 0) o[(long long)row * Ti_max + myc] = 1.f;
+  }
+  if (lane == 0) o[0] = 1.f;  // the reference's trailing opt[0, prev_ind[0, .]] = 1 with prev_ind[0, :] == 0
+}
+
 extern "C" int kantts_mas_width1(const float* attn, const int32_t* in_lens, const int32_t* out_lens, float* opt,
-                                 uint8_t* workspace, int B, int To_max, int Ti_max, void* stream) {
+                                 void* workspace, int B, int To_max, int Ti_max, void* stream) {
   if (!attn || !in_lens || !out_lens || !opt || !workspace || B < 0 || To_max < 1 || Ti_max < 1) return KANTTS_E_BADARG;
-  if ((size_t)Ti_max * 2 * sizeof(float) > 64 * 1024) return KANTTS_E_UNSUPPORTED;
+  if ((long long)To_max * Ti_max > 0x7fffffffLL) return KANTTS_E_UNSUPPORTED;
   if (B == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(mas_width1_kernel, dim3(B), dim3(MAS_THREADS), (size_t)Ti_max * 2 * sizeof(float), (hipStream_t)stream,
-                     attn, in_lens, out_lens, opt, workspace, To_max, Ti_max);
+  hipStream_t s = (hipStream_t)stream;
+  const int groups = (Ti_max + 63) / 64;
+  const int G = groups <= 1 ? 1 : (groups <= 2 ? 2 : 4);
+  const size_t bits = (size_t)To_max * G * sizeof(unsigned long long);
+  if (groups <= 4 && bits <= 64 * 1024) {
+    float* logs = (float*)workspace;
+    if (G == 1)
+      hipLaunchKernelGGL((mas_wave_kernel<1, 16>), dim3(B), dim3(MASW_THREADS), bits, s, attn, in_lens, out_lens, opt, logs,
+                         To_max, Ti_max);
+    else if (G == 2)
+      hipLaunchKernelGGL((mas_wave_kernel<2, 16>), dim3(B), dim3(MASW_THREADS), bits, s, attn, in_lens, out_lens, opt, logs,
+                         To_max, Ti_max);
+    else
+      hipLaunchKernelGGL((mas_wave_kernel<4, 8>), dim3(B), dim3(MASW_THREADS), bits, s, attn, in_lens, out_lens, opt, logs,
+                         To_max, Ti_max);
+    KANTTS_CHECK_LAUNCH();
+  }
+  if ((size_t)Ti_max * 2 * sizeof(float) > 64 * 1024) return KANTTS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(mas_block_kernel, dim3(B), dim3(MAS_THREADS), (size_t)Ti_max * 2 * sizeof(float), s, attn, in_lens,
+                     out_lens, opt, (uint8_t*)workspace, To_max, Ti_max);
   KANTTS_CHECK_LAUNCH();
 }
 

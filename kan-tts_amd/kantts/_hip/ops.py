@@ -1114,7 +1114,7 @@ def mas_width1(attn, in_lens, out_lens):
     a = _c(attn.detach())
     B, To, Ti = a.shape[0], a.shape[-2], a.shape[-1]
     opt = torch.empty_like(a)
-    ws = torch.empty((B, To, Ti), device=a.device, dtype=torch.uint8)
+    ws = torch.empty((B, To, Ti), device=a.device, dtype=torch.float32)
     il = in_lens.to(device=a.device, dtype=torch.int32).contiguous()
     ol = out_lens.to(device=a.device, dtype=torch.int32).contiguous()
     check(lib().kantts_mas_width1(ptr(a, torch.float32), ptr(il), ptr(ol), ptr(opt), ptr(ws), B, To, Ti, stream()),
