@@ -326,6 +326,12 @@ def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add,
     if _profile is not None:
         e1.record()
         _profile.append((e0, e1, 2.0 * B * Tdst * inner * groups * NG * CR * K / max(1, in_div)))
+        _profile_tags.append(("conv_win", dict(B=B, Tsrc=Tsrc, Tdst=Tdst, inner=inner, Cin=groups * CR, Cout=groups * NG,
+                                               groups=groups, K=K, in_mul=in_mul, in_div=in_div, up=up,
+                                               gated=in_gate is not None, res=res is not None),
+                              4.0 * (B * Tsrc * inner * groups * CR * (2 if in_gate is not None else 1) +
+                                     B * Tdst * inner * groups * NG * (1 + (res is not None) + (out_gate is not None)) +
+                                     K * groups * NG * CR)))
     return True
 
 
@@ -355,6 +361,11 @@ def conv_wgrad(x, dy, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, d
     if _profile is not None:
         e1.record()
         _profile.append((e0, e1, 2.0 * B * Tdst * inner * groups * NG * CR * K))
+        _profile_tags.append(("conv_wgrad", dict(B=B, Tsrc=Tsrc, Tdst=Tdst, inner=inner, Cin=groups * CR, Cout=groups * NG,
+                                                 groups=groups, K=K, stride=stride, dil=dil, up=up,
+                                                 gated=dy_gate is not None),
+                              4.0 * (B * Tsrc * inner * groups * CR + B * Tdst * inner * groups * NG *
+                                     (2 if dy_gate is not None else 1) + K * groups * NG * CR)))
     return True
 
 
@@ -402,11 +413,13 @@ def rng_ptr(device):
 # ----------------------------------------------------------------------------------------------
 # bench instrumentation: HIP events (on the launch stream) around every GEMM launch
 _profile = None
+_profile_tags = []  # (kernel, shape dict, algorithmic bytes) of the conv launches, parallel to their _profile entries
 
 
 def profile_begin():
     global _profile
     _profile = []
+    del _profile_tags[:]
 
 
 def profile_end():
@@ -415,3 +428,34 @@ def profile_end():
     torch.cuda.synchronize()
     ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
     return {"launches": len(rec), "ms": ms, "flops": sum(f for _, _, f in rec)}
+
+
+def profile_end_by_shape():
+    """Per distinct conv launch shape: count, total ms, TFLOP/s and algorithmic GB/s (conv launches only)."""
+    global _profile
+    rec, _profile = _profile, None
+    torch.cuda.synchronize()
+    by_flops = {}
+    for e0, e1, f in rec:
+        by_flops.setdefault(f, []).append(e0.elapsed_time(e1))
+    out = {}
+    # conv records are matched to their tags through the flop count + order of appearance
+    it = iter(_profile_tags)
+    conv = [(e0.elapsed_time(e1), f) for e0, e1, f in rec]
+    tags = list(_profile_tags)
+    ci = 0
+    for ms, f in conv:
+        if ci < len(tags) and abs(_tag_flops(tags[ci]) - f) <= 1e-6 * max(1.0, f):
+            kern, shape, nbytes = tags[ci]
+            ci += 1
+            key = kern + " " + " ".join("%s=%s" % kv for kv in shape.items())
+            o = out.setdefault(key, dict(n=0, ms=0.0, flops=f, bytes=nbytes))
+            o["n"] += 1
+            o["ms"] += ms
+    return out
+
+
+def _tag_flops(tag):
+    kern, s, _ = tag
+    f = 2.0 * s["B"] * s["Tdst"] * s["inner"] * s["Cout"] * (s["Cin"] // s["groups"]) * s["K"]
+    return f / max(1, s.get("in_div", 1)) if kern == "conv_win" else f
