@@ -52,7 +52,7 @@ __device__ __forceinline__ void cw_store4(void* base, int idx, float v0, float v
 // WM waves along the output tokens (4 or 2), the other 4/WM along the output channels;
 // every wave owns MREP x 4 accumulator fragments (16*MREP tokens x 64 channels).
 template <bool BF16, int WM, int MREP>
-__global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_args g) {
+__global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(kantts_conv_args g) {
   constexpr int WN = 4 / WM;
   constexpr int BQ = WM * MREP * 16;
   constexpr int BN = WN * 64;
@@ -73,6 +73,12 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
+#ifdef CW_DEBUG  // ablation mask (experiment builds only): 1 no window loads, 2 no output stores, 4 no weight loads, 8 no MFMA
+  const int dbg = g.up >> 16;
+  g.up &= 0xffff;
+#else
+  constexpr int dbg = 0;
+#endif
   const int ntpg = (g.NG + BN - 1) / BN;
   // XCD-aware order inside one (batch, phase) slab: workgroup L = y*gx + x runs on XCD L % 8; the gx channel tiles
   // of one token window are dealt to ONE XCD (consecutive virtual ids) so the window crosses the fabric once
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
 #pragma unroll
     for (int v = 0; v < NBV; ++v) {
       const int j = rslot + 32 * v;
-      const bool ok = (n0 + j < n_end) && (c0 + c4 < g.CR);
+      const bool ok = (n0 + j < n_end) && (c0 + c4 < g.CR) && !(dbg & 4);
       const long long o = ok ? (((long long)k * g.Ntot + n0 + j) * g.CR + c0 + c4) : 0;
       float4 x = *reinterpret_cast<const float4*>(g.w + o);
       if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
       for (int u = 0; u < 4; ++u) {
         const int rr = r0 + 32 * u;
         const int t = lo + ((inner > 1) ? rr / inner : rr);
-        ok[u] = cok && rr < WR && t >= 0 && t < g.Tsrc;
+        ok[u] = cok && rr < WR && t >= 0 && t < g.Tsrc && !(dbg & 1);
         const long long o = ok[u] ? (((long long)lo * inner + rr) * g.Cin_tot + c0 + c4) : 0;
         xv[u] = *reinterpret_cast<const float4*>(in_b + o);
         if (gate_b) gv[u] = *reinterpret_cast<const float4*>(gate_b + o);
@@ -259,11 +265,13 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           bfr[j] = *reinterpret_cast<const bf16x8*>(&Bh[(wn * 64 + j * 16 + (lane & 15)) * LDW + (lane >> 4) * 8]);
+        if (!(dbg & 8)) {
 #pragma unroll
-        for (int f = 0; f < MREP; ++f)
+          for (int f = 0; f < MREP; ++f)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfr[j], acc[f][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+              acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[f], bfr[j], acc[f][j], 0, 0, 0);
+        }
       } else {
         const float* Wf = reinterpret_cast<const float*>(win);
         const float* Bf = reinterpret_cast<const float*>(bcur);
@@ -286,52 +294,83 @@ __global__ __launch_bounds__(CW_THREADS) void conv_win_kernel(const kantts_conv_
     }
   }
 
-  // ---- epilogue: each wave transposes its fragments through a private 16 x 68 float LDS strip so that 16
-  // lanes write one 256-byte output row (bias, LeakyReLU, residual and LeakyReLU' gate fused)
-  __syncthreads();
+  // ---- epilogue: each wave transposes its fragments through a PRIVATE 16 x 68 float LDS strip (no workgroup barrier:
+  // LDS operations of one wave execute in order) so that LPR lanes write one contiguous output row segment; bias,
+  // LeakyReLU, residual and LeakyReLU' gate fused.  The ablation run of round 1 (profiles/r01_conv_win_ablation.log)
+  // charged 12-16 us of a 36-55 us launch to this block: per-element bias / residual loads, two barriers per
+  // fragment and half of the lanes idle when a tile has 32 live output channels.
+  __syncthreads();  // the strips overlay the window / weight tiles other waves may still be reading
   float* strip = reinterpret_cast<float*>(cw_lds) + wave * (16 * 68);
   const bool vec_ok = ((g.Ntot & 3) == 0) && ((g.NG & 3) == 0) && (((uintptr_t)g.out & 15) == 0) &&
-                      (!g.res || ((uintptr_t)g.res & 15) == 0) && (!g.out_gate || ((uintptr_t)g.out_gate & 15) == 0);
+                      (!g.res || ((uintptr_t)g.res & 15) == 0) && (!g.out_gate || ((uintptr_t)g.out_gate & 15) == 0) &&
+                      (!g.bias || ((uintptr_t)g.bias & 15) == 0);
+  // live channels of this wave's 64-column strip -> lanes per row (4 / 8 / 16) and rows per pass (16 / 8 / 4)
+  const int live = min(64, n_end - (n0 + wn * 64));
+  const int lpr = (live <= 16) ? 4 : ((live <= 32) ? 8 : 16);
+  const int rpp = 64 / lpr;  // rows per pass
+  const int lcol = (lane % lpr) * 4, lrow = lane / lpr;
+  const int n = n0 + wn * 64 + lcol;
+  const int cnt = min(4, n_end - n);  // <= 0: this lane has no live channel
+  const bool v4 = vec_ok && cnt == 4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias && cnt > 0) {
+    if (v4) {
+      const float4 t = *reinterpret_cast<const float4*>(g.bias + n);
+      bv[0] = t.x, bv[1] = t.y, bv[2] = t.z, bv[3] = t.w;
+    } else {
+      for (int e = 0; e < cnt; ++e) bv[e] = g.bias[n + e];
+    }
+  }
+  const long long obase = (long long)b * g.Tdst * inner * g.Ntot + n;  // rows of one batch item span < 2^31 elements
 #pragma unroll
   for (int f = 0; f < MREP; ++f) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) strip[((lane >> 4) * 4 + r) * 68 + j * 16 + (lane & 15)] = acc[f][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int rl = p * 4 + (lane >> 4);
+    __builtin_amdgcn_wave_barrier();
+    for (int rl = lrow; rl < 16; rl += rpp) {
       const int mp = m0 + wm * (MREP * 16) + f * 16 + rl;
-      const int n = n0 + wn * 64 + (lane & 15) * 4;
-      if (mp < R && n < n_end) {
-        const int m = (inner > 1) ? mp / inner : mp;
-        const int pin = (inner > 1) ? mp - m * inner : 0;
-        const long long d = (long long)m * g.phases + phase;
-        const long long o = (((long long)b * g.Tdst + d) * inner + pin) * g.Ntot + n;
-        const float4 a4 = *reinterpret_cast<const float4*>(&strip[rl * 68 + (lane & 15) * 4]);
-        float v[4] = {a4.x, a4.y, a4.z, a4.w};
-        const int cnt = min(4, n_end - n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (e < cnt) {
-            float x = v[e];
-            if (g.bias) x += g.bias[n + e];
-            if (g.out_act) x = x > 0.f ? x : x * g.out_slope;
-            if (g.res) x += g.res[o + e];
-            if (g.out_gate) x *= (g.out_gate[o + e] > 0.f) ? 1.f : g.out_gate_slope;
-            v[e] = x;
-          }
+      if (mp < R && cnt > 0 && !(dbg & 2)) {
+        int row;  // (d * inner + pin): output row inside the batch item
+        if (inner > 1) {
+          const int m = mp / inner;
+          row = (m * g.phases + phase) * inner + (mp - m * inner);
+        } else {
+          row = mp * g.phases + phase;
         }
-        if (vec_ok && cnt == 4) {
+        const long long o = obase + (long long)row * g.Ntot;
+        const float4 a4 = *reinterpret_cast<const float4*>(&strip[rl * 68 + lcol]);
+        float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+        if (g.out_act) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * g.out_slope;
+        }
+        if (v4) {
+          if (g.res) {
+            const float4 t = *reinterpret_cast<const float4*>(g.res + o);
+            v[0] += t.x, v[1] += t.y, v[2] += t.z, v[3] += t.w;
+          }
+          if (g.out_gate) {
+            const float4 t = *reinterpret_cast<const float4*>(g.out_gate + o);
+            v[0] *= (t.x > 0.f) ? 1.f : g.out_gate_slope;
+            v[1] *= (t.y > 0.f) ? 1.f : g.out_gate_slope;
+            v[2] *= (t.z > 0.f) ? 1.f : g.out_gate_slope;
+            v[3] *= (t.w > 0.f) ? 1.f : g.out_gate_slope;
+          }
           f32x4 nt = {v[0], v[1], v[2], v[3]};
           __builtin_nontemporal_store(nt, reinterpret_cast<f32x4*>(g.out + o));
         } else {
-          for (int e = 0; e < cnt; ++e) g.out[o + e] = v[e];
+          for (int e = 0; e < cnt; ++e) {
+            float x = v[e];
+            if (g.res) x += g.res[o + e];
+            if (g.out_gate) x *= (g.out_gate[o + e] > 0.f) ? 1.f : g.out_gate_slope;
+            g.out[o + e] = x;
+          }
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -408,7 +447,13 @@ static int cw_launch(const kantts_conv_args& g, hipStream_t st) {
   const int mrows = (g.Tdst + g.phases - 1) / g.phases;
   const int ntpg = (g.NG + BN - 1) / BN;
   dim3 grid(g.groups * ntpg, kantts_cdiv((long long)mrows * g.inner, BQ), g.B * g.phases);
+#ifdef CW_DEBUG
+  kantts_conv_args gd = g;
+  if (const char* e = getenv("KANTTS_CW_DBG")) gd.up = (gd.up & 0xffff) | (atoi(e) << 16);
+  hipLaunchKernelGGL((conv_win_kernel<BF16, WM, MREP>), grid, dim3(CW_THREADS), lds, st, gd);
+#else
   hipLaunchKernelGGL((conv_win_kernel<BF16, WM, MREP>), grid, dim3(CW_THREADS), lds, st, g);
+#endif
   KANTTS_CHECK_LAUNCH();
 }
 
