@@ -256,6 +256,11 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+#ifdef F_DEBUG  // ablation mask (experiment builds only, scripts/build_gdbg.sh): 1 no operand loads, 2 no output stores, 8 no MFMA
+  const int dbg = g.precision >> 8;
+#else
+  constexpr int dbg = 0;
+#endif
   // XCD-aware tile order.  The dispatcher deals workgroup L = y*gx + x to XCD L % 8, so the gx column tiles that
   // share one A row tile would land on 8 different L2s and the A operand would cross the fabric 8 times
   // (measured: 27 MB fetched for 3.3 MB of A at 6528x1024x128).  Workgroups of one XCD are given consecutive
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
         return q;
       };
       int t = next_owned(0);
-      if (t < ntile) {
+      if (t < ntile && !(dbg & 1)) {
         sa.fetch(t * BK);
         sb.fetch(t * BK);
       }
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
         sb.commit(Bl, s, seed_off);
         __syncthreads();
         const int tn = next_owned(t + 1);
-        if (tn < ntile) {
+        if (tn < ntile && !(dbg & 1)) {
           sa.fetch(tn * BK);
           sb.fetch(tn * BK);
         }
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
                 bfr[n] = *reinterpret_cast<const bf16x8*>(&Bh[(c0 + li) * LDB + kk * 32 + kg * 8]);
               }
             }
+            if (dbg & 8) continue;
 #pragma unroll
             for (int m = 0; m < MREP; ++m)
 #pragma unroll
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
     for (int v = 0; v < BM / 16; ++v) {
       const int rl = (tid >> 4) + 16 * v;
       const int i = i0 + rl, j = j0 + (tid & 15) * 4;
-      if (i < g.M && j < g.N) {
+      if (i < g.M && j < g.N && !(dbg & 2)) {
         const float4 a4 = *reinterpret_cast<const float4*>(&Cs[rl * CLD + (tid & 15) * 4]);
         float o[4] = {a4.x, a4.y, a4.z, a4.w};
         float rr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(F_THREADS) void gemm_fast_kernel(const kantts_gemm_
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wr * (BM / 2) + m * 16 + (lane >> 4) * 4 + r;
         const int j = j0 + wc * 32 + n * 16 + (lane & 15);
-        if (i < g.M && j < g.N) {
+        if (i < g.M && j < g.N && !(dbg & 2)) {
           const float v = f_epilogue(g, acc[m][n][r], i, j, first_slice, seed_off, grp);
           float* dst = &g.c[(long long)i * g.c_is + (long long)j * g.c_js + (long long)grp * g.c_gs +
                             (ztap > 0 ? (long long)ztap * g.c_tap : 0)];
@@ -536,8 +542,15 @@ static void launch_fast(const kantts_gemm_args& g, bool a_row, bool b_row, dim3 
 }
 
 // Returns 1 when the launch was taken by a fast kernel, 0 when the descriptor does not qualify.
-int kantts_gemm_try_fast(const kantts_gemm_args& g, hipStream_t st) {
-  if (g.precision > 1) return 0;
+int kantts_gemm_try_fast(const kantts_gemm_args& g_in, hipStream_t st) {
+  if (g_in.precision > 1) return 0;
+#ifdef F_DEBUG
+  kantts_gemm_args g = g_in;
+  static const char* dbg_env = getenv("KANTTS_GEMM_DBG");
+  const int dbg_mask = dbg_env ? atoi(dbg_env) : 0;
+#else
+  const kantts_gemm_args& g = g_in;
+#endif
   const int am = g.seg[0].a_mode, bm = g.seg[0].b_mode;
   if (am < 2 || bm < 2) return 0;
   for (int s = 0; s < g.nseg; ++s) {
@@ -573,7 +586,11 @@ int kantts_gemm_try_fast(const kantts_gemm_args& g, hipStream_t st) {
   const int bmr = small ? 32 : 64;
   dim3 grid(kantts_cdiv(g.N, F_BN), kantts_cdiv(g.M, bmr), splitk * groups * ztaps);
   const bool a_row = (am == 3), b_row = (bm == 3);
-  if (g.precision == 1) {
+  const int prec = g.precision;
+#ifdef F_DEBUG
+  g.precision |= dbg_mask << 8;
+#endif
+  if (prec == 1) {
     if (small)
       launch_fast<true, 32>(g, a_row, b_row, grid, st);
     else
