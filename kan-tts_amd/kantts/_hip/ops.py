@@ -797,6 +797,47 @@ def _upsample_tap_matrix(K, up, pad, dil, device):
     return hit
 
 
+_EYE_CACHE = {}
+
+
+def _group_pack(groups, cr, ng):
+    """Number P of ADJACENT groups that are merged into one dense block-diagonal contraction.  A group with 8 input and
+    16 output channels (the scale discriminator's k=41 layers, hifigan.py:332-407) fills 1/4 x 1/4 of a 32-deep x
+    64-wide MFMA tile; P groups side by side fill it, at P times the arithmetic -- 10-27 TFLOP/s effective became
+    the per-shape table's worst entries (profiles/r01_hifigan_conv_shapes.log).  Channels-last keeps the P*cr input
+    channels of adjacent groups contiguous, so only the (tiny) weight tensor is re-laid."""
+    if groups <= 1 or (cr >= 32 and ng >= 32):
+        return 1
+    P = 1
+    while P < groups and (P * cr < 32 or P * ng < 32) and groups % (2 * P) == 0:
+        P *= 2
+    return P
+
+
+def _eye(P, device):
+    key = (P, str(device))
+    if key not in _EYE_CACHE:
+        _EYE_CACHE[key] = torch.eye(P, device=device, dtype=torch.float32)
+    return _EYE_CACHE[key]
+
+
+def _blockdiag_pack(w, groups, P):
+    """(K, groups*NG, CR) -> (K, groups*NG, P*CR): output channel n of group g keeps its CR weights at channel block
+    g % P of its merged group, zeros elsewhere."""
+    K, N, CR = w.shape
+    NG = N // groups
+    v = w.view(K, groups // P, P, NG, 1, CR) * _eye(P, w.device).view(1, 1, P, 1, P, 1)
+    return v.reshape(K, N, P * CR)
+
+
+def _blockdiag_unpack(wp, groups, P):
+    """Inverse selection for gradients: (K, groups*NG, P*CR) -> (K, groups*NG, CR) (the diagonal blocks)."""
+    K, N, PCR = wp.shape
+    NG, CR = N // groups, PCR // P
+    d = torch.diagonal(wp.view(K, groups // P, P, NG, P, CR), dim1=2, dim2=4)  # (K, G', NG, CR, P)
+    return d.permute(0, 1, 4, 2, 3).reshape(K, N, CR)
+
+
 class _ConvCL(torch.autograd.Function):
     """Channels-last Conv1d / (k,1)-Conv2d:  x (B, Tin, inner, Cin) -> y (B, Tout, inner, Cout)
 
@@ -838,6 +879,12 @@ class _ConvCL(torch.autograd.Function):
             return y
         ctx.c1 = False
         wt = w if tap_major else (w.permute(2, 0, 1).contiguous() if K > 1 else w)  # (K, Cout, Cin_g)
+        P = _group_pack(groups, Cin_g, Cout_g) if up == 1 else 1
+        if P > 1 and conv_win(
+                x, _blockdiag_pack(wt.reshape(K, Cout, Cin_g), groups, P), y, B=B, Tsrc=Tin, Tdst=Tout, groups=groups // P,
+                CR=P * Cin_g, NG=P * Cout_g, K=K, in_mul=stride, in_add=-pad, in_kstep=dil, in_div=1, phases=1,
+                inner=inner, up=up, bias=bias, res=r, in_leaky=cfg["in_leaky"], out_leaky=cfg["out_leaky"]):
+            return y
         if conv_win(
                 x, wt, y, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K, in_mul=stride,
                 in_add=-pad, in_kstep=dil, in_div=1, phases=1, inner=inner, up=up, bias=bias, res=r, in_leaky=cfg["in_leaky"],
@@ -898,10 +945,16 @@ class _ConvCL(torch.autograd.Function):
                                 in_gate_slope=gslope, out_gate=x if cfg["in_leaky"] is not None else None,
                                 out_gate_slope=cfg["in_leaky"] or 0.0)
             else:
-                done = up == 1 and conv_win(
+                Pd = _group_pack(groups, Cout_g, Cin_g) if up == 1 else 1
+                done = Pd > 1 and conv_win(
+                    dy, _blockdiag_pack(wd.reshape(K, Cin, Cout_g), groups, Pd), dx, B=B, Tsrc=Tout, Tdst=Tin,
+                    groups=groups // Pd, CR=Pd * Cout_g, NG=Pd * Cin_g, K=K, in_mul=1, in_add=pad, in_kstep=-dil,
+                    in_div=stride, phases=stride, inner=inner, in_gate=gate, in_gate_slope=gslope,
+                    out_gate=x if cfg["in_leaky"] is not None else None, out_gate_slope=cfg["in_leaky"] or 0.0)
+                done = done or (up == 1 and conv_win(
                     dy, wd, dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups, CR=Cout_g, NG=Cin_g, K=K, in_mul=1, in_add=pad,
                     in_kstep=-dil, in_div=stride, phases=stride, inner=inner, in_gate=gate, in_gate_slope=gslope,
-                    out_gate=x if cfg["in_leaky"] is not None else None, out_gate_slope=cfg["in_leaky"] or 0.0)
+                    out_gate=x if cfg["in_leaky"] is not None else None, out_gate_slope=cfg["in_leaky"] or 0.0))
             first = True
             for r in range(0 if done else up):
                 # x-domain token t receives dy[(t*up + r + pad - k*dil) / stride] (exact division only)
@@ -914,10 +967,20 @@ class _ConvCL(torch.autograd.Function):
                      gate_slope=cfg["in_leaky"] or 0.0)
                 first = False
         if ctx.needs_input_grad[1]:
-            dwt = gzeros((K, Cout, Cin_g), dy.device)
             if has_bias:
                 db = gzeros((Cout,), dy.device)
             Mtok = B * Tout * inner
+            Pw = _group_pack(groups, Cin_g, Cout_g) if up == 1 else 1
+            if Pw > 1:
+                dwp = gzeros((K, Cout, Pw * Cin_g), dy.device)
+                if conv_wgrad(x, dy, dwp, db, B=B, Tsrc=Tin, Tdst=Tout, groups=groups // Pw, CR=Pw * Cin_g,
+                              NG=Pw * Cout_g, K=K, stride=stride, dil=dil, pad=pad, inner=inner, up=up, dy_gate=gate,
+                              dy_gate_slope=gslope, x_leaky=cfg["in_leaky"]):
+                    dwt = _blockdiag_unpack(dwp, groups, Pw)
+                    return dx, (dwt if tap_major else dwt.permute(1, 2, 0)), db, (dy if has_res else None), None
+                if has_bias:
+                    db.zero_()
+            dwt = gzeros((K, Cout, Cin_g), dy.device)
             if conv_wgrad(x, dy, dwt, db, B=B, Tsrc=Tin, Tdst=Tout, groups=groups, CR=Cin_g, NG=Cout_g, K=K,
                           stride=stride, dil=dil, pad=pad, inner=inner, up=up, dy_gate=gate, dy_gate_slope=gslope,
                           x_leaky=cfg["in_leaky"]):
