@@ -65,7 +65,7 @@ def _pin(d, pin):
     return {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in d.items()}
 
 
-def am_collate(batch, r, pad_ids, pin=False):
+def am_collate(batch, r, pad_ids, pin=False, se=False):
     """batch: list of (ling_data, mel, dur, f0, energy, attn_prior, fp_label, se) as AM_Dataset.__getitem__ returns
     (ling_data = [sy, tone, syllable_flag, word_segment, emotion, speaker] integer arrays including the trailing "~");
     pad_ids: the six per-stream pad ids (ling_unit._sub_unit_pad in stream order)."""
@@ -75,6 +75,8 @@ def am_collate(batch, r, pad_ids, pin=False):
     max_dur = max(x[2].shape[0] for x in batch) + 1 if with_duration else None
     streams = [padder._prepare_scalar_inputs([x[0][k] for x in batch], max_in, pad_ids[k]).long() for k in range(6)]
     out = {"input_lings": torch.stack(streams[:4], dim=2), "input_emotions": streams[4], "input_speakers": streams[5]}
+    if se:  # speaker-embedding models: one (1, D) vector per utterance, repeated over its symbols (dataset.py:757-762)
+        out["input_speakers"] = padder._prepare_targets([x[7].repeat(len(x[0][0]), axis=0) for x in batch], max_in, 0.0)
     out["valid_input_lengths"] = torch.as_tensor([len(x[0][0]) - 1 for x in batch], dtype=torch.long)  # minus "~"
     out["valid_output_lengths"] = torch.as_tensor([len(x[1]) for x in batch], dtype=torch.long)
     max_out = padder._round_up(int(out["valid_output_lengths"].max()), r)

@@ -6,8 +6,8 @@ deliberate (documented in DESIGN.md):
   * attention probability tensors (8 + 24 dense (B*H, L, L) maps, ~1 GB at the training shape) are
     only materialised when ``model.return_attns`` is True; the dict keys are always present;
   * padding is described by lengths, never by materialised (B, L, L) masks;
-  * the MAS alignment path (sambert_16k_MAS.yaml) is implemented; FP / SE / byte-input variants raise
-    NotImplementedError.
+  * the MAS alignment path (sambert_16k_MAS.yaml) and speaker-embedding input (SE: True) are implemented;
+    FP / byte-input variants raise NotImplementedError.
 """
 import torch
 import torch.nn as nn
@@ -332,9 +332,8 @@ class KanTtsSAMBERT(nn.Module):
         super(KanTtsSAMBERT, self).__init__()
         self.text_encoder = TextFftEncoder(config)
         self.se_enable = config.get("SE", False)
-        if self.se_enable:
-            raise NotImplementedError("SE speaker-embedding input is outside the hot path (SURVEY 8f-4)")
-        self.spk_tokenizer = nn.Embedding(config["speaker"], config["speaker_units"])
+        if not self.se_enable:  # SE: the speaker stream arrives as per-token embedding vectors (reference :717-720, :928)
+            self.spk_tokenizer = nn.Embedding(config["speaker"], config["speaker_units"])
         self.emo_tokenizer = nn.Embedding(config["emotion"], config["emotion_units"])
         self.variance_adaptor = VarianceAdaptor(config)
         self.mel_decoder = MelPNCADecoder(config)
@@ -391,7 +390,10 @@ class KanTtsSAMBERT(nn.Module):
             pad = (mel_targets.size(1) - output_lengths).to(duration_targets.dtype)
             duration_targets.scatter_(1, input_lengths.view(-1, 1), pad.view(-1, 1))
         (emo_hid, _) = ops.embed_sum(inputs_emotion, [self.emo_tokenizer.weight])
-        (spk_hid, _) = ops.embed_sum(inputs_speaker, [self.spk_tokenizer.weight])
+        if self.se_enable:
+            spk_hid = inputs_speaker.to(torch.float32)
+        else:
+            (spk_hid, _) = ops.embed_sum(inputs_speaker, [self.spk_tokenizer.weight])
         out_info = None
         max_out_len = None
         if output_lengths is not None:

@@ -189,6 +189,34 @@ def sambert_mas_case(name, B, T_in, min_len, dur_hi, seed_w=0, seed_b=4321, epoc
           os.path.getsize(os.path.join(OUT, name + ".pt")))
 
 
+def sambert_se_case(name, B, T_in, min_len, dur_hi, seed_w=0, seed_b=555):
+    """SE: True (configs/sambert_se_nsf_global_16k.yaml): the speaker stream is a 192-d embedding per token."""
+    cfg = O.sambert_config(tiny=True)
+    cfg["SE"] = True
+    cfg["speaker_units"] = 192
+    torch.manual_seed(seed_w)
+    m = KanTtsSAMBERT(dict(cfg))
+    m.eval()
+    batch = O.synthetic_sambert_batch(B=B, T_in=T_in, seed=seed_b, min_len=min_len, dur_hi=dur_hi)
+    g = torch.Generator().manual_seed(seed_b + 7)
+    batch["inputs_speaker"] = torch.randn(B, 1, 192, generator=g).repeat(1, T_in, 1)
+    res = m(**batch)
+    mel_, mel = MelReconLoss()(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+    d, p, e = ProsodyReconLoss()(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                 res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                 res["energy_predictions"])
+    total = mel_ + mel + d + p + e
+    total.backward()
+    gsum = {n: (float(p_.grad.double().sum()), float(p_.grad.double().norm())) for n, p_ in m.named_parameters()
+            if p_.grad is not None}
+    keep = ["dec_outputs", "postnet_outputs", "LR_length_rounded", "log_duration_predictions", "LR_spk_outputs"]
+    fix = dict(cfg=cfg, seed_w=seed_w, batch=batch, outputs={k: res[k].detach().clone() for k in keep},
+               x_band_width=res["x_band_width"], losses=dict(total=float(total)), grad_summaries=gsum,
+               weight_checksums=checksums(m.state_dict()), state_keys=sorted(m.state_dict().keys()))
+    torch.save(fix, os.path.join(OUT, name + ".pt"))
+    print(name, "loss", float(total), "bytes", os.path.getsize(os.path.join(OUT, name + ".pt")))
+
+
 def mas_dp_case():
     """b_mas (alignment.py:63-71; numba replaced by the identity jit of ref_harness, i.e. its plain-Python semantics)
     on random soft maps, on maps with exact ties (uniform rows) and with zeros (log -> -inf)."""
@@ -233,3 +261,4 @@ if __name__ == "__main__":
     collate_case()
     mas_dp_case()
     sambert_mas_case("sambert_tiny_mas", B=3, T_in=12, min_len=6, dur_hi=6)
+    sambert_se_case("sambert_tiny_se", B=2, T_in=10, min_len=5, dur_hi=5)
