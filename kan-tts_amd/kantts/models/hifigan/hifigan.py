@@ -14,7 +14,7 @@ from torch.nn.utils import spectral_norm, weight_norm
 
 from kantts._hip import ops
 from kantts.models.hifigan.layers import (CausalConv1d, CausalConvTranspose1d, Conv1d, ConvTranspose1d,
-                                          ResidualBlock, conv_weight, effective_weight)
+                                          ResidualBlock, SourceModule, conv_weight, effective_weight)
 
 DB3_DEC_LO = [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313,
               0.8068915093133388, 0.3326705529509569]
@@ -36,8 +36,6 @@ class Generator(torch.nn.Module):
         assert kernel_size % 2 == 1, "Kernal size must be odd number."
         assert len(upsample_scales) == len(upsample_kernal_sizes)
         assert len(resblock_dilations) == len(resblock_kernel_sizes)
-        if nsf_params is not None:
-            raise NotImplementedError("NSF generators are SURVEY row 8f-4 (next)")
         if nonlinear_activation != "LeakyReLU":
             raise NotImplementedError("only LeakyReLU (every shipped yaml)")
         self.upsample_scales = upsample_scales
@@ -45,7 +43,7 @@ class Generator(torch.nn.Module):
         self.num_upsamples = len(upsample_kernal_sizes)
         self.num_kernels = len(resblock_kernel_sizes)
         self.out_channels = out_channels
-        self.nsf_enable = False
+        self.nsf_enable = nsf_params is not None
         self.causal = causal
         self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
         self.transpose_upsamples = torch.nn.ModuleList()
@@ -72,8 +70,27 @@ class Generator(torch.nn.Module):
                     nonlinear_activation_params=nonlinear_activation_params, causal=causal))
         self.conv_post = conv_cls(channels // (2 ** (i + 1)), out_channels, kernel_size, 1,
                                   padding=(kernel_size - 1) // 2)
+        if self.nsf_enable:
+            # neural source filter (reference :119-143): a sine excitation at the sample rate, brought down to every
+            # stage's rate by a strided convolution (kernel 2u, stride u) and added to the stage input
+            self.source_module = SourceModule(nb_harmonics=nsf_params["nb_harmonics"],
+                                              upsample_ratio=np.cumprod(self.upsample_scales)[-1],
+                                              sampling_rate=nsf_params["sampling_rate"])
+            self.source_downs = nn.ModuleList()
+            self.downsample_rates = [1] + list(self.upsample_scales[::-1][:-1])
+            self.downsample_cum_rates = np.cumprod(self.downsample_rates)
+            for i, u in enumerate(self.downsample_cum_rates[::-1]):
+                u = int(u)
+                if u == 1:
+                    self.source_downs.append(Conv1d(1, channels // (2 ** (i + 1)), 1, 1))
+                else:
+                    self.source_downs.append(conv_cls(1, channels // (2 ** (i + 1)), u * 2, u, padding=u // 2))
 
     def forward(self, x):
+        excitation = None
+        if self.nsf_enable:  # the last two input channels carry f0 (Hz) and the voiced flag
+            excitation = self.source_module.forward_cl(x[:, -2:-1, :], x[:, -1:, :])
+            x = x[:, :-2, :]
         h = self.conv_pre.forward_cl(x.transpose(1, 2).contiguous())
         for i in range(self.num_upsamples):
             s = self.upsample_scales[i]
@@ -86,6 +103,8 @@ class Generator(torch.nn.Module):
                                   tap_major=tap)
             else:
                 rep = None
+            if excitation is not None:  # rep + e, accumulated in the strided convolution's epilogue
+                rep = self.source_downs[i].forward_cl(excitation, res=rep)
             h = self.transpose_upsamples[i][1].forward_cl(h, in_leaky=self.slope, res=rep)
             xs = None
             for j in range(self.num_kernels):
@@ -106,6 +125,10 @@ class Generator(torch.nn.Module):
             layer.remove_weight_norm()
         self.conv_pre.remove_weight_norm()
         self.conv_post.remove_weight_norm()
+        if self.nsf_enable:
+            self.source_module.remove_weight_norm()
+            for layer in self.source_downs:
+                layer.remove_weight_norm()
 
 
 def _norm_f(use_spectral_norm):

@@ -66,7 +66,8 @@ class Conv1d(torch.nn.Module):
         c = self.conv1d
         k, d, s = c.kernel_size[0], c.dilation[0], c.stride[0]
         Tin = x.shape[1]
-        Tout = Tin if self.causal else (Tin + 2 * self.pad - d * (k - 1) - 1) // s + 1
+        # causal: (k-1)*d zeros on the left only (reference :86-91) -> ceil(Tin / s) outputs
+        Tout = (Tin - 1) // s + 1 if self.causal else (Tin + 2 * self.pad - d * (k - 1) - 1) // s + 1
         w, tap = conv_weight(c)
         return ops.conv_cl(x, w, c.bias, stride=s, dilation=d, pad=self.pad, Tout=Tout, groups=c.groups,
                            in_leaky=in_leaky, out_leaky=out_leaky, res=res, tap_major=tap)
@@ -175,8 +176,57 @@ class ResidualBlock(torch.nn.Module):
 
 
 class SourceModule(torch.nn.Module):
-    """NSF sine-excitation source (reference :229-290) -- SURVEY row 8f-4 (next)."""
+    """NSF sine-excitation source (reference :229-290): harmonics 1..H+1 of the frame-level f0, phase by a running sum
+    of f0/sr, a random initial phase per harmonic, Gaussian noise, voiced / unvoiced mixing -- all without gradient --
+    then a weight-normed 1x1 convolution (H+1 -> 1) and tanh.
 
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        raise NotImplementedError("NSF SourceModule is SURVEY row 8f-4 (next)")
+    The excitation is a no-grad elementwise preamble of (B, H+1, T) floats and runs as device tensor ops; unlike the
+    reference, which samples phase and noise on the host and copies them over, the draws come from the generator of the
+    tensors' own device (on the CPU -- the emulated tests -- that is the same torch.distributions call sequence, hence
+    the same numbers as the reference for a given seed).  The projection runs on the conv kernels, channels last."""
+
+    def __init__(self, nb_harmonics, upsample_ratio, sampling_rate, alpha=0.1, sigma=0.003):
+        super(SourceModule, self).__init__()
+        self.nb_harmonics = nb_harmonics
+        self.upsample_ratio = upsample_ratio
+        self.sampling_rate = sampling_rate
+        self.alpha = alpha
+        self.sigma = sigma
+        self.ffn = nn.Sequential(weight_norm(nn.Conv1d(self.nb_harmonics + 1, 1, kernel_size=1, stride=1)), nn.Tanh())
+
+    @torch.no_grad()
+    def excitation(self, pitch, uv):
+        """pitch (Hz), uv: (B, 1, frames) -> e (B, H+1, frames * upsample_ratio)."""
+        import numpy as np
+        from torch.distributions.normal import Normal
+        from torch.distributions.uniform import Uniform
+
+        up = int(self.upsample_ratio)
+        dev = pitch.device
+        # the reference's own call (its source-index rounding for non-power-of-two ratios included)
+        pitch_samples = torch.nn.functional.interpolate(pitch, scale_factor=up, mode="nearest")
+        uv_samples = torch.nn.functional.interpolate(uv, scale_factor=up, mode="nearest")
+        harm = torch.arange(1, self.nb_harmonics + 2, device=dev, dtype=pitch.dtype).view(1, -1, 1)
+        F_mat = pitch_samples * harm / self.sampling_rate
+        theta_mat = 2 * np.pi * (torch.cumsum(F_mat, dim=-1) % 1)
+        one = torch.ones((), device=dev)
+        phase_vec = Uniform(low=-np.pi * one, high=np.pi * one).sample(sample_shape=(pitch.size(0), self.nb_harmonics + 1, 1))
+        phase_vec[:, 0, :] = 0
+        noise = Normal(loc=0.0 * one, scale=self.sigma * one).sample(
+            sample_shape=(pitch_samples.size(0), self.nb_harmonics + 1, pitch_samples.size(-1)))
+        e_voice = self.alpha * torch.sin(theta_mat + phase_vec) + noise
+        e_unvoice = self.alpha / 3 / self.sigma * noise
+        return e_voice * uv_samples + e_unvoice * (1 - uv_samples)
+
+    def forward_cl(self, pitch, uv):
+        """-> (B, T, 1) channels-last excitation signal."""
+        e = self.excitation(pitch, uv).transpose(1, 2).contiguous()
+        c = self.ffn[0]
+        w, tap = conv_weight(c)
+        return torch.tanh(ops.conv_cl(e, w, c.bias, tap_major=tap))
+
+    def forward(self, pitch, uv):
+        return self.forward_cl(pitch, uv).transpose(1, 2)
+
+    def remove_weight_norm(self):
+        remove_weight_norm(self.ffn[0])

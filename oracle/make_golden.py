@@ -217,6 +217,35 @@ def sambert_se_case(name, B, T_in, min_len, dur_hi, seed_w=0, seed_b=555):
     print(name, "loss", float(total), "bytes", os.path.getsize(os.path.join(OUT, name + ".pt")))
 
 
+def nsf_generator_case():
+    """NSF HiFi-GAN generator (hifigan.py:22-197 with nsf_params, layers.py:229-290): forward + backward of the reference
+    at a small width; the excitation's random phase / noise come from torch's global CPU generator, seeded right before
+    the forward -- the product draws through the same torch.distributions calls, so a CPU run reproduces them."""
+    from kantts.models.hifigan.hifigan import Generator
+
+    res = {}
+    for causal in (True, False):
+        torch.manual_seed(3)
+        G = Generator(in_channels=80, channels=32, upsample_scales=[4, 4, 2, 2], upsample_kernal_sizes=[8, 8, 4, 4],
+                      causal=causal, nsf_params={"nb_harmonics": 7, "sampling_rate": 16000})
+        g = torch.Generator().manual_seed(11)
+        frames = 6
+        mel = torch.randn(2, 80, frames, generator=g)
+        f0 = 80 + 300 * torch.rand(2, 1, frames, generator=g)
+        uv = (torch.rand(2, 1, frames, generator=g) > 0.3).float()
+        x = torch.cat([mel, f0 * uv, uv], dim=1)
+        torch.manual_seed(1234)
+        y = G(x)
+        cot = torch.randn(y.shape, generator=g)
+        (y * cot).sum().backward()
+        gsum = {n: float(p.grad.double().norm()) for n, p in G.named_parameters() if p.grad is not None}
+        res["causal" if causal else "noncausal"] = dict(
+            x=x, y=y.detach().clone(), cot=cot, grad_norms=gsum, state_keys=sorted(G.state_dict().keys()),
+            weight_checksums=checksums(G.state_dict()))
+    torch.save(res, os.path.join(OUT, "hifigan_nsf.pt"))
+    print("hifigan_nsf bytes", os.path.getsize(os.path.join(OUT, "hifigan_nsf.pt")), float(res["causal"]["y"].abs().mean()))
+
+
 def mas_dp_case():
     """b_mas (alignment.py:63-71; numba replaced by the identity jit of ref_harness, i.e. its plain-Python semantics)
     on random soft maps, on maps with exact ties (uniform rows) and with zeros (log -> -inf)."""
@@ -262,3 +291,4 @@ if __name__ == "__main__":
     mas_dp_case()
     sambert_mas_case("sambert_tiny_mas", B=3, T_in=12, min_len=6, dur_hi=6)
     sambert_se_case("sambert_tiny_se", B=2, T_in=10, min_len=5, dur_hi=5)
+    nsf_generator_case()
