@@ -279,6 +279,8 @@ def main():
 
             step = GraphedSambertStep(net, optimizer, scheduler, mel_crit, pros_crit, batch,
                                       overlap_wgrad=not args.no_wgrad_overlap)
+            step()  # first replay (and, data-parallel, the first all-reduce between the two graphs) inside the guard
+            torch.cuda.synchronize()
         except Exception as exc:  # capture is an optimisation; say so loudly and measure the eager path
             print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" % (
                 type(exc).__name__, str(exc)[:300]), file=sys.stderr)
