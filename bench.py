@@ -285,6 +285,8 @@ def main():
             print("[bench] hipGraph capture failed (%s: %s); falling back to eager launches" % (
                 type(exc).__name__, str(exc)[:300]), file=sys.stderr)
             mode = "eager"
+            step = eager_step
+            hip.ops.wgrad_overlap.enable(False)
             net.device_band_width = False
             optimizer.dyn = None
 
