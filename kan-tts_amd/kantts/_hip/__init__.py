@@ -431,27 +431,23 @@ def profile_end():
 
 
 def profile_end_by_shape():
-    """Per distinct conv launch shape: count, total ms, TFLOP/s and algorithmic GB/s (conv launches only)."""
+    """Per distinct conv launch shape: count, total ms, flops and algorithmic bytes per launch (conv launches only;
+    scripts/conv_shape_bench.py prints the table)."""
     global _profile
     rec, _profile = _profile, None
     torch.cuda.synchronize()
-    by_flops = {}
-    for e0, e1, f in rec:
-        by_flops.setdefault(f, []).append(e0.elapsed_time(e1))
     out = {}
-    # conv records are matched to their tags through the flop count + order of appearance
-    it = iter(_profile_tags)
-    conv = [(e0.elapsed_time(e1), f) for e0, e1, f in rec]
     tags = list(_profile_tags)
     ci = 0
-    for ms, f in conv:
+    # GEMM launches carry no tag: a conv record is recognised by the flop count of the next unmatched tag
+    for e0, e1, f in rec:
         if ci < len(tags) and abs(_tag_flops(tags[ci]) - f) <= 1e-6 * max(1.0, f):
             kern, shape, nbytes = tags[ci]
             ci += 1
             key = kern + " " + " ".join("%s=%s" % kv for kv in shape.items())
             o = out.setdefault(key, dict(n=0, ms=0.0, flops=f, bytes=nbytes))
             o["n"] += 1
-            o["ms"] += ms
+            o["ms"] += e0.elapsed_time(e1)
     return out
 
 
