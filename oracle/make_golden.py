@@ -246,6 +246,43 @@ def nsf_generator_case():
     print("hifigan_nsf bytes", os.path.getsize(os.path.join(OUT, "hifigan_nsf.pt")), float(res["causal"]["y"].abs().mean()))
 
 
+def sambert_curve_case(steps=6):
+    """Loss curve of the reference's own training step (Sambert_Trainer.train_step, trainer.py:898-1005: forward, five
+    losses, backward, clip_grad_norm_(1.0), Adam(1e-3, (0.9, 0.98), eps 1e-9), NoamLR) over `steps` steps on cycling
+    batches, dropout off (eval mode; incl. the Prenet's hard-wired Dropout(0.5)), NoamLR warm-up shortened to 4 steps so
+    that the updates are large enough to bend the curve."""
+    from kantts.train.scheduler import NoamLR
+
+    cfg = O.sambert_config(tiny=True)
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(dict(cfg))
+    m.eval()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0)
+    sch = NoamLR(opt, warmup_steps=4)
+    batches = [O.synthetic_sambert_batch(B=3, T_in=12, seed=10 + s, min_len=6, dur_hi=6) for s in range(3)]
+    losses, lrs = [], []
+    for it in range(steps):
+        b = batches[it % len(batches)]
+        res = m(**b)
+        mel_, mel = MelReconLoss()(b["output_lengths"], b["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+        d, p, e = ProsodyReconLoss()(b["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                     res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                     res["energy_predictions"])
+        total = mel_ + mel + d + p + e
+        opt.zero_grad()
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+        losses.append(float(total))
+    # parameter checksums after the last update: the whole optimisation trajectory in a few numbers
+    fix = dict(cfg=cfg, steps=steps, losses=losses, lrs=lrs, final_checksums=checksums(m.state_dict()))
+    torch.save(fix, os.path.join(OUT, "sambert_tiny_curve.pt"))
+    print("curve", [round(x, 4) for x in losses], "bytes",
+          os.path.getsize(os.path.join(OUT, "sambert_tiny_curve.pt")))
+
+
 def mas_dp_case():
     """b_mas (alignment.py:63-71; numba replaced by the identity jit of ref_harness, i.e. its plain-Python semantics)
     on random soft maps, on maps with exact ties (uniform rows) and with zeros (log -> -inf)."""
@@ -292,3 +329,4 @@ if __name__ == "__main__":
     sambert_mas_case("sambert_tiny_mas", B=3, T_in=12, min_len=6, dur_hi=6)
     sambert_se_case("sambert_tiny_se", B=2, T_in=10, min_len=5, dur_hi=5)
     nsf_generator_case()
+    sambert_curve_case()

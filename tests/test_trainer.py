@@ -115,3 +115,63 @@ def test_gan_trainer_checkpoint_resume_emulated(tmp_path):
         st = torch.load(ck, map_location="cpu")
         assert set(st) == {"optimizer", "scheduler", "steps", "model"} and "generator" in st["model"]
         assert set(st["model"]["discriminator"]) == {"MultiPeriodDiscriminator"}
+
+
+# ---------------------------------------------------------------------------------------- loss curve vs the reference
+def _curve(device):
+    """Six training steps of Sambert_Trainer (fused clip + arena Adam + NoamLR) must retrace the loss curve the
+    reference's own train_step produced from the same seed (tests/golden/sambert_tiny_curve.pt)."""
+    from kantts.models import model_builder
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+    from kantts.train.trainer import Sambert_Trainer
+    from util import GOLDEN
+
+    fix = torch.load(os.path.join(GOLDEN, "sambert_tiny_curve.pt"), weights_only=False)
+    config = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": dict(fix["cfg"]),
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4}}}}, "grad_norm": 1.0, "batch_size": 3,
+        "log_interval_steps": 100}
+    torch.manual_seed(0)
+    model, opt, sch = model_builder(config, device=device)
+    net = model["KanTtsSAMBERT"]
+    net.eval()
+    crit = {"MelReconLoss": MelReconLoss(), "ProsodyReconLoss": ProsodyReconLoss()}
+    batches = []
+    for s in range(3):
+        b = O.synthetic_sambert_batch(B=3, T_in=12, seed=10 + s, min_len=6, dur_hi=6)
+        batches.append({"input_lings": b["inputs_ling"], "input_emotions": b["inputs_emotion"],
+                        "input_speakers": b["inputs_speaker"], "valid_input_lengths": b["input_lengths"],
+                        "valid_output_lengths": b["output_lengths"], "mel_targets": b["mel_targets"],
+                        "durations": b["duration_targets"], "pitch_contours": b["pitch_targets"],
+                        "energy_contours": b["energy_targets"], "attn_priors": None})
+    tr = Sambert_Trainer(config, model, opt, sch, crit, torch.device(device), None, batches, None, max_steps=10 ** 6,
+                         save_dir=None, save_interval=10 ** 6, valid_interval=10 ** 6, log_interval=100, grad_clip=1.0)
+    tr.set_model_state = lambda state="train": None
+    losses, lrs = [], []
+    for it in range(fix["steps"]):
+        lrs.append(opt["KanTtsSAMBERT"].param_groups[0]["lr"])
+        losses.append(float(tr.train_step(batches[it % 3]).detach()))
+        tr.steps += 1
+    for a, b in zip(lrs, fix["lrs"]):
+        assert abs(a - b) <= 1e-12 + 1e-9 * b, (lrs, fix["lrs"])
+    for a, b in zip(losses, fix["losses"]):
+        assert abs(a - b) <= 2e-4, (losses, fix["losses"])
+    sd = net.state_dict()
+    for k, (shape, s, a) in fix["final_checksums"].items():
+        assert tuple(sd[k].shape) == shape
+        tol = 2e-4 * max(1.0, a)
+        assert abs(float(sd[k].double().sum()) - s) <= tol and abs(float(sd[k].double().abs().sum()) - a) <= tol, k
+
+
+def test_sambert_loss_curve_matches_reference_emulated():
+    with emulation():
+        _curve("cpu")
+
+
+@pytest.mark.gpu
+def test_sambert_loss_curve_matches_reference_gpu():
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _curve("cuda")
