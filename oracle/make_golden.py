@@ -283,6 +283,71 @@ def sambert_curve_case(steps=6):
           os.path.getsize(os.path.join(OUT, "sambert_tiny_curve.pt")))
 
 
+GAN_CURVE_CONFIG = {
+    "model_type": "hifigan",
+    "Model": {
+        "Generator": {"params": {"channels": 32, "out_channels": 1},
+                      "optimizer": {"type": "Adam", "params": {"lr": 2e-3, "betas": [0.5, 0.9], "weight_decay": 0.0}},
+                      "scheduler": {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [3]}}},
+        "MultiPeriodDiscriminator": {
+            "params": {"periods": [2, 3]},
+            "optimizer": {"type": "Adam", "params": {"lr": 2e-3, "betas": [0.5, 0.9], "weight_decay": 0.0}},
+            "scheduler": {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [3]}}},
+        "MultiScaleDiscriminator": {
+            "params": {"scales": 2, "discriminator_params": {
+                "in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 3], "channels": 16,
+                "max_downsample_channels": 64, "max_groups": 4, "bias": True, "downsample_scales": [2, 2, 4, 4, 1],
+                "nonlinear_activation": "LeakyReLU", "nonlinear_activation_params": {"negative_slope": 0.1}}},
+            "optimizer": {"type": "Adam", "params": {"lr": 2e-3, "betas": [0.5, 0.9], "weight_decay": 0.0}},
+            "scheduler": {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [3]}}}},
+    "Loss": {"generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+             "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+             "mel_loss": {"enable": True, "params": {}, "weights": 45.0},
+             "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+    "generator_grad_norm": 10.0, "discriminator_grad_norm": -1,  # > 0 crashes the reference (trainer.py:583: dict.parameters())
+     "discriminator_train_start_steps": 0,
+    "generator_train_start_steps": 0,
+}
+
+
+def gan_curve_case(steps=4):
+    """Loss curve of the reference's GAN_Trainer.train_step (trainer.py:469-589) over `steps` steps: generator update
+    (mel + adversarial + feature matching), generator re-run, discriminator updates, gradient clipping on both sides,
+    MultiStepLR with a milestone inside the window; small widths (G 32 ch, MPD 2/3, MSD 2 scales x 16 ch).  The trainer's
+    own method is executed on a bare instance (its logging / IO shell is not constructed)."""
+    import copy
+    from collections import defaultdict
+
+    from kantts.models import model_builder
+    from kantts.train.loss import criterion_builder
+    from kantts.train.trainer import GAN_Trainer
+
+    config = copy.deepcopy(GAN_CURVE_CONFIG)
+    torch.manual_seed(0)
+    model, optimizer, scheduler = model_builder(config, "cpu", 0, False)
+    criterion = criterion_builder(config, "cpu")
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(2, 1, 2048, generator=g).clamp(-1, 1) * 0.5, torch.randn(2, 80, 8, generator=g))
+               for _ in range(2)]
+    tr = GAN_Trainer.__new__(GAN_Trainer)
+    tr.model, tr.optimizer, tr.scheduler, tr.criterion, tr.config = model, optimizer, scheduler, criterion, config
+    tr.device = torch.device("cpu")
+    tr.total_train_loss = defaultdict(float)
+    curve = []
+    init = {"generator": checksums(model["generator"].state_dict())}
+    for it in range(steps):
+        tr.steps = it + 1
+        before = dict(tr.total_train_loss)
+        tr.train_step(batches[it % 2])
+        curve.append({k.split("/")[1]: tr.total_train_loss[k] - before.get(k, 0.0) for k in tr.total_train_loss})
+    fix = dict(config=GAN_CURVE_CONFIG, steps=steps, curve=curve, init_checksums=init,
+               final_checksums={"generator": checksums(model["generator"].state_dict()),
+                                **{k: checksums(d.state_dict()) for k, d in model["discriminator"].items()}})
+    torch.save(fix, os.path.join(OUT, "hifigan_curve.pt"))
+    print("gan curve", [(round(c["generator_loss"], 4), round(c["discriminator_loss"], 4)) for c in curve], "bytes",
+          os.path.getsize(os.path.join(OUT, "hifigan_curve.pt")))
+
+
 def mas_dp_case():
     """b_mas (alignment.py:63-71; numba replaced by the identity jit of ref_harness, i.e. its plain-Python semantics)
     on random soft maps, on maps with exact ties (uniform rows) and with zeros (log -> -inf)."""
@@ -330,3 +395,4 @@ if __name__ == "__main__":
     sambert_se_case("sambert_tiny_se", B=2, T_in=10, min_len=5, dur_hi=5)
     nsf_generator_case()
     sambert_curve_case()
+    gan_curve_case()

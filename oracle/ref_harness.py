@@ -58,6 +58,22 @@ def _install_stubs():
         nb.prange = range
         sys.modules["numba"] = nb
 
+    # logging / plotting / audio-file IO of the trainer shell (kantts/train/trainer.py:6-11): no arithmetic behind them
+    for name in ("tensorboardX", "soundfile", "matplotlib", "matplotlib.pyplot"):
+        try:
+            __import__(name)
+        except ImportError:
+            m = types.ModuleType(name)
+            if name == "tensorboardX":
+                m.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None,
+                                                             "add_scalar": lambda self, *a, **k: None,
+                                                             "add_figure": lambda self, *a, **k: None})
+            if name == "matplotlib":
+                m.use = lambda *a, **k: None
+            sys.modules[name] = m
+    if "matplotlib.pyplot" in sys.modules and not hasattr(sys.modules["matplotlib"], "pyplot"):
+        sys.modules["matplotlib"].pyplot = sys.modules["matplotlib.pyplot"]
+
     if "ttsfrd" not in sys.modules:
         sys.modules["ttsfrd"] = types.ModuleType("ttsfrd")
     if "unidecode" not in sys.modules:

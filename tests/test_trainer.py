@@ -175,3 +175,54 @@ def test_sambert_loss_curve_matches_reference_gpu():
 
     hip.set_precision("fp32")
     _curve("cuda")
+
+
+def _gan_curve(device, tol):
+    """Four GAN steps (generator + MPD + MSD updates, generator clipping, an LR milestone inside the window) must retrace
+    the curve of the reference's GAN_Trainer.train_step (tests/golden/hifigan_curve.pt)."""
+    import copy
+
+    from kantts.models import model_builder
+    from kantts.train.gan_step import gan_train_step
+    from kantts.train.loss import criterion_builder
+    from util import GOLDEN
+
+    fix = torch.load(os.path.join(GOLDEN, "hifigan_curve.pt"), weights_only=False)
+    config = copy.deepcopy(fix["config"])
+    torch.manual_seed(0)
+    model, optimizer, scheduler = model_builder(config, device=device)
+    crit = criterion_builder(config, device=device)
+    for k, (shape, s, a) in fix["init_checksums"]["generator"].items():
+        v = model["generator"].state_dict()[k]
+        assert tuple(v.shape) == shape and abs(float(v.double().sum()) - s) <= 1e-6 * max(1.0, a), k
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(2, 1, 2048, generator=g).clamp(-1, 1) * 0.5, torch.randn(2, 80, 8, generator=g))
+               for _ in range(2)]
+    got = []
+    for it in range(fix["steps"]):
+        y, x = batches[it % 2]
+        out = gan_train_step(model, optimizer, scheduler, crit, config, y.to(device), x.to(device), steps=it + 1)
+        got.append({k: float(v.detach()) for k, v in out.items()})
+    keys = ["generator_loss", "discriminator_loss", "mel_loss", "feature_matching_loss", "real_loss", "fake_loss"]
+    for it, (a, b) in enumerate(zip(got, fix["curve"])):
+        for k in keys:
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(b[k])), (it, k, a[k], b[k])
+    nets = {"generator": model["generator"], **model["discriminator"]}
+    for name, ref in fix["final_checksums"].items():
+        sd = nets[name].state_dict()
+        for k, (shape, s, a) in ref.items():
+            assert abs(float(sd[k].double().abs().sum()) - a) <= 5 * tol * max(1.0, a), (name, k)
+    return got
+
+
+def test_gan_loss_curve_matches_reference_emulated():
+    with emulation():
+        _gan_curve("cpu", tol=2e-3)
+
+
+@pytest.mark.gpu
+def test_gan_loss_curve_matches_reference_gpu():
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _gan_curve("cuda", tol=5e-3)
