@@ -9,7 +9,7 @@ import math
 
 import torch
 
-from . import (PREC_REF, check, get_precision, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
+from . import (check, get_precision, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
 
 _seed_counter = itertools.count(1)
 

@@ -1,7 +1,6 @@
 """Variance-adaptor building blocks on HIP kernels (reference kantts/models/sambert/adaptors.py:9-141)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from kantts._hip import ops
 from kantts.models.sambert import Prenet

@@ -11,7 +11,6 @@ It is injected ONLY by test fixtures (tests/conftest.py::emulated_cabi).  The pr
 this file and has no CPU fallback; bench.py / smoke() never enable it.
 """
 import ctypes
-import math
 
 import numpy as np
 import torch

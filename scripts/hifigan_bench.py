@@ -10,7 +10,6 @@ sys.path.insert(0, os.path.join(ROOT, "kan-tts_amd"))
 import torch
 
 import kantts._hip as hip
-from kantts._hip import ops
 from kantts.models import model_builder
 from kantts.train.gan_step import gan_train_step
 from kantts.train.loss import criterion_builder

@@ -1,7 +1,6 @@
 """GPU micro-benchmarks of single kernels (HIP events on the launch stream)."""
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kan-tts_amd"))

@@ -9,7 +9,7 @@ import torch
 import audio_oracle as A
 import hifigan_oracle as H
 import torch_oracle as O
-from util import assert_close, emulation, rel_l2
+from util import assert_close, emulation
 
 
 def _sambert_ragged(device):

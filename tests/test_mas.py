@@ -11,7 +11,6 @@ import numpy as np
 import pytest
 import torch
 
-import torch_oracle as O
 from util import GOLDEN, assert_close, rel_l2, run_both
 
 

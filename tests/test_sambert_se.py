@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import GOLDEN, rel_l2
+from util import GOLDEN
 
 
 def _run(device):

@@ -1,7 +1,6 @@
 """Shared helpers for the test-suite."""
 import contextlib
 import os
-import sys
 
 import torch
 
