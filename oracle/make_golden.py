@@ -348,6 +348,53 @@ def gan_curve_case(steps=4):
           os.path.getsize(os.path.join(OUT, "hifigan_curve.pt")))
 
 
+def voc_dataset_case():
+    """Items of the reference's Voc_Dataset (datasets/dataset.py:88-276) over a small synthetic data directory: plain and
+    NSF configuration, an utterance shorter than a crop (zero-padded branch) and longer ones (reflect-padded branch).
+    The raw file contents travel in the fixture so that the test can rebuild the directory."""
+    import tempfile
+
+    import numpy as np
+    from scipy.io import wavfile
+
+    import kantts.datasets.dataset as D
+
+    rs = np.random.RandomState(21)
+    hop, sr = 200, 16000
+    utts = {}
+    for name, frames in (("a01", 30), ("a02", 9), ("a03", 21), ("a04", 16)):
+        n = frames * hop - rs.randint(0, hop)  # the wav is a little shorter than frames * hop, as after trimming
+        utts[name] = dict(wav=np.clip(np.round(rs.randn(n) * 3000), -32768, 32767).astype(np.int16),
+                          mel=rs.randn(frames, 80).astype(np.float32), f0=rs.randn(frames).astype(np.float32),
+                          uv=(rs.rand(frames) > 0.4).astype(np.float32))
+    f0_mean, f0_std = 187.25, 41.5
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for sub in ("wav", "mel", "frame_f0", "frame_uv", "f0"):
+            os.makedirs(os.path.join(d, sub))
+        for name, u in utts.items():
+            wavfile.write(os.path.join(d, "wav", name + ".wav"), sr, u["wav"])
+            np.save(os.path.join(d, "mel", name + ".npy"), u["mel"])
+            np.save(os.path.join(d, "frame_f0", name + ".npy"), u["f0"])
+            np.save(os.path.join(d, "frame_uv", name + ".npy"), u["uv"])
+        np.savetxt(os.path.join(d, "f0", "f0_mean.txt"), np.array([f0_mean]))
+        np.savetxt(os.path.join(d, "f0", "f0_std.txt"), np.array([f0_std]))
+        with open(os.path.join(d, "train.lst"), "w") as f:
+            f.write("\n".join(sorted(utts)) + "\n")
+        for tag, nsf in (("plain", None), ("nsf", {"nb_harmonics": 7, "sampling_rate": sr})):
+            config = {"audio_config": {"sampling_rate": sr, "n_fft": 2048, "hop_length": hop}, "batch_max_steps": 3200,
+                      "allow_cache": False, "Model": {"Generator": {"params": {"nsf_params": nsf}}}}
+            ds = D.Voc_Dataset([os.path.join(d, "train.lst")], [d], config)
+            items = [ds[i] for i in range(len(ds))]
+            np.random.seed(9)
+            wav_b, mel_b = ds.collate_fn(items)
+            out[tag] = dict(items=[(np.asarray(w), np.asarray(m)) for w, m in items], batch=(wav_b, mel_b))
+    torch.save(dict(utts=utts, f0_mean=f0_mean, f0_std=f0_std, hop=hop, sr=sr, n_fft=2048, batch_max_steps=3200,
+                    collate_seed=9, expected=out), os.path.join(OUT, "voc_dataset.pt"))
+    print("voc_dataset bytes", os.path.getsize(os.path.join(OUT, "voc_dataset.pt")),
+          [tuple(m.shape) for _, m in out["nsf"]["items"]])
+
+
 def mas_dp_case():
     """b_mas (alignment.py:63-71; numba replaced by the identity jit of ref_harness, i.e. its plain-Python semantics)
     on random soft maps, on maps with exact ties (uniform rows) and with zeros (log -> -inf)."""
@@ -396,3 +443,4 @@ if __name__ == "__main__":
     nsf_generator_case()
     sambert_curve_case()
     gan_curve_case()
+    voc_dataset_case()

@@ -38,8 +38,13 @@ def _install_stubs():
         filters = types.ModuleType("librosa.filters")
         filters.mel = thirdparty.librosa_mel
         librosa.filters = filters
+        core = types.ModuleType("librosa.core")  # Voc_Dataset.__getitem__ (datasets/dataset.py:238): file IO only
+        core.load = thirdparty.wav_load
+        librosa.core = core
+        librosa.load = thirdparty.wav_load
         sys.modules["librosa"] = librosa
         sys.modules["librosa.filters"] = filters
+        sys.modules["librosa.core"] = core
 
     if "pytorch_wavelets" not in sys.modules:  # kantts/models/hifigan/hifigan.py:7
         pw = types.ModuleType("pytorch_wavelets")

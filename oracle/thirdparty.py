@@ -115,3 +115,16 @@ class DWT1DForward(nn.Module):
     def forward(self, x):
         lo, hi = dwt_db3_zero(x)
         return lo, [hi]
+
+
+def wav_load(path, sr=None):
+    """Stand-in for librosa.load on PCM files that are already at ``sr`` (no resampling here): int16 / 32768 as float32,
+    which is what librosa / soundfile return for 16-bit PCM."""
+    from scipy.io import wavfile
+
+    rate, data = wavfile.read(path)
+    if sr is not None and rate != sr:
+        raise ValueError("stand-in loader: %s is at %d Hz, asked for %d Hz" % (path, rate, sr))
+    if data.dtype == np.int16:
+        data = (data / 32768.0).astype(np.float32)
+    return data.astype(np.float32), rate

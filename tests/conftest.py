@@ -30,7 +30,9 @@ def _emulate(monkeypatch):
         assert not t.is_cuda
         return t.data_ptr()
 
-    for mod in (hip, ops):
+    import kantts.utils.audio_torch as audio_torch  # binds lib / ptr / stream by name at import time
+
+    for mod in (hip, ops, audio_torch):
         monkeypatch.setattr(mod, "lib", lambda: emu, raising=True)
         monkeypatch.setattr(mod, "ptr", ptr, raising=True)
         monkeypatch.setattr(mod, "stream", lambda: None, raising=True)
