@@ -149,10 +149,41 @@ def get_voc_datasets(config, root_dir, split_ratio=0.98):
     return Voc_Dataset(train_meta_lst, root_dir, config), Voc_Dataset(valid_meta_lst, root_dir, config)
 
 
+def reference_dataset_module():
+    """The reference's own kantts/datasets/dataset.py loaded from the checkout named by KANTTS_REFERENCE_ROOT (its
+    imports of kantts.utils.ling_unit etc. resolve through the same overlay); None without a checkout."""
+    import importlib.util
+    import sys
+
+    import kantts
+
+    name = "kantts.datasets._reference_dataset"
+    if name in sys.modules:
+        return sys.modules[name]
+    if not kantts.REFERENCE_ROOT:
+        return None
+    path = os.path.join(kantts.REFERENCE_ROOT, "kantts", "datasets", "dataset.py")
+    if not os.path.exists(path):
+        return None
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    try:
+        spec.loader.exec_module(mod)
+    except Exception:
+        del sys.modules[name]
+        raise
+    return mod
+
+
 def get_am_datasets(*args, **kwargs):
-    raise ImportError("the acoustic-model dataset needs the text front-end's symbol tables (kantts.utils.ling_unit of the "
-                      "reference package); batch assembly itself is kantts.datasets.batching.am_collate -- "
-                      "use --synthetic N or the reference's dataset module for SAM-BERT training")
+    """SAM-BERT datasets: the reference's AM_Dataset (symbol tables, metafile parsing, feature files) from a checkout,
+    when one is configured; its batches are what kantts.datasets.batching.am_collate reproduces."""
+    ref = reference_dataset_module()
+    if ref is None:
+        raise ImportError("the acoustic-model dataset needs the text front-end's symbol tables, which live with the "
+                          "reference package: set KANTTS_REFERENCE_ROOT to a KAN-TTS checkout, or pass --synthetic N")
+    return ref.get_am_datasets(*args, **kwargs)
 
 
 logging.getLogger(__name__).addHandler(logging.NullHandler())

@@ -114,3 +114,44 @@ def test_wav_to_batches_chain_emulated(tmp_path, emulated_cabi):
 @pytest.mark.gpu
 def test_wav_to_batches_chain_gpu(tmp_path):
     _chain(tmp_path, "cuda")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/kantts"), reason="needs a reference checkout (build container only)")
+def test_reference_overlay_supplies_the_text_side_only(tmp_path):
+    """KANTTS_REFERENCE_ROOT: modules this package does not ship (ling_unit, the AM dataset) resolve from the checkout,
+    modules it does ship still come from here, and models / train never fall back to reference code."""
+    import subprocess
+    import sys
+
+    from util import ROOT
+
+    code = """
+import sys, types
+for name in ('ttsfrd', 'unidecode', 'inflect'):            # text-normalisation wheels of the reference's environment
+    sys.modules[name] = types.ModuleType(name)
+sys.modules['unidecode'].unidecode = lambda s: s
+sys.modules['inflect'].engine = lambda: None
+import kantts, kantts.utils.audio_torch as at, kantts.datasets.dataset as ds
+from kantts.utils.ling_unit.ling_unit import KanTtsLinguisticUnit
+import kantts.utils.ling_unit.ling_unit as lu
+assert lu.__file__.startswith('/root/reference/'), lu.__file__
+assert at.__file__.startswith(%r) and ds.__file__.startswith(%r)
+try:
+    import kantts.models.pqmf
+    raise SystemExit('models fell back to the reference')
+except ImportError:
+    pass
+try:
+    ref = ds.reference_dataset_module()
+    print('AM_Dataset from', ref.AM_Dataset.__module__)
+except ImportError as e:                                   # librosa etc. are not installed in this container
+    print('reference dataset import needs', e)
+print('overlay ok')
+""" % (os.path.join(ROOT, "kan-tts_amd"), os.path.join(ROOT, "kan-tts_amd"))
+    env = dict(os.environ, KANTTS_REFERENCE_ROOT="/root/reference", PYTHONPATH=os.path.join(ROOT, "kan-tts_amd"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "overlay ok" in out.stdout, out.stdout + out.stderr
+    # without the variable nothing of the checkout is reachable
+    env.pop("KANTTS_REFERENCE_ROOT")
+    out = subprocess.run([sys.executable, "-c", "import kantts.utils.ling_unit"], env=env, capture_output=True, text=True)
+    assert out.returncode != 0 and "ModuleNotFoundError" in out.stderr
