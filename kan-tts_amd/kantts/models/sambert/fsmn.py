@@ -11,8 +11,10 @@ class FeedForwardNet(nn.Module):
 
     def __init__(self, d_in, d_hid, d_out, kernel_size=[1, 1], dropout=0.1):
         super().__init__()
-        self.w_1 = nn.Conv1d(d_in, d_hid, kernel_size=kernel_size[0], padding=(kernel_size[0] - 1) // 2)
-        self.w_2 = nn.Conv1d(d_hid, d_out, kernel_size=kernel_size[1], padding=(kernel_size[1] - 1) // 2, bias=False)
+        k_in, k_out = kernel_size
+        # parameter holders (checkpoint keys w_1.{weight,bias}, w_2.weight); creation order fixes the seeded init
+        self.w_1 = nn.Conv1d(d_in, d_hid, k_in, padding=(k_in - 1) // 2)
+        self.w_2 = nn.Conv1d(d_hid, d_out, k_out, padding=(k_out - 1) // 2, bias=False)
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
@@ -27,13 +29,13 @@ class MemoryBlockV2(nn.Module):
 
     def __init__(self, d, filter_size, shift, dropout=0.0):
         super(MemoryBlockV2, self).__init__()
-        left_padding = int(round((filter_size - 1) / 2))
-        right_padding = int((filter_size - 1) / 2)
-        if shift > 0:
-            left_padding += shift
-            right_padding -= shift
-        self.lp, self.rp = left_padding, right_padding
-        self.conv_dw = nn.Conv1d(d, d, filter_size, 1, 0, groups=d, bias=False)
+        # taps before / after the current frame: round-half-even on the left (the reference's int(round(.))), floor on
+        # the right; a positive shift moves `shift` taps from the future to the past (look-back only postnet)
+        span = filter_size - 1
+        look_back = max(shift, 0)
+        self.lp = int(round(span / 2)) + look_back
+        self.rp = span // 2 - look_back
+        self.conv_dw = nn.Conv1d(d, d, filter_size, stride=1, padding=0, groups=d, bias=False)
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, input, mask=None, res=None):
@@ -53,21 +55,15 @@ class FsmnEncoderV2(nn.Module):
     def __init__(self, filter_size, fsmn_num_layers, input_dim, num_memory_units, ffn_inner_dim, dropout=0.0,
                  shift=0):
         super(FsmnEncoderV2, self).__init__()
-        self.filter_size = filter_size
-        self.fsmn_num_layers = fsmn_num_layers
-        self.num_memory_units = num_memory_units
-        self.ffn_inner_dim = ffn_inner_dim
+        self.filter_size, self.fsmn_num_layers = filter_size, fsmn_num_layers
+        self.num_memory_units, self.ffn_inner_dim = num_memory_units, ffn_inner_dim
         self.dropout = dropout
-        self.shift = shift
-        if not isinstance(shift, list):
-            self.shift = [shift for _ in range(self.fsmn_num_layers)]
-        self.ffn_lst = nn.ModuleList()
-        self.ffn_lst.append(FeedForwardNet(input_dim, ffn_inner_dim, num_memory_units, dropout=dropout))
-        for i in range(1, fsmn_num_layers):
-            self.ffn_lst.append(FeedForwardNet(num_memory_units, ffn_inner_dim, num_memory_units, dropout=dropout))
-        self.memory_block_lst = nn.ModuleList()
-        for i in range(fsmn_num_layers):
-            self.memory_block_lst.append(MemoryBlockV2(num_memory_units, filter_size, self.shift[i], dropout))
+        self.shift = list(shift) if isinstance(shift, list) else [shift] * fsmn_num_layers
+        widths = [input_dim] + [num_memory_units] * (fsmn_num_layers - 1)  # only the first layer sees the input width
+        self.ffn_lst = nn.ModuleList(
+            FeedForwardNet(w, ffn_inner_dim, num_memory_units, dropout=dropout) for w in widths)
+        self.memory_block_lst = nn.ModuleList(
+            MemoryBlockV2(num_memory_units, filter_size, s, dropout) for s in self.shift[:fsmn_num_layers])
 
     def forward(self, input, mask=None):
         info = SeqInfo.of(mask)
