@@ -3,7 +3,8 @@
 Mirrors kantts/bin/infer_hifigan.py:34-163 of the reference (same function names, arguments, checkpoint layout
 ``states["model"]["generator"]``, ``<ckpt>/../../config.yaml`` discovery, ``<utt>_gen.wav`` outputs).  The generator
 runs on the MI355X kernels (kantts/models/hifigan); wav files are written with scipy (soundfile is not a
-dependency here).  PQMF / NSF generators are outside the hot path.
+dependency here).  NSF generators take (T, C + 2) features whose last column (voiced flag) is re-binarised first, as in
+the reference (:52-63, :112-113); multi-band (PQMF) generators are refused.
 """
 import argparse
 import glob
@@ -47,6 +48,13 @@ def load_model(ckpt, config=None):
     return model
 
 
+def binarize(mel, threshold=0.6):
+    """NSF features: the voiced / unvoiced column (last) predicted by the acoustic model back to {0, 1}."""
+    out = np.array(mel, copy=True)
+    out[:, -1] = (mel[:, -1] >= threshold).astype(out.dtype)
+    return out
+
+
 def _device():
     return torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
 
@@ -71,7 +79,10 @@ def hifigan_infer(input_mel, ckpt_path, output_dir, config=None):
         start = time.time()
         for mel in mel_lst:
             utt_id = os.path.splitext(os.path.basename(mel))[0]
-            mel_data = torch.from_numpy(np.load(mel)).float().to(device)
+            feats = np.load(mel)
+            if model.nsf_enable:
+                feats = binarize(feats)
+            mel_data = torch.from_numpy(np.ascontiguousarray(feats)).float().to(device)
             y = model(mel_data.transpose(1, 0).unsqueeze(0))  # (T, C) -> (1, C, T)
             y = y.view(-1).cpu().numpy()
             pcm_len += len(y)
