@@ -872,6 +872,7 @@ class _ConvCL(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has = (bias is not None, res is not None)
         ctx.save_for_backward(x, w, y if cfg["out_leaky"] is not None else None)
+        ctx.res_for_gate = r if cfg["out_leaky"] is not None else None  # y = act(conv) + res: the gate is sign(y - res)
         # one input channel (first discriminator layers): streaming kernels, weights stay (Cout, K)
         ctx.c1 = (Cin == 1 and groups == 1 and up == 1 and res is None and cfg["in_leaky"] is None and not tap_major)
         if ctx.c1 and conv_c1(0, x=x, y=y, w=w, bias=bias, B=B, Tsrc=Tin, Tdst=Tout, Cout=Cout, K=K, stride=stride,
@@ -913,6 +914,8 @@ class _ConvCL(torch.autograd.Function):
             Cout, Cin_g, K = w.shape
         Cout_g = Cout // groups
         gate, gslope = (y, cfg["out_leaky"]) if cfg["out_leaky"] is not None else (None, 0.0)
+        if gate is not None and ctx.res_for_gate is not None:
+            gate = y - ctx.res_for_gate  # (no shipped model combines an output activation with a residual)
         dx = dw = db = None
         if ctx.c1:
             kw = dict(B=B, Tsrc=Tin, Tdst=Tout, Cout=Cout, K=K, stride=stride, dil=dil, pad=pad, inner=inner, gate=gate,
