@@ -197,7 +197,14 @@ class _FusedLinear(torch.autograd.Function):
              relu=relu, T=T, drop_p=drop_p, drop_seed=seed)
         ctx.opts, ctx.seed, ctx.M, ctx.N, ctx.lead = opts, seed, M, N, lead
         ctx.has = (bias is not None, bias2 is not None, res is not None)
-        ctx.save_for_backward(y if relu else None, rm, *xs, *ws)
+        # ReLU backward gates on the activation's own output; with a residual on top that is y - res (no shipped model
+        # combines the two, the plain case keeps y itself), zeroed rows stay closed
+        gate_src = None
+        if relu:
+            gate_src = y if r is None else (y - r)
+            if r is not None and rm is not None:
+                gate_src = gate_src.masked_fill(rm.bool().view(M, 1), 0.0)
+        ctx.save_for_backward(gate_src, rm, *xs, *ws)
         return y.view(*lead, N)
 
     @staticmethod

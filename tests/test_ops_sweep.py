@@ -1,0 +1,231 @@
+"""Randomised sweeps of the SAM-BERT op wrappers (kantts._hip.ops through the emulated C ABI) against plain torch / the
+oracle's building blocks: fused linear in its three modes with every epilogue option, self / PNCA band attention over
+ragged lengths and band widths, (Bi)LSTM with packed-sequence semantics, FSMN memory, length regulator, embedding sum,
+masked L1.  Forward and gradients; fixed seeds; small shapes (a few seconds)."""
+import random
+
+import torch
+import torch.nn.functional as F
+
+import torch_oracle as O
+from util import rel_l2
+
+
+def _grads(out, cot, leaves):
+    return torch.autograd.grad((out * cot).sum(), leaves, allow_unused=True)
+
+
+def _cmp(got, exp, cfg, tol=2e-5):
+    for a, e in zip(got, exp):
+        if e is None:
+            assert a is None or float(a.abs().max()) == 0.0, cfg
+            continue
+        assert a is not None, cfg
+        assert rel_l2(a, e) < tol or float((a - e).abs().max()) < 1e-6, (cfg, rel_l2(a, e))
+
+
+def test_fused_linear_modes(emulated_cabi):
+    from kantts._hip import ops
+
+    rnd = random.Random(5)
+    g = torch.Generator().manual_seed(5)
+    for it in range(30):
+        mode = rnd.choice(["concat", "sum", "conv"])
+        B, T = rnd.choice([1, 2, 3]), rnd.randint(1, 19)
+        N = rnd.choice([1, 3, 8, 33, 64])
+        relu, alpha = rnd.random() < 0.4, rnd.choice([1.0, 0.5])
+        if mode == "conv":
+            cin, kt = rnd.choice([1, 4, 7, 32]), rnd.choice([1, 3, 9])
+            pad, dil = (kt - 1) // 2, 1
+            xs = [torch.randn(B, T, cin, generator=g).requires_grad_(True)]
+            ws = [(torch.randn(N, cin, kt, generator=g) / (cin * kt) ** 0.5).requires_grad_(True)]
+            ref = F.conv1d(xs[0].transpose(1, 2), ws[0], None, padding=pad).transpose(1, 2)
+            kw = dict(mode="conv", pad=pad, dilation=dil)
+        else:
+            ks = [rnd.choice([1, 5, 16, 40]) for _ in range(rnd.choice([1, 2, 3]))]
+            xs = [torch.randn(B, T, k, generator=g).requires_grad_(True) for k in ks]
+            if mode == "concat":
+                ws = [(torch.randn(N, sum(ks), generator=g) / sum(ks) ** 0.5).requires_grad_(True)]
+                ref = F.linear(torch.cat(xs, -1), ws[0])
+            else:
+                ws = [(torch.randn(N, k, generator=g) / k ** 0.5).requires_grad_(True) for k in ks]
+                ref = sum(F.linear(x, w) for x, w in zip(xs, ws))
+            kw = dict(mode=mode)
+        bias = torch.randn(N, generator=g).requires_grad_(True) if rnd.random() < 0.7 else None
+        bias2 = torch.randn(N, generator=g).requires_grad_(True) if (bias is not None and rnd.random() < 0.3) else None
+        res = torch.randn(B, T, N, generator=g).requires_grad_(True) if rnd.random() < 0.4 else None
+        rowmask = (torch.rand(B, T, generator=g) < 0.3) if rnd.random() < 0.4 else None
+        if bias is not None:
+            ref = ref + bias
+        if bias2 is not None:
+            ref = ref + bias2
+        ref = ref * alpha
+        if relu:
+            ref = torch.relu(ref)
+        if res is not None:
+            ref = ref + res
+        if rowmask is not None:
+            ref = ref.masked_fill(rowmask[..., None], 0.0)
+        cfg = dict(it=it, mode=mode, B=B, T=T, N=N, relu=relu, alpha=alpha, bias=bias is not None, bias2=bias2 is not None,
+                   res=res is not None, rowmask=rowmask is not None, shapes=[tuple(x.shape) for x in xs])
+        y = ops.linear(xs if len(xs) > 1 else xs[0], ws if len(ws) > 1 else ws[0], bias, bias2=bias2, res=res,
+                       rowmask=rowmask, relu=relu, alpha=alpha, **kw)
+        assert float((y - ref).detach().abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max())), cfg
+        cot = torch.randn(ref.shape, generator=g)
+        leaves = [t for t in (*xs, *ws, bias, bias2, res) if t is not None]
+        _cmp(_grads(y, cot, leaves), _grads(ref, cot, leaves), cfg)
+
+
+def test_attention_ragged_lengths_and_bands(emulated_cabi):
+    from kantts._hip import ops
+
+    rnd = random.Random(11)
+    g = torch.Generator().manual_seed(11)
+    for it in range(12):
+        B, L, H = rnd.choice([1, 2, 4]), rnd.randint(1, 23), rnd.choice([1, 2, 8])
+        D = H * 16
+        lens = torch.tensor([rnd.randint(1, L) for _ in range(B)])
+        lens[rnd.randrange(B)] = L
+        pad = O.pad_mask(lens, L)
+        qkv = torch.randn(B, L, 3 * D, generator=g).requires_grad_(True)
+        cfg = dict(it=it, B=B, L=L, H=H, lens=lens.tolist())
+        # encoder self-attention: keys beyond the length are masked for every query
+        o, _ = ops.self_attention(qkv, lens.to(torch.int32), H)
+        q, k, v = (O._split_heads(t, H) for t in qkv.chunk(3, -1))
+        ro, _ = O._attend(q, k, v, pad[:, None, :].expand(-1, L, -1).repeat(H, 1, 1))
+        ro = O._merge_heads(ro, H)
+        valid = (~pad)[..., None]
+        assert float(((o - ro) * valid).detach().abs().max()) < 2e-5, cfg
+        cot = torch.randn(B, L, D, generator=g) * valid
+        _cmp(_grads(o, cot, [qkv]), _grads(ro, cot, [qkv]), cfg)
+        # decoder PNCA attention: causal x-band over its own keys, look-ahead h-band over the memory
+        bwx, bwh = rnd.randint(0, L + 2), rnd.randint(0, L + 2)
+        hkv = torch.randn(B, L, 2 * D, generator=g).requires_grad_(True)
+        ox, oh, _, _ = ops.pnca_attention(qkv, hkv, lens.to(torch.int32), bwx, bwh, H)
+        xm, hm = O.pnca_masks(L, bwx, bwh, pad, qkv.device)
+        hk, hv = (O._split_heads(t, H) for t in hkv.chunk(2, -1))
+        rx, _ = O._attend(q, k, v, xm.expand(B, -1, -1).repeat(H, 1, 1))
+        rh, _ = O._attend(q, hk, hv, hm.expand(B, -1, -1).repeat(H, 1, 1))
+        rx, rh = O._merge_heads(rx, H), O._merge_heads(rh, H)
+        cfg.update(bwx=bwx, bwh=bwh)
+        assert float(((ox - rx) * valid).detach().abs().max()) < 2e-5, cfg
+        assert float(((oh - rh) * valid).detach().abs().max()) < 2e-5, cfg
+        c2 = torch.randn(B, L, D, generator=g) * valid
+        got = torch.autograd.grad((ox * cot).sum() + (oh * c2).sum(), [qkv, hkv])  # one pass: both outputs share a node
+        exp = torch.autograd.grad((rx * cot).sum() + (rh * c2).sum(), [qkv, hkv])
+        _cmp(got, exp, cfg)
+
+
+def test_lstm_uni_and_bidirectional_with_lengths(emulated_cabi):
+    from kantts._hip import ops
+
+    rnd = random.Random(3)
+    g = torch.Generator().manual_seed(3)
+    for it in range(8):
+        B, T, H = rnd.choice([1, 2, 3]), rnd.randint(1, 9), 128
+        ndir = rnd.choice([1, 2])
+        ks = [rnd.choice([3, 16, 32]) for _ in range(rnd.choice([1, 2]))]
+        xs = [torch.randn(B, T, k, generator=g).requires_grad_(True) for k in ks]
+        use_len = ndir == 2 or rnd.random() < 0.5
+        lens = torch.tensor([rnd.randint(1, T) for _ in range(B)]) if use_len else None
+        if lens is not None:
+            lens[0] = T
+        params = []
+        for _ in range(ndir):
+            params += [(torch.randn(4 * H, sum(ks), generator=g) * 0.1).requires_grad_(True),
+                       (torch.randn(4 * H, H, generator=g) * 0.05).requires_grad_(True),
+                       (torch.randn(4 * H, generator=g) * 0.1).requires_grad_(True),
+                       (torch.randn(4 * H, generator=g) * 0.1).requires_grad_(True)]
+        y = ops.lstm(xs, params, None if lens is None else lens.to(torch.int32))
+        xcat = torch.cat(xs, -1)
+        ref = torch.cat([O.lstm_layer(xcat, *params[4 * d:4 * d + 4], lengths=lens, reverse=(d == 1))
+                         for d in range(ndir)], -1)
+        cfg = dict(it=it, B=B, T=T, ndir=ndir, ks=ks, lens=None if lens is None else lens.tolist())
+        assert float((y - ref).detach().abs().max()) < 2e-5, cfg
+        cot = torch.randn(ref.shape, generator=g)
+        _cmp(_grads(y, cot, xs + params), _grads(ref, cot, xs + params), cfg, tol=5e-5)
+
+
+def test_fsmn_memory_length_regulator_embedding_and_masked_l1(emulated_cabi):
+    from kantts._hip import ops
+
+    rnd = random.Random(8)
+    g = torch.Generator().manual_seed(8)
+    for it in range(10):
+        B, T, C = rnd.choice([1, 2, 3]), rnd.randint(1, 30), rnd.choice([4, 32, 128])
+        lens = torch.tensor([rnd.randint(1, T) for _ in range(B)])
+        lens[-1] = T
+        pad = O.pad_mask(lens, T)
+        # FSMN memory: masked input -> depth-wise FIR with (lp, rp) zero padding -> + input -> masked (+ res)
+        K = rnd.choice([3, 11, 41])
+        lp = rnd.randint(0, K - 1)
+        x = torch.randn(B, T, C, generator=g).requires_grad_(True)
+        w = (torch.randn(C, 1, K, generator=g) / K ** 0.5).requires_grad_(True)
+        res = torch.randn(B, T, C, generator=g).requires_grad_(True) if rnd.random() < 0.5 else None
+        y = ops.fsmn_memory(x, w, lens, lp, res=res)
+        xm = x.masked_fill(pad[..., None], 0.0)
+        ref = F.conv1d(F.pad(xm.transpose(1, 2), (lp, K - 1 - lp)), w, groups=C).transpose(1, 2) + xm
+        ref = ref.masked_fill(pad[..., None], 0.0)
+        if res is not None:
+            ref = ref + res
+        cfg = dict(it=it, B=B, T=T, C=C, K=K, lp=lp, lens=lens.tolist(), res=res is not None)
+        assert float((y - ref).detach().abs().max()) < 2e-5, cfg
+        cot = torch.randn(ref.shape, generator=g)
+        leaves = [t for t in (x, w, res) if t is not None]
+        _cmp(_grads(y, cot, leaves), _grads(ref, cot, leaves), cfg)
+        # masked L1: mean |pred - target| over valid rows (all channels)
+        p = torch.randn(B, T, C, generator=g).requires_grad_(True)
+        t = torch.randn(B, T, C, generator=g)
+        loss = ops.masked_l1(p, t, lens)
+        valid = (~pad)[..., None].float()
+        rloss = ((p - t).abs() * valid).sum() / (valid.sum() * C)
+        assert abs(float(loss.detach()) - float(rloss.detach())) < 1e-5, cfg
+        _cmp(torch.autograd.grad(loss, [p]), torch.autograd.grad(rloss, [p]), cfg)
+    for it in range(8):
+        # length regulator: token n repeated trunc(dur + 0.5) times, frames beyond the total are empty
+        B, N, C = rnd.choice([1, 2, 4]), rnd.randint(1, 12), rnd.choice([4, 32])
+        as_float = rnd.random() < 0.5
+        dur = torch.randint(0, 5, (B, N), generator=g)
+        durs = (dur.float() + (torch.rand(B, N, generator=g) - 0.5) * 0.98) if as_float else dur
+        reps = (durs.float() + 0.5).long() if as_float else dur
+        Tp = int(reps.sum(1).max()) + rnd.randint(0, 3)
+        if Tp == 0:
+            continue
+        idx, pos, cs, tot = ops.lr_index(durs if as_float else durs.long(), Tp)
+        assert torch.equal(tot, reps.sum(1)), (it, durs, tot)
+        for b in range(B):
+            exp = torch.repeat_interleave(torch.arange(N), reps[b])
+            assert torch.equal(idx[b, :len(exp)].long(), exp) and torch.all(idx[b, len(exp):] == -1)
+            within = torch.cat([torch.arange(1, r + 1) for r in reps[b].tolist()] + [torch.zeros(0, dtype=torch.long)])
+            assert torch.equal(pos[b, :len(exp)].long(), within)
+        x = torch.randn(B, N, C, generator=g).requires_grad_(True)
+        vl = tot.clamp(max=Tp)
+        y = ops.lr_gather(x, idx, cs, vl)
+        ref = torch.zeros(B, Tp, C)
+        for b in range(B):
+            exp = torch.repeat_interleave(torch.arange(N), reps[b])
+            ref[b, :len(exp)] = x.detach()[b, exp]
+        assert torch.equal(y.detach(), ref), it
+        cot = torch.randn(B, Tp, C, generator=g)
+        gx = torch.autograd.grad((y * cot).sum(), [x])[0]
+        gref = torch.zeros_like(gx)
+        for b in range(B):
+            exp = torch.repeat_interleave(torch.arange(N), reps[b])
+            gref[b].index_add_(0, exp, cot[b, :len(exp)])
+        assert float((gx - gref).abs().max()) < 1e-5, it
+    for it in range(6):
+        # embedding gather-sum with scale and position table
+        B, T, D = rnd.choice([1, 3]), rnd.randint(1, 9), rnd.choice([8, 32])
+        sizes = [rnd.randint(2, 9) for _ in range(rnd.choice([1, 2, 4]))]
+        tabs = [torch.randn(n, D, generator=g).requires_grad_(True) for n in sizes]
+        ids = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in sizes], -1)
+        pos = torch.randn(T, D, generator=g) if rnd.random() < 0.5 else None
+        scale = rnd.choice([1.0, 11.3])
+        out, scaled = ops.embed_sum(ids, tabs, pos=pos, scale=scale, want_scaled="grad")
+        rs = sum(F.embedding(ids[..., k], tabs[k]) for k in range(len(sizes))) * scale
+        ro = rs if pos is None else rs + pos[None]
+        assert float((out - ro).detach().abs().max()) < 1e-5 and float((scaled - rs).detach().abs().max()) < 1e-5, it
+        c1, c2 = torch.randn(B, T, D, generator=g), torch.randn(B, T, D, generator=g)
+        got = torch.autograd.grad((out * c1).sum() + (scaled * c2).sum(), tabs)
+        exp = torch.autograd.grad((ro * c1).sum() + (rs * c2).sum(), tabs)
+        _cmp(got, exp, dict(it=it, sizes=sizes))
