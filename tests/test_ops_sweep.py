@@ -229,3 +229,42 @@ def test_fsmn_memory_length_regulator_embedding_and_masked_l1(emulated_cabi):
         got = torch.autograd.grad((out * c1).sum() + (scaled * c2).sum(), tabs)
         exp = torch.autograd.grad((ro * c1).sum() + (rs * c2).sum(), tabs)
         _cmp(got, exp, dict(it=it, sizes=sizes))
+
+
+def test_elementwise_losses_weight_norm_sin_add(emulated_cabi):
+    from kantts._hip import ops
+
+    rnd = random.Random(13)
+    g = torch.Generator().manual_seed(13)
+    for it in range(8):
+        shape = [rnd.randint(1, 9) for _ in range(rnd.choice([1, 2, 3]))]
+        a = torch.randn(shape, generator=g).requires_grad_(True)
+        b = torch.randn(shape, generator=g)
+        for got, exp in ((ops.l1_mean(a, b), F.l1_loss(a, b)), (ops.mse_to_const(a, 1.0), F.mse_loss(a, torch.ones_like(a))),
+                         (ops.mse_to_const(a, 0.0), F.mse_loss(a, torch.zeros_like(a)))):
+            assert abs(float(got.detach()) - float(exp.detach())) < 1e-5 * max(1.0, abs(float(exp.detach()))), (it, shape)
+            # a scaled use of the loss (loss weights of the GAN step) scales the gradient
+            ga, ge = torch.autograd.grad(got * 3.0, [a]), torch.autograd.grad(exp * 3.0, [a])
+            _cmp(ga, ge, dict(it=it, shape=shape))
+        x = torch.randn(shape, generator=g).requires_grad_(True)
+        y, ry = ops.sin_add(x), torch.sin(x) + x
+        assert float((y - ry).detach().abs().max()) < 1e-6
+        cot = torch.randn(shape, generator=g)
+        _cmp(_grads(y, cot, [x]), _grads(ry, cot, [x]), dict(it=it, op="sin_add"))
+    for it in range(10):
+        # weight norm over all dims but 0: parameter layout (Cout, Cin, K) and the kernels' tap-major (K, Cout, Cin)
+        cout, cin, K = rnd.choice([1, 4, 32]), rnd.choice([1, 4, 8, 12]), rnd.choice([1, 3, 7, 41])
+        v = torch.randn(cout, cin, K, generator=g).requires_grad_(True)
+        gg = (torch.rand(cout, 1, 1, generator=g) + 0.5).requires_grad_(True)
+        ref = gg * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+        w = ops.weight_norm(v, gg)
+        cfg = dict(it=it, cout=cout, cin=cin, K=K)
+        assert float((w - ref).detach().abs().max()) < 1e-5, cfg
+        cot = torch.randn(ref.shape, generator=g)
+        _cmp(_grads(w, cot, [v, gg]), _grads(ref, cot, [v, gg]), cfg)
+        if cin % 4 == 0:
+            wt = ops.weight_norm_tap(v, gg)
+            assert tuple(wt.shape) == (K, cout, cin) and float((wt - ref.permute(2, 0, 1)).detach().abs().max()) < 1e-5, cfg
+            cot_t = cot.permute(2, 0, 1).contiguous()
+            ref2 = gg * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
+            _cmp(_grads(wt, cot_t, [v, gg]), _grads(ref2, cot, [v, gg]), cfg)
