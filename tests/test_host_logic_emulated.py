@@ -171,3 +171,43 @@ def _infer_case(device, B, seed):
 def test_free_running_inference_matches_oracle(emulated_cabi):
     _infer_case("cpu", B=1, seed=77)
     _infer_case("cpu", B=3, seed=5)
+
+
+def test_ctypes_prototypes_match_the_header():
+    """Every entry point with declared argtypes: argument count and pointer / int / float / 64-bit kinds agree with the
+    C prototype in include/kantts_hip.h (a drifted binding would corrupt the call frame silently)."""
+    import kantts._hip as hip
+
+    if not hip.available():
+        import __graft_entry__ as g
+
+        g.build()
+    L = hip.lib()
+    header = open(os.path.join(ROOT, "include", "kantts_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = dict(re.findall(r"\bint\s+(kantts_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S))
+    kinds = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_float: "f", ctypes.c_longlong: "q", ctypes.c_uint64: "q",
+             ctypes.c_char_p: "p"}
+
+    def kind_of_c(param):
+        param = " ".join(param.split())
+        if "*" in param:
+            return "p"
+        if re.search(r"\b(long long|int64_t|uint64_t|size_t)\b", param):
+            return "q"
+        if re.search(r"\b(float)\b", param):
+            return "f"
+        if re.search(r"\b(int|int32_t|unsigned)\b", param):
+            return "i"
+        raise AssertionError("unclassified C parameter: " + param)
+
+    checked = 0
+    for name, params in protos.items():
+        fn = getattr(L, name)
+        if fn.argtypes is None:
+            continue
+        want = [kind_of_c(p) for p in params.split(",") if p.strip() and p.strip() != "void"]
+        got = ["p" if (isinstance(t, type) and issubclass(t, ctypes._Pointer)) else kinds[t] for t in fn.argtypes]
+        assert got == want, (name, "".join(got), "".join(want))
+        checked += 1
+    assert checked >= 30, checked
