@@ -211,3 +211,30 @@ def test_ctypes_prototypes_match_the_header():
         assert got == want, (name, "".join(got), "".join(want))
         checked += 1
     assert checked >= 30, checked
+
+
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """The argument structs are filled field by field from Python: size and every field offset must be what a C
+    compiler derives from include/kantts_hip.h (the header is plain C, so gcc is the judge)."""
+    import kantts._hip as hip
+
+    pairs = [(hip.GemmSeg, "kantts_gemm_seg"), (hip.GemmArgs, "kantts_gemm_args"), (hip.ConvArgs, "kantts_conv_args"),
+             (hip.ConvWArgs, "kantts_convw_args"), (hip.ConvC1Args, "kantts_conv_c1_args")]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "kantts_hip.h"', 'int main(void) {']
+    for cls, cname in pairs:
+        lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname.rstrip("_")))
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    c_layout = {}
+    for ln in out.splitlines():
+        cname, field, val = ln.split()
+        c_layout[(cname, field)] = int(val)
+    for cls, cname in pairs:
+        assert ctypes.sizeof(cls) == c_layout[(cname, "sizeof")], (cname, ctypes.sizeof(cls), c_layout[(cname, "sizeof")])
+        for fname, _ in cls._fields_:
+            assert getattr(cls, fname).offset == c_layout[(cname, fname)], (cname, fname)
