@@ -35,8 +35,18 @@ def train(model_config, root_dir, stage_dir, resume_path=None, local_rank=0, syn
         seg = config.get("batch_max_steps", 8192) // hop * hop
         B = config.get("batch_size", 16)
         g = torch.Generator().manual_seed(4321 + config.get("rank", 0))
-        train_loader = [(torch.randn(B, 1, seg, generator=g).clamp(-1, 1), torch.randn(B, 80, seg // hop, generator=g))
-                        for _ in range(synthetic)]
+        nsf = config["Model"]["Generator"]["params"].get("nsf_params") is not None
+
+        def feats():
+            mel = torch.randn(B, 80, seg // hop, generator=g)
+            if not nsf:
+                return mel
+            # NSF generators read two more channels: f0 in Hz (0 where unvoiced) and the voiced flag
+            uv = (torch.rand(B, 1, seg // hop, generator=g) > 0.3).float()
+            f0 = (80.0 + 300.0 * torch.rand(B, 1, seg // hop, generator=g)) * uv
+            return torch.cat([mel, f0, uv], dim=1)
+
+        train_loader = [(torch.randn(B, 1, seg, generator=g).clamp(-1, 1), feats()) for _ in range(synthetic)]
         valid_loader = None
     elif ds is not None:
         from torch.utils.data import DataLoader

@@ -103,3 +103,30 @@ def test_nsf_generator_gpu_matches_cpu_oracle_with_shared_excitation():
     finally:
         SourceModule.excitation = orig
     assert float((outs[0] - outs[1]).abs().max()) <= 5e-5
+
+
+def test_nsf_training_cli_emulated(tmp_path):
+    """kantts.bin.train_hifigan on synthetic NSF batches (mel + f0 + voiced flag): generator with source module,
+    discriminator, both updates, checkpoint."""
+    from util import emulation
+
+    from kantts.bin.train_hifigan import train as train_voc
+
+    opt = {"type": "Adam", "params": {"lr": 2e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}}
+    sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [200000]}}
+    voc = {"model_type": "hifigan", "Model": {
+        "Generator": {"params": {"channels": 32, "nsf_params": {"nb_harmonics": 7, "sampling_rate": 16000}},
+                      "optimizer": opt, "scheduler": sch},
+        "MultiPeriodDiscriminator": {"params": {"periods": [2, 3]}, "optimizer": opt, "scheduler": sch}},
+        "Loss": {"generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "mel_loss": {"enable": True, "params": {}, "weights": 45.0},
+                 "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+        "generator_grad_norm": -1, "discriminator_grad_norm": -1, "discriminator_train_start_steps": 0,
+        "generator_train_start_steps": 0, "batch_size": 2, "batch_max_steps": 1024, "log_interval_steps": 1,
+        "save_interval_steps": 2, "audio_config": {"hop_length": 256, "sampling_rate": 16000}}
+    with emulation():
+        tr = train_voc(voc, [], str(tmp_path / "voc_nsf"), synthetic=2)
+    assert tr.steps == 3 and os.path.exists(tmp_path / "voc_nsf" / "ckpt" / "checkpoint_2.pth")
+    sd = torch.load(tmp_path / "voc_nsf" / "ckpt" / "checkpoint_2.pth", map_location="cpu")["model"]["generator"]
+    assert "source_module.ffn.0.weight_v" in sd and "source_downs.0.conv1d.weight_g" in sd
