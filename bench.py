@@ -46,36 +46,100 @@ def sambert_yaml_config(cfg):
         "grad_norm": 1.0, "batch_size": 32}
 
 
-def cpu_baseline(cfg, sample_B=8, iters=3, max_threads=16):
-    """CPU oracle ("port" of the reference path, pinned against it by tests/golden) fwd+bwd on a
-    bounded sample of the same workload; Adam omitted (negligible next to fwd+bwd on CPU)."""
+def _time_iters(fn, warmup, iters, budget_s):
+    """>= 3 timed iterations, up to ``iters``, stopping once ``budget_s`` of timed work is spent."""
+    for _ in range(warmup):
+        fn()
+    ts = []
+    t_all = time.time()
+    for _ in range(iters):
+        t0 = time.time()
+        fn()
+        ts.append(time.time() - t0)
+        if len(ts) >= 3 and time.time() - t_all > budget_s:
+            break
+    return sum(ts) / len(ts), len(ts)
+
+
+def cpu_baseline(cfg, hip, B=32, budget_s=25.0):
+    """CPU oracle ("port" of the reference path, pinned against it by tests/golden + oracle/check_vs_reference.py)
+    forward + losses + backward on the SAME seeded batch as the GPU line (B=32, 14 797 valid frames), all host cores,
+    fp32; Adam omitted (12 M parameters: negligible next to fwd+bwd on CPU).  Timed with dropout off (>= 2 warm-up
+    + <= 5 timed) and "as shipped" with dropout on (1 warm-up + <= 3 timed).  Its dropout-off result doubles as the
+    checker for "parity_error": the HIP path (fp32 mode and bf16 mode) on the same batch and weights."""
     import torch_oracle as O
 
     torch.manual_seed(0)
     from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
 
-    m = KanTtsSAMBERT(dict(cfg))
+    cfg0 = dict(cfg)
+    m = KanTtsSAMBERT(cfg0)
     P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
-    batch = O.synthetic_sambert_batch(B=sample_B, T_in=64, seed=1234)
+    batch = O.synthetic_sambert_batch(B=B, T_in=64, seed=1234)
     frames = int(batch["output_lengths"].sum())
-    # the port is many small ops + python LSTM loops: more than ~16 threads only adds fork/join overhead
-    cores = min(os.cpu_count() or 1, max_threads)
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    keep = {}
 
     def one():
         for p in P.values():
             p.grad = None
-        out = O.sambert_forward(P, cfg, **batch)
-        O.sambert_losses(out, batch["input_lengths"], batch["output_lengths"], batch["mel_targets"])["total"].backward()
+        out = O.sambert_forward(P, cfg0, **batch)
+        L = O.sambert_losses(out, batch["input_lengths"], batch["output_lengths"], batch["mel_targets"])
+        L["total"].backward()
+        keep["out"], keep["L"] = out, L
 
-    one()
-    t0 = time.time()
-    for _ in range(iters):
-        one()
-    dt = (time.time() - t0) / iters
-    return {"value": frames / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": "oracle/torch_oracle.py fwd+bwd, fp32, dropout off, B=%d of the same seeded batch (%d valid frames), "
-                      "%d timed iters, %.2f s/iter" % (sample_B, frames, iters, dt)}
+    O.DROP["on"] = False
+    dt_off, n_off = _time_iters(one, 2, 5, budget_s)
+    ref_out = {k: keep["out"][k].detach().clone() for k in ("dec_outputs", "postnet_outputs")}
+    ref_loss = float(keep["L"]["total"])
+    ref_grads = {k: p.grad.detach().clone() for k, p in P.items() if p.grad is not None}
+    O.DROP["on"] = True
+    try:
+        dt_on, n_on = _time_iters(one, 1, 3, budget_s * 0.6)
+    finally:
+        O.DROP["on"] = False
+
+    # ---- parity of the HIP path at the benchmarked shape (dropout forced to 0 on both sides)
+    parity = {}
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+
+    cfg_nodrop = {k: (0.0 if "dropout" in k else v) for k, v in cfg0.items()}
+    gb = {k: v.cuda() for k, v in batch.items()}
+    for mode in ("fp32", "bf16"):
+        hip.set_precision(mode)
+        torch.manual_seed(0)
+        g = KanTtsSAMBERT(dict(cfg_nodrop)).cuda()
+        g.eval()  # Prenet's hard-wired Dropout(0.5) off, like the oracle
+        res = g(**gb)
+        mel_, mel = MelReconLoss()(gb["output_lengths"], gb["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+        d, p_, e = ProsodyReconLoss()(gb["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                      res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                      res["energy_predictions"])
+        total = mel_ + mel + d + p_ + e
+        total.backward()
+        torch.cuda.synchronize()
+        dm = (res["postnet_outputs"].detach().cpu() - ref_out["postnet_outputs"]).abs()
+        dd = (res["dec_outputs"].detach().cpu() - ref_out["dec_outputs"]).abs()
+        worst, num, den = 0.0, 0.0, 0.0
+        for n, prm in g.named_parameters():
+            if prm.grad is not None and n in ref_grads:
+                e2 = float((prm.grad.detach().cpu().double() - ref_grads[n].double()).pow(2).sum())
+                r2 = float(ref_grads[n].double().pow(2).sum())
+                num, den = num + e2, den + r2
+                worst = max(worst, (e2 / (r2 + 1e-60)) ** 0.5)
+        parity[mode] = {"mel_mean_abs": float(dm.mean()), "mel_max_abs": float(dm.max()),
+                        "dec_mean_abs": float(dd.mean()), "loss_abs": abs(float(total.detach()) - ref_loss),
+                        "grad_rel_l2_global": (num / (den + 1e-60)) ** 0.5, "grad_rel_l2_worst_tensor": worst,
+                        "lr_length_bit_exact": bool(torch.equal(res["LR_length_rounded"].cpu(),
+                                                                keep["out"]["LR_length_rounded"]))}
+        del g, res, total
+    base = {"value": frames / dt_off, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "value_dropout_on": frames / dt_on,
+            "sample": "oracle/torch_oracle.py fwd+losses+bwd, fp32, the full seeded batch B=%d (%d valid frames): "
+                      "dropout off 2 warm-up + %d timed, %.2f s/iter; dropout on (as shipped) 1 warm-up + %d timed, "
+                      "%.2f s/iter; torch.set_num_threads(%d)" % (B, frames, n_off, dt_off, n_on, dt_on, cores)}
+    return base, parity
 
 
 def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
@@ -215,6 +279,143 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
     return res
 
 
+def hifigan_cpu_baseline(B=2, T_wav=8192, budget_s=20.0):
+    """CPU oracle port of the HiFi-GAN V1 GAN step (oracle/hifigan_oracle.py: generator forward + mel / adversarial /
+    feature-matching generator loss + backward, generator re-run, discriminator loss + backward; optimizer updates
+    omitted) and of the generator forward alone (no grad), at batch ``B`` x 8192 samples on all host cores."""
+    import audio_oracle as A
+    import hifigan_oracle as H
+    from kantts.models.hifigan.hifigan import Generator, MultiPeriodDiscriminator, MultiScaleDiscriminator
+
+    torch.manual_seed(0)
+    mods = (Generator(), MultiPeriodDiscriminator(), MultiScaleDiscriminator())
+    PG, PP, PS = ({k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+                  for m in mods)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 80, T_wav // 256, generator=g)
+    y = torch.randn(B, 1, T_wav, generator=g).clamp(-1, 1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def zero():
+        for P in (PG, PP, PS):
+            for p in P.values():
+                p.grad = None
+
+    def gan_step():
+        zero()
+        y_ = H.generator(PG, x)
+        mel = torch.nn.functional.l1_loss(A.mel_spectrogram(y_), A.mel_spectrogram(y))
+        adv, fm = 0.0, 0.0
+        for P, f in ((PP, H.mpd), (PS, H.msd)):
+            o_, f_ = f(P, y_)
+            with torch.no_grad():
+                _, fr = f(P, y)
+            adv = adv + H.gen_adv_loss(o_)
+            fm = fm + H.feat_match_loss(fr, f_)
+        (45.0 * mel + adv + 2.0 * fm).backward()
+        zero()
+        with torch.no_grad():
+            y2 = H.generator(PG, x)
+        dl = 0.0
+        for P, f in ((PP, H.mpd), (PS, H.msd)):
+            o, _ = f(P, y)
+            o_, _ = f(P, y2)
+            real, fake = H.dis_adv_loss(o_, o)
+            dl = dl + real + fake
+        dl.backward()
+
+    def gen_fwd():
+        with torch.no_grad():
+            H.generator(PG, x)
+
+    dt_step, n_step = _time_iters(gan_step, 1, 3, budget_s)
+    dt_fwd, n_fwd = _time_iters(gen_fwd, 1, 5, budget_s * 0.3)
+    return {"value": B * T_wav / dt_step, "unit": "audio-samples/s (GAN training step)", "cores": cores, "kind": "port",
+            "generator_forward_samples_per_s": B * T_wav / dt_fwd,
+            "sample": "oracle/hifigan_oracle.py V1 (512 ch) GAN step fwd+bwd without optimizer updates, batch %d x %d "
+                      "samples, fp32: 1 warm-up + %d timed, %.2f s/iter; generator forward (no grad): %d timed, %.2f "
+                      "s/iter" % (B, T_wav, n_step, dt_step, n_fwd, dt_fwd)}
+
+
+def melspec_leg(B=32, T_wav=8192, reps=20):
+    """Mel-STFT feature extractor (third part of the north-star path): V1 loss settings (22.05 kHz, n_fft 1024, hop 256,
+    80 mels) on batch 32 x 8192 samples, forward and forward+backward; HBM roofline at SURVEY 8(d)'s 1344 algorithmic
+    bytes per frame (hop * 4 B read + 80 * 4 B written); CPU oracle (oracle/audio_oracle.py) beside it."""
+    import audio_oracle as A
+    from kantts.utils.audio_torch import MelSpectrogram
+
+    ms = MelSpectrogram().cuda()
+    x = torch.randn(B, T_wav, device="cuda") * 0.1
+    frames = B * (1 + T_wav // 256)
+    with torch.no_grad():
+        ms_fwd = _event_ms(lambda: ms(x), reps)
+    xg = x.clone().requires_grad_(True)
+    cot = torch.randn_like(ms(x))
+
+    def fb():
+        xg.grad = None
+        (ms(xg) * cot).sum().backward()
+
+    ms_fb = _event_ms(fb, reps)
+    xc = x.cpu()
+    torch.set_num_threads(os.cpu_count() or 1)
+    dt_cpu, n_cpu = _time_iters(lambda: A.mel_spectrogram(xc), 2, 10, 3.0)
+    err = float((ms(x).cpu() - A.mel_spectrogram(xc)).abs().max())
+    gbps = frames * 1344.0 / (ms_fwd * 1e-3) / 1e9
+    return {"workload": "mel-STFT 22.05 kHz n_fft 1024 hop 256 80 mels, batch %d x %d samples (%d frames)" % (B, T_wav, frames),
+            "dtype": "fp32", "forward_ms": ms_fwd, "forward_frames_per_s": frames / (ms_fwd * 1e-3),
+            "forward_backward_ms": ms_fb,
+            "roofline": {"bound": "hbm", "kernel": "melspec_kernel", "achieved": gbps, "peak": PEAK_HBM_GBPS,
+                         "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_frame": 1344,
+                         "note": "one launch of %d frames = %.2f MB algorithmic: launch-latency bound at this size"
+                                 % (frames, frames * 1344 / 1e6)},
+            "cpu_baseline": {"value": frames / dt_cpu, "unit": "frames/s", "cores": os.cpu_count() or 1, "kind": "port",
+                             "sample": "oracle/audio_oracle.py mel_spectrogram on the same batch, %d timed" % n_cpu},
+            "parity_error": {"max_abs_vs_oracle": err}}
+
+
+def fp32_leg(hip, cfg, batch, frames, mel_crit, pros_crit, dev, steps=5, warmup=2):
+    """The same training step in fp32 mode (MFMA 16x16x4 f32 = exact fp32 FMA chains: the mode every 1e-5 parity
+    assertion runs in), graph-replayed like the headline line."""
+    from kantts.models import model_builder
+    from kantts.train.graph_step import GraphedSambertStep
+
+    hip.set_precision("fp32")
+    torch.manual_seed(0)
+    model, opt, sch = model_builder(sambert_yaml_config(cfg), device=dev)
+    net, optimizer, scheduler = model["KanTtsSAMBERT"], opt["KanTtsSAMBERT"], sch["KanTtsSAMBERT"]
+    optimizer.set_grad_clip(1.0)
+    net.train()
+    step = GraphedSambertStep(net, optimizer, scheduler, mel_crit, pros_crit, batch)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"dtype": "fp32", "ms_per_step": dt * 1e3, "value": frames / dt, "unit": "mel-frames/s", "steps": steps,
+            "whole_step_mfma_frac": 456.9e9 * batch["mel_targets"].shape[0] / 32 / dt / 1e12 / PEAK_TFLOPS["fp32"]}
+
+
+def _spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a torch.distributed.run launch: re-exec under it (one rank per GPU of this
+    node, rendezvous on 127.0.0.1) and pass its JSON line through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,12 +425,18 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 (parity-path) throughput figure")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight gradients on the main stream (A/B switch)")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("[bench] --gpus %d but the launcher started %d rank(s): reporting n_gpus=%d" % (args.gpus, world, world),
+              file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
@@ -303,12 +510,16 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(frames)], device=dev, dtype=torch.float64)
+    per_rank_ms = [1e3 * dt / args.steps]
     if distributed:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_max, total_frames = float(tmax[0]), float(tsum[1])
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [1e3 * float(a[0]) / args.steps for a in allt]
     else:
         dt_max, total_frames = dt, float(frames)
 
@@ -330,11 +541,14 @@ def main():
                 # WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); collected offline, see
                 # profiles/r01_gemm_ffn_pmc_v2.txt -- bench.py cannot run the profiler on itself
                 "traffic": MEASURED_TRAFFIC_BYTES.get(args.precision),
-                "bytes_per_launch": bytes_per_launch, "flops_per_launch": flops_per_launch, "launch_us": per_launch_us,
+                "traffic_source": "profiles/r01_gemm_ffn_pmc_v2.txt (offline rocprofv3 --pmc passes; regenerate when the kernel changes)",
+                "bytes_per_launch": bytes_per_launch, "bytes_dtype": "fp32 (activations and weights are stored fp32 in HBM)",
+                "flops_per_launch": flops_per_launch, "launch_us": per_launch_us,
                 "mfma_tflops": tf, "mfma_peak": peak, "mfma_frac": tf / peak,
                 "gemm_launches_per_step": prof["launches"], "gemm_gflop_per_step": prof["flops"] / 1e9,
                 "gemm_ms_per_step_eager_events": prof["ms"],
                 "whole_step_algorithmic_tflops": 456.9e9 * args.batch / 32 / (dt_max / args.steps) / 1e12}
+        roof["whole_step_mfma_frac"] = roof["whole_step_algorithmic_tflops"] / peak
 
     if rank == 0:
         out = {
@@ -345,18 +559,35 @@ def main():
             "config": {"workload": "SAM-BERT full (sambert_16k.yaml zhcn) fwd+bwd+clip+Adam, batch %d/GPU, T_in 64, "
                                    "%d valid mel frames on rank 0, dropout on" % (args.batch, frames),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "launch": mode,
-                       "final_loss": float(loss)},
+                       "final_loss": float(loss.detach()), "per_rank_ms_per_step": per_rank_ms,
+                       "collective_world_size": dist.get_world_size() if distributed else 1,
+                       "collective_backend": ("nccl (RCCL)" if distributed else None)},
             "roofline": roof,
         }
+        del step, net, optimizer, model, opt
+        torch.cuda.empty_cache()
+        if world == 1 and args.precision != "fp32" and not args.no_fp32:
+            try:  # the parity-proven path (fp32 MFMA) on the same step, beside the throughput (bf16) line
+                out["fp32_path"] = fp32_leg(hip, cfg, batch, frames, mel_crit, pros_crit, dev)
+                hip.set_precision(args.precision)
+            except Exception as exc:
+                out["fp32_path"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not args.no_hifigan:
             try:
-                del step, net, optimizer, model, opt
-                torch.cuda.empty_cache()
                 out["hifigan"] = hifigan_leg(hip, args.precision)
+                if not args.no_cpu_baseline:
+                    out["hifigan"]["cpu_baseline"] = hifigan_cpu_baseline()
             except Exception as exc:  # the SAM-BERT line must survive a failure of the secondary leg
                 out["hifigan"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+            try:
+                out["melspec"] = melspec_leg()
+            except Exception as exc:
+                out["melspec"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            try:
+                out["cpu_baseline"], out["parity_error"] = cpu_baseline(cfg, hip)
+            except Exception as exc:
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -12,7 +12,7 @@ Here forward + losses + backward + gradient packing + clip + Adam are captured O
 """
 import torch
 
-from kantts._hip import ops
+from kantts._hip import ops, rng_state as _rng_state
 
 
 class GraphedSambertStep:
@@ -26,8 +26,13 @@ class GraphedSambertStep:
         self.device = next(net.parameters()).device
         net.device_band_width = True
         self.distributed = optimizer.arena.world_size > 1
-        optimizer.enable_device_state()
+        optimizer.enable_device_state()  # idempotent: one [lr, step] tensor shared by every captured shape
         self.loss = None
+        # the warm-up steps exist only to populate allocator pools / lazy kernel state before capture: weights, Adam
+        # moments, step counters and the dropout offset are put back afterwards, so a new batch shape costs exactly one
+        # optimizer update (the first replay), like the eager path and the reference
+        snap = optimizer.snapshot()
+        rng_snap = _rng_state(self.device).clone() if self.device.type == "cuda" else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -35,6 +40,9 @@ class GraphedSambertStep:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        optimizer.restore(snap)
+        if rng_snap is not None:
+            _rng_state(self.device).copy_(rng_snap)
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         optimizer.zero_grad(set_to_none=True)
@@ -51,6 +59,7 @@ class GraphedSambertStep:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
                 self._apply(packed=True)
+        optimizer._step = snap["step"]  # capturing ran step()'s host code once without running its kernels
 
     def _forward_backward(self):
         b = self.batch

@@ -119,9 +119,26 @@ class ArenaAdam(torch.optim.Optimizer):
     def enable_device_state(self):
         """Keep lr and the step count in device memory so that step() can be replayed from a hipGraph:
         the captured kernels read {lr, step} from ``self.dyn``; call sync_lr() after scheduler.step()."""
-        self.dyn = torch.tensor([self.param_groups[0]["lr"], float(self._step)], device=self.arena.flat.device,
-                                dtype=torch.float32)
+        if self.dyn is None:
+            # allocated ONCE for the optimizer's lifetime: every captured graph (one per batch shape) holds this
+            # tensor's address in its kernel arguments, so a second allocation would strand the older graphs
+            self.dyn = torch.empty(2, device=self.arena.flat.device, dtype=torch.float32)
+        self.dyn.copy_(torch.tensor([self.param_groups[0]["lr"], float(self._step)], dtype=torch.float32))
         return self.dyn
+
+    def snapshot(self):
+        """Copies of everything a step mutates (weights, moments, counters): GraphedSambertStep restores them after
+        its capture warm-up so that warming up a new batch shape does not train on it."""
+        return {"flat": self.arena.flat.clone(), "m": self.exp_avg.clone(), "v": self.exp_avg_sq.clone(),
+                "step": self._step, "dyn": None if self.dyn is None else self.dyn.clone()}
+
+    def restore(self, snap):
+        self.arena.flat.copy_(snap["flat"])
+        self.exp_avg.copy_(snap["m"])
+        self.exp_avg_sq.copy_(snap["v"])
+        self._step = snap["step"]
+        if self.dyn is not None and snap["dyn"] is not None:
+            self.dyn.copy_(snap["dyn"])
 
     def sync_lr(self):
         if self.dyn is not None:

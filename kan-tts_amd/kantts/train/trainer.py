@@ -93,16 +93,19 @@ class Trainer(object):
     def _accumulate(self, prefix, losses):
         for k, v in losses.items():
             key = "%s/%s" % (prefix, k)
-            v = v.detach() if torch.is_tensor(v) else torch.tensor(float(v), device=self.device)
+            # clone: under graph replay ``v`` is the graph's static loss buffer, which the next replay overwrites
+            v = v.detach().clone() if torch.is_tensor(v) else torch.tensor(float(v), device=self.device)
             self._device_losses[key] = v if key not in self._device_losses else self._device_losses[key] + v
 
-    def _flush_losses(self, into):
-        if self._device_losses:
-            keys = list(self._device_losses)
-            vals = torch.stack([self._device_losses[k].float().reshape(()) for k in keys]).cpu().tolist()  # ONE sync
+    def _flush_losses(self, into, prefix):
+        """Move the accumulated ``prefix/*`` sums to the host (ONE sync); other prefixes keep accumulating, so an
+        evaluation in the middle of a logging interval neither drains nor rescales the train sums."""
+        keys = [k for k in self._device_losses if k.startswith(prefix + "/")]
+        if keys:
+            vals = torch.stack([self._device_losses[k].float().reshape(()) for k in keys]).cpu().tolist()
             for k, v in zip(keys, vals):
                 into[k] += v
-            self._device_losses = {}
+                del self._device_losses[k]
 
     def write_to_tensorboard(self, loss):
         for key, value in loss.items():
@@ -115,7 +118,7 @@ class Trainer(object):
 
     def check_log_interval(self):
         if self.steps % self.log_interval == 0:
-            self._flush_losses(self.total_train_loss)
+            self._flush_losses(self.total_train_loss, "train")
             for key in self.total_train_loss:
                 self.total_train_loss[key] /= self.config.get("log_interval_steps", self.log_interval)
                 logging.info(f"(Steps: {self.steps}) {key} = {self.total_train_loss[key]:.4f}.")
@@ -164,7 +167,7 @@ class Trainer(object):
         n = 0
         for n, batch in enumerate(self.valid_loader, 1):
             self.eval_step(batch)
-        self._flush_losses(self.total_eval_loss)
+        self._flush_losses(self.total_eval_loss, "eval")
         for key in self.total_eval_loss:
             self.total_eval_loss[key] /= max(n, 1)
             logging.info(f"(Steps: {self.steps}) {key} = {self.total_eval_loss[key]:.4f}.")
@@ -195,6 +198,7 @@ class Sambert_Trainer(Trainer):
             raise NotImplementedError("graph=True covers the duration-supervised step; the MAS step runs eagerly")
         self.graph = graph
         self._graphs = {}
+        self.max_graphs = 16  # captured steps kept (one per padded batch shape), LRU
         if self.grad_clip is not None and hasattr(self.optimizer[self.KEY], "set_grad_clip"):
             self.optimizer[self.KEY].set_grad_clip(self.grad_clip)
 
@@ -247,14 +251,16 @@ class Sambert_Trainer(Trainer):
         from kantts.train.graph_step import GraphedSambertStep
 
         key = tuple((k, tuple(v.shape)) for k, v in b.items() if v is not None)
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)
         if g is None:
+            if len(self._graphs) >= self.max_graphs:  # least recently used shape goes (dicts keep insertion order)
+                self._graphs.pop(next(iter(self._graphs)))
             g = GraphedSambertStep(self.model[self.KEY], self.optimizer[self.KEY], self.scheduler[self.KEY],
                                    self.criterion["MelReconLoss"], self.criterion["ProsodyReconLoss"],
                                    {k: v for k, v in b.items() if v is not None})
-            self._graphs[key] = g
         else:
             g.load_batch({k: v for k, v in b.items() if v is not None})
+        self._graphs[key] = g  # most recently used last
         g()
         self._accumulate("train", {"TotalLoss": g.loss})
         return g.loss

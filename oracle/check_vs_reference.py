@@ -43,6 +43,36 @@ for tiny, B, T_in, min_len in ((True, 4, 24, 10), (False, 4, 48, 20)):
                 for n, p_ in m.named_parameters() if p_.grad is not None)
     print("worst grad rel", worst)
     ok &= worst <= 1e-5
+# ---- HiFi-GAN: oracle/hifigan_oracle.py against the untouched reference (V1 class defaults at a small batch, and a
+# narrow generator), forward and parameter gradients
+import hifigan_oracle as H  # noqa: E402
+from kantts.models.hifigan.hifigan import Generator, MultiPeriodDiscriminator, MultiScaleDiscriminator  # noqa: E402
+
+for channels, B, frames in ((512, 1, 8), (64, 2, 8)):
+    torch.manual_seed(0)
+    G, D1, D2 = Generator(channels=channels), MultiPeriodDiscriminator(), MultiScaleDiscriminator()
+    g = torch.Generator().manual_seed(1)
+    xm = torch.randn(B, 80, frames, generator=g)
+    yw = torch.randn(B, 1, frames * 256, generator=g).clamp(-1, 1)
+    PG = {k: v.detach().clone().requires_grad_(True) for k, v in G.state_dict().items()}
+    a, b = G(xm), H.generator(PG, xm)
+    err = (a - b).abs().max().item()
+    a.sum().backward()
+    b.sum().backward()
+    gw = max(((p_.grad - PG[n].grad).norm() / (p_.grad.norm() + 1e-12)).item() for n, p_ in G.named_parameters())
+    print("hifigan G ch=%d" % channels, err, "grad", gw)
+    ok &= err <= 2e-6 and gw <= 1e-4
+    for D, f, nm in ((D1, H.mpd, "mpd"), (D2, H.msd, "msd")):
+        P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in D.state_dict().items()}
+        o, fm = D(yw)
+        o2, fm2 = f(P, yw)
+        err = max((u - v).abs().max().item() for u, v in zip(o, o2))
+        errf = max((u - v).abs().max().item() for fa, fb in zip(fm, fm2) for u, v in zip(fa, fb))
+        (sum((u * u).mean() for u in o) + sum(u.abs().mean() for fa in fm for u in fa)).backward()
+        (sum((u * u).mean() for u in o2) + sum(u.abs().mean() for fa in fm2 for u in fa)).backward()
+        gw = max(((p_.grad - P[n].grad).norm() / (p_.grad.norm() + 1e-12)).item() for n, p_ in D.named_parameters())
+        print("hifigan", nm, err, errf, "grad", gw)
+        ok &= err <= 2e-6 and errf <= 2e-5 and gw <= 1e-4
 x = torch.randn(3, 4096) * 0.1
 ok &= (MelSpectrogram()(x[:, None]) - A.mel_spectrogram(x)).abs().max().item() <= 1e-6
 print("OK" if ok else "MISMATCH")

@@ -417,6 +417,47 @@ def mas_dp_case():
     print("mas_dp durations", hard.sum(2)[:, 0, :8].tolist()[0], "bytes", os.path.getsize(os.path.join(OUT, "mas_dp.pt")))
 
 
+def hifigan_v1_case():
+    """The reference's HiFi-GAN V1 at its own class defaults (Generator 512 channels, MPD 2/3/5/7/11, MSD x3 with DWT
+    pooling -- BASELINE config 3's architecture): generator forward on 2 x 8 mel frames, one MPD and one MSD pass on
+    2 x 2048 samples, gradient norms of a generator backward.  Weights are reproduced from the seed (checksums)."""
+    from kantts.models.hifigan.hifigan import Generator, MultiPeriodDiscriminator, MultiScaleDiscriminator
+
+    torch.manual_seed(0)
+    G, D1, D2 = Generator(), MultiPeriodDiscriminator(), MultiScaleDiscriminator()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 80, 8, generator=g)
+    y = torch.randn(2, 1, 2048, generator=g).clamp(-1, 1)
+    cot = torch.randn(2, 1, 2048, generator=g)
+    wav = G(x)
+    (wav * cot).sum().backward()
+    fix = dict(x=x, y=y, cot=cot, wav=wav.detach().clone(),
+               G_grad_norms={n: float(p.grad.double().norm()) for n, p in G.named_parameters()},
+               G_checksums=checksums(G.state_dict()))
+    for nm, D in (("mpd", D1), ("msd", D2)):
+        o, fm = D(y)
+        fix[nm + "_out"] = [a.detach().clone() for a in o]
+        fix[nm + "_fmap_sums"] = [[(tuple(a.shape), float(a.double().sum()), float(a.double().abs().sum())) for a in fa]
+                                  for fa in fm]
+        fix[nm + "_checksums"] = checksums(D.state_dict())
+    torch.save(fix, os.path.join(OUT, "hifigan_v1.pt"))
+    print("hifigan_v1 bytes", os.path.getsize(os.path.join(OUT, "hifigan_v1.pt")), float(wav.abs().mean()))
+
+
+def masks_case():
+    """get_mask_from_lengths (kantts/models/utils.py:13-23) and get_lfr_mask_from_lengths' ceil(len / r) rule on
+    seeded lengths, with and without an explicit max_len."""
+    from kantts.models.utils import get_mask_from_lengths
+
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for B, hi in ((1, 5), (7, 40), (32, 613)):
+        lens = torch.randint(1, hi, (B,), generator=g)
+        cases.append(dict(lengths=lens, mask=get_mask_from_lengths(lens).clone(),
+                          mask_maxlen=get_mask_from_lengths(lens, max_len=hi + 3).clone(), max_len=hi + 3))
+    torch.save(cases, os.path.join(OUT, "masks.pt"))
+
+
 def melspec_case():
     g = torch.Generator().manual_seed(7)
     x = torch.randn(4, 2048, generator=g) * 0.1
@@ -444,3 +485,5 @@ if __name__ == "__main__":
     sambert_curve_case()
     gan_curve_case()
     voc_dataset_case()
+    hifigan_v1_case()
+    masks_case()

@@ -10,7 +10,9 @@ tests/test_oracle_vs_reference.py compares live).
 
 All functions take ``P``: a dict name -> tensor holding a reference ``state_dict`` (same key names),
 so autograd through this file yields reference-equivalent parameter gradients.
-Dropout is not modelled (parity runs force every dropout p to 0, SURVEY.md section 7 "hard parts").
+Dropout: parity runs force every dropout p to 0 (SURVEY.md section 7 "hard parts"); ``DROP["on"] = True`` switches
+F.dropout on at the reference's sites (same p, torch's own generator) -- used only by bench.py's cpu_baseline leg to
+time the "as shipped" training mode, never for parity.
 """
 import math
 
@@ -19,6 +21,13 @@ import torch.nn.functional as F
 
 
 # ----------------------------------------------------------------------------- small helpers
+DROP = {"on": False}
+
+
+def _drop(x, p):
+    return F.dropout(x, p, True) if (DROP["on"] and p > 0) else x
+
+
 def pad_mask(lengths, max_len):
     """True = padded.  kantts/models/utils.py:13-23"""
     return torch.arange(max_len, device=lengths.device)[None, :] >= lengths[:, None]
@@ -45,17 +54,17 @@ def _merge_heads(t, n_head):
     return t.view(n_head, B, L, d).permute(1, 2, 0, 3).reshape(B, L, n_head * d)
 
 
-def _attend(q, k, v, mask):
+def _attend(q, k, v, mask, dropatt=0.0):
     """softmax(q k^T / sqrt(d) masked with -inf) v.  kantts/models/sambert/__init__.py:17-29"""
     s = torch.bmm(q, k.transpose(1, 2)) / math.sqrt(q.shape[-1])
     if mask is not None:
         s = s.masked_fill(mask, float("-inf"))
-    p = torch.softmax(s, dim=2)
+    p = _drop(torch.softmax(s, dim=2), dropatt)
     return torch.bmm(p, v), p
 
 
 # ----------------------------------------------------------------------------- encoder
-def self_attention(P, pre, x, key_pad, n_head):
+def self_attention(P, pre, x, key_pad, n_head, dropout=0.0, dropatt=0.0):
     """MultiHeadSelfAttention.forward, kantts/models/sambert/__init__.py:74-106"""
     B, L, d_in = x.shape
     h = _ln(x, P, pre + ".layer_norm")
@@ -64,22 +73,23 @@ def self_attention(P, pre, x, key_pad, n_head):
     mask = None
     if key_pad is not None:
         mask = key_pad[:, None, :].expand(-1, L, -1).repeat(n_head, 1, 1)
-    o, p = _attend(q, k, v, mask)
-    o = _linear(_merge_heads(o, n_head), P, pre + ".fc")
+    o, p = _attend(q, k, v, mask, dropatt)
+    o = _drop(_linear(_merge_heads(o, n_head), P, pre + ".fc"), dropout)
     if o.shape[-1] == d_in:
         o = o + x
     return o, p
 
 
-def conv_ffn(P, pre, x, pad):
+def conv_ffn(P, pre, x, pad, dropout=0.0, dropout_inner=0.0):
     """PositionwiseConvFeedForward.forward, kantts/models/sambert/__init__.py:134-149"""
     h = _ln(x, P, pre + ".layer_norm").transpose(1, 2)
     w1 = P[pre + ".w_1.weight"]
     h = F.relu(F.conv1d(h, w1, P[pre + ".w_1.bias"], padding=(w1.shape[-1] - 1) // 2))
     if pad is not None:
         h = h.masked_fill(pad[:, None, :], 0)
+    h = _drop(h, dropout_inner)
     w2 = P[pre + ".w_2.weight"]
-    h = F.conv1d(h, w2, P[pre + ".w_2.bias"], padding=(w2.shape[-1] - 1) // 2)
+    h = _drop(F.conv1d(h, w2, P[pre + ".w_2.bias"], padding=(w2.shape[-1] - 1) // 2), dropout)
     return h.transpose(1, 2) + x
 
 
@@ -111,33 +121,36 @@ def text_encoder(P, cfg, inputs_ling, pad, pre="text_encoder"):
     d_model = cfg["encoder_num_units"]
     emb = emb * d_model ** 0.5  # in-place in the reference: the returned ling_embedding is scaled
     L = emb.shape[1]
-    x = emb + P[pre + ".ling_enc.position_enc.position_enc"][:, :L, :]
+    x = _drop(emb + P[pre + ".ling_enc.position_enc.position_enc"][:, :L, :], cfg["encoder_dropout"])
     attns = []
     for i in range(cfg["encoder_num_layers"]):
         lp = "%s.ling_enc.fft.%d" % (pre, i)
-        x, p = self_attention(P, lp + ".slf_attn", x, pad, cfg["encoder_num_heads"])
+        x, p = self_attention(P, lp + ".slf_attn", x, pad, cfg["encoder_num_heads"], cfg["encoder_dropout"],
+                              cfg["encoder_attention_dropout"])
         x = _zero_pad_rows(x, pad)
-        x = _zero_pad_rows(conv_ffn(P, lp + ".pos_ffn", x, pad), pad)
+        x = _zero_pad_rows(conv_ffn(P, lp + ".pos_ffn", x, pad, cfg["encoder_dropout"], cfg["encoder_relu_dropout"]),
+                           pad)
         attns.append(p)
     x = _ln(x, P, pre + ".ling_enc.ln")
     return F.linear(x, P[pre + ".ling_proj.weight"]), attns, emb
 
 
 # ----------------------------------------------------------------------------- FSMN / LSTM
-def fsmn_encoder(P, pre, x, pad, n_layers, filter_size, shift):
+def fsmn_encoder(P, pre, x, pad, n_layers, filter_size, shift, dropout=0.0):
     """FsmnEncoderV2 / FeedForwardNet / MemoryBlockV2, kantts/models/sambert/fsmn.py:8-124"""
     lp = int(round((filter_size - 1) / 2))
     rp = int((filter_size - 1) / 2)
     if shift > 0:
         lp, rp = lp + shift, rp - shift
+    x = _drop(x, dropout)
     for i in range(n_layers):
         f = "%s.ffn_lst.%d" % (pre, i)
-        ctx = F.relu(F.conv1d(x.transpose(1, 2), P[f + ".w_1.weight"], P[f + ".w_1.bias"]))
+        ctx = _drop(F.relu(F.conv1d(x.transpose(1, 2), P[f + ".w_1.weight"], P[f + ".w_1.bias"])), dropout)
         ctx = F.conv1d(ctx, P[f + ".w_2.weight"]).transpose(1, 2)
         ctx = _zero_pad_rows(ctx, pad)
         w = P["%s.memory_block_lst.%d.conv_dw.weight" % (pre, i)]
         mem = F.conv1d(F.pad(ctx.transpose(1, 2), (lp, rp)), w, groups=w.shape[0]).transpose(1, 2)
-        mem = _zero_pad_rows(mem + ctx, pad)
+        mem = _drop(_zero_pad_rows(_drop(mem + ctx, dropout), pad), dropout)
         x = mem + x if mem.shape[-1] == x.shape[-1] else mem
     return x
 
@@ -183,7 +196,7 @@ def nar_predictor(P, cfg, pre, x, pad):
     """VarFsmnRnnNARPredictor.forward, kantts/models/sambert/adaptors.py:118-141"""
     lengths = None if pad is None else (~pad).sum(1)
     h = fsmn_encoder(P, pre + ".fsmn", x, pad, cfg["predictor_fsmn_num_layers"],
-                     cfg["predictor_filter_size"], cfg["predictor_shift"])
+                     cfg["predictor_filter_size"], cfg["predictor_shift"], cfg["predictor_dropout"])
     fw = _lstm_named(P, pre + ".blstm", h, 0, lengths, False)
     bw = _lstm_named(P, pre + ".blstm", h, 0, lengths, True)
     y = _linear(torch.cat([fw, bw], -1), P, pre + ".fc").squeeze(-1)
@@ -194,7 +207,7 @@ def prenet(P, pre, x, n_hidden, has_out):
     """Prenet.forward (dropout disabled), kantts/models/sambert/__init__.py:32-49.
     Linear layers sit at Sequential indices 0, 3, 6 ... because each is followed by ReLU, Dropout."""
     for i in range(n_hidden):
-        x = F.relu(_linear(x, P, "%s.fcs.%d" % (pre, 3 * i)))
+        x = _drop(F.relu(_linear(x, P, "%s.fcs.%d" % (pre, 3 * i))), 0.5)
     if has_out:
         x = _linear(x, P, "%s.fcs.%d" % (pre, 3 * n_hidden))
     return x
@@ -322,17 +335,17 @@ def pnca_masks(L, xbw, hbw, pad, device):
     return xm, hm
 
 
-def pnca_attention(P, pre, x, memory, xm, hm, n_head):
+def pnca_attention(P, pre, x, memory, xm, hm, n_head, dropout=0.0, dropatt=0.0):
     """MultiHeadPNCAAttention.forward, kantts/models/sambert/__init__.py:269-306"""
     q, k, v = _linear(_ln(x, P, pre + ".layer_norm"), P, pre + ".w_x_qkv").chunk(3, -1)
     hk, hv = _linear(memory, P, pre + ".w_h_kv").chunk(2, -1)
     q, k, v, hk, hv = (_split_heads(t, n_head) for t in (q, k, v, hk, hv))
     xm = None if xm is None else xm.expand(x.shape[0], -1, -1).repeat(n_head, 1, 1)
     hm = None if hm is None else hm.expand(x.shape[0], -1, -1).repeat(n_head, 1, 1)
-    ox, px = _attend(q, k, v, xm)
-    oh, ph = _attend(q, hk, hv, hm)
+    ox, px = _attend(q, k, v, xm, dropatt)
+    oh, ph = _attend(q, hk, hv, hm, dropatt)
     o = _linear(_merge_heads(ox, n_head), P, pre + ".fc_x") + _linear(_merge_heads(oh, n_head), P, pre + ".fc_h")
-    return o + x, px, ph
+    return _drop(o, dropout) + x, px, ph
 
 
 def mel_decoder_train(P, cfg, memory, xbw, hbw, target, lfr_pad, pre="mel_decoder.mel_dec"):
@@ -344,15 +357,17 @@ def mel_decoder_train(P, cfg, memory, xbw, hbw, target, lfr_pad, pre="mel_decode
     x = torch.cat([go, target[:, r - 1 :: r, :]], 1)[:, :-1]
     x = prenet(P, pre + ".prenet", x, len(cfg["decoder_prenet_units"]), True)
     x = _linear(torch.cat([memory, x], -1), P, pre + ".dec_in_proj")
-    x = _zero_pad_rows(x, lfr_pad) * cfg["decoder_num_units"] ** 0.5
+    x = _drop(_zero_pad_rows(x, lfr_pad) * cfg["decoder_num_units"] ** 0.5, cfg["decoder_dropout"])
     L = x.shape[1]
     xm, hm = pnca_masks(L, xbw, hbw, lfr_pad, x.device)
     px_l, ph_l = [], []
     for i in range(cfg["decoder_num_layers"]):
         lp = "%s.pnca.%d" % (pre, i)
-        x, px, ph = pnca_attention(P, lp + ".pnca_attn", x, memory, xm, hm, cfg["decoder_num_heads"])
+        x, px, ph = pnca_attention(P, lp + ".pnca_attn", x, memory, xm, hm, cfg["decoder_num_heads"],
+                                   cfg["decoder_dropout"], cfg["decoder_attention_dropout"])
         x = _zero_pad_rows(x, lfr_pad)
-        x = _zero_pad_rows(conv_ffn(P, lp + ".pos_ffn", x, lfr_pad), lfr_pad)
+        x = _zero_pad_rows(conv_ffn(P, lp + ".pos_ffn", x, lfr_pad, cfg["decoder_dropout"],
+                                    cfg["decoder_relu_dropout"]), lfr_pad)
         px_l.append(px)
         ph_l.append(ph)
     return _linear(_ln(x, P, pre + ".ln"), P, pre + ".dec_out_proj"), px_l, ph_l
@@ -399,7 +414,7 @@ def mel_decoder_infer(P, cfg, memory, xbw, hbw, pre="mel_decoder.mel_dec"):
 def postnet(P, cfg, x, pad, pre="mel_postnet"):
     """PostNet.forward, kantts/models/sambert/kantts_sambert.py:642-649"""
     h = fsmn_encoder(P, pre + ".fsmn", x, pad, cfg["postnet_fsmn_num_layers"],
-                     cfg["postnet_filter_size"], cfg["postnet_shift"])
+                     cfg["postnet_filter_size"], cfg["postnet_shift"], cfg["postnet_dropout"])
     return _linear(_lstm_named(P, pre + ".lstm", h, 0), P, pre + ".fc")
 
 

@@ -1,0 +1,182 @@
+"""Parity at the EXACT configurations and precisions bench.py reports (VERDICT r1 "next" item 1):
+
+* BASELINE config 2: SAM-BERT full (sambert_16k.yaml zhcn) on the SURVEY 8(d) seeded batch B=32 x T_in=64 (14 797 valid
+  frames), fp32 mode AND bf16 mode, against oracle/torch_oracle.py (forward, losses, every parameter gradient);
+* BASELINE config 3: HiFi-GAN V1 class defaults (512 channels, MPD 2/3/5/7/11, MSD x3) at B=4 x 8192 samples,
+  generator forward / backward and one MPD + MSD pass, fp32 mode and bf16 mode, against oracle/hifigan_oracle.py.
+
+fp32 bounds are the north-star tolerances (mel mean-abs <= 1e-4 asserted at 1e-5; wav mean-abs <= 1e-5).  bf16 bounds
+are <= 2x the errors measured on the device for this round's kernels (written next to each assertion and into the
+bench line's "parity_error").  The oracle runs on the GPU box's host cores (seconds)."""
+import json
+import os
+
+import pytest
+import torch
+
+import hifigan_oracle as H
+import torch_oracle as O
+from util import ROOT, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+_REPORT = os.path.join(ROOT, "gpurun_out", "parity_at_bench_configs.json")
+
+
+def _record(key, val):
+    try:
+        os.makedirs(os.path.dirname(_REPORT), exist_ok=True)
+        d = json.load(open(_REPORT)) if os.path.exists(_REPORT) else {}
+        d[key] = val
+        json.dump(d, open(_REPORT, "w"), indent=1)
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module")
+def sambert_b32_oracle():
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+
+    cfg = O.sambert_config(tiny=False)
+    cfg = {k: (0.0 if "dropout" in k else v) for k, v in cfg.items()}
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(dict(cfg))
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    batch = O.synthetic_sambert_batch(B=32, T_in=64, seed=1234)
+    assert int(batch["output_lengths"].sum()) == 14797 and batch["mel_targets"].shape[1] == 612
+    out = O.sambert_forward(P, cfg, **batch)
+    L = O.sambert_losses(out, batch["input_lengths"], batch["output_lengths"], batch["mel_targets"])
+    L["total"].backward()
+    return cfg, batch, P, out, L
+
+
+# measured on MI355X this round (gpurun_out/parity_at_bench_configs.json): see DESIGN.md section 2
+_SAMBERT_BOUNDS = {
+    "fp32": dict(mel_mean=1e-5, mel_max=5e-4, loss=1e-4, grad_global=2e-3, grad_worst=2e-2),
+    "bf16": dict(mel_mean=4e-3, mel_max=5e-2, loss=2e-2, grad_global=6e-2, grad_worst=0.2),
+}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_sambert_full_b32_matches_oracle(sambert_b32_oracle, mode):
+    import kantts._hip as hip
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+
+    cfg, batch, P, out, L = sambert_b32_oracle
+    bnd = _SAMBERT_BOUNDS[mode]
+    hip.set_precision(mode)
+    try:
+        torch.manual_seed(0)
+        m = KanTtsSAMBERT(dict(cfg)).cuda()
+        m.eval()  # the Prenet's hard-wired Dropout(0.5) off, as in the oracle
+        gb = {k: v.cuda() for k, v in batch.items()}
+        res = m(**gb)
+        mel_, mel = MelReconLoss()(gb["output_lengths"], gb["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+        d, p, e = ProsodyReconLoss()(gb["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                     res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                     res["energy_predictions"])
+        total = mel_ + mel + d + p + e
+        total.backward()
+        torch.cuda.synchronize()
+    finally:
+        hip.set_precision("fp32")
+    # index / integer outputs: bit-exact in both modes
+    assert torch.equal(res["LR_length_rounded"].cpu(), out["LR_length_rounded"])
+    assert res["x_band_width"] == out["x_band_width"] and res["h_band_width"] == out["h_band_width"]
+    rep = {}
+    for k in ("dec_outputs", "postnet_outputs", "log_duration_predictions", "pitch_predictions", "energy_predictions"):
+        dd = (res[k].detach().cpu() - out[k].detach()).abs()
+        rep[k] = (float(dd.mean()), float(dd.max()))
+    rep["loss_abs"] = abs(float(total.detach()) - float(L["total"].detach()))
+    num = den = worst = 0.0
+    wname = ""
+    for n, prm in m.named_parameters():
+        if prm.requires_grad and P[n].grad is not None:
+            e2 = float((prm.grad.cpu().double() - P[n].grad.double()).pow(2).sum())
+            r2 = float(P[n].grad.double().pow(2).sum())
+            num, den = num + e2, den + r2
+            if (e2 / (r2 + 1e-60)) ** 0.5 > worst:
+                worst, wname = (e2 / (r2 + 1e-60)) ** 0.5, n
+    rep["grad_rel_l2_global"], rep["grad_rel_l2_worst"] = (num / den) ** 0.5, (worst, wname)
+    _record("sambert_full_B32_" + mode, rep)
+    print("SAM-BERT full B=32", mode, rep)
+    assert rep["postnet_outputs"][0] <= bnd["mel_mean"] and rep["dec_outputs"][0] <= bnd["mel_mean"], rep
+    assert rep["postnet_outputs"][1] <= bnd["mel_max"], rep
+    assert rep["loss_abs"] <= bnd["loss"], rep
+    assert rep["grad_rel_l2_global"] <= bnd["grad_global"] and worst <= bnd["grad_worst"], rep
+
+
+_HIFI_BOUNDS = {
+    "fp32": dict(wav_mean=1e-5, d_out=5e-5, grad=2e-3),
+    "bf16": dict(wav_mean=2e-2, d_out=5e-2, grad=0.15),
+}
+
+
+@pytest.fixture(scope="module")
+def hifigan_v1_oracle():
+    from kantts.models.hifigan.hifigan import Generator, MultiPeriodDiscriminator, MultiScaleDiscriminator
+
+    torch.manual_seed(0)
+    mods = (Generator(), MultiPeriodDiscriminator(), MultiScaleDiscriminator())  # class defaults = V1, 512 channels
+    assert mods[0].state_dict()["conv_pre.conv1d.weight_v"].shape[0] == 512
+    Ps = [{k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()} for m in mods]
+    g = torch.Generator().manual_seed(1)
+    B, frames = 4, 32
+    x = torch.randn(B, 80, frames, generator=g)
+    y = torch.randn(B, 1, frames * 256, generator=g).clamp(-1, 1)
+    cot = torch.randn(B, 1, frames * 256, generator=g)
+    yr = H.generator(Ps[0], x)
+    (yr * cot).sum().backward()
+    douts = []
+    for P, f in ((Ps[1], H.mpd), (Ps[2], H.msd)):
+        o, fm = f(P, y)
+        loss = sum((a * a).mean() for a in o) + sum(a.abs().mean() for fa in fm for a in fa)
+        loss.backward()
+        douts.append(([a.detach() for a in o], [[a.detach() for a in fa] for fa in fm]))
+    return mods, Ps, x, y, cot, yr.detach(), douts
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_hifigan_v1_512ch_matches_oracle(hifigan_v1_oracle, mode):
+    import copy
+
+    import kantts._hip as hip
+
+    mods, Ps, x, y, cot, yr, douts = hifigan_v1_oracle
+    bnd = _HIFI_BOUNDS[mode]
+    hip.set_precision(mode)
+    rep = {}
+    try:
+        G = copy.deepcopy(mods[0]).cuda()
+        yo = G(x.cuda())
+        assert yo.shape == yr.shape == (4, 1, 8192)
+        dw = (yo.detach().cpu() - yr).abs()
+        rep["wav"] = (float(dw.mean()), float(dw.max()))
+        (yo * cot.cuda()).sum().backward()
+        num = den = 0.0
+        for n, p in G.named_parameters():
+            num += float((p.grad.cpu().double() - Ps[0][n].grad.double()).pow(2).sum())
+            den += float(Ps[0][n].grad.double().pow(2).sum())
+        rep["G_grad_rel_l2"] = (num / den) ** 0.5
+        for i, nm in ((1, "mpd"), (2, "msd")):
+            D = copy.deepcopy(mods[i]).cuda()
+            o, fm = D(y.cuda())
+            o_r, f_r = douts[i - 1]
+            rep[nm + "_out"] = max(float((a.detach().cpu() - b).abs().max()) for a, b in zip(o, o_r))
+            rep[nm + "_fmap_rel"] = max(rel_l2(a.detach().cpu(), b) for fa, fb in zip(fm, f_r) for a, b in zip(fa, fb))
+            loss = sum((a * a).mean() for a in o) + sum(a.abs().mean() for fa in fm for a in fa)
+            loss.backward()
+            num = den = 0.0
+            for n, p in D.named_parameters():
+                num += float((p.grad.cpu().double() - Ps[i][n].grad.double()).pow(2).sum())
+                den += float(Ps[i][n].grad.double().pow(2).sum())
+            rep[nm + "_grad_rel_l2"] = (num / den) ** 0.5
+        torch.cuda.synchronize()
+    finally:
+        hip.set_precision("fp32")
+    _record("hifigan_v1_512ch_B4x8192_" + mode, rep)
+    print("HiFi-GAN V1 512ch B=4x8192", mode, rep)
+    assert rep["wav"][0] <= bnd["wav_mean"], rep
+    assert rep["mpd_out"] <= bnd["d_out"] and rep["msd_out"] <= bnd["d_out"], rep
+    assert max(rep["G_grad_rel_l2"], rep["mpd_grad_rel_l2"], rep["msd_grad_rel_l2"]) <= bnd["grad"], rep

@@ -1,5 +1,8 @@
 """HiFi-GAN generator / MPD / MSD: host logic under the emulated ABI (CPU) and kernel parity on the GPU
-against oracle/hifigan_oracle.py (pinned live against the reference by oracle/check_vs_reference.py).
+against oracle/hifigan_oracle.py.  The oracle itself is pinned to the untouched reference twice: live in the build
+container by oracle/check_vs_reference.py (its HiFi-GAN section: G / MPD / MSD forward + gradients at 512 and 64
+channels) and, travelling with the repo, by tests/golden/hifigan_v1.pt (the reference's V1 class defaults;
+test_oracle_matches_reference_v1_fixture below).
 Tolerances: fp32 path wav mean-abs <= 1e-4 (asserted at 1e-5), parameter gradients rel-L2 <= 2e-3."""
 import pytest
 import torch
@@ -384,3 +387,71 @@ def test_noncausal_generator_and_spectral_norm_gpu():
 
     hip.set_precision("fp32")
     _noncausal_and_spectral("cuda")
+
+
+def _v1_fixture():
+    import os
+
+    from util import GOLDEN
+
+    return torch.load(os.path.join(GOLDEN, "hifigan_v1.pt"), weights_only=False)
+
+
+def _v1_models(fix):
+    """V1 class defaults from the fixture's seed; the seeded weights must be the reference's (checksums)."""
+    G, D1, D2 = _models(512, seed=0)
+    for m, key in ((G, "G_checksums"), (D1, "mpd_checksums"), (D2, "msd_checksums")):
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(fix[key].keys())
+        for k, (shape, s_, a_) in fix[key].items():
+            assert tuple(sd[k].shape) == tuple(shape), k
+            assert abs(float(sd[k].double().sum()) - s_) <= 1e-9 * max(1.0, a_), k
+    return G, D1, D2
+
+
+def test_oracle_matches_reference_v1_fixture():
+    """oracle/hifigan_oracle.py == the untouched reference at HiFi-GAN V1 (512 ch, MPD x5, MSD x3): outputs recorded by
+    oracle/make_golden.py::hifigan_v1_case."""
+    fix = _v1_fixture()
+    G, D1, D2 = _v1_models(fix)
+    PG = {k: v.detach().clone().requires_grad_(True) for k, v in G.state_dict().items()}
+    wav = H.generator(PG, fix["x"])
+    assert_close(wav.detach(), fix["wav"], 2e-6, what="oracle wav")
+    (wav * fix["cot"]).sum().backward()
+    for n, ref in fix["G_grad_norms"].items():
+        assert abs(float(PG[n].grad.double().norm()) - ref) <= 1e-3 * ref + 1e-7, n  # a LeakyReLU flip moves a small bias gradient by ~1e-4
+    for D, f, nm in ((D1, H.mpd, "mpd"), (D2, H.msd, "msd")):
+        o, fm = f({k: v for k, v in D.state_dict().items()}, fix["y"])
+        for a, b in zip(o, fix[nm + "_out"]):
+            assert_close(a, b, 2e-6, what=nm)
+        for fa, fb in zip(fm, fix[nm + "_fmap_sums"]):
+            for a, (shape, s_, a_) in zip(fa, fb):
+                assert tuple(a.shape) == tuple(shape)
+                assert abs(float(a.double().sum()) - s_) <= 1e-5 * max(1.0, a_)
+
+
+@pytest.mark.gpu
+def test_hifigan_v1_gpu_matches_reference_fixture():
+    """HIP path (fp32 mode) at the V1 class defaults against outputs recorded from the reference itself."""
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    fix = _v1_fixture()
+    G, D1, D2 = _v1_models(fix)
+    G = G.cuda()
+    wav = G(fix["x"].cuda())
+    d = (wav.detach().cpu() - fix["wav"]).abs()
+    assert float(d.mean()) <= 1e-5 and float(d.max()) <= 2e-4, (float(d.mean()), float(d.max()))
+    (wav * fix["cot"].cuda()).sum().backward()
+    for n, p in G.named_parameters():
+        ref = fix["G_grad_norms"][n]
+        assert abs(float(p.grad.double().norm()) - ref) <= 2e-3 * ref + 1e-6, n
+    for D, nm in ((D1, "mpd"), (D2, "msd")):
+        D = D.cuda()
+        o, fm = D(fix["y"].cuda())
+        for a, b in zip(o, fix[nm + "_out"]):
+            assert_close(a.detach().cpu(), b, 2e-5, what=nm)
+        for fa, fb in zip(fm, fix[nm + "_fmap_sums"]):
+            for a, (shape, s_, a_) in zip(fa, fb):
+                assert tuple(a.shape) == tuple(shape)
+                assert abs(float(a.double().sum()) - s_) <= 2e-4 * max(1.0, a_)

@@ -95,3 +95,17 @@ def test_oracle_reproduces_reference_free_running_inference():
     for k, ref in fix["outputs"].items():
         if ref.is_floating_point():
             assert_close(out[k], ref, atol=2e-5, what=k)
+
+
+def test_get_mask_from_lengths_bit_exact():
+    """kantts.models.utils.get_mask_from_lengths and the oracle's pad_mask against masks recorded from the reference's
+    own function (kantts/models/utils.py:13-23), with and without max_len; SeqInfo round-trips the lengths."""
+    from kantts.models.utils import SeqInfo, get_mask_from_lengths
+
+    for c in _load("masks"):
+        m = get_mask_from_lengths(c["lengths"])
+        assert m.dtype == torch.bool and torch.equal(m, c["mask"])
+        assert torch.equal(get_mask_from_lengths(c["lengths"], max_len=c["max_len"]), c["mask_maxlen"])
+        assert torch.equal(O.pad_mask(c["lengths"], c["max_len"]), c["mask_maxlen"])
+        info = SeqInfo.of(c["mask_maxlen"])
+        assert torch.equal(info.lens64, c["lengths"]) and torch.equal(info.mask, c["mask_maxlen"])

@@ -232,3 +232,61 @@ def test_gan_loss_curve_matches_reference_gpu():
 
     hip.set_precision("fp32")
     _gan_curve("cuda", tol=5e-3)
+
+
+def test_loss_accumulators_are_per_prefix(tmp_path):
+    """An evaluation in the middle of a logging interval must not drain the train sums: flushing "eval"
+    leaves "train/*" accumulating, and a first-accumulated tensor is not an alias of its (graph-static) source."""
+    from collections import defaultdict
+
+    with emulation():
+        tr, _ = _sambert_setup("cpu", str(tmp_path / "a"))
+        src = torch.tensor(1.0)
+        tr._accumulate("train", {"loss": src})
+        src.fill_(100.0)  # what a graph replay does to its static loss buffer
+        tr._accumulate("train", {"loss": torch.tensor(1.0)})
+        tr._accumulate("eval", {"loss": torch.tensor(5.0)})
+        ev, trn = defaultdict(float), defaultdict(float)
+        tr._flush_losses(ev, "eval")
+        assert dict(ev) == {"eval/loss": 5.0}
+        tr._accumulate("train", {"loss": torch.tensor(1.0)})
+        tr._flush_losses(trn, "train")
+        assert dict(trn) == {"train/loss": 3.0}
+        assert not tr._device_losses
+
+
+@pytest.mark.gpu
+def test_graph_trainer_alternating_shapes_matches_eager(tmp_path):
+    """Sambert_Trainer(graph=True) on batches of two alternating padded shapes == the eager trainer, step by step
+    (one shared device [lr, step] tensor for every captured shape, capture warm-up leaves weights / Adam
+    state / counters untouched, NoamLR reaches every graph)."""
+    import kantts._hip as hip
+    from kantts.train.trainer import Sambert_Trainer
+
+    hip.set_precision("fp32")
+
+    def run(graph):
+        tr, batches = _sambert_setup("cuda", str(tmp_path / ("g" if graph else "e")))
+        if graph:
+            tr.graph, tr._graphs = True, {}
+        extra = O.synthetic_sambert_batch(B=3, T_in=9, seed=77, min_len=5, dur_hi=5)
+        other = {"input_lings": extra["inputs_ling"], "input_emotions": extra["inputs_emotion"],
+                 "input_speakers": extra["inputs_speaker"], "valid_input_lengths": extra["input_lengths"],
+                 "valid_output_lengths": extra["output_lengths"], "mel_targets": extra["mel_targets"],
+                 "durations": extra["duration_targets"], "pitch_contours": extra["pitch_targets"],
+                 "energy_contours": extra["energy_targets"], "attn_priors": None}
+        seq = [batches[0], other, batches[0], other, batches[0], other]
+        losses = []
+        for b in seq:
+            losses.append(float(tr.train_step(b)))
+            tr.steps += 1
+        flat = tr.optimizer["KanTtsSAMBERT"].arena.flat.detach().cpu().clone()
+        return losses, flat, tr
+
+    le, fe, _ = run(False)
+    lg, fg, trg = run(True)
+    assert len(trg._graphs) == 2
+    for a, b in zip(lg, le):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (lg, le)
+    assert float((fg - fe).norm() / fe.norm()) < 1e-4
+    assert trg.optimizer["KanTtsSAMBERT"]._step == 6
