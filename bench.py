@@ -35,7 +35,8 @@ import torch.distributed as dist  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
 # mean over the FFN contractions profiled in profiles/r01_gemm_ffn_pmc_v2.txt (34.7 / 35.1 MB vs 30.6 MB algorithmic)
-MEASURED_TRAFFIC_BYTES = {"bf16": 34.9e6}
+MEASURED_TRAFFIC_BYTES = {"bf16": None, "fp32": 34.9e6}
+MEASURED_TRAFFIC_SOURCE = {"bf16": None, "fp32": "profiles/r01_gemm_ffn_pmc_v2.txt (round-1 fp32-storage kernel)"}
 
 
 def sambert_yaml_config(cfg):
@@ -44,6 +45,19 @@ def sambert_yaml_config(cfg):
         "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1.0e-9, "weight_decay": 0.0}},
         "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}},
         "grad_norm": 1.0, "batch_size": 32}
+
+
+CPU_THREADS = {"n": None}
+
+
+def _cpu_threads():
+    """Host threads of the CPU legs.  The oracle ports are chains of small ops (the postnet LSTM alone is 612 time steps
+    of eager ops per direction of autograd): beyond ~16 threads every op pays more fork/join than it gains -- round 1
+    measured that on the same box class, and this round's first bench visit, run with every core, did not finish its
+    CPU legs inside 13 minutes.  So: min(cores, 16) unless --cpu-threads says otherwise; both numbers are reported."""
+    n = CPU_THREADS["n"] or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(n)
+    return n
 
 
 def _time_iters(fn, warmup, iters, budget_s):
@@ -61,7 +75,7 @@ def _time_iters(fn, warmup, iters, budget_s):
     return sum(ts) / len(ts), len(ts)
 
 
-def cpu_baseline(cfg, hip, B=32, budget_s=25.0):
+def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
     """CPU oracle ("port" of the reference path, pinned against it by tests/golden + oracle/check_vs_reference.py)
     forward + losses + backward on the SAME seeded batch as the GPU line (B=32, 14 797 valid frames), all host cores,
     fp32; Adam omitted (12 M parameters: negligible next to fwd+bwd on CPU).  Timed with dropout off (>= 2 warm-up
@@ -77,8 +91,7 @@ def cpu_baseline(cfg, hip, B=32, budget_s=25.0):
     P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
     batch = O.synthetic_sambert_batch(B=B, T_in=64, seed=1234)
     frames = int(batch["output_lengths"].sum())
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = _cpu_threads()
     keep = {}
 
     def one():
@@ -138,38 +151,70 @@ def cpu_baseline(cfg, hip, B=32, budget_s=25.0):
             "value_dropout_on": frames / dt_on,
             "sample": "oracle/torch_oracle.py fwd+losses+bwd, fp32, the full seeded batch B=%d (%d valid frames): "
                       "dropout off 2 warm-up + %d timed, %.2f s/iter; dropout on (as shipped) 1 warm-up + %d timed, "
-                      "%.2f s/iter; torch.set_num_threads(%d)" % (B, frames, n_off, dt_off, n_on, dt_on, cores)}
+                      "%.2f s/iter; torch.set_num_threads(%d) of %d host cores" % (B, frames, n_off, dt_off, n_on, dt_on,
+                                                                                   cores, os.cpu_count() or 1)}
     return base, parity
 
 
 def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
-    """Roofline of the dominant kernel: the MFMA GEMM on the six decoder-FFN contractions (forward, dgrad, wgrad
-    of Conv1d(128->1024,k=1) and Conv1d(1024->128,k=1) at M = 32*204 decoder tokens; 12 layers each = 31 % of the
-    step's GEMM flops).  Each contraction is launched `reps` times inside a captured hipGraph (so the host is out
-    of the picture) and timed with HIP events on the replay stream; achieved = algorithmic flops / mean duration."""
-    from kantts._hip import gemm, make_seg, ops
+    """Roofline of the dominant kernel: the MFMA contractions of the decoder feed-forward block (forward, input
+    gradient, weight gradient of Conv1d(128->1024,k=1) and Conv1d(1024->128,k=1) at M = 32*204 decoder tokens; 12 layers
+    each = 31 % of the step's contraction flops).  Each contraction is launched `reps` times inside a captured hipGraph
+    (the host is out of the picture) and timed with HIP events on the replay stream.  Algorithmic bytes = every operand
+    read once + the output written once AT ITS STORAGE DTYPE: bf16 mode stores the LayerNorm output, the hidden
+    activation and the weights as bf16 and keeps the residual stream / its gradient fp32 (kantts/_hip/ops_bf16.py)."""
+    from kantts._hip import bgemm_nt, bgemm_tn, gemm, make_seg, ops
 
     dev = "cuda"
     M, C, F = 32 * 204, 128, 1024
-    p = {"fp32": hip.PREC_FP32, "bf16": hip.PREC_BF16}[precision]
-    x, h = torch.randn(M, C, device=dev), torch.randn(M, F, device=dev)
-    w1, w2 = torch.randn(F, C, device=dev) * 0.05, torch.randn(C, F, device=dev) * 0.05
-    yh, yx = torch.empty(M, F, device=dev), torch.empty(M, C, device=dev)
-    dw1, dw2 = torch.zeros(F, C, device=dev), torch.zeros(C, F, device=dev)
-    cases = {
-        "fwd 128->1024": lambda: gemm([make_seg(x, C, 1, w1, C, 1, C)], M, F, yh, F, 1, precision=p),
-        "fwd 1024->128": lambda: gemm([make_seg(h, F, 1, w2, F, 1, F)], M, C, yx, C, 1, precision=p),
-        "dgrad 128->1024": lambda: gemm([make_seg(h, F, 1, w1, 1, C, F)], M, C, yx, C, 1, precision=p),
-        "dgrad 1024->128": lambda: gemm([make_seg(x, C, 1, w2, 1, F, C)], M, F, yh, F, 1, precision=p),
-        "wgrad 128->1024": lambda: gemm([make_seg(h, 1, F, x, 1, C, M)], F, C, dw1, C, 1, accumulate=True,
-                                        splitk=ops._splitk_for(F, C, M), precision=p),
-        "wgrad 1024->128": lambda: gemm([make_seg(x, 1, C, h, 1, F, M)], C, F, dw2, F, 1, accumulate=True,
-                                        splitk=ops._splitk_for(C, F, M), precision=p),
-    }
     flops = 2.0 * M * C * F
-    per = {}
-    tot_us = 0.0
-    for name, fn in cases.items():
+    if precision == "bf16":
+        bf = torch.bfloat16
+        xb, hb = torch.randn(M, C, device=dev).to(bf), torch.randn(M, F, device=dev).relu().to(bf)
+        w1b, w2b = (torch.randn(F, C, device=dev) * 0.05).to(bf), (torch.randn(C, F, device=dev) * 0.05).to(bf)
+        b1, b2 = torch.zeros(F, device=dev), torch.zeros(C, device=dev)
+        res, dy = torch.randn(M, C, device=dev), torch.randn(M, C, device=dev)
+        yh, dz = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
+        yx, dh = torch.empty(M, C, device=dev), torch.empty(M, C, device=dev, dtype=bf)
+        dw1, dw2 = torch.zeros(F, C, device=dev), torch.zeros(C, F, device=dev)
+        cases = {
+            "fwd 128->1024 (bf16 -> bf16, bias+relu)": (
+                lambda: bgemm_nt([(xb, C, w1b, C, C, 0)], M, F, yh, F, bias=b1, relu=True), 2 * M * C + 2 * C * F + 2 * M * F),
+            "fwd 1024->128 (bf16 -> fp32, bias+residual)": (
+                lambda: bgemm_nt([(hb, F, w2b, F, F, 0)], M, C, yx, C, bias=b2, res=res, ldr=C),
+                2 * M * F + 2 * C * F + 8 * M * C),
+            "dgrad 1024<-128 (fp32 dy, gate by hidden -> bf16)": (
+                lambda: bgemm_nt([(dy, C, w2b, F, C, 0)], M, F, dz, F, b_kn=True, gate=hb, ldg=F),
+                4 * M * C + 2 * C * F + 4 * M * F),
+            "dgrad 128<-1024 (bf16 -> bf16)": (
+                lambda: bgemm_nt([(dz, F, w1b, C, F, 0)], M, C, dh, C, b_kn=True), 2 * M * F + 2 * C * F + 2 * M * C),
+            "wgrad 128x1024 (fp32 dy x bf16 hidden)": (
+                lambda: bgemm_tn(dy, C, hb, F, M, C, F, dw2, F, 1), 4 * M * C + 2 * M * F + 4 * C * F),
+            "wgrad 1024x128 (bf16 dz x bf16 ln-out)": (
+                lambda: bgemm_tn(dz, F, xb, C, M, F, C, dw1, C, 1), 2 * M * F + 2 * M * C + 4 * C * F),
+        }
+        kernel, bytes_dtype = "bgemm_nt_kernel / bgemm_tn_kernel (csrc/gemm_bf16.hip)", "bf16 activations + weights, fp32 residual stream"
+    else:
+        p = hip.PREC_FP32
+        x, h = torch.randn(M, C, device=dev), torch.randn(M, F, device=dev)
+        w1, w2 = torch.randn(F, C, device=dev) * 0.05, torch.randn(C, F, device=dev) * 0.05
+        yh, yx = torch.empty(M, F, device=dev), torch.empty(M, C, device=dev)
+        dw1, dw2 = torch.zeros(F, C, device=dev), torch.zeros(C, F, device=dev)
+        by = 4 * (M * C + C * F + M * F)
+        cases = {
+            "fwd 128->1024": (lambda: gemm([make_seg(x, C, 1, w1, C, 1, C)], M, F, yh, F, 1, precision=p), by),
+            "fwd 1024->128": (lambda: gemm([make_seg(h, F, 1, w2, F, 1, F)], M, C, yx, C, 1, precision=p), by),
+            "dgrad 128->1024": (lambda: gemm([make_seg(h, F, 1, w1, 1, C, F)], M, C, yx, C, 1, precision=p), by),
+            "dgrad 1024->128": (lambda: gemm([make_seg(x, C, 1, w2, 1, F, C)], M, F, yh, F, 1, precision=p), by),
+            "wgrad 128->1024": (lambda: gemm([make_seg(h, 1, F, x, 1, C, M)], F, C, dw1, C, 1, accumulate=True,
+                                             splitk=ops._splitk_for(F, C, M), precision=p), by),
+            "wgrad 1024->128": (lambda: gemm([make_seg(x, 1, C, h, 1, F, M)], C, F, dw2, F, 1, accumulate=True,
+                                             splitk=ops._splitk_for(C, F, M), precision=p), by),
+        }
+        kernel, bytes_dtype = "gemm_fast_kernel<fp32> (csrc/gemm_fast.hip)", "fp32"
+    per, per_gbps = {}, {}
+    tot_us, tot_bytes = 0.0, 0.0
+    for name, (fn, nbytes) in cases.items():
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -186,10 +231,12 @@ def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (reps * replays)
         per[name] = round(us, 2)
+        per_gbps[name] = round(nbytes / us / 1e3, 1)
         tot_us += us
-    bytes_per_launch = 4.0 * (M * C + C * F + M * F)  # both operands read once + the output written once, fp32
-    return flops * len(cases) / (tot_us * 1e-6) / 1e12, per, flops, bytes_per_launch * len(cases) / (tot_us * 1e-6) / 1e9, \
-        bytes_per_launch
+        tot_bytes += nbytes
+    return {"tflops": flops * len(cases) / (tot_us * 1e-6) / 1e12, "launch_us": per, "launch_gbps": per_gbps,
+            "flops_per_launch": flops, "gbps": tot_bytes / (tot_us * 1e-6) / 1e9, "bytes_per_launch": tot_bytes / len(cases),
+            "mean_launch_us": tot_us / len(cases), "kernel": kernel, "bytes_dtype": bytes_dtype}
 
 
 def hifigan_v1_config(channels=512):
@@ -275,11 +322,11 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
     res["gan_step_samples_per_s"] = B * T_wav / dt
     res["value"] = res["gan_step_samples_per_s"]
     res["unit"] = "audio-samples/s (GAN training step)"
-    res["losses"] = {k: float(v) for k, v in out.items()}
+    res["losses"] = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in out.items()}
     return res
 
 
-def hifigan_cpu_baseline(B=2, T_wav=8192, budget_s=20.0):
+def hifigan_cpu_baseline(B=2, T_wav=8192, budget_s=10.0):
     """CPU oracle port of the HiFi-GAN V1 GAN step (oracle/hifigan_oracle.py: generator forward + mel / adversarial /
     feature-matching generator loss + backward, generator re-run, discriminator loss + backward; optimizer updates
     omitted) and of the generator forward alone (no grad), at batch ``B`` x 8192 samples on all host cores."""
@@ -294,8 +341,7 @@ def hifigan_cpu_baseline(B=2, T_wav=8192, budget_s=20.0):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 80, T_wav // 256, generator=g)
     y = torch.randn(B, 1, T_wav, generator=g).clamp(-1, 1)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = _cpu_threads()
 
     def zero():
         for P in (PG, PP, PS):
@@ -359,7 +405,7 @@ def melspec_leg(B=32, T_wav=8192, reps=20):
 
     ms_fb = _event_ms(fb, reps)
     xc = x.cpu()
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = _cpu_threads()
     dt_cpu, n_cpu = _time_iters(lambda: A.mel_spectrogram(xc), 2, 10, 3.0)
     err = float((ms(x).cpu() - A.mel_spectrogram(xc)).abs().max())
     gbps = frames * 1344.0 / (ms_fwd * 1e-3) / 1e9
@@ -370,7 +416,7 @@ def melspec_leg(B=32, T_wav=8192, reps=20):
                          "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_frame": 1344,
                          "note": "one launch of %d frames = %.2f MB algorithmic: launch-latency bound at this size"
                                  % (frames, frames * 1344 / 1e6)},
-            "cpu_baseline": {"value": frames / dt_cpu, "unit": "frames/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "cpu_baseline": {"value": frames / dt_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
                              "sample": "oracle/audio_oracle.py mel_spectrogram on the same batch, %d timed" % n_cpu},
             "parity_error": {"max_abs_vs_oracle": err}}
 
@@ -426,11 +472,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 (parity-path) throughput figure")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU-oracle legs (default min(cores, 16))")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight gradients on the main stream (A/B switch)")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     args = ap.parse_args()
 
+    CPU_THREADS["n"] = args.cpu_threads or None
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -533,18 +581,19 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         prof = hip.profile_end()
-        tf, per_launch_us, flops_per_launch, gbps, bytes_per_launch = dominant_gemm_roofline(hip, args.precision)
+        dg = dominant_gemm_roofline(hip, args.precision)
         peak = PEAK_TFLOPS[args.precision]
-        roof = {"bound": "hbm", "kernel": "gemm_fast_kernel<%s> (decoder FFN contractions, M=6528, 128<->1024)" % args.precision,
-                "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                # memory-side bytes per launch from rocprofv3 PMC passes of the same contractions (2*FETCH_SIZE +
-                # WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); collected offline, see
-                # profiles/r01_gemm_ffn_pmc_v2.txt -- bench.py cannot run the profiler on itself
+        roof = {"bound": "hbm", "kernel": dg["kernel"] + ": decoder FFN contractions, M=6528, 128<->1024",
+                "achieved": dg["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": dg["gbps"] / PEAK_HBM_GBPS,
+                # memory-side bytes per launch come from rocprofv3 --pmc passes of scripts/bgemm_bench.py (2*FETCH_SIZE +
+                # WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), collected offline per round under profiles/
+                # -- bench.py cannot run the profiler on itself; null until this round's pass exists
                 "traffic": MEASURED_TRAFFIC_BYTES.get(args.precision),
-                "traffic_source": "profiles/r01_gemm_ffn_pmc_v2.txt (offline rocprofv3 --pmc passes; regenerate when the kernel changes)",
-                "bytes_per_launch": bytes_per_launch, "bytes_dtype": "fp32 (activations and weights are stored fp32 in HBM)",
-                "flops_per_launch": flops_per_launch, "launch_us": per_launch_us,
-                "mfma_tflops": tf, "mfma_peak": peak, "mfma_frac": tf / peak,
+                "traffic_source": MEASURED_TRAFFIC_SOURCE.get(args.precision),
+                "bytes_per_launch": dg["bytes_per_launch"], "bytes_dtype": dg["bytes_dtype"],
+                "flops_per_launch": dg["flops_per_launch"], "launch_us": dg["launch_us"], "launch_gbps": dg["launch_gbps"],
+                "mean_launch_us": dg["mean_launch_us"],
+                "mfma_tflops": dg["tflops"], "mfma_peak": peak, "mfma_frac": dg["tflops"] / peak,
                 "gemm_launches_per_step": prof["launches"], "gemm_gflop_per_step": prof["flops"] / 1e9,
                 "gemm_ms_per_step_eager_events": prof["ms"],
                 "whole_step_algorithmic_tflops": 456.9e9 * args.batch / 32 / (dt_max / args.steps) / 1e12}

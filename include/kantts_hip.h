@@ -391,6 +391,108 @@ int kantts_align_attn_bwd(const float* q, const float* k, const float* prior, co
                           const float* d_logprob, const float* d_soft, float* g_ws, float* dq, float* dk, int B, int T1,
                           int T2, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Contractions with bf16 operands in HBM (round 2; csrc/gemm_bf16.hip).  Same reference call sites as the segmented
+ * GEMM above (nn.Linear / Conv1d k=1,3 forward, input gradient, weight gradient:
+ * kantts/models/sambert/__init__.py:82,102,115-127,217,242,287,297; fsmn.py:14-29; kantts_sambert.py:173-174),
+ * used when the numerics mode is bf16: weights come from the parameter arena's bf16 shadow, activations that only feed
+ * contractions are stored bf16 by their producers.  All extents / leading dimensions are multiples of 8 elements and
+ * all base pointers 16-byte aligned (KANTTS_E_UNSUPPORTED otherwise: the caller falls back to the segmented GEMM).
+ *
+ * kantts_bgemm_nt:  C[i][j] = epilogue( sum_s sum_k A_s[tok(i) + a_shift_s][k] * B_s(j, k) )
+ *   A_s: (M, klen_s) rows of bf16 (or fp32 when a_f32: rounded to bf16 once per tile), row stride lda.
+ *   B_s: b_kn = 0: (N, klen_s) k-contiguous, row stride ldb (forward: the weight);
+ *        b_kn = 1: (klen_s, N) n-contiguous, row stride ldb (input gradient through the same weight buffer).
+ *   a_shift: conv tap -- row i reads token i + a_shift of its own sequence of T tokens, zero outside [0, T).
+ *   epilogue: v = (acc + bias[j] + bias2[j]) * alpha; relu; dropout(drop_p; element i*N + j of drop_seed + *seed_dev);
+ *             v += res[i][j] (fp32); v = gate[i][j] > 0 ? v : 0 (ReLU backward on a saved activation); rowmask[i] -> 0;
+ *             stored as bf16 (c_bf16) or fp32.
+ *   a_drop_p > 0 (a_f32 only): A is an incoming gradient through an epilogue dropout of the forward pass; element
+ *             (i, k) is multiplied by the keep-scale regenerated from (a_drop_seed + *seed_dev, i * a_drop_ld + k).
+ */
+#define KANTTS_BGEMM_MAX_SEG 12
+typedef struct kantts_bgemm_seg {
+  const void* a;
+  const void* b;
+  int64_t lda, ldb;
+  int32_t klen;
+  int32_t a_shift;
+} kantts_bgemm_seg;
+
+typedef struct kantts_bgemm_args {
+  kantts_bgemm_seg seg[KANTTS_BGEMM_MAX_SEG];
+  int32_t nseg, M, N, T;
+  int32_t a_f32, b_kn;
+  void* c;
+  int64_t ldc;
+  int32_t c_bf16;
+  int32_t relu;
+  const float* bias;
+  const float* bias2;
+  float alpha;
+  float drop_p;
+  uint64_t drop_seed;
+  const uint64_t* seed_dev;
+  const float* res;
+  int64_t ldr;
+  const void* gate;
+  int64_t ldg;
+  int32_t gate_bf16;
+  float a_drop_p;
+  uint64_t a_drop_seed;
+  int64_t a_drop_ld;
+  const uint8_t* rowmask;
+} kantts_bgemm_args;
+int kantts_bgemm_nt(const kantts_bgemm_args* args, void* stream);
+
+/* kantts_bgemm_tn:  c[n*c_ns + k*c_ks + tap*c_ts] += alpha * sum_m A[m][n] * B[tok(m) + shift0 + tap*shift_step][k]
+ *                   db[n] += alpha * sum_m A[m][n]                                   (optional)
+ * Weight / bias gradients: A = gradient of the layer output (M, N), B = layer input (M, K), tokens m are the reduction
+ * axis; fp32 atomics into a pre-zeroed gradient that may already be in the parameter's own layout (strides c_*).
+ * A / B are bf16 or fp32 (a_f32 / b_f32); a_drop_* as above with the logical index m*N + n.  slices = 0 lets the
+ * library choose the token split. */
+typedef struct kantts_bgemm_tn_args {
+  const void* a;
+  const void* b;
+  int64_t lda, ldb;
+  int32_t M, N, K, T;
+  int32_t a_f32, b_f32;
+  int32_t ntaps, shift0, shift_step, slices;
+  float* c;
+  int64_t c_ns, c_ks, c_ts;
+  float* db;
+  float alpha;
+  float a_drop_p;
+  uint64_t a_drop_seed;
+  const uint64_t* seed_dev;
+} kantts_bgemm_tn_args;
+int kantts_bgemm_tn(const kantts_bgemm_tn_args* args, void* stream);
+
+/* fp32 -> bf16 (round to nearest even) over n elements (n % 8 == 0, 16-byte aligned): the parameter arena's shadow. */
+int kantts_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+
+/* Conv1d weights (N, Cin, KT) fp32 at src + src_off -> tap-major (KT, N, Cin) bf16 at dst + dst_off, one table entry
+ * per weight (table in device memory), one launch for all of them (kantts/models/sambert/__init__.py:115-127). */
+typedef struct kantts_tapmajor_desc {
+  int64_t src_off, dst_off;
+  int32_t N, Cin, KT, pad_;
+} kantts_tapmajor_desc;
+int kantts_tapmajor_bf16(const float* src, void* dst_bf16, const kantts_tapmajor_desc* table_dev, int ndesc,
+                         int blocks_per_desc, void* stream);
+
+/* dz = (y > 0) ? dy * scale : 0 over n elements (n % 8 == 0), bf16 output: ReLU (+ dropout: scale = 1/(1-p), y is the
+ * post-dropout activation) backward of a fused linear whose output was stored for the gate
+ * (kantts/models/sambert/__init__.py:40-49,141-142). */
+int kantts_relu_gate_bf16(const void* dy, int dy_bf16, const void* y, int y_bf16, void* dz_bf16, float scale, long long n,
+                          void* stream);
+
+/* nn.LayerNorm(128, eps) forward / backward, 16 lanes per row; the output (and the incoming gradient) may be bf16 because
+ * LayerNorm outputs only feed contractions (kantts/models/sambert/__init__.py:63,130,198; kantts_sambert.py:58,128). */
+int kantts_ln128_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, float* mean, float* rstd,
+                     int M, float eps, void* stream);
+int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
+                     float* dx, float* dgamma_accum, float* dbeta_accum, int M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,616 @@
+// Contractions of the SAM-BERT step with bf16 operands in HBM (round 2).
+//
+// gemm_fast.hip keeps activations and weights fp32 in HBM and rounds them to bf16 while staging: its PMC profile
+// (profiles/r01_gemm_ablation.log) puts 11-15 us of a 19-23 us launch into that conversion / predication skeleton.
+// Here the operands a contraction reads ARE bf16 in memory (weights: the arena's bf16 shadow, refreshed once per
+// step; activations: written bf16 by the producing kernel), so staging is a 16-byte copy; fp32 operands (the residual
+// stream, incoming gradients of fp32 tensors) are still accepted and rounded once per tile.
+//
+//   bgemm_nt_kernel : C[M,N] = epi( sum_seg A_s[M,K_s] . B_s^T )      forward and input gradients
+//       B_s is (N, K_s) k-contiguous (forward: the weight itself) or, with b_kn, (K_s, N) n-contiguous (input gradient
+//       with the SAME weight buffer: the MFMA B fragments are formed by LDS transpose reads, no transposed copy).
+//       Conv taps are segments whose A rows are shifted tokens.  Epilogue: bias, alpha, ReLU, dropout, fp32 residual,
+//       gate by a saved activation (ReLU backward), row zeroing; bf16 or fp32 output, 16-byte stores.
+//   bgemm_tn_kernel : dW[N,K] += A[M,N]^T . B[M,K]   (+ bias gradient)  weight gradients, tokens are the reduction
+//       axis of both operands: natural [token][channel] LDS images, both fragments by transpose reads.
+//
+// Tiles: 256 threads = 4 waves.  NT: BM x 128 outputs (BM = 64: waves 2x2, 32x64 each; BM = 32: waves 1x4, 32x32
+// each), reduction tile 64, register-prefetched double-buffered LDS, one barrier per tile.  k-contiguous LDS images are
+// [row][64] bf16 with the 16-byte chunk index XORed by (row >> 1) & 7 (conflict-free 16- and 8-byte fragment reads);
+// n-contiguous images are [k][128 + 16] (8 consecutive k rows start 8 banks apart, as in gemm_fast.hip).
+// TN: 128 x 128 outputs, waves 2x2 with 64x64 each, token tile 32, atomics into the fp32 gradient.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define BG_THREADS 256
+#define BG_BN 128
+#define BG_BK 64
+#define BG_LDKN (BG_BN + 16)  // pitch (elements) of an n-contiguous image
+
+typedef __attribute__((address_space(3))) bf16x4 bg_lds_bf16x4;
+__device__ __forceinline__ bf16x4 bg_tr4(const __bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bg_lds_bf16x4*)(p));
+}
+
+__device__ __forceinline__ unsigned bg_pack2(float a, float b) {
+  bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)0.f, (__bf16)0.f};
+  return ((u32x2&)t).x;
+}
+__device__ __forceinline__ float bg_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bg_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// 8 consecutive elements of a row as bf16: either a 16-byte copy or two float4 loads rounded once.  `drop` regenerates
+// an epilogue dropout of the forward pass on the incoming gradient (element index = logical offset in the tensor).
+template <bool F32>
+__device__ __forceinline__ u32x4 bg_load8(const void* base, long long elem, bool ok, float drop_p, uint64_t seed,
+                                          uint64_t logical) {
+  u32x4 r = {0u, 0u, 0u, 0u};
+  if (!ok) return r;
+  if (F32) {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+    float4 a = p[0], b = p[1];
+    if (drop_p > 0.f) {
+      a.x *= kantts_dropout_scale(drop_p, seed, logical + 0);
+      a.y *= kantts_dropout_scale(drop_p, seed, logical + 1);
+      a.z *= kantts_dropout_scale(drop_p, seed, logical + 2);
+      a.w *= kantts_dropout_scale(drop_p, seed, logical + 3);
+      b.x *= kantts_dropout_scale(drop_p, seed, logical + 4);
+      b.y *= kantts_dropout_scale(drop_p, seed, logical + 5);
+      b.z *= kantts_dropout_scale(drop_p, seed, logical + 6);
+      b.w *= kantts_dropout_scale(drop_p, seed, logical + 7);
+    }
+    r.x = bg_pack2(a.x, a.y);
+    r.y = bg_pack2(a.z, a.w);
+    r.z = bg_pack2(b.x, b.y);
+    r.w = bg_pack2(b.z, b.w);
+  } else {
+    r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(base) + elem);
+  }
+  return r;
+}
+
+__device__ __forceinline__ void bg_xcd_remap(int& bx, int& by) {
+  // workgroups of one XCD get consecutive tiles in row-major order (same rule as gemm_fast.hip): the column tiles
+  // that share an A row tile stay behind one L2
+  const int gx = gridDim.x, total = gx * gridDim.y;
+  if (total >= 64) {
+    const int L = by * gx + bx, k = L & 7, j = L >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int vid = k * q + (k < r ? k : r) + j;
+    by = vid / gx;
+    bx = vid - by * gx;
+  }
+}
+
+// ================================================================================================ NT
+template <int BM, bool A_F32, bool B_KN>
+__global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm_args g) {
+  constexpr int A_BYTES = BM * BG_BK * 2;
+  constexpr int B_BYTES = B_KN ? BG_BK * BG_LDKN * 2 : BG_BN * BG_BK * 2;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int CLD = BG_BN + 4;
+  constexpr int CS_BYTES = BM * CLD * 4;
+  constexpr int LDS_BYTES = (2 * STAGE > CS_BYTES) ? 2 * STAGE : CS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  constexpr int NA = BM * 8 / BG_THREADS;  // 16-byte chunks of the A tile per thread (2 / 1)
+  constexpr int NB = 4;                    // B tile: 1024 chunks
+  constexpr int WM = (BM == 64) ? 2 : 1;   // waves along M
+  constexpr int NREP = (BM == 64) ? 4 : 2; // 16-column fragments per wave
+  constexpr int MREP = 2;                  // 32 rows per wave
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = (WM == 2) ? (wave >> 1) : 0, wc = (WM == 2) ? (wave & 1) : wave;
+  const int li = lane & 15, kg = lane >> 4;
+  int bx = blockIdx.x, by = blockIdx.y;
+  bg_xcd_remap(bx, by);
+  const int i0 = by * BM, j0 = bx * BG_BN;
+  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
+
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int m = 0; m < MREP; ++m)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-thread chunk coordinates (fixed over the reduction)
+  int a_row[NA], a_ch[NA];
+#pragma unroll
+  for (int v = 0; v < NA; ++v) {
+    const int id = tid + BG_THREADS * v;
+    a_row[v] = id >> 3;
+    a_ch[v] = id & 7;
+  }
+  int b_r[NB], b_c[NB];  // !B_KN: (n row, k chunk);  B_KN: (k row, n chunk)
+#pragma unroll
+  for (int v = 0; v < NB; ++v) {
+    const int id = tid + BG_THREADS * v;
+    if (B_KN) {
+      b_r[v] = id >> 4;
+      b_c[v] = id & 15;
+    } else {
+      b_r[v] = id >> 3;
+      b_c[v] = id & 7;
+    }
+  }
+
+  u32x4 ra[NA], rb[NB];
+  int seg = 0, k0 = 0;  // next tile to fetch
+
+  auto fetch = [&]() {
+    const kantts_bgemm_seg& s = g.seg[seg];
+#pragma unroll
+    for (int v = 0; v < NA; ++v) {
+      const int row = i0 + a_row[v];
+      const int kc = k0 + a_ch[v] * 8;
+      bool ok = row < g.M && kc < s.klen;
+      long long src = row;
+      if (s.a_shift != 0) {
+        const int t = row % g.T + s.a_shift;
+        ok = ok && t >= 0 && t < g.T;
+        src = (long long)row + s.a_shift;
+      }
+      ra[v] = bg_load8<A_F32>(s.a, src * s.lda + kc, ok, A_F32 ? g.a_drop_p : 0.f, g.a_drop_seed + seed_off,
+                              (uint64_t)src * (uint64_t)g.a_drop_ld + (uint64_t)kc);
+    }
+#pragma unroll
+    for (int v = 0; v < NB; ++v) {
+      if (B_KN) {
+        const int kr = k0 + b_r[v], nc = j0 + b_c[v] * 8;
+        const bool ok = kr < s.klen && nc < g.N;
+        rb[v] = bg_load8<false>(s.b, (long long)kr * s.ldb + nc, ok, 0.f, 0ull, 0ull);
+      } else {
+        const int n = j0 + b_r[v], kc = k0 + b_c[v] * 8;
+        const bool ok = n < g.N && kc < s.klen;
+        rb[v] = bg_load8<false>(s.b, (long long)n * s.ldb + kc, ok, 0.f, 0ull, 0ull);
+      }
+    }
+    k0 += BG_BK;
+    if (k0 >= s.klen) {
+      k0 = 0;
+      ++seg;
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* Ab = lds + buf * STAGE;
+    unsigned char* Bb = Ab + A_BYTES;
+#pragma unroll
+    for (int v = 0; v < NA; ++v) {
+      const int r = a_row[v];
+      *reinterpret_cast<u32x4*>(Ab + r * 128 + ((a_ch[v] ^ ((r >> 1) & 7)) << 4)) = ra[v];
+    }
+#pragma unroll
+    for (int v = 0; v < NB; ++v) {
+      if (B_KN) {
+        *reinterpret_cast<u32x4*>(Bb + (b_r[v] * BG_LDKN + b_c[v] * 8) * 2) = rb[v];
+      } else {
+        const int r = b_r[v];
+        *reinterpret_cast<u32x4*>(Bb + r * 128 + ((b_c[v] ^ ((r >> 1) & 7)) << 4)) = rb[v];
+      }
+    }
+  };
+
+  int ntile = 0;
+  for (int s = 0; s < g.nseg; ++s) ntile += (g.seg[s].klen + BG_BK - 1) / BG_BK;
+
+  fetch();
+  commit(0);
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const bool more = (t + 1) < ntile;
+    if (more) fetch();
+    const unsigned char* Ab = lds + (t & 1) * STAGE;
+    const unsigned char* Bb = Ab + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BG_BK / 32; ++kk) {
+      bf16x8 af[MREP], bf[NREP];
+#pragma unroll
+      for (int m = 0; m < MREP; ++m) {
+        const int r = wr * 32 + m * 16 + li;
+        const int sw = (r >> 1) & 7;
+        if (B_KN) {
+          // permuted-k convention of the transpose reads: lane group kg holds k = kg*4..+3 and 16 + kg*4..+3
+          const int c0 = kk * 4 + (kg >> 1), hb = (kg & 1) * 8;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Ab + r * 128 + ((c0 ^ sw) << 4) + hb);
+          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Ab + r * 128 + (((c0 + 2) ^ sw) << 4) + hb);
+          af[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+          af[m] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((kk * 4 + kg) ^ sw) << 4));
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NREP; ++n) {
+        const int c = wc * (NREP * 16) + n * 16;
+        if (B_KN) {
+          const __bf16* p = reinterpret_cast<const __bf16*>(Bb) + (kk * 32 + kg * 4 + (li >> 2)) * BG_LDKN + c + (li & 3) * 4;
+          const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * BG_LDKN);
+          bf[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else {
+          const int r = c + li;
+          bf[n] = *reinterpret_cast<const bf16x8*>(Bb + r * 128 + (((kk * 4 + kg) ^ ((r >> 1) & 7)) << 4));
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MREP; ++m)
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+    }
+    if (more) commit((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators through LDS so that 16 lanes write one 256 / 512-byte output row piece
+  float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int m = 0; m < MREP; ++m)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cs[(wr * 32 + m * 16 + kg * 4 + r) * CLD + wc * (NREP * 16) + n * 16 + li] = acc[m][n][r];
+  __syncthreads();
+
+  const int jc = (tid & 15) * 8;  // 8 output columns per thread
+  const int j = j0 + jc;
+  if (j >= g.N) return;
+  float bs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+  if (g.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + j), b1 = *reinterpret_cast<const float4*>(g.bias + j + 4);
+    bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+  }
+  if (g.bias2) {
+    const float4 b0 = *reinterpret_cast<const float4*>(g.bias2 + j), b1 = *reinterpret_cast<const float4*>(g.bias2 + j + 4);
+    bs[0] += b0.x; bs[1] += b0.y; bs[2] += b0.z; bs[3] += b0.w; bs[4] += b1.x; bs[5] += b1.y; bs[6] += b1.z; bs[7] += b1.w;
+  }
+#pragma unroll
+  for (int v = 0; v < BM / 16; ++v) {
+    const int rl = (tid >> 4) + 16 * v;
+    const int i = i0 + rl;
+    if (i >= g.M) continue;
+    const float4 c0 = *reinterpret_cast<const float4*>(&Cs[rl * CLD + jc]);
+    const float4 c1 = *reinterpret_cast<const float4*>(&Cs[rl * CLD + jc + 4]);
+    float o[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float val = (o[e] + bs[e]) * g.alpha;
+      if (g.relu) val = fmaxf(val, 0.f);
+      o[e] = val;
+    }
+    if (g.drop_p > 0.f) {
+      const uint64_t base = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] *= kantts_dropout_scale(g.drop_p, g.drop_seed + seed_off, base + e);
+    }
+    if (g.res) {
+      const float* rp = g.res + (long long)i * g.ldr + j;
+      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+      o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w; o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+    }
+    if (g.gate) {
+      float gv[8];
+      if (g.gate_bf16) {
+        const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(g.gate) + (long long)i * g.ldg + j);
+        gv[0] = bg_lo(q.x); gv[1] = bg_hi(q.x); gv[2] = bg_lo(q.y); gv[3] = bg_hi(q.y);
+        gv[4] = bg_lo(q.z); gv[5] = bg_hi(q.z); gv[6] = bg_lo(q.w); gv[7] = bg_hi(q.w);
+      } else {
+        const float* gp = reinterpret_cast<const float*>(g.gate) + (long long)i * g.ldg + j;
+        const float4 q0 = *reinterpret_cast<const float4*>(gp), q1 = *reinterpret_cast<const float4*>(gp + 4);
+        gv[0] = q0.x; gv[1] = q0.y; gv[2] = q0.z; gv[3] = q0.w; gv[4] = q1.x; gv[5] = q1.y; gv[6] = q1.z; gv[7] = q1.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (gv[e] > 0.f) ? o[e] : 0.f;
+    }
+    if (g.rowmask && g.rowmask[i]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    }
+    if (g.c_bf16) {
+      u32x4 w = {bg_pack2(o[0], o[1]), bg_pack2(o[2], o[3]), bg_pack2(o[4], o[5]), bg_pack2(o[6], o[7])};
+      *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.c) + (long long)i * g.ldc + j) = w;
+    } else {
+      float* cp = reinterpret_cast<float*>(g.c) + (long long)i * g.ldc + j;
+      f32x4 w0 = {o[0], o[1], o[2], o[3]}, w1 = {o[4], o[5], o[6], o[7]};
+      *reinterpret_cast<f32x4*>(cp) = w0;
+      *reinterpret_cast<f32x4*>(cp + 4) = w1;
+    }
+  }
+}
+
+template <int BM>
+static void bg_launch_nt(const kantts_bgemm_args& g, dim3 grid, hipStream_t st) {
+  const bool af = g.a_f32 != 0, kn = g.b_kn != 0;
+  if (af) {
+    if (kn)
+      hipLaunchKernelGGL((bgemm_nt_kernel<BM, true, true>), grid, dim3(BG_THREADS), 0, st, g);
+    else
+      hipLaunchKernelGGL((bgemm_nt_kernel<BM, true, false>), grid, dim3(BG_THREADS), 0, st, g);
+  } else {
+    if (kn)
+      hipLaunchKernelGGL((bgemm_nt_kernel<BM, false, true>), grid, dim3(BG_THREADS), 0, st, g);
+    else
+      hipLaunchKernelGGL((bgemm_nt_kernel<BM, false, false>), grid, dim3(BG_THREADS), 0, st, g);
+  }
+}
+
+static bool bg_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int kantts_bgemm_nt(const kantts_bgemm_args* gp, void* stream) {
+  if (!gp) return KANTTS_E_BADARG;
+  const kantts_bgemm_args& g = *gp;
+  if (g.nseg < 1 || g.nseg > KANTTS_BGEMM_MAX_SEG || g.M < 0 || g.N < 0 || !g.c) return KANTTS_E_BADARG;
+  if (g.M == 0 || g.N == 0) return KANTTS_OK;
+  // 16-byte vector access everywhere: 8-element granularity of every extent / leading dimension
+  if ((g.N & 7) || (g.ldc & 7) || !bg_aligned16(g.c)) return KANTTS_E_UNSUPPORTED;
+  if (g.res && ((g.ldr & 3) || !bg_aligned16(g.res))) return KANTTS_E_UNSUPPORTED;
+  if (g.gate && ((g.ldg & 7) || !bg_aligned16(g.gate))) return KANTTS_E_UNSUPPORTED;
+  if ((g.bias && !bg_aligned16(g.bias)) || (g.bias2 && !bg_aligned16(g.bias2))) return KANTTS_E_UNSUPPORTED;
+  for (int s = 0; s < g.nseg; ++s) {
+    const kantts_bgemm_seg& sg = g.seg[s];
+    if (!sg.a || !sg.b || sg.klen < 8 || (sg.klen & 7) || (sg.lda & 7) || (sg.ldb & 7)) return KANTTS_E_UNSUPPORTED;
+    if (!bg_aligned16(sg.a) || !bg_aligned16(sg.b)) return KANTTS_E_UNSUPPORTED;
+    if (sg.a_shift != 0 && g.T <= 0) return KANTTS_E_BADARG;
+  }
+  const long long blocks64 = (long long)kantts_cdiv(g.M, 64) * kantts_cdiv(g.N, BG_BN);
+  const bool small = blocks64 < 256;
+  hipStream_t st = (hipStream_t)stream;
+  if (small)
+    bg_launch_nt<32>(g, dim3(kantts_cdiv(g.N, BG_BN), kantts_cdiv(g.M, 32)), st);
+  else
+    bg_launch_nt<64>(g, dim3(kantts_cdiv(g.N, BG_BN), kantts_cdiv(g.M, 64)), st);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// ================================================================================================ TN (weight gradients)
+// dW[n][k] (+)= alpha * sum_m A[m][n] * B[m + shift][k];  db[n] += alpha * sum_m A[m][n]  (k-tile 0, tap 0 only).
+// grid = (k tiles, n tiles, taps * slices); slice z walks token tiles z, z + slices, ...
+#define TN_BT 32                 // tokens per tile (one MFMA k-step)
+#define TN_LD (128 + 16)         // pitch of a [token][128 channels] image
+template <bool A_F32, bool B_F32>
+__global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const kantts_bgemm_tn_args g) {
+  constexpr int IMG = TN_BT * TN_LD * 2;  // bytes of one operand image
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, kg = lane >> 4;
+  const int n0 = blockIdx.y * 128, c0 = blockIdx.x * 128;
+  const int tap = blockIdx.z / g.slices, slice = blockIdx.z % g.slices;
+  const int shift = g.shift0 + tap * g.shift_step;
+  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float colsum = 0.f;
+  const bool do_bias = g.db && blockIdx.x == 0 && tap == 0;
+
+  // 32 tokens x 16 chunks of 8 channels = 512 chunks per operand: 2 per thread
+  int tr_[2], ch_[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int id = tid + BG_THREADS * v;
+    tr_[v] = id >> 4;
+    ch_[v] = id & 15;
+  }
+  u32x4 ra[2], rb[2];
+  const int ntile = (g.M + TN_BT - 1) / TN_BT;
+
+  auto fetch = [&](int t) {
+    const int m0 = t * TN_BT;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int m = m0 + tr_[v];
+      const int nc = n0 + ch_[v] * 8, kc = c0 + ch_[v] * 8;
+      const bool oka = m < g.M && nc < g.N;
+      ra[v] = bg_load8<A_F32>(g.a, (long long)m * g.lda + nc, oka, A_F32 ? g.a_drop_p : 0.f, g.a_drop_seed + seed_off,
+                              (uint64_t)m * (uint64_t)g.N + (uint64_t)nc);
+      bool okb = m < g.M && kc < g.K;
+      long long src = m;
+      if (shift != 0) {
+        const int tt = m % g.T + shift;
+        okb = okb && tt >= 0 && tt < g.T;
+        src = (long long)m + shift;
+      }
+      rb[v] = bg_load8<B_F32>(g.b, src * g.ldb + kc, okb, 0.f, 0ull, 0ull);
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* Ab = lds + buf * 2 * IMG;
+    unsigned char* Bb = Ab + IMG;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      *reinterpret_cast<u32x4*>(Ab + (tr_[v] * TN_LD + ch_[v] * 8) * 2) = ra[v];
+      *reinterpret_cast<u32x4*>(Bb + (tr_[v] * TN_LD + ch_[v] * 8) * 2) = rb[v];
+    }
+  };
+
+  int t = slice;
+  if (t < ntile) {
+    fetch(t);
+    commit(0);
+  }
+  __syncthreads();
+  int it = 0;
+  for (; t < ntile; t += g.slices, ++it) {
+    const int tn = t + g.slices;
+    const bool more = tn < ntile;
+    if (more) fetch(tn);
+    const __bf16* Ah = reinterpret_cast<const __bf16*>(lds + (it & 1) * 2 * IMG);
+    const __bf16* Bh = Ah + TN_BT * TN_LD;
+    if (do_bias && tid < 128) {
+      float q = 0.f;
+#pragma unroll 8
+      for (int m = 0; m < TN_BT; ++m) q += (float)Ah[m * TN_LD + tid];
+      colsum += q;
+    }
+    bf16x8 af[4], bf[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const __bf16* p = Ah + (kg * 4 + (li >> 2)) * TN_LD + wr * 64 + m * 16 + (li & 3) * 4;
+      const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * TN_LD);
+      af[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const __bf16* p = Bh + (kg * 4 + (li >> 2)) * TN_LD + wc * 64 + n * 16 + (li & 3) * 4;
+      const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * TN_LD);
+      bf[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+    if (more) commit((it + 1) & 1);
+    __syncthreads();
+  }
+
+  if (do_bias && tid < 128 && (n0 + tid) < g.N && colsum != 0.f) atomicAdd(&g.db[n0 + tid], colsum * g.alpha);
+  float* cbase = g.c + (long long)tap * g.c_ts;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = n0 + wr * 64 + m * 16 + kg * 4 + r;  // output row  = channel of A
+        const int j = c0 + wc * 64 + n * 16 + li;          // output col  = channel of B
+        if (i < g.N && j < g.K) {
+          const float v = acc[m][n][r] * g.alpha;
+          if (v != 0.f) atomicAdd(cbase + (long long)i * g.c_ns + (long long)j * g.c_ks, v);
+        }
+      }
+}
+
+extern "C" int kantts_bgemm_tn(const kantts_bgemm_tn_args* gp, void* stream) {
+  if (!gp) return KANTTS_E_BADARG;
+  kantts_bgemm_tn_args g = *gp;
+  if (!g.a || !g.b || !g.c || g.M < 0 || g.N < 1 || g.K < 1 || g.ntaps < 1) return KANTTS_E_BADARG;
+  if (g.M == 0) return KANTTS_OK;
+  if ((g.N & 7) || (g.K & 7) || (g.lda & 7) || (g.ldb & 7) || !bg_aligned16(g.a) || !bg_aligned16(g.b))
+    return KANTTS_E_UNSUPPORTED;
+  if ((g.shift0 != 0 || g.shift_step != 0) && g.T <= 0) return KANTTS_E_BADARG;
+  const int tiles = kantts_cdiv(g.N, 128) * kantts_cdiv(g.K, 128) * g.ntaps;
+  const int ntile = kantts_cdiv(g.M, TN_BT);
+  int slices = g.slices > 0 ? g.slices : kantts_cdiv(512, tiles);
+  if (slices > ntile) slices = ntile;
+  if (slices < 1) slices = 1;
+  g.slices = slices;
+  dim3 grid(kantts_cdiv(g.K, 128), kantts_cdiv(g.N, 128), g.ntaps * slices);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.a_f32) {
+    if (g.b_f32)
+      hipLaunchKernelGGL((bgemm_tn_kernel<true, true>), grid, dim3(BG_THREADS), 0, st, g);
+    else
+      hipLaunchKernelGGL((bgemm_tn_kernel<true, false>), grid, dim3(BG_THREADS), 0, st, g);
+  } else {
+    if (g.b_f32)
+      hipLaunchKernelGGL((bgemm_tn_kernel<false, true>), grid, dim3(BG_THREADS), 0, st, g);
+    else
+      hipLaunchKernelGGL((bgemm_tn_kernel<false, false>), grid, dim3(BG_THREADS), 0, st, g);
+  }
+  KANTTS_CHECK_LAUNCH();
+}
+
+// ================================================================================================ casts
+// fp32 -> bf16 over a flat buffer (the parameter arena's shadow; activations that feed several contractions)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+  u32x4 w = {bg_pack2(a.x, a.y), bg_pack2(a.z, a.w), bg_pack2(b.x, b.y), bg_pack2(b.z, b.w)};
+  reinterpret_cast<u32x4*>(dst)[i] = w;
+}
+
+extern "C" int kantts_cast_f32_bf16(const float* src, void* dst, long long n, void* stream) {
+  if (!src || !dst || n < 0 || (n & 7) || !bg_aligned16(src) || !bg_aligned16(dst)) return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  const long long n8 = n / 8;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(kantts_cdiv(n8, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     reinterpret_cast<__bf16*>(dst), n8);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// Conv1d weights (N, Cin, KT) fp32 -> tap-major (KT, N, Cin) bf16, a table of them in one launch.
+__global__ __launch_bounds__(256) void tapmajor_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                                           const kantts_tapmajor_desc* __restrict__ tab) {
+  const kantts_tapmajor_desc d = tab[blockIdx.y];
+  const long long total = (long long)d.N * d.Cin * d.KT;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(o % d.Cin);
+    const long long q = o / d.Cin;
+    const int n = (int)(q % d.N), tap = (int)(q / d.N);
+    dst[d.dst_off + o] = (__bf16)src[d.src_off + ((long long)n * d.Cin + c) * d.KT + tap];
+  }
+}
+
+extern "C" int kantts_tapmajor_bf16(const float* src, void* dst, const kantts_tapmajor_desc* table_dev, int ndesc,
+                                    int blocks_per_desc, void* stream) {
+  if (!src || !dst || !table_dev || ndesc < 0 || blocks_per_desc < 1) return KANTTS_E_BADARG;
+  if (ndesc == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(tapmajor_bf16_kernel, dim3(blocks_per_desc, ndesc), dim3(256), 0, (hipStream_t)stream, src,
+                     reinterpret_cast<__bf16*>(dst), table_dev);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// ReLU(+dropout) backward on a saved activation: dz = (y > 0) ? dy * scale : 0, all operands bf16 or fp32, output bf16.
+// Used by the generic fused linear in bf16 mode (the fused FFN applies the same gate in its contraction epilogue).
+template <bool DY_BF16, bool Y_BF16>
+__global__ __launch_bounds__(256) void relu_gate_kernel(const void* __restrict__ dy, const void* __restrict__ y,
+                                                       __bf16* __restrict__ dz, float scale, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float d[8], a[8];
+  if (DY_BF16) {
+    const u32x4 q = reinterpret_cast<const u32x4*>(dy)[i];
+    d[0] = bg_lo(q.x); d[1] = bg_hi(q.x); d[2] = bg_lo(q.y); d[3] = bg_hi(q.y);
+    d[4] = bg_lo(q.z); d[5] = bg_hi(q.z); d[6] = bg_lo(q.w); d[7] = bg_hi(q.w);
+  } else {
+    const float4 p = reinterpret_cast<const float4*>(dy)[2 * i], q = reinterpret_cast<const float4*>(dy)[2 * i + 1];
+    d[0] = p.x; d[1] = p.y; d[2] = p.z; d[3] = p.w; d[4] = q.x; d[5] = q.y; d[6] = q.z; d[7] = q.w;
+  }
+  if (Y_BF16) {
+    const u32x4 q = reinterpret_cast<const u32x4*>(y)[i];
+    a[0] = bg_lo(q.x); a[1] = bg_hi(q.x); a[2] = bg_lo(q.y); a[3] = bg_hi(q.y);
+    a[4] = bg_lo(q.z); a[5] = bg_hi(q.z); a[6] = bg_lo(q.w); a[7] = bg_hi(q.w);
+  } else {
+    const float4 p = reinterpret_cast<const float4*>(y)[2 * i], q = reinterpret_cast<const float4*>(y)[2 * i + 1];
+    a[0] = p.x; a[1] = p.y; a[2] = p.z; a[3] = p.w; a[4] = q.x; a[5] = q.y; a[6] = q.z; a[7] = q.w;
+  }
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = a[e] > 0.f ? d[e] * scale : 0.f;
+  u32x4 w = {bg_pack2(o[0], o[1]), bg_pack2(o[2], o[3]), bg_pack2(o[4], o[5]), bg_pack2(o[6], o[7])};
+  reinterpret_cast<u32x4*>(dz)[i] = w;
+}
+
+extern "C" int kantts_relu_gate_bf16(const void* dy, int dy_bf16, const void* y, int y_bf16, void* dz_bf16, float scale,
+                                     long long n, void* stream) {
+  if (!dy || !y || !dz_bf16 || n < 0 || (n & 7) || !bg_aligned16(dy) || !bg_aligned16(y) || !bg_aligned16(dz_bf16))
+    return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  const long long n8 = n / 8;
+  dim3 grid(kantts_cdiv(n8, 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  __bf16* o = reinterpret_cast<__bf16*>(dz_bf16);
+  if (dy_bf16) {
+    if (y_bf16)
+      hipLaunchKernelGGL((relu_gate_kernel<true, true>), grid, block, 0, st, dy, y, o, scale, n8);
+    else
+      hipLaunchKernelGGL((relu_gate_kernel<true, false>), grid, block, 0, st, dy, y, o, scale, n8);
+  } else {
+    if (y_bf16)
+      hipLaunchKernelGGL((relu_gate_kernel<false, true>), grid, block, 0, st, dy, y, o, scale, n8);
+    else
+      hipLaunchKernelGGL((relu_gate_kernel<false, false>), grid, block, 0, st, dy, y, o, scale, n8);
+  }
+  KANTTS_CHECK_LAUNCH();
+}

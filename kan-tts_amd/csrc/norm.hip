@@ -152,3 +152,170 @@ extern "C" int kantts_layernorm_bwd(const float* dy, const float* x, const float
                      x, gamma, mean, rstd, dx, dgamma_accum, dbeta_accum, M, C, rows_per_block);
   KANTTS_CHECK_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// C = 128 specialisation (every LayerNorm of SAM-BERT except the first encoder layer's 512-wide input), round 2.
+// 16 lanes own one row (8 channels each: two float4 loads, one 16-byte bf16 store), a wave normalises 4 rows at once and
+// reduces over 16 lanes with 4 xor-shuffles; the generic kernel above spends a whole wave (and 6-step reductions) on a
+// 512-byte row.  The output / incoming gradient may be bf16: LayerNorm outputs only feed contractions
+// (csrc/gemm_bf16.hip), so the normalised activations never exist in fp32 in HBM.
+typedef unsigned int ln_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned ln_pack2(float a, float b) {
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  v2 t = {(__bf16)a, (__bf16)b};
+  return (unsigned&)t;
+}
+__device__ __forceinline__ float ln_sum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void ln128_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, void* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int M, float eps) {
+  const int sub = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < M;
+  const int c0 = sub * 8;
+  float v[8];
+  {
+    const float4* p = reinterpret_cast<const float4*>(x + (long long)(live ? row : 0) * 128 + c0);
+    const float4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += v[e];
+  const float mu = ln_sum16(s) * (1.f / 128.f);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float d = v[e] - mu;
+    q += d * d;
+  }
+  const float rs = 1.0f / sqrtf(ln_sum16(q) * (1.f / 128.f) + eps);
+  if (!live) return;
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+  const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (v[e] - mu) * rs * gm[e] + bt[e];
+  if (OUT_BF16) {
+    ln_u32x4 w = {ln_pack2(o[0], o[1]), ln_pack2(o[2], o[3]), ln_pack2(o[4], o[5]), ln_pack2(o[6], o[7])};
+    *reinterpret_cast<ln_u32x4*>(reinterpret_cast<__bf16*>(y) + (long long)row * 128 + c0) = w;
+  } else {
+    float4* yp = reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (long long)row * 128 + c0);
+    yp[0] = make_float4(o[0], o[1], o[2], o[3]);
+    yp[1] = make_float4(o[4], o[5], o[6], o[7]);
+  }
+  if (sub == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+// backward: grid-stride over 16-row slabs; dgamma / dbeta partials stay in registers, are reduced over the block's 16
+// row groups through LDS and leave as 256 atomics per block.
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void ln128_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ dx,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+  __shared__ float red[2][16][128];
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c0 = sub * 8;
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+  const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  float pg[8], pb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pg[e] = pb[e] = 0.f;
+  for (int r0 = blockIdx.x * 16; r0 < M; r0 += gridDim.x * 16) {
+    const int row = r0 + grp;
+    const bool live = row < M;
+    const long long off = (long long)(live ? row : 0) * 128 + c0;
+    float d[8], xv[8];
+    if (DY_BF16) {
+      const ln_u32x4 q = *reinterpret_cast<const ln_u32x4*>(reinterpret_cast<const __bf16*>(dy) + off);
+      d[0] = __uint_as_float(q.x << 16); d[1] = __uint_as_float(q.x & 0xffff0000u);
+      d[2] = __uint_as_float(q.y << 16); d[3] = __uint_as_float(q.y & 0xffff0000u);
+      d[4] = __uint_as_float(q.z << 16); d[5] = __uint_as_float(q.z & 0xffff0000u);
+      d[6] = __uint_as_float(q.w << 16); d[7] = __uint_as_float(q.w & 0xffff0000u);
+    } else {
+      const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy) + off);
+      const float4 a = p[0], b = p[1];
+      d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    }
+    {
+      const float4* p = reinterpret_cast<const float4*>(x + off);
+      const float4 a = p[0], b = p[1];
+      xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+    }
+    const float mu = mean[live ? row : 0], rs = rstd[live ? row : 0];
+    float xh[8], gg[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (!live) d[e] = 0.f;
+      xh[e] = (xv[e] - mu) * rs;
+      gg[e] = d[e] * gm[e];
+      s1 += gg[e];
+      s2 += gg[e] * xh[e];
+      pg[e] += d[e] * xh[e];
+      pb[e] += d[e];
+    }
+    s1 = ln_sum16(s1) * (1.f / 128.f);
+    s2 = ln_sum16(s2) * (1.f / 128.f);
+    if (live) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rs * (gg[e] - s1 - xh[e] * s2);
+      float4* op = reinterpret_cast<float4*>(dx + off);
+      op[0] = make_float4(o[0], o[1], o[2], o[3]);
+      op[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[0][grp][c0 + e] = pg[e];
+    red[1][grp][c0 + e] = pb[e];
+  }
+  __syncthreads();
+  const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+  float a = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) a += red[which][w][c];
+  if (a != 0.f) atomicAdd(which ? &dbeta[c] : &dgamma[c], a);
+}
+
+extern "C" int kantts_ln128_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, float* mean,
+                                float* rstd, int M, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || M < 0) return KANTTS_E_BADARG;
+  if (M == 0) return KANTTS_OK;
+  if (y_bf16)
+    hipLaunchKernelGGL(ln128_fwd_kernel<true>, dim3(kantts_cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                       mean, rstd, M, eps);
+  else
+    hipLaunchKernelGGL(ln128_fwd_kernel<false>, dim3(kantts_cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       y, mean, rstd, M, eps);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, float* dx, float* dgamma_accum, float* dbeta_accum, int M, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_accum || !dbeta_accum || M < 0) return KANTTS_E_BADARG;
+  if (M == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(M, 16);
+  if (blocks > 512) blocks = 512;  // <= 2 slabs per CU; every block ends with 256 atomics
+  if (dy_bf16)
+    hipLaunchKernelGGL(ln128_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx,
+                       dgamma_accum, dbeta_accum, M);
+  else
+    hipLaunchKernelGGL(ln128_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
+                       dx, dgamma_accum, dbeta_accum, M);
+  KANTTS_CHECK_LAUNCH();
+}

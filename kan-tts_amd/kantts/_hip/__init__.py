@@ -88,6 +88,48 @@ class ConvC1Args(Structure):
     ]
 
 
+BGEMM_MAX_SEG = 12
+
+
+class BGemmSeg(Structure):
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("lda", c_int64), ("ldb", c_int64), ("klen", c_int32),
+                ("a_shift", c_int32)]
+
+
+class BGemmArgs(Structure):
+    """kantts_bgemm_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("seg", BGemmSeg * BGEMM_MAX_SEG),
+        ("nseg", c_int32), ("M", c_int32), ("N", c_int32), ("T", c_int32),
+        ("a_f32", c_int32), ("b_kn", c_int32),
+        ("c", c_void_p), ("ldc", c_int64), ("c_bf16", c_int32), ("relu", c_int32),
+        ("bias", c_void_p), ("bias2", c_void_p), ("alpha", c_float), ("drop_p", c_float),
+        ("drop_seed", c_uint64), ("seed_dev", c_void_p),
+        ("res", c_void_p), ("ldr", c_int64),
+        ("gate", c_void_p), ("ldg", c_int64), ("gate_bf16", c_int32), ("a_drop_p", c_float),
+        ("a_drop_seed", c_uint64), ("a_drop_ld", c_int64),
+        ("rowmask", c_void_p),
+    ]
+
+
+class BGemmTnArgs(Structure):
+    """kantts_bgemm_tn_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("a", c_void_p), ("b", c_void_p), ("lda", c_int64), ("ldb", c_int64),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("T", c_int32),
+        ("a_f32", c_int32), ("b_f32", c_int32),
+        ("ntaps", c_int32), ("shift0", c_int32), ("shift_step", c_int32), ("slices", c_int32),
+        ("c", c_void_p), ("c_ns", c_int64), ("c_ks", c_int64), ("c_ts", c_int64),
+        ("db", c_void_p), ("alpha", c_float), ("a_drop_p", c_float),
+        ("a_drop_seed", c_uint64), ("seed_dev", c_void_p),
+    ]
+
+
+class TapMajorDesc(Structure):
+    _fields_ = [("src_off", c_int64), ("dst_off", c_int64), ("N", c_int32), ("Cin", c_int32), ("KT", c_int32),
+                ("pad_", c_int32)]
+
+
 def available() -> bool:
     return os.path.exists(LIB_PATH)
 
@@ -142,6 +184,13 @@ def lib():
         L.kantts_conv_win_launch.argtypes = [POINTER(ConvArgs), c_void_p]
         L.kantts_conv_wgrad_launch.argtypes = [POINTER(ConvWArgs), c_void_p]
         L.kantts_conv_c1_launch.argtypes = [POINTER(ConvC1Args), c_int, c_void_p]
+        L.kantts_bgemm_nt.argtypes = [POINTER(BGemmArgs), c_void_p]
+        L.kantts_bgemm_tn.argtypes = [POINTER(BGemmTnArgs), c_void_p]
+        L.kantts_cast_f32_bf16.argtypes = [p, p, ll, p]
+        L.kantts_tapmajor_bf16.argtypes = [p, p, p, i, i, p]
+        L.kantts_relu_gate_bf16.argtypes = [p, i, p, i, p, f, ll, p]
+        L.kantts_ln128_fwd.argtypes = [p, p, p, p, i, p, p, i, f, p]
+        L.kantts_ln128_bwd.argtypes = [p, i, p, p, p, p, p, p, p, i, p]
         _lib = L
     return _lib
 
@@ -154,6 +203,8 @@ EXPORTED_SYMBOLS = [
     "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_norm_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd", "kantts_weight_norm_strided_fwd", "kantts_weight_norm_strided_bwd",
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
+    "kantts_bgemm_nt", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
+    "kantts_ln128_fwd", "kantts_ln128_bwd",
 ]
 
 
@@ -293,6 +344,95 @@ def gemm(segs, M, N, c, c_is, c_js, bias=None, bias2=None, res=None, r_is=0, r_j
 
 
 E_UNSUPPORTED = -2
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16-operand contractions (csrc/gemm_bf16.hip)
+def _esz(t):
+    return 2 if t.dtype == torch.bfloat16 else 4
+
+
+def _addr(x):
+    """tensor or (tensor, element offset) -> device address"""
+    if isinstance(x, tuple):
+        return ptr(x[0]) + _esz(x[0]) * int(x[1])
+    return ptr(x)
+
+
+def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alpha=1.0, relu=False, drop_p=0.0,
+             drop_seed=0, res=None, ldr=0, gate=None, ldg=0, rowmask=None, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0):
+    """segs: list of (a, lda, b, ldb, klen, a_shift) with a / b tensors or (tensor, element offset).  All A operands share
+    one dtype (fp32 or bf16); B operands are bf16.  Returns False when the library declines the shape (caller falls
+    back to the segmented GEMM)."""
+    g = BGemmArgs()
+    assert 1 <= len(segs) <= BGEMM_MAX_SEG
+    a0 = segs[0][0][0] if isinstance(segs[0][0], tuple) else segs[0][0]
+    for k, (a, lda, b, ldb, klen, a_shift) in enumerate(segs):
+        at = a[0] if isinstance(a, tuple) else a
+        bt = b[0] if isinstance(b, tuple) else b
+        if at.dtype != a0.dtype or bt.dtype != torch.bfloat16:
+            raise TypeError("bgemm_nt: mixed A dtypes or a non-bf16 B operand")
+        s = g.seg[k]
+        s.a, s.b, s.lda, s.ldb, s.klen, s.a_shift = _addr(a), _addr(b), int(lda), int(ldb), int(klen), int(a_shift)
+    g.nseg, g.M, g.N, g.T = len(segs), int(M), int(N), int(T)
+    g.a_f32, g.b_kn = int(a0.dtype == torch.float32), int(bool(b_kn))
+    g.c, g.ldc, g.c_bf16 = _addr(c), int(ldc), int((c[0] if isinstance(c, tuple) else c).dtype == torch.bfloat16)
+    g.relu = int(bool(relu))
+    g.bias, g.bias2 = ptr(bias, torch.float32), ptr(bias2, torch.float32)
+    g.alpha, g.drop_p, g.drop_seed = float(alpha), float(drop_p), int(drop_seed)
+    g.res, g.ldr = ptr(res, torch.float32), int(ldr)
+    if gate is not None:
+        g.gate, g.ldg, g.gate_bf16 = ptr(gate), int(ldg), int(gate.dtype == torch.bfloat16)
+    g.a_drop_p, g.a_drop_seed, g.a_drop_ld = float(a_drop_p), int(a_drop_seed), int(a_drop_ld)
+    g.rowmask = ptr(rowmask)
+    dev = (c[0] if isinstance(c, tuple) else c).device
+    g.seed_dev = rng_ptr(dev) if (drop_p > 0 or a_drop_p > 0) else None
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().kantts_bgemm_nt(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "bgemm_nt")
+    if _profile is not None:
+        e1.record()
+        _profile.append((e0, e1, 2.0 * M * N * sum(sg[4] for sg in segs)))
+    return True
+
+
+def bgemm_tn(a, lda, b, ldb, M, N, K, c, c_ns, c_ks, *, c_ts=0, T=0, ntaps=1, shift0=0, shift_step=0, db=None, alpha=1.0,
+             a_drop_p=0.0, a_drop_seed=0, slices=0):
+    """c[n*c_ns + k*c_ks + tap*c_ts] += alpha * sum_m a[m][n] * b[m + shift][k] (+ db[n]); False when declined."""
+    g = BGemmTnArgs()
+    at = a[0] if isinstance(a, tuple) else a
+    bt = b[0] if isinstance(b, tuple) else b
+    g.a, g.b, g.lda, g.ldb = _addr(a), _addr(b), int(lda), int(ldb)
+    g.M, g.N, g.K, g.T = int(M), int(N), int(K), int(T)
+    g.a_f32, g.b_f32 = int(at.dtype == torch.float32), int(bt.dtype == torch.float32)
+    g.ntaps, g.shift0, g.shift_step, g.slices = int(ntaps), int(shift0), int(shift_step), int(slices)
+    g.c, g.c_ns, g.c_ks, g.c_ts = _addr(c), int(c_ns), int(c_ks), int(c_ts)
+    g.db, g.alpha = ptr(db, torch.float32), float(alpha)
+    g.a_drop_p, g.a_drop_seed = float(a_drop_p), int(a_drop_seed)
+    g.seed_dev = rng_ptr(at.device) if a_drop_p > 0 else None
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().kantts_bgemm_tn(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "bgemm_tn")
+    if _profile is not None:
+        e1.record()
+        _profile.append((e0, e1, 2.0 * M * N * K * ntaps))
+    return True
+
+
+def cast_bf16(src, dst=None):
+    """fp32 -> bf16 copy (numel % 8 == 0, contiguous)."""
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    check(lib().kantts_cast_f32_bf16(ptr(src, torch.float32), ptr(dst, torch.bfloat16), src.numel(), stream()), "cast_bf16")
+    return dst
 
 
 def conv_win(x, w_tap, out, *, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add, in_kstep, in_div, phases, inner=1, up=1,

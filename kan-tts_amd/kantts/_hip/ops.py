@@ -10,6 +10,7 @@ import math
 import torch
 
 from . import (check, get_precision, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
+from . import ops_bf16
 
 _seed_counter = itertools.count(1)
 
@@ -296,17 +297,28 @@ class _FusedLinear(torch.autograd.Function):
 
 
 def linear(xs, weights, bias=None, *, mode=None, bias2=None, res=None, rowmask=None, relu=False, alpha=1.0,
-           drop_p=0.0, pad=0, dilation=1, T=0):
-    """Functional entry: xs / weights are tensors or lists (see _FusedLinear)."""
+           drop_p=0.0, pad=0, dilation=1, T=0, out_bf16=False):
+    """Functional entry: xs / weights are tensors or lists (see _FusedLinear).  In bf16 mode the contraction runs on
+    the bf16-operand kernels (ops_bf16) whenever its extents allow; ``out_bf16`` then stores the result as bf16 (for
+    outputs whose only consumers are contractions).  fp32 mode ignores it."""
     xs = [xs] if torch.is_tensor(xs) else list(xs)
     weights = [weights] if torch.is_tensor(weights) else list(weights)
     if mode is None:
         mode = "conv" if weights[0].dim() == 3 and (weights[0].shape[2] > 1 or pad) else (
             "sum" if len(weights) > 1 else "concat")
+    params = weights
     if mode != "conv" and weights[0].dim() == 3:  # Conv1d with kernel 1 == Linear
         weights = [w.squeeze(-1) if w.dim() == 3 else w for w in weights]
     if mode == "conv":
         T = T or xs[0].shape[-2]
+    if get_precision() == "bf16" and ops_bf16.eligible(xs, weights, mode, relu, res):
+        if mode == "conv":
+            wbs = [ops_bf16.conv_weight_bf16(params[0])]
+        else:
+            wbs = [ops_bf16.bf16_weight(w) for w in params]
+        return ops_bf16.linear(xs, weights, wbs, bias, mode=mode, bias2=bias2, res=res, rowmask=rowmask, relu=relu,
+                               alpha=alpha, drop_p=drop_p, pad=pad, dilation=dilation, T=T, out_bf16=out_bf16)
+    xs = [x.float() if x.dtype != torch.float32 else x for x in xs]  # the segmented GEMM reads fp32 operands
     opts = dict(nx=len(xs), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p), pad=int(pad),
                 dilation=int(dilation), T=int(T))
     return _FusedLinear.apply(opts, bias, bias2, res, rowmask, *xs, *weights)
@@ -343,8 +355,25 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg, db, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-6):
+def layer_norm(x, gamma, beta, eps=1e-6, out_bf16=False):
+    """``out_bf16`` (bf16 mode, 128-wide rows only): the normalised activations are written bf16 -- they only feed
+    contractions.  128-wide rows use the 16-lanes-per-row kernels in both modes."""
+    if x.shape[-1] == 128 and x.dtype == torch.float32 and x.numel() > 0:
+        return ops_bf16.layer_norm128(x, gamma, beta, eps, out_bf16 and get_precision() == "bf16")
     return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p_out=0.0):
+    """Position-wise feed-forward after its LayerNorm (kantts/models/sambert/__init__.py:134-149):
+    Conv1d(k) -> ReLU -> zero padded rows -> dropout -> Conv1d(1) -> dropout -> + res (-> zero rows).
+    bf16 mode: one autograd node on the bf16-operand kernels; otherwise two fused linears."""
+    k1, k2 = w1.shape[2], w2.shape[2]
+    if get_precision() == "bf16" and ops_bf16.ffn_eligible(h, w1, w2):
+        return ops_bf16.ffn(h, w1, b1, w2, b2, res, pad_rows=pad_rows, zero_rows=zero_rows, p_inner=p_inner, p_out=p_out)
+    hid = linear(h, w1, b1, relu=True, rowmask=pad_rows, drop_p=p_inner, pad=(k1 - 1) // 2,
+                 mode="conv" if k1 > 1 else None)
+    return linear(hid, w2, b2, res=res, rowmask=zero_rows, drop_p=p_out, pad=(k2 - 1) // 2,
+                  mode="conv" if k2 > 1 else None)
 
 
 # ================================================================================================

@@ -1,0 +1,345 @@
+"""bf16-storage variants of the SAM-BERT contraction ops (numerics mode "bf16"; csrc/gemm_bf16.hip).
+
+In bf16 mode the operands a contraction reads are bf16 IN HBM: weights come from a bf16 shadow of the fp32 master
+parameters (the parameter arena refreshes it once per step; bare modules cast on demand), activations that only feed
+contractions (LayerNorm outputs, the FFN hidden layer, Prenet layers) are written bf16 by the kernel that produces
+them.  The residual stream, attention inputs / outputs, losses and every parameter gradient stay fp32.  The fp32 mode
+(kantts._hip.ops._FusedLinear on the segmented GEMM) is untouched: it is the parity path.
+
+Gradient dtypes follow autograd's rule (gradient dtype == forward tensor dtype): a bf16 activation receives a bf16
+gradient; those tensors have exactly one consumer, so nothing is ever accumulated in bf16.
+"""
+import math
+
+import torch
+
+from . import bgemm_nt, bgemm_tn, check, lib, ptr, stream
+
+BF16 = torch.bfloat16
+_wcache = {}
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def to_bf16(x):
+    """fp32 -> bf16 copy by the cast kernel (no autograd)."""
+    x = _c(x.detach())
+    if x.dtype == BF16:
+        return x
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    if x.numel() % 8 == 0:
+        check(lib().kantts_cast_f32_bf16(ptr(x, torch.float32), ptr(out, BF16), x.numel(), stream()), "cast_bf16")
+    else:
+        out.copy_(x)
+    return out
+
+
+def bf16_weight(w, tap_major=False):
+    """bf16 copy of a weight tensor ((N, K), or tap-major (KT, N, Cin) of a Conv1d weight (N, Cin, KT)).
+    Parameters that live in a ParamArena carry the arena's shadow views (refreshed once per step, also inside a captured
+    hipGraph); anything else is cast on demand and cached until the tensor's version or storage changes."""
+    sh = getattr(w, "_kantts_bf16_tap" if tap_major else "_kantts_bf16", None)
+    if sh is not None:
+        return sh
+    key = (id(w), bool(tap_major))
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr() and hit[2] == tuple(w.shape):
+        return hit[3]
+    with torch.no_grad():
+        src = w.detach()
+        if tap_major:
+            src = src.permute(2, 0, 1)
+        t = to_bf16(src)
+    if len(_wcache) > 4096:
+        _wcache.clear()
+    _wcache[key] = (w._version, w.data_ptr(), tuple(w.shape), t)
+    return t
+
+
+def conv_weight_bf16(w):
+    """(N, Cin, KT) Conv1d weight -> bf16 tap-major (KT, N, Cin) image; for KT = 1 that is the plain cast."""
+    return bf16_weight(w, tap_major=(w.shape[2] > 1))
+
+
+def eligible(xs, weights, mode, relu, res):
+    """Can the bf16 kernels take this fused linear?  (16-byte vectors: every extent a multiple of 8.)"""
+    if relu and res is not None:
+        return False
+    w0 = weights[0]
+    if mode == "conv":
+        if len(xs) != 1 or w0.shape[1] % 8 or w0.shape[0] % 8 or w0.shape[2] > 12 or xs[0].shape[-1] != w0.shape[1]:
+            return False
+        return xs[0].numel() > 0
+    if w0.shape[0] % 8 or len(xs) > 12:
+        return False
+    return all(x.shape[-1] % 8 == 0 and x.numel() > 0 for x in xs)
+
+
+def _splits(M):
+    return 0  # library default
+
+
+class _FusedLinearB(torch.autograd.Function):
+    """y = rowmask( dropout( act( (sum_k x_k @ W_k^T + bias [+ bias2]) * alpha ) ) + res ) on kantts_bgemm_nt/tn.
+    Same three modes as ops._FusedLinear (concat / sum / conv)."""
+
+    @staticmethod
+    def forward(ctx, opts, bias, bias2, res, rowmask, *t):
+        nx, nw = opts["nx"], opts["nw"]
+        xs_in = [_c(x) for x in t[:nx]]
+        ws = list(t[nx:nx + nw])          # fp32 parameters (shapes for the gradients)
+        wbs = list(t[nx + nw:])           # bf16 shadows
+        mode, relu, alpha, drop_p = opts["mode"], opts["relu"], opts["alpha"], opts["drop_p"]
+        lead = xs_in[0].shape[:-1]
+        M = int(math.prod(lead))
+        N = ws[0].shape[0]
+        T = opts.get("T", 0)
+        # the A operands of one launch share a dtype
+        dts = {x.dtype for x in xs_in}
+        xs = [to_bf16(x) for x in xs_in] if len(dts) > 1 else [x.detach() for x in xs_in]
+        dev = xs[0].device
+        y = torch.empty((M, N), device=dev, dtype=BF16 if opts["out_bf16"] else torch.float32)
+        segs = []
+        if mode == "conv":
+            cin, kt = ws[0].shape[1], ws[0].shape[2]
+            pad, dil = opts["pad"], opts.get("dilation", 1)
+            for tap in range(kt):
+                segs.append((xs[0], cin, (wbs[0], tap * N * cin), cin, cin, tap * dil - pad))
+        elif mode == "concat":
+            ldw = ws[0].shape[1]
+            off = 0
+            for x in xs:
+                k = x.shape[-1]
+                segs.append((x, k, (wbs[0], off), ldw, k, 0))
+                off += k
+            assert off == ldw, "concat widths do not match the weight"
+        else:
+            for x, wb in zip(xs, wbs):
+                k = x.shape[-1]
+                segs.append((x, k, wb, k, k, 0))
+        from .ops import next_seed
+
+        seed = next_seed() if drop_p > 0 else 0
+        r = _c(res).view(M, N) if res is not None else None
+        rm = _c(rowmask).view(M) if rowmask is not None else None
+        if not bgemm_nt(segs, M, N, y, N, T=T, bias=bias, bias2=bias2, alpha=alpha, relu=relu, drop_p=drop_p,
+                        drop_seed=seed, res=r, ldr=N, rowmask=rm):
+            raise RuntimeError("kantts_bgemm_nt declined a shape ops_bf16.eligible() accepted")
+        ctx.opts, ctx.seed, ctx.M, ctx.N, ctx.lead = opts, seed, M, N, lead
+        ctx.has = (bias is not None, bias2 is not None, res is not None)
+        ctx.x_dtypes = [x.dtype for x in xs_in]
+        ctx.w_shapes = [tuple(w.shape) for w in ws]
+        ctx.save_for_backward(y if relu else None, rm, *xs, *wbs)
+        return y.view(*lead, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .ops import gzeros, wgrad_overlap
+
+        opts, M, N = ctx.opts, ctx.M, ctx.N
+        nx, nw, mode, relu, alpha, drop_p = opts["nx"], opts["nw"], opts["mode"], opts["relu"], opts["alpha"], opts["drop_p"]
+        T = opts.get("T", 0)
+        sv = ctx.saved_tensors
+        y_gate, rm = sv[0], sv[1]
+        xs, wbs = list(sv[2:2 + nx]), list(sv[2 + nx:])
+        has_bias, has_bias2, has_res = ctx.has
+        dy = _c(dy).view(M, N)
+        if rm is not None and not relu:
+            dy = dy.masked_fill(rm.bool().view(M, 1), 0.0)
+        d_res = None
+        if has_res:
+            d_res = (dy if dy.dtype == torch.float32 else dy.float()).view(*ctx.lead, N)
+        a_drop_p, a_seed, balpha = 0.0, 0, alpha
+        if relu:
+            scale = alpha / (1.0 - drop_p) if drop_p > 0 else alpha
+            dz = torch.empty((M, N), device=dy.device, dtype=BF16)
+            check(lib().kantts_relu_gate_bf16(ptr(dy), int(dy.dtype == BF16), ptr(y_gate), int(y_gate.dtype == BF16),
+                                              ptr(dz, BF16), float(scale), M * N, stream()), "relu_gate")
+            balpha = 1.0
+        else:
+            dz = dy
+            if drop_p > 0:
+                if dz.dtype != torch.float32:
+                    dz = dz.float()
+                a_drop_p, a_seed = drop_p, ctx.seed
+        needs = ctx.needs_input_grad  # (opts, bias, bias2, res, rowmask, *xs, *ws, *wbs)
+        dxs, dws = [None] * nx, [None] * nw
+        dbias = gzeros((N,), dy.device) if (has_bias or has_bias2) else None
+        first = True
+        kw = dict(alpha=balpha, a_drop_p=a_drop_p, a_drop_seed=a_seed)
+        if mode == "conv":
+            n_, cin, kt = ctx.w_shapes[0]
+            pad, dil = opts["pad"], opts.get("dilation", 1)
+            x = xs[0]
+            if needs[5]:
+                dx = torch.empty(x.shape, device=x.device, dtype=ctx.x_dtypes[0])
+                segs = [(dz, N, (wbs[0], tap * N * cin), cin, N, pad - tap * dil) for tap in range(kt)]
+                if not bgemm_nt(segs, M, cin, dx, cin, T=T, b_kn=True, a_drop_ld=N, **kw):
+                    raise RuntimeError("bgemm_nt declined the conv input gradient")
+                dxs[0] = dx
+            if needs[5 + nx]:
+                dw = gzeros(ctx.w_shapes[0], dy.device)  # the parameter's own (N, Cin, KT) layout
+                with wgrad_overlap.side(dz, x):
+                    if not bgemm_tn(dz, N, x, cin, M, N, cin, dw, cin * kt, kt, c_ts=1, T=T, ntaps=kt, shift0=-pad,
+                                    shift_step=dil, db=dbias, **kw):
+                        raise RuntimeError("bgemm_tn declined the conv weight gradient")
+                first = False
+                dws[0] = dw
+        else:
+            off = 0
+            ldw = ctx.w_shapes[0][1]
+            if mode == "concat" and needs[5 + nx]:
+                dws[0] = gzeros(ctx.w_shapes[0], dy.device)
+            for k, x in enumerate(xs):
+                kk = x.shape[-1]
+                wb = wbs[0] if mode == "concat" else wbs[k]
+                woff = off if mode == "concat" else 0
+                wld = ldw if mode == "concat" else kk
+                if needs[5 + k]:
+                    dx = torch.empty(x.shape, device=x.device, dtype=ctx.x_dtypes[k])
+                    if not bgemm_nt([(dz, N, (wb, woff), wld, N, 0)], M, kk, dx, kk, b_kn=True, a_drop_ld=N, **kw):
+                        raise RuntimeError("bgemm_nt declined an input gradient")
+                    dxs[k] = dx
+                need_w = needs[5 + nx] if mode == "concat" else needs[5 + nx + k]
+                if need_w:
+                    if mode != "concat":
+                        dws[k] = gzeros(ctx.w_shapes[k], dy.device)
+                    dwt = dws[0] if mode == "concat" else dws[k]
+                    with wgrad_overlap.side(dz, x):
+                        if not bgemm_tn(dz, N, x, kk, M, N, kk, (dwt, woff), wld, 1, db=dbias if first else None, **kw):
+                            raise RuntimeError("bgemm_tn declined a weight gradient")
+                    first = False
+                off += kk
+        if dbias is not None and first:
+            raise RuntimeError("bias gradient without weight gradient is not supported")
+        return (None, dbias if has_bias else None, dbias if has_bias2 else None, d_res, None, *dxs, *dws,
+                *([None] * len(wbs)))
+
+
+def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, drop_p, pad, dilation, T, out_bf16):
+    opts = dict(nx=len(xs), nw=len(weights), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p),
+                pad=int(pad), dilation=int(dilation), T=int(T), out_bf16=bool(out_bf16))
+    return _FusedLinearB.apply(opts, bias, bias2, res, rowmask, *xs, *weights, *wbs)
+
+
+# ================================================================================================
+# LayerNorm(128)
+# ================================================================================================
+class _LayerNorm128(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_bf16):
+        from .ops import gzeros_like  # noqa: F401  (keeps the import graph one-directional at module load)
+
+        x = _c(x)
+        M = x.numel() // 128
+        y = torch.empty(x.shape, device=x.device, dtype=BF16 if out_bf16 else torch.float32)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        check(lib().kantts_ln128_fwd(ptr(x, torch.float32), ptr(gamma, torch.float32), ptr(beta, torch.float32), ptr(y),
+                                     int(out_bf16), ptr(mean), ptr(rstd), M, float(eps), stream()), "ln128_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .ops import gzeros_like
+
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        M = x.numel() // 128
+        dx = torch.empty_like(x)
+        dg, db = gzeros_like(gamma), gzeros_like(gamma)
+        check(lib().kantts_ln128_bwd(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                     ptr(dg), ptr(db), M, stream()), "ln128_bwd")
+        return dx, dg, db, None, None
+
+
+def layer_norm128(x, gamma, beta, eps, out_bf16):
+    return _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16))
+
+
+# ================================================================================================
+# Position-wise feed-forward block: LN output -> Conv1d(k) + ReLU + dropout -> Conv1d(1) + dropout + residual
+# ================================================================================================
+class _FusedFFNB(torch.autograd.Function):
+    """kantts/models/sambert/__init__.py:134-149 after the LayerNorm, as ONE autograd node: two contractions forward,
+    four backward.  The hidden activation is bf16 and is never gated by a separate pass: its ReLU / dropout / padded-row
+    gate is the epilogue of the input-gradient contraction through w_2."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2, res, pad_rows, zero_rows, wb1, wb2, cfg):
+        from .ops import next_seed
+
+        h = _c(h)
+        lead = h.shape[:-1]
+        M = int(math.prod(lead))
+        F, C, kt = w1.shape
+        N = w2.shape[0]
+        T, pad, p_in, p_out = cfg["T"], cfg["pad"], cfg["p_inner"], cfg["p_out"]
+        hb = h.detach() if h.dtype == BF16 else to_bf16(h)
+        s1 = next_seed() if p_in > 0 else 0
+        s2 = next_seed() if p_out > 0 else 0
+        pr = _c(pad_rows).view(M) if pad_rows is not None else None
+        zr = _c(zero_rows).view(M) if zero_rows is not None else None
+        hid = torch.empty((M, F), device=h.device, dtype=BF16)
+        segs = [(hb, C, (wb1, tap * F * C), C, C, tap - pad) for tap in range(kt)]
+        if not bgemm_nt(segs, M, F, hid, F, T=T, bias=b1, relu=True, drop_p=p_in, drop_seed=s1, rowmask=pr):
+            raise RuntimeError("bgemm_nt declined the FFN up-projection")
+        out = torch.empty((M, N), device=h.device, dtype=torch.float32)
+        r = _c(res).view(M, N)
+        if not bgemm_nt([(hid, F, wb2, F, F, 0)], M, N, out, N, bias=b2, drop_p=p_out, drop_seed=s2, res=r, ldr=N,
+                        rowmask=zr):
+            raise RuntimeError("bgemm_nt declined the FFN down-projection")
+        ctx.cfg, ctx.seeds, ctx.dims, ctx.lead = cfg, (s1, s2), (M, F, C, kt, N), lead
+        ctx.h_dtype = h.dtype
+        ctx.save_for_backward(hb, hid, zr, wb1, wb2)
+        return out.view(*lead, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .ops import gzeros, wgrad_overlap
+
+        hb, hid, zr, wb1, wb2 = ctx.saved_tensors
+        M, F, C, kt, N = ctx.dims
+        cfg = ctx.cfg
+        T, pad, p_in, p_out = cfg["T"], cfg["pad"], cfg["p_inner"], cfg["p_out"]
+        s1, s2 = ctx.seeds
+        dy = _c(dy).view(M, N)
+        if zr is not None:
+            dy = dy.masked_fill(zr.bool().view(M, 1), 0.0)
+        d_res = dy.view(*ctx.lead, N)
+        dev = dy.device
+        # gradient at the hidden pre-activation: (dropout(dy) @ w2) gated by hid > 0 (ReLU, inner dropout, padded rows)
+        dz = torch.empty((M, F), device=dev, dtype=BF16)
+        if not bgemm_nt([(dy, N, wb2, F, N, 0)], M, F, dz, F, b_kn=True, gate=hid, ldg=F,
+                        alpha=(1.0 / (1.0 - p_in) if p_in > 0 else 1.0), a_drop_p=p_out, a_drop_seed=s2, a_drop_ld=N):
+            raise RuntimeError("bgemm_nt declined the FFN hidden gradient")
+        dw2 = gzeros((N, F, 1), dev)
+        db2 = gzeros((N,), dev)
+        with wgrad_overlap.side(dy, hid):
+            if not bgemm_tn(dy, N, hid, F, M, N, F, dw2, F, 1, db=db2, a_drop_p=p_out, a_drop_seed=s2):
+                raise RuntimeError("bgemm_tn declined dW2")
+        dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
+        segs = [(dz, F, (wb1, tap * F * C), C, F, pad - tap) for tap in range(kt)]
+        if not bgemm_nt(segs, M, C, dh, C, T=T, b_kn=True):
+            raise RuntimeError("bgemm_nt declined the FFN input gradient")
+        dw1 = gzeros((F, C, kt), dev)
+        db1 = gzeros((F,), dev)
+        with wgrad_overlap.side(dz, hb):
+            if not bgemm_tn(dz, F, hb, C, M, F, C, dw1, C * kt, kt, c_ts=1, T=T, ntaps=kt, shift0=-pad, shift_step=1,
+                            db=db1):
+                raise RuntimeError("bgemm_tn declined dW1")
+        return dh.view(*ctx.lead, C), dw1, db1, dw2, db2, d_res, None, None, None, None, None
+
+
+def ffn_eligible(h, w1, w2):
+    return (w1.dim() == 3 and w2.dim() == 3 and w2.shape[2] == 1 and w1.shape[2] <= 12 and w1.shape[0] % 8 == 0 and
+            w1.shape[1] % 8 == 0 and w2.shape[0] % 8 == 0 and h.numel() > 0)
+
+
+def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p_out=0.0, T=0):
+    """h: LayerNorm output (B, T, C) (bf16 or fp32); w1 (F, C, k), w2 (C_out, F, 1) Conv1d weights; res (B, T, C_out)."""
+    cfg = dict(T=int(T or h.shape[-2]), pad=(w1.shape[2] - 1) // 2, p_inner=float(p_inner), p_out=float(p_out))
+    return _FusedFFNB.apply(h, w1, b1, w2, b2, res, pad_rows, zero_rows, conv_weight_bf16(w1), conv_weight_bf16(w2), cfg)

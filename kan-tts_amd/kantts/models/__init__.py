@@ -40,7 +40,7 @@ def sambert_model_builder(config, device, rank, distributed, use_arena=None):
     if use_arena is None:
         use_arena = _is_hip(device) and opt_type == "Adam" and not opt_params.get("amsgrad", False)
     if use_arena:
-        arena = ParamArena(net)
+        arena = ParamArena(net, bf16_shadow=True)  # operand images of the bf16-mode contractions
         optimizer["KanTtsSAMBERT"] = ArenaAdam(arena, **opt_params)
         if distributed:
             arena.enable_data_parallel()

@@ -50,7 +50,9 @@ class Prenet(nn.Module):
         while i < len(mods):
             fc = mods[i]
             if i + 2 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
-                x = ops.linear(x, fc.weight, fc.bias, relu=True, drop_p=_p(mods[i + 2], self.training))
+                # hidden Prenet layers feed the next Linear only: bf16 storage in bf16 mode
+                x = ops.linear(x, fc.weight, fc.bias, relu=True, drop_p=_p(mods[i + 2], self.training),
+                               out_bf16=(i + 3 < len(mods)))
                 i += 3
             else:
                 x = ops.linear(x, fc.weight, fc.bias)
@@ -82,7 +84,7 @@ class MultiHeadSelfAttention(nn.Module):
         if torch.is_tensor(mask) and mask.dim() == 3:
             mask = mask[:, 0, :]
         info = SeqInfo.of(mask)
-        x = ops.layer_norm(input, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        x = ops.layer_norm(input, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True)
         qkv = ops.linear(x, self.w_qkv.weight, self.w_qkv.bias)
         ctxv, attn = ops.self_attention(qkv, None if info is None else info.lens32, self.n_head,
                                         drop_p=_p(self.attention.dropatt, self.training), want_probs=return_attn)
@@ -107,16 +109,10 @@ class PositionwiseConvFeedForward(nn.Module):
     def forward(self, x, mask=None, zero_rows=None):
         info = SeqInfo.of(mask)
         pad_rows = None if info is None else info.mask
-        h = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
-        k1 = self.w_1.kernel_size[0]
-        h = ops.linear(h, self.w_1.weight, self.w_1.bias, relu=True, rowmask=pad_rows,
-                       drop_p=_p(self.dropout_inner, self.training), pad=(k1 - 1) // 2,
-                       mode="conv" if k1 > 1 else None)
-        k2 = self.w_2.kernel_size[0]
-        out = ops.linear(h, self.w_2.weight, self.w_2.bias, res=x, rowmask=zero_rows,
-                         drop_p=_p(self.dropout, self.training), pad=(k2 - 1) // 2,
-                         mode="conv" if k2 > 1 else None)
-        return out
+        h = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True)
+        return ops.ffn(h, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, x, pad_rows=pad_rows,
+                       zero_rows=zero_rows, p_inner=_p(self.dropout_inner, self.training),
+                       p_out=_p(self.dropout, self.training))
 
 
 class FFTBlock(nn.Module):
@@ -168,7 +164,7 @@ class MultiHeadPNCAAttention(nn.Module):
 
     def forward(self, x, h, info=None, x_band_width=0, h_band_width=0, zero_rows=None, return_attn=False,
                 bw_dev=None):
-        xn = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        xn = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True)
         qkv = ops.linear(xn, self.w_x_qkv.weight, self.w_x_qkv.bias)
         hkv = ops.linear(h, self.w_h_kv.weight, self.w_h_kv.bias)
         info = SeqInfo.of(info)

@@ -18,7 +18,7 @@ from kantts._hip import ops
 
 
 class ParamArena:
-    def __init__(self, module):
+    def __init__(self, module, bf16_shadow=False):
         self.module = module
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
@@ -44,6 +44,47 @@ class ParamArena:
         self._zero_cache = {}
         self.world_size = 1
         self.n_buckets = 4
+        self.flat_bf16 = None
+        if bf16_shadow:
+            self._build_shadow()
+
+    # ------------------------------------------------------------------------------------------ bf16 shadow
+    def _build_shadow(self):
+        """bf16 copy of every parameter at the same arena offset, plus tap-major (KT, N, Cin) copies of the Conv1d
+        weights with KT > 1 -- the operand images of csrc/gemm_bf16.hip.  Refreshed by ``refresh_shadow`` (two launches)
+        before every forward of the module (a forward pre-hook: also part of a captured training step), so the copies can
+        never be stale whatever changed the fp32 master (Adam, load_state_dict, a broadcast, a test poking a weight)."""
+        dev = self.flat.device
+        self.flat_bf16 = torch.zeros(self.numel, device=dev, dtype=torch.bfloat16)
+        rows, off = [], 0
+        for p, o in zip(self.params, self.offsets):
+            p._kantts_bf16 = self.flat_bf16[o:o + p.numel()].view(p.shape)
+            if p.dim() == 3 and p.shape[2] > 1:
+                n, cin, kt = p.shape
+                rows.append((o, off, n, cin, kt, p))
+                off += (p.numel() + self.align - 1) // self.align * self.align
+        self.tap_bf16 = torch.zeros(max(off, 8), device=dev, dtype=torch.bfloat16)
+        self._tap_blocks = 1
+        tab = []
+        for o, to, n, cin, kt, p in rows:
+            p._kantts_bf16_tap = self.tap_bf16[to:to + p.numel()].view(kt, n, cin)
+            tab.append([o, to, n | (cin << 32), kt])  # kantts_tapmajor_desc: two int64 offsets + N, Cin, KT, pad (int32)
+            self._tap_blocks = max(self._tap_blocks, min(64, (n * cin * kt + 1023) // 1024))
+        self._tap_table = torch.tensor(tab, dtype=torch.int64, device=dev) if tab else None
+        self.refresh_shadow()
+        self.module.register_forward_pre_hook(lambda m, a: self.refresh_shadow())
+
+    def refresh_shadow(self):
+        if self.flat_bf16 is None:
+            return
+        from kantts._hip import check, lib, ptr, stream
+
+        check(lib().kantts_cast_f32_bf16(ptr(self.flat, torch.float32), ptr(self.flat_bf16, torch.bfloat16), self.numel,
+                                         stream()), "cast_f32_bf16")
+        if self._tap_table is not None:
+            check(lib().kantts_tapmajor_bf16(ptr(self.flat, torch.float32), ptr(self.tap_bf16, torch.bfloat16),
+                                             ptr(self._tap_table), int(self._tap_table.shape[0]), int(self._tap_blocks),
+                                             stream()), "tapmajor_bf16")
 
     def view_of(self, flat, i):
         p = self.params[i]

@@ -62,6 +62,46 @@ def _val(x):
     return x.value if hasattr(x, "value") else x
 
 
+def _bf16_round(x):
+    """fp32 array -> fp32 array holding the bf16-rounded values (round to nearest even, like v_cvt_pk_bf16_f32)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    with np.errstate(over="ignore"):
+        return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+def _rd(ptr, n, bf16):
+    """n elements at ptr as fp32 values (bf16 storage is widened)."""
+    if bf16:
+        u = np.ctypeslib.as_array(ctypes.cast(int(ptr), ctypes.POINTER(ctypes.c_uint16)), shape=(int(n),))
+        return (u.astype(np.uint32) << np.uint32(16)).view(np.float32)
+    return _arr(ptr, n, np.float32).copy()
+
+
+def _wr(ptr, vals, bf16):
+    vals = np.ascontiguousarray(vals, dtype=np.float32).reshape(-1)
+    if bf16:
+        u = np.ctypeslib.as_array(ctypes.cast(int(ptr), ctypes.POINTER(ctypes.c_uint16)), shape=(vals.size,))
+        u[:] = (_bf16_round(vals).view(np.uint32) >> np.uint32(16)).astype(np.uint16)
+    else:
+        _arr(ptr, vals.size, np.float32)[:] = vals
+
+
+def _rd2d(ptr, rows, cols, ld, bf16, row_ok=None, row_src=None):
+    """(rows, cols) block with leading dimension ld; invalid rows read as zero; row_src remaps row indices."""
+    out = np.zeros((rows, cols), dtype=np.float32)
+    src = np.arange(rows, dtype=np.int64) if row_src is None else row_src
+    ok = np.ones(rows, dtype=bool) if row_ok is None else row_ok
+    if not ok.any() or cols == 0:
+        return out
+    lo, hi = int(src[ok].min()), int(src[ok].max())
+    esz = 2 if bf16 else 4
+    flat = _rd(int(ptr) + lo * ld * esz, (hi - lo) * ld + cols, bf16)
+    idx = (src[ok] - lo)[:, None] * ld + np.arange(cols)[None, :]
+    out[ok] = flat[idx]
+    return out
+
+
 class EmulatedLib:
     # ------------------------------------------------------------------------------------ misc
     def kantts_abi_version(self):
@@ -199,6 +239,151 @@ class EmulatedLib:
         xh = (X - mu[:, None]) * rs[:, None]
         g = DY * G
         DX = rs[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+        _arr(dx, M * C)[:] = DX.reshape(-1).numpy()
+        _arr(dgamma, C)[:] += (DY * xh).sum(0).numpy()
+        _arr(dbeta, C)[:] += DY.sum(0).numpy()
+        return 0
+
+    # ------------------------------------------------------------------------------------ bf16-operand contractions
+    def kantts_bgemm_nt(self, args_ref, stream):
+        g = args_ref._obj
+        M, N, T = g.M, g.N, g.T
+        if M == 0 or N == 0:
+            return 0
+        if N % 8 or g.ldc % 8:
+            return -2
+        for si in range(g.nseg):
+            s = g.seg[si]
+            if s.klen < 8 or s.klen % 8 or s.lda % 8 or s.ldb % 8:
+                return -2
+        soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
+        acc = np.zeros((M, N), dtype=np.float32)
+        rows = np.arange(M, dtype=np.int64)
+        for si in range(g.nseg):
+            s = g.seg[si]
+            ok = np.ones(M, dtype=bool)
+            src = rows.copy()
+            if s.a_shift != 0:
+                t = rows % T + s.a_shift
+                ok = (t >= 0) & (t < T)
+                src = rows + s.a_shift
+            A = _rd2d(s.a, M, s.klen, s.lda, not g.a_f32, ok, src)
+            if g.a_f32:
+                if g.a_drop_p > 0:
+                    idx = src[:, None] * g.a_drop_ld + np.arange(s.klen, dtype=np.int64)[None, :]
+                    A = A * dropout_scale(g.a_drop_p, g.a_drop_seed + soff, idx) * ok[:, None]
+                A = _bf16_round(A)
+            if g.b_kn:
+                Bm = _rd2d(s.b, s.klen, N, s.ldb, True)  # (K, N)
+                acc += A @ Bm
+            else:
+                Bm = _rd2d(s.b, N, s.klen, s.ldb, True)  # (N, K)
+                acc += A @ Bm.T
+        v = acc
+        if g.bias:
+            v = v + _arr(g.bias, N)[None, :]
+        if g.bias2:
+            v = v + _arr(g.bias2, N)[None, :]
+        v = v * np.float32(g.alpha)
+        if g.relu:
+            v = np.maximum(v, 0)
+        if g.drop_p > 0:
+            idx = rows[:, None] * N + np.arange(N, dtype=np.int64)[None, :]
+            v = v * dropout_scale(g.drop_p, g.drop_seed + soff, idx)
+        if g.res:
+            v = v + _rd2d(g.res, M, N, g.ldr, False)
+        if g.gate:
+            v = np.where(_rd2d(g.gate, M, N, g.ldg, bool(g.gate_bf16)) > 0, v, 0)
+        if g.rowmask:
+            v = np.where(_arr(g.rowmask, M, np.uint8)[:, None] != 0, 0, v)
+        v = v.astype(np.float32)
+        esz = 2 if g.c_bf16 else 4
+        for i in range(M):
+            _wr(int(g.c) + i * g.ldc * esz, v[i], bool(g.c_bf16))
+        return 0
+
+    def kantts_bgemm_tn(self, args_ref, stream):
+        g = args_ref._obj
+        M, N, K, T = g.M, g.N, g.K, g.T
+        if M == 0:
+            return 0
+        if N % 8 or K % 8 or g.lda % 8 or g.ldb % 8:
+            return -2
+        soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
+        rows = np.arange(M, dtype=np.int64)
+        A = _rd2d(g.a, M, N, g.lda, not g.a_f32)
+        if g.a_f32:
+            if g.a_drop_p > 0:
+                A = A * dropout_scale(g.a_drop_p, g.a_drop_seed + soff, rows[:, None] * N + np.arange(N, dtype=np.int64)[None, :])
+            A = _bf16_round(A)
+        if g.db:
+            _arr(g.db, N)[:] += (A.sum(0) * np.float32(g.alpha)).astype(np.float32)
+        for tap in range(g.ntaps):
+            shift = g.shift0 + tap * g.shift_step
+            ok = np.ones(M, dtype=bool)
+            src = rows.copy()
+            if shift != 0:
+                t = rows % T + shift
+                ok = (t >= 0) & (t < T)
+                src = rows + shift
+            Bm = _rd2d(g.b, M, K, g.ldb, not g.b_f32, ok, src)
+            if g.b_f32:
+                Bm = _bf16_round(Bm)
+            dW = (A.T @ Bm) * np.float32(g.alpha)
+            offs = (np.arange(N, dtype=np.int64)[:, None] * g.c_ns + np.arange(K, dtype=np.int64)[None, :] * g.c_ks
+                    + tap * g.c_ts)
+            span = int(offs.max()) + 1
+            mem = _arr(g.c, span)
+            np.add.at(mem, offs.reshape(-1), dW.reshape(-1).astype(np.float32))
+        return 0
+
+    def kantts_cast_f32_bf16(self, src, dst, n, stream):
+        if n % 8:
+            return -1
+        if n:
+            _wr(dst, _arr(src, n), True)
+        return 0
+
+    def kantts_tapmajor_bf16(self, src, dst, table, ndesc, blocks_per_desc, stream):
+        tab = np.ctypeslib.as_array(ctypes.cast(int(table), ctypes.POINTER(ctypes.c_int64)), shape=(int(ndesc) * 4,))
+        for d in range(int(ndesc)):
+            so, do = int(tab[4 * d]), int(tab[4 * d + 1])
+            n_cin = int(tab[4 * d + 2])
+            Nn, Cin = n_cin & 0xFFFFFFFF, n_cin >> 32
+            KT = int(tab[4 * d + 3]) & 0xFFFFFFFF
+            w = _arr(int(src) + 4 * so, Nn * Cin * KT).reshape(Nn, Cin, KT)
+            _wr(int(dst) + 2 * do, np.ascontiguousarray(w.transpose(2, 0, 1)), True)
+        return 0
+
+    def kantts_relu_gate_bf16(self, dy, dy_bf16, y, y_bf16, dz, scale, n, stream):
+        if n % 8:
+            return -1
+        if n:
+            d, a = _rd(dy, n, bool(dy_bf16)), _rd(y, n, bool(y_bf16))
+            _wr(dz, np.where(a > 0, d * np.float32(_val(scale)), 0), True)
+        return 0
+
+    def kantts_ln128_fwd(self, x, gamma, beta, y, y_bf16, mean, rstd, M, eps, stream):
+        C = 128
+        X = torch.from_numpy(_arr(x, M * C).copy()).view(M, C)
+        mu = X.mean(1)
+        var = ((X - mu[:, None]) ** 2).mean(1)
+        rs = 1.0 / torch.sqrt(var + _val(eps))
+        Y = (X - mu[:, None]) * rs[:, None] * torch.from_numpy(_arr(gamma, C)) + torch.from_numpy(_arr(beta, C))
+        _wr(y, Y.reshape(-1).numpy(), bool(y_bf16))
+        _arr(mean, M)[:] = mu.numpy()
+        _arr(rstd, M)[:] = rs.numpy()
+        return 0
+
+    def kantts_ln128_bwd(self, dy, dy_bf16, x, gamma, mean, rstd, dx, dgamma, dbeta, M, stream):
+        C = 128
+        DY = torch.from_numpy(_rd(dy, M * C, bool(dy_bf16))).view(M, C)
+        X = torch.from_numpy(_arr(x, M * C).copy()).view(M, C)
+        G = torch.from_numpy(_arr(gamma, C))
+        mu, rs = torch.from_numpy(_arr(mean, M)), torch.from_numpy(_arr(rstd, M))
+        xh = (X - mu[:, None]) * rs[:, None]
+        gq = DY * G
+        DX = rs[:, None] * (gq - gq.mean(1, keepdim=True) - xh * (gq * xh).mean(1, keepdim=True))
         _arr(dx, M * C)[:] = DX.reshape(-1).numpy()
         _arr(dgamma, C)[:] += (DY * xh).sum(0).numpy()
         _arr(dbeta, C)[:] += DY.sum(0).numpy()

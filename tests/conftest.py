@@ -32,6 +32,7 @@ def _emulate(monkeypatch):
     import cabi_numpy
     import kantts._hip as hip
     import kantts._hip.ops as ops
+    import kantts._hip.ops_bf16 as ops_bf16
 
     emu = cabi_numpy.EmulatedLib()
 
@@ -45,7 +46,7 @@ def _emulate(monkeypatch):
 
     import kantts.utils.audio_torch as audio_torch  # binds lib / ptr / stream by name at import time
 
-    for mod in (hip, ops, audio_torch):
+    for mod in (hip, ops, ops_bf16, audio_torch):
         monkeypatch.setattr(mod, "lib", lambda: emu, raising=True)
         monkeypatch.setattr(mod, "ptr", ptr, raising=True)
         monkeypatch.setattr(mod, "stream", lambda: None, raising=True)

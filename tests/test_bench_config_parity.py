@@ -113,12 +113,20 @@ _HIFI_BOUNDS = {
 }
 
 
+def _v1_modules():
+    """Class defaults = V1 (512 channels); rebuilt from the seed wherever a fresh copy is needed (weight-normalised
+    modules do not support deepcopy)."""
+    from kantts.models.hifigan.hifigan import Generator, MultiPeriodDiscriminator, MultiScaleDiscriminator
+
+    torch.manual_seed(0)
+    return Generator(), MultiPeriodDiscriminator(), MultiScaleDiscriminator()
+
+
 @pytest.fixture(scope="module")
 def hifigan_v1_oracle():
     from kantts.models.hifigan.hifigan import Generator, MultiPeriodDiscriminator, MultiScaleDiscriminator
 
-    torch.manual_seed(0)
-    mods = (Generator(), MultiPeriodDiscriminator(), MultiScaleDiscriminator())  # class defaults = V1, 512 channels
+    mods = _v1_modules()
     assert mods[0].state_dict()["conv_pre.conv1d.weight_v"].shape[0] == 512
     Ps = [{k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()} for m in mods]
     g = torch.Generator().manual_seed(1)
@@ -139,16 +147,15 @@ def hifigan_v1_oracle():
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_hifigan_v1_512ch_matches_oracle(hifigan_v1_oracle, mode):
-    import copy
-
     import kantts._hip as hip
 
-    mods, Ps, x, y, cot, yr, douts = hifigan_v1_oracle
+    _, Ps, x, y, cot, yr, douts = hifigan_v1_oracle
+    mods = _v1_modules()
     bnd = _HIFI_BOUNDS[mode]
     hip.set_precision(mode)
     rep = {}
     try:
-        G = copy.deepcopy(mods[0]).cuda()
+        G = mods[0].cuda()
         yo = G(x.cuda())
         assert yo.shape == yr.shape == (4, 1, 8192)
         dw = (yo.detach().cpu() - yr).abs()
@@ -160,7 +167,7 @@ def test_hifigan_v1_512ch_matches_oracle(hifigan_v1_oracle, mode):
             den += float(Ps[0][n].grad.double().pow(2).sum())
         rep["G_grad_rel_l2"] = (num / den) ** 0.5
         for i, nm in ((1, "mpd"), (2, "msd")):
-            D = copy.deepcopy(mods[i]).cuda()
+            D = mods[i].cuda()
             o, fm = D(y.cuda())
             o_r, f_r = douts[i - 1]
             rep[nm + "_out"] = max(float((a.detach().cpu() - b).abs().max()) for a, b in zip(o, o_r))

@@ -1,0 +1,162 @@
+"""bf16-operand kernels (csrc/gemm_bf16.hip, ln128 in csrc/norm.hip) on the GPU against the emulated C ABI: the same
+product wrapper is run once with device tensors and once, under oracle/cabi_numpy, with host tensors.  The emulation
+rounds to bf16 exactly like the kernels, so fp32 outputs agree to accumulation-order noise (1e-5) and bf16 outputs to
+one bf16 ulp on a few elements (rel-L2 2e-3).  Shapes include the benchmarked ones (M = 6528 decoder tokens,
+128 <-> 1024) and edge cases: ragged M, N < one tile, K with a partial 64-deep tile, conv taps at sequence borders."""
+import pytest
+import torch
+
+from util import rel_l2, run_both
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def bf16_mode():
+    import kantts._hip as hip
+
+    hip.set_precision("bf16")
+    yield
+    hip.set_precision("fp32")
+
+
+def _cmp(go, gg, co, cg, otol=2e-3, gtol=3e-3):
+    for a, b in zip(go, co):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert rel_l2(a.float(), b.float()) <= otol, ("out", rel_l2(a.float(), b.float()))
+    assert len(gg) == len(cg)
+    for k, (a, b) in enumerate(zip(gg, cg)):
+        if b is None:
+            continue
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert rel_l2(a.float(), b.float()) <= gtol, ("grad", k, rel_l2(a.float(), b.float()))
+
+
+@pytest.mark.parametrize("M,K,N,x_bf16,out_bf16", [
+    (6528, 128, 1024, True, True), (6528, 1024, 128, True, False), (6528, 128, 384, True, False),
+    (2048, 512, 384, False, False), (1000, 160, 256, False, False), (77, 80, 240, False, True),
+    (19584, 256, 512, False, False), (33, 8, 8, False, False),
+])
+def test_linear_plain(M, K, N, x_bf16, out_bf16):
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    if x_bf16:
+        x = x.to(torch.bfloat16)
+    x.requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, generator=g).requires_grad_(True)
+    _cmp(*run_both(lambda x_, w_, b_: ops.linear(x_, w_, b_, out_bf16=out_bf16), x, w, b))
+
+
+def test_linear_epilogues_and_modes():
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(3)
+    B, T = 6, 204
+    M = B * T
+    rm = torch.zeros(B, T, dtype=torch.bool)
+    rm[2, 150:] = True
+    rm[5, 10:] = True
+    # relu + dropout, bf16 out (Prenet / FFN up-projection)
+    x = torch.randn(B, T, 128, generator=g).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(1024, 128, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(1024, generator=g).requires_grad_(True)
+    _cmp(*run_both(lambda x_, w_, b_, rm_: ops.linear(x_, w_, b_, relu=True, drop_p=0.1, rowmask=rm_, out_bf16=True),
+                   x, w, b, rm))
+    # two projections summed + dropout + residual + row zeroing (fc_x + fc_h)
+    xa = torch.randn(B, T, 128, generator=g, requires_grad=True)
+    xb = torch.randn(B, T, 128, generator=g, requires_grad=True)
+    wa = (torch.randn(128, 128, generator=g) * 0.1).requires_grad_(True)
+    wb = (torch.randn(128, 128, generator=g) * 0.1).requires_grad_(True)
+    ba = torch.randn(128, generator=g).requires_grad_(True)
+    bb = torch.randn(128, generator=g).requires_grad_(True)
+    res = torch.randn(B, T, 128, generator=g, requires_grad=True)
+    _cmp(*run_both(lambda a, b_, c, d, e, f, r, m: ops.linear([a, b_], [c, d], e, bias2=f, mode="sum", res=r, rowmask=m,
+                                                             drop_p=0.1), xa, xb, wa, wb, ba, bb, res, rm))
+    # concat of a 160-wide fp32 input and a 128-wide bf16 one (dec_in_proj), alpha scaling
+    m1 = torch.randn(B, T, 160, generator=g, requires_grad=True)
+    m2 = torch.randn(B, T, 128, generator=g).to(torch.bfloat16).requires_grad_(True)
+    wc = (torch.randn(128, 288, generator=g) * 0.1).requires_grad_(True)
+    bc = torch.randn(128, generator=g).requires_grad_(True)
+    _cmp(*run_both(lambda a, b_, c, d, m: ops.linear([a, b_], c, d, mode="concat", rowmask=m, alpha=128 ** 0.5),
+                   m1, m2, wc, bc, rm))
+
+
+@pytest.mark.parametrize("k1", [3, 1])
+def test_conv_mode_and_fused_ffn(k1):
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(5 + k1)
+    B, T, C, Fh = 5, 64, 128, 1024
+    lens = torch.tensor([64, 40, 33, 64, 1])
+    pad_rows = torch.arange(T)[None, :] >= lens[:, None]
+    x = torch.randn(B, T, C, generator=g, requires_grad=True)
+    w1 = (torch.randn(Fh, C, k1, generator=g) * 0.05).requires_grad_(True)
+    b1 = torch.randn(Fh, generator=g).requires_grad_(True)
+    w2 = (torch.randn(C, Fh, 1, generator=g) * 0.03).requires_grad_(True)
+    b2 = torch.randn(C, generator=g).requires_grad_(True)
+    if k1 == 3:
+        _cmp(*run_both(lambda x_, w_, b_: ops.linear(x_, w_, b_, mode="conv", pad=1), x, w1, b1))
+    gam = torch.rand(C, generator=g).add(0.5).requires_grad_(True)
+    bet = torch.randn(C, generator=g).requires_grad_(True)
+
+    def block(x_, gam_, bet_, w1_, b1_, w2_, b2_, pr):
+        h = ops.layer_norm(x_, gam_, bet_, 1e-6, out_bf16=True)
+        assert h.dtype == torch.bfloat16
+        return ops.ffn(h, w1_, b1_, w2_, b2_, x_, pad_rows=pr, zero_rows=pr, p_inner=0.1, p_out=0.1)
+
+    _cmp(*run_both(block, x, gam, bet, w1, b1, w2, b2, pad_rows), otol=2e-3, gtol=5e-3)
+
+
+@pytest.mark.parametrize("M", [6528, 100, 16, 5])
+def test_layer_norm128(M):
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, 128, generator=g) * 3 + 1).requires_grad_(True)
+    gam = torch.rand(128, generator=g).add(0.5).requires_grad_(True)
+    bet = torch.randn(128, generator=g).requires_grad_(True)
+    for ob in (False, True):
+        go, gg, co, cg = run_both(lambda a, b, c: ops.layer_norm(a, b, c, 1e-6, out_bf16=ob), x, gam, bet)
+        assert go[0].dtype == (torch.bfloat16 if ob else torch.float32)
+        _cmp(go, gg, co, cg, otol=2e-3 if ob else 2e-6, gtol=1e-5)
+
+
+def test_arena_shadow_matches_master_and_follows_updates():
+    """ParamArena(bf16_shadow=True): every shadow view equals the bf16 cast of its parameter (tap-major for Conv1d
+    weights with KT > 1) and follows an optimizer step through the forward pre-hook."""
+    import kantts._hip as hip
+    import torch_oracle as O
+    from kantts.models import model_builder
+
+    cfg = O.sambert_config(tiny=True)
+    config = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": cfg, "optimizer": {"type": "Adam", "params": {"lr": 1e-2}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 10}}}}}
+    torch.manual_seed(0)
+    model, opt, _ = model_builder(config, device="cuda")
+    net, o = model["KanTtsSAMBERT"], opt["KanTtsSAMBERT"]
+
+    def check_all():
+        n_tap = 0
+        for name, p in net.named_parameters():
+            if not p.requires_grad:
+                continue
+            assert torch.equal(p._kantts_bf16, p.detach().to(torch.bfloat16)), name
+            if p.dim() == 3 and p.shape[2] > 1:
+                assert torch.equal(p._kantts_bf16_tap, p.detach().permute(2, 0, 1).to(torch.bfloat16)), name
+                n_tap += 1
+        return n_tap
+
+    assert check_all() >= 2
+    batch = {k: v.cuda() for k, v in O.synthetic_sambert_batch(B=2, T_in=10, min_len=5, dur_hi=5).items()}
+    from test_gpu_sambert import _losses
+
+    hip.set_precision("bf16")
+    o.zero_grad()
+    _losses(net(**batch), batch).backward()
+    o.step()
+    net(**batch)  # the pre-hook refreshes the shadow from the updated master
+    check_all()

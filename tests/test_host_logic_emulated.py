@@ -219,12 +219,15 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
     import kantts._hip as hip
 
     pairs = [(hip.GemmSeg, "kantts_gemm_seg"), (hip.GemmArgs, "kantts_gemm_args"), (hip.ConvArgs, "kantts_conv_args"),
-             (hip.ConvWArgs, "kantts_convw_args"), (hip.ConvC1Args, "kantts_conv_c1_args")]
+             (hip.ConvWArgs, "kantts_convw_args"), (hip.ConvC1Args, "kantts_conv_c1_args"),
+             (hip.BGemmSeg, "kantts_bgemm_seg"), (hip.BGemmArgs, "kantts_bgemm_args"),
+             (hip.BGemmTnArgs, "kantts_bgemm_tn_args"), (hip.TapMajorDesc, "kantts_tapmajor_desc")]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "kantts_hip.h"', 'int main(void) {']
     for cls, cname in pairs:
         lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
         for fname, _ in cls._fields_:
-            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname.rstrip("_")))
+            cfield = fname if fname == "pad_" else fname.rstrip("_")
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, cfield))
     lines += ['  return 0;', '}']
     src, exe = tmp_path / "layout.c", tmp_path / "layout"
     src.write_text("\n".join(lines))
