@@ -493,6 +493,12 @@ int kantts_ln128_fwd(const float* x, const float* gamma, const float* beta, void
 int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                      float* dx, float* dgamma_accum, float* dbeta_accum, int M, void* stream);
 
+/* Backward of kantts_melspec_fwd's magnitude output (the reference's stft(), kantts/utils/audio_torch.py:8-31:
+ * sqrt(clamp(re^2 + im^2, eps_power))): dwav_accum (B,T) += d loss / d wav given dmag (B, frames, n_fft/2+1).  Gradient
+ * path of STFTLoss / MultiResolutionSTFTLoss (kantts/train/loss.py:312-441); zero where the clamp is active. */
+int kantts_stft_mag_bwd(const float* wav, const float* dmag, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                        const float* window, const float* twiddle, float eps_power, float* dwav_accum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

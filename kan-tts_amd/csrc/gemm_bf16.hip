@@ -138,10 +138,13 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
     }
   }
 
-  u32x4 ra[NA], rb[NB];
+  // two register sets: the global loads of TWO reduction tiles are in flight while a third is multiplied (the
+  // contractions of this model are short chains of dependent L2 / HBM round trips: with one tile in flight a
+  // 1024-deep reduction paid 16 load latencies back to back)
+  u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
   int seg = 0, k0 = 0;  // next tile to fetch
 
-  auto fetch = [&]() {
+  auto fetch = [&](u32x4* ra, u32x4* rb) {
     const kantts_bgemm_seg& s = g.seg[seg];
 #pragma unroll
     for (int v = 0; v < NA; ++v) {
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
       ++seg;
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, const u32x4* ra, const u32x4* rb) {
     unsigned char* Ab = lds + buf * STAGE;
     unsigned char* Bb = Ab + A_BYTES;
 #pragma unroll
@@ -193,17 +196,8 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
       }
     }
   };
-
-  int ntile = 0;
-  for (int s = 0; s < g.nseg; ++s) ntile += (g.seg[s].klen + BG_BK - 1) / BG_BK;
-
-  fetch();
-  commit(0);
-  __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const bool more = (t + 1) < ntile;
-    if (more) fetch();
-    const unsigned char* Ab = lds + (t & 1) * STAGE;
+  auto compute = [&](int buf) {
+    const unsigned char* Ab = lds + buf * STAGE;
     const unsigned char* Bb = Ab + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BG_BK / 32; ++kk) {
@@ -240,9 +234,28 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
         for (int n = 0; n < NREP; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
     }
-    if (more) commit((t + 1) & 1);
+  };
+
+  int ntile = 0;
+  for (int s = 0; s < g.nseg; ++s) ntile += (g.seg[s].klen + BG_BK - 1) / BG_BK;
+
+  // tile t lives in register set t & 1 and LDS buffer t & 1.  A wave that reaches commit(buf) for tile t + 2 has
+  // passed the barrier in front of compute(t + 1), which every wave reaches only after compute(t): one barrier per tile.
+  fetch(ra0, rb0);
+  if (ntile > 1) fetch(ra1, rb1);
+  for (int t = 0; t < ntile; t += 2) {
+    commit(0, ra0, rb0);
     __syncthreads();
+    if (t + 2 < ntile) fetch(ra0, rb0);
+    compute(0);
+    if (t + 1 < ntile) {
+      commit(1, ra1, rb1);
+      __syncthreads();
+      if (t + 3 < ntile) fetch(ra1, rb1);
+      compute(1);
+    }
   }
+  __syncthreads();
 
   // ---- epilogue: accumulators through LDS so that 16 lanes write one 256 / 512-byte output row piece
   float* Cs = reinterpret_cast<float*>(lds);
@@ -369,119 +382,135 @@ extern "C" int kantts_bgemm_nt(const kantts_bgemm_args* gp, void* stream) {
 
 // ================================================================================================ TN (weight gradients)
 // dW[n][k] (+)= alpha * sum_m A[m][n] * B[m + shift][k];  db[n] += alpha * sum_m A[m][n]  (k-tile 0, tap 0 only).
-// grid = (k tiles, n tiles, taps * slices); slice z walks token tiles z, z + slices, ...
-#define TN_BT 32                 // tokens per tile (one MFMA k-step)
-#define TN_LD (128 + 16)         // pitch of a [token][128 channels] image
+// grid = (k tiles of 128, n tiles of 64, taps * slices); slice z walks token tiles z, z + slices, ...
+// What bounds this kernel is the fp32 atomics of the split over tokens (~200 G atomics/s measured: the first version,
+// 128x128 tiles x 64 slices = 8.4 M atomics, took 48 us where the round-1 kernel took 24) and the chain of dependent
+// load latencies of a short token tile.  Hence: 64 x 128 output tiles (more tiles, fewer slices for the same number of
+// workgroups), token tiles of 64 with the loads of two tiles in flight, and a slice count capped by the atomics budget.
+#define TN_BT 64                 // tokens per tile (two MFMA k-steps)
+#define TN_LDA (64 + 16)         // pitch of the [token][64 channels] image of A
+#define TN_LDB (128 + 16)        // pitch of the [token][128 channels] image of B
 template <bool A_F32, bool B_F32>
 __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const kantts_bgemm_tn_args g) {
-  constexpr int IMG = TN_BT * TN_LD * 2;  // bytes of one operand image
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * IMG];
+  constexpr int IMG_A = TN_BT * TN_LDA * 2, IMG_B = TN_BT * TN_LDB * 2, STAGE = IMG_A + IMG_B;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave >> 1, wc = wave & 1;  // wave tile: 32 (n) x 64 (k)
   const int li = lane & 15, kg = lane >> 4;
-  const int n0 = blockIdx.y * 128, c0 = blockIdx.x * 128;
+  const int n0 = blockIdx.y * 64, c0 = blockIdx.x * 128;
   const int tap = blockIdx.z / g.slices, slice = blockIdx.z % g.slices;
   const int shift = g.shift0 + tap * g.shift_step;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
 
-  f32x4 acc[4][4];
+  f32x4 acc[2][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float colsum = 0.f;
   const bool do_bias = g.db && blockIdx.x == 0 && tap == 0;
 
-  // 32 tokens x 16 chunks of 8 channels = 512 chunks per operand: 2 per thread
-  int tr_[2], ch_[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    const int id = tid + BG_THREADS * v;
-    tr_[v] = id >> 4;
-    ch_[v] = id & 15;
-  }
-  u32x4 ra[2], rb[2];
+  // A: 64 tokens x 8 chunks = 512 chunks (2 per thread); B: 64 tokens x 16 chunks = 1024 (4 per thread)
+  u32x4 ra0[2], rb0[4], ra1[2], rb1[4];
   const int ntile = (g.M + TN_BT - 1) / TN_BT;
 
-  auto fetch = [&](int t) {
+  auto fetch = [&](int t, u32x4* ra, u32x4* rb) {
     const int m0 = t * TN_BT;
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-      const int m = m0 + tr_[v];
-      const int nc = n0 + ch_[v] * 8, kc = c0 + ch_[v] * 8;
-      const bool oka = m < g.M && nc < g.N;
-      ra[v] = bg_load8<A_F32>(g.a, (long long)m * g.lda + nc, oka, A_F32 ? g.a_drop_p : 0.f, g.a_drop_seed + seed_off,
+      const int id = tid + BG_THREADS * v;
+      const int m = m0 + (id >> 3), nc = n0 + (id & 7) * 8;
+      const bool ok = m < g.M && nc < g.N;
+      ra[v] = bg_load8<A_F32>(g.a, (long long)m * g.lda + nc, ok, A_F32 ? g.a_drop_p : 0.f, g.a_drop_seed + seed_off,
                               (uint64_t)m * (uint64_t)g.N + (uint64_t)nc);
-      bool okb = m < g.M && kc < g.K;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int id = tid + BG_THREADS * v;
+      const int m = m0 + (id >> 4), kc = c0 + (id & 15) * 8;
+      bool ok = m < g.M && kc < g.K;
       long long src = m;
       if (shift != 0) {
         const int tt = m % g.T + shift;
-        okb = okb && tt >= 0 && tt < g.T;
+        ok = ok && tt >= 0 && tt < g.T;
         src = (long long)m + shift;
       }
-      rb[v] = bg_load8<B_F32>(g.b, src * g.ldb + kc, okb, 0.f, 0ull, 0ull);
+      rb[v] = bg_load8<B_F32>(g.b, src * g.ldb + kc, ok, 0.f, 0ull, 0ull);
     }
   };
-  auto commit = [&](int buf) {
-    unsigned char* Ab = lds + buf * 2 * IMG;
-    unsigned char* Bb = Ab + IMG;
+  auto commit = [&](int buf, const u32x4* ra, const u32x4* rb) {
+    unsigned char* Ab = lds + buf * STAGE;
+    unsigned char* Bb = Ab + IMG_A;
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-      *reinterpret_cast<u32x4*>(Ab + (tr_[v] * TN_LD + ch_[v] * 8) * 2) = ra[v];
-      *reinterpret_cast<u32x4*>(Bb + (tr_[v] * TN_LD + ch_[v] * 8) * 2) = rb[v];
+      const int id = tid + BG_THREADS * v;
+      *reinterpret_cast<u32x4*>(Ab + ((id >> 3) * TN_LDA + (id & 7) * 8) * 2) = ra[v];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int id = tid + BG_THREADS * v;
+      *reinterpret_cast<u32x4*>(Bb + ((id >> 4) * TN_LDB + (id & 15) * 8) * 2) = rb[v];
+    }
+  };
+  auto compute = [&](int buf) {
+    const __bf16* Ah = reinterpret_cast<const __bf16*>(lds + buf * STAGE);
+    const __bf16* Bh = reinterpret_cast<const __bf16*>(lds + buf * STAGE + IMG_A);
+    if (do_bias && tid < 64) {
+      float q = 0.f;
+#pragma unroll 8
+      for (int m = 0; m < TN_BT; ++m) q += (float)Ah[m * TN_LDA + tid];
+      colsum += q;
+    }
+#pragma unroll
+    for (int kk = 0; kk < TN_BT / 32; ++kk) {
+      bf16x8 af[2], bf[4];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const __bf16* p = Ah + (kk * 32 + kg * 4 + (li >> 2)) * TN_LDA + wr * 32 + m * 16 + (li & 3) * 4;
+        const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * TN_LDA);
+        af[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const __bf16* p = Bh + (kk * 32 + kg * 4 + (li >> 2)) * TN_LDB + wc * 64 + n * 16 + (li & 3) * 4;
+        const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * TN_LDB);
+        bf[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
     }
   };
 
+  // register set / LDS buffer i & 1 for this slice's i-th tile; same one-barrier-per-tile argument as the NT kernel
+  const int st = g.slices;
   int t = slice;
-  if (t < ntile) {
-    fetch(t);
-    commit(0);
-  }
-  __syncthreads();
-  int it = 0;
-  for (; t < ntile; t += g.slices, ++it) {
-    const int tn = t + g.slices;
-    const bool more = tn < ntile;
-    if (more) fetch(tn);
-    const __bf16* Ah = reinterpret_cast<const __bf16*>(lds + (it & 1) * 2 * IMG);
-    const __bf16* Bh = Ah + TN_BT * TN_LD;
-    if (do_bias && tid < 128) {
-      float q = 0.f;
-#pragma unroll 8
-      for (int m = 0; m < TN_BT; ++m) q += (float)Ah[m * TN_LD + tid];
-      colsum += q;
-    }
-    bf16x8 af[4], bf[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const __bf16* p = Ah + (kg * 4 + (li >> 2)) * TN_LD + wr * 64 + m * 16 + (li & 3) * 4;
-      const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * TN_LD);
-      af[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const __bf16* p = Bh + (kg * 4 + (li >> 2)) * TN_LD + wc * 64 + n * 16 + (li & 3) * 4;
-      const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * TN_LD);
-      bf[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
-    if (more) commit((it + 1) & 1);
+  if (t < ntile) fetch(t, ra0, rb0);
+  if (t + st < ntile) fetch(t + st, ra1, rb1);
+  for (; t < ntile; t += 2 * st) {
+    commit(0, ra0, rb0);
     __syncthreads();
+    if (t + 2 * st < ntile) fetch(t + 2 * st, ra0, rb0);
+    compute(0);
+    if (t + st < ntile) {
+      commit(1, ra1, rb1);
+      __syncthreads();
+      if (t + 3 * st < ntile) fetch(t + 3 * st, ra1, rb1);
+      compute(1);
+    }
   }
 
-  if (do_bias && tid < 128 && (n0 + tid) < g.N && colsum != 0.f) atomicAdd(&g.db[n0 + tid], colsum * g.alpha);
+  if (do_bias && tid < 64 && (n0 + tid) < g.N && colsum != 0.f) atomicAdd(&g.db[n0 + tid], colsum * g.alpha);
   float* cbase = g.c + (long long)tap * g.c_ts;
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = n0 + wr * 64 + m * 16 + kg * 4 + r;  // output row  = channel of A
+        const int i = n0 + wr * 32 + m * 16 + kg * 4 + r;  // output row  = channel of A
         const int j = c0 + wc * 64 + n * 16 + li;          // output col  = channel of B
         if (i < g.N && j < g.K) {
           const float v = acc[m][n][r] * g.alpha;
@@ -498,13 +527,18 @@ extern "C" int kantts_bgemm_tn(const kantts_bgemm_tn_args* gp, void* stream) {
   if ((g.N & 7) || (g.K & 7) || (g.lda & 7) || (g.ldb & 7) || !bg_aligned16(g.a) || !bg_aligned16(g.b))
     return KANTTS_E_UNSUPPORTED;
   if ((g.shift0 != 0 || g.shift_step != 0) && g.T <= 0) return KANTTS_E_BADARG;
-  const int tiles = kantts_cdiv(g.N, 128) * kantts_cdiv(g.K, 128) * g.ntaps;
+  const int tiles = kantts_cdiv(g.N, 64) * kantts_cdiv(g.K, 128) * g.ntaps;
   const int ntile = kantts_cdiv(g.M, TN_BT);
-  int slices = g.slices > 0 ? g.slices : kantts_cdiv(512, tiles);
+  int slices = g.slices;
+  if (slices <= 0) {
+    slices = kantts_cdiv(320, tiles);                                          // about 1.25 workgroups per CU
+    const long long cap = (3ll << 19) / ((long long)g.N * g.K * g.ntaps) + 1;  // <= ~1.5 M atomics per launch
+    if (slices > cap) slices = (int)cap;
+  }
   if (slices > ntile) slices = ntile;
   if (slices < 1) slices = 1;
   g.slices = slices;
-  dim3 grid(kantts_cdiv(g.K, 128), kantts_cdiv(g.N, 128), g.ntaps * slices);
+  dim3 grid(kantts_cdiv(g.K, 128), kantts_cdiv(g.N, 64), g.ntaps * slices);
   hipStream_t st = (hipStream_t)stream;
   if (g.a_f32) {
     if (g.b_f32)

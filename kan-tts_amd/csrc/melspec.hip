@@ -199,6 +199,7 @@ extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft
 struct MelBwdArgs {
   MelArgs f;
   const float* dmel;  // (B, n_mels, frames)
+  const float* dmag;  // alternative input: (B, frames, n_fft/2+1) gradient of the STFT magnitude itself (then dmel = NULL)
   float* dwav;        // (B, T) accumulated
 };
 
@@ -268,11 +269,11 @@ __global__ __launch_bounds__(MEL_THREADS) void melspec_bwd_kernel(const MelBwdAr
       im = ei + (orr * w.y + oi * w.x);
     }
     X[k] = make_float2(re, im);
-    damp[k] = 0.f;
+    damp[k] = ba.dmag ? ba.dmag[((long long)b * a.frames + f) * (M + 1) + k] : 0.f;
   }
   __syncthreads();
   // ---- d mel -> d amp (scatter over each filter's support)
-  if (tid < a.n_mels) {
+  if (!ba.dmag && tid < a.n_mels) {
     const int st = a.mel_start[tid], ln = a.mel_len[tid];
     const float* w = a.mel_w + a.mel_off[tid];
     float acc = 0.f;
@@ -352,6 +353,31 @@ extern "C" int kantts_melspec_bwd(const float* wav, const float* dmel, int B, in
   a.eps_mel = eps_mel;
   a.ref_db = 20.f; a.min_db = -100.f; a.max_norm = 4.f; a.symmetric = 1;
   ba.dmel = dmel; ba.dwav = dwav_accum;
+  int m = n_fft >> 1, l2 = 0;
+  while ((1 << l2) < m) ++l2;
+  a.log2m = l2;
+  size_t lds = (size_t)n_fft * 2 * sizeof(float2) + (size_t)(m + 1) * (sizeof(float2) + sizeof(float));
+  if (lds > 64 * 1024) return KANTTS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(melspec_bwd_kernel, dim3(frames, B), dim3(MEL_THREADS), lds, (hipStream_t)stream, ba);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// Backward of the STFT magnitude (kantts/utils/audio_torch.py:8-31: sqrt(clamp(re^2 + im^2, eps))) -- the gradient path
+// of MultiResolutionSTFTLoss (kantts/train/loss.py:312-441).  Same kernel as the mel backward with the d-amplitude taken
+// straight from dmag (B, frames, n_fft/2+1).
+extern "C" int kantts_stft_mag_bwd(const float* wav, const float* dmag, int B, int T, int n_fft, int hop, int frames,
+                                   int pad_mode, const float* window, const float* twiddle, float eps_power,
+                                   float* dwav_accum, void* stream) {
+  if (!wav || !dmag || !window || !twiddle || !dwav_accum) return KANTTS_E_BADARG;
+  if (B < 0 || T < 1 || n_fft < 8 || hop < 1 || frames < 0) return KANTTS_E_BADARG;
+  if (n_fft & (n_fft - 1)) return KANTTS_E_UNSUPPORTED;
+  if (B == 0 || frames == 0) return KANTTS_OK;
+  MelBwdArgs ba = {};
+  MelArgs& a = ba.f;
+  a.wav = wav; a.B = B; a.T = T; a.n_fft = n_fft; a.hop = hop; a.frames = frames; a.pad_mode = pad_mode;
+  a.window = window; a.tw = reinterpret_cast<const float2*>(twiddle); a.eps_power = eps_power;
+  a.n_mels = 0;
+  ba.dmel = nullptr; ba.dmag = dmag; ba.dwav = dwav_accum;
   int m = n_fft >> 1, l2 = 0;
   while ((1 << l2) < m) ++l2;
   a.log2m = l2;

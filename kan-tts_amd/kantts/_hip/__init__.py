@@ -184,6 +184,7 @@ def lib():
         L.kantts_conv_win_launch.argtypes = [POINTER(ConvArgs), c_void_p]
         L.kantts_conv_wgrad_launch.argtypes = [POINTER(ConvWArgs), c_void_p]
         L.kantts_conv_c1_launch.argtypes = [POINTER(ConvC1Args), c_int, c_void_p]
+        L.kantts_stft_mag_bwd.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p]
         L.kantts_bgemm_nt.argtypes = [POINTER(BGemmArgs), c_void_p]
         L.kantts_bgemm_tn.argtypes = [POINTER(BGemmTnArgs), c_void_p]
         L.kantts_cast_f32_bf16.argtypes = [p, p, ll, p]
@@ -204,7 +205,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
     "kantts_bgemm_nt", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
-    "kantts_ln128_fwd", "kantts_ln128_bwd",
+    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd",
 ]
 
 

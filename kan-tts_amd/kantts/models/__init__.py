@@ -79,8 +79,11 @@ def hifigan_model_builder(config, device, rank, distributed):
             scheduler["discriminator"][model_name] = scheduler_builder(
                 optimizer["discriminator"][model_name], conf["scheduler"].get("type", "StepLR"),
                 conf["scheduler"].get("params", {}))
-    if config["Model"]["Generator"]["params"].get("out_channels", 1) > 1:
-        raise NotImplementedError("multi-band (PQMF) generators are not shipped by any reference yaml (SURVEY row 11)")
+    out_channels = config["Model"]["Generator"]["params"].get("out_channels", 1)
+    if out_channels > 1:  # multi-band generator: reference models/__init__.py:64-68
+        from kantts.models.pqmf import PQMF
+
+        model["pqmf"] = PQMF(subbands=out_channels, **config.get("pqmf", {})).to(device)
     if distributed:
         model["generator"] = DistributedDataParallel(model["generator"], device_ids=[rank], output_device=rank,
                                                      broadcast_buffers=False)
@@ -119,8 +122,13 @@ def model_builder(config, device="cpu", rank=0, distributed=False):
 
 
 def __getattr__(name):  # lazy: the HiFi-GAN classes import their own kernels
-    if name in ("Generator", "MultiScaleDiscriminator", "MultiPeriodDiscriminator", "MultiSpecDiscriminator"):
+    if name in ("Generator", "MultiScaleDiscriminator", "MultiPeriodDiscriminator", "MultiSpecDiscriminator",
+                "SpecDiscriminator"):
         from kantts.models.hifigan import hifigan as _h
 
         return getattr(_h, name)
+    if name == "PQMF":
+        from kantts.models.pqmf import PQMF
+
+        return PQMF
     raise AttributeError(name)

@@ -313,9 +313,87 @@ class MultiScaleDiscriminator(torch.nn.Module):
         return y_d_rs, fmap_rs
 
 
-class MultiSpecDiscriminator(torch.nn.Module):
-    """Not enabled in any shipped yaml: out of scope."""
+class SpecDiscriminator(torch.nn.Module):
+    """(k,1)-Conv2d stack over the STFT magnitude (reference :481-581).  The spectrogram is computed under no_grad, as
+    in the reference (the generator receives no gradient through this discriminator's input transform), with the
+    magnitude kernel of kantts.utils.audio_torch.stft.  Layout: (B, frames, W, bins) channels-last; W is the reference's
+    trailing singleton axis, which its square ``padding=(k-1)//2`` widens by 2*pad of zero columns at every layer
+    (those columns carry bias-only activations into the feature maps and the output, and are reproduced here)."""
 
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("MultiSpecDiscriminator is out of scope (not enabled by any shipped yaml)")
+    def __init__(self, channels=32, init_kernel=15, kernel_size=11, stride=2, use_spectral_norm=False, fft_size=1024,
+                 shift_size=120, win_length=600, window="hann_window", nonlinear_activation="LeakyReLU",
+                 nonlinear_activation_params={"negative_slope": 0.1}):
+        super(SpecDiscriminator, self).__init__()
+        self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
+        norm_f = _norm_f(use_spectral_norm)
+        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        final_kernel, post_conv_kernel, blocks = 5, 3, 3
+        act = lambda: getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)  # noqa: E731
+        self.convs = nn.ModuleList()
+        self.convs.append(torch.nn.Sequential(
+            norm_f(nn.Conv2d(fft_size // 2 + 1, channels, (init_kernel, 1), (1, 1), padding=(init_kernel - 1) // 2)), act()))
+        for _ in range(blocks):
+            self.convs.append(torch.nn.Sequential(
+                norm_f(nn.Conv2d(channels, channels, (kernel_size, 1), (stride, 1), padding=(kernel_size - 1) // 2)), act()))
+        self.convs.append(torch.nn.Sequential(
+            norm_f(nn.Conv2d(channels, channels, (final_kernel, 1), (1, 1), padding=(final_kernel - 1) // 2)), act()))
+        self.conv_post = norm_f(nn.Conv2d(channels, 1, (post_conv_kernel, 1), (1, 1),
+                                          padding=((post_conv_kernel - 1) // 2, 0)))
+        self.window_name = window
+        self.register_buffer("window", getattr(torch, window)(win_length))
+
+    @staticmethod
+    def _widen(h, pw):
+        if pw == 0:
+            return h
+        z = h.new_zeros(h.shape[0], h.shape[1], pw, h.shape[3])
+        return torch.cat([z, h, z], dim=2)
+
+    def forward(self, wav):
+        from kantts.utils.audio_torch import stft
+
+        with torch.no_grad():
+            x_mag = stft(torch.squeeze(wav, 1).detach(), self.fft_size, self.shift_size, self.win_length, self.window_name)
+        h = x_mag.unsqueeze(2)  # (B, frames, W=1, bins)
+        fmap = []
+        for layer in self.convs:
+            conv = layer[0]
+            w, tap = conv_weight(conv)
+            ph, pw = conv.padding
+            h = self._widen(h, pw)
+            h = ops.conv_cl(h, w, conv.bias, stride=conv.stride[0], pad=ph, inner=h.shape[2], out_leaky=self.slope,
+                            tap_major=tap, Tout=(h.shape[1] + 2 * ph - conv.kernel_size[0]) // conv.stride[0] + 1)
+            fmap.append(h.permute(0, 3, 1, 2))
+        cp = self.conv_post
+        w, tap = conv_weight(cp)
+        h = ops.conv_cl(h, w, cp.bias, stride=1, pad=cp.padding[0], inner=h.shape[2], tap_major=tap,
+                        Tout=h.shape[1] + 2 * cp.padding[0] - cp.kernel_size[0] + 1)
+        out = h.permute(0, 3, 1, 2)
+        fmap.append(out)
+        return out.squeeze(-1), fmap
+
+
+class MultiSpecDiscriminator(torch.nn.Module):
+    """Reference :584-617.  (Its default ``discriminator_params`` carry a ``kernel_sizes`` key that SpecDiscriminator
+    does not accept -- constructing the reference with defaults raises TypeError, and so does this class; configs pass
+    their own parameters.)"""
+
+    def __init__(self, fft_sizes=[1024, 2048, 512], hop_sizes=[120, 240, 50], win_lengths=[600, 1200, 240],
+                 discriminator_params={"channels": 15, "init_kernel": 1, "kernel_sizes": 11, "stride": 2,
+                                       "use_spectral_norm": False, "window": "hann_window",
+                                       "nonlinear_activation": "LeakyReLU",
+                                       "nonlinear_activation_params": {"negative_slope": 0.1}}):
+        super(MultiSpecDiscriminator, self).__init__()
+        self.discriminators = nn.ModuleList()
+        for fft_size, hop_size, win_length in zip(fft_sizes, hop_sizes, win_lengths):
+            params = copy.deepcopy(discriminator_params)
+            params["fft_size"], params["shift_size"], params["win_length"] = fft_size, hop_size, win_length
+            self.discriminators += [SpecDiscriminator(**params)]
+
+    def forward(self, y):
+        y_d, fmap = [], []
+        for d in self.discriminators:
+            x, x_map = d(y)
+            y_d.append(x)
+            fmap.append(x_map)
+        return y_d, fmap

@@ -119,6 +119,65 @@ class MelSpectrogramLoss(torch.nn.Module):
         return ops.l1_mean(mel_hat, mel)
 
 
+class SpectralConvergenceLoss(torch.nn.Module):
+    """|| |Y| - |X| ||_F / || |Y| ||_F (reference :312-332)."""
+
+    def forward(self, x_mag, y_mag):
+        return torch.norm(y_mag - x_mag, p="fro") / torch.norm(y_mag, p="fro")
+
+
+class LogSTFTMagnitudeLoss(torch.nn.Module):
+    """L1(log |Y|, log |X|) (reference :335-354)."""
+
+    def forward(self, x_mag, y_mag):
+        return ops.l1_mean(torch.log(x_mag), torch.log(y_mag))
+
+
+class STFTLoss(torch.nn.Module):
+    """One resolution (reference :356-396): both magnitudes come from the fused framed-STFT kernel; the generated
+    branch back-propagates through kantts_stft_mag_bwd."""
+
+    def __init__(self, fft_size=1024, shift_size=120, win_length=600, window="hann_window"):
+        super(STFTLoss, self).__init__()
+        self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
+        self.window_name = window
+        self.spectral_convergence_loss = SpectralConvergenceLoss()
+        self.log_stft_magnitude_loss = LogSTFTMagnitudeLoss()
+        self.register_buffer("window", getattr(torch, window)(win_length))
+
+    def forward(self, x, y):
+        from kantts.utils.audio_torch import stft
+
+        x_mag = stft(x, self.fft_size, self.shift_size, self.win_length, self.window_name)
+        with torch.no_grad():
+            y_mag = stft(y, self.fft_size, self.shift_size, self.win_length, self.window_name)
+        return self.spectral_convergence_loss(x_mag, y_mag), self.log_stft_magnitude_loss(x_mag, y_mag)
+
+
+class MultiResolutionSTFTLoss(torch.nn.Module):
+    """Mean over resolutions of (spectral convergence, log-magnitude L1) -- reference :399-441; (B, T) or
+    (B, #subband, T) inputs."""
+
+    def __init__(self, fft_sizes=[1024, 2048, 512], hop_sizes=[120, 240, 50], win_lengths=[600, 1200, 240],
+                 window="hann_window"):
+        super(MultiResolutionSTFTLoss, self).__init__()
+        assert len(fft_sizes) == len(hop_sizes) == len(win_lengths)
+        self.stft_losses = torch.nn.ModuleList()
+        for fs, ss, wl in zip(fft_sizes, hop_sizes, win_lengths):
+            self.stft_losses += [STFTLoss(fs, ss, wl, window)]
+
+    def forward(self, x, y):
+        if len(x.shape) == 3:
+            x = x.reshape(-1, x.size(2))
+            y = y.reshape(-1, y.size(2))
+        sc_loss, mag_loss = 0.0, 0.0
+        for f in self.stft_losses:
+            sc_l, mag_l = f(x, y)
+            sc_loss = sc_loss + sc_l
+            mag_loss = mag_loss + mag_l
+        return sc_loss / len(self.stft_losses), mag_loss / len(self.stft_losses)
+
+
 class AttentionBinarizationLoss(torch.nn.Module):
     """-mean log soft attention on the hard (MAS) path, warmed up over epochs (reference :463-479).
     ``soft[hard == 1]`` of the reference is a boolean gather with a host sync; hard is 0/1, so the same sum is
@@ -170,6 +229,8 @@ loss_dict = {
     "discriminator_adv_loss": DiscriminatorAdversarialLoss,
     "feat_match_loss": FeatureMatchLoss,
     "mel_loss": MelSpectrogramLoss,
+    "stft_loss": MultiResolutionSTFTLoss,
+    "subband_stft_loss": MultiResolutionSTFTLoss,
 }
 
 

@@ -100,11 +100,40 @@ class _MelSpecFn(torch.autograd.Function):
         return dwav, None, None, None, None, None
 
 
+class _StftMagFn(torch.autograd.Function):
+    """Differentiable |STFT| (kantts_melspec_fwd's magnitude output + kantts_stft_mag_bwd): reference stft(),
+    kantts/utils/audio_torch.py:8-31, as used by STFTLoss (kantts/train/loss.py:356-396)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg):
+        n_fft, hop, win_length, window, pad_mode, eps_power = cfg
+        _, mag = _launch(x.detach(), n_fft, hop, win_length, window, pad_mode, eps_power, want_mag=True)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x)
+        return mag
+
+    @staticmethod
+    def backward(ctx, dmag):
+        (x,) = ctx.saved_tensors
+        n_fft, hop, win_length, window, pad_mode, eps_power = ctx.cfg
+        x = x.contiguous().float()
+        B, T = x.shape
+        frames = 1 + T // hop
+        wpad, tw = _fft_consts(n_fft, win_length, window, x.device)
+        dwav = torch.zeros_like(x)
+        check(lib().kantts_stft_mag_bwd(ptr(x, torch.float32), ptr(dmag.contiguous(), torch.float32), B, T, n_fft, hop,
+                                        frames, pad_mode, ptr(wpad), ptr(tw), float(eps_power), ptr(dwav), stream()),
+              "stft_mag_bwd")
+        return dwav, None
+
+
 def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, eps_mel=0.0, want_mag=False, norm=None):
     """norm: optional (ref_level_db, min_level_db, max_norm, symmetric) for the dB normalisation (forward only)."""
     if x.requires_grad:
+        if want_mag and mel is None and norm is None:
+            return None, _StftMagFn.apply(x, (n_fft, hop, win_length, window, pad_mode, eps_power))
         if want_mag or mel is None or norm is not None:
-            raise NotImplementedError("STFT-magnitude backward (STFTLoss) is SURVEY row 8f-4 (next)")
+            raise NotImplementedError("only the mel path and the plain magnitude are differentiable")
         return _MelSpecFn.apply(x, (n_fft, hop, win_length, window, pad_mode, eps_power, eps_mel), *mel), None
     x = x.contiguous().float()
     B, T = x.shape
@@ -132,11 +161,44 @@ def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, ep
     return out_mel, out_mag
 
 
+_dft_cache = {}
+
+
+def _stft_dft_gemm(x, fft_size, hop_size, win_length, window_name):
+    """|STFT| for FFT sizes that are not powers of two (the sub-band STFT loss resolutions 384 / 683 / 171 of
+    multi-band configs): the DFT is a dense contraction frames (.., n_fft) @ [cos | -sin] (n_fft, 2 * bins) on the
+    MFMA GEMM (differentiable through ops.linear); framing / windowing / magnitude are elementwise device ops."""
+    import torch.nn.functional as F
+
+    from kantts._hip import ops
+
+    nb = fft_size // 2 + 1
+    key = (fft_size, win_length, window_name, str(x.device))
+    c = _dft_cache.get(key)
+    if c is None:
+        w = getattr(torch, "%s_window" % window_name)(win_length, dtype=torch.float32)
+        left = (fft_size - win_length) // 2
+        wpad = torch.zeros(fft_size, dtype=torch.float32)
+        wpad[left:left + win_length] = w
+        ang = 2 * np.pi * np.outer(np.arange(nb, dtype=np.float64), np.arange(fft_size, dtype=np.float64)) / fft_size
+        basis = torch.from_numpy(np.concatenate([np.cos(ang), -np.sin(ang)], 0).astype(np.float32))  # (2 nb, n_fft)
+        c = (wpad.to(x.device), basis.to(x.device))
+        _dft_cache[key] = c
+    wpad, basis = c
+    xp = F.pad(x[:, None, :], (fft_size // 2, fft_size // 2), mode="reflect")[:, 0]
+    fr = (xp.unfold(1, fft_size, hop_size) * wpad).contiguous()
+    spec = ops.linear(fr, basis)
+    re, im = spec[..., :nb], spec[..., nb:]
+    return torch.sqrt(torch.clamp(re * re + im * im, min=1e-7))
+
+
 def stft(x, fft_size, hop_size, win_length, window):
-    """|STFT| (B, frames, fft_size//2+1) with clamp(re^2+im^2, 1e-7) (reference :8-31).  ``window`` may
-    be a window tensor (as the reference's callers pass) or a name like "hann"."""
+    """|STFT| (B, frames, fft_size//2+1) with clamp(re^2+im^2, 1e-7) (reference :8-31), differentiable.  ``window`` may
+    be a window tensor (as the reference's callers pass) or a name like "hann" / "hann_window"."""
     name = window if isinstance(window, str) else "hann"
     name = name.replace("_window", "")
+    if fft_size & (fft_size - 1):
+        return _stft_dft_gemm(x, fft_size, hop_size, win_length, name)
     _, mag = _launch(x, fft_size, hop_size, win_length, name, 1, 1e-7, want_mag=True)
     return mag
 

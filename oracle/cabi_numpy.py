@@ -773,6 +773,22 @@ class EmulatedLib:
         _arr(dwav, B * T)[:] += X.grad.reshape(-1).numpy()
         return 0
 
+    def kantts_stft_mag_bwd(self, wav, dmag, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, dwav, stream):
+        eps_power = _val(eps_power)
+        nb = n_fft // 2 + 1
+        X = torch.from_numpy(_arr(wav, B * T).copy()).view(B, T).requires_grad_(True)
+        W = torch.from_numpy(_arr(window, n_fft))
+        G = torch.from_numpy(_arr(dmag, B * frames * nb)).view(B, frames, nb)
+        with torch.enable_grad():
+            xp = torch.nn.functional.pad(X[:, None, :], (n_fft // 2, n_fft // 2),
+                                         mode="reflect" if pad_mode == 1 else "constant")[:, 0]
+            fr = xp.unfold(1, n_fft, hop)[:, :frames] * W
+            spec = torch.fft.rfft(fr, n=n_fft, dim=-1)
+            amp = torch.sqrt(torch.clamp(spec.real ** 2 + spec.imag ** 2, min=eps_power))
+            (amp * G).sum().backward()
+        _arr(dwav, B * T)[:] += X.grad.reshape(-1).numpy()
+        return 0
+
     # ------------------------------------------------------------------------------------ HiFi-GAN helpers
     def kantts_weight_norm_fwd(self, v, g, w, rows, cols, stream):
         V = _arr(v, rows * cols).reshape(rows, cols)

@@ -444,6 +444,61 @@ def hifigan_v1_case():
     print("hifigan_v1 bytes", os.path.getsize(os.path.join(OUT, "hifigan_v1.pt")), float(wav.abs().mean()))
 
 
+def multiband_case():
+    """SURVEY row f4 pieces recorded from the reference: PQMF analysis / synthesis (pqmf.py:50-148), the multi-resolution
+    STFT loss with its input gradient (loss.py:312-441; default resolutions, and a small one on sub-band shaped input),
+    SpecDiscriminator / MultiSpecDiscriminator outputs and feature maps (hifigan.py:481-617) with seeded weights."""
+    from kantts.models.pqmf import PQMF
+    from kantts.models.hifigan.hifigan import MultiSpecDiscriminator
+    from kantts.train.loss import MultiResolutionSTFTLoss
+
+    g = torch.Generator().manual_seed(31)
+    fix = {}
+    pq = PQMF()
+    x = torch.randn(2, 1, 2048, generator=g) * 0.3
+    z = pq.analysis(x)
+    fix["pqmf"] = dict(x=x, analysis=z.clone(), synthesis=pq.synthesis(z).clone(),
+                       filters={k: v.clone() for k, v in pq.state_dict().items()})
+    crit = MultiResolutionSTFTLoss()
+    yh = (torch.randn(2, 1, 4096, generator=g) * 0.2).requires_grad_(True)
+    y = torch.randn(2, 1, 4096, generator=g) * 0.2
+    sc, mag = crit(yh, y)
+    (sc + mag).backward()
+    fix["mrstft"] = dict(y_hat=yh.detach().clone(), y=y, sc=float(sc), mag=float(mag), grad=yh.grad.clone())
+    crit2 = MultiResolutionSTFTLoss(fft_sizes=[384, 683, 171], hop_sizes=[30, 60, 10], win_lengths=[150, 300, 60])
+    sh = (torch.randn(2, 4, 1024, generator=g) * 0.2).requires_grad_(True)
+    sy = torch.randn(2, 4, 1024, generator=g) * 0.2
+    try:
+        sc2, mag2 = crit2(sh, sy)
+        (sc2 + mag2).backward()
+        fix["mrstft_subband"] = dict(y_hat=sh.detach().clone(), y=sy, sc=float(sc2), mag=float(mag2), grad=sh.grad.clone())
+    except Exception as exc:  # non-power-of-two FFT sizes are legal for torch.stft; keep the record either way
+        fix["mrstft_subband"] = dict(error=repr(exc))
+    params = {"channels": 16, "init_kernel": 15, "kernel_size": 11, "stride": 2, "use_spectral_norm": False,
+              "window": "hann_window", "nonlinear_activation": "LeakyReLU",
+              "nonlinear_activation_params": {"negative_slope": 0.1}}
+    torch.manual_seed(4)
+    D = MultiSpecDiscriminator(fft_sizes=[256, 512], hop_sizes=[60, 120], win_lengths=[240, 400], discriminator_params=params)
+    yw = (torch.randn(2, 1, 2400, generator=g) * 0.3).requires_grad_(True)
+    outs, fmaps = D(yw)
+    loss = sum((o * o).mean() for o in outs) + sum(a.abs().mean() for fm in fmaps for a in fm)
+    loss.backward()
+    fix["multispec"] = dict(params=params, y=yw.detach().clone(), outs=[o.detach().clone() for o in outs],
+                            fmap_sums=[[(tuple(a.shape), float(a.double().sum()), float(a.double().abs().sum())) for a in fm]
+                                       for fm in fmaps],
+                            input_grad_is_none=yw.grad is None, loss=float(loss),
+                            grad_norms={n: float(p.grad.double().norm()) for n, p in D.named_parameters() if p.grad is not None},
+                            checksums=checksums(D.state_dict()))
+    try:
+        MultiSpecDiscriminator()
+        fix["multispec_default_ctor"] = "ok"
+    except TypeError as exc:
+        fix["multispec_default_ctor"] = "TypeError"
+    torch.save(fix, os.path.join(OUT, "multiband.pt"))
+    print("multiband bytes", os.path.getsize(os.path.join(OUT, "multiband.pt")), fix["mrstft"]["sc"], fix["mrstft"]["mag"],
+          fix["multispec_default_ctor"], fix["mrstft_subband"].get("error"))
+
+
 def masks_case():
     """get_mask_from_lengths (kantts/models/utils.py:13-23) and get_lfr_mask_from_lengths' ceil(len / r) rule on
     seeded lengths, with and without an explicit max_len."""
@@ -487,3 +542,4 @@ if __name__ == "__main__":
     voc_dataset_case()
     hifigan_v1_case()
     masks_case()
+    multiband_case()
