@@ -53,15 +53,25 @@ def sambert_model_builder(config, device, rank, distributed, use_arena=None):
     return model, optimizer, scheduler
 
 
-def hifigan_model_builder(config, device, rank, distributed):
+def hifigan_model_builder(config, device, rank, distributed, use_arena=None):
     from kantts.models.hifigan import hifigan as _h
 
     model, optimizer, scheduler = {}, {}, {}
     model["discriminator"], optimizer["discriminator"], scheduler["discriminator"] = {}, {}, {}
+    arena_nets = []
+
     def _opt(net, conf):
         otype, oparams = conf["optimizer"].get("type", "Adam"), conf["optimizer"].get("params", {})
-        if _is_hip(device) and otype == "Adam" and not oparams.get("amsgrad", False) and not distributed:
-            return ArenaAdam(ParamArena(net), **oparams)
+        if (use_arena if use_arena is not None else _is_hip(device)) and otype == "Adam" and not oparams.get("amsgrad", False):
+            arena = ParamArena(net)
+            if distributed:
+                # three independent reducers (generator, MPD, MSD), each exchanging its gradient arena in a few large
+                # bucketed all-reduces overlapped with its own backward; a discriminator arena is only armed by its own
+                # zero_grad, i.e. in the discriminator phase (the reference's DDP wrappers also all-reduce the
+                # discriminator gradients of the generator phase, which the next zero_grad throws away)
+                arena.enable_data_parallel()
+            arena_nets.append(net)
+            return ArenaAdam(arena, **oparams)
         return optimizer_builder(net.parameters(), otype, oparams)
 
     for model_name in config["Model"].keys():
@@ -84,12 +94,16 @@ def hifigan_model_builder(config, device, rank, distributed):
         from kantts.models.pqmf import PQMF
 
         model["pqmf"] = PQMF(subbands=out_channels, **config.get("pqmf", {})).to(device)
-    if distributed:
-        model["generator"] = DistributedDataParallel(model["generator"], device_ids=[rank], output_device=rank,
-                                                     broadcast_buffers=False)
+    if distributed:  # networks without a gradient arena (non-Adam optimizers, CPU) fall back to torch DDP
+        dev_ids = [rank] if _is_hip(device) else None
+        if not any(model["generator"] is n for n in arena_nets):
+            model["generator"] = DistributedDataParallel(model["generator"], device_ids=dev_ids, output_device=dev_ids and rank,
+                                                         broadcast_buffers=False)
         for name in model["discriminator"].keys():
-            model["discriminator"][name] = DistributedDataParallel(
-                model["discriminator"][name], device_ids=[rank], output_device=rank, broadcast_buffers=False)
+            if not any(model["discriminator"][name] is n for n in arena_nets):
+                model["discriminator"][name] = DistributedDataParallel(
+                    model["discriminator"][name], device_ids=dev_ids, output_device=dev_ids and rank,
+                    broadcast_buffers=False)
     return model, optimizer, scheduler
 
 

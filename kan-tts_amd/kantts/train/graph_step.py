@@ -26,6 +26,9 @@ class GraphedSambertStep:
         self.device = next(net.parameters()).device
         net.device_band_width = True
         self.distributed = optimizer.arena.world_size > 1
+        # collectives are not captured: the exchange sits between the two graph halves (bucketed, asynchronous), so
+        # the hook-driven overlap of the eager path is switched off for this optimizer
+        optimizer.arena.overlap = False
         optimizer.enable_device_state()  # idempotent: one [lr, step] tensor shared by every captured shape
         self.loss = None
         # the warm-up steps exist only to populate allocator pools / lazy kernel state before capture: weights, Adam

@@ -90,13 +90,96 @@ class ParamArena:
         p = self.params[i]
         return flat[self.offsets[i]:self.offsets[i] + p.numel()].view(p.shape)
 
-    def enable_data_parallel(self, n_buckets=4):
+    def enable_data_parallel(self, n_buckets=4, overlap=True):
+        """Data-parallel training over torch.distributed (RCCL over xGMI on MI355X, gloo in the CPU tests).
+        ``overlap``: the gradient arena is cut into ``n_buckets`` contiguous ranges; parameters were registered in
+        forward order, so the LAST range is the first whose gradients are complete in backward.  A post-accumulate hook
+        on every parameter counts its bucket down; when a bucket is complete its gradients are packed (one multi-tensor
+        copy) and its all-reduce is issued asynchronously -- it runs on the communication stream while backward
+        continues with the earlier layers (what the reference gets from DDP's 25 MB buckets,
+        kantts/models/__init__.py:118-121).  ``ArenaAdam.step`` waits for the handles.  xGMI rings are per-link bound:
+        few large messages (default 4 x ~12 MB for SAM-BERT), not hundreds of small ones."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.world_size = dist.get_world_size()
         self.n_buckets = n_buckets
         # replicas must start from identical weights (DDP broadcasts rank 0's copy at wrap time)
         dist.broadcast(self.flat, src=0)
+        self.refresh_shadow()
+        self.overlap = bool(overlap) and self.world_size > 1
+        if self.overlap:
+            self._build_buckets()
+
+    def _build_buckets(self):
+        n = self.numel
+        step = (n + self.n_buckets - 1) // self.n_buckets
+        step = (step + self.align - 1) // self.align * self.align
+        self.buckets = []
+        self.bucket_of = [0] * len(self.params)
+        for lo in range(0, n, step):
+            self.buckets.append({"lo": lo, "hi": min(n, lo + step), "params": [], "pending": 0, "handle": None})
+        for i, o in enumerate(self.offsets):
+            b = min(o // step, len(self.buckets) - 1)  # a parameter belongs to the bucket its first element falls in
+            self.bucket_of[i] = b
+            self.buckets[b]["params"].append(i)
+        # a parameter that straddles a boundary extends its bucket's range; ranges stay disjoint and cover the arena
+        for k, b in enumerate(self.buckets):
+            if b["params"]:
+                last = b["params"][-1]
+                end = self.offsets[last] + (self.params[last].numel() + self.align - 1) // self.align * self.align
+                b["hi"] = max(b["hi"], end)
+            if k + 1 < len(self.buckets):
+                self.buckets[k + 1]["lo"] = max(self.buckets[k + 1]["lo"], b["hi"])
+        self.buckets = [b for b in self.buckets if b["hi"] > b["lo"]]
+        self._active = False
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+
+    def begin_step(self):
+        """Arm the bucket counters for one backward pass (ArenaAdam.zero_grad calls this).  An un-armed arena ignores
+        gradient arrivals: the discriminators' parameters also receive gradients during the generator's backward, but
+        those are discarded by the next zero_grad and must not be exchanged."""
+        if not getattr(self, "overlap", False):
+            return
+        for b in self.buckets:
+            b["pending"], b["handle"] = len(b["params"]), None
+        self._active = True
+
+    def _on_grad(self, i):
+        if not self._active:
+            return
+        b = self.buckets[self.bucket_of[i]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch_bucket(b)
+
+    def _launch_bucket(self, b):
+        ops.wgrad_overlap.join()  # weight gradients produced on the side stream must have landed before they are packed
+        dst, src = [], []
+        for i in b["params"]:
+            p = self.params[i]
+            g = p.grad
+            if g is None:
+                self.grad_views[i].zero_()
+            else:
+                dst.append(self.grad_views[i])
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        b["handle"] = dist.all_reduce(self.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish_reduce(self):
+        """Issue whatever was not triggered during backward (parameters without a gradient this step), wait for every
+        bucket and average."""
+        for b in self.buckets:
+            if b["handle"] is None:
+                self._launch_bucket(b)
+        for b in self.buckets:
+            b["handle"].wait()
+            b["handle"] = None
+        self._active = False
+        self.grad.mul_(1.0 / self.world_size)
+        return self.grad
 
     def pack_grads(self):
         """Pack every ``p.grad`` into the (padded) gradient arena with one multi-tensor copy."""
@@ -114,7 +197,8 @@ class ParamArena:
         return self.grad
 
     def all_reduce_grads(self):
-        """Average the gradient arena over the data-parallel group (RCCL over xGMI; gloo in CPU tests)."""
+        """Average the (already packed) gradient arena over the data-parallel group: ``n_buckets`` large asynchronous
+        all-reduces (the non-overlapped form: between the two halves of a captured training step)."""
         if self.world_size <= 1:
             return
         n = self.numel
@@ -156,6 +240,7 @@ class ArenaAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=True)
         ops.zero_pool.reset()
+        self.arena.begin_step()
 
     def enable_device_state(self):
         """Keep lr and the step count in device memory so that step() can be replayed from a hipGraph:
@@ -199,6 +284,8 @@ class ArenaAdam(torch.optim.Optimizer):
         ops.wgrad_overlap.join()  # weight gradients produced on the side stream (no-op unless enabled)
         if packed:
             g = arena.grad
+        elif getattr(arena, "overlap", False) and arena._active:
+            g = arena.finish_reduce()  # buckets were exchanged while backward was still running
         else:
             g = arena.pack_grads()
             arena.all_reduce_grads()

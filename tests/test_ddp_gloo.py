@@ -168,8 +168,9 @@ def test_two_rank_sambert_step_equals_averaged_gradients(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# HiFi-GAN under torch DDP (what hifigan_model_builder(distributed=True) wraps the three networks in): the custom
-# autograd functions of the conv stack must feed DDP's gradient hooks like stock modules do.
+# HiFi-GAN data-parallel: hifigan_model_builder(distributed=True) gives every network (generator, each discriminator) its
+# own gradient-arena reducer, exchanged in buckets overlapped with that network's backward; discriminator arenas are
+# armed only in the discriminator phase.
 def _gan_config():
     opt = {"type": "Adam", "params": {"lr": 2e-3, "betas": [0.5, 0.9], "weight_decay": 0.0}}
     sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [200000]}}
@@ -195,20 +196,19 @@ def _gan_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from torch.nn.parallel import DistributedDataParallel as DDP
     from util import emulation
 
-    from kantts.models import model_builder
+    from kantts.models import hifigan_model_builder
     from kantts.train.gan_step import gan_train_step
     from kantts.train.loss import criterion_builder
+    from kantts.train.optim import ArenaAdam
 
     with emulation():
         config = _gan_config()
-        torch.manual_seed(7 + rank)  # DDP broadcasts rank 0's parameters at wrap time
-        model, optimizer, scheduler = model_builder(config, device="cpu")
-        model["generator"] = DDP(model["generator"], broadcast_buffers=False)
-        for k in list(model["discriminator"]):
-            model["discriminator"][k] = DDP(model["discriminator"][k], broadcast_buffers=False)
+        torch.manual_seed(7 + rank)  # enable_data_parallel broadcasts rank 0's parameters
+        model, optimizer, scheduler = hifigan_model_builder(config, "cpu", rank, True, use_arena=True)
+        assert isinstance(optimizer["generator"], ArenaAdam) and optimizer["generator"].arena.overlap
+        assert all(isinstance(o, ArenaAdam) and o.arena.overlap for o in optimizer["discriminator"].values())
         crit = criterion_builder(config, device="cpu")
         losses = []
         for step in range(2):
@@ -221,7 +221,7 @@ def _gan_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gan_step_under_ddp_keeps_replicas_identical(tmp_path):
+def test_two_rank_gan_step_with_arena_reducers_keeps_replicas_identical(tmp_path):
     port = _free_port()
     mp.spawn(_gan_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "gan_rank0.pt"))
@@ -230,3 +230,65 @@ def test_two_rank_gan_step_under_ddp_keeps_replicas_identical(tmp_path):
     assert r0["losses"][0]["generator_loss"] != r1["losses"][0]["generator_loss"]   # ... although the data differed
     for rec in r0["losses"] + r1["losses"]:
         assert all(v == v and abs(v) < 1e6 for v in rec.values())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The captured data-parallel step on hardware: two processes share the one GPU of the test box and exchange the gradient
+# arena over gloo (RCCL needs one device per rank), so graph_a -> bucketed all-reduce -> graph_b of GraphedSambertStep runs
+# with real hipGraphs and a real process group before the first multi-GPU launch.
+def _graph_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "kan-tts_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch_oracle as O
+
+    import kantts._hip as hip
+    from kantts.models import sambert_model_builder
+    from kantts.train.graph_step import GraphedSambertStep
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+
+    torch.cuda.set_device(0)
+    hip.set_precision("fp32")
+    try:
+        probe = torch.ones(4, device="cuda")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    except Exception as exc:  # a gloo build without device-tensor support: nothing to test here
+        torch.save({"unsupported": repr(exc)}, os.path.join(out_dir, "graph_rank%d.pt" % rank))
+        dist.destroy_process_group()
+        return
+    torch.manual_seed(rank)
+    model, opt, sch = sambert_model_builder(_sambert_cfg(), "cuda", 0, True)
+    net, optimizer, scheduler = model["KanTtsSAMBERT"], opt["KanTtsSAMBERT"], sch["KanTtsSAMBERT"]
+    net.eval()
+    optimizer.set_grad_clip(1.0)
+    b = {k: v.cuda() for k, v in O.synthetic_sambert_batch(B=2, T_in=10, seed=1234 + rank, min_len=5, dur_hi=5).items()}
+    step = GraphedSambertStep(net, optimizer, scheduler, MelReconLoss(), ProsodyReconLoss(), b)
+    losses = []
+    for it in range(3):
+        nb = O.synthetic_sambert_batch(B=2, T_in=10, seed=1234 + rank + 10 * it, min_len=5, dur_hi=5)
+        if all(nb[k].shape == b[k].shape for k in nb):
+            step.load_batch({k: v.cuda() for k, v in nb.items()})
+        losses.append(float(step()))
+    torch.cuda.synchronize()
+    torch.save({"flat": optimizer.arena.flat.cpu(), "losses": losses, "step": optimizer._step},
+               os.path.join(out_dir, "graph_rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_process_graphed_step_on_one_gpu(tmp_path):
+    port = _free_port()
+    mp.spawn(_graph_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "graph_rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "graph_rank1.pt"))
+    if "unsupported" in r0:
+        pytest.skip("gloo cannot reduce device tensors here: " + r0["unsupported"][:200])
+    assert torch.equal(r0["flat"], r1["flat"])  # replicas identical after three captured DP steps
+    assert r0["step"] == r1["step"] == 3
+    assert r0["losses"] != r1["losses"] and all(v == v for v in r0["losses"] + r1["losses"])
