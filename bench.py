@@ -474,6 +474,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 (parity-path) throughput figure")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU-oracle legs (default min(cores, 16))")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight gradients on the main stream (A/B switch)")
+    ap.add_argument("--no-wgrad-group", action="store_true", help="one launch per weight gradient (A/B switch)")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     args = ap.parse_args()
@@ -533,7 +534,7 @@ def main():
             from kantts.train.graph_step import GraphedSambertStep
 
             step = GraphedSambertStep(net, optimizer, scheduler, mel_crit, pros_crit, batch,
-                                      overlap_wgrad=not args.no_wgrad_overlap)
+                                      overlap_wgrad=not args.no_wgrad_overlap, group_wgrads=not args.no_wgrad_group)
             step()  # first replay (and, data-parallel, the first all-reduce between the two graphs) inside the guard
             torch.cuda.synchronize()
         except Exception as exc:  # capture is an optimisation; say so loudly and measure the eager path
@@ -576,7 +577,7 @@ def main():
     if rank == 0:
         hip.profile_begin()
     net.device_band_width = False
-    hip.ops.wgrad_overlap.enable(False)
+    hip.ops.wgrad_overlap.enable(False, group_wgrads=not args.no_wgrad_group)
     eager_step()  # instrumented launches are issued eagerly on every rank (the step holds a collective)
     torch.cuda.synchronize()
     if rank == 0:

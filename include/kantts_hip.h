@@ -468,6 +468,13 @@ typedef struct kantts_bgemm_tn_args {
 } kantts_bgemm_tn_args;
 int kantts_bgemm_tn(const kantts_bgemm_tn_args* args, void* stream);
 
+/* Up to KANTTS_TN_MAX_GROUP weight gradients of ONE shape (shape / dtypes / strides / alpha / dropout probability from
+ * *shape; operand, output, bias-gradient pointers and dropout seeds per problem, arrays in HOST memory) in a single
+ * launch.  The host layer defers the weight gradients of a backward pass and issues them grouped by shape. */
+#define KANTTS_TN_MAX_GROUP 16
+int kantts_bgemm_tn_grouped(const kantts_bgemm_tn_args* shape, int nprob, const void* const* a_host, const void* const* b_host,
+                            float* const* c_host, float* const* db_host, const uint64_t* a_drop_seed_host, void* stream);
+
 /* fp32 -> bf16 (round to nearest even) over n elements (n % 8 == 0, 16-byte aligned): the parameter arena's shadow. */
 int kantts_cast_f32_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 

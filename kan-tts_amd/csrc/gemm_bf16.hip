@@ -390,15 +390,37 @@ extern "C" int kantts_bgemm_nt(const kantts_bgemm_args* gp, void* stream) {
 #define TN_BT 64                 // tokens per tile (two MFMA k-steps)
 #define TN_LDA (64 + 16)         // pitch of the [token][64 channels] image of A
 #define TN_LDB (128 + 16)        // pitch of the [token][128 channels] image of B
+// The grouped form (kantts_bgemm_tn_grouped) runs up to KANTTS_TN_MAX_GROUP problems of one shape in a single launch:
+// weight gradients are leaves of the backward graph, so the host defers them and issues every layer's gradient of one
+// shape together -- each problem then needs only a 1/n_problems share of the token split (n_problems times fewer
+// atomics) and ~150 small launches per training step become ~15.
+struct TnGroupArgs {
+  kantts_bgemm_tn_args g;  // shape, dtypes, alpha, dropout probability of the whole group; a/b/c/db/a_drop_seed of problem 0
+  int nprob;
+  const void* a[KANTTS_TN_MAX_GROUP];
+  const void* b[KANTTS_TN_MAX_GROUP];
+  float* c[KANTTS_TN_MAX_GROUP];
+  float* db[KANTTS_TN_MAX_GROUP];
+  uint64_t a_drop_seed[KANTTS_TN_MAX_GROUP];
+};
+
 template <bool A_F32, bool B_F32>
-__global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const kantts_bgemm_tn_args g) {
+__global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs ga) {
   constexpr int IMG_A = TN_BT * TN_LDA * 2, IMG_B = TN_BT * TN_LDB * 2, STAGE = IMG_A + IMG_B;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  kantts_bgemm_tn_args g = ga.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // wave tile: 32 (n) x 64 (k)
   const int li = lane & 15, kg = lane >> 4;
   const int n0 = blockIdx.y * 64, c0 = blockIdx.x * 128;
-  const int tap = blockIdx.z / g.slices, slice = blockIdx.z % g.slices;
+  const int per_prob = g.ntaps * g.slices;
+  const int prob = blockIdx.z / per_prob, zr = blockIdx.z % per_prob;
+  const int tap = zr / g.slices, slice = zr % g.slices;
+  g.a = ga.a[prob];
+  g.b = ga.b[prob];
+  g.c = ga.c[prob];
+  g.db = ga.db[prob];
+  g.a_drop_seed = ga.a_drop_seed[prob];
   const int shift = g.shift0 + tap * g.shift_step;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
 
@@ -519,39 +541,64 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const kantts_bgemm
       }
 }
 
-extern "C" int kantts_bgemm_tn(const kantts_bgemm_tn_args* gp, void* stream) {
-  if (!gp) return KANTTS_E_BADARG;
-  kantts_bgemm_tn_args g = *gp;
-  if (!g.a || !g.b || !g.c || g.M < 0 || g.N < 1 || g.K < 1 || g.ntaps < 1) return KANTTS_E_BADARG;
+static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
+  kantts_bgemm_tn_args& g = ga.g;
+  if (g.M < 0 || g.N < 1 || g.K < 1 || g.ntaps < 1 || ga.nprob < 1 || ga.nprob > KANTTS_TN_MAX_GROUP) return KANTTS_E_BADARG;
   if (g.M == 0) return KANTTS_OK;
-  if ((g.N & 7) || (g.K & 7) || (g.lda & 7) || (g.ldb & 7) || !bg_aligned16(g.a) || !bg_aligned16(g.b))
-    return KANTTS_E_UNSUPPORTED;
+  if ((g.N & 7) || (g.K & 7) || (g.lda & 7) || (g.ldb & 7)) return KANTTS_E_UNSUPPORTED;
+  for (int p = 0; p < ga.nprob; ++p) {
+    if (!ga.a[p] || !ga.b[p] || !ga.c[p]) return KANTTS_E_BADARG;
+    if (!bg_aligned16(ga.a[p]) || !bg_aligned16(ga.b[p])) return KANTTS_E_UNSUPPORTED;
+  }
   if ((g.shift0 != 0 || g.shift_step != 0) && g.T <= 0) return KANTTS_E_BADARG;
-  const int tiles = kantts_cdiv(g.N, 64) * kantts_cdiv(g.K, 128) * g.ntaps;
+  const int tiles = kantts_cdiv(g.N, 64) * kantts_cdiv(g.K, 128) * g.ntaps * ga.nprob;
   const int ntile = kantts_cdiv(g.M, TN_BT);
   int slices = g.slices;
   if (slices <= 0) {
-    slices = kantts_cdiv(320, tiles);                                          // about 1.25 workgroups per CU
-    const long long cap = (3ll << 19) / ((long long)g.N * g.K * g.ntaps) + 1;  // <= ~1.5 M atomics per launch
+    slices = kantts_cdiv(320, tiles);                                                      // about 1.25 workgroups per CU
+    const long long cap = (3ll << 19) / ((long long)g.N * g.K * g.ntaps * ga.nprob) + 1;  // <= ~1.5 M atomics per launch
     if (slices > cap) slices = (int)cap;
   }
   if (slices > ntile) slices = ntile;
   if (slices < 1) slices = 1;
   g.slices = slices;
-  dim3 grid(kantts_cdiv(g.K, 128), kantts_cdiv(g.N, 64), g.ntaps * slices);
-  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(kantts_cdiv(g.K, 128), kantts_cdiv(g.N, 64), ga.nprob * g.ntaps * slices);
   if (g.a_f32) {
     if (g.b_f32)
-      hipLaunchKernelGGL((bgemm_tn_kernel<true, true>), grid, dim3(BG_THREADS), 0, st, g);
+      hipLaunchKernelGGL((bgemm_tn_kernel<true, true>), grid, dim3(BG_THREADS), 0, st, ga);
     else
-      hipLaunchKernelGGL((bgemm_tn_kernel<true, false>), grid, dim3(BG_THREADS), 0, st, g);
+      hipLaunchKernelGGL((bgemm_tn_kernel<true, false>), grid, dim3(BG_THREADS), 0, st, ga);
   } else {
     if (g.b_f32)
-      hipLaunchKernelGGL((bgemm_tn_kernel<false, true>), grid, dim3(BG_THREADS), 0, st, g);
+      hipLaunchKernelGGL((bgemm_tn_kernel<false, true>), grid, dim3(BG_THREADS), 0, st, ga);
     else
-      hipLaunchKernelGGL((bgemm_tn_kernel<false, false>), grid, dim3(BG_THREADS), 0, st, g);
+      hipLaunchKernelGGL((bgemm_tn_kernel<false, false>), grid, dim3(BG_THREADS), 0, st, ga);
   }
   KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_bgemm_tn(const kantts_bgemm_tn_args* gp, void* stream) {
+  if (!gp) return KANTTS_E_BADARG;
+  TnGroupArgs ga = {};
+  ga.g = *gp;
+  ga.nprob = 1;
+  ga.a[0] = gp->a; ga.b[0] = gp->b; ga.c[0] = gp->c; ga.db[0] = gp->db; ga.a_drop_seed[0] = gp->a_drop_seed;
+  return bg_tn_launch(ga, (hipStream_t)stream);
+}
+
+extern "C" int kantts_bgemm_tn_grouped(const kantts_bgemm_tn_args* shape, int nprob, const void* const* a,
+                                       const void* const* b, float* const* c, float* const* db,
+                                       const uint64_t* a_drop_seed, void* stream) {
+  if (!shape || !a || !b || !c || nprob < 1 || nprob > KANTTS_TN_MAX_GROUP) return KANTTS_E_BADARG;
+  TnGroupArgs ga = {};
+  ga.g = *shape;
+  ga.nprob = nprob;
+  for (int p = 0; p < nprob; ++p) {
+    ga.a[p] = a[p]; ga.b[p] = b[p]; ga.c[p] = c[p];
+    ga.db[p] = db ? db[p] : nullptr;
+    ga.a_drop_seed[p] = a_drop_seed ? a_drop_seed[p] : shape->a_drop_seed;
+  }
+  return bg_tn_launch(ga, (hipStream_t)stream);
 }
 
 // ================================================================================================ casts

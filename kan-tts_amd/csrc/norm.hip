@@ -309,8 +309,11 @@ extern "C" int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, con
                                 const float* rstd, float* dx, float* dgamma_accum, float* dbeta_accum, int M, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_accum || !dbeta_accum || M < 0) return KANTTS_E_BADARG;
   if (M == 0) return KANTTS_OK;
+  // every block ends with 256 atomics onto the SAME 256 addresses: with one block per 16-row slab (408 at the decoder's
+  // 6528 rows) the kernel took 13 us against 4.5 us for the forward pass -- same-address atomics serialise in L2
+  // (profiles/r02_runD_sambert_kernel_stats_top.csv).  128 blocks walk ~3 slabs each instead.
   int blocks = kantts_cdiv(M, 16);
-  if (blocks > 512) blocks = 512;  // <= 2 slabs per CU; every block ends with 256 atomics
+  if (blocks > 128) blocks = 128;
   if (dy_bf16)
     hipLaunchKernelGGL(ln128_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dx,
                        dgamma_accum, dbeta_accum, M);

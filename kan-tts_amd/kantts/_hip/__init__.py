@@ -187,6 +187,7 @@ def lib():
         L.kantts_stft_mag_bwd.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p]
         L.kantts_bgemm_nt.argtypes = [POINTER(BGemmArgs), c_void_p]
         L.kantts_bgemm_tn.argtypes = [POINTER(BGemmTnArgs), c_void_p]
+        L.kantts_bgemm_tn_grouped.argtypes = [POINTER(BGemmTnArgs), c_int, p, p, p, p, p, c_void_p]
         L.kantts_cast_f32_bf16.argtypes = [p, p, ll, p]
         L.kantts_tapmajor_bf16.argtypes = [p, p, p, i, i, p]
         L.kantts_relu_gate_bf16.argtypes = [p, i, p, i, p, f, ll, p]
@@ -205,7 +206,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
     "kantts_bgemm_nt", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
-    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd",
+    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped",
 ]
 
 
@@ -401,6 +402,51 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
     return True
 
 
+TN_MAX_GROUP = 16
+
+
+class _DeferredTN:
+    """Weight gradients are leaves of the backward graph: nothing downstream of a layer's backward reads them, only the
+    optimizer does.  When enabled (ops.wgrad_overlap.enable -- the captured training step and bench.py), bgemm_tn only
+    records the problem; ``flush`` (called where the side stream used to be joined: before the optimizer packs the
+    gradients, and before a data-parallel bucket is exchanged) issues all recorded problems grouped by shape, up to
+    TN_MAX_GROUP per launch.  A group needs only 1/n of the token split per problem, i.e. n times fewer fp32 atomics (the
+    resource that bounds the kernel, csrc/gemm_bf16.hip), and ~150 launches per SAM-BERT step become ~15.  Off by
+    default: code that reads ``p.grad`` right after ``backward()`` must see finished gradients."""
+
+    def __init__(self):
+        self.enabled = False
+        self.groups = {}
+
+    def add(self, key, g, a, b, c, db, seed, keep):
+        self.groups.setdefault(key, []).append((g, a, b, c, db, seed, keep))
+
+    def flush(self):
+        if not self.groups:
+            return
+        groups, self.groups = self.groups, {}
+        L = lib()
+        for probs in groups.values():
+            for s in range(0, len(probs), TN_MAX_GROUP):
+                chunk = probs[s:s + TN_MAX_GROUP]
+                n = len(chunk)
+                arr = lambda k: (c_void_p * n)(*[q[k] for q in chunk])  # noqa: E731
+                seeds = (c_uint64 * n)(*[q[5] for q in chunk])
+                g = chunk[0][0]
+                g.slices = 0
+                if _profile is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                check(L.kantts_bgemm_tn_grouped(ctypes.byref(g), n, arr(1), arr(2), arr(3), arr(4), seeds, stream()),
+                      "bgemm_tn_grouped")
+                if _profile is not None:
+                    e1.record()
+                    _profile.append((e0, e1, 2.0 * g.M * g.N * g.K * g.ntaps * n))
+
+
+deferred_tn = _DeferredTN()
+
+
 def bgemm_tn(a, lda, b, ldb, M, N, K, c, c_ns, c_ks, *, c_ts=0, T=0, ntaps=1, shift0=0, shift_step=0, db=None, alpha=1.0,
              a_drop_p=0.0, a_drop_seed=0, slices=0):
     """c[n*c_ns + k*c_ks + tap*c_ts] += alpha * sum_m a[m][n] * b[m + shift][k] (+ db[n]); False when declined."""
@@ -415,6 +461,16 @@ def bgemm_tn(a, lda, b, ldb, M, N, K, c, c_ns, c_ks, *, c_ts=0, T=0, ntaps=1, sh
     g.db, g.alpha = ptr(db, torch.float32), float(alpha)
     g.a_drop_p, g.a_drop_seed = float(a_drop_p), int(a_drop_seed)
     g.seed_dev = rng_ptr(at.device) if a_drop_p > 0 else None
+    if deferred_tn.enabled and M > 0 and not (N % 8 or K % 8 or lda % 8 or ldb % 8):
+        key = (int(lda), int(ldb), int(M), int(N), int(K), int(T), g.a_f32, g.b_f32, int(ntaps), int(shift0),
+               int(shift_step), int(c_ns), int(c_ks), int(c_ts), float(alpha), float(a_drop_p), str(at.device))
+        ct = c[0] if isinstance(c, tuple) else c
+        # operands are kept alive as tensors; the OUTPUTS only through their storages: autograd's AccumulateGrad adopts
+        # a returned gradient tensor as p.grad only while nobody else references the tensor object, otherwise it clones
+        # it (and the clone would be taken before the deferred launch has filled the buffer)
+        keep = (at, bt, ct.untyped_storage(), None if db is None else db.untyped_storage())
+        deferred_tn.add(key, g, g.a, g.b, g.c, g.db, int(a_drop_seed), keep)
+        return True
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

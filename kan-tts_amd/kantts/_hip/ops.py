@@ -9,7 +9,8 @@ import math
 
 import torch
 
-from . import (check, get_precision, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
+from . import (bgemm_nt, bgemm_tn, check, get_precision, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr,
+               rng_state, stream)
 from . import ops_bf16
 
 _seed_counter = itertools.count(1)
@@ -99,8 +100,15 @@ class _WgradOverlap:
         self._keep = []
         self._used = False
 
-    def enable(self, on=True):
+    def enable(self, on=True, group_wgrads=None):
+        """``group_wgrads`` (default: same as ``on``): bf16-mode weight gradients are recorded and issued grouped by
+        shape at ``join()`` instead of one launch each (kantts._hip.deferred_tn)."""
+        from . import deferred_tn
+
         self.enabled = bool(on)
+        deferred_tn.enabled = bool(on if group_wgrads is None else group_wgrads)
+        if not deferred_tn.enabled:
+            deferred_tn.flush()
 
     class _Ctx:
         def __init__(self, owner, keep):
@@ -130,6 +138,9 @@ class _WgradOverlap:
         return _WgradOverlap._Ctx(self, keep)
 
     def join(self):
+        from . import deferred_tn
+
+        deferred_tn.flush()  # recorded weight gradients: grouped launches on the current stream
         if self._used:
             ev = torch.cuda.Event()
             ev.record(self._stream)
@@ -522,15 +533,24 @@ class _LSTM(torch.autograd.Function):
         dev = xs[0].device
         M = B * T
         gx = torch.empty((M, ndir * G), device=dev, dtype=torch.float32)
+        # bf16 mode: the input projection and its gradients run on the bf16-operand kernels (fp32 activations are
+        # rounded while staged, W_ih comes from the bf16 shadow); the recurrence itself is unchanged
+        use_b = (get_precision() == "bf16" and M > 0 and all(x.shape[-1] % 8 == 0 and x.dtype == torch.float32 for x in xs)
+                 and len(xs) <= 12)
+        wbs = [ops_bf16.bf16_weight(params[4 * d]) for d in range(ndir)] if use_b else []
         for d in range(ndir):
             w_ih, b_ih = _c(params[4 * d]), params[4 * d + 2]
             ld = w_ih.shape[1]
             off, segs = 0, []
             for x in xs:
                 k = x.shape[-1]
-                segs.append(make_seg(x, k, 1, (w_ih, off), ld, 1, k))
+                segs.append((x, k, (wbs[d], off), ld, k, 0) if use_b else make_seg(x, k, 1, (w_ih, off), ld, 1, k))
                 off += k
-            gemm(segs, M, G, gx, ndir * G, 1, c_off=d * G, bias=b_ih)
+            if use_b:
+                if not bgemm_nt(segs, M, G, (gx, d * G), ndir * G, bias=b_ih):
+                    raise RuntimeError("bgemm_nt declined the LSTM input projection")
+            else:
+                gemm(segs, M, G, gx, ndir * G, 1, c_off=d * G, bias=b_ih)
         whh = torch.stack([_c(params[4 * d + 1]) for d in range(ndir)], 0) if ndir > 1 else _c(params[1]).unsqueeze(0)
         bhh = torch.stack([params[4 * d + 3] for d in range(ndir)], 0) if ndir > 1 else params[3].unsqueeze(0)
         whh, bhh = _c(whh), _c(bhh)
@@ -541,7 +561,8 @@ class _LSTM(torch.autograd.Function):
         check(lib().kantts_lstm_fwd(ptr(gx), ptr(whh), ptr(bhh), ptr(lens), ptr(out), ptr(gates), ptr(cst), B, T, H,
                                     ndir, 0, prec, stream()), "lstm_fwd")
         ctx.cfg = (nx, ndir, B, T, H, prec)
-        ctx.save_for_backward(lens, whh, out, gates, cst, *xs, *params)
+        ctx.use_b = use_b
+        ctx.save_for_backward(lens, whh, out, gates, cst, *xs, *params, *wbs)
         return out
 
     @staticmethod
@@ -550,7 +571,8 @@ class _LSTM(torch.autograd.Function):
         G, M = 4 * H, B * T
         sv = ctx.saved_tensors
         lens, whh, out, gates, cst = sv[:5]
-        xs, params = list(sv[5:5 + nx]), list(sv[5 + nx:])
+        xs, params = list(sv[5:5 + nx]), list(sv[5 + nx:5 + nx + 4 * ndir])
+        wbs = list(sv[5 + nx + 4 * ndir:])
         dout = _c(dout)
         dg = torch.empty((ndir, B, T, G), device=dout.device, dtype=torch.float32)
         check(lib().kantts_lstm_bwd(ptr(dout, torch.float32), ptr(whh), ptr(lens), ptr(gates), ptr(cst), ptr(dg), B, T,
@@ -568,20 +590,40 @@ class _LSTM(torch.autograd.Function):
             first = True
             for k, x in enumerate(xs):
                 kk = x.shape[-1]
-                if needs[3 + k]:
-                    if dxs[k] is None:
-                        dxs[k] = torch.zeros_like(x) if ndir > 1 else torch.empty_like(x)
-                    gemm([make_seg(dgd, G, 1, (w_ih, off), 1, ld, G)], M, kk, dxs[k], kk, 1, accumulate=(ndir > 1))
-                gemm([make_seg(dgd, 1, G, x, 1, kk, M)], G, kk, dw_ih, ld, 1, c_off=off, accumulate=True,
-                     splitk=_splitk_for(G, kk, M), a_rowsum=db if first else None)
+                if ctx.use_b:
+                    if needs[3 + k]:
+                        first_dir = dxs[k] is None
+                        if first_dir:
+                            dxs[k] = torch.empty_like(x)
+                        # the second direction adds onto the first one's result (read as the fp32 residual)
+                        if not bgemm_nt([(dgd, G, (wbs[d], off), ld, G, 0)], M, kk, dxs[k], kk, b_kn=True,
+                                        res=None if first_dir else dxs[k], ldr=kk):
+                            raise RuntimeError("bgemm_nt declined the LSTM input gradient")
+                    with wgrad_overlap.side(dgd, x):
+                        if not bgemm_tn(dgd, G, x, kk, M, G, kk, (dw_ih, off), ld, 1, db=db if first else None):
+                            raise RuntimeError("bgemm_tn declined the LSTM input-weight gradient")
+                else:
+                    if needs[3 + k]:
+                        if dxs[k] is None:
+                            dxs[k] = torch.zeros_like(x) if ndir > 1 else torch.empty_like(x)
+                        gemm([make_seg(dgd, G, 1, (w_ih, off), 1, ld, G)], M, kk, dxs[k], kk, 1, accumulate=(ndir > 1))
+                    gemm([make_seg(dgd, 1, G, x, 1, kk, M)], G, kk, dw_ih, ld, 1, c_off=off, accumulate=True,
+                         splitk=_splitk_for(G, kk, M), a_rowsum=db if first else None)
                 first = False
                 off += kk
             dw_hh = gzeros((G, H), dout.device)
             shift = 1 if d == 1 else -1  # h_{prev}: previous step in this direction's time order
-            seg = make_seg(dgd, 1, G, (out, d * H), 1, ndir * H, M, b_tok_axis=2, b_shift0=shift)
-            gemm([seg], G, H, dw_hh, H, 1, accumulate=True, splitk=_splitk_for(G, H, M), T=T)
-            dparams[4 * d], dparams[4 * d + 1], dparams[4 * d + 2], dparams[4 * d + 3] = dw_ih, dw_hh, db, db
-        return (None, None, None, *dxs, *dparams)
+            if ctx.use_b:
+                with wgrad_overlap.side(dgd, out):
+                    if not bgemm_tn(dgd, G, (out, d * H), ndir * H, M, G, H, dw_hh, H, 1, T=T, shift0=shift):
+                        raise RuntimeError("bgemm_tn declined the LSTM recurrent-weight gradient")
+            else:
+                seg = make_seg(dgd, 1, G, (out, d * H), 1, ndir * H, M, b_tok_axis=2, b_shift0=shift)
+                gemm([seg], G, H, dw_hh, H, 1, accumulate=True, splitk=_splitk_for(G, H, M), T=T)
+            # b_ih and b_hh share one gradient: two tensor objects over the same buffer (see ops_bf16._FusedLinearB)
+            dparams[4 * d], dparams[4 * d + 1] = dw_ih, dw_hh
+            dparams[4 * d + 2], dparams[4 * d + 3] = db.view(db.shape), db.view(db.shape)
+        return (None, None, None, *dxs, *dparams, *([None] * len(wbs)))
 
 
 def lstm(xs, params, lens_i32=None):

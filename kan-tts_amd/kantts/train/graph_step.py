@@ -17,9 +17,11 @@ from kantts._hip import ops, rng_state as _rng_state
 
 class GraphedSambertStep:
     def __init__(self, net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup=3,
-                 overlap_wgrad=True):
-        # weight gradients as parallel branches of the captured graph (see ops._WgradOverlap)
-        ops.wgrad_overlap.enable(overlap_wgrad)
+                 overlap_wgrad=True, group_wgrads=True):
+        # weight gradients leave the critical path: fp32-mode ones as parallel branches of the captured graph
+        # (ops._WgradOverlap), bf16-mode ones recorded and issued grouped by shape before the optimizer
+        # (kantts._hip.deferred_tn)
+        ops.wgrad_overlap.enable(overlap_wgrad, group_wgrads=group_wgrads)
         self.net, self.optimizer, self.scheduler = net, optimizer, scheduler
         self.mel_criterion, self.prosody_criterion = mel_criterion, prosody_criterion
         self.batch = {k: v.clone() for k, v in batch.items()}

@@ -337,6 +337,21 @@ class EmulatedLib:
             np.add.at(mem, offs.reshape(-1), dW.reshape(-1).astype(np.float32))
         return 0
 
+    def kantts_bgemm_tn_grouped(self, shape_ref, nprob, a, b, c, db, seeds, stream):
+        g0 = shape_ref._obj
+        for p in range(int(nprob)):
+            g = type(g0)()
+            ctypes.memmove(ctypes.byref(g), ctypes.byref(g0), ctypes.sizeof(g0))
+            g.a, g.b, g.c, g.db, g.a_drop_seed = a[p], b[p], c[p], db[p], seeds[p]
+
+            class _R:
+                _obj = g
+
+            rc = self.kantts_bgemm_tn(_R, stream)
+            if rc:
+                return rc
+        return 0
+
     def kantts_cast_f32_bf16(self, src, dst, n, stream):
         if n % 8:
             return -1

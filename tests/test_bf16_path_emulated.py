@@ -157,3 +157,42 @@ def test_tiny_sambert_bf16_mode_emulated_close_to_oracle(bf16_mode):
             num += float((prm.grad.double() - P[n].grad.double()).pow(2).sum())
             den += float(P[n].grad.double().pow(2).sum())
     assert (num / den) ** 0.5 < 0.15, (num / den) ** 0.5
+
+
+def test_deferred_grouped_weight_gradients_equal_immediate_ones(bf16_mode):
+    """kantts._hip.deferred_tn: recording the weight-gradient contractions during backward and issuing them grouped by
+    shape afterwards gives bit-identical parameter gradients (same arithmetic per problem), and every p.grad is the
+    buffer the deferred launch fills (autograd must adopt it, not clone it)."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+
+    cfg = O.sambert_config(tiny=True)
+    cfg = {k: (0.0 if "dropout" in k else v) for k, v in cfg.items()}
+    batch = O.synthetic_sambert_batch(B=3, T_in=12, seed=10, min_len=6, dur_hi=6)
+    grads = []
+    with emulation():
+        for on in (False, True):
+            torch.manual_seed(0)
+            m = KanTtsSAMBERT(dict(cfg))
+            m.eval()
+            hip.deferred_tn.enabled = on
+            try:
+                res = m(**batch)
+                mel_, mel = MelReconLoss()(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"],
+                                           res["postnet_outputs"])
+                d, p, e = ProsodyReconLoss()(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                             res["energy_targets"], res["log_duration_predictions"],
+                                             res["pitch_predictions"], res["energy_predictions"])
+                (mel_ + mel + d + p + e).backward()
+                if on:
+                    n_prob = sum(len(v) for v in hip.deferred_tn.groups.values())
+                    assert len(hip.deferred_tn.groups) < n_prob  # several layers share a launch
+                ops.wgrad_overlap.join()
+            finally:
+                hip.deferred_tn.enabled = False
+            grads.append({n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
