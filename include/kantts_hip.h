@@ -506,6 +506,11 @@ int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, const float* g
 int kantts_stft_mag_bwd(const float* wav, const float* dmag, int B, int T, int n_fft, int hop, int frames, int pad_mode,
                         const float* window, const float* twiddle, float eps_power, float* dwav_accum, void* stream);
 
+/* out[0] = sum x^2 with a fixed summation order (bit-reproducible: data-parallel replicas must derive the same
+ * clipping factor from the same all-reduced gradient).  workspace: >= 1025 floats, zero before the first call (word 0 is
+ * a ticket counter the kernel resets itself).  kantts/train/trainer.py:997-1004 (clip_grad_norm_). */
+int kantts_sumsq_det(const float* x, float* out, float* workspace, long long ws_floats, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -390,9 +390,20 @@ static int wg_launch(const kantts_convw_args& g, hipStream_t st) {
   }
   const long long total_steps = (long long)g.B * g.inner * kantts_cdiv(g.Tdst, WG_BQ);
   const long long xy = (long long)g.groups * ntn * ntc * ntg;
-  // enough token slabs to fill the chip (~2048 blocks), but at least 4 steps per block to amortise the atomics
+  // enough token slabs to fill the chip (~2048 blocks), but at least 4 steps per block to amortise the atomics ...
   long long slabs = (2048 + xy - 1) / xy;
   if (slabs > (total_steps + 3) / 4) slabs = (total_steps + 3) / 4;
+  // ... and within an atomics budget: every slab adds the whole dw once, and fp32 atomics retire at ~200 G/s (measured on
+  // the SAM-BERT weight gradients, round 2).  The generator's 32 / 64-channel residual convolutions have tiny weight
+  // tensors (11 K elements at 32 ch, k = 11) and many tokens: 2048 slabs meant 23 M atomics = 137 us for a 6 GFLOP
+  // contraction (profiles/r01_hifigan_conv_shapes_packed.log).  Never below ~256 blocks.
+  {
+    const long long dw_elems = (long long)g.K * g.Ntot * g.CR;
+    long long cap = (3ll << 20) / (dw_elems > 0 ? dw_elems : 1);
+    const long long floor_slabs = (256 + xy - 1) / xy;
+    if (cap < floor_slabs) cap = floor_slabs;
+    if (slabs > cap) slabs = cap;
+  }
   if (slabs < 1) slabs = 1;
   if (slabs > 65535) slabs = 65535;
   const int spb = (int)((total_steps + slabs - 1) / slabs);

@@ -69,6 +69,57 @@ extern "C" int kantts_sumsq(const float* x, float* out_accum, long long n, void*
   KANTTS_CHECK_LAUNCH();
 }
 
+// Deterministic variant for data-parallel training: out[0] = sum x^2 with a FIXED summation order, so that every replica
+// derives the bit-identical clipping factor from the bit-identical all-reduced gradient (the atomicAdd order of
+// sumsq_kernel differs from run to run; replicas drifted apart by ulps in the two-process GPU test of round 2).
+// Blocks store their partial sums into ws[1 + block]; the block that draws the last ticket (ws[0], reset for the next
+// launch) adds them in index order.  Publication follows the agent-scope release / acquire recipe of the CDNA4 guide.
+#define SUMSQ_DET_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_det_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                       float* __restrict__ ws, long long n) {
+  __shared__ float red[4];
+  __shared__ int is_last;
+  float part = 0.f;
+  const long long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = x4[i];
+    part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    part += x[i] * x[i];
+  part = kantts_block_sum(part, red);
+  unsigned* ticket = reinterpret_cast<unsigned*>(ws);
+  if (threadIdx.x == 0) {
+    ws[1 + blockIdx.x] = part;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1) ? 1 : 0;
+    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float acc = 0.f;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) acc += ws[1 + b];  // thread t: blocks t, t+256, ... (fixed)
+  acc = kantts_block_sum(acc, red);                                         // fixed tree
+  if (threadIdx.x == 0) {
+    out[0] = acc;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+extern "C" int kantts_sumsq_det(const float* x, float* out, float* workspace, long long ws_floats, long long n,
+                                void* stream) {
+  if (!x || !out || !workspace || n < 0 || ((uintptr_t)x & 15)) return KANTTS_E_BADARG;
+  if (ws_floats < SUMSQ_DET_BLOCKS + 1) return KANTTS_E_WORKSPACE;
+  int blocks = kantts_cdiv(n > 0 ? n : 1, 4096);
+  if (blocks > SUMSQ_DET_BLOCKS) blocks = SUMSQ_DET_BLOCKS;
+  hipLaunchKernelGGL(sumsq_det_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, workspace, n);
+  KANTTS_CHECK_LAUNCH();
+}
+
 // torch.optim.Adam (amsgrad=False) on flat fp32 buffers with optional global-norm clipping:
 //   clip = max_norm > 0 ? min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)) : 1      (clip_grad_norm_)
 //   g *= clip; g += wd * p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2

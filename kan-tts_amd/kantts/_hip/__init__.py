@@ -184,6 +184,7 @@ def lib():
         L.kantts_conv_win_launch.argtypes = [POINTER(ConvArgs), c_void_p]
         L.kantts_conv_wgrad_launch.argtypes = [POINTER(ConvWArgs), c_void_p]
         L.kantts_conv_c1_launch.argtypes = [POINTER(ConvC1Args), c_int, c_void_p]
+        L.kantts_sumsq_det.argtypes = [p, p, p, ll, ll, p]
         L.kantts_stft_mag_bwd.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p]
         L.kantts_bgemm_nt.argtypes = [POINTER(BGemmArgs), c_void_p]
         L.kantts_bgemm_tn.argtypes = [POINTER(BGemmTnArgs), c_void_p]
@@ -206,7 +207,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
     "kantts_bgemm_nt", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
-    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped",
+    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
 ]
 
 
@@ -417,14 +418,41 @@ class _DeferredTN:
     def __init__(self):
         self.enabled = False
         self.groups = {}
+        self.copies = []
 
     def add(self, key, g, a, b, c, db, seed, keep):
         self.groups.setdefault(key, []).append((g, a, b, c, db, seed, keep))
 
+    @staticmethod
+    def _desc(t):
+        return (t.untyped_storage(), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype, t.device)
+
+    @staticmethod
+    def _rebuild(d):
+        st, off, shape, stride, dtype, dev = d
+        return torch.empty(0, dtype=dtype, device=dev).set_(st, off, shape, stride)
+
+    def shared_gradient(self, src):
+        """A second gradient tensor with the same values as ``src`` (two biases sharing one gradient).  Immediate mode:
+        ``src`` itself (autograd clones it for the second parameter).  Deferred mode: a separate buffer that receives a
+        copy of ``src`` after the deferred launches have filled it -- never an alias: gradient tensors are scaled in
+        place by clipping.  Only storages are kept, so autograd can still adopt both tensors as p.grad."""
+        if not self.enabled:
+            return src
+        dst = torch.zeros_like(src)
+        self.copies.append((self._desc(dst), self._desc(src)))
+        return dst
+
     def flush(self):
-        if not self.groups:
+        if not self.groups and not self.copies:
             return
         groups, self.groups = self.groups, {}
+        copies, self.copies = self.copies, []
+        self._launch(groups)
+        if copies:
+            torch._foreach_copy_([self._rebuild(d) for d, _ in copies], [self._rebuild(s) for _, s in copies])
+
+    def _launch(self, groups):
         L = lib()
         for probs in groups.values():
             for s in range(0, len(probs), TN_MAX_GROUP):

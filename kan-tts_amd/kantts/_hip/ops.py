@@ -620,9 +620,11 @@ class _LSTM(torch.autograd.Function):
             else:
                 seg = make_seg(dgd, 1, G, (out, d * H), 1, ndir * H, M, b_tok_axis=2, b_shift0=shift)
                 gemm([seg], G, H, dw_hh, H, 1, accumulate=True, splitk=_splitk_for(G, H, M), T=T)
-            # b_ih and b_hh share one gradient: two tensor objects over the same buffer (see ops_bf16._FusedLinearB)
+            # b_ih and b_hh share one gradient (see deferred_tn.shared_gradient)
+            from . import deferred_tn
+
             dparams[4 * d], dparams[4 * d + 1] = dw_ih, dw_hh
-            dparams[4 * d + 2], dparams[4 * d + 3] = db.view(db.shape), db.view(db.shape)
+            dparams[4 * d + 2], dparams[4 * d + 3] = db, (deferred_tn.shared_gradient(db) if ctx.use_b else db)
         return (None, None, None, *dxs, *dparams, *([None] * len(wbs)))
 
 
@@ -832,7 +834,14 @@ def mse_to_const(a, target):
 # ================================================================================================
 # Optimiser kernels on flat arenas
 # ================================================================================================
-def sumsq_into(x_flat, out_scalar):
+def sumsq_into(x_flat, out_scalar, workspace=None):
+    """out += sum x^2 (atomics), or with a zero-initialised ``workspace`` (>= 1025 floats) out = sum x^2 in a fixed
+    summation order (bit-reproducible across replicas and runs)."""
+    if workspace is not None:
+        check(lib().kantts_sumsq_det(ptr(x_flat, torch.float32), ptr(out_scalar, torch.float32),
+                                     ptr(workspace, torch.float32), workspace.numel(), x_flat.numel(), stream()),
+              "sumsq_det")
+        return
     check(lib().kantts_sumsq(ptr(x_flat, torch.float32), ptr(out_scalar, torch.float32), x_flat.numel(), stream()),
           "sumsq")
 

@@ -214,13 +214,12 @@ class _FusedLinearB(torch.autograd.Function):
                 off += kk
         if dbias is not None and first:
             raise RuntimeError("bias gradient without weight gradient is not supported")
-        # two biases share one gradient: hand autograd two tensor OBJECTS over the same storage (it adopts a gradient
-        # as p.grad only if nobody else holds the object; a clone taken now would miss a deferred weight-gradient launch)
-        db1 = db2 = dbias
-        if has_bias and has_bias2:  # (a view keeps its base referenced, so both outputs must be views)
-            db1, db2 = dbias.view(dbias.shape), dbias.view(dbias.shape)
-        return (None, db1 if has_bias else None, db2 if has_bias2 else None, d_res, None, *dxs, *dws,
-                *([None] * len(wbs)))
+        db2 = None
+        if has_bias2:  # two biases share one gradient (see deferred_tn.shared_gradient)
+            from . import deferred_tn
+
+            db2 = deferred_tn.shared_gradient(dbias) if has_bias else dbias
+        return (None, dbias if has_bias else None, db2, d_res, None, *dxs, *dws, *([None] * len(wbs)))
 
 
 def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, drop_p, pad, dilation, T, out_bf16):

@@ -224,6 +224,7 @@ class ArenaAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(arena.flat)
         self.exp_avg_sq = torch.zeros_like(arena.flat)
         self.gnorm_sq = torch.zeros((), device=dev, dtype=torch.float32)
+        self._norm_ws = torch.zeros(1032, device=dev, dtype=torch.float32)  # fixed-order norm reduction (replica parity)
         self.max_grad_norm = 0.0
         self._step = 0
         self.dyn = None  # optional device tensor [lr, step] (hipGraph replay), see enable_device_state()
@@ -291,8 +292,7 @@ class ArenaAdam(torch.optim.Optimizer):
             arena.all_reduce_grads()
         gn = None
         if self.max_grad_norm > 0:
-            self.gnorm_sq.zero_()
-            ops.sumsq_into(g, self.gnorm_sq)
+            ops.sumsq_into(g, self.gnorm_sq, self._norm_ws)
             gn = self.gnorm_sq
         self._step += 1
         if self.dyn is not None:

@@ -701,6 +701,13 @@ class EmulatedLib:
             _arr(grad, n)[:] = gr.astype(np.float32)
         return 0
 
+    def kantts_sumsq_det(self, x, out, ws, ws_floats, n, stream):
+        if ws_floats < 1025:
+            return -3
+        X = _arr(x, n) if n else np.zeros(0, np.float32)
+        _arr(out, 1)[0] = np.float32((X.astype(np.float64) ** 2).sum()) if n else np.float32(0)
+        return 0
+
     def kantts_sumsq(self, x, out, n, stream):
         a = _arr(x, n)
         _arr(out, 1)[0] += np.float32((a.astype(np.float64) ** 2).sum())
