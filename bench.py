@@ -446,6 +446,76 @@ def fp32_leg(hip, cfg, batch, frames, mel_crit, pros_crit, dev, steps=5, warmup=
             "whole_step_mfma_frac": 456.9e9 * batch["mel_targets"].shape[0] / 32 / dt / 1e12 / PEAK_TFLOPS["fp32"]}
 
 
+def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4):
+    """BASELINE config 5: end-to-end SAM-BERT -> HiFi-GAN inference on 128 synthetic utterances (T_in uniform
+    20..80, the training id distributions, duration head biased to ~3.5 frames per symbol -- random-init weights predict
+    zero durations otherwise), free-running: AR duration predictor, AR mel decoder, postnet, HiFi-GAN V1 generator with
+    weight norm folded.  Decoder modes: "loop" = one launch per op and step issued from Python (round 1; the reference's
+    structure), "graph" = one decoder step captured in a hipGraph with the step index in device memory and replayed
+    (kantts/models/sambert/decode_graph.py).  Batch 1 (the reference's only mode) and length-sorted batches."""
+    from kantts.models.hifigan.hifigan import Generator
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+
+    hip.set_precision(precision)
+    dev = "cuda"
+    torch.manual_seed(0)
+    am = KanTtsSAMBERT(dict(cfg))
+    with torch.no_grad():
+        am.variance_adaptor.duration_predictor.fc.bias.fill_(1.5)
+    am = am.to(dev).eval()
+    voc = Generator().to(dev).eval()
+    voc.remove_weight_norm()
+    g = torch.Generator().manual_seed(4321)
+    vocab = (147, 10, 8, 8)
+    lens = torch.randint(20, 81, (n_utt,), generator=g)
+    T = int(lens.max())
+    ling = torch.stack([torch.randint(0, vocab[k] - 3, (n_utt, T), generator=g) for k in range(4)], -1)
+    emo = torch.randint(0, 33, (n_utt, T), generator=g)
+    spk = torch.zeros(n_utt, T, dtype=torch.long)
+    order = torch.argsort(lens, descending=True)
+
+    def synth(idx, mode):
+        am.mel_decoder.decode_mode = mode
+        ln = lens[idx]
+        Tm = int(ln.max())
+        args = dict(inputs_ling=ling[idx, :Tm].to(dev), inputs_emotion=emo[idx, :Tm].to(dev),
+                    inputs_speaker=spk[idx, :Tm].to(dev), input_lengths=ln.to(dev))
+        with torch.no_grad():
+            res = am(**args)
+            mel = res["postnet_outputs"].transpose(1, 2).contiguous()  # (B, 80, frames)
+            wav = voc(mel)
+        n = res["LR_length_rounded"].clamp(max=mel.shape[2])
+        return int(n.sum()), int(n.sum()) * 256, wav
+
+    def timed(groups, mode):
+        synth(groups[0], mode)  # warm-up / capture for the first shape
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames = samples = 0
+        for idx in groups:
+            f, s_, _ = synth(idx, mode)
+            frames += f
+            samples += s_
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"utterances": sum(len(i) for i in groups), "seconds": dt, "mel_frames_per_s": frames / dt,
+                "audio_samples_per_s": samples / dt, "rtf_22k": dt / (samples / 22050.0),
+                "utterances_per_s": sum(len(i) for i in groups) / dt, "mel_frames": frames}
+
+    singles = [order[i:i + 1] for i in range(n_utt)]
+    batches = [order[i:i + batch] for i in range(0, n_utt, batch)]
+    out = {"workload": "%d utterances, T_in 20..80 (mean %.1f symbols), SAM-BERT full free-running -> HiFi-GAN V1 (22.05 kHz, "
+                       "hop 256)" % (n_utt, float(lens.float().mean())), "dtype": precision}
+    # the Python-loop decoder on a bounded sample (it is ~10x slower); everything else on all utterances
+    out["batch1_loop"] = timed(singles[::max(1, n_utt // loop_sample)][:loop_sample], "loop")
+    out["batch1_graph"] = timed(singles, "graph")
+    out["batch%d_loop" % batch] = timed(batches[:1], "loop")
+    out["batch%d_graph" % batch] = timed(batches, "graph")
+    out["value"] = out["batch%d_graph" % batch]["audio_samples_per_s"]
+    out["unit"] = "audio-samples/s, symbols -> wav, %d utterances in length-sorted batches of %d, graph-replayed decoder" % (n_utt, batch)
+    return out
+
+
 def _spawn_ranks(n, argv):
     """`python bench.py --gpus N` outside a torch.distributed.run launch: re-exec under it (one rank per GPU of this
     node, rendezvous on 127.0.0.1) and pass its JSON line through."""
@@ -472,6 +542,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hifigan", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 (parity-path) throughput figure")
+    ap.add_argument("--no-inference", action="store_true", help="skip the end-to-end inference leg (BASELINE config 5)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU-oracle legs (default min(cores, 16))")
     ap.add_argument("--no-wgrad-overlap", action="store_true", help="weight gradients on the main stream (A/B switch)")
     ap.add_argument("--no-wgrad-group", action="store_true", help="one launch per weight gradient (A/B switch)")
@@ -633,6 +704,11 @@ def main():
                 out["melspec"] = melspec_leg()
             except Exception as exc:
                 out["melspec"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        if world == 1 and not args.no_inference:
+            try:
+                out["inference"] = inference_leg(hip, cfg, args.precision)
+            except Exception as exc:
+                out["inference"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["parity_error"] = cpu_baseline(cfg, hip)

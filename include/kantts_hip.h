@@ -511,6 +511,24 @@ int kantts_stft_mag_bwd(const float* wav, const float* dmag, int B, int T, int n
  * a ticket counter the kernel resets itself).  kantts/train/trainer.py:997-1004 (clip_grad_norm_). */
 int kantts_sumsq_det(const float* x, float* out, float* workspace, long long ws_floats, long long n, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Free-running decode with the step index in device memory (csrc/decode.hip; BASELINE config 5): one decoder step is a
+ * static launch sequence that a hipGraph replays per step.  `step_dev` (int32 device scalar) overrides `step` when set.
+ *
+ * kantts_pnca_decode_step -- MultiHeadPNCAAttention under update_x_state / update_h_state
+ *   (kantts/models/sambert/__init__.py:217-306): qkv (B, 3*H*16) rows = this step's [q | k | v]; k / v are appended to
+ *   xkv_cache (B, L, 2*H*16) at row `step`; ox / oh (B, H*16) = causal-band attention over the cache and look-ahead-band
+ *   attention over the memory projections hkv (B, L, 2*H*16).  Padded queries (step >= lens[b]) give 0.
+ * kantts_step_rows -- dst[b*dst_bs + step*dst_ss + e] = src[b*src_bs + step*src_ss + e], e < n  (memory[:, step, :] gather,
+ *   output-frame scatter; kantts_sambert.py:589-603).
+ * kantts_step_rowmask -- mask[b] = step >= lens[b]. */
+int kantts_pnca_decode_step(const float* qkv, int ldq, float* xkv_cache, const float* hkv, float* ox, float* oh,
+                            const int32_t* lens, const int32_t* bw_seq, int B, int H, int L, int d_head, int step,
+                            const int32_t* step_dev, int bw, void* stream);
+int kantts_step_rows(const float* src, float* dst, int B, int n, long long src_batch_stride, long long dst_batch_stride,
+                     long long src_step_stride, long long dst_step_stride, int step, const int32_t* step_dev, void* stream);
+int kantts_step_rowmask(const int32_t* lens, uint8_t* mask, int B, int step, const int32_t* step_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

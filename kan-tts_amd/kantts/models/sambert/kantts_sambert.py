@@ -257,6 +257,10 @@ class MelPNCADecoder(nn.Module):
         self.nb_layers = nb_layers
         self.mel_dec = HybridAttentionDecoder(d_mel, prenet_units, nb_layers, d_model, d_mem, nb_heads, d_head,
                                               d_inner, dropout, dropout_attn, dropout_relu, d_mel * outputs_per_step)
+        # free-running decode: "loop" = one launch per op and step from Python (the round-1 path), "fused" = the
+        # step function of decode_graph.py run eagerly, "graph" = that step captured in a hipGraph and replayed
+        self.decode_mode = "loop"
+        self._decode_cache = None
 
     def forward(self, memory, x_band_width, h_band_width, target=None, mask=None, return_attns=False, bw_dev=None):
         if target is None:
@@ -275,6 +279,26 @@ class MelPNCADecoder(nn.Module):
         """Free-running decode (reference :568-610): step t consumes the last mel frame of step t-1.  Outputs land
         in one preallocated (B, L, r*d_mel) buffer instead of a python list + torch.cat."""
         B, L = memory.size(0), memory.size(1)
+        if self.decode_mode in ("graph", "fused") and memory.is_cuda or self.decode_mode == "fused":
+            # one decoder step = a static launch sequence with the step index in device memory (decode_graph.py);
+            # "graph" replays it from a hipGraph captured per (B, L)
+            from kantts.models.sambert.decode_graph import DecodeGraphCache
+            from kantts.models.utils import SeqInfo as _SeqInfo
+
+            if self._decode_cache is None:
+                self._decode_cache = DecodeGraphCache()
+            info = _SeqInfo.of(mask)
+            lens32 = info.lens32 if info is not None else torch.full((B,), L, device=memory.device, dtype=torch.int32)
+            bw = bw_seq if bw_seq is not None else torch.full((B,), int(x_band_width), device=memory.device,
+                                                              dtype=torch.int32)
+            # decoder lengths are bucketed to multiples of 16 steps so that a handful of captured graphs serve every
+            # utterance length (steps past a sequence's length are masked rows, exactly like batch padding)
+            Lp = (L + 15) // 16 * 16 if self.decode_mode == "graph" else L
+            if Lp != L:
+                memory = F.pad(memory, (0, 0, 0, Lp - L))
+            fr = self._decode_cache.get(self.mel_dec, self.d_mel, self.r, B, Lp, memory.device)
+            fr.load(memory, lens32.clamp(max=L), bw)
+            return fr.run(graph=(self.decode_mode == "graph"))[:, :L].clone(), [], []
         self.mel_dec.reset_state()
         memory = memory.contiguous()
         out = torch.empty((B, L, self.d_mel * self.r), device=memory.device, dtype=torch.float32)

@@ -985,6 +985,54 @@ class EmulatedLib:
         mem[offs.ravel()] = out.reshape(B, D).ravel()
         return 0
 
+    def kantts_pnca_decode_step(self, qkv, ldq, xkv, hkv, ox, oh, lens, bw_seq, B, H, L, d_head, step, step_dev, bw, stream):
+        D = H * 16
+        if step_dev:
+            step = int(_arr(step_dev, 1, np.int32)[0])
+        if step < 0 or step >= L:
+            return 0
+        Q = _gather(qkv, (np.arange(B)[:, None] * ldq + np.arange(3 * D)[None, :]).astype(np.int64), None)
+        X = _arr(xkv, B * L * 2 * D).reshape(B, L, 2 * D)
+        Hm = _arr(hkv, B * L * 2 * D).reshape(B, L, 2 * D)
+        X[:, step, :D] = Q[:, D:2 * D]
+        X[:, step, D:] = Q[:, 2 * D:]
+        OX, OH = np.zeros((B, D), np.float32), np.zeros((B, D), np.float32)
+        lens_a = _arr(lens, B, np.int32) if lens else None
+        bws = _arr(bw_seq, B, np.int32) if bw_seq else None
+        for b in range(B):
+            ln_b = int(lens_a[b]) if lens_a is not None else L
+            band = int(bws[b]) if bws is not None else bw
+            if step >= ln_b:
+                continue
+            for buf, out, lo, hi in ((X, OX, max(0, step - band), step),
+                                     (Hm, OH, step, min(step + band, L - 1, ln_b - 1))):
+                if hi < lo:
+                    continue
+                for h in range(H):
+                    q = Q[b, h * 16:(h + 1) * 16]
+                    K = buf[b, lo:hi + 1, h * 16:(h + 1) * 16]
+                    V = buf[b, lo:hi + 1, D + h * 16:D + (h + 1) * 16]
+                    s_ = (K @ q) * np.float32(0.25)
+                    e = np.exp(s_ - s_.max())
+                    out[b, h * 16:(h + 1) * 16] = (e[:, None] * V).sum(0) / e.sum()
+        _arr(ox, B * D)[:] = OX.ravel()
+        _arr(oh, B * D)[:] = OH.ravel()
+        return 0
+
+    def kantts_step_rows(self, src, dst, B, n, src_bs, dst_bs, src_ss, dst_ss, step, step_dev, stream):
+        if step_dev:
+            step = int(_arr(step_dev, 1, np.int32)[0])
+        for b in range(B):
+            s_ = _arr(int(src) + 4 * (b * src_bs + step * src_ss), n)
+            _arr(int(dst) + 4 * (b * dst_bs + step * dst_ss), n)[:] = s_
+        return 0
+
+    def kantts_step_rowmask(self, lens, mask, B, step, step_dev, stream):
+        if step_dev:
+            step = int(_arr(step_dev, 1, np.int32)[0])
+        _arr(mask, B, np.uint8)[:] = (step >= _arr(lens, B, np.int32)).astype(np.uint8)
+        return 0
+
     def kantts_lstm_cell(self, gates, c_prev, h_out, c_out, B, H, stream):
         g = _arr(gates, B * 4 * H).reshape(B, 4, H).astype(np.float64)
         sig = lambda z: 1.0 / (1.0 + np.exp(-z))
