@@ -497,8 +497,9 @@ int kantts_relu_gate_bf16(const void* dy, int dy_bf16, const void* y, int y_bf16
  * LayerNorm outputs only feed contractions (kantts/models/sambert/__init__.py:63,130,198; kantts_sambert.py:58,128). */
 int kantts_ln128_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, float* mean, float* rstd,
                      int M, float eps, void* stream);
+/* dres (optional, fp32 (M,128)): gradient of a residual branch taken from the same x; dx = LN-gradient + dres in one pass. */
 int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
-                     float* dx, float* dgamma_accum, float* dbeta_accum, int M, void* stream);
+                     const float* dres, float* dx, float* dgamma_accum, float* dbeta_accum, int M, void* stream);
 
 /* Backward of kantts_melspec_fwd's magnitude output (the reference's stft(), kantts/utils/audio_torch.py:8-31:
  * sqrt(clamp(re^2 + im^2, eps_power))): dwav_accum (B,T) += d loss / d wav given dmag (B, frames, n_fft/2+1).  Gradient
@@ -528,6 +529,19 @@ int kantts_pnca_decode_step(const float* qkv, int ldq, float* xkv_cache, const f
 int kantts_step_rows(const float* src, float* dst, int B, int n, long long src_batch_stride, long long dst_batch_stride,
                      long long src_step_stride, long long dst_step_stride, int step, const int32_t* step_dev, void* stream);
 int kantts_step_rowmask(const int32_t* lens, uint8_t* mask, int B, int step, const int32_t* step_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HiFi-GAN upsampling as an HBM stream (csrc/upsample.hip): CausalConvTranspose1d with kernel 2*S, stride S
+ * (kantts/models/hifigan/layers.py:125-165, hifigan.py:67-80,160) in polyphase form on bf16 activations:
+ *   out[(b*T + t)*S + r][co] = bias[co] + sum_{j=0,1} sum_ci lrelu(x[b*T + t - j][ci]) * w[ci][co][r + j*S]  (+ res)
+ * x (B*T, Cin) bf16; wp (S*Cout, 2*Cin) bf16 = the weight with rows permuted for 16-byte stores: row mt*16 + rho,
+ * mt = (r*(Cout/32) + cb)*2 + h, holds output channel cb*32 + (rho >> 2)*8 + h*4 + (rho & 3) of phase r; column j*Cin + ci
+ * holds w[ci][co][r + j*S].  out / res (B*T*S, Cout) bf16 (out_bf16) or fp32.  in_slope = 1 for pre-activated input.
+ * Shapes: (Cin, Cout, S) in {(128, 64, 2), (64, 32, 2)}; wider layers are contractions (kantts_bgemm_nt, two segments). */
+int kantts_upsample_stream(const void* x_bf16, const void* wp_bf16, const float* bias, const void* res, void* out, int B,
+                           int T, int Cin, int Cout, int S, float in_slope, int out_bf16, void* stream);
+/* y = sin(x) + x (hifigan.py:157) and act = bf16(LeakyReLU(y, slope)) in one pass. */
+int kantts_sinadd_lrelu_fwd(const float* x, float* y, void* act_bf16, float slope, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -397,9 +397,11 @@ static int wg_launch(const kantts_convw_args& g, hipStream_t st) {
   // the SAM-BERT weight gradients, round 2).  The generator's 32 / 64-channel residual convolutions have tiny weight
   // tensors (11 K elements at 32 ch, k = 11) and many tokens: 2048 slabs meant 23 M atomics = 137 us for a 6 GFLOP
   // contraction (profiles/r01_hifigan_conv_shapes_packed.log).  Never below ~256 blocks.
-  {
+  static const char* cap_env = getenv("KANTTS_WGRAD_ATOMICS");  // A/B switch: "0" disables the budget, else millions
+  const long long budget = cap_env ? (long long)(atof(cap_env) * 1048576.0) : (3ll << 20);
+  if (budget > 0) {
     const long long dw_elems = (long long)g.K * g.Ntot * g.CR;
-    long long cap = (3ll << 20) / (dw_elems > 0 ? dw_elems : 1);
+    long long cap = budget / (dw_elems > 0 ? dw_elems : 1);
     const long long floor_slabs = (256 + xy - 1) / xy;
     if (cap < floor_slabs) cap = floor_slabs;
     if (slabs > cap) slabs = cap;

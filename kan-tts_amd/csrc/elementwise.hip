@@ -130,6 +130,27 @@ extern "C" int kantts_weight_norm_strided_bwd(const float* dw, const float* v, c
                      rs, cs, ks);
   KANTTS_CHECK_LAUNCH();
 }
+// y = sin(x) + x (fp32) and, in the same pass, a = LeakyReLU(y) rounded to bf16: the operand image of the transposed
+// convolution that consumes the stage input (csrc/upsample.hip); the fp32 y still feeds the repeat-upsample branch.
+__global__ void sinadd_lrelu_kernel(const float* __restrict__ x, float* __restrict__ y, __bf16* __restrict__ a, float slope,
+                                    long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const float s = sinf(v) + v;
+    y[i] = s;
+    a[i] = (__bf16)(s > 0.f ? s : s * slope);
+  }
+}
+extern "C" int kantts_sinadd_lrelu_fwd(const float* x, float* y, void* act_bf16, float slope, long long n, void* stream) {
+  if (!x || !y || !act_bf16 || n < 0) return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sinadd_lrelu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y,
+                     reinterpret_cast<__bf16*>(act_bf16), slope, n);
+  KANTTS_CHECK_LAUNCH();
+}
+
 extern "C" int kantts_sinadd_fwd(const float* x, float* y, long long n, void* stream) {
   if (!x || !y || n < 0) return KANTTS_E_BADARG;
   if (n == 0) return KANTTS_OK;

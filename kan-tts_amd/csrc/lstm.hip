@@ -73,54 +73,67 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
   float* gob = gates_out + (((long long)dir * B + b) * T) * LG;
   float* cob = c_out + (((long long)dir * B + b) * T) * LH;
   __syncthreads();
-  int t = rev ? len - 1 : 0;
-  float gnext = (len > 0) ? gxb[(long long)t * gx_ld] : 0.f;
-  for (int step = 0; step < len; ++step) {
-    const float gcur = gnext;
-    const int tn = rev ? t - 1 : t + 1;
-    if (step + 1 < len) gnext = gxb[(long long)tn * gx_ld];
-    float acc0 = gcur + bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    if (BF16) {
-      const uint4* hp = reinterpret_cast<const uint4*>(h_b);
+  // The step is a chain of dependent LDS / ALU latencies (~0.3 us); the input projection gx[t] comes from L2 / HBM
+  // (0.5-2 us).  With the load issued one step ahead every step waited for it (0.78 us per step measured over the
+  // 612-step postnet sequence, profiles/r02_runE_sambert_kernel_stats_top.csv): a ring of LSTM_PF steps in flight
+  // takes the load off the recurrence.
+  constexpr int PF = 4;
+  float gq[PF];
 #pragma unroll
-      for (int k = 0; k < LH / 8; ++k) {
-        LstmPack4 hv;
-        hv.u = hp[k];
-        acc0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k], hv.p[0], acc0, false);
-        acc1 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 1], hv.p[1], acc1, false);
-        acc2 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 2], hv.p[2], acc2, false);
-        acc3 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 3], hv.p[3], acc3, false);
-      }
-    } else {
-      const float4* hp = reinterpret_cast<const float4*>(h_s);
+  for (int u = 0; u < PF; ++u) {
+    const int tu = rev ? len - 1 - u : u;
+    gq[u] = (u < len) ? gxb[(long long)tu * gx_ld] : 0.f;
+  }
+  for (int step0 = 0; step0 < len; step0 += PF) {
 #pragma unroll
-      for (int k = 0; k < LH / 4; ++k) {
-        float4 hv = hp[k];
-        acc0 = fmaf(w[4 * k], hv.x, acc0);
-        acc1 = fmaf(w[4 * k + 1], hv.y, acc1);
-        acc2 = fmaf(w[4 * k + 2], hv.z, acc2);
-        acc3 = fmaf(w[4 * k + 3], hv.w, acc3);
+    for (int u = 0; u < PF; ++u) {
+      const int step = step0 + u;
+      if (step >= len) break;
+      const int t = rev ? len - 1 - step : step;
+      const float gcur = gq[u];
+      if (step + PF < len) gq[u] = gxb[(long long)(rev ? t - PF : t + PF) * gx_ld];
+      float acc0 = gcur + bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      if (BF16) {
+        const uint4* hp = reinterpret_cast<const uint4*>(h_b);
+#pragma unroll
+        for (int k = 0; k < LH / 8; ++k) {
+          LstmPack4 hv;
+          hv.u = hp[k];
+          acc0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k], hv.p[0], acc0, false);
+          acc1 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 1], hv.p[1], acc1, false);
+          acc2 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 2], hv.p[2], acc2, false);
+          acc3 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 3], hv.p[3], acc3, false);
+        }
+      } else {
+        const float4* hp = reinterpret_cast<const float4*>(h_s);
+#pragma unroll
+        for (int k = 0; k < LH / 4; ++k) {
+          float4 hv = hp[k];
+          acc0 = fmaf(w[4 * k], hv.x, acc0);
+          acc1 = fmaf(w[4 * k + 1], hv.y, acc1);
+          acc2 = fmaf(w[4 * k + 2], hv.z, acc2);
+          acc3 = fmaf(w[4 * k + 3], hv.w, acc3);
+        }
       }
+      const float pre = (acc0 + acc1) + (acc2 + acc3);
+      // activation by gate block: rows [0,256) sigmoid (i,f), [256,384) tanh (g), [384,512) sigmoid (o)
+      const float act = (r >= 2 * LH && r < 3 * LH) ? tanhf(pre) : sigmoidf_(pre);
+      g_s[r] = act;
+      gob[(long long)t * LG + r] = act;
+      __syncthreads();
+      if (r < LH) {
+        const float ig = g_s[r], fg = g_s[LH + r], gg = g_s[2 * LH + r], og = g_s[3 * LH + r];
+        c = fmaf(fg, c, ig * gg);
+        const float hn = og * tanhf(c);
+        if (BF16)
+          h_b[r] = (__bf16)hn;
+        else
+          h_s[r] = hn;
+        outb[(long long)t * ndir * LH + r] = hn;
+        cob[(long long)t * LH + r] = c;
+      }
+      __syncthreads();
     }
-    const float pre = (acc0 + acc1) + (acc2 + acc3);
-    // activation by gate block: rows [0,256) sigmoid (i,f), [256,384) tanh (g), [384,512) sigmoid (o)
-    const float act = (r >= 2 * LH && r < 3 * LH) ? tanhf(pre) : sigmoidf_(pre);
-    g_s[r] = act;
-    gob[(long long)t * LG + r] = act;
-    __syncthreads();
-    if (r < LH) {
-      const float ig = g_s[r], fg = g_s[LH + r], gg = g_s[2 * LH + r], og = g_s[3 * LH + r];
-      c = fmaf(fg, c, ig * gg);
-      const float hn = og * tanhf(c);
-      if (BF16)
-        h_b[r] = (__bf16)hn;
-      else
-        h_s[r] = hn;
-      outb[(long long)t * ndir * LH + r] = hn;
-      cob[(long long)t * LH + r] = c;
-    }
-    __syncthreads();
-    t = tn;
   }
   // zero the padded tail (pad_packed_sequence) -- outputs only; saved state is never read there
   for (int tt = len; tt < T; ++tt)
@@ -166,72 +179,91 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
   if (tid < LH) dh_s[tid] = 0.f;
   float dc = 0.f;
   __syncthreads();
-  // time runs opposite to the forward recurrence
-  int t = rev ? 0 : len - 1;
-  for (int step = 0; step < len; ++step) {
-    const int tprev = rev ? t + 1 : t - 1;  // the step that was computed BEFORE t in forward
-    const bool has_prev = (step + 1 < len);
-    if (tid < LH) {
-      const float ig = gb[(long long)t * LG + tid], fg = gb[(long long)t * LG + LH + tid];
-      const float gg = gb[(long long)t * LG + 2 * LH + tid], og = gb[(long long)t * LG + 3 * LH + tid];
-      const float cc = cb[(long long)t * LH + tid];
-      const float cprev = has_prev ? cb[(long long)tprev * LH + tid] : 0.f;
-      const float dh = doutb[(long long)t * ndir * LH + tid] + dh_s[tid];
-      const float tc = tanhf(cc);
-      const float d_o = dh * tc;
-      dc = dc + dh * og * (1.f - tc * tc);
-      const float d_i = dc * gg, d_g = dc * ig, d_f = dc * cprev;
-      const float pi = d_i * ig * (1.f - ig), pf = d_f * fg * (1.f - fg);
-      const float pg = d_g * (1.f - gg * gg), po = d_o * og * (1.f - og);
-      dc = dc * fg;
-      if (BF16) {
-        dg_b[tid] = (__bf16)pi;
-        dg_b[LH + tid] = (__bf16)pf;
-        dg_b[2 * LH + tid] = (__bf16)pg;
-        dg_b[3 * LH + tid] = (__bf16)po;
-      } else {
-        dg_s[tid] = pi;
-        dg_s[LH + tid] = pf;
-        dg_s[2 * LH + tid] = pg;
-        dg_s[3 * LH + tid] = po;
-      }
-      float* dst = dgb + (long long)t * LG;
-      dst[tid] = pi;
-      dst[LH + tid] = pf;
-      dst[2 * LH + tid] = pg;
-      dst[3 * LH + tid] = po;
+  // time runs opposite to the forward recurrence.  The seven operands of a step (four saved gates, c_t, c_{t-1}, dout_t)
+  // were loaded at the top of the step: a full L2 / HBM round trip on the critical path of every step (1.05 us per step
+  // measured).  They now travel PF steps ahead in a register ring.
+  constexpr int PF = 4;
+  float q_i[PF], q_f[PF], q_g[PF], q_o[PF], q_c[PF], q_cp[PF], q_d[PF];
+  auto fetch = [&](int step, float& vi, float& vf, float& vg, float& vo, float& vc, float& vcp, float& vd) {
+    if (tid < LH && step < len) {
+      const int t = rev ? step : len - 1 - step;
+      const int tprev = rev ? t + 1 : t - 1;
+      vi = gb[(long long)t * LG + tid];
+      vf = gb[(long long)t * LG + LH + tid];
+      vg = gb[(long long)t * LG + 2 * LH + tid];
+      vo = gb[(long long)t * LG + 3 * LH + tid];
+      vc = cb[(long long)t * LH + tid];
+      vcp = (step + 1 < len) ? cb[(long long)tprev * LH + tid] : 0.f;
+      vd = doutb[(long long)t * ndir * LH + tid];
     }
-    __syncthreads();
-    {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      if (BF16) {
-        const uint4* dp = reinterpret_cast<const uint4*>(dg_b + qd * LH);
+  };
 #pragma unroll
-        for (int rr = 0; rr < LH / 8; ++rr) {
-          LstmPack4 d4;
-          d4.u = dp[rr];
-          a0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr], d4.p[0], a0, false);
-          a1 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 1], d4.p[1], a1, false);
-          a2 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 2], d4.p[2], a2, false);
-          a3 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 3], d4.p[3], a3, false);
-        }
-      } else {
-        const float4* dp = reinterpret_cast<const float4*>(dg_s + qd * LH);
+  for (int u = 0; u < PF; ++u) fetch(u, q_i[u], q_f[u], q_g[u], q_o[u], q_c[u], q_cp[u], q_d[u]);
+  for (int step0 = 0; step0 < len; step0 += PF) {
 #pragma unroll
-        for (int rr = 0; rr < LH / 4; ++rr) {
-          float4 d4 = dp[rr];
-          a0 = fmaf(w[4 * rr], d4.x, a0);
-          a1 = fmaf(w[4 * rr + 1], d4.y, a1);
-          a2 = fmaf(w[4 * rr + 2], d4.z, a2);
-          a3 = fmaf(w[4 * rr + 3], d4.w, a3);
+    for (int u = 0; u < PF; ++u) {
+      const int step = step0 + u;
+      if (step >= len) break;
+      const int t = rev ? step : len - 1 - step;
+      if (tid < LH) {
+        const float ig = q_i[u], fg = q_f[u], gg = q_g[u], og = q_o[u], cc = q_c[u], cprev = q_cp[u];
+        const float dh = q_d[u] + dh_s[tid];
+        fetch(step + PF, q_i[u], q_f[u], q_g[u], q_o[u], q_c[u], q_cp[u], q_d[u]);
+        const float tc = tanhf(cc);
+        const float d_o = dh * tc;
+        dc = dc + dh * og * (1.f - tc * tc);
+        const float d_i = dc * gg, d_g = dc * ig, d_f = dc * cprev;
+        const float pi = d_i * ig * (1.f - ig), pf = d_f * fg * (1.f - fg);
+        const float pg = d_g * (1.f - gg * gg), po = d_o * og * (1.f - og);
+        dc = dc * fg;
+        if (BF16) {
+          dg_b[tid] = (__bf16)pi;
+          dg_b[LH + tid] = (__bf16)pf;
+          dg_b[2 * LH + tid] = (__bf16)pg;
+          dg_b[3 * LH + tid] = (__bf16)po;
+        } else {
+          dg_s[tid] = pi;
+          dg_s[LH + tid] = pf;
+          dg_s[2 * LH + tid] = pg;
+          dg_s[3 * LH + tid] = po;
         }
+        float* dst = dgb + (long long)t * LG;
+        dst[tid] = pi;
+        dst[LH + tid] = pf;
+        dst[2 * LH + tid] = pg;
+        dst[3 * LH + tid] = po;
       }
-      part_s[qd][kcol] = (a0 + a1) + (a2 + a3);
+      __syncthreads();
+      {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (BF16) {
+          const uint4* dp = reinterpret_cast<const uint4*>(dg_b + qd * LH);
+#pragma unroll
+          for (int rr = 0; rr < LH / 8; ++rr) {
+            LstmPack4 d4;
+            d4.u = dp[rr];
+            a0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr], d4.p[0], a0, false);
+            a1 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 1], d4.p[1], a1, false);
+            a2 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 2], d4.p[2], a2, false);
+            a3 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 3], d4.p[3], a3, false);
+          }
+        } else {
+          const float4* dp = reinterpret_cast<const float4*>(dg_s + qd * LH);
+#pragma unroll
+          for (int rr = 0; rr < LH / 4; ++rr) {
+            float4 d4 = dp[rr];
+            a0 = fmaf(w[4 * rr], d4.x, a0);
+            a1 = fmaf(w[4 * rr + 1], d4.y, a1);
+            a2 = fmaf(w[4 * rr + 2], d4.z, a2);
+            a3 = fmaf(w[4 * rr + 3], d4.w, a3);
+          }
+        }
+        part_s[qd][kcol] = (a0 + a1) + (a2 + a3);
+      }
+      __syncthreads();
+      if (tid < LH) dh_s[tid] = (part_s[0][tid] + part_s[1][tid]) + (part_s[2][tid] + part_s[3][tid]);
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid < LH) dh_s[tid] = (part_s[0][tid] + part_s[1][tid]) + (part_s[2][tid] + part_s[3][tid]);
-    __syncthreads();
-    t = tprev;
   }
   // padded tail contributes nothing
   for (int tt = len; tt < T; ++tt) dgb[(long long)tt * LG + tid] = 0.f;

@@ -187,6 +187,8 @@ def lib():
         L.kantts_pnca_decode_step.argtypes = [p, i, p, p, p, p, p, p, i, i, i, i, i, p, i, p]
         L.kantts_step_rows.argtypes = [p, p, i, i, ll, ll, ll, ll, i, p, p]
         L.kantts_step_rowmask.argtypes = [p, p, i, i, p, p]
+        L.kantts_upsample_stream.argtypes = [p, p, p, p, p, i, i, i, i, i, f, i, p]
+        L.kantts_sinadd_lrelu_fwd.argtypes = [p, p, p, f, ll, p]
         L.kantts_sumsq_det.argtypes = [p, p, p, ll, ll, p]
         L.kantts_stft_mag_bwd.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p]
         L.kantts_bgemm_nt.argtypes = [POINTER(BGemmArgs), c_void_p]
@@ -196,7 +198,7 @@ def lib():
         L.kantts_tapmajor_bf16.argtypes = [p, p, p, i, i, p]
         L.kantts_relu_gate_bf16.argtypes = [p, i, p, i, p, f, ll, p]
         L.kantts_ln128_fwd.argtypes = [p, p, p, p, i, p, p, i, f, p]
-        L.kantts_ln128_bwd.argtypes = [p, i, p, p, p, p, p, p, p, i, p]
+        L.kantts_ln128_bwd.argtypes = [p, i, p, p, p, p, p, p, p, p, i, p]
         _lib = L
     return _lib
 
@@ -211,7 +213,8 @@ EXPORTED_SYMBOLS = [
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
     "kantts_bgemm_nt", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
     "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
-    "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask",
+    "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
+    "kantts_sinadd_lrelu_fwd",
 ]
 
 

@@ -366,12 +366,15 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg, db, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-6, out_bf16=False):
+def layer_norm(x, gamma, beta, eps=1e-6, out_bf16=False, with_res=False):
     """``out_bf16`` (bf16 mode, 128-wide rows only): the normalised activations are written bf16 -- they only feed
-    contractions.  128-wide rows use the 16-lanes-per-row kernels in both modes."""
+    contractions.  128-wide rows use the 16-lanes-per-row kernels in both modes.
+    ``with_res``: returns (y, x_res) where x_res is x routed through this node -- use it as the sub-layer's residual input
+    and the two gradients of x are summed inside the LayerNorm backward kernel (see ops_bf16._LayerNorm128)."""
     if x.shape[-1] == 128 and x.dtype == torch.float32 and x.numel() > 0:
-        return ops_bf16.layer_norm128(x, gamma, beta, eps, out_bf16 and get_precision() == "bf16")
-    return _LayerNorm.apply(x, gamma, beta, eps)
+        return ops_bf16.layer_norm128(x, gamma, beta, eps, out_bf16 and get_precision() == "bf16", with_res)
+    y = _LayerNorm.apply(x, gamma, beta, eps)
+    return (y, x) if with_res else y
 
 
 def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p_out=0.0):
@@ -1109,12 +1112,20 @@ class _ConvTransposeCL(torch.autograd.Function):
     Reference: CausalConvTranspose1d, kantts/models/hifigan/layers.py:125-165, hifigan.py:67-80,160."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, s, in_leaky):
+    def forward(ctx, x, w, bias, res, s, in_leaky, act=None):
         x, w = _c(x), _c(w)
         B, Tin, Cin = x.shape
         _, Cout, K = w.shape
         assert K % s == 0
         taps = K // s
+        if act is not None and taps == 2 and get_precision() == "bf16":
+            # bf16 mode with the activated bf16 image of x at hand: forward through the streaming / two-segment kernels
+            # (backward below is unchanged: it works from the saved fp32 x)
+            y = upsample_forward(act, w, bias, s, res=res)
+            if y is not None:
+                ctx.cfg = (s, in_leaky, bias is not None, res is not None)
+                ctx.save_for_backward(x, w)
+                return y
         y = torch.empty((B, Tin * s, Cout), device=x.device, dtype=torch.float32)
         r_t = _c(res) if res is not None else None
         w2 = w.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).contiguous()  # (taps, s, Cout, Cin)
@@ -1169,11 +1180,13 @@ class _ConvTransposeCL(torch.autograd.Function):
                 db = db2.view(s, Cout).sum(0)
         elif has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1))
-        return dx, dw, db, (dy if has_res else None), None, None
+        return dx, dw, db, (dy if has_res else None), None, None, None
 
 
-def conv_transpose_cl(x, w, bias, stride, in_leaky=None, res=None):
-    return _ConvTransposeCL.apply(x, w, bias, res, int(stride), in_leaky)
+def conv_transpose_cl(x, w, bias, stride, in_leaky=None, res=None, act=None):
+    """``act``: optional bf16(LeakyReLU(x)) (ops.sin_add(..., act_slope=)): bf16 mode then runs the forward pass on the
+    streaming upsampling kernels."""
+    return _ConvTransposeCL.apply(x, w, bias, res, int(stride), in_leaky, act)
 
 
 class _WeightNorm(torch.autograd.Function):
@@ -1253,8 +1266,87 @@ class _SinAdd(torch.autograd.Function):
         return dx
 
 
-def sin_add(x):
+class _SinAddAct(torch.autograd.Function):
+    """sin(x) + x plus a non-differentiable bf16 LeakyReLU image of the result (kantts_sinadd_lrelu_fwd)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = _c(x)
+        y = torch.empty_like(x)
+        act = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+        check(lib().kantts_sinadd_lrelu_fwd(ptr(x, torch.float32), ptr(y), ptr(act), float(slope), x.numel(), stream()),
+              "sinadd_lrelu_fwd")
+        ctx.save_for_backward(x)
+        ctx.mark_non_differentiable(act)
+        return y, act
+
+    @staticmethod
+    def backward(ctx, dy, _da):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        check(lib().kantts_sinadd_bwd(ptr(dy, torch.float32), ptr(x), ptr(dx), x.numel(), stream()), "sinadd_bwd")
+        return dx, None
+
+
+def sin_add(x, act_slope=None):
+    """sin(x) + x; with ``act_slope`` also returns bf16(LeakyReLU(result)) -- the operand of the streaming transposed
+    convolution (bf16 mode)."""
+    if act_slope is not None:
+        return _SinAddAct.apply(x, float(act_slope))
     return _SinAdd.apply(x)
+
+
+def upsample_weights(w, s):
+    """(Cin, Cout, 2s) transposed-conv weight -> (linear, permuted) bf16 polyphase matrices (s*Cout, 2*Cin): row (r, co),
+    column (j, ci) = w[ci, co, r + j*s]; the permuted copy orders rows for csrc/upsample.hip's 16-byte stores."""
+    Cin, Cout, K = w.shape
+    assert K == 2 * s
+    wl = w.detach().view(Cin, Cout, 2, s).permute(3, 1, 2, 0).reshape(s * Cout, 2 * Cin)
+    wp = None
+    if Cout % 32 == 0:
+        wp = wl.view(s, Cout // 32, 4, 2, 4, 2 * Cin).permute(0, 1, 3, 2, 4, 5).reshape(s * Cout, 2 * Cin)
+        wp = ops_bf16.to_bf16(wp)
+    return ops_bf16.to_bf16(wl), wp
+
+
+_up_wcache = {}
+
+
+def upsample_forward(act, w, bias, s, res=None, out_bf16=False, in_slope=1.0, prepared=None):
+    """Polyphase CausalConvTranspose1d (kernel 2s, stride s) on a bf16 (B, T, Cin) input: the HBM-streaming kernel for the
+    narrow layers, the two-segment bf16 contraction for the wide ones.  Returns (B, T*s, Cout) or None if unsupported.
+    ``prepared``: the result of upsample_weights(w, s) when the caller keeps it (inference: weights are constants);
+    parameters are cached by version, freshly computed weights (weight norm in training) are re-laid per call."""
+    B, T, Cin = act.shape
+    Cout = w.shape[1]
+    if w.shape[2] != 2 * s or act.dtype != torch.bfloat16 or Cin % 8 or (s * Cout) % 8:
+        return None
+    if prepared is None and isinstance(w, torch.nn.Parameter):
+        hit = _up_wcache.get(id(w))
+        if hit is not None and hit[0] == (w._version, w.data_ptr(), s):
+            prepared = hit[1]
+        else:
+            prepared = upsample_weights(w, s)
+            _up_wcache[id(w)] = ((w._version, w.data_ptr(), s), prepared)
+    wl, wp = prepared if prepared is not None else upsample_weights(w, s)
+    out = torch.empty((B, T * s, Cout), device=act.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    r = _c(res) if res is not None else None
+    if wp is not None and (Cin, Cout, s) in ((128, 64, 2), (64, 32, 2)) and (r is None or r.dtype == out.dtype):
+        rc = lib().kantts_upsample_stream(ptr(act), ptr(wp), ptr(bias, torch.float32), ptr(r), ptr(out), B, T, Cin, Cout, s,
+                                          float(in_slope), int(out_bf16), stream())
+        if rc == 0:
+            return out
+        if rc != -2:
+            check(rc, "upsample_stream")
+    if in_slope != 1.0 or (r is not None and r.dtype != torch.float32):
+        return None
+    brep = bias.repeat(s) if bias is not None else None
+    segs = [(act, Cin, (wl, 0), 2 * Cin, Cin, 0), (act, Cin, (wl, Cin), 2 * Cin, Cin, -1)]
+    if not bgemm_nt(segs, B * T, s * Cout, out, s * Cout, T=T, bias=brep, res=None if r is None else r.view(B * T, s * Cout),
+                    ldr=s * Cout):
+        return None
+    return out
 
 
 # ================================================================================================

@@ -232,10 +232,12 @@ def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, dr
 # LayerNorm(128)
 # ================================================================================================
 class _LayerNorm128(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_bf16):
-        from .ops import gzeros_like  # noqa: F401  (keeps the import graph one-directional at module load)
+    """y = LayerNorm(x) and, with ``with_res``, a second output that IS x: the residual branch of a pre-LN sub-layer takes
+    that output instead of x itself, so both gradients of x arrive at this node and are summed inside the LayerNorm
+    backward kernel -- autograd would otherwise add them with a separate elementwise kernel per sub-layer."""
 
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res):
         x = _c(x)
         M = x.numel() // 128
         y = torch.empty(x.shape, device=x.device, dtype=BF16 if out_bf16 else torch.float32)
@@ -244,24 +246,30 @@ class _LayerNorm128(torch.autograd.Function):
         check(lib().kantts_ln128_fwd(ptr(x, torch.float32), ptr(gamma, torch.float32), ptr(beta, torch.float32), ptr(y),
                                      int(out_bf16), ptr(mean), ptr(rstd), M, float(eps), stream()), "ln128_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
-        return y
+        if with_res:
+            return y, x.view_as(x)
+        return y, None
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres):
         from .ops import gzeros_like
 
         x, gamma, mean, rstd = ctx.saved_tensors
-        dy = _c(dy)
         M = x.numel() // 128
         dx = torch.empty_like(x)
         dg, db = gzeros_like(gamma), gzeros_like(gamma)
-        check(lib().kantts_ln128_bwd(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
-                                     ptr(dg), ptr(db), M, stream()), "ln128_bwd")
-        return dx, dg, db, None, None
+        if dy is None:  # only the pass-through was used downstream
+            return (dres, None, None, None, None, None)
+        dy = _c(dy)
+        dres = _c(dres) if dres is not None else None
+        check(lib().kantts_ln128_bwd(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean), ptr(rstd),
+                                     ptr(dres, torch.float32), ptr(dx), ptr(dg), ptr(db), M, stream()), "ln128_bwd")
+        return dx, dg, db, None, None, None
 
 
-def layer_norm128(x, gamma, beta, eps, out_bf16):
-    return _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16))
+def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False):
+    y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res))
+    return (y, xr) if with_res else y
 
 
 # ================================================================================================

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm, weight_norm
 
-from kantts._hip import ops
+from kantts._hip import get_precision, ops
 from kantts.models.hifigan.layers import (CausalConv1d, CausalConvTranspose1d, Conv1d, ConvTranspose1d,
                                           ResidualBlock, SourceModule, conv_weight, effective_weight)
 
@@ -94,7 +94,13 @@ class Generator(torch.nn.Module):
         h = self.conv_pre.forward_cl(x.transpose(1, 2).contiguous())
         for i in range(self.num_upsamples):
             s = self.upsample_scales[i]
-            h = ops.sin_add(h)
+            act = None
+            up_layer = self.transpose_upsamples[i][1]
+            if get_precision() == "bf16" and h.is_cuda and isinstance(up_layer, CausalConvTranspose1d):
+                # sin(h) + h and the bf16 LeakyReLU image the streaming transposed convolution consumes, in one pass
+                h, act = ops.sin_add(h, act_slope=self.slope)
+            else:
+                h = ops.sin_add(h)
             if self.repeat_upsample:
                 conv = self.repeat_upsamples[i][2]
                 c = conv.conv1d
@@ -105,7 +111,10 @@ class Generator(torch.nn.Module):
                 rep = None
             if excitation is not None:  # rep + e, accumulated in the strided convolution's epilogue
                 rep = self.source_downs[i].forward_cl(excitation, res=rep)
-            h = self.transpose_upsamples[i][1].forward_cl(h, in_leaky=self.slope, res=rep)
+            if act is not None:
+                h = up_layer.forward_cl(h, in_leaky=self.slope, res=rep, act=act)
+            else:
+                h = up_layer.forward_cl(h, in_leaky=self.slope, res=rep)
             xs = None
             for j in range(self.num_kernels):
                 y = self.conv_blocks[i * self.num_kernels + j].forward_cl(h)

@@ -128,9 +128,9 @@ class CausalConvTranspose1d(torch.nn.Module):
         self.deconv.apply(init_weights)
         self.pad = kernel_size - stride
 
-    def forward_cl(self, x, in_leaky=None, res=None):
+    def forward_cl(self, x, in_leaky=None, res=None, act=None):
         return ops.conv_transpose_cl(x, effective_weight(self.deconv), self.deconv.bias, self.stride, in_leaky=in_leaky,
-                                     res=res)
+                                     res=res, act=act)
 
     def forward(self, x):
         return self.forward_cl(x.transpose(1, 2).contiguous()).transpose(1, 2)

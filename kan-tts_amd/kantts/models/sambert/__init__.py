@@ -84,7 +84,8 @@ class MultiHeadSelfAttention(nn.Module):
         if torch.is_tensor(mask) and mask.dim() == 3:
             mask = mask[:, 0, :]
         info = SeqInfo.of(mask)
-        x = ops.layer_norm(input, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True)
+        x, input = ops.layer_norm(input, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
+                                  with_res=True)
         qkv = ops.linear(x, self.w_qkv.weight, self.w_qkv.bias)
         ctxv, attn = ops.self_attention(qkv, None if info is None else info.lens32, self.n_head,
                                         drop_p=_p(self.attention.dropatt, self.training), want_probs=return_attn)
@@ -109,7 +110,8 @@ class PositionwiseConvFeedForward(nn.Module):
     def forward(self, x, mask=None, zero_rows=None):
         info = SeqInfo.of(mask)
         pad_rows = None if info is None else info.mask
-        h = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True)
+        h, x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
+                              with_res=True)
         return ops.ffn(h, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, x, pad_rows=pad_rows,
                        zero_rows=zero_rows, p_inner=_p(self.dropout_inner, self.training),
                        p_out=_p(self.dropout, self.training))
@@ -164,7 +166,8 @@ class MultiHeadPNCAAttention(nn.Module):
 
     def forward(self, x, h, info=None, x_band_width=0, h_band_width=0, zero_rows=None, return_attn=False,
                 bw_dev=None):
-        xn = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True)
+        xn, x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
+                               with_res=True)
         qkv = ops.linear(xn, self.w_x_qkv.weight, self.w_x_qkv.bias)
         hkv = ops.linear(h, self.w_h_kv.weight, self.w_h_kv.bias)
         info = SeqInfo.of(info)

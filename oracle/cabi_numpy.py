@@ -390,7 +390,7 @@ class EmulatedLib:
         _arr(rstd, M)[:] = rs.numpy()
         return 0
 
-    def kantts_ln128_bwd(self, dy, dy_bf16, x, gamma, mean, rstd, dx, dgamma, dbeta, M, stream):
+    def kantts_ln128_bwd(self, dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, M, stream):
         C = 128
         DY = torch.from_numpy(_rd(dy, M * C, bool(dy_bf16))).view(M, C)
         X = torch.from_numpy(_arr(x, M * C).copy()).view(M, C)
@@ -399,6 +399,8 @@ class EmulatedLib:
         xh = (X - mu[:, None]) * rs[:, None]
         gq = DY * G
         DX = rs[:, None] * (gq - gq.mean(1, keepdim=True) - xh * (gq * xh).mean(1, keepdim=True))
+        if dres:
+            DX = DX + torch.from_numpy(_arr(dres, M * C).copy()).view(M, C)
         _arr(dx, M * C)[:] = DX.reshape(-1).numpy()
         _arr(dgamma, C)[:] += (DY * xh).sum(0).numpy()
         _arr(dbeta, C)[:] += DY.sum(0).numpy()
@@ -826,6 +828,34 @@ class EmulatedLib:
         dgv = (DW * V).sum(1) / nrm
         _arr(dg, rows)[:] = dgv
         _arr(dv, rows * cols)[:] = ((G / nrm)[:, None] * (DW - V * (dgv / nrm)[:, None])).ravel()
+        return 0
+
+    def kantts_sinadd_lrelu_fwd(self, x, y, act, slope, n, stream):
+        X = _arr(x, n)
+        Y = (np.sin(X) + X).astype(np.float32)
+        _arr(y, n)[:] = Y
+        _wr(act, np.where(Y > 0, Y, Y * np.float32(_val(slope))), True)
+        return 0
+
+    def kantts_upsample_stream(self, x, wp, bias, res, out, B, T, Cin, Cout, S, in_slope, out_bf16, stream):
+        if (Cin, Cout, S) not in ((128, 64, 2), (64, 32, 2)):
+            return -2
+        slope = np.float32(_val(in_slope))
+        X = _rd(x, B * T * Cin, True).reshape(B, T, Cin)
+        if slope != 1:
+            X = _bf16_round(np.where(X > 0, X, X * slope)).reshape(B, T, Cin)
+        Xp = np.concatenate([np.zeros((B, 1, Cin), np.float32), X[:, :-1]], 1)
+        A = np.concatenate([X, Xp], -1).reshape(B * T, 2 * Cin)               # [x_t | x_{t-1}]
+        Wp = _rd(wp, S * Cout * 2 * Cin, True).reshape(S * Cout, 2 * Cin)
+        # undo the row permutation: row ((r*CB + cb)*2 + h)*16 + g*4 + i  ->  (r, co = cb*32 + g*8 + h*4 + i)
+        CB = Cout // 32
+        Wl = Wp.reshape(S, CB, 2, 4, 4, 2 * Cin).transpose(0, 1, 3, 2, 4, 5).reshape(S * Cout, 2 * Cin)
+        Y = (A @ Wl.T).reshape(B * T * S, Cout)
+        if bias:
+            Y = Y + _arr(bias, Cout)[None, :]
+        if res:
+            Y = Y + _rd(res, B * T * S * Cout, bool(out_bf16)).reshape(B * T * S, Cout)
+        _wr(out, Y.astype(np.float32), bool(out_bf16))
         return 0
 
     def kantts_sinadd_fwd(self, x, y, n, stream):

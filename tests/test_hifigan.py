@@ -455,3 +455,42 @@ def test_hifigan_v1_gpu_matches_reference_fixture():
             for a, (shape, s_, a_) in zip(fa, fb):
                 assert tuple(a.shape) == tuple(shape)
                 assert abs(float(a.double().sum()) - s_) <= 2e-4 * max(1.0, a_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,s,T", [(64, 32, 2, 4096), (128, 64, 2, 2048), (128, 64, 2, 37), (256, 128, 8, 256),
+                                            (512, 256, 8, 32)])
+def test_upsample_streaming_kernels_gpu(Cin, Cout, s, T):
+    """csrc/upsample.hip + the two-segment bf16 contraction against torch's conv_transpose1d on the same bf16-rounded
+    operands (causal trim), with bias and residual; bf16 and fp32 outputs; sequence starts inside a 16-token tile."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+
+    hip.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(Cin + T)
+        B = 3
+        x = torch.randn(B, T, Cin, generator=g)
+        w = torch.randn(Cin, Cout, 2 * s, generator=g) * (1.0 / (2 * Cin) ** 0.5)
+        b = torch.randn(Cout, generator=g)
+        res = torch.randn(B, T * s, Cout, generator=g)
+        h, act = ops.sin_add(x.cuda(), act_slope=0.1)
+        assert_close(h.cpu(), torch.sin(x) + x, 1e-6, what="sin_add")
+        a = F.leaky_relu(torch.sin(x) + x, 0.1).to(torch.bfloat16)
+        assert float((act.cpu().float() - a.float()).abs().max()) <= 2e-2  # one bf16 ulp where sinf differs in the last bit
+        a = act.cpu()
+        wq = w.to(torch.bfloat16).float()
+        ref = F.conv_transpose1d(a.float().transpose(1, 2), wq, b, stride=s)[:, :, :T * s].transpose(1, 2)
+        y = ops.upsample_forward(act, w.cuda(), b.cuda(), s, res=res.cuda())
+        assert y is not None and y.dtype == torch.float32
+        assert rel_l2(y.cpu(), ref + res) <= 2e-5
+        if Cin <= 128:
+            y2 = ops.upsample_forward(act, w.cuda(), b.cuda(), s, out_bf16=True)
+            assert y2.dtype == torch.bfloat16 and rel_l2(y2.cpu().float(), ref) <= 4e-3
+            hb = h.to(torch.bfloat16)
+            a3 = F.leaky_relu(hb.cpu().float(), 0.1).to(torch.bfloat16).float()
+            ref3 = F.conv_transpose1d(a3.transpose(1, 2), wq, b, stride=s)[:, :, :T * s].transpose(1, 2)
+            y3 = ops.upsample_forward(hb, w.cuda(), b.cuda(), s, out_bf16=True, in_slope=0.1)
+            assert rel_l2(y3.cpu().float(), ref3) <= 4e-3
+    finally:
+        hip.set_precision("fp32")
