@@ -394,11 +394,12 @@ static int wg_launch(const kantts_convw_args& g, hipStream_t st) {
   long long slabs = (2048 + xy - 1) / xy;
   if (slabs > (total_steps + 3) / 4) slabs = (total_steps + 3) / 4;
   // ... and within an atomics budget: every slab adds the whole dw once, and fp32 atomics retire at ~200 G/s (measured on
-  // the SAM-BERT weight gradients, round 2).  The generator's 32 / 64-channel residual convolutions have tiny weight
+  // the SAM-BERT weight gradients, round 2); A/B on the V1 GAN step: no budget 69.1 ms of conv launches, 3 M 74.5 ms (too few
+  // blocks), 12 M 63.9 ms (profiles/r02_runG_conv_shapes_cap*.log).  The generator's 32 / 64-channel residual convolutions have tiny weight
   // tensors (11 K elements at 32 ch, k = 11) and many tokens: 2048 slabs meant 23 M atomics = 137 us for a 6 GFLOP
   // contraction (profiles/r01_hifigan_conv_shapes_packed.log).  Never below ~256 blocks.
   static const char* cap_env = getenv("KANTTS_WGRAD_ATOMICS");  // A/B switch: "0" disables the budget, else millions
-  const long long budget = cap_env ? (long long)(atof(cap_env) * 1048576.0) : (3ll << 20);
+  const long long budget = cap_env ? (long long)(atof(cap_env) * 1048576.0) : (12ll << 20);
   if (budget > 0) {
     const long long dw_elems = (long long)g.K * g.Ntot * g.CR;
     long long cap = budget / (dw_elems > 0 ? dw_elems : 1);

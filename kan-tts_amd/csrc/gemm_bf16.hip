@@ -19,6 +19,8 @@
 // [row][64] bf16 with the 16-byte chunk index XORed by (row >> 1) & 7 (conflict-free 16- and 8-byte fragment reads);
 // n-contiguous images are [k][128 + 16] (8 consecutive k rows start 8 banks apart, as in gemm_fast.hip).
 // TN: 128 x 128 outputs, waves 2x2 with 64x64 each, token tile 32, atomics into the fp32 gradient.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -97,11 +99,12 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
   constexpr int CS_BYTES = BM * CLD * 4;
   constexpr int LDS_BYTES = (2 * STAGE > CS_BYTES) ? 2 * STAGE : CS_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-  constexpr int NA = BM * 8 / BG_THREADS;  // 16-byte chunks of the A tile per thread (2 / 1)
+  constexpr int NA = BM * 8 / BG_THREADS;  // 16-byte chunks of the A tile per thread (4 / 2 / 1)
   constexpr int NB = 4;                    // B tile: 1024 chunks
-  constexpr int WM = (BM == 64) ? 2 : 1;   // waves along M
-  constexpr int NREP = (BM == 64) ? 4 : 2; // 16-column fragments per wave
-  constexpr int MREP = 2;                  // 32 rows per wave
+  constexpr int WM = (BM >= 64) ? 2 : 1;   // waves along M
+  constexpr int NREP = (BM >= 64) ? 4 : 2; // 16-column fragments per wave
+  constexpr int MREP = BM / (WM * 16);     // 16-row fragments per wave (4 / 2 / 2)
+  constexpr int WROWS = MREP * 16;         // rows per wave
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = (WM == 2) ? (wave >> 1) : 0, wc = (WM == 2) ? (wave & 1) : wave;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
       bf16x8 af[MREP], bf[NREP];
 #pragma unroll
       for (int m = 0; m < MREP; ++m) {
-        const int r = wr * 32 + m * 16 + li;
+        const int r = wr * WROWS + m * 16 + li;
         const int sw = (r >> 1) & 7;
         if (B_KN) {
           // permuted-k convention of the transpose reads: lane group kg holds k = kg*4..+3 and 16 + kg*4..+3
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
     for (int n = 0; n < NREP; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        Cs[(wr * 32 + m * 16 + kg * 4 + r) * CLD + wc * (NREP * 16) + n * 16 + li] = acc[m][n][r];
+        Cs[(wr * WROWS + m * 16 + kg * 4 + r) * CLD + wc * (NREP * 16) + n * 16 + li] = acc[m][n][r];
   __syncthreads();
 
   const int jc = (tid & 15) * 8;  // 8 output columns per thread
@@ -370,13 +373,21 @@ extern "C" int kantts_bgemm_nt(const kantts_bgemm_args* gp, void* stream) {
     if (!bg_aligned16(sg.a) || !bg_aligned16(sg.b)) return KANTTS_E_UNSUPPORTED;
     if (sg.a_shift != 0 && g.T <= 0) return KANTTS_E_BADARG;
   }
-  const long long blocks64 = (long long)kantts_cdiv(g.M, 64) * kantts_cdiv(g.N, BG_BN);
-  const bool small = blocks64 < 256;
+  // the largest row tile that still gives every CU ~1.5 workgroups: these launches are a handful of dependent load /
+  // multiply / store chains per workgroup, so their duration is one workgroup's latency times the number of rounds the
+  // grid needs -- 816 workgroups of 64 rows (3 resident per CU) took two rounds where 408 of 128 rows take one
+  const long long nt = kantts_cdiv(g.N, BG_BN);
+  const long long wg128 = kantts_cdiv(g.M, 128) * nt, wg64 = kantts_cdiv(g.M, 64) * nt;
+  static const char* force_bm = getenv("KANTTS_BGEMM_BM");
+  int bm = wg128 >= 384 ? 128 : (wg64 >= 384 ? 64 : 32);
+  if (force_bm) bm = atoi(force_bm);
   hipStream_t st = (hipStream_t)stream;
-  if (small)
-    bg_launch_nt<32>(g, dim3(kantts_cdiv(g.N, BG_BN), kantts_cdiv(g.M, 32)), st);
+  if (bm == 128)
+    bg_launch_nt<128>(g, dim3(nt, kantts_cdiv(g.M, 128)), st);
+  else if (bm == 64)
+    bg_launch_nt<64>(g, dim3(nt, kantts_cdiv(g.M, 64)), st);
   else
-    bg_launch_nt<64>(g, dim3(kantts_cdiv(g.N, BG_BN), kantts_cdiv(g.M, 64)), st);
+    bg_launch_nt<32>(g, dim3(nt, kantts_cdiv(g.M, 32)), st);
   KANTTS_CHECK_LAUNCH();
 }
 

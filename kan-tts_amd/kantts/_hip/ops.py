@@ -1302,12 +1302,12 @@ def upsample_weights(w, s):
     column (j, ci) = w[ci, co, r + j*s]; the permuted copy orders rows for csrc/upsample.hip's 16-byte stores."""
     Cin, Cout, K = w.shape
     assert K == 2 * s
-    wl = w.detach().view(Cin, Cout, 2, s).permute(3, 1, 2, 0).reshape(s * Cout, 2 * Cin)
+    wb = ops_bf16.to_bf16(w) if w.numel() % 8 == 0 else w.detach().to(torch.bfloat16)  # one cast, then bf16 re-layouts
+    wl = wb.view(Cin, Cout, 2, s).permute(3, 1, 2, 0).reshape(s * Cout, 2 * Cin)
     wp = None
-    if Cout % 32 == 0:
+    if Cout % 32 == 0 and (Cin, Cout, s) in ((128, 64, 2), (64, 32, 2)):
         wp = wl.view(s, Cout // 32, 4, 2, 4, 2 * Cin).permute(0, 1, 3, 2, 4, 5).reshape(s * Cout, 2 * Cin)
-        wp = ops_bf16.to_bf16(wp)
-    return ops_bf16.to_bf16(wl), wp
+    return wl, wp
 
 
 _up_wcache = {}

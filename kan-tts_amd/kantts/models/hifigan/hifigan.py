@@ -5,6 +5,7 @@ and ``state_dict`` keys.  Internally everything is channels-last; feature maps a
 zero-copy ``(B, C, T[, p])`` views of the channels-last buffers.
 """
 import copy
+import os
 
 import numpy as np
 import torch
@@ -96,7 +97,8 @@ class Generator(torch.nn.Module):
             s = self.upsample_scales[i]
             act = None
             up_layer = self.transpose_upsamples[i][1]
-            if get_precision() == "bf16" and h.is_cuda and isinstance(up_layer, CausalConvTranspose1d):
+            if (get_precision() == "bf16" and h.is_cuda and isinstance(up_layer, CausalConvTranspose1d)
+                    and not os.environ.get("KANTTS_NO_UPSTREAM")):  # (A/B switch of scripts/gpu_*.sh)
                 # sin(h) + h and the bf16 LeakyReLU image the streaming transposed convolution consumes, in one pass
                 h, act = ops.sin_add(h, act_slope=self.slope)
             else:

@@ -207,10 +207,12 @@ class VarianceAdaptor(nn.Module):
         energy_src = energy_targets if energy_targets is not None else energy_predictions
         # text + Conv1d(1->32,k=9)(pitch) + Conv1d(1->32,k=9)(energy): two 9-tap GEMMs chained through the
         # residual port of the epilogue (reference :420-443)
-        aug = ops.linear(pitch_src.unsqueeze(-1), self.pitch_emb.weight, self.pitch_emb.bias, mode="conv", pad=4,
-                         res=inputs_text_embedding)
-        aug = ops.linear(energy_src.unsqueeze(-1), self.energy_emb.weight, self.energy_emb.bias, mode="conv", pad=4,
-                         res=aug)
+        # single-input-channel convolutions: the streaming kernels of csrc/conv_c1.hip (one launch forward, one for the
+        # weight gradient) -- as token-shifted GEMMs with K = 1 they took 9 launches per weight gradient on the generic
+        # contraction kernel (0.4 ms of a 13 ms step, profiles/r02_runE_sambert_kernel_stats_top.csv)
+        aug = (inputs_text_embedding
+               + ops.conv_cl(pitch_src.unsqueeze(-1).contiguous(), self.pitch_emb.weight, self.pitch_emb.bias, pad=4)
+               + ops.conv_cl(energy_src.unsqueeze(-1).contiguous(), self.energy_emb.weight, self.energy_emb.bias, pad=4))
         duration_predictor_cond = torch.cat([aug, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
         if duration_targets is not None:
             prev = F.pad(duration_targets[:, :-1].float(), (1, 0))
