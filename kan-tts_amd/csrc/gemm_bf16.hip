@@ -373,13 +373,13 @@ extern "C" int kantts_bgemm_nt(const kantts_bgemm_args* gp, void* stream) {
     if (!bg_aligned16(sg.a) || !bg_aligned16(sg.b)) return KANTTS_E_UNSUPPORTED;
     if (sg.a_shift != 0 && g.T <= 0) return KANTTS_E_BADARG;
   }
-  // the largest row tile that still gives every CU ~1.5 workgroups: these launches are a handful of dependent load /
-  // multiply / store chains per workgroup, so their duration is one workgroup's latency times the number of rounds the
-  // grid needs -- 816 workgroups of 64 rows (3 resident per CU) took two rounds where 408 of 128 rows take one
+  // 64-row tiles once they give every CU a workgroup, else 32-row tiles.  128-row tiles (one round of 408 workgroups
+  // instead of 816 in two) were measured and lost: 2 waves per SIMD and a 64-register epilogue made the 6528 x 128 -> 1024
+  // projection 17.0 us instead of 12.8 (profiles/r02_runH_bgemm_bm128.log); KANTTS_BGEMM_BM=128 still selects them.
   const long long nt = kantts_cdiv(g.N, BG_BN);
-  const long long wg128 = kantts_cdiv(g.M, 128) * nt, wg64 = kantts_cdiv(g.M, 64) * nt;
+  const long long wg64 = kantts_cdiv(g.M, 64) * nt;
   static const char* force_bm = getenv("KANTTS_BGEMM_BM");
-  int bm = wg128 >= 384 ? 128 : (wg64 >= 384 ? 64 : 32);
+  int bm = wg64 >= 256 ? 64 : 32;
   if (force_bm) bm = atoi(force_bm);
   hipStream_t st = (hipStream_t)stream;
   if (bm == 128)

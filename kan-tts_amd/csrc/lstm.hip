@@ -19,6 +19,11 @@
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. it waits
+// until the step's global STORES (saved gates / cell state / outputs: pure outputs, never re-read by this kernel) have
+// been acknowledged by L2 -- two or three such round trips on the critical path of every time step.
+__device__ __forceinline__ void lstm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // gx: (B,T,ndir*4H) [direction d at column offset d*4H]; out: (B,T,ndir*H)
 // whh: (ndir, 4H, H), bhh: (ndir, 4H); gates_out: (ndir,B,T,4H); c_out: (ndir,B,T,H)
 typedef __bf16 lstm_bf16x2 __attribute__((ext_vector_type(2)));
@@ -74,24 +79,32 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
   float* cob = c_out + (((long long)dir * B + b) * T) * LH;
   __syncthreads();
   // The step is a chain of dependent LDS / ALU latencies (~0.3 us); the input projection gx[t] comes from L2 / HBM
-  // (0.5-2 us).  With the load issued one step ahead every step waited for it (0.78 us per step measured over the
-  // 612-step postnet sequence, profiles/r02_runE_sambert_kernel_stats_top.csv): a ring of LSTM_PF steps in flight
-  // takes the load off the recurrence.
-  constexpr int PF = 4;
-  float gq[PF];
+  // (0.5-2 us).  Round 1 loaded it one step ahead inside an `if`: hipcc waits for a load issued in a conditional block
+  // where the branch re-joins (s_waitcnt vmcnt(0)), so every step paid the full load latency (0.78 us per step over the
+  // 612-step postnet sequence).  A register ring with the loads interleaved into the steps fared no better: the vector
+  // memory counter retires in order and the loop back-edge makes the compiler's count conservative (vmcnt(1)).  What
+  // works is CHUNKS: the gx values of the next LSTM_CH steps are loaded -- unconditionally, steps clamped into the
+  // sequence -- at the top of a chunk and first touched a whole chunk later.
+  constexpr int PF = 8;
+  float gq[PF], gn[PF];
+  const int last = len > 0 ? len - 1 : 0;
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
-    const int tu = rev ? len - 1 - u : u;
-    gq[u] = (u < len) ? gxb[(long long)tu * gx_ld] : 0.f;
+    const int su = min(u, last);
+    gq[u] = gxb[(long long)(rev ? last - su : su) * gx_ld];
   }
   for (int step0 = 0; step0 < len; step0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int sn = min(step0 + PF + u, last);
+      gn[u] = gxb[(long long)(rev ? last - sn : sn) * gx_ld];
+    }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int step = step0 + u;
       if (step >= len) break;
       const int t = rev ? len - 1 - step : step;
       const float gcur = gq[u];
-      if (step + PF < len) gq[u] = gxb[(long long)(rev ? t - PF : t + PF) * gx_ld];
       float acc0 = gcur + bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
       if (BF16) {
         const uint4* hp = reinterpret_cast<const uint4*>(h_b);
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
       const float act = (r >= 2 * LH && r < 3 * LH) ? tanhf(pre) : sigmoidf_(pre);
       g_s[r] = act;
       gob[(long long)t * LG + r] = act;
-      __syncthreads();
+      lstm_barrier();
       if (r < LH) {
         const float ig = g_s[r], fg = g_s[LH + r], gg = g_s[2 * LH + r], og = g_s[3 * LH + r];
         c = fmaf(fg, c, ig * gg);
@@ -132,8 +145,10 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
         outb[(long long)t * ndir * LH + r] = hn;
         cob[(long long)t * LH + r] = c;
       }
-      __syncthreads();
+      lstm_barrier();
     }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) gq[u] = gn[u];
   }
   // zero the padded tail (pad_packed_sequence) -- outputs only; saved state is never read there
   for (int tt = len; tt < T; ++tt)
@@ -181,25 +196,32 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
   __syncthreads();
   // time runs opposite to the forward recurrence.  The seven operands of a step (four saved gates, c_t, c_{t-1}, dout_t)
   // were loaded at the top of the step: a full L2 / HBM round trip on the critical path of every step (1.05 us per step
-  // measured).  They now travel PF steps ahead in a register ring.
+  // measured).  They are now loaded a CHUNK of PF steps ahead (see the forward kernel): the operands of the next chunk
+  // are requested at the top of a chunk by all 512 threads (column tid & 127, step clamped into the sequence), outside
+  // any divergent block, and first touched a chunk later.
   constexpr int PF = 4;
   float q_i[PF], q_f[PF], q_g[PF], q_o[PF], q_c[PF], q_cp[PF], q_d[PF];
+  float n_i[PF], n_f[PF], n_g[PF], n_o[PF], n_c[PF], n_cp[PF], n_d[PF];
+  const int last = len > 0 ? len - 1 : 0;
+  const int col = tid & (LH - 1);
   auto fetch = [&](int step, float& vi, float& vf, float& vg, float& vo, float& vc, float& vcp, float& vd) {
-    if (tid < LH && step < len) {
-      const int t = rev ? step : len - 1 - step;
-      const int tprev = rev ? t + 1 : t - 1;
-      vi = gb[(long long)t * LG + tid];
-      vf = gb[(long long)t * LG + LH + tid];
-      vg = gb[(long long)t * LG + 2 * LH + tid];
-      vo = gb[(long long)t * LG + 3 * LH + tid];
-      vc = cb[(long long)t * LH + tid];
-      vcp = (step + 1 < len) ? cb[(long long)tprev * LH + tid] : 0.f;
-      vd = doutb[(long long)t * ndir * LH + tid];
-    }
+    const int sc = min(step, last);
+    const int t = rev ? sc : last - sc;
+    const int tprev = min(max(rev ? t + 1 : t - 1, 0), T - 1);
+    vi = gb[(long long)t * LG + col];
+    vf = gb[(long long)t * LG + LH + col];
+    vg = gb[(long long)t * LG + 2 * LH + col];
+    vo = gb[(long long)t * LG + 3 * LH + col];
+    vc = cb[(long long)t * LH + col];
+    const float cp = cb[(long long)tprev * LH + col];
+    vcp = (sc + 1 < len) ? cp : 0.f;
+    vd = doutb[(long long)t * ndir * LH + col];
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) fetch(u, q_i[u], q_f[u], q_g[u], q_o[u], q_c[u], q_cp[u], q_d[u]);
   for (int step0 = 0; step0 < len; step0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(step0 + PF + u, n_i[u], n_f[u], n_g[u], n_o[u], n_c[u], n_cp[u], n_d[u]);
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int step = step0 + u;
@@ -208,7 +230,6 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
       if (tid < LH) {
         const float ig = q_i[u], fg = q_f[u], gg = q_g[u], og = q_o[u], cc = q_c[u], cprev = q_cp[u];
         const float dh = q_d[u] + dh_s[tid];
-        fetch(step + PF, q_i[u], q_f[u], q_g[u], q_o[u], q_c[u], q_cp[u], q_d[u]);
         const float tc = tanhf(cc);
         const float d_o = dh * tc;
         dc = dc + dh * og * (1.f - tc * tc);
@@ -233,7 +254,7 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
         dst[2 * LH + tid] = pg;
         dst[3 * LH + tid] = po;
       }
-      __syncthreads();
+      lstm_barrier();
       {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (BF16) {
@@ -260,9 +281,14 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
         }
         part_s[qd][kcol] = (a0 + a1) + (a2 + a3);
       }
-      __syncthreads();
+      lstm_barrier();
       if (tid < LH) dh_s[tid] = (part_s[0][tid] + part_s[1][tid]) + (part_s[2][tid] + part_s[3][tid]);
-      __syncthreads();
+      lstm_barrier();
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      q_i[u] = n_i[u], q_f[u] = n_f[u], q_g[u] = n_g[u], q_o[u] = n_o[u];
+      q_c[u] = n_c[u], q_cp[u] = n_cp[u], q_d[u] = n_d[u];
     }
   }
   // padded tail contributes nothing
