@@ -493,6 +493,63 @@ int kantts_tapmajor_bf16(const float* src, void* dst_bf16, const kantts_tapmajor
 int kantts_relu_gate_bf16(const void* dy, int dy_bf16, const void* y, int y_bf16, void* dz_bf16, float scale, long long n,
                           void* stream);
 
+/* kantts_ffn_pair: the two contractions of a position-wise feed-forward block in one launch
+ * (kantts/models/sambert/__init__.py:134-149; forward and, with `gate`, the input-gradient pass).
+ *   phase 1   t[m][f] = epi1( sum_tap x[m + tap - pad][:] . w1[tap][f][:] )          m < M, f < F, reduction K1 = 128
+ *             forward  (gate == NULL): epi1 = rowmask1( dropout_{drop1}( relu?( . + bias1 ) ) )
+ *             backward (gate != NULL): epi1 = gate[m][f] > 0 ? alpha1 * . : 0                      (KT == 1 only)
+ *   phase 2   y[m][n] = rowmask2( dropout_{drop2}( t[m][:] . w2[n][:] + bias2 ) + res[m][n] )      n < N = 128
+ * x: (M, 128) bf16 or fp32 (x_f32; fp32 rows may carry a regenerated dropout xdrop_* with index m*128 + k and are zeroed
+ * where xrowmask[m] != 0).  w1: the (KT*F, 128) matrix [tap*F + f][k], w2: the (128, F) matrix [n][f], both bf16 in the
+ * FRAGMENT-MAJOR layout of kantts_fragmajor_bf16 -- the backward pass hands in the transposed weights (w1 := W2^T as
+ * (F, 128), w2 := W1^T as (128, F)).  t_out (optional): bf16 (M, F) row-major, the intermediate the weight gradients need.
+ * Taps do not cross sequence boundaries: rows are B sequences of T tokens.  Dropout indices: m*F + f (drop1), m*128 + n
+ * (drop2); seeds are offset by *seed_dev (graph replay).  F = 1024.  Returns KANTTS_E_UNSUPPORTED for other shapes: the
+ * caller falls back to two kantts_bgemm_nt launches. */
+typedef struct kantts_ffn_args {
+  const void* x;
+  int64_t ldx;
+  int32_t x_f32;
+  int32_t M, T, K1, F, N, KT, pad;
+  const void* w1;
+  const void* w2;
+  const float* bias1;
+  const float* bias2;
+  int32_t relu;
+  float alpha1;
+  float drop1_p;
+  float drop2_p;
+  float xdrop_p;
+  uint64_t drop1_seed;
+  uint64_t drop2_seed;
+  uint64_t xdrop_seed;
+  const uint64_t* seed_dev;
+  const void* gate;
+  const uint8_t* rowmask1;
+  const uint8_t* rowmask2;
+  const uint8_t* xrowmask;
+  void* t_out;
+  const float* res;
+  int64_t ldr;
+  void* y;
+  int64_t ldy;
+  int32_t y_bf16;
+} kantts_ffn_args;
+int kantts_ffn_pair(const kantts_ffn_args* args, void* stream);
+
+/* Fragment-major bf16 images of weight matrices, a table of them in one launch (the parameter arena's per-step refresh).
+ * Entry: the (R, K) matrix with element (r, k) = src[src_off + r*sr + k*sk] (fp32; any orientation of the master weight)
+ * is written to dst + dst_off so that every 16 x 32 block (r/16, k/32) is 1 KB in the order one A-operand load of
+ * v_mfma_f32_16x16x32_bf16 reads it: dst[((r/16)*(K/32) + k/32)*512 + (((k%32)/8)*16 + r%16)*8 + k%8].
+ * R % 16 == 0, K % 32 == 0. */
+typedef struct kantts_fragmajor_desc {
+  int64_t src_off, dst_off;
+  int64_t sr, sk;
+  int32_t R, K;
+} kantts_fragmajor_desc;
+int kantts_fragmajor_bf16(const float* src, void* dst_bf16, const kantts_fragmajor_desc* table_dev, int ndesc,
+                          int blocks_per_desc, void* stream);
+
 /* nn.LayerNorm(128, eps) forward / backward, 16 lanes per row; the output (and the incoming gradient) may be bf16 because
  * LayerNorm outputs only feed contractions (kantts/models/sambert/__init__.py:63,130,198; kantts_sambert.py:58,128). */
 int kantts_ln128_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_bf16, float* mean, float* rstd,

@@ -125,6 +125,25 @@ class BGemmTnArgs(Structure):
     ]
 
 
+class FfnArgs(Structure):
+    """kantts_ffn_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("ldx", c_int64), ("x_f32", c_int32),
+        ("M", c_int32), ("T", c_int32), ("K1", c_int32), ("F", c_int32), ("N", c_int32), ("KT", c_int32), ("pad", c_int32),
+        ("w1", c_void_p), ("w2", c_void_p), ("bias1", c_void_p), ("bias2", c_void_p),
+        ("relu", c_int32), ("alpha1", c_float), ("drop1_p", c_float), ("drop2_p", c_float), ("xdrop_p", c_float),
+        ("drop1_seed", c_uint64), ("drop2_seed", c_uint64), ("xdrop_seed", c_uint64), ("seed_dev", c_void_p),
+        ("gate", c_void_p), ("rowmask1", c_void_p), ("rowmask2", c_void_p), ("xrowmask", c_void_p),
+        ("t_out", c_void_p), ("res", c_void_p), ("ldr", c_int64), ("y", c_void_p), ("ldy", c_int64), ("y_bf16", c_int32),
+    ]
+
+
+class FragMajorDesc(Structure):
+    """kantts_fragmajor_desc (include/kantts_hip.h)."""
+    _fields_ = [("src_off", c_int64), ("dst_off", c_int64), ("sr", c_int64), ("sk", c_int64), ("R", c_int32),
+                ("K", c_int32)]
+
+
 class TapMajorDesc(Structure):
     _fields_ = [("src_off", c_int64), ("dst_off", c_int64), ("N", c_int32), ("Cin", c_int32), ("KT", c_int32),
                 ("pad_", c_int32)]
@@ -192,6 +211,8 @@ def lib():
         L.kantts_sumsq_det.argtypes = [p, p, p, ll, ll, p]
         L.kantts_stft_mag_bwd.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p]
         L.kantts_bgemm_nt.argtypes = [POINTER(BGemmArgs), c_void_p]
+        L.kantts_ffn_pair.argtypes = [POINTER(FfnArgs), c_void_p]
+        L.kantts_fragmajor_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
         L.kantts_bgemm_tn.argtypes = [POINTER(BGemmTnArgs), c_void_p]
         L.kantts_bgemm_tn_grouped.argtypes = [POINTER(BGemmTnArgs), c_int, p, p, p, p, p, c_void_p]
         L.kantts_cast_f32_bf16.argtypes = [p, p, ll, p]
@@ -211,7 +232,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_norm_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd", "kantts_weight_norm_strided_fwd", "kantts_weight_norm_strided_bwd",
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
-    "kantts_bgemm_nt", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
+    "kantts_bgemm_nt", "kantts_ffn_pair", "kantts_fragmajor_bf16", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
     "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
     "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
     "kantts_sinadd_lrelu_fwd",
@@ -407,6 +428,39 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
     if _profile is not None:
         e1.record()
         _profile.append((e0, e1, 2.0 * M * N * sum(sg[4] for sg in segs)))
+    return True
+
+
+def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu=False, alpha1=1.0, drop1_p=0.0,
+             drop1_seed=0, drop2_p=0.0, drop2_seed=0, xdrop_p=0.0, xdrop_seed=0, gate=None, rowmask1=None, rowmask2=None,
+             xrowmask=None, t_out=None, res=None):
+    """Both contractions of a feed-forward block in one launch (csrc/ffn_pair.hip; kantts_ffn_pair in the header).
+    x (M, 128) bf16 / fp32; w1 / w2: FRAGMENT-MAJOR bf16 images (ops_bf16.frag_major) of the (KT*F, 128) and (128, F)
+    weight matrices; y (M, 128) fp32 / bf16; t_out bf16 (M, F).  Returns False when the library declines the shape."""
+    g = FfnArgs()
+    g.x, g.ldx, g.x_f32 = ptr(x), int(x.shape[-1]), int(x.dtype == torch.float32)
+    g.M, g.T, g.K1, g.F, g.N, g.KT, g.pad = int(M), int(T), int(x.shape[-1]), int(F), int(y.shape[-1]), int(KT), int(pad)
+    g.w1, g.w2 = ptr(w1, torch.bfloat16), ptr(w2, torch.bfloat16)
+    g.bias1, g.bias2 = ptr(bias1, torch.float32), ptr(bias2, torch.float32)
+    g.relu, g.alpha1 = int(bool(relu)), float(alpha1)
+    g.drop1_p, g.drop2_p, g.xdrop_p = float(drop1_p), float(drop2_p), float(xdrop_p)
+    g.drop1_seed, g.drop2_seed, g.xdrop_seed = int(drop1_seed), int(drop2_seed), int(xdrop_seed)
+    g.seed_dev = rng_ptr(y.device) if (drop1_p > 0 or drop2_p > 0 or xdrop_p > 0) else None
+    g.gate = ptr(gate, torch.bfloat16)
+    g.rowmask1, g.rowmask2, g.xrowmask = ptr(rowmask1), ptr(rowmask2), ptr(xrowmask)
+    g.t_out = ptr(t_out, torch.bfloat16)
+    g.res, g.ldr = ptr(res, torch.float32), int(y.shape[-1])
+    g.y, g.ldy, g.y_bf16 = ptr(y), int(y.shape[-1]), int(y.dtype == torch.bfloat16)
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().kantts_ffn_pair(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "ffn_pair")
+    if _profile is not None:
+        e1.record()
+        _profile.append((e0, e1, 2.0 * M * F * (x.shape[-1] * KT + y.shape[-1])))
     return True
 
 

@@ -10,13 +10,16 @@ Gradient dtypes follow autograd's rule (gradient dtype == forward tensor dtype):
 gradient; those tensors have exactly one consumer, so nothing is ever accumulated in bf16.
 """
 import math
+import os
 
 import torch
 
-from . import bgemm_nt, bgemm_tn, check, lib, ptr, stream
+from . import bgemm_nt, bgemm_tn, check, ffn_pair, lib, ptr, stream
 
 BF16 = torch.bfloat16
 _wcache = {}
+# the feed-forward pair as one launch (csrc/ffn_pair.hip); KANTTS_NO_FFN_PAIR=1 keeps the two-launch form (A/B runs)
+PAIR = {"on": os.environ.get("KANTTS_NO_FFN_PAIR", "") == ""}
 
 
 def _c(t):
@@ -56,6 +59,41 @@ def bf16_weight(w, tap_major=False):
         _wcache.clear()
     _wcache[key] = (w._version, w.data_ptr(), tuple(w.shape), t)
     return t
+
+
+def frag_major(mat):
+    """(R, K) matrix -> flat bf16 image in the fragment-major layout of kantts_fragmajor_bf16: every 16 x 32 block is the
+    1 KB one A-operand load of v_mfma_f32_16x16x32_bf16 reads (lane = ((k % 32) / 8) * 16 + r % 16, 8 consecutive k)."""
+    R, K = mat.shape
+    assert R % 16 == 0 and K % 32 == 0
+    return to_bf16(mat.detach().reshape(R // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()).view(-1)
+
+
+def ffn_frag_weights(w1, w2):
+    """The four weight images of csrc/ffn_pair.hip for Conv1d weights w1 (F, C, KT), w2 (N, F, 1):
+    (forward phase 1: rows tap*F + f, forward phase 2: (N, F), backward phase 1: W2^T (F, N), backward phase 2: W1^T
+    (C, F)); the backward pair only for KT = 1.  Arena parameters carry them as attributes (refreshed once per step by
+    one launch); anything else is converted on demand and cached until the tensors change."""
+    a = getattr(w1, "_kantts_frag", None)
+    b = getattr(w2, "_kantts_frag", None)
+    if a is not None and b is not None:
+        return a, b, getattr(w2, "_kantts_fragT", None), getattr(w1, "_kantts_fragT", None)
+    key = (id(w1), id(w2), "frag")
+    sig = (w1._version, w1.data_ptr(), tuple(w1.shape), w2._version, w2.data_ptr(), tuple(w2.shape))
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    F, C, KT = w1.shape
+    N = w2.shape[0]
+    with torch.no_grad():
+        f1 = frag_major(w1.detach().permute(2, 0, 1).reshape(KT * F, C))
+        f2 = frag_major(w2.detach().reshape(N, F))
+        t2 = frag_major(w2.detach().reshape(N, F).t()) if KT == 1 else None
+        t1 = frag_major(w1.detach().reshape(F, C).t()) if KT == 1 else None
+    if len(_wcache) > 4096:
+        _wcache.clear()
+    _wcache[key] = (sig, (f1, f2, t2, t1))
+    return f1, f2, t2, t1
 
 
 def conv_weight_bf16(w):
@@ -281,7 +319,7 @@ class _FusedFFNB(torch.autograd.Function):
     gate is the epilogue of the input-gradient contraction through w_2."""
 
     @staticmethod
-    def forward(ctx, h, w1, b1, w2, b2, res, pad_rows, zero_rows, wb1, wb2, cfg):
+    def forward(ctx, h, w1, b1, w2, b2, res, pad_rows, zero_rows, wb1, wb2, wf1, wf2, wt2, wt1, cfg):
         from .ops import next_seed
 
         h = _c(h)
@@ -296,24 +334,28 @@ class _FusedFFNB(torch.autograd.Function):
         pr = _c(pad_rows).view(M) if pad_rows is not None else None
         zr = _c(zero_rows).view(M) if zero_rows is not None else None
         hid = torch.empty((M, F), device=h.device, dtype=BF16)
-        segs = [(hb, C, (wb1, tap * F * C), C, C, tap - pad) for tap in range(kt)]
-        if not bgemm_nt(segs, M, F, hid, F, T=T, bias=b1, relu=True, drop_p=p_in, drop_seed=s1, rowmask=pr):
-            raise RuntimeError("bgemm_nt declined the FFN up-projection")
         out = torch.empty((M, N), device=h.device, dtype=torch.float32)
         r = _c(res).view(M, N)
-        if not bgemm_nt([(hid, F, wb2, F, F, 0)], M, N, out, N, bias=b2, drop_p=p_out, drop_seed=s2, res=r, ldr=N,
-                        rowmask=zr):
-            raise RuntimeError("bgemm_nt declined the FFN down-projection")
+        fused = cfg["pair"] and ffn_pair(hb.view(M, C), wf1, wf2, out, M=M, T=T, F=F, KT=kt, pad=pad, bias1=b1, bias2=b2,
+                                         relu=True, drop1_p=p_in, drop1_seed=s1, drop2_p=p_out, drop2_seed=s2,
+                                         rowmask1=pr, rowmask2=zr, t_out=hid, res=r)
+        if not fused:
+            segs = [(hb, C, (wb1, tap * F * C), C, C, tap - pad) for tap in range(kt)]
+            if not bgemm_nt(segs, M, F, hid, F, T=T, bias=b1, relu=True, drop_p=p_in, drop_seed=s1, rowmask=pr):
+                raise RuntimeError("bgemm_nt declined the FFN up-projection")
+            if not bgemm_nt([(hid, F, wb2, F, F, 0)], M, N, out, N, bias=b2, drop_p=p_out, drop_seed=s2, res=r, ldr=N,
+                            rowmask=zr):
+                raise RuntimeError("bgemm_nt declined the FFN down-projection")
         ctx.cfg, ctx.seeds, ctx.dims, ctx.lead = cfg, (s1, s2), (M, F, C, kt, N), lead
         ctx.h_dtype = h.dtype
-        ctx.save_for_backward(hb, hid, zr, wb1, wb2)
+        ctx.save_for_backward(hb, hid, zr, wb1, wb2, wt2, wt1)
         return out.view(*lead, N)
 
     @staticmethod
     def backward(ctx, dy):
         from .ops import gzeros, wgrad_overlap
 
-        hb, hid, zr, wb1, wb2 = ctx.saved_tensors
+        hb, hid, zr, wb1, wb2, wt2, wt1 = ctx.saved_tensors
         M, F, C, kt, N = ctx.dims
         cfg = ctx.cfg
         T, pad, p_in, p_out = cfg["T"], cfg["pad"], cfg["p_inner"], cfg["p_out"]
@@ -325,25 +367,30 @@ class _FusedFFNB(torch.autograd.Function):
         dev = dy.device
         # gradient at the hidden pre-activation: (dropout(dy) @ w2) gated by hid > 0 (ReLU, inner dropout, padded rows)
         dz = torch.empty((M, F), device=dev, dtype=BF16)
-        if not bgemm_nt([(dy, N, wb2, F, N, 0)], M, F, dz, F, b_kn=True, gate=hid, ldg=F,
-                        alpha=(1.0 / (1.0 - p_in) if p_in > 0 else 1.0), a_drop_p=p_out, a_drop_seed=s2, a_drop_ld=N):
+        dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
+        a1 = 1.0 / (1.0 - p_in) if p_in > 0 else 1.0
+        # both input-gradient contractions in one launch (images of the TRANSPOSED weights)
+        fused = (cfg["pair"] and kt == 1 and wt1 is not None and wt2 is not None and
+                 ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid, t_out=dz))
+        if not fused and not bgemm_nt([(dy, N, wb2, F, N, 0)], M, F, dz, F, b_kn=True, gate=hid, ldg=F, alpha=a1,
+                                      a_drop_p=p_out, a_drop_seed=s2, a_drop_ld=N):
             raise RuntimeError("bgemm_nt declined the FFN hidden gradient")
         dw2 = gzeros((N, F, 1), dev)
         db2 = gzeros((N,), dev)
         with wgrad_overlap.side(dy, hid):
             if not bgemm_tn(dy, N, hid, F, M, N, F, dw2, F, 1, db=db2, a_drop_p=p_out, a_drop_seed=s2):
                 raise RuntimeError("bgemm_tn declined dW2")
-        dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
-        segs = [(dz, F, (wb1, tap * F * C), C, F, pad - tap) for tap in range(kt)]
-        if not bgemm_nt(segs, M, C, dh, C, T=T, b_kn=True):
-            raise RuntimeError("bgemm_nt declined the FFN input gradient")
+        if not fused:
+            segs = [(dz, F, (wb1, tap * F * C), C, F, pad - tap) for tap in range(kt)]
+            if not bgemm_nt(segs, M, C, dh, C, T=T, b_kn=True):
+                raise RuntimeError("bgemm_nt declined the FFN input gradient")
         dw1 = gzeros((F, C, kt), dev)
         db1 = gzeros((F,), dev)
         with wgrad_overlap.side(dz, hb):
             if not bgemm_tn(dz, F, hb, C, M, F, C, dw1, C * kt, kt, c_ts=1, T=T, ntaps=kt, shift0=-pad, shift_step=1,
                             db=db1):
                 raise RuntimeError("bgemm_tn declined dW1")
-        return dh.view(*ctx.lead, C), dw1, db1, dw2, db2, d_res, None, None, None, None, None
+        return (dh.view(*ctx.lead, C), dw1, db1, dw2, db2, d_res) + (None,) * 9
 
 
 def ffn_eligible(h, w1, w2):
@@ -353,5 +400,12 @@ def ffn_eligible(h, w1, w2):
 
 def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p_out=0.0, T=0):
     """h: LayerNorm output (B, T, C) (bf16 or fp32); w1 (F, C, k), w2 (C_out, F, 1) Conv1d weights; res (B, T, C_out)."""
-    cfg = dict(T=int(T or h.shape[-2]), pad=(w1.shape[2] - 1) // 2, p_inner=float(p_inner), p_out=float(p_out))
-    return _FusedFFNB.apply(h, w1, b1, w2, b2, res, pad_rows, zero_rows, conv_weight_bf16(w1), conv_weight_bf16(w2), cfg)
+    F, C, kt = w1.shape
+    # csrc/ffn_pair.hip: 128 channels either side, 1024 hidden units, odd kernel width
+    pair = PAIR["on"] and C == 128 and w2.shape[0] == 128 and F == 1024 and kt % 2 == 1 and kt <= 9
+    cfg = dict(T=int(T or h.shape[-2]), pad=(kt - 1) // 2, p_inner=float(p_inner), p_out=float(p_out), pair=pair)
+    wf1 = wf2 = wt2 = wt1 = None
+    if pair:
+        wf1, wf2, wt2, wt1 = ffn_frag_weights(w1, w2)
+    return _FusedFFNB.apply(h, w1, b1, w2, b2, res, pad_rows, zero_rows, conv_weight_bf16(w1), conv_weight_bf16(w2), wf1,
+                            wf2, wt2, wt1, cfg)

@@ -106,6 +106,9 @@ class PositionwiseConvFeedForward(nn.Module):
         self.layer_norm = nn.LayerNorm(d_in, eps=1e-6)
         self.dropout_inner = nn.Dropout(dropout_inner)
         self.dropout = nn.Dropout(dropout)
+        # bf16 mode: the parameter arena also keeps the fragment-major images csrc/ffn_pair.hip streams (ops_bf16)
+        self.w_1.weight._kantts_ffn_role = "w1"
+        self.w_2.weight._kantts_ffn_role = "w2"
 
     def forward(self, x, mask=None, zero_rows=None):
         info = SeqInfo.of(mask)

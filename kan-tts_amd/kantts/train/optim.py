@@ -61,16 +61,47 @@ class ParamArena:
             p._kantts_bf16 = self.flat_bf16[o:o + p.numel()].view(p.shape)
             if p.dim() == 3 and p.shape[2] > 1:
                 n, cin, kt = p.shape
-                rows.append((o, off, n, cin, kt, p))
+                rows.append((o, off, n, cin, kt, p, "_kantts_bf16_tap"))
                 off += (p.numel() + self.align - 1) // self.align * self.align
         self.tap_bf16 = torch.zeros(max(off, 8), device=dev, dtype=torch.bfloat16)
         self._tap_blocks = 1
         tab = []
-        for o, to, n, cin, kt, p in rows:
-            p._kantts_bf16_tap = self.tap_bf16[to:to + p.numel()].view(kt, n, cin)
+        for o, to, n, cin, kt, p, attr in rows:
+            setattr(p, attr, self.tap_bf16[to:to + p.numel()].view(kt, n, cin))
             tab.append([o, to, n | (cin << 32), kt])  # kantts_tapmajor_desc: two int64 offsets + N, Cin, KT, pad (int32)
             self._tap_blocks = max(self._tap_blocks, min(64, (n * cin * kt + 1023) // 1024))
         self._tap_table = torch.tensor(tab, dtype=torch.int64, device=dev) if tab else None
+        # fragment-major images of the feed-forward weights (csrc/ffn_pair.hip; kantts_fragmajor_desc = src_off, dst_off,
+        # sr, sk (int64), R, K (int32)): forward images for every flagged pair of the supported shape, images of the
+        # transposed weights (the backward operands) when the first convolution has one tap
+        ftab, foff = [], 0
+        self._frag_blocks = 1
+
+        def image(p, src_off, R, K, sr, sk, attr, n_img=1):
+            nonlocal foff
+            base = foff
+            for t in range(n_img):
+                ftab.append([src_off + t, base + t * R * K, sr, sk, R | (K << 32)])
+            foff += (n_img * R * K + self.align - 1) // self.align * self.align
+            self._frag_blocks = max(self._frag_blocks, min(64, (R * K + 2047) // 2048))
+            return (attr, p, base, n_img * R * K)
+
+        views = []
+        for p, o in zip(self.params, self.offsets):
+            role = getattr(p, "_kantts_ffn_role", None)
+            if role == "w1" and p.dim() == 3 and p.shape[0] == 1024 and p.shape[1] == 128 and p.shape[2] % 2 == 1:
+                F_, C_, KT_ = p.shape
+                views.append(image(p, o, F_, C_, C_ * KT_, KT_, "_kantts_frag", n_img=KT_))
+                if KT_ == 1:
+                    views.append(image(p, o, C_, F_, 1, C_, "_kantts_fragT"))
+            elif role == "w2" and p.dim() == 3 and p.shape[0] == 128 and p.shape[1] == 1024 and p.shape[2] == 1:
+                N_, F_, _ = p.shape
+                views.append(image(p, o, N_, F_, F_, 1, "_kantts_frag"))
+                views.append(image(p, o, F_, N_, 1, F_, "_kantts_fragT"))
+        self.frag_bf16 = torch.zeros(max(foff, 8), device=dev, dtype=torch.bfloat16)
+        for attr, p, base, n in views:
+            setattr(p, attr, self.frag_bf16[base:base + n])
+        self._frag_table = torch.tensor(ftab, dtype=torch.int64, device=dev) if ftab else None
         self.refresh_shadow()
         self.module.register_forward_pre_hook(lambda m, a: self.refresh_shadow())
 
@@ -85,6 +116,10 @@ class ParamArena:
             check(lib().kantts_tapmajor_bf16(ptr(self.flat, torch.float32), ptr(self.tap_bf16, torch.bfloat16),
                                              ptr(self._tap_table), int(self._tap_table.shape[0]), int(self._tap_blocks),
                                              stream()), "tapmajor_bf16")
+        if self._frag_table is not None:
+            check(lib().kantts_fragmajor_bf16(ptr(self.flat, torch.float32), ptr(self.frag_bf16, torch.bfloat16),
+                                              ptr(self._frag_table), int(self._frag_table.shape[0]),
+                                              int(self._frag_blocks), stream()), "fragmajor_bf16")
 
     def view_of(self, flat, i):
         p = self.params[i]

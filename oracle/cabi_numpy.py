@@ -87,6 +87,12 @@ def _wr(ptr, vals, bf16):
         _arr(ptr, vals.size, np.float32)[:] = vals
 
 
+def _unfrag(ptr, R, K):
+    """(R, K) matrix from its fragment-major bf16 image (kantts_fragmajor_bf16)."""
+    flat = _rd(ptr, R * K, True)
+    return flat.reshape(R // 16, K // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(R, K)
+
+
 def _rd2d(ptr, rows, cols, ld, bf16, row_ok=None, row_src=None):
     """(rows, cols) block with leading dimension ld; invalid rows read as zero; row_src remaps row indices."""
     out = np.zeros((rows, cols), dtype=np.float32)
@@ -300,6 +306,80 @@ class EmulatedLib:
         esz = 2 if g.c_bf16 else 4
         for i in range(M):
             _wr(int(g.c) + i * g.ldc * esz, v[i], bool(g.c_bf16))
+        return 0
+
+    def kantts_fragmajor_bf16(self, src, dst, table, ndesc, blocks, stream):
+        tab = _arr(table, ndesc * 5, np.int64).reshape(ndesc, 5)
+        for src_off, dst_off, sr, sk, rk in tab:
+            R, K = int(rk) & 0xFFFFFFFF, int(rk) >> 32
+            r = np.arange(R, dtype=np.int64)[:, None]
+            k = np.arange(K, dtype=np.int64)[None, :]
+            span = int(src_off + (R - 1) * sr + (K - 1) * sk) + 1
+            mat = _arr(src, span)[src_off + r * sr + k * sk]
+            img = mat.reshape(R // 16, 16, K // 32, 4, 8).transpose(0, 2, 3, 1, 4).reshape(-1)
+            _wr(int(dst) + int(dst_off) * 2, img, True)
+        return 0
+
+    def kantts_ffn_pair(self, args_ref, stream):
+        """csrc/ffn_pair.hip: t = epi1(sum_tap x[m + tap - pad] . w1[tap]^T) rounded to bf16; y = epi2(t . w2^T)."""
+        g = args_ref._obj
+        M, T, K1, F, N, KT, pad = g.M, g.T, g.K1, g.F, g.N, g.KT, g.pad
+        if K1 != 128 or N != 128 or F != 1024:
+            return -2
+        if KT > 9 or pad < 0 or pad >= KT or (KT > 1 and T <= 0) or (g.gate and KT != 1) or (g.xdrop_p > 0 and not g.x_f32):
+            return -2
+        if M == 0:
+            return 0
+        soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
+        rows = np.arange(M, dtype=np.int64)
+        cols1 = np.arange(K1, dtype=np.int64)
+        X = _rd2d(g.x, M, K1, g.ldx, not g.x_f32)
+        if g.x_f32:
+            if g.xdrop_p > 0:
+                X = X * dropout_scale(g.xdrop_p, g.xdrop_seed + soff, rows[:, None] * K1 + cols1[None, :])
+            X = _bf16_round(X)
+        if g.xrowmask:
+            X = np.where(_arr(g.xrowmask, M, np.uint8)[:, None] != 0, 0, X).astype(np.float32)
+        acc = np.zeros((M, F), dtype=np.float32)
+        for tap in range(KT):
+            sh = tap - pad
+            ok = np.ones(M, dtype=bool)
+            if KT > 1:
+                t = rows % T + sh
+                ok = (t >= 0) & (t < T)
+            src = np.clip(rows + sh, 0, M - 1)
+            W = _unfrag(int(g.w1) + tap * F * K1 * 2, F, K1)
+            acc += (X[src] * ok[:, None]) @ W.T
+        fcols = np.arange(F, dtype=np.int64)
+        if g.gate:
+            v = np.where(_rd2d(g.gate, M, F, F, True) > 0, acc * np.float32(g.alpha1), 0)
+        else:
+            v = acc
+            if g.bias1:
+                v = v + _arr(g.bias1, F)[None, :]
+            if g.relu:
+                v = np.maximum(v, 0)
+            if g.drop1_p > 0:
+                v = v * dropout_scale(g.drop1_p, g.drop1_seed + soff, rows[:, None] * F + fcols[None, :])
+            if g.rowmask1:
+                v = np.where(_arr(g.rowmask1, M, np.uint8)[:, None] != 0, 0, v)
+        Tm = _bf16_round(v.astype(np.float32))
+        if g.t_out:
+            _wr(int(g.t_out), Tm, True)
+        W2 = _unfrag(g.w2, N, F)
+        y = Tm @ W2.T
+        if g.bias2:
+            y = y + _arr(g.bias2, N)[None, :]
+        if g.drop2_p > 0:
+            y = y * dropout_scale(g.drop2_p, g.drop2_seed + soff, rows[:, None] * N + np.arange(N, dtype=np.int64)[None, :])
+        if g.res:
+            y = y + _rd2d(g.res, M, N, g.ldr, False)
+        if g.rowmask2:
+            y = np.where(_arr(g.rowmask2, M, np.uint8)[:, None] != 0, 0, y)
+        y = y.astype(np.float32)
+        esz = 2 if g.y_bf16 else 4
+        for i in range(M):
+            _wr(int(g.y) + i * g.ldy * esz, y[i], bool(g.y_bf16))
         return 0
 
     def kantts_bgemm_tn(self, args_ref, stream):

@@ -196,3 +196,41 @@ def test_deferred_grouped_weight_gradients_equal_immediate_ones(bf16_mode):
     assert grads[0].keys() == grads[1].keys()
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+@pytest.mark.parametrize("k1,F,B,T", [(1, 1024, 3, 37), (3, 1024, 2, 50), (5, 1024, 2, 33)])
+def test_ffn_pair_equals_the_two_launch_form(bf16_mode, k1, F, B, T):
+    """csrc/ffn_pair.hip behind ops.ffn: one launch for both feed-forward contractions (forward; backward for k = 1 with
+    the transposed weight images) must give what the two-launch form gives -- same dropout masks, same bf16 rounding of
+    the hidden tensor; outputs and every gradient agree to accumulation-order noise."""
+    import itertools
+
+    from kantts._hip import ops, ops_bf16
+
+    g = torch.Generator().manual_seed(11 + k1)
+    C = 128
+    lens = torch.tensor([T, max(1, T - 9), 1][:B])
+    pr = torch.arange(T)[None, :] >= lens[:, None]
+    x = torch.randn(B, T, C, generator=g)
+    w1 = torch.randn(F, C, k1, generator=g) * 0.05
+    b1 = torch.randn(F, generator=g)
+    w2 = torch.randn(C, F, 1, generator=g) * 0.03
+    b2 = torch.randn(C, generator=g)
+    cot = torch.randn(B, T, C, generator=g)
+    res = {}
+    with emulation():
+        for on in (True, False):
+            ops_bf16.PAIR["on"] = on
+            ops._seed_counter = itertools.count(500)
+            try:
+                leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+                h = ops.layer_norm(leaves[0], torch.ones(C), torch.zeros(C), 1e-6, out_bf16=True)
+                y = ops.ffn(h, leaves[1], leaves[2], leaves[3], leaves[4], leaves[0], pad_rows=pr, zero_rows=pr,
+                            p_inner=0.1, p_out=0.1)
+                grads = torch.autograd.grad((y * cot).sum(), leaves)
+            finally:
+                ops_bf16.PAIR["on"] = True
+            res[on] = [y.detach()] + [q.detach() for q in grads]
+    for a, b in zip(res[True], res[False]):
+        assert a.shape == b.shape
+        assert rel_l2(a, b) < 1e-5, rel_l2(a, b)

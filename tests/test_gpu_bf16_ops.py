@@ -126,6 +126,59 @@ def test_conv_mode_and_fused_ffn(k1):
     _cmp(*run_both(_seeded(block), x, gam, bet, w1, b1, w2, b2, pad_rows), otol=2e-3, gtol=5e-3)
 
 
+@pytest.mark.parametrize("M,T,F,KT", [(6528, 204, 1024, 1), (2048, 64, 1024, 3), (111, 37, 1024, 1), (95, 19, 1024, 3),
+                                      (32, 32, 1024, 5), (19584, 612, 1024, 1)])
+def test_ffn_pair_kernel_forward_and_backward_forms(M, T, F, KT):
+    """kantts_ffn_pair called directly (it must ACCEPT these shapes: the bench sizes, ragged M, taps at sequence borders,
+    M not a multiple of 32): forward form (bias, ReLU, both dropouts, both row masks, residual, bf16 hidden written) and, for KT = 1, the
+    backward form (fp32 dy with regenerated dropout, gate by the hidden tensor, transposed weights, bf16 and fp32 dh)."""
+    import kantts._hip as hip
+    from kantts._hip.ops_bf16 import frag_major
+
+    g = torch.Generator().manual_seed(M + F + KT)
+    bf = torch.bfloat16
+    x = torch.randn(M, 128, generator=g).to(bf)
+    w1m = torch.randn(KT, F, 128, generator=g) * 0.08
+    w2m = torch.randn(128, F, generator=g) * 0.03
+    b1, b2 = torch.randn(F, generator=g) * 0.3, torch.randn(128, generator=g)
+    res = torch.randn(M, 128, generator=g)
+    rm = (torch.rand(M, generator=g) < 0.15)
+    dy = torch.randn(M, 128, generator=g)
+
+    img = frag_major                               # fragment-major bf16 image built with tensor ops + the cast kernel
+
+    w1, w2 = w1m.reshape(KT * F, 128), w2m
+    w2t, w1t = w2m.t().contiguous(), w1m[0].t().contiguous()   # (F, 128), (128, F)
+
+    def fwd(x_, w1_, w2_, b1_, b2_, res_, rm_):
+        hid = torch.zeros(M, F, dtype=bf, device=x_.device)
+        y = torch.zeros(M, 128, device=x_.device)
+        assert hip.ffn_pair(x_, img(w1_), img(w2_), y, M=M, T=T, F=F, KT=KT, pad=(KT - 1) // 2, bias1=b1_, bias2=b2_, relu=True,
+                            drop1_p=0.1, drop1_seed=77, drop2_p=0.2, drop2_seed=78, rowmask1=rm_, rowmask2=rm_,
+                            t_out=hid, res=res_)
+        return y, hid
+
+    go, _, co, _ = run_both(fwd, x, w1, w2, b1, b2, res, rm)
+    assert rel_l2(go[0], co[0]) < 1e-4, rel_l2(go[0], co[0])
+    assert rel_l2(go[1].float(), co[1].float()) < 2e-3           # bf16 hidden: an ulp on a few elements
+    assert (go[1] != co[1]).float().mean() < 0.02
+    if KT != 1:
+        return
+    hid = co[1]
+
+    def bwd(dy_, w2t_, w1t_, hid_, fp32_out):
+        dz = torch.zeros(M, F, dtype=bf, device=dy_.device)
+        dh = torch.zeros(M, 128, dtype=torch.float32 if fp32_out else bf, device=dy_.device)
+        assert hip.ffn_pair(dy_, img(w2t_), img(w1t_), dh, M=M, T=T, F=F, alpha1=1.0 / 0.9, xdrop_p=0.2, xdrop_seed=78, gate=hid_,
+                            t_out=dz)
+        return dh, dz
+
+    for fp32_out in (False, True):
+        go, _, co, _ = run_both(lambda *a: bwd(*a, fp32_out), dy, w2t, w1t, hid)
+        assert rel_l2(go[0].float(), co[0].float()) < (1e-4 if fp32_out else 3e-3)
+        assert rel_l2(go[1].float(), co[1].float()) < 2e-3
+
+
 @pytest.mark.parametrize("M", [6528, 100, 16, 5])
 def test_layer_norm128(M):
     from kantts._hip import ops
@@ -176,3 +229,48 @@ def test_arena_shadow_matches_master_and_follows_updates():
     o.step()
     net(**batch)  # the pre-hook refreshes the shadow from the updated master
     check_all()
+
+
+def test_arena_fragment_major_images_follow_the_master():
+    """The feed-forward weights of full-size blocks (128 <-> 1024) get fragment-major images in the arena
+    (kantts_fragmajor_bf16, one launch for the whole table): they must equal the images built from the parameter with
+    tensor ops, for k = 1 (forward + transposed images) and k = 3 (forward image, one per tap), and follow an update."""
+    import torch.nn as nn
+
+    from kantts._hip.ops_bf16 import ffn_frag_weights, frag_major
+    from kantts.models.sambert import PositionwiseConvFeedForward
+    from kantts.train.optim import ParamArena
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = PositionwiseConvFeedForward(128, 1024, (1, 1))
+            self.b = PositionwiseConvFeedForward(128, 1024, (3, 1))
+            self.c = PositionwiseConvFeedForward(64, 256, (3, 1))     # unsupported shape: no images
+
+        def forward(self, x):
+            return x
+
+    torch.manual_seed(3)
+    net = Net().cuda()
+    arena = ParamArena(net, bf16_shadow=True)
+
+    def check():
+        for blk, kt in ((net.a, 1), (net.b, 3)):
+            w1, w2 = blk.w_1.weight, blk.w_2.weight
+            f1, f2, t2, t1 = ffn_frag_weights(w1, w2)
+            assert f1 is w1._kantts_frag and f2 is w2._kantts_frag
+            assert torch.equal(f1, frag_major(w1.detach().permute(2, 0, 1).reshape(kt * 1024, 128)))
+            assert torch.equal(f2, frag_major(w2.detach().reshape(128, 1024)))
+            assert torch.equal(t2, frag_major(w2.detach().reshape(128, 1024).t()))
+            if kt == 1:
+                assert torch.equal(t1, frag_major(w1.detach().reshape(1024, 128).t()))
+            else:
+                assert t1 is None
+        assert not hasattr(net.c.w_1.weight, "_kantts_frag")
+
+    check()
+    with torch.no_grad():
+        arena.flat.mul_(1.5).add_(0.01)
+    net(torch.zeros(1, device="cuda"))  # forward pre-hook: refresh
+    check()
