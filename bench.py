@@ -34,9 +34,12 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
-# mean over the FFN contractions profiled in profiles/r01_gemm_ffn_pmc_v2.txt (34.7 / 35.1 MB vs 30.6 MB algorithmic)
-MEASURED_TRAFFIC_BYTES = {"bf16": None, "fp32": 34.9e6}
-MEASURED_TRAFFIC_SOURCE = {"bf16": None, "fp32": "profiles/r01_gemm_ffn_pmc_v2.txt (round-1 fp32-storage kernel)"}
+# memory-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of scripts/ffn_pmc_probe.py):
+# bf16: mean of the four launches of a feed-forward block (ffn_pair forward 26.4, backward 36.2, weight gradients
+# 47.3 / 33.8 MB against 22.2 / 32.3 / 17.2 / 15.6 MB algorithmic); fp32: the round-1 fp32-storage kernel
+MEASURED_TRAFFIC_BYTES = {"bf16": 35.9e6, "fp32": 34.9e6}
+MEASURED_TRAFFIC_SOURCE = {"bf16": "profiles/r02_runM_ffn_pair_pmc.txt",
+                           "fp32": "profiles/r01_gemm_ffn_pmc_v2.txt (round-1 fp32-storage kernel)"}
 
 
 def sambert_yaml_config(cfg):
@@ -182,23 +185,44 @@ def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
         yh, dz = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, F, device=dev, dtype=bf)
         yx, dh = torch.empty(M, C, device=dev), torch.empty(M, C, device=dev, dtype=bf)
         dw1, dw2 = torch.zeros(F, C, device=dev), torch.zeros(C, F, device=dev)
+        from kantts._hip import ffn_pair
+        from kantts._hip.ops_bf16 import frag_major
+
+        f1, f2 = frag_major(w1b.float()), frag_major(w2b.float())              # (F, C), (C, F) images: forward
+        t2, t1 = frag_major(w2b.float().t().contiguous()), frag_major(w1b.float().t().contiguous())  # backward
+
+        def pair_fwd():
+            assert ffn_pair(xb, f1, f2, yx, M=M, T=204, F=F, bias1=b1, bias2=b2, relu=True, t_out=yh, res=res)
+
+        def pair_bwd():
+            assert ffn_pair(dy, t2, t1, dh, M=M, T=204, F=F, gate=hb, t_out=dz)
+
+        wbytes = 2 * 2 * C * F
         cases = {
-            "fwd 128->1024 (bf16 -> bf16, bias+relu)": (
-                lambda: bgemm_nt([(xb, C, w1b, C, C, 0)], M, F, yh, F, bias=b1, relu=True), 2 * M * C + 2 * C * F + 2 * M * F),
-            "fwd 1024->128 (bf16 -> fp32, bias+residual)": (
-                lambda: bgemm_nt([(hb, F, w2b, F, F, 0)], M, C, yx, C, bias=b2, res=res, ldr=C),
-                2 * M * F + 2 * C * F + 8 * M * C),
-            "dgrad 1024<-128 (fp32 dy, gate by hidden -> bf16)": (
-                lambda: bgemm_nt([(dy, C, w2b, F, C, 0)], M, F, dz, F, b_kn=True, gate=hb, ldg=F),
-                4 * M * C + 2 * C * F + 4 * M * F),
-            "dgrad 128<-1024 (bf16 -> bf16)": (
-                lambda: bgemm_nt([(dz, F, w1b, C, F, 0)], M, C, dh, C, b_kn=True), 2 * M * F + 2 * C * F + 2 * M * C),
+            # one launch: x (bf16) -> hidden (bf16, written for the weight gradients) -> out (fp32) + residual (fp32)
+            "ffn_pair forward (LN-out bf16 -> hidden bf16 + out fp32; bias, ReLU, residual)": (
+                pair_fwd, 2 * M * C + wbytes + 2 * M * F + 8 * M * C),
+            # one launch: dy (fp32), gate = hidden (bf16) -> dz (bf16, written for dW1) -> dh (bf16)
+            "ffn_pair input gradients (dy fp32, gate by hidden -> dz bf16 -> dh bf16)": (
+                pair_bwd, 4 * M * C + 2 * M * F + wbytes + 2 * M * F + 2 * M * C),
             "wgrad 128x1024 (fp32 dy x bf16 hidden)": (
                 lambda: bgemm_tn(dy, C, hb, F, M, C, F, dw2, F, 1), 4 * M * C + 2 * M * F + 4 * C * F),
             "wgrad 1024x128 (bf16 dz x bf16 ln-out)": (
                 lambda: bgemm_tn(dz, F, xb, C, M, F, C, dw1, C, 1), 2 * M * F + 2 * M * C + 4 * C * F),
+            # the two-launch form of the same block (round 2 before csrc/ffn_pair.hip; still the fallback for other shapes)
+            "[two-launch form] fwd 128->1024 (bf16 -> bf16, bias+relu)": (
+                lambda: bgemm_nt([(xb, C, w1b, C, C, 0)], M, F, yh, F, bias=b1, relu=True), 2 * M * C + 2 * C * F + 2 * M * F),
+            "[two-launch form] fwd 1024->128 (bf16 -> fp32, bias+residual)": (
+                lambda: bgemm_nt([(hb, F, w2b, F, F, 0)], M, C, yx, C, bias=b2, res=res, ldr=C),
+                2 * M * F + 2 * C * F + 8 * M * C),
+            "[two-launch form] dgrad 1024<-128 (fp32 dy, gate by hidden -> bf16)": (
+                lambda: bgemm_nt([(dy, C, w2b, F, C, 0)], M, F, dz, F, b_kn=True, gate=hb, ldg=F),
+                4 * M * C + 2 * C * F + 4 * M * F),
+            "[two-launch form] dgrad 128<-1024 (bf16 -> bf16)": (
+                lambda: bgemm_nt([(dz, F, w1b, C, F, 0)], M, C, dh, C, b_kn=True), 2 * M * F + 2 * C * F + 2 * M * C),
         }
-        kernel, bytes_dtype = "bgemm_nt_kernel / bgemm_tn_kernel (csrc/gemm_bf16.hip)", "bf16 activations + weights, fp32 residual stream"
+        kernel, bytes_dtype = ("ffn_pair_kernel (csrc/ffn_pair.hip) + bgemm_tn_kernel (csrc/gemm_bf16.hip)",
+                               "bf16 activations + weights, fp32 residual stream")
     else:
         p = hip.PREC_FP32
         x, h = torch.randn(M, C, device=dev), torch.randn(M, F, device=dev)
@@ -218,7 +242,7 @@ def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
         }
         kernel, bytes_dtype = "gemm_fast_kernel<fp32> (csrc/gemm_fast.hip)", "fp32"
     per, per_gbps = {}, {}
-    tot_us, tot_bytes = 0.0, 0.0
+    tot_us, tot_bytes, n_live = 0.0, 0.0, 0
     for name, (fn, nbytes) in cases.items():
         fn()
         torch.cuda.synchronize()
@@ -237,11 +261,15 @@ def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
         us = e0.elapsed_time(e1) * 1e3 / (reps * replays)
         per[name] = round(us, 2)
         per_gbps[name] = round(nbytes / us / 1e3, 1)
-        tot_us += us
-        tot_bytes += nbytes
-    return {"tflops": flops * len(cases) / (tot_us * 1e-6) / 1e12, "launch_us": per, "launch_gbps": per_gbps,
-            "flops_per_launch": flops, "gbps": tot_bytes / (tot_us * 1e-6) / 1e9, "bytes_per_launch": tot_bytes / len(cases),
-            "mean_launch_us": tot_us / len(cases), "kernel": kernel, "bytes_dtype": bytes_dtype}
+        if not name.startswith("["):  # the launches the step actually issues
+            tot_us += us
+            tot_bytes += nbytes
+            n_live += 1
+    # the block's contraction flops: forward 2, input gradients 2, weight gradients 2 products of 2*M*C*F each
+    return {"tflops": flops * 6 / (tot_us * 1e-6) / 1e12, "launch_us": per, "launch_gbps": per_gbps,
+            "flops_per_launch": flops * 6 / n_live, "gbps": tot_bytes / (tot_us * 1e-6) / 1e9,
+            "bytes_per_launch": tot_bytes / n_live, "mean_launch_us": tot_us / n_live, "kernel": kernel,
+            "bytes_dtype": bytes_dtype}
 
 
 def hifigan_v1_config(channels=512):

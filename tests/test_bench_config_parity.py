@@ -53,7 +53,9 @@ def sambert_b32_oracle():
 # measured on MI355X this round (gpurun_out/parity_at_bench_configs.json): see DESIGN.md section 2
 _SAMBERT_BOUNDS = {
     "fp32": dict(mel_mean=1e-5, mel_max=5e-4, loss=1e-4, grad_global=2e-3, grad_worst=2e-2),
-    "bf16": dict(mel_mean=4e-3, mel_max=5e-2, loss=2e-2, grad_global=6e-2, grad_worst=0.2),
+    # measured on the device with this round's final kernels (profiles/r02_runL_*; gpurun_out/parity_at_bench_configs.json):
+    # mel mean 1.44e-3, max 1.14e-2, loss 4.6e-5, gradient global 5.96e-3, worst tensor 0.117 (a 1-element bias)
+    "bf16": dict(mel_mean=3e-3, mel_max=2.5e-2, loss=5e-4, grad_global=1.2e-2, grad_worst=0.2),
 }
 
 
