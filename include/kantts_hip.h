@@ -504,7 +504,8 @@ int kantts_relu_gate_bf16(const void* dy, int dy_bf16, const void* y, int y_bf16
  * FRAGMENT-MAJOR layout of kantts_fragmajor_bf16 -- the backward pass hands in the transposed weights (w1 := W2^T as
  * (F, 128), w2 := W1^T as (128, F)).  t_out (optional): bf16 (M, F) row-major, the intermediate the weight gradients need.
  * Taps do not cross sequence boundaries: rows are B sequences of T tokens.  Dropout indices: m*F + f (drop1), m*128 + n
- * (drop2); seeds are offset by *seed_dev (graph replay).  F = 1024.  Returns KANTTS_E_UNSUPPORTED for other shapes: the
+ * (drop2); seeds are offset by *seed_dev (graph replay).  F = 1024.  KT2 = 3 (backward form only, M % T == 0): phase 2
+ * sums three taps of the intermediate, w2 = three (128, F) images -- the input gradient of a k = 3 first convolution.  Returns KANTTS_E_UNSUPPORTED for other shapes: the
  * caller falls back to two kantts_bgemm_nt launches. */
 typedef struct kantts_ffn_args {
   const void* x;
@@ -534,6 +535,7 @@ typedef struct kantts_ffn_args {
   void* y;
   int64_t ldy;
   int32_t y_bf16;
+  int32_t KT2, s2_first, s2_step; /* taps of phase 2 (0 / 1: none): y[m] = sum_t t[m + s2_first + t*s2_step] . w2[t]^T */
 } kantts_ffn_args;
 int kantts_ffn_pair(const kantts_ffn_args* args, void* stream);
 

@@ -52,13 +52,21 @@ __device__ __forceinline__ unsigned fp_pack2(float a, float b) {
 __device__ __forceinline__ float fp_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float fp_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <bool BWD>
+// KT2 = taps of PHASE 2 (the backward pass of a k = 3 first convolution: dh[m] = sum_tap dz[m + pad - tap] . W1[tap]):
+// the tile then covers 32 rows of the intermediate of which the inner 32 - (KT2 - 1) are output rows -- the halo rows are
+// recomputed by the neighbouring workgroup (6 % more phase-1 work instead of a second launch that re-reads dz).
+template <bool BWD, int KT2>
 __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_args g) {
   __shared__ __attribute__((aligned(16))) __bf16 Xs[FP_XROWS * FP_XP];
   __shared__ __attribute__((aligned(16))) __bf16 Ts[FP_BM * FP_TP];
   __shared__ __attribute__((aligned(16))) float B1s[FP_F];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
-  const int m0 = blockIdx.x * FP_BM;
+  // phase-2 tap t reads tile row (output slot + HL + s2_first + t*s2_step)
+  constexpr int OUT = FP_BM - (KT2 - 1);
+  const int s2_lo = KT2 == 1 ? 0 : min(g.s2_first, g.s2_first + (KT2 - 1) * g.s2_step);
+  const int HL = KT2 == 1 ? 0 : -s2_lo;                 // halo rows in front of the first output row
+  const int mo0 = blockIdx.x * OUT;                     // first output row of this workgroup
+  const int m0 = mo0 - HL;                              // global row of tile row 0 (may be negative)
   const int M = g.M, KT = g.KT, pad = g.pad, T = g.T;
   constexpr int F = FP_F, TP = FP_TP;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
@@ -78,9 +86,10 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
   };
   auto load2 = [&](u32x4* w, int u) {
     const int nq = wave & 3, kh = wave >> 2;
+    const int tap = u >> 2, uu = u & 3;  // four units per tap and reduction half
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const __bf16* p = w2 + ((long long)(nq * 2 + a) * (F >> 5) + kh * 16 + u * 4) * 512 + lane * 8;
+      const __bf16* p = w2 + ((long long)(tap * (FP_N >> 4) + nq * 2 + a) * (F >> 5) + kh * 16 + uu * 4) * 512 + lane * 8;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) w[a * 4 + kk] = *reinterpret_cast<const u32x4*>(p + kk * 512);
     }
@@ -136,8 +145,8 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const long long m = (long long)m0 + b * 16 + li;
-    tpos[b] = (KT > 1 && T > 0) ? (int)(m % T) : 0;
-    rz1[b] = !BWD && g.rowmask1 && m < M && g.rowmask1[m] != 0;
+    tpos[b] = ((KT > 1 || KT2 > 1) && T > 0) ? (int)(((m % T) + T) % T) : 0;
+    rz1[b] = !BWD && g.rowmask1 && m >= 0 && m < M && g.rowmask1[m] != 0;
   }
 
   // wave-local coordinates of the T tile copy-out: the wave owns 32 columns (64 bytes) of a chunk: 4 lanes x 16 bytes
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int id = tid + FP_THREADS * it;
-      const long long row = min((long long)m0 + (id >> 7), (long long)M - 1);
+      const long long row = max(0ll, min((long long)m0 + (id >> 7), (long long)M - 1));
       gq[it] = *reinterpret_cast<const u32x4*>(gp + row * F + (id & 127) * 8);
     }
 #pragma unroll
@@ -237,7 +246,8 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
       for (int it = 0; it < 2; ++it) {
         const int i = crow + 16 * it;
         const u32x4 v = *reinterpret_cast<const u32x4*>(&Ts[i * TP + c * 256 + wave * 32 + ccol]);
-        if (m0 + i < M) *reinterpret_cast<u32x4*>(tp + ((long long)m0 + i) * F + c * 256 + wave * 32 + ccol) = v;
+        if (i >= HL && i < HL + OUT && m0 + i < M)  // rows this workgroup owns
+          *reinterpret_cast<u32x4*>(tp + ((long long)m0 + i) * F + c * 256 + wave * 32 + ccol) = v;
       }
     }
   };
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
   bool rz2[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
-    const long long m = min((long long)m0 + b * 16 + li, (long long)M - 1);
+    const long long m = min((long long)mo0 + b * 16 + li, (long long)M - 1);
     rv[b] = *reinterpret_cast<const float4*>(g.res ? g.res + m * g.ldr + n0 : dummy);
     if (!g.res) rv[b] = zero4;
     const uint8_t q = *(g.rowmask2 ? g.rowmask2 + m : reinterpret_cast<const uint8_t*>(dummy));
@@ -280,19 +290,38 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int tpo[2];  // position of the two OUTPUT tokens inside their sequences
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int b = 0; b < 2; ++b) tpo[b] = (KT2 > 1 && T > 0) ? (mo0 + b * 16 + li) % T : 0;
+  auto mfma2 = [&](const u32x4* w, int u) {
+    const int tap = u >> 2, uu = u & 3;
+    const int sh = KT2 == 1 ? 0 : g.s2_first + tap * g.s2_step;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 bf[2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-        bf[b] = *reinterpret_cast<const bf16x8*>(&Ts[(b * 16 + li) * TP + (kh * 16 + u * 4 + kk) * 32 + kg * 8]);
+      for (int b = 0; b < 2; ++b) {
+        const int row = min(b * 16 + li + HL + sh, FP_BM - 1);  // slots beyond OUT read a clamped row (never stored)
+        u32x4 v = *reinterpret_cast<const u32x4*>(&Ts[row * TP + (kh * 16 + uu * 4 + kk) * 32 + kg * 8]);
+        if (KT2 > 1) {
+          const int q = tpo[b] + sh;
+          if (q < 0 || q >= T) v = (u32x4){0u, 0u, 0u, 0u};
+        }
+        bf[b] = (bf16x8&)v;
+      }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)ring[u][a * 4 + kk], bf[b], acc2[a][b], 0, 0, 0);
+          acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)w[a * 4 + kk], bf[b], acc2[a][b], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int u0 = 0; u0 < 4 * KT2; u0 += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mfma2(ring[j], u0 + j);
+      if (u0 + 4 + j < 4 * KT2) load2(ring[j], u0 + 4 + j);
     }
   }
   // the two halves of the reduction meet through LDS (the T tile is dead): wave (nq, kh) finishes row block a = kh and
@@ -318,8 +347,8 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
   {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const long long m = (long long)m0 + b * 16 + li;
-      if (m >= M) continue;
+      const long long m = (long long)mo0 + b * 16 + li;
+      if (m >= M || b * 16 + li >= OUT) continue;
       float o[4] = {acc2[0][b][0] + bs2.x, acc2[0][b][1] + bs2.y, acc2[0][b][2] + bs2.z, acc2[0][b][3] + bs2.w};
       if (g.drop2_p > 0.f) {
         const uint64_t base = (uint64_t)m * (uint64_t)FP_N + (uint64_t)n0;
@@ -357,12 +386,17 @@ extern "C" int kantts_ffn_pair(const kantts_ffn_args* gp, void* stream) {
     return KANTTS_E_UNSUPPORTED;
   if (g.xdrop_p > 0.f && !g.x_f32) return KANTTS_E_UNSUPPORTED;
   if (g.gate && g.KT != 1) return KANTTS_E_UNSUPPORTED;
+  const int kt2 = g.KT2 < 1 ? 1 : g.KT2;
+  if (kt2 != 1 && kt2 != 3) return KANTTS_E_UNSUPPORTED;
+  if (kt2 == 3 && (!g.gate || g.T <= 0 || (g.s2_step != 1 && g.s2_step != -1) || g.M % g.T)) return KANTTS_E_UNSUPPORTED;
   if (g.M == 0) return KANTTS_OK;
-  const dim3 grid(kantts_cdiv(g.M, FP_BM));
-  if (g.gate)
-    hipLaunchKernelGGL(ffn_pair_kernel<true>, grid, dim3(FP_THREADS), 0, (hipStream_t)stream, g);
+  hipStream_t st = (hipStream_t)stream;
+  if (kt2 == 3)
+    hipLaunchKernelGGL((ffn_pair_kernel<true, 3>), dim3(kantts_cdiv(g.M, FP_BM - 2)), dim3(FP_THREADS), 0, st, g);
+  else if (g.gate)
+    hipLaunchKernelGGL((ffn_pair_kernel<true, 1>), dim3(kantts_cdiv(g.M, FP_BM)), dim3(FP_THREADS), 0, st, g);
   else
-    hipLaunchKernelGGL(ffn_pair_kernel<false>, grid, dim3(FP_THREADS), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((ffn_pair_kernel<false, 1>), dim3(kantts_cdiv(g.M, FP_BM)), dim3(FP_THREADS), 0, st, g);
   KANTTS_CHECK_LAUNCH();
 }
 

@@ -135,6 +135,7 @@ class FfnArgs(Structure):
         ("drop1_seed", c_uint64), ("drop2_seed", c_uint64), ("xdrop_seed", c_uint64), ("seed_dev", c_void_p),
         ("gate", c_void_p), ("rowmask1", c_void_p), ("rowmask2", c_void_p), ("xrowmask", c_void_p),
         ("t_out", c_void_p), ("res", c_void_p), ("ldr", c_int64), ("y", c_void_p), ("ldy", c_int64), ("y_bf16", c_int32),
+        ("KT2", c_int32), ("s2_first", c_int32), ("s2_step", c_int32),
     ]
 
 
@@ -433,10 +434,12 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
 
 def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu=False, alpha1=1.0, drop1_p=0.0,
              drop1_seed=0, drop2_p=0.0, drop2_seed=0, xdrop_p=0.0, xdrop_seed=0, gate=None, rowmask1=None, rowmask2=None,
-             xrowmask=None, t_out=None, res=None):
+             xrowmask=None, t_out=None, res=None, KT2=1, s2_first=0, s2_step=0):
     """Both contractions of a feed-forward block in one launch (csrc/ffn_pair.hip; kantts_ffn_pair in the header).
     x (M, 128) bf16 / fp32; w1 / w2: FRAGMENT-MAJOR bf16 images (ops_bf16.frag_major) of the (KT*F, 128) and (128, F)
-    weight matrices; y (M, 128) fp32 / bf16; t_out bf16 (M, F).  Returns False when the library declines the shape."""
+    weight matrices; y (M, 128) fp32 / bf16; t_out bf16 (M, F).  KT2 = 3 (backward form): phase 2 sums three taps of the
+    intermediate, y[m] = sum_t t[m + s2_first + t*s2_step] . w2[t]^T with w2 = three (128, F) images.  Returns False when
+    the library declines the shape."""
     g = FfnArgs()
     g.x, g.ldx, g.x_f32 = ptr(x), int(x.shape[-1]), int(x.dtype == torch.float32)
     g.M, g.T, g.K1, g.F, g.N, g.KT, g.pad = int(M), int(T), int(x.shape[-1]), int(F), int(y.shape[-1]), int(KT), int(pad)
@@ -451,6 +454,7 @@ def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu
     g.t_out = ptr(t_out, torch.bfloat16)
     g.res, g.ldr = ptr(res, torch.float32), int(y.shape[-1])
     g.y, g.ldy, g.y_bf16 = ptr(y), int(y.shape[-1]), int(y.dtype == torch.bfloat16)
+    g.KT2, g.s2_first, g.s2_step = int(KT2), int(s2_first), int(s2_step)
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -460,7 +464,7 @@ def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu
     check(rc, "ffn_pair")
     if _profile is not None:
         e1.record()
-        _profile.append((e0, e1, 2.0 * M * F * (x.shape[-1] * KT + y.shape[-1])))
+        _profile.append((e0, e1, 2.0 * M * F * (x.shape[-1] * KT + y.shape[-1] * KT2)))
     return True
 
 

@@ -72,7 +72,7 @@ def frag_major(mat):
 def ffn_frag_weights(w1, w2):
     """The four weight images of csrc/ffn_pair.hip for Conv1d weights w1 (F, C, KT), w2 (N, F, 1):
     (forward phase 1: rows tap*F + f, forward phase 2: (N, F), backward phase 1: W2^T (F, N), backward phase 2: W1^T
-    (C, F)); the backward pair only for KT = 1.  Arena parameters carry them as attributes (refreshed once per step by
+    (C, F) per tap: rows tap*C + c).  Arena parameters carry them as attributes (refreshed once per step by
     one launch); anything else is converted on demand and cached until the tensors change."""
     a = getattr(w1, "_kantts_frag", None)
     b = getattr(w2, "_kantts_frag", None)
@@ -88,8 +88,8 @@ def ffn_frag_weights(w1, w2):
     with torch.no_grad():
         f1 = frag_major(w1.detach().permute(2, 0, 1).reshape(KT * F, C))
         f2 = frag_major(w2.detach().reshape(N, F))
-        t2 = frag_major(w2.detach().reshape(N, F).t()) if KT == 1 else None
-        t1 = frag_major(w1.detach().reshape(F, C).t()) if KT == 1 else None
+        t2 = frag_major(w2.detach().reshape(N, F).t())
+        t1 = frag_major(w1.detach().permute(2, 1, 0).reshape(KT * C, F))
     if len(_wcache) > 4096:
         _wcache.clear()
     _wcache[key] = (sig, (f1, f2, t2, t1))
@@ -370,8 +370,10 @@ class _FusedFFNB(torch.autograd.Function):
         dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
         a1 = 1.0 / (1.0 - p_in) if p_in > 0 else 1.0
         # both input-gradient contractions in one launch (images of the TRANSPOSED weights)
-        fused = (cfg["pair"] and kt == 1 and wt1 is not None and wt2 is not None and
-                 ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid, t_out=dz))
+        # (k = 3: the three taps are summed in phase 2 from a tile of dz with one halo row either side)
+        fused = (cfg["pair"] and kt in (1, 3) and wt1 is not None and wt2 is not None and (kt == 1 or M % T == 0) and
+                 ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid, t_out=dz,
+                          KT2=kt, s2_first=pad, s2_step=-1))
         if not fused and not bgemm_nt([(dy, N, wb2, F, N, 0)], M, F, dz, F, b_kn=True, gate=hid, ldg=F, alpha=a1,
                                       a_drop_p=p_out, a_drop_seed=s2, a_drop_ld=N):
             raise RuntimeError("bgemm_nt declined the FFN hidden gradient")
@@ -407,5 +409,7 @@ def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p
     wf1 = wf2 = wt2 = wt1 = None
     if pair:
         wf1, wf2, wt2, wt1 = ffn_frag_weights(w1, w2)
+        if kt not in (1, 3):
+            wt2 = wt1 = None  # backward stays on the two-launch form
     return _FusedFFNB.apply(h, w1, b1, w2, b2, res, pad_rows, zero_rows, conv_weight_bf16(w1), conv_weight_bf16(w2), wf1,
                             wf2, wt2, wt1, cfg)

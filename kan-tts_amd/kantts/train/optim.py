@@ -72,8 +72,8 @@ class ParamArena:
             self._tap_blocks = max(self._tap_blocks, min(64, (n * cin * kt + 1023) // 1024))
         self._tap_table = torch.tensor(tab, dtype=torch.int64, device=dev) if tab else None
         # fragment-major images of the feed-forward weights (csrc/ffn_pair.hip; kantts_fragmajor_desc = src_off, dst_off,
-        # sr, sk (int64), R, K (int32)): forward images for every flagged pair of the supported shape, images of the
-        # transposed weights (the backward operands) when the first convolution has one tap
+        # sr, sk (int64), R, K (int32)): forward images for every flagged pair of the supported shape and images of the
+        # transposed weights (the backward operands), one per tap
         ftab, foff = [], 0
         self._frag_blocks = 1
 
@@ -92,8 +92,7 @@ class ParamArena:
             if role == "w1" and p.dim() == 3 and p.shape[0] == 1024 and p.shape[1] == 128 and p.shape[2] % 2 == 1:
                 F_, C_, KT_ = p.shape
                 views.append(image(p, o, F_, C_, C_ * KT_, KT_, "_kantts_frag", n_img=KT_))
-                if KT_ == 1:
-                    views.append(image(p, o, C_, F_, 1, C_, "_kantts_fragT"))
+                views.append(image(p, o, C_, F_, KT_, C_ * KT_, "_kantts_fragT", n_img=KT_))  # W1[tap]^T: rows tap*C + c
             elif role == "w2" and p.dim() == 3 and p.shape[0] == 128 and p.shape[1] == 1024 and p.shape[2] == 1:
                 N_, F_, _ = p.shape
                 views.append(image(p, o, N_, F_, F_, 1, "_kantts_frag"))

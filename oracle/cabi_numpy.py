@@ -366,8 +366,19 @@ class EmulatedLib:
         Tm = _bf16_round(v.astype(np.float32))
         if g.t_out:
             _wr(int(g.t_out), Tm, True)
-        W2 = _unfrag(g.w2, N, F)
-        y = Tm @ W2.T
+        kt2 = max(1, g.KT2)
+        if kt2 not in (1, 3) or (kt2 == 3 and (not g.gate or T <= 0 or M % T or g.s2_step not in (1, -1))):
+            return -2
+        y = np.zeros((M, N), dtype=np.float32)
+        for tap in range(kt2):
+            W2 = _unfrag(int(g.w2) + tap * N * F * 2, N, F)
+            if kt2 == 1:
+                y += Tm @ W2.T
+            else:
+                sh = g.s2_first + tap * g.s2_step
+                t = rows % T + sh
+                ok = (t >= 0) & (t < T)
+                y += (Tm[np.clip(rows + sh, 0, M - 1)] * ok[:, None]) @ W2.T
         if g.bias2:
             y = y + _arr(g.bias2, N)[None, :]
         if g.drop2_p > 0:

@@ -111,7 +111,9 @@ def test_sambert_full_b32_matches_oracle(sambert_b32_oracle, mode):
 
 _HIFI_BOUNDS = {
     "fp32": dict(wav_mean=1e-5, d_out=5e-5, grad=2e-3),
-    "bf16": dict(wav_mean=2e-2, d_out=5e-2, grad=0.15),
+    # measured (profiles/r02_runN_parity_at_bench_configs.json): wav mean 9.5e-4, discriminator outputs 1.2e-4 / 4.5e-5, gradients
+    # G 0.096 (deep chain of 12 residual blocks at random init), MPD 3.8e-3, MSD 1.2e-3
+    "bf16": dict(wav_mean=2e-3, d_out=3e-4, grad=0.15),
 }
 
 

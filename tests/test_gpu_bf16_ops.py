@@ -131,7 +131,8 @@ def test_conv_mode_and_fused_ffn(k1):
 def test_ffn_pair_kernel_forward_and_backward_forms(M, T, F, KT):
     """kantts_ffn_pair called directly (it must ACCEPT these shapes: the bench sizes, ragged M, taps at sequence borders,
     M not a multiple of 32): forward form (bias, ReLU, both dropouts, both row masks, residual, bf16 hidden written) and, for KT = 1, the
-    backward form (fp32 dy with regenerated dropout, gate by the hidden tensor, transposed weights, bf16 and fp32 dh)."""
+    backward form (fp32 dy with regenerated dropout, gate by the hidden tensor, transposed weights, bf16 and fp32 dh); for
+    KT = 3 the backward form sums the three taps in phase 2 (halo rows, sequence borders)."""
     import kantts._hip as hip
     from kantts._hip.ops_bf16 import frag_major
 
@@ -148,7 +149,7 @@ def test_ffn_pair_kernel_forward_and_backward_forms(M, T, F, KT):
     img = frag_major                               # fragment-major bf16 image built with tensor ops + the cast kernel
 
     w1, w2 = w1m.reshape(KT * F, 128), w2m
-    w2t, w1t = w2m.t().contiguous(), w1m[0].t().contiguous()   # (F, 128), (128, F)
+    w2t = w2m.t().contiguous()                                  # (F, 128)
 
     def fwd(x_, w1_, w2_, b1_, b2_, res_, rm_):
         hid = torch.zeros(M, F, dtype=bf, device=x_.device)
@@ -162,15 +163,17 @@ def test_ffn_pair_kernel_forward_and_backward_forms(M, T, F, KT):
     assert rel_l2(go[0], co[0]) < 1e-4, rel_l2(go[0], co[0])
     assert rel_l2(go[1].float(), co[1].float()) < 2e-3           # bf16 hidden: an ulp on a few elements
     assert (go[1] != co[1]).float().mean() < 0.02
-    if KT != 1:
+    if KT not in (1, 3) or M % T:
         return
     hid = co[1]
+    # W1[tap]^T stacked over taps: rows tap*128 + c
+    w1t = w1m.permute(0, 2, 1).reshape(KT * 128, F).contiguous()
 
     def bwd(dy_, w2t_, w1t_, hid_, fp32_out):
         dz = torch.zeros(M, F, dtype=bf, device=dy_.device)
         dh = torch.zeros(M, 128, dtype=torch.float32 if fp32_out else bf, device=dy_.device)
         assert hip.ffn_pair(dy_, img(w2t_), img(w1t_), dh, M=M, T=T, F=F, alpha1=1.0 / 0.9, xdrop_p=0.2, xdrop_seed=78, gate=hid_,
-                            t_out=dz)
+                            t_out=dz, KT2=KT, s2_first=(KT - 1) // 2, s2_step=-1)
         return dh, dz
 
     for fp32_out in (False, True):
@@ -234,7 +237,7 @@ def test_arena_shadow_matches_master_and_follows_updates():
 def test_arena_fragment_major_images_follow_the_master():
     """The feed-forward weights of full-size blocks (128 <-> 1024) get fragment-major images in the arena
     (kantts_fragmajor_bf16, one launch for the whole table): they must equal the images built from the parameter with
-    tensor ops, for k = 1 (forward + transposed images) and k = 3 (forward image, one per tap), and follow an update."""
+    tensor ops, for k = 1 and k = 3 (forward and transposed images, one per tap), and follow an update."""
     import torch.nn as nn
 
     from kantts._hip.ops_bf16 import ffn_frag_weights, frag_major
@@ -263,10 +266,7 @@ def test_arena_fragment_major_images_follow_the_master():
             assert torch.equal(f1, frag_major(w1.detach().permute(2, 0, 1).reshape(kt * 1024, 128)))
             assert torch.equal(f2, frag_major(w2.detach().reshape(128, 1024)))
             assert torch.equal(t2, frag_major(w2.detach().reshape(128, 1024).t()))
-            if kt == 1:
-                assert torch.equal(t1, frag_major(w1.detach().reshape(1024, 128).t()))
-            else:
-                assert t1 is None
+            assert torch.equal(t1, frag_major(w1.detach().permute(2, 1, 0).reshape(kt * 128, 1024)))
         assert not hasattr(net.c.w_1.weight, "_kantts_frag")
 
     check()
