@@ -117,13 +117,14 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(const AttnArgs a) {
   float l = 0.f;
   float* prow = a.probs ? a.probs + (((long long)h * a.B + b) * a.L + i) * a.L : nullptr;
   const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
+  KanttsDropSeq drop(a.drop_p, seed);  // consecutive keys share a 64-bit hash four at a time
   for (int j = lo; j <= hi; ++j) {
     float kk[DH], vv[DH];
     load16(kb + (long long)j * a.ldk, kk);
     load16(vb + (long long)j * a.ldv, vv);
     float e = expf(dot16(q, kk) * a.scale - m);
     l += e;
-    float ed = e * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+    float ed = e * drop.scale(rng_row + j);
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
   }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(const AttnArgs a) {
       if (j >= lo && j <= hi) {
         float kk[DH];
         load16(kb + (long long)j * a.ldk, kk);
-        p = expf(dot16(q, kk) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+        p = expf(dot16(q, kk) * a.scale - m) * inv * drop.scale(rng_row + j);
       }
       prow[j] = p;
     }
@@ -170,12 +171,13 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_kernel(const AttnArgs a) {
   const float* kb = a.k + (long long)b * a.L * a.ldk + h * DH;
   const float* vb = a.v + (long long)b * a.L * a.ldv + h * DH;
   const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
+  KanttsDropSeq drop(a.drop_p, seed);
   for (int j = lo; j <= hi; ++j) {
     float kk[DH], vv[DH];
     load16(kb + (long long)j * a.ldk, kk);
     load16(vb + (long long)j * a.ldv, vv);
     float p = expf(dot16(q, kk) * a.scale - lse);
-    float dp = dot16(go, vv) * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+    float dp = dot16(go, vv) * drop.scale(rng_row + j);
     float ds = p * (dp - D) * a.scale;
 #pragma unroll
     for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
@@ -288,10 +290,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs
     for (int j = lo; j <= hi; ++j) m = fmaxf(m, dot16(q, Ks + j * AT_LD) * a.scale);
     float l = 0.f;
     const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
+    KanttsDropSeq drop(a.drop_p, seed);
     for (int j = lo; j <= hi; ++j) {
       const float e = expf(dot16(q, Ks + j * AT_LD) * a.scale - m);
       l += e;
-      const float ed = e * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+      const float ed = e * drop.scale(rng_row + j);
       const float* vv = Vs + j * AT_LD;
 #pragma unroll
       for (int d = 0; d < DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs
       for (int j = 0; j < a.L; ++j) {
         float p = 0.f;
         if (j >= lo && j <= hi)
-          p = expf(dot16(q, Ks + j * AT_LD) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+          p = expf(dot16(q, Ks + j * AT_LD) * a.scale - m) * inv * drop.scale(rng_row + j);
         prow[j] = p;
       }
     }
@@ -340,10 +343,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_lds_kernel(const AttnA
 #pragma unroll
     for (int d = 0; d < DH; ++d) dq[d] = 0.f;
     const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
+    KanttsDropSeq drop(a.drop_p, seed);
     for (int j = lo; j <= hi; ++j) {
       const float* kk = Ks + j * AT_LD;
       const float p = expf(dot16(q, kk) * a.scale - lse);
-      const float dp = dot16(go, Vs + j * AT_LD) * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+      const float dp = dot16(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
       const float ds = p * (dp - D) * a.scale;
 #pragma unroll
       for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);

@@ -111,14 +111,11 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
           if (g.xdrop_p > 0.f) {
             const uint64_t base = (uint64_t)src * (uint64_t)FP_K1 + (uint64_t)(ch * 8);
             const uint64_t sd = g.xdrop_seed + seed_off;
-            a.x *= kantts_dropout_scale(g.xdrop_p, sd, base + 0);
-            a.y *= kantts_dropout_scale(g.xdrop_p, sd, base + 1);
-            a.z *= kantts_dropout_scale(g.xdrop_p, sd, base + 2);
-            a.w *= kantts_dropout_scale(g.xdrop_p, sd, base + 3);
-            b.x *= kantts_dropout_scale(g.xdrop_p, sd, base + 4);
-            b.y *= kantts_dropout_scale(g.xdrop_p, sd, base + 5);
-            b.z *= kantts_dropout_scale(g.xdrop_p, sd, base + 6);
-            b.w *= kantts_dropout_scale(g.xdrop_p, sd, base + 7);
+            float lo4[4] = {a.x, a.y, a.z, a.w}, hi4[4] = {b.x, b.y, b.z, b.w};
+            kantts_dropout_scale4(g.xdrop_p, sd, base, lo4);
+            kantts_dropout_scale4(g.xdrop_p, sd, base + 4, hi4);
+            a = make_float4(lo4[0], lo4[1], lo4[2], lo4[3]);
+            b = make_float4(hi4[0], hi4[1], hi4[2], hi4[3]);
           }
           v.x = fp_pack2(a.x, a.y);
           v.y = fp_pack2(a.z, a.w);
@@ -226,9 +223,8 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
             for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
           }
           if (g.drop1_p > 0.f) {
-            const uint64_t base = (uint64_t)m * (uint64_t)F + (uint64_t)f0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] *= kantts_dropout_scale(g.drop1_p, sd1, base + r);
+            const uint64_t base = (uint64_t)m * (uint64_t)F + (uint64_t)f0;  // f0 % 4 == 0: one hash
+            kantts_dropout_scale4(g.drop1_p, sd1, base, o);
           }
           if (rz1[b]) {
 #pragma unroll
@@ -352,8 +348,7 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
       float o[4] = {acc2[0][b][0] + bs2.x, acc2[0][b][1] + bs2.y, acc2[0][b][2] + bs2.z, acc2[0][b][3] + bs2.w};
       if (g.drop2_p > 0.f) {
         const uint64_t base = (uint64_t)m * (uint64_t)FP_N + (uint64_t)n0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] *= kantts_dropout_scale(g.drop2_p, sd2, base + r);
+        kantts_dropout_scale4(g.drop2_p, sd2, base, o);
       }
       o[0] += rv[b].x; o[1] += rv[b].y; o[2] += rv[b].z; o[3] += rv[b].w;
       if (rz2[b]) {

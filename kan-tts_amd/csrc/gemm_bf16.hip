@@ -56,15 +56,12 @@ __device__ __forceinline__ u32x4 bg_load8(const void* base, long long elem, bool
   if (F32) {
     const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
     float4 a = p[0], b = p[1];
-    if (drop_p > 0.f) {
-      a.x *= kantts_dropout_scale(drop_p, seed, logical + 0);
-      a.y *= kantts_dropout_scale(drop_p, seed, logical + 1);
-      a.z *= kantts_dropout_scale(drop_p, seed, logical + 2);
-      a.w *= kantts_dropout_scale(drop_p, seed, logical + 3);
-      b.x *= kantts_dropout_scale(drop_p, seed, logical + 4);
-      b.y *= kantts_dropout_scale(drop_p, seed, logical + 5);
-      b.z *= kantts_dropout_scale(drop_p, seed, logical + 6);
-      b.w *= kantts_dropout_scale(drop_p, seed, logical + 7);
+    if (drop_p > 0.f) {  // logical % 8 == 0 (8-element granularity of every extent)
+      float lo4[4] = {a.x, a.y, a.z, a.w}, hi4[4] = {b.x, b.y, b.z, b.w};
+      kantts_dropout_scale4(drop_p, seed, logical, lo4);
+      kantts_dropout_scale4(drop_p, seed, logical + 4, hi4);
+      a = make_float4(lo4[0], lo4[1], lo4[2], lo4[3]);
+      b = make_float4(hi4[0], hi4[1], hi4[2], hi4[3]);
     }
     r.x = bg_pack2(a.x, a.y);
     r.y = bg_pack2(a.z, a.w);
@@ -300,9 +297,9 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
       o[e] = val;
     }
     if (g.drop_p > 0.f) {
-      const uint64_t base = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] *= kantts_dropout_scale(g.drop_p, g.drop_seed + seed_off, base + e);
+      const uint64_t base = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;  // N % 8 == 0, j % 8 == 0
+      kantts_dropout_scale4(g.drop_p, g.drop_seed + seed_off, base, o);
+      kantts_dropout_scale4(g.drop_p, g.drop_seed + seed_off, base + 4, o + 4);
     }
     if (g.res) {
       const float* rp = g.res + (long long)i * g.ldr + j;

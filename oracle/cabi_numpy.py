@@ -40,21 +40,22 @@ def _gather(ptr, offs, valid, dtype=np.float32):
     return out
 
 
-def rng_u32(seed, idx):
-    """numpy twin of kantts_rng_u32 (csrc/common.h)."""
+def rng_u16(seed, idx):
+    """numpy twin of the dropout RNG (csrc/common.h): element idx takes 16 bits of one 64-bit hash per four elements."""
+    idx = idx.astype(U64)
     with np.errstate(over="ignore"):
-        z = U64(seed & 0xFFFFFFFFFFFFFFFF) + idx.astype(U64) * U64(0x9E3779B97F4A7C15)
+        z = U64(seed & 0xFFFFFFFFFFFFFFFF) + (idx >> U64(2)) * U64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> U64(30))) * U64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> U64(27))) * U64(0x94D049BB133111EB)
         z = z ^ (z >> U64(31))
-    return (z >> U64(32)).astype(np.uint32)
+    return ((z >> ((idx & U64(3)) * U64(16))) & U64(0xFFFF)).astype(np.uint32)
 
 
 def dropout_scale(p, seed, idx):
     if p <= 0:
         return np.ones(idx.shape, dtype=np.float32)
-    thr = np.uint32(min(np.float32(p) * np.float32(4294967296.0), np.float32(4294967295.0)))
-    r = rng_u32(seed, idx)
+    thr = np.uint32(min(np.float32(p) * np.float32(65536.0), np.float32(65535.0)))
+    r = rng_u16(seed, idx)
     return np.where(r < thr, np.float32(0), np.float32(1.0) / (np.float32(1.0) - np.float32(p))).astype(np.float32)
 
 

@@ -160,9 +160,12 @@ from kantts.utils.ling_unit.ling_unit import KanTtsLinguisticUnit
 import kantts.utils.ling_unit.ling_unit as lu
 assert lu.__file__.startswith('/root/reference/'), lu.__file__
 assert at.__file__.startswith(%r) and ds.__file__.startswith(%r)
+import kantts.models.pqmf as pq, kantts.models.hifigan.hifigan as hg, kantts.train.loss as lo
+for m in (pq, hg, lo):                                     # every module under models / train is this package's own
+    assert m.__file__.startswith(%r), m.__file__
 try:
-    import kantts.models.pqmf
-    raise SystemExit('models fell back to the reference')
+    import kantts.models.not_shipped_anywhere
+    raise SystemExit('the overlay serves kantts.models')
 except ImportError:
     pass
 try:
@@ -171,7 +174,7 @@ try:
 except ImportError as e:                                   # librosa etc. are not installed in this container
     print('reference dataset import needs', e)
 print('overlay ok')
-""" % (os.path.join(ROOT, "kan-tts_amd"), os.path.join(ROOT, "kan-tts_amd"))
+""" % ((os.path.join(ROOT, "kan-tts_amd"),) * 3)
     env = dict(os.environ, KANTTS_REFERENCE_ROOT="/root/reference", PYTHONPATH=os.path.join(ROOT, "kan-tts_amd"))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "overlay ok" in out.stdout, out.stdout + out.stderr
