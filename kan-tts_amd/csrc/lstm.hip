@@ -5,9 +5,10 @@
 //   kantts/models/sambert/kantts_sambert.py:637-646 (postnet LSTM over T_mel frames).
 // The input projection x @ W_ih^T + b_ih for all t is hoisted into one segmented GEMM (MFMA); this
 // kernel only runs the sequential part.  One workgroup (512 threads = 8 waves) owns one
-// (sequence, direction): thread r keeps row r of W_hh (128 floats) in VGPRs for the whole
-// sequence, h_{t-1} lives in LDS and is read as wave-uniform (broadcast) float4s, so a step costs
-// 128 FMAs per lane + two workgroup barriers and no HBM traffic besides gx[t] in / h[t] out.
+// (sequence, direction): a quad of lanes owns a cell and keeps its 4 x 128 recurrent weights in VGPRs
+// (128 per lane) for the whole sequence, h_{t-1} lives in LDS (double-buffered), so a step costs
+// 128 multiply-adds per lane, a few DPP moves and ONE workgroup barrier, and no HBM traffic besides
+// gx[t] in / h[t] out.
 // pack_padded_sequence semantics come from per-sequence lengths: a row only runs t < len (the
 // reverse direction starts at len-1) and writes zeros to the padded tail.
 //
@@ -18,6 +19,20 @@
 #define LG 512
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Activations of the recurrence.  All four lanes of a quad evaluate the cell update, so the step is VALU-bound (8 waves
+// on 4 SIMDs): libm's tanhf (~40 instructions, and a divergent branch beside the sigmoid) made the quad layout SLOWER
+// than the two-barrier one (fwd 135 -> 149 us, bwd 147 -> 228 us per call, profiles/r02_runQ_*).  tanh(x) = 2 s(2x) - 1
+// shares the sigmoid's code; FAST (bf16 mode) uses v_exp_f32 / v_rcp_f32 directly (1-2 ulp), the fp32 mode keeps libm's
+// expf and an IEEE division (absolute error ~1e-7 from the final subtraction, far inside the parity tolerance).
+template <bool FAST>
+__device__ __forceinline__ float lstm_sigmoid(float x) {
+  if (FAST) return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+  return 1.f / (1.f + expf(-x));
+}
+template <bool FAST>
+__device__ __forceinline__ float lstm_tanh(float x) {
+  return fmaf(2.f, lstm_sigmoid<FAST>(2.f * x), -1.f);
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. it waits
 // until the step's global STORES (saved gates / cell state / outputs: pure outputs, never re-read by this kernel) have
@@ -32,59 +47,74 @@ union LstmPack4 {
   lstm_bf16x2 p[4];
 };
 
-// BF16 = true (throughput mode): the recurrent product h_{t-1} . W_hh[r] runs on packed bf16 pairs with fp32
-// accumulation (v_dot2c_f32_bf16): 64 instead of 128 multiply-add instructions and 16 instead of 32 LDS reads per
-// step and lane -- the two things the sequential loop is made of.  Gates, cell state and outputs stay fp32.
+// ---- quad helpers: the four lanes 4j .. 4j+3 of a wave own cell j (one lane per reduction quarter / gate)
+__device__ __forceinline__ float lstm_dpp_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float lstm_dpp_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+}
+template <int N>
+__device__ __forceinline__ float lstm_quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), N * 0x55, 0xF, 0xF, false));  // quad_perm [N,N,N,N]
+}
+
+// Forward.  Round 1 / early round 2: thread r owned gate row r (128-long dot product), the 512 activations met in LDS,
+// 128 threads then updated the cells, h went back through LDS: two workgroup barriers and two LDS round trips on the
+// chain of every step (0.73 us per step measured, against ~0.2 us of dot products).  Now the QUAD of lanes 4j..4j+3 owns
+// cell j: lane kq holds columns [32 kq, 32 kq + 32) of the four gate rows of its cell (the same 128 weights per lane),
+// the four partial sums of each gate are combined by a DPP reduce-scatter (lane kq ends up with gate kq), each lane
+// applies ITS gate's activation, the activations are quad-broadcast, and all four lanes update c and h redundantly:
+// no LDS exchange of gates, h double-buffered in LDS, ONE barrier per step.
+// BF16 = true (throughput mode): packed bf16 pairs with fp32 accumulation (v_dot2_f32_bf16); gates, cell state and
+// outputs stay fp32.
 template <bool BF16>
 __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
                                                       const float* __restrict__ bhh, const int32_t* __restrict__ lens,
                                                       float* __restrict__ out, float* __restrict__ gates_out,
                                                       float* __restrict__ c_out, int B, int T, int ndir,
                                                       int reverse_first) {
-  __shared__ __attribute__((aligned(16))) float h_s[LH];
-  __shared__ __attribute__((aligned(16))) __bf16 h_b[LH];
-  __shared__ float g_s[LG];
-  const int r = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float h_s[2][LH];
+  __shared__ __attribute__((aligned(16))) __bf16 h_b[2][LH];
+  const int tid = threadIdx.x, j = tid >> 2, kq = tid & 3;
   const int b = blockIdx.x, dir = blockIdx.y;
   const bool rev = reverse_first ? true : (dir == 1);
   const int len = lens ? min(lens[b], T) : T;
-  float w[BF16 ? 1 : LH];
-  lstm_bf16x2 wq[BF16 ? LH / 2 : 1];
-  {
-    const float4* wp = reinterpret_cast<const float4*>(whh + ((long long)dir * LG + r) * LH);
+  float w[BF16 ? 1 : 4 * 32];
+  lstm_bf16x2 wq[BF16 ? 4 * 16 : 1];
 #pragma unroll
-    for (int k = 0; k < LH / 4; ++k) {
-      float4 t = wp[k];
+  for (int g = 0; g < 4; ++g) {
+    const float4* wp = reinterpret_cast<const float4*>(whh + ((long long)dir * LG + g * LH + j) * LH + kq * 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float4 t = wp[k];
       if (BF16) {
-        wq[2 * k] = (lstm_bf16x2){(__bf16)t.x, (__bf16)t.y};
-        wq[2 * k + 1] = (lstm_bf16x2){(__bf16)t.z, (__bf16)t.w};
+        wq[g * 16 + 2 * k] = (lstm_bf16x2){(__bf16)t.x, (__bf16)t.y};
+        wq[g * 16 + 2 * k + 1] = (lstm_bf16x2){(__bf16)t.z, (__bf16)t.w};
       } else {
-        w[4 * k] = t.x;
-        w[4 * k + 1] = t.y;
-        w[4 * k + 2] = t.z;
-        w[4 * k + 3] = t.w;
+        w[g * 32 + 4 * k] = t.x;
+        w[g * 32 + 4 * k + 1] = t.y;
+        w[g * 32 + 4 * k + 2] = t.z;
+        w[g * 32 + 4 * k + 3] = t.w;
       }
     }
   }
-  const float bias = bhh ? bhh[dir * LG + r] : 0.f;
-  if (r < LH) {
-    h_s[r] = 0.f;
-    h_b[r] = (__bf16)0.f;
+  // lane kq brings in gx + bias of gate kq
+  const float bias = bhh ? bhh[dir * LG + kq * LH + j] : 0.f;
+  if (kq == 0) {
+    h_s[0][j] = 0.f;
+    h_b[0][j] = (__bf16)0.f;
   }
   float c = 0.f;
   const long long gx_ld = (long long)ndir * LG;
-  const float* gxb = gx + (long long)b * T * gx_ld + dir * LG + r;
+  const float* gxb = gx + (long long)b * T * gx_ld + dir * LG + kq * LH + j;
   float* outb = out + (long long)b * T * ndir * LH + dir * LH;
-  float* gob = gates_out + (((long long)dir * B + b) * T) * LG;
+  float* gob = gates_out + (((long long)dir * B + b) * T) * LG + kq * LH + j;
   float* cob = c_out + (((long long)dir * B + b) * T) * LH;
   __syncthreads();
-  // The step is a chain of dependent LDS / ALU latencies (~0.3 us); the input projection gx[t] comes from L2 / HBM
-  // (0.5-2 us).  Round 1 loaded it one step ahead inside an `if`: hipcc waits for a load issued in a conditional block
-  // where the branch re-joins (s_waitcnt vmcnt(0)), so every step paid the full load latency (0.78 us per step over the
-  // 612-step postnet sequence).  A register ring with the loads interleaved into the steps fared no better: the vector
-  // memory counter retires in order and the loop back-edge makes the compiler's count conservative (vmcnt(1)).  What
-  // works is CHUNKS: the gx values of the next LSTM_CH steps are loaded -- unconditionally, steps clamped into the
-  // sequence -- at the top of a chunk and first touched a whole chunk later.
+  // gx[t] comes from L2 / HBM (0.5-2 us) while a step is ~0.4 us: the values of the next chunk of steps are loaded --
+  // unconditionally, steps clamped into the sequence -- at the top of a chunk and first touched a whole chunk later
+  // (a load inside an `if`, or a ring interleaved with the steps, puts a vmcnt(0) / vmcnt(1) wait on every step).
   constexpr int PF = 8;
   float gq[PF], gn[PF];
   const int last = len > 0 ? len - 1 : 0;
@@ -93,6 +123,7 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
     const int su = min(u, last);
     gq[u] = gxb[(long long)(rev ? last - su : su) * gx_ld];
   }
+  int cur = 0;
   for (int step0 = 0; step0 < len; step0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -104,47 +135,58 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
       const int step = step0 + u;
       if (step >= len) break;
       const int t = rev ? len - 1 - step : step;
-      const float gcur = gq[u];
-      float acc0 = gcur + bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
       if (BF16) {
-        const uint4* hp = reinterpret_cast<const uint4*>(h_b);
+        const uint4* hp = reinterpret_cast<const uint4*>(&h_b[cur][kq * 32]);
 #pragma unroll
-        for (int k = 0; k < LH / 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
           LstmPack4 hv;
           hv.u = hp[k];
-          acc0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k], hv.p[0], acc0, false);
-          acc1 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 1], hv.p[1], acc1, false);
-          acc2 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 2], hv.p[2], acc2, false);
-          acc3 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + 3], hv.p[3], acc3, false);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + e], hv.p[e], p0, false);
+            p1 = __builtin_amdgcn_fdot2_f32_bf16(wq[16 + 4 * k + e], hv.p[e], p1, false);
+            p2 = __builtin_amdgcn_fdot2_f32_bf16(wq[32 + 4 * k + e], hv.p[e], p2, false);
+            p3 = __builtin_amdgcn_fdot2_f32_bf16(wq[48 + 4 * k + e], hv.p[e], p3, false);
+          }
         }
       } else {
-        const float4* hp = reinterpret_cast<const float4*>(h_s);
+        const float4* hp = reinterpret_cast<const float4*>(&h_s[cur][kq * 32]);
 #pragma unroll
-        for (int k = 0; k < LH / 4; ++k) {
-          float4 hv = hp[k];
-          acc0 = fmaf(w[4 * k], hv.x, acc0);
-          acc1 = fmaf(w[4 * k + 1], hv.y, acc1);
-          acc2 = fmaf(w[4 * k + 2], hv.z, acc2);
-          acc3 = fmaf(w[4 * k + 3], hv.w, acc3);
+        for (int k = 0; k < 8; ++k) {
+          const float4 hv = hp[k];
+          const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p0 = fmaf(w[4 * k + e], hh[e], p0);
+            p1 = fmaf(w[32 + 4 * k + e], hh[e], p1);
+            p2 = fmaf(w[64 + 4 * k + e], hh[e], p2);
+            p3 = fmaf(w[96 + 4 * k + e], hh[e], p3);
+          }
         }
       }
-      const float pre = (acc0 + acc1) + (acc2 + acc3);
-      // activation by gate block: rows [0,256) sigmoid (i,f), [256,384) tanh (g), [384,512) sigmoid (o)
-      const float act = (r >= 2 * LH && r < 3 * LH) ? tanhf(pre) : sigmoidf_(pre);
-      g_s[r] = act;
-      gob[(long long)t * LG + r] = act;
-      lstm_barrier();
-      if (r < LH) {
-        const float ig = g_s[r], fg = g_s[LH + r], gg = g_s[2 * LH + r], og = g_s[3 * LH + r];
-        c = fmaf(fg, c, ig * gg);
-        const float hn = og * tanhf(c);
+      // reduce-scatter over the quad: lane kq ends with the full pre-activation of gate kq
+      const bool b0 = kq & 1, b1 = kq & 2;
+      const float ka = (b0 ? p1 : p0) + lstm_dpp_xor1(b0 ? p0 : p1);  // gate (kq & 1)
+      const float kb = (b0 ? p3 : p2) + lstm_dpp_xor1(b0 ? p2 : p3);  // gate (kq & 1) + 2
+      const float pre = (b1 ? kb : ka) + lstm_dpp_xor2(b1 ? ka : kb) + (gq[u] + bias);
+      // activation by gate: i, f, o sigmoid; g tanh
+      const float sg = lstm_sigmoid<BF16>((kq == 2) ? 2.f * pre : pre);
+      const float act = (kq == 2) ? fmaf(2.f, sg, -1.f) : sg;
+      gob[(long long)t * LG] = act;
+      const float ig = lstm_quad_bcast<0>(act), fg = lstm_quad_bcast<1>(act);
+      const float gg = lstm_quad_bcast<2>(act), og = lstm_quad_bcast<3>(act);
+      c = fmaf(fg, c, ig * gg);
+      const float hn = og * lstm_tanh<BF16>(c);
+      if (kq == 0) {
         if (BF16)
-          h_b[r] = (__bf16)hn;
+          h_b[cur ^ 1][j] = (__bf16)hn;
         else
-          h_s[r] = hn;
-        outb[(long long)t * ndir * LH + r] = hn;
-        cob[(long long)t * LH + r] = c;
+          h_s[cur ^ 1][j] = hn;
+        outb[(long long)t * ndir * LH + j] = hn;
+        cob[(long long)t * LH + j] = c;
       }
+      cur ^= 1;
       lstm_barrier();
     }
 #pragma unroll
@@ -152,73 +194,91 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
   }
   // zero the padded tail (pad_packed_sequence) -- outputs only; saved state is never read there
   for (int tt = len; tt < T; ++tt)
-    if (r < LH) outb[(long long)tt * ndir * LH + r] = 0.f;
+    if (tid < LH) outb[(long long)tt * ndir * LH + tid] = 0.f;
 }
 
-// Backward through time: produces dgates_pre (ndir,B,T,4H) (gradient w.r.t. the pre-activation
-// gates); the weight / input gradients are GEMMs over it (host layer).
-// dout: (B,T,ndir*H).  W_hh^T is held in registers as 4 K-slices: thread (k = tid&127, qd = tid>>7)
-// keeps W_hh[qd*128 + rr][k] for rr = 0..127.
+__device__ __forceinline__ float lstm_dpp_half_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, false));  // lane i <-> 7 - i
+}
+__device__ __forceinline__ float lstm_dpp_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, false));  // lane i <-> 15 - i
+}
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float lstm_row16_sum(float v) {
+  v += lstm_dpp_xor1(v);
+  v += lstm_dpp_xor2(v);
+  v += lstm_dpp_half_mirror(v);
+  v += lstm_dpp_mirror(v);
+  return v;
+}
+
+// Backward through time: produces dgates_pre (ndir,B,T,4H) (gradient w.r.t. the pre-activation gates); the weight /
+// input gradients are GEMMs over it (host layer).  dout: (B,T,ndir*H).
+// A DPP ROW of 16 lanes owns four cells.  Phase A: lane l of the row is (cell l >> 2, gate l & 3): all four lanes of a
+// cell carry its dh and dc and each publishes the gradient of ITS gate (one value per lane: LDS + the saved tensor).
+// After ONE barrier, phase B reduces dh_prev[k] = sum_r W_hh[r][k] . dg[r] for the row's four cells: lane l covers the
+// 32 gradient rows [32 l, 32 l + 32) (a 64-byte LDS read, shared by its four outputs: 128 weights per lane in registers)
+// and the 16 partial sums meet through four DPP adds -- no LDS round trip, dg double-buffered.
+// History: three barriers + two LDS round trips per step 0.82 us; a quad-per-cell layout whose lanes each read a whole
+// 128-row quarter of dg (16 wide LDS reads with four distinct addresses per wave: LDS-bound) 1.23 us.
 template <bool BF16>
 __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ whh,
                                                       const int32_t* __restrict__ lens,
                                                       const float* __restrict__ gates, const float* __restrict__ cst,
                                                       float* __restrict__ dgates, int B, int T, int ndir,
                                                       int reverse_first) {
-  __shared__ __attribute__((aligned(16))) float dg_s[LG];
-  __shared__ __attribute__((aligned(16))) __bf16 dg_b[LG];
-  __shared__ float part_s[4][LH];
-  __shared__ float dh_s[LH];
-  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float dg_s[2][LG];
+  __shared__ __attribute__((aligned(16))) __bf16 dg_b[2][LG];
+  const int tid = threadIdx.x, row = tid >> 4, l = tid & 15;
+  const int k = row * 4 + (l >> 2), kq = l & 3;  // phase-A identity: cell, gate
   const int b = blockIdx.x, dir = blockIdx.y;
   const bool rev = reverse_first ? true : (dir == 1);
   const int len = lens ? min(lens[b], T) : T;
-  const int kcol = tid & (LH - 1), qd = tid >> 7;
-  float w[BF16 ? 1 : LH];
-  lstm_bf16x2 wq[BF16 ? LH / 2 : 1];
+  // phase-B weights: W_hh[32 l + rr][4 row + c], c < 4, rr < 32
+  float w[BF16 ? 1 : 4 * 32];
+  lstm_bf16x2 wq[BF16 ? 4 * 16 : 1];
 #pragma unroll
-  for (int rr = 0; rr < LH; rr += 2) {
-    const float w0 = whh[((long long)dir * LG + qd * LH + rr) * LH + kcol];
-    const float w1 = whh[((long long)dir * LG + qd * LH + rr + 1) * LH + kcol];
-    if (BF16) {
-      wq[rr / 2] = (lstm_bf16x2){(__bf16)w0, (__bf16)w1};
-    } else {
-      w[rr] = w0;
-      w[rr + 1] = w1;
+  for (int rr = 0; rr < 32; rr += 2) {
+    const float4 w0 = *reinterpret_cast<const float4*>(whh + ((long long)dir * LG + l * 32 + rr) * LH + row * 4);
+    const float4 w1 = *reinterpret_cast<const float4*>(whh + ((long long)dir * LG + l * 32 + rr + 1) * LH + row * 4);
+    const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (BF16) {
+        wq[c * 16 + rr / 2] = (lstm_bf16x2){(__bf16)a0[c], (__bf16)a1[c]};
+      } else {
+        w[c * 32 + rr] = a0[c];
+        w[c * 32 + rr + 1] = a1[c];
+      }
     }
   }
   const float* doutb = dout + (long long)b * T * ndir * LH + dir * LH;
   const float* gb = gates + (((long long)dir * B + b) * T) * LG;
   const float* cb = cst + (((long long)dir * B + b) * T) * LH;
   float* dgb = dgates + (((long long)dir * B + b) * T) * LG;
-  if (tid < LH) dh_s[tid] = 0.f;
-  float dc = 0.f;
-  __syncthreads();
+  float dc = 0.f, dh_rec = 0.f;
   // time runs opposite to the forward recurrence.  The seven operands of a step (four saved gates, c_t, c_{t-1}, dout_t)
-  // were loaded at the top of the step: a full L2 / HBM round trip on the critical path of every step (1.05 us per step
-  // measured).  They are now loaded a CHUNK of PF steps ahead (see the forward kernel): the operands of the next chunk
-  // are requested at the top of a chunk by all 512 threads (column tid & 127, step clamped into the sequence), outside
-  // any divergent block, and first touched a chunk later.
+  // are loaded a CHUNK of PF steps ahead (see the forward kernel), by every lane for its cell, outside any divergent block.
   constexpr int PF = 4;
   float q_i[PF], q_f[PF], q_g[PF], q_o[PF], q_c[PF], q_cp[PF], q_d[PF];
   float n_i[PF], n_f[PF], n_g[PF], n_o[PF], n_c[PF], n_cp[PF], n_d[PF];
   const int last = len > 0 ? len - 1 : 0;
-  const int col = tid & (LH - 1);
   auto fetch = [&](int step, float& vi, float& vf, float& vg, float& vo, float& vc, float& vcp, float& vd) {
     const int sc = min(step, last);
     const int t = rev ? sc : last - sc;
     const int tprev = min(max(rev ? t + 1 : t - 1, 0), T - 1);
-    vi = gb[(long long)t * LG + col];
-    vf = gb[(long long)t * LG + LH + col];
-    vg = gb[(long long)t * LG + 2 * LH + col];
-    vo = gb[(long long)t * LG + 3 * LH + col];
-    vc = cb[(long long)t * LH + col];
-    const float cp = cb[(long long)tprev * LH + col];
+    vi = gb[(long long)t * LG + k];
+    vf = gb[(long long)t * LG + LH + k];
+    vg = gb[(long long)t * LG + 2 * LH + k];
+    vo = gb[(long long)t * LG + 3 * LH + k];
+    vc = cb[(long long)t * LH + k];
+    const float cp = cb[(long long)tprev * LH + k];
     vcp = (sc + 1 < len) ? cp : 0.f;
-    vd = doutb[(long long)t * ndir * LH + col];
+    vd = doutb[(long long)t * ndir * LH + k];
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) fetch(u, q_i[u], q_f[u], q_g[u], q_o[u], q_c[u], q_cp[u], q_d[u]);
+  int cur = 0;
   for (int step0 = 0; step0 < len; step0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch(step0 + PF + u, n_i[u], n_f[u], n_g[u], n_o[u], n_c[u], n_cp[u], n_d[u]);
@@ -227,63 +287,62 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
       const int step = step0 + u;
       if (step >= len) break;
       const int t = rev ? step : len - 1 - step;
-      if (tid < LH) {
+      {
         const float ig = q_i[u], fg = q_f[u], gg = q_g[u], og = q_o[u], cc = q_c[u], cprev = q_cp[u];
-        const float dh = q_d[u] + dh_s[tid];
-        const float tc = tanhf(cc);
-        const float d_o = dh * tc;
+        const float dh = q_d[u] + dh_rec;
+        const float tc = lstm_tanh<BF16>(cc);
         dc = dc + dh * og * (1.f - tc * tc);
-        const float d_i = dc * gg, d_g = dc * ig, d_f = dc * cprev;
-        const float pi = d_i * ig * (1.f - ig), pf = d_f * fg * (1.f - fg);
-        const float pg = d_g * (1.f - gg * gg), po = d_o * og * (1.f - og);
+        // lane kq publishes the gradient of gate kq: d(pre) = upstream * local derivative of the gate's activation
+        const float up = kq == 0 ? dc * gg : (kq == 1 ? dc * cprev : (kq == 2 ? dc * ig : dh * tc));
+        const float av = kq == 0 ? ig : (kq == 1 ? fg : (kq == 2 ? gg : og));
+        const float mine = up * (kq == 2 ? (1.f - av * av) : av * (1.f - av));
         dc = dc * fg;
-        if (BF16) {
-          dg_b[tid] = (__bf16)pi;
-          dg_b[LH + tid] = (__bf16)pf;
-          dg_b[2 * LH + tid] = (__bf16)pg;
-          dg_b[3 * LH + tid] = (__bf16)po;
-        } else {
-          dg_s[tid] = pi;
-          dg_s[LH + tid] = pf;
-          dg_s[2 * LH + tid] = pg;
-          dg_s[3 * LH + tid] = po;
-        }
-        float* dst = dgb + (long long)t * LG;
-        dst[tid] = pi;
-        dst[LH + tid] = pf;
-        dst[2 * LH + tid] = pg;
-        dst[3 * LH + tid] = po;
+        if (BF16)
+          dg_b[cur][kq * LH + k] = (__bf16)mine;
+        else
+          dg_s[cur][kq * LH + k] = mine;
+        dgb[(long long)t * LG + kq * LH + k] = mine;
       }
       lstm_barrier();
       {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // partial dh of the row's four cells over 32 gradient rows
         if (BF16) {
-          const uint4* dp = reinterpret_cast<const uint4*>(dg_b + qd * LH);
+          const uint4* dp = reinterpret_cast<const uint4*>(&dg_b[cur][l * 32]);
 #pragma unroll
-          for (int rr = 0; rr < LH / 8; ++rr) {
+          for (int q = 0; q < 4; ++q) {
             LstmPack4 d4;
-            d4.u = dp[rr];
-            a0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr], d4.p[0], a0, false);
-            a1 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 1], d4.p[1], a1, false);
-            a2 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 2], d4.p[2], a2, false);
-            a3 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * rr + 3], d4.p[3], a3, false);
+            d4.u = dp[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * q + e], d4.p[e], a0, false);
+              a1 = __builtin_amdgcn_fdot2_f32_bf16(wq[16 + 4 * q + e], d4.p[e], a1, false);
+              a2 = __builtin_amdgcn_fdot2_f32_bf16(wq[32 + 4 * q + e], d4.p[e], a2, false);
+              a3 = __builtin_amdgcn_fdot2_f32_bf16(wq[48 + 4 * q + e], d4.p[e], a3, false);
+            }
           }
         } else {
-          const float4* dp = reinterpret_cast<const float4*>(dg_s + qd * LH);
+          const float4* dp = reinterpret_cast<const float4*>(&dg_s[cur][l * 32]);
 #pragma unroll
-          for (int rr = 0; rr < LH / 4; ++rr) {
-            float4 d4 = dp[rr];
-            a0 = fmaf(w[4 * rr], d4.x, a0);
-            a1 = fmaf(w[4 * rr + 1], d4.y, a1);
-            a2 = fmaf(w[4 * rr + 2], d4.z, a2);
-            a3 = fmaf(w[4 * rr + 3], d4.w, a3);
+          for (int q = 0; q < 8; ++q) {
+            const float4 d4 = dp[q];
+            const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a0 = fmaf(w[4 * q + e], dd[e], a0);
+              a1 = fmaf(w[32 + 4 * q + e], dd[e], a1);
+              a2 = fmaf(w[64 + 4 * q + e], dd[e], a2);
+              a3 = fmaf(w[96 + 4 * q + e], dd[e], a3);
+            }
           }
         }
-        part_s[qd][kcol] = (a0 + a1) + (a2 + a3);
+        a0 = lstm_row16_sum(a0);
+        a1 = lstm_row16_sum(a1);
+        a2 = lstm_row16_sum(a2);
+        a3 = lstm_row16_sum(a3);
+        const int cq = l >> 2;  // this lane's cell inside the row
+        dh_rec = cq == 0 ? a0 : (cq == 1 ? a1 : (cq == 2 ? a2 : a3));
       }
-      lstm_barrier();
-      if (tid < LH) dh_s[tid] = (part_s[0][tid] + part_s[1][tid]) + (part_s[2][tid] + part_s[3][tid]);
-      lstm_barrier();
+      cur ^= 1;
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
