@@ -602,6 +602,12 @@ int kantts_upsample_stream(const void* x_bf16, const void* wp_bf16, const float*
 /* y = sin(x) + x (hifigan.py:157) and act = bf16(LeakyReLU(y, slope)) in one pass. */
 int kantts_sinadd_lrelu_fwd(const float* x, float* y, void* act_bf16, float slope, long long n, void* stream);
 
+/* y[i] = x[i] * keep_{p1,seed1}(i) * keep_{p2,seed2}(i) (+ res[i]): two stacked dropouts and a residual add in one pass
+ * with regenerated masks -- FsmnEncoderV2 / MemoryBlockV2 (kantts/models/sambert/fsmn.py:66-70,114-121).  The backward
+ * is the same call with x := dy, res := NULL.  n % 4 == 0, 16-byte aligned; seeds are offset by *seed_dev. */
+int kantts_dropout2_add(const float* x, const float* res, float* y, long long n, float p1, uint64_t seed1, float p2,
+                        uint64_t seed2, const uint64_t* seed_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

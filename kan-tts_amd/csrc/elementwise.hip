@@ -167,3 +167,36 @@ extern "C" int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, lon
   hipLaunchKernelGGL(sinadd_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n);
   KANTTS_CHECK_LAUNCH();
 }
+
+// y = x * keep1(i) * keep2(i) (+ res): the FSMN encoder's two stacked dropouts and its residual add
+// (kantts/models/sambert/fsmn.py:66-70,114-121: MemoryBlockV2's own dropout, the encoder's dropout on the block output,
+// "memory + x") as ONE pass with regenerated masks; the same entry point is the backward (x := dy, res := NULL).  As three
+// ATen kernels forward and two backward they moved 240 MB per postnet layer (saved boolean masks included) against 100.
+__global__ __launch_bounds__(256) void dropout2_add_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                          float* __restrict__ y, long long n4, float p1, uint64_t seed1,
+                                                          float p2, uint64_t seed2, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t off = seed_dev ? *seed_dev : 0ull;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float o[4] = {v.x, v.y, v.z, v.w};
+    kantts_dropout_scale4(p1, seed1 + off, (uint64_t)i * 4, o);
+    kantts_dropout_scale4(p2, seed2 + off, (uint64_t)i * 4, o);
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int kantts_dropout2_add(const float* x, const float* res, float* y, long long n, float p1, uint64_t seed1, float p2,
+                                   uint64_t seed2, const uint64_t* seed_dev, void* stream) {
+  if (!x || !y || n < 0 || (n & 3) || p1 < 0.f || p1 >= 1.f || p2 < 0.f || p2 >= 1.f) return KANTTS_E_BADARG;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) return KANTTS_E_BADARG;
+  if (n == 0) return KANTTS_OK;
+  const long long n4 = n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(dropout2_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, res, y, n4, p1, seed1, p2,
+                     seed2, seed_dev);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -209,6 +209,7 @@ def lib():
         L.kantts_step_rowmask.argtypes = [p, p, i, i, p, p]
         L.kantts_upsample_stream.argtypes = [p, p, p, p, p, i, i, i, i, i, f, i, p]
         L.kantts_sinadd_lrelu_fwd.argtypes = [p, p, p, f, ll, p]
+        L.kantts_dropout2_add.argtypes = [p, p, p, ll, f, c_uint64, f, c_uint64, p, p]
         L.kantts_sumsq_det.argtypes = [p, p, p, ll, ll, p]
         L.kantts_stft_mag_bwd.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p]
         L.kantts_bgemm_nt.argtypes = [POINTER(BGemmArgs), c_void_p]
@@ -236,7 +237,7 @@ EXPORTED_SYMBOLS = [
     "kantts_bgemm_nt", "kantts_ffn_pair", "kantts_fragmajor_bf16", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
     "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
     "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
-    "kantts_sinadd_lrelu_fwd",
+    "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
 ]
 
 

@@ -1289,6 +1289,49 @@ class _SinAddAct(torch.autograd.Function):
         return dx, None
 
 
+class _Dropout2Add(torch.autograd.Function):
+    """x * keep1 * keep2 (+ res) with regenerated masks (kantts_dropout2_add); backward = the same kernel on dy."""
+
+    @staticmethod
+    def forward(ctx, x, res, p1, p2):
+        from . import rng_ptr
+
+        x = _c(x)
+        y = torch.empty_like(x)
+        s1 = next_seed() if p1 > 0 else 0
+        s2 = next_seed() if p2 > 0 else 0
+        r = None if res is None else _c(res)
+        check(lib().kantts_dropout2_add(ptr(x, torch.float32), ptr(r, torch.float32), ptr(y), x.numel(), float(p1), s1,
+                                        float(p2), s2, rng_ptr(x.device), stream()), "dropout2_add")
+        ctx.cfg = (float(p1), s1, float(p2), s2, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import rng_ptr
+
+        p1, s1, p2, s2, has_res = ctx.cfg
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            check(lib().kantts_dropout2_add(ptr(dy, torch.float32), None, ptr(dx), dy.numel(), p1, s1, p2, s2,
+                                            rng_ptr(dy.device), stream()), "dropout2_add")
+        return dx, (dy if has_res and ctx.needs_input_grad[1] else None), None, None
+
+
+def dropout2_add(x, p1=0.0, p2=0.0, res=None):
+    """dropout_{p2}(dropout_{p1}(x)) (+ res) in one pass (fp32, numel % 4 == 0); plain add / identity when both p are 0."""
+    if p1 <= 0.0 and p2 <= 0.0:
+        return x if res is None else x + res
+    if x.dtype != torch.float32 or x.numel() % 4 or (res is not None and (res.shape != x.shape or res.dtype != x.dtype)):
+        import torch.nn.functional as F
+
+        y = F.dropout(F.dropout(x, p1, True), p2, True)
+        return y if res is None else y + res
+    return _Dropout2Add.apply(x, res, float(p1), float(p2))
+
+
 def sin_add(x, act_slope=None):
     """sin(x) + x; with ``act_slope`` also returns bf16(LeakyReLU(result)) -- the operand of the streaming transposed
     convolution (bf16 mode)."""

@@ -1,6 +1,5 @@
 """FSMN encoder on HIP kernels (reference kantts/models/sambert/fsmn.py:8-124), channels-last."""
 import torch.nn as nn
-import torch.nn.functional as F
 
 from kantts._hip import ops
 from kantts.models.utils import SeqInfo
@@ -38,14 +37,15 @@ class MemoryBlockV2(nn.Module):
         self.conv_dw = nn.Conv1d(d, d, filter_size, stride=1, padding=0, groups=d, bias=False)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, input, mask=None, res=None):
+    def forward(self, input, mask=None, res=None, outer_p=0.0):
+        """``outer_p``: the encoder's own dropout on this block's output (reference :118), applied in the same pass as
+        the block's dropout and the residual add (kantts_dropout2_add)."""
         info = SeqInfo.of(mask)
         lens = None if info is None else info.lens64
         p = float(self.dropout.p) if self.training else 0.0
-        if p > 0.0:
+        if p > 0.0 or outer_p > 0.0:
             out = ops.fsmn_memory(input, self.conv_dw.weight, lens, self.lp)
-            out = F.dropout(out, p, True)
-            return out if res is None else out + res
+            return ops.dropout2_add(out, p, outer_p, res)
         return ops.fsmn_memory(input, self.conv_dw.weight, lens, self.lp, res=res)
 
 
@@ -68,13 +68,9 @@ class FsmnEncoderV2(nn.Module):
     def forward(self, input, mask=None):
         info = SeqInfo.of(mask)
         p = float(self.dropout) if self.training else 0.0
-        x = F.dropout(input, p, True) if p > 0 else input
+        x = ops.dropout2_add(input, p) if p > 0 else input
         for ffn, memory_block in zip(self.ffn_lst, self.memory_block_lst):
             context = ffn(x)
             same = self.num_memory_units == x.size(-1)
-            if p > 0:
-                memory = F.dropout(memory_block(context, info), p, True)
-                x = memory + x if same else memory
-            else:
-                x = memory_block(context, info, res=x if same else None)
+            x = memory_block(context, info, res=x if same else None, outer_p=p)
         return x

@@ -922,6 +922,18 @@ class EmulatedLib:
         _arr(dv, rows * cols)[:] = ((G / nrm)[:, None] * (DW - V * (dgv / nrm)[:, None])).ravel()
         return 0
 
+    def kantts_dropout2_add(self, x, res, y, n, p1, seed1, p2, seed2, seed_dev, stream):
+        n = int(n)
+        if n % 4:
+            return -1
+        soff = int(_arr(seed_dev, 1, np.int64)[0]) if seed_dev else 0
+        idx = np.arange(n, dtype=np.int64)
+        v = _arr(x, n) * dropout_scale(_val(p1), int(_val(seed1)) + soff, idx) * dropout_scale(_val(p2), int(_val(seed2)) + soff, idx)
+        if res:
+            v = v + _arr(res, n)
+        _arr(y, n)[:] = v.astype(np.float32)
+        return 0
+
     def kantts_sinadd_lrelu_fwd(self, x, y, act, slope, n, stream):
         X = _arr(x, n)
         Y = (np.sin(X) + X).astype(np.float32)

@@ -291,6 +291,34 @@ def test_fsmn_memory(C, K, lp):
         assert rel_l2(a, c) < 1e-4, nm
 
 
+def test_dropout2_add_kernel():
+    """kantts_dropout2_add on the device against the emulated ABI: identical masks (same counter RNG), so outputs and
+    gradients agree to rounding; with and without the residual; p2 = 0."""
+    import itertools
+
+    from kantts._hip import ops
+
+    x, r = _rand(32, 612, 256, seed=4, grad=True), _rand(32, 612, 256, seed=5, grad=True)
+
+    def seeded(fn):
+        def f(*a):
+            ops._seed_counter = itertools.count(300)
+            torch.manual_seed(7)
+            return fn(*a)
+        return f
+
+    for p1, p2, with_res in ((0.1, 0.1, True), (0.25, 0.0, False), (0.0, 0.5, True)):
+        if with_res:
+            go, gg, co, cg = run_both(seeded(lambda a, b: ops.dropout2_add(a, p1, p2, b)), x, r)
+        else:
+            go, gg, co, cg = run_both(seeded(lambda a: ops.dropout2_add(a, p1, p2)), x)
+        assert_close(go[0], co[0], 1e-6, what="dropout2_add y")
+        keep = 1.0 - (go[0] - (r.detach() if with_res else 0) == 0).float().mean().item()
+        assert abs(keep - (1 - p1) * (1 - p2)) < 0.01
+        for a, c in zip(gg, cg):
+            assert_close(a, c, 1e-6, what="dropout2_add grad")
+
+
 def test_masked_l1_and_optimizer_kernels():
     from kantts._hip import ops
 

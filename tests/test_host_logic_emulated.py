@@ -101,6 +101,39 @@ def test_dropout_backward_consistent_with_forward_mask(emulated_cabi):
         assert_close(gb, eb, 1e-4, what="db relu=%s" % relu)
 
 
+def test_dropout2_add_and_fsmn_encoder_training_path(emulated_cabi):
+    """kantts_dropout2_add: two stacked dropouts (+ residual) in one pass; backward regenerates both masks.  The FSMN
+    encoder in training mode uses it for the block dropout, the encoder dropout and "memory + x" (fsmn.py:66-70,114-121)."""
+    from kantts._hip import ops
+    from kantts.models.sambert.fsmn import FsmnEncoderV2
+
+    torch.manual_seed(2)
+    x = torch.randn(5, 33, 64, requires_grad=True)
+    r = torch.randn(5, 33, 64, requires_grad=True)
+    y = ops.dropout2_add(x, 0.2, 0.3, r)
+    d = (y - r).detach()                             # 0 or x / (0.8 * 0.7)
+    keep = torch.isclose(d, x.detach() / 0.56, rtol=1e-4, atol=1e-5)
+    assert torch.all(keep | (d.abs() < 1e-5))
+    assert 0.50 < keep.float().mean().item() < 0.62  # 0.8 * 0.7 = 0.56 over 10 560 draws
+    k = keep.float() / 0.56
+    gx, gr = torch.autograd.grad((y * y).sum(), (x, r))
+    assert_close(gx, (2 * y * k).detach(), 1e-4, what="dx")
+    assert_close(gr, (2 * y).detach(), 1e-5, what="dres")
+    assert torch.equal(ops.dropout2_add(x, 0.0, 0.0, r), x + r)
+    # encoder wiring: eval equals the fused no-dropout path; training runs, keeps shapes, back-propagates
+    enc = FsmnEncoderV2(filter_size=11, fsmn_num_layers=3, input_dim=48, num_memory_units=32, ffn_inner_dim=64, dropout=0.1)
+    inp = torch.randn(2, 20, 48, requires_grad=True)
+    mask = torch.arange(20)[None, :] >= torch.tensor([20, 13])[:, None]
+    enc.eval()
+    y_eval = enc(inp, mask)
+    enc.train()
+    y_tr = enc(inp, mask)
+    assert y_tr.shape == y_eval.shape and not torch.allclose(y_tr, y_eval)
+    y_tr.sum().backward()
+    assert inp.grad is not None and torch.isfinite(inp.grad).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+
+
 def test_arena_adam_matches_torch_adam(emulated_cabi):
     from kantts.train.optim import ArenaAdam, ParamArena
 
