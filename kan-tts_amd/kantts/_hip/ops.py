@@ -5,6 +5,7 @@ kernels need (outputs for ReLU gating, LayerNorm statistics, attention log-sum-e
 Nothing here computes on the host or with ATen kernels except trivial views / allocations.
 """
 import itertools
+import os
 import math
 
 import torch
@@ -106,6 +107,7 @@ class _WgradOverlap:
         from . import deferred_tn
 
         self.enabled = bool(on)
+        side_branch.enabled = bool(on) and os.environ.get("KANTTS_NO_SIDE_BRANCH", "") == ""
         deferred_tn.enabled = bool(on if group_wgrads is None else group_wgrads)
         if not deferred_tn.enabled:
             deferred_tn.flush()
@@ -141,6 +143,8 @@ class _WgradOverlap:
         from . import deferred_tn
 
         deferred_tn.flush()  # recorded weight gradients: grouped launches on the current stream
+        side_branch.join()
+        side_branch.release()
         if self._used:
             ev = torch.cuda.Event()
             ev.record(self._stream)
@@ -150,6 +154,66 @@ class _WgradOverlap:
 
 
 wgrad_overlap = _WgradOverlap()
+
+
+class _SideBranch:
+    """Opt-in: a sub-network whose results the main chain does not need until the end of forward runs on a second HIP
+    stream -- in training the three variance predictors of SAM-BERT (pitch / energy / duration: FSMN + BiLSTM / LSTM
+    stacks over the 64-symbol text axis, ~0.75 ms of small launches per step that occupy a quarter of the chip) only feed
+    their own losses, while length regulation, decoder and postnet use the TARGET durations / pitch / energy
+    (kantts_sambert.py:392-470).  ``with side_branch.fork(*tensors)`` makes the side stream wait for the current one and
+    runs the body there; autograd replays every node on the stream of its forward op, so the branch's backward is
+    concurrent with the decoder's backward as well, and under hipGraph capture both become parallel graph branches.
+    ``tensors`` (allocated on the main stream, read by side-stream kernels) are kept alive until
+    ``wgrad_overlap.join()`` (the optimizer step): the caching allocator would otherwise hand their memory to a later
+    main-stream allocation while a side kernel is still pending.  ``join()`` makes the current stream wait for the branch.
+    Enabled together with ``wgrad_overlap`` (GraphedSambertStep, bench.py); off by default."""
+
+    def __init__(self):
+        self.enabled = False
+        self._stream = None
+        self._keep = []
+        self._open = False
+
+    class _Ctx:
+        def __init__(self, owner, keep):
+            self.owner, self.keep, self.cm = owner, keep, None
+
+        def __enter__(self):
+            o = self.owner
+            if not o.enabled or not torch.cuda.is_available():
+                return self
+            if o._stream is None:
+                o._stream = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            o._stream.wait_event(ev)
+            self.cm = torch.cuda.stream(o._stream)
+            self.cm.__enter__()
+            o._keep.extend(t for t in self.keep if t is not None)
+            o._open = True
+            return self
+
+        def __exit__(self, *exc):
+            if self.cm is not None:
+                self.cm.__exit__(*exc)
+            return False
+
+    def fork(self, *keep):
+        return _SideBranch._Ctx(self, keep)
+
+    def join(self):
+        if self._open:
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._open = False
+
+    def release(self):
+        self._keep.clear()
+
+
+side_branch = _SideBranch()
 
 
 # ================================================================================================

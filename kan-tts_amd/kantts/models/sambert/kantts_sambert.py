@@ -9,6 +9,8 @@ deliberate (documented in DESIGN.md):
   * the MAS alignment path (sambert_16k_MAS.yaml) and speaker-embedding input (SE: True) are implemented;
     FP / byte-input variants raise NotImplementedError.
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -201,8 +203,15 @@ class VarianceAdaptor(nn.Module):
         # [text | spk | emo] is consumed by three GEMMs (two FSMN inputs + the duration LSTM); build it once
         variance_predictor_inputs = torch.cat(
             [inputs_text_embedding, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
-        pitch_predictions = self.pitch_predictor(variance_predictor_inputs, info)
-        energy_predictions = self.energy_predictor(variance_predictor_inputs, info)
+        # Teacher-forced training: the predictors feed only their own losses (everything downstream uses the targets), so
+        # they run as a side branch beside the length regulator / decoder / postnet (ops.side_branch; joined at the end of
+        # KanTtsSAMBERT.forward).  Free-running inference needs their outputs at once: the branch is then a no-op.
+        teacher = (self.training and duration_targets is not None and pitch_targets is not None
+                   and energy_targets is not None)
+        lens_keep = None if info is None else (info.lens64, info.mask)
+        with ops.side_branch.fork(variance_predictor_inputs, *(lens_keep or ())) if teacher else contextlib.nullcontext():
+            pitch_predictions = self.pitch_predictor(variance_predictor_inputs, info)
+            energy_predictions = self.energy_predictor(variance_predictor_inputs, info)
         pitch_src = pitch_targets if pitch_targets is not None else pitch_predictions
         energy_src = energy_targets if energy_targets is not None else energy_predictions
         # text + Conv1d(1->32,k=9)(pitch) + Conv1d(1->32,k=9)(energy): two 9-tap GEMMs chained through the
@@ -215,9 +224,9 @@ class VarianceAdaptor(nn.Module):
                + ops.conv_cl(energy_src.unsqueeze(-1).contiguous(), self.energy_emb.weight, self.energy_emb.bias, pad=4))
         duration_predictor_cond = torch.cat([aug, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
         if duration_targets is not None:
-            prev = F.pad(duration_targets[:, :-1].float(), (1, 0))
-            log_duration_predictions, _ = self.duration_predictor(
-                torch.log(prev + 1).unsqueeze(-1), duration_predictor_cond, masks=info)
+            prev = torch.log(F.pad(duration_targets[:, :-1].float(), (1, 0)) + 1).unsqueeze(-1)
+            with ops.side_branch.fork(duration_predictor_cond, prev) if teacher else contextlib.nullcontext():
+                log_duration_predictions, _ = self.duration_predictor(prev, duration_predictor_cond, masks=info)
             durations = duration_targets
         else:
             log_duration_predictions = self.duration_predictor.infer(duration_predictor_cond, masks=info)
@@ -469,6 +478,7 @@ class KanTtsSAMBERT(nn.Module):
                                                                                          dec_outputs.size(1))
         # postnet residual add + final masking ride in the epilogue of the last GEMM
         postnet_outputs = self.mel_postnet(dec_outputs, post_info, res=dec_outputs, zero_rows=post_info.mask)
+        ops.side_branch.join()  # the predictors' outputs are read from here on (losses)
         res = {
             "x_band_width": x_band_width,
             "h_band_width": h_band_width,

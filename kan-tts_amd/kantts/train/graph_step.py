@@ -20,8 +20,20 @@ class GraphedSambertStep:
                  overlap_wgrad=True, group_wgrads=True):
         # weight gradients leave the critical path: fp32-mode ones as parallel branches of the captured graph
         # (ops._WgradOverlap), bf16-mode ones recorded and issued grouped by shape before the optimizer
-        # (kantts._hip.deferred_tn)
+        # (kantts._hip.deferred_tn); the variance predictors run as a side branch (ops.side_branch).  These switches only
+        # shape what is CAPTURED: they are put back when the constructor returns, so eager code that runs later in the same
+        # process (evaluation, tests reading p.grad right after backward()) never sees deferred gradients
+        from kantts._hip import deferred_tn
+
+        prev = (ops.wgrad_overlap.enabled, deferred_tn.enabled, ops.side_branch.enabled)
         ops.wgrad_overlap.enable(overlap_wgrad, group_wgrads=group_wgrads)
+        try:
+            self._build(net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup)
+        finally:
+            ops.wgrad_overlap.join()
+            ops.wgrad_overlap.enabled, deferred_tn.enabled, ops.side_branch.enabled = prev
+
+    def _build(self, net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup):
         self.net, self.optimizer, self.scheduler = net, optimizer, scheduler
         self.mel_criterion, self.prosody_criterion = mel_criterion, prosody_criterion
         self.batch = {k: v.clone() for k, v in batch.items()}

@@ -26,6 +26,21 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _global_switches_off():
+    """The scheduling switches of the host layer (weight gradients deferred / on a side stream, predictors as a side
+    branch) are process-wide; a test that turns them on must not change what the next test sees."""
+    yield
+    import kantts._hip as hip
+    import kantts._hip.ops as ops
+
+    hip.deferred_tn.groups, hip.deferred_tn.copies = {}, []  # drop, never launch, whatever a failed test left behind
+    ops.wgrad_overlap.enabled = False
+    hip.deferred_tn.enabled = False
+    ops.side_branch.enabled = False
+    ops.side_branch.release()
+
+
 def _emulate(monkeypatch):
     """Route the ctypes binding to oracle/cabi_numpy.EmulatedLib (HOST memory).  Test-only: lets the
     host logic of the product run without a GPU; the product itself has no such switch."""
