@@ -139,6 +139,18 @@ class _WgradOverlap:
     def side(self, *keep):
         return _WgradOverlap._Ctx(self, keep)
 
+    def flush_early(self):
+        """Issue the weight gradients recorded so far on the side stream NOW (called from ``wgrad_flush_point`` in the
+        middle of backward): they then run beside the rest of the backward chain instead of after it."""
+        from . import deferred_tn
+
+        if not self.enabled or not (deferred_tn.groups or deferred_tn.copies):
+            return
+        # operands were allocated on the main stream; flush() drops its references once the launches are issued
+        keep = [k for probs in deferred_tn.groups.values() for q in probs for k in q[6] if k is not None]
+        with self.side(*keep):
+            deferred_tn.flush()
+
     def join(self):
         from . import deferred_tn
 
@@ -154,6 +166,31 @@ class _WgradOverlap:
 
 
 wgrad_overlap = _WgradOverlap()
+
+
+class _FlushPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        wgrad_overlap.flush_early()
+        return g
+
+
+def wgrad_flush_point(x):
+    """Identity.  When the gradient of ``x`` arrives in backward, every weight gradient recorded so far (all layers
+    DOWNSTREAM of x in forward) is issued on the side stream.  Placed at the encoder output of SAM-BERT: the decoder's
+    ~100 deferred weight gradients (1.2 ms of grouped launches) then run beside the encoder's backward -- 8 blocks over
+    2048 tokens, a chain of launches with 64-128 workgroups on a 256-CU chip -- instead of after it; and at the postnet
+    input (its 19 584-row weight gradients run beside the decoder's backward)."""
+    from . import deferred_tn
+
+    if not (wgrad_overlap.enabled and deferred_tn.enabled and torch.is_tensor(x) and x.requires_grad
+            and os.environ.get("KANTTS_NO_EARLY_FLUSH", "") == ""):
+        return x
+    return _FlushPoint.apply(x)
 
 
 class _SideBranch:

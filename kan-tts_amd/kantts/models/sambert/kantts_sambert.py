@@ -409,6 +409,9 @@ class KanTtsSAMBERT(nn.Module):
         in_info = SeqInfo(input_lengths, T_in)
         is_training = mel_targets is not None
         text_hid, enc_sla_attn_lst, ling_embedding = self.text_encoder(inputs_ling, in_info, self.return_attns)
+        # backward: once the gradient reaches the encoder output, the weight gradients of everything downstream start on
+        # the side stream, beside the encoder's own backward (no-op unless weight gradients are deferred)
+        text_hid = ops.wgrad_flush_point(text_hid)
         inter_lengths = input_lengths
         attn_soft = attn_hard = attn_logprob = None
         if self.MAS and is_training:
@@ -473,7 +476,7 @@ class KanTtsSAMBERT(nn.Module):
         rows = out_info.mask
         if rows.size(1) != dec_outputs.size(1):
             rows = F.pad(rows, (0, dec_outputs.size(1) - rows.size(1)), value=True)
-        dec_outputs = dec_outputs.masked_fill(rows.unsqueeze(-1), 0)
+        dec_outputs = ops.wgrad_flush_point(dec_outputs.masked_fill(rows.unsqueeze(-1), 0))  # postnet weight gradients
         post_info = out_info if out_info.mask.size(1) == dec_outputs.size(1) else SeqInfo(out_info.lens64,
                                                                                          dec_outputs.size(1))
         # postnet residual add + final masking ride in the epilogue of the last GEMM
