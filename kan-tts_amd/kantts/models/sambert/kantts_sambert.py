@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from kantts._hip import ops
 from kantts.models.sambert import FFTBlock, PNCABlock, Prenet
 from kantts.models.sambert.alignment import b_mas
@@ -23,6 +25,11 @@ from kantts.models.sambert.adaptors import LengthRegulator, VarFsmnRnnNARPredict
 from kantts.models.sambert.fsmn import FsmnEncoderV2
 from kantts.models.sambert.positions import DurSinusoidalPositionEncoder, SinusoidalPositionEncoder
 from kantts.models.utils import SeqInfo, get_mask_from_lengths
+
+
+# extra flush points for deferred weight gradients inside the block stacks (ops.wgrad_flush_point): every N blocks; 0 = only
+# the points at the postnet input and the encoder output.  Measured on the bench step: see DESIGN section 5.
+_FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "0"))}
 
 
 class SelfAttentionEncoder(nn.Module):
@@ -52,7 +59,10 @@ class SelfAttentionEncoder(nn.Module):
         info = SeqInfo.of(mask)
         attns = []
         x = input
-        for layer in self.fft:
+        every = _FLUSH_EVERY["enc"] if self.training else 0
+        for i, layer in enumerate(self.fft):
+            if every and i and i % every == 0:
+                x = ops.wgrad_flush_point(x)  # backward: weight gradients of the later blocks start beside the earlier ones
             x, a = layer(x, mask=info, return_attn=return_attns)
             if return_attns:
                 attns.append(a)
@@ -93,7 +103,10 @@ class HybridAttentionDecoder(nn.Module):
         if self.training and self.dropout > 0:
             x = F.dropout(x, p=self.dropout, training=True)
         ax_l, ah_l = [], []
-        for layer in self.pnca:
+        every = _FLUSH_EVERY["dec"] if self.training else 0
+        for i, layer in enumerate(self.pnca):
+            if every and i and i % every == 0:
+                x = ops.wgrad_flush_point(x)
             x, ax, ah = layer(x, memory, mask=info, x_band_width=x_band_width, h_band_width=h_band_width,
                               return_attn=return_attns, bw_dev=bw_dev)
             if return_attns:
