@@ -168,6 +168,43 @@ class _WgradOverlap:
 wgrad_overlap = _WgradOverlap()
 
 
+_branch_streams = []
+
+
+def parallel_branches(thunks, inputs=()):
+    """Run independent sub-networks (``thunks``: callables without arguments) each on its own HIP stream and join them:
+    the eight sub-discriminators of HiFi-GAN's MPD / MSD read the same waveform and share nothing, and a good half of
+    their launches are tiny (weight-norm re-parametrisations, 1-channel first layers, strided layers over a few thousand
+    tokens) -- back to back on one stream they leave most of the chip idle.  autograd replays every node on the stream of
+    its forward op, so the backward passes are concurrent as well.  ``inputs``: tensors allocated on the current stream
+    that the branches read (recorded on every branch stream for the caching allocator).  Sequential on the host, and
+    when ``KANTTS_NO_BRANCH_STREAMS=1`` also on the device."""
+    if (len(thunks) < 2 or not torch.cuda.is_available() or os.environ.get("KANTTS_NO_BRANCH_STREAMS", "") != ""
+            ):
+        return [t() for t in thunks]
+    dev_inputs = [t for t in inputs if torch.is_tensor(t) and t.is_cuda]
+    if not dev_inputs:
+        return [t() for t in thunks]
+    while len(_branch_streams) < len(thunks):
+        _branch_streams.append(torch.cuda.Stream())
+    main = torch.cuda.current_stream()
+    fork = torch.cuda.Event()
+    fork.record(main)
+    outs, done = [], []
+    for t, st in zip(thunks, _branch_streams):
+        st.wait_event(fork)
+        for x in dev_inputs:
+            x.record_stream(st)
+        with torch.cuda.stream(st):
+            outs.append(t())
+        ev = torch.cuda.Event()
+        ev.record(st)
+        done.append(ev)
+    for ev in done:
+        main.wait_event(ev)
+    return outs
+
+
 class _FlushPoint(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -207,12 +207,9 @@ class MultiPeriodDiscriminator(torch.nn.Module):
             self.discriminators += [PeriodDiscriminator(**params)]
 
     def forward(self, y):
-        y_d_rs, fmap_rs = [], []
-        for d in self.discriminators:
-            y_d_r, fmap_r = d(y)
-            y_d_rs.append(y_d_r)
-            fmap_rs.append(fmap_r)
-        return y_d_rs, fmap_rs
+        # the period discriminators are independent: one HIP stream each (ops.parallel_branches), forward and backward
+        outs = ops.parallel_branches([(lambda d=d: d(y)) for d in self.discriminators], inputs=(y,))
+        return [o[0] for o in outs], [o[1] for o in outs]
 
 
 class ScaleDiscriminator(torch.nn.Module):
@@ -311,17 +308,15 @@ class MultiScaleDiscriminator(torch.nn.Module):
                                         weight_norm(nn.Conv1d(2, 1, 15, 1, padding=7))])
 
     def forward(self, y):
-        y_d_rs, fmap_rs = [], []
-        h = y.transpose(1, 2).contiguous()
-        for i, d in enumerate(self.discriminators):
-            if i != 0:
-                h = self.meanpools[i - 1].forward_cl(h)
-                c = self.aux_convs[i - 1]
-                h = ops.conv_cl(h, effective_weight(c), c.bias, pad=7, out_leaky=0.1)
-            y_d_r, fmap_r = d.forward_cl(h)
-            y_d_rs.append(y_d_r)
-            fmap_rs.append(fmap_r)
-        return y_d_rs, fmap_rs
+        # the pooling chain is sequential (and cheap); the scale discriminators on its outputs are independent
+        hs = [y.transpose(1, 2).contiguous()]
+        for i in range(1, len(self.discriminators)):
+            h = self.meanpools[i - 1].forward_cl(hs[-1])
+            c = self.aux_convs[i - 1]
+            hs.append(ops.conv_cl(h, effective_weight(c), c.bias, pad=7, out_leaky=0.1))
+        outs = ops.parallel_branches([(lambda d=d, h=h: d.forward_cl(h)) for d, h in zip(self.discriminators, hs)],
+                                     inputs=hs)
+        return [o[0] for o in outs], [o[1] for o in outs]
 
 
 class SpecDiscriminator(torch.nn.Module):
