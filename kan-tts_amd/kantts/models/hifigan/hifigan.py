@@ -117,10 +117,16 @@ class Generator(torch.nn.Module):
                 h = up_layer.forward_cl(h, in_leaky=self.slope, res=rep, act=act)
             else:
                 h = up_layer.forward_cl(h, in_leaky=self.slope, res=rep)
-            xs = None
-            for j in range(self.num_kernels):
-                y = self.conv_blocks[i * self.num_kernels + j].forward_cl(h)
-                xs = y if xs is None else xs + y
+            # the num_kernels residual stacks of a stage read the same h and are summed: independent branches.  One stream
+            # each when a backward pass will follow (their weight gradients are the low-occupancy launches that gain:
+            # GAN step 66.9 -> 60.3 ms); a forward-only pass is a chain of chip-filling launches and is 9 % faster
+            # sequentially (4.09 vs 4.47 ms at batch 32 x 8192, profiles/r02_runAB_*)
+            blocks = self.conv_blocks[i * self.num_kernels:(i + 1) * self.num_kernels]
+            thunks = [(lambda b=b, h=h: b.forward_cl(h)) for b in blocks]
+            ys = ops.parallel_branches(thunks, inputs=(h,)) if torch.is_grad_enabled() else [t() for t in thunks]
+            xs = ys[0]
+            for y in ys[1:]:
+                xs = xs + y
             h = xs / self.num_kernels
         # F.leaky_relu default slope 0.01 (reference :178), fused into conv_post's loader
         h = self.conv_post.forward_cl(h, in_leaky=0.01)
