@@ -473,6 +473,16 @@ def linear(xs, weights, bias=None, *, mode=None, bias2=None, res=None, rowmask=N
     return _FusedLinear.apply(opts, bias, bias2, res, rowmask, *xs, *weights)
 
 
+def shared_input_linears(x, linears):
+    """``[lin(x) for lin in linears]`` for nn.Linear holders that all read the same tensor.  bf16 mode with gradients
+    enabled: forward as usual, but ONE input-gradient launch for all of them (ops_bf16._SharedInputLinearsB)."""
+    if get_precision() == "bf16" and torch.is_grad_enabled() and x.requires_grad:
+        outs = ops_bf16.shared_input_linears(x, [m.weight for m in linears], [m.bias for m in linears])
+        if outs is not None:
+            return outs
+    return [linear(x, m.weight, m.bias) for m in linears]
+
+
 # ================================================================================================
 # LayerNorm
 # ================================================================================================

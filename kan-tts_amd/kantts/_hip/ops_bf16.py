@@ -395,6 +395,69 @@ class _FusedFFNB(torch.autograd.Function):
         return (dh.view(*ctx.lead, C), dw1, db1, dw2, db2, d_res) + (None,) * 9
 
 
+class _SharedInputLinearsB(torch.autograd.Function):
+    """n Linear layers that read the SAME input (the memory K/V projections ``w_h_kv`` of every PNCA block,
+    kantts/models/sambert/__init__.py:286-299: all twelve read the length-regulated memory tensor).  Forward: one launch
+    per layer (independent outputs).  Backward: ONE launch for the input gradient -- sum_b dy_b . W_b is a contraction with
+    one segment per layer -- instead of n launches plus the n - 1 accumulation adds autograd inserts for a tensor with n
+    consumers; weight / bias gradients as everywhere (deferred, grouped by shape)."""
+
+    @staticmethod
+    def forward(ctx, x, n, *t):
+        ws, bs, wbs = t[:n], t[n:2 * n], t[2 * n:3 * n]
+        x = _c(x)
+        lead, K = x.shape[:-1], x.shape[-1]
+        M = int(math.prod(lead))
+        outs = []
+        for w, b, wb in zip(ws, bs, wbs):
+            N = w.shape[0]
+            y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+            if not bgemm_nt([(x.detach(), K, wb, K, K, 0)], M, N, y, N, bias=b):
+                raise RuntimeError("bgemm_nt declined a shared-input projection")
+            outs.append(y.view(*lead, N))
+        ctx.dims = (n, M, K, lead, [tuple(w.shape) for w in ws], [b is not None for b in bs], x.dtype)
+        ctx.save_for_backward(x.detach(), *wbs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        from .ops import gzeros, wgrad_overlap
+
+        n, M, K, lead, wshapes, has_b, x_dtype = ctx.dims
+        x, wbs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dev = x.device
+        dys = [torch.zeros((M, ws[0]), device=dev) if d is None else _c(d).view(M, ws[0]) for d, ws in zip(dys, wshapes)]
+        needs = ctx.needs_input_grad  # (x, n, *ws, *bs, *wbs)
+        dx = None
+        if needs[0]:
+            dx = torch.empty((M, K), device=dev, dtype=x_dtype)
+            segs = [(d, ws[0], wb, K, ws[0], 0) for d, ws, wb in zip(dys, wshapes, wbs)]
+            if not bgemm_nt(segs, M, K, dx, K, b_kn=True):
+                raise RuntimeError("bgemm_nt declined the shared input gradient")
+            dx = dx.view(*lead, K)
+        dws, dbs = [None] * n, [None] * n
+        for i, (d, ws) in enumerate(zip(dys, wshapes)):
+            if not needs[2 + i]:
+                continue
+            N = ws[0]
+            dw = gzeros(ws, dev)
+            db = gzeros((N,), dev) if (has_b[i] and needs[2 + n + i]) else None
+            with wgrad_overlap.side(d, x):
+                if not bgemm_tn(d, N, x, K, M, N, K, dw, K, 1, db=db):
+                    raise RuntimeError("bgemm_tn declined a shared-input weight gradient")
+            dws[i], dbs[i] = dw, db
+        return (dx, None) + tuple(dws) + tuple(dbs) + (None,) * n
+
+
+def shared_input_linears(x, weights, biases):
+    """[x @ W_i^T + b_i for i] for Linear weights W_i (N_i, K) that all read x; None when the bf16 kernels cannot take it."""
+    n = len(weights)
+    if n < 2 or n > 12 or x.shape[-1] % 8 or x.numel() == 0 or any(w.dim() != 2 or w.shape[0] % 8 or w.shape[1] != x.shape[-1]
+                                                                   for w in weights):
+        return None
+    return list(_SharedInputLinearsB.apply(x, n, *weights, *biases, *[bf16_weight(w) for w in weights]))
+
+
 def ffn_eligible(h, w1, w2):
     return (w1.dim() == 3 and w2.dim() == 3 and w2.shape[2] == 1 and w1.shape[2] <= 12 and w1.shape[0] % 8 == 0 and
             w1.shape[1] % 8 == 0 and w2.shape[0] % 8 == 0 and h.numel() > 0)

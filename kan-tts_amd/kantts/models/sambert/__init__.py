@@ -168,11 +168,14 @@ class MultiHeadPNCAAttention(nn.Module):
         self.x_state_size = 0
 
     def forward(self, x, h, info=None, x_band_width=0, h_band_width=0, zero_rows=None, return_attn=False,
-                bw_dev=None):
+                bw_dev=None, hkv=None):
+        """``hkv``: this block's memory K/V projection when the decoder computed all of them together
+        (ops.shared_input_linears: one input-gradient launch for the twelve blocks)."""
         xn, x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
                                with_res=True)
         qkv = ops.linear(xn, self.w_x_qkv.weight, self.w_x_qkv.bias)
-        hkv = ops.linear(h, self.w_h_kv.weight, self.w_h_kv.bias)
+        if hkv is None:
+            hkv = ops.linear(h, self.w_h_kv.weight, self.w_h_kv.bias)
         info = SeqInfo.of(info)
         ox, oh, attn_x, attn_h = ops.pnca_attention(
             qkv, hkv, None if info is None else info.lens32, x_band_width, h_band_width, self.n_head,
@@ -219,11 +222,12 @@ class PNCABlock(nn.Module):
         self.pos_ffn = PositionwiseConvFeedForward(d_model, d_inner, kernel_size, dropout_inner=dropout_relu,
                                                    dropout=dropout)
 
-    def forward(self, input, memory, mask=None, x_band_width=0, h_band_width=0, return_attn=False, bw_dev=None):
+    def forward(self, input, memory, mask=None, x_band_width=0, h_band_width=0, return_attn=False, bw_dev=None,
+                hkv=None):
         info = SeqInfo.of(mask)
         rows = None if info is None else info.mask
         output, ax, ah = self.pnca_attn(input, memory, info, x_band_width, h_band_width, zero_rows=rows,
-                                        return_attn=return_attn, bw_dev=bw_dev)
+                                        return_attn=return_attn, bw_dev=bw_dev, hkv=hkv)
         output = self.pos_ffn(output, mask=info, zero_rows=rows)
         return output, ax, ah
 

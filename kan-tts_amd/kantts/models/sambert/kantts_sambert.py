@@ -104,11 +104,13 @@ class HybridAttentionDecoder(nn.Module):
             x = F.dropout(x, p=self.dropout, training=True)
         ax_l, ah_l = [], []
         every = _FLUSH_EVERY["dec"] if self.training else 0
+        # the memory K/V projections of all blocks read the same tensor: computed here, one input-gradient launch
+        hkvs = ops.shared_input_linears(memory, [layer.pnca_attn.w_h_kv for layer in self.pnca])
         for i, layer in enumerate(self.pnca):
             if every and i and i % every == 0:
                 x = ops.wgrad_flush_point(x)
             x, ax, ah = layer(x, memory, mask=info, x_band_width=x_band_width, h_band_width=h_band_width,
-                              return_attn=return_attns, bw_dev=bw_dev)
+                              return_attn=return_attns, bw_dev=bw_dev, hkv=hkvs[i])
             if return_attns:
                 ax_l.append(ax)
                 ah_l.append(ah)

@@ -234,3 +234,32 @@ def test_ffn_pair_equals_the_two_launch_form(bf16_mode, k1, F, B, T):
     for a, b in zip(res[True], res[False]):
         assert a.shape == b.shape
         assert rel_l2(a, b) < 1e-5, rel_l2(a, b)
+
+
+def test_shared_input_linears_equal_separate_ones(bf16_mode):
+    """ops.shared_input_linears (the memory K/V projections of all PNCA blocks): same outputs as n separate fused linears,
+    and the single multi-segment input-gradient launch equals the sum autograd forms from n separate ones."""
+    import torch.nn as nn
+
+    from kantts._hip import ops
+
+    torch.manual_seed(4)
+    lins = [nn.Linear(160, 256) for _ in range(5)]
+    x0 = torch.randn(3, 17, 160)
+    cots = [torch.randn(3, 17, 256) for _ in lins]
+    res = []
+    with emulation():
+        for shared in (True, False):
+            x = x0.clone().requires_grad_(True)
+            for m in lins:
+                m.zero_grad()
+            ys = ops.shared_input_linears(x, lins) if shared else [ops.linear(x, m.weight, m.bias) for m in lins]
+            sum((y * c).sum() for y, c in zip(ys, cots)).backward()
+            res.append(([y.detach() for y in ys], x.grad.clone(), [m.weight.grad.clone() for m in lins],
+                        [m.bias.grad.clone() for m in lins]))
+    (ya, gxa, gwa, gba), (yb, gxb, gwb, gbb) = res
+    for a, b in zip(ya, yb):
+        assert torch.equal(a, b)
+    assert rel_l2(gxa, gxb) < 1e-3          # one bf16-operand contraction over 5 x 256 vs five fp32 partial sums
+    for a, b in zip(gwa + gba, gwb + gbb):
+        assert rel_l2(a, b) < 1e-6
