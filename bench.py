@@ -750,6 +750,9 @@ def main():
             "config": {"workload": "SAM-BERT full (sambert_16k.yaml zhcn) fwd+bwd+clip+Adam, batch %d/GPU, T_in 64, "
                                    "%d valid mel frames on rank 0, dropout on" % (args.batch, frames),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "launch": mode,
+                       "scheduling": ("one hipGraph per step: variance predictors as a parallel branch, deferred weight "
+                                      "gradients grouped by shape and issued from flush points in backward"
+                                      if mode == "graph" else "eager launches, one stream"),
                        "final_loss": float(loss.detach()), "per_rank_ms_per_step": per_rank_ms,
                        "collective_world_size": dist.get_world_size() if distributed else 1,
                        "collective_backend": ("nccl (RCCL)" if distributed else None)},
