@@ -48,12 +48,9 @@ def am_infer(sentence, ckpt, output_dir, se_file=None, config=None, ling_unit=No
         path = config if config is not None else os.path.join(os.path.dirname(os.path.dirname(ckpt)), "config.yaml")
         with open(path) as f:
             config = yaml.load(f, Loader=yaml.Loader)
-    if ling_unit is None:
-        try:
-            from kantts.preprocess.languages import KanTtsLinguisticUnit  # text front-end: not shipped here
-        except ImportError as exc:
-            raise ImportError("the text front-end (kantts.preprocess.languages) is not part of this package; pass "
-                              "ling_unit= (encode_symbol_sequence / get_unit_size / using_byte)") from exc
+    if ling_unit is None:  # symbol tables of this package; the sentences file holds symbol sequences, not raw text
+        from kantts.utils.ling_unit import KanTtsLinguisticUnit
+
         ling_unit = KanTtsLinguisticUnit(config)
     config["Model"]["KanTtsSAMBERT"]["params"].update(ling_unit.get_unit_size())
     if config["Model"]["KanTtsSAMBERT"]["params"].get("SE", False) or se_file is not None:

@@ -61,8 +61,7 @@ def train(model_config, root_dir, stage_dir, resume_path=None, resume_bert_path=
                                   sampler=sampler["valid"], **kw)
         config["Model"]["KanTtsSAMBERT"]["params"].update(train_set.ling_unit.get_unit_size())
     else:
-        raise ImportError("kantts.datasets is not installed (the data pipeline is outside this package): "
-                          "pass --synthetic N or install the reference's dataset module")
+        raise ImportError("kantts.datasets could not be imported: pass --synthetic N")
     model, optimizer, scheduler = model_builder(config, device, local_rank, distributed)
     criterion = criterion_builder(config, device) if "Loss" in config else None
     if not criterion:

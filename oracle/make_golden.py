@@ -395,6 +395,86 @@ def voc_dataset_case():
           [tuple(m.shape) for _, m in out["nsf"]["items"]])
 
 
+def am_dataset_case():
+    """The reference's KanTtsLinguisticUnit (utils/ling_unit/ling_unit.py:56-398) and AM_Dataset (datasets/dataset.py:
+    391-827) on a small synthetic data directory: symbol lines over the PinYin inventory (incl. a symbol outside it, which
+    the sy stream drops), three model variants (durations; NSF with globally re-normalised f0; MAS = no durations +
+    alignment prior), items, one collated batch each, and the seeded train / valid split of gen_metafile.  The phone /
+    tone inventories and every input file travel in the fixture so that the test can rebuild language and data
+    directories anywhere."""
+    import tempfile
+
+    import numpy as np
+
+    import kantts.datasets.dataset as D
+    from kantts.utils.ling_unit.lang_symbols import get_language_symbols
+    from kantts.utils.ling_unit.ling_unit import KanTtsLinguisticUnit
+
+    phones, tones, _, _ = get_language_symbols("PinYin")
+    rs = np.random.RandomState(5)
+    flags = ["s_begin", "s_end", "s_none", "s_both", "s_middle"]
+    segs = ["word_begin", "word_end", "word_middle", "word_both", "word_none"]
+    emos = ["emotion_neutral", "emotion_happy", "emotion_none"]
+    spks = ["F7", "M3"]
+
+    def line(n, spk):
+        groups = []
+        for i in range(n):
+            ph = phones[rs.randint(len(phones))] if rs.rand() > 0.08 else "not_a_phone"
+            groups.append("{%s$%s$%s$%s$%s$%s}" % (ph, tones[rs.randint(len(tones))], flags[rs.randint(5)],
+                                                  segs[rs.randint(5)], emos[rs.randint(3)], spk))
+        return " ".join(groups)
+
+    utts = {}
+    for k in range(12):
+        name = "u%02d" % k
+        n_sym = int(rs.randint(4, 11))
+        ling = line(n_sym, spks[k % 2])
+        dur = rs.randint(1, 6, size=n_sym).astype(np.int64)          # one duration per symbol (the "~" slot is the collate's)
+        frames = int(dur.sum())
+        utts[name] = dict(ling=ling, mel=rs.randn(frames, 80).astype(np.float32), dur=dur,
+                          f0=rs.randn(n_sym).astype(np.float32), energy=rs.randn(n_sym).astype(np.float32),
+                          frame_f0=rs.randn(frames).astype(np.float32), frame_uv=(rs.rand(frames) > 0.4).astype(np.float32))
+    f0_mean, f0_std = 201.5, 37.25
+    base_params = {"outputs_per_step": 3}
+    unit = {"cleaners": "english_cleaners", "speaker_list": "F7,M3",
+            "lfeat_type_list": "sy,tone,syllable_flag,word_segment,emo_category,speaker_category"}
+    variants = {"plain": {}, "nsf_global": {"NSF": True, "nsf_norm_type": "global", "nsf_f0_global_minimum": 30.0,
+                                            "nsf_f0_global_maximum": 730.0}, "mas": {"MAS": True}}
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for sub in ("mel", "duration", "f0", "energy", "frame_f0", "frame_uv"):
+            os.makedirs(os.path.join(d, sub))
+        for name, u in utts.items():
+            for sub, key in (("mel", "mel"), ("duration", "dur"), ("f0", "f0"), ("energy", "energy"),
+                             ("frame_f0", "frame_f0"), ("frame_uv", "frame_uv")):
+                np.save(os.path.join(d, sub, name + ".npy"), u[key])
+        np.savetxt(os.path.join(d, "f0", "f0_mean.txt"), np.array([f0_mean]))
+        np.savetxt(os.path.join(d, "f0", "f0_std.txt"), np.array([f0_std]))
+        raw = os.path.join(d, "raw_metafile.txt")
+        with open(raw, "w") as f:
+            for name in sorted(utts):
+                f.write("%s\t%s\n" % (name, utts[name]["ling"]))
+        os.remove(os.path.join(d, "duration", "u07.npy"))                  # dropped by gen_metafile (no duration file)
+        tr, va = os.path.join(d, "am_train.lst"), os.path.join(d, "am_valid.lst")
+        D.AM_Dataset.gen_metafile(raw, d, tr, va, badlist=["u03"], split_ratio=0.8)
+        split = dict(train=open(tr).read(), valid=open(va).read())
+        for tag, extra in variants.items():
+            config = {"linguistic_unit": dict(unit), "Model": {"KanTtsSAMBERT": {"params": dict(base_params, **extra)}}}
+            ds = D.AM_Dataset(config, tr, d, allow_cache=False)
+            items = [ds[i] for i in range(len(ds))]
+            batch = ds.collate_fn(items[:5])
+            out[tag] = dict(items=items, batch=batch, with_duration=ds.with_duration)
+        lu = KanTtsLinguisticUnit({"linguistic_unit": dict(unit), "Model": {"KanTtsSAMBERT": {"params": dict(base_params)}}})
+        sizes, pads = lu.get_unit_size(), dict(lu._sub_unit_pad)
+    torch.save(dict(phones=phones[:-4], tones_file=[t[4:] if t != "tone_none" else "" for t in tones], utts=utts,
+                    f0_mean=f0_mean, f0_std=f0_std, unit=unit, base_params=base_params, variants=variants, split=split,
+                    missing_duration="u07", badlist=["u03"], split_ratio=0.8, unit_size=sizes, pad_ids=pads, expected=out),
+               os.path.join(OUT, "am_dataset.pt"))
+    print("am_dataset bytes", os.path.getsize(os.path.join(OUT, "am_dataset.pt")), sizes,
+          [len(out[k]["items"]) for k in out], split["valid"].count("\n"))
+
+
 def mas_dp_case():
     """b_mas (alignment.py:63-71; numba replaced by the identity jit of ref_harness, i.e. its plain-Python semantics)
     on random soft maps, on maps with exact ties (uniform rows) and with zeros (log -> -inf)."""
@@ -540,6 +620,7 @@ if __name__ == "__main__":
     sambert_curve_case()
     gan_curve_case()
     voc_dataset_case()
+    am_dataset_case()
     hifigan_v1_case()
     masks_case()
     multiband_case()
