@@ -608,6 +608,71 @@ int kantts_sinadd_lrelu_fwd(const float* x, float* y, void* act_bf16, float slop
 int kantts_dropout2_add(const float* x, const float* res, float* y, long long n, float p1, uint64_t seed1, float p2,
                         uint64_t seed2, const uint64_t* seed_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * bf16 convolution contractions for the HiFi-GAN layers (csrc/cconv.hip, round 3): the same token rule as
+ * kantts_conv_win_launch, but both operands are bf16 IN MEMORY (activations pre-activated by their producer, weights a
+ * bf16 tap-major image) and are copied global -> LDS by `global_load_lds` (16 bytes per lane, no VGPR staging, no
+ * conversion); a tile's rows run across batch items, padding / phase / group edges are lanes whose source address is a
+ * 16-byte block of zeros.  Replaces Conv1d / CausalConv1d / the (k,1) Conv2d of the period discriminators / the
+ * polyphase form of ConvTranspose1d and their input gradients (kantts/models/hifigan/layers.py:15-165,
+ * hifigan.py:200-267,305-407) for channel counts that are multiples of 8.
+ *   for phase in [0, phases), m in [0, ceil((Tdst - phase) / phases)):      d = m*phases + phase
+ *     v[b,d,p,n] = bias[n] + sum_{k : u_k % in_div == 0} sum_c in[b, (m*in_mul + u_k/in_div) / up, p, g*CR + c] * w[k][n][c]
+ *     u_k = in_add + phase + k*in_kstep;  virtual source tokens outside [0, Tsrc*up) contribute 0;  g = n / NG
+ *     v = LeakyReLU(v, out_slope) when out_act;  v += res;  v *= (out_gate > 0 ? 1 : out_gate_slope)
+ *     out[b,d,p,n] = v (fp32, optional);  out_bf[b,d,p,n] = bf16(bf_act ? LeakyReLU(v, bf_slope) : v) (optional)
+ * in (B, Tsrc, inner, Cin_tot) bf16;  w (K, Ntot, CR) bf16;  bias / res fp32;  out_gate bf16 (out_gate_bf16) or fp32.
+ * KANTTS_E_UNSUPPORTED unless CR % 8 == 0, NG % 8 == 0, K <= 64, phases <= 8 and all pointers are 16-byte aligned. */
+typedef struct {
+  const void* in;
+  const void* w;
+  const float* bias;
+  const float* res;
+  const void* out_gate;
+  float* out;
+  void* out_bf;
+  int B, Tsrc, Tdst, Cin_tot, Ntot, CR, NG, groups, K;
+  int in_mul, in_add, in_kstep, in_div, phases;
+  int inner;
+  int up;
+  float out_slope;
+  int out_act;
+  float out_gate_slope;
+  int out_gate_bf16;
+  float bf_slope;
+  int bf_act;
+  int tile; /* 0 = automatic; else BM*1000 + BN of a compiled tile (bench / tests) */
+} kantts_cconv_args;
+int kantts_cconv_launch(const kantts_cconv_args* args, void* stream);
+
+/* Weight / bias gradients of the same convolutions from bf16 operands (csrc/cconv.hip):
+ *   dw[k][n][c] += sum_{b,p,q} dy[b,q,p,n] * x[b, (q*stride + k*dil - pad) / up, p, g*CR + c];   db[n] += sum dy[b,q,p,n]
+ * x (B, Tsrc, inner, Cin_tot) bf16 (already activated), dy (B, Tdst, inner, Ntot) bf16 (already gated); dw tap-major
+ * (K, Ntot, CR) fp32, db fp32 or NULL.  Every workgroup owns one (tap, 128 x 128) output tile and walks a contiguous
+ * slice of the tokens; `slices` > 1 splits the token axis (0 = automatic: 1 whenever the output tiles alone fill the
+ * chip).  The slices' partial tiles go to `workspace` (caller-owned, >= kantts_cconv_wgrad_ws_floats(args) floats, 16-byte
+ * aligned, contents irrelevant) and are summed into dw by a second kernel in a fixed order; without a workspace they
+ * meet in fp32 atomics.  dw / db must be zero (or hold a value to accumulate onto) before the call. */
+typedef struct {
+  const void* x;
+  const void* dy;
+  float* dw;
+  float* db;
+  int B, Tsrc, Tdst, Cin_tot, Ntot, CR, NG, groups, K;
+  int stride, dil, pad, inner, up;
+  int slices;
+  float* workspace;
+  long long ws_floats;
+} kantts_cconvw_args;
+int kantts_cconv_wgrad_launch(const kantts_cconvw_args* args, void* stream);
+long long kantts_cconv_wgrad_ws_floats(const kantts_cconvw_args* args);
+
+/* dst = bf16(f(src)) over a flat fp32 buffer, n % 8 == 0: the bf16 operand images the kernels above read.
+ *   gate == NULL:  f(v) = act ? LeakyReLU(v, slope) : v                  (activated input image)
+ *   gate != NULL:  f(v) = v * (gate > 0 ? 1 : slope)                     (gated output gradient; gate fp32 or bf16) */
+int kantts_act_cast_bf16(const float* src, const void* gate, int gate_bf16, void* dst, int act, float slope, long long n,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,31 @@ class ConvC1Args(Structure):
     ]
 
 
+class CConvArgs(Structure):
+    """kantts_cconv_args (include/kantts_hip.h); ``in_`` is the C field ``in``."""
+    _fields_ = [
+        ("in_", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("res", c_void_p), ("out_gate", c_void_p),
+        ("out", c_void_p), ("out_bf", c_void_p),
+        ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cin_tot", c_int32), ("Ntot", c_int32),
+        ("CR", c_int32), ("NG", c_int32), ("groups", c_int32), ("K", c_int32),
+        ("in_mul", c_int32), ("in_add", c_int32), ("in_kstep", c_int32), ("in_div", c_int32), ("phases", c_int32),
+        ("inner", c_int32), ("up", c_int32),
+        ("out_slope", c_float), ("out_act", c_int32), ("out_gate_slope", c_float), ("out_gate_bf16", c_int32),
+        ("bf_slope", c_float), ("bf_act", c_int32), ("tile", c_int32),
+    ]
+
+
+class CConvWArgs(Structure):
+    """kantts_cconvw_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("db", c_void_p),
+        ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cin_tot", c_int32), ("Ntot", c_int32),
+        ("CR", c_int32), ("NG", c_int32), ("groups", c_int32), ("K", c_int32),
+        ("stride", c_int32), ("dil", c_int32), ("pad", c_int32), ("inner", c_int32), ("up", c_int32),
+        ("slices", c_int32), ("workspace", c_void_p), ("ws_floats", c_longlong),
+    ]
+
+
 BGEMM_MAX_SEG = 12
 
 
@@ -222,6 +247,11 @@ def lib():
         L.kantts_relu_gate_bf16.argtypes = [p, i, p, i, p, f, ll, p]
         L.kantts_ln128_fwd.argtypes = [p, p, p, p, i, p, p, i, f, p]
         L.kantts_ln128_bwd.argtypes = [p, i, p, p, p, p, p, p, p, p, i, p]
+        L.kantts_cconv_launch.argtypes = [POINTER(CConvArgs), c_void_p]
+        L.kantts_cconv_wgrad_launch.argtypes = [POINTER(CConvWArgs), c_void_p]
+        L.kantts_cconv_wgrad_ws_floats.argtypes = [POINTER(CConvWArgs)]
+        L.kantts_cconv_wgrad_ws_floats.restype = ll
+        L.kantts_act_cast_bf16.argtypes = [p, p, i, p, i, f, ll, p]
         _lib = L
     return _lib
 
@@ -238,6 +268,7 @@ EXPORTED_SYMBOLS = [
     "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
     "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
+    "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
 ]
 
 
@@ -660,6 +691,95 @@ def conv_wgrad(x, dy, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, d
     return True
 
 
+def act_cast_bf16(src, *, act_slope=None, gate=None, gate_slope=0.0, dst=None):
+    """bf16 operand image of an fp32 tensor (csrc/cconv.hip): LeakyReLU(src) when ``act_slope`` is given, or
+    src * (gate > 0 ? 1 : gate_slope) when ``gate`` (fp32 or bf16, same shape) is given, else a plain cast."""
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    gate_bf = gate is not None and gate.dtype == torch.bfloat16
+    check(lib().kantts_act_cast_bf16(ptr(src, torch.float32), ptr(gate), int(gate_bf), ptr(dst, torch.bfloat16),
+                                     int(act_slope is not None), float(gate_slope if gate is not None else (act_slope or 0.0)),
+                                     src.numel(), stream()), "act_cast_bf16")
+    return dst
+
+
+def cconv(x_bf, w_bf, *, out=None, out_bf=None, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add, in_kstep, in_div, phases,
+          inner=1, up=1, bias=None, res=None, out_leaky=None, out_gate=None, out_gate_slope=0.0, bf_leaky=None, tile=0):
+    """bf16 convolution contraction (csrc/cconv.hip, kantts_cconv_launch): x_bf (B, Tsrc, inner, groups*CR) bf16,
+    w_bf (K, groups*NG, CR) bf16; writes ``out`` (fp32) and / or ``out_bf`` (bf16, optionally LeakyReLU'd by
+    ``bf_leaky``).  Returns False when the kernel does not take the shape."""
+    if os.environ.get("KANTTS_NO_CCONV"):
+        return False
+    g = CConvArgs()
+    g.in_, g.w = ptr(x_bf, torch.bfloat16), ptr(w_bf, torch.bfloat16)
+    g.bias, g.res = ptr(bias, torch.float32), ptr(res, torch.float32)
+    g.out_gate = ptr(out_gate)
+    g.out_gate_bf16 = int(out_gate is not None and out_gate.dtype == torch.bfloat16)
+    g.out, g.out_bf = ptr(out, torch.float32), ptr(out_bf, torch.bfloat16)
+    g.B, g.Tsrc, g.Tdst = int(B), int(Tsrc), int(Tdst)
+    g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K = int(groups * CR), int(groups * NG), int(CR), int(NG), int(groups), int(K)
+    g.in_mul, g.in_add, g.in_kstep, g.in_div, g.phases = int(in_mul), int(in_add), int(in_kstep), int(in_div), int(phases)
+    g.inner, g.up = int(inner), int(up)
+    if out_leaky is not None:
+        g.out_act, g.out_slope = 1, float(out_leaky)
+    g.out_gate_slope = float(out_gate_slope)
+    if bf_leaky is not None:
+        g.bf_act, g.bf_slope = 1, float(bf_leaky)
+    g.tile = int(tile)
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().kantts_cconv_launch(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "cconv")
+    if _profile is not None:
+        e1.record()
+        _profile.append((e0, e1, 2.0 * B * Tdst * inner * groups * NG * CR * K / max(1, in_div)))
+        _profile_tags.append(("cconv", dict(B=B, Tsrc=Tsrc, Tdst=Tdst, inner=inner, Cin=groups * CR, Cout=groups * NG,
+                                            groups=groups, K=K, in_mul=in_mul, in_div=in_div, up=up,
+                                            gated=out_gate is not None, res=res is not None),
+                              2.0 * B * Tsrc * inner * groups * CR + 2.0 * K * groups * NG * CR +
+                              B * Tdst * inner * groups * NG * (4.0 * (out is not None) + 2.0 * (out_bf is not None) +
+                                                                4.0 * (res is not None) +
+                                                                (0.0 if out_gate is None else out_gate.element_size()))))
+    return True
+
+
+def cconv_wgrad(x_bf, dy_bf, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, dil, pad, inner=1, up=1, slices=0):
+    """Weight / bias gradient from bf16 operands (kantts_cconv_wgrad_launch): accumulates into dw_tap (K, groups*NG, CR)
+    fp32 and db.  Returns False when the kernel does not take the shape."""
+    if os.environ.get("KANTTS_NO_CCONV"):
+        return False
+    g = CConvWArgs()
+    g.x, g.dy = ptr(x_bf, torch.bfloat16), ptr(dy_bf, torch.bfloat16)
+    g.dw, g.db = ptr(dw_tap, torch.float32), ptr(db, torch.float32)
+    g.B, g.Tsrc, g.Tdst = int(B), int(Tsrc), int(Tdst)
+    g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K = int(groups * CR), int(groups * NG), int(CR), int(NG), int(groups), int(K)
+    g.stride, g.dil, g.pad, g.inner, g.up, g.slices = int(stride), int(dil), int(pad), int(inner), int(up), int(slices)
+    # partial tiles of the token slices: a scratch buffer from the caching allocator (ordered on the launch stream)
+    nws = int(lib().kantts_cconv_wgrad_ws_floats(ctypes.byref(g)))
+    ws = None
+    if nws > 0:
+        ws = torch.empty(nws, device=dw_tap.device, dtype=torch.float32)
+        g.workspace, g.ws_floats = ptr(ws), nws
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().kantts_cconv_wgrad_launch(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "cconv_wgrad")
+    if _profile is not None:
+        e1.record()
+        _profile.append((e0, e1, 2.0 * B * Tdst * inner * groups * NG * CR * K))
+        _profile_tags.append(("cconv_wgrad", dict(B=B, Tsrc=Tsrc, Tdst=Tdst, inner=inner, Cin=groups * CR, Cout=groups * NG,
+                                                  groups=groups, K=K, stride=stride, dil=dil, up=up, gated=False),
+                              2.0 * (B * Tsrc * inner * groups * CR + B * Tdst * inner * groups * NG) +
+                              4.0 * K * groups * NG * CR))
+    return True
+
+
 def conv_c1(mode, *, x=None, dx=None, y=None, gate=None, w=None, bias=None, dw=None, db=None, B, Tsrc, Tdst, Cout, K,
             stride, dil, pad, inner=1, out_leaky=None, gate_slope=0.0):
     """Single-input-channel convolution kernels (csrc/conv_c1.hip): mode 0 forward, 1 input gradient, 2 weight /
@@ -745,4 +865,4 @@ def profile_end_by_shape():
 def _tag_flops(tag):
     kern, s, _ = tag
     f = 2.0 * s["B"] * s["Tdst"] * s["inner"] * s["Cout"] * (s["Cin"] // s["groups"]) * s["K"]
-    return f / max(1, s.get("in_div", 1)) if kern == "conv_win" else f
+    return f / max(1, s.get("in_div", 1)) if kern in ("conv_win", "cconv") else f

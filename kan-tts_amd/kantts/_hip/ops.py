@@ -10,8 +10,8 @@ import math
 
 import torch
 
-from . import (bgemm_nt, bgemm_tn, check, get_precision, conv_c1, conv_wgrad, conv_win, gemm, lib, make_seg, ptr,
-               rng_state, stream)
+from . import (act_cast_bf16, bgemm_nt, bgemm_tn, cconv, cconv_wgrad, check, get_precision, conv_c1, conv_wgrad, conv_win,
+               gemm, lib, make_seg, ptr, rng_state, stream)
 from . import ops_bf16
 
 _seed_counter = itertools.count(1)
@@ -1238,16 +1238,177 @@ class _ConvCL(torch.autograd.Function):
         return dx, dw, db, (dy if has_res else None), None
 
 
+# bf16 mode: convolutions above this many multiply-adds x 2 run on csrc/cconv.hip (bf16 operand images + global_load_lds
+# tiles); smaller ones keep the fp32-operand kernels (two extra cast launches would cost more than they save)
+CCONV_MIN_FLOPS = float(os.environ.get("KANTTS_CCONV_MIN_FLOPS", 2e8))
+
+
+def _cconv_ok(x, Cin_g, Cout_g, K, M, groups):
+    return (get_precision() == "bf16" and not os.environ.get("KANTTS_NO_CCONV") and Cin_g % 8 == 0 and Cout_g % 8 == 0
+            and K <= 64 and x.dtype == torch.float32
+            and 2.0 * M * groups * Cout_g * Cin_g * K >= CCONV_MIN_FLOPS)
+
+
+class _CConvCL(torch.autograd.Function):
+    """The contract of _ConvCL on csrc/cconv.hip (bf16 mode, channel counts that are multiples of 8): the activated
+    input is rounded to bf16 ONCE (act_cast_bf16) and that image serves the forward contraction, the weight gradient
+    and the LeakyReLU' gate of the input gradient; the incoming gradient is gated and rounded once and serves both
+    gradient contractions.  Reference: kantts/models/hifigan/layers.py:15-91, hifigan.py:82-97,217-267,332-407."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, cfg, x_img):
+        x, w = _c(x), _c(w)
+        stride, dil, pad, up, groups = cfg["stride"], cfg["dilation"], cfg["pad"], cfg["up"], cfg["groups"]
+        inner, Tout = cfg["inner"], cfg["Tout"]
+        B, Tin, Cin = x.shape[0], x.shape[1], x.shape[-1]
+        tap_major = cfg.get("tap_major", False)
+        if tap_major:
+            K, Cout, Cin_g = w.shape
+            wt = w
+        else:
+            Cout, Cin_g, K = w.shape
+            wt = w.permute(2, 0, 1)
+        Cout_g = Cout // groups
+        # the bf16 image of the activated input: handed over by the producer (an epilogue wrote it) or made here
+        xa = x_img if x_img is not None else act_cast_bf16(x, act_slope=cfg["in_leaky"])
+        # small groups (the scale discriminators' 8 -> 16 / 16 -> 32 channel groups) are merged P at a time into dense
+        # block-diagonal groups, as in _ConvCL: a 32-deep x 32-wide MFMA tile is the least the kernel can fill
+        P = _group_pack(groups, Cin_g, Cout_g) if up == 1 else 1
+        if P > 1:
+            wb = _blockdiag_pack(wt.reshape(K, Cout, Cin_g), groups, P).to(torch.bfloat16)
+        else:
+            wb = torch.empty((K, Cout, Cin_g), device=x.device, dtype=torch.bfloat16).copy_(wt)
+        y = torch.empty((B, Tout, inner, Cout) if x.dim() == 4 else (B, Tout, Cout), device=x.device, dtype=torch.float32)
+        # cfg["image"]: also write bf16(LeakyReLU(y, slope)) (slope None: bf16(y)) for the convolution that consumes y
+        want = cfg.get("image", False)
+        y_img = torch.empty(y.shape, device=x.device, dtype=torch.bfloat16) if want is not False else None
+        r = _c(res) if res is not None else None
+        if not cconv(xa, wb, out=y, out_bf=y_img, bf_leaky=want if want is not False else None, B=B, Tsrc=Tin, Tdst=Tout,
+                     groups=groups // P, CR=P * Cin_g, NG=P * Cout_g, K=K, in_mul=stride, in_add=-pad, in_kstep=dil, in_div=1,
+                     phases=1, inner=inner, up=up, bias=bias, res=r, out_leaky=cfg["out_leaky"]):
+            raise RuntimeError("cconv refused a shape _cconv_ok accepted")
+        ctx.cfg = cfg
+        ctx.has = (bias is not None, res is not None)
+        ctx.xshape = tuple(x.shape)
+        ctx.save_for_backward(xa, w, y if cfg["out_leaky"] is not None else None)
+        ctx.res_for_gate = r if cfg["out_leaky"] is not None else None
+        if y_img is None:
+            return y
+        ctx.mark_non_differentiable(y_img)
+        return y, y_img
+
+    @staticmethod
+    def backward(ctx, dy, _dimg=None):
+        cfg = ctx.cfg
+        xa, w, y = ctx.saved_tensors
+        has_bias, has_res = ctx.has
+        stride, dil, pad, up, groups = cfg["stride"], cfg["dilation"], cfg["pad"], cfg["up"], cfg["groups"]
+        inner, Tout = cfg["inner"], cfg["Tout"]
+        dy = _c(dy)
+        B, Tin, Cin = xa.shape[0], xa.shape[1], xa.shape[-1]
+        tap_major = cfg.get("tap_major", False)
+        if tap_major:
+            K, Cout, Cin_g = w.shape
+        else:
+            Cout, Cin_g, K = w.shape
+        Cout_g = Cout // groups
+        gate, gslope = (y, cfg["out_leaky"]) if cfg["out_leaky"] is not None else (None, 0.0)
+        if gate is not None and ctx.res_for_gate is not None:
+            gate = y - ctx.res_for_gate
+        dyb = act_cast_bf16(dy, gate=gate, gate_slope=gslope)
+        dx = dw = db = None
+        in_gate = xa if cfg["in_leaky"] is not None else None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+            if tap_major:
+                wd = w.view(K, groups, Cout_g, Cin_g).transpose(2, 3)
+            else:
+                wd = w.view(groups, Cout_g, Cin_g, K).permute(3, 0, 2, 1)  # (K, groups, Cin_g, Cout_g)
+            if up > 1 and stride == 1:
+                # one strided pass over dy with the combined taps W'[j] (see _ConvCL.backward)
+                S, jmin = _upsample_tap_matrix(K, up, pad, dil, dy.device)
+                wj = torch.matmul(S, wd.reshape(K, -1)).to(torch.bfloat16)
+                ok = cconv(dyb, wj, out=dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups, CR=Cout_g, NG=Cin_g, K=S.shape[0],
+                           in_mul=up, in_add=jmin, in_kstep=1, in_div=1, phases=1, inner=inner, out_gate=in_gate,
+                           out_gate_slope=cfg["in_leaky"] or 0.0)
+            elif up == 1:
+                Pd = _group_pack(groups, Cout_g, Cin_g)
+                if Pd > 1:
+                    wdb = _blockdiag_pack(wd.reshape(K, Cin, Cout_g), groups, Pd).to(torch.bfloat16)
+                else:
+                    wdb = torch.empty((K, Cin, Cout_g), device=dy.device, dtype=torch.bfloat16).copy_(wd.reshape(K, Cin, Cout_g))
+                ok = cconv(dyb, wdb, out=dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups // Pd, CR=Pd * Cout_g, NG=Pd * Cin_g,
+                           K=K, in_mul=1, in_add=pad, in_kstep=-dil, in_div=stride, phases=stride, inner=inner,
+                           out_gate=in_gate, out_gate_slope=cfg["in_leaky"] or 0.0)
+            else:
+                ok = False
+            if not ok:
+                raise RuntimeError("cconv input gradient refused a shape its forward accepted")
+        if ctx.needs_input_grad[1]:
+            Pw = _group_pack(groups, Cin_g, Cout_g) if up == 1 else 1
+            dwt = gzeros((K, Cout, Pw * Cin_g), dy.device)
+            db = gzeros((Cout,), dy.device) if has_bias else None
+            if not cconv_wgrad(xa, dyb, dwt, db, B=B, Tsrc=Tin, Tdst=Tout, groups=groups // Pw, CR=Pw * Cin_g,
+                               NG=Pw * Cout_g, K=K, stride=stride, dil=dil, pad=pad, inner=inner, up=up):
+                raise RuntimeError("cconv weight gradient refused a shape its forward accepted")
+            if Pw > 1:
+                dwt = _blockdiag_unpack(dwt, groups, Pw)
+            dw = dwt if tap_major else dwt.permute(1, 2, 0)
+        elif has_bias and ctx.needs_input_grad[2]:
+            raise RuntimeError("bias gradient without weight gradient is not supported")
+        return dx, dw, db, (dy if has_res else None), None, None
+
+
+_IMG_ATTR = "_kantts_bf16_image"
+
+
+def set_image(t, slope, img):
+    """Attach bf16(LeakyReLU(t, slope)) (slope None: bf16(t)) to the tensor object ``t``: the next convolution that reads
+    ``t`` with that activation takes it as its operand image instead of making one (bf16 mode).  The attribute lives on
+    the Python object only -- views and copies do not carry it, which is the safe direction."""
+    setattr(t, _IMG_ATTR, (slope, img))
+    return t
+
+
+def get_image(t, slope):
+    hit = getattr(t, _IMG_ATTR, None)
+    if hit is not None and hit[0] == slope and hit[1].shape == t.shape and hit[1].device == t.device:
+        return hit[1]
+    return None
+
+
+def act_image(t, slope):
+    """Make (once) and attach the bf16 image of LeakyReLU(t, slope) in bf16 mode; a no-op otherwise.  Call it before
+    forking parallel branches that all read ``t``: the image is then produced once, on the forking stream."""
+    if get_precision() != "bf16" or not t.is_floating_point() or t.dtype != torch.float32 or t.numel() % 8:
+        return t
+    if get_image(t, slope) is None:
+        set_image(t, slope, act_cast_bf16(_c(t.detach()), act_slope=slope))
+    return t
+
+
 def conv_cl(x, w, bias=None, *, stride=1, dilation=1, pad=0, Tout=None, up=1, groups=1, inner=1, in_leaky=None,
-            out_leaky=None, res=None, tap_major=False):
+            out_leaky=None, res=None, tap_major=False, image=False):
     """pad = left padding in (upsampled) input samples; Tout defaults to the 'same'/causal length.
-    tap_major: w is (K, Cout, Cin_g) (ops.weight_norm_tap) instead of the parameter layout (Cout, Cin_g, K)."""
+    tap_major: w is (K, Cout, Cin_g) (ops.weight_norm_tap) instead of the parameter layout (Cout, Cin_g, K).
+    image: a slope (or None for no activation) asks the bf16-mode kernel to also write the bf16 image of
+    LeakyReLU(result, slope) and attach it to the result (set_image) for the convolution that consumes it; ignored by the
+    fp32-operand kernels."""
     K = w.shape[0] if tap_major else w.shape[-1]
     Tin = x.shape[1]
     if Tout is None:
         Tout = Tin * up if stride == 1 else (Tin + 2 * pad - dilation * (K - 1) - 1) // stride + 1
     cfg = dict(stride=int(stride), dilation=int(dilation), pad=int(pad), Tout=int(Tout), up=int(up), groups=int(groups),
                inner=int(inner), in_leaky=in_leaky, out_leaky=out_leaky, tap_major=bool(tap_major))
+    Cout, Cin_g = (w.shape[1], w.shape[2]) if tap_major else (w.shape[0], w.shape[1])
+    if (up == 1 or stride == 1) and _cconv_ok(x, Cin_g, Cout // int(groups), K, x.shape[0] * int(Tout) * int(inner),
+                                                int(groups)):
+        x_img = get_image(x, in_leaky) if x.is_contiguous() else None
+        if image is False:
+            return _CConvCL.apply(x, w, bias, res, cfg, x_img)
+        cfg["image"] = image
+        y, y_img = _CConvCL.apply(x, w, bias, res, cfg, x_img)
+        return set_image(y, image, y_img)
     return _ConvCL.apply(x, w, bias, res, cfg)
 
 
@@ -1266,14 +1427,24 @@ class _ConvTransposeCL(torch.autograd.Function):
         _, Cout, K = w.shape
         assert K % s == 0
         taps = K // s
-        if act is not None and taps == 2 and get_precision() == "bf16":
-            # bf16 mode with the activated bf16 image of x at hand: forward through the streaming / two-segment kernels
-            # (backward below is unchanged: it works from the saved fp32 x)
-            y = upsample_forward(act, w, bias, s, res=res)
-            if y is not None:
-                ctx.cfg = (s, in_leaky, bias is not None, res is not None)
-                ctx.save_for_backward(x, w)
-                return y
+        ctx.bf = False
+        if _cconv_ok(x, Cin, s * Cout, taps, B * Tin, 1) and Tin >= 16:
+            # bf16 mode: the activated bf16 image of x (handed over by the producer, or made here in one pass) feeds the
+            # forward contraction, the weight gradient and the LeakyReLU' gate of the input gradient
+            xa = act if act is not None else act_cast_bf16(x, act_slope=in_leaky)
+            y = upsample_forward(xa, w, bias, s, res=res) if taps == 2 else None
+            if y is None:
+                y = torch.empty((B, Tin * s, Cout), device=x.device, dtype=torch.float32)
+                w2b = w.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).to(torch.bfloat16).contiguous()  # (taps, s, Cout, Cin)
+                if not cconv(xa, w2b, out=y, B=B, Tsrc=Tin, Tdst=Tin, groups=1, CR=Cin, NG=s * Cout, K=taps, in_mul=1,
+                             in_add=0, in_kstep=-1, in_div=1, phases=1, bias=bias.repeat(s) if bias is not None else None,
+                             res=_c(res) if res is not None else None):
+                    raise RuntimeError("cconv refused a transposed convolution _cconv_ok accepted")
+            ctx.bf = True
+            ctx.cfg = (s, in_leaky, bias is not None, res is not None)
+            ctx.xshape = tuple(x.shape)
+            ctx.save_for_backward(xa, w)
+            return y
         y = torch.empty((B, Tin * s, Cout), device=x.device, dtype=torch.float32)
         r_t = _c(res) if res is not None else None
         w2 = w.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).contiguous()  # (taps, s, Cout, Cin)
@@ -1302,6 +1473,27 @@ class _ConvTransposeCL(torch.autograd.Function):
         N2 = s * Cout
         M = B * Tin
         dx = dw = db = None
+        if ctx.bf:  # x is the bf16 activated image
+            dyb = act_cast_bf16(dy)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+                w3b = w.view(Cin, Cout, taps, s).permute(2, 0, 3, 1).to(torch.bfloat16).contiguous()  # (taps, Cin, s, Cout)
+                if not cconv(dyb, w3b, out=dx, B=B, Tsrc=Tin, Tdst=Tin, groups=1, CR=N2, NG=Cin, K=taps, in_mul=1, in_add=0,
+                             in_kstep=1, in_div=1, phases=1, out_gate=x if in_leaky is not None else None,
+                             out_gate_slope=in_leaky or 0.0):
+                    raise RuntimeError("cconv input gradient refused a transposed convolution")
+            if ctx.needs_input_grad[1]:
+                dw2 = gzeros((taps, N2, Cin), dy.device)
+                db2 = gzeros((N2,), dy.device) if (has_bias and ctx.needs_input_grad[2]) else None
+                if not cconv_wgrad(x, dyb, dw2, db2, B=B, Tsrc=Tin, Tdst=Tin, groups=1, CR=Cin, NG=N2, K=taps, stride=1,
+                                   dil=1, pad=taps - 1):
+                    raise RuntimeError("cconv weight gradient refused a transposed convolution")
+                dw = dw2.flip(0).view(taps, s, Cout, Cin).permute(3, 2, 0, 1).reshape(Cin, Cout, K)
+                if db2 is not None:
+                    db = db2.view(s, Cout).sum(0)
+            elif has_bias and ctx.needs_input_grad[2]:
+                db = dy.sum(dim=(0, 1))
+            return dx, dw, db, (dy if has_res else None), None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             w3 = w.view(Cin, Cout, taps, s).permute(2, 0, 3, 1).contiguous()  # (taps, Cin, s, Cout)
@@ -1489,16 +1681,19 @@ def sin_add(x, act_slope=None):
 
 
 def upsample_weights(w, s):
-    """(Cin, Cout, 2s) transposed-conv weight -> (linear, permuted) bf16 polyphase matrices (s*Cout, 2*Cin): row (r, co),
-    column (j, ci) = w[ci, co, r + j*s]; the permuted copy orders rows for csrc/upsample.hip's 16-byte stores."""
+    """(Cin, Cout, 2s) transposed-conv weight -> bf16 polyphase images.  Narrow layers (csrc/upsample.hip): (linear,
+    permuted) matrices (s*Cout, 2*Cin), row (r, co), column (j, ci) = w[ci, co, r + j*s], the permuted copy ordered for
+    16-byte stores.  Wide layers (csrc/cconv.hip): (tap-major (2, s*Cout, Cin), None)."""
     Cin, Cout, K = w.shape
     assert K == 2 * s
     wb = ops_bf16.to_bf16(w) if w.numel() % 8 == 0 else w.detach().to(torch.bfloat16)  # one cast, then bf16 re-layouts
-    wl = wb.view(Cin, Cout, 2, s).permute(3, 1, 2, 0).reshape(s * Cout, 2 * Cin)
     wp = None
     if Cout % 32 == 0 and (Cin, Cout, s) in ((128, 64, 2), (64, 32, 2)):
+        wl = wb.view(Cin, Cout, 2, s).permute(3, 1, 2, 0).reshape(s * Cout, 2 * Cin)
         wp = wl.view(s, Cout // 32, 4, 2, 4, 2 * Cin).permute(0, 1, 3, 2, 4, 5).reshape(s * Cout, 2 * Cin)
-    return wl, wp
+        return wl, wp
+    # wide layers: the tap-major image (2, s*Cout, Cin) of csrc/cconv.hip
+    return wb.view(Cin, Cout, 2, s).permute(2, 3, 1, 0).reshape(2, s * Cout, Cin).contiguous(), None
 
 
 _up_wcache = {}
@@ -1530,12 +1725,12 @@ def upsample_forward(act, w, bias, s, res=None, out_bf16=False, in_slope=1.0, pr
             return out
         if rc != -2:
             check(rc, "upsample_stream")
-    if in_slope != 1.0 or (r is not None and r.dtype != torch.float32):
+    if in_slope != 1.0 or (r is not None and r.dtype != torch.float32) or wp is not None:
         return None
     brep = bias.repeat(s) if bias is not None else None
-    segs = [(act, Cin, (wl, 0), 2 * Cin, Cin, 0), (act, Cin, (wl, Cin), 2 * Cin, Cin, -1)]
-    if not bgemm_nt(segs, B * T, s * Cout, out, s * Cout, T=T, bias=brep, res=None if r is None else r.view(B * T, s * Cout),
-                    ldr=s * Cout):
+    # polyphase form = a 2-tap convolution onto s*Cout channels (tap j reads token t - j)
+    if not cconv(act, wl, out=None if out_bf16 else out, out_bf=out if out_bf16 else None, B=B, Tsrc=T, Tdst=T, groups=1,
+                 CR=Cin, NG=s * Cout, K=2, in_mul=1, in_add=0, in_kstep=-1, in_div=1, phases=1, bias=brep, res=r):
         return None
     return out
 

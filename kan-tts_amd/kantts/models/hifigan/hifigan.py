@@ -103,6 +103,8 @@ class Generator(torch.nn.Module):
                 h, act = ops.sin_add(h, act_slope=self.slope)
             else:
                 h = ops.sin_add(h)
+            if act is not None:
+                ops.set_image(h, self.slope, act)  # the repeat convolution below reads the same activated image
             if self.repeat_upsample:
                 conv = self.repeat_upsamples[i][2]
                 c = conv.conv1d
@@ -122,6 +124,7 @@ class Generator(torch.nn.Module):
             # GAN step 66.9 -> 60.3 ms); a forward-only pass is a chain of chip-filling launches and is 9 % faster
             # sequentially (4.09 vs 4.47 ms at batch 32 x 8192, profiles/r02_runAB_*)
             blocks = self.conv_blocks[i * self.num_kernels:(i + 1) * self.num_kernels]
+            ops.act_image(h, self.slope)  # one activated bf16 image for the first convolution of every stack (bf16 mode)
             thunks = [(lambda b=b, h=h: b.forward_cl(h)) for b in blocks]
             ys = ops.parallel_branches(thunks, inputs=(h,)) if torch.is_grad_enabled() else [t() for t in thunks]
             xs = ys[0]
@@ -189,7 +192,7 @@ class PeriodDiscriminator(torch.nn.Module):
             conv = layer[0]
             w, tap = conv_weight(conv)
             h = ops.conv_cl(h, w, conv.bias, stride=conv.stride[0], pad=conv.padding[0], inner=p,
-                            out_leaky=self.slope, tap_major=tap)
+                            out_leaky=self.slope, tap_major=tap, image=None)
             fmap.append(h.permute(0, 3, 1, 2))
         cp = self.conv_post
         h = ops.conv_cl(h, cp.weight.squeeze(-1), cp.bias, stride=1, pad=cp.padding[0], inner=p,
@@ -257,7 +260,7 @@ class ScaleDiscriminator(torch.nn.Module):
             c = layer[0]
             w, tap = conv_weight(c)
             h = ops.conv_cl(h, w, c.bias, stride=c.stride[0], pad=c.padding[0], groups=c.groups,
-                            out_leaky=self.slope, tap_major=tap)
+                            out_leaky=self.slope, tap_major=tap, image=None)
             fmap.append(h.transpose(1, 2))
         c = self.conv_post
         w, tap = conv_weight(c)

@@ -62,7 +62,7 @@ class Conv1d(torch.nn.Module):
         self.conv1d.apply(init_weights)
         self.pad = (kernel_size - 1) * dilation if self.causal else padding
 
-    def forward_cl(self, x, in_leaky=None, out_leaky=None, res=None):
+    def forward_cl(self, x, in_leaky=None, out_leaky=None, res=None, image=False):
         c = self.conv1d
         k, d, s = c.kernel_size[0], c.dilation[0], c.stride[0]
         Tin = x.shape[1]
@@ -70,7 +70,7 @@ class Conv1d(torch.nn.Module):
         Tout = (Tin - 1) // s + 1 if self.causal else (Tin + 2 * self.pad - d * (k - 1) - 1) // s + 1
         w, tap = conv_weight(c)
         return ops.conv_cl(x, w, c.bias, stride=s, dilation=d, pad=self.pad, Tout=Tout, groups=c.groups,
-                           in_leaky=in_leaky, out_leaky=out_leaky, res=res, tap_major=tap)
+                           in_leaky=in_leaky, out_leaky=out_leaky, res=res, tap_major=tap, image=image)
 
     def forward(self, x):
         return self.forward_cl(x.transpose(1, 2).contiguous()).transpose(1, 2)
@@ -160,9 +160,11 @@ class ResidualBlock(torch.nn.Module):
         self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
 
     def forward_cl(self, x):
-        for c1, c2 in zip(self.convs1, self.convs2):
-            xt = c1.forward_cl(x, in_leaky=self.slope)
-            x = c2.forward_cl(xt, in_leaky=self.slope, res=x)
+        # bf16 mode: every convolution also writes the activated bf16 image its successor reads (ops.set_image)
+        n = len(self.convs1)
+        for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+            xt = c1.forward_cl(x, in_leaky=self.slope, image=self.slope)
+            x = c2.forward_cl(xt, in_leaky=self.slope, res=x, image=self.slope if i + 1 < n else False)
         return x
 
     def forward(self, x):

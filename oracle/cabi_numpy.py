@@ -1052,6 +1052,99 @@ class EmulatedLib:
             _arr(g.db, N)[:] += dy.sum(axis=(0, 1)).astype(np.float32)
         return 0
 
+    # ------------------------------------------------------------------------------------ bf16 conv contractions
+    def kantts_act_cast_bf16(self, src, gate, gate_bf16, dst, act, slope, n, stream):
+        n = int(_val(n))
+        v = _arr(src, n).copy()
+        sl = np.float32(_val(slope))
+        if gate:
+            q = _rd(gate, n, bool(_val(gate_bf16)))
+            v = v * np.where(q > 0, np.float32(1), sl)
+        elif _val(act):
+            v = np.where(v > 0, v, v * sl)
+        _wr(dst, v.astype(np.float32), True)
+        return 0
+
+    def kantts_cconv_launch(self, args_ref, stream):
+        """csrc/cconv.hip: bf16 operands, exact products, fp32-or-better accumulation (here float64)."""
+        g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
+        if (g.CR % 8) or (g.NG % 8) or g.K > 64 or g.phases > 8:
+            return -2
+        P = g.inner
+        B, Ts, Td, Ci, N, CR, NG, G, K = g.B, g.Tsrc, g.Tdst, g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K
+
+        def fold(a, T, C):
+            return a.reshape(B, T, P, C).transpose(0, 2, 1, 3).reshape(B * P, T, C)
+
+        x = fold(_rd(g.in_, B * Ts * P * Ci, True), Ts, Ci).astype(np.float64)
+        w = _rd(g.w, K * N * CR, True).reshape(K, N, CR).astype(np.float64)
+        acc = np.zeros((B * P, Td, N), dtype=np.float64)
+        up = max(1, g.up)
+        for ph in range(g.phases):
+            m = np.arange((Td - ph + g.phases - 1) // g.phases)
+            if m.size == 0:
+                continue
+            d = m * g.phases + ph
+            for k in range(K):
+                u = g.in_add + ph + k * g.in_kstep
+                if u % g.in_div:
+                    continue
+                src = m * g.in_mul + u // g.in_div
+                ok = (src >= 0) & (src < Ts * up)
+                src = src // up
+                if not ok.any():
+                    continue
+                for gi in range(G):
+                    xs = x[:, src[ok], gi * CR:(gi + 1) * CR]
+                    acc[:, d[ok], gi * NG:(gi + 1) * NG] += xs @ w[k, gi * NG:(gi + 1) * NG, :].T
+        if g.bias:
+            acc += _arr(g.bias, N)
+        if g.out_act:
+            acc = np.where(acc > 0, acc, acc * np.float32(g.out_slope))
+        if g.res:
+            acc += fold(_arr(g.res, B * Td * P * N), Td, N)
+        if g.out_gate:
+            q = fold(_rd(g.out_gate, B * Td * P * N, bool(g.out_gate_bf16)), Td, N)
+            acc *= np.where(q > 0, 1.0, np.float32(g.out_gate_slope))
+        res = acc.reshape(B, P, Td, N).transpose(0, 2, 1, 3).astype(np.float32)
+        if g.out:
+            _arr(g.out, B * Td * P * N)[:] = res.reshape(-1)
+        if g.out_bf:
+            v = np.where(res > 0, res, res * np.float32(g.bf_slope)) if g.bf_act else res
+            _wr(g.out_bf, v, True)
+        return 0
+
+    def kantts_cconv_wgrad_ws_floats(self, args_ref):
+        return 0  # the model sums in one pass: no partial tiles
+
+    def kantts_cconv_wgrad_launch(self, args_ref, stream):
+        g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
+        if (g.CR % 8) or (g.NG % 8):
+            return -2
+        P, B, Ts, Td, Ci, N, CR, NG, G, K = g.inner, g.B, g.Tsrc, g.Tdst, g.Cin_tot, g.Ntot, g.CR, g.NG, g.groups, g.K
+
+        def fold(a, T, C):
+            return a.reshape(B, T, P, C).transpose(0, 2, 1, 3).reshape(B * P, T, C)
+
+        x = fold(_rd(g.x, B * Ts * P * Ci, True), Ts, Ci).astype(np.float64)
+        dy = fold(_rd(g.dy, B * Td * P * N, True), Td, N).astype(np.float64)
+        dw = _arr(g.dw, K * N * CR).reshape(K, N, CR)
+        q = np.arange(Td)
+        up = max(1, g.up)
+        for k in range(K):
+            src = q * g.stride + k * g.dil - g.pad
+            ok = (src >= 0) & (src < Ts * up)
+            src = src // up
+            if not ok.any():
+                continue
+            for gi in range(G):
+                d = dy[:, q[ok], gi * NG:(gi + 1) * NG]
+                xs = x[:, src[ok], gi * CR:(gi + 1) * CR]
+                dw[k, gi * NG:(gi + 1) * NG, :] += np.einsum("btn,btc->nc", d, xs).astype(np.float32)
+        if g.db:
+            _arr(g.db, N)[:] += dy.sum(axis=(0, 1)).astype(np.float32)
+        return 0
+
     def kantts_conv_c1_launch(self, args_ref, mode, stream):
         g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
         mode = _val(mode)

@@ -255,7 +255,8 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
              (hip.ConvWArgs, "kantts_convw_args"), (hip.ConvC1Args, "kantts_conv_c1_args"),
              (hip.BGemmSeg, "kantts_bgemm_seg"), (hip.BGemmArgs, "kantts_bgemm_args"),
              (hip.BGemmTnArgs, "kantts_bgemm_tn_args"), (hip.TapMajorDesc, "kantts_tapmajor_desc"),
-             (hip.FfnArgs, "kantts_ffn_args"), (hip.FragMajorDesc, "kantts_fragmajor_desc")]
+             (hip.FfnArgs, "kantts_ffn_args"), (hip.FragMajorDesc, "kantts_fragmajor_desc"),
+             (hip.CConvArgs, "kantts_cconv_args"), (hip.CConvWArgs, "kantts_cconvw_args")]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "kantts_hip.h"', 'int main(void) {']
     for cls, cname in pairs:
         lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
