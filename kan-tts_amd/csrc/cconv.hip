@@ -657,17 +657,32 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_wgrad_kernel(const CwArgs P)
 }
 
 // dw[e] += sum_s ws[s][e]: the token slices of a weight gradient, summed in a fixed order (no atomics: a launch is
-// bit-reproducible, and 50-120 slices adding into the same 50 k addresses at the same moment ran at ~60 G atomics/s)
+// bit-reproducible, and 50-120 slices adding into the same 50 k addresses at the same moment ran at ~60 G atomics/s).
+// A block owns 16 float4 columns; its 16 thread rows each sum every 16th slice, then meet in LDS -- a narrow gradient
+// (a 3-tap 32 x 32 layer is 768 float4) with 512 slices would otherwise be 768 threads doing 512 dependent-latency loads.
 __global__ __launch_bounds__(256) void cconv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                 long long n4, int slices) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  float4 a = reinterpret_cast<const float4*>(dw)[i];
-  for (int s = 0; s < slices; ++s) {
-    const float4 v = reinterpret_cast<const float4*>(ws)[(long long)s * n4 + i];
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  __shared__ float4 part[16][17];
+  const int col = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + col;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    for (int s = sg; s < slices; s += 16) {
+      const float4 v = reinterpret_cast<const float4*>(ws)[(long long)s * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
   }
-  reinterpret_cast<float4*>(dw)[i] = a;
+  part[sg][col] = a;
+  __syncthreads();
+  if (sg == 0 && i < n4) {
+    float4 t = reinterpret_cast<const float4*>(dw)[i];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float4 v = part[q][col];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = t;
+  }
 }
 
 template <int TW, int NSTAGE>
@@ -687,10 +702,256 @@ static int cw_launch2(const CwArgs& P, hipStream_t st) {
   hipLaunchKernelGGL((cconv_wgrad_kernel<TW, NSTAGE>), grid, dim3(CC_THREADS), LDS, st, P);
   if (P.to_ws) {
     const long long n4 = (long long)g.K * g.Ntot * g.CR / 4;
-    hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)kantts_cdiv(n4, 256)), dim3(256), 0, st, g.workspace, g.dw, n4,
+    hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)kantts_cdiv(n4, 16)), dim3(256), 0, st, g.workspace, g.dw, n4,
                        P.slices);
   }
   KANTTS_CHECK_LAUNCH();
+}
+
+// ================================================================================================ narrow weight gradient
+// Channel groups of at most 64 x 64 (the generator's 64- and 32-channel residual stacks, the scale discriminators' grouped
+// k = 41 layers): a (tap, 128 x 128) tile wastes 3/4 .. 15/16 of its MFMAs and re-reads dy and x once per tap.  Here a
+// workgroup keeps the accumulators of ALL taps of its channel group in registers (taps dealt to the four waves), and
+// per step of 64 output tokens loads the 64 dy rows and the x WINDOW those tokens can touch
+//   (64 - 1) * stride + (K - 1) * dil + 1 rows
+// once: tap k of output token j multiplies window row j * stride + k * dil.  dy and x cross HBM -> LDS once per launch
+// instead of once per tap.  Both operands are [token][channel] images read through ds_read_tr16_b64 as above.
+// Steps never straddle two batch items (the window of a step is one contiguous token range of one item).
+struct CtArgs {
+  kantts_cconvw_args a;
+  int slices, to_ws;
+  int rs;    // 64-token sub-steps per step (1, 2 or 4): one barrier and one load round trip per 64 * rs tokens
+  int spi;   // steps per batch item = ceil(Tdst / (64 * rs))
+  int wr;    // window rows
+  int ncp;   // window copies per wave and step
+};
+
+template <int NF, int CF, int TPW>
+__global__ __launch_bounds__(CC_THREADS) void cconv_wgrad_taps_kernel(const CtArgs P) {
+  constexpr int NT = NF * 16, CT = CF * 16;       // channel tiles of dy / x (32 or 64)
+  constexpr int DYB = NT * 2, XB = CT * 2;        // row bytes
+  constexpr int DY_CP = 64 * DYB / 4096;          // dy copies per wave and 64 tokens (1 or 2)
+  constexpr int X_RPC = 1024 / XB;                // window rows per 1 KB copy (16 or 8)
+  extern __shared__ __attribute__((aligned(16))) unsigned char cc_lds[];
+  const kantts_cconvw_args& g = P.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int RS = P.rs;
+  const int DY_IMG = RS * 64 * DYB;
+  const int X_IMG = P.ncp * 4 * 1024;
+  const int STAGE = DY_IMG + X_IMG;
+
+  const int tgroup = blockIdx.x;                 // taps tgroup*4*TPW .. + 4*TPW
+  const int grp = blockIdx.y;
+  const int slice = blockIdx.z;
+  const int NS = g.B * P.spi;
+  const int s_lo = (int)((long long)NS * slice / P.slices), s_hi = (int)((long long)NS * (slice + 1) / P.slices);
+  const int n0 = grp * g.NG, c0g = grp * g.CR;
+  const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(cc_zero16);
+
+  // ---- copy coordinates.  dy image: copy v of wave w = rows (v*4 + w) * (1024 / DYB) ..; 64-byte rows swizzle the
+  // 16-byte chunk by ((row >> 2) & 1) << 1, 128-byte rows by ((row >> 1) & 3) << 1 (conflict-free transpose reads)
+  constexpr int DY_RPC = 1024 / DYB;
+  const int dy_rsub = lane / (DYB / 16), dy_slot = lane % (DYB / 16);
+  const int x_rsub = lane / (XB / 16), x_slot = lane % (XB / 16);
+  auto swz = [](int row, int rowbytes) { return rowbytes == 64 ? (((row >> 2) & 1) << 1) : (((row >> 1) & 3) << 1); };
+
+  f32x4 acc[TPW][NF][CF];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int c = 0; c < CF; ++c) acc[t][n][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) accb[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = g.db != nullptr && tgroup == 0 && wave == 0;
+  const __bf16 one = (__bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+
+  auto issue = [&](int step, int buf) {
+    unsigned char* Ab = cc_lds + buf * STAGE;
+    unsigned char* Xb = Ab + DY_IMG;
+    const bool live = step < s_hi;
+    const int b = step / P.spi;
+    const int q0 = (step - b * P.spi) * 64 * RS;
+    for (int v = 0; v < DY_CP * RS; ++v) {
+      const int row = (v * 4 + wave) * DY_RPC + dy_rsub;
+      const int chunk = dy_slot ^ swz(row, DYB);
+      const int q = q0 + row;
+      const bool ok = live && q < g.Tdst && chunk * 8 < g.NG;
+      const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(g.dy) +
+                                          (((long long)b * g.Tdst + q) * g.Ntot + n0 + chunk * 8) * 2
+                                    : zsrc;
+      cc_glds16(src, Ab + (v * 4 + wave) * 1024);
+    }
+    const int t0 = q0 * g.stride - g.pad;
+    for (int v = 0; v < P.ncp; ++v) {
+      const int row = (v * 4 + wave) * X_RPC + x_rsub;
+      const int chunk = x_slot ^ swz(row, XB);
+      const int t = t0 + row;
+      const bool ok = live && row < P.wr && (unsigned)t < (unsigned)g.Tsrc && chunk * 8 < g.CR;
+      const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(g.x) +
+                                          (((long long)b * g.Tsrc + t) * g.Cin_tot + c0g + chunk * 8) * 2
+                                    : zsrc;
+      cc_glds16(src, Xb + (v * 4 + wave) * 1024);
+    }
+  };
+  auto compute = [&](int buf) {
+    const unsigned char* Ab = cc_lds + buf * STAGE;
+    const unsigned char* Xb = Ab + DY_IMG;
+    for (int kk = 0; kk < 2 * RS; ++kk) {
+      const int j = kk * 32 + kg * 4 + (li >> 2);  // output token of this lane's transpose read (and j + 16)
+      const int sub = ((li & 3) * 4 & 7) * 2;
+      bf16x8 af[NF];
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int col = n * 16 + (li & 3) * 4;
+        const unsigned char* p = Ab + j * DYB + (((col >> 3) ^ swz(j, DYB)) << 4) + sub;  // swz(j) == swz(j + 16)
+        const bf16x4 lo = cc_tr4(p), hi = cc_tr4(p + 16 * DYB);
+        af[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      if (do_bias) {
+#pragma unroll
+        for (int n = 0; n < NF; ++n) accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[n], ones, accb[n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int k = (tgroup * TPW + t) * 4 + wave;  // taps interleaved over the waves
+        if (k < g.K) {
+          const int r_lo = j * g.stride + k * g.dil, r_hi = r_lo + 16 * g.stride;
+          bf16x8 bf[CF];
+#pragma unroll
+          for (int c = 0; c < CF; ++c) {
+            const int col = c * 16 + (li & 3) * 4;
+            const bf16x4 lo = cc_tr4(Xb + r_lo * XB + (((col >> 3) ^ swz(r_lo, XB)) << 4) + sub);
+            const bf16x4 hi = cc_tr4(Xb + r_hi * XB + (((col >> 3) ^ swz(r_hi, XB)) << 4) + sub);
+            bf[c] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int n = 0; n < NF; ++n)
+#pragma unroll
+            for (int c = 0; c < CF; ++c)
+              acc[t][n][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[n], bf[c], acc[t][n][c], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  issue(s_lo, 0);
+  for (int s = s_lo; s < s_hi; ++s) {
+    cc_wait_vm<0>();
+    cc_barrier();
+    issue(s + 1, (s - s_lo + 1) & 1);
+    compute((s - s_lo) & 1);
+  }
+  cc_wait_vm<0>();
+
+  // ---- epilogue straight from the accumulators: lane (li, kg) holds dy channels kg*4 .. +3 x x channel li of a fragment
+  float* base = P.to_ws ? g.workspace + (long long)slice * g.K * g.Ntot * g.CR : g.dw;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int k = (tgroup * TPW + t) * 4 + wave;
+    if (k >= g.K) continue;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int c = 0; c < CF; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nn = n * 16 + kg * 4 + r, cc = c * 16 + li;
+          if (nn < g.NG && cc < g.CR) {
+            float* dst = base + ((long long)k * g.Ntot + n0 + nn) * g.CR + cc;
+            const float v = acc[t][n][c][r];
+            if (P.to_ws)
+              *dst = v;
+            else if (P.slices == 1)
+              *dst += v;
+            else if (v != 0.f)
+              atomicAdd(dst, v);
+          }
+        }
+  }
+  if (do_bias && li == 0) {
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n * 16 + kg * 4 + r;
+        const float v = accb[n][r];
+        if (nn < g.NG && v != 0.f) atomicAdd(&g.db[n0 + nn], v);
+      }
+  }
+}
+
+template <int NF, int CF, int TPW>
+static int ct_launch(const CtArgs& P, hipStream_t st) {
+  const kantts_cconvw_args& g = P.a;
+  const size_t LDS = 2 * (size_t)(P.rs * 64 * NF * 32 + P.ncp * 4096);
+  if (LDS > 150 * 1024) return KANTTS_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cconv_wgrad_taps_kernel<NF, CF, TPW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(kantts_cdiv(g.K, 4 * TPW), g.groups, P.slices);
+  hipLaunchKernelGGL((cconv_wgrad_taps_kernel<NF, CF, TPW>), grid, dim3(CC_THREADS), LDS, st, P);
+  if (P.to_ws) {
+    const long long n4 = (long long)g.K * g.Ntot * g.CR / 4;
+    hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)kantts_cdiv(n4, 16)), dim3(256), 0, st, g.workspace, g.dw, n4,
+                       P.slices);
+  }
+  KANTTS_CHECK_LAUNCH();
+}
+
+// 64 x 64 groups need two taps per wave: beyond one tap group (8 taps) the per-tap tiles above are as good
+// (scripts/bench_native/cconv_test: 16 groups of 64 x 64, k = 41: 69 vs 127 us)
+static bool ct_applies(const kantts_cconvw_args& g) {
+  static const char* off = getenv("KANTTS_NO_WGRAD_TAPS");
+  if (off || g.inner != 1 || g.up > 1 || g.CR > 64 || g.NG > 64 || g.K > 64) return false;
+  return !(g.CR > 32 && g.NG > 32 && g.K > 8);
+}
+// 64-token sub-steps per step: as many (4, 2, 1) as the sequence length and ~36 KB of LDS per stage allow
+static int ct_rs(const kantts_cconvw_args& g) {
+  static const char* e = getenv("KANTTS_WGRAD_TAPS_RS");
+  const int xb = (g.CR > 32) ? 128 : 64, dyb = (g.NG > 32) ? 128 : 64;
+  for (int rs = e ? atoi(e) : 4; rs > 1; rs >>= 1) {
+    const long long wr = (long long)(64 * rs - 1) * g.stride + (long long)(g.K - 1) * g.dil + 1;
+    if (g.Tdst >= 64 * rs && wr * xb + 64ll * rs * dyb <= 36 * 1024) return rs;
+  }
+  return 1;
+}
+// taps per wave: "deep" keeps up to 44 / 20 / 12 taps per workgroup in ~400 registers (one wave per SIMD), the default
+// 24 / 12 / 8 taps in < 256 (two waves per SIMD, more workgroups re-reading the step's rows)
+static bool ct_deep() {
+  static const char* e = getenv("KANTTS_WGRAD_TAPS_DEEP");
+  return e && atoi(e) != 0;
+}
+static int ct_tpw(const kantts_cconvw_args& g) {
+  const int nf = g.NG > 32 ? 4 : 2, cf = g.CR > 32 ? 4 : 2;
+  if (ct_deep()) return nf * cf == 4 ? 11 : (nf * cf == 8 ? 5 : 3);
+  return nf * cf == 4 ? 6 : (nf * cf == 8 ? 3 : 2);
+}
+static int ct_slices(const kantts_cconvw_args& g, bool have_ws) {
+  const long long NS = (long long)g.B * kantts_cdiv(g.Tdst, 64 * ct_rs(g));
+  long long slices = g.slices;
+  if (slices == 0) {
+    const long long wgs = (long long)kantts_cdiv(g.K, 4 * ct_tpw(g)) * g.groups;
+    slices = (512 + wgs - 1) / wgs;
+    if (!have_ws) {
+      const long long cap = (6ll << 20) / ((long long)g.K * g.Ntot * g.CR) + 1;
+      if (slices > cap) slices = cap;
+    }
+    if (slices > NS / 4) slices = NS / 4;
+    if (slices < 1) slices = 1;
+  }
+  if (slices > NS) slices = NS;
+  if (slices > 65535) slices = 65535;
+  return (int)slices;
 }
 
 // token slices of a launch: explicit, or enough workgroups for two per CU; with a workspace the partial tiles are
@@ -718,7 +979,7 @@ static int cw_slices(const kantts_cconvw_args& g, bool have_ws) {
 
 extern "C" long long kantts_cconv_wgrad_ws_floats(const kantts_cconvw_args* ap) {
   if (!ap || ap->K < 1 || ap->groups < 1 || ap->NG < 1 || ap->CR < 1 || ap->inner < 1 || ap->B < 1 || ap->Tdst < 1) return 0;
-  const int slices = cw_slices(*ap, true);
+  const int slices = ct_applies(*ap) ? ct_slices(*ap, true) : cw_slices(*ap, true);
   return slices > 1 ? (long long)slices * ap->K * ap->Ntot * ap->CR : 0;
 }
 
@@ -735,6 +996,48 @@ extern "C" int kantts_cconv_wgrad_launch(const kantts_cconvw_args* ap, void* str
   if (up > 64 || (long long)g.Tsrc * up * up >= (1ll << 31) || (long long)g.B * g.Tsrc * g.inner >= (1ll << 30) ||
       (long long)g.B * g.Tdst * g.inner >= (1ll << 30) || g.inner > 64)
     return KANTTS_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (ct_applies(g)) {
+    CtArgs T = {};
+    T.a = g;
+    int slices = ct_slices(g, g.workspace != nullptr);
+    bool ws = false;
+    if (slices > 1 && g.workspace) {
+      if (g.ws_floats >= (long long)slices * g.K * g.Ntot * g.CR && cc_aligned16(g.workspace))
+        ws = true;
+      else
+        slices = ct_slices(g, false);
+    }
+    T.slices = slices;
+    T.to_ws = ws ? 1 : 0;
+    T.rs = ct_rs(g);
+    T.spi = kantts_cdiv(g.Tdst, 64 * T.rs);
+    T.wr = (64 * T.rs - 1) * g.stride + (g.K - 1) * g.dil + 1;
+    const int xrpc = (g.CR > 32) ? 8 : 16;
+    T.ncp = kantts_cdiv(kantts_cdiv(T.wr, xrpc), 4);
+    const int nf = g.NG > 32 ? 4 : 2, cf = g.CR > 32 ? 4 : 2;
+    int rc;
+    if (ct_deep()) {
+      if (nf == 2 && cf == 2)
+        rc = ct_launch<2, 2, 11>(T, st);
+      else if (nf == 2 && cf == 4)
+        rc = ct_launch<2, 4, 5>(T, st);
+      else if (nf == 4 && cf == 2)
+        rc = ct_launch<4, 2, 5>(T, st);
+      else
+        rc = ct_launch<4, 4, 3>(T, st);
+    } else {
+      if (nf == 2 && cf == 2)
+        rc = ct_launch<2, 2, 6>(T, st);
+      else if (nf == 2 && cf == 4)
+        rc = ct_launch<2, 4, 3>(T, st);
+      else if (nf == 4 && cf == 2)
+        rc = ct_launch<4, 2, 3>(T, st);
+      else
+        rc = ct_launch<4, 4, 2>(T, st);
+    }
+    if (rc != KANTTS_E_UNSUPPORTED) return rc;
+  }
   CwArgs P = {};
   P.a = g;
   P.up_magic = (unsigned)((1ull << 32) / (unsigned)up) + 1u;
@@ -750,7 +1053,6 @@ extern "C" int kantts_cconv_wgrad_launch(const kantts_cconvw_args* ap, void* str
   if ((long long)g.K * slices > 65535) return KANTTS_E_UNSUPPORTED;
   P.to_ws = to_ws ? 1 : 0;
   P.slices = slices;
-  hipStream_t st = (hipStream_t)stream;
   static const char* env_stage = getenv("KANTTS_CCONV_STAGES");
   const int nst = env_stage ? atoi(env_stage) : 0;
   if (TW == 128) {

@@ -1,0 +1,83 @@
+"""Whole-step hipGraph capture of the HiFi-GAN training step.
+
+A GAN step at batch 32 x 8192 is ~2000 kernel launches and ~1500 small tensor operations issued from Python over up to
+eight streams (generator, five period and three scale discriminators, two phases: kantts/train/gan_step.py, reference
+kantts/train/trainer.py:469-589).  Once the convolutions run on the bf16 MFMA kernels the host cannot issue the step as
+fast as the device executes it.  Here both phases -- generator forward, the discriminators on generated and real audio,
+the four losses, both backward passes, the three Adam updates -- are captured ONCE (torch.cuda.CUDAGraph drives
+hipStreamBeginCapture; the per-discriminator / per-residual-stack streams of ops.parallel_branches become parallel
+branches of the graph) and replayed per step:
+  * inputs are static device buffers (``load_batch`` copies a new batch of the same shape in place);
+  * learning rates and step counts of the three optimizers live in device memory (ArenaAdam.enable_device_state);
+  * nothing in the step reads a value back to the host.
+The step must have both phases active (``steps`` past both start thresholds) -- before that the eager
+``gan_train_step`` runs.  Data-parallel training keeps the eager step (its bucketed all-reduces are issued from
+autograd hooks, which a capture cannot contain).
+"""
+import torch
+
+from kantts.train.gan_step import gan_train_step
+from kantts.train.optim import ArenaAdam
+
+
+class _NoSched:
+    def step(self):
+        pass
+
+
+class GraphedGanStep:
+    def __init__(self, model, optimizer, scheduler, criterion, config, y, x, warmup=2, steps=10 ** 9):
+        self.model, self.optimizer, self.scheduler, self.criterion, self.config = model, optimizer, scheduler, criterion, config
+        self.opts = [optimizer["generator"]] + list(optimizer["discriminator"].values())
+        self.scheds = [scheduler["generator"]] + list(scheduler["discriminator"].values())
+        if not all(isinstance(o, ArenaAdam) for o in self.opts):
+            raise NotImplementedError("GraphedGanStep needs the arena optimizers (hifigan_model_builder on a HIP device, Adam)")
+        if any(o.arena.world_size > 1 for o in self.opts):
+            raise NotImplementedError("data-parallel GAN training runs the eager step")
+        if steps <= config.get("discriminator_train_start_steps", 0) or steps < config.get("generator_train_start_steps", 0):
+            raise ValueError("both phases must be active in a captured GAN step")
+        if getattr(model["generator"], "nsf_enable", False):
+            raise NotImplementedError("the NSF excitation draws host-seeded random numbers per step: eager step only")
+        self.steps = steps
+        self.y, self.x = y.clone(), x.clone()
+        self._nosched = {"generator": _NoSched(), "discriminator": {k: _NoSched() for k in scheduler["discriminator"]}}
+        for o in self.opts:
+            o.arena.overlap = False
+            o.enable_device_state()
+        # warm-up (allocator pools, lazy kernel attributes) must not train: weights, moments and counters are put back
+        snaps = [o.snapshot() for o in self.opts]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for o, s in zip(self.opts, snaps):
+            o.restore(s)
+        for o in self.opts:
+            o.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.out = self._eager()
+        for o, s in zip(self.opts, snaps):
+            o._step = s["step"]  # capture ran step()'s host code once without running its kernels
+
+    def _eager(self):
+        return gan_train_step(self.model, self.optimizer, self._nosched, self.criterion, self.config, self.y, self.x,
+                              steps=self.steps)
+
+    def load_batch(self, y, x):
+        self.y.copy_(y, non_blocking=True)
+        self.x.copy_(x, non_blocking=True)
+
+    def __call__(self):
+        """One GAN step; returns the dict of (device) loss tensors of this step (overwritten by the next replay)."""
+        self.graph.replay()
+        for o, s in zip(self.opts, self.scheds):
+            o._step += 1  # the device-side count advances inside the graph; mirror it on the host
+            lr = o.param_groups[0]["lr"]
+            s.step()
+            if o.param_groups[0]["lr"] != lr:
+                o.sync_lr()
+        return self.out

@@ -112,4 +112,6 @@ def gan_train_step(model, optimizer, scheduler, criterion, config, y, x, steps=1
             optimizer["discriminator"][key].step()
         for key in scheduler["discriminator"]:
             scheduler["discriminator"][key].step()
-    return out
+    # detached: a caller that keeps the loss values must not keep both autograd graphs (and their AccumulateGrad nodes,
+    # which pin the stream they first ran on -- a later hipGraph capture of the step would trip over them) alive
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}

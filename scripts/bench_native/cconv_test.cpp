@@ -343,6 +343,12 @@ int main(int argc, char** argv) {
       {"w up4", 2, 50, 200, 1, 64, 64, 1, 7, 1, 1, 6, 4, 0, 0, 1},
       {"w c256 n64", 2, 130, 130, 1, 256, 64, 1, 3, 1, 1, 1, 1, 0, 1, 1},
       {"w long c64 auto ws", 4, 3000, 3000, 1, 64, 64, 1, 3, 1, 1, 1, 1, 0, 1, 1},
+      {"w taps c32 k11 dil5", 3, 333, 333, 1, 32, 32, 1, 11, 1, 5, 50, 1, 0, 1, 1},
+      {"w taps c32 k41 s2 g4", 2, 500, 250, 1, 128, 128, 4, 41, 2, 1, 20, 1, 0, 1, 1},
+      {"w taps 32x64 k41 s4 g2", 2, 600, 150, 1, 64, 128, 2, 41, 4, 1, 20, 1, 0, 1, 1},
+      {"w taps 64x32 k7", 2, 200, 200, 1, 64, 32, 1, 7, 1, 1, 3, 1, 3, 1, 0},
+      {"w taps c24 n40 k5 s3", 3, 100, 34, 1, 24, 40, 1, 5, 3, 1, 2, 1, 1, 1, 0},
+      {"w taps c64 k3 1 slice", 1, 70, 70, 1, 64, 64, 1, 3, 1, 1, 1, 1, 1, 0, 0},
   };
   for (auto& c : wsmall) fails += run_wgrad(c, 2);
   printf("---- small cases: %d failures\n", fails);

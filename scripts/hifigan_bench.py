@@ -89,7 +89,25 @@ def main():
     res["gan_step_ms"] = dt * 1e3
     res["gan_step_samples_per_s"] = B * 8192 / dt
     res["gan_step_tflops"] = 8.3e12 * B / 32 / dt / 1e12
-    res["losses"] = {k: float(v) for k, v in out.items()}
+    res["losses"] = {k: float(v.detach()) for k, v in out.items()}
+    if not os.environ.get("KANTTS_NO_GAN_GRAPH"):
+        from kantts.train.gan_graph_step import GraphedGanStep
+
+        t0 = time.perf_counter()
+        gstep = GraphedGanStep(model, optimizer, scheduler, crit, config, y, x)
+        torch.cuda.synchronize()
+        res["graph_capture_s"] = time.perf_counter() - t0
+        gstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(steps, 8)):
+            out = gstep()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / max(steps, 8)
+        res["gan_step_graph_ms"] = dt * 1e3
+        res["gan_step_graph_samples_per_s"] = B * 8192 / dt
+        res["gan_step_graph_tflops"] = 8.3e12 * B / 32 / dt / 1e12
+        res["graph_losses"] = {k: float(v.detach()) for k, v in out.items()}
     res["max_mem_GB"] = torch.cuda.max_memory_allocated() / 1e9
     print(json.dumps(res))
 

@@ -393,20 +393,25 @@ def _block_and_stack_run(ops, device, use_images):
         ops.get_image, ops.act_cast_bf16 = real_get, real_cast
 
 
-def _check_image_handover(ops, device):
+def _check_image_handover(ops, device, exact):
     y1, g1, n1 = _block_and_stack_run(ops, device, True)
     y0, g0, n0 = _block_and_stack_run(ops, device, False)
-    # the epilogue's image is the rounding of the very value the separate pass would round: bit-identical results
+    # the epilogue's image is the rounding of the very value the separate pass would round: the forward pass is
+    # bit-identical; gradients too, up to the summation order of the kernels that accumulate with atomics on the device
+    # (the one-input-channel first layer, weight-norm reductions)
     assert torch.equal(y1, y0)
     for a, b in zip(g1, g0):
-        assert torch.equal(a, b)
+        if exact:
+            assert torch.equal(a, b)
+        else:
+            assert rel_l2(a, b) < 1e-5
     assert n1 < n0 - 5, (n1, n0)  # the forward casts of the chained convolutions are gone
 
 
 def test_image_handover_is_bit_identical_emulated(emulated_cabi, bf16_all_sizes):
-    _check_image_handover(bf16_all_sizes, "cpu")
+    _check_image_handover(bf16_all_sizes, "cpu", True)
 
 
 @pytest.mark.gpu
-def test_image_handover_is_bit_identical_gpu(bf16_all_sizes):
-    _check_image_handover(bf16_all_sizes, "cuda")
+def test_image_handover_changes_nothing_gpu(bf16_all_sizes):
+    _check_image_handover(bf16_all_sizes, "cuda", False)

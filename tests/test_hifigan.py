@@ -336,6 +336,74 @@ def test_gan_train_step_runs_and_updates():
     assert float((optimizer["generator"].arena.flat - w0).abs().max()) > 0
 
 
+def _small_gan_setup(seed=0):
+    from kantts.models import model_builder
+    from kantts.train.loss import criterion_builder
+
+    opt = {"type": "Adam", "params": {"lr": 2e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}}
+    sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [2]}}  # the lr halves after the second step
+    config = {"model_type": "hifigan", "Model": {
+        "Generator": {"params": {"channels": 64}, "optimizer": opt, "scheduler": sch},
+        "MultiScaleDiscriminator": {"params": {}, "optimizer": opt, "scheduler": sch},
+        "MultiPeriodDiscriminator": {"params": {}, "optimizer": opt, "scheduler": sch}},
+        "Loss": {"generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "stft_loss": {"enable": False},
+                 "mel_loss": {"enable": True, "params": {}, "weights": 45.0},
+                 "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+        "generator_grad_norm": -1, "discriminator_grad_norm": -1, "discriminator_train_start_steps": 0,
+        "generator_train_start_steps": 0}
+    torch.manual_seed(seed)
+    model, optimizer, scheduler = model_builder(config, device="cuda")
+    crit = criterion_builder(config, device="cuda")
+    return config, model, optimizer, scheduler, crit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 2e-3)])
+def test_graphed_gan_step_matches_eager_gpu(prec, tol):
+    """The captured GAN step (kantts/train/gan_graph_step.py: both phases, eight branch streams, three Adam updates in
+    one hipGraph) against the eager step from the same initial state over four steps with a learning-rate milestone in
+    between: same losses, same weights.  Differences come from the fp32 atomics of the split weight gradients (summation
+    order) only; in bf16 mode the cconv kernels (forced on at this small size) are inside the capture."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+    from kantts.train.gan_graph_step import GraphedGanStep
+    from kantts.train.gan_step import gan_train_step
+
+    hip.set_precision(prec)
+    old_thr = ops.CCONV_MIN_FLOPS
+    ops.CCONV_MIN_FLOPS = 0.0
+    try:
+        g = torch.Generator().manual_seed(5)
+        xs = [torch.randn(2, 80, 16, generator=g).cuda() for _ in range(4)]
+        ys = [torch.randn(2, 1, 4096, generator=g).clamp(-1, 1).cuda() for _ in range(4)]
+        config, model, optimizer, scheduler, crit = _small_gan_setup()
+        eager_losses = []
+        for x, y in zip(xs, ys):
+            out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
+            eager_losses.append({k: float(v.detach()) for k, v in out.items()})
+        eager_w = [optimizer["generator"].arena.flat.clone()] + [o.arena.flat.clone() for o in optimizer["discriminator"].values()]
+        eager_lr = optimizer["generator"].param_groups[0]["lr"]
+
+        config, model, optimizer, scheduler, crit = _small_gan_setup()
+        step = GraphedGanStep(model, optimizer, scheduler, crit, config, ys[0], xs[0], steps=1)
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            step.load_batch(y, x)
+            out = step()
+            got = {k: float(v.detach()) for k, v in out.items()}
+            for k, v in eager_losses[i].items():
+                assert abs(got[k] - v) <= tol * max(1.0, abs(v)), (prec, i, k, got[k], v)
+        graph_w = [optimizer["generator"].arena.flat] + [o.arena.flat for o in optimizer["discriminator"].values()]
+        assert optimizer["generator"].param_groups[0]["lr"] == eager_lr
+        assert optimizer["generator"]._step == 4
+        for a, b in zip(graph_w, eager_w):
+            assert rel_l2(a, b) <= tol, prec
+    finally:
+        ops.CCONV_MIN_FLOPS = old_thr
+        hip.set_precision("fp32")
+
+
 def _noncausal_and_spectral(device):
     """causal=False generator (symmetric conv padding, ConvTranspose1d with padding (k-s)/2) vs the oracle, and the
     follow_official_norm discriminators (torch spectral_norm holders) vs the oracle fed with weight / sigma."""
