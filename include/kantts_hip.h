@@ -620,6 +620,7 @@ int kantts_dropout2_add(const float* x, const float* res, float* y, long long n,
  *     v[b,d,p,n] = bias[n] + sum_{k : u_k % in_div == 0} sum_c in[b, (m*in_mul + u_k/in_div) / up, p, g*CR + c] * w[k][n][c]
  *     u_k = in_add + phase + k*in_kstep;  virtual source tokens outside [0, Tsrc*up) contribute 0;  g = n / NG
  *     v = LeakyReLU(v, out_slope) when out_act;  v += res;  v *= (out_gate > 0 ? 1 : out_gate_slope)
+ *     (res_after_gate: the residual is added after the gate instead -- identity path of a gated input gradient)
  *     out[b,d,p,n] = v (fp32, optional);  out_bf[b,d,p,n] = bf16(bf_act ? LeakyReLU(v, bf_slope) : v) (optional)
  * in (B, Tsrc, inner, Cin_tot) bf16;  w (K, Ntot, CR) bf16;  bias / res fp32;  out_gate bf16 (out_gate_bf16) or fp32.
  * KANTTS_E_UNSUPPORTED unless CR % 8 == 0, NG % 8 == 0, K <= 64, phases <= 8 and all pointers are 16-byte aligned. */
@@ -642,6 +643,7 @@ typedef struct {
   float bf_slope;
   int bf_act;
   int tile; /* 0 = automatic; else BM*1000 + BN of a compiled tile (bench / tests) */
+  int res_after_gate;
 } kantts_cconv_args;
 int kantts_cconv_launch(const kantts_cconv_args* args, void* stream);
 

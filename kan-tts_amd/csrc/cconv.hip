@@ -292,9 +292,14 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_kernel(const CcArgs P) {
       if (g.out_act) x = x > 0.f ? x : x * g.out_slope;
       v[e] = x;
     }
+    float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (g.res) {
       const float4 r0 = *reinterpret_cast<const float4*>(g.res + o), r1 = *reinterpret_cast<const float4*>(g.res + o + 4);
-      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      rv[0] = r0.x; rv[1] = r0.y; rv[2] = r0.z; rv[3] = r0.w; rv[4] = r1.x; rv[5] = r1.y; rv[6] = r1.z; rv[7] = r1.w;
+      if (!g.res_after_gate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
     }
     if (g.out_gate) {
       float gv[8];
@@ -309,6 +314,10 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_kernel(const CcArgs P) {
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= (gv[e] > 0.f) ? 1.f : g.out_gate_slope;
+    }
+    if (g.res && g.res_after_gate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
     }
     if (g.out) {
       f32x4 w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};

@@ -11,6 +11,8 @@
 //   dgrad    dx[b,t,p]  += sum_k sum_n gate(dy[b,q,p,n]) * w[n][k]      at t = q*s + k*d - pad    (LDS scatter, one global add per token)
 //   wgrad    dw[n][k]   += sum_{b,q,p} gate(dy[b,q,p,n]) * x[b, q*s + k*d - pad, p];   db[n] += sum gate(dy)
 // fp32 throughout (no operand rounding), so the result does not depend on the GEMM precision mode.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define C1_THREADS 256
@@ -169,6 +171,158 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_wgrad_kernel(const kantts_
     for (int i = threadIdx.x; i < g.Cout; i += C1_THREADS) atomicAdd(&g.db[i], red[g.K * g.Cout + i]);
 }
 
+// ------------------------------------------------------------------------------------------- MFMA forms of the gradients
+// (round 3) The two kernels above spend their time in wave reductions (K shuffles trees per token) and per-thread tap
+// loops, not on the 268 MB of dy + gate they read at batch 32 x 8192 x 128: 300 us where HBM needs 60.  Both sums are
+// small contractions over the output channels / the tokens, so they go to v_mfma_f32_16x16x4_f32 -- fp32 operands, exact
+// fp32 FMA chains (the result still does not depend on the precision mode), 1/16 of the bf16 rate and still 10x more than
+// these layers need:
+//   dgrad   P[token][tap] = sum_n gate(dy[token][n]) * w[n][tap]   16 tokens x 16 taps per accumulator; a lane loads
+//           float4s of dy / gate (4 consecutive channels) and feeds element m to MFMA m, the weight operand uses the same
+//           channel permutation; P goes to LDS and every window position GATHERS its <= K terms (no LDS atomics)
+//   wgrad   dw[n][tap]    = sum_q gate(dy[q][n]) * x[q*s + tap*d - pad]   16 channels x 16 taps per accumulator over 4
+//           tokens per MFMA; element m of a lane's float4 is channel 4*li + m of its 64-channel half.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define C1_PLD 17  // pitch of the P tile
+
+template <int G16>  // Cout = 16 * G16
+__global__ __launch_bounds__(C1_THREADS) void conv_c1_dgrad_mfma_kernel(const kantts_conv_c1_args g) {
+  extern __shared__ __attribute__((aligned(16))) float c1_lds[];
+  constexpr int COUT = 16 * G16;
+  const int runs = (g.Tdst + C1_QB - 1) / C1_QB;
+  const int run = blockIdx.x % runs;
+  const int bp = blockIdx.x / runs;
+  const int b = bp / g.inner, p = bp % g.inner;
+  const int q0 = run * C1_QB;
+  const int nq = min(C1_QB, g.Tdst - q0);
+  const int W = (nq - 1) * g.stride + (g.K - 1) * g.dil + 1;
+  float* P = c1_lds;  // [C1_QB][C1_PLD]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  // weight operand of MFMA (group gg, element m): B[k = kg][j = li] = w[16*gg + 4*kg + m][tap li]
+  float wb[G16][4];
+#pragma unroll
+  for (int gg = 0; gg < G16; ++gg)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) wb[gg][m] = (li < g.K) ? g.w[(16 * gg + 4 * kg + m) * g.K + li] : 0.f;
+  for (int tt = wave; tt * 16 < nq; tt += C1_THREADS / 64) {
+    const int q = tt * 16 + li;
+    const bool ok = q < nq;
+    const long long row = (((long long)b * g.Tdst + q0 + (ok ? q : 0)) * g.inner + p) * COUT + 4 * kg;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gg = 0; gg < G16; ++gg) {
+      float4 d = *reinterpret_cast<const float4*>(g.y + row + 16 * gg);
+      if (g.gate) {
+        const float4 y = *reinterpret_cast<const float4*>(g.gate + row + 16 * gg);
+        d.x = c1_gate(d.x, y.x, g.gate_slope);
+        d.y = c1_gate(d.y, y.y, g.gate_slope);
+        d.z = c1_gate(d.z, y.z, g.gate_slope);
+        d.w = c1_gate(d.w, y.w, g.gate_slope);
+      }
+      if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d.x, wb[gg][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d.y, wb[gg][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d.z, wb[gg][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d.w, wb[gg][3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) P[(tt * 16 + kg * 4 + r) * C1_PLD + li] = acc[r];  // token kg*4 + r, tap li
+  }
+  __syncthreads();
+  const int lo = q0 * g.stride - g.pad;
+  for (int i = threadIdx.x; i < W; i += C1_THREADS) {
+    const int t = lo + i;
+    if (t < 0 || t >= g.Tsrc) continue;
+    float v = 0.f;
+    for (int k = 0; k < g.K; ++k) {
+      const int u = i - k * g.dil;
+      if (u < 0) break;
+      const int q = u / g.stride;
+      if (q * g.stride == u && q < nq) v += P[q * C1_PLD + k];
+    }
+    atomicAdd(&g.dx[((long long)b * g.Tsrc + t) * g.inner + p], v);
+  }
+}
+
+template <int H>  // Cout <= 64 * H (a multiple of 4)
+__global__ __launch_bounds__(C1_THREADS) void conv_c1_wgrad_mfma_kernel(const kantts_conv_c1_args g) {
+  extern __shared__ __attribute__((aligned(16))) float c1_lds[];
+  const int runs = (g.Tdst + C1_QB - 1) / C1_QB;
+  const int run = blockIdx.x % runs;
+  const int bp = blockIdx.x / runs;
+  const int b = bp / g.inner, p = bp % g.inner;
+  const int q0 = run * C1_QB;
+  const int nq = min(C1_QB, g.Tdst - q0);
+  const int W = (nq - 1) * g.stride + (g.K - 1) * g.dil + 1;
+  float* xs = c1_lds;
+  float* red = c1_lds + ((C1_QB - 1) * g.stride + (g.K - 1) * g.dil + 1 + 3) / 4 * 4;  // [(K+1)][Cout]
+  const int lo = q0 * g.stride - g.pad;
+  for (int i = threadIdx.x; i < W; i += C1_THREADS) {
+    const int t = lo + i;
+    xs[i] = (t >= 0 && t < g.Tsrc) ? g.x[((long long)b * g.Tsrc + t) * g.inner + p] : 0.f;
+  }
+  for (int i = threadIdx.x; i < (g.K + 1) * g.Cout; i += C1_THREADS) red[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  f32x4 acc[H][4];
+  float bs[H][4];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      acc[h][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bs[h][m] = 0.f;
+    }
+  for (int tg = wave; tg * 4 < nq; tg += C1_THREADS / 64) {
+    const int q = tg * 4 + kg;
+    const bool ok = q < nq;
+    const float bx = (ok && li < g.K) ? xs[q * g.stride + li * g.dil] : 0.f;  // B[k = token kg][j = tap li]
+    const long long row = (((long long)b * g.Tdst + q0 + (ok ? q : 0)) * g.inner + p) * g.Cout;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int n = 64 * h + 4 * li;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok && n < g.Cout) {
+        d = *reinterpret_cast<const float4*>(g.y + row + n);
+        if (g.gate) {
+          const float4 y = *reinterpret_cast<const float4*>(g.gate + row + n);
+          d.x = c1_gate(d.x, y.x, g.gate_slope);
+          d.y = c1_gate(d.y, y.y, g.gate_slope);
+          d.z = c1_gate(d.z, y.z, g.gate_slope);
+          d.w = c1_gate(d.w, y.w, g.gate_slope);
+        }
+      }
+      bs[h][0] += d.x; bs[h][1] += d.y; bs[h][2] += d.z; bs[h][3] += d.w;
+      acc[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.x, bx, acc[h][0], 0, 0, 0);
+      acc[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.y, bx, acc[h][1], 0, 0, 0);
+      acc[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.z, bx, acc[h][2], 0, 0, 0);
+      acc[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.w, bx, acc[h][3], 0, 0, 0);
+    }
+  }
+  // accumulator (h, m), register r, lane (li, kg): channel 64h + 4*(kg*4 + r) + m, tap li
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 64 * h + 4 * (kg * 4 + r) + m;
+        if (n < g.Cout && li < g.K) atomicAdd(&red[li * g.Cout + n], acc[h][m][r]);
+      }
+      const int nb = 64 * h + 4 * li + m;
+      if (nb < g.Cout) atomicAdd(&red[g.K * g.Cout + nb], bs[h][m]);
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < g.K * g.Cout; i += C1_THREADS) {
+    const int k = i / g.Cout, nn = i % g.Cout;
+    atomicAdd(&g.dw[nn * g.K + k], red[i]);
+  }
+  if (g.db)
+    for (int i = threadIdx.x; i < g.Cout; i += C1_THREADS) atomicAdd(&g.db[i], red[g.K * g.Cout + i]);
+}
+
 extern "C" int kantts_conv_c1_launch(const kantts_conv_c1_args* a, int mode, void* stream) {
   if (!a || !a->y || !a->w || (mode != 1 && !a->x) || (mode == 1 && !a->dx)) return KANTTS_E_BADARG;
   const kantts_conv_c1_args& g = *a;
@@ -185,11 +339,25 @@ extern "C" int kantts_conv_c1_launch(const kantts_conv_c1_args* a, int mode, voi
   const size_t lds = ((size_t)(wmax + 3) / 4 * 4 + (size_t)(g.K + 1) * g.Cout) * sizeof(float);
   if (lds > 64 * 1024) return KANTTS_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (mode == 0)
+  static const char* no_mfma = getenv("KANTTS_C1_NO_MFMA");  // A/B switch (scripts/gpu_*.sh)
+  const bool vec = !no_mfma && g.K <= 16 && (!g.gate || ((uintptr_t)g.gate & 15) == 0);
+  if (mode == 0) {
     hipLaunchKernelGGL(conv_c1_fwd_kernel, dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
-  else if (mode == 1)
-    hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
-  else
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
+  } else if (mode == 1) {
+    const size_t plds = (size_t)C1_QB * C1_PLD * sizeof(float);
+    if (vec && g.Cout == 128)
+      hipLaunchKernelGGL((conv_c1_dgrad_mfma_kernel<8>), dim3((unsigned)blocks), dim3(C1_THREADS), plds, st, g);
+    else if (vec && g.Cout == 32)
+      hipLaunchKernelGGL((conv_c1_dgrad_mfma_kernel<2>), dim3((unsigned)blocks), dim3(C1_THREADS), plds, st, g);
+    else
+      hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
+  } else {
+    if (vec && g.Cout <= 64)
+      hipLaunchKernelGGL((conv_c1_wgrad_mfma_kernel<1>), dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
+    else if (vec && g.Cout <= 128)
+      hipLaunchKernelGGL((conv_c1_wgrad_mfma_kernel<2>), dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
+    else
+      hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
+  }
   KANTTS_CHECK_LAUNCH();
 }

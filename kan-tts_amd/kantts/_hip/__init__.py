@@ -98,7 +98,7 @@ class CConvArgs(Structure):
         ("in_mul", c_int32), ("in_add", c_int32), ("in_kstep", c_int32), ("in_div", c_int32), ("phases", c_int32),
         ("inner", c_int32), ("up", c_int32),
         ("out_slope", c_float), ("out_act", c_int32), ("out_gate_slope", c_float), ("out_gate_bf16", c_int32),
-        ("bf_slope", c_float), ("bf_act", c_int32), ("tile", c_int32),
+        ("bf_slope", c_float), ("bf_act", c_int32), ("tile", c_int32), ("res_after_gate", c_int32),
     ]
 
 
@@ -704,7 +704,8 @@ def act_cast_bf16(src, *, act_slope=None, gate=None, gate_slope=0.0, dst=None):
 
 
 def cconv(x_bf, w_bf, *, out=None, out_bf=None, B, Tsrc, Tdst, groups, CR, NG, K, in_mul, in_add, in_kstep, in_div, phases,
-          inner=1, up=1, bias=None, res=None, out_leaky=None, out_gate=None, out_gate_slope=0.0, bf_leaky=None, tile=0):
+          inner=1, up=1, bias=None, res=None, out_leaky=None, out_gate=None, out_gate_slope=0.0, bf_leaky=None, tile=0,
+          res_after_gate=False):
     """bf16 convolution contraction (csrc/cconv.hip, kantts_cconv_launch): x_bf (B, Tsrc, inner, groups*CR) bf16,
     w_bf (K, groups*NG, CR) bf16; writes ``out`` (fp32) and / or ``out_bf`` (bf16, optionally LeakyReLU'd by
     ``bf_leaky``).  Returns False when the kernel does not take the shape."""
@@ -726,6 +727,7 @@ def cconv(x_bf, w_bf, *, out=None, out_bf=None, B, Tsrc, Tdst, groups, CR, NG, K
     if bf_leaky is not None:
         g.bf_act, g.bf_slope = 1, float(bf_leaky)
     g.tile = int(tile)
+    g.res_after_gate = int(bool(res_after_gate))
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

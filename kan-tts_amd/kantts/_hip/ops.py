@@ -1372,6 +1372,116 @@ class _CConvCL(torch.autograd.Function):
         return dx, dw, db, (dy if has_res else None), None, None
 
 
+class _ResStackBF16(torch.autograd.Function):
+    """A HiFi-GAN residual block -- n x [LeakyReLU -> conv(k, d_i) -> LeakyReLU -> conv(k, 1) -> + x] (reference
+    kantts/models/hifigan/layers.py:168-226) -- as ONE autograd node on csrc/cconv.hip (bf16 mode).  Only the residual
+    stream x_i and its gradient g_i exist in fp32; everything between two convolutions is a bf16 image written by the
+    producing epilogue and read by the consuming loader:
+      forward   a_i = bf16(LReLU(x_i))                          (epilogue of the previous conv, or one cast pass for i = 0)
+                ta_i = bf16(LReLU(conv1_i(a_i) + b1_i))         (the dilated conv writes ONLY this image)
+                x_{i+1} = conv2_i(ta_i) + b2_i + x_i  (fp32)  and  a_{i+1}
+      backward  gb = bf16(g_{i+1})                              (epilogue of the previous input gradient, or one cast pass)
+                dW2_i, db2_i from (ta_i, gb);   dt_i = bf16(dgrad2(gb) * LReLU'(ta_i))
+                dW1_i, db1_i from (a_i, dt_i);  g_i = g_{i+1} + dgrad1(dt_i) * LReLU'(a_i)  (fp32) and bf16(g_i)
+    against twelve separate nodes this drops the fp32 write of every dilated conv's output, every gate / cast pass of the
+    backward (two reads of 4 bytes and a write per element and conv) and half of the input-gradient writes.
+    Arguments: x, x_img (bf16(LReLU(x)) or None), slope, cfg = [(K, dil, pad), ...] per conv1 (conv2: dilation 1, pad2),
+    then w1_0, b1_0, w2_0, b2_0, w1_1, ... (tap-major (K, C, C) weights)."""
+
+    @staticmethod
+    def forward(ctx, x, x_img, slope, cfgs, *wb):
+        x = _c(x)
+        B, T, C = x.shape
+        n = len(cfgs)
+        a = x_img if x_img is not None else act_cast_bf16(x, act_slope=slope)
+        saved, wimgs = [], []
+        xi = x
+        for i, (K, dil, pad1, pad2) in enumerate(cfgs):
+            w1, b1, w2, b2 = wb[4 * i:4 * i + 4]
+            w1b = torch.empty((K, C, C), device=x.device, dtype=torch.bfloat16).copy_(w1)
+            w2b = torch.empty((K, C, C), device=x.device, dtype=torch.bfloat16).copy_(w2)
+            ta = torch.empty((B, T, C), device=x.device, dtype=torch.bfloat16)
+            if not cconv(a, w1b, out_bf=ta, bf_leaky=slope, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K, in_mul=1,
+                         in_add=-pad1, in_kstep=dil, in_div=1, phases=1, bias=b1):
+                raise RuntimeError("cconv refused a residual-block convolution")
+            xn = torch.empty((B, T, C), device=x.device, dtype=torch.float32)
+            an = torch.empty((B, T, C), device=x.device, dtype=torch.bfloat16) if i + 1 < n else None
+            if not cconv(ta, w2b, out=xn, out_bf=an, bf_leaky=slope, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K,
+                         in_mul=1, in_add=-pad2, in_kstep=1, in_div=1, phases=1, bias=b2, res=xi):
+                raise RuntimeError("cconv refused a residual-block convolution")
+            saved += [a, ta]
+            wimgs += [w1, w2]
+            a, xi = an, xn
+        ctx.cfgs, ctx.slope, ctx.shape = cfgs, slope, (B, T, C)
+        ctx.has_bias = [(wb[4 * i + 1] is not None, wb[4 * i + 3] is not None) for i in range(n)]
+        ctx.save_for_backward(*saved, *wimgs)
+        return xi
+
+    @staticmethod
+    def backward(ctx, g):
+        cfgs, slope = ctx.cfgs, ctx.slope
+        B, T, C = ctx.shape
+        n = len(cfgs)
+        t = ctx.saved_tensors
+        imgs, ws = t[:2 * n], t[2 * n:]
+        g = _c(g)
+        gb = act_cast_bf16(g)
+        grads = [None] * (4 * n)
+        need_x = ctx.needs_input_grad[0]
+        for i in range(n - 1, -1, -1):
+            K, dil, pad1, pad2 = cfgs[i]
+            a, ta = imgs[2 * i], imgs[2 * i + 1]
+            w1, w2 = ws[2 * i], ws[2 * i + 1]
+            # conv2 (dilation 1): weight / bias gradient, then the gradient of its input image gated by LReLU'(t_i)
+            b1, b2 = ctx.has_bias[i]
+            dw2 = gzeros((K, C, C), g.device)
+            db2 = gzeros((C,), g.device) if b2 else None
+            if not cconv_wgrad(ta, gb, dw2, db2, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K, stride=1, dil=1, pad=pad2):
+                raise RuntimeError("cconv weight gradient refused a residual-block convolution")
+            w2d = torch.empty((K, C, C), device=g.device, dtype=torch.bfloat16).copy_(w2.transpose(1, 2))
+            dt = torch.empty((B, T, C), device=g.device, dtype=torch.bfloat16)
+            if not cconv(gb, w2d, out_bf=dt, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K, in_mul=1, in_add=pad2,
+                         in_kstep=-1, in_div=1, phases=1, out_gate=ta, out_gate_slope=slope):
+                raise RuntimeError("cconv input gradient refused a residual-block convolution")
+            dw1 = gzeros((K, C, C), g.device)
+            db1 = gzeros((C,), g.device) if b1 else None
+            if not cconv_wgrad(a, dt, dw1, db1, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K, stride=1, dil=dil, pad=pad1):
+                raise RuntimeError("cconv weight gradient refused a residual-block convolution")
+            grads[4 * i:4 * i + 4] = [dw1, db1, dw2, db2]
+            if i > 0 or need_x:
+                w1d = torch.empty((K, C, C), device=g.device, dtype=torch.bfloat16).copy_(w1.transpose(1, 2))
+                gn = torch.empty((B, T, C), device=g.device, dtype=torch.float32)
+                gnb = torch.empty((B, T, C), device=g.device, dtype=torch.bfloat16) if i > 0 else None
+                # the identity path g joins AFTER the LeakyReLU' gate of the convolution branch (res_after_gate)
+                if not cconv(dt, w1d, out=gn, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K, in_mul=1, in_add=pad1,
+                             in_kstep=-dil, in_div=1, phases=1, out_gate=a, out_gate_slope=slope, res=g,
+                             res_after_gate=True, out_bf=gnb):
+                    raise RuntimeError("cconv input gradient refused a residual-block convolution")
+                g, gb = gn, gnb
+        return (g if need_x else None, None, None, None) + tuple(grads)
+
+
+def res_stack_ok(x, K):
+    """Does the fused residual-stack node apply to input x (B, T, C) with kernel size K?  (bf16 mode, MFMA-sized)"""
+    return (x.dim() == 3 and not os.environ.get("KANTTS_NO_RES_STACK")
+            and _cconv_ok(x, x.shape[2], x.shape[2], K, x.shape[0] * x.shape[1], 1))
+
+
+def res_stack(x, slope, convs):
+    """ResidualBlock forward on the fused bf16 node.  ``convs``: [(w1, b1, K, dil, pad1, w2, b2, pad2), ...] with
+    tap-major (K, C, C) weights; returns None when a weight has another shape."""
+    B, T, C = x.shape
+    for w1, b1, K, dil, pad1, w2, b2, pad2 in convs:
+        if tuple(w1.shape) != (K, C, C) or tuple(w2.shape) != (K, C, C):
+            return None
+    cfgs = [(int(K), int(dil), int(pad1), int(pad2)) for _, _, K, dil, pad1, _, _, pad2 in convs]
+    flat = []
+    for w1, b1, K, dil, pad1, w2, b2, pad2 in convs:
+        flat += [w1, b1, w2, b2]
+    x_img = get_image(x, slope) if x.is_contiguous() else None
+    return _ResStackBF16.apply(x, x_img, float(slope), cfgs, *flat)
+
+
 _IMG_ATTR = "_kantts_bf16_image"
 
 

@@ -160,7 +160,22 @@ class ResidualBlock(torch.nn.Module):
         self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
 
     def forward_cl(self, x):
-        # bf16 mode: every convolution also writes the activated bf16 image its successor reads (ops.set_image)
+        # bf16 mode, wide enough for the MFMA kernels: the whole stack as one autograd node (ops._ResStackBF16)
+        if (ops.res_stack_ok(x, self.convs1[0].conv1d.kernel_size[0])
+                and all(hasattr(c.conv1d, "weight_g") and c.conv1d.groups == 1 and c.conv1d.stride[0] == 1
+                        and c.conv1d.weight_v.shape[1] % 4 == 0 for c in list(self.convs1) + list(self.convs2))):
+            spec = []
+            for c1, c2 in zip(self.convs1, self.convs2):
+                (w1, t1), (w2, t2) = conv_weight(c1.conv1d), conv_weight(c2.conv1d)
+                if not (t1 and t2):
+                    spec = None
+                    break
+                spec.append((w1, c1.conv1d.bias, c1.conv1d.kernel_size[0], c1.conv1d.dilation[0], c1.pad, w2, c2.conv1d.bias,
+                             c2.pad))
+            y = ops.res_stack(x, self.slope, spec) if spec else None
+            if y is not None:
+                return y
+        # otherwise: every convolution also writes the activated bf16 image its successor reads (ops.set_image)
         n = len(self.convs1)
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
             xt = c1.forward_cl(x, in_leaky=self.slope, image=self.slope)

@@ -1101,11 +1101,13 @@ class EmulatedLib:
             acc += _arr(g.bias, N)
         if g.out_act:
             acc = np.where(acc > 0, acc, acc * np.float32(g.out_slope))
-        if g.res:
+        if g.res and not g.res_after_gate:
             acc += fold(_arr(g.res, B * Td * P * N), Td, N)
         if g.out_gate:
             q = fold(_rd(g.out_gate, B * Td * P * N, bool(g.out_gate_bf16)), Td, N)
             acc *= np.where(q > 0, 1.0, np.float32(g.out_gate_slope))
+        if g.res and g.res_after_gate:
+            acc += fold(_arr(g.res, B * Td * P * N), Td, N)
         res = acc.reshape(B, P, Td, N).transpose(0, 2, 1, 3).astype(np.float32)
         if g.out:
             _arr(g.out, B * Td * P * N)[:] = res.reshape(-1)

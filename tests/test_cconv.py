@@ -365,7 +365,8 @@ def _block_and_stack_run(ops, device, use_images):
     from kantts.models.hifigan.hifigan import PeriodDiscriminator
     from kantts.models.hifigan.layers import ResidualBlock
 
-    real_get = ops.get_image
+    real_get, real_ok = ops.get_image, ops.res_stack_ok
+    ops.res_stack_ok = lambda x, K: False  # this test is about the per-convolution chain (the fused node has its own)
     if not use_images:
         ops.get_image = lambda t, slope: None
     casts = {"n": 0}
@@ -390,7 +391,7 @@ def _block_and_stack_run(ops, device, use_images):
         grads = [x.grad, wav.grad] + [p.grad for p in list(blk.parameters()) + list(D.parameters())]
         return y.detach().cpu(), [t.detach().cpu() for t in grads], casts["n"]
     finally:
-        ops.get_image, ops.act_cast_bf16 = real_get, real_cast
+        ops.get_image, ops.act_cast_bf16, ops.res_stack_ok = real_get, real_cast, real_ok
 
 
 def _check_image_handover(ops, device, exact):
@@ -415,3 +416,45 @@ def test_image_handover_is_bit_identical_emulated(emulated_cabi, bf16_all_sizes)
 @pytest.mark.gpu
 def test_image_handover_changes_nothing_gpu(bf16_all_sizes):
     _check_image_handover(bf16_all_sizes, "cuda", False)
+
+
+# ------------------------------------------------------------------------------------------------- fused residual stack
+def _res_block_run(ops, device, fused, C=32, K=3, T=80):
+    from kantts.models.hifigan.layers import ResidualBlock
+
+    real_ok = ops.res_stack_ok
+    if not fused:
+        ops.res_stack_ok = lambda x, K: False
+    try:
+        torch.manual_seed(11)
+        blk = ResidualBlock(C, kernel_size=K, dilation=(1, 3, 5), causal=True).to(device)
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(2, T, C, generator=g).to(device).requires_grad_(True)
+        y = blk.forward_cl(x)
+        cot = torch.randn(y.shape, generator=g).to(device)
+        (y * cot).sum().backward()
+        return y.detach().cpu(), [x.grad.detach().cpu()] + [p.grad.detach().cpu() for p in blk.parameters()]
+    finally:
+        ops.res_stack_ok = real_ok
+
+
+def _check_res_stack(ops, device):
+    """The one-node residual stack (ops._ResStackBF16) against the chain of per-convolution nodes: the same bf16 images,
+    the same roundings of the gradients, the same kernels -- so the same numbers, not merely close ones."""
+    for C, K, T in ((32, 3, 80), (64, 7, 50), (40, 11, 300)):
+        y1, g1 = _res_block_run(ops, device, True, C, K, T)
+        y0, g0 = _res_block_run(ops, device, False, C, K, T)
+        assert torch.equal(y1, y0), (C, K)
+        for a, b in zip(g1, g0):
+            assert rel_l2(a, b) < 1e-6, (C, K)
+
+
+def test_fused_residual_stack_equals_the_chain_emulated(emulated_cabi, bf16_all_sizes, monkeypatch):
+    calls = _count_calls(monkeypatch, bf16_all_sizes)
+    _check_res_stack(bf16_all_sizes, "cpu")
+    assert calls["cconv"] > 0
+
+
+@pytest.mark.gpu
+def test_fused_residual_stack_equals_the_chain_gpu(bf16_all_sizes):
+    _check_res_stack(bf16_all_sizes, "cuda")
