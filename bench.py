@@ -375,7 +375,7 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
         res["upsampling"] = {"ms": msb, "bound": "hbm", "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": gb / PEAK_HBM_GBPS, "algorithmic_bytes": belems * 2, "bytes_dtype": "bf16",
                              "tflops": flops / (msb * 1e-3) / 1e12, "stage_us": stage_b,
-                             "kernel": "bgemm_nt_kernel (layers 0-1) + upsample_stream_kernel (layers 2-3)",
+                             "kernel": "cconv_kernel, 2-tap polyphase form (layers 0-1) + upsample_stream_kernel (layers 2-3)",
                              "weight_prep_ms_not_included": prep_ms,
                              "note": "4 launches; bf16 activations in and out; the polyphase re-layout + bf16 cast of the "
                                      "weights (6.7 MB, once per optimizer step / once for inference) is timed separately"}
@@ -388,11 +388,29 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
         out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    res["gan_step_eager_ms"] = dt * 1e3
+    res["losses"] = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in out.items()}
+    # the step as training runs it: both phases + the three Adam updates replayed from one hipGraph
+    # (kantts/train/gan_graph_step.py; graph == eager is tests/test_hifigan.py::test_graphed_gan_step_matches_eager_gpu)
+    from kantts.train.gan_graph_step import GraphedGanStep
+
+    gstep = GraphedGanStep(model, optimizer, scheduler, crit, config, y, x)
+    gstep()
+    torch.cuda.synchronize()
+    n = max(steps, 10)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = gstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
     res["gan_step_ms"] = dt * 1e3
+    res["gan_step_schedule"] = "hipGraph replay of the whole step (generator phase + discriminator phase + 3 Adam updates)"
     res["gan_step_samples_per_s"] = B * T_wav / dt
+    res["gan_step_tflops"] = 8.3e12 * B / 32 / dt / 1e12
+    res["gan_step_mfma_frac"] = res["gan_step_tflops"] / PEAK_TFLOPS["bf16"] if precision == "bf16" else None
     res["value"] = res["gan_step_samples_per_s"]
     res["unit"] = "audio-samples/s (GAN training step)"
-    res["losses"] = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in out.items()}
+    res["graph_losses"] = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in out.items()}
     return res
 
 

@@ -434,7 +434,13 @@ extern "C" int kantts_cconv_launch(const kantts_cconv_args* ap, void* stream) {
     }
   }
   static const char* env_stage = getenv("KANTTS_CCONV_STAGES");
-  const int nst = env_stage ? atoi(env_stage) : 0;
+  int nst = env_stage ? atoi(env_stage) : 0;
+  if (nst == 0 && tile == 128128) {
+    // a grid that cannot give every CU two tiles anyway gains nothing from two co-resident workgroups: spend the LDS
+    // on a 4-deep ring instead (three steps of loads in flight hide the L2 / HBM round trip of a short reduction)
+    const long long t128 = kantts_cdiv(rows, 128) * g.groups * kantts_cdiv(g.NG, 128) * g.phases;
+    if (t128 <= 320) nst = 4;
+  }
   switch (tile) {
     case 128128:
       if (nst == 3) return cc_launch<128, 128, 2, 2, 3>(P, st);

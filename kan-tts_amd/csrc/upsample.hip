@@ -17,6 +17,8 @@
 //     repeat-upsample branch) in the store.
 // The wide early layers (Cin = 512 / 256, weights 4 / 1 MB) are ordinary contractions and go through kantts_bgemm_nt with
 // two token-shifted segments (host layer).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -163,7 +165,9 @@ static int up_launch(const UpArgs& a, hipStream_t st) {
   }
   const int ntile = (a.ntok + 15) / 16;
   int blocks = kantts_cdiv(ntile, UP_THREADS / 64);
-  const int per_cu = lds > 40 * 1024 ? 2 : 4;  // workgroups a CU can hold (LDS bound)
+  int per_cu = lds > 40 * 1024 ? 2 : 4;  // workgroups a CU can hold (LDS bound)
+  static const char* env_pc = getenv("KANTTS_UPSTREAM_WG_PER_CU");  // experiment switch
+  if (env_pc && atoi(env_pc) > 0) per_cu = atoi(env_pc);
   if (blocks > 256 * per_cu) blocks = 256 * per_cu;
   hipLaunchKernelGGL((upsample_stream_kernel<CIN, COUT, S>), dim3(blocks), dim3(UP_THREADS), lds, st, a);
   KANTTS_CHECK_LAUNCH();

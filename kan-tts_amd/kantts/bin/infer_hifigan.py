@@ -40,11 +40,13 @@ def load_model(ckpt, config=None):
     from kantts.models.hifigan.hifigan import Generator
 
     params = config["Model"]["Generator"]["params"]
-    if params.get("out_channels", 1) > 1:
-        raise NotImplementedError("multi-band (PQMF) generators are outside the hot path")
     model = Generator(**params)
     states = torch.load(ckpt, map_location="cpu")
     model.load_state_dict(states["model"]["generator"])
+    if params.get("out_channels", 1) > 1:  # multi-band generator: PQMF synthesis after it (reference :47-52, :120-121)
+        from kantts.models.pqmf import PQMF
+
+        model.pqmf = PQMF(subbands=params["out_channels"], **config.get("pqmf", {}))
     return model
 
 
@@ -84,7 +86,9 @@ def hifigan_infer(input_mel, ckpt_path, output_dir, config=None):
                 feats = binarize(feats)
             mel_data = torch.from_numpy(np.ascontiguousarray(feats)).float().to(device)
             y = model(mel_data.transpose(1, 0).unsqueeze(0))  # (T, C) -> (1, C, T)
-            y = y.view(-1).cpu().numpy()
+            if hasattr(model, "pqmf"):
+                y = model.pqmf.synthesis(y)
+            y = y.reshape(-1).cpu().numpy()
             pcm_len += len(y)
             wavfile.write(os.path.join(output_dir, "%s_gen.wav" % utt_id), sr,
                           (np.clip(y, -1.0, 1.0) * 32767.0).astype(np.int16))

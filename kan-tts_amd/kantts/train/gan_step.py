@@ -25,6 +25,27 @@ def generator_loss(model, criterion, x, y, adversarial=True, feature_match_gradi
     y_ = model["generator"](x)
     losses = {}
     gen_loss = 0.0
+    # multi-band generators (out_channels = subbands): the full-band signal comes out of the PQMF synthesis bank and
+    # carries every full-band loss and the discriminators (reference trainer.py:476-478)
+    pqmf = model.get("pqmf", None)
+    y_mb_ = None
+    if pqmf is not None:
+        y_mb_ = y_
+        y_ = pqmf.synthesis(y_mb_)
+    if criterion.get("stft_loss", None) is not None:  # multi-resolution STFT loss (reference :484-493)
+        sc, mag = criterion["stft_loss"](y_, y)
+        losses["spectral_convergence_loss"], losses["log_stft_magnitude_loss"] = sc, mag
+        gen_loss = gen_loss + (sc + mag) * criterion["stft_loss"].weights
+    if criterion.get("subband_stft_loss", None) is not None:
+        # reference :496-506 halves what has been summed so far and adds half the sub-band loss.  (It looks the
+        # criterion up under the key "sub_stft", which criterion_builder never creates -- upstream raises KeyError as
+        # soon as the loss is enabled; the key it tests for, "subband_stft_loss", is used here.)
+        if pqmf is None:
+            raise ValueError("subband_stft_loss needs a multi-band generator (model['pqmf'])")
+        gen_loss = gen_loss * 0.5
+        ssc, smag = criterion["subband_stft_loss"](y_mb_, pqmf.analysis(y))
+        losses["sub_spectral_convergence_loss"], losses["sub_log_stft_magnitude_loss"] = ssc, smag
+        gen_loss = gen_loss + 0.5 * (ssc + smag)
     if criterion.get("mel_loss", None) is not None:
         losses["mel_loss"] = criterion["mel_loss"](y_, y)
         gen_loss = gen_loss + losses["mel_loss"] * criterion["mel_loss"].weights
@@ -57,6 +78,8 @@ def discriminator_loss(model, criterion, x, y, batched=True):
     reference (:556-577): half the launches, weight-norm / re-layout work and twice the rows per tile."""
     with torch.no_grad():
         y_ = model["generator"](x)
+        if model.get("pqmf", None) is not None:  # reference :561-562
+            y_ = model["pqmf"].synthesis(y_)
     dis_loss, losses = 0.0, {"real_loss": 0.0, "fake_loss": 0.0}
     B = y.size(0)
     both = torch.cat([y, y_.detach()], dim=0) if batched else None

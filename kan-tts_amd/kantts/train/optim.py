@@ -145,26 +145,32 @@ class ParamArena:
             self._build_buckets()
 
     def _build_buckets(self):
+        """Greedy cut of the arena into at most ``n_buckets`` contiguous parameter runs of about numel / n_buckets
+        elements: a bucket is closed once its (aligned) extent reaches the target, so the ranges are disjoint and cover
+        the arena by construction -- also when one parameter alone is larger than the target."""
         n = self.numel
         step = (n + self.n_buckets - 1) // self.n_buckets
-        step = (step + self.align - 1) // self.align * self.align
         self.buckets = []
         self.bucket_of = [0] * len(self.params)
-        for lo in range(0, n, step):
-            self.buckets.append({"lo": lo, "hi": min(n, lo + step), "params": [], "pending": 0, "handle": None})
+        cur = None
         for i, o in enumerate(self.offsets):
-            b = min(o // step, len(self.buckets) - 1)  # a parameter belongs to the bucket its first element falls in
-            self.bucket_of[i] = b
-            self.buckets[b]["params"].append(i)
-        # a parameter that straddles a boundary extends its bucket's range; ranges stay disjoint and cover the arena
-        for k, b in enumerate(self.buckets):
-            if b["params"]:
-                last = b["params"][-1]
-                end = self.offsets[last] + (self.params[last].numel() + self.align - 1) // self.align * self.align
-                b["hi"] = max(b["hi"], end)
-            if k + 1 < len(self.buckets):
-                self.buckets[k + 1]["lo"] = max(self.buckets[k + 1]["lo"], b["hi"])
-        self.buckets = [b for b in self.buckets if b["hi"] > b["lo"]]
+            if cur is None:
+                cur = {"lo": o, "hi": o, "params": [], "pending": 0, "handle": None}
+            cur["params"].append(i)
+            self.bucket_of[i] = len(self.buckets)
+            end = self.offsets[i + 1] if i + 1 < len(self.offsets) else n  # aligned start of the next parameter
+            cur["hi"] = end
+            if cur["hi"] - cur["lo"] >= step and len(self.buckets) + 1 < self.n_buckets:
+                self.buckets.append(cur)
+                cur = None
+        if cur is not None:
+            self.buckets.append(cur)
+        if self.buckets:
+            self.buckets[0]["lo"], self.buckets[-1]["hi"] = 0, n
+        # the ranges partition [0, numel): every element is exchanged exactly once
+        assert all(x["hi"] == y["lo"] for x, y in zip(self.buckets, self.buckets[1:])) and (
+            not self.buckets or (self.buckets[0]["lo"] == 0 and self.buckets[-1]["hi"] == n))
+        assert all(0 <= self.bucket_of[i] < len(self.buckets) for i in range(len(self.params)))
         self._active = False
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))

@@ -295,11 +295,37 @@ class Sambert_Trainer(Trainer):
 class GAN_Trainer(Trainer):
     """HiFi-GAN trainer (reference :276-675); batch = (y wav (B,1,T), x mel (B,C,T/hop))."""
 
+    def __init__(self, *args, graph=False, **kwargs):
+        """``graph=True``: once both phases are active, the whole step (both phases, three Adam updates) is captured into
+        one hipGraph per batch shape and replayed (kantts/train/gan_graph_step.py); the vocoder dataset crops every batch
+        to one shape, so this is a single capture.  Needs the arena optimizers and a single process."""
+        super().__init__(*args, **kwargs)
+        self.graph = graph
+        self._graphs = {}
+
+    def _graph_ready(self):
+        return (self.graph and self.steps > self.config.get("discriminator_train_start_steps", 0)
+                and self.steps >= self.config.get("generator_train_start_steps", 0))
+
     def train_step(self, batch):
         y, x = batch
         y, x = y.to(self.device, non_blocking=True), x.to(self.device, non_blocking=True)
-        losses = gan_train_step(self.model, self.optimizer, self.scheduler, self.criterion, self.config, y, x,
-                                steps=self.steps)
+        if self._graph_ready():
+            from kantts.train.gan_graph_step import GraphedGanStep
+
+            key = (tuple(y.shape), tuple(x.shape))
+            g = self._graphs.get(key)
+            if g is None:
+                if len(self._graphs) >= 4:
+                    self._graphs.pop(next(iter(self._graphs)))
+                g = self._graphs[key] = GraphedGanStep(self.model, self.optimizer, self.scheduler, self.criterion,
+                                                       self.config, y, x, steps=self.steps)
+            else:
+                g.load_batch(y, x)
+            losses = g()
+        else:
+            losses = gan_train_step(self.model, self.optimizer, self.scheduler, self.criterion, self.config, y, x,
+                                    steps=self.steps)
         self._accumulate("train", losses)
         return losses
 

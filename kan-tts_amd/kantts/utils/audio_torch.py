@@ -193,10 +193,18 @@ def _stft_dft_gemm(x, fft_size, hop_size, win_length, window_name):
 
 
 def stft(x, fft_size, hop_size, win_length, window):
-    """|STFT| (B, frames, fft_size//2+1) with clamp(re^2+im^2, 1e-7) (reference :8-31), differentiable.  ``window`` may
-    be a window tensor (as the reference's callers pass) or a name like "hann" / "hann_window"."""
-    name = window if isinstance(window, str) else "hann"
-    name = name.replace("_window", "")
+    """|STFT| (B, frames, fft_size//2+1) with clamp(re^2+im^2, 1e-7) (reference :8-31), differentiable.  ``window`` is a
+    name like "hann" / "hann_window", or a window TENSOR as the reference's callers pass: the kernels build their window
+    from the name, so a tensor is accepted only if it IS the periodic Hann window of ``win_length`` (every shipped config;
+    anything else raises instead of being silently replaced)."""
+    if isinstance(window, str):
+        name = window.replace("_window", "")
+    else:
+        w = torch.as_tensor(window)
+        if w.numel() != win_length or not torch.allclose(
+                w.detach().float().cpu(), torch.hann_window(win_length, dtype=torch.float32), atol=1e-6):
+            raise NotImplementedError("stft(): only the Hann window (by name, or the hann_window(win_length) tensor)")
+        name = "hann"
     if fft_size & (fft_size - 1):
         return _stft_dft_gemm(x, fft_size, hop_size, win_length, name)
     _, mag = _launch(x, fft_size, hop_size, win_length, name, 1, 1e-7, want_mag=True)

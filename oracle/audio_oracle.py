@@ -58,18 +58,13 @@ def mel_spectrogram(x, fs=22050, fft_size=1024, hop_size=256, win_length=None, n
     return out.transpose(1, 2)
 
 
-def dsp_melspectrogram(y, sample_rate, n_fft=1024, hop_length=256, win_length=1024, n_mels=80, max_norm=1.0,
-                       min_level_db=-100, ref_level_db=20, fmin=50, fmax=8000, symmetric=False, preemphasize=False):
-    """``melspectrogram`` of kantts/preprocess/audio_processor/core/dsp.py:165-201 in float64 numpy:
-    librosa.stft(y, n_fft, hop_length, win_length) [librosa 0.9.2: center=True with zero padding, periodic Hann window
-    centred in n_fft; PARITY UNPINNED -- librosa is not installed and the reference holds no fixture for this path]
-    -> |D| -> librosa mel basis (:135-139) -> 20 log10(max(1e-5, .)) - ref_level_db (:20, :190) -> _normalize (:66-75)
-    -> transpose to (frames, n_mels)."""
+def dsp_stft_magnitude(y, n_fft, hop_length, win_length):
+    """|librosa.stft(y, n_fft, hop_length, win_length)| under librosa 0.9.2's defaults (center=True, pad_mode="constant",
+    periodic Hann window centred in n_fft): (frames, bins) float64.  Pinned against scipy.signal.stft by
+    tests/test_independent_pins.py."""
     import numpy as np
 
     y = np.asarray(y, dtype=np.float64)
-    if preemphasize:
-        y = np.concatenate([y[:1], y[1:] - 0.98 * y[:-1]])
     pad = n_fft // 2
     yp = np.pad(y, (pad, pad))
     frames = 1 + len(y) // hop_length
@@ -79,9 +74,24 @@ def dsp_melspectrogram(y, sample_rate, n_fft=1024, hop_length=256, win_length=10
     wpad = np.zeros(n_fft)
     wpad[left:left + win_length] = w
     idx = np.arange(n_fft)[None, :] + hop_length * np.arange(frames)[:, None]
-    D = np.fft.rfft(yp[idx] * wpad, n=n_fft, axis=-1)  # (frames, bins)
+    return np.abs(np.fft.rfft(yp[idx] * wpad, n=n_fft, axis=-1))
+
+
+def dsp_melspectrogram(y, sample_rate, n_fft=1024, hop_length=256, win_length=1024, n_mels=80, max_norm=1.0,
+                       min_level_db=-100, ref_level_db=20, fmin=50, fmax=8000, symmetric=False, preemphasize=False):
+    """``melspectrogram`` of kantts/preprocess/audio_processor/core/dsp.py:165-201 in float64 numpy:
+    librosa.stft(y, n_fft, hop_length, win_length) [librosa 0.9.2: center=True with zero padding, periodic Hann window
+    centred in n_fft -- framing / window / padding pinned against scipy.signal.stft; the mel basis stays PARITY UNPINNED]
+    -> |D| -> librosa mel basis (:135-139) -> 20 log10(max(1e-5, .)) - ref_level_db (:20, :190) -> _normalize (:66-75)
+    -> transpose to (frames, n_mels)."""
+    import numpy as np
+
+    y = np.asarray(y, dtype=np.float64)
+    if preemphasize:
+        y = np.concatenate([y[:1], y[1:] - 0.98 * y[:-1]])
+    mag = dsp_stft_magnitude(y, n_fft, hop_length, win_length)  # (frames, bins)
     basis = librosa_mel(sr=sample_rate, n_fft=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax).astype(np.float64)
-    S = 20 * np.log10(np.maximum(1e-5, np.abs(D) @ basis.T)) - ref_level_db
+    S = 20 * np.log10(np.maximum(1e-5, mag @ basis.T)) - ref_level_db
     u = (S - min_level_db) / (-min_level_db)
     if symmetric:
         return np.clip(2 * max_norm * u - max_norm, -max_norm, max_norm)

@@ -292,3 +292,33 @@ def test_two_process_graphed_step_on_one_gpu(tmp_path):
     assert torch.equal(r0["flat"], r1["flat"])  # replicas identical after three captured DP steps
     assert r0["step"] == r1["step"] == 3
     assert r0["losses"] != r1["losses"] and all(v == v for v in r0["losses"] + r1["losses"])
+
+
+def test_gradient_buckets_partition_the_arena():
+    """ParamArena._build_buckets: contiguous, disjoint ranges covering [0, numel) with a valid bucket index per parameter
+    -- including a parameter larger than numel / n_buckets (params [64, 4000, 64, 64] with 4 buckets used to produce
+    overlapping ranges, i.e. a twice-reduced region, and stale indices) and more buckets than parameters."""
+    from kantts.train.optim import ParamArena
+
+    class Net(torch.nn.Module):
+        def __init__(self, sizes):
+            super().__init__()
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(n)) for n in sizes])
+
+    for sizes, nb in (([64, 4000, 64, 64], 4), ([5], 4), ([100] * 9, 4), ([7, 9000, 3, 3, 3, 8000, 1], 3), ([64] * 4, 8)):
+        arena = ParamArena(Net(sizes))
+        arena.n_buckets = nb
+        arena._build_buckets()
+        bs = arena.buckets
+        assert 1 <= len(bs) <= nb, (sizes, nb)
+        assert bs[0]["lo"] == 0 and bs[-1]["hi"] == arena.numel
+        for x, y in zip(bs, bs[1:]):
+            assert x["hi"] == y["lo"]
+        seen = []
+        for k, b in enumerate(bs):
+            assert b["params"], (sizes, nb)
+            for i in b["params"]:
+                assert arena.bucket_of[i] == k
+                assert b["lo"] <= arena.offsets[i] and arena.offsets[i] + arena.params[i].numel() <= b["hi"]
+                seen.append(i)
+        assert seen == list(range(len(sizes)))

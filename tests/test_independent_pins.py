@@ -1,0 +1,82 @@
+"""Independent pins for the third-party arithmetic the reference inherits from packages that are not installed here
+(librosa 0.9.2, pytorch_wavelets): code that was NOT written for this repository judges the restatements.
+
+  * STFT framing / window / padding -- ``scipy.signal.stft`` (independent implementation) against
+    oracle/audio_oracle.py (stft_magnitude: the torch.stft conventions of kantts/utils/audio_torch.py:8-31;
+    dsp_stft_magnitude: the librosa.stft(center=True, pad_mode="constant") conventions of
+    kantts/preprocess/audio_processor/core/dsp.py:8-9) and against the product's host path.  What this pins: centre
+    padding by n_fft // 2 (zeros for the mel paths -- librosa >= 0.9 / MelSpectrogram's hard-coded "constant" --, even
+    reflection for ``stft``), the PERIODIC Hann window of win_length centred inside n_fft, hop framing, frame count
+    1 + T // hop, one-sided bins.  What stays unpinned: librosa.filters.mel (Slaney basis) -- self-consistency KATs only
+    (tests/test_thirdparty_kat.py).
+  * db3 analysis filters of DWT1DForward -- the closed-form Daubechies D6 coefficients (textbook formula in sqrt(10) and
+    sqrt(5 + 2 sqrt(10))) against the decimal table the product ships (kantts/models/hifigan/hifigan.py DB3_DEC_LO)."""
+import math
+
+import numpy as np
+import pytest
+import scipy.signal
+import torch
+
+import audio_oracle as A
+
+
+def _scipy_mag(x, n_fft, hop, win_length, boundary):
+    w = scipy.signal.get_window("hann", win_length, fftbins=True)  # periodic
+    left = (n_fft - win_length) // 2
+    wpad = np.zeros(n_fft)
+    wpad[left:left + win_length] = w
+    _, _, Z = scipy.signal.stft(x, window=wpad, nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft, boundary=boundary,
+                                padded=False, return_onesided=True, scaling="spectrum")
+    return np.abs(Z).T * wpad.sum()  # (frames, bins), un-normalised like torch.stft / librosa.stft
+
+
+@pytest.mark.parametrize("n_fft,hop,win", [(1024, 256, 1024), (2048, 200, 1000), (1024, 120, 600), (512, 50, 240)])
+def test_stft_conventions_pinned_by_scipy(n_fft, hop, win):
+    rng = np.random.default_rng(n_fft + hop)
+    T = 5000
+    x = rng.standard_normal(T)
+    frames = 1 + T // hop
+    # librosa-style (zero padding): the offline extractor and MelSpectrogram
+    ref0 = _scipy_mag(x, n_fft, hop, win, "zeros")[:frames]
+    got0 = A.dsp_stft_magnitude(x, n_fft, hop, win)
+    assert got0.shape == ref0.shape
+    assert np.abs(got0 - ref0).max() < 1e-9 * max(1.0, ref0.max())
+    t0 = A.stft_magnitude(torch.from_numpy(x)[None], n_fft, hop, win, clamp=0.0, pad_mode="constant")[0].numpy()
+    assert np.abs(t0 - ref0).max() < 1e-9 * max(1.0, ref0.max())
+    # torch.stft default (reflect = even extension): the STFT losses / SpecDiscriminator
+    ref1 = _scipy_mag(x, n_fft, hop, win, "even")[:frames]
+    t1 = A.stft_magnitude(torch.from_numpy(x)[None], n_fft, hop, win, clamp=0.0, pad_mode="reflect")[0].numpy()
+    assert np.abs(t1 - ref1).max() < 1e-9 * max(1.0, ref1.max())
+
+
+def test_product_dsp_melspectrogram_sits_on_the_pinned_stft():
+    """The product's offline extractor (float32 host path) against mel(basis) o scipy-STFT: the only unpinned factor left
+    is the mel basis itself."""
+    from kantts.preprocess.audio_processor.core import dsp
+    from thirdparty import librosa_mel
+
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(6000) * 0.1).astype(np.float32)
+    n_fft, hop, win = 2048, 200, 1000
+    mag = _scipy_mag(x.astype(np.float64), n_fft, hop, win, "zeros")[:1 + len(x) // hop]
+    basis = librosa_mel(sr=16000, n_fft=n_fft, n_mels=80, fmin=0, fmax=8000).astype(np.float64)
+    S = 20 * np.log10(np.maximum(1e-5, mag @ basis.T)) - 20.0
+    want = np.clip((S + 100.0) / 100.0, 0, 1.0)
+    ref = A.dsp_melspectrogram(x, 16000, n_fft=n_fft, hop_length=hop, win_length=win, fmin=0, fmax=8000)
+    assert np.abs(ref - want).max() < 1e-9
+
+
+def test_db3_filter_table_equals_the_closed_form():
+    from kantts.models.hifigan.hifigan import DB3_DEC_HI, DB3_DEC_LO
+
+    s10 = math.sqrt(10.0)
+    s = math.sqrt(5.0 + 2.0 * s10)
+    d = 16.0 * math.sqrt(2.0)
+    rec_lo = [(1 + s10 + s) / d, (5 + s10 + 3 * s) / d, (10 - 2 * s10 + 2 * s) / d, (10 - 2 * s10 - 2 * s) / d,
+              (5 + s10 - 3 * s) / d, (1 + s10 - s) / d]  # Daubechies D6 scaling filter
+    dec_lo = rec_lo[::-1]  # analysis low-pass = time-reversed scaling filter
+    assert np.abs(np.array(DB3_DEC_LO) - np.array(dec_lo)).max() < 1e-10  # the table carries ~12 significant digits
+    dec_hi = [((-1.0) ** (k + 1)) * dec_lo[5 - k] for k in range(6)]  # quadrature mirror
+    assert np.abs(np.array(DB3_DEC_HI) - np.array(dec_hi)).max() < 1e-10
+    assert abs(sum(dec_lo) - math.sqrt(2.0)) < 1e-12 and abs(sum(dec_hi)) < 1e-12 and abs(sum(v * v for v in dec_lo) - 1.0) < 1e-12

@@ -144,3 +144,51 @@ def test_model_builder_multiband_and_criteria(emulated_cabi):
     sc2, mag2 = crit["subband_stft_loss"](y_mb, model["pqmf"].analysis(torch.randn(2, 1, 2560) * 0.1))
     (sc + mag + sc2 + mag2).backward()
     assert all(p.grad is not None for p in model["generator"].parameters())
+
+
+def test_multiband_gan_step_emulated(emulated_cabi):
+    """A multi-band GAN step (out_channels 4 + PQMF): generator_loss follows reference trainer.py:469-525 -- full-band
+    losses on the synthesised signal, the sum halved before half the sub-band STFT loss is added, discriminators on the
+    synthesised signal -- and gan_train_step runs both phases."""
+    from kantts.models import model_builder
+    from kantts.train.gan_step import gan_train_step, generator_loss
+    from kantts.train.loss import criterion_builder
+
+    opt = {"type": "Adam", "params": {"lr": 2e-4, "betas": [0.5, 0.9], "weight_decay": 0.0}}
+    sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [10]}}
+    sub = {"fft_sizes": [384, 683, 171], "hop_sizes": [30, 60, 10], "win_lengths": [150, 300, 60]}
+    config = {"model_type": "hifigan", "Model": {
+        "Generator": {"params": {"channels": 32, "out_channels": 4, "upsample_scales": [8, 4, 2],
+                                 "upsample_kernal_sizes": [16, 8, 4]}, "optimizer": opt, "scheduler": sch},
+        "MultiPeriodDiscriminator": {"params": {"periods": [2, 3]}, "optimizer": opt, "scheduler": sch}},
+        "Loss": {"stft_loss": {"enable": True, "params": {}, "weights": 1.5},
+                 "subband_stft_loss": {"enable": True, "params": sub, "weights": 1.0},
+                 "mel_loss": {"enable": True, "params": {}, "weights": 45.0},
+                 "generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+        "generator_grad_norm": -1, "discriminator_grad_norm": -1, "discriminator_train_start_steps": 0,
+        "generator_train_start_steps": 0}
+    torch.manual_seed(1)
+    model, optimizer, scheduler = model_builder(config, device="cpu")
+    crit = criterion_builder(config, device="cpu")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 80, 10, generator=g)
+    y = (torch.randn(2, 1, 2560, generator=g) * 0.3).clamp(-1, 1)
+    gen_loss, losses, y_ = generator_loss(model, crit, x, y)
+    assert y_.shape == y.shape  # the discriminators and the full-band losses see the synthesised signal
+    with torch.no_grad():
+        y_mb_ = model["generator"](x)
+        full = model["pqmf"].synthesis(y_mb_)
+        sc, mag = crit["stft_loss"](full, y)
+        ssc, smag = crit["subband_stft_loss"](y_mb_, model["pqmf"].analysis(y))
+        want = 0.5 * (sc + mag) * 1.5 + 0.5 * (ssc + smag) + 45.0 * losses["mel_loss"] + losses["adversarial_loss"] \
+            + 2.0 * losses["feature_matching_loss"]
+    assert abs(float(losses["spectral_convergence_loss"]) - float(sc)) < 1e-5
+    assert abs(float(losses["sub_log_stft_magnitude_loss"]) - float(smag)) < 1e-5
+    assert abs(float(gen_loss) - float(want)) < 1e-4 * max(1.0, abs(float(want)))
+    w0 = [p.detach().clone() for p in model["generator"].parameters()]
+    out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
+    assert {"generator_loss", "discriminator_loss", "sub_spectral_convergence_loss"} <= set(out)
+    assert all(bool(torch.isfinite(v)) for v in out.values())
+    assert any(float((p - q).abs().max()) > 0 for p, q in zip(model["generator"].parameters(), w0))
