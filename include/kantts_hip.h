@@ -675,6 +675,18 @@ long long kantts_cconv_wgrad_ws_floats(const kantts_cconvw_args* args);
 int kantts_act_cast_bf16(const float* src, const void* gate, int gate_bf16, void* dst, int act, float slope, long long n,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Batch assembly on the device (csrc/batching.hip): padding / cropping of ragged utterances resident in
+ * HBM -- Padder and the collate functions of kantts/datasets/dataset.py:34-85, 278-311, 690-827.
+ *   out[b][t][c] = t < len[b] ? src[(row_off[b] + start[b] + t) * C + c] : pad[c]     b < B, t < Tmax, c < C
+ * transpose != 0 writes out[b][c][t] instead (the vocoder's mel crop, (frames, C) -> (C, frames)).  row_off (B) int64 =
+ * first row of utterance b in the flat (rows, C) source; start (B) int32 or NULL = crop offset in rows; len (B) int32 =
+ * rows to copy (<= Tmax); pad (C) or NULL (zeros). */
+int kantts_ragged_rows_f32(const float* src, const int64_t* row_off, const int32_t* start, const int32_t* len,
+                           const float* pad, float* out, int B, int Tmax, int C, int transpose, void* stream);
+int kantts_ragged_rows_i64(const int64_t* src, const int64_t* row_off, const int32_t* start, const int32_t* len,
+                           const int64_t* pad, int64_t* out, int B, int Tmax, int C, int transpose, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

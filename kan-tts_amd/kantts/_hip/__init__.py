@@ -252,6 +252,8 @@ def lib():
         L.kantts_cconv_wgrad_ws_floats.argtypes = [POINTER(CConvWArgs)]
         L.kantts_cconv_wgrad_ws_floats.restype = ll
         L.kantts_act_cast_bf16.argtypes = [p, p, i, p, i, f, ll, p]
+        L.kantts_ragged_rows_f32.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
+        L.kantts_ragged_rows_i64.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
         _lib = L
     return _lib
 
@@ -269,6 +271,7 @@ EXPORTED_SYMBOLS = [
     "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
+    "kantts_ragged_rows_f32", "kantts_ragged_rows_i64",
 ]
 
 
@@ -689,6 +692,18 @@ def conv_wgrad(x, dy, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, stride, d
                               4.0 * (B * Tsrc * inner * groups * CR + B * Tdst * inner * groups * NG *
                                      (2 if dy_gate is not None else 1) + K * groups * NG * CR)))
     return True
+
+
+def ragged_rows(src, row_off, lens, Tmax, *, start=None, pad=None, transpose=False):
+    """Padded / cropped batch from a flat (rows, C) device buffer (csrc/batching.hip): out (B, Tmax, C) -- or (B, C, Tmax)
+    with ``transpose`` -- where out[b, t] = src[row_off[b] + start[b] + t] for t < lens[b], else ``pad`` (C values or None
+    for zeros).  src float32 or int64; row_off int64, start / lens int32 device tensors."""
+    B, C = int(row_off.shape[0]), int(src.shape[1])
+    out = torch.empty((B, C, Tmax) if transpose else (B, Tmax, C), device=src.device, dtype=src.dtype)
+    fn = {torch.float32: "kantts_ragged_rows_f32", torch.int64: "kantts_ragged_rows_i64"}[src.dtype]
+    check(getattr(lib(), fn)(ptr(src), ptr(row_off, torch.int64), ptr(start, torch.int32), ptr(lens, torch.int32),
+                             ptr(pad, src.dtype), ptr(out), B, int(Tmax), C, int(bool(transpose)), stream()), fn)
+    return out
 
 
 def act_cast_bf16(src, *, act_slope=None, gate=None, gate_slope=0.0, dst=None):

@@ -1052,6 +1052,31 @@ class EmulatedLib:
             _arr(g.db, N)[:] += dy.sum(axis=(0, 1)).astype(np.float32)
         return 0
 
+    # ------------------------------------------------------------------------------------ device batch assembly
+    def _ragged(self, src, row_off, start, lens, pad, out, B, Tmax, C, transpose, dtype):
+        B, Tmax, C = int(_val(B)), int(_val(Tmax)), int(_val(C))
+        off = _arr(row_off, B, np.int64)
+        st = _arr(start, B, np.int32) if start else np.zeros(B, np.int32)
+        ln = _arr(lens, B, np.int32)
+        pv = _arr(pad, C, dtype) if pad else np.zeros(C, dtype)
+        res = np.empty((B, Tmax, C), dtype=dtype)
+        res[:] = pv[None, None, :]
+        for b in range(B):
+            n = int(ln[b])
+            if n > 0:
+                r0 = int(off[b]) + int(st[b])
+                res[b, :n] = _arr(int(src) + r0 * C * np.dtype(dtype).itemsize, n * C, dtype).reshape(n, C)
+        if _val(transpose):
+            res = res.transpose(0, 2, 1)
+        _arr(out, B * Tmax * C, dtype)[:] = np.ascontiguousarray(res).reshape(-1)
+        return 0
+
+    def kantts_ragged_rows_f32(self, src, row_off, start, lens, pad, out, B, Tmax, C, transpose, stream):
+        return self._ragged(src, row_off, start, lens, pad, out, B, Tmax, C, transpose, np.float32)
+
+    def kantts_ragged_rows_i64(self, src, row_off, start, lens, pad, out, B, Tmax, C, transpose, stream):
+        return self._ragged(src, row_off, start, lens, pad, out, B, Tmax, C, transpose, np.int64)
+
     # ------------------------------------------------------------------------------------ bf16 conv contractions
     def kantts_act_cast_bf16(self, src, gate, gate_bf16, dst, act, slope, n, stream):
         n = int(_val(n))
