@@ -731,6 +731,47 @@ def main():
     else:
         dt_max, total_frames = dt, float(frames)
 
+    # ---- forward pass alone, as training runs it (dropout on, activations kept for backward, predictors on their side
+    # branch), replayed from its own hipGraph: SURVEY 8(d) prices the MFMA roofline on the forward pass
+    # (152.3 GFLOP at batch 32: roofline.forward_mfma_frac = 152.3e9 / t_fwd / peak)
+    fwd_ms = None
+    if rank == 0 and world == 1 and mode == "graph":
+        try:
+            def fwd_only():
+                hip.ops.advance_rng(dev)
+                res = net(**batch)
+                mel_, mel = mel_crit(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+                d, p, e = pros_crit(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                    res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                    res["energy_predictions"])
+                return mel_ + mel + d + p + e
+
+            hip.ops.wgrad_overlap.enable(True)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fwd_only()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            fg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fg, capture_error_mode="thread_local"):
+                keep = fwd_only()
+            hip.ops.wgrad_overlap.join()
+            fg.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fg.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            fwd_ms = e0.elapsed_time(e1) / 20
+            del keep, fg
+        except Exception as exc:
+            print("[bench] forward-only capture failed (%s: %s)" % (type(exc).__name__, str(exc)[:200]), file=sys.stderr)
+        finally:
+            hip.ops.wgrad_overlap.enable(False)
+
     # ---- roofline of the dominant kernel: HIP events around every GEMM launch of one extra step
     roof = None
     if rank == 0:
@@ -758,6 +799,10 @@ def main():
                 "gemm_ms_per_step_eager_events": prof["ms"],
                 "whole_step_algorithmic_tflops": 456.9e9 * args.batch / 32 / (dt_max / args.steps) / 1e12}
         roof["whole_step_mfma_frac"] = roof["whole_step_algorithmic_tflops"] / peak
+        if fwd_ms is not None:
+            roof["forward_ms"] = fwd_ms
+            roof["forward_algorithmic_tflops"] = 152.3e9 * args.batch / 32 / (fwd_ms * 1e-3) / 1e12
+            roof["forward_mfma_frac"] = roof["forward_algorithmic_tflops"] / peak
 
     if rank == 0:
         out = {

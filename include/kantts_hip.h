@@ -275,6 +275,12 @@ int kantts_weight_norm_strided_fwd(const float* v, const float* g, float* w, int
 int kantts_weight_norm_strided_bwd(const float* dw, const float* v, const float* g, float* dv, float* dg, int rows,
                                    int cin, int K, long long rs, long long cs, long long ks, void* stream);
 
+/* Tap-major weight norm with the bf16 operand images of kantts_cconv_launch in the same pass (v (rows, cin, K)):
+ * w (K, rows, cin) fp32; wf_bf16 (K, rows, cin) = bf16(w) (optional); wd_bf16 (K, groups, cin, rows / groups) = the
+ * per-tap transpose inside each group, the weight of the input-gradient contraction (optional). */
+int kantts_weight_norm_tap_images(const float* v, const float* g, float* w, void* wf_bf16, void* wd_bf16, int rows, int cin,
+                                  int K, int groups, void* stream);
+
 /* y = sin(x) + x and its backward dx = dy * (cos(x) + 1)  (kantts/models/hifigan/hifigan.py:157) */
 int kantts_sinadd_fwd(const float* x, float* y, long long n, void* stream);
 int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, long long n, void* stream);

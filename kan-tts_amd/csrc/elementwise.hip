@@ -60,6 +60,43 @@ __global__ __launch_bounds__(256) void weight_norm_strided_fwd_kernel(const floa
   }
 }
 
+// The tap-major weight-norm forward with the two bf16 operand images of csrc/cconv.hip written in the same pass:
+//   w   (K, rows, cin) fp32         (kept: the weight gradient's layout, and what the fp32-operand kernels read)
+//   wf  (K, rows, cin) bf16         forward contraction
+//   wd  (K, groups, cin, rows / groups) bf16   input-gradient contraction (per-tap transpose inside each group)
+// One launch per convolution instead of the reparametrisation plus two or three cast / transpose copies per use
+// (~480 copy launches and 2.8 ms of kernel time per HiFi-GAN step).
+__global__ __launch_bounds__(256) void weight_norm_tap_images_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                    float* __restrict__ w, __bf16* __restrict__ wf,
+                                                                    __bf16* __restrict__ wd, int rows, int cin, int K,
+                                                                    int groups) {
+  __shared__ float red[4];
+  const int r = blockIdx.x, cols = cin * K;
+  const float* vr = v + (long long)r * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) s += vr[c] * vr[c];
+  s = kantts_block_sum(s, red);
+  const float sc = g[r] / sqrtf(s);
+  const int rg = rows / groups, grp = r / rg, rl = r - grp * rg;
+  for (int j = threadIdx.x; j < cols; j += 256) {  // ci fastest: coalesced on the tap-major side
+    const int k = j / cin, ci = j - k * cin;
+    const float val = vr[ci * K + k] * sc;
+    const long long o = ((long long)k * rows + r) * cin + ci;
+    w[o] = val;
+    if (wf) wf[o] = (__bf16)val;
+    if (wd) wd[(((long long)k * groups + grp) * cin + ci) * rg + rl] = (__bf16)val;
+  }
+}
+
+extern "C" int kantts_weight_norm_tap_images(const float* v, const float* g, float* w, void* wf_bf16, void* wd_bf16, int rows,
+                                             int cin, int K, int groups, void* stream) {
+  if (!v || !g || !w || rows < 0 || cin < 1 || K < 1 || groups < 1 || (rows % groups)) return KANTTS_E_BADARG;
+  if (rows == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(weight_norm_tap_images_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, v, g, w,
+                     reinterpret_cast<__bf16*>(wf_bf16), reinterpret_cast<__bf16*>(wd_bf16), rows, cin, K, groups);
+  KANTTS_CHECK_LAUNCH();
+}
+
 __global__ __launch_bounds__(256) void weight_norm_strided_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
                                                                      const float* __restrict__ g, float* __restrict__ dv,
                                                                      float* __restrict__ dg, int cin, int K, long long rs,

@@ -253,6 +253,7 @@ def lib():
         L.kantts_cconv_wgrad_ws_floats.restype = ll
         L.kantts_act_cast_bf16.argtypes = [p, p, i, p, i, f, ll, p]
         L.kantts_ragged_rows_f32.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
+        L.kantts_weight_norm_tap_images.argtypes = [p, p, p, p, p, i, i, i, i, p]
         L.kantts_ragged_rows_i64.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
         _lib = L
     return _lib
@@ -271,7 +272,7 @@ EXPORTED_SYMBOLS = [
     "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
-    "kantts_ragged_rows_f32", "kantts_ragged_rows_i64",
+    "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
 ]
 
 
@@ -826,6 +827,11 @@ _rng_state = {}
 
 
 def rng_state(device):
+    # one offset per physical device: "cuda" and "cuda:0" must name the same tensor (a caller that advanced the offset
+    # of "cuda" while the kernels read the one of "cuda:0" would silently freeze its dropout masks)
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     key = str(device)
     t = _rng_state.get(key)
     if t is None:

@@ -599,6 +599,35 @@ class _SelfAttention(torch.autograd.Function):
         return dqkv.view(B, L, 3 * D), None, None, None, None
 
 
+_attn_side_stream = []
+
+
+def _pair_on_two_streams(fn_main, fn_side, side_inputs=()):
+    """The x-band and the h-band attention of a PNCA block share only their query: two launches of 256 workgroups, each
+    latency-bound (~15 us whatever else runs).  ``fn_side`` goes to a second stream, ``fn_main`` stays on the current
+    one, both are joined before returning; under hipGraph capture the pair becomes two parallel branches.  Tensors the
+    side function allocates are handed to the current stream (record_stream).  Sequential on the host / when
+    KANTTS_NO_ATTN_STREAMS is set."""
+    if (not torch.cuda.is_available() or os.environ.get("KANTTS_NO_ATTN_STREAMS")
+            or not any(torch.is_tensor(t) and t.is_cuda for t in side_inputs)):
+        return fn_main(), fn_side()
+    if not _attn_side_stream:
+        _attn_side_stream.append(torch.cuda.Stream())
+    side, main = _attn_side_stream[0], torch.cuda.current_stream()
+    side.wait_stream(main)
+    for t in side_inputs:
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        rs = fn_side()
+    rm = fn_main()
+    main.wait_stream(side)
+    for t in (rs if isinstance(rs, (tuple, list)) else (rs,)):
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(main)
+    return rm, rs
+
+
 class _PncaAttention(torch.autograd.Function):
     """PNCA dual attention sharing Q: x-band over the decoder's own K/V (from qkv) and h-band over
     the memory K/V (hkv = [k | v]).  Returns ctx_x, ctx_h (B, L, H*16) [, probs_x, probs_h]."""
@@ -611,10 +640,10 @@ class _PncaAttention(torch.autograd.Function):
         q2, h2 = qkv.view(B * L, W), hkv.view(B * L, 2 * D)
         sx = next_seed() if drop_p > 0 else 0
         sh = next_seed() if drop_p > 0 else 0
-        ox, lsex, px = _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, bw_dev, bw_x, B, H, L, MODE_BAND_X, drop_p, sx,
-                                 want_probs)
-        oh, lseh, ph = _attn_fwd(q2, 0, h2, 0, h2, D, lens, bw_dev, bw_h, B, H, L, MODE_BAND_H, drop_p, sh,
-                                 want_probs)
+        (ox, lsex, px), (oh, lseh, ph) = _pair_on_two_streams(
+            lambda: _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, bw_dev, bw_x, B, H, L, MODE_BAND_X, drop_p, sx, want_probs),
+            lambda: _attn_fwd(q2, 0, h2, 0, h2, D, lens, bw_dev, bw_h, B, H, L, MODE_BAND_H, drop_p, sh, want_probs),
+            side_inputs=(q2, h2, lens, bw_dev))
         ctx.save_for_backward(q2, h2, ox, oh, lsex, lseh, lens, bw_dev)
         ctx.cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)
         if want_probs:
@@ -629,10 +658,19 @@ class _PncaAttention(torch.autograd.Function):
         d_ox, d_oh = _c(d_ox).view(B * L, D), _c(d_oh).view(B * L, D)
         dqkv = torch.empty_like(q2)
         dhkv = torch.empty_like(h2)
-        _attn_bwd(q2, 0, q2, D, q2, 2 * D, ox, d_ox, lsex, dqkv, 0, dqkv, D, dqkv, 2 * D, 0, lens, bw_dev, bw_x, B, H,
-                  L, MODE_BAND_X, drop_p, sx)
-        _attn_bwd(q2, 0, h2, 0, h2, D, oh, d_oh, lseh, dqkv, 0, dhkv, 0, dhkv, D, 1, lens, bw_dev, bw_h, B, H, L,
-                  MODE_BAND_H, drop_p, sh)
+
+        def bwd_h():
+            # the h band's query gradient goes to its own buffer: the two bands then share nothing they write
+            dqh = torch.empty((B * L, D), device=q2.device, dtype=torch.float32)
+            _attn_bwd(q2, 0, h2, 0, h2, D, oh, d_oh, lseh, dqh, 0, dhkv, 0, dhkv, D, 0, lens, bw_dev, bw_h, B, H, L,
+                      MODE_BAND_H, drop_p, sh)
+            return dqh
+
+        _, dqh = _pair_on_two_streams(
+            lambda: _attn_bwd(q2, 0, q2, D, q2, 2 * D, ox, d_ox, lsex, dqkv, 0, dqkv, D, dqkv, 2 * D, 0, lens, bw_dev, bw_x,
+                              B, H, L, MODE_BAND_X, drop_p, sx),
+            bwd_h, side_inputs=(q2, h2, oh, d_oh, lseh, dhkv, lens, bw_dev))
+        dqkv[:, :D] += dqh
         return dqkv.view(B, L, 3 * D), dhkv.view(B, L, 2 * D), None, None, None, None, None, None, None
 
 
@@ -1269,7 +1307,7 @@ class _CConvCL(torch.autograd.Function):
     gradient contractions.  Reference: kantts/models/hifigan/layers.py:15-91, hifigan.py:82-97,217-267,332-407."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, cfg, x_img):
+    def forward(ctx, x, w, bias, res, cfg, x_img, w_imgs=(None, None)):
         x, w = _c(x), _c(w)
         stride, dil, pad, up, groups = cfg["stride"], cfg["dilation"], cfg["pad"], cfg["up"], cfg["groups"]
         inner, Tout = cfg["inner"], cfg["Tout"]
@@ -1287,8 +1325,11 @@ class _CConvCL(torch.autograd.Function):
         # small groups (the scale discriminators' 8 -> 16 / 16 -> 32 channel groups) are merged P at a time into dense
         # block-diagonal groups, as in _ConvCL: a 32-deep x 32-wide MFMA tile is the least the kernel can fill
         P = _group_pack(groups, Cin_g, Cout_g) if up == 1 else 1
+        ctx.wd_img = w_imgs[1] if P == 1 else None
         if P > 1:
             wb = _blockdiag_pack(wt.reshape(K, Cout, Cin_g), groups, P).to(torch.bfloat16)
+        elif w_imgs[0] is not None:
+            wb = w_imgs[0]
         else:
             wb = torch.empty((K, Cout, Cin_g), device=x.device, dtype=torch.bfloat16).copy_(wt)
         y = torch.empty((B, Tout, inner, Cout) if x.dim() == 4 else (B, Tout, Cout), device=x.device, dtype=torch.float32)
@@ -1348,6 +1389,8 @@ class _CConvCL(torch.autograd.Function):
                 Pd = _group_pack(groups, Cout_g, Cin_g)
                 if Pd > 1:
                     wdb = _blockdiag_pack(wd.reshape(K, Cin, Cout_g), groups, Pd).to(torch.bfloat16)
+                elif ctx.wd_img is not None:
+                    wdb = ctx.wd_img.view(K, Cin, Cout_g)
                 else:
                     wdb = torch.empty((K, Cin, Cout_g), device=dy.device, dtype=torch.bfloat16).copy_(wd.reshape(K, Cin, Cout_g))
                 ok = cconv(dyb, wdb, out=dx, B=B, Tsrc=Tout, Tdst=Tin, groups=groups // Pd, CR=Pd * Cout_g, NG=Pd * Cin_g,
@@ -1369,7 +1412,7 @@ class _CConvCL(torch.autograd.Function):
             dw = dwt if tap_major else dwt.permute(1, 2, 0)
         elif has_bias and ctx.needs_input_grad[2]:
             raise RuntimeError("bias gradient without weight gradient is not supported")
-        return dx, dw, db, (dy if has_res else None), None, None
+        return dx, dw, db, (dy if has_res else None), None, None, None
 
 
 class _ResStackBF16(torch.autograd.Function):
@@ -1389,17 +1432,19 @@ class _ResStackBF16(torch.autograd.Function):
     then w1_0, b1_0, w2_0, b2_0, w1_1, ... (tap-major (K, C, C) weights)."""
 
     @staticmethod
-    def forward(ctx, x, x_img, slope, cfgs, *wb):
+    def forward(ctx, x, x_img, slope, cfgs, imgs, *wb):
         x = _c(x)
         B, T, C = x.shape
         n = len(cfgs)
         a = x_img if x_img is not None else act_cast_bf16(x, act_slope=slope)
         saved, wimgs = [], []
         xi = x
+        ctx.wd_imgs = [(im1[1], im2[1]) for im1, im2 in imgs]
         for i, (K, dil, pad1, pad2) in enumerate(cfgs):
             w1, b1, w2, b2 = wb[4 * i:4 * i + 4]
-            w1b = torch.empty((K, C, C), device=x.device, dtype=torch.bfloat16).copy_(w1)
-            w2b = torch.empty((K, C, C), device=x.device, dtype=torch.bfloat16).copy_(w2)
+            (f1, _), (f2, _) = imgs[i]
+            w1b = f1 if f1 is not None else torch.empty((K, C, C), device=x.device, dtype=torch.bfloat16).copy_(w1)
+            w2b = f2 if f2 is not None else torch.empty((K, C, C), device=x.device, dtype=torch.bfloat16).copy_(w2)
             ta = torch.empty((B, T, C), device=x.device, dtype=torch.bfloat16)
             if not cconv(a, w1b, out_bf=ta, bf_leaky=slope, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K, in_mul=1,
                          in_add=-pad1, in_kstep=dil, in_div=1, phases=1, bias=b1):
@@ -1438,7 +1483,9 @@ class _ResStackBF16(torch.autograd.Function):
             db2 = gzeros((C,), g.device) if b2 else None
             if not cconv_wgrad(ta, gb, dw2, db2, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K, stride=1, dil=1, pad=pad2):
                 raise RuntimeError("cconv weight gradient refused a residual-block convolution")
-            w2d = torch.empty((K, C, C), device=g.device, dtype=torch.bfloat16).copy_(w2.transpose(1, 2))
+            d1, d2 = ctx.wd_imgs[i]
+            w2d = (d2.view(K, C, C) if d2 is not None
+                   else torch.empty((K, C, C), device=g.device, dtype=torch.bfloat16).copy_(w2.transpose(1, 2)))
             dt = torch.empty((B, T, C), device=g.device, dtype=torch.bfloat16)
             if not cconv(gb, w2d, out_bf=dt, B=B, Tsrc=T, Tdst=T, groups=1, CR=C, NG=C, K=K, in_mul=1, in_add=pad2,
                          in_kstep=-1, in_div=1, phases=1, out_gate=ta, out_gate_slope=slope):
@@ -1449,7 +1496,8 @@ class _ResStackBF16(torch.autograd.Function):
                 raise RuntimeError("cconv weight gradient refused a residual-block convolution")
             grads[4 * i:4 * i + 4] = [dw1, db1, dw2, db2]
             if i > 0 or need_x:
-                w1d = torch.empty((K, C, C), device=g.device, dtype=torch.bfloat16).copy_(w1.transpose(1, 2))
+                w1d = (d1.view(K, C, C) if d1 is not None
+                       else torch.empty((K, C, C), device=g.device, dtype=torch.bfloat16).copy_(w1.transpose(1, 2)))
                 gn = torch.empty((B, T, C), device=g.device, dtype=torch.float32)
                 gnb = torch.empty((B, T, C), device=g.device, dtype=torch.bfloat16) if i > 0 else None
                 # the identity path g joins AFTER the LeakyReLU' gate of the convolution branch (res_after_gate)
@@ -1458,7 +1506,7 @@ class _ResStackBF16(torch.autograd.Function):
                              res_after_gate=True, out_bf=gnb):
                     raise RuntimeError("cconv input gradient refused a residual-block convolution")
                 g, gb = gn, gnb
-        return (g if need_x else None, None, None, None) + tuple(grads)
+        return (g if need_x else None, None, None, None, None) + tuple(grads)
 
 
 def res_stack_ok(x, K):
@@ -1479,7 +1527,8 @@ def res_stack(x, slope, convs):
     for w1, b1, K, dil, pad1, w2, b2, pad2 in convs:
         flat += [w1, b1, w2, b2]
     x_img = get_image(x, slope) if x.is_contiguous() else None
-    return _ResStackBF16.apply(x, x_img, float(slope), cfgs, *flat)
+    imgs = [(weight_images(w1, 1), weight_images(w2, 1)) for w1, _, _, _, _, w2, _, _ in convs]
+    return _ResStackBF16.apply(x, x_img, float(slope), cfgs, imgs, *flat)
 
 
 _IMG_ATTR = "_kantts_bf16_image"
@@ -1527,10 +1576,11 @@ def conv_cl(x, w, bias=None, *, stride=1, dilation=1, pad=0, Tout=None, up=1, gr
     if (up == 1 or stride == 1) and _cconv_ok(x, Cin_g, Cout // int(groups), K, x.shape[0] * int(Tout) * int(inner),
                                                 int(groups)):
         x_img = get_image(x, in_leaky) if x.is_contiguous() else None
+        w_imgs = weight_images(w, groups) if tap_major else (None, None)
         if image is False:
-            return _CConvCL.apply(x, w, bias, res, cfg, x_img)
+            return _CConvCL.apply(x, w, bias, res, cfg, x_img, w_imgs)
         cfg["image"] = image
-        y, y_img = _CConvCL.apply(x, w, bias, res, cfg, x_img)
+        y, y_img = _CConvCL.apply(x, w, bias, res, cfg, x_img, w_imgs)
         return set_image(y, image, y_img)
     return _ConvCL.apply(x, w, bias, res, cfg)
 
@@ -1681,29 +1731,54 @@ class _WeightNormTap(torch.autograd.Function):
     the tap-major layout the convolution kernels read; backward takes the tap-major weight gradient they produce."""
 
     @staticmethod
-    def forward(ctx, v, g):
+    def forward(ctx, v, g, groups):
         v, g = _c(v), _c(g)
         Cout, cin, K = v.shape
         w = torch.empty((K, Cout, cin), device=v.device, dtype=torch.float32)
+        ctx.save_for_backward(v, g)
+        if groups:  # bf16 mode: the operand images of csrc/cconv.hip in the same launch
+            wf = torch.empty((K, Cout, cin), device=v.device, dtype=torch.bfloat16)
+            wd = torch.empty((K, groups, cin, Cout // groups), device=v.device, dtype=torch.bfloat16)
+            check(lib().kantts_weight_norm_tap_images(ptr(v, torch.float32), ptr(g, torch.float32), ptr(w), ptr(wf), ptr(wd),
+                                                      Cout, cin, K, int(groups), stream()), "weight_norm_tap_images")
+            ctx.mark_non_differentiable(wf, wd)
+            return w, wf, wd
         check(lib().kantts_weight_norm_strided_fwd(ptr(v, torch.float32), ptr(g, torch.float32), ptr(w), Cout, cin, K, cin,
                                                    1, Cout * cin, stream()), "weight_norm_strided_fwd")
-        ctx.save_for_backward(v, g)
         return w
 
     @staticmethod
-    def backward(ctx, dw):
+    def backward(ctx, dw, *_unused):
         v, g = ctx.saved_tensors
         dw = _c(dw)
         Cout, cin, K = v.shape
         dv, dg = torch.empty_like(v), torch.empty_like(g)
         check(lib().kantts_weight_norm_strided_bwd(ptr(dw, torch.float32), ptr(v), ptr(g), ptr(dv), ptr(dg), Cout, cin, K,
                                                    cin, 1, Cout * cin, stream()), "weight_norm_strided_bwd")
-        return dv, dg
+        return dv, dg, None
 
 
-def weight_norm_tap(v, g):
-    """Weight-normed conv weight in tap-major layout (K, Cout, Cin_g) for conv_cl(..., tap_major=True)."""
-    return _WeightNormTap.apply(v, g)
+_WIMG_ATTR = "_kantts_bf16_weight_images"
+
+
+def weight_norm_tap(v, g, groups=1):
+    """Weight-normed conv weight in tap-major layout (K, Cout, Cin_g) for conv_cl(..., tap_major=True).  In bf16 mode the
+    same launch also writes the bf16 images the MFMA convolution kernels read -- (K, Cout, Cin_g) for the forward and
+    (K, groups, Cin_g, Cout_g) for the input-gradient contraction -- and attaches them to the returned tensor object."""
+    if get_precision() == "bf16" and v.shape[1] % 8 == 0 and (v.shape[0] // int(groups)) % 8 == 0 and not os.environ.get(
+            "KANTTS_NO_WEIGHT_IMAGES"):
+        w, wf, wd = _WeightNormTap.apply(v, g, int(groups))
+        setattr(w, _WIMG_ATTR, (wf, wd, int(groups)))
+        return w
+    return _WeightNormTap.apply(v, g, 0)
+
+
+def weight_images(w, groups):
+    """(forward image, input-gradient image) attached by weight_norm_tap for this group count, or (None, None)."""
+    hit = getattr(w, _WIMG_ATTR, None)
+    if hit is not None and hit[2] == int(groups):
+        return hit[0], hit[1]
+    return None, None
 
 
 def weight_norm(v, g):

@@ -35,7 +35,7 @@ def conv_weight(m):
         if v.dim() == 4:  # Conv2d((k,1)) of the period discriminators
             v = v.squeeze(-1)
         if v.shape[1] % 4 == 0:
-            return ops.weight_norm_tap(v, m.weight_g), True
+            return ops.weight_norm_tap(v, m.weight_g, groups=getattr(m, "groups", 1)), True
         return ops.weight_norm(v, m.weight_g), False
     if hasattr(m, "weight_orig"):
         # torch.nn.utils.spectral_norm (follow_official_norm discriminators, reference hifigan.py:217,321): the

@@ -55,7 +55,9 @@ class SelfAttentionEncoder(nn.Module):
         if not prescaled:
             input = self.position_enc(input * self.d_model ** 0.5)
         if self.training and self.dropout > 0:
-            input = F.dropout(input, p=self.dropout, training=True)
+            # counter-based masks regenerated in backward (ops.dropout2_add): no mask tensor, no torch generator state --
+            # a captured step and an eager step given the same seeds draw the same masks
+            input = ops.dropout2_add(input, p1=self.dropout)
         info = SeqInfo.of(mask)
         attns = []
         x = input
@@ -101,7 +103,7 @@ class HybridAttentionDecoder(nn.Module):
         x = ops.linear([memory, x], self.dec_in_proj.weight, self.dec_in_proj.bias, mode="concat", rowmask=rows,
                        alpha=self.d_model ** 0.5)
         if self.training and self.dropout > 0:
-            x = F.dropout(x, p=self.dropout, training=True)
+            x = ops.dropout2_add(x, p1=self.dropout)
         ax_l, ah_l = [], []
         every = _FLUSH_EVERY["dec"] if self.training else 0
         # the memory K/V projections of all blocks read the same tensor: computed here, one input-gradient launch

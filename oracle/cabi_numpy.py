@@ -1296,6 +1296,20 @@ class EmulatedLib:
         _arr(h_out, B * H)[:] = (sig(g[:, 3]) * np.tanh(c)).astype(np.float32).ravel()
         return 0
 
+    def kantts_weight_norm_tap_images(self, v, g, w, wf, wd, rows, cin, K, groups, stream):
+        rows, cin, K, groups = int(_val(rows)), int(_val(cin)), int(_val(K)), int(_val(groups))
+        V = _arr(v, rows * cin * K).reshape(rows, cin * K)
+        nrm = np.sqrt((V.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32))
+        W = (V * (_arr(g, rows) / nrm)[:, None]).astype(np.float32).reshape(rows, cin, K)
+        tap = np.ascontiguousarray(W.transpose(2, 0, 1))  # (K, rows, cin)
+        _arr(w, K * rows * cin)[:] = tap.reshape(-1)
+        if wf:
+            _wr(wf, tap, True)
+        if wd:
+            rg = rows // groups
+            _wr(wd, np.ascontiguousarray(tap.reshape(K, groups, rg, cin).transpose(0, 1, 3, 2)), True)
+        return 0
+
     def kantts_weight_norm_strided_fwd(self, v, g, w, rows, cin, K, rs, cs, ks, stream):
         V = _arr(v, rows * cin * K).reshape(rows, cin, K).astype(np.float64)
         G = _arr(g, rows).astype(np.float64)

@@ -524,6 +524,36 @@ def hifigan_v1_case():
     print("hifigan_v1 bytes", os.path.getsize(os.path.join(OUT, "hifigan_v1.pt")), float(wav.abs().mean()))
 
 
+def hifigan_v1_b32_case():
+    """BASELINE config 3's size -- HiFi-GAN V1 at batch 32 x 8192 samples -- recorded from the reference: generator
+    output, gradient norms of a generator backward, MPD / MSD outputs and feature-map sums on the real batch.  Inputs are
+    regenerated from the seed by the test (they are 8 MB); the GPU box never needs a CPU oracle run at this size."""
+    from kantts.models.hifigan.hifigan import Generator, MultiPeriodDiscriminator, MultiScaleDiscriminator
+
+    torch.manual_seed(0)
+    G, D1, D2 = Generator(), MultiPeriodDiscriminator(), MultiScaleDiscriminator()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(32, 80, 32, generator=g)
+    y = torch.randn(32, 1, 8192, generator=g).clamp(-1, 1)
+    cot = torch.randn(32, 1, 8192, generator=g)
+    wav = G(x)
+    (wav * cot).sum().backward()
+    fix = dict(seed=77, wav=wav.detach().clone(),
+               G_grad_norms={n: float(p.grad.double().norm()) for n, p in G.named_parameters()},
+               G_grad_samples={n: p.grad.flatten()[:64].clone() for n, p in G.named_parameters()
+                               if n in ("conv_pre.conv1d.weight_v", "conv_post.conv1d.weight_v",
+                                        "conv_blocks.0.convs1.0.conv1d.weight_v", "conv_blocks.11.convs2.2.conv1d.weight_v",
+                                        "transpose_upsamples.1.1.deconv.weight_v")})
+    with torch.no_grad():
+        for nm, D in (("mpd", D1), ("msd", D2)):
+            o, fm = D(y)
+            fix[nm + "_out"] = [a.detach().clone() for a in o]
+            fix[nm + "_fmap_sums"] = [[(tuple(a.shape), float(a.double().sum()), float(a.double().abs().sum()))
+                                       for a in fa] for fa in fm]
+    torch.save(fix, os.path.join(OUT, "hifigan_v1_b32.pt"))
+    print("hifigan_v1_b32 bytes", os.path.getsize(os.path.join(OUT, "hifigan_v1_b32.pt")), float(wav.abs().mean()))
+
+
 def multiband_case():
     """SURVEY row f4 pieces recorded from the reference: PQMF analysis / synthesis (pqmf.py:50-148), the multi-resolution
     STFT loss with its input gradient (loss.py:312-441; default resolutions, and a small one on sub-band shaped input),
@@ -605,6 +635,10 @@ def melspec_case():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # python oracle/make_golden.py hifigan_v1_b32_case ...: only the named cases (no arguments)
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     gk = ("text_encoder.ling_proj.weight", "mel_decoder.mel_dec.dec_out_proj.weight", "mel_postnet.fc.weight",
           "variance_adaptor.duration_predictor.fc.weight", "emo_tokenizer.weight")
     sambert_case("sambert_tiny", True, B=3, T_in=12, min_len=6, dur_hi=6, grad_keys=gk)
@@ -622,5 +656,6 @@ if __name__ == "__main__":
     voc_dataset_case()
     am_dataset_case()
     hifigan_v1_case()
+    hifigan_v1_b32_case()
     masks_case()
     multiband_case()

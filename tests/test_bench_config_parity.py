@@ -191,3 +191,67 @@ def test_hifigan_v1_512ch_matches_oracle(hifigan_v1_oracle, mode):
     assert rep["wav"][0] <= bnd["wav_mean"], rep
     assert rep["mpd_out"] <= bnd["d_out"] and rep["msd_out"] <= bnd["d_out"], rep
     assert max(rep["G_grad_rel_l2"], rep["mpd_grad_rel_l2"], rep["msd_grad_rel_l2"]) <= bnd["grad"], rep
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HiFi-GAN V1 at the benchmarked batch: 32 x 8192 samples against outputs recorded from the REFERENCE at this size
+# (tests/golden/hifigan_v1_b32.pt, oracle/make_golden.py::hifigan_v1_b32_case) -- no CPU oracle runs on the GPU box.
+_HIFI_B32_BOUNDS = {
+    # wav mean-abs, discriminator outputs max-abs, feature-map sums (relative to the abs-sum), gradient norms per tensor
+    # (relative), recorded gradient samples rel-L2 (mean over the five recorded tensors)
+    "fp32": dict(wav_mean=1e-5, d_out=5e-5, fmap=1e-5, gnorm=5e-3, gsample=1e-2),
+    # measured on the device (gpurun_out/parity_at_bench_configs.json, copied to profiles/r03_parity_at_bench_configs.json):
+    # wav mean 9.5e-4, discriminator outputs 1.3e-4 / 4.8e-5, feature-map sums 5.0e-3 / 1.2e-3, worst gradient NORM 4.3 %
+    # (a residual-block bias), recorded gradient samples 8.9 % rel-L2; bounds <= 2x measured
+    "bf16": dict(wav_mean=2e-3, d_out=3e-4, fmap=1e-2, gnorm=0.09, gsample=0.18),
+}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_hifigan_v1_batch32_matches_reference_fixture(mode):
+    import os
+
+    import kantts._hip as hip
+    from util import GOLDEN
+
+    fix = torch.load(os.path.join(GOLDEN, "hifigan_v1_b32.pt"), weights_only=False)
+    g = torch.Generator().manual_seed(fix["seed"])
+    x = torch.randn(32, 80, 32, generator=g)
+    y = torch.randn(32, 1, 8192, generator=g).clamp(-1, 1)
+    cot = torch.randn(32, 1, 8192, generator=g)
+    G, D1, D2 = _v1_modules()
+    bnd = _HIFI_B32_BOUNDS[mode]
+    hip.set_precision(mode)
+    rep = {}
+    try:
+        G = G.cuda()
+        wav = G(x.cuda())
+        d = (wav.detach().cpu() - fix["wav"]).abs()
+        rep["wav"] = (float(d.mean()), float(d.max()))
+        (wav * cot.cuda()).sum().backward()
+        worst, wname = 0.0, ""
+        for n, p in G.named_parameters():
+            ref = fix["G_grad_norms"][n]
+            r = abs(float(p.grad.double().norm()) - ref) / (ref + 1e-30)
+            if r > worst:
+                worst, wname = r, n
+        rep["G_grad_norm_worst"] = (worst, wname)
+        sd = dict(G.named_parameters())
+        rep["G_grad_samples_rel_l2"] = float(sum(rel_l2(sd[n].grad.flatten()[:64].cpu(), v)
+                                                 for n, v in fix["G_grad_samples"].items()) / len(fix["G_grad_samples"]))
+        with torch.no_grad():
+            for D, nm in ((D1, "mpd"), (D2, "msd")):
+                o, fm = D.cuda()(y.cuda())
+                rep[nm + "_out"] = max(float((a.cpu() - b).abs().max()) for a, b in zip(o, fix[nm + "_out"]))
+                rep[nm + "_fmap"] = max(abs(float(a.double().sum()) - s_) / max(1.0, a_)
+                                        for fa, fb in zip(fm, fix[nm + "_fmap_sums"]) for a, (_, s_, a_) in zip(fa, fb))
+        torch.cuda.synchronize()
+    finally:
+        hip.set_precision("fp32")
+    _record("hifigan_v1_B32x8192_vs_reference_" + mode, rep)
+    print("HiFi-GAN V1 B=32x8192 vs reference", mode, rep)
+    assert rep["wav"][0] <= bnd["wav_mean"], rep
+    assert rep["mpd_out"] <= bnd["d_out"] and rep["msd_out"] <= bnd["d_out"], rep
+    assert rep["mpd_fmap"] <= bnd["fmap"] and rep["msd_fmap"] <= bnd["fmap"], rep
+    assert rep["G_grad_norm_worst"][0] <= bnd["gnorm"], rep
+    assert rep["G_grad_samples_rel_l2"] <= bnd["gsample"], rep

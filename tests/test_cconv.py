@@ -446,7 +446,7 @@ def _check_res_stack(ops, device):
         y0, g0 = _res_block_run(ops, device, False, C, K, T)
         assert torch.equal(y1, y0), (C, K)
         for a, b in zip(g1, g0):
-            assert rel_l2(a, b) < 1e-6, (C, K)
+            assert rel_l2(a, b) < 1e-5, (C, K)
 
 
 def test_fused_residual_stack_equals_the_chain_emulated(emulated_cabi, bf16_all_sizes, monkeypatch):

@@ -290,3 +290,125 @@ def test_graph_trainer_alternating_shapes_matches_eager(tmp_path):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (lg, le)
     assert float((fg - fe).norm() / fe.norm()) < 1e-4
     assert trg.optimizer["KanTtsSAMBERT"]._step == 6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-4)])
+def test_benchmarked_sambert_schedule_matches_single_stream_eager_gpu(prec, tol):
+    """The schedule bench.py times -- GraphedSambertStep at the FULL config (sambert_16k zhcn, batch 32 x 64 symbols,
+    dropout on): one hipGraph, variance predictors as a parallel branch, the x / h attentions of the PNCA blocks on two
+    streams, deferred weight gradients grouped by shape and issued from flush points -- against plain single-stream eager
+    steps from the same weights with the same dropout masks, over three optimizer steps.  The dropout generator is
+    counter-based (host seed + device offset), so the eager run can be given exactly the seeds the capture froze into its
+    kernel arguments; what remains is the summation order of the fp32 atomics in the split weight gradients."""
+    import itertools
+    import os
+
+    import kantts._hip as hip
+    from kantts._hip import ops
+    from kantts.models import model_builder
+    from kantts.train.graph_step import GraphedSambertStep
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+    from kantts.utils import synthetic
+
+    hip.set_precision(prec)
+    dev = torch.device("cuda")
+    cfg = synthetic.sambert_16k_config()
+    yaml_cfg = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": cfg,
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1.0e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}}, "grad_norm": 1.0, "batch_size": 32}
+    batch = {k: v.to(dev) for k, v in synthetic.sambert_batch(B=32, T_in=64, seed=1234).items()}
+    mel_crit, pros_crit = MelReconLoss(), ProsodyReconLoss()
+
+    def build():
+        torch.manual_seed(0)
+        model, opt, sch = model_builder(yaml_cfg, device=dev)
+        net, o, s = model["KanTtsSAMBERT"], opt["KanTtsSAMBERT"], sch["KanTtsSAMBERT"]
+        o.set_grad_clip(1.0)
+        net.train()
+        return net, o, s
+
+    def eager_step(net, o, s):
+        ops.advance_rng(dev)
+        o.zero_grad()
+        res = net(**batch)
+        mel_, mel = mel_crit(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+        d, p, e = pros_crit(batch["input_lengths"], res["duration_targets"], res["pitch_targets"], res["energy_targets"],
+                            res["log_duration_predictions"], res["pitch_predictions"], res["energy_predictions"])
+        loss = mel_ + mel + d + p + e
+        loss.backward()
+        o.step()
+        s.step()
+        return float(loss.detach())
+
+    rng0 = hip.rng_state(dev).clone()
+    old_counter = ops._seed_counter
+    try:
+        # ---- captured schedule: warm-up steps and the capture draw their seeds from a counter we restart at 1
+        ops._seed_counter = itertools.count(1)
+        net, o, s = build()
+        step = GraphedSambertStep(net, o, s, mel_crit, pros_crit, batch, warmup=1)
+        used = next(ops._seed_counter) - 1          # seeds drawn by one warm-up step + the capture
+        per_step = used // 2
+        assert per_step * 2 == used and per_step > 10
+        hip.rng_state(dev).copy_(rng0)
+        g_losses = [float(step().detach()) for _ in range(3)]
+        g_flat = o.arena.flat.detach().clone()
+        del step
+        # ---- eager, one stream, every step re-draws the capture's seeds (per_step + 1 .. 2 per_step)
+        net, o, s = build()
+        hip.rng_state(dev).copy_(rng0)
+        e_losses = []
+        os.environ["KANTTS_NO_ATTN_STREAMS"] = "1"
+        for _ in range(3):
+            ops._seed_counter = itertools.count(per_step + 1)
+            e_losses.append(eager_step(net, o, s))
+        e_flat = o.arena.flat.detach().clone()
+    finally:
+        os.environ.pop("KANTTS_NO_ATTN_STREAMS", None)
+        ops._seed_counter = old_counter
+        hip.rng_state(dev).copy_(rng0)
+        hip.set_precision("fp32")
+    for a, b in zip(g_losses, e_losses):
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (prec, g_losses, e_losses)
+    rel = float((g_flat - e_flat).norm() / e_flat.norm())
+    assert rel <= tol, (prec, rel)
+    assert g_losses[2] < g_losses[0]  # and it trains
+
+
+@pytest.mark.gpu
+def test_gan_step_branch_streams_change_nothing_gpu():
+    """gan_train_step with the discriminators / residual stacks on their own streams (ops.parallel_branches) against the
+    same step on one stream (KANTTS_NO_BRANCH_STREAMS): same losses, same weights after two steps."""
+    import os
+
+    import kantts._hip as hip
+    from test_hifigan import _small_gan_setup
+    from kantts.train.gan_step import gan_train_step
+
+    hip.set_precision("fp32")
+    g = torch.Generator().manual_seed(8)
+    xs = [torch.randn(2, 80, 16, generator=g).cuda() for _ in range(2)]
+    ys = [torch.randn(2, 1, 4096, generator=g).clamp(-1, 1).cuda() for _ in range(2)]
+    res = {}
+    for tag, env in (("streams", None), ("one", "1")):
+        if env is None:
+            os.environ.pop("KANTTS_NO_BRANCH_STREAMS", None)
+        else:
+            os.environ["KANTTS_NO_BRANCH_STREAMS"] = env
+        try:
+            config, model, optimizer, scheduler, crit = _small_gan_setup()
+            losses = []
+            for x, y in zip(xs, ys):
+                out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
+                losses.append({k: float(v) for k, v in out.items()})
+            flats = [optimizer["generator"].arena.flat.clone()] + [o.arena.flat.clone() for o in optimizer["discriminator"].values()]
+            res[tag] = (losses, flats)
+        finally:
+            os.environ.pop("KANTTS_NO_BRANCH_STREAMS", None)
+    for la, lb in zip(res["streams"][0], res["one"][0]):
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 2e-4 * max(1.0, abs(lb[k])), k
+    for a, b in zip(res["streams"][1], res["one"][1]):
+        assert float((a - b).norm() / b.norm()) <= 2e-4
