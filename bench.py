@@ -321,8 +321,25 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
            "dtype": precision}
     with torch.no_grad():
         ms = _event_ms(lambda: G(x), 5)
+        res["generator_forward_eager_ms"] = ms  # ~300 launches issued from Python: host-bound
+        try:  # the same forward replayed from a hipGraph (what an inference server runs: fixed-shape vocoder chunks)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                G(x)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gg, capture_error_mode="thread_local"):
+                yg = G(x)
+            ms = _event_ms(gg.replay, 20)
+            res["generator_forward_schedule"] = "hipGraph replay"
+            del gg, yg
+        except Exception as exc:
+            res["generator_forward_schedule"] = "eager (capture failed: %s)" % type(exc).__name__
         res["generator_forward_ms"] = ms
         res["generator_forward_samples_per_s"] = B * T_wav / (ms * 1e-3)
+        res["generator_forward_tflops"] = 696.5e9 * B / 32 / (ms * 1e-3) / 1e12
         hs, T, C, elems, flops = [], frames, 512, 0, 0.0
         for s_ in (8, 8, 2, 2):
             hs.append(torch.randn(B, T, C, device="cuda"))

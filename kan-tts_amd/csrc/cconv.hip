@@ -359,6 +359,234 @@ static int cc_launch(const CcArgs& P, hipStream_t st) {
   KANTTS_CHECK_LAUNCH();
 }
 
+// ================================================================================================ narrow forward / dgrad
+// Channel groups of at most 64 input channels (the generator's 64- / 32-channel residual stacks, the scale
+// discriminators' grouped k = 41 layers and their input gradients): in the gather form above every tap re-copies its
+// 64-deep A tile from L2 -- K copies of every activation row -- while the MFMAs of a 32-channel layer need a quarter of
+// a tile.  Here a workgroup copies the WINDOW of input tokens its BM outputs can touch
+//   (BM - 1) * in_mul + (off_max - off_min) + 1 rows of one batch item, all CR channels
+// ONCE, keeps it in LDS for every tap (tap j of output m reads window row (m - m0) * in_mul + off_j - off_min), and
+// streams the weights in groups of TG taps (double-buffered copies).  One (batch item, phase) per blockIdx.z.
+struct CnArgs {
+  kantts_cconv_args a;
+  int kper, doff;
+  int tg;        // taps per weight group
+  int wcopies;   // window copies per wave
+  int wr;        // window rows (worst case over the phases)
+  CcPhase ph[CC_MAXPH];
+};
+
+__device__ __forceinline__ int cn_swz(int row, int rowbytes) {
+  // 64-byte rows: chunk ^= (-(row >> 2)) & 3;  128-byte rows: chunk ^= (row >> 1) & 7  (conflict-free b128 fragment reads)
+  return rowbytes == 64 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7);
+}
+
+template <int BM, int BN, int CP>  // CP = padded input channels per group (32 or 64)
+__global__ __launch_bounds__(CC_THREADS) void cconv_narrow_kernel(const CnArgs P) {
+  constexpr int MREP = BM / 64, NREP = BN / 16, KK = CP / 32;
+  constexpr int ROWB = CP * 2;
+  constexpr int RPC = 1024 / ROWB;  // rows per 1 KB copy
+  constexpr int CPRW = ROWB / 16;   // chunks per row
+  constexpr int CLD = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char cc_lds[];
+  const kantts_cconv_args& g = P.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int phase = blockIdx.z % g.phases, b = blockIdx.z / g.phases;
+  const int ntpg = (g.NG + BN - 1) / BN;
+  const int grp = blockIdx.x / ntpg;
+  const int n0 = grp * g.NG + (blockIdx.x % ntpg) * BN;
+  const int n_end = (grp + 1) * g.NG;
+  const int mrows = (g.Tdst - phase + g.phases - 1) / g.phases;
+  const int m0 = blockIdx.y * BM;
+  if (m0 >= mrows) return;
+  const int nv = P.ph[phase].nv, kfirst = P.ph[phase].kfirst, off0 = P.ph[phase].off0;
+  const int off_last = off0 + (nv - 1) * P.doff;
+  const int off_min = nv > 0 ? min(off0, off_last) : 0;
+  const int win_bytes = P.wcopies * 4 * 1024;
+  const int wg_bytes = P.tg * BN * ROWB;  // one weight group
+  unsigned char* Win = cc_lds;
+  unsigned char* Wt = cc_lds + win_bytes;
+  const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(cc_zero16);
+
+  // ---- window: row r <-> token m0 * in_mul + off_min + r of batch item b
+  const int t_base = m0 * g.in_mul + off_min;
+  const int rsub = lane / CPRW, slot = lane % CPRW;
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(g.in) + ((long long)b * g.Tsrc * g.Cin_tot + (long long)grp * g.CR) * 2;
+  for (int v = 0; v < P.wcopies; ++v) {
+    const int row = (v * 4 + wave) * RPC + rsub;
+    const int chunk = slot ^ cn_swz(row, ROWB);
+    const int t = t_base + row;
+    const bool ok = row < P.wr && (unsigned)t < (unsigned)g.Tsrc && chunk * 8 < g.CR;
+    cc_glds16(ok ? xb + ((long long)t * g.Cin_tot + chunk * 8) * 2 : zsrc, Win + (v * 4 + wave) * 1024);
+  }
+  // ---- weight groups: tap slot s of group q holds tap ordinal q * tg + s; rows n0 .. n0 + BN - 1
+  const int wcop = (P.tg * BN + 4 * RPC - 1) / (4 * RPC);  // copies per wave and group
+  auto issue_w = [&](int q, int buf) {
+    unsigned char* dst = Wt + buf * wg_bytes;
+    for (int v = 0; v < wcop; ++v) {
+      const int row = (v * 4 + wave) * RPC + rsub;  // row inside the group image: s * BN + n
+      const int sidx = row / BN, nl = row - sidx * BN;
+      const int chunk = slot ^ cn_swz(row, ROWB);
+      const int j = q * P.tg + sidx;
+      const bool ok = sidx < P.tg && j < nv && (n0 + nl) < n_end && chunk * 8 < g.CR;
+      const long long wo = (((long long)(kfirst + j * P.kper) * g.Ntot + n0 + nl) * g.CR + chunk * 8) * 2;
+      if ((v * 4 + wave) * 1024 < wg_bytes)
+        cc_glds16(ok ? reinterpret_cast<const unsigned char*>(g.w) + wo : zsrc, dst + (v * 4 + wave) * 1024);
+    }
+  };
+  const int ngroups = (nv + P.tg - 1) / P.tg;
+  if (ngroups > 0) issue_w(0, 0);
+
+  f32x4 acc[MREP][NREP];
+#pragma unroll
+  for (int m = 0; m < MREP; ++m)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int q = 0; q < ngroups; ++q) {
+    cc_wait_vm<0>();
+    cc_barrier();  // group q (and, first time round, the window) has landed; group q - 1 is no longer read
+    if (q + 1 < ngroups) issue_w(q + 1, (q + 1) & 1);
+    const unsigned char* Wq = Wt + (q & 1) * wg_bytes;
+    const int jend = min(P.tg, nv - q * P.tg);
+    for (int s_ = 0; s_ < jend; ++s_) {
+      const int offj = off0 + (q * P.tg + s_) * P.doff - off_min;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        bf16x8 af[MREP], bf[NREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+          const int r = (wave * (BM / 4) + m * 16 + li) * g.in_mul + offj;
+          af[m] = *reinterpret_cast<const bf16x8*>(Win + r * ROWB + (((kk * 4 + kg) ^ cn_swz(r, ROWB)) << 4));
+        }
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+          const int r = s_ * BN + n * 16 + li;
+          bf[n] = *reinterpret_cast<const bf16x8*>(Wq + r * ROWB + (((kk * 4 + kg) ^ cn_swz(r, ROWB)) << 4));
+        }
+#pragma unroll
+        for (int m = 0; m < MREP; ++m)
+#pragma unroll
+          for (int n = 0; n < NREP; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+  cc_wait_vm<0>();
+  cc_barrier();
+
+  // ---- epilogue through LDS (the window / weight images are dead)
+  float* Cs = reinterpret_cast<float*>(cc_lds);
+#pragma unroll
+  for (int m = 0; m < MREP; ++m)
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cs[(wave * (BM / 4) + m * 16 + kg * 4 + r) * CLD + n * 16 + li] = acc[m][n][r];
+  __syncthreads();
+  constexpr int TPR = BN / 8;
+  constexpr int RPP = CC_THREADS / TPR;
+  const int jc = (tid % TPR) * 8;
+  const int j = n0 + jc;
+  if (j >= n_end) return;
+  float bs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+  if (g.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + j), b1 = *reinterpret_cast<const float4*>(g.bias + j + 4);
+    bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+  }
+#pragma unroll 2
+  for (int pass = 0; pass < BM / RPP; ++pass) {
+    const int rl = tid / TPR + pass * RPP;
+    const int m = m0 + rl;
+    if (m >= mrows) continue;
+    const long long o = ((long long)b * g.Tdst + (long long)m * g.phases + phase) * g.Ntot + j;
+    const float4 c0 = *reinterpret_cast<const float4*>(&Cs[rl * CLD + jc]);
+    const float4 c1 = *reinterpret_cast<const float4*>(&Cs[rl * CLD + jc + 4]);
+    float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e] + bs[e];
+      if (g.out_act) x = x > 0.f ? x : x * g.out_slope;
+      v[e] = x;
+    }
+    float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.res) {
+      const float4 r0 = *reinterpret_cast<const float4*>(g.res + o), r1 = *reinterpret_cast<const float4*>(g.res + o + 4);
+      rv[0] = r0.x; rv[1] = r0.y; rv[2] = r0.z; rv[3] = r0.w; rv[4] = r1.x; rv[5] = r1.y; rv[6] = r1.z; rv[7] = r1.w;
+      if (!g.res_after_gate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+    }
+    if (g.out_gate) {
+      float gv[8];
+      if (g.out_gate_bf16) {
+        const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(g.out_gate) + o);
+        gv[0] = cc_lo(q.x); gv[1] = cc_hi(q.x); gv[2] = cc_lo(q.y); gv[3] = cc_hi(q.y);
+        gv[4] = cc_lo(q.z); gv[5] = cc_hi(q.z); gv[6] = cc_lo(q.w); gv[7] = cc_hi(q.w);
+      } else {
+        const float* gp = reinterpret_cast<const float*>(g.out_gate) + o;
+        const float4 q0 = *reinterpret_cast<const float4*>(gp), q1 = *reinterpret_cast<const float4*>(gp + 4);
+        gv[0] = q0.x; gv[1] = q0.y; gv[2] = q0.z; gv[3] = q0.w; gv[4] = q1.x; gv[5] = q1.y; gv[6] = q1.z; gv[7] = q1.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= (gv[e] > 0.f) ? 1.f : g.out_gate_slope;
+    }
+    if (g.res && g.res_after_gate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    if (g.out) {
+      f32x4 w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(g.out + o) = w0;
+      *reinterpret_cast<f32x4*>(g.out + o + 4) = w1;
+    }
+    if (g.out_bf) {
+      if (g.bf_act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * g.bf_slope;
+      }
+      u32x4 w = {cc_pack2(v[0], v[1]), cc_pack2(v[2], v[3]), cc_pack2(v[4], v[5]), cc_pack2(v[6], v[7])};
+      *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.out_bf) + o) = w;
+    }
+  }
+}
+
+template <int BM, int BN, int CP>
+static int cn_launch(CnArgs& P, int span, hipStream_t st) {
+  const kantts_cconv_args& g = P.a;
+  constexpr int ROWB = CP * 2, RPC = 1024 / ROWB;
+  P.wr = (BM - 1) * g.in_mul + span + 1;
+  P.wcopies = kantts_cdiv(kantts_cdiv(P.wr, RPC), 4);
+  int tg = (16 * 1024) / (BN * ROWB);  // ~16 KB of weights per group
+  if (tg < 1) tg = 1;
+  if (tg > g.K) tg = g.K;
+  P.tg = tg;
+  const size_t wg_alloc = (size_t)kantts_cdiv(kantts_cdiv(tg * BN, RPC), 4) * 4 * 1024;  // whole copies
+  size_t lds = (size_t)P.wcopies * 4096 + 2 * wg_alloc;
+  const size_t epi = (size_t)BM * (BN + 4) * 4;
+  if (lds < epi) lds = epi;
+  if (lds > 72 * 1024) return KANTTS_E_UNSUPPORTED;  // (two workgroups per CU)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cconv_narrow_kernel<BM, BN, CP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int mrows = (g.Tdst + g.phases - 1) / g.phases;
+  const int ntpg = (g.NG + BN - 1) / BN;
+  if ((long long)g.B * g.phases > 65535) return KANTTS_E_UNSUPPORTED;
+  dim3 grid(g.groups * ntpg, kantts_cdiv(mrows, BM), g.B * g.phases);
+  hipLaunchKernelGGL((cconv_narrow_kernel<BM, BN, CP>), grid, dim3(CC_THREADS), lds, st, P);
+  KANTTS_CHECK_LAUNCH();
+}
+
 static bool cc_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static int cc_floordiv(int a, int b) {
   int q = a / b;
@@ -421,7 +649,40 @@ extern "C" int kantts_cconv_launch(const kantts_cconv_args* ap, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   const long long rows = (long long)g.B * ((g.Tdst + g.phases - 1) / g.phases) * g.inner;
-  int tile = g.tile;
+  static const char* no_narrow = getenv("KANTTS_NO_CCONV_NARROW");
+  if (!no_narrow && (g.tile == 0 || g.tile == 1) && g.inner == 1 && up == 1 && g.CR <= 64 &&
+      (g.Tdst + g.phases - 1) / g.phases >= 64) {
+    // window form: every activation row is copied once per workgroup instead of once per tap
+    CnArgs N = {};
+    N.a = g;
+    N.kper = P.kper;
+    N.doff = P.doff;
+    int span = 0;
+    for (int ph = 0; ph < g.phases; ++ph) {
+      N.ph[ph] = P.ph[ph];
+      if (P.ph[ph].nv > 0) {
+        const int sp = abs((P.ph[ph].nv - 1) * P.doff);
+        if (sp > span) span = sp;
+      }
+    }
+    const int mrows = (g.Tdst + g.phases - 1) / g.phases;
+    const bool big = mrows >= 192;
+    int rc;
+    if (g.CR <= 32) {
+      if (g.NG > 32)
+        rc = big ? cn_launch<256, 64, 32>(N, span, st) : cn_launch<128, 64, 32>(N, span, st);
+      else
+        rc = big ? cn_launch<256, 32, 32>(N, span, st) : cn_launch<128, 32, 32>(N, span, st);
+    } else {
+      if (g.NG > 32)
+        rc = big ? cn_launch<256, 64, 64>(N, span, st) : cn_launch<128, 64, 64>(N, span, st);
+      else
+        rc = big ? cn_launch<256, 32, 64>(N, span, st) : cn_launch<128, 32, 64>(N, span, st);
+    }
+    if (rc != KANTTS_E_UNSUPPORTED) return rc;
+    if (g.tile == 1) return rc;
+  }
+  int tile = g.tile == 1 ? 0 : g.tile;
   if (tile == 0) {
     // (measured, scripts/bench_native/cconv_test: 128 x 64 beats 256 x 64 at every 64-channel shape of the model)
     if (g.NG > 64) {

@@ -320,6 +320,14 @@ int main(int argc, char** argv) {
       {"k1 c256", 2, 77, 77, 1, 256, 64, 1, 1, 1, 0, 1, 1, 1, 1, F},
       {"c8 n8", 2, 33, 33, 1, 8, 8, 1, 5, 1, -2, 1, 1, 1, 1, F},
       {"inner11 tdst10", 4, 10, 10, 11, 64, 64, 1, 5, 1, -2, 1, 1, 1, 1, FB},
+      // window (narrow) form: CR <= 64, one batch item per workgroup
+      {"narrow c32 k11 dil5 res", 3, 300, 300, 1, 32, 32, 1, 11, 1, -50, 5, 1, 1, 1, F | 4 | 64 | 128},
+      {"narrow c64->n72 k7", 2, 333, 333, 1, 64, 72, 1, 7, 1, -3, 1, 1, 1, 1, FB},
+      {"narrow c24->n40 k5 s3", 3, 400, 134, 1, 24, 40, 1, 5, 3, -2, 1, 1, 1, 1, F},
+      {"narrow dgrad s3 40<-24", 3, 134, 400, 1, 40, 24, 1, 5, 1, 2, -1, 3, 3, 1, 32 | 8},
+      {"narrow c64 k41 g2 s4", 2, 1100, 275, 1, 128, 128, 2, 41, 4, -20, 1, 1, 1, 1, FB},
+      {"narrow c32 k3 gate T70", 2, 70, 70, 1, 32, 32, 1, 3, 1, -2, 1, 1, 1, 1, 32 | 16 | 4},
+      {"narrow c8 n8 k5 T100", 2, 100, 100, 1, 8, 8, 1, 5, 1, -2, 1, 1, 1, 1, F},
   };
   for (auto& c : small) {
     fails += run_fwd(c, 0, 2);
@@ -377,10 +385,15 @@ int main(int argc, char** argv) {
       {"rep up8 256->128 k7", 32, 256, 2048, 1, 256, 128, 1, 7, 1, -6, 1, 1, 1, 8, 1 | 64},
       {"msd g16 1024->1024 k41", 32, 130, 130, 1, 1024, 1024, 16, 41, 1, -20, 1, 1, 1, 1, FB},
       {"msd g4 128->128 k41 s2", 32, 8192, 4096, 1, 128, 128, 4, 41, 2, -20, 1, 1, 1, 1, FB},
+      {"msd g4 dgrad s2 B64", 64, 4096, 8192, 1, 128, 128, 4, 41, 1, 20, -1, 2, 2, 1, 32 | 8},
+      {"msd packed 32->64 k41 s2", 32, 4096, 2048, 1, 128, 256, 4, 41, 2, -20, 1, 1, 1, 1, FB},
+      {"gen res c64 k3 d3 bf", 32, 4096, 4096, 1, 64, 64, 1, 3, 1, -6, 3, 1, 1, 1, 1 | 2 | 64},
+      {"gen res c32 k7 res+img", 32, 8192, 8192, 1, 32, 32, 1, 7, 1, -6, 1, 1, 1, 1, F | 4 | 64 | 128},
   };
   for (auto& c : big) {
     fails += run_fwd(c, 0, iters);
     const int NG = c.Cout / c.groups;
+    if (c.Cin / c.groups <= 64 && c.inner == 1 && c.up <= 1) fails += run_fwd(c, c.Cout / c.groups > 32 ? 128064 : 256032, iters);
     if (!quick) {
       if (NG > 64) fails += run_fwd(c, 256064, iters);
       if (NG <= 64 && NG > 32) { fails += run_fwd(c, 128064, iters); fails += run_fwd(c, 256064, iters); }
