@@ -37,9 +37,19 @@ PEAK_HBM_GBPS = 8000.0
 # memory-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of scripts/ffn_pmc_probe.py):
 # bf16: mean of the four launches of a feed-forward block (ffn_pair forward 26.4, backward 36.2, weight gradients
 # 47.3 / 33.8 MB against 22.2 / 32.3 / 17.2 / 15.6 MB algorithmic); fp32: the round-1 fp32-storage kernel
-MEASURED_TRAFFIC_BYTES = {"bf16": 35.9e6, "fp32": 34.9e6}
-MEASURED_TRAFFIC_SOURCE = {"bf16": "profiles/r02_runM_ffn_pair_pmc.txt",
-                           "fp32": "profiles/r01_gemm_ffn_pmc_v2.txt (round-1 fp32-storage kernel)"}
+# -- read from the committed summary scripts/pmc_to_json.py writes (bench.py cannot run the profiler on itself)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "ffn_block_pmc.json")
+
+
+def measured_traffic(precision):
+    """(bytes per launch or None, source string or None, per-launch dict) from profiles/ffn_block_pmc.json."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            doc = json.load(f)
+        rec = doc[precision]
+        return rec["mean_traffic_bytes"], "profiles/ffn_block_pmc.json (%s)" % rec["source"], rec.get("launches")
+    except (OSError, KeyError, ValueError):
+        return None, None, None
 
 
 def sambert_yaml_config(cfg):
@@ -63,8 +73,8 @@ def _cpu_threads():
     return n
 
 
-def _time_iters(fn, warmup, iters, budget_s):
-    """>= 3 timed iterations, up to ``iters``, stopping once ``budget_s`` of timed work is spent."""
+def _time_iters(fn, warmup, iters, budget_s, min_iters=3):
+    """>= ``min_iters`` timed iterations, up to ``iters``, stopping once ``budget_s`` of timed work is spent."""
     for _ in range(warmup):
         fn()
     ts = []
@@ -73,7 +83,7 @@ def _time_iters(fn, warmup, iters, budget_s):
         t0 = time.time()
         fn()
         ts.append(time.time() - t0)
-        if len(ts) >= 3 and time.time() - t_all > budget_s:
+        if len(ts) >= min_iters and time.time() - t_all > budget_s:
             break
     return sum(ts) / len(ts), len(ts)
 
@@ -106,7 +116,7 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
         keep["out"], keep["L"] = out, L
 
     O.DROP["on"] = False
-    dt_off, n_off = _time_iters(one, 2, 5, budget_s)
+    dt_off, n_off = _time_iters(one, 2, 6, budget_s, min_iters=5)  # >= 2 warm-up + >= 5 timed
     ref_out = {k: keep["out"][k].detach().clone() for k in ("dec_outputs", "postnet_outputs")}
     ref_loss = float(keep["L"]["total"].detach())
     ref_grads = {k: p.grad.detach().clone() for k, p in P.items() if p.grad is not None}
@@ -115,6 +125,24 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
         dt_on, n_on = _time_iters(one, 1, 3, budget_s * 0.6)
     finally:
         O.DROP["on"] = False
+    # every host core, beside the default thread count: one warm-up + two timed iterations (the chain of small ops gets
+    # SLOWER beyond ~16 threads on this box class; reported so that the choice is visible, bounded so that it cannot eat
+    # the bench's time budget)
+    all_cores = os.cpu_count() or 1
+    all_core = None
+    if all_cores > cores and CPU_THREADS["n"] is None:
+        torch.set_num_threads(all_cores)
+        try:
+            t0 = time.time()
+            one()
+            if time.time() - t0 < 30.0:
+                dt_all, n_all = _time_iters(one, 0, 2, 30.0, min_iters=2)
+                all_core = {"cores": all_cores, "value": frames / dt_all, "timed": n_all, "s_per_iter": dt_all}
+            else:
+                all_core = {"cores": all_cores, "value": frames / (time.time() - t0), "timed": 1,
+                            "s_per_iter": time.time() - t0, "note": "first iteration only (> 30 s)"}
+        finally:
+            torch.set_num_threads(cores)
 
     # ---- parity of the HIP path at the benchmarked shape (dropout forced to 0 on both sides)
     parity = {}
@@ -155,7 +183,7 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
                                                                 keep["out"]["LR_length_rounded"]))}
         del g, res, total
     base = {"value": frames / dt_off, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "value_dropout_on": frames / dt_on,
+            "value_dropout_on": frames / dt_on, "all_cores": all_core,
             "sample": "oracle/torch_oracle.py fwd+losses+bwd, fp32, the full seeded batch B=%d (%d valid frames): "
                       "dropout off 2 warm-up + %d timed, %.2f s/iter; dropout on (as shipped) 1 warm-up + %d timed, "
                       "%.2f s/iter; torch.set_num_threads(%d) of %d host cores" % (B, frames, n_off, dt_off, n_on, dt_on,
@@ -163,19 +191,13 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
     return base, parity
 
 
-def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
-    """Roofline of the dominant kernel: the MFMA contractions of the decoder feed-forward block (forward, input
-    gradient, weight gradient of Conv1d(128->1024,k=1) and Conv1d(1024->128,k=1) at M = 32*204 decoder tokens; 12 layers
-    each = 31 % of the step's contraction flops).  Each contraction is launched `reps` times inside a captured hipGraph
-    (the host is out of the picture) and timed with HIP events on the replay stream.  Algorithmic bytes = every operand
-    read once + the output written once AT ITS STORAGE DTYPE: bf16 mode stores the LayerNorm output, the hidden
-    activation and the weights as bf16 and keeps the residual stream / its gradient fp32 (kantts/_hip/ops_bf16.py)."""
+def _ffn_cases(hip, precision):
+    """One fresh set of operand / output buffers of the decoder feed-forward block and the launches over it:
+    name -> (launch, algorithmic bytes)."""
     from kantts._hip import bgemm_nt, bgemm_tn, gemm, make_seg, ops
 
-    ops.wgrad_overlap.enable(False)  # every contraction is launched (and timed) on its own here
     dev = "cuda"
     M, C, F = 32 * 204, 128, 1024
-    flops = 2.0 * M * C * F
     if precision == "bf16":
         bf = torch.bfloat16
         xb, hb = torch.randn(M, C, device=dev).to(bf), torch.randn(M, F, device=dev).relu().to(bf)
@@ -241,14 +263,34 @@ def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
                                              splitk=ops._splitk_for(C, F, M), precision=p), by),
         }
         kernel, bytes_dtype = "gemm_fast_kernel<fp32> (csrc/gemm_fast.hip)", "fp32"
-    per, per_gbps = {}, {}
-    tot_us, tot_bytes, n_live = 0.0, 0.0, 0
-    for name, (fn, nbytes) in cases.items():
-        fn()
+    return cases, kernel, bytes_dtype
+
+
+def dominant_gemm_roofline(hip, precision, reps=20, replays=5, cold_sets=10):
+    """Roofline of the dominant kernel: the MFMA contractions of the decoder feed-forward block (forward, input
+    gradient, weight gradient of Conv1d(128->1024,k=1) and Conv1d(1024->128,k=1) at M = 32*204 decoder tokens; 12 layers
+    each = 31 %% of the step's contraction flops).  Each contraction is launched `reps` times inside a captured hipGraph
+    (the host is out of the picture) and timed with HIP events on the replay stream.  Algorithmic bytes = every operand
+    read once + the output written once AT ITS STORAGE DTYPE: bf16 mode stores the LayerNorm output, the hidden
+    activation and the weights as bf16 and keeps the residual stream / its gradient fp32 (kantts/_hip/ops_bf16.py).
+    Two figures per launch: WARM (the same buffers every repetition -- at 15-30 MB per launch the operands stay in the
+    256 MB Infinity Cache, as they partly do inside the training step, where the producer ran just before) and COLD
+    (``cold_sets`` disjoint buffer sets visited round-robin, so every operand comes from HBM)."""
+    from kantts._hip import ops
+
+    ops.wgrad_overlap.enable(False)  # every contraction is launched (and timed) on its own here
+    sets = []
+    for _ in range(cold_sets):
+        cases, kernel, bytes_dtype = _ffn_cases(hip, precision)
+        sets.append(cases)
+
+    def timed(launches):
+        for fn in launches[:2]:
+            fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            for _ in range(reps):
+            for fn in launches:
                 fn()
         g.replay()
         torch.cuda.synchronize()
@@ -258,18 +300,34 @@ def dominant_gemm_roofline(hip, precision, reps=20, replays=5):
             g.replay()
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / (reps * replays)
+        return e0.elapsed_time(e1) * 1e3 / (len(launches) * replays)
+
+    per, per_gbps, per_cold, per_cold_gbps = {}, {}, {}, {}
+    tot_us, tot_cold_us, tot_bytes, n_live = 0.0, 0.0, 0.0, 0
+    for name, (fn, nbytes) in sets[0].items():
+        us = timed([fn] * reps)
         per[name] = round(us, 2)
         per_gbps[name] = round(nbytes / us / 1e3, 1)
         if not name.startswith("["):  # the launches the step actually issues
+            # cold: consecutive launches walk `cold_sets` disjoint buffer sets (~55 MB each, > 2x the 256 MB Infinity
+            # Cache in total), so no operand of a launch is left in a cache by the previous visit of its set
+            cold = timed([sets[r % cold_sets][name][0] for r in range(max(reps, 2 * cold_sets))])
+            per_cold[name] = round(cold, 2)
+            per_cold_gbps[name] = round(nbytes / cold / 1e3, 1)
             tot_us += us
+            tot_cold_us += cold
             tot_bytes += nbytes
             n_live += 1
+    M, C, F = 32 * 204, 128, 1024
+    flops = 2.0 * M * C * F
     # the block's contraction flops: forward 2, input gradients 2, weight gradients 2 products of 2*M*C*F each
     return {"tflops": flops * 6 / (tot_us * 1e-6) / 1e12, "launch_us": per, "launch_gbps": per_gbps,
             "flops_per_launch": flops * 6 / n_live, "gbps": tot_bytes / (tot_us * 1e-6) / 1e9,
             "bytes_per_launch": tot_bytes / n_live, "mean_launch_us": tot_us / n_live, "kernel": kernel,
-            "bytes_dtype": bytes_dtype}
+            "bytes_dtype": bytes_dtype,
+            "cold": {"launch_us": per_cold, "launch_gbps": per_cold_gbps, "mean_launch_us": tot_cold_us / n_live,
+                     "gbps": tot_bytes / (tot_cold_us * 1e-6) / 1e9, "tflops": flops * 6 / (tot_cold_us * 1e-6) / 1e12,
+                     "buffer_sets": cold_sets}}
 
 
 def hifigan_v1_config(channels=512):
@@ -509,6 +567,23 @@ def melspec_leg(B=32, T_wav=8192, reps=20):
         (ms(xg) * cot).sum().backward()
 
     ms_fb = _event_ms(fb, reps)
+    # the same kernel at a size that can show bandwidth: 2048 x 8192 samples = 67 584 frames, 90.8 MB algorithmic (the
+    # batch-32 launch moves 1.4 MB and measures launch latency, not the kernel)
+    Bs = 2048
+    xs = torch.randn(Bs, T_wav, device="cuda") * 0.1
+    frames_s = Bs * (1 + T_wav // 256)
+    with torch.no_grad():
+        ms_s = _event_ms(lambda: ms(xs), 10)
+    xsg = xs.clone().requires_grad_(True)
+    cot_s = torch.randn_like(ms(xs))
+
+    def fb_s():
+        xsg.grad = None
+        (ms(xsg) * cot_s).sum().backward()
+
+    ms_s_fb = _event_ms(fb_s, 5)
+    gbps_s = frames_s * 1344.0 / (ms_s * 1e-3) / 1e9
+    del xs, xsg, cot_s
     xc = x.cpu()
     cores = _cpu_threads()
     dt_cpu, n_cpu = _time_iters(lambda: A.mel_spectrogram(xc), 2, 10, 3.0)
@@ -521,6 +596,10 @@ def melspec_leg(B=32, T_wav=8192, reps=20):
                          "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_frame": 1344,
                          "note": "one launch of %d frames = %.2f MB algorithmic: launch-latency bound at this size"
                                  % (frames, frames * 1344 / 1e6)},
+            "roofline_saturating": {"bound": "hbm", "kernel": "melspec_kernel", "workload": "%d x %d samples (%d frames)"
+                                    % (Bs, T_wav, frames_s), "forward_ms": ms_s, "forward_backward_ms": ms_s_fb,
+                                    "achieved": gbps_s, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps_s / PEAK_HBM_GBPS,
+                                    "algorithmic_bytes": frames_s * 1344.0},
             "cpu_baseline": {"value": frames / dt_cpu, "unit": "frames/s", "cores": cores, "kind": "port",
                              "sample": "oracle/audio_oracle.py mel_spectrogram on the same batch, %d timed" % n_cpu},
             "parity_error": {"max_abs_vs_oracle": err}}
@@ -653,6 +732,10 @@ def main():
     ap.add_argument("--no-wgrad-group", action="store_true", help="one launch per weight gradient (A/B switch)")
     ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo + --share-device runs the N-rank path on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses cuda:0 (a functional check of the distributed path, not a scaling figure)")
     args = ap.parse_args()
 
     CPU_THREADS["n"] = args.cpu_threads or None
@@ -665,11 +748,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    device_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        if args.backend == "nccl":  # RCCL refuses two ranks on one device: --share-device needs gloo
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group("gloo", init_method="env://")
 
     import kantts._hip as hip
     import kantts._hip.ops  # noqa: F401
@@ -681,7 +768,7 @@ def main():
     hip.set_precision(args.precision)
     cfg = synthetic.sambert_16k_config()
     torch.manual_seed(0)
-    model, opt, sch = model_builder(sambert_yaml_config(cfg), device=dev, rank=local_rank, distributed=distributed)
+    model, opt, sch = model_builder(sambert_yaml_config(cfg), device=dev, rank=device_index, distributed=distributed)
     net, optimizer, scheduler = model["KanTtsSAMBERT"], opt["KanTtsSAMBERT"], sch["KanTtsSAMBERT"]
     optimizer.set_grad_clip(1.0)
     net.train()
@@ -742,8 +829,9 @@ def main():
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_max, total_frames = float(tmax[0]), float(tsum[1])
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
+        tg = t if args.backend == "nccl" else t.cpu()  # gloo gathers host tensors only
+        allt = [torch.zeros_like(tg) for _ in range(world)]
+        dist.all_gather(allt, tg)
         per_rank_ms = [1e3 * float(a[0]) / args.steps for a in allt]
     else:
         dt_max, total_frames = dt, float(frames)
@@ -801,16 +889,18 @@ def main():
         prof = hip.profile_end()
         dg = dominant_gemm_roofline(hip, args.precision)
         peak = PEAK_TFLOPS[args.precision]
+        traffic, traffic_src, traffic_launches = measured_traffic(args.precision)
         roof = {"bound": "hbm", "kernel": dg["kernel"] + ": decoder FFN contractions, M=6528, 128<->1024",
                 "achieved": dg["gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": dg["gbps"] / PEAK_HBM_GBPS,
                 # memory-side bytes per launch come from rocprofv3 --pmc passes of scripts/bgemm_bench.py (2*FETCH_SIZE +
                 # WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md), collected offline per round under profiles/
                 # -- bench.py cannot run the profiler on itself; null until this round's pass exists
-                "traffic": MEASURED_TRAFFIC_BYTES.get(args.precision),
-                "traffic_source": MEASURED_TRAFFIC_SOURCE.get(args.precision),
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_per_launch": traffic_launches,
                 "bytes_per_launch": dg["bytes_per_launch"], "bytes_dtype": dg["bytes_dtype"],
                 "flops_per_launch": dg["flops_per_launch"], "launch_us": dg["launch_us"], "launch_gbps": dg["launch_gbps"],
                 "mean_launch_us": dg["mean_launch_us"],
+                "cold_cache": dict(dg["cold"], frac=dg["cold"]["gbps"] / PEAK_HBM_GBPS,
+                                   mfma_frac=dg["cold"]["tflops"] / peak),
                 "mfma_tflops": dg["tflops"], "mfma_peak": peak, "mfma_frac": dg["tflops"] / peak,
                 "gemm_launches_per_step": prof["launches"], "gemm_gflop_per_step": prof["flops"] / 1e9,
                 "gemm_ms_per_step_eager_events": prof["ms"],
@@ -835,7 +925,8 @@ def main():
                                       if mode == "graph" else "eager launches, one stream"),
                        "final_loss": float(loss.detach()), "per_rank_ms_per_step": per_rank_ms,
                        "collective_world_size": dist.get_world_size() if distributed else 1,
-                       "collective_backend": ("nccl (RCCL)" if distributed else None)},
+                       "collective_backend": (("nccl (RCCL)" if args.backend == "nccl" else "gloo") if distributed else None),
+                       "shared_device": bool(args.share_device and distributed)},
             "roofline": roof,
         }
         del step, net, optimizer, model, opt
