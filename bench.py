@@ -88,6 +88,55 @@ def _time_iters(fn, warmup, iters, budget_s, min_iters=3):
     return sum(ts) / len(ts), len(ts)
 
 
+def _note(msg):
+    """Progress marker on stderr (the JSON line on stdout stays the only stdout output)."""
+    print("[bench %7.1f s] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
+
+
+def oracle_probe_main(threads, B):
+    """Child-process body of ``_oracle_probe``: the CPU oracle step (dropout off) at ``threads`` host threads, one
+    warm-up + two timed iterations; prints one JSON line."""
+    import torch_oracle as O
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+    from kantts.utils import synthetic
+
+    torch.set_num_threads(threads)
+    cfg0 = dict(synthetic.sambert_16k_config())
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(cfg0)
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    batch = O.synthetic_sambert_batch(B=B, T_in=64, seed=1234)
+    frames = int(batch["output_lengths"].sum())
+    O.DROP["on"] = False
+
+    def one():
+        for p in P.values():
+            p.grad = None
+        out = O.sambert_forward(P, cfg0, **batch)
+        O.sambert_losses(out, batch["input_lengths"], batch["output_lengths"], batch["mel_targets"])["total"].backward()
+
+    dt, n = _time_iters(one, 1, 2, 1e9, min_iters=2)
+    print(json.dumps({"cores": threads, "value": frames / dt, "timed": n, "s_per_iter": dt}))
+
+
+def _oracle_probe(threads, B, limit_s):
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--oracle-probe", str(threads), "--batch", str(B)],
+                           capture_output=True, text=True, timeout=limit_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if lines:
+            return json.loads(lines[-1])
+        return {"cores": threads, "error": (r.stderr or "no output")[-200:]}
+    except subprocess.TimeoutExpired:
+        return {"cores": threads, "value": None,
+                "note": "1 warm-up + 2 timed iterations did not finish within %.0f s at %d threads" % (limit_s, threads)}
+
+
 def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
     """CPU oracle ("port" of the reference path, pinned against it by tests/golden + oracle/check_vs_reference.py)
     forward + losses + backward on the SAME seeded batch as the GPU line (B=32, 14 797 valid frames), all host cores,
@@ -122,27 +171,16 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
     ref_grads = {k: p.grad.detach().clone() for k, p in P.items() if p.grad is not None}
     O.DROP["on"] = True
     try:
-        dt_on, n_on = _time_iters(one, 1, 3, budget_s * 0.6)
+        dt_on, n_on = _time_iters(one, 1, 3, budget_s * 0.6, min_iters=2)
     finally:
         O.DROP["on"] = False
-    # every host core, beside the default thread count: one warm-up + two timed iterations (the chain of small ops gets
-    # SLOWER beyond ~16 threads on this box class; reported so that the choice is visible, bounded so that it cannot eat
-    # the bench's time budget)
+    # every host core, beside the default thread count (the chain of small ops gets SLOWER beyond ~16 threads on this box
+    # class; reported so that the choice is visible).  Runs in a child process under a hard time limit: one iteration at
+    # 256 threads must not be able to eat the bench's time budget.
     all_cores = os.cpu_count() or 1
     all_core = None
     if all_cores > cores and CPU_THREADS["n"] is None:
-        torch.set_num_threads(all_cores)
-        try:
-            t0 = time.time()
-            one()
-            if time.time() - t0 < 30.0:
-                dt_all, n_all = _time_iters(one, 0, 2, 30.0, min_iters=2)
-                all_core = {"cores": all_cores, "value": frames / dt_all, "timed": n_all, "s_per_iter": dt_all}
-            else:
-                all_core = {"cores": all_cores, "value": frames / (time.time() - t0), "timed": 1,
-                            "s_per_iter": time.time() - t0, "note": "first iteration only (> 30 s)"}
-        finally:
-            torch.set_num_threads(cores)
+        all_core = _oracle_probe(all_cores, B, limit_s=75.0)
 
     # ---- parity of the HIP path at the benchmarked shape (dropout forced to 0 on both sides)
     parity = {}
@@ -538,8 +576,8 @@ def hifigan_cpu_baseline(B=2, T_wav=8192, budget_s=10.0):
         with torch.no_grad():
             H.generator(PG, x)
 
-    dt_step, n_step = _time_iters(gan_step, 1, 3, budget_s)
-    dt_fwd, n_fwd = _time_iters(gen_fwd, 1, 5, budget_s * 0.3)
+    dt_step, n_step = _time_iters(gan_step, 1, 3, budget_s, min_iters=1)
+    dt_fwd, n_fwd = _time_iters(gen_fwd, 1, 5, budget_s * 0.3, min_iters=1)
     return {"value": B * T_wav / dt_step, "unit": "audio-samples/s (GAN training step)", "cores": cores, "kind": "port",
             "generator_forward_samples_per_s": B * T_wav / dt_fwd,
             "sample": "oracle/hifigan_oracle.py V1 (512 ch) GAN step fwd+bwd without optimizer updates, batch %d x %d "
@@ -734,11 +772,14 @@ def main():
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-device runs the N-rank path on a one-GPU box")
+    ap.add_argument("--oracle-probe", type=int, default=0, help=argparse.SUPPRESS)  # child process of cpu_baseline
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (a functional check of the distributed path, not a scaling figure)")
     args = ap.parse_args()
 
     CPU_THREADS["n"] = args.cpu_threads or None
+    if args.oracle_probe:
+        return oracle_probe_main(args.oracle_probe, args.batch)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -809,6 +850,7 @@ def main():
             net.device_band_width = False
             optimizer.dyn = None
 
+    _note("model built, step %s" % mode)
     for _ in range(args.warmup):
         step()
     if distributed:
@@ -821,6 +863,7 @@ def main():
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0
+    _note("timed %d steps: %.3f ms/step on this rank" % (args.steps, 1e3 * dt / args.steps))
     t = torch.tensor([dt, float(frames)], device=dev, dtype=torch.float64)
     per_rank_ms = [1e3 * dt / args.steps]
     if distributed:
@@ -887,7 +930,9 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         prof = hip.profile_end()
+        _note("forward-only pass and eager instrumented step done")
         dg = dominant_gemm_roofline(hip, args.precision)
+        _note("roofline microbench (warm + cold) done")
         peak = PEAK_TFLOPS[args.precision]
         traffic, traffic_src, traffic_launches = measured_traffic(args.precision)
         roof = {"bound": "hbm", "kernel": dg["kernel"] + ": decoder FFN contractions, M=6528, 128<->1024",
@@ -935,27 +980,33 @@ def main():
             try:  # the parity-proven path (fp32 MFMA) on the same step, beside the throughput (bf16) line
                 out["fp32_path"] = fp32_leg(hip, cfg, batch, frames, mel_crit, pros_crit, dev)
                 hip.set_precision(args.precision)
+                _note("fp32 leg done")
             except Exception as exc:
                 out["fp32_path"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not args.no_hifigan:
             try:
                 out["hifigan"] = hifigan_leg(hip, args.precision)
+                _note("HiFi-GAN leg done")
                 if not args.no_cpu_baseline:
                     out["hifigan"]["cpu_baseline"] = hifigan_cpu_baseline()
+                    _note("HiFi-GAN CPU baseline done")
             except Exception as exc:  # the SAM-BERT line must survive a failure of the secondary leg
                 out["hifigan"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
             try:
                 out["melspec"] = melspec_leg()
+                _note("mel-STFT leg done")
             except Exception as exc:
                 out["melspec"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not args.no_inference:
             try:
                 out["inference"] = inference_leg(hip, cfg, args.precision)
+                _note("inference leg done")
             except Exception as exc:
                 out["inference"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"], out["parity_error"] = cpu_baseline(cfg, hip)
+                _note("SAM-BERT CPU baseline + parity done")
             except Exception as exc:
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         print(json.dumps(out))

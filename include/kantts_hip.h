@@ -565,6 +565,13 @@ int kantts_ln128_fwd(const float* x, const float* gamma, const float* beta, void
 /* dres (optional, fp32 (M,128)): gradient of a residual branch taken from the same x; dx = LN-gradient + dres in one pass. */
 int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                      const float* dres, float* dx, float* dgamma_accum, float* dbeta_accum, int M, void* stream);
+/* ... and zero_rows (optional, uint8 (M)): rows of dx written as 0.  A pre-LN sub-layer's input x is the output of the
+ * previous sub-layer, which zeroes the padded rows of its output (kantts/models/sambert/__init__.py:177-178, 340-341) and
+ * therefore of its incoming gradient: when this LayerNorm is the only consumer of x, that masking is this kernel's store
+ * instead of a separate pass over the gradient. */
+int kantts_ln128_bwd_rows(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                          const float* rstd, const float* dres, float* dx, float* dgamma_accum, float* dbeta_accum,
+                          const unsigned char* zero_rows, int M, void* stream);
 
 /* Backward of kantts_melspec_fwd's magnitude output (the reference's stft(), kantts/utils/audio_torch.py:8-31:
  * sqrt(clamp(re^2 + im^2, eps_power))): dwav_accum (B,T) += d loss / d wav given dmag (B, frames, n_fft/2+1).  Gradient

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void ln128_bwd_kernel(const void* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ dres,
                                                        float* __restrict__ dx, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, int M) {
+                                                       float* __restrict__ dbeta, const unsigned char* __restrict__ zero_rows,
+                                                       int M) {
   __shared__ float red[2][16][128];
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int c0 = sub * 8;
@@ -280,6 +281,12 @@ __global__ __launch_bounds__(256) void ln128_bwd_kernel(const void* __restrict__
         const float4 a = rp[0], b = rp[1];
         o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; o[4] += b.x; o[5] += b.y; o[6] += b.z; o[7] += b.w;
       }
+      // the producer of x zeroes these rows of its output, so it would zero them of its incoming gradient first thing in
+      // its backward: done here on its behalf (dgamma / dbeta above are this node's own and are not affected)
+      if (zero_rows && zero_rows[row]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      }
       float4* op = reinterpret_cast<float4*>(dx + off);
       op[0] = make_float4(o[0], o[1], o[2], o[3]);
       op[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -311,9 +318,9 @@ extern "C" int kantts_ln128_fwd(const float* x, const float* gamma, const float*
   KANTTS_CHECK_LAUNCH();
 }
 
-extern "C" int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
-                                const float* rstd, const float* dres, float* dx, float* dgamma_accum, float* dbeta_accum,
-                                int M, void* stream) {
+extern "C" int kantts_ln128_bwd_rows(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                                     const float* rstd, const float* dres, float* dx, float* dgamma_accum,
+                                     float* dbeta_accum, const unsigned char* zero_rows, int M, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_accum || !dbeta_accum || M < 0) return KANTTS_E_BADARG;
   if (M == 0) return KANTTS_OK;
   // every block ends with 256 atomics onto the SAME 256 addresses: with one block per 16-row slab (408 at the decoder's
@@ -323,9 +330,15 @@ extern "C" int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, con
   if (blocks > 128) blocks = 128;
   if (dy_bf16)
     hipLaunchKernelGGL(ln128_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
-                       dres, dx, dgamma_accum, dbeta_accum, M);
+                       dres, dx, dgamma_accum, dbeta_accum, zero_rows, M);
   else
     hipLaunchKernelGGL(ln128_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
-                       dres, dx, dgamma_accum, dbeta_accum, M);
+                       dres, dx, dgamma_accum, dbeta_accum, zero_rows, M);
   KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_ln128_bwd(const void* dy, int dy_bf16, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, const float* dres, float* dx, float* dgamma_accum, float* dbeta_accum,
+                                int M, void* stream) {
+  return kantts_ln128_bwd_rows(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma_accum, dbeta_accum, nullptr, M, stream);
 }

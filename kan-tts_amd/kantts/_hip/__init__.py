@@ -247,6 +247,7 @@ def lib():
         L.kantts_relu_gate_bf16.argtypes = [p, i, p, i, p, f, ll, p]
         L.kantts_ln128_fwd.argtypes = [p, p, p, p, i, p, p, i, f, p]
         L.kantts_ln128_bwd.argtypes = [p, i, p, p, p, p, p, p, p, p, i, p]
+        L.kantts_ln128_bwd_rows.argtypes = [p, i, p, p, p, p, p, p, p, p, p, i, p]
         L.kantts_cconv_launch.argtypes = [POINTER(CConvArgs), c_void_p]
         L.kantts_cconv_wgrad_launch.argtypes = [POINTER(CConvWArgs), c_void_p]
         L.kantts_cconv_wgrad_ws_floats.argtypes = [POINTER(CConvWArgs)]
@@ -268,7 +269,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
     "kantts_bgemm_nt", "kantts_ffn_pair", "kantts_fragmajor_bf16", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
-    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
+    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_ln128_bwd_rows", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
     "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",

@@ -367,7 +367,8 @@ class _FusedLinear(torch.autograd.Function):
         xs, ws = list(saved[2:2 + nx]), list(saved[2 + nx:])
         has_bias, has_bias2, has_res = ctx.has
         dy = _c(dy).view(M, N)
-        if rm is not None and not relu:
+        token = opts.get("token")  # ops_bf16.RowMaskToken: the consuming LayerNorm has zeroed these rows already
+        if rm is not None and not relu and not (token is not None and token.delegated):
             dy = dy.masked_fill(rm.bool().view(M, 1), 0.0)
         d_res = dy.view(*ctx.lead, N) if has_res else None
         if has_res and rm is not None and relu:
@@ -468,9 +469,10 @@ def linear(xs, weights, bias=None, *, mode=None, bias2=None, res=None, rowmask=N
         return ops_bf16.linear(xs, weights, wbs, bias, mode=mode, bias2=bias2, res=res, rowmask=rowmask, relu=relu,
                                alpha=alpha, drop_p=drop_p, pad=pad, dilation=dilation, T=T, out_bf16=out_bf16)
     xs = [x.float() if x.dtype != torch.float32 else x for x in xs]  # the segmented GEMM reads fp32 operands
+    token = ops_bf16.RowMaskToken(rowmask) if (rowmask is not None and not relu and torch.is_grad_enabled()) else None
     opts = dict(nx=len(xs), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p), pad=int(pad),
-                dilation=int(dilation), T=int(T))
-    return _FusedLinear.apply(opts, bias, bias2, res, rowmask, *xs, *weights)
+                dilation=int(dilation), T=int(T), token=token)
+    return ops_bf16._attach_token(_FusedLinear.apply(opts, bias, bias2, res, rowmask, *xs, *weights), token)
 
 
 def shared_input_linears(x, linears):
@@ -514,13 +516,16 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg, db, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-6, out_bf16=False, with_res=False):
+def layer_norm(x, gamma, beta, eps=1e-6, out_bf16=False, with_res=False, private_input=False):
     """``out_bf16`` (bf16 mode, 128-wide rows only): the normalised activations are written bf16 -- they only feed
     contractions.  128-wide rows use the 16-lanes-per-row kernels in both modes.
     ``with_res``: returns (y, x_res) where x_res is x routed through this node -- use it as the sub-layer's residual input
-    and the two gradients of x are summed inside the LayerNorm backward kernel (see ops_bf16._LayerNorm128)."""
+    and the two gradients of x are summed inside the LayerNorm backward kernel (see ops_bf16._LayerNorm128).
+    ``private_input``: promise that nothing else consumes ``x`` -- the row mask its producer applies to the incoming
+    gradient moves into this node's backward kernel (ops_bf16.RowMaskToken)."""
     if x.shape[-1] == 128 and x.dtype == torch.float32 and x.numel() > 0:
-        return ops_bf16.layer_norm128(x, gamma, beta, eps, out_bf16 and get_precision() == "bf16", with_res)
+        return ops_bf16.layer_norm128(x, gamma, beta, eps, out_bf16 and get_precision() == "bf16", with_res,
+                                      private_input=private_input)
     y = _LayerNorm.apply(x, gamma, beta, eps)
     return (y, x) if with_res else y
 
@@ -670,7 +675,7 @@ class _PncaAttention(torch.autograd.Function):
             lambda: _attn_bwd(q2, 0, q2, D, q2, 2 * D, ox, d_ox, lsex, dqkv, 0, dqkv, D, dqkv, 2 * D, 0, lens, bw_dev, bw_x,
                               B, H, L, MODE_BAND_X, drop_p, sx),
             bwd_h, side_inputs=(q2, h2, oh, d_oh, lseh, dhkv, lens, bw_dev))
-        dqkv[:, :D] += dqh
+        dqkv[:, :D].add_(dqh)  # one launch (``+=`` on a slice is add + copy-back)
         return dqkv.view(B, L, 3 * D), dhkv.view(B, L, 2 * D), None, None, None, None, None, None, None
 
 

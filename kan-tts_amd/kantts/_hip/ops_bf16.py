@@ -119,6 +119,37 @@ def _splits(M):
     return 0  # library default
 
 
+class RowMaskToken:
+    """Hand-over of a sub-layer's output row mask to the LayerNorm that consumes the output.
+
+    y = zero_rows(x + f(LN(x))) is followed, in a stack of pre-LN sub-layers, by the next sub-layer's LayerNorm, which (with
+    ``with_res``) is the ONLY consumer of y.  The backward of the masking -- zero the same rows of the incoming gradient --
+    then is a property of what that LayerNorm's backward writes: kantts_ln128_bwd_rows zeroes the rows as it stores dx and
+    the producer skips its own pass over the gradient (one elementwise launch per sub-layer and step).  The producer
+    attaches the token to its output (``y._kantts_rowmask``); a consumer that KNOWS it is the only one
+    (``layer_norm(..., private_input=True)``) takes the mask and sets ``delegated``; any other flow leaves it unset and
+    the producer masks the gradient itself."""
+    __slots__ = ("mask", "delegated")
+
+    def __init__(self, mask):
+        self.mask, self.delegated = mask, False
+
+
+def _attach_token(y, token):
+    if token is not None:
+        y._kantts_rowmask = token
+    return y
+
+
+def take_rowmask(x):
+    """The row mask a private consumer of ``x`` applies to the gradient it sends back (None if there is none)."""
+    token = getattr(x, "_kantts_rowmask", None)
+    if token is None:
+        return None
+    token.delegated = True
+    return token.mask
+
+
 class _FusedLinearB(torch.autograd.Function):
     """y = rowmask( dropout( act( (sum_k x_k @ W_k^T + bias [+ bias2]) * alpha ) ) + res ) on kantts_bgemm_nt/tn.
     Same three modes as ops._FusedLinear (concat / sum / conv)."""
@@ -184,7 +215,8 @@ class _FusedLinearB(torch.autograd.Function):
         xs, wbs = list(sv[2:2 + nx]), list(sv[2 + nx:])
         has_bias, has_bias2, has_res = ctx.has
         dy = _c(dy).view(M, N)
-        if rm is not None and not relu:
+        token = opts.get("token")
+        if rm is not None and not relu and not (token is not None and token.delegated):
             dy = dy.masked_fill(rm.bool().view(M, 1), 0.0)
         d_res = None
         if has_res:
@@ -261,9 +293,10 @@ class _FusedLinearB(torch.autograd.Function):
 
 
 def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, drop_p, pad, dilation, T, out_bf16):
+    token = RowMaskToken(rowmask) if (rowmask is not None and not relu and torch.is_grad_enabled()) else None
     opts = dict(nx=len(xs), nw=len(weights), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p),
-                pad=int(pad), dilation=int(dilation), T=int(T), out_bf16=bool(out_bf16))
-    return _FusedLinearB.apply(opts, bias, bias2, res, rowmask, *xs, *weights, *wbs)
+                pad=int(pad), dilation=int(dilation), T=int(T), out_bf16=bool(out_bf16), token=token)
+    return _attach_token(_FusedLinearB.apply(opts, bias, bias2, res, rowmask, *xs, *weights, *wbs), token)
 
 
 # ================================================================================================
@@ -275,7 +308,7 @@ class _LayerNorm128(torch.autograd.Function):
     backward kernel -- autograd would otherwise add them with a separate elementwise kernel per sub-layer."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res):
+    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res, zero_rows):
         x = _c(x)
         M = x.numel() // 128
         y = torch.empty(x.shape, device=x.device, dtype=BF16 if out_bf16 else torch.float32)
@@ -283,7 +316,7 @@ class _LayerNorm128(torch.autograd.Function):
         rstd = torch.empty(M, device=x.device, dtype=torch.float32)
         check(lib().kantts_ln128_fwd(ptr(x, torch.float32), ptr(gamma, torch.float32), ptr(beta, torch.float32), ptr(y),
                                      int(out_bf16), ptr(mean), ptr(rstd), M, float(eps), stream()), "ln128_fwd")
-        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.save_for_backward(x, gamma, mean, rstd, zero_rows)
         if with_res:
             return y, x.view_as(x)
         return y, None
@@ -292,21 +325,31 @@ class _LayerNorm128(torch.autograd.Function):
     def backward(ctx, dy, dres):
         from .ops import gzeros_like
 
-        x, gamma, mean, rstd = ctx.saved_tensors
+        x, gamma, mean, rstd, zero_rows = ctx.saved_tensors
         M = x.numel() // 128
         dx = torch.empty_like(x)
         dg, db = gzeros_like(gamma), gzeros_like(gamma)
         if dy is None:  # only the pass-through was used downstream
-            return (dres, None, None, None, None, None)
+            if zero_rows is not None:
+                dres = dres.masked_fill(zero_rows.bool().view(*dres.shape[:-1], 1), 0.0)
+            return (dres, None, None, None, None, None, None)
         dy = _c(dy)
         dres = _c(dres) if dres is not None else None
-        check(lib().kantts_ln128_bwd(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean), ptr(rstd),
-                                     ptr(dres, torch.float32), ptr(dx), ptr(dg), ptr(db), M, stream()), "ln128_bwd")
-        return dx, dg, db, None, None, None
+        check(lib().kantts_ln128_bwd_rows(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean), ptr(rstd),
+                                          ptr(dres, torch.float32), ptr(dx), ptr(dg), ptr(db), ptr(zero_rows, torch.uint8),
+                                          M, stream()), "ln128_bwd")
+        return dx, dg, db, None, None, None, None
 
 
-def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False):
-    y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res))
+def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False, private_input=False):
+    """``private_input``: the caller guarantees that this LayerNorm (with its pass-through output, if ``with_res``) is the
+    only consumer of ``x``; a row mask the producer of ``x`` left on it (RowMaskToken) is then applied to dx here."""
+    zero_rows = take_rowmask(x) if (private_input and torch.is_grad_enabled()) else None
+    if zero_rows is not None:
+        zero_rows = _c(zero_rows).view(-1)
+        if zero_rows.dtype == torch.bool:
+            zero_rows = zero_rows.view(torch.uint8)
+    y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows)
     return (y, xr) if with_res else y
 
 
@@ -361,7 +404,8 @@ class _FusedFFNB(torch.autograd.Function):
         T, pad, p_in, p_out = cfg["T"], cfg["pad"], cfg["p_inner"], cfg["p_out"]
         s1, s2 = ctx.seeds
         dy = _c(dy).view(M, N)
-        if zr is not None:
+        token = cfg.get("token")
+        if zr is not None and not (token is not None and token.delegated):
             dy = dy.masked_fill(zr.bool().view(M, 1), 0.0)
         d_res = dy.view(*ctx.lead, N)
         dev = dy.device
@@ -469,10 +513,12 @@ def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p
     # csrc/ffn_pair.hip: 128 channels either side, 1024 hidden units, odd kernel width
     pair = PAIR["on"] and C == 128 and w2.shape[0] == 128 and F == 1024 and kt % 2 == 1 and kt <= 9
     cfg = dict(T=int(T or h.shape[-2]), pad=(kt - 1) // 2, p_inner=float(p_inner), p_out=float(p_out), pair=pair)
+    token = RowMaskToken(zero_rows) if (zero_rows is not None and torch.is_grad_enabled()) else None
+    cfg["token"] = token
     wf1 = wf2 = wt2 = wt1 = None
     if pair:
         wf1, wf2, wt2, wt1 = ffn_frag_weights(w1, w2)
         if kt not in (1, 3):
             wt2 = wt1 = None  # backward stays on the two-launch form
-    return _FusedFFNB.apply(h, w1, b1, w2, b2, res, pad_rows, zero_rows, conv_weight_bf16(w1), conv_weight_bf16(w2), wf1,
-                            wf2, wt2, wt1, cfg)
+    return _attach_token(_FusedFFNB.apply(h, w1, b1, w2, b2, res, pad_rows, zero_rows, conv_weight_bf16(w1),
+                                          conv_weight_bf16(w2), wf1, wf2, wt2, wt1, cfg), token)

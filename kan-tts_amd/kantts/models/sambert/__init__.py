@@ -79,13 +79,14 @@ class MultiHeadSelfAttention(nn.Module):
         self.fc = nn.Linear(n_head * d_head, d_model)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, input, mask=None, zero_rows=None, return_attn=False):
-        """mask: key padding (SeqInfo or bool (B, L) / (B, L, L) as the reference builds it)."""
+    def forward(self, input, mask=None, zero_rows=None, return_attn=False, private_input=False):
+        """mask: key padding (SeqInfo or bool (B, L) / (B, L, L) as the reference builds it).
+        ``private_input``: nothing but this sub-layer consumes ``input`` (see ops.layer_norm)."""
         if torch.is_tensor(mask) and mask.dim() == 3:
             mask = mask[:, 0, :]
         info = SeqInfo.of(mask)
         x, input = ops.layer_norm(input, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
-                                  with_res=True)
+                                  with_res=True, private_input=private_input)
         qkv = ops.linear(x, self.w_qkv.weight, self.w_qkv.bias)
         ctxv, attn = ops.self_attention(qkv, None if info is None else info.lens32, self.n_head,
                                         drop_p=_p(self.attention.dropatt, self.training), want_probs=return_attn)
@@ -110,11 +111,11 @@ class PositionwiseConvFeedForward(nn.Module):
         self.w_1.weight._kantts_ffn_role = "w1"
         self.w_2.weight._kantts_ffn_role = "w2"
 
-    def forward(self, x, mask=None, zero_rows=None):
+    def forward(self, x, mask=None, zero_rows=None, private_input=False):
         info = SeqInfo.of(mask)
         pad_rows = None if info is None else info.mask
         h, x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
-                              with_res=True)
+                              with_res=True, private_input=private_input)
         return ops.ffn(h, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, x, pad_rows=pad_rows,
                        zero_rows=zero_rows, p_inner=_p(self.dropout_inner, self.training),
                        p_out=_p(self.dropout, self.training))
@@ -130,12 +131,16 @@ class FFTBlock(nn.Module):
         self.pos_ffn = PositionwiseConvFeedForward(d_model, d_inner, kernel_size, dropout_inner=dropout_relu,
                                                    dropout=dropout)
 
-    def forward(self, input, mask=None, slf_attn_mask=None, return_attn=False):
+    def forward(self, input, mask=None, slf_attn_mask=None, return_attn=False, private_input=False):
+        """``private_input``: the caller hands ``input`` to this block only (a stack does, from its second block on): the
+        producer's masking of the incoming gradient then happens inside this block's first LayerNorm backward."""
         info = SeqInfo.of(mask)
         rows = None if info is None else info.mask
         key_info = info if info is not None else slf_attn_mask
-        output, slf_attn = self.slf_attn(input, mask=key_info, zero_rows=rows, return_attn=return_attn)
-        output = self.pos_ffn(output, mask=info, zero_rows=rows)
+        output, slf_attn = self.slf_attn(input, mask=key_info, zero_rows=rows, return_attn=return_attn,
+                                         private_input=private_input)
+        # the attention sub-layer's output goes nowhere but into the feed-forward sub-layer
+        output = self.pos_ffn(output, mask=info, zero_rows=rows, private_input=True)
         return output, slf_attn
 
 
@@ -168,11 +173,11 @@ class MultiHeadPNCAAttention(nn.Module):
         self.x_state_size = 0
 
     def forward(self, x, h, info=None, x_band_width=0, h_band_width=0, zero_rows=None, return_attn=False,
-                bw_dev=None, hkv=None):
+                bw_dev=None, hkv=None, private_input=False):
         """``hkv``: this block's memory K/V projection when the decoder computed all of them together
         (ops.shared_input_linears: one input-gradient launch for the twelve blocks)."""
         xn, x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
-                               with_res=True)
+                               with_res=True, private_input=private_input)
         qkv = ops.linear(xn, self.w_x_qkv.weight, self.w_x_qkv.bias)
         if hkv is None:
             hkv = ops.linear(h, self.w_h_kv.weight, self.w_h_kv.bias)
@@ -223,12 +228,12 @@ class PNCABlock(nn.Module):
                                                    dropout=dropout)
 
     def forward(self, input, memory, mask=None, x_band_width=0, h_band_width=0, return_attn=False, bw_dev=None,
-                hkv=None):
+                hkv=None, private_input=False):
         info = SeqInfo.of(mask)
         rows = None if info is None else info.mask
         output, ax, ah = self.pnca_attn(input, memory, info, x_band_width, h_band_width, zero_rows=rows,
-                                        return_attn=return_attn, bw_dev=bw_dev, hkv=hkv)
-        output = self.pos_ffn(output, mask=info, zero_rows=rows)
+                                        return_attn=return_attn, bw_dev=bw_dev, hkv=hkv, private_input=private_input)
+        output = self.pos_ffn(output, mask=info, zero_rows=rows, private_input=True)
         return output, ax, ah
 
     @torch.no_grad()

@@ -65,10 +65,11 @@ class SelfAttentionEncoder(nn.Module):
         for i, layer in enumerate(self.fft):
             if every and i and i % every == 0:
                 x = ops.wgrad_flush_point(x)  # backward: weight gradients of the later blocks start beside the earlier ones
-            x, a = layer(x, mask=info, return_attn=return_attns)
+            # from the second block on, x is the previous block's output and has no other reader
+            x, a = layer(x, mask=info, return_attn=return_attns, private_input=i > 0)
             if return_attns:
                 attns.append(a)
-        x = ops.layer_norm(x, self.ln.weight, self.ln.bias, self.ln.eps)
+        x = ops.layer_norm(x, self.ln.weight, self.ln.bias, self.ln.eps, private_input=len(self.fft) > 0)
         return x, attns
 
 
@@ -112,11 +113,11 @@ class HybridAttentionDecoder(nn.Module):
             if every and i and i % every == 0:
                 x = ops.wgrad_flush_point(x)
             x, ax, ah = layer(x, memory, mask=info, x_band_width=x_band_width, h_band_width=h_band_width,
-                              return_attn=return_attns, bw_dev=bw_dev, hkv=hkvs[i])
+                              return_attn=return_attns, bw_dev=bw_dev, hkv=hkvs[i], private_input=i > 0)
             if return_attns:
                 ax_l.append(ax)
                 ah_l.append(ah)
-        x = ops.layer_norm(x, self.ln.weight, self.ln.bias, self.ln.eps)
+        x = ops.layer_norm(x, self.ln.weight, self.ln.bias, self.ln.eps, private_input=len(self.pnca) > 0)
         x = ops.linear(x, self.dec_out_proj.weight, self.dec_out_proj.bias)
         return x, ax_l, ah_l
 

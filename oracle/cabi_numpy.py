@@ -483,6 +483,9 @@ class EmulatedLib:
         return 0
 
     def kantts_ln128_bwd(self, dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, M, stream):
+        return self.kantts_ln128_bwd_rows(dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, None, M, stream)
+
+    def kantts_ln128_bwd_rows(self, dy, dy_bf16, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, zero_rows, M, stream):
         C = 128
         DY = torch.from_numpy(_rd(dy, M * C, bool(dy_bf16))).view(M, C)
         X = torch.from_numpy(_arr(x, M * C).copy()).view(M, C)
@@ -493,6 +496,8 @@ class EmulatedLib:
         DX = rs[:, None] * (gq - gq.mean(1, keepdim=True) - xh * (gq * xh).mean(1, keepdim=True))
         if dres:
             DX = DX + torch.from_numpy(_arr(dres, M * C).copy()).view(M, C)
+        if zero_rows:
+            DX = DX * torch.from_numpy((_arr(zero_rows, M, np.uint8) == 0).astype(np.float32))[:, None]
         _arr(dx, M * C)[:] = DX.reshape(-1).numpy()
         _arr(dgamma, C)[:] += (DY * xh).sum(0).numpy()
         _arr(dbeta, C)[:] += DY.sum(0).numpy()

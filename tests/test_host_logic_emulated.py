@@ -134,6 +134,43 @@ def test_dropout2_add_and_fsmn_encoder_training_path(emulated_cabi):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_row_mask_handed_to_the_consuming_layernorm_changes_no_gradient(emulated_cabi, monkeypatch, precision):
+    """ops_bf16.RowMaskToken: inside a block stack the masking of a sub-layer's incoming gradient is done by the store of
+    the next LayerNorm's backward kernel (kantts_ln128_bwd_rows) instead of a masked_fill pass per sub-layer.  Same
+    gradients bit for bit with the hand-over switched off, and the elementwise passes are really gone."""
+    import kantts._hip as hip
+    from kantts._hip import ops_bf16
+    from kantts.models.sambert.kantts_sambert import SelfAttentionEncoder
+
+    hip.set_precision(precision)
+    try:
+        def run(handover):
+            if not handover:
+                monkeypatch.setattr(ops_bf16, "take_rowmask", lambda x: None)
+            torch.manual_seed(5)
+            enc = SelfAttentionEncoder(3, 128, 128, 8, 16, 1024, 0.0, 0.0, 0.0, position_encoder=None)
+            enc.train()
+            x = torch.randn(3, 21, 128, requires_grad=True)
+            mask = torch.arange(21)[None, :] >= torch.tensor([21, 9, 15])[:, None]
+            calls = []
+            orig = torch.Tensor.masked_fill
+            monkeypatch.setattr(torch.Tensor, "masked_fill", lambda self, *a, **k: (calls.append(tuple(self.shape)), orig(self, *a, **k))[1])
+            y, _ = enc(x, mask, prescaled=True)
+            (y * torch.randn_like(y)).sum().backward()
+            monkeypatch.setattr(torch.Tensor, "masked_fill", orig)
+            return [x.grad] + [p.grad for p in enc.parameters()], [c for c in calls if c == (63, 128)]
+
+        g_on, fills_on = run(True)
+        g_off, fills_off = run(False)
+        assert len(fills_off) == 6 and len(fills_on) == 0  # 3 blocks x 2 sub-layers
+        for a, b in zip(g_on, g_off):
+            assert torch.equal(a, b)
+        assert torch.all(g_on[0][1, 9:] == 0) and torch.all(g_on[0][2, 15:] == 0)
+    finally:
+        hip.set_precision("fp32")
+
+
 def test_arena_adam_matches_torch_adam(emulated_cabi):
     from kantts.train.optim import ArenaAdam, ParamArena
 
