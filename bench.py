@@ -772,6 +772,7 @@ def main():
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-device runs the N-rank path on a one-GPU box")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the roofline microbench (timing experiments only)")
     ap.add_argument("--oracle-probe", type=int, default=0, help=argparse.SUPPRESS)  # child process of cpu_baseline
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (a functional check of the distributed path, not a scaling figure)")
@@ -922,13 +923,17 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around every GEMM launch of one extra step
     roof = None
-    if rank == 0:
+    rank_roof = rank == 0 and not args.no_roofline
+    if rank_roof:
         hip.profile_begin()
     net.device_band_width = False
     hip.ops.wgrad_overlap.enable(False, group_wgrads=not args.no_wgrad_group)
-    eager_step()  # instrumented launches are issued eagerly on every rank (the step holds a collective)
+    if not args.no_roofline:
+        eager_step()  # instrumented launches are issued eagerly on every rank (the step holds a collective)
     torch.cuda.synchronize()
-    if rank == 0:
+    if rank == 0 and args.no_roofline and fwd_ms is not None:
+        roof = {"forward_ms": fwd_ms}
+    if rank_roof:
         prof = hip.profile_end()
         _note("forward-only pass and eager instrumented step done")
         dg = dominant_gemm_roofline(hip, args.precision)

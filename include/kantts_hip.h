@@ -156,6 +156,21 @@ int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int
                     const int32_t* bw_dev, int bw, int B, int H, int L, int d_head, int mode, float drop_p,
                     uint64_t seed, const uint64_t* seed_dev, void* stream);
 
+/* Both attentions of a PNCA block (MultiHeadPNCAAttention.forward, kantts/models/sambert/__init__.py:256-306: the causal
+ * band over x and the look-ahead band over the memory share the queries) as ONE launch forward and ONE backward.
+ * qkv (B,L,3D) = fused x projection [q | k_x | v_x], hkv (B,L,2D) = memory projection [k_h | v_h], D = H*16;
+ * ox / oh (B,L,D) contexts, lse_x / lse_h (B,H,L) saved.  Backward: dqkv (B,L,3D) = [dq of the x band | dk_x | dv_x],
+ * dqh (B,L,D) = dq of the memory band (the caller sums the two), dhkv (B,L,2D) = [dk_h | dv_h]; every output is written,
+ * none accumulated.  Same masks, dropout streams (seed_x / seed_h) and padded-row rules as kantts_attn_fwd / _bwd with
+ * mode 1 / mode 2.  KANTTS_E_UNSUPPORTED if a head's rows do not fit in LDS (L > ~440): use the per-band calls. */
+int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, float* ox, float* oh, float* lse_x, float* lse_h,
+                         const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B, int H, int L, int d_head,
+                         float drop_p, uint64_t seed_x, uint64_t seed_h, const uint64_t* seed_dev, void* stream);
+int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, const float* ox, const float* oh, const float* d_ox,
+                         const float* d_oh, const float* lse_x, const float* lse_h, float* dqkv, float* dqh, float* dhkv,
+                         const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B, int H, int L, int d_head,
+                         float drop_p, uint64_t seed_x, uint64_t seed_h, const uint64_t* seed_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LSTM recurrence, H = 128 (time loop of torch.nn.LSTM: kantts/models/sambert/adaptors.py:44-57,
  * :109-134; kantts_sambert.py:637-646).  gx (B,T,ndir*4H) = x W_ih^T + b_ih (from the GEMM);
@@ -448,6 +463,16 @@ typedef struct kantts_bgemm_args {
   uint64_t a_drop_seed;
   int64_t a_drop_ld;
   const uint8_t* rowmask;
+  /* optional: LayerNorm(128) of the output rows in the epilogue (N == 128, fp32 c): the pre-LN sub-layer that consumes c
+   * (kantts/models/sambert/__init__.py:130-131, 198) then needs no launch of its own.  ln_out (M,128) bf16 / fp32,
+   * ln_mean / ln_rstd (M) as kantts_ln128_fwd writes them (its backward is unchanged). */
+  const float* ln_gamma;
+  const float* ln_beta;
+  void* ln_out;
+  int32_t ln_out_bf16;
+  float ln_eps;
+  float* ln_mean;
+  float* ln_rstd;
 } kantts_bgemm_args;
 int kantts_bgemm_nt(const kantts_bgemm_args* args, void* stream);
 
@@ -542,6 +567,15 @@ typedef struct kantts_ffn_args {
   int64_t ldy;
   int32_t y_bf16;
   int32_t KT2, s2_first, s2_step; /* taps of phase 2 (0 / 1: none): y[m] = sum_t t[m + s2_first + t*s2_step] . w2[t]^T */
+  /* optional (forward form, KT2 <= 1): LayerNorm(128) of the output rows in the epilogue, as kantts_bgemm_args ln_* --
+   * the block's output feeds the next block's pre-LN attention sub-layer (kantts/models/sambert/__init__.py:63, 198) */
+  const float* ln_gamma;
+  const float* ln_beta;
+  void* ln_out;
+  int32_t ln_out_bf16;
+  float ln_eps;
+  float* ln_mean;
+  float* ln_rstd;
 } kantts_ffn_args;
 int kantts_ffn_pair(const kantts_ffn_args* args, void* stream);
 

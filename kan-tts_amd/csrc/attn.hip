@@ -266,11 +266,16 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld
   }
 }
 
-__global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+// Bodies of the LDS-staged kernels for head h of sequence b.  The first query / key row a thread owns is requested BEFORE
+// the staging loads and the barrier, so the two global round trips overlap instead of following each other.
+__device__ __forceinline__ void attn_fwd_lds_body(const AttnArgs& a, const int h, const int b, float* sm) {
   float* Ks = sm;
   float* Vs = sm + a.L * AT_LD;
-  const int h = blockIdx.x, b = blockIdx.y;
+  float q0[DH];
+  {
+    const int i0 = min((int)threadIdx.x, a.L - 1);
+    load16(a.q + ((long long)b * a.L + i0) * a.ldq + h * DH, q0);
+  }
   stage_rows(a.k + (long long)b * a.L * a.ldk + h * DH, a.ldk, a.L, Ks);
   stage_rows(a.v + (long long)b * a.L * a.ldv + h * DH, a.ldv, a.L, Vs);
   __syncthreads();
@@ -283,7 +288,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs
     if (a.mode != 0 && i >= len && !a.probs) hi = lo - 1;  // padded query: skipped (see header)
     const long long row = (long long)b * a.L + i;
     float q[DH], o[DH];
-    load16(a.q + row * a.ldq + h * DH, q);
+    if (i == (int)threadIdx.x) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) q[d] = q0[d];
+    } else {
+      load16(a.q + row * a.ldq + h * DH, q);
+    }
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] = 0.f;
     float m = -INFINITY;
@@ -316,11 +326,21 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs
   }
 }
 
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_lds_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  attn_fwd_lds_body(a, blockIdx.x, blockIdx.y, sm);
+}
+
+__device__ __forceinline__ void attn_bwd_dq_lds_body(const AttnArgs& a, const int h, const int b, float* sm) {
   float* Ks = sm;
   float* Vs = sm + a.L * AT_LD;
-  const int h = blockIdx.x, b = blockIdx.y;
+  float q0[DH], go0[DH], oo0[DH];
+  {
+    const long long r0 = (long long)b * a.L + min((int)threadIdx.x, a.L - 1);
+    load16(a.q + r0 * a.ldq + h * DH, q0);
+    load16(a.d_o + r0 * a.lddo + h * DH, go0);
+    load16(a.o + r0 * a.ldo + h * DH, oo0);
+  }
   stage_rows(a.k + (long long)b * a.L * a.ldk + h * DH, a.ldk, a.L, Ks);
   stage_rows(a.v + (long long)b * a.L * a.ldv + h * DH, a.ldv, a.L, Vs);
   __syncthreads();
@@ -333,13 +353,22 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_lds_kernel(const AttnA
     if (a.mode != 0 && i >= len) hi = lo - 1;  // padded query rows carry no gradient
     const long long row = (long long)b * a.L + i;
     float q[DH], go[DH], oo[DH], dq[DH];
-    load16(a.q + row * a.ldq + h * DH, q);
-    load16(a.d_o + row * a.lddo + h * DH, go);
-    load16(a.o + row * a.ldo + h * DH, oo);
+    if (i == (int)threadIdx.x) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        q[d] = q0[d];
+        go[d] = go0[d];
+        oo[d] = oo0[d];
+      }
+    } else {
+      load16(a.q + row * a.ldq + h * DH, q);
+      load16(a.d_o + row * a.lddo + h * DH, go);
+      load16(a.o + row * a.ldo + h * DH, oo);
+    }
     const float D = dot16(go, oo);
     const long long sidx = ((long long)b * a.H + h) * a.L + i;
     const float lse = a.lse[sidx];
-    a.dvec[sidx] = D;
+    if (a.dvec) a.dvec[sidx] = D;
 #pragma unroll
     for (int d = 0; d < DH; ++d) dq[d] = 0.f;
     const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
@@ -363,20 +392,39 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_lds_kernel(const AttnA
   }
 }
 
-// must run after attn_bwd_dq_* (needs dvec)
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_lds_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_lds_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  attn_bwd_dq_lds_body(a, blockIdx.x, blockIdx.y, sm);
+}
+
+// D_i = dO_i . O_i: read from dvec (written by the dq pass, which then has to run first) or, with RECOMPUTE_D, formed
+// here from the O rows -- the two passes of a backward then are independent and run as roles of ONE launch
+template <bool RECOMPUTE_D>
+__device__ __forceinline__ void attn_bwd_dkv_lds_body(const AttnArgs& a, const int h, const int b, float* sm) {
   float* Qs = sm;
   float* Gs = sm + a.L * AT_LD;
   float* Ls = Gs + a.L * AT_LD;  // lse
   float* Ds = Ls + a.L;          // dvec
-  const int h = blockIdx.x, b = blockIdx.y;
+  float kk0[DH], vv0[DH];
+  {
+    const long long r0 = (long long)b * a.L + min((int)threadIdx.x, a.L - 1);
+    load16(a.k + r0 * a.ldk + h * DH, kk0);
+    load16(a.v + r0 * a.ldv + h * DH, vv0);
+  }
   stage_rows(a.q + (long long)b * a.L * a.ldq + h * DH, a.ldq, a.L, Qs);
   stage_rows(a.d_o + (long long)b * a.L * a.lddo + h * DH, a.lddo, a.L, Gs);
   const long long sbase = ((long long)b * a.H + h) * a.L;
   for (int i = threadIdx.x; i < a.L; i += AT_THREADS) {
     Ls[i] = a.lse[sbase + i];
-    Ds[i] = a.dvec[sbase + i];
+    if (RECOMPUTE_D) {
+      const long long row = (long long)b * a.L + i;
+      float go[DH], oo[DH];
+      load16(a.d_o + row * a.lddo + h * DH, go);
+      load16(a.o + row * a.ldo + h * DH, oo);
+      Ds[i] = dot16(go, oo);
+    } else {
+      Ds[i] = a.dvec[sbase + i];
+    }
   }
   __syncthreads();
   const int len = a.lens ? a.lens[b] : a.L;
@@ -385,8 +433,16 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_lds_kernel(const Attn
   for (int j = threadIdx.x; j < a.L; j += AT_THREADS) {
     const long long krow = (long long)b * a.L + j;
     float kk[DH], vv[DH], dk[DH], dv[DH];
-    load16(a.k + krow * a.ldk + h * DH, kk);
-    load16(a.v + krow * a.ldv + h * DH, vv);
+    if (j == (int)threadIdx.x) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        kk[d] = kk0[d];
+        vv[d] = vv0[d];
+      }
+    } else {
+      load16(a.k + krow * a.ldk + h * DH, kk);
+      load16(a.v + krow * a.ldv + h * DH, vv);
+    }
 #pragma unroll
     for (int d = 0; d < DH; ++d) {
       dk[d] = 0.f;
@@ -426,6 +482,47 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_lds_kernel(const Attn
     store16(a.dk + krow * a.lddk + h * DH, dk);
     store16(a.dv + krow * a.lddv + h * DH, dv);
   }
+}
+
+// must run after attn_bwd_dq_* (needs dvec)
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_lds_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  attn_bwd_dkv_lds_body<false>(a, blockIdx.x, blockIdx.y, sm);
+}
+
+// Up to four attention passes over the same (B, H) grid as ONE launch: blockIdx.z picks the pass.  A PNCA block's
+// forward is two passes (causal band over x, look-ahead band over the memory), its backward four (dq and dk/dv of each
+// band); an encoder block's backward two.  The passes of a group are independent (dk/dv recomputes D), so nothing orders
+// them -- and a decoder block issues 2 attention launches per step instead of 6 on two streams.
+#define AT_ROLE_FWD 0
+#define AT_ROLE_DQ 1
+#define AT_ROLE_DKV 2
+struct AttnMulti {
+  AttnArgs p[4];
+  int role[4];
+};
+__global__ __launch_bounds__(AT_THREADS) void attn_multi_lds_kernel(const AttnMulti m) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int z = blockIdx.z;
+  // fixed kernarg offsets selected by scalar branches (indexing the by-value struct with z would put it in scratch)
+  AttnArgs a = m.p[0];
+  int role = m.role[0];
+  if (z == 1) {
+    a = m.p[1];
+    role = m.role[1];
+  } else if (z == 2) {
+    a = m.p[2];
+    role = m.role[2];
+  } else if (z == 3) {
+    a = m.p[3];
+    role = m.role[3];
+  }
+  if (role == AT_ROLE_FWD)
+    attn_fwd_lds_body(a, blockIdx.x, blockIdx.y, sm);
+  else if (role == AT_ROLE_DQ)
+    attn_bwd_dq_lds_body(a, blockIdx.x, blockIdx.y, sm);
+  else
+    attn_bwd_dkv_lds_body<true>(a, blockIdx.x, blockIdx.y, sm);
 }
 
 static inline size_t attn_lds_bytes(int L, bool dkv) {
@@ -476,15 +573,81 @@ extern "C" int kantts_attn_bwd(const float* q, const float* k, const float* v, i
   if (!d_o || !dq || !dk || !dv || !dvec || ((lddo | lddq | lddk | lddv) & 3)) return KANTTS_E_BADARG;
   if (B == 0 || L == 0) return KANTTS_OK;
   if (attn_lds_bytes(L, true) <= 64 * 1024) {
-    hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, false),
-                       (hipStream_t)stream, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, true),
-                       (hipStream_t)stream, a);
+    AttnMulti m = {};
+    m.p[0] = a; m.role[0] = AT_ROLE_DQ;
+    m.p[1] = a; m.role[1] = AT_ROLE_DKV;
+    hipLaunchKernelGGL(attn_multi_lds_kernel, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, true),
+                       (hipStream_t)stream, m);
   } else {
     dim3 grid(kantts_cdiv(L, 128), H, B), block(128);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, (hipStream_t)stream, a);
   }
+  KANTTS_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PNCA attention of one decoder block (MultiHeadPNCAAttention, kantts/models/sambert/__init__.py:256-306 of the
+// reference): the causal band over x (K/V = columns [D, 3D) of the fused QKV projection) and the look-ahead band over the
+// memory (K/V = the (B, L, 2D) memory projection) share the queries (columns [0, D) of qkv).  One launch forward, one
+// backward.  Returns KANTTS_E_UNSUPPORTED when a head does not fit the LDS-staged kernels (the caller then issues
+// kantts_attn_fwd / kantts_attn_bwd per band).
+static void pnca_fill(AttnArgs& a, const float* qkv, const float* kv, int ldkv, int koff, float* o, float* lse,
+                      const int32_t* lens, const int32_t* bw_dev, int bw, int B, int H, int L, int mode, float drop_p,
+                      uint64_t seed, const uint64_t* seed_dev) {
+  const int D = H * DH;
+  a = AttnArgs{};
+  a.q = qkv; a.ldq = 3 * D;
+  a.k = kv + koff; a.v = kv + koff + D; a.ldk = a.ldv = ldkv;
+  a.o = o; a.ldo = D; a.lse = lse; a.lens = lens; a.bw_dev = bw_dev; a.bw = bw; a.B = B; a.H = H; a.L = L; a.mode = mode;
+  a.scale = 0.25f; a.drop_p = drop_p; a.seed = seed; a.seed_dev = seed_dev;
+}
+
+extern "C" int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, float* ox, float* oh, float* lse_x, float* lse_h,
+                                    const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B, int H, int L,
+                                    int d_head, float drop_p, uint64_t seed_x, uint64_t seed_h, const uint64_t* seed_dev,
+                                    void* stream) {
+  if (d_head != DH) return KANTTS_E_UNSUPPORTED;
+  if (!qkv || !hkv || !ox || !oh || !lse_x || !lse_h || B < 0 || H < 1 || L < 0) return KANTTS_E_BADARG;
+  if (B == 0 || L == 0) return KANTTS_OK;
+  if (attn_lds_bytes(L, false) > 64 * 1024) return KANTTS_E_UNSUPPORTED;
+  const int D = H * DH;
+  AttnMulti m = {};
+  pnca_fill(m.p[0], qkv, qkv, 3 * D, D, ox, lse_x, lens, bw_dev, bw_x, B, H, L, 1, drop_p, seed_x, seed_dev);
+  pnca_fill(m.p[1], qkv, hkv, 2 * D, 0, oh, lse_h, lens, bw_dev, bw_h, B, H, L, 2, drop_p, seed_h, seed_dev);
+  m.role[0] = m.role[1] = AT_ROLE_FWD;
+  hipLaunchKernelGGL(attn_multi_lds_kernel, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, false), (hipStream_t)stream,
+                     m);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// dqkv (B, L, 3D): columns [0, D) receive the x band's query gradient, [D, 3D) its key / value gradients; dqh (B, L, D)
+// the memory band's query gradient (the caller adds it onto dqkv[..., :D]); dhkv (B, L, 2D) the memory K/V gradients.
+extern "C" int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, const float* ox, const float* oh, const float* d_ox,
+                                    const float* d_oh, const float* lse_x, const float* lse_h, float* dqkv, float* dqh,
+                                    float* dhkv, const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B,
+                                    int H, int L, int d_head, float drop_p, uint64_t seed_x, uint64_t seed_h,
+                                    const uint64_t* seed_dev, void* stream) {
+  if (d_head != DH) return KANTTS_E_UNSUPPORTED;
+  if (!qkv || !hkv || !ox || !oh || !d_ox || !d_oh || !lse_x || !lse_h || !dqkv || !dqh || !dhkv || B < 0 || H < 1 || L < 0)
+    return KANTTS_E_BADARG;
+  if (B == 0 || L == 0) return KANTTS_OK;
+  if (attn_lds_bytes(L, true) > 64 * 1024) return KANTTS_E_UNSUPPORTED;
+  const int D = H * DH;
+  AttnMulti m = {};
+  AttnArgs x, hh;
+  pnca_fill(x, qkv, qkv, 3 * D, D, const_cast<float*>(ox), const_cast<float*>(lse_x), lens, bw_dev, bw_x, B, H, L, 1, drop_p,
+            seed_x, seed_dev);
+  x.d_o = d_ox; x.lddo = D; x.dq = dqkv; x.dk = dqkv + D; x.dv = dqkv + 2 * D; x.lddq = x.lddk = x.lddv = 3 * D;
+  pnca_fill(hh, qkv, hkv, 2 * D, 0, const_cast<float*>(oh), const_cast<float*>(lse_h), lens, bw_dev, bw_h, B, H, L, 2, drop_p,
+            seed_h, seed_dev);
+  hh.d_o = d_oh; hh.lddo = D; hh.dq = dqh; hh.lddq = D; hh.dk = dhkv; hh.dv = dhkv + D; hh.lddk = hh.lddv = 2 * D;
+  m.p[0] = x; m.role[0] = AT_ROLE_DQ;
+  m.p[1] = x; m.role[1] = AT_ROLE_DKV;
+  m.p[2] = hh; m.role[2] = AT_ROLE_DQ;
+  m.p[3] = hh; m.role[3] = AT_ROLE_DKV;
+  hipLaunchKernelGGL(attn_multi_lds_kernel, dim3(H, B, 4), dim3(AT_THREADS), attn_lds_bytes(L, true), (hipStream_t)stream,
+                     m);
   KANTTS_CHECK_LAUNCH();
 }
 

@@ -272,6 +272,9 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
   const float* dummy = reinterpret_cast<const float*>(g.w2);
   float4 bs2 = *reinterpret_cast<const float4*>(g.bias2 ? g.bias2 + n0 : dummy), rv[2];
   if (!g.bias2) bs2 = zero4;
+  const bool ln_epi = !BWD && KT2 == 1 && g.ln_out != nullptr;
+  const float4 lg4 = *reinterpret_cast<const float4*>(ln_epi ? g.ln_gamma + n0 : dummy);
+  const float4 lb4 = *reinterpret_cast<const float4*>(ln_epi ? g.ln_beta + n0 : dummy);
   bool rz2[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
@@ -340,27 +343,85 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
 
   // ---- output: four consecutive channels of one token per accumulator -> 16-byte (fp32) / 8-byte (bf16) stores
   const uint64_t sd2 = g.drop2_seed + seed_off;
-  {
+  float ov[2][4];
+  bool live[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const long long m = (long long)mo0 + b * 16 + li;
+    live[b] = m < M && b * 16 + li < OUT;
+    float* o = ov[b];
+    o[0] = acc2[0][b][0] + bs2.x; o[1] = acc2[0][b][1] + bs2.y; o[2] = acc2[0][b][2] + bs2.z; o[3] = acc2[0][b][3] + bs2.w;
+    if (g.drop2_p > 0.f) {
+      const uint64_t base = (uint64_t)m * (uint64_t)FP_N + (uint64_t)n0;
+      kantts_dropout_scale4(g.drop2_p, sd2, base, o);
+    }
+    o[0] += rv[b].x; o[1] += rv[b].y; o[2] += rv[b].z; o[3] += rv[b].w;
+    if (rz2[b]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = 0.f;
+    }
+    if (!live[b]) continue;
+    if (g.y_bf16) {
+      const u32x2 pk = {fp_pack2(o[0], o[1]), fp_pack2(o[2], o[3])};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.y) + m * g.ldy + n0) = pk;
+    } else {
+      const f32x4 v = {o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.y) + m * g.ldy + n0) = v;
+    }
+  }
+  if (ln_epi) {
+    // LayerNorm(128) of the rows just formed (the pre-LN sub-layer that consumes y): a token's 128 channels sit in 4 lanes
+    // (kg) of each of the 8 waves -> two-pass statistics through 2 x 256 floats of LDS (the X tile is dead)
+    float* St = reinterpret_cast<float*>(Xs);
+    float mu[2], rs[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float ps[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = pass ? ov[b][r] - mu[b] : ov[b][r];
+          t += pass ? d * d : d;
+        }
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        ps[b] = t;
+      }
+      if (kg == 0) {
+        St[pass * 256 + (wave * 2 + 0) * 16 + li] = ps[0];
+        St[pass * 256 + (wave * 2 + 1) * 16 + li] = ps[1];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += St[pass * 256 + (w * 2 + b) * 16 + li];
+        if (pass)
+          rs[b] = 1.0f / sqrtf(t * (1.f / 128.f) + g.ln_eps);
+        else
+          mu[b] = t * (1.f / 128.f);
+      }
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const long long m = (long long)mo0 + b * 16 + li;
-      if (m >= M || b * 16 + li >= OUT) continue;
-      float o[4] = {acc2[0][b][0] + bs2.x, acc2[0][b][1] + bs2.y, acc2[0][b][2] + bs2.z, acc2[0][b][3] + bs2.w};
-      if (g.drop2_p > 0.f) {
-        const uint64_t base = (uint64_t)m * (uint64_t)FP_N + (uint64_t)n0;
-        kantts_dropout_scale4(g.drop2_p, sd2, base, o);
-      }
-      o[0] += rv[b].x; o[1] += rv[b].y; o[2] += rv[b].z; o[3] += rv[b].w;
-      if (rz2[b]) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = 0.f;
-      }
-      if (g.y_bf16) {
-        const u32x2 pk = {fp_pack2(o[0], o[1]), fp_pack2(o[2], o[3])};
-        *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.y) + m * g.ldy + n0) = pk;
+      if (!live[b]) continue;
+      const float* o = ov[b];
+      const float y0 = (o[0] - mu[b]) * rs[b] * lg4.x + lb4.x, y1 = (o[1] - mu[b]) * rs[b] * lg4.y + lb4.y;
+      const float y2 = (o[2] - mu[b]) * rs[b] * lg4.z + lb4.z, y3 = (o[3] - mu[b]) * rs[b] * lg4.w + lb4.w;
+      if (g.ln_out_bf16) {
+        const u32x2 pk = {fp_pack2(y0, y1), fp_pack2(y2, y3)};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.ln_out) + m * FP_N + n0) = pk;
       } else {
-        const f32x4 v = {o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.y) + m * g.ldy + n0) = v;
+        const f32x4 v = {y0, y1, y2, y3};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.ln_out) + m * FP_N + n0) = v;
+      }
+      if (wave == 0 && kg == 0) {
+        g.ln_mean[m] = mu[b];
+        g.ln_rstd[m] = rs[b];
       }
     }
   }
@@ -384,6 +445,11 @@ extern "C" int kantts_ffn_pair(const kantts_ffn_args* gp, void* stream) {
   const int kt2 = g.KT2 < 1 ? 1 : g.KT2;
   if (kt2 != 1 && kt2 != 3) return KANTTS_E_UNSUPPORTED;
   if (kt2 == 3 && (!g.gate || g.T <= 0 || (g.s2_step != 1 && g.s2_step != -1) || g.M % g.T)) return KANTTS_E_UNSUPPORTED;
+  if (g.ln_out) {
+    if (!g.ln_gamma || !g.ln_beta || !g.ln_mean || !g.ln_rstd) return KANTTS_E_BADARG;
+    if (g.gate || kt2 != 1 || !fp_aligned16(g.ln_out) || !fp_aligned16(g.ln_gamma) || !fp_aligned16(g.ln_beta))
+      return KANTTS_E_UNSUPPORTED;
+  }
   if (g.M == 0) return KANTTS_OK;
   hipStream_t st = (hipStream_t)stream;
   if (kt2 == 3)

@@ -73,6 +73,14 @@ __device__ __forceinline__ u32x4 bg_load8(const void* base, long long elem, bool
   return r;
 }
 
+__device__ __forceinline__ float bg_sum16(float v) {  // over the 16 lanes that share (tid >> 4)
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
 __device__ __forceinline__ void bg_xcd_remap(int& bx, int& by) {
   // workgroups of one XCD get consecutive tiles in row-major order (same rule as gemm_fast.hip): the column tiles
   // that share an A row tile stay behind one L2
@@ -282,6 +290,13 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
     const float4 b0 = *reinterpret_cast<const float4*>(g.bias2 + j), b1 = *reinterpret_cast<const float4*>(g.bias2 + j + 4);
     bs[0] += b0.x; bs[1] += b0.y; bs[2] += b0.z; bs[3] += b0.w; bs[4] += b1.x; bs[5] += b1.y; bs[6] += b1.z; bs[7] += b1.w;
   }
+  float lg[8], lb[8];
+  if (g.ln_out) {  // N == 128: the 16 lanes that share a row hold all of it
+    const float4 g0 = *reinterpret_cast<const float4*>(g.ln_gamma + j), g1 = *reinterpret_cast<const float4*>(g.ln_gamma + j + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(g.ln_beta + j), b1 = *reinterpret_cast<const float4*>(g.ln_beta + j + 4);
+    lg[0] = g0.x; lg[1] = g0.y; lg[2] = g0.z; lg[3] = g0.w; lg[4] = g1.x; lg[5] = g1.y; lg[6] = g1.z; lg[7] = g1.w;
+    lb[0] = b0.x; lb[1] = b0.y; lb[2] = b0.z; lb[3] = b0.w; lb[4] = b1.x; lb[5] = b1.y; lb[6] = b1.z; lb[7] = b1.w;
+  }
 #pragma unroll
   for (int v = 0; v < BM / 16; ++v) {
     const int rl = (tid >> 4) + 16 * v;
@@ -333,6 +348,35 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm
       *reinterpret_cast<f32x4*>(cp) = w0;
       *reinterpret_cast<f32x4*>(cp + 4) = w1;
     }
+    if (g.ln_out) {  // same arithmetic, in the same order, as ln128_fwd_kernel (csrc/norm.hip)
+      float sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm += o[e];
+      const float mu = bg_sum16(sm) * (1.f / 128.f);
+      float qq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = o[e] - mu;
+        qq += d * d;
+      }
+      const float rs = 1.0f / sqrtf(bg_sum16(qq) * (1.f / 128.f) + g.ln_eps);
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (o[e] - mu) * rs * lg[e] + lb[e];
+      if (g.ln_out_bf16) {
+        u32x4 w = {bg_pack2(y[0], y[1]), bg_pack2(y[2], y[3]), bg_pack2(y[4], y[5]), bg_pack2(y[6], y[7])};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.ln_out) + (long long)i * 128 + j) = w;
+      } else {
+        float* yp = reinterpret_cast<float*>(g.ln_out) + (long long)i * 128 + j;
+        f32x4 w0 = {y[0], y[1], y[2], y[3]}, w1 = {y[4], y[5], y[6], y[7]};
+        *reinterpret_cast<f32x4*>(yp) = w0;
+        *reinterpret_cast<f32x4*>(yp + 4) = w1;
+      }
+      if ((tid & 15) == 0) {
+        g.ln_mean[i] = mu;
+        g.ln_rstd[i] = rs;
+      }
+    }
   }
 }
 
@@ -364,6 +408,11 @@ extern "C" int kantts_bgemm_nt(const kantts_bgemm_args* gp, void* stream) {
   if (g.res && ((g.ldr & 3) || !bg_aligned16(g.res))) return KANTTS_E_UNSUPPORTED;
   if (g.gate && ((g.ldg & 7) || !bg_aligned16(g.gate))) return KANTTS_E_UNSUPPORTED;
   if ((g.bias && !bg_aligned16(g.bias)) || (g.bias2 && !bg_aligned16(g.bias2))) return KANTTS_E_UNSUPPORTED;
+  if (g.ln_out) {
+    if (!g.ln_gamma || !g.ln_beta || !g.ln_mean || !g.ln_rstd) return KANTTS_E_BADARG;
+    if (g.N != 128 || g.c_bf16 || !bg_aligned16(g.ln_out) || !bg_aligned16(g.ln_gamma) || !bg_aligned16(g.ln_beta))
+      return KANTTS_E_UNSUPPORTED;
+  }
   for (int s = 0; s < g.nseg; ++s) {
     const kantts_bgemm_seg& sg = g.seg[s];
     if (!sg.a || !sg.b || sg.klen < 8 || (sg.klen & 7) || (sg.lda & 7) || (sg.ldb & 7)) return KANTTS_E_UNSUPPORTED;

@@ -134,6 +134,8 @@ class BGemmArgs(Structure):
         ("gate", c_void_p), ("ldg", c_int64), ("gate_bf16", c_int32), ("a_drop_p", c_float),
         ("a_drop_seed", c_uint64), ("a_drop_ld", c_int64),
         ("rowmask", c_void_p),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_out", c_void_p), ("ln_out_bf16", c_int32), ("ln_eps", c_float),
+        ("ln_mean", c_void_p), ("ln_rstd", c_void_p),
     ]
 
 
@@ -161,6 +163,8 @@ class FfnArgs(Structure):
         ("gate", c_void_p), ("rowmask1", c_void_p), ("rowmask2", c_void_p), ("xrowmask", c_void_p),
         ("t_out", c_void_p), ("res", c_void_p), ("ldr", c_int64), ("y", c_void_p), ("ldy", c_int64), ("y_bf16", c_int32),
         ("KT2", c_int32), ("s2_first", c_int32), ("s2_step", c_int32),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_out", c_void_p), ("ln_out_bf16", c_int32), ("ln_eps", c_float),
+        ("ln_mean", c_void_p), ("ln_rstd", c_void_p),
     ]
 
 
@@ -197,6 +201,8 @@ def lib():
         L.kantts_attn_fwd.argtypes = [p, p, p, i, i, i, p, i, p, p, p, p, i, i, i, i, i, i, f, u64, p, p]
         L.kantts_attn_bwd.argtypes = [p, p, p, i, i, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p, p, i, i, i, i, i,
                                       i, f, u64, p, p]
+        L.kantts_pnca_attn_fwd.argtypes = [p, p, p, p, p, p, p, p, i, i, i, i, i, i, f, u64, u64, p, p]
+        L.kantts_pnca_attn_bwd.argtypes = [p, p, p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, i, f, u64, u64, p, p]
         L.kantts_lstm_fwd.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_attn_decode.argtypes = [p, p, p, i, i, i, p, i, p, p, i, i, i, i, i, i, i, p]
         L.kantts_lstm_cell.argtypes = [p, p, p, p, i, i, p]
@@ -262,7 +268,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "kantts_abi_version", "kantts_target_arch", "kantts_gemm_seg_launch", "kantts_layernorm_fwd",
-    "kantts_layernorm_bwd", "kantts_attn_fwd", "kantts_attn_bwd", "kantts_lstm_fwd", "kantts_lstm_bwd",
+    "kantts_layernorm_bwd", "kantts_attn_fwd", "kantts_attn_bwd", "kantts_pnca_attn_fwd", "kantts_pnca_attn_bwd", "kantts_lstm_fwd", "kantts_lstm_bwd",
     "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
     "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_fsmn_dwconv_bwd_ws", "kantts_masked_l1",
     "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_norm_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd", "kantts_weight_norm_strided_fwd", "kantts_weight_norm_strided_bwd",
@@ -429,10 +435,12 @@ def _addr(x):
 
 
 def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alpha=1.0, relu=False, drop_p=0.0,
-             drop_seed=0, res=None, ldr=0, gate=None, ldg=0, rowmask=None, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0):
+             drop_seed=0, res=None, ldr=0, gate=None, ldg=0, rowmask=None, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0,
+             ln=None):
     """segs: list of (a, lda, b, ldb, klen, a_shift) with a / b tensors or (tensor, element offset).  All A operands share
     one dtype (fp32 or bf16); B operands are bf16.  Returns False when the library declines the shape (caller falls
-    back to the segmented GEMM)."""
+    back to the segmented GEMM).  ``ln`` = (gamma, beta, eps, out (M,128) bf16 / fp32, mean (M), rstd (M)): LayerNorm of
+    the output rows in the epilogue (N == 128, fp32 output)."""
     g = BGemmArgs()
     assert 1 <= len(segs) <= BGEMM_MAX_SEG
     a0 = segs[0][0][0] if isinstance(segs[0][0], tuple) else segs[0][0]
@@ -454,6 +462,11 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
         g.gate, g.ldg, g.gate_bf16 = ptr(gate), int(ldg), int(gate.dtype == torch.bfloat16)
     g.a_drop_p, g.a_drop_seed, g.a_drop_ld = float(a_drop_p), int(a_drop_seed), int(a_drop_ld)
     g.rowmask = ptr(rowmask)
+    if ln is not None:
+        gamma, beta, eps, ln_out, ln_mean, ln_rstd = ln
+        g.ln_gamma, g.ln_beta, g.ln_eps = ptr(gamma, torch.float32), ptr(beta, torch.float32), float(eps)
+        g.ln_out, g.ln_out_bf16 = ptr(ln_out), int(ln_out.dtype == torch.bfloat16)
+        g.ln_mean, g.ln_rstd = ptr(ln_mean, torch.float32), ptr(ln_rstd, torch.float32)
     dev = (c[0] if isinstance(c, tuple) else c).device
     g.seed_dev = rng_ptr(dev) if (drop_p > 0 or a_drop_p > 0) else None
     if _profile is not None:
@@ -471,7 +484,7 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
 
 def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu=False, alpha1=1.0, drop1_p=0.0,
              drop1_seed=0, drop2_p=0.0, drop2_seed=0, xdrop_p=0.0, xdrop_seed=0, gate=None, rowmask1=None, rowmask2=None,
-             xrowmask=None, t_out=None, res=None, KT2=1, s2_first=0, s2_step=0):
+             xrowmask=None, t_out=None, res=None, KT2=1, s2_first=0, s2_step=0, ln=None):
     """Both contractions of a feed-forward block in one launch (csrc/ffn_pair.hip; kantts_ffn_pair in the header).
     x (M, 128) bf16 / fp32; w1 / w2: FRAGMENT-MAJOR bf16 images (ops_bf16.frag_major) of the (KT*F, 128) and (128, F)
     weight matrices; y (M, 128) fp32 / bf16; t_out bf16 (M, F).  KT2 = 3 (backward form): phase 2 sums three taps of the
@@ -492,6 +505,11 @@ def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu
     g.res, g.ldr = ptr(res, torch.float32), int(y.shape[-1])
     g.y, g.ldy, g.y_bf16 = ptr(y), int(y.shape[-1]), int(y.dtype == torch.bfloat16)
     g.KT2, g.s2_first, g.s2_step = int(KT2), int(s2_first), int(s2_step)
+    if ln is not None:  # (gamma, beta, eps, out (M,128), mean (M), rstd (M)): LayerNorm of the output rows in the epilogue
+        gamma, beta, eps, ln_out, ln_mean, ln_rstd = ln
+        g.ln_gamma, g.ln_beta, g.ln_eps = ptr(gamma, torch.float32), ptr(beta, torch.float32), float(eps)
+        g.ln_out, g.ln_out_bf16 = ptr(ln_out), int(ln_out.dtype == torch.bfloat16)
+        g.ln_mean, g.ln_rstd = ptr(ln_mean, torch.float32), ptr(ln_rstd, torch.float32)
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

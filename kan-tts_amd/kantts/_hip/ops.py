@@ -10,8 +10,8 @@ import math
 
 import torch
 
-from . import (act_cast_bf16, bgemm_nt, bgemm_tn, cconv, cconv_wgrad, check, get_precision, conv_c1, conv_wgrad, conv_win,
-               gemm, lib, make_seg, ptr, rng_state, stream)
+from . import (E_UNSUPPORTED, act_cast_bf16, bgemm_nt, bgemm_tn, cconv, cconv_wgrad, check, get_precision, conv_c1, conv_wgrad,
+               conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
 from . import ops_bf16
 
 _seed_counter = itertools.count(1)
@@ -447,10 +447,11 @@ class _FusedLinear(torch.autograd.Function):
 
 
 def linear(xs, weights, bias=None, *, mode=None, bias2=None, res=None, rowmask=None, relu=False, alpha=1.0,
-           drop_p=0.0, pad=0, dilation=1, T=0, out_bf16=False):
+           drop_p=0.0, pad=0, dilation=1, T=0, out_bf16=False, ln_next=None):
     """Functional entry: xs / weights are tensors or lists (see _FusedLinear).  In bf16 mode the contraction runs on
     the bf16-operand kernels (ops_bf16) whenever its extents allow; ``out_bf16`` then stores the result as bf16 (for
-    outputs whose only consumers are contractions).  fp32 mode ignores it."""
+    outputs whose only consumers are contractions).  fp32 mode ignores it.  ``ln_next``: the nn.LayerNorm(128) of the
+    pre-LN sub-layer that consumes the output -- bf16 mode computes it in this launch's epilogue (ops_bf16.PreNorm)."""
     xs = [xs] if torch.is_tensor(xs) else list(xs)
     weights = [weights] if torch.is_tensor(weights) else list(weights)
     if mode is None:
@@ -467,7 +468,8 @@ def linear(xs, weights, bias=None, *, mode=None, bias2=None, res=None, rowmask=N
         else:
             wbs = [ops_bf16.bf16_weight(w) for w in params]
         return ops_bf16.linear(xs, weights, wbs, bias, mode=mode, bias2=bias2, res=res, rowmask=rowmask, relu=relu,
-                               alpha=alpha, drop_p=drop_p, pad=pad, dilation=dilation, T=T, out_bf16=out_bf16)
+                               alpha=alpha, drop_p=drop_p, pad=pad, dilation=dilation, T=T, out_bf16=out_bf16,
+                               ln_next=ln_next)
     xs = [x.float() if x.dtype != torch.float32 else x for x in xs]  # the segmented GEMM reads fp32 operands
     token = ops_bf16.RowMaskToken(rowmask) if (rowmask is not None and not relu and torch.is_grad_enabled()) else None
     opts = dict(nx=len(xs), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p), pad=int(pad),
@@ -530,17 +532,18 @@ def layer_norm(x, gamma, beta, eps=1e-6, out_bf16=False, with_res=False, private
     return (y, x) if with_res else y
 
 
-def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p_out=0.0):
+def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p_out=0.0, ln_next=None):
     """Position-wise feed-forward after its LayerNorm (kantts/models/sambert/__init__.py:134-149):
     Conv1d(k) -> ReLU -> zero padded rows -> dropout -> Conv1d(1) -> dropout -> + res (-> zero rows).
     bf16 mode: one autograd node on the bf16-operand kernels; otherwise two fused linears."""
     k1, k2 = w1.shape[2], w2.shape[2]
     if get_precision() == "bf16" and ops_bf16.ffn_eligible(h, w1, w2):
-        return ops_bf16.ffn(h, w1, b1, w2, b2, res, pad_rows=pad_rows, zero_rows=zero_rows, p_inner=p_inner, p_out=p_out)
+        return ops_bf16.ffn(h, w1, b1, w2, b2, res, pad_rows=pad_rows, zero_rows=zero_rows, p_inner=p_inner, p_out=p_out,
+                            ln_next=ln_next)
     hid = linear(h, w1, b1, relu=True, rowmask=pad_rows, drop_p=p_inner, pad=(k1 - 1) // 2,
                  mode="conv" if k1 > 1 else None)
     return linear(hid, w2, b2, res=res, rowmask=zero_rows, drop_p=p_out, pad=(k2 - 1) // 2,
-                  mode="conv" if k2 > 1 else None)
+                  mode="conv" if k2 > 1 else None, ln_next=ln_next)
 
 
 # ================================================================================================
@@ -645,6 +648,23 @@ class _PncaAttention(torch.autograd.Function):
         q2, h2 = qkv.view(B * L, W), hkv.view(B * L, 2 * D)
         sx = next_seed() if drop_p > 0 else 0
         sh = next_seed() if drop_p > 0 else 0
+        ctx.save_cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)
+        if not want_probs and not os.environ.get("KANTTS_NO_PNCA_FUSED"):
+            # both bands as ONE launch (csrc/attn.hip: attn_multi_lds_kernel); declined when a head does not fit in LDS
+            dev = q2.device
+            ox = torch.empty((B * L, D), device=dev, dtype=torch.float32)
+            oh = torch.empty((B * L, D), device=dev, dtype=torch.float32)
+            lsex = torch.empty((B, H, L), device=dev, dtype=torch.float32)
+            lseh = torch.empty((B, H, L), device=dev, dtype=torch.float32)
+            rc = lib().kantts_pnca_attn_fwd(ptr(q2), ptr(h2), ptr(ox), ptr(oh), ptr(lsex), ptr(lseh), ptr(lens), ptr(bw_dev),
+                                            int(bw_x), int(bw_h), B, H, L, 16, float(drop_p), int(sx), int(sh),
+                                            ptr(rng_state(dev)) if drop_p > 0 else None, stream())
+            if rc == 0:
+                ctx.save_for_backward(q2, h2, ox, oh, lsex, lseh, lens, bw_dev)
+                ctx.cfg = ctx.save_cfg
+                return ox.view(B, L, D), oh.view(B, L, D), None, None
+            if rc != E_UNSUPPORTED:
+                check(rc, "pnca_attn_fwd")
         (ox, lsex, px), (oh, lseh, ph) = _pair_on_two_streams(
             lambda: _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, bw_dev, bw_x, B, H, L, MODE_BAND_X, drop_p, sx, want_probs),
             lambda: _attn_fwd(q2, 0, h2, 0, h2, D, lens, bw_dev, bw_h, B, H, L, MODE_BAND_H, drop_p, sh, want_probs),
@@ -663,6 +683,17 @@ class _PncaAttention(torch.autograd.Function):
         d_ox, d_oh = _c(d_ox).view(B * L, D), _c(d_oh).view(B * L, D)
         dqkv = torch.empty_like(q2)
         dhkv = torch.empty_like(h2)
+        if not os.environ.get("KANTTS_NO_PNCA_FUSED"):
+            dqh = torch.empty((B * L, D), device=q2.device, dtype=torch.float32)
+            rc = lib().kantts_pnca_attn_bwd(ptr(q2), ptr(h2), ptr(ox), ptr(oh), ptr(d_ox), ptr(d_oh), ptr(lsex), ptr(lseh),
+                                            ptr(dqkv), ptr(dqh), ptr(dhkv), ptr(lens), ptr(bw_dev), int(bw_x), int(bw_h), B,
+                                            H, L, 16, float(drop_p), int(sx), int(sh),
+                                            ptr(rng_state(q2.device)) if drop_p > 0 else None, stream())
+            if rc == 0:
+                dqkv[:, :D].add_(dqh)
+                return dqkv.view(B, L, 3 * D), dhkv.view(B, L, 2 * D), None, None, None, None, None, None, None
+            if rc != E_UNSUPPORTED:
+                check(rc, "pnca_attn_bwd")
 
         def bwd_h():
             # the h band's query gradient goes to its own buffer: the two bands then share nothing they write

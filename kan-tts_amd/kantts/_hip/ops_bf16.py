@@ -135,6 +135,27 @@ class RowMaskToken:
         self.mask, self.delegated = mask, False
 
 
+PRENORM = {"on": not os.environ.get("KANTTS_NO_PRENORM")}  # A/B switch: LayerNorm in the producer's epilogue
+
+
+class PreNorm:
+    """LayerNorm(128) of a sub-layer's OUTPUT computed by the epilogue of the launch that produces it (kantts_bgemm_nt
+    ``ln_*`` / kantts_ffn_pair ``ln_*``): the producer is told which nn.LayerNorm consumes its output (``ln_next``), leaves
+    the normalised rows + row statistics on the output tensor (``y._kantts_prenorm``), and ``layer_norm128`` called with
+    that very module's parameters adopts them instead of launching kantts_ln128_fwd.  Backward is the usual
+    kantts_ln128_bwd_rows on the saved statistics."""
+    __slots__ = ("gamma", "beta", "eps", "out_bf16", "xn", "mean", "rstd")
+
+    def __init__(self, ln):
+        self.gamma, self.beta, self.eps = ln.weight, ln.bias, float(ln.eps)
+        self.out_bf16 = bool(getattr(ln, "_kantts_out_bf16", True))
+        self.xn = self.mean = self.rstd = None
+
+    def matches(self, gamma, beta, eps, out_bf16):
+        return (self.xn is not None and self.gamma is gamma and self.beta is beta and self.eps == float(eps)
+                and self.out_bf16 == bool(out_bf16))
+
+
 def _attach_token(y, token):
     if token is not None:
         y._kantts_rowmask = token
@@ -193,8 +214,16 @@ class _FusedLinearB(torch.autograd.Function):
         seed = next_seed() if drop_p > 0 else 0
         r = _c(res).view(M, N) if res is not None else None
         rm = _c(rowmask).view(M) if rowmask is not None else None
+        ln = None
+        pre = opts.get("ln_next")
+        if pre is not None and N == 128 and not opts["out_bf16"]:
+            # LayerNorm of the consuming sub-layer, computed by this launch's epilogue (PreNorm)
+            pre.xn = torch.empty((M, N), device=dev, dtype=BF16 if pre.out_bf16 else torch.float32)
+            pre.mean = torch.empty(M, device=dev, dtype=torch.float32)
+            pre.rstd = torch.empty(M, device=dev, dtype=torch.float32)
+            ln = (pre.gamma.detach(), pre.beta.detach(), pre.eps, pre.xn, pre.mean, pre.rstd)
         if not bgemm_nt(segs, M, N, y, N, T=T, bias=bias, bias2=bias2, alpha=alpha, relu=relu, drop_p=drop_p,
-                        drop_seed=seed, res=r, ldr=N, rowmask=rm):
+                        drop_seed=seed, res=r, ldr=N, rowmask=rm, ln=ln):
             raise RuntimeError("kantts_bgemm_nt declined a shape ops_bf16.eligible() accepted")
         ctx.opts, ctx.seed, ctx.M, ctx.N, ctx.lead = opts, seed, M, N, lead
         ctx.has = (bias is not None, bias2 is not None, res is not None)
@@ -292,11 +321,17 @@ class _FusedLinearB(torch.autograd.Function):
         return (None, dbias if has_bias else None, db2, d_res, None, *dxs, *dws, *([None] * len(wbs)))
 
 
-def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, drop_p, pad, dilation, T, out_bf16):
+def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, drop_p, pad, dilation, T, out_bf16,
+           ln_next=None):
     token = RowMaskToken(rowmask) if (rowmask is not None and not relu and torch.is_grad_enabled()) else None
+    pre = PreNorm(ln_next) if (ln_next is not None and PRENORM["on"] and not relu and not out_bf16
+                               and weights[0].shape[0] == 128) else None
     opts = dict(nx=len(xs), nw=len(weights), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p),
-                pad=int(pad), dilation=int(dilation), T=int(T), out_bf16=bool(out_bf16), token=token)
-    return _attach_token(_FusedLinearB.apply(opts, bias, bias2, res, rowmask, *xs, *weights, *wbs), token)
+                pad=int(pad), dilation=int(dilation), T=int(T), out_bf16=bool(out_bf16), token=token, ln_next=pre)
+    y = _attach_token(_FusedLinearB.apply(opts, bias, bias2, res, rowmask, *xs, *weights, *wbs), token)
+    if pre is not None and pre.xn is not None:
+        y._kantts_prenorm = pre
+    return y
 
 
 # ================================================================================================
@@ -308,14 +343,17 @@ class _LayerNorm128(torch.autograd.Function):
     backward kernel -- autograd would otherwise add them with a separate elementwise kernel per sub-layer."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res, zero_rows):
+    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res, zero_rows, xn, mean, rstd):
         x = _c(x)
         M = x.numel() // 128
-        y = torch.empty(x.shape, device=x.device, dtype=BF16 if out_bf16 else torch.float32)
-        mean = torch.empty(M, device=x.device, dtype=torch.float32)
-        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-        check(lib().kantts_ln128_fwd(ptr(x, torch.float32), ptr(gamma, torch.float32), ptr(beta, torch.float32), ptr(y),
-                                     int(out_bf16), ptr(mean), ptr(rstd), M, float(eps), stream()), "ln128_fwd")
+        if xn is not None:  # computed by the epilogue of the launch that produced x (PreNorm)
+            y = xn.view(x.shape)
+        else:
+            y = torch.empty(x.shape, device=x.device, dtype=BF16 if out_bf16 else torch.float32)
+            mean = torch.empty(M, device=x.device, dtype=torch.float32)
+            rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+            check(lib().kantts_ln128_fwd(ptr(x, torch.float32), ptr(gamma, torch.float32), ptr(beta, torch.float32),
+                                         ptr(y), int(out_bf16), ptr(mean), ptr(rstd), M, float(eps), stream()), "ln128_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd, zero_rows)
         if with_res:
             return y, x.view_as(x)
@@ -332,13 +370,13 @@ class _LayerNorm128(torch.autograd.Function):
         if dy is None:  # only the pass-through was used downstream
             if zero_rows is not None:
                 dres = dres.masked_fill(zero_rows.bool().view(*dres.shape[:-1], 1), 0.0)
-            return (dres, None, None, None, None, None, None)
+            return (dres, None, None, None, None, None, None, None, None, None)
         dy = _c(dy)
         dres = _c(dres) if dres is not None else None
         check(lib().kantts_ln128_bwd_rows(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean), ptr(rstd),
                                           ptr(dres, torch.float32), ptr(dx), ptr(dg), ptr(db), ptr(zero_rows, torch.uint8),
                                           M, stream()), "ln128_bwd")
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
 def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False, private_input=False):
@@ -349,7 +387,12 @@ def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False, private_input=F
         zero_rows = _c(zero_rows).view(-1)
         if zero_rows.dtype == torch.bool:
             zero_rows = zero_rows.view(torch.uint8)
-    y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows)
+    pre = getattr(x, "_kantts_prenorm", None)
+    if pre is not None and pre.matches(gamma, beta, eps, out_bf16) and pre.xn.numel() == x.numel():
+        y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows, pre.xn, pre.mean,
+                                    pre.rstd)
+    else:
+        y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows, None, None, None)
     return (y, xr) if with_res else y
 
 
@@ -379,9 +422,18 @@ class _FusedFFNB(torch.autograd.Function):
         hid = torch.empty((M, F), device=h.device, dtype=BF16)
         out = torch.empty((M, N), device=h.device, dtype=torch.float32)
         r = _c(res).view(M, N)
+        ln = None
+        pre = cfg.get("ln_next")
+        if pre is not None and cfg["pair"] and N == 128:
+            pre.xn = torch.empty((M, N), device=h.device, dtype=BF16 if pre.out_bf16 else torch.float32)
+            pre.mean = torch.empty(M, device=h.device, dtype=torch.float32)
+            pre.rstd = torch.empty(M, device=h.device, dtype=torch.float32)
+            ln = (pre.gamma.detach(), pre.beta.detach(), pre.eps, pre.xn, pre.mean, pre.rstd)
         fused = cfg["pair"] and ffn_pair(hb.view(M, C), wf1, wf2, out, M=M, T=T, F=F, KT=kt, pad=pad, bias1=b1, bias2=b2,
                                          relu=True, drop1_p=p_in, drop1_seed=s1, drop2_p=p_out, drop2_seed=s2,
-                                         rowmask1=pr, rowmask2=zr, t_out=hid, res=r)
+                                         rowmask1=pr, rowmask2=zr, t_out=hid, res=r, ln=ln)
+        if not fused and pre is not None:
+            pre.xn = pre.mean = pre.rstd = None
         if not fused:
             segs = [(hb, C, (wb1, tap * F * C), C, C, tap - pad) for tap in range(kt)]
             if not bgemm_nt(segs, M, F, hid, F, T=T, bias=b1, relu=True, drop_p=p_in, drop_seed=s1, rowmask=pr):
@@ -507,7 +559,7 @@ def ffn_eligible(h, w1, w2):
             w1.shape[1] % 8 == 0 and w2.shape[0] % 8 == 0 and h.numel() > 0)
 
 
-def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p_out=0.0, T=0):
+def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p_out=0.0, T=0, ln_next=None):
     """h: LayerNorm output (B, T, C) (bf16 or fp32); w1 (F, C, k), w2 (C_out, F, 1) Conv1d weights; res (B, T, C_out)."""
     F, C, kt = w1.shape
     # csrc/ffn_pair.hip: 128 channels either side, 1024 hidden units, odd kernel width
@@ -515,10 +567,15 @@ def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p
     cfg = dict(T=int(T or h.shape[-2]), pad=(kt - 1) // 2, p_inner=float(p_inner), p_out=float(p_out), pair=pair)
     token = RowMaskToken(zero_rows) if (zero_rows is not None and torch.is_grad_enabled()) else None
     cfg["token"] = token
+    pre = PreNorm(ln_next) if (ln_next is not None and PRENORM["on"] and pair) else None
+    cfg["ln_next"] = pre
     wf1 = wf2 = wt2 = wt1 = None
     if pair:
         wf1, wf2, wt2, wt1 = ffn_frag_weights(w1, w2)
         if kt not in (1, 3):
             wt2 = wt1 = None  # backward stays on the two-launch form
-    return _attach_token(_FusedFFNB.apply(h, w1, b1, w2, b2, res, pad_rows, zero_rows, conv_weight_bf16(w1),
-                                          conv_weight_bf16(w2), wf1, wf2, wt2, wt1, cfg), token)
+    y = _attach_token(_FusedFFNB.apply(h, w1, b1, w2, b2, res, pad_rows, zero_rows, conv_weight_bf16(w1),
+                                       conv_weight_bf16(w2), wf1, wf2, wt2, wt1, cfg), token)
+    if pre is not None and pre.xn is not None:
+        y._kantts_prenorm = pre
+    return y

@@ -79,9 +79,10 @@ class MultiHeadSelfAttention(nn.Module):
         self.fc = nn.Linear(n_head * d_head, d_model)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, input, mask=None, zero_rows=None, return_attn=False, private_input=False):
+    def forward(self, input, mask=None, zero_rows=None, return_attn=False, private_input=False, next_ln=None):
         """mask: key padding (SeqInfo or bool (B, L) / (B, L, L) as the reference builds it).
-        ``private_input``: nothing but this sub-layer consumes ``input`` (see ops.layer_norm)."""
+        ``private_input``: nothing but this sub-layer consumes ``input`` (see ops.layer_norm).
+        ``next_ln``: the nn.LayerNorm of the sub-layer that consumes the output (computed in the output GEMM's epilogue)."""
         if torch.is_tensor(mask) and mask.dim() == 3:
             mask = mask[:, 0, :]
         info = SeqInfo.of(mask)
@@ -92,7 +93,7 @@ class MultiHeadSelfAttention(nn.Module):
                                         drop_p=_p(self.attention.dropatt, self.training), want_probs=return_attn)
         res = input if self.fc.out_features == input.size(-1) else None
         output = ops.linear(ctxv, self.fc.weight, self.fc.bias, res=res, rowmask=zero_rows,
-                            drop_p=_p(self.dropout, self.training))
+                            drop_p=_p(self.dropout, self.training), ln_next=next_ln)
         return output, attn
 
 
@@ -111,14 +112,14 @@ class PositionwiseConvFeedForward(nn.Module):
         self.w_1.weight._kantts_ffn_role = "w1"
         self.w_2.weight._kantts_ffn_role = "w2"
 
-    def forward(self, x, mask=None, zero_rows=None, private_input=False):
+    def forward(self, x, mask=None, zero_rows=None, private_input=False, next_ln=None):
         info = SeqInfo.of(mask)
         pad_rows = None if info is None else info.mask
         h, x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
                               with_res=True, private_input=private_input)
         return ops.ffn(h, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, x, pad_rows=pad_rows,
                        zero_rows=zero_rows, p_inner=_p(self.dropout_inner, self.training),
-                       p_out=_p(self.dropout, self.training))
+                       p_out=_p(self.dropout, self.training), ln_next=next_ln)
 
 
 class FFTBlock(nn.Module):
@@ -131,16 +132,17 @@ class FFTBlock(nn.Module):
         self.pos_ffn = PositionwiseConvFeedForward(d_model, d_inner, kernel_size, dropout_inner=dropout_relu,
                                                    dropout=dropout)
 
-    def forward(self, input, mask=None, slf_attn_mask=None, return_attn=False, private_input=False):
+    def forward(self, input, mask=None, slf_attn_mask=None, return_attn=False, private_input=False, next_ln=None):
         """``private_input``: the caller hands ``input`` to this block only (a stack does, from its second block on): the
-        producer's masking of the incoming gradient then happens inside this block's first LayerNorm backward."""
+        producer's masking of the incoming gradient then happens inside this block's first LayerNorm backward.
+        ``next_ln``: the nn.LayerNorm that consumes this block's output (the next block's, or the stack's final one)."""
         info = SeqInfo.of(mask)
         rows = None if info is None else info.mask
         key_info = info if info is not None else slf_attn_mask
         output, slf_attn = self.slf_attn(input, mask=key_info, zero_rows=rows, return_attn=return_attn,
-                                         private_input=private_input)
+                                         private_input=private_input, next_ln=self.pos_ffn.layer_norm)
         # the attention sub-layer's output goes nowhere but into the feed-forward sub-layer
-        output = self.pos_ffn(output, mask=info, zero_rows=rows, private_input=True)
+        output = self.pos_ffn(output, mask=info, zero_rows=rows, private_input=True, next_ln=next_ln)
         return output, slf_attn
 
 
@@ -173,7 +175,7 @@ class MultiHeadPNCAAttention(nn.Module):
         self.x_state_size = 0
 
     def forward(self, x, h, info=None, x_band_width=0, h_band_width=0, zero_rows=None, return_attn=False,
-                bw_dev=None, hkv=None, private_input=False):
+                bw_dev=None, hkv=None, private_input=False, next_ln=None):
         """``hkv``: this block's memory K/V projection when the decoder computed all of them together
         (ops.shared_input_linears: one input-gradient launch for the twelve blocks)."""
         xn, x = ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
@@ -186,7 +188,7 @@ class MultiHeadPNCAAttention(nn.Module):
             qkv, hkv, None if info is None else info.lens32, x_band_width, h_band_width, self.n_head,
             drop_p=_p(self.attention.dropatt, self.training), want_probs=return_attn, bw_dev=bw_dev)
         output = ops.linear([ox, oh], [self.fc_x.weight, self.fc_h.weight], self.fc_x.bias, bias2=self.fc_h.bias,
-                            mode="sum", res=x, rowmask=zero_rows, drop_p=_p(self.dropout, self.training))
+                            mode="sum", res=x, rowmask=zero_rows, drop_p=_p(self.dropout, self.training), ln_next=next_ln)
         return output, attn_x, attn_h
 
 
@@ -228,12 +230,13 @@ class PNCABlock(nn.Module):
                                                    dropout=dropout)
 
     def forward(self, input, memory, mask=None, x_band_width=0, h_band_width=0, return_attn=False, bw_dev=None,
-                hkv=None, private_input=False):
+                hkv=None, private_input=False, next_ln=None):
         info = SeqInfo.of(mask)
         rows = None if info is None else info.mask
         output, ax, ah = self.pnca_attn(input, memory, info, x_band_width, h_band_width, zero_rows=rows,
-                                        return_attn=return_attn, bw_dev=bw_dev, hkv=hkv, private_input=private_input)
-        output = self.pos_ffn(output, mask=info, zero_rows=rows, private_input=True)
+                                        return_attn=return_attn, bw_dev=bw_dev, hkv=hkv, private_input=private_input,
+                                        next_ln=self.pos_ffn.layer_norm)
+        output = self.pos_ffn(output, mask=info, zero_rows=rows, private_input=True, next_ln=next_ln)
         return output, ax, ah
 
     @torch.no_grad()

@@ -49,6 +49,7 @@ class SelfAttentionEncoder(nn.Module):
             for d in d_in_lst
         ])
         self.ln = nn.LayerNorm(d_model, eps=1e-6)
+        self.ln._kantts_out_bf16 = False  # read by more than contractions: fp32 output (ops_bf16.PreNorm)
         self.position_enc = position_encoder
 
     def forward(self, input, mask=None, return_attns=False, prescaled=False):
@@ -66,7 +67,8 @@ class SelfAttentionEncoder(nn.Module):
             if every and i and i % every == 0:
                 x = ops.wgrad_flush_point(x)  # backward: weight gradients of the later blocks start beside the earlier ones
             # from the second block on, x is the previous block's output and has no other reader
-            x, a = layer(x, mask=info, return_attn=return_attns, private_input=i > 0)
+            nxt = self.fft[i + 1].slf_attn.layer_norm if i + 1 < len(self.fft) else self.ln
+            x, a = layer(x, mask=info, return_attn=return_attns, private_input=i > 0, next_ln=nxt)
             if return_attns:
                 attns.append(a)
         x = ops.layer_norm(x, self.ln.weight, self.ln.bias, self.ln.eps, private_input=len(self.fft) > 0)
@@ -90,6 +92,7 @@ class HybridAttentionDecoder(nn.Module):
             for _ in range(n_layer)
         ])
         self.ln = nn.LayerNorm(d_model, eps=1e-6)
+        self.ln._kantts_out_bf16 = False
         self.dec_out_proj = nn.Linear(d_model, d_out)
 
     def reset_state(self):
@@ -113,7 +116,8 @@ class HybridAttentionDecoder(nn.Module):
             if every and i and i % every == 0:
                 x = ops.wgrad_flush_point(x)
             x, ax, ah = layer(x, memory, mask=info, x_band_width=x_band_width, h_band_width=h_band_width,
-                              return_attn=return_attns, bw_dev=bw_dev, hkv=hkvs[i], private_input=i > 0)
+                              return_attn=return_attns, bw_dev=bw_dev, hkv=hkvs[i], private_input=i > 0,
+                              next_ln=self.pnca[i + 1].pnca_attn.layer_norm if i + 1 < len(self.pnca) else self.ln)
             if return_attns:
                 ax_l.append(ax)
                 ah_l.append(ah)

@@ -307,6 +307,15 @@ class EmulatedLib:
         esz = 2 if g.c_bf16 else 4
         for i in range(M):
             _wr(int(g.c) + i * g.ldc * esz, v[i], bool(g.c_bf16))
+        if g.ln_out:  # LayerNorm(128) of the output rows (the epilogue option of the kernel): same as kantts_ln128_fwd
+            assert N == 128 and not g.c_bf16
+            X = torch.from_numpy(v.copy())
+            mu = X.mean(1)
+            rs = 1.0 / torch.sqrt(((X - mu[:, None]) ** 2).mean(1) + g.ln_eps)
+            Y = (X - mu[:, None]) * rs[:, None] * torch.from_numpy(_arr(g.ln_gamma, 128)) + torch.from_numpy(_arr(g.ln_beta, 128))
+            _wr(g.ln_out, Y.reshape(-1).numpy(), bool(g.ln_out_bf16))
+            _arr(g.ln_mean, M)[:] = mu.numpy()
+            _arr(g.ln_rstd, M)[:] = rs.numpy()
         return 0
 
     def kantts_fragmajor_bf16(self, src, dst, table, ndesc, blocks, stream):
@@ -392,6 +401,15 @@ class EmulatedLib:
         esz = 2 if g.y_bf16 else 4
         for i in range(M):
             _wr(int(g.y) + i * g.ldy * esz, y[i], bool(g.y_bf16))
+        if g.ln_out:  # LayerNorm(128) of the output rows in the epilogue (forward form only)
+            assert kt2 == 1 and not g.gate
+            X = torch.from_numpy(y.copy())
+            mu = X.mean(1)
+            rs = 1.0 / torch.sqrt(((X - mu[:, None]) ** 2).mean(1) + g.ln_eps)
+            Y = (X - mu[:, None]) * rs[:, None] * torch.from_numpy(_arr(g.ln_gamma, 128)) + torch.from_numpy(_arr(g.ln_beta, 128))
+            _wr(g.ln_out, Y.reshape(-1).numpy(), bool(g.ln_out_bf16))
+            _arr(g.ln_mean, M)[:] = mu.numpy()
+            _arr(g.ln_rstd, M)[:] = rs.numpy()
         return 0
 
     def kantts_bgemm_tn(self, args_ref, stream):
@@ -594,6 +612,29 @@ class EmulatedLib:
         scatter(dq, lddq, dQ, accumulate_dq)
         scatter(dk, lddk, dK, 0)
         scatter(dv, lddv, dV, 0)
+        return 0
+
+    def kantts_pnca_attn_fwd(self, qkv, hkv, ox, oh, lse_x, lse_h, lens, bw_dev, bw_x, bw_h, B, H, L, d_head, drop_p,
+                             seed_x, seed_h, seed_dev, stream):
+        """Both bands of a PNCA block: the per-band emulation twice (K/V of the x band at columns [D, 3D) of qkv)."""
+        D = H * 16
+        qkv, hkv = int(qkv), int(hkv)
+        self.kantts_attn_fwd(qkv, qkv + 4 * D, qkv + 8 * D, 3 * D, 3 * D, 3 * D, ox, D, lse_x, None, lens, bw_dev, bw_x, B,
+                             H, L, d_head, 1, drop_p, seed_x, seed_dev, stream)
+        self.kantts_attn_fwd(qkv, hkv, hkv + 4 * D, 3 * D, 2 * D, 2 * D, oh, D, lse_h, None, lens, bw_dev, bw_h, B, H, L,
+                             d_head, 2, drop_p, seed_h, seed_dev, stream)
+        return 0
+
+    def kantts_pnca_attn_bwd(self, qkv, hkv, ox, oh, d_ox, d_oh, lse_x, lse_h, dqkv, dqh, dhkv, lens, bw_dev, bw_x, bw_h,
+                             B, H, L, d_head, drop_p, seed_x, seed_h, seed_dev, stream):
+        D = H * 16
+        qkv, hkv, dqkv, dhkv = int(qkv), int(hkv), int(dqkv), int(dhkv)
+        self.kantts_attn_bwd(qkv, qkv + 4 * D, qkv + 8 * D, 3 * D, 3 * D, 3 * D, ox, D, d_ox, D, lse_x, None, dqkv,
+                             dqkv + 4 * D, dqkv + 8 * D, 3 * D, 3 * D, 3 * D, 0, lens, bw_dev, bw_x, B, H, L, d_head, 1,
+                             drop_p, seed_x, seed_dev, stream)
+        self.kantts_attn_bwd(qkv, hkv, hkv + 4 * D, 3 * D, 2 * D, 2 * D, oh, D, d_oh, D, lse_h, None, dqh, dhkv,
+                             dhkv + 4 * D, D, 2 * D, 2 * D, 0, lens, bw_dev, bw_h, B, H, L, d_head, 2, drop_p, seed_h,
+                             seed_dev, stream)
         return 0
 
     # ------------------------------------------------------------------------------------ LSTM

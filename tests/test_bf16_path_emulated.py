@@ -263,3 +263,33 @@ def test_shared_input_linears_equal_separate_ones(bf16_mode):
     assert rel_l2(gxa, gxb) < 1e-3          # one bf16-operand contraction over 5 x 256 vs five fp32 partial sums
     for a, b in zip(gwa + gba, gwb + gbb):
         assert rel_l2(a, b) < 1e-6
+
+
+def test_layernorm_in_the_producer_epilogue_equals_the_separate_launch(bf16_mode, monkeypatch):
+    """ops_bf16.PreNorm: the attention sub-layer's output GEMM computes the feed-forward sub-layer's LayerNorm in its
+    epilogue; the consumer adopts the rows + statistics instead of launching kantts_ln128_fwd.  Same outputs and
+    gradients as with the hand-over switched off; the launches are really gone."""
+    from kantts._hip import ops_bf16
+    from kantts.models.sambert.kantts_sambert import SelfAttentionEncoder
+
+    with emulation() as emu:
+        def run(on):
+            monkeypatch.setitem(ops_bf16.PRENORM, "on", on)
+            calls = []
+            orig = emu.kantts_ln128_fwd
+            monkeypatch.setattr(emu, "kantts_ln128_fwd", lambda *a: (calls.append(1), orig(*a))[1], raising=False)
+            torch.manual_seed(5)
+            enc = SelfAttentionEncoder(2, 128, 128, 8, 16, 1024, 0.0, 0.0, 0.0, position_encoder=None)
+            enc.train()
+            x = torch.randn(3, 21, 128, requires_grad=True)
+            mask = torch.arange(21)[None, :] >= torch.tensor([21, 9, 15])[:, None]
+            y, _ = enc(x, mask, prescaled=True)
+            (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(1))).sum().backward()
+            return y.detach(), [x.grad] + [p.grad for p in enc.parameters()], len(calls)
+
+        y_on, g_on, n_on = run(True)
+        y_off, g_off, n_off = run(False)
+    assert n_off == 5 and n_on == 1  # 2 blocks x 2 sub-layers + the final LayerNorm: all but the very first are adopted
+    assert torch.equal(y_on, y_off)
+    for a, b in zip(g_on, g_off):
+        assert torch.equal(a, b)

@@ -274,3 +274,61 @@ def test_arena_fragment_major_images_follow_the_master():
         arena.flat.mul_(1.5).add_(0.01)
     net(torch.zeros(1, device="cuda"))  # forward pre-hook: refresh
     check()
+
+
+def test_layernorm_in_the_producer_epilogues_equals_the_separate_kernel(monkeypatch):
+    """kantts_bgemm_nt / kantts_ffn_pair ``ln_*``: LayerNorm(128) of the rows the epilogue has just formed (bgemm_nt: same
+    arithmetic in the same order as ln128_fwd_kernel; ffn_pair: a token's channels are spread over the eight waves, so
+    the two-pass statistics are summed in another order -- fp32 rounding, an occasional bf16 tie in the normalised rows).
+    Encoder stack forward + backward with the hand-over on and off, and against the emulated C ABI."""
+    from kantts._hip import ops_bf16
+    from kantts.models.sambert.kantts_sambert import SelfAttentionEncoder
+
+    def run(on):
+        monkeypatch.setitem(ops_bf16.PRENORM, "on", on)
+        torch.manual_seed(5)
+        enc = SelfAttentionEncoder(3, 128, 128, 8, 16, 1024, 0.0, 0.0, 0.0, position_encoder=None).cuda()
+        enc.train()
+        x = torch.randn(5, 77, 128, generator=torch.Generator().manual_seed(2)).cuda().requires_grad_(True)
+        lens = torch.tensor([77, 9, 50, 33, 64])
+        mask = (torch.arange(77)[None, :] >= lens[:, None]).cuda()
+        y, _ = enc(x, mask, prescaled=True)
+        (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).cuda()).sum().backward()
+        return y.detach(), x.grad.clone()
+
+    y_on, g_on = run(True)
+    y_off, g_off = run(False)
+    assert rel_l2(y_on, y_off) < 1e-4, rel_l2(y_on, y_off)
+    assert rel_l2(g_on, g_off) < 1e-3, rel_l2(g_on, g_off)
+
+    # the two epilogues on their own against the emulation: rows, statistics
+    from kantts._hip import bgemm_nt, ffn_pair
+    from kantts._hip.ops_bf16 import frag_major
+
+    def epilogues(x, w, w1, w2, gam, bet, res):
+        M = x.shape[0]
+        dev = x.device
+        outs = []
+        for which in ("nt", "pair"):
+            y = torch.empty((M, 128), device=dev)
+            xn = torch.empty((M, 128), device=dev, dtype=torch.bfloat16)
+            mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+            ln = (gam, bet, 1e-6, xn, mean, rstd)
+            if which == "nt":
+                assert bgemm_nt([(x.to(torch.bfloat16), 128, w.to(torch.bfloat16), 128, 128, 0)], M, 128, y, 128, res=res,
+                                ldr=128, ln=ln)
+            else:
+                hid = torch.empty((M, 1024), device=dev, dtype=torch.bfloat16)
+                assert ffn_pair(x.to(torch.bfloat16), frag_major(w1), frag_major(w2), y, M=M, T=M, F=1024, relu=True,
+                                t_out=hid, res=res, ln=ln)
+            outs += [y, xn.float(), mean, rstd]
+        return tuple(outs)
+
+    g = torch.Generator().manual_seed(9)
+    M = 300
+    args = [torch.randn(M, 128, generator=g), torch.randn(128, 128, generator=g) * 0.1, torch.randn(1024, 128, generator=g) * 0.1,
+            torch.randn(128, 1024, generator=g) * 0.05, torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g),
+            torch.randn(M, 128, generator=g)]
+    go, _, co, _ = run_both(epilogues, *args)
+    for k, (a, b) in enumerate(zip(go, co)):
+        assert rel_l2(a, b) < (3e-3 if k % 4 == 1 else 2e-4), (k, rel_l2(a, b))

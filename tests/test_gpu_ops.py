@@ -172,6 +172,47 @@ def test_pnca_attention(bw):
     assert_close(go[0], co[0], 2e-5, what="pnca nolens")
 
 
+@pytest.mark.parametrize("bw,drop", [(0, 0.0), (3, 0.1), (50, 0.0)])
+def test_pnca_attention_one_launch_equals_per_band_launches(bw, drop, monkeypatch):
+    """kantts_pnca_attn_fwd / _bwd (both bands, dq and dk/dv passes as roles of ONE launch, D recomputed by the dk/dv
+    role) against the per-band launches of the same kernels bodies: identical bits, forward and backward; and against
+    the emulated C ABI."""
+    import itertools
+
+    import kantts._hip.ops as O_
+    from kantts._hip import ops
+
+    B, L, H = 3, 37, 8
+    lens = torch.tensor([37, 12, 25], dtype=torch.int32)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("KANTTS_NO_PNCA_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("KANTTS_NO_PNCA_FUSED", "1")
+        O_._seed_counter = itertools.count(31)
+        qkv = _rand(B, L, 3 * H * 16, seed=1, grad=True).cuda().detach().requires_grad_(True)
+        hkv = _rand(B, L, 2 * H * 16, seed=2, grad=True).cuda().detach().requires_grad_(True)
+        ox, oh, _, _ = ops.pnca_attention(qkv, hkv, lens.cuda(), bw, bw, H, drop_p=drop)
+        w = torch.randn(ox.shape, generator=torch.Generator().manual_seed(3)).cuda()
+        ((ox * w).sum() + (oh * w.flip(0)).sum()).backward()
+        return ox.detach(), oh.detach(), qkv.grad, hkv.grad
+
+    a, b = run(True), run(False)
+    for x, y, nm in zip(a, b, ("ctx x", "ctx h", "dqkv", "dhkv")):
+        assert torch.equal(x, y), nm
+
+    def f(qkv, hkv, lens):
+        O_._seed_counter = itertools.count(31)
+        return ops.pnca_attention(qkv, hkv, lens, bw, bw, H, drop_p=drop)[:2]
+
+    monkeypatch.delenv("KANTTS_NO_PNCA_FUSED", raising=False)
+    go, gg, co, cg = run_both(f, _rand(B, L, 3 * H * 16, seed=1, grad=True), _rand(B, L, 2 * H * 16, seed=2, grad=True), lens)
+    assert_close(go[0], co[0], 2e-5, what="x ctx")
+    assert_close(go[1], co[1], 2e-5, what="h ctx")
+    assert rel_l2(gg[0], cg[0]) < 1e-4 and rel_l2(gg[1], cg[1]) < 1e-4
+
+
 def test_attention_long_sequence_fallback_kernels():
     """L = 600 does not fit the 64 KB LDS staging -> direct-from-global kernels."""
     from kantts._hip import ops
