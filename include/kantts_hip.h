@@ -158,15 +158,16 @@ int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int
 
 /* Both attentions of a PNCA block (MultiHeadPNCAAttention.forward, kantts/models/sambert/__init__.py:256-306: the causal
  * band over x and the look-ahead band over the memory share the queries) as ONE launch forward and ONE backward.
- * qkv (B,L,3D) = fused x projection [q | k_x | v_x], hkv (B,L,2D) = memory projection [k_h | v_h], D = H*16;
+ * qkv (B,L,3D) = fused x projection [q | k_x | v_x], hkv = memory projection [k_h | v_h] with row pitch ldh >= 2D (the
+ * twelve blocks' projections are columns of one (B,L,12*2D) GEMM output), D = H*16;
  * ox / oh (B,L,D) contexts, lse_x / lse_h (B,H,L) saved.  Backward: dqkv (B,L,3D) = [dq of the x band | dk_x | dv_x],
  * dqh (B,L,D) = dq of the memory band (the caller sums the two), dhkv (B,L,2D) = [dk_h | dv_h]; every output is written,
  * none accumulated.  Same masks, dropout streams (seed_x / seed_h) and padded-row rules as kantts_attn_fwd / _bwd with
  * mode 1 / mode 2.  KANTTS_E_UNSUPPORTED if a head's rows do not fit in LDS (L > ~440): use the per-band calls. */
-int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, float* ox, float* oh, float* lse_x, float* lse_h,
+int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, int ldh, float* ox, float* oh, float* lse_x, float* lse_h,
                          const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B, int H, int L, int d_head,
                          float drop_p, uint64_t seed_x, uint64_t seed_h, const uint64_t* seed_dev, void* stream);
-int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, const float* ox, const float* oh, const float* d_ox,
+int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, int ldh, const float* ox, const float* oh, const float* d_ox,
                          const float* d_oh, const float* lse_x, const float* lse_h, float* dqkv, float* dqh, float* dhkv,
                          const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B, int H, int L, int d_head,
                          float drop_p, uint64_t seed_x, uint64_t seed_h, const uint64_t* seed_dev, void* stream);

@@ -20,6 +20,8 @@
 //
 // Layout: q/k/v/o are addressed as ptr[(b*L + t)*ld + h*16 + d], i.e. straight out of / into the
 // fused QKV projection buffers; probs (optional) is (H*B, L, L) head-major like the reference.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define DH 16
@@ -490,6 +492,255 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_lds_kernel(const Attn
   attn_bwd_dkv_lds_body<false>(a, blockIdx.x, blockIdx.y, sm);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Key-padding mode (encoder self-attention: every query attends to all len keys) with P lanes per query.  With one
+// thread per query an L = 64 encoder head keeps ONE wave of its workgroup busy for 2 x 64 sequential keys (29 us per
+// launch, profiles/r03_runR_*); here lane `part` of a query's group takes the 4-key blocks jb = part (mod P) -- blocks, not
+// single keys, so that the dropout hash, which covers 4 consecutive keys, is still evaluated once per block -- and the
+// partial max / sum / context meet through DPP quad permutes.  Same masks, same dropout stream, summation order differs.
+__device__ __forceinline__ float at_dpp_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float at_dpp_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float at_quad_sum(float v) {
+  v += at_dpp_xor1(v);
+  v += at_dpp_xor2(v);
+  return v;
+}
+__device__ __forceinline__ float at_quad_max(float v) {
+  v = fmaxf(v, at_dpp_xor1(v));
+  v = fmaxf(v, at_dpp_xor2(v));
+  return v;
+}
+#define AT_P 4
+#define AT_QPR (AT_THREADS / AT_P)  // queries (keys) per round of the workgroup
+
+__device__ __forceinline__ void attn_fwd_lds_quad_body(const AttnArgs& a, const int h, const int b, float* sm) {
+  float* Ks = sm;
+  float* Vs = sm + a.L * AT_LD;
+  const int part = threadIdx.x & (AT_P - 1), iq = threadIdx.x >> 2;
+  float q0[DH];
+  load16(a.q + ((long long)b * a.L + min(iq, a.L - 1)) * a.ldq + h * DH, q0);
+  stage_rows(a.k + (long long)b * a.L * a.ldk + h * DH, a.ldk, a.L, Ks);
+  stage_rows(a.v + (long long)b * a.L * a.ldv + h * DH, a.ldv, a.L, Vs);
+  __syncthreads();
+  const int len = a.lens ? a.lens[b] : a.L;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  const int hi = len - 1;  // mode 0: keys [0, len - 1] for every query
+  const int rounds = (a.L + AT_QPR - 1) / AT_QPR;
+  for (int r = 0; r < rounds; ++r) {  // all four lanes of a group run every round (DPP needs them), stores are guarded
+    const int i = r * AT_QPR + iq;
+    const bool live = i < a.L;
+    const long long row = (long long)b * a.L + min(i, a.L - 1);
+    float q[DH], o[DH];
+    if (r == 0) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) q[d] = q0[d];
+    } else {
+      load16(a.q + row * a.ldq + h * DH, q);
+    }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = 0.f;
+    float m = -INFINITY;
+    for (int jb = part; jb * 4 <= hi; jb += AT_P)
+      for (int j = jb * 4; j <= min(hi, jb * 4 + 3); ++j) m = fmaxf(m, dot16(q, Ks + j * AT_LD) * a.scale);
+    m = at_quad_max(m);
+    float l = 0.f;
+    const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + min(i, a.L - 1)) * (uint64_t)a.L;
+    KanttsDropSeq drop(a.drop_p, seed);
+    for (int jb = part; jb * 4 <= hi; jb += AT_P)
+      for (int j = jb * 4; j <= min(hi, jb * 4 + 3); ++j) {
+        const float e = expf(dot16(q, Ks + j * AT_LD) * a.scale - m);
+        l += e;
+        const float ed = e * drop.scale(rng_row + j);
+        const float* vv = Vs + j * AT_LD;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
+      }
+    l = at_quad_sum(l);
+    const float inv = (hi >= 0) ? 1.f / l : 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = at_quad_sum(o[d]) * inv;
+    if (live) {
+      // lane `part` stores dims [4 part, 4 part + 4): the group writes the 64-byte row piece with one 16-byte store each
+      float4 w;
+      w.x = part == 0 ? o[0] : part == 1 ? o[4] : part == 2 ? o[8] : o[12];
+      w.y = part == 0 ? o[1] : part == 1 ? o[5] : part == 2 ? o[9] : o[13];
+      w.z = part == 0 ? o[2] : part == 1 ? o[6] : part == 2 ? o[10] : o[14];
+      w.w = part == 0 ? o[3] : part == 1 ? o[7] : part == 2 ? o[11] : o[15];
+      *reinterpret_cast<float4*>(a.o + row * a.ldo + h * DH + part * 4) = w;
+      if (part == 0) a.lse[((long long)b * a.H + h) * a.L + i] = (hi >= 0) ? (m + logf(l)) : 0.f;
+      if (a.probs) {
+        float* prow = a.probs + (((long long)h * a.B + b) * a.L + i) * a.L;
+        for (int j = part; j < a.L; j += AT_P) {
+          float p = 0.f;
+          if (j <= hi) p = expf(dot16(q, Ks + j * AT_LD) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+          prow[j] = p;
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void attn_bwd_dq_lds_quad_body(const AttnArgs& a, const int h, const int b, float* sm) {
+  float* Ks = sm;
+  float* Vs = sm + a.L * AT_LD;
+  const int part = threadIdx.x & (AT_P - 1), iq = threadIdx.x >> 2;
+  float q0[DH], go0[DH], oo0[DH];
+  {
+    const long long r0 = (long long)b * a.L + min(iq, a.L - 1);
+    load16(a.q + r0 * a.ldq + h * DH, q0);
+    load16(a.d_o + r0 * a.lddo + h * DH, go0);
+    load16(a.o + r0 * a.ldo + h * DH, oo0);
+  }
+  stage_rows(a.k + (long long)b * a.L * a.ldk + h * DH, a.ldk, a.L, Ks);
+  stage_rows(a.v + (long long)b * a.L * a.ldv + h * DH, a.ldv, a.L, Vs);
+  __syncthreads();
+  const int len = a.lens ? a.lens[b] : a.L;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  const int hi = len - 1;
+  const int rounds = (a.L + AT_QPR - 1) / AT_QPR;
+  for (int r = 0; r < rounds; ++r) {
+    const int i = r * AT_QPR + iq;
+    const bool live = i < a.L;
+    const long long row = (long long)b * a.L + min(i, a.L - 1);
+    float q[DH], go[DH], oo[DH], dq[DH];
+    if (r == 0) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        q[d] = q0[d];
+        go[d] = go0[d];
+        oo[d] = oo0[d];
+      }
+    } else {
+      load16(a.q + row * a.ldq + h * DH, q);
+      load16(a.d_o + row * a.lddo + h * DH, go);
+      load16(a.o + row * a.ldo + h * DH, oo);
+    }
+    const float D = dot16(go, oo);
+    const long long sidx = ((long long)b * a.H + h) * a.L + min(i, a.L - 1);
+    const float lse = a.lse[sidx];
+    if (a.dvec && live && part == 0) a.dvec[sidx] = D;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+    const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + min(i, a.L - 1)) * (uint64_t)a.L;
+    KanttsDropSeq drop(a.drop_p, seed);
+    for (int jb = part; jb * 4 <= hi; jb += AT_P)
+      for (int j = jb * 4; j <= min(hi, jb * 4 + 3); ++j) {
+        const float* kk = Ks + j * AT_LD;
+        const float p = expf(dot16(q, kk) * a.scale - lse);
+        const float dp = dot16(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
+        const float ds = p * (dp - D) * a.scale;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
+      }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = at_quad_sum(dq[d]);
+    if (live) {
+      float4 w;
+      w.x = part == 0 ? dq[0] : part == 1 ? dq[4] : part == 2 ? dq[8] : dq[12];
+      w.y = part == 0 ? dq[1] : part == 1 ? dq[5] : part == 2 ? dq[9] : dq[13];
+      w.z = part == 0 ? dq[2] : part == 1 ? dq[6] : part == 2 ? dq[10] : dq[14];
+      w.w = part == 0 ? dq[3] : part == 1 ? dq[7] : part == 2 ? dq[11] : dq[15];
+      float4* dst = reinterpret_cast<float4*>(a.dq + row * a.lddq + h * DH + part * 4);
+      if (a.accumulate_dq) {
+        const float4 old = *dst;
+        w.x += old.x; w.y += old.y; w.z += old.z; w.w += old.w;
+      }
+      *dst = w;
+    }
+  }
+}
+
+// key j <-> group, lane `part` walks the queries i = part (mod P); D recomputed from the O rows (see attn_bwd_dkv_lds_body)
+__device__ __forceinline__ void attn_bwd_dkv_lds_quad_body(const AttnArgs& a, const int h, const int b, float* sm) {
+  float* Qs = sm;
+  float* Gs = sm + a.L * AT_LD;
+  float* Ls = Gs + a.L * AT_LD;  // lse
+  float* Ds = Ls + a.L;          // dvec
+  const int part = threadIdx.x & (AT_P - 1), jq = threadIdx.x >> 2;
+  float kk0[DH], vv0[DH];
+  {
+    const long long r0 = (long long)b * a.L + min(jq, a.L - 1);
+    load16(a.k + r0 * a.ldk + h * DH, kk0);
+    load16(a.v + r0 * a.ldv + h * DH, vv0);
+  }
+  stage_rows(a.q + (long long)b * a.L * a.ldq + h * DH, a.ldq, a.L, Qs);
+  stage_rows(a.d_o + (long long)b * a.L * a.lddo + h * DH, a.lddo, a.L, Gs);
+  const long long sbase = ((long long)b * a.H + h) * a.L;
+  for (int i = threadIdx.x; i < a.L; i += AT_THREADS) {
+    Ls[i] = a.lse[sbase + i];
+    const long long row = (long long)b * a.L + i;
+    float go[DH], oo[DH];
+    load16(a.d_o + row * a.lddo + h * DH, go);
+    load16(a.o + row * a.ldo + h * DH, oo);
+    Ds[i] = dot16(go, oo);
+  }
+  __syncthreads();
+  const int len = a.lens ? a.lens[b] : a.L;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  const int rounds = (a.L + AT_QPR - 1) / AT_QPR;
+  for (int r = 0; r < rounds; ++r) {
+    const int j = r * AT_QPR + jq;
+    const bool live = j < a.L;
+    const long long krow = (long long)b * a.L + min(j, a.L - 1);
+    float kk[DH], vv[DH], dk[DH], dv[DH];
+    if (r == 0) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) {
+        kk[d] = kk0[d];
+        vv[d] = vv0[d];
+      }
+    } else {
+      load16(a.k + krow * a.ldk + h * DH, kk);
+      load16(a.v + krow * a.ldv + h * DH, vv);
+    }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      dk[d] = 0.f;
+      dv[d] = 0.f;
+    }
+    // mode 0: query i sees key j iff j <= len - 1 (every query row, padded ones included, as the forward computes them)
+    if (live && j <= len - 1) {
+      for (int i = part; i < a.L; i += AT_P) {
+        const float* q = Qs + i * AT_LD;
+        const float* go = Gs + i * AT_LD;
+        const float p = expf(dot16(q, kk) * a.scale - Ls[i]);
+        const float dsc =
+            kantts_dropout_scale(a.drop_p, seed, ((((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L) + j);
+        const float pd = p * dsc;
+        const float dp = dot16(go, vv) * dsc;
+        const float ds = p * (dp - Ds[i]) * a.scale;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+          dv[d] = fmaf(pd, go[d], dv[d]);
+          dk[d] = fmaf(ds, q[d], dk[d]);
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+      dk[d] = at_quad_sum(dk[d]);
+      dv[d] = at_quad_sum(dv[d]);
+    }
+    if (live) {
+      float4 wk, wv;
+      wk.x = part == 0 ? dk[0] : part == 1 ? dk[4] : part == 2 ? dk[8] : dk[12];
+      wk.y = part == 0 ? dk[1] : part == 1 ? dk[5] : part == 2 ? dk[9] : dk[13];
+      wk.z = part == 0 ? dk[2] : part == 1 ? dk[6] : part == 2 ? dk[10] : dk[14];
+      wk.w = part == 0 ? dk[3] : part == 1 ? dk[7] : part == 2 ? dk[11] : dk[15];
+      wv.x = part == 0 ? dv[0] : part == 1 ? dv[4] : part == 2 ? dv[8] : dv[12];
+      wv.y = part == 0 ? dv[1] : part == 1 ? dv[5] : part == 2 ? dv[9] : dv[13];
+      wv.z = part == 0 ? dv[2] : part == 1 ? dv[6] : part == 2 ? dv[10] : dv[14];
+      wv.w = part == 0 ? dv[3] : part == 1 ? dv[7] : part == 2 ? dv[11] : dv[15];
+      *reinterpret_cast<float4*>(a.dk + krow * a.lddk + h * DH + part * 4) = wk;
+      *reinterpret_cast<float4*>(a.dv + krow * a.lddv + h * DH + part * 4) = wv;
+    }
+  }
+}
+
 // Up to four attention passes over the same (B, H) grid as ONE launch: blockIdx.z picks the pass.  A PNCA block's
 // forward is two passes (causal band over x, look-ahead band over the memory), its backward four (dq and dk/dv of each
 // band); an encoder block's backward two.  The passes of a group are independent (dk/dv recomputes D), so nothing orders
@@ -501,6 +752,7 @@ struct AttnMulti {
   AttnArgs p[4];
   int role[4];
 };
+template <bool QUAD>  // QUAD: key-padding problems, four lanes per query / key (separate kernel: separate register budget)
 __global__ __launch_bounds__(AT_THREADS) void attn_multi_lds_kernel(const AttnMulti m) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int z = blockIdx.z;
@@ -517,12 +769,26 @@ __global__ __launch_bounds__(AT_THREADS) void attn_multi_lds_kernel(const AttnMu
     a = m.p[3];
     role = m.role[3];
   }
-  if (role == AT_ROLE_FWD)
-    attn_fwd_lds_body(a, blockIdx.x, blockIdx.y, sm);
-  else if (role == AT_ROLE_DQ)
-    attn_bwd_dq_lds_body(a, blockIdx.x, blockIdx.y, sm);
-  else
-    attn_bwd_dkv_lds_body<true>(a, blockIdx.x, blockIdx.y, sm);
+  if (QUAD) {
+    if (role == AT_ROLE_FWD)
+      attn_fwd_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
+    else if (role == AT_ROLE_DQ)
+      attn_bwd_dq_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
+    else
+      attn_bwd_dkv_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
+  } else {
+    if (role == AT_ROLE_FWD)
+      attn_fwd_lds_body(a, blockIdx.x, blockIdx.y, sm);
+    else if (role == AT_ROLE_DQ)
+      attn_bwd_dq_lds_body(a, blockIdx.x, blockIdx.y, sm);
+    else
+      attn_bwd_dkv_lds_body<true>(a, blockIdx.x, blockIdx.y, sm);
+  }
+}
+
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_quad_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  attn_fwd_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
 }
 
 static inline size_t attn_lds_bytes(int L, bool dkv) {
@@ -549,7 +815,11 @@ extern "C" int kantts_attn_fwd(const float* q, const float* k, const float* v, i
   int rc = attn_check(a);
   if (rc) return rc;
   if (B == 0 || L == 0) return KANTTS_OK;
-  if (attn_lds_bytes(L, false) <= 64 * 1024)
+  static const bool no_quad = getenv("KANTTS_ATTN_NO_QUAD") != nullptr;
+  if (attn_lds_bytes(L, false) <= 64 * 1024 && mode == 0 && !no_quad)
+    hipLaunchKernelGGL(attn_fwd_lds_quad_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, false),
+                       (hipStream_t)stream, a);
+  else if (attn_lds_bytes(L, false) <= 64 * 1024)
     hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, false), (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(kantts_cdiv(L, 128), H, B), dim3(128), 0, (hipStream_t)stream, a);
@@ -576,8 +846,13 @@ extern "C" int kantts_attn_bwd(const float* q, const float* k, const float* v, i
     AttnMulti m = {};
     m.p[0] = a; m.role[0] = AT_ROLE_DQ;
     m.p[1] = a; m.role[1] = AT_ROLE_DKV;
-    hipLaunchKernelGGL(attn_multi_lds_kernel, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, true),
-                       (hipStream_t)stream, m);
+    static const bool no_quad = getenv("KANTTS_ATTN_NO_QUAD") != nullptr;
+    if (mode == 0 && !no_quad)
+      hipLaunchKernelGGL(attn_multi_lds_kernel<true>, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, true),
+                         (hipStream_t)stream, m);
+    else
+      hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, true),
+                         (hipStream_t)stream, m);
   } else {
     dim3 grid(kantts_cdiv(L, 128), H, B), block(128);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, (hipStream_t)stream, a);
@@ -603,33 +878,35 @@ static void pnca_fill(AttnArgs& a, const float* qkv, const float* kv, int ldkv, 
   a.scale = 0.25f; a.drop_p = drop_p; a.seed = seed; a.seed_dev = seed_dev;
 }
 
-extern "C" int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, float* ox, float* oh, float* lse_x, float* lse_h,
+extern "C" int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, int ldh, float* ox, float* oh, float* lse_x, float* lse_h,
                                     const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B, int H, int L,
                                     int d_head, float drop_p, uint64_t seed_x, uint64_t seed_h, const uint64_t* seed_dev,
                                     void* stream) {
   if (d_head != DH) return KANTTS_E_UNSUPPORTED;
-  if (!qkv || !hkv || !ox || !oh || !lse_x || !lse_h || B < 0 || H < 1 || L < 0) return KANTTS_E_BADARG;
+  if (!qkv || !hkv || !ox || !oh || !lse_x || !lse_h || B < 0 || H < 1 || L < 0 || ldh < 2 * H * DH || (ldh & 3))
+    return KANTTS_E_BADARG;
   if (B == 0 || L == 0) return KANTTS_OK;
   if (attn_lds_bytes(L, false) > 64 * 1024) return KANTTS_E_UNSUPPORTED;
   const int D = H * DH;
   AttnMulti m = {};
   pnca_fill(m.p[0], qkv, qkv, 3 * D, D, ox, lse_x, lens, bw_dev, bw_x, B, H, L, 1, drop_p, seed_x, seed_dev);
-  pnca_fill(m.p[1], qkv, hkv, 2 * D, 0, oh, lse_h, lens, bw_dev, bw_h, B, H, L, 2, drop_p, seed_h, seed_dev);
+  pnca_fill(m.p[1], qkv, hkv, ldh, 0, oh, lse_h, lens, bw_dev, bw_h, B, H, L, 2, drop_p, seed_h, seed_dev);
   m.role[0] = m.role[1] = AT_ROLE_FWD;
-  hipLaunchKernelGGL(attn_multi_lds_kernel, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, false), (hipStream_t)stream,
-                     m);
+  hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, false),
+                     (hipStream_t)stream, m);
   KANTTS_CHECK_LAUNCH();
 }
 
 // dqkv (B, L, 3D): columns [0, D) receive the x band's query gradient, [D, 3D) its key / value gradients; dqh (B, L, D)
 // the memory band's query gradient (the caller adds it onto dqkv[..., :D]); dhkv (B, L, 2D) the memory K/V gradients.
-extern "C" int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, const float* ox, const float* oh, const float* d_ox,
+extern "C" int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, int ldh, const float* ox, const float* oh, const float* d_ox,
                                     const float* d_oh, const float* lse_x, const float* lse_h, float* dqkv, float* dqh,
                                     float* dhkv, const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B,
                                     int H, int L, int d_head, float drop_p, uint64_t seed_x, uint64_t seed_h,
                                     const uint64_t* seed_dev, void* stream) {
   if (d_head != DH) return KANTTS_E_UNSUPPORTED;
-  if (!qkv || !hkv || !ox || !oh || !d_ox || !d_oh || !lse_x || !lse_h || !dqkv || !dqh || !dhkv || B < 0 || H < 1 || L < 0)
+  if (!qkv || !hkv || !ox || !oh || !d_ox || !d_oh || !lse_x || !lse_h || !dqkv || !dqh || !dhkv || B < 0 || H < 1 || L < 0 ||
+      ldh < 2 * H * DH || (ldh & 3))
     return KANTTS_E_BADARG;
   if (B == 0 || L == 0) return KANTTS_OK;
   if (attn_lds_bytes(L, true) > 64 * 1024) return KANTTS_E_UNSUPPORTED;
@@ -639,15 +916,15 @@ extern "C" int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, const fl
   pnca_fill(x, qkv, qkv, 3 * D, D, const_cast<float*>(ox), const_cast<float*>(lse_x), lens, bw_dev, bw_x, B, H, L, 1, drop_p,
             seed_x, seed_dev);
   x.d_o = d_ox; x.lddo = D; x.dq = dqkv; x.dk = dqkv + D; x.dv = dqkv + 2 * D; x.lddq = x.lddk = x.lddv = 3 * D;
-  pnca_fill(hh, qkv, hkv, 2 * D, 0, const_cast<float*>(oh), const_cast<float*>(lse_h), lens, bw_dev, bw_h, B, H, L, 2, drop_p,
+  pnca_fill(hh, qkv, hkv, ldh, 0, const_cast<float*>(oh), const_cast<float*>(lse_h), lens, bw_dev, bw_h, B, H, L, 2, drop_p,
             seed_h, seed_dev);
   hh.d_o = d_oh; hh.lddo = D; hh.dq = dqh; hh.lddq = D; hh.dk = dhkv; hh.dv = dhkv + D; hh.lddk = hh.lddv = 2 * D;
   m.p[0] = x; m.role[0] = AT_ROLE_DQ;
   m.p[1] = x; m.role[1] = AT_ROLE_DKV;
   m.p[2] = hh; m.role[2] = AT_ROLE_DQ;
   m.p[3] = hh; m.role[3] = AT_ROLE_DKV;
-  hipLaunchKernelGGL(attn_multi_lds_kernel, dim3(H, B, 4), dim3(AT_THREADS), attn_lds_bytes(L, true), (hipStream_t)stream,
-                     m);
+  hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 4), dim3(AT_THREADS), attn_lds_bytes(L, true),
+                     (hipStream_t)stream, m);
   KANTTS_CHECK_LAUNCH();
 }
 

@@ -201,8 +201,8 @@ def lib():
         L.kantts_attn_fwd.argtypes = [p, p, p, i, i, i, p, i, p, p, p, p, i, i, i, i, i, i, f, u64, p, p]
         L.kantts_attn_bwd.argtypes = [p, p, p, i, i, i, p, i, p, i, p, p, p, p, p, i, i, i, i, p, p, i, i, i, i, i,
                                       i, f, u64, p, p]
-        L.kantts_pnca_attn_fwd.argtypes = [p, p, p, p, p, p, p, p, i, i, i, i, i, i, f, u64, u64, p, p]
-        L.kantts_pnca_attn_bwd.argtypes = [p, p, p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, i, f, u64, u64, p, p]
+        L.kantts_pnca_attn_fwd.argtypes = [p, p, i, p, p, p, p, p, p, i, i, i, i, i, i, f, u64, u64, p, p]
+        L.kantts_pnca_attn_bwd.argtypes = [p, p, i, p, p, p, p, p, p, p, p, p, p, p, i, i, i, i, i, i, f, u64, u64, p, p]
         L.kantts_lstm_fwd.argtypes = [p, p, p, p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_attn_decode.argtypes = [p, p, p, i, i, i, p, i, p, p, i, i, i, i, i, i, i, p]
         L.kantts_lstm_cell.argtypes = [p, p, p, p, i, i, p]

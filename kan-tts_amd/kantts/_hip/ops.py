@@ -642,10 +642,16 @@ class _PncaAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, hkv, lens, bw_dev, bw_x, bw_h, H, drop_p, want_probs):
-        qkv, hkv = _c(qkv), _c(hkv)
+        qkv = _c(qkv)
         B, L, W = qkv.shape
         D = H * 16
-        q2, h2 = qkv.view(B * L, W), hkv.view(B * L, 2 * D)
+        # the memory projection may be a column block of a wider buffer (all blocks' projections from one GEMM): rows at
+        # a uniform pitch are all the fused kernels need
+        if not (hkv.dim() == 3 and hkv.stride(2) == 1 and hkv.stride(0) == L * hkv.stride(1) and hkv.stride(1) % 4 == 0):
+            hkv = hkv.contiguous()
+        ldh = hkv.stride(1)
+        q2 = qkv.view(B * L, W)
+        h2 = hkv.as_strided((B * L, 2 * D), (ldh, 1), hkv.storage_offset())
         sx = next_seed() if drop_p > 0 else 0
         sh = next_seed() if drop_p > 0 else 0
         ctx.save_cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)
@@ -656,7 +662,7 @@ class _PncaAttention(torch.autograd.Function):
             oh = torch.empty((B * L, D), device=dev, dtype=torch.float32)
             lsex = torch.empty((B, H, L), device=dev, dtype=torch.float32)
             lseh = torch.empty((B, H, L), device=dev, dtype=torch.float32)
-            rc = lib().kantts_pnca_attn_fwd(ptr(q2), ptr(h2), ptr(ox), ptr(oh), ptr(lsex), ptr(lseh), ptr(lens), ptr(bw_dev),
+            rc = lib().kantts_pnca_attn_fwd(ptr(q2), ptr(h2), ldh, ptr(ox), ptr(oh), ptr(lsex), ptr(lseh), ptr(lens), ptr(bw_dev),
                                             int(bw_x), int(bw_h), B, H, L, 16, float(drop_p), int(sx), int(sh),
                                             ptr(rng_state(dev)) if drop_p > 0 else None, stream())
             if rc == 0:
@@ -665,6 +671,7 @@ class _PncaAttention(torch.autograd.Function):
                 return ox.view(B, L, D), oh.view(B, L, D), None, None
             if rc != E_UNSUPPORTED:
                 check(rc, "pnca_attn_fwd")
+        h2 = _c(h2)  # the per-band launches take the row pitch from the shape
         (ox, lsex, px), (oh, lseh, ph) = _pair_on_two_streams(
             lambda: _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, bw_dev, bw_x, B, H, L, MODE_BAND_X, drop_p, sx, want_probs),
             lambda: _attn_fwd(q2, 0, h2, 0, h2, D, lens, bw_dev, bw_h, B, H, L, MODE_BAND_H, drop_p, sh, want_probs),
@@ -682,10 +689,11 @@ class _PncaAttention(torch.autograd.Function):
         D = H * 16
         d_ox, d_oh = _c(d_ox).view(B * L, D), _c(d_oh).view(B * L, D)
         dqkv = torch.empty_like(q2)
-        dhkv = torch.empty_like(h2)
+        dhkv = torch.empty((B * L, 2 * D), device=q2.device, dtype=torch.float32)
         if not os.environ.get("KANTTS_NO_PNCA_FUSED"):
             dqh = torch.empty((B * L, D), device=q2.device, dtype=torch.float32)
-            rc = lib().kantts_pnca_attn_bwd(ptr(q2), ptr(h2), ptr(ox), ptr(oh), ptr(d_ox), ptr(d_oh), ptr(lsex), ptr(lseh),
+            rc = lib().kantts_pnca_attn_bwd(ptr(q2), ptr(h2), h2.stride(0), ptr(ox), ptr(oh), ptr(d_ox), ptr(d_oh), ptr(lsex),
+                                            ptr(lseh),
                                             ptr(dqkv), ptr(dqh), ptr(dhkv), ptr(lens), ptr(bw_dev), int(bw_x), int(bw_h), B,
                                             H, L, 16, float(drop_p), int(sx), int(sh),
                                             ptr(rng_state(q2.device)) if drop_p > 0 else None, stream())
@@ -694,6 +702,7 @@ class _PncaAttention(torch.autograd.Function):
                 return dqkv.view(B, L, 3 * D), dhkv.view(B, L, 2 * D), None, None, None, None, None, None, None
             if rc != E_UNSUPPORTED:
                 check(rc, "pnca_attn_bwd")
+        h2 = _c(h2)
 
         def bwd_h():
             # the h band's query gradient goes to its own buffer: the two bands then share nothing they write

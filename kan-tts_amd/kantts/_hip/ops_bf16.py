@@ -491,10 +491,13 @@ class _FusedFFNB(torch.autograd.Function):
         return (dh.view(*ctx.lead, C), dw1, db1, dw2, db2, d_res) + (None,) * 9
 
 
+SHARED_ONE_GEMM = {"on": not os.environ.get("KANTTS_NO_SHARED_ONE_GEMM")}  # A/B switch
+
+
 class _SharedInputLinearsB(torch.autograd.Function):
     """n Linear layers that read the SAME input (the memory K/V projections ``w_h_kv`` of every PNCA block,
     kantts/models/sambert/__init__.py:286-299: all twelve read the length-regulated memory tensor).  Forward: one launch
-    per layer (independent outputs).  Backward: ONE launch for the input gradient -- sum_b dy_b . W_b is a contraction with
+    over the stacked weights when the layers have one shape (else one per layer).  Backward: ONE launch for the input gradient -- sum_b dy_b . W_b is a contraction with
     one segment per layer -- instead of n launches plus the n - 1 accumulation adds autograd inserts for a tensor with n
     consumers; weight / bias gradients as everywhere (deferred, grouped by shape)."""
 
@@ -505,12 +508,24 @@ class _SharedInputLinearsB(torch.autograd.Function):
         lead, K = x.shape[:-1], x.shape[-1]
         M = int(math.prod(lead))
         outs = []
-        for w, b, wb in zip(ws, bs, wbs):
-            N = w.shape[0]
-            y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-            if not bgemm_nt([(x.detach(), K, wb, K, K, 0)], M, N, y, N, bias=b):
-                raise RuntimeError("bgemm_nt declined a shared-input projection")
-            outs.append(y.view(*lead, N))
+        same = all(w.shape == ws[0].shape for w in ws) and (all(b is not None for b in bs) or all(b is None for b in bs))
+        if same and SHARED_ONE_GEMM["on"]:
+            # ONE launch: the n weights stacked (n*N, K) (a 1 MB bf16 copy per step), the n outputs are column blocks of
+            # one (M, n*N) buffer -- consumers take the row pitch (ops._PncaAttention)
+            N = ws[0].shape[0]
+            wcat = torch.cat([wb.view(N, K) for wb in wbs], 0)
+            bcat = torch.cat(list(bs), 0) if bs[0] is not None else None
+            y = torch.empty((M, n * N), device=x.device, dtype=torch.float32)
+            if not bgemm_nt([(x.detach(), K, wcat, K, K, 0)], M, n * N, y, n * N, bias=bcat):
+                raise RuntimeError("bgemm_nt declined the stacked shared-input projection")
+            outs = list(y.view(*lead, n, N).unbind(-2))
+        else:
+            for w, b, wb in zip(ws, bs, wbs):
+                N = w.shape[0]
+                y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+                if not bgemm_nt([(x.detach(), K, wb, K, K, 0)], M, N, y, N, bias=b):
+                    raise RuntimeError("bgemm_nt declined a shared-input projection")
+                outs.append(y.view(*lead, N))
         ctx.dims = (n, M, K, lead, [tuple(w.shape) for w in ws], [b is not None for b in bs], x.dtype)
         ctx.save_for_backward(x.detach(), *wbs)
         return tuple(outs)

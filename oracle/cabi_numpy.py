@@ -614,25 +614,25 @@ class EmulatedLib:
         scatter(dv, lddv, dV, 0)
         return 0
 
-    def kantts_pnca_attn_fwd(self, qkv, hkv, ox, oh, lse_x, lse_h, lens, bw_dev, bw_x, bw_h, B, H, L, d_head, drop_p,
+    def kantts_pnca_attn_fwd(self, qkv, hkv, ldh, ox, oh, lse_x, lse_h, lens, bw_dev, bw_x, bw_h, B, H, L, d_head, drop_p,
                              seed_x, seed_h, seed_dev, stream):
         """Both bands of a PNCA block: the per-band emulation twice (K/V of the x band at columns [D, 3D) of qkv)."""
         D = H * 16
         qkv, hkv = int(qkv), int(hkv)
         self.kantts_attn_fwd(qkv, qkv + 4 * D, qkv + 8 * D, 3 * D, 3 * D, 3 * D, ox, D, lse_x, None, lens, bw_dev, bw_x, B,
                              H, L, d_head, 1, drop_p, seed_x, seed_dev, stream)
-        self.kantts_attn_fwd(qkv, hkv, hkv + 4 * D, 3 * D, 2 * D, 2 * D, oh, D, lse_h, None, lens, bw_dev, bw_h, B, H, L,
+        self.kantts_attn_fwd(qkv, hkv, hkv + 4 * D, 3 * D, ldh, ldh, oh, D, lse_h, None, lens, bw_dev, bw_h, B, H, L,
                              d_head, 2, drop_p, seed_h, seed_dev, stream)
         return 0
 
-    def kantts_pnca_attn_bwd(self, qkv, hkv, ox, oh, d_ox, d_oh, lse_x, lse_h, dqkv, dqh, dhkv, lens, bw_dev, bw_x, bw_h,
+    def kantts_pnca_attn_bwd(self, qkv, hkv, ldh, ox, oh, d_ox, d_oh, lse_x, lse_h, dqkv, dqh, dhkv, lens, bw_dev, bw_x, bw_h,
                              B, H, L, d_head, drop_p, seed_x, seed_h, seed_dev, stream):
         D = H * 16
         qkv, hkv, dqkv, dhkv = int(qkv), int(hkv), int(dqkv), int(dhkv)
         self.kantts_attn_bwd(qkv, qkv + 4 * D, qkv + 8 * D, 3 * D, 3 * D, 3 * D, ox, D, d_ox, D, lse_x, None, dqkv,
                              dqkv + 4 * D, dqkv + 8 * D, 3 * D, 3 * D, 3 * D, 0, lens, bw_dev, bw_x, B, H, L, d_head, 1,
                              drop_p, seed_x, seed_dev, stream)
-        self.kantts_attn_bwd(qkv, hkv, hkv + 4 * D, 3 * D, 2 * D, 2 * D, oh, D, d_oh, D, lse_h, None, dqh, dhkv,
+        self.kantts_attn_bwd(qkv, hkv, hkv + 4 * D, 3 * D, ldh, ldh, oh, D, d_oh, D, lse_h, None, dqh, dhkv,
                              dhkv + 4 * D, D, 2 * D, 2 * D, 0, lens, bw_dev, bw_h, B, H, L, d_head, 2, drop_p, seed_h,
                              seed_dev, stream)
         return 0
