@@ -160,9 +160,11 @@ int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int
  * band over x and the look-ahead band over the memory share the queries) as ONE launch forward and ONE backward.
  * qkv (B,L,3D) = fused x projection [q | k_x | v_x], hkv = memory projection [k_h | v_h] with row pitch ldh >= 2D (the
  * twelve blocks' projections are columns of one (B,L,12*2D) GEMM output), D = H*16;
- * ox / oh (B,L,D) contexts, lse_x / lse_h (B,H,L) saved.  Backward: dqkv (B,L,3D) = [dq of the x band | dk_x | dv_x],
- * dqh (B,L,D) = dq of the memory band (the caller sums the two), dhkv (B,L,2D) = [dk_h | dv_h]; every output is written,
- * none accumulated.  Same masks, dropout streams (seed_x / seed_h) and padded-row rules as kantts_attn_fwd / _bwd with
+ * ox / oh (B,L,D) contexts, lse_x / lse_h (B,H,L) saved.  Backward: dqkv (B,L,3D) = [dq | dk_x | dv_x] with dq the SUM of
+ * both bands' query gradients, dhkv (B,L,2D) = [dk_h | dv_h]; every output is written, none accumulated.  When the four
+ * K/V images of a head do not fit in 64 KB of LDS together (L > ~240) the backward returns 1 instead of KANTTS_OK: dqkv's
+ * first D columns then hold the x band's query gradient only, dqh (B,L,D, required in that case) the memory band's, and
+ * the caller adds them.  Same masks, dropout streams (seed_x / seed_h) and padded-row rules as kantts_attn_fwd / _bwd with
  * mode 1 / mode 2.  KANTTS_E_UNSUPPORTED if a head's rows do not fit in LDS (L > ~440): use the per-band calls. */
 int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, int ldh, float* ox, float* oh, float* lse_x, float* lse_h,
                          const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B, int H, int L, int d_head,

@@ -741,6 +741,66 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_quad_body(const AttnArgs& a, co
   }
 }
 
+// Query gradient of BOTH bands of a PNCA block in one pass (the bands share the queries): K/V of the x band and of the
+// memory band are staged side by side, a thread owns a query, walks one band after the other and stores the sum --
+// instead of two passes into two buffers and an elementwise add over (B*L, D) per block and step.
+__device__ __forceinline__ void attn_bwd_dq2_lds_body(const AttnArgs& ax, const AttnArgs& ah, const int h, const int b,
+                                                      float* sm) {
+  const int L = ax.L;
+  float* Kx = sm;
+  float* Vx = Kx + L * AT_LD;
+  float* Kh = Vx + L * AT_LD;
+  float* Vh = Kh + L * AT_LD;
+  float q0[DH];
+  load16(ax.q + ((long long)b * L + min((int)threadIdx.x, L - 1)) * ax.ldq + h * DH, q0);
+  stage_rows(ax.k + (long long)b * L * ax.ldk + h * DH, ax.ldk, L, Kx);
+  stage_rows(ax.v + (long long)b * L * ax.ldv + h * DH, ax.ldv, L, Vx);
+  stage_rows(ah.k + (long long)b * L * ah.ldk + h * DH, ah.ldk, L, Kh);
+  stage_rows(ah.v + (long long)b * L * ah.ldv + h * DH, ah.ldv, L, Vh);
+  __syncthreads();
+  const int len = ax.lens ? ax.lens[b] : L;
+  const uint64_t seed_off = ax.seed_dev ? *ax.seed_dev : 0ull;
+  for (int i = threadIdx.x; i < L; i += AT_THREADS) {
+    const long long row = (long long)b * L + i;
+    float q[DH], dq[DH];
+    if (i == (int)threadIdx.x) {
+#pragma unroll
+      for (int d = 0; d < DH; ++d) q[d] = q0[d];
+    } else {
+      load16(ax.q + row * ax.ldq + h * DH, q);
+    }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+    const long long sidx = ((long long)b * ax.H + h) * L + i;
+    const uint64_t rng_row = (((uint64_t)h * ax.B + b) * L + i) * (uint64_t)L;
+#pragma unroll
+    for (int band = 0; band < 2; ++band) {
+      const AttnArgs& a = band ? ah : ax;
+      const float* Ks = band ? Kh : Kx;
+      const float* Vs = band ? Vh : Vx;
+      const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+      int lo, hi;
+      key_range(a.mode, i, len, L, bw, lo, hi);
+      if (i >= len) hi = lo - 1;  // padded query rows carry no gradient
+      float go[DH], oo[DH];
+      load16(a.d_o + row * a.lddo + h * DH, go);
+      load16(a.o + row * a.ldo + h * DH, oo);
+      const float D = dot16(go, oo);
+      const float lse = a.lse[sidx];
+      KanttsDropSeq drop(a.drop_p, a.seed + seed_off);
+      for (int j = lo; j <= hi; ++j) {
+        const float* kk = Ks + j * AT_LD;
+        const float p = expf(dot16(q, kk) * a.scale - lse);
+        const float dp = dot16(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
+        const float ds = p * (dp - D) * a.scale;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
+      }
+    }
+    store16(ax.dq + row * ax.lddq + h * DH, dq);
+  }
+}
+
 // Up to four attention passes over the same (B, H) grid as ONE launch: blockIdx.z picks the pass.  A PNCA block's
 // forward is two passes (causal band over x, look-ahead band over the memory), its backward four (dq and dk/dv of each
 // band); an encoder block's backward two.  The passes of a group are independent (dk/dv recomputes D), so nothing orders
@@ -748,6 +808,7 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_quad_body(const AttnArgs& a, co
 #define AT_ROLE_FWD 0
 #define AT_ROLE_DQ 1
 #define AT_ROLE_DKV 2
+#define AT_ROLE_DQ2 3  // p[z] = x band, p[3] = memory band (no block is launched for slot 3 then)
 struct AttnMulti {
   AttnArgs p[4];
   int role[4];
@@ -777,7 +838,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_multi_lds_kernel(const AttnMu
     else
       attn_bwd_dkv_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
   } else {
-    if (role == AT_ROLE_FWD)
+    if (role == AT_ROLE_DQ2)
+      attn_bwd_dq2_lds_body(a, m.p[3], blockIdx.x, blockIdx.y, sm);
+    else if (role == AT_ROLE_FWD)
       attn_fwd_lds_body(a, blockIdx.x, blockIdx.y, sm);
     else if (role == AT_ROLE_DQ)
       attn_bwd_dq_lds_body(a, blockIdx.x, blockIdx.y, sm);
@@ -897,15 +960,17 @@ extern "C" int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, int ldh,
   KANTTS_CHECK_LAUNCH();
 }
 
-// dqkv (B, L, 3D): columns [0, D) receive the x band's query gradient, [D, 3D) its key / value gradients; dqh (B, L, D)
-// the memory band's query gradient (the caller adds it onto dqkv[..., :D]); dhkv (B, L, 2D) the memory K/V gradients.
+// dqkv (B, L, 3D): columns [0, D) receive the query gradient, [D, 3D) the x band's key / value gradients; dhkv (B, L, 2D)
+// the memory K/V gradients.  Return value 1 (instead of KANTTS_OK = 0): the query gradients of the two bands were written
+// SEPARATELY -- the x band's to dqkv[..., :D], the memory band's to dqh (B, L, D) -- and the caller adds them (heads whose
+// four K/V images do not fit in 64 KB of LDS together); dqh may be NULL when the caller knows the summed form applies.
 extern "C" int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, int ldh, const float* ox, const float* oh, const float* d_ox,
                                     const float* d_oh, const float* lse_x, const float* lse_h, float* dqkv, float* dqh,
                                     float* dhkv, const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B,
                                     int H, int L, int d_head, float drop_p, uint64_t seed_x, uint64_t seed_h,
                                     const uint64_t* seed_dev, void* stream) {
   if (d_head != DH) return KANTTS_E_UNSUPPORTED;
-  if (!qkv || !hkv || !ox || !oh || !d_ox || !d_oh || !lse_x || !lse_h || !dqkv || !dqh || !dhkv || B < 0 || H < 1 || L < 0 ||
+  if (!qkv || !hkv || !ox || !oh || !d_ox || !d_oh || !lse_x || !lse_h || !dqkv || !dhkv || B < 0 || H < 1 || L < 0 ||
       ldh < 2 * H * DH || (ldh & 3))
     return KANTTS_E_BADARG;
   if (B == 0 || L == 0) return KANTTS_OK;
@@ -919,13 +984,28 @@ extern "C" int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, int ldh,
   pnca_fill(hh, qkv, hkv, ldh, 0, const_cast<float*>(oh), const_cast<float*>(lse_h), lens, bw_dev, bw_h, B, H, L, 2, drop_p,
             seed_h, seed_dev);
   hh.d_o = d_oh; hh.lddo = D; hh.dq = dqh; hh.lddq = D; hh.dk = dhkv; hh.dv = dhkv + D; hh.lddk = hh.lddv = 2 * D;
+  const size_t lds_dq2 = (size_t)4 * L * AT_LD * sizeof(float);
+  static const bool no_dq2 = getenv("KANTTS_ATTN_NO_DQ2") != nullptr;
+  if (!dqh && (lds_dq2 > 64 * 1024 || no_dq2)) return KANTTS_E_BADARG;
+  if (lds_dq2 <= 64 * 1024 && !no_dq2) {
+    // three roles: the query gradient of both bands summed in one pass (dqh is not written), dk/dv per band
+    m.p[0] = x; m.role[0] = AT_ROLE_DQ2;
+    m.p[1] = x; m.role[1] = AT_ROLE_DKV;
+    m.p[2] = hh; m.role[2] = AT_ROLE_DKV;
+    m.p[3] = hh; m.role[3] = AT_ROLE_DKV;
+    const size_t lds = lds_dq2 > attn_lds_bytes(L, true) ? lds_dq2 : attn_lds_bytes(L, true);
+    hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 3), dim3(AT_THREADS), lds, (hipStream_t)stream, m);
+    KANTTS_CHECK_LAUNCH();
+  }
   m.p[0] = x; m.role[0] = AT_ROLE_DQ;
   m.p[1] = x; m.role[1] = AT_ROLE_DKV;
   m.p[2] = hh; m.role[2] = AT_ROLE_DQ;
   m.p[3] = hh; m.role[3] = AT_ROLE_DKV;
   hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 4), dim3(AT_THREADS), attn_lds_bytes(L, true),
                      (hipStream_t)stream, m);
-  KANTTS_CHECK_LAUNCH();
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return 1;  // separate query gradients: the caller adds dqh onto dqkv[..., :D]
 }
 
 

@@ -425,7 +425,9 @@ extern "C" int kantts_bgemm_nt(const kantts_bgemm_args* gp, void* stream) {
   const long long nt = kantts_cdiv(g.N, BG_BN);
   const long long wg64 = kantts_cdiv(g.M, 64) * nt;
   static const char* force_bm = getenv("KANTTS_BGEMM_BM");
-  int bm = wg64 >= 256 ? 64 : 32;
+  // fp32 A operands (two float4 loads + a rounding pass per 8 elements) do better with 32-row tiles at every size measured:
+  // M = 19584, 512 -> 256: 28.1 us against 34.9 (profiles/r03_runU_postnet_gemm_tiles.log)
+  int bm = (wg64 >= 256 && !g.a_f32) ? 64 : 32;
   if (force_bm) bm = atoi(force_bm);
   hipStream_t st = (hipStream_t)stream;
   if (bm == 128)

@@ -559,7 +559,7 @@ class _DeferredTN:
         place by clipping.  Only storages are kept, so autograd can still adopt both tensors as p.grad."""
         if not self.enabled:
             return src
-        dst = torch.zeros_like(src)
+        dst = torch.empty_like(src)  # overwritten in full by the copy at flush time
         self.copies.append((self._desc(dst), self._desc(src)))
         return dst
 

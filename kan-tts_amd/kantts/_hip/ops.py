@@ -697,8 +697,9 @@ class _PncaAttention(torch.autograd.Function):
                                             ptr(dqkv), ptr(dqh), ptr(dhkv), ptr(lens), ptr(bw_dev), int(bw_x), int(bw_h), B,
                                             H, L, 16, float(drop_p), int(sx), int(sh),
                                             ptr(rng_state(q2.device)) if drop_p > 0 else None, stream())
-            if rc == 0:
-                dqkv[:, :D].add_(dqh)
+            if rc in (0, 1):
+                if rc == 1:  # long sequences: the two bands' query gradients come back separately
+                    dqkv[:, :D].add_(dqh)
                 return dqkv.view(B, L, 3 * D), dhkv.view(B, L, 2 * D), None, None, None, None, None, None, None
             if rc != E_UNSUPPORTED:
                 check(rc, "pnca_attn_bwd")

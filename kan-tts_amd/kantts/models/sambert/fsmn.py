@@ -18,7 +18,8 @@ class FeedForwardNet(nn.Module):
 
     def forward(self, x):
         p = float(self.dropout.p) if self.training else 0.0
-        h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=True, drop_p=p)
+        # the hidden activation only feeds the second contraction: bf16 in bf16 mode (fp32 mode ignores the flag)
+        h = ops.linear(x, self.w_1.weight, self.w_1.bias, relu=True, drop_p=p, out_bf16=True)
         return ops.linear(h, self.w_2.weight, None)
 
 

@@ -632,8 +632,9 @@ class EmulatedLib:
         self.kantts_attn_bwd(qkv, qkv + 4 * D, qkv + 8 * D, 3 * D, 3 * D, 3 * D, ox, D, d_ox, D, lse_x, None, dqkv,
                              dqkv + 4 * D, dqkv + 8 * D, 3 * D, 3 * D, 3 * D, 0, lens, bw_dev, bw_x, B, H, L, d_head, 1,
                              drop_p, seed_x, seed_dev, stream)
-        self.kantts_attn_bwd(qkv, hkv, hkv + 4 * D, 3 * D, ldh, ldh, oh, D, d_oh, D, lse_h, None, dqh, dhkv,
-                             dhkv + 4 * D, D, 2 * D, 2 * D, 0, lens, bw_dev, bw_h, B, H, L, d_head, 2, drop_p, seed_h,
+        # the summed form (return 0): the memory band's query gradient is accumulated onto dqkv[..., :D]; dqh stays untouched
+        self.kantts_attn_bwd(qkv, hkv, hkv + 4 * D, 3 * D, ldh, ldh, oh, D, d_oh, D, lse_h, None, dqkv, dhkv,
+                             dhkv + 4 * D, 3 * D, 2 * D, 2 * D, 1, lens, bw_dev, bw_h, B, H, L, d_head, 2, drop_p, seed_h,
                              seed_dev, stream)
         return 0
 

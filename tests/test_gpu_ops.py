@@ -200,7 +200,10 @@ def test_pnca_attention_one_launch_equals_per_band_launches(bw, drop, monkeypatc
 
     a, b = run(True), run(False)
     for x, y, nm in zip(a, b, ("ctx x", "ctx h", "dqkv", "dhkv")):
-        assert torch.equal(x, y), nm
+        if nm == "dqkv":  # the one-launch form sums the two bands' query gradients in one accumulator chain
+            assert torch.equal(x[..., H * 16:], y[..., H * 16:]) and rel_l2(x.cpu(), y.cpu()) < 1e-6, nm
+        else:
+            assert torch.equal(x, y), nm
 
     def f(qkv, hkv, lens):
         O_._seed_counter = itertools.count(31)
