@@ -772,6 +772,7 @@ def main():
                     help="graph: whole step captured once in a hipGraph and replayed; eager: launch per op")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-device runs the N-rank path on a one-GPU box")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only capture (kernel-trace runs)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline microbench (timing experiments only)")
     ap.add_argument("--oracle-probe", type=int, default=0, help=argparse.SUPPRESS)  # child process of cpu_baseline
     ap.add_argument("--share-device", action="store_true",
@@ -884,7 +885,7 @@ def main():
     # branch), replayed from its own hipGraph: SURVEY 8(d) prices the MFMA roofline on the forward pass
     # (152.3 GFLOP at batch 32: roofline.forward_mfma_frac = 152.3e9 / t_fwd / peak)
     fwd_ms = None
-    if rank == 0 and world == 1 and mode == "graph":
+    if rank == 0 and world == 1 and mode == "graph" and not args.no_forward_only:
         try:
             def fwd_only():
                 hip.ops.advance_rng(dev)

@@ -161,8 +161,8 @@ int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int
  * qkv (B,L,3D) = fused x projection [q | k_x | v_x], hkv = memory projection [k_h | v_h] with row pitch ldh >= 2D (the
  * twelve blocks' projections are columns of one (B,L,12*2D) GEMM output), D = H*16;
  * ox / oh (B,L,D) contexts, lse_x / lse_h (B,H,L) saved.  Backward: dqkv (B,L,3D) = [dq | dk_x | dv_x] with dq the SUM of
- * both bands' query gradients, dhkv (B,L,2D) = [dk_h | dv_h]; every output is written, none accumulated.  When the four
- * K/V images of a head do not fit in 64 KB of LDS together (L > ~240) the backward returns 1 instead of KANTTS_OK: dqkv's
+ * both bands' query gradients, dhkv (B,L,2D) = [dk_h | dv_h]; every output is written, none accumulated.  For L > 256
+ * (more queries than a workgroup has threads) the backward returns 1 instead of KANTTS_OK: dqkv's
  * first D columns then hold the x band's query gradient only, dqh (B,L,D, required in that case) the memory band's, and
  * the caller adds them.  Same masks, dropout streams (seed_x / seed_h) and padded-row rules as kantts_attn_fwd / _bwd with
  * mode 1 / mode 2.  KANTTS_E_UNSUPPORTED if a head's rows do not fit in LDS (L > ~440): use the per-band calls. */
@@ -217,7 +217,8 @@ int kantts_lr_gather_bwd(const float* dout, const int32_t* cs, const int64_t* va
 /* ------------------------------------------------------------------------------------------
  * FSMN memory block (kantts/models/sambert/fsmn.py:43-72), channels-last (B,T,C), w (C,K):
  *   xm = x*keep; y = keep*(sum_k w[c,k]*xm[t+k-left_pad] + xm[t]) (+ res); keep[b,t] = t < lens[b].
- * Backward: dx (w.r.t. x) and dw_accum (atomicAdd); d(res) = dy. */
+ * Backward: dx (w.r.t. x) and dw_accum (atomicAdd); d(res) = dy.  dx or dw_accum may be NULL: only the other gradient is
+ * computed (two calls on two streams: the filter gradient runs beside the backward pass's critical path). */
 int kantts_fsmn_dwconv_fwd(const float* x, const float* w, const float* res, const int64_t* lens, float* y, int B,
                            int T, int C, int K, int left_pad, void* stream);
 int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const float* w, const int64_t* lens, float* dx,

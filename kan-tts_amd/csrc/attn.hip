@@ -51,7 +51,13 @@ struct AttnArgs {
   int lddq, lddk, lddv;
   float* dvec;  // (B, H, L): D_i = dO_i . O_i
   int accumulate_dq;
+  // grid = (B, H, roles) instead of (H, B, roles): the workgroups of the 8 heads of one sequence then have linear ids
+  // b + B*(h + H*z), i.e. (for B a multiple of 8) they all run on XCD b % 8 -- a 128-byte line of a (B*L, 3D) projection
+  // holds the 64-byte row pieces of TWO heads, and with heads spread over the XCDs every line was filled into two L2s
+  int b_first;
 };
+#define AT_H(a) ((a).b_first ? (int)blockIdx.y : (int)blockIdx.x)
+#define AT_B(a) ((a).b_first ? (int)blockIdx.x : (int)blockIdx.y)
 
 __device__ __forceinline__ void key_range(int mode, int i, int len, int L, int bw, int& lo, int& hi) {
   if (mode == 0) {
@@ -256,15 +262,32 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const AttnArgs a) {
 // neighbouring rows, broadcast when all lanes read one row) and every thread then walks its interval
 // out of LDS.  The direct-from-global kernels above are latency-bound (two dependent L2 round trips
 // per key); these are the ones used whenever the head fits in 64 KB of LDS (L <= ~440).
-#define AT_LD 17
+#define AT_LD 20  // 80-byte rows: 16-byte LDS accesses, conflict-free for neighbouring rows in neighbouring lanes
 #define AT_THREADS 256
+
+// a staged row (16 floats at a 16-byte aligned LDS address) into registers: four ds_read_b128
+__device__ __forceinline__ void lds16(const float* p, float* r) {
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float4 t = p4[e];
+    r[4 * e + 0] = t.x;
+    r[4 * e + 1] = t.y;
+    r[4 * e + 2] = t.z;
+    r[4 * e + 3] = t.w;
+  }
+}
+__device__ __forceinline__ float dot16l(const float* a, const float* lrow) {
+  float b[DH];
+  lds16(lrow, b);
+  return dot16(a, b);
+}
 
 __device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld, int L, float* __restrict__ dst) {
   for (int idx = threadIdx.x; idx < L * 4; idx += AT_THREADS) {
     const int row = idx >> 2, part = idx & 3;
     const float4 t = *reinterpret_cast<const float4*>(src + (long long)row * ld + part * 4);
-    float* d = dst + row * AT_LD + part * 4;
-    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    *reinterpret_cast<float4*>(dst + row * AT_LD + part * 4) = t;
   }
 }
 
@@ -299,15 +322,16 @@ __device__ __forceinline__ void attn_fwd_lds_body(const AttnArgs& a, const int h
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] = 0.f;
     float m = -INFINITY;
-    for (int j = lo; j <= hi; ++j) m = fmaxf(m, dot16(q, Ks + j * AT_LD) * a.scale);
+    for (int j = lo; j <= hi; ++j) m = fmaxf(m, dot16l(q, Ks + j * AT_LD) * a.scale);
     float l = 0.f;
     const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
     KanttsDropSeq drop(a.drop_p, seed);
     for (int j = lo; j <= hi; ++j) {
-      const float e = expf(dot16(q, Ks + j * AT_LD) * a.scale - m);
+      const float e = expf(dot16l(q, Ks + j * AT_LD) * a.scale - m);
       l += e;
       const float ed = e * drop.scale(rng_row + j);
-      const float* vv = Vs + j * AT_LD;
+      float vv[DH];
+      lds16(Vs + j * AT_LD, vv);
 #pragma unroll
       for (int d = 0; d < DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
     }
@@ -321,7 +345,7 @@ __device__ __forceinline__ void attn_fwd_lds_body(const AttnArgs& a, const int h
       for (int j = 0; j < a.L; ++j) {
         float p = 0.f;
         if (j >= lo && j <= hi)
-          p = expf(dot16(q, Ks + j * AT_LD) * a.scale - m) * inv * drop.scale(rng_row + j);
+          p = expf(dot16l(q, Ks + j * AT_LD) * a.scale - m) * inv * drop.scale(rng_row + j);
         prow[j] = p;
       }
     }
@@ -330,7 +354,7 @@ __device__ __forceinline__ void attn_fwd_lds_body(const AttnArgs& a, const int h
 
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  attn_fwd_lds_body(a, blockIdx.x, blockIdx.y, sm);
+  attn_fwd_lds_body(a, AT_H(a), AT_B(a), sm);
 }
 
 __device__ __forceinline__ void attn_bwd_dq_lds_body(const AttnArgs& a, const int h, const int b, float* sm) {
@@ -376,9 +400,10 @@ __device__ __forceinline__ void attn_bwd_dq_lds_body(const AttnArgs& a, const in
     const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L;
     KanttsDropSeq drop(a.drop_p, seed);
     for (int j = lo; j <= hi; ++j) {
-      const float* kk = Ks + j * AT_LD;
+      float kk[DH];
+      lds16(Ks + j * AT_LD, kk);
       const float p = expf(dot16(q, kk) * a.scale - lse);
-      const float dp = dot16(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
+      const float dp = dot16l(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
       const float ds = p * (dp - D) * a.scale;
 #pragma unroll
       for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
@@ -396,7 +421,7 @@ __device__ __forceinline__ void attn_bwd_dq_lds_body(const AttnArgs& a, const in
 
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dq_lds_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  attn_bwd_dq_lds_body(a, blockIdx.x, blockIdx.y, sm);
+  attn_bwd_dq_lds_body(a, AT_H(a), AT_B(a), sm);
 }
 
 // D_i = dO_i . O_i: read from dvec (written by the dq pass, which then has to run first) or, with RECOMPUTE_D, formed
@@ -466,8 +491,9 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_body(const AttnArgs& a, const i
         int lo, hi;
         key_range(a.mode, i, len, a.L, bw, lo, hi);
         if (j < lo || j > hi) continue;
-        const float* q = Qs + i * AT_LD;
-        const float* go = Gs + i * AT_LD;
+        float q[DH], go[DH];
+        lds16(Qs + i * AT_LD, q);
+        lds16(Gs + i * AT_LD, go);
         const float p = expf(dot16(q, kk) * a.scale - Ls[i]);
         const float dsc =
             kantts_dropout_scale(a.drop_p, seed, ((((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L) + j);
@@ -489,7 +515,7 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_body(const AttnArgs& a, const i
 // must run after attn_bwd_dq_* (needs dvec)
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd_dkv_lds_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  attn_bwd_dkv_lds_body<false>(a, blockIdx.x, blockIdx.y, sm);
+  attn_bwd_dkv_lds_body<false>(a, AT_H(a), AT_B(a), sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -545,17 +571,18 @@ __device__ __forceinline__ void attn_fwd_lds_quad_body(const AttnArgs& a, const 
     for (int d = 0; d < DH; ++d) o[d] = 0.f;
     float m = -INFINITY;
     for (int jb = part; jb * 4 <= hi; jb += AT_P)
-      for (int j = jb * 4; j <= min(hi, jb * 4 + 3); ++j) m = fmaxf(m, dot16(q, Ks + j * AT_LD) * a.scale);
+      for (int j = jb * 4; j <= min(hi, jb * 4 + 3); ++j) m = fmaxf(m, dot16l(q, Ks + j * AT_LD) * a.scale);
     m = at_quad_max(m);
     float l = 0.f;
     const uint64_t rng_row = (((uint64_t)h * a.B + b) * a.L + min(i, a.L - 1)) * (uint64_t)a.L;
     KanttsDropSeq drop(a.drop_p, seed);
     for (int jb = part; jb * 4 <= hi; jb += AT_P)
       for (int j = jb * 4; j <= min(hi, jb * 4 + 3); ++j) {
-        const float e = expf(dot16(q, Ks + j * AT_LD) * a.scale - m);
+        const float e = expf(dot16l(q, Ks + j * AT_LD) * a.scale - m);
         l += e;
         const float ed = e * drop.scale(rng_row + j);
-        const float* vv = Vs + j * AT_LD;
+        float vv[DH];
+      lds16(Vs + j * AT_LD, vv);
 #pragma unroll
         for (int d = 0; d < DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
       }
@@ -576,7 +603,7 @@ __device__ __forceinline__ void attn_fwd_lds_quad_body(const AttnArgs& a, const 
         float* prow = a.probs + (((long long)h * a.B + b) * a.L + i) * a.L;
         for (int j = part; j < a.L; j += AT_P) {
           float p = 0.f;
-          if (j <= hi) p = expf(dot16(q, Ks + j * AT_LD) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
+          if (j <= hi) p = expf(dot16l(q, Ks + j * AT_LD) * a.scale - m) * inv * kantts_dropout_scale(a.drop_p, seed, rng_row + j);
           prow[j] = p;
         }
       }
@@ -629,9 +656,10 @@ __device__ __forceinline__ void attn_bwd_dq_lds_quad_body(const AttnArgs& a, con
     KanttsDropSeq drop(a.drop_p, seed);
     for (int jb = part; jb * 4 <= hi; jb += AT_P)
       for (int j = jb * 4; j <= min(hi, jb * 4 + 3); ++j) {
-        const float* kk = Ks + j * AT_LD;
+        float kk[DH];
+        lds16(Ks + j * AT_LD, kk);
         const float p = expf(dot16(q, kk) * a.scale - lse);
-        const float dp = dot16(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
+        const float dp = dot16l(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
         const float ds = p * (dp - D) * a.scale;
 #pragma unroll
         for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
@@ -705,8 +733,9 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_quad_body(const AttnArgs& a, co
     // mode 0: query i sees key j iff j <= len - 1 (every query row, padded ones included, as the forward computes them)
     if (live && j <= len - 1) {
       for (int i = part; i < a.L; i += AT_P) {
-        const float* q = Qs + i * AT_LD;
-        const float* go = Gs + i * AT_LD;
+        float q[DH], go[DH];
+        lds16(Qs + i * AT_LD, q);
+        lds16(Gs + i * AT_LD, go);
         const float p = expf(dot16(q, kk) * a.scale - Ls[i]);
         const float dsc =
             kantts_dropout_scale(a.drop_p, seed, ((((uint64_t)h * a.B + b) * a.L + i) * (uint64_t)a.L) + j);
@@ -746,59 +775,51 @@ __device__ __forceinline__ void attn_bwd_dkv_lds_quad_body(const AttnArgs& a, co
 // instead of two passes into two buffers and an elementwise add over (B*L, D) per block and step.
 __device__ __forceinline__ void attn_bwd_dq2_lds_body(const AttnArgs& ax, const AttnArgs& ah, const int h, const int b,
                                                       float* sm) {
+  // the two bands use the SAME two LDS images one after the other (x band, barrier, memory band): the role then needs no
+  // more LDS than the dk/dv roles of the launch (a launch has one dynamic LDS size: with four images resident it was
+  // 55 KB for every workgroup and two workgroups per CU)
   const int L = ax.L;
-  float* Kx = sm;
-  float* Vx = Kx + L * AT_LD;
-  float* Kh = Vx + L * AT_LD;
-  float* Vh = Kh + L * AT_LD;
-  float q0[DH];
-  load16(ax.q + ((long long)b * L + min((int)threadIdx.x, L - 1)) * ax.ldq + h * DH, q0);
-  stage_rows(ax.k + (long long)b * L * ax.ldk + h * DH, ax.ldk, L, Kx);
-  stage_rows(ax.v + (long long)b * L * ax.ldv + h * DH, ax.ldv, L, Vx);
-  stage_rows(ah.k + (long long)b * L * ah.ldk + h * DH, ah.ldk, L, Kh);
-  stage_rows(ah.v + (long long)b * L * ah.ldv + h * DH, ah.ldv, L, Vh);
-  __syncthreads();
+  float* Ks = sm;
+  float* Vs = sm + L * AT_LD;
   const int len = ax.lens ? ax.lens[b] : L;
   const uint64_t seed_off = ax.seed_dev ? *ax.seed_dev : 0ull;
-  for (int i = threadIdx.x; i < L; i += AT_THREADS) {
-    const long long row = (long long)b * L + i;
-    float q[DH], dq[DH];
-    if (i == (int)threadIdx.x) {
+  const int i = threadIdx.x;  // L <= 256 for the role (checked by the launcher): one query per thread, kept across bands
+  const bool live = i < L;
+  const long long row = (long long)b * L + min(i, L - 1);
+  float q[DH], dq[DH];
+  load16(ax.q + row * ax.ldq + h * DH, q);
 #pragma unroll
-      for (int d = 0; d < DH; ++d) q[d] = q0[d];
-    } else {
-      load16(ax.q + row * ax.ldq + h * DH, q);
+  for (int d = 0; d < DH; ++d) dq[d] = 0.f;
+  const long long sidx = ((long long)b * ax.H + h) * L + min(i, L - 1);
+  const uint64_t rng_row = (((uint64_t)h * ax.B + b) * L + min(i, L - 1)) * (uint64_t)L;
+#pragma unroll
+  for (int band = 0; band < 2; ++band) {
+    const AttnArgs& a = band ? ah : ax;
+    float go[DH], oo[DH];
+    load16(a.d_o + row * a.lddo + h * DH, go);
+    load16(a.o + row * a.ldo + h * DH, oo);
+    const float lse = a.lse[sidx];
+    if (band) __syncthreads();  // every thread is done with the x band's images
+    stage_rows(a.k + (long long)b * L * a.ldk + h * DH, a.ldk, L, Ks);
+    stage_rows(a.v + (long long)b * L * a.ldv + h * DH, a.ldv, L, Vs);
+    __syncthreads();
+    const int bw = a.bw_dev ? *a.bw_dev : a.bw;
+    int lo, hi;
+    key_range(a.mode, min(i, L - 1), len, L, bw, lo, hi);
+    if (!live || i >= len) hi = lo - 1;  // padded query rows carry no gradient
+    const float D = dot16(go, oo);
+    KanttsDropSeq drop(a.drop_p, a.seed + seed_off);
+    for (int j = lo; j <= hi; ++j) {
+      float kk[DH];
+      lds16(Ks + j * AT_LD, kk);
+      const float p = expf(dot16(q, kk) * a.scale - lse);
+      const float dp = dot16l(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
+      const float ds = p * (dp - D) * a.scale;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
     }
-#pragma unroll
-    for (int d = 0; d < DH; ++d) dq[d] = 0.f;
-    const long long sidx = ((long long)b * ax.H + h) * L + i;
-    const uint64_t rng_row = (((uint64_t)h * ax.B + b) * L + i) * (uint64_t)L;
-#pragma unroll
-    for (int band = 0; band < 2; ++band) {
-      const AttnArgs& a = band ? ah : ax;
-      const float* Ks = band ? Kh : Kx;
-      const float* Vs = band ? Vh : Vx;
-      const int bw = a.bw_dev ? *a.bw_dev : a.bw;
-      int lo, hi;
-      key_range(a.mode, i, len, L, bw, lo, hi);
-      if (i >= len) hi = lo - 1;  // padded query rows carry no gradient
-      float go[DH], oo[DH];
-      load16(a.d_o + row * a.lddo + h * DH, go);
-      load16(a.o + row * a.ldo + h * DH, oo);
-      const float D = dot16(go, oo);
-      const float lse = a.lse[sidx];
-      KanttsDropSeq drop(a.drop_p, a.seed + seed_off);
-      for (int j = lo; j <= hi; ++j) {
-        const float* kk = Ks + j * AT_LD;
-        const float p = expf(dot16(q, kk) * a.scale - lse);
-        const float dp = dot16(go, Vs + j * AT_LD) * drop.scale(rng_row + j);
-        const float ds = p * (dp - D) * a.scale;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
-      }
-    }
-    store16(ax.dq + row * ax.lddq + h * DH, dq);
   }
+  if (live) store16(ax.dq + row * ax.lddq + h * DH, dq);
 }
 
 // Up to four attention passes over the same (B, H) grid as ONE launch: blockIdx.z picks the pass.  A PNCA block's
@@ -832,33 +853,40 @@ __global__ __launch_bounds__(AT_THREADS) void attn_multi_lds_kernel(const AttnMu
   }
   if (QUAD) {
     if (role == AT_ROLE_FWD)
-      attn_fwd_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
+      attn_fwd_lds_quad_body(a, AT_H(a), AT_B(a), sm);
     else if (role == AT_ROLE_DQ)
-      attn_bwd_dq_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
+      attn_bwd_dq_lds_quad_body(a, AT_H(a), AT_B(a), sm);
     else
-      attn_bwd_dkv_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
+      attn_bwd_dkv_lds_quad_body(a, AT_H(a), AT_B(a), sm);
   } else {
     if (role == AT_ROLE_DQ2)
-      attn_bwd_dq2_lds_body(a, m.p[3], blockIdx.x, blockIdx.y, sm);
+      attn_bwd_dq2_lds_body(a, m.p[3], AT_H(a), AT_B(a), sm);
     else if (role == AT_ROLE_FWD)
-      attn_fwd_lds_body(a, blockIdx.x, blockIdx.y, sm);
+      attn_fwd_lds_body(a, AT_H(a), AT_B(a), sm);
     else if (role == AT_ROLE_DQ)
-      attn_bwd_dq_lds_body(a, blockIdx.x, blockIdx.y, sm);
+      attn_bwd_dq_lds_body(a, AT_H(a), AT_B(a), sm);
     else
-      attn_bwd_dkv_lds_body<true>(a, blockIdx.x, blockIdx.y, sm);
+      attn_bwd_dkv_lds_body<true>(a, AT_H(a), AT_B(a), sm);
   }
 }
 
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd_lds_quad_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  attn_fwd_lds_quad_body(a, blockIdx.x, blockIdx.y, sm);
+  attn_fwd_lds_quad_body(a, AT_H(a), AT_B(a), sm);
 }
+
+static bool at_b_first() {
+  static const bool head_major = getenv("KANTTS_ATTN_HEAD_MAJOR") != nullptr;  // A/B switch: the round-2 mapping
+  return !head_major;
+}
+static inline dim3 at_grid(int H, int B, int Z) { return at_b_first() ? dim3(B, H, Z) : dim3(H, B, Z); }
 
 static inline size_t attn_lds_bytes(int L, bool dkv) {
   return (size_t)(2 * L * AT_LD + (dkv ? 2 * L : 0)) * sizeof(float);
 }
 
-static int attn_check(const AttnArgs& a) {
+static int attn_check(AttnArgs& a) {
+  a.b_first = at_b_first() ? 1 : 0;
   if (!a.q || !a.k || !a.v || !a.o || !a.lse) return KANTTS_E_BADARG;
   if (a.B < 0 || a.H < 1 || a.L < 0 || a.mode < 0 || a.mode > 2) return KANTTS_E_BADARG;
   if ((a.ldq | a.ldk | a.ldv | a.ldo) & 3) return KANTTS_E_BADARG;  // float4 row access
@@ -880,10 +908,10 @@ extern "C" int kantts_attn_fwd(const float* q, const float* k, const float* v, i
   if (B == 0 || L == 0) return KANTTS_OK;
   static const bool no_quad = getenv("KANTTS_ATTN_NO_QUAD") != nullptr;
   if (attn_lds_bytes(L, false) <= 64 * 1024 && mode == 0 && !no_quad)
-    hipLaunchKernelGGL(attn_fwd_lds_quad_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, false),
+    hipLaunchKernelGGL(attn_fwd_lds_quad_kernel, at_grid(H, B, 1), dim3(AT_THREADS), attn_lds_bytes(L, false),
                        (hipStream_t)stream, a);
   else if (attn_lds_bytes(L, false) <= 64 * 1024)
-    hipLaunchKernelGGL(attn_fwd_lds_kernel, dim3(H, B), dim3(AT_THREADS), attn_lds_bytes(L, false), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_fwd_lds_kernel, at_grid(H, B, 1), dim3(AT_THREADS), attn_lds_bytes(L, false), (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(kantts_cdiv(L, 128), H, B), dim3(128), 0, (hipStream_t)stream, a);
   KANTTS_CHECK_LAUNCH();
@@ -911,10 +939,10 @@ extern "C" int kantts_attn_bwd(const float* q, const float* k, const float* v, i
     m.p[1] = a; m.role[1] = AT_ROLE_DKV;
     static const bool no_quad = getenv("KANTTS_ATTN_NO_QUAD") != nullptr;
     if (mode == 0 && !no_quad)
-      hipLaunchKernelGGL(attn_multi_lds_kernel<true>, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, true),
+      hipLaunchKernelGGL(attn_multi_lds_kernel<true>, at_grid(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, true),
                          (hipStream_t)stream, m);
     else
-      hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, true),
+      hipLaunchKernelGGL(attn_multi_lds_kernel<false>, at_grid(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, true),
                          (hipStream_t)stream, m);
   } else {
     dim3 grid(kantts_cdiv(L, 128), H, B), block(128);
@@ -939,6 +967,7 @@ static void pnca_fill(AttnArgs& a, const float* qkv, const float* kv, int ldkv, 
   a.k = kv + koff; a.v = kv + koff + D; a.ldk = a.ldv = ldkv;
   a.o = o; a.ldo = D; a.lse = lse; a.lens = lens; a.bw_dev = bw_dev; a.bw = bw; a.B = B; a.H = H; a.L = L; a.mode = mode;
   a.scale = 0.25f; a.drop_p = drop_p; a.seed = seed; a.seed_dev = seed_dev;
+  a.b_first = at_b_first() ? 1 : 0;
 }
 
 extern "C" int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, int ldh, float* ox, float* oh, float* lse_x, float* lse_h,
@@ -955,15 +984,15 @@ extern "C" int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, int ldh,
   pnca_fill(m.p[0], qkv, qkv, 3 * D, D, ox, lse_x, lens, bw_dev, bw_x, B, H, L, 1, drop_p, seed_x, seed_dev);
   pnca_fill(m.p[1], qkv, hkv, ldh, 0, oh, lse_h, lens, bw_dev, bw_h, B, H, L, 2, drop_p, seed_h, seed_dev);
   m.role[0] = m.role[1] = AT_ROLE_FWD;
-  hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, false),
+  hipLaunchKernelGGL(attn_multi_lds_kernel<false>, at_grid(H, B, 2), dim3(AT_THREADS), attn_lds_bytes(L, false),
                      (hipStream_t)stream, m);
   KANTTS_CHECK_LAUNCH();
 }
 
 // dqkv (B, L, 3D): columns [0, D) receive the query gradient, [D, 3D) the x band's key / value gradients; dhkv (B, L, 2D)
 // the memory K/V gradients.  Return value 1 (instead of KANTTS_OK = 0): the query gradients of the two bands were written
-// SEPARATELY -- the x band's to dqkv[..., :D], the memory band's to dqh (B, L, D) -- and the caller adds them (heads whose
-// four K/V images do not fit in 64 KB of LDS together); dqh may be NULL when the caller knows the summed form applies.
+// SEPARATELY -- the x band's to dqkv[..., :D], the memory band's to dqh (B, L, D) -- and the caller adds them (sequences
+// of more than 256 positions: the summed form keeps one query per thread across both bands); dqh may be NULL otherwise.
 extern "C" int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, int ldh, const float* ox, const float* oh, const float* d_ox,
                                     const float* d_oh, const float* lse_x, const float* lse_h, float* dqkv, float* dqh,
                                     float* dhkv, const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B,
@@ -984,24 +1013,24 @@ extern "C" int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, int ldh,
   pnca_fill(hh, qkv, hkv, ldh, 0, const_cast<float*>(oh), const_cast<float*>(lse_h), lens, bw_dev, bw_h, B, H, L, 2, drop_p,
             seed_h, seed_dev);
   hh.d_o = d_oh; hh.lddo = D; hh.dq = dqh; hh.lddq = D; hh.dk = dhkv; hh.dv = dhkv + D; hh.lddk = hh.lddv = 2 * D;
-  const size_t lds_dq2 = (size_t)4 * L * AT_LD * sizeof(float);
   static const bool no_dq2 = getenv("KANTTS_ATTN_NO_DQ2") != nullptr;
-  if (!dqh && (lds_dq2 > 64 * 1024 || no_dq2)) return KANTTS_E_BADARG;
-  if (lds_dq2 <= 64 * 1024 && !no_dq2) {
+  const bool dq2 = L <= AT_THREADS && !no_dq2;  // one query per thread, held in registers across the two bands
+  if (!dqh && !dq2) return KANTTS_E_BADARG;
+  if (dq2) {
     // three roles: the query gradient of both bands summed in one pass (dqh is not written), dk/dv per band
     m.p[0] = x; m.role[0] = AT_ROLE_DQ2;
     m.p[1] = x; m.role[1] = AT_ROLE_DKV;
     m.p[2] = hh; m.role[2] = AT_ROLE_DKV;
     m.p[3] = hh; m.role[3] = AT_ROLE_DKV;
-    const size_t lds = lds_dq2 > attn_lds_bytes(L, true) ? lds_dq2 : attn_lds_bytes(L, true);
-    hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 3), dim3(AT_THREADS), lds, (hipStream_t)stream, m);
+    hipLaunchKernelGGL(attn_multi_lds_kernel<false>, at_grid(H, B, 3), dim3(AT_THREADS), attn_lds_bytes(L, true),
+                       (hipStream_t)stream, m);
     KANTTS_CHECK_LAUNCH();
   }
   m.p[0] = x; m.role[0] = AT_ROLE_DQ;
   m.p[1] = x; m.role[1] = AT_ROLE_DKV;
   m.p[2] = hh; m.role[2] = AT_ROLE_DQ;
   m.p[3] = hh; m.role[3] = AT_ROLE_DKV;
-  hipLaunchKernelGGL(attn_multi_lds_kernel<false>, dim3(H, B, 4), dim3(AT_THREADS), attn_lds_bytes(L, true),
+  hipLaunchKernelGGL(attn_multi_lds_kernel<false>, at_grid(H, B, 4), dim3(AT_THREADS), attn_lds_bytes(L, true),
                      (hipStream_t)stream, m);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;

@@ -5,6 +5,8 @@
 // HBM-bound streaming kernels: one 64-lane wave per row, the row is held in registers
 // (C <= 1024 -> <= 16 values per lane), two-pass mean / variance like ATen's CPU kernel.
 // Backward: per-block partial dgamma/dbeta are reduced through LDS, one atomicAdd per column/block.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define LN_MAXPL 16  // max elements per lane (C <= 1024)
@@ -327,7 +329,9 @@ extern "C" int kantts_ln128_bwd_rows(const void* dy, int dy_bf16, const float* x
   // 6528 rows) the kernel took 13 us against 4.5 us for the forward pass -- same-address atomics serialise in L2
   // (profiles/r02_runD_sambert_kernel_stats_top.csv).  128 blocks walk ~3 slabs each instead.
   int blocks = kantts_cdiv(M, 16);
-  if (blocks > 128) blocks = 128;
+  static const char* cap_env = getenv("KANTTS_LN_BWD_BLOCKS");  // experiment switch
+  const int cap = cap_env ? atoi(cap_env) : 128;
+  if (blocks > cap) blocks = cap;
   if (dy_bf16)
     hipLaunchKernelGGL(ln128_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd,
                        dres, dx, dgamma_accum, dbeta_accum, zero_rows, M);

@@ -402,24 +402,31 @@ extern "C" int kantts_fsmn_dwconv_fwd(const float* x, const float* w, const floa
 extern "C" int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const float* w, const int64_t* lens, float* dx,
                                       float* dw_accum, float* workspace, long long ws_floats, int B, int T, int C, int K,
                                       int left_pad, void* stream) {
-  if (!dy || !x || !w || !dx || !dw_accum || B < 0 || T < 0 || C < 1 || K < 1) return KANTTS_E_BADARG;
+  // dx == NULL / dw_accum == NULL: only the other half (the filter gradient is a leaf of the backward graph -- the host
+  // issues it on the weight-gradient stream, beside the critical path)
+  if (!dy || !x || !w || (!dx && !dw_accum) || B < 0 || T < 0 || C < 1 || K < 1) return KANTTS_E_BADARG;
   if (B == 0 || T == 0) return KANTTS_OK;
   int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
   hipStream_t st = (hipStream_t)stream;
   if (K == FS_K) {
     const int nchunk = kantts_cdiv(T, FS_CH);
-    if (!workspace || ws_floats < (long long)B * nchunk * C * K) return KANTTS_E_WORKSPACE;
-    hipLaunchKernelGGL(fsmn_fir41_kernel<true>, dim3(kantts_cdiv(T, FS_TT), B), dim3(threads), 0, st, dy, w,
-                       (const float*)nullptr, lens, dx, B, T, C, left_pad);
-    hipLaunchKernelGGL(fsmn_dw41_partial_kernel, dim3(nchunk, B), dim3(threads), 0, st, dy, x, lens, workspace, B, T, C,
-                       left_pad);
-    hipLaunchKernelGGL(fsmn_dw_reduce_kernel, dim3(kantts_cdiv(C * K, 256)), dim3(256), 0, st, workspace, dw_accum,
-                       B * nchunk, C * K);
+    if (dw_accum && (!workspace || ws_floats < (long long)B * nchunk * C * K)) return KANTTS_E_WORKSPACE;
+    if (dx)
+      hipLaunchKernelGGL(fsmn_fir41_kernel<true>, dim3(kantts_cdiv(T, FS_TT), B), dim3(threads), 0, st, dy, w,
+                         (const float*)nullptr, lens, dx, B, T, C, left_pad);
+    if (dw_accum) {
+      hipLaunchKernelGGL(fsmn_dw41_partial_kernel, dim3(nchunk, B), dim3(threads), 0, st, dy, x, lens, workspace, B, T, C,
+                         left_pad);
+      hipLaunchKernelGGL(fsmn_dw_reduce_kernel, dim3(kantts_cdiv(C * K, 256)), dim3(256), 0, st, workspace, dw_accum,
+                         B * nchunk, C * K);
+    }
   } else {
-    hipLaunchKernelGGL(fsmn_dwconv_bwd_dx_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(threads), 0, st, dy, w, lens, dx, B,
-                       T, C, K, left_pad);
-    hipLaunchKernelGGL(fsmn_dwconv_bwd_dw_kernel, dim3(kantts_cdiv(T, DW_WT), B), dim3(threads), 0, st, dy, x, lens,
-                       dw_accum, B, T, C, K, left_pad);
+    if (dx)
+      hipLaunchKernelGGL(fsmn_dwconv_bwd_dx_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(threads), 0, st, dy, w, lens, dx,
+                         B, T, C, K, left_pad);
+    if (dw_accum)
+      hipLaunchKernelGGL(fsmn_dwconv_bwd_dw_kernel, dim3(kantts_cdiv(T, DW_WT), B), dim3(threads), 0, st, dy, x, lens,
+                         dw_accum, B, T, C, K, left_pad);
   }
   KANTTS_CHECK_LAUNCH();
 }

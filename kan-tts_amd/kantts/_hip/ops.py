@@ -26,6 +26,13 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _new_side_stream():
+    """Streams of work that runs BESIDE the step's critical path (deferred weight gradients, the variance-predictor branch).
+    KANTTS_SIDE_PRIORITY (experiment switch): HIP stream priority, larger = lower; default: the device default."""
+    pr = os.environ.get("KANTTS_SIDE_PRIORITY")
+    return torch.cuda.Stream(priority=int(pr)) if pr else torch.cuda.Stream()
+
+
 class _ZeroPool:
     """Bump allocator over one pre-zeroed device buffer for the per-step gradient accumulators (weight / bias
     gradients are produced by split-K atomics and row sums, so they must start at zero).  One memset per step
@@ -121,7 +128,7 @@ class _WgradOverlap:
             if not o.enabled:
                 return self
             if o._stream is None:
-                o._stream = torch.cuda.Stream()
+                o._stream = _new_side_stream()
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             o._stream.wait_event(ev)
@@ -186,7 +193,7 @@ def parallel_branches(thunks, inputs=()):
     if not dev_inputs:
         return [t() for t in thunks]
     while len(_branch_streams) < len(thunks):
-        _branch_streams.append(torch.cuda.Stream())
+        _branch_streams.append(_new_side_stream())
     main = torch.cuda.current_stream()
     fork = torch.cuda.Event()
     fork.record(main)
@@ -258,7 +265,7 @@ class _SideBranch:
             if not o.enabled or not torch.cuda.is_available():
                 return self
             if o._stream is None:
-                o._stream = torch.cuda.Stream()
+                o._stream = _new_side_stream()
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             o._stream.wait_event(ev)
@@ -997,8 +1004,13 @@ class _FsmnMemory(torch.autograd.Function):
         dw = gzeros_like(w)
         ws_n = int(lib().kantts_fsmn_dwconv_bwd_ws(B, T, C, K))
         ws = torch.empty(max(ws_n, 1), device=dy.device, dtype=torch.float32)
-        check(lib().kantts_fsmn_dwconv_bwd(ptr(dy, torch.float32), ptr(x), ptr(w), ptr(lens), ptr(dx), ptr(dw), ptr(ws),
-                                           ws_n, B, T, C, K, lp, stream()), "fsmn_dwconv_bwd")
+        check(lib().kantts_fsmn_dwconv_bwd(ptr(dy, torch.float32), ptr(x), ptr(w), ptr(lens), ptr(dx), None, None, 0,
+                                           B, T, C, K, lp, stream()), "fsmn_dwconv_bwd (dx)")
+        # the filter gradient is a leaf: on the weight-gradient stream when the step overlaps them (partials + reduce are
+        # 41 us per layer, ten layers per step)
+        with wgrad_overlap.side(dy, x, ws, dw):
+            check(lib().kantts_fsmn_dwconv_bwd(ptr(dy, torch.float32), ptr(x), ptr(w), ptr(lens), None, ptr(dw), ptr(ws),
+                                               ws_n, B, T, C, K, lp, stream()), "fsmn_dwconv_bwd (dw)")
         return dx, dw, (dy if has_res else None), None, None
 
 

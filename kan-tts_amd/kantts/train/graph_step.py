@@ -10,6 +10,8 @@ Here forward + losses + backward + gradient packing + clip + Adam are captured O
   * the data-parallel all-reduce is issued between graph replays of the two halves when
     world_size > 1 (RCCL calls are not captured).
 """
+import os
+
 import torch
 
 from kantts._hip import ops, rng_state as _rng_state
@@ -64,7 +66,9 @@ class GraphedSambertStep:
         self.graph_b = None
         optimizer.zero_grad(set_to_none=True)
         if not self.distributed:
-            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+            pr = os.environ.get("KANTTS_MAIN_PRIORITY")  # experiment switch: priority of the capture (critical-path) stream
+            kw = {"stream": torch.cuda.Stream(priority=int(pr))} if pr else {}
+            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local", **kw):
                 self._forward_backward()
                 self._apply()
         else:

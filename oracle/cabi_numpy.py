@@ -811,8 +811,10 @@ class EmulatedLib:
                                               groups=C)
             Y = keep * (conv.transpose(1, 2) + xm)
             Y.backward(DY)
-        _arr(dx, B * T * C)[:] = X.grad.reshape(-1).numpy()
-        _arr(dw, C * K)[:] += W.grad.reshape(-1).numpy()
+        if dx:
+            _arr(dx, B * T * C)[:] = X.grad.reshape(-1).numpy()
+        if dw:
+            _arr(dw, C * K)[:] += W.grad.reshape(-1).numpy()
         return 0
 
     # ------------------------------------------------------------------------------------ loss / optim

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round-3 visit AA: attention grid with the heads of one sequence on one XCD (microbench A/B, parity, step time)
+mkdir -p gpurun_out
+for v in "" "KANTTS_ATTN_HEAD_MAJOR=1"; do
+  echo "== $v" | tee -a gpurun_out/r3aa_attn_bench.log
+  env $v timeout 200 python scripts/attn_bench.py 2>&1 | grep -v Warning | grep "^L" | tee -a gpurun_out/r3aa_attn_bench.log
+done
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_sambert.py -m gpu -x -q 2>&1 | tail -n 3
+A="--steps 20 --warmup 5 --no-hifigan --no-cpu-baseline --no-fp32 --no-inference --no-roofline"
+for v in "" "KANTTS_ATTN_HEAD_MAJOR=1"; do
+  env $v timeout 300 python bench.py $A 2> gpurun_out/r3aa_err.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', 'step %.3f ms  forward %.3f ms' % (d['ms_per_step'], d['roofline']['forward_ms']))" | tee -a gpurun_out/r3aa_bench.log
+done
