@@ -45,6 +45,7 @@ def bf16_weight(w, tap_major=False):
     hipGraph); anything else is cast on demand and cached until the tensor's version or storage changes."""
     sh = getattr(w, "_kantts_bf16_tap" if tap_major else "_kantts_bf16", None)
     if sh is not None:
+        _fresh_shadow(w)
         return sh
     key = (id(w), bool(tap_major))
     hit = _wcache.get(key)
@@ -59,6 +60,15 @@ def bf16_weight(w, tap_major=False):
         _wcache.clear()
     _wcache[key] = (w._version, w.data_ptr(), tuple(w.shape), t)
     return t
+
+
+def _fresh_shadow(w):
+    """A parameter's arena images are rebuilt once per forward of the whole module; a direct sub-module call after an
+    optimizer step / load_state_dict (or the first bf16-mode use of a model built in fp32 mode) finds them stale."""
+    ref = getattr(w, "_kantts_arena", None)
+    arena = ref() if ref is not None else None
+    if arena is not None and arena.shadow_stale:
+        arena.refresh_shadow()
 
 
 def frag_major(mat):
@@ -76,6 +86,8 @@ def ffn_frag_weights(w1, w2):
     one launch); anything else is converted on demand and cached until the tensors change."""
     a = getattr(w1, "_kantts_frag", None)
     b = getattr(w2, "_kantts_frag", None)
+    if a is not None:
+        _fresh_shadow(w1)
     if a is not None and b is not None:
         return a, b, getattr(w2, "_kantts_fragT", None), getattr(w1, "_kantts_fragT", None)
     key = (id(w1), id(w2), "frag")

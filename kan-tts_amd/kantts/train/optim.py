@@ -101,13 +101,31 @@ class ParamArena:
         for attr, p, base, n in views:
             setattr(p, attr, self.frag_bf16[base:base + n])
         self._frag_table = torch.tensor(ftab, dtype=torch.int64, device=dev) if ftab else None
-        self.refresh_shadow()
-        self.module.register_forward_pre_hook(lambda m, a: self.refresh_shadow())
+        import weakref
 
-    def refresh_shadow(self):
+        ref = weakref.ref(self)
+        for p in self.params:
+            p._kantts_arena = ref  # ops_bf16.bf16_weight re-builds a stale shadow before handing it out
+        self.shadow_stale = True
+        self.refresh_shadow()
+        # once per forward of the WHOLE module (also inside a captured step).  A sub-module called on its own after an
+        # optimizer step / load_state_dict is covered by the staleness check in ops_bf16.bf16_weight; fp32 mode never reads
+        # the images, so it does not pay for the three launches either (they are built on the first bf16-mode use).
+        self.module.register_forward_pre_hook(lambda m, a: self.refresh_shadow(only_if_bf16=True))
+        self.module.register_load_state_dict_post_hook(lambda m, keys: self.mark_shadow_stale())
+
+    def mark_shadow_stale(self):
+        """The fp32 master weights changed (optimizer step, load_state_dict, broadcast, restore)."""
+        self.shadow_stale = True
+
+    def refresh_shadow(self, only_if_bf16=False):
         if self.flat_bf16 is None:
             return
-        from kantts._hip import check, lib, ptr, stream
+        from kantts._hip import check, get_precision, lib, ptr, stream
+
+        if only_if_bf16 and get_precision() != "bf16":
+            return
+        self.shadow_stale = False
 
         check(lib().kantts_cast_f32_bf16(ptr(self.flat, torch.float32), ptr(self.flat_bf16, torch.bfloat16), self.numel,
                                          stream()), "cast_f32_bf16")
@@ -139,7 +157,8 @@ class ParamArena:
         self.n_buckets = n_buckets
         # replicas must start from identical weights (DDP broadcasts rank 0's copy at wrap time)
         dist.broadcast(self.flat, src=0)
-        self.refresh_shadow()
+        self.shadow_stale = True
+        self.refresh_shadow(only_if_bf16=True)
         self.overlap = bool(overlap) and self.world_size > 1
         if self.overlap:
             self._build_buckets()
@@ -301,6 +320,7 @@ class ArenaAdam(torch.optim.Optimizer):
 
     def restore(self, snap):
         self.arena.flat.copy_(snap["flat"])
+        self.arena.shadow_stale = True
         self.exp_avg.copy_(snap["m"])
         self.exp_avg_sq.copy_(snap["v"])
         self._step = snap["step"]
@@ -340,6 +360,7 @@ class ArenaAdam(torch.optim.Optimizer):
         b1, b2 = group["betas"]
         ops.adam_step(arena.flat, g, self.exp_avg, self.exp_avg_sq, group["lr"], b1, b2, group["eps"],
                       group["weight_decay"], self._step, gnorm_sq=gn, max_norm=self.max_grad_norm, dyn=self.dyn)
+        arena.shadow_stale = True  # the bf16 operand images are rebuilt by the next forward (or the next direct use)
         return None  # per-parameter "step" entries are materialised lazily in state_dict()
 
     def grad_norm(self):

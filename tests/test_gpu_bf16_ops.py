@@ -232,6 +232,23 @@ def test_arena_shadow_matches_master_and_follows_updates():
     o.step()
     net(**batch)  # the pre-hook refreshes the shadow from the updated master
     check_all()
+    # a SUB-MODULE called on its own right after an optimizer step (no forward of the whole module in between) must not
+    # read the previous step's images: the arena is marked stale by step() and the first image handed out rebuilds it
+    o.zero_grad()
+    _losses(net(**batch), batch).backward()
+    o.step()
+    assert o.arena.shadow_stale
+    from kantts._hip import ops_bf16
+
+    w = net.text_encoder.ling_enc.fft[0].slf_attn.w_qkv.weight
+    assert torch.equal(ops_bf16.bf16_weight(w), w.detach().to(torch.bfloat16))
+    assert not o.arena.shadow_stale
+    check_all()
+    # load_state_dict changes the masters as well
+    sd = {k: (v + 1 if v.is_floating_point() else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    assert o.arena.shadow_stale
+    assert torch.equal(ops_bf16.bf16_weight(w), w.detach().to(torch.bfloat16))
 
 
 def test_arena_fragment_major_images_follow_the_master():
