@@ -98,7 +98,7 @@ _T0 = time.time()
 
 def oracle_probe_main(threads, B):
     """Child-process body of ``_oracle_probe``: the CPU oracle step (dropout off) at ``threads`` host threads, one
-    warm-up + two timed iterations; prints one JSON line."""
+    warm-up + one timed iteration; prints one JSON line."""
     import torch_oracle as O
     from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
     from kantts.utils import synthetic
@@ -118,11 +118,11 @@ def oracle_probe_main(threads, B):
         out = O.sambert_forward(P, cfg0, **batch)
         O.sambert_losses(out, batch["input_lengths"], batch["output_lengths"], batch["mel_targets"])["total"].backward()
 
-    dt, n = _time_iters(one, 1, 2, 1e9, min_iters=2)
+    dt, n = _time_iters(one, 1, 1, 1e9, min_iters=1)
     print(json.dumps({"cores": threads, "value": frames / dt, "timed": n, "s_per_iter": dt}))
 
 
-def _oracle_probe(threads, B, limit_s):
+def _oracle_probe(threads, B, limit_s, ref_s=float('nan')):
     import subprocess
 
     try:
@@ -134,7 +134,8 @@ def _oracle_probe(threads, B, limit_s):
         return {"cores": threads, "error": (r.stderr or "no output")[-200:]}
     except subprocess.TimeoutExpired:
         return {"cores": threads, "value": None,
-                "note": "1 warm-up + 2 timed iterations did not finish within %.0f s at %d threads" % (limit_s, threads)}
+                "note": "1 warm-up + 1 timed iteration did not finish within %.0f s at %d threads (%.1f s per iteration "
+                        "at the default thread count)" % (limit_s, threads, ref_s)}
 
 
 def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
@@ -180,7 +181,7 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
     all_cores = os.cpu_count() or 1
     all_core = None
     if all_cores > cores and CPU_THREADS["n"] is None:
-        all_core = _oracle_probe(all_cores, B, limit_s=75.0)
+        all_core = _oracle_probe(all_cores, B, limit_s=150.0, ref_s=dt_off)
 
     # ---- parity of the HIP path at the benchmarked shape (dropout forced to 0 on both sides)
     parity = {}

@@ -643,6 +643,49 @@ def _pair_on_two_streams(fn_main, fn_side, side_inputs=()):
     return rm, rs
 
 
+def _tensors_in(obj):
+    """Every tensor inside nested tuples / lists / dicts / __slots__ objects (SeqInfo)."""
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            yield from _tensors_in(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors_in(o)
+    elif hasattr(obj, "__slots__"):
+        for name in obj.__slots__:
+            yield from _tensors_in(getattr(obj, name, None))
+
+
+BESIDE = {"on": not os.environ.get("KANTTS_NO_PLAN_BESIDE")}  # A/B switch of run_beside
+
+
+def run_beside(fn_main, fn_side, side_inputs=()):
+    """``fn_side`` (work that depends only on the batch, not on ``fn_main``'s result) on a second stream while ``fn_main``
+    runs on the current one; joined before returning (two parallel branches under hipGraph capture).  Returns
+    (fn_main(), fn_side()); every tensor in the side result (nested containers, SeqInfo) is handed to the current
+    stream.  Sequential on the host or with KANTTS_NO_PLAN_BESIDE."""
+    if (not BESIDE["on"] or not torch.cuda.is_available()
+            or not any(torch.is_tensor(t) and t.is_cuda for t in side_inputs)):
+        return fn_main(), fn_side()
+    if not _attn_side_stream:
+        _attn_side_stream.append(torch.cuda.Stream())
+    side, main = _attn_side_stream[0], torch.cuda.current_stream()
+    side.wait_stream(main)
+    for t in side_inputs:
+        if torch.is_tensor(t) and t.is_cuda:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        rs = fn_side()
+    rm = fn_main()
+    main.wait_stream(side)
+    for t in _tensors_in(rs):
+        if t.is_cuda:
+            t.record_stream(main)
+    return rm, rs
+
+
 class _PncaAttention(torch.autograd.Function):
     """PNCA dual attention sharing Q: x-band over the decoder's own K/V (from qkv) and h-band over
     the memory K/V (hkv = [k | v]).  Returns ctx_x, ctx_h (B, L, H*16) [, probs_x, probs_h]."""

@@ -33,9 +33,11 @@ class LengthRegulator(nn.Module):
     def forward(self, inputs, durations, masks=None, plan=None):
         if plan is None:
             plan = self.index(durations)
-        idx, _, cs, output_lens, Tp, max_len = plan
+        idx, _, cs, output_lens, Tp, max_len = plan[:6]
         valid = None
-        if masks is not None:
+        if len(plan) > 6:  # the clamp below, computed once with the plan (three gathers share it)
+            valid = plan[6]
+        elif masks is not None:
             info = SeqInfo.of(masks)
             valid = torch.clamp(info.lens64, max=max_len)
         elif Tp != max_len:

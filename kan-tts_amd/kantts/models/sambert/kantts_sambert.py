@@ -218,8 +218,20 @@ class VarianceAdaptor(nn.Module):
         self.pitch_emb = nn.Conv1d(1, config["encoder_projection_units"], kernel_size=9, padding=4)
         self.energy_emb = nn.Conv1d(1, config["encoder_projection_units"], kernel_size=9, padding=4)
 
+    def position_term(self, plan, out_info):
+        """Duration-relative position encoding of the regulated frames: valid frames only, zero in the mask / r-padding
+        (reference positions.py:83-90).  Depends on the durations alone."""
+        idx, pos, cs, LR_length_rounded, Tp, max_len = plan[:6]
+        t = torch.arange(Tp, device=pos.device)[None, :]
+        limit = torch.full_like(LR_length_rounded, max_len) if out_info is None else out_info.lens64.clamp(max=max_len)
+        pos = torch.where(t < limit[:, None], pos, torch.zeros_like(pos))
+        return self.dur_position_encoder.from_positions(pos)
+
     def forward(self, inputs_text_embedding, inputs_emo_embedding, inputs_spk_embedding, masks=None,
-                output_masks=None, duration_targets=None, pitch_targets=None, energy_targets=None, max_out_len=None):
+                output_masks=None, duration_targets=None, pitch_targets=None, energy_targets=None, max_out_len=None,
+                teacher_plan=None):
+        """``teacher_plan`` (teacher_forced_plan): everything below that depends on the targets only, computed by the
+        caller beside the encoder."""
         info = SeqInfo.of(masks)
         out_info = SeqInfo.of(output_masks)
         # [text | spk | emo] is consumed by three GEMMs (two FSMN inputs + the duration LSTM); build it once
@@ -246,29 +258,37 @@ class VarianceAdaptor(nn.Module):
                + ops.conv_cl(energy_src.unsqueeze(-1).contiguous(), self.energy_emb.weight, self.energy_emb.bias, pad=4))
         duration_predictor_cond = torch.cat([aug, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
         if duration_targets is not None:
-            prev = torch.log(F.pad(duration_targets[:, :-1].float(), (1, 0)) + 1).unsqueeze(-1)
+            prev = (teacher_plan["prev"] if teacher_plan is not None
+                    else torch.log(F.pad(duration_targets[:, :-1].float(), (1, 0)) + 1).unsqueeze(-1))
             with ops.side_branch.fork(duration_predictor_cond, prev) if teacher else contextlib.nullcontext():
                 log_duration_predictions, _ = self.duration_predictor(prev, duration_predictor_cond, masks=info)
             durations = duration_targets
         else:
             log_duration_predictions = self.duration_predictor.infer(duration_predictor_cond, masks=info)
             durations = torch.exp(log_duration_predictions) - 1
-        plan = self.length_regulator.index(durations, max_len=max_out_len)
-        idx, pos, cs, LR_length_rounded, Tp, max_len = plan
+        if teacher_plan is not None:
+            plan, pos_enc = teacher_plan["lr_plan"], teacher_plan["pos_enc"]
+        else:
+            plan = self.length_regulator.index(durations, max_len=max_out_len)
+            pos_enc = self.position_term(plan, out_info)
+        LR_length_rounded = plan[3]
         LR_text_outputs, _ = self.length_regulator(aug, durations, masks=out_info, plan=plan)
         LR_emo_outputs, _ = self.length_regulator(inputs_emo_embedding, durations, masks=out_info, plan=plan)
         LR_spk_outputs, _ = self.length_regulator(inputs_spk_embedding, durations, masks=out_info, plan=plan)
-        # duration-relative position: valid frames only, zero in the mask / r-padding (reference positions.py:83-90)
-        t = torch.arange(Tp, device=pos.device)[None, :]
-        limit = torch.full_like(LR_length_rounded, max_len) if out_info is None else out_info.lens64.clamp(max=max_len)
-        pos = torch.where(t < limit[:, None], pos, torch.zeros_like(pos))
-        LR_text_outputs = LR_text_outputs + self.dur_position_encoder.from_positions(pos)
+        LR_text_outputs = LR_text_outputs + pos_enc
         return (LR_text_outputs, LR_emo_outputs, LR_spk_outputs, LR_length_rounded, log_duration_predictions,
                 pitch_predictions, energy_predictions)
 
 
 class MelPNCADecoder(nn.Module):
     """Teacher-forced / free-running mel decoder (reference :503-612)."""
+
+    def teacher_input(self, target, L):
+        """go-frame followed by every r-th target frame, shifted by one decoder step (reference :556-559)."""
+        B = target.size(0)
+        input = torch.zeros((B, L, self.d_mel), device=target.device, dtype=target.dtype)
+        input[:, 1:, :] = target[:, self.r - 1:: self.r, :][:, : L - 1, :]
+        return input
 
     def __init__(self, config):
         super(MelPNCADecoder, self).__init__()
@@ -295,14 +315,12 @@ class MelPNCADecoder(nn.Module):
         self.decode_mode = "loop"
         self._decode_cache = None
 
-    def forward(self, memory, x_band_width, h_band_width, target=None, mask=None, return_attns=False, bw_dev=None):
+    def forward(self, memory, x_band_width, h_band_width, target=None, mask=None, return_attns=False, bw_dev=None,
+                teacher_input=None):
         if target is None:
             return self._free_run(memory, x_band_width, h_band_width, mask, bw_dev)
         self.mel_dec.reset_state()
-        # go-frame followed by every r-th target frame, shifted by one decoder step (reference :556-559)
-        B, L = memory.size(0), memory.size(1)
-        input = torch.zeros((B, L, self.d_mel), device=memory.device, dtype=memory.dtype)
-        input[:, 1:, :] = target[:, self.r - 1:: self.r, :][:, : L - 1, :]
+        input = teacher_input if teacher_input is not None else self.teacher_input(target, memory.size(1))
         return self.mel_dec(input, memory, x_band_width, h_band_width, mask=mask, return_attns=return_attns,
                             bw_dev=bw_dev)
 
@@ -422,6 +440,28 @@ class KanTtsSAMBERT(nn.Module):
         with torch.no_grad():
             return b_mas(attn, in_lens, out_lens, width=1)
 
+    @torch.no_grad()
+    def teacher_forced_plan(self, in_info, output_lengths, mel_targets, duration_targets):
+        """Everything of a teacher-forced step that depends on the TARGETS only -- output / LFR masks, the length-regulator
+        index, duration positions and their sin / cos, the duration predictor's shifted input, the attention band width,
+        the decoder's teacher-forcing frames: ~40 small launches that the reference (and rounds 1-2 here) issue between the
+        encoder and the decoder.  ``forward`` runs them on a second stream BESIDE the encoder (ops.run_beside)."""
+        r = self.mel_decoder.r
+        va = self.variance_adaptor
+        max_out_len = mel_targets.size(1)
+        out_info = SeqInfo(output_lengths, max_out_len)
+        lr_plan = va.length_regulator.index(duration_targets, max_len=max_out_len)
+        Tp, max_len = lr_plan[4], lr_plan[5]
+        lr_plan = tuple(lr_plan) + (torch.clamp(out_info.lens64, max=max_len),)
+        plan = {"out_info": out_info, "lr_plan": lr_plan, "pos_enc": va.position_term(lr_plan, out_info),
+                "prev": torch.log(F.pad(duration_targets[:, :-1].float(), (1, 0)) + 1).unsqueeze(-1),
+                "lfr_info": SeqInfo((output_lengths + r - 1) // r, Tp // r),
+                "bw_val": duration_targets.float().masked_fill(in_info.mask, 0).max() / r + 0.5,
+                "dec_input": self.mel_decoder.teacher_input(mel_targets, Tp // r)}
+        if self.device_band_width:
+            plan["bw_dev"] = plan["bw_val"].to(torch.int32).reshape(1)  # trunc == int() for non-negative values
+        return plan
+
     def forward(self, inputs_ling, inputs_emotion, inputs_speaker, input_lengths, output_lengths=None,
                 mel_targets=None, duration_targets=None, pitch_targets=None, energy_targets=None, attn_priors=None,
                 fp_label=None):
@@ -430,7 +470,15 @@ class KanTtsSAMBERT(nn.Module):
         T_in = inputs_ling.size(1)
         in_info = SeqInfo(input_lengths, T_in)
         is_training = mel_targets is not None
-        text_hid, enc_sla_attn_lst, ling_embedding = self.text_encoder(inputs_ling, in_info, self.return_attns)
+        tplan = None
+        if (is_training and not self.MAS and output_lengths is not None and duration_targets is not None
+                and pitch_targets is not None and energy_targets is not None):
+            (text_hid, enc_sla_attn_lst, ling_embedding), tplan = ops.run_beside(
+                lambda: self.text_encoder(inputs_ling, in_info, self.return_attns),
+                lambda: self.teacher_forced_plan(in_info, output_lengths, mel_targets, duration_targets),
+                side_inputs=(output_lengths, mel_targets, duration_targets, in_info.mask, in_info.lens64))
+        else:
+            text_hid, enc_sla_attn_lst, ling_embedding = self.text_encoder(inputs_ling, in_info, self.return_attns)
         # backward: once the gradient reaches the encoder output, the weight gradients of everything downstream start on
         # the side stream, beside the encoder's own backward (no-op unless weight gradients are deferred)
         text_hid = ops.wgrad_flush_point(text_hid)
@@ -458,13 +506,15 @@ class KanTtsSAMBERT(nn.Module):
         max_out_len = None
         if output_lengths is not None:
             max_out_len = mel_targets.size(1)
-            out_info = SeqInfo(output_lengths, max_out_len)
+            out_info = tplan["out_info"] if tplan is not None else SeqInfo(output_lengths, max_out_len)
         (LR_text_outputs, LR_emo_outputs, LR_spk_outputs, LR_length_rounded, log_duration_predictions,
          pitch_predictions, energy_predictions) = self.variance_adaptor(
             text_hid, emo_hid, spk_hid, masks=in_info, output_masks=out_info, duration_targets=duration_targets,
-            pitch_targets=pitch_targets, energy_targets=energy_targets, max_out_len=max_out_len)
+            pitch_targets=pitch_targets, energy_targets=energy_targets, max_out_len=max_out_len, teacher_plan=tplan)
         Tp = LR_text_outputs.size(1)
-        if output_lengths is not None:
+        if tplan is not None:
+            lfr_info = tplan["lfr_info"]
+        elif output_lengths is not None:
             lfr_info = SeqInfo((output_lengths + r - 1) // r, Tp // r)
         else:
             out_info = SeqInfo(LR_length_rounded, Tp)
@@ -478,7 +528,9 @@ class KanTtsSAMBERT(nn.Module):
             LR_spk_outputs.reshape(batch_size, -1, r * d_s)[:, :, :d_s],
             LR_emo_outputs.reshape(batch_size, -1, r * d_e)[:, :, :d_e],
         ], dim=-1)
-        if duration_targets is not None:
+        if tplan is not None:
+            bw_val = tplan["bw_val"]
+        elif duration_targets is not None:
             bw_val = duration_targets.float().masked_fill(in_info.mask, 0).max() / r + 0.5
         else:
             bw_val = (torch.exp(log_duration_predictions) - 1).max() / r + 0.5
@@ -487,13 +539,14 @@ class KanTtsSAMBERT(nn.Module):
             pred = (torch.exp(log_duration_predictions) - 1)
             bw_dev = (pred.max(dim=1).values / r + 0.5).to(torch.int32).contiguous()  # per sequence (free-running)
         if self.device_band_width and duration_targets is not None:
-            bw_dev = bw_val.to(torch.int32).reshape(1)  # trunc == int() for non-negative values
+            bw_dev = tplan["bw_dev"] if (tplan is not None and "bw_dev" in tplan) else bw_val.to(torch.int32).reshape(1)
             x_band_width = h_band_width = bw_dev
             bw_int = 0
         else:
             x_band_width = h_band_width = bw_int = int(bw_val)  # host sync, as in the reference (:981-993)
         dec_outputs, pnca_x_attn_lst, pnca_h_attn_lst = self.mel_decoder(
-            memory, bw_int, bw_int, target=mel_targets, mask=lfr_info, return_attns=self.return_attns, bw_dev=bw_dev)
+            memory, bw_int, bw_int, target=mel_targets, mask=lfr_info, return_attns=self.return_attns, bw_dev=bw_dev,
+            teacher_input=None if tplan is None else tplan["dec_input"])
         dec_outputs = dec_outputs.reshape(batch_size, -1, self.mel_decoder.d_mel)
         rows = out_info.mask
         if rows.size(1) != dec_outputs.size(1):

@@ -28,6 +28,12 @@ class GraphedSambertStep:
         from kantts._hip import deferred_tn
 
         prev = (ops.wgrad_overlap.enabled, deferred_tn.enabled, ops.side_branch.enabled)
+        # Deferred weight gradients hand autograd a buffer that is only filled when the group is flushed.  That is sound
+        # as long as every parameter receives exactly ONE gradient per backward into an empty .grad (zero_grad(set_to_none)
+        # before each backward, which this class does): a tied parameter would have autograd add a still-empty buffer.
+        names = [n for n, _ in net.named_parameters(remove_duplicate=False)]
+        if len(names) != len(list(net.parameters())):
+            raise NotImplementedError("GraphedSambertStep defers weight gradients; tied parameters are not supported")
         ops.wgrad_overlap.enable(overlap_wgrad, group_wgrads=group_wgrads)
         try:
             self._build(net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup)

@@ -296,8 +296,8 @@ def test_graph_trainer_alternating_shapes_matches_eager(tmp_path):
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 3e-4)])
 def test_benchmarked_sambert_schedule_matches_single_stream_eager_gpu(prec, tol):
     """The schedule bench.py times -- GraphedSambertStep at the FULL config (sambert_16k zhcn, batch 32 x 64 symbols,
-    dropout on): one hipGraph, variance predictors as a parallel branch, the x / h attentions of the PNCA blocks on two
-    streams, deferred weight gradients grouped by shape and issued from flush points -- against plain single-stream eager
+    dropout on): one hipGraph, variance predictors as a parallel branch, the target-only plan of the step beside the
+    encoder, deferred weight gradients grouped by shape and issued from flush points -- against plain single-stream eager
     steps from the same weights with the same dropout masks, over three optimizer steps.  The dropout generator is
     counter-based (host seed + device offset), so the eager run can be given exactly the seeds the capture froze into its
     kernel arguments; what remains is the summation order of the fp32 atomics in the split weight gradients."""
@@ -361,11 +361,13 @@ def test_benchmarked_sambert_schedule_matches_single_stream_eager_gpu(prec, tol)
         hip.rng_state(dev).copy_(rng0)
         e_losses = []
         os.environ["KANTTS_NO_ATTN_STREAMS"] = "1"
+        ops.BESIDE["on"] = False  # the target-only plan inline, not beside the encoder
         for _ in range(3):
             ops._seed_counter = itertools.count(per_step + 1)
             e_losses.append(eager_step(net, o, s))
         e_flat = o.arena.flat.detach().clone()
     finally:
+        ops.BESIDE["on"] = True
         os.environ.pop("KANTTS_NO_ATTN_STREAMS", None)
         ops._seed_counter = old_counter
         hip.rng_state(dev).copy_(rng0)
