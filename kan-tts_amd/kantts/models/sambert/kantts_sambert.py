@@ -99,10 +99,13 @@ class HybridAttentionDecoder(nn.Module):
         for layer in self.pnca:
             layer.reset_state()
 
-    def forward(self, input, memory, x_band_width, h_band_width, mask=None, return_attns=False, bw_dev=None):
+    def forward(self, input, memory, x_band_width, h_band_width, mask=None, return_attns=False, bw_dev=None,
+                prenet_out=None):
+        """``prenet_out``: self.prenet(input) when the caller has already formed it (teacher forcing: the prenet reads
+        the target frames only, so it runs beside the text encoder)."""
         info = SeqInfo.of(mask)
         rows = None if info is None else info.mask
-        x = self.prenet(input)
+        x = prenet_out if prenet_out is not None else self.prenet(input)
         # cat([memory, prenet]) @ W^T as a two-segment GEMM; masked rows -> 0; * sqrt(d_model)
         x = ops.linear([memory, x], self.dec_in_proj.weight, self.dec_in_proj.bias, mode="concat", rowmask=rows,
                        alpha=self.d_model ** 0.5)
@@ -218,6 +221,11 @@ class VarianceAdaptor(nn.Module):
         self.pitch_emb = nn.Conv1d(1, config["encoder_projection_units"], kernel_size=9, padding=4)
         self.energy_emb = nn.Conv1d(1, config["encoder_projection_units"], kernel_size=9, padding=4)
 
+    def pitch_energy_embedding(self, pitch, energy):
+        """Conv1d(1->32, k=9)(pitch) + Conv1d(1->32, k=9)(energy) (reference :420-443)."""
+        return (ops.conv_cl(pitch.unsqueeze(-1).contiguous(), self.pitch_emb.weight, self.pitch_emb.bias, pad=4)
+                + ops.conv_cl(energy.unsqueeze(-1).contiguous(), self.energy_emb.weight, self.energy_emb.bias, pad=4))
+
     def position_term(self, plan, out_info):
         """Duration-relative position encoding of the regulated frames: valid frames only, zero in the mask / r-padding
         (reference positions.py:83-90).  Depends on the durations alone."""
@@ -253,9 +261,10 @@ class VarianceAdaptor(nn.Module):
         # single-input-channel convolutions: the streaming kernels of csrc/conv_c1.hip (one launch forward, one for the
         # weight gradient) -- as token-shifted GEMMs with K = 1 they took 9 launches per weight gradient on the generic
         # contraction kernel (0.4 ms of a 13 ms step, profiles/r02_runE_sambert_kernel_stats_top.csv)
-        aug = (inputs_text_embedding
-               + ops.conv_cl(pitch_src.unsqueeze(-1).contiguous(), self.pitch_emb.weight, self.pitch_emb.bias, pad=4)
-               + ops.conv_cl(energy_src.unsqueeze(-1).contiguous(), self.energy_emb.weight, self.energy_emb.bias, pad=4))
+        if teacher_plan is not None and "pe_emb" in teacher_plan:
+            aug = inputs_text_embedding + teacher_plan["pe_emb"]  # the two target embeddings were formed beside the encoder
+        else:
+            aug = inputs_text_embedding + self.pitch_energy_embedding(pitch_src, energy_src)
         duration_predictor_cond = torch.cat([aug, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
         if duration_targets is not None:
             prev = (teacher_plan["prev"] if teacher_plan is not None
@@ -273,8 +282,11 @@ class VarianceAdaptor(nn.Module):
             pos_enc = self.position_term(plan, out_info)
         LR_length_rounded = plan[3]
         LR_text_outputs, _ = self.length_regulator(aug, durations, masks=out_info, plan=plan)
-        LR_emo_outputs, _ = self.length_regulator(inputs_emo_embedding, durations, masks=out_info, plan=plan)
-        LR_spk_outputs, _ = self.length_regulator(inputs_spk_embedding, durations, masks=out_info, plan=plan)
+        if teacher_plan is not None and "LR_emo" in teacher_plan:
+            LR_emo_outputs, LR_spk_outputs = teacher_plan["LR_emo"], teacher_plan["LR_spk"]
+        else:
+            LR_emo_outputs, _ = self.length_regulator(inputs_emo_embedding, durations, masks=out_info, plan=plan)
+            LR_spk_outputs, _ = self.length_regulator(inputs_spk_embedding, durations, masks=out_info, plan=plan)
         LR_text_outputs = LR_text_outputs + pos_enc
         return (LR_text_outputs, LR_emo_outputs, LR_spk_outputs, LR_length_rounded, log_duration_predictions,
                 pitch_predictions, energy_predictions)
@@ -316,13 +328,13 @@ class MelPNCADecoder(nn.Module):
         self._decode_cache = None
 
     def forward(self, memory, x_band_width, h_band_width, target=None, mask=None, return_attns=False, bw_dev=None,
-                teacher_input=None):
+                teacher_input=None, teacher_prenet=None):
         if target is None:
             return self._free_run(memory, x_band_width, h_band_width, mask, bw_dev)
         self.mel_dec.reset_state()
         input = teacher_input if teacher_input is not None else self.teacher_input(target, memory.size(1))
         return self.mel_dec(input, memory, x_band_width, h_band_width, mask=mask, return_attns=return_attns,
-                            bw_dev=bw_dev)
+                            bw_dev=bw_dev, prenet_out=teacher_prenet)
 
 
     @torch.no_grad()
@@ -462,6 +474,30 @@ class KanTtsSAMBERT(nn.Module):
             plan["bw_dev"] = plan["bw_val"].to(torch.int32).reshape(1)  # trunc == int() for non-negative values
         return plan
 
+    def _embed_emo_spk(self, inputs_emotion, inputs_speaker):
+        (emo_hid, _) = ops.embed_sum(inputs_emotion, [self.emo_tokenizer.weight])
+        if self.se_enable:
+            spk_hid = inputs_speaker.to(torch.float32)
+        else:
+            (spk_hid, _) = ops.embed_sum(inputs_speaker, [self.spk_tokenizer.weight])
+        return emo_hid, spk_hid
+
+    def _beside_encoder(self, in_info, output_lengths, mel_targets, duration_targets, inputs_emotion, inputs_speaker,
+                        pitch_targets, energy_targets):
+        """What a teacher-forced step can do while the text encoder runs: the target-only plan (no gradient) and the
+        emotion / speaker embeddings with their length regulation (they read the inputs and two embedding tables only).
+        Autograd replays a node on the stream of its forward op, so the embedding-table gradients -- 31 us of atomics each,
+        at the very end of the main stream's backward before -- also run beside the encoder's backward."""
+        plan = self.teacher_forced_plan(in_info, output_lengths, mel_targets, duration_targets)
+        emo_hid, spk_hid = self._embed_emo_spk(inputs_emotion, inputs_speaker)
+        lr = self.variance_adaptor.length_regulator
+        plan["emo_hid"], plan["spk_hid"] = emo_hid, spk_hid
+        plan["LR_emo"], _ = lr(emo_hid, duration_targets, masks=plan["out_info"], plan=plan["lr_plan"])
+        plan["LR_spk"], _ = lr(spk_hid, duration_targets, masks=plan["out_info"], plan=plan["lr_plan"])
+        plan["pe_emb"] = self.variance_adaptor.pitch_energy_embedding(pitch_targets, energy_targets)
+        plan["dec_prenet"] = self.mel_decoder.mel_dec.prenet(plan["dec_input"])  # reads the target frames only
+        return plan
+
     def forward(self, inputs_ling, inputs_emotion, inputs_speaker, input_lengths, output_lengths=None,
                 mel_targets=None, duration_targets=None, pitch_targets=None, energy_targets=None, attn_priors=None,
                 fp_label=None):
@@ -475,8 +511,10 @@ class KanTtsSAMBERT(nn.Module):
                 and pitch_targets is not None and energy_targets is not None):
             (text_hid, enc_sla_attn_lst, ling_embedding), tplan = ops.run_beside(
                 lambda: self.text_encoder(inputs_ling, in_info, self.return_attns),
-                lambda: self.teacher_forced_plan(in_info, output_lengths, mel_targets, duration_targets),
-                side_inputs=(output_lengths, mel_targets, duration_targets, in_info.mask, in_info.lens64))
+                lambda: self._beside_encoder(in_info, output_lengths, mel_targets, duration_targets, inputs_emotion,
+                                             inputs_speaker, pitch_targets, energy_targets),
+                side_inputs=(output_lengths, mel_targets, duration_targets, in_info.mask, in_info.lens64, inputs_emotion,
+                             inputs_speaker, pitch_targets, energy_targets))
         else:
             text_hid, enc_sla_attn_lst, ling_embedding = self.text_encoder(inputs_ling, in_info, self.return_attns)
         # backward: once the gradient reaches the encoder output, the weight gradients of everything downstream start on
@@ -497,11 +535,10 @@ class KanTtsSAMBERT(nn.Module):
             # (reference loop :921-924, vectorised: no per-item .item())
             pad = (mel_targets.size(1) - output_lengths).to(duration_targets.dtype)
             duration_targets.scatter_(1, input_lengths.view(-1, 1), pad.view(-1, 1))
-        (emo_hid, _) = ops.embed_sum(inputs_emotion, [self.emo_tokenizer.weight])
-        if self.se_enable:
-            spk_hid = inputs_speaker.to(torch.float32)
+        if tplan is not None:
+            emo_hid, spk_hid = tplan["emo_hid"], tplan["spk_hid"]
         else:
-            (spk_hid, _) = ops.embed_sum(inputs_speaker, [self.spk_tokenizer.weight])
+            emo_hid, spk_hid = self._embed_emo_spk(inputs_emotion, inputs_speaker)
         out_info = None
         max_out_len = None
         if output_lengths is not None:
@@ -546,7 +583,8 @@ class KanTtsSAMBERT(nn.Module):
             x_band_width = h_band_width = bw_int = int(bw_val)  # host sync, as in the reference (:981-993)
         dec_outputs, pnca_x_attn_lst, pnca_h_attn_lst = self.mel_decoder(
             memory, bw_int, bw_int, target=mel_targets, mask=lfr_info, return_attns=self.return_attns, bw_dev=bw_dev,
-            teacher_input=None if tplan is None else tplan["dec_input"])
+            teacher_input=None if tplan is None else tplan["dec_input"],
+            teacher_prenet=None if tplan is None else tplan.get("dec_prenet"))
         dec_outputs = dec_outputs.reshape(batch_size, -1, self.mel_decoder.d_mel)
         rows = out_info.mask
         if rows.size(1) != dec_outputs.size(1):
