@@ -668,7 +668,8 @@ def run_beside(fn_main, fn_side, side_inputs=()):
     stream.  Sequential on the host or with KANTTS_NO_PLAN_BESIDE."""
     if (not BESIDE["on"] or not torch.cuda.is_available()
             or not any(torch.is_tensor(t) and t.is_cuda for t in side_inputs)):
-        return fn_main(), fn_side()
+        rs = fn_side()  # same host order as below: dropout seeds are drawn in issue order
+        return fn_main(), rs
     if not _attn_side_stream:
         _attn_side_stream.append(torch.cuda.Stream())
     side, main = _attn_side_stream[0], torch.cuda.current_stream()

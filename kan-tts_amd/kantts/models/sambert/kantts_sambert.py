@@ -29,6 +29,11 @@ from kantts.models.utils import SeqInfo, get_mask_from_lengths
 
 # extra flush points for deferred weight gradients inside the block stacks (ops.wgrad_flush_point): every N blocks; 0 = only
 # the points at the postnet input and the encoder output.  Measured on the bench step: see DESIGN section 5.
+# which gradient-carrying pieces run beside the encoder in a teacher-forced step (KanTtsSAMBERT._beside_encoder), measured
+# one by one (profiles/r03_runAH_beside_parts.log, step ms): plan only 7.83-7.86; + decoder prenet 7.70; + pitch / energy
+# embeddings 7.82; + emotion / speaker embeddings 8.33 (their table gradients are atomics-bound kernels that then share
+# the chip with the encoder's backward: off)
+_BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "pe,prenet").split(",") if x)
 _FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "0"))}
 
 
@@ -489,13 +494,17 @@ class KanTtsSAMBERT(nn.Module):
         Autograd replays a node on the stream of its forward op, so the embedding-table gradients -- 31 us of atomics each,
         at the very end of the main stream's backward before -- also run beside the encoder's backward."""
         plan = self.teacher_forced_plan(in_info, output_lengths, mel_targets, duration_targets)
-        emo_hid, spk_hid = self._embed_emo_spk(inputs_emotion, inputs_speaker)
-        lr = self.variance_adaptor.length_regulator
-        plan["emo_hid"], plan["spk_hid"] = emo_hid, spk_hid
-        plan["LR_emo"], _ = lr(emo_hid, duration_targets, masks=plan["out_info"], plan=plan["lr_plan"])
-        plan["LR_spk"], _ = lr(spk_hid, duration_targets, masks=plan["out_info"], plan=plan["lr_plan"])
-        plan["pe_emb"] = self.variance_adaptor.pitch_energy_embedding(pitch_targets, energy_targets)
-        plan["dec_prenet"] = self.mel_decoder.mel_dec.prenet(plan["dec_input"])  # reads the target frames only
+        parts = _BESIDE_PARTS
+        if "emb" in parts:
+            emo_hid, spk_hid = self._embed_emo_spk(inputs_emotion, inputs_speaker)
+            lr = self.variance_adaptor.length_regulator
+            plan["emo_hid"], plan["spk_hid"] = emo_hid, spk_hid
+            plan["LR_emo"], _ = lr(emo_hid, duration_targets, masks=plan["out_info"], plan=plan["lr_plan"])
+            plan["LR_spk"], _ = lr(spk_hid, duration_targets, masks=plan["out_info"], plan=plan["lr_plan"])
+        if "pe" in parts:
+            plan["pe_emb"] = self.variance_adaptor.pitch_energy_embedding(pitch_targets, energy_targets)
+        if "prenet" in parts:
+            plan["dec_prenet"] = self.mel_decoder.mel_dec.prenet(plan["dec_input"])  # reads the target frames only
         return plan
 
     def forward(self, inputs_ling, inputs_emotion, inputs_speaker, input_lengths, output_lengths=None,
@@ -535,7 +544,7 @@ class KanTtsSAMBERT(nn.Module):
             # (reference loop :921-924, vectorised: no per-item .item())
             pad = (mel_targets.size(1) - output_lengths).to(duration_targets.dtype)
             duration_targets.scatter_(1, input_lengths.view(-1, 1), pad.view(-1, 1))
-        if tplan is not None:
+        if tplan is not None and "emo_hid" in tplan:
             emo_hid, spk_hid = tplan["emo_hid"], tplan["spk_hid"]
         else:
             emo_hid, spk_hid = self._embed_emo_spk(inputs_emotion, inputs_speaker)

@@ -409,8 +409,11 @@ def test_gan_step_branch_streams_change_nothing_gpu():
             res[tag] = (losses, flats)
         finally:
             os.environ.pop("KANTTS_NO_BRANCH_STREAMS", None)
-    for la, lb in zip(res["streams"][0], res["one"][0]):
+    # step 1 sees identical weights: only the summation order of the weight-gradient atomics differs.  Adam's first update
+    # is lr * sign(g), so an element whose gradient is at that noise level may flip by 2 * lr: step 2 and the final
+    # weights get a bound that covers a handful of such flips (observed once in ~15 runs at 2e-4), not equality
+    for step, (la, lb) in enumerate(zip(res["streams"][0], res["one"][0])):
         for k in la:
-            assert abs(la[k] - lb[k]) <= 2e-4 * max(1.0, abs(lb[k])), k
+            assert abs(la[k] - lb[k]) <= (2e-4 if step == 0 else 5e-3) * max(1.0, abs(lb[k])), (step, k, la[k], lb[k])
     for a, b in zip(res["streams"][1], res["one"][1]):
-        assert float((a - b).norm() / b.norm()) <= 2e-4
+        assert float((a - b).norm() / b.norm()) <= 2e-3
