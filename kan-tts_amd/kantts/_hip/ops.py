@@ -234,7 +234,12 @@ def wgrad_flush_point(x):
     if not (wgrad_overlap.enabled and deferred_tn.enabled and torch.is_tensor(x) and x.requires_grad
             and os.environ.get("KANTTS_NO_EARLY_FLUSH", "") == ""):
         return x
-    return _FlushPoint.apply(x)
+    y = _FlushPoint.apply(x)
+    for attr in ("_kantts_rowmask", "_kantts_prenorm"):  # hand-overs between sub-layers ride through the identity
+        v = getattr(x, attr, None)
+        if v is not None:
+            setattr(y, attr, v)
+    return y
 
 
 class _SideBranch:

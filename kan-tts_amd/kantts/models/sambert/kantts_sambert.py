@@ -27,14 +27,17 @@ from kantts.models.sambert.positions import DurSinusoidalPositionEncoder, Sinuso
 from kantts.models.utils import SeqInfo, get_mask_from_lengths
 
 
-# extra flush points for deferred weight gradients inside the block stacks (ops.wgrad_flush_point): every N blocks; 0 = only
-# the points at the postnet input and the encoder output.  Measured on the bench step: see DESIGN section 5.
 # which gradient-carrying pieces run beside the encoder in a teacher-forced step (KanTtsSAMBERT._beside_encoder), measured
 # one by one (profiles/r03_runAH_beside_parts.log, step ms): plan only 7.83-7.86; + decoder prenet 7.70; + pitch / energy
 # embeddings 7.82; + emotion / speaker embeddings 8.33 (their table gradients are atomics-bound kernels that then share
 # the chip with the encoder's backward: off)
 _BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "pe,prenet").split(",") if x)
-_FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "0"))}
+# extra flush points for deferred weight gradients inside the block stacks (ops.wgrad_flush_point): every N blocks; 0 = only
+# the points at the postnet input and the encoder output.  Measured on the bench step: see DESIGN section 5.
+# Round 3 re-measured on the final schedule (profiles/r03_runAJ_flush_points.log): encoder every 4 blocks 7.67 ms against 7.75
+# (the encoder's own weight gradients start beside its second half instead of after it), every 2 blocks 8.10, decoder every
+# 4 blocks 8.03 (smaller groups, more launches), no early flush at all 8.42.
+_FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "4"))}
 
 
 class SelfAttentionEncoder(nn.Module):
