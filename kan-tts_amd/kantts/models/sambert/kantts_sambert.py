@@ -37,6 +37,10 @@ _BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "pe,prene
 # Round 3 re-measured on the final schedule (profiles/r03_runAJ_flush_points.log): encoder every 4 blocks 7.67 ms against 7.75
 # (the encoder's own weight gradients start beside its second half instead of after it), every 2 blocks 8.10, decoder every
 # 4 blocks 8.03 (smaller groups, more launches), no early flush at all 8.42.
+# in a teacher-forced step the variance predictors (a side branch that only feeds its own losses) start beside the POSTNET
+# (whose LSTM leaves 7/8 of the chip idle) instead of beside the decoder: 7.65 -> 7.60 ms (profiles/
+# r03_runAK_predictors_late.log); KANTTS_PREDICTORS_EARLY restores the round-2 placement
+_PREDICTORS_LATE = not os.environ.get("KANTTS_PREDICTORS_EARLY")
 _FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "4"))}
 
 
@@ -259,9 +263,13 @@ class VarianceAdaptor(nn.Module):
         teacher = (self.training and duration_targets is not None and pitch_targets is not None
                    and energy_targets is not None)
         lens_keep = None if info is None else (info.lens64, info.mask)
-        with ops.side_branch.fork(variance_predictor_inputs, *(lens_keep or ())) if teacher else contextlib.nullcontext():
-            pitch_predictions = self.pitch_predictor(variance_predictor_inputs, info)
-            energy_predictions = self.energy_predictor(variance_predictor_inputs, info)
+        late = teacher and _PREDICTORS_LATE  # the caller runs self.deferred() later (beside the postnet)
+        self.deferred = None
+        pitch_predictions = energy_predictions = None
+        if not late:
+            with ops.side_branch.fork(variance_predictor_inputs, *(lens_keep or ())) if teacher else contextlib.nullcontext():
+                pitch_predictions = self.pitch_predictor(variance_predictor_inputs, info)
+                energy_predictions = self.energy_predictor(variance_predictor_inputs, info)
         pitch_src = pitch_targets if pitch_targets is not None else pitch_predictions
         energy_src = energy_targets if energy_targets is not None else energy_predictions
         # text + Conv1d(1->32,k=9)(pitch) + Conv1d(1->32,k=9)(energy): two 9-tap GEMMs chained through the
@@ -277,8 +285,19 @@ class VarianceAdaptor(nn.Module):
         if duration_targets is not None:
             prev = (teacher_plan["prev"] if teacher_plan is not None
                     else torch.log(F.pad(duration_targets[:, :-1].float(), (1, 0)) + 1).unsqueeze(-1))
-            with ops.side_branch.fork(duration_predictor_cond, prev) if teacher else contextlib.nullcontext():
-                log_duration_predictions, _ = self.duration_predictor(prev, duration_predictor_cond, masks=info)
+            log_duration_predictions = None
+            if late:
+                def deferred():
+                    with ops.side_branch.fork(variance_predictor_inputs, duration_predictor_cond, prev, *(lens_keep or ())):
+                        p_ = self.pitch_predictor(variance_predictor_inputs, info)
+                        e_ = self.energy_predictor(variance_predictor_inputs, info)
+                        d_, _ = self.duration_predictor(prev, duration_predictor_cond, masks=info)
+                    return d_, p_, e_
+
+                self.deferred = deferred
+            else:
+                with ops.side_branch.fork(duration_predictor_cond, prev) if teacher else contextlib.nullcontext():
+                    log_duration_predictions, _ = self.duration_predictor(prev, duration_predictor_cond, masks=info)
             durations = duration_targets
         else:
             log_duration_predictions = self.duration_predictor.infer(duration_predictor_cond, masks=info)
@@ -604,6 +623,9 @@ class KanTtsSAMBERT(nn.Module):
         dec_outputs = ops.wgrad_flush_point(dec_outputs.masked_fill(rows.unsqueeze(-1), 0))  # postnet weight gradients
         post_info = out_info if out_info.mask.size(1) == dec_outputs.size(1) else SeqInfo(out_info.lens64,
                                                                                          dec_outputs.size(1))
+        if getattr(self.variance_adaptor, "deferred", None) is not None:
+            log_duration_predictions, pitch_predictions, energy_predictions = self.variance_adaptor.deferred()
+            self.variance_adaptor.deferred = None
         # postnet residual add + final masking ride in the epilogue of the last GEMM
         postnet_outputs = self.mel_postnet(dec_outputs, post_info, res=dec_outputs, zero_rows=post_info.mask)
         ops.side_branch.join()  # the predictors' outputs are read from here on (losses)

@@ -298,6 +298,15 @@ def test_embedding_and_length_regulator_bit_exact():
     assert_close(go[1], co[1], 1e-5, what="embed scaled")
     for a, c in zip(gg, cg):
         assert_close(a, c, 1e-4, what="embed grad")
+    # bench-sized call (32 x 64 tokens, 512 columns): tiny tables through the LDS images, a 500-row table through the
+    # scatter form, an index tensor with every token on ONE row (maximal collisions)
+    ids2 = torch.stack([torch.randint(0, n, (32, 64), generator=g) for n in (150, 7, 500, 5)], -1)
+    ids2[:, :, 3] = 2
+    tabs2 = [_rand(n, 512, seed=20 + k, grad=True) for k, n in enumerate((150, 7, 500, 5))]
+    go, gg, co, cg = run_both(lambda i, *t: ops.embed_sum(i, list(t), scale=2.0)[0], ids2, *tabs2)
+    assert_close(go[0], co[0], 1e-5, what="embed (bench size)")
+    for a, c in zip(gg, cg):
+        assert rel_l2(a, c) < 1e-5, "embed grad (bench size)"
     dur = torch.randint(0, 6, (B, T), generator=g)
     Tp = 60
     outs = {}
