@@ -198,12 +198,6 @@ int kantts_embed_sum_fwd(const float* const* tables_host, int ntab, const int64_
                          float* out, float* scaled_out, int rows, int T, int D, float scale, void* stream);
 int kantts_embed_sum_bwd(float* const* dtables_host, int ntab, const int64_t* ids, const float* dout, int rows,
                          int D, float scale, void* stream);
-/* The same with the tables' row counts (vocab_host: HOST array of ntab ints): tables of up to 384 rows are accumulated in an
- * LDS image per (table, 64 columns) and added to dtables once per address -- the scatter form serialises ~300 fp32 atomics
- * per address on the ten-row linguistic tables (tone, syllable flag, word segment). */
-int kantts_embed_sum_bwd_vocab(float* const* dtables_host, const int* vocab_host, int ntab, const int64_t* ids,
-                               const float* dout, int rows, int D, float scale, void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * Length regulator (kantts/models/sambert/adaptors.py:15-36, positions.py:72-90) in index form.
  * kantts_lr_index: reps = trunc(dur + 0.5) (dur_int (B,N) int64 or dur_float (B,N) fp32);

@@ -51,83 +51,6 @@ __global__ void embed_sum_bwd_kernel(const EmbedBwdArgs a) {
     if (a.dtab[k]) atomicAdd(&a.dtab[k][(long long)a.ids[(long long)row * a.ntab + k] * a.D + d], g);
 }
 
-// Vocabulary-aware form.  The linguistic tables are tiny (tone / syllable flag / word segment: under ten rows; symbols: a
-// few hundred), so 2048 tokens x D columns x ntab scatter-adds land on a handful of rows: ~300 fp32 atomics per ADDRESS,
-// serialised in L2 -- 31 us per call at the very end of the backward pass (profiles/r03_runX_*).  Here a workgroup owns
-// (table k, 64 columns), accumulates every token's row into an LDS image of the table's gradient (LDS atomics: no fabric
-// round trip, little contention across 64 columns) and adds the image to dtab once.
-#define EMB_COLS 64
-#define EMB_MAX_LDS_ROWS 384
-struct EmbedBwdV2Args {
-  EmbedBwdArgs a;
-  int vocab[4];
-};
-__global__ __launch_bounds__(256) void embed_sum_bwd_lds_kernel(const EmbedBwdV2Args P) {
-  extern __shared__ float emb_img[];
-  const EmbedBwdArgs& a = P.a;
-  const int k = blockIdx.y, c0 = blockIdx.x * EMB_COLS;
-  float* dtab = k == 0 ? a.dtab[0] : k == 1 ? a.dtab[1] : k == 2 ? a.dtab[2] : a.dtab[3];
-  const int V = k == 0 ? P.vocab[0] : k == 1 ? P.vocab[1] : k == 2 ? P.vocab[2] : P.vocab[3];
-  if (!dtab) return;
-  for (int i = threadIdx.x; i < V * EMB_COLS; i += 256) emb_img[i] = 0.f;
-  __syncthreads();
-  const int col = threadIdx.x & (EMB_COLS - 1), lane_row = threadIdx.x >> 6;
-  const bool col_ok = c0 + col < a.D;
-  // eight tokens per trip: their ids and gradient elements are requested together (an LDS atomic between two dependent
-  // global loads would expose one L2 round trip per token)
-  constexpr int U = 8;
-  for (int r0 = lane_row; r0 < a.rows; r0 += 4 * U) {
-    long long id[U];
-    float g[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = min(r0 + 4 * u, a.rows - 1);
-      id[u] = a.ids[(long long)r * a.ntab + k];
-      g[u] = a.dout[(long long)r * a.D + (col_ok ? c0 + col : 0)];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (col_ok && r0 + 4 * u < a.rows && id[u] >= 0 && id[u] < V)
-        atomicAdd(&emb_img[(int)id[u] * EMB_COLS + col], g[u] * a.scale);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < V * EMB_COLS; i += 256) {
-    const int v = i / EMB_COLS, c = i % EMB_COLS;
-    const float g = emb_img[i];
-    if (c0 + c < a.D && g != 0.f) atomicAdd(&dtab[(long long)v * a.D + c0 + c], g);  // one add per address and launch
-  }
-}
-
-extern "C" int kantts_embed_sum_bwd_vocab(float* const* dtables_host, const int* vocab_host, int ntab, const int64_t* ids,
-                                          const float* dout, int rows, int D, float scale, void* stream) {
-  if (!dtables_host || !vocab_host || ntab < 1 || ntab > 4 || !ids || !dout || rows < 0 || D < 1) return KANTTS_E_BADARG;
-  if (rows == 0) return KANTTS_OK;
-  EmbedBwdV2Args P = {};
-  int vmax = 0;
-  for (int k = 0; k < ntab; ++k) {
-    P.a.dtab[k] = dtables_host[k];
-    P.vocab[k] = vocab_host[k];
-    if (dtables_host[k] && vocab_host[k] > vmax) vmax = vocab_host[k];
-    if (vocab_host[k] < 1) return KANTTS_E_BADARG;
-  }
-  P.a.ntab = ntab; P.a.ids = ids; P.a.dout = dout; P.a.rows = rows; P.a.D = D; P.a.scale = scale;
-  if (vmax > EMB_MAX_LDS_ROWS) {  // a big table: the scatter form (few collisions per address there)
-    hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(kantts_cdiv((long long)rows * D, 256)), dim3(256), 0,
-                       (hipStream_t)stream, P.a);
-    KANTTS_CHECK_LAUNCH();
-  }
-  const size_t lds = (size_t)vmax * EMB_COLS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_sum_bwd_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, EMB_MAX_LDS_ROWS * EMB_COLS * 4);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(embed_sum_bwd_lds_kernel, dim3(kantts_cdiv(D, EMB_COLS), ntab), dim3(256), lds, (hipStream_t)stream, P);
-  KANTTS_CHECK_LAUNCH();
-}
-
 extern "C" int kantts_embed_sum_fwd(const float* const* tables_host, int ntab, const int64_t* ids, const float* pos,
                                     float* out, float* scaled_out, int rows, int T, int D, float scale, void* stream) {
   if (!tables_host || ntab < 1 || ntab > 4 || !ids || !out || rows < 0 || D < 1 || T < 1) return KANTTS_E_BADARG;

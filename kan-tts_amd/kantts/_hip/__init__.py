@@ -212,7 +212,6 @@ def lib():
         L.kantts_lstm_bwd.argtypes = [p, p, p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_embed_sum_fwd.argtypes = [POINTER(c_void_p), i, p, p, p, p, i, i, i, f, p]
         L.kantts_embed_sum_bwd.argtypes = [POINTER(c_void_p), i, p, p, i, i, f, p]
-        L.kantts_embed_sum_bwd_vocab.argtypes = [POINTER(c_void_p), POINTER(c_int), i, p, p, i, i, f, p]
         L.kantts_lr_index.argtypes = [p, p, p, p, p, p, i, i, i, p]
         L.kantts_lr_gather_fwd.argtypes = [p, p, p, p, i, i, i, i, i, i, p]
         L.kantts_lr_gather_bwd.argtypes = [p, p, p, p, i, i, i, i, i, i, i, p]
@@ -270,7 +269,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "kantts_abi_version", "kantts_target_arch", "kantts_gemm_seg_launch", "kantts_layernorm_fwd",
     "kantts_layernorm_bwd", "kantts_attn_fwd", "kantts_attn_bwd", "kantts_pnca_attn_fwd", "kantts_pnca_attn_bwd", "kantts_lstm_fwd", "kantts_lstm_bwd",
-    "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_embed_sum_bwd_vocab", "kantts_lr_index", "kantts_lr_gather_fwd",
+    "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
     "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_fsmn_dwconv_bwd_ws", "kantts_masked_l1",
     "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_norm_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd", "kantts_weight_norm_strided_fwd", "kantts_weight_norm_strided_bwd",
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",

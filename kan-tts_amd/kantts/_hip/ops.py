@@ -4,7 +4,6 @@ Activations are channels-last (rows = tokens) fp32; every Function saves only wh
 kernels need (outputs for ReLU gating, LayerNorm statistics, attention log-sum-exp, LSTM gates).
 Nothing here computes on the host or with ATen kernels except trivial views / allocations.
 """
-import ctypes
 import itertools
 import os
 import math
@@ -969,9 +968,8 @@ class _EmbedSum(torch.autograd.Function):
         B, T, n = ids.shape
         D = shapes[0][1]
         dt = [gzeros(s, dout.device) for s in shapes]
-        vocab = (ctypes.c_int * n)(*[int(s[0]) for s in shapes])
-        check(lib().kantts_embed_sum_bwd_vocab(_ptr_array(dt), vocab, n, ptr(ids), ptr(dout, torch.float32), B * T, D,
-                                               float(scale), stream()), "embed_sum_bwd")
+        check(lib().kantts_embed_sum_bwd(_ptr_array(dt), n, ptr(ids), ptr(dout, torch.float32), B * T, D, float(scale),
+                                         stream()), "embed_sum_bwd")
         return (None, None, None, None, *dt)
 
 

@@ -730,9 +730,6 @@ class EmulatedLib:
             np.add.at(tab, ID[:, k], DO)
         return 0
 
-    def kantts_embed_sum_bwd_vocab(self, dtables, vocab, ntab, ids, dout, rows, D, scale, stream):
-        return self.kantts_embed_sum_bwd(dtables, ntab, ids, dout, rows, D, scale, stream)
-
     # ------------------------------------------------------------------------------------ length regulator
     def kantts_lr_index(self, dur_int, dur_float, idx, pos, cs, lens, B, N, Tp, stream):
         if dur_int:
