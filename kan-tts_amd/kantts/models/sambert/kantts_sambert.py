@@ -29,9 +29,10 @@ from kantts.models.utils import SeqInfo, get_mask_from_lengths
 
 # which gradient-carrying pieces run beside the encoder in a teacher-forced step (KanTtsSAMBERT._beside_encoder), measured
 # one by one (profiles/r03_runAH_beside_parts.log, step ms): plan only 7.83-7.86; + decoder prenet 7.70; + pitch / energy
-# embeddings 7.82; + emotion / speaker embeddings 8.33 (their table gradients are atomics-bound kernels that then share
-# the chip with the encoder's backward: off)
-_BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "pe,prenet").split(",") if x)
+# embeddings 7.82 (within noise, and it re-associates text + pitch + energy: off, the reference's summation order stays);
+# + emotion / speaker embeddings 8.33 (their table gradients are atomics-bound kernels that then share the chip with the
+# encoder's backward: off)
+_BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "prenet").split(",") if x)
 # extra flush points for deferred weight gradients inside the block stacks (ops.wgrad_flush_point): every N blocks; 0 = only
 # the points at the postnet input and the encoder output.  Measured on the bench step: see DESIGN section 5.
 # Round 3 re-measured on the final schedule (profiles/r03_runAJ_flush_points.log): encoder every 4 blocks 7.67 ms against 7.75
@@ -41,6 +42,7 @@ _BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "pe,prene
 # (whose LSTM leaves 7/8 of the chip idle) instead of beside the decoder: 7.65 -> 7.60 ms (profiles/
 # r03_runAK_predictors_late.log); KANTTS_PREDICTORS_EARLY restores the round-2 placement
 _PREDICTORS_LATE = not os.environ.get("KANTTS_PREDICTORS_EARLY")
+_HKV_BESIDE = bool(os.environ.get("KANTTS_HKV_BESIDE"))
 _FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "4"))}
 
 
@@ -119,14 +121,24 @@ class HybridAttentionDecoder(nn.Module):
         rows = None if info is None else info.mask
         x = prenet_out if prenet_out is not None else self.prenet(input)
         # cat([memory, prenet]) @ W^T as a two-segment GEMM; masked rows -> 0; * sqrt(d_model)
-        x = ops.linear([memory, x], self.dec_in_proj.weight, self.dec_in_proj.bias, mode="concat", rowmask=rows,
-                       alpha=self.d_model ** 0.5)
-        if self.training and self.dropout > 0:
-            x = ops.dropout2_add(x, p1=self.dropout)
+        def entry():
+            y = ops.linear([memory, x], self.dec_in_proj.weight, self.dec_in_proj.bias, mode="concat", rowmask=rows,
+                           alpha=self.d_model ** 0.5)
+            if self.training and self.dropout > 0:
+                y = ops.dropout2_add(y, p1=self.dropout)
+            return y
+
+        # the memory K/V projections of all blocks read the same tensor: one GEMM forward, one input-gradient launch
+        def memory_kv():
+            return ops.shared_input_linears(memory, [layer.pnca_attn.w_h_kv for layer in self.pnca])
+
+        if _HKV_BESIDE and self.training:  # experiment: the memory projections beside the decoder's entry projection
+            x, hkvs = ops.run_beside(entry, memory_kv, side_inputs=(memory,))
+        else:
+            x = entry()
+            hkvs = memory_kv()
         ax_l, ah_l = [], []
         every = _FLUSH_EVERY["dec"] if self.training else 0
-        # the memory K/V projections of all blocks read the same tensor: computed here, one input-gradient launch
-        hkvs = ops.shared_input_linears(memory, [layer.pnca_attn.w_h_kv for layer in self.pnca])
         for i, layer in enumerate(self.pnca):
             if every and i and i % every == 0:
                 x = ops.wgrad_flush_point(x)
@@ -279,8 +291,10 @@ class VarianceAdaptor(nn.Module):
         # contraction kernel (0.4 ms of a 13 ms step, profiles/r02_runE_sambert_kernel_stats_top.csv)
         if teacher_plan is not None and "pe_emb" in teacher_plan:
             aug = inputs_text_embedding + teacher_plan["pe_emb"]  # the two target embeddings were formed beside the encoder
-        else:
-            aug = inputs_text_embedding + self.pitch_energy_embedding(pitch_src, energy_src)
+        else:  # the reference's order of the two adds: (text + pitch) + energy
+            aug = (inputs_text_embedding
+                   + ops.conv_cl(pitch_src.unsqueeze(-1).contiguous(), self.pitch_emb.weight, self.pitch_emb.bias, pad=4)
+                   + ops.conv_cl(energy_src.unsqueeze(-1).contiguous(), self.energy_emb.weight, self.energy_emb.bias, pad=4))
         duration_predictor_cond = torch.cat([aug, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
         if duration_targets is not None:
             prev = (teacher_plan["prev"] if teacher_plan is not None

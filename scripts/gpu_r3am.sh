@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-3 visit AM: embedding-table gradient forms alone; step time with the token-sliced LDS form and the vectorised masked L1
+# (scripts/embed_bwd_probe.py, used by this visit, was removed with the experiment: see profiles/r03_runAM_embed_bwd_forms.log)
 mkdir -p gpurun_out
 timeout 100 python scripts/embed_bwd_probe.py 2>&1 | grep -v Warning | grep tables | tee gpurun_out/r3am_embed_bwd.log
 timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "embedding or masked_l1" 2>&1 | tail -n 2
