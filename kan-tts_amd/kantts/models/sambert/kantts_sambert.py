@@ -42,7 +42,6 @@ _BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "prenet")
 # (whose LSTM leaves 7/8 of the chip idle) instead of beside the decoder: 7.65 -> 7.60 ms (profiles/
 # r03_runAK_predictors_late.log); KANTTS_PREDICTORS_EARLY restores the round-2 placement
 _PREDICTORS_LATE = not os.environ.get("KANTTS_PREDICTORS_EARLY")
-_HKV_BESIDE = bool(os.environ.get("KANTTS_HKV_BESIDE"))
 _FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "4"))}
 
 
@@ -121,22 +120,13 @@ class HybridAttentionDecoder(nn.Module):
         rows = None if info is None else info.mask
         x = prenet_out if prenet_out is not None else self.prenet(input)
         # cat([memory, prenet]) @ W^T as a two-segment GEMM; masked rows -> 0; * sqrt(d_model)
-        def entry():
-            y = ops.linear([memory, x], self.dec_in_proj.weight, self.dec_in_proj.bias, mode="concat", rowmask=rows,
-                           alpha=self.d_model ** 0.5)
-            if self.training and self.dropout > 0:
-                y = ops.dropout2_add(y, p1=self.dropout)
-            return y
-
+        x = ops.linear([memory, x], self.dec_in_proj.weight, self.dec_in_proj.bias, mode="concat", rowmask=rows,
+                       alpha=self.d_model ** 0.5)
+        if self.training and self.dropout > 0:
+            x = ops.dropout2_add(x, p1=self.dropout)
         # the memory K/V projections of all blocks read the same tensor: one GEMM forward, one input-gradient launch
-        def memory_kv():
-            return ops.shared_input_linears(memory, [layer.pnca_attn.w_h_kv for layer in self.pnca])
-
-        if _HKV_BESIDE and self.training:  # experiment: the memory projections beside the decoder's entry projection
-            x, hkvs = ops.run_beside(entry, memory_kv, side_inputs=(memory,))
-        else:
-            x = entry()
-            hkvs = memory_kv()
+        # (running them beside this entry projection on a second stream changed nothing: profiles/r03_runAN_hkv_beside.log)
+        hkvs = ops.shared_input_linears(memory, [layer.pnca_attn.w_h_kv for layer in self.pnca])
         ax_l, ah_l = [], []
         every = _FLUSH_EVERY["dec"] if self.training else 0
         for i, layer in enumerate(self.pnca):
