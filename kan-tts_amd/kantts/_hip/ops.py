@@ -178,14 +178,42 @@ wgrad_overlap = _WgradOverlap()
 _branch_streams = []
 
 
-def parallel_branches(thunks, inputs=()):
+class _BranchExit(torch.autograd.Function):
+    """Identity at the end of a branch (applied on the branch's stream).  Backward hands the branch a PRIVATE copy of the
+    incoming gradient.  Why: the gradient of ``sum(branch outputs)`` is ONE tensor that autograd gives to every branch,
+    each consuming it on its own stream.  Layers with a residual port pass their incoming gradient on as the residual's
+    gradient (the same tensor object), and autograd adds the next contribution INTO such a tensor in place once it holds
+    the last reference -- which it does as soon as the other branches' backward nodes have been *issued*, not when their
+    kernels have *finished*.  The in-place add on one stream then races with reads still pending on the other two
+    (batch 32 fp32 generator: 3-10 % error in some weight gradients, two runs out of five; profiles/r03_runAO-AR_*).
+    One copy per branch and stage on the branch's own stream (~0.1 ms per generator backward) removes the sharing."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone()
+
+
+def _private_grad(out):
+    if torch.is_tensor(out):
+        return _BranchExit.apply(out) if out.requires_grad else out
+    if isinstance(out, (tuple, list)):
+        return type(out)(_private_grad(o) for o in out)
+    return out
+
+
+def parallel_branches(thunks, inputs=(), private_grads=False):
     """Run independent sub-networks (``thunks``: callables without arguments) each on its own HIP stream and join them:
     the eight sub-discriminators of HiFi-GAN's MPD / MSD read the same waveform and share nothing, and a good half of
     their launches are tiny (weight-norm re-parametrisations, 1-channel first layers, strided layers over a few thousand
     tokens) -- back to back on one stream they leave most of the chip idle.  autograd replays every node on the stream of
     its forward op, so the backward passes are concurrent as well.  ``inputs``: tensors allocated on the current stream
-    that the branches read (recorded on every branch stream for the caching allocator).  Sequential on the host, and
-    when ``KANTTS_NO_BRANCH_STREAMS=1`` also on the device."""
+    that the branches read (recorded on every branch stream for the caching allocator).  ``private_grads``: the branch
+    outputs are summed by the caller and the branches contain residual ports -- see _BranchExit.  Sequential on the host,
+    and when ``KANTTS_NO_BRANCH_STREAMS=1`` also on the device."""
     if (len(thunks) < 2 or not torch.cuda.is_available() or os.environ.get("KANTTS_NO_BRANCH_STREAMS", "") != ""
             ):
         return [t() for t in thunks]
@@ -203,7 +231,8 @@ def parallel_branches(thunks, inputs=()):
         for x in dev_inputs:
             x.record_stream(st)
         with torch.cuda.stream(st):
-            outs.append(t())
+            o = t()
+            outs.append(_private_grad(o) if private_grads else o)
         ev = torch.cuda.Event()
         ev.record(st)
         done.append(ev)

@@ -126,7 +126,8 @@ class Generator(torch.nn.Module):
             blocks = self.conv_blocks[i * self.num_kernels:(i + 1) * self.num_kernels]
             ops.act_image(h, self.slope)  # one activated bf16 image for the first convolution of every stack (bf16 mode)
             thunks = [(lambda b=b, h=h: b.forward_cl(h)) for b in blocks]
-            ys = ops.parallel_branches(thunks, inputs=(h,)) if torch.is_grad_enabled() else [t() for t in thunks]
+            ys = (ops.parallel_branches(thunks, inputs=(h,), private_grads=True) if torch.is_grad_enabled()
+                  else [t() for t in thunks])
             xs = ys[0]
             for y in ys[1:]:
                 xs = xs + y
