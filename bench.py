@@ -13,10 +13,17 @@ Extra objects on the JSON line:
                  is HBM: achieved = algorithmic bytes (A + B + C once, fp32) / mean launch duration, each contraction
                  replayed from a captured hipGraph and timed with HIP events on the replay stream.  The MFMA view
                  (flop/s against the dense bf16 peak) is reported beside it as "mfma_frac".
-  "cpu_baseline" the CPU oracle port timed on the host cores on a bounded sample (rank 0, N=1 only).
+                 "cold_cache": the same launches over ten disjoint buffer sets (every operand from HBM); "traffic": memory-side
+                 bytes per launch from this round's rocprofv3 --pmc passes, read from profiles/ffn_block_pmc.json
+                 (scripts/ffn_pmc_probe.py + scripts/pmc_to_json.py); "forward_ms" / "forward_mfma_frac": the forward pass alone.
+  "cpu_baseline" the CPU oracle port timed on the host cores on a bounded sample (rank 0, N=1 only): >= 5 timed iterations at
+                 the default thread count + "all_cores": one attempt at every host core in a time-limited child process.
   "hifigan"      the second half of BASELINE.json's metric (audio-samples/s): HiFi-GAN V1 at batch 32 x 8192 samples --
                  full GAN training step, generator forward, and the transposed-conv upsampling stack against the HBM
                  roofline (rank 0, N=1 only; --no-hifigan skips it).
+Progress markers go to stderr ("[bench  12.3 s] ...").  --backend gloo --share-device runs the N-rank code path on ONE GPU (a
+functional check of spawn / rendezvous / barrier / max-over-ranks / the exchange between the two graphs, not a scaling
+figure); --no-roofline / --no-forward-only / --no-fp32 / --no-inference / --no-cpu-baseline trim legs for experiment runs.
 """
 import argparse
 import json
