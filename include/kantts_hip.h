@@ -165,7 +165,7 @@ int kantts_attn_bwd(const float* q, const float* k, const float* v, int ldq, int
  * (more queries than a workgroup has threads) the backward returns 1 instead of KANTTS_OK: dqkv's
  * first D columns then hold the x band's query gradient only, dqh (B,L,D, required in that case) the memory band's, and
  * the caller adds them.  Same masks, dropout streams (seed_x / seed_h) and padded-row rules as kantts_attn_fwd / _bwd with
- * mode 1 / mode 2.  KANTTS_E_UNSUPPORTED if a head's rows do not fit in LDS (L > ~440): use the per-band calls. */
+ * mode 1 / mode 2.  KANTTS_E_UNSUPPORTED if a head's rows do not fit in LDS (L > ~390): use the per-band calls. */
 int kantts_pnca_attn_fwd(const float* qkv, const float* hkv, int ldh, float* ox, float* oh, float* lse_x, float* lse_h,
                          const int32_t* lens, const int32_t* bw_dev, int bw_x, int bw_h, int B, int H, int L, int d_head,
                          float drop_p, uint64_t seed_x, uint64_t seed_h, const uint64_t* seed_dev, void* stream);

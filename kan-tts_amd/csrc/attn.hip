@@ -261,7 +261,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const AttnArgs a) {
 // once (coalesced float4 rows, 17-float LDS row stride => conflict-free when neighbouring lanes read
 // neighbouring rows, broadcast when all lanes read one row) and every thread then walks its interval
 // out of LDS.  The direct-from-global kernels above are latency-bound (two dependent L2 round trips
-// per key); these are the ones used whenever the head fits in 64 KB of LDS (L <= ~440).
+// per key); these are the ones used whenever the head fits in 64 KB of LDS (L <= ~390).
 #define AT_LD 20  // 80-byte rows: 16-byte LDS accesses, conflict-free for neighbouring rows in neighbouring lanes
 #define AT_THREADS 256
 
