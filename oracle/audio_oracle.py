@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE -- CPU restatement of the reference's mel-STFT feature extractor.
 
 Restates kantts/utils/audio_torch.py (torch path) with explicit framing + rFFT so that nothing
-depends on ``torch.stft`` defaults.  The mel basis comes from oracle/thirdparty.py (librosa
-restatement, PARITY UNPINNED by the reference -- see that file's header).  Only tests/, smoke()
+depends on ``torch.stft`` defaults.  The mel basis comes from oracle/thirdparty.py (librosa restatement; pinned against
+transformers.audio_utils.mel_filter_bank, the framing against scipy.signal.stft: tests/test_independent_pins.py).  Only tests/, smoke()
 and bench.py's cpu_baseline leg may import this file.
 """
 import torch
@@ -81,7 +81,8 @@ def dsp_melspectrogram(y, sample_rate, n_fft=1024, hop_length=256, win_length=10
                        min_level_db=-100, ref_level_db=20, fmin=50, fmax=8000, symmetric=False, preemphasize=False):
     """``melspectrogram`` of kantts/preprocess/audio_processor/core/dsp.py:165-201 in float64 numpy:
     librosa.stft(y, n_fft, hop_length, win_length) [librosa 0.9.2: center=True with zero padding, periodic Hann window
-    centred in n_fft -- framing / window / padding pinned against scipy.signal.stft; the mel basis stays PARITY UNPINNED]
+    centred in n_fft -- framing / window / padding pinned against scipy.signal.stft, the mel basis against
+    transformers.audio_utils.mel_filter_bank]
     -> |D| -> librosa mel basis (:135-139) -> 20 log10(max(1e-5, .)) - ref_level_db (:20, :190) -> _normalize (:66-75)
     -> transpose to (frames, n_mels)."""
     import numpy as np

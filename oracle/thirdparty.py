@@ -1,15 +1,19 @@
 """TEST INFRASTRUCTURE -- restatements of arithmetic that lives in un-vendored third-party
 dependencies of the reference (absent from /root/reference).
 
-PARITY UNPINNED: the reference holds no test/golden vector for any of these, and the packages are
-not installed in this image, so they are restated from their published algorithms and pinned only
-by self-consistency known-answer tests (tests/test_thirdparty_kat.py):
+The reference holds no test / golden vector for any of these and the packages are not installed in this image, so they
+are restated from their published algorithms.  What pins them:
 
 * ``librosa.filters.mel``  -- librosa 0.9.2 (environment.yaml:11); call sites
   kantts/utils/audio_torch.py:125-131 and kantts/preprocess/audio_processor/core/dsp.py:135-139.
   Slaney mel scale (htk=False), Slaney area normalisation, float32 result (n_mels, 1+n_fft//2).
+  PINNED (round 3) against an independent implementation that IS installed:
+  ``transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")`` -- <= 2e-9 at every configuration the
+  shipped yamls use (tests/test_independent_pins.py); self-consistency KATs in tests/test_thirdparty_kat.py.
 * ``pytorch_wavelets.DWT1DForward(wave="db3", J=1, mode="zero")`` -- unpinned git master
   (environment.yaml:64) + pywavelets 1.3.0; call site kantts/models/hifigan/hifigan.py:445-448,469-471.
+  Filter taps pinned by the closed-form Daubechies D6 coefficients (tests/test_independent_pins.py); the zero-padding /
+  decimation-phase convention is PARITY UNPINNED (orthonormality / reconstruction KATs only: no wavelet package here).
 """
 import numpy as np
 import torch

@@ -7,8 +7,12 @@
     kantts/preprocess/audio_processor/core/dsp.py:8-9) and against the product's host path.  What this pins: centre
     padding by n_fft // 2 (zeros for the mel paths -- librosa >= 0.9 / MelSpectrogram's hard-coded "constant" --, even
     reflection for ``stft``), the PERIODIC Hann window of win_length centred inside n_fft, hop framing, frame count
-    1 + T // hop, one-sided bins.  What stays unpinned: librosa.filters.mel (Slaney basis) -- self-consistency KATs only
-    (tests/test_thirdparty_kat.py).
+    1 + T // hop, one-sided bins.
+  * librosa.filters.mel(htk=False, norm="slaney") -- ``transformers.audio_utils.mel_filter_bank(norm="slaney",
+    mel_scale="slaney")`` (Hugging Face's own implementation, installed here, written to reproduce librosa) against the
+    oracle's restatement (oracle/thirdparty.py::librosa_mel) and the product's (kantts/utils/audio_torch.py::
+    slaney_mel_basis) at every (sr, n_fft, n_mels, fmin, fmax) the shipped yamls use: together with the STFT pin this
+    closes the chain waveform -> mel for MelSpectrogram / MelSpectrogramLoss and for the offline extractor.
   * db3 analysis filters of DWT1DForward -- the closed-form Daubechies D6 coefficients (textbook formula in sqrt(10) and
     sqrt(5 + 2 sqrt(10))) against the decimal table the product ships (kantts/models/hifigan/hifigan.py DB3_DEC_LO)."""
 import math
@@ -65,6 +69,33 @@ def test_product_dsp_melspectrogram_sits_on_the_pinned_stft():
     want = np.clip((S + 100.0) / 100.0, 0, 1.0)
     ref = A.dsp_melspectrogram(x, 16000, n_fft=n_fft, hop_length=hop, win_length=win, fmin=0, fmax=8000)
     assert np.abs(ref - want).max() < 1e-9
+
+
+@pytest.mark.parametrize("sr,n_fft,n_mels,fmin,fmax", [
+    (22050, 1024, 80, 0, 8000),      # hifigan_v1_22k loss / features
+    (16000, 1024, 80, 0, 8000),      # sambert_16k / hifigan_v1_16k
+    (16000, 2048, 80, 0.0, 8000.0),  # audio_config of the 16k recipes
+    (24000, 1024, 80, 0, 12000),
+    (22050, 1024, 80, 0, None),      # fmax = None -> sr / 2
+    (48000, 2048, 128, 20, 20000),
+])
+def test_slaney_mel_basis_pinned_by_an_independent_implementation(sr, n_fft, n_mels, fmin, fmax):
+    from transformers.audio_utils import mel_filter_bank
+
+    from kantts.utils.audio_torch import slaney_mel_basis
+    from thirdparty import librosa_mel
+
+    top = float(sr) / 2 if fmax is None else float(fmax)
+    ref = mel_filter_bank(num_frequency_bins=1 + n_fft // 2, num_mel_filters=n_mels, min_frequency=float(fmin),
+                          max_frequency=top, sampling_rate=sr, norm="slaney", mel_scale="slaney").T  # (n_mels, bins)
+    assert ref.shape == (n_mels, 1 + n_fft // 2) and ref.max() > 1e-3
+    for name, mine in (("oracle", librosa_mel(sr=sr, n_fft=n_fft, n_mels=n_mels, fmin=fmin, fmax=fmax)),
+                       ("product", slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax))):
+        mine = np.asarray(mine, dtype=np.float64)
+        assert mine.shape == ref.shape, name
+        # both restatements store float32: 1e-8 absolute on weights of order 1e-2 is float32 rounding
+        assert np.abs(mine - ref).max() < 2e-8, (name, float(np.abs(mine - ref).max()))
+        assert np.array_equal(mine > 0, ref > 1e-12) or np.abs((mine > 0).astype(int) - (ref > 1e-12).astype(int)).sum() <= 2, name
 
 
 def test_db3_filter_table_equals_the_closed_form():
