@@ -276,7 +276,8 @@ class ScaleDiscriminator(torch.nn.Module):
 
 class DWT1DForward(nn.Module):
     """Single-level db3 analysis, zero padding (pytorch_wavelets.DWT1DForward(wave="db3", J=1) in the reference,
-    hifigan.py:445-448 -- an un-vendored dependency, restated: PARITY UNPINNED).  One stride-2
+    hifigan.py:445-448 -- an un-vendored dependency, restated: taps pinned by their closed form, the zero-padding /
+    decimation-phase convention PARITY UNPINNED).  One stride-2
     two-channel FIR launch; output (B, out, 2) channels-last == cat([yl, yh], dim=1) of the reference."""
 
     def __init__(self, J=1, wave="db3", mode="zero"):

@@ -1,6 +1,7 @@
 """Offline mel extraction + on-disk feature formats: kantts.preprocess.audio_processor.AudioProcessor
 .mel_extract against the float64 numpy restatement of the reference's dsp.melspectrogram (oracle/audio_oracle.py) and the
-reference's statistics formulas (core/utils.py:404-434, :496-499).  librosa is not installed -> parity unpinned."""
+reference's statistics formulas (core/utils.py:404-434, :496-499).  librosa is not installed: its two ingredients are pinned by independent implementations
+(tests/test_independent_pins.py: STFT conventions by scipy, mel basis by transformers)."""
 import os
 
 import numpy as np

@@ -55,8 +55,8 @@ def test_stft_conventions_pinned_by_scipy(n_fft, hop, win):
 
 
 def test_product_dsp_melspectrogram_sits_on_the_pinned_stft():
-    """The product's offline extractor (float32 host path) against mel(basis) o scipy-STFT: the only unpinned factor left
-    is the mel basis itself."""
+    """The product's offline extractor (float32 host path) against mel(basis) o scipy-STFT; the mel basis has its own pin
+    below."""
     from kantts.preprocess.audio_processor.core import dsp
     from thirdparty import librosa_mel
 

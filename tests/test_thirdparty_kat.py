@@ -1,5 +1,6 @@
 """Self-consistency known-answer tests for the third-party arithmetic the reference never pins
-(librosa mel basis, pytorch_wavelets db3 DWT) -- "parity unpinned" pieces."""
+(librosa mel basis, pytorch_wavelets db3 DWT).  Independent pins (scipy STFT, transformers' mel filterbank,
+closed-form db3 taps) live in tests/test_independent_pins.py; the DWT's padding / phase convention stays "parity unpinned"."""
 import numpy as np
 import torch
 
