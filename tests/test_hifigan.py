@@ -562,3 +562,35 @@ def test_upsample_streaming_kernels_gpu(Cin, Cout, s, T):
             assert rel_l2(y3.cpu().float(), ref3) <= 4e-3
     finally:
         hip.set_precision("fp32")
+
+
+def test_branch_exit_is_an_identity_with_a_private_gradient():
+    """ops._BranchExit (end of a branch of ops.parallel_branches(private_grads=True)): identity forward; backward returns
+    a COPY of the incoming gradient, so in-place accumulation further down a branch never touches the tensor its sibling
+    branches still read (the cross-stream race of DESIGN section 5)."""
+    from kantts._hip import ops
+
+    x = torch.randn(3, 5, requires_grad=True)
+    y = ops._BranchExit.apply(x)
+    assert torch.equal(y, x) and y.data_ptr() == x.data_ptr()
+    seen = {}
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["in"] = g
+            return g
+
+    g0 = torch.randn(3, 5)
+    out = ops._private_grad([Probe.apply(x), "not a tensor"])
+    assert isinstance(out, list) and out[1] == "not a tensor"
+    y2 = ops._BranchExit.apply(x)
+    hooked = {}
+    y2.register_hook(lambda g: hooked.setdefault("g", g))
+    x.grad = None
+    y2.backward(g0)
+    assert torch.equal(x.grad, g0) and x.grad.data_ptr() != hooked["g"].data_ptr()
