@@ -456,6 +456,9 @@ class KanTtsSAMBERT(nn.Module):
         self.variance_adaptor = VarianceAdaptor(config)
         self.mel_decoder = MelPNCADecoder(config)
         self.mel_postnet = PostNet(config)
+        # True: the target-only part of a teacher-forced step (teacher_forced_plan) is computed inline, where the reference
+        # computes it, instead of beside the encoder -- same arithmetic (tests/test_host_logic_emulated.py)
+        self.inline_teacher_plan = False
         self.MAS = False
         if config.get("MAS", False):
             self.MAS = True
@@ -542,7 +545,8 @@ class KanTtsSAMBERT(nn.Module):
         in_info = SeqInfo(input_lengths, T_in)
         is_training = mel_targets is not None
         tplan = None
-        if (is_training and not self.MAS and output_lengths is not None and duration_targets is not None
+        if (is_training and not self.MAS and not getattr(self, "inline_teacher_plan", False) and output_lengths is not None
+                and duration_targets is not None
                 and pitch_targets is not None and energy_targets is not None):
             (text_hid, enc_sla_attn_lst, ling_embedding), tplan = ops.run_beside(
                 lambda: self.text_encoder(inputs_ling, in_info, self.return_attns),

@@ -171,6 +171,55 @@ def test_row_mask_handed_to_the_consuming_layernorm_changes_no_gradient(emulated
         hip.set_precision("fp32")
 
 
+def _tiny_training_run(monkeypatch, mutate):
+    """One teacher-forced training-mode forward + backward of the tiny SAM-BERT through the emulated ABI; every dropout
+    draws the SAME seed (masks then depend on the element index only, not on the order the launches are issued in)."""
+    import kantts.models.sambert.kantts_sambert as KS
+    from kantts._hip import ops
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+
+    monkeypatch.setattr(ops, "next_seed", lambda: 12345)
+    cfg = O.sambert_config(tiny=True)
+    torch.manual_seed(0)
+    m = KS.KanTtsSAMBERT(dict(cfg))
+    m.train()
+    mutate(m, KS)
+    batch = O.synthetic_sambert_batch(B=3, T_in=12, min_len=6, dur_hi=6)
+    res = m(**batch)
+    mel_, mel = MelReconLoss()(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
+    d, p, e = ProsodyReconLoss()(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
+                                 res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                 res["energy_predictions"])
+    (mel_ + mel + d + p + e).backward()
+    outs = [res[k].detach().clone() for k in ("dec_outputs", "postnet_outputs", "log_duration_predictions",
+                                              "pitch_predictions", "energy_predictions")]
+    return outs, {n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}
+
+
+def test_teacher_plan_beside_the_encoder_is_the_inline_arithmetic(emulated_cabi, monkeypatch):
+    """KanTtsSAMBERT.teacher_forced_plan / _beside_encoder (masks, length-regulator index, duration positions, band width,
+    teacher-forcing frames, decoder prenet -- computed ahead of the encoder on a second stream on the device) against the
+    same quantities computed where the reference computes them: identical outputs and gradients, dropout on."""
+    a_out, a_g = _tiny_training_run(monkeypatch, lambda m, KS: None)
+    b_out, b_g = _tiny_training_run(monkeypatch, lambda m, KS: setattr(m, "inline_teacher_plan", True))
+    for x, y in zip(a_out, b_out):
+        assert torch.equal(x, y)
+    assert a_g.keys() == b_g.keys()
+    for n in a_g:
+        assert torch.equal(a_g[n], b_g[n]), n
+
+
+def test_variance_predictors_beside_the_postnet_or_the_decoder_same_results(emulated_cabi, monkeypatch):
+    """The teacher-forced variance predictors only feed their own losses: started beside the postnet (default) or beside
+    the decoder (round 2, KANTTS_PREDICTORS_EARLY) they must give the same predictions and gradients."""
+    a_out, a_g = _tiny_training_run(monkeypatch, lambda m, KS: monkeypatch.setattr(KS, "_PREDICTORS_LATE", True))
+    b_out, b_g = _tiny_training_run(monkeypatch, lambda m, KS: monkeypatch.setattr(KS, "_PREDICTORS_LATE", False))
+    for x, y in zip(a_out, b_out):
+        assert torch.equal(x, y)
+    for n in a_g:
+        assert torch.equal(a_g[n], b_g[n]), n
+
+
 def test_arena_adam_matches_torch_adam(emulated_cabi):
     from kantts.train.optim import ArenaAdam, ParamArena
 
