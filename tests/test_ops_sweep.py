@@ -268,3 +268,42 @@ def test_elementwise_losses_weight_norm_sin_add(emulated_cabi):
             cot_t = cot.permute(2, 0, 1).contiguous()
             ref2 = gg * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)
             _cmp(_grads(wt, cot_t, [v, gg]), _grads(ref2, cot, [v, gg]), cfg)
+
+
+def test_pnca_backward_separate_query_gradients_are_summed_by_the_host(emulated_cabi, monkeypatch):
+    """kantts_pnca_attn_bwd returns 1 (not 0) for sequences of more than 256 positions: the two bands' query gradients then
+    come back in two buffers and ops._PncaAttention adds them.  The emulation always takes the summed form, so the
+    separate form is provided here (per-band emulation, memory band into dqh) and must give the same gradients."""
+    from kantts._hip import ops
+
+    emu = emulated_cabi
+    B, L, H = 2, 19, 8
+    D = H * 16
+    g = torch.Generator().manual_seed(3)
+    qkv0 = torch.randn(B, L, 3 * D, generator=g)
+    hkv0 = torch.randn(B, L, 2 * D, generator=g)
+    lens = torch.tensor([19, 11], dtype=torch.int32)
+    cot = torch.randn(B, L, D, generator=g)
+
+    def run():
+        qkv, hkv = qkv0.clone().requires_grad_(True), hkv0.clone().requires_grad_(True)
+        ox, oh, _, _ = ops.pnca_attention(qkv, hkv, lens, 3, 2, H)
+        ((ox * cot).sum() + (oh * cot.flip(0)).sum()).backward()
+        return qkv.grad.clone(), hkv.grad.clone()
+
+    want = run()
+
+    def separate(qkv, hkv, ldh, ox, oh, d_ox, d_oh, lse_x, lse_h, dqkv, dqh, dhkv, lens_, bw_dev, bw_x, bw_h, B_, H_, L_,
+                 d_head, drop_p, seed_x, seed_h, seed_dev, stream):
+        qkv, hkv, dqkv, dhkv = int(qkv), int(hkv), int(dqkv), int(dhkv)
+        emu.kantts_attn_bwd(qkv, qkv + 4 * D, qkv + 8 * D, 3 * D, 3 * D, 3 * D, ox, D, d_ox, D, lse_x, None, dqkv,
+                            dqkv + 4 * D, dqkv + 8 * D, 3 * D, 3 * D, 3 * D, 0, lens_, bw_dev, bw_x, B_, H_, L_, d_head, 1,
+                            drop_p, seed_x, seed_dev, stream)
+        emu.kantts_attn_bwd(qkv, hkv, hkv + 4 * D, 3 * D, ldh, ldh, oh, D, d_oh, D, lse_h, None, dqh, dhkv, dhkv + 4 * D,
+                            D, 2 * D, 2 * D, 0, lens_, bw_dev, bw_h, B_, H_, L_, d_head, 2, drop_p, seed_h, seed_dev, stream)
+        return 1
+
+    monkeypatch.setattr(emu, "kantts_pnca_attn_bwd", separate, raising=False)
+    got = run()
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=0, atol=1e-6)
