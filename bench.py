@@ -129,6 +129,23 @@ def oracle_probe_main(threads, B):
     print(json.dumps({"cores": threads, "value": frames / dt, "timed": n, "s_per_iter": dt}))
 
 
+def _usable_cores():
+    """Host cores this process may actually run on: the affinity mask, cut by the cgroup CPU quota when there is one
+    (a container that sees 256 cores but owns 32 of them makes an "all cores" thread count an oversubscription test)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _oracle_probe(threads, B, limit_s, ref_s=float('nan')):
     import subprocess
 
@@ -185,10 +202,11 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
     # every host core, beside the default thread count (the chain of small ops gets SLOWER beyond ~16 threads on this box
     # class; reported so that the choice is visible).  Runs in a child process under a hard time limit: one iteration at
     # 256 threads must not be able to eat the bench's time budget.
-    all_cores = os.cpu_count() or 1
+    all_cores = _usable_cores()
     all_core = None
     if all_cores > cores and CPU_THREADS["n"] is None:
-        all_core = _oracle_probe(all_cores, B, limit_s=150.0, ref_s=dt_off)
+        all_core = _oracle_probe(all_cores, B, limit_s=90.0, ref_s=dt_off)
+        all_core["visible_cores"] = os.cpu_count() or 1
 
     # ---- parity of the HIP path at the benchmarked shape (dropout forced to 0 on both sides)
     parity = {}
