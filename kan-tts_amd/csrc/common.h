@@ -14,6 +14,13 @@
     return KANTTS_OK;                                 \
   } while (0)
 
+// Marks a point where lanes of ONE wave read LDS cells that other lanes of the same wave wrote just before, relying on a
+// wave's LDS operations executing in order (no barrier instruction on the device).  Expands to nothing here; the host
+// build of the kernel sources used by the CPU tests (tests/hipemu) pre-defines it as a rendezvous of the wave's lanes.
+#ifndef KANTTS_WAVE_ORDERED
+#define KANTTS_WAVE_ORDERED()
+#endif
+
 static inline int kantts_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_a
       }
     }
     // the wave's own 32 columns of T -> HBM (LDS operations of a wave execute in order: no barrier)
+    KANTTS_WAVE_ORDERED();
     if (g.t_out) {
       __bf16* tp = reinterpret_cast<__bf16*>(g.t_out);
 #pragma unroll

@@ -6,76 +6,113 @@ import torch.nn.functional as F
 from kantts._hip import ops
 
 
+def _masked_mse(pred, target, lens):
+    """sum over valid rows of (target - pred)^2 / (valid rows * row width) -- loss_type="mse" of the two criteria below
+    (reference :13-14, :46-47).  No shipped yaml selects it, so it is a handful of elementwise launches rather than a
+    variant of kantts_masked_l1."""
+    T = pred.size(1)
+    valid = torch.arange(T, device=pred.device)[None, :] < lens.to(pred.device)[:, None]
+    width = pred.numel() // (pred.size(0) * T)
+    sq = (target.to(pred.dtype) - pred) ** 2
+    if sq.dim() == 3:
+        sq = sq * valid.unsqueeze(-1)
+    else:
+        sq = sq * valid
+    return sq.sum() / (valid.sum() * width)
+
+
+def _check_loss_type(loss_type):
+    if loss_type not in ("mae", "mse"):
+        raise ValueError("Unknown loss type: {}".format(loss_type))
+    return ops.masked_l1 if loss_type == "mae" else _masked_mse
+
+
 class MelReconLoss(torch.nn.Module):
-    """Masked mean |target - output| for decoder and postnet mels (reference :7-37)."""
+    """Masked mean |target - output| (``"mae"``) or squared error (``"mse"``) for decoder and postnet mels
+    (reference :7-37)."""
 
     def __init__(self, loss_type="mae"):
         super(MelReconLoss, self).__init__()
         self.loss_type = loss_type
-        if loss_type != "mae":
-            raise NotImplementedError("only loss_type='mae' is used by the shipped configs")
+        _check_loss_type(loss_type)
 
     def forward(self, output_lengths, mel_targets, dec_outputs, postnet_outputs=None):
         lens = output_lengths.to(torch.int64)
-        mel_loss_ = ops.masked_l1(dec_outputs, mel_targets, lens)
-        mel_loss = ops.masked_l1(postnet_outputs, mel_targets, lens) if postnet_outputs is not None else 0.0
+        criterion = _check_loss_type(self.loss_type)
+        mel_loss_ = criterion(dec_outputs, mel_targets, lens)
+        mel_loss = criterion(postnet_outputs, mel_targets, lens) if postnet_outputs is not None else 0.0
         return mel_loss_, mel_loss
 
 
 class ProsodyReconLoss(torch.nn.Module):
-    """Masked L1 on log-duration, pitch, energy (reference :40-85)."""
+    """Masked L1 (``"mae"``) or squared error (``"mse"``) on log-duration, pitch, energy (reference :40-85)."""
 
     def __init__(self, loss_type="mae"):
         super(ProsodyReconLoss, self).__init__()
         self.loss_type = loss_type
-        if loss_type != "mae":
-            raise NotImplementedError("only loss_type='mae' is used by the shipped configs")
+        _check_loss_type(loss_type)
 
     def forward(self, input_lengths, duration_targets, pitch_targets, energy_targets, log_duration_predictions,
                 pitch_predictions, energy_predictions):
         lens = input_lengths.to(torch.int64)
-        dur_loss = ops.masked_l1(log_duration_predictions, torch.log(duration_targets.float() + 1), lens)
-        pitch_loss = ops.masked_l1(pitch_predictions, pitch_targets, lens)
-        energy_loss = ops.masked_l1(energy_predictions, energy_targets, lens)
+        criterion = _check_loss_type(self.loss_type)
+        dur_loss = criterion(log_duration_predictions, torch.log(duration_targets.float() + 1), lens)
+        pitch_loss = criterion(pitch_predictions, pitch_targets, lens)
+        energy_loss = criterion(energy_predictions, energy_targets, lens)
         return dur_loss, pitch_loss, energy_loss
 
 
 class GeneratorAdversarialLoss(torch.nn.Module):
-    """LSGAN generator loss: mean over discriminators of mse(D(G(x)), 1) (reference :108-151)."""
+    """Generator adversarial loss, mean (or sum) over discriminators: LSGAN ``mse(D(G(x)), 1)`` (``"mse"``, every shipped
+    yaml: one reduction kernel per score) or ``-mean(D(G(x)))`` (``"hinge"``) (reference :108-151)."""
 
     def __init__(self, average_by_discriminators=True, loss_type="mse"):
         super().__init__()
-        if loss_type != "mse":
-            raise NotImplementedError("hinge adversarial loss is not used by the shipped yamls")
+        assert loss_type in ["mse", "hinge"], f"{loss_type} is not supported."
         self.average_by_discriminators = average_by_discriminators
+        self.loss_type = loss_type
+
+    def criterion(self, x):
+        return ops.mse_to_const(x, 1.0) if self.loss_type == "mse" else -x.mean()
 
     def forward(self, outputs):
         if not isinstance(outputs, (tuple, list)):
-            return ops.mse_to_const(outputs, 1.0)
+            return self.criterion(outputs)
         adv = 0.0
         for o in outputs:
-            adv = adv + ops.mse_to_const(o[-1] if isinstance(o, (tuple, list)) else o, 1.0)
+            adv = adv + self.criterion(o[-1] if isinstance(o, (tuple, list)) else o)
         return adv / len(outputs) if self.average_by_discriminators else adv
 
 
 class DiscriminatorAdversarialLoss(torch.nn.Module):
-    """LSGAN discriminator loss -> (real, fake) (reference :154-216)."""
+    """Discriminator adversarial loss -> (real, fake): LSGAN (``"mse"``, every shipped yaml) or hinge
+    ``mean(relu(1 - D(x)))``, ``mean(relu(1 + D(G(x))))`` (reference :154-216)."""
 
     def __init__(self, average_by_discriminators=True, loss_type="mse"):
         super().__init__()
-        if loss_type != "mse":
-            raise NotImplementedError("hinge adversarial loss is not used by the shipped yamls")
+        assert loss_type in ["mse", "hinge"], f"{loss_type} is not supported."
         self.average_by_discriminators = average_by_discriminators
+        self.loss_type = loss_type
+
+    def real_criterion(self, x):
+        if self.loss_type == "mse":
+            return ops.mse_to_const(x, 1.0)
+        return torch.clamp(1.0 - x, min=0.0).mean()  # = -mean(min(x - 1, 0)) of the reference
+
+    def fake_criterion(self, x):
+        if self.loss_type == "mse":
+            return ops.mse_to_const(x, 0.0)
+        return torch.clamp(1.0 + x, min=0.0).mean()  # = -mean(min(-x - 1, 0))
 
     def forward(self, outputs_hat, outputs):
         if not isinstance(outputs, (tuple, list)):
-            return ops.mse_to_const(outputs, 1.0), ops.mse_to_const(outputs_hat, 0.0)
+            return self.real_criterion(outputs), self.fake_criterion(outputs_hat)
         real, fake = 0.0, 0.0
         for oh, o in zip(outputs_hat, outputs):
             if isinstance(oh, (tuple, list)):
                 oh, o = oh[-1], o[-1]
-            real = real + ops.mse_to_const(o, 1.0)
-            fake = fake + ops.mse_to_const(oh, 0.0)
+            real = real + self.real_criterion(o)
+            fake = fake + self.fake_criterion(oh)
         if self.average_by_discriminators:
             real, fake = real / len(outputs), fake / len(outputs)
         return real, fake

@@ -609,6 +609,57 @@ def multiband_case():
           fix["multispec_default_ctor"], fix["mrstft_subband"].get("error"))
 
 
+def loss_variants_case():
+    """The criteria variants no shipped yaml selects (loss.py:7-85 with loss_type="mse"; :108-216 with loss_type="hinge"):
+    values and input gradients of the reference classes on seeded inputs (padded batch; discriminator outputs as plain
+    tensors, as lists, and as lists of feature-map lists)."""
+    from kantts.train.loss import DiscriminatorAdversarialLoss, GeneratorAdversarialLoss
+
+    g = torch.Generator().manual_seed(11)
+    B, T, C, N = 3, 17, 8, 9
+    out_len, in_len = torch.tensor([17, 9, 13]), torch.tensor([9, 4, 7])
+    fix = dict(output_lengths=out_len, input_lengths=in_len,
+               mel_targets=torch.randn(B, T, C, generator=g), dec=torch.randn(B, T, C, generator=g),
+               post=torch.randn(B, T, C, generator=g), dur=torch.randint(0, 9, (B, N), generator=g),
+               pitch=torch.randn(B, N, generator=g), energy=torch.randn(B, N, generator=g),
+               logdur_p=torch.randn(B, N, generator=g), pitch_p=torch.randn(B, N, generator=g),
+               energy_p=torch.randn(B, N, generator=g))
+    dec, post = fix["dec"].clone().requires_grad_(True), fix["post"].clone().requires_grad_(True)
+    a, b = MelReconLoss("mse")(out_len, fix["mel_targets"], dec, post)
+    (a + 2 * b).backward()
+    fix["mel_mse"] = (a.detach(), b.detach(), dec.grad.clone(), post.grad.clone())
+    fix["mel_mse_no_postnet"] = MelReconLoss("mse")(out_len, fix["mel_targets"], fix["dec"])[0]
+    lp, pp, ep = (fix[k].clone().requires_grad_(True) for k in ("logdur_p", "pitch_p", "energy_p"))
+    d, p_, e = ProsodyReconLoss("mse")(in_len, fix["dur"], fix["pitch"], fix["energy"], lp, pp, ep)
+    (d + 2 * p_ + 3 * e).backward()
+    fix["prosody_mse"] = (d.detach(), p_.detach(), e.detach(), lp.grad.clone(), pp.grad.clone(), ep.grad.clone())
+    # discriminator outputs: 3 discriminators, each a list of 2 feature maps + the score
+    shapes = [[(2, 4, 30), (2, 8, 10), (2, 1, 10)], [(2, 4, 6, 5), (2, 8, 3, 5), (2, 1, 3, 5)], [(2, 6, 12), (2, 6, 6), (2, 1, 6)]]
+    fake = [[torch.randn(*sh, generator=g) for sh in d_] for d_ in shapes]
+    real = [[torch.randn(*sh, generator=g) for sh in d_] for d_ in shapes]
+    fix["d_fake"], fix["d_real"] = fake, real
+    hinge = {}
+    for avg in (True, False):
+        scores = [f[-1].clone().requires_grad_(True) for f in fake]
+        v = GeneratorAdversarialLoss(average_by_discriminators=avg, loss_type="hinge")(scores)
+        v.backward()
+        hinge[("g_list", avg)] = (v.detach(), [s_.grad.clone() for s_ in scores])
+        fk = [[t.clone().requires_grad_(True) for t in f] for f in fake]
+        rl = [[t.clone().requires_grad_(True) for t in f] for f in real]
+        r_, f_ = DiscriminatorAdversarialLoss(average_by_discriminators=avg, loss_type="hinge")(fk, rl)
+        (r_ + 2 * f_).backward()
+        hinge[("d_nested", avg)] = (r_.detach(), f_.detach(), [f[-1].grad.clone() for f in fk], [f[-1].grad.clone() for f in rl])
+    one = fake[0][-1].clone().requires_grad_(True)
+    v = GeneratorAdversarialLoss(loss_type="hinge")(one)
+    v.backward()
+    hinge["g_tensor"] = (v.detach(), one.grad.clone())
+    r_, f_ = DiscriminatorAdversarialLoss(loss_type="hinge")(fake[1][-1], real[1][-1])
+    hinge["d_tensor"] = (r_, f_)
+    fix["hinge"] = hinge
+    torch.save(fix, os.path.join(OUT, "loss_variants.pt"))
+    print("loss_variants.pt", float(a), float(d), float(hinge[("g_list", True)][0]))
+
+
 def masks_case():
     """get_mask_from_lengths (kantts/models/utils.py:13-23) and get_lfr_mask_from_lengths' ceil(len / r) rule on
     seeded lengths, with and without an explicit max_len."""
@@ -659,3 +710,4 @@ if __name__ == "__main__":
     hifigan_v1_b32_case()
     masks_case()
     multiband_case()
+    loss_variants_case()

@@ -1,0 +1,157 @@
+"""The kernel SOURCES on the CPU (no GPU needed): kan-tts_amd/csrc/*.hip compiled for the host against tests/hipemu (every
+thread a fibre, every wave-level operation -- shuffles, DPP, ballots, MFMA, the transposing LDS read, direct-to-LDS loads --
+a rendezvous of the wave's 64 fibres) and loaded by the product's own ctypes loader in place of libkantts_hip.so.
+
+Nothing new is asserted here: the cases below ARE the suite's emulated-ABI tests and the op-level GPU tests, re-collected
+with ``conftest._emulate`` / ``run_both`` pointed at that library.  Where the original compares the product's host logic
+(under the numpy model of the C ABI) with the oracle or a reference-recorded golden, this module compares what the kernel
+source computes with the same oracle / golden; where the original compares GPU and numpy model per entry point, this one
+compares kernel source and numpy model.  What it cannot see: anything about timing, and hardware behaviour the stand-in
+does not model (tests/hipemu/README.md)."""
+import functools
+import importlib
+import os
+
+import pytest
+
+import util
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")),
+                                reason="the host build of the kernel sources needs the ROCm clang")
+FULL = os.environ.get("KANTTS_HOSTSIM_FULL", "") not in ("", "0")
+full_only = pytest.mark.skipif(not FULL, reason="minutes of CPU time: set KANTTS_HOSTSIM_FULL=1")
+
+# ---- emulated-ABI tests re-collected here (their fixtures come along)
+from test_host_logic_emulated import (  # noqa: F401
+    test_tiny_sambert_forward_backward_matches_oracle,
+    test_dropout_backward_consistent_with_forward_mask,
+    test_dropout2_add_and_fsmn_encoder_training_path,
+    test_row_mask_handed_to_the_consuming_layernorm_changes_no_gradient,
+    test_arena_adam_matches_torch_adam,
+    test_free_running_inference_matches_oracle,
+)
+from test_ops_sweep import (  # noqa: F401
+    test_fused_linear_modes,
+    test_attention_ragged_lengths_and_bands,
+    test_lstm_uni_and_bidirectional_with_lengths,
+    test_fsmn_memory_length_regulator_embedding_and_masked_l1,
+    test_elementwise_losses_weight_norm_sin_add,
+)
+from test_bf16_path_emulated import (  # noqa: F401
+    bf16_mode,
+    test_linear_modes_bf16_emulated,
+    test_conv_mode_and_ffn_bf16_emulated,
+    test_tiny_sambert_bf16_mode_emulated_close_to_oracle,
+)
+from test_conv_sweep import test_conv_cl_random_configurations, test_conv_transpose_cl_random_configurations  # noqa: F401
+from test_cconv import (  # noqa: F401
+    bf16_all_sizes,
+    test_cconv_path_random_configurations_emulated,
+    test_cconv_transposed_random_configurations_emulated,
+    test_image_handover_is_bit_identical_emulated,
+    test_fused_residual_stack_equals_the_chain_emulated,
+)
+from test_mas import (  # noqa: F401
+    test_mas_dp_emulation_is_bit_exact_vs_reference,
+    test_align_attention_host_logic,
+    test_sambert_mas_host_logic_matches_reference_fixture,
+)
+from test_melspec import test_melspec_host_logic_emulated, test_melspec_backward_emulated  # noqa: F401
+from test_hifigan import test_conv_variants_emulated_match_torch, test_conv_win_emulated_matches_torch  # noqa: F401
+from test_hifigan_nsf import test_nsf_generator_host_logic_matches_reference_fixture  # noqa: F401
+from test_sambert_se import test_sambert_se_host_logic_matches_reference_fixture  # noqa: F401
+from test_multiband import test_pqmf_emulated, test_multispec_emulated  # noqa: F401
+from test_edge_cases import test_sambert_single_and_one_token_utterances_emulated  # noqa: F401
+from test_device_batching import (  # noqa: F401
+    test_device_voc_batches_equal_host_collate_emulated,
+    test_device_am_batches_equal_host_collate_emulated,
+)
+
+
+@pytest.fixture(autouse=True)
+def kernel_source_instead_of_the_numpy_model(monkeypatch):
+    """Everything that would install oracle/cabi_numpy.EmulatedLib (the ``emulated_cabi`` fixture, ``util.emulation()``)
+    installs the host build of the kernel sources instead."""
+    import conftest
+
+    monkeypatch.setattr(conftest, "_emulate", util.install_kernel_source)
+    yield
+
+
+@pytest.mark.parametrize("B,seed", [(1, 77), pytest.param(3, 5, marks=full_only)])
+def test_fused_decode_step_on_the_kernel_source(B, seed):
+    importlib.import_module("test_decode_graph").test_fused_decode_step_matches_python_loop_emulated(B, seed)
+
+
+# ---- training steps on the kernel source
+@full_only
+def test_six_training_steps_retrace_the_reference_loss_curve_on_the_kernel_source():
+    """tests/golden/sambert_curve.pt (recorded from the reference's trainer): the six losses to 2e-4, as in the GPU test
+    (parameter checksums not compared, for the reason given at test_trainer.test_sambert_loss_curve_matches_reference_gpu)."""
+    import test_trainer
+
+    with util.kernel_source_on_cpu():
+        test_trainer._curve("cpu", param_tol=None)
+
+
+@full_only
+@pytest.mark.parametrize("name", ["test_hifigan_host_logic_emulated", "test_gan_step_losses_emulated"])
+def test_hifigan_generator_discriminators_and_gan_step_on_the_kernel_source(name):
+    getattr(importlib.import_module("test_hifigan"), name)()
+
+
+@full_only
+def test_vocoder_edge_cases_on_the_kernel_source():
+    importlib.import_module("test_edge_cases").test_vocoder_minimal_and_odd_lengths_emulated()
+
+
+# ---- the op-level GPU tests with the kernel source in the place of the device (second leg: the numpy model of the ABI)
+def _op_test(module, name, precision="fp32", **kw):
+    import kantts._hip as hip
+
+    m = importlib.import_module(module)
+    old_run, old_prec = m.run_both, hip.get_precision()
+    m.run_both = functools.partial(util.run_both, device="hostsim")
+    hip.set_precision(precision)
+    try:
+        getattr(m, name)(**kw)
+    finally:
+        m.run_both = old_run
+        hip.set_precision(old_prec)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("ref", 2e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("M,N,K", [(70, 50, 45), (256, 384, 128), (33, 1, 256), (130, 240, 80)])
+def test_op_linear_fwd_bwd(prec, tol, M, N, K):
+    _op_test("test_gpu_ops", "test_linear_fwd_bwd", prec=prec, tol=tol, M=M, N=N, K=K)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("test_layernorm", dict(M=37, C=128)), ("test_layernorm", dict(M=2048, C=512)), ("test_layernorm", dict(M=5, C=80)),
+    ("test_self_attention", dict(drop=0.0)), ("test_self_attention", dict(drop=0.1)),
+    ("test_pnca_attention", dict(bw=0)), ("test_pnca_attention", dict(bw=3)), ("test_pnca_attention", dict(bw=50)),
+    ("test_attention_long_sequence_fallback_kernels", {}),
+    ("test_lstm_uni_bi_and_concat", {}), ("test_lstm_bf16_recurrence_close_to_fp32", {}),
+    ("test_fsmn_memory", dict(C=128, K=41, lp=20)), ("test_fsmn_memory", dict(C=256, K=41, lp=37)),
+    ("test_dropout2_add_kernel", {}),
+], ids=lambda v: v if isinstance(v, str) else "-".join("%s" % x for x in v.values()))
+def test_op_fp32_mode(name, kw):
+    _op_test("test_gpu_ops", name, **kw)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("test_linear_plain", dict(M=6528, K=128, N=384, x_bf16=True, out_bf16=False)),
+    ("test_linear_plain", dict(M=1000, K=160, N=256, x_bf16=False, out_bf16=True)),
+    ("test_linear_plain", dict(M=77, K=80, N=240, x_bf16=False, out_bf16=False)),
+    ("test_linear_plain", dict(M=33, K=8, N=8, x_bf16=False, out_bf16=False)),
+    ("test_linear_epilogues_and_modes", {}),
+    ("test_conv_mode_and_fused_ffn", dict(k1=3)), ("test_conv_mode_and_fused_ffn", dict(k1=1)),
+    pytest.param("test_ffn_pair_kernel_forward_and_backward_forms", dict(M=6528, T=204, F=1024, KT=1),
+                 marks=full_only),  # the benchmarked block
+    ("test_ffn_pair_kernel_forward_and_backward_forms", dict(M=111, T=37, F=1024, KT=1)),
+    ("test_ffn_pair_kernel_forward_and_backward_forms", dict(M=95, T=19, F=1024, KT=3)),
+    ("test_ffn_pair_kernel_forward_and_backward_forms", dict(M=32, T=32, F=1024, KT=5)),
+    ("test_layer_norm128", dict(M=6528)), ("test_layer_norm128", dict(M=100)), ("test_layer_norm128", dict(M=5)),
+], ids=lambda v: v if isinstance(v, str) else "-".join("%s" % x for x in v.values()))
+def test_op_bf16_mode(name, kw):
+    _op_test("test_gpu_bf16_ops", name, precision="bf16", **kw)

@@ -109,3 +109,66 @@ def test_get_mask_from_lengths_bit_exact():
         assert torch.equal(O.pad_mask(c["lengths"], c["max_len"]), c["mask_maxlen"])
         info = SeqInfo.of(c["mask_maxlen"])
         assert torch.equal(info.lens64, c["lengths"]) and torch.equal(info.mask, c["mask_maxlen"])
+
+
+def test_mse_and_hinge_criteria_match_the_reference_classes():
+    """The criteria variants no shipped yaml selects (loss_type="mse" of the reconstruction losses, loss_type="hinge" of the
+    adversarial losses) against values and input gradients recorded from the reference classes
+    (tests/golden/loss_variants.pt, oracle/make_golden.py::loss_variants_case).  They are plain elementwise arithmetic on
+    whatever device the tensors live on, so the host tensors of the fixture exercise the shipped code."""
+    from kantts.train.loss import (DiscriminatorAdversarialLoss, GeneratorAdversarialLoss, MelReconLoss,
+                                   ProsodyReconLoss)
+
+    fix = torch.load(os.path.join(GOLDEN, "loss_variants.pt"), weights_only=False)
+
+    def close(a, b, tol=1e-6):
+        assert torch.allclose(torch.as_tensor(a), torch.as_tensor(b), rtol=1e-5, atol=tol), (a, b)
+
+    dec, post = fix["dec"].clone().requires_grad_(True), fix["post"].clone().requires_grad_(True)
+    a, b = MelReconLoss("mse")(fix["output_lengths"], fix["mel_targets"], dec, post)
+    (a + 2 * b).backward()
+    for got, want in zip((a, b, dec.grad, post.grad), fix["mel_mse"]):
+        close(got.detach(), want)
+    only, zero = MelReconLoss("mse")(fix["output_lengths"], fix["mel_targets"], fix["dec"])
+    close(only, fix["mel_mse_no_postnet"])
+    assert zero == 0.0
+    lp, pp, ep = (fix[k].clone().requires_grad_(True) for k in ("logdur_p", "pitch_p", "energy_p"))
+    d, p, e = ProsodyReconLoss("mse")(fix["input_lengths"], fix["dur"], fix["pitch"], fix["energy"], lp, pp, ep)
+    (d + 2 * p + 3 * e).backward()
+    for got, want in zip((d, p, e, lp.grad, pp.grad, ep.grad), fix["prosody_mse"]):
+        close(got.detach(), want)
+    with pytest.raises(ValueError):
+        MelReconLoss("huber")
+    with pytest.raises(ValueError):
+        ProsodyReconLoss("huber")
+
+    fake, real, hinge = fix["d_fake"], fix["d_real"], fix["hinge"]
+    for avg in (True, False):
+        scores = [f[-1].clone().requires_grad_(True) for f in fake]
+        v = GeneratorAdversarialLoss(average_by_discriminators=avg, loss_type="hinge")(scores)
+        v.backward()
+        want_v, want_g = hinge[("g_list", avg)]
+        close(v.detach(), want_v)
+        for s_, w in zip(scores, want_g):
+            close(s_.grad, w)
+        fk = [[t.clone().requires_grad_(True) for t in f] for f in fake]
+        rl = [[t.clone().requires_grad_(True) for t in f] for f in real]
+        r_, f_ = DiscriminatorAdversarialLoss(average_by_discriminators=avg, loss_type="hinge")(fk, rl)
+        (r_ + 2 * f_).backward()
+        want_r, want_f, gf, gr = hinge[("d_nested", avg)]
+        close(r_.detach(), want_r)
+        close(f_.detach(), want_f)
+        for t, w in zip(fk, gf):
+            close(t[-1].grad, w)
+        for t, w in zip(rl, gr):
+            close(t[-1].grad, w)
+    one = fake[0][-1].clone().requires_grad_(True)
+    v = GeneratorAdversarialLoss(loss_type="hinge")(one)
+    v.backward()
+    close(v.detach(), hinge["g_tensor"][0])
+    close(one.grad, hinge["g_tensor"][1])
+    r_, f_ = DiscriminatorAdversarialLoss(loss_type="hinge")(fake[1][-1], real[1][-1])
+    close(r_, hinge["d_tensor"][0])
+    close(f_, hinge["d_tensor"][1])
+    with pytest.raises(AssertionError):
+        GeneratorAdversarialLoss(loss_type="wasserstein")

@@ -34,6 +34,56 @@ def emulation():
         p.undo()
 
 
+def install_kernel_source(p):
+    """Same contract as conftest._emulate (``p``: a monkeypatch-like object), but what is installed is
+    tests/hipemu/_build/libkantts_hostsim.so -- the kernel SOURCES of kan-tts_amd/csrc compiled for the host and run by
+    the fibre scheduler of tests/hipemu -- loaded by the product's own loader in place of libkantts_hip.so, with host
+    tensors.  Test-only (the product refuses host tensors and has no such switch)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    try:
+        import build as hipemu_build
+    finally:
+        sys.path.pop(0)
+    import kantts._hip as hip
+    import kantts._hip.ops as ops
+    import kantts._hip.ops_bf16 as ops_bf16
+    import kantts.utils.audio_torch as audio_torch
+
+    so = hipemu_build.build()
+
+    def ptr(t, dtype=None):
+        if t is None:
+            return None
+        if dtype is not None and t.dtype != dtype:
+            raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+        assert not t.is_cuda
+        return t.data_ptr()
+
+    p.setattr(hip, "LIB_PATH", so)
+    p.setattr(hip, "_lib", _HOSTSIM.get("lib"))
+    _HOSTSIM["lib"] = real = hip.lib()  # the product's own loader: same argtypes as for the device library
+    for mod in (hip, ops, ops_bf16, audio_torch):
+        p.setattr(mod, "lib", lambda: real)
+        p.setattr(mod, "ptr", ptr)
+        p.setattr(mod, "stream", lambda: None)
+    return real
+
+
+@contextlib.contextmanager
+def kernel_source_on_cpu():
+    """Temporarily route the binding to the host build of the kernel sources (install_kernel_source) -- test-only."""
+    p = _Patch()
+    try:
+        yield install_kernel_source(p)
+    finally:
+        p.undo()
+
+
+_HOSTSIM = {}
+
+
 def to_dev(x, device):
     if torch.is_tensor(x):
         y = x.detach().to(device)
@@ -50,12 +100,13 @@ def to_dev(x, device):
 def run_both(fn, *args, grads_of=(), device="cuda"):
     """Run ``fn(*args)`` on the GPU through libkantts_hip.so and on the CPU through the emulated C ABI.
     fn returns a tensor or tuple of tensors; tensors in ``args`` flagged requires_grad get gradients of
-    sum(out_k * W_k) with fixed random cotangents.  Returns (gpu_outs, gpu_grads, cpu_outs, cpu_grads)."""
+    sum(out_k * W_k) with fixed random cotangents.  Returns (gpu_outs, gpu_grads, cpu_outs, cpu_grads).
+    ``device="hostsim"``: the first leg runs the kernel sources on the CPU (kernel_source_on_cpu) instead."""
     results = []
     cots = None
     for dev in (device, "cpu"):
-        a = [to_dev(t, dev) for t in args]
-        ctx = emulation() if dev == "cpu" else contextlib.nullcontext()
+        a = [to_dev(t, "cpu" if dev == "hostsim" else dev) for t in args]
+        ctx = emulation() if dev == "cpu" else (kernel_source_on_cpu() if dev == "hostsim" else contextlib.nullcontext())
         with ctx:
             out = fn(*a)
             outs = [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(o)]
