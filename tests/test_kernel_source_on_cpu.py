@@ -42,6 +42,9 @@ from test_bf16_path_emulated import (  # noqa: F401
     test_linear_modes_bf16_emulated,
     test_conv_mode_and_ffn_bf16_emulated,
     test_tiny_sambert_bf16_mode_emulated_close_to_oracle,
+    test_deferred_grouped_weight_gradients_equal_immediate_ones,
+    test_ffn_pair_equals_the_two_launch_form,
+    test_shared_input_linears_equal_separate_ones,
 )
 from test_conv_sweep import test_conv_cl_random_configurations, test_conv_transpose_cl_random_configurations  # noqa: F401
 from test_cconv import (  # noqa: F401
@@ -56,7 +59,11 @@ from test_mas import (  # noqa: F401
     test_align_attention_host_logic,
     test_sambert_mas_host_logic_matches_reference_fixture,
 )
-from test_melspec import test_melspec_host_logic_emulated, test_melspec_backward_emulated  # noqa: F401
+from test_melspec import (  # noqa: F401
+    test_melspec_host_logic_emulated,
+    test_melspec_backward_emulated,
+    test_dsp_melspectrogram_emulated,
+)
 from test_hifigan import test_conv_variants_emulated_match_torch, test_conv_win_emulated_matches_torch  # noqa: F401
 from test_hifigan_nsf import test_nsf_generator_host_logic_matches_reference_fixture  # noqa: F401
 from test_sambert_se import test_sambert_se_host_logic_matches_reference_fixture  # noqa: F401
@@ -98,6 +105,13 @@ def test_six_training_steps_retrace_the_reference_loss_curve_on_the_kernel_sourc
 @pytest.mark.parametrize("name", ["test_hifigan_host_logic_emulated", "test_gan_step_losses_emulated"])
 def test_hifigan_generator_discriminators_and_gan_step_on_the_kernel_source(name):
     getattr(importlib.import_module("test_hifigan"), name)()
+
+
+@pytest.mark.parametrize("key", ["mrstft", "mrstft_subband"])
+def test_multi_resolution_stft_loss_and_its_gradient_on_the_kernel_source(key):
+    """tests/golden/multiband.pt (reference values); gradient tolerance of the device test (two fp32 FFTs)."""
+    with util.kernel_source_on_cpu():
+        importlib.import_module("test_multiband")._mrstft("cpu", key, grad_tol=5e-3)
 
 
 @full_only
@@ -155,3 +169,135 @@ def test_op_fp32_mode(name, kw):
 ], ids=lambda v: v if isinstance(v, str) else "-".join("%s" % x for x in v.values()))
 def test_op_bf16_mode(name, kw):
     _op_test("test_gpu_bf16_ops", name, precision="bf16", **kw)
+
+
+# ---- entry points no emulated-ABI test reaches with host tensors: the GPU tests' arithmetic, on the kernel source
+@pytest.mark.parametrize("Cin,Cout,s,T", [(64, 32, 2, 70), (128, 64, 2, 37), (256, 128, 8, 19)])
+def test_upsampling_stream_kernel_and_sin_add_image(Cin, Cout, s, T):
+    """kantts_sinadd_lrelu_fwd + kantts_upsample_stream (narrow layers) / the 2-tap polyphase cconv form (wide layers)
+    against torch's conv_transpose1d on the same bf16-rounded operands (tests/test_hifigan.py::
+    test_upsample_streaming_kernels_gpu with host tensors)."""
+    import torch
+    import torch.nn.functional as F
+
+    import kantts._hip as hip
+    from kantts._hip import ops
+    from util import assert_close, rel_l2
+
+    with util.kernel_source_on_cpu():
+        hip.set_precision("bf16")
+        try:
+            g = torch.Generator().manual_seed(Cin + T)
+            B = 2
+            x = torch.randn(B, T, Cin, generator=g)
+            w = torch.randn(Cin, Cout, 2 * s, generator=g) * (1.0 / (2 * Cin) ** 0.5)
+            b = torch.randn(Cout, generator=g)
+            res = torch.randn(B, T * s, Cout, generator=g)
+            h, act = ops.sin_add(x, act_slope=0.1)
+            assert_close(h, torch.sin(x) + x, 1e-6, what="sin_add")
+            a = F.leaky_relu(torch.sin(x) + x, 0.1).to(torch.bfloat16)
+            assert float((act.float() - a.float()).abs().max()) <= 2e-2
+            wq = w.to(torch.bfloat16).float()
+            ref = F.conv_transpose1d(act.float().transpose(1, 2), wq, b, stride=s)[:, :, :T * s].transpose(1, 2)
+            y = ops.upsample_forward(act, w, b, s, res=res)
+            assert y is not None and y.dtype == torch.float32
+            assert rel_l2(y, ref + res) <= 2e-5
+            if Cin <= 128:
+                y2 = ops.upsample_forward(act, w, b, s, out_bf16=True)
+                assert y2.dtype == torch.bfloat16 and rel_l2(y2.float(), ref) <= 4e-3
+                hb = h.to(torch.bfloat16)
+                a3 = F.leaky_relu(hb.float(), 0.1).to(torch.bfloat16).float()
+                ref3 = F.conv_transpose1d(a3.transpose(1, 2), wq, b, stride=s)[:, :, :T * s].transpose(1, 2)
+                y3 = ops.upsample_forward(hb, w, b, s, out_bf16=True, in_slope=0.1)
+                assert rel_l2(y3.float(), ref3) <= 4e-3
+        finally:
+            hip.set_precision("fp32")
+
+
+def test_sum_of_squares_both_forms_and_the_legacy_layernorm_backward_entry():
+    import torch
+
+    from kantts._hip import ops
+
+    with util.kernel_source_on_cpu() as lib:
+        assert lib.kantts_abi_version() == 1 and lib.kantts_target_arch() == b"gfx950"
+        x = torch.randn(100003, generator=torch.Generator().manual_seed(0))
+        want = float((x.double() ** 2).sum())
+        out = torch.zeros(1)
+        ops.sumsq_into(x, out)
+        assert abs(float(out) - want) <= 1e-5 * want
+        out2, ws = torch.zeros(1), torch.zeros(2048)
+        ops.sumsq_into(x, out2, workspace=ws)
+        assert abs(float(out2) - want) <= 1e-5 * want
+        # kantts_ln128_bwd (kept for ABI stability) = kantts_ln128_bwd_rows without a row mask
+        M = 37
+        g = torch.Generator().manual_seed(1)
+        xx, dy, gam = torch.randn(M, 128, generator=g), torch.randn(M, 128, generator=g), torch.rand(128, generator=g) + 0.5
+        mean = xx.mean(-1).contiguous()
+        rstd = (xx.var(-1, unbiased=False) + 1e-6).rsqrt().contiguous()
+        outs = []
+        for entry in ("kantts_ln128_bwd", "kantts_ln128_bwd_rows"):
+            dx, dg, db = torch.empty_like(xx), torch.zeros(128), torch.zeros(128)
+            args = [dy.data_ptr(), 0, xx.data_ptr(), gam.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None, dx.data_ptr(),
+                    dg.data_ptr(), db.data_ptr()]
+            tail = [None, M, None] if entry.endswith("_rows") else [M, None]
+            assert getattr(lib, entry)(*(args + tail)) == 0
+            outs.append((dx, dg, db))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        xh = (xx - mean[:, None]) * rstd[:, None]
+        gy = dy * gam
+        want_dx = (gy - gy.mean(-1, keepdim=True) - xh * (gy * xh).mean(-1, keepdim=True)) * rstd[:, None]
+        assert float((outs[0][0] - want_dx).abs().max()) <= 1e-5
+        assert float((outs[0][1] - (dy * xh).sum(0)).abs().max()) <= 1e-4 and float((outs[0][2] - dy.sum(0)).abs().max()) <= 1e-4
+
+
+def test_arena_images_built_by_the_image_kernels():
+    """kantts_cast_f32_bf16 / kantts_tapmajor_bf16 / kantts_fragmajor_bf16 (ParamArena(bf16_shadow=True)): the images equal
+    the ones built from the parameters with tensor operations and follow an update of the master."""
+    import torch
+    import torch.nn as nn
+
+    from kantts._hip.ops_bf16 import ffn_frag_weights, frag_major
+    from kantts.models.sambert import PositionwiseConvFeedForward
+    from kantts.train.optim import ParamArena
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = PositionwiseConvFeedForward(128, 1024, (1, 1))
+            self.b = PositionwiseConvFeedForward(128, 1024, (3, 1))
+            self.c = PositionwiseConvFeedForward(64, 256, (3, 1))
+
+        def forward(self, x):
+            return x
+
+    import kantts._hip as hip
+
+    with util.kernel_source_on_cpu():
+        hip.set_precision("bf16")  # the forward pre-hook refreshes the images in bf16 mode only
+        torch.manual_seed(3)
+        net = Net()
+        arena = ParamArena(net, bf16_shadow=True)
+
+        def check():
+            for blk, kt in ((net.a, 1), (net.b, 3)):
+                w1, w2 = blk.w_1.weight, blk.w_2.weight
+                f1, f2, t2, t1 = ffn_frag_weights(w1, w2)
+                assert torch.equal(f1, frag_major(w1.detach().permute(2, 0, 1).reshape(kt * 1024, 128)))
+                assert torch.equal(f2, frag_major(w2.detach().reshape(128, 1024)))
+                assert torch.equal(t2, frag_major(w2.detach().reshape(128, 1024).t()))
+                assert torch.equal(t1, frag_major(w1.detach().permute(2, 1, 0).reshape(kt * 128, 1024)))
+            for p in net.parameters():
+                assert torch.equal(p._kantts_bf16, p.detach().to(torch.bfloat16))
+                if p.dim() == 3 and p.shape[2] > 1:
+                    assert torch.equal(p._kantts_bf16_tap, p.detach().permute(2, 0, 1).to(torch.bfloat16))
+
+        check()
+        with torch.no_grad():
+            arena.flat.mul_(1.5).add_(0.01)
+        try:
+            net(torch.zeros(1))  # forward pre-hook: refresh
+            check()
+        finally:
+            hip.set_precision("fp32")

@@ -35,7 +35,7 @@ def _pqmf(device):
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
 
 
-def _mrstft(device, key):
+def _mrstft(device, key, grad_tol=None):
     from kantts.train.loss import MultiResolutionSTFTLoss
 
     f = _fix()[key]
@@ -49,7 +49,7 @@ def _mrstft(device, key):
     assert abs(float(sc) - f["sc"]) <= 2e-5 * max(1.0, f["sc"]) and abs(float(mag) - f["mag"]) <= 2e-5 * max(1.0, f["mag"])
     (sc + mag).backward()
     # d log|X| = d|X| / |X|: bins with tiny magnitudes amplify the fp32 rounding of the two FFT implementations
-    assert rel_l2(yh.grad.cpu(), f["grad"]) <= (5e-3 if device == "cuda" else 2e-4)
+    assert rel_l2(yh.grad.cpu(), f["grad"]) <= (grad_tol or (5e-3 if device == "cuda" else 2e-4))
 
 
 def _multispec(device):
