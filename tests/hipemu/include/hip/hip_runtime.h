@@ -60,6 +60,7 @@ HIPEMU_VEC(short, short2, short3, short4)
 // ---- runtime (tests/hipemu/runtime.cpp)
 namespace hipemu {
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void register_dynamic_lds(void* base, size_t bytes);
 void sync_threads();
 void wave_sync();
 int lane();        // 0..63 within the wave
@@ -87,15 +88,39 @@ const unsigned char (*post_once(const void* payload, int n, void (*fn)(const uns
 #define __threadfence() ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_fetch_add(p, v, order, scope) hipemu_fetch_add(p, v)
-#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v)
+// atomics are real (relaxed) atomics of the host: one OS thread needs none, but the race-detector build (README.md) has to
+// see them as what they are
+template <class T>
+struct hipemu_bits { typedef T type; };
+template <>
+struct hipemu_bits<float> { typedef unsigned type; };
+template <>
+struct hipemu_bits<double> { typedef unsigned long long type; };
+template <class T, class F>
+static inline T hipemu_atomic_rmw(T* p, F f) {
+  typedef typename hipemu_bits<T>::type B;
+  static_assert(sizeof(B) == sizeof(T), "atomic width");
+  B* q = reinterpret_cast<B*>(p);
+  B old = __atomic_load_n(q, __ATOMIC_RELAXED), neu;
+  T o;
+  do {
+    memcpy(&o, &old, sizeof(T));
+    const T n = f(o);
+    memcpy(&neu, &n, sizeof(T));
+  } while (!__atomic_compare_exchange_n(q, &old, neu, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED));
+  return o;
+}
 template <class T, class U>
-static inline T hipemu_fetch_add(T* p, U v) { T o = *p; *p = (T)(o + v); return o; }
+static inline T hipemu_fetch_add(T* p, U v) { return hipemu_atomic_rmw(p, [v](T o) { return (T)(o + v); }); }
 template <class T, class U>
 static inline T atomicAdd(T* p, U v) { return hipemu_fetch_add(p, v); }
 template <class T, class U>
-static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+static inline T atomicMax(T* p, U v) { return hipemu_atomic_rmw(p, [v](T o) { return (T)v > o ? (T)v : o; }); }
 template <class T, class U>
-static inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
+static inline T atomicExch(T* p, U v) { return hipemu_atomic_rmw(p, [v](T) { return (T)v; }); }
+template <class T, class U>
+static inline void hipemu_atomic_store(T* p, U v) { hipemu_atomic_rmw(p, [v](T) { return (T)v; }); }
 
 // ---- scalar helpers
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
