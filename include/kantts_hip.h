@@ -479,6 +479,25 @@ typedef struct kantts_bgemm_args {
 } kantts_bgemm_args;
 int kantts_bgemm_nt(const kantts_bgemm_args* args, void* stream);
 
+/* kantts_bgemm_nt with the BACKWARD of a LayerNorm(128) as its epilogue.  The contraction's result (N == 128, b_kn) is
+ * the gradient dy of a LayerNorm's output -- the input gradient of the projection that consumes the normalised rows of a
+ * pre-LN sub-layer (kantts/models/sambert/__init__.py:63-64, 89-91, 198-199) -- and what the launch writes is what
+ * kantts_ln128_bwd_rows makes of it: dx (M,128) fp32 (+ dres; rows of zero_rows written as 0) and the dgamma / dbeta
+ * accumulations.  dy is rounded to bf16 first when args->c_bf16 is set (the value the two-launch form passes through
+ * memory) and is itself stored only if args->c is not NULL.  args->ln_out / gate / relu / drop_p must be unset. */
+typedef struct kantts_lnbwd_args {
+  const float* x;        /* (M,128) the LayerNorm's input */
+  const float* gamma;    /* (128) */
+  const float* mean;     /* (M) as kantts_ln128_fwd wrote them */
+  const float* rstd;
+  const float* dres;     /* optional (M,128): gradient of the residual branch that by-passes the normalisation */
+  const uint8_t* zero_rows; /* optional (M) */
+  float* dx;             /* (M,128) */
+  float* dgamma_accum;   /* (128), += */
+  float* dbeta_accum;
+} kantts_lnbwd_args;
+int kantts_bgemm_nt_lnbwd(const kantts_bgemm_args* args, const kantts_lnbwd_args* ln, void* stream);
+
 /* kantts_bgemm_tn:  c[n*c_ns + k*c_ks + tap*c_ts] += alpha * sum_m A[m][n] * B[tok(m) + shift0 + tap*shift_step][k]
  *                   db[n] += alpha * sum_m A[m][n]                                   (optional)
  * Weight / bias gradients: A = gradient of the layer output (M, N), B = layer input (M, K), tokens m are the reduction
@@ -581,6 +600,13 @@ typedef struct kantts_ffn_args {
   float* ln_rstd;
 } kantts_ffn_args;
 int kantts_ffn_pair(const kantts_ffn_args* args, void* stream);
+
+/* The backward form of kantts_ffn_pair (gate set, KT == 1, KT2 = 1 or 3) whose result y -- the gradient of the
+ * feed-forward sub-layer's LayerNorm output (kantts/models/sambert/__init__.py:134-136) -- goes through that LayerNorm's
+ * backward in the epilogue, as kantts_bgemm_nt_lnbwd does for the attention sub-layers: dx / dgamma / dbeta leave; y is
+ * rounded to bf16 first when args->y_bf16 is set and is itself stored only if args->y is not NULL.  args->res / bias2 /
+ * drop2_p / ln_out must be unset. */
+int kantts_ffn_pair_lnbwd(const kantts_ffn_args* args, const kantts_lnbwd_args* ln, void* stream);
 
 /* Fragment-major bf16 images of weight matrices, a table of them in one launch (the parameter arena's per-step refresh).
  * Entry: the (R, K) matrix with element (r, k) = src[src_off + r*sr + k*sk] (fp32; any orientation of the master weight)

@@ -95,289 +95,19 @@ __device__ __forceinline__ void bg_xcd_remap(int& bx, int& by) {
 }
 
 // ================================================================================================ NT
+// LNB: the epilogue is the backward of a LayerNorm(128) whose output gradient is this contraction's result
+// (kantts_bgemm_nt_lnbwd): dx / dgamma / dbeta leave instead of (or beside) the result itself.
 template <int BM, bool A_F32, bool B_KN>
 __global__ __launch_bounds__(BG_THREADS) void bgemm_nt_kernel(const kantts_bgemm_args g) {
-  constexpr int A_BYTES = BM * BG_BK * 2;
-  constexpr int B_BYTES = B_KN ? BG_BK * BG_LDKN * 2 : BG_BN * BG_BK * 2;
-  constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int CLD = BG_BN + 4;
-  constexpr int CS_BYTES = BM * CLD * 4;
-  constexpr int LDS_BYTES = (2 * STAGE > CS_BYTES) ? 2 * STAGE : CS_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-  constexpr int NA = BM * 8 / BG_THREADS;  // 16-byte chunks of the A tile per thread (4 / 2 / 1)
-  constexpr int NB = 4;                    // B tile: 1024 chunks
-  constexpr int WM = (BM >= 64) ? 2 : 1;   // waves along M
-  constexpr int NREP = (BM >= 64) ? 4 : 2; // 16-column fragments per wave
-  constexpr int MREP = BM / (WM * 16);     // 16-row fragments per wave (4 / 2 / 2)
-  constexpr int WROWS = MREP * 16;         // rows per wave
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = (WM == 2) ? (wave >> 1) : 0, wc = (WM == 2) ? (wave & 1) : wave;
-  const int li = lane & 15, kg = lane >> 4;
-  int bx = blockIdx.x, by = blockIdx.y;
-  bg_xcd_remap(bx, by);
-  const int i0 = by * BM, j0 = bx * BG_BN;
-  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
-
-  f32x4 acc[MREP][NREP];
-#pragma unroll
-  for (int m = 0; m < MREP; ++m)
-#pragma unroll
-    for (int n = 0; n < NREP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ---- per-thread chunk coordinates (fixed over the reduction)
-  int a_row[NA], a_ch[NA];
-#pragma unroll
-  for (int v = 0; v < NA; ++v) {
-    const int id = tid + BG_THREADS * v;
-    a_row[v] = id >> 3;
-    a_ch[v] = id & 7;
-  }
-  int b_r[NB], b_c[NB];  // !B_KN: (n row, k chunk);  B_KN: (k row, n chunk)
-#pragma unroll
-  for (int v = 0; v < NB; ++v) {
-    const int id = tid + BG_THREADS * v;
-    if (B_KN) {
-      b_r[v] = id >> 4;
-      b_c[v] = id & 15;
-    } else {
-      b_r[v] = id >> 3;
-      b_c[v] = id & 7;
-    }
-  }
-
-  // two register sets: the global loads of TWO reduction tiles are in flight while a third is multiplied (the
-  // contractions of this model are short chains of dependent L2 / HBM round trips: with one tile in flight a
-  // 1024-deep reduction paid 16 load latencies back to back)
-  u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-  int seg = 0, k0 = 0;  // next tile to fetch
-
-  auto fetch = [&](u32x4* ra, u32x4* rb) {
-    const kantts_bgemm_seg& s = g.seg[seg];
-#pragma unroll
-    for (int v = 0; v < NA; ++v) {
-      const int row = i0 + a_row[v];
-      const int kc = k0 + a_ch[v] * 8;
-      bool ok = row < g.M && kc < s.klen;
-      long long src = row;
-      if (s.a_shift != 0) {
-        const int t = row % g.T + s.a_shift;
-        ok = ok && t >= 0 && t < g.T;
-        src = (long long)row + s.a_shift;
-      }
-      ra[v] = bg_load8<A_F32>(s.a, src * s.lda + kc, ok, A_F32 ? g.a_drop_p : 0.f, g.a_drop_seed + seed_off,
-                              (uint64_t)src * (uint64_t)g.a_drop_ld + (uint64_t)kc);
-    }
-#pragma unroll
-    for (int v = 0; v < NB; ++v) {
-      if (B_KN) {
-        const int kr = k0 + b_r[v], nc = j0 + b_c[v] * 8;
-        const bool ok = kr < s.klen && nc < g.N;
-        rb[v] = bg_load8<false>(s.b, (long long)kr * s.ldb + nc, ok, 0.f, 0ull, 0ull);
-      } else {
-        const int n = j0 + b_r[v], kc = k0 + b_c[v] * 8;
-        const bool ok = n < g.N && kc < s.klen;
-        rb[v] = bg_load8<false>(s.b, (long long)n * s.ldb + kc, ok, 0.f, 0ull, 0ull);
-      }
-    }
-    k0 += BG_BK;
-    if (k0 >= s.klen) {
-      k0 = 0;
-      ++seg;
-    }
-  };
-  auto commit = [&](int buf, const u32x4* ra, const u32x4* rb) {
-    unsigned char* Ab = lds + buf * STAGE;
-    unsigned char* Bb = Ab + A_BYTES;
-#pragma unroll
-    for (int v = 0; v < NA; ++v) {
-      const int r = a_row[v];
-      *reinterpret_cast<u32x4*>(Ab + r * 128 + ((a_ch[v] ^ ((r >> 1) & 7)) << 4)) = ra[v];
-    }
-#pragma unroll
-    for (int v = 0; v < NB; ++v) {
-      if (B_KN) {
-        *reinterpret_cast<u32x4*>(Bb + (b_r[v] * BG_LDKN + b_c[v] * 8) * 2) = rb[v];
-      } else {
-        const int r = b_r[v];
-        *reinterpret_cast<u32x4*>(Bb + r * 128 + ((b_c[v] ^ ((r >> 1) & 7)) << 4)) = rb[v];
-      }
-    }
-  };
-  auto compute = [&](int buf) {
-    const unsigned char* Ab = lds + buf * STAGE;
-    const unsigned char* Bb = Ab + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < BG_BK / 32; ++kk) {
-      bf16x8 af[MREP], bf[NREP];
-#pragma unroll
-      for (int m = 0; m < MREP; ++m) {
-        const int r = wr * WROWS + m * 16 + li;
-        const int sw = (r >> 1) & 7;
-        if (B_KN) {
-          // permuted-k convention of the transpose reads: lane group kg holds k = kg*4..+3 and 16 + kg*4..+3
-          const int c0 = kk * 4 + (kg >> 1), hb = (kg & 1) * 8;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(Ab + r * 128 + ((c0 ^ sw) << 4) + hb);
-          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(Ab + r * 128 + (((c0 + 2) ^ sw) << 4) + hb);
-          af[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        } else {
-          af[m] = *reinterpret_cast<const bf16x8*>(Ab + r * 128 + (((kk * 4 + kg) ^ sw) << 4));
-        }
-      }
-#pragma unroll
-      for (int n = 0; n < NREP; ++n) {
-        const int c = wc * (NREP * 16) + n * 16;
-        if (B_KN) {
-          const __bf16* p = reinterpret_cast<const __bf16*>(Bb) + (kk * 32 + kg * 4 + (li >> 2)) * BG_LDKN + c + (li & 3) * 4;
-          const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * BG_LDKN);
-          bf[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        } else {
-          const int r = c + li;
-          bf[n] = *reinterpret_cast<const bf16x8*>(Bb + r * 128 + (((kk * 4 + kg) ^ ((r >> 1) & 7)) << 4));
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < MREP; ++m)
-#pragma unroll
-        for (int n = 0; n < NREP; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
-    }
-  };
-
-  int ntile = 0;
-  for (int s = 0; s < g.nseg; ++s) ntile += (g.seg[s].klen + BG_BK - 1) / BG_BK;
-
-  // tile t lives in register set t & 1 and LDS buffer t & 1.  A wave that reaches commit(buf) for tile t + 2 has
-  // passed the barrier in front of compute(t + 1), which every wave reaches only after compute(t): one barrier per tile.
-  fetch(ra0, rb0);
-  if (ntile > 1) fetch(ra1, rb1);
-  for (int t = 0; t < ntile; t += 2) {
-    commit(0, ra0, rb0);
-    __syncthreads();
-    if (t + 2 < ntile) fetch(ra0, rb0);
-    compute(0);
-    if (t + 1 < ntile) {
-      commit(1, ra1, rb1);
-      __syncthreads();
-      if (t + 3 < ntile) fetch(ra1, rb1);
-      compute(1);
-    }
-  }
-  __syncthreads();
-
-  // ---- epilogue: accumulators through LDS so that 16 lanes write one 256 / 512-byte output row piece
-  float* Cs = reinterpret_cast<float*>(lds);
-#pragma unroll
-  for (int m = 0; m < MREP; ++m)
-#pragma unroll
-    for (int n = 0; n < NREP; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cs[(wr * WROWS + m * 16 + kg * 4 + r) * CLD + wc * (NREP * 16) + n * 16 + li] = acc[m][n][r];
-  __syncthreads();
-
-  const int jc = (tid & 15) * 8;  // 8 output columns per thread
-  const int j = j0 + jc;
-  if (j >= g.N) return;
-  float bs[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bs[e] = 0.f;
-  if (g.bias) {
-    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + j), b1 = *reinterpret_cast<const float4*>(g.bias + j + 4);
-    bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
-  }
-  if (g.bias2) {
-    const float4 b0 = *reinterpret_cast<const float4*>(g.bias2 + j), b1 = *reinterpret_cast<const float4*>(g.bias2 + j + 4);
-    bs[0] += b0.x; bs[1] += b0.y; bs[2] += b0.z; bs[3] += b0.w; bs[4] += b1.x; bs[5] += b1.y; bs[6] += b1.z; bs[7] += b1.w;
-  }
-  float lg[8], lb[8];
-  if (g.ln_out) {  // N == 128: the 16 lanes that share a row hold all of it
-    const float4 g0 = *reinterpret_cast<const float4*>(g.ln_gamma + j), g1 = *reinterpret_cast<const float4*>(g.ln_gamma + j + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(g.ln_beta + j), b1 = *reinterpret_cast<const float4*>(g.ln_beta + j + 4);
-    lg[0] = g0.x; lg[1] = g0.y; lg[2] = g0.z; lg[3] = g0.w; lg[4] = g1.x; lg[5] = g1.y; lg[6] = g1.z; lg[7] = g1.w;
-    lb[0] = b0.x; lb[1] = b0.y; lb[2] = b0.z; lb[3] = b0.w; lb[4] = b1.x; lb[5] = b1.y; lb[6] = b1.z; lb[7] = b1.w;
-  }
-#pragma unroll
-  for (int v = 0; v < BM / 16; ++v) {
-    const int rl = (tid >> 4) + 16 * v;
-    const int i = i0 + rl;
-    if (i >= g.M) continue;
-    const float4 c0 = *reinterpret_cast<const float4*>(&Cs[rl * CLD + jc]);
-    const float4 c1 = *reinterpret_cast<const float4*>(&Cs[rl * CLD + jc + 4]);
-    float o[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float val = (o[e] + bs[e]) * g.alpha;
-      if (g.relu) val = fmaxf(val, 0.f);
-      o[e] = val;
-    }
-    if (g.drop_p > 0.f) {
-      const uint64_t base = (uint64_t)i * (uint64_t)g.N + (uint64_t)j;  // N % 8 == 0, j % 8 == 0
-      kantts_dropout_scale4(g.drop_p, g.drop_seed + seed_off, base, o);
-      kantts_dropout_scale4(g.drop_p, g.drop_seed + seed_off, base + 4, o + 4);
-    }
-    if (g.res) {
-      const float* rp = g.res + (long long)i * g.ldr + j;
-      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-      o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w; o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
-    }
-    if (g.gate) {
-      float gv[8];
-      if (g.gate_bf16) {
-        const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(g.gate) + (long long)i * g.ldg + j);
-        gv[0] = bg_lo(q.x); gv[1] = bg_hi(q.x); gv[2] = bg_lo(q.y); gv[3] = bg_hi(q.y);
-        gv[4] = bg_lo(q.z); gv[5] = bg_hi(q.z); gv[6] = bg_lo(q.w); gv[7] = bg_hi(q.w);
-      } else {
-        const float* gp = reinterpret_cast<const float*>(g.gate) + (long long)i * g.ldg + j;
-        const float4 q0 = *reinterpret_cast<const float4*>(gp), q1 = *reinterpret_cast<const float4*>(gp + 4);
-        gv[0] = q0.x; gv[1] = q0.y; gv[2] = q0.z; gv[3] = q0.w; gv[4] = q1.x; gv[5] = q1.y; gv[6] = q1.z; gv[7] = q1.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (gv[e] > 0.f) ? o[e] : 0.f;
-    }
-    if (g.rowmask && g.rowmask[i]) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    }
-    if (g.c_bf16) {
-      u32x4 w = {bg_pack2(o[0], o[1]), bg_pack2(o[2], o[3]), bg_pack2(o[4], o[5]), bg_pack2(o[6], o[7])};
-      *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.c) + (long long)i * g.ldc + j) = w;
-    } else {
-      float* cp = reinterpret_cast<float*>(g.c) + (long long)i * g.ldc + j;
-      f32x4 w0 = {o[0], o[1], o[2], o[3]}, w1 = {o[4], o[5], o[6], o[7]};
-      *reinterpret_cast<f32x4*>(cp) = w0;
-      *reinterpret_cast<f32x4*>(cp + 4) = w1;
-    }
-    if (g.ln_out) {  // same arithmetic, in the same order, as ln128_fwd_kernel (csrc/norm.hip)
-      float sm = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sm += o[e];
-      const float mu = bg_sum16(sm) * (1.f / 128.f);
-      float qq = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = o[e] - mu;
-        qq += d * d;
-      }
-      const float rs = 1.0f / sqrtf(bg_sum16(qq) * (1.f / 128.f) + g.ln_eps);
-      float y[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = (o[e] - mu) * rs * lg[e] + lb[e];
-      if (g.ln_out_bf16) {
-        u32x4 w = {bg_pack2(y[0], y[1]), bg_pack2(y[2], y[3]), bg_pack2(y[4], y[5]), bg_pack2(y[6], y[7])};
-        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(g.ln_out) + (long long)i * 128 + j) = w;
-      } else {
-        float* yp = reinterpret_cast<float*>(g.ln_out) + (long long)i * 128 + j;
-        f32x4 w0 = {y[0], y[1], y[2], y[3]}, w1 = {y[4], y[5], y[6], y[7]};
-        *reinterpret_cast<f32x4*>(yp) = w0;
-        *reinterpret_cast<f32x4*>(yp + 4) = w1;
-      }
-      if ((tid & 15) == 0) {
-        g.ln_mean[i] = mu;
-        g.ln_rstd[i] = rs;
-      }
-    }
-  }
+  constexpr bool LNB = false;
+  const kantts_lnbwd_args* const lnb = nullptr;
+#include "gemm_bf16_nt_body.inc"
+}
+template <int BM, bool A_F32>
+__global__ __launch_bounds__(BG_THREADS) void bgemm_nt_lnb_kernel(const kantts_bgemm_args g, const kantts_lnbwd_args lnb_args) {
+  constexpr bool LNB = true, B_KN = true;
+  const kantts_lnbwd_args* const lnb = &lnb_args;
+#include "gemm_bf16_nt_body.inc"
 }
 
 template <int BM>
@@ -436,6 +166,36 @@ extern "C" int kantts_bgemm_nt(const kantts_bgemm_args* gp, void* stream) {
     bg_launch_nt<64>(g, dim3(nt, kantts_cdiv(g.M, 64)), st);
   else
     bg_launch_nt<32>(g, dim3(nt, kantts_cdiv(g.M, 32)), st);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_bgemm_nt_lnbwd(const kantts_bgemm_args* gp, const kantts_lnbwd_args* lp, void* stream) {
+  if (!gp || !lp) return KANTTS_E_BADARG;
+  const kantts_bgemm_args& g = *gp;
+  const kantts_lnbwd_args& l = *lp;
+  if (g.nseg < 1 || g.nseg > KANTTS_BGEMM_MAX_SEG || g.M < 0) return KANTTS_E_BADARG;
+  if (!l.x || !l.gamma || !l.mean || !l.rstd || !l.dx || !l.dgamma_accum || !l.dbeta_accum) return KANTTS_E_BADARG;
+  // what the model has: the input gradient of a projection (weights stored (out, in) = [k][n]: b_kn) of LayerNorm-ed rows
+  if (g.N != 128 || !g.b_kn || g.ln_out || g.gate || g.relu || g.drop_p > 0.f) return KANTTS_E_UNSUPPORTED;
+  if (g.M == 0) return KANTTS_OK;
+  if (g.c && ((g.ldc & 7) || !bg_aligned16(g.c))) return KANTTS_E_UNSUPPORTED;
+  if (g.res && ((g.ldr & 3) || !bg_aligned16(g.res))) return KANTTS_E_UNSUPPORTED;
+  if ((g.bias && !bg_aligned16(g.bias)) || (g.bias2 && !bg_aligned16(g.bias2))) return KANTTS_E_UNSUPPORTED;
+  if (!bg_aligned16(l.x) || !bg_aligned16(l.gamma) || !bg_aligned16(l.dx) || (l.dres && !bg_aligned16(l.dres)))
+    return KANTTS_E_UNSUPPORTED;
+  for (int s = 0; s < g.nseg; ++s) {
+    const kantts_bgemm_seg& sg = g.seg[s];
+    if (!sg.a || !sg.b || sg.klen < 8 || (sg.klen & 7) || (sg.lda & 7) || (sg.ldb & 7)) return KANTTS_E_UNSUPPORTED;
+    if (!bg_aligned16(sg.a) || !bg_aligned16(sg.b)) return KANTTS_E_UNSUPPORTED;
+    if (sg.a_shift != 0 && g.T <= 0) return KANTTS_E_BADARG;
+  }
+  // 32-row tiles: 2 x 256 same-address atomics per workgroup, and one round of workgroups at the decoder's 6528 rows
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(1, kantts_cdiv(g.M, 32));
+  if (g.a_f32)
+    hipLaunchKernelGGL((bgemm_nt_lnb_kernel<32, true>), grid, dim3(BG_THREADS), 0, st, g, l);
+  else
+    hipLaunchKernelGGL((bgemm_nt_lnb_kernel<32, false>), grid, dim3(BG_THREADS), 0, st, g, l);
   KANTTS_CHECK_LAUNCH();
 }
 

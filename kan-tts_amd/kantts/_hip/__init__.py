@@ -139,6 +139,14 @@ class BGemmArgs(Structure):
     ]
 
 
+class LnBwdArgs(Structure):
+    """kantts_lnbwd_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("gamma", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("dres", c_void_p),
+        ("zero_rows", c_void_p), ("dx", c_void_p), ("dgamma_accum", c_void_p), ("dbeta_accum", c_void_p),
+    ]
+
+
 class BGemmTnArgs(Structure):
     """kantts_bgemm_tn_args (include/kantts_hip.h)."""
     _fields_ = [
@@ -253,6 +261,8 @@ def lib():
         L.kantts_relu_gate_bf16.argtypes = [p, i, p, i, p, f, ll, p]
         L.kantts_ln128_fwd.argtypes = [p, p, p, p, i, p, p, i, f, p]
         L.kantts_ln128_bwd.argtypes = [p, i, p, p, p, p, p, p, p, p, i, p]
+        L.kantts_bgemm_nt_lnbwd.argtypes = [POINTER(BGemmArgs), POINTER(LnBwdArgs), c_void_p]
+        L.kantts_ffn_pair_lnbwd.argtypes = [POINTER(FfnArgs), POINTER(LnBwdArgs), c_void_p]
         L.kantts_ln128_bwd_rows.argtypes = [p, i, p, p, p, p, p, p, p, p, p, i, p]
         L.kantts_cconv_launch.argtypes = [POINTER(CConvArgs), c_void_p]
         L.kantts_cconv_wgrad_launch.argtypes = [POINTER(CConvWArgs), c_void_p]
@@ -275,7 +285,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
     "kantts_bgemm_nt", "kantts_ffn_pair", "kantts_fragmajor_bf16", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
-    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_ln128_bwd_rows", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
+    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_ln128_bwd_rows", "kantts_bgemm_nt_lnbwd", "kantts_ffn_pair_lnbwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
     "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
@@ -436,11 +446,14 @@ def _addr(x):
 
 def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alpha=1.0, relu=False, drop_p=0.0,
              drop_seed=0, res=None, ldr=0, gate=None, ldg=0, rowmask=None, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0,
-             ln=None):
+             ln=None, lnb=None, c_bf16=None):
     """segs: list of (a, lda, b, ldb, klen, a_shift) with a / b tensors or (tensor, element offset).  All A operands share
     one dtype (fp32 or bf16); B operands are bf16.  Returns False when the library declines the shape (caller falls
     back to the segmented GEMM).  ``ln`` = (gamma, beta, eps, out (M,128) bf16 / fp32, mean (M), rstd (M)): LayerNorm of
-    the output rows in the epilogue (N == 128, fp32 output)."""
+    the output rows in the epilogue (N == 128, fp32 output).
+    ``lnb`` = (x, gamma, mean, rstd, dres | None, zero_rows | None, dx, dgamma, dbeta): the epilogue is the BACKWARD of a
+    LayerNorm(128) whose output gradient is this contraction's result (kantts_bgemm_nt_lnbwd); ``c`` may then be None (the
+    result itself is not stored) with ``c_bf16`` saying whether it is rounded to bf16 first, as the two-launch form would."""
     g = BGemmArgs()
     assert 1 <= len(segs) <= BGEMM_MAX_SEG
     a0 = segs[0][0][0] if isinstance(segs[0][0], tuple) else segs[0][0]
@@ -453,7 +466,11 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
         s.a, s.b, s.lda, s.ldb, s.klen, s.a_shift = _addr(a), _addr(b), int(lda), int(ldb), int(klen), int(a_shift)
     g.nseg, g.M, g.N, g.T = len(segs), int(M), int(N), int(T)
     g.a_f32, g.b_kn = int(a0.dtype == torch.float32), int(bool(b_kn))
-    g.c, g.ldc, g.c_bf16 = _addr(c), int(ldc), int((c[0] if isinstance(c, tuple) else c).dtype == torch.bfloat16)
+    if c is None:
+        assert lnb is not None and c_bf16 is not None
+        g.c, g.ldc, g.c_bf16 = None, int(ldc), int(bool(c_bf16))
+    else:
+        g.c, g.ldc, g.c_bf16 = _addr(c), int(ldc), int((c[0] if isinstance(c, tuple) else c).dtype == torch.bfloat16)
     g.relu = int(bool(relu))
     g.bias, g.bias2 = ptr(bias, torch.float32), ptr(bias2, torch.float32)
     g.alpha, g.drop_p, g.drop_seed = float(alpha), float(drop_p), int(drop_seed)
@@ -467,12 +484,20 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
         g.ln_gamma, g.ln_beta, g.ln_eps = ptr(gamma, torch.float32), ptr(beta, torch.float32), float(eps)
         g.ln_out, g.ln_out_bf16 = ptr(ln_out), int(ln_out.dtype == torch.bfloat16)
         g.ln_mean, g.ln_rstd = ptr(ln_mean, torch.float32), ptr(ln_rstd, torch.float32)
-    dev = (c[0] if isinstance(c, tuple) else c).device
+    dev = a0.device
     g.seed_dev = rng_ptr(dev) if (drop_p > 0 or a_drop_p > 0) else None
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().kantts_bgemm_nt(ctypes.byref(g), stream())
+    if lnb is not None:
+        x, gamma, mean, rstd, dres, zero_rows, dx, dgamma, dbeta = lnb
+        l = LnBwdArgs()
+        l.x, l.gamma, l.mean, l.rstd = (ptr(t, torch.float32) for t in (x, gamma, mean, rstd))
+        l.dres, l.zero_rows = ptr(dres, torch.float32), ptr(zero_rows, torch.uint8)
+        l.dx, l.dgamma_accum, l.dbeta_accum = (ptr(t, torch.float32) for t in (dx, dgamma, dbeta))
+        rc = lib().kantts_bgemm_nt_lnbwd(ctypes.byref(g), ctypes.byref(l), stream())
+    else:
+        rc = lib().kantts_bgemm_nt(ctypes.byref(g), stream())
     if rc == E_UNSUPPORTED:
         return False
     check(rc, "bgemm_nt")
@@ -484,26 +509,34 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
 
 def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu=False, alpha1=1.0, drop1_p=0.0,
              drop1_seed=0, drop2_p=0.0, drop2_seed=0, xdrop_p=0.0, xdrop_seed=0, gate=None, rowmask1=None, rowmask2=None,
-             xrowmask=None, t_out=None, res=None, KT2=1, s2_first=0, s2_step=0, ln=None):
+             xrowmask=None, t_out=None, res=None, KT2=1, s2_first=0, s2_step=0, ln=None, lnb=None, y_bf16=None):
     """Both contractions of a feed-forward block in one launch (csrc/ffn_pair.hip; kantts_ffn_pair in the header).
     x (M, 128) bf16 / fp32; w1 / w2: FRAGMENT-MAJOR bf16 images (ops_bf16.frag_major) of the (KT*F, 128) and (128, F)
     weight matrices; y (M, 128) fp32 / bf16; t_out bf16 (M, F).  KT2 = 3 (backward form): phase 2 sums three taps of the
     intermediate, y[m] = sum_t t[m + s2_first + t*s2_step] . w2[t]^T with w2 = three (128, F) images.  Returns False when
-    the library declines the shape."""
+    the library declines the shape.
+    ``lnb`` = (x, gamma, mean, rstd, dres | None, zero_rows | None, dx, dgamma, dbeta) (backward form only): y is the output
+    gradient of a LayerNorm(128) and the launch ends in that LayerNorm's backward (kantts_ffn_pair_lnbwd); ``y`` may then be
+    an int N (= 128: the result itself is not stored) with ``y_bf16`` saying whether it is rounded to bf16 first."""
     g = FfnArgs()
     g.x, g.ldx, g.x_f32 = ptr(x), int(x.shape[-1]), int(x.dtype == torch.float32)
-    g.M, g.T, g.K1, g.F, g.N, g.KT, g.pad = int(M), int(T), int(x.shape[-1]), int(F), int(y.shape[-1]), int(KT), int(pad)
+    NY = y if isinstance(y, int) else int(y.shape[-1])
+    g.M, g.T, g.K1, g.F, g.N, g.KT, g.pad = int(M), int(T), int(x.shape[-1]), int(F), NY, int(KT), int(pad)
     g.w1, g.w2 = ptr(w1, torch.bfloat16), ptr(w2, torch.bfloat16)
     g.bias1, g.bias2 = ptr(bias1, torch.float32), ptr(bias2, torch.float32)
     g.relu, g.alpha1 = int(bool(relu)), float(alpha1)
     g.drop1_p, g.drop2_p, g.xdrop_p = float(drop1_p), float(drop2_p), float(xdrop_p)
     g.drop1_seed, g.drop2_seed, g.xdrop_seed = int(drop1_seed), int(drop2_seed), int(xdrop_seed)
-    g.seed_dev = rng_ptr(y.device) if (drop1_p > 0 or drop2_p > 0 or xdrop_p > 0) else None
+    g.seed_dev = rng_ptr(x.device) if (drop1_p > 0 or drop2_p > 0 or xdrop_p > 0) else None
     g.gate = ptr(gate, torch.bfloat16)
     g.rowmask1, g.rowmask2, g.xrowmask = ptr(rowmask1), ptr(rowmask2), ptr(xrowmask)
     g.t_out = ptr(t_out, torch.bfloat16)
-    g.res, g.ldr = ptr(res, torch.float32), int(y.shape[-1])
-    g.y, g.ldy, g.y_bf16 = ptr(y), int(y.shape[-1]), int(y.dtype == torch.bfloat16)
+    g.res, g.ldr = ptr(res, torch.float32), NY
+    if isinstance(y, int):
+        assert lnb is not None and y_bf16 is not None
+        g.y, g.ldy, g.y_bf16 = None, NY, int(bool(y_bf16))
+    else:
+        g.y, g.ldy, g.y_bf16 = ptr(y), NY, int(y.dtype == torch.bfloat16)
     g.KT2, g.s2_first, g.s2_step = int(KT2), int(s2_first), int(s2_step)
     if ln is not None:  # (gamma, beta, eps, out (M,128), mean (M), rstd (M)): LayerNorm of the output rows in the epilogue
         gamma, beta, eps, ln_out, ln_mean, ln_rstd = ln
@@ -513,13 +546,21 @@ def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib().kantts_ffn_pair(ctypes.byref(g), stream())
+    if lnb is not None:
+        lx, gamma, mean, rstd, dres, zero_rows, dx, dgamma, dbeta = lnb
+        l = LnBwdArgs()
+        l.x, l.gamma, l.mean, l.rstd = (ptr(t, torch.float32) for t in (lx, gamma, mean, rstd))
+        l.dres, l.zero_rows = ptr(dres, torch.float32), ptr(zero_rows, torch.uint8)
+        l.dx, l.dgamma_accum, l.dbeta_accum = (ptr(t, torch.float32) for t in (dx, dgamma, dbeta))
+        rc = lib().kantts_ffn_pair_lnbwd(ctypes.byref(g), ctypes.byref(l), stream())
+    else:
+        rc = lib().kantts_ffn_pair(ctypes.byref(g), stream())
     if rc == E_UNSUPPORTED:
         return False
     check(rc, "ffn_pair")
     if _profile is not None:
         e1.record()
-        _profile.append((e0, e1, 2.0 * M * F * (x.shape[-1] * KT + y.shape[-1] * KT2)))
+        _profile.append((e0, e1, 2.0 * M * F * (x.shape[-1] * KT + NY * KT2)))
     return True
 
 

@@ -168,6 +168,36 @@ class PreNorm:
                 and self.out_bf16 == bool(out_bf16))
 
 
+# A/B switch, OFF until measured on the device: LayerNorm BACKWARD in the epilogue of the launch that produces its output
+# gradient (kantts_bgemm_nt_lnbwd)
+LNBWD = {"on": bool(os.environ.get("KANTTS_LN_BWD_EPILOGUE"))}
+
+
+class LnBwdToken:
+    """Hand-over for the backward pass of a pre-LN sub-layer, the mirror image of PreNorm: the projection that consumes a
+    LayerNorm's output computes, as the epilogue of its input-gradient launch, what kantts_ln128_bwd_rows would make of
+    that gradient (dx, dgamma, dbeta) -- the normalised rows' gradient never goes through memory and the LayerNorm's own
+    backward launch disappears.  ``layer_norm128`` leaves the token on both of its outputs; the consumer of the residual
+    output (the sub-layer's output projection, whose backward runs first) deposits the residual branch's gradient in
+    ``dres``; the consumer of the normalised output runs the fused launch and deposits dx / dgamma / dbeta, handing
+    autograd its own saved bf16 input as a stand-in gradient (``placeholder``); the LayerNorm node's backward checks that
+    what autograd delivers is exactly those two tensors -- anything else means another consumer contributed, and raises --
+    and returns the deposited results."""
+    __slots__ = ("x", "gamma", "mean", "rstd", "zero_rows", "with_res", "dres", "dx", "dg", "db", "placeholder")
+
+    def __init__(self, with_res):
+        self.with_res = bool(with_res)
+        self.x = self.gamma = self.mean = self.rstd = self.zero_rows = None
+        self.dres = self.dx = self.dg = self.db = self.placeholder = None
+
+    def ready(self):
+        return self.x is not None and self.dx is None and (self.dres is not None or not self.with_res)
+
+
+def _same_tensor(a, b):
+    return a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype
+
+
 def _attach_token(y, token):
     if token is not None:
         y._kantts_rowmask = token
@@ -262,6 +292,8 @@ class _FusedLinearB(torch.autograd.Function):
         d_res = None
         if has_res:
             d_res = (dy if dy.dtype == torch.float32 else dy.float()).view(*ctx.lead, N)
+            if opts.get("lnbwd_res") is not None:
+                opts["lnbwd_res"].dres = d_res
         a_drop_p, a_seed, balpha = 0.0, 0, alpha
         if relu:
             scale = alpha / (1.0 - drop_p) if drop_p > 0 else alpha
@@ -308,7 +340,19 @@ class _FusedLinearB(torch.autograd.Function):
                 wb = wbs[0] if mode == "concat" else wbs[k]
                 woff = off if mode == "concat" else 0
                 wld = ldw if mode == "concat" else kk
-                if needs[5 + k]:
+                tok = opts.get("lnbwd") if (needs[5 + k] and a_drop_p == 0 and balpha == 1.0) else None
+                if tok is not None and tok.ready():
+                    # the LayerNorm that produced x: its backward is this launch's epilogue (LnBwdToken)
+                    from .ops import gzeros_like
+
+                    ldx = torch.empty(tok.x.shape, device=x.device, dtype=torch.float32)
+                    ldg, ldb = gzeros_like(tok.gamma), gzeros_like(tok.gamma)
+                    if bgemm_nt([(dz, N, (wb, woff), wld, N, 0)], M, kk, None, kk, b_kn=True, a_drop_ld=N, c_bf16=True,
+                                lnb=(tok.x.view(M, 128), tok.gamma, tok.mean, tok.rstd,
+                                     None if tok.dres is None else _c(tok.dres).view(M, 128), tok.zero_rows, ldx, ldg, ldb)):
+                        tok.dx, tok.dg, tok.db, tok.placeholder = ldx, ldg, ldb, x
+                        dxs[k] = x  # stand-in: the LayerNorm node returns tok.dx and never reads this
+                if needs[5 + k] and dxs[k] is None:
                     dx = torch.empty(x.shape, device=x.device, dtype=ctx.x_dtypes[k])
                     if not bgemm_nt([(dz, N, (wb, woff), wld, N, 0)], M, kk, dx, kk, b_kn=True, a_drop_ld=N, **kw):
                         raise RuntimeError("bgemm_nt declined an input gradient")
@@ -340,6 +384,12 @@ def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, dr
                                and weights[0].shape[0] == 128) else None
     opts = dict(nx=len(xs), nw=len(weights), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p),
                 pad=int(pad), dilation=int(dilation), T=int(T), out_bf16=bool(out_bf16), token=token, ln_next=pre)
+    if LNBWD["on"] and torch.is_grad_enabled():
+        if res is not None:  # this launch's backward sees the residual branch's gradient first
+            opts["lnbwd_res"] = getattr(res, "_kantts_lnbwd_res", None)
+        if (len(xs) == 1 and mode != "conv" and not relu and drop_p == 0 and alpha == 1.0 and xs[0].dtype == BF16
+                and xs[0].shape[-1] == 128):
+            opts["lnbwd"] = getattr(xs[0], "_kantts_lnbwd", None)
     y = _attach_token(_FusedLinearB.apply(opts, bias, bias2, res, rowmask, *xs, *weights, *wbs), token)
     if pre is not None and pre.xn is not None:
         y._kantts_prenorm = pre
@@ -355,7 +405,7 @@ class _LayerNorm128(torch.autograd.Function):
     backward kernel -- autograd would otherwise add them with a separate elementwise kernel per sub-layer."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res, zero_rows, xn, mean, rstd):
+    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res, zero_rows, xn, mean, rstd, token=None):
         x = _c(x)
         M = x.numel() // 128
         if xn is not None:  # computed by the epilogue of the launch that produced x (PreNorm)
@@ -367,6 +417,9 @@ class _LayerNorm128(torch.autograd.Function):
             check(lib().kantts_ln128_fwd(ptr(x, torch.float32), ptr(gamma, torch.float32), ptr(beta, torch.float32),
                                          ptr(y), int(out_bf16), ptr(mean), ptr(rstd), M, float(eps), stream()), "ln128_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd, zero_rows)
+        ctx.token = token
+        if token is not None:
+            token.x, token.gamma, token.mean, token.rstd, token.zero_rows = x, gamma.detach(), mean, rstd, zero_rows
         if with_res:
             return y, x.view_as(x)
         return y, None
@@ -377,18 +430,28 @@ class _LayerNorm128(torch.autograd.Function):
 
         x, gamma, mean, rstd, zero_rows = ctx.saved_tensors
         M = x.numel() // 128
+        tok = ctx.token
+        if tok is not None and tok.dx is not None:  # done by the consumer's input-gradient launch (LnBwdToken)
+            if not _same_tensor(dy, tok.placeholder) or (tok.with_res and not _same_tensor(dres, tok.dres)) or (
+                    not tok.with_res and dres is not None):
+                raise RuntimeError("LayerNorm backward was fused into its consumer's launch, but autograd delivers other "
+                                   "gradients than the ones that launch saw: the normalised rows (or the residual output) "
+                                   "have a second consumer")
+            out = (tok.dx, tok.dg, tok.db)
+            tok.x = tok.dres = tok.dx = tok.dg = tok.db = tok.placeholder = None
+            return (*out, None, None, None, None, None, None, None, None)
         dx = torch.empty_like(x)
         dg, db = gzeros_like(gamma), gzeros_like(gamma)
         if dy is None:  # only the pass-through was used downstream
             if zero_rows is not None:
                 dres = dres.masked_fill(zero_rows.bool().view(*dres.shape[:-1], 1), 0.0)
-            return (dres, None, None, None, None, None, None, None, None, None)
+            return (dres, None, None, None, None, None, None, None, None, None, None)
         dy = _c(dy)
         dres = _c(dres) if dres is not None else None
         check(lib().kantts_ln128_bwd_rows(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean), ptr(rstd),
                                           ptr(dres, torch.float32), ptr(dx), ptr(dg), ptr(db), ptr(zero_rows, torch.uint8),
                                           M, stream()), "ln128_bwd")
-        return dx, dg, db, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None, None
 
 
 def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False, private_input=False):
@@ -399,12 +462,18 @@ def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False, private_input=F
         zero_rows = _c(zero_rows).view(-1)
         if zero_rows.dtype == torch.bool:
             zero_rows = zero_rows.view(torch.uint8)
+    token = LnBwdToken(with_res) if (LNBWD["on"] and out_bf16 and torch.is_grad_enabled() and x.requires_grad) else None
     pre = getattr(x, "_kantts_prenorm", None)
     if pre is not None and pre.matches(gamma, beta, eps, out_bf16) and pre.xn.numel() == x.numel():
         y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows, pre.xn, pre.mean,
-                                    pre.rstd)
+                                    pre.rstd, token)
     else:
-        y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows, None, None, None)
+        y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows, None, None, None,
+                                    token)
+    if token is not None:
+        y._kantts_lnbwd = token
+        if with_res:
+            xr._kantts_lnbwd_res = token
     return (y, xr) if with_res else y
 
 
@@ -472,16 +541,35 @@ class _FusedFFNB(torch.autograd.Function):
         if zr is not None and not (token is not None and token.delegated):
             dy = dy.masked_fill(zr.bool().view(M, 1), 0.0)
         d_res = dy.view(*ctx.lead, N)
+        if cfg.get("lnbwd_res") is not None:
+            cfg["lnbwd_res"].dres = d_res
         dev = dy.device
         # gradient at the hidden pre-activation: (dropout(dy) @ w2) gated by hid > 0 (ReLU, inner dropout, padded rows)
         dz = torch.empty((M, F), device=dev, dtype=BF16)
-        dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
+        dh = None
         a1 = 1.0 / (1.0 - p_in) if p_in > 0 else 1.0
         # both input-gradient contractions in one launch (images of the TRANSPOSED weights)
         # (k = 3: the three taps are summed in phase 2 from a tile of dz with one halo row either side)
-        fused = (cfg["pair"] and kt in (1, 3) and wt1 is not None and wt2 is not None and (kt == 1 or M % T == 0) and
-                 ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid, t_out=dz,
-                          KT2=kt, s2_first=pad, s2_step=-1))
+        can_pair = cfg["pair"] and kt in (1, 3) and wt1 is not None and wt2 is not None and (kt == 1 or M % T == 0)
+        tok = cfg.get("lnbwd")
+        fused = False
+        if can_pair and tok is not None and tok.ready() and ctx.h_dtype == BF16:
+            # ... ending in the backward of the LayerNorm that produced h (LnBwdToken): dh never goes through memory
+            from .ops import gzeros_like
+
+            ldx = torch.empty(tok.x.shape, device=dev, dtype=torch.float32)
+            ldg, ldb = gzeros_like(tok.gamma), gzeros_like(tok.gamma)
+            fused = ffn_pair(dy, wt2, wt1, C, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid, t_out=dz,
+                             KT2=kt, s2_first=pad, s2_step=-1, y_bf16=True,
+                             lnb=(tok.x.view(M, 128), tok.gamma, tok.mean, tok.rstd,
+                                  None if tok.dres is None else _c(tok.dres).view(M, 128), tok.zero_rows, ldx, ldg, ldb))
+            if fused:
+                tok.dx, tok.dg, tok.db, tok.placeholder = ldx, ldg, ldb, hb
+                dh = hb.view(M, C)  # stand-in for autograd: the LayerNorm node returns tok.dx and never reads this
+        if dh is None:
+            dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
+            fused = can_pair and ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid,
+                                          t_out=dz, KT2=kt, s2_first=pad, s2_step=-1)
         if not fused and not bgemm_nt([(dy, N, wb2, F, N, 0)], M, F, dz, F, b_kn=True, gate=hid, ldg=F, alpha=a1,
                                       a_drop_p=p_out, a_drop_seed=s2, a_drop_ld=N):
             raise RuntimeError("bgemm_nt declined the FFN hidden gradient")
@@ -596,6 +684,10 @@ def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p
     cfg["token"] = token
     pre = PreNorm(ln_next) if (ln_next is not None and PRENORM["on"] and pair) else None
     cfg["ln_next"] = pre
+    if LNBWD["on"] and torch.is_grad_enabled():
+        cfg["lnbwd_res"] = getattr(res, "_kantts_lnbwd_res", None)  # the LayerNorm whose pass-through output res is
+        if pair and kt in (1, 3) and h.dtype == BF16:
+            cfg["lnbwd"] = getattr(h, "_kantts_lnbwd", None)        # ... and the one whose normalised rows h are
     wf1 = wf2 = wt2 = wt1 = None
     if pair:
         wf1, wf2, wt2, wt1 = ffn_frag_weights(w1, w2)

@@ -254,15 +254,40 @@ class EmulatedLib:
     # ------------------------------------------------------------------------------------ bf16-operand contractions
     def kantts_bgemm_nt(self, args_ref, stream):
         g = args_ref._obj
-        M, N, T = g.M, g.N, g.T
-        if M == 0 or N == 0:
+        if g.M == 0 or g.N == 0:
             return 0
-        if N % 8 or g.ldc % 8:
+        v = self._bgemm_nt_values(g)
+        if v is None:
             return -2
+        self._bgemm_nt_store(g, v)
+        return 0
+
+    def kantts_bgemm_nt_lnbwd(self, args_ref, ln_ref, stream):
+        """kantts_bgemm_nt whose epilogue is kantts_ln128_bwd_rows on dy = the contraction's result."""
+        g, l = args_ref._obj, ln_ref._obj
+        if g.N != 128 or not g.b_kn or g.ln_out or g.gate or g.relu or g.drop_p > 0:
+            return -2
+        M = g.M
+        if M == 0:
+            return 0
+        v = self._bgemm_nt_values(g)
+        if v is None:
+            return -2
+        if g.c:
+            self._bgemm_nt_store(g, v)
+        if g.c_bf16:
+            v = _bf16_round(v)
+        self._ln128_bwd_values(l, M, v)
+        return 0
+
+    def _bgemm_nt_values(self, g):
+        M, N, T = g.M, g.N, g.T
+        if N % 8 or g.ldc % 8:
+            return None
         for si in range(g.nseg):
             s = g.seg[si]
             if s.klen < 8 or s.klen % 8 or s.lda % 8 or s.ldb % 8:
-                return -2
+                return None
         soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
         acc = np.zeros((M, N), dtype=np.float32)
         rows = np.arange(M, dtype=np.int64)
@@ -303,7 +328,10 @@ class EmulatedLib:
             v = np.where(_rd2d(g.gate, M, N, g.ldg, bool(g.gate_bf16)) > 0, v, 0)
         if g.rowmask:
             v = np.where(_arr(g.rowmask, M, np.uint8)[:, None] != 0, 0, v)
-        v = v.astype(np.float32)
+        return v.astype(np.float32)
+
+    def _bgemm_nt_store(self, g, v):
+        M, N = g.M, g.N
         esz = 2 if g.c_bf16 else 4
         for i in range(M):
             _wr(int(g.c) + i * g.ldc * esz, v[i], bool(g.c_bf16))
@@ -316,7 +344,6 @@ class EmulatedLib:
             _wr(g.ln_out, Y.reshape(-1).numpy(), bool(g.ln_out_bf16))
             _arr(g.ln_mean, M)[:] = mu.numpy()
             _arr(g.ln_rstd, M)[:] = rs.numpy()
-        return 0
 
     def kantts_fragmajor_bf16(self, src, dst, table, ndesc, blocks, stream):
         tab = _arr(table, ndesc * 5, np.int64).reshape(ndesc, 5)
@@ -330,7 +357,31 @@ class EmulatedLib:
             _wr(int(dst) + int(dst_off) * 2, img, True)
         return 0
 
-    def kantts_ffn_pair(self, args_ref, stream):
+    def kantts_ffn_pair_lnbwd(self, args_ref, ln_ref, stream):
+        """The backward form of kantts_ffn_pair followed by kantts_ln128_bwd_rows on dy = its result."""
+        g = args_ref._obj
+        if not g.gate or g.KT != 1 or g.res or g.bias2 or g.ln_out or g.drop2_p > 0:
+            return -2
+        return self.kantts_ffn_pair(args_ref, stream, lnb=ln_ref._obj)
+
+    def _ln128_bwd_values(self, l, M, v):
+        C = 128
+        DY = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+        X = torch.from_numpy(_arr(l.x, M * C).copy()).view(M, C)
+        G = torch.from_numpy(_arr(l.gamma, C))
+        mu, rs = torch.from_numpy(_arr(l.mean, M)), torch.from_numpy(_arr(l.rstd, M))
+        xh = (X - mu[:, None]) * rs[:, None]
+        gq = DY * G
+        DX = rs[:, None] * (gq - gq.mean(1, keepdim=True) - xh * (gq * xh).mean(1, keepdim=True))
+        if l.dres:
+            DX = DX + torch.from_numpy(_arr(l.dres, M * C).copy()).view(M, C)
+        if l.zero_rows:
+            DX = DX * torch.from_numpy((_arr(l.zero_rows, M, np.uint8) == 0).astype(np.float32))[:, None]
+        _arr(l.dx, M * C)[:] = DX.reshape(-1).numpy()
+        _arr(l.dgamma_accum, C)[:] += (DY * xh).sum(0).numpy()
+        _arr(l.dbeta_accum, C)[:] += DY.sum(0).numpy()
+
+    def kantts_ffn_pair(self, args_ref, stream, lnb=None):
         """csrc/ffn_pair.hip: t = epi1(sum_tap x[m + tap - pad] . w1[tap]^T) rounded to bf16; y = epi2(t . w2^T)."""
         g = args_ref._obj
         M, T, K1, F, N, KT, pad = g.M, g.T, g.K1, g.F, g.N, g.KT, g.pad
@@ -399,8 +450,11 @@ class EmulatedLib:
             y = np.where(_arr(g.rowmask2, M, np.uint8)[:, None] != 0, 0, y)
         y = y.astype(np.float32)
         esz = 2 if g.y_bf16 else 4
-        for i in range(M):
-            _wr(int(g.y) + i * g.ldy * esz, y[i], bool(g.y_bf16))
+        if g.y:
+            for i in range(M):
+                _wr(int(g.y) + i * g.ldy * esz, y[i], bool(g.y_bf16))
+        if lnb is not None:
+            self._ln128_bwd_values(lnb, M, _bf16_round(y) if g.y_bf16 else y)
         if g.ln_out:  # LayerNorm(128) of the output rows in the epilogue (forward form only)
             assert kt2 == 1 and not g.gate
             X = torch.from_numpy(y.copy())

@@ -74,6 +74,8 @@ struct Fibre {
   void* sp = nullptr;
   bool done = false;
   int wave = 0, lane = 0, par = 0;
+  int waiting = 0;  // diagnostics: 1 = at the workgroup barrier, 2 = at a wave rendezvous
+  unsigned long long nsync = 0;  // ... and how many barriers + rendezvous this thread has entered
   hipemu_idx tid;
 };
 
@@ -122,6 +124,25 @@ void yield() {
   if (++stalled > 4ull * (unsigned long long)nfib + 8) {
     fprintf(stderr, "hipemu: deadlock in workgroup (%u,%u,%u): the remaining threads wait at a barrier / wave rendezvous "
                     "the others never reach (divergent collective?)\n", blockIdx.x, blockIdx.y, blockIdx.z);
+    for (size_t w = 0; w < waves.size(); ++w) {
+      int at_barrier = 0, at_wave = 0, done = 0;
+      for (int t = (int)w * 64; t < std::min(nfib, (int)w * 64 + 64); ++t) {
+        done += fibres[t].done;
+        at_barrier += !fibres[t].done && fibres[t].waiting == 1;
+        at_wave += !fibres[t].done && fibres[t].waiting == 2;
+      }
+      fprintf(stderr, "  wave %zu: %d lanes at the workgroup barrier, %d at a wave rendezvous, %d finished\n", w, at_barrier,
+              at_wave, done);
+      if (at_wave && at_wave < 64) {
+        fprintf(stderr, "    at the rendezvous (thread: synchronisations entered):");
+        for (int t = (int)w * 64; t < std::min(nfib, (int)w * 64 + 64); ++t)
+          if (!fibres[t].done && fibres[t].waiting == 2) fprintf(stderr, " %d:%llu", t, fibres[t].nsync);
+        fprintf(stderr, "\n    elsewhere:");
+        for (int t = (int)w * 64; t < std::min(nfib, (int)w * 64 + 64); ++t)
+          if (!fibres[t].done && fibres[t].waiting != 2) fprintf(stderr, " %d:%llu", t, fibres[t].nsync);
+        fprintf(stderr, "\n");
+      }
+    }
     abort();
   }
   int nxt = cur;
@@ -190,16 +211,22 @@ uint64_t alive_mask() { return waves[fibres[cur].wave].mask; }
 void sync_threads() {
   const unsigned g = blk_gen;
   HIPEMU_TSAN_RELEASE(&blk_gen);
+  fibres[cur].waiting = 1;
+  ++fibres[cur].nsync;
   if (++blk_arrived == blk_alive) release_block();
   else while (blk_gen == g) yield();
+  fibres[cur].waiting = 0;
   HIPEMU_TSAN_ACQUIRE(&blk_gen);
 }
 void wave_sync() {
   Wave& w = waves[fibres[cur].wave];
   const unsigned g = w.gen;
   HIPEMU_TSAN_RELEASE(&w.gen);
+  fibres[cur].waiting = 2;
+  ++fibres[cur].nsync;
   if (++w.arrived == w.alive) release_wave(w);
   else while (w.gen == g) yield();
+  fibres[cur].waiting = 0;
   HIPEMU_TSAN_ACQUIRE(&w.gen);
 }
 const unsigned char (*post(const void* payload, int n))[64] {
@@ -220,6 +247,7 @@ const unsigned char (*post_once(const void* payload, int n, void (*fn)(const uns
   f.par ^= 1;
   memcpy(w.buf[p][f.lane], payload, (size_t)n);
   const unsigned g = w.gen;
+  ++f.nsync;
   HIPEMU_TSAN_RELEASE(&w.gen);
   if (++w.arrived == w.alive) {
     HIPEMU_TSAN_ACQUIRE(&w.gen);  // the other lanes' operands
@@ -227,7 +255,9 @@ const unsigned char (*post_once(const void* payload, int n, void (*fn)(const uns
     HIPEMU_TSAN_RELEASE(&w.gen);  // ... and the results
     release_wave(w);
   } else {
+    fibres[cur].waiting = 2;
     while (w.gen == g) yield();
+    fibres[cur].waiting = 0;
   }
   HIPEMU_TSAN_ACQUIRE(&w.gen);
   return w.res[p];
@@ -292,6 +322,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& fn
           Fibre& f = fibres[t];
           f.done = false;
           f.par = 0;
+          f.waiting = 0;
+          f.nsync = 0;
           f.wave = t / 64;
           f.lane = t % 64;
           f.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};

@@ -342,7 +342,8 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
              (hip.BGemmSeg, "kantts_bgemm_seg"), (hip.BGemmArgs, "kantts_bgemm_args"),
              (hip.BGemmTnArgs, "kantts_bgemm_tn_args"), (hip.TapMajorDesc, "kantts_tapmajor_desc"),
              (hip.FfnArgs, "kantts_ffn_args"), (hip.FragMajorDesc, "kantts_fragmajor_desc"),
-             (hip.CConvArgs, "kantts_cconv_args"), (hip.CConvWArgs, "kantts_cconvw_args")]
+             (hip.CConvArgs, "kantts_cconv_args"), (hip.CConvWArgs, "kantts_cconvw_args"),
+             (hip.LnBwdArgs, "kantts_lnbwd_args")]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "kantts_hip.h"', 'int main(void) {']
     for cls, cname in pairs:
         lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -362,3 +363,58 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
         assert ctypes.sizeof(cls) == c_layout[(cname, "sizeof")], (cname, ctypes.sizeof(cls), c_layout[(cname, "sizeof")])
         for fname, _ in cls._fields_:
             assert getattr(cls, fname).offset == c_layout[(cname, fname)], (cname, fname)
+
+
+def test_layernorm_backward_in_the_consumers_input_gradient_launch(emulated_cabi, monkeypatch):
+    """ops_bf16.LnBwdToken (KANTTS_LN_BWD_EPILOGUE, off by default): the backward of the LayerNorm in front of every
+    attention sub-layer is the epilogue of the QKV projection's input-gradient launch (kantts_bgemm_nt_lnbwd), that of the
+    LayerNorm in front of every feed-forward sub-layer the epilogue of the feed-forward pair's backward launch
+    (kantts_ffn_pair_lnbwd).  Same gradients as with the separate kantts_ln128_bwd_rows launches (same bf16-rounded dy on
+    both sides; the model of the ABI evaluates both with the same formulas), one launch less per sub-layer, and a second
+    consumer of the normalised rows is refused loudly instead of silently dropping its gradient."""
+    import kantts._hip as hip
+    from kantts._hip import ops, ops_bf16
+    from kantts.models.sambert.kantts_sambert import SelfAttentionEncoder
+
+    hip.set_precision("bf16")
+    try:
+        def run(on):
+            monkeypatch.setitem(ops_bf16.LNBWD, "on", on)
+            counts = {"kantts_ln128_bwd_rows": 0, "kantts_bgemm_nt_lnbwd": 0, "kantts_ffn_pair_lnbwd": 0}
+            local = pytest.MonkeyPatch()
+            for name in counts:
+                orig = getattr(emulated_cabi, name)
+                local.setattr(emulated_cabi, name, (lambda o, n: lambda *a: (counts.__setitem__(n, counts[n] + 1), o(*a))[1])(orig, name),
+                              raising=False)
+            torch.manual_seed(5)
+            enc = SelfAttentionEncoder(3, 128, 128, 8, 16, 1024, 0.0, 0.0, 0.0, position_encoder=None)
+            enc.train()
+            x = torch.randn(3, 21, 128, requires_grad=True)
+            mask = torch.arange(21)[None, :] >= torch.tensor([21, 9, 15])[:, None]
+            y, _ = enc(x, mask, prescaled=True)
+            try:
+                (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(1))).sum().backward()
+            finally:
+                local.undo()
+            return [x.grad] + [p.grad for p in enc.parameters()], counts
+
+        g_off, c_off = run(False)
+        g_on, c_on = run(True)
+        assert c_off["kantts_bgemm_nt_lnbwd"] == 0 and c_off["kantts_ffn_pair_lnbwd"] == 0
+        assert c_on["kantts_bgemm_nt_lnbwd"] == 3 and c_on["kantts_ffn_pair_lnbwd"] == 3  # one each per block
+        assert c_on["kantts_ln128_bwd_rows"] == c_off["kantts_ln128_bwd_rows"] - 6
+        for a, b in zip(g_on, g_off):
+            assert rel_l2(a, b) <= 1e-6, rel_l2(a, b)
+        assert torch.all(g_on[0][1, 9:] == 0) and torch.all(g_on[0][2, 15:] == 0)
+
+        # a second consumer of the normalised rows: autograd then delivers a sum the fused launch has not seen
+        monkeypatch.setitem(ops_bf16.LNBWD, "on", True)
+        x = torch.randn(4, 128, requires_grad=True)
+        gam, bet = torch.ones(128, requires_grad=True), torch.zeros(128, requires_grad=True)
+        w = torch.randn(384, 128, requires_grad=True) * 0.1
+        xn = ops.layer_norm(x, gam, bet, 1e-6, out_bf16=True)
+        q = ops.linear(xn, w)
+        with pytest.raises(RuntimeError, match="second consumer"):
+            (q.sum() + xn.float().sum()).backward()
+    finally:
+        hip.set_precision("fp32")

@@ -29,6 +29,7 @@ from test_host_logic_emulated import (  # noqa: F401
     test_row_mask_handed_to_the_consuming_layernorm_changes_no_gradient,
     test_arena_adam_matches_torch_adam,
     test_free_running_inference_matches_oracle,
+    test_layernorm_backward_in_the_consumers_input_gradient_launch,
 )
 from test_ops_sweep import (  # noqa: F401
     test_fused_linear_modes,
@@ -166,6 +167,20 @@ def test_op_fp32_mode(name, kw):
     ("test_ffn_pair_kernel_forward_and_backward_forms", dict(M=95, T=19, F=1024, KT=3)),
     ("test_ffn_pair_kernel_forward_and_backward_forms", dict(M=32, T=32, F=1024, KT=5)),
     ("test_layer_norm128", dict(M=6528)), ("test_layer_norm128", dict(M=100)), ("test_layer_norm128", dict(M=5)),
+    ("test_layernorm_backward_as_the_epilogue_of_the_input_gradient", dict(M=6528, a_f32=False, with_res=True, with_rows=True)),
+    ("test_layernorm_backward_as_the_epilogue_of_the_input_gradient", dict(M=100, a_f32=True, with_res=True, with_rows=False)),
+    ("test_layernorm_backward_as_the_epilogue_of_the_input_gradient", dict(M=37, a_f32=False, with_res=False, with_rows=True)),
+    ("test_layernorm_backward_as_the_epilogue_of_the_input_gradient", dict(M=5, a_f32=True, with_res=False, with_rows=False)),
+    ("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
+     dict(M=2048, T=64, KT=3, with_res=True, with_rows=False)),
+    ("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
+     dict(M=111, T=37, KT=1, with_res=False, with_rows=True)),
+    ("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
+     dict(M=95, T=19, KT=3, with_res=True, with_rows=True)),
+    ("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
+     dict(M=5, T=5, KT=1, with_res=False, with_rows=False)),
+    pytest.param("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
+                 dict(M=6528, T=204, KT=1, with_res=True, with_rows=True), marks=full_only),
 ], ids=lambda v: v if isinstance(v, str) else "-".join("%s" % x for x in v.values()))
 def test_op_bf16_mode(name, kw):
     _op_test("test_gpu_bf16_ops", name, precision="bf16", **kw)
