@@ -91,6 +91,11 @@ def test_fused_decode_step_on_the_kernel_source(B, seed):
     importlib.import_module("test_decode_graph").test_fused_decode_step_matches_python_loop_emulated(B, seed)
 
 
+def test_tiny_sambert_bf16_mode_with_the_layernorm_backward_epilogues_close_to_oracle(bf16_mode, monkeypatch):
+    importlib.import_module("test_bf16_path_emulated").test_tiny_sambert_bf16_mode_emulated_close_to_oracle(
+        None, monkeypatch, ln_bwd_epilogue=True)
+
+
 # ---- training steps on the kernel source
 @full_only
 def test_six_training_steps_retrace_the_reference_loss_curve_on_the_kernel_source():
@@ -171,8 +176,8 @@ def test_op_fp32_mode(name, kw):
     ("test_layernorm_backward_as_the_epilogue_of_the_input_gradient", dict(M=100, a_f32=True, with_res=True, with_rows=False)),
     ("test_layernorm_backward_as_the_epilogue_of_the_input_gradient", dict(M=37, a_f32=False, with_res=False, with_rows=True)),
     ("test_layernorm_backward_as_the_epilogue_of_the_input_gradient", dict(M=5, a_f32=True, with_res=False, with_rows=False)),
-    ("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
-     dict(M=2048, T=64, KT=3, with_res=True, with_rows=False)),
+    pytest.param("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
+                 dict(M=2048, T=64, KT=3, with_res=True, with_rows=False), marks=full_only),
     ("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
      dict(M=111, T=37, KT=1, with_res=False, with_rows=True)),
     ("test_layernorm_backward_as_the_epilogue_of_the_feed_forward_input_gradients",
