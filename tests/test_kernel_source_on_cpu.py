@@ -83,7 +83,17 @@ def kernel_source_instead_of_the_numpy_model(monkeypatch):
     import conftest
 
     monkeypatch.setattr(conftest, "_emulate", util.install_kernel_source)
+    nan_fill = os.environ.get("KANTTS_HOSTSIM_NANFILL", "") not in ("", "0")
+    if nan_fill:  # torch.empty() then returns NaN / max-int: an output cell no kernel writes, or an input read before it is
+        import torch  # written, shows up in the comparisons (the audit described in tests/hipemu/README.md)
+
+        old = (torch.are_deterministic_algorithms_enabled(), torch.utils.deterministic.fill_uninitialized_memory)
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
     yield
+    if nan_fill:
+        torch.use_deterministic_algorithms(old[0], warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = old[1]
 
 
 @pytest.mark.parametrize("B,seed", [(1, 77), pytest.param(3, 5, marks=full_only)])
