@@ -194,6 +194,26 @@ class LnBwdToken:
         return self.x is not None and self.dx is None and (self.dres is not None or not self.with_res)
 
 
+# A/B switch, OFF until measured on the device: the ReLU (+ dropout) gate of a hidden activation's gradient applied by the
+# epilogue of the launch that PRODUCES that gradient (the consumer's input-gradient contraction; the kernel has had the
+# ``gate`` epilogue since round 2) instead of a separate pass over it (kantts_relu_gate_bf16)
+RELUGATE = {"on": bool(os.environ.get("KANTTS_RELU_GATE_EPILOGUE"))}
+
+
+class ReluGateToken:
+    """h = dropout(relu(x W1 + b)) stored bf16 feeds exactly one contraction (kantts/models/sambert/fsmn.py:29-40,
+    __init__.py:40-49).  Backward: that contraction's input gradient dh is gated by h > 0 and scaled by 1 / (1 - p) before
+    anything else happens to it.  The producer of h leaves this token on it; the consumer's backward passes ``gate`` /
+    ``scale`` to its input-gradient launch and records the tensor it wrote in ``dz``; the producer's backward takes that
+    tensor as the already gated gradient -- after checking that what autograd delivers IS that tensor (a second consumer
+    of h would have been summed in un-gated: refused)."""
+    __slots__ = ("gate", "scale", "dz")
+
+    def __init__(self):
+        self.gate = self.dz = None
+        self.scale = 1.0
+
+
 def _same_tensor(a, b):
     return a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype
 
@@ -272,6 +292,9 @@ class _FusedLinearB(torch.autograd.Function):
         ctx.x_dtypes = [x.dtype for x in xs_in]
         ctx.w_shapes = [tuple(w.shape) for w in ws]
         ctx.save_for_backward(y if relu else None, rm, *xs, *wbs)
+        if opts.get("relugate_self") is not None and y.dtype == BF16:
+            tok = opts["relugate_self"]
+            tok.gate, tok.scale = y, (alpha / (1.0 - drop_p) if drop_p > 0 else alpha)
         return y.view(*lead, N)
 
     @staticmethod
@@ -295,7 +318,15 @@ class _FusedLinearB(torch.autograd.Function):
             if opts.get("lnbwd_res") is not None:
                 opts["lnbwd_res"].dres = d_res
         a_drop_p, a_seed, balpha = 0.0, 0, alpha
-        if relu:
+        rself = opts.get("relugate_self")
+        if relu and rself is not None and rself.dz is not None:
+            # gated and scaled by the launch that produced it (ReluGateToken)
+            if not _same_tensor(dy, rself.dz.view(M, N)):
+                raise RuntimeError("the ReLU gate of this gradient was applied by its producer's launch, but autograd "
+                                   "delivers another tensor: the hidden activation has a second consumer")
+            dz, balpha = dy, 1.0
+            rself.gate = rself.dz = None
+        elif relu:
             scale = alpha / (1.0 - drop_p) if drop_p > 0 else alpha
             dz = torch.empty((M, N), device=dy.device, dtype=BF16)
             check(lib().kantts_relu_gate_bf16(ptr(dy), int(dy.dtype == BF16), ptr(y_gate), int(y_gate.dtype == BF16),
@@ -352,6 +383,15 @@ class _FusedLinearB(torch.autograd.Function):
                                      None if tok.dres is None else _c(tok.dres).view(M, 128), tok.zero_rows, ldx, ldg, ldb)):
                         tok.dx, tok.dg, tok.db, tok.placeholder = ldx, ldg, ldb, x
                         dxs[k] = x  # stand-in: the LayerNorm node returns tok.dx and never reads this
+                rtok = opts.get("relugate") if (needs[5 + k] and dxs[k] is None and nx == 1) else None
+                if rtok is not None and rtok.gate is not None and rtok.dz is None and ctx.x_dtypes[k] == BF16:
+                    # x = dropout(relu(.)) of the producing layer: its gate and scale ride on this launch (ReluGateToken)
+                    dx = torch.empty(x.shape, device=x.device, dtype=BF16)
+                    gkw = dict(kw, alpha=kw["alpha"] * rtok.scale)
+                    if bgemm_nt([(dz, N, (wb, woff), wld, N, 0)], M, kk, dx, kk, b_kn=True, a_drop_ld=N, gate=rtok.gate,
+                                ldg=kk, **gkw):
+                        rtok.dz = dx
+                        dxs[k] = dx
                 if needs[5 + k] and dxs[k] is None:
                     dx = torch.empty(x.shape, device=x.device, dtype=ctx.x_dtypes[k])
                     if not bgemm_nt([(dz, N, (wb, woff), wld, N, 0)], M, kk, dx, kk, b_kn=True, a_drop_ld=N, **kw):
@@ -384,6 +424,11 @@ def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, dr
                                and weights[0].shape[0] == 128) else None
     opts = dict(nx=len(xs), nw=len(weights), mode=mode, relu=bool(relu), alpha=float(alpha), drop_p=float(drop_p),
                 pad=int(pad), dilation=int(dilation), T=int(T), out_bf16=bool(out_bf16), token=token, ln_next=pre)
+    if RELUGATE["on"] and torch.is_grad_enabled():
+        if relu and out_bf16:
+            opts["relugate_self"] = ReluGateToken()
+        if len(xs) == 1 and mode != "conv" and xs[0].dtype == BF16:
+            opts["relugate"] = getattr(xs[0], "_kantts_relugate", None)
     if LNBWD["on"] and torch.is_grad_enabled():
         if res is not None:  # this launch's backward sees the residual branch's gradient first
             opts["lnbwd_res"] = getattr(res, "_kantts_lnbwd_res", None)
@@ -393,6 +438,8 @@ def linear(xs, weights, wbs, bias, *, mode, bias2, res, rowmask, relu, alpha, dr
     y = _attach_token(_FusedLinearB.apply(opts, bias, bias2, res, rowmask, *xs, *weights, *wbs), token)
     if pre is not None and pre.xn is not None:
         y._kantts_prenorm = pre
+    if opts.get("relugate_self") is not None and opts["relugate_self"].gate is not None:
+        y._kantts_relugate = opts["relugate_self"]
     return y
 
 

@@ -418,3 +418,50 @@ def test_layernorm_backward_in_the_consumers_input_gradient_launch(emulated_cabi
             (q.sum() + xn.float().sum()).backward()
     finally:
         hip.set_precision("fp32")
+
+
+def test_relu_gate_of_a_hidden_gradient_in_its_producers_epilogue(emulated_cabi, monkeypatch):
+    """ops_bf16.ReluGateToken (KANTTS_RELU_GATE_EPILOGUE, off by default): the gradient of the bf16 hidden activation of an
+    FSMN feed-forward net is gated (ReLU, dropout) and scaled by the epilogue of the launch that computes it -- the second
+    contraction's input gradient -- instead of a kantts_relu_gate_bf16 pass over it.  Same gradients up to the one bf16
+    rounding the pass-through saved; the passes are gone; a second consumer of the hidden activation is refused."""
+    import kantts._hip as hip
+    from kantts._hip import ops, ops_bf16
+    from kantts.models.sambert.fsmn import FsmnEncoderV2
+
+    hip.set_precision("bf16")
+    try:
+        def run(on):
+            monkeypatch.setitem(ops_bf16.RELUGATE, "on", on)
+            monkeypatch.setattr(ops, "next_seed", lambda: 4242)
+            calls = []
+            local = pytest.MonkeyPatch()
+            orig = emulated_cabi.kantts_relu_gate_bf16
+            local.setattr(emulated_cabi, "kantts_relu_gate_bf16", lambda *a: (calls.append(1), orig(*a))[1], raising=False)
+            torch.manual_seed(3)
+            enc = FsmnEncoderV2(11, 3, 256, 256, 512, dropout=0.1, shift=2)
+            enc.train()
+            x = torch.randn(2, 37, 256, requires_grad=True)
+            mask = torch.arange(37)[None, :] >= torch.tensor([37, 20])[:, None]
+            try:
+                y = enc(x, mask)
+                (y * torch.randn(y.shape, generator=torch.Generator().manual_seed(1))).sum().backward()
+            finally:
+                local.undo()
+            return [x.grad] + [p.grad for p in enc.parameters()], len(calls)
+
+        g_off, n_off = run(False)
+        g_on, n_on = run(True)
+        assert n_off == 3 and n_on == 0
+        for a, b in zip(g_on, g_off):
+            assert rel_l2(a, b) <= 6e-3, rel_l2(a, b)   # one bf16 rounding of the hidden gradient instead of two
+
+        monkeypatch.setitem(ops_bf16.RELUGATE, "on", True)
+        x = torch.randn(8, 64, requires_grad=True)
+        w1, w2 = (torch.randn(32, 64) * 0.1).requires_grad_(True), (torch.randn(16, 32) * 0.1).requires_grad_(True)
+        h = ops.linear(x, w1, None, relu=True, out_bf16=True)
+        out = ops.linear(h, w2, None)
+        with pytest.raises(RuntimeError, match="second consumer"):
+            (out.sum() + h.float().sum()).backward()
+    finally:
+        hip.set_precision("fp32")

@@ -30,6 +30,7 @@ from test_host_logic_emulated import (  # noqa: F401
     test_arena_adam_matches_torch_adam,
     test_free_running_inference_matches_oracle,
     test_layernorm_backward_in_the_consumers_input_gradient_launch,
+    test_relu_gate_of_a_hidden_gradient_in_its_producers_epilogue,
 )
 from test_ops_sweep import (  # noqa: F401
     test_fused_linear_modes,
@@ -337,11 +338,12 @@ _FULL_CONFIG_BOUNDS = {  # the bounds of tests/test_bench_config_parity.py (devi
 }
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-ln_bwd_epilogue"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-ln_bwd_epilogue", "bf16-ln_bwd_epilogue-relu_gate_epilogue"])
 def test_full_sambert_configuration_matches_oracle_on_the_kernel_source(mode, monkeypatch):
     """BASELINE config 2's model (sambert_16k.yaml zhcn: 8 + 12 blocks of width 128 / 1024, FSMN + LSTM postnet) forward,
     losses and every parameter gradient against oracle/torch_oracle.py -- tests/test_bench_config_parity.py with host
-    tensors at B = 2 x T_in = 12 and the same bounds; third case with the opt-in LayerNorm-backward epilogues."""
+    tensors at B = 2 x T_in = 12 and the same bounds; the last cases with the opt-in LayerNorm-backward / ReLU-gate
+    epilogues."""
     import torch
 
     import kantts._hip as hip
@@ -351,7 +353,8 @@ def test_full_sambert_configuration_matches_oracle_on_the_kernel_source(mode, mo
     from kantts.train.loss import MelReconLoss, ProsodyReconLoss
 
     prec = mode.split("-")[0]
-    monkeypatch.setitem(ops_bf16.LNBWD, "on", mode.endswith("ln_bwd_epilogue"))
+    monkeypatch.setitem(ops_bf16.LNBWD, "on", "ln_bwd_epilogue" in mode)
+    monkeypatch.setitem(ops_bf16.RELUGATE, "on", "relu_gate_epilogue" in mode)
     cfg = O.sambert_config(tiny=False)
     cfg = {k: (0.0 if "dropout" in k else v) for k, v in cfg.items()}
     torch.manual_seed(0)
