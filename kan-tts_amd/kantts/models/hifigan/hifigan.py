@@ -312,16 +312,21 @@ class MultiScaleDiscriminator(torch.nn.Module):
             if follow_official_norm:
                 params["use_spectral_norm"] = True if i == 0 else False
             self.discriminators += [ScaleDiscriminator(**params)]
-        if downsample_pooling != "DWT":
-            raise NotImplementedError("AvgPool1d pooling is not used by any shipped yaml")
-        self.meanpools = nn.ModuleList([DWT1DForward(wave="db3", J=1), DWT1DForward(wave="db3", J=1)])
-        self.aux_convs = nn.ModuleList([weight_norm(nn.Conv1d(2, 1, 15, 1, padding=7)),
-                                        weight_norm(nn.Conv1d(2, 1, 15, 1, padding=7))])
+        if downsample_pooling == "DWT":
+            self.meanpools = nn.ModuleList([DWT1DForward(wave="db3", J=1), DWT1DForward(wave="db3", J=1)])
+            self.aux_convs = nn.ModuleList([weight_norm(nn.Conv1d(2, 1, 15, 1, padding=7)),
+                                            weight_norm(nn.Conv1d(2, 1, 15, 1, padding=7))])
+        else:  # any other value: the reference's fixed AvgPool1d(4, 2, padding=2) pair, no auxiliary convolutions (:456-459)
+            self.meanpools = nn.ModuleList([nn.AvgPool1d(4, 2, padding=2), nn.AvgPool1d(4, 2, padding=2)])
+            self.aux_convs = None
 
     def forward(self, y):
         # the pooling chain is sequential (and cheap); the scale discriminators on its outputs are independent
         hs = [y.transpose(1, 2).contiguous()]
         for i in range(1, len(self.discriminators)):
+            if self.aux_convs is None:  # one-channel average pooling (no shipped yaml selects it): two small launches
+                hs.append(self.meanpools[i - 1](hs[-1].transpose(1, 2)).transpose(1, 2).contiguous())
+                continue
             h = self.meanpools[i - 1].forward_cl(hs[-1])
             c = self.aux_convs[i - 1]
             hs.append(ops.conv_cl(h, effective_weight(c), c.bias, pad=7, out_leaky=0.1))

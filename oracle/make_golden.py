@@ -660,6 +660,26 @@ def loss_variants_case():
     print("loss_variants.pt", float(a), float(d), float(hinge[("g_list", True)][0]))
 
 
+def msd_avgpool_case():
+    """MultiScaleDiscriminator with the pooling no shipped yaml selects (hifigan.py:456-471: AvgPool1d(4, 2, padding=2),
+    no auxiliary convolutions): outputs, feature-map sums and an input gradient of the reference at a small width."""
+    from kantts.models.hifigan.hifigan import MultiScaleDiscriminator
+
+    dp = {"in_channels": 1, "out_channels": 1, "kernel_sizes": [15, 41, 5, 3], "channels": 16,
+          "max_downsample_channels": 64, "max_groups": 4, "bias": True, "downsample_scales": [2, 2, 4, 4, 1],
+          "nonlinear_activation": "LeakyReLU", "nonlinear_activation_params": {"negative_slope": 0.1}}
+    torch.manual_seed(21)
+    msd = MultiScaleDiscriminator(scales=3, downsample_pooling="AvgPool1d", discriminator_params=dp)
+    x = torch.randn(2, 1, 1537, generator=torch.Generator().manual_seed(22)).requires_grad_(True)
+    outs, fmaps = msd(x)
+    sum(o.pow(2).mean() for o in outs).backward()
+    fix = dict(discriminator_params=dp, x=x.detach().clone(), outs=[o.detach().clone() for o in outs],
+               fmap_sums=[[(tuple(f.shape), float(f.double().sum()), float(f.double().abs().sum())) for f in fm] for fm in fmaps],
+               dx=x.grad.clone(), keys=sorted(msd.state_dict().keys()), checksums=checksums(msd.state_dict()))
+    torch.save(fix, os.path.join(OUT, "msd_avgpool.pt"))
+    print("msd_avgpool.pt", [tuple(o.shape) for o in outs])
+
+
 def masks_case():
     """get_mask_from_lengths (kantts/models/utils.py:13-23) and get_lfr_mask_from_lengths' ceil(len / r) rule on
     seeded lengths, with and without an explicit max_len."""
@@ -711,3 +731,4 @@ if __name__ == "__main__":
     masks_case()
     multiband_case()
     loss_variants_case()
+    msd_avgpool_case()

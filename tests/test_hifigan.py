@@ -594,3 +594,32 @@ def test_branch_exit_is_an_identity_with_a_private_gradient():
     x.grad = None
     y2.backward(g0)
     assert torch.equal(x.grad, g0) and x.grad.data_ptr() != hooked["g"].data_ptr()
+
+
+def test_multiscale_discriminator_with_average_pooling_matches_the_reference_fixture():
+    """downsample_pooling other than "DWT" (no shipped yaml): the reference's AvgPool1d(4, 2, padding=2) pair without
+    auxiliary convolutions (hifigan.py:456-471) -- same state_dict keys, seeded weights, outputs, feature-map sums and
+    input gradient as recorded from the reference (tests/golden/msd_avgpool.pt, make_golden.py::msd_avgpool_case)."""
+    from kantts.models.hifigan.hifigan import MultiScaleDiscriminator
+
+    import os
+
+    from util import GOLDEN
+
+    fix = torch.load(os.path.join(GOLDEN, "msd_avgpool.pt"), weights_only=False)
+    torch.manual_seed(21)
+    msd = MultiScaleDiscriminator(scales=3, downsample_pooling="AvgPool1d", discriminator_params=fix["discriminator_params"])
+    sd = msd.state_dict()
+    assert sorted(sd.keys()) == fix["keys"]
+    for k, (shape, s_, a_) in fix["checksums"].items():
+        assert tuple(sd[k].shape) == shape and abs(float(sd[k].double().sum()) - s_) <= 1e-6 * max(1.0, a_), k
+    x = fix["x"].clone().requires_grad_(True)
+    with emulation():
+        outs, fmaps = msd(x)
+        sum(o.pow(2).mean() for o in outs).backward()
+    for o, w in zip(outs, fix["outs"]):
+        assert_close(o.detach(), w, 2e-6, what="MSD output")
+    for fm, ws in zip(fmaps, fix["fmap_sums"]):
+        for f, (shape, s_, a_) in zip(fm, ws):
+            assert tuple(f.shape) == shape and abs(float(f.double().sum()) - s_) <= 2e-5 * max(1.0, a_)
+    assert rel_l2(x.grad, fix["dx"]) <= 1e-5

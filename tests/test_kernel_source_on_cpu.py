@@ -66,7 +66,11 @@ from test_melspec import (  # noqa: F401
     test_melspec_backward_emulated,
     test_dsp_melspectrogram_emulated,
 )
-from test_hifigan import test_conv_variants_emulated_match_torch, test_conv_win_emulated_matches_torch  # noqa: F401
+from test_hifigan import (  # noqa: F401
+    test_conv_variants_emulated_match_torch,
+    test_conv_win_emulated_matches_torch,
+    test_multiscale_discriminator_with_average_pooling_matches_the_reference_fixture,
+)
 from test_hifigan_nsf import test_nsf_generator_host_logic_matches_reference_fixture  # noqa: F401
 from test_sambert_se import test_sambert_se_host_logic_matches_reference_fixture  # noqa: F401
 from test_multiband import test_pqmf_emulated, test_multispec_emulated  # noqa: F401
