@@ -6,6 +6,7 @@ Nothing here computes on the host or with ATen kernels except trivial views / al
 """
 import itertools
 import os
+import weakref
 import math
 
 import torch
@@ -2044,11 +2045,11 @@ def upsample_forward(act, w, bias, s, res=None, out_bf16=False, in_slope=1.0, pr
         return None
     if prepared is None and isinstance(w, torch.nn.Parameter):
         hit = _up_wcache.get(id(w))
-        if hit is not None and hit[0] == (w._version, w.data_ptr(), s):
+        if hit is not None and hit[2]() is w and hit[0] == (w._version, w.data_ptr(), s):  # see ops_bf16.bf16_weight
             prepared = hit[1]
         else:
             prepared = upsample_weights(w, s)
-            _up_wcache[id(w)] = ((w._version, w.data_ptr(), s), prepared)
+            _up_wcache[id(w)] = ((w._version, w.data_ptr(), s), prepared, weakref.ref(w))
     wl, wp = prepared if prepared is not None else upsample_weights(w, s)
     out = torch.empty((B, T * s, Cout), device=act.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     r = _c(res) if res is not None else None

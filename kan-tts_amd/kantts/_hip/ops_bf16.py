@@ -11,6 +11,7 @@ gradient; those tensors have exactly one consumer, so nothing is ever accumulate
 """
 import math
 import os
+import weakref
 
 import torch
 
@@ -49,7 +50,10 @@ def bf16_weight(w, tap_major=False):
         return sh
     key = (id(w), bool(tap_major))
     hit = _wcache.get(key)
-    if hit is not None and hit[0] == w._version and hit[1] == w.data_ptr() and hit[2] == tuple(w.shape):
+    # id() is only unique among LIVE objects: the entry remembers which tensor it was made from (weak reference), so a
+    # new tensor that inherits the id, address, shape and version of a dead one does not inherit its image
+    if (hit is not None and hit[4]() is w and hit[0] == w._version and hit[1] == w.data_ptr()
+            and hit[2] == tuple(w.shape)):
         return hit[3]
     with torch.no_grad():
         src = w.detach()
@@ -58,7 +62,7 @@ def bf16_weight(w, tap_major=False):
         t = to_bf16(src)
     if len(_wcache) > 4096:
         _wcache.clear()
-    _wcache[key] = (w._version, w.data_ptr(), tuple(w.shape), t)
+    _wcache[key] = (w._version, w.data_ptr(), tuple(w.shape), t, weakref.ref(w))
     return t
 
 
@@ -93,7 +97,7 @@ def ffn_frag_weights(w1, w2):
     key = (id(w1), id(w2), "frag")
     sig = (w1._version, w1.data_ptr(), tuple(w1.shape), w2._version, w2.data_ptr(), tuple(w2.shape))
     hit = _wcache.get(key)
-    if hit is not None and hit[0] == sig:
+    if hit is not None and hit[0] == sig and hit[2]() is w1 and hit[3]() is w2:
         return hit[1]
     F, C, KT = w1.shape
     N = w2.shape[0]
@@ -104,7 +108,7 @@ def ffn_frag_weights(w1, w2):
         t1 = frag_major(w1.detach().permute(2, 1, 0).reshape(KT * C, F))
     if len(_wcache) > 4096:
         _wcache.clear()
-    _wcache[key] = (sig, (f1, f2, t2, t1))
+    _wcache[key] = (sig, (f1, f2, t2, t1), weakref.ref(w1), weakref.ref(w2))
     return f1, f2, t2, t1
 
 

@@ -298,3 +298,30 @@ def test_layernorm_in_the_producer_epilogue_equals_the_separate_launch(bf16_mode
     assert torch.equal(y_on, y_off)
     for a, b in zip(g_on, g_off):
         assert torch.equal(a, b)
+
+
+def test_weight_image_cache_does_not_outlive_its_tensor(bf16_mode):
+    """ops_bf16.bf16_weight / ffn_frag_weights / ops.upsample_forward cache the bf16 images of tensors that live outside
+    a parameter arena under id(tensor).  id() is only unique among live objects: a new tensor that inherits the id, the
+    address, the shape and the version of a dead one (a second model built in the same process) used to inherit its
+    image.  The entries now remember their tensor by weak reference; simulated here by planting a stale entry whose
+    signature matches a live tensor."""
+    import weakref
+
+    from kantts._hip import ops_bf16
+
+    with emulation():
+        old = torch.randn(16, 32)
+        stale = ops_bf16.bf16_weight(old)
+        new = torch.randn(16, 32)
+        ops_bf16._wcache[(id(new), False)] = (new._version, new.data_ptr(), tuple(new.shape), stale, weakref.ref(old))
+        got = ops_bf16.bf16_weight(new)
+        assert torch.equal(got, new.to(torch.bfloat16)) and not torch.equal(got, stale)
+        assert ops_bf16.bf16_weight(new) is got  # and the fresh entry is a hit
+        w1o, w2o = torch.randn(1024, 128, 1), torch.randn(128, 1024, 1)
+        imgs = ops_bf16.ffn_frag_weights(w1o, w2o)
+        w1, w2 = torch.randn(1024, 128, 1), torch.randn(128, 1024, 1)
+        sig = (w1._version, w1.data_ptr(), tuple(w1.shape), w2._version, w2.data_ptr(), tuple(w2.shape))
+        ops_bf16._wcache[(id(w1), id(w2), "frag")] = (sig, imgs, weakref.ref(w1o), weakref.ref(w2o))
+        f1 = ops_bf16.ffn_frag_weights(w1, w2)[0]
+        assert torch.equal(f1, ops_bf16.frag_major(w1.permute(2, 0, 1).reshape(1024, 128))) and not torch.equal(f1, imgs[0])
