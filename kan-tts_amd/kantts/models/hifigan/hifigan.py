@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch.nn.utils import spectral_norm, weight_norm
 
 from kantts._hip import get_precision, ops
-from kantts.models.hifigan.layers import (CausalConv1d, CausalConvTranspose1d, Conv1d, ConvTranspose1d,
+from kantts.models.hifigan.layers import (activation_slope, CausalConv1d, CausalConvTranspose1d, Conv1d, ConvTranspose1d,
                                           ResidualBlock, SourceModule, conv_weight, effective_weight)
 
 DB3_DEC_LO = [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313,
@@ -37,8 +37,6 @@ class Generator(torch.nn.Module):
         assert kernel_size % 2 == 1, "Kernal size must be odd number."
         assert len(upsample_scales) == len(upsample_kernal_sizes)
         assert len(resblock_dilations) == len(resblock_kernel_sizes)
-        if nonlinear_activation != "LeakyReLU":
-            raise NotImplementedError("only LeakyReLU (every shipped yaml)")
         self.upsample_scales = upsample_scales
         self.repeat_upsample = repeat_upsample
         self.num_upsamples = len(upsample_kernal_sizes)
@@ -46,7 +44,7 @@ class Generator(torch.nn.Module):
         self.out_channels = out_channels
         self.nsf_enable = nsf_params is not None
         self.causal = causal
-        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.slope = activation_slope(nonlinear_activation, nonlinear_activation_params)
         self.transpose_upsamples = torch.nn.ModuleList()
         self.repeat_upsamples = torch.nn.ModuleList()
         self.conv_blocks = torch.nn.ModuleList()
@@ -168,7 +166,7 @@ class PeriodDiscriminator(torch.nn.Module):
         super(PeriodDiscriminator, self).__init__()
         weight_norm = _norm_f(use_spectral_norm)
         self.period = period
-        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.slope = activation_slope(nonlinear_activation, nonlinear_activation_params)
         self.convs = nn.ModuleList()
         in_chs, out_chs = in_channels, channels
         for downsample_scale in downsample_scales:
@@ -234,7 +232,7 @@ class ScaleDiscriminator(torch.nn.Module):
         assert len(kernel_sizes) == 4
         for ks in kernel_sizes:
             assert ks % 2 == 1
-        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.slope = activation_slope(nonlinear_activation, nonlinear_activation_params)
         act = lambda: getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)  # noqa: E731
         self.convs = nn.ModuleList()
         self.convs.append(torch.nn.Sequential(
@@ -348,7 +346,7 @@ class SpecDiscriminator(torch.nn.Module):
         super(SpecDiscriminator, self).__init__()
         self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
         norm_f = _norm_f(use_spectral_norm)
-        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.slope = activation_slope(nonlinear_activation, nonlinear_activation_params)
         final_kernel, post_conv_kernel, blocks = 5, 3, 3
         act = lambda: getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)  # noqa: E731
         self.convs = nn.ModuleList()

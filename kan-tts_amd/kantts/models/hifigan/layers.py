@@ -139,6 +139,17 @@ class CausalConvTranspose1d(torch.nn.Module):
         remove_weight_norm(self.deconv)
 
 
+def activation_slope(name, params):
+    """The reference instantiates ``getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)``
+    (hifigan.py:69-71, layers.py:209-211).  Every convolution kernel here applies its input / output activation itself,
+    parametrised by one slope: LeakyReLU(negative_slope) and ReLU (= slope 0) are expressible, anything else is not."""
+    if name == "LeakyReLU":
+        return float(params.get("negative_slope", 0.01))
+    if name == "ReLU":
+        return 0.0
+    raise NotImplementedError("activation %s: only LeakyReLU / ReLU are fused into the convolution kernels" % name)
+
+
 class ResidualBlock(torch.nn.Module):
     """3 x [LeakyReLU -> dilated conv -> LeakyReLU -> conv -> + x] (reference :168-226): 6 GEMM launches,
     activations and residual adds fused."""
@@ -147,8 +158,6 @@ class ResidualBlock(torch.nn.Module):
                  nonlinear_activation_params={"negative_slope": 0.1}, causal=False):
         super().__init__()
         assert kernel_size % 2 == 1, "Kernal size must be odd number."
-        if nonlinear_activation != "LeakyReLU":
-            raise NotImplementedError("only LeakyReLU (every shipped yaml)")
         conv_cls = CausalConv1d if causal else Conv1d
         self.convs1 = nn.ModuleList([
             conv_cls(channels, channels, kernel_size, 1, dilation=dilation[i],
@@ -157,7 +166,7 @@ class ResidualBlock(torch.nn.Module):
             conv_cls(channels, channels, kernel_size, 1, dilation=1, padding=get_padding(kernel_size, 1))
             for i in range(len(dilation))])
         self.activation = getattr(torch.nn, nonlinear_activation)(**nonlinear_activation_params)
-        self.slope = float(nonlinear_activation_params.get("negative_slope", 0.01))
+        self.slope = activation_slope(nonlinear_activation, nonlinear_activation_params)  # refuses what cannot be fused
 
     def forward_cl(self, x):
         # bf16 mode, wide enough for the MFMA kernels: the whole stack as one autograd node (ops._ResStackBF16)

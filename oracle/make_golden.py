@@ -680,6 +680,28 @@ def msd_avgpool_case():
     print("msd_avgpool.pt", [tuple(o.shape) for o in outs])
 
 
+def relu_generator_case():
+    """Generator with nonlinear_activation="ReLU" (hifigan.py:69-71, layers.py:209-211; no shipped yaml): forward +
+    gradient norms of the reference at a small width, causal and non-causal."""
+    from kantts.models.hifigan.hifigan import Generator
+
+    res = {}
+    for causal in (True, False):
+        torch.manual_seed(5)
+        G = Generator(in_channels=80, channels=32, upsample_scales=[4, 4, 2, 2], upsample_kernal_sizes=[8, 8, 4, 4],
+                      causal=causal, nonlinear_activation="ReLU", nonlinear_activation_params={})
+        g = torch.Generator().manual_seed(12)
+        x = torch.randn(2, 80, 7, generator=g)
+        y = G(x)
+        cot = torch.randn(y.shape, generator=g)
+        (y * cot).sum().backward()
+        res["causal" if causal else "noncausal"] = dict(
+            x=x, y=y.detach().clone(), cot=cot, weight_checksums=checksums(G.state_dict()),
+            grad_norms={n: float(p.grad.double().norm()) for n, p in G.named_parameters() if p.grad is not None})
+    torch.save(res, os.path.join(OUT, "hifigan_relu.pt"))
+    print("hifigan_relu.pt", float(res["causal"]["y"].abs().mean()))
+
+
 def masks_case():
     """get_mask_from_lengths (kantts/models/utils.py:13-23) and get_lfr_mask_from_lengths' ceil(len / r) rule on
     seeded lengths, with and without an explicit max_len."""
@@ -732,3 +754,4 @@ if __name__ == "__main__":
     multiband_case()
     loss_variants_case()
     msd_avgpool_case()
+    relu_generator_case()

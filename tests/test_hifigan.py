@@ -623,3 +623,32 @@ def test_multiscale_discriminator_with_average_pooling_matches_the_reference_fix
         for f, (shape, s_, a_) in zip(fm, ws):
             assert tuple(f.shape) == shape and abs(float(f.double().sum()) - s_) <= 2e-5 * max(1.0, a_)
     assert rel_l2(x.grad, fix["dx"]) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["causal", "noncausal"])
+def test_generator_with_relu_activation_matches_the_reference_fixture(name):
+    """nonlinear_activation="ReLU" (no shipped yaml): every convolution kernel applies its activation itself, parametrised
+    by one slope, and ReLU is slope 0 -- output and per-parameter gradient norms as recorded from the reference
+    (tests/golden/hifigan_relu.pt, make_golden.py::relu_generator_case); other activations are refused."""
+    import os
+
+    from kantts.models.hifigan.hifigan import Generator
+    from util import GOLDEN
+
+    fix = torch.load(os.path.join(GOLDEN, "hifigan_relu.pt"), weights_only=False)[name]
+    torch.manual_seed(5)
+    G = Generator(in_channels=80, channels=32, upsample_scales=[4, 4, 2, 2], upsample_kernal_sizes=[8, 8, 4, 4],
+                  causal=(name == "causal"), nonlinear_activation="ReLU", nonlinear_activation_params={})
+    sd = G.state_dict()
+    for k, (shape, s_, a_) in fix["weight_checksums"].items():
+        assert tuple(sd[k].shape) == shape and abs(float(sd[k].double().sum()) - s_) <= 1e-6 * max(1.0, a_), k
+    with emulation():
+        y = G(fix["x"])
+        (y * fix["cot"]).sum().backward()
+    assert_close(y.detach(), fix["y"], 2e-6, what="waveform")
+    for n, p in G.named_parameters():
+        if n in fix["grad_norms"]:
+            w = fix["grad_norms"][n]
+            assert abs(float(p.grad.double().norm()) - w) <= 2e-4 * max(w, 1e-3), n
+    with pytest.raises(NotImplementedError):
+        Generator(in_channels=80, channels=32, nonlinear_activation="ELU", nonlinear_activation_params={})

@@ -70,6 +70,7 @@ from test_hifigan import (  # noqa: F401
     test_conv_variants_emulated_match_torch,
     test_conv_win_emulated_matches_torch,
     test_multiscale_discriminator_with_average_pooling_matches_the_reference_fixture,
+    test_generator_with_relu_activation_matches_the_reference_fixture,
 )
 from test_hifigan_nsf import test_nsf_generator_host_logic_matches_reference_fixture  # noqa: F401
 from test_sambert_se import test_sambert_se_host_logic_matches_reference_fixture  # noqa: F401
