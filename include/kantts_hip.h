@@ -601,13 +601,6 @@ typedef struct kantts_ffn_args {
 } kantts_ffn_args;
 int kantts_ffn_pair(const kantts_ffn_args* args, void* stream);
 
-/* The backward form of kantts_ffn_pair (gate set, KT == 1, KT2 = 1 or 3) whose result y -- the gradient of the
- * feed-forward sub-layer's LayerNorm output (kantts/models/sambert/__init__.py:134-136) -- goes through that LayerNorm's
- * backward in the epilogue, as kantts_bgemm_nt_lnbwd does for the attention sub-layers: dx / dgamma / dbeta leave; y is
- * rounded to bf16 first when args->y_bf16 is set and is itself stored only if args->y is not NULL.  args->res / bias2 /
- * drop2_p / ln_out must be unset. */
-int kantts_ffn_pair_lnbwd(const kantts_ffn_args* args, const kantts_lnbwd_args* ln, void* stream);
-
 /* Fragment-major bf16 images of weight matrices, a table of them in one launch (the parameter arena's per-step refresh).
  * Entry: the (R, K) matrix with element (r, k) = src[src_off + r*sr + k*sk] (fp32; any orientation of the master weight)
  * is written to dst + dst_off so that every 16 x 32 block (r/16, k/32) is 1 KB in the order one A-operand load of

@@ -57,19 +57,8 @@ __device__ __forceinline__ float fp_hi(unsigned u) { return __uint_as_float(u & 
 // recomputed by the neighbouring workgroup (6 % more phase-1 work instead of a second launch that re-reads dz).
 template <bool BWD, int KT2>
 __global__ __launch_bounds__(FP_THREADS) void ffn_pair_kernel(const kantts_ffn_args g) {
-  constexpr bool LNB = false;
-  const kantts_lnbwd_args* const lnb = nullptr;
 #include "ffn_pair_body.inc"
 }
-// the backward form whose result is the output gradient of a LayerNorm(128): that LayerNorm's backward as the epilogue
-// (kantts_ffn_pair_lnbwd)
-template <int KT2>
-__global__ __launch_bounds__(FP_THREADS) void ffn_pair_lnb_kernel(const kantts_ffn_args g, const kantts_lnbwd_args lnb_args) {
-  constexpr bool BWD = true, LNB = true;
-  const kantts_lnbwd_args* const lnb = &lnb_args;
-#include "ffn_pair_body.inc"
-}
-
 static bool fp_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int kantts_ffn_pair(const kantts_ffn_args* gp, void* stream) {
@@ -101,32 +90,6 @@ extern "C" int kantts_ffn_pair(const kantts_ffn_args* gp, void* stream) {
     hipLaunchKernelGGL((ffn_pair_kernel<true, 1>), dim3(kantts_cdiv(g.M, FP_BM)), dim3(FP_THREADS), 0, st, g);
   else
     hipLaunchKernelGGL((ffn_pair_kernel<false, 1>), dim3(kantts_cdiv(g.M, FP_BM)), dim3(FP_THREADS), 0, st, g);
-  KANTTS_CHECK_LAUNCH();
-}
-
-extern "C" int kantts_ffn_pair_lnbwd(const kantts_ffn_args* gp, const kantts_lnbwd_args* lp, void* stream) {
-  if (!gp || !lp) return KANTTS_E_BADARG;
-  const kantts_ffn_args& g = *gp;
-  const kantts_lnbwd_args& l = *lp;
-  if (!g.x || !g.w1 || !g.w2 || g.M < 0 || g.KT != 1 || !g.gate) return KANTTS_E_BADARG;  // the backward form only
-  if (!l.x || !l.gamma || !l.mean || !l.rstd || !l.dx || !l.dgamma_accum || !l.dbeta_accum) return KANTTS_E_BADARG;
-  if (g.K1 != FP_K1 || g.N != FP_N || g.F != FP_F) return KANTTS_E_UNSUPPORTED;
-  if ((g.ldx & 7) || (g.y && (g.ldy & 3)) || g.res || g.bias2 || g.ln_out || g.drop2_p > 0.f) return KANTTS_E_UNSUPPORTED;
-  if (!fp_aligned16(g.x) || !fp_aligned16(g.w1) || !fp_aligned16(g.w2) || (g.y && !fp_aligned16(g.y)) ||
-      (g.t_out && !fp_aligned16(g.t_out)) || !fp_aligned16(g.gate) || (g.bias1 && !fp_aligned16(g.bias1)))
-    return KANTTS_E_UNSUPPORTED;
-  if (!fp_aligned16(l.x) || !fp_aligned16(l.gamma) || !fp_aligned16(l.dx) || (l.dres && !fp_aligned16(l.dres)))
-    return KANTTS_E_UNSUPPORTED;
-  if (g.xdrop_p > 0.f && !g.x_f32) return KANTTS_E_UNSUPPORTED;
-  const int kt2 = g.KT2 < 1 ? 1 : g.KT2;
-  if (kt2 != 1 && kt2 != 3) return KANTTS_E_UNSUPPORTED;
-  if (kt2 == 3 && (g.T <= 0 || (g.s2_step != 1 && g.s2_step != -1) || g.M % g.T)) return KANTTS_E_UNSUPPORTED;
-  if (g.M == 0) return KANTTS_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (kt2 == 3)
-    hipLaunchKernelGGL((ffn_pair_lnb_kernel<3>), dim3(kantts_cdiv(g.M, FP_BM - 2)), dim3(FP_THREADS), 0, st, g, l);
-  else
-    hipLaunchKernelGGL((ffn_pair_lnb_kernel<1>), dim3(kantts_cdiv(g.M, FP_BM)), dim3(FP_THREADS), 0, st, g, l);
   KANTTS_CHECK_LAUNCH();
 }
 

@@ -262,7 +262,6 @@ def lib():
         L.kantts_ln128_fwd.argtypes = [p, p, p, p, i, p, p, i, f, p]
         L.kantts_ln128_bwd.argtypes = [p, i, p, p, p, p, p, p, p, p, i, p]
         L.kantts_bgemm_nt_lnbwd.argtypes = [POINTER(BGemmArgs), POINTER(LnBwdArgs), c_void_p]
-        L.kantts_ffn_pair_lnbwd.argtypes = [POINTER(FfnArgs), POINTER(LnBwdArgs), c_void_p]
         L.kantts_ln128_bwd_rows.argtypes = [p, i, p, p, p, p, p, p, p, p, p, i, p]
         L.kantts_cconv_launch.argtypes = [POINTER(CConvArgs), c_void_p]
         L.kantts_cconv_wgrad_launch.argtypes = [POINTER(CConvWArgs), c_void_p]
@@ -285,7 +284,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
     "kantts_bgemm_nt", "kantts_ffn_pair", "kantts_fragmajor_bf16", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",
-    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_ln128_bwd_rows", "kantts_bgemm_nt_lnbwd", "kantts_ffn_pair_lnbwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
+    "kantts_ln128_fwd", "kantts_ln128_bwd", "kantts_ln128_bwd_rows", "kantts_bgemm_nt_lnbwd", "kantts_stft_mag_bwd", "kantts_bgemm_tn_grouped", "kantts_sumsq_det",
     "kantts_pnca_decode_step", "kantts_step_rows", "kantts_step_rowmask", "kantts_upsample_stream",
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
@@ -509,18 +508,15 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
 
 def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu=False, alpha1=1.0, drop1_p=0.0,
              drop1_seed=0, drop2_p=0.0, drop2_seed=0, xdrop_p=0.0, xdrop_seed=0, gate=None, rowmask1=None, rowmask2=None,
-             xrowmask=None, t_out=None, res=None, KT2=1, s2_first=0, s2_step=0, ln=None, lnb=None, y_bf16=None):
+             xrowmask=None, t_out=None, res=None, KT2=1, s2_first=0, s2_step=0, ln=None):
     """Both contractions of a feed-forward block in one launch (csrc/ffn_pair.hip; kantts_ffn_pair in the header).
     x (M, 128) bf16 / fp32; w1 / w2: FRAGMENT-MAJOR bf16 images (ops_bf16.frag_major) of the (KT*F, 128) and (128, F)
     weight matrices; y (M, 128) fp32 / bf16; t_out bf16 (M, F).  KT2 = 3 (backward form): phase 2 sums three taps of the
     intermediate, y[m] = sum_t t[m + s2_first + t*s2_step] . w2[t]^T with w2 = three (128, F) images.  Returns False when
-    the library declines the shape.
-    ``lnb`` = (x, gamma, mean, rstd, dres | None, zero_rows | None, dx, dgamma, dbeta) (backward form only): y is the output
-    gradient of a LayerNorm(128) and the launch ends in that LayerNorm's backward (kantts_ffn_pair_lnbwd); ``y`` may then be
-    an int N (= 128: the result itself is not stored) with ``y_bf16`` saying whether it is rounded to bf16 first."""
+    the library declines the shape."""
     g = FfnArgs()
     g.x, g.ldx, g.x_f32 = ptr(x), int(x.shape[-1]), int(x.dtype == torch.float32)
-    NY = y if isinstance(y, int) else int(y.shape[-1])
+    NY = int(y.shape[-1])
     g.M, g.T, g.K1, g.F, g.N, g.KT, g.pad = int(M), int(T), int(x.shape[-1]), int(F), NY, int(KT), int(pad)
     g.w1, g.w2 = ptr(w1, torch.bfloat16), ptr(w2, torch.bfloat16)
     g.bias1, g.bias2 = ptr(bias1, torch.float32), ptr(bias2, torch.float32)
@@ -532,11 +528,7 @@ def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu
     g.rowmask1, g.rowmask2, g.xrowmask = ptr(rowmask1), ptr(rowmask2), ptr(xrowmask)
     g.t_out = ptr(t_out, torch.bfloat16)
     g.res, g.ldr = ptr(res, torch.float32), NY
-    if isinstance(y, int):
-        assert lnb is not None and y_bf16 is not None
-        g.y, g.ldy, g.y_bf16 = None, NY, int(bool(y_bf16))
-    else:
-        g.y, g.ldy, g.y_bf16 = ptr(y), NY, int(y.dtype == torch.bfloat16)
+    g.y, g.ldy, g.y_bf16 = ptr(y), NY, int(y.dtype == torch.bfloat16)
     g.KT2, g.s2_first, g.s2_step = int(KT2), int(s2_first), int(s2_step)
     if ln is not None:  # (gamma, beta, eps, out (M,128), mean (M), rstd (M)): LayerNorm of the output rows in the epilogue
         gamma, beta, eps, ln_out, ln_mean, ln_rstd = ln
@@ -546,15 +538,7 @@ def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if lnb is not None:
-        lx, gamma, mean, rstd, dres, zero_rows, dx, dgamma, dbeta = lnb
-        l = LnBwdArgs()
-        l.x, l.gamma, l.mean, l.rstd = (ptr(t, torch.float32) for t in (lx, gamma, mean, rstd))
-        l.dres, l.zero_rows = ptr(dres, torch.float32), ptr(zero_rows, torch.uint8)
-        l.dx, l.dgamma_accum, l.dbeta_accum = (ptr(t, torch.float32) for t in (dx, dgamma, dbeta))
-        rc = lib().kantts_ffn_pair_lnbwd(ctypes.byref(g), ctypes.byref(l), stream())
-    else:
-        rc = lib().kantts_ffn_pair(ctypes.byref(g), stream())
+    rc = lib().kantts_ffn_pair(ctypes.byref(g), stream())
     if rc == E_UNSUPPORTED:
         return False
     check(rc, "ffn_pair")

@@ -172,9 +172,11 @@ class PreNorm:
                 and self.out_bf16 == bool(out_bf16))
 
 
-# A/B switch, OFF until measured on the device: LayerNorm BACKWARD in the epilogue of the launch that produces its output
-# gradient (kantts_bgemm_nt_lnbwd)
-LNBWD = {"on": bool(os.environ.get("KANTTS_LN_BWD_EPILOGUE"))}
+# A/B switch: LayerNorm BACKWARD in the epilogue of the launch that produces its output gradient (kantts_bgemm_nt_lnbwd: the
+# input gradient of the QKV projection of every attention sub-layer).  [round 4] first device run
+# (profiles/r04_runA_lnbwd_per_launch.log): 15.8 us against 17.4 us for the two launches at M = 6528, 11.9 against 14.7 us
+# at M = 2048 -> ON by default.  The feed-forward pair's analogue measured 35.1 us against 23.0 us and was removed.
+LNBWD = {"on": not os.environ.get("KANTTS_NO_LN_BWD_EPILOGUE")}
 
 
 class LnBwdToken:
@@ -592,35 +594,16 @@ class _FusedFFNB(torch.autograd.Function):
         if zr is not None and not (token is not None and token.delegated):
             dy = dy.masked_fill(zr.bool().view(M, 1), 0.0)
         d_res = dy.view(*ctx.lead, N)
-        if cfg.get("lnbwd_res") is not None:
-            cfg["lnbwd_res"].dres = d_res
         dev = dy.device
         # gradient at the hidden pre-activation: (dropout(dy) @ w2) gated by hid > 0 (ReLU, inner dropout, padded rows)
         dz = torch.empty((M, F), device=dev, dtype=BF16)
-        dh = None
         a1 = 1.0 / (1.0 - p_in) if p_in > 0 else 1.0
         # both input-gradient contractions in one launch (images of the TRANSPOSED weights)
         # (k = 3: the three taps are summed in phase 2 from a tile of dz with one halo row either side)
         can_pair = cfg["pair"] and kt in (1, 3) and wt1 is not None and wt2 is not None and (kt == 1 or M % T == 0)
-        tok = cfg.get("lnbwd")
-        fused = False
-        if can_pair and tok is not None and tok.ready() and ctx.h_dtype == BF16:
-            # ... ending in the backward of the LayerNorm that produced h (LnBwdToken): dh never goes through memory
-            from .ops import gzeros_like
-
-            ldx = torch.empty(tok.x.shape, device=dev, dtype=torch.float32)
-            ldg, ldb = gzeros_like(tok.gamma), gzeros_like(tok.gamma)
-            fused = ffn_pair(dy, wt2, wt1, C, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid, t_out=dz,
-                             KT2=kt, s2_first=pad, s2_step=-1, y_bf16=True,
-                             lnb=(tok.x.view(M, 128), tok.gamma, tok.mean, tok.rstd,
-                                  None if tok.dres is None else _c(tok.dres).view(M, 128), tok.zero_rows, ldx, ldg, ldb))
-            if fused:
-                tok.dx, tok.dg, tok.db, tok.placeholder = ldx, ldg, ldb, hb
-                dh = hb.view(M, C)  # stand-in for autograd: the LayerNorm node returns tok.dx and never reads this
-        if dh is None:
-            dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
-            fused = can_pair and ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid,
-                                          t_out=dz, KT2=kt, s2_first=pad, s2_step=-1)
+        dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
+        fused = can_pair and ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid,
+                                      t_out=dz, KT2=kt, s2_first=pad, s2_step=-1)
         if not fused and not bgemm_nt([(dy, N, wb2, F, N, 0)], M, F, dz, F, b_kn=True, gate=hid, ldg=F, alpha=a1,
                                       a_drop_p=p_out, a_drop_seed=s2, a_drop_ld=N):
             raise RuntimeError("bgemm_nt declined the FFN hidden gradient")
@@ -735,10 +718,6 @@ def ffn(h, w1, b1, w2, b2, res, *, pad_rows=None, zero_rows=None, p_inner=0.0, p
     cfg["token"] = token
     pre = PreNorm(ln_next) if (ln_next is not None and PRENORM["on"] and pair) else None
     cfg["ln_next"] = pre
-    if LNBWD["on"] and torch.is_grad_enabled():
-        cfg["lnbwd_res"] = getattr(res, "_kantts_lnbwd_res", None)  # the LayerNorm whose pass-through output res is
-        if pair and kt in (1, 3) and h.dtype == BF16:
-            cfg["lnbwd"] = getattr(h, "_kantts_lnbwd", None)        # ... and the one whose normalised rows h are
     wf1 = wf2 = wt2 = wt1 = None
     if pair:
         wf1, wf2, wt2, wt1 = ffn_frag_weights(w1, w2)

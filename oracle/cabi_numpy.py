@@ -357,13 +357,6 @@ class EmulatedLib:
             _wr(int(dst) + int(dst_off) * 2, img, True)
         return 0
 
-    def kantts_ffn_pair_lnbwd(self, args_ref, ln_ref, stream):
-        """The backward form of kantts_ffn_pair followed by kantts_ln128_bwd_rows on dy = its result."""
-        g = args_ref._obj
-        if not g.gate or g.KT != 1 or g.res or g.bias2 or g.ln_out or g.drop2_p > 0:
-            return -2
-        return self.kantts_ffn_pair(args_ref, stream, lnb=ln_ref._obj)
-
     def _ln128_bwd_values(self, l, M, v):
         C = 128
         DY = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
@@ -381,7 +374,7 @@ class EmulatedLib:
         _arr(l.dgamma_accum, C)[:] += (DY * xh).sum(0).numpy()
         _arr(l.dbeta_accum, C)[:] += DY.sum(0).numpy()
 
-    def kantts_ffn_pair(self, args_ref, stream, lnb=None):
+    def kantts_ffn_pair(self, args_ref, stream):
         """csrc/ffn_pair.hip: t = epi1(sum_tap x[m + tap - pad] . w1[tap]^T) rounded to bf16; y = epi2(t . w2^T)."""
         g = args_ref._obj
         M, T, K1, F, N, KT, pad = g.M, g.T, g.K1, g.F, g.N, g.KT, g.pad
@@ -453,8 +446,6 @@ class EmulatedLib:
         if g.y:
             for i in range(M):
                 _wr(int(g.y) + i * g.ldy * esz, y[i], bool(g.y_bf16))
-        if lnb is not None:
-            self._ln128_bwd_values(lnb, M, _bf16_round(y) if g.y_bf16 else y)
         if g.ln_out:  # LayerNorm(128) of the output rows in the epilogue (forward form only)
             assert kt2 == 1 and not g.gate
             X = torch.from_numpy(y.copy())

@@ -727,6 +727,67 @@ def melspec_case():
     print("melspec bytes", os.path.getsize(os.path.join(OUT, "melspec.pt")))
 
 
+def dsp_melspec_case():
+    """the reference's OWN numpy chain ``dsp.melspectrogram`` (preprocess/audio_processor/core/
+    dsp.py:165-201: _stft -> abs -> _linear_to_mel -> _amp_to_db -> - ref_level_db -> _normalize -> .T) and its OWN
+    ``AudioProcessor.mel_extract`` (audio_processor.py:317-387: per-utterance mel, corpus mean / std text files, normed
+    .npy per utterance) executed here; of librosa only ``librosa.stft`` and ``librosa.filters.mel`` run below them,
+    served by the scipy- / transformers-pinned restatements of oracle/thirdparty.py."""
+    import tempfile
+
+    import numpy as np
+    from scipy.io import wavfile
+
+    import kantts.preprocess.audio_processor.audio_processor as AP
+    import kantts.preprocess.audio_processor.core.dsp as dsp
+
+    rs = np.random.RandomState(31)
+    t = np.arange(7000) / 16000.0
+    y = (0.25 * np.sin(2 * np.pi * 180 * t) + 0.1 * np.sin(2 * np.pi * 1333 * t) + 0.03 * rs.randn(7000)).astype(np.float32)
+    cfgs = {
+        "audio_config_16k": dict(sample_rate=16000, n_fft=2048, hop_length=200, win_length=1000, n_mels=80, max_norm=1.0,
+                                 min_level_db=-100, ref_level_db=20, fmin=0.0, fmax=8000.0, symmetric=False,
+                                 preemphasize=False),
+        "defaults_24k": dict(sample_rate=24000),  # the function's own defaults: n_fft 1024, hop 256, fmin 50, fmax 8000
+        "symmetric_4": dict(sample_rate=22050, n_fft=1024, hop_length=256, win_length=1024, n_mels=80, max_norm=4.0,
+                            min_level_db=-100, ref_level_db=20, fmin=80, fmax=7600, symmetric=True, preemphasize=False),
+        "preemphasis": dict(sample_rate=16000, n_fft=1024, hop_length=160, win_length=800, n_mels=40, fmin=50, fmax=7600,
+                            preemphasize=True),
+    }
+    fix = dict(wav=y, configs=cfgs, mel={})
+    for name, kw in cfgs.items():
+        dsp._mel_basis = None  # the reference caches the basis of its FIRST call in a module global (dsp.py:143-151)
+        out = dsp.melspectrogram(y, **kw)
+        fix["mel"][name] = np.asarray(out).copy()
+        print("dsp_melspec", name, out.shape, out.dtype, float(out.mean()))
+    dsp._mel_basis = None
+
+    # AudioProcessor.mel_extract over a small 16 kHz corpus (one utterance under 0.5 s -> bad case)
+    cfg = {"sampling_rate": 16000, "hop_length": 200, "win_length": 1000, "n_mels": 80, "n_fft": 2048, "fmin": 0.0,
+           "fmax": 8000.0, "min_level_db": -100, "ref_level_db": 20, "max_norm": 1.0, "symmetric": False,
+           "preemphasize": False, "num_workers": 2}
+    pcm16 = {}
+    for i, n in enumerate([9000, 12345, 8000, 16001, 4000]):
+        tt = np.arange(n) / 16000.0
+        x = 0.3 * np.sin(2 * np.pi * (110 + 40 * i) * tt) + 0.05 * rs.randn(n)
+        pcm16["utt%02d" % i] = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "wav"))
+        for k, q in pcm16.items():
+            wavfile.write(os.path.join(d, "wav", k + ".wav"), 16000, q)
+        ap = AP.AudioProcessor(dict(cfg))
+        assert ap.mel_extract(os.path.join(d, "wav"), os.path.join(d, "mel"))
+        fix["extract"] = dict(config=cfg, pcm16=pcm16, badcases=list(ap.badcase_list),
+                              mel_dict={k: np.asarray(v).copy() for k, v in ap.mel_dict.items()},
+                              mel_mean_txt=open(os.path.join(d, "mel", "mel_mean.txt")).read(),
+                              mel_std_txt=open(os.path.join(d, "mel", "mel_std.txt")).read(),
+                              normed={k: np.load(os.path.join(d, "mel", k + ".npy")) for k in ap.mel_dict})
+    dsp._mel_basis = None
+    torch.save(fix, os.path.join(OUT, "dsp_melspec.pt"))
+    print("dsp_melspec bytes", os.path.getsize(os.path.join(OUT, "dsp_melspec.pt")), fix["extract"]["badcases"],
+          {k: (v.shape, v.dtype) for k, v in fix["extract"]["mel_dict"].items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # python oracle/make_golden.py hifigan_v1_b32_case ...: only the named cases (no arguments)
         for name in sys.argv[1:]:
@@ -755,3 +816,4 @@ if __name__ == "__main__":
     loss_variants_case()
     msd_avgpool_case()
     relu_generator_case()
+    dsp_melspec_case()

@@ -1,14 +1,15 @@
 """TEST INFRASTRUCTURE -- imports the *untouched* reference (``/root/reference``) on CPU.
 
 Only usable inside the build container (the GPU box has no ``/root/reference``).  It is used by
-``oracle/make_golden.py`` to dump golden vectors and by ``tests/test_oracle_vs_reference.py``
-(skipped when the reference is absent) to pin the restatement in ``oracle/torch_oracle.py``.
+``oracle/make_golden.py`` to dump golden vectors and by ``oracle/check_vs_reference.py`` (run by hand
+in the build container) to pin the restatements in ``oracle/torch_oracle.py`` / ``hifigan_oracle.py`` live.
 
 The reference imports six third-party packages that are not installed here.
-We install minimal ``sys.modules`` stubs for them.  Two of the stubs carry arithmetic
-(``librosa.filters.mel`` and ``pytorch_wavelets.DWT1DForward``); those are served by OUR
-restatements in ``oracle/thirdparty.py`` -- the reference never pins them, so they are "parity
-unpinned"  and are additionally covered by self-consistency KATs.
+We install minimal ``sys.modules`` stubs for them.  Three of the stubs carry arithmetic
+(``librosa.filters.mel``, ``librosa.stft`` and ``pytorch_wavelets.DWT1DForward``); those are served by OUR
+restatements in ``oracle/thirdparty.py`` of the packages' published algorithms -- the reference never pins them;
+each is pinned by an independent implementation or definition (transformers' mel filterbank, scipy.signal.stft,
+numpy.convolve + hand-computed DWT values: tests/test_independent_pins.py, tests/test_thirdparty_kat.py).
 """
 import os
 import sys
@@ -38,6 +39,7 @@ def _install_stubs():
         filters = types.ModuleType("librosa.filters")
         filters.mel = thirdparty.librosa_mel
         librosa.filters = filters
+        librosa.stft = thirdparty.librosa_stft  # kantts/preprocess/audio_processor/core/dsp.py:8-9 (scipy-pinned restatement)
         core = types.ModuleType("librosa.core")  # Voc_Dataset.__getitem__ (datasets/dataset.py:238): file IO only
         core.load = thirdparty.wav_load
         librosa.core = core
@@ -64,7 +66,9 @@ def _install_stubs():
         sys.modules["numba"] = nb
 
     # logging / plotting / audio-file IO of the trainer shell (kantts/train/trainer.py:6-11): no arithmetic behind them
-    for name in ("tensorboardX", "soundfile", "matplotlib", "matplotlib.pyplot"):
+    # "sox" / "pysptk": imported at the top of preprocess/audio_processor/core/utils.py (volume normalisation, pitch
+    # tracking); nothing on the mel-extraction path calls them
+    for name in ("tensorboardX", "soundfile", "matplotlib", "matplotlib.pyplot", "sox", "pysptk"):
         try:
             __import__(name)
         except ImportError:

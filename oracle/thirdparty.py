@@ -10,10 +10,25 @@ are restated from their published algorithms.  What pins them:
   PINNED (round 3) against an independent implementation that IS installed:
   ``transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")`` -- <= 2e-9 at every configuration the
   shipped yamls use (tests/test_independent_pins.py); self-consistency KATs in tests/test_thirdparty_kat.py.
+* ``librosa.stft`` -- librosa 0.9.2; call site kantts/preprocess/audio_processor/core/dsp.py:8-9.  ``librosa_stft`` below
+  restates the published algorithm (center=True with ZERO padding of n_fft // 2 [0.9.x default pad_mode="constant"],
+  periodic Hann window of win_length centred in n_fft, frames = 1 + len(y) // hop, float64 window x frames -> rfft ->
+  stored at the complex type matching the input: complex64 for float32 PCM).  PINNED against ``scipy.signal.stft``
+  (tests/test_independent_pins.py).  oracle/ref_harness.py serves it to the reference as ``librosa.stft`` so that the
+  reference's OWN ``dsp.melspectrogram`` / ``AudioProcessor.mel_extract`` can be run and recorded
+  (tests/golden/dsp_melspec.pt, made by oracle/make_golden.py::dsp_melspec_case).
 * ``pytorch_wavelets.DWT1DForward(wave="db3", J=1, mode="zero")`` -- unpinned git master
   (environment.yaml:64) + pywavelets 1.3.0; call site kantts/models/hifigan/hifigan.py:445-448,469-471.
-  Filter taps pinned by the closed-form Daubechies D6 coefficients (tests/test_independent_pins.py); the zero-padding /
-  decimation-phase convention is PARITY UNPINNED (orthonormality / reconstruction KATs only: no wavelet package here).
+  Filter taps pinned by the closed-form Daubechies D6 coefficients (tests/test_independent_pins.py).  Padding /
+  decimation phase: the PUBLISHED definition followed is PyWavelets' single-level ``dwt(x, 'db3', mode='zero')``
+  (pywt docs, "Signal extension modes" + ``dwt_coeff_len``): the signal is extended by zeros, fully convolved with
+  the decomposition filter and the ODD-indexed samples of the full convolution are kept:
+      cA[n] = (x * dec_lo)[2n + 1],  cD[n] = (x * dec_hi)[2n + 1],  n = 0 .. floor((N + 5) / 2) - 1,
+  i.e. cA[n] = sum_k dec_lo[k] x[2n + 1 - k] with x = 0 outside [0, N).  pytorch_wavelets' ``afb1d`` reaches the same
+  samples by padding p // 2 = 4 zeros on the left (+1 on the right for odd N) and a stride-2 cross-correlation with the
+  reversed filters.  Pinned by a KAT against ``numpy.convolve`` (independent full convolution) and hand-computed
+  values for N = 7 and N = 8 (tests/test_thirdparty_kat.py); no wavelet package is installed here, so the KAT pins
+  the restatement to the published definition, not to a run of the package.
 """
 import numpy as np
 import torch
@@ -70,6 +85,27 @@ def librosa_mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, **_unused):
     enorm = 2.0 / (mel_f[2 : n_mels + 2] - mel_f[:n_mels])
     weights *= enorm[:, np.newaxis].astype(np.float32)
     return weights
+
+
+# --------------------------------------------------------------------------- librosa.stft
+def librosa_stft(y, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, dtype=None,
+                 pad_mode="constant", **_unused):
+    """librosa 0.9.2 ``stft``: (1 + n_fft // 2, 1 + len(y) // hop) complex, complex64 for float32 input."""
+    assert window == "hann" and center and pad_mode == "constant"
+    y = np.asarray(y)
+    win_length = n_fft if win_length is None else win_length
+    hop_length = win_length // 4 if hop_length is None else hop_length
+    if dtype is None:
+        dtype = np.complex64 if y.dtype == np.float32 else np.complex128
+    n = np.arange(win_length)
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)  # scipy.signal.get_window("hann", fftbins=True)
+    left = (n_fft - win_length) // 2
+    wpad = np.zeros(n_fft)
+    wpad[left:left + win_length] = w
+    yp = np.pad(y, (n_fft // 2, n_fft // 2), mode="constant")
+    frames = 1 + (len(yp) - n_fft) // hop_length
+    idx = np.arange(n_fft)[:, None] + hop_length * np.arange(frames)[None, :]
+    return np.fft.rfft(wpad[:, None] * yp[idx], axis=0).astype(dtype)
 
 
 # --------------------------------------------------------------------------- db3 DWT

@@ -6,7 +6,7 @@ Every function cites the reference file:line it restates (paths relative to /roo
 The restatement is pinned against the untouched reference executed in the build container:
 ``oracle/make_golden.py`` dumps reference outputs to tests/golden/*.pt and
 tests/test_oracle_golden.py checks this file against them (and, when /root/reference is present,
-tests/test_oracle_vs_reference.py compares live).
+``python oracle/check_vs_reference.py`` compares live).
 
 All functions take ``P``: a dict name -> tensor holding a reference ``state_dict`` (same key names),
 so autograd through this file yields reference-equivalent parameter gradients.

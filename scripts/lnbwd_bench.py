@@ -1,7 +1,8 @@
 """LayerNorm backward as the epilogue of the launch that produces its output gradient, against the two-launch forms, per
 launch (written in round 3 without a GPU at hand: run it first thing in round 4):
   * input gradient of the QKV projection (M x 384 -> M x 128) + kantts_ln128_bwd_rows   vs   kantts_bgemm_nt_lnbwd
-  * backward form of the feed-forward pair (-> M x 128 bf16) + kantts_ln128_bwd_rows     vs   kantts_ffn_pair_lnbwd
+    (the feed-forward pair's analogue, kantts_ffn_pair_lnbwd, measured 35.1 us against 23.0 us in round 4 --
+    profiles/r04_runA_lnbwd_per_launch.log -- and was removed)
 at the decoder's M = 6528 (T = 204) and the encoder's M = 2048 (T = 64, k = 3).  Usage (GPU box): python scripts/lnbwd_bench.py"""
 import os
 import sys
@@ -45,21 +46,6 @@ def main():
         two(), one()
         print("M %5d  QKV input gradient: GEMM alone %6.2f us | + LayerNorm backward, two launches %6.2f us | one launch %6.2f us"
               % (M, timed(gemm), timed(two), timed(one)))
-
-        # ---- feed-forward sub-layer (backward form of the pair)
-        F = 1024
-        dy = torch.randn(M, 128, device=dev)
-        hid = torch.randn(M, F, device=dev).clamp(min=0).to(bf)
-        i2 = frag_major((torch.randn(128, F, device=dev) * 0.03).t().contiguous())
-        i1 = frag_major((torch.randn(KT, F, 128, device=dev) * 0.08).permute(0, 2, 1).reshape(KT * 128, F).contiguous())
-        dzh, dh = torch.empty(M, F, device=dev, dtype=bf), torch.empty(M, 128, device=dev, dtype=bf)
-        kw = dict(M=M, T=T, F=F, alpha1=1.0, gate=hid, t_out=dzh, KT2=KT, s2_first=(KT - 1) // 2, s2_step=-1)
-        pair = lambda: hip.ffn_pair(dy, i2, i1, dh, **kw)  # noqa: E731
-        two = lambda: (hip.ffn_pair(dy, i2, i1, dh, **kw), ln_bwd(dh))  # noqa: E731
-        one = lambda: hip.ffn_pair(dy, i2, i1, 128, y_bf16=True, lnb=lnb, **kw)  # noqa: E731
-        two(), one()
-        print("M %5d  feed-forward pair backward (k = %d): alone %6.2f us | + LayerNorm backward, two launches %6.2f us | one "
-              "launch %6.2f us" % (M, KT, timed(pair), timed(two), timed(one)))
 
 
 if __name__ == "__main__":

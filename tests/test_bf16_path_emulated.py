@@ -122,11 +122,11 @@ def test_conv_mode_and_ffn_bf16_emulated(bf16_mode):
                 assert a.shape == r_.shape and rel_l2(a.float(), r_.float()) < 2e-2, k1
 
 
-def test_tiny_sambert_bf16_mode_emulated_close_to_oracle(bf16_mode, monkeypatch, ln_bwd_epilogue=False):
+def test_tiny_sambert_bf16_mode_emulated_close_to_oracle(bf16_mode, monkeypatch, ln_bwd_epilogue=True):
     """The whole model through the bf16 path (shadow weights cast on demand: no arena on the CPU) stays within the bf16
     error of the oracle and produces every gradient; index outputs stay bit-exact.  ``ln_bwd_epilogue`` (run by
-    tests/test_kernel_source_on_cpu.py, where the whole case takes 2 s): with the LayerNorm backward of every pre-LN
-    sub-layer in its consumer's launch (ops_bf16.LnBwdToken, off by default)."""
+    tests/test_kernel_source_on_cpu.py, where the whole case takes 2 s): with / without the LayerNorm backward of
+    every attention sub-layer in the QKV input-gradient launch (ops_bf16.LnBwdToken, on by default)."""
     from kantts._hip import ops_bf16
     from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
 
