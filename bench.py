@@ -907,6 +907,37 @@ def main():
     else:
         dt_max, total_frames = dt, float(frames)
 
+    # ---- data-parallel runs: how much of the gradient exchange is NOT hidden behind backward.  The same captured step
+    # replayed without its collectives (weights diverge between the replicas from here on: nothing after this point reads
+    # them) -- exposed = step with the exchange - step without it, max over ranks.
+    dp_info = None
+    final_loss = float(loss.detach())
+    if distributed and mode == "graph":
+        dp_info = {"form": ("%d graph segments, one all-reduce per gradient bucket issued between the replays "
+                            "(kantts/train/segments.py)" % len(step.segments.segments)) if step.segments is not None
+                   else "two graphs: backward | bucketed all-reduce | update",
+                   "gradient_bytes": int(optimizer.arena.numel) * 4,
+                   "buckets": len(getattr(optimizer.arena, "buckets", None) or []) or optimizer.arena.n_buckets}
+        try:
+            step.skip_exchange = True
+            for _ in range(2):
+                step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt_free = time.perf_counter() - t1
+            tf = torch.tensor([dt_free], device=dev, dtype=torch.float64)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            dp_info["ms_per_step_without_exchange"] = 1e3 * float(tf[0]) / args.steps
+            dp_info["allreduce_ms_exposed"] = 1e3 * (dt_max - float(tf[0])) / args.steps
+        except Exception as exc:
+            dp_info["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+        finally:
+            step.skip_exchange = False
+
     # ---- forward pass alone, as training runs it (dropout on, activations kept for backward, predictors on their side
     # branch), replayed from its own hipGraph: SURVEY 8(d) prices the MFMA roofline on the forward pass
     # (152.3 GFLOP at batch 32: roofline.forward_mfma_frac = 152.3e9 / t_fwd / peak)
@@ -1000,10 +1031,11 @@ def main():
                        "scheduling": ("one hipGraph per step: variance predictors as a parallel branch, deferred weight "
                                       "gradients grouped by shape and issued from flush points in backward"
                                       if mode == "graph" else "eager launches, one stream"),
-                       "final_loss": float(loss.detach()), "per_rank_ms_per_step": per_rank_ms,
+                       "final_loss": final_loss, "per_rank_ms_per_step": per_rank_ms,
                        "collective_world_size": dist.get_world_size() if distributed else 1,
                        "collective_backend": (("nccl (RCCL)" if args.backend == "nccl" else "gloo") if distributed else None),
-                       "shared_device": bool(args.share_device and distributed)},
+                       "shared_device": bool(args.share_device and distributed),
+                       "data_parallel": dp_info},
             "roofline": roof,
         }
         del step, net, optimizer, model, opt

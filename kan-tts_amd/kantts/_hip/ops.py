@@ -332,6 +332,47 @@ class _SideBranch:
 side_branch = _SideBranch()
 
 
+def helper_streams():
+    """Every stream this module issues work on beside the caller's current one."""
+    return [st for st in [wgrad_overlap._stream, side_branch._stream] + list(_attn_side_stream) + list(_branch_streams)
+            if st is not None]
+
+
+def join_capturing_side_streams():
+    """Make the current (capturing) stream wait for every helper stream of this module that is part of the SAME capture.
+    A hipGraph capture can only end when all streams forked from the origin stream have been joined back; autograd joins
+    its streams at the end of backward(), so a capture that is cut IN THE MIDDLE of backward (train/segments.py: one graph
+    per gradient bucket of a data-parallel step) has to do it itself.  Streams that are not capturing are left alone:
+    waiting for an event recorded outside the capture would create a dependency across its boundary."""
+    if not torch.cuda.is_available():
+        return 0
+    main = torch.cuda.current_stream()
+    n = 0
+    for st in helper_streams():
+        if st == main:
+            continue
+        with torch.cuda.stream(st):
+            capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            main.wait_stream(st)
+            n += 1
+    return n
+
+
+def fork_helper_streams():
+    """The counterpart at the START of a capture segment: every helper stream waits for the current (capturing) stream and
+    thereby belongs to the new capture.  autograd replays a node on the stream of its forward op and synchronises that
+    stream with the producer of the node's input when the input is PRODUCED -- possibly in the segment that has just
+    ended; without this, the first backward node that runs on a helper stream after a cut would execute eagerly, outside
+    any capture."""
+    if not torch.cuda.is_available():
+        return
+    main = torch.cuda.current_stream()
+    for st in helper_streams():
+        if st != main:
+            st.wait_stream(main)
+
+
 # ================================================================================================
 # Fused linear / token-convolution
 # ================================================================================================

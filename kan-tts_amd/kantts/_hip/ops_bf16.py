@@ -200,10 +200,12 @@ class LnBwdToken:
         return self.x is not None and self.dx is None and (self.dres is not None or not self.with_res)
 
 
-# A/B switch, OFF until measured on the device: the ReLU (+ dropout) gate of a hidden activation's gradient applied by the
-# epilogue of the launch that PRODUCES that gradient (the consumer's input-gradient contraction; the kernel has had the
-# ``gate`` epilogue since round 2) instead of a separate pass over it (kantts_relu_gate_bf16)
-RELUGATE = {"on": bool(os.environ.get("KANTTS_RELU_GATE_EPILOGUE"))}
+# A/B switch: the ReLU (+ dropout) gate of a hidden activation's gradient applied by the epilogue of the launch that
+# PRODUCES that gradient (the consumer's input-gradient contraction; the kernel has had the ``gate`` epilogue since round 2)
+# instead of a separate pass over it (kantts_relu_gate_bf16).  [round 4] first device runs
+# (profiles/r04_runA_lnbwd_step_ab.log, r04_runB_step_ab.log: 40-step pairs on one box 7.386 -> 7.376, 7.404 -> 7.359 ms):
+# a small gain and 12 launches fewer per step -> ON by default; KANTTS_NO_RELU_GATE_EPILOGUE switches it off.
+RELUGATE = {"on": not os.environ.get("KANTTS_NO_RELU_GATE_EPILOGUE")}
 
 
 class ReluGateToken:

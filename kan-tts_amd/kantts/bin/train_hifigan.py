@@ -74,9 +74,11 @@ def train(model_config, root_dir, stage_dir, resume_path=None, local_rank=0, syn
                           save_dir=stage_dir, save_interval=config.get("save_interval_steps", 10 ** 9),
                           valid_interval=config.get("eval_interval_steps", 10 ** 9),
                           log_interval=config.get("log_interval_steps", 10),
-                          # ``capture_step: true`` (or KANTTS_GAN_GRAPH=1): replay the step from one hipGraph (single process)
+                          # ``capture_step: true`` (or KANTTS_GAN_GRAPH=1): replay the step from one hipGraph; data-parallel
+                          # replicas replay a chain of graph segments with the bucketed all-reduces between them
+                          # (kantts/train/segments.py)
                           graph=(bool(config.get("capture_step", os.environ.get("KANTTS_GAN_GRAPH", "") == "1"))
-                                 and not distributed and torch.device(device).type == "cuda"))
+                                 and torch.device(device).type == "cuda"))
     if resume_path is not None:
         trainer.load_checkpoint(resume_path, True, False)
         logging.info("Successfully resumed from %s.", resume_path)

@@ -11,8 +11,9 @@ branches of the graph) and replayed per step:
   * learning rates and step counts of the three optimizers live in device memory (ArenaAdam.enable_device_state);
   * nothing in the step reads a value back to the host.
 The step must have both phases active (``steps`` past both start thresholds) -- before that the eager
-``gan_train_step`` runs.  Data-parallel training keeps the eager step (its bucketed all-reduces are issued from
-autograd hooks, which a capture cannot contain).
+``gan_train_step`` runs.  Data-parallel replicas capture the step as a chain of graph segments cut where a gradient bucket
+of the generator's / a discriminator's arena is complete, with the all-reduces issued between the replays
+(kantts/train/segments.py): the step stays off the host, and a bucket's exchange runs beside the rest of its backward.
 """
 import torch
 
@@ -32,8 +33,7 @@ class GraphedGanStep:
         self.scheds = [scheduler["generator"]] + list(scheduler["discriminator"].values())
         if not all(isinstance(o, ArenaAdam) for o in self.opts):
             raise NotImplementedError("GraphedGanStep needs the arena optimizers (hifigan_model_builder on a HIP device, Adam)")
-        if any(o.arena.world_size > 1 for o in self.opts):
-            raise NotImplementedError("data-parallel GAN training runs the eager step")
+        self.distributed = any(o.arena.world_size > 1 for o in self.opts)
         if steps <= config.get("discriminator_train_start_steps", 0) or steps < config.get("generator_train_start_steps", 0):
             raise ValueError("both phases must be active in a captured GAN step")
         if getattr(model["generator"], "nsf_enable", False):
@@ -46,22 +46,45 @@ class GraphedGanStep:
             o.enable_device_state()
         # warm-up (allocator pools, lazy kernel attributes) must not train: weights, moments and counters are put back
         snaps = [o.snapshot() for o in self.opts]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        bufs = self._module_buffers()
+        buf_snap = [b.clone() for b in bufs]  # e.g. the spectral_norm power-iteration vectors of follow_official_norm
+        # one stream for warm-up and capture (AccumulateGrad nodes replay on the stream they were created on)
+        self._cap_stream = torch.cuda.Stream()
+        self._cap_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._cap_stream):
             for _ in range(warmup):
                 self._eager()
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(self._cap_stream)
         torch.cuda.synchronize()
         for o, s in zip(self.opts, snaps):
             o.restore(s)
+        with torch.no_grad():
+            for b, v in zip(bufs, buf_snap):
+                b.copy_(v)
         for o in self.opts:
             o.zero_grad(set_to_none=True)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = self._eager()
+        self.graph, self.segments = None, None
+        if self.distributed:
+            from kantts.train.segments import SegmentedCapture
+
+            self.segments = SegmentedCapture([o.arena for o in self.opts], self._cap_stream)
+            try:
+                self.out = self.segments.capture(self._eager)
+            except Exception:
+                self.segments.abort()
+                for o, s in zip(self.opts, snaps):
+                    o.restore(s)
+                raise
+        else:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local", stream=self._cap_stream):
+                self.out = self._eager()
         for o, s in zip(self.opts, snaps):
             o._step = s["step"]  # capture ran step()'s host code once without running its kernels
+
+    def _module_buffers(self):
+        mods = [self.model["generator"]] + list(self.model["discriminator"].values())
+        return [b for m in mods for b in m.buffers() if b.is_floating_point()]
 
     def _eager(self):
         return gan_train_step(self.model, self.optimizer, self._nosched, self.criterion, self.config, self.y, self.x,
@@ -73,7 +96,10 @@ class GraphedGanStep:
 
     def __call__(self):
         """One GAN step; returns the dict of (device) loss tensors of this step (overwritten by the next replay)."""
-        self.graph.replay()
+        if self.segments is not None:
+            self.segments.replay()
+        else:
+            self.graph.replay()
         for o, s in zip(self.opts, self.scheds):
             o._step += 1  # the device-side count advances inside the graph; mirror it on the host
             lr = o.param_groups[0]["lr"]

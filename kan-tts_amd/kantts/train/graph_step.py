@@ -7,8 +7,14 @@ Here forward + losses + backward + gradient packing + clip + Adam are captured O
   * band width, dropout offset, lr and step count live in device memory (no value is frozen into the
     captured kernel arguments that must change between steps);
   * inputs are static device buffers (`load_batch` copies a new batch of the same shape in place);
-  * the data-parallel all-reduce is issued between graph replays of the two halves when
-    world_size > 1 (RCCL calls are not captured).
+  * data-parallel (world_size > 1): RCCL calls are not captured.  The step is captured as a CHAIN OF GRAPH SEGMENTS cut
+    inside backward where a gradient bucket becomes complete (the arena's post-accumulate hooks, the same partition the
+    eager path uses): segment 0 = forward + backward down to the last bucket (+ its packing), segment k = backward down
+    to the next bucket, last segment = average + clip + Adam.  The host replays segment k, issues the asynchronous
+    all-reduce of the bucket it packed (it waits for the segment on the collective's own stream) and replays segment
+    k + 1 at once -- the exchange of bucket k runs beside the backward of the earlier layers, which is what the
+    reference gets from DDP's hooks (kantts/models/__init__.py:71-84,118-121).  KANTTS_DP_SEGMENTS=0 (or any failure of
+    the segmented capture) selects the two-graph form: backward | bucketed all-reduce | update, nothing overlapped.
 """
 import os
 
@@ -58,35 +64,72 @@ class GraphedSambertStep:
         # optimizer update (the first replay), like the eager path and the reference
         snap = optimizer.snapshot()
         rng_snap = _rng_state(self.device).clone() if self.device.type == "cuda" else None
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        # ONE stream for the warm-up and for the capture: autograd replays a parameter's AccumulateGrad node on the stream
+        # that was current when the node was created, and nodes created during the warm-up are still alive at capture
+        # time (the loss tensor holds the graph).  With a different warm-up stream every gradient accumulation of the
+        # captured step sat on a foreign stream, forked from and joined back into the capture (autograd's "AccumulateGrad
+        # node's stream does not match" warning) -- and a capture cut in the middle of backward could not end.
+        pr = os.environ.get("KANTTS_MAIN_PRIORITY")  # experiment switch: priority of the capture (critical-path) stream
+        self._cap_stream = torch.cuda.Stream(priority=int(pr)) if pr else torch.cuda.Stream()
+        self._cap_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._cap_stream):
             for _ in range(warmup):
                 self._eager_step()
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(self._cap_stream)
         torch.cuda.synchronize()
+        self.loss = None
         optimizer.restore(snap)
         if rng_snap is not None:
             _rng_state(self.device).copy_(rng_snap)
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
+        self.segments = None
+        self.skip_exchange = False  # measurement only (bench.py: exposed all-reduce time = step with - step without)
         optimizer.zero_grad(set_to_none=True)
-        if not self.distributed:
-            pr = os.environ.get("KANTTS_MAIN_PRIORITY")  # experiment switch: priority of the capture (critical-path) stream
-            kw = {"stream": torch.cuda.Stream(priority=int(pr))} if pr else {}
-            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local", **kw):
+        if self.distributed and os.environ.get("KANTTS_DP_SEGMENTS", "1") != "0":
+            try:
+                self._capture_segments()
+            except Exception as exc:  # the two-graph form below is the proven fallback
+                import sys
+
+                print("[GraphedSambertStep] segmented data-parallel capture failed (%s: %s); capturing the two-graph form"
+                      % (type(exc).__name__, str(exc)[:300]), file=sys.stderr)
+                self._abort_capture()
+                self.segments = None
+                optimizer.restore(snap)
+                if rng_snap is not None:
+                    _rng_state(self.device).copy_(rng_snap)
+                optimizer.zero_grad(set_to_none=True)
+        if self.segments is not None:
+            pass
+        elif not self.distributed:
+            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local", stream=self._cap_stream):
                 self._forward_backward()
                 self._apply()
         else:
             # thread_local: the RCCL watchdog thread polls events while this thread captures
-            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local", stream=self._cap_stream):
                 self._forward_backward()
                 ops.wgrad_overlap.join()
                 optimizer.arena.pack_grads()
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local",
+                                  stream=self._cap_stream):
                 self._apply(packed=True)
         optimizer._step = snap["step"]  # capturing ran step()'s host code once without running its kernels
+
+    # ---- data-parallel: one graph per gradient bucket (train/segments.py) -----------------------------------------
+    def _capture_segments(self):
+        from kantts.train.segments import SegmentedCapture
+
+        self._seg = SegmentedCapture([self.optimizer.arena], self._cap_stream)
+        self._seg.capture(lambda: (self._forward_backward(), self._apply()))
+        self.segments = self._seg
+
+    def _abort_capture(self):
+        if getattr(self, "_seg", None) is not None:
+            self._seg.abort()
+            self._seg = None
 
     def _forward_backward(self):
         b = self.batch
@@ -113,10 +156,15 @@ class GraphedSambertStep:
 
     def __call__(self):
         """One training step; returns the (device) loss tensor of this step."""
-        self.graph_a.replay()
-        if self.graph_b is not None:
-            self.optimizer.arena.all_reduce_grads()
-            self.graph_b.replay()
+        if self.segments is not None:
+            self.segments.skip_exchange = self.skip_exchange
+            self.segments.replay()
+        else:
+            self.graph_a.replay()
+            if self.graph_b is not None:
+                if not self.skip_exchange:
+                    self.optimizer.arena.all_reduce_grads()
+                self.graph_b.replay()
         self.optimizer._step += 1  # the device-side count advances inside the graph; mirror it on the host
         self.scheduler.step()
         self.optimizer.sync_lr()

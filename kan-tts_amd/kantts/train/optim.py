@@ -43,6 +43,8 @@ class ParamArena:
         self.grad_views = [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
         self._zero_cache = {}
         self.world_size = 1
+        self.bucket_ready = None  # set while a data-parallel step is being captured in segments (train/graph_step.py)
+        self.capture_stream = None
         self.n_buckets = 4
         self.flat_bf16 = None
         if bf16_shadow:
@@ -191,8 +193,10 @@ class ParamArena:
             not self.buckets or (self.buckets[0]["lo"] == 0 and self.buckets[-1]["hi"] == n))
         assert all(0 <= self.bucket_of[i] < len(self.buckets) for i in range(len(self.params)))
         self._active = False
-        for i, p in enumerate(self.params):
-            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+        if not getattr(self, "_hooked", False):
+            for i, p in enumerate(self.params):
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+            self._hooked = True
 
     def begin_step(self):
         """Arm the bucket counters for one backward pass (ArenaAdam.zero_grad calls this).  An un-armed arena ignores
@@ -213,6 +217,17 @@ class ParamArena:
             self._launch_bucket(b)
 
     def _launch_bucket(self, b):
+        cap = self.capture_stream
+        if cap is not None and torch.cuda.current_stream() != cap:
+            # segmented capture: the hook may run with a foreign current stream (an AccumulateGrad node created before
+            # the capture stream existed); pack and cut on the capture stream, after whatever that stream captured
+            if torch.cuda.is_current_stream_capturing():
+                cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                return self._launch_bucket_on_current_stream(b)
+        return self._launch_bucket_on_current_stream(b)
+
+    def _launch_bucket_on_current_stream(self, b):
         ops.wgrad_overlap.join()  # weight gradients produced on the side stream must have landed before they are packed
         dst, src = [], []
         for i in b["params"]:
@@ -225,7 +240,17 @@ class ParamArena:
                 src.append(g)
         if dst:
             torch._foreach_copy_(dst, src)
-        b["handle"] = dist.all_reduce(self.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, async_op=True)
+        if self.bucket_ready is not None:
+            # hipGraph capture of a data-parallel step (GraphedSambertStep): the exchange is issued by the host between
+            # the replays of two graph segments -- the segment that ends here has just packed this bucket
+            b["handle"] = "captured"
+            self.bucket_ready(b)
+            return
+        b["handle"] = self.exchange(b)
+
+    def exchange(self, b):
+        """Asynchronous all-reduce (sum) of one bucket's range of the gradient arena; returns the work handle."""
+        return dist.all_reduce(self.grad[b["lo"]:b["hi"]], op=dist.ReduceOp.SUM, async_op=True)
 
     def finish_reduce(self):
         """Issue whatever was not triggered during backward (parameters without a gradient this step), wait for every
@@ -234,7 +259,8 @@ class ParamArena:
             if b["handle"] is None:
                 self._launch_bucket(b)
         for b in self.buckets:
-            b["handle"].wait()
+            if self.bucket_ready is None:  # (captured step: train/segments.py waits between the replays)
+                b["handle"].wait()
             b["handle"] = None
         self._active = False
         self.grad.mul_(1.0 / self.world_size)

@@ -310,6 +310,7 @@ class GAN_Trainer(Trainer):
     def train_step(self, batch):
         y, x = batch
         y, x = y.to(self.device, non_blocking=True), x.to(self.device, non_blocking=True)
+        g = None
         if self._graph_ready():
             from kantts.train.gan_graph_step import GraphedGanStep
 
@@ -318,10 +319,19 @@ class GAN_Trainer(Trainer):
             if g is None:
                 if len(self._graphs) >= 4:
                     self._graphs.pop(next(iter(self._graphs)))
-                g = self._graphs[key] = GraphedGanStep(self.model, self.optimizer, self.scheduler, self.criterion,
-                                                       self.config, y, x, steps=self.steps)
+                try:
+                    g = self._graphs[key] = GraphedGanStep(self.model, self.optimizer, self.scheduler, self.criterion,
+                                                           self.config, y, x, steps=self.steps)
+                except (NotImplementedError, ValueError) as exc:
+                    # NSF generators (host-seeded excitation), non-arena optimizers: the step cannot be captured.
+                    # Say so once and keep training with the eager step (the run must not die thousands of steps in,
+                    # when both phases first become active).
+                    logging.warning("[GAN_Trainer] capture_step is off for this run: %s", exc)
+                    self.graph = False
+                    g = None
             else:
                 g.load_batch(y, x)
+        if g is not None:
             losses = g()
         else:
             losses = gan_train_step(self.model, self.optimizer, self.scheduler, self.criterion, self.config, y, x,

@@ -234,9 +234,12 @@ def test_two_rank_gan_step_with_arena_reducers_keeps_replicas_identical(tmp_path
 
 # ------------------------------------------------------------------------------------------------------------------
 # The captured data-parallel step on hardware: two processes share the one GPU of the test box and exchange the gradient
-# arena over gloo (RCCL needs one device per rank), so graph_a -> bucketed all-reduce -> graph_b of GraphedSambertStep runs
-# with real hipGraphs and a real process group before the first multi-GPU launch.
-def _graph_worker(rank, world, port, out_dir):
+# arena over gloo (RCCL needs one device per rank), so both captured forms of GraphedSambertStep -- the chain of graph
+# segments cut at the gradient buckets with the all-reduces issued between the replays (kantts/train/segments.py), and the
+# two-graph form graph_a -> bucketed all-reduce -> graph_b -- run with real hipGraphs and a real process group before the
+# first multi-GPU launch.
+def _graph_worker(rank, world, port, out_dir, form="segments"):
+    os.environ["KANTTS_DP_SEGMENTS"] = "1" if form == "segments" else "0"
     for p in (os.path.join(ROOT, "kan-tts_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -273,7 +276,9 @@ def _graph_worker(rank, world, port, out_dir):
             step.load_batch({k: v.cuda() for k, v in nb.items()})
         losses.append(float(step()))
     torch.cuda.synchronize()
-    torch.save({"flat": optimizer.arena.flat.cpu(), "losses": losses, "step": optimizer._step},
+    nseg = len(step.segments.segments) if step.segments is not None else 0
+    torch.save({"flat": optimizer.arena.flat.cpu(), "losses": losses, "step": optimizer._step, "segments": nseg,
+                "buckets": len(getattr(optimizer.arena, "buckets", []) or [])},
                os.path.join(out_dir, "graph_rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -283,15 +288,107 @@ import pytest  # noqa: E402
 
 @pytest.mark.gpu
 def test_two_process_graphed_step_on_one_gpu(tmp_path):
-    port = _free_port()
-    mp.spawn(_graph_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(os.path.join(tmp_path, "graph_rank0.pt"))
-    r1 = torch.load(os.path.join(tmp_path, "graph_rank1.pt"))
-    if "unsupported" in r0:
-        pytest.skip("gloo cannot reduce device tensors here: " + r0["unsupported"][:200])
-    assert torch.equal(r0["flat"], r1["flat"])  # replicas identical after three captured DP steps
-    assert r0["step"] == r1["step"] == 3
-    assert r0["losses"] != r1["losses"] and all(v == v for v in r0["losses"] + r1["losses"])
+    """Both captured data-parallel forms: replicas bit-identical after three steps, and the segmented form (exchange of
+    a bucket between the replays of two backward segments) equal to the two-graph form (exchange after the whole
+    backward).  The all-reduce of two ranks is one addition per element whatever the partition, so the exchange itself
+    adds no difference; the two RUNS differ by the summation order of the split-token weight-gradient atomics (two runs
+    of ONE form differ by as much), hence a 1e-5 relative bound and not torch.equal across runs."""
+    res = {}
+    for form in ("segments", "two_graph"):
+        d = tmp_path / form
+        os.makedirs(d)
+        mp.spawn(_graph_worker, args=(2, _free_port(), str(d), form), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "graph_rank0.pt"))
+        r1 = torch.load(os.path.join(d, "graph_rank1.pt"))
+        if "unsupported" in r0:
+            pytest.skip("gloo cannot reduce device tensors here: " + r0["unsupported"][:200])
+        assert torch.equal(r0["flat"], r1["flat"]), form  # replicas identical after three captured DP steps
+        assert r0["step"] == r1["step"] == 3
+        assert r0["losses"] != r1["losses"] and all(v == v for v in r0["losses"] + r1["losses"])
+        res[form] = r0
+    assert res["two_graph"]["segments"] == 0
+    # the segmented capture really was what ran (it falls back to the two-graph form on any capture error)
+    assert res["segments"]["segments"] == res["segments"]["buckets"] + 1 and res["segments"]["buckets"] >= 2, (
+        res["segments"]["segments"], res["segments"]["buckets"])
+    a, b = res["segments"]["flat"].double(), res["two_graph"]["flat"].double()
+    err = float((a - b).norm() / b.norm())
+    print("segmented vs two-graph form after 3 steps: weights rel %.2e, losses %s | %s" % (
+        err, res["segments"]["losses"], res["two_graph"]["losses"]))
+    assert err < 1e-5, err
+    for x, y in zip(res["segments"]["losses"], res["two_graph"]["losses"]):
+        assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), (x, y)
+
+
+def _gan_graph_worker(rank, world, port, out_dir, captured):
+    for p in (os.path.join(ROOT, "kan-tts_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import kantts._hip as hip
+    from kantts.models import hifigan_model_builder
+    from kantts.train.gan_graph_step import GraphedGanStep
+    from kantts.train.gan_step import gan_train_step
+    from kantts.train.loss import criterion_builder
+
+    torch.cuda.set_device(0)
+    hip.set_precision("fp32")
+    try:
+        probe = torch.ones(4, device="cuda")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    except Exception as exc:
+        torch.save({"unsupported": repr(exc)}, os.path.join(out_dir, "gan_graph_rank%d.pt" % rank))
+        dist.destroy_process_group()
+        return
+    config = _gan_config()
+    torch.manual_seed(7 + rank)
+    model, optimizer, scheduler = hifigan_model_builder(config, "cuda", 0, True)
+    crit = criterion_builder(config, device="cuda")
+    y, x = (t.cuda() for t in _gan_batch(100 * rank))
+    y, x = y.repeat(2, 1, 1), x.repeat(2, 1, 1)
+    nseg, losses = 0, []
+    if captured:
+        step = GraphedGanStep(model, optimizer, scheduler, crit, config, y, x, steps=5)
+        nseg = len(step.segments.segments)
+    for it in range(3):
+        yb, xb = (t.cuda() for t in _gan_batch(100 * rank + it))
+        yb, xb = yb.repeat(2, 1, 1), xb.repeat(2, 1, 1)
+        if captured:
+            step.load_batch(yb, xb)
+            out = step()
+        else:
+            out = gan_train_step(model, optimizer, scheduler, crit, config, yb, xb, steps=5)
+        losses.append({k: float(v.detach()) for k, v in out.items()})
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for net in (model["generator"], *model["discriminator"].values())
+                      for p in net.parameters()]).cpu()
+    nb = sum(len(o.arena.buckets) for o in [optimizer["generator"], *optimizer["discriminator"].values()])
+    torch.save(dict(flat=flat, losses=losses, segments=nseg, buckets=nb), os.path.join(out_dir, "gan_graph_rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_process_graphed_gan_step_on_one_gpu(tmp_path):
+    """GraphedGanStep under data parallelism (three arenas cutting one chain of graph segments) against the eager
+    data-parallel step on the same seeds: replicas identical, same losses, same weights after three steps."""
+    res = {}
+    for captured in (True, False):
+        d = tmp_path / ("captured" if captured else "eager")
+        os.makedirs(d)
+        mp.spawn(_gan_graph_worker, args=(2, _free_port(), str(d), captured), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "gan_graph_rank0.pt"))
+        r1 = torch.load(os.path.join(d, "gan_graph_rank1.pt"))
+        if "unsupported" in r0:
+            pytest.skip("gloo cannot reduce device tensors here: " + r0["unsupported"][:200])
+        assert torch.equal(r0["flat"], r1["flat"]), captured
+        res[captured] = r0
+    assert res[True]["segments"] == res[True]["buckets"] + 1
+    for a, b in zip(res[True]["losses"], res[False]["losses"]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    err = float((res[True]["flat"] - res[False]["flat"]).norm() / res[False]["flat"].norm())
+    assert err < 1e-5, err
 
 
 def test_gradient_buckets_partition_the_arena():

@@ -422,7 +422,7 @@ def test_layernorm_backward_in_the_consumers_input_gradient_launch(emulated_cabi
 
 
 def test_relu_gate_of_a_hidden_gradient_in_its_producers_epilogue(emulated_cabi, monkeypatch):
-    """ops_bf16.ReluGateToken (KANTTS_RELU_GATE_EPILOGUE, off by default): the gradient of the bf16 hidden activation of an
+    """ops_bf16.ReluGateToken (on by default since round 4; KANTTS_NO_RELU_GATE_EPILOGUE switches it off): the gradient of the bf16 hidden activation of an
     FSMN feed-forward net is gated (ReLU, dropout) and scaled by the epilogue of the launch that computes it -- the second
     contraction's input gradient -- instead of a kantts_relu_gate_bf16 pass over it.  Same gradients up to the one bf16
     rounding the pass-through saved; the passes are gone; a second consumer of the hidden activation is refused."""

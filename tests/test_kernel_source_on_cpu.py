@@ -333,12 +333,12 @@ _FULL_CONFIG_BOUNDS = {  # the bounds of tests/test_bench_config_parity.py (devi
 }
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-no_ln_bwd_epilogue", "bf16-relu_gate_epilogue"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16-no_ln_bwd_epilogue", "bf16-no_relu_gate_epilogue"])
 def test_full_sambert_configuration_matches_oracle_on_the_kernel_source(mode, monkeypatch):
     """BASELINE config 2's model (sambert_16k.yaml zhcn: 8 + 12 blocks of width 128 / 1024, FSMN + LSTM postnet) forward,
     losses and every parameter gradient against oracle/torch_oracle.py -- tests/test_bench_config_parity.py with host
     tensors at B = 2 x T_in = 12 and the same bounds; the last cases without the LayerNorm-backward epilogue of the QKV
-    input gradient (on by default) and with the opt-in ReLU-gate hand-over."""
+    input gradient (on by default) and without the ReLU-gate hand-over (both on by default)."""
     import torch
 
     import kantts._hip as hip
@@ -349,7 +349,7 @@ def test_full_sambert_configuration_matches_oracle_on_the_kernel_source(mode, mo
 
     prec = mode.split("-")[0]
     monkeypatch.setitem(ops_bf16.LNBWD, "on", "no_ln_bwd_epilogue" not in mode)
-    monkeypatch.setitem(ops_bf16.RELUGATE, "on", "relu_gate_epilogue" in mode)
+    monkeypatch.setitem(ops_bf16.RELUGATE, "on", "no_relu_gate_epilogue" not in mode)
     cfg = O.sambert_config(tiny=False)
     cfg = {k: (0.0 if "dropout" in k else v) for k, v in cfg.items()}
     torch.manual_seed(0)
