@@ -299,6 +299,20 @@ int kantts_weight_norm_strided_bwd(const float* dw, const float* v, const float*
 int kantts_weight_norm_tap_images(const float* v, const float* g, float* w, void* wf_bf16, void* wd_bf16, int rows, int cin,
                                   int K, int groups, void* stream);
 
+/* The same for EVERY weight-normed convolution of a network in ONE launch (the network's parameters live in one flat
+ * fp32 arena; images are rebuilt once per optimizer step, not once per layer and forward pass).  Table entry (device
+ * memory): v at flat + v_off (rows, cin, K), g at flat + g_off (rows); outputs at w + w_off (K, rows, cin) fp32,
+ * wf_bf16 + wf_off (K, rows, cin) and wd_bf16 + wd_off (K, groups, cin, rows / groups) -- wf_off / wd_off < 0: that layer
+ * has no bf16 images; row0 = number of 8-row TILES, ceil(rows / 8) each, of all earlier entries (the launch has one
+ * workgroup per tile; entries are found by bisection over row0); total_tiles = their sum.  Offsets of the bf16 images must
+ * be multiples of 8 elements.  kantts/models/hifigan/layers.py:29,67, hifigan.py:224,332. */
+typedef struct kantts_wn_desc {
+  int64_t v_off, g_off, w_off, wf_off, wd_off;
+  int32_t rows, cin, K, groups, row0, pad_;
+} kantts_wn_desc;
+int kantts_weight_norm_table(const float* flat, float* w, void* wf_bf16, void* wd_bf16, const kantts_wn_desc* table_dev,
+                             int ndesc, int total_tiles, void* stream);
+
 /* y = sin(x) + x and its backward dx = dy * (cos(x) + 1)  (kantts/models/hifigan/hifigan.py:157) */
 int kantts_sinadd_fwd(const float* x, float* y, long long n, void* stream);
 int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, long long n, void* stream);

@@ -246,24 +246,16 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_dgrad_mfma_kernel(const ka
 }
 
 template <int H>  // Cout <= 64 * H (a multiple of 4)
-__global__ __launch_bounds__(C1_THREADS) void conv_c1_wgrad_mfma_kernel(const kantts_conv_c1_args g) {
+__global__ __launch_bounds__(C1_THREADS) void conv_c1_wgrad_mfma_kernel(const kantts_conv_c1_args g, const int total_runs) {
+  // [round 4] PERSISTENT over runs: a workgroup walks runs blockIdx.x, blockIdx.x + gridDim.x, ... with its accumulators in
+  // registers and reduces (LDS atomics, then (K + 1) * Cout global atomics) ONCE.  One workgroup per run -- 2048 of them
+  // for the first MSD layer at batch 64 x 8192 -- put 4.2 M fp32 atomics on 2048 addresses: 511 us per launch, atomics-bound
+  // (profiles/r03_runFINAL_bench_kernel_stats_top.csv).
   extern __shared__ __attribute__((aligned(16))) float c1_lds[];
   const int runs = (g.Tdst + C1_QB - 1) / C1_QB;
-  const int run = blockIdx.x % runs;
-  const int bp = blockIdx.x / runs;
-  const int b = bp / g.inner, p = bp % g.inner;
-  const int q0 = run * C1_QB;
-  const int nq = min(C1_QB, g.Tdst - q0);
-  const int W = (nq - 1) * g.stride + (g.K - 1) * g.dil + 1;
   float* xs = c1_lds;
   float* red = c1_lds + ((C1_QB - 1) * g.stride + (g.K - 1) * g.dil + 1 + 3) / 4 * 4;  // [(K+1)][Cout]
-  const int lo = q0 * g.stride - g.pad;
-  for (int i = threadIdx.x; i < W; i += C1_THREADS) {
-    const int t = lo + i;
-    xs[i] = (t >= 0 && t < g.Tsrc) ? g.x[((long long)b * g.Tsrc + t) * g.inner + p] : 0.f;
-  }
   for (int i = threadIdx.x; i < (g.K + 1) * g.Cout; i += C1_THREADS) red[i] = 0.f;
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kg = lane >> 4;
   f32x4 acc[H][4];
@@ -275,30 +267,45 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_wgrad_mfma_kernel(const ka
       acc[h][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
       bs[h][m] = 0.f;
     }
-  for (int tg = wave; tg * 4 < nq; tg += C1_THREADS / 64) {
-    const int q = tg * 4 + kg;
-    const bool ok = q < nq;
-    const float bx = (ok && li < g.K) ? xs[q * g.stride + li * g.dil] : 0.f;  // B[k = token kg][j = tap li]
-    const long long row = (((long long)b * g.Tdst + q0 + (ok ? q : 0)) * g.inner + p) * g.Cout;
+  for (int blk = blockIdx.x; blk < total_runs; blk += gridDim.x) {
+    const int run = blk % runs;
+    const int bp = blk / runs;
+    const int b = bp / g.inner, p = bp % g.inner;
+    const int q0 = run * C1_QB;
+    const int nq = min(C1_QB, g.Tdst - q0);
+    const int W = (nq - 1) * g.stride + (g.K - 1) * g.dil + 1;
+    const int lo = q0 * g.stride - g.pad;
+    __syncthreads();  // the previous run's readers of xs are done (first pass: red is zeroed)
+    for (int i = threadIdx.x; i < W; i += C1_THREADS) {
+      const int t = lo + i;
+      xs[i] = (t >= 0 && t < g.Tsrc) ? g.x[((long long)b * g.Tsrc + t) * g.inner + p] : 0.f;
+    }
+    __syncthreads();
+    for (int tg = wave; tg * 4 < nq; tg += C1_THREADS / 64) {
+      const int q = tg * 4 + kg;
+      const bool ok = q < nq;
+      const float bx = (ok && li < g.K) ? xs[q * g.stride + li * g.dil] : 0.f;  // B[k = token kg][j = tap li]
+      const long long row = (((long long)b * g.Tdst + q0 + (ok ? q : 0)) * g.inner + p) * g.Cout;
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const int n = 64 * h + 4 * li;
-      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok && n < g.Cout) {
-        d = *reinterpret_cast<const float4*>(g.y + row + n);
-        if (g.gate) {
-          const float4 y = *reinterpret_cast<const float4*>(g.gate + row + n);
-          d.x = c1_gate(d.x, y.x, g.gate_slope);
-          d.y = c1_gate(d.y, y.y, g.gate_slope);
-          d.z = c1_gate(d.z, y.z, g.gate_slope);
-          d.w = c1_gate(d.w, y.w, g.gate_slope);
+      for (int h = 0; h < H; ++h) {
+        const int n = 64 * h + 4 * li;
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && n < g.Cout) {
+          d = *reinterpret_cast<const float4*>(g.y + row + n);
+          if (g.gate) {
+            const float4 y = *reinterpret_cast<const float4*>(g.gate + row + n);
+            d.x = c1_gate(d.x, y.x, g.gate_slope);
+            d.y = c1_gate(d.y, y.y, g.gate_slope);
+            d.z = c1_gate(d.z, y.z, g.gate_slope);
+            d.w = c1_gate(d.w, y.w, g.gate_slope);
+          }
         }
+        bs[h][0] += d.x; bs[h][1] += d.y; bs[h][2] += d.z; bs[h][3] += d.w;
+        acc[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.x, bx, acc[h][0], 0, 0, 0);
+        acc[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.y, bx, acc[h][1], 0, 0, 0);
+        acc[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.z, bx, acc[h][2], 0, 0, 0);
+        acc[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.w, bx, acc[h][3], 0, 0, 0);
       }
-      bs[h][0] += d.x; bs[h][1] += d.y; bs[h][2] += d.z; bs[h][3] += d.w;
-      acc[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.x, bx, acc[h][0], 0, 0, 0);
-      acc[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.y, bx, acc[h][1], 0, 0, 0);
-      acc[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.z, bx, acc[h][2], 0, 0, 0);
-      acc[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.w, bx, acc[h][3], 0, 0, 0);
     }
   }
   // accumulator (h, m), register r, lane (li, kg): channel 64h + 4*(kg*4 + r) + m, tap li
@@ -352,10 +359,14 @@ extern "C" int kantts_conv_c1_launch(const kantts_conv_c1_args* a, int mode, voi
     else
       hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
   } else {
+    // persistent grid: at most C1_WGRAD_WGS workgroups (two per CU), each reducing once
+    const char* wgs_env = getenv("KANTTS_C1_WGRAD_WGS");  // experiment / test switch (read per launch: tests change it)
+    const long long cap = (wgs_env && atoll(wgs_env) > 0) ? atoll(wgs_env) : 512;
+    const unsigned pgrid = (unsigned)(blocks < cap ? blocks : cap);
     if (vec && g.Cout <= 64)
-      hipLaunchKernelGGL((conv_c1_wgrad_mfma_kernel<1>), dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
+      hipLaunchKernelGGL((conv_c1_wgrad_mfma_kernel<1>), dim3(pgrid), dim3(C1_THREADS), lds, st, g, (int)blocks);
     else if (vec && g.Cout <= 128)
-      hipLaunchKernelGGL((conv_c1_wgrad_mfma_kernel<2>), dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
+      hipLaunchKernelGGL((conv_c1_wgrad_mfma_kernel<2>), dim3(pgrid), dim3(C1_THREADS), lds, st, g, (int)blocks);
     else
       hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
   }

@@ -97,6 +97,75 @@ extern "C" int kantts_weight_norm_tap_images(const float* v, const float* g, flo
   KANTTS_CHECK_LAUNCH();
 }
 
+// Every weight-normed convolution of a network in one launch: a workgroup per tile of WN_R consecutive output rows of a
+// layer, the layer found by bisection over the table's row0 (= tiles before the entry; uniform across the workgroup).
+// Per row the same arithmetic and summation order as weight_norm_tap_images_kernel.  WN_R rows at a time so that the
+// input-gradient image wd (K, groups, cin, rows / groups) -- rows fastest -- is written in 16-byte pieces: one row per
+// workgroup put every 2-byte element of it on a cache line of its own (first version: 351 us per launch at 1.4 TB/s of
+// useful traffic, profiles/r04_runC_gan_kernel_stats_top.csv).
+#define WN_R 8
+typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void weight_norm_table_kernel(const float* __restrict__ flat, float* __restrict__ w,
+                                                               __bf16* __restrict__ wf, __bf16* __restrict__ wd,
+                                                               const kantts_wn_desc* __restrict__ tab, int ndesc) {
+  __shared__ float red[4];
+  __shared__ float scs[WN_R];
+  const int tile = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].row0 <= tile)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const kantts_wn_desc d = tab[lo];
+  const int cin = d.cin, K = d.K, rows = d.rows, cols = cin * K;
+  const int r0 = (tile - d.row0) * WN_R, nr = min(WN_R, rows - r0);
+  const float* v0 = flat + d.v_off + (long long)r0 * cols;
+  for (int i = 0; i < nr; ++i) {
+    const float* vr = v0 + (long long)i * cols;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += vr[c] * vr[c];
+    s = kantts_block_sum(s, red);
+    if (threadIdx.x == 0) scs[i] = flat[d.g_off + r0 + i] / sqrtf(s);
+    __syncthreads();
+  }
+  const int rg = rows / d.groups;
+  float* wo = w + d.w_off;
+  __bf16* wfo = d.wf_off >= 0 ? wf + d.wf_off : nullptr;
+  __bf16* wdo = d.wd_off >= 0 ? wd + d.wd_off : nullptr;
+  // (a tile never straddles a group when there are bf16 images: rows / groups is a multiple of 8 then)
+  const int grp = r0 / rg, rl0 = r0 - grp * rg;
+  const bool vec = wdo && nr == WN_R && ((rg & 7) == 0);
+  for (int j = threadIdx.x; j < cols; j += 256) {  // ci fastest: coalesced on the tap-major side
+    const int k = j / cin, ci = j - k * cin;
+    wn_bf16x8 pk;
+#pragma unroll
+    for (int i = 0; i < WN_R; ++i) {
+      float val = 0.f;
+      if (i < nr) {
+        val = v0[(long long)i * cols + ci * K + k] * scs[i];
+        const long long o = ((long long)k * rows + r0 + i) * cin + ci;
+        wo[o] = val;
+        if (wfo) wfo[o] = (__bf16)val;
+        if (wdo && !vec) wdo[(((long long)k * d.groups + (r0 + i) / rg) * cin + ci) * rg + (r0 + i) % rg] = (__bf16)val;
+      }
+      pk[i] = (__bf16)val;
+    }
+    if (vec) *reinterpret_cast<wn_bf16x8*>(wdo + (((long long)k * d.groups + grp) * cin + ci) * rg + rl0) = pk;
+  }
+}
+
+extern "C" int kantts_weight_norm_table(const float* flat, float* w, void* wf_bf16, void* wd_bf16,
+                                        const kantts_wn_desc* table_dev, int ndesc, int total_tiles, void* stream) {
+  if (!flat || !w || !table_dev || ndesc < 0 || total_tiles < 0) return KANTTS_E_BADARG;
+  if (ndesc == 0 || total_tiles == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(weight_norm_table_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, flat, w,
+                     reinterpret_cast<__bf16*>(wf_bf16), reinterpret_cast<__bf16*>(wd_bf16), table_dev, ndesc);
+  KANTTS_CHECK_LAUNCH();
+}
+
 __global__ __launch_bounds__(256) void weight_norm_strided_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
                                                                      const float* __restrict__ g, float* __restrict__ dv,
                                                                      float* __restrict__ dg, int cin, int K, long long rs,

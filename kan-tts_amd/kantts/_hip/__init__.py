@@ -270,6 +270,7 @@ def lib():
         L.kantts_act_cast_bf16.argtypes = [p, p, i, p, i, f, ll, p]
         L.kantts_ragged_rows_f32.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
         L.kantts_weight_norm_tap_images.argtypes = [p, p, p, p, p, i, i, i, i, p]
+        L.kantts_weight_norm_table.argtypes = [p, p, p, p, p, i, i, p]
         L.kantts_ragged_rows_i64.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
         _lib = L
     return _lib
@@ -289,6 +290,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
+    "kantts_weight_norm_table",
 ]
 
 

@@ -1936,7 +1936,46 @@ class _WeightNormTap(torch.autograd.Function):
         return dv, dg, None
 
 
+class _WeightNormImage(torch.autograd.Function):
+    """The tap-major weight-normed weight of one layer, ALREADY computed for the whole network by the arena's table-driven
+    launch (ParamArena.build_weight_norm_images / kantts_weight_norm_table): forward hands out an alias of the layer's
+    slice of that buffer, backward is the per-layer reparametrisation backward of _WeightNormTap."""
+
+    @staticmethod
+    def forward(ctx, v, g, holder):
+        ctx.save_for_backward(v, g)
+        return holder[1].view(holder[1].shape)  # (holder: not a tensor argument -- the result is no view of an input)
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g = ctx.saved_tensors
+        v = _c(v)
+        if v.dim() == 4:
+            v = v.squeeze(-1)
+        dw = _c(dw)
+        Cout, cin, K = v.shape
+        dv, dg = torch.empty_like(v), torch.empty_like(g)
+        check(lib().kantts_weight_norm_strided_bwd(ptr(dw, torch.float32), ptr(v), ptr(g), ptr(dv), ptr(dg), Cout, cin, K,
+                                                   cin, 1, Cout * cin, stream()), "weight_norm_strided_bwd")
+        return dv.view(ctx.saved_tensors[0].shape), dg, None
+
+
 _WIMG_ATTR = "_kantts_bf16_weight_images"
+
+
+def weight_norm_image(m):
+    """(K, Cout, Cin_g) weight of the weight-normed convolution module ``m`` from its network's image buffers, or None
+    when there are none / they do not reflect the current parameters (the caller then re-parametrises this layer itself)."""
+    wn = getattr(m, "_kantts_wn", None)
+    if wn is None or os.environ.get("KANTTS_NO_WEIGHT_NORM_TABLE"):
+        return None
+    arena = wn[0]()
+    if arena is None or not arena.weight_norm_images_fresh():
+        return None
+    w = _WeightNormImage.apply(m.weight_v, m.weight_g, wn)
+    if get_precision() == "bf16" and wn[2] is not None and not os.environ.get("KANTTS_NO_WEIGHT_IMAGES"):
+        setattr(w, _WIMG_ATTR, (wn[2], wn[3], wn[4]))
+    return w
 
 
 def weight_norm_tap(v, g, groups=1):

@@ -64,6 +64,7 @@ def hifigan_model_builder(config, device, rank, distributed, use_arena=None):
         otype, oparams = conf["optimizer"].get("type", "Adam"), conf["optimizer"].get("params", {})
         if (use_arena if use_arena is not None else _is_hip(device)) and otype == "Adam" and not oparams.get("amsgrad", False):
             arena = ParamArena(net)
+            arena.build_weight_norm_images()
             if distributed:
                 # three independent reducers (generator, MPD, MSD), each exchanging its gradient arena in a few large
                 # bucketed all-reduces overlapped with its own backward; a discriminator arena is only armed by its own

@@ -31,6 +31,9 @@ def conv_weight(m):
     weight straight in the kernels' tap-major layout (K, Cout, Cin_g) from the weight-norm kernel; 1-3 channel
     layers (streaming kernels) and plain weights keep the parameter layout (Cout, Cin_g, K)."""
     if hasattr(m, "weight_g"):
+        w = ops.weight_norm_image(m)  # one launch per network and optimizer step (ParamArena.build_weight_norm_images)
+        if w is not None:
+            return w, True
         v = m.weight_v
         if v.dim() == 4:  # Conv2d((k,1)) of the period discriminators
             v = v.squeeze(-1)

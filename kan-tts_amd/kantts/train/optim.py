@@ -47,8 +47,115 @@ class ParamArena:
         self.capture_stream = None
         self.n_buckets = 4
         self.flat_bf16 = None
+        self._weights_version = 0  # bumped whenever the fp32 master weights change (the shadow_stale setter)
+        self._shadow_stale = False
+        self._wn_table = None
         if bf16_shadow:
             self._build_shadow()
+
+    @property
+    def shadow_stale(self):
+        return self._shadow_stale
+
+    @shadow_stale.setter
+    def shadow_stale(self, value):
+        """Every writer of the fp32 master (optimizer step, restore, broadcast, load_state_dict) sets this to True: the
+        version count also tells the weight-norm images (build_weight_norm_images) that they are out of date."""
+        self._shadow_stale = bool(value)
+        if value:
+            self._weights_version += 1
+
+    # ------------------------------------------------------------------------------------------ weight-norm images
+    def build_weight_norm_images(self):
+        """HiFi-GAN: the effective weight w = g * v / ||v|| of EVERY weight-normed convolution of the module
+        (kantts/models/hifigan/layers.py:29,67; hifigan.py:224,332 of the reference re-parametrise per layer and per
+        forward pass through torch's weight_norm hook) in the convolution kernels' tap-major layout -- fp32 (K, Cout, Cin_g)
+        plus the two bf16 operand images of csrc/cconv.hip -- rebuilt by ONE table-driven launch per optimizer step
+        (kantts_weight_norm_table) from the flat parameter arena, instead of one launch per layer and forward pass
+        (round 3: 6 700 launches of 15 us = 7.4 % of the kernel time of the benchmark).  The per-layer autograd node
+        (ops._WeightNormImage) hands out views of these buffers and keeps the per-layer backward.  Layers whose input
+        channel count is not a multiple of 4 (1-3 channel first layers) and transposed convolutions keep the per-layer
+        path."""
+        import torch.nn as nn
+
+        index = {id(p): i for i, p in enumerate(self.params)}
+        rows_tab, layers = [], []
+        w_off = wf_off = wd_off = row0 = 0
+        al = self.align
+        for m in self.module.modules():
+            g, v = getattr(m, "weight_g", None), getattr(m, "weight_v", None)
+            if g is None or v is None or id(g) not in index or id(v) not in index:
+                continue
+            if isinstance(m, (nn.ConvTranspose1d, nn.ConvTranspose2d)):
+                continue
+            shape = tuple(v.shape[:3]) if (v.dim() == 4 and v.shape[3] == 1) else tuple(v.shape)
+            if len(shape) != 3 or shape[1] % 4:
+                continue
+            cout, cin, k = shape
+            groups = int(getattr(m, "groups", 1))
+            n = cout * cin * k
+            img = cin % 8 == 0 and (cout // groups) % 8 == 0
+            rows_tab.append([self.offsets[index[id(v)]], self.offsets[index[id(g)]], w_off, wf_off if img else -1,
+                             wd_off if img else -1, cout | (cin << 32), k | (groups << 32), row0])
+            layers.append((m, w_off, wf_off if img else -1, wd_off if img else -1, (k, cout, cin), groups))
+            pad = (n + al - 1) // al * al
+            w_off += pad
+            if img:
+                wf_off += pad
+                wd_off += pad
+            row0 += (cout + 7) // 8  # the launch has one workgroup per tile of 8 output rows
+        if not layers:
+            return 0
+        dev = self.flat.device
+        self._wn_w = torch.zeros(max(w_off, 8), device=dev, dtype=torch.float32)
+        self._wn_wf = torch.zeros(max(wf_off, 8), device=dev, dtype=torch.bfloat16)
+        self._wn_wd = torch.zeros(max(wd_off, 8), device=dev, dtype=torch.bfloat16)
+        self._wn_table = torch.tensor(rows_tab, dtype=torch.int64, device=dev)
+        self._wn_rows = row0
+        self._wn_version = -1
+        self._wn_params = [q for m, *_ in layers for q in (m.weight_v, m.weight_g)]
+        self._wn_sig = None
+        import weakref
+
+        ref = weakref.ref(self)
+        for m, wo, fo, do, (k, cout, cin), groups in layers:
+            n = k * cout * cin
+            m._kantts_wn = (ref, self._wn_w[wo:wo + n].view(k, cout, cin),
+                            None if fo < 0 else self._wn_wf[fo:fo + n].view(k, cout, cin),
+                            None if do < 0 else self._wn_wd[do:do + n].view(k, groups, cin, cout // groups), groups)
+        # once per forward of the WHOLE module, before it forks its branch streams (every branch reads the images)
+        def _pre(m, a):  # (a pre-hook's return value replaces the module's input: return None)
+            self.refresh_weight_norm_images()
+
+        self.module.register_forward_pre_hook(_pre)
+        self.module.register_load_state_dict_post_hook(lambda m, keys: self.mark_shadow_stale())
+        return len(layers)
+
+    def weight_norm_images_fresh(self):
+        return self._wn_table is not None and self._wn_version == self._weights_version
+
+    def refresh_weight_norm_images(self, force=False):
+        import os
+
+        if self._wn_table is None or (os.environ.get("KANTTS_NO_WEIGHT_NORM_TABLE") and not force):  # (A/B switch)
+            return False
+        # in-place writes that did not go through the optimizer / load_state_dict (``with torch.no_grad(): p.copy_(..)``,
+        # an initialiser applied after the arena was built) bump the tensors' version counters: once per forward of the
+        # whole module that is cheap to look at
+        sig = sum(q._version for q in self._wn_params)
+        if sig != self._wn_sig:
+            self._wn_sig = sig
+            self._weights_version += 1
+        if not force and self._wn_version == self._weights_version:
+            return False
+        from kantts._hip import check, lib, ptr, stream
+
+        check(lib().kantts_weight_norm_table(ptr(self.flat, torch.float32), ptr(self._wn_w, torch.float32),
+                                             ptr(self._wn_wf, torch.bfloat16), ptr(self._wn_wd, torch.bfloat16),
+                                             ptr(self._wn_table), int(self._wn_table.shape[0]), int(self._wn_rows),
+                                             stream()), "weight_norm_table")
+        self._wn_version = self._weights_version
+        return True
 
     # ------------------------------------------------------------------------------------------ bf16 shadow
     def _build_shadow(self):

@@ -1391,6 +1391,9 @@ class EmulatedLib:
         return 0
 
     def kantts_weight_norm_tap_images(self, v, g, w, wf, wd, rows, cin, K, groups, stream):
+        return self._weight_norm_tap_images(v, g, w, wf, wd, rows, cin, K, groups)
+
+    def _weight_norm_tap_images(self, v, g, w, wf, wd, rows, cin, K, groups):
         rows, cin, K, groups = int(_val(rows)), int(_val(cin)), int(_val(K)), int(_val(groups))
         V = _arr(v, rows * cin * K).reshape(rows, cin * K)
         nrm = np.sqrt((V.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32))
@@ -1402,6 +1405,20 @@ class EmulatedLib:
         if wd:
             rg = rows // groups
             _wr(wd, np.ascontiguousarray(tap.reshape(K, groups, rg, cin).transpose(0, 1, 3, 2)), True)
+        return 0
+
+    def kantts_weight_norm_table(self, flat, w, wf, wd, table, ndesc, total_rows, stream):
+        """One table entry per layer (include/kantts_hip.h kantts_wn_desc = 5 int64 + 6 int32): the per-layer entry
+        point applied to each."""
+        ndesc = int(_val(ndesc))
+        tab = _arr(table, ndesc * 8, np.int64).reshape(ndesc, 8)
+        for e in tab:
+            v_off, g_off, w_off, wf_off, wd_off = (int(x) for x in e[:5])
+            rows, cin = int(e[5]) & 0xffffffff, int(e[5]) >> 32
+            K, groups = int(e[6]) & 0xffffffff, int(e[6]) >> 32
+            self._weight_norm_tap_images(int(flat) + 4 * v_off, int(flat) + 4 * g_off, int(w) + 4 * w_off,
+                                         int(wf) + 2 * wf_off if (wf and wf_off >= 0) else None,
+                                         int(wd) + 2 * wd_off if (wd and wd_off >= 0) else None, rows, cin, K, groups)
         return 0
 
     def kantts_weight_norm_strided_fwd(self, v, g, w, rows, cin, K, rs, cs, ks, stream):

@@ -4,6 +4,8 @@ container by oracle/check_vs_reference.py (its HiFi-GAN section: G / MPD / MSD f
 channels) and, travelling with the repo, by tests/golden/hifigan_v1.pt (the reference's V1 class defaults;
 test_oracle_matches_reference_v1_fixture below).
 Tolerances: fp32 path wav mean-abs <= 1e-4 (asserted at 1e-5), parameter gradients rel-L2 <= 2e-3."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -652,3 +654,142 @@ def test_generator_with_relu_activation_matches_the_reference_fixture(name):
             assert abs(float(p.grad.double().norm()) - w) <= 2e-4 * max(w, 1e-3), n
     with pytest.raises(NotImplementedError):
         Generator(in_channels=80, channels=32, nonlinear_activation="ELU", nonlinear_activation_params={})
+
+
+# ---- weight-norm images of a whole network from one table-driven launch (ParamArena.build_weight_norm_images) ----------
+def _wn_table_check(device, count_calls=None, train=True):
+    """Every layer's slice of the arena's image buffers equals what the per-layer entry point
+    (kantts_weight_norm_tap_images) writes for that layer -- fp32 weight and both bf16 images, bit for bit (same
+    arithmetic, same summation order per row); two training steps with the table equal two steps without it; and the
+    table is launched once per network and optimizer step, not once per layer and forward pass."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+    from kantts.models import hifigan_model_builder
+    from kantts.train.gan_step import gan_train_step
+    from kantts.train.loss import criterion_builder
+
+    opt = {"type": "Adam", "params": {"lr": 2e-3, "betas": [0.5, 0.9], "weight_decay": 0.0}}
+    sch = {"type": "MultiStepLR", "params": {"gamma": 0.5, "milestones": [200000]}}
+    config = {"model_type": "hifigan", "Model": {
+        "Generator": {"params": {"channels": 32, "upsample_scales": [4, 4], "upsample_kernal_sizes": [8, 8],
+                                 "resblock_kernel_sizes": [3, 7], "resblock_dilations": [[1, 3, 5], [1, 3, 5]]},
+                       "optimizer": opt, "scheduler": sch},
+        "MultiScaleDiscriminator": {"params": {"scales": 2}, "optimizer": opt, "scheduler": sch},
+        "MultiPeriodDiscriminator": {"params": {"periods": [2, 3]}, "optimizer": opt, "scheduler": sch}},
+        "Loss": {"generator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "discriminator_adv_loss": {"enable": True, "params": {}, "weights": 1.0},
+                 "mel_loss": {"enable": True, "params": {"fft_size": 256, "hop_size": 64, "win_length": 256}, "weights": 45.0},
+                 "feat_match_loss": {"enable": True, "params": {}, "weights": 2.0}},
+        "generator_grad_norm": -1, "discriminator_grad_norm": -1, "discriminator_train_start_steps": 0,
+        "generator_train_start_steps": 0}
+
+    def build():
+        torch.manual_seed(3)
+        model, optimizer, scheduler = hifigan_model_builder(config, device, 0, False, use_arena=True)
+        return model, optimizer, scheduler, criterion_builder(config, device=device)
+
+    hip.set_precision("bf16")
+    try:
+        model, optimizer, scheduler, crit = build()
+        n_layers = 0
+        for o in [optimizer["generator"], *optimizer["discriminator"].values()]:
+            arena = o.arena
+            assert arena._wn_table is not None
+            assert arena.refresh_weight_norm_images(force=True)
+            for m in arena.module.modules():
+                wn = getattr(m, "_kantts_wn", None)
+                if wn is None:
+                    continue
+                n_layers += 1
+                v = m.weight_v.detach()
+                v = v.squeeze(-1) if v.dim() == 4 else v
+                ref = ops.weight_norm_tap(v, m.weight_g.detach(), groups=wn[4])
+                rf, rd = ops.weight_images(ref, wn[4])
+                if wn[2] is not None:  # same kernel body per row: bit for bit
+                    assert torch.equal(ref, wn[1]), type(m)
+                    assert rf is not None and torch.equal(rf, wn[2]) and torch.equal(rd, wn[3])
+                else:  # layers without bf16 images take kantts_weight_norm_strided_fwd per layer (another summation order)
+                    assert rf is None and float((ref - wn[1]).abs().max()) <= 1e-6 * float(ref.abs().max())
+        assert n_layers >= 30
+        if not train:
+            return None
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(2, 80, 8, generator=g).to(device)
+        y = torch.randn(2, 1, 128, generator=g).clamp(-1, 1).to(device)
+        res = {}
+        for table in (True, False):
+            if not table:
+                os.environ["KANTTS_NO_WEIGHT_NORM_TABLE"] = "1"
+            try:
+                model, optimizer, scheduler, crit = build()
+                if count_calls is not None:
+                    count_calls.clear()
+                losses = []
+                for it in range(2):
+                    out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
+                    losses.append({k: float(v) for k, v in out.items()})
+                res[table] = (losses, [o.arena.flat.clone() for o in [optimizer["generator"], *optimizer["discriminator"].values()]],
+                              None if count_calls is None else dict(count_calls))
+            finally:
+                os.environ.pop("KANTTS_NO_WEIGHT_NORM_TABLE", None)
+        for a, b in zip(res[True][0], res[False][0]):
+            for k in a:
+                assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])
+        for a, b in zip(res[True][1], res[False][1]):
+            assert rel_l2(a, b) <= 1e-5
+        return res
+    finally:
+        hip.set_precision("fp32")
+
+
+def test_weight_norm_table_equals_per_layer_launches_emulated(emulated_cabi, monkeypatch):
+    import os  # noqa: F401
+
+    counts = {}
+    for name in ("kantts_weight_norm_table", "kantts_weight_norm_tap_images"):
+        orig = getattr(emulated_cabi, name)
+        monkeypatch.setattr(emulated_cabi, name, (lambda o, n: lambda *a: (counts.__setitem__(n, counts.get(n, 0) + 1), o(*a))[1])(orig, name),
+                            raising=False)
+    res = _wn_table_check("cpu", counts)
+    with_table, without = res[True][2], res[False][2]
+    # two steps, three networks: step 1 refreshes G, both discriminators, G again after its update; step 2 the
+    # discriminators (updated at the end of step 1) and G again -> 7 launches, none per layer
+    assert with_table.get("kantts_weight_norm_table", 0) == 7, with_table
+    assert with_table.get("kantts_weight_norm_tap_images", 0) == 0, with_table
+    assert without.get("kantts_weight_norm_table", 0) == 0 and without.get("kantts_weight_norm_tap_images", 0) > 100, without
+
+
+def test_weight_norm_table_images_equal_the_per_layer_kernel_emulated(emulated_cabi):
+    """The image comparison alone (the variant tests/test_kernel_source_on_cpu.py runs on the kernel source)."""
+    _wn_table_check("cpu", train=False)
+
+
+@pytest.mark.gpu
+def test_weight_norm_table_equals_per_layer_launches_gpu():
+    _wn_table_check("cuda")
+
+
+def _c1_persistent(device, monkeypatch):
+    """conv_c1_wgrad_mfma_kernel walks several runs per workgroup (at most 512 workgroups per launch): with the cap forced
+    down to 2 / 3 workgroups the 9 (MSD shape) and 4 (MPD shape) runs of these cases are spread unevenly -- same gradients
+    as torch's."""
+    for cap in ("2", "3", "512"):
+        monkeypatch.setenv("KANTTS_C1_WGRAD_WGS", cap)
+        for case in ((3, 700, 1, 128, 15, 1, 1, 7, 1, None, 0.1, False), (2, 333, 1, 32, 5, 3, 1, 2, 1, None, 0.1, False),
+                     (5, 1100, 1, 64, 15, 1, 1, 7, 1, None, 0.1, False)):
+            y, ref, gy, gr = _win_case(case, device)
+            assert_close(y, ref, 5e-5, what=str(case))
+            for a, c in zip(gy, gr):
+                assert rel_l2(a, c) < 2e-4, (cap, case, rel_l2(a, c))
+
+
+def test_one_channel_weight_gradient_with_a_persistent_grid_emulated(emulated_cabi, monkeypatch):
+    _c1_persistent("cpu", monkeypatch)
+
+
+@pytest.mark.gpu
+def test_one_channel_weight_gradient_with_a_persistent_grid_gpu(monkeypatch):
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _c1_persistent("cuda", monkeypatch)

@@ -71,6 +71,8 @@ from test_hifigan import (  # noqa: F401
     test_conv_win_emulated_matches_torch,
     test_multiscale_discriminator_with_average_pooling_matches_the_reference_fixture,
     test_generator_with_relu_activation_matches_the_reference_fixture,
+    test_weight_norm_table_images_equal_the_per_layer_kernel_emulated,
+    test_one_channel_weight_gradient_with_a_persistent_grid_emulated,
 )
 from test_hifigan_nsf import test_nsf_generator_host_logic_matches_reference_fixture  # noqa: F401
 from test_sambert_se import test_sambert_se_host_logic_matches_reference_fixture  # noqa: F401
