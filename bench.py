@@ -510,6 +510,22 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
             stage_b = [round(_event_ms(lambda i=i: up_b(i), 20) * 1e3, 1) for i in range(4)]
             msb = _event_ms(lambda: [up_b(i) for i in range(4)], 20)
             prep_ms = _event_ms(lambda: [_ops.upsample_weights(w, s_) for w, _, s_, _ in ws], 5)
+            # the whole dual-path stage (transposed convolution + k = 7 convolution over the repeated signal) as the model
+            # runs it since round 4: ONE polyphase contraction with the summed weights (Generator._dual_path_weight)
+            dws = []
+            for i, s_ in enumerate((8, 8, 2, 2)):
+                wd_, bd_ = G._dual_path_weight(i, s_)
+                wd_ = wd_.detach().contiguous()
+                dws.append((wd_, bd_.detach(), s_, _ops.upsample_weights(wd_, s_)))
+
+            def dual_b(i):
+                w, b, s_, prep = dws[i]
+                y = _ops.upsample_forward(acts[i], w, b, s_, out_bf16=True, prepared=prep)
+                assert y is not None
+                return y
+
+            dual_stage = [round(_event_ms(lambda i=i: dual_b(i), 20) * 1e3, 1) for i in range(4)]
+            ms_dual = _event_ms(lambda: [dual_b(i) for i in range(4)], 20)
         gb = belems * 2 / (msb * 1e-3) / 1e9
         res["upsampling"] = {"ms": msb, "bound": "hbm", "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": gb / PEAK_HBM_GBPS, "algorithmic_bytes": belems * 2, "bytes_dtype": "bf16",
@@ -518,6 +534,15 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
                              "weight_prep_ms_not_included": prep_ms,
                              "note": "4 launches; bf16 activations in and out; the polyphase re-layout + bf16 cast of the "
                                      "weights (6.7 MB, once per optimizer step / once for inference) is timed separately"}
+        dual_bytes = 50.5e6 * 2 * B / 32  # in + out + both weights of the fused dual-path stage, bf16
+        res["upsampling_dual_path"] = {
+            "ms": ms_dual, "bound": "hbm", "achieved": dual_bytes / (ms_dual * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
+            "unit": "GB/s", "frac": dual_bytes / (ms_dual * 1e-3) / 1e9 / PEAK_HBM_GBPS, "algorithmic_bytes": dual_bytes,
+            "stage_us": dual_stage, "taps_per_stage": [int(w.shape[2] // s_) for w, _, s_, _ in dws],
+            "algorithmic_gflop_two_launch_form": 87.0 * B / 32,
+            "note": "transposed convolution + repeat convolution of a stage as ONE polyphase contraction with summed "
+                    "weights (one output write, `rep` never formed): 2 taps at the x8 stages, 4 at the x2 stages; the "
+                    "weight combination (a few small operations per optimizer step) is not included"}
     else:
         res["upsampling"] = dict(res["upsampling_fp32_storage"], bound="hbm", peak=PEAK_HBM_GBPS)
     out = gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)

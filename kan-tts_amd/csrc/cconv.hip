@@ -683,11 +683,24 @@ extern "C" int kantts_cconv_launch(const kantts_cconv_args* ap, void* stream) {
     if (g.tile == 1) return rc;
   }
   int tile = g.tile == 1 ? 0 : g.tile;
+  int nst_arg = 0;  // args->tile = stages * 1000000 + tile code: experiments / the upsampling stages pick both
+  if (tile >= 1000000) {
+    nst_arg = tile / 1000000;
+    tile %= 1000000;
+  }
   if (tile == 0) {
     // (measured, scripts/bench_native/cconv_test: 128 x 64 beats 256 x 64 at every 64-channel shape of the model)
     if (g.NG > 64) {
       const long long t128 = kantts_cdiv(rows, 128) * g.groups * kantts_cdiv(g.NG, 128) * g.phases;
       tile = (t128 >= 200) ? 128128 : 128064;
+      // [round 4] few rows, a shallow reduction (the first transposed convolution of the generator: 1024 rows x 2048
+      // columns x 1024 deep): 128 x 64 tiles give 256 workgroups whose 16 reduction steps each wait for one L2 round
+      // trip; 64 x 64 tiles with a four-deep ring put two workgroups on every CU with three steps in flight
+      // (profiles/r04_runD_upsampling_tile_sweep.log: 17.0 -> 13.2 us; deeper reductions and larger grids lose)
+      if (t128 < 200 && (long long)g.K * g.CR <= 2048 && nst_arg == 0) {
+        tile = 64064;
+        nst_arg = 4;
+      }
     } else if (g.NG > 32) {
       tile = 128064;
     } else {
@@ -695,7 +708,7 @@ extern "C" int kantts_cconv_launch(const kantts_cconv_args* ap, void* stream) {
     }
   }
   static const char* env_stage = getenv("KANTTS_CCONV_STAGES");
-  int nst = env_stage ? atoi(env_stage) : 0;
+  int nst = nst_arg ? nst_arg : (env_stage ? atoi(env_stage) : 0);
   if (nst == 0 && tile == 128128) {
     // a grid that cannot give every CU two tiles anyway gains nothing from two co-resident workgroups: spend the LDS
     // on a 4-deep ring instead (three steps of loads in flight hide the L2 / HBM round trip of a short reduction)
@@ -712,7 +725,16 @@ extern "C" int kantts_cconv_launch(const kantts_cconv_args* ap, void* stream) {
       return cc_launch<256, 64, 4, 1, 2>(P, st);
     case 128064:
       if (nst == 3) return cc_launch<128, 64, 2, 2, 3>(P, st);
+      if (nst == 4) return cc_launch<128, 64, 2, 2, 4>(P, st);
       return cc_launch<128, 64, 2, 2, 2>(P, st);
+    case 64128:
+      if (nst == 3) return cc_launch<64, 128, 2, 2, 3>(P, st);
+      if (nst == 4) return cc_launch<64, 128, 2, 2, 4>(P, st);
+      return cc_launch<64, 128, 2, 2, 2>(P, st);
+    case 64064:
+      if (nst == 3) return cc_launch<64, 64, 2, 2, 3>(P, st);
+      if (nst == 4) return cc_launch<64, 64, 2, 2, 4>(P, st);
+      return cc_launch<64, 64, 2, 2, 2>(P, st);
     case 256032:
       if (nst == 3) return cc_launch<256, 32, 4, 1, 3>(P, st);
       return cc_launch<256, 32, 4, 1, 2>(P, st);

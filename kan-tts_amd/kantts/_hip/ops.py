@@ -1783,7 +1783,7 @@ class _ConvTransposeCL(torch.autograd.Function):
             # bf16 mode: the activated bf16 image of x (handed over by the producer, or made here in one pass) feeds the
             # forward contraction, the weight gradient and the LeakyReLU' gate of the input gradient
             xa = act if act is not None else act_cast_bf16(x, act_slope=in_leaky)
-            y = upsample_forward(xa, w, bias, s, res=res) if taps == 2 else None
+            y = upsample_forward(xa, w, bias, s, res=res)
             if y is None:
                 y = torch.empty((B, Tin * s, Cout), device=x.device, dtype=torch.float32)
                 w2b = w.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).to(torch.bfloat16).contiguous()  # (taps, s, Cout, Cin)
@@ -2100,9 +2100,12 @@ def upsample_weights(w, s):
     permuted) matrices (s*Cout, 2*Cin), row (r, co), column (j, ci) = w[ci, co, r + j*s], the permuted copy ordered for
     16-byte stores.  Wide layers (csrc/cconv.hip): (tap-major (2, s*Cout, Cin), None)."""
     Cin, Cout, K = w.shape
-    assert K == 2 * s
+    assert K % s == 0
+    taps = K // s
     wb = ops_bf16.to_bf16(w) if w.numel() % 8 == 0 else w.detach().to(torch.bfloat16)  # one cast, then bf16 re-layouts
     wp = None
+    if taps != 2:  # (the fused dual-path stages of the generator: J = 4 taps at stride 2) tap-major image only
+        return wb.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).reshape(taps, s * Cout, Cin).contiguous(), None
     if Cout % 32 == 0 and (Cin, Cout, s) in ((128, 64, 2), (64, 32, 2)):
         wl = wb.view(Cin, Cout, 2, s).permute(3, 1, 2, 0).reshape(s * Cout, 2 * Cin)
         wp = wl.view(s, Cout // 32, 4, 2, 4, 2 * Cin).permute(0, 1, 3, 2, 4, 5).reshape(s * Cout, 2 * Cin)
@@ -2121,8 +2124,9 @@ def upsample_forward(act, w, bias, s, res=None, out_bf16=False, in_slope=1.0, pr
     parameters are cached by version, freshly computed weights (weight norm in training) are re-laid per call."""
     B, T, Cin = act.shape
     Cout = w.shape[1]
-    if w.shape[2] != 2 * s or act.dtype != torch.bfloat16 or Cin % 8 or (s * Cout) % 8:
+    if w.shape[2] % s or w.shape[2] < 2 * s or act.dtype != torch.bfloat16 or Cin % 8 or (s * Cout) % 8:
         return None
+    taps = w.shape[2] // s
     if prepared is None and isinstance(w, torch.nn.Parameter):
         hit = _up_wcache.get(id(w))
         if hit is not None and hit[2]() is w and hit[0] == (w._version, w.data_ptr(), s):  # see ops_bf16.bf16_weight
@@ -2143,9 +2147,9 @@ def upsample_forward(act, w, bias, s, res=None, out_bf16=False, in_slope=1.0, pr
     if in_slope != 1.0 or (r is not None and r.dtype != torch.float32) or wp is not None:
         return None
     brep = bias.repeat(s) if bias is not None else None
-    # polyphase form = a 2-tap convolution onto s*Cout channels (tap j reads token t - j)
+    # polyphase form = a ``taps``-tap convolution onto s*Cout channels (tap j reads token t - j)
     if not cconv(act, wl, out=None if out_bf16 else out, out_bf=out if out_bf16 else None, B=B, Tsrc=T, Tdst=T, groups=1,
-                 CR=Cin, NG=s * Cout, K=2, in_mul=1, in_add=0, in_kstep=-1, in_div=1, phases=1, bias=brep, res=r):
+                 CR=Cin, NG=s * Cout, K=taps, in_mul=1, in_add=0, in_kstep=-1, in_div=1, phases=1, bias=brep, res=r):
         return None
     return out
 

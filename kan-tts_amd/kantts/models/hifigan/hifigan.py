@@ -22,11 +22,39 @@ DB3_DEC_LO = [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 
 DB3_DEC_HI = [((-1.0) ** (k + 1)) * DB3_DEC_LO[5 - k] for k in range(6)]
 
 
+_DUAL_SEL = {}
+
+
+def _dual_path_selector(k7, s, device):
+    """Sel[k, r + j*s] = 1 where tap k of the causal k7-wide convolution over the nearest-repeated signal, at output phase
+    r (output sample q*s + r), reads INPUT token q - j:  floor((r + k - (k7 - 1)) / s) == -j.  (k7, J*s) with
+    J = 1 + ceil((k7 - 1) / s) ... trimmed to the taps that occur."""
+    key = (k7, s, str(device))
+    hit = _DUAL_SEL.get(key)
+    if hit is None:
+        offs = [[-((r + k - (k7 - 1)) // s) for r in range(s)] for k in range(k7)]  # j >= 0
+        J = 1 + max(max(row) for row in offs)
+        sel = torch.zeros(k7, J * s)
+        for k in range(k7):
+            for r in range(s):
+                sel[k, r + offs[k][r] * s] = 1.0
+        hit = _DUAL_SEL[key] = (sel.to(device), J)
+    return hit
+
+
 class Generator(torch.nn.Module):
     """Dual-path upsampling generator (reference :22-197): per stage
     x = sin(x)+x;  x = ConvT(LReLU(x)) + Conv_k7(LReLU(nearest_x_s(x)));  x = mean_j ResBlock_j(x).
-    The x_s repeated tensor is never materialised (the k=7 conv reads x through a //s token map) and the
-    transposed conv adds the repeat path in its epilogue, so each stage writes its output once."""
+    [round 4] Both paths of a causal stage are ONE polyphase contraction, one launch, one output write: the k7-wide
+    convolution over the s-times repeated signal reads, at output phase r, only the input tokens q, q - 1, .. (tap k
+    reads token q + floor((r + k - 6) / s)), i.e. it IS a causal transposed convolution of stride s whose polyphase weight
+    is the sum of the taps that fall on the same token -- and it is applied to the same LeakyReLU(x) as the transposed
+    convolution proper.  The two weights are added (a few elementwise / small-matmul operations on the weight tensors,
+    differentiable, so both parameters receive their gradients from the ONE weight-gradient contraction) and the stage is
+    ``conv_transpose_cl`` with a kernel of J*s taps (J = 2 for the x8 stages: exactly the cost of the transposed
+    convolution alone -- the 67.6 GFLOP of the four repeat convolutions at batch 32 and their backward passes are gone;
+    J = 4 for the x2 stages).  ``rep`` is never formed.  KANTTS_NO_DUAL_FUSE=1 keeps the two-launch form (the k = 7
+    convolution reading x through a //s token map, added in the transposed convolution's epilogue)."""
 
     def __init__(self, in_channels=80, out_channels=1, channels=512, kernel_size=7, upsample_scales=(8, 8, 2, 2),
                  upsample_kernal_sizes=(16, 16, 4, 4), resblock_kernel_sizes=(3, 7, 11),
@@ -101,6 +129,13 @@ class Generator(torch.nn.Module):
                 h, act = ops.sin_add(h, act_slope=self.slope)
             else:
                 h = ops.sin_add(h)
+            if (self.repeat_upsample and isinstance(up_layer, CausalConvTranspose1d)
+                    and isinstance(self.repeat_upsamples[i][2], CausalConv1d) and not os.environ.get("KANTTS_NO_DUAL_FUSE")):
+                w_dual, b_dual = self._dual_path_weight(i, s)
+                exc = self.source_downs[i].forward_cl(excitation) if excitation is not None else None
+                h = ops.conv_transpose_cl(h, w_dual, b_dual, s, in_leaky=self.slope, res=exc, act=act)
+                h = self._residual_stacks(h, i)
+                continue
             if act is not None:
                 ops.set_image(h, self.slope, act)  # the repeat convolution below reads the same activated image
             if self.repeat_upsample:
@@ -117,22 +152,48 @@ class Generator(torch.nn.Module):
                 h = up_layer.forward_cl(h, in_leaky=self.slope, res=rep, act=act)
             else:
                 h = up_layer.forward_cl(h, in_leaky=self.slope, res=rep)
-            # the num_kernels residual stacks of a stage read the same h and are summed: independent branches.  One stream
-            # each when a backward pass will follow (their weight gradients are the low-occupancy launches that gain:
-            # GAN step 66.9 -> 60.3 ms); a forward-only pass is a chain of chip-filling launches and is 9 % faster
-            # sequentially (4.09 vs 4.47 ms at batch 32 x 8192, profiles/r02_runAB_*)
-            blocks = self.conv_blocks[i * self.num_kernels:(i + 1) * self.num_kernels]
-            ops.act_image(h, self.slope)  # one activated bf16 image for the first convolution of every stack (bf16 mode)
-            thunks = [(lambda b=b, h=h: b.forward_cl(h)) for b in blocks]
-            ys = (ops.parallel_branches(thunks, inputs=(h,), private_grads=True) if torch.is_grad_enabled()
-                  else [t() for t in thunks])
-            xs = ys[0]
-            for y in ys[1:]:
-                xs = xs + y
-            h = xs / self.num_kernels
+            h = self._residual_stacks(h, i)
         # F.leaky_relu default slope 0.01 (reference :178), fused into conv_post's loader
         h = self.conv_post.forward_cl(h, in_leaky=0.01)
         return torch.tanh(h).transpose(1, 2)
+
+    def _residual_stacks(self, h, i):
+        # the num_kernels residual stacks of a stage read the same h and are summed: independent branches.  One stream
+        # each when a backward pass will follow (their weight gradients are the low-occupancy launches that gain:
+        # GAN step 66.9 -> 60.3 ms); a forward-only pass is a chain of chip-filling launches and is 9 % faster
+        # sequentially (4.09 vs 4.47 ms at batch 32 x 8192, profiles/r02_runAB_*)
+        blocks = self.conv_blocks[i * self.num_kernels:(i + 1) * self.num_kernels]
+        ops.act_image(h, self.slope)  # one activated bf16 image for the first convolution of every stack (bf16 mode)
+        thunks = [(lambda b=b, h=h: b.forward_cl(h)) for b in blocks]
+        ys = (ops.parallel_branches(thunks, inputs=(h,), private_grads=True) if torch.is_grad_enabled()
+              else [t() for t in thunks])
+        xs = ys[0]
+        for y in ys[1:]:
+            xs = xs + y
+        return xs / self.num_kernels
+
+    def _dual_path_weight(self, i, s):
+        """(Cin, Cout, J*s) weight and (Cout) bias of the stage's two paths as one causal transposed convolution:
+        w[ci, co, r + j*s] = w_T[ci, co, r + j*s] (the transposed convolution's own taps, zero beyond its kernel)
+                             + sum_{k : tap k at phase r reads token q - j} w_7[co, ci, k]."""
+        up, conv = self.transpose_upsamples[i][1], self.repeat_upsamples[i][2]
+        w_t = effective_weight(up.deconv)                      # (Cin, Cout, K_T)
+        c = conv.conv1d
+        w7, tap = conv_weight(c)                               # (k7, Cout, Cin) tap-major, or (Cout, Cin, k7)
+        k7 = c.kernel_size[0]
+        sel, J = _dual_path_selector(k7, s, w_t.device)
+        J = max(J, w_t.shape[2] // s)
+        if sel.shape[1] < J * s:
+            sel = F.pad(sel, (0, J * s - sel.shape[1]))
+        if tap:
+            rep = torch.matmul(w7.permute(2, 1, 0), sel)       # (Cin, Cout, k7) @ (k7, J*s)
+        else:
+            rep = torch.matmul(w7.permute(1, 0, 2), sel)
+        w = rep + F.pad(w_t, (0, J * s - w_t.shape[2])) if w_t.shape[2] < J * s else rep + w_t
+        bias = None
+        if up.deconv.bias is not None or c.bias is not None:
+            bias = (up.deconv.bias if c.bias is None else c.bias if up.deconv.bias is None else up.deconv.bias + c.bias)
+        return w, bias
 
     def remove_weight_norm(self):
         print("Removing weight norm...")

@@ -223,7 +223,7 @@ def test_cconv_ops_gpu_vs_emulated(bf16_all_sizes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [0, 128128, 256064, 128064, 256032])
+@pytest.mark.parametrize("tile", [0, 128128, 256064, 128064, 256032, 64128, 64064, 4128064, 3064064, 4064128])
 def test_cconv_every_tile_gpu_vs_emulated(tile):
     """kantts_cconv_launch through the binding with a forced tile: epilogue variants (bias, LeakyReLU, residual, bf16 /
     fp32 gates, both outputs), ragged channel counts, phases, groups, fold and upsampling."""

@@ -195,12 +195,19 @@ def test_op_bf16_mode(name, kw):
 
 
 # ---- entry points no emulated-ABI test reaches with host tensors: the GPU tests' arithmetic, on the kernel source
-@pytest.mark.parametrize("Cin,Cout,s,T", [(64, 32, 2, 70), (128, 64, 2, 37), (256, 128, 8, 19)])
-def test_upsampling_stream_kernel_and_sin_add_image(Cin, Cout, s, T):
+@pytest.mark.parametrize("Cin,Cout,s,T,form", [(64, 32, 2, 70, ""), (128, 64, 2, 37, ""), (256, 128, 8, 19, ""),
+                                                (64, 32, 2, 131, "tpw3"), (128, 64, 2, 75, "tpw2"), (128, 64, 2, 37, "lds")])
+def test_upsampling_stream_kernel_and_sin_add_image(Cin, Cout, s, T, form, monkeypatch):
     """kantts_sinadd_lrelu_fwd + kantts_upsample_stream (narrow layers) / the 2-tap polyphase cconv form (wide layers)
     against torch's conv_transpose1d on the same bf16-rounded operands (tests/test_hifigan.py::
-    test_upsample_streaming_kernels_gpu with host tensors)."""
+    test_upsample_streaming_kernels_gpu with host tensors).  ``form``: the register-weight kernel of round 4 with several
+    token tiles per wave (KANTTS_UPSTREAM_TPW), and the LDS-staged kernel it replaced (KANTTS_UPSTREAM_LDS=1)."""
     import torch
+
+    if form.startswith("tpw"):
+        monkeypatch.setenv("KANTTS_UPSTREAM_TPW", form[3:])
+    elif form == "lds":
+        monkeypatch.setenv("KANTTS_UPSTREAM_LDS", "1")
     import torch.nn.functional as F
 
     import kantts._hip as hip
@@ -392,3 +399,68 @@ def test_full_sambert_configuration_matches_oracle_on_the_kernel_source(mode, mo
             if (e2 / (r2 + 1e-60)) ** 0.5 > worst:
                 worst, wname = (e2 / (r2 + 1e-60)) ** 0.5, n
     assert (num / den) ** 0.5 <= bnd["grad_global"] and worst <= bnd["grad_worst"], ((num / den) ** 0.5, worst, wname)
+
+
+@pytest.mark.parametrize("tile", [64128, 64064, 4128064, 3064064, 4064128])
+def test_cconv_round4_tiles_on_the_kernel_source(tile):
+    """The tile / ring-depth variants of cconv_kernel added for the upsampling stages (64 x 128, 64 x 64, four-stage
+    128 x 64; args->tile = stages * 1000000 + tile code) against the numpy model of the entry point: a 2-tap polyphase
+    contraction (the transposed-convolution form) and a 7-tap convolution with ragged channel counts."""
+    import torch
+
+    import kantts._hip as hip
+
+    g = torch.Generator().manual_seed(tile)
+    # (B, Tsrc, Tdst, Cin, Cout, K, in_add, in_kstep)
+    for si, (B, Ts, Td, Cin, Cout, K, add, kstep) in enumerate([(3, 37, 37, 64, 256, 2, 0, -1), (2, 50, 50, 80, 136, 7, -6, 1)]):
+        x = torch.randn(B, Ts, Cin, generator=g).to(torch.bfloat16)
+        w = (torch.randn(K, Cout, Cin, generator=g) / (K * Cin) ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(Cout, generator=g)
+        outs = []
+        for src in ("kernel", "model"):
+            o32 = torch.full((B, Td, Cout), float("nan"))
+            obf = torch.zeros((B, Td, Cout), dtype=torch.bfloat16)
+            ctx = util.kernel_source_on_cpu() if src == "kernel" else util.emulation()
+            import conftest
+
+            with ctx if src == "kernel" else _numpy_model():
+                assert hip.cconv(x, w, out=o32, out_bf=obf, B=B, Tsrc=Ts, Tdst=Td, groups=1, CR=Cin, NG=Cout, K=K, in_mul=1,
+                                 in_add=add, in_kstep=kstep, in_div=1, phases=1, bias=bias, out_leaky=0.1,
+                                 tile=tile if src == "kernel" else 0)
+            outs.append((o32, obf.float()))
+        (a32, abf), (c32, cbf) = outs
+        assert not torch.isnan(a32).any(), (tile, si)
+        assert float((a32 - c32).abs().max()) <= 2e-5 * max(1.0, float(c32.abs().max())), (tile, si)
+        assert float((abf - cbf).abs().max()) <= 1e-2 * max(1.0, float(cbf.abs().max())), (tile, si)
+
+
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def _numpy_model():
+    """oracle/cabi_numpy.EmulatedLib, whatever the autouse fixture of this file installed for conftest._emulate."""
+    import cabi_numpy
+    import kantts._hip as hip
+    import kantts._hip.ops as ops
+    import kantts._hip.ops_bf16 as ops_bf16
+    import kantts.utils.audio_torch as audio_torch
+
+    emu = cabi_numpy.EmulatedLib()
+
+    def ptr(t, dtype=None):
+        if t is None:
+            return None
+        if dtype is not None and t.dtype != dtype:
+            raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+        return t.data_ptr()
+
+    p = util._Patch()
+    try:
+        for mod in (hip, ops, ops_bf16, audio_torch):
+            p.setattr(mod, "lib", lambda: emu)
+            p.setattr(mod, "ptr", ptr)
+            p.setattr(mod, "stream", lambda: None)
+        yield emu
+    finally:
+        p.undo()
