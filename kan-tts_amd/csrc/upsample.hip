@@ -63,14 +63,6 @@ __global__ __launch_bounds__(UP_THREADS) void upsample_stream_kernel(const UpArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
 
-  // ---- weights -> LDS once per workgroup, chunk index XORed with (row & 15): 16 rows of a fragment read 16 distinct slots
-  for (int id = tid; id < NR * CPR; id += UP_THREADS) {
-    const int row = id / CPR, c = id % CPR;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(a.wp + (long long)row * K + c * 8);
-    *reinterpret_cast<u32x4*>(up_lds + ((long long)row * CPR + (c ^ (row & 15))) * 16) = v;
-  }
-  __syncthreads();
-
   const int ntile = (a.ntok + 15) >> 4;
   const int stride = gridDim.x * (UP_THREADS / 64);
   int tile = blockIdx.x * (UP_THREADS / 64) + wave;
@@ -90,6 +82,15 @@ __global__ __launch_bounds__(UP_THREADS) void upsample_stream_kernel(const UpArg
       f[kk] = v;
     }
   };
+  // ---- weights -> LDS once per workgroup, chunk index XORed with (row & 15): 16 rows of a fragment read 16 distinct slots
+  // ([round 4] requesting the first tile's activations BEFORE this copy measured no better: 17.2 against 13.8-14.9 us on
+  // other boxes for the 128 -> 64 stage, inside the box-to-box spread; the order of round 2 stays)
+  for (int id = tid; id < NR * CPR; id += UP_THREADS) {
+    const int row = id / CPR, c = id % CPR;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(a.wp + (long long)row * K + c * 8);
+    *reinterpret_cast<u32x4*>(up_lds + ((long long)row * CPR + (c ^ (row & 15))) * 16) = v;
+  }
+  __syncthreads();
   if (tile < ntile) fetch(tile, cur);
   for (; tile < ntile; tile += stride) {
     const int tn = tile + stride;
@@ -174,127 +175,10 @@ static int up_launch(const UpArgs& a, hipStream_t st) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// [round 4] The same contraction with the WEIGHTS IN REGISTERS.  upsample_stream_kernel above stages the whole weight
-// matrix (64 / 16 KB) into LDS per workgroup, synchronises, and then -- at batch 32 -- every wave multiplies ONE 16-token
-// tile: 512 workgroups x 64 KB of L2 -> LDS copies for 17 MB of activations, and the copy, the barrier, the activation
-// fetch and the stores of a tile all sit behind one another (13 / 12 us per stage = 2.6 TB/s of algorithmic traffic).
-// Here a wave owns ONE pair of 16-row weight tiles (8 consecutive output channels x 16 lanes: the store unit of the
-// kernel above) for the whole launch: its 2 * KS A fragments are 16-byte loads straight from L2 into 8 * KS registers,
-// issued together with the first activation fetch, and the wave then walks `tpw` token tiles with the next tile's
-// fragments in flight.  The NP = S * COUT / 32 pairs of a layer are spread over the four waves of a workgroup (NP = 4:
-// one token stream; NP = 2: two streams of alternating tiles): no LDS, no barrier.
-template <int CIN, int COUT, int S>
-__global__ __launch_bounds__(256) void upsample_regw_kernel(const UpArgs a, const int tpw) {
-  constexpr int K = 2 * CIN;
-  constexpr int NR = S * COUT;
-  constexpr int NP = NR / 32;            // fragment pairs = waves per token stream
-  constexpr int KS = K / 32;
-  static_assert(NP == 4 || NP == 2 || NP == 1, "pairs per layer");
-  constexpr int NSTREAM = 4 / NP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, kg = lane >> 4;
-  const int p = wave % NP, strm = wave / NP;
-  const int ntile = (a.ntok + 15) >> 4;
-  const int base = blockIdx.x * (NSTREAM * tpw) + strm;
-
-  u32x4 cur[KS], nxt[KS];
-  auto fetch = [&](int tl, u32x4* f) {
-    const int tok = tl * 16 + li;
-    const bool ok0 = tl < ntile && tok < a.ntok;
-    const bool ok1 = ok0 && (tok % a.T) != 0;  // x[t-1] of the same sequence (causal: zero at t = 0)
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const int j = (kk * 32) / CIN;
-      const int ci = (kk * 32) % CIN + kg * 8;
-      const bool ok = j ? ok1 : ok0;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const u32x4*>(a.x + (long long)(tok - j) * CIN + ci);
-      f[kk] = v;
-    }
-  };
-  fetch(base, cur);
-  bf16x8 af0[KS], af1[KS];
-  {
-    const int row0 = (2 * p) * 16 + li, row1 = row0 + 16;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      af0[kk] = *reinterpret_cast<const bf16x8*>(a.wp + (long long)row0 * K + kk * 32 + kg * 8);
-      af1[kk] = *reinterpret_cast<const bf16x8*>(a.wp + (long long)row1 * K + kk * 32 + kg * 8);
-    }
-  }
-  const int r = p / (COUT / 32), cb = p % (COUT / 32);
-  const int co = cb * 32 + kg * 8;
-  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (a.bias) {
-    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
-    bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
-  }
-  for (int i = 0; i < tpw; ++i) {
-    const int tile = base + i * NSTREAM;
-    if (tile >= ntile) break;  // wave-uniform
-    if (i + 1 < tpw) fetch(tile + NSTREAM, nxt);
-    if (a.slope != 1.f) {
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        cur[kk].x = up_lrelu2(cur[kk].x, a.slope);
-        cur[kk].y = up_lrelu2(cur[kk].y, a.slope);
-        cur[kk].z = up_lrelu2(cur[kk].z, a.slope);
-        cur[kk].w = up_lrelu2(cur[kk].w, a.slope);
-      }
-    }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const bf16x8 bf = (bf16x8&)cur[kk];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[kk], bf, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[kk], bf, acc1, 0, 0, 0);
-    }
-    const int tok = tile * 16 + li;
-    if (tok < a.ntok) {
-      float o[8] = {acc0[0] + bs[0], acc0[1] + bs[1], acc0[2] + bs[2], acc0[3] + bs[3],
-                    acc1[0] + bs[4], acc1[1] + bs[5], acc1[2] + bs[6], acc1[3] + bs[7]};
-      const long long off = ((long long)tok * S + r) * COUT + co;
-      if (a.out_bf16) {
-        if (a.res) {
-          const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(a.res) + off);
-          o[0] += up_lo(q.x); o[1] += up_hi(q.x); o[2] += up_lo(q.y); o[3] += up_hi(q.y);
-          o[4] += up_lo(q.z); o[5] += up_hi(q.z); o[6] += up_lo(q.w); o[7] += up_hi(q.w);
-        }
-        u32x4 w = {up_pack2(o[0], o[1]), up_pack2(o[2], o[3]), up_pack2(o[4], o[5]), up_pack2(o[6], o[7])};
-        *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.out) + off) = w;
-      } else {
-        if (a.res) {
-          const float* rp = reinterpret_cast<const float*>(a.res) + off;
-          const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-          o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w; o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
-        }
-        float* op = reinterpret_cast<float*>(a.out) + off;
-        *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) cur[kk] = nxt[kk];
-  }
-}
-
-template <int CIN, int COUT, int S>
-static int up_regw_launch(const UpArgs& a, hipStream_t st) {
-  constexpr int NSTREAM = 4 / (S * COUT / 32);
-  const int ntile = (a.ntok + 15) / 16;
-  // tiles per wave: enough workgroups for two per CU, at most 16 tiles behind one weight load
-  const char* env = getenv("KANTTS_UPSTREAM_TPW");  // experiment switch (read per launch)
-  int tpw = env && atoi(env) > 0 ? atoi(env) : 0;
-  if (tpw == 0) {
-    tpw = kantts_cdiv(ntile, 512 * NSTREAM);
-    if (tpw < 1) tpw = 1;
-    if (tpw > 16) tpw = 16;
-  }
-  const int blocks = kantts_cdiv(ntile, NSTREAM * tpw);
-  hipLaunchKernelGGL((upsample_regw_kernel<CIN, COUT, S>), dim3(blocks), dim3(256), 0, st, a, tpw);
-  KANTTS_CHECK_LAUNCH();
-}
+// [round 4] A variant with the weights in REGISTERS (a wave owning one pair of 16-row weight tiles for the whole launch,
+// fragments loaded straight from L2, no LDS, no barrier) was written and measured: 25.8 / 14.4 us per stage against
+// 14.9 / 12.5 us for the kernel above (profiles/r04_runE_upsampling_stream_forms.log) -- a lane's 16-byte piece of a
+// 512-byte weight row coalesces badly, the LDS staging reads whole rows -- and was removed.
 
 // x: (B*T, Cin) bf16 tokens; wp: (S*Cout, 2*Cin) bf16 with row (mt*16 + rho), mt = (r*(Cout/32) + cb)*2 + h, holding output
 // channel co = cb*32 + (rho >> 2)*8 + h*4 + (rho & 3) of phase r, and column j*Cin + ci holding w[ci, co, r + j*S];
@@ -311,13 +195,7 @@ extern "C" int kantts_upsample_stream(const void* x_bf16, const void* wp_bf16, c
   a.bias = bias; a.res = res; a.out = out;
   a.ntok = B * T; a.T = T; a.slope = in_slope; a.out_bf16 = out_bf16;
   hipStream_t st = (hipStream_t)stream;
-  const char* lds_form = getenv("KANTTS_UPSTREAM_LDS");  // A/B switch: the round-2 kernel (weights staged in LDS)
-  if (lds_form && lds_form[0] == '1') {
-    if (Cin == 128 && Cout == 64 && S == 2) return up_launch<128, 64, 2>(a, st);
-    if (Cin == 64 && Cout == 32 && S == 2) return up_launch<64, 32, 2>(a, st);
-    return KANTTS_E_UNSUPPORTED;
-  }
-  if (Cin == 128 && Cout == 64 && S == 2) return up_regw_launch<128, 64, 2>(a, st);
-  if (Cin == 64 && Cout == 32 && S == 2) return up_regw_launch<64, 32, 2>(a, st);
+  if (Cin == 128 && Cout == 64 && S == 2) return up_launch<128, 64, 2>(a, st);
+  if (Cin == 64 && Cout == 32 && S == 2) return up_launch<64, 32, 2>(a, st);
   return KANTTS_E_UNSUPPORTED;
 }

@@ -231,6 +231,9 @@ def parallel_branches(thunks, inputs=(), private_grads=False):
         st.wait_event(fork)
         for x in dev_inputs:
             x.record_stream(st)
+            img = getattr(x, _IMG_ATTR, None)  # the bf16 operand image the branches read instead of x (act_image)
+            if img is not None and torch.is_tensor(img[1]) and img[1].is_cuda:
+                img[1].record_stream(st)
         with torch.cuda.stream(st):
             o = t()
             outs.append(_private_grad(o) if private_grads else o)
@@ -1715,14 +1718,17 @@ _IMG_ATTR = "_kantts_bf16_image"
 def set_image(t, slope, img):
     """Attach bf16(LeakyReLU(t, slope)) (slope None: bf16(t)) to the tensor object ``t``: the next convolution that reads
     ``t`` with that activation takes it as its operand image instead of making one (bf16 mode).  The attribute lives on
-    the Python object only -- views and copies do not carry it, which is the safe direction."""
-    setattr(t, _IMG_ATTR, (slope, img))
+    the Python object only -- views and copies do not carry it, which is the safe direction.  The tensor's version
+    counter is recorded: an in-place change of ``t`` after this call (masked_fill_, add_, a user hook) makes the image
+    stale, and get_image then ignores it instead of handing the convolution yesterday's activations."""
+    setattr(t, _IMG_ATTR, (slope, img, t._version))
     return t
 
 
 def get_image(t, slope):
     hit = getattr(t, _IMG_ATTR, None)
-    if hit is not None and hit[0] == slope and hit[1].shape == t.shape and hit[1].device == t.device:
+    if (hit is not None and hit[0] == slope and hit[1].shape == t.shape and hit[1].device == t.device
+            and hit[2] == t._version):
         return hit[1]
     return None
 

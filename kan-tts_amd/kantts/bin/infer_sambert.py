@@ -20,8 +20,6 @@ logging.basicConfig(format="%(asctime)s, %(levelname)-4s [%(filename)s:%(lineno)
 
 
 def am_synthesis(symbol_seq, fsnet, ling_unit, device, se=None):
-    if se is not None:
-        raise NotImplementedError("SE speaker-embedding input is outside the hot path (SURVEY 8f-4)")
     if ling_unit.using_byte():
         raise NotImplementedError("byte-index inputs (sambert_16k_MAS_byte.yaml) are outside the hot path")
     feats = ling_unit.encode_symbol_sequence(symbol_seq)
@@ -29,7 +27,12 @@ def am_synthesis(symbol_seq, fsnet, ling_unit, device, se=None):
     # the trailing "~" token is dropped from every stream (reference :117-122)
     inputs_ling = torch.stack([sy, tone, syllable, ws], dim=-1).unsqueeze(0)[:, :-1, :]
     inputs_emo = emo.unsqueeze(0)[:, :-1]
-    inputs_spk = spk.unsqueeze(0)[:, :-1]
+    if se is not None:
+        # SE models (sambert_se_nsf_global_16k.yaml): the utterance-level speaker embedding of --se_file, (1, dim),
+        # repeated over the symbols instead of speaker ids (reference :99-106)
+        inputs_spk = torch.from_numpy(np.asarray(se).repeat(len(feats[5]), axis=0)).float().to(device).unsqueeze(0)[:, :-1, :]
+    else:
+        inputs_spk = spk.unsqueeze(0)[:, :-1]
     inputs_len = torch.full((1,), inputs_emo.size(1), dtype=torch.long, device=device)
     res = fsnet(inputs_ling, inputs_emo, inputs_spk, inputs_len)
     valid_length = int(res["LR_length_rounded"][0].item())
@@ -53,8 +56,12 @@ def am_infer(sentence, ckpt, output_dir, se_file=None, config=None, ling_unit=No
 
         ling_unit = KanTtsLinguisticUnit(config)
     config["Model"]["KanTtsSAMBERT"]["params"].update(ling_unit.get_unit_size())
-    if config["Model"]["KanTtsSAMBERT"]["params"].get("SE", False) or se_file is not None:
-        raise NotImplementedError("SE speaker-embedding input is outside the hot path (SURVEY 8f-4)")
+    se_enable = config["Model"]["KanTtsSAMBERT"]["params"].get("SE", False)
+    if se_enable and se_file is None:
+        raise ValueError("this checkpoint takes a speaker embedding (SE: True): --se_file is required")
+    se = np.load(se_file) if se_enable else None  # (the reference ignores --se_file for models without SE, :177-178)
+    if config["Model"]["KanTtsSAMBERT"]["params"].get("NSF", False):
+        raise NotImplementedError("NSF acoustic models (f0 / uv appended to the mel) are outside the hot path")
     from kantts.models import model_builder
 
     model, _, _ = model_builder(config, device)
@@ -73,7 +80,7 @@ def am_infer(sentence, ckpt, output_dir, se_file=None, config=None, ling_unit=No
                 continue
             logging.info("Inference sentence: %s", line[0])
             with torch.no_grad():
-                _, mel_post, dur, f0, energy = am_synthesis(line[1], fsnet, ling_unit, device)
+                _, mel_post, dur, f0, energy = am_synthesis(line[1], fsnet, ling_unit, device, se=se)
             np.save("%s/%s_mel.npy" % (results_dir, line[0]), mel_post)
             np.savetxt("%s/%s_dur.txt" % (results_dir, line[0]), dur)
             np.savetxt("%s/%s_f0.txt" % (results_dir, line[0]), f0)

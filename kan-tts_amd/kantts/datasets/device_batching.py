@@ -137,12 +137,16 @@ class PinnedPrefetcher:
     def _stage(self, slot, path, t):
         if self.stream is None or not torch.is_tensor(t):
             return t.to(self.device) if torch.is_tensor(t) else t
-        key = (path, tuple(t.shape), t.dtype)
+        # one grow-only flat pinned buffer per (field, dtype) and slot: acoustic-model batches come in hundreds of distinct
+        # (max_in, max_out) shapes, and a buffer per shape would page-lock host memory without bound
+        key = (path, t.dtype)
+        n = t.numel()
         buf = self._staging[slot].get(key)
-        if buf is None:
-            buf = self._staging[slot][key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-        buf.copy_(t)
-        return buf.to(self.device, non_blocking=True)
+        if buf is None or buf.numel() < n:
+            buf = self._staging[slot][key] = torch.empty(max(n, 1) * 5 // 4 + 16, dtype=t.dtype).pin_memory()
+        view = buf[:n].view(t.shape)
+        view.copy_(t)
+        return view.to(self.device, non_blocking=True)
 
     def _move(self, slot, batch, path=()):
         if isinstance(batch, dict):

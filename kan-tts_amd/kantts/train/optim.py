@@ -335,6 +335,17 @@ class ParamArena:
         return self._launch_bucket_on_current_stream(b)
 
     def _launch_bucket_on_current_stream(self, b):
+        # the bucket's gradients were accumulated on whatever streams their layers ran on (the sub-discriminators and the
+        # residual stacks of HiFi-GAN each have their own): the packing below must come after ALL of them, not only after
+        # the stream whose hook completed the bucket.  Under capture that is a graph edge (a missing one lets the replayed
+        # copy read half-written gradients); eagerly it is a stream wait.
+        if self.bucket_ready is not None:
+            ops.join_capturing_side_streams()
+        elif torch.cuda.is_available() and self.grad.is_cuda:
+            cur = torch.cuda.current_stream()
+            for st in ops.helper_streams():
+                if st != cur:
+                    cur.wait_stream(st)
         ops.wgrad_overlap.join()  # weight gradients produced on the side stream must have landed before they are packed
         dst, src = [], []
         for i in b["params"]:

@@ -192,6 +192,9 @@ def _stft_dft_gemm(x, fft_size, hop_size, win_length, window_name):
     return torch.sqrt(torch.clamp(re * re + im * im, min=1e-7))
 
 
+_hann_checked = set()
+
+
 def stft(x, fft_size, hop_size, win_length, window):
     """|STFT| (B, frames, fft_size//2+1) with clamp(re^2+im^2, 1e-7) (reference :8-31), differentiable.  ``window`` is a
     name like "hann" / "hann_window", or a window TENSOR as the reference's callers pass: the kernels build their window
@@ -201,9 +204,19 @@ def stft(x, fft_size, hop_size, win_length, window):
         name = window.replace("_window", "")
     else:
         w = torch.as_tensor(window)
-        if w.numel() != win_length or not torch.allclose(
-                w.detach().float().cpu(), torch.hann_window(win_length, dtype=torch.float32), atol=1e-6):
-            raise NotImplementedError("stft(): only the Hann window (by name, or the hann_window(win_length) tensor)")
+        # validated ONCE per (buffer, version, length): the comparison copies the window to the host -- a sync per call,
+        # and an aborted capture when a caller passes its registered ``window`` buffer inside a captured step
+        key = (w.data_ptr(), w._version, int(w.numel()), int(win_length), str(w.device))
+        if key not in _hann_checked:
+            if torch.cuda.is_available() and w.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("stft(): a window tensor must have been seen once outside hipGraph capture (or pass "
+                                   "the window by name)")
+            if w.numel() != win_length or not torch.allclose(
+                    w.detach().float().cpu(), torch.hann_window(win_length, dtype=torch.float32), atol=1e-6):
+                raise NotImplementedError("stft(): only the Hann window (by name, or the hann_window(win_length) tensor)")
+            if len(_hann_checked) > 64:
+                _hann_checked.clear()
+            _hann_checked.add(key)
         name = "hann"
     if fft_size & (fft_size - 1):
         return _stft_dft_gemm(x, fft_size, hop_size, win_length, name)

@@ -135,3 +135,45 @@ def _train_clis(tmp_path):
 def test_training_entry_points_emulated(tmp_path):
     with emulation():
         _train_clis(tmp_path)
+
+
+def test_infer_sambert_with_a_speaker_embedding_file_emulated(tmp_path):
+    """``infer_sambert --se_file`` (reference kantts/bin/infer_sambert.py:99-106,177-178): an SE checkpoint takes the
+    utterance's speaker embedding from a .npy file, repeated over the symbols; the file changes the output; without it
+    the entry point refuses instead of feeding speaker ids to an embedding-input model."""
+    from kantts.bin.infer_sambert import am_infer
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+    from util import GOLDEN
+
+    cfg = dict(torch.load(os.path.join(GOLDEN, "sambert_tiny_se.pt"), weights_only=False)["cfg"])
+    assert cfg.get("SE")
+    params = {k: v for k, v in cfg.items() if k not in O.SAMBERT_VOCAB}
+    am_dir = tmp_path / "am" / "ckpt"
+    am_dir.mkdir(parents=True)
+    config = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": params,
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}}, "grad_norm": 1.0, "batch_size": 2}
+    (tmp_path / "am" / "config.yaml").write_text(yaml.dump(config))
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(dict(cfg))
+    with torch.no_grad():
+        m.variance_adaptor.duration_predictor.fc.bias.fill_(1.2)
+    torch.save({"model": m.state_dict()}, am_dir / "checkpoint_1.pth")
+    sent = tmp_path / "sentences.txt"
+    sent.write_text("utt_a\ta b c d e f\n")
+    dim = int(cfg.get("speaker_units", 192))
+    mels = []
+    with emulation():
+        for seed in (1, 2):
+            se = np.random.default_rng(seed).standard_normal((1, dim)).astype(np.float32)
+            np.save(tmp_path / ("se%d.npy" % seed), se)
+            out = tmp_path / ("out%d" % seed)
+            am_infer(str(sent), str(am_dir / "checkpoint_1.pth"), str(out), se_file=str(tmp_path / ("se%d.npy" % seed)),
+                     ling_unit=_FakeLingUnit(cfg))
+            mels.append(np.load(out / "feat" / "utt_a_mel.npy"))
+        with pytest.raises(ValueError, match="se_file"):
+            am_infer(str(sent), str(am_dir / "checkpoint_1.pth"), str(tmp_path / "out3"), ling_unit=_FakeLingUnit(cfg))
+    assert all(x.ndim == 2 and x.shape[1] == 80 and np.isfinite(x).all() for x in mels)
+    n = min(len(mels[0]), len(mels[1]))
+    assert n > 0 and np.abs(mels[0][:n] - mels[1][:n]).max() > 1e-4  # the embedding reaches the decoder

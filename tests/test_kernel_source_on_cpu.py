@@ -195,19 +195,12 @@ def test_op_bf16_mode(name, kw):
 
 
 # ---- entry points no emulated-ABI test reaches with host tensors: the GPU tests' arithmetic, on the kernel source
-@pytest.mark.parametrize("Cin,Cout,s,T,form", [(64, 32, 2, 70, ""), (128, 64, 2, 37, ""), (256, 128, 8, 19, ""),
-                                                (64, 32, 2, 131, "tpw3"), (128, 64, 2, 75, "tpw2"), (128, 64, 2, 37, "lds")])
-def test_upsampling_stream_kernel_and_sin_add_image(Cin, Cout, s, T, form, monkeypatch):
+@pytest.mark.parametrize("Cin,Cout,s,T", [(64, 32, 2, 70), (128, 64, 2, 37), (256, 128, 8, 19)])
+def test_upsampling_stream_kernel_and_sin_add_image(Cin, Cout, s, T):
     """kantts_sinadd_lrelu_fwd + kantts_upsample_stream (narrow layers) / the 2-tap polyphase cconv form (wide layers)
     against torch's conv_transpose1d on the same bf16-rounded operands (tests/test_hifigan.py::
-    test_upsample_streaming_kernels_gpu with host tensors).  ``form``: the register-weight kernel of round 4 with several
-    token tiles per wave (KANTTS_UPSTREAM_TPW), and the LDS-staged kernel it replaced (KANTTS_UPSTREAM_LDS=1)."""
+    test_upsample_streaming_kernels_gpu with host tensors)."""
     import torch
-
-    if form.startswith("tpw"):
-        monkeypatch.setenv("KANTTS_UPSTREAM_TPW", form[3:])
-    elif form == "lds":
-        monkeypatch.setenv("KANTTS_UPSTREAM_LDS", "1")
     import torch.nn.functional as F
 
     import kantts._hip as hip
