@@ -145,181 +145,14 @@ __global__ __launch_bounds__(MEL_THREADS) void melspec_kernel(const MelArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// [round 4] One WAVE per frame, radix-4 passes, no workgroup barrier inside a frame.
-// melspec_kernel above walks a workgroup's 4 frames one after the other with all 256 threads on each: one radix-2
-// butterfly per thread and pass, nine passes, each an LDS round trip plus a workgroup barrier -- at a saturating size the
-// kernel ran at 3.3 % of the HBM roof, bound by barrier / LDS latency (profiles/r03_runFINAL_bench_full.log).  Here
-//   * a wave owns a frame (its two ping-pong buffers and its magnitude row are private LDS): a wave's LDS operations
-//     execute in order, so the passes need no barrier at all -- only the compiler has to be told
-//     (mel_wave_sync) -- and the four waves of a workgroup proceed independently, each with MEL_FPW frames;
-//   * radix-4 Stockham passes (one radix-2 pass first when log2(n_fft / 2) is odd): 5 passes instead of 9 for
-//     n_fft = 1024, every lane carrying (n_fft / 8) / 64 independent butterflies per pass;
-//   * window, twiddles and the sparse mel weights are staged into LDS once per workgroup (16 frames);
-//   * the wide top mel channels (64 and above) are summed by four lanes each (DPP-free xor shuffles);
-//   * a workgroup's 16 frames are consecutive in the flattened (batch, frame) order and leave through an LDS tile so
-//     that a mel row's stores are contiguous 64-byte pieces.
-#define MEL_WAVES 4
-#define MEL_FPW 4
-#define MEL_WGF (MEL_WAVES * MEL_FPW)
-
-__device__ __forceinline__ void mel_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-__global__ __launch_bounds__(MEL_WAVES * 64) void melspec_wave_kernel(const MelArgs a, const int nnz_cap) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = a.n_fft, M = N >> 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- LDS map (floats): window N | twiddles 2M | mel weights nnz (padded) | per wave: 2 x 2M + (M + 4) | mel tile
-  float* win = smem;
-  float2* tws = reinterpret_cast<float2*>(win + N);
-  float* mw = reinterpret_cast<float*>(tws + M);
-  // packed mel weights: their count is only known on the device (offset + length of the last channel); a triangular bank
-  // has at most two weights per bin, which is what the launch reserved -- anything larger is read from global memory
-  const int nnz = a.out_mel ? a.mel_off[a.n_mels - 1] + a.mel_len[a.n_mels - 1] : 0;
-  const bool w_in_lds = nnz <= nnz_cap;
-  const float* mwp = w_in_lds ? mw : a.mel_w;
-  const int nnz_pad = nnz_cap;
-  float* wbase = mw + nnz_pad + wave * (4 * M + M + 4);
-  float2* buf0 = reinterpret_cast<float2*>(wbase);
-  float2* buf1 = buf0 + M;
-  float* amp = reinterpret_cast<float*>(buf1 + M);
-  float* tile = mw + nnz_pad + MEL_WAVES * (4 * M + M + 4);  // [MEL_WGF][n_mels]
-  for (int i = tid; i < N; i += MEL_WAVES * 64) win[i] = a.window[i];
-  for (int i = tid; i < M; i += MEL_WAVES * 64) tws[i] = a.tw[i];
-  if (a.out_mel && w_in_lds)
-    for (int i = tid; i < nnz; i += MEL_WAVES * 64) mw[i] = a.mel_w[i];
-  __syncthreads();
-
-  const long long total = (long long)a.B * a.frames;
-  const long long F0 = (long long)blockIdx.x * MEL_WGF;
-  // this lane's mel channel(s): lane m for m < 64; channels >= 64 are shared by four lanes each
-  int st0 = 0, ln0 = 0, of0 = 0;
-  if (a.out_mel && lane < a.n_mels) {
-    st0 = a.mel_start[lane];
-    ln0 = a.mel_len[lane];
-    of0 = a.mel_off[lane];
-  }
-
-  for (int q = 0; q < MEL_FPW; ++q) {
-    const int slot = wave * MEL_FPW + q;
-    const long long F = F0 + slot;
-    if (F >= total) break;  // wave-uniform
-    const int b = (int)(F / a.frames), f = (int)(F - (long long)b * a.frames);
-    const float* x = a.wav + (long long)b * a.T;
-    const int start = f * a.hop - M;  // centre padding of n_fft/2
-    // ---- windowed frame, packed as z[n] = x[2n] + i x[2n+1]
-    for (int n = lane; n < M; n += 64) {
-      float v[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        int s = start + 2 * n + e;
-        float xv = 0.f;
-        if (a.pad_mode == 1) {
-          if (s < 0) s = -s;
-          if (s >= a.T) s = 2 * (a.T - 1) - s;
-          xv = (s >= 0 && s < a.T) ? x[s] : 0.f;
-        } else if (s >= 0 && s < a.T) {
-          xv = x[s];
-        }
-        v[e] = xv * win[2 * n + e];
-      }
-      buf0[n] = make_float2(v[0], v[1]);
-    }
-    mel_wave_sync();
-    // ---- complex Stockham FFT of size M: one radix-2 pass if log2(M) is odd, then radix-4 passes
-    float2* src = buf0;
-    float2* dst = buf1;
-    int s = 0;  // log2 of the sub-transform length Ns done so far
-    if (a.log2m & 1) {
-      for (int j = lane; j < (M >> 1); j += 64) {  // Ns = 1: no twiddle
-        const float2 u = src[j], t = src[j + (M >> 1)];
-        dst[2 * j] = make_float2(u.x + t.x, u.y + t.y);
-        dst[2 * j + 1] = make_float2(u.x - t.x, u.y - t.y);
-      }
-      mel_wave_sync();
-      float2* tmp = src; src = dst; dst = tmp;
-      s = 1;
-    }
-    for (; s < a.log2m; s += 2) {
-      const int Ns = 1 << s, Q = M >> 2;
-      for (int j = lane; j < Q; j += 64) {
-        const int k = j & (Ns - 1);
-        // w1 = exp(-2 pi i k / (4 Ns)) = tw_N[k * N / (4 Ns)] = tw_N[k * (M >> (s + 1))]  (index < M / 2)
-        const float2 w1 = tws[k * (M >> (s + 1))];
-        const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
-        const float2 v0 = src[j];
-        const float2 v1 = cmul(src[j + Q], w1);
-        const float2 v2 = cmul(src[j + 2 * Q], w2);
-        const float2 v3 = cmul(src[j + 3 * Q], w3);
-        const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y), a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-        const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-        const float2 a3 = make_float2(v1.y - v3.y, v3.x - v1.x);  // -i (v1 - v3)
-        const int d = ((j >> s) << (s + 2)) + k;
-        dst[d] = make_float2(a0.x + a2.x, a0.y + a2.y);
-        dst[d + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
-        dst[d + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
-        dst[d + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
-      }
-      mel_wave_sync();
-      float2* tmp = src; src = dst; dst = tmp;
-    }
-    // ---- split post-pass: X[k] = E + w_N^k O,  E = (Z[k] + conj Z[M-k]) / 2,  O = -i (Z[k] - conj Z[M-k]) / 2
-    for (int k = lane; k <= M; k += 64) {
-      float re, im;
-      if (k == 0 || k == M) {
-        const float2 z0 = src[0];
-        re = (k == 0) ? (z0.x + z0.y) : (z0.x - z0.y);
-        im = 0.f;
-      } else {
-        const float2 zk = src[k];
-        const float2 zc = src[M - k];
-        const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);
-        const float dr = zk.x - zc.x, di = zk.y + zc.y;
-        const float orr = 0.5f * di, oi = -0.5f * dr;
-        const float2 w = tws[k];
-        re = er + (orr * w.x - oi * w.y);
-        im = ei + (orr * w.y + oi * w.x);
-      }
-      const float mag = sqrtf(fmaxf(re * re + im * im, a.eps_power));
-      amp[k] = mag;
-      if (a.out_mag) a.out_mag[((long long)b * a.frames + f) * (M + 1) + k] = mag;
-    }
-    mel_wave_sync();
-    // ---- sparse mel filterbank + dB + normalisation into the workgroup's tile
-    if (a.out_mel) {
-      if (lane < a.n_mels) {
-        float acc = 0.f;
-        for (int i = 0; i < ln0; ++i) acc = fmaf(amp[st0 + i], mwp[of0 + i], acc);
-        tile[slot * a.n_mels + lane] = mel_normalise(a, fmaxf(acc, a.eps_mel));
-      }
-      for (int mb = 64; mb < a.n_mels; mb += 16) {  // four lanes per channel
-        const int m = mb + (lane >> 2), part = lane & 3;
-        float acc = 0.f;
-        if (m < a.n_mels) {
-          const int st = a.mel_start[m], ln = a.mel_len[m], of = a.mel_off[m];
-          for (int i = part; i < ln; i += 4) acc = fmaf(amp[st + i], mwp[of + i], acc);
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        if (m < a.n_mels && part == 0) tile[slot * a.n_mels + m] = mel_normalise(a, fmaxf(acc, a.eps_mel));
-      }
-    }
-    mel_wave_sync();  // amp / buffers are reused by the wave's next frame
-  }
-  if (!a.out_mel) return;
-  __syncthreads();
-  // ---- the 16 frames of the tile: consecutive frames of one (batch item, mel channel) row are contiguous in the output
-  for (int idx = tid; idx < MEL_WGF * a.n_mels; idx += MEL_WAVES * 64) {
-    const int m = idx / MEL_WGF, slot = idx - m * MEL_WGF;
-    const long long F = F0 + slot;
-    if (F >= total) continue;
-    const int b = (int)(F / a.frames), f = (int)(F - (long long)b * a.frames);
-    a.out_mel[((long long)b * a.n_mels + m) * a.frames + f] = tile[slot * a.n_mels + m];
-  }
-}
+// [round 4] A second form of this kernel -- one WAVE per frame with private ping-pong buffers, radix-4 Stockham passes and
+// no workgroup barrier inside a frame, window / twiddles / mel weights staged in LDS, 16 frames per workgroup -- was
+// written, passed every parity test (9.5e-7 against the oracle) and was measured against this one on one box
+// (profiles/r04_runG_melspec_wave_kernel_ab.log): 325 against 343 us at 67 584 frames of n_fft 1024, 35 against 25 us at
+// the benchmark's 1 056 frames, 812 against 518 us at n_fft 2048.  The barriers were not the bound: the kernel is
+// instruction-issue / LDS-latency bound per wave (address arithmetic and LDS instructions around ~10 flops per butterfly),
+// and the private buffers cut the resident waves per CU from 32 to 8.  Removed; what would pay is a register-resident
+// radix-8 FFT (three passes, two LDS exchanges per frame) -- DESIGN.md section 8.
 
 extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
                                        const float* window, const float* twiddle, float eps_power,
@@ -361,23 +194,6 @@ extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft
   int m = n_fft >> 1, l2 = 0;
   while ((1 << l2) < m) ++l2;
   a.log2m = l2;
-  const char* v1 = getenv("KANTTS_MELSPEC_V1");  // A/B switch: the round-1 kernel (a workgroup per frame group, radix 2)
-  const int nnz = out_mel ? ((2 * (m + 1) + 64 + 3) & ~3) : 0;  // room for a triangular bank's weights (see the kernel)
-  const size_t lds_w = ((size_t)n_fft + 2 * (size_t)m + (size_t)nnz + MEL_WAVES * (size_t)(5 * m + 4) +
-                        (size_t)MEL_WGF * (out_mel ? n_mels : 0)) * sizeof(float);
-  if (!(v1 && v1[0] == '1') && m >= 64 && lds_w <= 160 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&melspec_wave_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
-    const long long total = (long long)B * frames;
-    hipLaunchKernelGGL(melspec_wave_kernel, dim3((unsigned)kantts_cdiv(total, MEL_WGF)), dim3(MEL_WAVES * 64), lds_w,
-                       (hipStream_t)stream, a, nnz);
-    KANTTS_CHECK_LAUNCH();
-  }
   size_t lds = (size_t)m * 2 * sizeof(float2) + (size_t)(m + 1) * sizeof(float);
   if (lds > 160 * 1024) return KANTTS_E_UNSUPPORTED;
   hipLaunchKernelGGL(melspec_kernel, dim3(kantts_cdiv(frames, MEL_FB), B), dim3(MEL_THREADS), lds, (hipStream_t)stream, a);

@@ -504,7 +504,23 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
     check(rc, "bgemm_nt")
     if _profile is not None:
         e1.record()
-        _profile.append((e0, e1, 2.0 * M * N * sum(sg[4] for sg in segs)))
+        flops = 2.0 * M * N * sum(sg[4] for sg in segs)
+        _profile.append((e0, e1, flops))
+        # algorithmic bytes of the launch: every A segment, the weight slices, the result (and what the epilogue reads /
+        # writes beside it), each touched once at its storage dtype
+        ea = 4 if a0.dtype == torch.float32 else 2
+        nb = sum(M * sg[4] * ea + N * sg[4] * 2 for sg in segs)
+        if c is not None:
+            nb += M * N * (2 if g.c_bf16 else 4)
+        if res is not None:
+            nb += M * N * 4
+        if gate is not None:
+            nb += M * N * (2 if gate.dtype == torch.bfloat16 else 4)
+        if ln is not None:
+            nb += M * N * (2 if ln[3].dtype == torch.bfloat16 else 4)
+        if lnb is not None:
+            nb += M * 128 * 4 * (3 if lnb[4] is not None else 2)  # x in, dx out (+ the residual branch's gradient in)
+        _profile_families.append(("bgemm_nt", e0, e1, flops, float(nb)))
     return True
 
 
@@ -894,12 +910,27 @@ def rng_ptr(device):
 # bench instrumentation: HIP events (on the launch stream) around every GEMM launch
 _profile = None
 _profile_tags = []  # (kernel, shape dict, algorithmic bytes) of the conv launches, parallel to their _profile entries
+_profile_families = []  # (family, start event, end event, flops, algorithmic bytes) of the launches that account bytes
 
 
 def profile_begin():
     global _profile
     _profile = []
     del _profile_tags[:]
+    del _profile_families[:]
+
+
+def profile_families():
+    """Per kernel family of the launches recorded since profile_begin (call after profile_end, which synchronises):
+    launches, summed event time, algorithmic flops and bytes."""
+    out = {}
+    for name, e0, e1, flops, nbytes in _profile_families:
+        o = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        o["launches"] += 1
+        o["ms"] += e0.elapsed_time(e1)
+        o["flops"] += flops
+        o["bytes"] += nbytes
+    return out
 
 
 def profile_end():

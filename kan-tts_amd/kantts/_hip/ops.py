@@ -2101,8 +2101,10 @@ def sin_add(x, act_slope=None):
     return _SinAdd.apply(x)
 
 
-def upsample_weights(w, s):
-    """(Cin, Cout, 2s) transposed-conv weight -> bf16 polyphase images.  Narrow layers (csrc/upsample.hip): (linear,
+def upsample_weights(w, s, bias=None):
+    """(Cin, Cout, 2s) transposed-conv weight -> bf16 polyphase images; with ``bias`` a third element: the bias repeated
+    over the s phases, as the wide layers' contraction takes it (upsample_forward otherwise repeats it per call -- one
+    more launch per stage).  Narrow layers (csrc/upsample.hip): (linear,
     permuted) matrices (s*Cout, 2*Cin), row (r, co), column (j, ci) = w[ci, co, r + j*s], the permuted copy ordered for
     16-byte stores.  Wide layers (csrc/cconv.hip): (tap-major (2, s*Cout, Cin), None)."""
     Cin, Cout, K = w.shape
@@ -2110,14 +2112,15 @@ def upsample_weights(w, s):
     taps = K // s
     wb = ops_bf16.to_bf16(w) if w.numel() % 8 == 0 else w.detach().to(torch.bfloat16)  # one cast, then bf16 re-layouts
     wp = None
+    extra = () if bias is None else (bias.detach().repeat(s),)
     if taps != 2:  # (the fused dual-path stages of the generator: J = 4 taps at stride 2) tap-major image only
-        return wb.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).reshape(taps, s * Cout, Cin).contiguous(), None
+        return (wb.view(Cin, Cout, taps, s).permute(2, 3, 1, 0).reshape(taps, s * Cout, Cin).contiguous(), None) + extra
     if Cout % 32 == 0 and (Cin, Cout, s) in ((128, 64, 2), (64, 32, 2)):
         wl = wb.view(Cin, Cout, 2, s).permute(3, 1, 2, 0).reshape(s * Cout, 2 * Cin)
         wp = wl.view(s, Cout // 32, 4, 2, 4, 2 * Cin).permute(0, 1, 3, 2, 4, 5).reshape(s * Cout, 2 * Cin)
-        return wl, wp
+        return (wl, wp) + extra
     # wide layers: the tap-major image (2, s*Cout, Cin) of csrc/cconv.hip
-    return wb.view(Cin, Cout, 2, s).permute(2, 3, 1, 0).reshape(2, s * Cout, Cin).contiguous(), None
+    return (wb.view(Cin, Cout, 2, s).permute(2, 3, 1, 0).reshape(2, s * Cout, Cin).contiguous(), None) + extra
 
 
 _up_wcache = {}
@@ -2140,7 +2143,8 @@ def upsample_forward(act, w, bias, s, res=None, out_bf16=False, in_slope=1.0, pr
         else:
             prepared = upsample_weights(w, s)
             _up_wcache[id(w)] = ((w._version, w.data_ptr(), s), prepared, weakref.ref(w))
-    wl, wp = prepared if prepared is not None else upsample_weights(w, s)
+    prep = prepared if prepared is not None else upsample_weights(w, s)
+    wl, wp = prep[0], prep[1]
     out = torch.empty((B, T * s, Cout), device=act.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     r = _c(res) if res is not None else None
     if wp is not None and (Cin, Cout, s) in ((128, 64, 2), (64, 32, 2)) and (r is None or r.dtype == out.dtype):
@@ -2152,7 +2156,7 @@ def upsample_forward(act, w, bias, s, res=None, out_bf16=False, in_slope=1.0, pr
             check(rc, "upsample_stream")
     if in_slope != 1.0 or (r is not None and r.dtype != torch.float32) or wp is not None:
         return None
-    brep = bias.repeat(s) if bias is not None else None
+    brep = prep[2] if len(prep) > 2 else (bias.repeat(s) if bias is not None else None)
     # polyphase form = a ``taps``-tap convolution onto s*Cout channels (tap j reads token t - j)
     if not cconv(act, wl, out=None if out_bf16 else out, out_bf=out if out_bf16 else None, B=B, Tsrc=T, Tdst=T, groups=1,
                  CR=Cin, NG=s * Cout, K=taps, in_mul=1, in_add=0, in_kstep=-1, in_div=1, phases=1, bias=brep, res=r):

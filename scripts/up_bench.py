@@ -30,7 +30,7 @@ with torch.no_grad():
         layer = G.transpose_upsamples[i][1]
         acts.append(torch.randn(B, T, C, device="cuda").to(torch.bfloat16))
         w_ = effective_weight(layer.deconv).detach().contiguous()
-        ws.append((w_, layer.deconv.bias.detach(), s_, ops.upsample_weights(w_, s_)))
+        ws.append((w_, layer.deconv.bias.detach(), s_, ops.upsample_weights(w_, s_, layer.deconv.bias)))
         belems += B * T * C + B * T * s_ * (C // 2) + C * (C // 2) * 2 * s_
         T, C = T * s_, C // 2
 

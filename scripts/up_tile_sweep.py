@@ -38,7 +38,7 @@ with torch.no_grad():
         layer = G.transpose_upsamples[i][1]
         acts.append(torch.randn(B, T, C, device="cuda").to(torch.bfloat16))
         w_ = effective_weight(layer.deconv).detach().contiguous()
-        ws.append((w_, layer.deconv.bias.detach(), s_, ops.upsample_weights(w_, s_)))
+        ws.append((w_, layer.deconv.bias.detach(), s_, ops.upsample_weights(w_, s_, layer.deconv.bias)))
         T, C = T * s_, C // 2
     if len(sys.argv) > 1 and sys.argv[1] == "narrow":
         for i in (2, 3):
