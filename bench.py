@@ -203,10 +203,16 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
     # class; reported so that the choice is visible).  Runs in a child process under a hard time limit: one iteration at
     # 256 threads must not be able to eat the bench's time budget.
     all_cores = _usable_cores()
-    all_core = None
+    all_core = eight = None
     if all_cores > cores and CPU_THREADS["n"] is None:
-        all_core = _oracle_probe(all_cores, B, limit_s=90.0, ref_s=dt_off)
+        # a quarter of the batch (B = 8: the same model, 8 of the 32 seeded utterances' worth of frames) so that the
+        # probe FINISHES inside its limit -- at B = 32 one iteration on 256 threads did not end within 90 s in round 3
+        all_core = _oracle_probe(all_cores, 8, limit_s=60.0, ref_s=dt_off)
         all_core["visible_cores"] = os.cpu_count() or 1
+        all_core["batch"] = 8
+    if cores != 8 and CPU_THREADS["n"] is None:
+        eight = _oracle_probe(8, 8, limit_s=60.0, ref_s=dt_off)  # N = 8 for comparability with its probes
+        eight["batch"] = 8
 
     # ---- parity of the HIP path at the benchmarked shape (dropout forced to 0 on both sides)
     parity = {}
@@ -247,7 +253,7 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
                                                                 keep["out"]["LR_length_rounded"]))}
         del g, res, total
     base = {"value": frames / dt_off, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "value_dropout_on": frames / dt_on, "all_cores": all_core,
+            "value_dropout_on": frames / dt_on, "all_cores": all_core, "threads_8": eight,
             "sample": "oracle/torch_oracle.py fwd+losses+bwd, fp32, the full seeded batch B=%d (%d valid frames): "
                       "dropout off 2 warm-up + %d timed, %.2f s/iter; dropout on (as shipped) 1 warm-up + %d timed, "
                       "%.2f s/iter; torch.set_num_threads(%d) of %d host cores" % (B, frames, n_off, dt_off, n_on, dt_on,
@@ -604,7 +610,7 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
     return res
 
 
-def hifigan_cpu_baseline(B=2, T_wav=8192, budget_s=10.0):
+def hifigan_cpu_baseline(B=4, T_wav=8192, budget_s=14.0):
     """CPU oracle port of the HiFi-GAN V1 GAN step (oracle/hifigan_oracle.py: generator forward + mel / adversarial /
     feature-matching generator loss + backward, generator re-run, discriminator loss + backward; optimizer updates
     omitted) and of the generator forward alone (no grad), at batch ``B`` x 8192 samples on all host cores."""

@@ -313,6 +313,20 @@ typedef struct kantts_wn_desc {
 int kantts_weight_norm_table(const float* flat, float* w, void* wf_bf16, void* wd_bf16, const kantts_wn_desc* table_dev,
                              int ndesc, int total_tiles, void* stream);
 
+/* Backward of the same reparametrisation for up to KANTTS_WN_BWD_MAX layers of one network in one launch: layer l of the
+ * launch is table entry desc[l], its tap-major weight gradient (K, rows, cin) fp32 is dw[l]; dv (rows, cin, K) and dg
+ * (rows) are written into the network's flat GRADIENT arena at the entry's v_off / g_off (the parameters' own offsets).
+ * tile0[l] = 8-row tiles of the layers before l in THIS launch (tile0[nl] = their total = the grid). */
+#define KANTTS_WN_BWD_MAX 64
+typedef struct kantts_wn_bwd_args {
+  const float* dw[KANTTS_WN_BWD_MAX];
+  int32_t desc[KANTTS_WN_BWD_MAX];
+  int32_t tile0[KANTTS_WN_BWD_MAX + 1];
+  int32_t nl;
+} kantts_wn_bwd_args;
+int kantts_weight_norm_table_bwd(const float* flat, float* grad_flat, const kantts_wn_desc* table_dev,
+                                 const kantts_wn_bwd_args* args, void* stream);
+
 /* y = sin(x) + x and its backward dx = dy * (cos(x) + 1)  (kantts/models/hifigan/hifigan.py:157) */
 int kantts_sinadd_fwd(const float* x, float* y, long long n, void* stream);
 int kantts_sinadd_bwd(const float* dy, const float* x, float* dx, long long n, void* stream);

@@ -166,6 +166,61 @@ extern "C" int kantts_weight_norm_table(const float* flat, float* w, void* wf_bf
   KANTTS_CHECK_LAUNCH();
 }
 
+// Backward for many layers in one launch (kantts_weight_norm_table_bwd): per row the arithmetic of
+// weight_norm_strided_bwd_kernel on the tap-major gradient (element (r, ci, k) at (k * rows + r) * cin + ci).
+__global__ __launch_bounds__(256) void weight_norm_table_bwd_kernel(const float* __restrict__ flat, float* __restrict__ grad,
+                                                                   const kantts_wn_desc* __restrict__ tab,
+                                                                   const kantts_wn_bwd_args a) {
+  __shared__ float red[4];
+  const int tile = blockIdx.x;
+  int lo = 0, hi = a.nl - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.tile0[mid] <= tile)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const kantts_wn_desc d = tab[a.desc[lo]];
+  const float* dw = a.dw[lo];
+  const int cin = d.cin, K = d.K, rows = d.rows, cols = cin * K;
+  const int r0 = (tile - a.tile0[lo]) * WN_R, nr = min(WN_R, rows - r0);
+  for (int i = 0; i < nr; ++i) {
+    const int r = r0 + i;
+    const float* vr = flat + d.v_off + (long long)r * cols;
+    float s = 0.f, dd = 0.f;
+    for (int j = threadIdx.x; j < cols; j += 256) {
+      const int k = j / cin, ci = j - k * cin;
+      const float vv = vr[ci * K + k];
+      s += vv * vv;
+      dd += dw[((long long)k * rows + r) * cin + ci] * vv;
+    }
+    s = kantts_block_sum(s, red);
+    dd = kantts_block_sum(dd, red);
+    const float nrm = sqrtf(s);
+    const float gr = flat[d.g_off + r];
+    const float dgv = dd / nrm;
+    if (threadIdx.x == 0) grad[d.g_off + r] = dgv;
+    const float aa = gr / nrm, bq = dgv / nrm;
+    float* o = grad + d.v_off + (long long)r * cols;
+    for (int j = threadIdx.x; j < cols; j += 256) {
+      const int k = j / cin, ci = j - k * cin;
+      o[ci * K + k] = aa * (dw[((long long)k * rows + r) * cin + ci] - vr[ci * K + k] * bq);
+    }
+  }
+}
+
+extern "C" int kantts_weight_norm_table_bwd(const float* flat, float* grad_flat, const kantts_wn_desc* table_dev,
+                                            const kantts_wn_bwd_args* args, void* stream) {
+  if (!flat || !grad_flat || !table_dev || !args || args->nl < 0 || args->nl > KANTTS_WN_BWD_MAX) return KANTTS_E_BADARG;
+  if (args->nl == 0 || args->tile0[args->nl] == 0) return KANTTS_OK;
+  for (int l = 0; l < args->nl; ++l)
+    if (!args->dw[l]) return KANTTS_E_BADARG;
+  hipLaunchKernelGGL(weight_norm_table_bwd_kernel, dim3(args->tile0[args->nl]), dim3(256), 0, (hipStream_t)stream, flat,
+                     grad_flat, table_dev, *args);
+  KANTTS_CHECK_LAUNCH();
+}
+
 __global__ __launch_bounds__(256) void weight_norm_strided_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
                                                                      const float* __restrict__ g, float* __restrict__ dv,
                                                                      float* __restrict__ dg, int cin, int K, long long rs,

@@ -147,6 +147,15 @@ class LnBwdArgs(Structure):
     ]
 
 
+WN_BWD_MAX = 64
+
+
+class WnBwdArgs(Structure):
+    """kantts_wn_bwd_args (include/kantts_hip.h)."""
+    _fields_ = [("dw", c_void_p * WN_BWD_MAX), ("desc", c_int32 * WN_BWD_MAX), ("tile0", c_int32 * (WN_BWD_MAX + 1)),
+                ("nl", c_int32)]
+
+
 class BGemmTnArgs(Structure):
     """kantts_bgemm_tn_args (include/kantts_hip.h)."""
     _fields_ = [
@@ -271,6 +280,7 @@ def lib():
         L.kantts_ragged_rows_f32.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
         L.kantts_weight_norm_tap_images.argtypes = [p, p, p, p, p, i, i, i, i, p]
         L.kantts_weight_norm_table.argtypes = [p, p, p, p, p, i, i, p]
+        L.kantts_weight_norm_table_bwd.argtypes = [p, p, p, POINTER(WnBwdArgs), p]
         L.kantts_ragged_rows_i64.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
         _lib = L
     return _lib
@@ -290,7 +300,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
-    "kantts_weight_norm_table",
+    "kantts_weight_norm_table", "kantts_weight_norm_table_bwd",
 ]
 
 

@@ -163,6 +163,7 @@ class _WgradOverlap:
         from . import deferred_tn
 
         deferred_tn.flush()  # recorded weight gradients: grouped launches on the current stream
+        flush_weight_norm_backward()  # ... and the weight-norm backward of whole networks (one launch each)
         side_branch.join()
         side_branch.release()
         if self._used:
@@ -1950,20 +1951,34 @@ class _WeightNormImage(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, g, holder):
         ctx.save_for_backward(v, g)
+        ctx.holder = holder
         return holder[1].view(holder[1].shape)  # (holder: not a tensor argument -- the result is no view of an input)
 
     @staticmethod
     def backward(ctx, dw):
         v, g = ctx.saved_tensors
+        dw = _c(dw)
+        arena = ctx.holder[0]()
+        if arena is not None and arena.defer_weight_norm_backward(ctx.holder[5], dw):
+            # one table-driven launch per network before the optimizer step (ParamArena.flush_weight_norm_backward, called
+            # from wgrad_overlap.join()): autograd receives views of the gradient arena that are filled then
+            return arena.grad_slot(v), arena.grad_slot(g), None
         v = _c(v)
         if v.dim() == 4:
             v = v.squeeze(-1)
-        dw = _c(dw)
         Cout, cin, K = v.shape
         dv, dg = torch.empty_like(v), torch.empty_like(g)
         check(lib().kantts_weight_norm_strided_bwd(ptr(dw, torch.float32), ptr(v), ptr(g), ptr(dv), ptr(dg), Cout, cin, K,
                                                    cin, 1, Cout * cin, stream()), "weight_norm_strided_bwd")
         return dv.view(ctx.saved_tensors[0].shape), dg, None
+
+
+wn_pending_arenas = []  # arenas with deferred weight-norm backward work (flushed by wgrad_overlap.join)
+
+
+def flush_weight_norm_backward():
+    while wn_pending_arenas:
+        wn_pending_arenas.pop().flush_weight_norm_backward()
 
 
 _WIMG_ATTR = "_kantts_bf16_weight_images"

@@ -107,6 +107,10 @@ class ParamArena:
         if not layers:
             return 0
         dev = self.flat.device
+        self._wn_tiles = []    # 8-row tiles per table entry
+        self._wn_pending = []  # (table entry, weight gradient) of this backward pass, see defer_weight_norm_backward
+        self._wn_defer = False
+        self._index_of = index
         self._wn_w = torch.zeros(max(w_off, 8), device=dev, dtype=torch.float32)
         self._wn_wf = torch.zeros(max(wf_off, 8), device=dev, dtype=torch.bfloat16)
         self._wn_wd = torch.zeros(max(wd_off, 8), device=dev, dtype=torch.bfloat16)
@@ -122,7 +126,9 @@ class ParamArena:
             n = k * cout * cin
             m._kantts_wn = (ref, self._wn_w[wo:wo + n].view(k, cout, cin),
                             None if fo < 0 else self._wn_wf[fo:fo + n].view(k, cout, cin),
-                            None if do < 0 else self._wn_wd[do:do + n].view(k, groups, cin, cout // groups), groups)
+                            None if do < 0 else self._wn_wd[do:do + n].view(k, groups, cin, cout // groups), groups,
+                            len(self._wn_tiles))
+            self._wn_tiles.append((cout + 7) // 8)
         # once per forward of the WHOLE module, before it forks its branch streams (every branch reads the images)
         def _pre(m, a):  # (a pre-hook's return value replaces the module's input: return None)
             self.refresh_weight_norm_images()
@@ -130,6 +136,41 @@ class ParamArena:
         self.module.register_forward_pre_hook(_pre)
         self.module.register_load_state_dict_post_hook(lambda m, keys: self.mark_shadow_stale())
         return len(layers)
+
+    # ---- backward of the reparametrisation, deferred to ONE launch per network (kantts_weight_norm_table_bwd) ----------
+    def grad_slot(self, p):
+        """A fresh view of parameter ``p``'s range of the gradient arena (a new tensor object: autograd keeps it as
+        ``p.grad`` without copying; packing it into the arena later is a copy onto itself)."""
+        i = self._index_of[id(p)]
+        return self.grad[self.offsets[i]:self.offsets[i] + p.numel()].view(p.shape)
+
+    def defer_weight_norm_backward(self, entry, dw):
+        """Record (table entry, tap-major weight gradient) if an optimizer step of this arena will follow (zero_grad armed
+        it) -- else the caller runs the per-layer kernel at once (code that reads .grad right after backward())."""
+        if not self._wn_defer or self._wn_table is None:
+            return False
+        if not self._wn_pending:
+            ops.wn_pending_arenas.append(self)
+        self._wn_pending.append((int(entry), dw))
+        return True
+
+    def flush_weight_norm_backward(self):
+        import ctypes
+
+        from kantts._hip import WN_BWD_MAX, WnBwdArgs, check, lib, ptr, stream
+
+        pend, self._wn_pending = self._wn_pending, []
+        for s0 in range(0, len(pend), WN_BWD_MAX):
+            chunk = pend[s0:s0 + WN_BWD_MAX]
+            a = WnBwdArgs()
+            t = 0
+            for l, (entry, dw) in enumerate(chunk):
+                a.dw[l], a.desc[l], a.tile0[l] = ptr(dw, torch.float32), entry, t
+                t += self._wn_tiles[entry]
+            a.tile0[len(chunk)] = t
+            a.nl = len(chunk)
+            check(lib().kantts_weight_norm_table_bwd(ptr(self.flat, torch.float32), ptr(self.grad, torch.float32),
+                                                     ptr(self._wn_table), ctypes.byref(a), stream()), "weight_norm_table_bwd")
 
     def weight_norm_images_fresh(self):
         return self._wn_table is not None and self._wn_version == self._weights_version
@@ -306,9 +347,12 @@ class ParamArena:
             self._hooked = True
 
     def begin_step(self):
-        """Arm the bucket counters for one backward pass (ArenaAdam.zero_grad calls this).  An un-armed arena ignores
+        """Arm the bucket counters for one backward pass (ArenaAdam.zero_grad calls this); weight-norm backward passes of
+        this arena are deferred from here until the step (flush_weight_norm_backward).  An un-armed arena ignores
         gradient arrivals: the discriminators' parameters also receive gradients during the generator's backward, but
         those are discarded by the next zero_grad and must not be exchanged."""
+        if self._wn_table is not None and not __import__("os").environ.get("KANTTS_NO_WEIGHT_NORM_TABLE"):
+            self._wn_defer = True
         if not getattr(self, "overlap", False):
             return
         for b in self.buckets:
@@ -487,6 +531,7 @@ class ArenaAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         arena = self.arena
         ops.wgrad_overlap.join()  # weight gradients produced on the side stream (no-op unless enabled)
+        arena._wn_defer = False
         if packed:
             g = arena.grad
         elif getattr(arena, "overlap", False) and arena._active:

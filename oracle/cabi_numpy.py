@@ -1421,6 +1421,19 @@ class EmulatedLib:
                                          int(wd) + 2 * wd_off if (wd and wd_off >= 0) else None, rows, cin, K, groups)
         return 0
 
+    def kantts_weight_norm_table_bwd(self, flat, grad, table, args_ref, stream):
+        """Per listed layer: kantts_weight_norm_strided_bwd on the tap-major gradient, dv / dg into the gradient arena."""
+        a = args_ref._obj
+        for l in range(a.nl):
+            e = _arr(table, (a.desc[l] + 1) * 8, np.int64).reshape(-1, 8)[a.desc[l]]
+            v_off, g_off = int(e[0]), int(e[1])
+            rows, cin = int(e[5]) & 0xffffffff, int(e[5]) >> 32
+            K = int(e[6]) & 0xffffffff
+            self.kantts_weight_norm_strided_bwd(int(a.dw[l]), int(flat) + 4 * v_off, int(flat) + 4 * g_off,
+                                                int(grad) + 4 * v_off, int(grad) + 4 * g_off, rows, cin, K, cin, 1,
+                                                rows * cin, stream)
+        return 0
+
     def kantts_weight_norm_strided_fwd(self, v, g, w, rows, cin, K, rs, cs, ks, stream):
         V = _arr(v, rows * cin * K).reshape(rows, cin, K).astype(np.float64)
         G = _arr(g, rows).astype(np.float64)

@@ -746,7 +746,7 @@ def test_weight_norm_table_equals_per_layer_launches_emulated(emulated_cabi, mon
     import os  # noqa: F401
 
     counts = {}
-    for name in ("kantts_weight_norm_table", "kantts_weight_norm_tap_images"):
+    for name in ("kantts_weight_norm_table", "kantts_weight_norm_tap_images", "kantts_weight_norm_table_bwd"):
         orig = getattr(emulated_cabi, name)
         monkeypatch.setattr(emulated_cabi, name, (lambda o, n: lambda *a: (counts.__setitem__(n, counts.get(n, 0) + 1), o(*a))[1])(orig, name),
                             raising=False)
@@ -756,12 +756,65 @@ def test_weight_norm_table_equals_per_layer_launches_emulated(emulated_cabi, mon
     # discriminators (updated at the end of step 1) and G again -> 7 launches, none per layer
     assert with_table.get("kantts_weight_norm_table", 0) == 7, with_table
     assert with_table.get("kantts_weight_norm_tap_images", 0) == 0, with_table
+    # backward of the reparametrisation: one launch per network and backward pass (generator phase: the generator; the
+    # discriminator phase: each discriminator) = 3 per step
+    assert with_table.get("kantts_weight_norm_table_bwd", 0) == 6, with_table
+    assert without.get("kantts_weight_norm_table_bwd", 0) == 0, without
     assert without.get("kantts_weight_norm_table", 0) == 0 and without.get("kantts_weight_norm_tap_images", 0) > 100, without
 
 
 def test_weight_norm_table_images_equal_the_per_layer_kernel_emulated(emulated_cabi):
     """The image comparison alone (the variant tests/test_kernel_source_on_cpu.py runs on the kernel source)."""
     _wn_table_check("cpu", train=False)
+
+
+def _wn_table_bwd_check(device):
+    """kantts_weight_norm_table_bwd (every layer's dv / dg from one launch, written into the gradient arena) against the
+    per-layer kantts_weight_norm_strided_bwd on the same weight gradients."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+    from kantts.models.hifigan.hifigan import MultiPeriodDiscriminator
+    from kantts.train.optim import ArenaAdam, ParamArena
+
+    torch.manual_seed(5)
+    net = MultiPeriodDiscriminator(periods=[2, 3]).to(device)
+    arena = ParamArena(net)
+    assert arena.build_weight_norm_images() >= 8
+    opt = ArenaAdam(arena, lr=1e-3)
+    opt.zero_grad()  # arms the deferral
+    g = torch.Generator().manual_seed(6)
+    want = {}
+    for m in net.modules():
+        wn = getattr(m, "_kantts_wn", None)
+        if wn is None:
+            continue
+        v = m.weight_v.detach()
+        v3 = v.squeeze(-1) if v.dim() == 4 else v
+        cout, cin, k = v3.shape
+        dw = torch.randn(k, cout, cin, generator=g).to(device)
+        dv, dg = torch.empty_like(v3), torch.empty_like(m.weight_g.detach())
+        hip.check(hip.lib().kantts_weight_norm_strided_bwd(hip.ptr(dw), hip.ptr(v3.contiguous()), hip.ptr(m.weight_g.detach()),
+                                                           hip.ptr(dv), hip.ptr(dg), cout, cin, k, cin, 1, cout * cin,
+                                                           hip.stream()), "strided_bwd")
+        want[id(m)] = (dv.reshape(v.shape).clone(), dg.clone())
+        assert arena.defer_weight_norm_backward(wn[5], dw)
+    ops.flush_weight_norm_backward()
+    n = 0
+    for m in net.modules():
+        if id(m) in want:
+            dv, dg = want[id(m)]
+            assert rel_l2(arena.grad_slot(m.weight_v), dv) <= 1e-5 and rel_l2(arena.grad_slot(m.weight_g), dg) <= 1e-5
+            n += 1
+    assert n >= 8 and not arena._wn_pending
+
+
+def test_weight_norm_table_backward_equals_per_layer_emulated(emulated_cabi):
+    _wn_table_bwd_check("cpu")
+
+
+@pytest.mark.gpu
+def test_weight_norm_table_backward_equals_per_layer_gpu():
+    _wn_table_bwd_check("cuda")
 
 
 @pytest.mark.gpu

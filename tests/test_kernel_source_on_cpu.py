@@ -72,6 +72,7 @@ from test_hifigan import (  # noqa: F401
     test_multiscale_discriminator_with_average_pooling_matches_the_reference_fixture,
     test_generator_with_relu_activation_matches_the_reference_fixture,
     test_weight_norm_table_images_equal_the_per_layer_kernel_emulated,
+    test_weight_norm_table_backward_equals_per_layer_emulated,
     test_one_channel_weight_gradient_with_a_persistent_grid_emulated,
 )
 from test_hifigan_nsf import test_nsf_generator_host_logic_matches_reference_fixture  # noqa: F401
