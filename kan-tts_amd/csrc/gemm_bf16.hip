@@ -207,8 +207,6 @@ extern "C" int kantts_bgemm_nt_lnbwd(const kantts_bgemm_args* gp, const kantts_l
 // load latencies of a short token tile.  Hence: 64 x 128 output tiles (more tiles, fewer slices for the same number of
 // workgroups), token tiles of 64 with the loads of two tiles in flight, and a slice count capped by the atomics budget.
 #define TN_BT 64                 // tokens per tile (two MFMA k-steps)
-#define TN_LDA (64 + 16)         // pitch of the [token][64 channels] image of A
-#define TN_LDB (128 + 16)        // pitch of the [token][128 channels] image of B
 // The grouped form (kantts_bgemm_tn_grouped) runs up to KANTTS_TN_MAX_GROUP problems of one shape in a single launch:
 // weight gradients are leaves of the backward graph, so the host defers them and issues every layer's gradient of one
 // shape together -- each problem then needs only a 1/n_problems share of the token split (n_problems times fewer
@@ -223,15 +221,24 @@ struct TnGroupArgs {
   uint64_t a_drop_seed[KANTTS_TN_MAX_GROUP];
 };
 
-template <bool A_F32, bool B_F32>
+// BN x BK = output tile (channels of A x channels of B).  64 x 128 is the round-2 tile; [round 4] 128 x 256 for the large
+// problems: with 64 x 128 tiles every element of A is re-read K / 128 times and every element of B N / 64 times from L2, and
+// the grouped launches of the decoder / postnet weight gradients ran AT the L2 bandwidth that implies (e.g. four
+// 19 584 x 256 x 512 problems: 640 MB of tile traffic in 145 us; three 512 x 256 ones: 600 MB in 214 us -- kernel trace
+// profiles/r04_runH_*).  The four-times larger tile halves both re-read factors.
+template <bool A_F32, bool B_F32, int BN, int BK>
 __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs ga) {
-  constexpr int IMG_A = TN_BT * TN_LDA * 2, IMG_B = TN_BT * TN_LDB * 2, STAGE = IMG_A + IMG_B;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  constexpr int LDA = BN + 16, LDB = BK + 16;  // pitches of the [token][channel] images
+  constexpr int IMG_A = TN_BT * LDA * 2, IMG_B = TN_BT * LDB * 2, STAGE = IMG_A + IMG_B;
+  constexpr int NA = TN_BT * (BN / 8) / BG_THREADS, NB = TN_BT * (BK / 8) / BG_THREADS;  // 16-byte chunks per thread
+  constexpr int CA = BN / 8, CB = BK / 8;                                                // chunks per token row
+  constexpr int MR = BN / 32, NR = BK / 32;  // 16-wide fragments per wave and axis (waves 2 x 2)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   kantts_bgemm_tn_args g = ga.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;  // wave tile: 32 (n) x 64 (k)
+  const int wr = wave >> 1, wc = wave & 1;  // wave tile: BN / 2 (n) x BK / 2 (k)
   const int li = lane & 15, kg = lane >> 4;
-  const int n0 = blockIdx.y * 64, c0 = blockIdx.x * 128;
+  const int n0 = blockIdx.y * BN, c0 = blockIdx.x * BK;
   const int per_prob = g.ntaps * g.slices;
   const int prob = blockIdx.z / per_prob, zr = blockIdx.z % per_prob;
   const int tap = zr / g.slices, slice = zr % g.slices;
@@ -243,32 +250,31 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
   const int shift = g.shift0 + tap * g.shift_step;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
 
-  f32x4 acc[2][4];
+  f32x4 acc[MR][NR];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MR; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NR; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float colsum = 0.f;
   const bool do_bias = g.db && blockIdx.x == 0 && tap == 0;
 
-  // A: 64 tokens x 8 chunks = 512 chunks (2 per thread); B: 64 tokens x 16 chunks = 1024 (4 per thread)
-  u32x4 ra0[2], rb0[4], ra1[2], rb1[4];
+  u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
   const int ntile = (g.M + TN_BT - 1) / TN_BT;
 
   auto fetch = [&](int t, u32x4* ra, u32x4* rb) {
     const int m0 = t * TN_BT;
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < NA; ++v) {
       const int id = tid + BG_THREADS * v;
-      const int m = m0 + (id >> 3), nc = n0 + (id & 7) * 8;
+      const int m = m0 + id / CA, nc = n0 + (id % CA) * 8;
       const bool ok = m < g.M && nc < g.N;
       ra[v] = bg_load8<A_F32>(g.a, (long long)m * g.lda + nc, ok, A_F32 ? g.a_drop_p : 0.f, g.a_drop_seed + seed_off,
                               (uint64_t)m * (uint64_t)g.N + (uint64_t)nc);
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < NB; ++v) {
       const int id = tid + BG_THREADS * v;
-      const int m = m0 + (id >> 4), kc = c0 + (id & 15) * 8;
+      const int m = m0 + id / CB, kc = c0 + (id % CB) * 8;
       bool ok = m < g.M && kc < g.K;
       long long src = m;
       if (shift != 0) {
@@ -283,44 +289,44 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
     unsigned char* Ab = lds + buf * STAGE;
     unsigned char* Bb = Ab + IMG_A;
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < NA; ++v) {
       const int id = tid + BG_THREADS * v;
-      *reinterpret_cast<u32x4*>(Ab + ((id >> 3) * TN_LDA + (id & 7) * 8) * 2) = ra[v];
+      *reinterpret_cast<u32x4*>(Ab + ((id / CA) * LDA + (id % CA) * 8) * 2) = ra[v];
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < NB; ++v) {
       const int id = tid + BG_THREADS * v;
-      *reinterpret_cast<u32x4*>(Bb + ((id >> 4) * TN_LDB + (id & 15) * 8) * 2) = rb[v];
+      *reinterpret_cast<u32x4*>(Bb + ((id / CB) * LDB + (id % CB) * 8) * 2) = rb[v];
     }
   };
   auto compute = [&](int buf) {
     const __bf16* Ah = reinterpret_cast<const __bf16*>(lds + buf * STAGE);
     const __bf16* Bh = reinterpret_cast<const __bf16*>(lds + buf * STAGE + IMG_A);
-    if (do_bias && tid < 64) {
+    if (do_bias && tid < BN) {
       float q = 0.f;
 #pragma unroll 8
-      for (int m = 0; m < TN_BT; ++m) q += (float)Ah[m * TN_LDA + tid];
+      for (int m = 0; m < TN_BT; ++m) q += (float)Ah[m * LDA + tid];
       colsum += q;
     }
 #pragma unroll
     for (int kk = 0; kk < TN_BT / 32; ++kk) {
-      bf16x8 af[2], bf[4];
+      bf16x8 af[MR], bf[NR];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const __bf16* p = Ah + (kk * 32 + kg * 4 + (li >> 2)) * TN_LDA + wr * 32 + m * 16 + (li & 3) * 4;
-        const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * TN_LDA);
+      for (int m = 0; m < MR; ++m) {
+        const __bf16* p = Ah + (kk * 32 + kg * 4 + (li >> 2)) * LDA + wr * (BN / 2) + m * 16 + (li & 3) * 4;
+        const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * LDA);
         af[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const __bf16* p = Bh + (kk * 32 + kg * 4 + (li >> 2)) * TN_LDB + wc * 64 + n * 16 + (li & 3) * 4;
-        const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * TN_LDB);
+      for (int n = 0; n < NR; ++n) {
+        const __bf16* p = Bh + (kk * 32 + kg * 4 + (li >> 2)) * LDB + wc * (BK / 2) + n * 16 + (li & 3) * 4;
+        const bf16x4 lo = bg_tr4(p), hi = bg_tr4(p + 16 * LDB);
         bf[n] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < NR; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[n], acc[m][n], 0, 0, 0);
     }
   };
@@ -343,21 +349,46 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
     }
   }
 
-  if (do_bias && tid < 64 && (n0 + tid) < g.N && colsum != 0.f) atomicAdd(&g.db[n0 + tid], colsum * g.alpha);
+  if (do_bias && tid < BN && (n0 + tid) < g.N && colsum != 0.f) atomicAdd(&g.db[n0 + tid], colsum * g.alpha);
   float* cbase = g.c + (long long)tap * g.c_ts;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MR; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < NR; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = n0 + wr * 32 + m * 16 + kg * 4 + r;  // output row  = channel of A
-        const int j = c0 + wc * 64 + n * 16 + li;          // output col  = channel of B
+        const int i = n0 + wr * (BN / 2) + m * 16 + kg * 4 + r;  // output row  = channel of A
+        const int j = c0 + wc * (BK / 2) + n * 16 + li;          // output col  = channel of B
         if (i < g.N && j < g.K) {
           const float v = acc[m][n][r] * g.alpha;
           if (v != 0.f) atomicAdd(cbase + (long long)i * g.c_ns + (long long)j * g.c_ks, v);
         }
       }
+}
+
+template <bool A_F32, bool B_F32, int BN, int BK>
+static int bg_tn_go(TnGroupArgs& ga, dim3 grid, hipStream_t st) {
+  constexpr size_t LDS = 2 * (size_t)TN_BT * ((BN + 16) + (BK + 16)) * 2;
+  static bool attr_set = false;
+  if (!attr_set && LDS > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_tn_kernel<A_F32, B_F32, BN, BK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bgemm_tn_kernel<A_F32, B_F32, BN, BK>), grid, dim3(BG_THREADS), LDS, st, ga);
+  KANTTS_CHECK_LAUNCH();
+}
+
+template <int BN, int BK>
+static int bg_tn_dispatch(TnGroupArgs& ga, dim3 grid, hipStream_t st) {
+  const kantts_bgemm_tn_args& g = ga.g;
+  if (g.a_f32) {
+    if (g.b_f32) return bg_tn_go<true, true, BN, BK>(ga, grid, st);
+    return bg_tn_go<true, false, BN, BK>(ga, grid, st);
+  }
+  if (g.b_f32) return bg_tn_go<false, true, BN, BK>(ga, grid, st);
+  return bg_tn_go<false, false, BN, BK>(ga, grid, st);
 }
 
 static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
@@ -370,30 +401,29 @@ static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
     if (!bg_aligned16(ga.a[p]) || !bg_aligned16(ga.b[p])) return KANTTS_E_UNSUPPORTED;
   }
   if ((g.shift0 != 0 || g.shift_step != 0) && g.T <= 0) return KANTTS_E_BADARG;
-  const int tiles = kantts_cdiv(g.N, 64) * kantts_cdiv(g.K, 128) * g.ntaps * ga.nprob;
+  // tile: 128 x 256 when the problem is large enough for its re-read factors to matter and still leaves >= 24 tiles
+  // (KANTTS_TN_TILE=64 / 128 forces one: A/B switch and tests)
+  const char* tenv = getenv("KANTTS_TN_TILE");
+  const int forced = tenv ? atoi(tenv) : 0;
+  const long long big_tiles = (long long)kantts_cdiv(g.N, 128) * kantts_cdiv(g.K, 256) * g.ntaps * ga.nprob;
+  bool big = g.M >= 4096 && g.N >= 128 && g.K >= 256 && big_tiles >= 24;
+  if (forced == 64) big = false;
+  if (forced == 128) big = true;
+  const int BN = big ? 128 : 64, BK = big ? 256 : 128;
+  const int tiles = kantts_cdiv(g.N, BN) * kantts_cdiv(g.K, BK) * g.ntaps * ga.nprob;
   const int ntile = kantts_cdiv(g.M, TN_BT);
   int slices = g.slices;
   if (slices <= 0) {
-    slices = kantts_cdiv(320, tiles);                                                      // about 1.25 workgroups per CU
+    slices = kantts_cdiv(big ? 256 : 320, tiles);                                          // about one workgroup per CU
     const long long cap = (3ll << 19) / ((long long)g.N * g.K * g.ntaps * ga.nprob) + 1;  // <= ~1.5 M atomics per launch
     if (slices > cap) slices = (int)cap;
   }
   if (slices > ntile) slices = ntile;
   if (slices < 1) slices = 1;
   g.slices = slices;
-  dim3 grid(kantts_cdiv(g.K, 128), kantts_cdiv(g.N, 64), ga.nprob * g.ntaps * slices);
-  if (g.a_f32) {
-    if (g.b_f32)
-      hipLaunchKernelGGL((bgemm_tn_kernel<true, true>), grid, dim3(BG_THREADS), 0, st, ga);
-    else
-      hipLaunchKernelGGL((bgemm_tn_kernel<true, false>), grid, dim3(BG_THREADS), 0, st, ga);
-  } else {
-    if (g.b_f32)
-      hipLaunchKernelGGL((bgemm_tn_kernel<false, true>), grid, dim3(BG_THREADS), 0, st, ga);
-    else
-      hipLaunchKernelGGL((bgemm_tn_kernel<false, false>), grid, dim3(BG_THREADS), 0, st, ga);
-  }
-  KANTTS_CHECK_LAUNCH();
+  dim3 grid(kantts_cdiv(g.K, BK), kantts_cdiv(g.N, BN), ga.nprob * g.ntaps * slices);
+  if (big) return bg_tn_dispatch<128, 256>(ga, grid, st);
+  return bg_tn_dispatch<64, 128>(ga, grid, st);
 }
 
 extern "C" int kantts_bgemm_tn(const kantts_bgemm_tn_args* gp, void* stream) {

@@ -413,3 +413,41 @@ def test_layernorm_backward_as_the_epilogue_of_the_input_gradient(M, a_f32, with
         assert float(dx1[rows.bool()].abs().max()) == 0.0
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", ["64", "128"])
+def test_weight_gradient_contraction_with_both_output_tiles_gpu(tile, monkeypatch):
+    """bgemm_tn_kernel with the 64 x 128 and the 128 x 256 output tile (KANTTS_TN_TILE forces one; on its own the launcher
+    takes the large tile for M >= 4096 problems with enough tiles) against a float64 contraction of the bf16-rounded
+    operands: the decoder feed-forward shape, a ragged one, a 3-tap convolution gradient with a bias gradient."""
+    import kantts._hip as hip
+
+    monkeypatch.setenv("KANTTS_TN_TILE", tile)
+    g = torch.Generator().manual_seed(int(tile))
+    for (M, N, K, a32, b32, taps, T) in ((6528, 128, 1024, True, False, 1, 0), (1000, 136, 264, False, True, 1, 0),
+                                          (2048, 1024, 128, False, False, 3, 64), (4500, 256, 512, True, True, 1, 0)):
+        a = torch.randn(M, N, generator=g) * 0.5
+        b = torch.randn(M, K, generator=g) * 0.5
+        ad = (a if a32 else a.to(torch.bfloat16)).cuda()
+        bd = (b if b32 else b.to(torch.bfloat16)).cuda()
+        c = torch.zeros(taps, N, K, device="cuda")
+        db = torch.zeros(N, device="cuda")
+        assert hip.bgemm_tn(ad, N, bd, K, M, N, K, c, K, 1, c_ts=N * K, T=T, ntaps=taps, shift0=-(taps // 2), shift_step=1,
+                            db=db)
+        torch.cuda.synchronize()
+        A = a.to(torch.bfloat16).double()  # fp32 operands are rounded to bf16 when a tile is staged
+        Bq = b.to(torch.bfloat16).double()
+        for tap in range(taps):
+            sh = tap - taps // 2
+            Bs = torch.zeros_like(Bq)
+            if sh == 0:
+                Bs = Bq
+            else:
+                idx = torch.arange(M)
+                tt = idx % T + sh
+                ok = (tt >= 0) & (tt < T)
+                Bs[ok] = Bq[idx[ok] + sh]
+            ref = A.t() @ Bs
+            assert rel_l2(c[tap].cpu().double(), ref) <= 2e-5, (tile, M, N, K, tap)
+        assert rel_l2(db.cpu().double(), A.sum(0)) <= 2e-5

@@ -458,3 +458,15 @@ def _numpy_model():
         yield emu
     finally:
         p.undo()
+
+
+@pytest.mark.parametrize("tile", ["64", "128"])
+def test_weight_gradient_contraction_with_both_output_tiles(tile, bf16_mode, monkeypatch):
+    """bgemm_tn_kernel<.., BN, BK>: the 64 x 128 tile of round 2 and the 128 x 256 tile of round 4 (chosen by problem size
+    on the device; KANTTS_TN_TILE forces one), on the linear-layer cases (ragged channel counts, fp32 / bf16 operands,
+    taps, dropout on the A operand) and on the deferred / grouped launches."""
+    monkeypatch.setenv("KANTTS_TN_TILE", tile)
+    import test_bf16_path_emulated as T
+
+    T.test_linear_modes_bf16_emulated(bf16_mode)
+    T.test_deferred_grouped_weight_gradients_equal_immediate_ones(bf16_mode)
