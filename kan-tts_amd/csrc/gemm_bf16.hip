@@ -391,6 +391,15 @@ static int bg_tn_dispatch(TnGroupArgs& ga, dim3 grid, hipStream_t st) {
   return bg_tn_go<false, false, BN, BK>(ga, grid, st);
 }
 
+static int bg_tn_tile_rule(const kantts_bgemm_tn_args& g, int nprob) {
+  // [round 4] 128 x 128 / 64 x 256 / 128 x 256 tiles were measured over every grouped shape of the training step
+  // (profiles/r04_runL_tn_tile_sweep.log): the 64 x 128 tile with the right slice count is within a few per cent of the
+  // best everywhere except two shapes where 128 x 128 gains 10-15 %; the larger tiles stay available to the sweep only
+  (void)g;
+  (void)nprob;
+  return 64128;
+}
+
 static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
   kantts_bgemm_tn_args& g = ga.g;
   if (g.M < 0 || g.N < 1 || g.K < 1 || g.ntaps < 1 || ga.nprob < 1 || ga.nprob > KANTTS_TN_MAX_GROUP) return KANTTS_E_BADARG;
@@ -401,29 +410,38 @@ static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
     if (!bg_aligned16(ga.a[p]) || !bg_aligned16(ga.b[p])) return KANTTS_E_UNSUPPORTED;
   }
   if ((g.shift0 != 0 || g.shift_step != 0) && g.T <= 0) return KANTTS_E_BADARG;
-  // tile: 128 x 256 when the problem is large enough for its re-read factors to matter and still leaves >= 24 tiles
-  // (KANTTS_TN_TILE=64 / 128 forces one: A/B switch and tests)
+  // tile (BN x BK) and token slices.  KANTTS_TN_TILE = BN * 1000 + BK (64128 / 128128 / 64256 / 128256) and
+  // KANTTS_TN_SLICES force them (scripts/tn_sweep.py, tests); the rules below are what that sweep measured
+  // (profiles/r04_runL_tn_tile_sweep.log).
   const char* tenv = getenv("KANTTS_TN_TILE");
-  const int forced = tenv ? atoi(tenv) : 0;
-  const long long big_tiles = (long long)kantts_cdiv(g.N, 128) * kantts_cdiv(g.K, 256) * g.ntaps * ga.nprob;
-  bool big = g.M >= 4096 && g.N >= 128 && g.K >= 256 && big_tiles >= 24;
-  if (forced == 64) big = false;
-  if (forced == 128) big = true;
-  const int BN = big ? 128 : 64, BK = big ? 256 : 128;
+  const char* senv = getenv("KANTTS_TN_SLICES");
+  int code = tenv ? atoi(tenv) : 0;
+  if (code != 64128 && code != 128128 && code != 64256 && code != 128256) code = bg_tn_tile_rule(g, ga.nprob);
+  const int BN = code / 1000, BK = code % 1000;
   const int tiles = kantts_cdiv(g.N, BN) * kantts_cdiv(g.K, BK) * g.ntaps * ga.nprob;
   const int ntile = kantts_cdiv(g.M, TN_BT);
   int slices = g.slices;
+  if (senv && atoi(senv) > 0) slices = atoi(senv);
   if (slices <= 0) {
-    slices = kantts_cdiv(big ? 256 : 320, tiles);                                          // about one workgroup per CU
-    const long long cap = (3ll << 19) / ((long long)g.N * g.K * g.ntaps * ga.nprob) + 1;  // <= ~1.5 M atomics per launch
+    // [round 4, scripts/tn_sweep.py] as many token slices as still give ONE resident round of workgroups (two per CU: 512;
+    // 576 workgroups = a second, mostly empty round cost 123 us where 384 took 95), at most ~4 M fp32 atomics per launch
+    // (round 2's budget of 1.5 M left the 19 584-row postnet problems at 4 slices: 126 us where 8 slices take 80)
+    slices = 512 / tiles;
+    if (slices < 1) slices = 1;
+    if (slices > 16) slices = 16;
+    const long long cap = (1ll << 22) / ((long long)g.N * g.K * g.ntaps * ga.nprob) + 1;
     if (slices > cap) slices = (int)cap;
   }
   if (slices > ntile) slices = ntile;
   if (slices < 1) slices = 1;
   g.slices = slices;
   dim3 grid(kantts_cdiv(g.K, BK), kantts_cdiv(g.N, BN), ga.nprob * g.ntaps * slices);
-  if (big) return bg_tn_dispatch<128, 256>(ga, grid, st);
-  return bg_tn_dispatch<64, 128>(ga, grid, st);
+  switch (code) {
+    case 128256: return bg_tn_dispatch<128, 256>(ga, grid, st);
+    case 128128: return bg_tn_dispatch<128, 128>(ga, grid, st);
+    case 64256: return bg_tn_dispatch<64, 256>(ga, grid, st);
+    default: return bg_tn_dispatch<64, 128>(ga, grid, st);
+  }
 }
 
 extern "C" int kantts_bgemm_tn(const kantts_bgemm_tn_args* gp, void* stream) {

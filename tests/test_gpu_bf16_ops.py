@@ -433,7 +433,7 @@ def test_weight_gradient_contraction_with_both_output_tiles_gpu(tile, monkeypatc
         bd = (b if b32 else b.to(torch.bfloat16)).cuda()
         c = torch.zeros(taps, N, K, device="cuda")
         db = torch.zeros(N, device="cuda")
-        assert hip.bgemm_tn(ad, N, bd, K, M, N, K, c, K, 1, c_ts=N * K, T=T, ntaps=taps, shift0=-(taps // 2), shift_step=1,
+        assert hip.bgemm_tn(ad, N, bd, K, M, N, K, c, K, 1, c_ts=N * K, T=T, ntaps=taps, shift0=-(taps // 2), shift_step=1 if taps > 1 else 0,
                             db=db)
         torch.cuda.synchronize()
         A = a.to(torch.bfloat16).double()  # fp32 operands are rounded to bf16 when a tile is staged
