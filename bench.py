@@ -888,7 +888,7 @@ def main():
     import kantts._hip.ops  # noqa: F401
     from kantts.models import model_builder
     from kantts.utils import synthetic
-    from kantts.train.loss import MelReconLoss, ProsodyReconLoss
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss, sambert_loss_sum
 
     hip.lib()
     hip.set_precision(args.precision)
@@ -906,11 +906,7 @@ def main():
         hip.ops.advance_rng(dev)
         optimizer.zero_grad()
         res = net(**batch)
-        mel_, mel = mel_crit(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
-        d, p, e = pros_crit(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
-                            res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
-                            res["energy_predictions"])
-        loss = mel_ + mel + d + p + e
+        loss, _ = sambert_loss_sum(mel_crit, pros_crit, batch, res)
         loss.backward()
         optimizer.step()
         scheduler.step()
@@ -1004,11 +1000,7 @@ def main():
             def fwd_only():
                 hip.ops.advance_rng(dev)
                 res = net(**batch)
-                mel_, mel = mel_crit(batch["output_lengths"], batch["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
-                d, p, e = pros_crit(batch["input_lengths"], res["duration_targets"], res["pitch_targets"],
-                                    res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
-                                    res["energy_predictions"])
-                return mel_ + mel + d + p + e
+                return sambert_loss_sum(mel_crit, pros_crit, batch, res)[0]
 
             hip.ops.wgrad_overlap.enable(True)
             side = torch.cuda.Stream()

@@ -279,6 +279,24 @@ int kantts_melspec_bwd(const float* wav, const float* dmel, int B, int T, int n_
                        const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off, const float* mel_w,
                        int n_mels, float eps_mel, float* dwav_accum, void* stream);
 
+/* The five masked-L1 terms of a SAM-BERT training step (MelReconLoss on the decoder and postnet mels, ProsodyReconLoss on
+ * log-duration / pitch / energy: kantts/train/loss.py:7-85) in ONE launch: term k over pred (B, T, C) against target
+ * (float, or -- target_log1p -- int64 values v read as log(v + 1): the duration targets) on rows t < lens[b];
+ * losses[k] += mean |target - pred|, losses[KANTTS_LOSS_MAX_TERMS] += the same (the step's total); grad[k] (optional) =
+ * d term k / d pred as kantts_masked_l1 writes it.  losses must be zeroed by the caller. */
+#define KANTTS_LOSS_MAX_TERMS 5
+typedef struct kantts_loss_term {
+  const float* pred;
+  const void* target;
+  const int64_t* lens;
+  float* grad;
+  int32_t B, T, C, target_log1p;
+} kantts_loss_term;
+int kantts_masked_l1_many(const kantts_loss_term* terms, int nterms, float* losses, void* stream);
+/* x_k *= *scale_dev for up to KANTTS_LOSS_MAX_TERMS tensors in one launch (the backward of the call above: the upstream
+ * gradient of the total is a device scalar). */
+int kantts_scale_many(float* const* x, const long long* n, int count, const float* scale_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * weight_norm reparametrisation w = g * v / ||v|| per output row (torch.nn.utils.weight_norm, dim=0):
  * kantts/models/hifigan/layers.py:29,67,105,139, hifigan.py:224,332.  v,w,dw,dv: (rows, cols); g,dg: (rows). */

@@ -82,6 +82,95 @@ extern "C" int kantts_masked_l1(const float* pred, const float* target, const in
   KANTTS_CHECK_LAUNCH();
 }
 
+// ---- the five masked-L1 terms of a SAM-BERT step in one launch (kantts_masked_l1_many) ---------------------------------
+struct LossManyArgs {
+  kantts_loss_term t[KANTTS_LOSS_MAX_TERMS];
+  int first_block[KANTTS_LOSS_MAX_TERMS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void masked_l1_many_kernel(const LossManyArgs a, float* __restrict__ losses) {
+  __shared__ float red[4];
+  int k = 0;
+  while (k + 1 < a.n && (int)blockIdx.x >= a.first_block[k + 1]) ++k;
+  const kantts_loss_term q = a.t[k];
+  const int blk = blockIdx.x - a.first_block[k], nblk = a.first_block[k + 1] - a.first_block[k];
+  long long denom_rows = 0;
+  for (int b = 0; b < q.B; ++b) denom_rows += min((long long)q.lens[b], (long long)q.T);
+  const float inv = 1.f / ((float)denom_rows * (float)q.C);
+  const long long total = (long long)q.B * q.T * q.C;
+  const float* tf = reinterpret_cast<const float*>(q.target);
+  const int64_t* ti = reinterpret_cast<const int64_t*>(q.target);
+  float part = 0.f;
+  for (long long g = (long long)blk * 256 + threadIdx.x; g < total; g += (long long)nblk * 256) {
+    const long long bt = g / q.C;
+    const int t = (int)(bt % q.T), b = (int)(bt / q.T);
+    float gr = 0.f;
+    if (t < (int)q.lens[b]) {
+      const float y = q.target_log1p ? logf((float)ti[g] + 1.f) : tf[g];
+      const float d = q.pred[g] - y;
+      part += fabsf(d);
+      gr = (d > 0.f) ? inv : ((d < 0.f) ? -inv : 0.f);
+    }
+    if (q.grad) q.grad[g] = gr;
+  }
+  part = kantts_block_sum(part, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(losses + k, part * inv);
+    atomicAdd(losses + KANTTS_LOSS_MAX_TERMS, part * inv);
+  }
+}
+
+extern "C" int kantts_masked_l1_many(const kantts_loss_term* terms, int nterms, float* losses, void* stream) {
+  if (!terms || !losses || nterms < 1 || nterms > KANTTS_LOSS_MAX_TERMS) return KANTTS_E_BADARG;
+  LossManyArgs a = {};
+  a.n = nterms;
+  int nb = 0;
+  for (int k = 0; k < nterms; ++k) {
+    const kantts_loss_term& q = terms[k];
+    if (!q.pred || !q.target || !q.lens || q.B < 0 || q.T < 0 || q.C < 1) return KANTTS_E_BADARG;
+    a.t[k] = q;
+    a.first_block[k] = nb;
+    long long total = (long long)q.B * q.T * q.C;
+    int blocks = kantts_cdiv(total, 1024);  // four elements per thread and trip
+    if (blocks < 1) blocks = 1;
+    if (blocks > 512) blocks = 512;
+    nb += blocks;
+  }
+  a.first_block[nterms] = nb;
+  hipLaunchKernelGGL(masked_l1_many_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, losses);
+  KANTTS_CHECK_LAUNCH();
+}
+
+struct ScaleManyArgs {
+  float* x[KANTTS_LOSS_MAX_TERMS];
+  long long n[KANTTS_LOSS_MAX_TERMS];
+  int count;
+};
+__global__ __launch_bounds__(256) void scale_many_kernel(const ScaleManyArgs a, const float* __restrict__ scale) {
+  const float s = scale[0];
+  float* x = a.x[blockIdx.y];
+  const long long n = a.n[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] *= s;
+}
+extern "C" int kantts_scale_many(float* const* x, const long long* n, int count, const float* scale_dev, void* stream) {
+  if (!x || !n || !scale_dev || count < 0 || count > KANTTS_LOSS_MAX_TERMS) return KANTTS_E_BADARG;
+  if (count == 0) return KANTTS_OK;
+  ScaleManyArgs a = {};
+  a.count = count;
+  long long mx = 0;
+  for (int k = 0; k < count; ++k) {
+    if (!x[k] || n[k] < 0) return KANTTS_E_BADARG;
+    a.x[k] = x[k];
+    a.n[k] = n[k];
+    if (n[k] > mx) mx = n[k];
+  }
+  int blocks = kantts_cdiv(mx, 1024);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(scale_many_kernel, dim3(blocks, count), dim3(256), 0, (hipStream_t)stream, a, scale_dev);
+  KANTTS_CHECK_LAUNCH();
+}
+
 // out[0] += sum x^2
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, long long n) {
   __shared__ float red[4];

@@ -147,6 +147,15 @@ class LnBwdArgs(Structure):
     ]
 
 
+LOSS_MAX_TERMS = 5
+
+
+class LossTerm(Structure):
+    """kantts_loss_term (include/kantts_hip.h)."""
+    _fields_ = [("pred", c_void_p), ("target", c_void_p), ("lens", c_void_p), ("grad", c_void_p),
+                ("B", c_int32), ("T", c_int32), ("C", c_int32), ("target_log1p", c_int32)]
+
+
 WN_BWD_MAX = 64
 
 
@@ -281,6 +290,8 @@ def lib():
         L.kantts_weight_norm_tap_images.argtypes = [p, p, p, p, p, i, i, i, i, p]
         L.kantts_weight_norm_table.argtypes = [p, p, p, p, p, i, i, p]
         L.kantts_weight_norm_table_bwd.argtypes = [p, p, p, POINTER(WnBwdArgs), p]
+        L.kantts_masked_l1_many.argtypes = [POINTER(LossTerm), i, p, p]
+        L.kantts_scale_many.argtypes = [POINTER(c_void_p), POINTER(ll), i, p, p]
         L.kantts_ragged_rows_i64.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
         _lib = L
     return _lib
@@ -300,7 +311,7 @@ EXPORTED_SYMBOLS = [
     "kantts_sinadd_lrelu_fwd", "kantts_dropout2_add",
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
-    "kantts_weight_norm_table", "kantts_weight_norm_table_bwd",
+    "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
 ]
 
 

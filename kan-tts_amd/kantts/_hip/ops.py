@@ -1172,6 +1172,58 @@ def masked_l1(pred, target, lens_i64):
     return _MaskedL1.apply(pred, target, lens_i64)
 
 
+class _MaskedL1Many(torch.autograd.Function):
+    """Up to five masked-L1 terms and their sum from ONE launch (kantts_masked_l1_many), the gradients of all terms written
+    in the same pass; backward is one launch that scales them by the upstream gradient of the sum (a device scalar).
+    Returns (total, components (n,)); the components are detached values for logging."""
+
+    @staticmethod
+    def forward(ctx, spec, *preds):
+        from . import LOSS_MAX_TERMS, LossTerm
+
+        n = len(preds)
+        assert 1 <= n <= LOSS_MAX_TERMS and len(spec) == n
+        terms = (LossTerm * n)()
+        grads, keep = [], []
+        for k, (p, (target, lens, log1p)) in enumerate(zip(preds, spec)):
+            p, target = _c(p), _c(target)
+            B, T = p.shape[0], p.shape[1]
+            C = 1 if p.dim() == 2 else p.shape[2]
+            assert tuple(target.shape) == tuple(p.shape) and p.dtype == torch.float32
+            g = torch.empty_like(p) if ctx.needs_input_grad[1 + k] else None
+            q = terms[k]
+            q.pred, q.lens, q.grad = ptr(p, torch.float32), ptr(lens, torch.int64), ptr(g)
+            q.target = ptr(target, torch.int64) if log1p else ptr(target, torch.float32)
+            q.B, q.T, q.C, q.target_log1p = int(B), int(T), int(C), int(bool(log1p))
+            grads.append(g)
+            keep.extend((p, target, lens))
+        losses = gzeros((LOSS_MAX_TERMS + 1,), preds[0].device)
+        check(lib().kantts_masked_l1_many(terms, n, ptr(losses, torch.float32), stream()), "masked_l1_many")
+        ctx.grads = grads
+        total = losses[LOSS_MAX_TERMS]
+        comps = losses[:n]
+        ctx.mark_non_differentiable(comps)
+        return total, comps
+
+    @staticmethod
+    def backward(ctx, g, _gc):
+        import ctypes
+
+        live = [t for t in ctx.grads if t is not None]
+        if live:
+            g = _c(g).reshape(1)
+            xs = (ctypes.c_void_p * len(live))(*[ptr(t, torch.float32) for t in live])
+            ns = (ctypes.c_longlong * len(live))(*[t.numel() for t in live])
+            check(lib().kantts_scale_many(xs, ns, len(live), ptr(g, torch.float32), stream()), "scale_many")
+        return (None, *ctx.grads)
+
+
+def masked_l1_many(terms):
+    """terms: list of (pred, target, lens_i64, target_is_int64_log1p).  -> (sum of the terms, (n,) detached components)."""
+    spec = tuple((t, lens, bool(log1p)) for _, t, lens, log1p in terms)
+    return _MaskedL1Many.apply(spec, *[p for p, _, _, _ in terms])
+
+
 class _ElemLoss(torch.autograd.Function):
     """scale * sum |a - b|  (mode 0)  or  scale * sum (a - target)^2  (mode 1); b is treated as a constant."""
 

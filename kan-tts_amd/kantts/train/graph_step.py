@@ -136,11 +136,9 @@ class GraphedSambertStep:
         ops.advance_rng(self.device)
         self.optimizer.zero_grad(set_to_none=True)
         res = self.net(**b)
-        mel_, mel = self.mel_criterion(b["output_lengths"], b["mel_targets"], res["dec_outputs"], res["postnet_outputs"])
-        d, p, e = self.prosody_criterion(b["input_lengths"], res["duration_targets"], res["pitch_targets"],
-                                         res["energy_targets"], res["log_duration_predictions"],
-                                         res["pitch_predictions"], res["energy_predictions"])
-        self.loss = mel_ + mel + d + p + e
+        from kantts.train.loss import sambert_loss_sum
+
+        self.loss, self.loss_terms = sambert_loss_sum(self.mel_criterion, self.prosody_criterion, b, res)
         self.loss.backward()
 
     def _apply(self, packed=False):

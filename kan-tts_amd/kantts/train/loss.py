@@ -62,6 +62,38 @@ class ProsodyReconLoss(torch.nn.Module):
         return dur_loss, pitch_loss, energy_loss
 
 
+def sambert_loss_sum(mel_criterion, prosody_criterion, batch, res, prosody_lengths=None):
+    """The training objective of a SAM-BERT step as the reference's trainer forms it (kantts/train/trainer.py:940-975:
+    mel_loss_ + mel_loss + dur_loss + pitch_loss + energy_loss) -> (total, {name: detached component}).
+    Both criteria in their default "mae" form on device tensors: ONE launch for the five terms, their sum and all five
+    gradients, one launch in backward (ops.masked_l1_many) instead of five reductions, the duration-target logarithm and
+    the scalar sums / products around them (~30 graph nodes between the end of forward and the start of backward).
+    Anything else: the two criteria are called as modules."""
+    names = ("mel_loss_", "mel_loss", "dur_loss", "pitch_loss", "energy_loss")
+    dec, post = res["dec_outputs"], res["postnet_outputs"]
+    if (getattr(mel_criterion, "loss_type", None) == "mae" and getattr(prosody_criterion, "loss_type", None) == "mae"
+            and type(mel_criterion) is MelReconLoss and type(prosody_criterion) is ProsodyReconLoss and post is not None
+            and dec.dtype == torch.float32 and not __import__("os").environ.get("KANTTS_NO_FUSED_LOSS")):
+        il = (batch["input_lengths"] if prosody_lengths is None else prosody_lengths).to(torch.int64)
+        ol = batch["output_lengths"].to(torch.int64)
+        mel_t = batch["mel_targets"]
+        dur_t = res["duration_targets"]
+        if dur_t.dtype == torch.int64 and mel_t.dtype == torch.float32:
+            total, comps = ops.masked_l1_many([
+                (dec, mel_t, ol, False), (post, mel_t, ol, False),
+                (res["log_duration_predictions"], dur_t, il, True),
+                (res["pitch_predictions"], res["pitch_targets"].float(), il, False),
+                (res["energy_predictions"], res["energy_targets"].float(), il, False)])
+            return total, {n: comps[k] for k, n in enumerate(names)}
+    mel_, mel = mel_criterion(batch["output_lengths"], batch["mel_targets"], dec, post)
+    d, p, e = prosody_criterion(batch["input_lengths"] if prosody_lengths is None else prosody_lengths,
+                                res["duration_targets"], res["pitch_targets"],
+                                res["energy_targets"], res["log_duration_predictions"], res["pitch_predictions"],
+                                res["energy_predictions"])
+    comps = dict(zip(names, (mel_, mel, d, p, e)))
+    return mel_ + mel + d + p + e, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in comps.items()}
+
+
 class GeneratorAdversarialLoss(torch.nn.Module):
     """Generator adversarial loss, mean (or sum) over discriminators: LSGAN ``mse(D(G(x)), 1)`` (``"mse"``, every shipped
     yaml: one reduction kernel per score) or ``-mean(D(G(x)))`` (``"hinge"``) (reference :108-151)."""

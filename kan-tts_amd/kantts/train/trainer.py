@@ -211,13 +211,11 @@ class Sambert_Trainer(Trainer):
                 for k, v in names.items()}
 
     def _losses(self, b, res):
-        mel_, mel = self.criterion["MelReconLoss"](b["output_lengths"], b["mel_targets"], res["dec_outputs"],
-                                                   res["postnet_outputs"])
-        dur, pitch, energy = self.criterion["ProsodyReconLoss"](
-            res["valid_inter_lengths"], res["duration_targets"], res["pitch_targets"], res["energy_targets"],
-            res["log_duration_predictions"], res["pitch_predictions"], res["energy_predictions"])
-        total = mel_ + mel + dur + pitch + energy
-        losses = {"mel_loss_": mel_, "mel_loss": mel, "dur_loss": dur, "pitch_loss": pitch, "energy_loss": energy}
+        from kantts.train.loss import sambert_loss_sum
+
+        total, losses = sambert_loss_sum(self.criterion["MelReconLoss"], self.criterion["ProsodyReconLoss"], b, res,
+                                         prosody_lengths=res["valid_inter_lengths"])
+        losses = dict(losses)
         if self.with_MAS:  # reference :871-884 / :970-983
             ctc = self.criterion["AttentionCTCLoss"](res["attn_logprob"], b["input_lengths"], b["output_lengths"])
             kl = self.criterion["AttentionBinarizationLoss"](self.epoch, res["attn_hard"], res["attn_soft"])

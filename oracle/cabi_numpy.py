@@ -1421,6 +1421,34 @@ class EmulatedLib:
                                          int(wd) + 2 * wd_off if (wd and wd_off >= 0) else None, rows, cin, K, groups)
         return 0
 
+    def kantts_masked_l1_many(self, terms, nterms, losses, stream):
+        """kantts_masked_l1 per term (duration targets read as log(v + 1)); losses[k] and losses[5] accumulate."""
+        L = _arr(losses, 6)
+        for k in range(int(_val(nterms))):
+            q = terms[k]
+            n = q.B * q.T * q.C
+            pred = _arr(q.pred, n).reshape(q.B, q.T, q.C)
+            if q.target_log1p:
+                tgt = np.log(_arr(q.target, n, np.int64).astype(np.float32) + np.float32(1.0)).reshape(q.B, q.T, q.C)
+            else:
+                tgt = _arr(q.target, n).reshape(q.B, q.T, q.C)
+            lens = np.minimum(_arr(q.lens, q.B, np.int64), q.T)
+            valid = (np.arange(q.T)[None, :] < lens[:, None])[:, :, None]
+            inv = np.float32(1.0) / (np.float32(lens.sum()) * np.float32(q.C))
+            d = (pred - tgt) * valid
+            val = np.float32(np.abs(d).sum(dtype=np.float64)) * inv
+            L[k] += val
+            L[5] += val
+            if q.grad:
+                _arr(q.grad, n)[:] = (np.sign(d) * inv * valid).astype(np.float32).ravel()
+        return 0
+
+    def kantts_scale_many(self, x, n, count, scale_dev, stream):
+        s = _arr(scale_dev, 1)[0]
+        for k in range(int(_val(count))):
+            _arr(x[k], int(n[k]))[:] *= s
+        return 0
+
     def kantts_weight_norm_table_bwd(self, flat, grad, table, args_ref, stream):
         """Per listed layer: kantts_weight_norm_strided_bwd on the tap-major gradient, dv / dg into the gradient arena."""
         a = args_ref._obj

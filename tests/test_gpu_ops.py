@@ -372,6 +372,43 @@ def test_dropout2_add_kernel():
             assert_close(a, c, 1e-6, what="dropout2_add grad")
 
 
+def test_fused_sambert_loss_on_device_equals_the_two_criteria():
+    """kantts_masked_l1_many / kantts_scale_many on the GPU against the per-term criteria on the GPU: components, total and
+    the five gradients, bench-shaped (B=32, T=640, 80 bins) and ragged small cases."""
+    import os
+
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss, sambert_loss_sum
+
+    mel_c, pro_c = MelReconLoss(), ProsodyReconLoss()
+    for (B, T, N, seed) in ((32, 640, 96, 1), (3, 17, 5, 2), (1, 1, 1, 3)):
+        g = torch.Generator().manual_seed(seed)
+        ol = torch.randint(1, T + 1, (B,), generator=g)
+        il = torch.randint(1, N + 1, (B,), generator=g)
+        ol[0], il[-1] = T, N
+        batch = dict(output_lengths=ol.cuda(), input_lengths=il.cuda(), mel_targets=torch.randn(B, T, 80, generator=g).cuda())
+        leaves = [torch.randn(B, T, 80, generator=g), torch.randn(B, T, 80, generator=g), torch.randn(B, N, generator=g),
+                  torch.randn(B, N, generator=g), torch.randn(B, N, generator=g)]
+        leaves = [t.cuda().requires_grad_(True) for t in leaves]
+        res = dict(zip(("dec_outputs", "postnet_outputs", "log_duration_predictions", "pitch_predictions",
+                        "energy_predictions"), leaves))
+        res.update(duration_targets=torch.randint(0, 40, (B, N), generator=g).cuda(),
+                   pitch_targets=torch.randn(B, N, generator=g).cuda(), energy_targets=torch.randn(B, N, generator=g).cuda())
+        out = {}
+        for fused in (True, False):
+            if not fused:
+                os.environ["KANTTS_NO_FUSED_LOSS"] = "1"
+            try:
+                total, comps = sambert_loss_sum(mel_c, pro_c, batch, res)
+            finally:
+                os.environ.pop("KANTTS_NO_FUSED_LOSS", None)
+            out[fused] = (total.detach(), comps, torch.autograd.grad(total * 0.5, leaves))
+        assert abs(float(out[True][0]) - float(out[False][0])) < 2e-5 * max(1.0, abs(float(out[False][0])))
+        for k in out[False][1]:
+            assert abs(float(out[True][1][k]) - float(out[False][1][k])) < 2e-5 * max(1.0, abs(float(out[False][1][k]))), k
+        for a, c in zip(out[True][2], out[False][2]):
+            assert_close(a, c, 1e-10, rtol=2e-6, what="fused loss grad")
+
+
 def test_masked_l1_and_optimizer_kernels():
     from kantts._hip import ops
 

@@ -2,6 +2,7 @@
 oracle's building blocks: fused linear in its three modes with every epilogue option, self / PNCA band attention over
 ragged lengths and band widths, (Bi)LSTM with packed-sequence semantics, FSMN memory, length regulator, embedding sum,
 masked L1.  Forward and gradients; fixed seeds; small shapes (a few seconds)."""
+import os
 import random
 
 import torch
@@ -307,3 +308,45 @@ def test_pnca_backward_separate_query_gradients_are_summed_by_the_host(emulated_
     got = run()
     for a, b in zip(got, want):
         assert torch.allclose(a, b, rtol=0, atol=1e-6)
+
+
+def test_fused_sambert_loss_equals_the_two_criteria(emulated_cabi):
+    """ops.masked_l1_many (one launch: five masked-L1 terms, their sum, all gradients) against the two criteria called as
+    modules (MelReconLoss / ProsodyReconLoss, each term its own launches): same components, same total, same gradients --
+    for ragged lengths, one-frame utterances and a non-unit upstream gradient."""
+    from kantts.train.loss import MelReconLoss, ProsodyReconLoss, sambert_loss_sum
+
+    rnd = random.Random(21)
+    g = torch.Generator().manual_seed(21)
+    mel_c, pro_c = MelReconLoss(), ProsodyReconLoss()
+    for it in range(6):
+        B, T, N, C = rnd.choice([1, 2, 5]), rnd.randint(1, 70), rnd.randint(1, 23), rnd.choice([1, 80])
+        ol = torch.tensor([rnd.randint(1, T) for _ in range(B)])
+        il = torch.tensor([rnd.randint(1, N) for _ in range(B)])
+        ol[rnd.randrange(B)], il[rnd.randrange(B)] = T, N
+        batch = dict(output_lengths=ol, input_lengths=il, mel_targets=torch.randn(B, T, C, generator=g))
+        leaves = dict(dec_outputs=torch.randn(B, T, C, generator=g), postnet_outputs=torch.randn(B, T, C, generator=g),
+                      log_duration_predictions=torch.randn(B, N, generator=g),
+                      pitch_predictions=torch.randn(B, N, generator=g), energy_predictions=torch.randn(B, N, generator=g))
+        res = {k: v.requires_grad_(True) for k, v in leaves.items()}
+        res.update(duration_targets=torch.randint(0, 40, (B, N), generator=g), pitch_targets=torch.randn(B, N, generator=g),
+                   energy_targets=torch.randn(B, N, generator=g))
+        plens = il if it % 2 == 0 else torch.clamp(il - 1, min=1)  # the trainer hands valid_inter_lengths in
+        up = 1.0 if it < 3 else 0.37
+        out = {}
+        for fused in (True, False):
+            if fused:
+                os.environ.pop("KANTTS_NO_FUSED_LOSS", None)
+            else:
+                os.environ["KANTTS_NO_FUSED_LOSS"] = "1"
+            try:
+                total, comps = sambert_loss_sum(mel_c, pro_c, batch, res, prosody_lengths=plens)
+            finally:
+                os.environ.pop("KANTTS_NO_FUSED_LOSS", None)
+            grads = torch.autograd.grad(total * up, list(leaves.values()))
+            out[fused] = (total.detach(), comps, grads)
+        cfg = dict(it=it, B=B, T=T, N=N, C=C, ol=ol.tolist(), il=plens.tolist())
+        assert abs(float(out[True][0]) - float(out[False][0])) < 2e-5 * max(1.0, abs(float(out[False][0]))), cfg
+        for k in out[False][1]:
+            assert abs(float(out[True][1][k]) - float(out[False][1][k])) < 1e-5 * max(1.0, abs(float(out[False][1][k]))), (k, cfg)
+        _cmp(out[True][2], out[False][2], cfg, tol=1e-7)
