@@ -426,10 +426,11 @@ static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
     // [round 4, scripts/tn_sweep.py] as many token slices as still give ONE resident round of workgroups (two per CU: 512;
     // 576 workgroups = a second, mostly empty round cost 123 us where 384 took 95), at most ~4 M fp32 atomics per launch
     // (round 2's budget of 1.5 M left the 19 584-row postnet problems at 4 slices: 126 us where 8 slices take 80)
-    slices = 512 / tiles;
+    static const bool r2_rule = getenv("KANTTS_TN_SLICE_RULE_R2") != nullptr;  // A/B switch: rounds 2-3's rule
+    slices = r2_rule ? kantts_cdiv(320, tiles) : 512 / tiles;
     if (slices < 1) slices = 1;
-    if (slices > 16) slices = 16;
-    const long long cap = (1ll << 22) / ((long long)g.N * g.K * g.ntaps * ga.nprob) + 1;
+    if (slices > 16 && !r2_rule) slices = 16;
+    const long long cap = ((r2_rule ? 3ll << 19 : 1ll << 22)) / ((long long)g.N * g.K * g.ntaps * ga.nprob) + 1;
     if (slices > cap) slices = (int)cap;
   }
   if (slices > ntile) slices = ntile;

@@ -1197,7 +1197,9 @@ class _MaskedL1Many(torch.autograd.Function):
             q.B, q.T, q.C, q.target_log1p = int(B), int(T), int(C), int(bool(log1p))
             grads.append(g)
             keep.extend((p, target, lens))
-        losses = gzeros((LOSS_MAX_TERMS + 1,), preds[0].device)
+        # not from the per-step zero pool: the loss outlives optimizer.zero_grad() (the reference's trainer, and ours, clear
+        # the gradients between the forward pass and backward()), which re-zeroes the pool
+        losses = torch.zeros((LOSS_MAX_TERMS + 1,), device=preds[0].device, dtype=torch.float32)
         check(lib().kantts_masked_l1_many(terms, n, ptr(losses, torch.float32), stream()), "masked_l1_many")
         ctx.grads = grads
         total = losses[LOSS_MAX_TERMS]

@@ -377,8 +377,10 @@ def test_fused_sambert_loss_on_device_equals_the_two_criteria():
     the five gradients, bench-shaped (B=32, T=640, 80 bins) and ragged small cases."""
     import os
 
+    from kantts._hip import ops
     from kantts.train.loss import MelReconLoss, ProsodyReconLoss, sambert_loss_sum
 
+    ops.zero_pool.enable(1 << 16, "cuda")
     mel_c, pro_c = MelReconLoss(), ProsodyReconLoss()
     for (B, T, N, seed) in ((32, 640, 96, 1), (3, 17, 5, 2), (1, 1, 1, 3)):
         g = torch.Generator().manual_seed(seed)
@@ -401,7 +403,8 @@ def test_fused_sambert_loss_on_device_equals_the_two_criteria():
                 total, comps = sambert_loss_sum(mel_c, pro_c, batch, res)
             finally:
                 os.environ.pop("KANTTS_NO_FUSED_LOSS", None)
-            out[fused] = (total.detach(), comps, torch.autograd.grad(total * 0.5, leaves))
+            ops.zero_pool.reset()  # the trainer clears the gradients (and with them the accumulator pool) before backward()
+            out[fused] = (total.detach().clone(), comps, torch.autograd.grad(total * 0.5, leaves))
         assert abs(float(out[True][0]) - float(out[False][0])) < 2e-5 * max(1.0, abs(float(out[False][0])))
         for k in out[False][1]:
             assert abs(float(out[True][1][k]) - float(out[False][1][k])) < 2e-5 * max(1.0, abs(float(out[False][1][k]))), k
