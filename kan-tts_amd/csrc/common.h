@@ -21,6 +21,13 @@
 #define KANTTS_WAVE_ORDERED()
 #endif
 
+// Makes the compiler forget what it knows about a vector-register value at this point (no instruction is emitted): used to
+// keep loop-invariant operand shuffles from being hoisted into extra registers.  The host build of the kernel sources
+// (tests/hipemu) pre-defines it as nothing.
+#ifndef KANTTS_OPAQUE_VGPR
+#define KANTTS_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#endif
+
 static inline int kantts_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------

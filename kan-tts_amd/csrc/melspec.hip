@@ -145,14 +145,343 @@ __global__ __launch_bounds__(MEL_THREADS) void melspec_kernel(const MelArgs a) {
 }
 
 
-// [round 4] A second form of this kernel -- one WAVE per frame with private ping-pong buffers, radix-4 Stockham passes and
-// no workgroup barrier inside a frame, window / twiddles / mel weights staged in LDS, 16 frames per workgroup -- was
-// written, passed every parity test (9.5e-7 against the oracle) and was measured against this one on one box
-// (profiles/r04_runG_melspec_wave_kernel_ab.log): 325 against 343 us at 67 584 frames of n_fft 1024, 35 against 25 us at
-// the benchmark's 1 056 frames, 812 against 518 us at n_fft 2048.  The barriers were not the bound: the kernel is
-// instruction-issue / LDS-latency bound per wave (address arithmetic and LDS instructions around ~10 flops per butterfly),
-// and the private buffers cut the resident waves per CU from 32 to 8.  Removed; what would pay is a register-resident
-// radix-8 FFT (three passes, two LDS exchanges per frame) -- DESIGN.md section 8.
+// ------------------------------------------------------------------------------------------------
+// [round 4] Register-resident form for n_fft = 1024 (M = n_fft / 2 = 512 = 8 x 8 x 8 complex points).
+//
+// melspec_kernel above is instruction-issue / LDS-latency bound: nine radix-2 passes, every one a round trip of the whole
+// frame through LDS plus a twiddle load from global memory and a workgroup barrier (343 us for 67 584 frames of n_fft 1024
+// = 2 800 CU cycles per frame against ~200 of arithmetic).  A first attempt to fix that -- one wave per frame, radix-4
+// Stockham passes in private LDS buffers -- measured no better (325 us, profiles/r04_runG_melspec_wave_kernel_ab.log): it
+// still moved the frame through LDS five times.  Here ONE WAVE owns TWO consecutive frames and they live in its REGISTERS
+// (8 complex values per lane and frame):
+//   pass 1   lane L holds z[L + 64 a], a < 8: a radix-8 DFT over a in registers (no exchange), twiddle W_M^(L k0);
+//   pass 2/3 the 8 independent 64-point DFTs across the lanes as 8 x 8: exchange through a padded (bank-conflict free)
+//            wave-private LDS buffer, radix-8 DFT in registers, twiddle W_64^(c k1), exchange, radix-8 DFT;
+//   split    natural-order write, every lane reads the 4 pairs (Z[k], Z[M - k]) and emits BOTH |X[k]| and |X[M - k]|
+//            (E +- w^k O) into the wave's magnitude rows in LDS;
+//   mel      the sparse filterbank cut into chunks of 8 weights (table + weights staged once per workgroup in LDS),
+//            lane i reduces chunks i, i + 64, ..., then lane c adds channel c's chunk sums, dB + normalise.
+// Three LDS exchanges per frame instead of ten, no workgroup barrier inside the frame loop (a wave's LDS operations
+// execute in order), twiddles / window / split twiddles are per-lane constants held in registers across all the frames a
+// wave walks (persistent grid).  The two frames are the two halves of every packed fp32 operation (v_pk_add / v_pk_mul /
+// v_pk_fma_f32: real and imaginary parts are separate registers, frame A in .x and frame B in .y), so a complex multiply,
+// a rotation by -i or a butterfly needs no lane or half swizzle at all, and one 16-byte LDS cell carries one complex value of
+// both frames.  A first version with one frame per wave and (re, im) in the two halves spent a third of its instructions on
+// half swaps and selects: 168 us against this form's time in profiles/r04_runN_melspec_register_form.log.
+// n_fft = 2048 (16 values per lane and frame) was tried in the one-frame form: 298 VGPRs, one wave per SIMD, 1 018 us against
+// the radix-2 kernel's 835 -- that size stays on melspec_kernel.
+typedef float mf2 __attribute__((ext_vector_type(2)));
+typedef float mf4 __attribute__((ext_vector_type(4)));
+struct mc {  // one complex value of two frames
+  mf2 re, im;
+};
+__device__ __forceinline__ mc operator+(mc a, mc b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ mc operator-(mc a, mc b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ mc mc_mul(mc a, mf2 w) { return {a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x}; }
+__device__ __forceinline__ mc mc_mul_mi(mc a) { return {a.im, -a.re}; }  // * (-i)
+__device__ __forceinline__ void mc_dft4(mc& c0, mc& c1, mc& c2, mc& c3) {
+  const mc s0 = c0 + c2, s1 = c0 - c2, s2 = c1 + c3, s3 = mc_mul_mi(c1 - c3);
+  c0 = s0 + s2;
+  c1 = s1 + s3;
+  c2 = s0 - s2;
+  c3 = s1 - s3;
+}
+// in-place forward DFT of 8 values, natural order in and out
+__device__ __forceinline__ void mc_dft8(mc* v) {
+  const float h = 0.70710678118654752f;
+  mc a0 = v[0] + v[4], a1 = v[1] + v[5], a2 = v[2] + v[6], a3 = v[3] + v[7];
+  mc b0 = v[0] - v[4], b1 = v[1] - v[5], b2 = v[2] - v[6], b3 = v[3] - v[7];
+  b1 = {(b1.re + b1.im) * h, (b1.im - b1.re) * h};   // * W8^1 = (1 - i) / sqrt 2
+  b2 = mc_mul_mi(b2);                                // * W8^2 = -i
+  b3 = {(b3.im - b3.re) * h, (b3.re + b3.im) * -h};  // * W8^3 = (-1 - i) / sqrt 2
+  mc_dft4(a0, a1, a2, a3);
+  mc_dft4(b0, b1, b2, b3);
+  v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
+  v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+}
+__device__ __forceinline__ mf4 mc_pack(mc a) { return (mf4){a.re.x, a.re.y, a.im.x, a.im.y}; }
+__device__ __forceinline__ mc mc_unpack(mf4 q) { return {(mf2){q.x, q.y}, (mf2){q.z, q.w}}; }
+// a wave's own LDS writes are visible to its later reads (in-order LDS pipeline); this only pins the compiler's order
+__device__ __forceinline__ void mel_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// dB + normalisation of mel_normalise with the hardware's log2 / a multiplication by the reciprocal range (1-2 ulp each:
+// < 1e-6 in normalised units, the parity bound is 1e-4)
+__device__ __forceinline__ float mel_normalise_fast(const MelArgs& a, float mel, float inv_range) {
+  const float db = 6.0205999132796239f * __log2f(fmaxf(mel, 1e-5f)) - a.ref_db;
+  const float u = (db - a.min_db) * inv_range;
+  if (a.symmetric) return fminf(fmaxf(2.f * a.max_norm * u - a.max_norm, -a.max_norm), a.max_norm);
+  return fminf(fmaxf(a.max_norm * u, 0.f), a.max_norm);
+}
+
+#define MELR_WAVES 4    // waves per workgroup, each with its own pair of frames
+#define MELR_CH 8       // filterbank weights per chunk
+#define MELR_CHMAX 256  // chunks the table holds (else: per-channel loop over global weights, as melspec_kernel)
+#define MELR_WMAX 1536  // filterbank weights staged in LDS (triangular filters over n_fft / 2 + 1 bins: ~2 per bin)
+#define MELR_SLOTS 2    // mel channels per lane (n_mels <= 128; more: melspec_kernel)
+#define MELR_M 512
+#define MELR_XB (8 * 72)  // 16-byte cells of the exchange buffer (cell 512 = M is spare in the natural-order layout)
+
+// one waveform sample of a frame that reaches over an end of the utterance: zero or reflect padding, branch-free
+__device__ __forceinline__ float melr_edge_sample(const MelArgs& a, const float* __restrict__ x, int s) {
+  if (a.pad_mode == 1) {
+    s = s < 0 ? -s : s;
+    s = s >= a.T ? 2 * (a.T - 1) - s : s;
+  }
+  const float xv = x[min(max(s, 0), a.T - 1)];
+  return (s >= 0 && s < a.T) ? xv : 0.f;
+}
+// windowed samples 2 (lane + 64 r) + {0, 1} of frame f, r < 8, into half `H` (0: frame A, 1: frame B) of v[r]; zeros for a
+// frame beyond the utterance
+template <int H>
+__device__ __forceinline__ void melr_load(const MelArgs& a, const float* __restrict__ x, int f, int lane,
+                                          const float (&win)[16], mc (&v)[8]) {
+  const int start = f * a.hop - MELR_M;
+  const bool interior = f < a.frames && start >= 0 && start + 2 * MELR_M <= a.T;
+  if (interior) {
+    const float* xs = x + start + 2 * lane;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r].re[H] = xs[128 * r] * win[2 * r];
+      v[r].im[H] = xs[128 * r + 1] * win[2 * r + 1];
+    }
+  } else {
+    const float live = f < a.frames ? 1.f : 0.f;
+    const int s0 = start + 2 * lane;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      v[r].re[H] = melr_edge_sample(a, x, s0 + 128 * r) * (win[2 * r] * live);
+      v[r].im[H] = melr_edge_sample(a, x, s0 + 128 * r + 1) * (win[2 * r + 1] * live);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const MelArgs a, int items, int pairs_per_row) {
+  constexpr int M = MELR_M;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // workgroup-shared: filterbank weights, chunk table, channel -> first chunk;  then per wave: exchange buffer, magnitudes
+  float* lds_w = smem;
+  int2* tab = reinterpret_cast<int2*>(lds_w + MELR_WMAX);
+  int* cfirst = reinterpret_cast<int*>(tab + MELR_CHMAX);  // n_mels + 1 entries (<= 129), [130] = weights staged or -1
+  float* wave_base = reinterpret_cast<float*>(cfirst + 132);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  mf4* xbuf = reinterpret_cast<mf4*>(wave_base + (size_t)wv * (4 * MELR_XB));
+  mf2* amp = reinterpret_cast<mf2*>(xbuf);       // magnitude k of both frames: low half of cell k (amp[2 k]), see the split
+  mf2* part = reinterpret_cast<mf2*>(xbuf) + 1;  // chunk sum i: high half of cell i (part[2 i])
+
+  // ---- once per workgroup: chunk table of the sparse filterbank
+  bool mel_fast = false;
+  int nch_total = 0;
+  if (a.out_mel) {
+    if (tid == 0) {
+      int first = 0, wend = 0;
+      for (int c = 0; c < a.n_mels; ++c) {
+        cfirst[c] = first;
+        const int ln = a.mel_len[c];
+        first += (ln + MELR_CH - 1) / MELR_CH;
+        wend = max(wend, a.mel_off[c] + ln);
+      }
+      cfirst[a.n_mels] = first;
+      cfirst[130] = (first <= MELR_CHMAX && wend <= MELR_WMAX) ? wend : -1;
+    }
+    __syncthreads();
+    const int wend = cfirst[130];
+    mel_fast = wend >= 0;
+    nch_total = cfirst[a.n_mels];
+    if (mel_fast) {
+      for (int c = tid; c < a.n_mels; c += 64 * MELR_WAVES) {
+        const int st = a.mel_start[c], ln = a.mel_len[c], of = a.mel_off[c], fi = cfirst[c];
+        for (int q = 0; q * MELR_CH < ln; ++q)
+          tab[fi + q] = make_int2((st + q * MELR_CH) | (min(MELR_CH, ln - q * MELR_CH) << 16), of + q * MELR_CH);
+      }
+      for (int i = tid; i < wend; i += 64 * MELR_WAVES) lds_w[i] = a.mel_w[i];
+    }
+    __syncthreads();
+  }
+
+  // ---- per-lane constants
+  const int c8 = lane & 7, hi8 = lane >> 3;
+  mf2 tw1[8];  // W_M^(lane k0)                               (after pass 1)
+  mf2 tw2[8];  // W_64^(c k1) = W_M^(8 c k1), c = lane & 7    (after pass 2)
+  mf2 tws[4];  // W_N^k, k = lane + 64 j                      (split pass)
+  float win[16];
+  auto twM = [&](int x) -> mf2 {  // W_M^x = W_N^(2x), the table holds W_N^t for t < M
+    int t = 2 * x;
+    const bool neg = t >= M;
+    if (neg) t -= M;
+    const float2 w = a.tw[t];
+    return neg ? (mf2){-w.x, -w.y} : (mf2){w.x, w.y};
+  };
+#pragma unroll
+  for (int k0 = 0; k0 < 8; ++k0) tw1[k0] = twM(lane * k0);
+#pragma unroll
+  for (int k1 = 0; k1 < 8; ++k1) tw2[k1] = twM(8 * c8 * k1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float2 w = a.tw[lane + 64 * j];
+    tws[j] = (mf2){w.x, w.y};
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    win[2 * r] = a.window[2 * (lane + 64 * r)];
+    win[2 * r + 1] = a.window[2 * (lane + 64 * r) + 1];
+  }
+  const float inv_range = 1.f / (-a.min_db);
+
+  const int wave_global = blockIdx.x * MELR_WAVES + wv, wave_count = gridDim.x * MELR_WAVES;
+#pragma unroll 1
+  for (int item = wave_global; item < items; item += wave_count) {
+    const int b = item / pairs_per_row, fa = (item - b * pairs_per_row) * 2;  // frames fa, fa + 1 (the second may not exist)
+    // the (cos, sin) pairs stay ONE register pair each: opaque per iteration, so the compiler cannot hoist a (cos, cos) /
+    // (sin, sin) splat of every constant out of the loop (52 more VGPRs: 204 against the budget of 168 for three waves
+    // per SIMD); inside the loop the broadcast is an operand modifier of v_pk_mul / v_pk_fma (op_sel)
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      KANTTS_OPAQUE_VGPR(tw1[k]);
+      KANTTS_OPAQUE_VGPR(tw2[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) KANTTS_OPAQUE_VGPR(tws[k]);
+    const float* x = a.wav + (long long)b * a.T;
+    mc v[8];
+    melr_load<0>(a, x, fa, lane, win, v);
+    melr_load<1>(a, x, fa + 1, lane, win, v);
+    // ---- pass 1: DFT over a (registers), twiddle, exchange 1: cell (k0, L) at 72 k0 + L
+    mc_dft8(v);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) xbuf[72 * k0 + lane] = mc_pack((k0 == 0) ? v[0] : mc_mul(v[k0], tw1[k0]));
+    mel_wave_sync();
+    // ---- pass 2: lane (k0, c) = 8 k0 + c takes b = 0..7; DFT over b, twiddle W_64^(c k1), exchange 2: cell (k0, k1, c)
+    //      at 66 c + k0 + 8 k1
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) v[bb] = mc_unpack(xbuf[72 * hi8 + 8 * bb + c8]);
+    mel_wave_sync();
+    mc_dft8(v);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) xbuf[66 * c8 + hi8 + 8 * k1] = mc_pack((k1 == 0) ? v[0] : mc_mul(v[k1], tw2[k1]));
+    mel_wave_sync();
+    // ---- pass 3: lane l = k0 + 8 k1 takes c = 0..7; DFT over c -> k2; X[k], k = l + 64 k2, to cell k
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) v[cc] = mc_unpack(xbuf[66 * cc + lane]);
+    mel_wave_sync();
+    mc_dft8(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) xbuf[lane + 64 * k2] = mc_pack(v[k2]);
+    mel_wave_sync();
+    // ---- split: pairs (k, M - k), k = lane + 64 j < M / 2.  The magnitudes of both frames go IN PLACE into the low half
+    //      of cells k and M - k (each of these cells is read by this lane only; |X[M]| takes the spare cell M), so a wave
+    //      needs no second LDS array: 9 KB per wave, three workgroups per CU
+    const bool has_b = fa + 1 < a.frames;
+    float* omag = a.out_mag ? a.out_mag + ((long long)b * a.frames + fa) * (M + 1) : nullptr;
+    {
+      mf4 zkq[4], zmq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        zkq[j] = xbuf[lane + 64 * j];
+        zmq[j] = xbuf[(M - lane - 64 * j) & (M - 1)];
+      }
+      const mf4 zhq = xbuf[M / 2];
+      mel_wave_sync();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        const mc zk = mc_unpack(zkq[j]), zm = mc_unpack(zmq[j]);
+        const mc e = {(zk.re + zm.re) * 0.5f, (zk.im - zm.im) * 0.5f};
+        const mc o = {(zk.im + zm.im) * 0.5f, (zm.re - zk.re) * 0.5f};  // -i/2 (Z[k] - conj Z[M-k])
+        const mc t = mc_mul(o, tws[j]);
+        const mc x1 = e + t, x2 = e - t;
+        const mf2 p1 = x1.re * x1.re + x1.im * x1.im, p2 = x2.re * x2.re + x2.im * x2.im;
+        const mf2 m1 = {__builtin_amdgcn_sqrtf(fmaxf(p1.x, a.eps_power)), __builtin_amdgcn_sqrtf(fmaxf(p1.y, a.eps_power))};
+        const mf2 m2 = {__builtin_amdgcn_sqrtf(fmaxf(p2.x, a.eps_power)), __builtin_amdgcn_sqrtf(fmaxf(p2.y, a.eps_power))};
+        amp[2 * k] = m1;
+        amp[2 * (M - k)] = m2;
+        if (omag) {
+          omag[k] = m1.x;
+          omag[M - k] = m2.x;
+          if (has_b) {
+            omag[M + 1 + k] = m1.y;
+            omag[M + 1 + M - k] = m2.y;
+          }
+        }
+      }
+      if (lane == 0) {
+        const mc z = mc_unpack(zhq);
+        const mf2 p = z.re * z.re + z.im * z.im;
+        const mf2 mh = {__builtin_amdgcn_sqrtf(fmaxf(p.x, a.eps_power)), __builtin_amdgcn_sqrtf(fmaxf(p.y, a.eps_power))};
+        amp[M] = mh;  // cell M / 2
+        if (omag) {
+          omag[M / 2] = mh.x;
+          if (has_b) omag[M + 1 + M / 2] = mh.y;
+        }
+      }
+    }
+    mel_wave_sync();
+    // ---- sparse mel filterbank + dB + normalisation
+    if (a.out_mel) {
+      mf2 melv[MELR_SLOTS];
+      if (mel_fast) {
+        for (int i = lane; i < nch_total; i += 64) {
+          const int2 e = tab[i];
+          const int st = e.x & 0xffff, n = e.x >> 16;
+          mf2 acc = {0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < MELR_CH; ++t)
+            if (t < n) acc += amp[2 * (st + t)] * lds_w[e.y + t];
+          part[2 * i] = acc;
+        }
+        mel_wave_sync();
+#pragma unroll
+        for (int s = 0; s < MELR_SLOTS; ++s) {
+          const int c = lane + 64 * s;
+          mf2 acc = {0.f, 0.f};
+          if (c < a.n_mels)
+            for (int i = cfirst[c]; i < cfirst[c + 1]; ++i) acc += part[2 * i];
+          melv[s] = acc;
+        }
+        mel_wave_sync();  // the cells are rewritten by the next pair of frames
+      } else {
+#pragma unroll
+        for (int s = 0; s < MELR_SLOTS; ++s) {
+          const int c = lane + 64 * s;
+          mf2 acc = {0.f, 0.f};
+          if (c < a.n_mels) {
+            const int st = a.mel_start[c], ln = a.mel_len[c];
+            const float* w = a.mel_w + a.mel_off[c];
+            for (int i = 0; i < ln; ++i) acc += amp[2 * (st + i)] * w[i];
+          }
+          melv[s] = acc;
+        }
+        mel_wave_sync();
+      }
+#pragma unroll
+      for (int s = 0; s < MELR_SLOTS; ++s) {
+        const int c = lane + 64 * s;
+        if (c < a.n_mels) {
+          float* o = a.out_mel + ((long long)b * a.n_mels + c) * a.frames + fa;
+          o[0] = mel_normalise_fast(a, fmaxf(melv[s].x, a.eps_mel), inv_range);
+          if (has_b) o[1] = mel_normalise_fast(a, fmaxf(melv[s].y, a.eps_mel), inv_range);
+        }
+      }
+    }
+  }
+}
+
+static int melspec_reg_launch(const MelArgs& a, hipStream_t st) {
+  const int pairs = kantts_cdiv(a.frames, 2);
+  const long long items_ll = (long long)a.B * pairs;
+  if (items_ll > 0x7fffffffLL) return KANTTS_E_UNSUPPORTED;
+  const int items = (int)items_ll;
+  const size_t lds = ((size_t)MELR_WMAX + 2 * MELR_CHMAX + 132 + (size_t)MELR_WAVES * (4 * MELR_XB)) * sizeof(float);
+  // persistent grid: every workgroup resident (three per CU: 168 VGPRs, 46 KB of LDS), waves stride over the pairs of frames
+  const int cap_env = getenv("KANTTS_MEL_WGS") ? atoi(getenv("KANTTS_MEL_WGS")) : 0;  // sweep switch (scripts/mel_bench.py)
+  const int cap = cap_env > 0 ? cap_env : 768;
+  int grid = kantts_cdiv(items, MELR_WAVES);
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(melspec_reg_kernel, dim3(grid), dim3(64 * MELR_WAVES), lds, st, a, items, pairs);
+  KANTTS_CHECK_LAUNCH();
+}
 
 extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
                                        const float* window, const float* twiddle, float eps_power,
@@ -194,6 +523,8 @@ extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft
   int m = n_fft >> 1, l2 = 0;
   while ((1 << l2) < m) ++l2;
   a.log2m = l2;
+  const bool generic_only = getenv("KANTTS_MEL_GENERIC") != nullptr;  // A/B switch and tests (read per call)
+  if (!generic_only && n_fft == 2 * MELR_M && (!out_mel || n_mels <= 64 * MELR_SLOTS)) return melspec_reg_launch(a, (hipStream_t)stream);
   size_t lds = (size_t)m * 2 * sizeof(float2) + (size_t)(m + 1) * sizeof(float);
   if (lds > 160 * 1024) return KANTTS_E_UNSUPPORTED;
   hipLaunchKernelGGL(melspec_kernel, dim3(kantts_cdiv(frames, MEL_FB), B), dim3(MEL_THREADS), lds, (hipStream_t)stream, a);

@@ -79,6 +79,7 @@ const unsigned char (*post_once(const void* payload, int n, void (*fn)(const uns
 
 #define __syncthreads() hipemu::sync_threads()
 #define KANTTS_WAVE_ORDERED() hipemu::wave_sync()  // see kan-tts_amd/csrc/common.h
+#define KANTTS_OPAQUE_VGPR(x) ((void)0)            // a register-allocation hint on the device (common.h)
 #define __builtin_amdgcn_s_barrier() hipemu::sync_threads()
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
@@ -131,6 +132,10 @@ static inline float hipemu_expf(float x) { return expf(x); }
 static inline float hipemu_logf(float x) { return logf(x); }
 #define __expf hipemu_expf
 #define __logf hipemu_logf
+static inline float hipemu_log2f(float x) { return log2f(x); }
+#define __log2f hipemu_log2f
+static inline float __builtin_amdgcn_sqrtf_emu(float a) { return sqrtf(a); }
+#define __builtin_amdgcn_sqrtf __builtin_amdgcn_sqrtf_emu
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }

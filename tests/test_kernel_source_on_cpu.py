@@ -66,7 +66,14 @@ from test_melspec import (  # noqa: F401
     test_melspec_host_logic_emulated,
     test_melspec_backward_emulated,
     test_dsp_melspectrogram_emulated,
+    _register_form_cases,
 )
+
+
+def test_register_resident_fft_form_kernel_source(emulated_cabi):
+    """melspec_reg_kernel (one wave per frame, frame in registers, three wave-private LDS exchanges) compiled for the host:
+    against the oracle and against the radix-2 kernel, n_fft 1024 and 2048 (tests/test_melspec.py)."""
+    _register_form_cases("cpu")
 from test_hifigan import (  # noqa: F401
     test_conv_variants_emulated_match_torch,
     test_conv_win_emulated_matches_torch,

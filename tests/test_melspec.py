@@ -40,6 +40,53 @@ def _check(device):
                  2e-5, what="golden stft")
 
 
+def _register_form_cases(device):
+    """n_fft 1024 / 2048 take the register-resident FFT (csrc/melspec.hip: melspec_reg_kernel), KANTTS_MEL_GENERIC=1 the
+    radix-2 LDS kernel every other size uses: same mel / magnitudes to rounding, against the oracle as well -- odd lengths,
+    hops that leave a partial group of frames, both paddings, 128 mel channels (both channel slots of a lane), the
+    magnitude output, frames that reach over both ends of the waveform."""
+    from kantts.utils.audio_torch import MelSpectrogram, stft
+
+    g = torch.Generator().manual_seed(31)
+    cases = [
+        (dict(fft_size=1024, hop_size=256), (5, 4099)),
+        (dict(fft_size=1024, hop_size=200, win_length=800, num_mels=128, fmin=0, fmax=11025, pad_mode="reflect"), (2, 2311)),
+        (dict(fs=16000, fft_size=2048, hop_size=200, win_length=1000, fmin=0, fmax=8000), (3, 3001)),
+        (dict(fs=16000, fft_size=2048, hop_size=512, num_mels=40, fmin=50, fmax=7000, pad_mode="reflect"), (1, 2600)),
+    ]
+    for kw, (B, T) in cases:
+        x = torch.randn(B, T, generator=g) * 0.2
+        ms = MelSpectrogram(**kw).to(device)
+        out = {}
+        for generic in (False, True):
+            if generic:
+                os.environ["KANTTS_MEL_GENERIC"] = "1"
+            try:
+                out[generic] = ms(x[:, None, :].to(device)).cpu()
+            finally:
+                os.environ.pop("KANTTS_MEL_GENERIC", None)
+        if "pad_mode" not in kw:  # the oracle restates the reference's zero padding
+            assert_close(out[False], A.mel_spectrogram(x, **kw), 1e-4, what="register-form mel vs oracle %r" % (kw,))
+        assert_close(out[False], out[True], 5e-5, what="register-form mel vs generic kernel %r" % (kw,))
+    for n_fft, hop, win, (B, T) in ((1024, 120, 600, (3, 1500)), (2048, 240, 1200, (2, 4100))):
+        x = torch.randn(B, T, generator=g) * 0.2
+        out = {}
+        for generic in (False, True):
+            if generic:
+                os.environ["KANTTS_MEL_GENERIC"] = "1"
+            try:
+                out[generic] = stft(x.to(device), n_fft, hop, win, "hann").cpu()
+            finally:
+                os.environ.pop("KANTTS_MEL_GENERIC", None)
+        assert_close(out[False], A.stft_magnitude(x, n_fft, hop, win), 2e-5, rtol=2e-5, what="register-form |STFT| vs oracle")
+        assert_close(out[False], out[True], 2e-5, rtol=2e-5, what="register-form |STFT| vs generic kernel")
+
+
+@pytest.mark.gpu
+def test_register_resident_fft_form_gpu():
+    _register_form_cases("cuda")
+
+
 def test_melspec_host_logic_emulated():
     with emulation():
         _check("cpu")
