@@ -713,11 +713,11 @@ def melspec_leg(B=32, T_wav=8192, reps=20):
     return {"workload": "mel-STFT 22.05 kHz n_fft 1024 hop 256 80 mels, batch %d x %d samples (%d frames)" % (B, T_wav, frames),
             "dtype": "fp32", "forward_ms": ms_fwd, "forward_frames_per_s": frames / (ms_fwd * 1e-3),
             "forward_backward_ms": ms_fb,
-            "roofline": {"bound": "hbm", "kernel": "melspec_kernel", "achieved": gbps, "peak": PEAK_HBM_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "melspec_reg_kernel", "achieved": gbps, "peak": PEAK_HBM_GBPS,
                          "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "algorithmic_bytes_per_frame": 1344,
                          "note": "one launch of %d frames = %.2f MB algorithmic: launch-latency bound at this size"
                                  % (frames, frames * 1344 / 1e6)},
-            "roofline_saturating": {"bound": "hbm", "kernel": "melspec_kernel", "workload": "%d x %d samples (%d frames)"
+            "roofline_saturating": {"bound": "hbm", "kernel": "melspec_reg_kernel", "workload": "%d x %d samples (%d frames)"
                                     % (Bs, T_wav, frames_s), "forward_ms": ms_s, "forward_backward_ms": ms_s_fb,
                                     "achieved": gbps_s, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps_s / PEAK_HBM_GBPS,
                                     "algorithmic_bytes": frames_s * 1344.0},

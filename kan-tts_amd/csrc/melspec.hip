@@ -219,10 +219,9 @@ __device__ __forceinline__ float mel_normalise_fast(const MelArgs& a, float mel,
 #define MELR_WAVES 4    // waves per workgroup, each with its own pair of frames
 #define MELR_CH 8       // filterbank weights per chunk
 #define MELR_CHMAX 256  // chunks the table holds (else: per-channel loop over global weights, as melspec_kernel)
-#define MELR_WMAX 1536  // filterbank weights staged in LDS (triangular filters over n_fft / 2 + 1 bins: ~2 per bin)
 #define MELR_SLOTS 2    // mel channels per lane (n_mels <= 128; more: melspec_kernel)
 #define MELR_M 512
-#define MELR_XB (8 * 72)  // 16-byte cells of the exchange buffer (cell 512 = M is spare in the natural-order layout)
+#define MELR_XB (8 * 72 + 8)  // 16-byte cells of the exchange buffer; the magnitudes reuse it: bin k at cell k + (k >> 3) (<= 583)
 
 // one waveform sample of a frame that reaches over an end of the utterance: zero or reflect padding, branch-free
 __device__ __forceinline__ float melr_edge_sample(const MelArgs& a, const float* __restrict__ x, int s) {
@@ -233,27 +232,26 @@ __device__ __forceinline__ float melr_edge_sample(const MelArgs& a, const float*
   const float xv = x[min(max(s, 0), a.T - 1)];
   return (s >= 0 && s < a.T) ? xv : 0.f;
 }
-// windowed samples 2 (lane + 64 r) + {0, 1} of frame f, r < 8, into half `H` (0: frame A, 1: frame B) of v[r]; zeros for a
-// frame beyond the utterance
+// raw samples 2 (lane + 64 r) + {0, 1} of frame f, r < 8, into half `H` (0: frame A, 1: frame B) of v[r]; zeros for a
+// frame beyond the utterance (the window is applied when the pair is processed: the fetch runs one pair ahead)
 template <int H>
-__device__ __forceinline__ void melr_load(const MelArgs& a, const float* __restrict__ x, int f, int lane,
-                                          const float (&win)[16], mc (&v)[8]) {
+__device__ __forceinline__ void melr_load(const MelArgs& a, const float* __restrict__ x, int f, int lane, mc (&v)[8]) {
   const int start = f * a.hop - MELR_M;
   const bool interior = f < a.frames && start >= 0 && start + 2 * MELR_M <= a.T;
   if (interior) {
     const float* xs = x + start + 2 * lane;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      v[r].re[H] = xs[128 * r] * win[2 * r];
-      v[r].im[H] = xs[128 * r + 1] * win[2 * r + 1];
+      v[r].re[H] = xs[128 * r];
+      v[r].im[H] = xs[128 * r + 1];
     }
   } else {
     const float live = f < a.frames ? 1.f : 0.f;
     const int s0 = start + 2 * lane;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      v[r].re[H] = melr_edge_sample(a, x, s0 + 128 * r) * (win[2 * r] * live);
-      v[r].im[H] = melr_edge_sample(a, x, s0 + 128 * r + 1) * (win[2 * r + 1] * live);
+      v[r].re[H] = melr_edge_sample(a, x, s0 + 128 * r) * live;
+      v[r].im[H] = melr_edge_sample(a, x, s0 + 128 * r + 1) * live;
     }
   }
 }
@@ -263,50 +261,58 @@ __global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const M
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // workgroup-shared: filterbank weights, chunk table, channel -> first chunk;  then per wave: exchange buffer, magnitudes
   float* lds_w = smem;
-  int2* tab = reinterpret_cast<int2*>(lds_w + MELR_WMAX);
-  int* cfirst = reinterpret_cast<int*>(tab + MELR_CHMAX);  // n_mels + 1 entries (<= 129), [130] = weights staged or -1
-  float* wave_base = reinterpret_cast<float*>(cfirst + 132);
+  int* tab = reinterpret_cast<int*>(lds_w + MELR_CHMAX * MELR_CH);
+  int* cfirst = tab + MELR_CHMAX;  // n_mels + 1 entries (<= 129)
+  mf2* lds_win = reinterpret_cast<mf2*>(cfirst + 132);  // window[2 n], window[2 n + 1]
+  mf2* lds_tws = lds_win + MELR_M;                      // W_N^k, k < M / 2 (split pass)
+  float* wave_base = reinterpret_cast<float*>(lds_tws + MELR_M / 2);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   mf4* xbuf = reinterpret_cast<mf4*>(wave_base + (size_t)wv * (4 * MELR_XB));
-  mf2* amp = reinterpret_cast<mf2*>(xbuf);       // magnitude k of both frames: low half of cell k (amp[2 k]), see the split
+  mf2* amp = reinterpret_cast<mf2*>(xbuf);       // magnitude of bin k, both frames: low half of cell k + (k >> 3), see the split
   mf2* part = reinterpret_cast<mf2*>(xbuf) + 1;  // chunk sum i: high half of cell i (part[2 i])
 
-  // ---- once per workgroup: chunk table of the sparse filterbank
+  // ---- once per workgroup: the sparse filterbank cut into chunks over ALIGNED blocks of MELR_CH bins, zero padded:
+  //      chunk i = weights of bins 8 tab[i] .. 8 tab[i] + 7 (slots 0-3 of all chunks, then slots 4-7: 16-byte reads at a
+  //      16-byte lane stride), channel c = chunks cfirst[c] .. cfirst[c + 1] - 1
   bool mel_fast = false;
   int nch_total = 0;
+  for (int n = tid; n < MELR_M; n += 64 * MELR_WAVES) lds_win[n] = (mf2){a.window[2 * n], a.window[2 * n + 1]};
+  for (int k = tid; k < MELR_M / 2; k += 64 * MELR_WAVES) lds_tws[k] = (mf2){a.tw[k].x, a.tw[k].y};
   if (a.out_mel) {
     if (tid == 0) {
-      int first = 0, wend = 0;
+      int first = 0;
       for (int c = 0; c < a.n_mels; ++c) {
         cfirst[c] = first;
-        const int ln = a.mel_len[c];
-        first += (ln + MELR_CH - 1) / MELR_CH;
-        wend = max(wend, a.mel_off[c] + ln);
+        const int st = a.mel_start[c], ln = a.mel_len[c];
+        if (ln > 0) first += ((st + ln - 1) >> 3) - (st >> 3) + 1;
       }
       cfirst[a.n_mels] = first;
-      cfirst[130] = (first <= MELR_CHMAX && wend <= MELR_WMAX) ? wend : -1;
     }
     __syncthreads();
-    const int wend = cfirst[130];
-    mel_fast = wend >= 0;
     nch_total = cfirst[a.n_mels];
-    if (mel_fast) {
+    mel_fast = nch_total <= MELR_CHMAX;
+    if (mel_fast) {  // uniform
+      for (int i = tid; i < MELR_CHMAX * MELR_CH; i += 64 * MELR_WAVES) lds_w[i] = 0.f;
+      for (int i = tid; i < MELR_CHMAX; i += 64 * MELR_WAVES) tab[i] = 0;
+      __syncthreads();
       for (int c = tid; c < a.n_mels; c += 64 * MELR_WAVES) {
-        const int st = a.mel_start[c], ln = a.mel_len[c], of = a.mel_off[c], fi = cfirst[c];
-        for (int q = 0; q * MELR_CH < ln; ++q)
-          tab[fi + q] = make_int2((st + q * MELR_CH) | (min(MELR_CH, ln - q * MELR_CH) << 16), of + q * MELR_CH);
+        const int st = a.mel_start[c], ln = a.mel_len[c], fi = cfirst[c], blk0 = st >> 3;
+        const float* w = a.mel_w + a.mel_off[c];
+        for (int i = 0; i < ln; ++i) {
+          const int bin = st + i, ci = fi + (bin >> 3) - blk0, t = bin & 7;
+          lds_w[(t >> 2) * (4 * MELR_CHMAX) + 4 * ci + (t & 3)] = w[i];
+        }
+        if (ln > 0)
+          for (int q = blk0; q <= (st + ln - 1) >> 3; ++q) tab[fi + q - blk0] = q;
       }
-      for (int i = tid; i < wend; i += 64 * MELR_WAVES) lds_w[i] = a.mel_w[i];
     }
-    __syncthreads();
   }
+  __syncthreads();
 
   // ---- per-lane constants
   const int c8 = lane & 7, hi8 = lane >> 3;
   mf2 tw1[8];  // W_M^(lane k0)                               (after pass 1)
   mf2 tw2[8];  // W_64^(c k1) = W_M^(8 c k1), c = lane & 7    (after pass 2)
-  mf2 tws[4];  // W_N^k, k = lane + 64 j                      (split pass)
-  float win[16];
   auto twM = [&](int x) -> mf2 {  // W_M^x = W_N^(2x), the table holds W_N^t for t < M
     int t = 2 * x;
     const bool neg = t >= M;
@@ -318,19 +324,16 @@ __global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const M
   for (int k0 = 0; k0 < 8; ++k0) tw1[k0] = twM(lane * k0);
 #pragma unroll
   for (int k1 = 0; k1 < 8; ++k1) tw2[k1] = twM(8 * c8 * k1);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float2 w = a.tw[lane + 64 * j];
-    tws[j] = (mf2){w.x, w.y};
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    win[2 * r] = a.window[2 * (lane + 64 * r)];
-    win[2 * r + 1] = a.window[2 * (lane + 64 * r) + 1];
-  }
   const float inv_range = 1.f / (-a.min_db);
+  const int nit = (nch_total + 63) >> 6;
 
   const int wave_global = blockIdx.x * MELR_WAVES + wv, wave_count = gridDim.x * MELR_WAVES;
+  mc v[8];
+  if (wave_global < items) {
+    const int b = wave_global / pairs_per_row, fa = (wave_global - b * pairs_per_row) * 2;
+    melr_load<0>(a, a.wav + (long long)b * a.T, fa, lane, v);
+    melr_load<1>(a, a.wav + (long long)b * a.T, fa + 1, lane, v);
+  }
 #pragma unroll 1
   for (int item = wave_global; item < items; item += wave_count) {
     const int b = item / pairs_per_row, fa = (item - b * pairs_per_row) * 2;  // frames fa, fa + 1 (the second may not exist)
@@ -342,29 +345,30 @@ __global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const M
       KANTTS_OPAQUE_VGPR(tw1[k]);
       KANTTS_OPAQUE_VGPR(tw2[k]);
     }
+    // the samples of this pair were fetched (raw) while the previous pair's filterbank ran; window them now
 #pragma unroll
-    for (int k = 0; k < 4; ++k) KANTTS_OPAQUE_VGPR(tws[k]);
-    const float* x = a.wav + (long long)b * a.T;
-    mc v[8];
-    melr_load<0>(a, x, fa, lane, win, v);
-    melr_load<1>(a, x, fa + 1, lane, win, v);
+    for (int r = 0; r < 8; ++r) {
+      const mf2 w = lds_win[lane + 64 * r];
+      v[r].re *= w.x;
+      v[r].im *= w.y;
+    }
     // ---- pass 1: DFT over a (registers), twiddle, exchange 1: cell (k0, L) at 72 k0 + L
     mc_dft8(v);
 #pragma unroll
     for (int k0 = 0; k0 < 8; ++k0) xbuf[72 * k0 + lane] = mc_pack((k0 == 0) ? v[0] : mc_mul(v[k0], tw1[k0]));
     mel_wave_sync();
     // ---- pass 2: lane (k0, c) = 8 k0 + c takes b = 0..7; DFT over b, twiddle W_64^(c k1), exchange 2: cell (k0, k1, c)
-    //      at 66 c + k0 + 8 k1
+    //      at 65 c + k0 + 8 k1 (ds_write_b128 is serviced in groups of 8 contiguous lanes over 32 banks: 65 c mod 8 = c)
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) v[bb] = mc_unpack(xbuf[72 * hi8 + 8 * bb + c8]);
     mel_wave_sync();
     mc_dft8(v);
 #pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1) xbuf[66 * c8 + hi8 + 8 * k1] = mc_pack((k1 == 0) ? v[0] : mc_mul(v[k1], tw2[k1]));
+    for (int k1 = 0; k1 < 8; ++k1) xbuf[65 * c8 + hi8 + 8 * k1] = mc_pack((k1 == 0) ? v[0] : mc_mul(v[k1], tw2[k1]));
     mel_wave_sync();
     // ---- pass 3: lane l = k0 + 8 k1 takes c = 0..7; DFT over c -> k2; X[k], k = l + 64 k2, to cell k
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) v[cc] = mc_unpack(xbuf[66 * cc + lane]);
+    for (int cc = 0; cc < 8; ++cc) v[cc] = mc_unpack(xbuf[65 * cc + lane]);
     mel_wave_sync();
     mc_dft8(v);
 #pragma unroll
@@ -377,10 +381,12 @@ __global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const M
     float* omag = a.out_mag ? a.out_mag + ((long long)b * a.frames + fa) * (M + 1) : nullptr;
     {
       mf4 zkq[4], zmq[4];
+      mf2 tws[4];  // W_N^k, k = lane + 64 j
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         zkq[j] = xbuf[lane + 64 * j];
         zmq[j] = xbuf[(M - lane - 64 * j) & (M - 1)];
+        tws[j] = lds_tws[lane + 64 * j];
       }
       const mf4 zhq = xbuf[M / 2];
       mel_wave_sync();
@@ -395,8 +401,8 @@ __global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const M
         const mf2 p1 = x1.re * x1.re + x1.im * x1.im, p2 = x2.re * x2.re + x2.im * x2.im;
         const mf2 m1 = {__builtin_amdgcn_sqrtf(fmaxf(p1.x, a.eps_power)), __builtin_amdgcn_sqrtf(fmaxf(p1.y, a.eps_power))};
         const mf2 m2 = {__builtin_amdgcn_sqrtf(fmaxf(p2.x, a.eps_power)), __builtin_amdgcn_sqrtf(fmaxf(p2.y, a.eps_power))};
-        amp[2 * k] = m1;
-        amp[2 * (M - k)] = m2;
+        amp[2 * (k + (k >> 3))] = m1;
+        amp[2 * (M - k + ((M - k) >> 3))] = m2;
         if (omag) {
           omag[k] = m1.x;
           omag[M - k] = m2.x;
@@ -410,58 +416,97 @@ __global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const M
         const mc z = mc_unpack(zhq);
         const mf2 p = z.re * z.re + z.im * z.im;
         const mf2 mh = {__builtin_amdgcn_sqrtf(fmaxf(p.x, a.eps_power)), __builtin_amdgcn_sqrtf(fmaxf(p.y, a.eps_power))};
-        amp[M] = mh;  // cell M / 2
+        amp[2 * (M / 2 + M / 16)] = mh;
         if (omag) {
           omag[M / 2] = mh.x;
           if (has_b) omag[M + 1 + M / 2] = mh.y;
         }
       }
     }
+    // this lane's chunks (lane + 64 it) and channels (lane + 64 sl): first bin of each chunk, chunk range of each channel
+    // (from LDS, not held in registers across pairs: the register budget of three waves per SIMD is spent on the twiddles)
+    int ch_bin[MELR_CHMAX / 64], ch_first[MELR_SLOTS], ch_end[MELR_SLOTS];
+    int ln = lane;
+    KANTTS_OPAQUE_VGPR(ln);  // addresses derived from the lane are recomputed here, not hoisted out of the loop into registers
+    if (mel_fast) {
+#pragma unroll
+      for (int it = 0; it < MELR_CHMAX / 64; ++it) ch_bin[it] = tab[ln + 64 * it];
+#pragma unroll
+      for (int sl = 0; sl < MELR_SLOTS; ++sl) {
+        const int c = min(ln + 64 * sl, a.n_mels - 1);
+        ch_first[sl] = cfirst[c];
+        ch_end[sl] = cfirst[c + 1];
+      }
+    }
+    // the next pair's samples: issued here, first touched at the top of the next iteration (the filterbank below hides
+    // the memory latency; v is dead from the split pass on)
+    {
+      const int nitem = item + wave_count;
+      if (nitem < items) {
+        const int nb = nitem / pairs_per_row, nfa = (nitem - nb * pairs_per_row) * 2;
+        melr_load<0>(a, a.wav + (long long)nb * a.T, nfa, lane, v);
+        melr_load<1>(a, a.wav + (long long)nb * a.T, nfa + 1, lane, v);
+      }
+    }
+    if (lane < MELR_CH - 1) amp[2 * (M + M / 8 + 1 + lane)] = (mf2){0.f, 0.f};  // bins M + 1 .. M + 7 of the last block: weight 0, must be finite
     mel_wave_sync();
     // ---- sparse mel filterbank + dB + normalisation
     if (a.out_mel) {
       mf2 melv[MELR_SLOTS];
       if (mel_fast) {
-        for (int i = lane; i < nch_total; i += 64) {
-          const int2 e = tab[i];
-          const int st = e.x & 0xffff, n = e.x >> 16;
-          mf2 acc = {0.f, 0.f};
 #pragma unroll
-          for (int t = 0; t < MELR_CH; ++t)
-            if (t < n) acc += amp[2 * (st + t)] * lds_w[e.y + t];
-          part[2 * i] = acc;
+        for (int it = 0; it < MELR_CHMAX / 64; ++it) {
+          if (it < nit) {  // uniform
+            const int i = ln + 64 * it;
+            const mf4 w0 = reinterpret_cast<const mf4*>(lds_w)[i], w1 = reinterpret_cast<const mf4*>(lds_w)[MELR_CHMAX + i];
+            const mf2* ap = amp + 2 * 9 * ch_bin[it];  // block q: cells 9 q .. 9 q + 7 (lanes on neighbouring blocks: 144 B apart)
+            mf2 acc = ap[0] * w0.x;
+            acc += ap[2] * w0.y;
+            acc += ap[4] * w0.z;
+            acc += ap[6] * w0.w;
+            acc += ap[8] * w1.x;
+            acc += ap[10] * w1.y;
+            acc += ap[12] * w1.z;
+            acc += ap[14] * w1.w;
+            part[2 * i] = acc;
+          }
         }
         mel_wave_sync();
 #pragma unroll
-        for (int s = 0; s < MELR_SLOTS; ++s) {
-          const int c = lane + 64 * s;
+        for (int sl = 0; sl < MELR_SLOTS; ++sl) {
           mf2 acc = {0.f, 0.f};
-          if (c < a.n_mels)
-            for (int i = cfirst[c]; i < cfirst[c + 1]; ++i) acc += part[2 * i];
-          melv[s] = acc;
+          const mf2* pp = part + 2 * ch_first[sl];
+          const int cnt = (ln + 64 * sl < a.n_mels) ? ch_end[sl] - ch_first[sl] : 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {  // a lane's first four reads are always inside the wave's cells
+            const mf2 p = pp[2 * i];
+            acc += (i < cnt) ? p : (mf2){0.f, 0.f};
+          }
+          for (int i = 4; i < cnt; ++i) acc += pp[2 * i];
+          melv[sl] = acc;
         }
         mel_wave_sync();  // the cells are rewritten by the next pair of frames
       } else {
 #pragma unroll
-        for (int s = 0; s < MELR_SLOTS; ++s) {
-          const int c = lane + 64 * s;
+        for (int sl = 0; sl < MELR_SLOTS; ++sl) {
+          const int c = lane + 64 * sl;
           mf2 acc = {0.f, 0.f};
           if (c < a.n_mels) {
             const int st = a.mel_start[c], ln = a.mel_len[c];
             const float* w = a.mel_w + a.mel_off[c];
-            for (int i = 0; i < ln; ++i) acc += amp[2 * (st + i)] * w[i];
+            for (int i = 0; i < ln; ++i) acc += amp[2 * (st + i + ((st + i) >> 3))] * w[i];
           }
-          melv[s] = acc;
+          melv[sl] = acc;
         }
         mel_wave_sync();
       }
 #pragma unroll
-      for (int s = 0; s < MELR_SLOTS; ++s) {
-        const int c = lane + 64 * s;
+      for (int sl = 0; sl < MELR_SLOTS; ++sl) {
+        const int c = lane + 64 * sl;
         if (c < a.n_mels) {
           float* o = a.out_mel + ((long long)b * a.n_mels + c) * a.frames + fa;
-          o[0] = mel_normalise_fast(a, fmaxf(melv[s].x, a.eps_mel), inv_range);
-          if (has_b) o[1] = mel_normalise_fast(a, fmaxf(melv[s].y, a.eps_mel), inv_range);
+          o[0] = mel_normalise_fast(a, fmaxf(melv[sl].x, a.eps_mel), inv_range);
+          if (has_b) o[1] = mel_normalise_fast(a, fmaxf(melv[sl].y, a.eps_mel), inv_range);
         }
       }
     }
@@ -473,8 +518,8 @@ static int melspec_reg_launch(const MelArgs& a, hipStream_t st) {
   const long long items_ll = (long long)a.B * pairs;
   if (items_ll > 0x7fffffffLL) return KANTTS_E_UNSUPPORTED;
   const int items = (int)items_ll;
-  const size_t lds = ((size_t)MELR_WMAX + 2 * MELR_CHMAX + 132 + (size_t)MELR_WAVES * (4 * MELR_XB)) * sizeof(float);
-  // persistent grid: every workgroup resident (three per CU: 168 VGPRs, 46 KB of LDS), waves stride over the pairs of frames
+  const size_t lds = ((size_t)MELR_CHMAX * MELR_CH + MELR_CHMAX + 132 + 3 * MELR_M + (size_t)MELR_WAVES * (4 * MELR_XB)) * sizeof(float);
+  // persistent grid: every workgroup resident (three per CU: 168 VGPRs, 52.8 KB of LDS), waves stride over the pairs of frames
   const int cap_env = getenv("KANTTS_MEL_WGS") ? atoi(getenv("KANTTS_MEL_WGS")) : 0;  // sweep switch (scripts/mel_bench.py)
   const int cap = cap_env > 0 ? cap_env : 768;
   int grid = kantts_cdiv(items, MELR_WAVES);
