@@ -623,37 +623,41 @@ class _DeferredTN:
         place by clipping.  Only storages are kept, so autograd can still adopt both tensors as p.grad."""
         if not self.enabled:
             return src
-        dst = torch.empty_like(src)  # overwritten in full by the copy at flush time
+        from .ops import gzeros  # (from the accumulator pool: a candidate for the direct-gradient plan of the arena)
+
+        dst = gzeros(tuple(src.shape), src.device) if src.dtype == torch.float32 else torch.empty_like(src)
         self.copies.append((self._desc(dst), self._desc(src)))
         return dst
 
     def flush(self):
+        """[round 4] Spreading the LAST flush of a step (~8 grouped launches of 256-2048 workgroups, 160 us back to back at
+        the tail of the captured step) over four streams was measured: 7.12 ms against 7.14 ms on one stream, same box
+        (profiles/r04_runP_direct_grads_and_spread_flush_ab.log) -- the launches are bound by their fp32 atomics, not by
+        idle CUs.  Removed."""
         if not self.groups and not self.copies:
             return
         groups, self.groups = self.groups, {}
         copies, self.copies = self.copies, []
-        self._launch(groups)
+        self._launch([probs[s:s + TN_MAX_GROUP] for probs in groups.values() for s in range(0, len(probs), TN_MAX_GROUP)])
         if copies:
             torch._foreach_copy_([self._rebuild(d) for d, _ in copies], [self._rebuild(s) for _, s in copies])
 
-    def _launch(self, groups):
+    def _launch(self, chunks):
         L = lib()
-        for probs in groups.values():
-            for s in range(0, len(probs), TN_MAX_GROUP):
-                chunk = probs[s:s + TN_MAX_GROUP]
-                n = len(chunk)
-                arr = lambda k: (c_void_p * n)(*[q[k] for q in chunk])  # noqa: E731
-                seeds = (c_uint64 * n)(*[q[5] for q in chunk])
-                g = chunk[0][0]
-                g.slices = 0
-                if _profile is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                check(L.kantts_bgemm_tn_grouped(ctypes.byref(g), n, arr(1), arr(2), arr(3), arr(4), seeds, stream()),
-                      "bgemm_tn_grouped")
-                if _profile is not None:
-                    e1.record()
-                    _profile.append((e0, e1, 2.0 * g.M * g.N * g.K * g.ntaps * n))
+        for chunk in chunks:
+            n = len(chunk)
+            arr = lambda k: (c_void_p * n)(*[q[k] for q in chunk])  # noqa: E731
+            seeds = (c_uint64 * n)(*[q[5] for q in chunk])
+            g = chunk[0][0]
+            g.slices = 0
+            if _profile is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(L.kantts_bgemm_tn_grouped(ctypes.byref(g), n, arr(1), arr(2), arr(3), arr(4), seeds, stream()),
+                  "bgemm_tn_grouped")
+            if _profile is not None:
+                e1.record()
+                _profile.append((e0, e1, 2.0 * g.M * g.N * g.K * g.ntaps * n))
 
 
 deferred_tn = _DeferredTN()

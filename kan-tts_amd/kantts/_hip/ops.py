@@ -43,6 +43,11 @@ class _ZeroPool:
     def __init__(self):
         self.buf = None
         self.off = 0
+        # direct gradients (train/optim.py: ParamArena.enable_direct_grads): the n-th take() after a reset that turned out
+        # to become a parameter's .grad is served from that parameter's range of the gradient arena from then on
+        self.calls = 0
+        self.plan = None  # {call index: arena gradient view}
+        self.log = None   # while recording: [(call index, data pointer, numel)]
 
     def enable(self, numel, device):
         """Reserve room for ``numel`` more accumulators (every arena optimizer of the process adds its share:
@@ -52,6 +57,7 @@ class _ZeroPool:
         self.off = 0
 
     def reset(self):
+        self.calls = 0
         if self.buf is not None:
             self.buf.zero_()
             self.off = 0
@@ -60,6 +66,20 @@ class _ZeroPool:
         n = 1
         for d in shape:
             n *= int(d)
+        idx = self.calls
+        self.calls += 1
+        if self.plan is not None:
+            v = self.plan.get(idx)
+            # a changed call sequence (another code path, another module) only costs the copy that pack_grads() makes for
+            # every gradient it does not find in its own slot
+            if v is not None and v.numel() == n and v.device == device:
+                return v.view(shape)
+        t = self._take(shape, device, n)
+        if self.log is not None:
+            self.log.append((idx, t.data_ptr(), n))
+        return t
+
+    def _take(self, shape, device, n):
         if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
             return torch.zeros(shape, device=device, dtype=torch.float32)
         a = (self.off + 63) // 64 * 64

@@ -58,6 +58,9 @@ class GraphedSambertStep:
         # the hook-driven overlap of the eager path is switched off for this optimizer
         optimizer.arena.overlap = False
         optimizer.enable_device_state()  # idempotent: one [lr, step] tensor shared by every captured shape
+        # parameter gradients written straight into the gradient arena: recorded in the first warm-up step, in force
+        # from the second (train/optim.py: ParamArena.enable_direct_grads)
+        optimizer.arena.enable_direct_grads()
         self.loss = None
         # the warm-up steps exist only to populate allocator pools / lazy kernel state before capture: weights, Adam
         # moments, step counters and the dropout offset are put back afterwards, so a new batch shape costs exactly one

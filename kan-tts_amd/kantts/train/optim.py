@@ -50,6 +50,7 @@ class ParamArena:
         self._weights_version = 0  # bumped whenever the fp32 master weights change (the shadow_stale setter)
         self._shadow_stale = False
         self._wn_table = None
+        self._direct, self._plan = None, None  # None / "record" / "on": enable_direct_grads()
         if bf16_shadow:
             self._build_shadow()
 
@@ -64,6 +65,51 @@ class ParamArena:
         self._shadow_stale = bool(value)
         if value:
             self._weights_version += 1
+
+    # ------------------------------------------------------------------------------------------ direct gradients
+    def enable_direct_grads(self):
+        """Let the layers' backward kernels write parameter gradients straight into this arena's gradient buffer.
+
+        The gradient accumulators of a backward pass come from ops.zero_pool in a fixed order (same model, same mode).  The
+        next backward pass is RECORDED: which of those requests ended up as which parameter's ``.grad``.  From the pass
+        after it, exactly those requests are served from the parameter's own range of ``self.grad`` (zeroed per step like
+        the pool), autograd adopts the view as ``p.grad``, and pack_grads() finds every gradient in place: the ~7
+        multi-tensor copy launches (130 us, the serial tail of a captured SAM-BERT step: profiles/r04_runH) disappear.
+        Nothing depends on the order staying the same: pack_grads() copies whatever is not where it belongs.  Only for a
+        process with ONE arena optimizer (the pool's call counter restarts at every zero_grad of any of them)."""
+        if self._direct is None and not __import__("os").environ.get("KANTTS_NO_DIRECT_GRADS"):
+            self._direct = "record"
+
+    def _direct_begin(self):
+        """The plan is only in force between this arena's zero_grad and its step: another arena's backward pass in between
+        (a second model in the process) must not be handed ranges of this gradient buffer."""
+        if self._direct == "record":
+            ops.zero_pool.plan, ops.zero_pool.log = None, []
+        elif self._direct == "on":
+            self.grad.zero_()
+            ops.zero_pool.plan, ops.zero_pool.log = self._plan, None
+
+    def _direct_end(self):
+        if self._direct == "record":
+            self._direct_finish_recording()
+        elif self._direct == "on" and ops.zero_pool.plan is self._plan:
+            ops.zero_pool.plan = None
+
+    def _direct_finish_recording(self):
+        log, ops.zero_pool.log = ops.zero_pool.log, None
+        if not log:
+            return
+        where = {ptr_: (idx, n) for idx, ptr_, n in log}
+        plan = {}
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+                continue
+            hit = where.get(g.data_ptr())
+            if hit is not None and hit[1] == p.numel():
+                plan[hit[0]] = self.grad_views[i]
+        self._plan = plan
+        self._direct = "on"
 
     # ------------------------------------------------------------------------------------------ weight-norm images
     def build_weight_norm_images(self):
@@ -353,6 +399,8 @@ class ParamArena:
         those are discarded by the next zero_grad and must not be exchanged."""
         if self._wn_table is not None and not __import__("os").environ.get("KANTTS_NO_WEIGHT_NORM_TABLE"):
             self._wn_defer = True
+        if self._direct is not None:
+            self._direct_begin()
         if not getattr(self, "overlap", False):
             return
         for b in self.buckets:
@@ -397,9 +445,9 @@ class ParamArena:
             g = p.grad
             if g is None:
                 self.grad_views[i].zero_()
-            else:
+            elif g.data_ptr() != self.grad_views[i].data_ptr():  # (in place already: grad_slot / direct gradients)
                 dst.append(self.grad_views[i])
-                src.append(g)
+                src.append(self._out_of_arena(g))
         if dst:
             torch._foreach_copy_(dst, src)
         if self.bucket_ready is not None:
@@ -428,10 +476,21 @@ class ParamArena:
         self.grad.mul_(1.0 / self.world_size)
         return self.grad
 
+    def _out_of_arena(self, g):
+        """A gradient that lives in this arena's gradient buffer but NOT in its own slot (a direct-gradient plan applied
+        to a changed call sequence) is moved out before anything is copied into the arena."""
+        base = self.grad.data_ptr()
+        if base <= g.data_ptr() < base + 4 * self.numel:
+            return g.clone()
+        return g
+
     def pack_grads(self):
-        """Pack every ``p.grad`` into the (padded) gradient arena with one multi-tensor copy."""
-        src = []
-        for p in self.params:
+        """Every ``p.grad`` into the (padded) gradient arena with one multi-tensor copy; gradients that are already views of
+        their own slot (grad_slot, enable_direct_grads) are left alone."""
+        if self._direct is not None:
+            self._direct_end()
+        dst, src = [], []
+        for i, p in enumerate(self.params):
             g = p.grad
             if g is None:
                 z = self._zero_cache.get(tuple(p.shape))
@@ -439,8 +498,13 @@ class ParamArena:
                     z = torch.zeros(p.shape, device=self.grad.device, dtype=torch.float32)
                     self._zero_cache[tuple(p.shape)] = z
                 g = z
+            elif g.data_ptr() == self.grad_views[i].data_ptr():
+                continue
+            dst.append(self.grad_views[i])
             src.append(g)
-        torch._foreach_copy_(self.grad_views, src)
+        if dst:
+            src = [self._out_of_arena(g) for g in src]  # (all clones before the first copy)
+            torch._foreach_copy_(dst, src)
         return self.grad
 
     def all_reduce_grads(self):
@@ -532,6 +596,8 @@ class ArenaAdam(torch.optim.Optimizer):
         arena = self.arena
         ops.wgrad_overlap.join()  # weight gradients produced on the side stream (no-op unless enabled)
         arena._wn_defer = False
+        if arena._direct is not None:
+            arena._direct_end()  # (recording -> plan; the plan is out of force until the next zero_grad)
         if packed:
             g = arena.grad
         elif getattr(arena, "overlap", False) and arena._active:

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round 4, visit P: direct gradients (no packing copies) and the spread final weight-gradient flush: parity tests, then A/B
+# on the captured SAM-BERT step (same box)
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_trainer.py tests/test_bench_config_parity.py tests/test_gpu_ops.py -m gpu -q -x -k "direct_gradients or sambert or fused_sambert" 2>&1 | tail -3 | tee gpurun_out/r4p_tests.log
+A="--steps 40 --warmup 10 --no-hifigan --no-cpu-baseline --no-fp32 --no-inference --no-roofline --no-forward-only"
+for v in "X=1" "KANTTS_NO_DIRECT_GRADS=1" "KANTTS_NO_SPREAD_FLUSH=1" "X=2" "KANTTS_NO_DIRECT_GRADS=1" "KANTTS_NO_SPREAD_FLUSH=1" "X=3"; do
+  env $v timeout 300 python bench.py $A 2> gpurun_out/r4p_err.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', 'step %.3f ms  loss %.5f' % (d['ms_per_step'], d['config']['final_loss']))" | tee -a gpurun_out/r4p_step_ab.log
+done

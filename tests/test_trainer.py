@@ -9,8 +9,8 @@ import torch_oracle as O
 from util import emulation
 
 
-def _sambert_setup(device, save_dir, seed=0):
-    from kantts.models import model_builder
+def _sambert_setup(device, save_dir, seed=0, use_arena=None):
+    from kantts.models import model_builder, sambert_model_builder
     from kantts.train.loss import MelReconLoss, ProsodyReconLoss
     from kantts.train.trainer import Sambert_Trainer
 
@@ -24,7 +24,10 @@ def _sambert_setup(device, save_dir, seed=0):
         "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}}, "grad_norm": 1.0, "batch_size": 3,
         "log_interval_steps": 2}
     torch.manual_seed(seed)
-    model, opt, sch = model_builder(config, device=device)
+    if use_arena is None:
+        model, opt, sch = model_builder(config, device=device)
+    else:
+        model, opt, sch = sambert_model_builder(config, device, 0, False, use_arena=use_arena)
     model["KanTtsSAMBERT"].eval()  # Prenet's hard-wired Dropout(0.5) off: deterministic steps
     crit = {"MelReconLoss": MelReconLoss(), "ProsodyReconLoss": ProsodyReconLoss()}
     batches = []
@@ -57,6 +60,56 @@ def _sambert_resume(device, tmp_path):
     got = [float(tr2.train_step(b)) for b in batches[2:]]
     for a, b in zip(got, ref):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (got, ref)
+
+
+def _direct_gradients(device, tmp_path):
+    """ParamArena.enable_direct_grads (the captured step switches it on): the first step records which accumulator request
+    became which parameter's gradient, later steps have the layers write into the gradient arena itself.  Same losses and
+    weights as the packing path over batches of different shapes, nearly every gradient found in place, and a call
+    sequence that changes under the plan's feet (an extra request in front) still gives the same step."""
+    from kantts._hip import ops
+
+    tr_a, batches = _sambert_setup(device, str(tmp_path / "a"), use_arena=True)
+    tr_b, _ = _sambert_setup(device, str(tmp_path / "b"), use_arena=True)
+    arena = tr_a.optimizer["KanTtsSAMBERT"].arena
+    try:
+        arena.enable_direct_grads()
+        for k, b in enumerate(batches + batches[:2]):
+            if k == 4:  # shift the whole sequence by one request: every planned slot now goes to the "wrong" consumer
+                real_reset = ops.zero_pool.reset
+
+                def shifted_reset():
+                    real_reset()
+                    ops.zero_pool.take((7,), torch.device(device))
+
+                ops.zero_pool.reset = shifted_reset
+            la, lb = float(tr_a.train_step(b)), float(tr_b.train_step(b))
+            assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)), (k, la, lb)
+            if k in (2, 3):
+                placed = sum(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                             for p, v in zip(arena.params, arena.grad_views))
+                assert placed >= 0.9 * len(arena.params), (k, placed, len(arena.params))
+            gb = tr_b.optimizer["KanTtsSAMBERT"].arena.grad
+            assert float((arena.grad - gb).abs().max()) <= 1e-6 * float(gb.abs().max()), k
+            for (n, pa), pb in zip(tr_a.model["KanTtsSAMBERT"].named_parameters(), tr_b.model["KanTtsSAMBERT"].parameters()):
+                assert float((pa - pb).abs().max()) <= 1e-6, (k, n)
+    finally:
+        ops.zero_pool.plan = ops.zero_pool.log = None
+        ops.zero_pool.__dict__.pop("reset", None)
+    assert float((arena.grad - tr_b.optimizer["KanTtsSAMBERT"].arena.grad).abs().max()) <= 1e-7  # the last step's gradients
+
+
+def test_direct_gradients_equal_packed_gradients_emulated(tmp_path):
+    with emulation():
+        _direct_gradients("cpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_direct_gradients_equal_packed_gradients_gpu(tmp_path):
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _direct_gradients("cuda", tmp_path)
 
 
 def test_sambert_trainer_checkpoint_resume_emulated(tmp_path):
