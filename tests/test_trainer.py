@@ -74,8 +74,8 @@ def _direct_gradients(device, tmp_path):
     arena = tr_a.optimizer["KanTtsSAMBERT"].arena
     try:
         arena.enable_direct_grads()
-        for k, b in enumerate(batches + batches[:2]):
-            if k == 4:  # shift the whole sequence by one request: every planned slot now goes to the "wrong" consumer
+        for k, b in enumerate(batches):
+            if k == 3:  # shift the whole sequence by one request: every planned slot now goes to the "wrong" consumer
                 real_reset = ops.zero_pool.reset
 
                 def shifted_reset():
@@ -85,7 +85,7 @@ def _direct_gradients(device, tmp_path):
                 ops.zero_pool.reset = shifted_reset
             la, lb = float(tr_a.train_step(b)), float(tr_b.train_step(b))
             assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)), (k, la, lb)
-            if k in (2, 3):
+            if k in (1, 2):
                 placed = sum(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
                              for p, v in zip(arena.params, arena.grad_views))
                 assert placed >= 0.9 * len(arena.params), (k, placed, len(arena.params))
