@@ -210,6 +210,11 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
         all_core = _oracle_probe(all_cores, 8, limit_s=60.0, ref_s=dt_off)
         all_core["visible_cores"] = os.cpu_count() or 1
         all_core["batch"] = 8
+    elif CPU_THREADS["n"] is None:
+        # the default thread count IS every core this process may use (cgroup quota / affinity): the headline figure is the
+        # all-core figure
+        all_core = {"cores": cores, "value": frames / dt_off, "batch": B, "visible_cores": os.cpu_count() or 1,
+                    "note": "usable cores (cgroup quota / affinity) = the default thread count: same run as `value`"}
     if cores != 8 and CPU_THREADS["n"] is None:
         eight = _oracle_probe(8, 8, limit_s=60.0, ref_s=dt_off)  # N = 8 for comparability with its probes
         eight["batch"] = 8

@@ -20,9 +20,9 @@ WB = 2 * 2 * C * F
 LAUNCHES = [
     ("ffn_pair forward", ("ffn_pair_kernel<false",), 2 * M * C + WB + 2 * M * F + 8 * M * C),
     ("ffn_pair input gradients", ("ffn_pair_kernel<true",), 4 * M * C + 2 * M * F + WB + 2 * M * F + 2 * M * C),
-    # bgemm_tn_kernel<A_F32, B_F32>: the probe's two weight gradients are <true, false> (fp32 dy) and <false, false>
-    ("wgrad 128x1024 (fp32 dy x bf16 hidden)", ("bgemm_tn_kernel<true,false>",), 4 * M * C + 2 * M * F + 4 * C * F),
-    ("wgrad 1024x128 (bf16 dz x bf16 ln-out)", ("bgemm_tn_kernel<false,false>",), 2 * M * F + 2 * M * C + 4 * C * F),
+    # bgemm_tn_kernel<A_F32, B_F32, BN, BK>: the probe's two weight gradients are <true, false> (fp32 dy) and <false, false>
+    ("wgrad 128x1024 (fp32 dy x bf16 hidden)", ("bgemm_tn_kernel<true,false,",), 4 * M * C + 2 * M * F + 4 * C * F),
+    ("wgrad 1024x128 (bf16 dz x bf16 ln-out)", ("bgemm_tn_kernel<false,false,",), 2 * M * F + 2 * M * C + 4 * C * F),
 ]
 
 
