@@ -41,14 +41,58 @@ struct EmbedBwdArgs {
   float scale;
 };
 
-__global__ void embed_sum_bwd_kernel(const EmbedBwdArgs a) {
-  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = (long long)a.rows * a.D;
-  if (idx >= total) return;
-  int row = (int)(idx / a.D), d = (int)(idx % a.D);
-  float g = a.dout[idx] * a.scale;
-  for (int k = 0; k < a.ntab; ++k)
-    if (a.dtab[k]) atomicAdd(&a.dtab[k][(long long)a.ids[(long long)row * a.ntab + k] * a.D + d], g);
+// One thread per (chunk of EB_CHUNK rows, table, channel).  [round 4] The first form issued one global atomic per
+// (row, table, channel): the tone / syllable-flag / word-segment / speaker / emotion tables have a handful of rows, so all
+// 2 048 tokens of a batch hit the same few hundred addresses -- 70 us of serialised atomics in the middle of the captured
+// step's critical path (profiles/r04_runH).  Now a thread walks its chunk with an EB_WAYS-entry accumulator cache keyed by
+// the id (registers; all channels of a (chunk, table) take the same branches), and only evictions and the final flush
+// reach memory: <= EB_WAYS atomics per chunk and distinct id for the small tables, at most one per row for the phoneme
+// table (where the addresses differ anyway).
+#define EB_CHUNK 32
+#define EB_WAYS 8
+__global__ __launch_bounds__(256) void embed_sum_bwd_kernel(const EmbedBwdArgs a) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int d = (int)(idx % a.D);
+  const long long r = idx / a.D;
+  const int k = (int)(r % a.ntab);
+  const long long row0 = (r / a.ntab) * EB_CHUNK;
+  if (row0 >= a.rows) return;
+  float* __restrict__ tab = a.dtab[k];
+  if (!tab) return;
+  long long tag[EB_WAYS];
+  float acc[EB_WAYS];
+#pragma unroll
+  for (int w = 0; w < EB_WAYS; ++w) {
+    tag[w] = -1;
+    acc[w] = 0.f;
+  }
+  int next = 0;
+  const long long row1 = min((long long)a.rows, row0 + EB_CHUNK);
+  for (long long row = row0; row < row1; ++row) {
+    const long long id = a.ids[row * a.ntab + k];
+    const float g = a.dout[row * a.D + d] * a.scale;
+    bool hit = false;
+#pragma unroll
+    for (int w = 0; w < EB_WAYS; ++w) {
+      const bool m = tag[w] == id;
+      acc[w] += m ? g : 0.f;
+      hit |= m;
+    }
+    if (!hit) {  // evict way `next` (uniform across the channels of this chunk and table)
+#pragma unroll
+      for (int w = 0; w < EB_WAYS; ++w) {
+        if (w == next) {
+          if (tag[w] >= 0) atomicAdd(&tab[tag[w] * a.D + d], acc[w]);
+          tag[w] = id;
+          acc[w] = g;
+        }
+      }
+      next = (next + 1) & (EB_WAYS - 1);
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < EB_WAYS; ++w)
+    if (tag[w] >= 0) atomicAdd(&tab[tag[w] * a.D + d], acc[w]);
 }
 
 extern "C" int kantts_embed_sum_fwd(const float* const* tables_host, int ntab, const int64_t* ids, const float* pos,
@@ -70,8 +114,8 @@ extern "C" int kantts_embed_sum_bwd(float* const* dtables_host, int ntab, const 
   EmbedBwdArgs a = {};
   for (int k = 0; k < ntab; ++k) a.dtab[k] = dtables_host[k];
   a.ntab = ntab; a.ids = ids; a.dout = dout; a.rows = rows; a.D = D; a.scale = scale;
-  hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(kantts_cdiv((long long)rows * D, 256)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  const long long threads = (long long)kantts_cdiv(rows, EB_CHUNK) * ntab * D;
+  hipLaunchKernelGGL(embed_sum_bwd_kernel, dim3(kantts_cdiv(threads, 256)), dim3(256), 0, (hipStream_t)stream, a);
   KANTTS_CHECK_LAUNCH();
 }
 
