@@ -704,6 +704,15 @@ int kantts_step_rows(const float* src, float* dst, int B, int n, long long src_b
                      long long src_step_stride, long long dst_step_stride, int step, const int32_t* step_dev, void* stream);
 int kantts_step_rowmask(const int32_t* lens, uint8_t* mask, int B, int step, const int32_t* step_dev, void* stream);
 
+/* [round 4] HiFi-GAN multi-receptive-field fusion (kantts/models/hifigan/hifigan.py:160-176: xs += resblock(x) over the
+ * num_kernels residual stacks of a stage, then xs / num_kernels): out = scale * sum_k xs[k] in one pass, optionally with the
+ * bf16 image of LeakyReLU(out, slope) that the next convolution reads (act_bf16 may be NULL).  xs_host / outs_host: HOST
+ * arrays of n <= 8 DEVICE pointers; numel % 4 == 0, 16-byte aligned buffers.
+ * kantts_scale_to_many: its backward -- outs[k] = scale * g for every k (each branch its own gradient buffer). */
+int kantts_mean_many(const float* const* xs_host, int n, float scale, float* out, void* act_bf16, float slope,
+                     long long numel, void* stream);
+int kantts_scale_to_many(const float* g, float scale, float* const* outs_host, int n, long long numel, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * HiFi-GAN upsampling as an HBM stream (csrc/upsample.hip): CausalConvTranspose1d with kernel 2*S, stride S
  * (kantts/models/hifigan/layers.py:125-165, hifigan.py:67-80,160) in polyphase form on bf16 activations:

@@ -293,6 +293,78 @@ extern "C" int kantts_weight_norm_strided_bwd(const float* dw, const float* v, c
 }
 // y = sin(x) + x (fp32) and, in the same pass, a = LeakyReLU(y) rounded to bf16: the operand image of the transposed
 // convolution that consumes the stage input (csrc/upsample.hip); the fp32 y still feeds the repeat-upsample branch.
+// ---- [round 4] mean of up to 8 tensors in one pass (+ the bf16 LeakyReLU image of the result), and its backward
+// HiFi-GAN's multi-receptive-field fusion (kantts/models/hifigan/hifigan.py:160-176 of the reference: xs += block(x) over
+// the stage's residual stacks, then xs / num_kernels) was two ATen adds + a division + the operand-image cast of the next
+// convolution: four passes over the largest activations of the generator.  Backward: one launch writes every branch its
+// own copy of g * scale (the branches consume their gradients on their own streams: no shared tensor, ops._BranchExit).
+struct MeanManyArgs {
+  const float* x[8];
+  float* o[8];
+  int n;
+};
+typedef __bf16 mm_bf16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mean_many_kernel(const MeanManyArgs a, float scale, float* __restrict__ out,
+                                                        __bf16* __restrict__ act, float slope, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(a.x[0])[i];
+    for (int k = 1; k < a.n; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(a.x[k])[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+    reinterpret_cast<float4*>(out)[i] = s;
+    if (act) {
+      mm_bf16x4 b = {(__bf16)(s.x > 0.f ? s.x : s.x * slope), (__bf16)(s.y > 0.f ? s.y : s.y * slope),
+                     (__bf16)(s.z > 0.f ? s.z : s.z * slope), (__bf16)(s.w > 0.f ? s.w : s.w * slope)};
+      reinterpret_cast<mm_bf16x4*>(act)[i] = b;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void scale_to_many_kernel(const MeanManyArgs a, const float* __restrict__ g, float scale,
+                                                            long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(g)[i];
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    for (int k = 0; k < a.n; ++k) reinterpret_cast<float4*>(a.o[k])[i] = v;
+  }
+}
+extern "C" int kantts_mean_many(const float* const* xs_host, int n, float scale, float* out, void* act_bf16, float slope,
+                                long long numel, void* stream) {
+  if (!xs_host || !out || n < 1 || n > 8 || numel < 0) return KANTTS_E_BADARG;
+  if ((numel & 3) || ((uintptr_t)out & 15) || ((uintptr_t)act_bf16 & 7)) return KANTTS_E_UNSUPPORTED;
+  MeanManyArgs a = {};
+  a.n = n;
+  for (int k = 0; k < n; ++k) {
+    if (!xs_host[k]) return KANTTS_E_BADARG;
+    if ((uintptr_t)xs_host[k] & 15) return KANTTS_E_UNSUPPORTED;
+    a.x[k] = xs_host[k];
+  }
+  if (numel == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(numel >> 2, 256 * 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mean_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, scale, out,
+                     reinterpret_cast<__bf16*>(act_bf16), slope, numel >> 2);
+  KANTTS_CHECK_LAUNCH();
+}
+extern "C" int kantts_scale_to_many(const float* g, float scale, float* const* outs_host, int n, long long numel,
+                                    void* stream) {
+  if (!g || !outs_host || n < 1 || n > 8 || numel < 0) return KANTTS_E_BADARG;
+  if ((numel & 3) || ((uintptr_t)g & 15)) return KANTTS_E_UNSUPPORTED;
+  MeanManyArgs a = {};
+  a.n = n;
+  for (int k = 0; k < n; ++k) {
+    if (!outs_host[k]) return KANTTS_E_BADARG;
+    if ((uintptr_t)outs_host[k] & 15) return KANTTS_E_UNSUPPORTED;
+    a.o[k] = outs_host[k];
+  }
+  if (numel == 0) return KANTTS_OK;
+  int blocks = kantts_cdiv(numel >> 2, 256 * 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(scale_to_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, g, scale, numel >> 2);
+  KANTTS_CHECK_LAUNCH();
+}
+
 __global__ void sinadd_lrelu_kernel(const float* __restrict__ x, float* __restrict__ y, __bf16* __restrict__ a, float slope,
                                     long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {

@@ -292,6 +292,8 @@ def lib():
         L.kantts_weight_norm_table_bwd.argtypes = [p, p, p, POINTER(WnBwdArgs), p]
         L.kantts_masked_l1_many.argtypes = [POINTER(LossTerm), i, p, p]
         L.kantts_scale_many.argtypes = [POINTER(c_void_p), POINTER(ll), i, p, p]
+        L.kantts_mean_many.argtypes = [POINTER(c_void_p), i, f, p, p, f, ll, p]
+        L.kantts_scale_to_many.argtypes = [p, f, POINTER(c_void_p), i, ll, p]
         L.kantts_ragged_rows_i64.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
         _lib = L
     return _lib
@@ -312,6 +314,7 @@ EXPORTED_SYMBOLS = [
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
+    "kantts_mean_many", "kantts_scale_to_many",
 ]
 
 

@@ -1808,6 +1808,66 @@ def get_image(t, slope):
     return None
 
 
+class _MeanMany(torch.autograd.Function):
+    """scale * sum of n same-shaped fp32 tensors in ONE pass (kantts_mean_many), optionally with the bf16 image of
+    LeakyReLU(result, image_slope) for the convolution that consumes it; backward = one launch that writes every input
+    its OWN gradient buffer (the inputs are outputs of branches that ran on their own streams: see _BranchExit)."""
+
+    @staticmethod
+    def forward(ctx, scale, image_slope, *xs):
+        import ctypes
+
+        xs = [_c(x) for x in xs]
+        n, numel = len(xs), xs[0].numel()
+        out = torch.empty_like(xs[0])
+        img = None
+        if image_slope is not None and get_precision() == "bf16" and numel % 8 == 0:
+            img = torch.empty(xs[0].shape, device=xs[0].device, dtype=torch.bfloat16)
+        arr = (ctypes.c_void_p * n)(*[ptr(x, torch.float32) for x in xs])
+        check(lib().kantts_mean_many(arr, n, float(scale), ptr(out), ptr(img), float(image_slope or 0.0), numel, stream()),
+              "mean_many")
+        ctx.cfg = (float(scale), n)
+        if img is not None:
+            ctx.mark_non_differentiable(img)
+        return out, img
+
+    @staticmethod
+    def backward(ctx, g, _g_img):
+        import ctypes
+
+        scale, n = ctx.cfg
+        g = _c(g)
+        outs = [torch.empty_like(g) for _ in range(n)]
+        arr = (ctypes.c_void_p * n)(*[ptr(o, torch.float32) for o in outs])
+        check(lib().kantts_scale_to_many(ptr(g, torch.float32), scale, arr, n, g.numel(), stream()), "scale_to_many")
+        return (None, None, *outs)
+
+
+def mean_many_applies(n, like):
+    """Whether mean_many() will take its one-launch path for ``n`` tensors shaped like ``like`` (the caller then skips the
+    per-branch gradient clones of parallel_branches)."""
+    return (2 <= n <= 8 and like.dtype == torch.float32 and like.numel() % 4 == 0
+            and not os.environ.get("KANTTS_NO_MEAN_MANY"))
+
+
+def mean_many(xs, image_slope=None):
+    """mean of the tensors in ``xs`` (fp32, same shape, numel % 4 == 0; anything else: the ATen chain).  image_slope: also
+    attach the bf16 image of LeakyReLU(mean, image_slope) for the next convolution (bf16 mode)."""
+    xs = list(xs)
+    ok = (len(xs) >= 2 and len(xs) <= 8 and all(x.dtype == torch.float32 and x.shape == xs[0].shape and x.is_cuda == xs[0].is_cuda
+                                                 for x in xs) and xs[0].numel() % 4 == 0
+          and not os.environ.get("KANTTS_NO_MEAN_MANY"))
+    if not ok:
+        acc = xs[0]
+        for x in xs[1:]:
+            acc = acc + x
+        return acc / len(xs)
+    out, img = _MeanMany.apply(1.0 / len(xs), image_slope, *xs)
+    if img is not None:
+        set_image(out, image_slope, img)
+    return out
+
+
 def act_image(t, slope):
     """Make (once) and attach the bf16 image of LeakyReLU(t, slope) in bf16 mode; a no-op otherwise.  Call it before
     forking parallel branches that all read ``t``: the image is then produced once, on the forking stream."""

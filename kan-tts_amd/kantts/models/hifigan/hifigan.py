@@ -157,7 +157,7 @@ class Generator(torch.nn.Module):
         h = self.conv_post.forward_cl(h, in_leaky=0.01)
         return torch.tanh(h).transpose(1, 2)
 
-    def _residual_stacks(self, h, i):
+    def _residual_stacks(self, h, i, image_slope=None):
         # the num_kernels residual stacks of a stage read the same h and are summed: independent branches.  One stream
         # each when a backward pass will follow (their weight gradients are the low-occupancy launches that gain:
         # GAN step 66.9 -> 60.3 ms); a forward-only pass is a chain of chip-filling launches and is 9 % faster
@@ -165,8 +165,14 @@ class Generator(torch.nn.Module):
         blocks = self.conv_blocks[i * self.num_kernels:(i + 1) * self.num_kernels]
         ops.act_image(h, self.slope)  # one activated bf16 image for the first convolution of every stack (bf16 mode)
         thunks = [(lambda b=b, h=h: b.forward_cl(h)) for b in blocks]
-        ys = (ops.parallel_branches(thunks, inputs=(h,), private_grads=True) if torch.is_grad_enabled()
+        # [round 4] the mean over the stacks (reference :160-176) and the activated bf16 image its consumer reads are ONE
+        # launch (ops.mean_many); its backward hands every branch its own gradient buffer, which is what private_grads
+        # (one clone per branch) was for
+        fused = ops.mean_many_applies(len(blocks), h)
+        ys = (ops.parallel_branches(thunks, inputs=(h,), private_grads=not fused) if torch.is_grad_enabled()
               else [t() for t in thunks])
+        if fused:
+            return ops.mean_many(ys, image_slope=image_slope)
         xs = ys[0]
         for y in ys[1:]:
             xs = xs + y

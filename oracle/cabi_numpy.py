@@ -1449,6 +1449,29 @@ class EmulatedLib:
             _arr(x[k], int(n[k]))[:] *= s
         return 0
 
+    def kantts_mean_many(self, xs, n, scale, out, act, slope, numel, stream):
+        numel, n = int(_val(numel)), int(_val(n))
+        if numel % 4:
+            return -2
+        acc = _arr(xs[0], numel).copy()
+        for k in range(1, n):
+            acc = acc + _arr(xs[k], numel)
+        acc = (acc * np.float32(_val(scale))).astype(np.float32)
+        _arr(out, numel)[:] = acc
+        if act:
+            sl = np.float32(_val(slope))
+            _wr(act, np.where(acc > 0, acc, acc * sl).astype(np.float32), True)
+        return 0
+
+    def kantts_scale_to_many(self, g, scale, outs, n, numel, stream):
+        numel = int(_val(numel))
+        if numel % 4:
+            return -2
+        v = (_arr(g, numel) * np.float32(_val(scale))).astype(np.float32)
+        for k in range(int(_val(n))):
+            _arr(outs[k], numel)[:] = v
+        return 0
+
     def kantts_weight_norm_table_bwd(self, flat, grad, table, args_ref, stream):
         """Per listed layer: kantts_weight_norm_strided_bwd on the tap-major gradient, dv / dg into the gradient arena."""
         a = args_ref._obj

@@ -372,6 +372,33 @@ def test_dropout2_add_kernel():
             assert_close(a, c, 1e-6, what="dropout2_add grad")
 
 
+def test_mean_many_on_device():
+    """kantts_mean_many / kantts_scale_to_many: values, the bf16 LeakyReLU image, one gradient buffer per input."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+
+    prev = hip.get_precision()
+    hip.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(9)
+        for n, shape in ((3, (4, 2048, 64)), (2, (1, 8, 4)), (8, (2, 33, 8))):
+            xs = [(torch.randn(shape, generator=g)).cuda().requires_grad_(True) for _ in range(n)]
+            cot = torch.randn(shape, generator=g).cuda()
+            y = ops.mean_many(xs, image_slope=0.1)
+            ref = sum(x.detach() for x in xs) / n
+            assert_close(y.detach(), ref, 1e-6, what="mean_many")
+            img = ops.get_image(y, 0.1)
+            if shape[0] * shape[1] * shape[2] % 8 == 0:
+                assert img is not None and img.dtype == torch.bfloat16
+                assert_close(img.float(), torch.nn.functional.leaky_relu(y.detach(), 0.1), 1e-6, rtol=8e-3, what="image")
+            grads = torch.autograd.grad(y, xs, cot)
+            for gr in grads:
+                assert_close(gr, cot / n, 3e-7, what="mean_many grad")
+            assert len({gr.data_ptr() for gr in grads}) == n
+    finally:
+        hip.set_precision(prev)
+
+
 def test_fused_sambert_loss_on_device_equals_the_two_criteria():
     """kantts_masked_l1_many / kantts_scale_many on the GPU against the per-term criteria on the GPU: components, total and
     the five gradients, bench-shaped (B=32, T=640, 80 bins) and ragged small cases."""

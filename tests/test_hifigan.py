@@ -717,7 +717,9 @@ def _wn_table_check(device, count_calls=None, train=True):
         x = torch.randn(2, 80, 8, generator=g).to(device)
         y = torch.randn(2, 1, 128, generator=g).clamp(-1, 1).to(device)
         res = {}
-        for table in (True, False):
+        # third run (device only): the table arm again -- the weight gradients' fp32 atomics order differently from run to
+        # run and two Adam steps amplify that; what the two arms may differ by is measured, not assumed
+        for table in (True, False) + (("again",) if device != "cpu" else ()):
             if not table:
                 os.environ["KANTTS_NO_WEIGHT_NORM_TABLE"] = "1"
             try:
@@ -732,11 +734,15 @@ def _wn_table_check(device, count_calls=None, train=True):
                               None if count_calls is None else dict(count_calls))
             finally:
                 os.environ.pop("KANTTS_NO_WEIGHT_NORM_TABLE", None)
+        floor_l = floor_w = 0.0
+        if "again" in res:
+            floor_l = max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for a, b in zip(res[True][0], res["again"][0]) for k in a)
+            floor_w = max(rel_l2(a, b) for a, b in zip(res[True][1], res["again"][1]))
         for a, b in zip(res[True][0], res[False][0]):
             for k in a:
-                assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])
+                assert abs(a[k] - b[k]) <= max(1e-5, 3 * floor_l) * max(1.0, abs(b[k])), (k, a[k], b[k], floor_l)
         for a, b in zip(res[True][1], res[False][1]):
-            assert rel_l2(a, b) <= 1e-5
+            assert rel_l2(a, b) <= max(1e-5, 3 * floor_w), (rel_l2(a, b), floor_w)
         return res
     finally:
         hip.set_precision("fp32")

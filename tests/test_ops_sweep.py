@@ -350,3 +350,22 @@ def test_fused_sambert_loss_equals_the_two_criteria(emulated_cabi):
         for k in out[False][1]:
             assert abs(float(out[True][1][k]) - float(out[False][1][k])) < 1e-5 * max(1.0, abs(float(out[False][1][k]))), (k, cfg)
         _cmp(out[True][2], out[False][2], cfg, tol=1e-7)
+
+
+def test_mean_of_branch_outputs_in_one_launch(emulated_cabi):
+    """ops.mean_many (kantts_mean_many / kantts_scale_to_many) against the ATen chain it replaces in HiFi-GAN's
+    multi-receptive-field fusion (sum of the residual stacks / num_kernels): values, every input's gradient, and that each
+    input receives its OWN gradient buffer."""
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(3)
+    for n, shape in ((3, (2, 40, 32)), (2, (1, 8, 4)), (8, (3, 5, 12))):
+        xs = [torch.randn(shape, generator=g).requires_grad_(True) for _ in range(n)]
+        cot = torch.randn(shape, generator=g)
+        y = ops.mean_many(xs)
+        ref = sum(x.detach() for x in xs) / n
+        assert float((y.detach() - ref).abs().max()) <= 1e-6
+        grads = torch.autograd.grad(y, xs, cot)
+        for gr in grads:
+            assert float((gr - cot / n).abs().max()) <= 3e-7  # g * (1 / n) against g / n: one ulp
+        assert len({gr.data_ptr() for gr in grads}) == n
