@@ -272,6 +272,20 @@ int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft, int hop, 
                             float eps_mel, float ref_level_db, float min_level_db, float max_norm, int symmetric,
                             float* out_mel, float* out_mag, void* stream);
 
+/* [round 4] The same two functions with the mel tensor FRAME-major when mel_frame_major != 0: out_mel / dmel are
+ * (B, frames, n_mels) instead of (B, n_mels, frames) -- a frame's channels are one contiguous store (the channel-major
+ * layout makes every store a partial sector: 3 x the algorithmic write traffic); the host layer hands the reference's
+ * (B, n_mels, frames) shape out as a transposed view.  mel_frame_major == 0: identical to the functions above / below. */
+int kantts_melspec_norm_fwd_fm(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                               const float* window, const float* twiddle, float eps_power, const int32_t* mel_start,
+                               const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels, float eps_mel,
+                               float ref_level_db, float min_level_db, float max_norm, int symmetric, int mel_frame_major,
+                               float* out_mel, float* out_mag, void* stream);
+int kantts_melspec_bwd_fm(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                          const float* window, const float* twiddle, float eps_power, const int32_t* mel_start,
+                          const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels, float eps_mel,
+                          int mel_frame_major, float* dwav_accum, void* stream);
+
 /* Backward of the mel path of kantts_melspec_fwd (MelSpectrogramLoss on generated audio, kantts/train/loss.py:
  * 259-311): dwav_accum (B,T) += d loss / d wav given dmel (B, n_mels, frames).  The spectrum is recomputed. */
 int kantts_melspec_bwd(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames,

@@ -35,6 +35,7 @@ struct MelArgs {
   // +-max_norm) (spectral_normalize_torch);  else clip(max_norm*(S-min_db)/(-min_db), 0, max_norm) (dsp._normalize)
   float ref_db, min_db, max_norm;
   int symmetric;
+  int mel_fm;  // out_mel (and dmel of the backward) is (B, frames, n_mels) instead of (B, n_mels, frames)
 };
 
 __device__ __forceinline__ float mel_normalise(const MelArgs& a, float mel) {
@@ -137,10 +138,16 @@ __global__ __launch_bounds__(MEL_THREADS) void melspec_kernel(const MelArgs a) {
     __syncthreads();  // amp / buffers are reused by the next frame
   }
   if (a.out_mel && tid < a.n_mels) {
-    float* o = a.out_mel + ((long long)b * a.n_mels + tid) * a.frames + f0;
+    if (a.mel_fm) {
 #pragma unroll
-    for (int q = 0; q < MEL_FB; ++q)
-      if (f0 + q < a.frames) o[q] = melv[q];
+      for (int q = 0; q < MEL_FB; ++q)
+        if (f0 + q < a.frames) a.out_mel[((long long)b * a.frames + f0 + q) * a.n_mels + tid] = melv[q];
+    } else {
+      float* o = a.out_mel + ((long long)b * a.n_mels + tid) * a.frames + f0;
+#pragma unroll
+      for (int q = 0; q < MEL_FB; ++q)
+        if (f0 + q < a.frames) o[q] = melv[q];
+    }
   }
 }
 
@@ -504,9 +511,13 @@ __global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const M
       for (int sl = 0; sl < MELR_SLOTS; ++sl) {
         const int c = lane + 64 * sl;
         if (c < a.n_mels) {
-          float* o = a.out_mel + ((long long)b * a.n_mels + c) * a.frames + fa;
+          // frame-major output: a wave's 80 channels of a frame are 320 contiguous bytes; channel-major: 8-byte stores
+          // into n_mels rows (partial 32-byte sectors: 3 x the algorithmic write traffic, profiles/r04_runFINAL_melspec_pmc)
+          float* o = a.mel_fm ? a.out_mel + ((long long)b * a.frames + fa) * a.n_mels + c
+                              : a.out_mel + ((long long)b * a.n_mels + c) * a.frames + fa;
+          const long long step = a.mel_fm ? a.n_mels : 1;
           o[0] = mel_normalise_fast(a, fmaxf(melv[sl].x, a.eps_mel), inv_range);
-          if (has_b) o[1] = mel_normalise_fast(a, fmaxf(melv[sl].y, a.eps_mel), inv_range);
+          if (has_b) o[step] = mel_normalise_fast(a, fmaxf(melv[sl].y, a.eps_mel), inv_range);
         }
       }
     }
@@ -534,6 +545,12 @@ extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft
                                        const float* mel_w, int n_mels, float eps_mel, float ref_level_db,
                                        float min_level_db, float max_norm, int symmetric, float* out_mel, float* out_mag,
                                        void* stream);
+extern "C" int kantts_melspec_norm_fwd_fm(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                                          const float* window, const float* twiddle, float eps_power,
+                                          const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                                          const float* mel_w, int n_mels, float eps_mel, float ref_level_db,
+                                          float min_level_db, float max_norm, int symmetric, int mel_frame_major,
+                                          float* out_mel, float* out_mag, void* stream);
 
 extern "C" int kantts_melspec_fwd(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
                                   const float* window, const float* twiddle, float eps_power,
@@ -551,6 +568,17 @@ extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft
                                        const float* mel_w, int n_mels, float eps_mel, float ref_level_db,
                                        float min_level_db, float max_norm, int symmetric, float* out_mel, float* out_mag,
                                        void* stream) {
+  return kantts_melspec_norm_fwd_fm(wav, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start, mel_len,
+                                    mel_off, mel_w, n_mels, eps_mel, ref_level_db, min_level_db, max_norm, symmetric, 0,
+                                    out_mel, out_mag, stream);
+}
+
+extern "C" int kantts_melspec_norm_fwd_fm(const float* wav, int B, int T, int n_fft, int hop, int frames, int pad_mode,
+                                          const float* window, const float* twiddle, float eps_power,
+                                          const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                                          const float* mel_w, int n_mels, float eps_mel, float ref_level_db,
+                                          float min_level_db, float max_norm, int symmetric, int mel_frame_major,
+                                          float* out_mel, float* out_mag, void* stream) {
   if (!(min_level_db < 0.f) || !(max_norm > 0.f)) return KANTTS_E_BADARG;
   if (!wav || !window || !twiddle || B < 0 || T < 1 || n_fft < 8 || hop < 1 || frames < 0) return KANTTS_E_BADARG;
   if (n_fft & (n_fft - 1)) return KANTTS_E_UNSUPPORTED;
@@ -565,6 +593,7 @@ extern "C" int kantts_melspec_norm_fwd(const float* wav, int B, int T, int n_fft
   a.mel_start = mel_start; a.mel_len = mel_len; a.mel_off = mel_off; a.mel_w = mel_w; a.n_mels = n_mels;
   a.eps_mel = eps_mel; a.out_mel = out_mel; a.out_mag = out_mag;
   a.ref_db = ref_level_db; a.min_db = min_level_db; a.max_norm = max_norm; a.symmetric = symmetric;
+  a.mel_fm = mel_frame_major ? 1 : 0;
   int m = n_fft >> 1, l2 = 0;
   while ((1 << l2) < m) ++l2;
   a.log2m = l2;
@@ -667,7 +696,8 @@ __global__ __launch_bounds__(MEL_THREADS) void melspec_bwd_kernel(const MelBwdAr
       const float2 z = X[st + i];
       acc = fmaf(sqrtf(fmaxf(z.x * z.x + z.y * z.y, a.eps_power)), w[i], acc);
     }
-    const float g = ba.dmel[((long long)b * a.n_mels + tid) * a.frames + f];
+    const float g = a.mel_fm ? ba.dmel[((long long)b * a.frames + f) * a.n_mels + tid]
+                             : ba.dmel[((long long)b * a.n_mels + tid) * a.frames + f];
     const float melc = fmaxf(acc, a.eps_mel);
     const float db = 20.f * log10f(fmaxf(melc, 1e-5f)) - 20.f;
     const float nv = 8.f * ((db + 100.f) / 100.f) - 4.f;
@@ -722,10 +752,23 @@ __global__ __launch_bounds__(MEL_THREADS) void melspec_bwd_kernel(const MelBwdAr
   }
 }
 
+extern "C" int kantts_melspec_bwd_fm(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames,
+                                     int pad_mode, const float* window, const float* twiddle, float eps_power,
+                                     const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                                     const float* mel_w, int n_mels, float eps_mel, int mel_frame_major, float* dwav_accum,
+                                     void* stream);
 extern "C" int kantts_melspec_bwd(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames,
                                   int pad_mode, const float* window, const float* twiddle, float eps_power,
                                   const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
                                   const float* mel_w, int n_mels, float eps_mel, float* dwav_accum, void* stream) {
+  return kantts_melspec_bwd_fm(wav, dmel, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start, mel_len,
+                               mel_off, mel_w, n_mels, eps_mel, 0, dwav_accum, stream);
+}
+extern "C" int kantts_melspec_bwd_fm(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames,
+                                     int pad_mode, const float* window, const float* twiddle, float eps_power,
+                                     const int32_t* mel_start, const int32_t* mel_len, const int32_t* mel_off,
+                                     const float* mel_w, int n_mels, float eps_mel, int mel_frame_major, float* dwav_accum,
+                                     void* stream) {
   if (!wav || !dmel || !window || !twiddle || !dwav_accum || !mel_start || !mel_len || !mel_off || !mel_w)
     return KANTTS_E_BADARG;
   if (B < 0 || T < 1 || n_fft < 8 || hop < 1 || frames < 0 || n_mels < 1 || n_mels > MEL_THREADS) return KANTTS_E_BADARG;
@@ -738,6 +781,7 @@ extern "C" int kantts_melspec_bwd(const float* wav, const float* dmel, int B, in
   a.mel_start = mel_start; a.mel_len = mel_len; a.mel_off = mel_off; a.mel_w = mel_w; a.n_mels = n_mels;
   a.eps_mel = eps_mel;
   a.ref_db = 20.f; a.min_db = -100.f; a.max_norm = 4.f; a.symmetric = 1;
+  a.mel_fm = mel_frame_major ? 1 : 0;
   ba.dmel = dmel; ba.dwav = dwav_accum;
   int m = n_fft >> 1, l2 = 0;
   while ((1 << l2) < m) ++l2;

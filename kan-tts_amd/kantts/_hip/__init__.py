@@ -252,6 +252,8 @@ def lib():
         L.kantts_melspec_fwd.argtypes = [p, i, i, i, i, i, i, p, p, f, p, p, p, p, i, f, p, p, p]
         L.kantts_melspec_norm_fwd.argtypes = [p, i, i, i, i, i, i, p, p, f, p, p, p, p, i, f, f, f, f, i, p, p, p]
         L.kantts_melspec_bwd.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p, p, p, i, f, p, p]
+        L.kantts_melspec_norm_fwd_fm.argtypes = [p, i, i, i, i, i, i, p, p, f, p, p, p, p, i, f, f, f, f, i, i, p, p, p]
+        L.kantts_melspec_bwd_fm.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p, p, p, i, f, i, p, p]
         L.kantts_weight_norm_fwd.argtypes = [p, p, p, i, i, p]
         L.kantts_weight_norm_bwd.argtypes = [p, p, p, p, p, i, i, p]
         L.kantts_weight_norm_strided_fwd.argtypes = [p, p, p, i, i, i, ll, ll, ll, p]
@@ -304,7 +306,7 @@ EXPORTED_SYMBOLS = [
     "kantts_layernorm_bwd", "kantts_attn_fwd", "kantts_attn_bwd", "kantts_pnca_attn_fwd", "kantts_pnca_attn_bwd", "kantts_lstm_fwd", "kantts_lstm_bwd",
     "kantts_embed_sum_fwd", "kantts_embed_sum_bwd", "kantts_lr_index", "kantts_lr_gather_fwd",
     "kantts_lr_gather_bwd", "kantts_fsmn_dwconv_fwd", "kantts_fsmn_dwconv_bwd", "kantts_fsmn_dwconv_bwd_ws", "kantts_masked_l1",
-    "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_norm_fwd", "kantts_melspec_bwd", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd", "kantts_weight_norm_strided_fwd", "kantts_weight_norm_strided_bwd",
+    "kantts_sumsq", "kantts_elem_loss", "kantts_adam_step", "kantts_melspec_fwd", "kantts_melspec_norm_fwd", "kantts_melspec_bwd", "kantts_melspec_norm_fwd_fm", "kantts_melspec_bwd_fm", "kantts_weight_norm_fwd", "kantts_weight_norm_bwd", "kantts_weight_norm_strided_fwd", "kantts_weight_norm_strided_bwd",
     "kantts_sinadd_fwd", "kantts_sinadd_bwd", "kantts_conv_win_launch", "kantts_conv_wgrad_launch", "kantts_conv_c1_launch", "kantts_attn_decode",
     "kantts_lstm_cell", "kantts_mas_width1", "kantts_align_attn_fwd", "kantts_align_attn_bwd",
     "kantts_bgemm_nt", "kantts_ffn_pair", "kantts_fragmajor_bf16", "kantts_bgemm_tn", "kantts_cast_f32_bf16", "kantts_tapmajor_bf16", "kantts_relu_gate_bf16",

@@ -94,9 +94,12 @@ class _MelSpecFn(torch.autograd.Function):
         frames = 1 + T // hop
         wpad, tw = _fft_consts(n_fft, win_length, window, x.device)
         dwav = torch.zeros_like(x)
-        check(lib().kantts_melspec_bwd(ptr(x, torch.float32), ptr(dmel.contiguous(), torch.float32), B, T, n_fft, hop,
-                                       frames, pad_mode, ptr(wpad), ptr(tw), float(eps_power), ptr(ms), ptr(ml), ptr(mo),
-                                       ptr(mw), ms.numel(), float(eps_mel), ptr(dwav), stream()), "melspec_bwd")
+        # the forward handed out a transposed view of its frame-major buffer: a gradient that keeps that layout (the
+        # L1 / MSE criteria do) is read as it is, anything else is copied once
+        dmel_fm = dmel.transpose(1, 2).contiguous()
+        check(lib().kantts_melspec_bwd_fm(ptr(x, torch.float32), ptr(dmel_fm, torch.float32), B, T, n_fft, hop,
+                                          frames, pad_mode, ptr(wpad), ptr(tw), float(eps_power), ptr(ms), ptr(ml), ptr(mo),
+                                          ptr(mw), ms.numel(), float(eps_mel), 1, ptr(dwav), stream()), "melspec_bwd_fm")
         return dwav, None, None, None, None, None
 
 
@@ -145,20 +148,18 @@ def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, ep
     if mel is not None:
         ms, ml, mo, mw = mel
         n_mels = ms.numel()
-        out_mel = torch.empty((B, n_mels, frames), device=x.device, dtype=torch.float32)
+        # frame-major buffer (a frame's channels are one contiguous store), handed out in the reference's
+        # (B, n_mels, frames) shape as a transposed view
+        out_mel = torch.empty((B, frames, n_mels), device=x.device, dtype=torch.float32)
     if want_mag:
         out_mag = torch.empty((B, frames, n_fft // 2 + 1), device=x.device, dtype=torch.float32)
-    if norm is not None:
-        ref_db, min_db, max_norm, symmetric = norm
-        check(lib().kantts_melspec_norm_fwd(ptr(x, torch.float32), B, T, n_fft, hop, frames, pad_mode, ptr(wpad), ptr(tw),
-                                            float(eps_power), ptr(ms), ptr(ml), ptr(mo), ptr(mw), n_mels, float(eps_mel),
-                                            float(ref_db), float(min_db), float(max_norm), int(bool(symmetric)),
-                                            ptr(out_mel), ptr(out_mag), stream()), "melspec_norm_fwd")
-        return out_mel, out_mag
-    check(lib().kantts_melspec_fwd(ptr(x, torch.float32), B, T, n_fft, hop, frames, pad_mode, ptr(wpad), ptr(tw),
-                                   float(eps_power), ptr(ms), ptr(ml), ptr(mo), ptr(mw), n_mels, float(eps_mel),
-                                   ptr(out_mel), ptr(out_mag), stream()), "melspec_fwd")
-    return out_mel, out_mag
+    # MelSpectrogram.forward's fixed normalisation (ref 20 dB, floor -100 dB, symmetric +-4) unless the caller names one
+    ref_db, min_db, max_norm, symmetric = norm if norm is not None else (20.0, -100.0, 4.0, True)
+    check(lib().kantts_melspec_norm_fwd_fm(ptr(x, torch.float32), B, T, n_fft, hop, frames, pad_mode, ptr(wpad), ptr(tw),
+                                           float(eps_power), ptr(ms), ptr(ml), ptr(mo), ptr(mw), n_mels, float(eps_mel),
+                                           float(ref_db), float(min_db), float(max_norm), int(bool(symmetric)), 1,
+                                           ptr(out_mel), ptr(out_mag), stream()), "melspec_norm_fwd_fm")
+    return (None if out_mel is None else out_mel.transpose(1, 2)), out_mag
 
 
 _dft_cache = {}

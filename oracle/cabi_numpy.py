@@ -958,6 +958,26 @@ class EmulatedLib:
             _arr(out_mel, B * n_mels * frames)[:] = out.reshape(-1).numpy()
         return 0
 
+    def kantts_melspec_norm_fwd_fm(self, wav, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
+                                   mel_len, mel_off, mel_w, n_mels, eps_mel, ref_db, min_db, max_norm, symmetric, fm, out_mel,
+                                   out_mag, stream):
+        rc = self.kantts_melspec_norm_fwd(wav, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
+                                          mel_len, mel_off, mel_w, n_mels, eps_mel, ref_db, min_db, max_norm, symmetric,
+                                          out_mel, out_mag, stream)
+        if rc == 0 and out_mel and _val(fm):  # (B, n_mels, frames) -> (B, frames, n_mels), in place
+            a = _arr(out_mel, B * n_mels * frames)
+            a[:] = a.reshape(B, n_mels, frames).transpose(0, 2, 1).copy().reshape(-1)
+        return rc
+
+    def kantts_melspec_bwd_fm(self, wav, dmel, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
+                              mel_len, mel_off, mel_w, n_mels, eps_mel, fm, dwav, stream):
+        keep = None
+        if _val(fm):  # (B, frames, n_mels) -> the (B, n_mels, frames) layout the model below reads
+            keep = np.ascontiguousarray(_arr(dmel, B * n_mels * frames).reshape(B, frames, n_mels).transpose(0, 2, 1))
+            dmel = keep.ctypes.data
+        return self.kantts_melspec_bwd(wav, dmel, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
+                                       mel_len, mel_off, mel_w, n_mels, eps_mel, dwav, stream)
+
     def kantts_melspec_bwd(self, wav, dmel, B, T, n_fft, hop, frames, pad_mode, window, twiddle, eps_power, mel_start,
                            mel_len, mel_off, mel_w, n_mels, eps_mel, dwav, stream):
         eps_power, eps_mel = _val(eps_power), _val(eps_mel)

@@ -68,6 +68,7 @@ from test_melspec import (  # noqa: F401
     test_melspec_backward_emulated,
     test_dsp_melspectrogram_emulated,
     _register_form_cases,
+    test_mel_layouts_agree_emulated,
 )
 
 

@@ -87,6 +87,57 @@ def test_register_resident_fft_form_gpu():
     _register_form_cases("cuda")
 
 
+def _layouts_agree(device):
+    """The C ABI in both mel layouts: kantts_melspec_fwd / _norm_fwd / _bwd (channel-major, the reference's
+    (B, n_mels, frames)) against kantts_melspec_norm_fwd_fm / kantts_melspec_bwd_fm (frame-major, what the host layer uses
+    and hands out as a transposed view) -- the same numbers, forward bit for bit, the waveform gradient to the order of its
+    atomics; n_fft 1024 (register kernel) and 512 (radix-2 kernel)."""
+    from kantts._hip import check, lib, ptr
+    from kantts.utils.audio_torch import MelSpectrogram, _fft_consts
+
+    g = torch.Generator().manual_seed(41)
+    for n_fft, hop in ((1024, 256), (512, 128)):
+        ms = MelSpectrogram(fft_size=n_fft, hop_size=hop).to(device)
+        B, T = 3, 2500
+        x = (torch.randn(B, T, generator=g) * 0.2).to(device)
+        frames = 1 + T // hop
+        wpad, tw = _fft_consts(n_fft, n_fft, "hann", x.device)
+        st, ln, of, w = ms._mel_support(x.device)
+        n_mels = st.numel()
+        cm = torch.empty(B, n_mels, frames, device=device)
+        cm2 = torch.empty_like(cm)
+        fm = torch.empty(B, frames, n_mels, device=device)
+        L = lib()
+        check(L.kantts_melspec_fwd(ptr(x), B, T, n_fft, hop, frames, 0, ptr(wpad), ptr(tw), 1e-10, ptr(st), ptr(ln), ptr(of),
+                                   ptr(w), n_mels, 1e-10, ptr(cm), None, None), "melspec_fwd")
+        check(L.kantts_melspec_norm_fwd(ptr(x), B, T, n_fft, hop, frames, 0, ptr(wpad), ptr(tw), 1e-10, ptr(st), ptr(ln),
+                                        ptr(of), ptr(w), n_mels, 1e-10, 20.0, -100.0, 4.0, 1, ptr(cm2), None, None), "norm_fwd")
+        check(L.kantts_melspec_norm_fwd_fm(ptr(x), B, T, n_fft, hop, frames, 0, ptr(wpad), ptr(tw), 1e-10, ptr(st), ptr(ln),
+                                           ptr(of), ptr(w), n_mels, 1e-10, 20.0, -100.0, 4.0, 1, 1, ptr(fm), None, None),
+              "norm_fwd_fm")
+        assert torch.equal(cm, cm2) and torch.equal(cm, fm.transpose(1, 2)), n_fft
+        dm = torch.randn(B, n_mels, frames, generator=g).to(device)
+        da, db = torch.zeros_like(x), torch.zeros_like(x)
+        check(L.kantts_melspec_bwd(ptr(x), ptr(dm), B, T, n_fft, hop, frames, 0, ptr(wpad), ptr(tw), 1e-10, ptr(st), ptr(ln),
+                                   ptr(of), ptr(w), n_mels, 1e-10, ptr(da), None), "melspec_bwd")
+        dm_fm = dm.transpose(1, 2).contiguous()
+        check(L.kantts_melspec_bwd_fm(ptr(x), ptr(dm_fm), B, T, n_fft, hop, frames, 0, ptr(wpad),
+                                      ptr(tw), 1e-10, ptr(st), ptr(ln), ptr(of), ptr(w), n_mels, 1e-10, 1, ptr(db), None),
+              "melspec_bwd_fm")
+        assert float((da - db).abs().max()) <= 1e-5 * float(da.abs().max()), n_fft
+        assert float(da.abs().max()) > 0
+
+
+def test_mel_layouts_agree_emulated():
+    with emulation():
+        _layouts_agree("cpu")
+
+
+@pytest.mark.gpu
+def test_mel_layouts_agree_gpu():
+    _layouts_agree("cuda")
+
+
 def test_melspec_host_logic_emulated():
     with emulation():
         _check("cpu")
