@@ -307,9 +307,27 @@ typedef struct kantts_loss_term {
   int32_t B, T, C, target_log1p;
 } kantts_loss_term;
 int kantts_masked_l1_many(const kantts_loss_term* terms, int nterms, float* losses, void* stream);
-/* x_k *= *scale_dev for up to KANTTS_LOSS_MAX_TERMS tensors in one launch (the backward of the call above: the upstream
- * gradient of the total is a device scalar). */
+/* x_k *= *scale_dev for up to KANTTS_ELOSS_MAX_TERMS tensors in one launch (the backward of the call above and of
+ * kantts_elem_loss_many: the upstream gradient of a loss sum is a device scalar). */
 int kantts_scale_many(float* const* x, const long long* n, int count, const float* scale_dev, void* stream);
+
+/* [round 4] The mean-reduced element losses of a GAN step in ONE launch per criterion (kantts/train/loss.py:108-256: the
+ * feature-matching loss alone is ~48 l1_loss calls per step -- one per discriminator layer --, the adversarial criteria 8 /
+ * 16 mse_loss calls; each was a zero-fill, a reduction launch and an addition).  Term k adds into losses[out]:
+ *   mode 0: scale * sum |a - b|      grad (optional) = scale * sign(a - b)
+ *   mode 1: scale * sum (a - target)^2      grad = 2 * scale * (a - target)
+ * exactly as kantts_elem_loss does for one term.  terms: HOST array of nterms <= KANTTS_ELOSS_MAX_TERMS; losses: device
+ * accumulators, zeroed by the caller. */
+#define KANTTS_ELOSS_MAX_TERMS 64
+typedef struct kantts_eloss_term {
+  const float* a;
+  const float* b;  /* mode 0 only */
+  float* grad;     /* may be NULL */
+  long long n;
+  float target, scale;
+  int32_t mode, out;
+} kantts_eloss_term;
+int kantts_elem_loss_many(const kantts_eloss_term* terms, int nterms, float* losses, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * weight_norm reparametrisation w = g * v / ||v|| per output row (torch.nn.utils.weight_norm, dim=0):

@@ -142,8 +142,8 @@ extern "C" int kantts_masked_l1_many(const kantts_loss_term* terms, int nterms, 
 }
 
 struct ScaleManyArgs {
-  float* x[KANTTS_LOSS_MAX_TERMS];
-  long long n[KANTTS_LOSS_MAX_TERMS];
+  float* x[KANTTS_ELOSS_MAX_TERMS];
+  long long n[KANTTS_ELOSS_MAX_TERMS];
   int count;
 };
 __global__ __launch_bounds__(256) void scale_many_kernel(const ScaleManyArgs a, const float* __restrict__ scale) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void scale_many_kernel(const ScaleManyArgs a, 
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] *= s;
 }
 extern "C" int kantts_scale_many(float* const* x, const long long* n, int count, const float* scale_dev, void* stream) {
-  if (!x || !n || !scale_dev || count < 0 || count > KANTTS_LOSS_MAX_TERMS) return KANTTS_E_BADARG;
+  if (!x || !n || !scale_dev || count < 0 || count > KANTTS_ELOSS_MAX_TERMS) return KANTTS_E_BADARG;
   if (count == 0) return KANTTS_OK;
   ScaleManyArgs a = {};
   a.count = count;
@@ -312,6 +312,60 @@ __global__ __launch_bounds__(256) void elem_loss_kernel(const float* __restrict_
   }
   part = kantts_block_sum(part, red);
   if (threadIdx.x == 0) atomicAdd(loss, part * scale);
+}
+
+// ---- [round 4] many terms of the above in one launch (include/kantts_hip.h: kantts_elem_loss_many)
+struct ElossManyArgs {
+  kantts_eloss_term t[KANTTS_ELOSS_MAX_TERMS];
+  int first_block[KANTTS_ELOSS_MAX_TERMS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void elem_loss_many_kernel(const ElossManyArgs a, float* __restrict__ losses) {
+  __shared__ float red[4];
+  int lo = 0, hi = a.n;  // term of this block: first_block[lo] <= blockIdx.x < first_block[lo + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= a.first_block[mid]) lo = mid; else hi = mid;
+  }
+  const kantts_eloss_term q = a.t[lo];
+  const int blk = blockIdx.x - a.first_block[lo], nblk = a.first_block[lo + 1] - a.first_block[lo];
+  float part = 0.f;
+  for (long long i = (long long)blk * 256 + threadIdx.x; i < q.n; i += (long long)nblk * 256) {
+    const float d = q.a[i] - (q.mode == 0 ? q.b[i] : q.target);
+    float g;
+    if (q.mode == 0) {
+      part += fabsf(d);
+      g = (d > 0.f) ? q.scale : ((d < 0.f) ? -q.scale : 0.f);
+    } else {
+      part += d * d;
+      g = 2.f * q.scale * d;
+    }
+    if (q.grad) q.grad[i] = g;
+  }
+  part = kantts_block_sum(part, red);
+  if (threadIdx.x == 0) atomicAdd(losses + q.out, part * q.scale);
+}
+
+extern "C" int kantts_elem_loss_many(const kantts_eloss_term* terms, int nterms, float* losses, void* stream) {
+  if (!terms || !losses || nterms < 1 || nterms > KANTTS_ELOSS_MAX_TERMS) return KANTTS_E_BADARG;
+  ElossManyArgs a = {};
+  int nb = 0, k = 0;
+  for (int i = 0; i < nterms; ++i) {
+    const kantts_eloss_term& q = terms[i];
+    if (!q.a || q.n < 0 || q.mode < 0 || q.mode > 1 || (q.mode == 0 && !q.b) || q.out < 0) return KANTTS_E_BADARG;
+    if (q.n == 0) continue;
+    a.t[k] = q;
+    a.first_block[k] = nb;
+    int blocks = kantts_cdiv(q.n, 1024);
+    if (blocks > 512) blocks = 512;
+    nb += blocks;
+    ++k;
+  }
+  if (k == 0) return KANTTS_OK;
+  a.first_block[k] = nb;
+  a.n = k;
+  hipLaunchKernelGGL(elem_loss_many_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, losses);
+  KANTTS_CHECK_LAUNCH();
 }
 
 extern "C" int kantts_elem_loss(const float* a, const float* b, float target, int mode, float scale, float* loss_accum,

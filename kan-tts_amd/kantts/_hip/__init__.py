@@ -156,6 +156,15 @@ class LossTerm(Structure):
                 ("B", c_int32), ("T", c_int32), ("C", c_int32), ("target_log1p", c_int32)]
 
 
+ELOSS_MAX_TERMS = 64
+
+
+class ElossTerm(Structure):
+    """kantts_eloss_term (include/kantts_hip.h)."""
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("grad", c_void_p), ("n", ctypes.c_longlong), ("target", ctypes.c_float),
+                ("scale", ctypes.c_float), ("mode", c_int32), ("out", c_int32)]
+
+
 WN_BWD_MAX = 64
 
 
@@ -294,6 +303,7 @@ def lib():
         L.kantts_weight_norm_table_bwd.argtypes = [p, p, p, POINTER(WnBwdArgs), p]
         L.kantts_masked_l1_many.argtypes = [POINTER(LossTerm), i, p, p]
         L.kantts_scale_many.argtypes = [POINTER(c_void_p), POINTER(ll), i, p, p]
+        L.kantts_elem_loss_many.argtypes = [POINTER(ElossTerm), i, p, p]
         L.kantts_mean_many.argtypes = [POINTER(c_void_p), i, f, p, p, f, ll, p]
         L.kantts_scale_to_many.argtypes = [p, f, POINTER(c_void_p), i, ll, p]
         L.kantts_ragged_rows_i64.argtypes = [p, p, p, p, p, p, i, i, i, i, p]
@@ -316,7 +326,7 @@ EXPORTED_SYMBOLS = [
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
-    "kantts_mean_many", "kantts_scale_to_many",
+    "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many",
 ]
 
 

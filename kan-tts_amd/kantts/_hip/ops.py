@@ -1266,6 +1266,71 @@ class _ElemLoss(torch.autograd.Function):
         return (grad * g if grad is not None else None), None, None, None, None
 
 
+class _ElemLossMany(torch.autograd.Function):
+    """Many _ElemLoss terms from ONE launch per <= 64 terms (kantts_elem_loss_many): spec[k] = (b or None, target, mode,
+    scale, out); returns the (n_out,) sums.  Backward: the stored gradients times the upstream gradient of their sum, one
+    launch per output."""
+
+    @staticmethod
+    def forward(ctx, n_out, spec, *a_list):
+        from . import ELOSS_MAX_TERMS, ElossTerm
+
+        dev = a_list[0].device
+        losses = torch.zeros((n_out,), device=dev, dtype=torch.float32)
+        grads, keep = [], []
+        for s0 in range(0, len(a_list), ELOSS_MAX_TERMS):
+            chunk = list(zip(a_list[s0:s0 + ELOSS_MAX_TERMS], spec[s0:s0 + ELOSS_MAX_TERMS]))
+            terms = (ElossTerm * len(chunk))()
+            for k, (a, (b, target, mode, scale, out)) in enumerate(chunk):
+                a = _c(a)
+                g = torch.empty_like(a) if ctx.needs_input_grad[2 + s0 + k] else None
+                q = terms[k]
+                q.a, q.grad, q.n = ptr(a, torch.float32), ptr(g), a.numel()
+                if mode == 0:
+                    b = _c(b)
+                    assert b.numel() == a.numel()
+                    q.b = ptr(b, torch.float32)
+                    keep.append(b)
+                q.target, q.scale, q.mode, q.out = float(target), float(scale), int(mode), int(out)
+                grads.append(g)
+                keep.append(a)
+            check(lib().kantts_elem_loss_many(terms, len(chunk), ptr(losses, torch.float32), stream()), "elem_loss_many")
+        ctx.grads = grads
+        ctx.outs = [int(sp[4]) for sp in spec]
+        ctx.shapes = [tuple(a.shape) for a in a_list]
+        return losses
+
+    @staticmethod
+    def backward(ctx, g_losses):
+        import ctypes
+
+        from . import ELOSS_MAX_TERMS
+
+        g_losses = _c(g_losses)
+        for out in sorted(set(ctx.outs)):
+            live = [t for t, o in zip(ctx.grads, ctx.outs) if t is not None and o == out]
+            for s0 in range(0, len(live), ELOSS_MAX_TERMS):
+                part = live[s0:s0 + ELOSS_MAX_TERMS]
+                xs = (ctypes.c_void_p * len(part))(*[ptr(t, torch.float32) for t in part])
+                ns = (ctypes.c_longlong * len(part))(*[t.numel() for t in part])
+                check(lib().kantts_scale_many(xs, ns, len(part), ptr(g_losses[out:out + 1], torch.float32), stream()),
+                      "scale_many")
+        return (None, None, *[None if t is None else t.view(sh) for t, sh in zip(ctx.grads, ctx.shapes)])
+
+
+def elem_loss_many(terms, n_out=1):
+    """terms: list of (a, b_or_None, target, mode, scale, out) -- mode 0: scale * sum |a - b| (b constant), mode 1:
+    scale * sum (a - target)^2 -- summed into out < n_out.  Returns the (n_out,) tensor of sums."""
+    a_list, spec = [], []
+    for a, b, target, mode, scale, out in terms:
+        if mode == 0:
+            a, b = _dense_order(a, b.detach())
+            b = b.reshape(a.shape)
+        a_list.append(a)
+        spec.append((b, target, mode, scale, out))
+    return _ElemLossMany.apply(int(n_out), tuple(spec), *a_list)
+
+
 def _dense_order(a, b):
     """A mean over all elements does not care about their order: when a and b are the same permuted view of dense
     buffers (the discriminators hand their channels-last feature maps out as (B, C, T[, p]) views), undo the permutation

@@ -94,6 +94,12 @@ def sambert_loss_sum(mel_criterion, prosody_criterion, batch, res, prosody_lengt
     return mel_ + mel + d + p + e, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in comps.items()}
 
 
+def _fused_gan_losses(tensors):
+    """The one-launch criteria (ops.elem_loss_many) apply to fp32 tensors; KANTTS_NO_FUSED_GAN_LOSS=1: the per-term path."""
+    return (len(tensors) > 0 and all(torch.is_tensor(t) and t.dtype == torch.float32 and t.numel() > 0 for t in tensors)
+            and not __import__("os").environ.get("KANTTS_NO_FUSED_GAN_LOSS"))
+
+
 class GeneratorAdversarialLoss(torch.nn.Module):
     """Generator adversarial loss, mean (or sum) over discriminators: LSGAN ``mse(D(G(x)), 1)`` (``"mse"``, every shipped
     yaml: one reduction kernel per score) or ``-mean(D(G(x)))`` (``"hinge"``) (reference :108-151)."""
@@ -110,9 +116,14 @@ class GeneratorAdversarialLoss(torch.nn.Module):
     def forward(self, outputs):
         if not isinstance(outputs, (tuple, list)):
             return self.criterion(outputs)
+        scores = [o[-1] if isinstance(o, (tuple, list)) else o for o in outputs]
+        if self.loss_type == "mse" and _fused_gan_losses(scores):
+            # every discriminator's score in ONE launch (was: a zero-fill + a reduction + an addition per discriminator)
+            w = 1.0 / len(scores) if self.average_by_discriminators else 1.0
+            return ops.elem_loss_many([(s, None, 1.0, 1, w / s.numel(), 0) for s in scores])[0]
         adv = 0.0
-        for o in outputs:
-            adv = adv + self.criterion(o[-1] if isinstance(o, (tuple, list)) else o)
+        for o in scores:
+            adv = adv + self.criterion(o)
         return adv / len(outputs) if self.average_by_discriminators else adv
 
 
@@ -139,10 +150,14 @@ class DiscriminatorAdversarialLoss(torch.nn.Module):
     def forward(self, outputs_hat, outputs):
         if not isinstance(outputs, (tuple, list)):
             return self.real_criterion(outputs), self.fake_criterion(outputs_hat)
+        pairs = [(oh[-1], o[-1]) if isinstance(oh, (tuple, list)) else (oh, o) for oh, o in zip(outputs_hat, outputs)]
+        if self.loss_type == "mse" and _fused_gan_losses([t for p in pairs for t in p]):
+            w = 1.0 / len(pairs) if self.average_by_discriminators else 1.0
+            both = ops.elem_loss_many([(o, None, 1.0, 1, w / o.numel(), 0) for _, o in pairs]
+                                      + [(oh, None, 0.0, 1, w / oh.numel(), 1) for oh, _ in pairs], n_out=2)
+            return both[0], both[1]
         real, fake = 0.0, 0.0
-        for oh, o in zip(outputs_hat, outputs):
-            if isinstance(oh, (tuple, list)):
-                oh, o = oh[-1], o[-1]
+        for oh, o in pairs:
             real = real + self.real_criterion(o)
             fake = fake + self.fake_criterion(oh)
         if self.average_by_discriminators:
@@ -159,6 +174,14 @@ class FeatureMatchLoss(torch.nn.Module):
         self.average_by_discriminators = average_by_discriminators
 
     def forward(self, feats_hat, feats):
+        flat = [a for fh in feats_hat for a in fh]
+        if _fused_gan_losses(flat):
+            # ~48 feature maps (one per discriminator layer): ONE launch instead of 48 x (zero-fill, reduction, addition)
+            terms = []
+            for fh, fr in zip(feats_hat, feats):
+                w = (1.0 / len(fh) if self.average_by_layers else 1.0) * (1.0 / len(feats) if self.average_by_discriminators else 1.0)
+                terms += [(a, b, 0.0, 0, w / a.numel(), 0) for a, b in zip(fh, fr)]
+            return ops.elem_loss_many(terms)[0]
         total = 0.0
         for fh, fr in zip(feats_hat, feats):
             part = 0.0

@@ -1469,6 +1469,25 @@ class EmulatedLib:
             _arr(x[k], int(n[k]))[:] *= s
         return 0
 
+    def kantts_elem_loss_many(self, terms, nterms, losses, stream):
+        """kantts_elem_loss per term, into losses[term.out]."""
+        for k in range(int(_val(nterms))):
+            q = terms[k]
+            n = int(q.n)
+            if n == 0:
+                continue
+            a = _arr(q.a, n)
+            d = a - (_arr(q.b, n) if q.mode == 0 else np.float32(q.target))
+            sc = np.float32(q.scale)
+            if q.mode == 0:
+                part, g = np.abs(d).sum(dtype=np.float64), np.sign(d).astype(np.float32) * sc
+            else:
+                part, g = (d.astype(np.float64) ** 2).sum(), (np.float32(2.0) * sc * d).astype(np.float32)
+            _arr(losses, int(q.out) + 1)[int(q.out)] += np.float32(part * float(sc))
+            if q.grad:
+                _arr(q.grad, n)[:] = g
+        return 0
+
     def kantts_mean_many(self, xs, n, scale, out, act, slope, numel, stream):
         numel, n = int(_val(numel)), int(_val(n))
         if numel % 4:

@@ -372,6 +372,12 @@ def test_dropout2_add_kernel():
             assert_close(a, c, 1e-6, what="dropout2_add grad")
 
 
+def test_gan_criteria_in_one_launch_each_on_device():
+    from test_ops_sweep import _gan_criteria_fused_vs_per_term
+
+    _gan_criteria_fused_vs_per_term("cuda")
+
+
 def test_mean_many_on_device():
     """kantts_mean_many / kantts_scale_to_many: values, the bf16 LeakyReLU image, one gradient buffer per input."""
     import kantts._hip as hip

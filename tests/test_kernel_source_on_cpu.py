@@ -40,6 +40,7 @@ from test_ops_sweep import (  # noqa: F401
     test_elementwise_losses_weight_norm_sin_add,
     test_fused_sambert_loss_equals_the_two_criteria,
     test_mean_of_branch_outputs_in_one_launch,
+    test_gan_criteria_in_one_launch_each,
 )
 from test_bf16_path_emulated import (  # noqa: F401
     bf16_mode,

@@ -369,3 +369,43 @@ def test_mean_of_branch_outputs_in_one_launch(emulated_cabi):
         for gr in grads:
             assert float((gr - cot / n).abs().max()) <= 3e-7  # g * (1 / n) against g / n: one ulp
         assert len({gr.data_ptr() for gr in grads}) == n
+
+
+def _gan_criteria_fused_vs_per_term(device):
+    """The three mean-reduced GAN criteria through ops.elem_loss_many (one launch each) against their per-term forms
+    (KANTTS_NO_FUSED_GAN_LOSS=1): values and the gradient of every score / feature map, with channels-last feature maps
+    handed out as permuted views (as the discriminators do) and a non-unit upstream gradient."""
+    from kantts.train.loss import DiscriminatorAdversarialLoss, FeatureMatchLoss, GeneratorAdversarialLoss
+
+    g = torch.Generator().manual_seed(17)
+
+    def fmap(B, C, T):  # (B, T, C) buffer seen as (B, C, T)
+        return torch.randn(B, T, C, generator=g).to(device).transpose(1, 2)
+
+    shapes = [[(2, 8, 50), (2, 16, 17), (2, 1, 9)], [(2, 4, 33), (2, 1, 5)], [(2, 32, 7), (2, 8, 3), (2, 2, 11), (2, 1, 4)]]
+    feats_hat = [[fmap(*sh).requires_grad_(True) for sh in d] for d in shapes]
+    feats = [[fmap(*sh) for sh in d] for d in shapes]
+    leaves = [a for d in feats_hat for a in d]
+    out = {}
+    for fused in (True, False):
+        if not fused:
+            os.environ["KANTTS_NO_FUSED_GAN_LOSS"] = "1"
+        try:
+            fm = FeatureMatchLoss()(feats_hat, feats)
+            adv = GeneratorAdversarialLoss()(feats_hat)
+            real, fake = DiscriminatorAdversarialLoss()(feats_hat, feats)
+            total = 2.0 * fm + 0.7 * adv + 1.3 * fake + 0.0 * real
+            grads = torch.autograd.grad(total, leaves, allow_unused=True)
+        finally:
+            os.environ.pop("KANTTS_NO_FUSED_GAN_LOSS", None)
+        out[fused] = ([float(fm), float(adv), float(real), float(fake)], grads)
+    for a, b in zip(out[True][0], out[False][0]):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (out[True][0], out[False][0])
+    for a, b in zip(out[True][1], out[False][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-6 * max(1e-6, float(b.abs().max())), a.shape
+
+
+def test_gan_criteria_in_one_launch_each(emulated_cabi):
+    _gan_criteria_fused_vs_per_term("cpu")
