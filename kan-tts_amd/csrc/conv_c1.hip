@@ -281,30 +281,46 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_wgrad_mfma_kernel(const ka
       xs[i] = (t >= 0 && t < g.Tsrc) ? g.x[((long long)b * g.Tsrc + t) * g.inner + p] : 0.f;
     }
     __syncthreads();
-    for (int tg = wave; tg * 4 < nq; tg += C1_THREADS / 64) {
-      const int q = tg * 4 + kg;
-      const bool ok = q < nq;
-      const float bx = (ok && li < g.K) ? xs[q * g.stride + li * g.dil] : 0.f;  // B[k = token kg][j = tap li]
-      const long long row = (((long long)b * g.Tdst + q0 + (ok ? q : 0)) * g.inner + p) * g.Cout;
+    // two token groups per trip, every load of the trip issued before the first MFMA: the layer is a stream of dy (and
+    // the gate) -- 268 MB for the first MSD layer at batch 32 x 8192 -- and ran at 1.06 TB/s with one group in flight per
+    // wave (profiles/r04_runV: 253 us per launch, alone on the chip at the end of every sub-discriminator's backward)
+    constexpr int WV = C1_THREADS / 64;
+    for (int tg = wave; tg * 4 < nq; tg += 2 * WV) {
+      float4 dv[2][H], gv[2][H];
+      float bxv[2];
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const int n = 64 * h + 4 * li;
-        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && n < g.Cout) {
-          d = *reinterpret_cast<const float4*>(g.y + row + n);
+      for (int u = 0; u < 2; ++u) {
+        const int q = (tg + u * WV) * 4 + kg;
+        const bool ok = q < nq;
+        bxv[u] = (ok && li < g.K) ? xs[q * g.stride + li * g.dil] : 0.f;  // B[k = token kg][j = tap li]
+        const long long row = (((long long)b * g.Tdst + q0 + (ok ? q : 0)) * g.inner + p) * g.Cout;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const int n = 64 * h + 4 * li;
+          const bool live = ok && n < g.Cout;
+          dv[u][h] = live ? *reinterpret_cast<const float4*>(g.y + row + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          gv[u][h] = (live && g.gate) ? *reinterpret_cast<const float4*>(g.gate + row + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float bx = bxv[u];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          float4 d = dv[u][h];
           if (g.gate) {
-            const float4 y = *reinterpret_cast<const float4*>(g.gate + row + n);
+            const float4 y = gv[u][h];
             d.x = c1_gate(d.x, y.x, g.gate_slope);
             d.y = c1_gate(d.y, y.y, g.gate_slope);
             d.z = c1_gate(d.z, y.z, g.gate_slope);
             d.w = c1_gate(d.w, y.w, g.gate_slope);
           }
+          bs[h][0] += d.x; bs[h][1] += d.y; bs[h][2] += d.z; bs[h][3] += d.w;
+          acc[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.x, bx, acc[h][0], 0, 0, 0);
+          acc[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.y, bx, acc[h][1], 0, 0, 0);
+          acc[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.z, bx, acc[h][2], 0, 0, 0);
+          acc[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.w, bx, acc[h][3], 0, 0, 0);
         }
-        bs[h][0] += d.x; bs[h][1] += d.y; bs[h][2] += d.z; bs[h][3] += d.w;
-        acc[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.x, bx, acc[h][0], 0, 0, 0);
-        acc[h][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.y, bx, acc[h][1], 0, 0, 0);
-        acc[h][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.z, bx, acc[h][2], 0, 0, 0);
-        acc[h][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(d.w, bx, acc[h][3], 0, 0, 0);
       }
     }
   }
@@ -322,12 +338,21 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_wgrad_mfma_kernel(const ka
       if (nb < g.Cout) atomicAdd(&red[g.K * g.Cout + nb], bs[h][m]);
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < g.K * g.Cout; i += C1_THREADS) {
+  // every workgroup flushes the same (K + 1) * Cout addresses at about the same time: start each at its own offset, so
+  // that the L2 atomic units see distinct addresses instead of 512 queued adds on one (the flush, not the stream, was
+  // the launch: 1 M atomics ~ 250 us, profiles/r04_runW)
+  const int nflush = g.K * g.Cout, rot = (int)(((long long)blockIdx.x * 61) % nflush);
+  for (int i0 = threadIdx.x; i0 < nflush; i0 += C1_THREADS) {
+    int i = i0 + rot;
+    if (i >= nflush) i -= nflush;
     const int k = i / g.Cout, nn = i % g.Cout;
     atomicAdd(&g.dw[nn * g.K + k], red[i]);
   }
   if (g.db)
-    for (int i = threadIdx.x; i < g.Cout; i += C1_THREADS) atomicAdd(&g.db[i], red[g.K * g.Cout + i]);
+    for (int i0 = threadIdx.x; i0 < g.Cout; i0 += C1_THREADS) {
+      const int i = (i0 + blockIdx.x * 5) % g.Cout;
+      atomicAdd(&g.db[i], red[g.K * g.Cout + i]);
+    }
 }
 
 extern "C" int kantts_conv_c1_launch(const kantts_conv_c1_args* a, int mode, void* stream) {
@@ -359,9 +384,10 @@ extern "C" int kantts_conv_c1_launch(const kantts_conv_c1_args* a, int mode, voi
     else
       hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3((unsigned)blocks), dim3(C1_THREADS), lds, st, g);
   } else {
-    // persistent grid: at most C1_WGRAD_WGS workgroups (two per CU), each reducing once
+    // persistent grid: at most C1_WGRAD_WGS workgroups (one per CU), each reducing once: the launch is the sum of a stream
+    // (268 MB of dy + gate for the first MSD layer) and of (K + 1) * Cout global atomics per workgroup
     const char* wgs_env = getenv("KANTTS_C1_WGRAD_WGS");  // experiment / test switch (read per launch: tests change it)
-    const long long cap = (wgs_env && atoll(wgs_env) > 0) ? atoll(wgs_env) : 512;
+    const long long cap = (wgs_env && atoll(wgs_env) > 0) ? atoll(wgs_env) : 256;  // 512: 255 us, 256: 198, 128: 241 (r04_runX)
     const unsigned pgrid = (unsigned)(blocks < cap ? blocks : cap);
     if (vec && g.Cout <= 64)
       hipLaunchKernelGGL((conv_c1_wgrad_mfma_kernel<1>), dim3(pgrid), dim3(C1_THREADS), lds, st, g, (int)blocks);

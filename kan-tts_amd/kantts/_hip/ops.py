@@ -1389,6 +1389,30 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq=No
 # ================================================================================================
 _tap_matrix_cache = {}
 
+# Packed re-layouts of a weight (block-diagonal merges of small groups) are valid until ANY parameter arena's master weights
+# change (ParamArena.shadow_stale bumps the epoch): the discriminators run twice per phase of a GAN step on the same weights
+# (generated and real audio), and every re-layout is a zero-fill + copies + a cast of its own.
+weights_epoch = [0]
+_pack_cache = {}
+
+
+def _cached_pack(w, tag, make, stable):
+    """``stable``: ``w`` is a view of a network's weight-norm image buffer (ops.weight_norm_image) -- the same address for
+    the same layer all step long.  Anything else (a per-layer re-parametrisation: a fresh tensor per forward pass whose
+    address the allocator may hand to ANOTHER layer's weight next) is never cached."""
+    if not stable or os.environ.get("KANTTS_NO_PACK_CACHE"):
+        return make()
+    key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), tag, str(w.device))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == weights_epoch[0] and hit[2] == w._version:
+        return hit[1]
+    if len(_pack_cache) > 512:
+        for k in [k for k, v in _pack_cache.items() if v[0] != weights_epoch[0]]:
+            del _pack_cache[k]
+    out = make()
+    _pack_cache[key] = (weights_epoch[0], out, w._version)
+    return out
+
 
 def _upsample_tap_matrix(K, up, pad, dil, device):
     """S[j - jmin, k] = #{r in [0, up): r + pad - k*dil == j}: combines the K taps of a convolution over a
@@ -1648,7 +1672,9 @@ class _CConvCL(torch.autograd.Function):
         P = _group_pack(groups, Cin_g, Cout_g) if up == 1 else 1
         ctx.wd_img = w_imgs[1] if P == 1 else None
         if P > 1:
-            wb = _blockdiag_pack(wt.reshape(K, Cout, Cin_g), groups, P).to(torch.bfloat16)
+            wb = _cached_pack(w, ("fwd", groups, P, tap_major),
+                              lambda: _blockdiag_pack(wt.reshape(K, Cout, Cin_g), groups, P).to(torch.bfloat16),
+                              cfg.get("w_stable", False))
         elif w_imgs[0] is not None:
             wb = w_imgs[0]
         else:
@@ -1709,7 +1735,9 @@ class _CConvCL(torch.autograd.Function):
             elif up == 1:
                 Pd = _group_pack(groups, Cout_g, Cin_g)
                 if Pd > 1:
-                    wdb = _blockdiag_pack(wd.reshape(K, Cin, Cout_g), groups, Pd).to(torch.bfloat16)
+                    wdb = _cached_pack(w, ("bwd", groups, Pd, tap_major),
+                                       lambda: _blockdiag_pack(wd.reshape(K, Cin, Cout_g), groups, Pd).to(torch.bfloat16),
+                                       cfg.get("w_stable", False))
                 elif ctx.wd_img is not None:
                     wdb = ctx.wd_img.view(K, Cin, Cout_g)
                 else:
@@ -1955,7 +1983,8 @@ def conv_cl(x, w, bias=None, *, stride=1, dilation=1, pad=0, Tout=None, up=1, gr
     if Tout is None:
         Tout = Tin * up if stride == 1 else (Tin + 2 * pad - dilation * (K - 1) - 1) // stride + 1
     cfg = dict(stride=int(stride), dilation=int(dilation), pad=int(pad), Tout=int(Tout), up=int(up), groups=int(groups),
-               inner=int(inner), in_leaky=in_leaky, out_leaky=out_leaky, tap_major=bool(tap_major))
+               inner=int(inner), in_leaky=in_leaky, out_leaky=out_leaky, tap_major=bool(tap_major),
+               w_stable=bool(getattr(w, "_kantts_stable", False)))
     Cout, Cin_g = (w.shape[1], w.shape[2]) if tap_major else (w.shape[0], w.shape[1])
     if (up == 1 or stride == 1) and _cconv_ok(x, Cin_g, Cout // int(groups), K, x.shape[0] * int(Tout) * int(inner),
                                                 int(groups)):
@@ -2193,6 +2222,7 @@ def weight_norm_image(m):
     if arena is None or not arena.weight_norm_images_fresh():
         return None
     w = _WeightNormImage.apply(m.weight_v, m.weight_g, wn)
+    w._kantts_stable = True  # a view of the network's image buffer: same address all step long (_cached_pack)
     if get_precision() == "bf16" and wn[2] is not None and not os.environ.get("KANTTS_NO_WEIGHT_IMAGES"):
         setattr(w, _WIMG_ATTR, (wn[2], wn[3], wn[4]))
     return w

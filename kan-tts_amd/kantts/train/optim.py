@@ -65,6 +65,7 @@ class ParamArena:
         self._shadow_stale = bool(value)
         if value:
             self._weights_version += 1
+            ops.weights_epoch[0] += 1  # cached re-layouts of any weight (ops._cached_pack) are out of date
 
     # ------------------------------------------------------------------------------------------ direct gradients
     def enable_direct_grads(self):
