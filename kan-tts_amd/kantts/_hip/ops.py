@@ -698,6 +698,7 @@ class _SelfAttention(torch.autograd.Function):
         ctx.save_for_backward(q2, o, lse, lens)
         ctx.cfg = (B, H, L, drop_p, seed)
         if want_probs:
+            ctx.set_materialize_grads(False)  # no zero tensor for the gradient of a non-differentiable output
             ctx.mark_non_differentiable(probs)
             return o.view(B, L, D), probs
         return o.view(B, L, D), None
@@ -830,6 +831,7 @@ class _PncaAttention(torch.autograd.Function):
         ctx.save_for_backward(q2, h2, ox, oh, lsex, lseh, lens, bw_dev)
         ctx.cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)
         if want_probs:
+            ctx.set_materialize_grads(False)  # no zero tensor for the gradient of a non-differentiable output
             ctx.mark_non_differentiable(px, ph)
         return ox.view(B, L, D), oh.view(B, L, D), px, ph
 
@@ -1695,6 +1697,7 @@ class _CConvCL(torch.autograd.Function):
         ctx.res_for_gate = r if cfg["out_leaky"] is not None else None
         if y_img is None:
             return y
+        ctx.set_materialize_grads(False)  # no zero tensor for the gradient of a non-differentiable output
         ctx.mark_non_differentiable(y_img)
         return y, y_img
 
@@ -1921,6 +1924,7 @@ class _MeanMany(torch.autograd.Function):
               "mean_many")
         ctx.cfg = (float(scale), n)
         if img is not None:
+            ctx.set_materialize_grads(False)  # no zero tensor for the gradient of a non-differentiable output
             ctx.mark_non_differentiable(img)
         return out, img
 
@@ -2154,6 +2158,7 @@ class _WeightNormTap(torch.autograd.Function):
             wd = torch.empty((K, groups, cin, Cout // groups), device=v.device, dtype=torch.bfloat16)
             check(lib().kantts_weight_norm_tap_images(ptr(v, torch.float32), ptr(g, torch.float32), ptr(w), ptr(wf), ptr(wd),
                                                       Cout, cin, K, int(groups), stream()), "weight_norm_tap_images")
+            ctx.set_materialize_grads(False)  # no zero tensor for the gradient of a non-differentiable output
             ctx.mark_non_differentiable(wf, wd)
             return w, wf, wd
         check(lib().kantts_weight_norm_strided_fwd(ptr(v, torch.float32), ptr(g, torch.float32), ptr(w), Cout, cin, K, cin,
@@ -2282,6 +2287,7 @@ class _SinAddAct(torch.autograd.Function):
         check(lib().kantts_sinadd_lrelu_fwd(ptr(x, torch.float32), ptr(y), ptr(act), float(slope), x.numel(), stream()),
               "sinadd_lrelu_fwd")
         ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)  # no zero tensor for the gradient of a non-differentiable output
         ctx.mark_non_differentiable(act)
         return y, act
 
