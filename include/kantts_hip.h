@@ -459,6 +459,8 @@ typedef struct {
   float out_slope;
   int out_act;
   float gate_slope;
+  void* y_bf16; /* [round 4] mode 0, optional: the bf16 image of y (after the output activation) for the convolution that
+                   consumes it -- the second layer of every sub-discriminator otherwise starts with a cast pass over y */
 } kantts_conv_c1_args;
 int kantts_conv_c1_launch(const kantts_conv_c1_args* args, int mode, void* stream);
 

@@ -21,6 +21,7 @@
 
 __device__ __forceinline__ float c1_gate(float d, float y, float slope) { return d * ((y > 0.f) ? 1.f : slope); }
 
+typedef __bf16 c1_bf16x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------- forward
 __global__ __launch_bounds__(C1_THREADS) void conv_c1_fwd_kernel(const kantts_conv_c1_args g) {
   extern __shared__ __attribute__((aligned(16))) float c1_lds[];
@@ -65,7 +66,12 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_fwd_kernel(const kantts_co
       acc.z = acc.z > 0.f ? acc.z : acc.z * g.out_slope;
       acc.w = acc.w > 0.f ? acc.w : acc.w * g.out_slope;
     }
-    *reinterpret_cast<float4*>(g.y + (((long long)b * g.Tdst + q0 + ql) * g.inner + p) * g.Cout + n4) = acc;
+    const long long o = (((long long)b * g.Tdst + q0 + ql) * g.inner + p) * g.Cout + n4;
+    *reinterpret_cast<float4*>(g.y + o) = acc;
+    if (g.y_bf16) {
+      c1_bf16x4 v = {(__bf16)acc.x, (__bf16)acc.y, (__bf16)acc.z, (__bf16)acc.w};
+      *reinterpret_cast<c1_bf16x4*>(reinterpret_cast<__bf16*>(g.y_bf16) + o) = v;
+    }
   }
 }
 
@@ -362,7 +368,7 @@ extern "C" int kantts_conv_c1_launch(const kantts_conv_c1_args* a, int mode, voi
     return KANTTS_E_BADARG;
   if (mode < 0 || mode > 2 || (mode == 2 && !g.dw)) return KANTTS_E_BADARG;
   if (g.K > C1_MAXK || (g.Cout & 3) || g.Cout > 256 || (256 % (g.Cout / 4)) != 0 || (256 % g.Cout) != 0 ||
-      ((uintptr_t)g.y & 15) || (g.bias && ((uintptr_t)g.bias & 15)))
+      ((uintptr_t)g.y & 15) || (g.bias && ((uintptr_t)g.bias & 15)) || ((uintptr_t)g.y_bf16 & 7))
     return KANTTS_E_UNSUPPORTED;
   if (g.B == 0 || g.Tdst == 0) return KANTTS_OK;
   const long long blocks = (long long)g.B * g.inner * kantts_cdiv(g.Tdst, C1_QB);

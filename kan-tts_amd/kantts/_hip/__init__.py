@@ -84,7 +84,7 @@ class ConvC1Args(Structure):
         ("dw", c_void_p), ("db", c_void_p),
         ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cout", c_int32), ("K", c_int32), ("stride", c_int32),
         ("dil", c_int32), ("pad", c_int32), ("inner", c_int32),
-        ("out_slope", c_float), ("out_act", c_int32), ("gate_slope", c_float),
+        ("out_slope", c_float), ("out_act", c_int32), ("gate_slope", c_float), ("y_bf16", c_void_p),
     ]
 
 
@@ -901,7 +901,7 @@ def cconv_wgrad(x_bf, dy_bf, dw_tap, db, *, B, Tsrc, Tdst, groups, CR, NG, K, st
 
 
 def conv_c1(mode, *, x=None, dx=None, y=None, gate=None, w=None, bias=None, dw=None, db=None, B, Tsrc, Tdst, Cout, K,
-            stride, dil, pad, inner=1, out_leaky=None, gate_slope=0.0):
+            stride, dil, pad, inner=1, out_leaky=None, gate_slope=0.0, y_bf16=None):
     """Single-input-channel convolution kernels (csrc/conv_c1.hip): mode 0 forward, 1 input gradient, 2 weight /
     bias gradient.  Returns False when the shape is not supported."""
     if os.environ.get("KANTTS_NO_CONVWIN"):
@@ -914,6 +914,7 @@ def conv_c1(mode, *, x=None, dx=None, y=None, gate=None, w=None, bias=None, dw=N
     if out_leaky is not None:
         g.out_act, g.out_slope = 1, float(out_leaky)
     g.gate_slope = float(gate_slope)
+    g.y_bf16 = ptr(y_bf16, torch.bfloat16)
     rc = lib().kantts_conv_c1_launch(ctypes.byref(g), int(mode), stream())
     if rc == E_UNSUPPORTED:
         return False

@@ -1511,8 +1511,14 @@ class _ConvCL(torch.autograd.Function):
         ctx.res_for_gate = r if cfg["out_leaky"] is not None else None  # y = act(conv) + res: the gate is sign(y - res)
         # one input channel (first discriminator layers): streaming kernels, weights stay (Cout, K)
         ctx.c1 = (Cin == 1 and groups == 1 and up == 1 and res is None and cfg["in_leaky"] is None and not tap_major)
+        # bf16 mode: the 1-channel first layer also writes the bf16 image its consumer reads (cfg["image"] = None: no further
+        # activation), handed to conv_cl() through the cfg dict -- one more output would change the node's signature
+        y16 = None
+        if ctx.c1 and cfg.get("image", False) is None and get_precision() == "bf16" and y.numel() % 8 == 0:
+            y16 = torch.empty(y.shape, device=x.device, dtype=torch.bfloat16)
         if ctx.c1 and conv_c1(0, x=x, y=y, w=w, bias=bias, B=B, Tsrc=Tin, Tdst=Tout, Cout=Cout, K=K, stride=stride,
-                              dil=dil, pad=pad, inner=inner, out_leaky=cfg["out_leaky"]):
+                              dil=dil, pad=pad, inner=inner, out_leaky=cfg["out_leaky"], y_bf16=y16):
+            cfg["c1_image"] = y16
             return y
         ctx.c1 = False
         wt = w if tap_major else (w.permute(2, 0, 1).contiguous() if K > 1 else w)  # (K, Cout, Cin_g)
@@ -1999,7 +2005,11 @@ def conv_cl(x, w, bias=None, *, stride=1, dilation=1, pad=0, Tout=None, up=1, gr
         cfg["image"] = image
         y, y_img = _CConvCL.apply(x, w, bias, res, cfg, x_img, w_imgs)
         return set_image(y, image, y_img)
-    return _ConvCL.apply(x, w, bias, res, cfg)
+    if image is None:
+        cfg["image"] = None
+    y = _ConvCL.apply(x, w, bias, res, cfg)
+    img = cfg.pop("c1_image", None)
+    return y if img is None else set_image(y, None, img)
 
 
 class _ConvTransposeCL(torch.autograd.Function):

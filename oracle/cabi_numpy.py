@@ -1307,6 +1307,8 @@ class EmulatedLib:
             if g.out_act:
                 acc = np.where(acc > 0, acc, acc * np.float32(g.out_slope))
             yv[:] = acc.astype(np.float32)
+            if getattr(g, "y_bf16", None):
+                _wr(g.y_bf16, acc.astype(np.float32).reshape(-1), True)
             return 0
         dy = yv.astype(np.float64)
         if g.gate:

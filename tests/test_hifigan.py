@@ -741,8 +741,12 @@ def _wn_table_check(device, count_calls=None, train=True):
         for a, b in zip(res[True][0], res[False][0]):
             for k in a:
                 assert abs(a[k] - b[k]) <= max(1e-5, 3 * floor_l) * max(1.0, abs(b[k])), (k, a[k], b[k], floor_l)
+        # weights after two Adam steps: the two arms' weights of the layers WITHOUT bf16 images differ in the last bit
+        # (another summation order per row, asserted above at 1e-6), which now and then flips one LeakyReLU gate or one
+        # sign of an L1 gradient somewhere -- a discrete event that Adam (lr 2e-3, |update| = lr whatever the gradient's
+        # size) turns into 7.8e-5 of one arena's norm, always the same value, in about one run in five on the device
         for a, b in zip(res[True][1], res[False][1]):
-            assert rel_l2(a, b) <= max(1e-5, 3 * floor_w), (rel_l2(a, b), floor_w)
+            assert rel_l2(a, b) <= max(3e-4, 3 * floor_w), (rel_l2(a, b), floor_w)
         return res
     finally:
         hip.set_precision("fp32")
@@ -840,6 +844,36 @@ def _c1_persistent(device, monkeypatch):
             assert_close(y, ref, 5e-5, what=str(case))
             for a, c in zip(gy, gr):
                 assert rel_l2(a, c) < 2e-4, (cap, case, rel_l2(a, c))
+
+
+def _c1_image(device):
+    """bf16 mode: the 1-channel first layer of a sub-discriminator hands its consumer the bf16 image of its (activated)
+    output from the same launch (kantts_conv_c1_args.y_bf16) -- bit for bit what the cast pass it replaces would write."""
+    import kantts._hip as hip
+    from kantts._hip import ops
+
+    hip.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(12)
+        for (B, T, inner, Cout, K, stride, pad) in ((2, 301, 1, 128, 15, 1, 7), (3, 90, 2, 32, 5, 3, 2)):
+            x = torch.randn(B, T, inner, 1, generator=g).to(device) if inner > 1 else torch.randn(B, T, 1, generator=g).to(device)
+            w = (torch.randn(Cout, 1, K, generator=g) * 0.3).to(device)
+            b = torch.randn(Cout, generator=g).to(device)
+            y = ops.conv_cl(x, w, b, stride=stride, pad=pad, inner=inner, out_leaky=0.1, image=None)
+            img = ops.get_image(y, None)
+            assert img is not None and img.dtype == torch.bfloat16 and img.shape == y.shape
+            assert torch.equal(img, y.to(torch.bfloat16))
+    finally:
+        hip.set_precision("fp32")
+
+
+def test_one_channel_layer_hands_over_its_bf16_image_emulated(emulated_cabi):
+    _c1_image("cpu")
+
+
+@pytest.mark.gpu
+def test_one_channel_layer_hands_over_its_bf16_image_gpu():
+    _c1_image("cuda")
 
 
 def test_one_channel_weight_gradient_with_a_persistent_grid_emulated(emulated_cabi, monkeypatch):
