@@ -42,7 +42,7 @@ class _ZeroPool:
 
     def __init__(self):
         self.buf = None
-        self.off = 0
+        self.off = self.hw = 0
         # direct gradients (train/optim.py: ParamArena.enable_direct_grads): the n-th take() after a reset that turned out
         # to become a parameter's .grad is served from that parameter's range of the gradient arena from then on
         self.calls = 0
@@ -55,11 +55,18 @@ class _ZeroPool:
         have = 0 if (self.buf is None or self.buf.device != torch.device(device)) else self.buf.numel()
         self.buf = torch.zeros(int(have + numel), device=device, dtype=torch.float32)
         self.off = 0
+        self.hw = 0  # highest offset ever handed out: everything beyond it is still zero
 
     def reset(self):
+        """Re-zero what may have been written: the prefix up to the highest offset ever handed out, not the whole buffer
+        (sized for every arena of the process: 0.5 GB for the three HiFi-GAN models, reset by each of their zero_grad()
+        calls, three times per step).  ``hw`` only grows, so a captured reset covers at least what its own graph uses.
+        (Skipping a reset that follows another one without a request in between was tried and is WRONG under capture: the
+        reset in front of a capture is not part of the graph, the captured step then never re-zeroed its accumulators --
+        the bench loss moved in the fourth digit, profiles/r04_runAD.)"""
         self.calls = 0
         if self.buf is not None:
-            self.buf.zero_()
+            self.buf[:min(self.buf.numel(), max(64, (self.hw + 63) // 64 * 64))].zero_()
             self.off = 0
 
     def take(self, shape, device):
@@ -86,6 +93,7 @@ class _ZeroPool:
         if a + n > self.buf.numel():
             return torch.zeros(shape, device=device, dtype=torch.float32)
         self.off = a + n
+        self.hw = max(self.hw, self.off)
         return self.buf[a:a + n].view(shape)
 
 

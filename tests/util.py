@@ -108,6 +108,14 @@ def run_both(fn, *args, grads_of=(), device="cuda"):
         a = [to_dev(t, "cpu" if dev == "hostsim" else dev) for t in args]
         ctx = emulation() if dev == "cpu" else (kernel_source_on_cpu() if dev == "hostsim" else contextlib.nullcontext())
         with ctx:
+            # both legs draw their dropout masks from (host seed + device-resident offset): the offsets of the two devices
+            # are advanced independently by whatever training steps ran earlier in the session -- start both from zero
+            try:
+                import kantts._hip as _hip
+
+                _hip.rng_state("cpu" if dev in ("cpu", "hostsim") else dev).zero_()
+            except Exception:
+                pass
             out = fn(*a)
             outs = [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(o)]
             leaves = [t for t in _flatten(a) if torch.is_tensor(t) and t.requires_grad]
