@@ -464,6 +464,30 @@ typedef struct {
 } kantts_conv_c1_args;
 int kantts_conv_c1_launch(const kantts_conv_c1_args* args, int mode, void* stream);
 
+/* [round 4] Convolutions with ONE output channel (csrc/conv_n1.hip): the conv_post layers of the generator
+ * (kantts/models/hifigan/hifigan.py:178-180: Conv1d(32 -> 1, k = 7) after leaky_relu(x, 0.01)), of the period discriminators
+ * (:238-262, Conv2d(1024 -> 1, (3, 1))) and of the scale discriminators (:373-402).  A dot product per output position:
+ *   mode 0  y[b,q,p] = bias + sum_k sum_c w[k][c] act(x[b, q*stride + k*dil - pad, p, c])
+ *   mode 1  dx[b,t,p,c] = act'(x) sum_k w[k][c] dy[b, (t + pad - k*dil) / stride, p]   (y holds dy; dx fully written)
+ *   mode 2  dw[k][c] += sum act(x) dy,  db[0] += sum dy   (y holds dy; dw / db zeroed or accumulating, caller's choice)
+ * x (B, Tsrc, inner, Cin) fp32, y (B, Tdst, inner); the weight and its gradient are addressed as w[k * w_ks + c * w_cs]
+ * (tap-major (K, 1, Cin): w_ks = Cin, w_cs = 1; parameter layout (1, Cin, K): w_ks = 1, w_cs = K).  act = LeakyReLU(in_slope)
+ * when in_act.  KANTTS_E_UNSUPPORTED unless Cin is a power of two in [4, 1024], K <= 8 and (Cin / 4 / min(64, Cin / 4)) * K <= 16. */
+typedef struct {
+  const float* x;
+  float* dx;
+  float* y;
+  const float* w;
+  const float* bias;
+  float* dw;
+  float* db;
+  int B, Tsrc, Tdst, Cin, K, stride, dil, pad, inner;
+  int w_ks, w_cs;
+  float in_slope;
+  int in_act;
+} kantts_conv_n1_args;
+int kantts_conv_n1_launch(const kantts_conv_n1_args* args, int mode, void* stream);
+
 /* Free-running inference steps.
  * kantts_attn_decode: one query per sequence (decoder position `step`) against rows [lo, hi] of a (B, L, .) K/V
  *   buffer; the interval is the training kernels' function of (mode, step, len, bw) (HybridAttentionDecoder.infer,

@@ -88,6 +88,17 @@ class ConvC1Args(Structure):
     ]
 
 
+class ConvN1Args(Structure):
+    """kantts_conv_n1_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("dx", c_void_p), ("y", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("dw", c_void_p),
+        ("db", c_void_p),
+        ("B", c_int32), ("Tsrc", c_int32), ("Tdst", c_int32), ("Cin", c_int32), ("K", c_int32), ("stride", c_int32),
+        ("dil", c_int32), ("pad", c_int32), ("inner", c_int32), ("w_ks", c_int32), ("w_cs", c_int32),
+        ("in_slope", c_float), ("in_act", c_int32),
+    ]
+
+
 class CConvArgs(Structure):
     """kantts_cconv_args (include/kantts_hip.h); ``in_`` is the C field ``in``."""
     _fields_ = [
@@ -303,6 +314,7 @@ def lib():
         L.kantts_weight_norm_table_bwd.argtypes = [p, p, p, POINTER(WnBwdArgs), p]
         L.kantts_masked_l1_many.argtypes = [POINTER(LossTerm), i, p, p]
         L.kantts_scale_many.argtypes = [POINTER(c_void_p), POINTER(ll), i, p, p]
+        L.kantts_conv_n1_launch.argtypes = [POINTER(ConvN1Args), i, p]
         L.kantts_elem_loss_many.argtypes = [POINTER(ElossTerm), i, p, p]
         L.kantts_mean_many.argtypes = [POINTER(c_void_p), i, f, p, p, f, ll, p]
         L.kantts_scale_to_many.argtypes = [p, f, POINTER(c_void_p), i, ll, p]
@@ -326,7 +338,7 @@ EXPORTED_SYMBOLS = [
     "kantts_cconv_launch", "kantts_cconv_wgrad_launch", "kantts_cconv_wgrad_ws_floats", "kantts_act_cast_bf16",
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
-    "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many",
+    "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
 ]
 
 
@@ -919,6 +931,26 @@ def conv_c1(mode, *, x=None, dx=None, y=None, gate=None, w=None, bias=None, dw=N
     if rc == E_UNSUPPORTED:
         return False
     check(rc, "conv_c1")
+    return True
+
+
+def conv_n1(mode, *, x, y, w, w_ks, w_cs, dx=None, bias=None, dw=None, db=None, B, Tsrc, Tdst, Cin, K, stride, dil, pad,
+            inner=1, in_leaky=None):
+    """One-output-channel convolution kernels (csrc/conv_n1.hip): mode 0 forward, 1 input gradient, 2 weight / bias
+    gradient; ``y`` is the output (mode 0) or its gradient.  Returns False when the shape is not supported."""
+    if os.environ.get("KANTTS_NO_CONV_N1"):
+        return False
+    g = ConvN1Args()
+    g.x, g.dx, g.y, g.w = ptr(x, torch.float32), ptr(dx, torch.float32), ptr(y, torch.float32), ptr(w, torch.float32)
+    g.bias, g.dw, g.db = ptr(bias, torch.float32), ptr(dw, torch.float32), ptr(db, torch.float32)
+    g.B, g.Tsrc, g.Tdst, g.Cin, g.K = int(B), int(Tsrc), int(Tdst), int(Cin), int(K)
+    g.stride, g.dil, g.pad, g.inner, g.w_ks, g.w_cs = int(stride), int(dil), int(pad), int(inner), int(w_ks), int(w_cs)
+    if in_leaky is not None:
+        g.in_act, g.in_slope = 1, float(in_leaky)
+    rc = lib().kantts_conv_n1_launch(ctypes.byref(g), int(mode), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "conv_n1")
     return True
 
 

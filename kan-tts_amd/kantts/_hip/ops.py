@@ -11,7 +11,7 @@ import math
 
 import torch
 
-from . import (E_UNSUPPORTED, act_cast_bf16, bgemm_nt, bgemm_tn, cconv, cconv_wgrad, check, get_precision, conv_c1, conv_wgrad,
+from . import (E_UNSUPPORTED, act_cast_bf16, bgemm_nt, bgemm_tn, cconv, cconv_wgrad, check, get_precision, conv_c1, conv_n1, conv_wgrad,
                conv_win, gemm, lib, make_seg, ptr, rng_state, stream)
 from . import ops_bf16
 
@@ -1529,6 +1529,15 @@ class _ConvCL(torch.autograd.Function):
             cfg["c1_image"] = y16
             return y
         ctx.c1 = False
+        # one OUTPUT channel (conv_post of the generator and of every sub-discriminator): a dot product per position on
+        # csrc/conv_n1.hip -- as a windowed GEMM such a layer is a single output tile, i.e. one workgroup
+        ctx.n1 = (Cout == 1 and groups == 1 and up == 1 and res is None and cfg["out_leaky"] is None and Cin % 4 == 0)
+        if ctx.n1:
+            ks, cs = (Cin, 1) if tap_major else (1, K)
+            ctx.n1 = conv_n1(0, x=x, y=y, w=w, w_ks=ks, w_cs=cs, bias=bias, B=B, Tsrc=Tin, Tdst=Tout, Cin=Cin, K=K,
+                             stride=stride, dil=dil, pad=pad, inner=inner, in_leaky=cfg["in_leaky"])
+            if ctx.n1:
+                return y
         wt = w if tap_major else (w.permute(2, 0, 1).contiguous() if K > 1 else w)  # (K, Cout, Cin_g)
         P = _group_pack(groups, Cin_g, Cout_g) if up == 1 else 1
         if P > 1 and conv_win(
@@ -1579,6 +1588,20 @@ class _ConvCL(torch.autograd.Function):
                 db = gzeros((Cout,), dy.device) if has_bias else None
                 if not conv_c1(2, x=x, y=dy, w=w, dw=dw, db=db, **kw):
                     raise RuntimeError("conv_c1 wgrad refused a shape its forward accepted")
+            return dx, dw, db, None, None
+        if getattr(ctx, "n1", False):
+            ks, cs = (Cin, 1) if tap_major else (1, K)
+            kw = dict(w=w, w_ks=ks, w_cs=cs, B=B, Tsrc=Tin, Tdst=Tout, Cin=Cin, K=K, stride=stride, dil=dil, pad=pad,
+                      inner=inner, in_leaky=cfg["in_leaky"])
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                if not conv_n1(1, x=x, y=dy, dx=dx, **kw):
+                    raise RuntimeError("conv_n1 dgrad refused a shape its forward accepted")
+            if ctx.needs_input_grad[1]:
+                dw = gzeros(tuple(w.shape), dy.device)
+                db = gzeros((1,), dy.device) if has_bias else None
+                if not conv_n1(2, x=x, y=dy, dw=dw, db=db, **kw):
+                    raise RuntimeError("conv_n1 wgrad refused a shape its forward accepted")
             return dx, dw, db, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

@@ -1286,6 +1286,52 @@ class EmulatedLib:
             _arr(g.db, N)[:] += dy.sum(axis=(0, 1)).astype(np.float32)
         return 0
 
+    def kantts_conv_n1_launch(self, args_ref, mode, stream):
+        """csrc/conv_n1.hip: one output channel; float64 accumulation."""
+        g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
+        mode = _val(mode)
+        Ci, K, P, B, Ts, Td = g.Cin, g.K, g.inner, g.B, g.Tsrc, g.Tdst
+        C4 = Ci // 4
+        if Ci % 4 or Ci > 1024 or (C4 & (C4 - 1)) or K > 8 or (C4 // min(64, C4)) * K > 16:
+            return -2
+        span = (K - 1) * g.w_ks + (Ci - 1) * g.w_cs + 1
+        wflat = _arr(g.w, span)
+        idx = np.arange(K)[:, None] * g.w_ks + np.arange(Ci)[None, :] * g.w_cs
+        w = wflat[idx].astype(np.float64)  # (K, Cin)
+        x = _arr(g.x, B * Ts * P * Ci).reshape(B, Ts, P, Ci).astype(np.float64)
+        xa = np.where(x < 0, x * np.float32(g.in_slope), x) if g.in_act else x
+        yv = _arr(g.y, B * Td * P).reshape(B, Td, P)
+        q = np.arange(Td)
+        if mode == 0:
+            acc = np.zeros((B, Td, P))
+            for k in range(K):
+                src = q * g.stride + k * g.dil - g.pad
+                ok = (src >= 0) & (src < Ts)
+                acc[:, q[ok]] += xa[:, src[ok]] @ w[k]
+            if g.bias:
+                acc += _arr(g.bias, 1)[0]
+            yv[:] = acc.astype(np.float32)
+            return 0
+        dy = yv.astype(np.float64)
+        if mode == 1:
+            dx = np.zeros((B, Ts, P, Ci))
+            for k in range(K):
+                src = q * g.stride + k * g.dil - g.pad
+                ok = (src >= 0) & (src < Ts)
+                dx[:, src[ok]] += dy[:, q[ok], :, None] * w[k]
+            if g.in_act:
+                dx = dx * np.where(x < 0, np.float32(g.in_slope), 1.0)
+            _arr(g.dx, B * Ts * P * Ci)[:] = dx.astype(np.float32).reshape(-1)
+            return 0
+        dwf = _arr(g.dw, span)
+        for k in range(K):
+            src = q * g.stride + k * g.dil - g.pad
+            ok = (src >= 0) & (src < Ts)
+            dwf[idx[k]] += np.einsum("btp,btpc->c", dy[:, q[ok]], xa[:, src[ok]]).astype(np.float32)
+        if g.db:
+            _arr(g.db, 1)[0] += np.float32(dy.sum())
+        return 0
+
     def kantts_conv_c1_launch(self, args_ref, mode, stream):
         g = args_ref._obj if hasattr(args_ref, "_obj") else args_ref
         mode = _val(mode)

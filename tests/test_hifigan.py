@@ -846,6 +846,58 @@ def _c1_persistent(device, monkeypatch):
                 assert rel_l2(a, c) < 2e-4, (cap, case, rel_l2(a, c))
 
 
+def _one_output_channel(device):
+    """csrc/conv_n1.hip (conv_post of the generator / the sub-discriminators: one output channel = a dot product per output
+    position) against torch: forward, input gradient, weight and bias gradient -- 1024 -> 1 with the period axis folded,
+    32 -> 1 with k = 7 behind a LeakyReLU, a strided / dilated odd case, both weight layouts."""
+    import torch.nn.functional as F
+
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(23)
+    cases = [  # B, T, inner, Cin, K, stride, dil, pad, in_leaky, tap_major
+        (2, 23, 3, 1024, 3, 1, 1, 1, None, False),
+        (3, 301, 1, 32, 7, 1, 1, 6, 0.01, False),
+        (2, 40, 2, 64, 5, 2, 2, 3, 0.1, True),
+        (1, 9, 1, 1024, 3, 1, 1, 1, None, True),
+    ]
+    for (B, T, inner, Cin, K, stride, dil, pad, slope, tap) in cases:
+        shape = (B, T, inner, Cin) if inner > 1 else (B, T, Cin)
+        x = torch.randn(shape, generator=g).to(device).requires_grad_(True)
+        wp = (torch.randn(1, Cin, K, generator=g) / (Cin * K) ** 0.5).to(device)
+        w = (wp.permute(2, 0, 1).contiguous() if tap else wp).requires_grad_(True)
+        b = torch.randn(1, generator=g).to(device).requires_grad_(True)
+        Tout = (T + 2 * pad - dil * (K - 1) - 1) // stride + 1
+        y = ops.conv_cl(x, w, b, stride=stride, dilation=dil, pad=pad, inner=inner, in_leaky=slope, tap_major=tap, Tout=Tout)
+        xr = x.detach().clone().requires_grad_(True)
+        wr = wp.clone().requires_grad_(True)
+        br = b.detach().clone().requires_grad_(True)
+        xa = F.leaky_relu(xr, slope) if slope is not None else xr
+        xt = xa.reshape(B, T, inner, Cin).permute(0, 2, 3, 1).reshape(B * inner, Cin, T)
+        ref = F.conv1d(xt, wr, br, stride=stride, padding=pad, dilation=dil)  # (B * inner, 1, Tout)
+        ref = ref.reshape(B, inner, Tout).permute(0, 2, 1).reshape(y.shape)
+        assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), (Cin, K)
+        cot = torch.randn(y.shape, generator=g).to(device)
+        gy = torch.autograd.grad(y, [x, w, b], cot)
+        gr = torch.autograd.grad(ref, [xr, wr, br], cot)
+        assert rel_l2(gy[0], gr[0]) < 2e-5, ("dx", Cin, K, rel_l2(gy[0], gr[0]))
+        gw = gy[1].permute(1, 2, 0) if tap else gy[1]
+        assert rel_l2(gw, gr[1]) < 5e-5, ("dw", Cin, K, rel_l2(gw, gr[1]))
+        assert abs(float(gy[2]) - float(gr[2])) <= 1e-4 * max(1.0, abs(float(gr[2]))), ("db", Cin, K)
+
+
+def test_one_output_channel_convolution_emulated(emulated_cabi):
+    _one_output_channel("cpu")
+
+
+@pytest.mark.gpu
+def test_one_output_channel_convolution_gpu():
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    _one_output_channel("cuda")
+
+
 def _c1_image(device):
     """bf16 mode: the 1-channel first layer of a sub-discriminator hands its consumer the bf16 image of its (activated)
     output from the same launch (kantts_conv_c1_args.y_bf16) -- bit for bit what the cast pass it replaces would write."""

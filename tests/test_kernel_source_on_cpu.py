@@ -86,6 +86,7 @@ from test_hifigan import (  # noqa: F401
     test_weight_norm_table_backward_equals_per_layer_emulated,
     test_one_channel_weight_gradient_with_a_persistent_grid_emulated,
     test_one_channel_layer_hands_over_its_bf16_image_emulated,
+    test_one_output_channel_convolution_emulated,
 )
 from test_hifigan_nsf import test_nsf_generator_host_logic_matches_reference_fixture  # noqa: F401
 from test_sambert_se import test_sambert_se_host_logic_matches_reference_fixture  # noqa: F401
