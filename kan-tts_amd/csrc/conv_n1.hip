@@ -182,8 +182,13 @@ extern "C" int kantts_conv_n1_launch(const kantts_conv_n1_args* a, int mode, voi
   } else {
     const int RS = N1_THREADS / C4;
     const long long rows = (long long)g.B * g.Tsrc * g.inner;
+    // workgroups: enough to stream x, few enough that the K * Cin atomics per workgroup stay under ~0.5 M per launch
+    // (generator: 224 addresses -> up to 1024 workgroups over 33 MB; discriminators: 3072 addresses -> 170)
     int grid = kantts_cdiv(rows, (long long)RS * 16);
-    if (grid > 256) grid = 256;
+    int cap = (1 << 19) / (g.K * g.Cin);
+    if (cap < 64) cap = 64;
+    if (cap > 1024) cap = 1024;
+    if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)RS * g.K * g.Cin * sizeof(float);
     if (lds > 64 * 1024) return KANTTS_E_UNSUPPORTED;
