@@ -316,8 +316,10 @@ def test_two_process_graphed_step_on_one_gpu(tmp_path):
     print("after 3 steps: segmented vs two-graph %.2e, two-graph vs two-graph again %.2e; losses %s | %s | %s" % (
         err, floor, res["segments"]["losses"], res["two_graph"]["losses"], res["two_graph_again"]["losses"]))
     assert err <= max(3.0 * floor, 1e-6), (err, floor)
+    # the losses: a gross-error check only (the step-3 loss of this tiny fp32 model moves by up to 1.5e-4 relative between two
+    # runs of ONE form -- 4.595052 / 4.595539 / 4.595748 over the round's runs -- the weights above are the parity statement)
     for x, y in zip(res["segments"]["losses"], res["two_graph"]["losses"]):
-        assert abs(x - y) <= 1e-4 * max(1.0, abs(y)), (x, y)
+        assert abs(x - y) <= 1e-3 * max(1.0, abs(y)), (x, y)
 
 
 def _gan_graph_worker(rank, world, port, out_dir, captured):
