@@ -214,10 +214,12 @@ def test_fsmn_memory_length_regulator_embedding_and_masked_l1(emulated_cabi):
             exp = torch.repeat_interleave(torch.arange(N), reps[b])
             gref[b].index_add_(0, exp, cot[b, :len(exp)])
         assert float((gx - gref).abs().max()) < 1e-5, it
-    for it in range(6):
+    for it in range(7):
         # embedding gather-sum with scale and position table
         B, T, D = rnd.choice([1, 3]), rnd.randint(1, 9), rnd.choice([8, 32])
         sizes = [rnd.randint(2, 9) for _ in range(rnd.choice([1, 2, 4]))]
+        if it == 6:  # rows spanning several 32-row chunks of the gradient kernel, more distinct ids per chunk than its
+            B, T, D, sizes = 2, 75, 32, [40, 3, 1]  # 8-entry accumulator cache holds (evictions), and a one-row table
         tabs = [torch.randn(n, D, generator=g).requires_grad_(True) for n in sizes]
         ids = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in sizes], -1)
         pos = torch.randn(T, D, generator=g) if rnd.random() < 0.5 else None
