@@ -155,11 +155,12 @@ __global__ __launch_bounds__(N1_THREADS) void conv_n1_wgrad_kernel(const kantts_
 }
 
 extern "C" int kantts_conv_n1_launch(const kantts_conv_n1_args* a, int mode, void* stream) {
-  if (!a || !a->x || !a->y || !a->w || mode < 0 || mode > 2 || (mode == 1 && !a->dx) || (mode == 2 && !a->dw))
-    return KANTTS_E_BADARG;
+  if (!a || mode < 0 || mode > 2) return KANTTS_E_BADARG;
   const kantts_conv_n1_args& g = *a;
   if (g.B < 0 || g.Tsrc < 0 || g.Tdst < 0 || g.Cin < 4 || g.K < 1 || g.stride < 1 || g.dil < 1 || g.inner < 1 || g.pad < 0)
     return KANTTS_E_BADARG;
+  if (g.B == 0 || (g.Tdst == 0 && g.Tsrc == 0)) return KANTTS_OK;  // (empty tensors may carry NULL pointers)
+  if (!g.x || !g.y || !g.w || (mode == 1 && !g.dx) || (mode == 2 && !g.dw)) return KANTTS_E_BADARG;
   const int C4 = g.Cin >> 2;
   if ((g.Cin & 3) || g.Cin > 1024 || (C4 & (C4 - 1)) || g.K > N1_MAXK || ((uintptr_t)g.x & 15) || (g.dx && ((uintptr_t)g.dx & 15)) ||
       (g.w_cs == 1 && (((uintptr_t)g.w & 15) || (g.w_ks & 3))))

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void scale_to_many_kernel(const MeanManyArgs a
 }
 extern "C" int kantts_mean_many(const float* const* xs_host, int n, float scale, float* out, void* act_bf16, float slope,
                                 long long numel, void* stream) {
-  if (!xs_host || !out || n < 1 || n > 8 || numel < 0) return KANTTS_E_BADARG;
+  if (!xs_host || n < 1 || n > 8 || numel < 0) return KANTTS_E_BADARG;
+  if (numel == 0) return KANTTS_OK;  // (empty tensors may carry NULL pointers)
+  if (!out) return KANTTS_E_BADARG;
   if ((numel & 3) || ((uintptr_t)out & 15) || ((uintptr_t)act_bf16 & 7)) return KANTTS_E_UNSUPPORTED;
   MeanManyArgs a = {};
   a.n = n;
@@ -349,7 +351,9 @@ extern "C" int kantts_mean_many(const float* const* xs_host, int n, float scale,
 }
 extern "C" int kantts_scale_to_many(const float* g, float scale, float* const* outs_host, int n, long long numel,
                                     void* stream) {
-  if (!g || !outs_host || n < 1 || n > 8 || numel < 0) return KANTTS_E_BADARG;
+  if (!outs_host || n < 1 || n > 8 || numel < 0) return KANTTS_E_BADARG;
+  if (numel == 0) return KANTTS_OK;
+  if (!g) return KANTTS_E_BADARG;
   if ((numel & 3) || ((uintptr_t)g & 15)) return KANTTS_E_UNSUPPORTED;
   MeanManyArgs a = {};
   a.n = n;

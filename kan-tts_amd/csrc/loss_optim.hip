@@ -352,8 +352,9 @@ extern "C" int kantts_elem_loss_many(const kantts_eloss_term* terms, int nterms,
   int nb = 0, k = 0;
   for (int i = 0; i < nterms; ++i) {
     const kantts_eloss_term& q = terms[i];
-    if (!q.a || q.n < 0 || q.mode < 0 || q.mode > 1 || (q.mode == 0 && !q.b) || q.out < 0) return KANTTS_E_BADARG;
-    if (q.n == 0) continue;
+    if (q.n < 0 || q.mode < 0 || q.mode > 1 || q.out < 0) return KANTTS_E_BADARG;
+    if (q.n == 0) continue;  // (an empty tensor's pointer may be NULL)
+    if (!q.a || (q.mode == 0 && !q.b)) return KANTTS_E_BADARG;
     a.t[k] = q;
     a.first_block[k] = nb;
     int blocks = kantts_cdiv(q.n, 1024);

@@ -1241,7 +1241,7 @@ class _MaskedL1Many(torch.autograd.Function):
     def backward(ctx, g, _gc):
         import ctypes
 
-        live = [t for t in ctx.grads if t is not None]
+        live = [t for t in ctx.grads if t is not None and t.numel() > 0]
         if live:
             g = _c(g).reshape(1)
             xs = (ctypes.c_void_p * len(live))(*[ptr(t, torch.float32) for t in live])
@@ -1318,7 +1318,7 @@ class _ElemLossMany(torch.autograd.Function):
 
         g_losses = _c(g_losses)
         for out in sorted(set(ctx.outs)):
-            live = [t for t, o in zip(ctx.grads, ctx.outs) if t is not None and o == out]
+            live = [t for t, o in zip(ctx.grads, ctx.outs) if t is not None and o == out and t.numel() > 0]
             for s0 in range(0, len(live), ELOSS_MAX_TERMS):
                 part = live[s0:s0 + ELOSS_MAX_TERMS]
                 xs = (ctypes.c_void_p * len(part))(*[ptr(t, torch.float32) for t in part])

@@ -1514,7 +1514,8 @@ class EmulatedLib:
     def kantts_scale_many(self, x, n, count, scale_dev, stream):
         s = _arr(scale_dev, 1)[0]
         for k in range(int(_val(count))):
-            _arr(x[k], int(n[k]))[:] *= s
+            if int(n[k]) > 0:
+                _arr(x[k], int(n[k]))[:] *= s
         return 0
 
     def kantts_elem_loss_many(self, terms, nterms, losses, stream):

@@ -860,6 +860,9 @@ def _one_output_channel(device):
         (3, 301, 1, 32, 7, 1, 1, 6, 0.01, False),
         (2, 40, 2, 64, 5, 2, 2, 3, 0.1, True),
         (1, 9, 1, 1024, 3, 1, 1, 1, None, True),
+        (2, 11, 1, 4, 8, 1, 1, 0, None, False),    # the narrowest input (one float4 per position), the longest filter
+        (1, 5, 2, 128, 1, 1, 1, 0, 0.2, True),     # a 1-tap layer
+        (1, 2, 1, 8, 3, 1, 1, 2, None, False),     # more padding than signal
     ]
     for (B, T, inner, Cin, K, stride, dil, pad, slope, tap) in cases:
         shape = (B, T, inner, Cin) if inner > 1 else (B, T, Cin)

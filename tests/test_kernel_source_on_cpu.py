@@ -41,6 +41,7 @@ from test_ops_sweep import (  # noqa: F401
     test_fused_sambert_loss_equals_the_two_criteria,
     test_mean_of_branch_outputs_in_one_launch,
     test_gan_criteria_in_one_launch_each,
+    test_element_losses_beyond_one_launch_and_empty_terms,
 )
 from test_bf16_path_emulated import (  # noqa: F401
     bf16_mode,

@@ -53,6 +53,8 @@ def _register_form_cases(device):
         (dict(fft_size=1024, hop_size=200, win_length=800, num_mels=128, fmin=0, fmax=11025, pad_mode="reflect"), (2, 2311)),
         (dict(fs=16000, fft_size=2048, hop_size=200, win_length=1000, fmin=0, fmax=8000), (3, 3001)),
         (dict(fs=16000, fft_size=2048, hop_size=512, num_mels=40, fmin=50, fmax=7000, pad_mode="reflect"), (1, 2600)),
+        (dict(fft_size=1024, hop_size=256), (1, 700)),   # every frame reaches over an end of the waveform; odd frame count
+        (dict(fft_size=1024, hop_size=300, num_mels=20, fmin=0, fmax=4000), (4, 5)),  # one frame per utterance, T < hop
     ]
     for kw, (B, T) in cases:
         x = torch.randn(B, T, generator=g) * 0.2

@@ -411,3 +411,30 @@ def _gan_criteria_fused_vs_per_term(device):
 
 def test_gan_criteria_in_one_launch_each(emulated_cabi):
     _gan_criteria_fused_vs_per_term("cpu")
+
+
+def test_element_losses_beyond_one_launch_and_empty_terms(emulated_cabi):
+    """ops.elem_loss_many with more terms than one launch takes (64) and with empty tensors among them: the same sums and
+    gradients as the single-term op."""
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(29)
+    a_list = [torch.randn(3, 1 + k % 7, generator=g).requires_grad_(True) for k in range(70)]
+    a_list[5] = torch.zeros(0, 4).requires_grad_(True)
+    b_list = [torch.randn(a.shape, generator=g) for a in a_list]
+    terms, ref = [], [0.0, 0.0]
+    for k, (a, b) in enumerate(zip(a_list, b_list)):
+        out = k % 2
+        if k % 3 == 0:
+            terms.append((a, None, 0.5, 1, 0.25, out))
+            ref[out] = ref[out] + 0.25 * ((a - 0.5) ** 2).sum()
+        else:
+            terms.append((a, b, 0.0, 0, 0.5, out))
+            ref[out] = ref[out] + 0.5 * (a - b).abs().sum()
+    got = ops.elem_loss_many(terms, n_out=2)
+    for o in range(2):
+        assert abs(float(got[o]) - float(ref[o])) <= 2e-5 * max(1.0, abs(float(ref[o]))), o
+    live = [a for a in a_list if a.numel()]
+    gg = torch.autograd.grad(1.5 * got[0] - 0.5 * got[1], live)
+    gr = torch.autograd.grad(1.5 * ref[0] - 0.5 * ref[1], live)
+    _cmp(gg, gr, dict(case="70 terms"), tol=1e-6)
