@@ -70,6 +70,7 @@ from test_melspec import (  # noqa: F401
     test_melspec_backward_emulated,
     test_dsp_melspectrogram_emulated,
     _register_form_cases,
+    _wide_filterbank_case,
     test_mel_layouts_agree_emulated,
 )
 
@@ -78,6 +79,14 @@ def test_register_resident_fft_form_kernel_source(emulated_cabi):
     """melspec_reg_kernel (one wave per frame, frame in registers, three wave-private LDS exchanges) compiled for the host:
     against the oracle and against the radix-2 kernel, n_fft 1024 and 2048 (tests/test_melspec.py)."""
     _register_form_cases("cpu")
+
+
+def test_register_form_with_a_filterbank_beyond_its_chunk_table_kernel_source(emulated_cabi):
+    """More than 256 chunks of 8 bins: melspec_reg_kernel's per-channel loop over the global weights (a branch no shipped
+    configuration reaches; CPU only until it has been on a device)."""
+    _wide_filterbank_case("cpu")
+
+
 from test_hifigan import (  # noqa: F401
     test_conv_variants_emulated_match_torch,
     test_conv_win_emulated_matches_torch,

@@ -84,6 +84,47 @@ def _register_form_cases(device):
         assert_close(out[False], out[True], 2e-5, rtol=2e-5, what="register-form |STFT| vs generic kernel")
 
 
+def _wide_filterbank_case(device):
+    """A filterbank no MelSpectrogram builds (Slaney triangles of <= 128 channels over 513 bins stay under 242 chunks of 8
+    bins) but the C ABI accepts: 128 channels, each ~44 bins wide -> ~830 chunks, more than the register kernel's chunk table
+    holds (MELR_CHMAX 256), so its per-channel loop over the global weights runs instead (csrc/melspec.hip, the `else` of
+    `mel_fast`).  Against the radix-2 kernel and against the dense contraction of the magnitudes."""
+    from kantts.utils.audio_torch import MelSpectrogram, stft
+
+    g = torch.Generator().manual_seed(77)
+    ms = MelSpectrogram(fft_size=1024, hop_size=256, num_mels=128, fmin=0, fmax=11025)
+    nb = 513
+    W = torch.zeros(nb, 128)
+    for c in range(128):
+        lo = 3 + (c * 461) // 128 + (c % 5)  # unaligned starts, the last channel ends at bin 512
+        width = 40 + (c % 9)
+        hi = min(lo + width, nb)
+        W[lo:hi, c] = torch.rand(hi - lo, generator=g) * 0.05 + 0.001
+    nchunks = sum(int((W[:, c].nonzero()[-1] // 8) - (W[:, c].nonzero()[0] // 8) + 1) for c in range(128))
+    assert nchunks > 256  # the point of the case
+    ms.melmat.copy_(W)
+    ms._support = None
+    ms = ms.to(device)
+    x = torch.randn(3, 2900, generator=g) * 0.2
+    out = {}
+    for generic in (False, True):
+        if generic:
+            os.environ["KANTTS_MEL_GENERIC"] = "1"
+        try:
+            out[generic] = ms(x[:, None, :].to(device)).cpu()
+        finally:
+            os.environ.pop("KANTTS_MEL_GENERIC", None)
+    assert_close(out[False], out[True], 5e-5, what="wide filterbank: register-form kernel vs generic kernel")
+    # dense restatement from the magnitudes (zero padding, clamp(power, eps) -> sqrt; eps = 1e-10 as MelSpectrogram)
+    xp = torch.nn.functional.pad(x.double(), (512, 512))
+    fr = xp.unfold(1, 1024, 256) * torch.hann_window(1024, dtype=torch.float64)
+    spec = torch.fft.rfft(fr, dim=-1)
+    mag = torch.sqrt(torch.clamp(spec.real ** 2 + spec.imag ** 2, min=1e-10))
+    mel = torch.clamp(mag @ W.double(), min=1e-10)
+    ref = torch.clamp(2 * 4.0 * ((20 * torch.log10(torch.clamp(mel, min=1e-5)) - 20.0 + 100.0) / 100.0) - 4.0, -4.0, 4.0)
+    assert_close(out[False], ref.transpose(1, 2).float(), 1e-4, what="wide filterbank: register-form kernel vs dense restatement")
+
+
 @pytest.mark.gpu
 def test_register_resident_fft_form_gpu():
     _register_form_cases("cuda")
