@@ -493,3 +493,27 @@ def test_weight_gradient_contraction_with_both_output_tiles(tile, bf16_mode, mon
 
     T.test_linear_modes_bf16_emulated(bf16_mode)
     T.test_deferred_grouped_weight_gradients_equal_immediate_ones(bf16_mode)
+
+
+@pytest.mark.parametrize("To,Ti", [(90, 64), (75, 65), (70, 128), (60, 200), (33, 256), (40, 300)])
+def test_monotonic_alignment_search_every_kernel_variant_on_the_kernel_source(To, Ti):
+    """mas_wave_kernel with 1 / 2 / 4 ballot words per row, the exact 64-column boundaries, and mas_block_kernel (more than
+    256 symbols) -- bit-exact against the numpy model of the ABI, ties and -inf scores included (the device twin:
+    tests/test_mas.py::test_mas_dp_gpu_every_kernel_variant_vs_oracle)."""
+    import torch
+
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(To * 1000 + Ti)
+    B = 3
+    attn = torch.softmax(torch.randn(B, 1, To, Ti, generator=g) * 2, dim=3)
+    attn[1] = torch.round(attn[1] * 64) / 64  # coarse grid: ties and zeros (-inf scores)
+    in_lens = torch.tensor([Ti, max(1, Ti - 7), max(1, Ti // 2)])
+    out_lens = torch.tensor([To, To - 5, max(1, To // 3)])
+    with util.kernel_source_on_cpu():
+        hard = ops.mas_width1(attn, in_lens, out_lens)
+    with _numpy_model():
+        ref = ops.mas_width1(attn, in_lens, out_lens)
+    assert torch.equal(hard, ref)
+    if To >= 2 * Ti:
+        assert torch.equal(hard.sum((1, 2, 3)).long(), out_lens)
