@@ -517,3 +517,51 @@ def test_monotonic_alignment_search_every_kernel_variant_on_the_kernel_source(To
     assert torch.equal(hard, ref)
     if To >= 2 * Ti:
         assert torch.equal(hard.sum((1, 2, 3)).long(), out_lens)
+
+
+@pytest.mark.parametrize("CR,NG,T,G,mul", [(16, 48, 200, 2, 1), (16, 48, 70, 1, 1), (32, 32, 200, 1, 2), (24, 32, 70, 4, 1),
+                                           (64, 64, 200, 2, 1), (48, 64, 70, 1, 1), (64, 32, 200, 1, 1), (48, 24, 70, 2, 2)])
+def test_cconv_window_form_every_variant_on_the_kernel_source(CR, NG, T, G, mul):
+    """cconv_narrow_kernel<256 | 128 rows, 64 | 32 outputs per group, 32 | 64 reduction channels>: the grouped / narrow
+    layers of the discriminators (at most 64 input channels per group, no fold, no upsampling), every instantiation the
+    launcher picks from (rows >= 192 -> 256-row tiles), strides 1 and 2, against the numpy model of the ABI."""
+    import torch
+
+    import kantts._hip as hip
+
+    g = torch.Generator().manual_seed(CR * 1000 + NG + T)
+    B, K = 2, 5
+    Cin, Cout, Ts = G * CR, G * NG, T * mul + 3
+    x = torch.randn(B, Ts, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(K, Cout, CR, generator=g) / (K * CR) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(Cout, generator=g)
+    outs = []
+    for src in ("kernel", "model"):
+        o32 = torch.full((B, T, Cout), float("nan"))
+        obf = torch.zeros((B, T, Cout), dtype=torch.bfloat16)
+        with util.kernel_source_on_cpu() if src == "kernel" else _numpy_model():
+            assert hip.cconv(x, w, out=o32, out_bf=obf, B=B, Tsrc=Ts, Tdst=T, groups=G, CR=CR, NG=NG, K=K, in_mul=mul,
+                             in_add=-2, in_kstep=1, in_div=1, phases=1, bias=bias, out_leaky=0.1, bf_leaky=0.2, tile=0)
+        outs.append((o32, obf.float()))
+    (a32, abf), (c32, cbf) = outs
+    assert not torch.isnan(a32).any()
+    assert float((a32 - c32).abs().max()) <= 2e-5 * max(1.0, float(c32.abs().max()))
+    assert float((abf - cbf).abs().max()) <= 1e-2 * max(1.0, float(cbf.abs().max()))
+
+
+def test_one_channel_layer_scalar_kernels_on_the_kernel_source(monkeypatch):
+    """conv_c1_wgrad_kernel / conv_c1_dgrad_kernel without the matrix cores: what a 1 -> 256 layer takes (no shipped
+    configuration has one) and what KANTTS_C1_NO_MFMA=1 forces for the A/B runs -- same outputs and gradients as torch."""
+    import test_hifigan as T
+
+    from util import assert_close, rel_l2
+
+    def run():
+        for case in ((2, 300, 1, 256, 7, 1, 1, 3, 1, None, 0.1, False), (2, 333, 1, 32, 5, 3, 1, 2, 1, None, 0.1, False)):
+            y, ref, gy, gr = T._win_case(case, "cpu")
+            assert_close(y, ref, 5e-5, what=str(case))
+            for a, c in zip(gy, gr):
+                assert rel_l2(a, c) < 2e-4, (case, rel_l2(a, c))
+
+    with util.kernel_source_on_cpu():
+        run()
