@@ -71,6 +71,7 @@ from test_melspec import (  # noqa: F401
     test_dsp_melspectrogram_emulated,
     _register_form_cases,
     _wide_filterbank_case,
+    _several_pairs_per_wave_case,
     test_mel_layouts_agree_emulated,
 )
 
@@ -85,6 +86,13 @@ def test_register_form_with_a_filterbank_beyond_its_chunk_table_kernel_source(em
     """More than 256 chunks of 8 bins: melspec_reg_kernel's per-channel loop over the global weights (a branch no shipped
     configuration reaches; CPU only until it has been on a device)."""
     _wide_filterbank_case("cpu")
+
+
+def test_register_form_walks_several_pairs_of_frames_per_wave_kernel_source(emulated_cabi):
+    """The persistent-grid loop of melspec_reg_kernel (prefetch beside the filterbank, reuse of the exchange cells): found
+    untested by the line-coverage run of this file (scripts/kernel_coverage.py) -- the benchmark's 67 584-frame launch is
+    the only place the device takes it."""
+    _several_pairs_per_wave_case("cpu")
 
 
 from test_hifigan import (  # noqa: F401

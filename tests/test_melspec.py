@@ -125,6 +125,28 @@ def _wide_filterbank_case(device):
     assert_close(out[False], ref.transpose(1, 2).float(), 1e-4, what="wide filterbank: register-form kernel vs dense restatement")
 
 
+def _several_pairs_per_wave_case(device):
+    """melspec_reg_kernel is a persistent grid: past 768 workgroups x 4 waves a wave walks SEVERAL pairs of frames (the next
+    pair's samples are fetched beside the filterbank, the exchange cells are reused).  The shipped batch (32 x 8192 samples:
+    528 pairs) never gets there; KANTTS_MEL_WGS caps the grid, so that 45 pairs on one or two workgroups do: bit-identical
+    to the one-pair-per-wave launch, mel (both channel slots) and magnitudes."""
+    from kantts.utils.audio_torch import MelSpectrogram, stft
+
+    g = torch.Generator().manual_seed(3)
+    for kw, (B, T) in ((dict(fft_size=1024, hop_size=256), (5, 4099)),
+                       (dict(fft_size=1024, hop_size=200, win_length=800, num_mels=128, fmin=0, fmax=11025, pad_mode="reflect"), (3, 2311))):
+        x = (torch.randn(B, T, generator=g) * 0.2).to(device)
+        ms = MelSpectrogram(**kw).to(device)
+        full, mag = ms(x[:, None, :]).cpu(), stft(x, 1024, 120, 600, "hann").cpu()
+        for cap in ("1", "2"):
+            os.environ["KANTTS_MEL_WGS"] = cap
+            try:
+                assert torch.equal(ms(x[:, None, :]).cpu(), full), (kw, cap)
+                assert torch.equal(stft(x, 1024, 120, 600, "hann").cpu(), mag), (kw, cap)
+            finally:
+                os.environ.pop("KANTTS_MEL_WGS", None)
+
+
 @pytest.mark.gpu
 def test_register_resident_fft_form_gpu():
     _register_form_cases("cuda")
