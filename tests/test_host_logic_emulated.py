@@ -246,6 +246,34 @@ def test_arena_adam_matches_torch_adam(emulated_cabi):
     assert float(sd["state"][0]["step"]) == 4.0
 
 
+def test_arena_adam_with_lr_and_step_count_in_device_memory(emulated_cabi):
+    """The form a captured step replays (ArenaAdam.enable_device_state: kantts_adam_step reads {lr, step} from a device
+    buffer, sync_lr() after the scheduler): same weights as the host-argument form through a changing learning rate."""
+    from kantts.train.optim import ArenaAdam, ParamArena
+
+    torch.manual_seed(1)
+    nets = [torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)) for _ in range(2)]
+    nets[1].load_state_dict(nets[0].state_dict())
+    opts = [ArenaAdam(ParamArena(n), lr=1e-2, betas=(0.9, 0.98), eps=1e-9) for n in nets]
+    for o in opts:
+        o.set_grad_clip(0.05)
+    dyn = opts[1].enable_device_state()
+    assert dyn.shape == (2,) and float(dyn[1]) == 0.0
+    for step in range(4):
+        x = torch.randn(6, 7)
+        lr = 1e-2 / (1 + step)
+        for n, o in zip(nets, opts):
+            o.param_groups[0]["lr"] = lr
+            o.sync_lr()
+            o.zero_grad()
+            n(x).pow(2).sum().backward()
+            o.step()
+    assert float(dyn[1]) == 4.0 and abs(float(dyn[0]) - 1e-2 / 4) < 1e-9
+    for a, b in zip(nets[0].parameters(), nets[1].parameters()):
+        assert_close(a.detach(), b.detach(), 1e-7, what="param")
+    assert opts[1].enable_device_state() is dyn  # one buffer for the optimizer's lifetime (captured graphs hold its address)
+
+
 def test_oracle_matches_live_reference_when_present():
     """In the build container the restatement is also compared with the live reference (own process:
     the reference package is also called ``kantts``)."""

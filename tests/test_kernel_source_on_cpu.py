@@ -28,6 +28,7 @@ from test_host_logic_emulated import (  # noqa: F401
     test_dropout2_add_and_fsmn_encoder_training_path,
     test_row_mask_handed_to_the_consuming_layernorm_changes_no_gradient,
     test_arena_adam_matches_torch_adam,
+    test_arena_adam_with_lr_and_step_count_in_device_memory,
     test_free_running_inference_matches_oracle,
     test_layernorm_backward_in_the_consumers_input_gradient_launch,
     test_relu_gate_of_a_hidden_gradient_in_its_producers_epilogue,
@@ -573,3 +574,65 @@ def test_one_channel_layer_scalar_kernels_on_the_kernel_source(monkeypatch):
 
     with util.kernel_source_on_cpu():
         run()
+
+
+@pytest.mark.parametrize("slices", [1, 3])
+def test_cconv_weight_gradient_token_slices_on_the_kernel_source(slices):
+    """cconv_wgrad_kernel / cconv_wgrad_taps_kernel with the token range cut into slices: partial tiles into the workspace +
+    cconv_wgrad_reduce_kernel, or atomics when no workspace is handed over (one slice: read-modify-write) -- 2.6 % of the
+    GAN step on the device, device twin tests/test_cconv.py::test_cconv_wgrad_gpu_vs_emulated."""
+    import torch
+
+    import kantts._hip as hip
+
+    g = torch.Generator().manual_seed(slices + 11)
+    # (B, Tsrc, Tdst, inner, Cin, Cout, groups, K, stride, dil, pad, up)
+    shapes = [(2, 70, 70, 1, 64, 64, 1, 3, 1, 1, 1, 1), (3, 61, 21, 5, 64, 256, 1, 5, 3, 1, 2, 1),
+              (2, 90, 90, 1, 72, 136, 1, 3, 1, 1, 1, 1), (2, 120, 60, 1, 128, 256, 2, 9, 2, 1, 4, 1),
+              (2, 50, 200, 1, 64, 64, 1, 7, 1, 1, 6, 4), (1, 9, 9, 1, 8, 8, 1, 1, 1, 1, 0, 1)]
+    for si, (B, Ts, Td, P, Cin, Cout, G, K, stride, dil, pad, up) in enumerate(shapes):
+        CR, NG = Cin // G, Cout // G
+        x = torch.randn(B, Ts, P, Cin, generator=g).to(torch.bfloat16)
+        dy = torch.randn(B, Td, P, Cout, generator=g).to(torch.bfloat16)
+        base = torch.randn(K, Cout, CR, generator=g)  # the call accumulates
+        outs = []
+        for src in ("kernel", "model"):
+            dw, db = base.clone(), torch.ones(Cout)
+            with util.kernel_source_on_cpu() if src == "kernel" else _numpy_model():
+                assert hip.cconv_wgrad(x, dy, dw, db, B=B, Tsrc=Ts, Tdst=Td, groups=G, CR=CR, NG=NG, K=K, stride=stride,
+                                       dil=dil, pad=pad, inner=P, up=up, slices=slices if src == "kernel" else 0)
+            outs.append((dw, db))
+        (adw, adb), (cdw, cdb) = outs
+        scale = (B * Td * P) ** 0.5
+        assert float((adw - cdw).abs().max()) <= 2e-5 * scale, (slices, si)
+        assert float((adb - cdb).abs().max()) <= 2e-5 * scale, (slices, si)
+
+
+@pytest.mark.parametrize("tile,CR,NG,G,T", [(0, 32, 32, 2, 200), (0, 128, 136, 1, 37), (64064, 32, 128, 1, 2112)])
+def test_cconv_fp32_gate_epilogue_and_the_tile_remap_on_the_kernel_source(tile, CR, NG, G, T):
+    """(i) the epilogue that gates by an fp32 pre-activation (out_gate fp32 + residual), window form and tiled form;
+    (ii) 66 tiles of 64 x 64: the blockIdx -> tile remap that keeps the n tiles of a row tile behind one XCD's L2 (taken from
+    64 tiles on; 66 is not a multiple of 8) must still cover every tile exactly once."""
+    import torch
+
+    import kantts._hip as hip
+
+    g = torch.Generator().manual_seed(T + CR)
+    B, K = 1 if T > 1000 else 2, 1 if T > 1000 else 3
+    Cin, Cout = G * CR, G * NG
+    x = torch.randn(B, T, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(K, Cout, CR, generator=g) / (K * CR) ** 0.5).to(torch.bfloat16)
+    res, gate = torch.randn(B, T, Cout, generator=g), torch.randn(B, T, Cout, generator=g)
+    outs = []
+    for src in ("kernel", "model"):
+        o32 = torch.full((B, T, Cout), float("nan"))
+        obf = torch.zeros((B, T, Cout), dtype=torch.bfloat16)
+        with util.kernel_source_on_cpu() if src == "kernel" else _numpy_model():
+            assert hip.cconv(x, w, out=o32, out_bf=obf, B=B, Tsrc=T, Tdst=T, groups=G, CR=CR, NG=NG, K=K, in_mul=1,
+                             in_add=-(K // 2), in_kstep=1, in_div=1, phases=1, res=res, out_gate=gate, out_gate_slope=0.3,
+                             tile=tile if src == "kernel" else 0)
+        outs.append((o32, obf.float()))
+    (a32, abf), (c32, cbf) = outs
+    assert not torch.isnan(a32).any()
+    assert float((a32 - c32).abs().max()) <= 2e-5 * max(1.0, float(c32.abs().max()))
+    assert float((abf - cbf).abs().max()) <= 1e-2 * max(1.0, float(cbf.abs().max()))

@@ -371,6 +371,23 @@ def test_mean_of_branch_outputs_in_one_launch(emulated_cabi):
         for gr in grads:
             assert float((gr - cot / n).abs().max()) <= 3e-7  # g * (1 / n) against g / n: one ulp
         assert len({gr.data_ptr() for gr in grads}) == n
+    # bf16 mode: the same launch also leaves bf16(LeakyReLU(mean)) for the convolution that reads it next
+    import kantts._hip as hip
+
+    prev = hip.get_precision()
+    hip.set_precision("bf16")
+    try:
+        for n, shape in ((3, (2, 40, 32)), (2, (1, 8, 4))):
+            xs = [torch.randn(shape, generator=g).requires_grad_(True) for _ in range(n)]
+            y = ops.mean_many(xs, image_slope=0.1)
+            img = ops.get_image(y, 0.1)
+            assert img is not None and img.dtype == torch.bfloat16
+            want = torch.nn.functional.leaky_relu(y.detach(), 0.1)
+            assert float((img.float() - want).abs().max()) <= 8e-3 * max(1.0, float(want.abs().max()))
+            (gr,) = torch.autograd.grad(y, xs[:1], torch.ones(shape))
+            assert float((gr - 1.0 / n).abs().max()) <= 3e-7
+    finally:
+        hip.set_precision(prev)
 
 
 def _gan_criteria_fused_vs_per_term(device):
