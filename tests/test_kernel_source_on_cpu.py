@@ -36,6 +36,7 @@ from test_host_logic_emulated import (  # noqa: F401
 from test_ops_sweep import (  # noqa: F401
     test_fused_linear_modes,
     test_attention_ragged_lengths_and_bands,
+    test_attention_longer_than_a_workgroup,
     test_lstm_uni_and_bidirectional_with_lengths,
     test_fsmn_memory_length_regulator_embedding_and_masked_l1,
     test_elementwise_losses_weight_norm_sin_add,

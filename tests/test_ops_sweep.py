@@ -5,6 +5,7 @@ masked L1.  Forward and gradients; fixed seeds; small shapes (a few seconds)."""
 import os
 import random
 
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -115,6 +116,45 @@ def test_attention_ragged_lengths_and_bands(emulated_cabi):
         got = torch.autograd.grad((ox * cot).sum() + (oh * c2).sum(), [qkv, hkv])  # one pass: both outputs share a node
         exp = torch.autograd.grad((rx * cot).sum() + (rh * c2).sum(), [qkv, hkv])
         _cmp(got, exp, cfg)
+
+
+@pytest.mark.parametrize("L", [300, 400])
+def test_attention_longer_than_a_workgroup(emulated_cabi, L):
+    """More rows than the 256 threads of an attention workgroup: up to 390 rows the K / V tiles still fit the 64 KB of LDS
+    and a thread owns a second query / key row (read from global, not from its registers); past that the direct-from-global
+    kernels run.  Self-attention and both PNCA bands, outputs and gradients against the oracle (the shipped shapes stop at
+    204 rows; the device suite has 600)."""
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(L)
+    B, H = 2, 1
+    D = H * 16
+    lens = torch.tensor([L, L - 37])
+    pad = O.pad_mask(lens, L)
+    qkv = torch.randn(B, L, 3 * D, generator=g).requires_grad_(True)
+    cfg = dict(B=B, L=L, H=H)
+    o, _ = ops.self_attention(qkv, lens.to(torch.int32), H)
+    q, k, v = (O._split_heads(t, H) for t in qkv.chunk(3, -1))
+    ro, _ = O._attend(q, k, v, pad[:, None, :].expand(-1, L, -1).repeat(H, 1, 1))
+    ro = O._merge_heads(ro, H)
+    valid = (~pad)[..., None]
+    assert float(((o - ro) * valid).detach().abs().max()) < 2e-5, cfg
+    cot = torch.randn(B, L, D, generator=g) * valid
+    _cmp(_grads(o, cot, [qkv]), _grads(ro, cot, [qkv]), cfg)
+    bwx, bwh = 9, 5
+    hkv = torch.randn(B, L, 2 * D, generator=g).requires_grad_(True)
+    ox, oh, _, _ = ops.pnca_attention(qkv, hkv, lens.to(torch.int32), bwx, bwh, H)
+    xm, hm = O.pnca_masks(L, bwx, bwh, pad, qkv.device)
+    hk, hv = (O._split_heads(t, H) for t in hkv.chunk(2, -1))
+    rx, _ = O._attend(q, k, v, xm.expand(B, -1, -1).repeat(H, 1, 1))
+    rh, _ = O._attend(q, hk, hv, hm.expand(B, -1, -1).repeat(H, 1, 1))
+    rx, rh = O._merge_heads(rx, H), O._merge_heads(rh, H)
+    assert float(((ox - rx) * valid).detach().abs().max()) < 2e-5, cfg
+    assert float(((oh - rh) * valid).detach().abs().max()) < 2e-5, cfg
+    c2 = torch.randn(B, L, D, generator=g) * valid
+    got = torch.autograd.grad((ox * cot).sum() + (oh * c2).sum(), [qkv, hkv])
+    exp = torch.autograd.grad((rx * cot).sum() + (rh * c2).sum(), [qkv, hkv])
+    _cmp(got, exp, cfg)
 
 
 def test_lstm_uni_and_bidirectional_with_lengths(emulated_cabi):
