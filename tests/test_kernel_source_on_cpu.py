@@ -637,3 +637,51 @@ def test_cconv_fp32_gate_epilogue_and_the_tile_remap_on_the_kernel_source(tile, 
     assert not torch.isnan(a32).any()
     assert float((a32 - c32).abs().max()) <= 2e-5 * max(1.0, float(c32.abs().max()))
     assert float((abf - cbf).abs().max()) <= 1e-2 * max(1.0, float(cbf.abs().max()))
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_lstm_abi_forms_the_host_never_uses_on_the_kernel_source(precision):
+    """kantts_lstm_fwd / _bwd with reverse_first = 1 (a lone right-to-left direction) and without the recurrent bias: declared
+    in include/kantts_hip.h, never passed by kantts._hip.ops.  Kernel source against the numpy model of the ABI, and the
+    reversed single direction against direction 1 of a two-direction call with the same weights."""
+    import torch
+
+    import kantts._hip as hip
+
+    g = torch.Generator().manual_seed(41 + precision)
+    B, T, H = 3, 11, 128
+    G = 4 * H
+    lens = torch.tensor([T, 4, 1], dtype=torch.int32)
+    gx2 = torch.randn(B, T, 2 * G, generator=g) * 0.5
+    whh2 = torch.randn(2, G, H, generator=g) * 0.08
+    dout2 = torch.randn(B, T, 2 * H, generator=g)
+
+    def run(gx, whh, bhh, dout, ndir, rev):
+        gx, whh, dout = gx.contiguous(), whh.contiguous(), dout.contiguous()
+        out = torch.full((B, T, ndir * H), float("nan"))
+        gates, cst = torch.zeros(ndir, B, T, G), torch.zeros(ndir, B, T, H)
+        dg = torch.zeros(ndir, B, T, G)
+        L = hip.lib()
+        p = hip.ptr
+        assert L.kantts_lstm_fwd(p(gx), p(whh), p(bhh), p(lens), p(out), p(gates), p(cst), B, T, H, ndir, rev, precision,
+                                 hip.stream()) == 0
+        assert L.kantts_lstm_bwd(p(dout), p(whh), p(lens), p(gates), p(cst), p(dg), B, T, H, ndir, rev, precision,
+                                 hip.stream()) == 0
+        return out, dg
+
+    res = {}
+    for src in ("kernel", "model"):
+        with util.kernel_source_on_cpu() if src == "kernel" else _numpy_model():
+            both = run(gx2, whh2, None, dout2, 2, 0)
+            lone = run(gx2[..., G:], whh2[1:], None, dout2[..., H:], 1, 1)
+        res[src] = (both, lone)
+        # the lone reversed direction IS direction 1 of the pair (same arithmetic, same order)
+        assert torch.equal(lone[0], both[0][..., H:]), src
+        valid = (torch.arange(T)[None, :] < lens[:, None])[None, :, :, None]
+        assert torch.equal(lone[1] * valid, both[1][1:] * valid), src
+    tol = 2e-5 if precision == 0 else 2e-2
+    for a, c in zip(res["kernel"][1], res["model"][1]):
+        valid = (torch.arange(T)[None, :] < lens[:, None])
+        a = a * (valid[..., None] if a.dim() == 3 else valid[None, :, :, None])
+        c = c * (valid[..., None] if c.dim() == 3 else valid[None, :, :, None])
+        assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))
