@@ -262,6 +262,9 @@ def test_upsampling_stream_kernel_and_sin_add_image(Cin, Cout, s, T):
             if Cin <= 128:
                 y2 = ops.upsample_forward(act, w, b, s, out_bf16=True)
                 assert y2.dtype == torch.bfloat16 and rel_l2(y2.float(), ref) <= 4e-3
+                rb = res.to(torch.bfloat16)  # bf16 residual added before the bf16 store (the all-bf16 inference chain)
+                y4 = ops.upsample_forward(act, w, b, s, res=rb, out_bf16=True)
+                assert y4.dtype == torch.bfloat16 and rel_l2(y4.float(), ref + rb.float()) <= 4e-3
                 hb = h.to(torch.bfloat16)
                 a3 = F.leaky_relu(hb.float(), 0.1).to(torch.bfloat16).float()
                 ref3 = F.conv_transpose1d(a3.transpose(1, 2), wq, b, stride=s)[:, :, :T * s].transpose(1, 2)
