@@ -688,3 +688,28 @@ def test_lstm_abi_forms_the_host_never_uses_on_the_kernel_source(precision):
         a = a * (valid[..., None] if a.dim() == 3 else valid[None, :, :, None])
         c = c * (valid[..., None] if c.dim() == 3 else valid[None, :, :, None])
         assert float((a - c).abs().max()) <= tol * max(1.0, float(c.abs().max()))
+
+
+@pytest.mark.parametrize("no_cconv", [False, True])
+def test_convolutions_in_bf16_mode_on_the_kernel_source(no_cconv, monkeypatch):
+    """tests/test_hifigan.py::test_conv_win_gpu_matches_torch[bf16] with host tensors: bf16 operands, fp32 accumulation,
+    device tolerances.  With the channels-last bf16 kernels switched off (KANTTS_NO_CCONV=1) the LDS-window kernels take
+    their bf16-operand instantiations (conv_win_kernel<true, ...>, conv_wgrad_kernel<true, ...>) -- what a shape those
+    kernels decline falls back to."""
+    import kantts._hip as hip
+    import test_hifigan as T
+    from util import rel_l2
+
+    if no_cconv:
+        monkeypatch.setenv("KANTTS_NO_CCONV", "1")
+    with util.kernel_source_on_cpu():
+        prev = hip.get_precision()
+        hip.set_precision("bf16")
+        try:
+            for case in T._WIN_CASES[2:-1]:
+                y, ref, gy, gr = T._win_case(case, "cpu")
+                assert float((y - ref).abs().max()) <= 4e-2 * max(1.0, float(ref.abs().max())), case
+                for a, c in zip(gy, gr):
+                    assert rel_l2(a, c) < 6e-2, case
+        finally:
+            hip.set_precision(prev)
