@@ -713,3 +713,16 @@ def test_convolutions_in_bf16_mode_on_the_kernel_source(no_cconv, monkeypatch):
                     assert rel_l2(a, c) < 6e-2, case
         finally:
             hip.set_precision(prev)
+
+
+def test_fast_gemm_with_64_row_tiles_in_a_fresh_process():
+    """gemm_fast_kernel<.., 64, ..>: chosen on the device from 512 workgroups on; KANTTS_GEMM_BM forces it, but the
+    launcher reads the switch once per process -- the linear-layer cases of this file again, in a child process."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, KANTTS_GEMM_BM="64")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "test_op_linear_fwd_bwd or test_fused_linear_modes or linear_epilogues"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
