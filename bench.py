@@ -756,7 +756,7 @@ def fp32_leg(hip, cfg, batch, frames, mel_crit, pros_crit, dev, steps=5, warmup=
             "whole_step_mfma_frac": 456.9e9 * batch["mel_targets"].shape[0] / 32 / dt / 1e12 / PEAK_TFLOPS["fp32"]}
 
 
-def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4):
+def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parity_utts=32, cpu_threads=0):
     """BASELINE config 5: end-to-end SAM-BERT -> HiFi-GAN inference on 128 synthetic utterances (T_in uniform
     20..80, the training id distributions, duration head biased to ~3.5 frames per symbol -- random-init weights predict
     zero durations otherwise), free-running: AR duration predictor, AR mel decoder, postnet, HiFi-GAN V1 generator with
@@ -775,13 +775,9 @@ def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4):
     am = am.to(dev).eval()
     voc = Generator().to(dev).eval()
     voc.remove_weight_norm()
-    g = torch.Generator().manual_seed(4321)
-    vocab = (147, 10, 8, 8)
-    lens = torch.randint(20, 81, (n_utt,), generator=g)
-    T = int(lens.max())
-    ling = torch.stack([torch.randint(0, vocab[k] - 3, (n_utt, T), generator=g) for k in range(4)], -1)
-    emo = torch.randint(0, 33, (n_utt, T), generator=g)
-    spk = torch.zeros(n_utt, T, dtype=torch.long)
+    from kantts.utils.synthetic import inference_utterances
+
+    lens, ling, emo, spk = inference_utterances(n_utt)
     order = torch.argsort(lens, descending=True)
 
     def synth(idx, mode):
@@ -823,7 +819,92 @@ def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4):
     out["batch%d_graph" % batch] = timed(batches, "graph")
     out["value"] = out["batch%d_graph" % batch]["audio_samples_per_s"]
     out["unit"] = "audio-samples/s, symbols -> wav, %d utterances in length-sorted batches of %d, graph-replayed decoder" % (n_utt, batch)
+    if parity_utts:
+        # the benchmarked configuration checked against the CPU oracle's free-running inference (outside the timed regions),
+        # whose wall time is the CPU baseline of this leg
+        try:
+            par = config5_parity(am, cfg, (lens, ling, emo, spk), order[:: max(1, n_utt // parity_utts)][:parity_utts],
+                                 batch=batch, threads=cpu_threads)
+            out["cpu_baseline"] = par.pop("cpu_baseline")
+            out["parity_error"] = par
+        except Exception as exc:  # noqa: BLE001
+            out["parity_error"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     return out
+
+
+def config5_parity(am, cfg, utts, idx, batch=32, threads=0):
+    """BASELINE config 5 checked at the configuration that is timed: the product's batched, graph-replayed free-running
+    inference of the utterances ``idx`` (length-sorted batches of ``batch``) against oracle/torch_oracle.py's free-running
+    inference of the same utterances one at a time (the reference's only mode, kantts/bin/infer_sambert.py:58-227;
+    kantts_sambert.py:569-610; adaptors.py:67-83).  Reports (i) agreement of the frame counts and of the rounded durations
+    (free-running: a 1-ulp change of exp(log_dur) - 1 + 0.5 can flip a duration), (ii) the mel error
+    with the durations FORCED to the oracle's, over the valid frames, (iii) the oracle's speed as this leg's CPU baseline.
+    Checker only: nothing here runs inside a timed region."""
+    import torch_oracle as O
+
+    lens, ling, emo, spk = utts
+    idx = torch.as_tensor(idx)
+    r = cfg["outputs_per_step"]
+    P = {k: v.detach().cpu().clone() for k, v in am.state_dict().items()}
+    nthr = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    ref = {}
+    t0 = time.perf_counter()
+    try:
+        with torch.no_grad():
+            for b in idx.tolist():
+                n = int(lens[b])
+                o = O.sambert_forward(P, cfg, ling[b:b + 1, :n], emo[b:b + 1, :n], spk[b:b + 1, :n], lens[b:b + 1])
+                ref[b] = dict(frames=int(o["LR_length_rounded"][0]), mel=o["postnet_outputs"][0],
+                              dur=(torch.exp(o["log_duration_predictions"][0]) - 1 + 0.5).long())
+    finally:
+        cpu_s = time.perf_counter() - t0
+        used = torch.get_num_threads()
+        torch.set_num_threads(nthr)
+    dev = next(am.parameters()).device
+    am.mel_decoder.decode_mode = "graph"
+    order = idx[torch.argsort(lens[idx], descending=True)]
+    same_frames = same_dur = n_sym = 0
+    abs_sum = abs_max = 0.0
+    n_el = 0
+    free_abs_sum, free_n = 0.0, 0
+    for g0 in range(0, len(order), batch):
+        grp = order[g0:g0 + batch]
+        ln = lens[grp]
+        Tm = int(ln.max())
+        args = dict(inputs_ling=ling[grp, :Tm].to(dev), inputs_emotion=emo[grp, :Tm].to(dev),
+                    inputs_speaker=spk[grp, :Tm].to(dev), input_lengths=ln.to(dev))
+        dur_ref = torch.zeros(len(grp), Tm, dtype=torch.long)
+        for i, b in enumerate(grp.tolist()):
+            dur_ref[i, : int(lens[b])] = ref[b]["dur"]
+        with torch.no_grad():
+            free = am(**args)
+            forced = am(**args, duration_targets=dur_ref.to(dev))
+        fl = free["LR_length_rounded"].cpu()
+        dur_free = (torch.exp(free["log_duration_predictions"].cpu()) - 1 + 0.5).long()
+        for i, b in enumerate(grp.tolist()):
+            n, nf = int(lens[b]), ref[b]["frames"]
+            same_frames += int(int(fl[i]) == nf)
+            same_dur += int((dur_free[i, :n] == ref[b]["dur"]).sum())
+            n_sym += n
+            assert int(forced["LR_length_rounded"][i]) == nf, "forced durations must reproduce the oracle's frame count"
+            d = (forced["postnet_outputs"][i, :nf].cpu() - ref[b]["mel"][:nf]).abs()
+            abs_sum += float(d.sum())
+            abs_max = max(abs_max, float(d.max()))
+            n_el += d.numel()
+            if int(fl[i]) == nf and bool((dur_free[i, :n] == ref[b]["dur"]).all()):
+                df = (free["postnet_outputs"][i, :nf].cpu() - ref[b]["mel"][:nf]).abs()
+                free_abs_sum += float(df.sum())
+                free_n += df.numel()
+    frames = sum(v["frames"] for v in ref.values())
+    return {"utterances": len(ref), "decoder": "graph, length-sorted batches of %d" % batch,
+            "frame_count_agreement": same_frames / len(ref), "duration_agreement": same_dur / n_sym,
+            "mel_mean_abs_forced_durations": abs_sum / n_el, "mel_max_abs_forced_durations": abs_max,
+            "mel_mean_abs_free_running_where_durations_agree": (free_abs_sum / free_n) if free_n else None,
+            "cpu_baseline": {"value": len(ref) / cpu_s, "unit": "utterances/s (symbols -> mel, batch 1, free-running)",
+                             "mel_frames_per_s": frames / cpu_s, "cores": used, "kind": "port",
+                             "sample": "%d of the leg's utterances through oracle/torch_oracle.py, %.1f s" % (len(ref), cpu_s)}}
 
 
 def _spawn_ranks(n, argv):
@@ -865,6 +946,10 @@ def main():
     ap.add_argument("--oracle-probe", type=int, default=0, help=argparse.SUPPRESS)  # child process of cpu_baseline
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (a functional check of the distributed path, not a scaling figure)")
+    ap.add_argument("--rccl-world1", action="store_true",
+                    help="one rank, but with a REAL world-size-1 nccl (= RCCL) process group: the data-parallel code path "
+                         "(arena buckets, graph segments, the all-reduce between their replays, RCCL's init and its watchdog "
+                         "thread beside relaxed-mode captures) executes on a one-GPU box; not a scaling figure")
     args = ap.parse_args()
 
     CPU_THREADS["n"] = args.cpu_threads or None
@@ -878,7 +963,15 @@ def main():
               file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.rccl_world1
+    if args.rccl_world1 and world == 1 and "MASTER_PORT" not in os.environ:
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     device_index = 0 if args.share_device else local_rank
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
@@ -1132,7 +1225,8 @@ def main():
                 out["melspec"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
         if world == 1 and not args.no_inference:
             try:
-                out["inference"] = inference_leg(hip, cfg, args.precision)
+                out["inference"] = inference_leg(hip, cfg, args.precision, parity_utts=0 if args.no_cpu_baseline else 32,
+                                                 cpu_threads=_cpu_threads())
                 _note("inference leg done")
             except Exception as exc:
                 out["inference"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}

@@ -2233,7 +2233,10 @@ class _WeightNormImage(torch.autograd.Function):
         v, g = ctx.saved_tensors
         dw = _c(dw)
         arena = ctx.holder[0]()
-        if arena is not None and arena.defer_weight_norm_backward(ctx.holder[5], dw):
+        how = arena.defer_weight_norm_backward(ctx.holder[5], dw) if arena is not None else False
+        if how == "extra":  # a further application of the layer in this step: added to its slot at the flush
+            return None, None, None
+        if how:
             # one table-driven launch per network before the optimizer step (ParamArena.flush_weight_norm_backward, called
             # from wgrad_overlap.join()): autograd receives views of the gradient arena that are filled then
             return arena.grad_slot(v), arena.grad_slot(g), None

@@ -614,7 +614,12 @@ class KanTtsSAMBERT(nn.Module):
         if duration_targets is None:
             pred = (torch.exp(log_duration_predictions) - 1)
             bw_dev = (pred.max(dim=1).values / r + 0.5).to(torch.int32).contiguous()  # per sequence (free-running)
-        if self.device_band_width and duration_targets is not None:
+        elif mel_targets is None:
+            # inference with the durations given (no mel targets: the decoder free-runs): every sequence keeps its own band
+            # width, as in the free-running case above, so that a batch equals its utterances inferred one at a time
+            bw_dev = (duration_targets.float().masked_fill(in_info.mask, 0).max(dim=1).values / r + 0.5).to(
+                torch.int32).contiguous()
+        if self.device_band_width and duration_targets is not None and mel_targets is not None:
             bw_dev = tplan["bw_dev"] if (tplan is not None and "bw_dev" in tplan) else bw_val.to(torch.int32).reshape(1)
             x_band_width = h_band_width = bw_dev
             bw_int = 0

@@ -41,9 +41,18 @@ class GraphedGanStep:
         self.steps = steps
         self.y, self.x = y.clone(), x.clone()
         self._nosched = {"generator": _NoSched(), "discriminator": {k: _NoSched() for k in scheduler["discriminator"]}}
+        overlap_before = [getattr(o.arena, "overlap", False) for o in self.opts]
         for o in self.opts:
             o.arena.overlap = False
             o.enable_device_state()
+        try:
+            self._build(warmup)
+        finally:  # the eager step (a new batch shape's warm-up, a step no graph is ready for) keeps its own setting
+            for o, ov in zip(self.opts, overlap_before):
+                o.arena.overlap = ov
+
+    def _build(self, warmup):
+        model, optimizer, scheduler = self.model, self.optimizer, self.scheduler
         # warm-up (allocator pools, lazy kernel attributes) must not train: weights, moments and counters are put back
         snaps = [o.snapshot() for o in self.opts]
         bufs = self._module_buffers()
@@ -67,14 +76,23 @@ class GraphedGanStep:
         if self.distributed:
             from kantts.train.segments import SegmentedCapture
 
+            from kantts.train.segments import all_ranks_agree
+
             self.segments = SegmentedCapture([o.arena for o in self.opts], self._cap_stream)
+            err = None
             try:
                 self.out = self.segments.capture(self._eager)
-            except Exception:
+            except Exception as exc:
+                err = exc
                 self.segments.abort()
+            # every rank captures the step or none does (a rank replaying segments beside a rank running the eager step
+            # would issue different collectives); a refusal reaches the trainer as NotImplementedError -> eager step
+            if not all_ranks_agree(err is None, self.y.device):
                 for o, s in zip(self.opts, snaps):
                     o.restore(s)
-                raise
+                self.segments = None
+                raise NotImplementedError("the data-parallel GAN step could not be captured on every rank (%s)" % (
+                    "this rank: %s: %s" % (type(err).__name__, str(err)[:200]) if err is not None else "another rank failed"))
         else:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local", stream=self._cap_stream):

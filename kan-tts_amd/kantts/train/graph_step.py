@@ -90,15 +90,23 @@ class GraphedSambertStep:
         self.skip_exchange = False  # measurement only (bench.py: exposed all-reduce time = step with - step without)
         optimizer.zero_grad(set_to_none=True)
         if self.distributed and os.environ.get("KANTTS_DP_SEGMENTS", "1") != "0":
+            import sys
+
+            from kantts.train.segments import all_ranks_agree
+
             try:
                 self._capture_segments()
             except Exception as exc:  # the two-graph form below is the proven fallback
-                import sys
-
                 print("[GraphedSambertStep] segmented data-parallel capture failed (%s: %s); capturing the two-graph form"
                       % (type(exc).__name__, str(exc)[:300]), file=sys.stderr)
                 self._abort_capture()
                 self.segments = None
+            # the two forms exchange different message sizes in a different order: one form on EVERY rank
+            if not all_ranks_agree(self.segments is not None, self.device) and self.segments is not None:
+                print("[GraphedSambertStep] another rank could not capture the segmented form; capturing the two-graph form "
+                      "here as well", file=sys.stderr)
+                self.segments = self._seg = None
+            if self.segments is None:
                 optimizer.restore(snap)
                 if rng_snap is not None:
                     _rng_state(self.device).copy_(rng_snap)

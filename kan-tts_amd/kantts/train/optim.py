@@ -156,6 +156,8 @@ class ParamArena:
         dev = self.flat.device
         self._wn_tiles = []    # 8-row tiles per table entry
         self._wn_pending = []  # (table entry, weight gradient) of this backward pass, see defer_weight_norm_backward
+        self._wn_extra = []    # the same for a layer's second, third ... application since zero_grad (accumulated)
+        self._wn_seen = set()  # table entries whose slot the table launch fills / has filled since zero_grad
         self._wn_defer = False
         self._index_of = index
         self._wn_w = torch.zeros(max(w_off, 8), device=dev, dtype=torch.float32)
@@ -196,9 +198,18 @@ class ParamArena:
         it) -- else the caller runs the per-layer kernel at once (code that reads .grad right after backward())."""
         if not self._wn_defer or self._wn_table is None:
             return False
-        if not self._wn_pending:
+        entry = int(entry)
+        if not self._wn_pending and not self._wn_extra:
             ops.wn_pending_arenas.append(self)
-        self._wn_pending.append((int(entry), dw))
+        if entry in self._wn_seen:
+            # the layer was applied more than once between zero_grad and step (the two-pass discriminator loss, gradient
+            # accumulation over several backward passes, a shared module).  The table kernel ASSIGNS a layer's slot, so a
+            # second entry for the same layer cannot ride on it: its reparametrisation backward runs per layer at the flush
+            # and is ADDED to the slot the first application filled (the caller hands autograd no gradient for this one)
+            self._wn_extra.append((entry, dw))
+            return "extra"
+        self._wn_seen.add(entry)
+        self._wn_pending.append((entry, dw))
         return True
 
     def flush_weight_norm_backward(self):
@@ -207,6 +218,7 @@ class ParamArena:
         from kantts._hip import WN_BWD_MAX, WnBwdArgs, check, lib, ptr, stream
 
         pend, self._wn_pending = self._wn_pending, []
+        extra, self._wn_extra = self._wn_extra, []
         for s0 in range(0, len(pend), WN_BWD_MAX):
             chunk = pend[s0:s0 + WN_BWD_MAX]
             a = WnBwdArgs()
@@ -218,6 +230,27 @@ class ParamArena:
             a.nl = len(chunk)
             check(lib().kantts_weight_norm_table_bwd(ptr(self.flat, torch.float32), ptr(self.grad, torch.float32),
                                                      ptr(self._wn_table), ctypes.byref(a), stream()), "weight_norm_table_bwd")
+        for entry, _ in pend:
+            # autograd was handed VIEWS of the slots the launch above has just filled.  AccumulateGrad normally adopts such a
+            # view as ``p.grad``; if it copied instead (grad mode on, another reference to the view), ``p.grad`` is a copy of
+            # the slot from BEFORE it was filled and pack_grads() would write that copy over the result: re-point it
+            for q in self._wn_params[2 * entry:2 * entry + 2]:
+                slot = self.grad_slot(q)
+                if q.grad is not None and q.grad.data_ptr() != slot.data_ptr():
+                    q.grad = slot
+        for entry, dw in extra:
+            v, g = self._wn_params[2 * entry:2 * entry + 2]
+            v3 = v.detach().squeeze(-1) if v.dim() == 4 else v.detach()
+            v3 = v3 if v3.is_contiguous() else v3.contiguous()
+            cout, cin, k = v3.shape
+            dv, dg = torch.empty_like(v3), torch.empty_like(g)
+            check(lib().kantts_weight_norm_strided_bwd(ptr(dw, torch.float32), ptr(v3), ptr(g.detach()), ptr(dv), ptr(dg), cout,
+                                                       cin, k, cin, 1, cout * cin, stream()), "weight_norm_strided_bwd")
+            for q, d in ((v, dv), (g, dg)):
+                slot = self.grad_slot(q)
+                if q.grad is not None and q.grad.data_ptr() != slot.data_ptr():
+                    q.grad = slot
+                slot.add_(d.view(slot.shape))
 
     def weight_norm_images_fresh(self):
         return self._wn_table is not None and self._wn_version == self._weights_version
@@ -234,6 +267,9 @@ class ParamArena:
         if sig != self._wn_sig:
             self._wn_sig = sig
             self._weights_version += 1
+            # the images are rebuilt at the same addresses by a raw kernel: anything cached per weight image
+            # (ops._cached_pack: block-diagonal packs of the grouped convolutions) must not outlive them
+            ops.weights_epoch[0] += 1
         if not force and self._wn_version == self._weights_version:
             return False
         from kantts._hip import check, lib, ptr, stream
@@ -400,6 +436,7 @@ class ParamArena:
         those are discarded by the next zero_grad and must not be exchanged."""
         if self._wn_table is not None and not __import__("os").environ.get("KANTTS_NO_WEIGHT_NORM_TABLE"):
             self._wn_defer = True
+            self._wn_seen.clear()
         if self._direct is not None:
             self._direct_begin()
         if not getattr(self, "overlap", False):

@@ -22,8 +22,22 @@ helper streams are forked into it (ops.fork_helper_streams explains why).
 import gc
 
 import torch
+import torch.distributed as dist
 
 from kantts._hip import ops
+
+
+def all_ranks_agree(ok, device):
+    """The data-parallel forms of a captured step issue DIFFERENT collectives (segments: the arena's param-aligned buckets in
+    completion order; two graphs: ``n_buckets`` equal chunks in ascending order), so the choice between them must be the
+    same on every rank: a capture that failed on one rank only (memory, a shape-dependent path) makes every rank fall back.
+    MIN over the ranks of this rank's success flag; a collective, so every rank must call it at the same point."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return bool(ok)
+    on_host = dist.get_backend() == "gloo"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if on_host else device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
 
 
 class SegmentedCapture:
@@ -48,6 +62,7 @@ class SegmentedCapture:
 
     def capture(self, fn):
         """Run ``fn`` (zero_grad, forward, backward, optimizer steps of the arenas) under capture; returns fn()."""
+        self._saved = [(getattr(a, "overlap", False), getattr(a, "_active", False)) for a in self.arenas]
         for a in self.arenas:
             if not getattr(a, "buckets", None):
                 a._build_buckets()
@@ -67,23 +82,28 @@ class SegmentedCapture:
                 self.segments.append((self._graph, None, None, False))
                 self._graph = None
         finally:
-            for a in self.arenas:
-                a.bucket_ready = a.capture_stream = None
-                a.overlap = False
+            self._restore_arenas()
         torch.cuda.current_stream().wait_stream(self.stream)
         want = sum(len(a.buckets) for a in self.arenas) + 1
         if len(self.segments) != want:
             raise RuntimeError("expected %d segments, captured %d" % (want, len(self.segments)))
         return out
 
+    def _restore_arenas(self):
+        """The arenas' eager-path settings as they were before the capture: an eager step after it (the warm-up of a new
+        batch shape, a step for which no graph is ready) overlaps its exchange with backward exactly as before."""
+        saved = getattr(self, "_saved", None) or [(False, False)] * len(self.arenas)
+        for a, (overlap, _) in zip(self.arenas, saved):
+            a.bucket_ready = a.capture_stream = None
+            a.overlap, a._active = overlap, False  # (armed again by the next zero_grad)
+        self._saved = None
+
     def abort(self):
         """After a failed capture: leave no stream in capture mode and no arena armed."""
         from kantts._hip import deferred_tn
 
         deferred_tn.groups, deferred_tn.copies = {}, []
-        for a in self.arenas:
-            a.bucket_ready = a.capture_stream = None
-            a.overlap, a._active = False, False
+        self._restore_arenas()
         try:
             with torch.cuda.stream(self.stream):
                 if self._graph is not None and torch.cuda.is_current_stream_capturing():

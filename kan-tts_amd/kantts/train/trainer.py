@@ -320,8 +320,9 @@ class GAN_Trainer(Trainer):
                 try:
                     g = self._graphs[key] = GraphedGanStep(self.model, self.optimizer, self.scheduler, self.criterion,
                                                            self.config, y, x, steps=self.steps)
-                except (NotImplementedError, ValueError) as exc:
-                    # NSF generators (host-seeded excitation), non-arena optimizers: the step cannot be captured.
+                except (NotImplementedError, ValueError, RuntimeError) as exc:
+                    # NSF generators (host-seeded excitation), non-arena optimizers, a capture the runtime refused (RuntimeError;
+                    # data-parallel: on any rank): the step cannot be captured.
                     # Say so once and keep training with the eager step (the run must not die thousands of steps in,
                     # when both phases first become active).
                     logging.warning("[GAN_Trainer] capture_step is off for this run: %s", exc)

@@ -72,6 +72,20 @@ def sambert_mas_batch(B=32, T_in=64, seed=1234, min_len=32, dur_hi=17, r=3, num_
     return b
 
 
+def inference_utterances(n_utt=128, seed=4321):
+    """BASELINE config 5: ``n_utt`` synthetic utterances, T_in uniform 20..80, the id distributions of
+    ``sambert_batch``.  Returns (lens, ling (n, T, 4), emo, spk) padded to the longest utterance; draw order on the generator:
+    lens, the four linguistic streams, emotion ids."""
+    g = torch.Generator().manual_seed(seed)
+    vocab = (147, 10, 8, 8)
+    lens = torch.randint(20, 81, (n_utt,), generator=g)
+    T = int(lens.max())
+    ling = torch.stack([torch.randint(0, vocab[k] - 3, (n_utt, T), generator=g) for k in range(4)], -1)
+    emo = torch.randint(0, 33, (n_utt, T), generator=g)
+    spk = torch.zeros(n_utt, T, dtype=torch.long)
+    return lens, ling, emo, spk
+
+
 def to_collate_format(b):
     """Model-argument names -> the keys of the reference's collate_fn (what the trainers consume)."""
     return {"input_lings": b["inputs_ling"], "input_emotions": b["inputs_emotion"], "input_speakers": b["inputs_speaker"],

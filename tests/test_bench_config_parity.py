@@ -52,7 +52,8 @@ def sambert_b32_oracle():
 
 # measured on MI355X this round (gpurun_out/parity_at_bench_configs.json): see DESIGN.md section 2
 _SAMBERT_BOUNDS = {
-    "fp32": dict(mel_mean=1e-5, mel_max=5e-4, loss=1e-4, grad_global=2e-3, grad_worst=2e-2),
+    # gradients rel-L2 <= 1e-4; measured 2.1e-6 (all) / 9.0e-5 (worst tensor, a postnet FSMN weight)
+    "fp32": dict(mel_mean=1e-5, mel_max=5e-4, loss=1e-4, grad_global=1e-4, grad_worst=5e-4),
     # measured on the device with this round's final kernels (profiles/r02_runL_*; gpurun_out/parity_at_bench_configs.json):
     # mel mean 1.44e-3, max 1.14e-2, loss 4.6e-5, gradient global 5.96e-3, worst tensor 0.117 (a 1-element bias)
     "bf16": dict(mel_mean=3e-3, mel_max=2.5e-2, loss=5e-4, grad_global=1.2e-2, grad_worst=0.2),

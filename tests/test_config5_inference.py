@@ -1,0 +1,61 @@
+"""BASELINE config 5 at the configuration bench.py times: the FULL SAM-BERT (8 + 12 blocks), batch-32 graph-replayed
+free-running decode of 32 of the leg's 128 utterances, in fp32 AND bf16, against the CPU oracle's free-running inference
+one utterance at a time (reference: kantts/bin/infer_sambert.py:58-227, kantts_sambert.py:569-610, adaptors.py:67-83).
+
+fp32: frame counts bit-exact, mel <= 1e-4.  bf16: the duration agreement rate is REPORTED (a 1-ulp change of
+exp(log_dur) - 1 + 0.5 flips a duration: SURVEY section 7) and the mel error is measured with the durations forced to the
+oracle's; bounds = 2x what the device measured (gpurun_out/parity_at_bench_configs.json keeps the numbers)."""
+import json
+import os
+
+import pytest
+import torch
+
+import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# bf16 bounds: the decoder's contractions read bf16 operands over up to ~90 autoregressive steps
+_BOUNDS = {"fp32": dict(frames=1.0, dur=1.0, mel_mean=1e-4, mel_max=2e-3),
+           "bf16": dict(frames=0.5, dur=0.97, mel_mean=3e-2, mel_max=1.0)}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_config5_batched_graph_decode_matches_oracle(mode):
+    import bench
+    import kantts._hip as hip
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+    from kantts.utils.synthetic import inference_utterances
+
+    cfg = O.sambert_config(tiny=False)
+    hip.set_precision(mode)
+    try:
+        torch.manual_seed(0)
+        am = KanTtsSAMBERT(dict(cfg))
+        with torch.no_grad():
+            am.variance_adaptor.duration_predictor.fc.bias.fill_(1.5)
+        am = am.cuda().eval()
+        utts = inference_utterances(128)
+        order = torch.argsort(utts[0], descending=True)
+        rep = bench.config5_parity(am, cfg, utts, order[::4][:32], batch=32, threads=min(os.cpu_count() or 1, 16))
+    finally:
+        hip.set_precision("fp32")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        path = os.path.join(ROOT, "gpurun_out", "config5_parity.json")
+        d = json.load(open(path)) if os.path.exists(path) else {}
+        d[mode] = rep
+        json.dump(d, open(path, "w"), indent=1)
+    except OSError:
+        pass
+    print(mode, rep)
+    b = _BOUNDS[mode]
+    assert rep["utterances"] == 32
+    assert rep["frame_count_agreement"] >= b["frames"], rep
+    assert rep["duration_agreement"] >= b["dur"], rep
+    assert rep["mel_mean_abs_forced_durations"] <= b["mel_mean"], rep
+    assert rep["mel_max_abs_forced_durations"] <= b["mel_max"], rep
+    if mode == "fp32":
+        assert rep["mel_mean_abs_free_running_where_durations_agree"] <= 1e-4, rep

@@ -230,6 +230,50 @@ def test_attention_long_sequence_fallback_kernels():
     assert rel_l2(gg[0], cg[0]) < 1e-4 and rel_l2(gg[1], cg[1]) < 1e-4
 
 
+@pytest.mark.parametrize("L", [300, 400])
+def test_attention_longer_than_a_workgroup_gpu(L):
+    """Device twin of tests/test_ops_sweep.py::test_attention_longer_than_a_workgroup: 257 ... 390 rows (a thread owns a second
+    query / key row, K / V still staged in LDS) and past the LDS limit (direct-from-global kernels); self-attention and both
+    PNCA bands, outputs and gradients against the oracle."""
+    import torch_oracle as O
+    from kantts._hip import ops
+
+    g = torch.Generator().manual_seed(L)
+    B, H = 2, 2
+    D = H * 16
+    lens = torch.tensor([L, L - 37])
+    l32 = lens.to(torch.int32).cuda()
+    pad = O.pad_mask(lens, L)
+    valid = (~pad)[..., None]
+    qkv = torch.randn(B, L, 3 * D, generator=g).requires_grad_(True)
+    hkv = torch.randn(B, L, 2 * D, generator=g).requires_grad_(True)
+    q, k, v = (O._split_heads(t, H) for t in qkv.chunk(3, -1))
+    ro, _ = O._attend(q, k, v, pad[:, None, :].expand(-1, L, -1).repeat(H, 1, 1))
+    ro = O._merge_heads(ro, H)
+    dq = qkv.detach().cuda().requires_grad_(True)
+    dh = hkv.detach().cuda().requires_grad_(True)
+    o, _ = ops.self_attention(dq, l32, H)
+    cot = torch.randn(B, L, D, generator=g) * valid
+    c2 = torch.randn(B, L, D, generator=g) * valid
+    assert float(((o.cpu() - ro) * valid).detach().abs().max()) < 2e-5
+    (ga,) = torch.autograd.grad(o, dq, cot.cuda())
+    (gr,) = torch.autograd.grad(ro, qkv, cot)
+    assert rel_l2(ga.cpu(), gr) < 1e-4
+    bwx, bwh = 9, 5
+    ox, oh, _, _ = ops.pnca_attention(dq, dh, l32, bwx, bwh, H)
+    xm, hm = O.pnca_masks(L, bwx, bwh, pad, qkv.device)
+    hk, hv = (O._split_heads(t, H) for t in hkv.chunk(2, -1))
+    rx, _ = O._attend(q, k, v, xm.expand(B, -1, -1).repeat(H, 1, 1))
+    rh, _ = O._attend(q, hk, hv, hm.expand(B, -1, -1).repeat(H, 1, 1))
+    rx, rh = O._merge_heads(rx, H), O._merge_heads(rh, H)
+    assert float(((ox.cpu() - rx) * valid).detach().abs().max()) < 2e-5
+    assert float(((oh.cpu() - rh) * valid).detach().abs().max()) < 2e-5
+    got = torch.autograd.grad((ox * cot.cuda()).sum() + (oh * c2.cuda()).sum(), [dq, dh])
+    exp = torch.autograd.grad((rx * cot).sum() + (rh * c2).sum(), [qkv, hkv])
+    for a, b, nm in zip(got, exp, ("dqkv", "dhkv")):
+        assert rel_l2(a.cpu(), b) < 1e-4, nm
+
+
 # ------------------------------------------------------------------------------------------- LSTM
 def test_lstm_uni_bi_and_concat():
     from kantts._hip import ops

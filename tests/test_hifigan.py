@@ -822,6 +822,55 @@ def test_weight_norm_table_backward_equals_per_layer_emulated(emulated_cabi):
     _wn_table_bwd_check("cpu")
 
 
+def _wn_table_two_applications(device):
+    """A weight-normed network applied TWICE between zero_grad and step (the reference's two-pass discriminator loss,
+    kantts/train/trainer.py:540-560; gradient accumulation over two backward passes likewise): the table launch assigns a
+    layer's gradient slot, so the second application's reparametrisation backward is added to it at the flush.  Against
+    the same two passes with the deferral off (per-layer kernels, autograd's own accumulation)."""
+    from kantts._hip import ops
+    from kantts.models.hifigan.hifigan import MultiPeriodDiscriminator
+    from kantts.train.optim import ArenaAdam, ParamArena
+
+    g = torch.Generator().manual_seed(9)
+    ya = (torch.randn(2, 1, 600, generator=g) * 0.3).to(device)
+    yb = (torch.randn(2, 1, 600, generator=g) * 0.3).to(device)
+
+    def run(defer, two_backwards):
+        torch.manual_seed(5)
+        net = MultiPeriodDiscriminator(periods=[2, 3]).to(device)
+        arena = ParamArena(net)
+        assert arena.build_weight_norm_images() >= 8
+        opt = ArenaAdam(arena, lr=1e-3)
+        opt.zero_grad()
+        arena._wn_defer = defer
+        la = sum((o ** 2).mean() for o in net(ya)[0])
+        if two_backwards:
+            la.backward()
+            ops.wgrad_overlap.join()
+            sum(((o - 1) ** 2).mean() for o in net(yb)[0]).backward()
+        else:
+            (la + sum(((o - 1) ** 2).mean() for o in net(yb)[0])).backward()
+        ops.wgrad_overlap.join()  # flushes the deferred reparametrisation backward
+        assert not arena._wn_pending and not arena._wn_extra
+        return arena.pack_grads().clone(), (len(arena._wn_seen) if defer else 0)
+
+    for two in (False, True):
+        ref, _ = run(False, two)
+        got, seen = run(True, two)
+        assert seen >= 8
+        assert float(ref.abs().max()) > 0
+        assert rel_l2(got, ref) <= 1e-5, two
+
+
+def test_weight_norm_table_backward_with_a_layer_applied_twice_emulated(emulated_cabi):
+    _wn_table_two_applications("cpu")
+
+
+@pytest.mark.gpu
+def test_weight_norm_table_backward_with_a_layer_applied_twice_gpu():
+    _wn_table_two_applications("cuda")
+
+
 @pytest.mark.gpu
 def test_weight_norm_table_backward_equals_per_layer_gpu():
     _wn_table_bwd_check("cuda")

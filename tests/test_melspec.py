@@ -152,6 +152,42 @@ def test_register_resident_fft_form_gpu():
     _register_form_cases("cuda")
 
 
+@pytest.mark.gpu
+def test_register_form_walks_several_pairs_of_frames_per_wave_gpu():
+    """Device twin of the kernel-source case: the persistent-grid loop of melspec_reg_kernel (several pairs of frames per
+    wave) is bit-identical to the one-pair-per-wave launch."""
+    _several_pairs_per_wave_case("cuda")
+
+
+@pytest.mark.gpu
+def test_register_form_with_a_filterbank_beyond_its_chunk_table_gpu():
+    _wide_filterbank_case("cuda")
+
+
+@pytest.mark.gpu
+def test_saturating_launch_values_gpu():
+    """The 67 584-frame launch bench.py quotes as `roofline_saturating` (2048 x 8192 samples: every wave of the persistent
+    grid walks many pairs) compared by VALUE with the radix-2 kernel on the same input, and a sample of its rows with the
+    float64 oracle."""
+    import audio_oracle as A
+    from kantts.utils.audio_torch import MelSpectrogram
+
+    g = torch.Generator().manual_seed(11)
+    ms = MelSpectrogram().cuda()
+    x = (torch.randn(2048, 8192, generator=g) * 0.1).cuda()
+    a = ms(x[:, None, :])
+    assert a.shape == (2048, 80, 33)
+    os.environ["KANTTS_MEL_GENERIC"] = "1"
+    try:
+        b = ms(x[:, None, :])
+    finally:
+        os.environ.pop("KANTTS_MEL_GENERIC", None)
+    assert float((a - b).abs().max()) < 5e-5
+    rows = [0, 1, 777, 1024, 2047]
+    ref = A.mel_spectrogram(x[rows].cpu())
+    assert_close(a[rows].cpu(), ref.float(), 1e-4, what="67 584-frame launch vs the float64 oracle (sampled rows)")
+
+
 def _layouts_agree(device):
     """The C ABI in both mel layouts: kantts_melspec_fwd / _norm_fwd / _bwd (channel-major, the reference's
     (B, n_mels, frames)) against kantts_melspec_norm_fwd_fm / kantts_melspec_bwd_fm (frame-major, what the host layer uses
