@@ -970,7 +970,7 @@ def main():
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(so.getsockname()[1])
-        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", KANTTS_DP_FORCE="1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     device_index = 0 if args.share_device else local_rank
     torch.cuda.set_device(device_index)

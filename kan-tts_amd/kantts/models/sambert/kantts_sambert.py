@@ -245,7 +245,11 @@ class VarianceAdaptor(nn.Module):
         (reference positions.py:83-90).  Depends on the durations alone."""
         idx, pos, cs, LR_length_rounded, Tp, max_len = plan[:6]
         t = torch.arange(Tp, device=pos.device)[None, :]
-        limit = torch.full_like(LR_length_rounded, max_len) if out_info is None else out_info.lens64.clamp(max=max_len)
+        # no output masks = free-running inference, which the reference runs one utterance at a time: a frame past a sequence's
+        # own regulated length is then r-padding (position 0), also when a longer sequence of the batch makes it a frame
+        # < max_len -- the frames of a sequence's LAST decoder step (length % r != 0) would otherwise differ between batched
+        # and per-utterance inference (tests/test_config5_inference.py)
+        limit = (LR_length_rounded if out_info is None else out_info.lens64).clamp(max=max_len)
         pos = torch.where(t < limit[:, None], pos, torch.zeros_like(pos))
         return self.dur_position_encoder.from_positions(pos)
 

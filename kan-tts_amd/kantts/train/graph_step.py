@@ -53,7 +53,7 @@ class GraphedSambertStep:
         self.batch = {k: v.clone() for k, v in batch.items()}
         self.device = next(net.parameters()).device
         net.device_band_width = True
-        self.distributed = optimizer.arena.world_size > 1
+        self.distributed = optimizer.arena.world_size > 1 or getattr(optimizer.arena, "force_exchange", False)
         # collectives are not captured: the exchange sits between the two graph halves (bucketed, asynchronous), so
         # the hook-driven overlap of the eager path is switched off for this optimizer
         optimizer.arena.overlap = False

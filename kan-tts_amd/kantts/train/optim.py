@@ -43,6 +43,7 @@ class ParamArena:
         self.grad_views = [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
         self._zero_cache = {}
         self.world_size = 1
+        self.force_exchange = False
         self.bucket_ready = None  # set while a data-parallel step is being captured in segments (train/graph_step.py)
         self.capture_stream = None
         self.n_buckets = 4
@@ -392,7 +393,10 @@ class ParamArena:
         dist.broadcast(self.flat, src=0)
         self.shadow_stale = True
         self.refresh_shadow(only_if_bf16=True)
-        self.overlap = bool(overlap) and self.world_size > 1
+        # KANTTS_DP_FORCE=1 (bench.py --rccl-world1): a world of ONE rank still runs the whole exchange path -- buckets,
+        # hooks, graph segments, the collective itself -- so that a one-GPU box executes RCCL where the step does
+        self.force_exchange = bool(__import__("os").environ.get("KANTTS_DP_FORCE")) and self.world_size == 1
+        self.overlap = bool(overlap) and (self.world_size > 1 or self.force_exchange)
         if self.overlap:
             self._build_buckets()
 
@@ -548,7 +552,7 @@ class ParamArena:
     def all_reduce_grads(self):
         """Average the (already packed) gradient arena over the data-parallel group: ``n_buckets`` large asynchronous
         all-reduces (the non-overlapped form: between the two halves of a captured training step)."""
-        if self.world_size <= 1:
+        if self.world_size <= 1 and not getattr(self, "force_exchange", False):
             return
         n = self.numel
         step = (n + self.n_buckets - 1) // self.n_buckets

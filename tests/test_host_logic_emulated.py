@@ -494,3 +494,25 @@ def test_relu_gate_of_a_hidden_gradient_in_its_producers_epilogue(emulated_cabi,
             (out.sum() + h.float().sum()).backward()
     finally:
         hip.set_precision("fp32")
+
+
+def test_batched_free_running_inference_equals_per_utterance_inference(emulated_cabi):
+    """bench.config5_parity on the tiny model through the emulated ABI: length-sorted batches of free-running inference
+    against the oracle one utterance at a time.  Sequences whose regulated length is not a multiple of r have r-padding
+    frames INSIDE the batch's frame range: their duration-position term must be the padding's (position 0), as in
+    per-utterance inference (found at the full configuration on the device: tests/test_config5_inference.py)."""
+    import bench
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+    from kantts.utils.synthetic import inference_utterances
+
+    cfg = O.sambert_config(tiny=True)
+    torch.manual_seed(0)
+    am = KanTtsSAMBERT(dict(cfg))
+    with torch.no_grad():  # ~4 frames per symbol (random-init weights predict the bias): lengths 4 * T_in, mostly not
+        am.variance_adaptor.duration_predictor.fc.bias.fill_(1.6)  # multiples of r = 3
+    am = am.eval()
+    utts = inference_utterances(12, seed=99)
+    rep = bench.config5_parity(am, cfg, utts, torch.arange(12), batch=4, threads=4)
+    assert rep["frame_count_agreement"] == 1.0 and rep["duration_agreement"] == 1.0, rep
+    assert rep["mel_max_abs_forced_durations"] <= 2e-5, rep
+    assert rep["mel_mean_abs_free_running_where_durations_agree"] <= 1e-5, rep
