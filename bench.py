@@ -1097,7 +1097,13 @@ def main():
         try:
             def fwd_only():
                 hip.ops.advance_rng(dev)
-                res = net(**batch)
+                # the band width of this (static) batch, as the captured training step knows it (train/graph_step.py): the
+                # decoder blocks take the same form in both graphs
+                net.band_width_bound = getattr(step, "_bound", None)
+                try:
+                    res = net(**batch)
+                finally:
+                    net.band_width_bound = None
                 return sambert_loss_sum(mel_crit, pros_crit, batch, res)[0]
 
             hip.ops.wgrad_overlap.enable(True)

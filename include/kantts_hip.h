@@ -705,6 +705,99 @@ typedef struct kantts_ffn_args {
 } kantts_ffn_args;
 int kantts_ffn_pair(const kantts_ffn_args* args, void* stream);
 
+/* [round 5] One PNCA decoder block forward as ONE launch (csrc/pnca_block.hip; reference
+ * kantts/models/sambert/__init__.py:212-348 with the feed-forward of :134-149; band masks kantts_sambert.py:135-166):
+ *   [q|k|v] = xn Wqkv^T + bqkv;  ox / oh = x-band / memory-band attention (csrc/attn.hip conventions, 8 heads x 16);
+ *   y1 = rowmask(dropout_fc(ox Wfcx^T + oh Wfch^T + bfcx + bfch) + x);  xn1 = LN1(y1);
+ *   hid = rowmask(dropout_1(relu(xn1 W1^T + b1)));  out = rowmask(dropout_2(hid W2^T + b2) + y1);  ln2_out = LN2(out).
+ * x (M, 128) fp32 block input and xn (M, 128) bf16 its LayerNorm (M = B * L rows); hkv: this block's memory K | V rows,
+ * fp32, row pitch ldh >= 256 floats; wqkv (384 x 128), wfcx / wfch (128 x 128), w1 (1024 x 128), w2 (128 x 1024):
+ * fragment-major bf16 images (kantts_fragmajor_bf16).  Written for the backward pass (each optional unless noted): qkv
+ * (M, 384) fp32, ox / oh (M, 128) fp32 (required), lse_x / lse_h (B, 8, L) (required), y1 fp32, xn1 bf16 + mean1 / rstd1,
+ * hid (M, 1024) bf16; out (M, 128) fp32 (required); ln2_* as the ln_* fields of kantts_ffn_args.  Dropout seeds are offset
+ * by *seed_dev; indices are those of the separate launches (kantts_pnca_attn_fwd, kantts_bgemm_nt, kantts_ffn_pair), so the
+ * fused launch and the chain draw the same masks.  bw_dev (device scalar) overrides bw_x / bw_h.  Band widths above 16 are
+ * not supported: KANTTS_E_UNSUPPORTED when known on the host, NaN outputs when only the device knows. */
+typedef struct kantts_pnca_block_args {
+  const float* x;
+  const void* xn;
+  const float* hkv;
+  int64_t ldh;
+  int32_t B, L, H, C, F;
+  const int32_t* lens;
+  const int32_t* bw_dev;
+  int32_t bw_x, bw_h;
+  const uint8_t* rowmask;
+  const void* wqkv;
+  const float* bqkv;
+  const void* wfcx;
+  const void* wfch;
+  const float* bfcx;
+  const float* bfch;
+  const float* ln1_gamma;
+  const float* ln1_beta;
+  float ln1_eps;
+  const void* w1;
+  const void* w2;
+  const float* bias1;
+  const float* bias2;
+  float att_p, fc_p, drop1_p, drop2_p;
+  uint64_t seed_x, seed_h, fc_seed, drop1_seed, drop2_seed;
+  const uint64_t* seed_dev;
+  float* qkv;
+  float* ox;
+  float* oh;
+  float* lse_x;
+  float* lse_h;
+  float* y1;
+  void* xn1;
+  float* mean1;
+  float* rstd1;
+  void* hid;
+  float* out;
+  const float* ln2_gamma;
+  const float* ln2_beta;
+  void* ln2_out;
+  int32_t ln2_out_bf16;
+  float ln2_eps;
+  float* ln2_mean;
+  float* ln2_rstd;
+} kantts_pnca_block_args;
+int kantts_pnca_block_fwd(const kantts_pnca_block_args* args, void* stream);
+
+/* [round 5] The row-local half of a PNCA block's backward as one launch (csrc/pnca_block.hip): kantts_ffn_pair (backward
+ * form) + kantts_ln128_bwd_rows + the two input-gradient launches of the output projection, same arithmetic
+ * (kantts/models/sambert/__init__.py:134-149, 286-306 differentiated):
+ *   dz = gate_{hid > 0}(dropout_2(dy) W2) * alpha1 (bf16, (M, 1024); the weight gradient of W1 reads it);
+ *   dh = dz W1 (rounded to bf16);  g1 = rowmask(LN1'(dh; y1, mean1, rstd1, gamma1) + dy) (fp32 (M, 128));
+ *   d_ox = dropout_fc(g1) Wfcx, d_oh = dropout_fc(g1) Wfch (fp32 (M, 128)); dgamma1 / dbeta1 (128) are ACCUMULATED.
+ * dy: gradient of the block output (rows of rowmask are read as zero).  wt2 = W2^T (1024 x 128), wt1 = W1^T (128 x 1024),
+ * wfcxT / wfchT = Wfcx^T / Wfch^T (128 x 128): fragment-major bf16 images.  Dropout indices as in the forward launches. */
+typedef struct kantts_pnca_block_bwd_args {
+  const float* dy;
+  const void* hid;
+  const float* y1;
+  const float* mean1;
+  const float* rstd1;
+  const float* ln1_gamma;
+  const uint8_t* rowmask;
+  int32_t M, C, F;
+  const void* wt2;
+  const void* wt1;
+  const void* wfcxT;
+  const void* wfchT;
+  float alpha1, drop2_p, fc_p;
+  uint64_t drop2_seed, fc_seed;
+  const uint64_t* seed_dev;
+  void* dz;
+  float* g1;
+  float* d_ox;
+  float* d_oh;
+  float* dgamma1;
+  float* dbeta1;
+} kantts_pnca_block_bwd_args;
+int kantts_pnca_block_bwd(const kantts_pnca_block_bwd_args* args, void* stream);
+
 /* Fragment-major bf16 images of weight matrices, a table of them in one launch (the parameter arena's per-step refresh).
  * Entry: the (R, K) matrix with element (r, k) = src[src_off + r*sr + k*sk] (fp32; any orientation of the master weight)
  * is written to dst + dst_off so that every 16 x 32 block (r/16, k/32) is 1 KB in the order one A-operand load of

@@ -1,0 +1,899 @@
+// One PNCA decoder block FORWARD as ONE launch (round 5).
+//
+// reference: kantts/models/sambert/__init__.py:212-348 (MultiHeadPNCAAttention.forward + PNCABlock.forward) with the
+// position-wise feed-forward of :134-149 -- per block and training step
+//   xn = LN(x);  [q | k | v] = xn W_qkv^T + b;  ox = band_x(q, k, v);  oh = band_h(q, hk, hv)
+//   y1 = rowmask(dropout(ox W_fcx^T + oh W_fch^T + b_x + b_h) + x)
+//   out = rowmask(dropout(W_2 rowmask(dropout(relu(W_1 LN(y1) + b_1))) + b_2) + y1)   (+ LN of the NEXT sub-layer's input)
+// where the band masks of kantts_sambert.py:135-166 confine query i of a sequence to the keys [i - bw, i] of the decoder
+// stream and [i, i + bw] of the memory stream (bw = x_band_width = h_band_width, ~5 at the benchmark batch).
+//
+// Until round 4 this chain was five launches (QKV contraction, both attention bands, the output contraction with the
+// next LayerNorm in its epilogue, the feed-forward pair) over M = B * L = 6528 rows of 128 channels: 3.3 MB of block input,
+// every launch a 5-20 us kernel whose working set sits in L2, i.e. five dependent launch latencies per block and sixty per
+// decoder forward (profiles/r04_runH: exactly one kernel on the chip for 69 % of the step).  The band structure makes the
+// whole block TILE-LOCAL: a workgroup that owns 32 consecutive rows needs, beyond its own rows, only
+//   * the normalised rows of the PB_HX = 16 rows in front of the tile (their K / V are recomputed: 2/3 of a 16 x 384 x 128
+//     contraction, 6 % of the block's work) and
+//   * the memory K / V rows of the tile and of the PB_HH = 16 rows behind it (projected once for all twelve blocks by one
+//     GEMM, kantts_sambert.py: HybridAttentionDecoder.forward).
+// So: one workgroup of 8 waves carries its 32 rows through the whole block; q / k / v, the attention context, the
+// sub-layer output y1, its LayerNorm and the 32 x 1024 hidden tile live in LDS / registers; weights are the MFMA *A*
+// operand streamed from L2 in the fragment-major images of csrc/ffn_pair.hip (every weight element is used by exactly one
+// wave of the workgroup).  What backward needs is still written -- qkv, both contexts, the log-sum-exps, y1 with its
+// normalised rows and statistics, the hidden tile -- but nothing is read back, so those stores are off the critical path.
+// Band widths above 16 are not handled here (the caller keeps the five-launch chain for them); a device-resident band
+// width above 16 poisons the outputs with NaN rather than computing something else silently.
+//
+// Numerics: the same arithmetic as the chain (bf16 MFMA operands, fp32 accumulation, fp32 attention with the chain's key
+// order, the same counter-based dropout indices), so the fused launch and the chain agree to fp32 summation order.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define PB_THREADS 512
+#define PB_BM 32
+#define PB_HX 16                  // rows in front of the tile whose K / V are recomputed (x band)
+#define PB_HH 16                  // memory rows behind the tile (h band)
+#define PB_C 128                  // model width = H * 16
+#define PB_F 1024
+#define PB_XP (PB_C + 16)         // bf16 row pitch of the normalised-row tiles: 288 B = 32 mod 64
+#define PB_CP (2 * PB_C + 16)     // bf16 row pitch of the [ox | oh] context tile: 544 B = 32 mod 64
+#define PB_TP (PB_F + 16)         // bf16 row pitch of the hidden tile
+#define PB_QP (PB_C + 4)          // fp32 row pitch of the Q tile: neighbouring rows 4 banks apart
+#define PB_KP (2 * PB_C + 4)      // fp32 row pitch of the K | V tiles
+#define PB_DH 16
+
+#define PB_A_BYTES (PB_BM * PB_CP * 2)                                     // 17 408: Xq (48 x 288 B) / Cs / Xs
+#define PB_T_BYTES ((PB_BM * PB_QP + (PB_BM + PB_HX) * PB_KP) * 4)         // 66 816: Q + K|V tiles, later the hidden tile
+#define PB_H_BYTES ((PB_BM + PB_HH) * PB_KP * 4)                           // 49 920: memory K|V rows
+
+static_assert((PB_BM + PB_HX) * PB_XP * 2 <= PB_A_BYTES, "Xq tile");
+static_assert(PB_BM * PB_TP * 2 <= PB_T_BYTES, "hidden tile");
+
+__device__ __forceinline__ unsigned pb_pack2(float a, float b) {
+  bf16x4 t = {(__bf16)a, (__bf16)b, (__bf16)0.f, (__bf16)0.f};
+  return ((u32x2&)t).x;
+}
+
+__device__ __forceinline__ void pb_lds16(const float* p, float* r) {
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float4 t = p4[e];
+    r[4 * e + 0] = t.x;
+    r[4 * e + 1] = t.y;
+    r[4 * e + 2] = t.z;
+    r[4 * e + 3] = t.w;
+  }
+}
+__device__ __forceinline__ float pb_dot16(const float* a, const float* b) {
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < PB_DH; ++d) s = fmaf(a[d], b[d], s);
+  return s;
+}
+__device__ __forceinline__ float pb_dot16l(const float* a, const float* lrow) {
+  float b[PB_DH];
+  pb_lds16(lrow, b);
+  return pb_dot16(a, b);
+}
+
+__global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts_pnca_block_args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[PB_A_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char Tr[PB_T_BYTES];
+  __shared__ __attribute__((aligned(16))) float Hs[(PB_BM + PB_HH) * PB_KP];
+  __shared__ __attribute__((aligned(16))) float B1s[PB_F];
+  __shared__ __attribute__((aligned(16))) float St[512];
+  __bf16* Xq = reinterpret_cast<__bf16*>(As);   // (48, PB_XP): normalised rows m0 - 16 .. m0 + 31
+  __bf16* Cs = reinterpret_cast<__bf16*>(As);   // (32, PB_CP): [ox | oh] of the tile, bf16
+  __bf16* Xs = reinterpret_cast<__bf16*>(As);   // (32, PB_XP): LayerNorm(y1) of the tile
+  float* Qs = reinterpret_cast<float*>(Tr);                              // (32, PB_QP)
+  float* KVs = reinterpret_cast<float*>(Tr) + PB_BM * PB_QP;             // (48, PB_KP): [k | v] of rows m0 - 16 .. m0 + 31
+  __bf16* Ts = reinterpret_cast<__bf16*>(Tr);                            // (32, PB_TP): hidden tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
+  const int M = g.B * g.L, L = g.L;
+  const int m0 = blockIdx.x * PB_BM;
+  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
+  const __bf16* __restrict__ wq = reinterpret_cast<const __bf16*>(g.wqkv);
+  const __bf16* __restrict__ wfx = reinterpret_cast<const __bf16*>(g.wfcx);
+  const __bf16* __restrict__ wfh = reinterpret_cast<const __bf16*>(g.wfch);
+  const __bf16* __restrict__ w1 = reinterpret_cast<const __bf16*>(g.w1);
+  const __bf16* __restrict__ w2 = reinterpret_cast<const __bf16*>(g.w2);
+  const float* dummy = reinterpret_cast<const float*>(g.wqkv);  // any mapped, 16-byte aligned address
+  const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ------------------------------------------------------------------------------------------------ global loads, in the
+  // order they are consumed (the vector-memory counter retires in order): normalised rows, memory rows, QKV weights
+  u32x4 xq[2];
+  {
+    const __bf16* xn = reinterpret_cast<const __bf16*>(g.xn);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {  // 48 rows x 16 chunks of 16 B: 1.5 per thread (clamped source, masked below)
+      const int id = min(tid + PB_THREADS * it, (PB_BM + PB_HX) * 16 - 1);
+      const long long src = max(0ll, min((long long)m0 - PB_HX + (id >> 4), (long long)M - 1));
+      xq[it] = *reinterpret_cast<const u32x4*>(xn + src * PB_C + (id & 15) * 8);
+    }
+  }
+  float4 hreg[6];  // memory K | V rows m0 .. m0 + 47 (clamped to M - 1): 48 x 64 chunks of 16 B
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int id = tid + PB_THREADS * it;
+    const long long row = min((long long)m0 + (id >> 6), (long long)M - 1);
+    hreg[it] = *reinterpret_cast<const float4*>(g.hkv + row * g.ldh + (id & 63) * 4);
+  }
+  float4 b1reg = zero4;  // bias of the feed-forward's first contraction -> LDS (threads 0..255)
+  if (tid < PB_F / 4 && g.bias1) b1reg = *reinterpret_cast<const float4*>(g.bias1 + tid * 4);
+  u32x4 wqf[3][4];  // wave: output row blocks 3 wave + a (16 channels each) x 4 reduction blocks of 32
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      wqf[a][kk] = *reinterpret_cast<const u32x4*>(wq + ((long long)((wave * 3 + a) * 4 + kk)) * 512 + lane * 8);
+  // this lane's slice of the residual stream and of the epilogue vectors: tokens b * 16 + li, channels n0 .. n0 + 3
+  const int nq = wave & 3, kh = wave >> 2;
+  const int n0 = nq * 32 + kh * 16 + kg * 4;
+  float4 xres[2];
+  bool rz[2], live[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const long long m = min((long long)m0 + b * 16 + li, (long long)M - 1);
+    live[b] = m0 + b * 16 + li < M;
+    xres[b] = *reinterpret_cast<const float4*>(g.x + m * PB_C + n0);
+    const uint8_t q = *(g.rowmask ? g.rowmask + m : reinterpret_cast<const uint8_t*>(dummy));
+    rz[b] = g.rowmask && q != 0;
+  }
+  float4 bfc = *reinterpret_cast<const float4*>(g.bfcx ? g.bfcx + n0 : dummy);
+  if (!g.bfcx) bfc = zero4;
+  {
+    float4 t = *reinterpret_cast<const float4*>(g.bfch ? g.bfch + n0 : dummy);
+    if (!g.bfch) t = zero4;
+    bfc.x += t.x; bfc.y += t.y; bfc.z += t.z; bfc.w += t.w;
+  }
+  // the staged operands go to LDS before the first contraction (their registers are then free for it)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = tid + PB_THREADS * it;
+    if (id < (PB_BM + PB_HX) * 16) {
+      const long long src = (long long)m0 - PB_HX + (id >> 4);
+      const u32x4 v = (src >= 0 && src < M) ? xq[it] : (u32x4){0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(&Xq[(id >> 4) * PB_XP + (id & 15) * 8]) = v;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int id = tid + PB_THREADS * it;
+    *reinterpret_cast<float4*>(&Hs[(id >> 6) * PB_KP + (id & 63) * 4]) = hreg[it];
+  }
+  if (tid < PB_F / 4) *reinterpret_cast<float4*>(&B1s[tid * 4]) = b1reg;
+  __syncthreads();  // Xq, memory rows complete
+
+  // ------------------------------------------------------------------------------------------------ [q | k | v] of 48 rows
+  {
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) acc[a][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 bf[3];
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&Xq[(tb * 16 + li) * PB_XP + kk * 32 + kg * 8]);
+        bf[tb] = (bf16x8&)v;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb)
+          acc[a][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wqf[a][kk], bf[tb], acc[a][tb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int c0 = (wave * 3 + a) * 16 + kg * 4;  // 4 consecutive output channels of [q | k | v]
+      float4 bq = *reinterpret_cast<const float4*>(g.bqkv ? g.bqkv + c0 : dummy);
+      if (!g.bqkv) bq = zero4;
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+        const int j = tb * 16 + li;  // tile row: global row m0 - 16 + j
+        const f32x4 v = {acc[a][tb][0] + bq.x, acc[a][tb][1] + bq.y, acc[a][tb][2] + bq.z, acc[a][tb][3] + bq.w};
+        if (c0 < PB_C) {
+          if (tb > 0) *reinterpret_cast<f32x4*>(&Qs[(j - PB_HX) * PB_QP + c0]) = v;
+        } else {
+          *reinterpret_cast<f32x4*>(&KVs[j * PB_KP + (c0 - PB_C)]) = v;
+        }
+        const long long m = (long long)m0 - PB_HX + j;
+        if (tb > 0 && m < M && g.qkv) *reinterpret_cast<f32x4*>(g.qkv + m * (3 * PB_C) + c0) = v;
+      }
+    }
+  }
+  // weights of the output contraction (row block nq * 2 + kh; reduction blocks 0..3 over ox = fc_x, 4..7 over oh = fc_h) and
+  // the first LayerNorm's vectors: requested now, consumed after the attention phase
+  const float4 l1g = *reinterpret_cast<const float4*>(g.ln1_gamma + n0), l1b = *reinterpret_cast<const float4*>(g.ln1_beta + n0);
+  u32x4 wff[8];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    wff[kk] = *reinterpret_cast<const u32x4*>(wfx + ((long long)((nq * 2 + kh) * 4 + kk)) * 512 + lane * 8);
+    wff[4 + kk] = *reinterpret_cast<const u32x4*>(wfh + ((long long)((nq * 2 + kh) * 4 + kk)) * 512 + lane * 8);
+  }
+  // the feed-forward weight stream starts now: two units of phase 1 in flight across the attention phase (four would not
+  // fit the register file beside the attention's working set), the other two are requested right after it
+  //   phase 1, step s (chunk of 256 hidden units): rows s*256 + wave*32 + {0, 16}, 4 k-blocks of 32 each
+  //   phase 2, unit u: rows (wave & 3)*32 + {0, 16}, k-blocks (wave >> 2)*16 + u*4 + {0..3}
+  u32x4 ring[4][8];
+  auto load1 = [&](u32x4* w, int s) {
+    const __bf16* p = w1 + ((long long)(s * 16 + wave * 2) * 4) * 512 + lane * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(p + j * 512);
+  };
+  auto load2 = [&](u32x4* w, int u) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const __bf16* p = w2 + ((long long)(nq * 2 + a) * (PB_F >> 5) + kh * 16 + u * 4) * 512 + lane * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) w[a * 4 + kk] = *reinterpret_cast<const u32x4*>(p + kk * 512);
+    }
+  };
+  load1(ring[0], 0);
+  load1(ring[1], 1);
+  __syncthreads();  // Q, K | V and the memory rows are in LDS; Xq is dead
+
+  // ------------------------------------------------------------------------------------------------ both attention bands
+  // thread <-> (band, head, row): 16 consecutive lanes are 16 rows of one head (row pitch = 4 banks: conflict-free)
+  {
+    const int band = tid >> 8, head = (tid >> 5) & 7, row = tid & 31;
+    const long long m = (long long)m0 + row;
+    const bool valid = m < M;
+    const int b = valid ? (int)(m / L) : 0, i = valid ? (int)(m - (long long)b * L) : 0;
+    const int len = g.lens ? g.lens[b] : L;
+    const int bw = g.bw_dev ? *g.bw_dev : (band ? g.bw_h : g.bw_x);
+    int lo, hi;
+    if (!valid || i >= len) {  // padded query rows are skipped (csrc/attn.hip header): context 0
+      lo = 0;
+      hi = -1;
+    } else if (band == 0) {
+      lo = max(0, i - bw);
+      hi = i;
+    } else {
+      lo = i;
+      hi = min(min(i + bw, L - 1), len - 1);
+    }
+    // key j of the sequence <-> tile row: x band KVs[row + 16 - (i - j)], memory band Hs[row + (j - i)]
+    const float* ktile = (band ? Hs : KVs) + head * PB_DH;
+    const int r0 = band ? row - i : row + PB_HX - i;  // tile row of key j is r0 + j
+    float q[PB_DH], o[PB_DH];
+    pb_lds16(&Qs[row * PB_QP + head * PB_DH], q);
+#pragma unroll
+    for (int d = 0; d < PB_DH; ++d) o[d] = 0.f;
+    float mx = -INFINITY;
+    for (int j = lo; j <= hi; ++j) mx = fmaxf(mx, pb_dot16l(q, ktile + (r0 + j) * PB_KP) * 0.25f);
+    float l = 0.f;
+    const uint64_t rng_row = (((uint64_t)head * g.B + b) * L + i) * (uint64_t)L;
+    KanttsDropSeq drop(g.att_p, (band ? g.seed_h : g.seed_x) + seed_off);
+    for (int j = lo; j <= hi; ++j) {
+      const float e = expf(pb_dot16l(q, ktile + (r0 + j) * PB_KP) * 0.25f - mx);
+      l += e;
+      const float ed = e * drop.scale(rng_row + j);
+      float vv[PB_DH];
+      pb_lds16(ktile + (r0 + j) * PB_KP + PB_C, vv);
+#pragma unroll
+      for (int d = 0; d < PB_DH; ++d) o[d] = fmaf(ed, vv[d], o[d]);
+    }
+    const float inv = (hi >= lo) ? 1.f / l : 0.f;
+#pragma unroll
+    for (int d = 0; d < PB_DH; ++d) o[d] *= inv;
+    if (bw > PB_HX) {  // a band this launch cannot hold: never a silently different result
+#pragma unroll
+      for (int d = 0; d < PB_DH; ++d) o[d] = __builtin_nanf("");
+    }
+    if (valid) {
+      float* od = (band ? g.oh : g.ox) + m * PB_C + head * PB_DH;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<float4*>(od + 4 * e) = make_float4(o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]);
+      (band ? g.lse_h : g.lse_x)[((long long)b * (PB_C / PB_DH) + head) * L + i] = (hi >= lo) ? (mx + logf(l)) : 0.f;
+    }
+    u32x4 p0 = {pb_pack2(o[0], o[1]), pb_pack2(o[2], o[3]), pb_pack2(o[4], o[5]), pb_pack2(o[6], o[7])};
+    u32x4 p1 = {pb_pack2(o[8], o[9]), pb_pack2(o[10], o[11]), pb_pack2(o[12], o[13]), pb_pack2(o[14], o[15])};
+    *reinterpret_cast<u32x4*>(&Cs[row * PB_CP + band * PB_C + head * PB_DH]) = p0;
+    *reinterpret_cast<u32x4*>(&Cs[row * PB_CP + band * PB_C + head * PB_DH + 8]) = p1;
+  }
+  load1(ring[2], 2);
+  load1(ring[3], 3);
+  float4 bs2 = *reinterpret_cast<const float4*>(g.bias2 ? g.bias2 + n0 : dummy);
+  if (!g.bias2) bs2 = zero4;
+  const bool ln2 = g.ln2_out != nullptr;
+  const float4 l2g = *reinterpret_cast<const float4*>(ln2 ? g.ln2_gamma + n0 : dummy);
+  const float4 l2b = *reinterpret_cast<const float4*>(ln2 ? g.ln2_beta + n0 : dummy);
+  __syncthreads();  // context tile complete; Q / K / V / memory rows are dead
+
+  // ------------------------------------------------------------------------------------------------ y1 = fc_x(ox) + fc_h(oh)
+  float y1v[2][4];
+  {
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&Cs[(b * 16 + li) * PB_CP + kk * 32 + kg * 8]);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wff[kk], (const bf16x8&)v, acc[b], 0, 0, 0);
+      }
+    }
+    const uint64_t sdf = g.fc_seed + seed_off;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const long long m = (long long)m0 + b * 16 + li;
+      float* o = y1v[b];
+      o[0] = acc[b][0] + bfc.x; o[1] = acc[b][1] + bfc.y; o[2] = acc[b][2] + bfc.z; o[3] = acc[b][3] + bfc.w;
+      if (g.fc_p > 0.f) kantts_dropout_scale4(g.fc_p, sdf, (uint64_t)m * (uint64_t)PB_C + (uint64_t)n0, o);
+      o[0] += xres[b].x; o[1] += xres[b].y; o[2] += xres[b].z; o[3] += xres[b].w;
+      if (rz[b]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = 0.f;
+      }
+      if (live[b] && g.y1) *reinterpret_cast<f32x4*>(g.y1 + m * PB_C + n0) = (f32x4){o[0], o[1], o[2], o[3]};
+    }
+  }
+  // LayerNorm(128) of a token: its channels sit in 4 lanes (kg) of each of the 8 waves -> two-pass statistics through LDS
+  auto layer_norm_rows = [&](const auto& v, float (&mu)[2], float (&rs)[2], float eps) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float ps[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = pass ? v[b][r] - mu[b] : v[b][r];
+          t += pass ? d * d : d;
+        }
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        ps[b] = t;
+      }
+      if (kg == 0) {
+        St[pass * 256 + (wave * 2 + 0) * 16 + li] = ps[0];
+        St[pass * 256 + (wave * 2 + 1) * 16 + li] = ps[1];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += St[pass * 256 + (w * 2 + b) * 16 + li];
+        if (pass)
+          rs[b] = 1.0f / sqrtf(t * (1.f / 128.f) + eps);
+        else
+          mu[b] = t * (1.f / 128.f);
+      }
+    }
+  };
+  {
+    float mu[2], rs[2];
+    layer_norm_rows(y1v, mu, rs, g.ln1_eps);  // (its barriers also retire every wave's reads of the context tile)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const long long m = (long long)m0 + b * 16 + li;
+      const float* o = y1v[b];
+      const float z0 = (o[0] - mu[b]) * rs[b] * l1g.x + l1b.x, z1 = (o[1] - mu[b]) * rs[b] * l1g.y + l1b.y;
+      const float z2 = (o[2] - mu[b]) * rs[b] * l1g.z + l1b.z, z3 = (o[3] - mu[b]) * rs[b] * l1g.w + l1b.w;
+      const u32x2 pk = {pb_pack2(z0, z1), pb_pack2(z2, z3)};
+      *reinterpret_cast<u32x2*>(&Xs[(b * 16 + li) * PB_XP + n0]) = pk;
+      if (!live[b]) continue;
+      if (g.xn1) *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.xn1) + m * PB_C + n0) = pk;
+      if (wave == 0 && kg == 0 && g.mean1) {
+        g.mean1[m] = mu[b];
+        g.rstd1[m] = rs[b];
+      }
+    }
+  }
+  __syncthreads();  // normalised rows of the tile complete
+
+  // ------------------------------------------------------------------------------------------------ feed-forward, phase 1
+  // (csrc/ffn_pair.hip: T^T[f][tok] = W1[f][:] . X[tok][:], f in chunks of 256; no workgroup barrier inside the phase)
+  const int crow = lane >> 2, ccol = (lane & 3) * 8;
+  {
+    f32x4 acc[2][2];
+    const uint64_t sd1 = g.drop1_seed + seed_off;
+    auto mfma1 = [&](const u32x4* w, int c) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 bf[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[(b * 16 + li) * PB_XP + kk * 32 + kg * 8]);
+          bf[b] = (bf16x8&)v;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)w[a * 4 + kk], bf[b], acc[a][b], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int f0 = c * 256 + wave * 32 + a * 16 + kg * 4;
+        const float4 bs = *reinterpret_cast<const float4*>(&B1s[f0]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int tok = b * 16 + li;
+          const long long m = (long long)m0 + tok;
+          float o[4] = {acc[a][b][0] + bs.x, acc[a][b][1] + bs.y, acc[a][b][2] + bs.z, acc[a][b][3] + bs.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+          if (g.drop1_p > 0.f) kantts_dropout_scale4(g.drop1_p, sd1, (uint64_t)m * (uint64_t)PB_F + (uint64_t)f0, o);
+          if (rz[b]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = 0.f;
+          }
+          const u32x2 pk = {pb_pack2(o[0], o[1]), pb_pack2(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(&Ts[tok * PB_TP + f0]) = pk;
+        }
+      }
+      // the wave's own 32 columns of the hidden tile -> HBM (a wave's LDS operations execute in order: no barrier)
+      KANTTS_WAVE_ORDERED();
+      if (g.hid) {
+        __bf16* tp = reinterpret_cast<__bf16*>(g.hid);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int i = crow + 16 * it;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(&Ts[i * PB_TP + c * 256 + wave * 32 + ccol]);
+          if (m0 + i < M) *reinterpret_cast<u32x4*>(tp + ((long long)m0 + i) * PB_F + c * 256 + wave * 32 + ccol) = v;
+        }
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // PB_F / 256 = 4 steps; the tail pulls in the four units of phase 2
+      mfma1(ring[j], j);
+      load2(ring[j], j);
+    }
+  }
+  __syncthreads();  // hidden tile complete
+
+  // ------------------------------------------------------------------------------------------------ feed-forward, phase 2
+  float ov[2][4];
+  {
+    f32x4 acc2[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 bf[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(&Ts[(b * 16 + li) * PB_TP + (kh * 16 + u * 4 + kk) * 32 + kg * 8]);
+          bf[b] = (bf16x8&)v;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)ring[u][a * 4 + kk], bf[b], acc2[a][b], 0, 0, 0);
+      }
+    }
+    // the two halves of the reduction meet through LDS (the hidden tile is dead): wave (nq, kh) finishes row block a = kh
+    __syncthreads();
+    float* Ex = reinterpret_cast<float*>(Tr);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const f32x4 snd = kh ? acc2[0][b] : acc2[1][b];
+      *reinterpret_cast<f32x4*>(&Ex[(((nq * 2 + (kh ^ 1)) * 2 + b) * 64 + lane) * 4]) = snd;
+    }
+    __syncthreads();
+    const uint64_t sd2 = g.drop2_seed + seed_off;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&Ex[(((nq * 2 + kh) * 2 + b) * 64 + lane) * 4]);
+      const f32x4 s = (kh ? acc2[1][b] : acc2[0][b]) + v;
+      const long long m = (long long)m0 + b * 16 + li;
+      float* o = ov[b];
+      o[0] = s[0] + bs2.x; o[1] = s[1] + bs2.y; o[2] = s[2] + bs2.z; o[3] = s[3] + bs2.w;
+      if (g.drop2_p > 0.f) kantts_dropout_scale4(g.drop2_p, sd2, (uint64_t)m * (uint64_t)PB_C + (uint64_t)n0, o);
+      o[0] += y1v[b][0]; o[1] += y1v[b][1]; o[2] += y1v[b][2]; o[3] += y1v[b][3];
+      if (rz[b]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = 0.f;
+      }
+      if (live[b]) *reinterpret_cast<f32x4*>(g.out + m * PB_C + n0) = (f32x4){o[0], o[1], o[2], o[3]};
+    }
+  }
+  if (ln2) {  // LayerNorm of the sub-layer that consumes the block's output (the next block's attention, or the stack's)
+    float mu[2], rs[2];
+    layer_norm_rows(ov, mu, rs, g.ln2_eps);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const long long m = (long long)m0 + b * 16 + li;
+      if (!live[b]) continue;
+      const float* o = ov[b];
+      const float z0 = (o[0] - mu[b]) * rs[b] * l2g.x + l2b.x, z1 = (o[1] - mu[b]) * rs[b] * l2g.y + l2b.y;
+      const float z2 = (o[2] - mu[b]) * rs[b] * l2g.z + l2b.z, z3 = (o[3] - mu[b]) * rs[b] * l2g.w + l2b.w;
+      if (g.ln2_out_bf16) {
+        const u32x2 pk = {pb_pack2(z0, z1), pb_pack2(z2, z3)};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.ln2_out) + m * PB_C + n0) = pk;
+      } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.ln2_out) + m * PB_C + n0) = (f32x4){z0, z1, z2, z3};
+      }
+      if (wave == 0 && kg == 0) {
+        g.ln2_mean[m] = mu[b];
+        g.ln2_rstd[m] = rs[b];
+      }
+    }
+  }
+}
+
+// ================================================================================================================
+// The ROW-LOCAL half of the block's BACKWARD as one launch: from the gradient of the block output down to the gradients of
+// the two attention contexts --
+//   dz  = gate_{hid > 0}(dropout_2(dy) W_2) / (1 - p_1)          (feed-forward, hidden pre-activation; kept for dW_1)
+//   dh  = dz W_1                                                  (gradient of the normalised rows LN1(y1), bf16 like them)
+//   g1  = rowmask(LN1'(dh; y1) + dy)                              (gradient of y1: LayerNorm backward + residual branch)
+//   [d_ox | d_oh] = dropout_fc(g1) [W_fcx | W_fch]               (input gradient of the output projection)
+// -- i.e. kantts_ffn_pair (backward form) + kantts_ln128_bwd_rows + two kantts_bgemm_nt launches of the chain
+// (ops_bf16._FusedFFNB / _LayerNorm128 / _FusedLinearB .backward), with the same arithmetic: bf16 MFMA operands, dh rounded to
+// bf16 before the LayerNorm backward, fp32 everywhere else.  dgamma / dbeta of LN1 leave as 256 atomics per workgroup.
+// What crosses rows -- the attention backward, whose key gradients collect queries from neighbouring tiles -- stays a
+// launch of its own (csrc/attn.hip), followed by the QKV input gradient with the first LayerNorm's backward in its
+// epilogue (csrc/gemm_bf16.hip): a block's backward is 3 launches instead of 7.
+__global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts_pnca_block_bwd_args g) {
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[PB_BM * PB_XP];   // dropout_2(dy) tile, later dropout_fc(g1)
+  __shared__ __attribute__((aligned(16))) __bf16 Ts[PB_BM * PB_TP];   // gate tile -> dz tile
+  __shared__ __attribute__((aligned(16))) float St[512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
+  const int M = g.M;
+  const int m0 = blockIdx.x * PB_BM;
+  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
+  const __bf16* __restrict__ wt2 = reinterpret_cast<const __bf16*>(g.wt2);  // W2^T (F x 128)
+  const __bf16* __restrict__ wt1 = reinterpret_cast<const __bf16*>(g.wt1);  // W1^T (128 x F)
+  const __bf16* __restrict__ wxt = reinterpret_cast<const __bf16*>(g.wfcxT);
+  const __bf16* __restrict__ wht = reinterpret_cast<const __bf16*>(g.wfchT);
+  const float* dummy = reinterpret_cast<const float*>(g.wt2);
+  const int nq = wave & 3, kh = wave >> 2;
+  const int n0 = nq * 32 + kh * 16 + kg * 4;
+
+  u32x4 ring[4][8];
+  auto load1 = [&](u32x4* w, int s) {  // rows s*256 + wave*32 + {0, 16} of W2^T, 4 k-blocks
+    const __bf16* p = wt2 + ((long long)(s * 16 + wave * 2) * 4) * 512 + lane * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(p + j * 512);
+  };
+  auto load2 = [&](u32x4* w, int u) {  // rows nq*32 + {0, 16} of W1^T, k-blocks kh*16 + u*4 + {0..3}
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const __bf16* p = wt1 + ((long long)(nq * 2 + a) * (PB_F >> 5) + kh * 16 + u * 4) * 512 + lane * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) w[a * 4 + kk] = *reinterpret_cast<const u32x4*>(p + kk * 512);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load1(ring[j], j);
+
+  // ---- dy tile -> dropout_2 -> bf16 (masked rows and rows past M are zero)
+  {
+    const int j = tid >> 4, ch = tid & 15;
+    const long long src = (long long)m0 + j;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (src < M && !(g.rowmask && g.rowmask[src])) {
+      const float* p = g.dy + src * PB_C + ch * 8;
+      float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+      if (g.drop2_p > 0.f) {
+        const uint64_t base = (uint64_t)src * (uint64_t)PB_C + (uint64_t)(ch * 8);
+        const uint64_t sd = g.drop2_seed + seed_off;
+        float lo4[4] = {a.x, a.y, a.z, a.w}, hi4[4] = {b.x, b.y, b.z, b.w};
+        kantts_dropout_scale4(g.drop2_p, sd, base, lo4);
+        kantts_dropout_scale4(g.drop2_p, sd, base + 4, hi4);
+        a = make_float4(lo4[0], lo4[1], lo4[2], lo4[3]);
+        b = make_float4(hi4[0], hi4[1], hi4[2], hi4[3]);
+      }
+      v.x = pb_pack2(a.x, a.y);
+      v.y = pb_pack2(a.z, a.w);
+      v.z = pb_pack2(b.x, b.y);
+      v.w = pb_pack2(b.z, b.w);
+    }
+    *reinterpret_cast<u32x4*>(&Xs[j * PB_XP + ch * 8]) = v;
+  }
+  // ---- gate (the saved hidden activation) into the cells the gradient tile will overwrite
+  {
+    const __bf16* gp = reinterpret_cast<const __bf16*>(g.hid);
+    u32x4 gq[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int id = tid + PB_THREADS * it;
+      const long long row = min((long long)m0 + (id >> 7), (long long)M - 1);
+      gq[it] = *reinterpret_cast<const u32x4*>(gp + row * PB_F + (id & 127) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int id = tid + PB_THREADS * it;
+      *reinterpret_cast<u32x4*>(&Ts[(id >> 7) * PB_TP + (id & 127) * 8]) = gq[it];
+    }
+  }
+  // what the LayerNorm backward needs from memory, requested before the weight stream is consumed
+  float4 y1r[2], dyr[2];
+  float mu[2], rs[2];
+  bool rz[2], live[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const long long m = min((long long)m0 + b * 16 + li, (long long)M - 1);
+    live[b] = m0 + b * 16 + li < M;
+    y1r[b] = *reinterpret_cast<const float4*>(g.y1 + m * PB_C + n0);
+    dyr[b] = *reinterpret_cast<const float4*>(g.dy + m * PB_C + n0);
+    mu[b] = g.mean1[m];
+    rs[b] = g.rstd1[m];
+    const uint8_t q = *(g.rowmask ? g.rowmask + m : reinterpret_cast<const uint8_t*>(dummy));
+    rz[b] = g.rowmask && q != 0;
+  }
+  const float4 gm = *reinterpret_cast<const float4*>(g.ln1_gamma + n0);
+  __syncthreads();  // dy tile and gate tile complete
+
+  // ---- phase 1: dz^T[f][tok] = W2^T[f][:] . dy_d[tok][:], gated by the saved activation
+  const int crow = lane >> 2, ccol = (lane & 3) * 8;
+  {
+    f32x4 acc[2][2];
+    auto mfma1 = [&](const u32x4* w, int c) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 bf[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[(b * 16 + li) * PB_XP + kk * 32 + kg * 8]);
+          bf[b] = (bf16x8&)v;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)w[a * 4 + kk], bf[b], acc[a][b], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int f0 = c * 256 + wave * 32 + a * 16 + kg * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int tok = b * 16 + li;
+          const u32x2 q = *reinterpret_cast<const u32x2*>(&Ts[tok * PB_TP + f0]);
+          const float gv[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                               __uint_as_float(q.y & 0xffff0000u)};
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (gv[r] > 0.f) ? acc[a][b][r] * g.alpha1 : 0.f;
+          const u32x2 pk = {pb_pack2(o[0], o[1]), pb_pack2(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(&Ts[tok * PB_TP + f0]) = pk;
+        }
+      }
+      KANTTS_WAVE_ORDERED();
+      __bf16* tp = reinterpret_cast<__bf16*>(g.dz);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int i = crow + 16 * it;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&Ts[i * PB_TP + c * 256 + wave * 32 + ccol]);
+        if (m0 + i < M) *reinterpret_cast<u32x4*>(tp + ((long long)m0 + i) * PB_F + c * 256 + wave * 32 + ccol) = v;
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mfma1(ring[j], j);
+      load2(ring[j], j);
+    }
+  }
+  __syncthreads();  // dz tile complete
+
+  // ---- phase 2: dh^T[n][tok] = W1^T[n][:] . dz[tok][:]
+  float dh[2][4];
+  {
+    f32x4 acc2[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 bf[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(&Ts[(b * 16 + li) * PB_TP + (kh * 16 + u * 4 + kk) * 32 + kg * 8]);
+          bf[b] = (bf16x8&)v;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)ring[u][a * 4 + kk], bf[b], acc2[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // every wave is done with the dz tile: its cells carry the exchange of the two reduction halves
+    float* Ex = reinterpret_cast<float*>(Ts);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const f32x4 snd = kh ? acc2[0][b] : acc2[1][b];
+      *reinterpret_cast<f32x4*>(&Ex[(((nq * 2 + (kh ^ 1)) * 2 + b) * 64 + lane) * 4]) = snd;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&Ex[(((nq * 2 + kh) * 2 + b) * 64 + lane) * 4]);
+      const f32x4 s = (kh ? acc2[1][b] : acc2[0][b]) + v;
+      // the chain stores dh in the dtype of the normalised rows (bf16) and the LayerNorm backward reads that
+      const unsigned p01 = pb_pack2(s[0], s[1]), p23 = pb_pack2(s[2], s[3]);
+      dh[b][0] = __uint_as_float(p01 << 16); dh[b][1] = __uint_as_float(p01 & 0xffff0000u);
+      dh[b][2] = __uint_as_float(p23 << 16); dh[b][3] = __uint_as_float(p23 & 0xffff0000u);
+      if (!live[b]) dh[b][0] = dh[b][1] = dh[b][2] = dh[b][3] = 0.f;
+    }
+  }
+  // weights of the output projection's input gradient: rows 32 wave + {0, 16} of [W_fcx^T ; W_fch^T] (256 x 128)
+  u32x4 wcf[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int rb = wave * 2 + a;  // row block of the 256 context channels: 0..7 = fc_x, 8..15 = fc_h
+    const __bf16* p = (rb < 8 ? wxt : wht) + ((long long)((rb & 7) * 4)) * 512 + lane * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wcf[a][kk] = *reinterpret_cast<const u32x4*>(p + kk * 512);
+  }
+
+  // ---- LayerNorm backward of LN1 at y1 (csrc/norm.hip: ln128_bwd_kernel) + residual branch + row mask
+  float g1v[2][4];
+  {
+    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+    float xh[2][4], gg[2][4], pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    float ps1[2], ps2[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float xv[4] = {y1r[b].x, y1r[b].y, y1r[b].z, y1r[b].w};
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xh[b][r] = (xv[r] - mu[b]) * rs[b];
+        gg[b][r] = dh[b][r] * gmv[r];
+        s1 += gg[b][r];
+        s2 += gg[b][r] * xh[b][r];
+        pg[r] += dh[b][r] * xh[b][r];
+        pb[r] += dh[b][r];
+      }
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      ps1[b] = s1;
+      ps2[b] = s2;
+    }
+    if (kg == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        St[(wave * 2 + b) * 16 + li] = ps1[b];
+        St[256 + (wave * 2 + b) * 16 + li] = ps2[b];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        s1 += St[(w * 2 + b) * 16 + li];
+        s2 += St[256 + (w * 2 + b) * 16 + li];
+      }
+      s1 *= (1.f / 128.f);
+      s2 *= (1.f / 128.f);
+      const float dres[4] = {dyr[b].x, dyr[b].y, dyr[b].z, dyr[b].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float o = rs[b] * (gg[b][r] - s1 - xh[b][r] * s2) + dres[r];
+        if (rz[b]) o = 0.f;
+        g1v[b][r] = o;
+      }
+      const long long m = (long long)m0 + b * 16 + li;
+      if (live[b]) *reinterpret_cast<f32x4*>(g.g1 + m * PB_C + n0) = (f32x4){g1v[b][0], g1v[b][1], g1v[b][2], g1v[b][3]};
+      // dropout_fc(g1) -> bf16 tile (the dy tile is dead: every wave passed the barrier after phase 1)
+      float o[4] = {g1v[b][0], g1v[b][1], g1v[b][2], g1v[b][3]};
+      if (g.fc_p > 0.f) kantts_dropout_scale4(g.fc_p, g.fc_seed + seed_off, (uint64_t)m * (uint64_t)PB_C + (uint64_t)n0, o);
+      if (!live[b]) o[0] = o[1] = o[2] = o[3] = 0.f;
+      const u32x2 pk = {pb_pack2(o[0], o[1]), pb_pack2(o[2], o[3])};
+      *reinterpret_cast<u32x2*>(&Xs[(b * 16 + li) * PB_XP + n0]) = pk;
+    }
+    // dgamma / dbeta of LN1: sum over the tile's 32 tokens (16 lanes x 2), one atomic per channel and workgroup
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        pg[r] += __shfl_xor(pg[r], off, 64);
+        pb[r] += __shfl_xor(pb[r], off, 64);
+      }
+    }
+    if (li == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        atomicAdd(g.dgamma1 + n0 + r, pg[r]);
+        atomicAdd(g.dbeta1 + n0 + r, pb[r]);
+      }
+    }
+  }
+  __syncthreads();  // dropout_fc(g1) tile complete
+
+  // ---- [d_ox | d_oh]^T[c][tok] = [W_fcx^T ; W_fch^T][c][:] . g1_d[tok][:]
+  {
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 bf[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[(b * 16 + li) * PB_XP + kk * 32 + kg * 8]);
+        bf[b] = (bf16x8&)v;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wcf[a][kk], bf[b], acc[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int c0 = (wave * 2 + a) * 16 + kg * 4;  // context channel: [0, 128) = ox, [128, 256) = oh
+      float* dst = c0 < PB_C ? g.d_ox + c0 : g.d_oh + (c0 - PB_C);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const long long m = (long long)m0 + b * 16 + li;
+        if (m < M) *reinterpret_cast<f32x4*>(dst + m * PB_C) = acc[a][b];
+      }
+    }
+  }
+}
+
+static bool pb_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int kantts_pnca_block_fwd(const kantts_pnca_block_args* gp, void* stream) {
+  if (!gp) return KANTTS_E_BADARG;
+  const kantts_pnca_block_args& g = *gp;
+  if (!g.x || !g.xn || !g.hkv || !g.wqkv || !g.wfcx || !g.wfch || !g.w1 || !g.w2 || !g.ln1_gamma || !g.ln1_beta || !g.ox ||
+      !g.oh || !g.lse_x || !g.lse_h || !g.out || g.B < 0 || g.L < 0)
+    return KANTTS_E_BADARG;
+  if (g.H != PB_C / PB_DH || g.C != PB_C || g.F != PB_F) return KANTTS_E_UNSUPPORTED;
+  if (g.ldh < 2 * PB_C || (g.ldh & 3)) return KANTTS_E_UNSUPPORTED;
+  if (!g.bw_dev && (g.bw_x > PB_HX || g.bw_h > PB_HH || g.bw_x < 0 || g.bw_h < 0)) return KANTTS_E_UNSUPPORTED;
+  if (g.ln2_out && (!g.ln2_gamma || !g.ln2_beta || !g.ln2_mean || !g.ln2_rstd)) return KANTTS_E_BADARG;
+  if ((g.mean1 == nullptr) != (g.rstd1 == nullptr)) return KANTTS_E_BADARG;
+  const void* al[] = {g.x, g.xn, g.hkv, g.wqkv, g.bqkv, g.wfcx, g.wfch, g.bfcx, g.bfch, g.ln1_gamma, g.ln1_beta, g.w1, g.w2,
+                      g.bias1, g.bias2, g.ln2_gamma, g.ln2_beta, g.qkv, g.ox, g.oh, g.y1, g.xn1, g.hid, g.out, g.ln2_out};
+  for (const void* p : al)
+    if (p && !pb_aligned16(p)) return KANTTS_E_UNSUPPORTED;
+  const long long M = (long long)g.B * g.L;
+  if (M == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(pnca_block_fwd_kernel, dim3(kantts_cdiv(M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_pnca_block_bwd(const kantts_pnca_block_bwd_args* gp, void* stream) {
+  if (!gp) return KANTTS_E_BADARG;
+  const kantts_pnca_block_bwd_args& g = *gp;
+  if (!g.dy || !g.hid || !g.y1 || !g.mean1 || !g.rstd1 || !g.ln1_gamma || !g.wt2 || !g.wt1 || !g.wfcxT || !g.wfchT || !g.dz ||
+      !g.g1 || !g.d_ox || !g.d_oh || !g.dgamma1 || !g.dbeta1 || g.M < 0)
+    return KANTTS_E_BADARG;
+  if (g.C != PB_C || g.F != PB_F) return KANTTS_E_UNSUPPORTED;
+  const void* al[] = {g.dy, g.hid, g.y1, g.ln1_gamma, g.wt2, g.wt1, g.wfcxT, g.wfchT, g.dz, g.g1, g.d_ox, g.d_oh};
+  for (const void* p : al)
+    if (!pb_aligned16(p)) return KANTTS_E_UNSUPPORTED;
+  if (g.M == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(pnca_block_bwd_kernel, dim3(kantts_cdiv(g.M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -214,6 +214,37 @@ class FfnArgs(Structure):
     ]
 
 
+class PncaBlockArgs(Structure):
+    """kantts_pnca_block_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("xn", c_void_p), ("hkv", c_void_p), ("ldh", c_int64),
+        ("B", c_int32), ("L", c_int32), ("H", c_int32), ("C", c_int32), ("F", c_int32),
+        ("lens", c_void_p), ("bw_dev", c_void_p), ("bw_x", c_int32), ("bw_h", c_int32), ("rowmask", c_void_p),
+        ("wqkv", c_void_p), ("bqkv", c_void_p), ("wfcx", c_void_p), ("wfch", c_void_p), ("bfcx", c_void_p), ("bfch", c_void_p),
+        ("ln1_gamma", c_void_p), ("ln1_beta", c_void_p), ("ln1_eps", c_float),
+        ("w1", c_void_p), ("w2", c_void_p), ("bias1", c_void_p), ("bias2", c_void_p),
+        ("att_p", c_float), ("fc_p", c_float), ("drop1_p", c_float), ("drop2_p", c_float),
+        ("seed_x", c_uint64), ("seed_h", c_uint64), ("fc_seed", c_uint64), ("drop1_seed", c_uint64), ("drop2_seed", c_uint64),
+        ("seed_dev", c_void_p),
+        ("qkv", c_void_p), ("ox", c_void_p), ("oh", c_void_p), ("lse_x", c_void_p), ("lse_h", c_void_p), ("y1", c_void_p),
+        ("xn1", c_void_p), ("mean1", c_void_p), ("rstd1", c_void_p), ("hid", c_void_p), ("out", c_void_p),
+        ("ln2_gamma", c_void_p), ("ln2_beta", c_void_p), ("ln2_out", c_void_p), ("ln2_out_bf16", c_int32), ("ln2_eps", c_float),
+        ("ln2_mean", c_void_p), ("ln2_rstd", c_void_p),
+    ]
+
+
+class PncaBlockBwdArgs(Structure):
+    """kantts_pnca_block_bwd_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("dy", c_void_p), ("hid", c_void_p), ("y1", c_void_p), ("mean1", c_void_p), ("rstd1", c_void_p), ("ln1_gamma", c_void_p),
+        ("rowmask", c_void_p), ("M", c_int32), ("C", c_int32), ("F", c_int32),
+        ("wt2", c_void_p), ("wt1", c_void_p), ("wfcxT", c_void_p), ("wfchT", c_void_p),
+        ("alpha1", c_float), ("drop2_p", c_float), ("fc_p", c_float), ("drop2_seed", c_uint64), ("fc_seed", c_uint64),
+        ("seed_dev", c_void_p),
+        ("dz", c_void_p), ("g1", c_void_p), ("d_ox", c_void_p), ("d_oh", c_void_p), ("dgamma1", c_void_p), ("dbeta1", c_void_p),
+    ]
+
+
 class FragMajorDesc(Structure):
     """kantts_fragmajor_desc (include/kantts_hip.h)."""
     _fields_ = [("src_off", c_int64), ("dst_off", c_int64), ("sr", c_int64), ("sk", c_int64), ("R", c_int32),
@@ -293,6 +324,8 @@ def lib():
         L.kantts_stft_mag_bwd.argtypes = [p, p, i, i, i, i, i, i, p, p, f, p, p]
         L.kantts_bgemm_nt.argtypes = [POINTER(BGemmArgs), c_void_p]
         L.kantts_ffn_pair.argtypes = [POINTER(FfnArgs), c_void_p]
+        L.kantts_pnca_block_fwd.argtypes = [POINTER(PncaBlockArgs), c_void_p]
+        L.kantts_pnca_block_bwd.argtypes = [POINTER(PncaBlockBwdArgs), c_void_p]
         L.kantts_fragmajor_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
         L.kantts_bgemm_tn.argtypes = [POINTER(BGemmTnArgs), c_void_p]
         L.kantts_bgemm_tn_grouped.argtypes = [POINTER(BGemmTnArgs), c_int, p, p, p, p, p, c_void_p]
@@ -339,6 +372,7 @@ EXPORTED_SYMBOLS = [
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
+    "kantts_pnca_block_fwd", "kantts_pnca_block_bwd",
 ]
 
 
@@ -612,6 +646,62 @@ def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu
         e1.record()
         _profile.append((e0, e1, 2.0 * M * F * (x.shape[-1] * KT + NY * KT2)))
     return True
+
+
+def pnca_block_fwd(x, xn, hkv, ldh, B, L, *, lens, bw_dev, bw_x, bw_h, rowmask, wqkv, bqkv, wfcx, wfch, bfcx, bfch, ln1, w1, w2,
+                   bias1, bias2, att_p, fc_p, drop1_p, drop2_p, seeds, qkv, ox, oh, lse_x, lse_h, y1, xn1, mean1, rstd1, hid, out,
+                   ln2=None):
+    """One PNCA decoder block forward in one launch (csrc/pnca_block.hip; kantts_pnca_block_fwd in the header).  x (M, 128)
+    fp32, xn its LayerNorm (bf16), hkv: (M, >= 256) fp32 rows at pitch ``ldh``; w*: fragment-major bf16 images;
+    ln1 = (gamma, beta, eps) of the feed-forward's LayerNorm; ln2 = (gamma, beta, eps, out, mean, rstd) of the consumer's (or
+    None); seeds = (x band, memory band, output dropout, hidden dropout, feed-forward output dropout).  Returns False when
+    the library declines (band width above 16)."""
+    g = PncaBlockArgs()
+    g.x, g.xn, g.hkv, g.ldh = ptr(x, torch.float32), ptr(xn, torch.bfloat16), ptr(hkv, torch.float32), int(ldh)
+    g.B, g.L, g.H, g.C, g.F = int(B), int(L), 8, 128, 1024
+    g.lens, g.bw_dev, g.bw_x, g.bw_h, g.rowmask = ptr(lens), ptr(bw_dev), int(bw_x), int(bw_h), ptr(rowmask)
+    g.wqkv, g.bqkv = ptr(wqkv, torch.bfloat16), ptr(bqkv, torch.float32)
+    g.wfcx, g.wfch = ptr(wfcx, torch.bfloat16), ptr(wfch, torch.bfloat16)
+    g.bfcx, g.bfch = ptr(bfcx, torch.float32), ptr(bfch, torch.float32)
+    g.ln1_gamma, g.ln1_beta, g.ln1_eps = ptr(ln1[0], torch.float32), ptr(ln1[1], torch.float32), float(ln1[2])
+    g.w1, g.w2 = ptr(w1, torch.bfloat16), ptr(w2, torch.bfloat16)
+    g.bias1, g.bias2 = ptr(bias1, torch.float32), ptr(bias2, torch.float32)
+    g.att_p, g.fc_p, g.drop1_p, g.drop2_p = float(att_p), float(fc_p), float(drop1_p), float(drop2_p)
+    g.seed_x, g.seed_h, g.fc_seed, g.drop1_seed, g.drop2_seed = (int(v) for v in seeds)
+    g.seed_dev = rng_ptr(x.device) if (att_p > 0 or fc_p > 0 or drop1_p > 0 or drop2_p > 0) else None
+    g.qkv, g.ox, g.oh = ptr(qkv, torch.float32), ptr(ox, torch.float32), ptr(oh, torch.float32)
+    g.lse_x, g.lse_h, g.y1 = ptr(lse_x, torch.float32), ptr(lse_h, torch.float32), ptr(y1, torch.float32)
+    g.xn1, g.mean1, g.rstd1 = ptr(xn1, torch.bfloat16), ptr(mean1, torch.float32), ptr(rstd1, torch.float32)
+    g.hid, g.out = ptr(hid, torch.bfloat16), ptr(out, torch.float32)
+    if ln2 is not None:
+        gamma, beta, eps, ln_out, ln_mean, ln_rstd = ln2
+        g.ln2_gamma, g.ln2_beta, g.ln2_eps = ptr(gamma, torch.float32), ptr(beta, torch.float32), float(eps)
+        g.ln2_out, g.ln2_out_bf16 = ptr(ln_out), int(ln_out.dtype == torch.bfloat16)
+        g.ln2_mean, g.ln2_rstd = ptr(ln_mean, torch.float32), ptr(ln_rstd, torch.float32)
+    rc = lib().kantts_pnca_block_fwd(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "pnca_block_fwd")
+    return True
+
+
+def pnca_block_bwd(dy, hid, y1, mean1, rstd1, gamma1, rowmask, wt2, wt1, wfcxT, wfchT, *, alpha1, drop2_p, drop2_seed, fc_p,
+                   fc_seed, dz, g1, d_ox, d_oh, dgamma1, dbeta1):
+    """The row-local half of a PNCA block's backward in one launch (csrc/pnca_block.hip; kantts_pnca_block_bwd in the
+    header): feed-forward pair backward, LayerNorm backward + residual, input gradient of the output projection."""
+    g = PncaBlockBwdArgs()
+    g.dy, g.hid, g.y1 = ptr(dy, torch.float32), ptr(hid, torch.bfloat16), ptr(y1, torch.float32)
+    g.mean1, g.rstd1, g.ln1_gamma = ptr(mean1, torch.float32), ptr(rstd1, torch.float32), ptr(gamma1, torch.float32)
+    g.rowmask, g.M, g.C, g.F = ptr(rowmask), int(dy.shape[0]), 128, 1024
+    g.wt2, g.wt1 = ptr(wt2, torch.bfloat16), ptr(wt1, torch.bfloat16)
+    g.wfcxT, g.wfchT = ptr(wfcxT, torch.bfloat16), ptr(wfchT, torch.bfloat16)
+    g.alpha1, g.drop2_p, g.fc_p = float(alpha1), float(drop2_p), float(fc_p)
+    g.drop2_seed, g.fc_seed = int(drop2_seed), int(fc_seed)
+    g.seed_dev = rng_ptr(dy.device) if (drop2_p > 0 or fc_p > 0) else None
+    g.dz, g.g1 = ptr(dz, torch.bfloat16), ptr(g1, torch.float32)
+    g.d_ox, g.d_oh = ptr(d_ox, torch.float32), ptr(d_oh, torch.float32)
+    g.dgamma1, g.dbeta1 = ptr(dgamma1, torch.float32), ptr(dbeta1, torch.float32)
+    check(lib().kantts_pnca_block_bwd(ctypes.byref(g), stream()), "pnca_block_bwd")
 
 
 TN_MAX_GROUP = 16

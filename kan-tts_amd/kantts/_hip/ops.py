@@ -592,6 +592,16 @@ def linear(xs, weights, bias=None, *, mode=None, bias2=None, res=None, rowmask=N
     return ops_bf16._attach_token(_FusedLinear.apply(opts, bias, bias2, res, rowmask, *xs, *weights), token)
 
 
+def pnca_block_fused(blk, x, hkv, info, bw_x, bw_h, bw_dev, return_attn, next_ln, training):
+    """bf16 mode on a HIP device: ops_bf16.pnca_block_fused (one launch for the block's forward pass); otherwise a no-op
+    context (the fp32 parity path keeps its launches)."""
+    import contextlib
+
+    if get_precision() != "bf16":
+        return contextlib.nullcontext()
+    return ops_bf16.pnca_block_fused(blk, x, hkv, info, bw_x, bw_h, bw_dev, return_attn, next_ln, training)
+
+
 def shared_input_linears(x, linears):
     """``[lin(x) for lin in linears]`` for nn.Linear holders that all read the same tensor.  bf16 mode with gradients
     enabled: forward as usual, but ONE input-gradient launch for all of them (ops_bf16._SharedInputLinearsB)."""
@@ -812,6 +822,16 @@ class _PncaAttention(torch.autograd.Function):
         ldh = hkv.stride(1)
         q2 = qkv.view(B * L, W)
         h2 = hkv.as_strided((B * L, 2 * D), (ldh, 1), hkv.storage_offset())
+        ad = ops_bf16.ADOPT.take("attn") if ops_bf16.ADOPT.q else None
+        if ad is not None:
+            # both bands were computed by the fused block launch (ops_bf16.pnca_block_fused): adopt contexts, log-sum-exps and
+            # the seeds it drew; backward is the usual one
+            assert not want_probs
+            sx, sh = ad["sx"], ad["sh"]
+            ox, oh, lsex, lseh = ad["ox"], ad["oh"], ad["lse_x"], ad["lse_h"]
+            ctx.save_for_backward(q2, h2, ox, oh, lsex, lseh, lens, bw_dev)
+            ctx.cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)
+            return ox.view(B, L, D), oh.view(B, L, D), None, None
         sx = next_seed() if drop_p > 0 else 0
         sh = next_seed() if drop_p > 0 else 0
         ctx.save_cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)

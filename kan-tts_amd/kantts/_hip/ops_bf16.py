@@ -9,13 +9,14 @@ them.  The residual stream, attention inputs / outputs, losses and every paramet
 Gradient dtypes follow autograd's rule (gradient dtype == forward tensor dtype): a bf16 activation receives a bf16
 gradient; those tensors have exactly one consumer, so nothing is ever accumulated in bf16.
 """
+import contextlib
 import math
 import os
 import weakref
 
 import torch
 
-from . import bgemm_nt, bgemm_tn, check, ffn_pair, lib, ptr, stream
+from . import bgemm_nt, bgemm_tn, check, ffn_pair, lib, pnca_block_bwd, pnca_block_fwd, ptr, stream
 
 BF16 = torch.bfloat16
 _wcache = {}
@@ -160,12 +161,12 @@ class PreNorm:
     the normalised rows + row statistics on the output tensor (``y._kantts_prenorm``), and ``layer_norm128`` called with
     that very module's parameters adopts them instead of launching kantts_ln128_fwd.  Backward is the usual
     kantts_ln128_bwd_rows on the saved statistics."""
-    __slots__ = ("gamma", "beta", "eps", "out_bf16", "xn", "mean", "rstd")
+    __slots__ = ("gamma", "beta", "eps", "out_bf16", "xn", "mean", "rstd", "bwd")
 
     def __init__(self, ln):
         self.gamma, self.beta, self.eps = ln.weight, ln.bias, float(ln.eps)
         self.out_bf16 = bool(getattr(ln, "_kantts_out_bf16", True))
-        self.xn = self.mean = self.rstd = None
+        self.xn = self.mean = self.rstd = self.bwd = None
 
     def matches(self, gamma, beta, eps, out_bf16):
         return (self.xn is not None and self.gamma is gamma and self.beta is beta and self.eps == float(eps)
@@ -241,6 +242,205 @@ def take_rowmask(x):
     return token.mask
 
 
+# ================================================================================================
+# One PNCA decoder block forward in ONE launch (csrc/pnca_block.hip)
+# ================================================================================================
+# A/B switch: KANTTS_NO_PNCA_BLOCK=1 keeps the five-launch chain of a decoder block's forward pass
+PNCA_BLOCK = {"on": not os.environ.get("KANTTS_NO_PNCA_BLOCK")}
+# Upper bound of the band width of the batch in flight when the band width itself lives in device memory (captured training
+# step: KanTtsSAMBERT.device_band_width); set by whoever knows the batch on the host (train/graph_step.py), None = unknown.
+BAND_BOUND = {"max": None}
+PB_MAX_BAND = 16  # csrc/pnca_block.hip: PB_HX / PB_HH
+
+
+class _Adopt:
+    """Results the fused block launch has ALREADY produced, in the order the block's ops will ask for them.
+
+    The fused launch computes what the chain of autograd Functions of a PNCA block computes (QKV projection, both attention
+    bands, output projection + LayerNorm, feed-forward pair + LayerNorm) and writes every tensor their backward passes
+    save.  The block then runs its usual code: each Function's forward finds its entry here, adopts the tensors (and the
+    dropout seeds the launch used) instead of launching, and saves for backward exactly what it always saves -- the backward
+    pass, every hand-over between sub-layers (RowMaskToken, PreNorm, LnBwdToken) and the deferred weight gradients are
+    untouched."""
+
+    def __init__(self):
+        self.q = None
+
+    def take(self, kind):
+        if not self.q:
+            return None
+        k, payload = self.q[0]
+        if k != kind:
+            raise RuntimeError("fused PNCA block: the block's ops ran in another order than the launch assumed (%s, "
+                               "expected %s)" % (kind, k))
+        self.q.pop(0)
+        return payload
+
+
+ADOPT = _Adopt()
+
+
+@contextlib.contextmanager
+def _adopting(entries):
+    prev, ADOPT.q = ADOPT.q, list(entries)
+    try:
+        yield
+        if ADOPT.q:
+            raise RuntimeError("fused PNCA block: %d result(s) of the launch were never adopted" % len(ADOPT.q))
+    finally:
+        ADOPT.q = prev
+
+
+def lin_frag(w):
+    """Fragment-major bf16 image of an nn.Linear weight (N, K) (csrc/ffn_pair.hip layout): the arena's, refreshed once per
+    step, for arena parameters; converted on demand and cached otherwise."""
+    a = getattr(w, "_kantts_frag", None)
+    if a is not None:
+        _fresh_shadow(w)
+        return a
+    key = (id(w), "linfrag")
+    sig = (w._version, w.data_ptr(), tuple(w.shape))
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == sig and hit[2]() is w:
+        return hit[1]
+    with torch.no_grad():
+        f = frag_major(w.detach())
+    if len(_wcache) > 4096:
+        _wcache.clear()
+    _wcache[key] = (sig, f, weakref.ref(w))
+    return f
+
+
+def lin_fragT(w):
+    """Fragment-major image of the TRANSPOSE of an nn.Linear weight (N, K) -> (K, N): the A operand of its input gradient."""
+    a = getattr(w, "_kantts_fragT", None)
+    if a is not None:
+        _fresh_shadow(w)
+        return a
+    key = (id(w), "linfragT")
+    sig = (w._version, w.data_ptr(), tuple(w.shape))
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == sig and hit[2]() is w:
+        return hit[1]
+    with torch.no_grad():
+        f = frag_major(w.detach().t())
+    if len(_wcache) > 4096:
+        _wcache.clear()
+    _wcache[key] = (sig, f, weakref.ref(w))
+    return f
+
+
+# A/B switch: KANTTS_NO_PNCA_BLOCK_BWD=1 keeps the four launches of the row-local half of the block's backward
+PNCA_BLOCK_BWD = {"on": not os.environ.get("KANTTS_NO_PNCA_BLOCK_BWD")}
+
+
+class _BlockBwd:
+    """Hand-over between the three backward nodes of a fused block (feed-forward pair -> its LayerNorm -> output projection).
+
+    The feed-forward node runs first: with this plan on it, it launches kantts_pnca_block_bwd, which also computes what the
+    LayerNorm node and the output projection's input-gradient launches would compute, deposits the results here and hands
+    autograd stand-ins; the two later nodes check that autograd delivers exactly those stand-ins (anything else means a
+    tensor of the chain had another consumer: refused) and return the deposited results.  Weight gradients stay with their
+    nodes (deferred, grouped by shape as everywhere)."""
+    __slots__ = ("y1", "mean1", "rstd1", "gamma1", "rows", "wfcxT", "wfchT", "fc_p", "fc_seed", "placeholder", "d_res", "g1",
+                 "dg1", "db1", "d_ox", "d_oh")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+    def done(self):
+        return self.g1 is not None
+
+
+def pnca_block_fused(blk, x, hkv, info, bw_x, bw_h, bw_dev, return_attn, next_ln, training):
+    """Context manager for kantts.models.sambert.PNCABlock.forward: launches the whole block's forward pass
+    (csrc/pnca_block.hip) and lets the ops inside the ``with`` adopt its results; a no-op context when the launch does
+    not apply (fp32 mode is decided by the caller; other shapes, attention maps requested, band width above 16 or unknown,
+    KANTTS_NO_PNCA_BLOCK)."""
+    at, ff = blk.pnca_attn, blk.pos_ffn
+    if (not PNCA_BLOCK["on"] or not PAIR["on"] or not PRENORM["on"] or return_attn or hkv is None or next_ln is None
+            or not torch.is_tensor(x) or x.dim() != 3 or x.dtype != torch.float32 or x.shape[-1] != 128 or x.numel() == 0
+            or at.n_head != 8 or at.d_head != 16 or at.d_model != 128):
+        return contextlib.nullcontext()
+    w1, w2 = ff.w_1.weight, ff.w_2.weight
+    if tuple(w1.shape) != (1024, 128, 1) or tuple(w2.shape) != (128, 1024, 1) or next_ln.weight.numel() != 128:
+        return contextlib.nullcontext()
+    B, L, _ = x.shape
+    M = B * L
+    if not (hkv.dim() == 3 and hkv.shape[-1] == 256 and hkv.dtype == torch.float32 and hkv.stride(2) == 1
+            and hkv.stride(0) == L * hkv.stride(1) and hkv.stride(1) % 4 == 0 and hkv.data_ptr() % 16 == 0):
+        return contextlib.nullcontext()
+    if bw_dev is not None:
+        bound = BAND_BOUND["max"]
+        if bound is None or bound > PB_MAX_BAND:
+            return contextlib.nullcontext()
+    elif not (0 <= int(bw_x) <= PB_MAX_BAND and 0 <= int(bw_h) <= PB_MAX_BAND):
+        return contextlib.nullcontext()
+    from .ops import next_seed
+
+    def p_of(drop):
+        return float(drop.p) if (training and drop.p > 0) else 0.0
+
+    att_p, fc_p, p_in, p_out = p_of(at.attention.dropatt), p_of(at.dropout), p_of(ff.dropout_inner), p_of(ff.dropout)
+    x = _c(x)
+    dev = x.device
+    ln0 = at.layer_norm
+    pre0 = getattr(x, "_kantts_prenorm", None)
+    if pre0 is None or not pre0.matches(ln0.weight, ln0.bias, ln0.eps, True) or pre0.xn.numel() != x.numel():
+        # the block's input has no producer that normalised it (the first block of the stack): one LayerNorm launch, left on
+        # the tensor exactly as a producer's epilogue would have left it
+        pre0 = PreNorm(ln0)
+        pre0.out_bf16 = True
+        pre0.xn = torch.empty((M, 128), device=dev, dtype=BF16)
+        pre0.mean = torch.empty(M, device=dev, dtype=torch.float32)
+        pre0.rstd = torch.empty(M, device=dev, dtype=torch.float32)
+        check(lib().kantts_ln128_fwd(ptr(x.detach(), torch.float32), ptr(ln0.weight.detach(), torch.float32),
+                                     ptr(ln0.bias.detach(), torch.float32), ptr(pre0.xn), 1, ptr(pre0.mean), ptr(pre0.rstd), M,
+                                     float(ln0.eps), stream()), "ln128_fwd")
+        x._kantts_prenorm = pre0
+    # dropout seeds in the order the chain draws them (attention x, attention h, output projection, hidden, output)
+    sx = next_seed() if att_p > 0 else 0
+    sh = next_seed() if att_p > 0 else 0
+    sf = next_seed() if fc_p > 0 else 0
+    s1 = next_seed() if p_in > 0 else 0
+    s2 = next_seed() if p_out > 0 else 0
+    wf1, wf2, _, _ = ffn_frag_weights(w1, w2)
+    f32 = dict(device=dev, dtype=torch.float32)
+    qkv = torch.empty((B, L, 384), **f32)
+    ox, oh = torch.empty((M, 128), **f32), torch.empty((M, 128), **f32)
+    lsx, lsh = torch.empty((B, 8, L), **f32), torch.empty((B, 8, L), **f32)
+    y1, out = torch.empty((M, 128), **f32), torch.empty((M, 128), **f32)
+    xn1 = torch.empty((M, 128), device=dev, dtype=BF16)
+    mean1, rstd1 = torch.empty(M, **f32), torch.empty(M, **f32)
+    hid = torch.empty((M, 1024), device=dev, dtype=BF16)
+    out_bf16 = bool(getattr(next_ln, "_kantts_out_bf16", True))
+    xn2 = torch.empty((M, 128), device=dev, dtype=BF16 if out_bf16 else torch.float32)
+    mean2, rstd2 = torch.empty(M, **f32), torch.empty(M, **f32)
+    rows = None if info is None else _c(info.mask).view(M)
+    ok = pnca_block_fwd(
+        x.detach(), pre0.xn, hkv.detach(), hkv.stride(1), B, L, lens=None if info is None else info.lens32, bw_dev=bw_dev,
+        bw_x=int(bw_x), bw_h=int(bw_h), rowmask=rows, wqkv=lin_frag(at.w_x_qkv.weight), bqkv=at.w_x_qkv.bias.detach(),
+        wfcx=lin_frag(at.fc_x.weight), wfch=lin_frag(at.fc_h.weight), bfcx=at.fc_x.bias.detach(), bfch=at.fc_h.bias.detach(),
+        ln1=(ff.layer_norm.weight.detach(), ff.layer_norm.bias.detach(), ff.layer_norm.eps), w1=wf1, w2=wf2,
+        bias1=ff.w_1.bias.detach(), bias2=ff.w_2.bias.detach(), att_p=att_p, fc_p=fc_p, drop1_p=p_in, drop2_p=p_out,
+        seeds=(sx, sh, sf, s1, s2), qkv=qkv, ox=ox, oh=oh, lse_x=lsx, lse_h=lsh, y1=y1, xn1=xn1, mean1=mean1, rstd1=rstd1,
+        hid=hid, out=out, ln2=(next_ln.weight.detach(), next_ln.bias.detach(), next_ln.eps, xn2, mean2, rstd2))
+    if not ok:
+        raise RuntimeError("kantts_pnca_block_fwd declined a block pnca_block_fused() accepted")
+    plan = None
+    if PNCA_BLOCK_BWD["on"] and torch.is_grad_enabled() and x.requires_grad:
+        plan = _BlockBwd()
+        plan.y1, plan.mean1, plan.rstd1, plan.gamma1, plan.rows = y1, mean1, rstd1, ff.layer_norm.weight, rows
+        plan.wfcxT, plan.wfchT, plan.fc_p, plan.fc_seed = lin_fragT(at.fc_x.weight), lin_fragT(at.fc_h.weight), fc_p, sf
+    return _adopting([
+        ("linear", dict(y=qkv.view(M, 384), seed=0, ln=None)),
+        ("attn", dict(ox=ox, oh=oh, lse_x=lsx, lse_h=lsh, sx=sx, sh=sh)),
+        ("linear", dict(y=y1, seed=sf, ln=(xn1, mean1, rstd1), bwd=plan)),
+        ("ffn", dict(hid=hid, out=out, s1=s1, s2=s2, ln=(xn2, mean2, rstd2), bwd=plan)),
+    ])
+
+
 class _FusedLinearB(torch.autograd.Function):
     """y = rowmask( dropout( act( (sum_k x_k @ W_k^T + bias [+ bias2]) * alpha ) ) + res ) on kantts_bgemm_nt/tn.
     Same three modes as ops._FusedLinear (concat / sum / conv)."""
@@ -281,20 +481,30 @@ class _FusedLinearB(torch.autograd.Function):
                 segs.append((x, k, wb, k, k, 0))
         from .ops import next_seed
 
-        seed = next_seed() if drop_p > 0 else 0
         r = _c(res).view(M, N) if res is not None else None
         rm = _c(rowmask).view(M) if rowmask is not None else None
         ln = None
         pre = opts.get("ln_next")
-        if pre is not None and N == 128 and not opts["out_bf16"]:
-            # LayerNorm of the consuming sub-layer, computed by this launch's epilogue (PreNorm)
-            pre.xn = torch.empty((M, N), device=dev, dtype=BF16 if pre.out_bf16 else torch.float32)
-            pre.mean = torch.empty(M, device=dev, dtype=torch.float32)
-            pre.rstd = torch.empty(M, device=dev, dtype=torch.float32)
-            ln = (pre.gamma.detach(), pre.beta.detach(), pre.eps, pre.xn, pre.mean, pre.rstd)
-        if not bgemm_nt(segs, M, N, y, N, T=T, bias=bias, bias2=bias2, alpha=alpha, relu=relu, drop_p=drop_p,
-                        drop_seed=seed, res=r, ldr=N, rowmask=rm, ln=ln):
-            raise RuntimeError("kantts_bgemm_nt declined a shape ops_bf16.eligible() accepted")
+        ad = ADOPT.take("linear") if ADOPT.q else None
+        if ad is not None:
+            # computed by the fused block launch (pnca_block_fused): same values, same dropout seed, nothing to launch
+            y, seed = ad["y"], ad["seed"]
+            assert tuple(y.shape) == (M, N) and y.dtype == (BF16 if opts["out_bf16"] else torch.float32)
+            if pre is not None and ad["ln"] is not None:
+                pre.xn, pre.mean, pre.rstd = ad["ln"]
+                pre.bwd = ad.get("bwd")  # travels to the LayerNorm node that adopts these rows (_BlockBwd)
+            opts["bwd"] = ad.get("bwd")
+        else:
+            seed = next_seed() if drop_p > 0 else 0
+            if pre is not None and N == 128 and not opts["out_bf16"]:
+                # LayerNorm of the consuming sub-layer, computed by this launch's epilogue (PreNorm)
+                pre.xn = torch.empty((M, N), device=dev, dtype=BF16 if pre.out_bf16 else torch.float32)
+                pre.mean = torch.empty(M, device=dev, dtype=torch.float32)
+                pre.rstd = torch.empty(M, device=dev, dtype=torch.float32)
+                ln = (pre.gamma.detach(), pre.beta.detach(), pre.eps, pre.xn, pre.mean, pre.rstd)
+            if not bgemm_nt(segs, M, N, y, N, T=T, bias=bias, bias2=bias2, alpha=alpha, relu=relu, drop_p=drop_p,
+                            drop_seed=seed, res=r, ldr=N, rowmask=rm, ln=ln):
+                raise RuntimeError("kantts_bgemm_nt declined a shape ops_bf16.eligible() accepted")
         ctx.opts, ctx.seed, ctx.M, ctx.N, ctx.lead = opts, seed, M, N, lead
         ctx.has = (bias is not None, bias2 is not None, res is not None)
         ctx.x_dtypes = [x.dtype for x in xs_in]
@@ -316,7 +526,7 @@ class _FusedLinearB(torch.autograd.Function):
         y_gate, rm = sv[0], sv[1]
         xs, wbs = list(sv[2:2 + nx]), list(sv[2 + nx:])
         has_bias, has_bias2, has_res = ctx.has
-        dy = _c(dy).view(M, N)
+        dy = dy_in = _c(dy).view(M, N)
         token = opts.get("token")
         if rm is not None and not relu and not (token is not None and token.delegated):
             dy = dy.masked_fill(rm.bool().view(M, 1), 0.0)
@@ -348,6 +558,14 @@ class _FusedLinearB(torch.autograd.Function):
                 a_drop_p, a_seed = drop_p, ctx.seed
         needs = ctx.needs_input_grad  # (opts, bias, bias2, res, rowmask, *xs, *ws, *wbs)
         dxs, dws = [None] * nx, [None] * nw
+        plan = opts.get("bwd")
+        if plan is not None and plan.done():
+            # fused PNCA block: the input gradients of the two context segments came out of the block's backward launch
+            if not _same_tensor(dy_in, plan.g1) or nx != 2 or mode != "sum":
+                raise RuntimeError("the input gradient of a fused PNCA block's output projection was computed by the block's "
+                                   "backward launch, but autograd delivers another gradient than the one that launch produced")
+            dxs = [plan.d_ox.view(xs[0].shape), plan.d_oh.view(xs[1].shape)]
+            plan.g1 = plan.d_ox = plan.d_oh = plan.dg1 = plan.db1 = None
         dbias = gzeros((N,), dy.device) if (has_bias or has_bias2) else None
         first = True
         kw = dict(alpha=balpha, a_drop_p=a_drop_p, a_drop_seed=a_seed)
@@ -460,9 +678,10 @@ class _LayerNorm128(torch.autograd.Function):
     backward kernel -- autograd would otherwise add them with a separate elementwise kernel per sub-layer."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res, zero_rows, xn, mean, rstd, token=None):
+    def forward(ctx, x, gamma, beta, eps, out_bf16, with_res, zero_rows, xn, mean, rstd, token=None, bwd=None):
         x = _c(x)
         M = x.numel() // 128
+        ctx.bwd = bwd
         if xn is not None:  # computed by the epilogue of the launch that produced x (PreNorm)
             y = xn.view(x.shape)
         else:
@@ -486,6 +705,15 @@ class _LayerNorm128(torch.autograd.Function):
         x, gamma, mean, rstd, zero_rows = ctx.saved_tensors
         M = x.numel() // 128
         tok = ctx.token
+        plan = ctx.bwd
+        if plan is not None and plan.done():  # done by the fused block backward launch (_BlockBwd)
+            if not _same_tensor(dy, plan.placeholder) or not _same_tensor(dres, plan.d_res):
+                raise RuntimeError("the LayerNorm backward of a fused PNCA block was computed by the block's backward launch, "
+                                   "but autograd delivers other gradients than the ones that launch saw: the normalised rows "
+                                   "(or the residual output) have a second consumer")
+            out = (plan.g1.view(x.shape), plan.dg1, plan.db1)
+            plan.placeholder = plan.d_res = None
+            return (*out, None, None, None, None, None, None, None, None, None)
         if tok is not None and tok.dx is not None:  # done by the consumer's input-gradient launch (LnBwdToken)
             if not _same_tensor(dy, tok.placeholder) or (tok.with_res and not _same_tensor(dres, tok.dres)) or (
                     not tok.with_res and dres is not None):
@@ -494,19 +722,19 @@ class _LayerNorm128(torch.autograd.Function):
                                    "have a second consumer")
             out = (tok.dx, tok.dg, tok.db)
             tok.x = tok.dres = tok.dx = tok.dg = tok.db = tok.placeholder = None
-            return (*out, None, None, None, None, None, None, None, None)
+            return (*out, None, None, None, None, None, None, None, None, None)
         dx = torch.empty_like(x)
         dg, db = gzeros_like(gamma), gzeros_like(gamma)
         if dy is None:  # only the pass-through was used downstream
             if zero_rows is not None:
                 dres = dres.masked_fill(zero_rows.bool().view(*dres.shape[:-1], 1), 0.0)
-            return (dres, None, None, None, None, None, None, None, None, None, None)
+            return (dres, None, None, None, None, None, None, None, None, None, None, None)
         dy = _c(dy)
         dres = _c(dres) if dres is not None else None
         check(lib().kantts_ln128_bwd_rows(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean), ptr(rstd),
                                           ptr(dres, torch.float32), ptr(dx), ptr(dg), ptr(db), ptr(zero_rows, torch.uint8),
                                           M, stream()), "ln128_bwd")
-        return dx, dg, db, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None, None, None
 
 
 def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False, private_input=False):
@@ -521,7 +749,7 @@ def layer_norm128(x, gamma, beta, eps, out_bf16, with_res=False, private_input=F
     pre = getattr(x, "_kantts_prenorm", None)
     if pre is not None and pre.matches(gamma, beta, eps, out_bf16) and pre.xn.numel() == x.numel():
         y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows, pre.xn, pre.mean,
-                                    pre.rstd, token)
+                                    pre.rstd, token, pre.bwd if with_res else None)
     else:
         y, xr = _LayerNorm128.apply(x, gamma, beta, float(eps), bool(out_bf16), bool(with_res), zero_rows, None, None, None,
                                     token)
@@ -551,23 +779,32 @@ class _FusedFFNB(torch.autograd.Function):
         N = w2.shape[0]
         T, pad, p_in, p_out = cfg["T"], cfg["pad"], cfg["p_inner"], cfg["p_out"]
         hb = h.detach() if h.dtype == BF16 else to_bf16(h)
-        s1 = next_seed() if p_in > 0 else 0
-        s2 = next_seed() if p_out > 0 else 0
         pr = _c(pad_rows).view(M) if pad_rows is not None else None
         zr = _c(zero_rows).view(M) if zero_rows is not None else None
-        hid = torch.empty((M, F), device=h.device, dtype=BF16)
-        out = torch.empty((M, N), device=h.device, dtype=torch.float32)
         r = _c(res).view(M, N)
         ln = None
         pre = cfg.get("ln_next")
-        if pre is not None and cfg["pair"] and N == 128:
-            pre.xn = torch.empty((M, N), device=h.device, dtype=BF16 if pre.out_bf16 else torch.float32)
-            pre.mean = torch.empty(M, device=h.device, dtype=torch.float32)
-            pre.rstd = torch.empty(M, device=h.device, dtype=torch.float32)
-            ln = (pre.gamma.detach(), pre.beta.detach(), pre.eps, pre.xn, pre.mean, pre.rstd)
-        fused = cfg["pair"] and ffn_pair(hb.view(M, C), wf1, wf2, out, M=M, T=T, F=F, KT=kt, pad=pad, bias1=b1, bias2=b2,
-                                         relu=True, drop1_p=p_in, drop1_seed=s1, drop2_p=p_out, drop2_seed=s2,
-                                         rowmask1=pr, rowmask2=zr, t_out=hid, res=r, ln=ln)
+        ad = ADOPT.take("ffn") if ADOPT.q else None
+        if ad is not None:  # computed by the fused block launch (pnca_block_fused)
+            hid, out, s1, s2 = ad["hid"], ad["out"], ad["s1"], ad["s2"]
+            assert cfg["pair"] and tuple(hid.shape) == (M, F) and tuple(out.shape) == (M, N)
+            cfg["bwd"] = ad.get("bwd")
+            if pre is not None:
+                pre.xn, pre.mean, pre.rstd = ad["ln"]
+            fused = True
+        else:
+            s1 = next_seed() if p_in > 0 else 0
+            s2 = next_seed() if p_out > 0 else 0
+            hid = torch.empty((M, F), device=h.device, dtype=BF16)
+            out = torch.empty((M, N), device=h.device, dtype=torch.float32)
+            if pre is not None and cfg["pair"] and N == 128:
+                pre.xn = torch.empty((M, N), device=h.device, dtype=BF16 if pre.out_bf16 else torch.float32)
+                pre.mean = torch.empty(M, device=h.device, dtype=torch.float32)
+                pre.rstd = torch.empty(M, device=h.device, dtype=torch.float32)
+                ln = (pre.gamma.detach(), pre.beta.detach(), pre.eps, pre.xn, pre.mean, pre.rstd)
+            fused = cfg["pair"] and ffn_pair(hb.view(M, C), wf1, wf2, out, M=M, T=T, F=F, KT=kt, pad=pad, bias1=b1, bias2=b2,
+                                             relu=True, drop1_p=p_in, drop1_seed=s1, drop2_p=p_out, drop2_seed=s2,
+                                             rowmask1=pr, rowmask2=zr, t_out=hid, res=r, ln=ln)
         if not fused and pre is not None:
             pre.xn = pre.mean = pre.rstd = None
         if not fused:
@@ -603,9 +840,27 @@ class _FusedFFNB(torch.autograd.Function):
         # both input-gradient contractions in one launch (images of the TRANSPOSED weights)
         # (k = 3: the three taps are summed in phase 2 from a tile of dz with one halo row either side)
         can_pair = cfg["pair"] and kt in (1, 3) and wt1 is not None and wt2 is not None and (kt == 1 or M % T == 0)
-        dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
-        fused = can_pair and ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid,
-                                      t_out=dz, KT2=kt, s2_first=pad, s2_step=-1)
+        plan = cfg.get("bwd")
+        if (plan is not None and can_pair and kt == 1 and ctx.h_dtype == BF16 and dy.dtype == torch.float32
+                and ctx.needs_input_grad[0] and ctx.needs_input_grad[5]):
+            # fused PNCA block: this launch also runs the LayerNorm backward of the sub-layer's input and the input gradient of
+            # the attention's output projection (_BlockBwd); the two nodes that follow adopt its results
+            from .ops import gzeros_like
+
+            plan.g1 = torch.empty((M, N), device=dev, dtype=torch.float32)
+            plan.d_ox = torch.empty((M, N), device=dev, dtype=torch.float32)
+            plan.d_oh = torch.empty((M, N), device=dev, dtype=torch.float32)
+            plan.dg1, plan.db1 = gzeros_like(plan.gamma1), gzeros_like(plan.gamma1)
+            pnca_block_bwd(dy, hid, plan.y1, plan.mean1, plan.rstd1, plan.gamma1.detach(), plan.rows, wt2, wt1, plan.wfcxT,
+                           plan.wfchT, alpha1=a1, drop2_p=p_out, drop2_seed=s2, fc_p=plan.fc_p, fc_seed=plan.fc_seed, dz=dz,
+                           g1=plan.g1, d_ox=plan.d_ox, d_oh=plan.d_oh, dgamma1=plan.dg1, dbeta1=plan.db1)
+            plan.placeholder, plan.d_res = hb, d_res
+            plan.y1 = plan.mean1 = plan.rstd1 = plan.wfcxT = plan.wfchT = None
+            dh, fused = hb, True  # stand-in: the LayerNorm node returns plan.g1 and never reads this
+        else:
+            dh = torch.empty((M, C), device=dev, dtype=ctx.h_dtype)
+            fused = can_pair and ffn_pair(dy, wt2, wt1, dh, M=M, T=T, F=F, alpha1=a1, xdrop_p=p_out, xdrop_seed=s2, gate=hid,
+                                          t_out=dz, KT2=kt, s2_first=pad, s2_step=-1)
         if not fused and not bgemm_nt([(dy, N, wb2, F, N, 0)], M, F, dz, F, b_kn=True, gate=hid, ldg=F, alpha=a1,
                                       a_drop_p=p_out, a_drop_seed=s2, a_drop_ld=N):
             raise RuntimeError("bgemm_nt declined the FFN hidden gradient")

@@ -164,6 +164,9 @@ class MultiHeadPNCAAttention(nn.Module):
         self.fc_h = nn.Linear(n_head * d_head, d_model)
         self.attention = ScaledDotProductAttention(temperature=np.power(d_head, 0.5), dropatt=dropatt)
         self.dropout = nn.Dropout(dropout)
+        # bf16 mode: the parameter arena also keeps the fragment-major images csrc/pnca_block.hip streams
+        for lin in (self.w_x_qkv, self.fc_x, self.fc_h):
+            lin.weight._kantts_ffn_role = "lin"
         self.reset_state()
 
     def reset_state(self):
@@ -233,10 +236,14 @@ class PNCABlock(nn.Module):
                 hkv=None, private_input=False, next_ln=None):
         info = SeqInfo.of(mask)
         rows = None if info is None else info.mask
-        output, ax, ah = self.pnca_attn(input, memory, info, x_band_width, h_band_width, zero_rows=rows,
-                                        return_attn=return_attn, bw_dev=bw_dev, hkv=hkv, private_input=private_input,
-                                        next_ln=self.pos_ffn.layer_norm)
-        output = self.pos_ffn(output, mask=info, zero_rows=rows, private_input=True, next_ln=next_ln)
+        # bf16 mode: the whole block's forward pass as ONE launch (csrc/pnca_block.hip) whose results the ops below adopt
+        # instead of launching; a no-op context whenever that launch does not apply
+        with ops.pnca_block_fused(self, input, hkv, info, x_band_width, h_band_width, bw_dev, return_attn, next_ln,
+                                  self.training):
+            output, ax, ah = self.pnca_attn(input, memory, info, x_band_width, h_band_width, zero_rows=rows,
+                                            return_attn=return_attn, bw_dev=bw_dev, hkv=hkv, private_input=private_input,
+                                            next_ln=self.pos_ffn.layer_norm)
+            output = self.pos_ffn(output, mask=info, zero_rows=rows, private_input=True, next_ln=next_ln)
         return output, ax, ah
 
     @torch.no_grad()

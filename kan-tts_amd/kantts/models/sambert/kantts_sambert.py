@@ -432,6 +432,14 @@ class PostNet(nn.Module):
         return ops.linear(h, self.fc.weight, self.fc.bias, res=res, rowmask=zero_rows)
 
 
+def band_width_of(duration_targets, input_lengths, r):
+    """x_band_width = h_band_width of a teacher-forced batch as a host integer (reference :981-985): int(max valid duration
+    / r + 0.5).  On host tensors (a batch before its upload) this costs no device synchronisation."""
+    T = duration_targets.size(1)
+    valid = torch.arange(T, device=duration_targets.device)[None, :] < input_lengths[:, None]
+    return int(float((duration_targets * valid).max()) / r + 0.5)
+
+
 def average_frame_feat(pitch, durs):
     """Frame-level contour (B, F, T_mel) -> per-phoneme mean over each phoneme's NON-ZERO frames (B, F, N), 0 where a
     phoneme has none (reference :652-674).  Prefix sums + two gathers; durations are whole numbers stored as float."""
@@ -478,6 +486,11 @@ class KanTtsSAMBERT(nn.Module):
         # True: the band width stays in device memory (no host sync) so that a whole training step can be
         # captured in a hipGraph; res["x_band_width"] is then a 1-element int32 tensor instead of an int
         self.device_band_width = False
+        # with ``device_band_width``: an upper bound of the band width of the batches this module will see, promised by a
+        # caller that knows them on the host (train/graph_step.py; ``band_width_of``); None = unknown.  It lets the decoder
+        # choose the one-launch PNCA block (band <= 16) without reading the device value; that launch poisons its output
+        # with NaN if the promise is broken.
+        self.band_width_bound = None
 
     def get_lfr_mask_from_lengths(self, lengths, max_len):
         """ceil(len / r) valid decoder steps (reference :736-750, vectorised: no per-item .item())."""
@@ -629,10 +642,17 @@ class KanTtsSAMBERT(nn.Module):
             bw_int = 0
         else:
             x_band_width = h_band_width = bw_int = int(bw_val)  # host sync, as in the reference (:981-993)
-        dec_outputs, pnca_x_attn_lst, pnca_h_attn_lst = self.mel_decoder(
-            memory, bw_int, bw_int, target=mel_targets, mask=lfr_info, return_attns=self.return_attns, bw_dev=bw_dev,
-            teacher_input=None if tplan is None else tplan["dec_input"],
-            teacher_prenet=None if tplan is None else tplan.get("dec_prenet"))
+        from kantts._hip import ops_bf16
+
+        bound_before = ops_bf16.BAND_BOUND["max"]
+        ops_bf16.BAND_BOUND["max"] = self.band_width_bound if (self.device_band_width and mel_targets is not None) else None
+        try:
+            dec_outputs, pnca_x_attn_lst, pnca_h_attn_lst = self.mel_decoder(
+                memory, bw_int, bw_int, target=mel_targets, mask=lfr_info, return_attns=self.return_attns, bw_dev=bw_dev,
+                teacher_input=None if tplan is None else tplan["dec_input"],
+                teacher_prenet=None if tplan is None else tplan.get("dec_prenet"))
+        finally:
+            ops_bf16.BAND_BOUND["max"] = bound_before
         dec_outputs = dec_outputs.reshape(batch_size, -1, self.mel_decoder.d_mel)
         rows = out_info.mask
         if rows.size(1) != dec_outputs.size(1):

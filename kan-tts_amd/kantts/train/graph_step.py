@@ -25,7 +25,10 @@ from kantts._hip import ops, rng_state as _rng_state
 
 class GraphedSambertStep:
     def __init__(self, net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup=3,
-                 overlap_wgrad=True, group_wgrads=True):
+                 overlap_wgrad=True, group_wgrads=True, band_width=None):
+        """``band_width``: x_band_width of ``batch`` when the caller already knows it on the host (band_width_of on the
+        batch before its upload); None: read from the device batch here, once."""
+        self._band_width_arg = band_width
         # weight gradients leave the critical path: fp32-mode ones as parallel branches of the captured graph
         # (ops._WgradOverlap), bf16-mode ones recorded and issued grouped by shape before the optimizer
         # (kantts._hip.deferred_tn); the variance predictors run as a side branch (ops.side_branch).  These switches only
@@ -53,6 +56,19 @@ class GraphedSambertStep:
         self.batch = {k: v.clone() for k, v in batch.items()}
         self.device = next(net.parameters()).device
         net.device_band_width = True
+        # The band width itself stays in device memory, but the SHAPE of the captured step depends on it: up to 16 the
+        # decoder blocks are one launch each (csrc/pnca_block.hip), above that the five-launch chain.  The capture is made
+        # for the class this batch is in; load_batch() refuses a batch of the other class (the trainer keys its graph cache
+        # on it, train/trainer.py).
+        from kantts._hip import ops_bf16
+        from kantts.models.sambert.kantts_sambert import band_width_of
+
+        self._r = net.mel_decoder.r
+        bw = self._band_width_arg
+        if bw is None:
+            bw = band_width_of(self.batch["duration_targets"], self.batch["input_lengths"], self._r)
+        self.narrow_band = bw <= ops_bf16.PB_MAX_BAND
+        self._bound = ops_bf16.PB_MAX_BAND if self.narrow_band else None
         self.distributed = optimizer.arena.world_size > 1 or getattr(optimizer.arena, "force_exchange", False)
         # collectives are not captured: the exchange sits between the two graph halves (bucketed, asynchronous), so
         # the hook-driven overlap of the eager path is switched off for this optimizer
@@ -146,7 +162,11 @@ class GraphedSambertStep:
         b = self.batch
         ops.advance_rng(self.device)
         self.optimizer.zero_grad(set_to_none=True)
-        res = self.net(**b)
+        self.net.band_width_bound = self._bound
+        try:
+            res = self.net(**b)
+        finally:
+            self.net.band_width_bound = None
         from kantts.train.loss import sambert_loss_sum
 
         self.loss, self.loss_terms = sambert_loss_sum(self.mel_criterion, self.prosody_criterion, b, res)
@@ -159,7 +179,17 @@ class GraphedSambertStep:
         self._forward_backward()
         self.optimizer.step()
 
-    def load_batch(self, batch):
+    def load_batch(self, batch, band_width=None):
+        """Copy a new batch of the captured shape into the static buffers.  ``band_width``: its x_band_width if the caller
+        knows it on the host; else it is read from ``batch`` (a device synchronisation when the batch is on the device)."""
+        from kantts._hip import ops_bf16
+        from kantts.models.sambert.kantts_sambert import band_width_of
+
+        if band_width is None:
+            band_width = band_width_of(batch["duration_targets"], batch["input_lengths"], self._r)
+        if (band_width <= ops_bf16.PB_MAX_BAND) != self.narrow_band:
+            raise ValueError("this step was captured for band widths %s %d, the batch has %d: capture another step for it"
+                             % ("<=" if self.narrow_band else ">", ops_bf16.PB_MAX_BAND, band_width))
         for k, v in batch.items():
             self.batch[k].copy_(v, non_blocking=True)
 

@@ -331,6 +331,12 @@ class ParamArena:
                 N_, F_, _ = p.shape
                 views.append(image(p, o, N_, F_, F_, 1, "_kantts_frag"))
                 views.append(image(p, o, F_, N_, 1, F_, "_kantts_fragT"))
+            elif role == "lin" and p.dim() == 2 and p.shape[0] % 16 == 0 and p.shape[1] % 32 == 0:
+                # nn.Linear weights the fused PNCA block launch streams (csrc/pnca_block.hip: w_x_qkv, fc_x, fc_h)
+                N_, K_ = p.shape
+                views.append(image(p, o, N_, K_, K_, 1, "_kantts_frag"))
+                if N_ % 32 == 0 and K_ % 16 == 0:  # W^T: the A operand of the input gradient (pnca_block_bwd_kernel)
+                    views.append(image(p, o, K_, N_, 1, K_, "_kantts_fragT"))
         self.frag_bf16 = torch.zeros(max(foff, 8), device=dev, dtype=torch.bfloat16)
         for attr, p, base, n in views:
             setattr(p, attr, self.frag_bf16[base:base + n])

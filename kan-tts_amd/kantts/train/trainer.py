@@ -228,7 +228,11 @@ class Sambert_Trainer(Trainer):
         b = self._to_device(batch)
         net, opt, sch = self.model[self.KEY], self.optimizer[self.KEY], self.scheduler[self.KEY]
         if self.graph:
-            return self._graph_step(b)
+            # the attention band width of the batch, from the HOST copy (no device synchronisation): the captured step has
+            # one shape for bands up to 16 (one launch per decoder block) and another above
+            from kantts.models.sambert.kantts_sambert import band_width_of
+
+            return self._graph_step(b, band_width_of(batch["durations"], batch["valid_input_lengths"], net.mel_decoder.r))
         from kantts._hip import ops
 
         if b["mel_targets"].is_cuda:
@@ -245,19 +249,20 @@ class Sambert_Trainer(Trainer):
         sch.step()
         return total
 
-    def _graph_step(self, b):
+    def _graph_step(self, b, band_width):
+        from kantts._hip import ops_bf16
         from kantts.train.graph_step import GraphedSambertStep
 
-        key = tuple((k, tuple(v.shape)) for k, v in b.items() if v is not None)
+        key = tuple((k, tuple(v.shape)) for k, v in b.items() if v is not None) + (band_width <= ops_bf16.PB_MAX_BAND,)
         g = self._graphs.pop(key, None)
         if g is None:
             if len(self._graphs) >= self.max_graphs:  # least recently used shape goes (dicts keep insertion order)
                 self._graphs.pop(next(iter(self._graphs)))
             g = GraphedSambertStep(self.model[self.KEY], self.optimizer[self.KEY], self.scheduler[self.KEY],
                                    self.criterion["MelReconLoss"], self.criterion["ProsodyReconLoss"],
-                                   {k: v for k, v in b.items() if v is not None})
+                                   {k: v for k, v in b.items() if v is not None}, band_width=band_width)
         else:
-            g.load_batch({k: v for k, v in b.items() if v is not None})
+            g.load_batch({k: v for k, v in b.items() if v is not None}, band_width=band_width)
         self._graphs[key] = g  # most recently used last
         g()
         self._accumulate("train", {"TotalLoss": g.loss})

@@ -457,6 +457,131 @@ class EmulatedLib:
             _arr(g.ln_rstd, M)[:] = rs.numpy()
         return 0
 
+    def kantts_pnca_block_fwd(self, args_ref, stream):
+        """csrc/pnca_block.hip: one PNCA decoder block forward -- the QKV contraction, both attention bands (the per-band
+        emulation), the output contraction with its LayerNorm, the feed-forward pair with the consumer's LayerNorm; bf16
+        rounding of every MFMA operand as on the device."""
+        g = args_ref._obj
+        B, L, C, F = g.B, g.L, 128, 1024
+        if g.H != 8 or g.C != C or g.F != F or g.ldh < 2 * C or g.ldh % 4:
+            return -2
+        if not g.bw_dev and (g.bw_x > 16 or g.bw_h > 16 or g.bw_x < 0 or g.bw_h < 0):
+            return -2
+        M = B * L
+        if M == 0:
+            return 0
+        soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
+        rows = np.arange(M, dtype=np.int64)
+        cols = np.arange(C, dtype=np.int64)
+        mask = (_arr(g.rowmask, M, np.uint8) != 0) if g.rowmask else np.zeros(M, dtype=bool)
+        X = _rd2d(g.x, M, C, C, False)
+        Xn = _rd2d(g.xn, M, C, C, True)
+        qkv = (Xn @ _unfrag(g.wqkv, 3 * C, C).T).astype(np.float32)
+        if g.bqkv:
+            qkv = qkv + _arr(g.bqkv, 3 * C)[None, :]
+        qkv = np.ascontiguousarray(qkv, dtype=np.float32)
+        if g.qkv:
+            _wr(g.qkv, qkv, False)
+        ox = np.zeros((M, C), dtype=np.float32)
+        oh = np.zeros((M, C), dtype=np.float32)
+        self.kantts_pnca_attn_fwd(qkv.ctypes.data, g.hkv, g.ldh, ox.ctypes.data, oh.ctypes.data, g.lse_x, g.lse_h, g.lens,
+                                  g.bw_dev, g.bw_x, g.bw_h, B, 8, L, 16, g.att_p, g.seed_x, g.seed_h, g.seed_dev, stream)
+        if g.bw_dev and int(_arr(g.bw_dev, 1, np.int32)[0]) > 16:
+            ox[:], oh[:] = np.nan, np.nan
+        _wr(g.ox, ox, False)
+        _wr(g.oh, oh, False)
+        y1 = _bf16_round(ox) @ _unfrag(g.wfcx, C, C).T + _bf16_round(oh) @ _unfrag(g.wfch, C, C).T
+        if g.bfcx:
+            y1 = y1 + _arr(g.bfcx, C)[None, :]
+        if g.bfch:
+            y1 = y1 + _arr(g.bfch, C)[None, :]
+        y1 = y1.astype(np.float32)
+        if g.fc_p > 0:
+            y1 = y1 * dropout_scale(g.fc_p, g.fc_seed + soff, rows[:, None] * C + cols[None, :])
+        y1 = np.where(mask[:, None], 0, y1 + X).astype(np.float32)
+        if g.y1:
+            _wr(g.y1, y1, False)
+
+        def ln(v, gamma, beta, eps):
+            t = torch.from_numpy(np.ascontiguousarray(v))
+            mu = t.mean(1)
+            rs = 1.0 / torch.sqrt(((t - mu[:, None]) ** 2).mean(1) + eps)
+            out = (t - mu[:, None]) * rs[:, None] * torch.from_numpy(_arr(gamma, C)) + torch.from_numpy(_arr(beta, C))
+            return out.numpy(), mu.numpy(), rs.numpy()
+
+        xn1, mu1, rs1 = ln(y1, g.ln1_gamma, g.ln1_beta, g.ln1_eps)
+        xn1 = _bf16_round(xn1)
+        if g.xn1:
+            _wr(g.xn1, xn1, True)
+        if g.mean1:
+            _arr(g.mean1, M)[:] = mu1
+            _arr(g.rstd1, M)[:] = rs1
+        hid = xn1 @ _unfrag(g.w1, F, C).T
+        if g.bias1:
+            hid = hid + _arr(g.bias1, F)[None, :]
+        hid = np.maximum(hid, 0).astype(np.float32)
+        if g.drop1_p > 0:
+            hid = hid * dropout_scale(g.drop1_p, g.drop1_seed + soff, rows[:, None] * F + np.arange(F, dtype=np.int64)[None, :])
+        hid = _bf16_round(np.where(mask[:, None], 0, hid).astype(np.float32))
+        if g.hid:
+            _wr(g.hid, hid, True)
+        out = hid @ _unfrag(g.w2, C, F).T
+        if g.bias2:
+            out = out + _arr(g.bias2, C)[None, :]
+        out = out.astype(np.float32)
+        if g.drop2_p > 0:
+            out = out * dropout_scale(g.drop2_p, g.drop2_seed + soff, rows[:, None] * C + cols[None, :])
+        out = np.where(mask[:, None], 0, out + y1).astype(np.float32)
+        _wr(g.out, out, False)
+        if g.ln2_out:
+            z, mu2, rs2 = ln(out, g.ln2_gamma, g.ln2_beta, g.ln2_eps)
+            _wr(g.ln2_out, z, bool(g.ln2_out_bf16))
+            _arr(g.ln2_mean, M)[:] = mu2
+            _arr(g.ln2_rstd, M)[:] = rs2
+        return 0
+
+    def kantts_pnca_block_bwd(self, args_ref, stream):
+        """csrc/pnca_block.hip: feed-forward pair backward + LayerNorm backward (+ residual, row mask) + input gradient of the
+        output projection, with the bf16 roundings of the separate launches."""
+        g = args_ref._obj
+        M, C, F = g.M, 128, 1024
+        if g.C != C or g.F != F:
+            return -2
+        if M == 0:
+            return 0
+        soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
+        rows = np.arange(M, dtype=np.int64)
+        cols = np.arange(C, dtype=np.int64)
+        mask = (_arr(g.rowmask, M, np.uint8) != 0) if g.rowmask else np.zeros(M, dtype=bool)
+        dy = np.where(mask[:, None], 0, _rd2d(g.dy, M, C, C, False)).astype(np.float32)
+        X = dy
+        if g.drop2_p > 0:
+            X = X * dropout_scale(g.drop2_p, g.drop2_seed + soff, rows[:, None] * C + cols[None, :])
+        X = _bf16_round(X.astype(np.float32))
+        acc = X @ _unfrag(g.wt2, F, C).T
+        dz = _bf16_round(np.where(_rd2d(g.hid, M, F, F, True) > 0, acc * np.float32(g.alpha1), 0).astype(np.float32))
+        _wr(g.dz, dz, True)
+        dh = _bf16_round((dz @ _unfrag(g.wt1, C, F).T).astype(np.float32))
+        y1 = _rd2d(g.y1, M, C, C, False)
+        mu, rs = _arr(g.mean1, M), _arr(g.rstd1, M)
+        gam = _arr(g.ln1_gamma, C)
+        xh = (y1 - mu[:, None]) * rs[:, None]
+        gg = dh * gam[None, :]
+        s1 = gg.sum(1, keepdims=True) / np.float32(128)
+        s2 = (gg * xh).sum(1, keepdims=True) / np.float32(128)
+        g1 = rs[:, None] * (gg - s1 - xh * s2) + _rd2d(g.dy, M, C, C, False)
+        g1 = np.where(mask[:, None], 0, g1).astype(np.float32)
+        _wr(g.g1, g1, False)
+        _arr(g.dgamma1, C)[:] += (dh * xh).sum(0).astype(np.float32)
+        _arr(g.dbeta1, C)[:] += dh.sum(0).astype(np.float32)
+        gd = g1
+        if g.fc_p > 0:
+            gd = gd * dropout_scale(g.fc_p, g.fc_seed + soff, rows[:, None] * C + cols[None, :])
+        gd = _bf16_round(gd.astype(np.float32))
+        _wr(g.d_ox, (gd @ _unfrag(g.wfcxT, C, C).T).astype(np.float32), False)
+        _wr(g.d_oh, (gd @ _unfrag(g.wfchT, C, C).T).astype(np.float32), False)
+        return 0
+
     def kantts_bgemm_tn(self, args_ref, stream):
         g = args_ref._obj
         M, N, K, T = g.M, g.N, g.K, g.T

@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# bf16 bounds: the decoder's contractions read bf16 operands over up to ~90 autoregressive steps
-_BOUNDS = {"fp32": dict(frames=1.0, dur=1.0, mel_mean=1e-4, mel_max=2e-3),
-           "bf16": dict(frames=0.5, dur=0.97, mel_mean=3e-2, mel_max=1.0)}
+# measured on MI355X (profiles/r05_runB_config5_parity.json): fp32 frame counts / durations 100 % identical, mel mean-abs 2.7e-7,
+# max 1.9e-6; bf16 (contraction operands bf16 over up to ~105 autoregressive steps) frame counts 87.5 %, durations 99.76 %,
+# mel mean-abs 2.1e-3, max 1.2e-2 with the durations forced.  bf16 bounds = 2x measured.
+_BOUNDS = {"fp32": dict(frames=1.0, dur=1.0, mel_mean=1e-5, mel_max=1e-4),
+           "bf16": dict(frames=0.75, dur=0.99, mel_mean=4.5e-3, mel_max=2.5e-2)}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
