@@ -599,6 +599,9 @@ typedef struct kantts_lnbwd_args {
   float* dx;             /* (M,128) */
   float* dgamma_accum;   /* (128), += */
   float* dbeta_accum;
+  float* part_rows;      /* [round 5] optional (ceil(M / 32), 256): when set, workgroup w writes its 128 dgamma + 128 dbeta sums
+                          * to row w INSTEAD of adding them to the accumulators (256 atomics per workgroup on the same 256
+                          * addresses serialise in L2); the caller adds the rows: kantts_rows_sum_accum */
 } kantts_lnbwd_args;
 int kantts_bgemm_nt_lnbwd(const kantts_bgemm_args* args, const kantts_lnbwd_args* ln, void* stream);
 
@@ -770,7 +773,9 @@ int kantts_pnca_block_fwd(const kantts_pnca_block_args* args, void* stream);
  * (kantts/models/sambert/__init__.py:134-149, 286-306 differentiated):
  *   dz = gate_{hid > 0}(dropout_2(dy) W2) * alpha1 (bf16, (M, 1024); the weight gradient of W1 reads it);
  *   dh = dz W1 (rounded to bf16);  g1 = rowmask(LN1'(dh; y1, mean1, rstd1, gamma1) + dy) (fp32 (M, 128));
- *   d_ox = dropout_fc(g1) Wfcx, d_oh = dropout_fc(g1) Wfch (fp32 (M, 128)); dgamma1 / dbeta1 (128) are ACCUMULATED.
+ *   d_ox = dropout_fc(g1) Wfcx, d_oh = dropout_fc(g1) Wfch (fp32 (M, 128)).  The gradients of LN1's gamma / beta leave as
+ *   PARTIAL ROWS: workgroup w writes 128 dgamma sums and 128 dbeta sums of its 32 rows to ws[w*256 ..]; the caller adds the
+ *   rows (kantts_rows_sum_accum) -- same-address atomics from 204 workgroups cost half of the launch.
  * dy: gradient of the block output (rows of rowmask are read as zero).  wt2 = W2^T (1024 x 128), wt1 = W1^T (128 x 1024),
  * wfcxT / wfchT = Wfcx^T / Wfch^T (128 x 128): fragment-major bf16 images.  Dropout indices as in the forward launches. */
 typedef struct kantts_pnca_block_bwd_args {
@@ -793,10 +798,13 @@ typedef struct kantts_pnca_block_bwd_args {
   float* g1;
   float* d_ox;
   float* d_oh;
-  float* dgamma1;
-  float* dbeta1;
+  float* ws;            /* caller-owned, >= kantts_pnca_block_bwd_ws_floats(M) floats, 16-byte aligned: ceil(M / 32) rows */
+  long long ws_floats;  /* of [128 dgamma | 128 dbeta] partial sums, every element written */
 } kantts_pnca_block_bwd_args;
 int kantts_pnca_block_bwd(const kantts_pnca_block_bwd_args* args, void* stream);
+long long kantts_pnca_block_bwd_ws_floats(int M);
+/* dst0[c] += sum_r src[r*cols + c] for c < split, dst1[c - split] += ... for c >= split (fixed summation order). */
+int kantts_rows_sum_accum(const float* src, int rows, int cols, float* dst0, float* dst1, int split, void* stream);
 
 /* Fragment-major bf16 images of weight matrices, a table of them in one launch (the parameter arena's per-step refresh).
  * Entry: the (R, K) matrix with element (r, k) = src[src_off + r*sr + k*sk] (fp32; any orientation of the master weight)

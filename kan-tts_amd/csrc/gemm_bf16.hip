@@ -174,7 +174,8 @@ extern "C" int kantts_bgemm_nt_lnbwd(const kantts_bgemm_args* gp, const kantts_l
   const kantts_bgemm_args& g = *gp;
   const kantts_lnbwd_args& l = *lp;
   if (g.nseg < 1 || g.nseg > KANTTS_BGEMM_MAX_SEG || g.M < 0) return KANTTS_E_BADARG;
-  if (!l.x || !l.gamma || !l.mean || !l.rstd || !l.dx || !l.dgamma_accum || !l.dbeta_accum) return KANTTS_E_BADARG;
+  if (!l.x || !l.gamma || !l.mean || !l.rstd || !l.dx || (!l.part_rows && (!l.dgamma_accum || !l.dbeta_accum)))
+    return KANTTS_E_BADARG;
   // what the model has: the input gradient of a projection (weights stored (out, in) = [k][n]: b_kn) of LayerNorm-ed rows
   if (g.N != 128 || !g.b_kn || g.ln_out || g.gate || g.relu || g.drop_p > 0.f) return KANTTS_E_UNSUPPORTED;
   if (g.M == 0) return KANTTS_OK;

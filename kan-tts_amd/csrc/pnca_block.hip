@@ -35,6 +35,25 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// Ablation build only (scripts/build_pbdbg.sh, -DPB_DEBUG; never the product library): KANTTS_PB_DBG is a mask of phases to
+// skip -- forward: 1 attention loops, 2 stores of what backward saves (qkv / contexts / y1 / xn1 / hid), 4 feed-forward
+// phases; backward: 1 dgamma / dbeta atomics, 2 output-projection input gradient, 4 LayerNorm backward arithmetic, 8 dz store,
+// 16 gate load.  Timing only: the results are wrong by construction.
+#ifdef PB_DEBUG
+#include <stdlib.h>
+static int pb_dbg_mask() {
+  static const int m = getenv("KANTTS_PB_DBG") ? atoi(getenv("KANTTS_PB_DBG")) : 0;
+  return m;
+}
+#define PB_DBG(bit) ((dbg & (bit)) != 0)
+#define PB_DBG_PARAM , const int dbg
+#define PB_DBG_ARG , pb_dbg_mask()
+#else
+#define PB_DBG(bit) false
+#define PB_DBG_PARAM
+#define PB_DBG_ARG
+#endif
+
 #define PB_THREADS 512
 #define PB_BM 32
 #define PB_HX 16                  // rows in front of the tile whose K / V are recomputed (x band)
@@ -83,7 +102,7 @@ __device__ __forceinline__ float pb_dot16l(const float* a, const float* lrow) {
   return pb_dot16(a, b);
 }
 
-__global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts_pnca_block_args g) {
+__global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts_pnca_block_args g PB_DBG_PARAM) {
   __shared__ __attribute__((aligned(16))) unsigned char As[PB_A_BYTES];
   __shared__ __attribute__((aligned(16))) unsigned char Tr[PB_T_BYTES];
   __shared__ __attribute__((aligned(16))) float Hs[(PB_BM + PB_HH) * PB_KP];
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
           *reinterpret_cast<f32x4*>(&KVs[j * PB_KP + (c0 - PB_C)]) = v;
         }
         const long long m = (long long)m0 - PB_HX + j;
-        if (tb > 0 && m < M && g.qkv) *reinterpret_cast<f32x4*>(g.qkv + m * (3 * PB_C) + c0) = v;
+        if (tb > 0 && m < M && g.qkv && !PB_DBG(2)) *reinterpret_cast<f32x4*>(g.qkv + m * (3 * PB_C) + c0) = v;
       }
     }
   }
@@ -264,6 +283,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
       lo = i;
       hi = min(min(i + bw, L - 1), len - 1);
     }
+    if (PB_DBG(1)) hi = lo - 1;
     // key j of the sequence <-> tile row: x band KVs[row + 16 - (i - j)], memory band Hs[row + (j - i)]
     const float* ktile = (band ? Hs : KVs) + head * PB_DH;
     const int r0 = band ? row - i : row + PB_HX - i;  // tile row of key j is r0 + j
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
 #pragma unroll
       for (int d = 0; d < PB_DH; ++d) o[d] = __builtin_nanf("");
     }
-    if (valid) {
+    if (valid && !PB_DBG(2)) {
       float* od = (band ? g.oh : g.ox) + m * PB_C + head * PB_DH;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -337,7 +357,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = 0.f;
       }
-      if (live[b] && g.y1) *reinterpret_cast<f32x4*>(g.y1 + m * PB_C + n0) = (f32x4){o[0], o[1], o[2], o[3]};
+      if (live[b] && g.y1 && !PB_DBG(2)) *reinterpret_cast<f32x4*>(g.y1 + m * PB_C + n0) = (f32x4){o[0], o[1], o[2], o[3]};
     }
   }
   // LayerNorm(128) of a token: its channels sit in 4 lanes (kg) of each of the 8 waves -> two-pass statistics through LDS
@@ -386,7 +406,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
       const u32x2 pk = {pb_pack2(z0, z1), pb_pack2(z2, z3)};
       *reinterpret_cast<u32x2*>(&Xs[(b * 16 + li) * PB_XP + n0]) = pk;
       if (!live[b]) continue;
-      if (g.xn1) *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.xn1) + m * PB_C + n0) = pk;
+      if (g.xn1 && !PB_DBG(2)) *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.xn1) + m * PB_C + n0) = pk;
       if (wave == 0 && kg == 0 && g.mean1) {
         g.mean1[m] = mu[b];
         g.rstd1[m] = rs[b];
@@ -442,7 +462,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
       }
       // the wave's own 32 columns of the hidden tile -> HBM (a wave's LDS operations execute in order: no barrier)
       KANTTS_WAVE_ORDERED();
-      if (g.hid) {
+      if (g.hid && !PB_DBG(2)) {
         __bf16* tp = reinterpret_cast<__bf16*>(g.hid);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
     };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // PB_F / 256 = 4 steps; the tail pulls in the four units of phase 2
-      mfma1(ring[j], j);
+      if (!PB_DBG(4)) mfma1(ring[j], j);
       load2(ring[j], j);
     }
   }
@@ -470,6 +490,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
       for (int b = 0; b < 2; ++b) acc2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      if (PB_DBG(4)) continue;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         bf16x8 bf[2];
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
 // What crosses rows -- the attention backward, whose key gradients collect queries from neighbouring tiles -- stays a
 // launch of its own (csrc/attn.hip), followed by the QKV input gradient with the first LayerNorm's backward in its
 // epilogue (csrc/gemm_bf16.hip): a block's backward is 3 launches instead of 7.
-__global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts_pnca_block_bwd_args g) {
+__global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts_pnca_block_bwd_args g PB_DBG_PARAM) {
   __shared__ __attribute__((aligned(16))) __bf16 Xs[PB_BM * PB_XP];   // dropout_2(dy) tile, later dropout_fc(g1)
   __shared__ __attribute__((aligned(16))) __bf16 Ts[PB_BM * PB_TP];   // gate tile -> dz tile
   __shared__ __attribute__((aligned(16))) float St[512];
@@ -612,7 +633,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int id = tid + PB_THREADS * it;
-      const long long row = min((long long)m0 + (id >> 7), (long long)M - 1);
+      const long long row = PB_DBG(16) ? 0ll : min((long long)m0 + (id >> 7), (long long)M - 1);
       gq[it] = *reinterpret_cast<const u32x4*>(gp + row * PB_F + (id & 127) * 8);
     }
 #pragma unroll
@@ -684,7 +705,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts
       for (int it = 0; it < 2; ++it) {
         const int i = crow + 16 * it;
         const u32x4 v = *reinterpret_cast<const u32x4*>(&Ts[i * PB_TP + c * 256 + wave * 32 + ccol]);
-        if (m0 + i < M) *reinterpret_cast<u32x4*>(tp + ((long long)m0 + i) * PB_F + c * 256 + wave * 32 + ccol) = v;
+        if (m0 + i < M && !PB_DBG(8)) *reinterpret_cast<u32x4*>(tp + ((long long)m0 + i) * PB_F + c * 256 + wave * 32 + ccol) = v;
       }
     };
 #pragma unroll
@@ -807,7 +828,11 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts
       const u32x2 pk = {pb_pack2(o[0], o[1]), pb_pack2(o[2], o[3])};
       *reinterpret_cast<u32x2*>(&Xs[(b * 16 + li) * PB_XP + n0]) = pk;
     }
-    // dgamma / dbeta of LN1: sum over the tile's 32 tokens (16 lanes x 2), one atomic per channel and workgroup
+    // dgamma / dbeta of LN1: sum over the tile's 32 tokens (16 lanes x 2) -> this workgroup's row of the workspace; the
+    // caller sums the rows (kantts_rows_sum_accum, off the critical path: the sums are parameter gradients).  One atomic per
+    // channel and workgroup instead -- 204 workgroups on the same 256 addresses -- cost 18 of the launch's 35 us, a ticket
+    // counter with agent-scope fences (the last workgroup adds the rows) even more: the release writes back an L2 full of
+    // this launch's own output (profiles/r05_runF_pnca_block_ablation.log, r05_runG_*).
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -816,12 +841,10 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts
         pb[r] += __shfl_xor(pb[r], off, 64);
       }
     }
-    if (li == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        atomicAdd(g.dgamma1 + n0 + r, pg[r]);
-        atomicAdd(g.dbeta1 + n0 + r, pb[r]);
-      }
+    if (li == 0 && !PB_DBG(1)) {
+      float* part = g.ws + (long long)blockIdx.x * (2 * PB_C);
+      *reinterpret_cast<f32x4*>(part + n0) = (f32x4){pg[0], pg[1], pg[2], pg[3]};
+      *reinterpret_cast<f32x4*>(part + PB_C + n0) = (f32x4){pb[0], pb[1], pb[2], pb[3]};
     }
   }
   __syncthreads();  // dropout_fc(g1) tile complete
@@ -833,6 +856,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (PB_DBG(2)) return;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 bf[2];
@@ -879,21 +903,51 @@ extern "C" int kantts_pnca_block_fwd(const kantts_pnca_block_args* gp, void* str
     if (p && !pb_aligned16(p)) return KANTTS_E_UNSUPPORTED;
   const long long M = (long long)g.B * g.L;
   if (M == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(pnca_block_fwd_kernel, dim3(kantts_cdiv(M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(pnca_block_fwd_kernel, dim3(kantts_cdiv(M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g PB_DBG_ARG);
   KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" long long kantts_pnca_block_bwd_ws_floats(int M) {
+  return (long long)kantts_cdiv(M > 0 ? M : 1, PB_BM) * (2 * PB_C);
 }
 
 extern "C" int kantts_pnca_block_bwd(const kantts_pnca_block_bwd_args* gp, void* stream) {
   if (!gp) return KANTTS_E_BADARG;
   const kantts_pnca_block_bwd_args& g = *gp;
   if (!g.dy || !g.hid || !g.y1 || !g.mean1 || !g.rstd1 || !g.ln1_gamma || !g.wt2 || !g.wt1 || !g.wfcxT || !g.wfchT || !g.dz ||
-      !g.g1 || !g.d_ox || !g.d_oh || !g.dgamma1 || !g.dbeta1 || g.M < 0)
+      !g.g1 || !g.d_ox || !g.d_oh || g.M < 0)
     return KANTTS_E_BADARG;
   if (g.C != PB_C || g.F != PB_F) return KANTTS_E_UNSUPPORTED;
-  const void* al[] = {g.dy, g.hid, g.y1, g.ln1_gamma, g.wt2, g.wt1, g.wfcxT, g.wfchT, g.dz, g.g1, g.d_ox, g.d_oh};
+  if (!g.ws || g.ws_floats < kantts_pnca_block_bwd_ws_floats(g.M)) return KANTTS_E_WORKSPACE;
+  const void* al[] = {g.dy, g.hid, g.y1, g.ln1_gamma, g.wt2, g.wt1, g.wfcxT, g.wfchT, g.dz, g.g1, g.d_ox, g.d_oh, g.ws};
   for (const void* p : al)
     if (!pb_aligned16(p)) return KANTTS_E_UNSUPPORTED;
   if (g.M == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(pnca_block_bwd_kernel, dim3(kantts_cdiv(g.M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(pnca_block_bwd_kernel, dim3(kantts_cdiv(g.M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g PB_DBG_ARG);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// dst0[c] += sum_r src[r][c] (c < split), dst1[c - split] += sum_r src[r][c] (c >= split): the partial rows a launch left in
+// a workspace (pnca_block_bwd_kernel: one row of 128 dgamma + 128 dbeta sums per workgroup) summed in a fixed order.  One
+// workgroup per 64 columns; 4 lanes per column walk the rows.
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ src, int rows, int cols, float* dst0,
+                                                      float* dst1, int split) {
+  const int c = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+  float t = 0.f;
+  if (c < cols)
+    for (int r = part; r < rows; r += 4) t += src[(long long)r * cols + c];
+  t += __shfl_xor(t, 1, 64);
+  t += __shfl_xor(t, 2, 64);
+  if (c < cols && part == 0) {
+    float* d = c < split ? dst0 + c : dst1 + (c - split);
+    *d += t;
+  }
+}
+
+extern "C" int kantts_rows_sum_accum(const float* src, int rows, int cols, float* dst0, float* dst1, int split, void* stream) {
+  if (!src || !dst0 || rows < 0 || cols < 0 || split < 0 || split > cols || (split < cols && !dst1)) return KANTTS_E_BADARG;
+  if (rows == 0 || cols == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(rows_sum_kernel, dim3(kantts_cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, src, rows, cols, dst0, dst1,
+                     split);
   KANTTS_CHECK_LAUNCH();
 }

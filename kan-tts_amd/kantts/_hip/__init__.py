@@ -155,6 +155,7 @@ class LnBwdArgs(Structure):
     _fields_ = [
         ("x", c_void_p), ("gamma", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("dres", c_void_p),
         ("zero_rows", c_void_p), ("dx", c_void_p), ("dgamma_accum", c_void_p), ("dbeta_accum", c_void_p),
+        ("part_rows", c_void_p),
     ]
 
 
@@ -241,7 +242,7 @@ class PncaBlockBwdArgs(Structure):
         ("wt2", c_void_p), ("wt1", c_void_p), ("wfcxT", c_void_p), ("wfchT", c_void_p),
         ("alpha1", c_float), ("drop2_p", c_float), ("fc_p", c_float), ("drop2_seed", c_uint64), ("fc_seed", c_uint64),
         ("seed_dev", c_void_p),
-        ("dz", c_void_p), ("g1", c_void_p), ("d_ox", c_void_p), ("d_oh", c_void_p), ("dgamma1", c_void_p), ("dbeta1", c_void_p),
+        ("dz", c_void_p), ("g1", c_void_p), ("d_ox", c_void_p), ("d_oh", c_void_p), ("ws", c_void_p), ("ws_floats", c_int64),
     ]
 
 
@@ -326,6 +327,9 @@ def lib():
         L.kantts_ffn_pair.argtypes = [POINTER(FfnArgs), c_void_p]
         L.kantts_pnca_block_fwd.argtypes = [POINTER(PncaBlockArgs), c_void_p]
         L.kantts_pnca_block_bwd.argtypes = [POINTER(PncaBlockBwdArgs), c_void_p]
+        L.kantts_rows_sum_accum.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]
+        L.kantts_pnca_block_bwd_ws_floats.argtypes = [c_int]
+        L.kantts_pnca_block_bwd_ws_floats.restype = ctypes.c_longlong
         L.kantts_fragmajor_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
         L.kantts_bgemm_tn.argtypes = [POINTER(BGemmTnArgs), c_void_p]
         L.kantts_bgemm_tn_grouped.argtypes = [POINTER(BGemmTnArgs), c_int, p, p, p, p, p, c_void_p]
@@ -372,7 +376,7 @@ EXPORTED_SYMBOLS = [
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
-    "kantts_pnca_block_fwd", "kantts_pnca_block_bwd",
+    "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_accum",
 ]
 
 
@@ -573,8 +577,10 @@ def bgemm_nt(segs, M, N, c, ldc, *, T=0, b_kn=False, bias=None, bias2=None, alph
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if lnb is not None:
-        x, gamma, mean, rstd, dres, zero_rows, dx, dgamma, dbeta = lnb
+        x, gamma, mean, rstd, dres, zero_rows, dx, dgamma, dbeta = lnb[:9]
         l = LnBwdArgs()
+        # optional tenth element: (ceil(M / 32), 256) partial rows of [dgamma | dbeta] instead of atomics into them
+        l.part_rows = ptr(lnb[9], torch.float32) if len(lnb) > 9 else None
         l.x, l.gamma, l.mean, l.rstd = (ptr(t, torch.float32) for t in (x, gamma, mean, rstd))
         l.dres, l.zero_rows = ptr(dres, torch.float32), ptr(zero_rows, torch.uint8)
         l.dx, l.dgamma_accum, l.dbeta_accum = (ptr(t, torch.float32) for t in (dx, dgamma, dbeta))
@@ -644,7 +650,12 @@ def ffn_pair(x, w1, w2, y, *, M, T, F, KT=1, pad=0, bias1=None, bias2=None, relu
     check(rc, "ffn_pair")
     if _profile is not None:
         e1.record()
-        _profile.append((e0, e1, 2.0 * M * F * (x.shape[-1] * KT + NY * KT2)))
+        fl = 2.0 * M * F * (x.shape[-1] * KT + NY * KT2)
+        _profile.append((e0, e1, fl))
+        # x + hidden tile (written forward / read as the gate and written as dz backward) + residual / output + weights
+        nb = M * (x.shape[-1] * x.element_size() + F * 2 * (2 if gate is not None else 1) + NY * 4 * (2 if res is not None else 1)) \
+            + 2 * F * (x.shape[-1] * KT + NY * KT2)
+        _profile_families.append(("ffn_pair", e0, e1, fl, float(nb)))
     return True
 
 
@@ -678,17 +689,31 @@ def pnca_block_fwd(x, xn, hkv, ldh, B, L, *, lens, bw_dev, bw_x, bw_h, rowmask, 
         g.ln2_gamma, g.ln2_beta, g.ln2_eps = ptr(gamma, torch.float32), ptr(beta, torch.float32), float(eps)
         g.ln2_out, g.ln2_out_bf16 = ptr(ln_out), int(ln_out.dtype == torch.bfloat16)
         g.ln2_mean, g.ln2_rstd = ptr(ln_mean, torch.float32), ptr(ln_rstd, torch.float32)
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib().kantts_pnca_block_fwd(ctypes.byref(g), stream())
     if rc == E_UNSUPPORTED:
         return False
     check(rc, "pnca_block_fwd")
+    if _profile is not None:
+        e1.record()
+        M = int(B) * int(L)
+        # SURVEY 8(d)'s per-block count (dense attention: 8 B L^2 128) and the bytes the launch must move once: x, xn, memory
+        # K|V in; qkv, contexts, y1, its normalised rows, hidden tile, output, next normalised rows out; the weights
+        flops = 2.0 * M * 128 * 384 + 8.0 * B * L * L * 128 + 4.0 * M * 128 * 128 + 4.0 * M * 128 * 1024
+        nbytes = M * (128 * 4 + 128 * 2 + 256 * 4 + 384 * 4 + 2 * 128 * 4 + 128 * 4 + 128 * 2 + 1024 * 2 + 128 * 4 + 128 * 2) + \
+            2 * (384 * 128 + 2 * 128 * 128 + 2 * 128 * 1024)
+        _profile.append((e0, e1, flops))
+        _profile_families.append(("pnca_block_fwd", e0, e1, flops, float(nbytes)))
     return True
 
 
 def pnca_block_bwd(dy, hid, y1, mean1, rstd1, gamma1, rowmask, wt2, wt1, wfcxT, wfchT, *, alpha1, drop2_p, drop2_seed, fc_p,
-                   fc_seed, dz, g1, d_ox, d_oh, dgamma1, dbeta1):
+                   fc_seed, dz, g1, d_ox, d_oh):
     """The row-local half of a PNCA block's backward in one launch (csrc/pnca_block.hip; kantts_pnca_block_bwd in the
-    header): feed-forward pair backward, LayerNorm backward + residual, input gradient of the output projection."""
+    header): feed-forward pair backward, LayerNorm backward + residual, input gradient of the output projection.  Returns the
+    (workgroups, 256) partial rows of [dgamma | dbeta] of the LayerNorm: ``rows_sum_accum`` adds them into the gradients."""
     g = PncaBlockBwdArgs()
     g.dy, g.hid, g.y1 = ptr(dy, torch.float32), ptr(hid, torch.bfloat16), ptr(y1, torch.float32)
     g.mean1, g.rstd1, g.ln1_gamma = ptr(mean1, torch.float32), ptr(rstd1, torch.float32), ptr(gamma1, torch.float32)
@@ -700,8 +725,27 @@ def pnca_block_bwd(dy, hid, y1, mean1, rstd1, gamma1, rowmask, wt2, wt1, wfcxT, 
     g.seed_dev = rng_ptr(dy.device) if (drop2_p > 0 or fc_p > 0) else None
     g.dz, g.g1 = ptr(dz, torch.bfloat16), ptr(g1, torch.float32)
     g.d_ox, g.d_oh = ptr(d_ox, torch.float32), ptr(d_oh, torch.float32)
-    g.dgamma1, g.dbeta1 = ptr(dgamma1, torch.float32), ptr(dbeta1, torch.float32)
+    ws = torch.empty(((int(dy.shape[0]) + 31) // 32, 256), device=dy.device, dtype=torch.float32)
+    g.ws, g.ws_floats = ptr(ws, torch.float32), ws.numel()
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().kantts_pnca_block_bwd(ctypes.byref(g), stream()), "pnca_block_bwd")
+    if _profile is not None:
+        e1.record()
+        M = int(dy.shape[0])
+        flops = 4.0 * M * 128 * 1024 + 4.0 * M * 128 * 128
+        nbytes = M * (128 * 4 * 2 + 1024 * 2 * 2 + 128 * 4 * 2 + 2 * 128 * 4) + 2 * (2 * 128 * 1024 + 2 * 128 * 128)
+        _profile.append((e0, e1, flops))
+        _profile_families.append(("pnca_block_bwd", e0, e1, flops, float(nbytes)))
+    return ws
+
+
+def rows_sum_accum(src, dst0, dst1):
+    """dst0 += column sums of src[:, :len(dst0)], dst1 += column sums of the remaining columns (kantts_rows_sum_accum)."""
+    rows, cols = src.shape
+    check(lib().kantts_rows_sum_accum(ptr(src, torch.float32), int(rows), int(cols), ptr(dst0, torch.float32),
+                                      ptr(dst1, torch.float32), int(dst0.numel()), stream()), "rows_sum_accum")
 
 
 TN_MAX_GROUP = 16

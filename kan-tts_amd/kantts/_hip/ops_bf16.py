@@ -16,7 +16,7 @@ import weakref
 
 import torch
 
-from . import bgemm_nt, bgemm_tn, check, ffn_pair, lib, pnca_block_bwd, pnca_block_fwd, ptr, stream
+from . import bgemm_nt, bgemm_tn, check, ffn_pair, lib, pnca_block_bwd, pnca_block_fwd, ptr, rows_sum_accum, stream
 
 BF16 = torch.bfloat16
 _wcache = {}
@@ -178,6 +178,9 @@ class PreNorm:
 # (profiles/r04_runA_lnbwd_per_launch.log): 15.8 us against 17.4 us for the two launches at M = 6528, 11.9 against 14.7 us
 # at M = 2048 -> ON by default.  The feed-forward pair's analogue measured 35.1 us against 23.0 us and was removed.
 LNBWD = {"on": not os.environ.get("KANTTS_NO_LN_BWD_EPILOGUE")}
+
+
+LNB_ROWS = {"on": not os.environ.get("KANTTS_LNB_ATOMICS")}  # A/B switch: partial rows (default) / atomics
 
 
 class LnBwdToken:
@@ -604,9 +607,16 @@ class _FusedLinearB(torch.autograd.Function):
 
                     ldx = torch.empty(tok.x.shape, device=x.device, dtype=torch.float32)
                     ldg, ldb = gzeros_like(tok.gamma), gzeros_like(tok.gamma)
+                    # dgamma / dbeta leave the launch as one partial row per workgroup and are summed beside the critical path
+                    # (256 atomics per workgroup onto the same 256 addresses cost more than the contraction itself)
+                    part = torch.empty(((M + 31) // 32, 256), device=x.device, dtype=torch.float32) if LNB_ROWS["on"] else None
                     if bgemm_nt([(dz, N, (wb, woff), wld, N, 0)], M, kk, None, kk, b_kn=True, a_drop_ld=N, c_bf16=True,
                                 lnb=(tok.x.view(M, 128), tok.gamma, tok.mean, tok.rstd,
-                                     None if tok.dres is None else _c(tok.dres).view(M, 128), tok.zero_rows, ldx, ldg, ldb)):
+                                     None if tok.dres is None else _c(tok.dres).view(M, 128), tok.zero_rows, ldx, ldg, ldb)
+                                + ((part,) if part is not None else ())):
+                        if part is not None:
+                            with wgrad_overlap.side(part):
+                                rows_sum_accum(part, ldg, ldb)
                         tok.dx, tok.dg, tok.db, tok.placeholder = ldx, ldg, ldb, x
                         dxs[k] = x  # stand-in: the LayerNorm node returns tok.dx and never reads this
                 rtok = opts.get("relugate") if (needs[5 + k] and dxs[k] is None and nx == 1) else None
@@ -851,9 +861,13 @@ class _FusedFFNB(torch.autograd.Function):
             plan.d_ox = torch.empty((M, N), device=dev, dtype=torch.float32)
             plan.d_oh = torch.empty((M, N), device=dev, dtype=torch.float32)
             plan.dg1, plan.db1 = gzeros_like(plan.gamma1), gzeros_like(plan.gamma1)
-            pnca_block_bwd(dy, hid, plan.y1, plan.mean1, plan.rstd1, plan.gamma1.detach(), plan.rows, wt2, wt1, plan.wfcxT,
-                           plan.wfchT, alpha1=a1, drop2_p=p_out, drop2_seed=s2, fc_p=plan.fc_p, fc_seed=plan.fc_seed, dz=dz,
-                           g1=plan.g1, d_ox=plan.d_ox, d_oh=plan.d_oh, dgamma1=plan.dg1, dbeta1=plan.db1)
+            part = pnca_block_bwd(dy, hid, plan.y1, plan.mean1, plan.rstd1, plan.gamma1.detach(), plan.rows, wt2, wt1,
+                                  plan.wfcxT, plan.wfchT, alpha1=a1, drop2_p=p_out, drop2_seed=s2, fc_p=plan.fc_p,
+                                  fc_seed=plan.fc_seed, dz=dz, g1=plan.g1, d_ox=plan.d_ox, d_oh=plan.d_oh)
+            # the LayerNorm's dgamma / dbeta: per-workgroup partial rows, summed beside the critical path like every other
+            # parameter gradient (the side stream of the weight gradients when that is on)
+            with wgrad_overlap.side(part):
+                rows_sum_accum(part, plan.dg1, plan.db1)
             plan.placeholder, plan.d_res = hb, d_res
             plan.y1 = plan.mean1 = plan.rstd1 = plan.wfcxT = plan.wfchT = None
             dh, fused = hb, True  # stand-in: the LayerNorm node returns plan.g1 and never reads this

@@ -371,6 +371,14 @@ class EmulatedLib:
         if l.zero_rows:
             DX = DX * torch.from_numpy((_arr(l.zero_rows, M, np.uint8) == 0).astype(np.float32))[:, None]
         _arr(l.dx, M * C)[:] = DX.reshape(-1).numpy()
+        part = getattr(l, "part_rows", None)
+        if part:  # one row of partial sums per 32-row tile instead of the accumulators
+            nwg = (M + 31) // 32
+            ws = _arr(part, nwg * 256).reshape(nwg, 256)
+            pad = nwg * 32 - M
+            ws[:, :C] = torch.nn.functional.pad(DY * xh, (0, 0, 0, pad)).view(nwg, 32, C).sum(1).numpy()
+            ws[:, C:] = torch.nn.functional.pad(DY, (0, 0, 0, pad)).view(nwg, 32, C).sum(1).numpy()
+            return
         _arr(l.dgamma_accum, C)[:] += (DY * xh).sum(0).numpy()
         _arr(l.dbeta_accum, C)[:] += DY.sum(0).numpy()
 
@@ -540,6 +548,19 @@ class EmulatedLib:
             _arr(g.ln2_rstd, M)[:] = rs2
         return 0
 
+    def kantts_pnca_block_bwd_ws_floats(self, M):
+        return ((max(int(M), 1) + 31) // 32) * 256
+
+    def kantts_rows_sum_accum(self, src, rows, cols, dst0, dst1, split, stream):
+        if rows == 0 or cols == 0:
+            return 0
+        t = _arr(src, rows * cols).reshape(rows, cols).sum(0).astype(np.float32)
+        if split:
+            _arr(dst0, split)[:] += t[:split]
+        if cols > split:
+            _arr(dst1, cols - split)[:] += t[split:]
+        return 0
+
     def kantts_pnca_block_bwd(self, args_ref, stream):
         """csrc/pnca_block.hip: feed-forward pair backward + LayerNorm backward (+ residual, row mask) + input gradient of the
         output projection, with the bf16 roundings of the separate launches."""
@@ -572,8 +593,11 @@ class EmulatedLib:
         g1 = rs[:, None] * (gg - s1 - xh * s2) + _rd2d(g.dy, M, C, C, False)
         g1 = np.where(mask[:, None], 0, g1).astype(np.float32)
         _wr(g.g1, g1, False)
-        _arr(g.dgamma1, C)[:] += (dh * xh).sum(0).astype(np.float32)
-        _arr(g.dbeta1, C)[:] += dh.sum(0).astype(np.float32)
+        nwg = (M + 31) // 32  # partial rows, one per 32-row tile
+        ws = _arr(g.ws, nwg * 2 * C).reshape(nwg, 2 * C)
+        pad = nwg * 32 - M
+        ws[:, :C] = np.pad(dh * xh, ((0, pad), (0, 0))).reshape(nwg, 32, C).sum(1)
+        ws[:, C:] = np.pad(dh, ((0, pad), (0, 0))).reshape(nwg, 32, C).sum(1)
         gd = g1
         if g.fc_p > 0:
             gd = gd * dropout_scale(g.fc_p, g.fc_seed + soff, rows[:, None] * C + cols[None, :])
