@@ -803,8 +803,17 @@ typedef struct kantts_pnca_block_bwd_args {
 } kantts_pnca_block_bwd_args;
 int kantts_pnca_block_bwd(const kantts_pnca_block_bwd_args* args, void* stream);
 long long kantts_pnca_block_bwd_ws_floats(int M);
-/* dst0[c] += sum_r src[r*cols + c] for c < split, dst1[c - split] += ... for c >= split (fixed summation order). */
-int kantts_rows_sum_accum(const float* src, int rows, int cols, float* dst0, float* dst1, int split, void* stream);
+/* For each of n problems: dst0[c] += sum_r src[r*cols + c] for c < split, dst1[c - split] += ... for c >= split (fixed
+ * summation order) -- the partial rows of kantts_pnca_block_bwd / kantts_bgemm_nt_lnbwd, many of them in one launch. */
+#define KANTTS_ROWSUM_MAX 32
+typedef struct kantts_rowsum_args {
+  int32_t n, cols, split;
+  int32_t rows[KANTTS_ROWSUM_MAX];
+  const float* src[KANTTS_ROWSUM_MAX];
+  float* dst0[KANTTS_ROWSUM_MAX];
+  float* dst1[KANTTS_ROWSUM_MAX];
+} kantts_rowsum_args;
+int kantts_rows_sum_many(const kantts_rowsum_args* args, void* stream);
 
 /* Fragment-major bf16 images of weight matrices, a table of them in one launch (the parameter arena's per-step refresh).
  * Entry: the (R, K) matrix with element (r, k) = src[src_off + r*sr + k*sk] (fp32; any orientation of the master weight)

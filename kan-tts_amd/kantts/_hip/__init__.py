@@ -246,6 +246,15 @@ class PncaBlockBwdArgs(Structure):
     ]
 
 
+ROWSUM_MAX = 32
+
+
+class RowSumArgs(Structure):
+    """kantts_rowsum_args (include/kantts_hip.h)."""
+    _fields_ = [("n", c_int32), ("cols", c_int32), ("split", c_int32), ("rows", c_int32 * ROWSUM_MAX),
+                ("src", c_void_p * ROWSUM_MAX), ("dst0", c_void_p * ROWSUM_MAX), ("dst1", c_void_p * ROWSUM_MAX)]
+
+
 class FragMajorDesc(Structure):
     """kantts_fragmajor_desc (include/kantts_hip.h)."""
     _fields_ = [("src_off", c_int64), ("dst_off", c_int64), ("sr", c_int64), ("sk", c_int64), ("R", c_int32),
@@ -327,7 +336,7 @@ def lib():
         L.kantts_ffn_pair.argtypes = [POINTER(FfnArgs), c_void_p]
         L.kantts_pnca_block_fwd.argtypes = [POINTER(PncaBlockArgs), c_void_p]
         L.kantts_pnca_block_bwd.argtypes = [POINTER(PncaBlockBwdArgs), c_void_p]
-        L.kantts_rows_sum_accum.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]
+        L.kantts_rows_sum_many.argtypes = [POINTER(RowSumArgs), c_void_p]
         L.kantts_pnca_block_bwd_ws_floats.argtypes = [c_int]
         L.kantts_pnca_block_bwd_ws_floats.restype = ctypes.c_longlong
         L.kantts_fragmajor_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
@@ -376,7 +385,7 @@ EXPORTED_SYMBOLS = [
     "kantts_ragged_rows_f32", "kantts_ragged_rows_i64", "kantts_weight_norm_tap_images",
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
-    "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_accum",
+    "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
 ]
 
 
@@ -741,11 +750,32 @@ def pnca_block_bwd(dy, hid, y1, mean1, rstd1, gamma1, rowmask, wt2, wt1, wfcxT, 
     return ws
 
 
+def rows_sum_many(problems):
+    """problems: list of (src (rows, 256), dst0 (128), dst1 (128)): dst0 += column sums of src[:, :128], dst1 += those of
+    src[:, 128:], up to ROWSUM_MAX problems per launch (kantts_rows_sum_many)."""
+    for s0 in range(0, len(problems), ROWSUM_MAX):
+        chunk = problems[s0:s0 + ROWSUM_MAX]
+        g = RowSumArgs()
+        g.n, g.cols, g.split = len(chunk), 256, 128
+        for i, (src, d0, d1) in enumerate(chunk):
+            assert src.dim() == 2 and src.shape[1] == 256 and src.is_contiguous()
+            g.rows[i] = int(src.shape[0])
+            g.src[i], g.dst0[i], g.dst1[i] = _addr(src), _addr(d0), _addr(d1)
+        check(lib().kantts_rows_sum_many(ctypes.byref(g), stream()), "rows_sum_many")
+
+
 def rows_sum_accum(src, dst0, dst1):
-    """dst0 += column sums of src[:, :len(dst0)], dst1 += column sums of the remaining columns (kantts_rows_sum_accum)."""
-    rows, cols = src.shape
-    check(lib().kantts_rows_sum_accum(ptr(src, torch.float32), int(rows), int(cols), ptr(dst0, torch.float32),
-                                      ptr(dst1, torch.float32), int(dst0.numel()), stream()), "rows_sum_accum")
+    """dst0 (128) += column sums of src[:, :128], dst1 (128) += column sums of src[:, 128:]: the per-workgroup partial rows of
+    a LayerNorm's dgamma / dbeta (kantts_pnca_block_bwd, kantts_bgemm_nt_lnbwd).  Parameter gradients: when weight gradients
+    are deferred (deferred_tn.enabled: the captured step) the problem is only recorded and every recorded one leaves in ONE
+    launch at the next flush, on the weight gradients' side stream -- a fork of the stream per call would put a cross-queue
+    dependency (~7 us in a replayed graph) into the backward chain of every block."""
+    if deferred_tn.enabled:
+        # outputs only through their storages: autograd adopts dst0 / dst1 as p.grad only while nobody else references the
+        # tensor objects (see bgemm_tn below)
+        deferred_tn.rowsums.append((src, deferred_tn._desc(dst0), deferred_tn._desc(dst1)))
+        return
+    rows_sum_many([(src, dst0, dst1)])
 
 
 TN_MAX_GROUP = 16
@@ -764,6 +794,7 @@ class _DeferredTN:
         self.enabled = False
         self.groups = {}
         self.copies = []
+        self.rowsums = []  # (partial rows, descriptor of dgamma, descriptor of dbeta): rows_sum_accum
 
     def add(self, key, g, a, b, c, db, seed, keep):
         self.groups.setdefault(key, []).append((g, a, b, c, db, seed, keep))
@@ -795,11 +826,14 @@ class _DeferredTN:
         the tail of the captured step) over four streams was measured: 7.12 ms against 7.14 ms on one stream, same box
         (profiles/r04_runP_direct_grads_and_spread_flush_ab.log) -- the launches are bound by their fp32 atomics, not by
         idle CUs.  Removed."""
-        if not self.groups and not self.copies:
+        if not self.groups and not self.copies and not self.rowsums:
             return
         groups, self.groups = self.groups, {}
         copies, self.copies = self.copies, []
+        rowsums, self.rowsums = self.rowsums, []
         self._launch([probs[s:s + TN_MAX_GROUP] for probs in groups.values() for s in range(0, len(probs), TN_MAX_GROUP)])
+        if rowsums:
+            rows_sum_many([(src, self._rebuild(d0), self._rebuild(d1)) for src, d0, d1 in rowsums])
         if copies:
             torch._foreach_copy_([self._rebuild(d) for d, _ in copies], [self._rebuild(s) for _, s in copies])
 

@@ -180,10 +180,11 @@ class _WgradOverlap:
         middle of backward): they then run beside the rest of the backward chain instead of after it."""
         from . import deferred_tn
 
-        if not self.enabled or not (deferred_tn.groups or deferred_tn.copies):
+        if not self.enabled or not (deferred_tn.groups or deferred_tn.copies or deferred_tn.rowsums):
             return
         # operands were allocated on the main stream; flush() drops its references once the launches are issued
         keep = [k for probs in deferred_tn.groups.values() for q in probs for k in q[6] if k is not None]
+        keep += [r[0] for r in deferred_tn.rowsums]
         with self.side(*keep):
             deferred_tn.flush()
 

@@ -568,7 +568,7 @@ class _FusedLinearB(torch.autograd.Function):
                 raise RuntimeError("the input gradient of a fused PNCA block's output projection was computed by the block's "
                                    "backward launch, but autograd delivers another gradient than the one that launch produced")
             dxs = [plan.d_ox.view(xs[0].shape), plan.d_oh.view(xs[1].shape)]
-            plan.g1 = plan.d_ox = plan.d_oh = plan.dg1 = plan.db1 = None
+            plan.g1 = plan.d_ox = plan.d_oh = None
         dbias = gzeros((N,), dy.device) if (has_bias or has_bias2) else None
         first = True
         kw = dict(alpha=balpha, a_drop_p=a_drop_p, a_drop_seed=a_seed)
@@ -615,8 +615,7 @@ class _FusedLinearB(torch.autograd.Function):
                                      None if tok.dres is None else _c(tok.dres).view(M, 128), tok.zero_rows, ldx, ldg, ldb)
                                 + ((part,) if part is not None else ())):
                         if part is not None:
-                            with wgrad_overlap.side(part):
-                                rows_sum_accum(part, ldg, ldb)
+                            rows_sum_accum(part, ldg, ldb)
                         tok.dx, tok.dg, tok.db, tok.placeholder = ldx, ldg, ldb, x
                         dxs[k] = x  # stand-in: the LayerNorm node returns tok.dx and never reads this
                 rtok = opts.get("relugate") if (needs[5 + k] and dxs[k] is None and nx == 1) else None
@@ -721,8 +720,10 @@ class _LayerNorm128(torch.autograd.Function):
                 raise RuntimeError("the LayerNorm backward of a fused PNCA block was computed by the block's backward launch, "
                                    "but autograd delivers other gradients than the ones that launch saw: the normalised rows "
                                    "(or the residual output) have a second consumer")
+            # (autograd adopts dg1 / db1 as p.grad only while nobody else references the tensor objects; a clone would be taken
+            # before the deferred row sums have filled them)
             out = (plan.g1.view(x.shape), plan.dg1, plan.db1)
-            plan.placeholder = plan.d_res = None
+            plan.placeholder = plan.d_res = plan.dg1 = plan.db1 = None
             return (*out, None, None, None, None, None, None, None, None, None)
         if tok is not None and tok.dx is not None:  # done by the consumer's input-gradient launch (LnBwdToken)
             if not _same_tensor(dy, tok.placeholder) or (tok.with_res and not _same_tensor(dres, tok.dres)) or (
@@ -864,10 +865,9 @@ class _FusedFFNB(torch.autograd.Function):
             part = pnca_block_bwd(dy, hid, plan.y1, plan.mean1, plan.rstd1, plan.gamma1.detach(), plan.rows, wt2, wt1,
                                   plan.wfcxT, plan.wfchT, alpha1=a1, drop2_p=p_out, drop2_seed=s2, fc_p=plan.fc_p,
                                   fc_seed=plan.fc_seed, dz=dz, g1=plan.g1, d_ox=plan.d_ox, d_oh=plan.d_oh)
-            # the LayerNorm's dgamma / dbeta: per-workgroup partial rows, summed beside the critical path like every other
-            # parameter gradient (the side stream of the weight gradients when that is on)
-            with wgrad_overlap.side(part):
-                rows_sum_accum(part, plan.dg1, plan.db1)
+            # the LayerNorm's dgamma / dbeta: per-workgroup partial rows, summed like every other parameter gradient (deferred:
+            # one launch for all recorded sums at the next flush of the weight gradients)
+            rows_sum_accum(part, plan.dg1, plan.db1)
             plan.placeholder, plan.d_res = hb, d_res
             plan.y1 = plan.mean1 = plan.rstd1 = plan.wfcxT = plan.wfchT = None
             dh, fused = hb, True  # stand-in: the LayerNorm node returns plan.g1 and never reads this

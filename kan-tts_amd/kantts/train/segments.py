@@ -102,7 +102,7 @@ class SegmentedCapture:
         """After a failed capture: leave no stream in capture mode and no arena armed."""
         from kantts._hip import deferred_tn
 
-        deferred_tn.groups, deferred_tn.copies = {}, []
+        deferred_tn.groups, deferred_tn.copies, deferred_tn.rowsums = {}, [], []
         self._restore_arenas()
         try:
             with torch.cuda.stream(self.stream):

@@ -551,14 +551,17 @@ class EmulatedLib:
     def kantts_pnca_block_bwd_ws_floats(self, M):
         return ((max(int(M), 1) + 31) // 32) * 256
 
-    def kantts_rows_sum_accum(self, src, rows, cols, dst0, dst1, split, stream):
-        if rows == 0 or cols == 0:
-            return 0
-        t = _arr(src, rows * cols).reshape(rows, cols).sum(0).astype(np.float32)
-        if split:
-            _arr(dst0, split)[:] += t[:split]
-        if cols > split:
-            _arr(dst1, cols - split)[:] += t[split:]
+    def kantts_rows_sum_many(self, args_ref, stream):
+        g = args_ref._obj
+        for i in range(g.n):
+            rows = g.rows[i]
+            if rows == 0 or g.cols == 0:
+                continue
+            t = _arr(g.src[i], rows * g.cols).reshape(rows, g.cols).sum(0).astype(np.float32)
+            if g.split:
+                _arr(g.dst0[i], g.split)[:] += t[:g.split]
+            if g.cols > g.split:
+                _arr(g.dst1[i], g.cols - g.split)[:] += t[g.split:]
         return 0
 
     def kantts_pnca_block_bwd(self, args_ref, stream):

@@ -5,7 +5,7 @@ T=${1:-r5i}
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for v in fused fwdonly; do
+for v in fused; do
   unset KANTTS_NO_PNCA_BLOCK_BWD
   [ $v = fwdonly ] && export KANTTS_NO_PNCA_BLOCK_BWD=1
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${T}_prof_$v -o bench -- python $R/bench.py --no-hifigan --no-inference --no-cpu-baseline --no-fp32 --no-roofline --no-forward-only --steps 10 --warmup 2 > $R/gpurun_out/${T}_rocprof_$v.log 2>&1

@@ -34,7 +34,7 @@ def _global_switches_off():
     import kantts._hip as hip
     import kantts._hip.ops as ops
 
-    hip.deferred_tn.groups, hip.deferred_tn.copies = {}, []  # drop, never launch, whatever a failed test left behind
+    hip.deferred_tn.groups, hip.deferred_tn.copies, hip.deferred_tn.rowsums = {}, [], []  # drop whatever a failed test left
     ops.wgrad_overlap.enabled = False
     hip.deferred_tn.enabled = False
     ops.side_branch.enabled = False
