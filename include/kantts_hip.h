@@ -286,6 +286,12 @@ int kantts_melspec_bwd_fm(const float* wav, const float* dmel, int B, int T, int
                           const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels, float eps_mel,
                           int mel_frame_major, float* dwav_accum, void* stream);
 
+/* [round 5] The two knobs of the mel-STFT launchers, explicit instead of environment variables read on every launch: grid_cap
+ * > 0 caps the persistent grid of the register-resident n_fft 1024 kernel (0 = default, 768 workgroups) -- sweeps, and the
+ * tests that must reach its several-pairs-per-wave loop with small inputs; generic_only != 0 routes every size to the radix-2
+ * kernel (A/B, tests).  Process-global; the only state the library keeps. */
+int kantts_melspec_tuning(int grid_cap, int generic_only);
+
 /* Backward of the mel path of kantts_melspec_fwd (MelSpectrogramLoss on generated audio, kantts/train/loss.py:
  * 259-311): dwav_accum (B,T) += d loss / d wav given dmel (B, n_mels, frames).  The spectrum is recomputed. */
 int kantts_melspec_bwd(const float* wav, const float* dmel, int B, int T, int n_fft, int hop, int frames,

@@ -11,6 +11,8 @@
 //   * the mel filterbank is applied in its sparse (triangular support) form straight from LDS;
 //   * each thread owns one mel channel and stores MEL_FB consecutive frames (contiguous in the
 //     (B, n_mels, frames) output) at once.
+#include <atomic>
+
 #include "common.h"
 
 #define MEL_FB 4
@@ -524,6 +526,17 @@ __global__ __launch_bounds__(64 * MELR_WAVES, 3) void melspec_reg_kernel(const M
   }
 }
 
+// The launchers consult no environment variable (the ABI is stateless apart from these two explicit knobs, which exist for
+// sweeps and for the tests that must reach the persistent-grid loop and the radix-2 kernel): kantts_melspec_tuning sets them.
+static std::atomic<int> mel_grid_cap{0}, mel_generic_only{0};
+
+extern "C" int kantts_melspec_tuning(int grid_cap, int generic_only) {
+  if (grid_cap < 0) return KANTTS_E_BADARG;
+  mel_grid_cap.store(grid_cap, std::memory_order_relaxed);
+  mel_generic_only.store(generic_only ? 1 : 0, std::memory_order_relaxed);
+  return KANTTS_OK;
+}
+
 static int melspec_reg_launch(const MelArgs& a, hipStream_t st) {
   const int pairs = kantts_cdiv(a.frames, 2);
   const long long items_ll = (long long)a.B * pairs;
@@ -531,8 +544,8 @@ static int melspec_reg_launch(const MelArgs& a, hipStream_t st) {
   const int items = (int)items_ll;
   const size_t lds = ((size_t)MELR_CHMAX * MELR_CH + MELR_CHMAX + 132 + 3 * MELR_M + (size_t)MELR_WAVES * (4 * MELR_XB)) * sizeof(float);
   // persistent grid: every workgroup resident (three per CU: 168 VGPRs, 52.8 KB of LDS), waves stride over the pairs of frames
-  const int cap_env = getenv("KANTTS_MEL_WGS") ? atoi(getenv("KANTTS_MEL_WGS")) : 0;  // sweep switch (scripts/mel_bench.py)
-  const int cap = cap_env > 0 ? cap_env : 768;
+  const int cap_set = mel_grid_cap.load(std::memory_order_relaxed);  // kantts_melspec_tuning (sweeps / tests); 0 = default
+  const int cap = cap_set > 0 ? cap_set : 768;
   int grid = kantts_cdiv(items, MELR_WAVES);
   if (grid > cap) grid = cap;
   hipLaunchKernelGGL(melspec_reg_kernel, dim3(grid), dim3(64 * MELR_WAVES), lds, st, a, items, pairs);
@@ -597,7 +610,7 @@ extern "C" int kantts_melspec_norm_fwd_fm(const float* wav, int B, int T, int n_
   int m = n_fft >> 1, l2 = 0;
   while ((1 << l2) < m) ++l2;
   a.log2m = l2;
-  const bool generic_only = getenv("KANTTS_MEL_GENERIC") != nullptr;  // A/B switch and tests (read per call)
+  const bool generic_only = mel_generic_only.load(std::memory_order_relaxed) != 0;  // kantts_melspec_tuning (A/B, tests)
   if (!generic_only && n_fft == 2 * MELR_M && (!out_mel || n_mels <= 64 * MELR_SLOTS)) return melspec_reg_launch(a, (hipStream_t)stream);
   size_t lds = (size_t)m * 2 * sizeof(float2) + (size_t)(m + 1) * sizeof(float);
   if (lds > 160 * 1024) return KANTTS_E_UNSUPPORTED;

@@ -386,6 +386,7 @@ EXPORTED_SYMBOLS = [
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
+    "kantts_melspec_tuning",
 ]
 
 

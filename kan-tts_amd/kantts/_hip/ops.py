@@ -325,8 +325,8 @@ class _SideBranch:
         self._open = False
 
     class _Ctx:
-        def __init__(self, owner, keep):
-            self.owner, self.keep, self.cm = owner, keep, None
+        def __init__(self, owner, keep, after=None):
+            self.owner, self.keep, self.cm, self.after = owner, keep, None, after
 
         def __enter__(self):
             o = self.owner
@@ -334,8 +334,10 @@ class _SideBranch:
                 return self
             if o._stream is None:
                 o._stream = _new_side_stream()
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            ev = self.after
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
             o._stream.wait_event(ev)
             self.cm = torch.cuda.stream(o._stream)
             self.cm.__enter__()
@@ -348,8 +350,19 @@ class _SideBranch:
                 self.cm.__exit__(*exc)
             return False
 
-    def fork(self, *keep):
-        return _SideBranch._Ctx(self, keep)
+    def fork(self, *keep, after=None):
+        """``after``: an event recorded (``mark()``) where the branch's inputs became ready; the branch then waits for THAT
+        point of the issuing stream, not for everything issued since -- a branch that is issued late (so that autograd issues
+        its backward early) is still a parallel branch from where its inputs were produced."""
+        return _SideBranch._Ctx(self, keep, after)
+
+    def mark(self):
+        """An event on the current stream at this point (None when the side branch is off)."""
+        if not self.enabled or not torch.cuda.is_available():
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
 
     def join(self):
         if self._open:

@@ -42,6 +42,15 @@ _BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "prenet")
 # (whose LSTM leaves 7/8 of the chip idle) instead of beside the decoder: 7.65 -> 7.60 ms (profiles/
 # r03_runAK_predictors_late.log); KANTTS_PREDICTORS_EARLY restores the round-2 placement
 _PREDICTORS_LATE = not os.environ.get("KANTTS_PREDICTORS_EARLY")
+# [round 5] experiment switch KANTTS_PREDICTORS_AFTER_POSTNET=1: issue the predictors after the postnet's launches, so that
+# autograd (which issues backward nodes newest first) issues their backward BEFORE the postnet's and it could run beside the
+# postnet's 612-step LSTM backward (0.5 ms on 32 of 256 CUs with nothing beside it).  Measured (profiles/r05_runL_*): the
+# replayed hipGraph runs the two branches one after the other in capture order either way -- 6.74-6.89 ms against 6.45 ms
+# for the round-4 order on the same box -- so the round-4 order stays.
+_PREDICTORS_AFTER_POSTNET = bool(os.environ.get("KANTTS_PREDICTORS_AFTER_POSTNET"))
+# experiment switch KANTTS_EARLY_FORK=1: the predictor branch forks where its inputs became ready (beside the decoder) instead
+# of where it is issued.  Measured 6.41-6.46 against 6.40-6.42 ms, forward 1.89 against 1.86 ms (profiles/r05_runM_*): off.
+_EARLY_FORK = bool(os.environ.get("KANTTS_EARLY_FORK"))
 _FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "4"))}
 
 
@@ -295,8 +304,11 @@ class VarianceAdaptor(nn.Module):
                     else torch.log(F.pad(duration_targets[:, :-1].float(), (1, 0)) + 1).unsqueeze(-1))
             log_duration_predictions = None
             if late:
+                ready = ops.side_branch.mark() if _EARLY_FORK else None  # the predictors' inputs exist from here on
+
                 def deferred():
-                    with ops.side_branch.fork(variance_predictor_inputs, duration_predictor_cond, prev, *(lens_keep or ())):
+                    with ops.side_branch.fork(variance_predictor_inputs, duration_predictor_cond, prev, *(lens_keep or ()),
+                                              after=ready):
                         p_ = self.pitch_predictor(variance_predictor_inputs, info)
                         e_ = self.energy_predictor(variance_predictor_inputs, info)
                         d_, _ = self.duration_predictor(prev, duration_predictor_cond, masks=info)
@@ -660,11 +672,14 @@ class KanTtsSAMBERT(nn.Module):
         dec_outputs = ops.wgrad_flush_point(dec_outputs.masked_fill(rows.unsqueeze(-1), 0))  # postnet weight gradients
         post_info = out_info if out_info.mask.size(1) == dec_outputs.size(1) else SeqInfo(out_info.lens64,
                                                                                          dec_outputs.size(1))
-        if getattr(self.variance_adaptor, "deferred", None) is not None:
-            log_duration_predictions, pitch_predictions, energy_predictions = self.variance_adaptor.deferred()
-            self.variance_adaptor.deferred = None
+        deferred = getattr(self.variance_adaptor, "deferred", None)
+        if deferred is not None and not _PREDICTORS_AFTER_POSTNET:
+            log_duration_predictions, pitch_predictions, energy_predictions = deferred()
         # postnet residual add + final masking ride in the epilogue of the last GEMM
         postnet_outputs = self.mel_postnet(dec_outputs, post_info, res=dec_outputs, zero_rows=post_info.mask)
+        if deferred is not None and _PREDICTORS_AFTER_POSTNET:
+            log_duration_predictions, pitch_predictions, energy_predictions = deferred()
+        self.variance_adaptor.deferred = None
         ops.side_branch.join()  # the predictors' outputs are read from here on (losses)
         res = {
             "x_band_width": x_band_width,

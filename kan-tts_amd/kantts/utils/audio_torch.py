@@ -7,6 +7,8 @@ definition; the kernel consumes it in support form (start, length, packed weight
 import math
 
 import numpy as np
+import os
+
 import torch
 
 from kantts._hip import check, lib, ptr, stream
@@ -130,6 +132,20 @@ class _StftMagFn(torch.autograd.Function):
         return dwav, None
 
 
+_tuning = [None]
+
+
+def _apply_tuning():
+    """KANTTS_MEL_WGS (grid cap of the register-resident kernel) / KANTTS_MEL_GENERIC (radix-2 kernel only): sweep and test
+    switches, read HERE (the host layer) and handed to the library through kantts_melspec_tuning when they change -- the
+    C ABI itself consults no environment."""
+    L = lib()
+    want = (id(L), int(os.environ.get("KANTTS_MEL_WGS", "0") or 0), int(bool(os.environ.get("KANTTS_MEL_GENERIC"))))
+    if want != _tuning[0]:
+        check(L.kantts_melspec_tuning(want[1], want[2]), "melspec_tuning")
+        _tuning[0] = want
+
+
 def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, eps_mel=0.0, want_mag=False, norm=None):
     """norm: optional (ref_level_db, min_level_db, max_norm, symmetric) for the dB normalisation (forward only)."""
     if x.requires_grad:
@@ -155,6 +171,7 @@ def _launch(x, n_fft, hop, win_length, window, pad_mode, eps_power, mel=None, ep
         out_mag = torch.empty((B, frames, n_fft // 2 + 1), device=x.device, dtype=torch.float32)
     # MelSpectrogram.forward's fixed normalisation (ref 20 dB, floor -100 dB, symmetric +-4) unless the caller names one
     ref_db, min_db, max_norm, symmetric = norm if norm is not None else (20.0, -100.0, 4.0, True)
+    _apply_tuning()
     check(lib().kantts_melspec_norm_fwd_fm(ptr(x, torch.float32), B, T, n_fft, hop, frames, pad_mode, ptr(wpad), ptr(tw),
                                            float(eps_power), ptr(ms), ptr(ml), ptr(mo), ptr(mw), n_mels, float(eps_mel),
                                            float(ref_db), float(min_db), float(max_norm), int(bool(symmetric)), 1,

@@ -551,6 +551,9 @@ class EmulatedLib:
     def kantts_pnca_block_bwd_ws_floats(self, M):
         return ((max(int(M), 1) + 31) // 32) * 256
 
+    def kantts_melspec_tuning(self, grid_cap, generic_only):
+        return 0  # launch-shape knobs: nothing to model
+
     def kantts_rows_sum_many(self, args_ref, stream):
         g = args_ref._obj
         for i in range(g.n):
