@@ -198,6 +198,40 @@ int kantts_embed_sum_fwd(const float* const* tables_host, int ntab, const int64_
                          float* out, float* scaled_out, int rows, int T, int D, float scale, void* stream);
 int kantts_embed_sum_bwd(float* const* dtables_host, int ntab, const int64_t* ids, const float* dout, int rows,
                          int D, float scale, void* stream);
+/* [round 5] The length- / target-only preparation of a teacher-forced SAM-BERT step in one launch (csrc/seq.hip;
+ * kantts/models/utils.py:13-23, kantts_sambert.py:466-468, 556-559, 736-750, 981-985, positions.py:83-98):
+ *   in / out / lfr: lengths clamped to N / T_mel / Tp/r as int64 and int32, and masks (uint8, 1 = padding) of shapes (B, N),
+ *     (B, T_mel), (B, Tp/r) -- lfr lengths are ceil(out_lens / r);  valid[b] = min(out length, max_len);
+ *   pos_enc (B, Tp, depth): sin (even channels) / cos (odd) of pos_masked / inv_ts[c], pos = kantts_lr_index's, masked to 0
+ *     from frame min(out length, max_len) on;  prev (B, N) = log(dur[b, n-1] + 1) (0 for n = 0);
+ *   bw_val = max over valid (b, n) of dur / r + 0.5 (fp32), bw_dev = its truncation (int32);
+ *   dec_input (B, Tp/r, d_mel): row 0 zeros, row l = mel[b, l*r - 1]. */
+typedef struct kantts_plan_args {
+  const int64_t* in_lens;
+  const int64_t* out_lens;
+  const int64_t* dur;
+  const float* mel;
+  const float* pos;
+  const float* inv_ts;
+  int32_t B, N, T_mel, Tp, max_len, r, d_mel, depth;
+  int64_t* in_l64;
+  int32_t* in_l32;
+  uint8_t* in_mask;
+  int64_t* out_l64;
+  int32_t* out_l32;
+  uint8_t* out_mask;
+  int64_t* lfr_l64;
+  int32_t* lfr_l32;
+  uint8_t* lfr_mask;
+  int64_t* valid;
+  float* pos_enc;
+  float* prev;
+  float* bw_val;
+  int32_t* bw_dev;
+  float* dec_input;
+} kantts_plan_args;
+int kantts_teacher_plan(const kantts_plan_args* args, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Length regulator (kantts/models/sambert/adaptors.py:15-36, positions.py:72-90) in index form.
  * kantts_lr_index: reps = trunc(dur + 0.5) (dur_int (B,N) int64 or dur_float (B,N) fp32);

@@ -131,9 +131,12 @@ extern "C" int kantts_masked_l1_many(const kantts_loss_term* terms, int nterms, 
     a.t[k] = q;
     a.first_block[k] = nb;
     long long total = (long long)q.B * q.T * q.C;
-    int blocks = kantts_cdiv(total, 1024);  // four elements per thread and trip
+    // every block ends with two atomics, one of them onto the SAME address for all terms (the total): ~1000 blocks made
+    // the launch 42 us of serialised atomics for 19 MB of traffic (profiles/r05_runJ_trace_*); 96 blocks per term stream the
+    // same bytes in a few microseconds
+    int blocks = kantts_cdiv(total, 1024);
     if (blocks < 1) blocks = 1;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 96) blocks = 96;
     nb += blocks;
   }
   a.first_block[nterms] = nb;
@@ -242,8 +245,10 @@ extern "C" int kantts_sumsq_det(const float* x, float* out, float* workspace, lo
                                 void* stream) {
   if (!x || !out || !workspace || n < 0 || ((uintptr_t)x & 15)) return KANTTS_E_BADARG;
   if (ws_floats < SUMSQ_DET_BLOCKS + 1) return KANTTS_E_WORKSPACE;
+  // (every block ends with an agent-scope release + a ticket: a quarter of the round-2 block count reads the same bytes with
+  // a quarter of the fences)
   int blocks = kantts_cdiv(n > 0 ? n : 1, 4096);
-  if (blocks > SUMSQ_DET_BLOCKS) blocks = SUMSQ_DET_BLOCKS;
+  if (blocks > SUMSQ_DET_BLOCKS / 4) blocks = SUMSQ_DET_BLOCKS / 4;
   hipLaunchKernelGGL(sumsq_det_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, workspace, n);
   KANTTS_CHECK_LAUNCH();
 }

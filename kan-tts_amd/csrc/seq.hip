@@ -474,3 +474,104 @@ extern "C" int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const flo
   }
   KANTTS_CHECK_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------------------ [round 5]
+// Everything of a teacher-forced SAM-BERT step that depends on the batch's LENGTHS / TARGETS only, in one launch: the three
+// padding masks with their clamped lengths (get_mask_from_lengths, kantts/models/utils.py:13-23; the LFR mask of
+// kantts_sambert.py:736-750), the duration-position sinusoids of the regulated frames (positions.py:83-98, on the positions
+// kantts_lr_index produced), the duration predictor's shifted log input (kantts_sambert.py:466-468), the attention band
+// width (:981-985) and the decoder's teacher-forcing frames (:556-559).  These were ~50 stock elementwise launches of 2-5 us
+// with a ~4 us dependency gap each -- 0.37 ms at the head of every captured step, before the text encoder's first kernel
+// (profiles/r05_runJ_trace_*: the replayed graph runs its branches one after the other).  One flat index space; every
+// element is a few integer compares, a sin / cos, a log or a copied float.
+__global__ __launch_bounds__(256) void teacher_plan_kernel(const kantts_plan_args g) {
+  const long long nA = (long long)g.B * g.N, nB = (long long)g.B * g.T_mel, L = g.Tp / g.r, nC = (long long)g.B * L;
+  const long long nD = (long long)g.B * g.Tp * g.depth, nE = (long long)g.B * L * g.d_mel, nF = g.B;
+  const long long total = nA + nB + nC + nD + nE + nF;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long k = i;
+    if (k < nA) {  // input mask + shifted log durations
+      const int b = (int)(k / g.N), n = (int)(k % g.N);
+      const long long len = min(g.in_lens[b], (long long)g.N);
+      g.in_mask[k] = n >= len ? 1 : 0;
+      g.prev[k] = logf((n > 0 ? (float)g.dur[k - 1] : 0.f) + 1.f);
+      continue;
+    }
+    k -= nA;
+    if (k < nB) {  // output (mel frame) mask
+      const int b = (int)(k / g.T_mel), t = (int)(k % g.T_mel);
+      g.out_mask[k] = t >= min(g.out_lens[b], (long long)g.T_mel) ? 1 : 0;
+      continue;
+    }
+    k -= nB;
+    if (k < nC) {  // decoder-step (LFR) mask: ceil(len / r) valid steps
+      const int b = (int)(k / L), l = (int)(k % L);
+      g.lfr_mask[k] = l >= min((g.out_lens[b] + g.r - 1) / g.r, L) ? 1 : 0;
+      continue;
+    }
+    k -= nC;
+    if (k < nD) {  // duration-position sinusoid: sin on even channels, cos on odd; position 0 past the sequence's frames
+      const int c = (int)(k % g.depth);
+      const long long bt = k / g.depth;
+      const int b = (int)(bt / g.Tp), t = (int)(bt % g.Tp);
+      const long long limit = min(min(g.out_lens[b], (long long)g.T_mel), (long long)g.max_len);
+      const float p = t < limit ? g.pos[bt] : 0.f;
+      const float e = p / g.inv_ts[c];
+      g.pos_enc[k] = (c & 1) ? cosf(e) : sinf(e);
+      continue;
+    }
+    k -= nD;
+    if (k < nE) {  // teacher forcing: go frame, then the last frame of every previous decoder step
+      const int d = (int)(k % g.d_mel);
+      const long long bl = k / g.d_mel;
+      const int b = (int)(bl / L), l = (int)(bl % L);
+      g.dec_input[k] = l > 0 ? g.mel[((long long)b * g.T_mel + (long long)l * g.r - 1) * g.d_mel + d] : 0.f;
+      continue;
+    }
+    k -= nE;
+    {  // clamped lengths in both integer widths
+      const int b = (int)k;
+      const long long li = min(g.in_lens[b], (long long)g.N), lo = min(g.out_lens[b], (long long)g.T_mel);
+      const long long ll = min((g.out_lens[b] + g.r - 1) / g.r, L);
+      g.in_l64[b] = li; g.in_l32[b] = (int32_t)li;
+      g.out_l64[b] = lo; g.out_l32[b] = (int32_t)lo;
+      g.lfr_l64[b] = ll; g.lfr_l32[b] = (int32_t)ll;
+      g.valid[b] = min(lo, (long long)g.max_len);
+    }
+  }
+  if (blockIdx.x == 0) {  // band width: int(max valid duration / r + 0.5)
+    __shared__ float red[4];
+    float m = 0.f;  // masked positions count as 0 (masked_fill(mask, 0).max())
+    for (long long k = threadIdx.x; k < nA; k += blockDim.x) {
+      const int b = (int)(k / g.N), n = (int)(k % g.N);
+      if (n < min(g.in_lens[b], (long long)g.N)) m = fmaxf(m, (float)g.dur[k]);
+    }
+    m = kantts_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      const float v = m / (float)g.r + 0.5f;
+      g.bw_val[0] = v;
+      g.bw_dev[0] = (int32_t)v;
+    }
+  }
+}
+
+extern "C" int kantts_teacher_plan(const kantts_plan_args* gp, void* stream) {
+  if (!gp) return KANTTS_E_BADARG;
+  const kantts_plan_args& g = *gp;
+  if (g.B < 0 || g.N < 1 || g.T_mel < 1 || g.Tp < 1 || g.r < 1 || g.Tp % g.r || g.depth < 1 || g.d_mel < 1 || g.max_len < 0)
+    return KANTTS_E_BADARG;
+  if (!g.in_lens || !g.out_lens || !g.dur || !g.mel || !g.pos || !g.inv_ts || !g.in_l64 || !g.in_l32 || !g.in_mask ||
+      !g.out_l64 || !g.out_l32 || !g.out_mask || !g.lfr_l64 || !g.lfr_l32 || !g.lfr_mask || !g.valid || !g.pos_enc ||
+      !g.prev || !g.bw_val || !g.bw_dev || !g.dec_input)
+    return KANTTS_E_BADARG;
+  if (g.B == 0) return KANTTS_OK;
+  const long long L = g.Tp / g.r;
+  const long long total = (long long)g.B * (g.N + g.T_mel + L + (long long)g.Tp * g.depth + L * g.d_mel + 1);
+  int blocks = kantts_cdiv(total, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(teacher_plan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -246,6 +246,18 @@ class PncaBlockBwdArgs(Structure):
     ]
 
 
+class PlanArgs(Structure):
+    """kantts_plan_args (include/kantts_hip.h)."""
+    _fields_ = [("in_lens", c_void_p), ("out_lens", c_void_p), ("dur", c_void_p), ("mel", c_void_p), ("pos", c_void_p),
+                ("inv_ts", c_void_p),
+                ("B", c_int32), ("N", c_int32), ("T_mel", c_int32), ("Tp", c_int32), ("max_len", c_int32), ("r", c_int32),
+                ("d_mel", c_int32), ("depth", c_int32),
+                ("in_l64", c_void_p), ("in_l32", c_void_p), ("in_mask", c_void_p), ("out_l64", c_void_p), ("out_l32", c_void_p),
+                ("out_mask", c_void_p), ("lfr_l64", c_void_p), ("lfr_l32", c_void_p), ("lfr_mask", c_void_p),
+                ("valid", c_void_p), ("pos_enc", c_void_p), ("prev", c_void_p), ("bw_val", c_void_p), ("bw_dev", c_void_p),
+                ("dec_input", c_void_p)]
+
+
 ROWSUM_MAX = 32
 
 
@@ -337,6 +349,7 @@ def lib():
         L.kantts_pnca_block_fwd.argtypes = [POINTER(PncaBlockArgs), c_void_p]
         L.kantts_pnca_block_bwd.argtypes = [POINTER(PncaBlockBwdArgs), c_void_p]
         L.kantts_rows_sum_many.argtypes = [POINTER(RowSumArgs), c_void_p]
+        L.kantts_teacher_plan.argtypes = [POINTER(PlanArgs), c_void_p]
         L.kantts_pnca_block_bwd_ws_floats.argtypes = [c_int]
         L.kantts_pnca_block_bwd_ws_floats.restype = ctypes.c_longlong
         L.kantts_fragmajor_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
@@ -386,7 +399,7 @@ EXPORTED_SYMBOLS = [
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
-    "kantts_melspec_tuning",
+    "kantts_melspec_tuning", "kantts_teacher_plan",
 ]
 
 
@@ -749,6 +762,33 @@ def pnca_block_bwd(dy, hid, y1, mean1, rstd1, gamma1, rowmask, wt2, wt1, wfcxT, 
         _profile.append((e0, e1, flops))
         _profile_families.append(("pnca_block_bwd", e0, e1, flops, float(nbytes)))
     return ws
+
+
+def teacher_plan(in_lens, out_lens, dur, mel, pos, inv_ts, Tp, max_len, r):
+    """kantts_teacher_plan: returns a dict of the tensors it writes (see the header)."""
+    B, N = dur.shape
+    T_mel, d_mel = int(mel.shape[1]), int(mel.shape[2])
+    depth, L = int(inv_ts.numel()), Tp // r
+    dev = dur.device
+    i64, i32 = dict(device=dev, dtype=torch.int64), dict(device=dev, dtype=torch.int32)
+    o = {"in_l64": torch.empty(B, **i64), "in_l32": torch.empty(B, **i32),
+         "in_mask": torch.empty((B, N), device=dev, dtype=torch.bool),
+         "out_l64": torch.empty(B, **i64), "out_l32": torch.empty(B, **i32),
+         "out_mask": torch.empty((B, T_mel), device=dev, dtype=torch.bool),
+         "lfr_l64": torch.empty(B, **i64), "lfr_l32": torch.empty(B, **i32),
+         "lfr_mask": torch.empty((B, L), device=dev, dtype=torch.bool), "valid": torch.empty(B, **i64),
+         "pos_enc": torch.empty((B, Tp, depth), device=dev, dtype=torch.float32),
+         "prev": torch.empty((B, N, 1), device=dev, dtype=torch.float32),
+         "bw_val": torch.empty((), device=dev, dtype=torch.float32), "bw_dev": torch.empty(1, **i32),
+         "dec_input": torch.empty((B, L, d_mel), device=dev, dtype=torch.float32)}
+    g = PlanArgs()
+    g.in_lens, g.out_lens, g.dur = ptr(in_lens, torch.int64), ptr(out_lens, torch.int64), ptr(dur, torch.int64)
+    g.mel, g.pos, g.inv_ts = ptr(mel, torch.float32), ptr(pos, torch.float32), ptr(inv_ts, torch.float32)
+    g.B, g.N, g.T_mel, g.Tp, g.max_len, g.r, g.d_mel, g.depth = B, N, T_mel, int(Tp), int(max_len), int(r), d_mel, depth
+    for k, t in o.items():
+        setattr(g, k, ptr(t))
+    check(lib().kantts_teacher_plan(ctypes.byref(g), stream()), "teacher_plan")
+    return o
 
 
 def rows_sum_many(problems):

@@ -42,6 +42,7 @@ _BESIDE_PARTS = tuple(x for x in os.environ.get("KANTTS_BESIDE_PARTS", "prenet")
 # (whose LSTM leaves 7/8 of the chip idle) instead of beside the decoder: 7.65 -> 7.60 ms (profiles/
 # r03_runAK_predictors_late.log); KANTTS_PREDICTORS_EARLY restores the round-2 placement
 _PREDICTORS_LATE = not os.environ.get("KANTTS_PREDICTORS_EARLY")
+_PLAN_KERNEL = not os.environ.get("KANTTS_NO_PLAN_KERNEL")  # A/B switch: the target-only plan as one launch (csrc/seq.hip)
 # [round 5] experiment switch KANTTS_PREDICTORS_AFTER_POSTNET=1: issue the predictors after the postnet's launches, so that
 # autograd (which issues backward nodes newest first) issues their backward BEFORE the postnet's and it could run beside the
 # postnet's 612-step LSTM backward (0.5 ms on 32 of 256 CUs with nothing beside it).  Measured (profiles/r05_runL_*): the
@@ -537,6 +538,29 @@ class KanTtsSAMBERT(nn.Module):
             plan["bw_dev"] = plan["bw_val"].to(torch.int32).reshape(1)  # trunc == int() for non-negative values
         return plan
 
+    @torch.no_grad()
+    def teacher_forced_plan_fused(self, input_lengths, T_in, output_lengths, mel_targets, duration_targets):
+        """``SeqInfo(input_lengths, T_in)`` and ``teacher_forced_plan`` from TWO launches (kantts_lr_index, then
+        kantts_teacher_plan) instead of ~50 stock elementwise ones: in a replayed hipGraph those ran one after the other in
+        front of the text encoder, 0.37 ms of 2-5 us kernels and dependency gaps per step."""
+        from kantts._hip import teacher_plan
+
+        r = self.mel_decoder.r
+        va = self.variance_adaptor
+        max_out_len = mel_targets.size(1)
+        idx, pos, cs, lens, Tp, max_len = va.length_regulator.index(duration_targets, max_len=max_out_len)
+        o = teacher_plan(input_lengths.to(torch.int64).contiguous(), output_lengths.to(torch.int64).contiguous(),
+                         duration_targets.contiguous(), mel_targets.contiguous(), pos,
+                         va.dur_position_encoder.inv_timescales.detach(), Tp, max_len, r)
+        in_info = SeqInfo.from_parts(o["in_mask"], o["in_l64"], o["in_l32"])
+        plan = {"out_info": SeqInfo.from_parts(o["out_mask"], o["out_l64"], o["out_l32"]),
+                "lr_plan": (idx, pos, cs, lens, Tp, max_len, o["valid"]), "pos_enc": o["pos_enc"], "prev": o["prev"],
+                "lfr_info": SeqInfo.from_parts(o["lfr_mask"], o["lfr_l64"], o["lfr_l32"]), "bw_val": o["bw_val"],
+                "dec_input": o["dec_input"]}
+        if self.device_band_width:
+            plan["bw_dev"] = o["bw_dev"]
+        return in_info, plan
+
     def _embed_emo_spk(self, inputs_emotion, inputs_speaker):
         (emo_hid, _) = ops.embed_sum(inputs_emotion, [self.emo_tokenizer.weight])
         if self.se_enable:
@@ -546,12 +570,13 @@ class KanTtsSAMBERT(nn.Module):
         return emo_hid, spk_hid
 
     def _beside_encoder(self, in_info, output_lengths, mel_targets, duration_targets, inputs_emotion, inputs_speaker,
-                        pitch_targets, energy_targets):
+                        pitch_targets, energy_targets, base_plan=None):
         """What a teacher-forced step can do while the text encoder runs: the target-only plan (no gradient) and the
         emotion / speaker embeddings with their length regulation (they read the inputs and two embedding tables only).
         Autograd replays a node on the stream of its forward op, so the embedding-table gradients -- 31 us of atomics each,
         at the very end of the main stream's backward before -- also run beside the encoder's backward."""
-        plan = self.teacher_forced_plan(in_info, output_lengths, mel_targets, duration_targets)
+        plan = base_plan if base_plan is not None else self.teacher_forced_plan(in_info, output_lengths, mel_targets,
+                                                                                duration_targets)
         parts = _BESIDE_PARTS
         if "emb" in parts:
             emo_hid, spk_hid = self._embed_emo_spk(inputs_emotion, inputs_speaker)
@@ -571,16 +596,22 @@ class KanTtsSAMBERT(nn.Module):
         batch_size = inputs_ling.size(0)
         r = self.mel_decoder.r
         T_in = inputs_ling.size(1)
-        in_info = SeqInfo(input_lengths, T_in)
         is_training = mel_targets is not None
-        tplan = None
-        if (is_training and not self.MAS and not getattr(self, "inline_teacher_plan", False) and output_lengths is not None
-                and duration_targets is not None
-                and pitch_targets is not None and energy_targets is not None):
+        tplan = base_plan = in_info = None
+        teacher = (is_training and not self.MAS and not getattr(self, "inline_teacher_plan", False)
+                   and output_lengths is not None and duration_targets is not None and pitch_targets is not None
+                   and energy_targets is not None)
+        if (teacher and _PLAN_KERNEL and duration_targets.dtype == torch.int64 and mel_targets.dtype == torch.float32
+                and mel_targets.dim() == 3 and inputs_ling.numel() > 0):
+            in_info, base_plan = self.teacher_forced_plan_fused(input_lengths, T_in, output_lengths, mel_targets,
+                                                                duration_targets)
+        if in_info is None:
+            in_info = SeqInfo(input_lengths, T_in)
+        if teacher:
             (text_hid, enc_sla_attn_lst, ling_embedding), tplan = ops.run_beside(
                 lambda: self.text_encoder(inputs_ling, in_info, self.return_attns),
                 lambda: self._beside_encoder(in_info, output_lengths, mel_targets, duration_targets, inputs_emotion,
-                                             inputs_speaker, pitch_targets, energy_targets),
+                                             inputs_speaker, pitch_targets, energy_targets, base_plan=base_plan),
                 side_inputs=(output_lengths, mel_targets, duration_targets, in_info.mask, in_info.lens64, inputs_emotion,
                              inputs_speaker, pitch_targets, energy_targets))
         else:

@@ -30,6 +30,13 @@ class SeqInfo:
         self.lens32 = self.lens64.to(torch.int32)
         self.mask = get_mask_from_lengths(self.lens64, max_len)
 
+    @classmethod
+    def from_parts(cls, mask, lens64, lens32):
+        """The three members as some launch already produced them (kantts_teacher_plan)."""
+        o = cls.__new__(cls)
+        o.mask, o.lens64, o.lens32 = mask, lens64, lens32
+        return o
+
     @staticmethod
     def of(mask):
         """Accept None, a SeqInfo, or a prefix-valid boolean mask (B, T) as the reference passes."""

@@ -551,6 +551,42 @@ class EmulatedLib:
     def kantts_pnca_block_bwd_ws_floats(self, M):
         return ((max(int(M), 1) + 31) // 32) * 256
 
+    def kantts_teacher_plan(self, args_ref, stream):
+        """csrc/seq.hip: masks / clamped lengths / duration-position sinusoids / shifted log durations / band width /
+        teacher-forcing frames, written exactly as the stock-operator forms of the host layer compute them."""
+        g = args_ref._obj
+        B, N, T_mel, Tp, r, D, depth = g.B, g.N, g.T_mel, g.Tp, g.r, g.d_mel, g.depth
+        if B == 0:
+            return 0
+        L = Tp // r
+        il = torch.from_numpy(_arr(g.in_lens, B, np.int64).copy())
+        ol = torch.from_numpy(_arr(g.out_lens, B, np.int64).copy())
+        dur = torch.from_numpy(_arr(g.dur, B * N, np.int64).copy()).view(B, N)
+        mel = torch.from_numpy(_arr(g.mel, B * T_mel * D).copy()).view(B, T_mel, D)
+        pos = torch.from_numpy(_arr(g.pos, B * Tp).copy()).view(B, Tp)
+        inv = torch.from_numpy(_arr(g.inv_ts, depth).copy())
+        li, lo, ll = il.clamp(max=N), ol.clamp(max=T_mel), ((ol + r - 1) // r).clamp(max=L)
+        for (p64, p32, pm, ln, n) in ((g.in_l64, g.in_l32, g.in_mask, li, N), (g.out_l64, g.out_l32, g.out_mask, lo, T_mel),
+                                      (g.lfr_l64, g.lfr_l32, g.lfr_mask, ll, L)):
+            _arr(p64, B, np.int64)[:] = ln.numpy()
+            _arr(p32, B, np.int32)[:] = ln.to(torch.int32).numpy()
+            _arr(pm, B * n, np.uint8)[:] = (torch.arange(n)[None, :] >= ln[:, None]).to(torch.uint8).reshape(-1).numpy()
+        valid = lo.clamp(max=g.max_len)
+        _arr(g.valid, B, np.int64)[:] = valid.numpy()
+        pm = torch.where(torch.arange(Tp)[None, :] < valid[:, None], pos, torch.zeros_like(pos))
+        e = pm[:, :, None] / inv[None, None, :]
+        even = torch.arange(depth) % 2 == 0
+        _arr(g.pos_enc, B * Tp * depth)[:] = torch.where(even[None, None, :], torch.sin(e), torch.cos(e)).reshape(-1).numpy()
+        _arr(g.prev, B * N)[:] = torch.log(torch.nn.functional.pad(dur[:, :-1].float(), (1, 0)) + 1).reshape(-1).numpy()
+        mask = torch.arange(N)[None, :] >= li[:, None]
+        bw = dur.float().masked_fill(mask, 0).max() / r + 0.5
+        _arr(g.bw_val, 1)[:] = float(bw)
+        _arr(g.bw_dev, 1, np.int32)[:] = int(bw.to(torch.int32))
+        di = torch.zeros(B, L, D)
+        di[:, 1:, :] = mel[:, r - 1::r, :][:, :L - 1, :]
+        _arr(g.dec_input, B * L * D)[:] = di.reshape(-1).numpy()
+        return 0
+
     def kantts_melspec_tuning(self, grid_cap, generic_only):
         return 0  # launch-shape knobs: nothing to model
 
