@@ -45,6 +45,16 @@ def am_synthesis(symbol_seq, fsnet, ling_unit, device, se=None):
     return dec_outputs, postnet_outputs, duration_predictions, pitch_predictions, energy_predictions
 
 
+def denorm_f0(mel, scale, offset, f0_threshold=30.0, uv_threshold=0.6):
+    """The last two channels of an NSF acoustic model's output (frames, n_mels + 2): voicing score -> {0, 1} at
+    ``uv_threshold``, f0 -> ``f0 * scale + offset`` Hz floored at ``f0_threshold`` (reference :26-56; mean_std: scale = std,
+    offset = mean; global: scale = max - min, offset = min).  In place, like the reference."""
+    uv = mel[:, -1]
+    mel[:, -1] = np.where(uv < uv_threshold, 0.0, 1.0)
+    mel[:, -2] = np.maximum(mel[:, -2] * scale + offset, f0_threshold)
+    return mel
+
+
 def am_infer(sentence, ckpt, output_dir, se_file=None, config=None, ling_unit=None):
     device = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
     if not isinstance(config, dict):
@@ -60,8 +70,17 @@ def am_infer(sentence, ckpt, output_dir, se_file=None, config=None, ling_unit=No
     if se_enable and se_file is None:
         raise ValueError("this checkpoint takes a speaker embedding (SE: True): --se_file is required")
     se = np.load(se_file) if se_enable else None  # (the reference ignores --se_file for models without SE, :177-178)
-    if config["Model"]["KanTtsSAMBERT"]["params"].get("NSF", False):
-        raise NotImplementedError("NSF acoustic models (f0 / uv appended to the mel) are outside the hot path")
+    # NSF acoustic models predict two more channels behind the mel bins -- normalised f0 and a voicing score -- which the
+    # vocoder's source module wants in Hz / as a 0-1 flag (reference :26-56, :180-193, :219-220)
+    params = config["Model"]["KanTtsSAMBERT"]["params"]
+    nsf = None
+    if params.get("NSF", False):
+        if params.get("nsf_norm_type", "mean_std") == "mean_std":
+            mvn = np.load(os.path.join(os.path.dirname(os.path.dirname(ckpt)), "mvn.npy"))  # rows: mean, std of f0
+            nsf = (float(np.asarray(mvn[1:]).reshape(-1)[0]), float(np.asarray(mvn[0:1]).reshape(-1)[0]))
+        else:  # "global": f0 was mapped to [0, 1] between a global minimum and maximum
+            lo, hi = params.get("nsf_f0_global_minimum", 30.0), params.get("nsf_f0_global_maximum", 730.0)
+            nsf = (float(hi) - float(lo), float(lo))
     from kantts.models import model_builder
 
     model, _, _ = model_builder(config, device)
@@ -81,6 +100,8 @@ def am_infer(sentence, ckpt, output_dir, se_file=None, config=None, ling_unit=No
             logging.info("Inference sentence: %s", line[0])
             with torch.no_grad():
                 _, mel_post, dur, f0, energy = am_synthesis(line[1], fsnet, ling_unit, device, se=se)
+            if nsf is not None:
+                mel_post = denorm_f0(mel_post, scale=nsf[0], offset=nsf[1])
             np.save("%s/%s_mel.npy" % (results_dir, line[0]), mel_post)
             np.savetxt("%s/%s_dur.txt" % (results_dir, line[0]), dur)
             np.savetxt("%s/%s_f0.txt" % (results_dir, line[0]), f0)

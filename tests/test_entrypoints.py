@@ -177,3 +177,71 @@ def test_infer_sambert_with_a_speaker_embedding_file_emulated(tmp_path):
     assert all(x.ndim == 2 and x.shape[1] == 80 and np.isfinite(x).all() for x in mels)
     n = min(len(mels[0]), len(mels[1]))
     assert n > 0 and np.abs(mels[0][:n] - mels[1][:n]).max() > 1e-4  # the embedding reaches the decoder
+
+
+def _reference_denorm_f0():
+    """The reference's own ``denorm_f0`` (kantts/bin/infer_sambert.py:26-56), loaded from its source file when the checkout
+    is present (the build container); None on a box without it."""
+    import ast
+
+    path = "/root/reference/kantts/bin/infer_sambert.py"
+    if not os.path.exists(path):
+        return None
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "denorm_f0"]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    return ns["denorm_f0"]
+
+
+def test_nsf_f0_denormalisation_follows_the_reference():
+    """``denorm_f0`` of the NSF acoustic models (reference :26-56): both normalisations, against the reference's function when
+    its checkout is here and against the definition (hand values) everywhere."""
+    from kantts.bin.infer_sambert import denorm_f0
+
+    g = np.random.default_rng(3)
+    mel = g.standard_normal((50, 82)).astype(np.float32)
+    mel[:, -1] = g.uniform(0, 1, 50)
+    mel[:, -2] = g.uniform(-0.2, 1.0, 50)
+    mvn = np.array([[210.0], [45.0]], dtype=np.float32)  # mvn.npy: mean row, std row
+    got_ms = denorm_f0(mel.copy(), scale=float(mvn[1, 0]), offset=float(mvn[0, 0]))
+    got_gl = denorm_f0(mel.copy(), scale=730.0 - 30.0, offset=30.0)
+    assert np.array_equal(got_ms[:, :80], mel[:, :80]) and set(np.unique(got_ms[:, -1])) <= {0.0, 1.0}
+    assert np.allclose(got_ms[:, -2], np.maximum(mel[:, -2] * 45.0 + 210.0, 30.0), atol=1e-4)
+    assert np.allclose(got_gl[:, -2], np.maximum(mel[:, -2] * 700.0 + 30.0, 30.0), atol=1e-4)
+    assert np.array_equal(got_gl[:, -1], (mel[:, -1] >= 0.6).astype(np.float32))
+    ref = _reference_denorm_f0()
+    if ref is not None:
+        assert np.allclose(got_ms, ref(mel.copy(), norm_type="mean_std", f0_feature=mvn), atol=1e-4)
+        assert np.allclose(got_gl, ref(mel.copy(), norm_type="global", f0_feature=[730.0, 30.0]), atol=1e-4)
+
+
+def test_infer_sambert_accepts_an_nsf_acoustic_model_emulated(tmp_path):
+    """``infer_sambert`` on an NSF checkpoint (reference :180-193, 219-220; sambert_se_nsf_global_16k.yaml: num_mels 82,
+    nsf_norm_type global): the two channels behind the mel bins leave the entry point as f0 in Hz (>= 30) and a 0 / 1
+    voicing flag."""
+    from kantts.bin.infer_sambert import am_infer
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+
+    cfg = O.sambert_config(tiny=True)
+    cfg.update(num_mels=82, NSF=True, nsf_norm_type="global", nsf_f0_global_minimum=30.0, nsf_f0_global_maximum=730.0)
+    params = {k: v for k, v in cfg.items() if k not in O.SAMBERT_VOCAB}
+    am_dir = tmp_path / "am" / "ckpt"
+    am_dir.mkdir(parents=True)
+    config = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": params,
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}}, "grad_norm": 1.0, "batch_size": 2}
+    (tmp_path / "am" / "config.yaml").write_text(yaml.dump(config))
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(dict(cfg))
+    with torch.no_grad():
+        m.variance_adaptor.duration_predictor.fc.bias.fill_(1.2)
+    torch.save({"model": m.state_dict()}, am_dir / "checkpoint_1.pth")
+    sent = tmp_path / "sentences.txt"
+    sent.write_text("utt_a\ta b c d e f\n")
+    with emulation():
+        am_infer(str(sent), str(am_dir / "checkpoint_1.pth"), str(tmp_path / "out"), ling_unit=_FakeLingUnit(cfg))
+    mel = np.load(tmp_path / "out" / "feat" / "utt_a_mel.npy")
+    assert mel.ndim == 2 and mel.shape[1] == 82 and np.isfinite(mel).all()
+    assert (mel[:, -2] >= 30.0).all() and set(np.unique(mel[:, -1])) <= {0.0, 1.0}
