@@ -562,12 +562,37 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
 
             dual_stage = [round(_replay_ms(lambda i=i: dual_b(i), 20, reps=8) * 1e3, 1) for i in range(4)]
             ms_dual = _replay_ms(lambda: [dual_b(i) for i in range(4)], 20, reps=4)
+            # the copy roof of the same chain: per stage a launch that reads (input + weights) and writes (output) bytes once,
+            # whole chip, nothing else -- the achievable time of a 10-34 MB problem INCLUDING its launch ramp, measured in
+            # the same 4-launch graph form as the real kernels (kantts_copy_roof)
+            import kantts._hip as _hipmod
+
+            cbuf = []
+            T_, C_ = frames, 512
+            for s_ in (8, 8, 2, 2):
+                rd = (B * T_ * C_ + C_ * (C_ // 2) * 2 * s_) * 2
+                wr = (B * T_ * s_ * (C_ // 2)) * 2
+                cbuf.append((torch.empty((rd + 15) // 16 * 16, device="cuda", dtype=torch.uint8),
+                             torch.empty((wr + 15) // 16 * 16, device="cuda", dtype=torch.uint8), rd, wr))
+                T_, C_ = T_ * s_, C_ // 2
+
+            def copy_b(i):
+                src, dst, rd, wr = cbuf[i]
+                _hipmod.check(_hipmod.lib().kantts_copy_roof(_hipmod.ptr(src), rd, _hipmod.ptr(dst), wr, _hipmod.stream()),
+                              "copy_roof")
+
+            copy_stage = [round(_replay_ms(lambda i=i: copy_b(i), 20, reps=8) * 1e3, 1) for i in range(4)]
+            ms_copy = _replay_ms(lambda: [copy_b(i) for i in range(4)], 20, reps=4)
         gb = belems * 2 / (msb * 1e-3) / 1e9
         res["upsampling"] = {"ms": msb, "bound": "hbm", "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": gb / PEAK_HBM_GBPS, "algorithmic_bytes": belems * 2, "bytes_dtype": "bf16",
                              "tflops": flops / (msb * 1e-3) / 1e12, "stage_us": stage_b,
                              "kernel": "cconv_kernel, 2-tap polyphase form (layers 0-1) + upsample_stream_kernel (layers 2-3)",
                              "weight_prep_ms_not_included": prep_ms,
+                             "copy_roof_us": round(ms_copy * 1e3, 1), "copy_roof_stage_us": copy_stage,
+                             "copy_roof_gbps": belems * 2 / (ms_copy * 1e-3) / 1e9,
+                             "time_over_copy_roof": msb / ms_copy,
+                             "stage_time_over_copy_roof": [round(a / max(c, 1e-9), 2) for a, c in zip(stage_b, copy_stage)],
                              "timing": "hipGraph replay of the four launches (device time; eager issue from Python is host-bound)",
                              "note": "4 launches; bf16 activations in and out; the polyphase re-layout + bf16 cast of the "
                                      "weights (6.7 MB, once per optimizer step / once for inference) is timed separately"}

@@ -320,6 +320,11 @@ int kantts_melspec_bwd_fm(const float* wav, const float* dmel, int B, int T, int
                           const int32_t* mel_len, const int32_t* mel_off, const float* mel_w, int n_mels, float eps_mel,
                           int mel_frame_major, float* dwav_accum, void* stream);
 
+/* [round 5] Measurement aid, not part of the model: a launch that reads read_bytes from src and writes write_bytes to dst
+ * once each (16-byte chunks, whole chip) -- the copy roof a kernel with those algorithmic bytes is judged against
+ * (bench.py: upsampling.copy_roof_us). */
+int kantts_copy_roof(const void* src, long long read_bytes, void* dst, long long write_bytes, void* stream);
+
 /* [round 5] The two knobs of the mel-STFT launchers, explicit instead of environment variables read on every launch: grid_cap
  * > 0 caps the persistent grid of the register-resident n_fft 1024 kernel (0 = default, 768 workgroups) -- sweeps, and the
  * tests that must reach its several-pairs-per-wave loop with small inputs; generic_only != 0 routes every size to the radix-2

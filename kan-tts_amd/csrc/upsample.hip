@@ -199,3 +199,30 @@ extern "C" int kantts_upsample_stream(const void* x_bf16, const void* wp_bf16, c
   if (Cin == 64 && Cout == 32 && S == 2) return up_launch<64, 32, 2>(a, st);
   return KANTTS_E_UNSUPPORTED;
 }
+
+// ------------------------------------------------------------------------------------------------ [round 5] calibration
+// The achievable roof of a launch that must read `read_bytes` and write `write_bytes` once: every 16-byte chunk of the source
+// is loaded, every 16-byte chunk of the destination stored (the value stored is the chunk loaded at the same index, folded
+// with a running XOR so that no load is dead code).  bench.py runs it with the upsampling stages' algorithmic bytes inside
+// the same 4-launch graph as the real kernels: what a 10-34 MB problem can reach on this chip including its launch ramp.
+typedef unsigned int cr_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_roof_kernel(const cr_u32x4* __restrict__ src, long long nread,
+                                                       cr_u32x4* __restrict__ dst, long long nwrite) {
+  const long long n = nread > nwrite ? nread : nwrite;
+  cr_u32x4 acc = {0u, 0u, 0u, 0u};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (i < nread) acc ^= src[i];
+    if (i < nwrite) dst[i] = acc;
+  }
+}
+
+extern "C" int kantts_copy_roof(const void* src, long long read_bytes, void* dst, long long write_bytes, void* stream) {
+  if (!src || !dst || read_bytes < 0 || write_bytes < 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return KANTTS_E_BADARG;
+  const long long nr = read_bytes >> 4, nw = write_bytes >> 4, n = nr > nw ? nr : nw;
+  if (n == 0) return KANTTS_OK;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(copy_roof_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const cr_u32x4*>(src), nr, reinterpret_cast<cr_u32x4*>(dst), nw);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -350,6 +350,7 @@ def lib():
         L.kantts_pnca_block_bwd.argtypes = [POINTER(PncaBlockBwdArgs), c_void_p]
         L.kantts_rows_sum_many.argtypes = [POINTER(RowSumArgs), c_void_p]
         L.kantts_teacher_plan.argtypes = [POINTER(PlanArgs), c_void_p]
+        L.kantts_copy_roof.argtypes = [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p]
         L.kantts_pnca_block_bwd_ws_floats.argtypes = [c_int]
         L.kantts_pnca_block_bwd_ws_floats.restype = ctypes.c_longlong
         L.kantts_fragmajor_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
@@ -399,7 +400,7 @@ EXPORTED_SYMBOLS = [
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
-    "kantts_melspec_tuning", "kantts_teacher_plan",
+    "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof",
 ]
 
 

@@ -17,7 +17,7 @@ from kantts.train.trainer import Sambert_Trainer
 
 
 def train(model_config, root_dir, stage_dir, resume_path=None, resume_bert_path=None, local_rank=0, synthetic=0,
-          graph=False):
+          graph=False, device_corpus="off"):
     distributed, device, local_rank, world_size = setup_device()
     if local_rank != 0:
         sys.stdout = open(os.devnull, "w")
@@ -60,6 +60,11 @@ def train(model_config, root_dir, stage_dir, resume_path=None, resume_bert_path=
         valid_loader = DataLoader(valid_set, shuffle=not distributed, collate_fn=valid_set.collate_fn,
                                   sampler=sampler["valid"], **kw)
         config["Model"]["KanTtsSAMBERT"]["params"].update(train_set.ling_unit.get_unit_size())
+        if device_corpus != "off":  # the training set resident in HBM / staged through pinned memory (row f2 of SURVEY 8)
+            from kantts.datasets.device_batching import make_train_loader
+
+            train_loader = make_train_loader("am", train_set, train_loader, device, config["batch_size"],
+                                             sampler=sampler["train"], mode=device_corpus)
     else:
         raise ImportError("kantts.datasets could not be imported: pass --synthetic N")
     model, optimizer, scheduler = model_builder(config, device, local_rank, distributed)
@@ -101,5 +106,9 @@ if __name__ == "__main__":
     parser.add_argument("--local_rank", type=int, default=0, help="local rank for distributed training")
     parser.add_argument("--synthetic", type=int, default=0, help="train on N seeded synthetic batches (no dataset)")
     parser.add_argument("--graph", action="store_true", help="replay the training step from a hipGraph")
+    parser.add_argument("--device_corpus", default="off", choices=["off", "auto", "hbm", "pinned"],
+                        help="training set resident in HBM with batches assembled on the device (hbm), host batches staged "
+                             "through pinned memory one step ahead (pinned), hbm when it fits else pinned (auto), or the "
+                             "reference's DataLoader as is (off)")
     a = parser.parse_args()
-    train(a.model_config, a.root_dir, a.stage_dir, a.resume_path, a.resume_bert_path, a.local_rank, a.synthetic, a.graph)
+    train(a.model_config, a.root_dir, a.stage_dir, a.resume_path, a.resume_bert_path, a.local_rank, a.synthetic, a.graph, a.device_corpus)

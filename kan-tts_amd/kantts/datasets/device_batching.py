@@ -93,9 +93,16 @@ class DeviceAMSet:
         self.n_f0 = np.array([len(it[3]) for it in items], dtype=np.int64)
         self.n_en = np.array([len(it[4]) for it in items], dtype=np.int64)
         self.pad_ids = torch.as_tensor(list(pad_ids), dtype=torch.int64).to(self.device)
+        # longest duration among an utterance's real symbols (the trailing "~" excluded), on the host: a batch's attention
+        # band width (kantts_sambert.py:981-985) without reading the device batch back
+        self.max_dur = np.array([int(np.max(np.asarray(it[2])[: len(it[0][0]) - 1], initial=0)) for it in items], dtype=np.int64)
 
     def __len__(self):
         return len(self.n_sym)
+
+    def band_width(self, indices):
+        """x_band_width of the batch ``indices`` as the model computes it from the duration targets (host integer)."""
+        return int(float(self.max_dur[np.asarray(indices, dtype=np.int64)].max()) / self.r + 0.5)
 
     def batch(self, indices):
         idx = np.asarray(indices, dtype=np.int64)
@@ -120,6 +127,7 @@ class DeviceAMSet:
         out["pitch_contours"] = hip.ragged_rows(self.f0, i64(self.f0_off[idx]), i32(self.n_f0[idx]), max_in).view(len(idx), max_in)
         out["energy_contours"] = hip.ragged_rows(self.energy, i64(self.en_off[idx]), i32(self.n_en[idx]), max_in).view(len(idx), max_in)
         out["attn_priors"] = None
+        out["band_width"] = self.band_width(idx)  # host integer (Sambert_Trainer: captured-step class of the batch)
         return out
 
 
@@ -196,3 +204,75 @@ class PinnedPrefetcher:
                 for t in self._tensors(dev):
                     t.record_stream(torch.cuda.current_stream(self.device))
             yield dev
+
+
+class DeviceCorpusLoader:
+    """What the trainers iterate instead of a ``DataLoader`` when the corpus is resident in HBM: index batches (from a
+    sampler -- e.g. the DistributedSampler of the data-parallel run --, a seeded shuffle, or an explicit list) turned into
+    device batches by ``DeviceAMSet.batch`` / ``DeviceVocSet.batch``.  No worker processes, no host collate, no H2D copy of
+    the payload: per batch the host uploads B offsets / starts / lengths (reference: kantts/bin/train_sambert.py:108-132,
+    train_hifigan.py:96-121 build a DataLoader over the host collate)."""
+
+    def __init__(self, device_set, batch_size, sampler=None, shuffle=True, drop_last=False, seed=0, batches=None, rng=None):
+        self.set, self.batch_size, self.sampler = device_set, int(batch_size), sampler
+        self.shuffle, self.drop_last, self.batches, self.rng = bool(shuffle), bool(drop_last), batches, rng
+        self._gen = torch.Generator().manual_seed(int(seed))
+
+    def _index_batches(self):
+        if self.batches is not None:
+            return [list(b) for b in self.batches]
+        if self.sampler is not None:
+            order = list(iter(self.sampler))
+        elif self.shuffle:
+            order = torch.randperm(len(self.set), generator=self._gen).tolist()
+        else:
+            order = list(range(len(self.set)))
+        out = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        if self.drop_last and out and len(out[-1]) < self.batch_size:
+            out.pop()
+        return out
+
+    def __len__(self):
+        if self.batches is not None:
+            return len(self.batches)
+        n = len(self.sampler) if self.sampler is not None else len(self.set)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for idx in self._index_batches():
+            yield self.set.batch(idx, self.rng) if self.rng is not None else self.set.batch(idx)
+
+
+def corpus_bytes(items):
+    """Payload bytes of a list of dataset items (nested tuples / lists of arrays)."""
+    if items is None:
+        return 0
+    if isinstance(items, (tuple, list)):
+        return sum(corpus_bytes(x) for x in items)
+    return int(np.asarray(items).nbytes)
+
+
+def make_train_loader(kind, dataset, host_loader, device, batch_size, sampler=None, mode="auto"):
+    """``--device_corpus`` of the training entry points.  ``mode``: "hbm" = upload ``dataset`` once and assemble batches on
+    the device (DeviceCorpusLoader); "pinned" = keep the host DataLoader and stage / copy its batches one step ahead
+    (PinnedPrefetcher); "auto" = "hbm" when the payload takes less than half of the free device memory, else "pinned";
+    "off" = ``host_loader`` as the reference builds it.  ``kind``: "am" (dataset items of AM_Dataset, duration-supervised)
+    or "voc" (Voc_Dataset)."""
+    device = torch.device(device)
+    if mode == "off" or device.type != "cuda":
+        return host_loader
+    if kind == "am" and getattr(dataset, "mas_enable", False):
+        return PinnedPrefetcher(host_loader, device)  # MAS items carry a per-batch prior: host collate
+    if mode in ("auto", "hbm"):
+        items = [dataset[i] for i in range(len(dataset))]
+        if mode == "auto":
+            free, _ = torch.cuda.mem_get_info(device)
+            if corpus_bytes(items) > free // 2:
+                return PinnedPrefetcher(host_loader, device)
+        if kind == "am":
+            pad_ids = [dataset.ling_unit._sub_unit_pad[t] for t in dataset.ling_unit._lfeat_type_list]
+            dset = DeviceAMSet(items, dataset.r, pad_ids, device)
+        else:
+            dset = DeviceVocSet(items, dataset.hop_length, dataset.batch_max_steps, device)
+        return DeviceCorpusLoader(dset, batch_size, sampler=sampler, shuffle=sampler is None)
+    return PinnedPrefetcher(host_loader, device)

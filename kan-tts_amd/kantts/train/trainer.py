@@ -228,11 +228,15 @@ class Sambert_Trainer(Trainer):
         b = self._to_device(batch)
         net, opt, sch = self.model[self.KEY], self.optimizer[self.KEY], self.scheduler[self.KEY]
         if self.graph:
-            # the attention band width of the batch, from the HOST copy (no device synchronisation): the captured step has
-            # one shape for bands up to 16 (one launch per decoder block) and another above
+            # the attention band width of the batch, from the HOST copy (no device synchronisation) -- a batch assembled on
+            # the device brings it along (DeviceAMSet.batch): the captured step has one shape for bands up to 16 (one launch
+            # per decoder block) and another above
             from kantts.models.sambert.kantts_sambert import band_width_of
 
-            return self._graph_step(b, band_width_of(batch["durations"], batch["valid_input_lengths"], net.mel_decoder.r))
+            bw = batch.get("band_width")
+            if bw is None:
+                bw = band_width_of(batch["durations"], batch["valid_input_lengths"], net.mel_decoder.r)
+            return self._graph_step(b, bw)
         from kantts._hip import ops
 
         if b["mel_targets"].is_cuda:

@@ -587,6 +587,9 @@ class EmulatedLib:
         _arr(g.dec_input, B * L * D)[:] = di.reshape(-1).numpy()
         return 0
 
+    def kantts_copy_roof(self, src, read_bytes, dst, write_bytes, stream):
+        return 0  # a bandwidth calibration launch: no values to model
+
     def kantts_melspec_tuning(self, grid_cap, generic_only):
         return 0  # launch-shape knobs: nothing to model
 

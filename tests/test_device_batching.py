@@ -53,6 +53,7 @@ def _check_am(device):
     for idx in ([0, 1, 2], [5, 3, 3, 4], [2]):
         ref = am_collate([items[i] for i in idx], 3, pad_ids)
         got = ds.batch(idx)
+        assert isinstance(got.pop("band_width"), int)  # the batch's attention band width rides along (host integer)
         assert set(got) == set(ref)
         for k, v in ref.items():
             if v is None:
@@ -101,3 +102,67 @@ def test_pinned_prefetcher_overlaps_and_preserves_order_gpu():
         acc.append((y.sum() + x.sum()).item())  # consumer work on the current stream
     for a, (y, x) in zip(acc, batches):
         assert abs(a - float(y.sum() + x.sum())) < 1e-2 * max(1.0, abs(a))
+
+
+def _trainer_items(n=8, seed=4):
+    """Duration-supervised items with ids inside the PinYin vocabularies of the tiny SAM-BERT config."""
+    rng = np.random.RandomState(seed)
+    hi = (140, 7, 5, 5, 30, 1)
+    items = []
+    for _ in range(n):
+        nsym = int(rng.randint(6, 13))  # incl. the trailing "~"
+        dur = rng.randint(1, 6, size=nsym - 1).astype(np.int64)
+        ling = [rng.randint(0, hi[k], size=nsym).astype(np.int64) for k in range(6)]
+        items.append((ling, rng.randn(int(dur.sum()), 80).astype(np.float32), dur, rng.randn(nsym).astype(np.float32),
+                      rng.randn(nsym).astype(np.float32), None, None, None))
+    return items
+
+
+def _two_trainer_steps(device, feed):
+    """Two Sambert_Trainer steps on batches assembled by the host collate ("host") or on the device ("device")."""
+    from test_trainer import _sambert_setup
+
+    from kantts.datasets.batching import am_collate
+    from kantts.datasets.device_batching import DeviceAMSet, DeviceCorpusLoader
+
+    items = _trainer_items()
+    pad_ids = [146, 9, 7, 7, 35, 3]
+    index_batches = [[0, 3, 5], [7, 1, 2]]
+    tr, _ = _sambert_setup(device, "/tmp/kantts_feeder_test", seed=0)
+    if feed == "device":
+        loader = DeviceCorpusLoader(DeviceAMSet(items, 3, pad_ids, device), 3, batches=index_batches)
+        assert len(loader) == 2
+    else:
+        loader = [am_collate([items[i] for i in idx], 3, pad_ids) for idx in index_batches]
+    losses = []
+    for batch in loader:
+        if feed == "device":
+            assert isinstance(batch["band_width"], int) and batch["mel_targets"].device.type == torch.device(device).type
+        losses.append(float(tr.train_step({k: v for k, v in batch.items() if k != "band_width"} if feed == "host" else batch)))
+        tr.steps += 1
+    flat = torch.cat([p.detach().reshape(-1).cpu() for p in tr.model["KanTtsSAMBERT"].parameters()])
+    return losses, flat
+
+
+def _feeder_check(device):
+    la, wa = _two_trainer_steps(device, "host")
+    lb, wb = _two_trainer_steps(device, "device")
+    assert la == lb and torch.equal(wa, wb)  # identical batches -> identical steps
+    from kantts.datasets.device_batching import DeviceAMSet
+    from kantts.models.sambert.kantts_sambert import band_width_of
+
+    items = _trainer_items()
+    ds = DeviceAMSet(items, 3, [146, 9, 7, 7, 35, 3], device)
+    for idx in ([0, 3, 5], [7, 1, 2], [4]):
+        b = ds.batch(idx)
+        assert b["band_width"] == band_width_of(b["durations"].cpu(), b["valid_input_lengths"].cpu(), 3)
+
+
+def test_trainer_steps_fed_from_the_device_corpus_equal_host_fed_steps_emulated():
+    with emulation():
+        _feeder_check("cpu")
+
+
+@pytest.mark.gpu
+def test_trainer_steps_fed_from_the_device_corpus_equal_host_fed_steps_gpu():
+    _feeder_check("cuda")
