@@ -848,6 +848,47 @@ typedef struct kantts_pnca_block_bwd_args {
 } kantts_pnca_block_bwd_args;
 int kantts_pnca_block_bwd(const kantts_pnca_block_bwd_args* args, void* stream);
 long long kantts_pnca_block_bwd_ws_floats(int M);
+/* [round 5] The cross-row half of a PNCA block's backward as one launch (csrc/pnca_block.hip): kantts_pnca_attn_bwd +
+ * kantts_bgemm_nt_lnbwd of the chain, same arithmetic and conventions (kantts/models/sambert/__init__.py:212-306
+ * differentiated; band masks kantts_sambert.py:135-166):
+ *   dqkv (M, 384) fp32 = [query | key | value] gradients of both attention bands (the memory band's query gradient added);
+ *   dhkv: gradient of this block's memory K | V rows, row pitch lddh;
+ *   dx (M, 128) = rowmask_{zero_rows}(LN0'(bf16(dqkv Wqkv); x, mean0, rstd0, gamma0) + dres);
+ *   ws: ceil(M / 32) partial rows of [128 dgamma0 | 128 dbeta0] (kantts_rows_sum_many).
+ * wqkvT: fragment-major bf16 image of Wqkv^T (128 x 384).  Band widths above 16: KANTTS_E_UNSUPPORTED / NaN as the forward. */
+typedef struct kantts_pnca_attn_bwd_args {
+  const float* qkv;
+  const float* hkv;
+  int64_t ldh;
+  const float* ox;
+  const float* oh;
+  const float* d_ox;
+  const float* d_oh;
+  const float* lse_x;
+  const float* lse_h;
+  int32_t B, L, H, C;
+  const int32_t* lens;
+  const int32_t* bw_dev;
+  int32_t bw_x, bw_h;
+  float att_p;
+  uint64_t seed_x, seed_h;
+  const uint64_t* seed_dev;
+  const void* wqkvT;
+  const float* x;
+  const float* mean0;
+  const float* rstd0;
+  const float* ln0_gamma;
+  const float* dres;
+  const uint8_t* zero_rows;
+  float* dqkv;
+  float* dhkv;
+  int64_t lddh;
+  float* dx;
+  float* ws;
+  long long ws_floats;
+} kantts_pnca_attn_bwd_args;
+int kantts_pnca_attn_qkv_bwd(const kantts_pnca_attn_bwd_args* args, void* stream);
+
 /* For each of n problems: dst0[c] += sum_r src[r*cols + c] for c < split, dst1[c - split] += ... for c >= split (fixed
  * summation order) -- the partial rows of kantts_pnca_block_bwd / kantts_bgemm_nt_lnbwd, many of them in one launch. */
 #define KANTTS_ROWSUM_MAX 32

@@ -884,6 +884,363 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts
   }
 }
 
+// ================================================================================================================
+// The CROSS-ROW half of the block's backward as one launch: both attention bands' backward, the input gradient of the QKV
+// projection and the backward of the block's first LayerNorm --
+//   dq_i  = sum_{j in x band(i)} ds_ij k_j + sum_{j in h band(i)} ds_ij hk_j          ds = p (dp - D) / sqrt(16)
+//   dk_j, dv_j  (decoder stream) from the queries i in [j, j + bw];   dhk_j, dhv_j (memory) from the queries i in [j - bw, j]
+//   dxn = [dq | dk | dv] W_qkv  (rounded to bf16, as the chain hands it over);   dx = rowmask(LN0'(dxn; x) + g1)
+// -- i.e. kantts_pnca_attn_bwd (csrc/attn.hip: three roles over whole sequences staged per (batch, head)) followed by
+// kantts_bgemm_nt_lnbwd (csrc/gemm_bf16.hip), same arithmetic.  The band confines everything a 32-row tile needs to the 16
+// rows either side of it: k | v of the rows in front and the memory k | v behind for the query gradients; q, dO, D = dO . O and
+// the log-sum-exps of the rows behind (decoder band) / in front (memory band) for the key / value gradients, whose
+// probabilities are recomputed (as the separate launch does).  Stage 1 (thread = (band, head, row)) forms dq; the inputs of
+// stage 2 (thread = (stream, head, key row)) are fetched into registers meanwhile and take over stage 1's LDS; the 32 x 384
+// gradient tile then is the B operand of the contraction with W_qkv^T streamed from L2, and its LayerNorm backward epilogue
+// is the one of pnca_block_bwd_kernel (dgamma / dbeta as partial rows).
+#define PB2_QROWS (PB_BM + PB_HX + PB_HH)   // 64 query rows: 16 in front (memory band), 16 behind (decoder band)
+#define PB2_GP (3 * PB_C + 16)              // bf16 pitch of the [dq | dk | dv] tile: 800 B = 32 mod 64
+
+__global__ __launch_bounds__(PB_THREADS) void pnca_attn_qkv_bwd_kernel(const kantts_pnca_attn_bwd_args g PB_DBG_PARAM) {
+  // R: stage 1 = [k|v rows m0-16 .. m0+31 | memory k|v rows m0 .. m0+47]; stage 2 = [q rows m0-16 .. m0+47 | dOx rows m0 ..
+  // m0+47 | dOh rows m0-16 .. m0+31]; then the bf16 gradient tile
+  __shared__ __attribute__((aligned(16))) float R[2 * (PB_BM + PB_HX) * PB_KP];
+  __shared__ __attribute__((aligned(16))) float DQs[PB_BM * PB_QP];
+  __shared__ __attribute__((aligned(16))) float Lx[(PB_BM + PB_HX) * 8], Dx[(PB_BM + PB_HX) * 8];  // rows m0 .. m0+47
+  __shared__ __attribute__((aligned(16))) float Lh[(PB_BM + PB_HX) * 8], Dh[(PB_BM + PB_HX) * 8];  // rows m0-16 .. m0+31
+  __shared__ __attribute__((aligned(16))) float St[512];
+  float* KVs = R;
+  float* HKs = R + (PB_BM + PB_HX) * PB_KP;
+  float* Qs = R;                                   // (64, PB_QP)
+  float* Gx = R + PB2_QROWS * PB_QP;               // (48, PB_QP)
+  float* Gh = Gx + (PB_BM + PB_HX) * PB_QP;        // (48, PB_QP)
+  __bf16* Tg = reinterpret_cast<__bf16*>(R);       // (32, PB2_GP)
+  static_assert((PB2_QROWS + 2 * (PB_BM + PB_HX)) * PB_QP <= 2 * (PB_BM + PB_HX) * PB_KP, "stage 2 fits stage 1's region");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
+  const int L = g.L, H = PB_C / PB_DH;
+  const long long M = (long long)g.B * L;
+  const int m0 = blockIdx.x * PB_BM;
+  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
+  const int bw_x = g.bw_dev ? *g.bw_dev : g.bw_x, bw_h = g.bw_dev ? *g.bw_dev : g.bw_h;
+  const __bf16* __restrict__ wt = reinterpret_cast<const __bf16*>(g.wqkvT);  // W_qkv^T (128 x 384)
+  const float* dummy = reinterpret_cast<const float*>(g.wqkvT);
+
+  // ---- stage-1 operands: k | v of the tile and the 16 rows in front, memory k | v of the tile and the 16 rows behind
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float4 t4[6];
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int id = tid + PB_THREADS * it, j = id >> 6, c = (id & 63) * 4;
+      const long long mk = max(0ll, min((long long)m0 - PB_HX + j, M - 1)), mh = min((long long)m0 + j, M - 1);
+      t4[it] = half ? *reinterpret_cast<const float4*>(g.hkv + mh * g.ldh + c)
+                    : *reinterpret_cast<const float4*>(g.qkv + mk * (3 * PB_C) + PB_C + c);
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int id = tid + PB_THREADS * it, j = id >> 6, c = (id & 63) * 4;
+      *reinterpret_cast<float4*>(&(half ? HKs : KVs)[j * PB_KP + c]) = t4[it];
+    }
+  }
+  // ---- D = dO . O and the log-sum-exps: decoder band for rows m0 .. m0+47, memory band for rows m0-16 .. m0+31.
+  // Four lanes per (row, head), one float4 of dO and of O each.
+  for (int task = tid; task < 2 * (PB_BM + PB_HX) * 8 * 4; task += PB_THREADS) {
+    const int part = task & 3, head = (task >> 2) & 7, jr = (task >> 5) % (PB_BM + PB_HX), band = task / (32 * (PB_BM + PB_HX));
+    const long long m = (long long)m0 + jr - (band ? PB_HX : 0);
+    const bool ok = m >= 0 && m < M;
+    const long long mc = ok ? m : 0;
+    const float4 a = *reinterpret_cast<const float4*>((band ? g.d_oh : g.d_ox) + mc * PB_C + head * PB_DH + part * 4);
+    const float4 o = *reinterpret_cast<const float4*>((band ? g.oh : g.ox) + mc * PB_C + head * PB_DH + part * 4);
+    float d = a.x * o.x + a.y * o.y + a.z * o.z + a.w * o.w;
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    if (part == 0) {
+      const int b = (int)(mc / L), i = (int)(mc - (long long)b * L);
+      (band ? Dh : Dx)[jr * 8 + head] = ok ? d : 0.f;
+      (band ? Lh : Lx)[jr * 8 + head] = ok ? (band ? g.lse_h : g.lse_x)[((long long)b * H + head) * L + i] : 0.f;
+    }
+  }
+  // ---- stage-2 operands into registers (they take over the stage-1 region after the barrier that ends stage 1)
+  // (ext-vector registers, not float4 structs: arrays of the struct type stay memory objects across the long stage-1 code
+  // and the compiler parks them in LDS -- 32 KB for 512 threads -- or in scratch)
+  f32x4 pq[4], pgx[3], pgh[3];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {  // q rows m0-16 .. m0+47: 64 x 32 chunks
+    const int id = tid + PB_THREADS * it, j = id >> 5, c = (id & 31) * 4;
+    const long long m = max(0ll, min((long long)m0 - PB_HX + j, M - 1));
+    pq[it] = *reinterpret_cast<const f32x4*>(g.qkv + m * (3 * PB_C) + c);
+  }
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {  // dOx rows m0 .. m0+47, dOh rows m0-16 .. m0+31: 48 x 32 chunks each
+    const int id = tid + PB_THREADS * it, j = id >> 5, c = (id & 31) * 4;
+    const long long mx = min((long long)m0 + j, M - 1), mh = max(0ll, min((long long)m0 - PB_HX + j, M - 1));
+    pgx[it] = *reinterpret_cast<const f32x4*>(g.d_ox + mx * PB_C + c);
+    pgh[it] = *reinterpret_cast<const f32x4*>(g.d_oh + mh * PB_C + c);
+  }
+  // stage-1 / stage-2 thread coordinates: (band | stream, head, row); 16 consecutive lanes = 16 rows of one head
+  const int band = tid >> 8, head = (tid >> 5) & 7, row = tid & 31;
+  const long long m = (long long)m0 + row;
+  const bool valid = m < M;
+  const int b = valid ? (int)(m / L) : 0, i = valid ? (int)(m - (long long)b * L) : 0;
+  const int len = g.lens ? g.lens[b] : L;
+  const long long mc = valid ? m : 0;
+  // own query, output gradient (stage 1) and own key / value rows (stage 2), from memory
+  float q[PB_DH], go[PB_DH], kk[PB_DH], vv[PB_DH];
+  {
+    const float* qp = g.qkv + mc * (3 * PB_C) + head * PB_DH;
+    const float* gp = (band ? g.d_oh : g.d_ox) + mc * PB_C + head * PB_DH;
+    const float* kp = band ? g.hkv + mc * g.ldh + head * PB_DH : qp + PB_C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 a = *reinterpret_cast<const float4*>(qp + 4 * e), c = *reinterpret_cast<const float4*>(gp + 4 * e);
+      const float4 k4 = *reinterpret_cast<const float4*>(kp + 4 * e), v4 = *reinterpret_cast<const float4*>(kp + PB_C + 4 * e);
+      q[4 * e] = a.x; q[4 * e + 1] = a.y; q[4 * e + 2] = a.z; q[4 * e + 3] = a.w;
+      go[4 * e] = c.x; go[4 * e + 1] = c.y; go[4 * e + 2] = c.z; go[4 * e + 3] = c.w;
+      kk[4 * e] = k4.x; kk[4 * e + 1] = k4.y; kk[4 * e + 2] = k4.z; kk[4 * e + 3] = k4.w;
+      vv[4 * e] = v4.x; vv[4 * e + 1] = v4.y; vv[4 * e + 2] = v4.z; vv[4 * e + 3] = v4.w;
+    }
+  }
+  __syncthreads();  // stage-1 operands, D and log-sum-exps are in LDS
+
+  // ---------------------------------------------------------------------------------------- stage 1: query gradients
+  float dq[PB_DH];
+#pragma unroll
+  for (int d = 0; d < PB_DH; ++d) dq[d] = 0.f;
+  {
+    const int bw = band ? bw_h : bw_x;
+    int lo = 0, hi = -1;
+    if (valid && i < len) {
+      if (band == 0) { lo = max(0, i - bw); hi = i; }
+      else { lo = i; hi = min(min(i + bw, L - 1), len - 1); }
+    }
+    if (PB_DBG(1)) hi = lo - 1;
+    const float* ktile = (band ? HKs : KVs) + head * PB_DH;
+    const int r0 = band ? row - i : row + PB_HX - i;
+    const float D = band ? Dh[(row + PB_HX) * 8 + head] : Dx[row * 8 + head];
+    const float lse = band ? Lh[(row + PB_HX) * 8 + head] : Lx[row * 8 + head];
+    const uint64_t rng_row = (((uint64_t)head * g.B + b) * L + i) * (uint64_t)L;
+    KanttsDropSeq drop(g.att_p, (band ? g.seed_h : g.seed_x) + seed_off);
+    for (int j = lo; j <= hi; ++j) {
+      float kj[PB_DH];
+      pb_lds16(ktile + (r0 + j) * PB_KP, kj);
+      const float p = expf(pb_dot16(q, kj) * 0.25f - lse);
+      const float dp = pb_dot16l(go, ktile + (r0 + j) * PB_KP + PB_C) * drop.scale(rng_row + j);
+      const float ds = p * (dp - D) * 0.25f;
+#pragma unroll
+      for (int d = 0; d < PB_DH; ++d) dq[d] = fmaf(ds, kj[d], dq[d]);
+    }
+    if (bw > PB_HX) {
+#pragma unroll
+      for (int d = 0; d < PB_DH; ++d) dq[d] = __builtin_nanf("");
+    }
+  }
+  if (band == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      *reinterpret_cast<float4*>(&DQs[row * PB_QP + head * PB_DH + 4 * e]) = make_float4(dq[4 * e], dq[4 * e + 1], dq[4 * e + 2], dq[4 * e + 3]);
+  }
+  __syncthreads();  // stage 1 done with its region; the memory band's query gradients are in DQs
+  if (band == 0) {  // decoder band + memory band (the chain's summed form adds them in this order)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 o = *reinterpret_cast<const float4*>(&DQs[row * PB_QP + head * PB_DH + 4 * e]);
+      *reinterpret_cast<float4*>(&DQs[row * PB_QP + head * PB_DH + 4 * e]) =
+          make_float4(dq[4 * e] + o.x, dq[4 * e + 1] + o.y, dq[4 * e + 2] + o.z, dq[4 * e + 3] + o.w);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int id = tid + PB_THREADS * it, j = id >> 5, c = (id & 31) * 4;
+    *reinterpret_cast<f32x4*>(&Qs[j * PB_QP + c]) = pq[it];
+  }
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int id = tid + PB_THREADS * it, j = id >> 5, c = (id & 31) * 4;
+    *reinterpret_cast<f32x4*>(&Gx[j * PB_QP + c]) = pgx[it];
+    *reinterpret_cast<f32x4*>(&Gh[j * PB_QP + c]) = pgh[it];
+  }
+  // what the LayerNorm backward epilogue needs (tokens b2 * 16 + li, channels n0 .. n0 + 3)
+  const int n0 = wave * 16 + kg * 4;
+  float4 xr[2], gr[2];
+  float mu[2], rs[2];
+  bool rz[2], live[2];
+#pragma unroll
+  for (int b2 = 0; b2 < 2; ++b2) {
+    const long long mm = min((long long)m0 + b2 * 16 + li, M - 1);
+    live[b2] = (long long)m0 + b2 * 16 + li < M;
+    xr[b2] = *reinterpret_cast<const float4*>(g.x + mm * PB_C + n0);
+    gr[b2] = *reinterpret_cast<const float4*>(g.dres ? g.dres + mm * PB_C + n0 : dummy);
+    if (!g.dres) gr[b2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    mu[b2] = g.mean0[mm];
+    rs[b2] = g.rstd0[mm];
+    const uint8_t zq = *(g.zero_rows ? g.zero_rows + mm : reinterpret_cast<const uint8_t*>(dummy));
+    rz[b2] = g.zero_rows && zq != 0;
+  }
+  const float4 gm = *reinterpret_cast<const float4*>(g.ln0_gamma + n0);
+  u32x4 wf[12];  // W_qkv^T row block `wave` (16 output channels), 12 reduction blocks of 32
+#pragma unroll
+  for (int kk2 = 0; kk2 < 12; ++kk2) wf[kk2] = *reinterpret_cast<const u32x4*>(wt + ((long long)(wave * 12 + kk2)) * 512 + lane * 8);
+  __syncthreads();  // stage-2 operands in LDS; DQs holds the summed query gradients
+
+  // ---------------------------------------------------------------------------------------- stage 2: key / value gradients
+  // `band` now names the stream whose key row this thread owns: 0 = decoder k | v (queries behind), 1 = memory (queries in front)
+  float dk[PB_DH], dv[PB_DH];
+#pragma unroll
+  for (int d = 0; d < PB_DH; ++d) dk[d] = dv[d] = 0.f;
+  {
+    const int bw = band ? bw_h : bw_x;
+    int lo = 0, hi = -1;  // query positions i' of this sequence that see key i
+    if (valid) {
+      if (band == 0) { lo = i; hi = min(min(i + bw, L - 1), len - 1); }
+      else if (i <= len - 1) { lo = max(0, i - bw); hi = i; }  // (i <= L - 1 always)
+    }
+    if (PB_DBG(1)) hi = lo - 1;
+    const uint64_t seed = (band ? g.seed_h : g.seed_x) + seed_off;
+    const float* Gt = band ? Gh : Gx;
+    for (int ip = lo; ip <= hi; ++ip) {
+      const int qrow = row + PB_HX + (ip - i);                 // Qs row of query ip
+      const int grow = band ? row + PB_HX + (ip - i) : row + (ip - i);
+      float qi[PB_DH], gi[PB_DH];
+      pb_lds16(&Qs[qrow * PB_QP + head * PB_DH], qi);
+      pb_lds16(&Gt[grow * PB_QP + head * PB_DH], gi);
+      const float lse = band ? Lh[grow * 8 + head] : Lx[grow * 8 + head];
+      const float D = band ? Dh[grow * 8 + head] : Dx[grow * 8 + head];
+      const float p = expf(pb_dot16(qi, kk) * 0.25f - lse);
+      const float dsc = kantts_dropout_scale(g.att_p, seed, ((((uint64_t)head * g.B + b) * L + ip) * (uint64_t)L) + i);
+      const float pd = p * dsc;
+      const float dp = pb_dot16(gi, vv) * dsc;
+      const float ds = p * (dp - D) * 0.25f;
+#pragma unroll
+      for (int d = 0; d < PB_DH; ++d) {
+        dv[d] = fmaf(pd, gi[d], dv[d]);
+        dk[d] = fmaf(ds, qi[d], dk[d]);
+      }
+    }
+    if (bw > PB_HX) {
+#pragma unroll
+      for (int d = 0; d < PB_DH; ++d) dk[d] = dv[d] = __builtin_nanf("");
+    }
+  }
+  if (band == 1 && valid) {  // memory stream: gradients of this block's memory projection rows
+    float* dst = g.dhkv + m * g.lddh + head * PB_DH;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *reinterpret_cast<float4*>(dst + 4 * e) = make_float4(dk[4 * e], dk[4 * e + 1], dk[4 * e + 2], dk[4 * e + 3]);
+      *reinterpret_cast<float4*>(dst + PB_C + 4 * e) = make_float4(dv[4 * e], dv[4 * e + 1], dv[4 * e + 2], dv[4 * e + 3]);
+    }
+  }
+  float dqs[PB_DH];
+  pb_lds16(&DQs[row * PB_QP + head * PB_DH], dqs);  // (summed query gradient of (row, head); only the memory-stream threads use it)
+  __syncthreads();  // every thread is done with the stage-2 operands: the region becomes the bf16 gradient tile
+  {
+    // [dq | dk | dv] of the tile: fp32 to memory (the weight gradient of the projection reads it), bf16 to LDS
+    auto emit = [&](const float (&v)[PB_DH], int col) {
+      if (valid && g.dqkv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<float4*>(g.dqkv + m * (3 * PB_C) + col + 4 * e) = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+      }
+      const u32x4 p0 = {pb_pack2(v[0], v[1]), pb_pack2(v[2], v[3]), pb_pack2(v[4], v[5]), pb_pack2(v[6], v[7])};
+      const u32x4 p1 = {pb_pack2(v[8], v[9]), pb_pack2(v[10], v[11]), pb_pack2(v[12], v[13]), pb_pack2(v[14], v[15])};
+      *reinterpret_cast<u32x4*>(&Tg[row * PB2_GP + col]) = valid ? p0 : (u32x4){0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(&Tg[row * PB2_GP + col + 8]) = valid ? p1 : (u32x4){0u, 0u, 0u, 0u};
+    };
+    if (band == 0) {  // decoder stream threads hold dk, dv of (row, head)
+      emit(dk, PB_C + head * PB_DH);
+      emit(dv, 2 * PB_C + head * PB_DH);
+    } else {          // memory stream threads carry the summed query gradient of (row, head): saved in dqs below
+      emit(dqs, head * PB_DH);
+    }
+  }
+  __syncthreads();  // gradient tile complete
+
+  // ---------------------------------------------------------------------------------------- dxn = dqkv . W_qkv, LayerNorm backward
+  float dh[2][4];
+  {
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk2 = 0; kk2 < 12; ++kk2) {
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&Tg[(b2 * 16 + li) * PB2_GP + kk2 * 32 + kg * 8]);
+        acc[b2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wf[kk2], (const bf16x8&)v, acc[b2], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {  // the chain hands the normalised rows' gradient over in bf16
+      const unsigned p01 = pb_pack2(acc[b2][0], acc[b2][1]), p23 = pb_pack2(acc[b2][2], acc[b2][3]);
+      dh[b2][0] = __uint_as_float(p01 << 16); dh[b2][1] = __uint_as_float(p01 & 0xffff0000u);
+      dh[b2][2] = __uint_as_float(p23 << 16); dh[b2][3] = __uint_as_float(p23 & 0xffff0000u);
+      if (!live[b2]) dh[b2][0] = dh[b2][1] = dh[b2][2] = dh[b2][3] = 0.f;
+    }
+  }
+  {
+    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+    float xh[2][4], gg[2][4], pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    float ps1[2], ps2[2];
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      const float xv[4] = {xr[b2].x, xr[b2].y, xr[b2].z, xr[b2].w};
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xh[b2][r] = (xv[r] - mu[b2]) * rs[b2];
+        gg[b2][r] = dh[b2][r] * gmv[r];
+        s1 += gg[b2][r];
+        s2 += gg[b2][r] * xh[b2][r];
+        pg[r] += dh[b2][r] * xh[b2][r];
+        pb[r] += dh[b2][r];
+      }
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      ps1[b2] = s1;
+      ps2[b2] = s2;
+    }
+    if (kg == 0) {
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        St[(wave * 2 + b2) * 16 + li] = ps1[b2];
+        St[256 + (wave * 2 + b2) * 16 + li] = ps2[b2];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        s1 += St[(w * 2 + b2) * 16 + li];
+        s2 += St[256 + (w * 2 + b2) * 16 + li];
+      }
+      s1 *= (1.f / 128.f);
+      s2 *= (1.f / 128.f);
+      const float dres[4] = {gr[b2].x, gr[b2].y, gr[b2].z, gr[b2].w};
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] = rs[b2] * (gg[b2][r] - s1 - xh[b2][r] * s2) + dres[r];
+        if (rz[b2]) o[r] = 0.f;
+      }
+      const long long mm = (long long)m0 + b2 * 16 + li;
+      if (live[b2]) *reinterpret_cast<f32x4*>(g.dx + mm * PB_C + n0) = (f32x4){o[0], o[1], o[2], o[3]};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        pg[r] += __shfl_xor(pg[r], off, 64);
+        pb[r] += __shfl_xor(pb[r], off, 64);
+      }
+    }
+    if (li == 0) {
+      float* part = g.ws + (long long)blockIdx.x * (2 * PB_C);
+      *reinterpret_cast<f32x4*>(part + n0) = (f32x4){pg[0], pg[1], pg[2], pg[3]};
+      *reinterpret_cast<f32x4*>(part + PB_C + n0) = (f32x4){pb[0], pb[1], pb[2], pb[3]};
+    }
+  }
+}
+
 static bool pb_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int kantts_pnca_block_fwd(const kantts_pnca_block_args* gp, void* stream) {
@@ -960,5 +1317,24 @@ extern "C" int kantts_rows_sum_many(const kantts_rowsum_args* gp, void* stream) 
     if (!g.src[i] || g.rows[i] < 0 || (g.split > 0 && !g.dst0[i]) || (g.split < g.cols && !g.dst1[i])) return KANTTS_E_BADARG;
   if (g.n == 0 || g.cols == 0) return KANTTS_OK;
   hipLaunchKernelGGL(rows_sum_many_kernel, dim3(kantts_cdiv(g.cols, 32), g.n), dim3(256), 0, (hipStream_t)stream, g);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_pnca_attn_qkv_bwd(const kantts_pnca_attn_bwd_args* gp, void* stream) {
+  if (!gp) return KANTTS_E_BADARG;
+  const kantts_pnca_attn_bwd_args& g = *gp;
+  if (!g.qkv || !g.hkv || !g.ox || !g.oh || !g.d_ox || !g.d_oh || !g.lse_x || !g.lse_h || !g.wqkvT || !g.x || !g.mean0 ||
+      !g.rstd0 || !g.ln0_gamma || !g.dhkv || !g.dx || !g.ws || g.B < 0 || g.L < 0)
+    return KANTTS_E_BADARG;
+  if (g.H != PB_C / PB_DH || g.C != PB_C) return KANTTS_E_UNSUPPORTED;
+  if (g.ldh < 2 * PB_C || (g.ldh & 3) || g.lddh < 2 * PB_C || (g.lddh & 3)) return KANTTS_E_UNSUPPORTED;
+  if (!g.bw_dev && (g.bw_x > PB_HX || g.bw_h > PB_HH || g.bw_x < 0 || g.bw_h < 0)) return KANTTS_E_UNSUPPORTED;
+  const long long M = (long long)g.B * g.L;
+  if (g.ws_floats < kantts_pnca_block_bwd_ws_floats((int)M)) return KANTTS_E_WORKSPACE;
+  const void* al[] = {g.qkv, g.hkv, g.ox, g.oh, g.d_ox, g.d_oh, g.wqkvT, g.x, g.dres, g.ln0_gamma, g.dqkv, g.dhkv, g.dx, g.ws};
+  for (const void* p : al)
+    if (p && !pb_aligned16(p)) return KANTTS_E_UNSUPPORTED;
+  if (M == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(pnca_attn_qkv_bwd_kernel, dim3(kantts_cdiv(M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g PB_DBG_ARG);
   KANTTS_CHECK_LAUNCH();
 }

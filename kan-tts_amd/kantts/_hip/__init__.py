@@ -246,6 +246,20 @@ class PncaBlockBwdArgs(Structure):
     ]
 
 
+class PncaAttnBwdArgs(Structure):
+    """kantts_pnca_attn_bwd_args (include/kantts_hip.h)."""
+    _fields_ = [
+        ("qkv", c_void_p), ("hkv", c_void_p), ("ldh", c_int64), ("ox", c_void_p), ("oh", c_void_p), ("d_ox", c_void_p),
+        ("d_oh", c_void_p), ("lse_x", c_void_p), ("lse_h", c_void_p),
+        ("B", c_int32), ("L", c_int32), ("H", c_int32), ("C", c_int32),
+        ("lens", c_void_p), ("bw_dev", c_void_p), ("bw_x", c_int32), ("bw_h", c_int32), ("att_p", c_float),
+        ("seed_x", c_uint64), ("seed_h", c_uint64), ("seed_dev", c_void_p),
+        ("wqkvT", c_void_p), ("x", c_void_p), ("mean0", c_void_p), ("rstd0", c_void_p), ("ln0_gamma", c_void_p),
+        ("dres", c_void_p), ("zero_rows", c_void_p),
+        ("dqkv", c_void_p), ("dhkv", c_void_p), ("lddh", c_int64), ("dx", c_void_p), ("ws", c_void_p), ("ws_floats", c_int64),
+    ]
+
+
 class PlanArgs(Structure):
     """kantts_plan_args (include/kantts_hip.h)."""
     _fields_ = [("in_lens", c_void_p), ("out_lens", c_void_p), ("dur", c_void_p), ("mel", c_void_p), ("pos", c_void_p),
@@ -350,6 +364,7 @@ def lib():
         L.kantts_pnca_block_bwd.argtypes = [POINTER(PncaBlockBwdArgs), c_void_p]
         L.kantts_rows_sum_many.argtypes = [POINTER(RowSumArgs), c_void_p]
         L.kantts_teacher_plan.argtypes = [POINTER(PlanArgs), c_void_p]
+        L.kantts_pnca_attn_qkv_bwd.argtypes = [POINTER(PncaAttnBwdArgs), c_void_p]
         L.kantts_copy_roof.argtypes = [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p]
         L.kantts_pnca_block_bwd_ws_floats.argtypes = [c_int]
         L.kantts_pnca_block_bwd_ws_floats.restype = ctypes.c_longlong
@@ -400,7 +415,7 @@ EXPORTED_SYMBOLS = [
     "kantts_weight_norm_table", "kantts_weight_norm_table_bwd", "kantts_masked_l1_many", "kantts_scale_many",
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
-    "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof",
+    "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof", "kantts_pnca_attn_qkv_bwd",
 ]
 
 
@@ -790,6 +805,42 @@ def teacher_plan(in_lens, out_lens, dur, mel, pos, inv_ts, Tp, max_len, r):
         setattr(g, k, ptr(t))
     check(lib().kantts_teacher_plan(ctypes.byref(g), stream()), "teacher_plan")
     return o
+
+
+def pnca_attn_qkv_bwd(qkv, hkv, ldh, ox, oh, d_ox, d_oh, lse_x, lse_h, B, L, *, lens, bw_dev, bw_x, bw_h, att_p, seed_x, seed_h,
+                      wqkvT, x, mean0, rstd0, gamma0, dres, zero_rows, dqkv, dhkv, dx):
+    """The cross-row half of a PNCA block's backward in one launch (csrc/pnca_block.hip; kantts_pnca_attn_qkv_bwd in the
+    header): both attention bands' backward, the QKV projection's input gradient and the first LayerNorm's backward.
+    Returns the partial rows of [dgamma0 | dbeta0] (``rows_sum_accum``), or None when the library declines (band above 16)."""
+    g = PncaAttnBwdArgs()
+    g.qkv, g.hkv, g.ldh = ptr(qkv, torch.float32), ptr(hkv, torch.float32), int(ldh)
+    g.ox, g.oh, g.d_ox, g.d_oh = (ptr(t, torch.float32) for t in (ox, oh, d_ox, d_oh))
+    g.lse_x, g.lse_h = ptr(lse_x, torch.float32), ptr(lse_h, torch.float32)
+    g.B, g.L, g.H, g.C = int(B), int(L), 8, 128
+    g.lens, g.bw_dev, g.bw_x, g.bw_h = ptr(lens), ptr(bw_dev), int(bw_x), int(bw_h)
+    g.att_p, g.seed_x, g.seed_h = float(att_p), int(seed_x), int(seed_h)
+    g.seed_dev = rng_ptr(qkv.device) if att_p > 0 else None
+    g.wqkvT, g.x = ptr(wqkvT, torch.bfloat16), ptr(x, torch.float32)
+    g.mean0, g.rstd0, g.ln0_gamma = ptr(mean0, torch.float32), ptr(rstd0, torch.float32), ptr(gamma0, torch.float32)
+    g.dres, g.zero_rows = ptr(dres, torch.float32), ptr(zero_rows)
+    g.dqkv, g.dhkv, g.lddh, g.dx = ptr(dqkv, torch.float32), ptr(dhkv, torch.float32), int(dhkv.shape[-1]), ptr(dx, torch.float32)
+    M = int(B) * int(L)
+    ws = torch.empty(((M + 31) // 32, 256), device=qkv.device, dtype=torch.float32)
+    g.ws, g.ws_floats = ptr(ws, torch.float32), ws.numel()
+    if _profile is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib().kantts_pnca_attn_qkv_bwd(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return None
+    check(rc, "pnca_attn_qkv_bwd")
+    if _profile is not None:
+        e1.record()
+        flops = 2.0 * M * 384 * 128 + 2.0 * 8.0 * B * L * L * 128  # projection input gradient + dense-count attention backward
+        nbytes = M * (384 * 4 * 2 + 256 * 4 * 2 + 4 * 128 * 4 + 128 * 4 * 3) + 2 * 384 * 128
+        _profile.append((e0, e1, flops))
+        _profile_families.append(("pnca_attn_qkv_bwd", e0, e1, flops, float(nbytes)))
+    return ws
 
 
 def rows_sum_many(problems):

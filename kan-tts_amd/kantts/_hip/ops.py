@@ -845,7 +845,9 @@ class _PncaAttention(torch.autograd.Function):
             ox, oh, lsex, lseh = ad["ox"], ad["oh"], ad["lse_x"], ad["lse_h"]
             ctx.save_for_backward(q2, h2, ox, oh, lsex, lseh, lens, bw_dev)
             ctx.cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)
+            ctx.plan = ad.get("bwd")
             return ox.view(B, L, D), oh.view(B, L, D), None, None
+        ctx.plan = None
         sx = next_seed() if drop_p > 0 else 0
         sh = next_seed() if drop_p > 0 else 0
         ctx.save_cfg = (B, H, L, bw_x, bw_h, drop_p, sx, sh)
@@ -885,6 +887,26 @@ class _PncaAttention(torch.autograd.Function):
         d_ox, d_oh = _c(d_ox).view(B * L, D), _c(d_oh).view(B * L, D)
         dqkv = torch.empty_like(q2)
         dhkv = torch.empty((B * L, 2 * D), device=q2.device, dtype=torch.float32)
+        plan = getattr(ctx, "plan", None)
+        tok = plan.tok0 if plan is not None else None
+        if (tok is not None and ops_bf16.PNCA_ATTN_BWD["on"] and tok.ready() and plan.wqkvT is not None and H == 8
+                and tok.x.numel() == B * L * D and (bw_dev is not None or (bw_x <= 16 and bw_h <= 16))):
+            # fused block: this launch is also the input gradient of the QKV projection and the backward of the LayerNorm in
+            # front of it (ops_bf16.LnBwdToken: the projection's backward node only hands the stand-in over)
+            from kantts._hip import pnca_attn_qkv_bwd, rows_sum_accum
+
+            dx = torch.empty(tok.x.shape, device=q2.device, dtype=torch.float32)
+            part = pnca_attn_qkv_bwd(q2, h2, h2.stride(0), ox, oh, d_ox, d_oh, lsex, lseh, B, L, lens=lens, bw_dev=bw_dev,
+                                     bw_x=bw_x, bw_h=bw_h, att_p=drop_p, seed_x=sx, seed_h=sh, wqkvT=plan.wqkvT, x=tok.x,
+                                     mean0=tok.mean, rstd0=tok.rstd, gamma0=tok.gamma,
+                                     dres=None if tok.dres is None else _c(tok.dres).view(B * L, D),
+                                     zero_rows=tok.zero_rows, dqkv=dqkv, dhkv=dhkv, dx=dx)
+            if part is not None:
+                dg, db = gzeros_like(tok.gamma), gzeros_like(tok.gamma)
+                rows_sum_accum(part, dg, db)
+                tok.dx, tok.dg, tok.db, tok.by_block = dx, dg, db, True
+                plan.tok0 = plan.wqkvT = None
+                return dqkv.view(B, L, 3 * D), dhkv.view(B, L, 2 * D), None, None, None, None, None, None, None
         if not os.environ.get("KANTTS_NO_PNCA_FUSED"):
             dqh = torch.empty((B * L, D), device=q2.device, dtype=torch.float32)
             rc = lib().kantts_pnca_attn_bwd(ptr(q2), ptr(h2), h2.stride(0), ptr(ox), ptr(oh), ptr(d_ox), ptr(d_oh), ptr(lsex),

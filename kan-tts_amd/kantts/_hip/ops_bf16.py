@@ -193,12 +193,13 @@ class LnBwdToken:
     autograd its own saved bf16 input as a stand-in gradient (``placeholder``); the LayerNorm node's backward checks that
     what autograd delivers is exactly those two tensors -- anything else means another consumer contributed, and raises --
     and returns the deposited results."""
-    __slots__ = ("x", "gamma", "mean", "rstd", "zero_rows", "with_res", "dres", "dx", "dg", "db", "placeholder")
+    __slots__ = ("x", "gamma", "mean", "rstd", "zero_rows", "with_res", "dres", "dx", "dg", "db", "placeholder", "by_block")
 
     def __init__(self, with_res):
         self.with_res = bool(with_res)
         self.x = self.gamma = self.mean = self.rstd = self.zero_rows = None
         self.dres = self.dx = self.dg = self.db = self.placeholder = None
+        self.by_block = False  # dx / dg / db were produced by the fused block backward launch (ops._PncaAttention.backward)
 
     def ready(self):
         return self.x is not None and self.dx is None and (self.dres is not None or not self.with_res)
@@ -335,6 +336,8 @@ def lin_fragT(w):
 
 # A/B switch: KANTTS_NO_PNCA_BLOCK_BWD=1 keeps the four launches of the row-local half of the block's backward
 PNCA_BLOCK_BWD = {"on": not os.environ.get("KANTTS_NO_PNCA_BLOCK_BWD")}
+# A/B switch: KANTTS_NO_PNCA_ATTN_BWD=1 keeps the two launches of the cross-row half (attention backward, QKV input gradient)
+PNCA_ATTN_BWD = {"on": not os.environ.get("KANTTS_NO_PNCA_ATTN_BWD")}
 
 
 class _BlockBwd:
@@ -346,7 +349,7 @@ class _BlockBwd:
     tensor of the chain had another consumer: refused) and return the deposited results.  Weight gradients stay with their
     nodes (deferred, grouped by shape as everywhere)."""
     __slots__ = ("y1", "mean1", "rstd1", "gamma1", "rows", "wfcxT", "wfchT", "fc_p", "fc_seed", "placeholder", "d_res", "g1",
-                 "dg1", "db1", "d_ox", "d_oh")
+                 "dg1", "db1", "d_ox", "d_oh", "tok0", "wqkvT")
 
     def __init__(self):
         for k in self.__slots__:
@@ -436,9 +439,10 @@ def pnca_block_fused(blk, x, hkv, info, bw_x, bw_h, bw_dev, return_attn, next_ln
         plan = _BlockBwd()
         plan.y1, plan.mean1, plan.rstd1, plan.gamma1, plan.rows = y1, mean1, rstd1, ff.layer_norm.weight, rows
         plan.wfcxT, plan.wfchT, plan.fc_p, plan.fc_seed = lin_fragT(at.fc_x.weight), lin_fragT(at.fc_h.weight), fc_p, sf
+        plan.wqkvT = lin_fragT(at.w_x_qkv.weight)  # the cross-row half (ops._PncaAttention.backward: kantts_pnca_attn_qkv_bwd)
     return _adopting([
-        ("linear", dict(y=qkv.view(M, 384), seed=0, ln=None)),
-        ("attn", dict(ox=ox, oh=oh, lse_x=lsx, lse_h=lsh, sx=sx, sh=sh)),
+        ("linear", dict(y=qkv.view(M, 384), seed=0, ln=None, qkv_of=plan)),
+        ("attn", dict(ox=ox, oh=oh, lse_x=lsx, lse_h=lsh, sx=sx, sh=sh, bwd=plan)),
         ("linear", dict(y=y1, seed=sf, ln=(xn1, mean1, rstd1), bwd=plan)),
         ("ffn", dict(hid=hid, out=out, s1=s1, s2=s2, ln=(xn2, mean2, rstd2), bwd=plan)),
     ])
@@ -497,6 +501,8 @@ class _FusedLinearB(torch.autograd.Function):
                 pre.xn, pre.mean, pre.rstd = ad["ln"]
                 pre.bwd = ad.get("bwd")  # travels to the LayerNorm node that adopts these rows (_BlockBwd)
             opts["bwd"] = ad.get("bwd")
+            if ad.get("qkv_of") is not None:  # the QKV projection of a fused block: its LayerNorm's token goes to the plan
+                ad["qkv_of"].tok0 = opts.get("lnbwd")
         else:
             seed = next_seed() if drop_p > 0 else 0
             if pre is not None and N == 128 and not opts["out_bf16"]:
@@ -601,6 +607,11 @@ class _FusedLinearB(torch.autograd.Function):
                 woff = off if mode == "concat" else 0
                 wld = ldw if mode == "concat" else kk
                 tok = opts.get("lnbwd") if (needs[5 + k] and a_drop_p == 0 and balpha == 1.0) else None
+                if tok is not None and tok.by_block and tok.dx is not None and tok.placeholder is None:
+                    # the input gradient AND the LayerNorm backward came out of the block's backward launch
+                    # (kantts_pnca_attn_qkv_bwd, issued by the attention node): only the stand-in is left to hand over
+                    tok.placeholder = x
+                    dxs[k] = x
                 if tok is not None and tok.ready():
                     # the LayerNorm that produced x: its backward is this launch's epilogue (LnBwdToken)
                     from .ops import gzeros_like

@@ -548,6 +548,40 @@ class EmulatedLib:
             _arr(g.ln2_rstd, M)[:] = rs2
         return 0
 
+    def kantts_pnca_attn_qkv_bwd(self, args_ref, stream):
+        """csrc/pnca_block.hip: kantts_pnca_attn_bwd (summed query gradients) + the QKV projection's input gradient rounded
+        to bf16 + kantts_ln128_bwd_rows with partial rows."""
+        g = args_ref._obj
+        B, L, C = g.B, g.L, 128
+        if g.H != 8 or g.C != C or g.ldh < 2 * C or g.ldh % 4 or g.lddh < 2 * C or g.lddh % 4:
+            return -2
+        if not g.bw_dev and (g.bw_x > 16 or g.bw_h > 16 or g.bw_x < 0 or g.bw_h < 0):
+            return -2
+        M = B * L
+        if M == 0:
+            return 0
+        dqkv = np.zeros((M, 3 * C), dtype=np.float32)
+        dhkv = np.zeros((M, 2 * C), dtype=np.float32)
+        self.kantts_pnca_attn_bwd(g.qkv, g.hkv, g.ldh, g.ox, g.oh, g.d_ox, g.d_oh, g.lse_x, g.lse_h, dqkv.ctypes.data, None,
+                                  dhkv.ctypes.data, g.lens, g.bw_dev, g.bw_x, g.bw_h, B, 8, L, 16, g.att_p, g.seed_x, g.seed_h,
+                                  g.seed_dev, stream)
+        if g.bw_dev and int(_arr(g.bw_dev, 1, np.int32)[0]) > 16:
+            dqkv[:], dhkv[:] = np.nan, np.nan
+        if g.dqkv:
+            _wr(g.dqkv, dqkv, False)
+        for i in range(M):
+            _wr(int(g.dhkv) + i * g.lddh * 4, dhkv[i], False)
+        dxn = _bf16_round((_bf16_round(dqkv) @ _unfrag(g.wqkvT, C, 3 * C).T).astype(np.float32))
+
+        class _L:
+            pass
+
+        l = _L()
+        l.x, l.gamma, l.mean, l.rstd, l.dres, l.zero_rows, l.dx = g.x, g.ln0_gamma, g.mean0, g.rstd0, g.dres, g.zero_rows, g.dx
+        l.part_rows, l.dgamma_accum, l.dbeta_accum = g.ws, None, None
+        self._ln128_bwd_values(l, M, dxn)
+        return 0
+
     def kantts_pnca_block_bwd_ws_floats(self, M):
         return ((max(int(M), 1) + 31) // 32) * 256
 

@@ -147,7 +147,15 @@ def _two_trainer_steps(device, feed):
 def _feeder_check(device):
     la, wa = _two_trainer_steps(device, "host")
     lb, wb = _two_trainer_steps(device, "device")
-    assert la == lb and torch.equal(wa, wb)  # identical batches -> identical steps
+    if device == "cpu":
+        assert la == lb and torch.equal(wa, wb)  # identical batches -> identical steps
+    else:
+        # on the device the weight gradients are fp32 atomics whose order differs from run to run: identical up to the
+        # noise floor of two host-fed runs
+        lc, wc = _two_trainer_steps(device, "host")
+        floor = float((wa - wc).norm() / wa.norm())
+        assert float((wa - wb).norm() / wa.norm()) <= max(3 * floor, 1e-6), floor
+        assert all(abs(x - y) <= 1e-5 * max(1.0, abs(x)) for x, y in zip(la, lb))
     from kantts.datasets.device_batching import DeviceAMSet
     from kantts.models.sambert.kantts_sambert import band_width_of
 

@@ -52,10 +52,11 @@ def _case(device, B, L, lens, bw, drop, bw_on_device=False, private=False, final
             xin = ops.linear(x, torch.eye(128, device=device), None, rowmask=info.mask)
         ops_bf16.PNCA_BLOCK["on"] = fused
         ops_bf16.BAND_BOUND["max"] = bw if bw_on_device else None
-        calls, bcalls = [], []
-        real, real_b = ops_bf16.pnca_block_fwd, ops_bf16.pnca_block_bwd
+        calls, bcalls, ccalls = [], [], []
+        real, real_b, real_c = ops_bf16.pnca_block_fwd, ops_bf16.pnca_block_bwd, hip.pnca_attn_qkv_bwd
         ops_bf16.pnca_block_fwd = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
         ops_bf16.pnca_block_bwd = lambda *a, **k: (bcalls.append(1), real_b(*a, **k))[1]
+        hip.pnca_attn_qkv_bwd = lambda *a, **k: (ccalls.append(1), real_c(*a, **k))[1]
         try:
             out, _, _ = blk(xin, None, mask=info, x_band_width=0 if bw_on_device else bw,
                             h_band_width=0 if bw_on_device else bw, bw_dev=bw_dev, hkv=hkv, private_input=private,
@@ -63,10 +64,12 @@ def _case(device, B, L, lens, bw, drop, bw_on_device=False, private=False, final
             pre = out._kantts_prenorm
             (out * cot).sum().backward()
         finally:
-            ops_bf16.pnca_block_fwd, ops_bf16.pnca_block_bwd = real, real_b
+            ops_bf16.pnca_block_fwd, ops_bf16.pnca_block_bwd, hip.pnca_attn_qkv_bwd = real, real_b, real_c
             ops_bf16.PNCA_BLOCK["on"] = True
             ops_bf16.BAND_BOUND["max"] = None
-        assert len(bcalls) == len(calls)  # the row-local half of the backward is one launch whenever the forward was
+        # whenever the forward was one launch, the backward is three: its row-local half, its cross-row half (attention
+        # backward + QKV input gradient + LayerNorm backward) and nothing else but weight gradients
+        assert len(bcalls) == len(calls) and len(ccalls) == len(calls)
         grads = {n: p.grad.detach().cpu().clone() for n, p in blk.named_parameters() if p.grad is not None}
         return (len(calls), out.detach().cpu(), pre.xn.float().cpu(), pre.mean.cpu(), pre.rstd.cpu(), x.grad.cpu(),
                 hk.grad.cpu(), grads)
