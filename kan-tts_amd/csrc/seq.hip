@@ -374,53 +374,88 @@ __global__ __launch_bounds__(256, 2) void fsmn_fir41_kernel(const float* __restr
   }
 }
 
-// weight gradient partials: block = (chunk of FS_CH frames, b); part[(b*nchunk + chunk)][c][k]
-#define FS_CH 160
-__global__ __launch_bounds__(256, 2) void fsmn_dw41_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                               const int64_t* __restrict__ lens,
-                                                               float* __restrict__ part, int B, int T, int C, int lp) {
+// weight gradient partials: block = (chunk of FS_CH frames, b, group of 64 channels); wave w of the block takes the
+// w-th quarter of the chunk (two 16-frame windows), lane = channel; the four waves' 41 sums per channel meet in LDS and
+// leave as ONE partial row part[(b*nchunk + chunk)][c][k].  (Until round 5 a 256-thread block walked 160 frames alone:
+// 512 waves on 1024 SIMDs, ten dependent windows each -- 25.8 us at the postnet's 19 584 rows; this form has 2560 waves
+// of two windows.)
+#define FS_CH 128
+#define FS_SUB (FS_CH / 4)
+__global__ __launch_bounds__(256) void fsmn_dw41_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const int64_t* __restrict__ lens,
+                                                            float* __restrict__ part, int B, int T, int C, int lp) {
+  __shared__ float sm[4][FS_K][65];
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c0 = blockIdx.z * 64, c = c0 + lane;
+  const bool cok = c < C;
+  const int cc = cok ? c : 0;
   const int len = lens ? (int)min((long long)lens[b], (long long)T) : T;
   const float* xb = x + (long long)b * T * C;
   const float* db = dy + (long long)b * T * C;
-  const int tbeg = chunk * FS_CH, tend = min(tbeg + FS_CH, T);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc[FS_K];
+  const int tbeg = chunk * FS_CH + wave * FS_SUB, tend = min(tbeg + FS_SUB, T);
+  float acc[FS_K];
 #pragma unroll
-    for (int k = 0; k < FS_K; ++k) acc[k] = 0.f;
-    for (int t0 = tbeg; t0 < tend && t0 < len; t0 += FS_TT) {
-      float xin[FS_TT + FS_K - 1], dv[FS_TT];
+  for (int k = 0; k < FS_K; ++k) acc[k] = 0.f;
+  for (int t0 = tbeg; t0 < tend && t0 < len; t0 += FS_TT) {
+    float xin[FS_TT + FS_K - 1], dv[FS_TT];
 #pragma unroll
-      for (int n = 0; n < FS_TT + FS_K - 1; ++n) {
-        const int ts = t0 + n - lp;
-        const bool ok = (ts >= 0) && (ts < len);
-        const float v = xb[(long long)(ok ? ts : 0) * C + c];
-        xin[n] = ok ? v : 0.f;
-      }
-#pragma unroll
-      for (int o = 0; o < FS_TT; ++o) {
-        const int t = t0 + o;
-        const bool ok = (t < tend) && (t < len);
-        const float v = db[(long long)(ok ? t : 0) * C + c];
-        dv[o] = ok ? v : 0.f;
-      }
-#pragma unroll
-      for (int o = 0; o < FS_TT; ++o)
-#pragma unroll
-        for (int k = 0; k < FS_K; ++k) acc[k] = fmaf(dv[o], xin[o + k], acc[k]);
+    for (int n = 0; n < FS_TT + FS_K - 1; ++n) {
+      const int ts = t0 + n - lp;
+      const bool ok = cok && (ts >= 0) && (ts < len);
+      const float v = xb[(long long)(ok ? ts : 0) * C + cc];
+      xin[n] = ok ? v : 0.f;
     }
-    float* p = part + (((long long)b * nchunk + chunk) * C + c) * FS_K;
 #pragma unroll
-    for (int k = 0; k < FS_K; ++k) p[k] = acc[k];
+    for (int o = 0; o < FS_TT; ++o) {
+      const int t = t0 + o;
+      const bool ok = cok && (t < tend) && (t < len);
+      const float v = db[(long long)(ok ? t : 0) * C + cc];
+      dv[o] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < FS_TT; ++o)
+#pragma unroll
+      for (int k = 0; k < FS_K; ++k) acc[k] = fmaf(dv[o], xin[o + k], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < FS_K; ++k) sm[wave][k][lane] = acc[k];
+  __syncthreads();
+  // 64 channels x 41 taps are contiguous in the partial row; consecutive threads take consecutive taps (LDS pitch 65)
+  float* p = part + (((long long)b * nchunk + chunk) * C + c0) * FS_K;
+  const int nout = min(64, C - c0) * FS_K;
+  for (int o = threadIdx.x; o < nout; o += 256) {
+    const int cl = o / FS_K, k = o - cl * FS_K;
+    p[o] = (sm[0][k][cl] + sm[1][k][cl]) + (sm[2][k][cl] + sm[3][k][cl]);
   }
 }
 
-__global__ void fsmn_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int p = 0; p < nblk; ++p) s += part[(long long)p * n + i];
-  dw[i] += s;
+// dw[i] += sum over the partial rows, in a fixed order: thread = (output i, one of 8 interleaved slices of the rows), the
+// slices meet in LDS.  (One thread per output walking all rows -- 41 workgroups, 128 dependent loads -- took 21.5 us.)
+#define FS_RS 8
+__global__ __launch_bounds__(64 * FS_RS) void fsmn_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                    int nblk, int n) {
+  __shared__ float sm[FS_RS][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const bool ok = i < n;
+  const long long ii = ok ? i : 0;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = slice;
+  for (; p + 3 * FS_RS < nblk; p += 4 * FS_RS) {
+    const float a0 = part[(long long)p * n + ii], a1 = part[(long long)(p + FS_RS) * n + ii];
+    const float a2 = part[(long long)(p + 2 * FS_RS) * n + ii], a3 = part[(long long)(p + 3 * FS_RS) * n + ii];
+    s0 += a0, s1 += a1, s2 += a2, s3 += a3;
+  }
+  for (; p < nblk; p += FS_RS) s0 += part[(long long)p * n + ii];
+  sm[slice][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (slice == 0 && ok) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < FS_RS; ++q) s += sm[q][lane];
+    dw[i] += s;
+  }
 }
 
 extern "C" long long kantts_fsmn_dwconv_bwd_ws(int B, int T, int C, int K) {
@@ -459,9 +494,9 @@ extern "C" int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const flo
       hipLaunchKernelGGL(fsmn_fir41_kernel<true>, dim3(kantts_cdiv(T, FS_TT), B), dim3(threads), 0, st, dy, w,
                          (const float*)nullptr, lens, dx, B, T, C, left_pad);
     if (dw_accum) {
-      hipLaunchKernelGGL(fsmn_dw41_partial_kernel, dim3(nchunk, B), dim3(threads), 0, st, dy, x, lens, workspace, B, T, C,
-                         left_pad);
-      hipLaunchKernelGGL(fsmn_dw_reduce_kernel, dim3(kantts_cdiv(C * K, 256)), dim3(256), 0, st, workspace, dw_accum,
+      hipLaunchKernelGGL(fsmn_dw41_partial_kernel, dim3(nchunk, B, kantts_cdiv(C, 64)), dim3(256), 0, st, dy, x, lens,
+                         workspace, B, T, C, left_pad);
+      hipLaunchKernelGGL(fsmn_dw_reduce_kernel, dim3(kantts_cdiv(C * K, 64)), dim3(64 * FS_RS), 0, st, workspace, dw_accum,
                          B * nchunk, C * K);
     }
   } else {

@@ -374,14 +374,16 @@ def test_embedding_and_length_regulator_bit_exact():
     assert_close(gg[0], cg[0], 1e-5, what="lr bwd")
 
 
-@pytest.mark.parametrize("C,K,lp", [(128, 41, 20), (256, 41, 37)])
-def test_fsmn_memory(C, K, lp):
+@pytest.mark.parametrize("C,K,lp,T", [(128, 41, 20, 70), (256, 41, 37, 70), (80, 41, 40, 300)])
+def test_fsmn_memory(C, K, lp, T):
+    """The last case: several 128-frame chunks per sequence and a channel count that is no multiple of the filter
+    gradient's 64-channel groups."""
     from kantts._hip import ops
 
-    B, T = 3, 70
+    B = 3
     x, w = _rand(B, T, C, seed=1, grad=True), _rand(C, 1, K, seed=2, scale=0.2, grad=True)
     res = _rand(B, T, C, seed=3, grad=True)
-    lens = torch.tensor([70, 33, 51])
+    lens = torch.tensor([T, 33, T - 19])
     go, gg, co, cg = run_both(lambda x, w, r, l: ops.fsmn_memory(x, w, l, lp, res=r), x, w, res, lens)
     assert_close(go[0], co[0], 2e-5, what="fsmn y")
     for a, c, nm in zip(gg, cg, ("dx", "dw", "dres")):
