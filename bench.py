@@ -839,11 +839,19 @@ def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parit
                        "hop 256)" % (n_utt, float(lens.float().mean())), "dtype": precision}
     # the Python-loop decoder on a bounded sample (it is ~10x slower); everything else on all utterances
     out["batch1_loop"] = timed(singles[::max(1, n_utt // loop_sample)][:loop_sample], "loop")
+    dp = am.variance_adaptor.duration_predictor
+    dp.ar_kernel = False  # the round-4 configuration: duration tokens and decoder steps issued / replayed from the host
     out["batch1_graph"] = timed(singles, "graph")
     out["batch%d_loop" % batch] = timed(batches[:1], "loop")
     out["batch%d_graph" % batch] = timed(batches, "graph")
-    out["value"] = out["batch%d_graph" % batch]["audio_samples_per_s"]
-    out["unit"] = "audio-samples/s, symbols -> wav, %d utterances in length-sorted batches of %d, graph-replayed decoder" % (n_utt, batch)
+    dp.ar_kernel = None  # round 5: each autoregressive loop is ONE launch (csrc/ar_infer.hip; bf16 mode)
+    out["batch1_kernel"] = timed(singles, "kernel")
+    out["batch%d_kernel" % batch] = timed(batches, "kernel")
+    one_launch = getattr(am.mel_decoder, "_decode_kernel", None) is not None
+    best = "batch%d_kernel" % batch if one_launch else "batch%d_graph" % batch
+    out["value"] = out[best]["audio_samples_per_s"]
+    out["unit"] = ("audio-samples/s, symbols -> wav, %d utterances in length-sorted batches of %d, %s" % (
+        n_utt, batch, "duration predictor and mel decoder loops as one launch each" if one_launch else "graph-replayed decoder"))
     if parity_utts:
         # the benchmarked configuration checked against the CPU oracle's free-running inference (outside the timed regions),
         # whose wall time is the CPU baseline of this leg
@@ -857,8 +865,9 @@ def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parit
     return out
 
 
-def config5_parity(am, cfg, utts, idx, batch=32, threads=0):
-    """BASELINE config 5 checked at the configuration that is timed: the product's batched, graph-replayed free-running
+def config5_parity(am, cfg, utts, idx, batch=32, threads=0, mode="kernel"):
+    """BASELINE config 5 checked at the configuration that is timed: the product's batched free-running (decoder mode
+    ``mode``: "kernel" = each autoregressive loop one launch in bf16 mode / the replayed graph in fp32 mode, "graph")
     inference of the utterances ``idx`` (length-sorted batches of ``batch``) against oracle/torch_oracle.py's free-running
     inference of the same utterances one at a time (the reference's only mode, kantts/bin/infer_sambert.py:58-227;
     kantts_sambert.py:569-610; adaptors.py:67-83).  Reports (i) agreement of the frame counts and of the rounded durations
@@ -888,7 +897,7 @@ def config5_parity(am, cfg, utts, idx, batch=32, threads=0):
         used = torch.get_num_threads()
         torch.set_num_threads(nthr)
     dev = next(am.parameters()).device
-    am.mel_decoder.decode_mode = "graph"
+    am.mel_decoder.decode_mode = mode
     order = idx[torch.argsort(lens[idx], descending=True)]
     same_frames = same_dur = n_sym = 0
     abs_sum = abs_max = 0.0
@@ -923,7 +932,10 @@ def config5_parity(am, cfg, utts, idx, batch=32, threads=0):
                 free_abs_sum += float(df.sum())
                 free_n += df.numel()
     frames = sum(v["frames"] for v in ref.values())
-    return {"utterances": len(ref), "decoder": "graph, length-sorted batches of %d" % batch,
+    used_kernel = getattr(am.mel_decoder, "_decode_kernel", None) is not None
+    return {"utterances": len(ref),
+            "decoder": "%s, length-sorted batches of %d" % ("one launch per autoregressive loop" if used_kernel else
+                                                            ("graph" if mode != "loop" else "loop"), batch),
             "frame_count_agreement": same_frames / len(ref), "duration_agreement": same_dur / n_sym,
             "mel_mean_abs_forced_durations": abs_sum / n_el, "mel_max_abs_forced_durations": abs_max,
             "mel_mean_abs_free_running_where_durations_agree": (free_abs_sum / free_n) if free_n else None,

@@ -1065,6 +1065,63 @@ int kantts_ragged_rows_f32(const float* src, const int64_t* row_off, const int32
 int kantts_ragged_rows_i64(const int64_t* src, const int64_t* row_off, const int32_t* start, const int32_t* len,
                            const int64_t* pad, int64_t* out, int B, int Tmax, int C, int transpose, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * [round 5] Free-running inference loops as ONE launch each (csrc/ar_infer.hip; SURVEY 8 row e1, bf16 mode).
+ *
+ * kantts_pnca_decode_run: every step of the free-running mel decoder for every sequence of a batch -- the loop of
+ * kantts/models/sambert/kantts_sambert.py:569-610 around HybridAttentionDecoder.infer (:208-253; PNCA state updates
+ * kantts/models/sambert/__init__.py:217-306).  One workgroup owns one sequence and walks its steps; per step the
+ * matrix-vector products stream the bf16 weights from L2 as MFMA A operands (every column of the B operand is the
+ * sequence's vector), activations stay in LDS, the decoder's K / V cache and the output frames are the only HBM writes.
+ * Shapes fixed by the kernel: d_model 128, 8 heads x 16, feed-forward width 1024, prenet (d_mel -> 256 -> 256 -> 128).
+ *   w : bf16 blob, every matrix row-major (out, in) with the row pitch padded to a multiple of 128 (zeros):
+ *       P1 256 x pad(d_mel) | P2 256 x 256 | P3 128 x 256 | IN 128 x pad(d_mem + 128)  [columns: memory, prenet]
+ *       per layer: QKV 384 x 128 | FC 128 x 256 [fc_x | fc_h] | W1 1024 x 128 | W2 128 x 1024
+ *       OUT pad16(d_out) x 128
+ *   f : fp32 blob: b_P1 256 | b_P2 256 | b_P3 128 | b_IN 128 |
+ *       per layer: ln0 gamma 128, beta 128 | b_QKV 384 | b_FC 128 (= fc_x.bias + fc_h.bias) | ln1 gamma 128, beta 128 |
+ *                  b_W1 1024 | b_W2 128
+ *       final ln gamma 128, beta 128 | b_OUT pad16(d_out)
+ *   (kantts_pnca_decode_blob_sizes reports both element counts.)
+ *   memory (B, L, d_mem) fp32; hkv (B, L, n_layer * 256) fp32: the memory K | V projection of layer i at columns
+ *   [256 i, 256 i + 256); xkv (n_layer, B, L, 256) fp32 workspace (the decoder's own K | V cache, contents irrelevant);
+ *   out (B, L, d_out); lens (B) steps per sequence (rows at and after lens[b] are the reference's masked rows: x = 0);
+ *   bw_seq (B) band width per sequence or NULL (then `bw`).  Band widths above 127: KANTTS_E_UNSUPPORTED (bw) / NaN in
+ *   `out` (device-side bw_seq).  Frame fed back: the last d_mel values of a step's output. */
+typedef struct kantts_decode_args {
+  const void* w;
+  const float* f;
+  const float* memory;
+  const float* hkv;
+  float* xkv;
+  float* out;
+  const int32_t* lens;
+  const int32_t* bw_seq;
+  int B, L, d_mem, d_mel, d_out, n_layer, bw;
+  float in_scale; /* sqrt(d_model): the input projection's alpha */
+  float eps;      /* of every LayerNorm */
+} kantts_decode_args;
+int kantts_pnca_decode_run(const kantts_decode_args* args, void* stream);
+int kantts_pnca_decode_blob_sizes(int d_mel, int d_mem, int d_out, int n_layer, long long* w_elems, long long* f_elems);
+
+/* kantts_dur_ar_run: the free-running duration predictor (VarRnnARPredictor.infer, kantts/models/sambert/adaptors.py:67-83):
+ * token i consumes the prediction of token i - 1 through prenet (1 -> 128 -> 128) -> 2 LSTM cells (H = 128) -> Linear -> ReLU.
+ * One workgroup per sequence walks its tokens.  The part of the first cell's gate pre-activations that depends on the
+ * conditioning only is one GEMM the caller runs before:  gc (B, T, 512) = cond . W_ih0[:, 128:]^T + b_ih0 + b_hh0.
+ *   w : bf16 blob: P2 128 x 128 | G0 512 x 256 [W_ih0[:, :128] | W_hh0] | G1 512 x 256 [W_ih1 | W_hh1]
+ *   f : fp32 blob: w_P1 128 | b_P1 128 | b_P2 128 | b_G1 512 (= b_ih1 + b_hh1) | w_fc 128 | b_fc 1 | 0 0 0
+ *       (the one-input prenet layer and the one-row output layer are evaluated in fp32)
+ *   out (B, T): ReLU(fc(h1)) per token, 0 at and after lens[b] (lens NULL: every sequence has T tokens). */
+typedef struct kantts_durar_args {
+  const void* w;
+  const float* f;
+  const float* gc;
+  float* out;
+  const int32_t* lens;
+  int B, T;
+} kantts_durar_args;
+int kantts_dur_ar_run(const kantts_durar_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,442 @@
+// Free-running inference loops as ONE launch each (round 5; SURVEY 8 row e1, bf16 mode).
+//
+//   pnca_decode_run_kernel : every step of the free-running mel decoder -- kantts/models/sambert/kantts_sambert.py:569-610
+//                            (the loop), :208-253 (HybridAttentionDecoder.infer), kantts/models/sambert/__init__.py:217-306
+//                            (PNCA attention under update_x_state / update_h_state), :109-149 (feed-forward).
+//   dur_ar_run_kernel      : the autoregressive duration predictor -- kantts/models/sambert/adaptors.py:67-83.
+//
+// Until round 5 a decoder step was a replayed hipGraph of ~90 launches (0.36 ms per step at batch 1: 63 % of a batch-1
+// utterance, profiles/r05_runT_inference_batch1_breakdown.log) and a duration token was eight launches issued from
+// Python (20 %).  Both loops are chains of matrix-VECTOR products per sequence with no work shared between sequences, so
+// here ONE workgroup owns one sequence and walks the whole loop: nothing returns to the host between steps.
+//
+// A step is bound by streaming the weights (8.6 MB of bf16 per decoder step) into one CU and by the latency of ~50
+// dependent products, not by arithmetic.  The products run on v_mfma_f32_16x16x32_bf16 with the weight rows as the A operand
+// (16 output channels x 32 inputs per instruction, 16-byte loads straight from the row-major bf16 matrix, no cross-lane
+// reduction) and the sequence's vector broadcast into every column of B: the instruction does 16 x the useful work, at
+// the same issue cost per weight as v_dot2 and without its 4-step lane reduction per output.  Up to 16 weight loads per
+// lane are issued before the first is consumed.  Activations live in LDS; HBM sees the K / V cache and the output frames.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define AR_THREADS 512
+#define AR_WAVES 8
+#define AR_D 128        // model width
+#define AR_H 8          // heads
+#define AR_DH 16        // head width
+#define AR_FF 1024      // feed-forward width
+#define AR_PRE 256      // decoder prenet width
+#define AR_KMAX 128     // keys per band (band width + 1)
+
+__device__ __forceinline__ int ar_pad128(int k) { return (k + 127) / 128 * 128; }
+__device__ __forceinline__ int ar_pad16(int n) { return (n + 15) / 16 * 16; }
+
+// y[n] = sum_k W[n][k] x[k] for n < N (N % 16 == 0); W bf16 row-major with pitch 128 * KU, x = xs[0 .. 128 KU) bf16 in LDS.
+// Wave w takes the 16-row tiles w, w + 8, ...; epi(n, y + bias[n]) runs once per output (lanes 0, 16, 32, 48 of the
+// tile's wave, four consecutive outputs each).  TPI tiles x min(KU, 4) k-blocks of 128 = up to 16 weight loads in flight
+// per lane; the bias (N floats in global memory, 16-byte aligned) is fetched with the first of them, not after the last.
+template <int KU, class Epi>
+__device__ __forceinline__ void ar_gemv(const __bf16* __restrict__ W, int N, const __bf16* xs,
+                                        const float* __restrict__ bias, Epi epi) {
+  constexpr int TPI = KU == 1 ? 4 : (KU == 2 ? 2 : 1);
+  constexpr int UC = KU < 4 ? KU : 4;  // k-blocks per chunk
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kg = lane >> 4;
+  const int ntile = N >> 4;
+  const long long ldw = 128 * KU;
+  for (int t0 = wave; t0 < ntile; t0 += AR_WAVES * TPI) {
+    f32x4 acc[TPI], bia[TPI];
+#pragma unroll
+    for (int j = 0; j < TPI; ++j) {
+      acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bia[j] = *reinterpret_cast<const f32x4*>(bias + min(t0 + j * AR_WAVES, ntile - 1) * 16 + 4 * kg);
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < KU; u0 += UC) {
+      bf16x8 a[TPI][UC][4];
+#pragma unroll
+      for (int j = 0; j < TPI; ++j) {
+        const int tile = min(t0 + j * AR_WAVES, ntile - 1);  // clamped: loads stay unconditional
+        const __bf16* row = W + (long long)(tile * 16 + li) * ldw + kg * 8;
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+          const int uu = (u0 + u < KU) ? u0 + u : KU - 1;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) a[j][u][kk] = *reinterpret_cast<const bf16x8*>(row + uu * 128 + kk * 32);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        if (u0 + u < KU) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(xs + (u0 + u) * 128 + kk * 32 + kg * 8);
+#pragma unroll
+            for (int j = 0; j < TPI; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][u][kk], bv, acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (li == 0) {
+#pragma unroll
+      for (int j = 0; j < TPI; ++j) {
+        const int tile = t0 + j * AR_WAVES;
+        if (tile < ntile) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) epi(tile * 16 + 4 * kg + r, acc[j][r] + bia[j][r]);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float ar_wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// LayerNorm of the 128-wide row xs (fp32, LDS) into vout (bf16, LDS): wave 0 only, two elements per lane; the caller
+// synchronises the workgroup afterwards.  Two-pass variance like csrc/norm.hip.  The affine parameters arrive in registers
+// (ArLnParams, loaded by lanes of wave 0 BEFORE the product that precedes the LayerNorm: their latency is off the chain).
+struct ArLnParams {
+  float g0, g1, b0, b1;
+};
+__device__ __forceinline__ ArLnParams ar_ln_load(const float* __restrict__ gamma_beta) {
+  ArLnParams p = {0.f, 0.f, 0.f, 0.f};
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    p.g0 = gamma_beta[l], p.g1 = gamma_beta[l + 64], p.b0 = gamma_beta[AR_D + l], p.b1 = gamma_beta[AR_D + l + 64];
+  }
+  return p;
+}
+__device__ __forceinline__ void ar_layernorm(const float* xs, const ArLnParams p, float eps, __bf16* vout) {
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    const float a = xs[l], b = xs[l + 64];
+    const float mean = ar_wave_sum(a + b) * (1.f / AR_D);
+    const float da = a - mean, db = b - mean;
+    const float var = ar_wave_sum(da * da + db * db) * (1.f / AR_D);
+    const float rstd = rsqrtf(var + eps);
+    vout[l] = (__bf16)fmaf(da * rstd, p.g0, p.b0);
+    vout[l + 64] = (__bf16)fmaf(db * rstd, p.g1, p.b1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+struct ArDecLayout {
+  long long w_p1, w_p2, w_p3, w_in, w_layer0, w_layer, w_out, w_total;
+  long long f_p1, f_p2, f_p3, f_in, f_layer0, f_layer, f_lnf, f_out, f_total;
+  int k_p1, k_in, n_out;
+};
+// offsets inside a layer's slice
+#define AR_WL_QKV 0
+#define AR_WL_FC (384 * 128)
+#define AR_WL_W1 (AR_WL_FC + 128 * 256)
+#define AR_WL_W2 (AR_WL_W1 + AR_FF * 128)
+#define AR_WL_SIZE (AR_WL_W2 + 128 * AR_FF)
+#define AR_FL_LN0 0
+#define AR_FL_BQKV 256
+#define AR_FL_BFC (256 + 384)
+#define AR_FL_LN1 (AR_FL_BFC + 128)
+#define AR_FL_BW1 (AR_FL_LN1 + 256)
+#define AR_FL_BW2 (AR_FL_BW1 + AR_FF)
+#define AR_FL_SIZE (AR_FL_BW2 + 128)
+
+__host__ __device__ inline ArDecLayout ar_dec_layout(int d_mel, int d_mem, int d_out, int n_layer) {
+  ArDecLayout y;
+  y.k_p1 = (d_mel + 127) / 128 * 128;
+  y.k_in = (d_mem + AR_D + 127) / 128 * 128;
+  y.n_out = (d_out + 15) / 16 * 16;
+  y.w_p1 = 0;
+  y.w_p2 = y.w_p1 + (long long)AR_PRE * y.k_p1;
+  y.w_p3 = y.w_p2 + AR_PRE * AR_PRE;
+  y.w_in = y.w_p3 + AR_D * AR_PRE;
+  y.w_layer0 = y.w_in + (long long)AR_D * y.k_in;
+  y.w_layer = AR_WL_SIZE;
+  y.w_out = y.w_layer0 + y.w_layer * n_layer;
+  y.w_total = y.w_out + (long long)y.n_out * AR_D;
+  y.f_p1 = 0;
+  y.f_p2 = AR_PRE;
+  y.f_p3 = 2 * AR_PRE;
+  y.f_in = 2 * AR_PRE + AR_D;
+  y.f_layer0 = 2 * AR_PRE + 2 * AR_D;
+  y.f_layer = AR_FL_SIZE;
+  y.f_lnf = y.f_layer0 + y.f_layer * n_layer;
+  y.f_out = y.f_lnf + 2 * AR_D;
+  y.f_total = y.f_out + y.n_out;
+  return y;
+}
+
+__global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantts_decode_args g) {
+  __shared__ __attribute__((aligned(16))) __bf16 vA[AR_FF];
+  __shared__ __attribute__((aligned(16))) __bf16 vB[AR_FF];
+  __shared__ __attribute__((aligned(16))) float xs[AR_D];
+  __shared__ __attribute__((aligned(16))) float qkv[3 * AR_D];
+  __shared__ float sc[2][AR_H][AR_KMAX];
+  __shared__ float linv[2][AR_H];
+  __shared__ float frame[AR_D];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int L = g.L, d_mem = g.d_mem, d_mel = g.d_mel, d_out = g.d_out, NL = g.n_layer;
+  const ArDecLayout lay = ar_dec_layout(d_mel, d_mem, d_out, NL);
+  const __bf16* W = reinterpret_cast<const __bf16*>(g.w);
+  const float* F = g.f;
+  const int len = min(g.lens ? g.lens[b] : L, L);
+  const int bw = g.bw_seq ? g.bw_seq[b] : g.bw;
+  float* outb = g.out + (long long)b * L * d_out;
+  if (bw + 1 > AR_KMAX || bw < 0) {  // only reachable with a device-side band width: poison instead of a wrong answer
+    for (long long i = tid; i < (long long)L * d_out; i += AR_THREADS) outb[i] = __builtin_nanf("");
+    return;
+  }
+  const long long hkv_ld = (long long)NL * 256;
+  const float* memb = g.memory + (long long)b * L * d_mem;
+  const float* hkvb = g.hkv + (long long)b * L * hkv_ld;
+  if (tid < AR_D) frame[tid] = 0.f;
+  __syncthreads();
+  const ArLnParams lnf = ar_ln_load(F + lay.f_lnf);
+  for (int step = 0; step < L; ++step) {
+    const bool live = step < len;
+    if (live) {
+      // this step's memory row: in flight while the prenet runs
+      float memv = 0.f;
+      if (tid < d_mem) memv = memb[(long long)step * d_mem + tid];
+      // ---- prenet: d_mel -> 256 -> 256 -> 128 (ReLU, ReLU, none); dropout is off outside training
+      for (int k = tid; k < lay.k_p1; k += AR_THREADS) vA[k] = (__bf16)(k < d_mel ? frame[k] : 0.f);
+      __syncthreads();
+      ar_gemv<1>(W + lay.w_p1, AR_PRE, vA, F + lay.f_p1, [&](int n, float v) { vB[n] = (__bf16)fmaxf(v, 0.f); });
+      __syncthreads();
+      ar_gemv<2>(W + lay.w_p2, AR_PRE, vB, F + lay.f_p2, [&](int n, float v) { vA[n] = (__bf16)fmaxf(v, 0.f); });
+      __syncthreads();
+      // input of the entry projection: [memory[b, step, :] | prenet] (zero padded to the pitch)
+      for (int k = tid; k < lay.k_in; k += AR_THREADS)
+        if (k < d_mem || k >= d_mem + AR_D) vB[k] = (__bf16)(k < d_mem ? memv : 0.f);
+      ar_gemv<2>(W + lay.w_p3, AR_D, vA, F + lay.f_p3, [&](int n, float v) { vB[d_mem + n] = (__bf16)v; });
+      __syncthreads();
+      ArLnParams ln = ar_ln_load(F + lay.f_layer0 + AR_FL_LN0);
+      auto in_epi = [&](int n, float v) { xs[n] = v * g.in_scale; };
+      if (lay.k_in == 256)
+        ar_gemv<2>(W + lay.w_in, AR_D, vB, F + lay.f_in, in_epi);
+      else if (lay.k_in == 384)
+        ar_gemv<3>(W + lay.w_in, AR_D, vB, F + lay.f_in, in_epi);
+      else
+        ar_gemv<4>(W + lay.w_in, AR_D, vB, F + lay.f_in, in_epi);
+      __syncthreads();
+      for (int layer = 0; layer < NL; ++layer) {
+        const __bf16* Wl = W + lay.w_layer0 + (long long)layer * lay.w_layer;
+        const float* Fl = F + lay.f_layer0 + (long long)layer * lay.f_layer;
+        float* xkvb = g.xkv + ((long long)layer * g.B + b) * L * 256;
+        ar_layernorm(xs, ln, g.eps, vA);
+        __syncthreads();
+        // q | k | v of this step; k, v are appended to the sequence's cache
+        ar_gemv<1>(Wl + AR_WL_QKV, 3 * AR_D, vA, Fl + AR_FL_BQKV, [&](int n, float v) {
+          qkv[n] = v;
+          if (n >= AR_D) xkvb[(long long)step * 256 + (n - AR_D)] = v;
+        });
+        __syncthreads();
+        // ---- both attentions: causal band over the own cache, look-ahead band over the memory K / V.
+        // 32 lanes per (band, head): a key each (more than 32 keys: strided), softmax statistics by shuffles.
+        {
+          const int band = tid >> 8, head = (tid >> 5) & 7, jl = tid & 31;
+          const int lo = band == 0 ? max(0, step - bw) : step;
+          const int hi = band == 0 ? step : min(min(step + bw, L - 1), len - 1);
+          const int nk = hi - lo + 1;  // >= 1 on a live step
+          const float* kbase = (band == 0 ? xkvb : hkvb + layer * 256) + head * AR_DH;
+          const long long kst = band == 0 ? 256 : hkv_ld;
+          float q[AR_DH];
+#pragma unroll
+          for (int d = 0; d < AR_DH; ++d) q[d] = qkv[head * AR_DH + d];
+          float sv[AR_KMAX / 32];
+          float m = -INFINITY;
+#pragma unroll
+          for (int c = 0; c < AR_KMAX / 32; ++c) {
+            const int j = lo + jl + 32 * c;
+            float s = -INFINITY;
+            if (c * 32 < nk) {
+              const bool ok = j <= hi;
+              const bool own = (band == 0) && (j == step);  // this step's key never left the CU: read it from LDS
+              const float4* kp = reinterpret_cast<const float4*>(kbase + (long long)(ok ? j : lo) * kst);
+              float acc = 0.f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float4 kv = kp[e];
+                if (own) kv = *reinterpret_cast<const float4*>(&qkv[AR_D + head * AR_DH + 4 * e]);
+                acc = fmaf(q[4 * e], kv.x, acc);
+                acc = fmaf(q[4 * e + 1], kv.y, acc);
+                acc = fmaf(q[4 * e + 2], kv.z, acc);
+                acc = fmaf(q[4 * e + 3], kv.w, acc);
+              }
+              if (ok) s = acc * 0.25f;
+            }
+            sv[c] = s;
+            m = fmaxf(m, s);
+          }
+#pragma unroll
+          for (int x = 16; x >= 1; x >>= 1) m = fmaxf(m, __shfl_xor(m, x));
+          float l = 0.f;
+#pragma unroll
+          for (int c = 0; c < AR_KMAX / 32; ++c) {
+            if (c * 32 < nk) {
+              const float e = (lo + jl + 32 * c <= hi) ? expf(sv[c] - m) : 0.f;
+              sc[band][head][jl + 32 * c] = e;
+              l += e;
+            }
+          }
+#pragma unroll
+          for (int x = 16; x >= 1; x >>= 1) l += __shfl_xor(l, x);
+          if (jl == 0) linv[band][head] = 1.f / l;
+        }
+        __syncthreads();
+        if (tid < 2 * AR_D) {
+          const int band = tid >> 7, head = (tid >> 4) & 7, d = tid & 15;
+          const int lo = band == 0 ? max(0, step - bw) : step;
+          const int hi = band == 0 ? step : min(min(step + bw, L - 1), len - 1);
+          const int nk = hi - lo + 1;
+          const float* vbase = (band == 0 ? xkvb : hkvb + layer * 256) + AR_D + head * AR_DH + d;
+          const long long kst = band == 0 ? 256 : hkv_ld;
+          float o = 0.f;
+          for (int j0 = 0; j0 < nk; j0 += 4) {
+            float vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = lo + min(j0 + u, nk - 1);
+              vv[u] = vbase[(long long)j * kst];
+              if ((band == 0) && (j == step)) vv[u] = qkv[2 * AR_D + head * AR_DH + d];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (j0 + u < nk) o = fmaf(sc[band][head][j0 + u], vv[u], o);
+          }
+          vB[band * AR_D + head * AR_DH + d] = (__bf16)(o * linv[band][head]);
+        }
+        __syncthreads();
+        // fc_x(ox) + fc_h(oh) + residual
+        ln = ar_ln_load(Fl + AR_FL_LN1);
+        ar_gemv<2>(Wl + AR_WL_FC, AR_D, vB, Fl + AR_FL_BFC, [&](int n, float v) { xs[n] = v + xs[n]; });
+        __syncthreads();
+        ar_layernorm(xs, ln, g.eps, vA);
+        __syncthreads();
+        ar_gemv<1>(Wl + AR_WL_W1, AR_FF, vA, Fl + AR_FL_BW1, [&](int n, float v) { vB[n] = (__bf16)fmaxf(v, 0.f); });
+        __syncthreads();
+        if (layer + 1 < NL) ln = ar_ln_load(Fl + lay.f_layer + AR_FL_LN0);
+        ar_gemv<8>(Wl + AR_WL_W2, AR_D, vB, Fl + AR_FL_BW2, [&](int n, float v) { xs[n] = v + xs[n]; });
+        __syncthreads();
+      }
+    } else {
+      // a finished sequence: the reference zeroes the row after every sub-layer, so x = 0 enters the final LayerNorm
+      if (tid < AR_D) xs[tid] = 0.f;
+      __syncthreads();
+    }
+    ar_layernorm(xs, lnf, g.eps, vA);
+    __syncthreads();
+    ar_gemv<1>(W + lay.w_out, lay.n_out, vA, F + lay.f_out, [&](int n, float v) {
+      if (n < d_out) {
+        outb[(long long)step * d_out + n] = v;
+        if (n >= d_out - d_mel) frame[n - (d_out - d_mel)] = v;
+      }
+    });
+    __syncthreads();
+  }
+}
+
+extern "C" int kantts_pnca_decode_blob_sizes(int d_mel, int d_mem, int d_out, int n_layer, long long* w_elems,
+                                             long long* f_elems) {
+  if (d_mel < 1 || d_mel > AR_D || d_mem < 1 || d_mem + AR_D > 512 || d_out < d_mel || n_layer < 0) return KANTTS_E_UNSUPPORTED;
+  const ArDecLayout lay = ar_dec_layout(d_mel, d_mem, d_out, n_layer);
+  if (w_elems) *w_elems = lay.w_total;
+  if (f_elems) *f_elems = lay.f_total;
+  return KANTTS_OK;
+}
+
+extern "C" int kantts_pnca_decode_run(const kantts_decode_args* a, void* stream) {
+  if (!a || !a->w || !a->f || !a->memory || !a->hkv || !a->xkv || !a->out || a->B < 0 || a->L < 0) return KANTTS_E_BADARG;
+  if (a->d_mel < 1 || a->d_mel > AR_D || a->d_mem < 1 || a->d_mem + AR_D > 512 || a->d_out < a->d_mel || a->n_layer < 0)
+    return KANTTS_E_UNSUPPORTED;
+  if (!a->bw_seq && (a->bw < 0 || a->bw + 1 > AR_KMAX)) return KANTTS_E_UNSUPPORTED;
+  if (a->B == 0 || a->L == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(pnca_decode_run_kernel, dim3(a->B), dim3(AR_THREADS), 0, (hipStream_t)stream, *a);
+  KANTTS_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------ duration predictor
+#define DA_H 128
+#define DA_W_P2 0
+#define DA_W_G0 (DA_H * DA_H)
+#define DA_W_G1 (DA_W_G0 + 4 * DA_H * 2 * DA_H)
+#define DA_F_WP1 0
+#define DA_F_BP1 128
+#define DA_F_BP2 256
+#define DA_F_BG1 384
+#define DA_F_WFC (384 + 512)
+#define DA_F_BFC (DA_F_WFC + 128)
+
+__device__ __forceinline__ float da_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(AR_THREADS) void dur_ar_run_kernel(const kantts_durar_args g) {
+  __shared__ __attribute__((aligned(16))) __bf16 vA[2 * DA_H];
+  __shared__ __attribute__((aligned(16))) __bf16 vB[2 * DA_H];
+  __shared__ __attribute__((aligned(16))) float gate[4 * DA_H];
+  __shared__ float part[2];
+  __shared__ float xprev;
+  const int tid = threadIdx.x, b = blockIdx.x, T = g.T;
+  const __bf16* W = reinterpret_cast<const __bf16*>(g.w);
+  const float* F = g.f;
+  const int len = min(g.lens ? g.lens[b] : T, T);
+  const float* gcb = g.gc + (long long)b * T * 4 * DA_H;
+  float* outb = g.out + (long long)b * T;
+  float c0 = 0.f, c1 = 0.f;  // cell states of unit tid (threads < 128)
+  if (tid == 0) xprev = 0.f;
+  if (tid < DA_H) {
+    vB[DA_H + tid] = (__bf16)0.f;  // h0 of "token -1"
+    vA[DA_H + tid] = (__bf16)0.f;  // h1
+  }
+  __syncthreads();
+  for (int i = 0; i < len; ++i) {
+    // prenet layer 1 (one input) and the one-row output layer stay fp32: the bf16 contractions of this mode need extents
+    // that are multiples of 8, the per-launch path ran these two in fp32 as well
+    if (tid < DA_H) vA[tid] = (__bf16)fmaxf(fmaf(F[DA_F_WP1 + tid], xprev, F[DA_F_BP1 + tid]), 0.f);
+    __syncthreads();
+    // vA[128..255] still holds h1 of the previous token, but this product only reads the first 128 inputs
+    ar_gemv<1>(W + DA_W_P2, DA_H, vA, F + DA_F_BP2, [&](int n, float v) { vB[n] = (__bf16)fmaxf(v, 0.f); });
+    __syncthreads();
+    // cell 0: gates = gc[i] + [W_ih0[:, :128] | W_hh0] . [prenet | h0]
+    ar_gemv<2>(W + DA_W_G0, 4 * DA_H, vB, gcb + (long long)i * 4 * DA_H, [&](int n, float v) { gate[n] = v; });
+    __syncthreads();
+    if (tid < DA_H) {
+      const float gi = da_sigmoid(gate[tid]), gf = da_sigmoid(gate[DA_H + tid]);
+      const float gg = tanhf(gate[2 * DA_H + tid]), go = da_sigmoid(gate[3 * DA_H + tid]);
+      c0 = gf * c0 + gi * gg;
+      const __bf16 h = (__bf16)(go * tanhf(c0));
+      vA[tid] = h;           // input of cell 1: [h0 | h1]
+      vB[DA_H + tid] = h;    // recurrent input of cell 0 at the next token
+    }
+    __syncthreads();
+    ar_gemv<2>(W + DA_W_G1, 4 * DA_H, vA, F + DA_F_BG1, [&](int n, float v) { gate[n] = v; });
+    __syncthreads();
+    if (tid < DA_H) {
+      const float gi = da_sigmoid(gate[tid]), gf = da_sigmoid(gate[DA_H + tid]);
+      const float gg = tanhf(gate[2 * DA_H + tid]), go = da_sigmoid(gate[3 * DA_H + tid]);
+      c1 = gf * c1 + gi * gg;
+      const float h = go * tanhf(c1);
+      vA[DA_H + tid] = (__bf16)h;
+      // output layer: one row
+      const float p = ar_wave_sum(F[DA_F_WFC + tid] * h);
+      if ((tid & 63) == 0) part[tid >> 6] = p;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const float y = fmaxf(part[0] + part[1] + F[DA_F_BFC], 0.f);
+      xprev = y;
+      outb[i] = y;
+    }
+    __syncthreads();
+  }
+  for (int i = len + tid; i < T; i += AR_THREADS) outb[i] = 0.f;
+}
+
+extern "C" int kantts_dur_ar_run(const kantts_durar_args* a, void* stream) {
+  if (!a || !a->w || !a->f || !a->gc || !a->out || a->B < 0 || a->T < 0) return KANTTS_E_BADARG;
+  if (a->B == 0 || a->T == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(dur_ar_run_kernel, dim3(a->B), dim3(AR_THREADS), 0, (hipStream_t)stream, *a);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -272,6 +272,20 @@ class PlanArgs(Structure):
                 ("dec_input", c_void_p)]
 
 
+class DecodeArgs(Structure):
+    """kantts_decode_args (include/kantts_hip.h)."""
+    _fields_ = [("w", c_void_p), ("f", c_void_p), ("memory", c_void_p), ("hkv", c_void_p), ("xkv", c_void_p),
+                ("out", c_void_p), ("lens", c_void_p), ("bw_seq", c_void_p),
+                ("B", c_int32), ("L", c_int32), ("d_mem", c_int32), ("d_mel", c_int32), ("d_out", c_int32),
+                ("n_layer", c_int32), ("bw", c_int32), ("in_scale", c_float), ("eps", c_float)]
+
+
+class DurArArgs(Structure):
+    """kantts_durar_args (include/kantts_hip.h)."""
+    _fields_ = [("w", c_void_p), ("f", c_void_p), ("gc", c_void_p), ("out", c_void_p), ("lens", c_void_p),
+                ("B", c_int32), ("T", c_int32)]
+
+
 ROWSUM_MAX = 32
 
 
@@ -366,6 +380,10 @@ def lib():
         L.kantts_teacher_plan.argtypes = [POINTER(PlanArgs), c_void_p]
         L.kantts_pnca_attn_qkv_bwd.argtypes = [POINTER(PncaAttnBwdArgs), c_void_p]
         L.kantts_copy_roof.argtypes = [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p]
+        L.kantts_pnca_decode_run.argtypes = [POINTER(DecodeArgs), c_void_p]
+        L.kantts_dur_ar_run.argtypes = [POINTER(DurArArgs), c_void_p]
+        L.kantts_pnca_decode_blob_sizes.argtypes = [c_int, c_int, c_int, c_int, POINTER(ctypes.c_longlong),
+                                                    POINTER(ctypes.c_longlong)]
         L.kantts_pnca_block_bwd_ws_floats.argtypes = [c_int]
         L.kantts_pnca_block_bwd_ws_floats.restype = ctypes.c_longlong
         L.kantts_fragmajor_bf16.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
@@ -416,6 +434,7 @@ EXPORTED_SYMBOLS = [
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
     "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof", "kantts_pnca_attn_qkv_bwd",
+    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run",
 ]
 
 
@@ -805,6 +824,37 @@ def teacher_plan(in_lens, out_lens, dur, mel, pos, inv_ts, Tp, max_len, r):
         setattr(g, k, ptr(t))
     check(lib().kantts_teacher_plan(ctypes.byref(g), stream()), "teacher_plan")
     return o
+
+
+def decode_blob_sizes(d_mel, d_mem, d_out, n_layer):
+    """(bf16 elements, fp32 elements) of the two parameter blobs kantts_pnca_decode_run reads; None if unsupported."""
+    w, f = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    rc = lib().kantts_pnca_decode_blob_sizes(int(d_mel), int(d_mem), int(d_out), int(n_layer), ctypes.byref(w), ctypes.byref(f))
+    return None if rc != 0 else (int(w.value), int(f.value))
+
+
+def pnca_decode_run(w, f, memory, hkv, xkv, out, lens32, bw_seq, bw, d_mel, n_layer, in_scale, eps):
+    """Every step of the free-running mel decoder for every sequence in one launch (csrc/ar_infer.hip)."""
+    B, L, d_mem = memory.shape
+    g = DecodeArgs()
+    g.w, g.f = ptr(w, torch.bfloat16), ptr(f, torch.float32)
+    g.memory, g.hkv, g.xkv, g.out = (ptr(t, torch.float32) for t in (memory, hkv, xkv, out))
+    g.lens, g.bw_seq = ptr(lens32, torch.int32), ptr(bw_seq, torch.int32)
+    g.B, g.L, g.d_mem, g.d_mel, g.d_out, g.n_layer, g.bw = int(B), int(L), int(d_mem), int(d_mel), int(out.shape[2]), int(n_layer), int(bw)
+    g.in_scale, g.eps = float(in_scale), float(eps)
+    for t in (memory, hkv, xkv, out):
+        assert t.is_contiguous()
+    check(lib().kantts_pnca_decode_run(ctypes.byref(g), stream()), "pnca_decode_run")
+
+
+def dur_ar_run(w, f, gc, out, lens32):
+    """The free-running duration predictor for every sequence in one launch (csrc/ar_infer.hip)."""
+    B, T = out.shape
+    g = DurArArgs()
+    g.w, g.f, g.gc, g.out, g.lens = ptr(w, torch.bfloat16), ptr(f, torch.float32), ptr(gc, torch.float32), ptr(out, torch.float32), ptr(lens32, torch.int32)
+    g.B, g.T = int(B), int(T)
+    assert gc.is_contiguous() and out.is_contiguous() and gc.shape[-1] == 512
+    check(lib().kantts_dur_ar_run(ctypes.byref(g), stream()), "dur_ar_run")
 
 
 def pnca_attn_qkv_bwd(qkv, hkv, ldh, ox, oh, d_ox, d_oh, lse_x, lse_h, B, L, *, lens, bw_dev, bw_x, bw_h, att_p, seed_x, seed_h,

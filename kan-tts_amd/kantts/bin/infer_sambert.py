@@ -90,8 +90,10 @@ def am_infer(sentence, ckpt, output_dir, se_file=None, config=None, ling_unit=No
     results_dir = os.path.join(output_dir, "feat")
     os.makedirs(results_dir, exist_ok=True)
     fsnet.eval()
-    if device.type == "cuda":  # one decoder step = one hipGraph replay (kantts/models/sambert/decode_graph.py)
-        fsnet.mel_decoder.decode_mode = "graph"
+    if device.type == "cuda":
+        # bf16 mode: each autoregressive loop is one launch (kantts/models/sambert/ar_kernels.py); otherwise one decoder
+        # step = one hipGraph replay (kantts/models/sambert/decode_graph.py)
+        fsnet.mel_decoder.decode_mode = "kernel"
     with open(sentence, encoding="utf-8") as f:
         for line in f:
             line = line.strip().split("\t")

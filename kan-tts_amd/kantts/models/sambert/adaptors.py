@@ -57,6 +57,10 @@ class VarRnnARPredictor(nn.Module):
         self.lstm = nn.LSTM(prenet_units[-1] + cond_units, rnn_units, num_layers=2, batch_first=True,
                             bidirectional=False)
         self.fc = nn.Linear(rnn_units, 1)
+        # free-running inference: None = the one-launch loop where it applies (HIP device, bf16 mode), False = always the
+        # per-token launches, True = also on host tensors (the emulated C ABI of the CPU tests)
+        self.ar_kernel = None
+        self._ar = None
 
     def _layer(self, l):
         return [getattr(self.lstm, "%s_l%d" % (n, l)) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
@@ -79,6 +83,15 @@ class VarRnnARPredictor(nn.Module):
         GEMM over [prenet | cond | h] -- and the output GEMM; no tensor is concatenated or re-allocated per
         step (the reference re-runs nn.LSTM on a length-1 sequence and torch.cat's the outputs)."""
         B, T = cond.size(0), cond.size(1)
+        if self.ar_kernel is not False and (cond.is_cuda or self.ar_kernel is True):
+            # bf16 mode: the whole loop as ONE launch, a workgroup per sequence (csrc/ar_infer.hip)
+            from kantts.models.sambert.ar_kernels import DurationKernel
+
+            if DurationKernel.eligible(self, cond):
+                if self._ar is None:
+                    self._ar = DurationKernel(self)
+                info = SeqInfo.of(masks)
+                return self._ar.run(cond, None if info is None else info.lens32)
         w_ih0, w_hh0, b_ih0, b_hh0 = self._layer(0)
         w_ih1, w_hh1, b_ih1, b_hh1 = self._layer(1)
         d_p = w_ih0.shape[1] - cond.size(2)

@@ -372,8 +372,10 @@ class MelPNCADecoder(nn.Module):
                                               d_inner, dropout, dropout_attn, dropout_relu, d_mel * outputs_per_step)
         # free-running decode: "loop" = one launch per op and step from Python (the round-1 path), "fused" = the
         # step function of decode_graph.py run eagerly, "graph" = that step captured in a hipGraph and replayed
+        # "kernel" = the whole loop as one launch (ar_kernels.py; bf16 mode, falls back to "graph" / "loop")
         self.decode_mode = "loop"
         self._decode_cache = None
+        self._decode_kernel = None
 
     def forward(self, memory, x_band_width, h_band_width, target=None, mask=None, return_attns=False, bw_dev=None,
                 teacher_input=None, teacher_prenet=None):
@@ -390,7 +392,21 @@ class MelPNCADecoder(nn.Module):
         """Free-running decode (reference :568-610): step t consumes the last mel frame of step t-1.  Outputs land
         in one preallocated (B, L, r*d_mel) buffer instead of a python list + torch.cat."""
         B, L = memory.size(0), memory.size(1)
-        if self.decode_mode in ("graph", "fused") and memory.is_cuda or self.decode_mode == "fused":
+        if self.decode_mode == "kernel":
+            # the whole loop as ONE launch, a workgroup per sequence (csrc/ar_infer.hip); shapes / precisions it is not
+            # compiled for fall through to the replayed graph (HIP device) or the per-op loop
+            from kantts.models.sambert.ar_kernels import DecoderKernel
+            from kantts.models.utils import SeqInfo as _SeqInfo
+
+            host_bw = not torch.is_tensor(x_band_width) and not torch.is_tensor(h_band_width)
+            bw_max = int(x_band_width) if host_bw else -1
+            if host_bw and int(h_band_width) == bw_max and DecoderKernel.eligible(self.mel_dec, self.d_mel, bw_max):
+                if self._decode_kernel is None:
+                    self._decode_kernel = DecoderKernel(self.mel_dec, self.d_mel)
+                info = _SeqInfo.of(mask)
+                lens32 = None if info is None else info.lens32.clamp(max=L)
+                return self._decode_kernel.run(memory, lens32, bw_seq, bw_max), [], []
+        if (self.decode_mode in ("graph", "fused", "kernel") and memory.is_cuda) or self.decode_mode == "fused":
             # one decoder step = a static launch sequence with the step index in device memory (decode_graph.py);
             # "graph" replays it from a hipGraph captured per (B, L)
             from kantts.models.sambert.decode_graph import DecodeGraphCache
@@ -404,12 +420,12 @@ class MelPNCADecoder(nn.Module):
                                                               dtype=torch.int32)
             # decoder lengths are bucketed to multiples of 16 steps so that a handful of captured graphs serve every
             # utterance length (steps past a sequence's length are masked rows, exactly like batch padding)
-            Lp = (L + 15) // 16 * 16 if self.decode_mode == "graph" else L
+            Lp = (L + 15) // 16 * 16 if self.decode_mode != "fused" else L
             if Lp != L:
                 memory = F.pad(memory, (0, 0, 0, Lp - L))
             fr = self._decode_cache.get(self.mel_dec, self.d_mel, self.r, B, Lp, memory.device)
             fr.load(memory, lens32.clamp(max=L), bw)
-            return fr.run(graph=(self.decode_mode == "graph"))[:, :L].clone(), [], []
+            return fr.run(graph=(self.decode_mode != "fused"))[:, :L].clone(), [], []
         self.mel_dec.reset_state()
         memory = memory.contiguous()
         out = torch.empty((B, L, self.d_mel * self.r), device=memory.device, dtype=torch.float32)

@@ -621,6 +621,148 @@ class EmulatedLib:
         _arr(g.dec_input, B * L * D)[:] = di.reshape(-1).numpy()
         return 0
 
+    # ---- free-running inference loops as one launch each (csrc/ar_infer.hip) ----------------------------------------
+    @staticmethod
+    def _decode_layout(d_mel, d_mem, d_out, n_layer):
+        k_p1, k_in, n_out = (d_mel + 127) // 128 * 128, (d_mem + 128 + 127) // 128 * 128, (d_out + 15) // 16 * 16
+        w = {"p1": 0}
+        w["p2"] = w["p1"] + 256 * k_p1
+        w["p3"] = w["p2"] + 256 * 256
+        w["in"] = w["p3"] + 128 * 256
+        w["layer0"] = w["in"] + 128 * k_in
+        w["layer"] = 384 * 128 + 128 * 256 + 1024 * 128 + 128 * 1024
+        w["out"] = w["layer0"] + w["layer"] * n_layer
+        w["total"] = w["out"] + n_out * 128
+        f = {"p1": 0, "p2": 256, "p3": 512, "in": 640, "layer0": 768, "layer": 2176}
+        f["lnf"] = f["layer0"] + f["layer"] * n_layer
+        f["out"] = f["lnf"] + 256
+        f["total"] = f["out"] + n_out
+        return w, f, k_p1, k_in, n_out
+
+    def kantts_pnca_decode_blob_sizes(self, d_mel, d_mem, d_out, n_layer, w_elems, f_elems):
+        if d_mel < 1 or d_mel > 128 or d_mem < 1 or d_mem + 128 > 512 or d_out < d_mel or n_layer < 0:
+            return 3
+        w, f, _, _, _ = self._decode_layout(d_mel, d_mem, d_out, n_layer)
+        for ref, v in ((w_elems, w["total"]), (f_elems, f["total"])):
+            if ref is not None:
+                (ref._obj if hasattr(ref, "_obj") else ref).value = v
+        return 0
+
+    def kantts_pnca_decode_run(self, args_ref, stream):
+        """The free-running decoder loop, one sequence at a time, with the roundings of the kernel: contraction operands
+        (weights, LayerNorm outputs, contexts, prenet activations, the hidden feed-forward row) bf16, everything else fp32."""
+        g = args_ref._obj
+        B, L, d_mem, d_mel, d_out, NL = g.B, g.L, g.d_mem, g.d_mel, g.d_out, g.n_layer
+        if d_mel < 1 or d_mel > 128 or d_mem < 1 or d_mem + 128 > 512 or d_out < d_mel or NL < 0:
+            return 3
+        if not g.bw_seq and (g.bw < 0 or g.bw + 1 > 128):
+            return 3
+        if B == 0 or L == 0:
+            return 0
+        wl, fl, k_p1, k_in, n_out = self._decode_layout(d_mel, d_mem, d_out, NL)
+        W = _rd(g.w, wl["total"], True)
+        F = _arr(g.f, fl["total"]).copy()
+        mem = _arr(g.memory, B * L * d_mem).reshape(B, L, d_mem)
+        hkv = _arr(g.hkv, B * L * NL * 256).reshape(B, L, NL, 256)
+        xkv = _arr(g.xkv, NL * B * L * 256).reshape(NL, B, L, 256)
+        out = _arr(g.out, B * L * d_out).reshape(B, L, d_out)
+        lens = _arr(g.lens, B, np.int32) if g.lens else np.full(B, L, np.int32)
+        bws = _arr(g.bw_seq, B, np.int32) if g.bw_seq else np.full(B, g.bw, np.int32)
+        r16 = _bf16_round
+
+        def mat(off, n, k):
+            return W[off:off + n * k].reshape(n, k)
+
+        def ln(x, gb):
+            mu = x.mean(dtype=np.float32)
+            d = x - mu
+            var = np.mean(d * d, dtype=np.float32)
+            return r16(d / np.sqrt(var + np.float32(g.eps)) * gb[:128] + gb[128:256])
+
+        P1, P2, P3 = mat(wl["p1"], 256, k_p1), mat(wl["p2"], 256, 256), mat(wl["p3"], 128, 256)
+        IN, OUT = mat(wl["in"], 128, k_in), mat(wl["out"], n_out, 128)
+        for b in range(B):
+            ln_b, bw = min(int(lens[b]), L), int(bws[b])
+            if bw + 1 > 128 or bw < 0:
+                out[b] = np.nan
+                continue
+            frame = np.zeros(d_mel, np.float32)
+            for step in range(L):
+                if step < ln_b:
+                    v = np.zeros(k_p1, np.float32)
+                    v[:d_mel] = r16(frame)
+                    h = r16(np.maximum(P1 @ v + F[fl["p1"]:fl["p1"] + 256], 0))
+                    h = r16(np.maximum(P2 @ h + F[fl["p2"]:fl["p2"] + 256], 0))
+                    pre = r16(P3 @ h + F[fl["p3"]:fl["p3"] + 128])
+                    v = np.zeros(k_in, np.float32)
+                    v[:d_mem] = r16(mem[b, step])
+                    v[d_mem:d_mem + 128] = pre
+                    x = ((IN @ v + F[fl["in"]:fl["in"] + 128]) * np.float32(g.in_scale)).astype(np.float32)
+                    for i in range(NL):
+                        wo, fo = wl["layer0"] + i * wl["layer"], fl["layer0"] + i * fl["layer"]
+                        Fl = F[fo:fo + fl["layer"]]
+                        QKV = mat(wo, 384, 128)
+                        FC = mat(wo + 384 * 128, 128, 256)
+                        W1 = mat(wo + 384 * 128 + 128 * 256, 1024, 128)
+                        W2 = mat(wo + 384 * 128 + 128 * 256 + 1024 * 128, 128, 1024)
+                        qkv = (QKV @ ln(x, Fl[0:256]) + Fl[256:640]).astype(np.float32)
+                        xkv[i, b, step] = qkv[128:]
+                        ctx = np.zeros(256, np.float32)
+                        lo_x, hi_x = max(0, step - bw), step
+                        lo_h, hi_h = step, min(step + bw, L - 1, ln_b - 1)
+                        for band, (lo, hi, kv) in enumerate(((lo_x, hi_x, xkv[i, b]), (lo_h, hi_h, hkv[b, :, i]))):
+                            K = kv[lo:hi + 1, :128].reshape(-1, 8, 16)
+                            V = kv[lo:hi + 1, 128:].reshape(-1, 8, 16)
+                            sc = np.einsum("hd,jhd->hj", qkv[:128].reshape(8, 16), K).astype(np.float32) * np.float32(0.25)
+                            e = np.exp(sc - sc.max(axis=1, keepdims=True)).astype(np.float32)
+                            o = np.einsum("hj,jhd->hd", e, V).astype(np.float32) / e.sum(axis=1, keepdims=True)
+                            ctx[band * 128:(band + 1) * 128] = o.reshape(-1)
+                        x = (FC @ r16(ctx) + Fl[640:768] + x).astype(np.float32)
+                        hdn = r16(np.maximum(W1 @ ln(x, Fl[768:1024]) + Fl[1024:2048], 0))
+                        x = (W2 @ hdn + Fl[2048:2176] + x).astype(np.float32)
+                else:
+                    x = np.zeros(128, np.float32)
+                o = (OUT @ ln(x, F[fl["lnf"]:fl["lnf"] + 256]) + F[fl["out"]:fl["out"] + n_out]).astype(np.float32)[:d_out]
+                out[b, step] = o
+                frame = o[d_out - d_mel:]
+        return 0
+
+    def kantts_dur_ar_run(self, args_ref, stream):
+        """The free-running duration predictor: prenet(1 -> 128 -> 128) -> two LSTM cells -> Linear -> ReLU, fed back."""
+        g = args_ref._obj
+        B, T, H = g.B, g.T, 128
+        if B == 0 or T == 0:
+            return 0
+        W = _rd(g.w, H * H + 2 * 4 * H * 2 * H, True)
+        F = _arr(g.f, 1028).copy()
+        P2 = W[:H * H].reshape(H, H)
+        G0 = W[H * H:H * H + 4 * H * 2 * H].reshape(4 * H, 2 * H)
+        G1 = W[H * H + 4 * H * 2 * H:].reshape(4 * H, 2 * H)
+        gc = _arr(g.gc, B * T * 4 * H).reshape(B, T, 4 * H)
+        out = _arr(g.out, B * T).reshape(B, T)
+        lens = _arr(g.lens, B, np.int32) if g.lens else np.full(B, T, np.int32)
+        r16 = _bf16_round
+
+        def cell(gates, c):
+            sig = lambda v: (1.0 / (1.0 + np.exp(-v))).astype(np.float32)  # noqa: E731
+            c = sig(gates[H:2 * H]) * c + sig(gates[:H]) * np.tanh(gates[2 * H:3 * H])
+            return (sig(gates[3 * H:]) * np.tanh(c)).astype(np.float32), c.astype(np.float32)
+
+        for b in range(B):
+            h0 = h1 = np.zeros(H, np.float32)
+            c0 = c1 = np.zeros(H, np.float32)
+            x = np.float32(0)
+            n = min(int(lens[b]), T)
+            for i in range(n):
+                p = r16(np.maximum(F[0:128] * x + F[128:256], 0))
+                p = r16(np.maximum(P2 @ p + F[256:384], 0))
+                h0, c0 = cell((G0 @ np.concatenate([p, r16(h0)]) + gc[b, i]).astype(np.float32), c0)
+                h1, c1 = cell((G1 @ np.concatenate([r16(h0), r16(h1)]) + F[384:896]).astype(np.float32), c1)
+                x = np.float32(max(float(np.dot(F[896:1024], h1) + F[1024]), 0.0))
+                out[b, i] = x
+            out[b, n:] = 0
+        return 0
+
     def kantts_copy_roof(self, src, read_bytes, dst, write_bytes, stream):
         return 0  # a bandwidth calibration launch: no values to model
 

@@ -13,6 +13,7 @@ from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
 from kantts.utils.synthetic import inference_utterances
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+MODE = sys.argv[2] if len(sys.argv) > 2 else "graph"  # "kernel": each autoregressive loop as one launch
 from kantts.utils import synthetic
 cfg = synthetic.sambert_16k_config()
 hip.set_precision("bf16")
@@ -26,7 +27,8 @@ voc = Generator().to(dev).eval()
 voc.remove_weight_norm()
 lens, ling, emo, spk = inference_utterances(128)
 order = torch.argsort(lens, descending=True)
-am.mel_decoder.decode_mode = "graph"
+am.mel_decoder.decode_mode = MODE
+am.variance_adaptor.duration_predictor.ar_kernel = None if MODE == "kernel" else False
 T = collections.OrderedDict()
 
 
@@ -49,7 +51,7 @@ wrap(va.duration_predictor, "infer", "  duration AR loop")
 wrap(va.pitch_predictor, "forward", "  pitch predictor")
 wrap(va.energy_predictor, "forward", "  energy predictor")
 wrap(va, "forward", "variance adaptor (total)")
-wrap(am.mel_decoder, "forward", "mel decoder (graph replays)")
+wrap(am.mel_decoder, "forward", "mel decoder loop")
 wrap(am.mel_postnet, "forward", "postnet")
 wrap(voc, "forward", "vocoder")
 
@@ -75,7 +77,7 @@ t0 = time.perf_counter()
 frames = sum(synth(i) for i in sel)
 torch.cuda.synchronize()
 tot = time.perf_counter() - t0
-print("%d utterances, %d frames, %.2f ms per utterance (instrumented)" % (len(sel), frames, 1e3 * tot / len(sel)))
+print("decoder mode %s: %d utterances, %d frames, %.2f ms per utterance (instrumented)" % (MODE, len(sel), frames, 1e3 * tot / len(sel)))
 for k, v in T.items():
     print("%-32s %7.2f ms per utterance  %5.1f %%" % (k, 1e3 * v / len(sel), 100 * v / tot))
 print("%-32s %7.2f ms per utterance" % ("(outside the stages)", 1e3 * (tot - sum(v for k, v in T.items() if not k.startswith("  "))) / len(sel)))

@@ -1,0 +1,145 @@
+"""Free-running inference loops as one launch each (csrc/ar_infer.hip, kantts/models/sambert/ar_kernels.py): the mel
+decoder's loop (reference kantts/models/sambert/kantts_sambert.py:569-610, :208-253) and the duration predictor's
+(adaptors.py:67-83) against the per-launch paths they replace, which are pinned to the reference's own inference run
+(tests/test_decode_graph.py, tests/golden/sambert_tiny_infer.pt).  bf16 mode: both sides round the same contraction
+operands to bf16 and differ in summation order only -- and in the occasional bf16 tie that this flips."""
+import pytest
+import torch
+
+import torch_oracle as O
+from util import emulation, kernel_source_on_cpu, rel_l2
+
+
+def _model(device, layers=2):
+    from kantts.models.sambert.kantts_sambert import KanTtsSAMBERT
+
+    cfg = O.sambert_config(tiny=True)
+    cfg["decoder_num_layers"] = layers
+    torch.manual_seed(0)
+    m = KanTtsSAMBERT(dict(cfg))
+    with torch.no_grad():  # random-init LayerNorm / bias parameters are 1 / 0: make every term of the blobs matter
+        for n, p in m.named_parameters():
+            if n.endswith("bias") or "layer_norm" in n or n.endswith("ln.weight"):
+                p.add_(0.1 * torch.randn_like(p))
+    return m.to(device).eval()
+
+
+def _decode(m, device, mode, B, L, lens, bws, seed=3):
+    from kantts.models.utils import get_mask_from_lengths
+
+    g = torch.Generator().manual_seed(seed)
+    d_mem = m.mel_decoder.mel_dec.pnca[0].pnca_attn.d_mem
+    memory = (0.7 * torch.randn(B, L, d_mem, generator=g)).to(device)
+    lens_t = torch.tensor(lens, device=device)
+    bw_seq = torch.tensor(bws, device=device, dtype=torch.int32)
+    m.mel_decoder.decode_mode = mode
+    bw = int(max(bws))
+    with torch.no_grad():
+        out, _, _ = m.mel_decoder(memory, bw, bw, mask=get_mask_from_lengths(lens_t, L), bw_dev=bw_seq)
+    return out.detach().cpu()
+
+
+def _check_decoder(device, layers, B, L, lens, bws, ref_mode="fused"):
+    import kantts._hip as hip
+
+    hip.set_precision("bf16")
+    try:
+        m = _model(device, layers)
+        ref = _decode(m, device, ref_mode, B, L, lens, bws)
+        m.mel_decoder._decode_kernel = None
+        got = _decode(m, device, "kernel", B, L, lens, bws)
+        assert m.mel_decoder._decode_kernel is not None, "the one-launch decoder did not run"
+    finally:
+        hip.set_precision("fp32")
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    scale = float(ref.abs().max())
+    for b, n in enumerate(lens):  # the frames of a sequence, then the reference's masked rows behind them
+        assert rel_l2(got[b, :n], ref[b, :n]) < 3e-3, (b, rel_l2(got[b, :n], ref[b, :n]))
+        assert float((got[b] - ref[b]).abs().max()) < 3e-2 * scale, (b, float((got[b] - ref[b]).abs().max()), scale)
+
+
+def test_decoder_loop_as_one_launch_emulated():
+    """numpy model of kantts_pnca_decode_run against the per-launch step function on the emulated C ABI: ragged lengths, a
+    band wider than a sequence, band 0."""
+    with emulation():
+        _check_decoder("cpu", 2, 3, 9, [9, 5, 1], [2, 7, 0])
+
+
+def test_decoder_loop_as_one_launch_kernel_source():
+    """The kernel SOURCE on the CPU (tests/hipemu) against its own per-launch twins."""
+    with kernel_source_on_cpu():
+        _check_decoder("cpu", 2, 2, 6, [6, 3], [2, 4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,B,L,lens,bws", [(2, 3, 9, [9, 5, 1], [2, 7, 0]), (12, 4, 70, [70, 33, 64, 8], [6, 3, 40, 2])])
+def test_decoder_loop_as_one_launch_gpu(layers, B, L, lens, bws):
+    _check_decoder("cuda", layers, B, L, lens, bws, ref_mode="graph")
+
+
+@pytest.mark.gpu
+def test_decoder_loop_refuses_what_it_is_not_compiled_for_gpu():
+    """fp32 mode and band widths above 127 keep the replayed graph (the kernel object is never created)."""
+    import kantts._hip as hip
+
+    hip.set_precision("fp32")
+    m = _model("cuda")
+    _decode(m, "cuda", "kernel", 2, 6, [6, 4], [2, 2])
+    assert m.mel_decoder._decode_kernel is None
+    hip.set_precision("bf16")
+    try:
+        _decode(m, "cuda", "kernel", 1, 140, [140], [130])
+        assert m.mel_decoder._decode_kernel is None
+    finally:
+        hip.set_precision("fp32")
+
+
+def _durations(m, device, use_kernel, B, T, lens, seed=5):
+    from kantts.models.utils import get_mask_from_lengths
+
+    pred = m.variance_adaptor.duration_predictor
+    g = torch.Generator().manual_seed(seed)
+    cond = (0.8 * torch.randn(B, T, pred.lstm.input_size - 128, generator=g)).to(device)
+    pred.ar_kernel = True if use_kernel else False
+    pred._ar = None
+    with torch.no_grad():
+        out = pred.infer(cond, masks=None if lens is None else get_mask_from_lengths(torch.tensor(lens, device=device), T))
+    assert (pred._ar is not None) == bool(use_kernel)
+    return out.detach().cpu()
+
+
+def _check_durations(device, B, T, lens):
+    import kantts._hip as hip
+
+    hip.set_precision("bf16")
+    try:
+        m = _model(device)
+        with torch.no_grad():
+            m.variance_adaptor.duration_predictor.fc.bias.fill_(0.7)  # keep the fed-back value off the ReLU's zero
+        ref = _durations(m, device, False, B, T, lens)
+        got = _durations(m, device, True, B, T, lens)
+    finally:
+        hip.set_precision("fp32")
+    assert got.shape == ref.shape
+    assert float(ref.abs().max()) > 0.1
+    assert float((got - ref).abs().max()) < 5e-3 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+    if lens is not None:
+        for b, n in enumerate(lens):
+            assert float(got[b, n:].abs().max() if n < T else 0.0) == 0.0
+
+
+def test_duration_loop_as_one_launch_emulated():
+    with emulation():
+        _check_durations("cpu", 3, 7, [7, 4, 1])
+        _check_durations("cpu", 2, 5, None)
+
+
+def test_duration_loop_as_one_launch_kernel_source():
+    with kernel_source_on_cpu():
+        _check_durations("cpu", 2, 6, [6, 3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,lens", [(3, 7, [7, 4, 1]), (32, 80, None), (5, 61, [61, 20, 33, 60, 2])])
+def test_duration_loop_as_one_launch_gpu(B, T, lens):
+    _check_durations("cuda", B, T, lens)
