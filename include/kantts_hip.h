@@ -1074,7 +1074,9 @@ int kantts_ragged_rows_i64(const int64_t* src, const int64_t* row_off, const int
  * matrix-vector products stream the bf16 weights from L2 as MFMA A operands (every column of the B operand is the
  * sequence's vector), activations stay in LDS, the decoder's K / V cache and the output frames are the only HBM writes.
  * Shapes fixed by the kernel: d_model 128, 8 heads x 16, feed-forward width 1024, prenet (d_mel -> 256 -> 256 -> 128).
- *   w : bf16 blob, every matrix row-major (out, in) with the row pitch padded to a multiple of 128 (zeros):
+ *   w : bf16 blob; every matrix (out, in) has its input width padded to a multiple of 128 (zeros) and is stored
+ *       fragment-major like the images of kantts_fragmajor_bf16: element (16 t + i, 32 kb + 8 q + e) at
+ *       (((t * in/32 + kb) * 4 + q) * 16 + i) * 8 + e -- the 1 KB one MFMA A operand needs is contiguous:
  *       P1 256 x pad(d_mel) | P2 256 x 256 | P3 128 x 256 | IN 128 x pad(d_mem + 128)  [columns: memory, prenet]
  *       per layer: QKV 384 x 128 | FC 128 x 256 [fc_x | fc_h] | W1 1024 x 128 | W2 128 x 1024
  *       OUT pad16(d_out) x 128
@@ -1108,7 +1110,8 @@ int kantts_pnca_decode_blob_sizes(int d_mel, int d_mem, int d_out, int n_layer, 
  * token i consumes the prediction of token i - 1 through prenet (1 -> 128 -> 128) -> 2 LSTM cells (H = 128) -> Linear -> ReLU.
  * One workgroup per sequence walks its tokens.  The part of the first cell's gate pre-activations that depends on the
  * conditioning only is one GEMM the caller runs before:  gc (B, T, 512) = cond . W_ih0[:, 128:]^T + b_ih0 + b_hh0.
- *   w : bf16 blob: P2 128 x 128 | G0 512 x 256 [W_ih0[:, :128] | W_hh0] | G1 512 x 256 [W_ih1 | W_hh1]
+ *   w : bf16 blob (fragment-major matrices, as above): P2 128 x 128 | G0 512 x 256 [W_ih0[:, :128] | W_hh0] |
+ *       G1 512 x 256 [W_ih1 | W_hh1]
  *   f : fp32 blob: w_P1 128 | b_P1 128 | b_P2 128 | b_G1 512 (= b_ih1 + b_hh1) | w_fc 128 | b_fc 1 | 0 0 0
  *       (the one-input prenet layer and the one-row output layer are evaluated in fp32)
  *   out (B, T): ReLU(fc(h1)) per token, 0 at and after lens[b] (lens NULL: every sequence has T tokens). */

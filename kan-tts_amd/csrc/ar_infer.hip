@@ -29,11 +29,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define AR_FF 1024      // feed-forward width
 #define AR_PRE 256      // decoder prenet width
 #define AR_KMAX 128     // keys per band (band width + 1)
+#define AR_LK 16        // band rows kept in LDS per band (band widths up to 15); wider bands read the caches in place
+#define AR_LP 260       // their row pitch in floats
 
 __device__ __forceinline__ int ar_pad128(int k) { return (k + 127) / 128 * 128; }
 __device__ __forceinline__ int ar_pad16(int n) { return (n + 15) / 16 * 16; }
 
-// y[n] = sum_k W[n][k] x[k] for n < N (N % 16 == 0); W bf16 row-major with pitch 128 * KU, x = xs[0 .. 128 KU) bf16 in LDS.
+// Loads whose address is "uniform base + 32-bit lane offset": written so that the base stays in SGPRs (the saddr form of
+// global_load).  Folding the lane offset into the base pointer first makes every address a 64-bit VGPR pair, and the
+// pipelined layer loop has ~100 of them live: 444 bytes of scratch per lane.
+__device__ __forceinline__ bf16x8 ar_ldw(const __bf16* ubase, unsigned lane_elems) {
+  return *reinterpret_cast<const bf16x8*>(ubase + lane_elems);
+}
+__device__ __forceinline__ f32x4 ar_ldf(const float* ubase, unsigned lane_elems) {
+  return *reinterpret_cast<const f32x4*>(ubase + lane_elems);
+}
+
+// y[n] = sum_k W[n][k] x[k] for n < N (N % 16 == 0), K = 128 KU, x = xs[0 .. K) bf16 in LDS.  W is stored FRAGMENT-MAJOR:
+// the 16 rows x 32 inputs one MFMA takes as its A operand are 1 KB contiguous, lane l's eight values at +16 l bytes
+// (tile-major, then k-block; the layout of kantts_fragmajor_bf16), so one load instruction of a wave reads 1 KB of
+// consecutive addresses.  (First version: row-major rows, lane (row li, chunk kg) -> sixteen different 128-byte lines per
+// quarter-wave: 28 GB/s per CU, 9.5 us for the 262 KB of a feed-forward product -- profiles/r05_runW_decode_phases.log.)
 // Wave w takes the 16-row tiles w, w + 8, ...; epi(n, y + bias[n]) runs once per output (lanes 0, 16, 32, 48 of the
 // tile's wave, four consecutive outputs each).  TPI tiles x min(KU, 4) k-blocks of 128 = up to 16 weight loads in flight
 // per lane; the bias (N floats in global memory, 16-byte aligned) is fetched with the first of them, not after the last.
@@ -42,15 +58,23 @@ __device__ __forceinline__ void ar_gemv(const __bf16* __restrict__ W, int N, con
                                         const float* __restrict__ bias, Epi epi) {
   constexpr int TPI = KU == 1 ? 4 : (KU == 2 ? 2 : 1);
   constexpr int UC = KU < 4 ? KU : 4;  // k-blocks per chunk
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kg = lane >> 4;
+  // the wave index as a SCALAR: tile indices and matrix bases then live in SGPRs and a load is "scalar base + lane offset".
+  // (As a vector value every one of the ~150 load addresses of the kernel became a hoisted 64-bit VGPR pair: 344 bytes of
+  // scratch per lane.)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, kg = lane >> 4;
   const int ntile = N >> 4;
   const long long ldw = 128 * KU;
+  // lane offsets the compiler cannot see through: otherwise "matrix base + lane offset" of every product of the kernel is
+  // hoisted to the top as a 64-bit VGPR pair and most of them live in scratch
+  unsigned lane8 = 8u * lane, kg4 = 4u * kg;
+  KANTTS_OPAQUE_VGPR(lane8);
+  KANTTS_OPAQUE_VGPR(kg4);
   for (int t0 = wave; t0 < ntile; t0 += AR_WAVES * TPI) {
     f32x4 acc[TPI], bia[TPI];
 #pragma unroll
     for (int j = 0; j < TPI; ++j) {
       acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      bia[j] = *reinterpret_cast<const f32x4*>(bias + min(t0 + j * AR_WAVES, ntile - 1) * 16 + 4 * kg);
+      bia[j] = ar_ldf(bias + min(t0 + j * AR_WAVES, ntile - 1) * 16, kg4);
     }
 #pragma unroll
     for (int u0 = 0; u0 < KU; u0 += UC) {
@@ -58,14 +82,17 @@ __device__ __forceinline__ void ar_gemv(const __bf16* __restrict__ W, int N, con
 #pragma unroll
       for (int j = 0; j < TPI; ++j) {
         const int tile = min(t0 + j * AR_WAVES, ntile - 1);  // clamped: loads stay unconditional
-        const __bf16* row = W + (long long)(tile * 16 + li) * ldw + kg * 8;
+        const __bf16* frag = W + (long long)tile * 16 * ldw;
 #pragma unroll
         for (int u = 0; u < UC; ++u) {
           const int uu = (u0 + u < KU) ? u0 + u : KU - 1;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) a[j][u][kk] = *reinterpret_cast<const bf16x8*>(row + uu * 128 + kk * 32);
+          for (int kk = 0; kk < 4; ++kk) a[j][u][kk] = ar_ldw(frag + (uu * 4 + kk) * 512, lane8);
         }
       }
+      // every load above (and the bias) is issued before the first product: left alone, the scheduler sinks each load to
+      // just in front of its MFMA (2-4 in flight instead of 16) and the bias into the epilogue's branch (a second round trip)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < UC; ++u) {
         if (u0 + u < KU) {
@@ -78,6 +105,8 @@ __device__ __forceinline__ void ar_gemv(const __bf16* __restrict__ W, int N, con
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < TPI; ++j) KANTTS_OPAQUE_VGPR(bia[j]);  // the bias exists HERE: its load cannot sink into the branch
     if (li == 0) {
 #pragma unroll
       for (int j = 0; j < TPI; ++j) {
@@ -91,9 +120,26 @@ __device__ __forceinline__ void ar_gemv(const __bf16* __restrict__ W, int N, con
   }
 }
 
+// Sum over the 64 lanes of a wave, result in every lane: four DPP steps inside each row of 16 lanes, then two shuffles across
+// the rows (six shuffles were 0.6 us per LayerNorm: a ds_bpermute round trip each, all dependent).
+__device__ __forceinline__ float ar_row_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, false));  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float ar_row_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, false)));
+  return v;
+}
 __device__ __forceinline__ float ar_wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  v = ar_row_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
   return v;
 }
 
@@ -123,6 +169,30 @@ __device__ __forceinline__ void ar_layernorm(const float* xs, const ArLnParams p
     vout[l + 64] = (__bf16)fmaf(db * rstd, p.g1, p.b1);
   }
 }
+
+// Phase timing of the decoder kernel (-DAR_PROFILE variant build only, scripts/build_arprof.sh): thread 0 of workgroup 0
+// adds the 100 MHz wall-clock ticks between two marks to ar_prof[phase]; kantts_ar_profile_read copies them out.
+#ifdef AR_PROFILE
+__device__ unsigned long long ar_prof[16];
+#define AR_MARK(i)                                        \
+  do {                                                    \
+    if (threadIdx.x == 0 && blockIdx.x == 0) {            \
+      const unsigned long long now_ = wall_clock64();     \
+      ar_prof[i] += now_ - ar_last;                       \
+      ar_last = now_;                                     \
+    }                                                     \
+  } while (0)
+extern "C" int kantts_ar_profile_read(unsigned long long* out16, int reset) {
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(ar_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ar_prof), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define AR_MARK(i)
+#endif
 
 // ------------------------------------------------------------------------------------------------ decoder
 struct ArDecLayout {
@@ -175,6 +245,7 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
   __shared__ __attribute__((aligned(16))) float xs[AR_D];
   __shared__ __attribute__((aligned(16))) float qkv[3 * AR_D];
   __shared__ float sc[2][AR_H][AR_KMAX];
+  __shared__ __attribute__((aligned(16))) float kvs[2][AR_LK][AR_LP];  // K | V rows of the two bands (bw < AR_LK)
   __shared__ float linv[2][AR_H];
   __shared__ float frame[AR_D];
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -195,6 +266,9 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
   if (tid < AR_D) frame[tid] = 0.f;
   __syncthreads();
   const ArLnParams lnf = ar_ln_load(F + lay.f_lnf);
+#ifdef AR_PROFILE
+  unsigned long long ar_last = wall_clock64();
+#endif
   for (int step = 0; step < L; ++step) {
     const bool live = step < len;
     if (live) {
@@ -222,23 +296,52 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
       else
         ar_gemv<4>(W + lay.w_in, AR_D, vB, F + lay.f_in, in_epi);
       __syncthreads();
+      AR_MARK(0);
+      // (A software-pipelined form of this loop -- each product's first 16 weight loads issued during the previous phase --
+      // was built and measured: 182 us per step against 158.  A product is bound by what one CU can pull from L2
+      // (~85 GB/s here), not by the latency in front of it, and the pipeline's registers spilled.
+      // profiles/r05_runZ_decode_phases_pipelined.log)
+      const bool kv_lds = bw < AR_LK;
+      const int lo_x = max(0, step - bw);
       for (int layer = 0; layer < NL; ++layer) {
         const __bf16* Wl = W + lay.w_layer0 + (long long)layer * lay.w_layer;
         const float* Fl = F + lay.f_layer0 + (long long)layer * lay.f_layer;
         float* xkvb = g.xkv + ((long long)layer * g.B + b) * L * 256;
+        // the K | V rows both attentions of this layer will read -- earlier steps of the own cache, the look-ahead rows of
+        // the memory projection -- do not depend on this step's arithmetic: their loads are in flight during the LayerNorm
+        // and land in LDS (row r of band 0 = cache row lo_x + r, of band 1 = memory row step + r)
+        f32x4 kvp[4];
+        if (kv_lds) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int idx = tid + AR_THREADS * q4, band = idx >> 10, row = (idx >> 6) & 15, c4 = idx & 63;
+            const int j = band == 0 ? min(lo_x + row, max(step - 1, 0)) : min(step + row, L - 1);
+            const float* src = band == 0 ? xkvb + (long long)j * 256 : hkvb + (long long)j * hkv_ld + layer * 256;
+            kvp[q4] = *reinterpret_cast<const f32x4*>(src + 4 * c4);
+          }
+        }
         ar_layernorm(xs, ln, g.eps, vA);
+        if (kv_lds) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int idx = tid + AR_THREADS * q4, band = idx >> 10, row = (idx >> 6) & 15, c4 = idx & 63;
+            *reinterpret_cast<f32x4*>(&kvs[band][row][4 * c4]) = kvp[q4];
+          }
+        }
         __syncthreads();
+        AR_MARK(1);
         // q | k | v of this step; k, v are appended to the sequence's cache
         ar_gemv<1>(Wl + AR_WL_QKV, 3 * AR_D, vA, Fl + AR_FL_BQKV, [&](int n, float v) {
           qkv[n] = v;
           if (n >= AR_D) xkvb[(long long)step * 256 + (n - AR_D)] = v;
         });
         __syncthreads();
+        AR_MARK(2);
         // ---- both attentions: causal band over the own cache, look-ahead band over the memory K / V.
-        // 32 lanes per (band, head): a key each (more than 32 keys: strided), softmax statistics by shuffles.
+        // 32 lanes per (band, head): a key each (more than 32 keys: strided), softmax statistics by DPP + one shuffle.
         {
           const int band = tid >> 8, head = (tid >> 5) & 7, jl = tid & 31;
-          const int lo = band == 0 ? max(0, step - bw) : step;
+          const int lo = band == 0 ? lo_x : step;
           const int hi = band == 0 ? step : min(min(step + bw, L - 1), len - 1);
           const int nk = hi - lo + 1;  // >= 1 on a live step
           const float* kbase = (band == 0 ? xkvb : hkvb + layer * 256) + head * AR_DH;
@@ -255,7 +358,8 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
             if (c * 32 < nk) {
               const bool ok = j <= hi;
               const bool own = (band == 0) && (j == step);  // this step's key never left the CU: read it from LDS
-              const float4* kp = reinterpret_cast<const float4*>(kbase + (long long)(ok ? j : lo) * kst);
+              const float4* kp = kv_lds ? reinterpret_cast<const float4*>(&kvs[band][ok && !own ? j - lo : 0][head * AR_DH])
+                                        : reinterpret_cast<const float4*>(kbase + (long long)(ok ? j : lo) * kst);
               float acc = 0.f;
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
@@ -271,8 +375,8 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
             sv[c] = s;
             m = fmaxf(m, s);
           }
-#pragma unroll
-          for (int x = 16; x >= 1; x >>= 1) m = fmaxf(m, __shfl_xor(m, x));
+          m = ar_row_max(m);
+          m = fmaxf(m, __shfl_xor(m, 16));
           float l = 0.f;
 #pragma unroll
           for (int c = 0; c < AR_KMAX / 32; ++c) {
@@ -282,14 +386,15 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
               l += e;
             }
           }
-#pragma unroll
-          for (int x = 16; x >= 1; x >>= 1) l += __shfl_xor(l, x);
+          l = ar_row_sum(l);
+          l += __shfl_xor(l, 16);
           if (jl == 0) linv[band][head] = 1.f / l;
         }
         __syncthreads();
+        AR_MARK(3);
         if (tid < 2 * AR_D) {
           const int band = tid >> 7, head = (tid >> 4) & 7, d = tid & 15;
-          const int lo = band == 0 ? max(0, step - bw) : step;
+          const int lo = band == 0 ? lo_x : step;
           const int hi = band == 0 ? step : min(min(step + bw, L - 1), len - 1);
           const int nk = hi - lo + 1;
           const float* vbase = (band == 0 ? xkvb : hkvb + layer * 256) + AR_D + head * AR_DH + d;
@@ -300,8 +405,9 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int j = lo + min(j0 + u, nk - 1);
-              vv[u] = vbase[(long long)j * kst];
-              if ((band == 0) && (j == step)) vv[u] = qkv[2 * AR_D + head * AR_DH + d];
+              const bool own = (band == 0) && (j == step);
+              vv[u] = kv_lds ? kvs[band][own ? 0 : j - lo][AR_D + head * AR_DH + d] : vbase[(long long)j * kst];
+              if (own) vv[u] = qkv[2 * AR_D + head * AR_DH + d];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -310,17 +416,22 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
           vB[band * AR_D + head * AR_DH + d] = (__bf16)(o * linv[band][head]);
         }
         __syncthreads();
+        AR_MARK(4);
         // fc_x(ox) + fc_h(oh) + residual
         ln = ar_ln_load(Fl + AR_FL_LN1);
         ar_gemv<2>(Wl + AR_WL_FC, AR_D, vB, Fl + AR_FL_BFC, [&](int n, float v) { xs[n] = v + xs[n]; });
         __syncthreads();
+        AR_MARK(5);
         ar_layernorm(xs, ln, g.eps, vA);
         __syncthreads();
+        AR_MARK(6);
         ar_gemv<1>(Wl + AR_WL_W1, AR_FF, vA, Fl + AR_FL_BW1, [&](int n, float v) { vB[n] = (__bf16)fmaxf(v, 0.f); });
         __syncthreads();
+        AR_MARK(7);
         if (layer + 1 < NL) ln = ar_ln_load(Fl + lay.f_layer + AR_FL_LN0);
         ar_gemv<8>(Wl + AR_WL_W2, AR_D, vB, Fl + AR_FL_BW2, [&](int n, float v) { xs[n] = v + xs[n]; });
         __syncthreads();
+        AR_MARK(8);
       }
     } else {
       // a finished sequence: the reference zeroes the row after every sub-layer, so x = 0 enters the final LayerNorm
@@ -336,6 +447,7 @@ __global__ __launch_bounds__(AR_THREADS) void pnca_decode_run_kernel(const kantt
       }
     });
     __syncthreads();
+    AR_MARK(9);
   }
 }
 

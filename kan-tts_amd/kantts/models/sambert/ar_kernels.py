@@ -5,7 +5,7 @@ The reference walks both autoregressive loops of SAM-BERT inference from Python:
 (kantts/models/sambert/adaptors.py:67-83).  ``decode_graph.py`` made a decoder step one hipGraph replay; here a whole loop
 is one kernel launch -- a workgroup per sequence walks every step (kantts_pnca_decode_run / kantts_dur_ar_run in
 include/kantts_hip.h).  This file only prepares what the kernels read: the weights of a loop packed into one bf16 blob
-(row-major matrices, pitch padded to 128) and one fp32 blob (biases, LayerNorm parameters), rebuilt when a parameter
+(fragment-major matrices, input width padded to 128) and one fp32 blob (biases, LayerNorm parameters), rebuilt when a parameter
 changes.
 """
 import torch
@@ -20,16 +20,19 @@ def _key(params):
     return tuple((p.data_ptr(), p._version) for p in params)
 
 
-def _mat(w, pitch=None):
-    """(out, in) fp32 matrix -> flat bf16 with the row pitch padded to a multiple of 128."""
+def _mat(w):
+    """(out, in) fp32 matrix -> flat, input width zero-padded to a multiple of 128, FRAGMENT-MAJOR: the 16 rows x 32 inputs
+    one MFMA A operand takes are contiguous, lane (q, i) = (k-chunk, row) owning eight consecutive inputs (the layout of
+    kantts_fragmajor_bf16).  ``out`` must be a multiple of 16."""
     w = w.detach().float()
     if w.dim() == 3:
         w = w.squeeze(-1)
-    k = w.shape[1]
-    pitch = pitch or (k + 127) // 128 * 128
+    n, k = w.shape
+    pitch = (k + 127) // 128 * 128
     if pitch != k:
         w = F.pad(w, (0, pitch - k))
-    return w.reshape(-1)
+    assert n % 16 == 0, n
+    return w.view(n // 16, 16, pitch // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
 
 
 def _pad_to(v, n):

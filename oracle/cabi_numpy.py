@@ -670,8 +670,8 @@ class EmulatedLib:
         bws = _arr(g.bw_seq, B, np.int32) if g.bw_seq else np.full(B, g.bw, np.int32)
         r16 = _bf16_round
 
-        def mat(off, n, k):
-            return W[off:off + n * k].reshape(n, k)
+        def mat(off, n, k):  # fragment-major (kantts_fragmajor_bf16's layout) -> (n, k)
+            return W[off:off + n * k].reshape(n // 16, k // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(n, k)
 
         def ln(x, gb):
             mu = x.mean(dtype=np.float32)
@@ -735,9 +735,12 @@ class EmulatedLib:
             return 0
         W = _rd(g.w, H * H + 2 * 4 * H * 2 * H, True)
         F = _arr(g.f, 1028).copy()
-        P2 = W[:H * H].reshape(H, H)
-        G0 = W[H * H:H * H + 4 * H * 2 * H].reshape(4 * H, 2 * H)
-        G1 = W[H * H + 4 * H * 2 * H:].reshape(4 * H, 2 * H)
+        def mat(flat, n, k):  # fragment-major -> (n, k)
+            return flat.reshape(n // 16, k // 32, 4, 16, 8).transpose(0, 3, 1, 2, 4).reshape(n, k)
+
+        P2 = mat(W[:H * H], H, H)
+        G0 = mat(W[H * H:H * H + 4 * H * 2 * H], 4 * H, 2 * H)
+        G1 = mat(W[H * H + 4 * H * 2 * H:], 4 * H, 2 * H)
         gc = _arr(g.gc, B * T * 4 * H).reshape(B, T, 4 * H)
         out = _arr(g.out, B * T).reshape(B, T)
         lens = _arr(g.lens, B, np.int32) if g.lens else np.full(B, T, np.int32)

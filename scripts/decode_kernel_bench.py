@@ -14,7 +14,10 @@ from kantts.models.utils import get_mask_from_lengths
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 hip.set_precision("bf16")
-for layers in (1, 2, 4, 5, 6, 8, 12):
+PROF = "ARPROF" in os.environ.get("KANTTS_LIB", "")  # scripts/build_arprof.sh: per-phase wall-clock ticks (100 MHz)
+PHASES = ["prenet + entry projection", "LayerNorm 0", "QKV product", "attention scores + softmax", "attention values",
+          "output projection", "LayerNorm 1", "feed-forward 1", "feed-forward 2", "final LayerNorm + output product"]
+for layers in ((12,) if PROF else (1, 2, 4, 5, 6, 8, 12)):
     cfg = O.sambert_config(tiny=True)
     cfg["decoder_num_layers"] = layers
     torch.manual_seed(0)
@@ -33,6 +36,19 @@ for layers in (1, 2, 4, 5, 6, 8, 12):
 
     run()
     torch.cuda.synchronize()
+    if PROF:
+        import ctypes
+        buf = (ctypes.c_ulonglong * 16)()
+        hip.lib().kantts_ar_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        hip.lib().kantts_ar_profile_read(None, 1)
+        run()
+        torch.cuda.synchronize()
+        hip.lib().kantts_ar_profile_read(buf, 1)
+        tot = sum(buf[:10])
+        for i, nme in enumerate(PHASES):
+            per = L * (layers if 1 <= i <= 8 else 1)
+            print("  %-36s %8.2f us per step  (%.2f us per occurrence)  %5.1f %%" % (
+                nme, buf[i] / 100.0 / L, buf[i] / 100.0 / per, 100.0 * buf[i] / tot))
     t0 = time.perf_counter()
     n = 5
     for _ in range(n):
