@@ -979,6 +979,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-device runs the N-rank path on a one-GPU box")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only capture (kernel-trace runs)")
+    ap.add_argument("--forward-replays", type=int, default=20,
+                    help="timed replays of the forward-only graph (raise it for a kernel trace of the forward pass)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline microbench (timing experiments only)")
     ap.add_argument("--oracle-probe", type=int, default=0, help=argparse.SUPPRESS)  # child process of cpu_baseline
     ap.add_argument("--share-device", action="store_true",
@@ -1158,11 +1160,11 @@ def main():
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(20):
+            for _ in range(max(1, args.forward_replays)):
                 fg.replay()
             e1.record()
             torch.cuda.synchronize()
-            fwd_ms = e0.elapsed_time(e1) / 20
+            fwd_ms = e0.elapsed_time(e1) / max(1, args.forward_replays)
             del keep, fg
         except Exception as exc:
             print("[bench] forward-only capture failed (%s: %s)" % (type(exc).__name__, str(exc)[:200]), file=sys.stderr)

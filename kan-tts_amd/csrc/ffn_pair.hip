@@ -99,11 +99,39 @@ extern "C" int kantts_ffn_pair(const kantts_ffn_args* gp, void* stream) {
 // consecutive k it feeds to v_mfma_f32_16x16x32_bf16 as an A operand:
 //   dst[dst_off + ((r/16)*(K/32) + k/32)*512 + lane*8 + k%8]
 // One table entry per matrix, one launch for all of them (the parameter arena's refresh, also under graph capture).
+// [round 5] A thread forms one lane's 16-byte fragment (eight consecutive k of one row): 32-bit index arithmetic once per
+// eight elements, two 16-byte loads when the source is k-contiguous, one 16-byte store.  (Per element -- a 64-bit division,
+// a scalar load and a 2-byte store each -- the refresh of a SAM-BERT step's images took 32 us of the serial tail behind the
+// optimizer; profiles/r05_runPRE_sambert_steps_kernel_stats_top.csv.)
 __global__ __launch_bounds__(256) void fragmajor_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
                                                             const kantts_fragmajor_desc* __restrict__ tab) {
   const kantts_fragmajor_desc d = tab[blockIdx.y];
   const long long total = (long long)d.R * d.K;
-  const int KB = d.K >> 5;
+  const unsigned KB = (unsigned)d.K >> 5;
+  const bool fast = total < (1ll << 31) && (d.dst_off & 7) == 0;
+  if (fast) {
+    const unsigned total8 = (unsigned)(total >> 3);
+    const bool contig = d.sk == 1 && ((d.src_off | d.sr) & 3) == 0;
+    for (unsigned o8 = blockIdx.x * blockDim.x + threadIdx.x; o8 < total8; o8 += gridDim.x * blockDim.x) {
+      const unsigned lane = o8 & 63u, blk = o8 >> 6;
+      const unsigned rb = blk / KB, kb = blk - rb * KB;
+      const long long r = (long long)rb * 16 + (lane & 15u), k0 = (long long)kb * 32 + (lane >> 4) * 8;
+      const float* sp = src + d.src_off + r * d.sr + k0 * d.sk;
+      float v[8];
+      if (contig) {
+        const float4 a = reinterpret_cast<const float4*>(sp)[0], b = reinterpret_cast<const float4*>(sp)[1];
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = sp[(long long)e * d.sk];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+      *reinterpret_cast<bf16x8*>(dst + d.dst_off + (long long)o8 * 8) = o;
+    }
+    return;
+  }
   for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
     const int e = (int)(o & 7), lane = (int)((o >> 3) & 63);
     const long long blk = o >> 9;

@@ -90,28 +90,60 @@ struct LossManyArgs {
 };
 __global__ __launch_bounds__(256) void masked_l1_many_kernel(const LossManyArgs a, float* __restrict__ losses) {
   __shared__ float red[4];
+  __shared__ float inv_s;
   int k = 0;
   while (k + 1 < a.n && (int)blockIdx.x >= a.first_block[k + 1]) ++k;
   const kantts_loss_term q = a.t[k];
   const int blk = blockIdx.x - a.first_block[k], nblk = a.first_block[k + 1] - a.first_block[k];
-  long long denom_rows = 0;
-  for (int b = 0; b < q.B; ++b) denom_rows += min((long long)q.lens[b], (long long)q.T);
-  const float inv = 1.f / ((float)denom_rows * (float)q.C);
+  if (threadIdx.x == 0) {
+    long long denom_rows = 0;
+    for (int b = 0; b < q.B; ++b) denom_rows += min((long long)q.lens[b], (long long)q.T);
+    inv_s = 1.f / ((float)denom_rows * (float)q.C);
+  }
+  __syncthreads();
+  const float inv = inv_s;
   const long long total = (long long)q.B * q.T * q.C;
   const float* tf = reinterpret_cast<const float*>(q.target);
   const int64_t* ti = reinterpret_cast<const int64_t*>(q.target);
   float part = 0.f;
-  for (long long g = (long long)blk * 256 + threadIdx.x; g < total; g += (long long)nblk * 256) {
-    const long long bt = g / q.C;
-    const int t = (int)(bt % q.T), b = (int)(bt / q.T);
-    float gr = 0.f;
-    if (t < (int)q.lens[b]) {
-      const float y = q.target_log1p ? logf((float)ti[g] + 1.f) : tf[g];
-      const float d = q.pred[g] - y;
-      part += fabsf(d);
-      gr = (d > 0.f) ? inv : ((d < 0.f) ? -inv : 0.f);
+  // [round 5] The element loop used to split a 64-bit flat index into (row, channel) and (sequence, frame) with two 64-bit
+  // divisions PER ELEMENT: 61 us for the 19 MB of a SAM-BERT step's five terms, at the end of the forward pass where
+  // nothing overlaps it (profiles/r05_runPRE_forward_only_kernel_stats_top.csv).  Rows of four-channel groups with 32-bit
+  // indices and 16-byte accesses when the shapes allow it (the two mel terms: C = 80); the scalar form otherwise.
+  const bool vec = !q.target_log1p && (q.C & 3) == 0 && total < (1ll << 31) &&
+                   ((((uintptr_t)q.pred) | ((uintptr_t)q.target) | ((uintptr_t)q.grad)) & 15) == 0;
+  if (vec) {
+    const unsigned c4 = (unsigned)q.C >> 2, n4 = (unsigned)(total >> 2), T = (unsigned)q.T;
+    const float4* p4 = reinterpret_cast<const float4*>(q.pred);
+    const float4* t4 = reinterpret_cast<const float4*>(tf);
+    float4* g4 = reinterpret_cast<float4*>(q.grad);
+    for (unsigned i = (unsigned)blk * 256u + threadIdx.x; i < n4; i += (unsigned)nblk * 256u) {
+      const unsigned row = i / c4, b = row / T, t = row - b * T;
+      float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < (unsigned)q.lens[b]) {
+        const float4 pv = p4[i], yv = t4[i];
+        const float d0 = pv.x - yv.x, d1 = pv.y - yv.y, d2 = pv.z - yv.z, d3 = pv.w - yv.w;
+        part += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+        gr.x = (d0 > 0.f) ? inv : ((d0 < 0.f) ? -inv : 0.f);
+        gr.y = (d1 > 0.f) ? inv : ((d1 < 0.f) ? -inv : 0.f);
+        gr.z = (d2 > 0.f) ? inv : ((d2 < 0.f) ? -inv : 0.f);
+        gr.w = (d3 > 0.f) ? inv : ((d3 < 0.f) ? -inv : 0.f);
+      }
+      if (q.grad) g4[i] = gr;
     }
-    if (q.grad) q.grad[g] = gr;
+  } else {
+    for (long long g = (long long)blk * 256 + threadIdx.x; g < total; g += (long long)nblk * 256) {
+      const long long bt = g / q.C;
+      const int t = (int)(bt % q.T), b = (int)(bt / q.T);
+      float gr = 0.f;
+      if (t < (int)q.lens[b]) {
+        const float y = q.target_log1p ? logf((float)ti[g] + 1.f) : tf[g];
+        const float d = q.pred[g] - y;
+        part += fabsf(d);
+        gr = (d > 0.f) ? inv : ((d < 0.f) ? -inv : 0.f);
+      }
+      if (q.grad) q.grad[g] = gr;
+    }
   }
   part = kantts_block_sum(part, red);
   if (threadIdx.x == 0) {
@@ -131,12 +163,11 @@ extern "C" int kantts_masked_l1_many(const kantts_loss_term* terms, int nterms, 
     a.t[k] = q;
     a.first_block[k] = nb;
     long long total = (long long)q.B * q.T * q.C;
-    // every block ends with two atomics, one of them onto the SAME address for all terms (the total): ~1000 blocks made
-    // the launch 42 us of serialised atomics for 19 MB of traffic (profiles/r05_runJ_trace_*); 96 blocks per term stream the
-    // same bytes in a few microseconds
-    int blocks = kantts_cdiv(total, 1024);
+    // a thread takes ~8 sixteen-byte groups; at most 256 blocks per term (every block ends with two atomics, one of them
+    // onto the address all terms share)
+    int blocks = kantts_cdiv(total, 8192);
     if (blocks < 1) blocks = 1;
-    if (blocks > 96) blocks = 96;
+    if (blocks > 256) blocks = 256;
     nb += blocks;
   }
   a.first_block[nterms] = nb;
@@ -213,13 +244,24 @@ __global__ __launch_bounds__(256) void sumsq_det_kernel(const float* __restrict_
   float part = 0.f;
   const long long n4 = n >> 2;
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+  // four independent loads per trip (a fixed assignment of elements to the four partial sums: still one summation order per
+  // launch shape): one load in flight per thread kept a 49 MB gradient at 2 TB/s
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+    p0 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+    p1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+    p2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+    p3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+  }
+  for (; i < n4; i += stride) {
     float4 v = x4[i];
     part += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
-  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x)
-    part += x[i] * x[i];
+  part += (p0 + p1) + (p2 + p3);
+  for (long long j = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) part += x[j] * x[j];
   part = kantts_block_sum(part, red);
   unsigned* ticket = reinterpret_cast<unsigned*>(ws);
   if (threadIdx.x == 0) {

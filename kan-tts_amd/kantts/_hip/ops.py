@@ -1218,7 +1218,10 @@ class _FsmnMemory(torch.autograd.Function):
                                            B, T, C, K, lp, stream()), "fsmn_dwconv_bwd (dx)")
         # the filter gradient is a leaf: on the weight-gradient stream when the step overlaps them (partials + reduce are
         # 41 us per layer, ten layers per step)
-        with wgrad_overlap.side(dy, x, ws, dw):
+        # (dw itself must NOT be in the keep-alive list: a second reference to the returned gradient makes AccumulateGrad
+        # CLONE it on the main stream instead of adopting it -- before the side stream has written it.  The parameter's
+        # .grad keeps it alive.)
+        with wgrad_overlap.side(dy, x, ws):
             check(lib().kantts_fsmn_dwconv_bwd(ptr(dy, torch.float32), ptr(x), ptr(w), ptr(lens), None, ptr(dw), ptr(ws),
                                                ws_n, B, T, C, K, lp, stream()), "fsmn_dwconv_bwd (dw)")
         return dx, dw, (dy if has_res else None), None, None

@@ -92,7 +92,12 @@ def _compare(nf, f, c, expect_fused=True):
     # fp32 summation order differs between the forms; where that moves a normalised row's element across a bf16 rounding tie
     # (one element in ~10^4) the feed-forward's output moves by ~1e-4: rare, so the l2 bound is the sharp one
     assert float((of - oc).abs().max()) <= 2e-3 * max(1.0, float(oc.abs().max())) and rel_l2(of, oc) <= 1e-4, "block output"
-    assert float((mf - mc).abs().max()) <= 1e-5 and rel_l2(rf, rc) <= 1e-5, "LayerNorm statistics of the consumer"
+    # the consumer's statistics are means over the 128 channels of those rows: a row with a flipped tie moves its mean by
+    # (what the element moved) / 128 -- the bound follows the output's own difference (on the device the dropout masks, and
+    # with them which rows hold a tie, depend on how many draws the tests before this one made)
+    d_out = float((of - oc).abs().max())
+    assert float((mf - mc).abs().max()) <= 1e-5 + d_out / 32 and rel_l2(rf, rc) <= 1e-5 + 1e-2 * d_out, \
+        "LayerNorm statistics of the consumer"
     # normalised rows are bf16 (or fp32 for the stack's final LayerNorm): one ulp where the fp32 value sits on a tie
     assert float((xnf - xnc).abs().max()) <= 4e-2 and rel_l2(xnf, xnc) <= 2e-3, "normalised rows"
     # gradients: the backward pass is the SAME code reading the tensors the two forward forms saved (bf16 operands round
