@@ -66,9 +66,42 @@ def test_decoder_loop_as_one_launch_emulated():
 
 
 def test_decoder_loop_as_one_launch_kernel_source():
-    """The kernel SOURCE on the CPU (tests/hipemu) against its own per-launch twins."""
+    """The kernel SOURCE on the CPU (tests/hipemu) against its own per-launch twins; the second case has a band of more
+    than 15 rows (the attentions then read the caches in place instead of the rows parked in LDS)."""
     with kernel_source_on_cpu():
         _check_decoder("cpu", 2, 2, 6, [6, 3], [2, 4])
+        _check_decoder("cpu", 1, 2, 24, [24, 19], [20, 17])
+
+
+def _raw_decode(lib_ctx, d_mel, d_mem, d_out, n_layer, B, L, lens, bws, seed):
+    """kantts_pnca_decode_run called directly with random blobs (shapes no shipped configuration has)."""
+    import kantts._hip as hip
+
+    g = torch.Generator().manual_seed(seed)
+    with lib_ctx():
+        nw, nf = hip.decode_blob_sizes(d_mel, d_mem, d_out, n_layer)
+        w = (0.08 * torch.randn(nw, generator=g)).to(torch.bfloat16)
+        f = 0.1 * torch.randn(nf, generator=g)
+        memory = 0.7 * torch.randn(B, L, d_mem, generator=g)
+        hkv = 0.7 * torch.randn(B, L, n_layer * 256, generator=g)
+        xkv = torch.zeros(n_layer, B, L, 256)
+        out = torch.full((B, L, d_out), float("nan"))
+        hip.pnca_decode_run(w, f, memory, hkv, xkv, out, torch.tensor(lens, dtype=torch.int32),
+                            torch.tensor(bws, dtype=torch.int32), 0, d_mel, n_layer, 128 ** 0.5, 1e-6)
+    return out
+
+
+@pytest.mark.parametrize("d_mel,d_mem,d_out", [(80, 96, 240), (40, 300, 100), (128, 160, 130)])
+def test_decoder_kernel_source_equals_its_numpy_model_on_other_shapes(d_mel, d_mem, d_out):
+    """The entry-projection widths 256 / 384 / 512 (three instantiations of the product), an output width that is no
+    multiple of 16, a frame narrower / as wide as the model: kernel source against the numpy model, same random blobs.
+    (The weights here are NOT LayerNorm-friendly model weights; both sides round the same values, so the comparison is
+    tight anyway.)"""
+    args = (d_mel, d_mem, d_out, 2, 2, 5, [5, 3], [2, 1], 11)
+    ref = _raw_decode(emulation, *args)
+    got = _raw_decode(kernel_source_on_cpu, *args)
+    assert torch.isfinite(got).all() and torch.isfinite(ref).all()
+    assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
 
 
 @pytest.mark.gpu
