@@ -1065,6 +1065,13 @@ int kantts_ragged_rows_f32(const float* src, const int64_t* row_off, const int32
 int kantts_ragged_rows_i64(const int64_t* src, const int64_t* row_off, const int32_t* start, const int32_t* len,
                            const int64_t* pad, int64_t* out, int B, int Tmax, int C, int transpose, void* stream);
 
+/* Launch-shape knobs for sweeps and tests -- they never change a result.  tn_tile: output tile of kantts_bgemm_tn* as
+ * BN * 1000 + BK (64128 / 128128 / 64256 / 128256; anything else = the library's rule); tn_slices: token slices of the
+ * same launches (0 = the rule); c1_wgrad_wgs: workgroup cap of the persistent weight-gradient launch of kantts_conv_c1_launch
+ * (0 = 256).  The host layer maps KANTTS_TN_TILE / KANTTS_TN_SLICES / KANTTS_C1_WGRAD_WGS onto this call; the library reads
+ * no environment variable for them (until round 5 it did, per launch). */
+int kantts_launch_tuning(int tn_tile, int tn_slices, int c1_wgrad_wgs);
+
 /* ------------------------------------------------------------------------------------------
  * [round 5] Free-running inference loops as ONE launch each (csrc/ar_infer.hip; SURVEY 8 row e1, bf16 mode).
  *

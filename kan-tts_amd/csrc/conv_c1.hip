@@ -14,6 +14,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <atomic>
+extern std::atomic<int> kantts_tune_c1_wgrad_wgs;  // csrc/gemm_bf16.hip: kantts_launch_tuning
+
 
 #define C1_THREADS 256
 #define C1_QB 256      // output tokens per run
@@ -392,8 +395,8 @@ extern "C" int kantts_conv_c1_launch(const kantts_conv_c1_args* a, int mode, voi
   } else {
     // persistent grid: at most C1_WGRAD_WGS workgroups (one per CU), each reducing once: the launch is the sum of a stream
     // (268 MB of dy + gate for the first MSD layer) and of (K + 1) * Cout global atomics per workgroup
-    const char* wgs_env = getenv("KANTTS_C1_WGRAD_WGS");  // experiment / test switch (read per launch: tests change it)
-    const long long cap = (wgs_env && atoll(wgs_env) > 0) ? atoll(wgs_env) : 256;  // 512: 255 us, 256: 198, 128: 241 (r04_runX)
+    const int wgs_set = kantts_tune_c1_wgrad_wgs.load(std::memory_order_relaxed);  // kantts_launch_tuning (sweeps / tests)
+    const long long cap = wgs_set > 0 ? wgs_set : 256;  // 512: 255 us, 256: 198, 128: 241 (r04_runX)
     const unsigned pgrid = (unsigned)(blocks < cap ? blocks : cap);
     if (vec && g.Cout <= 64)
       hipLaunchKernelGGL((conv_c1_wgrad_mfma_kernel<1>), dim3(pgrid), dim3(C1_THREADS), lds, st, g, (int)blocks);

@@ -207,6 +207,16 @@ extern "C" int kantts_bgemm_nt_lnbwd(const kantts_bgemm_args* gp, const kantts_l
 // 128x128 tiles x 64 slices = 8.4 M atomics, took 48 us where the round-1 kernel took 24) and the chain of dependent
 // load latencies of a short token tile.  Hence: 64 x 128 output tiles (more tiles, fewer slices for the same number of
 // workgroups), token tiles of 64 with the loads of two tiles in flight, and a slice count capped by the atomics budget.
+#include <atomic>
+// Launch-shape knobs for sweeps and tests (kantts_launch_tuning): explicit state instead of an environment read per launch.
+std::atomic<int> kantts_tune_tn_tile{0}, kantts_tune_tn_slices{0}, kantts_tune_c1_wgrad_wgs{0};
+extern "C" int kantts_launch_tuning(int tn_tile, int tn_slices, int c1_wgrad_wgs) {
+  if (tn_slices < 0 || c1_wgrad_wgs < 0) return KANTTS_E_BADARG;
+  kantts_tune_tn_tile.store(tn_tile, std::memory_order_relaxed);
+  kantts_tune_tn_slices.store(tn_slices, std::memory_order_relaxed);
+  kantts_tune_c1_wgrad_wgs.store(c1_wgrad_wgs, std::memory_order_relaxed);
+  return KANTTS_OK;
+}
 #define TN_BT 64                 // tokens per tile (two MFMA k-steps)
 // The grouped form (kantts_bgemm_tn_grouped) runs up to KANTTS_TN_MAX_GROUP problems of one shape in a single launch:
 // weight gradients are leaves of the backward graph, so the host defers them and issues every layer's gradient of one
@@ -411,18 +421,18 @@ static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
     if (!bg_aligned16(ga.a[p]) || !bg_aligned16(ga.b[p])) return KANTTS_E_UNSUPPORTED;
   }
   if ((g.shift0 != 0 || g.shift_step != 0) && g.T <= 0) return KANTTS_E_BADARG;
-  // tile (BN x BK) and token slices.  KANTTS_TN_TILE = BN * 1000 + BK (64128 / 128128 / 64256 / 128256) and
-  // KANTTS_TN_SLICES force them (scripts/tn_sweep.py, tests); the rules below are what that sweep measured
+  // tile (BN x BK) and token slices.  kantts_launch_tuning(tn_tile = BN * 1000 + BK (64128 / 128128 / 64256 / 128256),
+  // tn_slices, ...) forces them (scripts/tn_sweep.py, tests; the host layer maps KANTTS_TN_TILE / KANTTS_TN_SLICES onto it:
+  // the library itself reads no environment here); the rules below are what that sweep measured
   // (profiles/r04_runL_tn_tile_sweep.log).
-  const char* tenv = getenv("KANTTS_TN_TILE");
-  const char* senv = getenv("KANTTS_TN_SLICES");
-  int code = tenv ? atoi(tenv) : 0;
+  int code = kantts_tune_tn_tile.load(std::memory_order_relaxed);  // kantts_launch_tuning (sweeps / tests); 0 = the rule
+  const int forced_slices = kantts_tune_tn_slices.load(std::memory_order_relaxed);
   if (code != 64128 && code != 128128 && code != 64256 && code != 128256) code = bg_tn_tile_rule(g, ga.nprob);
   const int BN = code / 1000, BK = code % 1000;
   const int tiles = kantts_cdiv(g.N, BN) * kantts_cdiv(g.K, BK) * g.ntaps * ga.nprob;
   const int ntile = kantts_cdiv(g.M, TN_BT);
   int slices = g.slices;
-  if (senv && atoi(senv) > 0) slices = atoi(senv);
+  if (forced_slices > 0) slices = forced_slices;
   if (slices <= 0) {
     // [round 4, scripts/tn_sweep.py] as many token slices as still give ONE resident round of workgroups (two per CU: 512;
     // 576 workgroups = a second, mostly empty round cost 123 us where 384 took 95), at most ~4 M fp32 atomics per launch

@@ -380,6 +380,7 @@ def lib():
         L.kantts_teacher_plan.argtypes = [POINTER(PlanArgs), c_void_p]
         L.kantts_pnca_attn_qkv_bwd.argtypes = [POINTER(PncaAttnBwdArgs), c_void_p]
         L.kantts_copy_roof.argtypes = [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p]
+        L.kantts_launch_tuning.argtypes = [c_int, c_int, c_int]
         L.kantts_pnca_decode_run.argtypes = [POINTER(DecodeArgs), c_void_p]
         L.kantts_dur_ar_run.argtypes = [POINTER(DurArArgs), c_void_p]
         L.kantts_pnca_decode_blob_sizes.argtypes = [c_int, c_int, c_int, c_int, POINTER(ctypes.c_longlong),
@@ -434,8 +435,26 @@ EXPORTED_SYMBOLS = [
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
     "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof", "kantts_pnca_attn_qkv_bwd",
-    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run",
+    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_launch_tuning",
 ]
+
+
+_launch_tuning = [None]
+
+
+def apply_launch_tuning():
+    """KANTTS_TN_TILE / KANTTS_TN_SLICES / KANTTS_C1_WGRAD_WGS (sweep and test switches of the weight-gradient launches) are
+    read HERE, in the host layer, and handed to the library through kantts_launch_tuning when they change: the C ABI
+    consults no environment for them.  Called by the wrappers of the launches they shape."""
+    L = lib()
+    env = os.environ
+    want = (id(L), int(env.get("KANTTS_TN_TILE", "0") or 0), int(env.get("KANTTS_TN_SLICES", "0") or 0),
+            int(env.get("KANTTS_C1_WGRAD_WGS", "0") or 0))
+    if want != _launch_tuning[0]:
+        rc = L.kantts_launch_tuning(want[1], max(want[2], 0), max(want[3], 0))
+        if rc != 0:
+            raise RuntimeError("libkantts_hip: launch_tuning failed with code %d" % rc)
+        _launch_tuning[0] = want
 
 
 def check(rc, what):
@@ -991,6 +1010,7 @@ class _DeferredTN:
             if _profile is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+            apply_launch_tuning()
             check(L.kantts_bgemm_tn_grouped(ctypes.byref(g), n, arr(1), arr(2), arr(3), arr(4), seeds, stream()),
                   "bgemm_tn_grouped")
             if _profile is not None:
@@ -1028,6 +1048,7 @@ def bgemm_tn(a, lda, b, ldb, M, N, K, c, c_ns, c_ks, *, c_ts=0, T=0, ntaps=1, sh
     if _profile is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    apply_launch_tuning()
     rc = lib().kantts_bgemm_tn(ctypes.byref(g), stream())
     if rc == E_UNSUPPORTED:
         return False
@@ -1238,6 +1259,8 @@ def conv_c1(mode, *, x=None, dx=None, y=None, gate=None, w=None, bias=None, dw=N
         g.out_act, g.out_slope = 1, float(out_leaky)
     g.gate_slope = float(gate_slope)
     g.y_bf16 = ptr(y_bf16, torch.bfloat16)
+    if int(mode) == 2:
+        apply_launch_tuning()
     rc = lib().kantts_conv_c1_launch(ctypes.byref(g), int(mode), stream())
     if rc == E_UNSUPPORTED:
         return False

@@ -769,6 +769,9 @@ class EmulatedLib:
     def kantts_copy_roof(self, src, read_bytes, dst, write_bytes, stream):
         return 0  # a bandwidth calibration launch: no values to model
 
+    def kantts_launch_tuning(self, tn_tile, tn_slices, c1_wgrad_wgs):
+        return 0  # launch-shape knobs: nothing to model
+
     def kantts_melspec_tuning(self, grid_cap, generic_only):
         return 0  # launch-shape knobs: nothing to model
 
