@@ -641,7 +641,7 @@ class EmulatedLib:
 
     def kantts_pnca_decode_blob_sizes(self, d_mel, d_mem, d_out, n_layer, w_elems, f_elems):
         if d_mel < 1 or d_mel > 128 or d_mem < 1 or d_mem + 128 > 512 or d_out < d_mel or n_layer < 0:
-            return 3
+            return -2  # KANTTS_E_UNSUPPORTED
         w, f, _, _, _ = self._decode_layout(d_mel, d_mem, d_out, n_layer)
         for ref, v in ((w_elems, w["total"]), (f_elems, f["total"])):
             if ref is not None:
@@ -654,9 +654,9 @@ class EmulatedLib:
         g = args_ref._obj
         B, L, d_mem, d_mel, d_out, NL = g.B, g.L, g.d_mem, g.d_mel, g.d_out, g.n_layer
         if d_mel < 1 or d_mel > 128 or d_mem < 1 or d_mem + 128 > 512 or d_out < d_mel or NL < 0:
-            return 3
+            return -2  # KANTTS_E_UNSUPPORTED
         if not g.bw_seq and (g.bw < 0 or g.bw + 1 > 128):
-            return 3
+            return -2  # KANTTS_E_UNSUPPORTED
         if B == 0 or L == 0:
             return 0
         wl, fl, k_p1, k_in, n_out = self._decode_layout(d_mel, d_mem, d_out, NL)

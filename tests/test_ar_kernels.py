@@ -104,6 +104,38 @@ def test_decoder_kernel_source_equals_its_numpy_model_on_other_shapes(d_mel, d_m
     assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
 
 
+@pytest.mark.parametrize("ctx", ["emulated", "kernel_source"])
+def test_decoder_entry_refuses_and_poisons(ctx):
+    """What kantts_pnca_decode_run is not compiled for: a host-known band above 127 and an entry projection wider than 512
+    are refused with KANTTS_E_UNSUPPORTED (-2); a DEVICE-side band width above 127 cannot be refused at launch -- that
+    sequence's output is NaN (never a wrong answer), the others are unaffected; empty batches are a no-op."""
+    import ctypes
+
+    import kantts._hip as hip
+
+    lib_ctx = emulation if ctx == "emulated" else kernel_source_on_cpu
+    ok = _raw_decode(lib_ctx, 80, 160, 240, 1, 2, 4, [4, 4], [1, 1], 3)
+    got = _raw_decode(lib_ctx, 80, 160, 240, 1, 2, 4, [4, 4], [1, 200], 3)
+    assert torch.isnan(got[1]).all() and torch.equal(got[0], ok[0])
+    with lib_ctx():
+        assert hip.decode_blob_sizes(80, 400, 240, 1) is None
+        g = hip.DecodeArgs()
+        z = torch.zeros(16)
+        for name in ("w", "f", "memory", "hkv", "xkv", "out"):
+            setattr(g, name, z.data_ptr())
+        g.B, g.L, g.d_mem, g.d_mel, g.d_out, g.n_layer, g.bw = 1, 1, 160, 80, 240, 1, 128
+        assert hip.lib().kantts_pnca_decode_run(ctypes.byref(g), None) == hip.E_UNSUPPORTED
+        g.bw, g.d_mem = 5, 400
+        assert hip.lib().kantts_pnca_decode_run(ctypes.byref(g), None) == hip.E_UNSUPPORTED
+        g.d_mem, g.B = 160, 0
+        assert hip.lib().kantts_pnca_decode_run(ctypes.byref(g), None) == 0
+        d = hip.DurArArgs()
+        for name in ("w", "f", "gc", "out"):
+            setattr(d, name, z.data_ptr())
+        d.B, d.T = 0, 5
+        assert hip.lib().kantts_dur_ar_run(ctypes.byref(d), None) == 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("layers,B,L,lens,bws", [(2, 3, 9, [9, 5, 1], [2, 7, 0]), (12, 4, 70, [70, 33, 64, 8], [6, 3, 40, 2])])
 def test_decoder_loop_as_one_launch_gpu(layers, B, L, lens, bws):
