@@ -372,7 +372,11 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
         const int j = c0 + wc * (BK / 2) + n * 16 + li;          // output col  = channel of B
         if (i < g.N && j < g.K) {
           const float v = acc[m][n][r] * g.alpha;
+#ifdef TN_NO_ATOMICS  // timing experiment only (scripts/build_tnprobe.sh): what the split-token atomics cost; results are wrong
+          if (v != 0.f) cbase[(long long)i * g.c_ns + (long long)j * g.c_ks] = v;
+#else
           if (v != 0.f) atomicAdd(cbase + (long long)i * g.c_ns + (long long)j * g.c_ks, v);
+#endif
         }
       }
 }
