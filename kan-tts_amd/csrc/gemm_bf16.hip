@@ -51,11 +51,16 @@ __device__ __forceinline__ float bg_hi(unsigned u) { return __uint_as_float(u & 
 template <bool F32>
 __device__ __forceinline__ u32x4 bg_load8(const void* base, long long elem, bool ok, float drop_p, uint64_t seed,
                                           uint64_t logical) {
+  // [round 5] The load is UNCONDITIONAL (a predicated-off chunk reads element 0 of the tensor and is zeroed afterwards): with
+  // `if (!ok) return` in front of it every chunk was a branch around its loads and `s_waitcnt vmcnt(0)` where the branch
+  // re-joins -- the staging of a tile was a chain of 4-6 memory round trips instead of one (the weight-gradient kernel
+  // issued its 48 loads two at a time; found by scanning the ISA of every kernel for load / wait bursts).
   u32x4 r = {0u, 0u, 0u, 0u};
-  if (!ok) return r;
+  const long long e_ = ok ? elem : 0;
   if (F32) {
-    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + e_);
     float4 a = p[0], b = p[1];
+    if (!ok) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (drop_p > 0.f) {  // logical % 8 == 0 (8-element granularity of every extent)
       float lo4[4] = {a.x, a.y, a.z, a.w}, hi4[4] = {b.x, b.y, b.z, b.w};
       kantts_dropout_scale4(drop_p, seed, logical, lo4);
@@ -68,7 +73,52 @@ __device__ __forceinline__ u32x4 bg_load8(const void* base, long long elem, bool
     r.z = bg_pack2(b.x, b.y);
     r.w = bg_pack2(b.z, b.w);
   } else {
-    r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(base) + elem);
+    r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(base) + e_);
+    if (!ok) r = (u32x4){0u, 0u, 0u, 0u};
+  }
+  return r;
+}
+
+// Staging in two halves (round 5): bg_fetch8 only ISSUES the loads of a chunk (unconditional, clamped address) and keeps
+// the raw bits; bg_finish8 -- at commit time, one tile later -- zeroes a predicated-off chunk, applies the A-operand dropout
+// and rounds fp32 to bf16.  With conversion right behind each load (bg_load8) the compiler produced `load pair; branch;
+// s_waitcnt vmcnt(0)` per chunk: the staging of a tile was a chain of 4-6 memory round trips that the compute of the
+// previous tile could not hide.
+template <bool F32>
+struct BgRaw {
+  u32x4 v[F32 ? 2 : 1];
+};
+template <bool F32>
+__device__ __forceinline__ BgRaw<F32> bg_fetch8(const void* base, long long elem, bool ok) {
+  BgRaw<F32> r;
+  const long long e_ = ok ? elem : 0;
+  if (F32) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(base) + e_);
+    r.v[0] = p[0];
+    r.v[F32 ? 1 : 0] = p[1];
+  } else {
+    r.v[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(base) + e_);
+  }
+  return r;
+}
+template <bool F32>
+__device__ __forceinline__ u32x4 bg_finish8(const BgRaw<F32>& raw, bool ok, float drop_p, uint64_t seed, uint64_t logical) {
+  u32x4 r = {0u, 0u, 0u, 0u};
+  if (!ok) return r;
+  if (F32) {
+    const u32x4 a = raw.v[0], b = raw.v[F32 ? 1 : 0];
+    float lo4[4] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w)};
+    float hi4[4] = {__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+    if (drop_p > 0.f) {  // logical % 8 == 0 (8-element granularity of every extent)
+      kantts_dropout_scale4(drop_p, seed, logical, lo4);
+      kantts_dropout_scale4(drop_p, seed, logical + 4, hi4);
+    }
+    r.x = bg_pack2(lo4[0], lo4[1]);
+    r.y = bg_pack2(lo4[2], lo4[3]);
+    r.z = bg_pack2(hi4[0], hi4[1]);
+    r.w = bg_pack2(hi4[2], hi4[3]);
+  } else {
+    r = raw.v[0];
   }
   return r;
 }
@@ -269,18 +319,19 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
   float colsum = 0.f;
   const bool do_bias = g.db && blockIdx.x == 0 && tap == 0;
 
-  u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+  BgRaw<A_F32> ra0[NA], ra1[NA];
+  BgRaw<B_F32> rb0[NB], rb1[NB];
   const int ntile = (g.M + TN_BT - 1) / TN_BT;
 
-  auto fetch = [&](int t, u32x4* ra, u32x4* rb) {
+  // fetch: loads only (see bg_fetch8); the tile index is clamped by the caller so that the loads are never inside a branch
+  auto fetch = [&](int t, BgRaw<A_F32>* ra, BgRaw<B_F32>* rb) {
     const int m0 = t * TN_BT;
 #pragma unroll
     for (int v = 0; v < NA; ++v) {
       const int id = tid + BG_THREADS * v;
       const int m = m0 + id / CA, nc = n0 + (id % CA) * 8;
       const bool ok = m < g.M && nc < g.N;
-      ra[v] = bg_load8<A_F32>(g.a, (long long)m * g.lda + nc, ok, A_F32 ? g.a_drop_p : 0.f, g.a_drop_seed + seed_off,
-                              (uint64_t)m * (uint64_t)g.N + (uint64_t)nc);
+      ra[v] = bg_fetch8<A_F32>(g.a, (long long)m * g.lda + nc, ok);
     }
 #pragma unroll
     for (int v = 0; v < NB; ++v) {
@@ -293,21 +344,33 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
         ok = ok && tt >= 0 && tt < g.T;
         src = (long long)m + shift;
       }
-      rb[v] = bg_load8<B_F32>(g.b, src * g.ldb + kc, ok, 0.f, 0ull, 0ull);
+      rb[v] = bg_fetch8<B_F32>(g.b, src * g.ldb + kc, ok);
     }
   };
-  auto commit = [&](int buf, const u32x4* ra, const u32x4* rb) {
+  // commit: predicate / dropout / rounding of the chunks fetched for tile t, then the LDS images
+  auto commit = [&](int buf, int t, const BgRaw<A_F32>* ra, const BgRaw<B_F32>* rb) {
     unsigned char* Ab = lds + buf * STAGE;
     unsigned char* Bb = Ab + IMG_A;
+    const int m0 = t * TN_BT;
 #pragma unroll
     for (int v = 0; v < NA; ++v) {
       const int id = tid + BG_THREADS * v;
-      *reinterpret_cast<u32x4*>(Ab + ((id / CA) * LDA + (id % CA) * 8) * 2) = ra[v];
+      const int m = m0 + id / CA, nc = n0 + (id % CA) * 8;
+      const bool ok = m < g.M && nc < g.N;
+      *reinterpret_cast<u32x4*>(Ab + ((id / CA) * LDA + (id % CA) * 8) * 2) =
+          bg_finish8<A_F32>(ra[v], ok, A_F32 ? g.a_drop_p : 0.f, g.a_drop_seed + seed_off,
+                            (uint64_t)m * (uint64_t)g.N + (uint64_t)nc);
     }
 #pragma unroll
     for (int v = 0; v < NB; ++v) {
       const int id = tid + BG_THREADS * v;
-      *reinterpret_cast<u32x4*>(Bb + ((id / CB) * LDB + (id % CB) * 8) * 2) = rb[v];
+      const int m = m0 + id / CB, kc = c0 + (id % CB) * 8;
+      bool ok = m < g.M && kc < g.K;
+      if (shift != 0) {
+        const int tt = m % g.T + shift;
+        ok = ok && tt >= 0 && tt < g.T;
+      }
+      *reinterpret_cast<u32x4*>(Bb + ((id / CB) * LDB + (id % CB) * 8) * 2) = bg_finish8<B_F32>(rb[v], ok, 0.f, 0ull, 0ull);
     }
   };
   auto compute = [&](int buf) {
@@ -345,17 +408,18 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
   // register set / LDS buffer i & 1 for this slice's i-th tile; same one-barrier-per-tile argument as the NT kernel
   const int st = g.slices;
   int t = slice;
-  if (t < ntile) fetch(t, ra0, rb0);
-  if (t + st < ntile) fetch(t + st, ra1, rb1);
+  const int tlast = ntile - 1;  // fetches past the slice's last tile re-read that tile: loads stay unconditional
+  fetch(min(t, tlast), ra0, rb0);
+  fetch(min(t + st, tlast), ra1, rb1);
   for (; t < ntile; t += 2 * st) {
-    commit(0, ra0, rb0);
+    commit(0, t, ra0, rb0);
     __syncthreads();
-    if (t + 2 * st < ntile) fetch(t + 2 * st, ra0, rb0);
+    fetch(min(t + 2 * st, tlast), ra0, rb0);
     compute(0);
     if (t + st < ntile) {
-      commit(1, ra1, rb1);
+      commit(1, t + st, ra1, rb1);
       __syncthreads();
-      if (t + 3 * st < ntile) fetch(t + 3 * st, ra1, rb1);
+      fetch(min(t + 3 * st, tlast), ra1, rb1);
       compute(1);
     }
   }

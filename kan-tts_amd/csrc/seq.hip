@@ -427,6 +427,9 @@ __global__ __launch_bounds__(256) void fsmn_dw41_partial_kernel(const float* __r
       const float v = db[(long long)(ok ? t : 0) * C + cc];
       dv[o] = ok ? v : 0.f;
     }
+    // all 72 loads of the window are issued before the first product: left alone, the scheduler sinks every load to just in
+    // front of its first use (`global_load; s_waitcnt vmcnt(0)` 72 times: 21 us per launch whatever the shape)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int o = 0; o < FS_TT; ++o)
 #pragma unroll
