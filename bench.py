@@ -1232,7 +1232,7 @@ def main():
                 "unit": "GB/s", "frac": nt_gbps / PEAK_HBM_GBPS, "tflops": fam["flops"] / (fam["ms"] * 1e-3) / 1e12,
                 "mfma_frac": fam["flops"] / (fam["ms"] * 1e-3) / 1e12 / peak,
                 "note": "launch-latency sized: 6528 x 128 x 384 is 0.64 GFLOP / 5 MB; the rocprofv3 averages of the same "
-                        "command are under profiles/ (r04_*_bench_kernel_stats_top.csv)"}
+                        "command are under profiles/ (r05_runFINAL_bench_command_kernel_stats_top.csv)"}
         if fwd_ms is not None:
             roof["forward_ms"] = fwd_ms
             roof["forward_algorithmic_tflops"] = 152.3e9 * args.batch / 32 / (fwd_ms * 1e-3) / 1e12
