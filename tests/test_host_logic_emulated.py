@@ -516,3 +516,27 @@ def test_batched_free_running_inference_equals_per_utterance_inference(emulated_
     assert rep["frame_count_agreement"] == 1.0 and rep["duration_agreement"] == 1.0, rep
     assert rep["mel_max_abs_forced_durations"] <= 2e-5, rep
     assert rep["mel_mean_abs_free_running_where_durations_agree"] <= 1e-5, rep
+
+
+def test_launch_tuning_is_fed_from_the_environment_by_the_host_layer(emulated_cabi, monkeypatch):
+    """KANTTS_TN_TILE / KANTTS_TN_SLICES / KANTTS_C1_WGRAD_WGS are read by kantts._hip (not by the library) and handed over
+    through kantts_launch_tuning -- once per change, again when the variables go away."""
+    import kantts._hip as hip
+
+    calls = []
+    monkeypatch.setattr(type(emulated_cabi), "kantts_launch_tuning",
+                        lambda self, a, b, c: calls.append((a, b, c)) or 0, raising=False)
+    monkeypatch.setattr(hip, "_launch_tuning", [None])
+    for k in ("KANTTS_TN_TILE", "KANTTS_TN_SLICES", "KANTTS_C1_WGRAD_WGS"):
+        monkeypatch.delenv(k, raising=False)
+    hip.apply_launch_tuning()
+    hip.apply_launch_tuning()
+    assert calls == [(0, 0, 0)]
+    monkeypatch.setenv("KANTTS_TN_TILE", "128256")
+    monkeypatch.setenv("KANTTS_C1_WGRAD_WGS", "128")
+    hip.apply_launch_tuning()
+    hip.apply_launch_tuning()
+    assert calls[-1] == (128256, 0, 128) and len(calls) == 2
+    monkeypatch.delenv("KANTTS_TN_TILE")
+    hip.apply_launch_tuning()
+    assert calls[-1] == (0, 0, 128) and len(calls) == 3
