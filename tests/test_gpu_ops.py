@@ -374,16 +374,15 @@ def test_embedding_and_length_regulator_bit_exact():
     assert_close(gg[0], cg[0], 1e-5, what="lr bwd")
 
 
-@pytest.mark.parametrize("C,K,lp,T", [(128, 41, 20, 70), (256, 41, 37, 70), (80, 41, 40, 300)])
-def test_fsmn_memory(C, K, lp, T):
-    """The last case: several 128-frame chunks per sequence and a channel count that is no multiple of the filter
-    gradient's 64-channel groups."""
+@pytest.mark.parametrize("C,K,lp,T,B", [(128, 41, 20, 70, 3), (256, 41, 37, 70, 3), (80, 41, 40, 300, 3), (64, 41, 20, 520, 8)])
+def test_fsmn_memory(C, K, lp, T, B):
+    """The third case: several 128-frame chunks per sequence and a channel count that is no multiple of the filter
+    gradient's 64-channel groups; the fourth: 40 partial rows, enough for the reduce kernel's four-loads-per-trip loop."""
     from kantts._hip import ops
 
-    B = 3
     x, w = _rand(B, T, C, seed=1, grad=True), _rand(C, 1, K, seed=2, scale=0.2, grad=True)
     res = _rand(B, T, C, seed=3, grad=True)
-    lens = torch.tensor([T, 33, T - 19])
+    lens = torch.tensor(([T, 33, T - 19] + [T - 7 * i for i in range(B)])[:B])
     go, gg, co, cg = run_both(lambda x, w, r, l: ops.fsmn_memory(x, w, l, lp, res=r), x, w, res, lens)
     assert_close(go[0], co[0], 2e-5, what="fsmn y")
     for a, c, nm in zip(gg, cg, ("dx", "dw", "dres")):

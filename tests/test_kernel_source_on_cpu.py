@@ -199,8 +199,8 @@ def test_op_linear_fwd_bwd(prec, tol, M, N, K):
     ("test_pnca_attention", dict(bw=0)), ("test_pnca_attention", dict(bw=3)), ("test_pnca_attention", dict(bw=50)),
     ("test_attention_long_sequence_fallback_kernels", {}),
     ("test_lstm_uni_bi_and_concat", {}), ("test_lstm_bf16_recurrence_close_to_fp32", {}),
-    ("test_fsmn_memory", dict(C=128, K=41, lp=20, T=70)), ("test_fsmn_memory", dict(C=256, K=41, lp=37, T=70)),
-    ("test_fsmn_memory", dict(C=80, K=41, lp=40, T=300)),
+    ("test_fsmn_memory", dict(C=128, K=41, lp=20, T=70, B=3)), ("test_fsmn_memory", dict(C=256, K=41, lp=37, T=70, B=3)),
+    ("test_fsmn_memory", dict(C=80, K=41, lp=40, T=300, B=3)), ("test_fsmn_memory", dict(C=64, K=41, lp=20, T=520, B=8)),
     ("test_dropout2_add_kernel", {}),
 ], ids=lambda v: v if isinstance(v, str) else "-".join("%s" % x for x in v.values()))
 def test_op_fp32_mode(name, kw):
