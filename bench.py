@@ -781,7 +781,7 @@ def fp32_leg(hip, cfg, batch, frames, mel_crit, pros_crit, dev, steps=5, warmup=
             "whole_step_mfma_frac": 456.9e9 * batch["mel_targets"].shape[0] / 32 / dt / 1e12 / PEAK_TFLOPS["fp32"]}
 
 
-def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parity_utts=32, cpu_threads=0):
+def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parity_utts=32, cpu_threads=0, wav_utts=6):
     """BASELINE config 5: end-to-end SAM-BERT -> HiFi-GAN inference on 128 synthetic utterances (T_in uniform
     20..80, the training id distributions, duration head biased to ~3.5 frames per symbol -- random-init weights predict
     zero durations otherwise), free-running: AR duration predictor, AR mel decoder, postnet, HiFi-GAN V1 generator with
@@ -798,7 +798,9 @@ def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parit
     with torch.no_grad():
         am.variance_adaptor.duration_predictor.fc.bias.fill_(1.5)
     am = am.to(dev).eval()
-    voc = Generator().to(dev).eval()
+    voc = Generator()
+    voc_P = {k: v.detach().clone() for k, v in voc.state_dict().items()}  # weight_g / weight_v: what the oracle reads
+    voc = voc.to(dev).eval()
     voc.remove_weight_norm()
     from kantts.utils.synthetic import inference_utterances
 
@@ -857,7 +859,7 @@ def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parit
         # whose wall time is the CPU baseline of this leg
         try:
             par = config5_parity(am, cfg, (lens, ling, emo, spk), order[:: max(1, n_utt // parity_utts)][:parity_utts],
-                                 batch=batch, threads=cpu_threads)
+                                 batch=batch, threads=cpu_threads, voc=voc, voc_P=voc_P, wav_utts=wav_utts)
             out["cpu_baseline"] = par.pop("cpu_baseline")
             out["parity_error"] = par
         except Exception as exc:  # noqa: BLE001
@@ -865,14 +867,17 @@ def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parit
     return out
 
 
-def config5_parity(am, cfg, utts, idx, batch=32, threads=0, mode="kernel"):
+def config5_parity(am, cfg, utts, idx, batch=32, threads=0, mode="kernel", voc=None, voc_P=None, wav_utts=0):
     """BASELINE config 5 checked at the configuration that is timed: the product's batched free-running (decoder mode
     ``mode``: "kernel" = each autoregressive loop one launch in bf16 mode / the replayed graph in fp32 mode, "graph")
     inference of the utterances ``idx`` (length-sorted batches of ``batch``) against oracle/torch_oracle.py's free-running
     inference of the same utterances one at a time (the reference's only mode, kantts/bin/infer_sambert.py:58-227;
     kantts_sambert.py:569-610; adaptors.py:67-83).  Reports (i) agreement of the frame counts and of the rounded durations
     (free-running: a 1-ulp change of exp(log_dur) - 1 + 0.5 can flip a duration), (ii) the mel error
-    with the durations FORCED to the oracle's, over the valid frames, (iii) the oracle's speed as this leg's CPU baseline.
+    with the durations FORCED to the oracle's, over the valid frames, (iii) the oracle's speed as this leg's CPU baseline,
+    (iv) with ``voc`` (the product's Generator) and ``voc_P`` (its state_dict before weight norm was folded): the VOCODER half
+    (kantts/bin/infer_hifigan.py:66-139) on ``wav_utts`` of the utterances -- the product's generator on the product's
+    FREE-RUNNING mel against oracle/hifigan_oracle.py's generator on the oracle's mel, over the utterance's samples.
     Checker only: nothing here runs inside a timed region."""
     import torch_oracle as O
 
@@ -890,7 +895,7 @@ def config5_parity(am, cfg, utts, idx, batch=32, threads=0, mode="kernel"):
             for b in idx.tolist():
                 n = int(lens[b])
                 o = O.sambert_forward(P, cfg, ling[b:b + 1, :n], emo[b:b + 1, :n], spk[b:b + 1, :n], lens[b:b + 1])
-                ref[b] = dict(frames=int(o["LR_length_rounded"][0]), mel=o["postnet_outputs"][0],
+                ref[b] = dict(frames=int(o["LR_length_rounded"][0]), mel=o["postnet_outputs"][0], bw=int(o["x_band_width"]),
                               dur=(torch.exp(o["log_duration_predictions"][0]) - 1 + 0.5).long())
     finally:
         cpu_s = time.perf_counter() - t0
@@ -899,10 +904,14 @@ def config5_parity(am, cfg, utts, idx, batch=32, threads=0, mode="kernel"):
     dev = next(am.parameters()).device
     am.mel_decoder.decode_mode = mode
     order = idx[torch.argsort(lens[idx], descending=True)]
-    same_frames = same_dur = n_sym = 0
+    same_frames = same_dur = n_sym = same_bw = 0
     abs_sum = abs_max = 0.0
     n_el = 0
     free_abs_sum, free_n = 0.0, 0
+    wav = {"n": 0, "abs": 0.0, "max": 0.0, "ref_sq": 0.0, "el": 0, "cpu_s": 0.0}
+    wav_set = set(idx.tolist()[:wav_utts]) if (voc is not None and wav_utts) else set()
+    if wav_set:
+        import hifigan_oracle as H
     for g0 in range(0, len(order), batch):
         grp = order[g0:g0 + batch]
         ln = lens[grp]
@@ -915,12 +924,16 @@ def config5_parity(am, cfg, utts, idx, batch=32, threads=0, mode="kernel"):
         with torch.no_grad():
             free = am(**args)
             forced = am(**args, duration_targets=dur_ref.to(dev))
+            wav_free = (voc(free["postnet_outputs"].transpose(1, 2).contiguous()).float().cpu()
+                        if wav_set.intersection(grp.tolist()) else None)
         fl = free["LR_length_rounded"].cpu()
         dur_free = (torch.exp(free["log_duration_predictions"].cpu()) - 1 + 0.5).long()
+        bw_free = free["band_width_per_sequence"].cpu() if "band_width_per_sequence" in free else None
         for i, b in enumerate(grp.tolist()):
             n, nf = int(lens[b]), ref[b]["frames"]
             same_frames += int(int(fl[i]) == nf)
             same_dur += int((dur_free[i, :n] == ref[b]["dur"]).sum())
+            same_bw += int(bw_free is not None and int(bw_free[i]) == ref[b]["bw"])
             n_sym += n
             assert int(forced["LR_length_rounded"][i]) == nf, "forced durations must reproduce the oracle's frame count"
             d = (forced["postnet_outputs"][i, :nf].cpu() - ref[b]["mel"][:nf]).abs()
@@ -931,14 +944,35 @@ def config5_parity(am, cfg, utts, idx, batch=32, threads=0, mode="kernel"):
                 df = (free["postnet_outputs"][i, :nf].cpu() - ref[b]["mel"][:nf]).abs()
                 free_abs_sum += float(df.sum())
                 free_n += df.numel()
+            if b in wav_set and int(fl[i]) == nf:
+                t1 = time.perf_counter()
+                if threads:
+                    torch.set_num_threads(threads)
+                try:
+                    with torch.no_grad():
+                        w_ref = H.generator(voc_P, ref[b]["mel"][:nf].t().unsqueeze(0).contiguous())[0, 0]
+                finally:
+                    torch.set_num_threads(nthr)
+                wav["cpu_s"] += time.perf_counter() - t1
+                dw = (wav_free[i, 0, : w_ref.numel()] - w_ref).abs()
+                wav["n"] += 1
+                wav["abs"] += float(dw.sum())
+                wav["max"] = max(wav["max"], float(dw.max()))
+                wav["ref_sq"] += float((w_ref.double() ** 2).sum())
+                wav["el"] += dw.numel()
     frames = sum(v["frames"] for v in ref.values())
     used_kernel = getattr(am.mel_decoder, "_decode_kernel", None) is not None
     return {"utterances": len(ref),
             "decoder": "%s, length-sorted batches of %d" % ("one launch per autoregressive loop" if used_kernel else
                                                             ("graph" if mode != "loop" else "loop"), batch),
             "frame_count_agreement": same_frames / len(ref), "duration_agreement": same_dur / n_sym,
+            "band_width_agreement": same_bw / len(ref),
             "mel_mean_abs_forced_durations": abs_sum / n_el, "mel_max_abs_forced_durations": abs_max,
             "mel_mean_abs_free_running_where_durations_agree": (free_abs_sum / free_n) if free_n else None,
+            "wav": None if not wav["n"] else {
+                "utterances": wav["n"], "samples": wav["el"], "mean_abs": wav["abs"] / wav["el"], "max_abs": wav["max"],
+                "reference_rms": (wav["ref_sq"] / wav["el"]) ** 0.5, "oracle_generator_cpu_s": wav["cpu_s"],
+                "what": "product generator on the product's free-running mel vs oracle generator on the oracle's mel"},
             "cpu_baseline": {"value": len(ref) / cpu_s, "unit": "utterances/s (symbols -> mel, batch 1, free-running)",
                              "mel_frames_per_s": frames / cpu_s, "cores": used, "kind": "port",
                              "sample": "%d of the leg's utterances through oracle/torch_oracle.py, %.1f s" % (len(ref), cpu_s)}}

@@ -1131,6 +1131,12 @@ typedef struct kantts_durar_args {
   int B, T;
 } kantts_durar_args;
 int kantts_dur_ar_run(const kantts_durar_args* args, void* stream);
+/* kantts_dur_ar_run_f32: the same loop in fp32 arithmetic (products are fp32 FMAs in k order) -- what inference uses for
+ * the duration predictor in EVERY precision mode, so that the index tensors derived from its output (durations, regulated
+ * lengths, band widths: kantts/models/sambert/kantts_sambert.py:455-460,989-993) equal the reference's bit for bit.
+ *   w : fp32 blob, the same three matrices, each (N, K) stored k-chunk-major: element (n, k) at ((k / 4) * N + n) * 4 + k % 4
+ *   f, gc, out, lens: as kantts_dur_ar_run. */
+int kantts_dur_ar_run_f32(const kantts_durar_args* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -546,9 +546,112 @@ __global__ __launch_bounds__(AR_THREADS) void dur_ar_run_kernel(const kantts_dur
   for (int i = len + tid; i < T; i += AR_THREADS) outb[i] = 0.f;
 }
 
+// ---- fp32 twin (round 6).  In bf16 mode the token-level front of inference (text encoder, variance adaptor, this loop)
+// stays fp32 so that the INDEX tensors of inference -- durations = int(exp(log_dur) - 1 + 0.5), the regulated lengths, the
+// band widths (kantts_sambert.py:455-460, 989-993) -- are the reference's bit for bit; the bf16 loop above flipped ~0.2 % of
+// the durations.  Same structure, a workgroup per sequence; the products are plain fp32 FMAs in k order.
+//   w : fp32 blob, each matrix (N, K) stored K-CHUNK-MAJOR: element (n, k) at ((k / 4) * N + n) * 4 + k % 4, so that
+//       thread n reads 16 bytes per chunk and a wave 1 KB of consecutive addresses:  P2 128 x 128 | G0 512 x 256 | G1 512 x 256
+//   f : as above.
+// The bound is the 1.1 MB weight stream per token from L2 into one CU (the bf16 loop streams half of it).
+template <int NCH>
+__device__ __forceinline__ float da_dot_f32(const float* __restrict__ Wn, int pitch, const float* xs) {
+  // Wn = chunk 0 of this thread's output; pitch = floats between two chunks (4 N); xs = the chunked inputs in LDS
+  float acc = 0.f;
+  constexpr int G = NCH < 16 ? NCH : 16;
+#pragma unroll
+  for (int c0 = 0; c0 < NCH; c0 += G) {
+    f32x4 w[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) w[j] = *reinterpret_cast<const f32x4*>(Wn + (long long)(c0 + j) * pitch);
+    __builtin_amdgcn_sched_barrier(0);  // all G loads in flight before the first FMA (see ar_gemv)
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xs + 4 * (c0 + j));
+      acc = fmaf(w[j][0], x[0], acc);
+      acc = fmaf(w[j][1], x[1], acc);
+      acc = fmaf(w[j][2], x[2], acc);
+      acc = fmaf(w[j][3], x[3], acc);
+    }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(AR_THREADS) void dur_ar_run_f32_kernel(const kantts_durar_args g) {
+  static_assert(AR_THREADS == 4 * DA_H, "a thread per gate pre-activation");
+  __shared__ __attribute__((aligned(16))) float vA[2 * DA_H];
+  __shared__ __attribute__((aligned(16))) float vB[2 * DA_H];
+  __shared__ __attribute__((aligned(16))) float gate[4 * DA_H];
+  __shared__ float part[2];
+  __shared__ float xprev;
+  const int tid = threadIdx.x, b = blockIdx.x, T = g.T;
+  const float* W = reinterpret_cast<const float*>(g.w);
+  const float* F = g.f;
+  const int len = min(g.lens ? g.lens[b] : T, T);
+  const float* gcb = g.gc + (long long)b * T * 4 * DA_H;
+  float* outb = g.out + (long long)b * T;
+  float c0 = 0.f, c1 = 0.f;
+  if (tid == 0) xprev = 0.f;
+  if (tid < DA_H) {
+    vB[DA_H + tid] = 0.f;
+    vA[DA_H + tid] = 0.f;
+  }
+  __syncthreads();
+  const int pn = tid & (DA_H - 1), pq = tid >> 7;  // prenet layer 2: output pn, k quarter pq
+  for (int i = 0; i < len; ++i) {
+    const float gci = gcb[(long long)i * 4 * DA_H + tid];  // requested before the products, used after them
+    if (tid < DA_H) vA[tid] = fmaxf(fmaf(F[DA_F_WP1 + tid], xprev, F[DA_F_BP1 + tid]), 0.f);
+    __syncthreads();
+    // prenet layer 2 (128 x 128): four threads per output, a quarter of k each; combined in a fixed order
+    gate[pq * DA_H + pn] = da_dot_f32<8>(W + DA_W_P2 + (long long)(pq * 8) * 4 * DA_H + 4 * pn, 4 * DA_H, vA + 32 * pq);
+    __syncthreads();
+    if (tid < DA_H)
+      vB[tid] = fmaxf(((gate[tid] + gate[DA_H + tid]) + (gate[2 * DA_H + tid] + gate[3 * DA_H + tid])) + F[DA_F_BP2 + tid], 0.f);
+    __syncthreads();
+    // cell 0: gates = gc[i] + [W_ih0[:, :128] | W_hh0] . [prenet | h0]; thread = gate row
+    gate[tid] = da_dot_f32<64>(W + DA_W_G0 + 4 * tid, 4 * 4 * DA_H, vB) + gci;
+    __syncthreads();
+    if (tid < DA_H) {
+      const float gi = da_sigmoid(gate[tid]), gf = da_sigmoid(gate[DA_H + tid]);
+      const float gg = tanhf(gate[2 * DA_H + tid]), go = da_sigmoid(gate[3 * DA_H + tid]);
+      c0 = gf * c0 + gi * gg;
+      const float h = go * tanhf(c0);
+      vA[tid] = h;
+      vB[DA_H + tid] = h;
+    }
+    __syncthreads();
+    gate[tid] = da_dot_f32<64>(W + DA_W_G1 + 4 * tid, 4 * 4 * DA_H, vA) + F[DA_F_BG1 + tid];
+    __syncthreads();
+    if (tid < DA_H) {
+      const float gi = da_sigmoid(gate[tid]), gf = da_sigmoid(gate[DA_H + tid]);
+      const float gg = tanhf(gate[2 * DA_H + tid]), go = da_sigmoid(gate[3 * DA_H + tid]);
+      c1 = gf * c1 + gi * gg;
+      const float h = go * tanhf(c1);
+      vA[DA_H + tid] = h;
+      const float p = ar_wave_sum(F[DA_F_WFC + tid] * h);
+      if ((tid & 63) == 0) part[tid >> 6] = p;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const float y = fmaxf(part[0] + part[1] + F[DA_F_BFC], 0.f);
+      xprev = y;
+      outb[i] = y;
+    }
+    __syncthreads();
+  }
+  for (int i = len + tid; i < T; i += AR_THREADS) outb[i] = 0.f;
+}
+
 extern "C" int kantts_dur_ar_run(const kantts_durar_args* a, void* stream) {
   if (!a || !a->w || !a->f || !a->gc || !a->out || a->B < 0 || a->T < 0) return KANTTS_E_BADARG;
   if (a->B == 0 || a->T == 0) return KANTTS_OK;
   hipLaunchKernelGGL(dur_ar_run_kernel, dim3(a->B), dim3(AR_THREADS), 0, (hipStream_t)stream, *a);
+  KANTTS_CHECK_LAUNCH();
+}
+
+extern "C" int kantts_dur_ar_run_f32(const kantts_durar_args* a, void* stream) {
+  if (!a || !a->w || !a->f || !a->gc || !a->out || a->B < 0 || a->T < 0) return KANTTS_E_BADARG;
+  if (a->B == 0 || a->T == 0) return KANTTS_OK;
+  hipLaunchKernelGGL(dur_ar_run_f32_kernel, dim3(a->B), dim3(AR_THREADS), 0, (hipStream_t)stream, *a);
   KANTTS_CHECK_LAUNCH();
 }

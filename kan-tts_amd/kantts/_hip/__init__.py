@@ -383,6 +383,7 @@ def lib():
         L.kantts_launch_tuning.argtypes = [c_int, c_int, c_int]
         L.kantts_pnca_decode_run.argtypes = [POINTER(DecodeArgs), c_void_p]
         L.kantts_dur_ar_run.argtypes = [POINTER(DurArArgs), c_void_p]
+        L.kantts_dur_ar_run_f32.argtypes = [POINTER(DurArArgs), c_void_p]
         L.kantts_pnca_decode_blob_sizes.argtypes = [c_int, c_int, c_int, c_int, POINTER(ctypes.c_longlong),
                                                     POINTER(ctypes.c_longlong)]
         L.kantts_pnca_block_bwd_ws_floats.argtypes = [c_int]
@@ -435,7 +436,7 @@ EXPORTED_SYMBOLS = [
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
     "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof", "kantts_pnca_attn_qkv_bwd",
-    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_launch_tuning",
+    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_dur_ar_run_f32", "kantts_launch_tuning",
 ]
 
 
@@ -490,6 +491,25 @@ def set_precision(mode: str):
 
 def get_precision() -> str:
     return {PREC_FP32: "fp32", PREC_BF16: "bf16", PREC_REF: "ref"}[_precision["gemm"]]
+
+
+class precision_scope:
+    """``with precision_scope("fp32"): ...`` -- the contraction mode for the ops issued inside the block (the per-module
+    precision override: in bf16 mode the token-level front of INFERENCE -- text encoder, variance adaptor, duration loop --
+    runs fp32 so that the index tensors derived from it are bit-exact; KanTtsSAMBERT.forward).  ``None`` = leave as is."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.before = _precision["gemm"]
+        if self.mode is not None:
+            set_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _precision["gemm"] = self.before
+        return False
 
 
 def make_seg(a, a_is, a_ks, b, b_js, b_ks, klen, ntaps=1, b_tap=0, a_tok_axis=0, a_shift0=0, a_shift_step=0,
@@ -870,10 +890,15 @@ def dur_ar_run(w, f, gc, out, lens32):
     """The free-running duration predictor for every sequence in one launch (csrc/ar_infer.hip)."""
     B, T = out.shape
     g = DurArArgs()
-    g.w, g.f, g.gc, g.out, g.lens = ptr(w, torch.bfloat16), ptr(f, torch.float32), ptr(gc, torch.float32), ptr(out, torch.float32), ptr(lens32, torch.int32)
+    f32 = w.dtype == torch.float32  # k-chunk-major fp32 blob: the fp32 loop (kantts_dur_ar_run_f32)
+    g.w, g.f, g.gc, g.out, g.lens = ptr(w, w.dtype if f32 else torch.bfloat16), ptr(f, torch.float32), ptr(gc, torch.float32), ptr(out, torch.float32), ptr(lens32, torch.int32)
     g.B, g.T = int(B), int(T)
     assert gc.is_contiguous() and out.is_contiguous() and gc.shape[-1] == 512
-    check(lib().kantts_dur_ar_run(ctypes.byref(g), stream()), "dur_ar_run")
+    assert w.numel() == 128 * 128 + 2 * 512 * 256
+    if f32:
+        check(lib().kantts_dur_ar_run_f32(ctypes.byref(g), stream()), "dur_ar_run_f32")
+    else:
+        check(lib().kantts_dur_ar_run(ctypes.byref(g), stream()), "dur_ar_run")
 
 
 def pnca_attn_qkv_bwd(qkv, hkv, ldh, ox, oh, d_ox, d_oh, lse_x, lse_h, B, L, *, lens, bw_dev, bw_x, bw_h, att_p, seed_x, seed_h,

@@ -292,31 +292,4 @@ def get_am_datasets(metafile, root_dir, config, allow_cache, split_ratio=0.98, s
     return AM_Dataset(config, train_lst, root_dir, allow_cache), AM_Dataset(config, valid_lst, root_dir, allow_cache)
 
 
-def reference_dataset_module():
-    """The reference's own kantts/datasets/dataset.py, loaded from a checkout (KANTTS_REFERENCE_ROOT) under a private
-    name, for the datasets this package does not implement (BERT_Text_Dataset of the sy-BERT pre-training)."""
-    import importlib.util
-    import sys
-
-    import kantts
-
-    name = "kantts.datasets._reference_dataset"
-    if name in sys.modules:
-        return sys.modules[name]
-    if not kantts.REFERENCE_ROOT:
-        return None
-    path = os.path.join(kantts.REFERENCE_ROOT, "kantts", "datasets", "dataset.py")
-    if not os.path.exists(path):
-        return None
-    spec = importlib.util.spec_from_file_location(name, path)
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules[name] = mod
-    try:
-        spec.loader.exec_module(mod)
-    except Exception:
-        del sys.modules[name]
-        raise
-    return mod
-
-
 logging.getLogger(__name__).addHandler(logging.NullHandler())

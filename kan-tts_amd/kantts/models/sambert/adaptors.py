@@ -60,6 +60,7 @@ class VarRnnARPredictor(nn.Module):
         # free-running inference: None = the one-launch loop where it applies (HIP device, bf16 mode), False = always the
         # per-token launches, True = also on host tensors (the emulated C ABI of the CPU tests)
         self.ar_kernel = None
+        self.ar_bf16 = False  # True: the bf16 MFMA loop of round 5 (flips ~0.2 % of the integer durations; bf16 mode only)
         self._ar = None
 
     def _layer(self, l):
@@ -84,12 +85,12 @@ class VarRnnARPredictor(nn.Module):
         step (the reference re-runs nn.LSTM on a length-1 sequence and torch.cat's the outputs)."""
         B, T = cond.size(0), cond.size(1)
         if self.ar_kernel is not False and (cond.is_cuda or self.ar_kernel is True):
-            # bf16 mode: the whole loop as ONE launch, a workgroup per sequence (csrc/ar_infer.hip)
+            # the whole loop as ONE launch, a workgroup per sequence (csrc/ar_infer.hip); fp32 arithmetic in every mode
             from kantts.models.sambert.ar_kernels import DurationKernel
 
-            if DurationKernel.eligible(self, cond):
-                if self._ar is None:
-                    self._ar = DurationKernel(self)
+            if DurationKernel.eligible(self, cond, self.ar_bf16):
+                if self._ar is None or self._ar.bf16 != bool(self.ar_bf16):
+                    self._ar = DurationKernel(self, self.ar_bf16)
                 info = SeqInfo.of(masks)
                 return self._ar.run(cond, None if info is None else info.lens32)
         w_ih0, w_hh0, b_ih0, b_hh0 = self._layer(0)

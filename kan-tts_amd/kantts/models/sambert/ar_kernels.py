@@ -17,7 +17,19 @@ from kantts._hip import ops
 
 
 def _key(params):
-    return tuple((p.data_ptr(), p._version) for p in params)
+    """Identity of the weights a packed blob was built from.  ``ops.weights_epoch`` counts the raw in-place parameter
+    writes that do not bump ``Tensor._version`` (ArenaAdam's kantts_adam_step, optimizer restore, broadcast): without it
+    inference between two training steps would keep the blob of the first call."""
+    return (ops.weights_epoch[0],) + tuple((p.data_ptr(), p._version) for p in params)
+
+
+def _kmajor4(w):
+    """(out, in) fp32 matrix -> flat k-chunk-major: element (n, k) at ((k // 4) * out + n) * 4 + k % 4 (the layout of
+    kantts_dur_ar_run_f32: thread n reads 16 bytes per chunk, a wave 1 KB of consecutive addresses)."""
+    w = w.detach().float()
+    n, k = w.shape
+    assert k % 4 == 0
+    return w.view(n, k // 4, 4).permute(1, 0, 2).reshape(-1)
 
 
 def _mat(w):
@@ -120,16 +132,19 @@ class DecoderKernel:
 
 
 class DurationKernel:
-    """kantts_dur_ar_run for one VarRnnARPredictor."""
+    """kantts_dur_ar_run_f32 / kantts_dur_ar_run for one VarRnnARPredictor.  ``bf16=False`` (the default in every
+    precision mode): the fp32 loop, whose outputs become index tensors downstream; ``bf16=True`` keeps the bf16 MFMA loop
+    of round 5 reachable (``pred.ar_bf16 = True``; bf16 mode only)."""
 
-    def __init__(self, pred):
+    def __init__(self, pred, bf16=False):
         self.pred = pred
+        self.bf16 = bool(bf16)
         self.key = None
         self.w = self.f = self.gc_w = self.gc_b = None
 
     @staticmethod
-    def eligible(pred, cond):
-        if hip.get_precision() != "bf16" or pred.lstm.num_layers != 2 or pred.lstm.hidden_size != 128:
+    def eligible(pred, cond, bf16=False):
+        if (bf16 and hip.get_precision() != "bf16") or pred.lstm.num_layers != 2 or pred.lstm.hidden_size != 128:
             return False
         fcs = [m for m in pred.prenet.fcs if isinstance(m, nn.Linear)]
         return (len(fcs) == 2 and fcs[0].in_features == 1 and [m.out_features for m in fcs] == [128, 128]
@@ -149,8 +164,11 @@ class DurationKernel:
         fc1, fc2 = [m for m in p.prenet.fcs if isinstance(m, nn.Linear)]
         w_ih0, w_hh0, b_ih0, b_hh0 = p._layer(0)
         w_ih1, w_hh1, b_ih1, b_hh1 = p._layer(1)
-        self.w = torch.cat([_mat(fc2.weight), _mat(torch.cat([w_ih0[:, :128], w_hh0], dim=1)),
-                            _mat(torch.cat([w_ih1, w_hh1], dim=1))]).to(torch.bfloat16).contiguous()
+        mats = (fc2.weight, torch.cat([w_ih0[:, :128], w_hh0], dim=1), torch.cat([w_ih1, w_hh1], dim=1))
+        if self.bf16:
+            self.w = torch.cat([_mat(m) for m in mats]).to(torch.bfloat16).contiguous()
+        else:
+            self.w = torch.cat([_kmajor4(m) for m in mats]).contiguous()
         self.f = torch.cat([t.detach().float().reshape(-1) for t in
                             (fc1.weight, fc1.bias, fc2.bias, b_ih1 + b_hh1, p.fc.weight, p.fc.bias,
                              torch.zeros(3, device=fc1.weight.device))]).contiguous()
@@ -163,7 +181,8 @@ class DurationKernel:
         """cond (B, T, C) -> (B, T) predictions (0 at padded tokens)."""
         self.refresh()
         B, T = cond.size(0), cond.size(1)
-        gc = ops.linear(cond.contiguous(), self.gc_w, self.gc_b).float().contiguous()  # (B, T, 512)
+        with hip.precision_scope(None if self.bf16 else "fp32"):
+            gc = ops.linear(cond.contiguous(), self.gc_w, self.gc_b).float().contiguous()  # (B, T, 512)
         out = torch.empty((B, T), device=cond.device, dtype=torch.float32)
         hip.dur_ar_run(self.w, self.f, gc, out, lens32)
         return out

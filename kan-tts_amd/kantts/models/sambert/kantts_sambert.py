@@ -17,6 +17,7 @@ import torch.nn.functional as F
 
 import os
 
+import kantts._hip as hip_rt
 from kantts._hip import ops
 from kantts.models.sambert import FFTBlock, PNCABlock, Prenet
 from kantts.models.sambert.alignment import b_mas
@@ -520,6 +521,9 @@ class KanTtsSAMBERT(nn.Module):
         # choose the one-launch PNCA block (band <= 16) without reading the device value; that launch poisons its output
         # with NaN if the promise is broken.
         self.band_width_bound = None
+        # inference: text encoder + variance adaptor (+ duration loop) in fp32 whatever the precision mode, so that the
+        # index tensors derived from them are the reference's (forward(); False = round 5's all-bf16 front)
+        self.infer_front_fp32 = True
 
     def get_lfr_mask_from_lengths(self, lengths, max_len):
         """ceil(len / r) valid decoder steps (reference :736-750, vectorised: no per-item .item())."""
@@ -623,46 +627,52 @@ class KanTtsSAMBERT(nn.Module):
                                                                 duration_targets)
         if in_info is None:
             in_info = SeqInfo(input_lengths, T_in)
-        if teacher:
-            (text_hid, enc_sla_attn_lst, ling_embedding), tplan = ops.run_beside(
-                lambda: self.text_encoder(inputs_ling, in_info, self.return_attns),
-                lambda: self._beside_encoder(in_info, output_lengths, mel_targets, duration_targets, inputs_emotion,
-                                             inputs_speaker, pitch_targets, energy_targets, base_plan=base_plan),
-                side_inputs=(output_lengths, mel_targets, duration_targets, in_info.mask, in_info.lens64, inputs_emotion,
-                             inputs_speaker, pitch_targets, energy_targets))
-        else:
-            text_hid, enc_sla_attn_lst, ling_embedding = self.text_encoder(inputs_ling, in_info, self.return_attns)
-        # backward: once the gradient reaches the encoder output, the weight gradients of everything downstream start on
-        # the side stream, beside the encoder's own backward (no-op unless weight gradients are deferred)
-        text_hid = ops.wgrad_flush_point(text_hid)
-        inter_lengths = input_lengths
-        attn_soft = attn_hard = attn_logprob = None
-        if self.MAS and is_training:
-            # Monotonic-Alignment-Search (reference :901-925): soft attention mel <-> (scaled) linguistic embedding,
-            # hard path by DP, durations = frames per phoneme, frame-level pitch / energy averaged per phoneme
-            attn_soft, attn_logprob = self.align_attention.forward_cl(mel_targets, ling_embedding, input_lengths,
-                                                                      attn_priors)
-            attn_hard = self.binarize_attention_parallel(attn_soft, input_lengths, output_lengths)
-            duration_targets = attn_hard.sum(2)[:, 0, :]
-            pitch_targets = average_frame_feat(pitch_targets.unsqueeze(1), duration_targets).squeeze(1)
-            energy_targets = average_frame_feat(energy_targets.unsqueeze(1), duration_targets).squeeze(1)
-            # the slot after the last phoneme absorbs the r-padding so that durations sum to the padded mel length
-            # (reference loop :921-924, vectorised: no per-item .item())
-            pad = (mel_targets.size(1) - output_lengths).to(duration_targets.dtype)
-            duration_targets.scatter_(1, input_lengths.view(-1, 1), pad.view(-1, 1))
-        if tplan is not None and "emo_hid" in tplan:
-            emo_hid, spk_hid = tplan["emo_hid"], tplan["spk_hid"]
-        else:
-            emo_hid, spk_hid = self._embed_emo_spk(inputs_emotion, inputs_speaker)
-        out_info = None
-        max_out_len = None
-        if output_lengths is not None:
-            max_out_len = mel_targets.size(1)
-            out_info = tplan["out_info"] if tplan is not None else SeqInfo(output_lengths, max_out_len)
-        (LR_text_outputs, LR_emo_outputs, LR_spk_outputs, LR_length_rounded, log_duration_predictions,
-         pitch_predictions, energy_predictions) = self.variance_adaptor(
-            text_hid, emo_hid, spk_hid, masks=in_info, output_masks=out_info, duration_targets=duration_targets,
-            pitch_targets=pitch_targets, energy_targets=energy_targets, max_out_len=max_out_len, teacher_plan=tplan)
+        # Inference: the token-level front (text encoder, embeddings, variance adaptor incl. the duration loop) runs fp32
+        # in EVERY precision mode.  Its outputs become index tensors -- durations = int(exp(log_dur) - 1 + 0.5), regulated
+        # lengths, band widths (reference :455-460, :989-993) -- which north_star wants bit-exact; in bf16 it flipped 0.2 %
+        # of the durations = 3 of 32 utterance lengths.  It is T_in <= ~80 tokens: a few % of an utterance's time.
+        front = hip_rt.precision_scope("fp32" if (not is_training and self.infer_front_fp32) else None)
+        with front:
+            if teacher:
+                (text_hid, enc_sla_attn_lst, ling_embedding), tplan = ops.run_beside(
+                    lambda: self.text_encoder(inputs_ling, in_info, self.return_attns),
+                    lambda: self._beside_encoder(in_info, output_lengths, mel_targets, duration_targets, inputs_emotion,
+                                                 inputs_speaker, pitch_targets, energy_targets, base_plan=base_plan),
+                    side_inputs=(output_lengths, mel_targets, duration_targets, in_info.mask, in_info.lens64, inputs_emotion,
+                                 inputs_speaker, pitch_targets, energy_targets))
+            else:
+                text_hid, enc_sla_attn_lst, ling_embedding = self.text_encoder(inputs_ling, in_info, self.return_attns)
+            # backward: once the gradient reaches the encoder output, the weight gradients of everything downstream start on
+            # the side stream, beside the encoder's own backward (no-op unless weight gradients are deferred)
+            text_hid = ops.wgrad_flush_point(text_hid)
+            inter_lengths = input_lengths
+            attn_soft = attn_hard = attn_logprob = None
+            if self.MAS and is_training:
+                # Monotonic-Alignment-Search (reference :901-925): soft attention mel <-> (scaled) linguistic embedding,
+                # hard path by DP, durations = frames per phoneme, frame-level pitch / energy averaged per phoneme
+                attn_soft, attn_logprob = self.align_attention.forward_cl(mel_targets, ling_embedding, input_lengths,
+                                                                          attn_priors)
+                attn_hard = self.binarize_attention_parallel(attn_soft, input_lengths, output_lengths)
+                duration_targets = attn_hard.sum(2)[:, 0, :]
+                pitch_targets = average_frame_feat(pitch_targets.unsqueeze(1), duration_targets).squeeze(1)
+                energy_targets = average_frame_feat(energy_targets.unsqueeze(1), duration_targets).squeeze(1)
+                # the slot after the last phoneme absorbs the r-padding so that durations sum to the padded mel length
+                # (reference loop :921-924, vectorised: no per-item .item())
+                pad = (mel_targets.size(1) - output_lengths).to(duration_targets.dtype)
+                duration_targets.scatter_(1, input_lengths.view(-1, 1), pad.view(-1, 1))
+            if tplan is not None and "emo_hid" in tplan:
+                emo_hid, spk_hid = tplan["emo_hid"], tplan["spk_hid"]
+            else:
+                emo_hid, spk_hid = self._embed_emo_spk(inputs_emotion, inputs_speaker)
+            out_info = None
+            max_out_len = None
+            if output_lengths is not None:
+                max_out_len = mel_targets.size(1)
+                out_info = tplan["out_info"] if tplan is not None else SeqInfo(output_lengths, max_out_len)
+            (LR_text_outputs, LR_emo_outputs, LR_spk_outputs, LR_length_rounded, log_duration_predictions,
+             pitch_predictions, energy_predictions) = self.variance_adaptor(
+                text_hid, emo_hid, spk_hid, masks=in_info, output_masks=out_info, duration_targets=duration_targets,
+                pitch_targets=pitch_targets, energy_targets=energy_targets, max_out_len=max_out_len, teacher_plan=tplan)
         Tp = LR_text_outputs.size(1)
         if tplan is not None:
             lfr_info = tplan["lfr_info"]
@@ -746,6 +756,10 @@ class KanTtsSAMBERT(nn.Module):
             "fp_predictions": None,
             "valid_inter_lengths": inter_lengths,
         }
+        if bw_dev is not None and bw_dev.numel() == batch_size and mel_targets is None:
+            # batched inference: every sequence keeps the band width its own utterance would have had (an extra key; the
+            # reference infers one utterance at a time, where x_band_width is this value)
+            res["band_width_per_sequence"] = bw_dev
         res["LR_text_outputs"] = LR_text_outputs
         res["LR_emo_outputs"] = LR_emo_outputs
         res["LR_spk_outputs"] = LR_spk_outputs

@@ -35,14 +35,11 @@ _PHONESET, _TONELIST = "PhoneSet.xml", "tonelist.txt"
 
 def language_directory(language, language_dir=None):
     """Directory holding PhoneSet.xml / tonelist.txt of ``language`` ("PinYin", "ZhHK", "Sichuan", "WuuShanghai", ...).
-    Looked up, in order: the argument (``linguistic_unit.language_dir`` of the yaml), $KANTTS_LANGUAGE_DIR, a KAN-TTS
-    checkout named by $KANTTS_REFERENCE_ROOT, ``kantts/preprocess/languages`` of this package.  Each candidate may be the
-    language's own directory or the directory of all languages."""
-    import kantts
-
+    Looked up, in order: the argument (``linguistic_unit.language_dir`` of the yaml), $KANTTS_LANGUAGE_DIR,
+    ``kantts/preprocess/languages`` of this package.  Each candidate may be the language's own directory or the directory
+    of all languages."""
     here = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "preprocess", "languages"))
-    cands = [language_dir, os.environ.get("KANTTS_LANGUAGE_DIR"),
-             os.path.join(kantts.REFERENCE_ROOT, "kantts", "preprocess", "languages") if kantts.REFERENCE_ROOT else None, here]
+    cands = [language_dir, os.environ.get("KANTTS_LANGUAGE_DIR"), here]
     tried = []
     for c in cands:
         if not c:
@@ -52,8 +49,8 @@ def language_directory(language, language_dir=None):
             if os.path.isfile(os.path.join(d, _PHONESET)) and os.path.isfile(os.path.join(d, _TONELIST)):
                 return d
     raise FileNotFoundError(
-        "no %s / %s for language %r (looked in %s): set linguistic_unit.language_dir in the yaml, KANTTS_LANGUAGE_DIR, or "
-        "KANTTS_REFERENCE_ROOT" % (_PHONESET, _TONELIST, language, ", ".join(tried) or "nowhere"))
+        "no %s / %s for language %r (looked in %s): set linguistic_unit.language_dir in the yaml or "
+        "KANTTS_LANGUAGE_DIR" % (_PHONESET, _TONELIST, language, ", ".join(tried) or "nowhere"))
 
 
 def load_language_symbols(language="PinYin", language_dir=None):

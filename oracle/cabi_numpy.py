@@ -766,6 +766,45 @@ class EmulatedLib:
             out[b, n:] = 0
         return 0
 
+    def kantts_dur_ar_run_f32(self, args_ref, stream):
+        """kantts_dur_ar_run in fp32 arithmetic; matrices k-chunk-major: (n, k) at ((k // 4) * N + n) * 4 + k % 4."""
+        g = args_ref._obj
+        B, T, H = g.B, g.T, 128
+        if B == 0 or T == 0:
+            return 0
+        W = _arr(g.w, H * H + 2 * 4 * H * 2 * H).copy()
+        F = _arr(g.f, 1028).copy()
+
+        def mat(flat, n, k):
+            return flat.reshape(k // 4, n, 4).transpose(1, 0, 2).reshape(n, k)
+
+        P2 = mat(W[:H * H], H, H)
+        G0 = mat(W[H * H:H * H + 4 * H * 2 * H], 4 * H, 2 * H)
+        G1 = mat(W[H * H + 4 * H * 2 * H:], 4 * H, 2 * H)
+        gc = _arr(g.gc, B * T * 4 * H).reshape(B, T, 4 * H)
+        out = _arr(g.out, B * T).reshape(B, T)
+        lens = _arr(g.lens, B, np.int32) if g.lens else np.full(B, T, np.int32)
+
+        def cell(gates, c):
+            sig = lambda v: (1.0 / (1.0 + np.exp(-v))).astype(np.float32)  # noqa: E731
+            c = sig(gates[H:2 * H]) * c + sig(gates[:H]) * np.tanh(gates[2 * H:3 * H])
+            return (sig(gates[3 * H:]) * np.tanh(c)).astype(np.float32), c.astype(np.float32)
+
+        for b in range(B):
+            h0 = h1 = np.zeros(H, np.float32)
+            c0 = c1 = np.zeros(H, np.float32)
+            x = np.float32(0)
+            n = min(int(lens[b]), T)
+            for i in range(n):
+                p = np.maximum(F[0:128] * x + F[128:256], 0).astype(np.float32)
+                p = np.maximum(P2 @ p + F[256:384], 0).astype(np.float32)
+                h0, c0 = cell((G0 @ np.concatenate([p, h0]) + gc[b, i]).astype(np.float32), c0)
+                h1, c1 = cell((G1 @ np.concatenate([h0, h1]) + F[384:896]).astype(np.float32), c1)
+                x = np.float32(max(float(np.dot(F[896:1024], h1) + F[1024]), 0.0))
+                out[b, i] = x
+            out[b, n:] = 0
+        return 0
+
     def kantts_copy_roof(self, src, read_bytes, dst, write_bytes, stream):
         return 0  # a bandwidth calibration launch: no values to model
 

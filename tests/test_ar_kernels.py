@@ -134,6 +134,7 @@ def test_decoder_entry_refuses_and_poisons(ctx):
             setattr(d, name, z.data_ptr())
         d.B, d.T = 0, 5
         assert hip.lib().kantts_dur_ar_run(ctypes.byref(d), None) == 0
+        assert hip.lib().kantts_dur_ar_run_f32(ctypes.byref(d), None) == 0
 
 
 @pytest.mark.gpu
@@ -159,38 +160,52 @@ def test_decoder_loop_refuses_what_it_is_not_compiled_for_gpu():
         hip.set_precision("fp32")
 
 
-def _durations(m, device, use_kernel, B, T, lens, seed=5):
+def _durations(m, device, use_kernel, B, T, lens, seed=5, bf16=False):
     from kantts.models.utils import get_mask_from_lengths
 
     pred = m.variance_adaptor.duration_predictor
     g = torch.Generator().manual_seed(seed)
     cond = (0.8 * torch.randn(B, T, pred.lstm.input_size - 128, generator=g)).to(device)
     pred.ar_kernel = True if use_kernel else False
+    pred.ar_bf16 = bf16
     pred._ar = None
     with torch.no_grad():
         out = pred.infer(cond, masks=None if lens is None else get_mask_from_lengths(torch.tensor(lens, device=device), T))
     assert (pred._ar is not None) == bool(use_kernel)
+    if use_kernel:
+        assert pred._ar.w.dtype == (torch.bfloat16 if bf16 else torch.float32)
     return out.detach().cpu()
 
 
 def _check_durations(device, B, T, lens):
+    """The one-launch loops against the per-token launches.  fp32 loop (what inference uses in EVERY precision mode: its
+    outputs become index tensors) against the fp32 per-token path: 2e-5; it must not depend on the precision mode.  The bf16
+    MFMA loop of round 5 (``ar_bf16``) against the bf16 per-token path: 5e-3."""
     import kantts._hip as hip
 
+    m = _model(device)
+    with torch.no_grad():
+        m.variance_adaptor.duration_predictor.fc.bias.fill_(0.7)  # keep the fed-back value off the ReLU's zero
+    hip.set_precision("fp32")
+    ref32 = _durations(m, device, False, B, T, lens)
+    got32 = _durations(m, device, True, B, T, lens)
     hip.set_precision("bf16")
     try:
-        m = _model(device)
-        with torch.no_grad():
-            m.variance_adaptor.duration_predictor.fc.bias.fill_(0.7)  # keep the fed-back value off the ReLU's zero
         ref = _durations(m, device, False, B, T, lens)
-        got = _durations(m, device, True, B, T, lens)
+        got = _durations(m, device, True, B, T, lens, bf16=True)
+        got32_in_bf16_mode = _durations(m, device, True, B, T, lens)
     finally:
         hip.set_precision("fp32")
-    assert got.shape == ref.shape
+    assert got.shape == ref.shape == got32.shape
     assert float(ref.abs().max()) > 0.1
-    assert float((got - ref).abs().max()) < 5e-3 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+    scale = max(1.0, float(ref32.abs().max()))
+    assert float((got32 - ref32).abs().max()) < 2e-5 * scale, float((got32 - ref32).abs().max())
+    assert torch.equal(got32, got32_in_bf16_mode)
+    assert float((got - ref).abs().max()) < 5e-3 * scale, float((got - ref).abs().max())
     if lens is not None:
         for b, n in enumerate(lens):
-            assert float(got[b, n:].abs().max() if n < T else 0.0) == 0.0
+            for o in (got, got32):
+                assert float(o[b, n:].abs().max() if n < T else 0.0) == 0.0
 
 
 def test_duration_loop_as_one_launch_emulated():
@@ -208,3 +223,48 @@ def test_duration_loop_as_one_launch_kernel_source():
 @pytest.mark.parametrize("B,T,lens", [(3, 7, [7, 4, 1]), (32, 80, None), (5, 61, [61, 20, 33, 60, 2])])
 def test_duration_loop_as_one_launch_gpu(B, T, lens):
     _check_durations("cuda", B, T, lens)
+
+
+def test_packed_blobs_follow_raw_optimizer_writes_emulated():
+    """ArenaAdam writes the weights with a raw kernel that never bumps ``Tensor._version``; the packed blobs of
+    the one-launch loops must still be rebuilt (their key carries ops.weights_epoch).  A step of ArenaAdam between two
+    inference calls: the kernel path follows the per-launch path both times."""
+    import kantts._hip as hip
+    from kantts.train.optim import ArenaAdam, ParamArena
+
+    with emulation():
+        hip.set_precision("bf16")
+        try:
+            m = _model("cpu")
+            with torch.no_grad():
+                m.variance_adaptor.duration_predictor.fc.bias.fill_(0.7)
+            arena = ParamArena(m)
+            opt = ArenaAdam(arena, lr=0.05)
+            dec_before = _decode(m, "cpu", "kernel", 2, 5, [5, 3], [2, 1])
+            dur_before = _durations(m, "cpu", True, 2, 6, [6, 3])
+            kern, durk = m.mel_decoder._decode_kernel, m.variance_adaptor.duration_predictor._ar
+            versions = [p._version for p in m.parameters()]
+            opt.zero_grad()
+            for p in m.parameters():
+                p.grad = torch.ones_like(p) if p.grad is None else p.grad.fill_(1.0)
+            opt.step()
+            assert [p._version for p in m.parameters()] == versions  # the raw write is invisible to autograd's counter
+            dec_after = _decode(m, "cpu", "kernel", 2, 5, [5, 3], [2, 1])
+            assert m.mel_decoder._decode_kernel is kern               # same kernel object, refreshed blobs
+            ref_after = _decode(m, "cpu", "graph", 2, 5, [5, 3], [2, 1])
+            pred = m.variance_adaptor.duration_predictor
+            pred.ar_kernel = True
+            pred._ar = durk                                           # keep the object that cached the old blob
+            from kantts.models.utils import get_mask_from_lengths
+            g = torch.Generator().manual_seed(5)
+            cond = 0.8 * torch.randn(2, 6, pred.lstm.input_size - 128, generator=g)
+            with torch.no_grad():
+                dur_after = pred.infer(cond, masks=get_mask_from_lengths(torch.tensor([6, 3]), 6))
+            assert pred._ar is durk
+            dur_ref_after = _durations(m, "cpu", False, 2, 6, [6, 3])
+        finally:
+            hip.set_precision("fp32")
+    assert float((dec_after - dec_before).abs().max()) > 1e-2, "the step must move the decoder output"
+    assert rel_l2(dec_after, ref_after) < 2e-2, rel_l2(dec_after, ref_after)
+    assert float((dur_after - dur_before).abs().max()) > 1e-3
+    assert float((dur_after - dur_ref_after).abs().max()) < 5e-3 * max(1.0, float(dur_ref_after.abs().max()))
