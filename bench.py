@@ -48,6 +48,21 @@ PEAK_HBM_GBPS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "ffn_block_pmc.json")
 
 
+def port_over_reference(leg):
+    """Speed of the oracle ("port") relative to the untouched reference on one host, measured in the build container by
+    oracle/time_vs_reference.py (the reference cannot travel to the GPU box): seconds per iteration of the port / of the
+    reference for ``leg`` ("sambert_b32_dropout_off", "sambert_b32_dropout_on", "hifigan_gan_step", "inference"); > 1 = the
+    port is slower, i.e. ``cpu_baseline.value`` understates the reference by that factor.  None if the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_time_vs_reference.json")) as f:
+            doc = json.load(f)
+        return {"ratio": doc["port_over_reference"][leg], "source": "profiles/r06_time_vs_reference.json "
+                "(oracle/time_vs_reference.py, %d threads of the build container, reference and port interleaved)"
+                % doc["host_threads"]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def measured_traffic(precision):
     """(bytes per launch or None, source string or None, per-launch dict) from profiles/ffn_block_pmc.json."""
     try:
@@ -259,6 +274,8 @@ def cpu_baseline(cfg, hip, B=32, budget_s=20.0):
         del g, res, total
     base = {"value": frames / dt_off, "unit": "mel-frames/s", "cores": cores, "kind": "port",
             "value_dropout_on": frames / dt_on, "all_cores": all_core, "threads_8": eight,
+            "port_over_reference": port_over_reference("sambert_b32_dropout_off"),
+            "port_over_reference_dropout_on": port_over_reference("sambert_b32_dropout_on"),
             "sample": "oracle/torch_oracle.py fwd+losses+bwd, fp32, the full seeded batch B=%d (%d valid frames): "
                       "dropout off 2 warm-up + %d timed, %.2f s/iter; dropout on (as shipped) 1 warm-up + %d timed, "
                       "%.2f s/iter; torch.set_num_threads(%d) of %d host cores" % (B, frames, n_off, dt_off, n_on, dt_on,
@@ -692,6 +709,9 @@ def hifigan_cpu_baseline(B=4, T_wav=8192, budget_s=14.0):
     dt_step, n_step = _time_iters(gan_step, 1, 3, budget_s, min_iters=1)
     dt_fwd, n_fwd = _time_iters(gen_fwd, 1, 5, budget_s * 0.3, min_iters=1)
     return {"value": B * T_wav / dt_step, "unit": "audio-samples/s (GAN training step)", "cores": cores, "kind": "port",
+            "port_over_reference": port_over_reference("hifigan_gan_step"),
+            "batch_note": "CPU batch %d against the GPU leg's 32: samples/s normalises the batch, and the CPU rate does not "
+                          "grow with the batch (every layer already fills the cores at B = 4)" % B,
             "generator_forward_samples_per_s": B * T_wav / dt_fwd,
             "sample": "oracle/hifigan_oracle.py V1 (512 ch) GAN step fwd+bwd without optimizer updates, batch %d x %d "
                       "samples, fp32: 1 warm-up + %d timed, %.2f s/iter; generator forward (no grad): %d timed, %.2f "
@@ -975,6 +995,7 @@ def config5_parity(am, cfg, utts, idx, batch=32, threads=0, mode="kernel", voc=N
                 "what": "product generator on the product's free-running mel vs oracle generator on the oracle's mel"},
             "cpu_baseline": {"value": len(ref) / cpu_s, "unit": "utterances/s (symbols -> mel, batch 1, free-running)",
                              "mel_frames_per_s": frames / cpu_s, "cores": used, "kind": "port",
+                             "port_over_reference": port_over_reference("inference"),
                              "sample": "%d of the leg's utterances through oracle/torch_oracle.py, %.1f s" % (len(ref), cpu_s)}}
 
 

@@ -1138,6 +1138,31 @@ int kantts_dur_ar_run(const kantts_durar_args* args, void* stream);
  *   f, gc, out, lens: as kantts_dur_ar_run. */
 int kantts_dur_ar_run_f32(const kantts_durar_args* args, void* stream);
 
+/* kantts_ctc_attn: AttentionCTCLoss (kantts/train/loss.py:481-508) and its gradient in one launch, a workgroup per utterance
+ * (replaces torch.nn.CTCLoss, whose ATen implementation copies the lengths to the host: the MAS training step could not be
+ * captured).  Per utterance b: classes 0..S (S = in_lens[b]) with logit[t, 0] = `blank` (a constant) and logit[t, c] =
+ * logits[b, t, c - 1]; log_softmax over those classes; CTC with the target 1..S over the first out_lens[b] frames;
+ * zero_infinity semantics.
+ *   logits (B, T1, T2) fp32 (attn_logprob[:, 0]); in_lens / out_lens (B) int32 on the device;
+ *   ws: workspace of kantts_ctc_attn_workspace(B, T1, T2) floats (alpha and beta rows; contents irrelevant);
+ *   loss (B): nll_b / S_b (0 for an impossible alignment or an empty utterance);
+ *   grad (B, T1, T2): grad_scale * d loss[b] / d logits (zero at frames >= out_lens[b] and columns >= in_lens[b]) -- the
+ *   caller passes grad_scale = 1 / B for the reference's mean over the batch and multiplies by the incoming gradient.
+ * Limits: T2 <= 511 phonemes, T1 <= 24576 frames (KANTTS_E_UNSUPPORTED beyond). */
+typedef struct kantts_ctc_args {
+  const float* logits;
+  const int32_t* in_lens;
+  const int32_t* out_lens;
+  float* ws;
+  float* loss;
+  float* grad;
+  int B, T1, T2;
+  float blank;
+  float grad_scale;
+} kantts_ctc_args;
+long long kantts_ctc_attn_workspace(int B, int T1, int T2);
+int kantts_ctc_attn(const kantts_ctc_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

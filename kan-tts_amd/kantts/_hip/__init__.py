@@ -286,6 +286,13 @@ class DurArArgs(Structure):
                 ("B", c_int32), ("T", c_int32)]
 
 
+class CtcArgs(Structure):
+    """kantts_ctc_args (include/kantts_hip.h)."""
+    _fields_ = [("logits", c_void_p), ("in_lens", c_void_p), ("out_lens", c_void_p), ("ws", c_void_p), ("loss", c_void_p),
+                ("grad", c_void_p), ("B", c_int32), ("T1", c_int32), ("T2", c_int32), ("blank", c_float),
+                ("grad_scale", c_float)]
+
+
 ROWSUM_MAX = 32
 
 
@@ -384,6 +391,9 @@ def lib():
         L.kantts_pnca_decode_run.argtypes = [POINTER(DecodeArgs), c_void_p]
         L.kantts_dur_ar_run.argtypes = [POINTER(DurArArgs), c_void_p]
         L.kantts_dur_ar_run_f32.argtypes = [POINTER(DurArArgs), c_void_p]
+        L.kantts_ctc_attn.argtypes = [POINTER(CtcArgs), c_void_p]
+        L.kantts_ctc_attn_workspace.argtypes = [c_int, c_int, c_int]
+        L.kantts_ctc_attn_workspace.restype = c_longlong
         L.kantts_pnca_decode_blob_sizes.argtypes = [c_int, c_int, c_int, c_int, POINTER(ctypes.c_longlong),
                                                     POINTER(ctypes.c_longlong)]
         L.kantts_pnca_block_bwd_ws_floats.argtypes = [c_int]
@@ -436,7 +446,8 @@ EXPORTED_SYMBOLS = [
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
     "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof", "kantts_pnca_attn_qkv_bwd",
-    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_dur_ar_run_f32", "kantts_launch_tuning",
+    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_dur_ar_run_f32", "kantts_ctc_attn", "kantts_ctc_attn_workspace",
+    "kantts_launch_tuning",
 ]
 
 
@@ -899,6 +910,24 @@ def dur_ar_run(w, f, gc, out, lens32):
         check(lib().kantts_dur_ar_run_f32(ctypes.byref(g), stream()), "dur_ar_run_f32")
     else:
         check(lib().kantts_dur_ar_run(ctypes.byref(g), stream()), "dur_ar_run")
+
+
+def ctc_attn(logits, in_lens32, out_lens32, blank, grad_scale):
+    """AttentionCTCLoss and its gradient in one launch (csrc/ctc.hip; kantts_ctc_attn in the header).  logits (B, T1, T2)
+    fp32 contiguous; lengths int32 on the device.  Returns (loss (B,) = nll_b / S_b, grad (B, T1, T2) = grad_scale * d loss_b
+    / d logits)."""
+    B, T1, T2 = logits.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32
+    n = int(lib().kantts_ctc_attn_workspace(int(B), int(T1), int(T2)))
+    ws = torch.empty((max(n, 1),), device=logits.device, dtype=torch.float32)
+    loss = torch.empty((B,), device=logits.device, dtype=torch.float32)
+    grad = torch.empty_like(logits)
+    g = CtcArgs()
+    g.logits, g.in_lens, g.out_lens = ptr(logits, torch.float32), ptr(in_lens32, torch.int32), ptr(out_lens32, torch.int32)
+    g.ws, g.loss, g.grad = ptr(ws, torch.float32), ptr(loss, torch.float32), ptr(grad, torch.float32)
+    g.B, g.T1, g.T2, g.blank, g.grad_scale = int(B), int(T1), int(T2), float(blank), float(grad_scale)
+    check(lib().kantts_ctc_attn(ctypes.byref(g), stream()), "ctc_attn")
+    return loss, grad
 
 
 def pnca_attn_qkv_bwd(qkv, hkv, ldh, ox, oh, d_ox, d_oh, lse_x, lse_h, B, L, *, lens, bw_dev, bw_x, bw_h, att_p, seed_x, seed_h,

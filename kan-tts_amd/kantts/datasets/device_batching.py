@@ -48,6 +48,11 @@ class DeviceVocSet:
         for w, m in items:
             if len(w) != len(m) * self.hop:
                 raise ValueError("wav / mel lengths disagree (len(wav) must be frames * hop_length)")
+            if len(m) <= self.frames:
+                # Voc_Dataset.__getitem__ pads every item to at least one frame more than a crop (dataset.py:124-130, as the
+                # reference does); anything shorter would make the crop's randint(0, len - frames) raise mid-epoch
+                raise ValueError("an item has %d frames, a crop needs more than %d: pad short utterances as "
+                                 "Voc_Dataset.__getitem__ does" % (len(m), self.frames))
         self.wav, self.wav_off = _flat([np.asarray(w).reshape(-1, 1) for w, _ in items], np.float32, self.device)
         self.mel, self.mel_off = _flat([m for _, m in items], np.float32, self.device)
 
@@ -136,8 +141,12 @@ class PinnedPrefetcher:
     DEVICE batches: batch i + 1 is staged in pinned memory and copied on a side stream while the consumer runs step i
     (two staging sets, recycled).  The consumer's stream waits for the copy's event -- no host synchronisation."""
 
-    def __init__(self, loader, device):
-        self.loader, self.device = loader, torch.device(device)
+    def __init__(self, loader, device, r=None):
+        """``r`` (outputs_per_step) for acoustic-model batches: the band width of a batch is then computed HERE, from the
+        host copy, and travels in the dict as the host integer ``band_width`` (as DeviceAMSet.batch does) -- the trainer's
+        captured step needs it per batch and would otherwise read it back from the device: a blocking synchronisation per
+        step, the thing this prefetcher exists to remove."""
+        self.loader, self.device, self.r = loader, torch.device(device), r
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._staging = [{}, {}]
         self._copied = [None, None]  # event of the last copy out of each staging set
@@ -158,7 +167,13 @@ class PinnedPrefetcher:
 
     def _move(self, slot, batch, path=()):
         if isinstance(batch, dict):
-            return {k: self._move(slot, v, path + (k,)) for k, v in batch.items()}
+            out = {k: self._move(slot, v, path + (k,)) for k, v in batch.items()}
+            if (self.r and not path and "band_width" not in batch and torch.is_tensor(batch.get("durations"))
+                    and torch.is_tensor(batch.get("valid_input_lengths")) and not batch["durations"].is_cuda):
+                d, n = batch["durations"], batch["valid_input_lengths"]
+                valid = torch.arange(d.size(1))[None, :] < n[:, None]
+                out["band_width"] = int(float((d * valid).max()) / self.r + 0.5)  # == kantts_sambert.band_width_of
+            return out
         if isinstance(batch, (tuple, list)):
             return type(batch)(self._move(slot, v, path + (i,)) for i, v in enumerate(batch))
         return self._stage(slot, path, batch)
@@ -261,18 +276,24 @@ def make_train_loader(kind, dataset, host_loader, device, batch_size, sampler=No
     device = torch.device(device)
     if mode == "off" or device.type != "cuda":
         return host_loader
+    r = getattr(dataset, "r", None) if kind == "am" else None
     if kind == "am" and getattr(dataset, "mas_enable", False):
         return PinnedPrefetcher(host_loader, device)  # MAS items carry a per-batch prior: host collate
     if mode in ("auto", "hbm"):
-        items = [dataset[i] for i in range(len(dataset))]
         if mode == "auto":
+            # decide from a SAMPLE before materialising the corpus: loading every item only to fall back to the prefetcher
+            # paid the whole load time and held the corpus in host memory
+            n = len(dataset)
+            probe = [dataset[i] for i in sorted({int(j * (n - 1) / 15) for j in range(16)})] if n else []
             free, _ = torch.cuda.mem_get_info(device)
-            if corpus_bytes(items) > free // 2:
-                return PinnedPrefetcher(host_loader, device)
+            if probe and corpus_bytes(probe) / len(probe) * n > free // 2:
+                return PinnedPrefetcher(host_loader, device, r=r)
+        items = [dataset[i] for i in range(len(dataset))]
         if kind == "am":
             pad_ids = [dataset.ling_unit._sub_unit_pad[t] for t in dataset.ling_unit._lfeat_type_list]
             dset = DeviceAMSet(items, dataset.r, pad_ids, device)
         else:
             dset = DeviceVocSet(items, dataset.hop_length, dataset.batch_max_steps, device)
-        return DeviceCorpusLoader(dset, batch_size, sampler=sampler, shuffle=sampler is None)
-    return PinnedPrefetcher(host_loader, device)
+        return DeviceCorpusLoader(dset, batch_size, sampler=sampler, shuffle=sampler is None,
+                                  drop_last=bool(getattr(host_loader, "drop_last", False)))
+    return PinnedPrefetcher(host_loader, device, r=r)

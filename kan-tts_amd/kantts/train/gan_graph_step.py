@@ -26,6 +26,11 @@ class _NoSched:
         pass
 
 
+class CaptureRefused(NotImplementedError):
+    """The runtime refused to capture the step (an operation that is not permitted while capturing): the one RuntimeError
+    of building a GraphedGanStep that the trainer answers with the eager step instead of propagating."""
+
+
 class GraphedGanStep:
     def __init__(self, model, optimizer, scheduler, criterion, config, y, x, warmup=2, steps=10 ** 9):
         self.model, self.optimizer, self.scheduler, self.criterion, self.config = model, optimizer, scheduler, criterion, config
@@ -95,8 +100,16 @@ class GraphedGanStep:
                     "this rank: %s: %s" % (type(err).__name__, str(err)[:200]) if err is not None else "another rank failed"))
         else:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local", stream=self._cap_stream):
-                self.out = self._eager()
+            try:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local", stream=self._cap_stream):
+                    self.out = self._eager()
+            except RuntimeError as exc:
+                # only what the CAPTURE refused becomes a refusal the trainer may answer with the eager step; an error of
+                # the warm-up steps above (out of memory, a kernel's failed check, a shape assertion) is a bug and propagates
+                for o, s in zip(self.opts, snaps):
+                    o.restore(s)
+                self.graph = None
+                raise CaptureRefused("the GAN step could not be captured (%s: %s)" % (type(exc).__name__, str(exc)[:300])) from exc
         for o, s in zip(self.opts, snaps):
             o._step = s["step"]  # capture ran step()'s host code once without running its kernels
 

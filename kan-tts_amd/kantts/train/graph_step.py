@@ -25,10 +25,21 @@ from kantts._hip import ops, rng_state as _rng_state
 
 class GraphedSambertStep:
     def __init__(self, net, optimizer, scheduler, mel_criterion, prosody_criterion, batch, warmup=3,
-                 overlap_wgrad=True, group_wgrads=True, band_width=None):
+                 overlap_wgrad=True, group_wgrads=True, band_width=None, force_wide=False, mas_criteria=None):
         """``band_width``: x_band_width of ``batch`` when the caller already knows it on the host (band_width_of on the
-        batch before its upload); None: read from the device batch here, once."""
+        batch before its upload); None: read from the device batch here, once.  ``force_wide``: capture the wide-band form
+        (the five-launch decoder chain, any band width) whatever this batch's band is -- data parallel: the form must be
+        the same on every rank, and another rank's batch needs it (train/trainer.py::_agree_on_graph)."""
         self._band_width_arg = band_width
+        self._force_wide = bool(force_wide)
+        # Monotonic-Alignment-Search step (sambert_16k_MAS*.yaml; reference trainer.py:871-884, 970-983): the two alignment
+        # criteria {"AttentionCTCLoss": ..., "AttentionBinarizationLoss": ...} join the objective.  Capturable since round 6:
+        # the CTC term is one launch with device-side lengths (csrc/ctc.hip).  The durations come out of the alignment ON THE
+        # DEVICE, so the host cannot promise a band class: the wide form is captured.  The KL term's warm-up ratio depends on
+        # the epoch: it is a device scalar the host refreshes before a replay (``set_epoch``).
+        self.mas_criteria = mas_criteria
+        if mas_criteria is not None:
+            self._force_wide = True
         # weight gradients leave the critical path: fp32-mode ones as parallel branches of the captured graph
         # (ops._WgradOverlap), bf16-mode ones recorded and issued grouped by shape before the optimizer
         # (kantts._hip.deferred_tn); the variance predictors run as a side branch (ops.side_branch).  These switches only
@@ -65,9 +76,13 @@ class GraphedSambertStep:
 
         self._r = net.mel_decoder.r
         bw = self._band_width_arg
-        if bw is None:
+        if self.mas_criteria is not None:
+            bw = ops_bf16.PB_MAX_BAND + 1  # unknown on the host (device-side alignment): the wide form
+            self.kl_ratio = torch.zeros((), device=self.device, dtype=torch.float32)
+            self.set_epoch(0)
+        elif bw is None:
             bw = band_width_of(self.batch["duration_targets"], self.batch["input_lengths"], self._r)
-        self.narrow_band = bw <= ops_bf16.PB_MAX_BAND
+        self.narrow_band = bw <= ops_bf16.PB_MAX_BAND and not self._force_wide
         self._bound = ops_bf16.PB_MAX_BAND if self.narrow_band else None
         self.distributed = optimizer.arena.world_size > 1 or getattr(optimizer.arena, "force_exchange", False)
         # collectives are not captured: the exchange sits between the two graph halves (bucketed, asynchronous), so
@@ -169,7 +184,16 @@ class GraphedSambertStep:
             self.net.band_width_bound = None
         from kantts.train.loss import sambert_loss_sum
 
-        self.loss, self.loss_terms = sambert_loss_sum(self.mel_criterion, self.prosody_criterion, b, res)
+        if self.mas_criteria is None:
+            self.loss, self.loss_terms = sambert_loss_sum(self.mel_criterion, self.prosody_criterion, b, res)
+        else:
+            total, terms = sambert_loss_sum(self.mel_criterion, self.prosody_criterion, b, res,
+                                            prosody_lengths=res["valid_inter_lengths"])
+            ctc = self.mas_criteria["AttentionCTCLoss"](res["attn_logprob"], b["input_lengths"], b["output_lengths"])
+            # the criterion at "fully warmed up" (ratio 1) times the device-side ratio of the current epoch
+            kl = self.mas_criteria["AttentionBinarizationLoss"](10 ** 9, res["attn_hard"], res["attn_soft"]) * self.kl_ratio
+            self.loss = total + ctc + kl
+            self.loss_terms = dict(terms, attn_ctc_loss=ctc.detach(), attn_kl_loss=kl.detach())
         self.loss.backward()
 
     def _apply(self, packed=False):
@@ -179,17 +203,27 @@ class GraphedSambertStep:
         self._forward_backward()
         self.optimizer.step()
 
+    def set_epoch(self, epoch):
+        """MAS step: refresh the device-side warm-up ratio of the attention-binarisation term (reference loss.py:474-478)."""
+        if self.mas_criteria is None:
+            return
+        c = self.mas_criteria["AttentionBinarizationLoss"]
+        ratio = 0.0 if epoch < c.start_epoch else min(1.0, (epoch - c.start_epoch) / c.warmup_epoch)
+        self.kl_ratio.fill_(float(ratio))
+
     def load_batch(self, batch, band_width=None):
         """Copy a new batch of the captured shape into the static buffers.  ``band_width``: its x_band_width if the caller
         knows it on the host; else it is read from ``batch`` (a device synchronisation when the batch is on the device)."""
         from kantts._hip import ops_bf16
         from kantts.models.sambert.kantts_sambert import band_width_of
 
+        if band_width is None and not self.narrow_band:
+            band_width = 0  # the wide form serves every band width: nothing to check (MAS batches carry no durations)
         if band_width is None:
             band_width = band_width_of(batch["duration_targets"], batch["input_lengths"], self._r)
-        if (band_width <= ops_bf16.PB_MAX_BAND) != self.narrow_band:
-            raise ValueError("this step was captured for band widths %s %d, the batch has %d: capture another step for it"
-                             % ("<=" if self.narrow_band else ">", ops_bf16.PB_MAX_BAND, band_width))
+        if self.narrow_band and band_width > ops_bf16.PB_MAX_BAND:  # (the wide form serves every band width)
+            raise ValueError("this step was captured for band widths <= %d, the batch has %d: capture another step for it"
+                             % (ops_bf16.PB_MAX_BAND, band_width))
         for k, v in batch.items():
             self.batch[k].copy_(v, non_blocking=True)
 

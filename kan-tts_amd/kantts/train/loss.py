@@ -290,26 +290,42 @@ class AttentionBinarizationLoss(torch.nn.Module):
         return kl_loss * warmup_ratio
 
 
+class _CtcAttn(torch.autograd.Function):
+    """loss (B,) = CTC(log_softmax([blank | logits]), target 1..S) / S per utterance; the launch (csrc/ctc.hip) computes the
+    gradient with the loss, backward only scales it."""
+
+    @staticmethod
+    def forward(ctx, logits, in_lens32, out_lens32, blank):
+        from kantts._hip import ctc_attn
+
+        loss, grad = ctc_attn(logits, in_lens32, out_lens32, blank, 1.0)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (grad,) = ctx.saved_tensors
+        return grad * dloss.view(-1, 1, 1), None, None, None
+
+
 class AttentionCTCLoss(torch.nn.Module):
     """CTC over the alignment log-probabilities with the phoneme sequence 1..N as target and a constant blank score
-    (reference :482-508).  The reference loops over utterances (slice, log_softmax, one CTCLoss call each); here the
-    batch goes through ONE ctc_loss call: classes beyond an utterance's phoneme count get a large negative score (their
-    softmax weight underflows to exactly 0, so every row's normaliser equals the sliced one) and frames beyond its mel
-    length are excluded by input_lengths.  'mean' reduction = mean_b(loss_b / target_len_b), which is what the
-    reference's sum of per-utterance means / B computes."""
+    (reference :482-508).  The reference loops over utterances (slice, log_softmax, one torch.nn.CTCLoss call each, whose
+    ATen implementation copies the lengths to the host); here the batch is ONE launch of kantts_ctc_attn (csrc/ctc.hip:
+    a workgroup per utterance walks the alpha and beta recurrences and writes the gradient), with the lengths read on the
+    device -- so the MAS training step can be captured in a hipGraph.  Result = mean_b(nll_b / S_b), which is what the
+    reference's sum of per-utterance "mean" losses / B computes; zero_infinity semantics."""
 
     def __init__(self, blank_logprob=-1):
         super(AttentionCTCLoss, self).__init__()
         self.blank_logprob = blank_logprob
 
     def forward(self, attn_logprob, in_lens, out_lens):
-        B, _, T1, T2 = attn_logprob.shape
-        lp = F.pad(attn_logprob[:, 0], (1, 0), value=self.blank_logprob)  # (B, T1, T2 + 1), class 0 = blank
-        cls = torch.arange(T2 + 1, device=lp.device)
-        lp = lp.masked_fill((cls[None, :] > in_lens[:, None])[:, None, :], -1e9)
-        lp = F.log_softmax(lp, dim=2).transpose(0, 1)  # (T1, B, classes)
-        targets = cls[1:].unsqueeze(0).expand(B, -1)
-        return F.ctc_loss(lp, targets, out_lens, in_lens, blank=0, reduction="mean", zero_infinity=True)
+        lg = attn_logprob[:, 0]
+        if not lg.is_contiguous():
+            lg = lg.contiguous()
+        loss = _CtcAttn.apply(lg.float(), in_lens.to(torch.int32), out_lens.to(torch.int32), float(self.blank_logprob))
+        return loss.mean()
 
 
 loss_dict = {

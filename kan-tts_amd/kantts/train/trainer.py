@@ -194,10 +194,10 @@ class Sambert_Trainer(Trainer):
         self.with_MAS, self.fp_enable = params.get("MAS", False), params.get("FP", False)
         if self.fp_enable:
             raise NotImplementedError("filled-pause training is outside the hot path (DESIGN.md section 7)")
-        if self.with_MAS and graph:
-            raise NotImplementedError("graph=True covers the duration-supervised step; the MAS step runs eagerly")
+        # graph=True serves the MAS step too since round 6 (the CTC criterion is a device-side launch: csrc/ctc.hip)
         self.graph = graph
         self._graphs = {}
+        self._ctl_group = None  # host-side (gloo) group of the data-parallel graph-cache agreement, made on first use
         self.max_graphs = 16  # captured steps kept (one per padded batch shape), LRU
         if self.grad_clip is not None and hasattr(self.optimizer[self.KEY], "set_grad_clip"):
             self.optimizer[self.KEY].set_grad_clip(self.grad_clip)
@@ -234,7 +234,11 @@ class Sambert_Trainer(Trainer):
             from kantts.models.sambert.kantts_sambert import band_width_of
 
             bw = batch.get("band_width")
-            if bw is None:
+            if self.with_MAS:
+                from kantts._hip import ops_bf16
+
+                bw = ops_bf16.PB_MAX_BAND + 1  # the durations are aligned on the device: the wide-band form (graph_step.py)
+            elif bw is None:
                 bw = band_width_of(batch["durations"], batch["valid_input_lengths"], net.mel_decoder.r)
             return self._graph_step(b, bw)
         from kantts._hip import ops
@@ -253,21 +257,47 @@ class Sambert_Trainer(Trainer):
         sch.step()
         return total
 
+    def _agree_on_graph(self, shape_key, wide):
+        """Data parallel: building a captured step issues collectives (warm-up steps all-reduce gradients, the capture form
+        is agreed with a MIN all-reduce), replaying one issues others, and both the band class of a batch and the contents of
+        the LRU cache are PER RANK.  So before the lookup the ranks agree -- one MAX all-reduce of three flags over a host
+        (gloo) group, no device synchronisation: (this batch needs the wide-band form, no narrow-form graph for this shape
+        here, no wide-form graph for this shape here).  Every rank then uses the wide form if any rank needs it, and every
+        rank BUILDS if any rank has to (a rank that still had the graph rebuilds it: the collectives of a build have to
+        pair up).  Single process: the local answer."""
+        import torch.distributed as dist
+
+        missing_narrow, missing_wide = (shape_key + (True,)) not in self._graphs, (shape_key + (False,)) not in self._graphs
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if self._ctl_group is None:
+                self._ctl_group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+            flags = torch.tensor([int(wide), int(missing_narrow), int(missing_wide)], dtype=torch.int32)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._ctl_group)
+            wide, missing_narrow, missing_wide = (bool(int(v)) for v in flags)
+        return wide, (missing_wide if wide else missing_narrow)
+
     def _graph_step(self, b, band_width):
         from kantts._hip import ops_bf16
         from kantts.train.graph_step import GraphedSambertStep
 
-        key = tuple((k, tuple(v.shape)) for k, v in b.items() if v is not None) + (band_width <= ops_bf16.PB_MAX_BAND,)
+        shape_key = tuple((k, tuple(v.shape)) for k, v in b.items() if v is not None)
+        wide, build = self._agree_on_graph(shape_key, band_width > ops_bf16.PB_MAX_BAND)
+        key = shape_key + (not wide,)
         g = self._graphs.pop(key, None)
-        if g is None:
+        if build:
+            g = None  # (data parallel: another rank has to build, so this one builds with it)
             if len(self._graphs) >= self.max_graphs:  # least recently used shape goes (dicts keep insertion order)
                 self._graphs.pop(next(iter(self._graphs)))
+            mas = ({k: self.criterion[k] for k in ("AttentionCTCLoss", "AttentionBinarizationLoss")} if self.with_MAS
+                   else None)
             g = GraphedSambertStep(self.model[self.KEY], self.optimizer[self.KEY], self.scheduler[self.KEY],
                                    self.criterion["MelReconLoss"], self.criterion["ProsodyReconLoss"],
-                                   {k: v for k, v in b.items() if v is not None}, band_width=band_width)
+                                   {k: v for k, v in b.items() if v is not None}, band_width=band_width, force_wide=wide,
+                                   mas_criteria=mas)
         else:
             g.load_batch({k: v for k, v in b.items() if v is not None}, band_width=band_width)
         self._graphs[key] = g  # most recently used last
+        g.set_epoch(self.epoch)
         g()
         self._accumulate("train", {"TotalLoss": g.loss})
         return g.loss
@@ -329,9 +359,10 @@ class GAN_Trainer(Trainer):
                 try:
                     g = self._graphs[key] = GraphedGanStep(self.model, self.optimizer, self.scheduler, self.criterion,
                                                            self.config, y, x, steps=self.steps)
-                except (NotImplementedError, ValueError, RuntimeError) as exc:
-                    # NSF generators (host-seeded excitation), non-arena optimizers, a capture the runtime refused (RuntimeError;
-                    # data-parallel: on any rank): the step cannot be captured.
+                except (NotImplementedError, ValueError) as exc:
+                    # NSF generators (host-seeded excitation), non-arena optimizers, a capture the runtime refused
+                    # (gan_graph_step.CaptureRefused; data-parallel: on any rank, agreed across ranks): the step cannot be
+                    # captured.  Any other error (out of memory, a kernel's failed check in the warm-up steps) propagates.
                     # Say so once and keep training with the eager step (the run must not die thousands of steps in,
                     # when both phases first become active).
                     logging.warning("[GAN_Trainer] capture_step is off for this run: %s", exc)

@@ -805,6 +805,40 @@ class EmulatedLib:
             out[b, n:] = 0
         return 0
 
+    def kantts_ctc_attn_workspace(self, B, T1, T2):
+        return int(B) * 2 * int(T1) * (2 * int(T2) + 1)
+
+    def kantts_ctc_attn(self, args_ref, stream):
+        """AttentionCTCLoss per utterance through ATen's CPU ctc_loss + autograd, the way the reference computes it
+        (kantts/train/loss.py:488-508: slice, log_softmax, CTCLoss(zero_infinity=True) with the target 1..S)."""
+        import torch
+        import torch.nn.functional as F
+
+        g = args_ref._obj
+        B, T1, T2 = g.B, g.T1, g.T2
+        if B == 0 or T1 == 0 or T2 == 0:
+            return 0
+        if 2 * T2 + 1 > 1024 or T1 > 24576:
+            return -2
+        lg = _arr(g.logits, B * T1 * T2).reshape(B, T1, T2)
+        in_l, out_l = _arr(g.in_lens, B, np.int32), _arr(g.out_lens, B, np.int32)
+        loss, grad = _arr(g.loss, B), _arr(g.grad, B * T1 * T2).reshape(B, T1, T2)
+        grad[:] = 0
+        for b in range(B):
+            S, T = min(max(int(in_l[b]), 0), T2), min(max(int(out_l[b]), 0), T1)
+            if S == 0 or T == 0:
+                loss[b] = 0
+                continue
+            with torch.enable_grad():  # (called from inside an autograd.Function's forward)
+                x = torch.from_numpy(lg[b, :T, :S].copy()).requires_grad_(True)
+                lp = F.log_softmax(F.pad(x, (1, 0), value=float(g.blank)), dim=1)[:, None, :]  # (T, 1, S + 1)
+                c = F.ctc_loss(lp, torch.arange(1, S + 1)[None], torch.tensor([T]), torch.tensor([S]), blank=0,
+                               reduction="mean", zero_infinity=True)
+                c.backward()
+            loss[b] = float(c)
+            grad[b, :T, :S] = x.grad.numpy() * np.float32(g.grad_scale)
+        return 0
+
     def kantts_copy_roof(self, src, read_bytes, dst, write_bytes, stream):
         return 0  # a bandwidth calibration launch: no values to model
 

@@ -184,11 +184,38 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, lengths=None, reverse=False):
 
 
 def _lstm_named(P, pre, x, layer=0, lengths=None, reverse=False):
+    """One direction of one layer through the readable time loop above (kept as the DEFINITION: tests/test_oracle_golden.py
+    checks ``lstm_aten`` against it)."""
     sfx = "_l%d%s" % (layer, "_reverse" if reverse else "")
     return lstm_layer(
         x, P[pre + ".weight_ih" + sfx], P[pre + ".weight_hh" + sfx],
         P[pre + ".bias_ih" + sfx], P[pre + ".bias_hh" + sfx], lengths, reverse,
     )
+
+
+def lstm_aten(P, pre, x, num_layers=1, bidirectional=False, lengths=None):
+    """nn.LSTM(batch_first=True) forward on the weights in ``P`` through the SAME ATen kernel the reference's modules call
+    (``torch._VF.lstm``: nn.LSTM.forward, torch/nn/modules/rnn.py), zero initial state, no inter-layer dropout.  With
+    ``lengths``: packed exactly where the reference packs (kantts/models/sambert/adaptors.py:126-134:
+    pack_padded_sequence(enforce_sorted=False) -> LSTM -> pad_packed_sequence(total_length=T)).  Round 6: the time loop in
+    ``lstm_layer`` made this oracle 2.2-2.4x slower than the reference it stands in for as ``cpu_baseline``; the values are
+    the same (tests/test_oracle_golden.py::test_lstm_aten_equals_the_time_loop)."""
+    dirs = 2 if bidirectional else 1
+    flat = []
+    for l in range(num_layers):
+        for d in range(dirs):
+            sfx = "_l%d%s" % (l, "_reverse" if d else "")
+            flat += [P[pre + ".weight_ih" + sfx], P[pre + ".weight_hh" + sfx], P[pre + ".bias_ih" + sfx], P[pre + ".bias_hh" + sfx]]
+    B, T, _ = x.shape
+    H = flat[1].shape[1]
+    z = x.new_zeros(num_layers * dirs, B, H)
+    if lengths is None:
+        return torch._VF.lstm(x, (z, z), flat, True, num_layers, 0.0, False, bidirectional, True)[0]
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lengths.tolist(), batch_first=True, enforce_sorted=False)
+    # the packed sequence is in sorted order: so is the (zero) initial state -- nothing to permute
+    y = torch._VF.lstm(packed.data, packed.batch_sizes, (z, z), flat, True, num_layers, 0.0, False, bidirectional)[0]
+    y = torch.nn.utils.rnn.PackedSequence(y, packed.batch_sizes, packed.sorted_indices, packed.unsorted_indices)
+    return torch.nn.utils.rnn.pad_packed_sequence(y, batch_first=True, total_length=T)[0]
 
 
 # ----------------------------------------------------------------------------- variance adaptor
@@ -197,9 +224,7 @@ def nar_predictor(P, cfg, pre, x, pad):
     lengths = None if pad is None else (~pad).sum(1)
     h = fsmn_encoder(P, pre + ".fsmn", x, pad, cfg["predictor_fsmn_num_layers"],
                      cfg["predictor_filter_size"], cfg["predictor_shift"], cfg["predictor_dropout"])
-    fw = _lstm_named(P, pre + ".blstm", h, 0, lengths, False)
-    bw = _lstm_named(P, pre + ".blstm", h, 0, lengths, True)
-    y = _linear(torch.cat([fw, bw], -1), P, pre + ".fc").squeeze(-1)
+    y = _linear(lstm_aten(P, pre + ".blstm", h, 1, True, lengths), P, pre + ".fc").squeeze(-1)
     return y if pad is None else y.masked_fill(pad, 0.0)
 
 
@@ -216,8 +241,7 @@ def prenet(P, pre, x, n_hidden, has_out):
 def ar_duration_predictor(P, cfg, pre, inputs, cond, pad):
     """VarRnnARPredictor.forward (teacher forced), kantts/models/sambert/adaptors.py:53-65"""
     x = torch.cat([prenet(P, pre + ".prenet", inputs, len(cfg["dur_pred_prenet_units"]), False), cond], -1)
-    x = _lstm_named(P, pre + ".lstm", x, 0)
-    x = _lstm_named(P, pre + ".lstm", x, 1)
+    x = lstm_aten(P, pre + ".lstm", x, 2)
     x = F.relu(_linear(x, P, pre + ".fc").squeeze(-1))
     return x if pad is None else x.masked_fill(pad, 0.0)
 
@@ -415,7 +439,7 @@ def postnet(P, cfg, x, pad, pre="mel_postnet"):
     """PostNet.forward, kantts/models/sambert/kantts_sambert.py:642-649"""
     h = fsmn_encoder(P, pre + ".fsmn", x, pad, cfg["postnet_fsmn_num_layers"],
                      cfg["postnet_filter_size"], cfg["postnet_shift"], cfg["postnet_dropout"])
-    return _linear(_lstm_named(P, pre + ".lstm", h, 0), P, pre + ".fc")
+    return _linear(lstm_aten(P, pre + ".lstm", h, 1), P, pre + ".fc")
 
 
 # ----------------------------------------------------------------------------- whole model

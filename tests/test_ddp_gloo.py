@@ -427,3 +427,65 @@ def test_gradient_buckets_partition_the_arena():
                 assert b["lo"] <= arena.offsets[i] and arena.offsets[i] + arena.params[i].numel() <= b["hi"]
                 seen.append(i)
         assert seen == list(range(len(sizes)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the key of the captured-step cache carries a per-rank, data-dependent bit (band width <= 16) and the
+# cache is an LRU per rank, while BUILDING a captured step issues collectives.  Sambert_Trainer._agree_on_graph makes the
+# ranks agree before the lookup.  Here: two gloo ranks, the capture class replaced by a recorder whose "build" is a real
+# all-reduce (as the warm-up steps of the real build are) -- a rank that built alone would hang the test.
+def _agree_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "kan-tts_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import kantts.train.graph_step as gs
+    from kantts.train.trainer import Sambert_Trainer
+
+    log = []
+
+    class Recorder:
+        def __init__(self, net, opt, sch, mc, pc, batch, band_width=None, force_wide=False):
+            t = torch.ones(1)
+            dist.all_reduce(t)  # a build is collective: it must happen on both ranks in the same step
+            assert float(t) == world
+            self.wide = bool(force_wide) or band_width > 16
+            self.loss = torch.zeros(())
+            log.append(("build", "wide" if self.wide else "narrow"))
+
+        def load_batch(self, batch, band_width=None):
+            assert self.wide or band_width <= 16
+            log.append(("load", "wide" if self.wide else "narrow"))
+
+        def __call__(self):
+            return self.loss
+
+    gs.GraphedSambertStep = Recorder
+    tr = object.__new__(Sambert_Trainer)
+    tr._graphs, tr._ctl_group, tr.max_graphs = {}, None, 2
+    tr.model = tr.optimizer = tr.scheduler = {Sambert_Trainer.KEY: None}
+    tr.criterion = {"MelReconLoss": None, "ProsodyReconLoss": None}
+    tr._accumulate = lambda *a, **k: None
+    shape = lambda T: {"x": torch.zeros(2, T)}  # noqa: E731
+    # step 1: rank 0's batch is wide, rank 1's narrow -> both build the wide form
+    tr._graph_step(shape(5), 40 if rank == 0 else 3)
+    # step 2: same shapes, both narrow now -> no narrow graph anywhere -> both build narrow
+    tr._graph_step(shape(5), 4)
+    # step 3: rank 1 sees a new shape (its LRU holds 2 entries: the oldest goes), rank 0 the old one -> both build
+    tr._graph_step(shape(5) if rank == 0 else shape(7), 4)
+    # step 4: shape 5 narrow everywhere: rank 0 has it, rank 1 has it too (evicted: the wide one) -> both only load
+    tr._graph_step(shape(5), 2)
+    # step 5: shape 5, rank 1 wide: rank 0 still has the wide graph, rank 1 evicted it -> both build
+    tr._graph_step(shape(5), 2 if rank == 0 else 99)
+    torch.save(log, os.path.join(out_dir, "agree%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_captured_step_before_building(tmp_path):
+    port = _free_port()
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    l0 = torch.load(os.path.join(tmp_path, "agree0.pt"))
+    l1 = torch.load(os.path.join(tmp_path, "agree1.pt"))
+    expect = [("build", "wide"), ("build", "narrow"), ("build", "narrow"), ("load", "narrow"), ("build", "wide")]
+    assert l0 == expect and l1 == expect, (l0, l1)

@@ -84,6 +84,32 @@ def test_pinned_prefetcher_passes_batches_through_on_cpu():
         assert torch.equal(b["t"][0], batches[i]["t"][0])
 
 
+def test_pinned_prefetcher_carries_the_band_width_of_acoustic_batches():
+    """with ``r`` the prefetcher computes x_band_width from the HOST batch and hands it on as the host integer
+    ``band_width`` (what DeviceAMSet.batch does), so that the trainer's captured step does not read it back from the
+    device; it equals the model's band_width_of; vocoder batches (tuples) and dicts without durations pass unchanged;
+    short vocoder items are refused when the device set is built, not mid-epoch."""
+    import numpy as np
+
+    from kantts.datasets.device_batching import DeviceVocSet, PinnedPrefetcher
+    from kantts.models.sambert.kantts_sambert import band_width_of
+
+    g = torch.Generator().manual_seed(0)
+    batches = []
+    for _ in range(3):
+        d = torch.randint(1, 60, (4, 9), generator=g)
+        n = torch.tensor([9, 4, 7, 1])
+        batches.append({"durations": d, "valid_input_lengths": n, "mel_targets": torch.randn(4, 5, 2, generator=g)})
+    out = list(PinnedPrefetcher(batches, "cpu", r=3))
+    for a, b in zip(batches, out):
+        assert b["band_width"] == band_width_of(a["durations"], a["valid_input_lengths"], 3)
+        assert isinstance(b["band_width"], int) and torch.equal(a["mel_targets"], b["mel_targets"])
+    assert "band_width" not in list(PinnedPrefetcher(batches, "cpu"))[0]
+    assert "band_width" not in list(PinnedPrefetcher([{"x": torch.zeros(2)}], "cpu", r=3))[0]
+    with pytest.raises(ValueError, match="a crop needs more than"):
+        DeviceVocSet([(np.zeros(4 * 8, np.float32), np.zeros((4, 3), np.float32))], 8, 32, "cpu")
+
+
 @pytest.mark.gpu
 def test_device_batches_equal_host_collate_gpu():
     _check_voc("cuda")

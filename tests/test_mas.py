@@ -333,3 +333,59 @@ def test_mas_training_cli_emulated(tmp_path):
 @pytest.mark.gpu
 def test_mas_training_cli_gpu(tmp_path):
     _mas_cli(tmp_path)
+
+
+@pytest.mark.gpu
+def test_captured_mas_step_equals_eager_mas_step_gpu(tmp_path):
+    """Sambert_Trainer(graph=True) on a sambert_16k_MAS-shaped config -- the whole MAS step (alignment
+    learner, device-side Monotonic Alignment Search, CTC + binarisation terms, backward, clip + Adam) replayed from a
+    hipGraph -- against the eager MAS trainer: same seeded weights and batches, dropout off (eval-mode modules, dropout
+    probabilities 0), four steps over two batch shapes; weights after the steps agree."""
+    import kantts._hip as hip
+    from kantts.models import model_builder
+    from kantts.train.loss import criterion_builder
+    from kantts.train.trainer import Sambert_Trainer
+    from kantts.utils.synthetic import SAMBERT_VOCAB, sambert_16k_config, sambert_mas_batch, to_collate_format
+
+    hip.set_precision("fp32")
+    cfg = sambert_16k_config(tiny=True)
+    cfg["MAS"] = True
+    for k in list(cfg):
+        if "dropout" in k:
+            cfg[k] = 0.0
+    for k, v in SAMBERT_VOCAB.items():
+        cfg.setdefault(k, v)
+    config = {"model_type": "sambert", "Model": {"KanTtsSAMBERT": {
+        "params": cfg,
+        "optimizer": {"type": "Adam", "params": {"lr": 0.001, "betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0}},
+        "scheduler": {"type": "NoamLR", "params": {"warmup_steps": 4000}}}},
+        "Loss": {"MelReconLoss": {"enable": True, "params": {"loss_type": "mae"}},
+                 "ProsodyReconLoss": {"enable": True, "params": {"loss_type": "mae"}},
+                 "AttentionCTCLoss": {"enable": True},
+                 "AttentionBinarizationLoss": {"enable": True, "params": {"start_epoch": 0, "warmup_epoch": 4}}},
+        "grad_norm": 1.0, "batch_size": 2, "log_interval_steps": 1}
+    batches = [to_collate_format(sambert_mas_batch(B=2, seed=1234 + s)) for s in range(2)]
+
+    def run(graph):
+        torch.manual_seed(0)
+        model, opt, sch = model_builder(config, device="cuda")
+        model["KanTtsSAMBERT"].eval()
+        crit = criterion_builder(config, "cuda")
+        tr = Sambert_Trainer(config, model, opt, sch, crit, torch.device("cuda"), None, batches, None, max_steps=10 ** 6,
+                             save_dir=str(tmp_path / ("g" if graph else "e")), save_interval=10 ** 6, valid_interval=10 ** 6,
+                             log_interval=1, grad_clip=1.0, graph=graph)
+        tr.set_model_state = lambda state="train": None
+        tr.epoch = 2  # a binarisation warm-up ratio of 0.5: the device-side ratio of the captured step must carry it
+        losses = []
+        for b in (batches[0], batches[1], batches[0], batches[1]):
+            losses.append(float(tr.train_step(b)))
+            tr.steps += 1
+        flat = tr.optimizer["KanTtsSAMBERT"].arena.flat.detach().cpu().clone()
+        return losses, flat, tr
+
+    le, fe, _ = run(False)
+    lg, fg, trg = run(True)
+    assert trg.with_MAS and len(trg._graphs) >= 1
+    for a, b in zip(lg, le):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (lg, le)
+    assert float((fg - fe).norm() / fe.norm()) < 1e-4

@@ -172,3 +172,42 @@ def test_mse_and_hinge_criteria_match_the_reference_classes():
     close(f_, hinge["d_tensor"][1])
     with pytest.raises(AssertionError):
         GeneratorAdversarialLoss(loss_type="wasserstein")
+
+
+def test_lstm_aten_equals_the_time_loop():
+    """oracle/torch_oracle.py::lstm_aten (the ATen kernel the reference's nn.LSTM modules call, packed where the reference
+    packs) against the readable time loop ``lstm_layer`` it replaced: values and gradients, uni- and bidirectional, one and
+    two layers, ragged lengths (padded outputs zero, the reverse direction starting at each row's last valid token)."""
+    import torch_oracle as O
+
+    g = torch.Generator().manual_seed(3)
+    B, T, C, H = 5, 11, 12, 8
+
+    def weights(pre, layers, bidir):
+        P = {}
+        for l in range(layers):
+            for sfx in ("", "_reverse") if bidir else ("",):
+                cin = C if l == 0 else H * (2 if bidir else 1)
+                for n, shape in (("weight_ih", (4 * H, cin)), ("weight_hh", (4 * H, H)), ("bias_ih", (4 * H,)), ("bias_hh", (4 * H,))):
+                    P["%s.%s_l%d%s" % (pre, n, l, sfx)] = (0.4 * torch.randn(*shape, generator=g)).requires_grad_(True)
+        return P
+
+    for layers, bidir, lens in ((1, False, None), (2, False, None), (1, True, [11, 3, 7, 1, 11]), (1, True, None)):
+        P = weights("m", layers, bidir)
+        x = torch.randn(B, T, C, generator=g).requires_grad_(True)
+        lengths = None if lens is None else torch.tensor(lens)
+        got = O.lstm_aten(P, "m", x, layers, bidir, lengths)
+        h = x
+        for l in range(layers):
+            outs = [O._lstm_named(P, "m", h, l, lengths, rev) for rev in ((False, True) if bidir else (False,))]
+            h = torch.cat(outs, -1)
+        assert got.shape == h.shape
+        assert float((got - h).abs().max()) < 2e-6
+        if lens is not None:
+            for b, n in enumerate(lens):
+                assert float(got[b, n:].abs().max() if n < T else 0.0) == 0.0
+        w = torch.randn(got.shape, generator=g)
+        ga = torch.autograd.grad((got * w).sum(), [x] + list(P.values()))
+        gb = torch.autograd.grad((h * w).sum(), [x] + list(P.values()))
+        for a, b in zip(ga, gb):
+            assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(b.abs().max()))
