@@ -78,3 +78,50 @@ def has_gpu():
     import torch
 
     return torch.cuda.is_available()
+
+
+# ---- op sweeps on two back ends (tests/test_ops_sweep.py, test_conv_sweep.py): expected values from the oracle / plain torch
+class _Bridge:
+    """Maps the CPU leaves of a sweep onto the back end under test (identity for the emulated ABI, device twins for the GPU:
+    one twin per leaf so that gradients w.r.t. the leaves can be asked for) and results back to the CPU."""
+
+    def __init__(self, device):
+        self.device, self._twins = device, {}
+
+    def __call__(self, obj):
+        import torch
+
+        if obj is None or self.device is None:
+            return obj
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self(o) for o in obj)
+        if not torch.is_tensor(obj):
+            return obj
+        key = id(obj)
+        if key not in self._twins:
+            t = obj.detach().to(self.device)
+            self._twins[key] = (obj, t.requires_grad_(True) if obj.requires_grad else t)  # (keeps ``obj`` alive: ids stay unique)
+        return self._twins[key][1]
+
+    def back(self, obj):
+        import torch
+
+        if obj is None or self.device is None:
+            return obj
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self.back(o) for o in obj)
+        return obj.detach().cpu() if torch.is_tensor(obj) else obj
+
+
+@pytest.fixture(params=["emulated", pytest.param("gpu", marks=pytest.mark.gpu)])
+def dv(request, monkeypatch):
+    if request.param == "emulated":
+        _emulate(monkeypatch)
+        return _Bridge(None)
+    import kantts._hip as hip
+
+    hip.lib()
+    hip.set_precision("fp32")
+    return _Bridge("cuda")
+
+

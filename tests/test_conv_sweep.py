@@ -1,5 +1,5 @@
-"""Randomised sweep of the channels-last convolution host logic (ops.conv_cl / conv_transpose_cl through the emulated
-C ABI) against ATen's conv1d / conv_transpose1d: strides, dilations, paddings, groups (incl. the block-diagonal group
+"""Randomised sweep of the channels-last convolutions (ops.conv_cl / conv_transpose_cl; fixture ``dv``: the emulated C ABI on
+the CPU suite, the HIP kernels on device tensors under ``-m gpu``) against ATen's conv1d / conv_transpose1d on the CPU: strides, dilations, paddings, groups (incl. the block-diagonal group
 packing), nearest-neighbour read-through upsampling, the MPD fold, fused LeakyReLU on either side, residuals -- forward,
 input gradient, weight and bias gradients.  Small shapes, fixed seed: ~40 configurations in a few seconds; the same
 wrapper code then drives the HIP kernels (per-entry-point GPU parity is in test_hifigan.py)."""
@@ -36,7 +36,7 @@ def _ref_conv(x, w, b, stride, dil, pad, Tout, groups, up, il, ol, res):
     return y if res is None else y + res
 
 
-def test_conv_cl_random_configurations(emulated_cabi):
+def test_conv_cl_random_configurations(dv):
     from kantts._hip import ops
 
     rnd = random.Random(20240917)
@@ -64,21 +64,21 @@ def test_conv_cl_random_configurations(emulated_cabi):
         res = torch.randn(rshape, generator=g).requires_grad_(True) if rnd.random() < 0.3 else None
         cfg = dict(groups=groups, cr=cr, ng=ng, K=K, stride=stride, dil=dil, up=up, P=P, B=B, T=T, pad=pad, Tout=Tout,
                    il=il, ol=ol, bias=b is not None, res=res is not None)
-        y = ops.conv_cl(x, w, b, stride=stride, dilation=dil, pad=pad, Tout=Tout, up=up, groups=groups, inner=P,
-                        in_leaky=il, out_leaky=ol, res=res)
+        y = ops.conv_cl(dv(x), dv(w), dv(b), stride=stride, dilation=dil, pad=pad, Tout=Tout, up=up, groups=groups, inner=P,
+                        in_leaky=il, out_leaky=ol, res=dv(res))
         ref = _ref_conv(x, w, b, stride, dil, pad, Tout, groups, up, il, ol, res)
         assert y.shape == ref.shape, cfg
-        assert float((y - ref).detach().abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max())), cfg
+        assert float((dv.back(y) - ref).detach().abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max())), cfg
         cot = torch.randn(ref.shape, generator=g)
         leaves = [t for t in (x, w, b, res) if t is not None]
-        got = torch.autograd.grad((y * cot).sum(), leaves)
+        got = dv.back(torch.autograd.grad((y * dv(cot)).sum(), dv(leaves)))
         exp = torch.autograd.grad((ref * cot).sum(), leaves)
         for a, e in zip(got, exp):
             assert rel_l2(a, e) < 2e-5 or float((a - e).abs().max()) < 1e-6, cfg
         done += 1
 
 
-def test_conv_transpose_cl_random_configurations(emulated_cabi):
+def test_conv_transpose_cl_random_configurations(dv):
     """Causal polyphase transposed convolution (kernel = taps * stride, output trimmed to T * stride) vs ATen."""
     from kantts._hip import ops
 
@@ -95,15 +95,16 @@ def test_conv_transpose_cl_random_configurations(emulated_cabi):
         b = torch.randn(Cout, generator=g).requires_grad_(True)
         res = torch.randn(B, T * s, Cout, generator=g).requires_grad_(True) if rnd.random() < 0.5 else None
         cfg = dict(s=s, taps=taps, Cin=Cin, Cout=Cout, B=B, T=T, il=il, res=res is not None)
-        y = ops.conv_transpose_cl(x, w, b, s, in_leaky=il, res=res)
+        y = ops.conv_transpose_cl(dv(x), dv(w), dv(b), s, in_leaky=il, res=dv(res))
         xx = x.transpose(1, 2)
         if il is not None:
             xx = F.leaky_relu(xx, il)
         ref = F.conv_transpose1d(xx, w, b, stride=s)[:, :, :T * s].transpose(1, 2)
         if res is not None:
             ref = ref + res
-        assert float((y - ref).detach().abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max())), cfg
+        assert float((dv.back(y) - ref).detach().abs().max()) <= 2e-5 * max(1.0, float(ref.detach().abs().max())), cfg
         cot = torch.randn(ref.shape, generator=g)
         leaves = [t for t in (x, w, b, res) if t is not None]
-        for a, e in zip(torch.autograd.grad((y * cot).sum(), leaves), torch.autograd.grad((ref * cot).sum(), leaves)):
+        for a, e in zip(dv.back(torch.autograd.grad((y * dv(cot)).sum(), dv(leaves))),
+                        torch.autograd.grad((ref * cot).sum(), leaves)):
             assert rel_l2(a, e) < 2e-5, cfg

@@ -1,9 +1,11 @@
 """AttentionCTCLoss on kantts_ctc_attn (csrc/ctc.hip) against the REFERENCE'S formulation executed with stock PyTorch: per
 utterance slice -> pad a constant blank score -> log_softmax -> torch.nn.CTCLoss(zero_infinity=True) with the target
 1..S -> sum / B (kantts/train/loss.py:481-508 of the reference, restated below line by line), values and the gradient
-w.r.t. attn_logprob.  The reference side runs in float64 (the exact answer); tolerances: loss 2e-5 relative, gradient 1e-4
-of its largest entry -- the gradient is exp(alpha + beta + nll - lp) with |nll| ~ 100, so one fp32 rounding of the exponent is
-~1e-5 relative (ATen's own float32 CPU path differs from float64 by as much)."""
+w.r.t. attn_logprob.  The reference side runs in float64 (the exact answer) AND in float32 (what the reference itself
+computes).  Tolerances: loss 2e-5 relative; gradient: 1e-4 of its largest entry, or -- long utterances -- four times the
+error ATen's own float32 path makes against float64 on the same input: the gradient is exp(alpha + beta + nll - lp), a
+difference of log-domain sums whose magnitude grows with T (|nll| ~ 2000 at 612 frames: one fp32 ulp of the exponent is
+1e-4), so ANY float32 implementation, the reference's included, is that far from the exact value."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -37,13 +39,17 @@ def _check(device, B, T1, T2, in_lens, out_lens, seed=0, scale=3.0):
     xr = x.double().requires_grad_(True)
     ref = reference_attention_ctc(xr, il, ol)
     ref.backward()
+    x32 = x.clone().requires_grad_(True)
+    reference_attention_ctc(x32, il, ol).backward()
+    err_aten = float((x32.grad.double() - xr.grad).abs().max())
     xd = x.to(device).requires_grad_(True)
     got = AttentionCTCLoss()(xd, il.to(device), ol.to(device))
     (2.5 * got).backward()
     assert abs(float(got) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), (float(got), float(ref))
     gd = xd.grad.cpu() / 2.5
     gmax = float(xr.grad.abs().max())
-    assert float((gd - xr.grad).abs().max()) <= 1e-4 * max(gmax, 1e-6), (float((gd - xr.grad).abs().max()), gmax)
+    err = float((gd - xr.grad).abs().max())
+    assert err <= max(1e-4 * max(gmax, 1e-6), 4.0 * err_aten), (err, gmax, err_aten)
     # frames past the utterance / classes past its phonemes receive no gradient
     for b in range(B):
         assert float(gd[b, 0, int(ol[b]):].abs().max() if int(ol[b]) < T1 else 0.0) == 0.0
