@@ -50,6 +50,7 @@ struct UpArgs {
   int ntok, T;        // B*T tokens, tokens per sequence
   float slope;        // LeakyReLU slope on the input; 1 = identity
   int out_bf16;
+  int early_fetch;    // launch-shape choice (no effect on results): see the kernel
 };
 
 template <int CIN, int COUT, int S>
@@ -85,13 +86,14 @@ __global__ __launch_bounds__(UP_THREADS) void upsample_stream_kernel(const UpArg
   // ---- weights -> LDS once per workgroup, chunk index XORed with (row & 15): 16 rows of a fragment read 16 distinct slots
   // ([round 4] requesting the first tile's activations BEFORE this copy measured no better: 17.2 against 13.8-14.9 us on
   // other boxes for the 128 -> 64 stage, inside the box-to-box spread; the order of round 2 stays)
+  if (a.early_fetch && tile < ntile) fetch(tile, cur);  // [round 6 A/B] the first tile's activations requested BEFORE the weights
   for (int id = tid; id < NR * CPR; id += UP_THREADS) {
     const int row = id / CPR, c = id % CPR;
     const u32x4 v = *reinterpret_cast<const u32x4*>(a.wp + (long long)row * K + c * 8);
     *reinterpret_cast<u32x4*>(up_lds + ((long long)row * CPR + (c ^ (row & 15))) * 16) = v;
   }
   __syncthreads();
-  if (tile < ntile) fetch(tile, cur);
+  if (!a.early_fetch && tile < ntile) fetch(tile, cur);
   for (; tile < ntile; tile += stride) {
     const int tn = tile + stride;
     if (tn < ntile) fetch(tn, nxt);
@@ -194,6 +196,8 @@ extern "C" int kantts_upsample_stream(const void* x_bf16, const void* wp_bf16, c
   a.wp = reinterpret_cast<const __bf16*>(wp_bf16);
   a.bias = bias; a.res = res; a.out = out;
   a.ntok = B * T; a.T = T; a.slope = in_slope; a.out_bf16 = out_bf16;
+  static const char* env_ef = getenv("KANTTS_UP_EARLY_FETCH");  // experiment switch, read once per process
+  a.early_fetch = env_ef ? atoi(env_ef) : 0;
   hipStream_t st = (hipStream_t)stream;
   if (Cin == 128 && Cout == 64 && S == 2) return up_launch<128, 64, 2>(a, st);
   if (Cin == 64 && Cout == 32 && S == 2) return up_launch<64, 32, 2>(a, st);

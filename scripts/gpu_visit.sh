@@ -36,7 +36,7 @@ for step in "$@"; do
            rm -rf $O/${T}_pmc_$name
            echo "== pmc $name"; head -30 $O/${T}_${name}_pmc.txt | cut -c1-160 ;;
     run)   name=${rest%%:*}; cmd=${rest#*:}
-           eval timeout 1800 $cmd > $O/${T}_$name.log 2>&1; echo "$name exit $?"; tail -n 25 $O/${T}_$name.log | cut -c1-300 ;;
+           timeout 1800 bash -c "$cmd" > $O/${T}_$name.log 2>&1; echo "$name exit $?"; tail -n 25 $O/${T}_$name.log | cut -c1-300 ;;
     *) echo "unknown step $step" ;;
   esac
 done

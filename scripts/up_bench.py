@@ -38,6 +38,24 @@ with torch.no_grad():
         w, b, s_, prep = ws[i]
         return ops.upsample_forward(acts[i], w, b, s_, out_bf16=True, in_slope=0.1 if acts[i].shape[2] <= 128 else 1.0, prepared=prep)
 
-    st = [round(ev(lambda i=i: up_b(i)), 1) for i in range(4)]
-    chain = ev(lambda: [up_b(i) for i in range(4)])
+    def graph_us(fn, reps=8, n=20):
+        """device time per call from a replayed hipGraph of ``reps`` back-to-back calls (eager issue is host-bound)"""
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            fn()
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_, capture_error_mode="thread_local"):
+            for _ in range(reps):
+                fn()
+        return ev(g_.replay, n) / reps
+
+    if len(sys.argv) > 1 and sys.argv[1] == "graph":
+        st = [round(graph_us(lambda i=i: up_b(i)), 1) for i in range(4)]
+        chain = graph_us(lambda: [up_b(i) for i in range(4)], reps=4)
+    else:
+        st = [round(ev(lambda i=i: up_b(i)), 1) for i in range(4)]
+        chain = ev(lambda: [up_b(i) for i in range(4)])
     print("stage_us", st, "chain_us %.1f" % chain, "GB/s %.0f" % (belems * 2 / chain / 1e3), "frac %.3f" % (belems * 2 / chain / 1e3 / 8000))

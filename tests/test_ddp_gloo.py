@@ -446,7 +446,7 @@ def _agree_worker(rank, world, port, out_dir):
     log = []
 
     class Recorder:
-        def __init__(self, net, opt, sch, mc, pc, batch, band_width=None, force_wide=False):
+        def __init__(self, net, opt, sch, mc, pc, batch, band_width=None, force_wide=False, mas_criteria=None):
             t = torch.ones(1)
             dist.all_reduce(t)  # a build is collective: it must happen on both ranks in the same step
             assert float(t) == world
@@ -458,12 +458,15 @@ def _agree_worker(rank, world, port, out_dir):
             assert self.wide or band_width <= 16
             log.append(("load", "wide" if self.wide else "narrow"))
 
+        def set_epoch(self, epoch):
+            pass
+
         def __call__(self):
             return self.loss
 
     gs.GraphedSambertStep = Recorder
     tr = object.__new__(Sambert_Trainer)
-    tr._graphs, tr._ctl_group, tr.max_graphs = {}, None, 2
+    tr._graphs, tr._ctl_group, tr.max_graphs, tr.with_MAS, tr.epoch = {}, None, 2, False, 0
     tr.model = tr.optimizer = tr.scheduler = {Sambert_Trainer.KEY: None}
     tr.criterion = {"MelReconLoss": None, "ProsodyReconLoss": None}
     tr._accumulate = lambda *a, **k: None
