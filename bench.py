@@ -801,6 +801,59 @@ def fp32_leg(hip, cfg, batch, frames, mel_crit, pros_crit, dev, steps=5, warmup=
             "whole_step_mfma_frac": 456.9e9 * batch["mel_targets"].shape[0] / 32 / dt / 1e12 / PEAK_TFLOPS["fp32"]}
 
 
+def mas_leg(hip, cfg, precision, dev, steps=10, warmup=3, B=32):
+    """The Monotonic-Alignment-Search training step (configs/sambert_16k_MAS.yaml: no duration targets; alignment learner,
+    device-side MAS, CTC + binarisation terms; reference trainer.py:862-1005) on the full model at batch 32, replayed from a
+    hipGraph -- capturable since round 6 (the CTC criterion is one launch with device-side lengths: csrc/ctc.hip).  The
+    eager step (round 5's only form: ATen's ctc_loss synchronises with the host) is timed beside it."""
+    from kantts.models import model_builder
+    from kantts.train.graph_step import GraphedSambertStep
+    from kantts.train.loss import AttentionBinarizationLoss, AttentionCTCLoss, MelReconLoss, ProsodyReconLoss, sambert_loss_sum
+    from kantts.utils.synthetic import sambert_mas_batch
+
+    hip.set_precision(precision)
+    torch.manual_seed(0)
+    cfg = dict(cfg, MAS=True)
+    model, opt, sch = model_builder(sambert_yaml_config(cfg), device=dev)
+    net, optimizer, scheduler = model["KanTtsSAMBERT"], opt["KanTtsSAMBERT"], sch["KanTtsSAMBERT"]
+    optimizer.set_grad_clip(1.0)
+    net.train()
+    batch = {k: v.to(dev) for k, v in sambert_mas_batch(B=B, T_in=64, seed=1234).items() if v is not None}
+    frames = int(batch["output_lengths"].sum())
+    mc, pc = MelReconLoss(), ProsodyReconLoss()
+    mas = {"AttentionCTCLoss": AttentionCTCLoss(), "AttentionBinarizationLoss": AttentionBinarizationLoss()}
+
+    def eager():
+        hip.ops.advance_rng(torch.device(dev))
+        optimizer.zero_grad(set_to_none=True)
+        res = net(**batch)
+        total, _ = sambert_loss_sum(mc, pc, batch, res, prosody_lengths=res["valid_inter_lengths"])
+        total = (total + mas["AttentionCTCLoss"](res["attn_logprob"], batch["input_lengths"], batch["output_lengths"])
+                 + mas["AttentionBinarizationLoss"](50, res["attn_hard"], res["attn_soft"]))
+        total.backward()
+        optimizer.step()
+        return total
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, float(last.detach())
+
+    dt_e, loss_e = timed(eager)
+    step = GraphedSambertStep(net, optimizer, scheduler, mc, pc, batch, mas_criteria=mas)
+    step.set_epoch(50)
+    dt_g, loss_g = timed(step)
+    return {"dtype": precision, "workload": "SAM-BERT full, MAS: True (alignment learner + device-side MAS + CTC + binarisation "
+            "terms), batch %d, %d valid frames" % (B, frames), "ms_per_step": dt_g * 1e3, "value": frames / dt_g,
+            "unit": "mel-frames/s", "launch": "one hipGraph per step (wide-band decoder form)", "steps": steps,
+            "eager_ms_per_step": dt_e * 1e3, "final_loss": loss_g, "eager_final_loss": loss_e}
+
+
 def inference_leg(hip, cfg, precision, n_utt=128, batch=32, loop_sample=4, parity_utts=32, cpu_threads=0, wav_utts=6):
     """BASELINE config 5: end-to-end SAM-BERT -> HiFi-GAN inference on 128 synthetic utterances (T_in uniform
     20..80, the training id distributions, duration head biased to ~3.5 frames per symbol -- random-init weights predict
@@ -1361,6 +1414,14 @@ def main():
                 _note("fp32 leg done")
             except Exception as exc:
                 out["fp32_path"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        if world == 1 and not args.no_fp32:
+            try:  # the MAS training step, captured since round 6
+                out["mas_step"] = mas_leg(hip, cfg, args.precision, dev)
+                hip.set_precision(args.precision)
+                _note("MAS leg done")
+            except Exception as exc:
+                out["mas_step"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_hifigan:
             try:
                 out["hifigan"] = hifigan_leg(hip, args.precision)
