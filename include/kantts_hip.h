@@ -1163,6 +1163,43 @@ typedef struct kantts_ctc_args {
 long long kantts_ctc_attn_workspace(int B, int T1, int T2);
 int kantts_ctc_attn(const kantts_ctc_args* args, void* stream);
 
+/* kantts_enc_attn_fwd: the attention sub-layer of an encoder FFT block (MultiHeadSelfAttention.forward,
+ * kantts/models/sambert/__init__.py:52-106 inside FFTBlock.forward :152-184) as ONE launch, a workgroup per sequence:
+ *   qkv = xn . W_qkv^T + b;  8-head attention over the keys [0, lens[b]) of every query (+ attention dropout);
+ *   y1 = rowmask(dropout(context . W_fc^T + b_fc) + x);  xn1 = LayerNorm(y1)  (the feed-forward sub-layer's, optional)
+ * -- what kantts_bgemm_nt + kantts_attn_fwd (mode 0) + kantts_bgemm_nt with its LayerNorm epilogue compute, with the same
+ * dropout streams (element index (row, channel) for the projection; ((head * B + b) * L + query) * L + key for the attention).
+ *   x (M, 128) fp32, M = B * L; xn (M, 128) bf16: LayerNorm of x (the caller's); lens (B) or NULL; rowmask (M) or NULL;
+ *   wqkv / wfc: fragment-major bf16 images (kantts_fragmajor_bf16) of the (384, 128) / (128, 128) weights;
+ *   written for the backward pass: qkv (M, 384) fp32, o (M, 128) contexts, lse (B, 8, L), y1 (M, 128), xn1 (M, 128) bf16 or
+ *   fp32 (xn1_bf16) with mean1 / rstd1 (M).  d_model 128, 8 heads of 16, L <= 64 (KANTTS_E_UNSUPPORTED beyond). */
+typedef struct kantts_enc_attn_args {
+  const float* x;
+  const void* xn;
+  const int32_t* lens;
+  const uint8_t* rowmask;
+  const void* wqkv;
+  const float* bqkv;
+  const void* wfc;
+  const float* bfc;
+  const float* ln1_gamma;
+  const float* ln1_beta;
+  float ln1_eps;
+  float att_p, fc_p;
+  uint64_t att_seed, fc_seed;
+  const uint64_t* seed_dev;
+  float* qkv;
+  float* o;
+  float* lse;
+  float* y1;
+  void* xn1;
+  int xn1_bf16;
+  float* mean1;
+  float* rstd1;
+  int B, L;
+} kantts_enc_attn_args;
+int kantts_enc_attn_fwd(const kantts_enc_attn_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

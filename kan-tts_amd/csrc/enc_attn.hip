@@ -1,0 +1,311 @@
+// The attention sub-layer of an encoder FFT block as ONE launch (round 6).
+//
+// Reference: MultiHeadSelfAttention.forward, kantts/models/sambert/__init__.py:52-106 inside FFTBlock.forward :152-184
+// (SelfAttentionEncoder, kantts_sambert.py:20-89): LayerNorm -> fused QKV projection -> 8-head scaled-dot-product attention
+// with key padding (+ attention dropout) -> output projection + dropout + residual + zeroing of padded rows -> and, in the
+// same epilogue, the LayerNorm of the feed-forward sub-layer that consumes the result.  Until round 5 that was three launches
+// over M = B * T = 2048 rows (kantts_bgemm_nt 12 us, kantts_attn_fwd 9 us, kantts_bgemm_nt 8-12 us: each launch-latency
+// sized, 2048 x 128 activations) per block, 8 blocks per forward pass.
+//
+// One workgroup per sequence (T <= 64 tokens), WAVE = HEAD (8 waves, 8 heads of 16 channels):
+//   * Q^T, K^T of the wave's head come out of the bf16 MFMA (A = weight rows, B = normalised token rows from LDS) in the
+//     accumulator layout "lane (kg, li): token li, channels 4 kg + r"; V comes out of the SAME fragments with the operand
+//     roles swapped (A = token rows, B = weight rows): "lane (kg, li): channel li, tokens 4 kg + r".
+//   * Scores S^T = K Q^T and contexts O^T = V^T P^T run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, like the VALU
+//     attention of csrc/attn.hip) STRAIGHT FROM THOSE ACCUMULATORS: an fp32 MFMA step takes one float per lane for A[i][k] and
+//     B[k][j] with (i | j) = lane % 16, k = lane / 16; a contraction index may be visited in any order, so step r takes the
+//     index 4 kg + r -- which is accumulator element r of every lane.  K and Q need no transpose (contraction over channels),
+//     the probabilities leave the score MFMA in exactly the layout the context MFMA wants as B (contraction over keys), and V
+//     was produced transposed for it.  Nothing of the attention touches LDS.
+//   * softmax statistics: a query is a column (li); its keys sit in the 4 accumulator elements, the 4 key blocks and the 4
+//     lane groups kg: in-lane reductions + two shuffles.
+//   * the contexts go to LDS as bf16 (the output projection's B operand), wave w then computes output channels 16 w .. +15
+//     for all tokens; LayerNorm statistics of a token meet across the 8 waves through LDS (as in csrc/pnca_block.hip).
+// What backward needs (the existing launches: kantts_attn_bwd, kantts_bgemm_nt/tn, LayerNorm backward) is written once:
+// qkv (fp32), contexts, log-sum-exps, y1, its normalised rows and their statistics.  Same arithmetic as the three-launch
+// chain (bf16 MFMA operands for the projections, fp32 attention, the chain's dropout streams); summation orders differ.
+//
+// The bound is latency, not a roof: 0.13 MB of weights per workgroup from L2, ~5 k MFMA cycles per wave.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define EA_THREADS 512
+#define EA_T 64             // tokens of a sequence a workgroup can hold
+#define EA_NB (EA_T / 16)   // token blocks
+#define EA_C 128
+#define EA_H 8
+#define EA_XP (EA_C + 16)   // bf16 row pitch of the token tiles: 288 B = 32 mod 64
+
+__device__ __forceinline__ unsigned ea_pack2(float a, float b) {
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  v2 t = {(__bf16)a, (__bf16)b};
+  return (unsigned&)t;
+}
+
+__device__ __forceinline__ float ea_col_max(float v) {  // over the 4 lane groups kg that share a column li
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float ea_col_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+__global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_enc_attn_args g) {
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[EA_T * EA_XP];  // normalised rows, later the bf16 contexts
+  __shared__ float St[2 * EA_H * EA_T];                            // LayerNorm partial sums: [pass][wave][token]
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = head
+  const int b = blockIdx.x, T = g.L;
+  const long long m0 = (long long)b * T;
+  const int len = g.lens ? min(max(g.lens[b], 0), T) : T;
+  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
+  const __bf16* __restrict__ wq = reinterpret_cast<const __bf16*>(g.wqkv);
+  const __bf16* __restrict__ wf = reinterpret_cast<const __bf16*>(g.wfc);
+  const float* dummy = reinterpret_cast<const float*>(g.wqkv);  // any mapped, 16-byte aligned address
+  const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- global loads in consumption order: token rows, the head's q / k / v weight fragments, biases
+  u32x4 xr[2];
+  {
+    const __bf16* xn = reinterpret_cast<const __bf16*>(g.xn);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {  // 64 rows x 16 chunks of 16 B: 2 per thread (source row clamped, zeroed below)
+      const int id = tid + EA_THREADS * it;
+      const int row = min(id >> 4, T - 1);
+      xr[it] = *reinterpret_cast<const u32x4*>(xn + (m0 + row) * EA_C + (id & 15) * 8);
+    }
+  }
+  u32x4 wqf[3][4];  // row blocks wave (q), 8 + wave (k), 16 + wave (v) of the fragment-major (384 x 128) image
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      wqf[a][kk] = *reinterpret_cast<const u32x4*>(wq + ((long long)((a * EA_H + wave) * 4 + kk)) * 512 + lane * 8);
+  float4 bq = *reinterpret_cast<const float4*>(g.bqkv ? g.bqkv + wave * 16 + kg * 4 : dummy);
+  float4 bk = *reinterpret_cast<const float4*>(g.bqkv ? g.bqkv + EA_C + wave * 16 + kg * 4 : dummy);
+  float bv = *(g.bqkv ? g.bqkv + 2 * EA_C + wave * 16 + li : dummy);
+  if (!g.bqkv) {
+    bq = bk = zero4;
+    bv = 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = tid + EA_THREADS * it;
+    const u32x4 v = ((id >> 4) < T) ? xr[it] : (u32x4){0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(&Xs[(id >> 4) * EA_XP + (id & 15) * 8]) = v;
+  }
+  __syncthreads();
+
+  // ---- the head's Q^T, K^T (channels x tokens) and V (tokens x channels), all 64 tokens
+  f32x4 aq[EA_NB], ak[EA_NB], av[EA_NB];
+#pragma unroll
+  for (int tb = 0; tb < EA_NB; ++tb) aq[tb] = ak[tb] = av[tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+    for (int tb = 0; tb < EA_NB; ++tb) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[(tb * 16 + li) * EA_XP + kk * 32 + kg * 8]);
+      const bf16x8 xf = (bf16x8&)v;
+      aq[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wqf[0][kk], xf, aq[tb], 0, 0, 0);
+      ak[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wqf[1][kk], xf, ak[tb], 0, 0, 0);
+      av[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, (const bf16x8&)wqf[2][kk], av[tb], 0, 0, 0);
+    }
+  }
+  // the output projection's weights (row block = wave) and this lane's epilogue vectors: requested now, used after the attention
+  u32x4 wff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) wff[kk] = *reinterpret_cast<const u32x4*>(wf + ((long long)(wave * 4 + kk)) * 512 + lane * 8);
+  const int n0 = wave * 16 + kg * 4;  // this lane's 4 output channels of the projection
+  float4 bfc = *reinterpret_cast<const float4*>(g.bfc ? g.bfc + n0 : dummy);
+  if (!g.bfc) bfc = zero4;
+  const float4 l1g = *reinterpret_cast<const float4*>(g.ln1_gamma + n0), l1b = *reinterpret_cast<const float4*>(g.ln1_beta + n0);
+  float4 xres[EA_NB];
+  bool rz[EA_NB], live[EA_NB];
+#pragma unroll
+  for (int tb = 0; tb < EA_NB; ++tb) {
+    const int t = tb * 16 + li;
+    live[tb] = t < T;
+    const long long m = m0 + min(t, T - 1);
+    xres[tb] = *reinterpret_cast<const float4*>(g.x + m * EA_C + n0);
+    const uint8_t q = *(g.rowmask ? g.rowmask + m : reinterpret_cast<const uint8_t*>(dummy));
+    rz[tb] = g.rowmask && q != 0;
+  }
+  // biases, and qkv -> HBM for the backward pass (fp32, (M, 384): q | k | v)
+#pragma unroll
+  for (int tb = 0; tb < EA_NB; ++tb) {
+    aq[tb] += (f32x4){bq.x, bq.y, bq.z, bq.w};
+    ak[tb] += (f32x4){bk.x, bk.y, bk.z, bk.w};
+    av[tb] += (f32x4){bv, bv, bv, bv};
+    if (g.qkv) {
+      const int t = tb * 16 + li;
+      if (t < T) {
+        float* row = g.qkv + (m0 + t) * (3 * EA_C) + wave * 16 + kg * 4;
+        *reinterpret_cast<f32x4*>(row) = aq[tb];
+        *reinterpret_cast<f32x4*>(row + EA_C) = ak[tb];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tv = tb * 16 + kg * 4 + r;
+        if (tv < T) g.qkv[(m0 + tv) * (3 * EA_C) + 2 * EA_C + wave * 16 + li] = av[tb][r];
+      }
+    }
+  }
+
+  // ---- attention of this head, one query block (16 queries = columns li) at a time: S^T[key][query] on the fp32 MFMA
+  f32x4 ao[EA_NB];  // contexts, transposed: lane (kg, li) = query li, channels 4 kg + r
+  const uint64_t att_seed = g.att_seed + seed_off;
+#pragma unroll
+  for (int qb = 0; qb < EA_NB; ++qb) {
+    f32x4 s[EA_NB];
+#pragma unroll
+    for (int kb = 0; kb < EA_NB; ++kb) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[kb][r], aq[qb][r], acc, 0, 0, 0);
+      s[kb] = acc;
+    }
+    // keys kb * 16 + 4 kg + r < len (mode 0 of csrc/attn.hip: every query, padded ones included, sees keys [0, len - 1])
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < EA_NB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = kb * 16 + kg * 4 + r < len;
+        s[kb][r] = ok ? s[kb][r] * 0.25f : -INFINITY;
+        mx = fmaxf(mx, s[kb][r]);
+      }
+    mx = ea_col_max(mx);
+    const int i = min(qb * 16 + li, T - 1);  // this lane's query
+    const uint64_t rng_row = (((uint64_t)wave * g.B + b) * T + i) * (uint64_t)T;
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < EA_NB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = kb * 16 + kg * 4 + r;
+        const float e = (j < len) ? expf(s[kb][r] - mx) : 0.f;
+        l += e;
+        s[kb][r] = e * kantts_dropout_scale(g.att_p, att_seed, rng_row + j);
+      }
+    l = ea_col_sum(l);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < EA_NB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][r], s[kb][r], acc, 0, 0, 0);
+    const float inv = (len > 0) ? 1.f / l : 0.f;
+    ao[qb] = acc * inv;
+    const int t = qb * 16 + li;
+    if (t < T) {
+      if (g.o) *reinterpret_cast<f32x4*>(g.o + (m0 + t) * EA_C + wave * 16 + kg * 4) = ao[qb];
+      if (kg == 0 && g.lse) g.lse[((long long)b * EA_H + wave) * T + t] = (len > 0) ? (mx + logf(l)) : 0.f;
+    }
+  }
+  __syncthreads();  // every wave has read the normalised rows: the tile becomes the context tile
+#pragma unroll
+  for (int qb = 0; qb < EA_NB; ++qb) {
+    const u32x2 pk = {ea_pack2(ao[qb][0], ao[qb][1]), ea_pack2(ao[qb][2], ao[qb][3])};
+    *reinterpret_cast<u32x2*>(&Xs[(qb * 16 + li) * EA_XP + wave * 16 + kg * 4]) = pk;
+  }
+  __syncthreads();
+
+  // ---- y1 = rowmask(dropout(fc(context)) + x): wave w -> output channels 16 w .. 16 w + 15 of every token
+  float y1v[EA_NB][4];
+  {
+    f32x4 acc[EA_NB];
+#pragma unroll
+    for (int tb = 0; tb < EA_NB; ++tb) acc[tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int tb = 0; tb < EA_NB; ++tb) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[(tb * 16 + li) * EA_XP + kk * 32 + kg * 8]);
+        acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wff[kk], (const bf16x8&)v, acc[tb], 0, 0, 0);
+      }
+    const uint64_t sdf = g.fc_seed + seed_off;
+#pragma unroll
+    for (int tb = 0; tb < EA_NB; ++tb) {
+      const long long m = m0 + tb * 16 + li;
+      float* o = y1v[tb];
+      o[0] = acc[tb][0] + bfc.x; o[1] = acc[tb][1] + bfc.y; o[2] = acc[tb][2] + bfc.z; o[3] = acc[tb][3] + bfc.w;
+      if (g.fc_p > 0.f) kantts_dropout_scale4(g.fc_p, sdf, (uint64_t)m * (uint64_t)EA_C + (uint64_t)n0, o);
+      o[0] += xres[tb].x; o[1] += xres[tb].y; o[2] += xres[tb].z; o[3] += xres[tb].w;
+      if (rz[tb] || !live[tb]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = 0.f;
+      }
+      if (live[tb] && g.y1) *reinterpret_cast<f32x4*>(g.y1 + m * EA_C + n0) = (f32x4){o[0], o[1], o[2], o[3]};
+    }
+  }
+  if (!g.xn1) return;  // (uniform) no consumer asked for the LayerNorm of y1
+
+  // ---- LayerNorm(128) of every token of y1: its channels sit in 4 lanes (kg) of each of the 8 waves
+  float mu[EA_NB], rs[EA_NB];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int tb = 0; tb < EA_NB; ++tb) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = pass ? y1v[tb][r] - mu[tb] : y1v[tb][r];
+        t += pass ? d * d : d;
+      }
+      t = ea_col_sum(t);
+      if (kg == 0) St[(pass * EA_H + wave) * EA_T + tb * 16 + li] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tb = 0; tb < EA_NB; ++tb) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < EA_H; ++w) t += St[(pass * EA_H + w) * EA_T + tb * 16 + li];
+      if (pass)
+        rs[tb] = 1.0f / sqrtf(t * (1.f / 128.f) + g.ln1_eps);
+      else
+        mu[tb] = t * (1.f / 128.f);
+    }
+  }
+#pragma unroll
+  for (int tb = 0; tb < EA_NB; ++tb) {
+    if (!live[tb]) continue;
+    const long long m = m0 + tb * 16 + li;
+    const float* o = y1v[tb];
+    const float z0 = (o[0] - mu[tb]) * rs[tb] * l1g.x + l1b.x, z1 = (o[1] - mu[tb]) * rs[tb] * l1g.y + l1b.y;
+    const float z2 = (o[2] - mu[tb]) * rs[tb] * l1g.z + l1b.z, z3 = (o[3] - mu[tb]) * rs[tb] * l1g.w + l1b.w;
+    if (g.xn1_bf16) {
+      const u32x2 pk = {ea_pack2(z0, z1), ea_pack2(z2, z3)};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.xn1) + m * EA_C + n0) = pk;
+    } else {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.xn1) + m * EA_C + n0) = (f32x4){z0, z1, z2, z3};
+    }
+    if (wave == 0 && kg == 0 && g.mean1) {
+      g.mean1[m] = mu[tb];
+      g.rstd1[m] = rs[tb];
+    }
+  }
+}
+
+static bool ea_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int kantts_enc_attn_fwd(const kantts_enc_attn_args* gp, void* stream) {
+  if (!gp) return KANTTS_E_BADARG;
+  const kantts_enc_attn_args& g = *gp;
+  if (g.B < 0 || g.L < 0) return KANTTS_E_BADARG;
+  if (g.B == 0 || g.L == 0) return KANTTS_OK;
+  if (!g.x || !g.xn || !g.wqkv || !g.wfc || !g.ln1_gamma || !g.ln1_beta || !g.y1) return KANTTS_E_BADARG;
+  if (g.L > EA_T) return KANTTS_E_UNSUPPORTED;  // one workgroup holds a sequence of up to 64 tokens
+  if (g.xn1 && (!g.mean1 || !g.rstd1)) return KANTTS_E_BADARG;
+  const void* ps[] = {g.x, g.xn, g.wqkv, g.wfc, g.bqkv, g.bfc, g.ln1_gamma, g.ln1_beta, g.qkv, g.o, g.y1, g.xn1};
+  for (const void* p : ps)
+    if (!ea_aligned16(p)) return KANTTS_E_UNSUPPORTED;
+  hipLaunchKernelGGL(enc_attn_fwd_kernel, dim3(g.B), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
+  KANTTS_CHECK_LAUNCH();
+}

@@ -286,6 +286,16 @@ class DurArArgs(Structure):
                 ("B", c_int32), ("T", c_int32)]
 
 
+class EncAttnArgs(Structure):
+    """kantts_enc_attn_args (include/kantts_hip.h)."""
+    _fields_ = [("x", c_void_p), ("xn", c_void_p), ("lens", c_void_p), ("rowmask", c_void_p), ("wqkv", c_void_p),
+                ("bqkv", c_void_p), ("wfc", c_void_p), ("bfc", c_void_p), ("ln1_gamma", c_void_p), ("ln1_beta", c_void_p),
+                ("ln1_eps", c_float), ("att_p", c_float), ("fc_p", c_float), ("att_seed", c_uint64), ("fc_seed", c_uint64),
+                ("seed_dev", c_void_p), ("qkv", c_void_p), ("o", c_void_p), ("lse", c_void_p), ("y1", c_void_p),
+                ("xn1", c_void_p), ("xn1_bf16", c_int32), ("mean1", c_void_p), ("rstd1", c_void_p), ("B", c_int32),
+                ("L", c_int32)]
+
+
 class CtcArgs(Structure):
     """kantts_ctc_args (include/kantts_hip.h)."""
     _fields_ = [("logits", c_void_p), ("in_lens", c_void_p), ("out_lens", c_void_p), ("ws", c_void_p), ("loss", c_void_p),
@@ -391,6 +401,7 @@ def lib():
         L.kantts_pnca_decode_run.argtypes = [POINTER(DecodeArgs), c_void_p]
         L.kantts_dur_ar_run.argtypes = [POINTER(DurArArgs), c_void_p]
         L.kantts_dur_ar_run_f32.argtypes = [POINTER(DurArArgs), c_void_p]
+        L.kantts_enc_attn_fwd.argtypes = [POINTER(EncAttnArgs), c_void_p]
         L.kantts_ctc_attn.argtypes = [POINTER(CtcArgs), c_void_p]
         L.kantts_ctc_attn_workspace.argtypes = [c_int, c_int, c_int]
         L.kantts_ctc_attn_workspace.restype = c_longlong
@@ -446,7 +457,7 @@ EXPORTED_SYMBOLS = [
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
     "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof", "kantts_pnca_attn_qkv_bwd",
-    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_dur_ar_run_f32", "kantts_ctc_attn", "kantts_ctc_attn_workspace",
+    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_dur_ar_run_f32", "kantts_ctc_attn", "kantts_ctc_attn_workspace", "kantts_enc_attn_fwd",
     "kantts_launch_tuning",
 ]
 
@@ -910,6 +921,28 @@ def dur_ar_run(w, f, gc, out, lens32):
         check(lib().kantts_dur_ar_run_f32(ctypes.byref(g), stream()), "dur_ar_run_f32")
     else:
         check(lib().kantts_dur_ar_run(ctypes.byref(g), stream()), "dur_ar_run")
+
+
+def enc_attn_fwd(x, xn, B, L, *, lens, rowmask, wqkv, bqkv, wfc, bfc, ln1, att_p, fc_p, seeds, qkv, o, lse, y1, xn1, mean1, rstd1):
+    """The attention sub-layer of an encoder block in one launch (csrc/enc_attn.hip; kantts_enc_attn_fwd in the header).
+    Returns False when the library declines the shape (L > 64)."""
+    g = EncAttnArgs()
+    g.x, g.xn = ptr(x, torch.float32), ptr(xn, torch.bfloat16)
+    g.lens, g.rowmask = ptr(lens, torch.int32), ptr(rowmask)
+    g.wqkv, g.bqkv, g.wfc, g.bfc = ptr(wqkv, torch.bfloat16), ptr(bqkv, torch.float32), ptr(wfc, torch.bfloat16), ptr(bfc, torch.float32)
+    g.ln1_gamma, g.ln1_beta, g.ln1_eps = ptr(ln1[0], torch.float32), ptr(ln1[1], torch.float32), float(ln1[2])
+    g.att_p, g.fc_p, g.att_seed, g.fc_seed = float(att_p), float(fc_p), int(seeds[0]), int(seeds[1])
+    g.seed_dev = rng_ptr(x.device) if (att_p > 0 or fc_p > 0) else None
+    g.qkv, g.o, g.lse, g.y1 = ptr(qkv, torch.float32), ptr(o, torch.float32), ptr(lse, torch.float32), ptr(y1, torch.float32)
+    g.xn1 = ptr(xn1)
+    g.xn1_bf16 = int(xn1 is not None and xn1.dtype == torch.bfloat16)
+    g.mean1, g.rstd1 = ptr(mean1, torch.float32), ptr(rstd1, torch.float32)
+    g.B, g.L = int(B), int(L)
+    rc = lib().kantts_enc_attn_fwd(ctypes.byref(g), stream())
+    if rc == E_UNSUPPORTED:
+        return False
+    check(rc, "enc_attn_fwd")
+    return True
 
 
 def ctc_attn(logits, in_lens32, out_lens32, blank, grad_scale):

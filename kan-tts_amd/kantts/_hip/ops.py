@@ -616,6 +616,16 @@ def pnca_block_fused(blk, x, hkv, info, bw_x, bw_h, bw_dev, return_attn, next_ln
     return ops_bf16.pnca_block_fused(blk, x, hkv, info, bw_x, bw_h, bw_dev, return_attn, next_ln, training)
 
 
+def enc_attn_fused(att, x, info, rows, return_attn, next_ln, training):
+    """bf16 mode on a HIP device: ops_bf16.enc_attn_fused (one launch for the forward pass of an encoder block's attention
+    sub-layer); otherwise a no-op context (the fp32 parity path keeps its launches)."""
+    import contextlib
+
+    if get_precision() != "bf16":
+        return contextlib.nullcontext()
+    return ops_bf16.enc_attn_fused(att, x, info, rows, return_attn, next_ln, training)
+
+
 def shared_input_linears(x, linears):
     """``[lin(x) for lin in linears]`` for nn.Linear holders that all read the same tensor.  bf16 mode with gradients
     enabled: forward as usual, but ONE input-gradient launch for all of them (ops_bf16._SharedInputLinearsB)."""
@@ -723,10 +733,16 @@ class _SelfAttention(torch.autograd.Function):
         B, L, W = qkv.shape
         D = H * 16
         assert W == 3 * D
-        seed = next_seed() if drop_p > 0 else 0
         q2 = qkv.view(B * L, W)
-        o, lse, probs = _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, None, 0, B, H, L, MODE_KEYPAD, drop_p, seed,
-                                  want_probs)
+        ad = ops_bf16.ADOPT.take("attn") if ops_bf16.ADOPT.q else None
+        if ad is not None:
+            # computed by the fused sub-layer launch (ops_bf16.enc_attn_fused): same values, same dropout stream
+            assert not want_probs
+            o, lse, seed, probs = ad["o"], ad["lse"], ad["seed"], None
+        else:
+            seed = next_seed() if drop_p > 0 else 0
+            o, lse, probs = _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, None, 0, B, H, L, MODE_KEYPAD, drop_p, seed,
+                                      want_probs)
         ctx.save_for_backward(q2, o, lse, lens)
         ctx.cfg = (B, H, L, drop_p, seed)
         if want_probs:

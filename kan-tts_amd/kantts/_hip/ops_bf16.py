@@ -448,6 +448,72 @@ def pnca_block_fused(blk, x, hkv, info, bw_x, bw_h, bw_dev, return_attn, next_ln
     ])
 
 
+# A/B switch: KANTTS_NO_ENC_ATTN=1 keeps the three launches of an encoder block's attention sub-layer
+ENC_ATTN = {"on": not os.environ.get("KANTTS_NO_ENC_ATTN")}
+
+
+def enc_attn_fused(att, x, info, rows, return_attn, next_ln, training):
+    """Context manager for kantts.models.sambert.MultiHeadSelfAttention.forward: launches the whole sub-layer's forward pass
+    (csrc/enc_attn.hip: QKV projection, 8-head attention, output projection + dropout + residual + row mask, the consumer's
+    LayerNorm) and lets the three ops inside the ``with`` adopt its results (the protocol of pnca_block_fused); a no-op context
+    when the launch does not apply (other shapes, sequences of more than 64 tokens, attention maps requested, no consumer
+    LayerNorm, KANTTS_NO_ENC_ATTN)."""
+    if (not ENC_ATTN["on"] or not PRENORM["on"] or return_attn or next_ln is None or not torch.is_tensor(x) or x.dim() != 3
+            or x.dtype != torch.float32 or x.shape[-1] != 128 or x.numel() == 0 or x.shape[1] > 64
+            or att.n_head != 8 or att.d_head != 16 or att.d_model != 128 or att.d_in != 128 or att.fc.out_features != 128
+            or next_ln.weight.numel() != 128 or att.w_qkv.bias is None or att.fc.bias is None):
+        return contextlib.nullcontext()
+    from .ops import next_seed
+
+    def p_of(drop):
+        return float(drop.p) if (training and drop.p > 0) else 0.0
+
+    att_p, fc_p = p_of(att.attention.dropatt), p_of(att.dropout)
+    x = _c(x)
+    dev = x.device
+    B, L, _ = x.shape
+    M = B * L
+    ln0 = att.layer_norm
+    pre0 = getattr(x, "_kantts_prenorm", None)
+    if pre0 is None or not pre0.matches(ln0.weight, ln0.bias, ln0.eps, True) or pre0.xn.numel() != x.numel():
+        # the sub-layer's input has no producer that normalised it (the first block of the stack): one LayerNorm launch, left
+        # on the tensor exactly as a producer's epilogue would have left it
+        pre0 = PreNorm(ln0)
+        pre0.out_bf16 = True
+        pre0.xn = torch.empty((M, 128), device=dev, dtype=BF16)
+        pre0.mean = torch.empty(M, device=dev, dtype=torch.float32)
+        pre0.rstd = torch.empty(M, device=dev, dtype=torch.float32)
+        check(lib().kantts_ln128_fwd(ptr(x.detach(), torch.float32), ptr(ln0.weight.detach(), torch.float32),
+                                     ptr(ln0.bias.detach(), torch.float32), ptr(pre0.xn), 1, ptr(pre0.mean), ptr(pre0.rstd), M,
+                                     float(ln0.eps), stream()), "ln128_fwd")
+        x._kantts_prenorm = pre0
+    # dropout seeds in the order the chain draws them (attention, output projection)
+    sa = next_seed() if att_p > 0 else 0
+    sf = next_seed() if fc_p > 0 else 0
+    f32 = dict(device=dev, dtype=torch.float32)
+    qkv = torch.empty((B, L, 384), **f32)
+    o = torch.empty((M, 128), **f32)
+    lse = torch.empty((B, 8, L), **f32)
+    y1 = torch.empty((M, 128), **f32)
+    out_bf16 = bool(getattr(next_ln, "_kantts_out_bf16", True))
+    xn1 = torch.empty((M, 128), device=dev, dtype=BF16 if out_bf16 else torch.float32)
+    mean1, rstd1 = torch.empty(M, **f32), torch.empty(M, **f32)
+    rowmask = None if rows is None else _c(rows).view(M)
+    from . import enc_attn_fwd
+
+    ok = enc_attn_fwd(x.detach(), pre0.xn, B, L, lens=None if info is None else info.lens32, rowmask=rowmask,
+                      wqkv=lin_frag(att.w_qkv.weight), bqkv=att.w_qkv.bias.detach(), wfc=lin_frag(att.fc.weight),
+                      bfc=att.fc.bias.detach(), ln1=(next_ln.weight.detach(), next_ln.bias.detach(), next_ln.eps),
+                      att_p=att_p, fc_p=fc_p, seeds=(sa, sf), qkv=qkv, o=o, lse=lse, y1=y1, xn1=xn1, mean1=mean1, rstd1=rstd1)
+    if not ok:
+        raise RuntimeError("kantts_enc_attn_fwd declined a sub-layer enc_attn_fused() accepted")
+    return _adopting([
+        ("linear", dict(y=qkv.view(M, 384), seed=0, ln=None)),
+        ("attn", dict(o=o, lse=lse, seed=sa)),
+        ("linear", dict(y=y1, seed=sf, ln=(xn1, mean1, rstd1))),
+    ])
+
+
 class _FusedLinearB(torch.autograd.Function):
     """y = rowmask( dropout( act( (sum_k x_k @ W_k^T + bias [+ bias2]) * alpha ) ) + res ) on kantts_bgemm_nt/tn.
     Same three modes as ops._FusedLinear (concat / sum / conv)."""

@@ -78,6 +78,9 @@ class MultiHeadSelfAttention(nn.Module):
         self.attention = ScaledDotProductAttention(temperature=np.power(d_head, 0.5), dropatt=dropatt)
         self.fc = nn.Linear(n_head * d_head, d_model)
         self.dropout = nn.Dropout(dropout)
+        # bf16 mode: the parameter arena also keeps the fragment-major images csrc/enc_attn.hip streams
+        for lin in (self.w_qkv, self.fc):
+            lin.weight._kantts_ffn_role = "lin"
 
     def forward(self, input, mask=None, zero_rows=None, return_attn=False, private_input=False, next_ln=None):
         """mask: key padding (SeqInfo or bool (B, L) / (B, L, L) as the reference builds it).
@@ -86,14 +89,17 @@ class MultiHeadSelfAttention(nn.Module):
         if torch.is_tensor(mask) and mask.dim() == 3:
             mask = mask[:, 0, :]
         info = SeqInfo.of(mask)
-        x, input = ops.layer_norm(input, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, out_bf16=True,
-                                  with_res=True, private_input=private_input)
-        qkv = ops.linear(x, self.w_qkv.weight, self.w_qkv.bias)
-        ctxv, attn = ops.self_attention(qkv, None if info is None else info.lens32, self.n_head,
-                                        drop_p=_p(self.attention.dropatt, self.training), want_probs=return_attn)
-        res = input if self.fc.out_features == input.size(-1) else None
-        output = ops.linear(ctxv, self.fc.weight, self.fc.bias, res=res, rowmask=zero_rows,
-                            drop_p=_p(self.dropout, self.training), ln_next=next_ln)
+        # bf16 mode: the sub-layer's forward pass as ONE launch (csrc/enc_attn.hip) whose results the three ops below adopt
+        # instead of launching; a no-op context whenever that launch does not apply
+        with ops.enc_attn_fused(self, input, info, zero_rows, return_attn, next_ln, self.training):
+            x, input = ops.layer_norm(input, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps,
+                                      out_bf16=True, with_res=True, private_input=private_input)
+            qkv = ops.linear(x, self.w_qkv.weight, self.w_qkv.bias)
+            ctxv, attn = ops.self_attention(qkv, None if info is None else info.lens32, self.n_head,
+                                            drop_p=_p(self.attention.dropatt, self.training), want_probs=return_attn)
+            res = input if self.fc.out_features == input.size(-1) else None
+            output = ops.linear(ctxv, self.fc.weight, self.fc.bias, res=res, rowmask=zero_rows,
+                                drop_p=_p(self.dropout, self.training), ln_next=next_ln)
         return output, attn
 
 

@@ -548,6 +548,55 @@ class EmulatedLib:
             _arr(g.ln2_rstd, M)[:] = rs2
         return 0
 
+    def kantts_enc_attn_fwd(self, args_ref, stream):
+        """csrc/enc_attn.hip: the attention sub-layer of an encoder block -- QKV contraction (bf16 operands), the mode-0
+        attention of this emulation (kantts_attn_fwd), the output contraction + dropout + residual + row mask, LayerNorm."""
+        g = args_ref._obj
+        B, L, C = g.B, g.L, 128
+        if B == 0 or L == 0:
+            return 0
+        if L > 64:
+            return -2
+        M = B * L
+        soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
+        rows = np.arange(M, dtype=np.int64)
+        cols = np.arange(C, dtype=np.int64)
+        mask = (_arr(g.rowmask, M, np.uint8) != 0) if g.rowmask else np.zeros(M, dtype=bool)
+        X = _rd2d(g.x, M, C, C, False)
+        Xn = _rd2d(g.xn, M, C, C, True)
+        qkv = (Xn @ _unfrag(g.wqkv, 3 * C, C).T).astype(np.float32)
+        if g.bqkv:
+            qkv = qkv + _arr(g.bqkv, 3 * C)[None, :]
+        qkv = np.ascontiguousarray(qkv, dtype=np.float32)
+        if g.qkv:
+            _wr(g.qkv, qkv, False)
+        o = np.zeros((M, C), dtype=np.float32)
+        lse = np.zeros((B, 8, L), dtype=np.float32)
+        q0 = qkv.ctypes.data
+        self.kantts_attn_fwd(q0, q0 + 4 * C, q0 + 8 * C, 3 * C, 3 * C, 3 * C, o.ctypes.data, C, lse.ctypes.data, None, g.lens,
+                             None, 0, B, 8, L, 16, 0, g.att_p, g.att_seed, g.seed_dev, stream)
+        if g.o:
+            _wr(g.o, o, False)
+        if g.lse:
+            _arr(g.lse, B * 8 * L)[:] = lse.reshape(-1)
+        y1 = _bf16_round(o) @ _unfrag(g.wfc, C, C).T
+        if g.bfc:
+            y1 = y1 + _arr(g.bfc, C)[None, :]
+        y1 = y1.astype(np.float32)
+        if g.fc_p > 0:
+            y1 = y1 * dropout_scale(g.fc_p, g.fc_seed + soff, rows[:, None] * C + cols[None, :])
+        y1 = np.where(mask[:, None], 0, y1 + X).astype(np.float32)
+        _wr(g.y1, y1, False)
+        if g.xn1:
+            t = torch.from_numpy(np.ascontiguousarray(y1))
+            mu = t.mean(1)
+            rs = 1.0 / torch.sqrt(((t - mu[:, None]) ** 2).mean(1) + g.ln1_eps)
+            z = ((t - mu[:, None]) * rs[:, None] * torch.from_numpy(_arr(g.ln1_gamma, C)) + torch.from_numpy(_arr(g.ln1_beta, C)))
+            _wr(g.xn1, z.numpy(), bool(g.xn1_bf16))
+            _arr(g.mean1, M)[:] = mu.numpy()
+            _arr(g.rstd1, M)[:] = rs.numpy()
+        return 0
+
     def kantts_pnca_attn_qkv_bwd(self, args_ref, stream):
         """csrc/pnca_block.hip: kantts_pnca_attn_bwd (summed query gradients) + the QKV projection's input gradient rounded
         to bf16 + kantts_ln128_bwd_rows with partial rows."""
