@@ -7,7 +7,9 @@
 // over M = B * T = 2048 rows (kantts_bgemm_nt 12 us, kantts_attn_fwd 9 us, kantts_bgemm_nt 8-12 us: each launch-latency
 // sized, 2048 x 128 activations) per block, 8 blocks per forward pass.
 //
-// One workgroup per sequence (T <= 64 tokens), WAVE = HEAD (8 waves, 8 heads of 16 channels):
+// One workgroup per (sequence, block of 16 queries) (T <= 64 tokens: up to 4 workgroups per sequence, each recomputing the
+// sequence's K and V -- 32 of its 36 projection MFMAs per wave -- so that the attention's VALU work, the softmax and the one
+// dropout hash per four keys, spreads over 4 CUs), WAVE = HEAD (8 waves, 8 heads of 16 channels):
 //   * Q^T, K^T of the wave's head come out of the bf16 MFMA (A = weight rows, B = normalised token rows from LDS) in the
 //     accumulator layout "lane (kg, li): token li, channels 4 kg + r"; V comes out of the SAME fragments with the operand
 //     roles swapped (A = token rows, B = weight rows): "lane (kg, li): channel li, tokens 4 kg + r".
@@ -25,7 +27,9 @@
 // qkv (fp32), contexts, log-sum-exps, y1, its normalised rows and their statistics.  Same arithmetic as the three-launch
 // chain (bf16 MFMA operands for the projections, fp32 attention, the chain's dropout streams); summation orders differ.
 //
-// The bound is latency, not a roof: 0.13 MB of weights per workgroup from L2, ~5 k MFMA cycles per wave.
+// The bound is latency, not a roof: 0.13 MB of weights per workgroup from L2, ~2 k MFMA cycles per wave.
+// Measured (profiles/r06_run{J,K,L}_*): one workgroup per sequence with libm expf and a dropout hash per element 28.2 us;
+// one hash per four keys 20.8 us; a workgroup per 16 queries: see DESIGN.md section 5.
 #include <stdlib.h>
 
 #include "common.h"
@@ -58,11 +62,11 @@ __device__ __forceinline__ float ea_col_sum(float v) {
 }
 
 __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_enc_attn_args g) {
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[EA_T * EA_XP];  // normalised rows, later the bf16 contexts
-  __shared__ float St[2 * EA_H * EA_T];                            // LayerNorm partial sums: [pass][wave][token]
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[EA_T * EA_XP];  // normalised rows; rows 0..15 later hold the bf16 contexts
+  __shared__ float St[2 * EA_H * 16];                              // LayerNorm partial sums: [pass][wave][token]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = head
-  const int b = blockIdx.x, T = g.L;
+  const int b = blockIdx.x, qb = blockIdx.y, T = g.L;         // this workgroup: queries qb * 16 .. + 15 of sequence b
   const long long m0 = (long long)b * T;
   const int len = g.lens ? min(max(g.lens[b], 0), T) : T;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
@@ -103,17 +107,20 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
   }
   __syncthreads();
 
-  // ---- the head's Q^T, K^T (channels x tokens) and V (tokens x channels), all 64 tokens
-  f32x4 aq[EA_NB], ak[EA_NB], av[EA_NB];
+  // ---- the head's K^T (channels x tokens) and V (tokens x channels) of all 64 tokens, Q^T of the workgroup's 16 queries
+  f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak[EA_NB], av[EA_NB];
 #pragma unroll
-  for (int tb = 0; tb < EA_NB; ++tb) aq[tb] = ak[tb] = av[tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int tb = 0; tb < EA_NB; ++tb) ak[tb] = av[tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
+    {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[(qb * 16 + li) * EA_XP + kk * 32 + kg * 8]);
+      aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wqf[0][kk], (const bf16x8&)v, aq, 0, 0, 0);
+    }
 #pragma unroll
     for (int tb = 0; tb < EA_NB; ++tb) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[(tb * 16 + li) * EA_XP + kk * 32 + kg * 8]);
       const bf16x8 xf = (bf16x8&)v;
-      aq[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wqf[0][kk], xf, aq[tb], 0, 0, 0);
       ak[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wqf[1][kk], xf, ak[tb], 0, 0, 0);
       av[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, (const bf16x8&)wqf[2][kk], av[tb], 0, 0, 0);
     }
@@ -126,28 +133,22 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
   float4 bfc = *reinterpret_cast<const float4*>(g.bfc ? g.bfc + n0 : dummy);
   if (!g.bfc) bfc = zero4;
   const float4 l1g = *reinterpret_cast<const float4*>(g.ln1_gamma + n0), l1b = *reinterpret_cast<const float4*>(g.ln1_beta + n0);
-  float4 xres[EA_NB];
-  bool rz[EA_NB], live[EA_NB];
+  const int tq = qb * 16 + li;  // this lane's token (query / output row)
+  const bool live = tq < T;
+  const long long mq = m0 + min(tq, T - 1);
+  const float4 xres = *reinterpret_cast<const float4*>(g.x + mq * EA_C + n0);
+  const uint8_t rmq = *(g.rowmask ? g.rowmask + mq : reinterpret_cast<const uint8_t*>(dummy));
+  const bool rz = g.rowmask && rmq != 0;
+  // biases; q | k | v of the workgroup's OWN 16 tokens -> HBM for the backward pass (fp32, (M, 384))
+  aq += (f32x4){bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
   for (int tb = 0; tb < EA_NB; ++tb) {
-    const int t = tb * 16 + li;
-    live[tb] = t < T;
-    const long long m = m0 + min(t, T - 1);
-    xres[tb] = *reinterpret_cast<const float4*>(g.x + m * EA_C + n0);
-    const uint8_t q = *(g.rowmask ? g.rowmask + m : reinterpret_cast<const uint8_t*>(dummy));
-    rz[tb] = g.rowmask && q != 0;
-  }
-  // biases, and qkv -> HBM for the backward pass (fp32, (M, 384): q | k | v)
-#pragma unroll
-  for (int tb = 0; tb < EA_NB; ++tb) {
-    aq[tb] += (f32x4){bq.x, bq.y, bq.z, bq.w};
     ak[tb] += (f32x4){bk.x, bk.y, bk.z, bk.w};
     av[tb] += (f32x4){bv, bv, bv, bv};
-    if (g.qkv) {
-      const int t = tb * 16 + li;
-      if (t < T) {
-        float* row = g.qkv + (m0 + t) * (3 * EA_C) + wave * 16 + kg * 4;
-        *reinterpret_cast<f32x4*>(row) = aq[tb];
+    if (g.qkv && tb == qb) {  // (uniform)
+      if (live) {
+        float* row = g.qkv + (m0 + tq) * (3 * EA_C) + wave * 16 + kg * 4;
+        *reinterpret_cast<f32x4*>(row) = aq;
         *reinterpret_cast<f32x4*>(row + EA_C) = ak[tb];
       }
 #pragma unroll
@@ -158,17 +159,16 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
     }
   }
 
-  // ---- attention of this head, one query block (16 queries = columns li) at a time: S^T[key][query] on the fp32 MFMA
-  f32x4 ao[EA_NB];  // contexts, transposed: lane (kg, li) = query li, channels 4 kg + r
-  const uint64_t att_seed = g.att_seed + seed_off;
-#pragma unroll
-  for (int qb = 0; qb < EA_NB; ++qb) {
+  // ---- attention of this head for the 16 queries (columns li): S^T[key][query] on the fp32 MFMA
+  f32x4 ao;  // contexts, transposed: lane (kg, li) = query li, channels 4 kg + r
+  {
+    const uint64_t att_seed = g.att_seed + seed_off;
     f32x4 s[EA_NB];
 #pragma unroll
     for (int kb = 0; kb < EA_NB; ++kb) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[kb][r], aq[qb][r], acc, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[kb][r], aq[r], acc, 0, 0, 0);
       s[kb] = acc;
     }
     // keys kb * 16 + 4 kg + r < len (mode 0 of csrc/attn.hip: every query, padded ones included, sees keys [0, len - 1])
@@ -182,18 +182,33 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
         mx = fmaxf(mx, s[kb][r]);
       }
     mx = ea_col_max(mx);
-    const int i = min(qb * 16 + li, T - 1);  // this lane's query
+    const int i = min(tq, T - 1);  // this lane's query
     const uint64_t rng_row = (((uint64_t)wave * g.B + b) * T + i) * (uint64_t)T;
+    // One hash per FOUR keys: a lane's four keys are consecutive, kantts_dropout_scale4 serves them from one hash whenever
+    // the row's first index is a multiple of 4 (one 64-bit hash per element was 13 of the first version's 28 us:
+    // profiles/r06_runJ_*, where a whole sequence's 8 x 64 x 64 probabilities were evaluated on ONE CU).
     float l = 0.f;
+    const bool quad_rng = (rng_row & 3ull) == 0ull;
 #pragma unroll
-    for (int kb = 0; kb < EA_NB; ++kb)
+    for (int kb = 0; kb < EA_NB; ++kb) {
+      float e4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = kb * 16 + kg * 4 + r;
-        const float e = (j < len) ? expf(s[kb][r] - mx) : 0.f;
-        l += e;
-        s[kb][r] = e * kantts_dropout_scale(g.att_p, att_seed, rng_row + j);
+        e4[r] = (j < len) ? expf(s[kb][r] - mx) : 0.f;
+        l += e4[r];
       }
+      if (g.att_p > 0.f) {
+        const uint64_t j0 = rng_row + (uint64_t)(kb * 16 + kg * 4);
+        if (quad_rng) {
+          kantts_dropout_scale4(g.att_p, att_seed, j0, e4);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e4[r] *= kantts_dropout_scale(g.att_p, att_seed, j0 + r);
+        }
+      }
+      s[kb] = (f32x4){e4[0], e4[1], e4[2], e4[3]};
+    }
     l = ea_col_sum(l);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -201,85 +216,66 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][r], s[kb][r], acc, 0, 0, 0);
     const float inv = (len > 0) ? 1.f / l : 0.f;
-    ao[qb] = acc * inv;
-    const int t = qb * 16 + li;
-    if (t < T) {
-      if (g.o) *reinterpret_cast<f32x4*>(g.o + (m0 + t) * EA_C + wave * 16 + kg * 4) = ao[qb];
-      if (kg == 0 && g.lse) g.lse[((long long)b * EA_H + wave) * T + t] = (len > 0) ? (mx + logf(l)) : 0.f;
+    ao = acc * inv;
+    if (live) {
+      if (g.o) *reinterpret_cast<f32x4*>(g.o + (m0 + tq) * EA_C + wave * 16 + kg * 4) = ao;
+      if (kg == 0 && g.lse) g.lse[((long long)b * EA_H + wave) * T + tq] = (len > 0) ? (mx + logf(l)) : 0.f;
     }
   }
-  __syncthreads();  // every wave has read the normalised rows: the tile becomes the context tile
-#pragma unroll
-  for (int qb = 0; qb < EA_NB; ++qb) {
-    const u32x2 pk = {ea_pack2(ao[qb][0], ao[qb][1]), ea_pack2(ao[qb][2], ao[qb][3])};
-    *reinterpret_cast<u32x2*>(&Xs[(qb * 16 + li) * EA_XP + wave * 16 + kg * 4]) = pk;
+  __syncthreads();  // every wave has read the normalised rows: rows 0..15 of the tile become the context tile
+  {
+    const u32x2 pk = {ea_pack2(ao[0], ao[1]), ea_pack2(ao[2], ao[3])};
+    *reinterpret_cast<u32x2*>(&Xs[li * EA_XP + wave * 16 + kg * 4]) = pk;
   }
   __syncthreads();
 
-  // ---- y1 = rowmask(dropout(fc(context)) + x): wave w -> output channels 16 w .. 16 w + 15 of every token
-  float y1v[EA_NB][4];
+  // ---- y1 = rowmask(dropout(fc(context)) + x): wave w -> output channels 16 w .. 16 w + 15 of the 16 tokens
+  float y1v[4];
   {
-    f32x4 acc[EA_NB];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tb = 0; tb < EA_NB; ++tb) acc[tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int tb = 0; tb < EA_NB; ++tb) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[(tb * 16 + li) * EA_XP + kk * 32 + kg * 8]);
-        acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wff[kk], (const bf16x8&)v, acc[tb], 0, 0, 0);
-      }
-    const uint64_t sdf = g.fc_seed + seed_off;
-#pragma unroll
-    for (int tb = 0; tb < EA_NB; ++tb) {
-      const long long m = m0 + tb * 16 + li;
-      float* o = y1v[tb];
-      o[0] = acc[tb][0] + bfc.x; o[1] = acc[tb][1] + bfc.y; o[2] = acc[tb][2] + bfc.z; o[3] = acc[tb][3] + bfc.w;
-      if (g.fc_p > 0.f) kantts_dropout_scale4(g.fc_p, sdf, (uint64_t)m * (uint64_t)EA_C + (uint64_t)n0, o);
-      o[0] += xres[tb].x; o[1] += xres[tb].y; o[2] += xres[tb].z; o[3] += xres[tb].w;
-      if (rz[tb] || !live[tb]) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = 0.f;
-      }
-      if (live[tb] && g.y1) *reinterpret_cast<f32x4*>(g.y1 + m * EA_C + n0) = (f32x4){o[0], o[1], o[2], o[3]};
+    for (int kk = 0; kk < 4; ++kk) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&Xs[li * EA_XP + kk * 32 + kg * 8]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wff[kk], (const bf16x8&)v, acc, 0, 0, 0);
     }
+    const uint64_t sdf = g.fc_seed + seed_off;
+    const long long m = m0 + tq;
+    y1v[0] = acc[0] + bfc.x; y1v[1] = acc[1] + bfc.y; y1v[2] = acc[2] + bfc.z; y1v[3] = acc[3] + bfc.w;
+    if (g.fc_p > 0.f) kantts_dropout_scale4(g.fc_p, sdf, (uint64_t)m * (uint64_t)EA_C + (uint64_t)n0, y1v);
+    y1v[0] += xres.x; y1v[1] += xres.y; y1v[2] += xres.z; y1v[3] += xres.w;
+    if (rz || !live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y1v[r] = 0.f;
+    }
+    if (live && g.y1) *reinterpret_cast<f32x4*>(g.y1 + m * EA_C + n0) = (f32x4){y1v[0], y1v[1], y1v[2], y1v[3]};
   }
   if (!g.xn1) return;  // (uniform) no consumer asked for the LayerNorm of y1
 
-  // ---- LayerNorm(128) of every token of y1: its channels sit in 4 lanes (kg) of each of the 8 waves
-  float mu[EA_NB], rs[EA_NB];
+  // ---- LayerNorm(128) of the 16 tokens of y1: a token's channels sit in 4 lanes (kg) of each of the 8 waves
+  float mu = 0.f, rs = 0.f;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
+    float t = 0.f;
 #pragma unroll
-    for (int tb = 0; tb < EA_NB; ++tb) {
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = pass ? y1v[tb][r] - mu[tb] : y1v[tb][r];
-        t += pass ? d * d : d;
-      }
-      t = ea_col_sum(t);
-      if (kg == 0) St[(pass * EA_H + wave) * EA_T + tb * 16 + li] = t;
+    for (int r = 0; r < 4; ++r) {
+      const float d = pass ? y1v[r] - mu : y1v[r];
+      t += pass ? d * d : d;
     }
+    t = ea_col_sum(t);
+    if (kg == 0) St[(pass * EA_H + wave) * 16 + li] = t;
     __syncthreads();
+    t = 0.f;
 #pragma unroll
-    for (int tb = 0; tb < EA_NB; ++tb) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < EA_H; ++w) t += St[(pass * EA_H + w) * EA_T + tb * 16 + li];
-      if (pass)
-        rs[tb] = 1.0f / sqrtf(t * (1.f / 128.f) + g.ln1_eps);
-      else
-        mu[tb] = t * (1.f / 128.f);
-    }
+    for (int w = 0; w < EA_H; ++w) t += St[(pass * EA_H + w) * 16 + li];
+    if (pass)
+      rs = 1.0f / sqrtf(t * (1.f / 128.f) + g.ln1_eps);
+    else
+      mu = t * (1.f / 128.f);
   }
-#pragma unroll
-  for (int tb = 0; tb < EA_NB; ++tb) {
-    if (!live[tb]) continue;
-    const long long m = m0 + tb * 16 + li;
-    const float* o = y1v[tb];
-    const float z0 = (o[0] - mu[tb]) * rs[tb] * l1g.x + l1b.x, z1 = (o[1] - mu[tb]) * rs[tb] * l1g.y + l1b.y;
-    const float z2 = (o[2] - mu[tb]) * rs[tb] * l1g.z + l1b.z, z3 = (o[3] - mu[tb]) * rs[tb] * l1g.w + l1b.w;
+  if (live) {
+    const long long m = m0 + tq;
+    const float z0 = (y1v[0] - mu) * rs * l1g.x + l1b.x, z1 = (y1v[1] - mu) * rs * l1g.y + l1b.y;
+    const float z2 = (y1v[2] - mu) * rs * l1g.z + l1b.z, z3 = (y1v[3] - mu) * rs * l1g.w + l1b.w;
     if (g.xn1_bf16) {
       const u32x2 pk = {ea_pack2(z0, z1), ea_pack2(z2, z3)};
       *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.xn1) + m * EA_C + n0) = pk;
@@ -287,8 +283,8 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
       *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.xn1) + m * EA_C + n0) = (f32x4){z0, z1, z2, z3};
     }
     if (wave == 0 && kg == 0 && g.mean1) {
-      g.mean1[m] = mu[tb];
-      g.rstd1[m] = rs[tb];
+      g.mean1[m] = mu;
+      g.rstd1[m] = rs;
     }
   }
 }
@@ -306,6 +302,6 @@ extern "C" int kantts_enc_attn_fwd(const kantts_enc_attn_args* gp, void* stream)
   const void* ps[] = {g.x, g.xn, g.wqkv, g.wfc, g.bqkv, g.bfc, g.ln1_gamma, g.ln1_beta, g.qkv, g.o, g.y1, g.xn1};
   for (const void* p : ps)
     if (!ea_aligned16(p)) return KANTTS_E_UNSUPPORTED;
-  hipLaunchKernelGGL(enc_attn_fwd_kernel, dim3(g.B), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(enc_attn_fwd_kernel, dim3(g.B, (g.L + 15) / 16), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
   KANTTS_CHECK_LAUNCH();
 }
