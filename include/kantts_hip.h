@@ -1172,7 +1172,7 @@ int kantts_ctc_attn(const kantts_ctc_args* args, void* stream);
  *   x (M, 128) fp32, M = B * L; xn (M, 128) bf16: LayerNorm of x (the caller's); lens (B) or NULL; rowmask (M) or NULL;
  *   wqkv / wfc: fragment-major bf16 images (kantts_fragmajor_bf16) of the (384, 128) / (128, 128) weights;
  *   written for the backward pass: qkv (M, 384) fp32, o (M, 128) contexts, lse (B, 8, L), y1 (M, 128), xn1 (M, 128) bf16 or
- *   fp32 (xn1_bf16) with mean1 / rstd1 (M).  d_model 128, 8 heads of 16, L <= 64 (KANTTS_E_UNSUPPORTED beyond). */
+ *   fp32 (xn1_bf16) with mean1 / rstd1 (M).  d_model 128, 8 heads of 16, L <= 128 (KANTTS_E_UNSUPPORTED beyond). */
 typedef struct kantts_enc_attn_args {
   const float* x;
   const void* xn;

@@ -7,7 +7,7 @@
 // over M = B * T = 2048 rows (kantts_bgemm_nt 12 us, kantts_attn_fwd 9 us, kantts_bgemm_nt 8-12 us: each launch-latency
 // sized, 2048 x 128 activations) per block, 8 blocks per forward pass.
 //
-// One workgroup per (sequence, block of 16 queries) (T <= 64 tokens: up to 4 workgroups per sequence, each recomputing the
+// One workgroup per (sequence, block of 16 queries) (T <= 128 tokens: up to 8 workgroups per sequence, each recomputing the
 // sequence's K and V -- 32 of its 36 projection MFMAs per wave -- so that the attention's VALU work, the softmax and the one
 // dropout hash per four keys, spreads over 4 CUs), WAVE = HEAD (8 waves, 8 heads of 16 channels):
 //   * Q^T, K^T of the wave's head come out of the bf16 MFMA (A = weight rows, B = normalised token rows from LDS) in the
@@ -40,8 +40,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define EA_THREADS 512
-#define EA_T 64             // tokens of a sequence a workgroup can hold
-#define EA_NB (EA_T / 16)   // token blocks
+#define EA_TMAX 128          // longest sequence (tokens): 8 token blocks of 16 (the 64-token instantiation holds 4)
 #define EA_C 128
 #define EA_H 8
 #define EA_XP (EA_C + 16)   // bf16 row pitch of the token tiles: 288 B = 32 mod 64
@@ -61,8 +60,9 @@ __device__ __forceinline__ float ea_col_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+template <int EA_NB>  // token blocks of 16 a sequence may have (4: T <= 64, 8: T <= 128)
 __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_enc_attn_args g) {
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[EA_T * EA_XP];  // normalised rows; rows 0..15 later hold the bf16 contexts
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[EA_NB * 16 * EA_XP];  // normalised rows; rows 0..15 later hold the contexts
   __shared__ float St[2 * EA_H * 16];                              // LayerNorm partial sums: [pass][wave][token]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = head
@@ -76,11 +76,12 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
   const float4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   // ---- global loads in consumption order: token rows, the head's q / k / v weight fragments, biases
-  u32x4 xr[2];
+  constexpr int NXR = EA_NB / 2;  // 16 EA_NB rows x 16 chunks of 16 B: EA_NB / 2 per thread (source row clamped, zeroed below)
+  u32x4 xr[NXR];
   {
     const __bf16* xn = reinterpret_cast<const __bf16*>(g.xn);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {  // 64 rows x 16 chunks of 16 B: 2 per thread (source row clamped, zeroed below)
+    for (int it = 0; it < NXR; ++it) {
       const int id = tid + EA_THREADS * it;
       const int row = min(id >> 4, T - 1);
       xr[it] = *reinterpret_cast<const u32x4*>(xn + (m0 + row) * EA_C + (id & 15) * 8);
@@ -100,14 +101,14 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
     bv = 0.f;
   }
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < NXR; ++it) {
     const int id = tid + EA_THREADS * it;
     const u32x4 v = ((id >> 4) < T) ? xr[it] : (u32x4){0u, 0u, 0u, 0u};
     *reinterpret_cast<u32x4*>(&Xs[(id >> 4) * EA_XP + (id & 15) * 8]) = v;
   }
   __syncthreads();
 
-  // ---- the head's K^T (channels x tokens) and V (tokens x channels) of all 64 tokens, Q^T of the workgroup's 16 queries
+  // ---- the head's K^T (channels x tokens) and V (tokens x channels) of all tokens, Q^T of the workgroup's 16 queries
   f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak[EA_NB], av[EA_NB];
 #pragma unroll
   for (int tb = 0; tb < EA_NB; ++tb) ak[tb] = av[tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -297,11 +298,14 @@ extern "C" int kantts_enc_attn_fwd(const kantts_enc_attn_args* gp, void* stream)
   if (g.B < 0 || g.L < 0) return KANTTS_E_BADARG;
   if (g.B == 0 || g.L == 0) return KANTTS_OK;
   if (!g.x || !g.xn || !g.wqkv || !g.wfc || !g.ln1_gamma || !g.ln1_beta || !g.y1) return KANTTS_E_BADARG;
-  if (g.L > EA_T) return KANTTS_E_UNSUPPORTED;  // one workgroup holds a sequence of up to 64 tokens
+  if (g.L > EA_TMAX) return KANTTS_E_UNSUPPORTED;  // a workgroup holds K and V of a sequence of up to 128 tokens
   if (g.xn1 && (!g.mean1 || !g.rstd1)) return KANTTS_E_BADARG;
   const void* ps[] = {g.x, g.xn, g.wqkv, g.wfc, g.bqkv, g.bfc, g.ln1_gamma, g.ln1_beta, g.qkv, g.o, g.y1, g.xn1};
   for (const void* p : ps)
     if (!ea_aligned16(p)) return KANTTS_E_UNSUPPORTED;
-  hipLaunchKernelGGL(enc_attn_fwd_kernel, dim3(g.B, (g.L + 15) / 16), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
+  if (g.L <= 64)
+    hipLaunchKernelGGL(enc_attn_fwd_kernel<4>, dim3(g.B, (g.L + 15) / 16), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(enc_attn_fwd_kernel<8>, dim3(g.B, (g.L + 15) / 16), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
   KANTTS_CHECK_LAUNCH();
 }

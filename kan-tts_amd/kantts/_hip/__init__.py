@@ -925,7 +925,7 @@ def dur_ar_run(w, f, gc, out, lens32):
 
 def enc_attn_fwd(x, xn, B, L, *, lens, rowmask, wqkv, bqkv, wfc, bfc, ln1, att_p, fc_p, seeds, qkv, o, lse, y1, xn1, mean1, rstd1):
     """The attention sub-layer of an encoder block in one launch (csrc/enc_attn.hip; kantts_enc_attn_fwd in the header).
-    Returns False when the library declines the shape (L > 64)."""
+    Returns False when the library declines the shape (L > 128)."""
     g = EncAttnArgs()
     g.x, g.xn = ptr(x, torch.float32), ptr(xn, torch.bfloat16)
     g.lens, g.rowmask = ptr(lens, torch.int32), ptr(rowmask)

@@ -456,10 +456,10 @@ def enc_attn_fused(att, x, info, rows, return_attn, next_ln, training):
     """Context manager for kantts.models.sambert.MultiHeadSelfAttention.forward: launches the whole sub-layer's forward pass
     (csrc/enc_attn.hip: QKV projection, 8-head attention, output projection + dropout + residual + row mask, the consumer's
     LayerNorm) and lets the three ops inside the ``with`` adopt its results (the protocol of pnca_block_fused); a no-op context
-    when the launch does not apply (other shapes, sequences of more than 64 tokens, attention maps requested, no consumer
+    when the launch does not apply (other shapes, sequences of more than 128 tokens, attention maps requested, no consumer
     LayerNorm, KANTTS_NO_ENC_ATTN)."""
     if (not ENC_ATTN["on"] or not PRENORM["on"] or return_attn or next_ln is None or not torch.is_tensor(x) or x.dim() != 3
-            or x.dtype != torch.float32 or x.shape[-1] != 128 or x.numel() == 0 or x.shape[1] > 64
+            or x.dtype != torch.float32 or x.shape[-1] != 128 or x.numel() == 0 or x.shape[1] > 128
             or att.n_head != 8 or att.d_head != 16 or att.d_model != 128 or att.d_in != 128 or att.fc.out_features != 128
             or next_ln.weight.numel() != 128 or att.w_qkv.bias is None or att.fc.bias is None):
         return contextlib.nullcontext()

@@ -555,7 +555,7 @@ class EmulatedLib:
         B, L, C = g.B, g.L, 128
         if B == 0 or L == 0:
             return 0
-        if L > 64:
+        if L > 128:
             return -2
         M = B * L
         soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0

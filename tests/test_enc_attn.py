@@ -90,6 +90,7 @@ _CASES = [
     dict(B=3, L=64, lens=[30, 64, 1], drop=0.1),                # the largest sequence a workgroup holds; one-key attention
     dict(B=2, L=16, lens=[16, 9], drop=0.1, private=True),      # one token block; input row mask travelling on the tensor
     dict(B=1, L=5, lens=[5], drop=0.0),
+    dict(B=2, L=100, lens=[100, 77], drop=0.1),                 # the 8-token-block instantiation (65 .. 128 tokens)
 ]
 _ID = lambda k: "B%d-L%d-p%g" % (k["B"], k["L"], k["drop"])  # noqa: E731
 
@@ -108,9 +109,9 @@ def test_fused_sublayer_equals_the_chain_kernel_source(kw):
 
 
 def test_longer_sequences_keep_the_chain_emulated():
-    """More than 64 tokens per sequence: the launch does not apply, the sub-layer runs its three launches."""
+    """More than 128 tokens per sequence: the launch does not apply, the sub-layer runs its three launches."""
     with emulation():
-        f, c = _case("cpu", B=1, L=70, lens=[66], drop=0.0)
+        f, c = _case("cpu", B=1, L=130, lens=[129], drop=0.0)
         _compare(f, c, expect_fused=False)
 
 
