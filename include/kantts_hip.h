@@ -1200,28 +1200,6 @@ typedef struct kantts_enc_attn_args {
 } kantts_enc_attn_args;
 int kantts_enc_attn_fwd(const kantts_enc_attn_args* args, void* stream);
 
-/* kantts_enc_attn_bwd: the middle of that sub-layer's backward as ONE launch, a workgroup per (sequence, head): the output
- * projection's input gradient  d_ctx = dropout_fc(dz) . W_fc  (the kantts_bgemm_nt launch of the chain; bf16 operands, the
- * dropout of the forward pass regenerated from fc_seed) and the attention backward of mode 0 (kantts_attn_bwd) on it --
- * d_ctx itself is never written.
- *   dz (M, 128) fp32: gradient of the projection's output BEFORE its dropout (rows already masked by the caller);
- *   wfcT: fragment-major bf16 image of W_fc^T (128 x 128); qkv (M, 384), o (M, 128), lse (B, 8, L): as saved by the forward;
- *   dqkv (M, 384) fp32: [dq | dk | dv], every element written.  L <= 64 (KANTTS_E_UNSUPPORTED beyond). */
-typedef struct kantts_enc_attn_bwd_args {
-  const float* dz;
-  const void* wfcT;
-  const float* qkv;
-  const float* o;
-  const float* lse;
-  const int32_t* lens;
-  float att_p, fc_p;
-  uint64_t att_seed, fc_seed;
-  const uint64_t* seed_dev;
-  float* dqkv;
-  int B, L;
-} kantts_enc_attn_bwd_args;
-int kantts_enc_attn_bwd(const kantts_enc_attn_bwd_args* args, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

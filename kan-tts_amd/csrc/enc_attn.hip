@@ -290,184 +290,6 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(const kantts_e
   }
 }
 
-// ================================================================================================================
-// BACKWARD of the sub-layer's middle: the output projection's input gradient and the attention backward as one launch.
-//
-//   d_ctx = dropout_fc(dz) . W_fc          (kantts_bgemm_nt input-gradient form of ops_bf16._FusedLinearB.backward: bf16 operands)
-//   dq, dk, dv = attention backward of every head (kantts_attn_bwd, mode 0: csrc/attn.hip)
-//
-// Attention backward is independent per head, and d_ctx of head h is 16 columns of the projection's input gradient: a
-// workgroup per (sequence, head) computes its own 16 columns of d_ctx on the bf16 MFMA and everything else from there on the
-// fp32 MFMA -- no cross-workgroup sum, the 2048 x 128 d_ctx never exists in memory.  (The QKV projection's input gradient
-// needs all heads of a token and stays a launch of its own, with the first LayerNorm's backward in its epilogue.)
-//
-// Register layouts as in the forward kernel ("K-like": lane (kg, li) = token li, channels 4 kg + r -- a float4 of a row;
-// "V-like": lane (kg, li) = channel li, tokens 4 kg + r): with queries in the columns
-//     S^T = K Q^T, dP^T = V dO^T            A = K-like K / V,   B = K-like Q / dO          (contraction over channels)
-//     dQ^T += K^T dS^T                      A = V-like K,       B = dS^T accumulator       (contraction over keys)
-// and the probabilities p = exp(s - lse), the dropout factor (one hash per four keys) and ds = p (dp - D) / 4 are elementwise
-// on the accumulators.  dK and dV contract over QUERIES: the tiles P' = p * drop and dS go through LDS once (written as
-// [key][query], read back as four consecutive queries of a key = a float4) and become the B operands of
-//     dK^T += Q^T dS,  dV^T += dO^T P'       A = V-like Q / dO
-// Waves 0..3 each own a block of 16 queries (first phase), then all eight waves own (a block of 16 keys, dK or dV).
-#define EB_PP 68  // fp32 row pitch of the [key][query] tiles (64 queries + 4: rows 16-byte aligned, 4 banks apart)
-
-__global__ __launch_bounds__(EA_THREADS) void enc_attn_bwd_kernel(const kantts_enc_attn_bwd_args g) {
-  constexpr int NB = 4;  // token blocks: T <= 64
-  __shared__ __attribute__((aligned(16))) __bf16 Zs[NB * 16 * EA_XP];  // dropout_fc(dz) of the sequence, bf16
-  __shared__ __attribute__((aligned(16))) float Ps[NB * 16 * EB_PP];   // P' = p * drop  [key][query]
-  __shared__ __attribute__((aligned(16))) float Ds[NB * 16 * EB_PP];   // dS             [key][query]
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kg = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x, h = blockIdx.y, T = g.L;
-  const long long m0 = (long long)b * T;
-  const int len = g.lens ? min(max(g.lens[b], 0), T) : T;
-  const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
-  const __bf16* __restrict__ wt = reinterpret_cast<const __bf16*>(g.wfcT);
-  const float* qkv = g.qkv;
-
-  // ---- dropout_fc(dz) of the sequence -> LDS (bf16): 64 rows x 32 chunks of 4 floats, 4 per thread
-  {
-    const uint64_t sdf = g.fc_seed + seed_off;
-    float4 zr[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int id = tid + EA_THREADS * it;
-      const int row = min(id >> 5, T - 1);
-      zr[it] = *reinterpret_cast<const float4*>(g.dz + (m0 + row) * EA_C + (id & 31) * 4);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int id = tid + EA_THREADS * it;
-      const int row = id >> 5, c = (id & 31) * 4;
-      float v[4] = {zr[it].x, zr[it].y, zr[it].z, zr[it].w};
-      if (row < T) {
-        if (g.fc_p > 0.f) kantts_dropout_scale4(g.fc_p, sdf, (uint64_t)(m0 + row) * (uint64_t)EA_C + (uint64_t)c, v);
-      } else {
-        v[0] = v[1] = v[2] = v[3] = 0.f;
-      }
-      const u32x2 pk = {ea_pack2(v[0], v[1]), ea_pack2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(&Zs[row * EA_XP + c]) = pk;
-    }
-  }
-  // W_fc^T rows 16 h .. 16 h + 15 (the head's context channels), fragment-major: 4 reduction blocks of 32 output channels
-  u32x4 wf[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) wf[kk] = *reinterpret_cast<const u32x4*>(wt + ((long long)(h * 4 + kk)) * 512 + lane * 8);
-  __syncthreads();
-
-  const int qcol = h * 16, kcol = EA_C + h * 16, vcol = 2 * EA_C + h * 16;
-  const uint64_t att_seed = g.att_seed + seed_off;
-  // d_ctx of a token block in both layouts, from the same fragments (operand roles swapped)
-  auto dctx_klike = [&](int tb) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(&Zs[(tb * 16 + li) * EA_XP + kk * 32 + kg * 8]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)wf[kk], (const bf16x8&)v, acc, 0, 0, 0);
-    }
-    return acc;
-  };
-  auto dctx_vlike = [&](int tb) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(&Zs[(tb * 16 + li) * EA_XP + kk * 32 + kg * 8]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16((const bf16x8&)v, (const bf16x8&)wf[kk], acc, 0, 0, 0);
-    }
-    return acc;
-  };
-  auto row_klike = [&](const float* base, int ld, int col, int tb) {  // float4 of token tb*16 + li, channels col + 4 kg ..
-    const int t = min(tb * 16 + li, T - 1);
-    return *reinterpret_cast<const f32x4*>(base + (m0 + t) * ld + col + kg * 4);
-  };
-  auto rows_vlike = [&](const float* base, int ld, int col, int tb) {  // channel col + li of tokens tb*16 + 4 kg + r
-    f32x4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int t = min(tb * 16 + kg * 4 + r, T - 1);
-      v[r] = base[(m0 + t) * ld + col + li];
-    }
-    return v;
-  };
-
-  if (wave < NB) {
-    // ---- first phase: queries qb * 16 .. + 15 against every key
-    const int qb = wave;
-    const f32x4 aq = row_klike(qkv, 3 * EA_C, qcol, qb);
-    const f32x4 ao = row_klike(g.o, EA_C, qcol, qb);
-    const f32x4 dO = dctx_klike(qb);
-    const int i = min(qb * 16 + li, T - 1);  // this lane's query
-    const float lse = g.lse[((long long)b * EA_H + h) * T + i];
-    float D = dO[0] * ao[0] + dO[1] * ao[1] + dO[2] * ao[2] + dO[3] * ao[3];
-    D = ea_col_sum(D);
-    const uint64_t rng_row = (((uint64_t)h * g.B + b) * T + i) * (uint64_t)T;
-    const bool quad_rng = (rng_row & 3ull) == 0ull;
-    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      const f32x4 ak = row_klike(qkv, 3 * EA_C, kcol, kb);
-      const f32x4 av = row_klike(qkv, 3 * EA_C, vcol, kb);
-      const f32x4 akv = rows_vlike(qkv, 3 * EA_C, kcol, kb);
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[r], aq[r], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], dO[r], dp, 0, 0, 0);
-      }
-      float dsc[4] = {1.f, 1.f, 1.f, 1.f};
-      if (g.att_p > 0.f) {
-        const uint64_t j0 = rng_row + (uint64_t)(kb * 16 + kg * 4);
-        if (quad_rng) {
-          kantts_dropout_scale4(g.att_p, att_seed, j0, dsc);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dsc[r] = kantts_dropout_scale(g.att_p, att_seed, j0 + r);
-        }
-      }
-      f32x4 ds;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = kb * 16 + kg * 4 + r;  // key of accumulator element r
-        const float p = (j < len) ? expf(s[r] * 0.25f - lse) : 0.f;
-        ds[r] = p * (dp[r] * dsc[r] - D) * 0.25f;
-        // [key][query] tiles for the second phase (queries of a key are consecutive: a wave writes 16 x 64-byte pieces)
-        Ps[j * EB_PP + qb * 16 + li] = p * dsc[r];
-        Ds[j * EB_PP + qb * 16 + li] = ds[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dq = __builtin_amdgcn_mfma_f32_16x16x4f32(akv[r], ds[r], dq, 0, 0, 0);
-    }
-    if (qb * 16 + li < T) *reinterpret_cast<f32x4*>(g.dqkv + (m0 + qb * 16 + li) * (3 * EA_C) + qcol + kg * 4) = dq;
-  }
-  __syncthreads();
-
-  // ---- second phase: wave = (block of 16 keys, dK | dV): contraction over the queries
-  {
-    const int kb = wave & 3;
-    const bool is_v = wave >= NB;
-    const float* tile = is_v ? Ps : Ds;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int qb = 0; qb < NB; ++qb) {
-      const f32x4 a = is_v ? dctx_vlike(qb) : rows_vlike(qkv, 3 * EA_C, qcol, qb);
-      // B[k <-> query 4 kg + r][j <-> key li]: four consecutive queries of key kb * 16 + li
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(&tile[(kb * 16 + li) * EB_PP + qb * 16 + kg * 4]);
-      f32x4 bm = bt;
-      if (qb * 16 + kg * 4 + 3 >= T) {  // queries past the sequence (T not a multiple of 16) contribute nothing
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (qb * 16 + kg * 4 + r >= T) bm[r] = 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], bm[r], acc, 0, 0, 0);
-    }
-    // lane (kg, li): key kb * 16 + li, channels 4 kg + r
-    if (kb * 16 + li < T)
-      *reinterpret_cast<f32x4*>(g.dqkv + (m0 + kb * 16 + li) * (3 * EA_C) + (is_v ? vcol : kcol) + kg * 4) = acc;
-  }
-}
-
 static bool ea_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int kantts_enc_attn_fwd(const kantts_enc_attn_args* gp, void* stream) {
@@ -485,19 +307,5 @@ extern "C" int kantts_enc_attn_fwd(const kantts_enc_attn_args* gp, void* stream)
     hipLaunchKernelGGL(enc_attn_fwd_kernel<4>, dim3(g.B, (g.L + 15) / 16), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
   else
     hipLaunchKernelGGL(enc_attn_fwd_kernel<8>, dim3(g.B, (g.L + 15) / 16), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
-  KANTTS_CHECK_LAUNCH();
-}
-
-extern "C" int kantts_enc_attn_bwd(const kantts_enc_attn_bwd_args* gp, void* stream) {
-  if (!gp) return KANTTS_E_BADARG;
-  const kantts_enc_attn_bwd_args& g = *gp;
-  if (g.B < 0 || g.L < 0) return KANTTS_E_BADARG;
-  if (g.B == 0 || g.L == 0) return KANTTS_OK;
-  if (!g.dz || !g.wfcT || !g.qkv || !g.o || !g.lse || !g.dqkv) return KANTTS_E_BADARG;
-  if (g.L > 64) return KANTTS_E_UNSUPPORTED;  // the [key][query] tiles of a head hold 64 x 64 probabilities
-  const void* ps[] = {g.dz, g.wfcT, g.qkv, g.o, g.dqkv};
-  for (const void* p : ps)
-    if (!ea_aligned16(p)) return KANTTS_E_UNSUPPORTED;
-  hipLaunchKernelGGL(enc_attn_bwd_kernel, dim3(g.B, EA_H), dim3(EA_THREADS), 0, (hipStream_t)stream, g);
   KANTTS_CHECK_LAUNCH();
 }

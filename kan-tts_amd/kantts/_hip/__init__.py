@@ -296,13 +296,6 @@ class EncAttnArgs(Structure):
                 ("L", c_int32)]
 
 
-class EncAttnBwdArgs(Structure):
-    """kantts_enc_attn_bwd_args (include/kantts_hip.h)."""
-    _fields_ = [("dz", c_void_p), ("wfcT", c_void_p), ("qkv", c_void_p), ("o", c_void_p), ("lse", c_void_p),
-                ("lens", c_void_p), ("att_p", c_float), ("fc_p", c_float), ("att_seed", c_uint64), ("fc_seed", c_uint64),
-                ("seed_dev", c_void_p), ("dqkv", c_void_p), ("B", c_int32), ("L", c_int32)]
-
-
 class CtcArgs(Structure):
     """kantts_ctc_args (include/kantts_hip.h)."""
     _fields_ = [("logits", c_void_p), ("in_lens", c_void_p), ("out_lens", c_void_p), ("ws", c_void_p), ("loss", c_void_p),
@@ -409,7 +402,6 @@ def lib():
         L.kantts_dur_ar_run.argtypes = [POINTER(DurArArgs), c_void_p]
         L.kantts_dur_ar_run_f32.argtypes = [POINTER(DurArArgs), c_void_p]
         L.kantts_enc_attn_fwd.argtypes = [POINTER(EncAttnArgs), c_void_p]
-        L.kantts_enc_attn_bwd.argtypes = [POINTER(EncAttnBwdArgs), c_void_p]
         L.kantts_ctc_attn.argtypes = [POINTER(CtcArgs), c_void_p]
         L.kantts_ctc_attn_workspace.argtypes = [c_int, c_int, c_int]
         L.kantts_ctc_attn_workspace.restype = c_longlong
@@ -465,7 +457,7 @@ EXPORTED_SYMBOLS = [
     "kantts_mean_many", "kantts_scale_to_many", "kantts_elem_loss_many", "kantts_conv_n1_launch",
     "kantts_pnca_block_fwd", "kantts_pnca_block_bwd", "kantts_pnca_block_bwd_ws_floats", "kantts_rows_sum_many",
     "kantts_melspec_tuning", "kantts_teacher_plan", "kantts_copy_roof", "kantts_pnca_attn_qkv_bwd",
-    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_dur_ar_run_f32", "kantts_ctc_attn", "kantts_ctc_attn_workspace", "kantts_enc_attn_fwd", "kantts_enc_attn_bwd",
+    "kantts_pnca_decode_run", "kantts_pnca_decode_blob_sizes", "kantts_dur_ar_run", "kantts_dur_ar_run_f32", "kantts_ctc_attn", "kantts_ctc_attn_workspace", "kantts_enc_attn_fwd",
     "kantts_launch_tuning",
 ]
 
@@ -950,23 +942,6 @@ def enc_attn_fwd(x, xn, B, L, *, lens, rowmask, wqkv, bqkv, wfc, bfc, ln1, att_p
     if rc == E_UNSUPPORTED:
         return False
     check(rc, "enc_attn_fwd")
-    return True
-
-
-def enc_attn_bwd(dz, wfcT, qkv, o, lse, lens, B, L, *, att_p, att_seed, fc_p, fc_seed, dqkv):
-    """The output projection's input gradient + the attention backward of an encoder block in one launch
-    (csrc/enc_attn.hip; kantts_enc_attn_bwd in the header).  Returns False when the library declines the shape (L > 64)."""
-    g = EncAttnBwdArgs()
-    g.dz, g.wfcT = ptr(dz, torch.float32), ptr(wfcT, torch.bfloat16)
-    g.qkv, g.o, g.lse, g.lens = ptr(qkv, torch.float32), ptr(o, torch.float32), ptr(lse, torch.float32), ptr(lens, torch.int32)
-    g.att_p, g.fc_p, g.att_seed, g.fc_seed = float(att_p), float(fc_p), int(att_seed), int(fc_seed)
-    g.seed_dev = rng_ptr(dz.device) if (att_p > 0 or fc_p > 0) else None
-    g.dqkv = ptr(dqkv, torch.float32)
-    g.B, g.L = int(B), int(L)
-    rc = lib().kantts_enc_attn_bwd(ctypes.byref(g), stream())
-    if rc == E_UNSUPPORTED:
-        return False
-    check(rc, "enc_attn_bwd")
     return True
 
 

@@ -739,7 +739,6 @@ class _SelfAttention(torch.autograd.Function):
             # computed by the fused sub-layer launch (ops_bf16.enc_attn_fused): same values, same dropout stream
             assert not want_probs
             o, lse, seed, probs = ad["o"], ad["lse"], ad["seed"], None
-            ctx.enc_bwd = ad.get("enc_bwd")
         else:
             seed = next_seed() if drop_p > 0 else 0
             o, lse, probs = _attn_fwd(q2, 0, q2, D, q2, 2 * D, lens, None, 0, B, H, L, MODE_KEYPAD, drop_p, seed,
@@ -757,22 +756,6 @@ class _SelfAttention(torch.autograd.Function):
         q2, o, lse, lens = ctx.saved_tensors
         B, H, L, drop_p, seed = ctx.cfg
         D = H * 16
-        plan = getattr(ctx, "enc_bwd", None)
-        if plan is not None and plan.dz is not None:
-            # fused encoder sub-layer: the output projection's node deposited its masked gradient instead of launching its
-            # input gradient; one launch forms that gradient per head and runs the attention backward on it
-            if d_o.data_ptr() != plan.placeholder.data_ptr() or d_o.numel() != plan.placeholder.numel():
-                raise RuntimeError("the context gradient of a fused encoder attention sub-layer is formed inside its backward "
-                                   "launch, but autograd delivers another tensor than the stand-in: the context has a second "
-                                   "consumer")
-            from . import enc_attn_bwd
-
-            dqkv = torch.empty_like(q2)
-            dz, plan.dz, plan.placeholder = plan.dz, None, None
-            if enc_attn_bwd(dz, plan.wfcT, q2, o, lse, lens, B, L, att_p=drop_p, att_seed=seed, fc_p=plan.fc_p,
-                            fc_seed=plan.fc_seed, dqkv=dqkv):
-                return dqkv.view(B, L, 3 * D), None, None, None, None
-            raise RuntimeError("kantts_enc_attn_bwd declined a sub-layer its forward launch accepted")
         d_o = _c(d_o).view(B * L, D)
         dqkv = torch.empty_like(q2)
         _attn_bwd(q2, 0, q2, D, q2, 2 * D, o, d_o, lse, dqkv, 0, dqkv, D, dqkv, 2 * D, 0, lens, None, 0, B, H, L,

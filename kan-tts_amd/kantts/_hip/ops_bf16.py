@@ -450,23 +450,6 @@ def pnca_block_fused(blk, x, hkv, info, bw_x, bw_h, bw_dev, return_attn, next_ln
 
 # A/B switch: KANTTS_NO_ENC_ATTN=1 keeps the three launches of an encoder block's attention sub-layer
 ENC_ATTN = {"on": not os.environ.get("KANTTS_NO_ENC_ATTN")}
-# A/B switch: KANTTS_NO_ENC_ATTN_BWD=1 keeps the two launches of the middle of its backward (output projection's input gradient,
-# attention backward)
-ENC_ATTN_BWD = {"on": not os.environ.get("KANTTS_NO_ENC_ATTN_BWD")}
-
-
-class _EncAttnBwd:
-    """Hand-over between the two backward nodes in the middle of a fused encoder attention sub-layer.  The output projection's
-    node runs first: instead of launching its input gradient it deposits what that launch would read (the masked gradient,
-    the dropout stream of its forward pass) here and hands autograd its saved input as a stand-in; the attention node checks
-    that autograd delivers exactly that stand-in (anything else: the context tensor had another consumer, refused) and runs
-    kantts_enc_attn_bwd (csrc/enc_attn.hip), which forms the input gradient per head on the fly."""
-    __slots__ = ("wfcT", "dz", "fc_p", "fc_seed", "placeholder")
-
-    def __init__(self, wfcT):
-        self.wfcT = wfcT
-        self.dz = self.placeholder = None
-        self.fc_p, self.fc_seed = 0.0, 0
 
 
 def enc_attn_fused(att, x, info, rows, return_attn, next_ln, training):
@@ -524,13 +507,10 @@ def enc_attn_fused(att, x, info, rows, return_attn, next_ln, training):
                       att_p=att_p, fc_p=fc_p, seeds=(sa, sf), qkv=qkv, o=o, lse=lse, y1=y1, xn1=xn1, mean1=mean1, rstd1=rstd1)
     if not ok:
         raise RuntimeError("kantts_enc_attn_fwd declined a sub-layer enc_attn_fused() accepted")
-    plan = None
-    if ENC_ATTN_BWD["on"] and L <= 64 and torch.is_grad_enabled() and x.requires_grad:
-        plan = _EncAttnBwd(lin_fragT(att.fc.weight))
     return _adopting([
         ("linear", dict(y=qkv.view(M, 384), seed=0, ln=None)),
-        ("attn", dict(o=o, lse=lse, seed=sa, enc_bwd=plan)),
-        ("linear", dict(y=y1, seed=sf, ln=(xn1, mean1, rstd1), enc_bwd=plan)),
+        ("attn", dict(o=o, lse=lse, seed=sa)),
+        ("linear", dict(y=y1, seed=sf, ln=(xn1, mean1, rstd1))),
     ])
 
 
@@ -587,7 +567,6 @@ class _FusedLinearB(torch.autograd.Function):
                 pre.xn, pre.mean, pre.rstd = ad["ln"]
                 pre.bwd = ad.get("bwd")  # travels to the LayerNorm node that adopts these rows (_BlockBwd)
             opts["bwd"] = ad.get("bwd")
-            opts["enc_bwd"] = ad.get("enc_bwd")  # fused encoder sub-layer: this node's input gradient moves into the attention's launch
             if ad.get("qkv_of") is not None:  # the QKV projection of a fused block: its LayerNorm's token goes to the plan
                 ad["qkv_of"].tok0 = opts.get("lnbwd")
         else:
@@ -693,13 +672,6 @@ class _FusedLinearB(torch.autograd.Function):
                 wb = wbs[0] if mode == "concat" else wbs[k]
                 woff = off if mode == "concat" else 0
                 wld = ldw if mode == "concat" else kk
-                eplan = opts.get("enc_bwd")
-                if (eplan is not None and needs[5 + k] and nx == 1 and mode != "conv" and not relu and balpha == 1.0
-                        and dz.dtype == torch.float32 and x.dtype == torch.float32 and kk == 128 and N == 128):
-                    # fused encoder attention sub-layer: the attention node's launch (kantts_enc_attn_bwd) forms this input
-                    # gradient per head from dz; autograd gets the saved input as a stand-in (_EncAttnBwd)
-                    eplan.dz, eplan.fc_p, eplan.fc_seed, eplan.placeholder = dz, a_drop_p, a_seed, x
-                    dxs[k] = x
                 tok = opts.get("lnbwd") if (needs[5 + k] and a_drop_p == 0 and balpha == 1.0) else None
                 if tok is not None and tok.by_block and tok.dx is not None and tok.placeholder is None:
                     # the input gradient AND the LayerNorm backward came out of the block's backward launch

@@ -597,32 +597,6 @@ class EmulatedLib:
             _arr(g.rstd1, M)[:] = rs.numpy()
         return 0
 
-    def kantts_enc_attn_bwd(self, args_ref, stream):
-        """csrc/enc_attn.hip: the output projection's input gradient (bf16 operands, the forward's dropout regenerated) and
-        this emulation's kantts_attn_bwd (mode 0) on it."""
-        g = args_ref._obj
-        B, L, C = g.B, g.L, 128
-        if B == 0 or L == 0:
-            return 0
-        if L > 64:
-            return -2
-        M = B * L
-        soff = int(_arr(g.seed_dev, 1, np.int64)[0]) if g.seed_dev else 0
-        dz = _rd2d(g.dz, M, C, C, False)
-        if g.fc_p > 0:
-            rows = np.arange(M, dtype=np.int64)
-            dz = dz * dropout_scale(g.fc_p, g.fc_seed + soff, rows[:, None] * C + np.arange(C, dtype=np.int64)[None, :])
-        # d_ctx[m][c] = sum_n dz'[m][n] W[n][c]; the image holds W^T (rows c, columns n)
-        dctx = np.ascontiguousarray((_bf16_round(dz.astype(np.float32)) @ _unfrag(g.wfcT, C, C).T).astype(np.float32))
-        dqkv = np.zeros((M, 3 * C), dtype=np.float32)
-        dvec = np.zeros(B * 8 * L, dtype=np.float32)
-        q0, d0 = int(g.qkv), dqkv.ctypes.data
-        self.kantts_attn_bwd(q0, q0 + 4 * C, q0 + 8 * C, 3 * C, 3 * C, 3 * C, g.o, C, dctx.ctypes.data, C, g.lse,
-                             dvec.ctypes.data, d0, d0 + 4 * C, d0 + 8 * C, 3 * C, 3 * C, 3 * C, 0, g.lens, None, 0, B, 8, L, 16, 0,
-                             g.att_p, g.att_seed, g.seed_dev, stream)
-        _wr(g.dqkv, dqkv, False)
-        return 0
-
     def kantts_pnca_attn_qkv_bwd(self, args_ref, stream):
         """csrc/pnca_block.hip: kantts_pnca_attn_bwd (summed query gradients) + the QKV projection's input gradient rounded
         to bf16 + kantts_ln128_bwd_rows with partial rows."""
