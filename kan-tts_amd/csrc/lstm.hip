@@ -197,6 +197,117 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
     if (tid < LH) outb[(long long)tt * ndir * LH + tid] = 0.f;
 }
 
+// [round 6] A PAIR of lanes per cell (256 threads = one wave per SIMD) instead of a quad (512 threads = two waves per SIMD),
+// bf16 mode -- measured 0.569 against 0.607 us per step (postnet recurrence, 612 steps: 348 against 372 us,
+// profiles/r06_runT_lstm_pair_vs_quad.log; KANTTS_LSTM_PAIR=0 selects the quad kernel, which also stays the fp32 form):
+// the dot products of a step are the same 512 issue cycles per SIMD either way, but everything
+// else of a step -- the activation, the cell update, the stores, which every lane of a cell executes redundantly -- is issued
+// by HALF as many lanes, and one wave per SIMD has no second wave's redundant work in its way.  Lane p of a pair holds columns
+// [64 p, 64 p + 64) of the four gate rows of its cell (256 weights as 128 packed pairs); after the dot products one DPP
+// exchange leaves lane 0 with the gates (i, f) and lane 1 with (g, o); each applies its two activations, a second exchange
+// gives both lanes all four.
+__global__ __launch_bounds__(256) void lstm_fwd_pair_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                           const float* __restrict__ bhh, const int32_t* __restrict__ lens,
+                                                           float* __restrict__ out, float* __restrict__ gates_out,
+                                                           float* __restrict__ c_out, int B, int T, int ndir,
+                                                           int reverse_first) {
+  __shared__ __attribute__((aligned(16))) __bf16 h_b[2][LH];
+  const int tid = threadIdx.x, j = tid >> 1, p = tid & 1;
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const bool rev = reverse_first ? true : (dir == 1);
+  const int len = lens ? min(lens[b], T) : T;
+  lstm_bf16x2 wq[4 * 32];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4* wp = reinterpret_cast<const float4*>(whh + ((long long)dir * LG + g * LH + j) * LH + p * 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 t = wp[k];
+      wq[g * 32 + 2 * k] = (lstm_bf16x2){(__bf16)t.x, (__bf16)t.y};
+      wq[g * 32 + 2 * k + 1] = (lstm_bf16x2){(__bf16)t.z, (__bf16)t.w};
+    }
+  }
+  // lane p brings in gx + bias of the gates 2 p and 2 p + 1
+  const float bias0 = bhh ? bhh[dir * LG + (2 * p) * LH + j] : 0.f;
+  const float bias1 = bhh ? bhh[dir * LG + (2 * p + 1) * LH + j] : 0.f;
+  if (p == 0) h_b[0][j] = (__bf16)0.f;
+  float c = 0.f;
+  const long long gx_ld = (long long)ndir * LG;
+  const float* gxb = gx + (long long)b * T * gx_ld + dir * LG + (2 * p) * LH + j;
+  float* outb = out + (long long)b * T * ndir * LH + dir * LH;
+  float* gob = gates_out + (((long long)dir * B + b) * T) * LG + (2 * p) * LH + j;
+  float* cob = c_out + (((long long)dir * B + b) * T) * LH;
+  __syncthreads();
+  constexpr int PF = 8;
+  float gq0[PF], gq1[PF], gn0[PF], gn1[PF];
+  const int last = len > 0 ? len - 1 : 0;
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int su = min(u, last);
+    const long long o = (long long)(rev ? last - su : su) * gx_ld;
+    gq0[u] = gxb[o];
+    gq1[u] = gxb[o + LH];
+  }
+  int cur = 0;
+  for (int step0 = 0; step0 < len; step0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int sn = min(step0 + PF + u, last);
+      const long long o = (long long)(rev ? last - sn : sn) * gx_ld;
+      gn0[u] = gxb[o];
+      gn1[u] = gxb[o + LH];
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int step = step0 + u;
+      if (step < len) {  // uniform
+        const int t = rev ? len - 1 - step : step;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        const uint4* hp = reinterpret_cast<const uint4*>(&h_b[cur][p * 64]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          LstmPack4 hv;
+          hv.u = hp[k];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p0 = __builtin_amdgcn_fdot2_f32_bf16(wq[4 * k + e], hv.p[e], p0, false);
+            p1 = __builtin_amdgcn_fdot2_f32_bf16(wq[32 + 4 * k + e], hv.p[e], p1, false);
+            p2 = __builtin_amdgcn_fdot2_f32_bf16(wq[64 + 4 * k + e], hv.p[e], p2, false);
+            p3 = __builtin_amdgcn_fdot2_f32_bf16(wq[96 + 4 * k + e], hv.p[e], p3, false);
+          }
+        }
+        // exchange over the pair: lane 0 ends with the full pre-activations of (i, f), lane 1 with (g, o)
+        const float pa = (p ? p2 : p0) + lstm_dpp_xor1(p ? p0 : p2) + (gq0[u] + bias0);
+        const float pb = (p ? p3 : p1) + lstm_dpp_xor1(p ? p1 : p3) + (gq1[u] + bias1);
+        // lane 0: sigmoid(i), sigmoid(f); lane 1: tanh(g) = 2 sigmoid(2 g) - 1, sigmoid(o)
+        const float sa = lstm_sigmoid<true>(p ? 2.f * pa : pa);
+        const float a0 = p ? fmaf(2.f, sa, -1.f) : sa;
+        const float a1 = lstm_sigmoid<true>(pb);
+        gob[(long long)t * LG] = a0;
+        gob[(long long)t * LG + LH] = a1;
+        const float o0 = lstm_dpp_xor1(a0), o1 = lstm_dpp_xor1(a1);
+        const float ig = p ? o0 : a0, fg = p ? o1 : a1, gg = p ? a0 : o0, og = p ? a1 : o1;
+        c = fmaf(fg, c, ig * gg);
+        const float hn = og * lstm_tanh<true>(c);
+        if (p == 0) {
+          h_b[cur ^ 1][j] = (__bf16)hn;
+          outb[(long long)t * ndir * LH + j] = hn;
+          cob[(long long)t * LH + j] = c;
+        }
+        cur ^= 1;
+        lstm_barrier();
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      gq0[u] = gn0[u];
+      gq1[u] = gn1[u];
+    }
+  }
+  for (int tt = len; tt < T; ++tt)
+    if (tid < LH) outb[(long long)tt * ndir * LH + tid] = 0.f;
+}
+
 __device__ __forceinline__ float lstm_dpp_half_mirror(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, false));  // lane i <-> 7 - i
 }
@@ -354,13 +465,130 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
   for (int tt = len; tt < T; ++tt) dgb[(long long)tt * LG + tid] = 0.f;
 }
 
+// [round 6] The pair-of-lanes form of the backward recurrence (bf16 mode; see lstm_fwd_pair_kernel): 256 threads = one wave
+// per SIMD.  A DPP row of 16 lanes owns EIGHT cells.  Phase A: lane l of the row is (cell l >> 1, gate pair l & 1) and
+// publishes the gradients of its two gates (i, f | g, o).  After the barrier, phase B: lane l covers the 32 gradient rows
+// [32 l, 32 l + 32) for the row's eight cells (256 weights per lane), the 16 partial sums of each cell meet through four DPP
+// adds.  Same dot-product issue per SIMD as the quad form (512 cycles), half the lanes for everything else.
+__global__ __launch_bounds__(256) void lstm_bwd_pair_kernel(const float* __restrict__ dout, const float* __restrict__ whh,
+                                                           const int32_t* __restrict__ lens, const float* __restrict__ gates,
+                                                           const float* __restrict__ cst, float* __restrict__ dgates, int B,
+                                                           int T, int ndir, int reverse_first) {
+  __shared__ __attribute__((aligned(16))) __bf16 dg_b[2][LG];
+  const int tid = threadIdx.x, row = tid >> 4, l = tid & 15;
+  const int k = row * 8 + (l >> 1), gp = l & 1;  // phase-A identity: cell, gate pair
+  const int b = blockIdx.x, dir = blockIdx.y;
+  const bool rev = reverse_first ? true : (dir == 1);
+  const int len = lens ? min(lens[b], T) : T;
+  // phase-B weights: W_hh[32 l + rr][8 row + c], c < 8, rr < 32 (pairs over rr)
+  lstm_bf16x2 wq[8 * 16];
+#pragma unroll
+  for (int rr = 0; rr < 32; rr += 2) {
+    const float* r0 = whh + ((long long)dir * LG + l * 32 + rr) * LH + row * 8;
+    const float4 w00 = *reinterpret_cast<const float4*>(r0), w01 = *reinterpret_cast<const float4*>(r0 + 4);
+    const float4 w10 = *reinterpret_cast<const float4*>(r0 + LH), w11 = *reinterpret_cast<const float4*>(r0 + LH + 4);
+    const float a0[8] = {w00.x, w00.y, w00.z, w00.w, w01.x, w01.y, w01.z, w01.w};
+    const float a1[8] = {w10.x, w10.y, w10.z, w10.w, w11.x, w11.y, w11.z, w11.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) wq[c * 16 + rr / 2] = (lstm_bf16x2){(__bf16)a0[c], (__bf16)a1[c]};
+  }
+  const float* doutb = dout + (long long)b * T * ndir * LH + dir * LH;
+  const float* gb = gates + (((long long)dir * B + b) * T) * LG;
+  const float* cb = cst + (((long long)dir * B + b) * T) * LH;
+  float* dgb = dgates + (((long long)dir * B + b) * T) * LG;
+  float dc = 0.f, dh_rec = 0.f;
+  constexpr int PF = 4;
+  float q_i[PF], q_f[PF], q_g[PF], q_o[PF], q_c[PF], q_cp[PF], q_d[PF];
+  float n_i[PF], n_f[PF], n_g[PF], n_o[PF], n_c[PF], n_cp[PF], n_d[PF];
+  const int last = len > 0 ? len - 1 : 0;
+  auto fetch = [&](int step, float& vi, float& vf, float& vg, float& vo, float& vc, float& vcp, float& vd) {
+    const int sc = min(step, last);
+    const int t = rev ? sc : last - sc;
+    const int tprev = min(max(rev ? t + 1 : t - 1, 0), T - 1);
+    vi = gb[(long long)t * LG + k];
+    vf = gb[(long long)t * LG + LH + k];
+    vg = gb[(long long)t * LG + 2 * LH + k];
+    vo = gb[(long long)t * LG + 3 * LH + k];
+    vc = cb[(long long)t * LH + k];
+    const float cp = cb[(long long)tprev * LH + k];
+    vcp = (sc + 1 < len) ? cp : 0.f;
+    vd = doutb[(long long)t * ndir * LH + k];
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u) fetch(u, q_i[u], q_f[u], q_g[u], q_o[u], q_c[u], q_cp[u], q_d[u]);
+  int cur = 0;
+  for (int step0 = 0; step0 < len; step0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(step0 + PF + u, n_i[u], n_f[u], n_g[u], n_o[u], n_c[u], n_cp[u], n_d[u]);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int step = step0 + u;
+      if (step < len) {  // uniform
+        const int t = rev ? step : len - 1 - step;
+        {
+          const float ig = q_i[u], fg = q_f[u], gg = q_g[u], og = q_o[u], cc = q_c[u], cprev = q_cp[u];
+          const float dh = q_d[u] + dh_rec;
+          const float tc = lstm_tanh<true>(cc);
+          dc = dc + dh * og * (1.f - tc * tc);
+          // lane gp publishes the gradients of gates 2 gp, 2 gp + 1: d(pre) = upstream * derivative of the gate's activation
+          const float m0 = gp ? dc * ig * (1.f - gg * gg) : dc * gg * (ig * (1.f - ig));
+          const float m1 = gp ? dh * tc * (og * (1.f - og)) : dc * cprev * (fg * (1.f - fg));
+          dc = dc * fg;
+          dg_b[cur][(2 * gp) * LH + k] = (__bf16)m0;
+          dg_b[cur][(2 * gp + 1) * LH + k] = (__bf16)m1;
+          dgb[(long long)t * LG + (2 * gp) * LH + k] = m0;
+          dgb[(long long)t * LG + (2 * gp + 1) * LH + k] = m1;
+        }
+        lstm_barrier();
+        {
+          float a[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) a[c] = 0.f;
+          const uint4* dp = reinterpret_cast<const uint4*>(&dg_b[cur][l * 32]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            LstmPack4 d4;
+            d4.u = dp[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 8; ++c) a[c] = __builtin_amdgcn_fdot2_f32_bf16(wq[c * 16 + 4 * q + e], d4.p[e], a[c], false);
+          }
+#pragma unroll
+          for (int c = 0; c < 8; ++c) a[c] = lstm_row16_sum(a[c]);
+          const int cq = l >> 1;  // this lane's cell inside the row
+          float v = a[0];
+#pragma unroll
+          for (int c = 1; c < 8; ++c) v = cq == c ? a[c] : v;
+          dh_rec = v;
+        }
+        cur ^= 1;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      q_i[u] = n_i[u], q_f[u] = n_f[u], q_g[u] = n_g[u], q_o[u] = n_o[u];
+      q_c[u] = n_c[u], q_cp[u] = n_cp[u], q_d[u] = n_d[u];
+    }
+  }
+  // padded tail contributes nothing
+  for (int tt = len; tt < T; ++tt) {
+    dgb[(long long)tt * LG + tid] = 0.f;
+    dgb[(long long)tt * LG + 256 + tid] = 0.f;
+  }
+}
+
 extern "C" int kantts_lstm_fwd(const float* gx, const float* whh, const float* bhh, const int32_t* lens, float* out,
                                float* gates_save, float* c_save, int B, int T, int H, int ndir, int reverse_first,
                                int precision, void* stream) {
   if (!gx || !whh || !out || !gates_save || !c_save || B < 0 || T < 0 || ndir < 1 || ndir > 2) return KANTTS_E_BADARG;
   if (H != LH) return KANTTS_E_UNSUPPORTED;
   if (B == 0 || T == 0) return KANTTS_OK;
-  if (precision == 1)
+  static const char* env_pair = getenv("KANTTS_LSTM_PAIR");  // A/B switch (read once per process): 0 = the quad kernel
+  if (precision == 1 && !(env_pair && atoi(env_pair) == 0))
+    hipLaunchKernelGGL(lstm_fwd_pair_kernel, dim3(B, ndir), dim3(256), 0, (hipStream_t)stream, gx, whh, bhh, lens, out,
+                       gates_save, c_save, B, T, ndir, reverse_first);
+  else if (precision == 1)
     hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, gx, whh, bhh, lens, out,
                        gates_save, c_save, B, T, ndir, reverse_first);
   else
@@ -376,7 +604,11 @@ extern "C" int kantts_lstm_bwd(const float* dout, const float* whh, const int32_
     return KANTTS_E_BADARG;
   if (H != LH) return KANTTS_E_UNSUPPORTED;
   if (B == 0 || T == 0) return KANTTS_OK;
-  if (precision == 1)
+  static const char* env_pair = getenv("KANTTS_LSTM_PAIR_BWD");  // A/B switch (read once per process): 0 = the quad kernel
+  if (precision == 1 && !(env_pair && atoi(env_pair) == 0))
+    hipLaunchKernelGGL(lstm_bwd_pair_kernel, dim3(B, ndir), dim3(256), 0, (hipStream_t)stream, dout, whh, lens,
+                       gates_save, c_save, dgates, B, T, ndir, reverse_first);
+  else if (precision == 1)
     hipLaunchKernelGGL(lstm_bwd_kernel<true>, dim3(B, ndir), dim3(LG), 0, (hipStream_t)stream, dout, whh, lens,
                        gates_save, c_save, dgates, B, T, ndir, reverse_first);
   else
