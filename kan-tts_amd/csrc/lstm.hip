@@ -206,6 +206,11 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
 // [64 p, 64 p + 64) of the four gate rows of its cell (256 weights as 128 packed pairs); after the dot products one DPP
 // exchange leaves lane 0 with the gates (i, f) and lane 1 with (g, o); each applies its two activations, a second exchange
 // gives both lanes all four.
+// Measured and refused on top of this form (profiles/r06_runX_lstm_pair_mfma_split.log): HALF of the dot products on the matrix
+// pipe -- the sixteen v_mfma_f32_16x16x32_bf16 of the gates (g, o) of a wave's 32 cells (A rows permuted so that every lane
+// finds its own cell in its own accumulator, B = h broadcast) issued between the 64 v_dot2 of (i, f), one MFMA per four
+// v_dot2: 0.70 us per step against 0.57 -- the step is a latency chain, not an issue-bound loop, and the accumulators of
+// four dependent 16-cycle MFMAs arrive later than the last v_dot2.
 __global__ __launch_bounds__(256) void lstm_fwd_pair_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
                                                            const float* __restrict__ bhh, const int32_t* __restrict__ lens,
                                                            float* __restrict__ out, float* __restrict__ gates_out,
