@@ -540,3 +540,32 @@ def test_launch_tuning_is_fed_from_the_environment_by_the_host_layer(emulated_ca
     monkeypatch.delenv("KANTTS_TN_TILE")
     hip.apply_launch_tuning()
     assert calls[-1] == (0, 0, 128) and len(calls) == 3
+
+
+def test_adoption_queue_refuses_what_the_launch_did_not_promise():
+    """ops_bf16.ADOPT, the hand-over between a fused launch (pnca_block.hip, enc_attn.hip) and the unchanged autograd
+    Functions of the block: entries are taken in the order the launch promised them; a Function asking out of order, or a
+    result nobody asked for when the block ends, raises instead of silently running with another launch's tensors; scopes
+    nest and restore (a fused encoder sub-layer inside an outer scope), also when the body raises."""
+    from kantts._hip import ops_bf16
+    A = ops_bf16.ADOPT
+    assert A.q is None and A.take("linear") is None  # no launch in flight: every Function runs its own kernel
+    with ops_bf16._adopting([("linear", 1), ("attn", 2)]):
+        assert A.take("linear") == 1
+        with ops_bf16._adopting([("ffn", 3)]):
+            assert A.take("ffn") == 3
+        assert A.q == [("attn", 2)]
+        assert A.take("attn") == 2
+    assert A.q is None
+    with pytest.raises(RuntimeError, match="another order"):
+        with ops_bf16._adopting([("linear", 1), ("attn", 2)]):
+            A.take("attn")
+    assert A.q is None
+    with pytest.raises(RuntimeError, match="never adopted"):
+        with ops_bf16._adopting([("linear", 1), ("attn", 2)]):
+            A.take("linear")
+    assert A.q is None
+    with pytest.raises(ValueError):
+        with ops_bf16._adopting([("linear", 1)]):
+            raise ValueError("the block's own error is not masked by the left-over entry")
+    assert A.q is None
