@@ -633,6 +633,25 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
     dt = (time.perf_counter() - t0) / steps
     res["gan_step_eager_ms"] = dt * 1e3
     res["losses"] = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in out.items()}
+    # the arithmetic the step EXECUTES, per convolution family: HIP events around every convolution launch of one eager
+    # step (launches back to back on one stream: the times are those of each kernel alone, their sum exceeds the captured
+    # step, which overlaps launches).  The single-input-channel layers (conv_c1 / conv_n1) carry no tag: < 0.5 % of the flops.
+    hip.profile_begin()
+    gan_train_step(model, optimizer, scheduler, crit, config, y, x, steps=1)
+    fams = {}
+    for key, v in hip.profile_end_by_shape().items():
+        o = fams.setdefault(key.split(" ", 1)[0], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        o["launches"] += v["n"]
+        o["ms"] += v["ms"]
+        o["flops"] += v["flops"] * v["n"]
+        o["bytes"] += v["bytes"] * v["n"]
+    peak = PEAK_TFLOPS["bf16" if precision == "bf16" else "fp32"]
+    for o in fams.values():
+        t = max(o["ms"], 1e-9) * 1e-3
+        o.update(tflops=o["flops"] / t / 1e12, mfma_frac=o["flops"] / t / 1e12 / peak, gbps=o["bytes"] / t / 1e9,
+                 hbm_frac=o["bytes"] / t / 1e9 / PEAK_HBM_GBPS)
+    res["gan_step_families"] = fams
+    executed = sum(o["flops"] for o in fams.values())
     # the step as training runs it: both phases + the three Adam updates replayed from one hipGraph
     # (kantts/train/gan_graph_step.py; graph == eager is tests/test_hifigan.py::test_graphed_gan_step_matches_eager_gpu)
     from kantts.train.gan_graph_step import GraphedGanStep
@@ -651,6 +670,10 @@ def hifigan_leg(hip, precision, B=32, T_wav=8192, steps=3):
     res["gan_step_samples_per_s"] = B * T_wav / dt
     res["gan_step_tflops"] = 8.3e12 * B / 32 / dt / 1e12
     res["gan_step_mfma_frac"] = res["gan_step_tflops"] / PEAK_TFLOPS["bf16"] if precision == "bf16" else None
+    # beside the reference count (8.3 TFLOP: the dense arithmetic of the reference's modules) the flops the convolution
+    # launches of a step execute (polyphase transposed convolutions, grouped layers on their real group width)
+    res["gan_step_executed_tflop"] = executed / 1e12
+    res["gan_step_mfma_frac_executed"] = executed / dt / 1e12 / peak
     res["value"] = res["gan_step_samples_per_s"]
     res["unit"] = "audio-samples/s (GAN training step)"
     res["graph_losses"] = {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in out.items()}
