@@ -1066,7 +1066,8 @@ int kantts_ragged_rows_i64(const int64_t* src, const int64_t* row_off, const int
                            const int64_t* pad, int64_t* out, int B, int Tmax, int C, int transpose, void* stream);
 
 /* Launch-shape knobs for sweeps and tests -- they never change a result.  tn_tile: output tile of kantts_bgemm_tn* as
- * BN * 1000 + BK (64128 / 128128 / 64256 / 128256; anything else = the library's rule); tn_slices: token slices of the
+ * BN * 1000 + BK (64128 / 128128 / 64256 / 128256; anything else = the library's rule; the code + 1, e.g. 64129, selects
+ * that tile WITHOUT the XCD-aware workgroup mapping of round 6 -- the 3-D grid of rounds 2-5, for A/B runs); tn_slices: token slices of the
  * same launches (0 = the rule); c1_wgrad_wgs: workgroup cap of the persistent weight-gradient launch of kantts_conv_c1_launch
  * (0 = 256).  The host layer maps KANTTS_TN_TILE / KANTTS_TN_SLICES / KANTTS_C1_WGRAD_WGS onto this call; the library reads
  * no environment variable for them (until round 5 it did, per launch). */

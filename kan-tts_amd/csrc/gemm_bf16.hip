@@ -280,6 +280,9 @@ struct TnGroupArgs {
   float* c[KANTTS_TN_MAX_GROUP];
   float* db[KANTTS_TN_MAX_GROUP];
   uint64_t a_drop_seed[KANTTS_TN_MAX_GROUP];
+  // [round 6] XCD-aware launch (1-D grid): ktiles * ntiles output tiles of one (problem, tap, slice) = one GROUP; 0 = the
+  // 3-D grid of rounds 2-5
+  int ktiles, ntiles, ngroups;
 };
 
 // BN x BK = output tile (channels of A x channels of B).  64 x 128 is the round-2 tile; [round 4] 128 x 256 for the large
@@ -299,9 +302,24 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;  // wave tile: BN / 2 (n) x BK / 2 (k)
   const int li = lane & 15, kg = lane >> 4;
-  const int n0 = blockIdx.y * BN, c0 = blockIdx.x * BK;
+  // Workgroup -> (k tile, n tile, group).  The output tiles of one group read the SAME token rows of A and B (ntiles x and
+  // ktiles x over); the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own L2, so on
+  // the 3-D grid the tiles of a group landed on 8 different L2s and every re-read went back to HBM / the memory-side cache
+  // (PMC: 2.3-2.8 x the algorithmic traffic, profiles/r05_runPMC_*).  Here a group's tiles are the consecutive workgroups of
+  // ONE XCD (id % 8 = XCD, id / 8 = position inside it): they start together, walk the tokens in step, and every token
+  // tile is fetched from HBM once and re-read from that XCD's L2.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (ga.ngroups > 0) {
+    const int P = ga.ktiles * ga.ntiles, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    bz = xcd + 8 * (j / P);
+    if (bz >= ga.ngroups) return;  // padding of the last round of groups (uniform over the workgroup)
+    const int tile = j % P;
+    bx = tile % ga.ktiles;
+    by = tile / ga.ktiles;
+  }
+  const int n0 = by * BN, c0 = bx * BK;
   const int per_prob = g.ntaps * g.slices;
-  const int prob = blockIdx.z / per_prob, zr = blockIdx.z % per_prob;
+  const int prob = bz / per_prob, zr = bz % per_prob;
   const int tap = zr / g.slices, slice = zr % g.slices;
   g.a = ga.a[prob];
   g.b = ga.b[prob];
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(BG_THREADS) void bgemm_tn_kernel(const TnGroupArgs 
 #pragma unroll
     for (int n = 0; n < NR; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float colsum = 0.f;
-  const bool do_bias = g.db && blockIdx.x == 0 && tap == 0;
+  const bool do_bias = g.db && bx == 0 && tap == 0;
 
   BgRaw<A_F32> ra0[NA], ra1[NA];
   BgRaw<B_F32> rb0[NB], rb1[NB];
@@ -495,6 +513,9 @@ static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
   // (profiles/r04_runL_tn_tile_sweep.log).
   int code = kantts_tune_tn_tile.load(std::memory_order_relaxed);  // kantts_launch_tuning (sweeps / tests); 0 = the rule
   const int forced_slices = kantts_tune_tn_slices.load(std::memory_order_relaxed);
+  // (code + 1, e.g. 64129: that tile on the 3-D grid of rounds 2-5, without the XCD-aware mapping -- for A/B runs)
+  bool xcd_map = true;
+  if (code == 64129 || code == 128129 || code == 64257 || code == 128257) code -= 1, xcd_map = false;
   if (code != 64128 && code != 128128 && code != 64256 && code != 128256) code = bg_tn_tile_rule(g, ga.nprob);
   const int BN = code / 1000, BK = code % 1000;
   const int tiles = kantts_cdiv(g.N, BN) * kantts_cdiv(g.K, BK) * g.ntaps * ga.nprob;
@@ -516,6 +537,11 @@ static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
   if (slices < 1) slices = 1;
   g.slices = slices;
   dim3 grid(kantts_cdiv(g.K, BK), kantts_cdiv(g.N, BN), ga.nprob * g.ntaps * slices);
+  ga.ktiles = ga.ntiles = ga.ngroups = 0;
+  if (xcd_map) {
+    ga.ktiles = (int)grid.x, ga.ntiles = (int)grid.y, ga.ngroups = (int)grid.z;
+    grid = dim3(8u * grid.x * grid.y * (unsigned)kantts_cdiv(ga.ngroups, 8), 1, 1);
+  }
   switch (code) {
     case 128256: return bg_tn_dispatch<128, 256>(ga, grid, st);
     case 128128: return bg_tn_dispatch<128, 128>(ga, grid, st);

@@ -47,7 +47,8 @@ for (M, N, K, n, a32, b32, taps, T) in SHAPES:
     uniq = n * M * (N * (4 if a32 else 2) + K * (4 if b32 else 2)) / 1e6
     line = "M %5d N %4d K %4d x%2d %s%s taps %d (%.0f MB):" % (M, N, K, n, "f" if a32 else "b", "f" if b32 else "b", taps, uniq)
     best = None
-    for tile in (64128, 128128, 64256, 128256):
+    # code + 1 = the same tile on the 3-D grid of rounds 2-5 (without the XCD-aware workgroup mapping of round 6)
+    for tile in (64128, 64129, 128128, 128129, 128256, 128257):
         os.environ["KANTTS_TN_TILE"] = str(tile)
         res = []
         for sl in (0, 1, 2, 3, 4, 6, 8, 12):

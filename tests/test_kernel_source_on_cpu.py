@@ -497,11 +497,12 @@ def _numpy_model():
         p.undo()
 
 
-@pytest.mark.parametrize("tile", ["64", "128"])
+@pytest.mark.parametrize("tile", ["64128", "128256", "64129", "128257"])
 def test_weight_gradient_contraction_with_both_output_tiles(tile, bf16_mode, monkeypatch):
-    """bgemm_tn_kernel<.., BN, BK>: the 64 x 128 tile of round 2 and the 128 x 256 tile of round 4 (chosen by problem size
-    on the device; KANTTS_TN_TILE forces one), on the linear-layer cases (ragged channel counts, fp32 / bf16 operands,
-    taps, dropout on the A operand) and on the deferred / grouped launches."""
+    """bgemm_tn_kernel<.., BN, BK>: the 64 x 128 tile of round 2 and the 128 x 256 tile of round 4 (KANTTS_TN_TILE forces
+    one), each under the XCD-aware workgroup mapping of round 6 (1-D grid, padded last round of groups) and under the 3-D
+    grid it replaced (code + 1), on the linear-layer cases (ragged channel counts, fp32 / bf16 operands, taps, dropout on
+    the A operand) and on the deferred / grouped launches."""
     monkeypatch.setenv("KANTTS_TN_TILE", tile)
     import test_bf16_path_emulated as T
 
