@@ -751,6 +751,7 @@ struct CwArgs {
   int slices;
   int to_ws;  // slices > 1 with a workspace: every slice stores its partial tile, cconv_wgrad_reduce_kernel sums them
   unsigned up_magic;
+  int xcd_map;  // [round 6] 1-D grid, the tiles of one token slice on one XCD (see the kernel); 0 = the 3-D grid
 };
 
 template <int TW, int NSTAGE>
@@ -774,12 +775,30 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_wgrad_kernel(const CwArgs P)
 
   const int ctiles = (g.CR + TW - 1) / TW;
   const int ntpg = (g.NG + TW - 1) / TW;
-  const int ct = blockIdx.x % ctiles;
-  const int grp = blockIdx.y / ntpg;
-  const int n0 = grp * g.NG + (blockIdx.y % ntpg) * TW;
+  // Workgroup -> (channel tile, output-channel tile, tap, token slice).  Every tile and every tap of one token slice reads
+  // the SAME rows of dy and (shifted by the tap) of x.  On the 3-D grid (x = channel tile, y = output tile, z = tap * slices
+  // + slice) the hardware deals consecutive ids to the 8 XCDs in turn, so the K taps of a slice ran behind up to 8
+  // different L2s and its rows crossed the fabric once per XCD.  [round 6] With at least 8 slices the launch is a 1-D grid in
+  // which a slice's ctiles * ntiles * K workgroups are consecutive workgroups of ONE XCD (id % 8 = XCD, id / 8 = position
+  // inside it; the last round of slices is padded with idle workgroups).
+  int bx = blockIdx.x, by = blockIdx.y, tap_ = blockIdx.z / P.slices, slice_ = blockIdx.z % P.slices;
+  if (P.xcd_map) {
+    const int ny = g.groups * ntpg, per = ctiles * ny * g.K;
+    const int j = blockIdx.x >> 3;
+    slice_ = (blockIdx.x & 7) + 8 * (j / per);
+    if (slice_ >= P.slices) return;
+    int m = j % per;
+    bx = m % ctiles;
+    m /= ctiles;
+    by = m % ny;
+    tap_ = m / ny;
+  }
+  const int ct = bx % ctiles;
+  const int grp = by / ntpg;
+  const int n0 = grp * g.NG + (by % ntpg) * TW;
   const int n_end = (grp + 1) * g.NG;
   const int c0 = ct * TW;  // channel offset inside the group
-  const int tap = blockIdx.z / P.slices, slice = blockIdx.z % P.slices;
+  const int tap = tap_, slice = slice_;
   const int inner = g.inner;
   const int up = g.up > 1 ? g.up : 1;
   const unsigned lim = (unsigned)(g.Tsrc * up);
@@ -997,6 +1016,7 @@ static int cw_launch2(const CwArgs& P, hipStream_t st) {
   }
   const kantts_cconvw_args& g = P.a;
   dim3 grid((g.CR + TW - 1) / TW, g.groups * ((g.NG + TW - 1) / TW), g.K * P.slices);
+  if (P.xcd_map) grid = dim3(8u * grid.x * grid.y * (unsigned)g.K * (unsigned)kantts_cdiv(P.slices, 8), 1, 1);
   hipLaunchKernelGGL((cconv_wgrad_kernel<TW, NSTAGE>), grid, dim3(CC_THREADS), LDS, st, P);
   if (P.to_ws) {
     const long long n4 = (long long)g.K * g.Ntot * g.CR / 4;
@@ -1351,6 +1371,8 @@ extern "C" int kantts_cconv_wgrad_launch(const kantts_cconvw_args* ap, void* str
   if ((long long)g.K * slices > 65535) return KANTTS_E_UNSUPPORTED;
   P.to_ws = to_ws ? 1 : 0;
   P.slices = slices;
+  static const bool no_xcd = getenv("KANTTS_CCONV_WGRAD_NO_XCD_MAP") != nullptr;  // A/B switch: the 3-D grid of rounds 4-5
+  P.xcd_map = (slices >= 8 && !no_xcd) ? 1 : 0;  // fewer slices than XCDs: the 3-D grid (a slice per XCD would idle the rest)
   static const char* env_stage = getenv("KANTTS_CCONV_STAGES");
   const int nst = env_stage ? atoi(env_stage) : 0;
   if (TW == 128) {

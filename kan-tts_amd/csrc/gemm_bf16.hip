@@ -252,7 +252,8 @@ extern "C" int kantts_bgemm_nt_lnbwd(const kantts_bgemm_args* gp, const kantts_l
 
 // ================================================================================================ TN (weight gradients)
 // dW[n][k] (+)= alpha * sum_m A[m][n] * B[m + shift][k];  db[n] += alpha * sum_m A[m][n]  (k-tile 0, tap 0 only).
-// grid = (k tiles of 128, n tiles of 64, taps * slices); slice z walks token tiles z, z + slices, ...
+// grid = (k tiles of 128, n tiles of 64, taps * slices) -- since round 6 as a 1-D grid in XCD-aware order (see the kernel);
+// slice z walks token tiles z, z + slices, ...
 // What bounds this kernel is the fp32 atomics of the split over tokens (~200 G atomics/s measured: the first version,
 // 128x128 tiles x 64 slices = 8.4 M atomics, took 48 us where the round-1 kernel took 24) and the chain of dependent
 // load latencies of a short token tile.  Hence: 64 x 128 output tiles (more tiles, fewer slices for the same number of

@@ -582,7 +582,7 @@ def test_one_channel_layer_scalar_kernels_on_the_kernel_source(monkeypatch):
         run()
 
 
-@pytest.mark.parametrize("slices", [1, 3])
+@pytest.mark.parametrize("slices", [1, 3, 8, 11])
 def test_cconv_weight_gradient_token_slices_on_the_kernel_source(slices):
     """cconv_wgrad_kernel / cconv_wgrad_taps_kernel with the token range cut into slices: partial tiles into the workspace +
     cconv_wgrad_reduce_kernel, or atomics when no workspace is handed over (one slice: read-modify-write) -- 2.6 % of the
@@ -595,7 +595,10 @@ def test_cconv_weight_gradient_token_slices_on_the_kernel_source(slices):
     # (B, Tsrc, Tdst, inner, Cin, Cout, groups, K, stride, dil, pad, up)
     shapes = [(2, 70, 70, 1, 64, 64, 1, 3, 1, 1, 1, 1), (3, 61, 21, 5, 64, 256, 1, 5, 3, 1, 2, 1),
               (2, 90, 90, 1, 72, 136, 1, 3, 1, 1, 1, 1), (2, 120, 60, 1, 128, 256, 2, 9, 2, 1, 4, 1),
-              (2, 50, 200, 1, 64, 64, 1, 7, 1, 1, 6, 4), (1, 9, 9, 1, 8, 8, 1, 1, 1, 1, 0, 1)]
+              (2, 50, 200, 1, 64, 64, 1, 7, 1, 1, 6, 4), (1, 9, 9, 1, 8, 8, 1, 1, 1, 1, 0, 1),
+              # enough 64-token steps for >= 8 slices: the XCD-aware 1-D grid of cconv_wgrad_kernel (round 6), with a padded
+              # last round of slices at 11
+              (2, 400, 400, 1, 136, 72, 1, 3, 1, 1, 1, 1), (2, 380, 380, 1, 256, 256, 2, 3, 1, 2, 2, 1)]
     for si, (B, Ts, Td, P, Cin, Cout, G, K, stride, dil, pad, up) in enumerate(shapes):
         CR, NG = Cin // G, Cout // G
         x = torch.randn(B, Ts, P, Cin, generator=g).to(torch.bfloat16)
