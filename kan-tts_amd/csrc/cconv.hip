@@ -75,6 +75,7 @@ struct CcArgs {
   int kper, doff;
   int hpt;             // 32-channel halves per tap = ceil(CR / 32)
   unsigned up_magic;   // floor(2^32 / up) + 1: n / up == mulhi(n, up_magic) for 0 <= n < 2^31 / up
+  int band_min_gx;     // XCD-band order of the tiles from this many output-channel tiles per row tile up (see the kernel)
   CcPhase ph[CC_MAXPH];
 };
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_kernel(const CcArgs P) {
   int bx = blockIdx.x, by = blockIdx.y;
   {  // consecutive tiles of one XCD share their A rows (the n tiles of a row tile sit behind one L2)
     const int gx = gridDim.x, total = gx * gridDim.y;
-    if (total >= 64 && gx > 1) {
+    if (total >= 64 && gx >= P.band_min_gx) {
       const int L = by * gx + bx, k = L & 7, j = L >> 3;
       const int q = total >> 3, r = total & 7;
       const int vid = k * q + (k < r ? k : r) + j;
@@ -393,13 +394,17 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_narrow_kernel(const CnArgs P
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kg = lane >> 4;
-  const int phase = blockIdx.z % g.phases, b = blockIdx.z / g.phases;
+  // ([round 6] walking the tiles in XCD-band order -- neighbouring row tiles share the (K - 1) * dilation rows of their
+  // windows -- was measured on the GAN step and the generator forward and gained nothing: 27.27 / 26.19 / 27.09 ms in id order,
+  // 27.28 / 27.13 / 27.21 ms banded; profiles/r06_runNB_cconv_narrow_xcd_band_ab.log.  The id order stays.)
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int phase = bz % g.phases, b = bz / g.phases;
   const int ntpg = (g.NG + BN - 1) / BN;
-  const int grp = blockIdx.x / ntpg;
-  const int n0 = grp * g.NG + (blockIdx.x % ntpg) * BN;
+  const int grp = bx / ntpg;
+  const int n0 = grp * g.NG + (bx % ntpg) * BN;
   const int n_end = (grp + 1) * g.NG;
   const int mrows = (g.Tdst - phase + g.phases - 1) / g.phases;
-  const int m0 = blockIdx.y * BM;
+  const int m0 = by * BM;
   if (m0 >= mrows) return;
   const int nv = P.ph[phase].nv, kfirst = P.ph[phase].kfirst, off0 = P.ph[phase].off0;
   const int off_last = off0 + (nv - 1) * P.doff;
@@ -629,6 +634,8 @@ extern "C" int kantts_cconv_launch(const kantts_cconv_args* ap, void* stream) {
   P.doff = (g.in_kstep == 0) ? 0 : g.in_kstep * P.kper / g.in_div;
   P.hpt = (g.CR + 31) / 32;
   P.up_magic = (unsigned)((1ull << 32) / (unsigned)up) + 1u;
+  static const bool band_gx1 = getenv("KANTTS_CCONV_BAND_GX1") != nullptr;  // [round 6 A/B] band order also for a single n tile
+  P.band_min_gx = band_gx1 ? 1 : 2;
   for (int ph = 0; ph < g.phases; ++ph) {
     int nv = 0, kf = 0, o0 = 0;
     for (int k = 0; k < g.K; ++k) {

@@ -102,7 +102,23 @@ __device__ __forceinline__ float pb_dot16l(const float* a, const float* lrow) {
   return pb_dot16(a, b);
 }
 
-__global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts_pnca_block_args g PB_DBG_PARAM) {
+// [round 6] Row tile of this workgroup.  Neighbouring 32-row tiles share their halo rows (the band of both attentions, the
+// taps' rows), and consecutive workgroup ids are dealt to the 8 XCDs in turn, each with its own L2: in id order every halo row
+// was fetched from HBM / the memory-side cache by two XCDs.  XCD k (= id % 8) owns a contiguous band of tiles instead
+// (KANTTS_PNCA_NO_XCD_BAND=1: id order, for A/B runs).  The partial rows of dgamma / dbeta are indexed by the TILE, so the
+// order of their sum does not depend on the mapping.
+__device__ __forceinline__ int pb_tile(int xcd_band) {
+  const int L = blockIdx.x, total = gridDim.x;
+  if (!xcd_band || total < 64) return L;
+  const int k = L & 7, j = L >> 3, q = total >> 3, r = total & 7;
+  return k * q + (k < r ? k : r) + j;
+}
+static int pb_xcd_band() {
+  static const bool off = getenv("KANTTS_PNCA_NO_XCD_BAND") != nullptr;
+  return off ? 0 : 1;
+}
+
+__global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts_pnca_block_args g, const int xcd_band PB_DBG_PARAM) {
   __shared__ __attribute__((aligned(16))) unsigned char As[PB_A_BYTES];
   __shared__ __attribute__((aligned(16))) unsigned char Tr[PB_T_BYTES];
   __shared__ __attribute__((aligned(16))) float Hs[(PB_BM + PB_HH) * PB_KP];
@@ -117,7 +133,8 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
   const int M = g.B * g.L, L = g.L;
-  const int m0 = blockIdx.x * PB_BM;
+  const int tile_id = pb_tile(xcd_band);
+  const int m0 = tile_id * PB_BM;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
   const __bf16* __restrict__ wq = reinterpret_cast<const __bf16*>(g.wqkv);
   const __bf16* __restrict__ wfx = reinterpret_cast<const __bf16*>(g.wfcx);
@@ -569,13 +586,14 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_fwd_kernel(const kantts
 // What crosses rows -- the attention backward, whose key gradients collect queries from neighbouring tiles -- stays a
 // launch of its own (csrc/attn.hip), followed by the QKV input gradient with the first LayerNorm's backward in its
 // epilogue (csrc/gemm_bf16.hip): a block's backward is 3 launches instead of 7.
-__global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts_pnca_block_bwd_args g PB_DBG_PARAM) {
+__global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts_pnca_block_bwd_args g, const int xcd_band PB_DBG_PARAM) {
   __shared__ __attribute__((aligned(16))) __bf16 Xs[PB_BM * PB_XP];   // dropout_2(dy) tile, later dropout_fc(g1)
   __shared__ __attribute__((aligned(16))) __bf16 Ts[PB_BM * PB_TP];   // gate tile -> dz tile
   __shared__ __attribute__((aligned(16))) float St[512];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
   const int M = g.M;
-  const int m0 = blockIdx.x * PB_BM;
+  const int tile_id = pb_tile(xcd_band);
+  const int m0 = tile_id * PB_BM;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
   const __bf16* __restrict__ wt2 = reinterpret_cast<const __bf16*>(g.wt2);  // W2^T (F x 128)
   const __bf16* __restrict__ wt1 = reinterpret_cast<const __bf16*>(g.wt1);  // W1^T (128 x F)
@@ -842,7 +860,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts
       }
     }
     if (li == 0 && !PB_DBG(1)) {
-      float* part = g.ws + (long long)blockIdx.x * (2 * PB_C);
+      float* part = g.ws + (long long)tile_id * (2 * PB_C);
       *reinterpret_cast<f32x4*>(part + n0) = (f32x4){pg[0], pg[1], pg[2], pg[3]};
       *reinterpret_cast<f32x4*>(part + PB_C + n0) = (f32x4){pb[0], pb[1], pb[2], pb[3]};
     }
@@ -901,7 +919,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_block_bwd_kernel(const kantts
 #define PB2_QROWS (PB_BM + PB_HX + PB_HH)   // 64 query rows: 16 in front (memory band), 16 behind (decoder band)
 #define PB2_GP (3 * PB_C + 16)              // bf16 pitch of the [dq | dk | dv] tile: 800 B = 32 mod 64
 
-__global__ __launch_bounds__(PB_THREADS) void pnca_attn_qkv_bwd_kernel(const kantts_pnca_attn_bwd_args g PB_DBG_PARAM) {
+__global__ __launch_bounds__(PB_THREADS) void pnca_attn_qkv_bwd_kernel(const kantts_pnca_attn_bwd_args g, const int xcd_band PB_DBG_PARAM) {
   // R: stage 1 = [k|v rows m0-16 .. m0+31 | memory k|v rows m0 .. m0+47]; stage 2 = [q rows m0-16 .. m0+47 | dOx rows m0 ..
   // m0+47 | dOh rows m0-16 .. m0+31]; then the bf16 gradient tile
   __shared__ __attribute__((aligned(16))) float R[2 * (PB_BM + PB_HX) * PB_KP];
@@ -920,7 +938,8 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_attn_qkv_bwd_kernel(const kan
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
   const int L = g.L, H = PB_C / PB_DH;
   const long long M = (long long)g.B * L;
-  const int m0 = blockIdx.x * PB_BM;
+  const int tile_id = pb_tile(xcd_band);
+  const int m0 = tile_id * PB_BM;
   const uint64_t seed_off = g.seed_dev ? *g.seed_dev : 0ull;
   const int bw_x = g.bw_dev ? *g.bw_dev : g.bw_x, bw_h = g.bw_dev ? *g.bw_dev : g.bw_h;
   const __bf16* __restrict__ wt = reinterpret_cast<const __bf16*>(g.wqkvT);  // W_qkv^T (128 x 384)
@@ -1234,7 +1253,7 @@ __global__ __launch_bounds__(PB_THREADS) void pnca_attn_qkv_bwd_kernel(const kan
       }
     }
     if (li == 0) {
-      float* part = g.ws + (long long)blockIdx.x * (2 * PB_C);
+      float* part = g.ws + (long long)tile_id * (2 * PB_C);
       *reinterpret_cast<f32x4*>(part + n0) = (f32x4){pg[0], pg[1], pg[2], pg[3]};
       *reinterpret_cast<f32x4*>(part + PB_C + n0) = (f32x4){pb[0], pb[1], pb[2], pb[3]};
     }
@@ -1260,7 +1279,7 @@ extern "C" int kantts_pnca_block_fwd(const kantts_pnca_block_args* gp, void* str
     if (p && !pb_aligned16(p)) return KANTTS_E_UNSUPPORTED;
   const long long M = (long long)g.B * g.L;
   if (M == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(pnca_block_fwd_kernel, dim3(kantts_cdiv(M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g PB_DBG_ARG);
+  hipLaunchKernelGGL(pnca_block_fwd_kernel, dim3(kantts_cdiv(M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g, pb_xcd_band() PB_DBG_ARG);
   KANTTS_CHECK_LAUNCH();
 }
 
@@ -1280,7 +1299,7 @@ extern "C" int kantts_pnca_block_bwd(const kantts_pnca_block_bwd_args* gp, void*
   for (const void* p : al)
     if (!pb_aligned16(p)) return KANTTS_E_UNSUPPORTED;
   if (g.M == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(pnca_block_bwd_kernel, dim3(kantts_cdiv(g.M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g PB_DBG_ARG);
+  hipLaunchKernelGGL(pnca_block_bwd_kernel, dim3(kantts_cdiv(g.M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g, pb_xcd_band() PB_DBG_ARG);
   KANTTS_CHECK_LAUNCH();
 }
 
@@ -1335,6 +1354,6 @@ extern "C" int kantts_pnca_attn_qkv_bwd(const kantts_pnca_attn_bwd_args* gp, voi
   for (const void* p : al)
     if (p && !pb_aligned16(p)) return KANTTS_E_UNSUPPORTED;
   if (M == 0) return KANTTS_OK;
-  hipLaunchKernelGGL(pnca_attn_qkv_bwd_kernel, dim3(kantts_cdiv(M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g PB_DBG_ARG);
+  hipLaunchKernelGGL(pnca_attn_qkv_bwd_kernel, dim3(kantts_cdiv(M, PB_BM)), dim3(PB_THREADS), 0, (hipStream_t)stream, g, pb_xcd_band() PB_DBG_ARG);
   KANTTS_CHECK_LAUNCH();
 }

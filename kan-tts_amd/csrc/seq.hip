@@ -347,8 +347,23 @@ template <bool FLIP>
 __global__ __launch_bounds__(256, 2) void fsmn_fir41_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ res,
                                                         const int64_t* __restrict__ lens, float* __restrict__ y, int B,
-                                                        int T, int C, int lp) {
-  const int b = blockIdx.y, t0 = blockIdx.x * FS_TT;
+                                                        int T, int C, int lp, int xcd_order) {
+  // [round 6] XCD-aware order: a block reads a 56-frame window for its 16 output frames, so neighbouring blocks share 40 of
+  // their rows -- and consecutive block ids are dealt to the 8 XCDs in turn, each with its own L2: the counters showed
+  // 2.6 x the input fetched from HBM / the memory-side cache (profiles/r06_runFINAL_fetch_pmc.txt: 52 MB for 20 MB at the
+  // postnet's 19 584 rows).  XCD k (= id % 8) now owns a contiguous band of (sequence, time block) pairs, walked in time order.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_order) {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    if (total >= 64) {
+      const int L = by * gx + bx, k = L & 7, j = L >> 3;
+      const int q = total >> 3, r = total & 7;
+      const int vid = k * q + (k < r ? k : r) + j;
+      by = vid / gx;
+      bx = vid - by * gx;
+    }
+  }
+  const int b = by, t0 = bx * FS_TT;
   const int len = lens ? (int)min((long long)lens[b], (long long)T) : T;
   const int lpe = FLIP ? (FS_K - 1 - lp) : lp;
   const float* xb = x + (long long)b * T * C;
@@ -475,6 +490,11 @@ __global__ __launch_bounds__(64 * FS_RS) void fsmn_dw_reduce_kernel(const float*
   }
 }
 
+static int fs_xcd_order() {
+  static const bool off = getenv("KANTTS_FIR_NO_XCD_ORDER") != nullptr;  // A/B switch: block (time, sequence) = (x, y) as dealt
+  return off ? 0 : 1;
+}
+
 extern "C" long long kantts_fsmn_dwconv_bwd_ws(int B, int T, int C, int K) {
   if (K != FS_K) return 0;
   return (long long)B * kantts_cdiv(T, FS_CH) * C * K;
@@ -487,7 +507,7 @@ extern "C" int kantts_fsmn_dwconv_fwd(const float* x, const float* w, const floa
   const int threads = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
   if (K == FS_K) {
     hipLaunchKernelGGL(fsmn_fir41_kernel<false>, dim3(kantts_cdiv(T, FS_TT), B), dim3(threads), 0, (hipStream_t)stream, x, w,
-                       res, lens, y, B, T, C, left_pad);
+                       res, lens, y, B, T, C, left_pad, fs_xcd_order());
   } else {
     hipLaunchKernelGGL(fsmn_dwconv_fwd_kernel, dim3(kantts_cdiv(T, DW_TT), B), dim3(threads), 0, (hipStream_t)stream, x, w,
                        res, lens, y, B, T, C, K, left_pad);
@@ -509,7 +529,7 @@ extern "C" int kantts_fsmn_dwconv_bwd(const float* dy, const float* x, const flo
     if (dw_accum && (!workspace || ws_floats < (long long)B * nchunk * C * K)) return KANTTS_E_WORKSPACE;
     if (dx)
       hipLaunchKernelGGL(fsmn_fir41_kernel<true>, dim3(kantts_cdiv(T, FS_TT), B), dim3(threads), 0, st, dy, w,
-                         (const float*)nullptr, lens, dx, B, T, C, left_pad);
+                         (const float*)nullptr, lens, dx, B, T, C, left_pad, fs_xcd_order());
     if (dw_accum) {
       hipLaunchKernelGGL(fsmn_dw41_partial_kernel, dim3(nchunk, B, kantts_cdiv(C, 64)), dim3(256), 0, st, dy, x, lens,
                          workspace, B, T, C, left_pad);

@@ -535,7 +535,9 @@ def test_monotonic_alignment_search_every_kernel_variant_on_the_kernel_source(To
 
 
 @pytest.mark.parametrize("CR,NG,T,G,mul", [(16, 48, 200, 2, 1), (16, 48, 70, 1, 1), (32, 32, 200, 1, 2), (24, 32, 70, 4, 1),
-                                           (64, 64, 200, 2, 1), (48, 64, 70, 1, 1), (64, 32, 200, 1, 1), (48, 24, 70, 2, 2)])
+                                           (64, 64, 200, 2, 1), (48, 64, 70, 1, 1), (64, 32, 200, 1, 1), (48, 24, 70, 2, 2),
+                                           # 2 x 35 row tiles of 256 (x 2 groups): many workgroups, long sequences
+                                           (32, 32, 8900, 1, 1), (16, 48, 4400, 2, 1)])
 def test_cconv_window_form_every_variant_on_the_kernel_source(CR, NG, T, G, mul):
     """cconv_narrow_kernel<256 | 128 rows, 64 | 32 outputs per group, 32 | 64 reduction channels>: the grouped / narrow
     layers of the discriminators (at most 64 input channels per group, no fold, no upsampling), every instantiation the

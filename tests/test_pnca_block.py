@@ -124,8 +124,12 @@ def test_fused_block_equals_the_chain_emulated(kw):
         _compare(*_case("cpu", **kw))
 
 
+# 66 row tiles: from 64 tiles up the three launches walk the tiles in XCD-band order (pb_tile; 66 = 8 * 8 + 2: uneven bands)
+_BANDED = dict(B=11, L=190, lens=[190 - 7 * i for i in range(11)], bw=6, drop=0.1)
+
+
 @pytest.mark.skipif(not HOSTSIM, reason="the host build of the kernel sources needs the ROCm clang")
-@pytest.mark.parametrize("kw", _CASES, ids=lambda k: "B%d-L%d-bw%d-p%g" % (k["B"], k["L"], k["bw"], k["drop"]))
+@pytest.mark.parametrize("kw", _CASES + [_BANDED], ids=lambda k: "B%d-L%d-bw%d-p%g" % (k["B"], k["L"], k["bw"], k["drop"]))
 def test_fused_block_equals_the_chain_kernel_source(kw):
     with kernel_source_on_cpu():
         _compare(*_case("cpu", **kw))
