@@ -75,7 +75,6 @@ struct CcArgs {
   int kper, doff;
   int hpt;             // 32-channel halves per tap = ceil(CR / 32)
   unsigned up_magic;   // floor(2^32 / up) + 1: n / up == mulhi(n, up_magic) for 0 <= n < 2^31 / up
-  int band_min_gx;     // XCD-band order of the tiles from this many output-channel tiles per row tile up (see the kernel)
   CcPhase ph[CC_MAXPH];
 };
 
@@ -105,7 +104,9 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_kernel(const CcArgs P) {
   int bx = blockIdx.x, by = blockIdx.y;
   {  // consecutive tiles of one XCD share their A rows (the n tiles of a row tile sit behind one L2)
     const int gx = gridDim.x, total = gx * gridDim.y;
-    if (total >= 64 && gx >= P.band_min_gx) {
+    // (with a single n tile the band order -- neighbouring row tiles behind one L2 for their shared tap rows -- was measured
+    // and is slower: GAN step 27.03 against 26.81 ms, profiles/r06_runGX_cconv_band_single_n_tile_ab.log)
+    if (total >= 64 && gx > 1) {
       const int L = by * gx + bx, k = L & 7, j = L >> 3;
       const int q = total >> 3, r = total & 7;
       const int vid = k * q + (k < r ? k : r) + j;
@@ -634,8 +635,6 @@ extern "C" int kantts_cconv_launch(const kantts_cconv_args* ap, void* stream) {
   P.doff = (g.in_kstep == 0) ? 0 : g.in_kstep * P.kper / g.in_div;
   P.hpt = (g.CR + 31) / 32;
   P.up_magic = (unsigned)((1ull << 32) / (unsigned)up) + 1u;
-  static const bool band_gx1 = getenv("KANTTS_CCONV_BAND_GX1") != nullptr;  // [round 6 A/B] band order also for a single n tile
-  P.band_min_gx = band_gx1 ? 1 : 2;
   for (int ph = 0; ph < g.phases; ++ph) {
     int nv = 0, kf = 0, o0 = 0;
     for (int k = 0; k < g.K; ++k) {
