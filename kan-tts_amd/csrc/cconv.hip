@@ -1378,7 +1378,8 @@ extern "C" int kantts_cconv_wgrad_launch(const kantts_cconvw_args* ap, void* str
   P.to_ws = to_ws ? 1 : 0;
   P.slices = slices;
   static const bool no_xcd = getenv("KANTTS_CCONV_WGRAD_NO_XCD_MAP") != nullptr;  // A/B switch: the 3-D grid of rounds 4-5
-  P.xcd_map = (slices >= 8 && !no_xcd) ? 1 : 0;  // fewer slices than XCDs: the 3-D grid (a slice per XCD would idle the rest)
+  // a slice per XCD and round: fewer slices than XCDs, or a last round that leaves more than a quarter of them idle -> 3-D grid
+  P.xcd_map = (slices >= 8 && slices * 4 >= 3 * 8 * kantts_cdiv(slices, 8) && !no_xcd) ? 1 : 0;
   static const char* env_stage = getenv("KANTTS_CCONV_STAGES");
   const int nst = env_stage ? atoi(env_stage) : 0;
   if (TW == 128) {

@@ -539,6 +539,9 @@ static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
   g.slices = slices;
   dim3 grid(kantts_cdiv(g.K, BK), kantts_cdiv(g.N, BN), ga.nprob * g.ntaps * slices);
   ga.ktiles = ga.ntiles = ga.ngroups = 0;
+  // a group per XCD and round: with fewer than 8 groups, or a last round that leaves more than a quarter of the XCDs idle,
+  // the 3-D grid (every XCD busy, every re-read through the fabric) is the better of two evils
+  if (xcd_map && (int)grid.z * 4 < 3 * 8 * kantts_cdiv((int)grid.z, 8)) xcd_map = false;
   if (xcd_map) {
     ga.ktiles = (int)grid.x, ga.ntiles = (int)grid.y, ga.ngroups = (int)grid.z;
     grid = dim3(8u * grid.x * grid.y * (unsigned)kantts_cdiv(ga.ngroups, 8), 1, 1);

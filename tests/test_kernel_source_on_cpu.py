@@ -510,6 +510,49 @@ def test_weight_gradient_contraction_with_both_output_tiles(tile, bf16_mode, mon
     T.test_deferred_grouped_weight_gradients_equal_immediate_ones(bf16_mode)
 
 
+@pytest.mark.parametrize("tile,slices", [("64128", 13), ("64128", 9), ("128256", 16), ("64129", 13)])
+def test_weight_gradient_contraction_in_xcd_order_on_the_kernel_source(tile, slices, monkeypatch):
+    """bgemm_tn_kernel on the XCD-aware 1-D grid of round 6: 13 token slices = 13 groups of output tiles dealt to 8 XCDs (a
+    padded second round), 16 = two full rounds, 9 = below 3/4 of the places of its last round -> the launcher keeps the 3-D
+    grid, and "64129" = the 3-D grid forced; ragged channel counts, three taps, against float64."""
+    import torch
+
+    import kantts._hip as hip
+
+    monkeypatch.setenv("KANTTS_TN_TILE", tile)
+    monkeypatch.setenv("KANTTS_TN_SLICES", str(slices))
+    g = torch.Generator().manual_seed(slices)
+    T, B, N, K, taps = 300, 4, 72, 136, 3
+    M = B * T
+    a = torch.randn(M, N, generator=g)
+    b = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    c0 = torch.randn(N, K * taps, generator=g)
+    c, db = c0.clone(), torch.zeros(N)
+    with util.kernel_source_on_cpu():
+        hip._launch_tuning[0] = None
+        try:
+            assert hip.bgemm_tn(a, N, b, K, M, N, K, c, K * taps, taps, c_ts=1, T=T, ntaps=taps, shift0=-1, shift_step=1, db=db)
+        finally:
+            monkeypatch.delenv("KANTTS_TN_TILE")
+            monkeypatch.delenv("KANTTS_TN_SLICES")
+            hip.apply_launch_tuning()
+    ab = a.to(torch.bfloat16).double().view(B, T, N)
+    bb = b.double().view(B, T, K)
+    ref = c0.double().clone().view(N, K, taps)
+    for tap in range(taps):
+        sh = tap - 1
+        shifted = torch.zeros_like(bb)
+        if sh < 0:
+            shifted[:, -sh:] = bb[:, :T + sh]
+        elif sh > 0:
+            shifted[:, :T - sh] = bb[:, sh:]
+        else:
+            shifted = bb
+        ref[:, :, tap] += torch.einsum("btn,btk->nk", ab, shifted)
+    assert float((c.double().view(N, K, taps) - ref).abs().max()) <= 2e-3 * M ** 0.5
+    assert float((db.double() - ab.sum((0, 1))).abs().max()) <= 2e-3 * M ** 0.5
+
+
 @pytest.mark.parametrize("To,Ti", [(90, 64), (75, 65), (70, 128), (60, 200), (33, 256), (40, 300)])
 def test_monotonic_alignment_search_every_kernel_variant_on_the_kernel_source(To, Ti):
     """mas_wave_kernel with 1 / 2 / 4 ballot words per row, the exact 64-column boundaries, and mas_block_kernel (more than
@@ -584,7 +627,7 @@ def test_one_channel_layer_scalar_kernels_on_the_kernel_source(monkeypatch):
         run()
 
 
-@pytest.mark.parametrize("slices", [1, 3, 8, 11])
+@pytest.mark.parametrize("slices", [1, 3, 8, 13])
 def test_cconv_weight_gradient_token_slices_on_the_kernel_source(slices):
     """cconv_wgrad_kernel / cconv_wgrad_taps_kernel with the token range cut into slices: partial tiles into the workspace +
     cconv_wgrad_reduce_kernel, or atomics when no workspace is handed over (one slice: read-modify-write) -- 2.6 % of the
@@ -599,7 +642,7 @@ def test_cconv_weight_gradient_token_slices_on_the_kernel_source(slices):
               (2, 90, 90, 1, 72, 136, 1, 3, 1, 1, 1, 1), (2, 120, 60, 1, 128, 256, 2, 9, 2, 1, 4, 1),
               (2, 50, 200, 1, 64, 64, 1, 7, 1, 1, 6, 4), (1, 9, 9, 1, 8, 8, 1, 1, 1, 1, 0, 1),
               # enough 64-token steps for >= 8 slices: the XCD-aware 1-D grid of cconv_wgrad_kernel (round 6), with a padded
-              # last round of slices at 11
+              # last round of slices at 13 (13 of 16 places taken; below 3/4 the launcher keeps the 3-D grid)
               (2, 400, 400, 1, 136, 72, 1, 3, 1, 1, 1, 1), (2, 380, 380, 1, 256, 256, 2, 3, 1, 2, 2, 1)]
     for si, (B, Ts, Td, P, Cin, Cout, G, K, stride, dil, pad, up) in enumerate(shapes):
         CR, NG = Cin // G, Cout // G
