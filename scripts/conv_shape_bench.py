@@ -32,7 +32,7 @@ rows = sorted(tab.items(), key=lambda kv: -kv[1]["ms"])
 tot = sum(v["ms"] for v in tab.values())
 print("conv launches total %.2f ms over %d shapes" % (tot, len(rows)))
 print("%7s %4s %8s %8s %8s  shape" % ("ms", "n", "us/call", "TFLOP/s", "GB/s"))
-for k, v in rows[:60]:
+for k, v in rows[:int(os.environ.get('ROWS', '60'))]:
     us = v["ms"] / v["n"] * 1e3
     print("%7.2f %4d %8.1f %8.1f %8.0f  %s" % (v["ms"], v["n"], us, v["flops"] / (us * 1e-6) / 1e12,
                                                 v["bytes"] / (us * 1e-6) / 1e9, k))
