@@ -1288,7 +1288,12 @@ static int cw_slices(const kantts_cconvw_args& g, bool have_ws) {
   if (slices == 0) {
     slices = 1;
     if (tiles < 200) {
-      slices = (512 + tiles - 1) / tiles;
+      // [round 6] the launch is dealt slice by slice to the 8 XCDs (cconv_wgrad_kernel), each with 64 places (32 CUs x 2
+      // workgroups): as many slices per XCD as fit in ONE round of its places.  (The rule of rounds 4-5, ceil(512 / tiles)
+      // slices, put 6 x 11 = 66 workgroups on an XCD for the 128 -> 128, k = 11 layers -- a second round for two of them:
+      // 91 us against 65 us at 36 slices; 128 -> 128 k = 7: 61 -> 44 us, 256 -> 256 k = 11: 54 -> 45 us;
+      // profiles/r06_runSL_cconv_wgrad_slices.log.)  More than 64 tiles per slice: fewer than 8 slices, the 3-D grid.
+      slices = tiles <= 64 ? 8 * (64 / tiles) : 512 / tiles;
       if (!have_ws) {
         const long long cap = (6ll << 20) / ((long long)g.K * g.Ntot * g.CR) + 1;  // <= ~6 M atomics per launch
         if (slices > cap) slices = cap;

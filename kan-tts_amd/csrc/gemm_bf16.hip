@@ -529,6 +529,14 @@ static int bg_tn_launch(TnGroupArgs& ga, hipStream_t st) {
     // (round 2's budget of 1.5 M left the 19 584-row postnet problems at 4 slices: 126 us where 8 slices take 80)
     static const bool r2_rule = getenv("KANTTS_TN_SLICE_RULE_R2") != nullptr;  // A/B switch: rounds 2-3's rule
     slices = r2_rule ? kantts_cdiv(320, tiles) : 512 / tiles;
+    if (xcd_map && !r2_rule) {
+      // [round 6] groups (= problem x tap x slice) are dealt to the 8 XCDs whole, each XCD has 64 places (32 CUs x 2
+      // workgroups): as many groups per XCD as fit in ONE round of its places (7 problems of 6 tiles: 12 slices were 11
+      // groups = 66 workgroups on an XCD, a second round for two of them)
+      const int P = kantts_cdiv(g.N, BN) * kantts_cdiv(g.K, BK);
+      const int per_xcd = P <= 64 ? 64 / P : 1;
+      slices = 8 * per_xcd / (g.ntaps * ga.nprob);
+    }
     if (slices < 1) slices = 1;
     if (slices > 16 && !r2_rule) slices = 16;
     const long long cap = ((r2_rule ? 3ll << 19 : 1ll << 22)) / ((long long)g.N * g.K * g.ntaps * ga.nprob) + 1;
