@@ -367,6 +367,10 @@ class ParamArena:
             return
         self.shadow_stale = False
 
+        # (three launches one after the other, ~49 us at the head of a step.  [round 6] Forked onto two side streams -- same
+        # masters in, disjoint images out, joined before the first consumer -- they should cost the longest of them, ~21 us;
+        # measured, the captured step got SLOWER: 5.69 / 5.67 / 5.66 ms side by side against 5.43 / 5.60 / 5.61 ms serial,
+        # interleaved on one box (profiles/r06_runIM_image_refresh_side_streams_ab.log).  Serial stays.)
         check(lib().kantts_cast_f32_bf16(ptr(self.flat, torch.float32), ptr(self.flat_bf16, torch.bfloat16), self.numel,
                                          stream()), "cast_f32_bf16")
         if self._tap_table is not None:
