@@ -319,6 +319,9 @@ __device__ __forceinline__ float lstm_dpp_half_mirror(float v) {
 __device__ __forceinline__ float lstm_dpp_mirror(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, false));  // lane i <-> 15 - i
 }
+__device__ __forceinline__ float lstm_dpp_ror8(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, false));  // row_ror:8, lane i <-> i ^ 8
+}
 // sum over the 16 lanes of a DPP row, result in every lane
 __device__ __forceinline__ float lstm_row16_sum(float v) {
   v += lstm_dpp_xor1(v);
@@ -471,21 +474,29 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
 }
 
 // [round 6] The pair-of-lanes form of the backward recurrence (bf16 mode; see lstm_fwd_pair_kernel): 256 threads = one wave
-// per SIMD.  A DPP row of 16 lanes owns EIGHT cells.  Phase A: lane l of the row is (cell l >> 1, gate pair l & 1) and
+// per SIMD.  A DPP row of 16 lanes owns EIGHT cells.  Phase A: lane l of the row is (cell g(l & 7), gate pair l >> 3) and
 // publishes the gradients of its two gates (i, f | g, o).  After the barrier, phase B: lane l covers the 32 gradient rows
-// [32 l, 32 l + 32) for the row's eight cells (256 weights per lane), the 16 partial sums of each cell meet through four DPP
-// adds.  Same dot-product issue per SIMD as the quad form (512 cycles), half the lanes for everything else.
+// [32 l, 32 l + 32) for the row's eight cells (256 weights per lane).  Same dot-product issue per SIMD as the quad form
+// (512 cycles), half the lanes for everything else.
+// The 16 partial sums of each of the 8 cells meet in a HALVING reduction: 4 + 2 + 1 + 1 = 8 DPP adds and no select, where
+// an all-reduce of every cell (the first form of this kernel) took 32 adds and a 7-deep select chain to pick the lane's own.
+// Lane l keeps its accumulators in SLOTS: slot s belongs to cell s ^ g(l & 7), g(b) = b0 ^ 2 b1 ^ 7 b2 (a bijection of three
+// bits, applied when the weights are loaded, once per launch).  The partner of each level then holds the same cell in the
+// slot with one bit flipped -- xor 1: g(l ^ 1) = g(l) ^ 1 -> slot s ^ 1; xor 2 -> slot s ^ 2; row_half_mirror = xor 7:
+// g(l ^ 7) = g(l) ^ 4 -> slot s ^ 4; row_ror:8 = xor 8: same g, slot 0 -- so every lane keeps the even slots, then slots 0
+// and 4, then slot 0, and lanes l and l ^ 8 (the two gate pairs of cell g(l & 7)) both end with that cell's dh.
 __global__ __launch_bounds__(256) void lstm_bwd_pair_kernel(const float* __restrict__ dout, const float* __restrict__ whh,
                                                            const int32_t* __restrict__ lens, const float* __restrict__ gates,
                                                            const float* __restrict__ cst, float* __restrict__ dgates, int B,
                                                            int T, int ndir, int reverse_first) {
   __shared__ __attribute__((aligned(16))) __bf16 dg_b[2][LG];
   const int tid = threadIdx.x, row = tid >> 4, l = tid & 15;
-  const int k = row * 8 + (l >> 1), gp = l & 1;  // phase-A identity: cell, gate pair
+  const int g3 = (l & 1) ^ (((l >> 1) & 1) * 2) ^ (((l >> 2) & 1) * 7);  // g(l & 7)
+  const int k = row * 8 + g3, gp = l >> 3;  // phase-A identity: cell, gate pair
   const int b = blockIdx.x, dir = blockIdx.y;
   const bool rev = reverse_first ? true : (dir == 1);
   const int len = lens ? min(lens[b], T) : T;
-  // phase-B weights: W_hh[32 l + rr][8 row + c], c < 8, rr < 32 (pairs over rr)
+  // phase-B weights: slot s = W_hh[32 l + rr][8 row + (s ^ g3)], s < 8, rr < 32 (pairs over rr)
   lstm_bf16x2 wq[8 * 16];
 #pragma unroll
   for (int rr = 0; rr < 32; rr += 2) {
@@ -495,7 +506,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_pair_kernel(const float* __restr
     const float a0[8] = {w00.x, w00.y, w00.z, w00.w, w01.x, w01.y, w01.z, w01.w};
     const float a1[8] = {w10.x, w10.y, w10.z, w10.w, w11.x, w11.y, w11.z, w11.w};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) wq[c * 16 + rr / 2] = (lstm_bf16x2){(__bf16)a0[c], (__bf16)a1[c]};
+    for (int c = 0; c < 8; ++c) {
+      // slot c ^ g3 <- cell c: a static register index needs the select over the 8 slots (setup, once per launch)
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl)
+        if ((c ^ g3) == sl) wq[sl * 16 + rr / 2] = (lstm_bf16x2){(__bf16)a0[c], (__bf16)a1[c]};
+    }
   }
   const float* doutb = dout + (long long)b * T * ndir * LH + dir * LH;
   const float* gb = gates + (((long long)dir * B + b) * T) * LG;
@@ -559,13 +575,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_pair_kernel(const float* __restr
 #pragma unroll
               for (int c = 0; c < 8; ++c) a[c] = __builtin_amdgcn_fdot2_f32_bf16(wq[c * 16 + 4 * q + e], d4.p[e], a[c], false);
           }
-#pragma unroll
-          for (int c = 0; c < 8; ++c) a[c] = lstm_row16_sum(a[c]);
-          const int cq = l >> 1;  // this lane's cell inside the row
-          float v = a[0];
-#pragma unroll
-          for (int c = 1; c < 8; ++c) v = cq == c ? a[c] : v;
-          dh_rec = v;
+          // halving reduction over the row's 16 lanes (see the header): slot s of lane l = cell s ^ g(l & 7)
+          a[0] += lstm_dpp_xor1(a[1]);
+          a[2] += lstm_dpp_xor1(a[3]);
+          a[4] += lstm_dpp_xor1(a[5]);
+          a[6] += lstm_dpp_xor1(a[7]);
+          a[0] += lstm_dpp_xor2(a[2]);
+          a[4] += lstm_dpp_xor2(a[6]);
+          a[0] += lstm_dpp_half_mirror(a[4]);
+          a[0] += lstm_dpp_ror8(a[0]);
+          dh_rec = a[0];
         }
         cur ^= 1;
       }

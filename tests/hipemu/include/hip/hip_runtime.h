@@ -200,7 +200,7 @@ static inline int hipemu_readfirstlane(int v) {
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 
 // DPP controls used by the kernels: quad_perm (0x00-0xFF), row_shl/row_shr (0x101-0x11F), wave_shr:1 (0x138),
-// row_mirror (0x140), row_half_mirror (0x141); full row / bank masks only
+// row_ror (0x121-0x12F), row_mirror (0x140), row_half_mirror (0x141); full row / bank masks only
 static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   const int l = hipemu::lane();
   auto slots = hipemu::post(&src, 4);
@@ -208,6 +208,7 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int row_mask, in
   if (ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
   else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl & 15; from = ((l & 15) + n < 16) ? l + n : -1; }
   else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl & 15; from = ((l & 15) >= n) ? l - n : -1; }
+  else if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl & 15; from = (l & ~15) | (((l & 15) - n) & 15); }
   else if (ctrl == 0x138) from = l >= 1 ? l - 1 : -1;
   else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
   else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
