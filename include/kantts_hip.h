@@ -178,7 +178,8 @@ int kantts_pnca_attn_bwd(const float* qkv, const float* hkv, int ldh, const floa
  * LSTM recurrence, H = 128 (time loop of torch.nn.LSTM: kantts/models/sambert/adaptors.py:44-57,
  * :109-134; kantts_sambert.py:637-646).  gx (B,T,ndir*4H) = x W_ih^T + b_ih (from the GEMM);
  * whh (ndir,4H,H), bhh (ndir,4H) or NULL; lens (B) int32 or NULL = pack_padded_sequence lengths;
- * out (B,T,ndir*H); gates_save (ndir,B,T,4H) and c_save (ndir,B,T,H) are kept for backward.
+ * out (B,T,ndir*H); gates_save (ndir*B*T*4H floats; private to the fwd / bwd pair: since round 6 a cell's four activations
+ * side by side, (ndir,B,T,H,4)) and c_save (ndir,B,T,H) are kept for backward.
  * Backward returns dgates (ndir,B,T,4H) = gradient w.r.t. the pre-activation gates.
  * precision 0: fp32 recurrent products; 1: h / dgates and W_hh rounded to bf16 for the recurrent product only
  * (packed v_dot2c_f32_bf16, fp32 accumulate) -- gates, cell state, outputs stay fp32. */

@@ -40,7 +40,17 @@ __device__ __forceinline__ float lstm_tanh(float x) {
 __device__ __forceinline__ void lstm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // gx: (B,T,ndir*4H) [direction d at column offset d*4H]; out: (B,T,ndir*H)
-// whh: (ndir, 4H, H), bhh: (ndir, 4H); gates_out: (ndir,B,T,4H); c_out: (ndir,B,T,H)
+// whh: (ndir, 4H, H), bhh: (ndir, 4H); c_out: (ndir,B,T,H);
+// gates_out: (ndir,B,T,H,4) -- the saved activations i, f, g, o of a cell side by side.  The tensor is private to the fwd / bwd
+// pair of this file.  [round 6] Until then gate-major (ndir,B,T,4,H): a lane of the pair form stored its two gates with two
+// instructions and the backward pass fetched a cell's four with four; the step's stores were measured at 0.059 of the
+// 0.570 us of a forward step (profiles/r06_runLA_lstm_fwd_ablation.log).  Cell-major: one 8-byte store, one 16-byte load.
+// Experiment builds only (scripts/build_lstm_abl.sh; the product Makefile never defines it): which part of a forward step
+// of lstm_fwd_pair_kernel costs what -- bit 0 the step's global stores, bit 1 the transcendental activations, bit 2 the LDS
+// publication of h + the barrier, bit 3 seven eighths of the dot products.  Results are wrong under any of them.
+#ifndef LSTM_ABL
+#define LSTM_ABL 0
+#endif
 typedef __bf16 lstm_bf16x2 __attribute__((ext_vector_type(2)));
 union LstmPack4 {
   uint4 u;
@@ -106,10 +116,10 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
     h_b[0][j] = (__bf16)0.f;
   }
   float c = 0.f;
-  const long long gx_ld = (long long)ndir * LG;
+  const int gx_ld = ndir * LG;  // offsets inside one sequence are 32-bit (T * ndir * 4H < 2^31: checked by the launchers)
   const float* gxb = gx + (long long)b * T * gx_ld + dir * LG + kq * LH + j;
   float* outb = out + (long long)b * T * ndir * LH + dir * LH;
-  float* gob = gates_out + (((long long)dir * B + b) * T) * LG + kq * LH + j;
+  float* gob = gates_out + (((long long)dir * B + b) * T) * LG + 4 * j + kq;
   float* cob = c_out + (((long long)dir * B + b) * T) * LH;
   __syncthreads();
   // gx[t] comes from L2 / HBM (0.5-2 us) while a step is ~0.4 us: the values of the next chunk of steps are loaded --
@@ -121,14 +131,14 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     const int su = min(u, last);
-    gq[u] = gxb[(long long)(rev ? last - su : su) * gx_ld];
+    gq[u] = gxb[(rev ? last - su : su) * gx_ld];
   }
   int cur = 0;
   for (int step0 = 0; step0 < len; step0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int sn = min(step0 + PF + u, last);
-      gn[u] = gxb[(long long)(rev ? last - sn : sn) * gx_ld];
+      gn[u] = gxb[(rev ? last - sn : sn) * gx_ld];
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
       // activation by gate: i, f, o sigmoid; g tanh
       const float sg = lstm_sigmoid<BF16>((kq == 2) ? 2.f * pre : pre);
       const float act = (kq == 2) ? fmaf(2.f, sg, -1.f) : sg;
-      gob[(long long)t * LG] = act;
+      gob[t * LG] = act;
       const float ig = lstm_quad_bcast<0>(act), fg = lstm_quad_bcast<1>(act);
       const float gg = lstm_quad_bcast<2>(act), og = lstm_quad_bcast<3>(act);
       c = fmaf(fg, c, ig * gg);
@@ -183,8 +193,8 @@ __global__ __launch_bounds__(LG) void lstm_fwd_kernel(const float* __restrict__ 
           h_b[cur ^ 1][j] = (__bf16)hn;
         else
           h_s[cur ^ 1][j] = hn;
-        outb[(long long)t * ndir * LH + j] = hn;
-        cob[(long long)t * LH + j] = c;
+        outb[t * ndir * LH + j] = hn;
+        cob[t * LH + j] = c;
       }
       cur ^= 1;
       lstm_barrier();
@@ -224,7 +234,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_pair_kernel(const float* __restr
   lstm_bf16x2 wq[4 * 32];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const float4* wp = reinterpret_cast<const float4*>(whh + ((long long)dir * LG + g * LH + j) * LH + p * 64);
+    // slot g of lane p holds gate g ^ 2 p: every lane KEEPS slots 0, 1 (its own gate pair) and SENDS slots 2, 3 (its
+    // partner's pair) -- the exchange below needs no select
+    const float4* wp = reinterpret_cast<const float4*>(whh + ((long long)dir * LG + (g ^ (2 * p)) * LH + j) * LH + p * 64);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const float4 t = wp[k];
@@ -237,10 +249,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_pair_kernel(const float* __restr
   const float bias1 = bhh ? bhh[dir * LG + (2 * p + 1) * LH + j] : 0.f;
   if (p == 0) h_b[0][j] = (__bf16)0.f;
   float c = 0.f;
-  const long long gx_ld = (long long)ndir * LG;
+  const int gx_ld = ndir * LG;  // offsets inside one sequence are 32-bit (T * ndir * 4H < 2^31: checked by the launchers)
   const float* gxb = gx + (long long)b * T * gx_ld + dir * LG + (2 * p) * LH + j;
   float* outb = out + (long long)b * T * ndir * LH + dir * LH;
-  float* gob = gates_out + (((long long)dir * B + b) * T) * LG + (2 * p) * LH + j;
+  float* gob = gates_out + (((long long)dir * B + b) * T) * LG + 4 * j + 2 * p;
   float* cob = c_out + (((long long)dir * B + b) * T) * LH;
   __syncthreads();
   constexpr int PF = 8;
@@ -249,16 +261,18 @@ __global__ __launch_bounds__(256) void lstm_fwd_pair_kernel(const float* __restr
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     const int su = min(u, last);
-    const long long o = (long long)(rev ? last - su : su) * gx_ld;
-    gq0[u] = gxb[o];
-    gq1[u] = gxb[o + LH];
+    const int o = (rev ? last - su : su) * gx_ld;
+    gq0[u] = gxb[o] + bias0;
+    gq1[u] = gxb[o + LH] + bias1;
   }
+  const float k1 = p ? 2.f : 1.f, k3 = p ? -1.f : 0.f;  // lane 1's first gate is tanh(g) = 2 sigmoid(2 g) - 1
   int cur = 0;
+  float p_sink = 0.f;  // (ablation builds only: keeps the chain alive when the stores are masked)
   for (int step0 = 0; step0 < len; step0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int sn = min(step0 + PF + u, last);
-      const long long o = (long long)(rev ? last - sn : sn) * gx_ld;
+      const int o = (rev ? last - sn : sn) * gx_ld;
       gn0[u] = gxb[o];
       gn1[u] = gxb[o + LH];
     }
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_pair_kernel(const float* __restr
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
         const uint4* hp = reinterpret_cast<const uint4*>(&h_b[cur][p * 64]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < (LSTM_ABL & 8 ? 1 : 8); ++k) {
           LstmPack4 hv;
           hv.u = hp[k];
 #pragma unroll
@@ -282,62 +296,55 @@ __global__ __launch_bounds__(256) void lstm_fwd_pair_kernel(const float* __restr
           }
         }
         // exchange over the pair: lane 0 ends with the full pre-activations of (i, f), lane 1 with (g, o)
-        const float pa = (p ? p2 : p0) + lstm_dpp_xor1(p ? p0 : p2) + (gq0[u] + bias0);
-        const float pb = (p ? p3 : p1) + lstm_dpp_xor1(p ? p1 : p3) + (gq1[u] + bias1);
+        const float pa = p0 + lstm_dpp_xor1(p2) + gq0[u];  // (the ring holds gx + bias)
+        const float pb = p1 + lstm_dpp_xor1(p3) + gq1[u];
         // lane 0: sigmoid(i), sigmoid(f); lane 1: tanh(g) = 2 sigmoid(2 g) - 1, sigmoid(o)
-        const float sa = lstm_sigmoid<true>(p ? 2.f * pa : pa);
-        const float a0 = p ? fmaf(2.f, sa, -1.f) : sa;
-        const float a1 = lstm_sigmoid<true>(pb);
-        gob[(long long)t * LG] = a0;
-        gob[(long long)t * LG + LH] = a1;
-        const float o0 = lstm_dpp_xor1(a0), o1 = lstm_dpp_xor1(a1);
-        const float ig = p ? o0 : a0, fg = p ? o1 : a1, gg = p ? a0 : o0, og = p ? a1 : o1;
-        c = fmaf(fg, c, ig * gg);
-        const float hn = og * lstm_tanh<true>(c);
-        if (p == 0) {
-          h_b[cur ^ 1][j] = (__bf16)hn;
-          outb[(long long)t * ndir * LH + j] = hn;
-          cob[(long long)t * LH + j] = c;
+        const float sa = (LSTM_ABL & 2) ? 0.25f * pa : lstm_sigmoid<true>(k1 * pa);
+        const float a0 = fmaf(k1, sa, k3);
+        const float a1 = (LSTM_ABL & 2) ? 0.25f * pb : lstm_sigmoid<true>(pb);
+        if (!(LSTM_ABL & 1)) {
+          *reinterpret_cast<float2*>(gob + t * LG) = make_float2(a0, a1);
         }
+        const float o0 = lstm_dpp_xor1(a0), o1 = lstm_dpp_xor1(a1);
+        const float fg = p ? o1 : a1, og = p ? a1 : o1;  // i . g = a0 . o0 in both lanes
+        c = fmaf(fg, c, a0 * o0);
+        const float hn = og * ((LSTM_ABL & 2) ? 0.5f * c : lstm_tanh<true>(c));
+        if (!(LSTM_ABL & 4)) h_b[cur ^ 1][j] = (__bf16)hn;  // both lanes of the pair write the same value: no exec-mask detour
+        if (!(LSTM_ABL & 1)) {  // both lanes hold hn and c: lane 0 stores the output, lane 1 the cell state
+          float* dst = p ? cob + t * LH + j : outb + t * ndir * LH + j;
+          *dst = p ? c : hn;
+        }
+        if (LSTM_ABL & 1) p_sink += hn;
         cur ^= 1;
-        lstm_barrier();
+        if (!(LSTM_ABL & 4)) lstm_barrier();
       }
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      gq0[u] = gn0[u];
-      gq1[u] = gn1[u];
+      gq0[u] = gn0[u] + bias0;
+      gq1[u] = gn1[u] + bias1;
     }
   }
   for (int tt = len; tt < T; ++tt)
     if (tid < LH) outb[(long long)tt * ndir * LH + tid] = 0.f;
+  if ((LSTM_ABL & 1) && p_sink == 123.456f) outb[0] = p_sink;
 }
 
 __device__ __forceinline__ float lstm_dpp_half_mirror(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, false));  // lane i <-> 7 - i
 }
-__device__ __forceinline__ float lstm_dpp_mirror(float v) {
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, false));  // lane i <-> 15 - i
-}
 __device__ __forceinline__ float lstm_dpp_ror8(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, false));  // row_ror:8, lane i <-> i ^ 8
-}
-// sum over the 16 lanes of a DPP row, result in every lane
-__device__ __forceinline__ float lstm_row16_sum(float v) {
-  v += lstm_dpp_xor1(v);
-  v += lstm_dpp_xor2(v);
-  v += lstm_dpp_half_mirror(v);
-  v += lstm_dpp_mirror(v);
-  return v;
 }
 
 // Backward through time: produces dgates_pre (ndir,B,T,4H) (gradient w.r.t. the pre-activation gates); the weight /
 // input gradients are GEMMs over it (host layer).  dout: (B,T,ndir*H).
-// A DPP ROW of 16 lanes owns four cells.  Phase A: lane l of the row is (cell l >> 2, gate l & 3): all four lanes of a
+// A DPP ROW of 16 lanes owns four cells.  Phase A: lane l of the row is (cell g2(l & 7), gate l >> 2; see below): all four lanes of a
 // cell carry its dh and dc and each publishes the gradient of ITS gate (one value per lane: LDS + the saved tensor).
 // After ONE barrier, phase B reduces dh_prev[k] = sum_r W_hh[r][k] . dg[r] for the row's four cells: lane l covers the
 // 32 gradient rows [32 l, 32 l + 32) (a 64-byte LDS read, shared by its four outputs: 128 weights per lane in registers)
-// and the 16 partial sums meet through four DPP adds -- no LDS round trip, dg double-buffered.
+// and the 16 partial sums meet through DPP adds (since round 6 a halving reduction in slot order: 5 adds for the four cells)
+// -- no LDS round trip, dg double-buffered.
 // History: three barriers + two LDS round trips per step 0.82 us; a quad-per-cell layout whose lanes each read a whole
 // 128-row quarter of dg (16 wide LDS reads with four distinct addresses per wave: LDS-bound) 1.23 us.
 template <bool BF16>
@@ -349,18 +356,30 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float dg_s[2][LG];
   __shared__ __attribute__((aligned(16))) __bf16 dg_b[2][LG];
   const int tid = threadIdx.x, row = tid >> 4, l = tid & 15;
-  const int k = row * 4 + (l >> 2), kq = l & 3;  // phase-A identity: cell, gate
+  // [round 6] slot order of the halving reduction (see lstm_bwd_pair_kernel): slot s of lane l = cell s ^ g2(l & 7) with
+  // g2(b) = (b0 ^ b2) + 2 (b1 ^ b2) -- g2(l ^ 1) = g2 ^ 1, g2(l ^ 2) = g2 ^ 2, g2(l ^ 7) = g2 -- so 2 + 1 + 1 + 1 = 5 DPP adds
+  // leave every lane with ITS cell's dh where four all-reduces (16 adds) and a select chain did; the four lanes of a cell are
+  // told apart by l >> 2, which is their gate.
+  const int g2 = ((l ^ (l >> 2)) & 1) | ((((l >> 1) ^ (l >> 2)) & 1) << 1);
+  const int k = row * 4 + g2, kq = l >> 2;  // phase-A identity: cell, gate
   const int b = blockIdx.x, dir = blockIdx.y;
   const bool rev = reverse_first ? true : (dir == 1);
   const int len = lens ? min(lens[b], T) : T;
-  // phase-B weights: W_hh[32 l + rr][4 row + c], c < 4, rr < 32
+  // phase-B weights: slot s = W_hh[32 l + rr][4 row + (s ^ g2)], s < 4, rr < 32
   float w[BF16 ? 1 : 4 * 32];
   lstm_bf16x2 wq[BF16 ? 4 * 16 : 1];
 #pragma unroll
   for (int rr = 0; rr < 32; rr += 2) {
     const float4 w0 = *reinterpret_cast<const float4*>(whh + ((long long)dir * LG + l * 32 + rr) * LH + row * 4);
     const float4 w1 = *reinterpret_cast<const float4*>(whh + ((long long)dir * LG + l * 32 + rr + 1) * LH + row * 4);
-    const float a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+    const float c0[4] = {w0.x, w0.y, w0.z, w0.w}, c1[4] = {w1.x, w1.y, w1.z, w1.w};
+    float a0[4], a1[4];  // slot order (selects instead of a dynamic register index; once per launch)
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int c = sl ^ g2;
+      a0[sl] = c == 0 ? c0[0] : (c == 1 ? c0[1] : (c == 2 ? c0[2] : c0[3]));
+      a1[sl] = c == 0 ? c1[0] : (c == 1 ? c1[1] : (c == 2 ? c1[2] : c1[3]));
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (BF16) {
@@ -386,14 +405,12 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
     const int sc = min(step, last);
     const int t = rev ? sc : last - sc;
     const int tprev = min(max(rev ? t + 1 : t - 1, 0), T - 1);
-    vi = gb[(long long)t * LG + k];
-    vf = gb[(long long)t * LG + LH + k];
-    vg = gb[(long long)t * LG + 2 * LH + k];
-    vo = gb[(long long)t * LG + 3 * LH + k];
-    vc = cb[(long long)t * LH + k];
-    const float cp = cb[(long long)tprev * LH + k];
+    const float4 gv = *reinterpret_cast<const float4*>(gb + t * LG + 4 * k);
+    vi = gv.x, vf = gv.y, vg = gv.z, vo = gv.w;
+    vc = cb[t * LH + k];
+    const float cp = cb[tprev * LH + k];
     vcp = (sc + 1 < len) ? cp : 0.f;
-    vd = doutb[(long long)t * ndir * LH + k];
+    vd = doutb[t * ndir * LH + k];
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) fetch(u, q_i[u], q_f[u], q_g[u], q_o[u], q_c[u], q_cp[u], q_d[u]);
@@ -420,7 +437,7 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
           dg_b[cur][kq * LH + k] = (__bf16)mine;
         else
           dg_s[cur][kq * LH + k] = mine;
-        dgb[(long long)t * LG + kq * LH + k] = mine;
+        dgb[t * LG + kq * LH + k] = mine;
       }
       lstm_barrier();
       {
@@ -454,12 +471,12 @@ __global__ __launch_bounds__(LG) void lstm_bwd_kernel(const float* __restrict__ 
             }
           }
         }
-        a0 = lstm_row16_sum(a0);
-        a1 = lstm_row16_sum(a1);
-        a2 = lstm_row16_sum(a2);
-        a3 = lstm_row16_sum(a3);
-        const int cq = l >> 2;  // this lane's cell inside the row
-        dh_rec = cq == 0 ? a0 : (cq == 1 ? a1 : (cq == 2 ? a2 : a3));
+        a0 += lstm_dpp_xor1(a1);
+        a2 += lstm_dpp_xor1(a3);
+        a0 += lstm_dpp_xor2(a2);
+        a0 += lstm_dpp_half_mirror(a0);
+        a0 += lstm_dpp_ror8(a0);
+        dh_rec = a0;
       }
       cur ^= 1;
     }
@@ -519,46 +536,53 @@ __global__ __launch_bounds__(256) void lstm_bwd_pair_kernel(const float* __restr
   float* dgb = dgates + (((long long)dir * B + b) * T) * LG;
   float dc = 0.f, dh_rec = 0.f;
   constexpr int PF = 4;
-  float q_i[PF], q_f[PF], q_g[PF], q_o[PF], q_c[PF], q_cp[PF], q_d[PF];
-  float n_i[PF], n_f[PF], n_g[PF], n_o[PF], n_c[PF], n_cp[PF], n_d[PF];
+  // two register rings used in turn (chunk A computes from ring 0 while ring 1 is being loaded, chunk B the other way
+  // round): copying "next" into "current" after every chunk was 7 moves per step on the serial path
+  struct Ring {
+    float i[PF], f[PF], g[PF], o[PF], c[PF], cp[PF], d[PF];
+  };
+  Ring r0, r1;
   const int last = len > 0 ? len - 1 : 0;
   auto fetch = [&](int step, float& vi, float& vf, float& vg, float& vo, float& vc, float& vcp, float& vd) {
     const int sc = min(step, last);
     const int t = rev ? sc : last - sc;
     const int tprev = min(max(rev ? t + 1 : t - 1, 0), T - 1);
-    vi = gb[(long long)t * LG + k];
-    vf = gb[(long long)t * LG + LH + k];
-    vg = gb[(long long)t * LG + 2 * LH + k];
-    vo = gb[(long long)t * LG + 3 * LH + k];
-    vc = cb[(long long)t * LH + k];
-    const float cp = cb[(long long)tprev * LH + k];
+    const float4 gv = *reinterpret_cast<const float4*>(gb + t * LG + 4 * k);
+    vi = gv.x, vf = gv.y, vg = gv.z, vo = gv.w;
+    vc = cb[t * LH + k];
+    const float cp = cb[tprev * LH + k];
     vcp = (sc + 1 < len) ? cp : 0.f;
-    vd = doutb[(long long)t * ndir * LH + k];
+    vd = doutb[t * ndir * LH + k];
   };
 #pragma unroll
-  for (int u = 0; u < PF; ++u) fetch(u, q_i[u], q_f[u], q_g[u], q_o[u], q_c[u], q_cp[u], q_d[u]);
+  for (int u = 0; u < PF; ++u) fetch(u, r0.i[u], r0.f[u], r0.g[u], r0.o[u], r0.c[u], r0.cp[u], r0.d[u]);
   int cur = 0;
-  for (int step0 = 0; step0 < len; step0 += PF) {
+  auto chunk = [&](int step0, const Ring& q, Ring& n) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) fetch(step0 + PF + u, n_i[u], n_f[u], n_g[u], n_o[u], n_c[u], n_cp[u], n_d[u]);
+    for (int u = 0; u < PF; ++u) fetch(step0 + PF + u, n.i[u], n.f[u], n.g[u], n.o[u], n.c[u], n.cp[u], n.d[u]);
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int step = step0 + u;
       if (step < len) {  // uniform
         const int t = rev ? step : len - 1 - step;
         {
-          const float ig = q_i[u], fg = q_f[u], gg = q_g[u], og = q_o[u], cc = q_c[u], cprev = q_cp[u];
-          const float dh = q_d[u] + dh_rec;
+          const float ig = q.i[u], fg = q.f[u], gg = q.g[u], og = q.o[u], cc = q.c[u], cprev = q.cp[u];
+          const float dh = q.d[u] + dh_rec;
           const float tc = lstm_tanh<true>(cc);
           dc = dc + dh * og * (1.f - tc * tc);
           // lane gp publishes the gradients of gates 2 gp, 2 gp + 1: d(pre) = upstream * derivative of the gate's activation
-          const float m0 = gp ? dc * ig * (1.f - gg * gg) : dc * gg * (ig * (1.f - ig));
-          const float m1 = gp ? dh * tc * (og * (1.f - og)) : dc * cprev * (fg * (1.f - fg));
+          //   gp = 0: (dc g) i (1 - i), (dc c_prev) f (1 - f);  gp = 1: (dc i) (1 - g g), (dh tanh c) o (1 - o)
+          // written as selects of OPERANDS around common products (as two whole expressions per side the compiler built an
+          // exec-mask detour: both sides issued, plus the mask bookkeeping, on the serial path of the step)
+          const float x1 = gp ? og : fg, u1 = gp ? dh * tc : dc * cprev;
+          const float m1 = u1 * (x1 * (1.f - x1));
+          const float v0 = gp ? fmaf(-gg, gg, 1.f) : gg * (1.f - ig);
+          const float m0 = dc * ig * v0;
           dc = dc * fg;
           dg_b[cur][(2 * gp) * LH + k] = (__bf16)m0;
           dg_b[cur][(2 * gp + 1) * LH + k] = (__bf16)m1;
-          dgb[(long long)t * LG + (2 * gp) * LH + k] = m0;
-          dgb[(long long)t * LG + (2 * gp + 1) * LH + k] = m1;
+          dgb[t * LG + (2 * gp) * LH + k] = m0;
+          dgb[t * LG + (2 * gp + 1) * LH + k] = m1;
         }
         lstm_barrier();
         {
@@ -589,11 +613,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_pair_kernel(const float* __restr
         cur ^= 1;
       }
     }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      q_i[u] = n_i[u], q_f[u] = n_f[u], q_g[u] = n_g[u], q_o[u] = n_o[u];
-      q_c[u] = n_c[u], q_cp[u] = n_cp[u], q_d[u] = n_d[u];
-    }
+  };
+  for (int step0 = 0; step0 < len; step0 += 2 * PF) {
+    chunk(step0, r0, r1);
+    if (step0 + PF < len) chunk(step0 + PF, r1, r0);
   }
   // padded tail contributes nothing
   for (int tt = len; tt < T; ++tt) {
@@ -607,6 +630,7 @@ extern "C" int kantts_lstm_fwd(const float* gx, const float* whh, const float* b
                                int precision, void* stream) {
   if (!gx || !whh || !out || !gates_save || !c_save || B < 0 || T < 0 || ndir < 1 || ndir > 2) return KANTTS_E_BADARG;
   if (H != LH) return KANTTS_E_UNSUPPORTED;
+  if ((long long)T * ndir * LG >= (1ll << 31)) return KANTTS_E_UNSUPPORTED;  // 32-bit offsets inside one sequence
   if (B == 0 || T == 0) return KANTTS_OK;
   static const char* env_pair = getenv("KANTTS_LSTM_PAIR");  // A/B switch (read once per process): 0 = the quad kernel
   if (precision == 1 && !(env_pair && atoi(env_pair) == 0))
@@ -627,6 +651,7 @@ extern "C" int kantts_lstm_bwd(const float* dout, const float* whh, const int32_
   if (!dout || !whh || !gates_save || !c_save || !dgates || B < 0 || T < 0 || ndir < 1 || ndir > 2)
     return KANTTS_E_BADARG;
   if (H != LH) return KANTTS_E_UNSUPPORTED;
+  if ((long long)T * ndir * LG >= (1ll << 31)) return KANTTS_E_UNSUPPORTED;  // 32-bit offsets inside one sequence
   if (B == 0 || T == 0) return KANTTS_OK;
   static const char* env_pair = getenv("KANTTS_LSTM_PAIR_BWD");  // A/B switch (read once per process): 0 = the quad kernel
   if (precision == 1 && !(env_pair && atoi(env_pair) == 0))

@@ -1205,7 +1205,7 @@ class EmulatedLib:
                     c = f * c + i * g
                     h = o * torch.tanh(c)
                     OUT[b, t, d] = h
-                    GS[d, b, t] = torch.cat([i, f, g, o])
+                    GS[d, b, t] = torch.stack([i, f, g, o], 1).reshape(-1)  # (H, 4): a cell's four activations side by side
                     CS[d, b, t] = c
         _arr(out, B * T * ndir * H)[:] = OUT.reshape(-1).numpy()
         _arr(gates_save, ndir * B * T * G)[:] = GS.reshape(-1).numpy()
@@ -1230,7 +1230,7 @@ class EmulatedLib:
                 for pos in range(n - 1, -1, -1):
                     t = fwd_order[pos]
                     cprev = CS[d, b, fwd_order[pos - 1]] if pos > 0 else torch.zeros(H)
-                    i, f, g, o = GS[d, b, t].split(H)
+                    i, f, g, o = GS[d, b, t].view(H, 4).unbind(1)  # saved cell-major (csrc/lstm.hip)
                     tc = torch.tanh(CS[d, b, t])
                     dht = DO[b, t, d] + dh
                     do = dht * tc
