@@ -543,6 +543,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_pair_kernel(const float* __restr
   // round): copying "next" into "current" after every chunk was 7 moves per step on the serial path.  (ONE ring refilled in
   // place, as in the forward kernel, was measured too: 0.547 against 0.525 us per step -- here the four loads and their
   // addresses land inside every step's phase A instead of in front of every fourth; profiles/r06_runLH_*.)
+  // (Also measured and refused: forming everything a step derives from its SAVED operands alone -- tanh c, o (1 - tanh^2 c),
+  // x (1 - x), ... -- one step ahead, so that only five operations stay behind dh_rec: 0.539 us per step with that work in
+  // front of the previous barrier, 0.566 in the shadow of the LDS reads, against 0.525.  One wave per SIMD issues in order:
+  // a shorter dependence chain buys nothing, the instruction count is the time; profiles/r06_runLI_*, r06_runLJ_*.)
   struct Ring {
     float i[PF], f[PF], g[PF], o[PF], c[PF], cp[PF], d[PF];
   };
