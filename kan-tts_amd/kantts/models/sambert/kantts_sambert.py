@@ -53,6 +53,8 @@ _PREDICTORS_AFTER_POSTNET = bool(os.environ.get("KANTTS_PREDICTORS_AFTER_POSTNET
 # experiment switch KANTTS_EARLY_FORK=1: the predictor branch forks where its inputs became ready (beside the decoder) instead
 # of where it is issued.  Measured 6.41-6.46 against 6.40-6.42 ms, forward 1.89 against 1.86 ms (profiles/r05_runM_*): off.
 _EARLY_FORK = bool(os.environ.get("KANTTS_EARLY_FORK"))
+# A/B switch: the predictor-only concatenations on the main chain, as until round 6 (VarianceAdaptor.forward)
+_CATS_EARLY = bool(os.environ.get("KANTTS_CATS_EARLY"))
 _FLUSH_EVERY = {"dec": int(os.environ.get("KANTTS_FLUSH_EVERY_DEC", "0")), "enc": int(os.environ.get("KANTTS_FLUSH_EVERY_ENC", "4"))}
 
 
@@ -272,8 +274,9 @@ class VarianceAdaptor(nn.Module):
         info = SeqInfo.of(masks)
         out_info = SeqInfo.of(output_masks)
         # [text | spk | emo] is consumed by three GEMMs (two FSMN inputs + the duration LSTM); build it once
-        variance_predictor_inputs = torch.cat(
-            [inputs_text_embedding, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
+
+        def vp_inputs():
+            return torch.cat([inputs_text_embedding, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
         # Teacher-forced training: the predictors feed only their own losses (everything downstream uses the targets), so
         # they run as a side branch beside the length regulator / decoder / postnet (ops.side_branch; joined at the end of
         # KanTtsSAMBERT.forward).  Free-running inference needs their outputs at once: the branch is then a no-op.
@@ -281,6 +284,10 @@ class VarianceAdaptor(nn.Module):
                    and energy_targets is not None)
         lens_keep = None if info is None else (info.lens64, info.mask)
         late = teacher and _PREDICTORS_LATE  # the caller runs self.deferred() later (beside the postnet)
+        # [round 6] the two concatenations only the predictors read are formed INSIDE their side branch when that branch is
+        # issued late: two launches fewer on the main chain in front of the length regulator (KANTTS_CATS_EARLY=1: as before)
+        cats_late = late and duration_targets is not None and not _CATS_EARLY
+        variance_predictor_inputs = None if cats_late else vp_inputs()
         self.deferred = None
         pitch_predictions = energy_predictions = None
         if not late:
@@ -300,7 +307,8 @@ class VarianceAdaptor(nn.Module):
             aug = (inputs_text_embedding
                    + ops.conv_cl(pitch_src.unsqueeze(-1).contiguous(), self.pitch_emb.weight, self.pitch_emb.bias, pad=4)
                    + ops.conv_cl(energy_src.unsqueeze(-1).contiguous(), self.energy_emb.weight, self.energy_emb.bias, pad=4))
-        duration_predictor_cond = torch.cat([aug, inputs_spk_embedding, inputs_emo_embedding], dim=-1)
+        duration_predictor_cond = (None if cats_late
+                                   else torch.cat([aug, inputs_spk_embedding, inputs_emo_embedding], dim=-1))
         if duration_targets is not None:
             prev = (teacher_plan["prev"] if teacher_plan is not None
                     else torch.log(F.pad(duration_targets[:, :-1].float(), (1, 0)) + 1).unsqueeze(-1))
@@ -309,11 +317,15 @@ class VarianceAdaptor(nn.Module):
                 ready = ops.side_branch.mark() if _EARLY_FORK else None  # the predictors' inputs exist from here on
 
                 def deferred():
-                    with ops.side_branch.fork(variance_predictor_inputs, duration_predictor_cond, prev, *(lens_keep or ()),
-                                              after=ready):
-                        p_ = self.pitch_predictor(variance_predictor_inputs, info)
-                        e_ = self.energy_predictor(variance_predictor_inputs, info)
-                        d_, _ = self.duration_predictor(prev, duration_predictor_cond, masks=info)
+                    with ops.side_branch.fork(variance_predictor_inputs, duration_predictor_cond, prev, aug,
+                                              inputs_text_embedding, inputs_spk_embedding, inputs_emo_embedding,
+                                              *(lens_keep or ()), after=ready):
+                        vpi = variance_predictor_inputs if variance_predictor_inputs is not None else vp_inputs()
+                        cond = (duration_predictor_cond if duration_predictor_cond is not None
+                                else torch.cat([aug, inputs_spk_embedding, inputs_emo_embedding], dim=-1))
+                        p_ = self.pitch_predictor(vpi, info)
+                        e_ = self.energy_predictor(vpi, info)
+                        d_, _ = self.duration_predictor(prev, cond, masks=info)
                     return d_, p_, e_
 
                 self.deferred = deferred

@@ -216,8 +216,17 @@ def test_variance_predictors_beside_the_postnet_or_the_decoder_same_results(emul
     b_out, b_g = _tiny_training_run(monkeypatch, lambda m, KS: monkeypatch.setattr(KS, "_PREDICTORS_LATE", False))
     for x, y in zip(a_out, b_out):
         assert torch.equal(x, y)
+    # since round 6 the late branch forms its two concatenations itself (two launches fewer on the main chain), so the
+    # gradient contributions of the embeddings they read are summed in another order: equal to fp32 rounding, bit-equal
+    # when the concatenations stay on the main chain (KANTTS_CATS_EARLY)
     for n in a_g:
-        assert torch.equal(a_g[n], b_g[n]), n
+        assert rel_l2(a_g[n], b_g[n]) <= 1e-6, (n, rel_l2(a_g[n], b_g[n]))
+    c_out, c_g = _tiny_training_run(monkeypatch, lambda m, KS: (monkeypatch.setattr(KS, "_PREDICTORS_LATE", True),
+                                                                monkeypatch.setattr(KS, "_CATS_EARLY", True)))
+    for x, y in zip(c_out, b_out):
+        assert torch.equal(x, y)
+    for n in c_g:
+        assert torch.equal(c_g[n], b_g[n]), n
 
 
 def test_arena_adam_matches_torch_adam(emulated_cabi):
