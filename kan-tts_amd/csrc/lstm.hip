@@ -590,8 +590,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_pair_kernel(const float* __restr
           dc = dc * fg;
           dg_b[cur][(2 * gp) * LH + k] = (__bf16)m0;
           dg_b[cur][(2 * gp + 1) * LH + k] = (__bf16)m1;
-          dgb[t * LG + (2 * gp) * LH + k] = m0;
-          dgb[t * LG + (2 * gp + 1) * LH + k] = m1;
+          float* const d0 = dgb + t * LG + (2 * gp) * LH + k;  // one address, the second store at an immediate offset
+          d0[0] = m0;
+          d0[LH] = m1;
         }
         lstm_barrier();
         {
